@@ -1,0 +1,285 @@
+/*
+ * engine_capi.cpp -- thin C wrapper over the header-only srba::RbaEngine<> front-end (include/srba.h) so that the
+ * Python drivers (bench.py, tests/) can feed keyframes through exactly the code path a C++ user of the reference's
+ * API would (rba.define_new_keyframe(obs, info), apps/srba-slam/srba-run-generic-impl.h:461), harvest the
+ * problem capsules of every optimize_local_area() call, and read back edges / landmarks / spanning-tree tables.
+ *
+ * The numeric back-end is the GPU (srba::hip_backend) unless a plain C function is plugged in with
+ * srba_engine_set_backend_fn(): tests use that to run the same front-end against the CPU oracle.  This file never
+ * references anything under oracle/.
+ */
+#include "../../include/srba.h"
+#include "engine_capi.h"
+
+using namespace srba;
+
+namespace {
+
+template <class OBS> struct obs_io;
+template <> struct obs_io<observations::RelativePoses_2D> { static void set(observations::RelativePoses_2D::obs_data_t &o, const double *z) { o.x = z[0]; o.y = z[1]; o.yaw = z[2]; } };
+template <> struct obs_io<observations::RangeBearing_2D> { static void set(observations::RangeBearing_2D::obs_data_t &o, const double *z) { o.range = z[0]; o.yaw = z[1]; } };
+template <> struct obs_io<observations::Cartesian_2D> { static void set(observations::Cartesian_2D::obs_data_t &o, const double *z) { o.pt.x = z[0]; o.pt.y = z[1]; } };
+template <> struct obs_io<observations::Cartesian_3D> { static void set(observations::Cartesian_3D::obs_data_t &o, const double *z) { o.pt.x = z[0]; o.pt.y = z[1]; o.pt.z = z[2]; } };
+template <> struct obs_io<observations::MonocularCamera> { static void set(observations::MonocularCamera::obs_data_t &o, const double *z) { o.px.x = (float)z[0]; o.px.y = (float)z[1]; } };
+template <> struct obs_io<observations::StereoCamera> { static void set(observations::StereoCamera::obs_data_t &o, const double *z) { o.left_px.x = (float)z[0]; o.left_px.y = (float)z[1]; o.right_px.x = (float)z[2]; o.right_px.y = (float)z[3]; } };
+
+template <class NOISE> struct noise_io;
+template <> struct noise_io<options::observation_noise_identity> { template <class P> static void set(P &p, const srba_engine_config &c) { p.std_noise_observations = c.std_noise_observations; } };
+template <class OBS> struct noise_io<options::observation_noise_constant_matrix<OBS> > { template <class P> static void set(P &p, const srba_engine_config &c) { for (size_t i = 0; i < OBS::OBS_DIMS * OBS::OBS_DIMS; i++) p.lambda.m[i] = c.lambda[i]; } };
+template <class SP> struct spose_io;
+template <> struct spose_io<options::sensor_pose_on_robot_none> { template <class P> static void set(P &, const srba_engine_config &) {} };
+template <> struct spose_io<options::sensor_pose_on_robot_se3> { template <class P> static void set(P &p, const srba_engine_config &c) { p.relative_pose = mrpt::poses::CPose3D(c.sensor_pose_xyzypr[0], c.sensor_pose_xyzypr[1], c.sensor_pose_xyzypr[2], c.sensor_pose_xyzypr[3], c.sensor_pose_xyzypr[4], c.sensor_pose_xyzypr[5]); } };
+template <class OBS> struct sensor_io { template <class P> static void set(P &, const srba_engine_config &) {} };
+template <> struct sensor_io<observations::MonocularCamera> { template <class P> static void set(P &p, const srba_engine_config &c) { p.camera_calib.setIntrinsicParamsFromValues(c.cam_left[0], c.cam_left[1], c.cam_left[2], c.cam_left[3]); } };
+template <> struct sensor_io<observations::StereoCamera> { template <class P> static void set(P &p, const srba_engine_config &c) {
+	p.camera_calib.leftCamera.setIntrinsicParamsFromValues(c.cam_left[0], c.cam_left[1], c.cam_left[2], c.cam_left[3]);
+	p.camera_calib.rightCamera.setIntrinsicParamsFromValues(c.cam_right[0], c.cam_right[1], c.cam_right[2], c.cam_right[3]);
+	p.camera_calib.rightCameraPose = mrpt::poses::CPose3DQuat(c.right_cam_pose[0], c.right_cam_pose[1], c.right_cam_pose[2], mrpt::math::CQuaternionDouble(c.right_cam_pose[3], c.right_cam_pose[4], c.right_cam_pose[5], c.right_cam_pose[6])); } };
+
+struct Harvest {
+	std::deque<CapsuleData> data; std::vector<srba_problem_capsule> views; std::vector<uint64_t> kf_of; bool dirty = true;
+};
+
+struct EngineBase {
+	srba_engine_config cfg; Harvest harvest; srba_hip_params last_params; bool in_stage1 = false; std::string error;
+	virtual ~EngineBase() {}
+	virtual int add_keyframe(int n_obs, const uint64_t *feat_id, const double *z, const uint8_t *flags, const double *relpos, srba_kf_info *out) = 0;
+	virtual void set_backend(const std::shared_ptr<numeric_backend> &b) = 0;
+	virtual int optimize_local_area(uint64_t root, unsigned win, srba_kf_info *out) = 0;
+	virtual int64_t num_edges() const = 0; virtual int get_edge(int64_t i, uint64_t *from, uint64_t *to, double *pose) const = 0;
+	virtual int64_t num_unknown_lms() const = 0; virtual int get_unknown_lms(uint64_t *ids, uint64_t *base, double *pos) const = 0;
+	virtual int64_t st_dump(int what, int64_t *out, int64_t cap) const = 0;
+	virtual int get_rel_pose(uint64_t query, uint64_t reference, double *pose) const = 0;
+	virtual double profiler_mean(const char *name) const = 0;
+};
+
+template <class KF, class LM, class OBS, class NOISE, class SPOSE, class SOLVER>
+struct EngineImpl : public EngineBase {
+	struct OPTS : public RBA_OPTIONS_DEFAULT { typedef SPOSE sensor_pose_on_robot_t; typedef NOISE obs_noise_matrix_t; typedef SOLVER solver_t; };
+	typedef RbaEngine<KF, LM, OBS, OPTS> rba_t;
+	rba_t rba; uint64_t cur_kf = 0;
+
+	explicit EngineImpl(const srba_engine_config &c) {
+		cfg = c;
+		rba.setVerbosityLevel(c.verbose); rba.get_time_profiler().enable(c.enable_profiler != 0);
+		typename rba_t::TSRBAParameters &s = rba.parameters.srba;
+		s.max_tree_depth = c.max_tree_depth; s.max_optimize_depth = c.max_optimize_depth; s.optimize_new_edges_alone = c.optimize_new_edges_alone != 0;
+		s.use_robust_kernel = c.use_robust_kernel != 0; s.use_robust_kernel_stage1 = c.use_robust_kernel_stage1 != 0; s.kernel_param = c.kernel_param; s.max_iters = c.max_iters;
+		s.max_error_per_obs_to_stop = c.max_error_per_obs_to_stop; s.max_rho = c.max_rho; s.max_lambda = c.max_lambda; s.min_error_reduction_ratio_to_relinearize = c.min_error_reduction_ratio_to_relinearize;
+		s.cov_recovery = c.cov_recovery ? crpLandmarksApprox : crpNone;
+		rba.parameters.ecp.submap_size = c.submap_size; rba.parameters.ecp.min_obs_to_loop_closure = c.min_obs_to_loop_closure;
+		noise_io<NOISE>::set(rba.parameters.obs_noise, c); spose_io<SPOSE>::set(rba.parameters.sensor_pose, c); sensor_io<OBS>::set(rba.parameters.sensor, c);
+		rba.set_hip_device(c.hip_device);
+		rba.on_capsule = [this](const srba_hip_params &hp, CapsuleData &cd) {
+			last_params = hp;
+			const bool stage1 = (cd.n_unk_edges == 1 && cd.n_unk_lms == 0 && in_stage1);
+			if ((cfg.harvest & 1) && !stage1) { harvest.data.push_back(cd); harvest.kf_of.push_back(cur_kf); harvest.dirty = true; }
+			if ((cfg.harvest & 2) && stage1) { harvest.data.push_back(cd); harvest.kf_of.push_back(cur_kf); harvest.dirty = true; }
+		};
+	}
+	void set_backend(const std::shared_ptr<numeric_backend> &b) { rba.set_numeric_backend(b); }
+	static void fill_info(srba_kf_info *out, const typename rba_t::TOptimizeExtraOutputInfo &r, const typename rba_t::TOptimizeExtraOutputInfo *s1) {
+		out->num_observations = r.num_observations; out->num_jacobians = r.num_jacobians; out->num_k2k = r.num_kf2kf_edges_optimized; out->num_k2f = r.num_kf2lm_edges_optimized;
+		out->chi2_init = r.total_sqr_error_init; out->chi2_final = r.total_sqr_error_final; out->obs_rmse = r.obs_rmse; out->lm = r.lm;
+		if (s1) out->lm_stage1 = s1->lm;
+	}
+	int add_keyframe(int n_obs, const uint64_t *feat_id, const double *z, const uint8_t *flags, const double *relpos, srba_kf_info *out) {
+		try {
+			typename rba_t::new_kf_observations_t list;
+			for (int i = 0; i < n_obs; i++) {
+				typename rba_t::new_kf_observation_t o;
+				o.obs.feat_id = feat_id[i]; obs_io<OBS>::set(o.obs.obs_data, z + (size_t)i * OBS::OBS_DIMS);
+				o.is_fixed = (flags && (flags[i] & 1)); o.is_unknown_with_init_val = (flags && (flags[i] & 2));
+				if (relpos) for (size_t k = 0; k < LM::LM_DIMS; k++) o.feat_rel_pos[k] = relpos[(size_t)i * LM::LM_DIMS + k];
+				list.push_back(o);
+			}
+			typename rba_t::TNewKeyFrameInfo info;
+			cur_kf = rba.get_rba_state().keyframes.size(); in_stage1 = true; // stage-1 calls come first inside define_new_keyframe
+			// (the on_capsule hook distinguishes stage-1 by its single unknown edge; local-area calls with 1 edge and no LM are also
+			// possible for the 2nd keyframe: those are harvested as local-area capsules because stage-1 only runs for edges without init value)
+			rba.define_new_keyframe(list, info, cfg.run_local_optimization != 0);
+			in_stage1 = false;
+			if (out) {
+				std::memset(out, 0, sizeof(*out));
+				out->kf_id = info.kf_id; out->n_new_edges = (int)std::min<size_t>(info.created_edge_ids.size(), 4);
+				for (int i = 0; i < out->n_new_edges; i++) { const TNewEdgeInfo &e = info.created_edge_ids[i]; out->edge_id[i] = e.id; out->edge_has_init[i] = e.has_approx_init_val; out->lc_observer[i] = e.loopclosure_observer_kf; out->lc_base[i] = e.loopclosure_base_kf; }
+				fill_info(out, info.optimize_results, &info.optimize_results_stg1);
+			}
+			return 0;
+		} catch (std::exception &e) { in_stage1 = false; error = e.what(); return -1; }
+	}
+	int optimize_local_area(uint64_t root, unsigned win, srba_kf_info *out) {
+		try { typename rba_t::TOptimizeExtraOutputInfo r; rba.optimize_local_area(root, win, r); if (out) { std::memset(out, 0, sizeof(*out)); out->kf_id = root; fill_info(out, r, NULL); } return 0; }
+		catch (std::exception &e) { error = e.what(); return -1; }
+	}
+	int64_t num_edges() const { return (int64_t)rba.get_k2k_edges().size(); }
+	int get_edge(int64_t i, uint64_t *from, uint64_t *to, double *pose) const {
+		if (i < 0 || i >= num_edges()) return -1;
+		const typename rba_t::k2k_edge_t &e = rba.get_k2k_edges()[i]; *from = e.from; *to = e.to; e.inv_pose.storeTo(pose); return 0;
+	}
+	int64_t num_unknown_lms() const { return (int64_t)rba.get_unknown_feats().size(); }
+	int get_unknown_lms(uint64_t *ids, uint64_t *base, double *pos) const {
+		size_t i = 0;
+		for (typename rba_t::TRelativeLandmarkPosMap::const_iterator it = rba.get_unknown_feats().begin(); it != rba.get_unknown_feats().end(); ++it, ++i) { ids[i] = it->first; base[i] = it->second.id_frame_base; for (size_t k = 0; k < LM::LM_DIMS; k++) pos[i * LM::LM_DIMS + k] = it->second.pos[k]; }
+		return 0;
+	}
+	/** what=0: next_edge rows [src trg next dist]; what=1: all_edges rows [from to len e0 e1 ...] ; returns the number of int64 needed */
+	int64_t st_dump(int what, int64_t *out, int64_t cap) const {
+		int64_t n = 0; const typename rba_t::rba_problem_state_t &st = rba.get_rba_state();
+		auto put = [&](int64_t v) { if (out && n < cap) out[n] = v; n++; };
+		if (what == 0) {
+			for (size_t s = 0; s < st.spanning_tree.sym.next_edge.size(); s++) { const std::map<TKeyFrameID, TSpanTreeEntry> *m = st.spanning_tree.sym.next_edge.find(s); if (!m) continue;
+				for (std::map<TKeyFrameID, TSpanTreeEntry>::const_iterator it = m->begin(); it != m->end(); ++it) { put(s); put(it->first); put(it->second.next); put(it->second.distance); } }
+		} else {
+			for (size_t s = 0; s < st.spanning_tree.sym.all_edges.size(); s++) { const std::map<TKeyFrameID, std::vector<size_t> > *m = st.spanning_tree.sym.all_edges.find(s); if (!m) continue;
+				for (std::map<TKeyFrameID, std::vector<size_t> >::const_iterator it = m->begin(); it != m->end(); ++it) { put(s); put(it->first); put(it->second.size()); for (size_t k = 0; k < it->second.size(); k++) put(it->second[k]); } }
+		}
+		return n;
+	}
+	int get_rel_pose(uint64_t query, uint64_t reference, double *pose) const { const typename rba_t::pose_t *p = rba.get_kf_relative_pose(query, reference); if (!p) return -1; p->storeTo(pose); return 0; }
+	double profiler_mean(const char *name) const { return const_cast<rba_t &>(rba).get_time_profiler().getMeanTime(name); }
+};
+
+typedef options::observation_noise_identity N_ID;
+typedef options::sensor_pose_on_robot_none SP_NONE;
+typedef options::sensor_pose_on_robot_se3 SP_SE3;
+typedef options::solver_LM_schur_dense_cholesky S_SD;
+typedef options::solver_LM_schur_sparse_cholesky S_SS;
+typedef options::solver_LM_no_schur_sparse_cholesky S_NS;
+
+template <class KF, class LM, class OBS, class NOISE, class SPOSE>
+EngineBase *make_solver(const srba_engine_config &c) {
+	switch (c.solver) {
+		case SRBA_SOLVER_SCHUR_DENSE_CHOL: return new EngineImpl<KF, LM, OBS, NOISE, SPOSE, S_SD>(c);
+		case SRBA_SOLVER_SCHUR_SPARSE_CHOL: return new EngineImpl<KF, LM, OBS, NOISE, SPOSE, S_SS>(c);
+		case SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL: return new EngineImpl<KF, LM, OBS, NOISE, SPOSE, S_NS>(c);
+	}
+	return NULL;
+}
+template <class KF, class LM, class OBS>
+EngineBase *make_point_engine(const srba_engine_config &c) { // landmark families: identity noise (the only policy the reference apps use for them)
+	if (c.noise != SRBA_NOISE_IDENTITY) return NULL;
+	if (c.sensor_pose == SRBA_SENSOR_POSE_SE3) return make_solver<KF, LM, OBS, N_ID, SP_SE3>(c);
+	return make_solver<KF, LM, OBS, N_ID, SP_NONE>(c);
+}
+template <class KF, class LM, class OBS>
+EngineBase *make_point_engine_2d(const srba_engine_config &c) {
+	if (c.noise != SRBA_NOISE_IDENTITY || c.sensor_pose != SRBA_SENSOR_POSE_NONE) return NULL;
+	return make_solver<KF, LM, OBS, N_ID, SP_NONE>(c);
+}
+
+std::string g_error;
+} // namespace
+
+extern "C" {
+
+void srba_engine_config_default(srba_engine_config *c, int family) {
+	std::memset(c, 0, sizeof(*c));
+	c->family = family; c->solver = SRBA_SOLVER_SCHUR_DENSE_CHOL; c->noise = SRBA_NOISE_IDENTITY; c->sensor_pose = SRBA_SENSOR_POSE_NONE;
+	c->std_noise_observations = 1.0; for (int i = 0; i < 6; i++) c->lambda[i * 7 % 36] = 0; for (int i = 0; i < 6; i++) c->lambda[i * 6 + i] = 1.0;
+	c->right_cam_pose[3] = 1.0; c->cam_left[0] = c->cam_left[1] = c->cam_right[0] = c->cam_right[1] = 1.0;
+	c->max_tree_depth = 4; c->max_optimize_depth = 4; c->submap_size = 15; c->min_obs_to_loop_closure = 4; // rba_problem_common.h:35-56, ecps/local_areas_fixed_size.h:24-33
+	c->optimize_new_edges_alone = 1; c->use_robust_kernel = 0; c->use_robust_kernel_stage1 = 0; c->kernel_param = 3.0; c->max_iters = 20;
+	c->max_error_per_obs_to_stop = 1e-6; c->max_rho = 10.0; c->max_lambda = 1e20; c->min_error_reduction_ratio_to_relinearize = 0.01; c->cov_recovery = 1;
+	c->run_local_optimization = 1; c->harvest = 0; c->verbose = 0; c->enable_profiler = 0; c->hip_device = -1;
+}
+
+void *srba_engine_create(const srba_engine_config *c) {
+	EngineBase *e = NULL;
+	try {
+		switch (c->family) {
+			case SRBA_SE2_RELPOSE2D:
+				if (c->noise == SRBA_NOISE_CONSTANT_MATRIX && c->sensor_pose == SRBA_SENSOR_POSE_NONE)
+					e = make_solver<kf2kf_poses::SE2, landmarks::RelativePoses2D, observations::RelativePoses_2D, options::observation_noise_constant_matrix<observations::RelativePoses_2D>, SP_NONE>(*c);
+				else if (c->noise == SRBA_NOISE_IDENTITY && c->sensor_pose == SRBA_SENSOR_POSE_NONE)
+					e = make_solver<kf2kf_poses::SE2, landmarks::RelativePoses2D, observations::RelativePoses_2D, N_ID, SP_NONE>(*c);
+				break;
+			case SRBA_SE2_RB2D: e = make_point_engine_2d<kf2kf_poses::SE2, landmarks::Euclidean2D, observations::RangeBearing_2D>(*c); break;
+			case SRBA_SE2_CART2D: e = make_point_engine_2d<kf2kf_poses::SE2, landmarks::Euclidean2D, observations::Cartesian_2D>(*c); break;
+			case SRBA_SE3_STEREO: e = make_point_engine<kf2kf_poses::SE3, landmarks::Euclidean3D, observations::StereoCamera>(*c); break;
+			case SRBA_SE3_MONO: e = make_point_engine<kf2kf_poses::SE3, landmarks::Euclidean3D, observations::MonocularCamera>(*c); break;
+			case SRBA_SE3_CART3D: e = make_point_engine<kf2kf_poses::SE3, landmarks::Euclidean3D, observations::Cartesian_3D>(*c); break;
+		}
+	} catch (std::exception &ex) { g_error = ex.what(); return NULL; }
+	if (!e) g_error = "srba_engine_create: unsupported family / policy combination";
+	return e;
+}
+void srba_engine_destroy(void *h) { delete static_cast<EngineBase *>(h); }
+const char *srba_engine_last_error(void *h) { return h ? static_cast<EngineBase *>(h)->error.c_str() : g_error.c_str(); }
+int srba_engine_set_backend_fn(void *h, srba_backend_fn fn, const char *name) {
+	static_cast<EngineBase *>(h)->set_backend(std::shared_ptr<numeric_backend>(new function_backend(fn, name ? name : "external"))); return 0;
+}
+int srba_engine_add_keyframe(void *h, int n_obs, const uint64_t *feat_id, const double *z, const uint8_t *flags, const double *relpos, srba_kf_info *out) {
+	return static_cast<EngineBase *>(h)->add_keyframe(n_obs, feat_id, z, flags, relpos, out);
+}
+int srba_engine_optimize_local_area(void *h, uint64_t root, unsigned win, srba_kf_info *out) { return static_cast<EngineBase *>(h)->optimize_local_area(root, win, out); }
+int64_t srba_engine_num_edges(void *h) { return static_cast<EngineBase *>(h)->num_edges(); }
+int srba_engine_get_edge(void *h, int64_t i, uint64_t *from, uint64_t *to, double *pose) { return static_cast<EngineBase *>(h)->get_edge(i, from, to, pose); }
+int64_t srba_engine_num_unknown_lms(void *h) { return static_cast<EngineBase *>(h)->num_unknown_lms(); }
+int srba_engine_get_unknown_lms(void *h, uint64_t *ids, uint64_t *base, double *pos) { return static_cast<EngineBase *>(h)->get_unknown_lms(ids, base, pos); }
+int64_t srba_engine_st_dump(void *h, int what, int64_t *out, int64_t cap) { return static_cast<EngineBase *>(h)->st_dump(what, out, cap); }
+int srba_engine_get_rel_pose(void *h, uint64_t query, uint64_t reference, double *pose) { return static_cast<EngineBase *>(h)->get_rel_pose(query, reference, pose); }
+double srba_engine_profiler_mean(void *h, const char *name) { return static_cast<EngineBase *>(h)->profiler_mean(name); }
+
+int64_t srba_engine_harvest_count(void *h) { return (int64_t)static_cast<EngineBase *>(h)->harvest.data.size(); }
+/* Array of capsule views over the harvested (pre-optimisation) problems; valid until the next add_keyframe / clear. */
+srba_problem_capsule *srba_engine_harvest_capsules(void *h) {
+	Harvest &hv = static_cast<EngineBase *>(h)->harvest;
+	if (hv.dirty) { hv.views.clear(); for (size_t i = 0; i < hv.data.size(); i++) hv.views.push_back(hv.data[i].view()); hv.dirty = false; }
+	return hv.views.empty() ? NULL : &hv.views[0];
+}
+uint64_t srba_engine_harvest_kf(void *h, int64_t i) { return static_cast<EngineBase *>(h)->harvest.kf_of[i]; }
+void srba_engine_harvest_clear(void *h) { Harvest &hv = static_cast<EngineBase *>(h)->harvest; hv.data.clear(); hv.views.clear(); hv.kf_of.clear(); hv.dirty = true; }
+int srba_engine_get_hip_params(void *h, srba_hip_params *out) { *out = static_cast<EngineBase *>(h)->last_params; return 0; }
+/* Serialise / load harvested capsules (golden fixtures, capsule caches). */
+int srba_engine_harvest_save(void *h, const char *path, int64_t first, int64_t count) {
+	EngineBase *e = static_cast<EngineBase *>(h); FILE *f = fopen(path, "wb"); if (!f) return -1;
+	const int64_t n = std::min<int64_t>(count, (int64_t)e->harvest.data.size() - first);
+	const uint64_t magic = 0x53524241434150ULL; fwrite(&magic, 8, 1, f); fwrite(&n, 8, 1, f); fwrite(&e->last_params, sizeof(srba_hip_params), 1, f);
+	for (int64_t i = 0; i < n; i++) e->harvest.data[first + i].write(f);
+	fclose(f); return 0;
+}
+
+/* Stand-alone capsule file reader (no engine needed). */
+struct CapsuleFile { std::deque<CapsuleData> data; std::vector<srba_problem_capsule> views; srba_hip_params params; };
+void *srba_capsule_file_load(const char *path) {
+	FILE *f = fopen(path, "rb"); if (!f) { g_error = std::string("cannot open ") + path; return NULL; }
+	CapsuleFile *cf = new CapsuleFile();
+	try {
+		uint64_t magic = 0; int64_t n = 0;
+		if (fread(&magic, 8, 1, f) != 1 || magic != 0x53524241434150ULL || fread(&n, 8, 1, f) != 1 || fread(&cf->params, sizeof(srba_hip_params), 1, f) != 1) throw std::runtime_error("bad capsule file header");
+		for (int64_t i = 0; i < n; i++) { cf->data.push_back(CapsuleData()); cf->data.back().read(f); }
+		for (size_t i = 0; i < cf->data.size(); i++) cf->views.push_back(cf->data[i].view());
+	} catch (std::exception &e) { g_error = e.what(); delete cf; fclose(f); return NULL; }
+	fclose(f); return cf;
+}
+int64_t srba_capsule_file_count(void *h) { return (int64_t)static_cast<CapsuleFile *>(h)->views.size(); }
+srba_problem_capsule *srba_capsule_file_capsules(void *h) { CapsuleFile *cf = static_cast<CapsuleFile *>(h); return cf->views.empty() ? NULL : &cf->views[0]; }
+int srba_capsule_file_params(void *h, srba_hip_params *out) { *out = static_cast<CapsuleFile *>(h)->params; return 0; }
+void srba_capsule_file_free(void *h) { delete static_cast<CapsuleFile *>(h); }
+/* Deep copy of a capsule array (so that a pristine batch can be re-optimised by several back-ends). */
+void *srba_capsule_clone(const srba_problem_capsule *caps, int64_t n, int family) {
+	int P, L, O, PD; if (srba_family_dims(family, &P, &L, &O, &PD) != 0) return NULL;
+	CapsuleFile *cf = new CapsuleFile(); std::memset(&cf->params, 0, sizeof(cf->params)); cf->params.family = family;
+	for (int64_t i = 0; i < n; i++) {
+		const srba_problem_capsule &c = caps[i]; cf->data.push_back(CapsuleData()); CapsuleData &d = cf->data.back();
+		d.P = P; d.L = L; d.O = O; d.PD = PD; d.n_unk_edges = c.n_unk_edges; d.n_unk_lms = c.n_unk_lms; d.n_valid = c.n_valid;
+#define CP(field, ptr, count) d.field.assign(ptr, ptr + (size_t)(count))
+		CP(edge_pose, c.edge_pose, (size_t)c.n_edges * PD); CP(ulm_pos, c.ulm_pos, (size_t)c.n_unk_lms * L); CP(klm_pos, c.klm_pos, (size_t)c.n_known_lms * L); CP(obs_z, c.obs_z, (size_t)c.n_obs * O);
+		CP(pair_path_off, c.pair_path_off, c.n_pairs + 1); CP(path_edge, c.path_edge, c.n_path); CP(pair_needed, c.pair_needed, c.n_pairs); CP(pose_required, c.pose_required, 2 * c.n_pairs);
+		CP(obs_pose, c.obs_pose, c.n_obs); CP(obs_lm, c.obs_lm, c.n_obs); CP(obs_valid, c.obs_valid, c.n_obs);
+		CP(bp_col, c.bp_col, c.n_bp); CP(bp_res, c.bp_res, c.n_bp); CP(bp_A, c.bp_A, c.n_bp); CP(bp_D, c.bp_D, c.n_bp); CP(bp_lm, c.bp_lm, c.n_bp); CP(bp_normal, c.bp_normal, c.n_bp); CP(colp_off, c.colp_off, c.n_unk_edges + 1);
+		CP(bf_col, c.bf_col, c.n_bf); CP(bf_res, c.bf_res, c.n_bf); CP(bf_pose, c.bf_pose, c.n_bf); CP(colf_off, c.colf_off, c.n_unk_lms + 1);
+		CP(hap_i, c.hap_i, c.n_hap); CP(hap_j, c.hap_j, c.n_hap); CP(hap_term_off, c.hap_term_off, c.n_hap + 1); CP(hap_t1, c.hap_t1, c.n_hap_terms); CP(hap_t2, c.hap_t2, c.n_hap_terms);
+		CP(hf_i, c.hf_i, c.n_hf); CP(hf_j, c.hf_j, c.n_hf); CP(hf_term_off, c.hf_term_off, c.n_hf + 1); CP(hf_t1, c.hf_t1, c.n_hf_terms); CP(hf_t2, c.hf_t2, c.n_hf_terms);
+		CP(hapf_i, c.hapf_i, c.n_hapf); CP(hapf_j, c.hapf_j, c.n_hapf); CP(hapf_term_off, c.hapf_term_off, c.n_hapf + 1); CP(hapf_t1, c.hapf_t1, c.n_hapf_terms); CP(hapf_t2, c.hapf_t2, c.n_hapf_terms);
+		CP(hap_diag, c.hap_diag, c.n_unk_edges); CP(hf_diag, c.hf_diag, c.n_unk_lms);
+		if (c.sch_term_off) { CP(sch_term_off, c.sch_term_off, c.n_hap + 1); CP(sch_b1, c.sch_b1, c.n_sch_terms); CP(sch_b2, c.sch_b2, c.n_sch_terms); CP(sch_lm, c.sch_lm, c.n_sch_terms); }
+		CP(lm_hapf_off, c.lm_hapf_off, c.n_unk_lms + 1); CP(lm_hapf_idx, c.lm_hapf_idx, c.n_hapf);
+#undef CP
+	}
+	for (size_t i = 0; i < cf->data.size(); i++) cf->views.push_back(cf->data[i].view());
+	return cf;
+}
+
+} // extern "C"

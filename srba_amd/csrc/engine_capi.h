@@ -1,0 +1,71 @@
+/*
+ * engine_capi.h -- C view of the srba::RbaEngine<> front-end for script drivers (ctypes).
+ * One handle = one RbaEngine<KF2KF,LM,OBS,OPTS> instance (reference include/srba/RbaEngine.h:66-816).
+ */
+#ifndef SRBA_ENGINE_CAPI_H
+#define SRBA_ENGINE_CAPI_H
+#include "../../include/srba_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct srba_engine_config {
+	int32_t family, solver, noise, sensor_pose;          /* template arguments of RbaEngine<> / RBA_OPTIONS (RbaEngine.h:39-45) */
+	double  std_noise_observations;                      /* parameters.obs_noise (identity policy) */
+	double  lambda[36];                                  /* parameters.obs_noise.lambda (constant-matrix policy), O x O row-major */
+	double  sensor_pose_xyzypr[6];                       /* parameters.sensor_pose.relative_pose as CPose3D(x,y,z,yaw,pitch,roll) */
+	double  cam_left[4], cam_right[4], right_cam_pose[7];/* parameters.sensor.camera_calib */
+	uint64_t max_tree_depth, max_optimize_depth;         /* parameters.srba.* (RbaEngine.h:424-460) */
+	uint64_t submap_size, min_obs_to_loop_closure;       /* parameters.ecp.* (ecps/local_areas_fixed_size.h:24-33) */
+	int32_t optimize_new_edges_alone, use_robust_kernel, use_robust_kernel_stage1, max_iters;
+	double  kernel_param, max_error_per_obs_to_stop, max_rho, max_lambda, min_error_reduction_ratio_to_relinearize;
+	int32_t cov_recovery;
+	int32_t run_local_optimization;                      /* 3rd argument of define_new_keyframe */
+	int32_t harvest;                                     /* bit0: keep a copy of every optimize_local_area capsule; bit1: of stage-1 capsules */
+	int32_t verbose, enable_profiler, hip_device;
+} srba_engine_config;
+
+typedef struct srba_kf_info {                            /* TNewKeyFrameInfo (RbaEngine.h:180-195) */
+	uint64_t kf_id;
+	int32_t  n_new_edges, reserved;
+	uint64_t edge_id[4], lc_observer[4], lc_base[4];
+	int32_t  edge_has_init[4];
+	uint64_t num_observations, num_jacobians, num_k2k, num_k2f; /* TOptimizeExtraOutputInfo of the local-area optimisation */
+	double   chi2_init, chi2_final, obs_rmse;
+	srba_lm_result lm, lm_stage1;
+} srba_kf_info;
+
+typedef int (*srba_backend_fn)(const srba_hip_params *, srba_problem_capsule *, srba_lm_result *);
+
+void  srba_engine_config_default(srba_engine_config *c, int family);
+void *srba_engine_create(const srba_engine_config *c);
+void  srba_engine_destroy(void *h);
+const char *srba_engine_last_error(void *h);
+int   srba_engine_set_backend_fn(void *h, srba_backend_fn fn, const char *name);
+/* flags[i]: bit0 is_fixed, bit1 is_unknown_with_init_val (srba_types.h:473-495); z: n_obs x O; relpos: n_obs x L or NULL */
+int   srba_engine_add_keyframe(void *h, int n_obs, const uint64_t *feat_id, const double *z, const uint8_t *flags, const double *relpos, srba_kf_info *out);
+int   srba_engine_optimize_local_area(void *h, uint64_t root, unsigned win, srba_kf_info *out);
+int64_t srba_engine_num_edges(void *h);
+int   srba_engine_get_edge(void *h, int64_t i, uint64_t *from, uint64_t *to, double *pose /*PD*/);
+int64_t srba_engine_num_unknown_lms(void *h);
+int   srba_engine_get_unknown_lms(void *h, uint64_t *ids, uint64_t *base, double *pos);
+int64_t srba_engine_st_dump(void *h, int what, int64_t *out, int64_t cap);
+int   srba_engine_get_rel_pose(void *h, uint64_t query, uint64_t reference, double *pose);
+double srba_engine_profiler_mean(void *h, const char *name);
+int64_t srba_engine_harvest_count(void *h);
+srba_problem_capsule *srba_engine_harvest_capsules(void *h);
+uint64_t srba_engine_harvest_kf(void *h, int64_t i);
+void  srba_engine_harvest_clear(void *h);
+int   srba_engine_get_hip_params(void *h, srba_hip_params *out);
+int   srba_engine_harvest_save(void *h, const char *path, int64_t first, int64_t count);
+void *srba_capsule_file_load(const char *path);
+int64_t srba_capsule_file_count(void *h);
+srba_problem_capsule *srba_capsule_file_capsules(void *h);
+int   srba_capsule_file_params(void *h, srba_hip_params *out);
+void  srba_capsule_file_free(void *h);
+void *srba_capsule_clone(const srba_problem_capsule *caps, int64_t n, int family);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

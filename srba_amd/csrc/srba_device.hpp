@@ -1,0 +1,527 @@
+/*
+ * srba_device.hpp -- gfx950 device code of the SRBA local-optimisation hot path (FP64 throughout).
+ *
+ * One problem capsule (= one reference optimize_edges() call, include/srba/impl/optimize_edges.h:44-793) is owned by
+ * one 256-thread workgroup (4 wave64).  Work items inside the capsule (ST pairs, Jacobian blocks, observations,
+ * Hessian blocks, landmarks) are spread over the lanes; phases are separated by workgroup barriers; reductions are
+ * fixed-shape LDS trees (deterministic, no FP64 atomics).  The dense system matrix of the LM step lives in LDS
+ * (packed lower triangle) when it fits, else in an HBM workspace.
+ *
+ * Device restatement of the reference hot loops:
+ *   K1  phase_spantree      impl/spantree_update_numeric.h:19-81
+ *   K2  jac_dh_dp           impl/jacobians.h:207-354 (+ :364-494 SE3 points, :501-634 SE2 points, :645-744 SE2 relative poses)
+ *   K3  jac_dh_df           impl/jacobians.h:888-1013
+ *   K4  phase_residuals     impl/reprojection_residuals.h:16-81, RbaEngine.h:810-813 (pseudo-Huber)
+ *   K5  phase_gradient      impl/compute_minus_gradient.h:20-91
+ *   K6  phase_hessian       impl/sparse_hessian_update_numeric.h:22-60, srba_options_noise.h:44-71,102-131
+ *   K7,K8,K10 schur_*       impl/schur.h:180-311
+ *   K9  chol_* / dense assembly   impl/lev-marq_solvers.h:80-187,279-381,474-568 (all three solvers solve the same SPD system;
+ *                                 here always by dense LL^t -- "not positive definite" == a pivot <= 0 in every variant)
+ *   K11,K12 phase_apply / phase_restore + LM control   impl/optimize_edges.h:361-696
+ * The SE2 Jacobians are evaluated in closed form (products J0*J1*J2 of jacobians.h:720-736 multiplied out), which needs one
+ * sincos instead of four; results agree with the reference formula to rounding.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/srba_hip.h"
+
+#define SRBA_WG 256
+
+namespace srbadev {
+
+// ------------------------------------------------------------------------------------------------ problem descriptor
+struct ProbDesc {
+	int n_edges, nK, nF, n_klm, n_pairs, n_obs, n_valid, n_bp, n_bf, n_hap, n_hf, n_hapf, n_sch, n_req, n_sys, n_scal;
+	// element offsets into the batch-wide arrays
+	long long o_edge, o_unk, o_ulm, o_klm, o_pair, o_ppoff, o_path, o_obs, o_valid, o_bp, o_colp, o_bf, o_colf;
+	long long o_hap, o_hapoff, o_hapt, o_hf, o_hfoff, o_hft, o_hapf, o_hapfoff, o_hapft, o_sch, o_lmoff, o_req, o_scal, o_yw, o_dense;
+	int dense_in_lds, pad;
+};
+
+struct Batch {
+	int n_prob; int max_lds_doubles;
+	const ProbDesc *desc;
+	// inputs
+	const double *edge0, *ulm0, *klm, *obs_z;
+	const int *pair_path_off, *path_edge, *obs_pose, *obs_lm, *obs_valid;
+	const int *bp_col, *bp_res, *bp_A, *bp_D, *bp_lm, *colp_off, *bf_col, *bf_res, *bf_pose, *colf_off;
+	const int *hap_i, *hap_j, *hap_term_off, *hap_t1, *hap_t2, *hf_i, *hf_j, *hf_term_off, *hf_t1, *hf_t2;
+	const int *hapf_i, *hapf_j, *hapf_term_off, *hapf_t1, *hapf_t2, *hap_diag, *hf_diag;
+	const int *sch_term_off, *sch_b1, *sch_b2, *sch_lm, *sch_yw, *lm_hapf_off, *lm_hapf_idx, *req_idx;
+	const unsigned char *pair_needed, *bp_normal;
+	// state + workspace
+	double *edge, *ulm, *pose, *Jp, *Jf, *resid, *resid2, *HAp, *HAp0, *Hf, *HApf, *grad, *delta, *Hfinv, *YW;
+	double *old_edge, *old_ulm, *old_pose, *dense, *ulm_inf;
+	int *valid, *first_fail, *hf_ok;
+	unsigned char *ulm_inf_valid;
+	srba_lm_result *results;
+	double *lambda_io, *chi2; int *notpd;
+};
+
+struct DevParams {
+	int solver, noise, sensor_pose, max_iters, use_robust_kernel, cov_recovery;
+	double inv_sigma, lambda[16], kernel_param, max_err, max_rho, max_lambda, min_relin;
+	double SPt[3], SPR[9];      // sensor pose on the robot
+	double camL[4], camR[4];    // fx fy cx cy
+	double R2Lt[3], R2LR[9];    // (-)rightCameraPose
+};
+
+// ------------------------------------------------------------------------------------------------ family traits
+template <int FAM> struct Tr;
+template <> struct Tr<SRBA_SE2_RELPOSE2D> { static constexpr int P = 3, L = 3, O = 3, PD = 3; static constexpr bool SE3 = false, REL = true; };
+template <> struct Tr<SRBA_SE2_RB2D>      { static constexpr int P = 3, L = 2, O = 2, PD = 3; static constexpr bool SE3 = false, REL = false; };
+template <> struct Tr<SRBA_SE2_CART2D>    { static constexpr int P = 3, L = 2, O = 2, PD = 3; static constexpr bool SE3 = false, REL = false; };
+template <> struct Tr<SRBA_SE3_STEREO>    { static constexpr int P = 6, L = 3, O = 4, PD = 12; static constexpr bool SE3 = true, REL = false; };
+template <> struct Tr<SRBA_SE3_MONO>      { static constexpr int P = 6, L = 3, O = 2, PD = 12; static constexpr bool SE3 = true, REL = false; };
+template <> struct Tr<SRBA_SE3_CART3D>    { static constexpr int P = 6, L = 3, O = 3, PD = 12; static constexpr bool SE3 = true, REL = false; };
+
+// ------------------------------------------------------------------------------------------------ poses
+__device__ __forceinline__ double wrap_pi(double a) { // mrpt::math::wrapToPi
+	a += M_PI; const bool neg = a < 0; a = fmod(a, 2.0 * M_PI); if (neg) a += 2.0 * M_PI; return a - M_PI;
+}
+struct P2 { double x, y, phi; };
+struct P3 { double t[3]; double R[9]; };
+__device__ __forceinline__ P2 ident2() { P2 r; r.x = 0; r.y = 0; r.phi = 0; return r; }
+__device__ __forceinline__ P3 ident3() { P3 r; r.t[0] = r.t[1] = r.t[2] = 0; r.R[0] = 1; r.R[1] = 0; r.R[2] = 0; r.R[3] = 0; r.R[4] = 1; r.R[5] = 0; r.R[6] = 0; r.R[7] = 0; r.R[8] = 1; return r; }
+__device__ __forceinline__ P2 ld2(const double *p) { P2 r; r.x = p[0]; r.y = p[1]; r.phi = p[2]; return r; }
+__device__ __forceinline__ void st2(double *p, const P2 &a) { p[0] = a.x; p[1] = a.y; p[2] = a.phi; }
+__device__ __forceinline__ P3 ld3(const double *p) { P3 r; for (int i = 0; i < 3; i++) r.t[i] = p[i]; for (int i = 0; i < 9; i++) r.R[i] = p[3 + i]; return r; }
+__device__ __forceinline__ void st3(double *p, const P3 &a) { for (int i = 0; i < 3; i++) p[i] = a.t[i]; for (int i = 0; i < 9; i++) p[3 + i] = a.R[i]; }
+__device__ __forceinline__ P2 comp(const P2 &A, const P2 &B) { double s, c; sincos(A.phi, &s, &c); P2 r; r.x = A.x + B.x * c - B.y * s; r.y = A.y + B.x * s + B.y * c; r.phi = wrap_pi(A.phi + B.phi); return r; }
+__device__ __forceinline__ P2 inv(const P2 &A) { double s, c; sincos(A.phi, &s, &c); P2 r; r.x = -A.x * c - A.y * s; r.y = A.x * s - A.y * c; r.phi = -A.phi; return r; }
+__device__ __forceinline__ P3 comp(const P3 &A, const P3 &B) {
+	P3 r;
+#pragma unroll
+	for (int i = 0; i < 3; i++) {
+#pragma unroll
+		for (int j = 0; j < 3; j++) r.R[3 * i + j] = A.R[3 * i] * B.R[j] + A.R[3 * i + 1] * B.R[3 + j] + A.R[3 * i + 2] * B.R[6 + j];
+		r.t[i] = A.t[i] + A.R[3 * i] * B.t[0] + A.R[3 * i + 1] * B.t[1] + A.R[3 * i + 2] * B.t[2];
+	}
+	return r;
+}
+__device__ __forceinline__ P3 inv(const P3 &A) {
+	P3 r;
+#pragma unroll
+	for (int i = 0; i < 3; i++) {
+#pragma unroll
+		for (int j = 0; j < 3; j++) r.R[3 * i + j] = A.R[3 * j + i];
+		r.t[i] = -(A.R[i] * A.t[0] + A.R[3 + i] * A.t[1] + A.R[6 + i] * A.t[2]);
+	}
+	return r;
+}
+__device__ __forceinline__ P3 exp_se3(const double *v) { // SE_traits<3>::pseudo_exp: t=v[0:3], R=Rodrigues(v[3:6])
+	P3 r; r.t[0] = v[0]; r.t[1] = v[1]; r.t[2] = v[2];
+	const double wx = v[3], wy = v[4], wz = v[5], th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
+	double a, b;
+	if (th < 1e-8) { a = 1.0 - th2 * (1.0 / 6.0); b = 0.5 - th2 * (1.0 / 24.0); } else { double s, c; sincos(th, &s, &c); a = s / th; b = (1.0 - c) / th2; }
+	r.R[0] = 1.0 - b * (wy * wy + wz * wz); r.R[1] = -a * wz + b * wx * wy; r.R[2] = a * wy + b * wx * wz;
+	r.R[3] = a * wz + b * wx * wy; r.R[4] = 1.0 - b * (wx * wx + wz * wz); r.R[5] = -a * wx + b * wy * wz;
+	r.R[6] = -a * wy + b * wx * wz; r.R[7] = a * wx + b * wy * wz; r.R[8] = 1.0 - b * (wx * wx + wy * wy);
+	return r;
+}
+template <bool SE3> struct PoseOps;
+template <> struct PoseOps<false> { typedef P2 T; static __device__ __forceinline__ T ident() { return ident2(); } static __device__ __forceinline__ T ld(const double *p) { return ld2(p); } static __device__ __forceinline__ void st(double *p, const T &a) { st2(p, a); }
+	static __device__ __forceinline__ T expm(const double *v) { T r; r.x = v[0]; r.y = v[1]; r.phi = v[2]; return r; } };
+template <> struct PoseOps<true> { typedef P3 T; static __device__ __forceinline__ T ident() { return ident3(); } static __device__ __forceinline__ T ld(const double *p) { return ld3(p); } static __device__ __forceinline__ void st(double *p, const T &a) { st3(p, a); }
+	static __device__ __forceinline__ T expm(const double *v) { return exp_se3(v); } };
+
+// ------------------------------------------------------------------------------------------------ block reductions (deterministic)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+	return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+	return v;
+}
+// red: LDS scratch of >= 8 doubles. All threads get the same result. Contains barriers.
+__device__ __forceinline__ double block_sum(double v, double *red) {
+	v = wave_sum(v);
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+	__syncthreads();
+	double r = 0;
+#pragma unroll
+	for (int w = 0; w < SRBA_WG / 64; w++) r += red[w];
+	return r;
+}
+__device__ __forceinline__ double block_max(double v, double *red) {
+	v = wave_max(v);
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+	__syncthreads();
+	double r = red[0];
+#pragma unroll
+	for (int w = 1; w < SRBA_WG / 64; w++) r = fmax(r, red[w]);
+	return r;
+}
+
+// ------------------------------------------------------------------------------------------------ full-pivot LU inverse (schur.h:200-206)
+template <int N> __device__ __forceinline__ bool fullpiv_inverse(const double *A, double *Ai) {
+	double lu[N * N]; int rp[N], cp[N]; double piv[N];
+#pragma unroll
+	for (int i = 0; i < N * N; i++) lu[i] = A[i];
+#pragma unroll
+	for (int i = 0; i < N; i++) { rp[i] = i; cp[i] = i; piv[i] = 0; }
+	double maxpiv = 0;
+#pragma unroll
+	for (int k = 0; k < N; k++) {
+		int br = k, bc = k; double best = -1;
+		for (int c = k; c < N; c++) for (int r = k; r < N; r++) { const double v = fabs(lu[r * N + c]); if (v > best) { best = v; br = r; bc = c; } }
+		if (best == 0.0) break;
+		if (best > maxpiv) maxpiv = best;
+		if (br != k) { for (int c = 0; c < N; c++) { const double t = lu[k * N + c]; lu[k * N + c] = lu[br * N + c]; lu[br * N + c] = t; } const int t = rp[k]; rp[k] = rp[br]; rp[br] = t; }
+		if (bc != k) { for (int r = 0; r < N; r++) { const double t = lu[r * N + k]; lu[r * N + k] = lu[r * N + bc]; lu[r * N + bc] = t; } const int t = cp[k]; cp[k] = cp[bc]; cp[bc] = t; }
+		piv[k] = lu[k * N + k];
+		for (int r = k + 1; r < N; r++) lu[r * N + k] /= lu[k * N + k];
+		for (int r = k + 1; r < N; r++) for (int c = k + 1; c < N; c++) lu[r * N + c] -= lu[r * N + k] * lu[k * N + c];
+	}
+	const double thr = 2.220446049250313e-16 * N * fabs(maxpiv);
+	int rank = 0;
+#pragma unroll
+	for (int k = 0; k < N; k++) if (fabs(piv[k]) > thr) rank++;
+	if (rank != N) return false;
+	for (int col = 0; col < N; col++) {
+		double b[N];
+		for (int r = 0; r < N; r++) b[r] = (rp[r] == col) ? 1.0 : 0.0;
+		for (int r = 0; r < N; r++) for (int c = 0; c < r; c++) b[r] -= lu[r * N + c] * b[c];
+		for (int r = N - 1; r >= 0; r--) { for (int c = r + 1; c < N; c++) b[r] -= lu[r * N + c] * b[c]; b[r] /= lu[r * N + r]; }
+		for (int r = 0; r < N; r++) Ai[cp[r] * N + col] = b[r];
+	}
+	return true;
+}
+
+// ------------------------------------------------------------------------------------------------ dense packed-lower Cholesky by one workgroup
+__device__ __forceinline__ long long tri(int i) { return (long long)i * (i + 1) / 2; }
+// A: packed lower (row-major: A[tri(i)+j], j<=i). Returns false (uniformly) if a pivot is <= 0. flag: LDS int.
+__device__ bool chol_factor(double *A, int n, int *flag) {
+	const int tid = threadIdx.x;
+	if (tid == 0) *flag = 0;
+	__syncthreads();
+	for (int k = 0; k < n; k++) {
+		if (tid == 0) { const double d = A[tri(k) + k]; if (!(d > 0.0)) *flag = 1; else A[tri(k) + k] = sqrt(d); }
+		__syncthreads();
+		if (*flag) return false;
+		const double dk = A[tri(k) + k];
+		for (int i = k + 1 + tid; i < n; i += SRBA_WG) A[tri(i) + k] /= dk;
+		__syncthreads();
+		// trailing update A[i][j] -= A[i][k]*A[j][k], k<j<=i<n ; 16x16 thread tiles
+		const int m = n - k - 1, tx = tid & 15, ty = tid >> 4;
+		for (int ib = 0; ib < m; ib += 16) {
+			const int i = k + 1 + ib + ty;
+			if (i < n) {
+				const double lik = A[tri(i) + k];
+				for (int jb = 0; jb <= ib; jb += 16) {
+					const int j = k + 1 + jb + tx;
+					if (j <= i) A[tri(i) + j] -= lik * A[tri(j) + k];
+				}
+			}
+		}
+		__syncthreads();
+	}
+	return true;
+}
+// Solve L L^t x = b ; b is overwritten with x (both in global memory).
+__device__ void chol_solve(const double *A, int n, double *b) {
+	const int tid = threadIdx.x;
+	for (int k = 0; k < n; k++) { // forward
+		if (tid == 0) b[k] /= A[tri(k) + k];
+		__syncthreads();
+		const double yk = b[k];
+		for (int i = k + 1 + tid; i < n; i += SRBA_WG) b[i] -= A[tri(i) + k] * yk;
+		__syncthreads();
+	}
+	for (int k = n - 1; k >= 0; k--) { // backward
+		if (tid == 0) b[k] /= A[tri(k) + k];
+		__syncthreads();
+		const double xk = b[k];
+		for (int j = tid; j < k; j += SRBA_WG) b[j] -= A[tri(k) + j] * xk;
+		__syncthreads();
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ the per-problem worker
+template <int FAM>
+struct Worker {
+	typedef Tr<FAM> T; typedef PoseOps<T::SE3> PO; typedef typename PO::T pose_t;
+	static constexpr int P = T::P, L = T::L, O = T::O, PD = T::PD;
+	const Batch &B; const ProbDesc &d; const DevParams &prm; const int tid;
+	__device__ Worker(const Batch &B_, const ProbDesc &d_, const DevParams &p_) : B(B_), d(d_), prm(p_), tid(threadIdx.x) {}
+
+	__device__ __forceinline__ pose_t pose_at(int idx) const { return idx >= 0 ? PO::ld(B.pose + (d.o_pair * 2 + idx) * PD) : PO::ident(); }
+	__device__ __forceinline__ const double *lm_ptr(int ref) const { return ref >= 0 ? B.ulm + (d.o_ulm + ref) * L : B.klm + (d.o_klm + (-1 - ref)) * L; }
+
+	// ---- K1
+	__device__ void phase_spantree(bool only_needed) {
+		for (int p = tid; p < d.n_pairs; p += SRBA_WG) {
+			if (only_needed && !B.pair_needed[d.o_pair + p]) continue;
+			const int b = B.pair_path_off[d.o_ppoff + p], e = B.pair_path_off[d.o_ppoff + p + 1];
+			pose_t acc = PO::ident();
+			for (int k = b; k < e; k++) {
+				const int pe = B.path_edge[d.o_path + k];
+				const pose_t ed = PO::ld(B.edge + (d.o_edge + (pe >> 1)) * PD);
+				acc = (pe & 1) ? comp(acc, inv(ed)) : comp(acc, ed);
+			}
+			PO::st(B.pose + (d.o_pair + p) * 2 * PD, acc);
+			PO::st(B.pose + ((d.o_pair + p) * 2 + 1) * PD, inv(acc));
+		}
+	}
+
+	// ---- sensor helpers
+	__device__ __forceinline__ void to_sensor_point(double *x) const { // point_robot2sensor (srba_options_sensor_pose.h:117-120)
+		if constexpr (T::SE3) if (prm.sensor_pose == SRBA_SENSOR_POSE_SE3) {
+			const double dx = x[0] - prm.SPt[0], dy = x[1] - prm.SPt[1], dz = x[2] - prm.SPt[2];
+			x[0] = prm.SPR[0] * dx + prm.SPR[3] * dy + prm.SPR[6] * dz; x[1] = prm.SPR[1] * dx + prm.SPR[4] * dy + prm.SPR[7] * dz; x[2] = prm.SPR[2] * dx + prm.SPR[5] * dy + prm.SPR[8] * dz;
+		}
+	}
+	// h-Jacobian wrt the point in the sensor frame, already multiplied by R_S^t (jacob_dh_dx_rotate). Returns false if invalid.
+	__device__ __forceinline__ bool dh_dx(double *H, const double *x) const {
+		if constexpr (FAM == SRBA_SE2_RELPOSE2D || FAM == SRBA_SE2_CART2D) { for (int i = 0; i < O * L; i++) H[i] = 0; for (int i = 0; i < O; i++) H[i * L + i] = 1; return true; }
+		else if constexpr (FAM == SRBA_SE2_RB2D) {
+			const double r = hypot(x[0], x[1]); if (r == 0) return false;
+			const double ri = 1.0 / r, ri2 = ri * ri; H[0] = x[0] * ri; H[1] = x[1] * ri; H[2] = -x[1] * ri2; H[3] = x[0] * ri2; return true;
+		} else {
+			double Hs[O * 3];
+			if constexpr (FAM == SRBA_SE3_CART3D) { for (int i = 0; i < 9; i++) Hs[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+			else {
+				if (x[2] <= 0) return false;
+				{ const double zi = 1.0 / x[2], zi2 = zi * zi; Hs[0] = prm.camL[0] * zi; Hs[1] = 0; Hs[2] = -prm.camL[0] * x[0] * zi2; Hs[3] = 0; Hs[4] = prm.camL[1] * zi; Hs[5] = -prm.camL[1] * x[1] * zi2; }
+				if constexpr (FAM == SRBA_SE3_STEREO) {
+					double xr[3];
+					for (int i = 0; i < 3; i++) xr[i] = prm.R2Lt[i] + prm.R2LR[3 * i] * x[0] + prm.R2LR[3 * i + 1] * x[1] + prm.R2LR[3 * i + 2] * x[2];
+					const double zi = 1.0 / xr[2], zi2 = zi * zi; Hs[6] = prm.camR[0] * zi; Hs[7] = 0; Hs[8] = -prm.camR[0] * xr[0] * zi2; Hs[9] = 0; Hs[10] = prm.camR[1] * zi; Hs[11] = -prm.camR[1] * xr[1] * zi2;
+				}
+			}
+			if (prm.sensor_pose == SRBA_SENSOR_POSE_SE3) {
+				for (int i = 0; i < O; i++) for (int j = 0; j < 3; j++) H[i * 3 + j] = Hs[i * 3] * prm.SPR[3 * j] + Hs[i * 3 + 1] * prm.SPR[3 * j + 1] + Hs[i * 3 + 2] * prm.SPR[3 * j + 2];
+			} else for (int i = 0; i < O * 3; i++) H[i] = Hs[i];
+			return true;
+		}
+	}
+
+	// ---- K4 : one residual row
+	__device__ __forceinline__ double residual_row(int i, double *out) const {
+		const int gi = d.o_obs + i;
+		const pose_t bp = pose_at(B.obs_pose[gi]);
+		const double *z = B.obs_z + (long long)gi * O; const double *lm = lm_ptr(B.obs_lm[gi]);
+		double r[O];
+		if constexpr (FAM == SRBA_SE2_RELPOSE2D) { // r = P(z) (-) pose (sensors.h:780-784)
+			double s, c; sincos(bp.phi, &s, &c); const double dx = z[0] - bp.x, dy = z[1] - bp.y;
+			r[0] = dx * c + dy * s; r[1] = -dx * s + dy * c; r[2] = wrap_pi(z[2] - bp.phi);
+		} else if constexpr (!T::SE3) {
+			double s, c; sincos(bp.phi, &s, &c); const double lx = bp.x + lm[0] * c - lm[1] * s, ly = bp.y + lm[0] * s + lm[1] * c;
+			if constexpr (FAM == SRBA_SE2_RB2D) { r[0] = z[0] - hypot(lx, ly); r[1] = z[1] - atan2(ly, lx); } else { r[0] = z[0] - lx; r[1] = z[1] - ly; }
+		} else {
+			double l[3];
+			for (int k = 0; k < 3; k++) l[k] = bp.t[k] + bp.R[3 * k] * lm[0] + bp.R[3 * k + 1] * lm[1] + bp.R[3 * k + 2] * lm[2];
+			to_sensor_point(l); // == (pose (-) S) (+) lm
+			if constexpr (FAM == SRBA_SE3_CART3D) { for (int k = 0; k < 3; k++) r[k] = z[k] - l[k]; }
+			else {
+				r[0] = z[0] - (prm.camL[2] + prm.camL[0] * l[0] / l[2]); r[1] = z[1] - (prm.camL[3] + prm.camL[1] * l[1] / l[2]);
+				if constexpr (FAM == SRBA_SE3_STEREO) {
+					double rr[3]; for (int k = 0; k < 3; k++) rr[k] = prm.R2Lt[k] + prm.R2LR[3 * k] * l[0] + prm.R2LR[3 * k + 1] * l[1] + prm.R2LR[3 * k + 2] * l[2];
+					r[2] = z[2] - (prm.camR[2] + prm.camR[0] * rr[0] / rr[2]); r[3] = z[3] - (prm.camR[3] + prm.camR[1] * rr[1] / rr[2]);
+				}
+			}
+		}
+		double sum2 = 0;
+#pragma unroll
+		for (int k = 0; k < O; k++) sum2 += r[k] * r[k];
+		double contrib = sum2;
+		if (prm.use_robust_kernel) {
+			const double nrm = fmax(1e-11, sqrt(sum2)), q = nrm / prm.kernel_param;
+			const double hub = fabs(2.0 * prm.kernel_param * prm.kernel_param * (sqrt(1.0 + q * q) - 1.0));
+			const double w = sqrt(hub) / nrm;
+#pragma unroll
+			for (int k = 0; k < O; k++) r[k] *= w;
+			contrib = (w * w) * sum2;
+		}
+#pragma unroll
+		for (int k = 0; k < O; k++) out[(long long)gi * O + k] = r[k];
+		return contrib;
+	}
+	__device__ double phase_residuals(double *out, double *red) {
+		double acc = 0;
+		for (int i = tid; i < d.n_obs; i += SRBA_WG) acc += residual_row(i, out);
+		return block_sum(acc, red);
+	}
+
+	// ---- K2
+	__device__ __forceinline__ void jac_dh_dp(int b) {
+		const int gb = d.o_bp + b;
+		const int row = B.bp_res[gb], vs = B.obs_valid[d.o_obs + row];
+		double *J = B.Jp + (long long)gb * O * P;
+		const int iA = B.bp_A[gb]; const bool normal = B.bp_normal[gb] != 0;
+		pose_t D = pose_at(B.bp_D[gb]); pose_t A = pose_at(iA); bool hasA = iA >= 0;
+		const double *xi = lm_ptr(B.bp_lm[gb]);
+		double Jl[O * P]; bool ok = true;
+		if constexpr (!T::SE3) {
+			if (!normal) { // D' = p (+) D ; A' = A (+) (-)p (jacobians.h:565-587,684-711)
+				const P2 p = ld2(B.edge + (d.o_edge + B.bp_col[gb]) * PD);
+				D = comp(p, D); A = hasA ? comp(A, inv(p)) : inv(p); hasA = true;
+			}
+			const double sg = normal ? 1.0 : -1.0;
+			if constexpr (T::REL) { // closed form of dh_dx*J0*J1*J2: depends on D only
+				double sd, cd; sincos(D.phi, &sd, &cd);
+				Jl[0] = sg * cd; Jl[1] = sg * sd; Jl[2] = sg * (D.x * sd - D.y * cd);
+				Jl[3] = -sg * sd; Jl[4] = sg * cd; Jl[5] = sg * (D.x * cd + D.y * sd);
+				Jl[6] = 0; Jl[7] = 0; Jl[8] = sg;
+			} else {
+				const double pa = hasA ? A.phi : 0.0; const P2 AD = hasA ? comp(A, D) : D;
+				double sa, ca, sad, cad; sincos(pa, &sa, &ca); sincos(AD.phi, &sad, &cad);
+				double xl[2] = {AD.x + xi[0] * cad - xi[1] * sad, AD.y + xi[0] * sad + xi[1] * cad};
+				double H[O * L]; ok = dh_dx(H, xl);
+				if (ok) {
+					const double m02 = (-sa * D.x - ca * D.y) + (-xi[0] * sad - xi[1] * cad), m12 = (ca * D.x - sa * D.y) + (xi[0] * cad - xi[1] * sad);
+					for (int i = 0; i < O; i++) { Jl[i * 3] = sg * (H[i * 2] * ca + H[i * 2 + 1] * sa); Jl[i * 3 + 1] = sg * (-H[i * 2] * sa + H[i * 2 + 1] * ca); Jl[i * 3 + 2] = sg * (H[i * 2] * m02 + H[i * 2 + 1] * m12); }
+				}
+			}
+		} else {
+			double RA[9]; bool haveRA = hasA;
+			if (hasA) for (int k = 0; k < 9; k++) RA[k] = A.R[k];
+			// landmark in the observer frame uses the ORIGINAL A (+) D (jacobians.h:259-270)
+			const P3 AD = hasA ? comp(A, D) : D;
+			double xl[3]; for (int k = 0; k < 3; k++) xl[k] = AD.t[k] + AD.R[3 * k] * xi[0] + AD.R[3 * k + 1] * xi[1] + AD.R[3 * k + 2] * xi[2];
+			to_sensor_point(xl);
+			double H[O * 3]; ok = dh_dx(H, xl);
+			if (ok) {
+				if (!normal) { // D' = p (+) D ; R(A') = R(A) R(p)^t (jacobians.h:436-461)
+					const P3 p = ld3(B.edge + (d.o_edge + B.bp_col[gb]) * PD);
+					D = comp(p, D);
+					double T2[9];
+					if (hasA) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) T2[3 * i + j] = A.R[3 * i] * p.R[3 * j] + A.R[3 * i + 1] * p.R[3 * j + 1] + A.R[3 * i + 2] * p.R[3 * j + 2]; }
+					else { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) T2[3 * i + j] = p.R[3 * j + i]; }
+					for (int k = 0; k < 9; k++) RA[k] = T2[k]; haveRA = true;
+				}
+				double HR[O * 3];
+				if (haveRA) { for (int i = 0; i < O; i++) for (int j = 0; j < 3; j++) HR[i * 3 + j] = H[i * 3] * RA[j] + H[i * 3 + 1] * RA[3 + j] + H[i * 3 + 2] * RA[6 + j]; }
+				else for (int k = 0; k < O * 3; k++) HR[k] = H[k];
+				double v[3]; for (int k = 0; k < 3; k++) v[k] = -D.t[k] - (D.R[3 * k] * xi[0] + D.R[3 * k + 1] * xi[1] + D.R[3 * k + 2] * xi[2]);
+				const double sg = normal ? 1.0 : -1.0;
+				for (int i = 0; i < O; i++) {
+					const double h0 = HR[i * 3], h1 = HR[i * 3 + 1], h2 = HR[i * 3 + 2];
+					Jl[i * 6] = sg * h0; Jl[i * 6 + 1] = sg * h1; Jl[i * 6 + 2] = sg * h2;
+					Jl[i * 6 + 3] = sg * (h1 * v[2] - h2 * v[1]); Jl[i * 6 + 4] = sg * (-h0 * v[2] + h2 * v[0]); Jl[i * 6 + 5] = sg * (h0 * v[1] - h1 * v[0]);
+				}
+			}
+		}
+		if (ok) { for (int k = 0; k < O * P; k++) J[k] = Jl[k]; }
+		else atomicMin(&B.first_fail[d.o_valid + vs], b); // sweep index of a dh_dAp block = b
+	}
+	// ---- K3
+	__device__ __forceinline__ void jac_dh_df(int b) {
+		if constexpr (!T::REL) {
+			const int gb = d.o_bf + b;
+			const int row = B.bf_res[gb], vs = B.obs_valid[d.o_obs + row];
+			double *J = B.Jf + (long long)gb * O * L;
+			const int ip = B.bf_pose[gb];
+			const pose_t bp = pose_at(ip);
+			const double *xi = B.ulm + (d.o_ulm + B.bf_col[gb]) * L;
+			double Jl[O * L]; bool ok;
+			if constexpr (!T::SE3) {
+				double s, c; sincos(bp.phi, &s, &c);
+				double xl[2] = {bp.x + xi[0] * c - xi[1] * s, bp.y + xi[0] * s + xi[1] * c};
+				double H[O * L]; ok = dh_dx(H, xl);
+				if (ok) for (int i = 0; i < O; i++) { Jl[i * 2] = H[i * 2] * c + H[i * 2 + 1] * s; Jl[i * 2 + 1] = -H[i * 2] * s + H[i * 2 + 1] * c; }
+			} else {
+				double xl[3]; for (int k = 0; k < 3; k++) xl[k] = bp.t[k] + bp.R[3 * k] * xi[0] + bp.R[3 * k + 1] * xi[1] + bp.R[3 * k + 2] * xi[2];
+				to_sensor_point(xl);
+				double H[O * 3]; ok = dh_dx(H, xl);
+				if (ok) for (int i = 0; i < O; i++) for (int j = 0; j < 3; j++) Jl[i * 3 + j] = H[i * 3] * bp.R[j] + H[i * 3 + 1] * bp.R[3 + j] + H[i * 3 + 2] * bp.R[6 + j];
+			}
+			if (ok) { for (int k = 0; k < O * L; k++) J[k] = Jl[k]; }
+			else atomicMin(&B.first_fail[d.o_valid + vs], d.n_bp + b); // dh_df blocks are swept after all dh_dAp blocks
+		}
+	}
+	// Jacobians of all blocks + validity semantics of jacobians.h:215-216,321-327 (see DESIGN.md "invalid rows")
+	__device__ void phase_jacobians() {
+		for (int i = tid; i < d.n_valid; i += SRBA_WG) { B.valid[d.o_valid + i] = 1; B.first_fail[d.o_valid + i] = 0x7fffffff; }
+		__syncthreads();
+		for (int b = tid; b < d.n_bp; b += SRBA_WG) jac_dh_dp(b);
+		for (int b = tid; b < d.n_bf; b += SRBA_WG) jac_dh_df(b);
+		__syncthreads();
+		for (int i = tid; i < d.n_valid; i += SRBA_WG) if (B.first_fail[d.o_valid + i] != 0x7fffffff) B.valid[d.o_valid + i] = 0;
+		// the first failing block of a row (in sweep order) is zeroed; later ones keep stale values
+		for (int b = tid; b < d.n_bp; b += SRBA_WG) { const int vs = B.obs_valid[d.o_obs + B.bp_res[d.o_bp + b]]; if (B.first_fail[d.o_valid + vs] == b) { double *J = B.Jp + (long long)(d.o_bp + b) * O * P; for (int k = 0; k < O * P; k++) J[k] = 0; } }
+		for (int b = tid; b < d.n_bf; b += SRBA_WG) { const int vs = B.obs_valid[d.o_obs + B.bf_res[d.o_bf + b]]; if (B.first_fail[d.o_valid + vs] == d.n_bp + b) { double *J = B.Jf + (long long)(d.o_bf + b) * O * L; for (int k = 0; k < O * L; k++) J[k] = 0; } }
+		__syncthreads();
+	}
+
+	// ---- K6: H_ij = sum J1^t Lambda J2
+	template <int M1, int M2>
+	__device__ __forceinline__ int hess_block(double *Hout, const int *t1, const int *t2, int tb, int te, const double *J1, const double *J2, const int *res1, const int *res2) {
+		double H[M1 * M2];
+#pragma unroll
+		for (int k = 0; k < M1 * M2; k++) H[k] = 0;
+		int ninv = 0;
+		for (int t = tb; t < te; t++) {
+			const int b1 = t1[t], b2 = t2[t];
+			if (B.valid[d.o_valid + B.obs_valid[d.o_obs + res1[b1]]] && B.valid[d.o_valid + B.obs_valid[d.o_obs + res2[b2]]]) {
+				const double *A = J1 + (long long)b1 * O * M1, *Bm = J2 + (long long)b2 * O * M2;
+				if (prm.noise == SRBA_NOISE_CONSTANT_MATRIX) {
+					for (int i = 0; i < M1; i++) {
+						double jl[O];
+						for (int j = 0; j < O; j++) { double s = 0; for (int k = 0; k < O; k++) s += A[k * M1 + i] * prm.lambda[k * O + j]; jl[j] = s; }
+						for (int j = 0; j < M2; j++) { double s = 0; for (int k = 0; k < O; k++) s += jl[k] * Bm[k * M2 + j]; H[i * M2 + j] += s; }
+					}
+				} else {
+					for (int i = 0; i < M1; i++) for (int j = 0; j < M2; j++) { double s = 0; for (int k = 0; k < O; k++) s += A[k * M1 + i] * Bm[k * M2 + j]; H[i * M2 + j] += s; }
+				}
+			} else ninv++;
+		}
+		const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0;
+#pragma unroll
+		for (int k = 0; k < M1 * M2; k++) Hout[k] = H[k] * sc;
+		return ninv;
+	}
+	__device__ int phase_hessian() { // returns the per-thread invalid count (to be reduced by the caller if wanted)
+		int ninv = 0;
+		const double *Jp = B.Jp + d.o_bp * O * P, *Jf = B.Jf + d.o_bf * O * L;
+		const int *rp = B.bp_res + d.o_bp, *rf = B.bf_res + d.o_bf;
+		for (int b = tid; b < d.n_hap; b += SRBA_WG) {
+			const long long g = d.o_hap + b;
+			ninv += hess_block<P, P>(B.HAp + g * P * P, B.hap_t1 + d.o_hapt, B.hap_t2 + d.o_hapt, B.hap_term_off[d.o_hapoff + b], B.hap_term_off[d.o_hapoff + b + 1], Jp, Jp, rp, rp);
+			for (int k = 0; k < P * P; k++) B.HAp0[g * P * P + k] = B.HAp[g * P * P + k]; // latch for Schur (schur.h:38,165-168)
+		}
+		if constexpr (!T::REL) {
+			for (int b = tid; b < d.n_hf; b += SRBA_WG)
+				ninv += hess_block<L, L>(B.Hf + (d.o_hf + b) * L * L, B.hf_t1 + d.o_hft, B.hf_t2 + d.o_hft, B.hf_term_off[d.o_hfoff + b], B.hf_term_off[d.o_hfoff + b + 1], Jf, Jf, rf, rf);
+			for (int b = tid; b < d.n_hapf; b += SRBA_WG)
+				ninv += hess_block<P, L>(B.HApf + (d.o_hapf + b) * P * L, B.hapf_t1 + d.o_hapft, B.hapf_t2 + d.o_hapft, B.hapf_term_off[d.o_hapfoff + b], B.hapf_term_off[d.o_hapfoff + b + 1], Jp, Jf, rp, rf);
+		}
+		return ninv;
+	}
+
+	// ---- K5
+	template <int M>
+	__device__ __forceinline__ void grad_col(double *g, const double *J, const int *res, int bb, int be, const double *resid) {
+		double acc[M];
+#pragma unroll
+		for (int k = 0; k < M; k++) acc[k] = 0;
+		for (int b = bb; b < be; b++) {
+			const double *A = J + (long long)b * O * M, *r = resid + (long long)(d.o_obs + res[b]) * O;
+			double lr[O];
+			if (prm.noise == SRBA_NOISE_CONSTANT_MATRIX) { for (int k = 0; k < O; k++) { double s = 0; for (int j = 0; j < O; j++) s += prm.lambda[k * O + j] * r[j]; lr[k] = s; } }
+			else for (int k = 0; k < O; k++) lr[k] = r[k];
+			for (int i = 0; i < M; i++) { double s = 0; for (int k = 0; k < O; k++) s += A[k * M + i] * lr[k]; acc[i] += s; }
+		}
+		const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0;
+#pragma unroll
+		for (int k = 0; k < M; k++) g[k] = acc[k] * sc;
+	}
+	__device__ void phase_gradient(const double *resid) {
+		double *g = B.grad + d.o_scal;
+		for (int i = tid; i < d.nK; i += SRBA_WG) grad_col<P>(g + i * P, B.Jp + d.o_bp * O * P, B.bp_res + d.o_bp, B.colp_off[d.o_colp + i], B.colp_off[d.o_colp + i + 1], resid);
+		if constexpr (!T::REL) for (int i = tid; i < d.nF; i += SRBA_WG) grad_col<L>(g + d.nK * P + i * L, B.Jf + d.o_bf * O * L, B.bf_res + d.o_bf, B.colf_off[d.o_colf + i], B.colf_off[d.o_colf + i + 1], resid);
+	}
+	__device__ double lambda_guess(double *red) { // optimize_edges.h:366-390
+		double mx = 0;
+		for (int i = tid; i < d.nK; i += SRBA_WG) { const double *H = B.HAp + (d.o_hap + B.hap_diag[d.o_unk + i]) * P * P; double m = H[0]; for (int k = 1; k < P; k++) m = fmax(m, H[k * P + k]); mx = fmax(mx, m); }
+		if constexpr (!T::REL) for (int i = tid; i < d.nF; i += SRBA_WG) { const double *H = B.Hf + (d.o_hf + B.hf_diag[d.o_ulm + i]) * L * L; double m = H[0]; for (int k = 1; k < L; k++) m = fmax(m, H[k * L + k]); mx = fmax(mx, m); }
+		return 1e-3 * block_max(mx, red);
+	}
+};
+
+} // namespace srbadev

@@ -1,0 +1,601 @@
+/*
+ * srba_hip.hip -- kernels + C ABI (include/srba_hip.h) of the MI355X back-end.  Build: hipcc --offload-arch=gfx950.
+ *
+ * Kernels (all templated on the model family):
+ *   k_lm_run        : the whole Levenberg-Marquardt loop of optimize_edges() (impl/optimize_edges.h:256-751), one workgroup per capsule
+ *   k_spantree, k_residuals, k_linearize, k_solve, k_apply, k_rollback : the same phases as separate launches (stepwise API)
+ * HBM layout: every capsule array is concatenated batch-wide into one device arena (SoA, 256-byte aligned sub-arrays); a second arena
+ * holds state + workspaces.  A per-capsule descriptor (ProbDesc) carries sizes and element offsets.
+ */
+#include "srba_device.hpp"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace srbadev;
+
+// =================================================================================================== device: phases that need the dense system
+namespace srbadev {
+
+template <int FAM>
+struct Solver : public Worker<FAM> {
+	typedef Worker<FAM> W; using W::B; using W::d; using W::prm; using W::tid;
+	static constexpr int P = W::P, L = W::L, O = W::O, PD = W::PD;
+	__device__ Solver(const Batch &B_, const ProbDesc &d_, const DevParams &p_) : W(B_, d_, p_) {}
+	__device__ __forceinline__ bool schur_active() const { return prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0; }
+
+	// K7 + K8 (schur.h:180-268). Mutates HAp and minus_grad in place like the reference.
+	__device__ void schur_reduce(double lambda) {
+		if constexpr (!W::T::REL) {
+			for (int l = tid; l < d.nF; l += SRBA_WG) {
+				double M[L * L], Mi[L * L]; const double *src = B.Hf + (d.o_hf + B.hf_diag[d.o_ulm + l]) * L * L;
+				for (int k = 0; k < L * L; k++) M[k] = src[k];
+				for (int k = 0; k < L; k++) M[k * L + k] += lambda;
+				const bool ok = fullpiv_inverse<L>(M, Mi);
+				B.hf_ok[d.o_ulm + l] = ok ? 1 : 0;
+				if (ok) for (int k = 0; k < L * L; k++) B.Hfinv[(d.o_ulm + l) * L * L + k] = Mi[k];
+			}
+			for (int k = tid; k < d.n_hap * P * P; k += SRBA_WG) B.HAp[d.o_hap * P * P + k] = B.HAp0[d.o_hap * P * P + k];
+			__syncthreads();
+			for (int b = tid; b < d.n_hap; b += SRBA_WG) {
+				double *H = B.HAp + (d.o_hap + b) * P * P;
+				const int tb = B.sch_term_off[d.o_hapoff + b], te = B.sch_term_off[d.o_hapoff + b + 1];
+				if (tb == te) continue;
+				double Hl[P * P]; for (int k = 0; k < P * P; k++) Hl[k] = H[k];
+				for (int t = tb; t < te; t++) {
+					const int l = B.sch_lm[d.o_sch + t]; if (!B.hf_ok[d.o_ulm + l]) continue;
+					const double *W1 = B.HApf + (d.o_hapf + B.sch_b1[d.o_sch + t]) * P * L, *W2 = B.HApf + (d.o_hapf + B.sch_b2[d.o_sch + t]) * P * L, *Hi = B.Hfinv + (d.o_ulm + l) * L * L;
+					double Y[P * L];
+					for (int i = 0; i < P; i++) for (int j = 0; j < L; j++) { double s = 0; for (int k = 0; k < L; k++) s += W1[i * L + k] * Hi[k * L + j]; Y[i * L + j] = s; }
+					for (int i = 0; i < P; i++) for (int j = 0; j < P; j++) { double s = 0; for (int k = 0; k < L; k++) s += Y[i * L + k] * W2[j * L + k]; Hl[i * P + j] -= s; }
+					const int yw = B.sch_yw[d.o_sch + t];
+					if (yw >= 0) for (int k = 0; k < P * L; k++) B.YW[(d.o_yw + yw) * P * L + k] = Y[k];
+				}
+				for (int k = 0; k < P * P; k++) H[k] = Hl[k];
+			}
+			__syncthreads();
+			double *g = B.grad + d.o_scal; const double *gf = g + d.nK * P;
+			for (int i = tid; i < d.nK; i += SRBA_WG) {
+				const int b = B.hap_diag[d.o_unk + i];
+				double acc[P]; for (int r = 0; r < P; r++) acc[r] = g[i * P + r];
+				for (int t = B.sch_term_off[d.o_hapoff + b]; t < B.sch_term_off[d.o_hapoff + b + 1]; t++) {
+					const int l = B.sch_lm[d.o_sch + t]; if (!B.hf_ok[d.o_ulm + l]) continue;
+					const double *Y = B.YW + (d.o_yw + B.sch_yw[d.o_sch + t]) * P * L;
+					for (int r = 0; r < P; r++) { double s = 0; for (int k = 0; k < L; k++) s += Y[r * L + k] * gf[l * L + k]; acc[r] -= s; }
+				}
+				for (int r = 0; r < P; r++) g[i * P + r] = acc[r];
+			}
+			__syncthreads();
+		}
+	}
+	// K10 (schur.h:271-311)
+	__device__ void schur_features() {
+		if constexpr (!W::T::REL) {
+			double *g = B.grad + d.o_scal, *dl = B.delta + d.o_scal;
+			for (int l = tid; l < d.nF; l += SRBA_WG) {
+				if (!B.hf_ok[d.o_ulm + l]) continue;
+				double gl[L]; for (int k = 0; k < L; k++) gl[k] = g[d.nK * P + l * L + k];
+				for (int q = B.lm_hapf_off[d.o_lmoff + l]; q < B.lm_hapf_off[d.o_lmoff + l + 1]; q++) {
+					const int hb = B.lm_hapf_idx[d.o_hapf + q]; const int i = B.hapf_i[d.o_hapf + hb];
+					const double *Wm = B.HApf + (d.o_hapf + hb) * P * L;
+					for (int k = 0; k < L; k++) { double s = 0; for (int r = 0; r < P; r++) s += Wm[r * L + k] * dl[i * P + r]; gl[k] -= s; }
+				}
+				const double *Hi = B.Hfinv + (d.o_ulm + l) * L * L;
+				for (int k = 0; k < L; k++) g[d.nK * P + l * L + k] = gl[k];
+				for (int r = 0; r < L; r++) { double s = 0; for (int k = 0; k < L; k++) s += Hi[r * L + k] * gl[k]; dl[d.nK * P + l * L + r] = s; }
+			}
+			__syncthreads();
+		}
+	}
+	// Dense (H + lambda I), packed lower. (lev-marq_solvers.h:88-150 / :303-325 / :492-519)
+	__device__ void assemble(double *A, double lambda) {
+		const int n = d.n_sys; const long long tot = tri(n);
+		for (long long k = tid; k < tot; k += SRBA_WG) A[k] = 0;
+		__syncthreads();
+		for (int e = tid; e < d.n_hap * P * P; e += SRBA_WG) {
+			const int b = e / (P * P), r = (e / P) % P, q = e % P; const int i = B.hap_i[d.o_hap + b], j = B.hap_j[d.o_hap + b];
+			if (i == j && r > q) continue;
+			const int row = P * i + r, col = P * j + q;
+			A[tri(col) + row] = B.HAp[(d.o_hap + b) * P * P + r * P + q] + ((i == j && r == q) ? lambda : 0.0);
+		}
+		if constexpr (!W::T::REL) if (prm.solver == SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL) {
+			const int base = P * d.nK;
+			for (int e = tid; e < d.n_hapf * P * L; e += SRBA_WG) {
+				const int b = e / (P * L), r = (e / L) % P, q = e % L; const int row = P * B.hapf_i[d.o_hapf + b] + r, col = base + L * B.hapf_j[d.o_hapf + b] + q;
+				A[tri(col) + row] = B.HApf[(d.o_hapf + b) * P * L + r * L + q];
+			}
+			for (int e = tid; e < d.n_hf * L * L; e += SRBA_WG) {
+				const int b = e / (L * L), r = (e / L) % L, q = e % L; const int i = B.hf_i[d.o_hf + b], j = B.hf_j[d.o_hf + b];
+				if (i == j && r > q) continue;
+				const int row = base + L * i + r, col = base + L * j + q;
+				A[tri(col) + row] = B.Hf[(d.o_hf + b) * L * L + r * L + q] + ((i == j && r == q) ? lambda : 0.0);
+			}
+		}
+		__syncthreads();
+	}
+	// solve(lambda): returns false if not positive definite (uniform across the workgroup)
+	__device__ bool solve(double *A, double lambda, int *flag) {
+		if (schur_active()) schur_reduce(lambda);
+		assemble(A, lambda);
+		if (!chol_factor(A, d.n_sys, flag)) return false;
+		double *g = B.grad + d.o_scal, *dl = B.delta + d.o_scal;
+		for (int k = tid; k < d.n_scal; k += SRBA_WG) dl[k] = (k < d.n_sys) ? g[k] : 0.0;
+		__syncthreads();
+		chol_solve(A, d.n_sys, dl);
+		if (schur_active()) schur_features();
+		return true;
+	}
+
+	// K12 backup + K11 apply (optimize_edges.h:491-557)
+	__device__ void apply_update() {
+		typedef typename W::PO PO;
+		const double *dl = B.delta + d.o_scal;
+		for (int i = tid; i < d.nK; i += SRBA_WG) {
+			double *e = B.edge + (d.o_edge + i) * PD, *o = B.old_edge + (d.o_unk + i) * PD;
+			for (int k = 0; k < PD; k++) o[k] = e[k];
+			const typename W::pose_t np = comp(PO::expm(dl + i * P), PO::ld(e));
+			PO::st(e, np);
+		}
+		for (int k = tid; k < d.nF * L; k += SRBA_WG) { B.old_ulm[d.o_ulm * L + k] = B.ulm[d.o_ulm * L + k]; B.ulm[d.o_ulm * L + k] += dl[d.nK * P + k]; }
+		for (int r = tid; r < d.n_req; r += SRBA_WG) { const double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD; double *o = B.old_pose + (d.o_req + r) * PD; for (int k = 0; k < PD; k++) o[k] = s[k]; }
+		__syncthreads();
+	}
+	__device__ void restore() { // optimize_edges.h:664-680
+		for (int i = tid; i < d.nK * PD; i += SRBA_WG) B.edge[d.o_edge * PD + i] = B.old_edge[d.o_unk * PD + i];
+		for (int k = tid; k < d.nF * L; k += SRBA_WG) B.ulm[d.o_ulm * L + k] = B.old_ulm[d.o_ulm * L + k];
+		for (int r = tid; r < d.n_req; r += SRBA_WG) { double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD; const double *o = B.old_pose + (d.o_req + r) * PD; for (int k = 0; k < PD; k++) s[k] = o[k]; }
+		__syncthreads();
+	}
+};
+
+extern __shared__ double srba_lds[]; // [0..15] reductions / flags, [16..] dense system when it fits
+
+template <int FAM>
+__global__ void __launch_bounds__(SRBA_WG) k_lm_run(const Batch B, const DevParams prm) {
+	const ProbDesc &d = B.desc[blockIdx.x];
+	Solver<FAM> S(B, d, prm);
+	constexpr int P = Solver<FAM>::P, L = Solver<FAM>::L, O = Solver<FAM>::O;
+	double *red = srba_lds; int *flag = (int *)(srba_lds + 8);
+	double *A = d.dense_in_lds ? (srba_lds + 16) : (B.dense + d.o_dense);
+	const int tid = threadIdx.x; srba_lm_result *out = B.results + blockIdx.x;
+	const int nObs = d.n_obs, n = d.n_scal;
+	double *resid = B.resid, *resid2 = B.resid2;
+
+	S.phase_spantree(false); // S5
+	__syncthreads();
+	S.phase_jacobians(); // S6,S7
+	const int ninv = (int)block_sum((double)S.phase_hessian(), red); // S10
+	__syncthreads();
+	if (tid == 0) {
+		out->status = 0; out->num_iters = 0; out->num_trials = 0; out->num_not_pd = 0; out->num_accepted = 0; out->num_relinearized = 0; out->stop_reason = 0;
+		out->num_invalid_jacobs = ninv; out->num_observations = nObs; out->num_jacobians = d.n_bp + d.n_bf; out->num_span_tree_numeric_updates = d.n_pairs;
+		for (int k = 0; k < SRBA_TRACE_LEN; k++) { out->trace_chi2[k] = NAN; out->trace_lambda[k] = NAN; out->trace_rho[k] = NAN; }
+	}
+	if ((long long)O * nObs < (long long)n) { if (tid == 0) out->status = 1; return; } // S11
+	double lambda = S.lambda_guess(red), nu = 2.0; // S12
+	double total_err = S.phase_residuals(resid, red); // S13
+	double RMSE = sqrt(total_err / nObs);
+	if (tid == 0) { out->lambda_init = lambda; out->total_sqr_error_init = total_err; }
+	__syncthreads();
+	S.phase_gradient(resid); // S14
+	__syncthreads();
+	int iter = 0, trials = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0; bool stop = false;
+	for (iter = 0; iter < prm.max_iters && !stop; iter++) {
+		double rho = 0;
+		if (lambda >= prm.max_lambda) { stop = true; stopmask |= 1 << SRBA_STOP_LAMBDA; }
+		if (RMSE < prm.max_err) { stop = true; stopmask |= 1 << SRBA_STOP_RMSE; }
+		while (rho <= 0 && !stop) {
+			const int tr = trials++;
+			if (tid == 0 && tr < SRBA_TRACE_LEN) out->trace_lambda[tr] = lambda;
+			if (!S.solve(A, lambda, flag)) {
+				n_notpd++; lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
+				__syncthreads();
+				continue;
+			}
+			S.apply_update();
+			S.phase_spantree(true);
+			__syncthreads();
+			const double new_err = S.phase_residuals(resid2, red);
+			const double new_RMSE = sqrt(new_err / nObs);
+			const double err_red = total_err > 0 ? (total_err - new_err) / total_err : 0;
+			double den = 0; { const double *dl = B.delta + d.o_scal, *g = B.grad + d.o_scal; for (int k = tid; k < n; k += SRBA_WG) den += dl[k] * (lambda * dl[k] + g[k]); }
+			den = block_sum(den, red);
+			rho = (total_err - new_err) / den;
+			if (tid == 0 && tr < SRBA_TRACE_LEN) { out->trace_chi2[tr] = new_err; out->trace_rho[tr] = rho; }
+			if (rho > 0) {
+				n_acc++;
+				const bool relin = (err_red < 0 || err_red > prm.min_relin);
+				{ double *t = resid; resid = resid2; resid2 = t; }
+				total_err = new_err; RMSE = new_RMSE;
+				__syncthreads();
+				if (relin) { n_relin++; S.phase_jacobians(); S.phase_hessian(); __syncthreads(); }
+				S.phase_gradient(resid);
+				__syncthreads();
+				double ninf = 0; { const double *g = B.grad + d.o_scal; for (int k = tid; k < n; k += SRBA_WG) ninf = fmax(ninf, fabs(g[k])); }
+				ninf = block_max(ninf, red);
+				if (ninf <= 1e-15) { stop = true; stopmask |= 1 << SRBA_STOP_GRADIENT; }
+				if (RMSE < prm.max_err) { stop = true; stopmask |= 1 << SRBA_STOP_RMSE; }
+				if (rho > prm.max_rho) { stop = true; stopmask |= 1 << SRBA_STOP_RHO; }
+				lambda *= 1.0 / 3.0; nu = 2.0;
+			} else {
+				S.restore();
+				lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
+			}
+		}
+	}
+	if (!stop) stopmask |= 1 << SRBA_STOP_MAX_ITERS;
+	// S17: crpLandmarksApprox
+	if constexpr (!Solver<FAM>::W::T::REL) {
+		for (int l = tid; l < d.nF; l += SRBA_WG) {
+			const bool ok = prm.cov_recovery == 1 && (S.schur_active() ? (B.hf_ok[d.o_ulm + l] != 0) : true);
+			B.ulm_inf_valid[d.o_ulm + l] = ok ? 1 : 0;
+			if (ok) for (int k = 0; k < L * L; k++) B.ulm_inf[(d.o_ulm + l) * L * L + k] = B.Hf[(d.o_hf + B.hf_diag[d.o_ulm + l]) * L * L + k];
+		}
+	}
+	if (tid == 0) {
+		out->num_iters = iter; out->num_trials = trials; out->num_not_pd = n_notpd; out->num_accepted = n_acc; out->num_relinearized = n_relin; out->stop_reason = stopmask;
+		out->total_sqr_error_final = total_err; out->obs_rmse = RMSE; out->lambda_final = lambda;
+	}
+	(void)P;
+}
+
+// ---- stepwise kernels
+template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_spantree(const Batch B, const DevParams prm, int only_needed) { Solver<FAM> S(B, B.desc[blockIdx.x], prm); S.phase_spantree(only_needed != 0); }
+template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_residuals(const Batch B, const DevParams prm) {
+	Solver<FAM> S(B, B.desc[blockIdx.x], prm); const double e = S.phase_residuals(B.resid, srba_lds); if (threadIdx.x == 0) B.chi2[blockIdx.x] = e;
+}
+template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_linearize(const Batch B, const DevParams prm) {
+	Solver<FAM> S(B, B.desc[blockIdx.x], prm);
+	S.phase_jacobians(); const int ninv = (int)block_sum((double)S.phase_hessian(), srba_lds); __syncthreads();
+	S.phase_gradient(B.resid); __syncthreads();
+	const double l0 = S.lambda_guess(srba_lds);
+	if (threadIdx.x == 0) { B.lambda_io[blockIdx.x] = l0; B.results[blockIdx.x].num_invalid_jacobs = ninv; }
+}
+template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_solve(const Batch B, const DevParams prm) {
+	const ProbDesc &d = B.desc[blockIdx.x]; Solver<FAM> S(B, d, prm);
+	double *A = d.dense_in_lds ? (srba_lds + 16) : (B.dense + d.o_dense);
+	const bool ok = S.solve(A, B.lambda_io[blockIdx.x], (int *)(srba_lds + 8));
+	if (threadIdx.x == 0) B.notpd[blockIdx.x] = ok ? 0 : 1;
+}
+template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_apply(const Batch B, const DevParams prm) { Solver<FAM> S(B, B.desc[blockIdx.x], prm); S.apply_update(); }
+template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_rollback(const Batch B, const DevParams prm) { Solver<FAM> S(B, B.desc[blockIdx.x], prm); S.restore(); }
+
+} // namespace srbadev
+
+// =================================================================================================== host side
+namespace {
+
+struct FamDims { int P, L, O, PD; };
+const FamDims kDims[SRBA_NUM_FAMILIES] = {{3, 3, 3, 3}, {3, 2, 2, 3}, {3, 2, 2, 3}, {6, 3, 4, 12}, {6, 3, 2, 12}, {6, 3, 3, 12}};
+thread_local std::string g_last_error;
+
+struct Arena { // layout builder: 256-byte aligned sub-allocations inside one buffer
+	size_t size = 0;
+	size_t add(size_t bytes) { const size_t off = (size + 255) & ~size_t(255); size = off + bytes; return off; }
+};
+
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->fail(std::string(#call) + ": " + hipGetErrorString(e_)); return -1; } } while (0)
+
+} // namespace
+
+struct srba_hip_ctx {
+	int device = 0; srba_hip_params params; DevParams dp; FamDims dm;
+	hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	std::string error;
+	// batch
+	int n_prob = 0; std::vector<ProbDesc> desc; Batch B; srba_batch_stats stats;
+	char *d_in = nullptr; size_t cap_in = 0; char *d_wk = nullptr; size_t cap_wk = 0;
+	std::vector<char> h_in; // host staging of the input arena
+	size_t lds_bytes = 0; double last_ms = 0;
+	// offsets needed for downloads (bytes inside the wk arena)
+	size_t off_edge = 0, off_ulm = 0, off_pose = 0, off_inf = 0, off_infv = 0, off_res = 0;
+	size_t off_dbg[10] = {0}; int64_t len_dbg[10] = {0};
+	size_t in_off_edge0 = 0, in_off_ulm0 = 0; long long tot_edge = 0, tot_ulm = 0;
+	void fail(const std::string &m) { error = m; g_last_error = m; }
+};
+
+static void make_dev_params(const srba_hip_params &p, DevParams &dp, const FamDims &dm) {
+	std::memset(&dp, 0, sizeof(dp));
+	dp.solver = p.solver; dp.noise = p.noise; dp.sensor_pose = p.sensor_pose; dp.max_iters = p.max_iters; dp.use_robust_kernel = p.use_robust_kernel; dp.cov_recovery = p.cov_recovery;
+	dp.inv_sigma = 1.0 / p.std_noise_observations;
+	for (int i = 0; i < dm.O * dm.O; i++) dp.lambda[i] = p.lambda[i];
+	dp.kernel_param = p.kernel_param; dp.max_err = p.max_error_per_obs_to_stop; dp.max_rho = p.max_rho; dp.max_lambda = p.max_lambda; dp.min_relin = p.min_error_reduction_ratio_to_relinearize;
+	for (int i = 0; i < 3; i++) dp.SPt[i] = p.sensor_pose_se3[i];
+	for (int i = 0; i < 9; i++) dp.SPR[i] = p.sensor_pose_se3[3 + i];
+	for (int i = 0; i < 4; i++) { dp.camL[i] = p.cam_left[i]; dp.camR[i] = p.cam_right[i]; }
+	// R2L = (-)rightCameraPose (models/sensors.h:193): quaternion -> R, then invert
+	const double r = p.right_cam_pose[3], x = p.right_cam_pose[4], y = p.right_cam_pose[5], z = p.right_cam_pose[6];
+	const double R[9] = {r * r + x * x - y * y - z * z, 2 * (x * y - r * z), 2 * (z * x + r * y), 2 * (x * y + r * z), r * r - x * x + y * y - z * z, 2 * (y * z - r * x), 2 * (z * x - r * y), 2 * (y * z + r * x), r * r - x * x - y * y + z * z};
+	for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) dp.R2LR[3 * i + j] = R[3 * j + i];
+	for (int i = 0; i < 3; i++) dp.R2Lt[i] = -(R[i] * p.right_cam_pose[0] + R[3 + i] * p.right_cam_pose[1] + R[6 + i] * p.right_cam_pose[2]);
+}
+
+static int check_params(const srba_hip_params *p) {
+	if (!p || p->family < 0 || p->family >= SRBA_NUM_FAMILIES) { g_last_error = "bad family"; return -1; }
+	if (p->solver < 0 || p->solver > 2) { g_last_error = "bad solver"; return -1; }
+	if (p->noise == SRBA_NOISE_IDENTITY && !(p->std_noise_observations > 0)) { g_last_error = "std_noise_observations must be > 0"; return -1; }
+	if (p->sensor_pose == SRBA_SENSOR_POSE_SE3 && kDims[p->family].PD != 12) { g_last_error = "sensor_pose_on_robot_se3 is only supported with SE3 keyframe poses"; return -1; }
+	return 0;
+}
+
+extern "C" {
+
+int srba_family_dims(int family, int *P, int *L, int *O, int *PD) {
+	if (family < 0 || family >= SRBA_NUM_FAMILIES) return -1;
+	if (P) *P = kDims[family].P; if (L) *L = kDims[family].L; if (O) *O = kDims[family].O; if (PD) *PD = kDims[family].PD; return 0;
+}
+
+void srba_hip_params_default(srba_hip_params *p, int family) {
+	std::memset(p, 0, sizeof(*p));
+	p->family = family; p->solver = SRBA_SOLVER_SCHUR_DENSE_CHOL; p->noise = SRBA_NOISE_IDENTITY; p->sensor_pose = SRBA_SENSOR_POSE_NONE;
+	p->std_noise_observations = 1.0; for (int i = 0; i < 6; i++) p->lambda[i * 6 + i] = 1.0; // overwritten by the caller for O x O
+	for (int i = 0; i < 9; i++) p->sensor_pose_se3[3 + i] = (i % 4 == 0) ? 1.0 : 0.0;
+	p->cam_left[0] = p->cam_left[1] = p->cam_right[0] = p->cam_right[1] = 1.0; p->right_cam_pose[3] = 1.0;
+	p->max_iters = 20; p->use_robust_kernel = 0; p->kernel_param = 3.0; p->max_error_per_obs_to_stop = 1e-6; p->max_rho = 10.0; p->max_lambda = 1e20;
+	p->min_error_reduction_ratio_to_relinearize = 0.01; p->cov_recovery = 1;
+}
+
+const char *srba_hip_last_error(const srba_hip_ctx *ctx) { return ctx ? ctx->error.c_str() : g_last_error.c_str(); }
+
+srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
+	if (check_params(params) != 0) return nullptr;
+	int ndev = 0; hipError_t e = hipGetDeviceCount(&ndev);
+	if (e != hipSuccess || ndev <= 0) { g_last_error = std::string("no HIP device available: ") + hipGetErrorString(e); return nullptr; }
+	if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+	if (device >= ndev) { g_last_error = "HIP device index out of range"; return nullptr; }
+	if ((e = hipSetDevice(device)) != hipSuccess) { g_last_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return nullptr; }
+	srba_hip_ctx *c = new srba_hip_ctx();
+	c->device = device; c->params = *params; c->dm = kDims[params->family]; make_dev_params(*params, c->dp, c->dm);
+	std::memset(&c->B, 0, sizeof(c->B)); std::memset(&c->stats, 0, sizeof(c->stats));
+	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
+	return c;
+}
+
+int srba_hip_set_params(srba_hip_ctx *c, const srba_hip_params *params) {
+	if (!c) return -1;
+	if (check_params(params) != 0) { c->fail(g_last_error); return -1; }
+	if (params->family != c->params.family) { c->fail("srba_hip_set_params: the family of a context cannot change"); return -1; }
+	c->params = *params; make_dev_params(*params, c->dp, c->dm); return 0;
+}
+
+int srba_hip_destroy(srba_hip_ctx *c) {
+	if (!c) return 0;
+	hipSetDevice(c->device);
+	if (c->d_in) hipFree(c->d_in); if (c->d_wk) hipFree(c->d_wk);
+	if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1); if (c->stream) hipStreamDestroy(c->stream);
+	delete c; return 0;
+}
+
+void *srba_hip_stream(srba_hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+double srba_hip_last_kernel_ms(srba_hip_ctx *c) { return c ? c->last_ms : 0.0; }
+
+int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, int n) {
+	if (!c || !caps || n <= 0) { if (c) c->fail("upload: bad arguments"); return -1; }
+	HIPCHK(c, hipSetDevice(c->device));
+	const int P = c->dm.P, L = c->dm.L, O = c->dm.O, PD = c->dm.PD;
+	const bool schur_solver = c->params.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL;
+	c->desc.assign(n, ProbDesc()); srba_batch_stats &st = c->stats; std::memset(&st, 0, sizeof(st)); st.n_problems = n;
+	// ---- pass 1: descriptors and totals
+	long long t_edge = 0, t_unk = 0, t_ulm = 0, t_klm = 0, t_pair = 0, t_path = 0, t_obs = 0, t_valid = 0, t_bp = 0, t_bf = 0, t_hap = 0, t_hapt = 0, t_hf = 0, t_hft = 0, t_hapf = 0, t_hapft = 0, t_sch = 0, t_req = 0, t_scal = 0, t_yw = 0, t_dense = 0;
+	size_t max_lds_doubles = 0; const size_t LDS_BUDGET_DOUBLES = (size_t)(150 * 1024) / 8 - 16;
+	for (int p = 0; p < n; p++) {
+		const srba_problem_capsule &k = caps[p]; ProbDesc &d = c->desc[p];
+		if (k.n_unk_edges < 0 || k.n_unk_lms < 0 || k.n_unk_edges > k.n_edges || (k.n_unk_edges + k.n_unk_lms) == 0) { c->fail("upload: malformed capsule"); return -1; }
+		d.n_edges = k.n_edges; d.nK = k.n_unk_edges; d.nF = k.n_unk_lms; d.n_klm = k.n_known_lms; d.n_pairs = k.n_pairs; d.n_obs = k.n_obs; d.n_valid = k.n_valid; d.n_bp = k.n_bp; d.n_bf = k.n_bf;
+		d.n_hap = k.n_hap; d.n_hf = k.n_hf; d.n_hapf = k.n_hapf; d.n_sch = k.n_sch_terms;
+		d.n_scal = P * d.nK + L * d.nF; d.n_sys = (schur_solver && d.nF > 0 && d.nK > 0) ? P * d.nK : d.n_scal;
+		if (schur_solver && d.nK == 0) { c->fail("upload: Schur solvers need at least one unknown kf2kf edge (the reference has the same restriction, schur.h:34)"); return -1; }
+		int nreq = 0; for (int i = 0; i < 2 * k.n_pairs; i++) nreq += k.pose_required[i] ? 1 : 0; d.n_req = nreq;
+		d.o_edge = t_edge; d.o_unk = t_unk; d.o_ulm = t_ulm; d.o_klm = t_klm; d.o_pair = t_pair; d.o_ppoff = t_pair + p; d.o_path = t_path; d.o_obs = t_obs; d.o_valid = t_valid;
+		d.o_bp = t_bp; d.o_colp = t_unk + p; d.o_bf = t_bf; d.o_colf = t_ulm + p; d.o_hap = t_hap; d.o_hapoff = t_hap + p; d.o_hapt = t_hapt; d.o_hf = t_hf; d.o_hfoff = t_hf + p; d.o_hft = t_hft;
+		d.o_hapf = t_hapf; d.o_hapfoff = t_hapf + p; d.o_hapft = t_hapft; d.o_sch = t_sch; d.o_lmoff = t_ulm + p; d.o_req = t_req; d.o_scal = t_scal; d.o_yw = t_yw; d.o_dense = t_dense;
+		const size_t tri_n = (size_t)d.n_sys * (d.n_sys + 1) / 2;
+		d.dense_in_lds = tri_n <= LDS_BUDGET_DOUBLES ? 1 : 0;
+		if (d.dense_in_lds) max_lds_doubles = std::max(max_lds_doubles, tri_n);
+		int nyw = 0; if (k.n_sch_terms > 0) for (int b = 0; b < k.n_hap; b++) if (k.hap_i[b] == k.hap_j[b]) nyw += k.sch_term_off[b + 1] - k.sch_term_off[b];
+		long long npath_needed = 0; for (int q = 0; q < k.n_pairs; q++) if (k.pair_needed[q]) { st.n_pairs_needed++; npath_needed += k.pair_path_off[q + 1] - k.pair_path_off[q]; }
+		st.n_path_needed += npath_needed;
+		t_edge += k.n_edges; t_unk += d.nK; t_ulm += d.nF; t_klm += d.n_klm; t_pair += k.n_pairs; t_path += k.n_path; t_obs += k.n_obs; t_valid += k.n_valid; t_bp += k.n_bp; t_bf += k.n_bf;
+		t_hap += k.n_hap; t_hapt += k.n_hap_terms; t_hf += k.n_hf; t_hft += k.n_hf_terms; t_hapf += k.n_hapf; t_hapft += k.n_hapf_terms; t_sch += k.n_sch_terms; t_req += nreq; t_scal += d.n_scal; t_yw += nyw; t_dense += (long long)tri_n;
+	}
+	st.n_edges = t_edge; st.n_unk_edges = t_unk; st.n_unk_lms = t_ulm; st.n_pairs = t_pair; st.n_path = t_path; st.n_obs = t_obs; st.n_bp = t_bp; st.n_bf = t_bf; st.n_hap = t_hap; st.n_hap_terms = t_hapt;
+	st.n_hf_terms = t_hft; st.n_hapf_terms = t_hapft; st.n_sch_terms = t_sch; st.n_scalars = t_scal;
+	c->tot_edge = t_edge; c->tot_ulm = t_ulm;
+	// ---- input arena layout
+	Arena in; struct { size_t desc, edge0, ulm0, klm, obs_z, pair_path_off, path_edge, obs_pose, obs_lm, obs_valid, bp_col, bp_res, bp_A, bp_D, bp_lm, colp_off, bf_col, bf_res, bf_pose, colf_off,
+		hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hf_i, hf_j, hf_term_off, hf_t1, hf_t2, hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag, sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw,
+		lm_hapf_off, lm_hapf_idx, req_idx, pair_needed, bp_normal; } o;
+	o.desc = in.add(sizeof(ProbDesc) * n);
+	o.edge0 = in.add(8 * t_edge * PD); o.ulm0 = in.add(8 * t_ulm * L); o.klm = in.add(8 * t_klm * L); o.obs_z = in.add(8 * t_obs * O);
+	o.pair_path_off = in.add(4 * (t_pair + n)); o.path_edge = in.add(4 * t_path); o.obs_pose = in.add(4 * t_obs); o.obs_lm = in.add(4 * t_obs); o.obs_valid = in.add(4 * t_obs);
+	o.bp_col = in.add(4 * t_bp); o.bp_res = in.add(4 * t_bp); o.bp_A = in.add(4 * t_bp); o.bp_D = in.add(4 * t_bp); o.bp_lm = in.add(4 * t_bp); o.colp_off = in.add(4 * (t_unk + n));
+	o.bf_col = in.add(4 * t_bf); o.bf_res = in.add(4 * t_bf); o.bf_pose = in.add(4 * t_bf); o.colf_off = in.add(4 * (t_ulm + n));
+	o.hap_i = in.add(4 * t_hap); o.hap_j = in.add(4 * t_hap); o.hap_term_off = in.add(4 * (t_hap + n)); o.hap_t1 = in.add(4 * t_hapt); o.hap_t2 = in.add(4 * t_hapt);
+	o.hf_i = in.add(4 * t_hf); o.hf_j = in.add(4 * t_hf); o.hf_term_off = in.add(4 * (t_hf + n)); o.hf_t1 = in.add(4 * t_hft); o.hf_t2 = in.add(4 * t_hft);
+	o.hapf_i = in.add(4 * t_hapf); o.hapf_j = in.add(4 * t_hapf); o.hapf_term_off = in.add(4 * (t_hapf + n)); o.hapf_t1 = in.add(4 * t_hapft); o.hapf_t2 = in.add(4 * t_hapft);
+	o.hap_diag = in.add(4 * t_unk); o.hf_diag = in.add(4 * t_ulm);
+	o.sch_term_off = in.add(4 * (t_hap + n)); o.sch_b1 = in.add(4 * t_sch); o.sch_b2 = in.add(4 * t_sch); o.sch_lm = in.add(4 * t_sch); o.sch_yw = in.add(4 * t_sch);
+	o.lm_hapf_off = in.add(4 * (t_ulm + n)); o.lm_hapf_idx = in.add(4 * t_hapf); o.req_idx = in.add(4 * t_req); o.pair_needed = in.add(t_pair); o.bp_normal = in.add(t_bp);
+	in.add(0);
+	c->h_in.assign(in.size + 256, 0); char *h = c->h_in.data();
+	c->in_off_edge0 = o.edge0; c->in_off_ulm0 = o.ulm0;
+	// ---- pass 2: pack
+#define CPY(dstoff, elem_off, src, count, T) do { if ((count) > 0) std::memcpy(h + (dstoff) + sizeof(T) * (size_t)(elem_off), (src), sizeof(T) * (size_t)(count)); } while (0)
+	for (int p = 0; p < n; p++) {
+		const srba_problem_capsule &k = caps[p]; const ProbDesc &d = c->desc[p];
+		CPY(o.edge0, d.o_edge * PD, k.edge_pose, (size_t)k.n_edges * PD, double); CPY(o.ulm0, d.o_ulm * L, k.ulm_pos, (size_t)d.nF * L, double); CPY(o.klm, d.o_klm * L, k.klm_pos, (size_t)d.n_klm * L, double); CPY(o.obs_z, d.o_obs * O, k.obs_z, (size_t)k.n_obs * O, double);
+		CPY(o.pair_path_off, d.o_ppoff, k.pair_path_off, k.n_pairs + 1, int32_t); CPY(o.path_edge, d.o_path, k.path_edge, k.n_path, int32_t);
+		CPY(o.obs_pose, d.o_obs, k.obs_pose, k.n_obs, int32_t); CPY(o.obs_lm, d.o_obs, k.obs_lm, k.n_obs, int32_t); CPY(o.obs_valid, d.o_obs, k.obs_valid, k.n_obs, int32_t);
+		CPY(o.bp_col, d.o_bp, k.bp_col, k.n_bp, int32_t); CPY(o.bp_res, d.o_bp, k.bp_res, k.n_bp, int32_t); CPY(o.bp_A, d.o_bp, k.bp_A, k.n_bp, int32_t); CPY(o.bp_D, d.o_bp, k.bp_D, k.n_bp, int32_t); CPY(o.bp_lm, d.o_bp, k.bp_lm, k.n_bp, int32_t);
+		CPY(o.colp_off, d.o_colp, k.colp_off, d.nK + 1, int32_t);
+		CPY(o.bf_col, d.o_bf, k.bf_col, k.n_bf, int32_t); CPY(o.bf_res, d.o_bf, k.bf_res, k.n_bf, int32_t); CPY(o.bf_pose, d.o_bf, k.bf_pose, k.n_bf, int32_t);
+		if (k.colf_off) CPY(o.colf_off, d.o_colf, k.colf_off, d.nF + 1, int32_t);
+		CPY(o.hap_i, d.o_hap, k.hap_i, k.n_hap, int32_t); CPY(o.hap_j, d.o_hap, k.hap_j, k.n_hap, int32_t); CPY(o.hap_term_off, d.o_hapoff, k.hap_term_off, k.n_hap + 1, int32_t); CPY(o.hap_t1, d.o_hapt, k.hap_t1, k.n_hap_terms, int32_t); CPY(o.hap_t2, d.o_hapt, k.hap_t2, k.n_hap_terms, int32_t);
+		CPY(o.hf_i, d.o_hf, k.hf_i, k.n_hf, int32_t); CPY(o.hf_j, d.o_hf, k.hf_j, k.n_hf, int32_t); if (k.hf_term_off) CPY(o.hf_term_off, d.o_hfoff, k.hf_term_off, k.n_hf + 1, int32_t); CPY(o.hf_t1, d.o_hft, k.hf_t1, k.n_hf_terms, int32_t); CPY(o.hf_t2, d.o_hft, k.hf_t2, k.n_hf_terms, int32_t);
+		CPY(o.hapf_i, d.o_hapf, k.hapf_i, k.n_hapf, int32_t); CPY(o.hapf_j, d.o_hapf, k.hapf_j, k.n_hapf, int32_t); if (k.hapf_term_off) CPY(o.hapf_term_off, d.o_hapfoff, k.hapf_term_off, k.n_hapf + 1, int32_t); CPY(o.hapf_t1, d.o_hapft, k.hapf_t1, k.n_hapf_terms, int32_t); CPY(o.hapf_t2, d.o_hapft, k.hapf_t2, k.n_hapf_terms, int32_t);
+		CPY(o.hap_diag, d.o_unk, k.hap_diag, d.nK, int32_t); CPY(o.hf_diag, d.o_ulm, k.hf_diag, d.nF, int32_t);
+		if (k.n_sch_terms > 0) {
+			CPY(o.sch_term_off, d.o_hapoff, k.sch_term_off, k.n_hap + 1, int32_t); CPY(o.sch_b1, d.o_sch, k.sch_b1, k.n_sch_terms, int32_t); CPY(o.sch_b2, d.o_sch, k.sch_b2, k.n_sch_terms, int32_t); CPY(o.sch_lm, d.o_sch, k.sch_lm, k.n_sch_terms, int32_t);
+			int32_t *yw = (int32_t *)(h + o.sch_yw) + d.o_sch; int cnt = 0;
+			for (int b = 0; b < k.n_hap; b++) for (int t = k.sch_term_off[b]; t < k.sch_term_off[b + 1]; t++) yw[t] = (k.hap_i[b] == k.hap_j[b]) ? cnt++ : -1;
+		} // else: zeros = empty term lists
+		if (k.lm_hapf_off) CPY(o.lm_hapf_off, d.o_lmoff, k.lm_hapf_off, d.nF + 1, int32_t); CPY(o.lm_hapf_idx, d.o_hapf, k.lm_hapf_idx, k.n_hapf, int32_t);
+		{ int32_t *rq = (int32_t *)(h + o.req_idx) + d.o_req; int cnt = 0; for (int i = 0; i < 2 * k.n_pairs; i++) if (k.pose_required[i]) rq[cnt++] = i; }
+		CPY(o.pair_needed, d.o_pair, k.pair_needed, k.n_pairs, uint8_t); CPY(o.bp_normal, d.o_bp, k.bp_normal, k.n_bp, uint8_t);
+	}
+#undef CPY
+	std::memcpy(h + o.desc, c->desc.data(), sizeof(ProbDesc) * n);
+	// ---- work arena layout
+	Arena wk; struct { size_t edge, ulm, pose, Jp, Jf, resid, resid2, HAp, HAp0, Hf, HApf, grad, delta, Hfinv, YW, old_edge, old_ulm, old_pose, dense, ulm_inf, valid, first_fail, hf_ok, ulm_inf_valid, results, lambda_io, chi2, notpd; } w;
+	w.edge = wk.add(8 * t_edge * PD); w.ulm = wk.add(8 * t_ulm * L); w.pose = wk.add(8 * 2 * t_pair * PD); w.Jp = wk.add(8 * t_bp * O * P); w.Jf = wk.add(8 * t_bf * O * L);
+	w.resid = wk.add(8 * t_obs * O); w.resid2 = wk.add(8 * t_obs * O); w.HAp = wk.add(8 * t_hap * P * P); w.HAp0 = wk.add(8 * t_hap * P * P); w.Hf = wk.add(8 * t_hf * L * L); w.HApf = wk.add(8 * t_hapf * P * L);
+	w.grad = wk.add(8 * t_scal); w.delta = wk.add(8 * t_scal); w.Hfinv = wk.add(8 * t_ulm * L * L); w.YW = wk.add(8 * t_yw * P * L); w.old_edge = wk.add(8 * t_unk * PD); w.old_ulm = wk.add(8 * t_ulm * L); w.old_pose = wk.add(8 * t_req * PD);
+	w.dense = wk.add(8 * t_dense); w.ulm_inf = wk.add(8 * t_ulm * L * L); w.valid = wk.add(4 * t_valid); w.first_fail = wk.add(4 * t_valid); w.hf_ok = wk.add(4 * t_ulm); w.ulm_inf_valid = wk.add(t_ulm);
+	w.results = wk.add(sizeof(srba_lm_result) * n); w.lambda_io = wk.add(8 * n); w.chi2 = wk.add(8 * n); w.notpd = wk.add(4 * n);
+	wk.add(0);
+	if (in.size + 256 > c->cap_in) { if (c->d_in) hipFree(c->d_in); c->d_in = nullptr; c->cap_in = 0; const size_t want = (in.size + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_in, want)); c->cap_in = want; }
+	if (wk.size + 256 > c->cap_wk) { if (c->d_wk) hipFree(c->d_wk); c->d_wk = nullptr; c->cap_wk = 0; const size_t want = (wk.size + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_wk, want)); c->cap_wk = want; }
+	HIPCHK(c, hipMemcpyAsync(c->d_in, h, in.size, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(c, hipMemsetAsync(c->d_wk, 0, wk.size, c->stream));
+	// ---- batch struct
+	Batch &B = c->B; std::memset(&B, 0, sizeof(B)); B.n_prob = n; B.max_lds_doubles = (int)max_lds_doubles;
+	char *di = c->d_in, *dw = c->d_wk;
+#define DI(field, T) B.field = (const T *)(di + o.field)
+	B.desc = (const ProbDesc *)(di + o.desc); DI(edge0, double); DI(ulm0, double); DI(klm, double); DI(obs_z, double);
+	DI(pair_path_off, int); DI(path_edge, int); DI(obs_pose, int); DI(obs_lm, int); DI(obs_valid, int); DI(bp_col, int); DI(bp_res, int); DI(bp_A, int); DI(bp_D, int); DI(bp_lm, int); DI(colp_off, int);
+	DI(bf_col, int); DI(bf_res, int); DI(bf_pose, int); DI(colf_off, int); DI(hap_i, int); DI(hap_j, int); DI(hap_term_off, int); DI(hap_t1, int); DI(hap_t2, int); DI(hf_i, int); DI(hf_j, int); DI(hf_term_off, int); DI(hf_t1, int); DI(hf_t2, int);
+	DI(hapf_i, int); DI(hapf_j, int); DI(hapf_term_off, int); DI(hapf_t1, int); DI(hapf_t2, int); DI(hap_diag, int); DI(hf_diag, int); DI(sch_term_off, int); DI(sch_b1, int); DI(sch_b2, int); DI(sch_lm, int); DI(sch_yw, int);
+	DI(lm_hapf_off, int); DI(lm_hapf_idx, int); DI(req_idx, int); DI(pair_needed, unsigned char); DI(bp_normal, unsigned char);
+#undef DI
+#define DW(field, T) B.field = (T *)(dw + w.field)
+	DW(edge, double); DW(ulm, double); DW(pose, double); DW(Jp, double); DW(Jf, double); DW(resid, double); DW(resid2, double); DW(HAp, double); DW(HAp0, double); DW(Hf, double); DW(HApf, double); DW(grad, double); DW(delta, double);
+	DW(Hfinv, double); DW(YW, double); DW(old_edge, double); DW(old_ulm, double); DW(old_pose, double); DW(dense, double); DW(ulm_inf, double); DW(valid, int); DW(first_fail, int); DW(hf_ok, int); DW(ulm_inf_valid, unsigned char);
+	DW(results, srba_lm_result); DW(lambda_io, double); DW(chi2, double); DW(notpd, int);
+#undef DW
+	c->off_edge = w.edge; c->off_ulm = w.ulm; c->off_pose = w.pose; c->off_inf = w.ulm_inf; c->off_infv = w.ulm_inf_valid; c->off_res = w.results;
+	const size_t dbg_off[10] = {w.resid, w.Jp, w.Jf, w.HAp, w.Hf, w.HApf, w.grad, w.delta, w.valid, w.pose};
+	const int64_t dbg_len[10] = {t_obs * O, t_bp * O * P, t_bf * O * L, t_hap * P * P, t_hf * L * L, t_hapf * P * L, t_scal, t_scal, t_valid, 2 * t_pair * PD};
+	for (int i = 0; i < 10; i++) { c->off_dbg[i] = dbg_off[i]; c->len_dbg[i] = dbg_len[i]; }
+	c->n_prob = n; c->lds_bytes = (16 + max_lds_doubles) * 8; st.device_bytes = (int64_t)(in.size + wk.size);
+	if (srba_hip_reset_state(c) != 0) return -1;
+	HIPCHK(c, hipStreamSynchronize(c->stream)); // the staging buffer is pageable and reused by the next upload
+	return 0;
+}
+
+int srba_hip_reset_state(srba_hip_ctx *c) {
+	if (!c || !c->n_prob) return -1;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipMemcpyAsync(c->d_wk + c->off_edge, c->d_in + c->in_off_edge0, 8 * (size_t)c->tot_edge * c->dm.PD, hipMemcpyDeviceToDevice, c->stream));
+	if (c->tot_ulm) HIPCHK(c, hipMemcpyAsync(c->d_wk + c->off_ulm, c->d_in + c->in_off_ulm0, 8 * (size_t)c->tot_ulm * c->dm.L, hipMemcpyDeviceToDevice, c->stream));
+	return 0;
+}
+
+int srba_hip_batch_stats(srba_hip_ctx *c, srba_batch_stats *out) { if (!c || !out) return -1; *out = c->stats; return 0; }
+
+} // extern "C"
+
+// ---- launch helpers
+#define SRBA_DISPATCH(c, KERNEL, lds, ...) do { \
+	const dim3 grid((c)->n_prob), block(SRBA_WG); \
+	switch ((c)->params.family) { \
+		case SRBA_SE2_RELPOSE2D: hipLaunchKernelGGL(srbadev::KERNEL<SRBA_SE2_RELPOSE2D>, grid, block, (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); break; \
+		case SRBA_SE2_RB2D: hipLaunchKernelGGL(srbadev::KERNEL<SRBA_SE2_RB2D>, grid, block, (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); break; \
+		case SRBA_SE2_CART2D: hipLaunchKernelGGL(srbadev::KERNEL<SRBA_SE2_CART2D>, grid, block, (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); break; \
+		case SRBA_SE3_STEREO: hipLaunchKernelGGL(srbadev::KERNEL<SRBA_SE3_STEREO>, grid, block, (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); break; \
+		case SRBA_SE3_MONO: hipLaunchKernelGGL(srbadev::KERNEL<SRBA_SE3_MONO>, grid, block, (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); break; \
+		case SRBA_SE3_CART3D: hipLaunchKernelGGL(srbadev::KERNEL<SRBA_SE3_CART3D>, grid, block, (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); break; \
+	} } while (0)
+
+template <class K> static int allow_big_lds(srba_hip_ctx *c, K kernel, size_t bytes) {
+	if (bytes > 64 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess) { c->fail(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e)); return -1; } }
+	return 0;
+}
+static int prep_lds(srba_hip_ctx *c, bool for_lm) {
+	const size_t b = c->lds_bytes; if (b <= 64 * 1024) return 0;
+	switch (c->params.family) {
+#define CASE(F) case F: return for_lm ? allow_big_lds(c, srbadev::k_lm_run<F>, b) : allow_big_lds(c, srbadev::k_solve<F>, b);
+		CASE(SRBA_SE2_RELPOSE2D) CASE(SRBA_SE2_RB2D) CASE(SRBA_SE2_CART2D) CASE(SRBA_SE3_STEREO) CASE(SRBA_SE3_MONO) CASE(SRBA_SE3_CART3D)
+#undef CASE
+	}
+	return -1;
+}
+
+extern "C" {
+
+int srba_hip_sync(srba_hip_ctx *c) { if (!c) return -1; HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+
+int srba_hip_lm_run_async(srba_hip_ctx *c) {
+	if (!c || !c->n_prob) { if (c) c->fail("lm_run: no batch uploaded"); return -1; }
+	HIPCHK(c, hipSetDevice(c->device));
+	if (prep_lds(c, true) != 0) return -1;
+	HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+	SRBA_DISPATCH(c, k_lm_run, c->lds_bytes);
+	HIPCHK(c, hipGetLastError());
+	HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+	return 0;
+}
+int srba_hip_download_results(srba_hip_ctx *c, srba_lm_result *results, int n) {
+	if (!c || !results || n > c->n_prob) return -1;
+	HIPCHK(c, hipMemcpyAsync(results, c->d_wk + c->off_res, sizeof(srba_lm_result) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream)); return 0;
+}
+int srba_hip_lm_run(srba_hip_ctx *c, srba_lm_result *results) {
+	if (srba_hip_lm_run_async(c) != 0) return -1;
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_ms = ms;
+	if (results) return srba_hip_download_results(c, results, c->n_prob);
+	return 0;
+}
+
+int srba_hip_update_spantree(srba_hip_ctx *c, int only_needed) { if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device)); SRBA_DISPATCH(c, k_spantree, 0, only_needed); HIPCHK(c, hipGetLastError()); return 0; }
+int srba_hip_eval_residuals(srba_hip_ctx *c, double *chi2_out) {
+	if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device));
+	SRBA_DISPATCH(c, k_residuals, 16 * 8); HIPCHK(c, hipGetLastError());
+	if (chi2_out) { HIPCHK(c, hipMemcpyAsync(chi2_out, c->B.chi2, 8 * (size_t)c->n_prob, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+	return 0;
+}
+int srba_hip_linearize(srba_hip_ctx *c) { if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device)); SRBA_DISPATCH(c, k_linearize, 16 * 8); HIPCHK(c, hipGetLastError()); return 0; }
+int srba_hip_solve(srba_hip_ctx *c, const double *lambda, int32_t *not_pd_out) {
+	if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device));
+	if (lambda) HIPCHK(c, hipMemcpyAsync(c->B.lambda_io, lambda, 8 * (size_t)c->n_prob, hipMemcpyHostToDevice, c->stream)); // else: use the lambda guess left by srba_hip_linearize
+	if (prep_lds(c, false) != 0) return -1;
+	SRBA_DISPATCH(c, k_solve, c->lds_bytes); HIPCHK(c, hipGetLastError());
+	if (not_pd_out) { HIPCHK(c, hipMemcpyAsync(not_pd_out, c->B.notpd, 4 * (size_t)c->n_prob, hipMemcpyDeviceToHost, c->stream)); }
+	HIPCHK(c, hipStreamSynchronize(c->stream)); return 0;
+}
+int srba_hip_apply_update(srba_hip_ctx *c) { if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device)); SRBA_DISPATCH(c, k_apply, 0); HIPCHK(c, hipGetLastError()); return 0; }
+int srba_hip_rollback(srba_hip_ctx *c) { if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device)); SRBA_DISPATCH(c, k_rollback, 0); HIPCHK(c, hipGetLastError()); return 0; }
+
+int srba_hip_download_state(srba_hip_ctx *c, srba_problem_capsule *caps, int n) {
+	if (!c || !caps || n != c->n_prob) { if (c) c->fail("download_state: capsule count differs from the uploaded batch"); return -1; }
+	HIPCHK(c, hipSetDevice(c->device));
+	const int L = c->dm.L, PD = c->dm.PD;
+	std::vector<double> edge((size_t)c->tot_edge * PD), ulm((size_t)c->tot_ulm * L), inf((size_t)c->tot_ulm * L * L), pose((size_t)2 * c->stats.n_pairs * PD); std::vector<uint8_t> infv((size_t)c->tot_ulm);
+	HIPCHK(c, hipMemcpyAsync(edge.data(), c->d_wk + c->off_edge, 8 * edge.size(), hipMemcpyDeviceToHost, c->stream));
+	if (!ulm.empty()) { HIPCHK(c, hipMemcpyAsync(ulm.data(), c->d_wk + c->off_ulm, 8 * ulm.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipMemcpyAsync(inf.data(), c->d_wk + c->off_inf, 8 * inf.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipMemcpyAsync(infv.data(), c->d_wk + c->off_infv, infv.size(), hipMemcpyDeviceToHost, c->stream)); }
+	if (!pose.empty()) HIPCHK(c, hipMemcpyAsync(pose.data(), c->d_wk + c->off_pose, 8 * pose.size(), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	for (int p = 0; p < n; p++) {
+		const ProbDesc &d = c->desc[p]; srba_problem_capsule &k = caps[p];
+		if (k.n_unk_edges != d.nK || k.n_unk_lms != d.nF || k.n_pairs != d.n_pairs) { c->fail("download_state: capsule layout differs from the uploaded batch"); return -1; }
+		std::memcpy(k.edge_pose, &edge[(size_t)d.o_edge * PD], 8 * (size_t)d.nK * PD);
+		if (d.nF) std::memcpy(k.ulm_pos, &ulm[(size_t)d.o_ulm * L], 8 * (size_t)d.nF * L);
+		if (k.pose && d.n_pairs) std::memcpy(k.pose, &pose[(size_t)d.o_pair * 2 * PD], 8 * (size_t)d.n_pairs * 2 * PD);
+		if (k.ulm_inf && d.nF) std::memcpy(k.ulm_inf, &inf[(size_t)d.o_ulm * L * L], 8 * (size_t)d.nF * L * L);
+		if (k.ulm_inf_valid && d.nF) std::memcpy(k.ulm_inf_valid, &infv[(size_t)d.o_ulm], (size_t)d.nF);
+	}
+	return 0;
+}
+
+int64_t srba_hip_debug_size(srba_hip_ctx *c, int what) { return (c && what >= 0 && what < 10) ? c->len_dbg[what] : -1; }
+int srba_hip_debug_read(srba_hip_ctx *c, int what, double *out, int64_t n_doubles) {
+	if (!c || what < 0 || what >= 10 || n_doubles < c->len_dbg[what]) return -1;
+	HIPCHK(c, hipSetDevice(c->device));
+	if (what == 8) { std::vector<int> v((size_t)c->len_dbg[8]); HIPCHK(c, hipMemcpyAsync(v.data(), c->d_wk + c->off_dbg[8], 4 * v.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); for (size_t i = 0; i < v.size(); i++) out[i] = v[i]; return 0; }
+	HIPCHK(c, hipMemcpyAsync(out, c->d_wk + c->off_dbg[what], 8 * (size_t)c->len_dbg[what], hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream)); return 0;
+}
+
+} // extern "C"

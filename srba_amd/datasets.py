@@ -1,0 +1,128 @@
+"""Input data for tests and benchmarks.
+
+* Literal datasets quoted from the reference's own tests/tutorials (DATA, not code; origin cited per item).
+* Deterministic synthetic generators for the BASELINE.json configurations (the reference ships only generator
+  configs for the external RWT tool, datasets/README.txt:1-5, so the 30k-keyframe graph-SLAM data is produced here).
+
+A dataset is a list with one entry per keyframe: dict(feat_ids uint64[n], z float64[n,O], flags uint8[n], relpos float64[n,L] or None)
+in the order the reference apps feed define_new_keyframe (apps/srba-slam/srba-run-generic-impl.h:365-461).
+"""
+import math
+import numpy as np
+
+FLAG_FIXED, FLAG_INIT = 1, 2
+
+# tests/submaps_edge_init_values.cpp:61-79 -- (current_kf, observed_kf, x, y, yaw): pose of observed_kf seen from current_kf
+C1_SUBMAPS = [(1, 0, -1.0, 0.0, 0.0), (2, 1, -1.0, 0.0, 0.0), (3, 2, -1.0, 0.0, 0.0), (4, 3, -1.0, 0.0, 0.0), (5, 4, -1.0, 0.0, 0.0), (6, 5, -1.0, 0.0, 0.0),
+              (7, 6, -1.0, 0.0, 0.0), (8, 7, -1.0, 0.0, 0.0), (9, 8, -1.0, 0.0, 0.0), (10, 9, -1.0, 0.0, 0.0), (11, 10, -1.0, 0.0, 0.0), (11, 1, -10.05, 0.0, 0.0),
+              (12, 11, -1.0, 0.0, 0.0), (13, 12, -1.0, 0.0, 0.0), (14, 13, -1.0, 0.0, 0.0), (15, 14, -1.0, 0.0, 0.0), (16, 15, -1.0, 0.0, 0.0)]
+
+# examples/cpp/tutorial-srba-relative-graph-slam-se2.cpp:48-76 -- (current_kf, observed_kf, x, y, yaw)
+C2_TUTORIAL_SE2 = [
+    (1, 0, -1.78055512, 1.11331694, -0.37399920), (2, 1, -1.71545942, 2.05914961, -0.37399882), (2, 0, -2.96619160, 3.74601658, -0.74799802),
+    (3, 2, -1.15014065, 2.45631509, -0.37399920), (4, 3, -0.71839088, 2.17858845, -0.37399920), (4, 2, -0.89163376, 4.88530127, -0.74799839),
+    (5, 4, -1.33870852, 1.73631597, -0.37399882), (5, 3, -1.21151269, 4.02676447, -0.74799802), (6, 5, -1.67977719, 2.03565806, -0.37399920),
+    (6, 4, -2.29159821, 4.14103420, -0.74799802), (7, 6, -1.49006905, 2.30876608, -0.37399920), (8, 7, -1.15992524, 2.21845386, -0.37399882),
+    (9, 8, -1.28889269, 1.78614744, -0.37399920), (9, 7, -1.55814427, 4.27501619, -0.74799802), (10, 9, -1.67026750, 1.96210498, -0.37399920),
+    (10, 8, -2.21751078, 4.09566815, -0.74799839), (11, 10, -1.55210516, 2.27651848, -0.37399882), (12, 11, -1.21625554, 2.27164636, -0.37399920),
+    (13, 12, -1.45455725, 1.51179033, -0.22440012), (13, 11, -2.13482825, 3.99712454, -0.59839931), (14, 13, -2.36655195, 0.41536284, 0.00000000),
+    (14, 12, -3.82110920, 1.92715317, -0.22440012), (15, 14, -2.74448431, -0.11373775, 0.00000000), (15, 0, 4.16910212, 0.67638546, 1.57079633),
+    (16, 0, 1.58658626, 0.30349575, 1.57079633), (16, 15, -2.58251586, -0.37288971, 0.00000000), (16, 1, 1.97243380, 2.36770815, 1.94479552)]
+
+
+def graph_slam_from_entries(entries, sigma_xy=0.0, sigma_yaw=0.0, seed=0):
+    """(current, observed, x, y, yaw) rows -> per-keyframe observation lists, the way the reference test/tutorial builds them
+    (tests/submaps_edge_init_values.cpp:115-146): first the keyframe's own fixed "fake landmark", then its relative-pose observations."""
+    rng = np.random.RandomState(seed)
+    n_kf = max(e[0] for e in entries) + 1
+    out = []
+    for kf in range(n_kf):
+        rows = [e for e in entries if e[0] == kf]
+        ids = [kf] + [e[1] for e in rows]
+        z = [[0.0, 0.0, 0.0]] + [[e[2] + sigma_xy * rng.randn(), e[3] + sigma_xy * rng.randn(), e[4] + sigma_yaw * rng.randn()] for e in rows]
+        flags = [FLAG_FIXED] + [0] * len(rows)
+        out.append(dict(feat_ids=np.array(ids, np.uint64), z=np.array(z, np.float64).reshape(-1, 3), flags=np.array(flags, np.uint8), relpos=None))
+    return out
+
+
+def _compose2(a, b):
+    c, s = math.cos(a[2]), math.sin(a[2])
+    return (a[0] + b[0] * c - b[1] * s, a[1] + b[0] * s + b[1] * c, a[2] + b[2])
+
+
+def _inv_compose2(a, b):
+    """a (-) b : pose a as seen from b"""
+    c, s = math.cos(b[2]), math.sin(b[2])
+    dx, dy = a[0] - b[0], a[1] - b[1]
+    ang = (a[2] - b[2] + math.pi) % (2 * math.pi) - math.pi
+    return (dx * c + dy * s, -dx * s + dy * c, ang)
+
+
+def manhattan_path(n_kf, seed=1, block=100.0, grid=16, step=2.0):
+    """Ground-truth SE2 path: random walk on a `grid` x `grid` Manhattan street map with `block`-metre blocks, <= `step` m and <= 30 deg
+    per keyframe (datasets/world-2d-30k-rel-graph-slam.cfg:26-27 max_step_lin=2.0, max_step_ang=30)."""
+    rng = np.random.RandomState(seed)
+    ix, iy = grid // 2, grid // 2  # current intersection
+    heading = 0  # 0:+x 1:+y 2:-x 3:-y
+    poses = []
+    x, y, th = ix * block, iy * block, 0.0
+    dirs = [(1, 0), (0, 1), (-1, 0), (0, -1)]
+    while len(poses) < n_kf:
+        # choose the next street: no U-turn, stay inside the map
+        cand = [h for h in ((heading + k) % 4 for k in (0, 1, 3)) if 0 <= ix + dirs[h][0] <= grid and 0 <= iy + dirs[h][1] <= grid]
+        if not cand:
+            cand = [(heading + 2) % 4]
+        new_h = cand[rng.randint(len(cand))]
+        # turn in place in <= 30 deg increments, creeping 0.5 m forward per keyframe
+        dth = ((new_h - heading + 1) % 4 - 1) * (math.pi / 2) if new_h != (heading + 2) % 4 else math.pi
+        nturn = int(round(abs(dth) / (math.pi / 6)))
+        for _ in range(nturn):
+            th += dth / nturn
+            x += 0.5 * math.cos(th); y += 0.5 * math.sin(th)
+            poses.append((x, y, th))
+        heading = new_h
+        tx, ty = (ix + dirs[heading][0]) * block, (iy + dirs[heading][1]) * block
+        th = heading * math.pi / 2
+        dist = math.hypot(tx - x, ty - y)
+        nstep = max(1, int(math.ceil(dist / step)))
+        for k in range(1, nstep + 1):
+            poses.append((x + (tx - x) * k / nstep, y + (ty - y) * k / nstep, th))
+        x, y = tx, ty
+        ix += dirs[heading][0]; iy += dirs[heading][1]
+    return poses[:n_kf]
+
+
+def graph_slam_se2(n_kf=30000, seed=1, sigma_xy=1e-3, sigma_yaw_deg=0.2, max_range=9.0, grid=16, block=100.0):
+    """cfg2 of BASELINE.md: SE2 relative graph-SLAM, every keyframe observes all EARLIER keyframes within `max_range` metres
+    ("relative_poses" sensor, datasets/world-2d-30k-rel-graph-slam.cfg:42-45, maxRange 9 m), noise 0.001 m / 0.2 deg (README.md:68)."""
+    rng = np.random.RandomState(seed + 7919)
+    gt = manhattan_path(n_kf, seed=seed, block=block, grid=grid)
+    sig_yaw = math.radians(sigma_yaw_deg)
+    cell = max_range
+    buckets = {}
+    out = []
+    for kf, p in enumerate(gt):
+        cx, cy = int(math.floor(p[0] / cell)), int(math.floor(p[1] / cell))
+        near = []
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for j in buckets.get((cx + dx, cy + dy), ()):
+                    q = gt[j]
+                    if math.hypot(q[0] - p[0], q[1] - p[1]) <= max_range:
+                        near.append(j)
+        near.sort()
+        ids = [kf] + near
+        z = [[0.0, 0.0, 0.0]]
+        for j in near:
+            r = _inv_compose2(gt[j], p)
+            z.append([r[0] + sigma_xy * rng.randn(), r[1] + sigma_xy * rng.randn(), r[2] + sig_yaw * rng.randn()])
+        flags = [FLAG_FIXED] + [0] * len(near)
+        out.append(dict(feat_ids=np.array(ids, np.uint64), z=np.array(z, np.float64).reshape(-1, 3), flags=np.array(flags, np.uint8), relpos=None))
+        buckets.setdefault((cx, cy), []).append(kf)
+    return out
+
+
+def graph_slam_lambda(sigma_xy=1e-3, sigma_yaw_deg=0.2):
+    """Information matrix of apps/srba-slam/CDatasetParser_RelGraphSLAM2D.h:45-52"""
+    s = math.radians(sigma_yaw_deg)
+    return np.diag([1.0 / sigma_xy ** 2, 1.0 / sigma_xy ** 2, 1.0 / s ** 2])

@@ -1,0 +1,274 @@
+"""Script-level drivers over the C ABIs (tests / bench plumbing).
+
+Engine        : srba::RbaEngine<> through libsrba_engine.so (the source-compatible C++ front-end; GPU back-end by default)
+CapsuleBatch  : an array of srba_problem_capsule harvested from an Engine (pre-optimisation state of every optimize_local_area call)
+run_batch_hip : upload + srba_hip_lm_run on the GPU                       (product path)
+run_batch_oracle : CPU oracle on a deep copy of the batch                 (test infrastructure only)
+"""
+import ctypes as C
+import numpy as np
+from . import capi
+
+_RES_FIELDS = ("status", "num_iters", "num_trials", "num_not_pd", "num_accepted", "num_relinearized", "num_invalid_jacobs", "stop_reason",
+               "num_observations", "num_jacobians", "num_span_tree_numeric_updates", "total_sqr_error_init", "total_sqr_error_final", "obs_rmse", "lambda_init", "lambda_final")
+
+
+def results_to_dict(res, n):
+    out = {}
+    for f in _RES_FIELDS:
+        out[f] = np.array([getattr(res[i], f) for i in range(n)])
+    out["chi2_init"] = out["total_sqr_error_init"]; out["chi2_final"] = out["total_sqr_error_final"]
+    out["trace_chi2"] = np.array([list(res[i].trace_chi2) for i in range(n)]).reshape(n, capi.TRACE_LEN)
+    out["trace_lambda"] = np.array([list(res[i].trace_lambda) for i in range(n)]).reshape(n, capi.TRACE_LEN)
+    out["trace_rho"] = np.array([list(res[i].trace_rho) for i in range(n)]).reshape(n, capi.TRACE_LEN)
+    return out
+
+
+class Engine(object):
+    def __init__(self, family, backend="hip", **kw):
+        self.lib = capi.engine_lib()
+        self.family = family
+        self.P, self.L, self.O, self.PD = capi.DIMS[family]
+        cfg = capi.EngineConfig()
+        self.lib.srba_engine_config_default(C.byref(cfg), family)
+        lam = kw.pop("lambda_", None)
+        if lam is not None:
+            lam = np.asarray(lam, np.float64).reshape(-1)
+            for i, v in enumerate(lam):
+                cfg.lambda_[i] = v
+        for k in ("sensor_pose_xyzypr", "cam_left", "cam_right", "right_cam_pose"):
+            if k in kw:
+                for i, v in enumerate(kw.pop(k)):
+                    getattr(cfg, k)[i] = v
+        for k, v in kw.items():
+            if not hasattr(cfg, k):
+                raise KeyError(k)
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        self.h = self.lib.srba_engine_create(C.byref(cfg))
+        if not self.h:
+            raise RuntimeError(self.lib.srba_engine_last_error(None).decode())
+        self._cb = None
+        if backend == "oracle":
+            ora = capi.oracle_lib()
+            fn = C.cast(ora.srba_oracle_run_one, C.c_void_p)
+            self.lib.srba_engine_set_backend_fn(self.h, fn, b"cpu-oracle")
+        elif backend != "hip":
+            raise ValueError(backend)
+
+    def close(self):
+        if self.h:
+            self.lib.srba_engine_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_keyframe(self, feat_ids, z, flags=None, relpos=None):
+        n = len(feat_ids)
+        ids = np.ascontiguousarray(feat_ids, np.uint64); z = np.ascontiguousarray(z, np.float64).reshape(n, self.O)
+        fl = np.ascontiguousarray(flags if flags is not None else np.zeros(n), np.uint8)
+        rp = None if relpos is None else np.ascontiguousarray(relpos, np.float64).reshape(n, self.L)
+        info = capi.KfInfo()
+        rc = self.lib.srba_engine_add_keyframe(self.h, n, ids.ctypes.data_as(C.POINTER(C.c_uint64)), z.ctypes.data_as(capi.PF64), fl.ctypes.data_as(capi.PU8),
+                                                rp.ctypes.data_as(capi.PF64) if rp is not None else None, C.byref(info))
+        if rc != 0:
+            raise RuntimeError(self.lib.srba_engine_last_error(self.h).decode())
+        return info
+
+    def run(self, dataset):
+        return [self.add_keyframe(k["feat_ids"], k["z"], k["flags"], k.get("relpos")) for k in dataset]
+
+    def edges(self):
+        n = self.lib.srba_engine_num_edges(self.h)
+        fr = np.zeros(n, np.uint64); to = np.zeros(n, np.uint64); pose = np.zeros((n, self.PD))
+        f, t = C.c_uint64(), C.c_uint64(); buf = (C.c_double * self.PD)()
+        for i in range(n):
+            self.lib.srba_engine_get_edge(self.h, i, C.byref(f), C.byref(t), buf)
+            fr[i], to[i], pose[i] = f.value, t.value, list(buf)
+        return fr, to, pose
+
+    def unknown_lms(self):
+        n = self.lib.srba_engine_num_unknown_lms(self.h)
+        ids = np.zeros(n, np.uint64); base = np.zeros(n, np.uint64); pos = np.zeros((n, self.L))
+        if n:
+            self.lib.srba_engine_get_unknown_lms(self.h, ids.ctypes.data_as(C.POINTER(C.c_uint64)), base.ctypes.data_as(C.POINTER(C.c_uint64)), pos.ctypes.data_as(capi.PF64))
+        return ids, base, pos
+
+    def st_dump(self, what):
+        n = self.lib.srba_engine_st_dump(self.h, what, None, 0)
+        out = np.zeros(n, np.int64)
+        self.lib.srba_engine_st_dump(self.h, what, out.ctypes.data_as(C.POINTER(C.c_int64)), n)
+        return out
+
+    def rel_pose(self, query, reference):
+        buf = (C.c_double * self.PD)()
+        if self.lib.srba_engine_get_rel_pose(self.h, query, reference, buf) != 0:
+            return None
+        return np.array(list(buf))
+
+    def harvest(self):
+        return CapsuleBatch(self)
+
+
+class CapsuleBatch(object):
+    """View over capsules owned by an Engine (harvest) or by a capsule file / clone."""
+    def __init__(self, owner=None, handle=None, params=None, family=None):
+        self.lib = capi.engine_lib()
+        self.owner = owner; self.handle = handle
+        if owner is not None:
+            self.n = int(self.lib.srba_engine_harvest_count(owner.h))
+            self.ptr = self.lib.srba_engine_harvest_capsules(owner.h)
+            self.params = capi.HipParams(); self.lib.srba_engine_get_hip_params(owner.h, C.byref(self.params))
+            self.family = owner.family
+        else:
+            self.n = int(self.lib.srba_capsule_file_count(handle))
+            self.ptr = self.lib.srba_capsule_file_capsules(handle)
+            self.params = params; self.family = family if family is not None else params.family
+
+    @staticmethod
+    def load(path):
+        lib = capi.engine_lib()
+        h = lib.srba_capsule_file_load(path.encode())
+        if not h:
+            raise RuntimeError(lib.srba_engine_last_error(None).decode())
+        p = capi.HipParams(); lib.srba_capsule_file_params(h, C.byref(p))
+        return CapsuleBatch(handle=h, params=p)
+
+    def clone(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        sub = C.cast(C.addressof(self.ptr.contents) + first * C.sizeof(capi.Capsule), capi.PCAP)
+        h = self.lib.srba_capsule_clone(sub, count, self.family)
+        return CapsuleBatch(handle=h, params=self.params, family=self.family)
+
+    def sub(self, first, count):
+        b = CapsuleBatch.__new__(CapsuleBatch)
+        b.lib = self.lib; b.owner = self.owner; b.handle = None; b._parent = self
+        b.n = count; b.ptr = C.cast(C.addressof(self.ptr.contents) + first * C.sizeof(capi.Capsule), capi.PCAP); b.params = self.params; b.family = self.family
+        return b
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return self.ptr[i]
+
+    def array(self, i, field, dtype, count):
+        p = getattr(self.ptr[i], field)
+        if not p or count == 0:
+            return np.zeros(0, dtype)
+        return np.ctypeslib.as_array(p, shape=(count,)).copy()
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.srba_capsule_file_free(self.handle); self.handle = None
+        except Exception:
+            pass
+
+
+class HipContext(object):
+    def __init__(self, params, device=-1):
+        self.lib = capi.hip_lib()
+        self.params = params
+        self.ctx = self.lib.srba_hip_create(device, C.byref(params))
+        if not self.ctx:
+            raise RuntimeError("srba_hip_create failed: " + self.lib.srba_hip_last_error(None).decode())
+        self.n = 0
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: %s" % (what, self.lib.srba_hip_last_error(self.ctx).decode()))
+
+    def upload(self, batch):
+        self._chk(self.lib.srba_hip_upload_problems(self.ctx, batch.ptr, batch.n), "upload"); self.n = batch.n; self.batch = batch
+
+    def lm_run(self):
+        res = (capi.LmResult * self.n)()
+        self._chk(self.lib.srba_hip_lm_run(self.ctx, res), "lm_run")
+        return results_to_dict(res, self.n)
+
+    def stats(self):
+        s = capi.BatchStats(); self.lib.srba_hip_batch_stats(self.ctx, C.byref(s))
+        return {f[0]: getattr(s, f[0]) for f in capi.BatchStats._fields_}
+
+    def debug(self, what):
+        n = self.lib.srba_hip_debug_size(self.ctx, what)
+        out = np.zeros(max(n, 1))
+        self._chk(self.lib.srba_hip_debug_read(self.ctx, what, out.ctypes.data_as(capi.PF64), out.size), "debug_read")
+        return out[:n]
+
+    def close(self):
+        if self.ctx:
+            self.lib.srba_hip_destroy(self.ctx); self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def run_batch_hip(batch, download=False):
+    ctx = HipContext(batch.params)
+    ctx.upload(batch)
+    out = ctx.lm_run()
+    out["kernel_ms"] = ctx.lib.srba_hip_last_kernel_ms(ctx.ctx)
+    if download:
+        work = batch.clone()
+        ctx._chk(ctx.lib.srba_hip_download_state(ctx.ctx, work.ptr, work.n), "download_state")
+        out["state"] = work
+    ctx.close()
+    return out
+
+
+def run_batch_oracle(batch, threads=1, keep_state=False):
+    ora = capi.oracle_lib()
+    work = batch.clone()
+    res = (capi.LmResult * work.n)()
+    rc = ora.srba_oracle_lm_run(C.byref(batch.params), work.ptr, work.n, res, threads)
+    if rc != 0:
+        raise RuntimeError("oracle failed")
+    out = results_to_dict(res, work.n)
+    if keep_state:
+        out["state"] = work
+    return out
+
+
+def oracle_stage(batch, i, do_solve=False, lam=0.0):
+    """Initial linearisation (S5..S14) of capsule i by the oracle (+ optionally one solve): arrays for per-kernel parity tests."""
+    ora = capi.oracle_lib()
+    work = batch.clone(i, 1)
+    c = work.ptr[0]; P, L, O, PD = capi.DIMS[batch.family]
+    n = P * c.n_unk_edges + L * c.n_unk_lms
+    arr = dict(resid=np.zeros(c.n_obs * O), Jp=np.zeros(c.n_bp * O * P), Jf=np.zeros(c.n_bf * O * L), HAp=np.zeros(c.n_hap * P * P), Hf=np.zeros(c.n_hf * L * L),
+               HApf=np.zeros(c.n_hapf * P * L), grad=np.zeros(n), delta=np.zeros(n), poses=np.zeros(2 * c.n_pairs * PD), scalars=np.zeros(4))
+    p = lambda a: a.ctypes.data_as(capi.PF64)
+    rc = ora.srba_oracle_stage(C.byref(batch.params), work.ptr, 1 if do_solve else 0, lam, p(arr["resid"]), p(arr["Jp"]), p(arr["Jf"]), p(arr["HAp"]), p(arr["Hf"]), p(arr["HApf"]),
+                               p(arr["grad"]), p(arr["delta"]), p(arr["poses"]), p(arr["scalars"]))
+    if rc != 0:
+        raise RuntimeError("oracle stage failed")
+    return arr
+
+
+def graph_slam_engine(backend="hip", submap=10, depth=3, sigma_xy=1e-3, sigma_yaw_deg=0.2, solver=capi.SOLVER_NO_SCHUR_SPARSE, harvest=1, **kw):
+    """srba-slam --se2 --graph-slam configuration (apps/srba-slam/instance_relative_graph_slam_se2.cpp:17-24, srba-run-generic-impl.h:127-182)."""
+    from . import datasets
+    args = dict(solver=solver, noise=capi.NOISE_MATRIX, lambda_=_lam36(datasets.graph_slam_lambda(sigma_xy, sigma_yaw_deg), 3),
+                max_tree_depth=depth, max_optimize_depth=depth, submap_size=submap, min_obs_to_loop_closure=1, optimize_new_edges_alone=1,
+                use_robust_kernel=0, max_error_per_obs_to_stop=1e-8, harvest=harvest)
+    args.update(kw)
+    return Engine(capi.SE2_RELPOSE2D, backend=backend, **args)
+
+
+def _lam36(m, O):
+    out = np.zeros(36); out[:O * O] = np.asarray(m, np.float64).reshape(-1); return out
+
+
+def harvest_graph_slam(dataset, backend="hip", **kw):
+    eng = graph_slam_engine(backend=backend, **kw)
+    eng.run(dataset)
+    b = eng.harvest(); b.engine = eng
+    return b
