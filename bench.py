@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""bench.py -- LM iterations/sec on the 30k-keyframe SE2 relative graph-SLAM workload (BASELINE.json configs[1]).
+
+A "step" = one pass of the hot path over one batch: every local-area problem (capsule) produced by running the 30 000-keyframe
+synthetic map through RbaEngine<>::define_new_keyframe() is re-optimised from its pre-optimisation state by ONE launch of the
+fused Levenberg-Marquardt kernel (srba_hip_lm_run).  Inputs are resident in HBM before the timed region; the only per-step host
+work is a device-to-device reset of the unknowns.  metric value = LM trials (passes of the reference's inner while loop,
+include/srba/impl/optimize_edges.h:471-692) per second, summed over all ranks.
+
+Multi-GPU (BASELINE.json configs[4]): rank r owns an independent map (seed 1+r) -- replicas, no data-path collective;
+torch.distributed is used only for the barrier / max-over-ranks timing the contract asks for.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def algorithmic_bytes(stats, res, P, L, O, PD, relpose):
+    """Algorithmic HBM bytes of one fused launch (DESIGN.md "Roofline accounting"; per-unit figures from SURVEY.md 8d)."""
+    import numpy as np
+    pb = 8 * PD
+    n = len(res["num_trials"])
+    # per-problem counts are not all in `stats` (batch totals); use batch totals x per-problem event counts where the unit is batch-uniform,
+    # and exact per-problem arrays otherwise.
+    per = stats["per_problem"]
+    solves_ok = res["num_trials"] - res["num_not_pd"]
+    relin = 1 + res["num_relinearized"]
+    grad_evals = 1 + res["num_accepted"]
+    k1_init = per["n_path"] * (pb + 4) + per["n_pairs"] * 2 * pb
+    k1_trial = per["n_path_needed"] * (pb + 4) + per["n_pairs_needed"] * 2 * pb
+    blk_in = 2 * pb + pb + (0 if relpose else L * 8) + 16          # A, D, edge pose (inverse edges), landmark, indices/flags
+    k2 = per["n_bp"] * blk_in + per["n_bf"] * (pb + L * 8 + 16)     # fused: J blocks never leave the workgroup's working set
+    hwrite = per["n_hap"] * P * P * 8 + per["n_hf"] * L * L * 8 + per["n_hapf"] * P * L * 8
+    k4 = per["n_obs"] * (pb + (0 if relpose else L * 8) + O * 8 + 12 + O * 8)
+    k5 = per["n_scal"] * 8
+    k9 = per["n_sys"].astype(np.float64) ** 2 * 8                   # dense system read once per factorisation
+    k11 = per["n_unk_edges"] * 2 * pb + per["n_unk_lms"] * 2 * L * 8
+    total = (k1_init + relin * (k2 + hwrite) + (1 + solves_ok) * k4 + grad_evals * k5 + res["num_trials"] * k9 + solves_ok * (k1_trial + k11))
+    return float(total.sum())
+
+
+def per_problem_counts(batch, family):
+    import numpy as np
+    from srba_amd import capi
+    P, L, O, PD = capi.DIMS[family]
+    n = batch.n
+    out = {k: np.zeros(n, np.int64) for k in ("n_path", "n_pairs", "n_path_needed", "n_pairs_needed", "n_bp", "n_bf", "n_hap", "n_hf", "n_hapf", "n_obs", "n_scal", "n_sys", "n_unk_edges", "n_unk_lms")}
+    schur = batch.params.solver != capi.SOLVER_NO_SCHUR_SPARSE
+    for i in range(n):
+        c = batch.ptr[i]
+        out["n_path"][i] = c.n_path; out["n_pairs"][i] = c.n_pairs; out["n_bp"][i] = c.n_bp; out["n_bf"][i] = c.n_bf
+        out["n_hap"][i] = c.n_hap; out["n_hf"][i] = c.n_hf; out["n_hapf"][i] = c.n_hapf; out["n_obs"][i] = c.n_obs
+        out["n_unk_edges"][i] = c.n_unk_edges; out["n_unk_lms"][i] = c.n_unk_lms
+        out["n_scal"][i] = P * c.n_unk_edges + L * c.n_unk_lms
+        out["n_sys"][i] = P * c.n_unk_edges if (schur and c.n_unk_lms > 0) else out["n_scal"][i]
+        if c.n_pairs:
+            need = np.ctypeslib.as_array(c.pair_needed, shape=(c.n_pairs,)).astype(bool)
+            off = np.ctypeslib.as_array(c.pair_path_off, shape=(c.n_pairs + 1,))
+            out["n_pairs_needed"][i] = int(need.sum()); out["n_path_needed"][i] = int((off[1:] - off[:-1])[need].sum())
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n-kf", type=int, default=30000, help="keyframes of the synthetic SE2 graph-SLAM map (BASELINE: 30000)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    import __graft_entry__ as ge
+    ge.build()
+    from srba_amd import capi, datasets, runner
+
+    t0 = time.time()
+    ds = datasets.graph_slam_se2(n_kf=args.n_kf, seed=1 + rank)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    # The drop-in path: the header-only RbaEngine<> front-end with the GPU back-end, keyframe by keyframe (srba-slam --se2 --graph-slam
+    # --submap-size 10 --max-spanning-tree-depth 3 --max-optimize-depth 3 --noise 0.001 --noise-ang 0.2, README.md:65-71), harvesting capsules.
+    batch = runner.harvest_graph_slam(ds, backend="hip", submap=10, depth=3, sigma_xy=1e-3, sigma_yaw_deg=0.2, hip_device=local_rank)
+    t_harvest = time.time() - t0
+    P, L, O, PD = capi.DIMS[batch.family]
+
+    ctx = runner.HipContext(batch.params, device=local_rank)
+    ctx.upload(batch)
+    lib = ctx.lib
+    res = ctx.lm_run()  # functional run: per-problem trial counts (deterministic: identical in every step)
+    trials_per_step = int(res["num_trials"].sum())
+    obs_trials_per_step = int((res["num_trials"] * res["num_observations"]).sum())
+    for _ in range(args.warmup):
+        lib.srba_hip_reset_state(ctx.ctx); lib.srba_hip_lm_run_async(ctx.ctx)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kern_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lib.srba_hip_reset_state(ctx.ctx)
+        lib.srba_hip_lm_run_async(ctx.ctx)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # kernel-only duration with HIP events on the context's stream (one extra, untimed, synchronous launch per sample)
+    for _ in range(min(5, max(1, args.steps))):
+        lib.srba_hip_reset_state(ctx.ctx); lib.srba_hip_lm_run(ctx.ctx, None); kern_ms.append(lib.srba_hip_last_kernel_ms(ctx.ctx))
+    kernel_ms = float(np.mean(kern_ms))
+
+    tot_trials = trials_per_step; tot_obs = obs_trials_per_step; max_elapsed = elapsed
+    if dist is not None:
+        t = torch.tensor([float(trials_per_step), float(obs_trials_per_step)], device="cuda", dtype=torch.float64); dist.all_reduce(t)
+        m = torch.tensor([elapsed], device="cuda", dtype=torch.float64); dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        tot_trials, tot_obs, max_elapsed = int(t[0].item()), int(t[1].item()), float(m[0].item())
+
+    if rank == 0:
+        stats = ctx.stats(); stats["per_problem"] = per_problem_counts(batch, batch.family)
+        abytes = algorithmic_bytes(stats, res, P, L, O, PD, relpose=True)
+        achieved = abytes / (kernel_ms * 1e-3) / 1e9
+        cpu = None
+        if args.cpu_seconds > 0 and world >= 1:
+            probe = min(batch.n, 200)
+            t1 = time.perf_counter(); r = runner.run_batch_oracle(batch.sub(0, probe)); dt = time.perf_counter() - t1
+            m = int(min(batch.n, max(probe, probe * args.cpu_seconds / max(dt, 1e-6))))
+            t1 = time.perf_counter(); r = runner.run_batch_oracle(batch.sub(0, m)); dt = time.perf_counter() - t1
+            cpu = {"value": float(r["num_trials"].sum() / dt), "unit": "LM iterations/s", "cores": 1, "kind": "port",
+                   "sample": "oracle/srba_oracle.cpp (g++ -O2, 1 thread) on the first %d of %d capsules of the same batch, %.1f s" % (m, batch.n, dt),
+                   "obs_per_s": float((r["num_trials"] * r["num_observations"]).sum() / dt)}
+        line = {
+            "metric": "LM iterations/sec (and obs/sec) on 30k-KF graph-SLAM; chi2 match vs CPU", "value": tot_trials * args.steps / max_elapsed, "unit": "LM iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * max_elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "world-2d-30k relative graph-SLAM, SE2 graph-slam, submap=10 depth=3: %d keyframes per GPU -> %d optimize_local_area capsules per GPU, re-optimised per step" % (args.n_kf, batch.n),
+                       "keyframes_per_gpu": args.n_kf, "capsules_per_gpu": batch.n, "lm_trials_per_step_per_gpu": trials_per_step, "obs_per_s": tot_obs * args.steps / max_elapsed,
+                       "parallelism": "replicas x%d (independent maps, no collective)" % world, "solver": "no-Schur, dense LL^t on device (reference: CSparse)",
+                       "setup_s": {"dataset": round(t_gen, 2), "sequential_slam_harvest_gpu_backend": round(t_harvest, 2)}},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "kernel": "k_lm_run<SE2_RELPOSE2D>", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -251,7 +251,8 @@ int  srba_hip_debug_read(srba_hip_ctx *ctx, int what, double *out, int64_t n_dou
 /* Totals over the uploaded batch: used by bench.py for the algorithmic-bytes roofline. */
 typedef struct srba_batch_stats {
 	int64_t n_problems, n_edges, n_unk_edges, n_unk_lms, n_pairs, n_pairs_needed, n_path, n_path_needed,
-	        n_obs, n_bp, n_bf, n_hap, n_hap_terms, n_hf_terms, n_hapf_terms, n_sch_terms, n_scalars;
+	        n_obs, n_bp, n_bf, n_hap, n_hap_terms, n_hf_terms, n_hapf_terms, n_sch_terms, n_scalars,
+	        n_chol_blocks /* 3x3 blocks of the symbolic Cholesky factors */, n_chol_items /* block updates per factorisation */;
 	int64_t device_bytes;   /* HBM held by the context for this batch */
 } srba_batch_stats;
 int  srba_hip_batch_stats(srba_hip_ctx *ctx, srba_batch_stats *out);

@@ -51,7 +51,7 @@ class LmResult(C.Structure):
 
 class BatchStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("n_problems", "n_edges", "n_unk_edges", "n_unk_lms", "n_pairs", "n_pairs_needed", "n_path", "n_path_needed", "n_obs", "n_bp", "n_bf",
-                                         "n_hap", "n_hap_terms", "n_hf_terms", "n_hapf_terms", "n_sch_terms", "n_scalars", "device_bytes")]
+                                         "n_hap", "n_hap_terms", "n_hf_terms", "n_hapf_terms", "n_sch_terms", "n_scalars", "n_chol_blocks", "n_chol_items", "device_bytes")]
 
 
 class EngineConfig(C.Structure):
@@ -132,6 +132,8 @@ def engine_lib():
         lib.srba_engine_st_dump.argtypes = [C.c_void_p, c_i32, C.POINTER(C.c_int64), C.c_int64]; lib.srba_engine_st_dump.restype = C.c_int64
         lib.srba_engine_get_rel_pose.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, PF64]
         lib.srba_engine_profiler_mean.argtypes = [C.c_void_p, C.c_char_p]; lib.srba_engine_profiler_mean.restype = c_f64
+        lib.srba_engine_alloc_keyframe.argtypes = [C.c_void_p]; lib.srba_engine_alloc_keyframe.restype = C.c_uint64
+        lib.srba_engine_create_edge.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, PF64]; lib.srba_engine_create_edge.restype = C.c_int64
         lib.srba_engine_harvest_count.argtypes = [C.c_void_p]; lib.srba_engine_harvest_count.restype = C.c_int64
         lib.srba_engine_harvest_capsules.argtypes = [C.c_void_p]; lib.srba_engine_harvest_capsules.restype = PCAP
         lib.srba_engine_harvest_kf.argtypes = [C.c_void_p, C.c_int64]; lib.srba_engine_harvest_kf.restype = C.c_uint64

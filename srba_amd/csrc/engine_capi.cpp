@@ -51,6 +51,8 @@ struct EngineBase {
 	virtual int64_t st_dump(int what, int64_t *out, int64_t cap) const = 0;
 	virtual int get_rel_pose(uint64_t query, uint64_t reference, double *pose) const = 0;
 	virtual double profiler_mean(const char *name) const = 0;
+	virtual uint64_t alloc_keyframe() = 0;
+	virtual int64_t create_edge(uint64_t new_kf, uint64_t from, uint64_t to, const double *pose) = 0;
 };
 
 template <class KF, class LM, class OBS, class NOISE, class SPOSE, class SOLVER>
@@ -138,6 +140,11 @@ struct EngineImpl : public EngineBase {
 	}
 	int get_rel_pose(uint64_t query, uint64_t reference, double *pose) const { const typename rba_t::pose_t *p = rba.get_kf_relative_pose(query, reference); if (!p) return -1; p->storeTo(pose); return 0; }
 	double profiler_mean(const char *name) const { return const_cast<rba_t &>(rba).get_time_profiler().getMeanTime(name); }
+	uint64_t alloc_keyframe() { return rba.alloc_keyframe(); }
+	int64_t create_edge(uint64_t new_kf, uint64_t from, uint64_t to, const double *pose) {
+		try { typename rba_t::pose_t p; if (pose) p.loadFrom(pose); typename rba_t::new_kf_observations_t dummy; return (int64_t)rba.create_kf2kf_edge(new_kf, TPairKeyFrameID(from, to), dummy, p); }
+		catch (std::exception &e) { error = e.what(); return -1; }
+	}
 };
 
 typedef options::observation_noise_identity N_ID;
@@ -219,6 +226,8 @@ int64_t srba_engine_num_unknown_lms(void *h) { return static_cast<EngineBase *>(
 int srba_engine_get_unknown_lms(void *h, uint64_t *ids, uint64_t *base, double *pos) { return static_cast<EngineBase *>(h)->get_unknown_lms(ids, base, pos); }
 int64_t srba_engine_st_dump(void *h, int what, int64_t *out, int64_t cap) { return static_cast<EngineBase *>(h)->st_dump(what, out, cap); }
 int srba_engine_get_rel_pose(void *h, uint64_t query, uint64_t reference, double *pose) { return static_cast<EngineBase *>(h)->get_rel_pose(query, reference, pose); }
+uint64_t srba_engine_alloc_keyframe(void *h) { return static_cast<EngineBase *>(h)->alloc_keyframe(); }
+int64_t srba_engine_create_edge(void *h, uint64_t new_kf, uint64_t from, uint64_t to, const double *pose) { return static_cast<EngineBase *>(h)->create_edge(new_kf, from, to, pose); }
 double srba_engine_profiler_mean(void *h, const char *name) { return static_cast<EngineBase *>(h)->profiler_mean(name); }
 
 int64_t srba_engine_harvest_count(void *h) { return (int64_t)static_cast<EngineBase *>(h)->harvest.data.size(); }

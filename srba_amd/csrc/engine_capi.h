@@ -52,6 +52,9 @@ int   srba_engine_get_unknown_lms(void *h, uint64_t *ids, uint64_t *base, double
 int64_t srba_engine_st_dump(void *h, int what, int64_t *out, int64_t cap);
 int   srba_engine_get_rel_pose(void *h, uint64_t query, uint64_t reference, double *pose);
 double srba_engine_profiler_mean(void *h, const char *name);
+/* Low-level graph construction (RbaEngine.h:334-347), used by the spanning-tree property tests */
+uint64_t srba_engine_alloc_keyframe(void *h);
+int64_t srba_engine_create_edge(void *h, uint64_t new_kf, uint64_t from, uint64_t to, const double *pose /*PD or NULL*/);
 int64_t srba_engine_harvest_count(void *h);
 srba_problem_capsule *srba_engine_harvest_capsules(void *h);
 uint64_t srba_engine_harvest_kf(void *h, int64_t i);

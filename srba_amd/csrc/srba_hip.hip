@@ -8,8 +8,10 @@
  * holds state + workspaces.  A per-capsule descriptor (ProbDesc) carries sizes and element offsets.
  */
 #include "srba_device.hpp"
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -89,43 +91,89 @@ struct Solver : public Worker<FAM> {
 			__syncthreads();
 		}
 	}
-	// Dense (H + lambda I), packed lower. (lev-marq_solvers.h:88-150 / :303-325 / :492-519)
-	__device__ void assemble(double *A, double lambda) {
-		const int n = d.n_sys; const long long tot = tri(n);
-		for (long long k = tid; k < tot; k += SRBA_WG) A[k] = 0;
+	// (H + lambda I) scattered into the block-sparse storage + right-hand side (lev-marq_solvers.h:88-150 / :303-325 / :492-519)
+	__device__ __forceinline__ void put(const SparseSys &S, int row, int col, double v) const { // row <= col in the upper triangle -> stored at (col,row)
+		double *p = sp_elem(S, col, row); if (p) *p = v;
+	}
+	// store element (r,q) of an upper-triangle sub-block whose destination block is `dst` (>=0 off-diagonal, stored transposed; <0 diagonal)
+	__device__ __forceinline__ void put_dst(const SparseSys &S, int dst, int r3, int q3, double v) const {
+		if (dst >= 0) S.off[9 * dst + q3 * 3 + r3] = v;
+		else if (dst != (int)0x80000000 && r3 <= q3) S.diag[9 * (-1 - dst) + q3 * 3 + r3] = v;
+	}
+	__device__ void assemble(const SparseSys &S, double lambda) {
+		const int n = d.n_sys, nb = d.nb;
+		for (int k = tid; k < 9 * nb; k += SRBA_WG) S.diag[k] = 0;
+		for (int k = tid; k < 9 * S.nnzoff; k += SRBA_WG) S.off[k] = 0;
+		const double *g = B.grad + d.o_scal;
+		for (int k = tid; k < 3 * nb; k += SRBA_WG) S.rhs[k] = (k < n) ? g[k] : 0.0;
 		__syncthreads();
+		constexpr int PB = P / 3;
 		for (int e = tid; e < d.n_hap * P * P; e += SRBA_WG) {
-			const int b = e / (P * P), r = (e / P) % P, q = e % P; const int i = B.hap_i[d.o_hap + b], j = B.hap_j[d.o_hap + b];
-			if (i == j && r > q) continue;
-			const int row = P * i + r, col = P * j + q;
-			A[tri(col) + row] = B.HAp[(d.o_hap + b) * P * P + r * P + q] + ((i == j && r == q) ? lambda : 0.0);
+			const int b = e / (P * P), r = (e / P) % P, q = e % P;
+			const bool dg = (r == q) && (B.hap_i[d.o_hap + b] == B.hap_j[d.o_hap + b]);
+			put_dst(S, B.hap_dst[(d.o_hap + b) * PB * PB + (r / 3) * PB + (q / 3)], r % 3, q % 3, B.HAp[(d.o_hap + b) * P * P + r * P + q] + (dg ? lambda : 0.0));
 		}
 		if constexpr (!W::T::REL) if (prm.solver == SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL) {
 			const int base = P * d.nK;
-			for (int e = tid; e < d.n_hapf * P * L; e += SRBA_WG) {
-				const int b = e / (P * L), r = (e / L) % P, q = e % L; const int row = P * B.hapf_i[d.o_hapf + b] + r, col = base + L * B.hapf_j[d.o_hapf + b] + q;
-				A[tri(col) + row] = B.HApf[(d.o_hapf + b) * P * L + r * L + q];
-			}
-			for (int e = tid; e < d.n_hf * L * L; e += SRBA_WG) {
-				const int b = e / (L * L), r = (e / L) % L, q = e % L; const int i = B.hf_i[d.o_hf + b], j = B.hf_j[d.o_hf + b];
-				if (i == j && r > q) continue;
-				const int row = base + L * i + r, col = base + L * j + q;
-				A[tri(col) + row] = B.Hf[(d.o_hf + b) * L * L + r * L + q] + ((i == j && r == q) ? lambda : 0.0);
+			if (d.aligned) {
+				if constexpr (L == 3) {
+					for (int e = tid; e < d.n_hapf * P * L; e += SRBA_WG) {
+						const int b = e / (P * L), r = (e / L) % P, q = e % L;
+						put_dst(S, B.hapf_dst[(d.o_hapf + b) * PB + (r / 3)], r % 3, q, B.HApf[(d.o_hapf + b) * P * L + r * L + q]);
+					}
+					for (int e = tid; e < d.n_hf * L * L; e += SRBA_WG) {
+						const int b = e / (L * L), r = (e / L) % L, q = e % L;
+						const bool dg = (r == q) && (B.hf_i[d.o_hf + b] == B.hf_j[d.o_hf + b]);
+						put_dst(S, B.hf_dst[d.o_hf + b], r, q, B.Hf[(d.o_hf + b) * L * L + r * L + q] + (dg ? lambda : 0.0));
+					}
+				}
+			} else { // landmark blocks straddle 3x3 block boundaries (L == 2): generic per-element placement
+				for (int e = tid; e < d.n_hapf * P * L; e += SRBA_WG) {
+					const int b = e / (P * L), r = (e / L) % P, q = e % L;
+					put(S, P * B.hapf_i[d.o_hapf + b] + r, base + L * B.hapf_j[d.o_hapf + b] + q, B.HApf[(d.o_hapf + b) * P * L + r * L + q]);
+				}
+				for (int e = tid; e < d.n_hf * L * L; e += SRBA_WG) {
+					const int b = e / (L * L), r = (e / L) % L, q = e % L; const int i = B.hf_i[d.o_hf + b], j = B.hf_j[d.o_hf + b];
+					if (i == j && r > q) continue;
+					put(S, base + L * i + r, base + L * j + q, B.Hf[(d.o_hf + b) * L * L + r * L + q] + ((i == j && r == q) ? lambda : 0.0));
+				}
 			}
 		}
+		for (int k = n + tid; k < 3 * nb; k += SRBA_WG) S.diag[9 * (k / 3) + 4 * (k % 3)] = 1.0; // identity padding
 		__syncthreads();
 	}
-	// solve(lambda): returns false if not positive definite (uniform across the workgroup)
-	__device__ bool solve(double *A, double lambda, int *flag) {
-		if (schur_active()) schur_reduce(lambda);
-		assemble(A, lambda);
-		if (!chol_factor(A, d.n_sys, flag)) return false;
-		double *g = B.grad + d.o_scal, *dl = B.delta + d.o_scal;
-		for (int k = tid; k < d.n_scal; k += SRBA_WG) dl[k] = (k < d.n_sys) ? g[k] : 0.0;
-		__syncthreads();
-		chol_solve(A, d.n_sys, dl);
-		if (schur_active()) schur_features();
+	// solve(lambda): returns false if not positive definite (uniform across the wavefront)
+	__device__ bool solve(const SparseSys &S, double lambda, long long *pc = nullptr) {
+		long long t0 = 0;
+#define STIC() do { if (pc) { __syncthreads(); t0 = wall_clock64(); } } while (0)
+#define STOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - t0; } } while (0)
+		STIC(); if (schur_active()) schur_reduce(lambda); STOC(9);
+		STIC(); assemble(S, lambda); STOC(10);
+		STIC(); const bool ok = sp_factor_fsub(S); STOC(11);
+		if (!ok) return false;
+		STIC(); sp_bsub(S);
+		double *dl = B.delta + d.o_scal;
+		for (int k = tid; k < d.n_scal; k += SRBA_WG) dl[k] = (k < d.n_sys) ? S.rhs[k] : 0.0;
+		__syncthreads(); STOC(12);
+		STIC(); if (schur_active()) schur_features(); STOC(13);
 		return true;
+#undef STIC
+#undef STOC
+	}
+	template <bool DLDS> __device__ __forceinline__ SparseSys make_sys(double *lds) const {
+		SparseSys S; S.nb = d.nb; S.nnzoff = d.nnzoff;
+		S.col_off = B.sp_col_off + d.o_spcol; S.row = B.sp_row + d.o_sprow; S.item_off = B.sp_item_off + d.o_spcol; S.tgt = B.sp_tgt + d.o_spitem;
+		double *base; if constexpr (DLDS) base = lds; else base = B.dense + d.o_dense;
+		S.diag = base; S.off = base + 9 * d.nb; S.rhs = S.off + 9 * d.nnzoff;
+		if constexpr (DLDS) { // symbolic structure next to the numbers: the factorisation's dependent index loads hit LDS, not L2
+			int *ip = (int *)(S.rhs + 3 * d.nb); int *c0 = ip, *i0 = ip + d.nb + 1, *r0 = i0 + d.nb + 1, *t0 = r0 + d.nnzoff;
+			for (int k = tid; k <= d.nb; k += SRBA_WG) { c0[k] = S.col_off[k]; i0[k] = S.item_off[k]; }
+			for (int k = tid; k < d.nnzoff; k += SRBA_WG) r0[k] = S.row[k];
+			for (int k = tid; k < d.n_items; k += SRBA_WG) t0[k] = S.tgt[k];
+			S.col_off = c0; S.item_off = i0; S.row = r0; S.tgt = t0;
+			__syncthreads();
+		}
+		return S;
 	}
 
 	// K12 backup + K11 apply (optimize_edges.h:491-557)
@@ -150,24 +198,28 @@ struct Solver : public Worker<FAM> {
 	}
 };
 
-extern __shared__ double srba_lds[]; // [0..15] reductions / flags, [16..] dense system when it fits
+extern __shared__ double srba_lds[]; // block-sparse system of the capsule (diag | off | rhs) when it fits
 
-template <int FAM>
-__global__ void __launch_bounds__(SRBA_WG) k_lm_run(const Batch B, const DevParams prm) {
-	const ProbDesc &d = B.desc[blockIdx.x];
+// DLDS: the dense system lives in LDS (size classes 0..2) -> the compiler can prove the address space and emit ds_* instead of flat_*
+template <int FAM, bool DLDS>
+__global__ void __launch_bounds__(SRBA_WG) k_lm_run(const Batch B, const DevParams prm, int first) {
+	const int pidx = B.order[first + blockIdx.x]; const ProbDesc &d = B.desc[pidx];
 	Solver<FAM> S(B, d, prm);
 	constexpr int P = Solver<FAM>::P, L = Solver<FAM>::L, O = Solver<FAM>::O;
-	double *red = srba_lds; int *flag = (int *)(srba_lds + 8);
-	double *A = d.dense_in_lds ? (srba_lds + 16) : (B.dense + d.o_dense);
-	const int tid = threadIdx.x; srba_lm_result *out = B.results + blockIdx.x;
+	double *red = nullptr;
+	const SparseSys A = S.template make_sys<DLDS>(srba_lds);
+	const int tid = threadIdx.x; srba_lm_result *out = B.results + pidx;
 	const int nObs = d.n_obs, n = d.n_scal;
 	double *resid = B.resid, *resid2 = B.resid2;
 
-	S.phase_spantree(false); // S5
-	__syncthreads();
-	S.phase_jacobians(); // S6,S7
-	const int ninv = (int)block_sum((double)S.phase_hessian(), red); // S10
-	__syncthreads();
+	long long *pc = B.phase_cycles ? B.phase_cycles + (long long)pidx * 16 : nullptr; long long tc0 = 0;
+#define TIC() do { if (pc) { __syncthreads(); tc0 = wall_clock64(); } } while (0)
+#define TOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - tc0; } } while (0)
+	TIC(); S.phase_spantree(false); // S5
+	__syncthreads(); TOC(0);
+	TIC(); S.phase_jacobians(); TOC(1); // S6,S7
+	TIC(); const int ninv = (int)block_sum((double)S.phase_hessian(), red); // S10
+	__syncthreads(); TOC(2);
 	if (tid == 0) {
 		out->status = 0; out->num_iters = 0; out->num_trials = 0; out->num_not_pd = 0; out->num_accepted = 0; out->num_relinearized = 0; out->stop_reason = 0;
 		out->num_invalid_jacobs = ninv; out->num_observations = nObs; out->num_jacobians = d.n_bp + d.n_bf; out->num_span_tree_numeric_updates = d.n_pairs;
@@ -175,12 +227,12 @@ __global__ void __launch_bounds__(SRBA_WG) k_lm_run(const Batch B, const DevPara
 	}
 	if ((long long)O * nObs < (long long)n) { if (tid == 0) out->status = 1; return; } // S11
 	double lambda = S.lambda_guess(red), nu = 2.0; // S12
-	double total_err = S.phase_residuals(resid, red); // S13
+	TIC(); double total_err = S.phase_residuals(resid, red); TOC(3); // S13
 	double RMSE = sqrt(total_err / nObs);
 	if (tid == 0) { out->lambda_init = lambda; out->total_sqr_error_init = total_err; }
 	__syncthreads();
-	S.phase_gradient(resid); // S14
-	__syncthreads();
+	TIC(); S.phase_gradient(resid); // S14
+	__syncthreads(); TOC(4);
 	int iter = 0, trials = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0; bool stop = false;
 	for (iter = 0; iter < prm.max_iters && !stop; iter++) {
 		double rho = 0;
@@ -189,15 +241,16 @@ __global__ void __launch_bounds__(SRBA_WG) k_lm_run(const Batch B, const DevPara
 		while (rho <= 0 && !stop) {
 			const int tr = trials++;
 			if (tid == 0 && tr < SRBA_TRACE_LEN) out->trace_lambda[tr] = lambda;
-			if (!S.solve(A, lambda, flag)) {
+			TIC(); const bool solved = S.solve(A, lambda, pc); TOC(5);
+			if (!solved) {
 				n_notpd++; lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
 				__syncthreads();
 				continue;
 			}
-			S.apply_update();
-			S.phase_spantree(true);
-			__syncthreads();
-			const double new_err = S.phase_residuals(resid2, red);
+			TIC(); S.apply_update(); TOC(6);
+			TIC(); S.phase_spantree(true);
+			__syncthreads(); TOC(7);
+			TIC(); const double new_err = S.phase_residuals(resid2, red); TOC(3);
 			const double new_RMSE = sqrt(new_err / nObs);
 			const double err_red = total_err > 0 ? (total_err - new_err) / total_err : 0;
 			double den = 0; { const double *dl = B.delta + d.o_scal, *g = B.grad + d.o_scal; for (int k = tid; k < n; k += SRBA_WG) den += dl[k] * (lambda * dl[k] + g[k]); }
@@ -210,9 +263,9 @@ __global__ void __launch_bounds__(SRBA_WG) k_lm_run(const Batch B, const DevPara
 				{ double *t = resid; resid = resid2; resid2 = t; }
 				total_err = new_err; RMSE = new_RMSE;
 				__syncthreads();
-				if (relin) { n_relin++; S.phase_jacobians(); S.phase_hessian(); __syncthreads(); }
-				S.phase_gradient(resid);
-				__syncthreads();
+				if (relin) { n_relin++; TIC(); S.phase_jacobians(); TOC(1); TIC(); S.phase_hessian(); __syncthreads(); TOC(2); }
+				TIC(); S.phase_gradient(resid);
+				__syncthreads(); TOC(4);
 				double ninf = 0; { const double *g = B.grad + d.o_scal; for (int k = tid; k < n; k += SRBA_WG) ninf = fmax(ninf, fabs(g[k])); }
 				ninf = block_max(ninf, red);
 				if (ninf <= 1e-15) { stop = true; stopmask |= 1 << SRBA_STOP_GRADIENT; }
@@ -220,7 +273,7 @@ __global__ void __launch_bounds__(SRBA_WG) k_lm_run(const Batch B, const DevPara
 				if (rho > prm.max_rho) { stop = true; stopmask |= 1 << SRBA_STOP_RHO; }
 				lambda *= 1.0 / 3.0; nu = 2.0;
 			} else {
-				S.restore();
+				TIC(); S.restore(); TOC(8);
 				lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
 			}
 		}
@@ -253,11 +306,11 @@ template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_linearize(const 
 	const double l0 = S.lambda_guess(srba_lds);
 	if (threadIdx.x == 0) { B.lambda_io[blockIdx.x] = l0; B.results[blockIdx.x].num_invalid_jacobs = ninv; }
 }
-template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_solve(const Batch B, const DevParams prm) {
-	const ProbDesc &d = B.desc[blockIdx.x]; Solver<FAM> S(B, d, prm);
-	double *A = d.dense_in_lds ? (srba_lds + 16) : (B.dense + d.o_dense);
-	const bool ok = S.solve(A, B.lambda_io[blockIdx.x], (int *)(srba_lds + 8));
-	if (threadIdx.x == 0) B.notpd[blockIdx.x] = ok ? 0 : 1;
+template <int FAM, bool DLDS> __global__ void __launch_bounds__(SRBA_WG) k_solve(const Batch B, const DevParams prm, int first) {
+	const int pidx = B.order[first + blockIdx.x]; const ProbDesc &d = B.desc[pidx]; Solver<FAM> S(B, d, prm);
+	const SparseSys A = S.template make_sys<DLDS>(srba_lds);
+	const bool ok = S.solve(A, B.lambda_io[pidx]);
+	if (threadIdx.x == 0) B.notpd[pidx] = ok ? 0 : 1;
 }
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_apply(const Batch B, const DevParams prm) { Solver<FAM> S(B, B.desc[blockIdx.x], prm); S.apply_update(); }
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_rollback(const Batch B, const DevParams prm) { Solver<FAM> S(B, B.desc[blockIdx.x], prm); S.restore(); }
@@ -280,19 +333,67 @@ struct Arena { // layout builder: 256-byte aligned sub-allocations inside one bu
 
 } // namespace
 
+#define SRBA_NCLS 6
+// Symbolic block factorisation of one capsule's system (natural block order): the numeric kernel never discovers structure.
+struct Symbolic { std::vector<int32_t> col_off, row, item_off, tgt, hap_dst, hapf_dst, hf_dst; bool aligned = true; };
+static void symbolic_factor(const srba_problem_capsule &k, const ProbDesc &d, int P, int L, bool full_system, Symbolic &out) {
+	const int nb = d.nb; std::vector<std::vector<int> > cols(nb); // cols[c] = block rows r > c that are structurally non-zero in column c of the lower triangle
+	auto add_scalar_block = [&](int r0, int c0, int nr, int nc) { // upper-triangle block at scalar rows r0.., cols c0.. (r0 <= c0)
+		for (int i = 0; i < nr; i++) for (int j = 0; j < nc; j++) { int a = (r0 + i) / 3, b = (c0 + j) / 3; if (a == b) continue; if (a > b) std::swap(a, b); cols[a].push_back(b); }
+	};
+	for (int b = 0; b < k.n_hap; b++) add_scalar_block(P * k.hap_i[b], P * k.hap_j[b], P, P);
+	if (full_system) {
+		for (int b = 0; b < k.n_hapf; b++) add_scalar_block(P * k.hapf_i[b], P * d.nK + L * k.hapf_j[b], P, L);
+		for (int b = 0; b < k.n_hf; b++) add_scalar_block(P * d.nK + L * k.hf_i[b], P * d.nK + L * k.hf_j[b], L, L);
+	}
+	for (int c = 0; c < nb; c++) { // elimination: struct(L_c) is merged into its parent column (first off-diagonal row)
+		std::vector<int> &v = cols[c]; std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end());
+		if (!v.empty()) { std::vector<int> &par = cols[v[0]]; par.insert(par.end(), v.begin() + 1, v.end()); }
+	}
+	out.col_off.assign(nb + 1, 0); out.row.clear(); out.item_off.assign(nb + 1, 0); out.tgt.clear();
+	for (int c = 0; c < nb; c++) { out.row.insert(out.row.end(), cols[c].begin(), cols[c].end()); out.col_off[c + 1] = (int32_t)out.row.size(); }
+	for (int c = 0; c < nb; c++) {
+		const std::vector<int> &v = cols[c]; const int cn = (int)v.size();
+		for (int a = 0; a < cn; a++) for (int b = 0; b <= a; b++) { // item t = a(a+1)/2 + b : target block (v[a], v[b])
+			if (a == b) { out.tgt.push_back(-1 - v[a]); continue; }
+			const std::vector<int> &cb = cols[v[b]]; const int pos = (int)(std::lower_bound(cb.begin(), cb.end(), v[a]) - cb.begin());
+			out.tgt.push_back(out.col_off[v[b]] + pos);
+		}
+		out.item_off[c + 1] = (int32_t)out.tgt.size();
+	}
+	// destination of every aligned 3x3 sub-block of the upper-triangle Hessian blocks (transposed into the lower factor storage)
+	auto dst_of = [&](int a, int b) -> int32_t { // block row a, block col b of the UPPER triangle
+		if (a == b) return -1 - a;
+		if (a > b) return (int32_t)0x80000000; // lower half of a symmetric diagonal block: duplicate, skipped
+		const std::vector<int> &cb = cols[a]; const int pos = (int)(std::lower_bound(cb.begin(), cb.end(), b) - cb.begin());
+		return out.col_off[a] + pos;
+	};
+	const int PB = P / 3;
+	out.hap_dst.clear(); out.hapf_dst.clear(); out.hf_dst.clear();
+	for (int b = 0; b < k.n_hap; b++) for (int si = 0; si < PB; si++) for (int sj = 0; sj < PB; sj++) out.hap_dst.push_back(dst_of(k.hap_i[b] * PB + si, k.hap_j[b] * PB + sj));
+	out.aligned = !(full_system && L != 3 && k.n_unk_lms > 0);
+	if (full_system && L == 3) {
+		const int lb = PB * d.nK;
+		for (int b = 0; b < k.n_hapf; b++) for (int si = 0; si < PB; si++) out.hapf_dst.push_back(dst_of(k.hapf_i[b] * PB + si, lb + k.hapf_j[b]));
+		for (int b = 0; b < k.n_hf; b++) out.hf_dst.push_back(dst_of(lb + k.hf_i[b], lb + k.hf_j[b]));
+	} else { out.hapf_dst.assign((size_t)k.n_hapf * PB, 0); out.hf_dst.assign(k.n_hf, 0); }
+}
+
 struct srba_hip_ctx {
 	int device = 0; srba_hip_params params; DevParams dp; FamDims dm;
 	hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	hipStream_t cls_stream[SRBA_NCLS] = {nullptr}; hipEvent_t ev_fork = nullptr, cls_done[SRBA_NCLS] = {nullptr}; // size classes run concurrently
 	std::string error;
 	// batch
 	int n_prob = 0; std::vector<ProbDesc> desc; Batch B; srba_batch_stats stats;
 	char *d_in = nullptr; size_t cap_in = 0; char *d_wk = nullptr; size_t cap_wk = 0;
 	std::vector<char> h_in; // host staging of the input arena
-	size_t lds_bytes = 0; double last_ms = 0;
+	double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
 	// offsets needed for downloads (bytes inside the wk arena)
 	size_t off_edge = 0, off_ulm = 0, off_pose = 0, off_inf = 0, off_infv = 0, off_res = 0;
 	size_t off_dbg[10] = {0}; int64_t len_dbg[10] = {0};
 	size_t in_off_edge0 = 0, in_off_ulm0 = 0; long long tot_edge = 0, tot_ulm = 0;
+	size_t off_phase = 0; bool phase_timing = false;
 	void fail(const std::string &m) { error = m; g_last_error = m; }
 };
 
@@ -349,7 +450,11 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	srba_hip_ctx *c = new srba_hip_ctx();
 	c->device = device; c->params = *params; c->dm = kDims[params->family]; make_dev_params(*params, c->dp, c->dm);
 	std::memset(&c->B, 0, sizeof(c->B)); std::memset(&c->stats, 0, sizeof(c->stats));
+	{ const char *e = getenv("SRBA_HIP_PHASE_TIMING"); c->phase_timing = (e && e[0] == '1'); }
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
+	bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+	for (int k = 1; k < SRBA_NCLS && ok; k++) ok = hipStreamCreateWithFlags(&c->cls_stream[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->cls_done[k], hipEventDisableTiming) == hipSuccess;
+	if (!ok) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	return c;
 }
 
@@ -364,7 +469,9 @@ int srba_hip_destroy(srba_hip_ctx *c) {
 	if (!c) return 0;
 	hipSetDevice(c->device);
 	if (c->d_in) hipFree(c->d_in); if (c->d_wk) hipFree(c->d_wk);
-	if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1); if (c->stream) hipStreamDestroy(c->stream);
+	if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1); if (c->ev_fork) hipEventDestroy(c->ev_fork);
+	for (int k = 1; k < SRBA_NCLS; k++) { if (c->cls_done[k]) hipEventDestroy(c->cls_done[k]); if (c->cls_stream[k]) hipStreamDestroy(c->cls_stream[k]); }
+	if (c->stream) hipStreamDestroy(c->stream);
 	delete c; return 0;
 }
 
@@ -379,7 +486,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	c->desc.assign(n, ProbDesc()); srba_batch_stats &st = c->stats; std::memset(&st, 0, sizeof(st)); st.n_problems = n;
 	// ---- pass 1: descriptors and totals
 	long long t_edge = 0, t_unk = 0, t_ulm = 0, t_klm = 0, t_pair = 0, t_path = 0, t_obs = 0, t_valid = 0, t_bp = 0, t_bf = 0, t_hap = 0, t_hapt = 0, t_hf = 0, t_hft = 0, t_hapf = 0, t_hapft = 0, t_sch = 0, t_req = 0, t_scal = 0, t_yw = 0, t_dense = 0;
-	size_t max_lds_doubles = 0; const size_t LDS_BUDGET_DOUBLES = (size_t)(150 * 1024) / 8 - 16;
+	std::vector<int> cls(n, 0); int cls_nbmax[SRBA_NCLS] = {0}; std::vector<Symbolic> sym(n); long long t_spcol = 0, t_sprow = 0, t_spitem = 0;
 	for (int p = 0; p < n; p++) {
 		const srba_problem_capsule &k = caps[p]; ProbDesc &d = c->desc[p];
 		if (k.n_unk_edges < 0 || k.n_unk_lms < 0 || k.n_unk_edges > k.n_edges || (k.n_unk_edges + k.n_unk_lms) == 0) { c->fail("upload: malformed capsule"); return -1; }
@@ -391,14 +498,22 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 		d.o_edge = t_edge; d.o_unk = t_unk; d.o_ulm = t_ulm; d.o_klm = t_klm; d.o_pair = t_pair; d.o_ppoff = t_pair + p; d.o_path = t_path; d.o_obs = t_obs; d.o_valid = t_valid;
 		d.o_bp = t_bp; d.o_colp = t_unk + p; d.o_bf = t_bf; d.o_colf = t_ulm + p; d.o_hap = t_hap; d.o_hapoff = t_hap + p; d.o_hapt = t_hapt; d.o_hf = t_hf; d.o_hfoff = t_hf + p; d.o_hft = t_hft;
 		d.o_hapf = t_hapf; d.o_hapfoff = t_hapf + p; d.o_hapft = t_hapft; d.o_sch = t_sch; d.o_lmoff = t_ulm + p; d.o_req = t_req; d.o_scal = t_scal; d.o_yw = t_yw; d.o_dense = t_dense;
-		const size_t tri_n = (size_t)d.n_sys * (d.n_sys + 1) / 2;
-		d.dense_in_lds = tri_n <= LDS_BUDGET_DOUBLES ? 1 : 0;
-		if (d.dense_in_lds) max_lds_doubles = std::max(max_lds_doubles, tri_n);
+		d.nb = (d.n_sys + 2) / 3;
+		symbolic_factor(k, d, P, L, !schur_solver, sym[p]);
+		d.nnzoff = (int)sym[p].row.size(); d.n_items = (int)sym[p].tgt.size(); d.aligned = sym[p].aligned ? 1 : 0;
+		d.o_spcol = t_spcol; d.o_sprow = t_sprow; d.o_spitem = t_spitem;
+		t_spcol += d.nb + 1; t_sprow += d.nnzoff; t_spitem += (long long)sym[p].tgt.size();
+		const size_t n_ints = 2 * ((size_t)d.nb + 1) + (size_t)d.nnzoff + (size_t)d.n_items;
+		const size_t tri_n = 9 * (size_t)d.nb + 9 * (size_t)d.nnzoff + 3 * (size_t)d.nb + (n_ints + 1) / 2; // diag | off | rhs | symbolic ints
+		// LDS size classes (bytes per wavefront): 12 KB, 24 KB, 48 KB, 96 KB, 150 KB; larger systems are factored in HBM
+		const size_t bytes = tri_n * 8;
+		cls[p] = bytes <= 12 * 1024 ? 0 : bytes <= 24 * 1024 ? 1 : bytes <= 48 * 1024 ? 2 : bytes <= 96 * 1024 ? 3 : bytes <= 150 * 1024 ? 4 : 5;
+		d.dense_in_lds = cls[p] < 5 ? 1 : 0; cls_nbmax[cls[p]] = std::max(cls_nbmax[cls[p]], (int)tri_n);
 		int nyw = 0; if (k.n_sch_terms > 0) for (int b = 0; b < k.n_hap; b++) if (k.hap_i[b] == k.hap_j[b]) nyw += k.sch_term_off[b + 1] - k.sch_term_off[b];
 		long long npath_needed = 0; for (int q = 0; q < k.n_pairs; q++) if (k.pair_needed[q]) { st.n_pairs_needed++; npath_needed += k.pair_path_off[q + 1] - k.pair_path_off[q]; }
 		st.n_path_needed += npath_needed;
 		t_edge += k.n_edges; t_unk += d.nK; t_ulm += d.nF; t_klm += d.n_klm; t_pair += k.n_pairs; t_path += k.n_path; t_obs += k.n_obs; t_valid += k.n_valid; t_bp += k.n_bp; t_bf += k.n_bf;
-		t_hap += k.n_hap; t_hapt += k.n_hap_terms; t_hf += k.n_hf; t_hft += k.n_hf_terms; t_hapf += k.n_hapf; t_hapft += k.n_hapf_terms; t_sch += k.n_sch_terms; t_req += nreq; t_scal += d.n_scal; t_yw += nyw; t_dense += (long long)tri_n;
+		t_hap += k.n_hap; t_hapt += k.n_hap_terms; t_hf += k.n_hf; t_hft += k.n_hf_terms; t_hapf += k.n_hapf; t_hapft += k.n_hapf_terms; t_sch += k.n_sch_terms; t_req += nreq; t_scal += d.n_scal; t_yw += nyw; t_dense += d.dense_in_lds ? 0 : (long long)tri_n;
 	}
 	st.n_edges = t_edge; st.n_unk_edges = t_unk; st.n_unk_lms = t_ulm; st.n_pairs = t_pair; st.n_path = t_path; st.n_obs = t_obs; st.n_bp = t_bp; st.n_bf = t_bf; st.n_hap = t_hap; st.n_hap_terms = t_hapt;
 	st.n_hf_terms = t_hft; st.n_hapf_terms = t_hapft; st.n_sch_terms = t_sch; st.n_scalars = t_scal;
@@ -406,7 +521,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	// ---- input arena layout
 	Arena in; struct { size_t desc, edge0, ulm0, klm, obs_z, pair_path_off, path_edge, obs_pose, obs_lm, obs_valid, bp_col, bp_res, bp_A, bp_D, bp_lm, colp_off, bf_col, bf_res, bf_pose, colf_off,
 		hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hf_i, hf_j, hf_term_off, hf_t1, hf_t2, hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag, sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw,
-		lm_hapf_off, lm_hapf_idx, req_idx, pair_needed, bp_normal; } o;
+		lm_hapf_off, lm_hapf_idx, req_idx, pair_needed, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, hap_dst, hapf_dst, hf_dst; } o;
 	o.desc = in.add(sizeof(ProbDesc) * n);
 	o.edge0 = in.add(8 * t_edge * PD); o.ulm0 = in.add(8 * t_ulm * L); o.klm = in.add(8 * t_klm * L); o.obs_z = in.add(8 * t_obs * O);
 	o.pair_path_off = in.add(4 * (t_pair + n)); o.path_edge = in.add(4 * t_path); o.obs_pose = in.add(4 * t_obs); o.obs_lm = in.add(4 * t_obs); o.obs_valid = in.add(4 * t_obs);
@@ -417,7 +532,9 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	o.hapf_i = in.add(4 * t_hapf); o.hapf_j = in.add(4 * t_hapf); o.hapf_term_off = in.add(4 * (t_hapf + n)); o.hapf_t1 = in.add(4 * t_hapft); o.hapf_t2 = in.add(4 * t_hapft);
 	o.hap_diag = in.add(4 * t_unk); o.hf_diag = in.add(4 * t_ulm);
 	o.sch_term_off = in.add(4 * (t_hap + n)); o.sch_b1 = in.add(4 * t_sch); o.sch_b2 = in.add(4 * t_sch); o.sch_lm = in.add(4 * t_sch); o.sch_yw = in.add(4 * t_sch);
-	o.lm_hapf_off = in.add(4 * (t_ulm + n)); o.lm_hapf_idx = in.add(4 * t_hapf); o.req_idx = in.add(4 * t_req); o.pair_needed = in.add(t_pair); o.bp_normal = in.add(t_bp);
+	o.lm_hapf_off = in.add(4 * (t_ulm + n)); o.lm_hapf_idx = in.add(4 * t_hapf); o.req_idx = in.add(4 * t_req); o.pair_needed = in.add(t_pair); o.bp_normal = in.add(t_bp); o.order = in.add(4 * (size_t)n);
+	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem);
+	o.hap_dst = in.add(4 * t_hap * (P / 3) * (P / 3)); o.hapf_dst = in.add(4 * t_hapf * (P / 3)); o.hf_dst = in.add(4 * t_hf);
 	in.add(0);
 	c->h_in.assign(in.size + 256, 0); char *h = c->h_in.data();
 	c->in_off_edge0 = o.edge0; c->in_off_ulm0 = o.ulm0;
@@ -444,26 +561,35 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 		if (k.lm_hapf_off) CPY(o.lm_hapf_off, d.o_lmoff, k.lm_hapf_off, d.nF + 1, int32_t); CPY(o.lm_hapf_idx, d.o_hapf, k.lm_hapf_idx, k.n_hapf, int32_t);
 		{ int32_t *rq = (int32_t *)(h + o.req_idx) + d.o_req; int cnt = 0; for (int i = 0; i < 2 * k.n_pairs; i++) if (k.pose_required[i]) rq[cnt++] = i; }
 		CPY(o.pair_needed, d.o_pair, k.pair_needed, k.n_pairs, uint8_t); CPY(o.bp_normal, d.o_bp, k.bp_normal, k.n_bp, uint8_t);
+		CPY(o.sp_col_off, d.o_spcol, sym[p].col_off.data(), d.nb + 1, int32_t); CPY(o.sp_row, d.o_sprow, sym[p].row.data(), d.nnzoff, int32_t);
+		CPY(o.sp_item_off, d.o_spcol, sym[p].item_off.data(), d.nb + 1, int32_t); CPY(o.sp_tgt, d.o_spitem, sym[p].tgt.data(), sym[p].tgt.size(), int32_t);
+		CPY(o.hap_dst, d.o_hap * (P / 3) * (P / 3), sym[p].hap_dst.data(), sym[p].hap_dst.size(), int32_t); CPY(o.hapf_dst, d.o_hapf * (P / 3), sym[p].hapf_dst.data(), sym[p].hapf_dst.size(), int32_t); CPY(o.hf_dst, d.o_hf, sym[p].hf_dst.data(), sym[p].hf_dst.size(), int32_t);
+		st.n_chol_blocks += d.nb + d.nnzoff; st.n_chol_items += (int64_t)sym[p].tgt.size();
 	}
 #undef CPY
 	std::memcpy(h + o.desc, c->desc.data(), sizeof(ProbDesc) * n);
+	{ // launch order: capsules grouped by LDS size class
+		int32_t *ord = (int32_t *)(h + o.order); int pos = 0;
+		for (int k = 0; k < SRBA_NCLS; k++) { c->cls_first[k] = pos; for (int p = 0; p < n; p++) if (cls[p] == k) ord[pos++] = p; c->cls_count[k] = pos - c->cls_first[k];
+			c->cls_lds[k] = k < SRBA_NCLS - 1 ? (size_t)cls_nbmax[k] * 8 : 0; }
+	}
 	// ---- work arena layout
-	Arena wk; struct { size_t edge, ulm, pose, Jp, Jf, resid, resid2, HAp, HAp0, Hf, HApf, grad, delta, Hfinv, YW, old_edge, old_ulm, old_pose, dense, ulm_inf, valid, first_fail, hf_ok, ulm_inf_valid, results, lambda_io, chi2, notpd; } w;
+	Arena wk; struct { size_t edge, ulm, pose, Jp, Jf, resid, resid2, HAp, HAp0, Hf, HApf, grad, delta, Hfinv, YW, old_edge, old_ulm, old_pose, dense, ulm_inf, valid, first_fail, hf_ok, ulm_inf_valid, results, lambda_io, chi2, notpd, phase_cycles; } w;
 	w.edge = wk.add(8 * t_edge * PD); w.ulm = wk.add(8 * t_ulm * L); w.pose = wk.add(8 * 2 * t_pair * PD); w.Jp = wk.add(8 * t_bp * O * P); w.Jf = wk.add(8 * t_bf * O * L);
 	w.resid = wk.add(8 * t_obs * O); w.resid2 = wk.add(8 * t_obs * O); w.HAp = wk.add(8 * t_hap * P * P); w.HAp0 = wk.add(8 * t_hap * P * P); w.Hf = wk.add(8 * t_hf * L * L); w.HApf = wk.add(8 * t_hapf * P * L);
 	w.grad = wk.add(8 * t_scal); w.delta = wk.add(8 * t_scal); w.Hfinv = wk.add(8 * t_ulm * L * L); w.YW = wk.add(8 * t_yw * P * L); w.old_edge = wk.add(8 * t_unk * PD); w.old_ulm = wk.add(8 * t_ulm * L); w.old_pose = wk.add(8 * t_req * PD);
 	w.dense = wk.add(8 * t_dense); w.ulm_inf = wk.add(8 * t_ulm * L * L); w.valid = wk.add(4 * t_valid); w.first_fail = wk.add(4 * t_valid); w.hf_ok = wk.add(4 * t_ulm); w.ulm_inf_valid = wk.add(t_ulm);
-	w.results = wk.add(sizeof(srba_lm_result) * n); w.lambda_io = wk.add(8 * n); w.chi2 = wk.add(8 * n); w.notpd = wk.add(4 * n);
+	w.results = wk.add(sizeof(srba_lm_result) * n); w.lambda_io = wk.add(8 * n); w.chi2 = wk.add(8 * n); w.notpd = wk.add(4 * n); w.phase_cycles = wk.add(8 * 16 * (size_t)n);
 	wk.add(0);
 	if (in.size + 256 > c->cap_in) { if (c->d_in) hipFree(c->d_in); c->d_in = nullptr; c->cap_in = 0; const size_t want = (in.size + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_in, want)); c->cap_in = want; }
 	if (wk.size + 256 > c->cap_wk) { if (c->d_wk) hipFree(c->d_wk); c->d_wk = nullptr; c->cap_wk = 0; const size_t want = (wk.size + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_wk, want)); c->cap_wk = want; }
 	HIPCHK(c, hipMemcpyAsync(c->d_in, h, in.size, hipMemcpyHostToDevice, c->stream));
 	HIPCHK(c, hipMemsetAsync(c->d_wk, 0, wk.size, c->stream));
 	// ---- batch struct
-	Batch &B = c->B; std::memset(&B, 0, sizeof(B)); B.n_prob = n; B.max_lds_doubles = (int)max_lds_doubles;
+	Batch &B = c->B; std::memset(&B, 0, sizeof(B)); B.n_prob = n; B.max_lds_doubles = 0;
 	char *di = c->d_in, *dw = c->d_wk;
 #define DI(field, T) B.field = (const T *)(di + o.field)
-	B.desc = (const ProbDesc *)(di + o.desc); DI(edge0, double); DI(ulm0, double); DI(klm, double); DI(obs_z, double);
+	B.desc = (const ProbDesc *)(di + o.desc); DI(order, int); DI(sp_col_off, int); DI(sp_row, int); DI(sp_item_off, int); DI(sp_tgt, int); DI(hap_dst, int); DI(hapf_dst, int); DI(hf_dst, int); DI(edge0, double); DI(ulm0, double); DI(klm, double); DI(obs_z, double);
 	DI(pair_path_off, int); DI(path_edge, int); DI(obs_pose, int); DI(obs_lm, int); DI(obs_valid, int); DI(bp_col, int); DI(bp_res, int); DI(bp_A, int); DI(bp_D, int); DI(bp_lm, int); DI(colp_off, int);
 	DI(bf_col, int); DI(bf_res, int); DI(bf_pose, int); DI(colf_off, int); DI(hap_i, int); DI(hap_j, int); DI(hap_term_off, int); DI(hap_t1, int); DI(hap_t2, int); DI(hf_i, int); DI(hf_j, int); DI(hf_term_off, int); DI(hf_t1, int); DI(hf_t2, int);
 	DI(hapf_i, int); DI(hapf_j, int); DI(hapf_term_off, int); DI(hapf_t1, int); DI(hapf_t2, int); DI(hap_diag, int); DI(hf_diag, int); DI(sch_term_off, int); DI(sch_b1, int); DI(sch_b2, int); DI(sch_lm, int); DI(sch_yw, int);
@@ -473,12 +599,13 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	DW(edge, double); DW(ulm, double); DW(pose, double); DW(Jp, double); DW(Jf, double); DW(resid, double); DW(resid2, double); DW(HAp, double); DW(HAp0, double); DW(Hf, double); DW(HApf, double); DW(grad, double); DW(delta, double);
 	DW(Hfinv, double); DW(YW, double); DW(old_edge, double); DW(old_ulm, double); DW(old_pose, double); DW(dense, double); DW(ulm_inf, double); DW(valid, int); DW(first_fail, int); DW(hf_ok, int); DW(ulm_inf_valid, unsigned char);
 	DW(results, srba_lm_result); DW(lambda_io, double); DW(chi2, double); DW(notpd, int);
+	c->off_phase = w.phase_cycles; B.phase_cycles = c->phase_timing ? (long long *)(dw + w.phase_cycles) : nullptr;
 #undef DW
 	c->off_edge = w.edge; c->off_ulm = w.ulm; c->off_pose = w.pose; c->off_inf = w.ulm_inf; c->off_infv = w.ulm_inf_valid; c->off_res = w.results;
 	const size_t dbg_off[10] = {w.resid, w.Jp, w.Jf, w.HAp, w.Hf, w.HApf, w.grad, w.delta, w.valid, w.pose};
 	const int64_t dbg_len[10] = {t_obs * O, t_bp * O * P, t_bf * O * L, t_hap * P * P, t_hf * L * L, t_hapf * P * L, t_scal, t_scal, t_valid, 2 * t_pair * PD};
 	for (int i = 0; i < 10; i++) { c->off_dbg[i] = dbg_off[i]; c->len_dbg[i] = dbg_len[i]; }
-	c->n_prob = n; c->lds_bytes = (16 + max_lds_doubles) * 8; st.device_bytes = (int64_t)(in.size + wk.size);
+	c->n_prob = n; st.device_bytes = (int64_t)(in.size + wk.size);
 	if (srba_hip_reset_state(c) != 0) return -1;
 	HIPCHK(c, hipStreamSynchronize(c->stream)); // the staging buffer is pageable and reused by the next upload
 	return 0;
@@ -497,8 +624,8 @@ int srba_hip_batch_stats(srba_hip_ctx *c, srba_batch_stats *out) { if (!c || !ou
 } // extern "C"
 
 // ---- launch helpers
-#define SRBA_DISPATCH(c, KERNEL, lds, ...) do { \
-	const dim3 grid((c)->n_prob), block(SRBA_WG); \
+#define SRBA_DISPATCH_N(c, KERNEL, nblocks, lds, ...) do { \
+	const dim3 grid(nblocks), block(SRBA_WG); \
 	switch ((c)->params.family) { \
 		case SRBA_SE2_RELPOSE2D: hipLaunchKernelGGL(srbadev::KERNEL<SRBA_SE2_RELPOSE2D>, grid, block, (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); break; \
 		case SRBA_SE2_RB2D: hipLaunchKernelGGL(srbadev::KERNEL<SRBA_SE2_RB2D>, grid, block, (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); break; \
@@ -507,15 +634,29 @@ int srba_hip_batch_stats(srba_hip_ctx *c, srba_batch_stats *out) { if (!c || !ou
 		case SRBA_SE3_MONO: hipLaunchKernelGGL(srbadev::KERNEL<SRBA_SE3_MONO>, grid, block, (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); break; \
 		case SRBA_SE3_CART3D: hipLaunchKernelGGL(srbadev::KERNEL<SRBA_SE3_CART3D>, grid, block, (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); break; \
 	} } while (0)
+#define SRBA_DISPATCH(c, KERNEL, lds, ...) SRBA_DISPATCH_N(c, KERNEL, (c)->n_prob, lds, ##__VA_ARGS__)
+#define SRBA_DISPATCH_LDS1(c, KERNEL, FAMILY, inlds, nblocks, lds, ...) do { \
+	if (inlds) hipLaunchKernelGGL((srbadev::KERNEL<FAMILY, true>), dim3(nblocks), dim3(SRBA_WG), (lds), launch_stream, (c)->B, (c)->dp, ##__VA_ARGS__); \
+	else hipLaunchKernelGGL((srbadev::KERNEL<FAMILY, false>), dim3(nblocks), dim3(SRBA_WG), (lds), launch_stream, (c)->B, (c)->dp, ##__VA_ARGS__); } while (0)
+#define SRBA_DISPATCH_LDS(c, KERNEL, inlds, nblocks, lds, ...) do { \
+	switch ((c)->params.family) { \
+		case SRBA_SE2_RELPOSE2D: SRBA_DISPATCH_LDS1(c, KERNEL, SRBA_SE2_RELPOSE2D, inlds, nblocks, lds, ##__VA_ARGS__); break; \
+		case SRBA_SE2_RB2D: SRBA_DISPATCH_LDS1(c, KERNEL, SRBA_SE2_RB2D, inlds, nblocks, lds, ##__VA_ARGS__); break; \
+		case SRBA_SE2_CART2D: SRBA_DISPATCH_LDS1(c, KERNEL, SRBA_SE2_CART2D, inlds, nblocks, lds, ##__VA_ARGS__); break; \
+		case SRBA_SE3_STEREO: SRBA_DISPATCH_LDS1(c, KERNEL, SRBA_SE3_STEREO, inlds, nblocks, lds, ##__VA_ARGS__); break; \
+		case SRBA_SE3_MONO: SRBA_DISPATCH_LDS1(c, KERNEL, SRBA_SE3_MONO, inlds, nblocks, lds, ##__VA_ARGS__); break; \
+		case SRBA_SE3_CART3D: SRBA_DISPATCH_LDS1(c, KERNEL, SRBA_SE3_CART3D, inlds, nblocks, lds, ##__VA_ARGS__); break; \
+	} } while (0)
 
 template <class K> static int allow_big_lds(srba_hip_ctx *c, K kernel, size_t bytes) {
 	if (bytes > 64 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess) { c->fail(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e)); return -1; } }
 	return 0;
 }
 static int prep_lds(srba_hip_ctx *c, bool for_lm) {
-	const size_t b = c->lds_bytes; if (b <= 64 * 1024) return 0;
+	size_t b = 0; for (int k = 0; k < SRBA_NCLS; k++) if (c->cls_count[k]) b = std::max(b, c->cls_lds[k]);
+	if (b <= 64 * 1024) return 0;
 	switch (c->params.family) {
-#define CASE(F) case F: return for_lm ? allow_big_lds(c, srbadev::k_lm_run<F>, b) : allow_big_lds(c, srbadev::k_solve<F>, b);
+#define CASE(F) case F: return for_lm ? allow_big_lds(c, srbadev::k_lm_run<F, true>, b) : allow_big_lds(c, srbadev::k_solve<F, true>, b);
 		CASE(SRBA_SE2_RELPOSE2D) CASE(SRBA_SE2_RB2D) CASE(SRBA_SE2_CART2D) CASE(SRBA_SE3_STEREO) CASE(SRBA_SE3_MONO) CASE(SRBA_SE3_CART3D)
 #undef CASE
 	}
@@ -531,8 +672,17 @@ int srba_hip_lm_run_async(srba_hip_ctx *c) {
 	HIPCHK(c, hipSetDevice(c->device));
 	if (prep_lds(c, true) != 0) return -1;
 	HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-	SRBA_DISPATCH(c, k_lm_run, c->lds_bytes);
-	HIPCHK(c, hipGetLastError());
+	// fork: the most populated class stays on the main stream, the others run beside it (their tails overlap), then join
+	int main_cls = 0; for (int k = 1; k < SRBA_NCLS; k++) if (c->cls_count[k] > c->cls_count[main_cls]) main_cls = k;
+	HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+	for (int k = SRBA_NCLS - 1; k >= 0; k--) if (c->cls_count[k] && k != main_cls) { // big systems first
+		hipStream_t launch_stream = c->cls_stream[k ? k : main_cls]; // class 0 borrows the (idle) stream slot of the main class when it is not the main one
+		HIPCHK(c, hipStreamWaitEvent(launch_stream, c->ev_fork, 0));
+		SRBA_DISPATCH_LDS(c, k_lm_run, k < SRBA_NCLS - 1, c->cls_count[k], c->cls_lds[k], c->cls_first[k]); HIPCHK(c, hipGetLastError());
+		HIPCHK(c, hipEventRecord(c->cls_done[k ? k : main_cls], launch_stream));
+	}
+	{ hipStream_t launch_stream = c->stream; SRBA_DISPATCH_LDS(c, k_lm_run, main_cls < SRBA_NCLS - 1, c->cls_count[main_cls], c->cls_lds[main_cls], c->cls_first[main_cls]); HIPCHK(c, hipGetLastError()); }
+	for (int k = 0; k < SRBA_NCLS; k++) if (c->cls_count[k] && k != main_cls) HIPCHK(c, hipStreamWaitEvent(c->stream, c->cls_done[k ? k : main_cls], 0));
 	HIPCHK(c, hipEventRecord(c->ev1, c->stream));
 	return 0;
 }
@@ -561,7 +711,7 @@ int srba_hip_solve(srba_hip_ctx *c, const double *lambda, int32_t *not_pd_out) {
 	if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device));
 	if (lambda) HIPCHK(c, hipMemcpyAsync(c->B.lambda_io, lambda, 8 * (size_t)c->n_prob, hipMemcpyHostToDevice, c->stream)); // else: use the lambda guess left by srba_hip_linearize
 	if (prep_lds(c, false) != 0) return -1;
-	SRBA_DISPATCH(c, k_solve, c->lds_bytes); HIPCHK(c, hipGetLastError());
+	for (int k = 0; k < SRBA_NCLS; k++) if (c->cls_count[k]) { hipStream_t launch_stream = c->stream; SRBA_DISPATCH_LDS(c, k_solve, k < SRBA_NCLS - 1, c->cls_count[k], c->cls_lds[k], c->cls_first[k]); HIPCHK(c, hipGetLastError()); }
 	if (not_pd_out) { HIPCHK(c, hipMemcpyAsync(not_pd_out, c->B.notpd, 4 * (size_t)c->n_prob, hipMemcpyDeviceToHost, c->stream)); }
 	HIPCHK(c, hipStreamSynchronize(c->stream)); return 0;
 }
@@ -589,8 +739,13 @@ int srba_hip_download_state(srba_hip_ctx *c, srba_problem_capsule *caps, int n) 
 	return 0;
 }
 
-int64_t srba_hip_debug_size(srba_hip_ctx *c, int what) { return (c && what >= 0 && what < 10) ? c->len_dbg[what] : -1; }
+int64_t srba_hip_debug_size(srba_hip_ctx *c, int what) { if (c && what == 10) return c->phase_timing ? 16 * (int64_t)c->n_prob : 0; return (c && what >= 0 && what < 10) ? c->len_dbg[what] : -1; }
 int srba_hip_debug_read(srba_hip_ctx *c, int what, double *out, int64_t n_doubles) {
+	if (c && what == 10) { // per-capsule phase cycle counters (100 MHz wall clock ticks), as doubles
+		if (!c->phase_timing) return -1;
+		std::vector<long long> v(16 * (size_t)c->n_prob); HIPCHK(c, hipMemcpyAsync(v.data(), c->d_wk + c->off_phase, 8 * v.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+		for (size_t i = 0; i < v.size() && (int64_t)i < n_doubles; i++) out[i] = (double)v[i]; return 0;
+	}
 	if (!c || what < 0 || what >= 10 || n_doubles < c->len_dbg[what]) return -1;
 	HIPCHK(c, hipSetDevice(c->device));
 	if (what == 8) { std::vector<int> v((size_t)c->len_dbg[8]); HIPCHK(c, hipMemcpyAsync(v.data(), c->d_wk + c->off_dbg[8], 4 * v.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); for (size_t i = 0; i < v.size(); i++) out[i] = v[i]; return 0; }

@@ -92,11 +92,54 @@ def manhattan_path(n_kf, seed=1, block=100.0, grid=16, step=2.0):
     return poses[:n_kf]
 
 
-def graph_slam_se2(n_kf=30000, seed=1, sigma_xy=1e-3, sigma_yaw_deg=0.2, max_range=9.0, grid=16, block=100.0):
+def manhattan_tour(n_kf, block=100.0, step=2.0):
+    """Ground-truth SE2 path of the benchmark map: a serpentine tour over all east-west streets of a square Manhattan grid followed by a
+    serpentine over all north-south streets.  The first half is pure exploration, the second half crosses an already mapped street at every
+    intersection, i.e. one loop-closure event per `block` metres -- the "corridor loop walk" of SURVEY 8d for which the reference's RWT path
+    (datasets/world-2d-30k-rel-graph-slam.cfg:22) is the model.  The grid size is chosen so that the tour is just long enough for n_kf keyframes."""
+    G = 1
+    while 2 * (G + 1) * (G * block + block) / step < n_kf:
+        G += 1
+    wp = []
+    for r in range(G + 1):  # rows, alternating direction, connected by one block of the outer columns
+        xs = (0.0, G * block) if r % 2 == 0 else (G * block, 0.0)
+        wp += [(xs[0], r * block), (xs[1], r * block)]
+    last = wp[-1]
+    cols = range(G + 1) if last[0] == 0.0 else range(G, -1, -1)
+    down = True  # we are at the top row
+    for cidx in cols:
+        ys = (G * block, 0.0) if down else (0.0, G * block)
+        wp += [(cidx * block, ys[0]), (cidx * block, ys[1])]
+        down = not down
+    poses = []; x, y = wp[0]; th = 0.0
+    for (tx, ty) in wp[1:]:
+        d = math.hypot(tx - x, ty - y)
+        if d < 1e-9:
+            continue
+        new_th = math.atan2(ty - y, tx - x)
+        dth = (new_th - th + math.pi) % (2 * math.pi) - math.pi
+        nturn = int(math.ceil(abs(dth) / (math.pi / 6) - 1e-9))
+        for _ in range(nturn):  # turn in <= 30 degree increments while creeping forward
+            th += dth / nturn
+            x += 0.25 * math.cos(th); y += 0.25 * math.sin(th)
+            poses.append((x, y, th))
+        th = new_th
+        d = math.hypot(tx - x, ty - y); nstep = max(1, int(math.ceil(d / step)))
+        sx, sy = x, y
+        for k in range(1, nstep + 1):
+            poses.append((sx + (tx - sx) * k / nstep, sy + (ty - sy) * k / nstep, th))
+        x, y = tx, ty
+        if len(poses) >= n_kf:
+            break
+    assert len(poses) >= n_kf
+    return poses[:n_kf]
+
+
+def graph_slam_se2(n_kf=30000, seed=1, sigma_xy=1e-3, sigma_yaw_deg=0.2, max_range=9.0, grid=16, block=100.0, path="random"):
     """cfg2 of BASELINE.md: SE2 relative graph-SLAM, every keyframe observes all EARLIER keyframes within `max_range` metres
     ("relative_poses" sensor, datasets/world-2d-30k-rel-graph-slam.cfg:42-45, maxRange 9 m), noise 0.001 m / 0.2 deg (README.md:68)."""
     rng = np.random.RandomState(seed + 7919)
-    gt = manhattan_path(n_kf, seed=seed, block=block, grid=grid)
+    gt = manhattan_tour(n_kf, block=block) if path == "tour" else manhattan_path(n_kf, seed=seed, block=block, grid=grid)
     sig_yaw = math.radians(sigma_yaw_deg)
     cell = max_range
     buckets = {}
@@ -126,3 +169,117 @@ def graph_slam_lambda(sigma_xy=1e-3, sigma_yaw_deg=0.2):
     """Information matrix of apps/srba-slam/CDatasetParser_RelGraphSLAM2D.h:45-52"""
     s = math.radians(sigma_yaw_deg)
     return np.diag([1.0 / sigma_xy ** 2, 1.0 / sigma_xy ** 2, 1.0 / s ** 2])
+
+
+# ------------------------------------------------------------------------------------------------- SE3 / point-landmark generators
+def rot_ypr(yaw, pitch, roll):
+    """R = Rz(yaw) Ry(pitch) Rx(roll) (MRPT CPose3D convention)"""
+    cy, sy, cp, sp, cr, sr = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch), math.cos(roll), math.sin(roll)
+    return np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr], [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr], [-sp, cp * sr, cp * cr]])
+
+
+def pose3(x, y, z, yaw=0.0, pitch=0.0, roll=0.0):
+    T = np.eye(4); T[:3, :3] = rot_ypr(yaw, pitch, roll); T[:3, 3] = (x, y, z); return T
+
+
+def pose3_to_pd(T):
+    """4x4 -> the PD=12 boundary layout [t, R row-major]"""
+    return np.concatenate([T[:3, 3], T[:3, :3].reshape(-1)])
+
+
+CAMERA_ON_ROBOT = (0.0, 0.0, 0.0, math.radians(-90), 0.0, math.radians(-90))  # apps/srba-slam/srba-run-generic-impl.h:79 ; tutorial-srba-stereo-se3.cpp:147
+
+
+def spiral_path_se3(n_kf, seed=1, radius=6.0, step=0.35):
+    """Forward-looking spiral inside a room: smooth 3D trajectory with gentle pitch/roll."""
+    rng = np.random.RandomState(seed)
+    out = []
+    for k in range(n_kf):
+        a = step * k / radius
+        r = radius * (0.6 + 0.4 * math.cos(0.13 * a))
+        x, y, z = r * math.cos(a), r * math.sin(a), 0.6 * math.sin(0.37 * a)
+        yaw = a + math.pi / 2 + 0.05 * rng.randn()
+        out.append(pose3(x, y, z, yaw, 0.05 * math.sin(0.5 * a), 0.04 * math.cos(0.3 * a)))
+    return out
+
+
+def landmarks_dataset_se3(kind="cart3d", n_kf=40, n_lm=400, seed=1, max_range=5.0, noise=0.0, cam=(200.0, 150.0, 512.0, 384.0), baseline=0.2, with_sensor_pose=None,
+                          known_first=0, room=9.0, init_from_gt_noise=None):
+    """SE3 keyframes observing 3D point landmarks.
+    kind: 'cart3d' (observations = landmark in the robot frame), 'stereo' or 'mono' (pinhole, camera looking along robot +X through CAMERA_ON_ROBOT).
+    known_first: the first `known_first` landmarks seen from keyframe 0 are given as FIXED (known relative position), like the reference tutorials do to fix the gauge.
+    Returns (dataset, gt_poses)."""
+    rng = np.random.RandomState(seed)
+    gt = spiral_path_se3(n_kf, seed)
+    lms = np.column_stack([rng.uniform(-room, room, n_lm), rng.uniform(-room, room, n_lm), rng.uniform(-2.0, 2.0, n_lm)])
+    if with_sensor_pose is None:
+        with_sensor_pose = kind in ("stereo", "mono")
+    S = pose3(*CAMERA_ON_ROBOT) if with_sensor_pose else np.eye(4)
+    fx, fy, cx, cy = cam
+    O = {"cart3d": 3, "stereo": 4, "mono": 2}[kind]
+    seen = set(); out = []
+    for kf, T in enumerate(gt):
+        Tinv = np.linalg.inv(T @ S)
+        ids, zs, flags, rel = [], [], [], []
+        p_s = (Tinv[:3, :3] @ lms.T).T + Tinv[:3, 3]  # landmarks in the sensor frame
+        p_r = (np.linalg.inv(T)[:3, :3] @ lms.T).T + np.linalg.inv(T)[:3, 3]  # in the robot frame
+        for j in range(n_lm):
+            q = p_s[j]
+            d = np.linalg.norm(q)
+            if d > max_range or d < 0.4:
+                continue
+            if kind == "cart3d":
+                if with_sensor_pose is False and q[0] < 0.2:  # looks along +X of the robot
+                    continue
+                z = q + noise * rng.randn(3)
+            else:
+                if q[2] < 0.5:
+                    continue
+                u, v = cx + fx * q[0] / q[2], cy + fy * q[1] / q[2]
+                if not (0 <= u < 2 * cx and 0 <= v < 2 * cy):
+                    continue
+                if kind == "stereo":
+                    ur = cx + fx * (q[0] - baseline) / q[2]
+                    z = np.array([u, v, ur, v]) + noise * rng.randn(4)
+                else:
+                    z = np.array([u, v]) + noise * rng.randn(2)
+            first = j not in seen
+            fl = 0; rp = np.zeros(3)
+            if first and len(seen) < known_first and kf == 0:
+                fl = FLAG_FIXED; rp = p_r[j]
+            elif first and init_from_gt_noise is not None:
+                fl = FLAG_INIT; rp = p_r[j] + init_from_gt_noise * rng.randn(3)
+            seen.add(j)
+            ids.append(j); zs.append(z); flags.append(fl); rel.append(rp)
+        out.append(dict(feat_ids=np.array(ids, np.uint64), z=np.array(zs, np.float64).reshape(-1, O), flags=np.array(flags, np.uint8), relpos=np.array(rel, np.float64).reshape(-1, 3)))
+    return out, gt
+
+
+def landmarks_dataset_se2(kind="rb2d", n_kf=50, n_lm=300, seed=1, max_range=4.0, fov_deg=100.0, noise=1e-3, known_first=0):
+    """cfg1 of BASELINE.md: planar random walk, step U(0.4,0.8) m, turn U(-30,30) deg; point landmarks; range-bearing (or cartesian) sensor
+    (datasets/tutorials_dataset-range-bearing-2d.cfg:27-28,44-46)."""
+    rng = np.random.RandomState(seed)
+    gt = [(0.0, 0.0, 0.0)]
+    for _ in range(n_kf - 1):
+        gt.append(_compose2(gt[-1], (rng.uniform(0.4, 0.8), 0.0, math.radians(rng.uniform(-30, 30)))))
+    xs = np.array([p[0] for p in gt]); ys = np.array([p[1] for p in gt])
+    lms = np.column_stack([rng.uniform(xs.min() - 4, xs.max() + 4, n_lm), rng.uniform(ys.min() - 4, ys.max() + 4, n_lm)])
+    seen = set(); out = []
+    for kf, p in enumerate(gt):
+        ids, zs, flags, rel = [], [], [], []
+        c, s = math.cos(p[2]), math.sin(p[2])
+        for j in range(n_lm):
+            dx, dy = lms[j, 0] - p[0], lms[j, 1] - p[1]
+            lx, ly = dx * c + dy * s, -dx * s + dy * c
+            r, b = math.hypot(lx, ly), math.atan2(ly, lx)
+            if r > max_range or r < 0.2 or abs(b) > math.radians(fov_deg) / 2:
+                continue
+            z = np.array([r + noise * rng.randn(), b + noise * rng.randn()]) if kind == "rb2d" else np.array([lx + noise * rng.randn(), ly + noise * rng.randn()])
+            first = j not in seen
+            fl = 0; rp = np.zeros(2)
+            if first and len(seen) < known_first and kf == 0:
+                fl = FLAG_FIXED; rp = np.array([lx, ly])
+            seen.add(j)
+            ids.append(j); zs.append(z); flags.append(fl); rel.append(rp)
+        out.append(dict(feat_ids=np.array(ids, np.uint64), z=np.array(zs, np.float64).reshape(-1, 2), flags=np.array(flags, np.uint8), relpos=np.array(rel, np.float64).reshape(-1, 2)))
+    return out, gt

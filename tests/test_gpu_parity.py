@@ -1,0 +1,114 @@
+"""GPU parity tests (-m gpu): the HIP path (through the C ABI) against the CPU oracle on the same capsules.
+
+Tolerances: chi2 / residual-derived scalars 1e-6 relative (BASELINE.json north_star); integer outputs (trial counts, accept /
+relinearise decisions, stop reasons) exact; unknowns 1e-6 relative to their scale.
+"""
+import numpy as np
+import pytest
+
+from srba_amd import capi, datasets, runner
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-6
+
+
+def _close(a, b, rel=REL, abs_=1e-15):
+    a = np.asarray(a, float); b = np.asarray(b, float)
+    return np.all(np.abs(a - b) <= rel * np.maximum(np.abs(a), np.abs(b)) + abs_)
+
+
+@pytest.fixture(scope="module")
+def se2_batch():
+    # capsules harvested with the oracle as numeric back-end (tests may use the oracle); 240 keyframes with loop closures
+    ds = datasets.graph_slam_se2(n_kf=240, seed=5, grid=2, block=30.0)
+    return runner.harvest_graph_slam(ds, backend="oracle", submap=10, depth=3)
+
+
+def _compare_lm(b, gpu, cpu):
+    """chi2 parity (1e-6 relative, BASELINE.json) + exact agreement of everything that is well conditioned.
+    Trial COUNTS are not compared: with max_error_per_obs_to_stop=1e-8 (srba-slam default) the reference keeps iterating at the noise floor,
+    where accept/reject (sign of rho = (E-E')/...) is decided by the last bits of E-E' and legitimately differs between any two
+    floating-point evaluation orders.  The per-trial chi2 traces must agree on the whole prefix where the two runs take the same decisions."""
+    assert np.all(gpu["status"] == cpu["status"])
+    for k in ("num_observations", "num_jacobians", "num_span_tree_numeric_updates", "num_invalid_jacobs"):
+        assert np.array_equal(gpu[k], cpu[k]), k
+    for k in ("chi2_init", "lambda_init"):
+        assert _close(gpu[k], cpu[k], rel=1e-9), k
+    assert _close(gpu["chi2_final"], cpu["chi2_final"], rel=1e-6, abs_=1e-20)
+    assert _close(gpu["obs_rmse"], cpu["obs_rmse"], rel=1e-6, abs_=1e-12)
+    n_full = 0
+    for i in range(b.n):
+        m = int(min(gpu["num_trials"][i], cpu["num_trials"][i], capi.TRACE_LEN))
+        g, c = gpu["trace_chi2"][i][:m], cpu["trace_chi2"][i][:m]
+        same_dec = (np.sign(gpu["trace_rho"][i][:m]) == np.sign(cpu["trace_rho"][i][:m])) & (np.isnan(g) == np.isnan(c))
+        k = m if same_dec.all() else int(np.argmin(same_dec))  # first trial where the decisions differ
+        assert k >= min(m, 2), (i, k, m)                      # the descent phase is always identical
+        ok = ~np.isnan(c[:k])
+        assert _close(g[:k][ok], c[:k][ok], rel=1e-6, abs_=1e-20), i
+        assert _close(gpu["trace_lambda"][i][:k], cpu["trace_lambda"][i][:k], rel=1e-9), i
+        n_full += int(k == m and gpu["num_trials"][i] == cpu["num_trials"][i])
+    return n_full
+
+
+def test_lm_run_matches_oracle_se2(se2_batch):
+    b = se2_batch
+    assert b.n > 200
+    gpu = runner.run_batch_hip(b, download=True)
+    cpu = runner.run_batch_oracle(b, keep_state=True)
+    n_full = _compare_lm(b, gpu, cpu)
+    assert n_full > b.n // 5  # a good share of the capsules follow the identical trial sequence to the end
+    # final unknowns and spanning-tree poses (metres / radians; both runs stop at the same minimum)
+    P, L, O, PD = capi.DIMS[b.family]
+    for i in range(b.n):
+        nk = b[i].n_unk_edges
+        g = gpu["state"].array(i, "edge_pose", np.float64, nk * PD); c = cpu["state"].array(i, "edge_pose", np.float64, nk * PD)
+        assert np.allclose(g, c, rtol=1e-6, atol=1e-7), i
+        g = gpu["state"].array(i, "pose", np.float64, 2 * b[i].n_pairs * PD); c = cpu["state"].array(i, "pose", np.float64, 2 * b[i].n_pairs * PD)
+        assert np.allclose(g, c, rtol=1e-6, atol=1e-6), i
+
+
+def test_stepwise_kernels_match_oracle_se2(se2_batch):
+    b = se2_batch
+    ctx = runner.HipContext(b.params); ctx.upload(b)
+    lib = ctx.lib
+    assert lib.srba_hip_update_spantree(ctx.ctx, 0) == 0
+    chi2 = np.zeros(b.n); assert lib.srba_hip_eval_residuals(ctx.ctx, chi2.ctypes.data_as(capi.PF64)) == 0
+    assert lib.srba_hip_linearize(ctx.ctx) == 0
+    res, Jp, HAp, grad, poses = ctx.debug(0), ctx.debug(1), ctx.debug(3), ctx.debug(6), ctx.debug(9)
+    assert lib.srba_hip_solve(ctx.ctx, None, None) == 0  # lambda = the guess computed by linearize
+    delta = ctx.debug(7)
+    P, L, O, PD = capi.DIMS[b.family]
+    o = dict(res=0, Jp=0, HAp=0, grad=0, poses=0)
+    for i in range(b.n):
+        c = b[i]
+        ref = runner.oracle_stage(b, i, do_solve=True, lam=0.0)  # lam filled below
+        n = P * c.n_unk_edges + L * c.n_unk_lms
+        sl = lambda key, cnt: slice(o[key], o[key] + cnt)
+        assert _close(chi2[i], ref["scalars"][0]), i
+        assert np.allclose(res[sl("res", c.n_obs * O)], ref["resid"], rtol=1e-9, atol=1e-12), i
+        assert np.allclose(Jp[sl("Jp", c.n_bp * O * P)], ref["Jp"], rtol=1e-9, atol=1e-12), i
+        assert np.allclose(poses[sl("poses", 2 * c.n_pairs * PD)], ref["poses"], rtol=1e-9, atol=1e-12), i
+        assert np.allclose(grad[sl("grad", n)], ref["grad"], rtol=1e-7, atol=1e-9 * np.abs(ref["grad"]).max()), i
+        # HAp (no Schur here: unchanged by the solve) and the LM step for lambda0
+        ref2 = runner.oracle_stage(b, i, do_solve=True, lam=ref["scalars"][1])
+        assert np.allclose(HAp[sl("HAp", c.n_hap * P * P)], ref2["HAp"], rtol=1e-9, atol=1e-9 * np.abs(ref2["HAp"]).max()), i
+        assert np.allclose(delta[sl("grad", n)], ref2["delta"], rtol=1e-6, atol=1e-9 * max(1e-30, np.abs(ref2["delta"]).max())), i
+        o["res"] += c.n_obs * O; o["Jp"] += c.n_bp * O * P; o["HAp"] += c.n_hap * P * P; o["grad"] += n; o["poses"] += 2 * c.n_pairs * PD
+    ctx.close()
+
+
+def test_engine_with_hip_backend_submaps_loop_closure():
+    """tests/submaps_edge_init_values.cpp:81-173 (MiniProblems.SubmapsEdgesInitValues) through the product front-end + GPU."""
+    ds = datasets.graph_slam_from_entries(datasets.C1_SUBMAPS, 1e-3, np.radians(0.05), seed=1)
+    eng = runner.graph_slam_engine(backend="hip", submap=5, depth=3, sigma_xy=1e-3, sigma_yaw_deg=0.05, solver=capi.SOLVER_SCHUR_DENSE, max_error_per_obs_to_stop=1e-6)
+    seen_lc = False
+    for k in ds:
+        info = eng.add_keyframe(k["feat_ids"], k["z"], k["flags"])
+        if info.n_new_edges == 2:
+            seen_lc = True
+            inv = 2 ** 64 - 1
+            assert info.lc_base[0] != inv or info.lc_base[1] != inv
+            assert info.lc_observer[0] != inv or info.lc_observer[1] != inv
+            assert info.num_observations > 1 and info.obs_rmse < 1e-6
+    assert seen_lc

@@ -1,0 +1,94 @@
+"""Spanning-tree property tests, restating tests/spantree_unittest.cpp:38-245 of the reference (SpanTreeTests.*):
+the incrementally maintained depth-limited symbolic spanning trees must equal a brute-force BFS on the keyframe graph
+(same reachable sets, same distances), the stored edge paths must be valid shortest chains, and composing the edges'
+inverse poses along them must reproduce the ground-truth relative poses (1e-6, as the reference).
+Grid of the reference: N in {10,50,300}, depth 1..4, seeds 1..9, linear / linear+5% loop closures, both edge directions."""
+import collections
+
+import numpy as np
+import pytest
+
+from srba_amd import capi, datasets, runner
+
+
+def _build(topo, n, depth, seed):
+    rng = np.random.RandomState(seed)
+    gt = [datasets.pose3(*rng.uniform(-10, 10, 3), rng.uniform(-np.pi, np.pi), rng.uniform(-0.5 * np.pi, 0.5 * np.pi), rng.uniform(-np.pi, np.pi)) for _ in range(n)]
+    eng = runner.Engine(capi.SE3_CART3D, backend="oracle", max_tree_depth=depth, max_optimize_depth=depth)
+    lib, h = eng.lib, eng.h
+    adj = collections.defaultdict(list); edges = []
+    for kf in range(n):
+        new_kf = lib.srba_engine_alloc_keyframe(h)
+        assert new_kf == kf
+        if kf == 0:
+            continue
+        new_edges = [(kf - 1, kf)] if topo < 100 else [(kf, kf - 1)]
+        if topo % 100 == 1:
+            new_edges = [(kf - 1, kf)]
+            if kf > 2:
+                while rng.uniform() < 0.05:
+                    other = int(rng.randint(0, kf - 1))
+                    if other not in [e[1] for e in adj[kf]]:
+                        new_edges.append((kf, other) if topo > 100 else (other, kf))
+        for fr, to in new_edges:
+            if (fr if to == kf else to) in [e[1] for e in adj[kf]]:
+                continue
+            inv_pose = np.linalg.inv(gt[to]) @ gt[fr]  # pose of `from` as seen from `to` (k2k_edge_t::inv_pose)
+            pd = np.ascontiguousarray(datasets.pose3_to_pd(inv_pose))
+            eid = lib.srba_engine_create_edge(h, kf, fr, to, pd.ctypes.data_as(capi.PF64))
+            assert eid == len(edges)
+            edges.append((fr, to, inv_pose)); adj[fr].append((eid, to)); adj[to].append((eid, fr))
+    return eng, gt, edges, adj
+
+
+def _bfs(adj, root, depth):
+    dist = {root: 0}; q = collections.deque([root])
+    while q:
+        u = q.popleft()
+        if dist[u] >= depth:
+            continue
+        for _, v in adj[u]:
+            if v not in dist:
+                dist[v] = dist[u] + 1; q.append(v)
+    return dist
+
+
+def _check(topo, n, depth, seed):
+    eng, gt, edges, adj = _build(topo, n, depth, seed)
+    ne = eng.st_dump(0).reshape(-1, 4)
+    st = collections.defaultdict(dict)
+    for s, t, nxt, d in ne:
+        st[int(s)][int(t)] = (int(nxt), int(d))
+    for kf in range(n):
+        bfs = _bfs(adj, kf, depth); bfs.pop(kf)
+        assert set(st[kf].keys()) == set(bfs.keys()), (topo, n, depth, seed, kf)  # spantree_unittest.cpp:140
+        for t, (nxt, d) in st[kf].items():
+            assert d == bfs[t]                                                     # :197
+            assert nxt in [v for _, v in adj[kf]] and (nxt == t or st[nxt][t][1] == d - 1)
+    ae = eng.st_dump(1); i = 0; npaths = 0
+    while i < len(ae):
+        fr, to, ln = int(ae[i]), int(ae[i + 1]), int(ae[i + 2]); path = [int(x) for x in ae[i + 3:i + 3 + ln]]; i += 3 + ln; npaths += 1
+        assert fr > to and ln == st[fr][to][1]
+        cur, acc = fr, np.eye(4)
+        for eid in path:  # spantree_update_numeric.h:47-65
+            efr, eto, inv_pose = edges[eid]
+            if eto == cur:
+                acc = acc @ inv_pose; cur = efr
+            else:
+                assert efr == cur
+                acc = acc @ np.linalg.inv(inv_pose); cur = eto
+        assert cur == to
+        gt_rel = np.linalg.inv(gt[fr]) @ gt[to]                                   # pose of `to` as seen from `fr`
+        assert np.abs(acc - gt_rel).sum() < 1e-6                                    # :208,:216
+    assert npaths == sum(len(v) for v in st.values()) // 2
+    eng.close()
+
+
+@pytest.mark.parametrize("topo", [0, 100, 1, 101])
+def test_spanning_trees_equal_bfs(topo):
+    for n in (10, 50):
+        for depth in (1, 2, 3, 4):
+            for seed in range(1, 10):
+                _check(topo, n, depth, seed)
+    for depth in (1, 2, 3, 4):
+        _check(topo, 300, depth, 1)
