@@ -93,7 +93,7 @@ def main():
     from srba_amd import capi, datasets, runner
 
     t0 = time.time()
-    ds = datasets.graph_slam_se2(n_kf=args.n_kf, seed=1 + rank)
+    ds = datasets.graph_slam_se2(n_kf=args.n_kf, seed=1 + rank, path="tour")
     t_gen = time.time() - t0
     t0 = time.time()
     # The drop-in path: the header-only RbaEngine<> front-end with the GPU back-end, keyframe by keyframe (srba-slam --se2 --graph-slam

@@ -381,9 +381,13 @@ public:
 		double kernel_param; size_t max_iters; double max_error_per_obs_to_stop, max_rho, max_lambda, min_error_reduction_ratio_to_relinearize;
 		bool numeric_jacobians; void (*feedback_user_iteration)(unsigned int, const double, const double);
 		bool compute_condition_number, compute_sparsity_stats; double max_rmse_show_red_warning; TCovarianceRecoveryPolicy cov_recovery;
+		/** (extension, default false = reference behaviour) The reference refreshes, inside the LM loop, only the spanning-tree poses that Jacobian blocks of the
+		 *  optimised columns reference (optimize_edges.h:550-566, spantree_update_numeric.h:34-35); residuals of observations whose observer-side edge is not being
+		 *  optimised are then evaluated with pre-step poses. Set to true to refresh every pose a residual reads as well. */
+		bool refresh_all_read_poses;
 		TSRBAParameters() : max_tree_depth(4), max_optimize_depth(4), optimize_new_edges_alone(true), use_robust_kernel(false), use_robust_kernel_stage1(false), kernel_param(3.), max_iters(20),
 			max_error_per_obs_to_stop(1e-6), max_rho(10.0), max_lambda(1e20), min_error_reduction_ratio_to_relinearize(0.01), numeric_jacobians(false), feedback_user_iteration(NULL),
-			compute_condition_number(false), compute_sparsity_stats(false), max_rmse_show_red_warning(0.5), cov_recovery(crpLandmarksApprox) {}
+			compute_condition_number(false), compute_sparsity_stats(false), max_rmse_show_red_warning(0.5), cov_recovery(crpLandmarksApprox), refresh_all_read_poses(false) {}
 	};
 	struct TAllParameters {
 		TSRBAParameters srba;
@@ -814,6 +818,7 @@ protected:
 			const k2f_edge_t &k2f = rba_state.all_observations[involved_obs[i]];
 			const TKeyFrameID obs_kf = k2f.obs.kf_id, base_kf = k2f.feat_rel_pos->id_frame_base;
 			cd.obs_pose.push_back(obs_kf == base_kf ? -1 : pose_idx(obs_kf, base_kf));
+			if (parameters.srba.refresh_all_read_poses && cd.obs_pose.back() >= 0) cd.pose_required[cd.obs_pose.back()] = 1;
 			cd.obs_lm.push_back(lm_ref(k2f.obs.obs.feat_id));
 			std::map<size_t, int>::iterator vs = valid_slot.find(involved_obs[i]); if (vs == valid_slot.end()) vs = valid_slot.insert(std::make_pair(involved_obs[i], (int)valid_slot.size())).first;
 			cd.obs_valid.push_back(vs->second);

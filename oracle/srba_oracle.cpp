@@ -40,12 +40,16 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <thread>
 #include <vector>
 
 namespace {
+
+static const bool g_refresh_all = (getenv("SRBA_ORACLE_REFRESH_ALL") != nullptr); // diagnostic: refresh every ST pose in every trial (study of App. B-12)
+static const bool g_exact_relpose_jacobian = (getenv("SRBA_ORACLE_EXACT_JAC") != nullptr); // diagnostic switch, see jacobian_dh_dp
 
 // ------------------------------------------------------------------------------------------------
 // MRPT angle wrapping  [EXT mrpt/math/wrap2pi.h]
@@ -481,6 +485,21 @@ struct Problem {
 			const double J2[9] = {ca, -sa, 0, sa, ca, 0, 0, 0, 1};
 			double T0[9], T1[9]; mm<3, 3, 3>(dh_dx, J0, T0); mm<3, 3, 3>(T0, J1, T1); mm<3, 3, 3>(T1, J2, J);
 			if (inverse_edge) for (int k = 0; k < 9; k++) J[k] = -J[k];
+			if (g_exact_relpose_jacobian) { // DIAGNOSTIC ONLY (SRBA_ORACLE_EXACT_JAC=1): J = -dr/deps by central differences, to study App. B-13
+				const double *z = c.obs_z + (size_t)c.bp_res[b] * O; Pose2 Z; Z.x = z[0]; Z.y = z[1]; Z.phi = z[2];
+				const Pose2 Drest = inverse_edge ? compose(pe, D) : D;
+				for (int dd = 0; dd < 3; dd++) {
+					double rr[2][3];
+					for (int sgn = 0; sgn < 2; sgn++) {
+						double e[3] = {0, 0, 0}; e[dd] = sgn ? 1e-6 : -1e-6;
+						Pose2 T;
+						if (!inverse_edge) { T = compose(pseudo_exp2(e), D); if (hasA) T = compose(A, T); }
+						else { const Pose2 pe2 = compose(pseudo_exp2(e), pe); T = compose(inverse(pe2), Drest); if (hasA) T = compose(A, T); }
+						const Pose2 h = inv_compose(Z, T); rr[sgn][0] = h.x; rr[sgn][1] = h.y; rr[sgn][2] = wrapToPi(h.phi);
+					}
+					for (int k = 0; k < 3; k++) J[k * 3 + dd] = -(rr[1][k] - rr[0][k]) / 2e-6;
+				}
+			}
 		} else if constexpr (!SE3) { // SE2 + 2D points, jacobians.h:501-634
 			double Xd, Yd, PHIa; Pose2 AD;
 			if (!inverse_edge) { Xd = D.x; Yd = D.y; PHIa = hasA ? A.phi : 0.0; AD = i_wrt_l; }
@@ -738,7 +757,7 @@ struct Problem {
 		if (!(use_schur && dense_chol)) sparse_setup();
 		const double MAX_LAMBDA = prm.max_lambda;
 		std::vector<pose_t> old_edges(nK), old_poses; std::vector<double> old_ulm;
-		std::vector<int> req; for (int i = 0; i < 2 * c.n_pairs; i++) if (c.pose_required[i]) req.push_back(i);
+		std::vector<int> req; for (int i = 0; i < 2 * c.n_pairs; i++) if (c.pose_required[i] || g_refresh_all) req.push_back(i);
 		old_poses.resize(req.size());
 		int iter; bool stop = false; int trials = 0;
 		for (iter = 0; iter < prm.max_iters && !stop; iter++) { // :454
@@ -761,7 +780,7 @@ struct Problem {
 				}
 				for (int i = 0; i < nF * L; i++) ulm[i] += delta[(size_t)P * nK + i]; // :534-539
 				for (size_t i = 0; i < req.size(); i++) old_poses[i] = pose[req[i]]; // :550-557
-				update_spantree(true); // :562-565
+				update_spantree(!g_refresh_all); // :562-565
 				const double new_err = residuals(new_resid); // :573-577
 				const double new_RMSE = std::sqrt(new_err / nObs);
 				const double err_red = total_err > 0 ? (total_err - new_err) / total_err : 0; // :581

@@ -98,18 +98,22 @@ def manhattan_tour(n_kf, block=100.0, step=2.0):
     intersection, i.e. one loop-closure event per `block` metres -- the "corridor loop walk" of SURVEY 8d for which the reference's RWT path
     (datasets/world-2d-30k-rel-graph-slam.cfg:22) is the model.  The grid size is chosen so that the tour is just long enough for n_kf keyframes."""
     G = 1
-    while 2 * (G + 1) * (G * block + block) / step < n_kf:
+    while ((G + 1) * (G + 1) + G * (G + 2)) * block / step < n_kf:
         G += 1
     wp = []
-    for r in range(G + 1):  # rows, alternating direction, connected by one block of the outer columns
+    for r in range(G + 1):  # phase 1: east-west streets y = r*block, alternating direction, joined along x = 0 / x = G*block
         xs = (0.0, G * block) if r % 2 == 0 else (G * block, 0.0)
         wp += [(xs[0], r * block), (xs[1], r * block)]
-    last = wp[-1]
-    cols = range(G + 1) if last[0] == 0.0 else range(G, -1, -1)
-    down = True  # we are at the top row
+    # phase 2: north-south streets half a block off the phase-1 connectors (x = (c+0.5)*block), running from half a block above the
+    # top row to half a block below the bottom row: every crossing of a phase-1 street is perpendicular, the joins are new ground.
+    end_x = wp[-1][0]
+    cols = list(range(G)) if end_x == 0.0 else list(range(G - 1, -1, -1))
+    top, bot = (G + 0.5) * block, -0.5 * block
+    wp.append((end_x, top))
+    down = True
     for cidx in cols:
-        ys = (G * block, 0.0) if down else (0.0, G * block)
-        wp += [(cidx * block, ys[0]), (cidx * block, ys[1])]
+        xc = (cidx + 0.5) * block
+        wp += [(xc, top if down else bot), (xc, bot if down else top)]
         down = not down
     poses = []; x, y = wp[0]; th = 0.0
     for (tx, ty) in wp[1:]:
