@@ -1,0 +1,169 @@
+"""Checks that pin the ORACLE itself (CPU only), independent of the GPU:
+ * Schur complement: block-sparse reduction + back-substitution == naive dense algebra (the property of the reference's
+   tests/schur_unittest.cpp:71-279, tolerance 1e-10 on the reduced Hessian, :258,:267), on real visibility patterns of all landmark families
+   and for the three solver variants;
+ * analytic Jacobian blocks == finite differences of the oracle's own residual function (reference debug path SRBA_VERIFY_AGAINST_NUMERIC_JACOBIANS,
+   jacobians.h:339-349,998-1008). For the relative-pose family the reference Jacobian is exact only at zero residual, so that family
+   is checked on noise-free, converged data."""
+import numpy as np
+import pytest
+
+from srba_amd import capi, datasets, runner
+
+
+def _harvest(kind, solver=capi.SOLVER_SCHUR_DENSE, n_kf=14, seed=3, **kw):
+    if kind in ("rb2d", "cart2d"):
+        ds, gt = datasets.landmarks_dataset_se2(kind, n_kf=n_kf + 10, n_lm=900, seed=seed, noise=1e-3)
+    else:
+        ds, gt = datasets.landmarks_dataset_se3(kind, n_kf=n_kf, n_lm=350, seed=seed, noise=(1e-3 if kind == "cart3d" else 0.1), init_from_gt_noise=(0.2 if kind == "mono" else None))
+    eng = runner.landmark_engine(kind, backend="oracle", solver=solver, **kw)
+    eng.run(ds)
+    b = eng.harvest(); b.engine = eng
+    return b
+
+
+def _dense_system(b, i, a):
+    P, L, O, PD = capi.DIMS[b.family]
+    c = b[i]; nK, nF = c.n_unk_edges, c.n_unk_lms; n = P * nK + L * nF
+    H = np.zeros((n, n))
+    hi, hj = b.array(i, "hap_i", np.int32, c.n_hap), b.array(i, "hap_j", np.int32, c.n_hap)
+    for k in range(c.n_hap):
+        blk = a["HAp"][k * P * P:(k + 1) * P * P].reshape(P, P)
+        H[P * hi[k]:P * hi[k] + P, P * hj[k]:P * hj[k] + P] = blk
+        if hi[k] != hj[k]:
+            H[P * hj[k]:P * hj[k] + P, P * hi[k]:P * hi[k] + P] = blk.T
+    fi, fj = b.array(i, "hf_i", np.int32, c.n_hf), b.array(i, "hf_j", np.int32, c.n_hf)
+    for k in range(c.n_hf):
+        blk = a["Hf"][k * L * L:(k + 1) * L * L].reshape(L, L)
+        H[P * nK + L * fi[k]:P * nK + L * fi[k] + L, P * nK + L * fj[k]:P * nK + L * fj[k] + L] = blk
+    pi, pj = b.array(i, "hapf_i", np.int32, c.n_hapf), b.array(i, "hapf_j", np.int32, c.n_hapf)
+    for k in range(c.n_hapf):
+        blk = a["HApf"][k * P * L:(k + 1) * P * L].reshape(P, L)
+        H[P * pi[k]:P * pi[k] + P, P * nK + L * pj[k]:P * nK + L * pj[k] + L] = blk
+        H[P * nK + L * pj[k]:P * nK + L * pj[k] + L, P * pi[k]:P * pi[k] + P] = blk.T
+    # diagonal blocks are stored with both triangles: symmetrise from the upper one
+    H = np.triu(H) + np.triu(H, 1).T
+    return H, n, nK, nF
+
+
+@pytest.mark.parametrize("kind", ["cart3d", "stereo", "rb2d"])
+def test_schur_sparse_equals_dense(kind):
+    b = _harvest(kind)
+    P, L, O, PD = capi.DIMS[b.family]
+    checked = 0
+    for i in range(max(0, b.n - 5), b.n):
+        c = b[i]
+        if c.n_unk_lms == 0 or c.n_unk_edges < 2:
+            continue
+        a0 = runner.oracle_stage(b, i)                      # un-reduced blocks, gradient
+        lam = 1e3                                           # schur_unittest.cpp uses lambda = 1e3
+        a1 = runner.oracle_stage(b, i, do_solve=True, lam=lam)
+        assert a1["scalars"][2] == 0                        # positive definite
+        H, n, nK, nF = _dense_system(b, i, a0)
+        Hpp, Hpf, Hff = H[:P * nK, :P * nK], H[:P * nK, P * nK:], H[P * nK:, P * nK:]
+        S = Hpp - Hpf @ np.linalg.inv(Hff + lam * np.eye(L * nF)) @ Hpf.T
+        hi, hj = b.array(i, "hap_i", np.int32, c.n_hap), b.array(i, "hap_j", np.int32, c.n_hap)
+        covered = np.zeros((nK, nK), bool)
+        for k in range(c.n_hap):
+            blk = a1["HAp"][k * P * P:(k + 1) * P * P].reshape(P, P)
+            ref = S[P * hi[k]:P * hi[k] + P, P * hj[k]:P * hj[k] + P]
+            if hi[k] == hj[k]:
+                blk = np.triu(blk); ref = np.triu(ref)
+            assert np.abs(blk - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max()), (kind, i, k)
+            covered[hi[k], hj[k]] = covered[hj[k], hi[k]] = True
+        for r in range(nK):  # blocks outside the plan are structurally zero in the dense Schur complement
+            for q in range(nK):
+                if not covered[r, q]:
+                    assert np.abs(S[P * r:P * r + P, P * q:P * q + P]).max() < 1e-9 * np.abs(S).max()
+        delta = np.linalg.solve(H + lam * np.eye(n), a0["grad"])
+        assert np.allclose(a1["delta"], delta, rtol=1e-7, atol=1e-9 * np.abs(delta).max()), (kind, i)
+        checked += 1
+    assert checked >= 2
+
+
+def test_three_solvers_give_the_same_step():
+    out = {}
+    for solver in (capi.SOLVER_SCHUR_DENSE, capi.SOLVER_SCHUR_SPARSE, capi.SOLVER_NO_SCHUR_SPARSE):
+        b = _harvest("cart3d", solver=solver, run_local_optimization=1)
+        i = b.n - 1
+        a = runner.oracle_stage(b, i, do_solve=True, lam=10.0)
+        out[solver] = a["delta"]
+    assert np.allclose(out[0], out[1], rtol=1e-8, atol=1e-12) and np.allclose(out[0], out[2], rtol=1e-7, atol=1e-11)
+
+
+def _so3_exp(w):
+    th = np.linalg.norm(w)
+    W = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-12:
+        return np.eye(3) + W
+    return np.eye(3) + np.sin(th) / th * W + (1 - np.cos(th)) / th ** 2 * W @ W
+
+
+def _perturb_edge(pose, eps, PD):
+    """exp(eps) (+) pose  (optimize_edges.h:515-521)"""
+    if PD == 3:
+        c, s = np.cos(eps[2]), np.sin(eps[2])
+        return np.array([eps[0] + pose[0] * c - pose[1] * s, eps[1] + pose[0] * s + pose[1] * c, pose[2] + eps[2]])
+    R = pose[3:].reshape(3, 3); t = pose[:3]; E = _so3_exp(eps[3:])
+    return np.concatenate([eps[:3] + E @ t, (E @ R).reshape(-1)])
+
+
+@pytest.mark.parametrize("kind", ["cart3d", "stereo", "mono", "rb2d", "cart2d"])
+def test_point_family_jacobians_match_finite_differences(kind):
+    b = _harvest(kind, n_kf=8)
+    P, L, O, PD = capi.DIMS[b.family]
+    i = b.n - 1; c = b[i]
+    a0 = runner.oracle_stage(b, i)
+    Jp = a0["Jp"].reshape(c.n_bp, O, P); Jf = a0["Jf"].reshape(c.n_bf, O, L)
+    bp_col, bp_res = b.array(i, "bp_col", np.int32, c.n_bp), b.array(i, "bp_res", np.int32, c.n_bp)
+    bf_col, bf_res = b.array(i, "bf_col", np.int32, c.n_bf), b.array(i, "bf_res", np.int32, c.n_bf)
+    w = b.clone(i, 1); cw = w.ptr[0]
+    edge = np.ctypeslib.as_array(cw.edge_pose, shape=(cw.n_edges * PD,)); ulm = np.ctypeslib.as_array(cw.ulm_pos, shape=(max(1, cw.n_unk_lms * L),))
+    res = lambda: runner.oracle_stage(w, 0)["resid"].reshape(-1, O)
+    h = 1e-6
+    for col in range(min(c.n_unk_edges, 3)):
+        save = edge[PD * col:PD * col + PD].copy(); Jn = np.zeros((c.n_obs, O, P))
+        for d in range(P):
+            e = np.zeros(P); e[d] = h; edge[PD * col:PD * col + PD] = _perturb_edge(save, e, PD); rp = res()
+            e[d] = -h; edge[PD * col:PD * col + PD] = _perturb_edge(save, e, PD); rm = res()
+            edge[PD * col:PD * col + PD] = save
+            Jn[:, :, d] = -(rp - rm) / (2 * h)   # r = z - h  =>  dh/deps = -dr/deps
+        for blk in np.where(bp_col == col)[0]:
+            scale = max(1.0, np.abs(Jp[blk]).max())
+            assert np.abs(Jn[bp_res[blk]] - Jp[blk]).max() < 2e-5 * scale, (kind, col, blk)
+    for col in range(min(c.n_unk_lms, 4)):
+        save = ulm[L * col:L * col + L].copy(); Jn = np.zeros((c.n_obs, O, L))
+        for d in range(L):
+            ulm[L * col + d] = save[d] + h; rp = res(); ulm[L * col + d] = save[d] - h; rm = res(); ulm[L * col + d] = save[d]
+            Jn[:, :, d] = -(rp - rm) / (2 * h)
+        for blk in np.where(bf_col == col)[0]:
+            scale = max(1.0, np.abs(Jf[blk]).max())
+            assert np.abs(Jn[bf_res[blk]] - Jf[blk]).max() < 2e-5 * scale, (kind, col, blk)
+
+
+def test_relpose_jacobian_is_minus_dr_deps_at_zero_residual():
+    # a loop-free stretch of the tour (with loop closures the stored Jacobian path of an old observation may differ from the current
+    # shortest path used for its residual -- a property of the reference's design, not of the formulas under test)
+    ds = datasets.graph_slam_se2(n_kf=48, seed=2, sigma_xy=0.0, sigma_yaw_deg=0.0, path="tour")
+    # noise-free data converge to zero residual; a second optimisation of the last window then starts from the converged state
+    eng = runner.graph_slam_engine(backend="oracle", submap=5, depth=3)
+    eng.run(ds[:-1]); eng.lib.srba_engine_harvest_clear(eng.h); eng.cfg.harvest = 1
+    info = eng.add_keyframe(ds[-1]["feat_ids"], ds[-1]["z"], ds[-1]["flags"])
+    assert info.obs_rmse < 1e-6
+    kinfo = capi.KfInfo(); eng.lib.srba_engine_harvest_clear(eng.h)
+    eng.lib.srba_engine_optimize_local_area(eng.h, len(ds) - 1, 3, kinfo)  # a second call starts from the converged state
+    b = eng.harvest(); i = b.n - 1; c = b[i]
+    a0 = runner.oracle_stage(b, i)
+    assert np.abs(a0["resid"]).max() < 1e-6
+    Jp = a0["Jp"].reshape(c.n_bp, 3, 3); bp_col, bp_res = b.array(i, "bp_col", np.int32, c.n_bp), b.array(i, "bp_res", np.int32, c.n_bp)
+    w = b.clone(i, 1); cw = w.ptr[0]; edge = np.ctypeslib.as_array(cw.edge_pose, shape=(cw.n_edges * 3,))
+    res = lambda: runner.oracle_stage(w, 0)["resid"].reshape(-1, 3)
+    h = 1e-6
+    for col in range(min(c.n_unk_edges, 6)):
+        save = edge[3 * col:3 * col + 3].copy(); Jn = np.zeros((c.n_obs, 3, 3))
+        for d in range(3):
+            e = np.zeros(3); e[d] = h; edge[3 * col:3 * col + 3] = _perturb_edge(save, e, 3); rp = res()
+            e[d] = -h; edge[3 * col:3 * col + 3] = _perturb_edge(save, e, 3); rm = res(); edge[3 * col:3 * col + 3] = save
+            Jn[:, :, d] = -(rp - rm) / (2 * h)
+        for blk in np.where(bp_col == col)[0]:
+            assert np.abs(Jn[bp_res[blk]] - Jp[blk]).max() < 1e-5, (col, blk)
