@@ -34,7 +34,7 @@ struct ProbDesc {
 	int n_edges, nK, nF, n_klm, n_pairs, n_obs, n_valid, n_bp, n_bf, n_hap, n_hf, n_hapf, n_sch, n_req, n_sys, n_scal, nb, nnzoff;
 	// element offsets into the batch-wide arrays
 	long long o_edge, o_unk, o_ulm, o_klm, o_pair, o_ppoff, o_path, o_obs, o_valid, o_bp, o_colp, o_bf, o_colf;
-	long long o_hap, o_hapoff, o_hapt, o_hf, o_hfoff, o_hft, o_hapf, o_hapfoff, o_hapft, o_sch, o_lmoff, o_req, o_scal, o_yw, o_dense, o_spcol, o_sprow, o_spitem;
+	long long o_hap, o_hapoff, o_hapt, o_hf, o_hfoff, o_hft, o_hapf, o_hapfoff, o_hapft, o_sch, o_lmoff, o_req, o_scal, o_yw, o_dense, o_spcol, o_sprow, o_spitem, o_spperm;
 	int n_items, aligned; // block updates per factorisation; 1 if every Hessian block maps onto whole 3x3 blocks (always, except L==2 with the no-Schur solver)
 	int dense_in_lds, pad;
 };
@@ -50,7 +50,7 @@ struct Batch {
 	const int *hapf_i, *hapf_j, *hapf_term_off, *hapf_t1, *hapf_t2, *hap_diag, *hf_diag;
 	const int *sch_term_off, *sch_b1, *sch_b2, *sch_lm, *sch_yw, *lm_hapf_off, *lm_hapf_idx, *req_idx;
 	const unsigned char *pair_needed, *bp_normal;
-	const int *sp_col_off, *sp_row, *sp_item_off, *sp_tgt; // symbolic factorisation of every capsule's system
+	const int *sp_col_off, *sp_row, *sp_item_off, *sp_tgt, *sp_perm; // symbolic factorisation of every capsule's system
 	const int *hap_dst, *hapf_dst, *hf_dst; // destination 3x3 block of every aligned sub-block of the Hessian blocks (see symbolic_factor)
 	// state + workspace
 	double *edge, *ulm, *pose, *Jp, *Jf, *resid, *resid2, *HAp, *HAp0, *Hf, *HApf, *grad, *delta, *Hfinv, *YW;
@@ -193,6 +193,7 @@ template <int N> __device__ __forceinline__ bool fullpiv_inverse(const double *A
 struct SparseSys { // per-capsule symbolic structure (global memory, read-only) + numeric storage (LDS or HBM)
 	int nb, nnzoff;
 	const int *col_off, *row, *item_off, *tgt; // col_off[nb+1], row[nnzoff], item_off[nb+1], tgt[n_items]: >=0 offdiag block index, <0: -(1+diag block)
+	const int *perm;                           // perm[original 3-row block] = position in the fill-reducing elimination order
 	double *diag, *off, *rhs;
 };
 struct Chol3 { double l10, l20, l21, r0, r1, r2, l00, l11, l22; };
@@ -280,7 +281,7 @@ __device__ __forceinline__ void sp_bsub(const SparseSys &S) {
 }
 // location of scalar element (r,c), r>=c (block-permutation already applied); returns nullptr if the block is structurally absent
 __device__ __forceinline__ double *sp_elem(const SparseSys &S, int r, int c) {
-	const int br = r / 3, bc = c / 3;
+	const int br = r / 3, bc = c / 3; // (already permuted, r >= c)
 	if (br == bc) return S.diag + 9 * br + (r % 3) * 3 + (c % 3);
 	int lo = S.col_off[bc], hi = S.col_off[bc + 1] - 1;
 	while (lo <= hi) { const int mid = (lo + hi) >> 1; const int v = S.row[mid]; if (v == br) return S.off + 9 * mid + (r % 3) * 3 + (c % 3); if (v < br) lo = mid + 1; else hi = mid - 1; }

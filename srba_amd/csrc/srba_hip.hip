@@ -9,6 +9,7 @@
  */
 #include "srba_device.hpp"
 #include <algorithm>
+#include <iterator>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -92,12 +93,14 @@ struct Solver : public Worker<FAM> {
 		}
 	}
 	// (H + lambda I) scattered into the block-sparse storage + right-hand side (lev-marq_solvers.h:88-150 / :303-325 / :492-519)
-	__device__ __forceinline__ void put(const SparseSys &S, int row, int col, double v) const { // row <= col in the upper triangle -> stored at (col,row)
-		double *p = sp_elem(S, col, row); if (p) *p = v;
+	__device__ __forceinline__ void put(const SparseSys &S, int row, int col, double v) const { // symmetric entry (row,col) of the original numbering
+		const int pr = 3 * S.perm[row / 3] + row % 3, pc = 3 * S.perm[col / 3] + col % 3;
+		double *p = pr >= pc ? sp_elem(S, pr, pc) : sp_elem(S, pc, pr); if (p) *p = v;
 	}
 	// store element (r,q) of an upper-triangle sub-block whose destination block is `dst` (>=0 off-diagonal, stored transposed; <0 diagonal)
+	// dst >= 0: off-diagonal block (dst>>1), bit0 = stored transposed ; dst < 0: diagonal block -(1+dst) (lower triangle kept) ; 0x80000000: duplicate, skipped
 	__device__ __forceinline__ void put_dst(const SparseSys &S, int dst, int r3, int q3, double v) const {
-		if (dst >= 0) S.off[9 * dst + q3 * 3 + r3] = v;
+		if (dst >= 0) S.off[9 * (dst >> 1) + ((dst & 1) ? q3 * 3 + r3 : r3 * 3 + q3)] = v;
 		else if (dst != (int)0x80000000 && r3 <= q3) S.diag[9 * (-1 - dst) + q3 * 3 + r3] = v;
 	}
 	__device__ void assemble(const SparseSys &S, double lambda) {
@@ -105,7 +108,7 @@ struct Solver : public Worker<FAM> {
 		for (int k = tid; k < 9 * nb; k += SRBA_WG) S.diag[k] = 0;
 		for (int k = tid; k < 9 * S.nnzoff; k += SRBA_WG) S.off[k] = 0;
 		const double *g = B.grad + d.o_scal;
-		for (int k = tid; k < 3 * nb; k += SRBA_WG) S.rhs[k] = (k < n) ? g[k] : 0.0;
+		for (int k = tid; k < 3 * nb; k += SRBA_WG) S.rhs[3 * S.perm[k / 3] + k % 3] = (k < n) ? g[k] : 0.0;
 		__syncthreads();
 		constexpr int PB = P / 3;
 		for (int e = tid; e < d.n_hap * P * P; e += SRBA_WG) {
@@ -139,7 +142,7 @@ struct Solver : public Worker<FAM> {
 				}
 			}
 		}
-		for (int k = n + tid; k < 3 * nb; k += SRBA_WG) S.diag[9 * (k / 3) + 4 * (k % 3)] = 1.0; // identity padding
+		for (int k = n + tid; k < 3 * nb; k += SRBA_WG) S.diag[9 * S.perm[k / 3] + 4 * (k % 3)] = 1.0; // identity padding
 		__syncthreads();
 	}
 	// solve(lambda): returns false if not positive definite (uniform across the wavefront)
@@ -153,7 +156,7 @@ struct Solver : public Worker<FAM> {
 		if (!ok) return false;
 		STIC(); sp_bsub(S);
 		double *dl = B.delta + d.o_scal;
-		for (int k = tid; k < d.n_scal; k += SRBA_WG) dl[k] = (k < d.n_sys) ? S.rhs[k] : 0.0;
+		for (int k = tid; k < d.n_scal; k += SRBA_WG) dl[k] = (k < d.n_sys) ? S.rhs[3 * S.perm[k / 3] + k % 3] : 0.0;
 		__syncthreads(); STOC(12);
 		STIC(); if (schur_active()) schur_features(); STOC(13);
 		return true;
@@ -162,15 +165,16 @@ struct Solver : public Worker<FAM> {
 	}
 	template <bool DLDS> __device__ __forceinline__ SparseSys make_sys(double *lds) const {
 		SparseSys S; S.nb = d.nb; S.nnzoff = d.nnzoff;
-		S.col_off = B.sp_col_off + d.o_spcol; S.row = B.sp_row + d.o_sprow; S.item_off = B.sp_item_off + d.o_spcol; S.tgt = B.sp_tgt + d.o_spitem;
+		S.col_off = B.sp_col_off + d.o_spcol; S.row = B.sp_row + d.o_sprow; S.item_off = B.sp_item_off + d.o_spcol; S.tgt = B.sp_tgt + d.o_spitem; S.perm = B.sp_perm + d.o_spperm;
 		double *base; if constexpr (DLDS) base = lds; else base = B.dense + d.o_dense;
 		S.diag = base; S.off = base + 9 * d.nb; S.rhs = S.off + 9 * d.nnzoff;
 		if constexpr (DLDS) { // symbolic structure next to the numbers: the factorisation's dependent index loads hit LDS, not L2
-			int *ip = (int *)(S.rhs + 3 * d.nb); int *c0 = ip, *i0 = ip + d.nb + 1, *r0 = i0 + d.nb + 1, *t0 = r0 + d.nnzoff;
+			int *ip = (int *)(S.rhs + 3 * d.nb); int *c0 = ip, *i0 = ip + d.nb + 1, *r0 = i0 + d.nb + 1, *t0 = r0 + d.nnzoff, *p0 = t0 + d.n_items;
 			for (int k = tid; k <= d.nb; k += SRBA_WG) { c0[k] = S.col_off[k]; i0[k] = S.item_off[k]; }
+			for (int k = tid; k < d.nb; k += SRBA_WG) p0[k] = S.perm[k];
 			for (int k = tid; k < d.nnzoff; k += SRBA_WG) r0[k] = S.row[k];
 			for (int k = tid; k < d.n_items; k += SRBA_WG) t0[k] = S.tgt[k];
-			S.col_off = c0; S.item_off = i0; S.row = r0; S.tgt = t0;
+			S.col_off = c0; S.item_off = i0; S.row = r0; S.tgt = t0; S.perm = p0;
 			__syncthreads();
 		}
 		return S;
@@ -335,18 +339,42 @@ struct Arena { // layout builder: 256-byte aligned sub-allocations inside one bu
 
 #define SRBA_NCLS 6
 // Symbolic block factorisation of one capsule's system (natural block order): the numeric kernel never discovers structure.
-struct Symbolic { std::vector<int32_t> col_off, row, item_off, tgt, hap_dst, hapf_dst, hf_dst; bool aligned = true; };
+struct Symbolic { std::vector<int32_t> col_off, row, item_off, tgt, perm, hap_dst, hapf_dst, hf_dst; bool aligned = true; };
 static void symbolic_factor(const srba_problem_capsule &k, const ProbDesc &d, int P, int L, bool full_system, Symbolic &out) {
-	const int nb = d.nb; std::vector<std::vector<int> > cols(nb); // cols[c] = block rows r > c that are structurally non-zero in column c of the lower triangle
-	auto add_scalar_block = [&](int r0, int c0, int nr, int nc) { // upper-triangle block at scalar rows r0.., cols c0.. (r0 <= c0)
-		for (int i = 0; i < nr; i++) for (int j = 0; j < nc; j++) { int a = (r0 + i) / 3, b = (c0 + j) / 3; if (a == b) continue; if (a > b) std::swap(a, b); cols[a].push_back(b); }
+	const int nb = d.nb;
+	// 1) block-level adjacency of the system (original numbering)
+	std::vector<std::vector<int> > adj(nb);
+	auto add_scalar_block = [&](int r0, int c0, int nr, int nc) {
+		for (int i = 0; i < nr; i++) for (int j = 0; j < nc; j++) { const int a = (r0 + i) / 3, b = (c0 + j) / 3; if (a != b) { adj[a].push_back(b); adj[b].push_back(a); } }
 	};
 	for (int b = 0; b < k.n_hap; b++) add_scalar_block(P * k.hap_i[b], P * k.hap_j[b], P, P);
 	if (full_system) {
 		for (int b = 0; b < k.n_hapf; b++) add_scalar_block(P * k.hapf_i[b], P * d.nK + L * k.hapf_j[b], P, L);
 		for (int b = 0; b < k.n_hf; b++) add_scalar_block(P * d.nK + L * k.hf_i[b], P * d.nK + L * k.hf_j[b], L, L);
 	}
-	for (int c = 0; c < nb; c++) { // elimination: struct(L_c) is merged into its parent column (first off-diagonal row)
+	for (int a = 0; a < nb; a++) { std::sort(adj[a].begin(), adj[a].end()); adj[a].erase(std::unique(adj[a].begin(), adj[a].end()), adj[a].end()); }
+	// 2) fill-reducing order: exact minimum degree on the elimination graph (ties: lowest index). Stands where CSparse's cs_amd stands in the
+	//    reference (cs_schol(order=1)); any permutation gives the same solution up to rounding.
+	out.perm.assign(nb, 0);
+	{
+		std::vector<std::vector<int> > g(adj); std::vector<char> gone(nb, 0); std::vector<int> tmp;
+		for (int step = 0; step < nb; step++) {
+			int best = -1; size_t bestdeg = ~size_t(0);
+			for (int v = 0; v < nb; v++) if (!gone[v] && g[v].size() < bestdeg) { bestdeg = g[v].size(); best = v; }
+			out.perm[best] = step; gone[best] = 1;
+			const std::vector<int> nbrs = g[best];
+			for (size_t x = 0; x < nbrs.size(); x++) { // connect the neighbours into a clique, drop the eliminated node
+				std::vector<int> &gx = g[nbrs[x]]; tmp.clear();
+				std::set_union(gx.begin(), gx.end(), nbrs.begin(), nbrs.end(), std::back_inserter(tmp));
+				gx.clear(); for (size_t q = 0; q < tmp.size(); q++) if (tmp[q] != best && tmp[q] != nbrs[x]) gx.push_back(tmp[q]);
+			}
+			g[best].clear();
+		}
+	}
+	// 3) symbolic factorisation in the permuted numbering: cols[c] = block rows r > c of column c of L
+	std::vector<std::vector<int> > cols(nb);
+	for (int a = 0; a < nb; a++) for (size_t q = 0; q < adj[a].size(); q++) { const int pa = out.perm[a], pb = out.perm[adj[a][q]]; if (pa < pb) cols[pa].push_back(pb); }
+	for (int c = 0; c < nb; c++) {
 		std::vector<int> &v = cols[c]; std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end());
 		if (!v.empty()) { std::vector<int> &par = cols[v[0]]; par.insert(par.end(), v.begin() + 1, v.end()); }
 	}
@@ -361,12 +389,13 @@ static void symbolic_factor(const srba_problem_capsule &k, const ProbDesc &d, in
 		}
 		out.item_off[c + 1] = (int32_t)out.tgt.size();
 	}
-	// destination of every aligned 3x3 sub-block of the upper-triangle Hessian blocks (transposed into the lower factor storage)
-	auto dst_of = [&](int a, int b) -> int32_t { // block row a, block col b of the UPPER triangle
-		if (a == b) return -1 - a;
+	// 4) destination of every aligned 3x3 sub-block (a,b) of the UPPER-triangle Hessian blocks, original numbering a <= b
+	auto dst_of = [&](int a, int b) -> int32_t {
+		if (a == b) return -1 - out.perm[a];
 		if (a > b) return (int32_t)0x80000000; // lower half of a symmetric diagonal block: duplicate, skipped
-		const std::vector<int> &cb = cols[a]; const int pos = (int)(std::lower_bound(cb.begin(), cb.end(), b) - cb.begin());
-		return out.col_off[a] + pos;
+		const int pa = out.perm[a], pb = out.perm[b]; const int lo = std::min(pa, pb), hi = std::max(pa, pb);
+		const std::vector<int> &cb = cols[lo]; const int pos = (int)(std::lower_bound(cb.begin(), cb.end(), hi) - cb.begin());
+		return ((out.col_off[lo] + pos) << 1) | (pa < pb ? 1 : 0); // pa<pb: the factor stores block (pb,pa) = transpose of the given one
 	};
 	const int PB = P / 3;
 	out.hap_dst.clear(); out.hapf_dst.clear(); out.hf_dst.clear();
@@ -501,9 +530,9 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 		d.nb = (d.n_sys + 2) / 3;
 		symbolic_factor(k, d, P, L, !schur_solver, sym[p]);
 		d.nnzoff = (int)sym[p].row.size(); d.n_items = (int)sym[p].tgt.size(); d.aligned = sym[p].aligned ? 1 : 0;
-		d.o_spcol = t_spcol; d.o_sprow = t_sprow; d.o_spitem = t_spitem;
+		d.o_spcol = t_spcol; d.o_sprow = t_sprow; d.o_spitem = t_spitem; d.o_spperm = t_spcol - p;
 		t_spcol += d.nb + 1; t_sprow += d.nnzoff; t_spitem += (long long)sym[p].tgt.size();
-		const size_t n_ints = 2 * ((size_t)d.nb + 1) + (size_t)d.nnzoff + (size_t)d.n_items;
+		const size_t n_ints = 2 * ((size_t)d.nb + 1) + (size_t)d.nnzoff + (size_t)d.n_items + (size_t)d.nb;
 		const size_t tri_n = 9 * (size_t)d.nb + 9 * (size_t)d.nnzoff + 3 * (size_t)d.nb + (n_ints + 1) / 2; // diag | off | rhs | symbolic ints
 		// LDS size classes (bytes per wavefront): 12 KB, 24 KB, 48 KB, 96 KB, 150 KB; larger systems are factored in HBM
 		const size_t bytes = tri_n * 8;
@@ -521,7 +550,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	// ---- input arena layout
 	Arena in; struct { size_t desc, edge0, ulm0, klm, obs_z, pair_path_off, path_edge, obs_pose, obs_lm, obs_valid, bp_col, bp_res, bp_A, bp_D, bp_lm, colp_off, bf_col, bf_res, bf_pose, colf_off,
 		hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hf_i, hf_j, hf_term_off, hf_t1, hf_t2, hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag, sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw,
-		lm_hapf_off, lm_hapf_idx, req_idx, pair_needed, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, hap_dst, hapf_dst, hf_dst; } o;
+		lm_hapf_off, lm_hapf_idx, req_idx, pair_needed, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_perm, hap_dst, hapf_dst, hf_dst; } o;
 	o.desc = in.add(sizeof(ProbDesc) * n);
 	o.edge0 = in.add(8 * t_edge * PD); o.ulm0 = in.add(8 * t_ulm * L); o.klm = in.add(8 * t_klm * L); o.obs_z = in.add(8 * t_obs * O);
 	o.pair_path_off = in.add(4 * (t_pair + n)); o.path_edge = in.add(4 * t_path); o.obs_pose = in.add(4 * t_obs); o.obs_lm = in.add(4 * t_obs); o.obs_valid = in.add(4 * t_obs);
@@ -533,7 +562,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	o.hap_diag = in.add(4 * t_unk); o.hf_diag = in.add(4 * t_ulm);
 	o.sch_term_off = in.add(4 * (t_hap + n)); o.sch_b1 = in.add(4 * t_sch); o.sch_b2 = in.add(4 * t_sch); o.sch_lm = in.add(4 * t_sch); o.sch_yw = in.add(4 * t_sch);
 	o.lm_hapf_off = in.add(4 * (t_ulm + n)); o.lm_hapf_idx = in.add(4 * t_hapf); o.req_idx = in.add(4 * t_req); o.pair_needed = in.add(t_pair); o.bp_normal = in.add(t_bp); o.order = in.add(4 * (size_t)n);
-	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem);
+	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_perm = in.add(4 * t_spcol);
 	o.hap_dst = in.add(4 * t_hap * (P / 3) * (P / 3)); o.hapf_dst = in.add(4 * t_hapf * (P / 3)); o.hf_dst = in.add(4 * t_hf);
 	in.add(0);
 	c->h_in.assign(in.size + 256, 0); char *h = c->h_in.data();
@@ -562,7 +591,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 		{ int32_t *rq = (int32_t *)(h + o.req_idx) + d.o_req; int cnt = 0; for (int i = 0; i < 2 * k.n_pairs; i++) if (k.pose_required[i]) rq[cnt++] = i; }
 		CPY(o.pair_needed, d.o_pair, k.pair_needed, k.n_pairs, uint8_t); CPY(o.bp_normal, d.o_bp, k.bp_normal, k.n_bp, uint8_t);
 		CPY(o.sp_col_off, d.o_spcol, sym[p].col_off.data(), d.nb + 1, int32_t); CPY(o.sp_row, d.o_sprow, sym[p].row.data(), d.nnzoff, int32_t);
-		CPY(o.sp_item_off, d.o_spcol, sym[p].item_off.data(), d.nb + 1, int32_t); CPY(o.sp_tgt, d.o_spitem, sym[p].tgt.data(), sym[p].tgt.size(), int32_t);
+		CPY(o.sp_item_off, d.o_spcol, sym[p].item_off.data(), d.nb + 1, int32_t); CPY(o.sp_perm, d.o_spperm, sym[p].perm.data(), d.nb, int32_t); CPY(o.sp_tgt, d.o_spitem, sym[p].tgt.data(), sym[p].tgt.size(), int32_t);
 		CPY(o.hap_dst, d.o_hap * (P / 3) * (P / 3), sym[p].hap_dst.data(), sym[p].hap_dst.size(), int32_t); CPY(o.hapf_dst, d.o_hapf * (P / 3), sym[p].hapf_dst.data(), sym[p].hapf_dst.size(), int32_t); CPY(o.hf_dst, d.o_hf, sym[p].hf_dst.data(), sym[p].hf_dst.size(), int32_t);
 		st.n_chol_blocks += d.nb + d.nnzoff; st.n_chol_items += (int64_t)sym[p].tgt.size();
 	}
@@ -589,7 +618,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	Batch &B = c->B; std::memset(&B, 0, sizeof(B)); B.n_prob = n; B.max_lds_doubles = 0;
 	char *di = c->d_in, *dw = c->d_wk;
 #define DI(field, T) B.field = (const T *)(di + o.field)
-	B.desc = (const ProbDesc *)(di + o.desc); DI(order, int); DI(sp_col_off, int); DI(sp_row, int); DI(sp_item_off, int); DI(sp_tgt, int); DI(hap_dst, int); DI(hapf_dst, int); DI(hf_dst, int); DI(edge0, double); DI(ulm0, double); DI(klm, double); DI(obs_z, double);
+	B.desc = (const ProbDesc *)(di + o.desc); DI(order, int); DI(sp_col_off, int); DI(sp_row, int); DI(sp_item_off, int); DI(sp_tgt, int); DI(sp_perm, int); DI(hap_dst, int); DI(hapf_dst, int); DI(hf_dst, int); DI(edge0, double); DI(ulm0, double); DI(klm, double); DI(obs_z, double);
 	DI(pair_path_off, int); DI(path_edge, int); DI(obs_pose, int); DI(obs_lm, int); DI(obs_valid, int); DI(bp_col, int); DI(bp_res, int); DI(bp_A, int); DI(bp_D, int); DI(bp_lm, int); DI(colp_off, int);
 	DI(bf_col, int); DI(bf_res, int); DI(bf_pose, int); DI(colf_off, int); DI(hap_i, int); DI(hap_j, int); DI(hap_term_off, int); DI(hap_t1, int); DI(hap_t2, int); DI(hf_i, int); DI(hf_j, int); DI(hf_term_off, int); DI(hf_t1, int); DI(hf_t2, int);
 	DI(hapf_i, int); DI(hapf_j, int); DI(hapf_term_off, int); DI(hapf_t1, int); DI(hapf_t2, int); DI(hap_diag, int); DI(hf_diag, int); DI(sch_term_off, int); DI(sch_b1, int); DI(sch_b2, int); DI(sch_lm, int); DI(sch_yw, int);
