@@ -71,28 +71,32 @@ struct DevParams {
 };
 
 // ------------------------------------------------------------------------------------------------ family traits
+// PD here is the DEVICE pose stride: SE2 poses are kept as [x y phi cos(phi) sin(phi)] so that composing / inverting poses (K1), the
+// residuals (K4) and the closed-form SE2 Jacobians (K2) need no trigonometric function at all; sincos is evaluated once per unknown edge
+// per LM update (and once per edge at upload, on the host).  The ABI layout stays [x y phi] (srba_hip.h); conversion happens in
+// srba_hip_upload_problems / srba_hip_download_state.  SE3: [t R] on both sides.
 template <int FAM> struct Tr;
-template <> struct Tr<SRBA_SE2_RELPOSE2D> { static constexpr int P = 3, L = 3, O = 3, PD = 3; static constexpr bool SE3 = false, REL = true; };
-template <> struct Tr<SRBA_SE2_RB2D>      { static constexpr int P = 3, L = 2, O = 2, PD = 3; static constexpr bool SE3 = false, REL = false; };
-template <> struct Tr<SRBA_SE2_CART2D>    { static constexpr int P = 3, L = 2, O = 2, PD = 3; static constexpr bool SE3 = false, REL = false; };
+template <> struct Tr<SRBA_SE2_RELPOSE2D> { static constexpr int P = 3, L = 3, O = 3, PD = 5; static constexpr bool SE3 = false, REL = true; };
+template <> struct Tr<SRBA_SE2_RB2D>      { static constexpr int P = 3, L = 2, O = 2, PD = 5; static constexpr bool SE3 = false, REL = false; };
+template <> struct Tr<SRBA_SE2_CART2D>    { static constexpr int P = 3, L = 2, O = 2, PD = 5; static constexpr bool SE3 = false, REL = false; };
 template <> struct Tr<SRBA_SE3_STEREO>    { static constexpr int P = 6, L = 3, O = 4, PD = 12; static constexpr bool SE3 = true, REL = false; };
 template <> struct Tr<SRBA_SE3_MONO>      { static constexpr int P = 6, L = 3, O = 2, PD = 12; static constexpr bool SE3 = true, REL = false; };
 template <> struct Tr<SRBA_SE3_CART3D>    { static constexpr int P = 6, L = 3, O = 3, PD = 12; static constexpr bool SE3 = true, REL = false; };
 
 // ------------------------------------------------------------------------------------------------ poses
-__device__ __forceinline__ double wrap_pi(double a) { // mrpt::math::wrapToPi
-	a += M_PI; const bool neg = a < 0; a = fmod(a, 2.0 * M_PI); if (neg) a += 2.0 * M_PI; return a - M_PI;
+__device__ __forceinline__ double wrap_pi(double a) { // mrpt::math::wrapToPi up to rounding (and the sign of an exact +-pi)
+	return a - (2.0 * M_PI) * rint(a * (0.5 / M_PI));
 }
-struct P2 { double x, y, phi; };
+struct P2 { double x, y, phi, c, s; };
 struct P3 { double t[3]; double R[9]; };
-__device__ __forceinline__ P2 ident2() { P2 r; r.x = 0; r.y = 0; r.phi = 0; return r; }
+__device__ __forceinline__ P2 ident2() { P2 r; r.x = 0; r.y = 0; r.phi = 0; r.c = 1; r.s = 0; return r; }
 __device__ __forceinline__ P3 ident3() { P3 r; r.t[0] = r.t[1] = r.t[2] = 0; r.R[0] = 1; r.R[1] = 0; r.R[2] = 0; r.R[3] = 0; r.R[4] = 1; r.R[5] = 0; r.R[6] = 0; r.R[7] = 0; r.R[8] = 1; return r; }
-__device__ __forceinline__ P2 ld2(const double *p) { P2 r; r.x = p[0]; r.y = p[1]; r.phi = p[2]; return r; }
-__device__ __forceinline__ void st2(double *p, const P2 &a) { p[0] = a.x; p[1] = a.y; p[2] = a.phi; }
+__device__ __forceinline__ P2 ld2(const double *p) { P2 r; r.x = p[0]; r.y = p[1]; r.phi = p[2]; r.c = p[3]; r.s = p[4]; return r; }
+__device__ __forceinline__ void st2(double *p, const P2 &a) { p[0] = a.x; p[1] = a.y; p[2] = a.phi; p[3] = a.c; p[4] = a.s; }
 __device__ __forceinline__ P3 ld3(const double *p) { P3 r; for (int i = 0; i < 3; i++) r.t[i] = p[i]; for (int i = 0; i < 9; i++) r.R[i] = p[3 + i]; return r; }
 __device__ __forceinline__ void st3(double *p, const P3 &a) { for (int i = 0; i < 3; i++) p[i] = a.t[i]; for (int i = 0; i < 9; i++) p[3 + i] = a.R[i]; }
-__device__ __forceinline__ P2 comp(const P2 &A, const P2 &B) { double s, c; sincos(A.phi, &s, &c); P2 r; r.x = A.x + B.x * c - B.y * s; r.y = A.y + B.x * s + B.y * c; r.phi = wrap_pi(A.phi + B.phi); return r; }
-__device__ __forceinline__ P2 inv(const P2 &A) { double s, c; sincos(A.phi, &s, &c); P2 r; r.x = -A.x * c - A.y * s; r.y = A.x * s - A.y * c; r.phi = -A.phi; return r; }
+__device__ __forceinline__ P2 comp(const P2 &A, const P2 &B) { P2 r; r.x = A.x + B.x * A.c - B.y * A.s; r.y = A.y + B.x * A.s + B.y * A.c; r.phi = wrap_pi(A.phi + B.phi); r.c = A.c * B.c - A.s * B.s; r.s = A.s * B.c + A.c * B.s; return r; }
+__device__ __forceinline__ P2 inv(const P2 &A) { P2 r; r.x = -A.x * A.c - A.y * A.s; r.y = A.x * A.s - A.y * A.c; r.phi = -A.phi; r.c = A.c; r.s = -A.s; return r; }
 __device__ __forceinline__ P3 comp(const P3 &A, const P3 &B) {
 	P3 r;
 #pragma unroll
@@ -125,7 +129,7 @@ __device__ __forceinline__ P3 exp_se3(const double *v) { // SE_traits<3>::pseudo
 }
 template <bool SE3> struct PoseOps;
 template <> struct PoseOps<false> { typedef P2 T; static __device__ __forceinline__ T ident() { return ident2(); } static __device__ __forceinline__ T ld(const double *p) { return ld2(p); } static __device__ __forceinline__ void st(double *p, const T &a) { st2(p, a); }
-	static __device__ __forceinline__ T expm(const double *v) { T r; r.x = v[0]; r.y = v[1]; r.phi = v[2]; return r; } };
+	static __device__ __forceinline__ T expm(const double *v) { T r; r.x = v[0]; r.y = v[1]; r.phi = v[2]; sincos(v[2], &r.s, &r.c); return r; } };
 template <> struct PoseOps<true> { typedef P3 T; static __device__ __forceinline__ T ident() { return ident3(); } static __device__ __forceinline__ T ld(const double *p) { return ld3(p); } static __device__ __forceinline__ void st(double *p, const T &a) { st3(p, a); }
 	static __device__ __forceinline__ T expm(const double *v) { return exp_se3(v); } };
 
@@ -354,10 +358,10 @@ struct Worker {
 		const double *z = B.obs_z + (long long)gi * O; const double *lm = lm_ptr(B.obs_lm[gi]);
 		double r[O];
 		if constexpr (FAM == SRBA_SE2_RELPOSE2D) { // r = P(z) (-) pose (sensors.h:780-784)
-			double s, c; sincos(bp.phi, &s, &c); const double dx = z[0] - bp.x, dy = z[1] - bp.y;
+			const double s = bp.s, c = bp.c, dx = z[0] - bp.x, dy = z[1] - bp.y;
 			r[0] = dx * c + dy * s; r[1] = -dx * s + dy * c; r[2] = wrap_pi(z[2] - bp.phi);
 		} else if constexpr (!T::SE3) {
-			double s, c; sincos(bp.phi, &s, &c); const double lx = bp.x + lm[0] * c - lm[1] * s, ly = bp.y + lm[0] * s + lm[1] * c;
+			const double s = bp.s, c = bp.c, lx = bp.x + lm[0] * c - lm[1] * s, ly = bp.y + lm[0] * s + lm[1] * c;
 			if constexpr (FAM == SRBA_SE2_RB2D) { r[0] = z[0] - hypot(lx, ly); r[1] = z[1] - atan2(ly, lx); } else { r[0] = z[0] - lx; r[1] = z[1] - ly; }
 		} else {
 			double l[3];
@@ -406,17 +410,18 @@ struct Worker {
 		if constexpr (!T::SE3) {
 			if (!normal) { // D' = p (+) D ; A' = A (+) (-)p (jacobians.h:565-587,684-711)
 				const P2 p = ld2(B.edge + (d.o_edge + B.bp_col[gb]) * PD);
-				D = comp(p, D); A = hasA ? comp(A, inv(p)) : inv(p); hasA = true;
+				D = comp(p, D);
+				if constexpr (!T::REL) { A = hasA ? comp(A, inv(p)) : inv(p); hasA = true; } // the relative-pose block depends on D' only
 			}
 			const double sg = normal ? 1.0 : -1.0;
 			if constexpr (T::REL) { // closed form of dh_dx*J0*J1*J2: depends on D only
-				double sd, cd; sincos(D.phi, &sd, &cd);
+				const double sd = D.s, cd = D.c;
 				Jl[0] = sg * cd; Jl[1] = sg * sd; Jl[2] = sg * (D.x * sd - D.y * cd);
 				Jl[3] = -sg * sd; Jl[4] = sg * cd; Jl[5] = sg * (D.x * cd + D.y * sd);
 				Jl[6] = 0; Jl[7] = 0; Jl[8] = sg;
 			} else {
-				const double pa = hasA ? A.phi : 0.0; const P2 AD = hasA ? comp(A, D) : D;
-				double sa, ca, sad, cad; sincos(pa, &sa, &ca); sincos(AD.phi, &sad, &cad);
+				const P2 AD = hasA ? comp(A, D) : D;
+				const double sa = hasA ? A.s : 0.0, ca = hasA ? A.c : 1.0, sad = AD.s, cad = AD.c;
 				double xl[2] = {AD.x + xi[0] * cad - xi[1] * sad, AD.y + xi[0] * sad + xi[1] * cad};
 				double H[O * L]; ok = dh_dx(H, xl);
 				if (ok) {
@@ -467,7 +472,7 @@ struct Worker {
 			const double *xi = B.ulm + (d.o_ulm + B.bf_col[gb]) * L;
 			double Jl[O * L]; bool ok;
 			if constexpr (!T::SE3) {
-				double s, c; sincos(bp.phi, &s, &c);
+				const double s = bp.s, c = bp.c;
 				double xl[2] = {bp.x + xi[0] * c - xi[1] * s, bp.y + xi[0] * s + xi[1] * c};
 				double H[O * L]; ok = dh_dx(H, xl);
 				if (ok) for (int i = 0; i < O; i++) { Jl[i * 2] = H[i * 2] * c + H[i * 2 + 1] * s; Jl[i * 2 + 1] = -H[i * 2] * s + H[i * 2 + 1] * c; }

@@ -324,7 +324,7 @@ template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_rollback(const B
 // =================================================================================================== host side
 namespace {
 
-struct FamDims { int P, L, O, PD; };
+struct FamDims { int P, L, O, PD; int PDX() const { return PD == 3 ? 5 : PD; } }; // PDX: device pose stride (SE2: [x y phi cos sin])
 const FamDims kDims[SRBA_NUM_FAMILIES] = {{3, 3, 3, 3}, {3, 2, 2, 3}, {3, 2, 2, 3}, {6, 3, 4, 12}, {6, 3, 2, 12}, {6, 3, 3, 12}};
 thread_local std::string g_last_error;
 
@@ -337,7 +337,7 @@ struct Arena { // layout builder: 256-byte aligned sub-allocations inside one bu
 
 } // namespace
 
-#define SRBA_NCLS 6
+#define SRBA_NCLS 20  /* 19 LDS size classes (6 KB ... 152 KB per wavefront) + one class for systems factored in HBM */
 // Symbolic block factorisation of one capsule's system (natural block order): the numeric kernel never discovers structure.
 struct Symbolic { std::vector<int32_t> col_off, row, item_off, tgt, perm, hap_dst, hapf_dst, hf_dst; bool aligned = true; };
 static void symbolic_factor(const srba_problem_capsule &k, const ProbDesc &d, int P, int L, bool full_system, Symbolic &out) {
@@ -422,7 +422,7 @@ struct srba_hip_ctx {
 	size_t off_edge = 0, off_ulm = 0, off_pose = 0, off_inf = 0, off_infv = 0, off_res = 0;
 	size_t off_dbg[10] = {0}; int64_t len_dbg[10] = {0};
 	size_t in_off_edge0 = 0, in_off_ulm0 = 0; long long tot_edge = 0, tot_ulm = 0;
-	size_t off_phase = 0; bool phase_timing = false;
+	size_t off_phase = 0; bool phase_timing = false; long long n_pose_total = 0;
 	void fail(const std::string &m) { error = m; g_last_error = m; }
 };
 
@@ -510,7 +510,7 @@ double srba_hip_last_kernel_ms(srba_hip_ctx *c) { return c ? c->last_ms : 0.0; }
 int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, int n) {
 	if (!c || !caps || n <= 0) { if (c) c->fail("upload: bad arguments"); return -1; }
 	HIPCHK(c, hipSetDevice(c->device));
-	const int P = c->dm.P, L = c->dm.L, O = c->dm.O, PD = c->dm.PD;
+	const int P = c->dm.P, L = c->dm.L, O = c->dm.O, PD = c->dm.PD, PDX = c->dm.PDX();
 	const bool schur_solver = c->params.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL;
 	c->desc.assign(n, ProbDesc()); srba_batch_stats &st = c->stats; std::memset(&st, 0, sizeof(st)); st.n_problems = n;
 	// ---- pass 1: descriptors and totals
@@ -534,10 +534,12 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 		t_spcol += d.nb + 1; t_sprow += d.nnzoff; t_spitem += (long long)sym[p].tgt.size();
 		const size_t n_ints = 2 * ((size_t)d.nb + 1) + (size_t)d.nnzoff + (size_t)d.n_items + (size_t)d.nb;
 		const size_t tri_n = 9 * (size_t)d.nb + 9 * (size_t)d.nnzoff + 3 * (size_t)d.nb + (n_ints + 1) / 2; // diag | off | rhs | symbolic ints
-		// LDS size classes (bytes per wavefront): 12 KB, 24 KB, 48 KB, 96 KB, 150 KB; larger systems are factored in HBM
+		// LDS footprint x residency time is what bounds the batch: capsules are grouped in fine size classes so that each launch
+		// reserves little more LDS per wavefront than its capsules need; systems above 152 KB are factored in an HBM workspace
 		const size_t bytes = tri_n * 8;
-		cls[p] = bytes <= 12 * 1024 ? 0 : bytes <= 24 * 1024 ? 1 : bytes <= 48 * 1024 ? 2 : bytes <= 96 * 1024 ? 3 : bytes <= 150 * 1024 ? 4 : 5;
-		d.dense_in_lds = cls[p] < 5 ? 1 : 0; cls_nbmax[cls[p]] = std::max(cls_nbmax[cls[p]], (int)tri_n);
+		static const int kClsKB[SRBA_NCLS - 1] = {6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64, 80, 96, 112, 128, 152};
+		cls[p] = SRBA_NCLS - 1; for (int q = 0; q < SRBA_NCLS - 1; q++) if (bytes <= (size_t)kClsKB[q] * 1024) { cls[p] = q; break; }
+		d.dense_in_lds = cls[p] < SRBA_NCLS - 1 ? 1 : 0; cls_nbmax[cls[p]] = std::max(cls_nbmax[cls[p]], (int)tri_n);
 		int nyw = 0; if (k.n_sch_terms > 0) for (int b = 0; b < k.n_hap; b++) if (k.hap_i[b] == k.hap_j[b]) nyw += k.sch_term_off[b + 1] - k.sch_term_off[b];
 		long long npath_needed = 0; for (int q = 0; q < k.n_pairs; q++) if (k.pair_needed[q]) { st.n_pairs_needed++; npath_needed += k.pair_path_off[q + 1] - k.pair_path_off[q]; }
 		st.n_path_needed += npath_needed;
@@ -552,7 +554,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 		hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hf_i, hf_j, hf_term_off, hf_t1, hf_t2, hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag, sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw,
 		lm_hapf_off, lm_hapf_idx, req_idx, pair_needed, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_perm, hap_dst, hapf_dst, hf_dst; } o;
 	o.desc = in.add(sizeof(ProbDesc) * n);
-	o.edge0 = in.add(8 * t_edge * PD); o.ulm0 = in.add(8 * t_ulm * L); o.klm = in.add(8 * t_klm * L); o.obs_z = in.add(8 * t_obs * O);
+	o.edge0 = in.add(8 * t_edge * PDX); o.ulm0 = in.add(8 * t_ulm * L); o.klm = in.add(8 * t_klm * L); o.obs_z = in.add(8 * t_obs * O);
 	o.pair_path_off = in.add(4 * (t_pair + n)); o.path_edge = in.add(4 * t_path); o.obs_pose = in.add(4 * t_obs); o.obs_lm = in.add(4 * t_obs); o.obs_valid = in.add(4 * t_obs);
 	o.bp_col = in.add(4 * t_bp); o.bp_res = in.add(4 * t_bp); o.bp_A = in.add(4 * t_bp); o.bp_D = in.add(4 * t_bp); o.bp_lm = in.add(4 * t_bp); o.colp_off = in.add(4 * (t_unk + n));
 	o.bf_col = in.add(4 * t_bf); o.bf_res = in.add(4 * t_bf); o.bf_pose = in.add(4 * t_bf); o.colf_off = in.add(4 * (t_ulm + n));
@@ -571,7 +573,9 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 #define CPY(dstoff, elem_off, src, count, T) do { if ((count) > 0) std::memcpy(h + (dstoff) + sizeof(T) * (size_t)(elem_off), (src), sizeof(T) * (size_t)(count)); } while (0)
 	for (int p = 0; p < n; p++) {
 		const srba_problem_capsule &k = caps[p]; const ProbDesc &d = c->desc[p];
-		CPY(o.edge0, d.o_edge * PD, k.edge_pose, (size_t)k.n_edges * PD, double); CPY(o.ulm0, d.o_ulm * L, k.ulm_pos, (size_t)d.nF * L, double); CPY(o.klm, d.o_klm * L, k.klm_pos, (size_t)d.n_klm * L, double); CPY(o.obs_z, d.o_obs * O, k.obs_z, (size_t)k.n_obs * O, double);
+		if (PDX == PD) { CPY(o.edge0, d.o_edge * PD, k.edge_pose, (size_t)k.n_edges * PD, double); }
+		else { double *e = (double *)(h + o.edge0) + d.o_edge * PDX; for (int q = 0; q < k.n_edges; q++) { const double *s3 = k.edge_pose + 3 * (size_t)q; e[5 * q] = s3[0]; e[5 * q + 1] = s3[1]; e[5 * q + 2] = s3[2]; e[5 * q + 3] = std::cos(s3[2]); e[5 * q + 4] = std::sin(s3[2]); } }
+		CPY(o.ulm0, d.o_ulm * L, k.ulm_pos, (size_t)d.nF * L, double); CPY(o.klm, d.o_klm * L, k.klm_pos, (size_t)d.n_klm * L, double); CPY(o.obs_z, d.o_obs * O, k.obs_z, (size_t)k.n_obs * O, double);
 		CPY(o.pair_path_off, d.o_ppoff, k.pair_path_off, k.n_pairs + 1, int32_t); CPY(o.path_edge, d.o_path, k.path_edge, k.n_path, int32_t);
 		CPY(o.obs_pose, d.o_obs, k.obs_pose, k.n_obs, int32_t); CPY(o.obs_lm, d.o_obs, k.obs_lm, k.n_obs, int32_t); CPY(o.obs_valid, d.o_obs, k.obs_valid, k.n_obs, int32_t);
 		CPY(o.bp_col, d.o_bp, k.bp_col, k.n_bp, int32_t); CPY(o.bp_res, d.o_bp, k.bp_res, k.n_bp, int32_t); CPY(o.bp_A, d.o_bp, k.bp_A, k.n_bp, int32_t); CPY(o.bp_D, d.o_bp, k.bp_D, k.n_bp, int32_t); CPY(o.bp_lm, d.o_bp, k.bp_lm, k.n_bp, int32_t);
@@ -604,9 +608,9 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	}
 	// ---- work arena layout
 	Arena wk; struct { size_t edge, ulm, pose, Jp, Jf, resid, resid2, HAp, HAp0, Hf, HApf, grad, delta, Hfinv, YW, old_edge, old_ulm, old_pose, dense, ulm_inf, valid, first_fail, hf_ok, ulm_inf_valid, results, lambda_io, chi2, notpd, phase_cycles; } w;
-	w.edge = wk.add(8 * t_edge * PD); w.ulm = wk.add(8 * t_ulm * L); w.pose = wk.add(8 * 2 * t_pair * PD); w.Jp = wk.add(8 * t_bp * O * P); w.Jf = wk.add(8 * t_bf * O * L);
+	w.edge = wk.add(8 * t_edge * PDX); w.ulm = wk.add(8 * t_ulm * L); w.pose = wk.add(8 * 2 * t_pair * PDX); w.Jp = wk.add(8 * t_bp * O * P); w.Jf = wk.add(8 * t_bf * O * L);
 	w.resid = wk.add(8 * t_obs * O); w.resid2 = wk.add(8 * t_obs * O); w.HAp = wk.add(8 * t_hap * P * P); w.HAp0 = wk.add(8 * t_hap * P * P); w.Hf = wk.add(8 * t_hf * L * L); w.HApf = wk.add(8 * t_hapf * P * L);
-	w.grad = wk.add(8 * t_scal); w.delta = wk.add(8 * t_scal); w.Hfinv = wk.add(8 * t_ulm * L * L); w.YW = wk.add(8 * t_yw * P * L); w.old_edge = wk.add(8 * t_unk * PD); w.old_ulm = wk.add(8 * t_ulm * L); w.old_pose = wk.add(8 * t_req * PD);
+	w.grad = wk.add(8 * t_scal); w.delta = wk.add(8 * t_scal); w.Hfinv = wk.add(8 * t_ulm * L * L); w.YW = wk.add(8 * t_yw * P * L); w.old_edge = wk.add(8 * t_unk * PDX); w.old_ulm = wk.add(8 * t_ulm * L); w.old_pose = wk.add(8 * t_req * PDX);
 	w.dense = wk.add(8 * t_dense); w.ulm_inf = wk.add(8 * t_ulm * L * L); w.valid = wk.add(4 * t_valid); w.first_fail = wk.add(4 * t_valid); w.hf_ok = wk.add(4 * t_ulm); w.ulm_inf_valid = wk.add(t_ulm);
 	w.results = wk.add(sizeof(srba_lm_result) * n); w.lambda_io = wk.add(8 * n); w.chi2 = wk.add(8 * n); w.notpd = wk.add(4 * n); w.phase_cycles = wk.add(8 * 16 * (size_t)n);
 	wk.add(0);
@@ -633,6 +637,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	c->off_edge = w.edge; c->off_ulm = w.ulm; c->off_pose = w.pose; c->off_inf = w.ulm_inf; c->off_infv = w.ulm_inf_valid; c->off_res = w.results;
 	const size_t dbg_off[10] = {w.resid, w.Jp, w.Jf, w.HAp, w.Hf, w.HApf, w.grad, w.delta, w.valid, w.pose};
 	const int64_t dbg_len[10] = {t_obs * O, t_bp * O * P, t_bf * O * L, t_hap * P * P, t_hf * L * L, t_hapf * P * L, t_scal, t_scal, t_valid, 2 * t_pair * PD};
+	c->n_pose_total = 2 * t_pair;
 	for (int i = 0; i < 10; i++) { c->off_dbg[i] = dbg_off[i]; c->len_dbg[i] = dbg_len[i]; }
 	c->n_prob = n; st.device_bytes = (int64_t)(in.size + wk.size);
 	if (srba_hip_reset_state(c) != 0) return -1;
@@ -643,7 +648,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 int srba_hip_reset_state(srba_hip_ctx *c) {
 	if (!c || !c->n_prob) return -1;
 	HIPCHK(c, hipSetDevice(c->device));
-	HIPCHK(c, hipMemcpyAsync(c->d_wk + c->off_edge, c->d_in + c->in_off_edge0, 8 * (size_t)c->tot_edge * c->dm.PD, hipMemcpyDeviceToDevice, c->stream));
+	HIPCHK(c, hipMemcpyAsync(c->d_wk + c->off_edge, c->d_in + c->in_off_edge0, 8 * (size_t)c->tot_edge * c->dm.PDX(), hipMemcpyDeviceToDevice, c->stream));
 	if (c->tot_ulm) HIPCHK(c, hipMemcpyAsync(c->d_wk + c->off_ulm, c->d_in + c->in_off_ulm0, 8 * (size_t)c->tot_ulm * c->dm.L, hipMemcpyDeviceToDevice, c->stream));
 	return 0;
 }
@@ -750,8 +755,8 @@ int srba_hip_rollback(srba_hip_ctx *c) { if (!c || !c->n_prob) return -1; HIPCHK
 int srba_hip_download_state(srba_hip_ctx *c, srba_problem_capsule *caps, int n) {
 	if (!c || !caps || n != c->n_prob) { if (c) c->fail("download_state: capsule count differs from the uploaded batch"); return -1; }
 	HIPCHK(c, hipSetDevice(c->device));
-	const int L = c->dm.L, PD = c->dm.PD;
-	std::vector<double> edge((size_t)c->tot_edge * PD), ulm((size_t)c->tot_ulm * L), inf((size_t)c->tot_ulm * L * L), pose((size_t)2 * c->stats.n_pairs * PD); std::vector<uint8_t> infv((size_t)c->tot_ulm);
+	const int L = c->dm.L, PD = c->dm.PD, PDX = c->dm.PDX();
+	std::vector<double> edge((size_t)c->tot_edge * PDX), ulm((size_t)c->tot_ulm * L), inf((size_t)c->tot_ulm * L * L), pose((size_t)2 * c->stats.n_pairs * PDX); std::vector<uint8_t> infv((size_t)c->tot_ulm);
 	HIPCHK(c, hipMemcpyAsync(edge.data(), c->d_wk + c->off_edge, 8 * edge.size(), hipMemcpyDeviceToHost, c->stream));
 	if (!ulm.empty()) { HIPCHK(c, hipMemcpyAsync(ulm.data(), c->d_wk + c->off_ulm, 8 * ulm.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipMemcpyAsync(inf.data(), c->d_wk + c->off_inf, 8 * inf.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipMemcpyAsync(infv.data(), c->d_wk + c->off_infv, infv.size(), hipMemcpyDeviceToHost, c->stream)); }
 	if (!pose.empty()) HIPCHK(c, hipMemcpyAsync(pose.data(), c->d_wk + c->off_pose, 8 * pose.size(), hipMemcpyDeviceToHost, c->stream));
@@ -759,9 +764,9 @@ int srba_hip_download_state(srba_hip_ctx *c, srba_problem_capsule *caps, int n) 
 	for (int p = 0; p < n; p++) {
 		const ProbDesc &d = c->desc[p]; srba_problem_capsule &k = caps[p];
 		if (k.n_unk_edges != d.nK || k.n_unk_lms != d.nF || k.n_pairs != d.n_pairs) { c->fail("download_state: capsule layout differs from the uploaded batch"); return -1; }
-		std::memcpy(k.edge_pose, &edge[(size_t)d.o_edge * PD], 8 * (size_t)d.nK * PD);
+		for (int q = 0; q < d.nK; q++) std::memcpy(k.edge_pose + (size_t)q * PD, &edge[((size_t)d.o_edge + q) * PDX], 8 * (size_t)PD); // SE2: drop the cached cos/sin
 		if (d.nF) std::memcpy(k.ulm_pos, &ulm[(size_t)d.o_ulm * L], 8 * (size_t)d.nF * L);
-		if (k.pose && d.n_pairs) std::memcpy(k.pose, &pose[(size_t)d.o_pair * 2 * PD], 8 * (size_t)d.n_pairs * 2 * PD);
+		if (k.pose) for (long long q = 0; q < 2LL * d.n_pairs; q++) std::memcpy(k.pose + (size_t)q * PD, &pose[((size_t)d.o_pair * 2 + q) * PDX], 8 * (size_t)PD);
 		if (k.ulm_inf && d.nF) std::memcpy(k.ulm_inf, &inf[(size_t)d.o_ulm * L * L], 8 * (size_t)d.nF * L * L);
 		if (k.ulm_inf_valid && d.nF) std::memcpy(k.ulm_inf_valid, &infv[(size_t)d.o_ulm], (size_t)d.nF);
 	}
@@ -777,6 +782,12 @@ int srba_hip_debug_read(srba_hip_ctx *c, int what, double *out, int64_t n_double
 	}
 	if (!c || what < 0 || what >= 10 || n_doubles < c->len_dbg[what]) return -1;
 	HIPCHK(c, hipSetDevice(c->device));
+	if (what == 9 && c->dm.PDX() != c->dm.PD) { // ST poses: strip the cached cos/sin of the device layout
+		const int PD = c->dm.PD, PDX = c->dm.PDX(); std::vector<double> v((size_t)c->n_pose_total * PDX);
+		HIPCHK(c, hipMemcpyAsync(v.data(), c->d_wk + c->off_dbg[9], 8 * v.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+		for (long long q = 0; q < c->n_pose_total; q++) for (int k = 0; k < PD; k++) out[q * PD + k] = v[(size_t)q * PDX + k];
+		return 0;
+	}
 	if (what == 8) { std::vector<int> v((size_t)c->len_dbg[8]); HIPCHK(c, hipMemcpyAsync(v.data(), c->d_wk + c->off_dbg[8], 4 * v.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); for (size_t i = 0; i < v.size(); i++) out[i] = v[i]; return 0; }
 	HIPCHK(c, hipMemcpyAsync(out, c->d_wk + c->off_dbg[what], 8 * (size_t)c->len_dbg[what], hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream)); return 0;
