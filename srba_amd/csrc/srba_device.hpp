@@ -34,6 +34,7 @@ struct ProbDesc {
 	int n_edges, nK, nF, n_klm, n_pairs, n_obs, n_valid, n_bp, n_bf, n_hap, n_hf, n_hapf, n_sch, n_req, n_sys, n_scal, nb, nnzoff;
 	// element offsets into the batch-wide arrays
 	long long o_edge, o_unk, o_ulm, o_klm, o_pair, o_ppoff, o_path, o_obs, o_valid, o_bp, o_colp, o_bf, o_colf;
+	int n_need; // pairs whose pose is re-evaluated inside the LM loop (pair_needed != 0)
 	long long o_hap, o_hapoff, o_hapt, o_hf, o_hfoff, o_hft, o_hapf, o_hapfoff, o_hapft, o_sch, o_lmoff, o_req, o_scal, o_yw, o_dense, o_spcol, o_sprow, o_spitem, o_spperm;
 	int n_items, aligned; // block updates per factorisation; 1 if every Hessian block maps onto whole 3x3 blocks (always, except L==2 with the no-Schur solver)
 	int dense_in_lds, pad;
@@ -48,14 +49,15 @@ struct Batch {
 	const int *bp_col, *bp_res, *bp_A, *bp_D, *bp_lm, *colp_off, *bf_col, *bf_res, *bf_pose, *colf_off;
 	const int *hap_i, *hap_j, *hap_term_off, *hap_t1, *hap_t2, *hf_i, *hf_j, *hf_term_off, *hf_t1, *hf_t2;
 	const int *hapf_i, *hapf_j, *hapf_term_off, *hapf_t1, *hapf_t2, *hap_diag, *hf_diag;
-	const int *sch_term_off, *sch_b1, *sch_b2, *sch_lm, *sch_yw, *lm_hapf_off, *lm_hapf_idx, *req_idx;
+	const int *sch_term_off, *sch_b1, *sch_b2, *sch_lm, *sch_yw, *lm_hapf_off, *lm_hapf_idx, *req_idx, *need_idx;
 	const unsigned char *pair_needed, *bp_normal;
-	const int *sp_col_off, *sp_row, *sp_item_off, *sp_tgt, *sp_perm; // symbolic factorisation of every capsule's system
+	const int *sp_col_off, *sp_row, *sp_item_off, *sp_tgt, *sp_ab, *sp_rptr, *sp_rcol, *sp_rblk, *sp_perm; // symbolic factorisation of every capsule's system
 	const int *hap_dst, *hapf_dst, *hf_dst; // destination 3x3 block of every aligned sub-block of the Hessian blocks (see symbolic_factor)
 	// state + workspace
 	double *edge, *ulm, *pose, *Jp, *Jf, *resid, *resid2, *HAp, *HAp0, *Hf, *HApf, *grad, *delta, *Hfinv, *YW;
 	double *old_edge, *old_ulm, *old_pose, *dense, *ulm_inf;
 	int *valid, *first_fail, *hf_ok;
+	unsigned char *bp_ok, *bf_ok; // per Jacobian block: its observation row is valid (set by phase_jacobians, read by phase_hessian)
 	unsigned char *ulm_inf_valid;
 	srba_lm_result *results;
 	double *lambda_io, *chi2; int *notpd;
@@ -134,15 +136,26 @@ template <> struct PoseOps<true> { typedef P3 T; static __device__ __forceinline
 	static __device__ __forceinline__ T expm(const double *v) { return exp_se3(v); } };
 
 // ------------------------------------------------------------------------------------------------ block reductions (deterministic)
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-	return v;
+// DPP cross-lane moves (no LDS traffic, ~8 cycles): row_shr within rows of 16 lanes, then row_bcast15 / row_bcast31 across rows; the
+// total lands in lane 63 and is broadcast with v_readlane. Fixed order -> deterministic.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_shift0(double v) { // lanes without a source read 0.0
+	int lo = __double2loint(v), hi = __double2hiint(v);
+	lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+	return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-	return v;
+__device__ __forceinline__ double readlane63(double v) {
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+	return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+	v += dpp_shift0<0x111, 0xf>(v); v += dpp_shift0<0x112, 0xf>(v); v += dpp_shift0<0x114, 0xf>(v); v += dpp_shift0<0x118, 0xf>(v); // row_shr:1,2,4,8
+	v += dpp_shift0<0x142, 0xa>(v); v += dpp_shift0<0x143, 0xc>(v); // row_bcast:15 (rows 1,3), row_bcast:31 (rows 2,3)
+	return readlane63(v);
+}
+__device__ __forceinline__ double wave_max(double v) { // operands are >= 0 here (|g|, Hessian diagonals): 0-fill is neutral
+	v = fmax(v, dpp_shift0<0x111, 0xf>(v)); v = fmax(v, dpp_shift0<0x112, 0xf>(v)); v = fmax(v, dpp_shift0<0x114, 0xf>(v)); v = fmax(v, dpp_shift0<0x118, 0xf>(v));
+	{ const double t = dpp_shift0<0x142, 0xa>(v); v = fmax(v, t); } { const double t = dpp_shift0<0x143, 0xc>(v); v = fmax(v, t); }
+	return readlane63(v);
 }
 // One wavefront per capsule: "block" reductions are wave reductions; every lane gets the same result.
 __device__ __forceinline__ double block_sum(double v, double *) { return wave_sum(v); }
@@ -194,12 +207,25 @@ template <int N> __device__ __forceinline__ bool fullpiv_inverse(const double *A
 //             blocks they need and subtract L_ak L_bk^t from their precomputed target block; then the panel blocks are overwritten
 //             by L_ak and the right-hand side is eliminated (forward substitution fused).  Two wave barriers per step.
 // "Not positive definite" == a scalar pivot <= 0 (Eigen LLT / cs_chol criterion), decided identically by all lanes.
-struct SparseSys { // per-capsule symbolic structure (global memory, read-only) + numeric storage (LDS or HBM)
+struct SparseSys { // per-capsule symbolic structure (LDS copy, or global memory for the HBM class) + numeric storage (LDS or HBM)
 	int nb, nnzoff;
-	const int *col_off, *row, *item_off, *tgt; // col_off[nb+1], row[nnzoff], item_off[nb+1], tgt[n_items]: >=0 offdiag block index, <0: -(1+diag block)
-	const int *perm;                           // perm[original 3-row block] = position in the fill-reducing elimination order
+	const int *col_off, *row;  // col_off[nb+1], row[nnzoff] (rows ascending inside a column)
+	const int *item;           // update items of all columns, column after column (cn(cn+1)/2 each, a>=b row positions inside the column):
+	                           //   LDS copy: one packed word  u<<18 | a<<9 | b  (u = unified block index: diag k -> k, off-diag i -> nb+i)
+	                           //   HBM class: item = target (>=0 off-diag index, <0: -(1+diag)), item_ab = a<<16 | b
+	const int *item_ab;
+	const int *rptr, *rent;    // row view for the backward substitution: entries of block-row a = rent[rptr[a]..rptr[a+1]) = col<<14 | off-diag index (LDS), or col / rent_blk (HBM class)
+	const int *rent_blk;
+	const int *perm;           // perm[original 3-row block] = position in the fill-reducing elimination order
 	double *diag, *off, *rhs;
 };
+// Cross-lane hand-off inside the solver. LDS instructions of one wavefront execute in issue order, so a ds_write followed by a ds_read of
+// another lane's data needs no s_waitcnt -- only the compiler must keep the program order (wavefront-scope fence = no instructions).
+// The HBM-class path hands data over through global memory and keeps the full barrier (s_waitcnt vmcnt(0)).
+template <bool DLDS> __device__ __forceinline__ void solver_sync() {
+	if constexpr (DLDS) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+	else __syncthreads();
+}
 struct Chol3 { double l10, l20, l21, r0, r1, r2, l00, l11, l22; };
 __device__ __forceinline__ bool chol3(const double *D, Chol3 &c) {
 	const double a00 = D[0], a10 = D[3], a11 = D[4], a20 = D[6], a21 = D[7], a22 = D[8];
@@ -220,34 +246,31 @@ __device__ __forceinline__ void panel3(const double *Ab, const Chol3 &c, double 
 	}
 }
 // Factor in place and overwrite rhs with y = L^-1 rhs. Returns false (uniformly) if not positive definite.
-__device__ __forceinline__ bool sp_factor_fsub(const SparseSys &S) {
+//   step k : every lane refactors the 3x3 diagonal block (no broadcast); update items (a>=b) of column k recompute the two panel blocks
+//            they need and subtract L_ak L_bk^t from their precomputed target block; then the panel blocks are overwritten by L_ak and
+//            the right-hand side is eliminated (forward substitution fused).
+template <bool DLDS> __device__ __forceinline__ bool sp_factor_fsub(const SparseSys &S) {
 	const int lane = threadIdx.x;
+	int cb = S.col_off[0], ib = 0;
 	for (int k = 0; k < S.nb; k++) {
+		const int ce = S.col_off[k + 1], cn = ce - cb, nitems = cn * (cn + 1) / 2;
 		double *D = S.diag + 9 * k;
 		Chol3 c;
 		if (!chol3(D, c)) return false;
 		const double y0 = S.rhs[3 * k] * c.r0, y1 = (S.rhs[3 * k + 1] - c.l10 * y0) * c.r1, y2 = (S.rhs[3 * k + 2] - c.l20 * y0 - c.l21 * y1) * c.r2;
-		const int cb = S.col_off[k], cn = S.col_off[k + 1] - cb;
-		const int ib = S.item_off[k], nitems = cn * (cn + 1) / 2;
 		for (int t = lane; t < nitems; t += SRBA_WG) { // trailing update: target -= L_ak L_bk^t
-			int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-			while (a * (a + 1) / 2 > t) a--;
-			while ((a + 1) * (a + 2) / 2 <= t) a++;
-			const int b = t - a * (a + 1) / 2;
+			int a, b; double *T;
+			if constexpr (DLDS) { const unsigned w = (unsigned)S.item[ib + t]; a = (w >> 9) & 511; b = w & 511; T = S.diag + 9 * (w >> 18); }
+			else { const int tg = S.item[ib + t], ab = S.item_ab[ib + t]; a = ab >> 16; b = ab & 0xffff; T = tg >= 0 ? S.off + 9 * tg : S.diag + 9 * (-1 - tg); }
 			double La[9], Lb[9];
 			panel3(S.off + 9 * (cb + a), c, La);
-			if (a == b) {
-#pragma unroll
-				for (int q = 0; q < 9; q++) Lb[q] = La[q];
-			} else panel3(S.off + 9 * (cb + b), c, Lb);
-			const int tg = S.tgt[ib + t];
-			double *T = tg >= 0 ? S.off + 9 * tg : S.diag + 9 * (-1 - tg);
+			panel3(S.off + 9 * (cb + b), c, Lb);
 #pragma unroll
 			for (int rr = 0; rr < 3; rr++)
 #pragma unroll
 				for (int q = 0; q < 3; q++) T[rr * 3 + q] -= La[rr * 3] * Lb[q * 3] + La[rr * 3 + 1] * Lb[q * 3 + 1] + La[rr * 3 + 2] * Lb[q * 3 + 2];
 		}
-		__syncthreads();
+		solver_sync<DLDS>();
 		for (int a = lane; a < cn; a += SRBA_WG) { // panel: A_ak -> L_ak ; rhs_a -= L_ak y_k
 			double *Ab = S.off + 9 * (cb + a); double Lp[9];
 			panel3(Ab, c, Lp);
@@ -261,26 +284,29 @@ __device__ __forceinline__ bool sp_factor_fsub(const SparseSys &S) {
 			D[0] = c.l00; D[3] = c.l10; D[4] = c.l11; D[6] = c.l20; D[7] = c.l21; D[8] = c.l22; D[1] = c.r0; D[2] = c.r1; D[5] = c.r2;
 			S.rhs[3 * k] = y0; S.rhs[3 * k + 1] = y1; S.rhs[3 * k + 2] = y2;
 		}
-		__syncthreads();
+		solver_sync<DLDS>();
+		cb = ce; ib += nitems;
 	}
 	return true;
 }
-// Solve L^t x = y in place (rhs: y -> x). Every lane gathers redundantly over the (short) column: no cross-lane traffic.
-__device__ __forceinline__ void sp_bsub(const SparseSys &S) {
+// Solve L^t x = y in place (rhs: y -> x), row-oriented: once x_a is known (every lane computes it, no broadcast) the lanes push
+// y_k -= L_ak^t x_a into the earlier rows k that have a block in block-row a. No reduction, one hand-off per step.
+template <bool DLDS> __device__ __forceinline__ void sp_bsub(const SparseSys &S) {
 	const int lane = threadIdx.x;
-	for (int k = S.nb - 1; k >= 0; k--) {
-		const double *D = S.diag + 9 * k;
-		double s0 = S.rhs[3 * k], s1 = S.rhs[3 * k + 1], s2 = S.rhs[3 * k + 2];
-		const int cb = S.col_off[k], ce = S.col_off[k + 1];
-		for (int p = cb; p < ce; p++) { // y_k -= L_ik^t x_i
-			const double *Lb = S.off + 9 * p; const int ri = S.row[p];
-			const double x0 = S.rhs[3 * ri], x1 = S.rhs[3 * ri + 1], x2 = S.rhs[3 * ri + 2];
-			s0 -= Lb[0] * x0 + Lb[3] * x1 + Lb[6] * x2; s1 -= Lb[1] * x0 + Lb[4] * x1 + Lb[7] * x2; s2 -= Lb[2] * x0 + Lb[5] * x1 + Lb[8] * x2;
+	int re = S.rptr[S.nb];
+	for (int a = S.nb - 1; a >= 0; a--) {
+		const int rb = S.rptr[a];
+		const double *D = S.diag + 9 * a;
+		const double x2 = S.rhs[3 * a + 2] * D[5], x1 = (S.rhs[3 * a + 1] - D[7] * x2) * D[2], x0 = (S.rhs[3 * a] - D[3] * x1 - D[6] * x2) * D[1];
+		for (int j = rb + lane; j < re; j += SRBA_WG) {
+			int kcol, blk;
+			if constexpr (DLDS) { const unsigned w = (unsigned)S.rent[j]; kcol = w >> 14; blk = w & 0x3fff; } else { kcol = S.rent[j]; blk = S.rent_blk[j]; }
+			const double *Lb = S.off + 9 * blk; double *y = S.rhs + 3 * kcol;
+			y[0] -= Lb[0] * x0 + Lb[3] * x1 + Lb[6] * x2; y[1] -= Lb[1] * x0 + Lb[4] * x1 + Lb[7] * x2; y[2] -= Lb[2] * x0 + Lb[5] * x1 + Lb[8] * x2;
 		}
-		const double x2 = s2 * D[5], x1 = (s1 - D[7] * x2) * D[2], x0 = (s0 - D[3] * x1 - D[6] * x2) * D[1];
-		__syncthreads();
-		if (lane == 0) { S.rhs[3 * k] = x0; S.rhs[3 * k + 1] = x1; S.rhs[3 * k + 2] = x2; }
-		__syncthreads();
+		if (lane == SRBA_WG - 1) { S.rhs[3 * a] = x0; S.rhs[3 * a + 1] = x1; S.rhs[3 * a + 2] = x2; }
+		solver_sync<DLDS>();
+		re = rb;
 	}
 }
 // location of scalar element (r,c), r>=c (block-permutation already applied); returns nullptr if the block is structurally absent
@@ -297,22 +323,34 @@ template <int FAM>
 struct Worker {
 	typedef Tr<FAM> T; typedef PoseOps<T::SE3> PO; typedef typename PO::T pose_t;
 	static constexpr int P = T::P, L = T::L, O = T::O, PD = T::PD;
-	const Batch &B; const ProbDesc &d; const DevParams &prm; const int tid;
+	const Batch &B; const ProbDesc &d; const DevParams &prm; int tid;
+	// Re-materialise the lane id at the head of every phase: it stops the compiler from hoisting the per-lane address arithmetic of ALL
+	// phases out of the LM loop (which costs >100 VGPRs of loop-invariant addresses and halves the occupancy).
+	__device__ __forceinline__ void fresh() { int t = threadIdx.x; asm volatile("" : "+v"(t)); tid = t; }
 	__device__ Worker(const Batch &B_, const ProbDesc &d_, const DevParams &p_) : B(B_), d(d_), prm(p_), tid(threadIdx.x) {}
 
 	__device__ __forceinline__ pose_t pose_at(int idx) const { return idx >= 0 ? PO::ld(B.pose + (d.o_pair * 2 + idx) * PD) : PO::ident(); }
 	__device__ __forceinline__ const double *lm_ptr(int ref) const { return ref >= 0 ? B.ulm + (d.o_ulm + ref) * L : B.klm + (d.o_klm + (-1 - ref)) * L; }
 
 	// ---- K1
-	__device__ void phase_spantree(bool only_needed) {
-		for (int p = tid; p < d.n_pairs; p += SRBA_WG) {
-			if (only_needed && !B.pair_needed[d.o_pair + p]) continue;
+	__device__ void phase_spantree(bool only_needed) { fresh();
+		constexpr int U = T::SE3 ? 2 : 4; // path edges fetched together (their loads do not depend on the running composition)
+		const int cnt = only_needed ? d.n_need : d.n_pairs;
+		for (int q = tid; q < cnt; q += SRBA_WG) {
+			const int p = only_needed ? B.need_idx[d.o_pair + q] : q;
 			const int b = B.pair_path_off[d.o_ppoff + p], e = B.pair_path_off[d.o_ppoff + p + 1];
+			int pe[U]; pose_t ed[U];
+#pragma unroll
+			for (int u = 0; u < U; u++) pe[u] = (b + u < e) ? B.path_edge[d.o_path + b + u] : -1;
+#pragma unroll
+			for (int u = 0; u < U; u++) if (pe[u] >= 0) ed[u] = PO::ld(B.edge + (d.o_edge + (pe[u] >> 1)) * PD);
 			pose_t acc = PO::ident();
-			for (int k = b; k < e; k++) {
-				const int pe = B.path_edge[d.o_path + k];
-				const pose_t ed = PO::ld(B.edge + (d.o_edge + (pe >> 1)) * PD);
-				acc = (pe & 1) ? comp(acc, inv(ed)) : comp(acc, ed);
+#pragma unroll
+			for (int u = 0; u < U; u++) if (pe[u] >= 0) acc = (pe[u] & 1) ? comp(acc, inv(ed[u])) : comp(acc, ed[u]);
+			for (int k = b + U; k < e; k++) {
+				const int pk = B.path_edge[d.o_path + k];
+				const pose_t ek = PO::ld(B.edge + (d.o_edge + (pk >> 1)) * PD);
+				acc = (pk & 1) ? comp(acc, inv(ek)) : comp(acc, ek);
 			}
 			PO::st(B.pose + (d.o_pair + p) * 2 * PD, acc);
 			PO::st(B.pose + ((d.o_pair + p) * 2 + 1) * PD, inv(acc));
@@ -352,11 +390,10 @@ struct Worker {
 	}
 
 	// ---- K4 : one residual row
-	__device__ __forceinline__ double residual_row(int i, double *out) const {
+	__device__ __forceinline__ double residual_row(int i, double *r) const { // r[O] <- (robustified) residual of row i ; returns its chi2 term
 		const int gi = d.o_obs + i;
 		const pose_t bp = pose_at(B.obs_pose[gi]);
 		const double *z = B.obs_z + (long long)gi * O; const double *lm = lm_ptr(B.obs_lm[gi]);
-		double r[O];
 		if constexpr (FAM == SRBA_SE2_RELPOSE2D) { // r = P(z) (-) pose (sensors.h:780-784)
 			const double s = bp.s, c = bp.c, dx = z[0] - bp.x, dy = z[1] - bp.y;
 			r[0] = dx * c + dy * s; r[1] = -dx * s + dy * c; r[2] = wrap_pi(z[2] - bp.phi);
@@ -388,13 +425,21 @@ struct Worker {
 			for (int k = 0; k < O; k++) r[k] *= w;
 			contrib = (w * w) * sum2;
 		}
-#pragma unroll
-		for (int k = 0; k < O; k++) out[(long long)gi * O + k] = r[k];
 		return contrib;
 	}
-	__device__ double phase_residuals(double *out, double *red) {
+	__device__ double phase_residuals(double *out, double *red) { fresh();
 		double acc = 0;
-		for (int i = tid; i < d.n_obs; i += SRBA_WG) acc += residual_row(i, out);
+		for (int i = tid; i < d.n_obs; i += 2 * SRBA_WG) { // two rows per lane and pass: both rows' loads are issued before either row's stores
+			double r0[O], r1[O]; const int j = i + SRBA_WG; const bool two = j < d.n_obs;
+			const double c0 = residual_row(i, r0); double c1 = 0; if (two) c1 = residual_row(j, r1);
+#pragma unroll
+			for (int k = 0; k < O; k++) out[(long long)(d.o_obs + i) * O + k] = r0[k];
+			if (two) {
+#pragma unroll
+				for (int k = 0; k < O; k++) out[(long long)(d.o_obs + j) * O + k] = r1[k];
+			}
+			acc += c0; if (two) acc += c1;
+		}
 		return block_sum(acc, red);
 	}
 
@@ -487,7 +532,7 @@ struct Worker {
 		}
 	}
 	// Jacobians of all blocks + validity semantics of jacobians.h:215-216,321-327 (see DESIGN.md "invalid rows")
-	__device__ void phase_jacobians() {
+	__device__ void phase_jacobians() { fresh();
 		for (int i = tid; i < d.n_valid; i += SRBA_WG) { B.valid[d.o_valid + i] = 1; B.first_fail[d.o_valid + i] = 0x7fffffff; }
 		__syncthreads();
 		for (int b = tid; b < d.n_bp; b += SRBA_WG) jac_dh_dp(b);
@@ -495,42 +540,64 @@ struct Worker {
 		__syncthreads();
 		for (int i = tid; i < d.n_valid; i += SRBA_WG) if (B.first_fail[d.o_valid + i] != 0x7fffffff) B.valid[d.o_valid + i] = 0;
 		// the first failing block of a row (in sweep order) is zeroed; later ones keep stale values
-		for (int b = tid; b < d.n_bp; b += SRBA_WG) { const int vs = B.obs_valid[d.o_obs + B.bp_res[d.o_bp + b]]; if (B.first_fail[d.o_valid + vs] == b) { double *J = B.Jp + (long long)(d.o_bp + b) * O * P; for (int k = 0; k < O * P; k++) J[k] = 0; } }
-		for (int b = tid; b < d.n_bf; b += SRBA_WG) { const int vs = B.obs_valid[d.o_obs + B.bf_res[d.o_bf + b]]; if (B.first_fail[d.o_valid + vs] == d.n_bp + b) { double *J = B.Jf + (long long)(d.o_bf + b) * O * L; for (int k = 0; k < O * L; k++) J[k] = 0; } }
+		for (int b = tid; b < d.n_bp; b += SRBA_WG) {
+			const int ff = B.first_fail[d.o_valid + B.obs_valid[d.o_obs + B.bp_res[d.o_bp + b]]]; B.bp_ok[d.o_bp + b] = (ff == 0x7fffffff);
+			if (ff == b) { double *J = B.Jp + (long long)(d.o_bp + b) * O * P; for (int k = 0; k < O * P; k++) J[k] = 0; }
+		}
+		for (int b = tid; b < d.n_bf; b += SRBA_WG) {
+			const int ff = B.first_fail[d.o_valid + B.obs_valid[d.o_obs + B.bf_res[d.o_bf + b]]]; B.bf_ok[d.o_bf + b] = (ff == 0x7fffffff);
+			if (ff == d.n_bp + b) { double *J = B.Jf + (long long)(d.o_bf + b) * O * L; for (int k = 0; k < O * L; k++) J[k] = 0; }
+		}
 		__syncthreads();
 	}
 
 	// ---- K6: H_ij = sum J1^t Lambda J2
 	template <int M1, int M2>
-	__device__ __forceinline__ int hess_block(double *Hout, const int *t1, const int *t2, int tb, int te, const double *J1, const double *J2, const int *res1, const int *res2) {
+	__device__ __forceinline__ void hess_term(double *H, const double *A, const double *Bm) const {
+		if (prm.noise == SRBA_NOISE_CONSTANT_MATRIX) {
+			for (int i = 0; i < M1; i++) {
+				double jl[O];
+				for (int j = 0; j < O; j++) { double s = 0; for (int k = 0; k < O; k++) s += A[k * M1 + i] * prm.lambda[k * O + j]; jl[j] = s; }
+				for (int j = 0; j < M2; j++) { double s = 0; for (int k = 0; k < O; k++) s += jl[k] * Bm[k * M2 + j]; H[i * M2 + j] += s; }
+			}
+		} else {
+			for (int i = 0; i < M1; i++) for (int j = 0; j < M2; j++) { double s = 0; for (int k = 0; k < O; k++) s += A[k * M1 + i] * Bm[k * M2 + j]; H[i * M2 + j] += s; }
+		}
+	}
+	template <int M1, int M2>
+	__device__ __forceinline__ int hess_block(double *Hout, const int *t1, const int *t2, int tb, int te, const double *J1, const double *J2, const unsigned char *ok1, const unsigned char *ok2) {
 		double H[M1 * M2];
 #pragma unroll
 		for (int k = 0; k < M1 * M2; k++) H[k] = 0;
 		int ninv = 0;
-		for (int t = tb; t < te; t++) {
+		constexpr bool PAIR = (O * (M1 + M2) <= 24); // two terms in flight when their Jacobian blocks fit the register budget
+		int t = tb;
+		if constexpr (PAIR) {
+			for (; t + 1 < te; t += 2) { // the loads of both terms are independent of the accumulator: issue them together (same summation order)
+				const int a1 = t1[t], a2 = t2[t], c1 = t1[t + 1], c2 = t2[t + 1];
+				const bool oka = ok1[a1] && ok2[a2], okc = ok1[c1] && ok2[c2];
+				double A[O * M1], Bm[O * M2], C[O * M1], Dm[O * M2];
+#pragma unroll
+				for (int k = 0; k < O * M1; k++) { A[k] = J1[(long long)a1 * O * M1 + k]; C[k] = J1[(long long)c1 * O * M1 + k]; }
+#pragma unroll
+				for (int k = 0; k < O * M2; k++) { Bm[k] = J2[(long long)a2 * O * M2 + k]; Dm[k] = J2[(long long)c2 * O * M2 + k]; }
+				if (oka) hess_term<M1, M2>(H, A, Bm); else ninv++;
+				if (okc) hess_term<M1, M2>(H, C, Dm); else ninv++;
+			}
+		}
+		for (; t < te; t++) {
 			const int b1 = t1[t], b2 = t2[t];
-			if (B.valid[d.o_valid + B.obs_valid[d.o_obs + res1[b1]]] && B.valid[d.o_valid + B.obs_valid[d.o_obs + res2[b2]]]) {
-				const double *A = J1 + (long long)b1 * O * M1, *Bm = J2 + (long long)b2 * O * M2;
-				if (prm.noise == SRBA_NOISE_CONSTANT_MATRIX) {
-					for (int i = 0; i < M1; i++) {
-						double jl[O];
-						for (int j = 0; j < O; j++) { double s = 0; for (int k = 0; k < O; k++) s += A[k * M1 + i] * prm.lambda[k * O + j]; jl[j] = s; }
-						for (int j = 0; j < M2; j++) { double s = 0; for (int k = 0; k < O; k++) s += jl[k] * Bm[k * M2 + j]; H[i * M2 + j] += s; }
-					}
-				} else {
-					for (int i = 0; i < M1; i++) for (int j = 0; j < M2; j++) { double s = 0; for (int k = 0; k < O; k++) s += A[k * M1 + i] * Bm[k * M2 + j]; H[i * M2 + j] += s; }
-				}
-			} else ninv++;
+			if (ok1[b1] && ok2[b2]) hess_term<M1, M2>(H, J1 + (long long)b1 * O * M1, J2 + (long long)b2 * O * M2); else ninv++;
 		}
 		const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0;
 #pragma unroll
 		for (int k = 0; k < M1 * M2; k++) Hout[k] = H[k] * sc;
 		return ninv;
 	}
-	__device__ int phase_hessian() { // returns the per-thread invalid count (to be reduced by the caller if wanted)
+	__device__ int phase_hessian() { fresh(); // returns the per-thread invalid count (to be reduced by the caller if wanted)
 		int ninv = 0;
 		const double *Jp = B.Jp + d.o_bp * O * P, *Jf = B.Jf + d.o_bf * O * L;
-		const int *rp = B.bp_res + d.o_bp, *rf = B.bf_res + d.o_bf;
+		const unsigned char *rp = B.bp_ok + d.o_bp, *rf = B.bf_ok + d.o_bf;
 		for (int b = tid; b < d.n_hap; b += SRBA_WG) {
 			const long long g = d.o_hap + b;
 			ninv += hess_block<P, P>(B.HAp + g * P * P, B.hap_t1 + d.o_hapt, B.hap_t2 + d.o_hapt, B.hap_term_off[d.o_hapoff + b], B.hap_term_off[d.o_hapoff + b + 1], Jp, Jp, rp, rp);
@@ -546,28 +613,43 @@ struct Worker {
 	}
 
 	// ---- K5
+	// S lanes share one column (blocks dealt round-robin, partial sums combined in a fixed butterfly order -> deterministic)
 	template <int M>
-	__device__ __forceinline__ void grad_col(double *g, const double *J, const int *res, int bb, int be, const double *resid) {
-		double acc[M];
-#pragma unroll
-		for (int k = 0; k < M; k++) acc[k] = 0;
-		for (int b = bb; b < be; b++) {
-			const double *A = J + (long long)b * O * M, *r = resid + (long long)(d.o_obs + res[b]) * O;
-			double lr[O];
-			if (prm.noise == SRBA_NOISE_CONSTANT_MATRIX) { for (int k = 0; k < O; k++) { double s = 0; for (int j = 0; j < O; j++) s += prm.lambda[k * O + j] * r[j]; lr[k] = s; } }
-			else for (int k = 0; k < O; k++) lr[k] = r[k];
-			for (int i = 0; i < M; i++) { double s = 0; for (int k = 0; k < O; k++) s += A[k * M + i] * lr[k]; acc[i] += s; }
-		}
+	__device__ __forceinline__ void grad_cols(double *g, int ncol, const double *J, const int *res, const int *col_off, const double *resid) {
+		int S = 1; while (S < 8 && 2 * S * ncol <= SRBA_WG) S *= 2;
+		const int per = SRBA_WG / S, sub = tid % S;
 		const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0;
+		for (int base = 0; base < ncol; base += per) {
+			const int i = base + tid / S; const bool live = i < ncol;
+			double acc[M];
 #pragma unroll
-		for (int k = 0; k < M; k++) g[k] = acc[k] * sc;
+			for (int k = 0; k < M; k++) acc[k] = 0;
+			if (live) {
+				const int bb = col_off[i], be = col_off[i + 1];
+				for (int b = bb + sub; b < be; b += S) {
+					const double *A = J + (long long)b * O * M, *r = resid + (long long)(d.o_obs + res[b]) * O;
+					double lr[O];
+					if (prm.noise == SRBA_NOISE_CONSTANT_MATRIX) { for (int k = 0; k < O; k++) { double s = 0; for (int j = 0; j < O; j++) s += prm.lambda[k * O + j] * r[j]; lr[k] = s; } }
+					else for (int k = 0; k < O; k++) lr[k] = r[k];
+					for (int q = 0; q < M; q++) { double s = 0; for (int k = 0; k < O; k++) s += A[k * M + q] * lr[k]; acc[q] += s; }
+				}
+			}
+			for (int m = 1; m < S; m *= 2) {
+#pragma unroll
+				for (int k = 0; k < M; k++) acc[k] += __shfl_xor(acc[k], m);
+			}
+			if (live && sub == 0) {
+#pragma unroll
+				for (int k = 0; k < M; k++) g[i * M + k] = acc[k] * sc;
+			}
+		}
 	}
-	__device__ void phase_gradient(const double *resid) {
+	__device__ void phase_gradient(const double *resid) { fresh();
 		double *g = B.grad + d.o_scal;
-		for (int i = tid; i < d.nK; i += SRBA_WG) grad_col<P>(g + i * P, B.Jp + d.o_bp * O * P, B.bp_res + d.o_bp, B.colp_off[d.o_colp + i], B.colp_off[d.o_colp + i + 1], resid);
-		if constexpr (!T::REL) for (int i = tid; i < d.nF; i += SRBA_WG) grad_col<L>(g + d.nK * P + i * L, B.Jf + d.o_bf * O * L, B.bf_res + d.o_bf, B.colf_off[d.o_colf + i], B.colf_off[d.o_colf + i + 1], resid);
+		grad_cols<P>(g, d.nK, B.Jp + d.o_bp * O * P, B.bp_res + d.o_bp, B.colp_off + d.o_colp, resid);
+		if constexpr (!T::REL) grad_cols<L>(g + d.nK * P, d.nF, B.Jf + d.o_bf * O * L, B.bf_res + d.o_bf, B.colf_off + d.o_colf, resid);
 	}
-	__device__ double lambda_guess(double *red) { // optimize_edges.h:366-390
+	__device__ double lambda_guess(double *red) { fresh(); // optimize_edges.h:366-390
 		double mx = 0;
 		for (int i = tid; i < d.nK; i += SRBA_WG) { const double *H = B.HAp + (d.o_hap + B.hap_diag[d.o_unk + i]) * P * P; double m = H[0]; for (int k = 1; k < P; k++) m = fmax(m, H[k * P + k]); mx = fmax(mx, m); }
 		if constexpr (!T::REL) for (int i = tid; i < d.nF; i += SRBA_WG) { const double *H = B.Hf + (d.o_hf + B.hf_diag[d.o_ulm + i]) * L * L; double m = H[0]; for (int k = 1; k < L; k++) m = fmax(m, H[k * L + k]); mx = fmax(mx, m); }

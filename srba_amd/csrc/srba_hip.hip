@@ -30,7 +30,7 @@ struct Solver : public Worker<FAM> {
 	__device__ __forceinline__ bool schur_active() const { return prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0; }
 
 	// K7 + K8 (schur.h:180-268). Mutates HAp and minus_grad in place like the reference.
-	__device__ void schur_reduce(double lambda) {
+	__device__ void schur_reduce(double lambda) { this->fresh();
 		if constexpr (!W::T::REL) {
 			for (int l = tid; l < d.nF; l += SRBA_WG) {
 				double M[L * L], Mi[L * L]; const double *src = B.Hf + (d.o_hf + B.hf_diag[d.o_ulm + l]) * L * L;
@@ -74,7 +74,7 @@ struct Solver : public Worker<FAM> {
 		}
 	}
 	// K10 (schur.h:271-311)
-	__device__ void schur_features() {
+	__device__ void schur_features() { this->fresh();
 		if constexpr (!W::T::REL) {
 			double *g = B.grad + d.o_scal, *dl = B.delta + d.o_scal;
 			for (int l = tid; l < d.nF; l += SRBA_WG) {
@@ -103,7 +103,33 @@ struct Solver : public Worker<FAM> {
 		if (dst >= 0) S.off[9 * (dst >> 1) + ((dst & 1) ? q3 * 3 + r3 : r3 * 3 + q3)] = v;
 		else if (dst != (int)0x80000000 && r3 <= q3) S.diag[9 * (-1 - dst) + q3 * 3 + r3] = v;
 	}
-	__device__ void assemble(const SparseSys &S, double lambda) {
+	// copy one 3x3 block (row stride LD) to its destination; diagonal destinations keep the lower triangle and get +lambda on the diagonal
+	template <int LD> __device__ __forceinline__ void put_block(const SparseSys &S, int dst, const double *H, double lambda) const {
+		double v[9];
+#pragma unroll
+		for (int r = 0; r < 3; r++)
+#pragma unroll
+			for (int q = 0; q < 3; q++) v[r * 3 + q] = H[r * LD + q];
+		if (dst >= 0) {
+			double *o = S.off + 9 * (dst >> 1);
+			if (dst & 1) {
+#pragma unroll
+				for (int r = 0; r < 3; r++)
+#pragma unroll
+					for (int q = 0; q < 3; q++) o[q * 3 + r] = v[r * 3 + q];
+			} else {
+#pragma unroll
+				for (int k = 0; k < 9; k++) o[k] = v[k];
+			}
+		} else {
+			double *o = S.diag + 9 * (-1 - dst);
+#pragma unroll
+			for (int r = 0; r < 3; r++)
+#pragma unroll
+				for (int q = r; q < 3; q++) o[q * 3 + r] = v[r * 3 + q] + (r == q ? lambda : 0.0);
+		}
+	}
+	__device__ void assemble(const SparseSys &S, double lambda) { this->fresh();
 		const int n = d.n_sys, nb = d.nb;
 		for (int k = tid; k < 9 * nb; k += SRBA_WG) S.diag[k] = 0;
 		for (int k = tid; k < 9 * S.nnzoff; k += SRBA_WG) S.off[k] = 0;
@@ -111,23 +137,23 @@ struct Solver : public Worker<FAM> {
 		for (int k = tid; k < 3 * nb; k += SRBA_WG) S.rhs[3 * S.perm[k / 3] + k % 3] = (k < n) ? g[k] : 0.0;
 		__syncthreads();
 		constexpr int PB = P / 3;
-		for (int e = tid; e < d.n_hap * P * P; e += SRBA_WG) {
-			const int b = e / (P * P), r = (e / P) % P, q = e % P;
-			const bool dg = (r == q) && (B.hap_i[d.o_hap + b] == B.hap_j[d.o_hap + b]);
-			put_dst(S, B.hap_dst[(d.o_hap + b) * PB * PB + (r / 3) * PB + (q / 3)], r % 3, q % 3, B.HAp[(d.o_hap + b) * P * P + r * P + q] + (dg ? lambda : 0.0));
+		// one lane per aligned 3x3 sub-block: its 9 loads are in flight together (one memory round trip per pass instead of one per element)
+		for (int sb = tid; sb < d.n_hap * PB * PB; sb += SRBA_WG) {
+			const int dst = B.hap_dst[d.o_hap * PB * PB + sb]; if (dst == (int)0x80000000) continue;
+			const int b = sb / (PB * PB), si = (sb / PB) % PB, sj = sb % PB;
+			put_block<P>(S, dst, B.HAp + (d.o_hap + b) * P * P + si * 3 * P + sj * 3, lambda);
 		}
 		if constexpr (!W::T::REL) if (prm.solver == SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL) {
 			const int base = P * d.nK;
 			if (d.aligned) {
 				if constexpr (L == 3) {
-					for (int e = tid; e < d.n_hapf * P * L; e += SRBA_WG) {
-						const int b = e / (P * L), r = (e / L) % P, q = e % L;
-						put_dst(S, B.hapf_dst[(d.o_hapf + b) * PB + (r / 3)], r % 3, q, B.HApf[(d.o_hapf + b) * P * L + r * L + q]);
+					for (int sb = tid; sb < d.n_hapf * PB; sb += SRBA_WG) {
+						const int dst = B.hapf_dst[d.o_hapf * PB + sb]; if (dst == (int)0x80000000) continue;
+						put_block<L>(S, dst, B.HApf + (d.o_hapf + sb / PB) * P * L + (sb % PB) * 3 * L, 0.0);
 					}
-					for (int e = tid; e < d.n_hf * L * L; e += SRBA_WG) {
-						const int b = e / (L * L), r = (e / L) % L, q = e % L;
-						const bool dg = (r == q) && (B.hf_i[d.o_hf + b] == B.hf_j[d.o_hf + b]);
-						put_dst(S, B.hf_dst[d.o_hf + b], r, q, B.Hf[(d.o_hf + b) * L * L + r * L + q] + (dg ? lambda : 0.0));
+					for (int b = tid; b < d.n_hf; b += SRBA_WG) {
+						const int dst = B.hf_dst[d.o_hf + b]; if (dst == (int)0x80000000) continue;
+						put_block<L>(S, dst, B.Hf + (d.o_hf + b) * L * L, lambda);
 					}
 				}
 			} else { // landmark blocks straddle 3x3 block boundaries (L == 2): generic per-element placement
@@ -146,15 +172,15 @@ struct Solver : public Worker<FAM> {
 		__syncthreads();
 	}
 	// solve(lambda): returns false if not positive definite (uniform across the wavefront)
-	__device__ bool solve(const SparseSys &S, double lambda, long long *pc = nullptr) {
+	template <bool DLDS> __device__ bool solve(const SparseSys &S, double lambda, long long *pc = nullptr) {
 		long long t0 = 0;
 #define STIC() do { if (pc) { __syncthreads(); t0 = wall_clock64(); } } while (0)
 #define STOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - t0; } } while (0)
 		STIC(); if (schur_active()) schur_reduce(lambda); STOC(9);
 		STIC(); assemble(S, lambda); STOC(10);
-		STIC(); const bool ok = sp_factor_fsub(S); STOC(11);
+		STIC(); const bool ok = sp_factor_fsub<DLDS>(S); STOC(11);
 		if (!ok) return false;
-		STIC(); sp_bsub(S);
+		STIC(); sp_bsub<DLDS>(S);
 		double *dl = B.delta + d.o_scal;
 		for (int k = tid; k < d.n_scal; k += SRBA_WG) dl[k] = (k < d.n_sys) ? S.rhs[3 * S.perm[k / 3] + k % 3] : 0.0;
 		__syncthreads(); STOC(12);
@@ -165,23 +191,24 @@ struct Solver : public Worker<FAM> {
 	}
 	template <bool DLDS> __device__ __forceinline__ SparseSys make_sys(double *lds) const {
 		SparseSys S; S.nb = d.nb; S.nnzoff = d.nnzoff;
-		S.col_off = B.sp_col_off + d.o_spcol; S.row = B.sp_row + d.o_sprow; S.item_off = B.sp_item_off + d.o_spcol; S.tgt = B.sp_tgt + d.o_spitem; S.perm = B.sp_perm + d.o_spperm;
+		S.col_off = B.sp_col_off + d.o_spcol; S.row = B.sp_row + d.o_sprow; S.item = B.sp_tgt + d.o_spitem; S.item_ab = B.sp_ab + d.o_spitem; S.perm = B.sp_perm + d.o_spperm;
+		S.rptr = B.sp_rptr + d.o_spcol; S.rent = B.sp_rcol + d.o_sprow; S.rent_blk = B.sp_rblk + d.o_sprow;
 		double *base; if constexpr (DLDS) base = lds; else base = B.dense + d.o_dense;
 		S.diag = base; S.off = base + 9 * d.nb; S.rhs = S.off + 9 * d.nnzoff;
-		if constexpr (DLDS) { // symbolic structure next to the numbers: the factorisation's dependent index loads hit LDS, not L2
-			int *ip = (int *)(S.rhs + 3 * d.nb); int *c0 = ip, *i0 = ip + d.nb + 1, *r0 = i0 + d.nb + 1, *t0 = r0 + d.nnzoff, *p0 = t0 + d.n_items;
-			for (int k = tid; k <= d.nb; k += SRBA_WG) { c0[k] = S.col_off[k]; i0[k] = S.item_off[k]; }
+		if constexpr (DLDS) { // symbolic structure next to the numbers (packed): the factorisation's dependent index loads hit LDS, not L2
+			int *ip = (int *)(S.rhs + 3 * d.nb); int *c0 = ip, *rp0 = c0 + d.nb + 1, *p0 = rp0 + d.nb + 1, *r0 = p0 + d.nb, *re0 = r0 + d.nnzoff, *t0 = re0 + d.nnzoff;
+			for (int k = tid; k <= d.nb; k += SRBA_WG) { c0[k] = S.col_off[k]; rp0[k] = S.rptr[k]; }
 			for (int k = tid; k < d.nb; k += SRBA_WG) p0[k] = S.perm[k];
-			for (int k = tid; k < d.nnzoff; k += SRBA_WG) r0[k] = S.row[k];
-			for (int k = tid; k < d.n_items; k += SRBA_WG) t0[k] = S.tgt[k];
-			S.col_off = c0; S.item_off = i0; S.row = r0; S.tgt = t0; S.perm = p0;
+			for (int k = tid; k < d.nnzoff; k += SRBA_WG) { r0[k] = S.row[k]; re0[k] = (S.rent[k] << 14) | S.rent_blk[k]; }
+			for (int k = tid; k < d.n_items; k += SRBA_WG) { const int tg = S.item[k], ab = S.item_ab[k]; t0[k] = ((tg >= 0 ? d.nb + tg : -1 - tg) << 18) | ((ab >> 16) << 9) | (ab & 0xffff); }
+			S.col_off = c0; S.rptr = rp0; S.perm = p0; S.row = r0; S.rent = re0; S.item = t0;
 			__syncthreads();
 		}
 		return S;
 	}
 
 	// K12 backup + K11 apply (optimize_edges.h:491-557)
-	__device__ void apply_update() {
+	__device__ void apply_update() { this->fresh();
 		typedef typename W::PO PO;
 		const double *dl = B.delta + d.o_scal;
 		for (int i = tid; i < d.nK; i += SRBA_WG) {
@@ -194,7 +221,7 @@ struct Solver : public Worker<FAM> {
 		for (int r = tid; r < d.n_req; r += SRBA_WG) { const double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD; double *o = B.old_pose + (d.o_req + r) * PD; for (int k = 0; k < PD; k++) o[k] = s[k]; }
 		__syncthreads();
 	}
-	__device__ void restore() { // optimize_edges.h:664-680
+	__device__ void restore() { this->fresh(); // optimize_edges.h:664-680
 		for (int i = tid; i < d.nK * PD; i += SRBA_WG) B.edge[d.o_edge * PD + i] = B.old_edge[d.o_unk * PD + i];
 		for (int k = tid; k < d.nF * L; k += SRBA_WG) B.ulm[d.o_ulm * L + k] = B.old_ulm[d.o_ulm * L + k];
 		for (int r = tid; r < d.n_req; r += SRBA_WG) { double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD; const double *o = B.old_pose + (d.o_req + r) * PD; for (int k = 0; k < PD; k++) s[k] = o[k]; }
@@ -205,8 +232,13 @@ struct Solver : public Worker<FAM> {
 extern __shared__ double srba_lds[]; // block-sparse system of the capsule (diag | off | rhs) when it fits
 
 // DLDS: the dense system lives in LDS (size classes 0..2) -> the compiler can prove the address space and emit ds_* instead of flat_*
+#ifdef SRBA_WAVES_PER_EU
+#define SRBA_OCC __attribute__((amdgpu_waves_per_eu(SRBA_WAVES_PER_EU, SRBA_WAVES_PER_EU)))
+#else
+#define SRBA_OCC
+#endif
 template <int FAM, bool DLDS>
-__global__ void __launch_bounds__(SRBA_WG) k_lm_run(const Batch B, const DevParams prm, int first) {
+__global__ void __launch_bounds__(SRBA_WG) SRBA_OCC k_lm_run(const Batch B, const DevParams prm, int first) {
 	const int pidx = B.order[first + blockIdx.x]; const ProbDesc &d = B.desc[pidx];
 	Solver<FAM> S(B, d, prm);
 	constexpr int P = Solver<FAM>::P, L = Solver<FAM>::L, O = Solver<FAM>::O;
@@ -245,7 +277,7 @@ __global__ void __launch_bounds__(SRBA_WG) k_lm_run(const Batch B, const DevPara
 		while (rho <= 0 && !stop) {
 			const int tr = trials++;
 			if (tid == 0 && tr < SRBA_TRACE_LEN) out->trace_lambda[tr] = lambda;
-			TIC(); const bool solved = S.solve(A, lambda, pc); TOC(5);
+			TIC(); const bool solved = S.template solve<DLDS>(A, lambda, pc); TOC(5);
 			if (!solved) {
 				n_notpd++; lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
 				__syncthreads();
@@ -313,7 +345,7 @@ template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_linearize(const 
 template <int FAM, bool DLDS> __global__ void __launch_bounds__(SRBA_WG) k_solve(const Batch B, const DevParams prm, int first) {
 	const int pidx = B.order[first + blockIdx.x]; const ProbDesc &d = B.desc[pidx]; Solver<FAM> S(B, d, prm);
 	const SparseSys A = S.template make_sys<DLDS>(srba_lds);
-	const bool ok = S.solve(A, B.lambda_io[pidx]);
+	const bool ok = S.template solve<DLDS>(A, B.lambda_io[pidx]);
 	if (threadIdx.x == 0) B.notpd[pidx] = ok ? 0 : 1;
 }
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_apply(const Batch B, const DevParams prm) { Solver<FAM> S(B, B.desc[blockIdx.x], prm); S.apply_update(); }
@@ -339,7 +371,7 @@ struct Arena { // layout builder: 256-byte aligned sub-allocations inside one bu
 
 #define SRBA_NCLS 20  /* 19 LDS size classes (6 KB ... 152 KB per wavefront) + one class for systems factored in HBM */
 // Symbolic block factorisation of one capsule's system (natural block order): the numeric kernel never discovers structure.
-struct Symbolic { std::vector<int32_t> col_off, row, item_off, tgt, perm, hap_dst, hapf_dst, hf_dst; bool aligned = true; };
+struct Symbolic { std::vector<int32_t> col_off, row, item_off, tgt, ab, rptr, rcol, rblk, perm, hap_dst, hapf_dst, hf_dst; int max_cn = 0; bool aligned = true; };
 static void symbolic_factor(const srba_problem_capsule &k, const ProbDesc &d, int P, int L, bool full_system, Symbolic &out) {
 	const int nb = d.nb;
 	// 1) block-level adjacency of the system (original numbering)
@@ -378,17 +410,24 @@ static void symbolic_factor(const srba_problem_capsule &k, const ProbDesc &d, in
 		std::vector<int> &v = cols[c]; std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end());
 		if (!v.empty()) { std::vector<int> &par = cols[v[0]]; par.insert(par.end(), v.begin() + 1, v.end()); }
 	}
-	out.col_off.assign(nb + 1, 0); out.row.clear(); out.item_off.assign(nb + 1, 0); out.tgt.clear();
+	out.col_off.assign(nb + 1, 0); out.row.clear(); out.item_off.assign(nb + 1, 0); out.tgt.clear(); out.ab.clear(); out.max_cn = 0;
 	for (int c = 0; c < nb; c++) { out.row.insert(out.row.end(), cols[c].begin(), cols[c].end()); out.col_off[c + 1] = (int32_t)out.row.size(); }
 	for (int c = 0; c < nb; c++) {
-		const std::vector<int> &v = cols[c]; const int cn = (int)v.size();
+		const std::vector<int> &v = cols[c]; const int cn = (int)v.size(); out.max_cn = std::max(out.max_cn, cn);
 		for (int a = 0; a < cn; a++) for (int b = 0; b <= a; b++) { // item t = a(a+1)/2 + b : target block (v[a], v[b])
+			out.ab.push_back((a << 16) | b);
 			if (a == b) { out.tgt.push_back(-1 - v[a]); continue; }
 			const std::vector<int> &cb = cols[v[b]]; const int pos = (int)(std::lower_bound(cb.begin(), cb.end(), v[a]) - cb.begin());
 			out.tgt.push_back(out.col_off[v[b]] + pos);
 		}
 		out.item_off[c + 1] = (int32_t)out.tgt.size();
 	}
+	// row view of the strictly-lower blocks (backward substitution pushes along block-rows)
+	out.rptr.assign(nb + 1, 0); out.rcol.assign(out.row.size(), 0); out.rblk.assign(out.row.size(), 0);
+	for (size_t i = 0; i < out.row.size(); i++) out.rptr[out.row[i] + 1]++;
+	for (int a = 0; a < nb; a++) out.rptr[a + 1] += out.rptr[a];
+	{ std::vector<int32_t> fill(out.rptr.begin(), out.rptr.end() - 1);
+	  for (int c = 0; c < nb; c++) for (int i = out.col_off[c]; i < out.col_off[c + 1]; i++) { const int q = fill[out.row[i]]++; out.rcol[q] = c; out.rblk[q] = i; } }
 	// 4) destination of every aligned 3x3 sub-block (a,b) of the UPPER-triangle Hessian blocks, original numbering a <= b
 	auto dst_of = [&](int a, int b) -> int32_t {
 		if (a == b) return -1 - out.perm[a];
@@ -408,6 +447,10 @@ static void symbolic_factor(const srba_problem_capsule &k, const ProbDesc &d, in
 	} else { out.hapf_dst.assign((size_t)k.n_hapf * PB, 0); out.hf_dst.assign(k.n_hf, 0); }
 }
 
+struct LaunchJob { int queue, cls, first, count; double cost; };
+// first element of slice q when cnt items are dealt round-robin to nq slices
+static inline int slice_begin(int cnt, int q, int nq) { return q * (cnt / nq) + std::min(q, cnt % nq); }
+
 struct srba_hip_ctx {
 	int device = 0; srba_hip_params params; DevParams dp; FamDims dm;
 	hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -417,14 +460,53 @@ struct srba_hip_ctx {
 	int n_prob = 0; std::vector<ProbDesc> desc; Batch B; srba_batch_stats stats;
 	char *d_in = nullptr; size_t cap_in = 0; char *d_wk = nullptr; size_t cap_wk = 0;
 	std::vector<char> h_in; // host staging of the input arena
-	double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
+	int n_queues = 8, sched = 1, n_streams_used = 1; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
 	// offsets needed for downloads (bytes inside the wk arena)
 	size_t off_edge = 0, off_ulm = 0, off_pose = 0, off_inf = 0, off_infv = 0, off_res = 0;
 	size_t off_dbg[10] = {0}; int64_t len_dbg[10] = {0};
 	size_t in_off_edge0 = 0, in_off_ulm0 = 0; long long tot_edge = 0, tot_ulm = 0;
-	size_t off_phase = 0; bool phase_timing = false; long long n_pose_total = 0;
+	size_t off_phase = 0; bool phase_timing = false; long long n_pose_total = 0; std::vector<int> cls_of;
 	void fail(const std::string &m) { error = m; g_last_error = m; }
 };
+// Launch plan of the fused LM kernel. Every size class is one or more launches (a launch has ONE dynamic-LDS size); the HIP runtime
+// multiplexes streams onto 4 hardware queues and kernels of one queue run in order, so the plan uses n_queues streams and decides what
+// shares the chip at any time. Small capsules are wave-slot bound (VGPRs), big ones LDS bound: running them side by side fills both.
+//   sched 0: every class cut into n_queues interleaved slices, one per stream (all queues walk the classes in step, biggest first)
+//   sched 1: classes cut into chunks, chunks dealt to the least-loaded queue (cost ~ sum of system sizes); even queues run their chunks
+//            biggest-LDS first, odd queues smallest first -> big and small capsules overlap for the whole run
+//   sched 2: one stream per class, biggest first
+static void plan_launches(srba_hip_ctx *c, const int32_t *ord) {
+	c->plan.clear(); const int nq = c->n_queues;
+	auto cost_of = [&](int first, int count) { double s = 0; for (int i = 0; i < count; i++) s += c->desc[ord[first + i]].nb + 4; return s; };
+	if (c->sched == 2) {
+		int q = 0;
+		for (int k = SRBA_NCLS - 1; k >= 0; k--) if (c->cls_count[k]) { c->plan.push_back({q, k, c->cls_first[k], c->cls_count[k], 0.0}); q++; }
+		c->n_streams_used = std::max(q, 1); return;
+	}
+	c->n_streams_used = nq;
+	if (c->sched == 0) {
+		int rr = 0;
+		for (int k = SRBA_NCLS - 1; k >= 0; k--) if (c->cls_count[k]) {
+			const int cnt = c->cls_count[k], parts = cnt >= 16 * nq ? nq : 1;
+			for (int q = 0; q < parts; q++) { const int a = slice_begin(cnt, q, parts), b = slice_begin(cnt, q + 1, parts); if (b > a) c->plan.push_back({parts == 1 ? (rr++ % nq) : q, k, c->cls_first[k] + a, b - a, 0.0}); }
+		}
+		return;
+	}
+	std::vector<LaunchJob> jobs;
+	for (int k = SRBA_NCLS - 1; k >= 0; k--) if (c->cls_count[k]) {
+		const int cnt = c->cls_count[k], parts = std::max(1, std::min(nq, cnt / 512));
+		for (int q = 0; q < parts; q++) { const int a = slice_begin(cnt, q, parts), b = slice_begin(cnt, q + 1, parts); if (b > a) jobs.push_back({0, k, c->cls_first[k] + a, b - a, cost_of(c->cls_first[k] + a, b - a)}); }
+	}
+	std::vector<size_t> by_cost(jobs.size()); for (size_t i = 0; i < jobs.size(); i++) by_cost[i] = i;
+	std::stable_sort(by_cost.begin(), by_cost.end(), [&](size_t a, size_t b) { return jobs[a].cost > jobs[b].cost; });
+	std::vector<double> load(nq, 0.0); std::vector<std::vector<LaunchJob> > perq(nq);
+	for (size_t i = 0; i < by_cost.size(); i++) { int q = 0; for (int x = 1; x < nq; x++) if (load[x] < load[q]) q = x; LaunchJob J = jobs[by_cost[i]]; J.queue = q; load[q] += J.cost; perq[q].push_back(J); }
+	for (int q = 0; q < nq; q++) { // class index grows with the LDS footprint (the HBM class last = biggest)
+		std::stable_sort(perq[q].begin(), perq[q].end(), [&](const LaunchJob &a, const LaunchJob &b) { return (q & 1) ? a.cls < b.cls : a.cls > b.cls; });
+	}
+	for (size_t i = 0;; i++) { bool any = false; for (int q = 0; q < nq; q++) if (i < perq[q].size()) { c->plan.push_back(perq[q][i]); any = true; } if (!any) break; }
+}
+
 
 static void make_dev_params(const srba_hip_params &p, DevParams &dp, const FamDims &dm) {
 	std::memset(&dp, 0, sizeof(dp));
@@ -480,6 +562,9 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	c->device = device; c->params = *params; c->dm = kDims[params->family]; make_dev_params(*params, c->dp, c->dm);
 	std::memset(&c->B, 0, sizeof(c->B)); std::memset(&c->stats, 0, sizeof(c->stats));
 	{ const char *e = getenv("SRBA_HIP_PHASE_TIMING"); c->phase_timing = (e && e[0] == '1'); }
+	{ const char *e = getenv("SRBA_HIP_LDS_PAD"); c->lds_pad = e ? (size_t)atol(e) : 0; } // diagnostics: extra LDS bytes per workgroup (lowers residency)
+	{ const char *e = getenv("SRBA_HIP_SCHED"); if (e) c->sched = atoi(e); } // tuning knob: launch plan (see plan_launches)
+	{ const char *e = getenv("SRBA_HIP_QUEUES"); if (e && atoi(e) >= 1 && atoi(e) < SRBA_NCLS) c->n_queues = atoi(e); } // tuning knob: concurrent launch streams
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
 	for (int k = 1; k < SRBA_NCLS && ok; k++) ok = hipStreamCreateWithFlags(&c->cls_stream[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->cls_done[k], hipEventDisableTiming) == hipSuccess;
@@ -532,13 +617,14 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 		d.nnzoff = (int)sym[p].row.size(); d.n_items = (int)sym[p].tgt.size(); d.aligned = sym[p].aligned ? 1 : 0;
 		d.o_spcol = t_spcol; d.o_sprow = t_sprow; d.o_spitem = t_spitem; d.o_spperm = t_spcol - p;
 		t_spcol += d.nb + 1; t_sprow += d.nnzoff; t_spitem += (long long)sym[p].tgt.size();
-		const size_t n_ints = 2 * ((size_t)d.nb + 1) + (size_t)d.nnzoff + (size_t)d.n_items + (size_t)d.nb;
+		const size_t n_ints = 2 * ((size_t)d.nb + 1) + 2 * (size_t)d.nnzoff + (size_t)d.n_items + (size_t)d.nb;
+		const bool packable = d.nb + d.nnzoff < 16384 && d.nb < 16384 && sym[p].max_cn < 512; // item / row-entry words of the LDS copy
 		const size_t tri_n = 9 * (size_t)d.nb + 9 * (size_t)d.nnzoff + 3 * (size_t)d.nb + (n_ints + 1) / 2; // diag | off | rhs | symbolic ints
 		// LDS footprint x residency time is what bounds the batch: capsules are grouped in fine size classes so that each launch
 		// reserves little more LDS per wavefront than its capsules need; systems above 152 KB are factored in an HBM workspace
 		const size_t bytes = tri_n * 8;
 		static const int kClsKB[SRBA_NCLS - 1] = {6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64, 80, 96, 112, 128, 152};
-		cls[p] = SRBA_NCLS - 1; for (int q = 0; q < SRBA_NCLS - 1; q++) if (bytes <= (size_t)kClsKB[q] * 1024) { cls[p] = q; break; }
+		cls[p] = SRBA_NCLS - 1; for (int q = 0; q < SRBA_NCLS - 1 && packable; q++) if (bytes <= (size_t)kClsKB[q] * 1024) { cls[p] = q; break; }
 		d.dense_in_lds = cls[p] < SRBA_NCLS - 1 ? 1 : 0; cls_nbmax[cls[p]] = std::max(cls_nbmax[cls[p]], (int)tri_n);
 		int nyw = 0; if (k.n_sch_terms > 0) for (int b = 0; b < k.n_hap; b++) if (k.hap_i[b] == k.hap_j[b]) nyw += k.sch_term_off[b + 1] - k.sch_term_off[b];
 		long long npath_needed = 0; for (int q = 0; q < k.n_pairs; q++) if (k.pair_needed[q]) { st.n_pairs_needed++; npath_needed += k.pair_path_off[q + 1] - k.pair_path_off[q]; }
@@ -552,7 +638,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	// ---- input arena layout
 	Arena in; struct { size_t desc, edge0, ulm0, klm, obs_z, pair_path_off, path_edge, obs_pose, obs_lm, obs_valid, bp_col, bp_res, bp_A, bp_D, bp_lm, colp_off, bf_col, bf_res, bf_pose, colf_off,
 		hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hf_i, hf_j, hf_term_off, hf_t1, hf_t2, hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag, sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw,
-		lm_hapf_off, lm_hapf_idx, req_idx, pair_needed, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_perm, hap_dst, hapf_dst, hf_dst; } o;
+		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, pair_needed, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_ab, sp_rptr, sp_rcol, sp_rblk, sp_perm, hap_dst, hapf_dst, hf_dst; } o;
 	o.desc = in.add(sizeof(ProbDesc) * n);
 	o.edge0 = in.add(8 * t_edge * PDX); o.ulm0 = in.add(8 * t_ulm * L); o.klm = in.add(8 * t_klm * L); o.obs_z = in.add(8 * t_obs * O);
 	o.pair_path_off = in.add(4 * (t_pair + n)); o.path_edge = in.add(4 * t_path); o.obs_pose = in.add(4 * t_obs); o.obs_lm = in.add(4 * t_obs); o.obs_valid = in.add(4 * t_obs);
@@ -563,8 +649,8 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	o.hapf_i = in.add(4 * t_hapf); o.hapf_j = in.add(4 * t_hapf); o.hapf_term_off = in.add(4 * (t_hapf + n)); o.hapf_t1 = in.add(4 * t_hapft); o.hapf_t2 = in.add(4 * t_hapft);
 	o.hap_diag = in.add(4 * t_unk); o.hf_diag = in.add(4 * t_ulm);
 	o.sch_term_off = in.add(4 * (t_hap + n)); o.sch_b1 = in.add(4 * t_sch); o.sch_b2 = in.add(4 * t_sch); o.sch_lm = in.add(4 * t_sch); o.sch_yw = in.add(4 * t_sch);
-	o.lm_hapf_off = in.add(4 * (t_ulm + n)); o.lm_hapf_idx = in.add(4 * t_hapf); o.req_idx = in.add(4 * t_req); o.pair_needed = in.add(t_pair); o.bp_normal = in.add(t_bp); o.order = in.add(4 * (size_t)n);
-	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_perm = in.add(4 * t_spcol);
+	o.lm_hapf_off = in.add(4 * (t_ulm + n)); o.lm_hapf_idx = in.add(4 * t_hapf); o.req_idx = in.add(4 * t_req); o.need_idx = in.add(4 * t_pair); o.pair_needed = in.add(t_pair); o.bp_normal = in.add(t_bp); o.order = in.add(4 * (size_t)n);
+	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_ab = in.add(4 * t_spitem); o.sp_rptr = in.add(4 * t_spcol); o.sp_rcol = in.add(4 * t_sprow); o.sp_rblk = in.add(4 * t_sprow); o.sp_perm = in.add(4 * t_spcol);
 	o.hap_dst = in.add(4 * t_hap * (P / 3) * (P / 3)); o.hapf_dst = in.add(4 * t_hapf * (P / 3)); o.hf_dst = in.add(4 * t_hf);
 	in.add(0);
 	c->h_in.assign(in.size + 256, 0); char *h = c->h_in.data();
@@ -592,26 +678,36 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 			for (int b = 0; b < k.n_hap; b++) for (int t = k.sch_term_off[b]; t < k.sch_term_off[b + 1]; t++) yw[t] = (k.hap_i[b] == k.hap_j[b]) ? cnt++ : -1;
 		} // else: zeros = empty term lists
 		if (k.lm_hapf_off) CPY(o.lm_hapf_off, d.o_lmoff, k.lm_hapf_off, d.nF + 1, int32_t); CPY(o.lm_hapf_idx, d.o_hapf, k.lm_hapf_idx, k.n_hapf, int32_t);
+		{ int32_t *nd = (int32_t *)(h + o.need_idx) + d.o_pair; int cnt = 0; for (int i = 0; i < k.n_pairs; i++) if (k.pair_needed[i]) nd[cnt++] = i; c->desc[p].n_need = cnt; }
 		{ int32_t *rq = (int32_t *)(h + o.req_idx) + d.o_req; int cnt = 0; for (int i = 0; i < 2 * k.n_pairs; i++) if (k.pose_required[i]) rq[cnt++] = i; }
 		CPY(o.pair_needed, d.o_pair, k.pair_needed, k.n_pairs, uint8_t); CPY(o.bp_normal, d.o_bp, k.bp_normal, k.n_bp, uint8_t);
 		CPY(o.sp_col_off, d.o_spcol, sym[p].col_off.data(), d.nb + 1, int32_t); CPY(o.sp_row, d.o_sprow, sym[p].row.data(), d.nnzoff, int32_t);
-		CPY(o.sp_item_off, d.o_spcol, sym[p].item_off.data(), d.nb + 1, int32_t); CPY(o.sp_perm, d.o_spperm, sym[p].perm.data(), d.nb, int32_t); CPY(o.sp_tgt, d.o_spitem, sym[p].tgt.data(), sym[p].tgt.size(), int32_t);
+		CPY(o.sp_item_off, d.o_spcol, sym[p].item_off.data(), d.nb + 1, int32_t); CPY(o.sp_perm, d.o_spperm, sym[p].perm.data(), d.nb, int32_t); CPY(o.sp_tgt, d.o_spitem, sym[p].tgt.data(), sym[p].tgt.size(), int32_t); CPY(o.sp_ab, d.o_spitem, sym[p].ab.data(), sym[p].ab.size(), int32_t);
+		CPY(o.sp_rptr, d.o_spcol, sym[p].rptr.data(), d.nb + 1, int32_t); CPY(o.sp_rcol, d.o_sprow, sym[p].rcol.data(), d.nnzoff, int32_t); CPY(o.sp_rblk, d.o_sprow, sym[p].rblk.data(), d.nnzoff, int32_t);
 		CPY(o.hap_dst, d.o_hap * (P / 3) * (P / 3), sym[p].hap_dst.data(), sym[p].hap_dst.size(), int32_t); CPY(o.hapf_dst, d.o_hapf * (P / 3), sym[p].hapf_dst.data(), sym[p].hapf_dst.size(), int32_t); CPY(o.hf_dst, d.o_hf, sym[p].hf_dst.data(), sym[p].hf_dst.size(), int32_t);
 		st.n_chol_blocks += d.nb + d.nnzoff; st.n_chol_items += (int64_t)sym[p].tgt.size();
 	}
 #undef CPY
 	std::memcpy(h + o.desc, c->desc.data(), sizeof(ProbDesc) * n);
+	c->cls_of = cls;
 	{ // launch order: capsules grouped by LDS size class
 		int32_t *ord = (int32_t *)(h + o.order); int pos = 0;
-		for (int k = 0; k < SRBA_NCLS; k++) { c->cls_first[k] = pos; for (int p = 0; p < n; p++) if (cls[p] == k) ord[pos++] = p; c->cls_count[k] = pos - c->cls_first[k];
-			c->cls_lds[k] = k < SRBA_NCLS - 1 ? (size_t)cls_nbmax[k] * 8 : 0; }
+		for (int k = 0; k < SRBA_NCLS; k++) {
+			c->cls_first[k] = pos; for (int p = 0; p < n; p++) if (cls[p] == k) ord[pos++] = p; c->cls_count[k] = pos - c->cls_first[k];
+			c->cls_lds[k] = k < SRBA_NCLS - 1 ? (size_t)cls_nbmax[k] * 8 : 0;
+			// longest (most block updates per factorisation) first, dealt round-robin to the queue slices of lm_run_async
+			int32_t *b = ord + c->cls_first[k]; const int cnt = c->cls_count[k], nq = c->n_queues;
+			std::stable_sort(b, b + cnt, [&](int x, int y) { return c->desc[x].n_items > c->desc[y].n_items; });
+			if (c->sched == 0 && cnt >= 16 * nq) { std::vector<int32_t> t(b, b + cnt); for (int q = 0; q < nq; q++) { int i = slice_begin(cnt, q, nq); for (int src = q; src < cnt; src += nq) b[i++] = t[src]; } }
+		}
+		plan_launches(c, ord);
 	}
 	// ---- work arena layout
-	Arena wk; struct { size_t edge, ulm, pose, Jp, Jf, resid, resid2, HAp, HAp0, Hf, HApf, grad, delta, Hfinv, YW, old_edge, old_ulm, old_pose, dense, ulm_inf, valid, first_fail, hf_ok, ulm_inf_valid, results, lambda_io, chi2, notpd, phase_cycles; } w;
+	Arena wk; struct { size_t edge, ulm, pose, Jp, Jf, resid, resid2, HAp, HAp0, Hf, HApf, grad, delta, Hfinv, YW, old_edge, old_ulm, old_pose, dense, ulm_inf, valid, first_fail, hf_ok, bp_ok, bf_ok, ulm_inf_valid, results, lambda_io, chi2, notpd, phase_cycles; } w;
 	w.edge = wk.add(8 * t_edge * PDX); w.ulm = wk.add(8 * t_ulm * L); w.pose = wk.add(8 * 2 * t_pair * PDX); w.Jp = wk.add(8 * t_bp * O * P); w.Jf = wk.add(8 * t_bf * O * L);
 	w.resid = wk.add(8 * t_obs * O); w.resid2 = wk.add(8 * t_obs * O); w.HAp = wk.add(8 * t_hap * P * P); w.HAp0 = wk.add(8 * t_hap * P * P); w.Hf = wk.add(8 * t_hf * L * L); w.HApf = wk.add(8 * t_hapf * P * L);
 	w.grad = wk.add(8 * t_scal); w.delta = wk.add(8 * t_scal); w.Hfinv = wk.add(8 * t_ulm * L * L); w.YW = wk.add(8 * t_yw * P * L); w.old_edge = wk.add(8 * t_unk * PDX); w.old_ulm = wk.add(8 * t_ulm * L); w.old_pose = wk.add(8 * t_req * PDX);
-	w.dense = wk.add(8 * t_dense); w.ulm_inf = wk.add(8 * t_ulm * L * L); w.valid = wk.add(4 * t_valid); w.first_fail = wk.add(4 * t_valid); w.hf_ok = wk.add(4 * t_ulm); w.ulm_inf_valid = wk.add(t_ulm);
+	w.dense = wk.add(8 * t_dense); w.ulm_inf = wk.add(8 * t_ulm * L * L); w.valid = wk.add(4 * t_valid); w.first_fail = wk.add(4 * t_valid); w.hf_ok = wk.add(4 * t_ulm); w.bp_ok = wk.add(t_bp); w.bf_ok = wk.add(t_bf); w.ulm_inf_valid = wk.add(t_ulm);
 	w.results = wk.add(sizeof(srba_lm_result) * n); w.lambda_io = wk.add(8 * n); w.chi2 = wk.add(8 * n); w.notpd = wk.add(4 * n); w.phase_cycles = wk.add(8 * 16 * (size_t)n);
 	wk.add(0);
 	if (in.size + 256 > c->cap_in) { if (c->d_in) hipFree(c->d_in); c->d_in = nullptr; c->cap_in = 0; const size_t want = (in.size + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_in, want)); c->cap_in = want; }
@@ -622,15 +718,15 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	Batch &B = c->B; std::memset(&B, 0, sizeof(B)); B.n_prob = n; B.max_lds_doubles = 0;
 	char *di = c->d_in, *dw = c->d_wk;
 #define DI(field, T) B.field = (const T *)(di + o.field)
-	B.desc = (const ProbDesc *)(di + o.desc); DI(order, int); DI(sp_col_off, int); DI(sp_row, int); DI(sp_item_off, int); DI(sp_tgt, int); DI(sp_perm, int); DI(hap_dst, int); DI(hapf_dst, int); DI(hf_dst, int); DI(edge0, double); DI(ulm0, double); DI(klm, double); DI(obs_z, double);
+	B.desc = (const ProbDesc *)(di + o.desc); DI(order, int); DI(sp_col_off, int); DI(sp_row, int); DI(sp_item_off, int); DI(sp_tgt, int); DI(sp_ab, int); DI(sp_rptr, int); DI(sp_rcol, int); DI(sp_rblk, int); DI(sp_perm, int); DI(hap_dst, int); DI(hapf_dst, int); DI(hf_dst, int); DI(edge0, double); DI(ulm0, double); DI(klm, double); DI(obs_z, double);
 	DI(pair_path_off, int); DI(path_edge, int); DI(obs_pose, int); DI(obs_lm, int); DI(obs_valid, int); DI(bp_col, int); DI(bp_res, int); DI(bp_A, int); DI(bp_D, int); DI(bp_lm, int); DI(colp_off, int);
 	DI(bf_col, int); DI(bf_res, int); DI(bf_pose, int); DI(colf_off, int); DI(hap_i, int); DI(hap_j, int); DI(hap_term_off, int); DI(hap_t1, int); DI(hap_t2, int); DI(hf_i, int); DI(hf_j, int); DI(hf_term_off, int); DI(hf_t1, int); DI(hf_t2, int);
 	DI(hapf_i, int); DI(hapf_j, int); DI(hapf_term_off, int); DI(hapf_t1, int); DI(hapf_t2, int); DI(hap_diag, int); DI(hf_diag, int); DI(sch_term_off, int); DI(sch_b1, int); DI(sch_b2, int); DI(sch_lm, int); DI(sch_yw, int);
-	DI(lm_hapf_off, int); DI(lm_hapf_idx, int); DI(req_idx, int); DI(pair_needed, unsigned char); DI(bp_normal, unsigned char);
+	DI(lm_hapf_off, int); DI(lm_hapf_idx, int); DI(req_idx, int); DI(need_idx, int); DI(pair_needed, unsigned char); DI(bp_normal, unsigned char);
 #undef DI
 #define DW(field, T) B.field = (T *)(dw + w.field)
 	DW(edge, double); DW(ulm, double); DW(pose, double); DW(Jp, double); DW(Jf, double); DW(resid, double); DW(resid2, double); DW(HAp, double); DW(HAp0, double); DW(Hf, double); DW(HApf, double); DW(grad, double); DW(delta, double);
-	DW(Hfinv, double); DW(YW, double); DW(old_edge, double); DW(old_ulm, double); DW(old_pose, double); DW(dense, double); DW(ulm_inf, double); DW(valid, int); DW(first_fail, int); DW(hf_ok, int); DW(ulm_inf_valid, unsigned char);
+	DW(Hfinv, double); DW(YW, double); DW(old_edge, double); DW(old_ulm, double); DW(old_pose, double); DW(dense, double); DW(ulm_inf, double); DW(valid, int); DW(first_fail, int); DW(hf_ok, int); DW(bp_ok, unsigned char); DW(bf_ok, unsigned char); DW(ulm_inf_valid, unsigned char);
 	DW(results, srba_lm_result); DW(lambda_io, double); DW(chi2, double); DW(notpd, int);
 	c->off_phase = w.phase_cycles; B.phase_cycles = c->phase_timing ? (long long *)(dw + w.phase_cycles) : nullptr;
 #undef DW
@@ -688,6 +784,7 @@ template <class K> static int allow_big_lds(srba_hip_ctx *c, K kernel, size_t by
 }
 static int prep_lds(srba_hip_ctx *c, bool for_lm) {
 	size_t b = 0; for (int k = 0; k < SRBA_NCLS; k++) if (c->cls_count[k]) b = std::max(b, c->cls_lds[k]);
+	b += c->lds_pad;
 	if (b <= 64 * 1024) return 0;
 	switch (c->params.family) {
 #define CASE(F) case F: return for_lm ? allow_big_lds(c, srbadev::k_lm_run<F, true>, b) : allow_big_lds(c, srbadev::k_solve<F, true>, b);
@@ -696,6 +793,10 @@ static int prep_lds(srba_hip_ctx *c, bool for_lm) {
 	}
 	return -1;
 }
+
+// The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable when it initialises: ask for 8
+// (one per concurrent launch stream of the plan) unless the user chose a value. No effect if the process already initialised HIP.
+__attribute__((constructor)) static void srba_hip_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 extern "C" {
 
@@ -706,17 +807,16 @@ int srba_hip_lm_run_async(srba_hip_ctx *c) {
 	HIPCHK(c, hipSetDevice(c->device));
 	if (prep_lds(c, true) != 0) return -1;
 	HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-	// fork: the most populated class stays on the main stream, the others run beside it (their tails overlap), then join
-	int main_cls = 0; for (int k = 1; k < SRBA_NCLS; k++) if (c->cls_count[k] > c->cls_count[main_cls]) main_cls = k;
+	// fork/join: the launch plan (made at upload) spreads the size classes over a few streams; see plan_launches()
+	const int nq = c->n_streams_used;
 	HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-	for (int k = SRBA_NCLS - 1; k >= 0; k--) if (c->cls_count[k] && k != main_cls) { // big systems first
-		hipStream_t launch_stream = c->cls_stream[k ? k : main_cls]; // class 0 borrows the (idle) stream slot of the main class when it is not the main one
-		HIPCHK(c, hipStreamWaitEvent(launch_stream, c->ev_fork, 0));
-		SRBA_DISPATCH_LDS(c, k_lm_run, k < SRBA_NCLS - 1, c->cls_count[k], c->cls_lds[k], c->cls_first[k]); HIPCHK(c, hipGetLastError());
-		HIPCHK(c, hipEventRecord(c->cls_done[k ? k : main_cls], launch_stream));
+	for (int q = 1; q < nq; q++) HIPCHK(c, hipStreamWaitEvent(c->cls_stream[q], c->ev_fork, 0));
+	for (size_t j = 0; j < c->plan.size(); j++) {
+		const LaunchJob &J = c->plan[j]; const int k = J.cls;
+		hipStream_t launch_stream = J.queue ? c->cls_stream[J.queue] : c->stream;
+		SRBA_DISPATCH_LDS(c, k_lm_run, k < SRBA_NCLS - 1, J.count, c->cls_lds[k] + c->lds_pad, J.first); HIPCHK(c, hipGetLastError());
 	}
-	{ hipStream_t launch_stream = c->stream; SRBA_DISPATCH_LDS(c, k_lm_run, main_cls < SRBA_NCLS - 1, c->cls_count[main_cls], c->cls_lds[main_cls], c->cls_first[main_cls]); HIPCHK(c, hipGetLastError()); }
-	for (int k = 0; k < SRBA_NCLS; k++) if (c->cls_count[k] && k != main_cls) HIPCHK(c, hipStreamWaitEvent(c->stream, c->cls_done[k ? k : main_cls], 0));
+	for (int q = 1; q < nq; q++) { HIPCHK(c, hipEventRecord(c->cls_done[q], c->cls_stream[q])); HIPCHK(c, hipStreamWaitEvent(c->stream, c->cls_done[q], 0)); }
 	HIPCHK(c, hipEventRecord(c->ev1, c->stream));
 	return 0;
 }
@@ -773,8 +873,13 @@ int srba_hip_download_state(srba_hip_ctx *c, srba_problem_capsule *caps, int n) 
 	return 0;
 }
 
-int64_t srba_hip_debug_size(srba_hip_ctx *c, int what) { if (c && what == 10) return c->phase_timing ? 16 * (int64_t)c->n_prob : 0; return (c && what >= 0 && what < 10) ? c->len_dbg[what] : -1; }
+int64_t srba_hip_debug_size(srba_hip_ctx *c, int what) { if (c && what == 10) return c->phase_timing ? 16 * (int64_t)c->n_prob : 0; if (c && what == 11) return 4 * (int64_t)c->n_prob; return (c && what >= 0 && what < 10) ? c->len_dbg[what] : -1; }
 int srba_hip_debug_read(srba_hip_ctx *c, int what, double *out, int64_t n_doubles) {
+	if (c && what == 11) { // per-capsule solver shape: [LDS bytes reserved by its launch, nb, off-diagonal blocks, block updates per factorisation]
+		if (n_doubles < 4 * (int64_t)c->n_prob) return -1;
+		for (int p = 0; p < c->n_prob; p++) { const ProbDesc &d = c->desc[p]; out[4 * p] = (double)c->cls_lds[c->cls_of[p]]; out[4 * p + 1] = d.nb; out[4 * p + 2] = d.nnzoff; out[4 * p + 3] = d.n_items; }
+		return 0;
+	}
 	if (c && what == 10) { // per-capsule phase cycle counters (100 MHz wall clock ticks), as doubles
 		if (!c->phase_timing) return -1;
 		std::vector<long long> v(16 * (size_t)c->n_prob); HIPCHK(c, hipMemcpyAsync(v.data(), c->d_wk + c->off_phase, 8 * v.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
