@@ -20,6 +20,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The launch plan of libsrba_hip runs its size classes on 8 streams; the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues
+# (default 4) and reads the variable when it initialises, i.e. before torch touches the device.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def algorithmic_bytes(stats, res, P, L, O, PD, relpose):
@@ -44,6 +47,21 @@ def algorithmic_bytes(stats, res, P, L, O, PD, relpose):
     k11 = per["n_unk_edges"] * 2 * pb + per["n_unk_lms"] * 2 * L * 8
     total = (k1_init + relin * (k2 + hwrite) + (1 + solves_ok) * k4 + grad_evals * k5 + res["num_trials"] * k9 + solves_ok * (k1_trial + k11))
     return float(total.sum())
+
+
+def measured_traffic(n_kf, n_capsules):
+    """HBM bytes per fused launch from the committed PMC passes (profiles/r*_pmc_traffic.json, tools/gpu_round.sh) of THIS workload, else None:
+    rocprofv3 counters cannot be collected from inside the timed process."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
+        try:
+            t = json.load(open(f))
+            if t["workload"]["n_kf"] == n_kf and t["workload"]["capsules"] == n_capsules:
+                best = float(t["traffic_bytes_per_launch"])
+        except Exception:
+            pass
+    return best
 
 
 def per_problem_counts(batch, family):
@@ -77,29 +95,26 @@ def main():
     ap.add_argument("--cache-dir", default="/tmp/srba_bench_cache", help="keep the harvested capsules here so that a second invocation (e.g. under rocprofv3) skips the sequential SLAM run; '' disables")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import numpy as np
     import torch
+    from srba_amd import multi
+    rank, world, local_rank = multi.rank_info()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    dist = multi.init_process_group("nccl")  # RCCL; used for the barrier and the sum/max of the result line only
 
     import __graft_entry__ as ge
     ge.build()
     from srba_amd import capi, datasets, runner
 
     t0 = time.time()
-    ds = datasets.graph_slam_se2(n_kf=args.n_kf, seed=1 + rank, path="tour")
+    ds = datasets.graph_slam_se2(n_kf=args.n_kf, seed=multi.replica_seed(rank), path="tour")
     t_gen = time.time() - t0
     t0 = time.time()
     # The drop-in path: the header-only RbaEngine<> front-end with the GPU back-end, keyframe by keyframe (srba-slam --se2 --graph-slam
     # --submap-size 10 --max-spanning-tree-depth 3 --max-optimize-depth 3 --noise 0.001 --noise-ang 0.2, README.md:65-71), harvesting capsules.
-    cache = os.path.join(args.cache_dir, "caps_se2_tour_%d_seed%d.bin" % (args.n_kf, 1 + rank)) if args.cache_dir else None
+    cache = os.path.join(args.cache_dir, "caps_se2_tour_%d_seed%d.bin" % (args.n_kf, multi.replica_seed(rank))) if args.cache_dir else None
     if cache and os.path.exists(cache):
         batch = runner.CapsuleBatch.load(cache)   # same capsules, harvested by an earlier invocation on this box
     else:
@@ -118,30 +133,20 @@ def main():
     obs_trials_per_step = int((res["num_trials"] * res["num_observations"]).sum())
     for _ in range(args.warmup):
         lib.srba_hip_reset_state(ctx.ctx); lib.srba_hip_lm_run_async(ctx.ctx)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    kern_ms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    def step():
         lib.srba_hip_reset_state(ctx.ctx)
         lib.srba_hip_lm_run_async(ctx.ctx)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    # kernel-only duration with HIP events on the context's stream (one extra, untimed, synchronous launch per sample)
-    for _ in range(min(5, max(1, args.steps))):
-        lib.srba_hip_reset_state(ctx.ctx); lib.srba_hip_lm_run(ctx.ctx, None); kern_ms.append(lib.srba_hip_last_kernel_ms(ctx.ctx))
-    kernel_ms = float(np.mean(kern_ms))
 
-    tot_trials = trials_per_step; tot_obs = obs_trials_per_step; max_elapsed = elapsed
-    if dist is not None:
-        t = torch.tensor([float(trials_per_step), float(obs_trials_per_step)], device="cuda", dtype=torch.float64); dist.all_reduce(t)
-        m = torch.tensor([elapsed], device="cuda", dtype=torch.float64); dist.all_reduce(m, op=dist.ReduceOp.MAX)
-        tot_trials, tot_obs, max_elapsed = int(t[0].item()), int(t[1].item()), float(m[0].item())
+    def device_sync():
+        lib.srba_hip_sync(ctx.ctx)   # the library launches on its own (non-blocking) stream ...
+        torch.cuda.synchronize()     # ... and the contract asks for torch.cuda.synchronize() around the timed region
+    elapsed = multi.timed_region(dist, device_sync, step, args.steps)
+    # duration of the fused launches OF THE TIMED REGION, from the HIP events the library records on its own stream around every launch
+    hist = (C.c_double * 64)(); nh = lib.srba_hip_kernel_ms_history(ctx.ctx, hist, min(64, args.steps))
+    kern_ms = [hist[i] for i in range(max(nh, 0))]
+    kernel_ms = float(np.mean(kern_ms)) if kern_ms else float("nan")
+
+    tot_trials, tot_obs, max_elapsed = multi.aggregate(dist, "cuda", trials_per_step, obs_trials_per_step, elapsed)
 
     if rank == 0:
         stats = ctx.stats(); stats["per_problem"] = per_problem_counts(batch, batch.family)
@@ -162,10 +167,10 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "world-2d-30k relative graph-SLAM, SE2 graph-slam, submap=10 depth=3: %d keyframes per GPU -> %d optimize_local_area capsules per GPU, re-optimised per step" % (args.n_kf, batch.n),
                        "keyframes_per_gpu": args.n_kf, "capsules_per_gpu": batch.n, "lm_trials_per_step_per_gpu": trials_per_step, "obs_per_s": tot_obs * args.steps / max_elapsed,
-                       "parallelism": "replicas x%d (independent maps, no collective)" % world, "solver": "no-Schur, dense LL^t on device (reference: CSparse)",
+                       "parallelism": "replicas x%d (independent maps, no collective)" % world, "solver": "no-Schur, block-sparse LL^t in LDS, symbolic factorisation on the host (reference: CSparse)",
                        "setup_s": {"dataset": round(t_gen, 2), "sequential_slam_harvest_gpu_backend": round(t_harvest, 2)}},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                         "kernel": "k_lm_run<SE2_RELPOSE2D>", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": measured_traffic(args.n_kf, batch.n),
+                         "kernel": "k_lm_run<SE2_RELPOSE2D> (one launch per LDS size class, concurrent; duration = fork..join)", "kernel_ms": kernel_ms, "kernel_ms_samples": len(kern_ms), "algorithmic_bytes_per_launch": abytes},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -259,6 +259,9 @@ int  srba_hip_batch_stats(srba_hip_ctx *ctx, srba_batch_stats *out);
 
 /* Time (ms) spent inside the last srba_hip_lm_run* kernel launch, measured with HIP events on the context stream. */
 double srba_hip_last_kernel_ms(srba_hip_ctx *ctx);
+/* Durations (ms, most recent first) of the last `n` srba_hip_lm_run / srba_hip_lm_run_async launches: HIP events recorded on the context
+ * stream around the launch (fork to join of the size-class kernels). Synchronises the stream; returns how many were written (<= 64). */
+int    srba_hip_kernel_ms_history(srba_hip_ctx *ctx, double *out_ms, int n);
 
 #ifdef __cplusplus
 }

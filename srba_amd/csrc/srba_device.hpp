@@ -246,9 +246,9 @@ __device__ __forceinline__ void panel3(const double *Ab, const Chol3 &c, double 
 	}
 }
 // Factor in place and overwrite rhs with y = L^-1 rhs. Returns false (uniformly) if not positive definite.
-//   step k : every lane refactors the 3x3 diagonal block (no broadcast); update items (a>=b) of column k recompute the two panel blocks
-//            they need and subtract L_ak L_bk^t from their precomputed target block; then the panel blocks are overwritten by L_ak and
-//            the right-hand side is eliminated (forward substitution fused).
+//   step k : every lane refactors the 3x3 diagonal block (no broadcast); the panel lanes overwrite A_ak by L_ak and eliminate the
+//            right-hand side (forward substitution fused); then the update items (a>=b) of column k subtract L_ak L_bk^t from their
+//            precomputed target block.
 template <bool DLDS> __device__ __forceinline__ bool sp_factor_fsub(const SparseSys &S) {
 	const int lane = threadIdx.x;
 	int cb = S.col_off[0], ib = 0;
@@ -258,19 +258,6 @@ template <bool DLDS> __device__ __forceinline__ bool sp_factor_fsub(const Sparse
 		Chol3 c;
 		if (!chol3(D, c)) return false;
 		const double y0 = S.rhs[3 * k] * c.r0, y1 = (S.rhs[3 * k + 1] - c.l10 * y0) * c.r1, y2 = (S.rhs[3 * k + 2] - c.l20 * y0 - c.l21 * y1) * c.r2;
-		for (int t = lane; t < nitems; t += SRBA_WG) { // trailing update: target -= L_ak L_bk^t
-			int a, b; double *T;
-			if constexpr (DLDS) { const unsigned w = (unsigned)S.item[ib + t]; a = (w >> 9) & 511; b = w & 511; T = S.diag + 9 * (w >> 18); }
-			else { const int tg = S.item[ib + t], ab = S.item_ab[ib + t]; a = ab >> 16; b = ab & 0xffff; T = tg >= 0 ? S.off + 9 * tg : S.diag + 9 * (-1 - tg); }
-			double La[9], Lb[9];
-			panel3(S.off + 9 * (cb + a), c, La);
-			panel3(S.off + 9 * (cb + b), c, Lb);
-#pragma unroll
-			for (int rr = 0; rr < 3; rr++)
-#pragma unroll
-				for (int q = 0; q < 3; q++) T[rr * 3 + q] -= La[rr * 3] * Lb[q * 3] + La[rr * 3 + 1] * Lb[q * 3 + 1] + La[rr * 3 + 2] * Lb[q * 3 + 2];
-		}
-		solver_sync<DLDS>();
 		for (int a = lane; a < cn; a += SRBA_WG) { // panel: A_ak -> L_ak ; rhs_a -= L_ak y_k
 			double *Ab = S.off + 9 * (cb + a); double Lp[9];
 			panel3(Ab, c, Lp);
@@ -283,6 +270,20 @@ template <bool DLDS> __device__ __forceinline__ bool sp_factor_fsub(const Sparse
 		if (lane == SRBA_WG - 1) { // L_kk, reciprocal diagonal in the unused upper part, y_k
 			D[0] = c.l00; D[3] = c.l10; D[4] = c.l11; D[6] = c.l20; D[7] = c.l21; D[8] = c.l22; D[1] = c.r0; D[2] = c.r1; D[5] = c.r2;
 			S.rhs[3 * k] = y0; S.rhs[3 * k + 1] = y1; S.rhs[3 * k + 2] = y2;
+		}
+		solver_sync<DLDS>();
+		for (int t = lane; t < nitems; t += SRBA_WG) { // trailing update: target -= L_ak L_bk^t
+			int a, b; double *T;
+			if constexpr (DLDS) { const unsigned w = (unsigned)S.item[ib + t]; a = (w >> 9) & 511; b = w & 511; T = S.diag + 9 * (w >> 18); }
+			else { const int tg = S.item[ib + t], ab = S.item_ab[ib + t]; a = ab >> 16; b = ab & 0xffff; T = tg >= 0 ? S.off + 9 * tg : S.diag + 9 * (-1 - tg); }
+			const double *La = S.off + 9 * (cb + a), *Lb = S.off + 9 * (cb + b);
+			double la[9], lb[9], tv[9];
+#pragma unroll
+			for (int q = 0; q < 9; q++) { la[q] = La[q]; lb[q] = Lb[q]; tv[q] = T[q]; }
+#pragma unroll
+			for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+				for (int q = 0; q < 3; q++) T[rr * 3 + q] = tv[rr * 3 + q] - (la[rr * 3] * lb[q * 3] + la[rr * 3 + 1] * lb[q * 3 + 1] + la[rr * 3 + 2] * lb[q * 3 + 2]);
 		}
 		solver_sync<DLDS>();
 		cb = ce; ib += nitems;

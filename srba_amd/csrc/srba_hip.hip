@@ -454,6 +454,7 @@ static inline int slice_begin(int cnt, int q, int nq) { return q * (cnt / nq) + 
 struct srba_hip_ctx {
 	int device = 0; srba_hip_params params; DevParams dp; FamDims dm;
 	hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	static constexpr int kRing = 64; hipEvent_t ring0[kRing] = {nullptr}, ring1[kRing] = {nullptr}; long long n_launches = 0; // event pairs of the last launches (srba_hip_kernel_ms_history)
 	hipStream_t cls_stream[SRBA_NCLS] = {nullptr}; hipEvent_t ev_fork = nullptr, cls_done[SRBA_NCLS] = {nullptr}; // size classes run concurrently
 	std::string error;
 	// batch
@@ -565,7 +566,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_LDS_PAD"); c->lds_pad = e ? (size_t)atol(e) : 0; } // diagnostics: extra LDS bytes per workgroup (lowers residency)
 	{ const char *e = getenv("SRBA_HIP_SCHED"); if (e) c->sched = atoi(e); } // tuning knob: launch plan (see plan_launches)
 	{ const char *e = getenv("SRBA_HIP_QUEUES"); if (e && atoi(e) >= 1 && atoi(e) < SRBA_NCLS) c->n_queues = atoi(e); } // tuning knob: concurrent launch streams
-	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
+	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || false) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
 	for (int k = 1; k < SRBA_NCLS && ok; k++) ok = hipStreamCreateWithFlags(&c->cls_stream[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->cls_done[k], hipEventDisableTiming) == hipSuccess;
 	if (!ok) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
@@ -583,7 +584,8 @@ int srba_hip_destroy(srba_hip_ctx *c) {
 	if (!c) return 0;
 	hipSetDevice(c->device);
 	if (c->d_in) hipFree(c->d_in); if (c->d_wk) hipFree(c->d_wk);
-	if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1); if (c->ev_fork) hipEventDestroy(c->ev_fork);
+	for (int i = 0; i < srba_hip_ctx::kRing; i++) { if (c->ring0[i]) hipEventDestroy(c->ring0[i]); if (c->ring1[i]) hipEventDestroy(c->ring1[i]); }
+	if (c->ev_fork) hipEventDestroy(c->ev_fork);
 	for (int k = 1; k < SRBA_NCLS; k++) { if (c->cls_done[k]) hipEventDestroy(c->cls_done[k]); if (c->cls_stream[k]) hipStreamDestroy(c->cls_stream[k]); }
 	if (c->stream) hipStreamDestroy(c->stream);
 	delete c; return 0;
@@ -591,6 +593,17 @@ int srba_hip_destroy(srba_hip_ctx *c) {
 
 void *srba_hip_stream(srba_hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
 double srba_hip_last_kernel_ms(srba_hip_ctx *c) { return c ? c->last_ms : 0.0; }
+int srba_hip_kernel_ms_history(srba_hip_ctx *c, double *out_ms, int n) {
+	if (!c || !out_ms || n < 0) return -1;
+	if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+	const int have = (int)std::min<long long>(std::min<long long>(n, c->n_launches), srba_hip_ctx::kRing);
+	for (int i = 0; i < have; i++) { // most recent first
+		const int slot = (int)((c->n_launches - 1 - i) % srba_hip_ctx::kRing); float ms = 0;
+		if (hipEventElapsedTime(&ms, c->ring0[slot], c->ring1[slot]) != hipSuccess) return i;
+		out_ms[i] = ms;
+	}
+	return have;
+}
 
 int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, int n) {
 	if (!c || !caps || n <= 0) { if (c) c->fail("upload: bad arguments"); return -1; }
@@ -806,6 +819,9 @@ int srba_hip_lm_run_async(srba_hip_ctx *c) {
 	if (!c || !c->n_prob) { if (c) c->fail("lm_run: no batch uploaded"); return -1; }
 	HIPCHK(c, hipSetDevice(c->device));
 	if (prep_lds(c, true) != 0) return -1;
+	{ const int slot = (int)(c->n_launches % srba_hip_ctx::kRing);
+	  if (!c->ring0[slot]) { HIPCHK(c, hipEventCreate(&c->ring0[slot])); HIPCHK(c, hipEventCreate(&c->ring1[slot])); }
+	  c->ev0 = c->ring0[slot]; c->ev1 = c->ring1[slot]; c->n_launches++; }
 	HIPCHK(c, hipEventRecord(c->ev0, c->stream));
 	// fork/join: the launch plan (made at upload) spreads the size classes over a few streams; see plan_launches()
 	const int nq = c->n_streams_used;
