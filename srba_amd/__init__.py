@@ -5,8 +5,8 @@ The product is native code: the HIP kernels + C ABI in `srba_amd/csrc` (-> `lib/
 This Python package is only a ctypes driver used by `tests/` and `bench.py`.
 """
 import os as _os
-# the launch plan of libsrba_hip uses 8 concurrent streams; the HIP runtime reads this when it initialises (see srba_hip.hip)
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# the launch plan of libsrba_hip uses 16 concurrent streams; the HIP runtime reads this when it initialises (see srba_hip.hip)
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 from . import capi  # noqa: F401,E402
 
 __all__ = ["capi", "datasets", "runner"]

@@ -337,24 +337,37 @@ struct Worker {
 	__device__ void phase_spantree(bool only_needed) { fresh();
 		constexpr int U = T::SE3 ? 2 : 4; // path edges fetched together (their loads do not depend on the running composition)
 		const int cnt = only_needed ? d.n_need : d.n_pairs;
-		for (int q = tid; q < cnt; q += SRBA_WG) {
-			const int p = only_needed ? B.need_idx[d.o_pair + q] : q;
-			const int b = B.pair_path_off[d.o_ppoff + p], e = B.pair_path_off[d.o_ppoff + p + 1];
-			int pe[U]; pose_t ed[U];
+		constexpr int V = T::SE3 ? 1 : 2; // pairs per lane and pass (all their loads are issued before the first store)
+		for (int q0 = tid; q0 < cnt; q0 += V * SRBA_WG) {
+			int p[V], pe[V][U], b[V], e[V]; pose_t ed[V][U], acc[V];
 #pragma unroll
-			for (int u = 0; u < U; u++) pe[u] = (b + u < e) ? B.path_edge[d.o_path + b + u] : -1;
+			for (int v = 0; v < V; v++) { const int q = q0 + v * SRBA_WG; p[v] = q < cnt ? (only_needed ? B.need_idx[d.o_pair + q] : q) : -1; }
 #pragma unroll
-			for (int u = 0; u < U; u++) if (pe[u] >= 0) ed[u] = PO::ld(B.edge + (d.o_edge + (pe[u] >> 1)) * PD);
-			pose_t acc = PO::ident();
+			for (int v = 0; v < V; v++) { b[v] = e[v] = 0; if (p[v] >= 0) { b[v] = B.pair_path_off[d.o_ppoff + p[v]]; e[v] = B.pair_path_off[d.o_ppoff + p[v] + 1]; } }
 #pragma unroll
-			for (int u = 0; u < U; u++) if (pe[u] >= 0) acc = (pe[u] & 1) ? comp(acc, inv(ed[u])) : comp(acc, ed[u]);
-			for (int k = b + U; k < e; k++) {
-				const int pk = B.path_edge[d.o_path + k];
-				const pose_t ek = PO::ld(B.edge + (d.o_edge + (pk >> 1)) * PD);
-				acc = (pk & 1) ? comp(acc, inv(ek)) : comp(acc, ek);
+			for (int v = 0; v < V; v++)
+#pragma unroll
+				for (int u = 0; u < U; u++) pe[v][u] = (b[v] + u < e[v]) ? B.path_edge[d.o_path + b[v] + u] : -1;
+#pragma unroll
+			for (int v = 0; v < V; v++)
+#pragma unroll
+				for (int u = 0; u < U; u++) if (pe[v][u] >= 0) ed[v][u] = PO::ld(B.edge + (d.o_edge + (pe[v][u] >> 1)) * PD);
+#pragma unroll
+			for (int v = 0; v < V; v++) {
+				acc[v] = PO::ident();
+#pragma unroll
+				for (int u = 0; u < U; u++) if (pe[v][u] >= 0) acc[v] = (pe[v][u] & 1) ? comp(acc[v], inv(ed[v][u])) : comp(acc[v], ed[v][u]);
+				for (int k = b[v] + U; k < e[v]; k++) {
+					const int pk = B.path_edge[d.o_path + k];
+					const pose_t ek = PO::ld(B.edge + (d.o_edge + (pk >> 1)) * PD);
+					acc[v] = (pk & 1) ? comp(acc[v], inv(ek)) : comp(acc[v], ek);
+				}
 			}
-			PO::st(B.pose + (d.o_pair + p) * 2 * PD, acc);
-			PO::st(B.pose + ((d.o_pair + p) * 2 + 1) * PD, inv(acc));
+#pragma unroll
+			for (int v = 0; v < V; v++) if (p[v] >= 0) {
+				PO::st(B.pose + (d.o_pair + p[v]) * 2 * PD, acc[v]);
+				PO::st(B.pose + ((d.o_pair + p[v]) * 2 + 1) * PD, inv(acc[v]));
+			}
 		}
 	}
 
@@ -627,12 +640,27 @@ struct Worker {
 			for (int k = 0; k < M; k++) acc[k] = 0;
 			if (live) {
 				const int bb = col_off[i], be = col_off[i + 1];
-				for (int b = bb + sub; b < be; b += S) {
-					const double *A = J + (long long)b * O * M, *r = resid + (long long)(d.o_obs + res[b]) * O;
-					double lr[O];
-					if (prm.noise == SRBA_NOISE_CONSTANT_MATRIX) { for (int k = 0; k < O; k++) { double s = 0; for (int j = 0; j < O; j++) s += prm.lambda[k * O + j] * r[j]; lr[k] = s; } }
-					else for (int k = 0; k < O; k++) lr[k] = r[k];
-					for (int q = 0; q < M; q++) { double s = 0; for (int k = 0; k < O; k++) s += A[k * M + q] * lr[k]; acc[q] += s; }
+				constexpr int U = (O * M <= 9) ? 4 : 2; // blocks in flight per lane (their loads do not depend on the running sum)
+				for (int b0 = bb + sub; b0 < be; b0 += U * S) {
+					double A[U][O * M], lr[U][O];
+#pragma unroll
+					for (int u = 0; u < U; u++) {
+						const int b = b0 + u * S;
+						if (b < be) {
+							const double *Ab = J + (long long)b * O * M, *r = resid + (long long)(d.o_obs + res[b]) * O;
+#pragma unroll
+							for (int k = 0; k < O * M; k++) A[u][k] = Ab[k];
+#pragma unroll
+							for (int k = 0; k < O; k++) lr[u][k] = r[k];
+						}
+					}
+#pragma unroll
+					for (int u = 0; u < U; u++) {
+						if (b0 + u * S < be) {
+							if (prm.noise == SRBA_NOISE_CONSTANT_MATRIX) { double t[O]; for (int k = 0; k < O; k++) { double q = 0; for (int j = 0; j < O; j++) q += prm.lambda[k * O + j] * lr[u][j]; t[k] = q; } for (int k = 0; k < O; k++) lr[u][k] = t[k]; }
+							for (int q = 0; q < M; q++) { double sm = 0; for (int k = 0; k < O; k++) sm += A[u][k * M + q] * lr[u][k]; acc[q] += sm; }
+						}
+					}
 				}
 			}
 			for (int m = 1; m < S; m *= 2) {

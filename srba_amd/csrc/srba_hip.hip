@@ -218,7 +218,20 @@ struct Solver : public Worker<FAM> {
 			PO::st(e, np);
 		}
 		for (int k = tid; k < d.nF * L; k += SRBA_WG) { B.old_ulm[d.o_ulm * L + k] = B.ulm[d.o_ulm * L + k]; B.ulm[d.o_ulm * L + k] += dl[d.nK * P + k]; }
-		for (int r = tid; r < d.n_req; r += SRBA_WG) { const double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD; double *o = B.old_pose + (d.o_req + r) * PD; for (int k = 0; k < PD; k++) o[k] = s[k]; }
+		for (int r = tid; r < d.n_req; r += 2 * SRBA_WG) { // two poses per lane and pass: both loads before the stores
+			const int r2 = r + SRBA_WG; const bool two = r2 < d.n_req;
+			const double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD, *s2 = two ? B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r2]) * PD : s;
+			double v[PD], v2[PD];
+#pragma unroll
+			for (int k = 0; k < PD; k++) { v[k] = s[k]; v2[k] = s2[k]; }
+			double *o = B.old_pose + (d.o_req + r) * PD, *o2 = B.old_pose + (d.o_req + r2) * PD;
+#pragma unroll
+			for (int k = 0; k < PD; k++) o[k] = v[k];
+			if (two) {
+#pragma unroll
+				for (int k = 0; k < PD; k++) o2[k] = v2[k];
+			}
+		}
 		__syncthreads();
 	}
 	__device__ void restore() { this->fresh(); // optimize_edges.h:664-680
@@ -461,7 +474,7 @@ struct srba_hip_ctx {
 	int n_prob = 0; std::vector<ProbDesc> desc; Batch B; srba_batch_stats stats;
 	char *d_in = nullptr; size_t cap_in = 0; char *d_wk = nullptr; size_t cap_wk = 0;
 	std::vector<char> h_in; // host staging of the input arena
-	int n_queues = 8, sched = 1, n_streams_used = 1; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
+	int n_queues = 16, sched = 1, n_streams_used = 1; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
 	// offsets needed for downloads (bytes inside the wk arena)
 	size_t off_edge = 0, off_ulm = 0, off_pose = 0, off_inf = 0, off_infv = 0, off_res = 0;
 	size_t off_dbg[10] = {0}; int64_t len_dbg[10] = {0};
@@ -478,7 +491,9 @@ struct srba_hip_ctx {
 //   sched 2: one stream per class, biggest first
 static void plan_launches(srba_hip_ctx *c, const int32_t *ord) {
 	c->plan.clear(); const int nq = c->n_queues;
-	auto cost_of = [&](int first, int count) { double s = 0; for (int i = 0; i < count; i++) s += c->desc[ord[first + i]].nb + 4; return s; };
+	// cost of a chunk ~ sum over its capsules of (system size) x (LDS footprint): a trial takes time ~ nb, and how many capsules run at once
+	// is set by the LDS they hold (measured on the benchmark: 43 us per loop-closure window vs 5.5 us per typical window, chip-wide)
+	auto cost_of = [&](int cls, int first, int count) { const double w = cls == SRBA_NCLS - 1 ? 24.0 : std::max(1.0, (double)c->cls_lds[cls] / 8192.0); double s = 0; for (int i = 0; i < count; i++) s += (c->desc[ord[first + i]].nb + 4) * w; return s; };
 	if (c->sched == 2) {
 		int q = 0;
 		for (int k = SRBA_NCLS - 1; k >= 0; k--) if (c->cls_count[k]) { c->plan.push_back({q, k, c->cls_first[k], c->cls_count[k], 0.0}); q++; }
@@ -495,8 +510,8 @@ static void plan_launches(srba_hip_ctx *c, const int32_t *ord) {
 	}
 	std::vector<LaunchJob> jobs;
 	for (int k = SRBA_NCLS - 1; k >= 0; k--) if (c->cls_count[k]) {
-		const int cnt = c->cls_count[k], parts = std::max(1, std::min(nq, cnt / 512));
-		for (int q = 0; q < parts; q++) { const int a = slice_begin(cnt, q, parts), b = slice_begin(cnt, q + 1, parts); if (b > a) jobs.push_back({0, k, c->cls_first[k] + a, b - a, cost_of(c->cls_first[k] + a, b - a)}); }
+		const int cnt = c->cls_count[k], parts = std::max(1, std::min(2 * nq, cnt / 384));
+		for (int q = 0; q < parts; q++) { const int a = slice_begin(cnt, q, parts), b = slice_begin(cnt, q + 1, parts); if (b > a) jobs.push_back({0, k, c->cls_first[k] + a, b - a, cost_of(k, c->cls_first[k] + a, b - a)}); }
 	}
 	std::vector<size_t> by_cost(jobs.size()); for (size_t i = 0; i < jobs.size(); i++) by_cost[i] = i;
 	std::stable_sort(by_cost.begin(), by_cost.end(), [&](size_t a, size_t b) { return jobs[a].cost > jobs[b].cost; });
@@ -807,9 +822,9 @@ static int prep_lds(srba_hip_ctx *c, bool for_lm) {
 	return -1;
 }
 
-// The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable when it initialises: ask for 8
+// The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable when it initialises: ask for 16
 // (one per concurrent launch stream of the plan) unless the user chose a value. No effect if the process already initialised HIP.
-__attribute__((constructor)) static void srba_hip_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+__attribute__((constructor)) static void srba_hip_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 extern "C" {
 

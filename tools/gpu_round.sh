@@ -2,7 +2,7 @@
 # One GPU session: parity tests, the full benchmark, a rocprofv3 kernel trace of the same command, and two PMC passes (HBM bytes).
 # Summaries land in gpurun_out/ ; copy the ones to keep into profiles/.
 set -x
-export GPU_MAX_HW_QUEUES=8
+export GPU_MAX_HW_QUEUES=16
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1
