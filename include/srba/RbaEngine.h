@@ -38,6 +38,8 @@ struct numeric_backend {
 	/** Optimise the capsule in place (unknowns, ST poses, landmark information matrices) and fill the result. Throws on failure. */
 	virtual void run(const srba_hip_params &params, srba_problem_capsule &capsule, srba_lm_result &result) = 0;
 	virtual const char *name() const = 0;
+	/** Optional: where to record the back-end's own stage timings ("opt.backend.*"). */
+	virtual void set_profiler(mrpt::utils::CTimeLogger *) {}
 };
 /** Adapter over a plain C function (used by tests to plug the CPU oracle in from outside the product). */
 struct function_backend : public numeric_backend {
@@ -866,6 +868,7 @@ protected:
 		srba_problem_capsule cap = cd.view();
 		srba_lm_result res; std::memset(&res, 0, sizeof(res));
 		if (!m_backend) m_backend = make_hip_backend(m_hip_device);
+		m_backend->set_profiler(&m_profiler);
 		m_profiler.enter("opt.backend");
 		m_backend->run(hp, cap, res);
 		m_profiler.leave("opt.backend");

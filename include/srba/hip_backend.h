@@ -11,7 +11,7 @@ namespace srba {
 
 class hip_backend : public numeric_backend {
 public:
-	explicit hip_backend(int device) : m_ctx(NULL), m_device(device) { std::memset(&m_params, 0, sizeof(m_params)); }
+	explicit hip_backend(int device) : m_ctx(NULL), m_device(device), m_prof(NULL) { std::memset(&m_params, 0, sizeof(m_params)); }
 	~hip_backend() { if (m_ctx) srba_hip_destroy(m_ctx); }
 	const char *name() const { return "hip-gfx950"; }
 	void run(const srba_hip_params &p, srba_problem_capsule &c, srba_lm_result &r) {
@@ -22,14 +22,19 @@ public:
 		} else if (std::memcmp(&m_params, &p, sizeof(p)) != 0) {
 			check(srba_hip_set_params(m_ctx, &p), "srba_hip_set_params"); m_params = p;
 		}
+		if (m_prof) m_prof->enter("opt.backend.upload");
 		check(srba_hip_upload_problems(m_ctx, &c, 1), "srba_hip_upload_problems");
+		if (m_prof) { m_prof->leave("opt.backend.upload"); m_prof->enter("opt.backend.lm_run"); }
 		check(srba_hip_lm_run(m_ctx, &r), "srba_hip_lm_run");
+		if (m_prof) { m_prof->leave("opt.backend.lm_run"); m_prof->registerUserMeasure("opt.backend.lm_run.kernel", 1e-3 * srba_hip_last_kernel_ms(m_ctx)); m_prof->enter("opt.backend.download"); }
 		check(srba_hip_download_state(m_ctx, &c, 1), "srba_hip_download_state");
+		if (m_prof) m_prof->leave("opt.backend.download");
 	}
+	void set_profiler(mrpt::utils::CTimeLogger *p) { m_prof = p; }
 	srba_hip_ctx *context() { return m_ctx; }
 private:
 	void check(int rc, const char *what) { if (rc != 0) throw std::runtime_error(std::string("srba::hip_backend: ") + what + " failed: " + srba_hip_last_error(m_ctx)); }
-	srba_hip_ctx *m_ctx; int m_device; srba_hip_params m_params;
+	srba_hip_ctx *m_ctx; int m_device; srba_hip_params m_params; mrpt::utils::CTimeLogger *m_prof;
 };
 
 inline std::shared_ptr<numeric_backend> make_hip_backend(int device) { return std::shared_ptr<numeric_backend>(new hip_backend(device)); }

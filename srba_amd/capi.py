@@ -123,6 +123,7 @@ def engine_lib():
         lib.srba_engine_create.argtypes = [C.POINTER(EngineConfig)]; lib.srba_engine_create.restype = C.c_void_p
         lib.srba_engine_destroy.argtypes = [C.c_void_p]; lib.srba_engine_destroy.restype = None
         lib.srba_engine_last_error.argtypes = [C.c_void_p]; lib.srba_engine_last_error.restype = C.c_char_p
+        lib.srba_engine_profiler_mean.argtypes = [C.c_void_p, C.c_char_p]; lib.srba_engine_profiler_mean.restype = c_f64
         lib.srba_engine_set_backend_fn.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
         lib.srba_engine_add_keyframe.argtypes = [C.c_void_p, c_i32, C.POINTER(C.c_uint64), PF64, PU8, PF64, C.POINTER(KfInfo)]
         lib.srba_engine_optimize_local_area.argtypes = [C.c_void_p, C.c_uint64, C.c_uint, C.POINTER(KfInfo)]

@@ -22,4 +22,8 @@ for pad_kb in [int(x) for x in os.environ.get('OCC_PADS', '0,4,8,12,16,24,32,48,
     shp = ctx.debug(11).reshape(copies, 4)
     lds = shp[0, 0] + pad_kb * 1024
     print("LDS/WG %6.1f KB -> %2d WG/CU by LDS: kernel %.2f ms, %d trials, %.2f M trials/s, per-CU-resident-wave rate %.1f trials/ms" % (lds / 1024, int(160 * 1024 // lds), kms, r["num_trials"].sum(), r["num_trials"].sum() / kms / 1e3, r["num_trials"].sum() / kms / 256 / max(1, int(160 * 1024 // lds))))
+    if os.environ.get("SRBA_HIP_PHASE_TIMING") == "1":
+        pc = ctx.debug(10).reshape(copies, 16).sum(axis=0); tr = r["num_trials"].sum() * 2  # two runs accumulated
+        names = ["K1all", "jac", "hess", "resid", "grad", "solve", "apply", "K1need", "restore", "schur", "assemble", "factor", "bsub", "feat"]
+        print("   us/trial:", " ".join("%s %.1f" % (names[k], pc[k] * 1e-2 / tr) for k in range(14)), "| sum %.1f" % (pc[:9].sum() * 1e-2 / tr))
     del ctx
