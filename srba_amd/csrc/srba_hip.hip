@@ -592,6 +592,7 @@ int srba_hip_set_params(srba_hip_ctx *c, const srba_hip_params *params) {
 	if (!c) return -1;
 	if (check_params(params) != 0) { c->fail(g_last_error); return -1; }
 	if (params->family != c->params.family) { c->fail("srba_hip_set_params: the family of a context cannot change"); return -1; }
+	if (c->n_prob && (params->solver != c->params.solver || params->noise != c->params.noise)) c->n_prob = 0; // the uploaded batch was laid out for the old solver / noise policy: upload again
 	c->params = *params; make_dev_params(*params, c->dp, c->dm); return 0;
 }
 
