@@ -40,6 +40,8 @@ struct numeric_backend {
 	virtual const char *name() const = 0;
 	/** Optional: where to record the back-end's own stage timings ("opt.backend.*"). */
 	virtual void set_profiler(mrpt::utils::CTimeLogger *) {}
+	/** Whole-map squared error over prepared path lists (eval_overall_squared_error). */
+	virtual double eval_overall(const srba_hip_params &, const srba_overall_problem &) { throw std::runtime_error(std::string("numeric back-end '") + name() + "' does not implement eval_overall"); }
 };
 /** Adapter over a plain C function (used by tests to plug the CPU oracle in from outside the product). */
 struct function_backend : public numeric_backend {
@@ -48,6 +50,9 @@ struct function_backend : public numeric_backend {
 	function_backend(fn_t f, const std::string &n) : fn(f), nm(n) {}
 	void run(const srba_hip_params &p, srba_problem_capsule &c, srba_lm_result &r) { if (fn(&p, &c, &r) != 0) throw std::runtime_error("numeric back-end '" + nm + "' failed"); }
 	const char *name() const { return nm.c_str(); }
+	typedef int (*overall_fn_t)(const srba_hip_params *, const srba_overall_problem *, double *);
+	overall_fn_t overall_fn = NULL;
+	double eval_overall(const srba_hip_params &p, const srba_overall_problem &q) { double v = 0; if (!overall_fn || overall_fn(&p, &q, &v) != 0) throw std::runtime_error("numeric back-end '" + nm + "': eval_overall failed or not provided"); return v; }
 };
 std::shared_ptr<numeric_backend> make_hip_backend(int device); // srba/hip_backend.h
 
@@ -536,6 +541,67 @@ public:
 	/** Called with every capsule right before it is optimised (pre-optimisation values): capsule harvesting for batch replay. */
 	std::function<void(const srba_hip_params &, CapsuleData &)> on_capsule;
 
+
+	/** Squared error of ALL observations of the map with the current estimate (impl/eval_overall_error.h:15-137).
+	  * Host: for every root = min(observer, base) a breadth-first search over the k2k graph (impl/spantree_create_complete.h:18-126; stopped as
+	  * soon as every wanted target has been discovered -- the paths found are those of the complete search) gives the edge path to each target;
+	  * the numeric back-end composes the poses along the paths and evaluates the residuals (GPU: srba_hip_eval_overall_sqr_error). */
+	double eval_overall_squared_error() const {
+		m_profiler.enter("eval_overall_squared_error");
+		const size_t nObs = rba_state.all_observations.size();
+		if (!nObs) { m_profiler.leave("eval_overall_squared_error"); return 0; }
+		std::map<TKeyFrameID, std::set<TKeyFrameID> > ob_pairs; // minimum id first (:29-38)
+		for (size_t i = 0; i < nObs; i++) { const k2f_edge_t &o = rba_state.all_observations[i]; const TKeyFrameID a = o.obs.kf_id, b = o.feat_rel_pos->id_frame_base; if (a != b) ob_pairs[std::min(a, b)].insert(std::max(a, b)); }
+		// pairs + paths
+		std::map<std::pair<TKeyFrameID, TKeyFrameID>, int32_t> pair_index; // (root, target) -> pair
+		std::vector<int32_t> pair_path_off(1, 0), path_edge;
+		std::vector<TKeyFrameID> prev(rba_state.keyframes.size()); std::vector<const k2k_edge_t *> via(rba_state.keyframes.size()); std::vector<char> seen(rba_state.keyframes.size(), 0); std::vector<TKeyFrameID> touched;
+		for (typename std::map<TKeyFrameID, std::set<TKeyFrameID> >::const_iterator it1 = ob_pairs.begin(); it1 != ob_pairs.end(); ++it1) {
+			const TKeyFrameID root = it1->first; size_t missing = it1->second.size();
+			std::queue<TKeyFrameID> pending; pending.push(root); seen[root] = 1; touched.clear(); touched.push_back(root);
+			while (!pending.empty() && missing) {
+				const TKeyFrameID cur = pending.front(); pending.pop();
+				const typename rba_problem_state_t::keyframe_info &kfi = rba_state.keyframes[cur];
+				for (size_t i = 0; i < kfi.adjacent_k2k_edges.size() && missing; i++) {
+					const k2k_edge_t *ed = kfi.adjacent_k2k_edges[i]; const TKeyFrameID nk = getTheOtherFromPair2(cur, *ed);
+					if (seen[nk]) continue;
+					seen[nk] = 1; touched.push_back(nk); prev[nk] = cur; via[nk] = ed; pending.push(nk);
+					if (it1->second.count(nk)) missing--;
+				}
+			}
+			for (typename std::set<TKeyFrameID>::const_iterator itT = it1->second.begin(); itT != it1->second.end(); ++itT) {
+				if (!seen[*itT]) { for (size_t k = 0; k < touched.size(); k++) seen[touched[k]] = 0; throw std::runtime_error("eval_overall_squared_error: an observation relates two key-frames that are not connected"); }
+				std::vector<int32_t> rev; // leaf -> root
+				for (TKeyFrameID k = *itT; k != root; k = prev[k]) { const k2k_edge_t *ed = via[k]; rev.push_back((int32_t)((ed->id << 1) | (ed->to == k ? 1 : 0))); } // parent->me edge: my pose = parent (+) (-inv_pose) (:111-116)
+				pair_index[std::make_pair(root, *itT)] = (int32_t)pair_path_off.size() - 1;
+				path_edge.insert(path_edge.end(), rev.rbegin(), rev.rend()); pair_path_off.push_back((int32_t)path_edge.size());
+			}
+			for (size_t k = 0; k < touched.size(); k++) seen[touched[k]] = 0;
+		}
+		// observations + landmark table
+		std::vector<int32_t> obs_pose(nObs), obs_lm(nObs); std::vector<double> obs_z(nObs * OBS_DIMS), lm_pos;
+		typedef std::map<const void *, int32_t> lm_index_t; lm_index_t lm_index;
+		for (size_t i = 0; i < nObs; i++) {
+			const k2f_edge_t &o = rba_state.all_observations[i]; const TKeyFrameID a = o.obs.kf_id, b = o.feat_rel_pos->id_frame_base;
+			// pose of the base as seen from the observer: root==observer -> stored pose of the target; root==base -> its inverse (:68-71)
+			obs_pose[i] = a == b ? -1 : (a < b ? 2 * pair_index[std::make_pair(a, b)] : 2 * pair_index[std::make_pair(b, a)] + 1);
+			lm_index_t::const_iterator itL = lm_index.find((const void *)o.feat_rel_pos);
+			if (itL == lm_index.end()) { itL = lm_index.insert(std::make_pair((const void *)o.feat_rel_pos, (int32_t)(lm_pos.size() / LM_DIMS))).first; for (size_t k = 0; k < LM_DIMS; k++) lm_pos.push_back(o.feat_rel_pos->pos[k]); }
+			obs_lm[i] = itL->second;
+			for (size_t k = 0; k < OBS_DIMS; k++) obs_z[i * OBS_DIMS + k] = o.obs.obs_arr[k];
+		}
+		std::vector<double> edge_pose(rba_state.k2k_edges.size() * pose_t::storage_doubles());
+		for (size_t e = 0; e < rba_state.k2k_edges.size(); e++) rba_state.k2k_edges[e].inv_pose.storeTo(&edge_pose[e * pose_t::storage_doubles()]);
+		srba_overall_problem q; std::memset(&q, 0, sizeof(q));
+		q.n_edges = (int32_t)rba_state.k2k_edges.size(); q.n_pairs = (int32_t)pair_path_off.size() - 1; q.n_path = (int32_t)path_edge.size(); q.n_obs = (int32_t)nObs; q.n_lms = (int32_t)(lm_pos.size() / LM_DIMS);
+		q.edge_pose = edge_pose.data(); q.pair_path_off = pair_path_off.data(); q.path_edge = path_edge.data(); q.obs_pose = obs_pose.data(); q.obs_lm = obs_lm.data(); q.obs_z = obs_z.data(); q.lm_pos = lm_pos.data();
+		srba_hip_params hp; fill_hip_params(hp);
+		if (!m_backend) m_backend = make_hip_backend(m_hip_device);
+		const double sqerr = m_backend->eval_overall(hp, q);
+		m_profiler.leave("eval_overall_squared_error");
+		return sqerr;
+	}
+
 	/** Fill the back-end parameter block from `parameters` (what the reference hot loops read from RbaEngine::parameters). */
 	void fill_hip_params(srba_hip_params &hp) const {
 		std::memset(&hp, 0, sizeof(hp));
@@ -896,7 +962,7 @@ protected:
 private:
 	rba_problem_state_t rba_state;
 	mutable mrpt::utils::CTimeLogger m_profiler;
-	std::shared_ptr<numeric_backend> m_backend;
+	mutable std::shared_ptr<numeric_backend> m_backend;
 	int m_hip_device;
 };
 

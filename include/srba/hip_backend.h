@@ -14,7 +14,7 @@ public:
 	explicit hip_backend(int device) : m_ctx(NULL), m_device(device), m_prof(NULL) { std::memset(&m_params, 0, sizeof(m_params)); }
 	~hip_backend() { if (m_ctx) srba_hip_destroy(m_ctx); }
 	const char *name() const { return "hip-gfx950"; }
-	void run(const srba_hip_params &p, srba_problem_capsule &c, srba_lm_result &r) {
+	void ensure(const srba_hip_params &p) {
 		if (!m_ctx) {
 			m_ctx = srba_hip_create(m_device, &p);
 			if (!m_ctx) throw std::runtime_error(std::string("srba::hip_backend: cannot create the HIP context: ") + srba_hip_last_error(NULL));
@@ -22,6 +22,9 @@ public:
 		} else if (std::memcmp(&m_params, &p, sizeof(p)) != 0) {
 			check(srba_hip_set_params(m_ctx, &p), "srba_hip_set_params"); m_params = p;
 		}
+	}
+	void run(const srba_hip_params &p, srba_problem_capsule &c, srba_lm_result &r) {
+		ensure(p);
 		if (m_prof) m_prof->enter("opt.backend.upload");
 		check(srba_hip_upload_problems(m_ctx, &c, 1), "srba_hip_upload_problems");
 		if (m_prof) { m_prof->leave("opt.backend.upload"); m_prof->enter("opt.backend.lm_run"); }
@@ -31,6 +34,10 @@ public:
 		if (m_prof) m_prof->leave("opt.backend.download");
 	}
 	void set_profiler(mrpt::utils::CTimeLogger *p) { m_prof = p; }
+	double eval_overall(const srba_hip_params &p, const srba_overall_problem &q) {
+		ensure(p);
+		double v = 0; check(srba_hip_eval_overall_sqr_error(m_ctx, &q, &v), "srba_hip_eval_overall_sqr_error"); return v;
+	}
 	srba_hip_ctx *context() { return m_ctx; }
 private:
 	void check(int rc, const char *what) { if (rc != 0) throw std::runtime_error(std::string("srba::hip_backend: ") + what + " failed: " + srba_hip_last_error(m_ctx)); }

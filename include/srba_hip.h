@@ -236,6 +236,23 @@ int  srba_hip_lm_run_async(srba_hip_ctx *ctx);
 int  srba_hip_sync(srba_hip_ctx *ctx);
 void *srba_hip_stream(srba_hip_ctx *ctx);   /* hipStream_t the kernels are launched on */
 
+/* ---- whole-map squared error: RbaEngine<>::eval_overall_squared_error() (impl/eval_overall_error.h:15-137) ----
+ * The host front-end lists, for every distinct (observer KF, base KF) pair of the map, the breadth-first path between the two key-frames
+ * (impl/spantree_create_complete.h:18-126; root = the smaller id) and every observation of the map; the device composes the poses along
+ * the paths (root towards the leaf, same association order as the reference) and evaluates sum ||z - h(pose (+) landmark)||^2 without
+ * robust kernel. All arrays are host pointers, copied per call; the context's family / sensor parameters apply. */
+typedef struct srba_overall_problem {
+	int32_t n_edges, n_pairs, n_path, n_obs, n_lms, reserved;
+	const double  *edge_pose;      /* [n_edges * PD] inv_pose of every kf2kf edge */
+	const int32_t *pair_path_off;  /* [n_pairs + 1] CSR into path_edge */
+	const int32_t *path_edge;      /* [n_path] (edge << 1) | use_inverse, in composition order from the root of the pair */
+	const int32_t *obs_pose;       /* [n_obs] 2*pair (pose of the leaf seen from the root) or 2*pair+1 (its inverse); -1 = identity */
+	const int32_t *obs_lm;         /* [n_obs] index into lm_pos */
+	const double  *obs_z;          /* [n_obs * O] */
+	const double  *lm_pos;         /* [n_lms * L] landmark position relative to its base key-frame */
+} srba_overall_problem;
+int  srba_hip_eval_overall_sqr_error(srba_hip_ctx *ctx, const srba_overall_problem *prob, double *sqr_error_out);
+
 /* ---- read back ---- */
 /* Writes unknown edge poses / landmark positions / ST poses / ulm_inf back into the arrays of the SAME capsule
  * structs (host pointers) that describe the batch layout (optimize_edges.h:526,538 write in place in the reference). */

@@ -873,6 +873,19 @@ void stage_one(const srba_hip_params &p, srba_problem_capsule &c, int do_solve, 
 	if (scalars) { scalars[0] = chi2; scalars[1] = 1e-3 * mx; scalars[2] = not_pd; scalars[3] = ninv; }
 }
 
+/* Whole-map squared error (impl/eval_overall_error.h:15-137) on the path lists prepared by the front-end: poses composed from the root of
+ * every pair towards the leaf (impl/spantree_create_complete.h:96-124), then sum ||z - h||^2 without robust kernel (:116-129). */
+template <int FAM> static double overall_error(const srba_hip_params &p, const srba_overall_problem &q) {
+	srba_hip_params pp = p; pp.use_robust_kernel = 0;
+	srba_problem_capsule cap; std::memset(&cap, 0, sizeof(cap));
+	cap.n_edges = q.n_edges; cap.edge_pose = const_cast<double *>(q.edge_pose); cap.n_pairs = q.n_pairs; cap.n_path = q.n_path;
+	cap.pair_path_off = const_cast<int32_t *>(q.pair_path_off); cap.path_edge = const_cast<int32_t *>(q.path_edge);
+	cap.n_obs = q.n_obs; cap.obs_pose = const_cast<int32_t *>(q.obs_pose); cap.obs_z = const_cast<double *>(q.obs_z);
+	std::vector<int32_t> lmref(q.n_obs); for (int i = 0; i < q.n_obs; i++) lmref[i] = -1 - q.obs_lm[i]; // landmarks enter as the capsule's known-landmark table
+	cap.obs_lm = lmref.data(); cap.n_known_lms = q.n_lms; cap.klm_pos = const_cast<double *>(q.lm_pos);
+	Problem<FAM> P(pp, cap); P.update_spantree(false);
+	std::vector<double> res; return P.residuals(res);
+}
 } // namespace
 
 extern "C" {
@@ -893,6 +906,17 @@ int srba_oracle_run_one(const srba_hip_params *params, srba_problem_capsule *cap
 	if (!params || !cap || !result) return -1;
 	dispatch_run(*params, *cap, *result);
 	return result->status < 0 ? -1 : 0;
+}
+
+int srba_oracle_eval_overall(const srba_hip_params *p, const srba_overall_problem *q, double *out) {
+	if (!p || !q || !out) return -1;
+	switch (p->family) {
+		case SRBA_SE2_RELPOSE2D: *out = overall_error<SRBA_SE2_RELPOSE2D>(*p, *q); break; case SRBA_SE2_RB2D: *out = overall_error<SRBA_SE2_RB2D>(*p, *q); break;
+		case SRBA_SE2_CART2D: *out = overall_error<SRBA_SE2_CART2D>(*p, *q); break; case SRBA_SE3_STEREO: *out = overall_error<SRBA_SE3_STEREO>(*p, *q); break;
+		case SRBA_SE3_MONO: *out = overall_error<SRBA_SE3_MONO>(*p, *q); break; case SRBA_SE3_CART3D: *out = overall_error<SRBA_SE3_CART3D>(*p, *q); break;
+		default: return -1;
+	}
+	return 0;
 }
 
 int srba_oracle_stage(const srba_hip_params *p, srba_problem_capsule *c, int do_solve, double lambda,

@@ -124,6 +124,8 @@ def engine_lib():
         lib.srba_engine_destroy.argtypes = [C.c_void_p]; lib.srba_engine_destroy.restype = None
         lib.srba_engine_last_error.argtypes = [C.c_void_p]; lib.srba_engine_last_error.restype = C.c_char_p
         lib.srba_engine_profiler_mean.argtypes = [C.c_void_p, C.c_char_p]; lib.srba_engine_profiler_mean.restype = c_f64
+        lib.srba_engine_set_overall_fn.argtypes = [C.c_void_p, C.c_void_p]
+        lib.srba_engine_eval_overall_sqr_error.argtypes = [C.c_void_p, C.POINTER(c_f64)]
         lib.srba_engine_set_backend_fn.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
         lib.srba_engine_add_keyframe.argtypes = [C.c_void_p, c_i32, C.POINTER(C.c_uint64), PF64, PU8, PF64, C.POINTER(KfInfo)]
         lib.srba_engine_optimize_local_area.argtypes = [C.c_void_p, C.c_uint64, C.c_uint, C.POINTER(KfInfo)]
@@ -134,6 +136,8 @@ def engine_lib():
         lib.srba_engine_st_dump.argtypes = [C.c_void_p, c_i32, C.POINTER(C.c_int64), C.c_int64]; lib.srba_engine_st_dump.restype = C.c_int64
         lib.srba_engine_get_rel_pose.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, PF64]
         lib.srba_engine_profiler_mean.argtypes = [C.c_void_p, C.c_char_p]; lib.srba_engine_profiler_mean.restype = c_f64
+        lib.srba_engine_set_overall_fn.argtypes = [C.c_void_p, C.c_void_p]
+        lib.srba_engine_eval_overall_sqr_error.argtypes = [C.c_void_p, C.POINTER(c_f64)]
         lib.srba_engine_alloc_keyframe.argtypes = [C.c_void_p]; lib.srba_engine_alloc_keyframe.restype = C.c_uint64
         lib.srba_engine_create_edge.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, PF64]; lib.srba_engine_create_edge.restype = C.c_int64
         lib.srba_engine_harvest_count.argtypes = [C.c_void_p]; lib.srba_engine_harvest_count.restype = C.c_int64

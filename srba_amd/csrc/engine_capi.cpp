@@ -51,6 +51,8 @@ struct EngineBase {
 	virtual int64_t st_dump(int what, int64_t *out, int64_t cap) const = 0;
 	virtual int get_rel_pose(uint64_t query, uint64_t reference, double *pose) const = 0;
 	virtual double profiler_mean(const char *name) const = 0;
+	virtual int eval_overall(double *out) = 0;
+	std::shared_ptr<function_backend> fn_backend; // set when a C function was plugged in
 	virtual uint64_t alloc_keyframe() = 0;
 	virtual int64_t create_edge(uint64_t new_kf, uint64_t from, uint64_t to, const double *pose) = 0;
 };
@@ -140,6 +142,7 @@ struct EngineImpl : public EngineBase {
 	}
 	int get_rel_pose(uint64_t query, uint64_t reference, double *pose) const { const typename rba_t::pose_t *p = rba.get_kf_relative_pose(query, reference); if (!p) return -1; p->storeTo(pose); return 0; }
 	double profiler_mean(const char *name) const { return const_cast<rba_t &>(rba).get_time_profiler().getMeanTime(name); }
+	int eval_overall(double *out) { try { *out = rba.eval_overall_squared_error(); return 0; } catch (std::exception &e) { error = e.what(); return -1; } }
 	uint64_t alloc_keyframe() { return rba.alloc_keyframe(); }
 	int64_t create_edge(uint64_t new_kf, uint64_t from, uint64_t to, const double *pose) {
 		try { typename rba_t::pose_t p; if (pose) p.loadFrom(pose); typename rba_t::new_kf_observations_t dummy; return (int64_t)rba.create_kf2kf_edge(new_kf, TPairKeyFrameID(from, to), dummy, p); }
@@ -214,8 +217,11 @@ void *srba_engine_create(const srba_engine_config *c) {
 void srba_engine_destroy(void *h) { delete static_cast<EngineBase *>(h); }
 const char *srba_engine_last_error(void *h) { return h ? static_cast<EngineBase *>(h)->error.c_str() : g_error.c_str(); }
 int srba_engine_set_backend_fn(void *h, srba_backend_fn fn, const char *name) {
-	static_cast<EngineBase *>(h)->set_backend(std::shared_ptr<numeric_backend>(new function_backend(fn, name ? name : "external"))); return 0;
+	EngineBase *e = static_cast<EngineBase *>(h);
+	e->fn_backend.reset(new function_backend(fn, name ? name : "external")); e->set_backend(e->fn_backend); return 0;
 }
+int srba_engine_set_overall_fn(void *h, srba_overall_fn fn) { EngineBase *e = static_cast<EngineBase *>(h); if (!e->fn_backend) { e->error = "set_overall_fn: plug a back-end function first"; return -1; } e->fn_backend->overall_fn = fn; return 0; }
+int srba_engine_eval_overall_sqr_error(void *h, double *out) { return static_cast<EngineBase *>(h)->eval_overall(out); }
 int srba_engine_add_keyframe(void *h, int n_obs, const uint64_t *feat_id, const double *z, const uint8_t *flags, const double *relpos, srba_kf_info *out) {
 	return static_cast<EngineBase *>(h)->add_keyframe(n_obs, feat_id, z, flags, relpos, out);
 }

@@ -44,6 +44,11 @@ void *srba_engine_create(const srba_engine_config *c);
 void  srba_engine_destroy(void *h);
 const char *srba_engine_last_error(void *h);
 int   srba_engine_set_backend_fn(void *h, srba_backend_fn fn, const char *name);
+/* optional second entry point of a plugged back-end: whole-map squared error (include/srba_hip.h: srba_overall_problem) */
+typedef int (*srba_overall_fn)(const srba_hip_params *, const srba_overall_problem *, double *);
+int   srba_engine_set_overall_fn(void *h, srba_overall_fn fn);
+/* RbaEngine<>::eval_overall_squared_error() (impl/eval_overall_error.h:15-137) */
+int   srba_engine_eval_overall_sqr_error(void *h, double *out);
 /* flags[i]: bit0 is_fixed, bit1 is_unknown_with_init_val (srba_types.h:473-495); z: n_obs x O; relpos: n_obs x L or NULL */
 int   srba_engine_add_keyframe(void *h, int n_obs, const uint64_t *feat_id, const double *z, const uint8_t *flags, const double *relpos, srba_kf_info *out);
 int   srba_engine_optimize_local_area(void *h, uint64_t root, unsigned win, srba_kf_info *out);

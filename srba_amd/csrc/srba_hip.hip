@@ -364,6 +364,33 @@ template <int FAM, bool DLDS> __global__ void __launch_bounds__(SRBA_WG) k_solve
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_apply(const Batch B, const DevParams prm) { Solver<FAM> S(B, B.desc[blockIdx.x], prm); S.apply_update(); }
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_rollback(const Batch B, const DevParams prm) { Solver<FAM> S(B, B.desc[blockIdx.x], prm); S.restore(); }
 
+// ---- whole-map squared error (eval_overall_error.h:15-137): a plain streaming pair of kernels over ONE problem (desc[0]), grid-stride
+// K1 over all (observer, base) pairs: compose the breadth-first path from the root of the pair (spantree_create_complete.h:96-124)
+template <int FAM> __global__ void __launch_bounds__(256) k_overall_pairs(const Batch B, const DevParams prm) {
+	typedef Worker<FAM> W; typedef typename W::PO PO; typedef typename W::pose_t pose_t; constexpr int PD = W::PD;
+	const ProbDesc &d = B.desc[0];
+	for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < d.n_pairs; p += gridDim.x * blockDim.x) {
+		pose_t acc = PO::ident();
+		for (int k = B.pair_path_off[p]; k < B.pair_path_off[p + 1]; k++) {
+			const int pe = B.path_edge[k]; const pose_t ed = PO::ld(B.edge + (long long)(pe >> 1) * PD);
+			acc = (pe & 1) ? comp(acc, inv(ed)) : comp(acc, ed);
+		}
+		PO::st(B.pose + (long long)p * 2 * PD, acc); PO::st(B.pose + ((long long)p * 2 + 1) * PD, inv(acc));
+	}
+}
+// K4 over all observations; one partial sum per workgroup (fixed order -> deterministic), summed by the host
+template <int FAM> __global__ void __launch_bounds__(256) k_overall_residuals(const Batch B, const DevParams prm, double *partial) {
+	Worker<FAM> Wk(B, B.desc[0], prm); constexpr int O = Worker<FAM>::O;
+	const ProbDesc &d = B.desc[0];
+	double acc = 0;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.n_obs; i += gridDim.x * blockDim.x) { double r[O]; acc += Wk.residual_row(i, r); }
+	__shared__ double sh[4];
+	const double v = wave_sum(acc);
+	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+	__syncthreads();
+	if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
 } // namespace srbadev
 
 // =================================================================================================== host side
@@ -851,6 +878,51 @@ int srba_hip_lm_run_async(srba_hip_ctx *c) {
 	for (int q = 1; q < nq; q++) { HIPCHK(c, hipEventRecord(c->cls_done[q], c->cls_stream[q])); HIPCHK(c, hipStreamWaitEvent(c->stream, c->cls_done[q], 0)); }
 	HIPCHK(c, hipEventRecord(c->ev1, c->stream));
 	return 0;
+}
+
+int srba_hip_eval_overall_sqr_error(srba_hip_ctx *c, const srba_overall_problem *q, double *out) {
+	if (!c || !q || !out) return -1;
+	if (q->n_edges < 0 || q->n_pairs < 0 || q->n_obs < 0 || q->n_lms < 0 || (q->n_obs > 0 && (!q->obs_pose || !q->obs_lm || !q->obs_z)) || (q->n_pairs > 0 && (!q->pair_path_off || (q->n_path > 0 && !q->path_edge)))) { c->fail("eval_overall_sqr_error: malformed problem"); return -1; }
+	*out = 0; if (q->n_obs == 0) return 0;
+	HIPCHK(c, hipSetDevice(c->device));
+	const int L = c->dm.L, O = c->dm.O, PD = c->dm.PD, PDX = c->dm.PDX();
+	for (int i = 0; i < q->n_obs; i++) if (q->obs_pose[i] >= 2 * q->n_pairs || q->obs_lm[i] < 0 || q->obs_lm[i] >= q->n_lms) { c->fail("eval_overall_sqr_error: observation index out of range"); return -1; }
+	for (int k = 0; k < q->n_path; k++) if ((q->path_edge[k] >> 1) >= q->n_edges || q->path_edge[k] < 0) { c->fail("eval_overall_sqr_error: path edge out of range"); return -1; }
+	// one host arena -> one H2D copy
+	Arena in; const size_t o_desc = in.add(sizeof(ProbDesc)), o_edge = in.add(8 * (size_t)q->n_edges * PDX), o_ppo = in.add(4 * ((size_t)q->n_pairs + 1)), o_path = in.add(4 * (size_t)std::max(q->n_path, 1)),
+		o_op = in.add(4 * (size_t)q->n_obs), o_ol = in.add(4 * (size_t)q->n_obs), o_z = in.add(8 * (size_t)q->n_obs * O), o_lm = in.add(8 * (size_t)std::max(q->n_lms, 1) * L);
+	const int nblk = std::min(1024, (q->n_obs + 255) / 256);
+	Arena wk; const size_t o_pose = wk.add(8 * 2 * (size_t)std::max(q->n_pairs, 1) * PDX), o_part = wk.add(8 * (size_t)nblk);
+	std::vector<char> h(in.size, 0);
+	ProbDesc d; std::memset(&d, 0, sizeof(d)); d.n_edges = q->n_edges; d.n_pairs = q->n_pairs; d.n_obs = q->n_obs; d.nF = q->n_lms;
+	std::memcpy(h.data() + o_desc, &d, sizeof(d));
+	{ double *e = (double *)(h.data() + o_edge);
+	  for (int i = 0; i < q->n_edges; i++) { const double *s = q->edge_pose + (size_t)i * PD; double *t = e + (size_t)i * PDX; for (int k = 0; k < PD; k++) t[k] = s[k]; if (PDX == 5) { t[3] = std::cos(s[2]); t[4] = std::sin(s[2]); } } }
+	if (q->n_pairs) std::memcpy(h.data() + o_ppo, q->pair_path_off, 4 * ((size_t)q->n_pairs + 1));
+	if (q->n_path) std::memcpy(h.data() + o_path, q->path_edge, 4 * (size_t)q->n_path);
+	std::memcpy(h.data() + o_op, q->obs_pose, 4 * (size_t)q->n_obs); std::memcpy(h.data() + o_ol, q->obs_lm, 4 * (size_t)q->n_obs);
+	std::memcpy(h.data() + o_z, q->obs_z, 8 * (size_t)q->n_obs * O); if (q->n_lms) std::memcpy(h.data() + o_lm, q->lm_pos, 8 * (size_t)q->n_lms * L);
+	char *di = nullptr, *dw = nullptr;
+	HIPCHK(c, hipMalloc(&di, in.size)); if (hipMalloc(&dw, wk.size) != hipSuccess) { hipFree(di); c->fail("eval_overall_sqr_error: hipMalloc failed"); return -1; }
+	int rc = 0; std::vector<double> part(nblk, 0.0);
+	do {
+		if (hipMemcpyAsync(di, h.data(), in.size, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = -1; break; }
+		Batch B; std::memset(&B, 0, sizeof(B)); B.n_prob = 1;
+		B.desc = (const ProbDesc *)(di + o_desc); B.edge = (double *)(di + o_edge); B.pair_path_off = (const int *)(di + o_ppo); B.path_edge = (const int *)(di + o_path);
+		B.obs_pose = (const int *)(di + o_op); B.obs_lm = (const int *)(di + o_ol); B.obs_z = (const double *)(di + o_z); B.ulm = (double *)(di + o_lm); B.pose = (double *)(dw + o_pose);
+		DevParams dp = c->dp; dp.use_robust_kernel = 0; // the reference sums plain squared norms (eval_overall_error.h:129)
+		const int pblk = std::max(1, std::min(1024, (q->n_pairs + 255) / 256));
+#define CASE(F) case F: if (q->n_pairs) hipLaunchKernelGGL((srbadev::k_overall_pairs<F>), dim3(pblk), dim3(256), 0, c->stream, B, dp); \
+		hipLaunchKernelGGL((srbadev::k_overall_residuals<F>), dim3(nblk), dim3(256), 0, c->stream, B, dp, (double *)(dw + o_part)); break;
+		switch (c->params.family) { CASE(SRBA_SE2_RELPOSE2D) CASE(SRBA_SE2_RB2D) CASE(SRBA_SE2_CART2D) CASE(SRBA_SE3_STEREO) CASE(SRBA_SE3_MONO) CASE(SRBA_SE3_CART3D) }
+#undef CASE
+		if (hipGetLastError() != hipSuccess) { rc = -1; break; }
+		if (hipMemcpyAsync(part.data(), dw + o_part, 8 * (size_t)nblk, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rc = -1; break; }
+	} while (0);
+	hipFree(di); hipFree(dw);
+	if (rc != 0) { c->fail("eval_overall_sqr_error: HIP error"); return -1; }
+	double s = 0; for (int b = 0; b < nblk; b++) s += part[b];
+	*out = s; return 0;
 }
 int srba_hip_download_results(srba_hip_ctx *c, srba_lm_result *results, int n) {
 	if (!c || !results || n > c->n_prob) return -1;

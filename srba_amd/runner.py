@@ -53,6 +53,7 @@ class Engine(object):
             ora = capi.oracle_lib()
             fn = C.cast(ora.srba_oracle_run_one, C.c_void_p)
             self.lib.srba_engine_set_backend_fn(self.h, fn, b"cpu-oracle")
+            self.lib.srba_engine_set_overall_fn(self.h, C.cast(ora.srba_oracle_eval_overall, C.c_void_p))
         elif backend != "hip":
             raise ValueError(backend)
 
@@ -108,6 +109,13 @@ class Engine(object):
         if self.lib.srba_engine_get_rel_pose(self.h, query, reference, buf) != 0:
             return None
         return np.array(list(buf))
+
+    def eval_overall_squared_error(self):
+        """RbaEngine<>::eval_overall_squared_error(): squared error of every observation of the map with the current estimate"""
+        v = C.c_double()
+        if self.lib.srba_engine_eval_overall_sqr_error(self.h, C.byref(v)) != 0:
+            raise RuntimeError(self.lib.srba_engine_last_error(self.h).decode())
+        return v.value
 
     def harvest(self):
         return CapsuleBatch(self)

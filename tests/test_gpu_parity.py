@@ -112,3 +112,24 @@ def test_engine_with_hip_backend_submaps_loop_closure():
             assert info.lc_observer[0] != inv or info.lc_observer[1] != inv
             assert info.num_observations > 1 and info.obs_rmse < 1e-6
     assert seen_lc
+
+
+@pytest.mark.gpu
+def test_eval_overall_squared_error_hip_vs_oracle():
+    """srba_hip_eval_overall_sqr_error (K1 + K4 over the whole map) against the oracle's restatement, through the same front-end."""
+    from srba_amd import datasets
+    ds = datasets.graph_slam_se2(n_kf=400, seed=5, path="tour", sigma_xy=0.02, sigma_yaw_deg=0.5)
+    vals = {}
+    for backend in ("oracle", "hip"):
+        eng = runner.graph_slam_engine(backend=backend, submap=10, depth=3, sigma_xy=0.02, sigma_yaw_deg=0.5, harvest=0)
+        eng.run(ds)
+        vals[backend] = eng.eval_overall_squared_error()
+    assert vals["oracle"] > 0 and abs(vals["hip"] - vals["oracle"]) <= 1e-6 * vals["oracle"], vals
+    # landmark family (SE3 + stereo, sensor pose on the robot)
+    ds3, _ = datasets.landmarks_dataset_se3("stereo", n_kf=12, n_lm=300, seed=5, noise=0.3)
+    vals = {}
+    for backend in ("oracle", "hip"):
+        eng = runner.landmark_engine("stereo", backend=backend, harvest=0)
+        eng.run(ds3)
+        vals[backend] = eng.eval_overall_squared_error()
+    assert vals["oracle"] > 0 and abs(vals["hip"] - vals["oracle"]) <= 1e-6 * vals["oracle"] + 1e-9, vals

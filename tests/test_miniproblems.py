@@ -61,3 +61,53 @@ def test_both_graph_slam_solvers_agree():
         out.append(np.array([i.chi2_final for i in infos]))
         eng.close()
     assert np.allclose(out[0], out[1], rtol=1e-6, atol=1e-12) and np.allclose(out[0], out[2], rtol=1e-6, atol=1e-12)
+
+
+def test_eval_overall_squared_error_graph_slam():
+    """RbaEngine<>::eval_overall_squared_error (impl/eval_overall_error.h:15-137) through the front-end with the oracle plugged in:
+    ~0 on the noise-free tutorial map after optimisation, and equal to a direct numpy evaluation over the final edges."""
+    import numpy as np
+    from srba_amd import datasets, runner
+    ds = datasets.graph_slam_from_entries(datasets.C2_TUTORIAL_SE2)
+    eng = runner.graph_slam_engine(backend="oracle", submap=5, depth=3, sigma_xy=0.1, sigma_yaw_deg=4.0, harvest=0)
+    eng.run(ds)
+    e = eng.eval_overall_squared_error()
+    assert 0 <= e < 1e-6
+    # a noisy random-walk map: compare with an independent evaluation (poses chained over the same breadth-first paths)
+    ds = datasets.graph_slam_se2(n_kf=60, seed=3, path="tour", sigma_xy=0.02, sigma_yaw_deg=0.5)
+    eng = runner.graph_slam_engine(backend="oracle", submap=10, depth=3, sigma_xy=0.02, sigma_yaw_deg=0.5, harvest=0)
+    eng.run(ds)
+    e = eng.eval_overall_squared_error()
+    fr, to, pose = eng.edges()
+    adj = {}
+    for i in range(len(fr)):
+        adj.setdefault(int(fr[i]), []).append((int(to[i]), i, False)); adj.setdefault(int(to[i]), []).append((int(fr[i]), i, True))
+
+    def comp(a, b):
+        c, s = np.cos(a[2]), np.sin(a[2]); return np.array([a[0] + b[0] * c - b[1] * s, a[1] + b[0] * s + b[1] * c, a[2] + b[2]])
+
+    def inv(a):
+        c, s = np.cos(a[2]), np.sin(a[2]); return np.array([-a[0] * c - a[1] * s, a[0] * s - a[1] * c, -a[2]])
+
+    def rel(root, target):  # pose of target seen from root: breadth-first, adjacency order (spantree_create_complete.h)
+        prev = {root: None}; q = [root]
+        while q and target not in prev:
+            cur = q.pop(0)
+            for nk, ei, to_is_cur in adj[cur]:
+                if nk not in prev: prev[nk] = (cur, ei, to_is_cur); q.append(nk)
+        chain = []; k = target
+        while prev[k] is not None: chain.append(prev[k]); k = prev[k][0]
+        acc = np.zeros(3)
+        for cur, ei, to_is_cur in reversed(chain):   # edge seen from `cur`: to_is_cur -> the child is edge.from -> pose = inv_pose ; else child is edge.to -> (-)inv_pose
+            acc = comp(acc, pose[ei] if to_is_cur else inv(pose[ei]))
+        return acc
+    tot = 0.0
+    for kf, frame in enumerate(ds):
+        for fid, z, fl in zip(frame["feat_ids"], np.asarray(frame["z"]).reshape(-1, 3), frame["flags"]):
+            if int(fid) == kf: continue   # the fixed self-landmark: zero residual by construction only if z == 0 (it is)
+            a, b = kf, int(fid)
+            p = rel(a, b) if a < b else inv(rel(b, a))
+            c, s = np.cos(p[2]), np.sin(p[2]); dx, dy = z[0] - p[0], z[1] - p[1]
+            r = np.array([dx * c + dy * s, -dx * s + dy * c, (z[2] - p[2] + np.pi) % (2 * np.pi) - np.pi])
+            tot += float(r @ r)
+    assert abs(e - tot) <= 1e-9 * max(1.0, tot), (e, tot)
