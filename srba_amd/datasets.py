@@ -287,3 +287,37 @@ def landmarks_dataset_se2(kind="rb2d", n_kf=50, n_lm=300, seed=1, max_range=4.0,
             ids.append(j); zs.append(z); flags.append(fl); rel.append(rp)
         out.append(dict(feat_ids=np.array(ids, np.uint64), z=np.array(zs, np.float64).reshape(-1, 2), flags=np.array(flags, np.uint8), relpos=np.array(rel, np.float64).reshape(-1, 2)))
     return out, gt
+
+
+# ------------------------------------------------------------------------------------------------ text formats of apps/srba-slam
+def write_text_dataset(frames, path, kind):
+    """Writes key-frame dictionaries in the text format read by srba-slam (apps/srba-slam/CDatasetParserBase.h:82: FRAME_ID FEAT_ID fields...).
+    kind: 'graph-slam' (12 columns: X Y Z YAW PITCH ROLL QR QX QY QZ, CDatasetParser_RelGraphSLAM2D.h:28-32; the fixed self-landmark rows are
+    not part of the file), or a landmark sensor: 'rb2d' / 'cart2d' (4 columns), 'cart3d' (5), 'mono' (4), 'stereo' (6)."""
+    with open(path, "w") as f:
+        f.write("% FRAME_ID FEAT_ID sensor-specific fields\n")
+        for kf, fr in enumerate(frames):
+            z = np.asarray(fr["z"], np.float64).reshape(len(fr["feat_ids"]), -1)
+            for fid, zi in zip(fr["feat_ids"], z):
+                if kind == "graph-slam":
+                    if int(fid) == kf:
+                        continue
+                    h = 0.5 * zi[2]
+                    f.write("%d %d %.17g %.17g 0 %.17g 0 0 %.17g 0 0 %.17g\n" % (kf, int(fid), zi[0], zi[1], zi[2], math.cos(h), math.sin(h)))
+                else:
+                    f.write("%d %d %s\n" % (kf, int(fid), " ".join("%.17g" % v for v in zi)))
+
+
+def write_gt_path(poses_xyz_quat, path):
+    """ground-truth path file: idx x y z qr qx qy qz (CDatasetParserBase.h:213-226)"""
+    with open(path, "w") as f:
+        for i, p in enumerate(poses_xyz_quat):
+            f.write("%d %s\n" % (i, " ".join("%.17g" % v for v in p)))
+
+
+def write_stereo_cfg(path, cam=(200.0, 150.0, 512.0, 384.0), baseline=0.2):
+    """sensor parameter file of --sensor-params-cfg-file ([EXT] TStereoCamera::loadFromConfigFile("CAMERA"): fx fy cx cy per camera, left-to-right pose)"""
+    with open(path, "w") as f:
+        for sec in ("CAMERA", "CAMERA_LEFT", "CAMERA_RIGHT"):
+            f.write("[%s]\nfx = %.17g\nfy = %.17g\ncx = %.17g\ncy = %.17g\n\n" % ((sec,) + tuple(cam)))
+        f.write("[CAMERA_LEFT2RIGHT_POSE]\npose_quaternion = [%.17g 0 0 1 0 0 0]\n" % baseline)
