@@ -122,6 +122,12 @@ template <> struct Parser<observations::Cartesian_3D> {
 	template <class O> void get(const std::vector<double> &r, O &o, bool noisy) const { o.obs_data.pt.x = r[2] + (noisy ? gauss(s) : 0); o.obs_data.pt.y = r[3] + (noisy ? gauss(s) : 0); o.obs_data.pt.z = r[4] + (noisy ? gauss(s) : 0); }
 	template <class RBA> void params(RBA &rba, const Args &) const { rba.parameters.obs_noise.std_noise_observations = s; }
 };
+template <> struct Parser<observations::RangeBearing_3D> { // CDatasetParser_RangeBearing3D: FRAME_ID FEAT_ID range yaw pitch
+	static const size_t COLS = 5; double sr, sa;
+	explicit Parser(const Args &a) : sr(a.num("noise", 1e-4)), sa(a.has("noise") ? a.num("noise", 1e-5) : 1e-5) {}
+	template <class O> void get(const std::vector<double> &r, O &o, bool noisy) const { o.obs_data.range = r[2] + (noisy ? gauss(sr) : 0); o.obs_data.yaw = r[3] + (noisy ? gauss(sa) : 0); o.obs_data.pitch = r[4] + (noisy ? gauss(sa) : 0); }
+	template <class RBA> void params(RBA &rba, const Args &) const { rba.parameters.obs_noise.std_noise_observations = sr; }
+};
 template <> struct Parser<observations::MonocularCamera> {
 	static const size_t COLS = 4; double s;
 	explicit Parser(const Args &a) : s(a.num("noise", 1e-4)) {}
@@ -208,7 +214,7 @@ int run(const Args &a, const Dataset &ds) {
 
 void list_problems() {
 	std::cout << "Implemented RBA problem types:\n"
-		" --se2 --graph-slam\n --se2 --lm-2d --obs RangeBearing_2D\n --se2 --lm-2d --obs Cartesian_2D\n --se3 --lm-3d --obs Cartesian_3D\n --se3 --lm-3d --obs MonocularCamera\n --se3 --lm-3d --obs StereoCamera\n";
+		" --se2 --graph-slam\n --se2 --lm-2d --obs RangeBearing_2D\n --se2 --lm-2d --obs Cartesian_2D\n --se3 --lm-3d --obs Cartesian_3D\n --se3 --lm-3d --obs RangeBearing_3D\n --se3 --lm-3d --obs MonocularCamera\n --se3 --lm-3d --obs StereoCamera\n";
 }
 
 } // namespace
@@ -229,6 +235,7 @@ int main(int argc, char **argv) {
 		if (a.has("se2") && a.has("lm-2d") && obs == "RangeBearing_2D") return run<kf2kf_poses::SE2, landmarks::Euclidean2D, observations::RangeBearing_2D, RBA_OPTIONS_DEFAULT>(a, ds);
 		if (a.has("se2") && a.has("lm-2d") && obs == "Cartesian_2D") return run<kf2kf_poses::SE2, landmarks::Euclidean2D, observations::Cartesian_2D, RBA_OPTIONS_DEFAULT>(a, ds);
 		if (a.has("se3") && a.has("lm-3d") && obs == "Cartesian_3D") return run<kf2kf_poses::SE3, landmarks::Euclidean3D, observations::Cartesian_3D, RBA_OPTIONS_DEFAULT>(a, ds);
+		if (a.has("se3") && a.has("lm-3d") && obs == "RangeBearing_3D") return run<kf2kf_poses::SE3, landmarks::Euclidean3D, observations::RangeBearing_3D, RBA_OPTIONS_DEFAULT>(a, ds);
 		if (a.has("se3") && a.has("lm-3d") && obs == "MonocularCamera") return run<kf2kf_poses::SE3, landmarks::Euclidean3D, observations::MonocularCamera, OPT_CAMERA>(a, ds);
 		if (a.has("se3") && a.has("lm-3d") && obs == "StereoCamera") return run<kf2kf_poses::SE3, landmarks::Euclidean3D, observations::StereoCamera, OPT_CAMERA>(a, ds);
 		throw std::runtime_error("Sorry: the given combination of pose, point and sensor was not precompiled in this program! (see --list-problems)");

@@ -53,6 +53,11 @@ struct Cartesian_3D {
 	struct obs_data_t { mrpt::math::TPoint3D pt; template <class A> void getAsArray(A &o) const { o[0] = pt.x; o[1] = pt.y; o[2] = pt.z; } };
 	struct TObservationParams {};
 };
+struct RangeBearing_3D {
+	static const size_t OBS_DIMS = 3;
+	struct obs_data_t { double range, yaw, pitch; obs_data_t() : range(0), yaw(0), pitch(0) {} template <class A> void getAsArray(A &o) const { o[0] = range; o[1] = yaw; o[2] = pitch; } };
+	struct TObservationParams {};
+};
 struct Cartesian_2D {
 	static const size_t OBS_DIMS = 2;
 	struct obs_data_t { mrpt::math::TPoint2D pt; template <class A> void getAsArray(A &o) const { o[0] = pt.x; o[1] = pt.y; } };
@@ -102,6 +107,15 @@ template <> struct landmark_matcher<Cartesian_2D> {
 	template <class POSE> static bool find_relative_pose(const std::vector<Cartesian_2D::obs_data_t> &n, const std::vector<Cartesian_2D::obs_data_t> &o, const Cartesian_2D::TObservationParams &, POSE &out) {
 		mrpt::utils::TMatchingPairList m;
 		for (size_t i = 0; i < n.size(); i++) m.push_back(mrpt::utils::TMatchingPair(i, i, o[i].pt.x, o[i].pt.y, 0, n[i].pt.x, n[i].pt.y, 0));
+		return detail::pose_from_matches(m, out);
+	}
+};
+/** observations_RangeBearing_3D.h:47-86 */
+template <> struct landmark_matcher<RangeBearing_3D> {
+	template <class POSE> static bool find_relative_pose(const std::vector<RangeBearing_3D::obs_data_t> &n, const std::vector<RangeBearing_3D::obs_data_t> &o, const RangeBearing_3D::TObservationParams &, POSE &out) {
+		mrpt::utils::TMatchingPairList m;
+		for (size_t i = 0; i < n.size(); i++) m.push_back(mrpt::utils::TMatchingPair(i, i, o[i].range * std::cos(o[i].yaw) * std::cos(o[i].pitch), o[i].range * std::sin(o[i].yaw) * std::cos(o[i].pitch), -o[i].range * std::sin(o[i].pitch),
+			n[i].range * std::cos(n[i].yaw) * std::cos(n[i].pitch), n[i].range * std::sin(n[i].yaw) * std::cos(n[i].pitch), -n[i].range * std::sin(n[i].pitch)));
 		return detail::pose_from_matches(m, out);
 	}
 };
@@ -165,6 +179,14 @@ template <> struct sensor_model<landmarks::Euclidean3D, observations::StereoCame
 template <> struct sensor_model<landmarks::Euclidean3D, observations::Cartesian_3D> {
 	static const int family = SRBA_SE3_CART3D;
 	template <class LM, class OBSD, class PRM> static void inverse_sensor_model(LM &out, const OBSD &obs, const PRM &) { out[0] = obs.pt.x; out[1] = obs.pt.y; out[2] = obs.pt.z; } // sensors.h:396-407
+	template <class PRM> static void fill_params(srba_hip_params &, const PRM &) {}
+};
+template <> struct sensor_model<landmarks::Euclidean3D, observations::RangeBearing_3D> {
+	static const int family = SRBA_SE3_RB3D;
+	template <class LM, class OBSD, class PRM> static void inverse_sensor_model(LM &out, const OBSD &obs, const PRM &) { // sensors.h:620-634
+		const double cy = std::cos(obs.yaw), sy = std::sin(obs.yaw), cp = std::cos(obs.pitch), sp = std::sin(obs.pitch);
+		out[0] = obs.range * cy * cp; out[1] = obs.range * sy * cp; out[2] = -obs.range * sp;
+	}
 	template <class PRM> static void fill_params(srba_hip_params &, const PRM &) {}
 };
 template <> struct sensor_model<landmarks::Euclidean2D, observations::Cartesian_2D> {

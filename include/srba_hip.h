@@ -37,7 +37,8 @@ enum srba_family {
 	SRBA_SE3_STEREO    = 3, /* <SE3,Euclidean3D,StereoCamera>         P6 L3 O4  models/sensors.h:149 ; jacobians.h:364-494 */
 	SRBA_SE3_MONO      = 4, /* <SE3,Euclidean3D,MonocularCamera>      P6 L3 O2  models/sensors.h:24 */
 	SRBA_SE3_CART3D    = 5, /* <SE3,Euclidean3D,Cartesian_3D>         P6 L3 O3  models/sensors.h:323 */
-	SRBA_NUM_FAMILIES  = 6
+	SRBA_SE3_RB3D      = 6, /* <SE3,Euclidean3D,RangeBearing_3D>      P6 L3 O3  models/sensors.h:517 (range, yaw, pitch) */
+	SRBA_NUM_FAMILIES  = 7
 };
 
 /* Pose storage at the boundary ("PD" doubles per pose):

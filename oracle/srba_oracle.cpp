@@ -295,6 +295,7 @@ template <> struct Fam<SRBA_SE2_CART2D>    { using pose_t = Pose2; static conste
 template <> struct Fam<SRBA_SE3_STEREO>    { using pose_t = Pose3; static constexpr int P = 6, L = 3, O = 4; static constexpr bool relpose = false; };
 template <> struct Fam<SRBA_SE3_MONO>      { using pose_t = Pose3; static constexpr int P = 6, L = 3, O = 2; static constexpr bool relpose = false; };
 template <> struct Fam<SRBA_SE3_CART3D>    { using pose_t = Pose3; static constexpr int P = 6, L = 3, O = 3; static constexpr bool relpose = false; };
+template <> struct Fam<SRBA_SE3_RB3D>      { using pose_t = Pose3; static constexpr int P = 6, L = 3, O = 3; static constexpr bool relpose = false; };
 
 // ------------------------------------------------------------------------------------------------
 // The optimiser
@@ -380,6 +381,10 @@ struct Problem {
 			double lx, ly; compose_point(base_wrt_sensor, lm[0], lm[1], lx, ly); r[0] = z[0] - lx; r[1] = z[1] - ly;
 		} else if constexpr (FAM == SRBA_SE3_CART3D) { // sensors.h:347-362
 			double l[3]; compose_point(base_wrt_sensor, lm, l); for (int i = 0; i < 3; i++) r[i] = z[i] - l[i];
+		} else if constexpr (FAM == SRBA_SE3_RB3D) { // sensors.h:545-566; [EXT] CPose3D::sphericalCoordinates: range, yaw = atan2(y,x), pitch = -asin(z/range)
+			double l[3]; compose_point(base_wrt_sensor, lm, l);
+			const double rg = std::sqrt(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
+			r[0] = z[0] - rg; r[1] = z[1] - std::atan2(l[1], l[0]); r[2] = z[2] - (-std::asin(l[2] / rg));
 		} else if constexpr (FAM == SRBA_SE3_MONO) { // sensors.h:50-66
 			double l[3]; compose_point(base_wrt_sensor, lm, l);
 			r[0] = z[0] - (prm.cam_left[2] + prm.cam_left[0] * l[0] / l[2]); r[1] = z[1] - (prm.cam_left[3] + prm.cam_left[1] * l[1] / l[2]);
@@ -398,6 +403,11 @@ struct Problem {
 			const double r = std::hypot(x[0], x[1]); if (r == 0) return false;
 			const double ri = 1.0 / r, ri2 = ri * ri;
 			H[0] = x[0] * ri; H[1] = x[1] * ri; H[2] = -x[1] * ri2; H[3] = x[0] * ri2; return true;
+		} else if constexpr (FAM == SRBA_SE3_RB3D) { // sensors.h:588-608; [EXT] Jacobian of sphericalCoordinates wrt the point
+			const double x2y2 = x[0] * x[0] + x[1] * x[1], r2 = x2y2 + x[2] * x[2], rg = std::sqrt(r2), rxy = std::sqrt(x2y2);
+			H[0] = x[0] / rg; H[1] = x[1] / rg; H[2] = x[2] / rg;
+			H[3] = -x[1] / x2y2; H[4] = x[0] / x2y2; H[5] = 0;
+			H[6] = x[0] * x[2] / (r2 * rxy); H[7] = x[1] * x[2] / (r2 * rxy); H[8] = -rxy / r2; return true;
 		} else if constexpr (FAM == SRBA_SE3_MONO) { // sensors.h:85-110
 			if (x[2] <= 0) return false;
 			const double zi = 1.0 / x[2], zi2 = zi * zi, fx = prm.cam_left[0], fy = prm.cam_left[1];
@@ -839,6 +849,7 @@ void dispatch_run(const srba_hip_params &p, srba_problem_capsule &c, srba_lm_res
 		case SRBA_SE3_STEREO: run_one<SRBA_SE3_STEREO>(p, c, r); break;
 		case SRBA_SE3_MONO: run_one<SRBA_SE3_MONO>(p, c, r); break;
 		case SRBA_SE3_CART3D: run_one<SRBA_SE3_CART3D>(p, c, r); break;
+		case SRBA_SE3_RB3D: run_one<SRBA_SE3_RB3D>(p, c, r); break;
 		default: std::memset(&r, 0, sizeof(r)); r.status = -1;
 	}
 }
@@ -913,7 +924,7 @@ int srba_oracle_eval_overall(const srba_hip_params *p, const srba_overall_proble
 	switch (p->family) {
 		case SRBA_SE2_RELPOSE2D: *out = overall_error<SRBA_SE2_RELPOSE2D>(*p, *q); break; case SRBA_SE2_RB2D: *out = overall_error<SRBA_SE2_RB2D>(*p, *q); break;
 		case SRBA_SE2_CART2D: *out = overall_error<SRBA_SE2_CART2D>(*p, *q); break; case SRBA_SE3_STEREO: *out = overall_error<SRBA_SE3_STEREO>(*p, *q); break;
-		case SRBA_SE3_MONO: *out = overall_error<SRBA_SE3_MONO>(*p, *q); break; case SRBA_SE3_CART3D: *out = overall_error<SRBA_SE3_CART3D>(*p, *q); break;
+		case SRBA_SE3_MONO: *out = overall_error<SRBA_SE3_MONO>(*p, *q); break; case SRBA_SE3_CART3D: *out = overall_error<SRBA_SE3_CART3D>(*p, *q); break; case SRBA_SE3_RB3D: *out = overall_error<SRBA_SE3_RB3D>(*p, *q); break;
 		default: return -1;
 	}
 	return 0;
@@ -924,7 +935,7 @@ int srba_oracle_stage(const srba_hip_params *p, srba_problem_capsule *c, int do_
                       double *poses, double *scalars) {
 	switch (p->family) {
 #define CASE(F) case F: stage_one<F>(*p, *c, do_solve, lambda, residuals, Jp, Jf, HAp, Hf, HApf, grad, delta, poses, scalars); return 0;
-		CASE(SRBA_SE2_RELPOSE2D) CASE(SRBA_SE2_RB2D) CASE(SRBA_SE2_CART2D) CASE(SRBA_SE3_STEREO) CASE(SRBA_SE3_MONO) CASE(SRBA_SE3_CART3D)
+		CASE(SRBA_SE2_RELPOSE2D) CASE(SRBA_SE2_RB2D) CASE(SRBA_SE2_CART2D) CASE(SRBA_SE3_STEREO) CASE(SRBA_SE3_MONO) CASE(SRBA_SE3_CART3D) CASE(SRBA_SE3_RB3D)
 #undef CASE
 	}
 	return -1;

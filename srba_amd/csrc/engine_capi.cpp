@@ -20,6 +20,7 @@ template <> struct obs_io<observations::RelativePoses_2D> { static void set(obse
 template <> struct obs_io<observations::RangeBearing_2D> { static void set(observations::RangeBearing_2D::obs_data_t &o, const double *z) { o.range = z[0]; o.yaw = z[1]; } };
 template <> struct obs_io<observations::Cartesian_2D> { static void set(observations::Cartesian_2D::obs_data_t &o, const double *z) { o.pt.x = z[0]; o.pt.y = z[1]; } };
 template <> struct obs_io<observations::Cartesian_3D> { static void set(observations::Cartesian_3D::obs_data_t &o, const double *z) { o.pt.x = z[0]; o.pt.y = z[1]; o.pt.z = z[2]; } };
+template <> struct obs_io<observations::RangeBearing_3D> { static void set(observations::RangeBearing_3D::obs_data_t &o, const double *z) { o.range = z[0]; o.yaw = z[1]; o.pitch = z[2]; } };
 template <> struct obs_io<observations::MonocularCamera> { static void set(observations::MonocularCamera::obs_data_t &o, const double *z) { o.px.x = (float)z[0]; o.px.y = (float)z[1]; } };
 template <> struct obs_io<observations::StereoCamera> { static void set(observations::StereoCamera::obs_data_t &o, const double *z) { o.left_px.x = (float)z[0]; o.left_px.y = (float)z[1]; o.right_px.x = (float)z[2]; o.right_px.y = (float)z[3]; } };
 
@@ -209,6 +210,7 @@ void *srba_engine_create(const srba_engine_config *c) {
 			case SRBA_SE3_STEREO: e = make_point_engine<kf2kf_poses::SE3, landmarks::Euclidean3D, observations::StereoCamera>(*c); break;
 			case SRBA_SE3_MONO: e = make_point_engine<kf2kf_poses::SE3, landmarks::Euclidean3D, observations::MonocularCamera>(*c); break;
 			case SRBA_SE3_CART3D: e = make_point_engine<kf2kf_poses::SE3, landmarks::Euclidean3D, observations::Cartesian_3D>(*c); break;
+			case SRBA_SE3_RB3D: e = make_point_engine<kf2kf_poses::SE3, landmarks::Euclidean3D, observations::RangeBearing_3D>(*c); break;
 		}
 	} catch (std::exception &ex) { g_error = ex.what(); return NULL; }
 	if (!e) g_error = "srba_engine_create: unsupported family / policy combination";

@@ -84,6 +84,7 @@ template <> struct Tr<SRBA_SE2_CART2D>    { static constexpr int P = 3, L = 2, O
 template <> struct Tr<SRBA_SE3_STEREO>    { static constexpr int P = 6, L = 3, O = 4, PD = 12; static constexpr bool SE3 = true, REL = false; };
 template <> struct Tr<SRBA_SE3_MONO>      { static constexpr int P = 6, L = 3, O = 2, PD = 12; static constexpr bool SE3 = true, REL = false; };
 template <> struct Tr<SRBA_SE3_CART3D>    { static constexpr int P = 6, L = 3, O = 3, PD = 12; static constexpr bool SE3 = true, REL = false; };
+template <> struct Tr<SRBA_SE3_RB3D>      { static constexpr int P = 6, L = 3, O = 3, PD = 12; static constexpr bool SE3 = true, REL = false; };
 
 // ------------------------------------------------------------------------------------------------ poses
 __device__ __forceinline__ double wrap_pi(double a) { // mrpt::math::wrapToPi up to rounding (and the sign of an exact +-pi)
@@ -429,6 +430,12 @@ struct Worker {
 		} else {
 			double Hs[O * 3];
 			if constexpr (FAM == SRBA_SE3_CART3D) { for (int i = 0; i < 9; i++) Hs[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+			else if constexpr (FAM == SRBA_SE3_RB3D) { // d(range, yaw, pitch)/d(x,y,z), pitch = -asin(z/range)  (sensors.h:588-608, [EXT] CPose3DQuat::sphericalCoordinates)
+				const double x2y2 = x[0] * x[0] + x[1] * x[1], r2 = x2y2 + x[2] * x[2], r = sqrt(r2), rxy = sqrt(x2y2);
+				Hs[0] = x[0] / r; Hs[1] = x[1] / r; Hs[2] = x[2] / r;
+				Hs[3] = -x[1] / x2y2; Hs[4] = x[0] / x2y2; Hs[5] = 0;
+				Hs[6] = x[0] * x[2] / (r2 * rxy); Hs[7] = x[1] * x[2] / (r2 * rxy); Hs[8] = -rxy / r2;
+			}
 			else {
 				if (x[2] <= 0) return false;
 				{ const double zi = 1.0 / x[2], zi2 = zi * zi; Hs[0] = prm.camL[0] * zi; Hs[1] = 0; Hs[2] = -prm.camL[0] * x[0] * zi2; Hs[3] = 0; Hs[4] = prm.camL[1] * zi; Hs[5] = -prm.camL[1] * x[1] * zi2; }
@@ -461,6 +468,10 @@ struct Worker {
 			for (int k = 0; k < 3; k++) l[k] = bp.t[k] + bp.R[3 * k] * lm[0] + bp.R[3 * k + 1] * lm[1] + bp.R[3 * k + 2] * lm[2];
 			to_sensor_point(l); // == (pose (-) S) (+) lm
 			if constexpr (FAM == SRBA_SE3_CART3D) { for (int k = 0; k < 3; k++) r[k] = z[k] - l[k]; }
+			else if constexpr (FAM == SRBA_SE3_RB3D) { // sensors.h:545-566: plain differences, angles not wrapped
+				const double rg = sqrt(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
+				r[0] = z[0] - rg; r[1] = z[1] - atan2(l[1], l[0]); r[2] = z[2] + asin(l[2] / rg);
+			}
 			else {
 				r[0] = z[0] - (prm.camL[2] + prm.camL[0] * l[0] / l[2]); r[1] = z[1] - (prm.camL[3] + prm.camL[1] * l[1] / l[2]);
 				if constexpr (FAM == SRBA_SE3_STEREO) {

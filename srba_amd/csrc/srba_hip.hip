@@ -397,7 +397,7 @@ template <int FAM> __global__ void __launch_bounds__(256) k_overall_residuals(co
 namespace {
 
 struct FamDims { int P, L, O, PD; int PDX() const { return PD == 3 ? 5 : PD; } }; // PDX: device pose stride (SE2: [x y phi cos sin])
-const FamDims kDims[SRBA_NUM_FAMILIES] = {{3, 3, 3, 3}, {3, 2, 2, 3}, {3, 2, 2, 3}, {6, 3, 4, 12}, {6, 3, 2, 12}, {6, 3, 3, 12}};
+const FamDims kDims[SRBA_NUM_FAMILIES] = {{3, 3, 3, 3}, {3, 2, 2, 3}, {3, 2, 2, 3}, {6, 3, 4, 12}, {6, 3, 2, 12}, {6, 3, 3, 12}, {6, 3, 3, 12}};
 thread_local std::string g_last_error;
 
 struct Arena { // layout builder: 256-byte aligned sub-allocations inside one buffer
@@ -819,6 +819,7 @@ int srba_hip_batch_stats(srba_hip_ctx *c, srba_batch_stats *out) { if (!c || !ou
 		case SRBA_SE3_STEREO: hipLaunchKernelGGL(srbadev::KERNEL<SRBA_SE3_STEREO>, grid, block, (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); break; \
 		case SRBA_SE3_MONO: hipLaunchKernelGGL(srbadev::KERNEL<SRBA_SE3_MONO>, grid, block, (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); break; \
 		case SRBA_SE3_CART3D: hipLaunchKernelGGL(srbadev::KERNEL<SRBA_SE3_CART3D>, grid, block, (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); break; \
+		case SRBA_SE3_RB3D: hipLaunchKernelGGL(srbadev::KERNEL<SRBA_SE3_RB3D>, grid, block, (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); break; \
 	} } while (0)
 #define SRBA_DISPATCH(c, KERNEL, lds, ...) SRBA_DISPATCH_N(c, KERNEL, (c)->n_prob, lds, ##__VA_ARGS__)
 #define SRBA_DISPATCH_LDS1(c, KERNEL, FAMILY, inlds, nblocks, lds, ...) do { \
@@ -832,6 +833,7 @@ int srba_hip_batch_stats(srba_hip_ctx *c, srba_batch_stats *out) { if (!c || !ou
 		case SRBA_SE3_STEREO: SRBA_DISPATCH_LDS1(c, KERNEL, SRBA_SE3_STEREO, inlds, nblocks, lds, ##__VA_ARGS__); break; \
 		case SRBA_SE3_MONO: SRBA_DISPATCH_LDS1(c, KERNEL, SRBA_SE3_MONO, inlds, nblocks, lds, ##__VA_ARGS__); break; \
 		case SRBA_SE3_CART3D: SRBA_DISPATCH_LDS1(c, KERNEL, SRBA_SE3_CART3D, inlds, nblocks, lds, ##__VA_ARGS__); break; \
+		case SRBA_SE3_RB3D: SRBA_DISPATCH_LDS1(c, KERNEL, SRBA_SE3_RB3D, inlds, nblocks, lds, ##__VA_ARGS__); break; \
 	} } while (0)
 
 template <class K> static int allow_big_lds(srba_hip_ctx *c, K kernel, size_t bytes) {
@@ -844,7 +846,7 @@ static int prep_lds(srba_hip_ctx *c, bool for_lm) {
 	if (b <= 64 * 1024) return 0;
 	switch (c->params.family) {
 #define CASE(F) case F: return for_lm ? allow_big_lds(c, srbadev::k_lm_run<F, true>, b) : allow_big_lds(c, srbadev::k_solve<F, true>, b);
-		CASE(SRBA_SE2_RELPOSE2D) CASE(SRBA_SE2_RB2D) CASE(SRBA_SE2_CART2D) CASE(SRBA_SE3_STEREO) CASE(SRBA_SE3_MONO) CASE(SRBA_SE3_CART3D)
+		CASE(SRBA_SE2_RELPOSE2D) CASE(SRBA_SE2_RB2D) CASE(SRBA_SE2_CART2D) CASE(SRBA_SE3_STEREO) CASE(SRBA_SE3_MONO) CASE(SRBA_SE3_CART3D) CASE(SRBA_SE3_RB3D)
 #undef CASE
 	}
 	return -1;
@@ -914,7 +916,7 @@ int srba_hip_eval_overall_sqr_error(srba_hip_ctx *c, const srba_overall_problem 
 		const int pblk = std::max(1, std::min(1024, (q->n_pairs + 255) / 256));
 #define CASE(F) case F: if (q->n_pairs) hipLaunchKernelGGL((srbadev::k_overall_pairs<F>), dim3(pblk), dim3(256), 0, c->stream, B, dp); \
 		hipLaunchKernelGGL((srbadev::k_overall_residuals<F>), dim3(nblk), dim3(256), 0, c->stream, B, dp, (double *)(dw + o_part)); break;
-		switch (c->params.family) { CASE(SRBA_SE2_RELPOSE2D) CASE(SRBA_SE2_RB2D) CASE(SRBA_SE2_CART2D) CASE(SRBA_SE3_STEREO) CASE(SRBA_SE3_MONO) CASE(SRBA_SE3_CART3D) }
+		switch (c->params.family) { CASE(SRBA_SE2_RELPOSE2D) CASE(SRBA_SE2_RB2D) CASE(SRBA_SE2_CART2D) CASE(SRBA_SE3_STEREO) CASE(SRBA_SE3_MONO) CASE(SRBA_SE3_CART3D) CASE(SRBA_SE3_RB3D) }
 #undef CASE
 		if (hipGetLastError() != hipSuccess) { rc = -1; break; }
 		if (hipMemcpyAsync(part.data(), dw + o_part, 8 * (size_t)nblk, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rc = -1; break; }

@@ -210,7 +210,7 @@ def spiral_path_se3(n_kf, seed=1, radius=6.0, step=0.35):
 def landmarks_dataset_se3(kind="cart3d", n_kf=40, n_lm=400, seed=1, max_range=5.0, noise=0.0, cam=(200.0, 150.0, 512.0, 384.0), baseline=0.2, with_sensor_pose=None,
                           known_first=0, room=9.0, init_from_gt_noise=None):
     """SE3 keyframes observing 3D point landmarks.
-    kind: 'cart3d' (observations = landmark in the robot frame), 'stereo' or 'mono' (pinhole, camera looking along robot +X through CAMERA_ON_ROBOT).
+    kind: 'cart3d' (observations = landmark in the robot frame), 'rb3d' (range / yaw / pitch of the same point), 'stereo' or 'mono' (pinhole, camera looking along robot +X through CAMERA_ON_ROBOT).
     known_first: the first `known_first` landmarks seen from keyframe 0 are given as FIXED (known relative position), like the reference tutorials do to fix the gauge.
     Returns (dataset, gt_poses)."""
     rng = np.random.RandomState(seed)
@@ -220,7 +220,7 @@ def landmarks_dataset_se3(kind="cart3d", n_kf=40, n_lm=400, seed=1, max_range=5.
         with_sensor_pose = kind in ("stereo", "mono")
     S = pose3(*CAMERA_ON_ROBOT) if with_sensor_pose else np.eye(4)
     fx, fy, cx, cy = cam
-    O = {"cart3d": 3, "stereo": 4, "mono": 2}[kind]
+    O = {"cart3d": 3, "rb3d": 3, "stereo": 4, "mono": 2}[kind]
     seen = set(); out = []
     for kf, T in enumerate(gt):
         Tinv = np.linalg.inv(T @ S)
@@ -236,6 +236,10 @@ def landmarks_dataset_se3(kind="cart3d", n_kf=40, n_lm=400, seed=1, max_range=5.
                 if with_sensor_pose is False and q[0] < 0.2:  # looks along +X of the robot
                     continue
                 z = q + noise * rng.randn(3)
+            elif kind == "rb3d":   # range, yaw, pitch = -asin(z/range) (models/sensors.h:545-566); keep away from the poles of the parameterisation
+                if q[0] < 0.2 or abs(q[2]) > 0.8 * d:
+                    continue
+                z = np.array([d, math.atan2(q[1], q[0]), -math.asin(q[2] / d)]) + noise * rng.randn(3) * np.array([1.0, 0.2, 0.2])
             else:
                 if q[2] < 0.5:
                     continue

@@ -286,11 +286,11 @@ def landmark_engine(kind, backend="hip", depth=3, submap=15, sigma=None, robust=
     """Engines for the point-landmark families with the reference apps' policies: identity noise, Schur + dense Cholesky
     (apps/srba-slam/instance_se3_lm3d_stereo.cpp:36-45, instance_se3_lm3d_monocular.cpp:33-42, instance_se2_lm2d_rangebearing2d.cpp:17)."""
     from . import datasets
-    fam = {"cart3d": capi.SE3_CART3D, "stereo": capi.SE3_STEREO, "mono": capi.SE3_MONO, "rb2d": capi.SE2_RB2D, "cart2d": capi.SE2_CART2D}[kind]
+    fam = {"cart3d": capi.SE3_CART3D, "rb3d": capi.SE3_RB3D, "stereo": capi.SE3_STEREO, "mono": capi.SE3_MONO, "rb2d": capi.SE2_RB2D, "cart2d": capi.SE2_CART2D}[kind]
     if with_sensor_pose is None:
         with_sensor_pose = kind in ("stereo", "mono")
     if sigma is None:
-        sigma = {"cart3d": 0.01, "stereo": 0.5, "mono": 0.5, "rb2d": 0.05, "cart2d": 0.05}[kind]
+        sigma = {"cart3d": 0.01, "rb3d": 0.01, "stereo": 0.5, "mono": 0.5, "rb2d": 0.05, "cart2d": 0.05}[kind]
     args = dict(solver=capi.SOLVER_SCHUR_DENSE, noise=capi.NOISE_IDENTITY, std_noise_observations=sigma, max_tree_depth=depth, max_optimize_depth=depth, submap_size=submap,
                 use_robust_kernel=robust, harvest=harvest, cam_left=cam, cam_right=cam, right_cam_pose=(baseline, 0, 0, 1, 0, 0, 0))
     if with_sensor_pose:

@@ -46,7 +46,7 @@ def main():
     for kind in ("rb2d", "cart2d"):
         ds, _ = datasets.landmarks_dataset_se2(kind, n_kf=24, n_lm=900, seed=4, noise=1e-3)
         eng = runner.landmark_engine(kind, backend="oracle"); eng.run(ds); save("lm_" + kind, eng, 20, 3)
-    for kind, noise in (("cart3d", 1e-3), ("stereo", 0.1), ("mono", 0.1)):
+    for kind, noise in (("cart3d", 1e-3), ("rb3d", 1e-3), ("stereo", 0.1), ("mono", 0.1)):
         ds, _ = datasets.landmarks_dataset_se3(kind, n_kf=12, n_lm=300, seed=5, noise=noise, init_from_gt_noise=(0.2 if kind == "mono" else None))
         eng = runner.landmark_engine(kind, backend="oracle", robust=(1 if kind == "stereo" else 0)); eng.run(ds); save("lm_" + kind, eng, 9, 3)
 

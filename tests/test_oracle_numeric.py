@@ -15,7 +15,7 @@ def _harvest(kind, solver=capi.SOLVER_SCHUR_DENSE, n_kf=14, seed=3, **kw):
     if kind in ("rb2d", "cart2d"):
         ds, gt = datasets.landmarks_dataset_se2(kind, n_kf=n_kf + 10, n_lm=900, seed=seed, noise=1e-3)
     else:
-        ds, gt = datasets.landmarks_dataset_se3(kind, n_kf=n_kf, n_lm=350, seed=seed, noise=(1e-3 if kind == "cart3d" else 0.1), init_from_gt_noise=(0.2 if kind == "mono" else None))
+        ds, gt = datasets.landmarks_dataset_se3(kind, n_kf=n_kf, n_lm=350, seed=seed, noise=(1e-3 if kind in ("cart3d", "rb3d") else 0.1), init_from_gt_noise=(0.2 if kind == "mono" else None))
     eng = runner.landmark_engine(kind, backend="oracle", solver=solver, **kw)
     eng.run(ds)
     b = eng.harvest(); b.engine = eng
@@ -46,7 +46,7 @@ def _dense_system(b, i, a):
     return H, n, nK, nF
 
 
-@pytest.mark.parametrize("kind", ["cart3d", "stereo", "rb2d"])
+@pytest.mark.parametrize("kind", ["cart3d", "rb3d", "stereo", "rb2d"])
 def test_schur_sparse_equals_dense(kind):
     b = _harvest(kind)
     P, L, O, PD = capi.DIMS[b.family]
@@ -108,7 +108,7 @@ def _perturb_edge(pose, eps, PD):
     return np.concatenate([eps[:3] + E @ t, (E @ R).reshape(-1)])
 
 
-@pytest.mark.parametrize("kind", ["cart3d", "stereo", "mono", "rb2d", "cart2d"])
+@pytest.mark.parametrize("kind", ["cart3d", "rb3d", "stereo", "mono", "rb2d", "cart2d"])
 def test_point_family_jacobians_match_finite_differences(kind):
     b = _harvest(kind, n_kf=8)
     P, L, O, PD = capi.DIMS[b.family]
