@@ -66,7 +66,7 @@ template <class V> struct kf_indexed {
 	void clear() { data.clear(); present.clear(); }
 };
 
-namespace ecps { struct local_areas_fixed_size; }
+namespace ecps { struct local_areas_fixed_size; struct classic_linear_rba; }
 
 /** Default RBA_OPTIONS (reference RbaEngine.h:39-45) */
 struct RBA_OPTIONS_DEFAULT;
@@ -321,6 +321,39 @@ struct local_areas_fixed_size {
 			}
 		}
 		ASSERTMSG_(new_k2k_edge_ids.size() >= 1, "Error for new KF: no suitable linking KF found with the minimum number of common observations: the node becomes isolated of the graph!");
+	}
+};
+
+/** Edge creation policy: the classic linear graph -- always an edge (n-1) -> n, plus loop-closure edges towards the base key-frames of
+  * re-observed landmarks that are farther than max_tree_depth (reference ecps/classic_linear_rba.h:22-118) */
+struct classic_linear_rba {
+	struct parameters_t { size_t min_obs_to_loop_closure; parameters_t() : min_obs_to_loop_closure(4) {} };
+
+	template <class traits_t, class rba_engine_t>
+	void eval(const TKeyFrameID new_kf_id, const typename traits_t::new_kf_observations_t &obs, std::vector<TNewEdgeInfo> &new_k2k_edge_ids, rba_engine_t &rba_engine, const parameters_t &params) {
+		using namespace std;
+		ASSERT_(new_kf_id >= 1);
+		// (1/2) always an edge (n-1) => (n), initialised at the null pose: each key-frame starts at the pose of the previous one (:61-69)
+		const typename traits_t::original_kf2kf_pose_t::pose_t init_inv_pose;
+		TNewEdgeInfo nei1; nei1.has_approx_init_val = true;
+		nei1.id = rba_engine.create_kf2kf_edge(new_kf_id, TPairKeyFrameID(new_kf_id - 1, new_kf_id), obs, init_inv_pose);
+		new_k2k_edge_ids.push_back(nei1);
+		// (2/2) loop closures (:71-114)
+		const topo_dist_t min_dist_for_loop_closure = rba_engine.parameters.srba.max_tree_depth + 1;
+		base_sorted_lst_t obs_for_each_base_sorted;
+		srba::internal::make_ordered_list_base_kfs<traits_t, typename rba_engine_t::rba_problem_state_t>(obs, rba_engine.get_rba_state(), obs_for_each_base_sorted);
+		for (base_sorted_lst_t::const_iterator it = obs_for_each_base_sorted.begin(); it != obs_for_each_base_sorted.end(); ++it) {
+			const size_t num_obs_this_base = it->first; const TKeyFrameID from_id = new_kf_id, to_id = it->second;
+			topo_dist_t found_distance = numeric_limits<topo_dist_t>::max();
+			const map<TKeyFrameID, TSpanTreeEntry> *from_Ds = rba_engine.get_rba_state().spanning_tree.sym.next_edge.find(from_id);
+			if (from_Ds) { map<TKeyFrameID, TSpanTreeEntry>::const_iterator it_to = from_Ds->find(to_id); if (it_to != from_Ds->end()) found_distance = it_to->second.distance; }
+			if (found_distance >= min_dist_for_loop_closure && num_obs_this_base >= params.min_obs_to_loop_closure) {
+				TNewEdgeInfo nei;
+				nei.id = rba_engine.create_kf2kf_edge(new_kf_id, TPairKeyFrameID(to_id, new_kf_id), obs);
+				nei.has_approx_init_val = false;
+				new_k2k_edge_ids.push_back(nei);
+			}
+		}
 	}
 };
 } // namespace ecps

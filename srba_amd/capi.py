@@ -61,7 +61,7 @@ class EngineConfig(C.Structure):
                 ("max_tree_depth", C.c_uint64), ("max_optimize_depth", C.c_uint64), ("submap_size", C.c_uint64), ("min_obs_to_loop_closure", C.c_uint64),
                 ("optimize_new_edges_alone", c_i32), ("use_robust_kernel", c_i32), ("use_robust_kernel_stage1", c_i32), ("max_iters", c_i32),
                 ("kernel_param", c_f64), ("max_error_per_obs_to_stop", c_f64), ("max_rho", c_f64), ("max_lambda", c_f64), ("min_error_reduction_ratio_to_relinearize", c_f64),
-                ("cov_recovery", c_i32), ("run_local_optimization", c_i32), ("harvest", c_i32), ("verbose", c_i32), ("enable_profiler", c_i32), ("hip_device", c_i32), ("refresh_all_read_poses", c_i32), ("reserved", c_i32)]
+                ("cov_recovery", c_i32), ("run_local_optimization", c_i32), ("harvest", c_i32), ("verbose", c_i32), ("enable_profiler", c_i32), ("hip_device", c_i32), ("refresh_all_read_poses", c_i32), ("ecp", c_i32)]
 
 
 class KfInfo(C.Structure):

@@ -58,9 +58,13 @@ struct EngineBase {
 	virtual int64_t create_edge(uint64_t new_kf, uint64_t from, uint64_t to, const double *pose) = 0;
 };
 
-template <class KF, class LM, class OBS, class NOISE, class SPOSE, class SOLVER>
+template <class ECP> struct ecp_io;
+template <> struct ecp_io<ecps::local_areas_fixed_size> { template <class P> static void set(P &p, const srba_engine_config &c) { p.submap_size = c.submap_size; p.min_obs_to_loop_closure = c.min_obs_to_loop_closure; } };
+template <> struct ecp_io<ecps::classic_linear_rba> { template <class P> static void set(P &p, const srba_engine_config &c) { p.min_obs_to_loop_closure = c.min_obs_to_loop_closure; } };
+
+template <class KF, class LM, class OBS, class NOISE, class SPOSE, class SOLVER, class ECP = ecps::local_areas_fixed_size>
 struct EngineImpl : public EngineBase {
-	struct OPTS : public RBA_OPTIONS_DEFAULT { typedef SPOSE sensor_pose_on_robot_t; typedef NOISE obs_noise_matrix_t; typedef SOLVER solver_t; };
+	struct OPTS : public RBA_OPTIONS_DEFAULT { typedef ECP edge_creation_policy_t; typedef SPOSE sensor_pose_on_robot_t; typedef NOISE obs_noise_matrix_t; typedef SOLVER solver_t; };
 	typedef RbaEngine<KF, LM, OBS, OPTS> rba_t;
 	rba_t rba; uint64_t cur_kf = 0;
 
@@ -72,7 +76,7 @@ struct EngineImpl : public EngineBase {
 		s.use_robust_kernel = c.use_robust_kernel != 0; s.use_robust_kernel_stage1 = c.use_robust_kernel_stage1 != 0; s.kernel_param = c.kernel_param; s.max_iters = c.max_iters;
 		s.max_error_per_obs_to_stop = c.max_error_per_obs_to_stop; s.max_rho = c.max_rho; s.max_lambda = c.max_lambda; s.min_error_reduction_ratio_to_relinearize = c.min_error_reduction_ratio_to_relinearize;
 		s.cov_recovery = c.cov_recovery ? crpLandmarksApprox : crpNone; s.refresh_all_read_poses = c.refresh_all_read_poses != 0;
-		rba.parameters.ecp.submap_size = c.submap_size; rba.parameters.ecp.min_obs_to_loop_closure = c.min_obs_to_loop_closure;
+		ecp_io<ECP>::set(rba.parameters.ecp, c);
 		noise_io<NOISE>::set(rba.parameters.obs_noise, c); spose_io<SPOSE>::set(rba.parameters.sensor_pose, c); sensor_io<OBS>::set(rba.parameters.sensor, c);
 		rba.set_hip_device(c.hip_device);
 		rba.on_capsule = [this](const srba_hip_params &hp, CapsuleData &cd) {
@@ -198,6 +202,12 @@ void srba_engine_config_default(srba_engine_config *c, int family) {
 void *srba_engine_create(const srba_engine_config *c) {
 	EngineBase *e = NULL;
 	try {
+		if (c->ecp == 1) { // classic linear RBA: the two problem types the reference tutorials use it with
+			if (c->family == SRBA_SE2_RELPOSE2D && c->noise == SRBA_NOISE_CONSTANT_MATRIX && c->sensor_pose == SRBA_SENSOR_POSE_NONE && c->solver == SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL)
+				e = new EngineImpl<kf2kf_poses::SE2, landmarks::RelativePoses2D, observations::RelativePoses_2D, options::observation_noise_constant_matrix<observations::RelativePoses_2D>, SP_NONE, S_NS, ecps::classic_linear_rba>(*c);
+			else if (c->family == SRBA_SE3_CART3D && c->noise == SRBA_NOISE_IDENTITY && c->sensor_pose == SRBA_SENSOR_POSE_NONE && c->solver == SRBA_SOLVER_SCHUR_DENSE_CHOL)
+				e = new EngineImpl<kf2kf_poses::SE3, landmarks::Euclidean3D, observations::Cartesian_3D, N_ID, SP_NONE, S_SD, ecps::classic_linear_rba>(*c);
+		} else
 		switch (c->family) {
 			case SRBA_SE2_RELPOSE2D:
 				if (c->noise == SRBA_NOISE_CONSTANT_MATRIX && c->sensor_pose == SRBA_SENSOR_POSE_NONE)

@@ -111,3 +111,25 @@ def test_eval_overall_squared_error_graph_slam():
             r = np.array([dx * c + dy * s, -dx * s + dy * c, (z[2] - p[2] + np.pi) % (2 * np.pi) - np.pi])
             tot += float(r @ r)
     assert abs(e - tot) <= 1e-9 * max(1.0, tot), (e, tot)
+
+
+def test_classic_linear_rba_edge_creation_policy():
+    """ecps::classic_linear_rba (ecps/classic_linear_rba.h:50-118): always an edge (n-1)->n with a null initial pose, plus a loop-closure
+    edge new_kf <- base_kf whenever a re-observed landmark's base is farther than max_tree_depth; the map still converges."""
+    import numpy as np
+    from srba_amd import capi, datasets, runner
+    ds = datasets.graph_slam_se2(n_kf=80, seed=6, path="tour", sigma_xy=1e-3, sigma_yaw_deg=0.05, max_range=5.0)
+    eng = runner.graph_slam_engine(backend="oracle", depth=3, sigma_xy=1e-3, sigma_yaw_deg=0.05, harvest=0, ecp=1)
+    infos = eng.run(ds)
+    fr, to, pose = eng.edges()
+    edges = list(zip(fr.astype(int).tolist(), to.astype(int).tolist()))
+    for n in range(1, 80):
+        assert (n - 1, n) in edges                       # the linear backbone
+    extra = [e for e in edges if e[1] - e[0] != 1]
+    assert all(e[0] < e[1] for e in extra)               # loop closures are (base -> new key-frame)
+    # every loop closure links key-frames that were more than max_tree_depth apart along the backbone when it was created
+    assert all(e[1] - e[0] > 3 for e in extra)
+    # each key-frame reports its backbone edge first, with an approximate initial value
+    assert all(i.n_new_edges >= 1 and i.edge_has_init[0] == 1 for i in infos[1:])
+    assert max(i.obs_rmse for i in infos[5:]) < 0.05
+    assert eng.eval_overall_squared_error() < 1.0
