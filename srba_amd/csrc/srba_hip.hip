@@ -501,7 +501,7 @@ struct srba_hip_ctx {
 	int n_prob = 0; std::vector<ProbDesc> desc; Batch B; srba_batch_stats stats;
 	char *d_in = nullptr; size_t cap_in = 0; char *d_wk = nullptr; size_t cap_wk = 0;
 	std::vector<char> h_in; // host staging of the input arena
-	int n_queues = 16, sched = 1, n_streams_used = 1; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
+	int max_lds_kb = 1 << 20; int n_queues = 16, sched = 1, n_streams_used = 1; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
 	// offsets needed for downloads (bytes inside the wk arena)
 	size_t off_edge = 0, off_ulm = 0, off_pose = 0, off_inf = 0, off_infv = 0, off_res = 0;
 	size_t off_dbg[10] = {0}; int64_t len_dbg[10] = {0};
@@ -605,6 +605,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	c->device = device; c->params = *params; c->dm = kDims[params->family]; make_dev_params(*params, c->dp, c->dm);
 	std::memset(&c->B, 0, sizeof(c->B)); std::memset(&c->stats, 0, sizeof(c->stats));
 	{ const char *e = getenv("SRBA_HIP_PHASE_TIMING"); c->phase_timing = (e && e[0] == '1'); }
+	{ const char *e = getenv("SRBA_HIP_MAX_LDS_KB"); c->max_lds_kb = e ? atoi(e) : 1 << 20; } // test knob: systems above this many KB are factored in the HBM workspace (0 = all of them)
 	{ const char *e = getenv("SRBA_HIP_LDS_PAD"); c->lds_pad = e ? (size_t)atol(e) : 0; } // diagnostics: extra LDS bytes per workgroup (lowers residency)
 	{ const char *e = getenv("SRBA_HIP_SCHED"); if (e) c->sched = atoi(e); } // tuning knob: launch plan (see plan_launches)
 	{ const char *e = getenv("SRBA_HIP_QUEUES"); if (e && atoi(e) >= 1 && atoi(e) < SRBA_NCLS) c->n_queues = atoi(e); } // tuning knob: concurrent launch streams
@@ -680,7 +681,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 		// reserves little more LDS per wavefront than its capsules need; systems above 152 KB are factored in an HBM workspace
 		const size_t bytes = tri_n * 8;
 		static const int kClsKB[SRBA_NCLS - 1] = {6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64, 80, 96, 112, 128, 152};
-		cls[p] = SRBA_NCLS - 1; for (int q = 0; q < SRBA_NCLS - 1 && packable; q++) if (bytes <= (size_t)kClsKB[q] * 1024) { cls[p] = q; break; }
+		cls[p] = SRBA_NCLS - 1; for (int q = 0; q < SRBA_NCLS - 1 && packable && kClsKB[q] <= c->max_lds_kb; q++) if (bytes <= (size_t)kClsKB[q] * 1024) { cls[p] = q; break; }
 		d.dense_in_lds = cls[p] < SRBA_NCLS - 1 ? 1 : 0; cls_nbmax[cls[p]] = std::max(cls_nbmax[cls[p]], (int)tri_n);
 		int nyw = 0; if (k.n_sch_terms > 0) for (int b = 0; b < k.n_hap; b++) if (k.hap_i[b] == k.hap_j[b]) nyw += k.sch_term_off[b + 1] - k.sch_term_off[b];
 		long long npath_needed = 0; for (int q = 0; q < k.n_pairs; q++) if (k.pair_needed[q]) { st.n_pairs_needed++; npath_needed += k.pair_path_off[q + 1] - k.pair_path_off[q]; }

@@ -133,3 +133,29 @@ def test_eval_overall_squared_error_hip_vs_oracle():
         eng.run(ds3)
         vals[backend] = eng.eval_overall_squared_error()
     assert vals["oracle"] > 0 and abs(vals["hip"] - vals["oracle"]) <= 1e-6 * vals["oracle"] + 1e-9, vals
+
+
+@pytest.mark.gpu
+def test_hbm_workspace_path_and_mixed_classes(se2_batch, monkeypatch):
+    """Systems too large for the LDS classes are factored in an HBM workspace (same code, global pointers, full barriers). The knob
+    SRBA_HIP_MAX_LDS_KB forces that path: all capsules (0) or only the larger ones (10 KB -> a ragged mix of LDS and HBM launches)."""
+    ref = runner.run_batch_oracle(se2_batch)
+    for kb in ("0", "10"):
+        monkeypatch.setenv("SRBA_HIP_MAX_LDS_KB", kb)
+        gpu = runner.run_batch_hip(se2_batch)
+        _compare_lm(se2_batch, gpu, ref)
+    monkeypatch.delenv("SRBA_HIP_MAX_LDS_KB")
+
+
+@pytest.mark.gpu
+def test_large_windows_depth5():
+    """Maximum-size case for the LDS path: depth-5 windows of 20-key-frame sub-maps (systems of 100+ block rows), SE2 graph-SLAM."""
+    from srba_amd import datasets
+    ds = datasets.graph_slam_se2(n_kf=260, seed=9, path="tour")
+    eng = runner.graph_slam_engine(backend="oracle", submap=20, depth=5)
+    eng.run(ds)
+    b = eng.harvest(); b.engine = eng
+    sub = b.sub(b.n - 40, 40)
+    ref = runner.run_batch_oracle(sub); gpu = runner.run_batch_hip(sub)
+    assert max(sub.ptr[i].n_unk_edges for i in range(sub.n)) >= 60
+    _compare_lm(sub, gpu, ref)
