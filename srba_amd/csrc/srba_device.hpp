@@ -51,6 +51,7 @@ struct Batch {
 	const int *hapf_i, *hapf_j, *hapf_term_off, *hapf_t1, *hapf_t2, *hap_diag, *hf_diag;
 	const int *sch_term_off, *sch_b1, *sch_b2, *sch_lm, *sch_yw, *lm_hapf_off, *lm_hapf_idx, *req_idx, *need_idx;
 	const unsigned char *pair_needed, *bp_normal;
+	const int *hap_order; // H blocks of a capsule sorted by decreasing term count (longest first: balances the lanes of K6)
 	const int *sp_col_off, *sp_row, *sp_item_off, *sp_tgt, *sp_ab, *sp_rptr, *sp_rcol, *sp_rblk, *sp_perm; // symbolic factorisation of every capsule's system
 	const int *hap_dst, *hapf_dst, *hf_dst; // destination 3x3 block of every aligned sub-block of the Hessian blocks (see symbolic_factor)
 	// state + workspace
@@ -665,8 +666,8 @@ struct Worker {
 		int ninv = 0;
 		const double *Jp = B.Jp + d.o_bp * O * P, *Jf = B.Jf + d.o_bf * O * L;
 		const unsigned char *rp = B.bp_ok + d.o_bp, *rf = B.bf_ok + d.o_bf;
-		for (int b = tid; b < d.n_hap; b += SRBA_WG) {
-			const long long g = d.o_hap + b;
+		for (int bi = tid; bi < d.n_hap; bi += SRBA_WG) {
+			const int b = B.hap_order[d.o_hap + bi]; const long long g = d.o_hap + b;
 			ninv += hess_block<P, P>(B.HAp + g * P * P, B.hap_t1 + d.o_hapt, B.hap_t2 + d.o_hapt, B.hap_term_off[d.o_hapoff + b], B.hap_term_off[d.o_hapoff + b + 1], Jp, Jp, rp, rp);
 			for (int k = 0; k < P * P; k++) B.HAp0[g * P * P + k] = B.HAp[g * P * P + k]; // latch for Schur (schur.h:38,165-168)
 		}
