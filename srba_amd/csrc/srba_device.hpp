@@ -34,7 +34,7 @@ struct ProbDesc {
 	int n_edges, nK, nF, n_klm, n_pairs, n_obs, n_valid, n_bp, n_bf, n_hap, n_hf, n_hapf, n_sch, n_req, n_sys, n_scal, nb, nnzoff;
 	// element offsets into the batch-wide arrays
 	long long o_edge, o_unk, o_ulm, o_klm, o_pair, o_ppoff, o_path, o_obs, o_valid, o_bp, o_colp, o_bf, o_colf;
-	int n_need; // pairs whose pose is re-evaluated inside the LM loop (pair_needed != 0)
+	int n_need, need_flat; // pairs whose pose is re-evaluated inside the LM loop (pair_needed != 0); need_flat: all their paths have <= 4 edges (need_rec usable)
 	long long o_hap, o_hapoff, o_hapt, o_hf, o_hfoff, o_hft, o_hapf, o_hapfoff, o_hapft, o_sch, o_lmoff, o_req, o_scal, o_yw, o_dense, o_spcol, o_sprow, o_spitem, o_spperm;
 	int n_items, aligned; // block updates per factorisation; 1 if every Hessian block maps onto whole 3x3 blocks (always, except L==2 with the no-Schur solver)
 	int dense_in_lds, pad;
@@ -49,7 +49,7 @@ struct Batch {
 	const int *bp_col, *bp_res, *bp_A, *bp_D, *bp_lm, *colp_off, *bf_col, *bf_res, *bf_pose, *colf_off;
 	const int *hap_i, *hap_j, *hap_term_off, *hap_t1, *hap_t2, *hf_i, *hf_j, *hf_term_off, *hf_t1, *hf_t2;
 	const int *hapf_i, *hapf_j, *hapf_term_off, *hapf_t1, *hapf_t2, *hap_diag, *hf_diag;
-	const int *sch_term_off, *sch_b1, *sch_b2, *sch_lm, *sch_yw, *lm_hapf_off, *lm_hapf_idx, *req_idx, *need_idx;
+	const int *sch_term_off, *sch_b1, *sch_b2, *sch_lm, *sch_yw, *lm_hapf_off, *lm_hapf_idx, *req_idx, *need_idx, *need_rec; // need_rec: per needed pair {pair, 4 path entries (edge<<1|inv, -1 = none)}
 	const unsigned char *pair_needed, *bp_normal;
 	const int *hap_order; // H blocks of a capsule sorted by decreasing term count (longest first: balances the lanes of K6)
 	const int *sp_col_off, *sp_row, *sp_item_off, *sp_tgt, *sp_ab, *sp_rptr, *sp_rcol, *sp_rblk, *sp_perm; // symbolic factorisation of every capsule's system
@@ -380,8 +380,40 @@ struct Worker {
 	// ---- K1
 	__device__ void phase_spantree(bool only_needed) { fresh();
 		constexpr int U = T::SE3 ? 2 : 4; // path edges fetched together (their loads do not depend on the running composition)
-		const int cnt = only_needed ? d.n_need : d.n_pairs;
 		constexpr int V = T::SE3 ? 1 : 2; // pairs per lane and pass (all their loads are issued before the first store)
+		if (only_needed && d.need_flat) { // in-loop refresh: one flat record per pair -> two dependent memory levels (record, edges) instead of four
+			for (int q0 = tid; q0 < d.n_need; q0 += V * SRBA_WG) {
+				int p[V], pe[V][4]; pose_t acc[V];
+#pragma unroll
+				for (int v = 0; v < V; v++) {
+					const int q = q0 + v * SRBA_WG; const int *rec = B.need_rec + (d.o_pair + (q < d.n_need ? q : 0)) * 5;
+					p[v] = q < d.n_need ? rec[0] : -1;
+#pragma unroll
+					for (int u = 0; u < 4; u++) pe[v][u] = q < d.n_need ? rec[1 + u] : -1;
+				}
+#pragma unroll
+				for (int v = 0; v < V; v++) acc[v] = PO::ident();
+#pragma unroll
+				for (int u0 = 0; u0 < 4; u0 += U) {
+					pose_t ed[V][U];
+#pragma unroll
+					for (int v = 0; v < V; v++)
+#pragma unroll
+						for (int u = 0; u < U; u++) if (pe[v][u0 + u] >= 0) ed[v][u] = PO::ld(B.edge + (d.o_edge + (pe[v][u0 + u] >> 1)) * PD);
+#pragma unroll
+					for (int v = 0; v < V; v++)
+#pragma unroll
+						for (int u = 0; u < U; u++) if (pe[v][u0 + u] >= 0) acc[v] = (pe[v][u0 + u] & 1) ? comp(acc[v], inv(ed[v][u])) : comp(acc[v], ed[v][u]);
+				}
+#pragma unroll
+				for (int v = 0; v < V; v++) if (p[v] >= 0) {
+					PO::st(B.pose + (d.o_pair + p[v]) * 2 * PD, acc[v]);
+					PO::st(B.pose + ((d.o_pair + p[v]) * 2 + 1) * PD, inv(acc[v]));
+				}
+			}
+			return;
+		}
+		const int cnt = only_needed ? d.n_need : d.n_pairs;
 		for (int q0 = tid; q0 < cnt; q0 += V * SRBA_WG) {
 			int p[V], pe[V][U], b[V], e[V]; pose_t ed[V][U], acc[V];
 #pragma unroll
