@@ -51,7 +51,7 @@ struct Batch {
 	const int *hapf_i, *hapf_j, *hapf_term_off, *hapf_t1, *hapf_t2, *hap_diag, *hf_diag;
 	const int *sch_term_off, *sch_b1, *sch_b2, *sch_lm, *sch_yw, *lm_hapf_off, *lm_hapf_idx, *req_idx, *need_idx, *need_rec; // need_rec: per needed pair {pair, 4 path entries (edge<<1|inv, -1 = none)}
 	const unsigned char *pair_needed, *bp_normal;
-	const int *hap_order; // H blocks of a capsule sorted by decreasing term count (longest first: balances the lanes of K6)
+	const int *hap_rec; // per H block, sorted by decreasing term count (longest first: balances the lanes of K6): {block, first term, end term}
 	const int *sp_col_off, *sp_row, *sp_item_off, *sp_tgt, *sp_ab, *sp_rptr, *sp_rcol, *sp_rblk, *sp_perm; // symbolic factorisation of every capsule's system
 	const int *hap_dst, *hapf_dst, *hf_dst; // destination 3x3 block of every aligned sub-block of the Hessian blocks (see symbolic_factor)
 	// state + workspace
@@ -665,7 +665,7 @@ struct Worker {
 		}
 	}
 	template <int M1, int M2>
-	__device__ __forceinline__ int hess_block(double *Hout, const int *t1, const int *t2, int tb, int te, const double *J1, const double *J2, const unsigned char *ok1, const unsigned char *ok2) {
+	__device__ __forceinline__ int hess_block(double *Hout, double *Hlatch, const int *t1, const int *t2, int tb, int te, const double *J1, const double *J2, const unsigned char *ok1, const unsigned char *ok2) {
 		double H[M1 * M2];
 #pragma unroll
 		for (int k = 0; k < M1 * M2; k++) H[k] = 0;
@@ -691,23 +691,24 @@ struct Worker {
 		}
 		const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0;
 #pragma unroll
-		for (int k = 0; k < M1 * M2; k++) Hout[k] = H[k] * sc;
+		for (int k = 0; k < M1 * M2; k++) { const double v = H[k] * sc; Hout[k] = v; if (Hlatch) Hlatch[k] = v; }
 		return ninv;
 	}
 	__device__ int phase_hessian() { fresh(); // returns the per-thread invalid count (to be reduced by the caller if wanted)
 		int ninv = 0;
 		const double *Jp = B.Jp + d.o_bp * O * P, *Jf = B.Jf + d.o_bf * O * L;
 		const unsigned char *rp = B.bp_ok + d.o_bp, *rf = B.bf_ok + d.o_bf;
+		const bool latch = prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL;
 		for (int bi = tid; bi < d.n_hap; bi += SRBA_WG) {
-			const int b = B.hap_order[d.o_hap + bi]; const long long g = d.o_hap + b;
-			ninv += hess_block<P, P>(B.HAp + g * P * P, B.hap_t1 + d.o_hapt, B.hap_t2 + d.o_hapt, B.hap_term_off[d.o_hapoff + b], B.hap_term_off[d.o_hapoff + b + 1], Jp, Jp, rp, rp);
-			for (int k = 0; k < P * P; k++) B.HAp0[g * P * P + k] = B.HAp[g * P * P + k]; // latch for Schur (schur.h:38,165-168)
+			const int *rec = B.hap_rec + (d.o_hap + bi) * 3; const int b = rec[0]; const long long g = d.o_hap + b; // {block, first term, end term}: longest lists first
+			// the Schur complement works on HAp in place and restores it from the latch for every lambda (schur.h:38,165-168,188)
+			ninv += hess_block<P, P>(B.HAp + g * P * P, latch ? B.HAp0 + g * P * P : nullptr, B.hap_t1 + d.o_hapt, B.hap_t2 + d.o_hapt, rec[1], rec[2], Jp, Jp, rp, rp);
 		}
 		if constexpr (!T::REL) {
 			for (int b = tid; b < d.n_hf; b += SRBA_WG)
-				ninv += hess_block<L, L>(B.Hf + (d.o_hf + b) * L * L, B.hf_t1 + d.o_hft, B.hf_t2 + d.o_hft, B.hf_term_off[d.o_hfoff + b], B.hf_term_off[d.o_hfoff + b + 1], Jf, Jf, rf, rf);
+				ninv += hess_block<L, L>(B.Hf + (d.o_hf + b) * L * L, nullptr, B.hf_t1 + d.o_hft, B.hf_t2 + d.o_hft, B.hf_term_off[d.o_hfoff + b], B.hf_term_off[d.o_hfoff + b + 1], Jf, Jf, rf, rf);
 			for (int b = tid; b < d.n_hapf; b += SRBA_WG)
-				ninv += hess_block<P, L>(B.HApf + (d.o_hapf + b) * P * L, B.hapf_t1 + d.o_hapft, B.hapf_t2 + d.o_hapft, B.hapf_term_off[d.o_hapfoff + b], B.hapf_term_off[d.o_hapfoff + b + 1], Jp, Jf, rp, rf);
+				ninv += hess_block<P, L>(B.HApf + (d.o_hapf + b) * P * L, nullptr, B.hapf_t1 + d.o_hapft, B.hapf_t2 + d.o_hapft, B.hapf_term_off[d.o_hapfoff + b], B.hapf_term_off[d.o_hapfoff + b + 1], Jp, Jf, rp, rf);
 		}
 		return ninv;
 	}

@@ -695,7 +695,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	// ---- input arena layout
 	Arena in; struct { size_t desc, edge0, ulm0, klm, obs_z, pair_path_off, path_edge, obs_pose, obs_lm, obs_valid, bp_col, bp_res, bp_A, bp_D, bp_lm, colp_off, bf_col, bf_res, bf_pose, colf_off,
 		hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hf_i, hf_j, hf_term_off, hf_t1, hf_t2, hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag, sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw,
-		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, pair_needed, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_ab, sp_rptr, sp_rcol, sp_rblk, sp_perm, hap_order, hap_dst, hapf_dst, hf_dst; } o;
+		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, pair_needed, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_ab, sp_rptr, sp_rcol, sp_rblk, sp_perm, hap_rec, hap_dst, hapf_dst, hf_dst; } o;
 	o.desc = in.add(sizeof(ProbDesc) * n);
 	o.edge0 = in.add(8 * t_edge * PDX); o.ulm0 = in.add(8 * t_ulm * L); o.klm = in.add(8 * t_klm * L); o.obs_z = in.add(8 * t_obs * O);
 	o.pair_path_off = in.add(4 * (t_pair + n)); o.path_edge = in.add(4 * t_path); o.obs_pose = in.add(4 * t_obs); o.obs_lm = in.add(4 * t_obs); o.obs_valid = in.add(4 * t_obs);
@@ -707,7 +707,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	o.hap_diag = in.add(4 * t_unk); o.hf_diag = in.add(4 * t_ulm);
 	o.sch_term_off = in.add(4 * (t_hap + n)); o.sch_b1 = in.add(4 * t_sch); o.sch_b2 = in.add(4 * t_sch); o.sch_lm = in.add(4 * t_sch); o.sch_yw = in.add(4 * t_sch);
 	o.lm_hapf_off = in.add(4 * (t_ulm + n)); o.lm_hapf_idx = in.add(4 * t_hapf); o.req_idx = in.add(4 * t_req); o.need_idx = in.add(4 * t_pair); o.need_rec = in.add(4 * 5 * std::max<long long>(t_pair, 1)); o.pair_needed = in.add(t_pair); o.bp_normal = in.add(t_bp); o.order = in.add(4 * (size_t)n);
-	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_ab = in.add(4 * t_spitem); o.sp_rptr = in.add(4 * t_spcol); o.sp_rcol = in.add(4 * t_sprow); o.sp_rblk = in.add(4 * t_sprow); o.sp_perm = in.add(4 * t_spcol); o.hap_order = in.add(4 * std::max<long long>(t_hap, 1));
+	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_ab = in.add(4 * t_spitem); o.sp_rptr = in.add(4 * t_spcol); o.sp_rcol = in.add(4 * t_sprow); o.sp_rblk = in.add(4 * t_sprow); o.sp_perm = in.add(4 * t_spcol); o.hap_rec = in.add(4 * 3 * std::max<long long>(t_hap, 1));
 	o.hap_dst = in.add(4 * t_hap * (P / 3) * (P / 3)); o.hapf_dst = in.add(4 * t_hapf * (P / 3)); o.hf_dst = in.add(4 * t_hf);
 	in.add(0);
 	c->h_in.assign(in.size + 256, 0); char *h = c->h_in.data();
@@ -746,8 +746,9 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 		CPY(o.sp_col_off, d.o_spcol, sym[p].col_off.data(), d.nb + 1, int32_t); CPY(o.sp_row, d.o_sprow, sym[p].row.data(), d.nnzoff, int32_t);
 		CPY(o.sp_item_off, d.o_spcol, sym[p].item_off.data(), d.nb + 1, int32_t); CPY(o.sp_perm, d.o_spperm, sym[p].perm.data(), d.nb, int32_t); CPY(o.sp_tgt, d.o_spitem, sym[p].tgt.data(), sym[p].tgt.size(), int32_t); CPY(o.sp_ab, d.o_spitem, sym[p].ab.data(), sym[p].ab.size(), int32_t);
 		CPY(o.sp_rptr, d.o_spcol, sym[p].rptr.data(), d.nb + 1, int32_t); CPY(o.sp_rcol, d.o_sprow, sym[p].rcol.data(), d.nnzoff, int32_t); CPY(o.sp_rblk, d.o_sprow, sym[p].rblk.data(), d.nnzoff, int32_t);
-		{ int32_t *ho = (int32_t *)(h + o.hap_order) + d.o_hap; for (int b = 0; b < k.n_hap; b++) ho[b] = b;
-		  std::stable_sort(ho, ho + k.n_hap, [&](int x, int y) { return k.hap_term_off[x + 1] - k.hap_term_off[x] > k.hap_term_off[y + 1] - k.hap_term_off[y]; }); }
+		{ std::vector<int32_t> ho(k.n_hap); for (int b = 0; b < k.n_hap; b++) ho[b] = b;
+		  std::stable_sort(ho.begin(), ho.end(), [&](int x, int y) { return k.hap_term_off[x + 1] - k.hap_term_off[x] > k.hap_term_off[y + 1] - k.hap_term_off[y]; });
+		  int32_t *hr = (int32_t *)(h + o.hap_rec) + 3 * d.o_hap; for (int i = 0; i < k.n_hap; i++) { hr[3 * i] = ho[i]; hr[3 * i + 1] = k.hap_term_off[ho[i]]; hr[3 * i + 2] = k.hap_term_off[ho[i] + 1]; } }
 		CPY(o.hap_dst, d.o_hap * (P / 3) * (P / 3), sym[p].hap_dst.data(), sym[p].hap_dst.size(), int32_t); CPY(o.hapf_dst, d.o_hapf * (P / 3), sym[p].hapf_dst.data(), sym[p].hapf_dst.size(), int32_t); CPY(o.hf_dst, d.o_hf, sym[p].hf_dst.data(), sym[p].hf_dst.size(), int32_t);
 		st.n_chol_blocks += d.nb + d.nnzoff; st.n_chol_items += (int64_t)sym[p].tgt.size();
 	}
@@ -782,7 +783,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	Batch &B = c->B; std::memset(&B, 0, sizeof(B)); B.n_prob = n; B.max_lds_doubles = 0;
 	char *di = c->d_in, *dw = c->d_wk;
 #define DI(field, T) B.field = (const T *)(di + o.field)
-	B.desc = (const ProbDesc *)(di + o.desc); DI(order, int); DI(sp_col_off, int); DI(sp_row, int); DI(sp_item_off, int); DI(sp_tgt, int); DI(sp_ab, int); DI(sp_rptr, int); DI(sp_rcol, int); DI(sp_rblk, int); DI(sp_perm, int); DI(hap_order, int); DI(hap_dst, int); DI(hapf_dst, int); DI(hf_dst, int); DI(edge0, double); DI(ulm0, double); DI(klm, double); DI(obs_z, double);
+	B.desc = (const ProbDesc *)(di + o.desc); DI(order, int); DI(sp_col_off, int); DI(sp_row, int); DI(sp_item_off, int); DI(sp_tgt, int); DI(sp_ab, int); DI(sp_rptr, int); DI(sp_rcol, int); DI(sp_rblk, int); DI(sp_perm, int); DI(hap_rec, int); DI(hap_dst, int); DI(hapf_dst, int); DI(hf_dst, int); DI(edge0, double); DI(ulm0, double); DI(klm, double); DI(obs_z, double);
 	DI(pair_path_off, int); DI(path_edge, int); DI(obs_pose, int); DI(obs_lm, int); DI(obs_valid, int); DI(bp_col, int); DI(bp_res, int); DI(bp_A, int); DI(bp_D, int); DI(bp_lm, int); DI(colp_off, int);
 	DI(bf_col, int); DI(bf_res, int); DI(bf_pose, int); DI(colf_off, int); DI(hap_i, int); DI(hap_j, int); DI(hap_term_off, int); DI(hap_t1, int); DI(hap_t2, int); DI(hf_i, int); DI(hf_j, int); DI(hf_term_off, int); DI(hf_t1, int); DI(hf_t2, int);
 	DI(hapf_i, int); DI(hapf_j, int); DI(hapf_term_off, int); DI(hapf_t1, int); DI(hapf_t2, int); DI(hap_diag, int); DI(hf_diag, int); DI(sch_term_off, int); DI(sch_b1, int); DI(sch_b2, int); DI(sch_lm, int); DI(sch_yw, int);
