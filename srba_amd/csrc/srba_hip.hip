@@ -131,8 +131,14 @@ struct Solver : public Worker<FAM> {
 	}
 	__device__ void assemble(const SparseSys &S, double lambda) { this->fresh();
 		const int n = d.n_sys, nb = d.nb;
-		for (int k = tid; k < 9 * nb; k += SRBA_WG) S.diag[k] = 0;
-		for (int k = tid; k < 9 * S.nnzoff; k += SRBA_WG) S.off[k] = 0;
+		if (d.aligned) { // every block is overwritten whole by put_block below, except the fill-in blocks (listed by the host): zero only those
+			for (int i = tid; i < d.n_fill; i += SRBA_WG) { double *o = S.diag + 9 * B.sp_fill[d.o_spfill + i];
+#pragma unroll
+				for (int q = 0; q < 9; q++) o[q] = 0; }
+		} else {
+			for (int k = tid; k < 9 * nb; k += SRBA_WG) S.diag[k] = 0;
+			for (int k = tid; k < 9 * S.nnzoff; k += SRBA_WG) S.off[k] = 0;
+		}
 		const double *g = B.grad + d.o_scal;
 		for (int k = tid; k < 3 * nb; k += SRBA_WG) S.rhs[3 * S.perm[k / 3] + k % 3] = (k < n) ? g[k] : 0.0;
 		__syncthreads();
@@ -411,7 +417,7 @@ struct Arena { // layout builder: 256-byte aligned sub-allocations inside one bu
 
 #define SRBA_NCLS 20  /* 19 LDS size classes (6 KB ... 152 KB per wavefront) + one class for systems factored in HBM */
 // Symbolic block factorisation of one capsule's system (natural block order): the numeric kernel never discovers structure.
-struct Symbolic { std::vector<int32_t> col_off, row, item_off, tgt, ab, rptr, rcol, rblk, perm, hap_dst, hapf_dst, hf_dst; int max_cn = 0; bool aligned = true; };
+struct Symbolic { std::vector<int32_t> fill; std::vector<int32_t> col_off, row, item_off, tgt, ab, rptr, rcol, rblk, perm, hap_dst, hapf_dst, hf_dst; int max_cn = 0; bool aligned = true; };
 static void symbolic_factor(const srba_problem_capsule &k, const ProbDesc &d, int P, int L, bool full_system, Symbolic &out) {
 	const int nb = d.nb;
 	// 1) block-level adjacency of the system (original numbering)
@@ -485,6 +491,11 @@ static void symbolic_factor(const srba_problem_capsule &k, const ProbDesc &d, in
 		for (int b = 0; b < k.n_hapf; b++) for (int si = 0; si < PB; si++) out.hapf_dst.push_back(dst_of(k.hapf_i[b] * PB + si, lb + k.hapf_j[b]));
 		for (int b = 0; b < k.n_hf; b++) out.hf_dst.push_back(dst_of(lb + k.hf_i[b], lb + k.hf_j[b]));
 	} else { out.hapf_dst.assign((size_t)k.n_hapf * PB, 0); out.hf_dst.assign(k.n_hf, 0); }
+	// 5) blocks without a source (fill-in; unified index: diag k -> k, off-diagonal i -> nb+i)
+	{ std::vector<char> covered(nb + out.row.size(), 0);
+	  auto mark = [&](const std::vector<int32_t> &v) { for (size_t i = 0; i < v.size(); i++) { const int32_t dsti = v[i]; if (dsti == (int32_t)0x80000000) continue; covered[dsti >= 0 ? nb + (dsti >> 1) : -1 - dsti] = 1; } };
+	  mark(out.hap_dst); if (full_system && L == 3) { mark(out.hapf_dst); mark(out.hf_dst); }
+	  out.fill.clear(); for (size_t u = 0; u < covered.size(); u++) if (!covered[u]) out.fill.push_back((int32_t)u); }
 }
 
 struct LaunchJob { int queue, cls, first, count; double cost; };
@@ -657,7 +668,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	c->desc.assign(n, ProbDesc()); srba_batch_stats &st = c->stats; std::memset(&st, 0, sizeof(st)); st.n_problems = n;
 	// ---- pass 1: descriptors and totals
 	long long t_edge = 0, t_unk = 0, t_ulm = 0, t_klm = 0, t_pair = 0, t_path = 0, t_obs = 0, t_valid = 0, t_bp = 0, t_bf = 0, t_hap = 0, t_hapt = 0, t_hf = 0, t_hft = 0, t_hapf = 0, t_hapft = 0, t_sch = 0, t_req = 0, t_scal = 0, t_yw = 0, t_dense = 0;
-	std::vector<int> cls(n, 0); int cls_nbmax[SRBA_NCLS] = {0}; std::vector<Symbolic> sym(n); long long t_spcol = 0, t_sprow = 0, t_spitem = 0;
+	std::vector<int> cls(n, 0); int cls_nbmax[SRBA_NCLS] = {0}; std::vector<Symbolic> sym(n); long long t_spcol = 0, t_sprow = 0, t_spitem = 0, t_spfill = 0;
 	for (int p = 0; p < n; p++) {
 		const srba_problem_capsule &k = caps[p]; ProbDesc &d = c->desc[p];
 		if (k.n_unk_edges < 0 || k.n_unk_lms < 0 || k.n_unk_edges > k.n_edges || (k.n_unk_edges + k.n_unk_lms) == 0) { c->fail("upload: malformed capsule"); return -1; }
@@ -674,6 +685,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 		d.nnzoff = (int)sym[p].row.size(); d.n_items = (int)sym[p].tgt.size(); d.aligned = sym[p].aligned ? 1 : 0;
 		d.o_spcol = t_spcol; d.o_sprow = t_sprow; d.o_spitem = t_spitem; d.o_spperm = t_spcol - p;
 		t_spcol += d.nb + 1; t_sprow += d.nnzoff; t_spitem += (long long)sym[p].tgt.size();
+		d.n_fill = (int)sym[p].fill.size(); d.o_spfill = t_spfill; t_spfill += d.n_fill;
 		const size_t n_ints = 2 * ((size_t)d.nb + 1) + 2 * (size_t)d.nnzoff + (size_t)d.n_items + (size_t)d.nb;
 		const bool packable = d.nb + d.nnzoff < 16384 && d.nb < 16384 && sym[p].max_cn < 512; // item / row-entry words of the LDS copy
 		const size_t tri_n = 9 * (size_t)d.nb + 9 * (size_t)d.nnzoff + 3 * (size_t)d.nb + (n_ints + 1) / 2; // diag | off | rhs | symbolic ints
@@ -695,7 +707,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	// ---- input arena layout
 	Arena in; struct { size_t desc, edge0, ulm0, klm, obs_z, pair_path_off, path_edge, obs_pose, obs_lm, obs_valid, bp_col, bp_res, bp_A, bp_D, bp_lm, colp_off, bf_col, bf_res, bf_pose, colf_off,
 		hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hf_i, hf_j, hf_term_off, hf_t1, hf_t2, hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag, sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw,
-		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, pair_needed, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_ab, sp_rptr, sp_rcol, sp_rblk, sp_perm, hap_rec, hap_dst, hapf_dst, hf_dst; } o;
+		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, pair_needed, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_ab, sp_rptr, sp_rcol, sp_rblk, sp_perm, sp_fill, hap_rec, hap_dst, hapf_dst, hf_dst; } o;
 	o.desc = in.add(sizeof(ProbDesc) * n);
 	o.edge0 = in.add(8 * t_edge * PDX); o.ulm0 = in.add(8 * t_ulm * L); o.klm = in.add(8 * t_klm * L); o.obs_z = in.add(8 * t_obs * O);
 	o.pair_path_off = in.add(4 * (t_pair + n)); o.path_edge = in.add(4 * t_path); o.obs_pose = in.add(4 * t_obs); o.obs_lm = in.add(4 * t_obs); o.obs_valid = in.add(4 * t_obs);
@@ -707,7 +719,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	o.hap_diag = in.add(4 * t_unk); o.hf_diag = in.add(4 * t_ulm);
 	o.sch_term_off = in.add(4 * (t_hap + n)); o.sch_b1 = in.add(4 * t_sch); o.sch_b2 = in.add(4 * t_sch); o.sch_lm = in.add(4 * t_sch); o.sch_yw = in.add(4 * t_sch);
 	o.lm_hapf_off = in.add(4 * (t_ulm + n)); o.lm_hapf_idx = in.add(4 * t_hapf); o.req_idx = in.add(4 * t_req); o.need_idx = in.add(4 * t_pair); o.need_rec = in.add(4 * 5 * std::max<long long>(t_pair, 1)); o.pair_needed = in.add(t_pair); o.bp_normal = in.add(t_bp); o.order = in.add(4 * (size_t)n);
-	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_ab = in.add(4 * t_spitem); o.sp_rptr = in.add(4 * t_spcol); o.sp_rcol = in.add(4 * t_sprow); o.sp_rblk = in.add(4 * t_sprow); o.sp_perm = in.add(4 * t_spcol); o.hap_rec = in.add(4 * 3 * std::max<long long>(t_hap, 1));
+	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_ab = in.add(4 * t_spitem); o.sp_rptr = in.add(4 * t_spcol); o.sp_rcol = in.add(4 * t_sprow); o.sp_rblk = in.add(4 * t_sprow); o.sp_perm = in.add(4 * t_spcol); o.hap_rec = in.add(4 * 3 * std::max<long long>(t_hap, 1)); o.sp_fill = in.add(4 * std::max<long long>(t_spfill, 1));
 	o.hap_dst = in.add(4 * t_hap * (P / 3) * (P / 3)); o.hapf_dst = in.add(4 * t_hapf * (P / 3)); o.hf_dst = in.add(4 * t_hf);
 	in.add(0);
 	c->h_in.assign(in.size + 256, 0); char *h = c->h_in.data();
@@ -745,7 +757,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 		CPY(o.pair_needed, d.o_pair, k.pair_needed, k.n_pairs, uint8_t); CPY(o.bp_normal, d.o_bp, k.bp_normal, k.n_bp, uint8_t);
 		CPY(o.sp_col_off, d.o_spcol, sym[p].col_off.data(), d.nb + 1, int32_t); CPY(o.sp_row, d.o_sprow, sym[p].row.data(), d.nnzoff, int32_t);
 		CPY(o.sp_item_off, d.o_spcol, sym[p].item_off.data(), d.nb + 1, int32_t); CPY(o.sp_perm, d.o_spperm, sym[p].perm.data(), d.nb, int32_t); CPY(o.sp_tgt, d.o_spitem, sym[p].tgt.data(), sym[p].tgt.size(), int32_t); CPY(o.sp_ab, d.o_spitem, sym[p].ab.data(), sym[p].ab.size(), int32_t);
-		CPY(o.sp_rptr, d.o_spcol, sym[p].rptr.data(), d.nb + 1, int32_t); CPY(o.sp_rcol, d.o_sprow, sym[p].rcol.data(), d.nnzoff, int32_t); CPY(o.sp_rblk, d.o_sprow, sym[p].rblk.data(), d.nnzoff, int32_t);
+		CPY(o.sp_rptr, d.o_spcol, sym[p].rptr.data(), d.nb + 1, int32_t); CPY(o.sp_rcol, d.o_sprow, sym[p].rcol.data(), d.nnzoff, int32_t); CPY(o.sp_rblk, d.o_sprow, sym[p].rblk.data(), d.nnzoff, int32_t); CPY(o.sp_fill, d.o_spfill, sym[p].fill.data(), d.n_fill, int32_t);
 		{ std::vector<int32_t> ho(k.n_hap); for (int b = 0; b < k.n_hap; b++) ho[b] = b;
 		  std::stable_sort(ho.begin(), ho.end(), [&](int x, int y) { return k.hap_term_off[x + 1] - k.hap_term_off[x] > k.hap_term_off[y + 1] - k.hap_term_off[y]; });
 		  int32_t *hr = (int32_t *)(h + o.hap_rec) + 3 * d.o_hap; for (int i = 0; i < k.n_hap; i++) { hr[3 * i] = ho[i]; hr[3 * i + 1] = k.hap_term_off[ho[i]]; hr[3 * i + 2] = k.hap_term_off[ho[i] + 1]; } }
@@ -783,7 +795,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	Batch &B = c->B; std::memset(&B, 0, sizeof(B)); B.n_prob = n; B.max_lds_doubles = 0;
 	char *di = c->d_in, *dw = c->d_wk;
 #define DI(field, T) B.field = (const T *)(di + o.field)
-	B.desc = (const ProbDesc *)(di + o.desc); DI(order, int); DI(sp_col_off, int); DI(sp_row, int); DI(sp_item_off, int); DI(sp_tgt, int); DI(sp_ab, int); DI(sp_rptr, int); DI(sp_rcol, int); DI(sp_rblk, int); DI(sp_perm, int); DI(hap_rec, int); DI(hap_dst, int); DI(hapf_dst, int); DI(hf_dst, int); DI(edge0, double); DI(ulm0, double); DI(klm, double); DI(obs_z, double);
+	B.desc = (const ProbDesc *)(di + o.desc); DI(order, int); DI(sp_col_off, int); DI(sp_row, int); DI(sp_item_off, int); DI(sp_tgt, int); DI(sp_ab, int); DI(sp_rptr, int); DI(sp_rcol, int); DI(sp_rblk, int); DI(sp_perm, int); DI(hap_rec, int); DI(sp_fill, int); DI(hap_dst, int); DI(hapf_dst, int); DI(hf_dst, int); DI(edge0, double); DI(ulm0, double); DI(klm, double); DI(obs_z, double);
 	DI(pair_path_off, int); DI(path_edge, int); DI(obs_pose, int); DI(obs_lm, int); DI(obs_valid, int); DI(bp_col, int); DI(bp_res, int); DI(bp_A, int); DI(bp_D, int); DI(bp_lm, int); DI(colp_off, int);
 	DI(bf_col, int); DI(bf_res, int); DI(bf_pose, int); DI(colf_off, int); DI(hap_i, int); DI(hap_j, int); DI(hap_term_off, int); DI(hap_t1, int); DI(hap_t2, int); DI(hf_i, int); DI(hf_j, int); DI(hf_term_off, int); DI(hf_t1, int); DI(hf_t2, int);
 	DI(hapf_i, int); DI(hapf_j, int); DI(hapf_term_off, int); DI(hapf_t1, int); DI(hapf_t2, int); DI(hap_diag, int); DI(hf_diag, int); DI(sch_term_off, int); DI(sch_b1, int); DI(sch_b2, int); DI(sch_lm, int); DI(sch_yw, int);
