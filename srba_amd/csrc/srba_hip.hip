@@ -499,6 +499,38 @@ static void symbolic_factor(const srba_problem_capsule &k, const ProbDesc &d, in
 }
 
 struct LaunchJob { int queue, cls, first, count; double cost; };
+// Index-range check of one capsule (every index the kernels dereference): a wrong capsule is reported at upload instead of reading out of bounds on the device
+static const char *validate_capsule(const srba_problem_capsule &k) {
+	auto in = [](int v, int lo, int hi) { return v >= lo && v < hi; };
+	if (k.n_edges < 0 || k.n_unk_edges < 0 || k.n_unk_lms < 0 || k.n_known_lms < 0 || k.n_pairs < 0 || k.n_path < 0 || k.n_obs < 0 || k.n_valid < 0 || k.n_bp < 0 || k.n_bf < 0 || k.n_hap < 0 || k.n_hf < 0 || k.n_hapf < 0 || k.n_sch_terms < 0) return "negative size";
+	if (k.n_unk_edges > k.n_edges || k.n_unk_edges + k.n_unk_lms == 0) return "no unknowns / more unknown edges than edges";
+	const int np2 = 2 * k.n_pairs;
+	auto lmref = [&](int v) { return v >= 0 ? v < k.n_unk_lms : (-1 - v) < k.n_known_lms; };
+	if (k.n_pairs && (!k.pair_path_off || !k.pair_needed || !k.pose_required || k.pair_path_off[0] != 0 || k.pair_path_off[k.n_pairs] != k.n_path)) return "pair_path_off";
+	for (int i = 0; i < k.n_pairs; i++) if (k.pair_path_off[i + 1] < k.pair_path_off[i]) return "pair_path_off not monotone";
+	for (int i = 0; i < k.n_path; i++) if (k.path_edge[i] < 0 || (k.path_edge[i] >> 1) >= k.n_edges) return "path_edge";
+	for (int i = 0; i < k.n_obs; i++) if (!in(k.obs_pose[i], -1, np2) || !lmref(k.obs_lm[i]) || !in(k.obs_valid[i], 0, std::max(k.n_valid, 1))) return "observation table";
+	if (k.n_unk_edges && (!k.colp_off || k.colp_off[0] != 0 || k.colp_off[k.n_unk_edges] != k.n_bp)) return "colp_off";
+	for (int i = 0; i < k.n_bp; i++) if (!in(k.bp_col[i], 0, k.n_unk_edges) || !in(k.bp_res[i], 0, k.n_obs) || !in(k.bp_A[i], -1, np2) || !in(k.bp_D[i], -1, np2) || !lmref(k.bp_lm[i])) return "dh_dAp block table";
+	if (k.n_unk_lms && k.n_bf && (!k.colf_off || k.colf_off[0] != 0 || k.colf_off[k.n_unk_lms] != k.n_bf)) return "colf_off";
+	for (int i = 0; i < k.n_bf; i++) if (!in(k.bf_col[i], 0, k.n_unk_lms) || !in(k.bf_res[i], 0, k.n_obs) || !in(k.bf_pose[i], -1, np2)) return "dh_df block table";
+	if (k.n_hap && (k.hap_term_off[0] != 0 || k.hap_term_off[k.n_hap] != k.n_hap_terms)) return "hap_term_off";
+	for (int i = 0; i < k.n_hap; i++) if (!in(k.hap_i[i], 0, k.n_unk_edges) || !in(k.hap_j[i], 0, k.n_unk_edges) || k.hap_term_off[i + 1] < k.hap_term_off[i]) return "HAp block table";
+	for (int i = 0; i < k.n_hap_terms; i++) if (!in(k.hap_t1[i], 0, k.n_bp) || !in(k.hap_t2[i], 0, k.n_bp)) return "HAp terms";
+	for (int i = 0; i < k.n_unk_edges; i++) if (!in(k.hap_diag[i], 0, k.n_hap)) return "hap_diag";
+	if (k.n_hf && (k.hf_term_off[0] != 0 || k.hf_term_off[k.n_hf] != k.n_hf_terms)) return "hf_term_off";
+	for (int i = 0; i < k.n_hf; i++) if (!in(k.hf_i[i], 0, k.n_unk_lms) || !in(k.hf_j[i], 0, k.n_unk_lms)) return "Hf block table";
+	for (int i = 0; i < k.n_hf_terms; i++) if (!in(k.hf_t1[i], 0, k.n_bf) || !in(k.hf_t2[i], 0, k.n_bf)) return "Hf terms";
+	for (int i = 0; i < k.n_unk_lms && k.n_hf; i++) if (!in(k.hf_diag[i], 0, k.n_hf)) return "hf_diag";
+	if (k.n_hapf && (k.hapf_term_off[0] != 0 || k.hapf_term_off[k.n_hapf] != k.n_hapf_terms)) return "hapf_term_off";
+	for (int i = 0; i < k.n_hapf; i++) if (!in(k.hapf_i[i], 0, k.n_unk_edges) || !in(k.hapf_j[i], 0, k.n_unk_lms)) return "HApf block table";
+	for (int i = 0; i < k.n_hapf_terms; i++) if (!in(k.hapf_t1[i], 0, k.n_bp) || !in(k.hapf_t2[i], 0, k.n_bf)) return "HApf terms";
+	if (k.n_sch_terms) { if (!k.sch_term_off || k.sch_term_off[k.n_hap] != k.n_sch_terms) return "sch_term_off";
+		for (int i = 0; i < k.n_sch_terms; i++) if (!in(k.sch_b1[i], 0, k.n_hapf) || !in(k.sch_b2[i], 0, k.n_hapf) || !in(k.sch_lm[i], 0, k.n_unk_lms)) return "Schur terms";
+		for (int i = 0; i < k.n_hapf; i++) if (!in(k.lm_hapf_idx[i], 0, k.n_hapf)) return "lm_hapf_idx"; }
+	return nullptr;
+}
+
 // first element of slice q when cnt items are dealt round-robin to nq slices
 static inline int slice_begin(int cnt, int q, int nq) { return q * (cnt / nq) + std::min(q, cnt % nq); }
 
@@ -671,7 +703,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	std::vector<int> cls(n, 0); int cls_nbmax[SRBA_NCLS] = {0}; std::vector<Symbolic> sym(n); long long t_spcol = 0, t_sprow = 0, t_spitem = 0, t_spfill = 0;
 	for (int p = 0; p < n; p++) {
 		const srba_problem_capsule &k = caps[p]; ProbDesc &d = c->desc[p];
-		if (k.n_unk_edges < 0 || k.n_unk_lms < 0 || k.n_unk_edges > k.n_edges || (k.n_unk_edges + k.n_unk_lms) == 0) { c->fail("upload: malformed capsule"); return -1; }
+		if (const char *why = validate_capsule(k)) { c->fail(std::string("upload: malformed capsule (") + why + ")"); return -1; }
 		d.n_edges = k.n_edges; d.nK = k.n_unk_edges; d.nF = k.n_unk_lms; d.n_klm = k.n_known_lms; d.n_pairs = k.n_pairs; d.n_obs = k.n_obs; d.n_valid = k.n_valid; d.n_bp = k.n_bp; d.n_bf = k.n_bf;
 		d.n_hap = k.n_hap; d.n_hf = k.n_hf; d.n_hapf = k.n_hapf; d.n_sch = k.n_sch_terms;
 		d.n_scal = P * d.nK + L * d.nF; d.n_sys = (schur_solver && d.nF > 0 && d.nK > 0) ? P * d.nK : d.n_scal;

@@ -159,3 +159,49 @@ def test_large_windows_depth5():
     ref = runner.run_batch_oracle(sub); gpu = runner.run_batch_hip(sub)
     assert max(sub.ptr[i].n_unk_edges for i in range(sub.n)) >= 60
     _compare_lm(sub, gpu, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,solver", [(k, s) for k in ("rb2d", "cart3d", "stereo", "rb3d") for s in (capi.SOLVER_SCHUR_DENSE, capi.SOLVER_SCHUR_SPARSE, capi.SOLVER_NO_SCHUR_SPARSE)])
+def test_landmark_families_all_solvers(kind, solver):
+    """Every reference solver (lev-marq_solvers.h: Schur+dense LLT, Schur+sparse, full sparse) on landmark problems: the device factors the
+    same SPD system in one way, so all three must reproduce the oracle's chi2 (which runs the reference's three code paths)."""
+    if kind in ("rb2d",):
+        ds, _ = datasets.landmarks_dataset_se2(kind, n_kf=30, n_lm=900, seed=7, noise=1e-3)
+    else:
+        ds, _ = datasets.landmarks_dataset_se3(kind, n_kf=16, n_lm=320, seed=7, noise=(0.1 if kind == "stereo" else 1e-3))
+    eng = runner.landmark_engine(kind, backend="oracle", solver=solver)
+    eng.run(ds)
+    b = eng.harvest(); b.engine = eng
+    sub = b.sub(max(0, b.n - 8), min(8, b.n))
+    ref = runner.run_batch_oracle(sub); gpu = runner.run_batch_hip(sub)
+    assert np.all(gpu["status"] == ref["status"])
+    assert _close(gpu["chi2_init"], ref["chi2_init"], rel=1e-9)
+    assert _close(gpu["chi2_final"], ref["chi2_final"], rel=1e-6, abs_=1e-18)
+    assert np.array_equal(gpu["num_observations"], ref["num_observations"]) and np.array_equal(gpu["num_jacobians"], ref["num_jacobians"])
+
+
+@pytest.mark.gpu
+def test_abi_misuse_is_reported_not_fatal(se2_batch):
+    """error behaviour of the C ABI: run before upload, empty upload, malformed capsule, under-determined problem (optimize_edges.h:355)"""
+    import ctypes as C
+    ctx = runner.HipContext(se2_batch.params)
+    lib = ctx.lib
+    assert lib.srba_hip_lm_run(ctx.ctx, None) != 0 and b"no batch" in lib.srba_hip_last_error(ctx.ctx)
+    assert lib.srba_hip_upload_problems(ctx.ctx, se2_batch.ptr, 0) != 0
+    bad = se2_batch.clone(0, 1); bad.ptr[0].n_unk_edges = bad.ptr[0].n_edges + 1
+    assert lib.srba_hip_upload_problems(ctx.ctx, bad.ptr, 1) != 0 and b"malformed" in lib.srba_hip_last_error(ctx.ctx)
+    bad = se2_batch.clone(0, 1); bad.ptr[0].n_obs = 1      # block tables now point past the observation table
+    assert lib.srba_hip_upload_problems(ctx.ctx, bad.ptr, 1) != 0 and b"malformed" in lib.srba_hip_last_error(ctx.ctx)
+    ctx.upload(se2_batch.sub(0, 4)); r = ctx.lm_run()   # the context stays usable
+    assert np.all(r["status"] == 0)
+
+
+@pytest.mark.gpu
+def test_underdetermined_problem_raises_like_the_reference():
+    """optimize_edges.h:355 ASSERT_ABOVEEQ_(OBS_DIMS*nObs, nUnknowns): one range-bearing landmark shared by two key-frames gives 4 observation
+    scalars for 5 unknowns; the kernel reports status 1 without iterating and the front-end throws."""
+    eng = runner.landmark_engine("rb2d", backend="hip", harvest=0, min_obs_to_loop_closure=1)
+    eng.add_keyframe([7], np.array([[2.0, 0.1]]), flags=np.zeros(1))
+    with pytest.raises(RuntimeError, match="OBS_DIMS"):
+        eng.add_keyframe([7], np.array([[1.5, 0.2]]), flags=np.zeros(1))
