@@ -544,7 +544,7 @@ struct srba_hip_ctx {
 	int n_prob = 0; std::vector<ProbDesc> desc; Batch B; srba_batch_stats stats;
 	char *d_in = nullptr; size_t cap_in = 0; char *d_wk = nullptr; size_t cap_wk = 0;
 	std::vector<char> h_in; // host staging of the input arena
-	int max_lds_kb = 1 << 20; int n_queues = 16, sched = 1, n_streams_used = 1; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
+	int max_lds_kb = 1 << 20, min_chunk = 384, max_parts_per_queue = 2; int n_queues = 16, sched = 1, n_streams_used = 1; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
 	// offsets needed for downloads (bytes inside the wk arena)
 	size_t off_edge = 0, off_ulm = 0, off_pose = 0, off_inf = 0, off_infv = 0, off_res = 0;
 	size_t off_dbg[10] = {0}; int64_t len_dbg[10] = {0};
@@ -580,7 +580,7 @@ static void plan_launches(srba_hip_ctx *c, const int32_t *ord) {
 	}
 	std::vector<LaunchJob> jobs;
 	for (int k = SRBA_NCLS - 1; k >= 0; k--) if (c->cls_count[k]) {
-		const int cnt = c->cls_count[k], parts = std::max(1, std::min(2 * nq, cnt / 384));
+		const int cnt = c->cls_count[k], parts = std::max(1, std::min(c->max_parts_per_queue * nq, cnt / c->min_chunk));
 		for (int q = 0; q < parts; q++) { const int a = slice_begin(cnt, q, parts), b = slice_begin(cnt, q + 1, parts); if (b > a) jobs.push_back({0, k, c->cls_first[k] + a, b - a, cost_of(k, c->cls_first[k] + a, b - a)}); }
 	}
 	std::vector<size_t> by_cost(jobs.size()); for (size_t i = 0; i < jobs.size(); i++) by_cost[i] = i;
@@ -650,6 +650,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_PHASE_TIMING"); c->phase_timing = (e && e[0] == '1'); }
 	{ const char *e = getenv("SRBA_HIP_MAX_LDS_KB"); c->max_lds_kb = e ? atoi(e) : 1 << 20; } // test knob: systems above this many KB are factored in the HBM workspace (0 = all of them)
 	{ const char *e = getenv("SRBA_HIP_LDS_PAD"); c->lds_pad = e ? (size_t)atol(e) : 0; } // diagnostics: extra LDS bytes per workgroup (lowers residency)
+	{ const char *e = getenv("SRBA_HIP_CHUNK"); if (e && atoi(e) > 0) c->min_chunk = atoi(e); e = getenv("SRBA_HIP_PARTS"); if (e && atoi(e) > 0) c->max_parts_per_queue = atoi(e); } // tuning knobs of the launch plan
 	{ const char *e = getenv("SRBA_HIP_SCHED"); if (e) c->sched = atoi(e); } // tuning knob: launch plan (see plan_launches)
 	{ const char *e = getenv("SRBA_HIP_QUEUES"); if (e && atoi(e) >= 1 && atoi(e) < SRBA_NCLS) c->n_queues = atoi(e); } // tuning knob: concurrent launch streams
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || false) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
