@@ -167,6 +167,19 @@ def main():
             if cores > 1:   # and the scalar figure, on a smaller sample
                 m1 = max(200, m // (2 * cores)); t1 = time.perf_counter(); r1 = runner.run_batch_oracle(batch.sub(0, m1), threads=1); dt1 = time.perf_counter() - t1
                 cpu["one_thread_value"] = float(r1["num_trials"].sum() / dt1)
+        # the batch-wide streaming kernels of the same C ABI (one launch per phase over all capsules, no LDS-resident state): their HBM rates
+        def _timed(fn, reps=10):
+            fn(); lib.srba_hip_sync(ctx.ctx); t1 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            lib.srba_hip_sync(ctx.ctx); return (time.perf_counter() - t1) / reps
+        lib.srba_hip_reset_state(ctx.ctx); pbytes = 8 * PD
+        stream = []
+        for name, fn, by in (("k_spantree (K1, all pairs)", lambda: lib.srba_hip_update_spantree(ctx.ctx, 0), stats["n_path"] * (pbytes + 4) + stats["n_pairs"] * 2 * pbytes),
+                             ("k_residuals (K4)", lambda: lib.srba_hip_eval_residuals(ctx.ctx, None), stats["n_obs"] * (pbytes + O * 8 + 12 + O * 8)),
+                             ("k_linearize (K2+K6+K5: Jacobians, Hessian blocks, gradient)", lambda: lib.srba_hip_linearize(ctx.ctx),
+                              stats["n_bp"] * (3 * pbytes + 16 + O * P * 8) + stats["n_hap"] * P * P * 8 + stats["n_hap_terms"] * 2 * O * P * 8 + stats["n_unk_edges"] * P * 8)):
+            tt = _timed(fn); stream.append({"kernel": name, "ms": 1e3 * tt, "algorithmic_bytes": float(by), "GBps": by / tt / 1e9, "frac_of_hbm_peak": by / tt / 8e12})
         line = {
             "metric": "LM iterations/sec (and obs/sec) on 30k-KF graph-SLAM; chi2 match vs CPU", "value": tot_trials * args.steps / max_elapsed, "unit": "LM iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * max_elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -179,6 +192,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": measured_traffic(args.n_kf, batch.n),
                          "kernel": "k_lm_run<SE2_RELPOSE2D> (one launch per LDS size class, concurrent; duration = fork..join)", "kernel_ms": kernel_ms, "kernel_ms_samples": len(kern_ms), "algorithmic_bytes_per_launch": abytes},
             "cpu_baseline": cpu,
+            "streaming_kernels": stream,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
