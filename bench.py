@@ -102,8 +102,12 @@ def main():
     rank, world, local_rank = multi.rank_info()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # test hooks (tests/test_bench_multi.py runs two ranks on ONE GPU over gloo): the driver never sets them
+    if os.environ.get("SRBA_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["SRBA_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
-    dist = multi.init_process_group("nccl")  # RCCL; used for the barrier and the sum/max of the result line only
+    backend = os.environ.get("SRBA_BENCH_BACKEND", "nccl")
+    dist = multi.init_process_group(backend)  # RCCL; used for the barrier and the sum/max of the result line only
 
     import __graft_entry__ as ge
     ge.build()
@@ -147,7 +151,7 @@ def main():
     kern_ms = [hist[i] for i in range(max(nh, 0))]
     kernel_ms = float(np.mean(kern_ms)) if kern_ms else float("nan")
 
-    tot_trials, tot_obs, max_elapsed = multi.aggregate(dist, "cuda", trials_per_step, obs_trials_per_step, elapsed)
+    tot_trials, tot_obs, max_elapsed = multi.aggregate(dist, "cuda" if backend == "nccl" else "cpu", trials_per_step, obs_trials_per_step, elapsed)
 
     if rank == 0:
         stats = ctx.stats(); stats["per_problem"] = per_problem_counts(batch, batch.family)

@@ -1,0 +1,29 @@
+"""bench.py under torch.distributed.run with two ranks (the driver's N>1 launch line), squeezed onto ONE GPU for the test: both ranks use
+device 0 and rendezvous over gloo (RCCL refuses two ranks on one device). Checks the contract of the result line: one JSON line from rank 0,
+n_gpus = 2, whole-job value = sum of both ranks' work over the max elapsed."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_one_json_line(tmp_path):
+    env = dict(os.environ, SRBA_BENCH_DEVICE="0", SRBA_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--n-kf", "1500", "--cpu-seconds", "0", "--cache-dir", str(tmp_path)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["config"]["capsules_per_gpu"] == 1498 and "replicas x2" in d["config"]["parallelism"]
+    per_rank = d["config"]["lm_trials_per_step_per_gpu"]
+    total_per_step = d["value"] * d["ms_per_step"] * 1e-3
+    assert 1.6 * per_rank < total_per_step < 2.4 * per_rank      # two different maps of the same size
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["kernel_ms_samples"] == 3
