@@ -3,6 +3,7 @@ device 0 and rendezvous over gloo (RCCL refuses two ranks on one device). Checks
 n_gpus = 2, whole-job value = sum of both ranks' work over the max elapsed."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -14,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_two_ranks_one_json_line(tmp_path):
     env = dict(os.environ, SRBA_BENCH_DEVICE="0", SRBA_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--n-kf", "1500", "--cpu-seconds", "0", "--cache-dir", str(tmp_path)]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
