@@ -854,6 +854,7 @@ protected:
 		for (size_t i = 0; i < nUnknowns_k2f; i++) cd.unk_lm_ids.push_back(run_feat_ids[i]);
 		std::map<TLandmarkID, int> unk_lm_slot; for (size_t i = 0; i < nUnknowns_k2f; i++) unk_lm_slot[run_feat_ids[i]] = (int)i;
 
+		m_profiler.enter("opt.capsule.s3s4");
 		// S3: involved observations, with the reference's duplicates for k2k columns (:171-234)
 		std::map<size_t, size_t> obs_global_idx2residual_idx; std::vector<size_t> involved_obs;
 		if (in_observation_indices_to_optimize.empty()) {
@@ -871,6 +872,7 @@ protected:
 		for (size_t i = 0; i < nUnknowns_k2f; i++) { const std::vector<TJacobianSymbolicInfo_dh_df> &col = rba_state.lin_system.dh_df[run_feat_cols[i]];
 			for (size_t b = 0; b < col.size(); b++) { const k2f_edge_t &k2f = rba_state.all_observations[col[b].obs_idx]; kfs_num_spantrees_to_update.insert(k2f.feat_rel_pos->id_frame_base); kfs_num_spantrees_to_update.insert(k2f.obs.kf_id); } }
 
+		m_profiler.leave("opt.capsule.s3s4"); m_profiler.enter("opt.capsule.pairs");
 		// ST pair table: every stored path of every root (spantree_update_numeric.h:111-127), local edge table, path flags
 		std::map<size_t, int> local_edge; // global edge id -> local slot
 		for (size_t i = 0; i < nUnknowns_k2k; i++) local_edge[run_k2k_edges[i]] = (int)i;
@@ -903,6 +905,7 @@ protected:
 			if (it == m.end()) throw std::logic_error("optimize_edges: numeric spanning-tree entry not available (graph deeper than max_tree_depth?)");
 			return 2 * it->second + (src > trg ? 0 : 1); } } pose_idx = {pair_index};
 
+		m_profiler.leave("opt.capsule.pairs"); m_profiler.enter("opt.capsule.tables");
 		// landmarks: unknown slots / constants
 		cd.ulm_pos.resize(nUnknowns_k2f * L);
 		for (size_t i = 0; i < nUnknowns_k2f; i++) for (int k = 0; k < L; k++) cd.ulm_pos[i * L + k] = rba_state.all_lms[run_feat_ids[i]].rfp->pos[k];
@@ -956,6 +959,7 @@ protected:
 			cd.colf_off.push_back((int32_t)cd.bf_col.size());
 		}
 		for (size_t p = 0; p < nPairs; p++) cd.pair_needed[p] = (cd.pose_required[2 * p] || cd.pose_required[2 * p + 1]) ? 1 : 0;
+		m_profiler.leave("opt.capsule.tables");
 		// S9 + S15: symbolic Hessian / Schur plan
 		m_profiler.enter("opt.sparse_hessian_build_symbolic");
 		cd.build_plan(bp_row, bf_row, RBA_OPTIONS::solver_t::USE_SCHUR);
