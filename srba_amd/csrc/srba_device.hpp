@@ -719,7 +719,9 @@ struct Worker {
 	// S lanes share one column (blocks dealt round-robin, partial sums combined in a fixed butterfly order -> deterministic)
 	template <int M>
 	__device__ __forceinline__ void grad_cols(double *g, int ncol, const double *J, const int *res, const int *col_off, const double *resid) {
-		int S = 1; while (S < 8 && 2 * S * ncol <= SRBA_WG) S *= 2;
+		// lanes per column: 8 while a single pass covers all columns, else 4 -- ceil(4*ncol/64) quarter-length passes beat ceil(ncol/64) full-length ones
+		// whenever ncol is not a multiple of 64 (67 columns: 1.25 instead of 2 column-times)
+		const int S = 8 * ncol <= SRBA_WG ? 8 : 4;
 		const int per = SRBA_WG / S, sub = tid % S;
 		const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0;
 		for (int base = 0; base < ncol; base += per) {
