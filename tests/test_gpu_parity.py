@@ -205,3 +205,39 @@ def test_underdetermined_problem_raises_like_the_reference():
     eng.add_keyframe([7], np.array([[2.0, 0.1]]), flags=np.zeros(1))
     with pytest.raises(RuntimeError, match="OBS_DIMS"):
         eng.add_keyframe([7], np.array([[1.5, 0.2]]), flags=np.zeros(1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["rb2d", "cart3d", "stereo"])
+def test_schur_complement_on_device_equals_dense(kind):
+    """The reference's SchurTests (tests/schur_unittest.cpp:147-267: block-sparse Schur complement == dense formula, 1e-10 relative, lambda = 1e3) on the
+    device: K7 reduces HAp in place, so after srba_hip_solve the HAp read-back must equal Hpp - Hpf (Hff + lambda I)^-1 Hpf^t built in numpy from the
+    un-reduced device blocks, and the step must solve the full damped system."""
+    from test_oracle_numeric import _dense_system, _harvest
+    b = _harvest(kind)
+    P, L, O, PD = capi.DIMS[b.family]
+    checked = 0
+    for i in range(max(0, b.n - 4), b.n):
+        c = b[i]
+        if c.n_unk_lms == 0 or c.n_unk_edges < 2:
+            continue
+        sub = b.sub(i, 1)
+        ctx = runner.HipContext(b.params); ctx.upload(sub); lib = ctx.lib
+        assert lib.srba_hip_update_spantree(ctx.ctx, 0) == 0 and lib.srba_hip_eval_residuals(ctx.ctx, None) == 0 and lib.srba_hip_linearize(ctx.ctx) == 0
+        a0 = dict(HAp=ctx.debug(3).copy(), Hf=ctx.debug(4).copy(), HApf=ctx.debug(5).copy(), grad=ctx.debug(6).copy())
+        H, n, nK, nF = _dense_system(sub, 0, a0)
+        lam = np.array([1e3]); notpd = np.zeros(1, np.int32)
+        assert lib.srba_hip_solve(ctx.ctx, lam.ctypes.data_as(capi.PF64), notpd.ctypes.data_as(capi.PI32)) == 0 and notpd[0] == 0
+        HAp1, delta = ctx.debug(3), ctx.debug(7)
+        Hpp, Hpf, Hff = H[:P * nK, :P * nK], H[:P * nK, P * nK:], H[P * nK:, P * nK:]
+        S = Hpp - Hpf @ np.linalg.inv(Hff + lam[0] * np.eye(L * nF)) @ Hpf.T
+        hi, hj = sub.array(0, "hap_i", np.int32, c.n_hap), sub.array(0, "hap_j", np.int32, c.n_hap)
+        for k in range(c.n_hap):
+            blk = HAp1[k * P * P:(k + 1) * P * P].reshape(P, P); ref = S[P * hi[k]:P * hi[k] + P, P * hj[k]:P * hj[k] + P]
+            if hi[k] == hj[k]:
+                blk = np.triu(blk); ref = np.triu(ref)
+            assert np.abs(blk - ref).max() <= 1e-10 * np.abs(S).max(), (kind, i, k)
+        full = np.linalg.solve(H + lam[0] * np.eye(n), a0["grad"])
+        assert np.allclose(delta, full, rtol=1e-7, atol=1e-9 * np.abs(full).max()), (kind, i)
+        ctx.close(); checked += 1
+    assert checked >= 2
