@@ -241,3 +241,26 @@ def test_schur_complement_on_device_equals_dense(kind):
         assert np.allclose(delta, full, rtol=1e-7, atol=1e-9 * np.abs(full).max()), (kind, i)
         ctx.close(); checked += 1
     assert checked >= 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["rb2d", "cart2d", "cart3d", "rb3d", "stereo", "mono"])
+def test_stepwise_kernels_match_oracle_landmark_families(kind):
+    """K1, K4, K2, K3, K6, K5 one launch each (srba_hip_update_spantree / eval_residuals / linearize) against the oracle's arrays of the same capsule:
+    residuals, dh_dAp and dh_df blocks, the three Hessian block sets and the gradient, for every landmark family."""
+    from test_oracle_numeric import _harvest
+    b = _harvest(kind)
+    P, L, O, PD = capi.DIMS[b.family]
+    for i in range(max(0, b.n - 3), b.n):
+        c = b[i]; sub = b.sub(i, 1)
+        ctx = runner.HipContext(b.params); ctx.upload(sub); lib = ctx.lib
+        chi = np.zeros(1)
+        assert lib.srba_hip_update_spantree(ctx.ctx, 0) == 0 and lib.srba_hip_eval_residuals(ctx.ctx, chi.ctypes.data_as(capi.PF64)) == 0 and lib.srba_hip_linearize(ctx.ctx) == 0
+        ref = runner.oracle_stage(b, i)
+        assert _close(chi[0], ref["scalars"][0], rel=1e-9)
+        for what, key in ((0, "resid"), (1, "Jp"), (2, "Jf"), (3, "HAp"), (4, "Hf"), (5, "HApf"), (6, "grad"), (9, "poses")):
+            g = ctx.debug(what); r = ref[key]
+            assert g.shape == r.shape, (kind, key)
+            if r.size:
+                assert np.allclose(g, r, rtol=1e-8, atol=1e-9 * max(1e-300, np.abs(r).max())), (kind, i, key, float(np.abs(g - r).max()), float(np.abs(r).max()))
+        ctx.close()
