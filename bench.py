@@ -159,17 +159,19 @@ def main():
         achieved = abytes / (kernel_ms * 1e-3) / 1e9
         cpu = None
         if args.cpu_seconds > 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import _oracle  # tests/_oracle.py: the CPU checker (test infrastructure) -- only this cpu_baseline leg uses it
             # the oracle batched over the host cores (one capsule per thread at a time), on a bounded sample of the same batch
             cores = max(1, min(os.cpu_count() or 1, args.cpu_threads if args.cpu_threads > 0 else 64))
             probe = min(batch.n, 50 * cores)
-            t1 = time.perf_counter(); r = runner.run_batch_oracle(batch.sub(0, probe), threads=cores); dt = time.perf_counter() - t1
+            t1 = time.perf_counter(); r = _oracle.run_batch(batch.sub(0, probe), threads=cores); dt = time.perf_counter() - t1
             m = int(min(batch.n, max(probe, probe * args.cpu_seconds / max(dt, 1e-6))))
-            t1 = time.perf_counter(); r = runner.run_batch_oracle(batch.sub(0, m), threads=cores); dt = time.perf_counter() - t1
+            t1 = time.perf_counter(); r = _oracle.run_batch(batch.sub(0, m), threads=cores); dt = time.perf_counter() - t1
             cpu = {"value": float(r["num_trials"].sum() / dt), "unit": "LM iterations/s", "cores": cores, "kind": "port",
                    "sample": "oracle/srba_oracle.cpp (g++ -O2, %d threads, one capsule per thread at a time) on the first %d of %d capsules of the same batch, %.1f s wall" % (cores, m, batch.n, dt),
                    "obs_per_s": float((r["num_trials"] * r["num_observations"]).sum() / dt)}
             if cores > 1:   # and the scalar figure, on a smaller sample
-                m1 = max(200, m // (2 * cores)); t1 = time.perf_counter(); r1 = runner.run_batch_oracle(batch.sub(0, m1), threads=1); dt1 = time.perf_counter() - t1
+                m1 = max(200, m // (2 * cores)); t1 = time.perf_counter(); r1 = _oracle.run_batch(batch.sub(0, m1), threads=1); dt1 = time.perf_counter() - t1
                 cpu["one_thread_value"] = float(r1["num_trials"].sum() / dt1)
         # the batch-wide streaming kernels of the same C ABI (one launch per phase over all capsules, no LDS-resident state): their HBM rates
         def _timed(fn, reps=10):

@@ -154,14 +154,3 @@ def engine_lib():
         lib.srba_capsule_clone.argtypes = [PCAP, C.c_int64, c_i32]; lib.srba_capsule_clone.restype = C.c_void_p
         lib._proto = True
     return lib
-
-
-def oracle_lib():
-    """CPU oracle -- TEST INFRASTRUCTURE. Only tests/, smoke() and bench.py's cpu_baseline leg may call this."""
-    lib = _load("oracle", os.path.join(ROOT, "oracle", "_build", "libsrba_oracle.so"))
-    if not getattr(lib, "_proto", False):
-        lib.srba_oracle_lm_run.argtypes = [C.POINTER(HipParams), PCAP, c_i32, C.POINTER(LmResult), c_i32]
-        lib.srba_oracle_run_one.argtypes = [C.POINTER(HipParams), PCAP, C.POINTER(LmResult)]
-        lib.srba_oracle_stage.argtypes = [C.POINTER(HipParams), PCAP, c_i32, c_f64] + [PF64] * 10
-        lib._proto = True
-    return lib

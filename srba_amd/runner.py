@@ -3,7 +3,7 @@
 Engine        : srba::RbaEngine<> through libsrba_engine.so (the source-compatible C++ front-end; GPU back-end by default)
 CapsuleBatch  : an array of srba_problem_capsule harvested from an Engine (pre-optimisation state of every optimize_local_area call)
 run_batch_hip : upload + srba_hip_lm_run on the GPU                       (product path)
-run_batch_oracle : CPU oracle on a deep copy of the batch                 (test infrastructure only)
+The CPU oracle is NOT reachable from this package: tests plug it in from tests/_oracle.py (Engine(backend=<plug object>)).
 """
 import ctypes as C
 import numpy as np
@@ -49,13 +49,12 @@ class Engine(object):
         if not self.h:
             raise RuntimeError(self.lib.srba_engine_last_error(None).decode())
         self._cb = None
-        if backend == "oracle":
-            ora = capi.oracle_lib()
-            fn = C.cast(ora.srba_oracle_run_one, C.c_void_p)
-            self.lib.srba_engine_set_backend_fn(self.h, fn, b"cpu-oracle")
-            self.lib.srba_engine_set_overall_fn(self.h, C.cast(ora.srba_oracle_eval_overall, C.c_void_p))
+        # backend: "hip" (the GPU, default and only built-in back-end) or an object with .plug(engine) that installs an external numeric
+        # back-end through srba_engine_set_backend_fn (how tests/ run the same front-end against the CPU oracle)
+        if hasattr(backend, "plug"):
+            backend.plug(self)
         elif backend != "hip":
-            raise ValueError(backend)
+            raise ValueError("unknown back-end %r: the product has no CPU path" % (backend,))
 
     def close(self):
         if self.h:
@@ -230,35 +229,6 @@ def run_batch_hip(batch, download=False):
         out["state"] = work
     ctx.close()
     return out
-
-
-def run_batch_oracle(batch, threads=1, keep_state=False):
-    ora = capi.oracle_lib()
-    work = batch.clone()
-    res = (capi.LmResult * work.n)()
-    rc = ora.srba_oracle_lm_run(C.byref(batch.params), work.ptr, work.n, res, threads)
-    if rc != 0:
-        raise RuntimeError("oracle failed")
-    out = results_to_dict(res, work.n)
-    if keep_state:
-        out["state"] = work
-    return out
-
-
-def oracle_stage(batch, i, do_solve=False, lam=0.0):
-    """Initial linearisation (S5..S14) of capsule i by the oracle (+ optionally one solve): arrays for per-kernel parity tests."""
-    ora = capi.oracle_lib()
-    work = batch.clone(i, 1)
-    c = work.ptr[0]; P, L, O, PD = capi.DIMS[batch.family]
-    n = P * c.n_unk_edges + L * c.n_unk_lms
-    arr = dict(resid=np.zeros(c.n_obs * O), Jp=np.zeros(c.n_bp * O * P), Jf=np.zeros(c.n_bf * O * L), HAp=np.zeros(c.n_hap * P * P), Hf=np.zeros(c.n_hf * L * L),
-               HApf=np.zeros(c.n_hapf * P * L), grad=np.zeros(n), delta=np.zeros(n), poses=np.zeros(2 * c.n_pairs * PD), scalars=np.zeros(4))
-    p = lambda a: a.ctypes.data_as(capi.PF64)
-    rc = ora.srba_oracle_stage(C.byref(batch.params), work.ptr, 1 if do_solve else 0, lam, p(arr["resid"]), p(arr["Jp"]), p(arr["Jf"]), p(arr["HAp"]), p(arr["Hf"]), p(arr["HApf"]),
-                               p(arr["grad"]), p(arr["delta"]), p(arr["poses"]), p(arr["scalars"]))
-    if rc != 0:
-        raise RuntimeError("oracle stage failed")
-    return arr
 
 
 def graph_slam_engine(backend="hip", submap=10, depth=3, sigma_xy=1e-3, sigma_yaw_deg=0.2, solver=capi.SOLVER_NO_SCHUR_SPARSE, harvest=1, **kw):

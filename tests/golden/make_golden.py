@@ -12,6 +12,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from srba_amd import capi, datasets, runner  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")); import _oracle  # tests/_oracle.py: the CPU checker (test infrastructure)
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 
@@ -22,7 +23,7 @@ def save(name, eng, first, count):
     path = os.path.join(OUT, name + ".caps")
     assert eng.lib.srba_engine_harvest_save(eng.h, path.encode(), first, count) == 0
     sub = runner.CapsuleBatch.load(path)
-    r = runner.run_batch_oracle(sub, keep_state=True)
+    r = _oracle.run_batch(sub, keep_state=True)
     P, L, O, PD = capi.DIMS[sub.family]
     edges = [r["state"].array(i, "edge_pose", np.float64, sub[i].n_unk_edges * PD) for i in range(sub.n)]
     lms = [r["state"].array(i, "ulm_pos", np.float64, sub[i].n_unk_lms * L) for i in range(sub.n)]
@@ -34,21 +35,21 @@ def save(name, eng, first, count):
 
 def main():
     # C-1: tests/submaps_edge_init_values.cpp (loop closure at KF 11)
-    eng = runner.graph_slam_engine(backend="oracle", submap=5, depth=3, sigma_xy=1e-3, sigma_yaw_deg=0.05, solver=capi.SOLVER_SCHUR_DENSE, max_error_per_obs_to_stop=1e-6)
+    eng = runner.graph_slam_engine(backend=_oracle.BACKEND, submap=5, depth=3, sigma_xy=1e-3, sigma_yaw_deg=0.05, solver=capi.SOLVER_SCHUR_DENSE, max_error_per_obs_to_stop=1e-6)
     eng.run(datasets.graph_slam_from_entries(datasets.C1_SUBMAPS, 1e-3, np.radians(0.05), seed=1)); save("c1_submaps_se2", eng, 8, 6)
     # C-2: tutorial-srba-relative-graph-slam-se2.cpp with its noise level, srba-slam's solver
-    eng = runner.graph_slam_engine(backend="oracle", submap=5, depth=3, sigma_xy=1e-3, sigma_yaw_deg=0.05)
+    eng = runner.graph_slam_engine(backend=_oracle.BACKEND, submap=5, depth=3, sigma_xy=1e-3, sigma_yaw_deg=0.05)
     eng.run(datasets.graph_slam_from_entries(datasets.C2_TUTORIAL_SE2, 1e-3, np.radians(0.05), seed=2)); save("c2_tutorial_se2", eng, 10, 6)
     # cfg2-like synthetic windows (submap 10, depth 3)
-    eng = runner.graph_slam_engine(backend="oracle")
+    eng = runner.graph_slam_engine(backend=_oracle.BACKEND)
     eng.run(datasets.graph_slam_se2(n_kf=70, seed=3, path="tour")); save("cfg2_tour_se2", eng, 60, 4)
     # landmark families
     for kind in ("rb2d", "cart2d"):
         ds, _ = datasets.landmarks_dataset_se2(kind, n_kf=24, n_lm=900, seed=4, noise=1e-3)
-        eng = runner.landmark_engine(kind, backend="oracle"); eng.run(ds); save("lm_" + kind, eng, 20, 3)
+        eng = runner.landmark_engine(kind, backend=_oracle.BACKEND); eng.run(ds); save("lm_" + kind, eng, 20, 3)
     for kind, noise in (("cart3d", 1e-3), ("rb3d", 1e-3), ("stereo", 0.1), ("mono", 0.1)):
         ds, _ = datasets.landmarks_dataset_se3(kind, n_kf=12, n_lm=300, seed=5, noise=noise, init_from_gt_noise=(0.2 if kind == "mono" else None))
-        eng = runner.landmark_engine(kind, backend="oracle", robust=(1 if kind == "stereo" else 0)); eng.run(ds); save("lm_" + kind, eng, 9, 3)
+        eng = runner.landmark_engine(kind, backend=_oracle.BACKEND, robust=(1 if kind == "stereo" else 0)); eng.run(ds); save("lm_" + kind, eng, 9, 3)
 
 
 if __name__ == "__main__":

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from srba_amd import capi, datasets, runner
+import _oracle  # tests/_oracle.py: the CPU checker
 
 pytestmark = pytest.mark.gpu
 
@@ -22,7 +23,7 @@ def _close(a, b, rel=REL, abs_=1e-15):
 def se2_batch():
     # capsules harvested with the oracle as numeric back-end (tests may use the oracle); 240 keyframes with loop closures
     ds = datasets.graph_slam_se2(n_kf=240, seed=5, grid=2, block=30.0)
-    return runner.harvest_graph_slam(ds, backend="oracle", submap=10, depth=3)
+    return runner.harvest_graph_slam(ds, backend=_oracle.BACKEND, submap=10, depth=3)
 
 
 def _compare_lm(b, gpu, cpu):
@@ -55,7 +56,7 @@ def test_lm_run_matches_oracle_se2(se2_batch):
     b = se2_batch
     assert b.n > 200
     gpu = runner.run_batch_hip(b, download=True)
-    cpu = runner.run_batch_oracle(b, keep_state=True)
+    cpu = _oracle.run_batch(b, keep_state=True)
     n_full = _compare_lm(b, gpu, cpu)
     assert n_full > b.n // 5  # a good share of the capsules follow the identical trial sequence to the end
     # final unknowns and spanning-tree poses (metres / radians; both runs stop at the same minimum)
@@ -82,7 +83,7 @@ def test_stepwise_kernels_match_oracle_se2(se2_batch):
     o = dict(res=0, Jp=0, HAp=0, grad=0, poses=0)
     for i in range(b.n):
         c = b[i]
-        ref = runner.oracle_stage(b, i, do_solve=True, lam=0.0)  # lam filled below
+        ref = _oracle.stage(b, i, do_solve=True, lam=0.0)  # lam filled below
         n = P * c.n_unk_edges + L * c.n_unk_lms
         sl = lambda key, cnt: slice(o[key], o[key] + cnt)
         assert _close(chi2[i], ref["scalars"][0]), i
@@ -91,7 +92,7 @@ def test_stepwise_kernels_match_oracle_se2(se2_batch):
         assert np.allclose(poses[sl("poses", 2 * c.n_pairs * PD)], ref["poses"], rtol=1e-9, atol=1e-12), i
         assert np.allclose(grad[sl("grad", n)], ref["grad"], rtol=1e-7, atol=1e-9 * np.abs(ref["grad"]).max()), i
         # HAp (no Schur here: unchanged by the solve) and the LM step for lambda0
-        ref2 = runner.oracle_stage(b, i, do_solve=True, lam=ref["scalars"][1])
+        ref2 = _oracle.stage(b, i, do_solve=True, lam=ref["scalars"][1])
         assert np.allclose(HAp[sl("HAp", c.n_hap * P * P)], ref2["HAp"], rtol=1e-9, atol=1e-9 * np.abs(ref2["HAp"]).max()), i
         assert np.allclose(delta[sl("grad", n)], ref2["delta"], rtol=1e-6, atol=1e-9 * max(1e-30, np.abs(ref2["delta"]).max())), i
         o["res"] += c.n_obs * O; o["Jp"] += c.n_bp * O * P; o["HAp"] += c.n_hap * P * P; o["grad"] += n; o["poses"] += 2 * c.n_pairs * PD
@@ -121,7 +122,7 @@ def test_eval_overall_squared_error_hip_vs_oracle():
     ds = datasets.graph_slam_se2(n_kf=400, seed=5, path="tour", sigma_xy=0.02, sigma_yaw_deg=0.5)
     vals = {}
     for backend in ("oracle", "hip"):
-        eng = runner.graph_slam_engine(backend=backend, submap=10, depth=3, sigma_xy=0.02, sigma_yaw_deg=0.5, harvest=0)
+        eng = runner.graph_slam_engine(backend=_oracle.BACKEND if backend == "oracle" else "hip", submap=10, depth=3, sigma_xy=0.02, sigma_yaw_deg=0.5, harvest=0)
         eng.run(ds)
         vals[backend] = eng.eval_overall_squared_error()
     assert vals["oracle"] > 0 and abs(vals["hip"] - vals["oracle"]) <= 1e-6 * vals["oracle"], vals
@@ -129,7 +130,7 @@ def test_eval_overall_squared_error_hip_vs_oracle():
     ds3, _ = datasets.landmarks_dataset_se3("stereo", n_kf=12, n_lm=300, seed=5, noise=0.3)
     vals = {}
     for backend in ("oracle", "hip"):
-        eng = runner.landmark_engine("stereo", backend=backend, harvest=0)
+        eng = runner.landmark_engine("stereo", backend=_oracle.BACKEND if backend == "oracle" else "hip", harvest=0)
         eng.run(ds3)
         vals[backend] = eng.eval_overall_squared_error()
     assert vals["oracle"] > 0 and abs(vals["hip"] - vals["oracle"]) <= 1e-6 * vals["oracle"] + 1e-9, vals
@@ -139,7 +140,7 @@ def test_eval_overall_squared_error_hip_vs_oracle():
 def test_hbm_workspace_path_and_mixed_classes(se2_batch, monkeypatch):
     """Systems too large for the LDS classes are factored in an HBM workspace (same code, global pointers, full barriers). The knob
     SRBA_HIP_MAX_LDS_KB forces that path: all capsules (0) or only the larger ones (10 KB -> a ragged mix of LDS and HBM launches)."""
-    ref = runner.run_batch_oracle(se2_batch)
+    ref = _oracle.run_batch(se2_batch)
     for kb in ("0", "10"):
         monkeypatch.setenv("SRBA_HIP_MAX_LDS_KB", kb)
         gpu = runner.run_batch_hip(se2_batch)
@@ -152,11 +153,11 @@ def test_large_windows_depth5():
     """Maximum-size case for the LDS path: depth-5 windows of 20-key-frame sub-maps (systems of 100+ block rows), SE2 graph-SLAM."""
     from srba_amd import datasets
     ds = datasets.graph_slam_se2(n_kf=260, seed=9, path="tour")
-    eng = runner.graph_slam_engine(backend="oracle", submap=20, depth=5)
+    eng = runner.graph_slam_engine(backend=_oracle.BACKEND, submap=20, depth=5)
     eng.run(ds)
     b = eng.harvest(); b.engine = eng
     sub = b.sub(b.n - 40, 40)
-    ref = runner.run_batch_oracle(sub); gpu = runner.run_batch_hip(sub)
+    ref = _oracle.run_batch(sub); gpu = runner.run_batch_hip(sub)
     assert max(sub.ptr[i].n_unk_edges for i in range(sub.n)) >= 60
     _compare_lm(sub, gpu, ref)
 
@@ -170,11 +171,11 @@ def test_landmark_families_all_solvers(kind, solver):
         ds, _ = datasets.landmarks_dataset_se2(kind, n_kf=30, n_lm=900, seed=7, noise=1e-3)
     else:
         ds, _ = datasets.landmarks_dataset_se3(kind, n_kf=16, n_lm=320, seed=7, noise=(0.1 if kind == "stereo" else 1e-3))
-    eng = runner.landmark_engine(kind, backend="oracle", solver=solver)
+    eng = runner.landmark_engine(kind, backend=_oracle.BACKEND, solver=solver)
     eng.run(ds)
     b = eng.harvest(); b.engine = eng
     sub = b.sub(max(0, b.n - 8), min(8, b.n))
-    ref = runner.run_batch_oracle(sub); gpu = runner.run_batch_hip(sub)
+    ref = _oracle.run_batch(sub); gpu = runner.run_batch_hip(sub)
     assert np.all(gpu["status"] == ref["status"])
     assert _close(gpu["chi2_init"], ref["chi2_init"], rel=1e-9)
     assert _close(gpu["chi2_final"], ref["chi2_final"], rel=1e-6, abs_=1e-18)
@@ -256,7 +257,7 @@ def test_stepwise_kernels_match_oracle_landmark_families(kind):
         ctx = runner.HipContext(b.params); ctx.upload(sub); lib = ctx.lib
         chi = np.zeros(1)
         assert lib.srba_hip_update_spantree(ctx.ctx, 0) == 0 and lib.srba_hip_eval_residuals(ctx.ctx, chi.ctypes.data_as(capi.PF64)) == 0 and lib.srba_hip_linearize(ctx.ctx) == 0
-        ref = runner.oracle_stage(b, i)
+        ref = _oracle.stage(b, i)
         assert _close(chi[0], ref["scalars"][0], rel=1e-9)
         for what, key in ((0, "resid"), (1, "Jp"), (2, "Jf"), (3, "HAp"), (4, "Hf"), (5, "HApf"), (6, "grad"), (9, "poses")):
             g = ctx.debug(what); r = ref[key]

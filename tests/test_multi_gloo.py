@@ -21,11 +21,12 @@ def _worker(rank, world, port, q):
     import time
     import torch  # noqa: F401
     from srba_amd import datasets, multi, runner
+    import _oracle  # tests/_oracle.py: the CPU checker
     dist = multi.init_process_group("gloo")
     assert dist is not None and dist.get_world_size() == world and multi.rank_info() == (rank, world, rank)
     ds = datasets.graph_slam_se2(n_kf=120, seed=multi.replica_seed(rank), path="tour")
-    batch = runner.harvest_graph_slam(ds, backend="oracle", submap=10, depth=3)
-    res = runner.run_batch_oracle(batch)
+    batch = runner.harvest_graph_slam(ds, backend=_oracle.BACKEND, submap=10, depth=3)
+    res = _oracle.run_batch(batch)
     trials = int(res["num_trials"].sum()); obs = int((res["num_trials"] * res["num_observations"]).sum())
     calls = []
 

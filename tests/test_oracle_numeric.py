@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from srba_amd import capi, datasets, runner
+import _oracle  # tests/_oracle.py: the CPU checker
 
 
 def _harvest(kind, solver=capi.SOLVER_SCHUR_DENSE, n_kf=14, seed=3, **kw):
@@ -16,7 +17,7 @@ def _harvest(kind, solver=capi.SOLVER_SCHUR_DENSE, n_kf=14, seed=3, **kw):
         ds, gt = datasets.landmarks_dataset_se2(kind, n_kf=n_kf + 10, n_lm=900, seed=seed, noise=1e-3)
     else:
         ds, gt = datasets.landmarks_dataset_se3(kind, n_kf=n_kf, n_lm=350, seed=seed, noise=(1e-3 if kind in ("cart3d", "rb3d") else 0.1), init_from_gt_noise=(0.2 if kind == "mono" else None))
-    eng = runner.landmark_engine(kind, backend="oracle", solver=solver, **kw)
+    eng = runner.landmark_engine(kind, backend=_oracle.BACKEND, solver=solver, **kw)
     eng.run(ds)
     b = eng.harvest(); b.engine = eng
     return b
@@ -55,9 +56,9 @@ def test_schur_sparse_equals_dense(kind):
         c = b[i]
         if c.n_unk_lms == 0 or c.n_unk_edges < 2:
             continue
-        a0 = runner.oracle_stage(b, i)                      # un-reduced blocks, gradient
+        a0 = _oracle.stage(b, i)                      # un-reduced blocks, gradient
         lam = 1e3                                           # schur_unittest.cpp uses lambda = 1e3
-        a1 = runner.oracle_stage(b, i, do_solve=True, lam=lam)
+        a1 = _oracle.stage(b, i, do_solve=True, lam=lam)
         assert a1["scalars"][2] == 0                        # positive definite
         H, n, nK, nF = _dense_system(b, i, a0)
         Hpp, Hpf, Hff = H[:P * nK, :P * nK], H[:P * nK, P * nK:], H[P * nK:, P * nK:]
@@ -86,7 +87,7 @@ def test_three_solvers_give_the_same_step():
     for solver in (capi.SOLVER_SCHUR_DENSE, capi.SOLVER_SCHUR_SPARSE, capi.SOLVER_NO_SCHUR_SPARSE):
         b = _harvest("cart3d", solver=solver, run_local_optimization=1)
         i = b.n - 1
-        a = runner.oracle_stage(b, i, do_solve=True, lam=10.0)
+        a = _oracle.stage(b, i, do_solve=True, lam=10.0)
         out[solver] = a["delta"]
     assert np.allclose(out[0], out[1], rtol=1e-8, atol=1e-12) and np.allclose(out[0], out[2], rtol=1e-7, atol=1e-11)
 
@@ -113,13 +114,13 @@ def test_point_family_jacobians_match_finite_differences(kind):
     b = _harvest(kind, n_kf=8)
     P, L, O, PD = capi.DIMS[b.family]
     i = b.n - 1; c = b[i]
-    a0 = runner.oracle_stage(b, i)
+    a0 = _oracle.stage(b, i)
     Jp = a0["Jp"].reshape(c.n_bp, O, P); Jf = a0["Jf"].reshape(c.n_bf, O, L)
     bp_col, bp_res = b.array(i, "bp_col", np.int32, c.n_bp), b.array(i, "bp_res", np.int32, c.n_bp)
     bf_col, bf_res = b.array(i, "bf_col", np.int32, c.n_bf), b.array(i, "bf_res", np.int32, c.n_bf)
     w = b.clone(i, 1); cw = w.ptr[0]
     edge = np.ctypeslib.as_array(cw.edge_pose, shape=(cw.n_edges * PD,)); ulm = np.ctypeslib.as_array(cw.ulm_pos, shape=(max(1, cw.n_unk_lms * L),))
-    res = lambda: runner.oracle_stage(w, 0)["resid"].reshape(-1, O)
+    res = lambda: _oracle.stage(w, 0)["resid"].reshape(-1, O)
     h = 1e-6
     for col in range(min(c.n_unk_edges, 3)):
         save = edge[PD * col:PD * col + PD].copy(); Jn = np.zeros((c.n_obs, O, P))
@@ -146,18 +147,18 @@ def test_relpose_jacobian_is_minus_dr_deps_at_zero_residual():
     # shortest path used for its residual -- a property of the reference's design, not of the formulas under test)
     ds = datasets.graph_slam_se2(n_kf=48, seed=2, sigma_xy=0.0, sigma_yaw_deg=0.0, path="tour")
     # noise-free data converge to zero residual; a second optimisation of the last window then starts from the converged state
-    eng = runner.graph_slam_engine(backend="oracle", submap=5, depth=3)
+    eng = runner.graph_slam_engine(backend=_oracle.BACKEND, submap=5, depth=3)
     eng.run(ds[:-1]); eng.lib.srba_engine_harvest_clear(eng.h); eng.cfg.harvest = 1
     info = eng.add_keyframe(ds[-1]["feat_ids"], ds[-1]["z"], ds[-1]["flags"])
     assert info.obs_rmse < 1e-6
     kinfo = capi.KfInfo(); eng.lib.srba_engine_harvest_clear(eng.h)
     eng.lib.srba_engine_optimize_local_area(eng.h, len(ds) - 1, 3, kinfo)  # a second call starts from the converged state
     b = eng.harvest(); i = b.n - 1; c = b[i]
-    a0 = runner.oracle_stage(b, i)
+    a0 = _oracle.stage(b, i)
     assert np.abs(a0["resid"]).max() < 1e-6
     Jp = a0["Jp"].reshape(c.n_bp, 3, 3); bp_col, bp_res = b.array(i, "bp_col", np.int32, c.n_bp), b.array(i, "bp_res", np.int32, c.n_bp)
     w = b.clone(i, 1); cw = w.ptr[0]; edge = np.ctypeslib.as_array(cw.edge_pose, shape=(cw.n_edges * 3,))
-    res = lambda: runner.oracle_stage(w, 0)["resid"].reshape(-1, 3)
+    res = lambda: _oracle.stage(w, 0)["resid"].reshape(-1, 3)
     h = 1e-6
     for col in range(min(c.n_unk_edges, 6)):
         save = edge[3 * col:3 * col + 3].copy(); Jn = np.zeros((c.n_obs, 3, 3))

@@ -10,6 +10,11 @@ import numpy as np
 import pytest
 
 from srba_amd import capi, runner
+import _oracle  # tests/_oracle.py: the CPU checker
+
+
+def _be(backend):
+    return _oracle.BACKEND if backend == "oracle" else backend
 
 T = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_test_tables.json")))
 
@@ -41,7 +46,7 @@ def edge0_inv_pose(eng):
 
 def run_fixed(backend, incr, inverse):
     ft = T["fixed_transformations"]
-    eng = runner.landmark_engine("cart3d", backend=backend, depth=3, sigma=1.0, robust=0, harvest=0, with_sensor_pose=False, max_error_per_obs_to_stop=1e-9)
+    eng = runner.landmark_engine("cart3d", backend=_be(backend), depth=3, sigma=1.0, robust=0, harvest=0, with_sensor_pose=False, max_error_per_obs_to_stop=1e-9)
     ids = [r[0] for r in ft["landmarks"]]; pts = np.array([r[1:] for r in ft["landmarks"]])
     eng.add_keyframe(ids, pts, flags=np.zeros(len(ids)))
     R = rot_ypr(*incr[3:]); t = np.array(incr[:3])
@@ -57,9 +62,9 @@ def run_sensor(backend, displaced):
     sp = T["sensor_pose"]
     kw = dict(depth=3, sigma=sp["std_noise_observations"], robust=1 if sp["use_robust_kernel"] else 0, harvest=0, max_error_per_obs_to_stop=1e-9)
     if displaced:
-        eng = runner.landmark_engine("cart3d", backend=backend, with_sensor_pose=True, sensor_pose_xyzypr=sp["sensor_pose_on_robot_xyz_ypr"], **kw)
+        eng = runner.landmark_engine("cart3d", backend=_be(backend), with_sensor_pose=True, sensor_pose_xyzypr=sp["sensor_pose_on_robot_xyz_ypr"], **kw)
     else:
-        eng = runner.landmark_engine("cart3d", backend=backend, with_sensor_pose=False, **kw)
+        eng = runner.landmark_engine("cart3d", backend=_be(backend), with_sensor_pose=False, **kw)
     for key in (("obs_kf0_displaced", "obs_kf1_displaced") if displaced else ("obs_kf0", "obs_kf1")):
         tab = sp[key]
         eng.add_keyframe([r[0] for r in tab], np.array([r[1:] for r in tab]), flags=np.zeros(len(tab)))

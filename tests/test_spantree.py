@@ -9,12 +9,13 @@ import numpy as np
 import pytest
 
 from srba_amd import capi, datasets, runner
+import _oracle  # tests/_oracle.py: the CPU checker
 
 
 def _build(topo, n, depth, seed):
     rng = np.random.RandomState(seed)
     gt = [datasets.pose3(*rng.uniform(-10, 10, 3), rng.uniform(-np.pi, np.pi), rng.uniform(-0.5 * np.pi, 0.5 * np.pi), rng.uniform(-np.pi, np.pi)) for _ in range(n)]
-    eng = runner.Engine(capi.SE3_CART3D, backend="oracle", max_tree_depth=depth, max_optimize_depth=depth)
+    eng = runner.Engine(capi.SE3_CART3D, backend=_oracle.BACKEND, max_tree_depth=depth, max_optimize_depth=depth)
     lib, h = eng.lib, eng.h
     adj = collections.defaultdict(list); edges = []
     for kf in range(n):

@@ -5,6 +5,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 from srba_amd import capi, datasets, runner
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests")); import _oracle  # tests/_oracle.py: the CPU checker (test infrastructure)
 kind = sys.argv[1] if len(sys.argv) > 1 else "stereo"
 copies = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 if kind in ("rb2d", "cart2d"):
@@ -20,7 +21,7 @@ class Fake: pass
 fb = Fake(); fb.ptr = C.cast(arr, capi.PCAP); fb.n = n0 * copies; fb.params = b.params; fb.family = b.family
 ctx = runner.HipContext(b.params); ctx.upload(fb)
 ctx.lm_run(); r = ctx.lm_run(); kms = ctx.lib.srba_hip_last_kernel_ms(ctx.ctx)
-t = time.perf_counter(); ro = runner.run_batch_oracle(b, threads=1); dt = time.perf_counter() - t
+t = time.perf_counter(); ro = _oracle.run_batch(b, threads=1); dt = time.perf_counter() - t
 nk = np.array([b.ptr[i].n_unk_edges for i in range(n0)]); nf = np.array([b.ptr[i].n_unk_lms for i in range(n0)]); no = np.array([b.ptr[i].n_obs for i in range(n0)])
 print("%s: %d capsules x %d copies; mean unknowns %.1f edges + %.1f landmarks, %.0f observations; GPU %.2f ms -> %.3f M LM iterations/s ; oracle 1 thread %.1f k it/s ; ratio %.0f" % (
     kind, n0, copies, nk.mean(), nf.mean(), no.mean(), kms, r["num_trials"].sum() / kms / 1e3, ro["num_trials"].sum() / dt / 1e3, (r["num_trials"].sum() / kms * 1e3) / (ro["num_trials"].sum() / dt)))

@@ -2,6 +2,7 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from srba_amd import capi, runner
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests")); import _oracle  # tests/_oracle.py: the CPU checker (test infrastructure)
 name = sys.argv[1]
 G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 b = runner.CapsuleBatch.load(os.path.join(G, name + ".caps")); g = np.load(os.path.join(G, name + ".npz"))
@@ -25,7 +26,7 @@ lib.srba_hip_update_spantree(ctx.ctx, 0); chi2 = np.zeros(b.n); lib.srba_hip_eva
 res, Jp, Jf, HAp, Hf, HApf, grad = [ctx.debug(k) for k in range(7)]
 P, L, O, PD = capi.DIMS[b.family]; o = [0] * 7
 for i in range(b.n):
-    c = b[i]; ref = runner.oracle_stage(b, i); n = P * c.n_unk_edges + L * c.n_unk_lms
+    c = b[i]; ref = _oracle.stage(b, i); n = P * c.n_unk_edges + L * c.n_unk_lms
     for k, (arr, key, cnt) in enumerate(((res, "resid", c.n_obs * O), (Jp, "Jp", c.n_bp * O * P), (Jf, "Jf", c.n_bf * O * L), (HAp, "HAp", c.n_hap * P * P), (Hf, "Hf", c.n_hf * L * L), (HApf, "HApf", c.n_hapf * P * L), (grad, "grad", n))):
         a = arr[o[k]:o[k] + cnt]; d = np.abs(a - ref[key]); sc = max(1e-300, np.abs(ref[key]).max())
         print("capsule %d %-5s max abs diff %.3e (scale %.3e) at %d" % (i, key, d.max() if cnt else 0, sc, int(d.argmax()) if cnt else -1))

@@ -4,18 +4,19 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["SRBA_HIP_PHASE_TIMING"] = "1"
 from srba_amd import capi, datasets, runner
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests")); import _oracle  # tests/_oracle.py: the CPU checker (test infrastructure)
 
 n_kf = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 grid = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 t = time.time(); ds = datasets.graph_slam_se2(n_kf=n_kf, seed=1, grid=grid); print("dataset %.1fs obs/kf %.2f" % (time.time() - t, np.mean([len(k["feat_ids"]) for k in ds])))
-t = time.time(); b = runner.harvest_graph_slam(ds, backend="oracle", submap=10, depth=3); print("harvest(oracle) %.1fs  capsules %d" % (time.time() - t, b.n))
+t = time.time(); b = runner.harvest_graph_slam(ds, backend=_oracle.BACKEND, submap=10, depth=3); print("harvest(oracle) %.1fs  capsules %d" % (time.time() - t, b.n))
 for f in ("n_unk_edges", "n_obs", "n_bp", "n_pairs", "n_path", "n_hap", "n_edges"):
     v = np.array([getattr(b[i], f) for i in range(b.n)]); print("  %-12s mean %8.1f  p50 %6d  p95 %6d  max %6d" % (f, v.mean(), np.median(v), np.percentile(v, 95), v.max()))
 need = np.array([np.ctypeslib.as_array(b[i].pair_needed, shape=(b[i].n_pairs,)).sum() for i in range(b.n)]); print("  pairs_needed mean %.1f" % need.mean())
 ctx = runner.HipContext(b.params); ctx.upload(b)
 t = time.time(); gpu = ctx.lm_run(); t_gpu = time.time() - t
 kms = ctx.lib.srba_hip_last_kernel_ms(ctx.ctx)
-t = time.time(); cpu = runner.run_batch_oracle(b); t_cpu = time.time() - t
+t = time.time(); cpu = _oracle.run_batch(b); t_cpu = time.time() - t
 print("GPU kernel %.2f ms, %d trials -> %.0f trials/s | oracle %.2f s -> %.0f trials/s" % (kms, gpu["num_trials"].sum(), gpu["num_trials"].sum() / (kms * 1e-3), t_cpu, cpu["num_trials"].sum() / t_cpu))
 same = gpu["num_trials"] == cpu["num_trials"]
 print("trial-count identical: %d / %d" % (same.sum(), b.n))
