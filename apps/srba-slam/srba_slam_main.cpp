@@ -17,6 +17,7 @@
 #include <iostream>
 #include <sstream>
 #include <random>
+#include <set>
 
 using namespace srba;
 

@@ -12,7 +12,6 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
-#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -33,72 +32,86 @@ struct CapsuleData {
 	// bookkeeping for the host engine (not part of the ABI): global ids behind the local slots
 	std::vector<uint64_t> unk_edge_ids, unk_lm_ids; std::vector<std::pair<uint64_t, uint64_t> > pair_kfs;
 
-	/** Build HAp/Hf/HApf block + term lists from the Jacobian block tables, and the Schur plan if requested.
-	 *  bp_row/bf_row: global observation index of each block (ascending inside each column). */
+	/** Hessian block + term lists (sparse_hessian_build_symbolic.h:22-237) and, if requested, the Schur plan (schur.h:25-159) from the Jacobian
+	 *  block tables. bp_row/bf_row: global observation index of each block (ascending inside each column).
+	 *  One pass over the observation rows emits every (block, term) pair tagged with its block key; a stable sort by key then yields the
+	 *  reference's orders: blocks by (column j, row i) like getCol(j)[i] (HApf: by (edge i, landmark j), it is stored by rows), terms inside a
+	 *  block by ascending observation. Linear in the number of emitted terms (+ the sorts); no node-based containers. */
 	void build_plan(const std::vector<uint64_t> &bp_row, const std::vector<uint64_t> &bf_row, bool with_schur) {
 		const int nK = n_unk_edges, nF = n_unk_lms;
-		typedef std::pair<int, int> key_t; // (col j, row i) so that std::map order == reference iteration order getCol(j)[i]
-		typedef std::vector<std::pair<int32_t, int32_t> > terms_t;
-		std::map<key_t, terms_t> HAp, Hf; std::map<key_t, terms_t> HApf; // HApf keyed (row i = edge, col j = lm): stored by rows
-		// group blocks by observation row, ascending row; inside a row ascending column slot
-		std::map<uint64_t, std::vector<std::pair<int, int> > > rows_p; // row -> (col slot, block idx)
-		for (size_t b = 0; b < bp_col.size(); b++) rows_p[bp_row[b]].push_back(std::make_pair(bp_col[b], (int)b));
-		std::map<uint64_t, std::pair<int, int> > rows_f; // row -> (lm slot, block idx): one landmark per observation
-		for (size_t b = 0; b < bf_col.size(); b++) rows_f[bf_row[b]] = std::make_pair(bf_col[b], (int)b);
-		for (int i = 0; i < nK; i++) HAp[key_t(i, i)]; // diagonal blocks always exist (columns are non-empty after filtering)
-		for (int i = 0; i < nF; i++) Hf[key_t(i, i)];
-		for (std::map<uint64_t, std::vector<std::pair<int, int> > >::iterator it = rows_p.begin(); it != rows_p.end(); ++it) {
-			std::vector<std::pair<int, int> > &v = it->second; std::sort(v.begin(), v.end());
-			for (size_t a = 0; a < v.size(); a++) for (size_t b = a; b < v.size(); b++) HAp[key_t(v[b].first, v[a].first)].push_back(std::make_pair(v[a].second, v[b].second));
-			std::map<uint64_t, std::pair<int, int> >::const_iterator f = rows_f.find(it->first);
-			if (f != rows_f.end()) for (size_t a = 0; a < v.size(); a++) HApf[key_t(v[a].first, f->second.first)].push_back(std::make_pair(v[a].second, f->second.second));
+		struct term { uint64_t key; int32_t a, b; };
+		struct by_key { bool operator()(const term &x, const term &y) const { return x.key < y.key; } };
+		struct rowrec { uint64_t row; int32_t col, blk; };
+		struct by_row_col { bool operator()(const rowrec &x, const rowrec &y) const { return x.row != y.row ? x.row < y.row : x.col < y.col; } };
+		// dh_dAp blocks grouped by observation row (ascending), ascending column slot inside a row
+		std::vector<rowrec> rp(bp_col.size());
+		for (size_t b = 0; b < bp_col.size(); b++) { rp[b].row = bp_row[b]; rp[b].col = bp_col[b]; rp[b].blk = (int32_t)b; }
+		std::sort(rp.begin(), rp.end(), by_row_col());
+		// dh_df blocks by observation row: an observation sees exactly one landmark
+		std::vector<rowrec> rf(bf_col.size());
+		for (size_t b = 0; b < bf_col.size(); b++) { rf[b].row = bf_row[b]; rf[b].col = bf_col[b]; rf[b].blk = (int32_t)b; }
+		std::sort(rf.begin(), rf.end(), by_row_col());
+		std::vector<term> tp, tpf; tp.reserve(2 * rp.size()); tpf.reserve(rp.size());
+		size_t f = 0;
+		for (size_t g = 0; g < rp.size();) {
+			size_t h = g; while (h < rp.size() && rp[h].row == rp[g].row) h++;
+			for (size_t a = g; a < h; a++) for (size_t b = a; b < h; b++) { term t = {(uint64_t)rp[b].col * (uint64_t)nK + (uint64_t)rp[a].col, rp[a].blk, rp[b].blk}; tp.push_back(t); }
+			while (f < rf.size() && rf[f].row < rp[g].row) f++;
+			if (f < rf.size() && rf[f].row == rp[g].row) for (size_t a = g; a < h; a++) { term t = {(uint64_t)rp[a].col * (uint64_t)nF + (uint64_t)rf[f].col, rp[a].blk, rf[f].blk}; tpf.push_back(t); }
+			g = h;
 		}
-		for (std::map<uint64_t, std::pair<int, int> >::iterator it = rows_f.begin(); it != rows_f.end(); ++it) Hf[key_t(it->second.first, it->second.first)].push_back(std::make_pair(it->second.second, it->second.second));
-		// HApf flatten (ordered by (i,j))
+		std::stable_sort(tp.begin(), tp.end(), by_key()); std::stable_sort(tpf.begin(), tpf.end(), by_key());
+		// ---- HApf: blocks in (edge, landmark) order
 		hapf_i.clear(); hapf_j.clear(); hapf_term_off.assign(1, 0); hapf_t1.clear(); hapf_t2.clear();
-		std::map<key_t, int> hapf_index;
-		for (std::map<key_t, terms_t>::iterator it = HApf.begin(); it != HApf.end(); ++it) {
-			hapf_index[it->first] = (int)hapf_i.size(); hapf_i.push_back(it->first.first); hapf_j.push_back(it->first.second);
-			for (size_t t = 0; t < it->second.size(); t++) { hapf_t1.push_back(it->second[t].first); hapf_t2.push_back(it->second[t].second); }
-			hapf_term_off.push_back((int)hapf_t1.size());
+		for (size_t t = 0; t < tpf.size(); t++) {
+			if (t == 0 || tpf[t].key != tpf[t - 1].key) { if (t) hapf_term_off.push_back((int32_t)hapf_t1.size()); hapf_i.push_back((int32_t)(tpf[t].key / (uint64_t)nF)); hapf_j.push_back((int32_t)(tpf[t].key % (uint64_t)nF)); }
+			hapf_t1.push_back(tpf[t].a); hapf_t2.push_back(tpf[t].b);
 		}
-		// lm -> HApf blocks in ascending edge slot
+		if (!tpf.empty()) hapf_term_off.push_back((int32_t)hapf_t1.size());
+		// landmark -> its HApf blocks by ascending edge slot (counting sort; the block list is already ascending in the edge slot)
 		lm_hapf_off.assign(nF + 1, 0); lm_hapf_idx.assign(hapf_i.size(), 0);
 		for (size_t b = 0; b < hapf_j.size(); b++) lm_hapf_off[hapf_j[b] + 1]++;
 		for (int l = 0; l < nF; l++) lm_hapf_off[l + 1] += lm_hapf_off[l];
-		{ std::vector<int> cur(lm_hapf_off.begin(), lm_hapf_off.end() - 1); for (size_t b = 0; b < hapf_j.size(); b++) lm_hapf_idx[cur[hapf_j[b]]++] = (int)b; }
-		// Schur plan: for every landmark, every pair of edges that see it (schur.h:56-157). Creates fill-in HAp blocks.
-		std::map<key_t, std::vector<int32_t> > sch; // HAp key -> flat triplets (b1,b2,lm)
+		{ std::vector<int32_t> cur(lm_hapf_off.begin(), lm_hapf_off.end() - 1); for (size_t b = 0; b < hapf_j.size(); b++) lm_hapf_idx[cur[hapf_j[b]]++] = (int32_t)b; }
+		// ---- Schur plan: per landmark every pair of edges that see it (schur.h:56-157); pairs without a J^t J block create fill-in HAp blocks (:142-149)
 		const bool schur = with_schur && nF > 0 && nK > 0;
+		std::vector<term> ts; std::vector<int32_t> ts_lm;
 		if (schur) {
-			for (int l = 0; l < nF; l++) // ascending lm => ascending inside every block's term list (set_intersection order)
+			struct sterm { uint64_t key; int32_t a, b, l; };
+			struct by_skey { bool operator()(const sterm &x, const sterm &y) const { return x.key < y.key; } };
+			std::vector<sterm> raw;
+			for (int l = 0; l < nF; l++) // ascending landmark => ascending inside every block's list
 				for (int a = lm_hapf_off[l]; a < lm_hapf_off[l + 1]; a++) for (int b = a; b < lm_hapf_off[l + 1]; b++) {
-					const int ba = lm_hapf_idx[a], bb = lm_hapf_idx[b]; // hapf_i[ba] <= hapf_i[bb]
-					const key_t k(hapf_i[bb], hapf_i[ba]);
-					HAp[k]; // fill-in block if absent (schur.h:142-149)
-					std::vector<int32_t> &v = sch[k]; v.push_back(ba); v.push_back(bb); v.push_back(l);
+					const int32_t ba = lm_hapf_idx[a], bb = lm_hapf_idx[b]; // hapf_i[ba] <= hapf_i[bb]
+					sterm t = {(uint64_t)hapf_i[bb] * (uint64_t)nK + (uint64_t)hapf_i[ba], ba, bb, l}; raw.push_back(t);
 				}
+			std::stable_sort(raw.begin(), raw.end(), by_skey());
+			ts.resize(raw.size()); ts_lm.resize(raw.size());
+			for (size_t t = 0; t < raw.size(); t++) { term x = {raw[t].key, raw[t].a, raw[t].b}; ts[t] = x; ts_lm[t] = raw[t].l; }
 		}
-		// HAp flatten, ordered by (col j, row i)
+		// ---- HAp: union of the J^t J keys, the diagonal (always present: columns are non-empty after filtering) and the Schur fill-in keys
+		std::vector<uint64_t> keys; keys.reserve(tp.size() / 2 + nK + ts.size() / 2);
+		for (int i = 0; i < nK; i++) keys.push_back((uint64_t)i * (uint64_t)nK + (uint64_t)i);
+		for (size_t t = 0; t < tp.size(); t++) if (t == 0 || tp[t].key != tp[t - 1].key) keys.push_back(tp[t].key);
+		for (size_t t = 0; t < ts.size(); t++) if (t == 0 || ts[t].key != ts[t - 1].key) keys.push_back(ts[t].key);
+		std::sort(keys.begin(), keys.end()); keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
 		hap_i.clear(); hap_j.clear(); hap_term_off.assign(1, 0); hap_t1.clear(); hap_t2.clear(); hap_diag.assign(nK, -1);
 		sch_term_off.clear(); sch_b1.clear(); sch_b2.clear(); sch_lm.clear(); if (schur) sch_term_off.push_back(0);
-		for (std::map<key_t, terms_t>::iterator it = HAp.begin(); it != HAp.end(); ++it) {
-			if (it->first.first == it->first.second) hap_diag[it->first.first] = (int)hap_i.size();
-			hap_j.push_back(it->first.first); hap_i.push_back(it->first.second);
-			for (size_t t = 0; t < it->second.size(); t++) { hap_t1.push_back(it->second[t].first); hap_t2.push_back(it->second[t].second); }
-			hap_term_off.push_back((int)hap_t1.size());
-			if (schur) {
-				std::map<key_t, std::vector<int32_t> >::iterator s = sch.find(it->first);
-				if (s != sch.end()) for (size_t t = 0; t + 2 < s->second.size(); t += 3) { sch_b1.push_back(s->second[t]); sch_b2.push_back(s->second[t + 1]); sch_lm.push_back(s->second[t + 2]); }
-				sch_term_off.push_back((int)sch_b1.size());
-			}
+		size_t it = 0, is = 0;
+		for (size_t k = 0; k < keys.size(); k++) {
+			const int32_t j = (int32_t)(keys[k] / (uint64_t)nK), i = (int32_t)(keys[k] % (uint64_t)nK);
+			if (i == j) hap_diag[i] = (int32_t)hap_i.size();
+			hap_j.push_back(j); hap_i.push_back(i);
+			for (; it < tp.size() && tp[it].key == keys[k]; it++) { hap_t1.push_back(tp[it].a); hap_t2.push_back(tp[it].b); }
+			hap_term_off.push_back((int32_t)hap_t1.size());
+			if (schur) { for (; is < ts.size() && ts[is].key == keys[k]; is++) { sch_b1.push_back(ts[is].a); sch_b2.push_back(ts[is].b); sch_lm.push_back(ts_lm[is]); } sch_term_off.push_back((int32_t)sch_b1.size()); }
 		}
+		// ---- Hf: block-diagonal (one landmark per observation); the terms of landmark l are its own dh_df blocks in column order
 		hf_i.clear(); hf_j.clear(); hf_term_off.assign(1, 0); hf_t1.clear(); hf_t2.clear(); hf_diag.assign(nF, -1);
-		for (std::map<key_t, terms_t>::iterator it = Hf.begin(); it != Hf.end(); ++it) {
-			if (it->first.first == it->first.second) hf_diag[it->first.first] = (int)hf_i.size();
-			hf_j.push_back(it->first.first); hf_i.push_back(it->first.second);
-			for (size_t t = 0; t < it->second.size(); t++) { hf_t1.push_back(it->second[t].first); hf_t2.push_back(it->second[t].second); }
-			hf_term_off.push_back((int)hf_t1.size());
+		for (int l = 0; l < nF; l++) {
+			hf_diag[l] = l; hf_i.push_back(l); hf_j.push_back(l);
+			for (int32_t b = colf_off[l]; b < colf_off[l + 1]; b++) { hf_t1.push_back(b); hf_t2.push_back(b); }
+			hf_term_off.push_back((int32_t)hf_t1.size());
 		}
 	}
 

@@ -42,7 +42,7 @@ struct Harvest {
 };
 
 struct EngineBase {
-	srba_engine_config cfg; Harvest harvest; srba_hip_params last_params; bool in_stage1 = false; std::string error;
+	srba_engine_config cfg; Harvest harvest; srba_hip_params last_params; std::string error;
 	virtual ~EngineBase() {}
 	virtual int add_keyframe(int n_obs, const uint64_t *feat_id, const double *z, const uint8_t *flags, const double *relpos, srba_kf_info *out) = 0;
 	virtual void set_backend(const std::shared_ptr<numeric_backend> &b) = 0;
@@ -79,9 +79,9 @@ struct EngineImpl : public EngineBase {
 		ecp_io<ECP>::set(rba.parameters.ecp, c);
 		noise_io<NOISE>::set(rba.parameters.obs_noise, c); spose_io<SPOSE>::set(rba.parameters.sensor_pose, c); sensor_io<OBS>::set(rba.parameters.sensor, c);
 		rba.set_hip_device(c.hip_device);
-		rba.on_capsule = [this](const srba_hip_params &hp, CapsuleData &cd) {
+		rba.on_capsule = [this](const srba_hip_params &hp, CapsuleData &cd, int stage) {
 			last_params = hp;
-			const bool stage1 = (cd.n_unk_edges == 1 && cd.n_unk_lms == 0 && in_stage1);
+			const bool stage1 = (stage == 1); // define_new_keyframe's single-edge optimisations, tagged by the engine itself
 			if ((cfg.harvest & 1) && !stage1) { harvest.data.push_back(cd); harvest.kf_of.push_back(cur_kf); harvest.dirty = true; }
 			if ((cfg.harvest & 2) && stage1) { harvest.data.push_back(cd); harvest.kf_of.push_back(cur_kf); harvest.dirty = true; }
 		};
@@ -103,11 +103,8 @@ struct EngineImpl : public EngineBase {
 				list.push_back(o);
 			}
 			typename rba_t::TNewKeyFrameInfo info;
-			cur_kf = rba.get_rba_state().keyframes.size(); in_stage1 = true; // stage-1 calls come first inside define_new_keyframe
-			// (the on_capsule hook distinguishes stage-1 by its single unknown edge; local-area calls with 1 edge and no LM are also
-			// possible for the 2nd keyframe: those are harvested as local-area capsules because stage-1 only runs for edges without init value)
+			cur_kf = rba.get_rba_state().keyframes.size();
 			rba.define_new_keyframe(list, info, cfg.run_local_optimization != 0);
-			in_stage1 = false;
 			if (out) {
 				std::memset(out, 0, sizeof(*out));
 				out->kf_id = info.kf_id; out->n_new_edges = (int)std::min<size_t>(info.created_edge_ids.size(), 4);
@@ -115,7 +112,7 @@ struct EngineImpl : public EngineBase {
 				fill_info(out, info.optimize_results, &info.optimize_results_stg1);
 			}
 			return 0;
-		} catch (std::exception &e) { in_stage1 = false; error = e.what(); return -1; }
+		} catch (std::exception &e) { error = e.what(); return -1; }
 	}
 	int optimize_local_area(uint64_t root, unsigned win, srba_kf_info *out) {
 		try { typename rba_t::TOptimizeExtraOutputInfo r; rba.optimize_local_area(root, win, r); if (out) { std::memset(out, 0, sizeof(*out)); out->kf_id = root; fill_info(out, r, NULL); } return 0; }
@@ -134,14 +131,14 @@ struct EngineImpl : public EngineBase {
 	}
 	/** what=0: next_edge rows [src trg next dist]; what=1: all_edges rows [from to len e0 e1 ...] ; returns the number of int64 needed */
 	int64_t st_dump(int what, int64_t *out, int64_t cap) const {
-		int64_t n = 0; const typename rba_t::rba_problem_state_t &st = rba.get_rba_state();
+		int64_t n = 0; const graph::topology &T = rba.get_rba_state().topo;
 		auto put = [&](int64_t v) { if (out && n < cap) out[n] = v; n++; };
-		if (what == 0) {
-			for (size_t s = 0; s < st.spanning_tree.sym.next_edge.size(); s++) { const std::map<TKeyFrameID, TSpanTreeEntry> *m = st.spanning_tree.sym.next_edge.find(s); if (!m) continue;
-				for (std::map<TKeyFrameID, TSpanTreeEntry>::const_iterator it = m->begin(); it != m->end(); ++it) { put(s); put(it->first); put(it->second.next); put(it->second.distance); } }
-		} else {
-			for (size_t s = 0; s < st.spanning_tree.sym.all_edges.size(); s++) { const std::map<TKeyFrameID, std::vector<size_t> > *m = st.spanning_tree.sym.all_edges.find(s); if (!m) continue;
-				for (std::map<TKeyFrameID, std::vector<size_t> >::const_iterator it = m->begin(); it != m->end(); ++it) { put(s); put(it->first); put(it->second.size()); for (size_t k = 0; k < it->second.size(); k++) put(it->second[k]); } }
+		for (size_t s = 0; s < T.st.rows(); s++) {
+			const graph::st_entry *r = T.st.row((graph::id32)s);
+			for (size_t i = 0; i < T.st.len((graph::id32)s); i++) {
+				if (what == 0) { put((int64_t)s); put(r[i].trg); put(r[i].next); put(r[i].dist); }
+				else if (r[i].trg < s && r[i].path != graph::NIL) { put((int64_t)s); put(r[i].trg); put(r[i].path_len); for (uint32_t k = 0; k < r[i].path_len; k++) put(T.path_pool[r[i].path + k]); }
+			}
 		}
 		return n;
 	}
