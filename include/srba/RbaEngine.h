@@ -192,7 +192,7 @@ struct local_areas_fixed_size {
 	TKeyFrameID get_center_kf_for_kf(const TKeyFrameID kf_id, const parameters_t &params) const { return params.submap_size * (kf_id / params.submap_size); }
 
 	template <class traits_t, class rba_engine_t>
-	void eval(const TKeyFrameID new_kf_id, const typename traits_t::new_kf_observations_t &obs, std::vector<TNewEdgeInfo> &new_k2k_edge_ids, rba_engine_t &rba_engine, const parameters_t &params) {
+	void eval(const TKeyFrameID new_kf_id, const typename traits_t::new_kf_observations_t &obs, std::vector<TNewEdgeInfo> &out_edges, rba_engine_t &rba_engine, const parameters_t &params) {
 		ASSERT_(new_kf_id >= 1);
 		const TKeyFrameID my_centre = get_center_kf_for_kf(new_kf_id, params);
 		// votes: observations of already-known landmarks per base key-frame, most voted first (ties: lower id first)
@@ -210,9 +210,9 @@ struct local_areas_fixed_size {
 		std::sort(areas.begin(), areas.end(), by_centre()); std::stable_sort(areas.begin(), areas.end(), by_votes());
 		// (1) a key-frame that does not open an area is linked to the centre of its area
 		if (my_centre != new_kf_id) {
-			TNewEdgeInfo nei; nei.has_approx_init_val = false;
-			nei.id = rba_engine.create_kf2kf_edge(new_kf_id, TPairKeyFrameID(my_centre, new_kf_id), obs);
-			new_k2k_edge_ids.push_back(nei);
+			TNewEdgeInfo link; link.has_approx_init_val = false;
+			link.id = rba_engine.create_kf2kf_edge(new_kf_id, TPairKeyFrameID(my_centre, new_kf_id), obs);
+			out_edges.push_back(link);
 		}
 		// (2) centre-to-centre edges towards areas whose centre is farther than what the spanning trees (plus the links of this very step) will cover
 		const topo_dist_t reach = rba_engine.parameters.srba.max_tree_depth + 1;
@@ -221,12 +221,12 @@ struct local_areas_fixed_size {
 			const topo_dist_t known_dist = rba_engine.symbolic_distance(my_centre, remote);
 			topo_dist_t slack = 2; if (my_centre == new_kf_id) slack--; if (areas[a].only_centre_is_base) slack--;
 			if (known_dist < reach - slack || areas[a].votes < params.min_obs_to_loop_closure) continue;
-			TNewEdgeInfo nei; nei.has_approx_init_val = false;
-			nei.id = rba_engine.create_kf2kf_edge(my_centre, TPairKeyFrameID(remote, my_centre), obs);
-			nei.loopclosure_observer_kf = new_kf_id; nei.loopclosure_base_kf = areas[a].best_base;
-			new_k2k_edge_ids.push_back(nei);
+			TNewEdgeInfo link; link.has_approx_init_val = false;
+			link.id = rba_engine.create_kf2kf_edge(my_centre, TPairKeyFrameID(remote, my_centre), obs);
+			link.loopclosure_observer_kf = new_kf_id; link.loopclosure_base_kf = areas[a].best_base;
+			out_edges.push_back(link);
 		}
-		ASSERTMSG_(new_k2k_edge_ids.size() >= 1, "Error for new KF: no suitable linking KF found with the minimum number of common observations: the node becomes isolated of the graph!");
+		ASSERTMSG_(out_edges.size() >= 1, "Error for new KF: no suitable linking KF found with the minimum number of common observations: the node becomes isolated of the graph!");
 	}
 };
 
@@ -236,18 +236,18 @@ struct classic_linear_rba {
 	struct parameters_t { size_t min_obs_to_loop_closure; parameters_t() : min_obs_to_loop_closure(4) {} };
 
 	template <class traits_t, class rba_engine_t>
-	void eval(const TKeyFrameID new_kf_id, const typename traits_t::new_kf_observations_t &obs, std::vector<TNewEdgeInfo> &new_k2k_edge_ids, rba_engine_t &rba_engine, const parameters_t &params) {
+	void eval(const TKeyFrameID new_kf_id, const typename traits_t::new_kf_observations_t &obs, std::vector<TNewEdgeInfo> &out_edges, rba_engine_t &rba_engine, const parameters_t &params) {
 		ASSERT_(new_kf_id >= 1);
 		TNewEdgeInfo chain; chain.has_approx_init_val = true; // identity: the new key-frame starts where the previous one is
 		chain.id = rba_engine.create_kf2kf_edge(new_kf_id, TPairKeyFrameID(new_kf_id - 1, new_kf_id), obs, typename traits_t::original_kf2kf_pose_t::pose_t());
-		new_k2k_edge_ids.push_back(chain);
+		out_edges.push_back(chain);
 		std::vector<std::pair<TKeyFrameID, size_t> > votes; rba_engine.count_observations_per_base_kf(obs, votes);
 		const topo_dist_t reach = rba_engine.parameters.srba.max_tree_depth + 1;
 		for (size_t v = 0; v < votes.size(); v++) {
 			if (rba_engine.symbolic_distance(new_kf_id, votes[v].first) < reach || votes[v].second < params.min_obs_to_loop_closure) continue;
-			TNewEdgeInfo nei; nei.has_approx_init_val = false;
-			nei.id = rba_engine.create_kf2kf_edge(new_kf_id, TPairKeyFrameID(votes[v].first, new_kf_id), obs);
-			new_k2k_edge_ids.push_back(nei);
+			TNewEdgeInfo link; link.has_approx_init_val = false;
+			link.id = rba_engine.create_kf2kf_edge(new_kf_id, TPairKeyFrameID(votes[v].first, new_kf_id), obs);
+			out_edges.push_back(link);
 		}
 	}
 };
@@ -580,25 +580,25 @@ protected:
 		if (T.n_keyframes() == 1) return; // the very first key-frame has nothing to link to
 		edge_creation_policy.template eval<traits_t, rba_engine_t>(new_kf_id, obs, created, *this, parameters.ecp);
 		for (size_t i = 0; i < created.size(); i++) {
-			TNewEdgeInfo &nei = created[i]; if (nei.has_approx_init_val) continue;
-			k2k_edge_t &ed = rba_state.k2k_edges[nei.id];
+			TNewEdgeInfo &info = created[i]; if (info.has_approx_init_val) continue;
+			k2k_edge_t &ed = rba_state.k2k_edges[info.id];
 			const bool touches_new_kf = (ed.to == new_kf_id || ed.from == new_kf_id), points_to_new_kf = (ed.to == new_kf_id);
 			if (touches_new_kf && std::binary_search(T.last_touched_kfs.begin(), T.last_touched_kfs.end(), (graph::id32)ed.from)) {
-				if (const pose_t *prev = get_kf_relative_pose(new_kf_id - 1, ed.from)) { ed.inv_pose = points_to_new_kf ? -(*prev) : *prev; nei.has_approx_init_val = true; continue; }
+				if (const pose_t *prev = get_kf_relative_pose(new_kf_id - 1, ed.from)) { ed.inv_pose = points_to_new_kf ? -(*prev) : *prev; info.has_approx_init_val = true; continue; }
 			}
 			pose_t align; // pose of the later key-frame with respect to the earlier one, from matched observations
 			bool ok = touches_new_kf ? align_by_common_landmarks(obs, true, new_kf_id, points_to_new_kf ? ed.from : ed.to, align)
 			                         : align_by_common_landmarks(obs, false, ed.from, ed.to, align);
-			const bool have_lc_hint = nei.loopclosure_observer_kf != SRBA_INVALID_KEYFRAMEID && nei.loopclosure_base_kf != SRBA_INVALID_KEYFRAMEID;
-			if (!ok && have_lc_hint) ok = align_by_common_landmarks(obs, nei.loopclosure_observer_kf == new_kf_id, nei.loopclosure_observer_kf, nei.loopclosure_base_kf, align);
+			const bool have_lc_hint = info.loopclosure_observer_kf != SRBA_INVALID_KEYFRAMEID && info.loopclosure_base_kf != SRBA_INVALID_KEYFRAMEID;
+			if (!ok && have_lc_hint) ok = align_by_common_landmarks(obs, info.loopclosure_observer_kf == new_kf_id, info.loopclosure_observer_kf, info.loopclosure_base_kf, align);
 			if (!ok) { if (m_verbose_level >= 2) std::cout << "[determine_kf2kf_edges_to_create] Could not provide initial value to relative pose " << ed.from << "<=>" << ed.to << "\n"; continue; }
 			// the alignment relates SENSOR frames: move it to the robot frames
 			const mrpt::poses::CPose3D S = RBA_OPTIONS::sensor_pose_on_robot_t::sensor_pose_as_3d(parameters.sensor_pose);
 			align = pose_t((S + mrpt::poses::CPose3D(align)) + (-S));
-			nei.has_approx_init_val = true;
+			info.has_approx_init_val = true;
 			if (touches_new_kf) { ed.inv_pose = points_to_new_kf ? -align : align; continue; }
 			// edge between two older key-frames: (base wrt remote end) (+) align (+) (-)(observer wrt local end), the "local" end being the one the observer is known from
-			const pose_t I; const TKeyFrameID ob = nei.loopclosure_observer_kf, bs = nei.loopclosure_base_kf;
+			const pose_t I; const TKeyFrameID ob = info.loopclosure_observer_kf, bs = info.loopclosure_base_kf;
 			const pose_t *ob_to = (ob == ed.to) ? &I : get_kf_relative_pose(ob, ed.to), *bs_to = (bs == ed.to) ? &I : get_kf_relative_pose(bs, ed.to);
 			const pose_t *ob_from = (ob == ed.from) ? &I : get_kf_relative_pose(ob, ed.from), *bs_from = (bs == ed.from) ? &I : get_kf_relative_pose(bs, ed.from);
 			const bool local_is_to = (ob_to || bs_from) || !(ob_from || bs_to);

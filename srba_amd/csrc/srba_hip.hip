@@ -510,24 +510,37 @@ static const char *validate_capsule(const srba_problem_capsule &k) {
 	for (int i = 0; i < k.n_pairs; i++) if (k.pair_path_off[i + 1] < k.pair_path_off[i]) return "pair_path_off not monotone";
 	for (int i = 0; i < k.n_path; i++) if (k.path_edge[i] < 0 || (k.path_edge[i] >> 1) >= k.n_edges) return "path_edge";
 	for (int i = 0; i < k.n_obs; i++) if (!in(k.obs_pose[i], -1, np2) || !lmref(k.obs_lm[i]) || !in(k.obs_valid[i], 0, std::max(k.n_valid, 1))) return "observation table";
+	if (!k.edge_pose || (k.n_unk_lms && !k.ulm_pos) || (k.n_known_lms && !k.klm_pos) || (k.n_obs && (!k.obs_pose || !k.obs_lm || !k.obs_valid || !k.obs_z)) || (k.n_path && !k.path_edge)) return "null data array";
+	if (k.n_bp && (!k.bp_col || !k.bp_res || !k.bp_A || !k.bp_D || !k.bp_lm || !k.bp_normal)) return "null dh_dAp table";
+	if (k.n_bf && (!k.bf_col || !k.bf_res || !k.bf_pose)) return "null dh_df table";
 	if (k.n_unk_edges && (!k.colp_off || k.colp_off[0] != 0 || k.colp_off[k.n_unk_edges] != k.n_bp)) return "colp_off";
+	for (int i = 0; i < k.n_unk_edges; i++) if (k.colp_off[i + 1] < k.colp_off[i]) return "colp_off not monotone";
 	for (int i = 0; i < k.n_bp; i++) if (!in(k.bp_col[i], 0, k.n_unk_edges) || !in(k.bp_res[i], 0, k.n_obs) || !in(k.bp_A[i], -1, np2) || !in(k.bp_D[i], -1, np2) || !lmref(k.bp_lm[i])) return "dh_dAp block table";
-	if (k.n_unk_lms && k.n_bf && (!k.colf_off || k.colf_off[0] != 0 || k.colf_off[k.n_unk_lms] != k.n_bf)) return "colf_off";
+	if (k.n_unk_lms && (!k.colf_off || k.colf_off[0] != 0 || k.colf_off[k.n_unk_lms] != k.n_bf)) return "colf_off";
+	for (int i = 0; i < k.n_unk_lms; i++) if (k.colf_off[i + 1] < k.colf_off[i]) return "colf_off not monotone";
 	for (int i = 0; i < k.n_bf; i++) if (!in(k.bf_col[i], 0, k.n_unk_lms) || !in(k.bf_res[i], 0, k.n_obs) || !in(k.bf_pose[i], -1, np2)) return "dh_df block table";
+	if (k.n_hap && (!k.hap_i || !k.hap_j || !k.hap_term_off || (k.n_hap_terms && (!k.hap_t1 || !k.hap_t2)))) return "null HAp table";
+	if (k.n_unk_edges && !k.hap_diag) return "null hap_diag";
 	if (k.n_hap && (k.hap_term_off[0] != 0 || k.hap_term_off[k.n_hap] != k.n_hap_terms)) return "hap_term_off";
 	for (int i = 0; i < k.n_hap; i++) if (!in(k.hap_i[i], 0, k.n_unk_edges) || !in(k.hap_j[i], 0, k.n_unk_edges) || k.hap_term_off[i + 1] < k.hap_term_off[i]) return "HAp block table";
 	for (int i = 0; i < k.n_hap_terms; i++) if (!in(k.hap_t1[i], 0, k.n_bp) || !in(k.hap_t2[i], 0, k.n_bp)) return "HAp terms";
 	for (int i = 0; i < k.n_unk_edges; i++) if (!in(k.hap_diag[i], 0, k.n_hap)) return "hap_diag";
+	if (k.n_hf && (!k.hf_i || !k.hf_j || !k.hf_term_off || !k.hf_diag || (k.n_hf_terms && (!k.hf_t1 || !k.hf_t2)))) return "null Hf table";
 	if (k.n_hf && (k.hf_term_off[0] != 0 || k.hf_term_off[k.n_hf] != k.n_hf_terms)) return "hf_term_off";
+	for (int i = 0; i < k.n_hf; i++) if (k.hf_term_off[i + 1] < k.hf_term_off[i]) return "hf_term_off not monotone";
 	for (int i = 0; i < k.n_hf; i++) if (!in(k.hf_i[i], 0, k.n_unk_lms) || !in(k.hf_j[i], 0, k.n_unk_lms)) return "Hf block table";
 	for (int i = 0; i < k.n_hf_terms; i++) if (!in(k.hf_t1[i], 0, k.n_bf) || !in(k.hf_t2[i], 0, k.n_bf)) return "Hf terms";
 	for (int i = 0; i < k.n_unk_lms && k.n_hf; i++) if (!in(k.hf_diag[i], 0, k.n_hf)) return "hf_diag";
+	if (k.n_hapf && (!k.hapf_i || !k.hapf_j || !k.hapf_term_off || !k.hapf_t1 || !k.hapf_t2 || !k.lm_hapf_off || !k.lm_hapf_idx)) return "null HApf table";
 	if (k.n_hapf && (k.hapf_term_off[0] != 0 || k.hapf_term_off[k.n_hapf] != k.n_hapf_terms)) return "hapf_term_off";
+	for (int i = 0; i < k.n_hapf; i++) if (k.hapf_term_off[i + 1] < k.hapf_term_off[i]) return "hapf_term_off not monotone";
+	if (k.n_hapf) { if (k.lm_hapf_off[0] != 0 || k.lm_hapf_off[k.n_unk_lms] != k.n_hapf) return "lm_hapf_off"; for (int i = 0; i < k.n_unk_lms; i++) if (k.lm_hapf_off[i + 1] < k.lm_hapf_off[i]) return "lm_hapf_off not monotone";
+		for (int i = 0; i < k.n_hapf; i++) if (!in(k.lm_hapf_idx[i], 0, k.n_hapf)) return "lm_hapf_idx"; }
 	for (int i = 0; i < k.n_hapf; i++) if (!in(k.hapf_i[i], 0, k.n_unk_edges) || !in(k.hapf_j[i], 0, k.n_unk_lms)) return "HApf block table";
 	for (int i = 0; i < k.n_hapf_terms; i++) if (!in(k.hapf_t1[i], 0, k.n_bp) || !in(k.hapf_t2[i], 0, k.n_bf)) return "HApf terms";
-	if (k.n_sch_terms) { if (!k.sch_term_off || k.sch_term_off[k.n_hap] != k.n_sch_terms) return "sch_term_off";
-		for (int i = 0; i < k.n_sch_terms; i++) if (!in(k.sch_b1[i], 0, k.n_hapf) || !in(k.sch_b2[i], 0, k.n_hapf) || !in(k.sch_lm[i], 0, k.n_unk_lms)) return "Schur terms";
-		for (int i = 0; i < k.n_hapf; i++) if (!in(k.lm_hapf_idx[i], 0, k.n_hapf)) return "lm_hapf_idx"; }
+	if (k.n_sch_terms) { if (!k.sch_term_off || !k.sch_b1 || !k.sch_b2 || !k.sch_lm || k.sch_term_off[0] != 0 || k.sch_term_off[k.n_hap] != k.n_sch_terms) return "sch_term_off";
+		for (int i = 0; i < k.n_hap; i++) if (k.sch_term_off[i + 1] < k.sch_term_off[i]) return "sch_term_off not monotone";
+		for (int i = 0; i < k.n_sch_terms; i++) if (!in(k.sch_b1[i], 0, k.n_hapf) || !in(k.sch_b2[i], 0, k.n_hapf) || !in(k.sch_lm[i], 0, k.n_unk_lms)) return "Schur terms"; }
 	return nullptr;
 }
 
@@ -696,6 +709,7 @@ int srba_hip_kernel_ms_history(srba_hip_ctx *c, double *out_ms, int n) {
 int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, int n) {
 	if (!c || !caps || n <= 0) { if (c) c->fail("upload: bad arguments"); return -1; }
 	HIPCHK(c, hipSetDevice(c->device));
+	c->n_prob = 0; // whatever was uploaded before stops being launchable / readable now: a failed upload leaves the context empty, not half-updated
 	const int P = c->dm.P, L = c->dm.L, O = c->dm.O, PD = c->dm.PD, PDX = c->dm.PDX();
 	const bool schur_solver = c->params.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL;
 	c->desc.assign(n, ProbDesc()); srba_batch_stats &st = c->stats; std::memset(&st, 0, sizeof(st)); st.n_problems = n;
@@ -923,12 +937,12 @@ int srba_hip_lm_run_async(srba_hip_ctx *c) {
 	  c->ev0 = c->ring0[slot]; c->ev1 = c->ring1[slot]; c->n_launches++; }
 	HIPCHK(c, hipEventRecord(c->ev0, c->stream));
 	// fork/join: the launch plan (made at upload) spreads the size classes over a few streams; see plan_launches()
-	const int nq = c->n_streams_used;
-	HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+	const int nq = c->plan.size() == 1 ? 1 : c->n_streams_used; // a single launch (the per-key-frame use) stays on the context stream: no fork / join
+	if (nq > 1) HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
 	for (int q = 1; q < nq; q++) HIPCHK(c, hipStreamWaitEvent(c->cls_stream[q], c->ev_fork, 0));
 	for (size_t j = 0; j < c->plan.size(); j++) {
 		const LaunchJob &J = c->plan[j]; const int k = J.cls;
-		hipStream_t launch_stream = J.queue ? c->cls_stream[J.queue] : c->stream;
+		hipStream_t launch_stream = (J.queue && nq > 1) ? c->cls_stream[J.queue] : c->stream;
 		SRBA_DISPATCH_LDS(c, k_lm_run, k < SRBA_NCLS - 1, J.count, c->cls_lds[k] + c->lds_pad, J.first); HIPCHK(c, hipGetLastError());
 	}
 	for (int q = 1; q < nq; q++) { HIPCHK(c, hipEventRecord(c->cls_done[q], c->cls_stream[q])); HIPCHK(c, hipStreamWaitEvent(c->stream, c->cls_done[q], 0)); }

@@ -43,6 +43,7 @@ def lib(opt="O2"):
 def _proto(l):
     l.srba_oracle_lm_run.argtypes = [C.POINTER(capi.HipParams), capi.PCAP, capi.c_i32, C.POINTER(capi.LmResult), capi.c_i32]
     l.srba_oracle_run_one.argtypes = [C.POINTER(capi.HipParams), capi.PCAP, C.POINTER(capi.LmResult)]
+    l.srba_oracle_take_symbolic_seconds.restype = capi.c_f64
     l.srba_oracle_stage.argtypes = [C.POINTER(capi.HipParams), capi.PCAP, capi.c_i32, capi.c_f64] + [capi.PF64] * 10
 
 

@@ -1,6 +1,7 @@
-"""bench.py under torch.distributed.run with two ranks (the driver's N>1 launch line), squeezed onto ONE GPU for the test: both ranks use
-device 0 and rendezvous over gloo (RCCL refuses two ranks on one device). Checks the contract of the result line: one JSON line from rank 0,
-n_gpus = 2, whole-job value = sum of both ranks' work over the max elapsed."""
+"""bench.py under torch.distributed.run with two ranks (the driver's N>1 launch line). On a box with >= 2 GPUs this is the real thing: one rank
+per device, `nccl` (= RCCL) process group, no test hooks. On the 1-GPU test box both ranks are squeezed onto device 0 and rendezvous over gloo
+(RCCL refuses two ranks on one device). Checks the contract of the result line: one JSON line from rank 0, n_gpus = 2, whole-job value = sum of
+both ranks' work over the max elapsed."""
 import json
 import os
 import socket
@@ -14,7 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 def test_bench_two_ranks_one_json_line(tmp_path):
-    env = dict(os.environ, SRBA_BENCH_DEVICE="0", SRBA_BENCH_BACKEND="gloo")
+    import torch
+    env = dict(os.environ)
+    if torch.cuda.device_count() < 2:
+        env.update(SRBA_BENCH_DEVICE="0", SRBA_BENCH_BACKEND="gloo")
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--n-kf", "1500", "--cpu-seconds", "0", "--cache-dir", str(tmp_path)]
