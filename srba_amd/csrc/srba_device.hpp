@@ -356,6 +356,94 @@ template <bool DLDS> __device__ __forceinline__ void sp_bsub(const SparseSys &S)
 		re = rb; rb = rb_n; rb_n = rb_nn; kc = kc_n; bl = bl_n;
 	}
 }
+// ---- LDS solver, lane-per-block-row form. The one-lane-per-3x3-block loops above keep 1..10 of 64 lanes busy and every wave instruction
+// costs an issue slot whatever the number of live lanes, so the factorisation was issue-bound at ~250 instructions per column. Here a 3x3
+// block is worked on by THREE lanes, one per block row (lane = 3*block + row; lane 63 idles in these phases):
+//   panel   : row r of L_ak = A_ak L_kk^-t is a 3-term forward substitution of row r of A_ak alone      (3 loads, 6 flops, 3 stores per lane)
+//   rhs     : rhs_a[r] -= L_ak[r,:] . y_k                                                                (same lane, 1 load, 1 store)
+//   update  : row r of T -= L_ak L_bk^t needs row r of L_ak, all of L_bk and row r of T                  (15 loads, 9 fma, 3 stores per lane)
+//   backward: y_k[q] -= (L_ak^t x_a)[q] = sum_r L_ak[r][q] x_a[r], one lane per (entry, q)               (4 loads, 3 fma, 1 store per lane)
+// so a column with 4 panel blocks and 10 update items occupies 12 / 30 lanes instead of 4 / 10 and the dependent chain per lane is a third as
+// long; the instruction count per column drops to about half. The diagonal 3x3 Cholesky stays redundant in every lane (no broadcast).
+// Same arithmetic per scalar as the lane-per-block form (same operation order inside every dot product): results are bit-identical.
+__device__ __forceinline__ bool sp_factor_fsub_rows(const SparseSys &S) {
+	const int lane = threadIdx.x, nb = S.nb;
+	const int grp = (lane * 171) >> 9, sub = lane - 3 * grp; // lane / 3, lane % 3 for lane < 64
+	const bool worker = lane < 63;
+	int cb = S.col_off[0], ce = nb > 0 ? S.col_off[1] : cb, ib = 0;
+	int ra = (worker && cb + grp < ce) ? S.row[cb + grp] : 0; // block-row of this lane's panel block in the coming column
+	for (int k = 0; k < nb; k++) {
+		const int cn = ce - cb, nitems = cn * (cn + 1) / 2;
+		double *D = S.diag + 9 * k;
+		const double a00 = D[0], a10 = D[3], a11 = D[4], a20 = D[6], a21 = D[7], a22 = D[8];
+		const double b0 = S.rhs[3 * k], b1 = S.rhs[3 * k + 1], b2 = S.rhs[3 * k + 2];
+		const bool pl = worker && grp < cn;
+		double *Arow = S.off + 9 * (cb + grp) + 3 * sub; double *rr = S.rhs + 3 * ra + sub;
+		double A0 = 0, A1 = 0, A2 = 0, rv = 0;
+		if (pl) { A0 = Arow[0]; A1 = Arow[1]; A2 = Arow[2]; rv = *rr; }
+		// index loads for the next column
+		const int ce_n = (k + 2 <= nb) ? S.col_off[k + 2] : ce;
+		const int ra_n = (worker && ce + grp < ce_n) ? S.row[ce + grp] : 0;
+		Chol3 c;
+		if (!chol3v(a00, a10, a11, a20, a21, a22, c)) return false;
+		const double y0 = b0 * c.r0, y1 = (b1 - c.l10 * y0) * c.r1, y2 = (b2 - c.l20 * y0 - c.l21 * y1) * c.r2;
+		if (pl) {
+			const double x0 = A0 * c.r0, x1 = (A1 - x0 * c.l10) * c.r1, x2 = (A2 - x0 * c.l20 - x1 * c.l21) * c.r2;
+			Arow[0] = x0; Arow[1] = x1; Arow[2] = x2;
+			*rr = rv - (x0 * y0 + x1 * y1 + x2 * y2);
+		}
+		if (worker) for (int p = grp + 21; p < cn; p += 21) { // columns with more than 21 blocks
+			double *Ax = S.off + 9 * (cb + p) + 3 * sub; double *rx = S.rhs + 3 * S.row[cb + p] + sub;
+			const double x0 = Ax[0] * c.r0, x1 = (Ax[1] - x0 * c.l10) * c.r1, x2 = (Ax[2] - x0 * c.l20 - x1 * c.l21) * c.r2;
+			Ax[0] = x0; Ax[1] = x1; Ax[2] = x2; *rx -= x0 * y0 + x1 * y1 + x2 * y2;
+		}
+		if (lane == SRBA_WG - 1) { // L_kk, reciprocal diagonal in the unused upper part, y_k
+			D[0] = c.l00; D[3] = c.l10; D[4] = c.l11; D[6] = c.l20; D[7] = c.l21; D[8] = c.l22; D[1] = c.r0; D[2] = c.r1; D[5] = c.r2;
+			S.rhs[3 * k] = y0; S.rhs[3 * k + 1] = y1; S.rhs[3 * k + 2] = y2;
+		}
+		solver_sync<true>();
+		if (worker) for (int t = grp; t < nitems; t += 21) { // trailing update, row `sub` of target -= L_ak L_bk^t
+			const unsigned w = (unsigned)S.item[ib + t];
+			const double *La = S.off + 9 * (cb + ((w >> 9) & 511)) + 3 * sub, *Lb = S.off + 9 * (cb + (w & 511)); double *T = S.diag + 9 * (w >> 18) + 3 * sub;
+			const double la0 = La[0], la1 = La[1], la2 = La[2];
+			double lb[9];
+#pragma unroll
+			for (int q = 0; q < 9; q++) lb[q] = Lb[q];
+			const double t0 = T[0], t1 = T[1], t2 = T[2];
+			T[0] = t0 - (la0 * lb[0] + la1 * lb[1] + la2 * lb[2]);
+			T[1] = t1 - (la0 * lb[3] + la1 * lb[4] + la2 * lb[5]);
+			T[2] = t2 - (la0 * lb[6] + la1 * lb[7] + la2 * lb[8]);
+		}
+		solver_sync<true>();
+		cb = ce; ce = ce_n; ib += nitems; ra = ra_n;
+	}
+	return true;
+}
+__device__ __forceinline__ void sp_bsub_rows(const SparseSys &S) {
+	const int lane = threadIdx.x, nb = S.nb;
+	if (nb <= 0) return;
+	const int grp = (lane * 171) >> 9, sub = lane - 3 * grp; const bool worker = lane < 63;
+	int re = S.rptr[nb], rb = S.rptr[nb - 1], rb_n = nb >= 2 ? S.rptr[nb - 2] : 0;
+	unsigned w = (worker && rb + grp < re) ? (unsigned)S.rent[rb + grp] : 0u; // col << 14 | off-diagonal block
+	for (int a = nb - 1; a >= 0; a--) {
+		const bool act = worker && rb + grp < re;
+		const double *D = S.diag + 9 * a; const double *Lb = S.off + 9 * (w & 0x3fff) + sub; double *y = S.rhs + 3 * (w >> 14) + sub;
+		const double r0 = S.rhs[3 * a], r1 = S.rhs[3 * a + 1], r2 = S.rhs[3 * a + 2], d5 = D[5], d7 = D[7], d2 = D[2], d3 = D[3], d6 = D[6], d1 = D[1];
+		double l0 = 0, l1 = 0, l2 = 0, yv = 0;
+		if (act) { l0 = Lb[0]; l1 = Lb[3]; l2 = Lb[6]; yv = *y; }
+		const unsigned w_n = (worker && a > 0 && rb_n + grp < rb) ? (unsigned)S.rent[rb_n + grp] : 0u;
+		const int rb_nn = a >= 2 ? S.rptr[a - 2] : 0;
+		const double x2 = r2 * d5, x1 = (r1 - d7 * x2) * d2, x0 = (r0 - d3 * x1 - d6 * x2) * d1;
+		if (act) *y = yv - (l0 * x0 + l1 * x1 + l2 * x2);
+		if (worker) for (int j = rb + grp + 21; j < re; j += 21) { // rows with more than 21 blocks
+			const unsigned wx = (unsigned)S.rent[j]; const double *Lx = S.off + 9 * (wx & 0x3fff) + sub; double *yx = S.rhs + 3 * (wx >> 14) + sub;
+			*yx -= Lx[0] * x0 + Lx[3] * x1 + Lx[6] * x2;
+		}
+		if (lane == SRBA_WG - 1) { S.rhs[3 * a] = x0; S.rhs[3 * a + 1] = x1; S.rhs[3 * a + 2] = x2; }
+		solver_sync<true>();
+		re = rb; rb = rb_n; rb_n = rb_nn; w = w_n;
+	}
+}
 // location of scalar element (r,c), r>=c (block-permutation already applied); returns nullptr if the block is structurally absent
 __device__ __forceinline__ double *sp_elem(const SparseSys &S, int r, int c) {
 	const int br = r / 3, bc = c / 3; // (already permuted, r >= c)

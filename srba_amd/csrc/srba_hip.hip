@@ -184,9 +184,9 @@ struct Solver : public Worker<FAM> {
 #define STOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - t0; } } while (0)
 		STIC(); if (schur_active()) schur_reduce(lambda); STOC(9);
 		STIC(); assemble(S, lambda); STOC(10);
-		STIC(); const bool ok = sp_factor_fsub<DLDS>(S); STOC(11);
+		STIC(); bool ok; if constexpr (DLDS) ok = sp_factor_fsub_rows(S); else ok = sp_factor_fsub<false>(S); STOC(11);
 		if (!ok) return false;
-		STIC(); sp_bsub<DLDS>(S);
+		STIC(); if constexpr (DLDS) sp_bsub_rows(S); else sp_bsub<false>(S);
 		double *dl = B.delta + d.o_scal;
 		for (int k = tid; k < d.n_scal; k += SRBA_WG) dl[k] = (k < d.n_sys) ? S.rhs[3 * S.perm[k / 3] + k % 3] : 0.0;
 		__syncthreads(); STOC(12);
@@ -257,8 +257,8 @@ extern __shared__ double srba_lds[]; // block-sparse system of the capsule (diag
 #define SRBA_OCC
 #endif
 template <int FAM, bool DLDS>
-__global__ void __launch_bounds__(SRBA_WG) SRBA_OCC k_lm_run(const Batch B, const DevParams prm, int first) {
-	const int pidx = B.order[first + blockIdx.x]; const ProbDesc &d = B.desc[pidx];
+__device__ __forceinline__ void lm_one(const Batch &B, const DevParams &prm, const int pidx) {
+	const ProbDesc &d = B.desc[pidx];
 	Solver<FAM> S(B, d, prm);
 	constexpr int P = Solver<FAM>::P, L = Solver<FAM>::L, O = Solver<FAM>::O;
 	double *red = nullptr;
@@ -347,6 +347,19 @@ __global__ void __launch_bounds__(SRBA_WG) SRBA_OCC k_lm_run(const Batch B, cons
 		out->total_sqr_error_final = total_err; out->obs_rmse = RMSE; out->lambda_final = lambda;
 	}
 	(void)P;
+}
+// Persistent workgroups: a launch covers one LDS size class with a grid of at most the number of wavefronts the chip can hold for that class; every
+// wavefront pulls capsules (sorted longest-first inside the class) from a shared counter until the class is exhausted. A launch therefore has ONE
+// tail (its last capsules) instead of one per chunk, and the chip stays full while big (LDS-bound) and small (wave-slot-bound) classes drain side by side.
+template <int FAM, bool DLDS>
+__global__ void __launch_bounds__(SRBA_WG) SRBA_OCC k_lm_run(const Batch B, const DevParams prm, int first, int count, int *next) {
+	for (;;) {
+		int i = 0; if (threadIdx.x == 0) i = atomicAdd(next, 1);
+		i = __builtin_amdgcn_readfirstlane(i);
+		if (i >= count) break;
+		lm_one<FAM, DLDS>(B, prm, B.order[first + i]);
+		__syncthreads(); // the LDS image and the symbolic copy are rebuilt by the next capsule
+	}
 }
 
 // ---- stepwise kernels
@@ -498,7 +511,8 @@ static void symbolic_factor(const srba_problem_capsule &k, const ProbDesc &d, in
 	  out.fill.clear(); for (size_t u = 0; u < covered.size(); u++) if (!covered[u]) out.fill.push_back((int32_t)u); }
 }
 
-struct LaunchJob { int queue, cls, first, count; double cost; };
+struct LaunchJob { int queue, cls, first, count; double cost; int grid; };
+static const int kMaxJobs = 1024;
 // Index-range check of one capsule (every index the kernels dereference): a wrong capsule is reported at upload instead of reading out of bounds on the device
 static const char *validate_capsule(const srba_problem_capsule &k) {
 	auto in = [](int v, int lo, int hi) { return v >= lo && v < hi; };
@@ -555,9 +569,9 @@ struct srba_hip_ctx {
 	std::string error;
 	// batch
 	int n_prob = 0; std::vector<ProbDesc> desc; Batch B; srba_batch_stats stats;
-	char *d_in = nullptr; size_t cap_in = 0; char *d_wk = nullptr; size_t cap_wk = 0;
+	char *d_in = nullptr; size_t cap_in = 0; char *d_wk = nullptr; size_t cap_wk = 0; int *d_next = nullptr;
 	std::vector<char> h_in; // host staging of the input arena
-	int max_lds_kb = 1 << 20, min_chunk = 384, max_parts_per_queue = 2; int n_queues = 16, sched = 1, n_streams_used = 1; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
+	int max_lds_kb = 1 << 20, min_chunk = 384, max_parts_per_queue = 2; int n_queues = 16, sched = 3, n_streams_used = 1, n_cu = 256, waves_per_cu = 8, lds_per_cu = 160 * 1024; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
 	// offsets needed for downloads (bytes inside the wk arena)
 	size_t off_edge = 0, off_ulm = 0, off_pose = 0, off_inf = 0, off_infv = 0, off_res = 0;
 	size_t off_dbg[10] = {0}; int64_t len_dbg[10] = {0};
@@ -574,12 +588,20 @@ struct srba_hip_ctx {
 //   sched 2: one stream per class, biggest first
 static void plan_launches(srba_hip_ctx *c, const int32_t *ord) {
 	c->plan.clear(); const int nq = c->n_queues;
+	struct fin { srba_hip_ctx *c; ~fin() { // grid of every job: persistent launches hold as many wavefronts as the chip can keep resident for that LDS size, the rest one per capsule
+		for (size_t j = 0; j < c->plan.size(); j++) { LaunchJob &J = c->plan[j]; J.grid = J.count;
+			if (c->sched == 3) { const size_t lds = c->cls_lds[J.cls] + c->lds_pad; const int fit = lds ? (int)std::max<size_t>(1, (size_t)c->lds_per_cu / lds) : c->waves_per_cu; J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(c->waves_per_cu, fit))); } } } } finish = {c};
+	if (c->sched == 3) { // one persistent launch per size class, every class on its own stream, biggest LDS footprint first (the HBM class is the biggest)
+		int q = 0;
+		for (int k = SRBA_NCLS - 1; k >= 0; k--) if (c->cls_count[k]) { c->plan.push_back({q, k, c->cls_first[k], c->cls_count[k], 0.0, 0}); q++; }
+		c->n_streams_used = std::max(q, 1); return;
+	}
 	// cost of a chunk ~ sum over its capsules of (system size) x (LDS footprint): a trial takes time ~ nb, and how many capsules run at once
 	// is set by the LDS they hold (measured on the benchmark: 43 us per loop-closure window vs 5.5 us per typical window, chip-wide)
 	auto cost_of = [&](int cls, int first, int count) { const double w = cls == SRBA_NCLS - 1 ? 24.0 : std::max(1.0, (double)c->cls_lds[cls] / 8192.0); double s = 0; for (int i = 0; i < count; i++) s += (c->desc[ord[first + i]].nb + 4) * w; return s; };
 	if (c->sched == 2) {
 		int q = 0;
-		for (int k = SRBA_NCLS - 1; k >= 0; k--) if (c->cls_count[k]) { c->plan.push_back({q, k, c->cls_first[k], c->cls_count[k], 0.0}); q++; }
+		for (int k = SRBA_NCLS - 1; k >= 0; k--) if (c->cls_count[k]) { c->plan.push_back({q, k, c->cls_first[k], c->cls_count[k], 0.0, 0}); q++; }
 		c->n_streams_used = std::max(q, 1); return;
 	}
 	c->n_streams_used = nq;
@@ -587,14 +609,14 @@ static void plan_launches(srba_hip_ctx *c, const int32_t *ord) {
 		int rr = 0;
 		for (int k = SRBA_NCLS - 1; k >= 0; k--) if (c->cls_count[k]) {
 			const int cnt = c->cls_count[k], parts = cnt >= 16 * nq ? nq : 1;
-			for (int q = 0; q < parts; q++) { const int a = slice_begin(cnt, q, parts), b = slice_begin(cnt, q + 1, parts); if (b > a) c->plan.push_back({parts == 1 ? (rr++ % nq) : q, k, c->cls_first[k] + a, b - a, 0.0}); }
+			for (int q = 0; q < parts; q++) { const int a = slice_begin(cnt, q, parts), b = slice_begin(cnt, q + 1, parts); if (b > a) c->plan.push_back({parts == 1 ? (rr++ % nq) : q, k, c->cls_first[k] + a, b - a, 0.0, 0}); }
 		}
 		return;
 	}
 	std::vector<LaunchJob> jobs;
 	for (int k = SRBA_NCLS - 1; k >= 0; k--) if (c->cls_count[k]) {
 		const int cnt = c->cls_count[k], parts = std::max(1, std::min(c->max_parts_per_queue * nq, cnt / c->min_chunk));
-		for (int q = 0; q < parts; q++) { const int a = slice_begin(cnt, q, parts), b = slice_begin(cnt, q + 1, parts); if (b > a) jobs.push_back({0, k, c->cls_first[k] + a, b - a, cost_of(k, c->cls_first[k] + a, b - a)}); }
+		for (int q = 0; q < parts; q++) { const int a = slice_begin(cnt, q, parts), b = slice_begin(cnt, q + 1, parts); if (b > a) jobs.push_back({0, k, c->cls_first[k] + a, b - a, cost_of(k, c->cls_first[k] + a, b - a), 0}); }
 	}
 	std::vector<size_t> by_cost(jobs.size()); for (size_t i = 0; i < jobs.size(); i++) by_cost[i] = i;
 	std::stable_sort(by_cost.begin(), by_cost.end(), [&](size_t a, size_t b) { return jobs[a].cost > jobs[b].cost; });
@@ -665,11 +687,13 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_LDS_PAD"); c->lds_pad = e ? (size_t)atol(e) : 0; } // diagnostics: extra LDS bytes per workgroup (lowers residency)
 	{ const char *e = getenv("SRBA_HIP_CHUNK"); if (e && atoi(e) > 0) c->min_chunk = atoi(e); e = getenv("SRBA_HIP_PARTS"); if (e && atoi(e) > 0) c->max_parts_per_queue = atoi(e); } // tuning knobs of the launch plan
 	{ const char *e = getenv("SRBA_HIP_SCHED"); if (e) c->sched = atoi(e); } // tuning knob: launch plan (see plan_launches)
+	{ hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) c->n_cu = pr.multiProcessorCount; }
+	{ const char *e = getenv("SRBA_HIP_WAVES_PER_CU"); if (e && atoi(e) > 0) c->waves_per_cu = atoi(e); e = getenv("SRBA_HIP_LDS_PER_CU_KB"); if (e && atoi(e) > 0) c->lds_per_cu = atoi(e) * 1024; } // tuning knobs: resident wavefronts / LDS per CU assumed by the persistent plan
 	{ const char *e = getenv("SRBA_HIP_QUEUES"); if (e && atoi(e) >= 1 && atoi(e) < SRBA_NCLS) c->n_queues = atoi(e); } // tuning knob: concurrent launch streams
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || false) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
 	for (int k = 1; k < SRBA_NCLS && ok; k++) ok = hipStreamCreateWithFlags(&c->cls_stream[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->cls_done[k], hipEventDisableTiming) == hipSuccess;
-	if (!ok) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
+	if (!ok || hipMalloc((void **)&c->d_next, sizeof(int) * kMaxJobs) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	return c;
 }
 
@@ -684,7 +708,7 @@ int srba_hip_set_params(srba_hip_ctx *c, const srba_hip_params *params) {
 int srba_hip_destroy(srba_hip_ctx *c) {
 	if (!c) return 0;
 	hipSetDevice(c->device);
-	if (c->d_in) hipFree(c->d_in); if (c->d_wk) hipFree(c->d_wk);
+	if (c->d_in) hipFree(c->d_in); if (c->d_wk) hipFree(c->d_wk); if (c->d_next) hipFree(c->d_next);
 	for (int i = 0; i < srba_hip_ctx::kRing; i++) { if (c->ring0[i]) hipEventDestroy(c->ring0[i]); if (c->ring1[i]) hipEventDestroy(c->ring1[i]); }
 	if (c->ev_fork) hipEventDestroy(c->ev_fork);
 	for (int k = 1; k < SRBA_NCLS; k++) { if (c->cls_done[k]) hipEventDestroy(c->cls_done[k]); if (c->cls_stream[k]) hipStreamDestroy(c->cls_stream[k]); }
@@ -936,6 +960,7 @@ int srba_hip_lm_run_async(srba_hip_ctx *c) {
 	  if (!c->ring0[slot]) { HIPCHK(c, hipEventCreate(&c->ring0[slot])); HIPCHK(c, hipEventCreate(&c->ring1[slot])); }
 	  c->ev0 = c->ring0[slot]; c->ev1 = c->ring1[slot]; c->n_launches++; }
 	HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+	HIPCHK(c, hipMemsetAsync(c->d_next, 0, sizeof(int) * kMaxJobs, c->stream)); // work counters of the persistent launches
 	// fork/join: the launch plan (made at upload) spreads the size classes over a few streams; see plan_launches()
 	const int nq = c->plan.size() == 1 ? 1 : c->n_streams_used; // a single launch (the per-key-frame use) stays on the context stream: no fork / join
 	if (nq > 1) HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
@@ -943,7 +968,7 @@ int srba_hip_lm_run_async(srba_hip_ctx *c) {
 	for (size_t j = 0; j < c->plan.size(); j++) {
 		const LaunchJob &J = c->plan[j]; const int k = J.cls;
 		hipStream_t launch_stream = (J.queue && nq > 1) ? c->cls_stream[J.queue] : c->stream;
-		SRBA_DISPATCH_LDS(c, k_lm_run, k < SRBA_NCLS - 1, J.count, c->cls_lds[k] + c->lds_pad, J.first); HIPCHK(c, hipGetLastError());
+		SRBA_DISPATCH_LDS(c, k_lm_run, k < SRBA_NCLS - 1, J.grid, c->cls_lds[k] + c->lds_pad, J.first, J.count, c->d_next + j); HIPCHK(c, hipGetLastError());
 	}
 	for (int q = 1; q < nq; q++) { HIPCHK(c, hipEventRecord(c->cls_done[q], c->cls_stream[q])); HIPCHK(c, hipStreamWaitEvent(c->stream, c->cls_done[q], 0)); }
 	HIPCHK(c, hipEventRecord(c->ev1, c->stream));

@@ -28,7 +28,7 @@ def test_bench_two_ranks_one_json_line(tmp_path):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
-    assert d["config"]["capsules_per_gpu"] == 1498 and "replicas x2" in d["config"]["parallelism"]
+    assert d["config"]["capsules_per_gpu"] == 1499 and "replicas x2" in d["config"]["parallelism"]
     per_rank = d["config"]["lm_trials_per_step_per_gpu"]
     total_per_step = d["value"] * d["ms_per_step"] * 1e-3
     assert 1.6 * per_rank < total_per_step < 2.4 * per_rank      # two different maps of the same size

@@ -90,11 +90,12 @@ def test_stepwise_kernels_match_oracle_se2(se2_batch):
         assert np.allclose(res[sl("res", c.n_obs * O)], ref["resid"], rtol=1e-9, atol=1e-12), i
         assert np.allclose(Jp[sl("Jp", c.n_bp * O * P)], ref["Jp"], rtol=1e-9, atol=1e-12), i
         assert np.allclose(poses[sl("poses", 2 * c.n_pairs * PD)], ref["poses"], rtol=1e-9, atol=1e-12), i
-        assert np.allclose(grad[sl("grad", n)], ref["grad"], rtol=1e-7, atol=1e-9 * np.abs(ref["grad"]).max()), i
+        noise_only = ref["scalars"][0] < 1e-24   # e.g. the 2-key-frame window of KF#1: the residual is rounding noise, so are g and delta; nothing to compare relatively
+        assert noise_only or np.allclose(grad[sl("grad", n)], ref["grad"], rtol=1e-7, atol=1e-9 * np.abs(ref["grad"]).max()), i
         # HAp (no Schur here: unchanged by the solve) and the LM step for lambda0
         ref2 = _oracle.stage(b, i, do_solve=True, lam=ref["scalars"][1])
         assert np.allclose(HAp[sl("HAp", c.n_hap * P * P)], ref2["HAp"], rtol=1e-9, atol=1e-9 * np.abs(ref2["HAp"]).max()), i
-        assert np.allclose(delta[sl("grad", n)], ref2["delta"], rtol=1e-6, atol=1e-9 * max(1e-30, np.abs(ref2["delta"]).max())), i
+        assert noise_only or np.allclose(delta[sl("grad", n)], ref2["delta"], rtol=1e-6, atol=1e-9 * max(1e-30, np.abs(ref2["delta"]).max())), i
         o["res"] += c.n_obs * O; o["Jp"] += c.n_bp * O * P; o["HAp"] += c.n_hap * P * P; o["grad"] += n; o["poses"] += 2 * c.n_pairs * PD
     ctx.close()
 
@@ -192,7 +193,7 @@ def test_abi_misuse_is_reported_not_fatal(se2_batch):
     assert lib.srba_hip_upload_problems(ctx.ctx, se2_batch.ptr, 0) != 0
     bad = se2_batch.clone(0, 1); bad.ptr[0].n_unk_edges = bad.ptr[0].n_edges + 1
     assert lib.srba_hip_upload_problems(ctx.ctx, bad.ptr, 1) != 0 and b"malformed" in lib.srba_hip_last_error(ctx.ctx)
-    bad = se2_batch.clone(0, 1); bad.ptr[0].n_obs = 1      # block tables now point past the observation table
+    bad = se2_batch.clone(40, 1); assert bad.ptr[0].n_obs > 1; bad.ptr[0].n_obs = 1      # block tables now point past the observation table
     assert lib.srba_hip_upload_problems(ctx.ctx, bad.ptr, 1) != 0 and b"malformed" in lib.srba_hip_last_error(ctx.ctx)
     ctx.upload(se2_batch.sub(0, 4)); r = ctx.lm_run()   # the context stays usable
     assert np.all(r["status"] == 0)

@@ -1,0 +1,38 @@
+#!/bin/bash
+# SQ instruction-mix / stall counters of the fused LM kernel on the BENCHMARK batch (separate --pmc passes, kernel trace only, as the guide prescribes).
+# Output: gpurun_out/sq_summary.json (per-launch sums over the k_lm_run dispatches) -> copy to profiles/rNN_sq_summary.json
+R=$PWD; mkdir -p gpurun_out/pmcb; rm -rf gpurun_out/pmcb/*
+export GPU_MAX_HW_QUEUES=16
+python bench.py --steps 2 --warmup 1 --cpu-seconds 0 > gpurun_out/pmcb_bench.json 2> gpurun_out/pmcb_bench.err   # fills the capsule cache
+cd /tmp; export TMPDIR=/tmp
+N=1
+run() { timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmcb -o p$N -- python $R/bench.py --steps 1 --warmup 0 --cpu-seconds 0 > /dev/null 2> $R/gpurun_out/pmcb/p$N.err; N=$((N+1)); }
+run SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU
+run SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA
+run SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_BRANCH
+run SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM GRBM_GUI_ACTIVE SQ_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_ADDR_CONFLICT
+cd $R
+python - <<'PY'
+import csv, glob, collections, json
+out = {}
+for f in sorted(glob.glob('gpurun_out/pmcb/*counter_collection.csv')):
+    rows = [r for r in csv.DictReader(open(f)) if 'k_lm_run' in r['Kernel_Name']]
+    if not rows: continue
+    disp = sorted(set(int(r['Dispatch_Id']) for r in rows))
+    # the bench makes 2 fused launches with --steps 1 --warmup 0 (functional run + timed step): average per launch
+    n_launch = 2
+    acc = collections.defaultdict(float)
+    for r in rows: acc[r['Counter_Name']] += float(r['Counter_Value'])
+    for k, v in acc.items(): out[k] = v / n_launch
+    out.setdefault('_dispatches_per_launch', len(disp) / n_launch)
+d = json.loads([l for l in open('gpurun_out/pmcb_bench.json') if l.startswith('{')][-1])
+out['_lm_trials_per_launch'] = d['config']['lm_trials_per_step_per_gpu']; out['_kernel_ms'] = d['roofline']['kernel_ms']
+tot = sum(out.get(k, 0) for k in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM_RD', 'SQ_INSTS_VMEM_WR', 'SQ_INSTS_SMEM', 'SQ_INSTS_BRANCH'))
+out['_derived'] = {'wave_instructions_per_launch': tot, 'wave_instructions_per_trial': tot / max(1, out['_lm_trials_per_launch']),
+                   'wait_any_over_wave_cycles': out.get('SQ_WAIT_ANY', 0) / max(1, out.get('SQ_WAVE_CYCLES', 1)),
+                   'active_inst_any_over_wave_cycles': out.get('SQ_ACTIVE_INST_ANY', 0) / max(1, out.get('SQ_WAVE_CYCLES', 1)),
+                   'mean_active_lanes_per_valu_inst': out.get('SQ_THREAD_CYCLES_VALU', 0) / max(1, 4 * out.get('SQ_ACTIVE_INST_VALU', 1)) if out.get('SQ_THREAD_CYCLES_VALU') else None}
+json.dump(out, open('gpurun_out/sq_summary.json', 'w'), indent=1, sort_keys=True)
+print(json.dumps(out, indent=1, sort_keys=True))
+PY
+find gpurun_out/pmcb -name "*.csv" -size +3M -delete
