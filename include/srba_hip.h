@@ -265,6 +265,11 @@ int  srba_hip_download_results(srba_hip_ctx *ctx, srba_lm_result *results, int n
  *       9 ST poses [2*n_pairs*PD] */
 int64_t srba_hip_debug_size(srba_hip_ctx *ctx, int what);
 int  srba_hip_debug_read(srba_hip_ctx *ctx, int what, double *out, int64_t n_doubles);
+/* Write twin of srba_hip_debug_read for what = 1 (dh_dAp blocks), 2 (dh_df blocks), 6 (minus_grad), and K6 alone on the blocks in device memory
+ * (every row valid): together with srba_hip_solve they replay the reference's SchurTests (tests/schur_unittest.cpp:71-279 -- Hessians and Schur
+ * complement from GIVEN Jacobian blocks) on the device. After srba_hip_solve, what = 3 reads the Schur-reduced HAp and what = 6 the reduced gradient. */
+int  srba_hip_debug_write(srba_hip_ctx *ctx, int what, const double *in, int64_t n_doubles);
+int  srba_hip_hessian_from_jacobians(srba_hip_ctx *ctx);
 
 /* Totals over the uploaded batch: used by bench.py for the algorithmic-bytes roofline. */
 typedef struct srba_batch_stats {

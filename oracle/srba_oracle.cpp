@@ -889,6 +889,21 @@ void stage_one(const srba_hip_params &p, srba_problem_capsule &c, int do_solve, 
 	if (scalars) { scalars[0] = chi2; scalars[1] = 1e-3 * mx; scalars[2] = not_pd; scalars[3] = ninv; }
 }
 
+// The reference's SchurTests body (tests/schur_unittest.cpp:71-279) on GIVEN Jacobian blocks: numeric Hessians over the capsule's symbolic plan
+// (sparse_hessian_update_numeric), then SchurComplement::numeric_build_reduced_system(lambda) with the given minus-gradient.
+template <int FAM>
+void schur_from_jacobians(const srba_hip_params &p, srba_problem_capsule &c, const double *Jp, const double *Jf, const double *grad_in, double lambda, double *HAp_out, double *Hf_out, double *HApf_out, double *grad_out) {
+	Problem<FAM> pr(p, c);
+	std::fill(pr.valid.begin(), pr.valid.end(), 1);
+	std::copy(Jp, Jp + pr.Jp.size(), pr.Jp.begin()); std::copy(Jf, Jf + pr.Jf.size(), pr.Jf.begin());
+	pr.hessian_update_numeric();
+	if (Hf_out) std::copy(pr.Hf.begin(), pr.Hf.end(), Hf_out);
+	if (HApf_out) std::copy(pr.HApf.begin(), pr.HApf.end(), HApf_out);
+	std::copy(grad_in, grad_in + pr.grad.size(), pr.grad.begin());
+	if (pr.schur_active()) { pr.schur_ctor(); pr.schur_build_reduced(lambda); }
+	std::copy(pr.HAp.begin(), pr.HAp.end(), HAp_out); std::copy(pr.grad.begin(), pr.grad.end(), grad_out);
+}
+
 /* Whole-map squared error (impl/eval_overall_error.h:15-137) on the path lists prepared by the front-end: poses composed from the root of
  * every pair towards the leaf (impl/spantree_create_complete.h:96-124), then sum ||z - h||^2 without robust kernel (:116-129). */
 template <int FAM> static double overall_error(const srba_hip_params &p, const srba_overall_problem &q) {
@@ -937,6 +952,16 @@ int srba_oracle_eval_overall(const srba_hip_params *p, const srba_overall_proble
 		default: return -1;
 	}
 	return 0;
+}
+
+int srba_oracle_schur_from_jacobians(const srba_hip_params *p, srba_problem_capsule *c, const double *Jp, const double *Jf, const double *grad_in, double lambda,
+                                     double *HAp_out, double *Hf_out, double *HApf_out, double *grad_out) {
+	switch (p->family) {
+#define CASE(F) case F: schur_from_jacobians<F>(*p, *c, Jp, Jf, grad_in, lambda, HAp_out, Hf_out, HApf_out, grad_out); return 0;
+		CASE(SRBA_SE2_RELPOSE2D) CASE(SRBA_SE2_RB2D) CASE(SRBA_SE2_CART2D) CASE(SRBA_SE3_STEREO) CASE(SRBA_SE3_MONO) CASE(SRBA_SE3_CART3D) CASE(SRBA_SE3_RB3D)
+#undef CASE
+	}
+	return -1;
 }
 
 int srba_oracle_stage(const srba_hip_params *p, srba_problem_capsule *c, int do_solve, double lambda,

@@ -108,6 +108,8 @@ def hip_lib():
         lib.srba_hip_download_results.argtypes = [C.c_void_p, C.POINTER(LmResult), c_i32]
         lib.srba_hip_debug_size.argtypes = [C.c_void_p, c_i32]; lib.srba_hip_debug_size.restype = C.c_int64
         lib.srba_hip_debug_read.argtypes = [C.c_void_p, c_i32, PF64, C.c_int64]
+        lib.srba_hip_debug_write.argtypes = [C.c_void_p, c_i32, PF64, C.c_int64]
+        lib.srba_hip_hessian_from_jacobians.argtypes = [C.c_void_p]
         lib.srba_hip_batch_stats.argtypes = [C.c_void_p, C.POINTER(BatchStats)]
         lib.srba_hip_last_kernel_ms.argtypes = [C.c_void_p]; lib.srba_hip_last_kernel_ms.restype = c_f64
         lib.srba_hip_kernel_ms_history.argtypes = [C.c_void_p, PF64, c_i32]
@@ -152,5 +154,6 @@ def engine_lib():
         lib.srba_capsule_file_params.argtypes = [C.c_void_p, C.POINTER(HipParams)]
         lib.srba_capsule_file_free.argtypes = [C.c_void_p]; lib.srba_capsule_file_free.restype = None
         lib.srba_capsule_clone.argtypes = [PCAP, C.c_int64, c_i32]; lib.srba_capsule_clone.restype = C.c_void_p
+        lib.srba_capsule_from_blocks.argtypes = [c_i32, c_i32, c_i32, c_i32, PI32, PI32, c_i32]; lib.srba_capsule_from_blocks.restype = C.c_void_p
         lib._proto = True
     return lib

@@ -281,6 +281,27 @@ int64_t srba_capsule_file_count(void *h) { return (int64_t)static_cast<CapsuleFi
 srba_problem_capsule *srba_capsule_file_capsules(void *h) { CapsuleFile *cf = static_cast<CapsuleFile *>(h); return cf->views.empty() ? NULL : &cf->views[0]; }
 int srba_capsule_file_params(void *h, srba_hip_params *out) { *out = static_cast<CapsuleFile *>(h)->params; return 0; }
 void srba_capsule_file_free(void *h) { delete static_cast<CapsuleFile *>(h); }
+/* A capsule whose Jacobian structure is given directly (no graph): observation `r` has an optional dh_dAp block in column bp_col and a dh_df block in column
+ * bf_col (-1 = none); every pose is the identity. The Hessian / Schur plan comes from the product's CapsuleData::build_plan. Used to replay the reference's
+ * SchurTests, whose Jacobians are filled by hand (tests/schur_unittest.cpp:96-139). Rows must be listed in ascending order per column: callers pass rows 0..n-1. */
+void *srba_capsule_from_blocks(int family, int nK, int nF, int n_obs, const int32_t *row_bp_col, const int32_t *row_bf_col, int with_schur) {
+	int P, L, O, PD; if (srba_family_dims(family, &P, &L, &O, &PD) != 0 || nK < 0 || nF < 0 || n_obs <= 0) return NULL;
+	CapsuleFile *cf = new CapsuleFile(); std::memset(&cf->params, 0, sizeof(cf->params)); cf->params.family = family;
+	cf->data.push_back(CapsuleData()); CapsuleData &d = cf->data.back();
+	d.P = P; d.L = L; d.O = O; d.PD = PD; d.n_unk_edges = nK; d.n_unk_lms = nF; d.n_valid = n_obs;
+	d.edge_pose.assign((size_t)nK * PD, 0.0); if (PD == 12) for (int e = 0; e < nK; e++) for (int k = 0; k < 3; k++) d.edge_pose[(size_t)e * 12 + 3 + 4 * k] = 1.0;
+	d.ulm_pos.assign((size_t)nF * L, 0.0); d.obs_z.assign((size_t)n_obs * O, 0.0); d.pair_path_off.assign(1, 0);
+	std::vector<uint64_t> bp_row, bf_row;
+	for (int r = 0; r < n_obs; r++) { d.obs_pose.push_back(-1); d.obs_lm.push_back(row_bf_col[r] >= 0 ? row_bf_col[r] : 0); d.obs_valid.push_back(r); }
+	d.colp_off.assign(1, 0);
+	for (int c = 0; c < nK; c++) { for (int r = 0; r < n_obs; r++) if (row_bp_col[r] == c) { d.bp_col.push_back(c); d.bp_res.push_back(r); d.bp_A.push_back(-1); d.bp_D.push_back(-1); d.bp_lm.push_back(d.obs_lm[r]); d.bp_normal.push_back(1); bp_row.push_back(r); } d.colp_off.push_back((int32_t)d.bp_col.size()); }
+	d.colf_off.assign(1, 0);
+	for (int c = 0; c < nF; c++) { for (int r = 0; r < n_obs; r++) if (row_bf_col[r] == c) { d.bf_col.push_back(c); d.bf_res.push_back(r); d.bf_pose.push_back(-1); bf_row.push_back(r); } d.colf_off.push_back((int32_t)d.bf_col.size()); }
+	d.build_plan(bp_row, bf_row, with_schur != 0);
+	cf->views.push_back(d.view());
+	return cf;
+}
+
 /* Deep copy of a capsule array (so that a pristine batch can be re-optimised by several back-ends). */
 void *srba_capsule_clone(const srba_problem_capsule *caps, int64_t n, int family) {
 	int P, L, O, PD; if (srba_family_dims(family, &P, &L, &O, &PD) != 0) return NULL;

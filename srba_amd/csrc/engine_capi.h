@@ -74,6 +74,8 @@ srba_problem_capsule *srba_capsule_file_capsules(void *h);
 int   srba_capsule_file_params(void *h, srba_hip_params *out);
 void  srba_capsule_file_free(void *h);
 void *srba_capsule_clone(const srba_problem_capsule *caps, int64_t n, int family);
+/* one capsule from per-observation Jacobian columns (identity poses; Hessian / Schur plan by CapsuleData::build_plan) -- replays tests/schur_unittest.cpp */
+void *srba_capsule_from_blocks(int family, int nK, int nF, int n_obs, const int32_t *row_bp_col, const int32_t *row_bf_col, int with_schur);
 
 #ifdef __cplusplus
 }

@@ -469,8 +469,12 @@ struct Worker {
 
 	// ---- K1
 	__device__ void phase_spantree(bool only_needed) { fresh();
+#ifdef SRBA_K1SMALL
+		constexpr int U = 2, V = 1;
+#else
 		constexpr int U = T::SE3 ? 2 : 4; // path edges fetched together (their loads do not depend on the running composition)
 		constexpr int V = T::SE3 ? 1 : 2; // pairs per lane and pass (all their loads are issued before the first store)
+#endif
 		if (only_needed && d.need_flat) { // in-loop refresh: one flat record per pair -> two dependent memory levels (record, edges) instead of four
 			for (int q0 = tid; q0 < d.n_need; q0 += V * SRBA_WG) {
 				int p[V], pe[V][4]; pose_t acc[V];
@@ -760,7 +764,11 @@ struct Worker {
 #pragma unroll
 		for (int k = 0; k < M1 * M2; k++) H[k] = 0;
 		int ninv = 0;
-		constexpr bool PAIR = (O * (M1 + M2) <= 24); // two terms in flight when their Jacobian blocks fit the register budget
+		#ifdef SRBA_NOPAIR
+		constexpr bool PAIR = false;
+#else
+		constexpr bool PAIR = (O * (M1 + M2) <= 24);
+#endif // two terms in flight when their Jacobian blocks fit the register budget
 		int t = tb;
 		if constexpr (PAIR) {
 			for (; t + 1 < te; t += 2) { // the loads of both terms are independent of the accumulator: issue them together (same summation order)
@@ -819,7 +827,11 @@ struct Worker {
 			for (int k = 0; k < M; k++) acc[k] = 0;
 			if (live) {
 				const int bb = col_off[i], be = col_off[i + 1];
+#ifdef SRBA_GRADU2
+				constexpr int U = 2;
+#else
 				constexpr int U = (O * M <= 9) ? 4 : 2; // blocks in flight per lane (their loads do not depend on the running sum)
+#endif
 				for (int b0 = bb + sub; b0 < be; b0 += U * S) {
 					double A[U][O * M], lr[U][O];
 #pragma unroll

@@ -374,6 +374,14 @@ template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_linearize(const 
 	const double l0 = S.lambda_guess(srba_lds);
 	if (threadIdx.x == 0) { B.lambda_io[blockIdx.x] = l0; B.results[blockIdx.x].num_invalid_jacobs = ninv; }
 }
+// K6 alone on whatever Jacobian blocks are in device memory (every row taken as valid): the algebra of the reference's SchurTests starts from given blocks
+template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_hessian_only(const Batch B, const DevParams prm) {
+	Solver<FAM> S(B, B.desc[blockIdx.x], prm); const ProbDesc &d = B.desc[blockIdx.x];
+	for (int b = threadIdx.x; b < d.n_bp; b += SRBA_WG) B.bp_ok[d.o_bp + b] = 1;
+	for (int b = threadIdx.x; b < d.n_bf; b += SRBA_WG) B.bf_ok[d.o_bf + b] = 1;
+	__syncthreads();
+	S.phase_hessian();
+}
 template <int FAM, bool DLDS> __global__ void __launch_bounds__(SRBA_WG) k_solve(const Batch B, const DevParams prm, int first) {
 	const int pidx = B.order[first + blockIdx.x]; const ProbDesc &d = B.desc[pidx]; Solver<FAM> S(B, d, prm);
 	const SparseSys A = S.template make_sys<DLDS>(srba_lds);
@@ -1047,6 +1055,12 @@ int srba_hip_solve(srba_hip_ctx *c, const double *lambda, int32_t *not_pd_out) {
 	for (int k = 0; k < SRBA_NCLS; k++) if (c->cls_count[k]) { hipStream_t launch_stream = c->stream; SRBA_DISPATCH_LDS(c, k_solve, k < SRBA_NCLS - 1, c->cls_count[k], c->cls_lds[k], c->cls_first[k]); HIPCHK(c, hipGetLastError()); }
 	if (not_pd_out) { HIPCHK(c, hipMemcpyAsync(not_pd_out, c->B.notpd, 4 * (size_t)c->n_prob, hipMemcpyDeviceToHost, c->stream)); }
 	HIPCHK(c, hipStreamSynchronize(c->stream)); return 0;
+}
+int srba_hip_hessian_from_jacobians(srba_hip_ctx *c) { if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device)); SRBA_DISPATCH(c, k_hessian_only, 0); HIPCHK(c, hipGetLastError()); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+int srba_hip_debug_write(srba_hip_ctx *c, int what, const double *in, int64_t n_doubles) {
+	if (!c || !in || !(what == 1 || what == 2 || what == 6) || n_doubles != c->len_dbg[what]) { if (c) c->fail("debug_write: only the Jacobian blocks (1, 2) and the minus-gradient (6) can be written, with their exact sizes"); return -1; }
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipMemcpyAsync(c->d_wk + c->off_dbg[what], in, 8 * (size_t)n_doubles, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0;
 }
 int srba_hip_apply_update(srba_hip_ctx *c) { if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device)); SRBA_DISPATCH(c, k_apply, 0); HIPCHK(c, hipGetLastError()); return 0; }
 int srba_hip_rollback(srba_hip_ctx *c) { if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device)); SRBA_DISPATCH(c, k_rollback, 0); HIPCHK(c, hipGetLastError()); return 0; }

@@ -44,6 +44,7 @@ def _proto(l):
     l.srba_oracle_lm_run.argtypes = [C.POINTER(capi.HipParams), capi.PCAP, capi.c_i32, C.POINTER(capi.LmResult), capi.c_i32]
     l.srba_oracle_run_one.argtypes = [C.POINTER(capi.HipParams), capi.PCAP, C.POINTER(capi.LmResult)]
     l.srba_oracle_take_symbolic_seconds.restype = capi.c_f64
+    l.srba_oracle_schur_from_jacobians.argtypes = [C.POINTER(capi.HipParams), capi.PCAP, capi.PF64, capi.PF64, capi.PF64, capi.c_f64] + [capi.PF64] * 4
     l.srba_oracle_stage.argtypes = [C.POINTER(capi.HipParams), capi.PCAP, capi.c_i32, capi.c_f64] + [capi.PF64] * 10
 
 
@@ -86,3 +87,17 @@ def stage(batch, i, do_solve=False, lam=0.0):
     if rc != 0:
         raise RuntimeError("oracle stage failed")
     return arr
+
+
+def schur_from_jacobians(batch, i, Jp, Jf, grad, lam):
+    """Hessians over the capsule's plan from GIVEN Jacobian blocks + SchurComplement::numeric_build_reduced_system(lam): reduced HAp blocks, Hf, HApf, reduced gradient."""
+    ora = lib(); c = batch[i]; P, L, O, PD = capi.DIMS[batch.family]
+    out = dict(HAp=np.zeros(c.n_hap * P * P), Hf=np.zeros(c.n_hf * L * L), HApf=np.zeros(c.n_hapf * P * L), grad=np.zeros(P * c.n_unk_edges + L * c.n_unk_lms))
+    p = lambda a: np.ascontiguousarray(a, np.float64).ctypes.data_as(capi.PF64)
+    Jp = np.ascontiguousarray(Jp, np.float64); Jf = np.ascontiguousarray(Jf, np.float64); grad = np.ascontiguousarray(grad, np.float64)
+    sub = C.cast(C.addressof(batch.ptr.contents) + i * C.sizeof(capi.Capsule), capi.PCAP)
+    rc = ora.srba_oracle_schur_from_jacobians(C.byref(batch.params), sub, Jp.ctypes.data_as(capi.PF64), Jf.ctypes.data_as(capi.PF64), grad.ctypes.data_as(capi.PF64), lam,
+                                              out["HAp"].ctypes.data_as(capi.PF64), out["Hf"].ctypes.data_as(capi.PF64), out["HApf"].ctypes.data_as(capi.PF64), out["grad"].ctypes.data_as(capi.PF64))
+    if rc != 0:
+        raise RuntimeError("oracle schur_from_jacobians failed")
+    return out
