@@ -536,7 +536,8 @@ public:
 	/** The parameter block of the numeric back-end: everything the reference's hot loops read from RbaEngine::parameters. */
 	void fill_hip_params(srba_hip_params &hp) const {
 		std::memset(&hp, 0, sizeof(hp));
-		hp.family = sensor_model_t::family; hp.solver = RBA_OPTIONS::solver_t::solver_id;
+		static_assert(family_pose_dims(device_family<kf2kf_pose_t, landmark_t, obs_t>::value) == (int)REL_POSE_DIMS, "this <key-frame pose, landmark, observation> combination has no device kernels");
+		hp.family = device_family<kf2kf_pose_t, landmark_t, obs_t>::value; hp.solver = RBA_OPTIONS::solver_t::solver_id;
 		hp.std_noise_observations = 1.0; for (int i = 0; i < 9; i++) hp.sensor_pose_se3[3 + i] = (i % 4 == 0) ? 1.0 : 0.0; hp.right_cam_pose[3] = 1.0;
 		RBA_OPTIONS::obs_noise_matrix_t::fill_params(hp, parameters.obs_noise);
 		RBA_OPTIONS::sensor_pose_on_robot_t::fill_params(hp, parameters.sensor_pose);

@@ -33,6 +33,10 @@ struct RelativePoses2D {
 	static const size_t LM_DIMS = 3; static const landmark_jacob_family_t jacob_family = jacob_relpose_landmark;
 	template <class POSE, class VECTOR> static void composePosePoint(VECTOR &, const POSE &) {}
 };
+struct RelativePoses3D { // SE(3) relative poses as "landmarks" (graph-SLAM in 3D): x y z yaw pitch roll
+	static const size_t LM_DIMS = 6; static const landmark_jacob_family_t jacob_family = jacob_relpose_landmark;
+	template <class POSE, class VECTOR> static void composePosePoint(VECTOR &, const POSE &) {}
+};
 } // namespace landmarks
 
 namespace observations {
@@ -74,6 +78,12 @@ struct RelativePoses_2D {
 	struct TObservationParams {};
 };
 
+struct RelativePoses_3D {
+	static const size_t OBS_DIMS = 6;
+	struct obs_data_t { double x, y, z, yaw, pitch, roll; obs_data_t() : x(0), y(0), z(0), yaw(0), pitch(0), roll(0) {} template <class A> void getAsArray(A &o) const { o[0] = x; o[1] = y; o[2] = z; o[3] = yaw; o[4] = pitch; o[5] = roll; } };
+	struct TObservationParams {};
+};
+
 namespace detail {
 template <class POSE> bool pose_from_matches(const mrpt::utils::TMatchingPairList &matches, POSE &out) {
 	if (POSE::rotation_dimensions == 2) { mrpt::math::TPose2D f; if (!mrpt::tfest::se2_l2(matches, f)) return false; out = POSE(mrpt::poses::CPose2D(f)); }
@@ -90,6 +100,19 @@ template <> struct landmark_matcher<RelativePoses_2D> {
 			if ((kf0.x != 0 || kf0.y != 0 || kf0.yaw != 0) && (kf1.x != 0 || kf1.y != 0 || kf1.yaw != 0)) continue;
 			const mrpt::poses::CPose2D new_obs(kf0.x, kf0.y, kf0.yaw), old_obs(kf1.x, kf1.y, kf1.yaw);
 			pose_new_kf_wrt_old_kf = POSE(old_obs - new_obs);
+			return true;
+		}
+		return false;
+	}
+};
+/** observations_RelativePoses_3D.h:47-72: as in 2D, one of the two key-frames observes itself at exactly the null pose */
+template <> struct landmark_matcher<RelativePoses_3D> {
+	template <class POSE> static bool find_relative_pose(const std::vector<RelativePoses_3D::obs_data_t> &new_kf_obs, const std::vector<RelativePoses_3D::obs_data_t> &old_kf_obs, const RelativePoses_3D::TObservationParams &, POSE &pose_new_kf_wrt_old_kf) {
+		struct is_null { static bool of(const RelativePoses_3D::obs_data_t &o) { return o.x == 0 && o.y == 0 && o.z == 0 && o.yaw == 0 && o.pitch == 0 && o.roll == 0; } };
+		for (size_t i = 0; i < new_kf_obs.size(); i++) {
+			const RelativePoses_3D::obs_data_t &n = new_kf_obs[i], &o = old_kf_obs[i];
+			if (!is_null::of(n) && !is_null::of(o)) continue;
+			pose_new_kf_wrt_old_kf = POSE(mrpt::poses::CPose3D(o.x, o.y, o.z, o.yaw, o.pitch, o.roll) - mrpt::poses::CPose3D(n.x, n.y, n.z, n.yaw, n.pitch, n.roll));
 			return true;
 		}
 		return false;
@@ -199,10 +222,21 @@ template <> struct sensor_model<landmarks::Euclidean2D, observations::RangeBeari
 	template <class LM, class OBSD, class PRM> static void inverse_sensor_model(LM &out, const OBSD &obs, const PRM &) { out[0] = obs.range * std::cos(obs.yaw); out[1] = obs.range * std::sin(obs.yaw); } // sensors.h:726-736
 	template <class PRM> static void fill_params(srba_hip_params &, const PRM &) {}
 };
+template <> struct sensor_model<landmarks::RelativePoses3D, observations::RelativePoses_3D> {
+	static const int family = SRBA_SE3_RELPOSE3D;
+	template <class LM, class OBSD, class PRM> static void inverse_sensor_model(LM &out, const OBSD &obs, const PRM &) { out[0] = obs.x; out[1] = obs.y; out[2] = obs.z; out[3] = obs.yaw; out[4] = obs.pitch; out[5] = obs.roll; } // sensors.h:915-927
+	template <class PRM> static void fill_params(srba_hip_params &, const PRM &) {}
+};
 template <> struct sensor_model<landmarks::RelativePoses2D, observations::RelativePoses_2D> {
 	static const int family = SRBA_SE2_RELPOSE2D;
 	template <class LM, class OBSD, class PRM> static void inverse_sensor_model(LM &out, const OBSD &obs, const PRM &) { out[0] = obs.x; out[1] = obs.y; out[2] = obs.yaw; } // sensors.h:825-834
 	template <class PRM> static void fill_params(srba_hip_params &, const PRM &) {}
 };
+
+/** Device family of a <key-frame pose, landmark, observation> triple: the sensor model's family, except where the pose parameterisation changes the kernels */
+template <class KF, class LM, class OBS> struct device_family { static const int value = sensor_model<LM, OBS>::family; };
+template <> struct device_family<kf2kf_poses::SE2, landmarks::Euclidean3D, observations::StereoCamera> { static const int value = SRBA_SE2_STEREO; }; // SE(2) key-frames, 3D points (tutorial-srba-stereo-se2.cpp)
+/** REL_POSE_DIMS the kernels of a family are written for (checked against KF::REL_POSE_DIMS at compile time in RbaEngine) */
+constexpr int family_pose_dims(int family) { return (family == SRBA_SE2_RELPOSE2D || family == SRBA_SE2_RB2D || family == SRBA_SE2_CART2D || family == SRBA_SE2_STEREO) ? 3 : 6; }
 
 } // namespace srba

@@ -38,7 +38,9 @@ enum srba_family {
 	SRBA_SE3_MONO      = 4, /* <SE3,Euclidean3D,MonocularCamera>      P6 L3 O2  models/sensors.h:24 */
 	SRBA_SE3_CART3D    = 5, /* <SE3,Euclidean3D,Cartesian_3D>         P6 L3 O3  models/sensors.h:323 */
 	SRBA_SE3_RB3D      = 6, /* <SE3,Euclidean3D,RangeBearing_3D>      P6 L3 O3  models/sensors.h:517 (range, yaw, pitch) */
-	SRBA_NUM_FAMILIES  = 7
+	SRBA_SE3_RELPOSE3D = 7, /* <SE3,RelativePoses3D,RelativePoses_3D> P6 L6 O6  models/sensors.h:842 ; jacobians.h:748-873 (x y z yaw pitch roll) */
+	SRBA_SE2_STEREO    = 8, /* <SE2,Euclidean3D,StereoCamera>         P3 L3 O4  SE(2) key-frames with 3D points: jacobians.h:501-641 (POINT_DIMS = 3) */
+	SRBA_NUM_FAMILIES  = 9
 };
 
 /* Pose storage at the boundary ("PD" doubles per pose):

@@ -132,6 +132,37 @@ inline Pose3 pseudo_exp3(const double v[6]) {
 	for (int i = 0; i < 9; i++) r.R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * W[i] + b * W2[i];
 	return r;
 }
+// [EXT] CPose3D(x,y,z,yaw,pitch,roll): R = Rz(yaw) Ry(pitch) Rx(roll)
+inline Pose3 pose3_from_ypr(const double v[6]) {
+	Pose3 r; r.t[0] = v[0]; r.t[1] = v[1]; r.t[2] = v[2];
+	const double cy = std::cos(v[3]), sy = std::sin(v[3]), cp = std::cos(v[4]), sp = std::sin(v[4]), cr = std::cos(v[5]), sr = std::sin(v[5]);
+	const double R[9] = {cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr, sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr, -sp, cp * sr, cp * cr};
+	for (int k = 0; k < 9; k++) r.R[k] = R[k];
+	return r;
+}
+// [EXT] SE_traits<3>::pseudo_ln: (t, ln(R)); ln(R) = theta / (2 sin theta) * vee(R - R^t), theta = acos((tr R - 1)/2)  (include/mrpt_lite.h CPose3D::ln_rotation)
+inline void pseudo_ln3(const Pose3 &P, double out[6]) {
+	for (int i = 0; i < 3; i++) out[i] = P.t[i];
+	double c = 0.5 * (P.R[0] + P.R[4] + P.R[8] - 1.0); c = std::max(-1.0, std::min(1.0, c));
+	const double th = std::acos(c), f = (th < 1e-8) ? 0.5 : th / (2.0 * std::sin(th));
+	out[3] = f * (P.R[7] - P.R[5]); out[4] = f * (P.R[2] - P.R[6]); out[5] = f * (P.R[3] - P.R[1]);
+}
+// [EXT] CPose3D::ln_rot_jacob: d ln(R) / d vec(R), 3x9, vec(R) = stacked COLUMNS (Blanco, "A tutorial on SE(3) transformation parameterizations and on-manifold
+// optimization", section 10.3.2): the derivative of the formula above taking the nine entries as independent; small-angle branch at (tr R - 1)/2 > 0.99999.
+inline void ln_rot_jacob(const double R[9], double M[27]) {
+	const double d = 0.5 * (R[0] + R[4] + R[8] - 1.0); double a[3] = {0, 0, 0}, b = 0.5;
+	if (!(d > 0.99999)) {
+		const double th = std::acos(d), sq = std::sqrt(1.0 - d * d), k = (d * th - sq) / (4.0 * sq * sq * sq);
+		b = th / (2.0 * sq); a[0] = k * (R[7] - R[5]); a[1] = k * (R[2] - R[6]); a[2] = k * (R[3] - R[1]);
+	}
+	const double m[27] = {a[0], 0, 0, 0, a[0], b, 0, -b, a[0],   a[1], 0, -b, 0, a[1], 0, b, 0, a[1],   a[2], b, 0, -b, a[2], 0, 0, 0, a[2]};
+	for (int k = 0; k < 27; k++) M[k] = m[k];
+}
+// [EXT] CPose3D(CPose2D): rotation about z, z = 0
+inline Pose3 pose3_from_pose2(const Pose2 &p) {
+	Pose3 r; r.t[0] = p.x; r.t[1] = p.y; r.t[2] = 0; const double c = std::cos(p.phi), s = std::sin(p.phi);
+	const double R[9] = {c, -s, 0, s, c, 0, 0, 0, 1}; for (int k = 0; k < 9; k++) r.R[k] = R[k]; return r;
+}
 inline Pose2 pseudo_exp2(const double v[3]) { Pose2 r; r.x = v[0]; r.y = v[1]; r.phi = v[2]; return r; } // SE_traits<2>: identity map [EXT]
 
 // quaternion (r,x,y,z) -> rotation matrix [EXT CQuaternion::rotationMatrixNoResize]
@@ -300,6 +331,10 @@ template <> struct Fam<SRBA_SE3_STEREO>    { using pose_t = Pose3; static conste
 template <> struct Fam<SRBA_SE3_MONO>      { using pose_t = Pose3; static constexpr int P = 6, L = 3, O = 2; static constexpr bool relpose = false; };
 template <> struct Fam<SRBA_SE3_CART3D>    { using pose_t = Pose3; static constexpr int P = 6, L = 3, O = 3; static constexpr bool relpose = false; };
 template <> struct Fam<SRBA_SE3_RB3D>      { using pose_t = Pose3; static constexpr int P = 6, L = 3, O = 3; static constexpr bool relpose = false; };
+template <> struct Fam<SRBA_SE3_RELPOSE3D> { using pose_t = Pose3; static constexpr int P = 6, L = 6, O = 6; static constexpr bool relpose = true; };
+template <> struct Fam<SRBA_SE2_STEREO>    { using pose_t = Pose2; static constexpr int P = 3, L = 3, O = 4; static constexpr bool relpose = false; }; // SE(2) key-frames + 3D points
+// every family the oracle is instantiated for
+#define ORACLE_ALL_FAMILIES(X) X(SRBA_SE2_RELPOSE2D) X(SRBA_SE2_RB2D) X(SRBA_SE2_CART2D) X(SRBA_SE3_STEREO) X(SRBA_SE3_MONO) X(SRBA_SE3_CART3D) X(SRBA_SE3_RB3D) X(SRBA_SE3_RELPOSE3D) X(SRBA_SE2_STEREO)
 
 // ------------------------------------------------------------------------------------------------
 // The optimiser
@@ -328,6 +363,8 @@ struct Problem {
 	std::vector<double> YW;              // Hpi_lk * inv(Hf_lk) of the diagonal blocks' terms, reused for the gradient (schur.h:104-111)
 	std::vector<int> ywt_of_term;        // for a Schur term of a diagonal block: index into YW ; else -1
 	pose_t sensor_pose; double RS[9];    // sensor pose on robot
+	Pose3 sensor_pose3;                  // the same as an SE(3) pose: what <SE2, Euclidean3D, StereoCamera> composes with (srba_options_sensor_pose.h:101-113 on CPose2D key-frame poses)
+	static constexpr bool SE2_3D = (FAM == SRBA_SE2_STEREO);
 	double R2L_R[9], R2L_t[3];           // stereo: (-)rightCameraPose
 
 	bool use_schur, dense_chol;
@@ -345,9 +382,9 @@ struct Problem {
 		resid.assign((size_t)c.n_obs * O, 0.0); grad.assign(n, 0.0); delta.assign(n, 0.0);
 		use_schur = (prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL);
 		dense_chol = (prm.solver == SRBA_SOLVER_SCHUR_DENSE_CHOL);
-		if constexpr (SE3) {
-			if (prm.sensor_pose == SRBA_SENSOR_POSE_SE3) sensor_pose.load(prm.sensor_pose_se3);
-			for (int i = 0; i < 9; i++) RS[i] = sensor_pose.R[i];
+		if constexpr (SE3 || SE2_3D) {
+			if (prm.sensor_pose == SRBA_SENSOR_POSE_SE3) { sensor_pose3.load(prm.sensor_pose_se3); if constexpr (SE3) sensor_pose.load(prm.sensor_pose_se3); }
+			for (int i = 0; i < 9; i++) RS[i] = sensor_pose3.R[i];
 			double Rq[9]; quat_to_R(prm.right_cam_pose + 3, Rq); // R2L = (-)rightCameraPose  (sensors.h:193)
 			for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R2L_R[3 * i + j] = Rq[3 * j + i];
 			for (int i = 0; i < 3; i++) R2L_t[i] = -(Rq[0 + i] * prm.right_cam_pose[0] + Rq[3 + i] * prm.right_cam_pose[1] + Rq[6 + i] * prm.right_cam_pose[2]);
@@ -374,8 +411,16 @@ struct Problem {
 
 	// ---------------- sensor models (models/sensors.h) ----------------
 	// residual = z - h(pose (+) lm), pose = base wrt SENSOR
-	void observe_error(double *r, const double *z, const pose_t &base_wrt_sensor, const double *lm) const {
-		if constexpr (FAM == SRBA_SE2_RELPOSE2D) { // sensors.h:770-785
+	template <class SENSOR_POSE>
+	void observe_error(double *r, const double *z, const SENSOR_POSE &base_wrt_sensor, const double *lm) const {
+		if constexpr (FAM == SRBA_SE3_RELPOSE3D) { // sensors.h:873-879: h = P(z) (-) pose ; err = pseudo_ln(h)
+			const Pose3 h = inv_compose(pose3_from_ypr(z), base_wrt_sensor); pseudo_ln3(h, r);
+		} else if constexpr (FAM == SRBA_SE2_STEREO) { // the stereo model of sensors.h:175-211 on the SE(3) pose "base wrt sensor"
+			double l[3]; compose_point(base_wrt_sensor, lm, l);
+			r[0] = z[0] - (prm.cam_left[2] + prm.cam_left[0] * l[0] / l[2]); r[1] = z[1] - (prm.cam_left[3] + prm.cam_left[1] * l[1] / l[2]);
+			double rr[3]; for (int i = 0; i < 3; i++) rr[i] = R2L_t[i] + R2L_R[3 * i] * l[0] + R2L_R[3 * i + 1] * l[1] + R2L_R[3 * i + 2] * l[2];
+			r[2] = z[2] - (prm.cam_right[2] + prm.cam_right[0] * rr[0] / rr[2]); r[3] = z[3] - (prm.cam_right[3] + prm.cam_right[1] * rr[1] / rr[2]);
+		} else if constexpr (FAM == SRBA_SE2_RELPOSE2D) { // sensors.h:770-785
 			Pose2 Z; Z.x = z[0]; Z.y = z[1]; Z.phi = z[2];
 			const Pose2 h = inv_compose(Z, base_wrt_sensor); r[0] = h.x; r[1] = h.y; r[2] = h.phi;
 		} else if constexpr (FAM == SRBA_SE2_RB2D) { // sensors.h:661-679
@@ -401,7 +446,7 @@ struct Problem {
 	}
 	// dh_dx (O x L) at x = landmark wrt sensor; false => invalid
 	bool eval_dh_dx(double *H, const double *x) const {
-		if constexpr (FAM == SRBA_SE2_RELPOSE2D || FAM == SRBA_SE2_CART2D || FAM == SRBA_SE3_CART3D) { // identity (:804-814, :481-490, :380-389)
+		if constexpr (FAM == SRBA_SE2_RELPOSE2D || FAM == SRBA_SE2_CART2D || FAM == SRBA_SE3_CART3D || FAM == SRBA_SE3_RELPOSE3D) { // identity (:804-814, :481-490, :380-389, :905-913)
 			for (int i = 0; i < O * L; i++) H[i] = 0; for (int i = 0; i < O; i++) H[i * L + i] = 1; return true;
 		} else if constexpr (FAM == SRBA_SE2_RB2D) { // sensors.h:698-715
 			const double r = std::hypot(x[0], x[1]); if (r == 0) return false;
@@ -432,10 +477,10 @@ struct Problem {
 		return p;
 	}
 	void point_robot2sensor(double *x) const { // (:63-66,:117-120)
-		if constexpr (SE3) if (prm.sensor_pose == SRBA_SENSOR_POSE_SE3) { double l[3]; inv_compose_point(sensor_pose, x, l); x[0] = l[0]; x[1] = l[1]; x[2] = l[2]; }
+		if constexpr (SE3 || SE2_3D) if (prm.sensor_pose == SRBA_SENSOR_POSE_SE3) { double l[3]; inv_compose_point(sensor_pose3, x, l); x[0] = l[0]; x[1] = l[1]; x[2] = l[2]; }
 	}
 	void dh_dx_rotate(double *H) const { // dh_dx = dh_dx * R_S^t (:124-128)
-		if constexpr (SE3) if (prm.sensor_pose == SRBA_SENSOR_POSE_SE3) {
+		if constexpr (SE3 || SE2_3D) if (prm.sensor_pose == SRBA_SENSOR_POSE_SE3) {
 			double T[O * 3];
 			for (int i = 0; i < O; i++) for (int j = 0; j < 3; j++) T[i * 3 + j] = H[i * 3 + 0] * RS[3 * j + 0] + H[i * 3 + 1] * RS[3 * j + 1] + H[i * 3 + 2] * RS[3 * j + 2];
 			for (int i = 0; i < O * 3; i++) H[i] = T[i];
@@ -448,9 +493,11 @@ struct Problem {
 		double total = 0;
 		for (int i = 0; i < c.n_obs; i++) {
 			pose_t bp; if (c.obs_pose[i] >= 0) bp = pose[c.obs_pose[i]]; // else identity (aux_null_pose :36-39)
-			const pose_t bs = pose_robot2sensor(bp);
 			double *r = &res[(size_t)i * O];
-			observe_error(r, c.obs_z + (size_t)i * O, bs, lm_ptr(c.obs_lm[i]));
+			if constexpr (SE2_3D) { // pose_robot2sensor with a CPose2D key-frame pose gives an SE(3) pose (srba_options_sensor_pose.h:108-113)
+				Pose3 bs = pose3_from_pose2(bp); if (prm.sensor_pose == SRBA_SENSOR_POSE_SE3) bs = inv_compose(bs, sensor_pose3);
+				observe_error(r, c.obs_z + (size_t)i * O, bs, lm_ptr(c.obs_lm[i]));
+			} else { const pose_t bs = pose_robot2sensor(bp); observe_error(r, c.obs_z + (size_t)i * O, bs, lm_ptr(c.obs_lm[i])); }
 			double sum2 = 0; for (int k = 0; k < O; k++) sum2 += r[k] * r[k];
 			if (prm.use_robust_kernel) { // :67-72, huber RbaEngine.h:810-813
 				const double nrm = std::max(1e-11, std::sqrt(sum2));
@@ -478,7 +525,7 @@ struct Problem {
 		// xji_l = pose_i_wrt_l (+) xji_i (:269-270; not applicable to relative-pose landmarks, landmarks.h:112-116)
 		if constexpr (!F::relpose) {
 			if constexpr (SE3) { double g[3]; compose_point(i_wrt_l, xl, g); xl[0] = g[0]; xl[1] = g[1]; xl[2] = g[2]; }
-			else { double gx, gy; compose_point(i_wrt_l, xl[0], xl[1], gx, gy); xl[0] = gx; xl[1] = gy; }
+			else { double gx, gy; compose_point(i_wrt_l, xl[0], xl[1], gx, gy); xl[0] = gx; xl[1] = gy; } // a 2D pose leaves z untouched (landmarks.h Euclidean3D::composePosePoint)
 			point_robot2sensor(xl); // :318
 		}
 		double dh_dx[O * L];
@@ -514,6 +561,39 @@ struct Problem {
 					for (int k = 0; k < 3; k++) J[k * 3 + dd] = -(rr[1][k] - rr[0][k]) / 2e-6;
 				}
 			}
+		} else if constexpr (FAM == SRBA_SE3_RELPOSE3D) { // jacobians.h:748-873, verbatim: jacob = dLnRelPose_deps (6x12) * dAeD_de (12x6)
+			Pose3 Dd, ad; double ROTA[9];
+			if (!inverse_edge) { Dd = D; if (hasA) { ad = compose(A, Dd); for (int k = 0; k < 9; k++) ROTA[k] = A.R[k]; } else { ad = Dd; for (int k = 0; k < 9; k++) ROTA[k] = (k % 4 == 0) ? 1.0 : 0.0; } }
+			else {
+				const Pose3 Dp = compose(pe, D), pinv = inverse(pe); const Pose3 Ap = hasA ? compose(A, pinv) : pinv;
+				for (int k = 0; k < 9; k++) ROTA[k] = Ap.R[k]; Dd = Dp; ad = compose(Ap, Dp);
+			}
+			double dLn[6 * 12]; for (int k = 0; k < 72; k++) dLn[k] = 0;
+			for (int k = 0; k < 3; k++) dLn[k * 12 + 9 + k] = 1; // block<3,3>(0,9) = I
+			{ double M[27]; ln_rot_jacob(ad.R, M); for (int r = 0; r < 3; r++) for (int q = 0; q < 9; q++) dLn[(3 + r) * 12 + q] = M[r * 9 + q]; } // block<3,9>(3,0)
+			double dAeD[12 * 6]; for (int k = 0; k < 72; k++) dAeD[k] = 0;
+			{ double RD[9]; mm<3, 3, 3>(ROTA, Dd.R, RD); for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) dAeD[(9 + r) * 6 + q] = RD[3 * q + r]; } // block<3,3>(9,0) = (ROTA * R(D))^t (:842)
+			for (int i = 0; i < 4; i++) { // blocks (i,2) = -ROTA * [column i of the homogeneous matrix of D]_x (:848-856)
+				const double h0 = i < 3 ? Dd.R[i] : Dd.t[0], h1 = i < 3 ? Dd.R[3 + i] : Dd.t[1], h2 = i < 3 ? Dd.R[6 + i] : Dd.t[2];
+				const double aux[9] = {0, -h2, h1, h2, 0, -h0, -h1, h0, 0}; double G[9]; mm<3, 3, 3>(ROTA, aux, G);
+				for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) dAeD[(3 * i + r) * 6 + 3 + q] = -G[3 * r + q];
+			}
+			mm<6, 12, 6>(dLn, dAeD, J);
+			if (inverse_edge) for (int k = 0; k < 36; k++) J[k] = -J[k];
+		} else if constexpr (FAM == SRBA_SE2_STEREO) { // SE2 + 3D points, jacobians.h:501-641 with POINT_DIMS = 3
+			double Xd, Yd, PHIa; Pose2 AD;
+			if (!inverse_edge) { Xd = D.x; Yd = D.y; PHIa = hasA ? A.phi : 0.0; AD = i_wrt_l; }
+			else {
+				const Pose2 Dp = compose(pe, D); const Pose2 pinv = inverse(pe);
+				const Pose2 Ap = hasA ? compose(A, pinv) : pinv;
+				AD = compose(Ap, Dp); Xd = Dp.x; Yd = Dp.y; PHIa = Ap.phi;
+			}
+			const double cad = std::cos(AD.phi), sad = std::sin(AD.phi);
+			const double dPx[9] = {1, 0, -xji_i[0] * sad - xji_i[1] * cad, 0, 1, xji_i[0] * cad - xji_i[1] * sad, 0, 0, 1}; // (2,2) = 1 as in the reference (:546)
+			const double ca = std::cos(PHIa), sa = std::sin(PHIa);
+			const double dAD[9] = {ca, -sa, -sa * Xd - ca * Yd, sa, ca, ca * Xd - sa * Yd, 0, 0, 1};
+			double T[O * 3]; mm<O, 3, 3>(dh_dx, dPx, T); mm<O, 3, 3>(T, dAD, J);
+			if (inverse_edge) for (int k = 0; k < O * P; k++) J[k] = -J[k];
 		} else if constexpr (!SE3) { // SE2 + 2D points, jacobians.h:501-634
 			double Xd, Yd, PHIa; Pose2 AD;
 			if (!inverse_edge) { Xd = D.x; Yd = D.y; PHIa = hasA ? A.phi : 0.0; AD = i_wrt_l; }
@@ -569,6 +649,7 @@ struct Problem {
 			dh_dx_rotate(dh_dx); // :980
 			if (hasP) { // J = dh_dx * R(base<-obs) (:984-989)
 				if constexpr (SE3) mm<O, 3, 3>(dh_dx, bp.R, J);
+				else if constexpr (SE2_3D) { const double cc = std::cos(bp.phi), ss = std::sin(bp.phi); const double R[9] = {cc, -ss, 0, ss, cc, 0, 0, 0, 1}; mm<O, 3, 3>(dh_dx, R, J); } // [EXT] CPose2D::getRotationMatrix into a 3x3
 				else { const double cc = std::cos(bp.phi), ss = std::sin(bp.phi); const double R[4] = {cc, -ss, ss, cc}; mm<O, 2, 2>(dh_dx, R, J); }
 			} else for (int k = 0; k < O * L; k++) J[k] = dh_dx[k];
 		}
@@ -848,13 +929,9 @@ template <int FAM> void run_one(const srba_hip_params &p, srba_problem_capsule &
 
 void dispatch_run(const srba_hip_params &p, srba_problem_capsule &c, srba_lm_result &r) {
 	switch (p.family) {
-		case SRBA_SE2_RELPOSE2D: run_one<SRBA_SE2_RELPOSE2D>(p, c, r); break;
-		case SRBA_SE2_RB2D: run_one<SRBA_SE2_RB2D>(p, c, r); break;
-		case SRBA_SE2_CART2D: run_one<SRBA_SE2_CART2D>(p, c, r); break;
-		case SRBA_SE3_STEREO: run_one<SRBA_SE3_STEREO>(p, c, r); break;
-		case SRBA_SE3_MONO: run_one<SRBA_SE3_MONO>(p, c, r); break;
-		case SRBA_SE3_CART3D: run_one<SRBA_SE3_CART3D>(p, c, r); break;
-		case SRBA_SE3_RB3D: run_one<SRBA_SE3_RB3D>(p, c, r); break;
+#define X(F) case F: run_one<F>(p, c, r); break;
+		ORACLE_ALL_FAMILIES(X)
+#undef X
 		default: std::memset(&r, 0, sizeof(r)); r.status = -1;
 	}
 }
@@ -946,9 +1023,9 @@ int srba_oracle_run_one(const srba_hip_params *params, srba_problem_capsule *cap
 int srba_oracle_eval_overall(const srba_hip_params *p, const srba_overall_problem *q, double *out) {
 	if (!p || !q || !out) return -1;
 	switch (p->family) {
-		case SRBA_SE2_RELPOSE2D: *out = overall_error<SRBA_SE2_RELPOSE2D>(*p, *q); break; case SRBA_SE2_RB2D: *out = overall_error<SRBA_SE2_RB2D>(*p, *q); break;
-		case SRBA_SE2_CART2D: *out = overall_error<SRBA_SE2_CART2D>(*p, *q); break; case SRBA_SE3_STEREO: *out = overall_error<SRBA_SE3_STEREO>(*p, *q); break;
-		case SRBA_SE3_MONO: *out = overall_error<SRBA_SE3_MONO>(*p, *q); break; case SRBA_SE3_CART3D: *out = overall_error<SRBA_SE3_CART3D>(*p, *q); break; case SRBA_SE3_RB3D: *out = overall_error<SRBA_SE3_RB3D>(*p, *q); break;
+#define X(F) case F: *out = overall_error<F>(*p, *q); break;
+		ORACLE_ALL_FAMILIES(X)
+#undef X
 		default: return -1;
 	}
 	return 0;
@@ -958,7 +1035,7 @@ int srba_oracle_schur_from_jacobians(const srba_hip_params *p, srba_problem_caps
                                      double *HAp_out, double *Hf_out, double *HApf_out, double *grad_out) {
 	switch (p->family) {
 #define CASE(F) case F: schur_from_jacobians<F>(*p, *c, Jp, Jf, grad_in, lambda, HAp_out, Hf_out, HApf_out, grad_out); return 0;
-		CASE(SRBA_SE2_RELPOSE2D) CASE(SRBA_SE2_RB2D) CASE(SRBA_SE2_CART2D) CASE(SRBA_SE3_STEREO) CASE(SRBA_SE3_MONO) CASE(SRBA_SE3_CART3D) CASE(SRBA_SE3_RB3D)
+		ORACLE_ALL_FAMILIES(CASE)
 #undef CASE
 	}
 	return -1;
@@ -969,7 +1046,7 @@ int srba_oracle_stage(const srba_hip_params *p, srba_problem_capsule *c, int do_
                       double *poses, double *scalars) {
 	switch (p->family) {
 #define CASE(F) case F: stage_one<F>(*p, *c, do_solve, lambda, residuals, Jp, Jf, HAp, Hf, HApf, grad, delta, poses, scalars); return 0;
-		CASE(SRBA_SE2_RELPOSE2D) CASE(SRBA_SE2_RB2D) CASE(SRBA_SE2_CART2D) CASE(SRBA_SE3_STEREO) CASE(SRBA_SE3_MONO) CASE(SRBA_SE3_CART3D) CASE(SRBA_SE3_RB3D)
+		ORACLE_ALL_FAMILIES(CASE)
 #undef CASE
 	}
 	return -1;

@@ -6,11 +6,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 
 # enum srba_family
-SE2_RELPOSE2D, SE2_RB2D, SE2_CART2D, SE3_STEREO, SE3_MONO, SE3_CART3D, SE3_RB3D = range(7)
+SE2_RELPOSE2D, SE2_RB2D, SE2_CART2D, SE3_STEREO, SE3_MONO, SE3_CART3D, SE3_RB3D, SE3_RELPOSE3D, SE2_STEREO = range(9)
 SOLVER_SCHUR_DENSE, SOLVER_SCHUR_SPARSE, SOLVER_NO_SCHUR_SPARSE = range(3)
 NOISE_IDENTITY, NOISE_MATRIX = range(2)
 SENSOR_POSE_NONE, SENSOR_POSE_SE3 = range(2)
-DIMS = {0: (3, 3, 3, 3), 1: (3, 2, 2, 3), 2: (3, 2, 2, 3), 3: (6, 3, 4, 12), 4: (6, 3, 2, 12), 5: (6, 3, 3, 12), 6: (6, 3, 3, 12)}  # P, L, O, PD
+DIMS = {0: (3, 3, 3, 3), 1: (3, 2, 2, 3), 2: (3, 2, 2, 3), 3: (6, 3, 4, 12), 4: (6, 3, 2, 12), 5: (6, 3, 3, 12), 6: (6, 3, 3, 12), 7: (6, 6, 6, 12), 8: (3, 3, 4, 3)}  # P, L, O, PD
 TRACE_LEN = 48
 
 c_i32, c_u8, c_f64 = C.c_int32, C.c_uint8, C.c_double

@@ -21,6 +21,7 @@ template <> struct obs_io<observations::RangeBearing_2D> { static void set(obser
 template <> struct obs_io<observations::Cartesian_2D> { static void set(observations::Cartesian_2D::obs_data_t &o, const double *z) { o.pt.x = z[0]; o.pt.y = z[1]; } };
 template <> struct obs_io<observations::Cartesian_3D> { static void set(observations::Cartesian_3D::obs_data_t &o, const double *z) { o.pt.x = z[0]; o.pt.y = z[1]; o.pt.z = z[2]; } };
 template <> struct obs_io<observations::RangeBearing_3D> { static void set(observations::RangeBearing_3D::obs_data_t &o, const double *z) { o.range = z[0]; o.yaw = z[1]; o.pitch = z[2]; } };
+template <> struct obs_io<observations::RelativePoses_3D> { static void set(observations::RelativePoses_3D::obs_data_t &o, const double *z) { o.x = z[0]; o.y = z[1]; o.z = z[2]; o.yaw = z[3]; o.pitch = z[4]; o.roll = z[5]; } };
 template <> struct obs_io<observations::MonocularCamera> { static void set(observations::MonocularCamera::obs_data_t &o, const double *z) { o.px.x = (float)z[0]; o.px.y = (float)z[1]; } };
 template <> struct obs_io<observations::StereoCamera> { static void set(observations::StereoCamera::obs_data_t &o, const double *z) { o.left_px.x = (float)z[0]; o.left_px.y = (float)z[1]; o.right_px.x = (float)z[2]; o.right_px.y = (float)z[3]; } };
 
@@ -218,6 +219,16 @@ void *srba_engine_create(const srba_engine_config *c) {
 			case SRBA_SE3_MONO: e = make_point_engine<kf2kf_poses::SE3, landmarks::Euclidean3D, observations::MonocularCamera>(*c); break;
 			case SRBA_SE3_CART3D: e = make_point_engine<kf2kf_poses::SE3, landmarks::Euclidean3D, observations::Cartesian_3D>(*c); break;
 			case SRBA_SE3_RB3D: e = make_point_engine<kf2kf_poses::SE3, landmarks::Euclidean3D, observations::RangeBearing_3D>(*c); break;
+			case SRBA_SE3_RELPOSE3D: // SE(3) relative graph-SLAM (tutorial-srba-relative-graph-slam-se3.cpp): constant 6x6 information matrix, or identity noise
+				if (c->noise == SRBA_NOISE_CONSTANT_MATRIX && c->sensor_pose == SRBA_SENSOR_POSE_NONE)
+					e = make_solver<kf2kf_poses::SE3, landmarks::RelativePoses3D, observations::RelativePoses_3D, options::observation_noise_constant_matrix<observations::RelativePoses_3D>, SP_NONE>(*c);
+				else if (c->noise == SRBA_NOISE_IDENTITY && c->sensor_pose == SRBA_SENSOR_POSE_NONE)
+					e = make_solver<kf2kf_poses::SE3, landmarks::RelativePoses3D, observations::RelativePoses_3D, N_ID, SP_NONE>(*c);
+				break;
+			case SRBA_SE2_STEREO: // SE(2) key-frames + 3D landmarks + stereo camera (tutorial-srba-stereo-se2.cpp)
+				if (c->noise == SRBA_NOISE_IDENTITY) e = (c->sensor_pose == SRBA_SENSOR_POSE_SE3) ? make_solver<kf2kf_poses::SE2, landmarks::Euclidean3D, observations::StereoCamera, N_ID, SP_SE3>(*c)
+				                                                                                     : make_solver<kf2kf_poses::SE2, landmarks::Euclidean3D, observations::StereoCamera, N_ID, SP_NONE>(*c);
+				break;
 		}
 	} catch (std::exception &ex) { g_error = ex.what(); return NULL; }
 	if (!e) g_error = "srba_engine_create: unsupported family / policy combination";

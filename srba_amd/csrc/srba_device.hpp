@@ -69,7 +69,7 @@ struct Batch {
 
 struct DevParams {
 	int solver, noise, sensor_pose, max_iters, use_robust_kernel, cov_recovery;
-	double inv_sigma, lambda[16], kernel_param, max_err, max_rho, max_lambda, min_relin;
+	double inv_sigma, lambda[36], kernel_param, max_err, max_rho, max_lambda, min_relin;
 	double SPt[3], SPR[9];      // sensor pose on the robot
 	double camL[4], camR[4];    // fx fy cx cy
 	double R2Lt[3], R2LR[9];    // (-)rightCameraPose
@@ -88,6 +88,8 @@ template <> struct Tr<SRBA_SE3_STEREO>    { static constexpr int P = 6, L = 3, O
 template <> struct Tr<SRBA_SE3_MONO>      { static constexpr int P = 6, L = 3, O = 2, PD = 12; static constexpr bool SE3 = true, REL = false; };
 template <> struct Tr<SRBA_SE3_CART3D>    { static constexpr int P = 6, L = 3, O = 3, PD = 12; static constexpr bool SE3 = true, REL = false; };
 template <> struct Tr<SRBA_SE3_RB3D>      { static constexpr int P = 6, L = 3, O = 3, PD = 12; static constexpr bool SE3 = true, REL = false; };
+template <> struct Tr<SRBA_SE3_RELPOSE3D> { static constexpr int P = 6, L = 6, O = 6, PD = 12; static constexpr bool SE3 = true, REL = true; };
+template <> struct Tr<SRBA_SE2_STEREO>    { static constexpr int P = 3, L = 3, O = 4, PD = 5; static constexpr bool SE3 = false, REL = false; };  // SE(2) key-frames, 3D points
 
 // ------------------------------------------------------------------------------------------------ poses
 __device__ __forceinline__ double wrap_pi(double a) { // mrpt::math::wrapToPi up to rounding (and the sign of an exact +-pi)
@@ -543,14 +545,15 @@ struct Worker {
 
 	// ---- sensor helpers
 	__device__ __forceinline__ void to_sensor_point(double *x) const { // point_robot2sensor (srba_options_sensor_pose.h:117-120)
-		if constexpr (T::SE3) if (prm.sensor_pose == SRBA_SENSOR_POSE_SE3) {
+		if constexpr (T::SE3 || FAM == SRBA_SE2_STEREO) if (prm.sensor_pose == SRBA_SENSOR_POSE_SE3) {
 			const double dx = x[0] - prm.SPt[0], dy = x[1] - prm.SPt[1], dz = x[2] - prm.SPt[2];
 			x[0] = prm.SPR[0] * dx + prm.SPR[3] * dy + prm.SPR[6] * dz; x[1] = prm.SPR[1] * dx + prm.SPR[4] * dy + prm.SPR[7] * dz; x[2] = prm.SPR[2] * dx + prm.SPR[5] * dy + prm.SPR[8] * dz;
 		}
 	}
 	// h-Jacobian wrt the point in the sensor frame, already multiplied by R_S^t (jacob_dh_dx_rotate). Returns false if invalid.
 	__device__ __forceinline__ bool dh_dx(double *H, const double *x) const {
-		if constexpr (FAM == SRBA_SE2_RELPOSE2D || FAM == SRBA_SE2_CART2D) { for (int i = 0; i < O * L; i++) H[i] = 0; for (int i = 0; i < O; i++) H[i * L + i] = 1; return true; }
+		if constexpr (FAM == SRBA_SE3_RELPOSE3D) return true; // identity, never multiplied out (sensors.h:905-913; jacobians.h:748-873 does not use dh_dx)
+		else if constexpr (FAM == SRBA_SE2_RELPOSE2D || FAM == SRBA_SE2_CART2D) { for (int i = 0; i < O * L; i++) H[i] = 0; for (int i = 0; i < O; i++) H[i * L + i] = 1; return true; }
 		else if constexpr (FAM == SRBA_SE2_RB2D) {
 			const double r = hypot(x[0], x[1]); if (r == 0) return false;
 			const double ri = 1.0 / r, ri2 = ri * ri; H[0] = x[0] * ri; H[1] = x[1] * ri; H[2] = -x[1] * ri2; H[3] = x[0] * ri2; return true;
@@ -579,6 +582,12 @@ struct Worker {
 		}
 	}
 
+	// z - h for the stereo pair: left pinhole, right pinhole behind (-)rightCameraPose (sensors.h:175-211)
+	__device__ __forceinline__ void project_stereo(const double *l, const double *z, double *r) const {
+		r[0] = z[0] - (prm.camL[2] + prm.camL[0] * l[0] / l[2]); r[1] = z[1] - (prm.camL[3] + prm.camL[1] * l[1] / l[2]);
+		double rr[3]; for (int k = 0; k < 3; k++) rr[k] = prm.R2Lt[k] + prm.R2LR[3 * k] * l[0] + prm.R2LR[3 * k + 1] * l[1] + prm.R2LR[3 * k + 2] * l[2];
+		r[2] = z[2] - (prm.camR[2] + prm.camR[0] * rr[0] / rr[2]); r[3] = z[3] - (prm.camR[3] + prm.camR[1] * rr[1] / rr[2]);
+	}
 	// ---- K4 : one residual row
 	__device__ __forceinline__ double residual_row(int i, double *r) const { // r[O] <- (robustified) residual of row i ; returns its chi2 term
 		const int gi = d.o_obs + i;
@@ -587,6 +596,22 @@ struct Worker {
 		if constexpr (FAM == SRBA_SE2_RELPOSE2D) { // r = P(z) (-) pose (sensors.h:780-784)
 			const double s = bp.s, c = bp.c, dx = z[0] - bp.x, dy = z[1] - bp.y;
 			r[0] = dx * c + dy * s; r[1] = -dx * s + dy * c; r[2] = wrap_pi(z[2] - bp.phi);
+		} else if constexpr (FAM == SRBA_SE2_STEREO) { // the 2D pose moves x,y and leaves z (landmarks.h Euclidean3D::composePosePoint with a CPose2D), then robot -> sensor, then the stereo model
+			const double s = bp.s, c = bp.c; double l[3] = {bp.x + lm[0] * c - lm[1] * s, bp.y + lm[0] * s + lm[1] * c, lm[2]};
+			to_sensor_point(l); project_stereo(l, z, r);
+		} else if constexpr (FAM == SRBA_SE3_RELPOSE3D) { // r = pseudo_ln( P(z) (-) pose ) (sensors.h:873-879): h = pose^-1 (+) P(z), z = (x y z yaw pitch roll)
+			double sy, cy, sp, cp, sr, cr; sincos(z[3], &sy, &cy); sincos(z[4], &sp, &cp); sincos(z[5], &sr, &cr);
+			const double Rz[9] = {cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr, sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr, -sp, cp * sr, cp * cr};
+			const double dt[3] = {z[0] - bp.t[0], z[1] - bp.t[1], z[2] - bp.t[2]};
+			double Rh[9];
+#pragma unroll
+			for (int i = 0; i < 3; i++) {
+				r[i] = bp.R[i] * dt[0] + bp.R[3 + i] * dt[1] + bp.R[6 + i] * dt[2];
+#pragma unroll
+				for (int j = 0; j < 3; j++) Rh[3 * i + j] = bp.R[i] * Rz[j] + bp.R[3 + i] * Rz[3 + j] + bp.R[6 + i] * Rz[6 + j];
+			}
+			const double ct = fmin(1.0, fmax(-1.0, 0.5 * (Rh[0] + Rh[4] + Rh[8] - 1.0))), th = acos(ct), f = th < 1e-8 ? 0.5 : th / (2.0 * sin(th)); // [EXT] CPose3D::ln_rotation as restated in include/mrpt_lite.h
+			r[3] = f * (Rh[7] - Rh[5]); r[4] = f * (Rh[2] - Rh[6]); r[5] = f * (Rh[3] - Rh[1]);
 		} else if constexpr (!T::SE3) {
 			const double s = bp.s, c = bp.c, lx = bp.x + lm[0] * c - lm[1] * s, ly = bp.y + lm[0] * s + lm[1] * c;
 			if constexpr (FAM == SRBA_SE2_RB2D) { r[0] = z[0] - hypot(lx, ly); r[1] = z[1] - atan2(ly, lx); } else { r[0] = z[0] - lx; r[1] = z[1] - ly; }
@@ -653,7 +678,21 @@ struct Worker {
 				if constexpr (!T::REL) { A = hasA ? comp(A, inv(p)) : inv(p); hasA = true; } // the relative-pose block depends on D' only
 			}
 			const double sg = normal ? 1.0 : -1.0;
-			if constexpr (T::REL) { // closed form of dh_dx*J0*J1*J2: depends on D only
+			if constexpr (FAM == SRBA_SE2_STEREO) { // SE(2) poses, 3D points (jacobians.h:501-641 with POINT_DIMS = 3): J = dh_dx * dPx_P * dAD_deps
+				const P2 AD = hasA ? comp(A, D) : D;
+				const double sa = hasA ? A.s : 0.0, ca = hasA ? A.c : 1.0, sad = AD.s, cad = AD.c;
+				double xl[3] = {AD.x + xi[0] * cad - xi[1] * sad, AD.y + xi[0] * sad + xi[1] * cad, xi[2]};
+				to_sensor_point(xl);
+				double H[O * 3]; ok = dh_dx(H, xl);
+				if (ok) {
+					// dPx_P = [1 0 px; 0 1 py; 0 0 1] -- the reference sets d z / d phi = 1 (jacobians.h:546, sic) -- and dAD_deps = [ca -sa qx; sa ca qy; 0 0 1]
+					const double px = -xi[0] * sad - xi[1] * cad, py = xi[0] * cad - xi[1] * sad, qx = -sa * D.x - ca * D.y, qy = ca * D.x - sa * D.y;
+					for (int i = 0; i < O; i++) {
+						const double h0 = H[i * 3], h1 = H[i * 3 + 1], h2 = H[i * 3 + 2], m2 = h0 * px + h1 * py + h2; // row i of dh_dx*dPx_P = [h0 h1 m2]
+						Jl[i * 3] = sg * (h0 * ca + h1 * sa); Jl[i * 3 + 1] = sg * (-h0 * sa + h1 * ca); Jl[i * 3 + 2] = sg * (h0 * qx + h1 * qy + m2);
+					}
+				}
+			} else if constexpr (T::REL) { // closed form of dh_dx*J0*J1*J2: depends on D only
 				const double sd = D.s, cd = D.c;
 				Jl[0] = sg * cd; Jl[1] = sg * sd; Jl[2] = sg * (D.x * sd - D.y * cd);
 				Jl[3] = -sg * sd; Jl[4] = sg * cd; Jl[5] = sg * (D.x * cd + D.y * sd);
@@ -668,6 +707,45 @@ struct Worker {
 					for (int i = 0; i < O; i++) { Jl[i * 3] = sg * (H[i * 2] * ca + H[i * 2 + 1] * sa); Jl[i * 3 + 1] = sg * (-H[i * 2] * sa + H[i * 2 + 1] * ca); Jl[i * 3 + 2] = sg * (H[i * 2] * m02 + H[i * 2 + 1] * m12); }
 				}
 			}
+		} else if constexpr (FAM == SRBA_SE3_RELPOSE3D) { // jacobians.h:748-873: J = [d pseudo_ln / d (R,t)] (6x12) * [d (A e^eps D) / d eps] (12x6)
+			double RA[9];
+			if (!normal) { // D' = p (+) D ; A' = A (+) (-)p
+				const P3 p = ld3(B.edge + (d.o_edge + B.bp_col[gb]) * PD); const P3 pin = inv(p);
+				D = comp(p, D); const P3 Ap = hasA ? comp(A, pin) : pin;
+				for (int k = 0; k < 9; k++) RA[k] = Ap.R[k]; A = Ap; hasA = true;
+			} else if (hasA) { for (int k = 0; k < 9; k++) RA[k] = A.R[k]; }
+			else { for (int k = 0; k < 9; k++) RA[k] = (k % 4 == 0) ? 1.0 : 0.0; }
+			const P3 AD = hasA ? comp(A, D) : D;
+			// d ln(R) / d vec(R), vec = stacked columns ([EXT] CPose3D::ln_rot_jacob: omega = theta / (2 sin theta) * vee(R - R^t), theta = acos((tr R - 1) / 2))
+			const double dd = 0.5 * (AD.R[0] + AD.R[4] + AD.R[8] - 1.0); double a0 = 0, a1 = 0, a2 = 0, bb = 0.5;
+			if (!(dd > 0.99999)) { const double th = acos(dd), sq = sqrt(1.0 - dd * dd), kk = (dd * th - sq) / (4.0 * sq * sq * sq); bb = th / (2.0 * sq); a0 = kk * (AD.R[7] - AD.R[5]); a1 = kk * (AD.R[2] - AD.R[6]); a2 = kk * (AD.R[3] - AD.R[1]); }
+			const double M[27] = {a0, 0, 0, 0, a0, bb, 0, -bb, a0,   a1, 0, -bb, 0, a1, 0, bb, 0, a1,   a2, bb, 0, -bb, a2, 0, 0, 0, a2};
+			// G_i = -R(A) [c_i]_x for the three columns c_i of R(D) and for t(D): rows 3i..3i+2 of the right half of d(A e^eps D)/d eps
+			double Jr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Gt[9];
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				const double v0 = i < 3 ? D.R[i] : D.t[0], v1 = i < 3 ? D.R[3 + i] : D.t[1], v2 = i < 3 ? D.R[6 + i] : D.t[2];
+				const double sk[9] = {0, -v2, v1, v2, 0, -v0, -v1, v0, 0}; double G[9];
+#pragma unroll
+				for (int r = 0; r < 3; r++)
+#pragma unroll
+					for (int q = 0; q < 3; q++) G[3 * r + q] = -(RA[3 * r] * sk[q] + RA[3 * r + 1] * sk[3 + q] + RA[3 * r + 2] * sk[6 + q]);
+				if (i < 3) {
+#pragma unroll
+					for (int m = 0; m < 3; m++)
+#pragma unroll
+						for (int q = 0; q < 3; q++) Jr[3 * m + q] += M[9 * m + 3 * i] * G[q] + M[9 * m + 3 * i + 1] * G[3 + q] + M[9 * m + 3 * i + 2] * G[6 + q];
+				} else for (int k = 0; k < 9; k++) Gt[k] = G[k];
+			}
+			const double sg = normal ? 1.0 : -1.0;
+#pragma unroll
+			for (int r = 0; r < 3; r++)
+#pragma unroll
+				for (int q = 0; q < 3; q++) {
+					Jl[6 * r + q] = sg * (RA[3 * q] * D.R[r] + RA[3 * q + 1] * D.R[3 + r] + RA[3 * q + 2] * D.R[6 + r]); // ((R(A) R(D))^t)[r][q] (jacobians.h:842, sic: the comment there says R(A))
+					Jl[6 * r + 3 + q] = sg * Gt[3 * r + q];
+					Jl[6 * (3 + r) + q] = 0; Jl[6 * (3 + r) + 3 + q] = sg * Jr[3 * r + q];
+				}
 		} else {
 			double RA[9]; bool haveRA = hasA;
 			if (hasA) for (int k = 0; k < 9; k++) RA[k] = A.R[k];
@@ -710,7 +788,13 @@ struct Worker {
 			const pose_t bp = pose_at(ip);
 			const double *xi = B.ulm + (d.o_ulm + B.bf_col[gb]) * L;
 			double Jl[O * L]; bool ok;
-			if constexpr (!T::SE3) {
+			if constexpr (FAM == SRBA_SE2_STEREO) { // dh_dx * R(base <- obs), R = the 3x3 rotation about z of the 2D pose (jacobians.h:984-989)
+				const double s = bp.s, c = bp.c;
+				double xl[3] = {bp.x + xi[0] * c - xi[1] * s, bp.y + xi[0] * s + xi[1] * c, xi[2]};
+				to_sensor_point(xl);
+				double H[O * 3]; ok = dh_dx(H, xl);
+				if (ok) for (int i = 0; i < O; i++) { Jl[i * 3] = H[i * 3] * c + H[i * 3 + 1] * s; Jl[i * 3 + 1] = -H[i * 3] * s + H[i * 3 + 1] * c; Jl[i * 3 + 2] = H[i * 3 + 2]; }
+			} else if constexpr (!T::SE3) {
 				const double s = bp.s, c = bp.c;
 				double xl[2] = {bp.x + xi[0] * c - xi[1] * s, bp.y + xi[0] * s + xi[1] * c};
 				double H[O * L]; ok = dh_dx(H, xl);
@@ -830,7 +914,7 @@ struct Worker {
 #ifdef SRBA_GRADU2
 				constexpr int U = 2;
 #else
-				constexpr int U = (O * M <= 9) ? 4 : 2; // blocks in flight per lane (their loads do not depend on the running sum)
+				constexpr int U = (O * M <= 9) ? 4 : (O * M <= 24 ? 2 : 1); // blocks in flight per lane (their loads do not depend on the running sum)
 #endif
 				for (int b0 = bb + sub; b0 < be; b0 += U * S) {
 					double A[U][O * M], lr[U][O];

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 using namespace srbadev;
@@ -424,7 +425,9 @@ template <int FAM> __global__ void __launch_bounds__(256) k_overall_residuals(co
 namespace {
 
 struct FamDims { int P, L, O, PD; int PDX() const { return PD == 3 ? 5 : PD; } }; // PDX: device pose stride (SE2: [x y phi cos sin])
-const FamDims kDims[SRBA_NUM_FAMILIES] = {{3, 3, 3, 3}, {3, 2, 2, 3}, {3, 2, 2, 3}, {6, 3, 4, 12}, {6, 3, 2, 12}, {6, 3, 3, 12}, {6, 3, 3, 12}};
+const FamDims kDims[SRBA_NUM_FAMILIES] = {{3, 3, 3, 3}, {3, 2, 2, 3}, {3, 2, 2, 3}, {6, 3, 4, 12}, {6, 3, 2, 12}, {6, 3, 3, 12}, {6, 3, 3, 12}, {6, 6, 6, 12}, {3, 3, 4, 3}};
+// every model family the kernels are instantiated for
+#define SRBA_ALL_FAMILIES(X) X(SRBA_SE2_RELPOSE2D) X(SRBA_SE2_RB2D) X(SRBA_SE2_CART2D) X(SRBA_SE3_STEREO) X(SRBA_SE3_MONO) X(SRBA_SE3_CART3D) X(SRBA_SE3_RB3D) X(SRBA_SE3_RELPOSE3D) X(SRBA_SE2_STEREO)
 thread_local std::string g_last_error;
 
 struct Arena { // layout builder: 256-byte aligned sub-allocations inside one buffer
@@ -657,7 +660,8 @@ static int check_params(const srba_hip_params *p) {
 	if (!p || p->family < 0 || p->family >= SRBA_NUM_FAMILIES) { g_last_error = "bad family"; return -1; }
 	if (p->solver < 0 || p->solver > 2) { g_last_error = "bad solver"; return -1; }
 	if (p->noise == SRBA_NOISE_IDENTITY && !(p->std_noise_observations > 0)) { g_last_error = "std_noise_observations must be > 0"; return -1; }
-	if (p->sensor_pose == SRBA_SENSOR_POSE_SE3 && kDims[p->family].PD != 12) { g_last_error = "sensor_pose_on_robot_se3 is only supported with SE3 keyframe poses"; return -1; }
+	if (p->sensor_pose == SRBA_SENSOR_POSE_SE3 && kDims[p->family].PD != 12 && p->family != SRBA_SE2_STEREO) { g_last_error = "sensor_pose_on_robot_se3 is supported with SE3 keyframe poses and with <SE2, Euclidean3D, StereoCamera>"; return -1; }
+	if (p->family == SRBA_SE3_RELPOSE3D && p->sensor_pose != SRBA_SENSOR_POSE_NONE) { g_last_error = "relative-pose observations take no sensor pose"; return -1; }
 	return 0;
 }
 
@@ -910,31 +914,21 @@ int srba_hip_batch_stats(srba_hip_ctx *c, srba_batch_stats *out) { if (!c || !ou
 } // extern "C"
 
 // ---- launch helpers
-#define SRBA_DISPATCH_N(c, KERNEL, nblocks, lds, ...) do { \
-	const dim3 grid(nblocks), block(SRBA_WG); \
-	switch ((c)->params.family) { \
-		case SRBA_SE2_RELPOSE2D: hipLaunchKernelGGL(srbadev::KERNEL<SRBA_SE2_RELPOSE2D>, grid, block, (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); break; \
-		case SRBA_SE2_RB2D: hipLaunchKernelGGL(srbadev::KERNEL<SRBA_SE2_RB2D>, grid, block, (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); break; \
-		case SRBA_SE2_CART2D: hipLaunchKernelGGL(srbadev::KERNEL<SRBA_SE2_CART2D>, grid, block, (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); break; \
-		case SRBA_SE3_STEREO: hipLaunchKernelGGL(srbadev::KERNEL<SRBA_SE3_STEREO>, grid, block, (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); break; \
-		case SRBA_SE3_MONO: hipLaunchKernelGGL(srbadev::KERNEL<SRBA_SE3_MONO>, grid, block, (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); break; \
-		case SRBA_SE3_CART3D: hipLaunchKernelGGL(srbadev::KERNEL<SRBA_SE3_CART3D>, grid, block, (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); break; \
-		case SRBA_SE3_RB3D: hipLaunchKernelGGL(srbadev::KERNEL<SRBA_SE3_RB3D>, grid, block, (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); break; \
-	} } while (0)
+// family id -> template argument: f(std::integral_constant<int, FAM>()) for the family of the context
+template <class F> static bool with_family(int family, F &&f) {
+	switch (family) {
+#define X(FAM) case FAM: f(std::integral_constant<int, FAM>()); return true;
+		SRBA_ALL_FAMILIES(X)
+#undef X
+	}
+	return false;
+}
+#define SRBA_DISPATCH_N(c, KERNEL, nblocks, lds, ...) with_family((c)->params.family, [&](auto fam_) { \
+	hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), dim3(nblocks), dim3(SRBA_WG), (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); })
 #define SRBA_DISPATCH(c, KERNEL, lds, ...) SRBA_DISPATCH_N(c, KERNEL, (c)->n_prob, lds, ##__VA_ARGS__)
-#define SRBA_DISPATCH_LDS1(c, KERNEL, FAMILY, inlds, nblocks, lds, ...) do { \
-	if (inlds) hipLaunchKernelGGL((srbadev::KERNEL<FAMILY, true>), dim3(nblocks), dim3(SRBA_WG), (lds), launch_stream, (c)->B, (c)->dp, ##__VA_ARGS__); \
-	else hipLaunchKernelGGL((srbadev::KERNEL<FAMILY, false>), dim3(nblocks), dim3(SRBA_WG), (lds), launch_stream, (c)->B, (c)->dp, ##__VA_ARGS__); } while (0)
-#define SRBA_DISPATCH_LDS(c, KERNEL, inlds, nblocks, lds, ...) do { \
-	switch ((c)->params.family) { \
-		case SRBA_SE2_RELPOSE2D: SRBA_DISPATCH_LDS1(c, KERNEL, SRBA_SE2_RELPOSE2D, inlds, nblocks, lds, ##__VA_ARGS__); break; \
-		case SRBA_SE2_RB2D: SRBA_DISPATCH_LDS1(c, KERNEL, SRBA_SE2_RB2D, inlds, nblocks, lds, ##__VA_ARGS__); break; \
-		case SRBA_SE2_CART2D: SRBA_DISPATCH_LDS1(c, KERNEL, SRBA_SE2_CART2D, inlds, nblocks, lds, ##__VA_ARGS__); break; \
-		case SRBA_SE3_STEREO: SRBA_DISPATCH_LDS1(c, KERNEL, SRBA_SE3_STEREO, inlds, nblocks, lds, ##__VA_ARGS__); break; \
-		case SRBA_SE3_MONO: SRBA_DISPATCH_LDS1(c, KERNEL, SRBA_SE3_MONO, inlds, nblocks, lds, ##__VA_ARGS__); break; \
-		case SRBA_SE3_CART3D: SRBA_DISPATCH_LDS1(c, KERNEL, SRBA_SE3_CART3D, inlds, nblocks, lds, ##__VA_ARGS__); break; \
-		case SRBA_SE3_RB3D: SRBA_DISPATCH_LDS1(c, KERNEL, SRBA_SE3_RB3D, inlds, nblocks, lds, ##__VA_ARGS__); break; \
-	} } while (0)
+#define SRBA_DISPATCH_LDS(c, KERNEL, inlds, nblocks, lds, ...) with_family((c)->params.family, [&](auto fam_) { \
+	if (inlds) hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value, true>), dim3(nblocks), dim3(SRBA_WG), (lds), launch_stream, (c)->B, (c)->dp, ##__VA_ARGS__); \
+	else hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value, false>), dim3(nblocks), dim3(SRBA_WG), (lds), launch_stream, (c)->B, (c)->dp, ##__VA_ARGS__); })
 
 template <class K> static int allow_big_lds(srba_hip_ctx *c, K kernel, size_t bytes) {
 	if (bytes > 64 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess) { c->fail(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e)); return -1; } }
@@ -944,12 +938,9 @@ static int prep_lds(srba_hip_ctx *c, bool for_lm) {
 	size_t b = 0; for (int k = 0; k < SRBA_NCLS; k++) if (c->cls_count[k]) b = std::max(b, c->cls_lds[k]);
 	b += c->lds_pad;
 	if (b <= 64 * 1024) return 0;
-	switch (c->params.family) {
-#define CASE(F) case F: return for_lm ? allow_big_lds(c, srbadev::k_lm_run<F, true>, b) : allow_big_lds(c, srbadev::k_solve<F, true>, b);
-		CASE(SRBA_SE2_RELPOSE2D) CASE(SRBA_SE2_RB2D) CASE(SRBA_SE2_CART2D) CASE(SRBA_SE3_STEREO) CASE(SRBA_SE3_MONO) CASE(SRBA_SE3_CART3D) CASE(SRBA_SE3_RB3D)
-#undef CASE
-	}
-	return -1;
+	int rc = -1;
+	with_family(c->params.family, [&](auto fam_) { constexpr int F = decltype(fam_)::value; rc = for_lm ? allow_big_lds(c, srbadev::k_lm_run<F, true>, b) : allow_big_lds(c, srbadev::k_solve<F, true>, b); });
+	return rc;
 }
 
 // The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable when it initialises: ask for 16
@@ -1015,10 +1006,9 @@ int srba_hip_eval_overall_sqr_error(srba_hip_ctx *c, const srba_overall_problem 
 		B.obs_pose = (const int *)(di + o_op); B.obs_lm = (const int *)(di + o_ol); B.obs_z = (const double *)(di + o_z); B.ulm = (double *)(di + o_lm); B.pose = (double *)(dw + o_pose);
 		DevParams dp = c->dp; dp.use_robust_kernel = 0; // the reference sums plain squared norms (eval_overall_error.h:129)
 		const int pblk = std::max(1, std::min(1024, (q->n_pairs + 255) / 256));
-#define CASE(F) case F: if (q->n_pairs) hipLaunchKernelGGL((srbadev::k_overall_pairs<F>), dim3(pblk), dim3(256), 0, c->stream, B, dp); \
-		hipLaunchKernelGGL((srbadev::k_overall_residuals<F>), dim3(nblk), dim3(256), 0, c->stream, B, dp, (double *)(dw + o_part)); break;
-		switch (c->params.family) { CASE(SRBA_SE2_RELPOSE2D) CASE(SRBA_SE2_RB2D) CASE(SRBA_SE2_CART2D) CASE(SRBA_SE3_STEREO) CASE(SRBA_SE3_MONO) CASE(SRBA_SE3_CART3D) CASE(SRBA_SE3_RB3D) }
-#undef CASE
+		with_family(c->params.family, [&](auto fam_) { constexpr int F = decltype(fam_)::value;
+			if (q->n_pairs) hipLaunchKernelGGL((srbadev::k_overall_pairs<F>), dim3(pblk), dim3(256), 0, c->stream, B, dp);
+			hipLaunchKernelGGL((srbadev::k_overall_residuals<F>), dim3(nblk), dim3(256), 0, c->stream, B, dp, (double *)(dw + o_part)); });
 		if (hipGetLastError() != hipSuccess) { rc = -1; break; }
 		if (hipMemcpyAsync(part.data(), dw + o_part, 8 * (size_t)nblk, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rc = -1; break; }
 	} while (0);

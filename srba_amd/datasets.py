@@ -263,6 +263,66 @@ def landmarks_dataset_se3(kind="cart3d", n_kf=40, n_lm=400, seed=1, max_range=5.
     return out, gt
 
 
+def ypr_of(R):
+    return np.array([math.atan2(R[1, 0], R[0, 0]), math.asin(-R[2, 0]), math.atan2(R[2, 1], R[2, 2])])
+
+
+def graph_slam_se3(n_kf=60, seed=1, sigma_xyz=1e-3, sigma_ang_deg=0.1, max_range=2.5, max_back=40):
+    """SE(3) relative graph-SLAM (the 3D counterpart of graph_slam_se2; examples/cpp/tutorial-srba-relative-graph-slam-se3.cpp feeds the engine the same way):
+    every key-frame first lists itself as a fixed "fake landmark" at the null pose, then the relative pose (x y z yaw pitch roll) of every earlier key-frame
+    closer than max_range, with Gaussian noise. Returns (dataset, gt_poses)."""
+    rng = np.random.RandomState(seed)
+    gt = spiral_path_se3(n_kf, seed)
+    out = []
+    for kf, T in enumerate(gt):
+        ids, zs, flags = [kf], [np.zeros(6)], [FLAG_FIXED]
+        Tinv = np.linalg.inv(T)
+        for j in range(max(0, kf - max_back), kf):
+            rel = Tinv @ gt[j]
+            if np.linalg.norm(rel[:3, 3]) > max_range:
+                continue
+            z = np.concatenate([rel[:3, 3], ypr_of(rel[:3, :3])]) + np.concatenate([sigma_xyz * rng.randn(3), math.radians(sigma_ang_deg) * rng.randn(3)])
+            ids.append(j); zs.append(z); flags.append(0)
+        out.append(dict(feat_ids=np.array(ids, np.uint64), z=np.array(zs, np.float64).reshape(-1, 6), flags=np.array(flags, np.uint8), relpos=np.zeros((len(ids), 6))))
+    return out, gt
+
+
+def graph_slam_lambda_se3(sigma_xyz=1e-3, sigma_ang_deg=0.1):
+    a = 1.0 / sigma_xyz ** 2; b = 1.0 / math.radians(sigma_ang_deg) ** 2
+    return np.diag([a, a, a, b, b, b])
+
+
+def landmarks_dataset_se2_stereo(n_kf=30, n_lm=500, seed=1, max_range=6.0, noise=0.0, cam=(200.0, 150.0, 512.0, 384.0), baseline=0.2, init_from_gt_noise=None):
+    """Planar robot (SE(2) key-frames) with a forward-looking stereo camera mounted through CAMERA_ON_ROBOT observing 3D point landmarks
+    (the problem type of examples/cpp/tutorial-srba-stereo-se2.cpp). Returns (dataset, gt as (x, y, phi))."""
+    rng = np.random.RandomState(seed)
+    gt = [(0.0, 0.0, 0.0)]
+    for _ in range(n_kf - 1):
+        gt.append(_compose2(gt[-1], (rng.uniform(0.3, 0.6), 0.0, math.radians(rng.uniform(-20, 20)))))
+    xs = np.array([p[0] for p in gt]); ys = np.array([p[1] for p in gt])
+    lms = np.column_stack([rng.uniform(xs.min() - 5, xs.max() + 5, n_lm), rng.uniform(ys.min() - 5, ys.max() + 5, n_lm), rng.uniform(-1.5, 1.5, n_lm)])
+    S = pose3(*CAMERA_ON_ROBOT); fx, fy, cx, cy = cam
+    seen = set(); out = []
+    for kf, p in enumerate(gt):
+        T = pose3(p[0], p[1], 0.0, p[2], 0.0, 0.0)
+        Ts = np.linalg.inv(T @ S); Tr = np.linalg.inv(T)
+        ids, zs, flags, rel = [], [], [], []
+        for j in range(n_lm):
+            q = Ts[:3, :3] @ lms[j] + Ts[:3, 3]
+            if q[2] < 0.6 or np.linalg.norm(q) > max_range:
+                continue
+            u, v, ur = cx + fx * q[0] / q[2], cy + fy * q[1] / q[2], cx + fx * (q[0] - baseline) / q[2]
+            if not (0 <= u < 2 * cx and 0 <= v < 2 * cy and 0 <= ur < 2 * cx):
+                continue
+            first = j not in seen; fl = 0; rp = np.zeros(3)
+            if first and init_from_gt_noise is not None:
+                fl = FLAG_INIT; rp = Tr[:3, :3] @ lms[j] + Tr[:3, 3] + init_from_gt_noise * rng.randn(3)
+            seen.add(j)
+            ids.append(j); zs.append(np.array([u, v, ur, v]) + noise * rng.randn(4)); flags.append(fl); rel.append(rp)
+        out.append(dict(feat_ids=np.array(ids, np.uint64), z=np.array(zs, np.float64).reshape(-1, 4), flags=np.array(flags, np.uint8), relpos=np.array(rel, np.float64).reshape(-1, 3)))
+    return out, gt
+
+
 def landmarks_dataset_se2(kind="rb2d", n_kf=50, n_lm=300, seed=1, max_range=4.0, fov_deg=100.0, noise=1e-3, known_first=0):
     """cfg1 of BASELINE.md: planar random walk, step U(0.4,0.8) m, turn U(-30,30) deg; point landmarks; range-bearing (or cartesian) sensor
     (datasets/tutorials_dataset-range-bearing-2d.cfg:27-28,44-46)."""

@@ -241,6 +241,15 @@ def graph_slam_engine(backend="hip", submap=10, depth=3, sigma_xy=1e-3, sigma_ya
     return Engine(capi.SE2_RELPOSE2D, backend=backend, **args)
 
 
+def graph_slam_engine_se3(backend="hip", submap=5, depth=3, sigma_xyz=1e-3, sigma_ang_deg=0.1, solver=capi.SOLVER_NO_SCHUR_SPARSE, harvest=1, **kw):
+    """SE(3) relative graph-SLAM: <SE3, RelativePoses3D, RelativePoses_3D> with a constant 6x6 information matrix (examples/cpp/tutorial-srba-relative-graph-slam-se3.cpp:20-33)."""
+    from . import datasets
+    args = dict(solver=solver, noise=capi.NOISE_MATRIX, lambda_=_lam36(datasets.graph_slam_lambda_se3(sigma_xyz, sigma_ang_deg), 6), max_tree_depth=depth, max_optimize_depth=depth,
+                submap_size=submap, min_obs_to_loop_closure=1, optimize_new_edges_alone=1, use_robust_kernel=0, max_error_per_obs_to_stop=1e-8, harvest=harvest)
+    args.update(kw)
+    return Engine(capi.SE3_RELPOSE3D, backend=backend, **args)
+
+
 def _lam36(m, O):
     out = np.zeros(36); out[:O * O] = np.asarray(m, np.float64).reshape(-1); return out
 
@@ -256,11 +265,11 @@ def landmark_engine(kind, backend="hip", depth=3, submap=15, sigma=None, robust=
     """Engines for the point-landmark families with the reference apps' policies: identity noise, Schur + dense Cholesky
     (apps/srba-slam/instance_se3_lm3d_stereo.cpp:36-45, instance_se3_lm3d_monocular.cpp:33-42, instance_se2_lm2d_rangebearing2d.cpp:17)."""
     from . import datasets
-    fam = {"cart3d": capi.SE3_CART3D, "rb3d": capi.SE3_RB3D, "stereo": capi.SE3_STEREO, "mono": capi.SE3_MONO, "rb2d": capi.SE2_RB2D, "cart2d": capi.SE2_CART2D}[kind]
+    fam = {"cart3d": capi.SE3_CART3D, "rb3d": capi.SE3_RB3D, "stereo": capi.SE3_STEREO, "mono": capi.SE3_MONO, "rb2d": capi.SE2_RB2D, "cart2d": capi.SE2_CART2D, "stereo_se2": capi.SE2_STEREO}[kind]
     if with_sensor_pose is None:
-        with_sensor_pose = kind in ("stereo", "mono")
+        with_sensor_pose = kind in ("stereo", "mono", "stereo_se2")
     if sigma is None:
-        sigma = {"cart3d": 0.01, "rb3d": 0.01, "stereo": 0.5, "mono": 0.5, "rb2d": 0.05, "cart2d": 0.05}[kind]
+        sigma = {"cart3d": 0.01, "rb3d": 0.01, "stereo": 0.5, "mono": 0.5, "rb2d": 0.05, "cart2d": 0.05, "stereo_se2": 0.5}[kind]
     args = dict(solver=capi.SOLVER_SCHUR_DENSE, noise=capi.NOISE_IDENTITY, std_noise_observations=sigma, max_tree_depth=depth, max_optimize_depth=depth, submap_size=submap,
                 use_robust_kernel=robust, harvest=harvest, cam_left=cam, cam_right=cam, right_cam_pose=(baseline, 0, 0, 1, 0, 0, 0))
     if with_sensor_pose:

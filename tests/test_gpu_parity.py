@@ -164,12 +164,14 @@ def test_large_windows_depth5():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,solver", [(k, s) for k in ("rb2d", "cart3d", "stereo", "rb3d") for s in (capi.SOLVER_SCHUR_DENSE, capi.SOLVER_SCHUR_SPARSE, capi.SOLVER_NO_SCHUR_SPARSE)])
+@pytest.mark.parametrize("kind,solver", [(k, s) for k in ("rb2d", "cart3d", "stereo", "rb3d", "stereo_se2") for s in (capi.SOLVER_SCHUR_DENSE, capi.SOLVER_SCHUR_SPARSE, capi.SOLVER_NO_SCHUR_SPARSE)])
 def test_landmark_families_all_solvers(kind, solver):
     """Every reference solver (lev-marq_solvers.h: Schur+dense LLT, Schur+sparse, full sparse) on landmark problems: the device factors the
     same SPD system in one way, so all three must reproduce the oracle's chi2 (which runs the reference's three code paths)."""
     if kind in ("rb2d",):
         ds, _ = datasets.landmarks_dataset_se2(kind, n_kf=30, n_lm=900, seed=7, noise=1e-3)
+    elif kind == "stereo_se2":
+        ds, _ = datasets.landmarks_dataset_se2_stereo(n_kf=16, n_lm=90, seed=7, noise=0.1)
     else:
         ds, _ = datasets.landmarks_dataset_se3(kind, n_kf=16, n_lm=320, seed=7, noise=(0.1 if kind == "stereo" else 1e-3))
     eng = runner.landmark_engine(kind, backend=_oracle.BACKEND, solver=solver)
@@ -246,7 +248,7 @@ def test_schur_complement_on_device_equals_dense(kind):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["rb2d", "cart2d", "cart3d", "rb3d", "stereo", "mono"])
+@pytest.mark.parametrize("kind", ["rb2d", "cart2d", "cart3d", "rb3d", "stereo", "mono", "stereo_se2"])
 def test_stepwise_kernels_match_oracle_landmark_families(kind):
     """K1, K4, K2, K3, K6, K5 one launch each (srba_hip_update_spantree / eval_residuals / linearize) against the oracle's arrays of the same capsule:
     residuals, dh_dAp and dh_df blocks, the three Hessian block sets and the gradient, for every landmark family."""
@@ -266,3 +268,43 @@ def test_stepwise_kernels_match_oracle_landmark_families(kind):
             if r.size:
                 assert np.allclose(g, r, rtol=1e-8, atol=1e-9 * max(1e-300, np.abs(r).max())), (kind, i, key, float(np.abs(g - r).max()), float(np.abs(r).max()))
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_relpose_se3_family_matches_oracle():
+    """<SE3, RelativePoses3D, RelativePoses_3D> (SE(3) relative graph-SLAM, 6x6 blocks, constant 6x6 information matrix): per-kernel arrays and the whole LM loop against the oracle."""
+    ds, _ = datasets.graph_slam_se3(n_kf=40, seed=6)
+    eng = runner.graph_slam_engine_se3(backend=_oracle.BACKEND); eng.run(ds)
+    b = eng.harvest(); b.engine = eng
+    for i in (b.n - 1, b.n - 7):
+        sub = b.sub(i, 1); ctx = runner.HipContext(b.params); ctx.upload(sub); lib = ctx.lib; chi = np.zeros(1)
+        assert lib.srba_hip_update_spantree(ctx.ctx, 0) == 0 and lib.srba_hip_eval_residuals(ctx.ctx, chi.ctypes.data_as(capi.PF64)) == 0 and lib.srba_hip_linearize(ctx.ctx) == 0
+        ref = _oracle.stage(b, i)
+        assert _close(chi[0], ref["scalars"][0], rel=1e-9)
+        for what, key in ((0, "resid"), (1, "Jp"), (3, "HAp"), (6, "grad"), (9, "poses")):
+            g = ctx.debug(what); r = ref[key]
+            assert g.shape == r.shape and np.allclose(g, r, rtol=1e-8, atol=1e-9 * max(1e-300, np.abs(r).max())), (i, key, float(np.abs(g - r).max()))
+        ctx.close()
+    sub = b.sub(b.n - 24, 24)
+    ref = _oracle.run_batch(sub); gpu = runner.run_batch_hip(sub)
+    assert np.all(gpu["status"] == ref["status"]) and _close(gpu["chi2_init"], ref["chi2_init"], rel=1e-9)
+    assert _close(gpu["chi2_final"], ref["chi2_final"], rel=1e-6, abs_=1e-18)
+
+
+@pytest.mark.gpu
+def test_new_families_through_the_engine_with_hip_backend():
+    """define_new_keyframe() with the GPU back-end for the two families added in round 2: SE(3) relative graph-SLAM recovers a noise-free map; the planar robot with
+    a stereo camera (SE(2) key-frames, 3D landmarks) ends at the noise floor and at the ground-truth edges."""
+    ds, gt = datasets.graph_slam_se3(n_kf=8, seed=1, sigma_xyz=0, sigma_ang_deg=0)
+    eng = runner.graph_slam_engine_se3(backend="hip", harvest=0); infos = eng.run(ds)
+    assert all(i.chi2_final < 1e-12 for i in infos)
+    fr, to, pose = eng.edges()
+    for k in range(len(fr)):
+        T = np.linalg.inv(gt[int(to[k])]) @ gt[int(fr[k])]
+        assert np.abs(pose[k][:3] - T[:3, 3]).max() < 1e-7 and np.abs(pose[k][3:].reshape(3, 3) - T[:3, :3]).max() < 1e-7
+    ds2, gt2 = datasets.landmarks_dataset_se2_stereo(n_kf=14, n_lm=120, seed=2, noise=0.05)
+    eng2 = runner.landmark_engine("stereo_se2", backend="hip", robust=0, harvest=0); infos = eng2.run(ds2)
+    assert infos[-1].obs_rmse < 0.15
+    fr, to, pose = eng2.edges()
+    for k in range(len(fr)):
+        assert np.abs(pose[k] - np.array(datasets._inv_compose2(gt2[int(fr[k])], gt2[int(to[k])]))).max() < 5e-3

@@ -15,6 +15,8 @@ import _oracle  # tests/_oracle.py: the CPU checker
 def _harvest(kind, solver=capi.SOLVER_SCHUR_DENSE, n_kf=14, seed=3, **kw):
     if kind in ("rb2d", "cart2d"):
         ds, gt = datasets.landmarks_dataset_se2(kind, n_kf=n_kf + 10, n_lm=900, seed=seed, noise=1e-3)
+    elif kind == "stereo_se2":
+        ds, gt = datasets.landmarks_dataset_se2_stereo(n_kf=n_kf, n_lm=90, seed=seed, noise=0.1)
     else:
         ds, gt = datasets.landmarks_dataset_se3(kind, n_kf=n_kf, n_lm=350, seed=seed, noise=(1e-3 if kind in ("cart3d", "rb3d") else 0.1), init_from_gt_noise=(0.2 if kind == "mono" else None))
     eng = runner.landmark_engine(kind, backend=_oracle.BACKEND, solver=solver, **kw)
@@ -109,7 +111,7 @@ def _perturb_edge(pose, eps, PD):
     return np.concatenate([eps[:3] + E @ t, (E @ R).reshape(-1)])
 
 
-@pytest.mark.parametrize("kind", ["cart3d", "rb3d", "stereo", "mono", "rb2d", "cart2d"])
+@pytest.mark.parametrize("kind", ["cart3d", "rb3d", "stereo", "mono", "rb2d", "cart2d", "stereo_se2"])
 def test_point_family_jacobians_match_finite_differences(kind):
     b = _harvest(kind, n_kf=8)
     P, L, O, PD = capi.DIMS[b.family]
@@ -131,6 +133,12 @@ def test_point_family_jacobians_match_finite_differences(kind):
             Jn[:, :, d] = -(rp - rm) / (2 * h)   # r = z - h  =>  dh/deps = -dr/deps
         for blk in np.where(bp_col == col)[0]:
             scale = max(1.0, np.abs(Jp[blk]).max())
+            if kind == "stereo_se2":
+                # jacobians.h:546 sets d z / d phi = 1 for 3D points on SE(2) poses (a planar rotation cannot move z: the exact value is 0). The oracle and the kernels
+                # keep the reference's value, so the yaw column carries dh/dz on top of the true derivative; x and y columns are exact.
+                assert np.abs(Jn[bp_res[blk]][:, :2] - Jp[blk][:, :2]).max() < 2e-5 * scale, (kind, col, blk)
+                assert np.abs(Jn[bp_res[blk]][:, 2] - Jp[blk][:, 2]).max() > 1e-3   # the quirk is really there ...
+                continue                                                          # ... and is characterised exactly in test_se2_3d_points_yaw_column_quirk
             assert np.abs(Jn[bp_res[blk]] - Jp[blk]).max() < 2e-5 * scale, (kind, col, blk)
     for col in range(min(c.n_unk_lms, 4)):
         save = ulm[L * col:L * col + L].copy(); Jn = np.zeros((c.n_obs, O, L))
@@ -168,3 +176,79 @@ def test_relpose_jacobian_is_minus_dr_deps_at_zero_residual():
             Jn[:, :, d] = -(rp - rm) / (2 * h)
         for blk in np.where(bp_col == col)[0]:
             assert np.abs(Jn[bp_res[blk]] - Jp[blk]).max() < 1e-5, (col, blk)
+
+
+def test_se2_3d_points_yaw_column_quirk():
+    """<SE2, Euclidean3D, StereoCamera>: analytic yaw column = exact derivative + sign * dh/dz, dh/dz being the third column of the dh_df block of the same observation
+    rotated back (dh_df = dh_dx R, R about z leaves the third column of dh_dx unchanged) -- i.e. exactly the reference's dPx_P(2,2) = 1 (jacobians.h:546)."""
+    b = _harvest("stereo_se2", n_kf=8)
+    P, L, O, PD = capi.DIMS[b.family]; i = b.n - 1; c = b[i]
+    a0 = _oracle.stage(b, i); Jp = a0["Jp"].reshape(c.n_bp, O, P); Jf = a0["Jf"].reshape(c.n_bf, O, L)
+    bp_col, bp_res, bp_n = b.array(i, "bp_col", np.int32, c.n_bp), b.array(i, "bp_res", np.int32, c.n_bp), b.array(i, "bp_normal", np.uint8, c.n_bp)
+    bf_res = b.array(i, "bf_res", np.int32, c.n_bf); df_of_row = {int(r): k for k, r in enumerate(bf_res)}
+    w = b.clone(i, 1); cw = w.ptr[0]; edge = np.ctypeslib.as_array(cw.edge_pose, shape=(cw.n_edges * PD,))
+    res = lambda: _oracle.stage(w, 0)["resid"].reshape(-1, O)
+    h = 1e-6; checked = 0
+    for col in range(min(c.n_unk_edges, 3)):
+        save = edge[PD * col:PD * col + PD].copy()
+        e = np.zeros(P); e[2] = h; edge[PD * col:PD * col + PD] = _perturb_edge(save, e, PD); rp = res()
+        e[2] = -h; edge[PD * col:PD * col + PD] = _perturb_edge(save, e, PD); rm = res(); edge[PD * col:PD * col + PD] = save
+        dyaw = -(rp - rm) / (2 * h)
+        for blk in np.where(bp_col == col)[0]:
+            if int(bp_res[blk]) not in df_of_row:
+                continue
+            sg = 1.0 if bp_n[blk] else -1.0
+            assert np.abs(Jp[blk][:, 2] - (dyaw[bp_res[blk]] + sg * Jf[df_of_row[int(bp_res[blk])]][:, 2])).max() < 2e-5 * max(1.0, np.abs(Jp[blk]).max()), (col, blk)
+            checked += 1
+    assert checked > 10
+
+
+def _so3_log(R):
+    c = np.clip(0.5 * (np.trace(R) - 1), -1, 1); th = np.arccos(c); f = 0.5 if th < 1e-8 else th / (2 * np.sin(th))
+    return f * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+
+
+def test_relpose_se3_jacobian_is_the_derivative_of_pseudo_ln_of_the_predicted_pose():
+    """<SE3, RelativePoses3D, RelativePoses_3D> (jacobians.h:748-873). The reference differentiates pseudo_ln(A (+) exp(eps) (+) D) -- the log of the PREDICTED pose --
+    through CPose3D::ln_rot_jacob, whose source is not vendored: it is derived here as the derivative of ln(R) = theta/(2 sin theta) vee(R - R^t) with respect to
+    the nine entries (Blanco's SE(3) report, 10.3.2) and pinned by central differences of that very function:
+        columns 3..5 (rotation increments), all six rows : +-d pseudo_ln(A e^eps D)/d eps        to 1e-6
+        rows 3..5, columns 0..2                         : 0
+        rows 0..2, columns 0..2                         : +-(R(A) R(D))^t  -- what the reference writes (:842); the derivative of that function would be R(A).
+    This is NOT the exact derivative of the residual pseudo_ln(P(z) (-) pose) unless rotations are small (like SURVEY App. B-13 for SE(2)); oracle and kernels keep the reference's formula."""
+    ds, gt = datasets.graph_slam_se3(n_kf=26, seed=4)
+    eng = runner.graph_slam_engine_se3(backend=_oracle.BACKEND)
+    eng.run(ds); b = eng.harvest(); i = b.n - 1; c = b[i]
+    a = _oracle.stage(b, i); J = a["Jp"].reshape(c.n_bp, 6, 6); poses = a["poses"].reshape(-1, 12)
+    bp_col, bp_A, bp_D = (b.array(i, k, np.int32, c.n_bp) for k in ("bp_col", "bp_A", "bp_D")); bp_n = b.array(i, "bp_normal", np.uint8, c.n_bp)
+    edge = b.array(i, "edge_pose", np.float64, c.n_edges * 12).reshape(-1, 12)
+    H = lambda v: np.block([[v[3:].reshape(3, 3), v[:3].reshape(3, 1)], [np.zeros((1, 3)), np.ones((1, 1))]])
+    def F(A, D, eps):
+        E = np.eye(4); E[:3, :3] = _so3_exp(eps[3:]); E[:3, 3] = eps[:3]; T = A @ E @ D
+        return np.concatenate([T[:3, 3], _so3_log(T[:3, :3])])
+    kinds = set()
+    for k in range(c.n_bp):
+        A = H(poses[bp_A[k]]) if bp_A[k] >= 0 else np.eye(4); D = H(poses[bp_D[k]]); sg = 1.0
+        if not bp_n[k]:
+            p = H(edge[bp_col[k]]); D = p @ D; A = A @ np.linalg.inv(p); sg = -1.0   # D' = p (+) D, A' = A (-) p, result negated (:798-820,:866-870)
+        G = np.zeros((6, 6)); h = 1e-6
+        for d in range(6):
+            e = np.zeros(6); e[d] = h; G[:, d] = (F(A, D, e) - F(A, D, -e)) / (2 * h)
+        near_identity = 0.5 * (np.trace((A @ D)[:3, :3]) - 1) > 0.99999   # [EXT] ln_rot_jacob switches to its zero-angle limit there: error up to theta^2 / 12 ~ 2e-6
+        assert np.abs(J[k][:, 3:] - sg * G[:, 3:]).max() < (1e-5 if near_identity else 1e-6) * max(1.0, np.abs(G).max()), k
+        assert np.abs(J[k][3:, :3]).max() == 0
+        assert np.abs(J[k][:3, :3] - sg * (A[:3, :3] @ D[:3, :3]).T).max() < 1e-12, k
+        assert np.abs(G[:3, :3] - A[:3, :3]).max() < 1e-6
+        kinds.add((bool(bp_n[k]), bool(bp_A[k] >= 0)))
+    assert len(kinds) >= 3   # normal / inverse edges, with and without a leading pose A
+
+
+def test_relpose_se3_noise_free_map_is_recovered():
+    """8 key-frames of noise-free SE(3) relative-pose data: every kf2kf edge ends at the ground truth (the reference's inexact Jacobian still converges on short chains)."""
+    ds, gt = datasets.graph_slam_se3(n_kf=8, seed=1, sigma_xyz=0, sigma_ang_deg=0)
+    eng = runner.graph_slam_engine_se3(backend=_oracle.BACKEND, harvest=0); infos = eng.run(ds)
+    assert all(i.chi2_final < 1e-12 for i in infos)
+    fr, to, pose = eng.edges()
+    for k in range(len(fr)):
+        T = np.linalg.inv(gt[int(to[k])]) @ gt[int(fr[k])]
+        assert np.abs(pose[k][:3] - T[:3, 3]).max() < 1e-7 and np.abs(pose[k][3:].reshape(3, 3) - T[:3, :3]).max() < 1e-7
