@@ -142,6 +142,7 @@ def engine_lib():
         lib.srba_engine_eval_overall_sqr_error.argtypes = [C.c_void_p, C.POINTER(c_f64)]
         lib.srba_engine_alloc_keyframe.argtypes = [C.c_void_p]; lib.srba_engine_alloc_keyframe.restype = C.c_uint64
         lib.srba_engine_create_edge.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, PF64]; lib.srba_engine_create_edge.restype = C.c_int64
+        lib.srba_engine_export_graphslam.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), PF64, C.c_int64, C.POINTER(C.c_uint64), PF64, C.c_int64]; lib.srba_engine_export_graphslam.restype = C.c_int64
         lib.srba_engine_harvest_count.argtypes = [C.c_void_p]; lib.srba_engine_harvest_count.restype = C.c_int64
         lib.srba_engine_harvest_capsules.argtypes = [C.c_void_p]; lib.srba_engine_harvest_capsules.restype = PCAP
         lib.srba_engine_harvest_kf.argtypes = [C.c_void_p, C.c_int64]; lib.srba_engine_harvest_kf.restype = C.c_uint64

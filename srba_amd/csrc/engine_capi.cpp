@@ -56,6 +56,7 @@ struct EngineBase {
 	virtual int eval_overall(double *out) = 0;
 	std::shared_ptr<function_backend> fn_backend; // set when a C function was plugged in
 	virtual uint64_t alloc_keyframe() = 0;
+	virtual int64_t export_graphslam(uint64_t root, uint64_t *node_id, double *node_pose, int64_t node_cap, uint64_t *edge_from_to, double *edge_pose, int64_t edge_cap) const = 0;
 	virtual int64_t create_edge(uint64_t new_kf, uint64_t from, uint64_t to, const double *pose) = 0;
 };
 
@@ -147,6 +148,20 @@ struct EngineImpl : public EngineBase {
 	double profiler_mean(const char *name) const { return const_cast<rba_t &>(rba).get_time_profiler().getMeanTime(name); }
 	int eval_overall(double *out) { try { *out = rba.eval_overall_squared_error(); return 0; } catch (std::exception &e) { error = e.what(); return -1; } }
 	uint64_t alloc_keyframe() { return rba.alloc_keyframe(); }
+	/** RbaEngine<>::get_global_graphslam_problem() into a minimal pose-graph container (what mrpt::graphs::CNetworkOfPoses offers the reference: clear(), nodes[id], insertEdgeAtEnd) */
+	struct pose_graph_t {
+		std::map<uint64_t, typename rba_t::pose_t> nodes; std::vector<std::pair<std::pair<uint64_t, uint64_t>, typename rba_t::pose_t> > edges;
+		void clear() { nodes.clear(); edges.clear(); }
+		void insertEdgeAtEnd(uint64_t from, uint64_t to, const typename rba_t::pose_t &p) { edges.push_back(std::make_pair(std::make_pair(from, to), p)); }
+	};
+	int64_t export_graphslam(uint64_t root, uint64_t *node_id, double *node_pose, int64_t node_cap, uint64_t *edge_from_to, double *edge_pose, int64_t edge_cap) const {
+		pose_graph_t g; typename rba_t::ExportGraphSLAM_Params prm; prm.root_kf_id = root;
+		rba.get_global_graphslam_problem(g, prm);
+		const size_t PD = rba_t::pose_t::storage_doubles(); int64_t i = 0;
+		for (typename std::map<uint64_t, typename rba_t::pose_t>::const_iterator it = g.nodes.begin(); it != g.nodes.end() && i < node_cap; ++it, ++i) { node_id[i] = it->first; it->second.storeTo(node_pose + (size_t)i * PD); }
+		for (size_t e = 0; e < g.edges.size() && (int64_t)e < edge_cap; e++) { edge_from_to[2 * e] = g.edges[e].first.first; edge_from_to[2 * e + 1] = g.edges[e].first.second; g.edges[e].second.storeTo(edge_pose + e * PD); }
+		return (int64_t)g.nodes.size();
+	}
 	int64_t create_edge(uint64_t new_kf, uint64_t from, uint64_t to, const double *pose) {
 		try { typename rba_t::pose_t p; if (pose) p.loadFrom(pose); typename rba_t::new_kf_observations_t dummy; return (int64_t)rba.create_kf2kf_edge(new_kf, TPairKeyFrameID(from, to), dummy, p); }
 		catch (std::exception &e) { error = e.what(); return -1; }
@@ -254,6 +269,8 @@ int64_t srba_engine_st_dump(void *h, int what, int64_t *out, int64_t cap) { retu
 int srba_engine_get_rel_pose(void *h, uint64_t query, uint64_t reference, double *pose) { return static_cast<EngineBase *>(h)->get_rel_pose(query, reference, pose); }
 uint64_t srba_engine_alloc_keyframe(void *h) { return static_cast<EngineBase *>(h)->alloc_keyframe(); }
 int64_t srba_engine_create_edge(void *h, uint64_t new_kf, uint64_t from, uint64_t to, const double *pose) { return static_cast<EngineBase *>(h)->create_edge(new_kf, from, to, pose); }
+int64_t srba_engine_export_graphslam(void *h, uint64_t root, uint64_t *node_id, double *node_pose, int64_t node_cap, uint64_t *edge_from_to, double *edge_pose, int64_t edge_cap) {
+	return static_cast<EngineBase *>(h)->export_graphslam(root, node_id, node_pose, node_cap, edge_from_to, edge_pose, edge_cap); }
 double srba_engine_profiler_mean(void *h, const char *name) { return static_cast<EngineBase *>(h)->profiler_mean(name); }
 
 int64_t srba_engine_harvest_count(void *h) { return (int64_t)static_cast<EngineBase *>(h)->harvest.data.size(); }

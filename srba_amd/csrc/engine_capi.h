@@ -73,6 +73,8 @@ int64_t srba_capsule_file_count(void *h);
 srba_problem_capsule *srba_capsule_file_capsules(void *h);
 int   srba_capsule_file_params(void *h, srba_hip_params *out);
 void  srba_capsule_file_free(void *h);
+/* RbaEngine<>::get_global_graphslam_problem(): global node poses (complete breadth-first spanning tree from `root`) + one constraint per kf2kf edge as (to, from, inv_pose). Returns the node count. */
+int64_t srba_engine_export_graphslam(void *h, uint64_t root, uint64_t *node_id, double *node_pose, int64_t node_cap, uint64_t *edge_from_to, double *edge_pose, int64_t edge_cap);
 void *srba_capsule_clone(const srba_problem_capsule *caps, int64_t n, int family);
 /* one capsule from per-observation Jacobian columns (identity poses; Hessian / Schur plan by CapsuleData::build_plan) -- replays tests/schur_unittest.cpp */
 void *srba_capsule_from_blocks(int family, int nK, int nF, int n_obs, const int32_t *row_bp_col, const int32_t *row_bf_col, int with_schur);

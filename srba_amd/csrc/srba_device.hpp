@@ -569,7 +569,7 @@ struct Worker {
 			else {
 				if (x[2] <= 0) return false;
 				{ const double zi = 1.0 / x[2], zi2 = zi * zi; Hs[0] = prm.camL[0] * zi; Hs[1] = 0; Hs[2] = -prm.camL[0] * x[0] * zi2; Hs[3] = 0; Hs[4] = prm.camL[1] * zi; Hs[5] = -prm.camL[1] * x[1] * zi2; }
-				if constexpr (FAM == SRBA_SE3_STEREO) {
+				if constexpr (FAM == SRBA_SE3_STEREO || FAM == SRBA_SE2_STEREO) {
 					double xr[3];
 					for (int i = 0; i < 3; i++) xr[i] = prm.R2Lt[i] + prm.R2LR[3 * i] * x[0] + prm.R2LR[3 * i + 1] * x[1] + prm.R2LR[3 * i + 2] * x[2];
 					const double zi = 1.0 / xr[2], zi2 = zi * zi; Hs[6] = prm.camR[0] * zi; Hs[7] = 0; Hs[8] = -prm.camR[0] * xr[0] * zi2; Hs[9] = 0; Hs[10] = prm.camR[1] * zi; Hs[11] = -prm.camR[1] * xr[1] * zi2;

