@@ -213,25 +213,20 @@ template <int N> __device__ __forceinline__ bool fullpiv_inverse(const double *A
 //             blocks they need and subtract L_ak L_bk^t from their precomputed target block; then the panel blocks are overwritten
 //             by L_ak and the right-hand side is eliminated (forward substitution fused).  Two wave barriers per step.
 // "Not positive definite" == a scalar pivot <= 0 (Eigen LLT / cs_chol criterion), decided identically by all lanes.
-struct SparseSys { // per-capsule symbolic structure (LDS copy, or global memory for the HBM class) + numeric storage (LDS or HBM)
+struct SparseSys { // per-capsule symbolic structure (LDS copy of the host's symbolic factorisation) + numeric storage, all in LDS
 	int nb, nnzoff;
 	const int *col_off, *row;  // col_off[nb+1], row[nnzoff] (rows ascending inside a column)
 	const int *item;           // update items of all columns, column after column (cn(cn+1)/2 each, a>=b row positions inside the column):
-	                           //   LDS copy: one packed word  u<<18 | a<<9 | b  (u = unified block index: diag k -> k, off-diag i -> nb+i)
-	                           //   HBM class: item = target (>=0 off-diag index, <0: -(1+diag)), item_ab = a<<16 | b
-	const int *item_ab;
-	const int *rptr, *rent;    // row view for the backward substitution: entries of block-row a = rent[rptr[a]..rptr[a+1]) = col<<14 | off-diag index (LDS), or col / rent_blk (HBM class)
+	                           //   one packed word  u<<18 | a<<9 | b  (u = unified block index: diag k -> k, off-diag i -> nb+i)
+	const int *item_ab;        //   (global-memory source: target / a<<16|b pairs, packed into `item` when copied to LDS)
+	const int *rptr, *rent;    // row view for the backward substitution: entries of block-row a = rent[rptr[a]..rptr[a+1]) = col<<14 | off-diag index
 	const int *rent_blk;
 	const int *perm;           // perm[original 3-row block] = position in the fill-reducing elimination order
 	double *diag, *off, *rhs;
 };
 // Cross-lane hand-off inside the solver. LDS instructions of one wavefront execute in issue order, so a ds_write followed by a ds_read of
 // another lane's data needs no s_waitcnt -- only the compiler must keep the program order (wavefront-scope fence = no instructions).
-// The HBM-class path hands data over through global memory and keeps the full barrier (s_waitcnt vmcnt(0)).
-template <bool DLDS> __device__ __forceinline__ void solver_sync() {
-	if constexpr (DLDS) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
-	else __syncthreads();
-}
+__device__ __forceinline__ void solver_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 struct Chol3 { double l10, l20, l21, r0, r1, r2, l00, l11, l22; };
 // Branch-free 3x3 Cholesky of the lower triangle (a00 a10 a11 a20 a21 a22): the three pivots are tested together at the end, so the six
 // loads and the whole dependent chain are issued without a scalar branch in between. Garbage in c when it returns false.
@@ -244,120 +239,6 @@ __device__ __forceinline__ bool chol3v(double a00, double a10, double a11, doubl
 	return (a00 > 0.0) & (d1 > 0.0) & (d2 > 0.0); // NaN-safe: any non-positive or NaN pivot fails
 }
 __device__ __forceinline__ bool chol3(const double *D, Chol3 &c) { return chol3v(D[0], D[3], D[4], D[6], D[7], D[8], c); }
-// X = Ablk * Lkk^-T  (each row: forward substitution against Lkk)
-__device__ __forceinline__ void panel3(const double *Ab, const Chol3 &c, double *X) {
-#pragma unroll
-	for (int r = 0; r < 3; r++) {
-		const double x0 = Ab[r * 3] * c.r0, x1 = (Ab[r * 3 + 1] - x0 * c.l10) * c.r1, x2 = (Ab[r * 3 + 2] - x0 * c.l20 - x1 * c.l21) * c.r2;
-		X[r * 3] = x0; X[r * 3 + 1] = x1; X[r * 3 + 2] = x2;
-	}
-}
-template <bool DLDS> __device__ __forceinline__ void item_decode(const SparseSys &S, int idx, int &a, int &b, double *&T) {
-	if constexpr (DLDS) { const unsigned w = (unsigned)S.item[idx]; a = (w >> 9) & 511; b = w & 511; T = S.diag + 9 * (w >> 18); }
-	else { const int tg = S.item[idx], ab = S.item_ab[idx]; a = ab >> 16; b = ab & 0xffff; T = tg >= 0 ? S.off + 9 * tg : S.diag + 9 * (-1 - tg); }
-}
-__device__ __forceinline__ void item_update(const double *La, const double *Lb, double *T) { // T -= La Lb^t
-	double la[9], lb[9], tv[9];
-#pragma unroll
-	for (int q = 0; q < 9; q++) { la[q] = La[q]; lb[q] = Lb[q]; tv[q] = T[q]; }
-#pragma unroll
-	for (int rr = 0; rr < 3; rr++)
-#pragma unroll
-		for (int q = 0; q < 3; q++) T[rr * 3 + q] = tv[rr * 3 + q] - (la[rr * 3] * lb[q * 3] + la[rr * 3 + 1] * lb[q * 3 + 1] + la[rr * 3 + 2] * lb[q * 3 + 2]);
-}
-// Factor in place and overwrite rhs with y = L^-1 rhs. Returns false (uniformly) if not positive definite.
-//   step k : every lane refactors the 3x3 diagonal block (no broadcast); the panel lanes overwrite A_ak by L_ak and eliminate the
-//            right-hand side (forward substitution fused); then the update items (a>=b) of column k subtract L_ak L_bk^t from their
-//            precomputed target block.
-// A step is a chain of dependent LDS round trips and FP64 operations executed by one wavefront, so its latency is the cost: everything a
-// step reads that does not depend on the previous step's numbers (column pointer, row index and item word of the lane) is fetched one
-// step ahead, and the numeric loads of a step are all issued before its arithmetic.
-template <bool DLDS> __device__ __forceinline__ bool sp_factor_fsub(const SparseSys &S) {
-	const int lane = threadIdx.x, nb = S.nb;
-	int cb = S.col_off[0], ce = nb > 0 ? S.col_off[1] : cb, ib = 0;
-	int ra = (cb + lane < ce) ? S.row[cb + lane] : 0; // row index of this lane's panel block in the coming column
-	for (int k = 0; k < nb; k++) {
-		const int cn = ce - cb, nitems = cn * (cn + 1) / 2;
-		double *D = S.diag + 9 * k, *Ab = S.off + 9 * (cb + lane);
-		// numeric loads of the step
-		const double a00 = D[0], a10 = D[3], a11 = D[4], a20 = D[6], a21 = D[7], a22 = D[8];
-		const double b0 = S.rhs[3 * k], b1 = S.rhs[3 * k + 1], b2 = S.rhs[3 * k + 2];
-		const bool pl = lane < cn;
-		double Av[9], rv[3];
-		if (pl) {
-#pragma unroll
-			for (int q = 0; q < 9; q++) Av[q] = Ab[q];
-#pragma unroll
-			for (int r = 0; r < 3; r++) rv[r] = S.rhs[3 * ra + r];
-		}
-		// index loads for the next step
-		const int ce_n = (k + 2 <= nb) ? S.col_off[k + 2] : ce;
-		const int ra_n = (ce + lane < ce_n) ? S.row[ce + lane] : 0;
-		Chol3 c;
-		if (!chol3v(a00, a10, a11, a20, a21, a22, c)) return false;
-		const double y0 = b0 * c.r0, y1 = (b1 - c.l10 * y0) * c.r1, y2 = (b2 - c.l20 * y0 - c.l21 * y1) * c.r2;
-		if (pl) { // panel: A_ak -> L_ak ; rhs_a -= L_ak y_k
-			double Lp[9]; panel3(Av, c, Lp);
-#pragma unroll
-			for (int r = 0; r < 3; r++) S.rhs[3 * ra + r] = rv[r] - (Lp[r * 3] * y0 + Lp[r * 3 + 1] * y1 + Lp[r * 3 + 2] * y2);
-#pragma unroll
-			for (int q = 0; q < 9; q++) Ab[q] = Lp[q];
-		}
-		for (int a = lane + SRBA_WG; a < cn; a += SRBA_WG) { // columns with more than 64 blocks
-			double *Ax = S.off + 9 * (cb + a); double Lp[9]; panel3(Ax, c, Lp);
-			const int rx = S.row[cb + a];
-#pragma unroll
-			for (int r = 0; r < 3; r++) S.rhs[3 * rx + r] -= Lp[r * 3] * y0 + Lp[r * 3 + 1] * y1 + Lp[r * 3 + 2] * y2;
-#pragma unroll
-			for (int q = 0; q < 9; q++) Ax[q] = Lp[q];
-		}
-		if (lane == SRBA_WG - 1) { // L_kk, reciprocal diagonal in the unused upper part, y_k
-			D[0] = c.l00; D[3] = c.l10; D[4] = c.l11; D[6] = c.l20; D[7] = c.l21; D[8] = c.l22; D[1] = c.r0; D[2] = c.r1; D[5] = c.r2;
-			S.rhs[3 * k] = y0; S.rhs[3 * k + 1] = y1; S.rhs[3 * k + 2] = y2;
-		}
-		solver_sync<DLDS>();
-		for (int t = lane; t < nitems; t += SRBA_WG) { // trailing update: target -= L_ak L_bk^t
-			int a, b; double *T; item_decode<DLDS>(S, ib + t, a, b, T);
-			item_update(S.off + 9 * (cb + a), S.off + 9 * (cb + b), T);
-		}
-		solver_sync<DLDS>();
-		cb = ce; ce = ce_n; ib += nitems; ra = ra_n;
-	}
-	return true;
-}
-// Solve L^t x = y in place (rhs: y -> x), row-oriented: once x_a is known (every lane computes it, no broadcast) the lanes push
-// y_k -= L_ak^t x_a into the earlier rows k that have a block in block-row a. No reduction, one hand-off per step; the row pointer and
-// the lane's entry word of the next row are fetched one step ahead.
-template <bool DLDS> __device__ __forceinline__ void sp_bsub(const SparseSys &S) {
-	const int lane = threadIdx.x, nb = S.nb;
-	if (nb <= 0) return;
-	int re = S.rptr[nb], rb = S.rptr[nb - 1], rb_n = nb >= 2 ? S.rptr[nb - 2] : 0;
-	auto entry = [&](int j, int &kcol, int &blk) { if constexpr (DLDS) { const unsigned w = (unsigned)S.rent[j]; kcol = w >> 14; blk = w & 0x3fff; } else { kcol = S.rent[j]; blk = S.rent_blk[j]; } };
-	int kc = 0, bl = 0; if (rb + lane < re) entry(rb + lane, kc, bl);
-	for (int a = nb - 1; a >= 0; a--) {
-		const bool act = rb + lane < re;
-		const double *D = S.diag + 9 * a, *Lb = S.off + 9 * bl; double *y = S.rhs + 3 * kc;
-		const double r0 = S.rhs[3 * a], r1 = S.rhs[3 * a + 1], r2 = S.rhs[3 * a + 2], d5 = D[5], d7 = D[7], d2 = D[2], d3 = D[3], d6 = D[6], d1 = D[1];
-		double Lv[9], yv[3];
-		if (act) {
-#pragma unroll
-			for (int q = 0; q < 9; q++) Lv[q] = Lb[q];
-#pragma unroll
-			for (int r = 0; r < 3; r++) yv[r] = y[r];
-		}
-		int kc_n = 0, bl_n = 0; if (a > 0 && rb_n + lane < rb) entry(rb_n + lane, kc_n, bl_n);
-		const int rb_nn = a >= 2 ? S.rptr[a - 2] : 0;
-		const double x2 = r2 * d5, x1 = (r1 - d7 * x2) * d2, x0 = (r0 - d3 * x1 - d6 * x2) * d1;
-		if (act) { y[0] = yv[0] - (Lv[0] * x0 + Lv[3] * x1 + Lv[6] * x2); y[1] = yv[1] - (Lv[1] * x0 + Lv[4] * x1 + Lv[7] * x2); y[2] = yv[2] - (Lv[2] * x0 + Lv[5] * x1 + Lv[8] * x2); }
-		for (int j = rb + lane + SRBA_WG; j < re; j += SRBA_WG) { // rows with more than 64 blocks
-			int kx, bx; entry(j, kx, bx); const double *Lx = S.off + 9 * bx; double *yx = S.rhs + 3 * kx;
-			yx[0] -= Lx[0] * x0 + Lx[3] * x1 + Lx[6] * x2; yx[1] -= Lx[1] * x0 + Lx[4] * x1 + Lx[7] * x2; yx[2] -= Lx[2] * x0 + Lx[5] * x1 + Lx[8] * x2;
-		}
-		if (lane == SRBA_WG - 1) { S.rhs[3 * a] = x0; S.rhs[3 * a + 1] = x1; S.rhs[3 * a + 2] = x2; }
-		solver_sync<DLDS>();
-		re = rb; rb = rb_n; rb_n = rb_nn; kc = kc_n; bl = bl_n;
-	}
-}
 // ---- LDS solver, lane-per-block-row form. The one-lane-per-3x3-block loops above keep 1..10 of 64 lanes busy and every wave instruction
 // costs an issue slot whatever the number of live lanes, so the factorisation was issue-bound at ~250 instructions per column. Here a 3x3
 // block is worked on by THREE lanes, one per block row (lane = 3*block + row; lane 63 idles in these phases):
@@ -403,7 +284,7 @@ __device__ __forceinline__ bool sp_factor_fsub_rows(const SparseSys &S) {
 			D[0] = c.l00; D[3] = c.l10; D[4] = c.l11; D[6] = c.l20; D[7] = c.l21; D[8] = c.l22; D[1] = c.r0; D[2] = c.r1; D[5] = c.r2;
 			S.rhs[3 * k] = y0; S.rhs[3 * k + 1] = y1; S.rhs[3 * k + 2] = y2;
 		}
-		solver_sync<true>();
+		solver_sync();
 		if (worker) for (int t = grp; t < nitems; t += 21) { // trailing update, row `sub` of target -= L_ak L_bk^t
 			const unsigned w = (unsigned)S.item[ib + t];
 			const double *La = S.off + 9 * (cb + ((w >> 9) & 511)) + 3 * sub, *Lb = S.off + 9 * (cb + (w & 511)); double *T = S.diag + 9 * (w >> 18) + 3 * sub;
@@ -416,7 +297,7 @@ __device__ __forceinline__ bool sp_factor_fsub_rows(const SparseSys &S) {
 			T[1] = t1 - (la0 * lb[3] + la1 * lb[4] + la2 * lb[5]);
 			T[2] = t2 - (la0 * lb[6] + la1 * lb[7] + la2 * lb[8]);
 		}
-		solver_sync<true>();
+		solver_sync();
 		cb = ce; ce = ce_n; ib += nitems; ra = ra_n;
 	}
 	return true;
@@ -442,7 +323,7 @@ __device__ __forceinline__ void sp_bsub_rows(const SparseSys &S) {
 			*yx -= Lx[0] * x0 + Lx[3] * x1 + Lx[6] * x2;
 		}
 		if (lane == SRBA_WG - 1) { S.rhs[3 * a] = x0; S.rhs[3 * a + 1] = x1; S.rhs[3 * a + 2] = x2; }
-		solver_sync<true>();
+		solver_sync();
 		re = rb; rb = rb_n; rb_n = rb_nn; w = w_n;
 	}
 }

@@ -179,15 +179,15 @@ struct Solver : public Worker<FAM> {
 		__syncthreads();
 	}
 	// solve(lambda): returns false if not positive definite (uniform across the wavefront)
-	template <bool DLDS> __device__ bool solve(const SparseSys &S, double lambda, long long *pc = nullptr) {
+	__device__ bool solve(const SparseSys &S, double lambda, long long *pc = nullptr) {
 		long long t0 = 0;
 #define STIC() do { if (pc) { __syncthreads(); t0 = wall_clock64(); } } while (0)
 #define STOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - t0; } } while (0)
 		STIC(); if (schur_active()) schur_reduce(lambda); STOC(9);
 		STIC(); assemble(S, lambda); STOC(10);
-		STIC(); bool ok; if constexpr (DLDS) ok = sp_factor_fsub_rows(S); else ok = sp_factor_fsub<false>(S); STOC(11);
+		STIC(); const bool ok = sp_factor_fsub_rows(S); STOC(11);
 		if (!ok) return false;
-		STIC(); if constexpr (DLDS) sp_bsub_rows(S); else sp_bsub<false>(S);
+		STIC(); sp_bsub_rows(S);
 		double *dl = B.delta + d.o_scal;
 		for (int k = tid; k < d.n_scal; k += SRBA_WG) dl[k] = (k < d.n_sys) ? S.rhs[3 * S.perm[k / 3] + k % 3] : 0.0;
 		__syncthreads(); STOC(12);
@@ -196,13 +196,13 @@ struct Solver : public Worker<FAM> {
 #undef STIC
 #undef STOC
 	}
-	template <bool DLDS> __device__ __forceinline__ SparseSys make_sys(double *lds) const {
+	__device__ __forceinline__ SparseSys make_sys(double *lds) const {
 		SparseSys S; S.nb = d.nb; S.nnzoff = d.nnzoff;
 		S.col_off = B.sp_col_off + d.o_spcol; S.row = B.sp_row + d.o_sprow; S.item = B.sp_tgt + d.o_spitem; S.item_ab = B.sp_ab + d.o_spitem; S.perm = B.sp_perm + d.o_spperm;
 		S.rptr = B.sp_rptr + d.o_spcol; S.rent = B.sp_rcol + d.o_sprow; S.rent_blk = B.sp_rblk + d.o_sprow;
-		double *base; if constexpr (DLDS) base = lds; else base = B.dense + d.o_dense;
+		double *base = lds;
 		S.diag = base; S.off = base + 9 * d.nb; S.rhs = S.off + 9 * d.nnzoff;
-		if constexpr (DLDS) { // symbolic structure next to the numbers (packed): the factorisation's dependent index loads hit LDS, not L2
+		{ // symbolic structure next to the numbers (packed): the factorisation's dependent index loads hit LDS, not L2
 			int *ip = (int *)(S.rhs + 3 * d.nb); int *c0 = ip, *rp0 = c0 + d.nb + 1, *p0 = rp0 + d.nb + 1, *r0 = p0 + d.nb, *re0 = r0 + d.nnzoff, *t0 = re0 + d.nnzoff;
 			for (int k = tid; k <= d.nb; k += SRBA_WG) { c0[k] = S.col_off[k]; rp0[k] = S.rptr[k]; }
 			for (int k = tid; k < d.nb; k += SRBA_WG) p0[k] = S.perm[k];
@@ -251,19 +251,18 @@ struct Solver : public Worker<FAM> {
 
 extern __shared__ double srba_lds[]; // block-sparse system of the capsule (diag | off | rhs) when it fits
 
-// DLDS: the dense system lives in LDS (size classes 0..2) -> the compiler can prove the address space and emit ds_* instead of flat_*
 #ifdef SRBA_WAVES_PER_EU
 #define SRBA_OCC __attribute__((amdgpu_waves_per_eu(SRBA_WAVES_PER_EU, SRBA_WAVES_PER_EU)))
 #else
 #define SRBA_OCC
 #endif
-template <int FAM, bool DLDS>
+template <int FAM>
 __device__ __forceinline__ void lm_one(const Batch &B, const DevParams &prm, const int pidx) {
 	const ProbDesc &d = B.desc[pidx];
 	Solver<FAM> S(B, d, prm);
 	constexpr int P = Solver<FAM>::P, L = Solver<FAM>::L, O = Solver<FAM>::O;
 	double *red = nullptr;
-	const SparseSys A = S.template make_sys<DLDS>(srba_lds);
+	const SparseSys A = S.make_sys(srba_lds);
 	const int tid = threadIdx.x; srba_lm_result *out = B.results + pidx;
 	const int nObs = d.n_obs, n = d.n_scal;
 	double *resid = B.resid, *resid2 = B.resid2;
@@ -297,7 +296,7 @@ __device__ __forceinline__ void lm_one(const Batch &B, const DevParams &prm, con
 		while (rho <= 0 && !stop) {
 			const int tr = trials++;
 			if (tid == 0 && tr < SRBA_TRACE_LEN) out->trace_lambda[tr] = lambda;
-			TIC(); const bool solved = S.template solve<DLDS>(A, lambda, pc); TOC(5);
+			TIC(); const bool solved = S.solve(A, lambda, pc); TOC(5);
 			if (!solved) {
 				n_notpd++; lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
 				__syncthreads();
@@ -352,13 +351,13 @@ __device__ __forceinline__ void lm_one(const Batch &B, const DevParams &prm, con
 // Persistent workgroups: a launch covers one LDS size class with a grid of at most the number of wavefronts the chip can hold for that class; every
 // wavefront pulls capsules (sorted longest-first inside the class) from a shared counter until the class is exhausted. A launch therefore has ONE
 // tail (its last capsules) instead of one per chunk, and the chip stays full while big (LDS-bound) and small (wave-slot-bound) classes drain side by side.
-template <int FAM, bool DLDS>
+template <int FAM>
 __global__ void __launch_bounds__(SRBA_WG) SRBA_OCC k_lm_run(const Batch B, const DevParams prm, int first, int count, int *next) {
 	for (;;) {
 		int i = 0; if (threadIdx.x == 0) i = atomicAdd(next, 1);
 		i = __builtin_amdgcn_readfirstlane(i);
 		if (i >= count) break;
-		lm_one<FAM, DLDS>(B, prm, B.order[first + i]);
+		lm_one<FAM>(B, prm, B.order[first + i]);
 		__syncthreads(); // the LDS image and the symbolic copy are rebuilt by the next capsule
 	}
 }
@@ -383,15 +382,18 @@ template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_hessian_only(con
 	__syncthreads();
 	S.phase_hessian();
 }
-template <int FAM, bool DLDS> __global__ void __launch_bounds__(SRBA_WG) k_solve(const Batch B, const DevParams prm, int first) {
+template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_solve(const Batch B, const DevParams prm, int first) {
 	const int pidx = B.order[first + blockIdx.x]; const ProbDesc &d = B.desc[pidx]; Solver<FAM> S(B, d, prm);
-	const SparseSys A = S.template make_sys<DLDS>(srba_lds);
-	const bool ok = S.template solve<DLDS>(A, B.lambda_io[pidx]);
+	const SparseSys A = S.make_sys(srba_lds);
+	const bool ok = S.solve(A, B.lambda_io[pidx]);
 	if (threadIdx.x == 0) B.notpd[pidx] = ok ? 0 : 1;
 }
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_apply(const Batch B, const DevParams prm) { Solver<FAM> S(B, B.desc[blockIdx.x], prm); S.apply_update(); }
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_rollback(const Batch B, const DevParams prm) { Solver<FAM> S(B, B.desc[blockIdx.x], prm); S.restore(); }
 
+} // namespace srbadev
+#include "srba_big.hpp"
+namespace srbadev {
 // ---- whole-map squared error (eval_overall_error.h:15-137): a plain streaming pair of kernels over ONE problem (desc[0]), grid-stride
 // K1 over all (observer, base) pairs: compose the breadth-first path from the root of the pair (spantree_create_complete.h:96-124)
 template <int FAM> __global__ void __launch_bounds__(256) k_overall_pairs(const Batch B, const DevParams prm) {
@@ -524,6 +526,7 @@ static void symbolic_factor(const srba_problem_capsule &k, const ProbDesc &d, in
 
 struct LaunchJob { int queue, cls, first, count; double cost; int grid; };
 static const int kMaxJobs = 1024;
+static const int kBigPart = 4096;
 // Index-range check of one capsule (every index the kernels dereference): a wrong capsule is reported at upload instead of reading out of bounds on the device
 static const char *validate_capsule(const srba_problem_capsule &k) {
 	auto in = [](int v, int lo, int hi) { return v >= lo && v < hi; };
@@ -581,7 +584,10 @@ struct srba_hip_ctx {
 	// batch
 	int n_prob = 0; std::vector<ProbDesc> desc; Batch B; srba_batch_stats stats;
 	char *d_in = nullptr; size_t cap_in = 0; char *d_wk = nullptr; size_t cap_wk = 0; int *d_next = nullptr;
-	std::vector<char> h_in; // host staging of the input arena
+	double *d_part = nullptr; double *d_scal = nullptr; int *d_iscal = nullptr; // big path: partial sums [3][kBigPart], scalars, int flags (ninv, not-pd)
+	std::vector<int> big_ld; // per capsule: leading dimension of its dense system when it runs on the big path, else 0
+	int big_min_sys = 480;   // systems with more scalar unknowns than this skip the block-sparse symbolic analysis and go dense (big path)
+	std::vector<char> h_in; size_t h_off_order = 0; // host staging of the input arena (kept: the launch order is read back from it)
 	int max_lds_kb = 1 << 20, min_chunk = 384, max_parts_per_queue = 2; int n_queues = 16, sched = 3, n_streams_used = 1, n_cu = 256, waves_per_cu = 8, lds_per_cu = 160 * 1024; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
 	// offsets needed for downloads (bytes inside the wk arena)
 	size_t off_edge = 0, off_ulm = 0, off_pose = 0, off_inf = 0, off_infv = 0, off_res = 0;
@@ -604,7 +610,7 @@ static void plan_launches(srba_hip_ctx *c, const int32_t *ord) {
 			if (c->sched == 3) { const size_t lds = c->cls_lds[J.cls] + c->lds_pad; const int fit = lds ? (int)std::max<size_t>(1, (size_t)c->lds_per_cu / lds) : c->waves_per_cu; J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(c->waves_per_cu, fit))); } } } } finish = {c};
 	if (c->sched == 3) { // one persistent launch per size class, every class on its own stream, biggest LDS footprint first (the HBM class is the biggest)
 		int q = 0;
-		for (int k = SRBA_NCLS - 1; k >= 0; k--) if (c->cls_count[k]) { c->plan.push_back({q, k, c->cls_first[k], c->cls_count[k], 0.0, 0}); q++; }
+		for (int k = SRBA_NCLS - 2; k >= 0; k--) if (c->cls_count[k]) { c->plan.push_back({q, k, c->cls_first[k], c->cls_count[k], 0.0, 0}); q++; }
 		c->n_streams_used = std::max(q, 1); return;
 	}
 	// cost of a chunk ~ sum over its capsules of (system size) x (LDS footprint): a trial takes time ~ nb, and how many capsules run at once
@@ -612,20 +618,20 @@ static void plan_launches(srba_hip_ctx *c, const int32_t *ord) {
 	auto cost_of = [&](int cls, int first, int count) { const double w = cls == SRBA_NCLS - 1 ? 24.0 : std::max(1.0, (double)c->cls_lds[cls] / 8192.0); double s = 0; for (int i = 0; i < count; i++) s += (c->desc[ord[first + i]].nb + 4) * w; return s; };
 	if (c->sched == 2) {
 		int q = 0;
-		for (int k = SRBA_NCLS - 1; k >= 0; k--) if (c->cls_count[k]) { c->plan.push_back({q, k, c->cls_first[k], c->cls_count[k], 0.0, 0}); q++; }
+		for (int k = SRBA_NCLS - 2; k >= 0; k--) if (c->cls_count[k]) { c->plan.push_back({q, k, c->cls_first[k], c->cls_count[k], 0.0, 0}); q++; }
 		c->n_streams_used = std::max(q, 1); return;
 	}
 	c->n_streams_used = nq;
 	if (c->sched == 0) {
 		int rr = 0;
-		for (int k = SRBA_NCLS - 1; k >= 0; k--) if (c->cls_count[k]) {
+		for (int k = SRBA_NCLS - 2; k >= 0; k--) if (c->cls_count[k]) {
 			const int cnt = c->cls_count[k], parts = cnt >= 16 * nq ? nq : 1;
 			for (int q = 0; q < parts; q++) { const int a = slice_begin(cnt, q, parts), b = slice_begin(cnt, q + 1, parts); if (b > a) c->plan.push_back({parts == 1 ? (rr++ % nq) : q, k, c->cls_first[k] + a, b - a, 0.0, 0}); }
 		}
 		return;
 	}
 	std::vector<LaunchJob> jobs;
-	for (int k = SRBA_NCLS - 1; k >= 0; k--) if (c->cls_count[k]) {
+	for (int k = SRBA_NCLS - 2; k >= 0; k--) if (c->cls_count[k]) {
 		const int cnt = c->cls_count[k], parts = std::max(1, std::min(c->max_parts_per_queue * nq, cnt / c->min_chunk));
 		for (int q = 0; q < parts; q++) { const int a = slice_begin(cnt, q, parts), b = slice_begin(cnt, q + 1, parts); if (b > a) jobs.push_back({0, k, c->cls_first[k] + a, b - a, cost_of(k, c->cls_first[k] + a, b - a), 0}); }
 	}
@@ -705,7 +711,8 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || false) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
 	for (int k = 1; k < SRBA_NCLS && ok; k++) ok = hipStreamCreateWithFlags(&c->cls_stream[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->cls_done[k], hipEventDisableTiming) == hipSuccess;
-	if (!ok || hipMalloc((void **)&c->d_next, sizeof(int) * kMaxJobs) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
+	if (!ok || hipMalloc((void **)&c->d_next, sizeof(int) * kMaxJobs) != hipSuccess || hipMalloc((void **)&c->d_part, 8 * 3 * kBigPart) != hipSuccess || hipMalloc((void **)&c->d_scal, 8 * 16) != hipSuccess || hipMalloc((void **)&c->d_iscal, 4 * 8) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
+	{ const char *e = getenv("SRBA_HIP_BIG_MIN_SYS"); if (e && atoi(e) >= 0) c->big_min_sys = atoi(e); } // tuning / test knob
 	return c;
 }
 
@@ -720,7 +727,7 @@ int srba_hip_set_params(srba_hip_ctx *c, const srba_hip_params *params) {
 int srba_hip_destroy(srba_hip_ctx *c) {
 	if (!c) return 0;
 	hipSetDevice(c->device);
-	if (c->d_in) hipFree(c->d_in); if (c->d_wk) hipFree(c->d_wk); if (c->d_next) hipFree(c->d_next);
+	if (c->d_in) hipFree(c->d_in); if (c->d_wk) hipFree(c->d_wk); if (c->d_next) hipFree(c->d_next); if (c->d_part) hipFree(c->d_part); if (c->d_scal) hipFree(c->d_scal); if (c->d_iscal) hipFree(c->d_iscal);
 	for (int i = 0; i < srba_hip_ctx::kRing; i++) { if (c->ring0[i]) hipEventDestroy(c->ring0[i]); if (c->ring1[i]) hipEventDestroy(c->ring1[i]); }
 	if (c->ev_fork) hipEventDestroy(c->ev_fork);
 	for (int k = 1; k < SRBA_NCLS; k++) { if (c->cls_done[k]) hipEventDestroy(c->cls_done[k]); if (c->cls_stream[k]) hipStreamDestroy(c->cls_stream[k]); }
@@ -751,7 +758,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	c->desc.assign(n, ProbDesc()); srba_batch_stats &st = c->stats; std::memset(&st, 0, sizeof(st)); st.n_problems = n;
 	// ---- pass 1: descriptors and totals
 	long long t_edge = 0, t_unk = 0, t_ulm = 0, t_klm = 0, t_pair = 0, t_path = 0, t_obs = 0, t_valid = 0, t_bp = 0, t_bf = 0, t_hap = 0, t_hapt = 0, t_hf = 0, t_hft = 0, t_hapf = 0, t_hapft = 0, t_sch = 0, t_req = 0, t_scal = 0, t_yw = 0, t_dense = 0;
-	std::vector<int> cls(n, 0); int cls_nbmax[SRBA_NCLS] = {0}; std::vector<Symbolic> sym(n); long long t_spcol = 0, t_sprow = 0, t_spitem = 0, t_spfill = 0;
+	std::vector<int> cls(n, 0), big_lds(n, 0); int cls_nbmax[SRBA_NCLS] = {0}; std::vector<Symbolic> sym(n); long long t_spcol = 0, t_sprow = 0, t_spitem = 0, t_spfill = 0;
 	for (int p = 0; p < n; p++) {
 		const srba_problem_capsule &k = caps[p]; ProbDesc &d = c->desc[p];
 		if (const char *why = validate_capsule(k)) { c->fail(std::string("upload: malformed capsule (") + why + ")"); return -1; }
@@ -764,7 +771,10 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 		d.o_bp = t_bp; d.o_colp = t_unk + p; d.o_bf = t_bf; d.o_colf = t_ulm + p; d.o_hap = t_hap; d.o_hapoff = t_hap + p; d.o_hapt = t_hapt; d.o_hf = t_hf; d.o_hfoff = t_hf + p; d.o_hft = t_hft;
 		d.o_hapf = t_hapf; d.o_hapfoff = t_hapf + p; d.o_hapft = t_hapft; d.o_sch = t_sch; d.o_lmoff = t_ulm + p; d.o_req = t_req; d.o_scal = t_scal; d.o_yw = t_yw; d.o_dense = t_dense;
 		d.nb = (d.n_sys + 2) / 3;
-		symbolic_factor(k, d, P, L, !schur_solver, sym[p]);
+		const bool surely_big = d.n_sys > c->big_min_sys; // far beyond what one wavefront's LDS holds: dense system on the multi-workgroup path, no block-sparse symbolic analysis
+		if (!surely_big) symbolic_factor(k, d, P, L, !schur_solver, sym[p]);
+		else { Symbolic &y = sym[p]; y.col_off.assign(d.nb + 1, 0); y.item_off.assign(d.nb + 1, 0); y.rptr.assign(d.nb + 1, 0); y.perm.resize(d.nb); for (int q = 0; q < d.nb; q++) y.perm[q] = q;
+			y.hap_dst.assign((size_t)k.n_hap * (P / 3) * (P / 3), 0); y.hapf_dst.assign((size_t)k.n_hapf * (P / 3), 0); y.hf_dst.assign(k.n_hf, 0); y.aligned = true; }
 		d.nnzoff = (int)sym[p].row.size(); d.n_items = (int)sym[p].tgt.size(); d.aligned = sym[p].aligned ? 1 : 0;
 		d.o_spcol = t_spcol; d.o_sprow = t_sprow; d.o_spitem = t_spitem; d.o_spperm = t_spcol - p;
 		t_spcol += d.nb + 1; t_sprow += d.nnzoff; t_spitem += (long long)sym[p].tgt.size();
@@ -776,13 +786,14 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 		// reserves little more LDS per wavefront than its capsules need; systems above 152 KB are factored in an HBM workspace
 		const size_t bytes = tri_n * 8;
 		static const int kClsKB[SRBA_NCLS - 1] = {6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64, 80, 96, 112, 128, 152};
-		cls[p] = SRBA_NCLS - 1; for (int q = 0; q < SRBA_NCLS - 1 && packable && kClsKB[q] <= c->max_lds_kb; q++) if (bytes <= (size_t)kClsKB[q] * 1024) { cls[p] = q; break; }
-		d.dense_in_lds = cls[p] < SRBA_NCLS - 1 ? 1 : 0; cls_nbmax[cls[p]] = std::max(cls_nbmax[cls[p]], (int)tri_n);
+		cls[p] = SRBA_NCLS - 1; for (int q = 0; q < SRBA_NCLS - 1 && packable && !surely_big && kClsKB[q] <= c->max_lds_kb; q++) if (bytes <= (size_t)kClsKB[q] * 1024) { cls[p] = q; break; }
+		d.dense_in_lds = cls[p] < SRBA_NCLS - 1 ? 1 : 0; if (d.dense_in_lds) cls_nbmax[cls[p]] = std::max(cls_nbmax[cls[p]], (int)tri_n);
+		const long long big_ld = d.dense_in_lds ? 0 : ((d.n_sys + srbadev::CB - 1) / srbadev::CB) * srbadev::CB; // dense path: ld x ld matrix + ld x CB diagonal factors + rhs + y
 		int nyw = 0; if (k.n_sch_terms > 0) for (int b = 0; b < k.n_hap; b++) if (k.hap_i[b] == k.hap_j[b]) nyw += k.sch_term_off[b + 1] - k.sch_term_off[b];
 		long long npath_needed = 0; for (int q = 0; q < k.n_pairs; q++) if (k.pair_needed[q]) { st.n_pairs_needed++; npath_needed += k.pair_path_off[q + 1] - k.pair_path_off[q]; }
 		st.n_path_needed += npath_needed;
 		t_edge += k.n_edges; t_unk += d.nK; t_ulm += d.nF; t_klm += d.n_klm; t_pair += k.n_pairs; t_path += k.n_path; t_obs += k.n_obs; t_valid += k.n_valid; t_bp += k.n_bp; t_bf += k.n_bf;
-		t_hap += k.n_hap; t_hapt += k.n_hap_terms; t_hf += k.n_hf; t_hft += k.n_hf_terms; t_hapf += k.n_hapf; t_hapft += k.n_hapf_terms; t_sch += k.n_sch_terms; t_req += nreq; t_scal += d.n_scal; t_yw += nyw; t_dense += d.dense_in_lds ? 0 : (long long)tri_n;
+		t_hap += k.n_hap; t_hapt += k.n_hap_terms; t_hf += k.n_hf; t_hft += k.n_hf_terms; t_hapf += k.n_hapf; t_hapft += k.n_hapf_terms; t_sch += k.n_sch_terms; t_req += nreq; t_scal += d.n_scal; t_yw += nyw; t_dense += big_ld * big_ld + big_ld * srbadev::CB + 2 * big_ld; big_lds[p] = (int)big_ld;
 	}
 	st.n_edges = t_edge; st.n_unk_edges = t_unk; st.n_unk_lms = t_ulm; st.n_pairs = t_pair; st.n_path = t_path; st.n_obs = t_obs; st.n_bp = t_bp; st.n_bf = t_bf; st.n_hap = t_hap; st.n_hap_terms = t_hapt;
 	st.n_hf_terms = t_hft; st.n_hapf_terms = t_hapft; st.n_sch_terms = t_sch; st.n_scalars = t_scal;
@@ -806,7 +817,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	o.hap_dst = in.add(4 * t_hap * (P / 3) * (P / 3)); o.hapf_dst = in.add(4 * t_hapf * (P / 3)); o.hf_dst = in.add(4 * t_hf);
 	in.add(0);
 	c->h_in.assign(in.size + 256, 0); char *h = c->h_in.data();
-	c->in_off_edge0 = o.edge0; c->in_off_ulm0 = o.ulm0;
+	c->in_off_edge0 = o.edge0; c->in_off_ulm0 = o.ulm0; c->h_off_order = o.order;
 	// ---- pass 2: pack
 #define CPY(dstoff, elem_off, src, count, T) do { if ((count) > 0) std::memcpy(h + (dstoff) + sizeof(T) * (size_t)(elem_off), (src), sizeof(T) * (size_t)(count)); } while (0)
 	for (int p = 0; p < n; p++) {
@@ -849,7 +860,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	}
 #undef CPY
 	std::memcpy(h + o.desc, c->desc.data(), sizeof(ProbDesc) * n);
-	c->cls_of = cls;
+	c->cls_of = cls; c->big_ld = big_lds;
 	{ // launch order: capsules grouped by LDS size class
 		int32_t *ord = (int32_t *)(h + o.order); int pos = 0;
 		for (int k = 0; k < SRBA_NCLS; k++) {
@@ -926,9 +937,8 @@ template <class F> static bool with_family(int family, F &&f) {
 #define SRBA_DISPATCH_N(c, KERNEL, nblocks, lds, ...) with_family((c)->params.family, [&](auto fam_) { \
 	hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), dim3(nblocks), dim3(SRBA_WG), (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); })
 #define SRBA_DISPATCH(c, KERNEL, lds, ...) SRBA_DISPATCH_N(c, KERNEL, (c)->n_prob, lds, ##__VA_ARGS__)
-#define SRBA_DISPATCH_LDS(c, KERNEL, inlds, nblocks, lds, ...) with_family((c)->params.family, [&](auto fam_) { \
-	if (inlds) hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value, true>), dim3(nblocks), dim3(SRBA_WG), (lds), launch_stream, (c)->B, (c)->dp, ##__VA_ARGS__); \
-	else hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value, false>), dim3(nblocks), dim3(SRBA_WG), (lds), launch_stream, (c)->B, (c)->dp, ##__VA_ARGS__); })
+#define SRBA_DISPATCH_LDS(c, KERNEL, nblocks, lds, ...) with_family((c)->params.family, [&](auto fam_) { \
+	hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), dim3(nblocks), dim3(SRBA_WG), (lds), launch_stream, (c)->B, (c)->dp, ##__VA_ARGS__); })
 
 template <class K> static int allow_big_lds(srba_hip_ctx *c, K kernel, size_t bytes) {
 	if (bytes > 64 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess) { c->fail(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e)); return -1; } }
@@ -939,13 +949,112 @@ static int prep_lds(srba_hip_ctx *c, bool for_lm) {
 	b += c->lds_pad;
 	if (b <= 64 * 1024) return 0;
 	int rc = -1;
-	with_family(c->params.family, [&](auto fam_) { constexpr int F = decltype(fam_)::value; rc = for_lm ? allow_big_lds(c, srbadev::k_lm_run<F, true>, b) : allow_big_lds(c, srbadev::k_solve<F, true>, b); });
+	with_family(c->params.family, [&](auto fam_) { constexpr int F = decltype(fam_)::value; rc = for_lm ? allow_big_lds(c, srbadev::k_lm_run<F>, b) : allow_big_lds(c, srbadev::k_solve<F>, b); });
 	return rc;
 }
 
 // The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable when it initialises: ask for 16
 // (one per concurrent launch stream of the plan) unless the user chose a value. No effect if the process already initialised HIP.
 __attribute__((constructor)) static void srba_hip_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
+
+// =================================================================================================== the multi-workgroup path for large capsules (srba_big.hpp)
+static inline int big_grid(long long items, int block) { return (int)std::max<long long>(1, std::min<long long>((items + block - 1) / block, 4096)); }
+static srbadev::BigSys big_sys(srba_hip_ctx *c, int p) {
+	const ProbDesc &d = c->desc[p]; const int ld = c->big_ld[p]; srbadev::BigSys S;
+	double *base = c->B.dense + d.o_dense; S.A = base; S.Ldiag = base + (size_t)ld * ld; S.rhs = S.Ldiag + (size_t)ld * srbadev::CB; S.y = S.rhs + ld; S.flag = c->d_iscal + 1; S.n = d.n_sys; S.ld = ld; return S;
+}
+#define BIGK(KERNEL, items, block, ...) with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), dim3(big_grid((items), (block))), dim3(block), 0, c->stream, c->B, c->dp, p, ##__VA_ARGS__); })
+// deterministic reduction of per-workgroup partials into d_scal[slot]
+static void big_reduce(srba_hip_ctx *c, int which, int nblk, int slot, int is_max) { hipLaunchKernelGGL(srbadev::kb_reduce, dim3(1), dim3(1), 0, c->stream, c->d_part + (size_t)which * kBigPart, nblk, c->d_scal + slot, is_max); }
+// solve(lambda) of lev-marq_solvers.h for one big capsule: Schur reduction (if the solver has one), dense blocked Cholesky, back-substitution, landmark increments
+static int big_solve(srba_hip_ctx *c, int p, double lambda, bool *pos_def) {
+	const ProbDesc &d = c->desc[p]; const srbadev::BigSys S = big_sys(c, p); const int P = c->dm.P;
+	const bool schur = c->params.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0;
+	if (schur) { BIGK(kb_schur_inv, std::max<long long>(d.nF, (long long)d.n_hap * P * P), 128, lambda); BIGK(kb_schur_reduce, d.n_hap, 128); BIGK(kb_schur_grad, d.nK, 128); }
+	hipLaunchKernelGGL(srbadev::kb_dense_clear, dim3(big_grid((long long)S.ld * S.ld, 256)), dim3(256), 0, c->stream, S);
+	BIGK(kb_dense_assemble, d.n_hap + d.n_hapf + d.n_hf, 128, S, lambda, schur ? 0 : 1);
+	for (int k0 = 0; k0 < S.ld; k0 += srbadev::CB) {
+		const int below = S.ld - k0 - srbadev::CB;
+		hipLaunchKernelGGL(srbadev::k_chol_panel, dim3(1 + (below + 63) / 64), dim3(64), 0, c->stream, S, k0);
+		if (below > 0) { const int nt = (below + srbadev::CT - 1) / srbadev::CT; hipLaunchKernelGGL(srbadev::k_chol_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, S, k0, nt); }
+	}
+	int flag = 0; HIPCHK(c, hipMemcpyAsync(&flag, S.flag, 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+	*pos_def = (flag == 0);
+	if (!*pos_def) return 0;
+	hipLaunchKernelGGL(srbadev::k_chol_bsub, dim3(1), dim3(256), 0, c->stream, S);
+	hipLaunchKernelGGL(srbadev::kb_take_delta, dim3(big_grid(d.n_scal, 256)), dim3(256), 0, c->stream, c->B, p, S);
+	if (schur) BIGK(kb_schur_features, d.nF, 128);
+	HIPCHK(c, hipGetLastError());
+	return 0;
+}
+// optimize_edges S5..S17 for one big capsule: the control flow of k_lm_run (optimize_edges.h:256-751) on the host, every phase a grid-wide launch
+static int big_lm_run(srba_hip_ctx *c, int p) {
+	const ProbDesc &d = c->desc[p]; const int O = c->dm.O, L = c->dm.L; const srba_hip_params &prm = c->params;
+	const bool schur = prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0;
+	srba_lm_result out; std::memset(&out, 0, sizeof(out));
+	for (int k = 0; k < SRBA_TRACE_LEN; k++) { out.trace_chi2[k] = NAN; out.trace_lambda[k] = NAN; out.trace_rho[k] = NAN; }
+	double *resid = c->B.resid, *resid2 = c->B.resid2;
+	auto residuals = [&](double *dst, double *val) -> int { const int nb = big_grid(d.n_obs, 256); BIGK(kb_residuals, d.n_obs, 256, dst, c->d_part); big_reduce(c, 0, nb, 0, 0);
+		HIPCHK(c, hipMemcpyAsync(val, c->d_scal, 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; };
+	auto linearize = [&]() { BIGK(kb_jac_init, d.n_valid, 256); BIGK(kb_jac, d.n_bp + d.n_bf, 128); BIGK(kb_jac_post, d.n_bp + d.n_bf, 256); BIGK(kb_hessian, d.n_hap + d.n_hf + d.n_hapf, 128, c->d_iscal); };
+	HIPCHK(c, hipMemsetAsync(c->d_iscal, 0, 32, c->stream));
+	BIGK(kb_spantree, d.n_pairs, 256, 0);   // S5
+	linearize();                            // S6, S7, S10
+	int ninv = 0; HIPCHK(c, hipMemcpyAsync(&ninv, c->d_iscal, 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+	out.num_invalid_jacobs = ninv; out.num_observations = d.n_obs; out.num_jacobians = d.n_bp + d.n_bf; out.num_span_tree_numeric_updates = d.n_pairs;
+	auto finish = [&]() -> int { HIPCHK(c, hipMemcpyAsync(c->B.results + p, &out, sizeof(out), hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; };
+	if ((long long)O * d.n_obs < (long long)d.n_scal) { out.status = 1; return finish(); } // S11
+	double lambda = 0, nu = 2.0, total_err = 0;
+	{ const int nb = big_grid(d.nK + d.nF, 256); BIGK(kb_maxdiag, d.nK + d.nF, 256, c->d_part); big_reduce(c, 0, nb, 1, 1); HIPCHK(c, hipMemcpyAsync(&lambda, c->d_scal + 1, 8, hipMemcpyDeviceToHost, c->stream)); } // S12
+	if (residuals(resid, &total_err) != 0) return -1;   // S13
+	lambda *= 1e-3; double RMSE = std::sqrt(total_err / d.n_obs);
+	out.lambda_init = lambda; out.total_sqr_error_init = total_err;
+	BIGK(kb_gradient, d.nK + d.nF, 128, resid); // S14
+	int iter = 0, trials = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0; bool stop = false;
+	for (iter = 0; iter < prm.max_iters && !stop; iter++) {
+		double rho = 0;
+		if (lambda >= prm.max_lambda) { stop = true; stopmask |= 1 << SRBA_STOP_LAMBDA; }
+		if (RMSE < prm.max_error_per_obs_to_stop) { stop = true; stopmask |= 1 << SRBA_STOP_RMSE; }
+		while (rho <= 0 && !stop) {
+			const int tr = trials++; if (tr < SRBA_TRACE_LEN) out.trace_lambda[tr] = lambda;
+			bool pd = true; if (big_solve(c, p, lambda, &pd) != 0) return -1;
+			if (!pd) { n_notpd++; lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA; continue; }
+			BIGK(kb_apply, d.nK + (long long)d.nF * L + d.n_req, 128);
+			BIGK(kb_spantree, d.n_need, 256, 1);
+			double new_err = 0; if (residuals(resid2, &new_err) != 0) return -1;
+			const double new_RMSE = std::sqrt(new_err / d.n_obs), err_red = total_err > 0 ? (total_err - new_err) / total_err : 0;
+			double dn[2] = {0, 0};
+			{ const int nb = big_grid(d.n_scal, 256); BIGK(kb_dot, d.n_scal, 256, lambda, c->d_part + kBigPart, c->d_part + 2 * kBigPart); big_reduce(c, 1, nb, 2, 0);
+			  HIPCHK(c, hipMemcpyAsync(dn, c->d_scal + 2, 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+			rho = (total_err - new_err) / dn[0];
+			if (tr < SRBA_TRACE_LEN) { out.trace_chi2[tr] = new_err; out.trace_rho[tr] = rho; }
+			if (rho > 0) {
+				n_acc++;
+				const bool relin = (err_red < 0 || err_red > prm.min_error_reduction_ratio_to_relinearize);
+				std::swap(resid, resid2); total_err = new_err; RMSE = new_RMSE;
+				if (relin) { n_relin++; linearize(); }
+				BIGK(kb_gradient, d.nK + d.nF, 128, resid);
+				double ninf = 0; { const int nb = big_grid(d.n_scal, 256); BIGK(kb_dot, d.n_scal, 256, lambda, c->d_part + kBigPart, c->d_part + 2 * kBigPart); big_reduce(c, 2, nb, 3, 1);
+				  HIPCHK(c, hipMemcpyAsync(&ninf, c->d_scal + 3, 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+				if (ninf <= 1e-15) { stop = true; stopmask |= 1 << SRBA_STOP_GRADIENT; }
+				if (RMSE < prm.max_error_per_obs_to_stop) { stop = true; stopmask |= 1 << SRBA_STOP_RMSE; }
+				if (rho > prm.max_rho) { stop = true; stopmask |= 1 << SRBA_STOP_RHO; }
+				lambda *= 1.0 / 3.0; nu = 2.0;
+			} else {
+				BIGK(kb_restore, d.nK + (long long)d.nF * L + d.n_req, 128);
+				lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
+			}
+		}
+	}
+	if (!stop) stopmask |= 1 << SRBA_STOP_MAX_ITERS;
+	BIGK(kb_cov_recovery, std::max(d.nF, 1), 128, schur ? 1 : 0); // S17
+	out.num_iters = iter; out.num_trials = trials; out.num_not_pd = n_notpd; out.num_accepted = n_acc; out.num_relinearized = n_relin; out.stop_reason = stopmask;
+	out.total_sqr_error_final = total_err; out.obs_rmse = RMSE; out.lambda_final = lambda;
+	HIPCHK(c, hipGetLastError());
+	return finish();
+}
+#undef BIGK
 
 extern "C" {
 
@@ -961,14 +1070,18 @@ int srba_hip_lm_run_async(srba_hip_ctx *c) {
 	HIPCHK(c, hipEventRecord(c->ev0, c->stream));
 	HIPCHK(c, hipMemsetAsync(c->d_next, 0, sizeof(int) * kMaxJobs, c->stream)); // work counters of the persistent launches
 	// fork/join: the launch plan (made at upload) spreads the size classes over a few streams; see plan_launches()
-	const int nq = c->plan.size() == 1 ? 1 : c->n_streams_used; // a single launch (the per-key-frame use) stays on the context stream: no fork / join
+	const int nq = c->plan.size() <= 1 ? 1 : c->n_streams_used; // a single launch (the per-key-frame use) stays on the context stream: no fork / join
 	if (nq > 1) HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
 	for (int q = 1; q < nq; q++) HIPCHK(c, hipStreamWaitEvent(c->cls_stream[q], c->ev_fork, 0));
 	for (size_t j = 0; j < c->plan.size(); j++) {
 		const LaunchJob &J = c->plan[j]; const int k = J.cls;
 		hipStream_t launch_stream = (J.queue && nq > 1) ? c->cls_stream[J.queue] : c->stream;
-		SRBA_DISPATCH_LDS(c, k_lm_run, k < SRBA_NCLS - 1, J.grid, c->cls_lds[k] + c->lds_pad, J.first, J.count, c->d_next + j); HIPCHK(c, hipGetLastError());
+		SRBA_DISPATCH_LDS(c, k_lm_run, J.grid, c->cls_lds[k] + c->lds_pad, J.first, J.count, c->d_next + j); HIPCHK(c, hipGetLastError());
 	}
+	// capsules too large for one wavefront's LDS: the multi-workgroup path, one capsule after the other on the context stream (host-driven LM loop: this part
+	// of the call synchronises with the device once per LM trial), overlapping with the persistent launches of the other classes on their own streams
+	{ const int32_t *ord = (const int32_t *)(c->h_in.data() + c->h_off_order);
+	  for (int i = 0; i < c->cls_count[SRBA_NCLS - 1]; i++) if (big_lm_run(c, ord[c->cls_first[SRBA_NCLS - 1] + i]) != 0) return -1; }
 	for (int q = 1; q < nq; q++) { HIPCHK(c, hipEventRecord(c->cls_done[q], c->cls_stream[q])); HIPCHK(c, hipStreamWaitEvent(c->stream, c->cls_done[q], 0)); }
 	HIPCHK(c, hipEventRecord(c->ev1, c->stream));
 	return 0;
@@ -1042,7 +1155,10 @@ int srba_hip_solve(srba_hip_ctx *c, const double *lambda, int32_t *not_pd_out) {
 	if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device));
 	if (lambda) HIPCHK(c, hipMemcpyAsync(c->B.lambda_io, lambda, 8 * (size_t)c->n_prob, hipMemcpyHostToDevice, c->stream)); // else: use the lambda guess left by srba_hip_linearize
 	if (prep_lds(c, false) != 0) return -1;
-	for (int k = 0; k < SRBA_NCLS; k++) if (c->cls_count[k]) { hipStream_t launch_stream = c->stream; SRBA_DISPATCH_LDS(c, k_solve, k < SRBA_NCLS - 1, c->cls_count[k], c->cls_lds[k], c->cls_first[k]); HIPCHK(c, hipGetLastError()); }
+	for (int k = 0; k < SRBA_NCLS - 1; k++) if (c->cls_count[k]) { hipStream_t launch_stream = c->stream; SRBA_DISPATCH_LDS(c, k_solve, c->cls_count[k], c->cls_lds[k], c->cls_first[k]); HIPCHK(c, hipGetLastError()); }
+	{ const int32_t *ord = (const int32_t *)(c->h_in.data() + c->h_off_order); // dense multi-workgroup solver for the capsules of the big class
+	  for (int i = 0; i < c->cls_count[SRBA_NCLS - 1]; i++) { const int p = ord[c->cls_first[SRBA_NCLS - 1] + i]; double lam = 0; HIPCHK(c, hipMemcpyAsync(&lam, c->B.lambda_io + p, 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+		bool pd = true; if (big_solve(c, p, lam, &pd) != 0) return -1; const int np = pd ? 0 : 1; HIPCHK(c, hipMemcpyAsync(c->B.notpd + p, &np, 4, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); } }
 	if (not_pd_out) { HIPCHK(c, hipMemcpyAsync(not_pd_out, c->B.notpd, 4 * (size_t)c->n_prob, hipMemcpyDeviceToHost, c->stream)); }
 	HIPCHK(c, hipStreamSynchronize(c->stream)); return 0;
 }

@@ -138,15 +138,32 @@ def test_eval_overall_squared_error_hip_vs_oracle():
 
 
 @pytest.mark.gpu
-def test_hbm_workspace_path_and_mixed_classes(se2_batch, monkeypatch):
-    """Systems too large for the LDS classes are factored in an HBM workspace (same code, global pointers, full barriers). The knob
-    SRBA_HIP_MAX_LDS_KB forces that path: all capsules (0) or only the larger ones (10 KB -> a ragged mix of LDS and HBM launches)."""
-    ref = _oracle.run_batch(se2_batch)
+def test_big_capsule_path_and_mixed_classes(se2_batch, monkeypatch):
+    """Capsules whose system does not fit one wavefront's LDS run on the multi-workgroup path (srba_big.hpp: grid-wide phase kernels, dense blocked Cholesky with FP64
+    MFMA updates, LM control on the host). The knob SRBA_HIP_MAX_LDS_KB forces ordinary capsules onto it: all of a batch (0), or only its larger ones (10 KB -> a mix of
+    persistent one-wavefront launches and big-path capsules in the same call)."""
+    sub = se2_batch.sub(se2_batch.n - 60, 60)
+    ref = _oracle.run_batch(sub)
     for kb in ("0", "10"):
         monkeypatch.setenv("SRBA_HIP_MAX_LDS_KB", kb)
-        gpu = runner.run_batch_hip(se2_batch)
-        _compare_lm(se2_batch, gpu, ref)
+        gpu = runner.run_batch_hip(sub)
+        _compare_lm(sub, gpu, ref)
     monkeypatch.delenv("SRBA_HIP_MAX_LDS_KB")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,solver", [("stereo", capi.SOLVER_SCHUR_DENSE), ("mono", capi.SOLVER_SCHUR_DENSE), ("cart3d", capi.SOLVER_NO_SCHUR_SPARSE), ("rb2d", capi.SOLVER_SCHUR_SPARSE)])
+def test_big_capsule_path_landmark_families(kind, solver, monkeypatch):
+    """The same path with landmarks: Schur reduction, dense reduced system, landmark back-substitution (and the full system for the no-Schur solver), forced on small capsules."""
+    from test_oracle_numeric import _harvest
+    b = _harvest(kind, solver=solver, n_kf=12)
+    sub = b.sub(max(0, b.n - 5), min(5, b.n)); ref = _oracle.run_batch(sub)
+    monkeypatch.setenv("SRBA_HIP_MAX_LDS_KB", "0")
+    gpu = runner.run_batch_hip(sub)
+    monkeypatch.delenv("SRBA_HIP_MAX_LDS_KB")
+    assert np.all(gpu["status"] == ref["status"]) and _close(gpu["chi2_init"], ref["chi2_init"], rel=1e-9)
+    assert _close(gpu["chi2_final"], ref["chi2_final"], rel=1e-6, abs_=1e-18)
+    assert np.array_equal(gpu["num_observations"], ref["num_observations"]) and np.array_equal(gpu["num_jacobians"], ref["num_jacobians"])
 
 
 @pytest.mark.gpu
