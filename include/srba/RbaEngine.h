@@ -322,9 +322,13 @@ public:
 		 *  optimised columns read (optimize_edges.h:550-566); residuals of observations whose observer-side edge is not optimised are then evaluated with
 		 *  pre-step poses. true: every pose a residual reads is refreshed as well. */
 		bool refresh_all_read_poses;
+		/** (extension, default false = reference behaviour) every LM trial recomputes BOTH poses num[r][t], num[t][r] of a refreshed spanning-tree pair, but a rejected step restores only
+		 *  the ones Jacobian blocks read (optimize_edges.h:664-670): the twin keeps the value of the rejected trial until some later optimisation refreshes it, and meanwhile
+		 *  determine_kf2kf_edges_to_create may seed the next edge from it. true: back up and restore both. */
+		bool restore_spanning_tree_twins;
 		TSRBAParameters() : max_tree_depth(4), max_optimize_depth(4), optimize_new_edges_alone(true), use_robust_kernel(false), use_robust_kernel_stage1(false), kernel_param(3.), max_iters(20),
 			max_error_per_obs_to_stop(1e-6), max_rho(10.0), max_lambda(1e20), min_error_reduction_ratio_to_relinearize(0.01), numeric_jacobians(false), feedback_user_iteration(NULL),
-			compute_condition_number(false), compute_sparsity_stats(false), max_rmse_show_red_warning(0.5), cov_recovery(crpLandmarksApprox), refresh_all_read_poses(false) {}
+			compute_condition_number(false), compute_sparsity_stats(false), max_rmse_show_red_warning(0.5), cov_recovery(crpLandmarksApprox), refresh_all_read_poses(false), restore_spanning_tree_twins(false) {}
 		void dumpToConsole() const { std::cout << "max_tree_depth=" << max_tree_depth << " max_optimize_depth=" << max_optimize_depth << " optimize_new_edges_alone=" << optimize_new_edges_alone << " use_robust_kernel=" << use_robust_kernel
 			<< " kernel_param=" << kernel_param << " max_iters=" << max_iters << " max_error_per_obs_to_stop=" << max_error_per_obs_to_stop << " max_rho=" << max_rho << " max_lambda=" << max_lambda << "\n"; }
 	};
@@ -641,7 +645,7 @@ protected:
 		graph::topology &T = rba_state.topo;
 		CapsuleData &cd = m_cd; graph::capsule_index &ix = m_ix;
 		{ internal::profiler_scope p2(m_profiler, "opt.capsule");
-		  if (!m_builder.build(T, run_k2k_edges_in, run_feat_ids_in, in_observation_indices_to_optimize, parameters.srba.refresh_all_read_poses, RBA_OPTIONS::solver_t::USE_SCHUR, P, L, O, PD, cd, ix)) return;
+		  if (!m_builder.build(T, run_k2k_edges_in, run_feat_ids_in, in_observation_indices_to_optimize, parameters.srba.refresh_all_read_poses, RBA_OPTIONS::solver_t::USE_SCHUR, P, L, O, PD, cd, ix, parameters.srba.restore_spanning_tree_twins)) return;
 		  // typed payload
 		  cd.edge_pose.resize(ix.edge_ids.size() * PD); for (size_t i = 0; i < ix.edge_ids.size(); i++) rba_state.k2k_edges[ix.edge_ids[i]].inv_pose.storeTo(&cd.edge_pose[i * PD]);
 		  cd.ulm_pos.resize(ix.unk_lms.size() * L); for (size_t i = 0; i < ix.unk_lms.size(); i++) for (int k = 0; k < L; k++) cd.ulm_pos[i * L + k] = rba_state.lm_table[ix.unk_lms[i]].pos[k];

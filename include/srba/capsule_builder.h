@@ -35,7 +35,7 @@ public:
 	capsule_builder() : m_tag(0) {}
 	/** false: nothing left to optimise after filtering */
 	bool build(topology &T, const std::vector<size_t> &edges_in, const std::vector<size_t> &lms_in, const std::vector<size_t> &obs_subset,
-	           bool refresh_all_read_poses, bool with_schur, int P, int L, int O, int PD, CapsuleData &cd, capsule_index &ix) {
+	           bool refresh_all_read_poses, bool with_schur, int P, int L, int O, int PD, CapsuleData &cd, capsule_index &ix, bool restore_twins = false) {
 		next_tag(T);
 		ix.edge_ids.clear(); ix.unk_lms.clear(); ix.const_lms.clear(); ix.obs_rows.clear(); ix.pairs.clear();
 		// ---- S1
@@ -134,6 +134,7 @@ public:
 			cd.colf_off.push_back((int32_t)cd.bf_col.size());
 		}
 		for (size_t p = 0; p < nPairs; p++) cd.pair_needed[p] = (cd.pose_required[2 * p] || cd.pose_required[2 * p + 1]) ? 1 : 0;
+		if (restore_twins) for (size_t p = 0; p < nPairs; p++) if (cd.pair_needed[p]) cd.pose_required[2 * p] = cd.pose_required[2 * p + 1] = 1; // (extension) back up / restore both poses of every refreshed pair
 		cd.pair_kfs.resize(nPairs); for (size_t p = 0; p < nPairs; p++) cd.pair_kfs[p] = std::make_pair((uint64_t)ix.pairs[p].first, (uint64_t)ix.pairs[p].second);
 		cd.build_plan(m_bp_row, m_bf_row, with_schur);
 		return true;

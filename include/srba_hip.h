@@ -282,6 +282,9 @@ typedef struct srba_batch_stats {
 } srba_batch_stats;
 int  srba_hip_batch_stats(srba_hip_ctx *ctx, srba_batch_stats *out);
 
+/* Large-window path (capsules whose system does not fit one wavefront's LDS; srba_amd/csrc/srba_big.hpp): dense Cholesky factorisations since the last upload.
+ * out = { total milliseconds inside the blocked factorisation (HIP events on the context stream), total flops ld^3/3, number of factorisations, largest system }. */
+int    srba_hip_big_path_stats(srba_hip_ctx *ctx, double out[4]);
 /* Time (ms) spent inside the last srba_hip_lm_run* kernel launch, measured with HIP events on the context stream. */
 double srba_hip_last_kernel_ms(srba_hip_ctx *ctx);
 /* Durations (ms, most recent first) of the last `n` srba_hip_lm_run / srba_hip_lm_run_async launches: HIP events recorded on the context

@@ -77,7 +77,7 @@ struct EngineImpl : public EngineBase {
 		s.max_tree_depth = c.max_tree_depth; s.max_optimize_depth = c.max_optimize_depth; s.optimize_new_edges_alone = c.optimize_new_edges_alone != 0;
 		s.use_robust_kernel = c.use_robust_kernel != 0; s.use_robust_kernel_stage1 = c.use_robust_kernel_stage1 != 0; s.kernel_param = c.kernel_param; s.max_iters = c.max_iters;
 		s.max_error_per_obs_to_stop = c.max_error_per_obs_to_stop; s.max_rho = c.max_rho; s.max_lambda = c.max_lambda; s.min_error_reduction_ratio_to_relinearize = c.min_error_reduction_ratio_to_relinearize;
-		s.cov_recovery = c.cov_recovery ? crpLandmarksApprox : crpNone; s.refresh_all_read_poses = c.refresh_all_read_poses != 0;
+		s.cov_recovery = c.cov_recovery ? crpLandmarksApprox : crpNone; s.refresh_all_read_poses = (c.refresh_all_read_poses & 1) != 0; s.restore_spanning_tree_twins = (c.refresh_all_read_poses & 2) != 0; // bit 0 / bit 1 of the config field: the two extensions of SURVEY App. B-12
 		ecp_io<ECP>::set(rba.parameters.ecp, c);
 		noise_io<NOISE>::set(rba.parameters.obs_noise, c); spose_io<SPOSE>::set(rba.parameters.sensor_pose, c); sensor_io<OBS>::set(rba.parameters.sensor, c);
 		rba.set_hip_device(c.hip_device);

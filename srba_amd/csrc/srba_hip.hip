@@ -586,6 +586,7 @@ struct srba_hip_ctx {
 	char *d_in = nullptr; size_t cap_in = 0; char *d_wk = nullptr; size_t cap_wk = 0; int *d_next = nullptr;
 	double *d_part = nullptr; double *d_scal = nullptr; int *d_iscal = nullptr; // big path: partial sums [3][kBigPart], scalars, int flags (ninv, not-pd)
 	std::vector<int> big_ld; // per capsule: leading dimension of its dense system when it runs on the big path, else 0
+	double big_chol_ms = 0, big_chol_flops = 0; long long big_chol_count = 0; int big_chol_nmax = 0; hipEvent_t big_e0 = nullptr, big_e1 = nullptr; // Cholesky time / flops of the big path since the last upload
 	int big_min_sys = 480;   // systems with more scalar unknowns than this skip the block-sparse symbolic analysis and go dense (big path)
 	std::vector<char> h_in; size_t h_off_order = 0; // host staging of the input arena (kept: the launch order is read back from it)
 	int max_lds_kb = 1 << 20, min_chunk = 384, max_parts_per_queue = 2; int n_queues = 16, sched = 3, n_streams_used = 1, n_cu = 256, waves_per_cu = 8, lds_per_cu = 160 * 1024; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
@@ -752,6 +753,7 @@ int srba_hip_kernel_ms_history(srba_hip_ctx *c, double *out_ms, int n) {
 int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, int n) {
 	if (!c || !caps || n <= 0) { if (c) c->fail("upload: bad arguments"); return -1; }
 	HIPCHK(c, hipSetDevice(c->device));
+	c->big_chol_ms = c->big_chol_flops = 0; c->big_chol_count = 0; c->big_chol_nmax = 0;
 	c->n_prob = 0; // whatever was uploaded before stops being launchable / readable now: a failed upload leaves the context empty, not half-updated
 	const int P = c->dm.P, L = c->dm.L, O = c->dm.O, PD = c->dm.PD, PDX = c->dm.PDX();
 	const bool schur_solver = c->params.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL;
@@ -920,6 +922,7 @@ int srba_hip_reset_state(srba_hip_ctx *c) {
 	return 0;
 }
 
+int srba_hip_big_path_stats(srba_hip_ctx *c, double out[4]) { if (!c || !out) return -1; out[0] = c->big_chol_ms; out[1] = c->big_chol_flops; out[2] = (double)c->big_chol_count; out[3] = c->big_chol_nmax; return 0; }
 int srba_hip_batch_stats(srba_hip_ctx *c, srba_batch_stats *out) { if (!c || !out) return -1; *out = c->stats; return 0; }
 
 } // extern "C"
@@ -974,12 +977,16 @@ static int big_solve(srba_hip_ctx *c, int p, double lambda, bool *pos_def) {
 	if (schur) { BIGK(kb_schur_inv, std::max<long long>(d.nF, (long long)d.n_hap * P * P), 128, lambda); BIGK(kb_schur_reduce, d.n_hap, 128); BIGK(kb_schur_grad, d.nK, 128); }
 	hipLaunchKernelGGL(srbadev::kb_dense_clear, dim3(big_grid((long long)S.ld * S.ld, 256)), dim3(256), 0, c->stream, S);
 	BIGK(kb_dense_assemble, d.n_hap + d.n_hapf + d.n_hf, 128, S, lambda, schur ? 0 : 1);
+	if (!c->big_e0) { HIPCHK(c, hipEventCreate(&c->big_e0)); HIPCHK(c, hipEventCreate(&c->big_e1)); }
+	HIPCHK(c, hipEventRecord(c->big_e0, c->stream));
 	for (int k0 = 0; k0 < S.ld; k0 += srbadev::CB) {
 		const int below = S.ld - k0 - srbadev::CB;
 		hipLaunchKernelGGL(srbadev::k_chol_panel, dim3(1 + (below + 63) / 64), dim3(64), 0, c->stream, S, k0);
 		if (below > 0) { const int nt = (below + srbadev::CT - 1) / srbadev::CT; hipLaunchKernelGGL(srbadev::k_chol_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, S, k0, nt); }
 	}
+	HIPCHK(c, hipEventRecord(c->big_e1, c->stream));
 	int flag = 0; HIPCHK(c, hipMemcpyAsync(&flag, S.flag, 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+	{ float ms = 0; if (hipEventElapsedTime(&ms, c->big_e0, c->big_e1) == hipSuccess) { c->big_chol_ms += ms; c->big_chol_flops += (double)S.ld * S.ld * S.ld / 3.0; c->big_chol_count++; c->big_chol_nmax = std::max(c->big_chol_nmax, S.n); } }
 	*pos_def = (flag == 0);
 	if (!*pos_def) return 0;
 	hipLaunchKernelGGL(srbadev::k_chol_bsub, dim3(1), dim3(256), 0, c->stream, S);

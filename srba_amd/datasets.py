@@ -263,6 +263,42 @@ def landmarks_dataset_se3(kind="cart3d", n_kf=40, n_lm=400, seed=1, max_range=5.
     return out, gt
 
 
+def mono_deep_window(n_kf=500, n_lm=20000, seed=1, step=0.35, max_range=6.0, noise=0.5, cam=(200.0, 200.0, 400.0, 320.0), init_noise=0.05, fix_first_kf=True):
+    """BASELINE config 4 at any scale ("synthetic monocular SE3, 5k KFs x 200k landmarks, deep local window"): one lap of a wide circle with gentle 3D motion, point landmarks in a
+    band around the path, forward-looking monocular camera (fx fy cx cy of tutorial-srba-monocular-se3.cpp:125-131, mounted through CAMERA_ON_ROBOT), pixel noise, every landmark
+    entered with an initial value near the truth (is_unknown_with_init_val, as SURVEY 8d prescribes). The landmarks first seen from key-frame 0 are given as FIXED (known
+    relative position) when fix_first_kf is set: a monocular map has a free global scale, and along that flat direction the reference's LM takes wild rejected steps whose
+    spanning-tree twins are never restored and then seed the next edge -- pinning the scale keeps the synthetic run meaningful.
+    Meant for max_tree_depth = max_optimize_depth = 8, submap 20.
+    Returns (dataset, gt_poses)."""
+    rng = np.random.RandomState(seed)
+    radius = max(20.0, step * n_kf / (2 * math.pi) * 1.15)   # short maps walk an arc of a 20 m circle, long ones a full lap
+    gt = []
+    for k in range(n_kf):
+        a = step * k / radius
+        gt.append(pose3(radius * math.cos(a), radius * math.sin(a), 0.4 * math.sin(3 * a), a + math.pi / 2 + 0.03 * rng.randn(), 0.04 * math.sin(5 * a), 0.03 * math.cos(4 * a)))
+    ang = rng.uniform(-0.1, step * n_kf / radius + 0.35, n_lm); rad = radius + rng.uniform(-5.0, 5.0, n_lm)
+    lms = np.column_stack([rad * np.cos(ang), rad * np.sin(ang), rng.uniform(-2.0, 2.0, n_lm)])
+    S = pose3(*CAMERA_ON_ROBOT); fx, fy, cx, cy = cam
+    seen = np.zeros(n_lm, bool); out = []
+    for kf, T in enumerate(gt):
+        Ts = np.linalg.inv(T @ S); Tr = np.linalg.inv(T)
+        q = (Ts[:3, :3] @ lms.T).T + Ts[:3, 3]
+        ok = (q[:, 2] > 0.5) & (np.linalg.norm(q, axis=1) < max_range)
+        u = cx + fx * q[:, 0] / np.where(ok, q[:, 2], 1.0); v = cy + fy * q[:, 1] / np.where(ok, q[:, 2], 1.0)
+        ok &= (u >= 0) & (u < 2 * cx) & (v >= 0) & (v < 2 * cy)
+        idx = np.flatnonzero(ok)
+        z = np.column_stack([u[idx], v[idx]]) + noise * rng.randn(len(idx), 2)
+        first = ~seen[idx]; seen[idx] = True
+        rel = (Tr[:3, :3] @ lms[idx].T).T + Tr[:3, 3] + init_noise * rng.randn(len(idx), 3)
+        if kf == 0 and fix_first_kf:
+            rel = (Tr[:3, :3] @ lms[idx].T).T + Tr[:3, 3]; flags = np.full(len(idx), FLAG_FIXED, np.uint8)
+        else:
+            flags = np.where(first, FLAG_INIT, 0).astype(np.uint8)
+        out.append(dict(feat_ids=idx.astype(np.uint64), z=z, flags=flags, relpos=np.where(first[:, None], rel, 0.0)))
+    return out, gt
+
+
 def ypr_of(R):
     return np.array([math.atan2(R[1, 0], R[0, 0]), math.asin(-R[2, 0]), math.atan2(R[2, 1], R[2, 2])])
 

@@ -325,3 +325,31 @@ def test_new_families_through_the_engine_with_hip_backend():
     fr, to, pose = eng2.edges()
     for k in range(len(fr)):
         assert np.abs(pose[k] - np.array(datasets._inv_compose2(gt2[int(fr[k])], gt2[int(to[k])]))).max() < 5e-3
+
+
+@pytest.mark.gpu
+def test_deep_monocular_window_on_the_big_path_matches_oracle():
+    """BASELINE config 4 at reduced scale (100 key-frames, 2 000 landmarks, max_tree_depth = max_optimize_depth = 8, sub-maps of 20, Schur + dense Cholesky): the local area
+    covers the whole map -- ~100 unknown edges (a dense reduced system of ~600), ~1 600 unknown landmarks, ~35 000 observations per capsule -- and runs on the multi-workgroup
+    path (grid-wide phases, blocked Cholesky with FP64 MFMA updates). chi2 against the oracle at 1e-6, identical counters, same accept / reject prefix."""
+    ds, _ = datasets.mono_deep_window(n_kf=100, n_lm=2000, seed=1)
+    eng = runner.landmark_engine("mono", backend=_oracle.BACKEND, depth=8, submap=20, sigma=0.5, robust=0, harvest=1, cam=(200., 200., 400., 320.), refresh_all_read_poses=2)
+    eng.run(ds); b = eng.harvest(); b.engine = eng
+    sub = b.sub(b.n - 2, 2)
+    assert sub[1].n_unk_edges == 99 and sub[1].n_unk_lms > 1000 and sub[1].n_obs > 20000
+    ref = _oracle.run_batch(sub, keep_state=True)
+    ctx = runner.HipContext(sub.params); ctx.upload(sub); gpu = ctx.lm_run()
+    import ctypes as C
+    st = (C.c_double * 4)(); ctx.lib.srba_hip_big_path_stats(ctx.ctx, st)
+    assert st[2] >= gpu["num_trials"].sum() - gpu["num_not_pd"].sum() and st[3] == 6 * 99   # every solve went through the dense blocked factorisation of the 594-unknown reduced system
+    assert np.all(gpu["status"] == 0) and np.array_equal(gpu["num_observations"], ref["num_observations"]) and np.array_equal(gpu["num_jacobians"], ref["num_jacobians"])
+    assert _close(gpu["chi2_init"], ref["chi2_init"], rel=1e-9) and _close(gpu["lambda_init"], ref["lambda_init"], rel=1e-9)
+    assert _close(gpu["chi2_final"], ref["chi2_final"], rel=1e-6)
+    for i in range(sub.n):   # accepted / rejected decisions agree while both are away from the rounding floor
+        m = min(gpu["num_trials"][i], ref["num_trials"][i], 4)
+        assert np.array_equal(np.sign(gpu["trace_rho"][i][:m]), np.sign(ref["trace_rho"][i][:m]))
+        assert _close(gpu["trace_chi2"][i][:m], ref["trace_chi2"][i][:m], rel=1e-6)
+    work = sub.clone(); ctx._chk(ctx.lib.srba_hip_download_state(ctx.ctx, work.ptr, work.n), "download"); ctx.close()
+    for i in range(sub.n):
+        g = work.array(i, "edge_pose", np.float64, sub[i].n_unk_edges * 12); c = ref["state"].array(i, "edge_pose", np.float64, sub[i].n_unk_edges * 12)
+        assert np.allclose(g, c, rtol=1e-5, atol=1e-6), i
