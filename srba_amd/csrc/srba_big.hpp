@@ -25,84 +25,114 @@ struct BigSys { double *A; double *Ldiag; double *rhs; double *y; int *flag; int
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-// In-LDS Cholesky of a CB x CB block (row-major, leading dimension CB+1) by one wavefront: lane = row. Uniform result.
-__device__ __forceinline__ bool chol_block_lds(double *S, int lane) {
-	bool ok = true;
+__device__ __forceinline__ double lane_bcast(double v, int l) { // l is wave-uniform
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+	return __hiloint2double(hi, lo);
+}
+// 1/sqrt(d) in full double precision without the sqrt + divide sequences: v_rsq_f64 seed, two Newton steps
+__device__ __forceinline__ double rsqrt_nr(double d) {
+	double r = __builtin_amdgcn_rsq(d);
+	r = r * (1.5 - 0.5 * d * r * r); r = r * (1.5 - 0.5 * d * r * r);
+	return r;
+}
+// Cholesky of a CB x CB block held one ROW PER LANE in registers (a[c] = A[lane][c]): the pivot and the column of L travel by v_readlane, no LDS round trip on
+// the critical path. Lanes >= CB may carry extra rows b^t of an augmented matrix [A b; b^t .]: they come out as (L^-1 b)^t, i.e. the forward substitution of a
+// right-hand side rides along for free. rinv[j] = 1 / L_jj (every lane). Uniform result.
+__device__ __forceinline__ bool chol_block_regs(double (&a)[CB], double (&rinv)[CB], int lane) {
+#pragma unroll
 	for (int j = 0; j < CB; j++) {
-		const double d = S[j * (CB + 1) + j];
-		if (!(d > 0.0)) { ok = false; break; }
-		const double r = 1.0 / sqrt(d);
-		double lij = 0;
-		if (lane > j && lane < CB) { lij = S[lane * (CB + 1) + j] * r; S[lane * (CB + 1) + j] = lij; }
-		if (lane == j) S[j * (CB + 1) + j] = d * r;
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		if (lane > j && lane < CB) for (int k = j + 1; k <= lane; k++) S[lane * (CB + 1) + k] -= lij * S[k * (CB + 1) + j];
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		const double d = lane_bcast(a[j], j);
+		if (!(d > 0.0)) return false;
+		const double r = rsqrt_nr(d); rinv[j] = r;
+		const double l = (lane == j) ? d * r : ((lane > j) ? a[j] * r : 0.0);
+		a[j] = l;
+#pragma unroll
+		for (int k = j + 1; k < CB; k++) a[k] -= l * lane_bcast(l, k); // only the lower part (lane >= k) is ever read back
 	}
-	return ok;
+	return true;
 }
 
-// Panel step k0: workgroup 0 owns the diagonal block (writes L_kk to Ldiag and y_k), workgroup b >= 1 owns rows k0+CB+64(b-1) .. +63 of the panel.
+// Panel step k0: every workgroup factors the diagonal block itself (registers, lane CB carries the right-hand side); workgroup 0 publishes L_kk (Ldiag) and
+// y_k, workgroup b >= 1 solves rows k0+CB+64(b-1) .. +63 of the panel against it and eliminates them from the right-hand side.
 __global__ void __launch_bounds__(64) k_chol_panel(const BigSys S, int k0) {
-	__shared__ double Ls[CB * (CB + 1)]; __shared__ double ys[CB];
+	__shared__ double Ls[(CB + 1) * (CB + 1)]; __shared__ double ri[CB];
 	const int lane = threadIdx.x, ld = S.ld;
-	for (int e = lane; e < CB * CB; e += 64) { const int r = e / CB, c = e % CB; Ls[r * (CB + 1) + c] = (c <= r) ? S.A[(size_t)(k0 + r) * ld + k0 + c] : 0.0; }
-	__syncthreads();
-	if (!chol_block_lds(Ls, lane)) { if (blockIdx.x == 0 && lane == 0) *S.flag = 1; return; }
-	// y_k = L_kk^-1 rhs_k (every workgroup needs it; only workgroup 0 publishes it)
-	if (lane < CB) ys[lane] = S.rhs[k0 + lane];
-	__syncthreads();
-	for (int j = 0; j < CB; j++) {
-		if (lane == j) ys[j] = ys[j] / Ls[j * (CB + 1) + j];
-		__syncthreads();
-		if (lane > j && lane < CB) ys[lane] -= Ls[lane * (CB + 1) + j] * ys[j];
-		__syncthreads();
+	if (*S.flag) return; // an earlier panel met a non-positive pivot
+	const int row = k0 + CB + 64 * ((int)blockIdx.x - 1) + lane; const bool has_row = blockIdx.x > 0 && row < ld;
+	double *Arow = (double *)__builtin_assume_aligned(S.A + (size_t)(has_row ? row : k0) * ld + k0, 16);
+	double x[CB];
+	if (has_row) { // issued first: in flight while the diagonal block is factored
+#pragma unroll
+		for (int c = 0; c < CB; c++) x[c] = Arow[c];
 	}
+	double a[CB], rinv[CB];
+	{ const double *src = (const double *)__builtin_assume_aligned(S.A + (size_t)(k0 + (lane & (CB - 1))) * ld + k0, 16);
+	  const double *rh = (const double *)__builtin_assume_aligned(S.rhs + k0, 16);
+#pragma unroll
+	  for (int c = 0; c < CB; c++) { const double v = src[c], b = rh[c]; a[c] = lane < CB ? (c <= lane ? v : 0.0) : (lane == CB ? b : 0.0); } }
+	if (!chol_block_regs(a, rinv, lane)) { if (blockIdx.x == 0 && lane == 0) *S.flag = 1; return; }
 	if (blockIdx.x == 0) {
-		for (int e = lane; e < CB * CB; e += 64) { const int r = e / CB, c = e % CB; S.Ldiag[(size_t)(k0 + r) * CB + c] = Ls[r * (CB + 1) + c]; }
-		if (lane < CB) S.y[k0 + lane] = ys[lane];
+		if (lane < CB) {
+			double *dst = (double *)__builtin_assume_aligned(S.Ldiag + (size_t)(k0 + lane) * CB, 16);
+#pragma unroll
+			for (int c = 0; c < CB; c++) dst[c] = a[c];
+		} else if (lane == CB) {
+#pragma unroll
+			for (int c = 0; c < CB; c++) S.y[k0 + c] = a[c];
+		}
 		return;
 	}
-	const int row = k0 + CB + 64 * (blockIdx.x - 1) + lane;
-	if (row >= S.ld) return;
-	double *Arow = S.A + (size_t)row * ld + k0;
-	double x[CB];
+	if (lane <= CB) {
 #pragma unroll
-	for (int c = 0; c < CB; c++) x[c] = Arow[c];
+		for (int c = 0; c < CB; c++) Ls[lane * (CB + 1) + c] = a[c];
+	}
+	if (lane == 0) {
+#pragma unroll
+		for (int c = 0; c < CB; c++) ri[c] = rinv[c];
+	}
+	__syncthreads();
+	if (!has_row) return;
 	double acc = 0;
 #pragma unroll
 	for (int j = 0; j < CB; j++) { // x_j = (a_j - sum_{m<j} x_m L[j][m]) / L[j][j]
 		double s = x[j];
 #pragma unroll
 		for (int m = 0; m < j; m++) s -= x[m] * Ls[j * (CB + 1) + m];
-		x[j] = s / Ls[j * (CB + 1) + j];
-		acc += x[j] * ys[j];
+		x[j] = s * ri[j];
+		acc += x[j] * Ls[CB * (CB + 1) + j];
 	}
 #pragma unroll
 	for (int c = 0; c < CB; c++) Arow[c] = x[c];
 	S.rhs[row] -= acc;
 }
 
-// Trailing update after panel k0: tile (ti, tj), tj <= ti, of the matrix below/right of the panel: C -= X_i X_j^t, X = A[:, k0 .. k0+CB)
+// Trailing update after panel k0: tile (ti, tj), tj <= ti, of the matrix below/right of the panel: C -= X_i X_j^t, X = A[:, k0 .. k0+CB). C is loaded straight
+// into the MFMA accumulators (D = (-X_i) X_j^t + C) while the operands travel through LDS: two dependent memory phases instead of three.
 __global__ void __launch_bounds__(256) k_chol_update(const BigSys S, int k0, int ntile) {
 	__shared__ double Xi[CT * (CB + 1)], Xj[CT * (CB + 1)];
-	// linear tile index -> (ti, tj) of the lower triangle
-	int t = blockIdx.x, ti = 0; while ((ti + 1) * (ti + 2) / 2 <= t) ti++; const int tj = t - ti * (ti + 1) / 2;
+	if (*S.flag) return;
+	int t = blockIdx.x, ti = 0; while ((ti + 1) * (ti + 2) / 2 <= t) ti++; const int tj = t - ti * (ti + 1) / 2; // linear tile index -> (ti, tj) of the lower triangle
 	(void)ntile;
 	const int base = k0 + CB, i0 = base + CT * ti, j0 = base + CT * tj, ld = S.ld, tid = threadIdx.x;
-	for (int e = tid; e < CT * CB; e += 256) {
-		const int r = e / CB, c = e % CB;
-		Xi[r * (CB + 1) + c] = (i0 + r < ld) ? S.A[(size_t)(i0 + r) * ld + k0 + c] : 0.0;
-		Xj[r * (CB + 1) + c] = (j0 + r < ld) ? S.A[(size_t)(j0 + r) * ld + k0 + c] : 0.0;
-	}
-	__syncthreads();
 	const int w = tid >> 6, lane = tid & 63, wr = w >> 1, wc = w & 1;
-	if (ti == tj && wc > wr) return; // strictly upper part of a diagonal tile
+	const bool active = !(ti == tj && wc > wr); // the strictly upper quarter of a diagonal tile is never read
 	f64x4 acc[2][2];
 #pragma unroll
 	for (int a = 0; a < 2; a++)
 #pragma unroll
-		for (int b = 0; b < 2; b++) acc[a][b] = (f64x4){0, 0, 0, 0};
+		for (int b = 0; b < 2; b++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) { // D: col = lane & 15, row = (lane >> 4) + 4 r
+				const int gi = i0 + wr * 32 + a * 16 + (lane >> 4) + 4 * r, gj = j0 + wc * 32 + b * 16 + (lane & 15);
+				acc[a][b][r] = (active && gi < ld && gj < ld) ? S.A[(size_t)gi * ld + gj] : 0.0;
+			}
+	for (int e = tid; e < CT * CB; e += 256) {
+		const int r = e / CB, c = e % CB;
+		Xi[r * (CB + 1) + c] = (i0 + r < ld) ? -S.A[(size_t)(i0 + r) * ld + k0 + c] : 0.0;
+		Xj[r * (CB + 1) + c] = (j0 + r < ld) ? S.A[(size_t)(j0 + r) * ld + k0 + c] : 0.0;
+	}
+	__syncthreads();
+	if (!active) return;
 #pragma unroll
 	for (int kk = 0; kk < CB / 4; kk++) {
 		double fa[2], fb[2];
@@ -120,28 +150,35 @@ __global__ void __launch_bounds__(256) k_chol_update(const BigSys S, int k0, int
 #pragma unroll
 		for (int b = 0; b < 2; b++)
 #pragma unroll
-			for (int r = 0; r < 4; r++) { // D: col = lane & 15, row = (lane >> 4) + 4 r
+			for (int r = 0; r < 4; r++) {
 				const int gi = i0 + wr * 32 + a * 16 + (lane >> 4) + 4 * r, gj = j0 + wc * 32 + b * 16 + (lane & 15);
-				if (gi < ld && gj < ld) S.A[(size_t)gi * ld + gj] -= acc[a][b][r];
+				if (gi < ld && gj < ld) S.A[(size_t)gi * ld + gj] = acc[a][b][r];
 			}
 }
 
-// L^t x = y in place in S.y (one workgroup): block rows from the last to the first
+// L^t x = y in place in S.y (one workgroup): block rows from the last to the first. The CB x CB triangular solve runs in the first wavefront with column
+// `lane` of L_kk in registers (x_c travels by v_readlane); all four wavefronts then eliminate x_k from the rows above.
 __global__ void __launch_bounds__(256) k_chol_bsub(const BigSys S) {
-	__shared__ double Ls[CB * (CB + 1)], xs[CB];
-	const int tid = threadIdx.x, ld = S.ld, nblk = ld / CB;
+	__shared__ double xs[CB];
+	const int tid = threadIdx.x, lane = tid & 63, ld = S.ld, nblk = ld / CB;
+	if (*S.flag) return;
 	for (int kb = nblk - 1; kb >= 0; kb--) {
 		const int k0 = kb * CB;
-		for (int e = tid; e < CB * CB; e += 256) { const int r = e / CB, c = e % CB; Ls[r * (CB + 1) + c] = S.Ldiag[(size_t)(k0 + r) * CB + c]; }
-		if (tid < CB) xs[tid] = S.y[k0 + tid];
-		__syncthreads();
-		for (int c = CB - 1; c >= 0; c--) { // x_c = (y_c - sum_{m>c} L[m][c] x_m) / L[c][c]
-			if (tid == c) xs[c] = xs[c] / Ls[c * (CB + 1) + c];
-			__syncthreads();
-			if (tid < c) xs[tid] -= Ls[c * (CB + 1) + tid] * xs[c];
-			__syncthreads();
+		if (tid < 64) {
+			double a[CB];
+#pragma unroll
+			for (int m = 0; m < CB; m++) a[m] = (lane < CB) ? S.Ldiag[(size_t)(k0 + m) * CB + lane] : 0.0; // a[m] = L[m][lane]
+			double acc = lane < CB ? S.y[k0 + lane] : 0.0, dinv = 1.0;
+#pragma unroll
+			for (int c = 0; c < CB; c++) if (lane == c) dinv = 1.0 / a[c]; // all the reciprocals of the diagonal at once
+#pragma unroll
+			for (int c = CB - 1; c >= 0; c--) { // x_c = (y_c - sum_{m>c} L[m][c] x_m) / L[c][c]
+				const double xc = lane_bcast(acc, c) * lane_bcast(dinv, c);
+				if (lane == c) acc = xc; else if (lane < c) acc -= a[c] * xc;
+			}
+			if (lane < CB) { xs[lane] = acc; S.y[k0 + lane] = acc; }
 		}
-		if (tid < CB) S.y[k0 + tid] = xs[tid];
+		__syncthreads();
 		for (int i = tid; i < k0; i += 256) { // y_i -= sum_c L[k0+c][i] x_c
 			double s = 0;
 #pragma unroll 8
@@ -156,8 +193,9 @@ __global__ void __launch_bounds__(256) k_chol_bsub(const BigSys S) {
 #define BIG_GID() (blockIdx.x * blockDim.x + threadIdx.x)
 #define BIG_STRIDE() (gridDim.x * blockDim.x)
 
-template <int FAM> __global__ void __launch_bounds__(256) kb_spantree(const Batch B, const DevParams prm, int p, int only_needed) {
+template <int FAM> __global__ void __launch_bounds__(256) kb_spantree(const Batch B, const DevParams prm, int p, int only_needed, const int *skip) {
 	typedef Worker<FAM> W; typedef typename W::PO PO; typedef typename W::pose_t pose_t; constexpr int PD = W::PD;
+	if (skip && *skip) return;
 	const ProbDesc &d = B.desc[p]; const int cnt = only_needed ? d.n_need : d.n_pairs;
 	for (int q = BIG_GID(); q < cnt; q += BIG_STRIDE()) {
 		const int pr = only_needed ? B.need_idx[d.o_pair + q] : q;
@@ -191,13 +229,28 @@ template <int FAM> __global__ void __launch_bounds__(256) kb_jac_post(const Batc
 		}
 	}
 }
+// sum of N per-thread values over a 256-thread workgroup in a fixed order: wavefront sums (DPP tree), then the four wavefronts; the result is valid in thread k < N
+template <int N> __device__ __forceinline__ double wg_sum(const double (&acc)[N], double *sh /* 4 N */) {
+	const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+	for (int k = 0; k < N; k++) { const double v = wave_sum(acc[k]); if (lane == 0) sh[w * N + k] = v; }
+	__syncthreads();
+	const int k = threadIdx.x < N ? threadIdx.x : 0;
+	return (sh[k] + sh[N + k]) + (sh[2 * N + k] + sh[3 * N + k]);
+}
+constexpr int BIG_HEAVY = 48;   // Hessian / Schur blocks with more terms than this are summed by a whole workgroup
+
+// Hessian blocks (K6): one thread per block; the U_Ap blocks with many terms (an edge near the root of a deep window collects thousands of observations) are left
+// to kb_hessian_heavy.
 template <int FAM> __global__ void __launch_bounds__(128) kb_hessian(const Batch B, const DevParams prm, int p, int *ninv_out) {
 	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L, O = W::O; Worker<FAM> Wk(B, B.desc[p], prm); const ProbDesc &d = B.desc[p];
 	const double *Jp = B.Jp + d.o_bp * O * P, *Jf = B.Jf + d.o_bf * O * L; const unsigned char *rp = B.bp_ok + d.o_bp, *rf = B.bf_ok + d.o_bf;
 	const bool latch = prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL; int ninv = 0;
 	const int total = d.n_hap + (W::T::REL ? 0 : d.n_hf + d.n_hapf);
 	for (int b = BIG_GID(); b < total; b += BIG_STRIDE()) {
-		if (b < d.n_hap) { const long long g = d.o_hap + b; ninv += Wk.template hess_block<P, P>(B.HAp + g * P * P, latch ? B.HAp0 + g * P * P : nullptr, B.hap_t1 + d.o_hapt, B.hap_t2 + d.o_hapt, B.hap_term_off[d.o_hapoff + b], B.hap_term_off[d.o_hapoff + b + 1], Jp, Jp, rp, rp); }
+		if (b < d.n_hap) {
+			const int tb = B.hap_term_off[d.o_hapoff + b], te = B.hap_term_off[d.o_hapoff + b + 1]; if (te - tb > BIG_HEAVY) continue;
+			const long long g = d.o_hap + b; ninv += Wk.template hess_block<P, P>(B.HAp + g * P * P, latch ? B.HAp0 + g * P * P : nullptr, B.hap_t1 + d.o_hapt, B.hap_t2 + d.o_hapt, tb, te, Jp, Jp, rp, rp); }
 		else if constexpr (!W::T::REL) {
 			if (b < d.n_hap + d.n_hf) { const int q = b - d.n_hap; ninv += Wk.template hess_block<L, L>(B.Hf + (d.o_hf + q) * L * L, nullptr, B.hf_t1 + d.o_hft, B.hf_t2 + d.o_hft, B.hf_term_off[d.o_hfoff + q], B.hf_term_off[d.o_hfoff + q + 1], Jf, Jf, rf, rf); }
 			else { const int q = b - d.n_hap - d.n_hf; ninv += Wk.template hess_block<P, L>(B.HApf + (d.o_hapf + q) * P * L, nullptr, B.hapf_t1 + d.o_hapft, B.hapf_t2 + d.o_hapft, B.hapf_term_off[d.o_hapfoff + q], B.hapf_term_off[d.o_hapfoff + q + 1], Jp, Jf, rp, rf); }
@@ -205,8 +258,27 @@ template <int FAM> __global__ void __launch_bounds__(128) kb_hessian(const Batch
 	}
 	if (ninv) atomicAdd(ninv_out, ninv);
 }
+// one workgroup per U_Ap block (grid = n_hap; the light ones return at once): terms strided over the threads, fixed-order reduction
+template <int FAM> __global__ void __launch_bounds__(256) kb_hessian_heavy(const Batch B, const DevParams prm, int p, int *ninv_out) {
+	typedef Worker<FAM> W; constexpr int P = W::P, O = W::O; Worker<FAM> Wk(B, B.desc[p], prm); const ProbDesc &d = B.desc[p];
+	__shared__ double sh[4 * P * P];
+	const int b = blockIdx.x, tb = B.hap_term_off[d.o_hapoff + b], te = B.hap_term_off[d.o_hapoff + b + 1];
+	if (te - tb <= BIG_HEAVY) return;
+	const double *Jp = B.Jp + d.o_bp * O * P; const unsigned char *rp = B.bp_ok + d.o_bp; const int *t1 = B.hap_t1 + d.o_hapt, *t2 = B.hap_t2 + d.o_hapt;
+	double H[P * P]; int ninv = 0;
+#pragma unroll
+	for (int k = 0; k < P * P; k++) H[k] = 0;
+	for (int t = tb + threadIdx.x; t < te; t += 256) {
+		const int b1 = t1[t], b2 = t2[t];
+		if (rp[b1] && rp[b2]) Wk.template hess_term<P, P>(H, Jp + (long long)b1 * O * P, Jp + (long long)b2 * O * P); else ninv++;
+	}
+	const double v = wg_sum<P * P>(H, sh) * ((prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0);
+	if (threadIdx.x < P * P) { const long long g = d.o_hap + b; B.HAp[g * P * P + threadIdx.x] = v; if (prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL) B.HAp0[g * P * P + threadIdx.x] = v; }
+	if (ninv) atomicAdd(ninv_out, ninv);
+}
 // per-workgroup partial sums in a fixed order; kb_reduce adds them sequentially (deterministic)
-template <int FAM> __global__ void __launch_bounds__(256) kb_residuals(const Batch B, const DevParams prm, int p, double *out, double *partial) {
+template <int FAM> __global__ void __launch_bounds__(256) kb_residuals(const Batch B, const DevParams prm, int p, double *out, double *partial, const int *skip) {
+	if (skip && *skip) return;
 	Worker<FAM> Wk(B, B.desc[p], prm); constexpr int O = Worker<FAM>::O; const ProbDesc &d = B.desc[p];
 	double acc = 0;
 	for (int i = BIG_GID(); i < d.n_obs; i += BIG_STRIDE()) { double r[O]; acc += Wk.residual_row(i, r); for (int k = 0; k < O; k++) out[(long long)(d.o_obs + i) * O + k] = r[k]; }
@@ -215,27 +287,49 @@ template <int FAM> __global__ void __launch_bounds__(256) kb_residuals(const Bat
 	__syncthreads();
 	if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
-__global__ void kb_reduce(const double *partial, int n, double *out, int is_max) { // one thread: n is at most a few thousand
-	if (threadIdx.x || blockIdx.x) return;
-	double s = 0; for (int i = 0; i < n; i++) s = is_max ? fmax(s, partial[i]) : s + partial[i];
-	*out = s;
+__global__ void __launch_bounds__(256) kb_reduce(const double *partial, int n, double *out, int is_max) { // one workgroup, fixed order (n <= 4096)
+	__shared__ double sh[4];
+	double v = 0; for (int i = threadIdx.x; i < n; i += 256) v = is_max ? fmax(v, partial[i]) : v + partial[i];
+	v = is_max ? wave_max(v) : wave_sum(v);
+	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+	__syncthreads();
+	if (threadIdx.x == 0) *out = is_max ? fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3])) : (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
-template <int FAM> __global__ void __launch_bounds__(128) kb_gradient(const Batch B, const DevParams prm, int p, const double *resid) { // one thread per unknown column, blocks in ascending order
+__global__ void kb_set_scalar(double *dst, double v) { *dst = v; }
+template <int O, int M> __device__ __forceinline__ void grad_term(double (&acc)[M], const double *A, const double *r, const DevParams &prm) {
+	double lr[O];
+#pragma unroll
+	for (int k = 0; k < O; k++) lr[k] = r[k];
+	if (prm.noise == SRBA_NOISE_CONSTANT_MATRIX) { double t[O]; for (int k = 0; k < O; k++) { double q = 0; for (int j = 0; j < O; j++) q += prm.lambda[k * O + j] * lr[j]; t[k] = q; } for (int k = 0; k < O; k++) lr[k] = t[k]; }
+#pragma unroll
+	for (int q = 0; q < M; q++) { double sm = 0;
+#pragma unroll
+		for (int k = 0; k < O; k++) sm += A[k * M + q] * lr[k];
+		acc[q] += sm; }
+}
+// Gradient (K5). Workgroups 0 .. nK-1: one per unknown edge, its dh_dAp blocks strided over the 256 threads (an edge of a deep window has 10^3..10^4 of them),
+// fixed-order reduction; the following workgroups: one thread per unknown landmark (tens of dh_df blocks each).
+template <int FAM> __global__ void __launch_bounds__(256) kb_gradient(const Batch B, const DevParams prm, int p, const double *resid) {
 	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L, O = W::O; const ProbDesc &d = B.desc[p];
 	const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0; double *g = B.grad + d.o_scal;
-	for (int col = BIG_GID(); col < d.nK + d.nF; col += BIG_STRIDE()) {
-		const bool isp = col < d.nK; const int M = isp ? P : L, ci = isp ? col : col - d.nK;
-		const int bb = isp ? B.colp_off[d.o_colp + ci] : B.colf_off[d.o_colf + ci], be = isp ? B.colp_off[d.o_colp + ci + 1] : B.colf_off[d.o_colf + ci + 1];
-		double acc[6] = {0, 0, 0, 0, 0, 0};
-		for (int b = bb; b < be; b++) {
-			const double *A = isp ? B.Jp + (long long)(d.o_bp + b) * O * P : B.Jf + (long long)(d.o_bf + b) * O * L;
-			const double *r = resid + (long long)(d.o_obs + (isp ? B.bp_res[d.o_bp + b] : B.bf_res[d.o_bf + b])) * O;
-			double lr[O]; for (int k = 0; k < O; k++) lr[k] = r[k];
-			if (prm.noise == SRBA_NOISE_CONSTANT_MATRIX) { double t[O]; for (int k = 0; k < O; k++) { double q = 0; for (int j = 0; j < O; j++) q += prm.lambda[k * O + j] * lr[j]; t[k] = q; } for (int k = 0; k < O; k++) lr[k] = t[k]; }
-			for (int q = 0; q < M; q++) { double sm = 0; for (int k = 0; k < O; k++) sm += A[k * M + q] * lr[k]; acc[q] += sm; }
-		}
-		double *go = isp ? g + ci * P : g + d.nK * P + ci * L;
-		for (int q = 0; q < M; q++) go[q] = acc[q] * sc;
+	__shared__ double sh[4 * P];
+	if ((int)blockIdx.x < d.nK) {
+		const int ci = blockIdx.x, bb = B.colp_off[d.o_colp + ci], be = B.colp_off[d.o_colp + ci + 1];
+		double acc[P];
+#pragma unroll
+		for (int q = 0; q < P; q++) acc[q] = 0;
+		for (int b = bb + threadIdx.x; b < be; b += 256) grad_term<O, P>(acc, B.Jp + (long long)(d.o_bp + b) * O * P, resid + (long long)(d.o_obs + B.bp_res[d.o_bp + b]) * O, prm);
+		const double v = wg_sum<P>(acc, sh);
+		if (threadIdx.x < P) g[ci * P + threadIdx.x] = v * sc;
+		return;
+	}
+	if constexpr (!W::T::REL) {
+		const int ci = ((int)blockIdx.x - d.nK) * 256 + threadIdx.x; if (ci >= d.nF) return;
+		double acc[L];
+#pragma unroll
+		for (int q = 0; q < L; q++) acc[q] = 0;
+		for (int b = B.colf_off[d.o_colf + ci]; b < B.colf_off[d.o_colf + ci + 1]; b++) grad_term<O, L>(acc, B.Jf + (long long)(d.o_bf + b) * O * L, resid + (long long)(d.o_obs + B.bf_res[d.o_bf + b]) * O, prm);
+		for (int q = 0; q < L; q++) g[d.nK * P + ci * L + q] = acc[q] * sc;
 	}
 }
 template <int FAM> __global__ void __launch_bounds__(256) kb_maxdiag(const Batch B, const DevParams prm, int p, double *partial) {
@@ -250,8 +344,9 @@ template <int FAM> __global__ void __launch_bounds__(256) kb_maxdiag(const Batch
 	if (threadIdx.x == 0) partial[blockIdx.x] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
 }
 // rho denominator sum dl (lambda dl + g) and |g|_inf
-template <int FAM> __global__ void __launch_bounds__(256) kb_dot(const Batch B, const DevParams prm, int p, double lambda, double *partial_den, double *partial_ninf) {
-	const ProbDesc &d = B.desc[p]; const double *dl = B.delta + d.o_scal, *g = B.grad + d.o_scal; double den = 0, ninf = 0;
+template <int FAM> __global__ void __launch_bounds__(256) kb_dot(const Batch B, const DevParams prm, int p, const double *lam, double *partial_den, double *partial_ninf, const int *skip) {
+	if (skip && *skip) return;
+	const double lambda = *lam; const ProbDesc &d = B.desc[p]; const double *dl = B.delta + d.o_scal, *g = B.grad + d.o_scal; double den = 0, ninf = 0;
 	for (int k = BIG_GID(); k < d.n_scal; k += BIG_STRIDE()) { den += dl[k] * (lambda * dl[k] + g[k]); ninf = fmax(ninf, fabs(g[k])); }
 	__shared__ double sh[8]; const double v = wave_sum(den), m = wave_max(ninf);
 	if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = v; sh[4 + (threadIdx.x >> 6)] = m; }
@@ -259,8 +354,8 @@ template <int FAM> __global__ void __launch_bounds__(256) kb_dot(const Batch B, 
 	if (threadIdx.x == 0) { partial_den[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]); partial_ninf[blockIdx.x] = fmax(fmax(sh[4], sh[5]), fmax(sh[6], sh[7])); }
 }
 // ---- Schur complement (schur.h:180-311), grid-wide
-template <int FAM> __global__ void __launch_bounds__(128) kb_schur_inv(const Batch B, const DevParams prm, int p, double lambda) {
-	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L; const ProbDesc &d = B.desc[p];
+template <int FAM> __global__ void __launch_bounds__(128) kb_schur_inv(const Batch B, const DevParams prm, int p, const double *lam) {
+	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L; const ProbDesc &d = B.desc[p]; const double lambda = *lam;
 	if constexpr (!W::T::REL) {
 		for (int l = BIG_GID(); l < d.nF; l += BIG_STRIDE()) {
 			double M[L * L], Mi[L * L]; const double *src = B.Hf + (d.o_hf + B.hf_diag[d.o_ulm + l]) * L * L;
@@ -272,42 +367,75 @@ template <int FAM> __global__ void __launch_bounds__(128) kb_schur_inv(const Bat
 		for (int k = BIG_GID(); k < d.n_hap * P * P; k += BIG_STRIDE()) B.HAp[d.o_hap * P * P + k] = B.HAp0[d.o_hap * P * P + k]; // restore from the snapshot (schur.h:188)
 	}
 }
-template <int FAM> __global__ void __launch_bounds__(128) kb_schur_reduce(const Batch B, const DevParams prm, int p) {
+// H_Ap(i,j) -= sum_l W_il Hf_l^-1 W_jl^t (schur.h:213-260). One workgroup per U_Ap block: the terms (landmarks seen through both edges, up to
+// all of them for a diagonal block) are strided over the 256 threads, each term writes its own Y = W Hf^-1 where the gradient / back-substitution need it.
+template <int FAM> __global__ void __launch_bounds__(256) kb_schur_reduce(const Batch B, const DevParams prm, int p) {
 	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L; const ProbDesc &d = B.desc[p];
 	if constexpr (!W::T::REL) {
-		for (int b = BIG_GID(); b < d.n_hap; b += BIG_STRIDE()) {
-			double *H = B.HAp + (d.o_hap + b) * P * P; const int tb = B.sch_term_off[d.o_hapoff + b], te = B.sch_term_off[d.o_hapoff + b + 1];
-			if (tb == te) continue;
-			double Hl[P * P]; for (int k = 0; k < P * P; k++) Hl[k] = H[k];
-			for (int t = tb; t < te; t++) {
-				const int l = B.sch_lm[d.o_sch + t]; if (!B.hf_ok[d.o_ulm + l]) continue;
-				const double *W1 = B.HApf + (d.o_hapf + B.sch_b1[d.o_sch + t]) * P * L, *W2 = B.HApf + (d.o_hapf + B.sch_b2[d.o_sch + t]) * P * L, *Hi = B.Hfinv + (d.o_ulm + l) * L * L;
-				double Y[P * L];
-				for (int i = 0; i < P; i++) for (int j = 0; j < L; j++) { double s = 0; for (int k = 0; k < L; k++) s += W1[i * L + k] * Hi[k * L + j]; Y[i * L + j] = s; }
-				for (int i = 0; i < P; i++) for (int j = 0; j < P; j++) { double s = 0; for (int k = 0; k < L; k++) s += Y[i * L + k] * W2[j * L + k]; Hl[i * P + j] -= s; }
-				const int yw = B.sch_yw[d.o_sch + t]; if (yw >= 0) for (int k = 0; k < P * L; k++) B.YW[(d.o_yw + yw) * P * L + k] = Y[k];
+		__shared__ double sh[4 * P * P];
+		const int b = blockIdx.x, tb = B.sch_term_off[d.o_hapoff + b], te = B.sch_term_off[d.o_hapoff + b + 1];
+		if (tb == te) return;
+		double Hl[P * P];
+#pragma unroll
+		for (int k = 0; k < P * P; k++) Hl[k] = 0;
+		for (int t = tb + threadIdx.x; t < te; t += 256) {
+			const int l = B.sch_lm[d.o_sch + t]; if (!B.hf_ok[d.o_ulm + l]) continue;
+			const double *W1 = B.HApf + (d.o_hapf + B.sch_b1[d.o_sch + t]) * P * L, *W2 = B.HApf + (d.o_hapf + B.sch_b2[d.o_sch + t]) * P * L, *Hi = B.Hfinv + (d.o_ulm + l) * L * L;
+			double Y[P * L], w1[P * L], w2[P * L], hi[L * L];
+#pragma unroll
+			for (int k = 0; k < P * L; k++) { w1[k] = W1[k]; w2[k] = W2[k]; }
+#pragma unroll
+			for (int k = 0; k < L * L; k++) hi[k] = Hi[k];
+#pragma unroll
+			for (int i = 0; i < P; i++)
+#pragma unroll
+				for (int j = 0; j < L; j++) { double s = 0;
+#pragma unroll
+					for (int k = 0; k < L; k++) s += w1[i * L + k] * hi[k * L + j];
+					Y[i * L + j] = s; }
+#pragma unroll
+			for (int i = 0; i < P; i++)
+#pragma unroll
+				for (int j = 0; j < P; j++) { double s = 0;
+#pragma unroll
+					for (int k = 0; k < L; k++) s += Y[i * L + k] * w2[j * L + k];
+					Hl[i * P + j] += s; }
+			const int yw = B.sch_yw[d.o_sch + t];
+			if (yw >= 0) {
+#pragma unroll
+				for (int k = 0; k < P * L; k++) B.YW[(d.o_yw + yw) * P * L + k] = Y[k];
 			}
-			for (int k = 0; k < P * P; k++) H[k] = Hl[k];
 		}
+		const double v = wg_sum<P * P>(Hl, sh);
+		if (threadIdx.x < P * P) B.HAp[(d.o_hap + b) * P * P + threadIdx.x] -= v;
 	}
 }
-template <int FAM> __global__ void __launch_bounds__(128) kb_schur_grad(const Batch B, const DevParams prm, int p) {
+// g_Ap(i) -= sum_l Y_il g_f(l) (schur.h:262-283): one workgroup per unknown edge
+template <int FAM> __global__ void __launch_bounds__(256) kb_schur_grad(const Batch B, const DevParams prm, int p) {
 	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L; const ProbDesc &d = B.desc[p];
 	if constexpr (!W::T::REL) {
+		__shared__ double sh[4 * P];
 		double *g = B.grad + d.o_scal; const double *gf = g + d.nK * P;
-		for (int i = BIG_GID(); i < d.nK; i += BIG_STRIDE()) {
-			const int b = B.hap_diag[d.o_unk + i]; double acc[P]; for (int r = 0; r < P; r++) acc[r] = g[i * P + r];
-			for (int t = B.sch_term_off[d.o_hapoff + b]; t < B.sch_term_off[d.o_hapoff + b + 1]; t++) {
-				const int l = B.sch_lm[d.o_sch + t]; if (!B.hf_ok[d.o_ulm + l]) continue;
-				const double *Y = B.YW + (d.o_yw + B.sch_yw[d.o_sch + t]) * P * L;
-				for (int r = 0; r < P; r++) { double s = 0; for (int k = 0; k < L; k++) s += Y[r * L + k] * gf[l * L + k]; acc[r] -= s; }
-			}
-			for (int r = 0; r < P; r++) g[i * P + r] = acc[r];
+		const int i = blockIdx.x, b = B.hap_diag[d.o_unk + i];
+		double acc[P];
+#pragma unroll
+		for (int r = 0; r < P; r++) acc[r] = 0;
+		for (int t = B.sch_term_off[d.o_hapoff + b] + threadIdx.x; t < B.sch_term_off[d.o_hapoff + b + 1]; t += 256) {
+			const int l = B.sch_lm[d.o_sch + t]; if (!B.hf_ok[d.o_ulm + l]) continue;
+			const double *Y = B.YW + (d.o_yw + B.sch_yw[d.o_sch + t]) * P * L;
+#pragma unroll
+			for (int r = 0; r < P; r++) { double s = 0;
+#pragma unroll
+				for (int k = 0; k < L; k++) s += Y[r * L + k] * gf[l * L + k];
+				acc[r] += s; }
 		}
+		const double v = wg_sum<P>(acc, sh);
+		if (threadIdx.x < P) g[i * P + threadIdx.x] -= v;
 	}
 }
-template <int FAM> __global__ void __launch_bounds__(128) kb_schur_features(const Batch B, const DevParams prm, int p) {
+template <int FAM> __global__ void __launch_bounds__(128) kb_schur_features(const Batch B, const DevParams prm, int p, const int *skip) {
 	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L; const ProbDesc &d = B.desc[p];
+	if (skip && *skip) return;
 	if constexpr (!W::T::REL) {
 		double *g = B.grad + d.o_scal, *dl = B.delta + d.o_scal;
 		for (int l = BIG_GID(); l < d.nF; l += BIG_STRIDE()) {
@@ -325,8 +453,8 @@ template <int FAM> __global__ void __launch_bounds__(128) kb_schur_features(cons
 }
 // (H + lambda I) into the dense lower triangle + right-hand side; identity padding up to ld
 __global__ void kb_dense_clear(const BigSys S) { for (size_t k = BIG_GID(); k < (size_t)S.ld * S.ld; k += BIG_STRIDE()) { const int r = (int)(k / S.ld), c = (int)(k % S.ld); S.A[k] = (r == c && r >= S.n) ? 1.0 : 0.0; } if (BIG_GID() == 0) *S.flag = 0; }
-template <int FAM> __global__ void __launch_bounds__(128) kb_dense_assemble(const Batch B, const DevParams prm, int p, const BigSys S, double lambda, int full_system) {
-	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L; const ProbDesc &d = B.desc[p];
+template <int FAM> __global__ void __launch_bounds__(128) kb_dense_assemble(const Batch B, const DevParams prm, int p, const BigSys S, const double *lam, int full_system) {
+	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L; const ProbDesc &d = B.desc[p]; const double lambda = *lam;
 	const int total = d.n_hap + (full_system ? d.n_hapf + d.n_hf : 0);
 	for (int b = BIG_GID(); b < total; b += BIG_STRIDE()) {
 		if (b < d.n_hap) { // upper block (i <= j) -> lower triangle: A[Pj+q][Pi+r] = H[r][q]
@@ -343,10 +471,11 @@ template <int FAM> __global__ void __launch_bounds__(128) kb_dense_assemble(cons
 	const double *g = B.grad + d.o_scal;
 	for (int k = BIG_GID(); k < S.ld; k += BIG_STRIDE()) S.rhs[k] = k < S.n ? g[k] : 0.0;
 }
-__global__ void kb_take_delta(const Batch B, int p, const BigSys S) { const ProbDesc &d = B.desc[p]; double *dl = B.delta + d.o_scal; for (int k = BIG_GID(); k < d.n_scal; k += BIG_STRIDE()) if (k < S.n) dl[k] = S.y[k]; else if (S.n == d.n_scal) dl[k] = 0; }
+__global__ void kb_take_delta(const Batch B, int p, const BigSys S) { if (*S.flag) return; const ProbDesc &d = B.desc[p]; double *dl = B.delta + d.o_scal; for (int k = BIG_GID(); k < d.n_scal; k += BIG_STRIDE()) if (k < S.n) dl[k] = S.y[k]; else if (S.n == d.n_scal) dl[k] = 0; }
 // K12 backup + K11 apply / restore
-template <int FAM> __global__ void __launch_bounds__(128) kb_apply(const Batch B, const DevParams prm, int p) {
+template <int FAM> __global__ void __launch_bounds__(128) kb_apply(const Batch B, const DevParams prm, int p, const int *skip) {
 	typedef Worker<FAM> W; typedef typename W::PO PO; constexpr int P = W::P, L = W::L, PD = W::PD; const ProbDesc &d = B.desc[p]; const double *dl = B.delta + d.o_scal;
+	if (skip && *skip) return;
 	for (int i = BIG_GID(); i < d.nK + d.nF * L + d.n_req; i += BIG_STRIDE()) {
 		if (i < d.nK) { double *e = B.edge + (d.o_edge + i) * PD, *o = B.old_edge + (d.o_unk + i) * PD; for (int k = 0; k < PD; k++) o[k] = e[k]; PO::st(e, comp(PO::expm(dl + i * P), PO::ld(e))); }
 		else if (i < d.nK + d.nF * L) { const int k = i - d.nK; B.old_ulm[d.o_ulm * L + k] = B.ulm[d.o_ulm * L + k]; B.ulm[d.o_ulm * L + k] += dl[d.nK * P + k]; }

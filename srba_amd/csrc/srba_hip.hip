@@ -10,6 +10,7 @@
 #include "srba_device.hpp"
 #include <algorithm>
 #include <iterator>
+#include <map>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -587,6 +588,8 @@ struct srba_hip_ctx {
 	double *d_part = nullptr; double *d_scal = nullptr; int *d_iscal = nullptr; // big path: partial sums [3][kBigPart], scalars, int flags (ninv, not-pd)
 	std::vector<int> big_ld; // per capsule: leading dimension of its dense system when it runs on the big path, else 0
 	double big_chol_ms = 0, big_chol_flops = 0; long long big_chol_count = 0; int big_chol_nmax = 0; hipEvent_t big_e0 = nullptr, big_e1 = nullptr; // Cholesky time / flops of the big path since the last upload
+	struct BigGraphSet { hipGraphExec_t g[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; }; // assemble, Cholesky, back-substitution .. rho, accept + relinearise, accept
+	std::map<int, BigGraphSet> big_graphs; bool big_use_graphs = false; // captured launch sequences of the big path, per capsule; dropped at upload
 	int big_min_sys = 480;   // systems with more scalar unknowns than this skip the block-sparse symbolic analysis and go dense (big path)
 	std::vector<char> h_in; size_t h_off_order = 0; // host staging of the input arena (kept: the launch order is read back from it)
 	int max_lds_kb = 1 << 20, min_chunk = 384, max_parts_per_queue = 2; int n_queues = 16, sched = 3, n_streams_used = 1, n_cu = 256, waves_per_cu = 8, lds_per_cu = 160 * 1024; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
@@ -597,6 +600,7 @@ struct srba_hip_ctx {
 	size_t off_phase = 0; bool phase_timing = false; long long n_pose_total = 0; std::vector<int> cls_of;
 	void fail(const std::string &m) { error = m; g_last_error = m; }
 };
+static void big_drop_graphs(srba_hip_ctx *c);
 // Launch plan of the fused LM kernel. Every size class is one or more launches (a launch has ONE dynamic-LDS size); the HIP runtime
 // multiplexes streams onto 4 hardware queues and kernels of one queue run in order, so the plan uses n_queues streams and decides what
 // shares the chip at any time. Small capsules are wave-slot bound (VGPRs), big ones LDS bound: running them side by side fills both.
@@ -714,6 +718,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	for (int k = 1; k < SRBA_NCLS && ok; k++) ok = hipStreamCreateWithFlags(&c->cls_stream[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->cls_done[k], hipEventDisableTiming) == hipSuccess;
 	if (!ok || hipMalloc((void **)&c->d_next, sizeof(int) * kMaxJobs) != hipSuccess || hipMalloc((void **)&c->d_part, 8 * 3 * kBigPart) != hipSuccess || hipMalloc((void **)&c->d_scal, 8 * 16) != hipSuccess || hipMalloc((void **)&c->d_iscal, 4 * 8) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	{ const char *e = getenv("SRBA_HIP_BIG_MIN_SYS"); if (e && atoi(e) >= 0) c->big_min_sys = atoi(e); } // tuning / test knob
+	{ const char *e = getenv("SRBA_HIP_BIG_GRAPHS"); if (e) c->big_use_graphs = atoi(e) != 0; }         // 1 = replay the big path's launch sequences as HIP graphs (measured: no gain, the path is bound by its kernels)
 	return c;
 }
 
@@ -722,12 +727,14 @@ int srba_hip_set_params(srba_hip_ctx *c, const srba_hip_params *params) {
 	if (check_params(params) != 0) { c->fail(g_last_error); return -1; }
 	if (params->family != c->params.family) { c->fail("srba_hip_set_params: the family of a context cannot change"); return -1; }
 	if (c->n_prob && (params->solver != c->params.solver || params->noise != c->params.noise)) c->n_prob = 0; // the uploaded batch was laid out for the old solver / noise policy: upload again
+	big_drop_graphs(c); // the captured launches carry the old parameters by value
 	c->params = *params; make_dev_params(*params, c->dp, c->dm); return 0;
 }
 
 int srba_hip_destroy(srba_hip_ctx *c) {
 	if (!c) return 0;
 	hipSetDevice(c->device);
+	big_drop_graphs(c);
 	if (c->d_in) hipFree(c->d_in); if (c->d_wk) hipFree(c->d_wk); if (c->d_next) hipFree(c->d_next); if (c->d_part) hipFree(c->d_part); if (c->d_scal) hipFree(c->d_scal); if (c->d_iscal) hipFree(c->d_iscal);
 	for (int i = 0; i < srba_hip_ctx::kRing; i++) { if (c->ring0[i]) hipEventDestroy(c->ring0[i]); if (c->ring1[i]) hipEventDestroy(c->ring1[i]); }
 	if (c->ev_fork) hipEventDestroy(c->ev_fork);
@@ -753,7 +760,7 @@ int srba_hip_kernel_ms_history(srba_hip_ctx *c, double *out_ms, int n) {
 int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, int n) {
 	if (!c || !caps || n <= 0) { if (c) c->fail("upload: bad arguments"); return -1; }
 	HIPCHK(c, hipSetDevice(c->device));
-	c->big_chol_ms = c->big_chol_flops = 0; c->big_chol_count = 0; c->big_chol_nmax = 0;
+	c->big_chol_ms = c->big_chol_flops = 0; c->big_chol_count = 0; c->big_chol_nmax = 0; big_drop_graphs(c);
 	c->n_prob = 0; // whatever was uploaded before stops being launchable / readable now: a failed upload leaves the context empty, not half-updated
 	const int P = c->dm.P, L = c->dm.L, O = c->dm.O, PD = c->dm.PD, PDX = c->dm.PDX();
 	const bool schur_solver = c->params.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL;
@@ -967,31 +974,72 @@ static srbadev::BigSys big_sys(srba_hip_ctx *c, int p) {
 	const ProbDesc &d = c->desc[p]; const int ld = c->big_ld[p]; srbadev::BigSys S;
 	double *base = c->B.dense + d.o_dense; S.A = base; S.Ldiag = base + (size_t)ld * ld; S.rhs = S.Ldiag + (size_t)ld * srbadev::CB; S.y = S.rhs + ld; S.flag = c->d_iscal + 1; S.n = d.n_sys; S.ld = ld; return S;
 }
+#define BIGKG(KERNEL, grid, block, ...) with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), dim3(std::max(1, (int)(grid))), dim3(block), 0, c->stream, c->B, c->dp, p, ##__VA_ARGS__); })
 #define BIGK(KERNEL, items, block, ...) with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), dim3(big_grid((items), (block))), dim3(block), 0, c->stream, c->B, c->dp, p, ##__VA_ARGS__); })
 // deterministic reduction of per-workgroup partials into d_scal[slot]
-static void big_reduce(srba_hip_ctx *c, int which, int nblk, int slot, int is_max) { hipLaunchKernelGGL(srbadev::kb_reduce, dim3(1), dim3(1), 0, c->stream, c->d_part + (size_t)which * kBigPart, nblk, c->d_scal + slot, is_max); }
-// solve(lambda) of lev-marq_solvers.h for one big capsule: Schur reduction (if the solver has one), dense blocked Cholesky, back-substitution, landmark increments
-static int big_solve(srba_hip_ctx *c, int p, double lambda, bool *pos_def) {
-	const ProbDesc &d = c->desc[p]; const srbadev::BigSys S = big_sys(c, p); const int P = c->dm.P;
+static void big_reduce(srba_hip_ctx *c, int which, int nblk, int slot, int is_max) { hipLaunchKernelGGL(srbadev::kb_reduce, dim3(1), dim3(256), 0, c->stream, c->d_part + (size_t)which * kBigPart, nblk, c->d_scal + slot, is_max); }
+// scalar slots of the big path on the device: d_scal = {chi2, max diag, rho denominator, |g|_inf, lambda}; d_iscal = {invalid Jacobians, not-positive-definite flag}
+enum { BS_CHI2 = 0, BS_MAXDIAG = 1, BS_DEN = 2, BS_NINF = 3, BS_LAMBDA = 4 };
+// A trial of the host-driven LM loop is ~80 short dependent launches; their sequence depends only on the capsule, so it is captured once per capsule into
+// HIP graphs (lambda travels through d_scal, a failed factorisation through the device flag that the later kernels test) and replayed.
+template <class F> static int big_replay(srba_hip_ctx *c, int p, int which, F &&enqueue) {
+	if (!c->big_use_graphs) { enqueue(); return 0; }
+	hipGraphExec_t &slot = c->big_graphs[p].g[which];
+	if (!slot) {
+		hipGraph_t g = nullptr;
+		HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+		enqueue();
+		HIPCHK(c, hipStreamEndCapture(c->stream, &g));
+		HIPCHK(c, hipGraphInstantiate(&slot, g, nullptr, nullptr, 0));
+		HIPCHK(c, hipGraphDestroy(g));
+	}
+	HIPCHK(c, hipGraphLaunch(slot, c->stream));
+	return 0;
+}
+static void big_drop_graphs(srba_hip_ctx *c) { for (auto &kv : c->big_graphs) for (hipGraphExec_t g : kv.second.g) if (g) hipGraphExecDestroy(g); c->big_graphs.clear(); }
+// solve(lambda) of lev-marq_solvers.h for one big capsule, lambda in d_scal[BS_LAMBDA]: (a) Schur reduction (if the solver has one) + dense assembly,
+// (b) blocked Cholesky, (c) back-substitution + landmark increments. The not-positive-definite verdict stays in the device flag.
+static void big_enqueue_assemble(srba_hip_ctx *c, int p) {
+	const ProbDesc &d = c->desc[p]; const srbadev::BigSys S = big_sys(c, p); const int P = c->dm.P; const double *lam = c->d_scal + BS_LAMBDA;
 	const bool schur = c->params.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0;
-	if (schur) { BIGK(kb_schur_inv, std::max<long long>(d.nF, (long long)d.n_hap * P * P), 128, lambda); BIGK(kb_schur_reduce, d.n_hap, 128); BIGK(kb_schur_grad, d.nK, 128); }
+	if (schur) { BIGK(kb_schur_inv, std::max<long long>(d.nF, (long long)d.n_hap * P * P), 128, lam); BIGKG(kb_schur_reduce, d.n_hap, 256); BIGKG(kb_schur_grad, d.nK, 256); }
 	hipLaunchKernelGGL(srbadev::kb_dense_clear, dim3(big_grid((long long)S.ld * S.ld, 256)), dim3(256), 0, c->stream, S);
-	BIGK(kb_dense_assemble, d.n_hap + d.n_hapf + d.n_hf, 128, S, lambda, schur ? 0 : 1);
-	if (!c->big_e0) { HIPCHK(c, hipEventCreate(&c->big_e0)); HIPCHK(c, hipEventCreate(&c->big_e1)); }
-	HIPCHK(c, hipEventRecord(c->big_e0, c->stream));
+	BIGK(kb_dense_assemble, d.n_hap + d.n_hapf + d.n_hf, 128, S, lam, schur ? 0 : 1);
+}
+static void big_enqueue_cholesky(srba_hip_ctx *c, int p) {
+	const srbadev::BigSys S = big_sys(c, p);
 	for (int k0 = 0; k0 < S.ld; k0 += srbadev::CB) {
 		const int below = S.ld - k0 - srbadev::CB;
 		hipLaunchKernelGGL(srbadev::k_chol_panel, dim3(1 + (below + 63) / 64), dim3(64), 0, c->stream, S, k0);
 		if (below > 0) { const int nt = (below + srbadev::CT - 1) / srbadev::CT; hipLaunchKernelGGL(srbadev::k_chol_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, S, k0, nt); }
 	}
-	HIPCHK(c, hipEventRecord(c->big_e1, c->stream));
-	int flag = 0; HIPCHK(c, hipMemcpyAsync(&flag, S.flag, 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
-	{ float ms = 0; if (hipEventElapsedTime(&ms, c->big_e0, c->big_e1) == hipSuccess) { c->big_chol_ms += ms; c->big_chol_flops += (double)S.ld * S.ld * S.ld / 3.0; c->big_chol_count++; c->big_chol_nmax = std::max(c->big_chol_nmax, S.n); } }
-	*pos_def = (flag == 0);
-	if (!*pos_def) return 0;
+}
+static void big_enqueue_backsub(srba_hip_ctx *c, int p) {
+	const ProbDesc &d = c->desc[p]; const srbadev::BigSys S = big_sys(c, p);
+	const bool schur = c->params.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0;
 	hipLaunchKernelGGL(srbadev::k_chol_bsub, dim3(1), dim3(256), 0, c->stream, S);
 	hipLaunchKernelGGL(srbadev::kb_take_delta, dim3(big_grid(d.n_scal, 256)), dim3(256), 0, c->stream, c->B, p, S);
-	if (schur) BIGK(kb_schur_features, d.nF, 128);
+	if (schur) BIGK(kb_schur_features, d.nF, 128, S.flag);
+}
+static int big_timed_cholesky(srba_hip_ctx *c, int p) {
+	if (!c->big_e0) { HIPCHK(c, hipEventCreate(&c->big_e0)); HIPCHK(c, hipEventCreate(&c->big_e1)); }
+	HIPCHK(c, hipEventRecord(c->big_e0, c->stream));
+	if (big_replay(c, p, 1, [&]() { big_enqueue_cholesky(c, p); }) != 0) return -1;
+	HIPCHK(c, hipEventRecord(c->big_e1, c->stream));
+	return 0;
+}
+static void big_account_cholesky(srba_hip_ctx *c, int p) { // after a stream synchronisation
+	float ms = 0; const int ld = c->big_ld[p];
+	if (hipEventElapsedTime(&ms, c->big_e0, c->big_e1) == hipSuccess) { c->big_chol_ms += ms; c->big_chol_flops += (double)ld * ld * ld / 3.0; c->big_chol_count++; c->big_chol_nmax = std::max(c->big_chol_nmax, c->desc[p].n_sys); }
+}
+static int big_solve(srba_hip_ctx *c, int p, double lambda, bool *pos_def) { // the stepwise entry point (srba_hip_solve)
+	hipLaunchKernelGGL(srbadev::kb_set_scalar, dim3(1), dim3(1), 0, c->stream, c->d_scal + BS_LAMBDA, lambda);
+	big_enqueue_assemble(c, p);
+	if (big_timed_cholesky(c, p) != 0) return -1;
+	big_enqueue_backsub(c, p);
+	int flag = 0; HIPCHK(c, hipMemcpyAsync(&flag, c->d_iscal + 1, 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+	big_account_cholesky(c, p);
+	*pos_def = (flag == 0);
 	HIPCHK(c, hipGetLastError());
 	return 0;
 }
@@ -1001,23 +1049,26 @@ static int big_lm_run(srba_hip_ctx *c, int p) {
 	const bool schur = prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0;
 	srba_lm_result out; std::memset(&out, 0, sizeof(out));
 	for (int k = 0; k < SRBA_TRACE_LEN; k++) { out.trace_chi2[k] = NAN; out.trace_lambda[k] = NAN; out.trace_rho[k] = NAN; }
-	double *resid = c->B.resid, *resid2 = c->B.resid2;
-	auto residuals = [&](double *dst, double *val) -> int { const int nb = big_grid(d.n_obs, 256); BIGK(kb_residuals, d.n_obs, 256, dst, c->d_part); big_reduce(c, 0, nb, 0, 0);
-		HIPCHK(c, hipMemcpyAsync(val, c->d_scal, 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; };
-	auto linearize = [&]() { BIGK(kb_jac_init, d.n_valid, 256); BIGK(kb_jac, d.n_bp + d.n_bf, 128); BIGK(kb_jac_post, d.n_bp + d.n_bf, 256); BIGK(kb_hessian, d.n_hap + d.n_hf + d.n_hapf, 128, c->d_iscal); };
+	double *resid = c->B.resid, *resid2 = c->B.resid2; const int *flag = c->d_iscal + 1; const double *lam = c->d_scal + BS_LAMBDA;
+	auto enqueue_residuals = [&](double *dst, const int *skip) { const int nb = big_grid(d.n_obs, 256); BIGK(kb_residuals, d.n_obs, 256, dst, c->d_part, skip); big_reduce(c, 0, nb, BS_CHI2, 0); };
+	auto enqueue_linearize = [&]() { BIGK(kb_jac_init, d.n_valid, 256); BIGK(kb_jac, d.n_bp + d.n_bf, 128); BIGK(kb_jac_post, d.n_bp + d.n_bf, 256); BIGK(kb_hessian, d.n_hap + d.n_hf + d.n_hapf, 128, c->d_iscal); BIGKG(kb_hessian_heavy, d.n_hap, 256, c->d_iscal); };
+	auto enqueue_gradient = [&]() { BIGKG(kb_gradient, d.nK + (d.nF + 255) / 256, 256, resid); };
+	auto enqueue_dot = [&](int which, int slot, int is_max, const int *skip) { const int nb = big_grid(d.n_scal, 256); BIGK(kb_dot, d.n_scal, 256, lam, c->d_part + kBigPart, c->d_part + 2 * kBigPart, skip); big_reduce(c, which, nb, slot, is_max); };
+	double hs[4] = {0, 0, 0, 0}; int hflag = 0;
+	auto fetch = [&]() -> int { HIPCHK(c, hipMemcpyAsync(hs, c->d_scal, 32, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipMemcpyAsync(&hflag, flag, 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; };
 	HIPCHK(c, hipMemsetAsync(c->d_iscal, 0, 32, c->stream));
-	BIGK(kb_spantree, d.n_pairs, 256, 0);   // S5
-	linearize();                            // S6, S7, S10
+	BIGK(kb_spantree, d.n_pairs, 256, 0, (const int *)nullptr);   // S5
+	enqueue_linearize();                                          // S6, S7, S10
 	int ninv = 0; HIPCHK(c, hipMemcpyAsync(&ninv, c->d_iscal, 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
 	out.num_invalid_jacobs = ninv; out.num_observations = d.n_obs; out.num_jacobians = d.n_bp + d.n_bf; out.num_span_tree_numeric_updates = d.n_pairs;
 	auto finish = [&]() -> int { HIPCHK(c, hipMemcpyAsync(c->B.results + p, &out, sizeof(out), hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; };
 	if ((long long)O * d.n_obs < (long long)d.n_scal) { out.status = 1; return finish(); } // S11
-	double lambda = 0, nu = 2.0, total_err = 0;
-	{ const int nb = big_grid(d.nK + d.nF, 256); BIGK(kb_maxdiag, d.nK + d.nF, 256, c->d_part); big_reduce(c, 0, nb, 1, 1); HIPCHK(c, hipMemcpyAsync(&lambda, c->d_scal + 1, 8, hipMemcpyDeviceToHost, c->stream)); } // S12
-	if (residuals(resid, &total_err) != 0) return -1;   // S13
-	lambda *= 1e-3; double RMSE = std::sqrt(total_err / d.n_obs);
+	{ const int nb = big_grid(d.nK + d.nF, 256); BIGK(kb_maxdiag, d.nK + d.nF, 256, c->d_part + kBigPart); big_reduce(c, 1, nb, BS_MAXDIAG, 1); } // S12
+	enqueue_residuals(resid, nullptr);   // S13
+	enqueue_gradient();                  // S14
+	if (fetch() != 0) return -1;
+	double lambda = hs[BS_MAXDIAG] * 1e-3, nu = 2.0, total_err = hs[BS_CHI2], RMSE = std::sqrt(total_err / d.n_obs);
 	out.lambda_init = lambda; out.total_sqr_error_init = total_err;
-	BIGK(kb_gradient, d.nK + d.nF, 128, resid); // S14
 	int iter = 0, trials = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0; bool stop = false;
 	for (iter = 0; iter < prm.max_iters && !stop; iter++) {
 		double rho = 0;
@@ -1025,26 +1076,34 @@ static int big_lm_run(srba_hip_ctx *c, int p) {
 		if (RMSE < prm.max_error_per_obs_to_stop) { stop = true; stopmask |= 1 << SRBA_STOP_RMSE; }
 		while (rho <= 0 && !stop) {
 			const int tr = trials++; if (tr < SRBA_TRACE_LEN) out.trace_lambda[tr] = lambda;
-			bool pd = true; if (big_solve(c, p, lambda, &pd) != 0) return -1;
-			if (!pd) { n_notpd++; lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA; continue; }
-			BIGK(kb_apply, d.nK + (long long)d.nF * L + d.n_req, 128);
-			BIGK(kb_spantree, d.n_need, 256, 1);
-			double new_err = 0; if (residuals(resid2, &new_err) != 0) return -1;
-			const double new_RMSE = std::sqrt(new_err / d.n_obs), err_red = total_err > 0 ? (total_err - new_err) / total_err : 0;
-			double dn[2] = {0, 0};
-			{ const int nb = big_grid(d.n_scal, 256); BIGK(kb_dot, d.n_scal, 256, lambda, c->d_part + kBigPart, c->d_part + 2 * kBigPart); big_reduce(c, 1, nb, 2, 0);
-			  HIPCHK(c, hipMemcpyAsync(dn, c->d_scal + 2, 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
-			rho = (total_err - new_err) / dn[0];
+			// one trial = solve, apply, numeric spanning tree of the poses in use, residuals, rho denominator; kernels after the factorisation return at once if it failed
+			hipLaunchKernelGGL(srbadev::kb_set_scalar, dim3(1), dim3(1), 0, c->stream, c->d_scal + BS_LAMBDA, lambda);
+			if (big_replay(c, p, 0, [&]() { big_enqueue_assemble(c, p); }) != 0) return -1;
+			if (big_timed_cholesky(c, p) != 0) return -1;
+			if (big_replay(c, p, 2, [&]() {
+				big_enqueue_backsub(c, p);
+				BIGK(kb_apply, d.nK + (long long)d.nF * L + d.n_req, 128, flag);
+				BIGK(kb_spantree, d.n_need, 256, 1, flag);
+				enqueue_residuals(resid2, flag);
+				enqueue_dot(1, BS_DEN, 0, flag); }) != 0) return -1;
+			if (fetch() != 0) return -1;
+			big_account_cholesky(c, p);
+			if (hflag) { n_notpd++; lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA; continue; }
+			const double new_err = hs[BS_CHI2], new_RMSE = std::sqrt(new_err / d.n_obs), err_red = total_err > 0 ? (total_err - new_err) / total_err : 0;
+			rho = (total_err - new_err) / hs[BS_DEN];
 			if (tr < SRBA_TRACE_LEN) { out.trace_chi2[tr] = new_err; out.trace_rho[tr] = rho; }
 			if (rho > 0) {
 				n_acc++;
 				const bool relin = (err_red < 0 || err_red > prm.min_error_reduction_ratio_to_relinearize);
-				std::swap(resid, resid2); total_err = new_err; RMSE = new_RMSE;
-				if (relin) { n_relin++; linearize(); }
-				BIGK(kb_gradient, d.nK + d.nF, 128, resid);
-				double ninf = 0; { const int nb = big_grid(d.n_scal, 256); BIGK(kb_dot, d.n_scal, 256, lambda, c->d_part + kBigPart, c->d_part + 2 * kBigPart); big_reduce(c, 2, nb, 3, 1);
-				  HIPCHK(c, hipMemcpyAsync(&ninf, c->d_scal + 3, 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
-				if (ninf <= 1e-15) { stop = true; stopmask |= 1 << SRBA_STOP_GRADIENT; }
+				total_err = new_err; RMSE = new_RMSE;
+				if (relin) n_relin++;
+				if (big_replay(c, p, relin ? 3 : 4, [&]() {
+					hipMemcpyAsync(resid + (long long)d.o_obs * O, resid2 + (long long)d.o_obs * O, sizeof(double) * (size_t)d.n_obs * O, hipMemcpyDeviceToDevice, c->stream);
+					if (relin) enqueue_linearize();
+					enqueue_gradient();
+					enqueue_dot(2, BS_NINF, 1, nullptr); }) != 0) return -1;
+				if (fetch() != 0) return -1;
+				if (hs[BS_NINF] <= 1e-15) { stop = true; stopmask |= 1 << SRBA_STOP_GRADIENT; }
 				if (RMSE < prm.max_error_per_obs_to_stop) { stop = true; stopmask |= 1 << SRBA_STOP_RMSE; }
 				if (rho > prm.max_rho) { stop = true; stopmask |= 1 << SRBA_STOP_RHO; }
 				lambda *= 1.0 / 3.0; nu = 2.0;
@@ -1062,6 +1121,7 @@ static int big_lm_run(srba_hip_ctx *c, int p) {
 	return finish();
 }
 #undef BIGK
+#undef BIGKG
 
 extern "C" {
 
