@@ -205,11 +205,8 @@ int run(const Args &a, const Dataset &ds) {
 		std::ofstream f(a.str("save-edges").c_str()); f.precision(17);
 		for (size_t i = 0; i < rba.get_k2k_edges().size(); i++) { const typename my_srba_t::k2k_edge_t &e = rba.get_k2k_edges()[i]; double p[12]; e.inv_pose.storeTo(p); f << e.id << " " << e.from << " " << e.to; for (size_t k = 0; k < my_srba_t::pose_t::storage_doubles(); k++) f << " " << p[k]; f << "\n"; }
 	}
-	if (a.has("save-final-graph")) { // Graphviz file of the key-frame graph (RbaEngine::save_graph_as_dot)
-		std::ofstream f(a.str("save-final-graph").c_str()); f << "graph G {\n";
-		for (size_t i = 0; i < rba.get_k2k_edges().size(); i++) f << " " << rba.get_k2k_edges()[i].from << " -- " << rba.get_k2k_edges()[i].to << ";\n";
-		f << "}\n";
-	}
+	if (a.has("save-final-graph")) { if (!rba.save_graph_as_dot(a.str("save-final-graph"), false)) throw std::runtime_error("cannot write " + a.str("save-final-graph")); }   // key-frames only
+	if (a.has("save-final-graph-landmarks")) { if (!rba.save_graph_as_dot(a.str("save-final-graph-landmarks"), true)) throw std::runtime_error("cannot write " + a.str("save-final-graph-landmarks")); }
 	return 0;
 }
 

@@ -16,10 +16,16 @@
 #include <algorithm>
 #include <cmath>
 #include <cstddef>
+#include <cstdarg>
 #include <cstdint>
+#include <cstdio>
 #include <deque>
+#include <fstream>
 #include <iostream>
+#include <list>
 #include <map>
+#include <random>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -31,14 +37,31 @@
 #define SRBA_STR2(x) #x
 #define SRBA_STR(x) SRBA_STR2(x)
 #ifndef ASSERT_
-#define ASSERT_(c) do { if (!(c)) throw std::logic_error(std::string("Assert failed: " #c " at " __FILE__ ":" SRBA_STR(__LINE__))); } while (0)
-#define ASSERTMSG_(c, msg) do { if (!(c)) throw std::logic_error(std::string(msg)); } while (0)
+// (MRPT's assertion macros are complete statements: code written for it uses them with and without a trailing ';')
+#define ASSERT_(c) { if (!(c)) throw std::logic_error(std::string("Assert failed: " #c " at " __FILE__ ":" SRBA_STR(__LINE__))); }
+#define ASSERTMSG_(c, msg) { if (!(c)) throw std::logic_error(std::string(msg)); }
 #define ASSERTDEB_(c) ((void)0)
 #define MRPT_UNUSED_PARAM(x) (void)(x)
+#define ASSERT_EQUAL_(a, b) ASSERT_((a) == (b))
+#define ASSERT_ABOVE_(a, b) ASSERT_((a) > (b))
+#define ASSERT_BELOW_(a, b) ASSERT_((a) < (b))
+#define ASSERT_ABOVEEQ_(a, b) ASSERT_((a) >= (b))
+#define ASSERT_BELOWEQ_(a, b) ASSERT_((a) <= (b))
+#define THROW_EXCEPTION(msg) { throw std::logic_error(std::string(msg)); }
+#define MRPT_TODO(x)
+#define MRPT_START
+#define MRPT_END
+#endif
+#ifndef MRPT_HAS_WXWIDGETS
+#define MRPT_HAS_WXWIDGETS 0
+#endif
+#ifndef MRPT_HAS_CXX11
+#define MRPT_HAS_CXX11 1
 #endif
 
 namespace mrpt {
 namespace utils {
+class CConfigFileBase;
 template <class T> inline T square(const T x) { return x * x; }
 inline double DEG2RAD(const double x) { return x * M_PI / 180.0; }
 inline double RAD2DEG(const double x) { return x * 180.0 / M_PI; }
@@ -47,10 +70,13 @@ struct TPixelCoordf { float x, y; TPixelCoordf() : x(0), y(0) {} TPixelCoordf(fl
 /** Pinhole intrinsics, the subset SRBA reads (models/sensors.h:59-60,98-99). */
 struct TCamera {
 	double m_fx, m_fy, m_cx, m_cy; unsigned ncols, nrows;
+	struct dist_t { double v[5]; dist_t() { setZero(); } void setZero() { for (int i = 0; i < 5; i++) v[i] = 0; } double &operator[](int i) { return v[i]; } const double &operator[](int i) const { return v[i]; } } dist; // [k1 k2 t1 t2 k3]; SRBA's sensor models ignore distortion
 	TCamera() : m_fx(1), m_fy(1), m_cx(0), m_cy(0), ncols(640), nrows(480) {}
 	double fx() const { return m_fx; } double fy() const { return m_fy; } double cx() const { return m_cx; } double cy() const { return m_cy; }
 	void fx(double v) { m_fx = v; } void fy(double v) { m_fy = v; } void cx(double v) { m_cx = v; } void cy(double v) { m_cy = v; }
 	void setIntrinsicParamsFromValues(double fx_, double fy_, double cx_, double cy_) { m_fx = fx_; m_fy = fy_; m_cx = cx_; m_cy = cy_; }
+	/** keys resolution = [W H], cx, cy, fx, fy, dist = [k1 k2 t1 t2 k3] of the given section (the layout of the reference's dataset .cfg files) */
+	void loadFromConfigFile(const std::string &section, const CConfigFileBase &cfg);
 };
 } // namespace utils
 
@@ -76,6 +102,8 @@ template <std::size_t N> struct CArrayDouble {
 template <std::size_t R, std::size_t C> struct CMatrixFixed {
 	double m[R * C];
 	CMatrixFixed() { setZero(); }
+	/** from any matrix expression with operator()(r, c) (an Eigen matrix in user code written for the reference) */
+	template <class M, class = decltype(std::declval<const M &>()(0, 0))> CMatrixFixed(const M &o) { for (std::size_t r = 0; r < R; r++) for (std::size_t c = 0; c < C; c++) m[r * C + c] = o(r, c); }
 	double &operator()(std::size_t r, std::size_t c) { return m[r * C + c]; } const double &operator()(std::size_t r, std::size_t c) const { return m[r * C + c]; }
 	double &coeffRef(std::size_t r, std::size_t c) { return m[r * C + c]; } double coeff(std::size_t r, std::size_t c) const { return m[r * C + c]; }
 	void setZero() { for (std::size_t i = 0; i < R * C; i++) m[i] = 0; }
@@ -85,6 +113,17 @@ template <std::size_t R, std::size_t C> struct CMatrixFixed {
 };
 typedef CMatrixFixed<3, 3> CMatrixDouble33;
 typedef CMatrixFixed<4, 4> CMatrixDouble44;
+/** Run-time sized row-major matrix (mrpt::math::CMatrixDouble / CMatrixD), the subset the reference's tutorials and apps use. */
+struct CMatrixDouble {
+	std::size_t nr, nc; std::vector<double> m;
+	CMatrixDouble(std::size_t r = 0, std::size_t c = 0) : nr(r), nc(c), m(r * c, 0.0) {}
+	void setSize(std::size_t r, std::size_t c) { nr = r; nc = c; m.assign(r * c, 0.0); }
+	double &operator()(std::size_t r, std::size_t c) { return m[r * nc + c]; } const double &operator()(std::size_t r, std::size_t c) const { return m[r * nc + c]; }
+	double &coeffRef(std::size_t r, std::size_t c) { return m[r * nc + c]; } double coeff(std::size_t r, std::size_t c) const { return m[r * nc + c]; }
+	std::size_t size() const { return nr * nc; } std::size_t rows() const { return nr; } std::size_t cols() const { return nc; } std::size_t getRowCount() const { return nr; } std::size_t getColCount() const { return nc; }
+	void loadFromTextFile(const std::string &file); void saveToTextFile(const std::string &file) const;
+};
+typedef CMatrixDouble CMatrixD;
 
 struct CQuaternionDouble {
 	double q[4]; // r,x,y,z
@@ -232,8 +271,26 @@ public:
 	CPose3DQuat(double x, double y, double z, const math::CQuaternionDouble &q) : m_q(q) { m_t[0] = x; m_t[1] = y; m_t[2] = z; }
 	double x() const { return m_t[0]; } double y() const { return m_t[1]; } double z() const { return m_t[2]; }
 	const math::CQuaternionDouble &quat() const { return m_q; }
+	explicit CPose3DQuat(const CPose3D &p);
+	/** "[x y z qr qx qy qz]" */
+	void fromString(const std::string &s) { std::string t(s); for (char &ch : t) if (ch == '[' || ch == ']' || ch == ',') ch = ' '; std::istringstream is(t); double v[7] = {0, 0, 0, 1, 0, 0, 0}; for (int i = 0; i < 7 && (is >> v[i]); i++) {} *this = CPose3DQuat(v[0], v[1], v[2], math::CQuaternionDouble(v[3], v[4], v[5], v[6])); }
+	std::string asString() const { std::ostringstream o; o << "[" << m_t[0] << " " << m_t[1] << " " << m_t[2] << " " << m_q.r() << " " << m_q.x() << " " << m_q.y() << " " << m_q.z() << "]"; return o.str(); }
 };
 inline CPose3D::CPose3D(const CPose3DQuat &q) { m_t[0] = q.m_t[0]; m_t[1] = q.m_t[1]; m_t[2] = q.m_t[2]; q.m_q.rotationMatrix(m_R); }
+
+/** quaternion of a rotation matrix (row-major), w >= 0 */
+inline CPose3DQuat::CPose3DQuat(const CPose3D &p) {
+	m_t[0] = p.m_t[0]; m_t[1] = p.m_t[1]; m_t[2] = p.m_t[2]; const double *R = p.m_R; const double tr = R[0] + R[4] + R[8]; double q[4];
+	if (tr > 0) { const double s = 2 * std::sqrt(tr + 1); q[0] = 0.25 * s; q[1] = (R[7] - R[5]) / s; q[2] = (R[2] - R[6]) / s; q[3] = (R[3] - R[1]) / s; }
+	else if (R[0] > R[4] && R[0] > R[8]) { const double s = 2 * std::sqrt(1 + R[0] - R[4] - R[8]); q[0] = (R[7] - R[5]) / s; q[1] = 0.25 * s; q[2] = (R[1] + R[3]) / s; q[3] = (R[2] + R[6]) / s; }
+	else if (R[4] > R[8]) { const double s = 2 * std::sqrt(1 + R[4] - R[0] - R[8]); q[0] = (R[2] - R[6]) / s; q[1] = (R[1] + R[3]) / s; q[2] = 0.25 * s; q[3] = (R[5] + R[7]) / s; }
+	else { const double s = 2 * std::sqrt(1 + R[8] - R[0] - R[4]); q[0] = (R[3] - R[1]) / s; q[1] = (R[2] + R[6]) / s; q[2] = (R[5] + R[7]) / s; q[3] = 0.25 * s; }
+	if (q[0] < 0) for (int i = 0; i < 4; i++) q[i] = -q[i];
+	m_q = math::CQuaternionDouble(q[0], q[1], q[2], q[3]);
+}
+/** A - B = (-)B (+) A: the pose of A as seen from B */
+inline CPose3DQuat operator-(const CPose3DQuat &a, const CPose3DQuat &b) { return CPose3DQuat(CPose3D(a) - CPose3D(b)); }
+inline std::ostream &operator<<(std::ostream &o, const CPose3DQuat &p) { return o << p.asString(); }
 
 template <std::size_t DOF> struct SE_traits;
 template <> struct SE_traits<3> {
@@ -250,7 +307,11 @@ template <> struct SE_traits<2> {
 
 namespace utils {
 /** Stereo rig calibration (mrpt::utils::TStereoCamera). */
-struct TStereoCamera { TCamera leftCamera, rightCamera; poses::CPose3DQuat rightCameraPose; };
+struct TStereoCamera {
+	TCamera leftCamera, rightCamera; poses::CPose3DQuat rightCameraPose;
+	/** sections <section>_LEFT, <section>_RIGHT (TCamera keys) and <section>_LEFT2RIGHT_POSE with pose_quaternion = [x y z qr qx qy qz] */
+	void loadFromConfigFile(const std::string &section, const CConfigFileBase &cfg);
+};
 struct TMatchingPair {
 	unsigned this_idx, other_idx; double this_x, this_y, this_z, other_x, other_y, other_z;
 	TMatchingPair(unsigned ti, unsigned oi, double tx, double ty, double tz, double ox, double oy, double oz) : this_idx(ti), other_idx(oi), this_x(tx), this_y(ty), this_z(tz), other_x(ox), other_y(oy), other_z(oz) {}
@@ -333,6 +394,11 @@ public:
 	void registerUserMeasure(const char *name, double v) { if (m_enabled) { auto &d = m_data[name]; d.n++; d.total += v; } }
 	struct TCallData { std::size_t n = 0; double total = 0, t0 = 0; };
 	const std::map<std::string, TCallData> &getStats() const { return m_data; }
+	struct TCallStats { double min_t, max_t, mean_t, total_t; std::size_t n_calls; TCallStats() : min_t(0), max_t(0), mean_t(0), total_t(0), n_calls(0) {} };
+	/** per-section summary with the reference's field names (min / max are not tracked here: both report the mean) */
+	void getStats(std::map<std::string, TCallStats> &out) const { out.clear(); for (std::map<std::string, TCallData>::const_iterator it = m_data.begin(); it != m_data.end(); ++it) { TCallStats &s = out[it->first]; s.n_calls = it->second.n; s.total_t = it->second.total; s.mean_t = it->second.n ? it->second.total / it->second.n : 0; s.min_t = s.max_t = s.mean_t; } }
+	void clear(bool = false) { m_data.clear(); }
+	void dumpAllStats(std::size_t = 0) const { for (std::map<std::string, TCallData>::const_iterator it = m_data.begin(); it != m_data.end(); ++it) std::cout << it->first << ": calls " << it->second.n << " total " << it->second.total << " s\n"; }
 	double getMeanTime(const std::string &name) const { auto it = m_data.find(name); return (it == m_data.end() || !it->second.n) ? 0 : it->second.total / it->second.n; }
 private:
 	bool m_enabled; std::map<std::string, TCallData> m_data;
@@ -351,3 +417,138 @@ inline double mrpt::utils::CTimeLogger::leave(const char *name) {
 	const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - d.t0;
 	d.n++; d.total += dt; return dt;
 }
+
+inline void mrpt::math::CMatrixDouble::loadFromTextFile(const std::string &file) {
+	std::ifstream f(file.c_str()); if (!f) throw std::runtime_error("CMatrixDouble::loadFromTextFile: cannot open " + file);
+	std::vector<std::vector<double> > rowsv; std::string line;
+	while (std::getline(f, line)) { if (line.empty() || line[0] == '%' || line[0] == '#') continue; std::istringstream is(line); std::vector<double> r; double v; while (is >> v) r.push_back(v); if (!r.empty()) rowsv.push_back(r); }
+	setSize(rowsv.size(), rowsv.empty() ? 0 : rowsv[0].size());
+	for (std::size_t r = 0; r < nr; r++) for (std::size_t c = 0; c < nc && c < rowsv[r].size(); c++) m[r * nc + c] = rowsv[r][c];
+}
+inline void mrpt::math::CMatrixDouble::saveToTextFile(const std::string &file) const {
+	std::ofstream f(file.c_str()); f.precision(17); for (std::size_t r = 0; r < nr; r++) { for (std::size_t c = 0; c < nc; c++) f << (c ? " " : "") << m[r * nc + c]; f << "\n"; }
+}
+
+namespace mrpt {
+namespace utils {
+/** INI-style configuration source/sink (mrpt::utils::CConfigFileBase): sections of name = value lines, '#' / ';' / '//' comments. */
+class CConfigFileBase {
+public:
+	virtual ~CConfigFileBase() {}
+	template <class T> T read(const std::string &section, const std::string &name, const T &def, bool fail_if_missing = false) const {
+		const std::string *v = find(section, name);
+		if (!v) { if (fail_if_missing) throw std::runtime_error("config value not found: [" + section + "] " + name); return def; }
+		return parse(*v, def);
+	}
+	double read_double(const std::string &s, const std::string &n, double d, bool f = false) const { return read<double>(s, n, d, f); }
+	int read_int(const std::string &s, const std::string &n, int d, bool f = false) const { return read<int>(s, n, d, f); }
+	uint64_t read_uint64_t(const std::string &s, const std::string &n, uint64_t d, bool f = false) const { return read<uint64_t>(s, n, d, f); }
+	bool read_bool(const std::string &s, const std::string &n, bool d, bool f = false) const { return read<bool>(s, n, d, f); }
+	std::string read_string(const std::string &s, const std::string &n, const std::string &d, bool f = false) const { return read<std::string>(s, n, d, f); }
+	bool sectionExists(const std::string &section) const { return m_data.count(section) != 0; }
+	template <class T> void write(const std::string &section, const std::string &name, const T &value, int = -1, int = -1, const std::string &comment = std::string()) {
+		std::ostringstream o; o.precision(17); o << value; m_data[section][name] = o.str(); if (!comment.empty()) m_comments[section + "\n" + name] = comment; m_dirty = true;
+	}
+	void write(const std::string &section, const std::string &name, const bool &value, int = -1, int = -1, const std::string &comment = std::string()) { write<std::string>(section, name, value ? "true" : "false", -1, -1, comment); }
+protected:
+	const std::string *find(const std::string &section, const std::string &name) const {
+		const std::map<std::string, std::map<std::string, std::string> >::const_iterator s = m_data.find(section); if (s == m_data.end()) return NULL;
+		const std::map<std::string, std::string>::const_iterator v = s->second.find(name); return v == s->second.end() ? NULL : &v->second;
+	}
+	template <class T> static T parse(const std::string &v, const T &) { std::istringstream is(v); T out = T(); is >> out; return out; }
+	static bool parse(const std::string &v, const bool &) { return !v.empty() && (v[0] == '1' || v[0] == 't' || v[0] == 'T' || v[0] == 'y' || v[0] == 'Y'); }
+	static std::string parse(const std::string &v, const std::string &) { return v; }
+	std::map<std::string, std::map<std::string, std::string> > m_data; std::map<std::string, std::string> m_comments; bool m_dirty = false;
+};
+/** file-backed variant: parsed on construction, written back by writeNow() or on destruction if modified */
+class CConfigFile : public CConfigFileBase {
+public:
+	explicit CConfigFile(const std::string &file) : m_file(file) {
+		std::ifstream f(file.c_str()); std::string line, section;
+		while (std::getline(f, line)) {
+			const size_t c = line.find_first_of("#;"); if (c != std::string::npos) line.erase(c); const size_t c2 = line.find("//"); if (c2 != std::string::npos) line.erase(c2);
+			const size_t a = line.find_first_not_of(" \t\r"); if (a == std::string::npos) continue; const size_t b = line.find_last_not_of(" \t\r"); line = line.substr(a, b - a + 1);
+			if (line[0] == '[') { const size_t e = line.find(']'); section = line.substr(1, e == std::string::npos ? std::string::npos : e - 1); continue; }
+			const size_t eq = line.find('='); if (eq == std::string::npos) continue;
+			std::string k = line.substr(0, eq), v = line.substr(eq + 1);
+			k.erase(k.find_last_not_of(" \t") + 1); const size_t vs = v.find_first_not_of(" \t"); v = vs == std::string::npos ? std::string() : v.substr(vs);
+			m_data[section][k] = v;
+		}
+	}
+	~CConfigFile() { if (m_dirty) writeNow(); }
+	void writeNow() {
+		std::ofstream f(m_file.c_str());
+		for (std::map<std::string, std::map<std::string, std::string> >::const_iterator s = m_data.begin(); s != m_data.end(); ++s) {
+			f << "[" << s->first << "]\n";
+			for (std::map<std::string, std::string>::const_iterator v = s->second.begin(); v != s->second.end(); ++v) {
+				f << v->first << " = " << v->second; const std::map<std::string, std::string>::const_iterator c = m_comments.find(s->first + "\n" + v->first); if (c != m_comments.end()) f << "   // " << c->second; f << "\n";
+			}
+			f << "\n";
+		}
+		m_dirty = false;
+	}
+private:
+	std::string m_file;
+};
+/** in-memory variant */
+class CConfigFileMemory : public CConfigFileBase {
+public:
+	std::string getContent() const { std::ostringstream o; for (std::map<std::string, std::map<std::string, std::string> >::const_iterator s = m_data.begin(); s != m_data.end(); ++s) { o << "[" << s->first << "]\n"; for (std::map<std::string, std::string>::const_iterator v = s->second.begin(); v != s->second.end(); ++v) o << v->first << " = " << v->second << "\n"; } return o.str(); }
+};
+/** parameter blocks that read / write themselves from a configuration section (mrpt::utils::CLoadableOptions) */
+class CLoadableOptions {
+public:
+	virtual ~CLoadableOptions() {}
+	virtual void loadFromConfigFile(const CConfigFileBase &source, const std::string &section) = 0;
+	virtual void saveToConfigFile(CConfigFileBase &, const std::string &) const {}
+	void loadFromConfigFileName(const std::string &config_file, const std::string &section) { CConfigFile f(config_file); loadFromConfigFile(f, section); }
+	void saveToConfigFileName(const std::string &config_file, const std::string &section) const { CConfigFile f(config_file); saveToConfigFile(f, section); f.writeNow(); }
+	virtual void dumpToConsole() const { CConfigFileMemory m; saveToConfigFile(m, ""); std::cout << m.getContent(); }
+};
+} // namespace utils
+namespace utils {
+namespace detail { inline std::vector<double> numbers_of(const std::string &s) { std::string t(s); for (char &ch : t) if (ch == '[' || ch == ']' || ch == ',' || ch == ';') ch = ' '; std::istringstream is(t); std::vector<double> v; double x; while (is >> x) v.push_back(x); return v; } }
+inline void TCamera::loadFromConfigFile(const std::string &section, const CConfigFileBase &cfg) {
+	const std::vector<double> res = detail::numbers_of(cfg.read<std::string>(section, "resolution", "", true));
+	if (res.size() != 2) throw std::runtime_error("[" + section + "] resolution: expected [W H]");
+	ncols = (unsigned)res[0]; nrows = (unsigned)res[1];
+	m_fx = cfg.read<double>(section, "fx", 0, true); m_fy = cfg.read<double>(section, "fy", 0, true); m_cx = cfg.read<double>(section, "cx", 0, true); m_cy = cfg.read<double>(section, "cy", 0, true);
+	const std::vector<double> d = detail::numbers_of(cfg.read<std::string>(section, "dist", "")); dist.setZero(); for (std::size_t i = 0; i < d.size() && i < 5; i++) dist[(int)i] = d[i];
+}
+inline void TStereoCamera::loadFromConfigFile(const std::string &section, const CConfigFileBase &cfg) {
+	leftCamera.loadFromConfigFile(section + "_LEFT", cfg); rightCamera.loadFromConfigFile(section + "_RIGHT", cfg);
+	rightCameraPose.fromString(cfg.read<std::string>(section + "_LEFT2RIGHT_POSE", "pose_quaternion", "", true));
+}
+} // namespace utils
+#define MRPT_LOAD_CONFIG_VAR(var, type, source, section) var = (source).template read<type>((section), #var, static_cast<type>(var));
+/** printf-style formatting into a std::string (mrpt::format) */
+inline std::string format(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+inline std::string format(const char *fmt, ...) { char buf[2048]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap); return std::string(buf); }
+template <class T1, class T2 = void> struct aligned_containers { typedef std::vector<T1> vector_t; typedef std::deque<T1> deque_t; typedef std::map<T1, T2> map_t; };
+template <class T1> struct aligned_containers<T1, void> { typedef std::vector<T1> vector_t; typedef std::deque<T1> deque_t; };
+namespace random {
+/** mrpt::random::CRandomGenerator, the draws SRBA's callers use (Gaussian / uniform), on std::mt19937_64 */
+class CRandomGenerator {
+public:
+	CRandomGenerator() : m_gen(5489u) {}
+	void randomize(const uint32_t seed) { m_gen.seed(seed); } void randomize() { m_gen.seed(std::random_device()()); }
+	double drawGaussian1D_normalized() { return m_norm(m_gen); }
+	double drawGaussian1D(const double mean, const double std) { return mean + std * m_norm(m_gen); }
+	double drawUniform(const double a, const double b) { return a + (b - a) * std::generate_canonical<double, 53>(m_gen); }
+	uint32_t drawUniform32bit() { return (uint32_t)m_gen(); }
+private:
+	std::mt19937_64 m_gen; std::normal_distribution<double> m_norm;
+};
+inline CRandomGenerator &getRandomGenerator() { static CRandomGenerator g; return g; }
+static CRandomGenerator &randomGenerator = getRandomGenerator();
+} // namespace random
+} // namespace mrpt
+
+/** User code written for the reference spells fixed-size matrices as Eigen::Matrix<double,R,C> (e.g. parameters.obs_noise.lambda); without Eigen
+ *  the same spelling maps to mrpt::math::CMatrixFixed. Skipped when the real Eigen has been included first. */
+#if !defined(EIGEN_CORE_H) && !defined(EIGEN_CORE_MODULE_H) && !defined(SRBA_NO_EIGEN_ALIAS)
+namespace Eigen {
+template <class T, int R, int C> using Matrix = mrpt::math::CMatrixFixed<(std::size_t)R, (std::size_t)C>;
+typedef Matrix<double, 2, 2> Matrix2d; typedef Matrix<double, 3, 3> Matrix3d; typedef Matrix<double, 4, 4> Matrix4d;
+} // namespace Eigen
+#endif

@@ -1,0 +1,2 @@
+#pragma once
+#include <mrpt_lite_apps.h>

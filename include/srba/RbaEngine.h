@@ -19,6 +19,7 @@
 #include "capsule_builder.h"
 #include "srba_options.h"
 #include <cstring>
+#include <fstream>
 #include <functional>
 #include <limits>
 #include <memory>
@@ -188,7 +189,11 @@ namespace ecps {
 /** Sub-maps of fixed size: every key-frame hangs from the centre of its area (first key-frame of each block of submap_size ids); a key-frame that
  *  opens a new area, or that re-observes landmarks of another area far away in the graph, adds centre-to-centre edges (ecps/local_areas_fixed_size.h). */
 struct local_areas_fixed_size {
-	struct parameters_t { size_t submap_size, min_obs_to_loop_closure; parameters_t() : submap_size(15), min_obs_to_loop_closure(4) {} };
+	struct parameters_t : public mrpt::utils::CLoadableOptions {
+		size_t submap_size, min_obs_to_loop_closure; parameters_t() : submap_size(15), min_obs_to_loop_closure(4) {}
+		void loadFromConfigFile(const mrpt::utils::CConfigFileBase &source, const std::string &section) override { submap_size = (size_t)source.read<uint64_t>(section, "submap_size", submap_size); min_obs_to_loop_closure = (size_t)source.read<uint64_t>(section, "min_obs_to_loop_closure", min_obs_to_loop_closure); }
+		void saveToConfigFile(mrpt::utils::CConfigFileBase &out, const std::string &section) const override { out.write(section, "submap_size", (uint64_t)submap_size, 30, 30, "Key-frames per sub-map"); out.write(section, "min_obs_to_loop_closure", (uint64_t)min_obs_to_loop_closure, 30, 30, "Min. num. of covisible observations to add a loop closure edge"); }
+	};
 	TKeyFrameID get_center_kf_for_kf(const TKeyFrameID kf_id, const parameters_t &params) const { return params.submap_size * (kf_id / params.submap_size); }
 
 	template <class traits_t, class rba_engine_t>
@@ -233,7 +238,11 @@ struct local_areas_fixed_size {
 /** The classic linear graph: key-frame n hangs from n-1 (starting at the same pose), plus a direct edge to every base key-frame of re-observed
  *  landmarks that is out of reach of the spanning trees (ecps/classic_linear_rba.h). */
 struct classic_linear_rba {
-	struct parameters_t { size_t min_obs_to_loop_closure; parameters_t() : min_obs_to_loop_closure(4) {} };
+	struct parameters_t : public mrpt::utils::CLoadableOptions {
+		size_t min_obs_to_loop_closure; parameters_t() : min_obs_to_loop_closure(4) {}
+		void loadFromConfigFile(const mrpt::utils::CConfigFileBase &source, const std::string &section) override { min_obs_to_loop_closure = (size_t)source.read<uint64_t>(section, "min_obs_to_loop_closure", min_obs_to_loop_closure); }
+		void saveToConfigFile(mrpt::utils::CConfigFileBase &out, const std::string &section) const override { out.write(section, "min_obs_to_loop_closure", (uint64_t)min_obs_to_loop_closure, 30, 30, "Min. num. of covisible observations to add a loop closure edge"); }
+	};
 
 	template <class traits_t, class rba_engine_t>
 	void eval(const TKeyFrameID new_kf_id, const typename traits_t::new_kf_observations_t &obs, std::vector<TNewEdgeInfo> &out_edges, rba_engine_t &rba_engine, const parameters_t &params) {
@@ -312,7 +321,7 @@ public:
 		TOptimizeLocalAreaParams() : optimize_k2k_edges(true), optimize_landmarks(true), max_visitable_kf_id(static_cast<TKeyFrameID>(-1)), dont_optimize_landmarks_seen_less_than_n_times(2) {}
 	};
 	/** Run-time parameters (reference RbaEngine.h:424-460; default VALUES are those of impl/rba_problem_common.h:35-56) */
-	struct TSRBAParameters {
+	struct TSRBAParameters : public mrpt::utils::CLoadableOptions {
 		topo_dist_t max_tree_depth, max_optimize_depth;
 		bool optimize_new_edges_alone, use_robust_kernel, use_robust_kernel_stage1;
 		double kernel_param; size_t max_iters; double max_error_per_obs_to_stop, max_rho, max_lambda, min_error_reduction_ratio_to_relinearize;
@@ -329,8 +338,25 @@ public:
 		TSRBAParameters() : max_tree_depth(4), max_optimize_depth(4), optimize_new_edges_alone(true), use_robust_kernel(false), use_robust_kernel_stage1(false), kernel_param(3.), max_iters(20),
 			max_error_per_obs_to_stop(1e-6), max_rho(10.0), max_lambda(1e20), min_error_reduction_ratio_to_relinearize(0.01), numeric_jacobians(false), feedback_user_iteration(NULL),
 			compute_condition_number(false), compute_sparsity_stats(false), max_rmse_show_red_warning(0.5), cov_recovery(crpLandmarksApprox), refresh_all_read_poses(false), restore_spanning_tree_twins(false) {}
-		void dumpToConsole() const { std::cout << "max_tree_depth=" << max_tree_depth << " max_optimize_depth=" << max_optimize_depth << " optimize_new_edges_alone=" << optimize_new_edges_alone << " use_robust_kernel=" << use_robust_kernel
-			<< " kernel_param=" << kernel_param << " max_iters=" << max_iters << " max_error_per_obs_to_stop=" << max_error_per_obs_to_stop << " max_rho=" << max_rho << " max_lambda=" << max_lambda << "\n"; }
+		/** keys of the reference's configuration files (impl/rba_problem_common.h:60-92); cov_recovery by enumerator name or number */
+		void loadFromConfigFile(const mrpt::utils::CConfigFileBase &source, const std::string &section) override {
+			max_tree_depth = (topo_dist_t)source.read<uint64_t>(section, "max_tree_depth", max_tree_depth); max_optimize_depth = (topo_dist_t)source.read<uint64_t>(section, "max_optimize_depth", max_optimize_depth);
+			optimize_new_edges_alone = source.read<bool>(section, "optimize_new_edges_alone", optimize_new_edges_alone);
+			use_robust_kernel = source.read<bool>(section, "use_robust_kernel", use_robust_kernel); use_robust_kernel_stage1 = source.read<bool>(section, "use_robust_kernel_stage1", use_robust_kernel_stage1);
+			max_rho = source.read<double>(section, "max_rho", max_rho); max_lambda = source.read<double>(section, "max_lambda", max_lambda); kernel_param = source.read<double>(section, "kernel_param", kernel_param);
+			max_iters = (size_t)source.read<uint64_t>(section, "max_iters", max_iters); max_error_per_obs_to_stop = source.read<double>(section, "max_error_per_obs_to_stop", max_error_per_obs_to_stop);
+			const std::string cr = source.read<std::string>(section, "cov_recovery", cov_recovery == crpNone ? "crpNone" : "crpLandmarksApprox");
+			cov_recovery = (cr == "crpNone" || cr == "0") ? crpNone : crpLandmarksApprox;
+		}
+		void saveToConfigFile(mrpt::utils::CConfigFileBase &out, const std::string &section) const override {
+			out.write(section, "max_tree_depth", (uint64_t)max_tree_depth, 30, 30, "Maximum depth of all spanning trees"); out.write(section, "max_optimize_depth", (uint64_t)max_optimize_depth, 30, 30, "Max. local optimization distance");
+			out.write(section, "optimize_new_edges_alone", optimize_new_edges_alone, 30, 30, "Optimize new edges alone before optimizing the entire local area?");
+			out.write(section, "use_robust_kernel", use_robust_kernel, 30, 30, "Use pseudo-Huber kernel?"); out.write(section, "use_robust_kernel_stage1", use_robust_kernel_stage1, 30, 30, "Use pseudo-Huber kernel at stage1?");
+			out.write(section, "kernel_param", kernel_param, 30, 30, "robust kernel parameter"); out.write(section, "max_rho", max_rho, 30, 30, "Lev-Marq optimization: maximum rho value to stop");
+			out.write(section, "max_lambda", max_lambda, 30, 30, "Lev-Marq optimization: maximum lambda to stop"); out.write(section, "max_iters", (uint64_t)max_iters, 30, 30, "Max. iterations for optimization");
+			out.write(section, "max_error_per_obs_to_stop", max_error_per_obs_to_stop, 30, 30, "Another criterion for stopping optimization");
+			out.write(section, "cov_recovery", std::string(cov_recovery == crpNone ? "crpNone" : "crpLandmarksApprox"), 30, 30, "Covariance recovery policy");
+		}
 	};
 	struct TAllParameters {
 		TSRBAParameters srba;
@@ -478,6 +504,104 @@ public:
 		frameid2pose_map_t tree; create_complete_spanning_tree(params.root_kf_id, tree);
 		for (typename frameid2pose_map_t::const_iterator it = tree.begin(); it != tree.end(); ++it) global_graph.nodes[it->first] = it->second.pose;
 		for (size_t e = 0; e < rba_state.k2k_edges.size(); e++) global_graph.insertEdgeAtEnd(rba_state.k2k_edges[e].to, rba_state.k2k_edges[e].from, rba_state.k2k_edges[e].inv_pose);
+	}
+
+	/** The map as a graphviz digraph (impl/export_dot.h:15-84): key-frames as boxes, kf2kf edges in bold, and -- if asked -- every landmark as a triangle hanging
+	 *  from its base key-frame (grey = fixed relative position, white = unknown) with dotted observation arcs. Returns false if the file cannot be written. */
+	bool save_graph_as_dot(const std::string &targetFileName, const bool all_landmarks = false) const {
+		std::ofstream f(targetFileName.c_str()); if (!f.is_open()) return false;
+		f << "digraph G {\n";
+		const size_t nKF = rba_state.keyframes.size();
+		if (nKF) {
+			f << "/* KEYFRAMES */\nnode [shape=box,style=filled];\n";
+			for (size_t id = 0; id < nKF; id++) f << id << "; ";
+			f << "\n/* KEYFRAME->KEYFRAME edges */\nedge [style=bold];\n";
+			for (size_t e = 0; e < rba_state.k2k_edges.size(); e++) f << rba_state.k2k_edges[e].from << "->" << rba_state.k2k_edges[e].to << ";\n";
+			if (all_landmarks) {
+				const struct { const TRelativeLandmarkPosMap *lms; const char *header; } groups[2] = {
+					{&rba_state.known_lms, "/* LANDMARKS with known relative position, and its base keyframe */\nnode [shape=triangle,style=filled,fillcolor=gray80];\nedge [style=bold,color=black];\n"},
+					{&rba_state.unknown_lms, "/* LANDMARKS with unknown relative position */\nnode [shape=triangle,style=filled,fillcolor=white];\nedge [style=solid,color=gray20];\n"}};
+				for (int g = 0; g < 2; g++) {
+					f << groups[g].header;
+					for (typename TRelativeLandmarkPosMap::const_iterator it = groups[g].lms->begin(); it != groups[g].lms->end(); ++it) f << it->second.id_frame_base << " -> L" << it->first << "; ";
+					f << "\n";
+				}
+				f << "/* OBSERVATIONS */\nedge [style=dotted,color=black];\n";
+				for (size_t o = 0; o < rba_state.obs_table.size(); o++) f << rba_state.obs_table[o].kf_id << " -> L" << rba_state.obs_table[o].obs.feat_id << ";\n";
+				f << "\n";
+			}
+		}
+		f << "\n}\n";
+		return f.good();
+	}
+	/** Only the key-frames with two or more kf2kf edges (the sub-map centres and loop closures) as an undirected graph (impl/export_dot.h:87-126); with
+	 *  set_node_coordinates each node carries its position in the frame of key-frame 0 (complete spanning tree) as a graphviz "pos" attribute. */
+	bool save_graph_top_structure_as_dot(const std::string &targetFileName, const bool set_node_coordinates) const {
+		std::ofstream f(targetFileName.c_str()); if (!f.is_open()) return false;
+		f << "graph G {\n";
+		const size_t nKF = rba_state.keyframes.size();
+		if (nKF) {
+			std::vector<size_t> degree(nKF, 0);
+			for (size_t e = 0; e < rba_state.k2k_edges.size(); e++) { degree[rba_state.k2k_edges[e].from]++; degree[rba_state.k2k_edges[e].to]++; }
+			frameid2pose_map_t tree; if (set_node_coordinates) create_complete_spanning_tree(0, tree);
+			f << "/* KEYFRAMES */\nnode [shape=box,style=filled];\n";
+			for (size_t id = 0; id < nKF; id++) if (degree[id] >= 2) {
+				f << id;
+				if (set_node_coordinates) { const typename frameid2pose_map_t::const_iterator it = tree.find((TKeyFrameID)id); if (it != tree.end()) f << " [pos=\"" << it->second.pose.x() << "," << it->second.pose.y() << "!\"]"; }
+				f << "; ";
+			}
+			f << "\n/* KEYFRAME->KEYFRAME edges */\nedge [style=bold];\n";
+			for (size_t e = 0; e < rba_state.k2k_edges.size(); e++) if (degree[rba_state.k2k_edges[e].from] >= 2 && degree[rba_state.k2k_edges[e].to] >= 2) f << rba_state.k2k_edges[e].from << "--" << rba_state.k2k_edges[e].to << ";\n";
+		}
+		f << "\n}\n";
+		return f.good();
+	}
+
+	/** Rendering options of build_opengl_representation() (RbaEngine.h:244-264 of the reference). */
+	struct TOpenGLRepresentationOptions {
+		size_t span_tree_max_depth; bool draw_unknown_feats, draw_unknown_feats_ellipses; double draw_unknown_feats_ellipses_quantiles; bool show_unknown_feats_ids, draw_kf_hierarchical; double draw_kf_hierarchical_height;
+		TOpenGLRepresentationOptions() : span_tree_max_depth(std::numeric_limits<size_t>::max()), draw_unknown_feats(true), draw_unknown_feats_ellipses(true), draw_unknown_feats_ellipses_quantiles(1), show_unknown_feats_ids(true), draw_kf_hierarchical(false), draw_kf_hierarchical_height(10.0) {}
+	};
+	/** The geometry of the 3D view of the reference (impl/export_opengl.h:24-224): every key-frame within span_tree_max_depth of root_keyframe as a corner at its
+	 *  pose in the root's frame, a line per kf2kf edge between drawn key-frames, and the landmarks as points (relative position composed with their base key-frame).
+	 *  SCENE_PTR is mrpt::opengl::CSetOfObjectsPtr; this layer only emits primitives through insert_corner / insert_line / insert_point / insert_text (the
+	 *  mrpt_lite stand-in records them, a build against the real MRPT maps them onto stock_objects::CornerXYZSimple, CSetOfLines and CPointCloud). */
+	template <class SCENE_PTR> void build_opengl_representation(const TKeyFrameID root_keyframe, const TOpenGLRepresentationOptions &options, SCENE_PTR out_scene, SCENE_PTR out_root_tree = SCENE_PTR()) const {
+		if (out_scene) {
+			out_scene->clear();
+			if (rba_state.keyframes.empty()) return;
+			frameid2pose_map_t tree; create_complete_spanning_tree(root_keyframe, tree, options.span_tree_max_depth);
+			std::vector<size_t> degree(rba_state.keyframes.size(), 0);
+			for (size_t e = 0; e < rba_state.k2k_edges.size(); e++) { degree[rba_state.k2k_edges[e].from]++; degree[rba_state.k2k_edges[e].to]++; }
+			auto lifted = [&](TKeyFrameID id, const pose_t &p) { mrpt::poses::CPose3D q(p); if (options.draw_kf_hierarchical && degree[id] >= 2) q.m_t[2] += options.draw_kf_hierarchical_height; return q; };
+			for (typename frameid2pose_map_t::const_iterator it = tree.begin(); it != tree.end(); ++it) { out_scene->insert_corner(lifted(it->first, it->second.pose), it->first == root_keyframe ? 1.0 : 0.25); out_scene->insert_text(lifted(it->first, it->second.pose), mrpt::format("%u", (unsigned)it->first)); }
+			for (size_t e = 0; e < rba_state.k2k_edges.size(); e++) {
+				const typename frameid2pose_map_t::const_iterator a = tree.find(rba_state.k2k_edges[e].from), b = tree.find(rba_state.k2k_edges[e].to);
+				if (a != tree.end() && b != tree.end()) out_scene->insert_line(lifted(a->first, a->second.pose), lifted(b->first, b->second.pose));
+			}
+			for (int g = 0; g < (options.draw_unknown_feats ? 2 : 1); g++) {
+				const TRelativeLandmarkPosMap &lms = g ? rba_state.unknown_lms : rba_state.known_lms;
+				for (typename TRelativeLandmarkPosMap::const_iterator it = lms.begin(); it != lms.end(); ++it) {
+					const typename frameid2pose_map_t::const_iterator base = tree.find(it->second.id_frame_base); if (base == tree.end()) continue;
+					double l[3] = {0, 0, 0}, gl[3]; for (size_t k = 0; k < LM_DIMS && k < 3; k++) l[k] = it->second.pos[k];
+					mrpt::poses::CPose3D(base->second.pose).composePoint(l[0], l[1], l[2], gl[0], gl[1], gl[2]);
+					out_scene->insert_point(gl[0], gl[1], gl[2], g != 0);
+					if (g && options.show_unknown_feats_ids) out_scene->insert_text(mrpt::poses::CPose3D(gl[0], gl[1], gl[2], 0, 0, 0), mrpt::format("%u", (unsigned)it->first));
+				}
+			}
+		}
+		if (out_root_tree) { // schematic view of the root's symbolic spanning tree: one line per (key-frame, next key-frame towards the root), laid out by distance
+			out_root_tree->clear();
+			std::map<TKeyFrameID, std::pair<double, double> > where; where[root_keyframe] = std::make_pair(0.0, 0.0); std::map<topo_dist_t, size_t> used;
+			const graph::st_table &st = rba_state.topo.st; const graph::st_entry *row = st.row((graph::id32)root_keyframe); const size_t n_row = st.len((graph::id32)root_keyframe);
+			for (size_t i = 0; i < n_row; i++) where[row[i].trg] = std::make_pair((double)(used[row[i].dist]++), -(double)row[i].dist);
+			for (size_t i = 0; i < n_row; i++) {
+				const graph::st_entry *back = st.find(row[i].trg, (graph::id32)root_keyframe); if (!back) continue;
+				const k2k_edge_t &ed = rba_state.k2k_edges[back->next]; const TKeyFrameID nxt = ed.from == (TKeyFrameID)row[i].trg ? ed.to : ed.from;
+				const std::pair<double, double> a = where[row[i].trg], b = where[nxt];
+				out_root_tree->insert_line(mrpt::poses::CPose3D(a.first, a.second, 0, 0, 0, 0), mrpt::poses::CPose3D(b.first, b.second, 0, 0, 0, 0));
+			}
+		}
 	}
 
 	void enable_time_profiler(bool enable = true) { m_profiler.enable(enable); }
