@@ -297,14 +297,12 @@ __global__ void __launch_bounds__(256) kb_reduce(const double *partial, int n, d
 }
 __global__ void kb_set_scalar(double *dst, double v) { *dst = v; }
 template <int O, int M> __device__ __forceinline__ void grad_term(double (&acc)[M], const double *A, const double *r, const DevParams &prm) {
-	double lr[O];
-#pragma unroll
-	for (int k = 0; k < O; k++) lr[k] = r[k];
+	double lr[O], a[O * M]; ldn<O>(lr, r); ldn<O * M>(a, A);
 	if (prm.noise == SRBA_NOISE_CONSTANT_MATRIX) { double t[O]; for (int k = 0; k < O; k++) { double q = 0; for (int j = 0; j < O; j++) q += prm.lambda[k * O + j] * lr[j]; t[k] = q; } for (int k = 0; k < O; k++) lr[k] = t[k]; }
 #pragma unroll
 	for (int q = 0; q < M; q++) { double sm = 0;
 #pragma unroll
-		for (int k = 0; k < O; k++) sm += A[k * M + q] * lr[k];
+		for (int k = 0; k < O; k++) sm += a[k * M + q] * lr[k];
 		acc[q] += sm; }
 }
 // Gradient (K5). Workgroups 0 .. nK-1: one per unknown edge, its dh_dAp blocks strided over the 256 threads (an edge of a deep window has 10^3..10^4 of them),

@@ -99,10 +99,24 @@ struct P2 { double x, y, phi, c, s; };
 struct P3 { double t[3]; double R[9]; };
 __device__ __forceinline__ P2 ident2() { P2 r; r.x = 0; r.y = 0; r.phi = 0; r.c = 1; r.s = 0; return r; }
 __device__ __forceinline__ P3 ident3() { P3 r; r.t[0] = r.t[1] = r.t[2] = 0; r.R[0] = 1; r.R[1] = 0; r.R[2] = 0; r.R[3] = 0; r.R[4] = 1; r.R[5] = 0; r.R[6] = 0; r.R[7] = 0; r.R[8] = 1; return r; }
-__device__ __forceinline__ P2 ld2(const double *p) { P2 r; r.x = p[0]; r.y = p[1]; r.phi = p[2]; r.c = p[3]; r.s = p[4]; return r; }
-__device__ __forceinline__ void st2(double *p, const P2 &a) { p[0] = a.x; p[1] = a.y; p[2] = a.phi; p[3] = a.c; p[4] = a.s; }
-__device__ __forceinline__ P3 ld3(const double *p) { P3 r; for (int i = 0; i < 3; i++) r.t[i] = p[i]; for (int i = 0; i < 9; i++) r.R[i] = p[3 + i]; return r; }
-__device__ __forceinline__ void st3(double *p, const P3 &a) { for (int i = 0; i < 3; i++) p[i] = a.t[i]; for (int i = 0; i < 9; i++) p[3 + i] = a.R[i]; }
+// Small fixed-size records (poses, Jacobian / Hessian blocks) are gathered by lanes that each read their own record: the vector memory pipeline then handles one
+// request per lane and per instruction, whatever its width. Records are therefore moved 16 bytes at a time (global_load / store_dwordx4; gfx950 only asks for dword
+// alignment of the address, and the records are 8-byte aligned): a 72-byte block costs 5 requests instead of 9.
+typedef double f64x2u __attribute__((ext_vector_type(2), aligned(8)));
+template <int N> __device__ __forceinline__ void ldn(double *dst, const double *src) {
+#pragma unroll
+	for (int k = 0; k + 1 < N; k += 2) { const f64x2u v = *(const f64x2u *)(src + k); dst[k] = v.x; dst[k + 1] = v.y; }
+	if (N & 1) dst[N - 1] = src[N - 1];
+}
+template <int N> __device__ __forceinline__ void stn(double *dst, const double *src) {
+#pragma unroll
+	for (int k = 0; k + 1 < N; k += 2) { f64x2u v; v.x = src[k]; v.y = src[k + 1]; *(f64x2u *)(dst + k) = v; }
+	if (N & 1) dst[N - 1] = src[N - 1];
+}
+__device__ __forceinline__ P2 ld2(const double *p) { double v[5]; ldn<5>(v, p); P2 r; r.x = v[0]; r.y = v[1]; r.phi = v[2]; r.c = v[3]; r.s = v[4]; return r; }
+__device__ __forceinline__ void st2(double *p, const P2 &a) { const double v[5] = {a.x, a.y, a.phi, a.c, a.s}; stn<5>(p, v); }
+__device__ __forceinline__ P3 ld3(const double *p) { double v[12]; ldn<12>(v, p); P3 r; for (int i = 0; i < 3; i++) r.t[i] = v[i]; for (int i = 0; i < 9; i++) r.R[i] = v[3 + i]; return r; }
+__device__ __forceinline__ void st3(double *p, const P3 &a) { double v[12]; for (int i = 0; i < 3; i++) v[i] = a.t[i]; for (int i = 0; i < 9; i++) v[3 + i] = a.R[i]; stn<12>(p, v); }
 __device__ __forceinline__ P2 comp(const P2 &A, const P2 &B) { P2 r; r.x = A.x + B.x * A.c - B.y * A.s; r.y = A.y + B.x * A.s + B.y * A.c; r.phi = wrap_pi(A.phi + B.phi); r.c = A.c * B.c - A.s * B.s; r.s = A.s * B.c + A.c * B.s; return r; }
 __device__ __forceinline__ P2 inv(const P2 &A) { P2 r; r.x = -A.x * A.c - A.y * A.s; r.y = A.x * A.s - A.y * A.c; r.phi = -A.phi; r.c = A.c; r.s = -A.s; return r; }
 __device__ __forceinline__ P3 comp(const P3 &A, const P3 &B) {
@@ -656,7 +670,7 @@ struct Worker {
 				}
 			}
 		}
-		if (ok) { for (int k = 0; k < O * P; k++) J[k] = Jl[k]; }
+		if (ok) stn<O * P>(J, Jl);
 		else atomicMin(&B.first_fail[d.o_valid + vs], b); // sweep index of a dh_dAp block = b
 	}
 	// ---- K3
@@ -686,7 +700,7 @@ struct Worker {
 				double H[O * 3]; ok = dh_dx(H, xl);
 				if (ok) for (int i = 0; i < O; i++) for (int j = 0; j < 3; j++) Jl[i * 3 + j] = H[i * 3] * bp.R[j] + H[i * 3 + 1] * bp.R[3 + j] + H[i * 3 + 2] * bp.R[6 + j];
 			}
-			if (ok) { for (int k = 0; k < O * L; k++) J[k] = Jl[k]; }
+			if (ok) stn<O * L>(J, Jl);
 			else atomicMin(&B.first_fail[d.o_valid + vs], d.n_bp + b); // dh_df blocks are swept after all dh_dAp blocks
 		}
 	}
@@ -740,21 +754,21 @@ struct Worker {
 				const int a1 = t1[t], a2 = t2[t], c1 = t1[t + 1], c2 = t2[t + 1];
 				const bool oka = ok1[a1] && ok2[a2], okc = ok1[c1] && ok2[c2];
 				double A[O * M1], Bm[O * M2], C[O * M1], Dm[O * M2];
-#pragma unroll
-				for (int k = 0; k < O * M1; k++) { A[k] = J1[(long long)a1 * O * M1 + k]; C[k] = J1[(long long)c1 * O * M1 + k]; }
-#pragma unroll
-				for (int k = 0; k < O * M2; k++) { Bm[k] = J2[(long long)a2 * O * M2 + k]; Dm[k] = J2[(long long)c2 * O * M2 + k]; }
+				ldn<O * M1>(A, J1 + (long long)a1 * O * M1); ldn<O * M1>(C, J1 + (long long)c1 * O * M1);
+				ldn<O * M2>(Bm, J2 + (long long)a2 * O * M2); ldn<O * M2>(Dm, J2 + (long long)c2 * O * M2);
 				if (oka) hess_term<M1, M2>(H, A, Bm); else ninv++;
 				if (okc) hess_term<M1, M2>(H, C, Dm); else ninv++;
 			}
 		}
 		for (; t < te; t++) {
 			const int b1 = t1[t], b2 = t2[t];
-			if (ok1[b1] && ok2[b2]) hess_term<M1, M2>(H, J1 + (long long)b1 * O * M1, J2 + (long long)b2 * O * M2); else ninv++;
+			double A[O * M1], Bm[O * M2]; ldn<O * M1>(A, J1 + (long long)b1 * O * M1); ldn<O * M2>(Bm, J2 + (long long)b2 * O * M2);
+			if (ok1[b1] && ok2[b2]) hess_term<M1, M2>(H, A, Bm); else ninv++;
 		}
 		const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0;
 #pragma unroll
-		for (int k = 0; k < M1 * M2; k++) { const double v = H[k] * sc; Hout[k] = v; if (Hlatch) Hlatch[k] = v; }
+		for (int k = 0; k < M1 * M2; k++) H[k] *= sc;
+		stn<M1 * M2>(Hout, H); if (Hlatch) stn<M1 * M2>(Hlatch, H);
 		return ninv;
 	}
 	__device__ int phase_hessian() { fresh(); // returns the per-thread invalid count (to be reduced by the caller if wanted)
@@ -804,10 +818,7 @@ struct Worker {
 						const int b = b0 + u * S;
 						if (b < be) {
 							const double *Ab = J + (long long)b * O * M, *r = resid + (long long)(d.o_obs + res[b]) * O;
-#pragma unroll
-							for (int k = 0; k < O * M; k++) A[u][k] = Ab[k];
-#pragma unroll
-							for (int k = 0; k < O; k++) lr[u][k] = r[k];
+							ldn<O * M>(A[u], Ab); ldn<O>(lr[u], r);
 						}
 					}
 #pragma unroll

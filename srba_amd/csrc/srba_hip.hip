@@ -394,6 +394,7 @@ template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_rollback(const B
 
 } // namespace srbadev
 #include "srba_big.hpp"
+#include "srba_flat.hpp"
 namespace srbadev {
 // ---- whole-map squared error (eval_overall_error.h:15-137): a plain streaming pair of kernels over ONE problem (desc[0]), grid-stride
 // K1 over all (observer, base) pairs: compose the breadth-first path from the root of the pair (spantree_create_complete.h:96-124)
@@ -590,6 +591,7 @@ struct srba_hip_ctx {
 	double big_chol_ms = 0, big_chol_flops = 0; long long big_chol_count = 0; int big_chol_nmax = 0; hipEvent_t big_e0 = nullptr, big_e1 = nullptr; // Cholesky time / flops of the big path since the last upload
 	struct BigGraphSet { hipGraphExec_t g[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; }; // assemble, Cholesky, back-substitution .. rho, accept + relinearise, accept
 	std::map<int, BigGraphSet> big_graphs; bool big_use_graphs = false; // captured launch sequences of the big path, per capsule; dropped at upload
+	srbadev::FlatMap flat; bool flat_ready = false, use_flat = true; // pair -> capsule map of the flat spanning-tree kernel (srba_flat.hpp), filled on first use after an upload
 	int big_min_sys = 480;   // systems with more scalar unknowns than this skip the block-sparse symbolic analysis and go dense (big path)
 	std::vector<char> h_in; size_t h_off_order = 0; // host staging of the input arena (kept: the launch order is read back from it)
 	int max_lds_kb = 1 << 20, min_chunk = 384, max_parts_per_queue = 2; int n_queues = 16, sched = 3, n_streams_used = 1, n_cu = 256, waves_per_cu = 8, lds_per_cu = 160 * 1024; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
@@ -718,6 +720,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	for (int k = 1; k < SRBA_NCLS && ok; k++) ok = hipStreamCreateWithFlags(&c->cls_stream[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->cls_done[k], hipEventDisableTiming) == hipSuccess;
 	if (!ok || hipMalloc((void **)&c->d_next, sizeof(int) * kMaxJobs) != hipSuccess || hipMalloc((void **)&c->d_part, 8 * 3 * kBigPart) != hipSuccess || hipMalloc((void **)&c->d_scal, 8 * 16) != hipSuccess || hipMalloc((void **)&c->d_iscal, 4 * 8) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	{ const char *e = getenv("SRBA_HIP_BIG_MIN_SYS"); if (e && atoi(e) >= 0) c->big_min_sys = atoi(e); } // tuning / test knob
+	{ const char *e = getenv("SRBA_HIP_FLAT"); if (e) c->use_flat = atoi(e) != 0; }                     // 0 = one wavefront per capsule for the stepwise spanning-tree launch
 	{ const char *e = getenv("SRBA_HIP_BIG_GRAPHS"); if (e) c->big_use_graphs = atoi(e) != 0; }         // 1 = replay the big path's launch sequences as HIP graphs (measured: no gain, the path is bound by its kernels)
 	return c;
 }
@@ -883,12 +886,13 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 		plan_launches(c, ord);
 	}
 	// ---- work arena layout
-	Arena wk; struct { size_t edge, ulm, pose, Jp, Jf, resid, resid2, HAp, HAp0, Hf, HApf, grad, delta, Hfinv, YW, old_edge, old_ulm, old_pose, dense, ulm_inf, valid, first_fail, hf_ok, bp_ok, bf_ok, ulm_inf_valid, results, lambda_io, chi2, notpd, phase_cycles; } w;
+	Arena wk; struct { size_t edge, ulm, pose, Jp, Jf, resid, resid2, HAp, HAp0, Hf, HApf, grad, delta, Hfinv, YW, old_edge, old_ulm, old_pose, dense, ulm_inf, valid, first_fail, hf_ok, bp_ok, bf_ok, ulm_inf_valid, results, lambda_io, chi2, notpd, phase_cycles, m_pair; } w;
 	w.edge = wk.add(8 * t_edge * PDX); w.ulm = wk.add(8 * t_ulm * L); w.pose = wk.add(8 * 2 * t_pair * PDX); w.Jp = wk.add(8 * t_bp * O * P); w.Jf = wk.add(8 * t_bf * O * L);
 	w.resid = wk.add(8 * t_obs * O); w.resid2 = wk.add(8 * t_obs * O); w.HAp = wk.add(8 * t_hap * P * P); w.HAp0 = wk.add(8 * t_hap * P * P); w.Hf = wk.add(8 * t_hf * L * L); w.HApf = wk.add(8 * t_hapf * P * L);
 	w.grad = wk.add(8 * t_scal); w.delta = wk.add(8 * t_scal); w.Hfinv = wk.add(8 * t_ulm * L * L); w.YW = wk.add(8 * t_yw * P * L); w.old_edge = wk.add(8 * t_unk * PDX); w.old_ulm = wk.add(8 * t_ulm * L); w.old_pose = wk.add(8 * t_req * PDX);
 	w.dense = wk.add(8 * t_dense); w.ulm_inf = wk.add(8 * t_ulm * L * L); w.valid = wk.add(4 * t_valid); w.first_fail = wk.add(4 * t_valid); w.hf_ok = wk.add(4 * t_ulm); w.bp_ok = wk.add(t_bp); w.bf_ok = wk.add(t_bf); w.ulm_inf_valid = wk.add(t_ulm);
 	w.results = wk.add(sizeof(srba_lm_result) * n); w.lambda_io = wk.add(8 * n); w.chi2 = wk.add(8 * n); w.notpd = wk.add(4 * n); w.phase_cycles = wk.add(8 * 16 * (size_t)n);
+	w.m_pair = wk.add(4 * t_pair);
 	wk.add(0);
 	if (in.size + 256 > c->cap_in) { if (c->d_in) hipFree(c->d_in); c->d_in = nullptr; c->cap_in = 0; const size_t want = (in.size + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_in, want)); c->cap_in = want; }
 	if (wk.size + 256 > c->cap_wk) { if (c->d_wk) hipFree(c->d_wk); c->d_wk = nullptr; c->cap_wk = 0; const size_t want = (wk.size + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_wk, want)); c->cap_wk = want; }
@@ -908,6 +912,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	DW(edge, double); DW(ulm, double); DW(pose, double); DW(Jp, double); DW(Jf, double); DW(resid, double); DW(resid2, double); DW(HAp, double); DW(HAp0, double); DW(Hf, double); DW(HApf, double); DW(grad, double); DW(delta, double);
 	DW(Hfinv, double); DW(YW, double); DW(old_edge, double); DW(old_ulm, double); DW(old_pose, double); DW(dense, double); DW(ulm_inf, double); DW(valid, int); DW(first_fail, int); DW(hf_ok, int); DW(bp_ok, unsigned char); DW(bf_ok, unsigned char); DW(ulm_inf_valid, unsigned char);
 	DW(results, srba_lm_result); DW(lambda_io, double); DW(chi2, double); DW(notpd, int);
+	c->flat.pair = (int *)(dw + w.m_pair); c->flat.n_pair = t_pair; c->flat_ready = false;
 	c->off_phase = w.phase_cycles; B.phase_cycles = c->phase_timing ? (long long *)(dw + w.phase_cycles) : nullptr;
 #undef DW
 	c->off_edge = w.edge; c->off_ulm = w.ulm; c->off_pose = w.pose; c->off_inf = w.ulm_inf; c->off_infv = w.ulm_inf_valid; c->off_res = w.results;
@@ -1210,7 +1215,20 @@ int srba_hip_lm_run(srba_hip_ctx *c, srba_lm_result *results) {
 	return 0;
 }
 
-int srba_hip_update_spantree(srba_hip_ctx *c, int only_needed) { if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device)); SRBA_DISPATCH(c, k_spantree, 0, only_needed); HIPCHK(c, hipGetLastError()); return 0; }
+// the flat (one thread per item of the batch) launches of srba_flat.hpp
+static inline int flat_grid(long long items, int block) { return (int)std::max<long long>(1, std::min<long long>((items + block - 1) / block, 1 << 20)); }
+#define FLATK(KERNEL, items, block, ...) with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), dim3(flat_grid((items), (block))), dim3(block), 0, c->stream, c->B, c->dp, ##__VA_ARGS__); })
+static int flat_prepare(srba_hip_ctx *c) {
+	if (c->flat_ready) return 0;
+	hipLaunchKernelGGL(srbadev::kf_fill_maps, dim3(c->n_prob), dim3(256), 0, c->stream, c->B, c->flat); HIPCHK(c, hipGetLastError());
+	c->flat_ready = true; return 0;
+}
+int srba_hip_update_spantree(srba_hip_ctx *c, int only_needed) {
+	if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device));
+	if (c->use_flat) { if (flat_prepare(c) != 0) return -1; FLATK(kf_spantree, c->flat.n_pair, 256, c->flat, only_needed); }
+	else SRBA_DISPATCH(c, k_spantree, 0, only_needed);
+	HIPCHK(c, hipGetLastError()); return 0;
+}
 int srba_hip_eval_residuals(srba_hip_ctx *c, double *chi2_out) {
 	if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device));
 	SRBA_DISPATCH(c, k_residuals, 16 * 8); HIPCHK(c, hipGetLastError());

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ instruction-mix / stall counters of the fused LM kernel on the BENCHMARK batch (separate --pmc passes, kernel trace only, as the guide prescribes).
+# SQ instruction-mix / stall counters and HBM byte counters of the fused LM kernel and of the streaming kernels on the BENCHMARK batch (separate --pmc passes, kernel trace only, as the guide prescribes).
 # Output: gpurun_out/sq_summary.json (per-launch sums over the k_lm_run dispatches) -> copy to profiles/rNN_sq_summary.json
 R=$PWD; mkdir -p gpurun_out/pmcb; rm -rf gpurun_out/pmcb/*
 export GPU_MAX_HW_QUEUES=16
@@ -11,28 +11,39 @@ run SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
 run SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA
 run SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_BRANCH
 run SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM GRBM_GUI_ACTIVE SQ_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_ADDR_CONFLICT
+run FETCH_SIZE
+run WRITE_SIZE
 cd $R
 python - <<'PY'
 import csv, glob, collections, json
-out = {}
-for f in sorted(glob.glob('gpurun_out/pmcb/*counter_collection.csv')):
-    rows = [r for r in csv.DictReader(open(f)) if 'k_lm_run' in r['Kernel_Name']]
-    if not rows: continue
-    disp = sorted(set(int(r['Dispatch_Id']) for r in rows))
-    # the bench makes 2 fused launches with --steps 1 --warmup 0 (functional run + timed step): average per launch
-    n_launch = 2
-    acc = collections.defaultdict(float)
-    for r in rows: acc[r['Counter_Name']] += float(r['Counter_Value'])
-    for k, v in acc.items(): out[k] = v / n_launch
-    out.setdefault('_dispatches_per_launch', len(disp) / n_launch)
 d = json.loads([l for l in open('gpurun_out/pmcb_bench.json') if l.startswith('{')][-1])
-out['_lm_trials_per_launch'] = d['config']['lm_trials_per_step_per_gpu']; out['_kernel_ms'] = d['roofline']['kernel_ms']
-tot = sum(out.get(k, 0) for k in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM_RD', 'SQ_INSTS_VMEM_WR', 'SQ_INSTS_SMEM', 'SQ_INSTS_BRANCH'))
-out['_derived'] = {'wave_instructions_per_launch': tot, 'wave_instructions_per_trial': tot / max(1, out['_lm_trials_per_launch']),
-                   'wait_any_over_wave_cycles': out.get('SQ_WAIT_ANY', 0) / max(1, out.get('SQ_WAVE_CYCLES', 1)),
-                   'active_inst_any_over_wave_cycles': out.get('SQ_ACTIVE_INST_ANY', 0) / max(1, out.get('SQ_WAVE_CYCLES', 1)),
-                   'mean_active_lanes_per_valu_inst': out.get('SQ_THREAD_CYCLES_VALU', 0) / max(1, 4 * out.get('SQ_ACTIVE_INST_VALU', 1)) if out.get('SQ_THREAD_CYCLES_VALU') else None}
-json.dump(out, open('gpurun_out/sq_summary.json', 'w'), indent=1, sort_keys=True)
-print(json.dumps(out, indent=1, sort_keys=True))
+# per launch: the bench (--steps 1 --warmup 0) makes 2 fused launches (functional run + timed step) and 11 launches of each streaming kernel
+KERNELS = {'k_lm_run': 2, 'k_linearize': 11, 'k_spantree': 11, 'k_residuals': 11}
+res = {}
+for kname, n_launch in KERNELS.items():
+    out = {}
+    for f in sorted(glob.glob('gpurun_out/pmcb/*counter_collection.csv')):
+        rows = [r for r in csv.DictReader(open(f)) if kname + '<' in r['Kernel_Name'] or kname + 'ILi' in r['Kernel_Name']]
+        rows = [r for r in rows if int(r.get('Grid_Size', 1 << 20)) > 4096]   # not the single-capsule launches of the sequential harvest (when the cache is cold)
+        if not rows: continue
+        disp = sorted(set(int(r['Dispatch_Id']) for r in rows))
+        acc = collections.defaultdict(float)
+        for r in rows: acc[r['Counter_Name']] += float(r['Counter_Value'])
+        for k, v in acc.items(): out[k] = v / n_launch
+        out.setdefault('_dispatches_per_launch', len(disp) / n_launch)
+    if not out: continue
+    tot = sum(out.get(k, 0) for k in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM_RD', 'SQ_INSTS_VMEM_WR', 'SQ_INSTS_SMEM', 'SQ_INSTS_BRANCH'))
+    out['_derived'] = {'wave_instructions_per_launch': tot,
+                       'wait_any_over_wave_cycles': out.get('SQ_WAIT_ANY', 0) / max(1, out.get('SQ_WAVE_CYCLES', 1)),
+                       'active_inst_any_over_wave_cycles': out.get('SQ_ACTIVE_INST_ANY', 0) / max(1, out.get('SQ_WAVE_CYCLES', 1)),
+                       'mean_active_lanes_per_valu_inst': out.get('SQ_THREAD_CYCLES_VALU', 0) / max(1, 4 * out.get('SQ_ACTIVE_INST_VALU', 1)) if out.get('SQ_THREAD_CYCLES_VALU') else None,
+                       'hbm_bytes_per_launch': {'FETCH_SIZE_KB_raw': out.get('FETCH_SIZE'), 'WRITE_SIZE_KB_raw': out.get('WRITE_SIZE'),
+                                                'note': 'rocprofv3 derived counters in KB, as reported; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 128-B requests of wide coalesced reads at 64 B (x2 for such reads), other widths and WRITE_SIZE uncalibrated'}}
+    res[kname] = out
+res['k_lm_run']['_lm_trials_per_launch'] = d['config']['lm_trials_per_step_per_gpu']; res['k_lm_run']['_kernel_ms'] = d['roofline']['kernel_ms']
+res['k_lm_run']['_derived']['wave_instructions_per_trial'] = res['k_lm_run']['_derived']['wave_instructions_per_launch'] / max(1, d['config']['lm_trials_per_step_per_gpu'])
+res['_bench'] = {'value': d['value'], 'ms_per_step': d['ms_per_step'], 'capsules': d['config']['capsules_per_gpu'], 'streaming_kernels': d['streaming_kernels'], 'algorithmic_bytes_per_launch': d['roofline']['algorithmic_bytes_per_launch']}
+json.dump(res, open('gpurun_out/sq_summary.json', 'w'), indent=1, sort_keys=True)
+print(json.dumps({k: (v.get('_derived') if isinstance(v, dict) else v) for k, v in res.items()}, indent=1, sort_keys=True))
 PY
 find gpurun_out/pmcb -name "*.csv" -size +3M -delete
