@@ -1,0 +1,20 @@
+"""Copies the summaries of the last tools/gpu_round.sh session (gpurun_out/round/) into profiles/rNN_*. usage: collect_profiles.py NN"""
+import json, os, shutil, sys
+rnd = int(sys.argv[1]); src = os.path.join("gpurun_out", "round"); dst = "profiles"; tag = "r%02d_" % rnd
+def last_json(path):
+    return json.loads([l for l in open(path) if l.startswith("{")][-1])
+bench = last_json(os.path.join(src, "bench.json")); cfg4 = last_json(os.path.join(src, "bench_cfg4.json")); sq = json.load(open(os.path.join(src, "sq_summary.json")))
+json.dump(bench, open(os.path.join(dst, tag + "bench.json"), "w"), indent=1)
+json.dump(cfg4, open(os.path.join(dst, tag + "bench_cfg4.json"), "w"), indent=1)
+json.dump(sq, open(os.path.join(dst, tag + "sq_summary.json"), "w"), indent=1, sort_keys=True)
+for a, b in (("prof/lm_kernel_stats.csv", "bench_kernel_stats.csv"), ("prof_cfg4/c4_kernel_stats.csv", "cfg4_kernel_stats.csv"), ("pytest_gpu.log", "pytest_gpu.log"), ("smoke.log", "smoke.log")):
+    shutil.copy(os.path.join(src, a), os.path.join(dst, tag + b))
+lm = sq["k_lm_run"]; fetch_kb, write_kb = lm["FETCH_SIZE"], lm["WRITE_SIZE"]
+traffic = {"round": rnd, "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --steps 1 --warmup 0 --cpu-seconds 0 (tools/pmc_bench.sh)",
+           "workload": {"n_kf": bench["config"]["keyframes_per_gpu"], "capsules": bench["config"]["capsules_per_gpu"]},
+           "fetch_size_kb_per_launch": fetch_kb, "write_size_kb_per_launch": write_kb,
+           "correction": "both counters as reported by rocprofv3 (KB). MI355X_MICROARCH.md calibrates a x2 on FETCH_SIZE for wide coalesced streaming reads only; this kernel's reads are 8..16-byte gathers, for which the guide gives no factor, so none is applied (round 1 applied the x2 and called it an upper bound); WRITE_SIZE is uncalibrated",
+           "traffic_bytes_per_launch": 1024.0 * (fetch_kb + write_kb), "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+           "streaming_kernels_kb_per_launch": {k: {"FETCH_SIZE": sq[k].get("FETCH_SIZE"), "WRITE_SIZE": sq[k].get("WRITE_SIZE")} for k in ("k_linearize", "kf_spantree", "k_residuals") if k in sq}}
+json.dump(traffic, open(os.path.join(dst, tag + "pmc_traffic.json"), "w"), indent=1)
+print("value %.3f M it/s, %.2f ms/step, kernel %.2f ms, frac %.4f | cfg4 %.0f it/s | traffic %.1f GB (fetch %.1f + write %.1f)" % (bench["value"] / 1e6, bench["ms_per_step"], bench["roofline"]["kernel_ms"], bench["roofline"]["frac"], cfg4["value"], traffic["traffic_bytes_per_launch"] / 1e9, fetch_kb * 1024 / 1e9, write_kb * 1024 / 1e9))
