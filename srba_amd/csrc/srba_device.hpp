@@ -1,11 +1,11 @@
 /*
  * srba_device.hpp -- gfx950 device code of the SRBA local-optimisation hot path (FP64 throughout).
  *
- * One problem capsule (= one reference optimize_edges() call, include/srba/impl/optimize_edges.h:44-793) is owned by
- * one 256-thread workgroup (4 wave64).  Work items inside the capsule (ST pairs, Jacobian blocks, observations,
- * Hessian blocks, landmarks) are spread over the lanes; phases are separated by workgroup barriers; reductions are
- * fixed-shape LDS trees (deterministic, no FP64 atomics).  The dense system matrix of the LM step lives in LDS
- * (packed lower triangle) when it fits, else in an HBM workspace.
+ * One problem capsule (= one reference optimize_edges() call, include/srba/impl/optimize_edges.h:44-793) is owned by ONE wavefront
+ * (a 64-lane workgroup: no cross-wave barriers).  Work items inside the capsule (spanning-tree pairs, Jacobian blocks, observations,
+ * Hessian blocks, landmarks) are spread over the lanes; reductions are DPP trees (deterministic, no FP64 atomics).  The system of the
+ * LM step is a block-sparse LL^t on 3x3 blocks held in LDS (symbolic factorisation on the host); capsules too large for that run on
+ * the multi-workgroup path of srba_big.hpp with a dense blocked factorisation in HBM.
  *
  * Device restatement of the reference hot loops:
  *   K1  phase_spantree      impl/spantree_update_numeric.h:19-81
@@ -15,8 +15,8 @@
  *   K5  phase_gradient      impl/compute_minus_gradient.h:20-91
  *   K6  phase_hessian       impl/sparse_hessian_update_numeric.h:22-60, srba_options_noise.h:44-71,102-131
  *   K7,K8,K10 schur_*       impl/schur.h:180-311
- *   K9  chol_* / dense assembly   impl/lev-marq_solvers.h:80-187,279-381,474-568 (all three solvers solve the same SPD system;
- *                                 here always by dense LL^t -- "not positive definite" == a pivot <= 0 in every variant)
+ *   K9  sp_factor_fsub_rows / sp_bsub_rows   impl/lev-marq_solvers.h:80-187,279-381,474-568 (all three solvers solve the same SPD
+ *                                 system; here always by block-sparse LL^t -- "not positive definite" == a pivot <= 0 in every variant)
  *   K11,K12 phase_apply / phase_restore + LM control   impl/optimize_edges.h:361-696
  * The SE2 Jacobians are evaluated in closed form (products J0*J1*J2 of jacobians.h:720-736 multiplied out), which needs one
  * sincos instead of four; results agree with the reference formula to rounding.

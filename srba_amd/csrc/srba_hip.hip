@@ -2,8 +2,11 @@
  * srba_hip.hip -- kernels + C ABI (include/srba_hip.h) of the MI355X back-end.  Build: hipcc --offload-arch=gfx950.
  *
  * Kernels (all templated on the model family):
- *   k_lm_run        : the whole Levenberg-Marquardt loop of optimize_edges() (impl/optimize_edges.h:256-751), one workgroup per capsule
- *   k_spantree, k_residuals, k_linearize, k_solve, k_apply, k_rollback : the same phases as separate launches (stepwise API)
+ *   k_lm_run        : the whole Levenberg-Marquardt loop of optimize_edges() (impl/optimize_edges.h:256-751), one wavefront per capsule,
+ *                     persistent workgroups pulling capsules of one LDS size class from a counter
+ *   k_spantree, k_residuals, k_linearize, k_solve, k_apply, k_rollback : the same phases as separate launches (stepwise API);
+ *                     srba_flat.hpp: the batch-flat form of K1
+ *   srba_big.hpp    : grid-wide phases + dense blocked Cholesky for ONE large capsule, LM control on the host (big_lm_run)
  * HBM layout: every capsule array is concatenated batch-wide into one device arena (SoA, 256-byte aligned sub-arrays); a second arena
  * holds state + workspaces.  A per-capsule descriptor (ProbDesc) carries sizes and element offsets.
  */
