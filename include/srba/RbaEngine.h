@@ -192,7 +192,7 @@ struct local_areas_fixed_size {
 	struct parameters_t : public mrpt::utils::CLoadableOptions {
 		size_t submap_size, min_obs_to_loop_closure; parameters_t() : submap_size(15), min_obs_to_loop_closure(4) {}
 		void loadFromConfigFile(const mrpt::utils::CConfigFileBase &source, const std::string &section) override { submap_size = (size_t)source.read<uint64_t>(section, "submap_size", submap_size); min_obs_to_loop_closure = (size_t)source.read<uint64_t>(section, "min_obs_to_loop_closure", min_obs_to_loop_closure); }
-		void saveToConfigFile(mrpt::utils::CConfigFileBase &out, const std::string &section) const override { out.write(section, "submap_size", (uint64_t)submap_size, 30, 30, "Key-frames per sub-map"); out.write(section, "min_obs_to_loop_closure", (uint64_t)min_obs_to_loop_closure, 30, 30, "Min. num. of covisible observations to add a loop closure edge"); }
+		void saveToConfigFile(mrpt::utils::CConfigFileBase &out, const std::string &section) const override { out.write(section, "submap_size", (uint64_t)submap_size, 30, 30, "Key-frames per sub-map"); out.write(section, "min_obs_to_loop_closure", (uint64_t)min_obs_to_loop_closure, 30, 30, "shared landmark observations needed before a loop-closure edge is created"); }
 	};
 	TKeyFrameID get_center_kf_for_kf(const TKeyFrameID kf_id, const parameters_t &params) const { return params.submap_size * (kf_id / params.submap_size); }
 
@@ -241,7 +241,7 @@ struct classic_linear_rba {
 	struct parameters_t : public mrpt::utils::CLoadableOptions {
 		size_t min_obs_to_loop_closure; parameters_t() : min_obs_to_loop_closure(4) {}
 		void loadFromConfigFile(const mrpt::utils::CConfigFileBase &source, const std::string &section) override { min_obs_to_loop_closure = (size_t)source.read<uint64_t>(section, "min_obs_to_loop_closure", min_obs_to_loop_closure); }
-		void saveToConfigFile(mrpt::utils::CConfigFileBase &out, const std::string &section) const override { out.write(section, "min_obs_to_loop_closure", (uint64_t)min_obs_to_loop_closure, 30, 30, "Min. num. of covisible observations to add a loop closure edge"); }
+		void saveToConfigFile(mrpt::utils::CConfigFileBase &out, const std::string &section) const override { out.write(section, "min_obs_to_loop_closure", (uint64_t)min_obs_to_loop_closure, 30, 30, "shared landmark observations needed before a loop-closure edge is created"); }
 	};
 
 	template <class traits_t, class rba_engine_t>
@@ -349,13 +349,13 @@ public:
 			cov_recovery = (cr == "crpNone" || cr == "0") ? crpNone : crpLandmarksApprox;
 		}
 		void saveToConfigFile(mrpt::utils::CConfigFileBase &out, const std::string &section) const override {
-			out.write(section, "max_tree_depth", (uint64_t)max_tree_depth, 30, 30, "Maximum depth of all spanning trees"); out.write(section, "max_optimize_depth", (uint64_t)max_optimize_depth, 30, 30, "Max. local optimization distance");
-			out.write(section, "optimize_new_edges_alone", optimize_new_edges_alone, 30, 30, "Optimize new edges alone before optimizing the entire local area?");
-			out.write(section, "use_robust_kernel", use_robust_kernel, 30, 30, "Use pseudo-Huber kernel?"); out.write(section, "use_robust_kernel_stage1", use_robust_kernel_stage1, 30, 30, "Use pseudo-Huber kernel at stage1?");
-			out.write(section, "kernel_param", kernel_param, 30, 30, "robust kernel parameter"); out.write(section, "max_rho", max_rho, 30, 30, "Lev-Marq optimization: maximum rho value to stop");
-			out.write(section, "max_lambda", max_lambda, 30, 30, "Lev-Marq optimization: maximum lambda to stop"); out.write(section, "max_iters", (uint64_t)max_iters, 30, 30, "Max. iterations for optimization");
-			out.write(section, "max_error_per_obs_to_stop", max_error_per_obs_to_stop, 30, 30, "Another criterion for stopping optimization");
-			out.write(section, "cov_recovery", std::string(cov_recovery == crpNone ? "crpNone" : "crpLandmarksApprox"), 30, 30, "Covariance recovery policy");
+			out.write(section, "max_tree_depth", (uint64_t)max_tree_depth, 30, 30, "depth limit of the spanning trees kept per key-frame"); out.write(section, "max_optimize_depth", (uint64_t)max_optimize_depth, 30, 30, "radius (in kf2kf edges) of the local area that is optimised");
+			out.write(section, "optimize_new_edges_alone", optimize_new_edges_alone, 30, 30, "first optimise each new kf2kf edge on its own");
+			out.write(section, "use_robust_kernel", use_robust_kernel, 30, 30, "pseudo-Huber robust cost in the local-area optimisation"); out.write(section, "use_robust_kernel_stage1", use_robust_kernel_stage1, 30, 30, "pseudo-Huber robust cost while new edges are optimised alone");
+			out.write(section, "kernel_param", kernel_param, 30, 30, "threshold of the pseudo-Huber cost"); out.write(section, "max_rho", max_rho, 30, 30, "LM stops once the gain ratio rho exceeds this");
+			out.write(section, "max_lambda", max_lambda, 30, 30, "LM stops once the damping lambda exceeds this"); out.write(section, "max_iters", (uint64_t)max_iters, 30, 30, "upper bound on LM iterations");
+			out.write(section, "max_error_per_obs_to_stop", max_error_per_obs_to_stop, 30, 30, "LM stops below this RMSE per observation");
+			out.write(section, "cov_recovery", std::string(cov_recovery == crpNone ? "crpNone" : "crpLandmarksApprox"), 30, 30, "crpNone | crpLandmarksApprox");
 		}
 	};
 	struct TAllParameters {

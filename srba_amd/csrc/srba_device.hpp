@@ -42,13 +42,13 @@ struct ProbDesc {
 };
 
 struct Batch {
-	int n_prob; int max_lds_doubles;
+	int n_prob; int max_lds_doubles; int hess_terms; // hess_terms: the fused kernel accumulates U_Ap term-parallel in LDS
 	const ProbDesc *desc; const int *order; // order: capsule indices grouped by LDS size class (one launch per class)
 	// inputs
 	const double *edge0, *ulm0, *klm, *obs_z;
 	const int *pair_path_off, *path_edge, *obs_pose, *obs_lm, *obs_valid;
 	const int *bp_col, *bp_res, *bp_A, *bp_D, *bp_lm, *colp_off, *bf_col, *bf_res, *bf_pose, *colf_off;
-	const int *hap_i, *hap_j, *hap_term_off, *hap_t1, *hap_t2, *hf_i, *hf_j, *hf_term_off, *hf_t1, *hf_t2;
+	const int *hap_i, *hap_j, *hap_term_off, *hap_t1, *hap_t2, *hap_tblk /* block of every U_Ap term */, *hf_i, *hf_j, *hf_term_off, *hf_t1, *hf_t2;
 	const int *hapf_i, *hapf_j, *hapf_term_off, *hapf_t1, *hapf_t2, *hap_diag, *hf_diag;
 	const int *sch_term_off, *sch_b1, *sch_b2, *sch_lm, *sch_yw, *lm_hapf_off, *lm_hapf_idx, *req_idx, *need_idx, *need_rec; // need_rec: per needed pair {pair, 4 path entries (edge<<1|inv, -1 = none)}
 	const unsigned char *pair_needed, *bp_normal;
@@ -782,6 +782,52 @@ struct Worker {
 			ninv += hess_block<P, P>(B.HAp + g * P * P, latch ? B.HAp0 + g * P * P : nullptr, B.hap_t1 + d.o_hapt, B.hap_t2 + d.o_hapt, rec[1], rec[2], Jp, Jp, rp, rp);
 		}
 		if constexpr (!T::REL) {
+			for (int b = tid; b < d.n_hf; b += SRBA_WG)
+				ninv += hess_block<L, L>(B.Hf + (d.o_hf + b) * L * L, nullptr, B.hf_t1 + d.o_hft, B.hf_t2 + d.o_hft, B.hf_term_off[d.o_hfoff + b], B.hf_term_off[d.o_hfoff + b + 1], Jf, Jf, rf, rf);
+			for (int b = tid; b < d.n_hapf; b += SRBA_WG)
+				ninv += hess_block<P, L>(B.HApf + (d.o_hapf + b) * P * L, nullptr, B.hapf_t1 + d.o_hapft, B.hapf_t2 + d.o_hapft, B.hapf_term_off[d.o_hapfoff + b], B.hapf_term_off[d.o_hapfoff + b + 1], Jp, Jf, rp, rf);
+		}
+		return ninv;
+	}
+
+	// K6, U_Ap blocks, TERM-parallel: the per-block form above walks the term lists one lane per block, so a pass lasts as long as its longest list (18..30 terms for
+	// the diagonal blocks against 2..4 for most); here the lanes stride over the flat term list of the capsule (11 passes of 64 for the typical window instead of
+	// ~36 sequential terms), every term adds its M x M product into the block's accumulator in LDS with ds_add_f64 (conflicting lanes of one instruction are
+	// serialised by the LDS in a fixed order and the passes are in program order: reproducible), and the finished blocks go out as one contiguous span.
+	// acc: n_hap * P * P doubles of LDS. Returns the per-lane count of skipped terms.
+	__device__ int phase_hessian_terms(double *acc) { fresh();
+		const int n_acc = d.n_hap * P * P, n_terms = B.hap_term_off[d.o_hapoff + d.n_hap];
+		for (int k = tid; k < n_acc; k += SRBA_WG) acc[k] = 0;
+		solver_sync();
+		const double *Jp = B.Jp + d.o_bp * O * P; const unsigned char *rp = B.bp_ok + d.o_bp; const int *t1 = B.hap_t1 + d.o_hapt, *t2 = B.hap_t2 + d.o_hapt, *tb = B.hap_tblk + d.o_hapt;
+		int ninv = 0;
+		for (int t = tid; t < n_terms; t += SRBA_WG) {
+			const int b1 = t1[t], b2 = t2[t], blk = tb[t];
+			double A[O * P], Bm[O * P]; ldn<O * P>(A, Jp + (long long)b1 * O * P); ldn<O * P>(Bm, Jp + (long long)b2 * O * P);
+			if (rp[b1] && rp[b2]) {
+				double H[P * P];
+#pragma unroll
+				for (int k = 0; k < P * P; k++) H[k] = 0;
+				hess_term<P, P>(H, A, Bm);
+				double *dst = acc + blk * P * P;
+#pragma unroll
+				for (int k = 0; k < P * P; k++) atomicAdd(dst + k, H[k]);
+			} else ninv++;
+		}
+		solver_sync();
+		const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0; const bool latch = prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL;
+		double *Hg = B.HAp + d.o_hap * P * P, *H0 = B.HAp0 + d.o_hap * P * P;
+		for (int k = 2 * tid; k < n_acc; k += 2 * SRBA_WG) { // n_acc is a multiple of 9 or 36; an odd tail is a single double
+			if (k + 1 < n_acc) { f64x2u v; v.x = acc[k] * sc; v.y = acc[k + 1] * sc; *(f64x2u *)(Hg + k) = v; if (latch) *(f64x2u *)(H0 + k) = v; }
+			else { const double v = acc[k] * sc; Hg[k] = v; if (latch) H0[k] = v; }
+		}
+		return ninv;
+	}
+	// U_f and U_Apf blocks, one lane per block (landmark families)
+	__device__ int phase_hessian_landmark_blocks() { fresh();
+		int ninv = 0;
+		if constexpr (!T::REL) {
+			const double *Jp = B.Jp + d.o_bp * O * P, *Jf = B.Jf + d.o_bf * O * L; const unsigned char *rp = B.bp_ok + d.o_bp, *rf = B.bf_ok + d.o_bf;
 			for (int b = tid; b < d.n_hf; b += SRBA_WG)
 				ninv += hess_block<L, L>(B.Hf + (d.o_hf + b) * L * L, nullptr, B.hf_t1 + d.o_hft, B.hf_t2 + d.o_hft, B.hf_term_off[d.o_hfoff + b], B.hf_term_off[d.o_hfoff + b + 1], Jf, Jf, rf, rf);
 			for (int b = tid; b < d.n_hapf; b += SRBA_WG)

@@ -277,7 +277,10 @@ __device__ __forceinline__ void lm_one(const Batch &B, const DevParams &prm, con
 	TIC(); S.phase_spantree(false); // S5
 	__syncthreads(); TOC(0);
 	TIC(); S.phase_jacobians(); TOC(1); // S6,S7
-	TIC(); const int ninv = (int)block_sum((double)S.phase_hessian(), red); // S10
+	// K6: the LDS image of the system is idle while the capsule is linearised (it is assembled per trial): the U_Ap accumulators of the term-parallel form live there
+	const bool hess_terms = B.hess_terms && d.dense_in_lds && d.n_hap * P * P <= 9 * (d.nb + d.nnzoff);
+	auto hessian = [&]() -> int { return hess_terms ? S.phase_hessian_terms(A.diag) + S.phase_hessian_landmark_blocks() : S.phase_hessian(); };
+	TIC(); const int ninv = (int)block_sum((double)hessian(), red); // S10
 	__syncthreads(); TOC(2);
 	if (tid == 0) {
 		out->status = 0; out->num_iters = 0; out->num_trials = 0; out->num_not_pd = 0; out->num_accepted = 0; out->num_relinearized = 0; out->stop_reason = 0;
@@ -322,7 +325,7 @@ __device__ __forceinline__ void lm_one(const Batch &B, const DevParams &prm, con
 				{ double *t = resid; resid = resid2; resid2 = t; }
 				total_err = new_err; RMSE = new_RMSE;
 				__syncthreads();
-				if (relin) { n_relin++; TIC(); S.phase_jacobians(); TOC(1); TIC(); S.phase_hessian(); __syncthreads(); TOC(2); }
+				if (relin) { n_relin++; TIC(); S.phase_jacobians(); TOC(1); TIC(); hessian(); __syncthreads(); TOC(2); }
 				TIC(); S.phase_gradient(resid);
 				__syncthreads(); TOC(4);
 				double ninf = 0; { const double *g = B.grad + d.o_scal; for (int k = tid; k < n; k += SRBA_WG) ninf = fmax(ninf, fabs(g[k])); }
@@ -371,9 +374,14 @@ template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_spantree(const B
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_residuals(const Batch B, const DevParams prm) {
 	Solver<FAM> S(B, B.desc[blockIdx.x], prm); const double e = S.phase_residuals(B.resid, srba_lds); if (threadIdx.x == 0) B.chi2[blockIdx.x] = e;
 }
-template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_linearize(const Batch B, const DevParams prm) {
+template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_linearize(const Batch B, const DevParams prm, int lds_doubles) {
+	constexpr int P = Worker<FAM>::P;
 	Solver<FAM> S(B, B.desc[blockIdx.x], prm);
-	S.phase_jacobians(); const int ninv = (int)block_sum((double)S.phase_hessian(), srba_lds); __syncthreads();
+	const ProbDesc &d = B.desc[blockIdx.x];
+	S.phase_jacobians();
+	// U_Ap blocks term-parallel with LDS accumulators when they fit the launch's LDS (lds_doubles; the first 16 doubles are the reduction scratch), else one lane per block
+	int nv = (d.n_hap * P * P <= lds_doubles - 16) ? S.phase_hessian_terms(srba_lds + 16) + S.phase_hessian_landmark_blocks() : S.phase_hessian();
+	const int ninv = (int)block_sum((double)nv, srba_lds); __syncthreads();
 	S.phase_gradient(B.resid); __syncthreads();
 	const double l0 = S.lambda_guess(srba_lds);
 	if (threadIdx.x == 0) { B.lambda_io[blockIdx.x] = l0; B.results[blockIdx.x].num_invalid_jacobs = ninv; }
@@ -594,6 +602,7 @@ struct srba_hip_ctx {
 	double big_chol_ms = 0, big_chol_flops = 0; long long big_chol_count = 0; int big_chol_nmax = 0; hipEvent_t big_e0 = nullptr, big_e1 = nullptr; // Cholesky time / flops of the big path since the last upload
 	struct BigGraphSet { hipGraphExec_t g[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; }; // assemble, Cholesky, back-substitution .. rho, accept + relinearise, accept
 	std::map<int, BigGraphSet> big_graphs; bool big_use_graphs = false; // captured launch sequences of the big path, per capsule; dropped at upload
+	bool lin_terms = true, lm_terms = true; // term-parallel U_Ap accumulation in LDS: srba_hip_linearize / the fused LM kernel
 	srbadev::FlatMap flat; bool flat_ready = false, use_flat = true; // pair -> capsule map of the flat spanning-tree kernel (srba_flat.hpp), filled on first use after an upload
 	int big_min_sys = 480;   // systems with more scalar unknowns than this skip the block-sparse symbolic analysis and go dense (big path)
 	std::vector<char> h_in; size_t h_off_order = 0; // host staging of the input arena (kept: the launch order is read back from it)
@@ -723,6 +732,8 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	for (int k = 1; k < SRBA_NCLS && ok; k++) ok = hipStreamCreateWithFlags(&c->cls_stream[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->cls_done[k], hipEventDisableTiming) == hipSuccess;
 	if (!ok || hipMalloc((void **)&c->d_next, sizeof(int) * kMaxJobs) != hipSuccess || hipMalloc((void **)&c->d_part, 8 * 3 * kBigPart) != hipSuccess || hipMalloc((void **)&c->d_scal, 8 * 16) != hipSuccess || hipMalloc((void **)&c->d_iscal, 4 * 8) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	{ const char *e = getenv("SRBA_HIP_BIG_MIN_SYS"); if (e && atoi(e) >= 0) c->big_min_sys = atoi(e); } // tuning / test knob
+	{ const char *e = getenv("SRBA_HIP_LIN_TERMS"); if (e) c->lin_terms = atoi(e) != 0; }
+	{ const char *e = getenv("SRBA_HIP_LM_TERMS"); if (e) c->lm_terms = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_FLAT"); if (e) c->use_flat = atoi(e) != 0; }                     // 0 = one wavefront per capsule for the stepwise spanning-tree launch
 	{ const char *e = getenv("SRBA_HIP_BIG_GRAPHS"); if (e) c->big_use_graphs = atoi(e) != 0; }         // 1 = replay the big path's launch sequences as HIP graphs (measured: no gain, the path is bound by its kernels)
 	return c;
@@ -815,14 +826,14 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	c->tot_edge = t_edge; c->tot_ulm = t_ulm;
 	// ---- input arena layout
 	Arena in; struct { size_t desc, edge0, ulm0, klm, obs_z, pair_path_off, path_edge, obs_pose, obs_lm, obs_valid, bp_col, bp_res, bp_A, bp_D, bp_lm, colp_off, bf_col, bf_res, bf_pose, colf_off,
-		hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hf_i, hf_j, hf_term_off, hf_t1, hf_t2, hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag, sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw,
+		hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hap_tblk, hf_i, hf_j, hf_term_off, hf_t1, hf_t2, hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag, sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw,
 		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, pair_needed, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_ab, sp_rptr, sp_rcol, sp_rblk, sp_perm, sp_fill, hap_rec, hap_dst, hapf_dst, hf_dst; } o;
 	o.desc = in.add(sizeof(ProbDesc) * n);
 	o.edge0 = in.add(8 * t_edge * PDX); o.ulm0 = in.add(8 * t_ulm * L); o.klm = in.add(8 * t_klm * L); o.obs_z = in.add(8 * t_obs * O);
 	o.pair_path_off = in.add(4 * (t_pair + n)); o.path_edge = in.add(4 * t_path); o.obs_pose = in.add(4 * t_obs); o.obs_lm = in.add(4 * t_obs); o.obs_valid = in.add(4 * t_obs);
 	o.bp_col = in.add(4 * t_bp); o.bp_res = in.add(4 * t_bp); o.bp_A = in.add(4 * t_bp); o.bp_D = in.add(4 * t_bp); o.bp_lm = in.add(4 * t_bp); o.colp_off = in.add(4 * (t_unk + n));
 	o.bf_col = in.add(4 * t_bf); o.bf_res = in.add(4 * t_bf); o.bf_pose = in.add(4 * t_bf); o.colf_off = in.add(4 * (t_ulm + n));
-	o.hap_i = in.add(4 * t_hap); o.hap_j = in.add(4 * t_hap); o.hap_term_off = in.add(4 * (t_hap + n)); o.hap_t1 = in.add(4 * t_hapt); o.hap_t2 = in.add(4 * t_hapt);
+	o.hap_i = in.add(4 * t_hap); o.hap_j = in.add(4 * t_hap); o.hap_term_off = in.add(4 * (t_hap + n)); o.hap_t1 = in.add(4 * t_hapt); o.hap_t2 = in.add(4 * t_hapt); o.hap_tblk = in.add(4 * t_hapt);
 	o.hf_i = in.add(4 * t_hf); o.hf_j = in.add(4 * t_hf); o.hf_term_off = in.add(4 * (t_hf + n)); o.hf_t1 = in.add(4 * t_hft); o.hf_t2 = in.add(4 * t_hft);
 	o.hapf_i = in.add(4 * t_hapf); o.hapf_j = in.add(4 * t_hapf); o.hapf_term_off = in.add(4 * (t_hapf + n)); o.hapf_t1 = in.add(4 * t_hapft); o.hapf_t2 = in.add(4 * t_hapft);
 	o.hap_diag = in.add(4 * t_unk); o.hf_diag = in.add(4 * t_ulm);
@@ -847,6 +858,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 		CPY(o.bf_col, d.o_bf, k.bf_col, k.n_bf, int32_t); CPY(o.bf_res, d.o_bf, k.bf_res, k.n_bf, int32_t); CPY(o.bf_pose, d.o_bf, k.bf_pose, k.n_bf, int32_t);
 		if (k.colf_off) CPY(o.colf_off, d.o_colf, k.colf_off, d.nF + 1, int32_t);
 		CPY(o.hap_i, d.o_hap, k.hap_i, k.n_hap, int32_t); CPY(o.hap_j, d.o_hap, k.hap_j, k.n_hap, int32_t); CPY(o.hap_term_off, d.o_hapoff, k.hap_term_off, k.n_hap + 1, int32_t); CPY(o.hap_t1, d.o_hapt, k.hap_t1, k.n_hap_terms, int32_t); CPY(o.hap_t2, d.o_hapt, k.hap_t2, k.n_hap_terms, int32_t);
+		{ int32_t *tb = (int32_t *)(h + o.hap_tblk) + d.o_hapt; for (int b = 0; b < k.n_hap; b++) for (int t = k.hap_term_off[b]; t < k.hap_term_off[b + 1]; t++) tb[t] = b; }
 		CPY(o.hf_i, d.o_hf, k.hf_i, k.n_hf, int32_t); CPY(o.hf_j, d.o_hf, k.hf_j, k.n_hf, int32_t); if (k.hf_term_off) CPY(o.hf_term_off, d.o_hfoff, k.hf_term_off, k.n_hf + 1, int32_t); CPY(o.hf_t1, d.o_hft, k.hf_t1, k.n_hf_terms, int32_t); CPY(o.hf_t2, d.o_hft, k.hf_t2, k.n_hf_terms, int32_t);
 		CPY(o.hapf_i, d.o_hapf, k.hapf_i, k.n_hapf, int32_t); CPY(o.hapf_j, d.o_hapf, k.hapf_j, k.n_hapf, int32_t); if (k.hapf_term_off) CPY(o.hapf_term_off, d.o_hapfoff, k.hapf_term_off, k.n_hapf + 1, int32_t); CPY(o.hapf_t1, d.o_hapft, k.hapf_t1, k.n_hapf_terms, int32_t); CPY(o.hapf_t2, d.o_hapft, k.hapf_t2, k.n_hapf_terms, int32_t);
 		CPY(o.hap_diag, d.o_unk, k.hap_diag, d.nK, int32_t); CPY(o.hf_diag, d.o_ulm, k.hf_diag, d.nF, int32_t);
@@ -902,12 +914,12 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	HIPCHK(c, hipMemcpyAsync(c->d_in, h, in.size, hipMemcpyHostToDevice, c->stream));
 	HIPCHK(c, hipMemsetAsync(c->d_wk, 0, wk.size, c->stream));
 	// ---- batch struct
-	Batch &B = c->B; std::memset(&B, 0, sizeof(B)); B.n_prob = n; B.max_lds_doubles = 0;
+	Batch &B = c->B; std::memset(&B, 0, sizeof(B)); B.n_prob = n; B.max_lds_doubles = 0; B.hess_terms = c->lm_terms ? 1 : 0;
 	char *di = c->d_in, *dw = c->d_wk;
 #define DI(field, T) B.field = (const T *)(di + o.field)
 	B.desc = (const ProbDesc *)(di + o.desc); DI(order, int); DI(sp_col_off, int); DI(sp_row, int); DI(sp_item_off, int); DI(sp_tgt, int); DI(sp_ab, int); DI(sp_rptr, int); DI(sp_rcol, int); DI(sp_rblk, int); DI(sp_perm, int); DI(hap_rec, int); DI(sp_fill, int); DI(hap_dst, int); DI(hapf_dst, int); DI(hf_dst, int); DI(edge0, double); DI(ulm0, double); DI(klm, double); DI(obs_z, double);
 	DI(pair_path_off, int); DI(path_edge, int); DI(obs_pose, int); DI(obs_lm, int); DI(obs_valid, int); DI(bp_col, int); DI(bp_res, int); DI(bp_A, int); DI(bp_D, int); DI(bp_lm, int); DI(colp_off, int);
-	DI(bf_col, int); DI(bf_res, int); DI(bf_pose, int); DI(colf_off, int); DI(hap_i, int); DI(hap_j, int); DI(hap_term_off, int); DI(hap_t1, int); DI(hap_t2, int); DI(hf_i, int); DI(hf_j, int); DI(hf_term_off, int); DI(hf_t1, int); DI(hf_t2, int);
+	DI(bf_col, int); DI(bf_res, int); DI(bf_pose, int); DI(colf_off, int); DI(hap_i, int); DI(hap_j, int); DI(hap_term_off, int); DI(hap_t1, int); DI(hap_t2, int); DI(hap_tblk, int); DI(hf_i, int); DI(hf_j, int); DI(hf_term_off, int); DI(hf_t1, int); DI(hf_t2, int);
 	DI(hapf_i, int); DI(hapf_j, int); DI(hapf_term_off, int); DI(hapf_t1, int); DI(hapf_t2, int); DI(hap_diag, int); DI(hf_diag, int); DI(sch_term_off, int); DI(sch_b1, int); DI(sch_b2, int); DI(sch_lm, int); DI(sch_yw, int);
 	DI(lm_hapf_off, int); DI(lm_hapf_idx, int); DI(req_idx, int); DI(need_idx, int); DI(need_rec, int); DI(pair_needed, unsigned char); DI(bp_normal, unsigned char);
 #undef DI
@@ -1238,7 +1250,11 @@ int srba_hip_eval_residuals(srba_hip_ctx *c, double *chi2_out) {
 	if (chi2_out) { HIPCHK(c, hipMemcpyAsync(chi2_out, c->B.chi2, 8 * (size_t)c->n_prob, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
 	return 0;
 }
-int srba_hip_linearize(srba_hip_ctx *c) { if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device)); SRBA_DISPATCH(c, k_linearize, 16 * 8); HIPCHK(c, hipGetLastError()); return 0; }
+int srba_hip_linearize(srba_hip_ctx *c) {
+	if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device));
+	const int lds_doubles = c->lin_terms ? 16 + 1536 : 16; // 12 KB of Hessian accumulators per wavefront: U_Ap of up to 170 SE2 / 42 SE3 blocks (bigger capsules take the per-block path)
+	SRBA_DISPATCH(c, k_linearize, (size_t)lds_doubles * 8, lds_doubles); HIPCHK(c, hipGetLastError()); return 0;
+}
 int srba_hip_solve(srba_hip_ctx *c, const double *lambda, int32_t *not_pd_out) {
 	if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device));
 	if (lambda) HIPCHK(c, hipMemcpyAsync(c->B.lambda_io, lambda, 8 * (size_t)c->n_prob, hipMemcpyHostToDevice, c->stream)); // else: use the lambda guess left by srba_hip_linearize
