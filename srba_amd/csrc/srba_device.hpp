@@ -151,8 +151,10 @@ __device__ __forceinline__ P3 exp_se3(const double *v) { // SE_traits<3>::pseudo
 }
 template <bool SE3> struct PoseOps;
 template <> struct PoseOps<false> { typedef P2 T; static __device__ __forceinline__ T ident() { return ident2(); } static __device__ __forceinline__ T ld(const double *p) { return ld2(p); } static __device__ __forceinline__ void st(double *p, const T &a) { st2(p, a); }
+	static __device__ __forceinline__ T from(const double *v) { P2 r; r.x = v[0]; r.y = v[1]; r.phi = v[2]; r.c = v[3]; r.s = v[4]; return r; } static __device__ __forceinline__ void to(double *v, const T &a) { v[0] = a.x; v[1] = a.y; v[2] = a.phi; v[3] = a.c; v[4] = a.s; }
 	static __device__ __forceinline__ T expm(const double *v) { T r; r.x = v[0]; r.y = v[1]; r.phi = v[2]; sincos(v[2], &r.s, &r.c); return r; } };
 template <> struct PoseOps<true> { typedef P3 T; static __device__ __forceinline__ T ident() { return ident3(); } static __device__ __forceinline__ T ld(const double *p) { return ld3(p); } static __device__ __forceinline__ void st(double *p, const T &a) { st3(p, a); }
+	static __device__ __forceinline__ T from(const double *v) { P3 r; for (int i = 0; i < 3; i++) r.t[i] = v[i]; for (int i = 0; i < 9; i++) r.R[i] = v[3 + i]; return r; } static __device__ __forceinline__ void to(double *v, const T &a) { for (int i = 0; i < 3; i++) v[i] = a.t[i]; for (int i = 0; i < 9; i++) v[3 + i] = a.R[i]; }
 	static __device__ __forceinline__ T expm(const double *v) { return exp_se3(v); } };
 
 // ------------------------------------------------------------------------------------------------ block reductions (deterministic)
@@ -365,7 +367,9 @@ struct Worker {
 	__device__ __forceinline__ const double *lm_ptr(int ref) const { return ref >= 0 ? B.ulm + (d.o_ulm + ref) * L : B.klm + (d.o_klm + (-1 - ref)) * L; }
 
 	// ---- K1
-	__device__ void phase_spantree(bool only_needed) { fresh();
+	// edge_lds: optional copy of ALL edge poses of the capsule in LDS (stride PD, local edge order) -- the in-loop refresh then composes from LDS instead of
+	// waiting for the global stores of the update it follows
+	__device__ void phase_spantree(bool only_needed, const double *edge_lds = nullptr) { fresh();
 #ifdef SRBA_K1SMALL
 		constexpr int U = 2, V = 1;
 #else
@@ -390,7 +394,13 @@ struct Worker {
 #pragma unroll
 					for (int v = 0; v < V; v++)
 #pragma unroll
-						for (int u = 0; u < U; u++) if (pe[v][u0 + u] >= 0) ed[v][u] = PO::ld(B.edge + (d.o_edge + (pe[v][u0 + u] >> 1)) * PD);
+						for (int u = 0; u < U; u++) if (pe[v][u0 + u] >= 0) {
+							if (edge_lds) { double t[PD]; const double *src = edge_lds + (pe[v][u0 + u] >> 1) * PD;
+#pragma unroll
+								for (int k = 0; k < PD; k++) t[k] = src[k];
+								ed[v][u] = PO::from(t); }
+							else ed[v][u] = PO::ld(B.edge + (d.o_edge + (pe[v][u0 + u] >> 1)) * PD);
+						}
 #pragma unroll
 					for (int v = 0; v < V; v++)
 #pragma unroll

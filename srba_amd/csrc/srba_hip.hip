@@ -245,6 +245,39 @@ struct Solver : public Worker<FAM> {
 		}
 		__syncthreads();
 	}
+	// K12 + K11 with the increment of the edges taken straight from the solved right-hand side in LDS (no round trip through B.delta) and, when it fits, a copy of
+	// ALL edge poses of the capsule left in the (now idle) off-diagonal area of the LDS image for the spanning-tree refresh that follows. Returns that copy or nullptr.
+	__device__ const double *apply_update_lds(const SparseSys &S) { this->fresh();
+		typedef typename W::PO PO; typedef typename W::pose_t pose_t;
+		const double *dl = B.delta + d.o_scal;
+		const bool stage = d.n_edges * PD <= 9 * S.nnzoff; double *el = S.off;
+		for (int i = tid; i < (stage ? d.n_edges : d.nK); i += SRBA_WG) {
+			double *e = B.edge + (d.o_edge + i) * PD; pose_t cur = PO::ld(e);
+			if (i < d.nK) {
+				double inc[P];
+#pragma unroll
+				for (int k = 0; k < P; k++) { const int q = i * P + k; inc[k] = S.rhs[3 * S.perm[q / 3] + q % 3]; }
+				PO::st(B.old_edge + (d.o_unk + i) * PD, cur);
+				cur = comp(PO::expm(inc), cur);
+				PO::st(e, cur);
+			}
+			if (stage) { double t[PD]; PO::to(t, cur);
+#pragma unroll
+				for (int k = 0; k < PD; k++) el[i * PD + k] = t[k]; }
+		}
+		for (int k = tid; k < d.nF * L; k += SRBA_WG) { B.old_ulm[d.o_ulm * L + k] = B.ulm[d.o_ulm * L + k]; B.ulm[d.o_ulm * L + k] += dl[d.nK * P + k]; }
+		for (int r = tid; r < d.n_req; r += 2 * SRBA_WG) { // two poses per lane and pass: both loads before the stores
+			const int r2 = r + SRBA_WG; const bool two = r2 < d.n_req;
+			const double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD, *s2 = two ? B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r2]) * PD : s;
+			double v[PD], v2[PD]; ldn<PD>(v, s); ldn<PD>(v2, s2);
+			stn<PD>(B.old_pose + (d.o_req + r) * PD, v);
+			if (two) stn<PD>(B.old_pose + (d.o_req + r2) * PD, v2);
+		}
+		// with the staged copy the refresh that follows reads LDS only, and nothing reads the arrays written here before the next full barrier (end of that refresh):
+		// the hand-off is an LDS one (no wait for the global stores to be acknowledged)
+		if (stage) solver_sync(); else __syncthreads();
+		return stage ? el : nullptr;
+	}
 	__device__ void restore() { this->fresh(); // optimize_edges.h:664-680
 		for (int i = tid; i < d.nK * PD; i += SRBA_WG) B.edge[d.o_edge * PD + i] = B.old_edge[d.o_unk * PD + i];
 		for (int k = tid; k < d.nF * L; k += SRBA_WG) B.ulm[d.o_ulm * L + k] = B.old_ulm[d.o_ulm * L + k];
@@ -309,8 +342,8 @@ __device__ __forceinline__ void lm_one(const Batch &B, const DevParams &prm, con
 				__syncthreads();
 				continue;
 			}
-			TIC(); S.apply_update(); TOC(6);
-			TIC(); S.phase_spantree(true);
+			TIC(); const double *edge_lds = S.apply_update_lds(A); TOC(6);
+			TIC(); S.phase_spantree(true, edge_lds);
 			__syncthreads(); TOC(7);
 			TIC(); const double new_err = S.phase_residuals(resid2, red); TOC(3);
 			const double new_RMSE = sqrt(new_err / nObs);
