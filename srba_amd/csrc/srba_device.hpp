@@ -38,7 +38,7 @@ struct ProbDesc {
 	int n_need, need_flat; // pairs whose pose is re-evaluated inside the LM loop (pair_needed != 0); need_flat: all their paths have <= 4 edges (need_rec usable)
 	long long o_hap, o_hapoff, o_hapt, o_hf, o_hfoff, o_hft, o_hapf, o_hapfoff, o_hapft, o_sch, o_lmoff, o_req, o_scal, o_yw, o_dense, o_spcol, o_sprow, o_spitem, o_spperm;
 	int n_items, aligned; // block updates per factorisation; 1 if every Hessian block maps onto whole 3x3 blocks (always, except L==2 with the no-Schur solver)
-	int dense_in_lds, pad;
+	int dense_in_lds, dense_blocks; // dense_blocks: the LDS image holds ALL blocks of the lower triangle (column-major), no symbolic structure (mid-size, nearly dense systems)
 };
 
 struct Batch {
@@ -230,7 +230,7 @@ template <int N> __device__ __forceinline__ bool fullpiv_inverse(const double *A
 //             by L_ak and the right-hand side is eliminated (forward substitution fused).  Two wave barriers per step.
 // "Not positive definite" == a scalar pivot <= 0 (Eigen LLT / cs_chol criterion), decided identically by all lanes.
 struct SparseSys { // per-capsule symbolic structure (LDS copy of the host's symbolic factorisation) + numeric storage, all in LDS
-	int nb, nnzoff;
+	int nb, nnzoff, dense; // dense: every off-diagonal block (r > c) is stored, column after column: index c (nb-1) - c (c-1)/2 + (r-c-1); no index arrays
 	const int *col_off, *row;  // col_off[nb+1], row[nnzoff] (rows ascending inside a column)
 	const int *item;           // update items of all columns, column after column (cn(cn+1)/2 each, a>=b row positions inside the column):
 	                           //   one packed word  u<<18 | a<<9 | b  (u = unified block index: diag k -> k, off-diag i -> nb+i)
@@ -343,10 +343,70 @@ __device__ __forceinline__ void sp_bsub_rows(const SparseSys &S) {
 		re = rb; rb = rb_n; rb_n = rb_nn; w = w_n;
 	}
 }
+// ---- the same two sweeps for the DENSE block layout (SparseSys::dense): column k holds the blocks of rows k+1 .. nb-1, update item t = a(a+1)/2 + b of column k
+// targets block (k+1+a, k+1+b); every index is arithmetic, the LDS image carries numbers only. Used for mid-size systems whose factor is (nearly) full -- the
+// Schur-reduced systems of landmark windows -- where the item list of the sparse form (~nb^3/6 words) would not fit next to the numbers.
+__device__ __forceinline__ int dense_col_start(int nb, int c) { return c * (nb - 1) - c * (c - 1) / 2; }
+// GLOBAL: the numbers live in HBM (ProbDesc::dense_blocks == 2): the hand-off between the sub-steps waits for the memory operations instead of relying on LDS order
+template <bool GLOBAL> __device__ __forceinline__ void dense_sync() { if constexpr (GLOBAL) __syncthreads(); else solver_sync(); }
+template <bool GLOBAL> __device__ __forceinline__ bool sp_factor_fsub_dense(const SparseSys &S) {
+	const int lane = threadIdx.x, nb = S.nb;
+	const int grp = (lane * 171) >> 9, sub = lane - 3 * grp; const bool worker = lane < 63;
+	for (int k = 0; k < nb; k++) {
+		const int cb = dense_col_start(nb, k), cn = nb - 1 - k, nitems = cn * (cn + 1) / 2;
+		double *D = S.diag + 9 * k;
+		const double a00 = D[0], a10 = D[3], a11 = D[4], a20 = D[6], a21 = D[7], a22 = D[8];
+		const double b0 = S.rhs[3 * k], b1 = S.rhs[3 * k + 1], b2 = S.rhs[3 * k + 2];
+		Chol3 c;
+		if (!chol3v(a00, a10, a11, a20, a21, a22, c)) return false;
+		const double y0 = b0 * c.r0, y1 = (b1 - c.l10 * y0) * c.r1, y2 = (b2 - c.l20 * y0 - c.l21 * y1) * c.r2;
+		if (worker) for (int p = grp; p < cn; p += 21) { // row `sub` of panel block (k+1+p, k) and its share of the forward substitution
+			double *Ax = S.off + 9 * (cb + p) + 3 * sub; double *rx = S.rhs + 3 * (k + 1 + p) + sub;
+			const double x0 = Ax[0] * c.r0, x1 = (Ax[1] - x0 * c.l10) * c.r1, x2 = (Ax[2] - x0 * c.l20 - x1 * c.l21) * c.r2;
+			Ax[0] = x0; Ax[1] = x1; Ax[2] = x2; *rx -= x0 * y0 + x1 * y1 + x2 * y2;
+		}
+		if (lane == SRBA_WG - 1) { // L_kk, reciprocal diagonal in the unused upper part, y_k
+			D[0] = c.l00; D[3] = c.l10; D[4] = c.l11; D[6] = c.l20; D[7] = c.l21; D[8] = c.l22; D[1] = c.r0; D[2] = c.r1; D[5] = c.r2;
+			S.rhs[3 * k] = y0; S.rhs[3 * k + 1] = y1; S.rhs[3 * k + 2] = y2;
+		}
+		dense_sync<GLOBAL>();
+		if (worker) for (int t = grp; t < nitems; t += 21) { // trailing update, row `sub` of block (k+1+a, k+1+b) -= L_ak L_bk^t
+			int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f); a += ((a + 1) * (a + 2) / 2 <= t) ? 1 : 0; a -= (a * (a + 1) / 2 > t) ? 1 : 0; const int b = t - a * (a + 1) / 2;
+			const double *La = S.off + 9 * (cb + a) + 3 * sub, *Lb = S.off + 9 * (cb + b);
+			double *T = (a == b ? S.diag + 9 * (k + 1 + a) : S.off + 9 * (dense_col_start(nb, k + 1 + b) + (a - b - 1))) + 3 * sub;
+			const double la0 = La[0], la1 = La[1], la2 = La[2];
+			double lb[9];
+#pragma unroll
+			for (int q = 0; q < 9; q++) lb[q] = Lb[q];
+			const double t0 = T[0], t1 = T[1], t2 = T[2];
+			T[0] = t0 - (la0 * lb[0] + la1 * lb[1] + la2 * lb[2]);
+			T[1] = t1 - (la0 * lb[3] + la1 * lb[4] + la2 * lb[5]);
+			T[2] = t2 - (la0 * lb[6] + la1 * lb[7] + la2 * lb[8]);
+		}
+		dense_sync<GLOBAL>();
+	}
+	return true;
+}
+template <bool GLOBAL> __device__ __forceinline__ void sp_bsub_dense(const SparseSys &S) {
+	const int lane = threadIdx.x, nb = S.nb;
+	const int grp = (lane * 171) >> 9, sub = lane - 3 * grp; const bool worker = lane < 63;
+	for (int a = nb - 1; a >= 0; a--) {
+		const double *D = S.diag + 9 * a;
+		const double r0 = S.rhs[3 * a], r1 = S.rhs[3 * a + 1], r2 = S.rhs[3 * a + 2], d5 = D[5], d7 = D[7], d2 = D[2], d3 = D[3], d6 = D[6], d1 = D[1];
+		const double x2 = r2 * d5, x1 = (r1 - d7 * x2) * d2, x0 = (r0 - d3 * x1 - d6 * x2) * d1;
+		if (worker) for (int cidx = grp; cidx < a; cidx += 21) { // y_c[sub] -= (L_ac^t x_a)[sub] for every column c < a
+			const double *Lx = S.off + 9 * (dense_col_start(nb, cidx) + (a - cidx - 1)) + sub; double *yx = S.rhs + 3 * cidx + sub;
+			*yx -= Lx[0] * x0 + Lx[3] * x1 + Lx[6] * x2;
+		}
+		if (lane == SRBA_WG - 1) { S.rhs[3 * a] = x0; S.rhs[3 * a + 1] = x1; S.rhs[3 * a + 2] = x2; }
+		dense_sync<GLOBAL>();
+	}
+}
 // location of scalar element (r,c), r>=c (block-permutation already applied); returns nullptr if the block is structurally absent
 __device__ __forceinline__ double *sp_elem(const SparseSys &S, int r, int c) {
 	const int br = r / 3, bc = c / 3; // (already permuted, r >= c)
 	if (br == bc) return S.diag + 9 * br + (r % 3) * 3 + (c % 3);
+	if (S.dense) return S.off + 9 * (bc * (S.nb - 1) - bc * (bc - 1) / 2 + (br - bc - 1)) + (r % 3) * 3 + (c % 3);
 	int lo = S.col_off[bc], hi = S.col_off[bc + 1] - 1;
 	while (lo <= hi) { const int mid = (lo + hi) >> 1; const int v = S.row[mid]; if (v == br) return S.off + 9 * mid + (r % 3) * 3 + (c % 3); if (v < br) lo = mid + 1; else hi = mid - 1; }
 	return nullptr;
@@ -369,7 +429,7 @@ struct Worker {
 	// ---- K1
 	// edge_lds: optional copy of ALL edge poses of the capsule in LDS (stride PD, local edge order) -- the in-loop refresh then composes from LDS instead of
 	// waiting for the global stores of the update it follows
-	__device__ void phase_spantree(bool only_needed, const double *edge_lds = nullptr) { fresh();
+	__device__ __forceinline__ void phase_spantree(bool only_needed, const double *edge_lds = nullptr) { fresh();
 #ifdef SRBA_K1SMALL
 		constexpr int U = 2, V = 1;
 #else
@@ -551,7 +611,7 @@ struct Worker {
 		}
 		return contrib;
 	}
-	__device__ double phase_residuals(double *out, double *red) { fresh();
+	__device__ __forceinline__ double phase_residuals(double *out, double *red) { fresh();
 		double acc = 0;
 		for (int i = tid; i < d.n_obs; i += 2 * SRBA_WG) { // two rows per lane and pass: both rows' loads are issued before either row's stores
 			double r0[O], r1[O]; const int j = i + SRBA_WG; const bool two = j < d.n_obs;
@@ -715,7 +775,7 @@ struct Worker {
 		}
 	}
 	// Jacobians of all blocks + validity semantics of jacobians.h:215-216,321-327 (see DESIGN.md "invalid rows")
-	__device__ void phase_jacobians() { fresh();
+	__device__ __forceinline__ void phase_jacobians() { fresh();
 		for (int i = tid; i < d.n_valid; i += SRBA_WG) { B.valid[d.o_valid + i] = 1; B.first_fail[d.o_valid + i] = 0x7fffffff; }
 		__syncthreads();
 		for (int b = tid; b < d.n_bp; b += SRBA_WG) jac_dh_dp(b);
@@ -781,7 +841,7 @@ struct Worker {
 		stn<M1 * M2>(Hout, H); if (Hlatch) stn<M1 * M2>(Hlatch, H);
 		return ninv;
 	}
-	__device__ int phase_hessian() { fresh(); // returns the per-thread invalid count (to be reduced by the caller if wanted)
+	__device__ __forceinline__ int phase_hessian() { fresh(); // returns the per-thread invalid count (to be reduced by the caller if wanted)
 		int ninv = 0;
 		const double *Jp = B.Jp + d.o_bp * O * P, *Jf = B.Jf + d.o_bf * O * L;
 		const unsigned char *rp = B.bp_ok + d.o_bp, *rf = B.bf_ok + d.o_bf;
@@ -805,7 +865,7 @@ struct Worker {
 	// ~36 sequential terms), every term adds its M x M product into the block's accumulator in LDS with ds_add_f64 (conflicting lanes of one instruction are
 	// serialised by the LDS in a fixed order and the passes are in program order: reproducible), and the finished blocks go out as one contiguous span.
 	// acc: n_hap * P * P doubles of LDS. Returns the per-lane count of skipped terms.
-	__device__ int phase_hessian_terms(double *acc) { fresh();
+	__device__ __forceinline__ int phase_hessian_terms(double *acc) { fresh();
 		const int n_acc = d.n_hap * P * P, n_terms = B.hap_term_off[d.o_hapoff + d.n_hap];
 		for (int k = tid; k < n_acc; k += SRBA_WG) acc[k] = 0;
 		solver_sync();
@@ -834,7 +894,7 @@ struct Worker {
 		return ninv;
 	}
 	// U_f and U_Apf blocks, one lane per block (landmark families)
-	__device__ int phase_hessian_landmark_blocks() { fresh();
+	__device__ __forceinline__ int phase_hessian_landmark_blocks() { fresh();
 		int ninv = 0;
 		if constexpr (!T::REL) {
 			const double *Jp = B.Jp + d.o_bp * O * P, *Jf = B.Jf + d.o_bf * O * L; const unsigned char *rp = B.bp_ok + d.o_bp, *rf = B.bf_ok + d.o_bf;
@@ -896,12 +956,12 @@ struct Worker {
 			}
 		}
 	}
-	__device__ void phase_gradient(const double *resid) { fresh();
+	__device__ __forceinline__ void phase_gradient(const double *resid) { fresh();
 		double *g = B.grad + d.o_scal;
 		grad_cols<P>(g, d.nK, B.Jp + d.o_bp * O * P, B.bp_res + d.o_bp, B.colp_off + d.o_colp, resid);
 		if constexpr (!T::REL) grad_cols<L>(g + d.nK * P, d.nF, B.Jf + d.o_bf * O * L, B.bf_res + d.o_bf, B.colf_off + d.o_colf, resid);
 	}
-	__device__ double lambda_guess(double *red) { fresh(); // optimize_edges.h:366-390
+	__device__ __forceinline__ double lambda_guess(double *red) { fresh(); // optimize_edges.h:366-390
 		double mx = 0;
 		for (int i = tid; i < d.nK; i += SRBA_WG) { const double *H = B.HAp + (d.o_hap + B.hap_diag[d.o_unk + i]) * P * P; double m = H[0]; for (int k = 1; k < P; k++) m = fmax(m, H[k * P + k]); mx = fmax(mx, m); }
 		if constexpr (!T::REL) for (int i = tid; i < d.nF; i += SRBA_WG) { const double *H = B.Hf + (d.o_hf + B.hf_diag[d.o_ulm + i]) * L * L; double m = H[0]; for (int k = 1; k < L; k++) m = fmax(m, H[k * L + k]); mx = fmax(mx, m); }

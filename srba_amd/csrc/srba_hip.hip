@@ -18,7 +18,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -35,7 +37,7 @@ struct Solver : public Worker<FAM> {
 	__device__ __forceinline__ bool schur_active() const { return prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0; }
 
 	// K7 + K8 (schur.h:180-268). Mutates HAp and minus_grad in place like the reference.
-	__device__ void schur_reduce(double lambda) { this->fresh();
+	__device__ __forceinline__ void schur_reduce(double lambda) { this->fresh();
 		if constexpr (!W::T::REL) {
 			for (int l = tid; l < d.nF; l += SRBA_WG) {
 				double M[L * L], Mi[L * L]; const double *src = B.Hf + (d.o_hf + B.hf_diag[d.o_ulm + l]) * L * L;
@@ -79,7 +81,7 @@ struct Solver : public Worker<FAM> {
 		}
 	}
 	// K10 (schur.h:271-311)
-	__device__ void schur_features() { this->fresh();
+	__device__ __forceinline__ void schur_features() { this->fresh();
 		if constexpr (!W::T::REL) {
 			double *g = B.grad + d.o_scal, *dl = B.delta + d.o_scal;
 			for (int l = tid; l < d.nF; l += SRBA_WG) {
@@ -134,7 +136,7 @@ struct Solver : public Worker<FAM> {
 				for (int q = r; q < 3; q++) o[q * 3 + r] = v[r * 3 + q] + (r == q ? lambda : 0.0);
 		}
 	}
-	__device__ void assemble(const SparseSys &S, double lambda) { this->fresh();
+	__device__ __forceinline__ void assemble(const SparseSys &S, double lambda) { this->fresh();
 		const int n = d.n_sys, nb = d.nb;
 		if (d.aligned) { // every block is overwritten whole by put_block below, except the fill-in blocks (listed by the host): zero only those
 			for (int i = tid; i < d.n_fill; i += SRBA_WG) { double *o = S.diag + 9 * B.sp_fill[d.o_spfill + i];
@@ -183,15 +185,15 @@ struct Solver : public Worker<FAM> {
 		__syncthreads();
 	}
 	// solve(lambda): returns false if not positive definite (uniform across the wavefront)
-	__device__ bool solve(const SparseSys &S, double lambda, long long *pc = nullptr) {
+	__device__ __forceinline__ bool solve(const SparseSys &S, double lambda, long long *pc = nullptr) {
 		long long t0 = 0;
 #define STIC() do { if (pc) { __syncthreads(); t0 = wall_clock64(); } } while (0)
 #define STOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - t0; } } while (0)
 		STIC(); if (schur_active()) schur_reduce(lambda); STOC(9);
 		STIC(); assemble(S, lambda); STOC(10);
-		STIC(); const bool ok = sp_factor_fsub_rows(S); STOC(11);
+		STIC(); const bool ok = d.dense_blocks == 2 ? sp_factor_fsub_dense<true>(S) : (S.dense ? sp_factor_fsub_dense<false>(S) : sp_factor_fsub_rows(S)); STOC(11);
 		if (!ok) return false;
-		STIC(); sp_bsub_rows(S);
+		STIC(); if (d.dense_blocks == 2) sp_bsub_dense<true>(S); else if (S.dense) sp_bsub_dense<false>(S); else sp_bsub_rows(S);
 		double *dl = B.delta + d.o_scal;
 		for (int k = tid; k < d.n_scal; k += SRBA_WG) dl[k] = (k < d.n_sys) ? S.rhs[3 * S.perm[k / 3] + k % 3] : 0.0;
 		__syncthreads(); STOC(12);
@@ -201,12 +203,17 @@ struct Solver : public Worker<FAM> {
 #undef STOC
 	}
 	__device__ __forceinline__ SparseSys make_sys(double *lds) const {
-		SparseSys S; S.nb = d.nb; S.nnzoff = d.nnzoff;
+		SparseSys S; S.nb = d.nb; S.nnzoff = d.nnzoff; S.dense = d.dense_blocks;
 		S.col_off = B.sp_col_off + d.o_spcol; S.row = B.sp_row + d.o_sprow; S.item = B.sp_tgt + d.o_spitem; S.item_ab = B.sp_ab + d.o_spitem; S.perm = B.sp_perm + d.o_spperm;
 		S.rptr = B.sp_rptr + d.o_spcol; S.rent = B.sp_rcol + d.o_sprow; S.rent_blk = B.sp_rblk + d.o_sprow;
-		double *base = lds;
+		double *base = d.dense_blocks == 2 ? B.dense + d.o_dense : lds; // 2: the numbers live in an HBM workspace, LDS holds the permutation only
 		S.diag = base; S.off = base + 9 * d.nb; S.rhs = S.off + 9 * d.nnzoff;
-		{ // symbolic structure next to the numbers (packed): the factorisation's dependent index loads hit LDS, not L2
+		if (S.dense) { // numbers only: every index of the dense block layout is arithmetic; the block permutation is the one table kept
+			int *p0 = d.dense_blocks == 2 ? (int *)lds : (int *)(S.rhs + 3 * d.nb);
+			for (int k = tid; k < d.nb; k += SRBA_WG) p0[k] = S.perm[k];
+			S.perm = p0; S.col_off = S.row = S.item = S.rptr = S.rent = nullptr;
+			__syncthreads();
+		} else { // symbolic structure next to the numbers (packed): the factorisation's dependent index loads hit LDS, not L2
 			int *ip = (int *)(S.rhs + 3 * d.nb); int *c0 = ip, *rp0 = c0 + d.nb + 1, *p0 = rp0 + d.nb + 1, *r0 = p0 + d.nb, *re0 = r0 + d.nnzoff, *t0 = re0 + d.nnzoff;
 			for (int k = tid; k <= d.nb; k += SRBA_WG) { c0[k] = S.col_off[k]; rp0[k] = S.rptr[k]; }
 			for (int k = tid; k < d.nb; k += SRBA_WG) p0[k] = S.perm[k];
@@ -219,7 +226,7 @@ struct Solver : public Worker<FAM> {
 	}
 
 	// K12 backup + K11 apply (optimize_edges.h:491-557)
-	__device__ void apply_update() { this->fresh();
+	__device__ __forceinline__ void apply_update() { this->fresh();
 		typedef typename W::PO PO;
 		const double *dl = B.delta + d.o_scal;
 		for (int i = tid; i < d.nK; i += SRBA_WG) {
@@ -247,10 +254,10 @@ struct Solver : public Worker<FAM> {
 	}
 	// K12 + K11 with the increment of the edges taken straight from the solved right-hand side in LDS (no round trip through B.delta) and, when it fits, a copy of
 	// ALL edge poses of the capsule left in the (now idle) off-diagonal area of the LDS image for the spanning-tree refresh that follows. Returns that copy or nullptr.
-	__device__ const double *apply_update_lds(const SparseSys &S) { this->fresh();
+	__device__ __forceinline__ const double *apply_update_lds(const SparseSys &S) { this->fresh();
 		typedef typename W::PO PO; typedef typename W::pose_t pose_t;
 		const double *dl = B.delta + d.o_scal;
-		const bool stage = d.n_edges * PD <= 9 * S.nnzoff; double *el = S.off;
+		const bool stage = d.dense_in_lds && d.n_edges * PD <= 9 * S.nnzoff; double *el = S.off;
 		for (int i = tid; i < (stage ? d.n_edges : d.nK); i += SRBA_WG) {
 			double *e = B.edge + (d.o_edge + i) * PD; pose_t cur = PO::ld(e);
 			if (i < d.nK) {
@@ -278,7 +285,7 @@ struct Solver : public Worker<FAM> {
 		if (stage) solver_sync(); else __syncthreads();
 		return stage ? el : nullptr;
 	}
-	__device__ void restore() { this->fresh(); // optimize_edges.h:664-680
+	__device__ __forceinline__ void restore() { this->fresh(); // optimize_edges.h:664-680
 		for (int i = tid; i < d.nK * PD; i += SRBA_WG) B.edge[d.o_edge * PD + i] = B.old_edge[d.o_unk * PD + i];
 		for (int k = tid; k < d.nF * L; k += SRBA_WG) B.ulm[d.o_ulm * L + k] = B.old_ulm[d.o_ulm * L + k];
 		for (int r = tid; r < d.n_req; r += SRBA_WG) { double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD; const double *o = B.old_pose + (d.o_req + r) * PD; for (int k = 0; k < PD; k++) s[k] = o[k]; }
@@ -484,6 +491,9 @@ struct Arena { // layout builder: 256-byte aligned sub-allocations inside one bu
 };
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->fail(std::string(#call) + ": " + hipGetErrorString(e_)); return -1; } } while (0)
+#define LNCHK(lane, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (lane)->error = std::string(#call) + ": " + hipGetErrorString(e_); return -1; } } while (0)
+static const int kBigLanes = 8;
+struct BigLane { int id = 0; hipStream_t stream = nullptr; double *d_part = nullptr, *d_scal = nullptr; int *d_iscal = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; double chol_ms = 0, chol_flops = 0; long long chol_count = 0; int chol_nmax = 0; std::string error; };
 
 } // namespace
 
@@ -570,9 +580,37 @@ static void symbolic_factor(const srba_problem_capsule &k, const ProbDesc &d, in
 	  out.fill.clear(); for (size_t u = 0; u < covered.size(); u++) if (!covered[u]) out.fill.push_back((int32_t)u); }
 }
 
+// The same outputs for the DENSE block layout of a mid-size, nearly full system (ProbDesc::dense_blocks): identity order, every block (r > c) present at
+// c (nb-1) - c (c-1)/2 + (r-c-1), no index arrays for the device (the solver computes them); only the destinations of the Hessian sub-blocks and the list of
+// blocks without a source (to be zeroed at assembly) are needed.
+static void symbolic_dense(const srba_problem_capsule &k, const ProbDesc &d, int P, int L, bool full_system, Symbolic &out) {
+	const int nb = d.nb; out = Symbolic();
+	out.perm.resize(nb); for (int q = 0; q < nb; q++) out.perm[q] = q;
+	out.col_off.assign(nb + 1, 0); out.item_off.assign(nb + 1, 0); out.rptr.assign(nb + 1, 0); out.max_cn = nb - 1;
+	auto cstart = [&](int c) { return c * (nb - 1) - c * (c - 1) / 2; };
+	auto dst_of = [&](int a, int b) -> int32_t {
+		if (a == b) return -1 - a;
+		if (a > b) return (int32_t)0x80000000; // lower half of a symmetric diagonal block: duplicate, skipped
+		return ((cstart(a) + (b - a - 1)) << 1) | 1; // the factor stores block (b,a) = transpose of the given upper block
+	};
+	const int PB = P / 3;
+	for (int b = 0; b < k.n_hap; b++) for (int si = 0; si < PB; si++) for (int sj = 0; sj < PB; sj++) out.hap_dst.push_back(dst_of(k.hap_i[b] * PB + si, k.hap_j[b] * PB + sj));
+	out.aligned = !(full_system && L != 3 && k.n_unk_lms > 0);
+	if (full_system && L == 3) {
+		const int lb = PB * d.nK;
+		for (int b = 0; b < k.n_hapf; b++) for (int si = 0; si < PB; si++) out.hapf_dst.push_back(dst_of(k.hapf_i[b] * PB + si, lb + k.hapf_j[b]));
+		for (int b = 0; b < k.n_hf; b++) out.hf_dst.push_back(dst_of(lb + k.hf_i[b], lb + k.hf_j[b]));
+	} else { out.hapf_dst.assign((size_t)k.n_hapf * PB, 0); out.hf_dst.assign(k.n_hf, 0); }
+	const int nnz = nb * (nb - 1) / 2; std::vector<char> covered(nb + nnz, 0);
+	auto mark = [&](const std::vector<int32_t> &v) { for (size_t i = 0; i < v.size(); i++) { const int32_t dsti = v[i]; if (dsti == (int32_t)0x80000000) continue; covered[dsti >= 0 ? nb + (dsti >> 1) : -1 - dsti] = 1; } };
+	mark(out.hap_dst); if (full_system && L == 3) { mark(out.hapf_dst); mark(out.hf_dst); }
+	for (size_t u = 0; u < covered.size(); u++) if (!covered[u]) out.fill.push_back((int32_t)u);
+}
+
 struct LaunchJob { int queue, cls, first, count; double cost; int grid; };
-static const int kMaxJobs = 1024;
 static const int kBigPart = 4096;
+static const int kMaxJobs = 1024;
+
 // Index-range check of one capsule (every index the kernels dereference): a wrong capsule is reported at upload instead of reading out of bounds on the device
 static const char *validate_capsule(const srba_problem_capsule &k) {
 	auto in = [](int v, int lo, int hi) { return v >= lo && v < hi; };
@@ -632,9 +670,11 @@ struct srba_hip_ctx {
 	char *d_in = nullptr; size_t cap_in = 0; char *d_wk = nullptr; size_t cap_wk = 0; int *d_next = nullptr;
 	double *d_part = nullptr; double *d_scal = nullptr; int *d_iscal = nullptr; // big path: partial sums [3][kBigPart], scalars, int flags (ninv, not-pd)
 	std::vector<int> big_ld; // per capsule: leading dimension of its dense system when it runs on the big path, else 0
-	double big_chol_ms = 0, big_chol_flops = 0; long long big_chol_count = 0; int big_chol_nmax = 0; hipEvent_t big_e0 = nullptr, big_e1 = nullptr; // Cholesky time / flops of the big path since the last upload
+	double big_chol_ms = 0, big_chol_flops = 0; long long big_chol_count = 0; int big_chol_nmax = 0; // Cholesky time / flops of the big path since the last upload (sum over the lanes)
+	BigLane lanes[kBigLanes]; int n_lanes_ready = 0; // lane 0 = the context stream and buffers; the others are created on first use
 	struct BigGraphSet { hipGraphExec_t g[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; }; // assemble, Cholesky, back-substitution .. rho, accept + relinearise, accept
-	std::map<int, BigGraphSet> big_graphs; bool big_use_graphs = false; // captured launch sequences of the big path, per capsule; dropped at upload
+	std::map<int, BigGraphSet> big_graphs; bool big_use_graphs = false; int big_lanes_max = kBigLanes; // captured launch sequences of the big path, per capsule; dropped at upload
+	bool dense_blocks_ok = true; // mid-size nearly-full systems use the dense block layout in LDS
 	bool lin_terms = true, lm_terms = true; // term-parallel U_Ap accumulation in LDS: srba_hip_linearize / the fused LM kernel
 	srbadev::FlatMap flat; bool flat_ready = false, use_flat = true; // pair -> capsule map of the flat spanning-tree kernel (srba_flat.hpp), filled on first use after an upload
 	int big_min_sys = 480;   // systems with more scalar unknowns than this skip the block-sparse symbolic analysis and go dense (big path)
@@ -765,9 +805,11 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	for (int k = 1; k < SRBA_NCLS && ok; k++) ok = hipStreamCreateWithFlags(&c->cls_stream[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->cls_done[k], hipEventDisableTiming) == hipSuccess;
 	if (!ok || hipMalloc((void **)&c->d_next, sizeof(int) * kMaxJobs) != hipSuccess || hipMalloc((void **)&c->d_part, 8 * 3 * kBigPart) != hipSuccess || hipMalloc((void **)&c->d_scal, 8 * 16) != hipSuccess || hipMalloc((void **)&c->d_iscal, 4 * 8) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	{ const char *e = getenv("SRBA_HIP_BIG_MIN_SYS"); if (e && atoi(e) >= 0) c->big_min_sys = atoi(e); } // tuning / test knob
+	{ const char *e = getenv("SRBA_HIP_DENSE_BLOCKS"); if (e) c->dense_blocks_ok = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_LIN_TERMS"); if (e) c->lin_terms = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_LM_TERMS"); if (e) c->lm_terms = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_FLAT"); if (e) c->use_flat = atoi(e) != 0; }                     // 0 = one wavefront per capsule for the stepwise spanning-tree launch
+	{ const char *e = getenv("SRBA_HIP_BIG_LANES"); if (e && atoi(e) >= 1) c->big_lanes_max = std::min(atoi(e), kBigLanes); } // large capsules of one batch in flight at once
 	{ const char *e = getenv("SRBA_HIP_BIG_GRAPHS"); if (e) c->big_use_graphs = atoi(e) != 0; }         // 1 = replay the big path's launch sequences as HIP graphs (measured: no gain, the path is bound by its kernels)
 	return c;
 }
@@ -785,6 +827,7 @@ int srba_hip_destroy(srba_hip_ctx *c) {
 	if (!c) return 0;
 	hipSetDevice(c->device);
 	big_drop_graphs(c);
+	for (int i = 0; i < kBigLanes; i++) { BigLane &l = c->lanes[i]; if (l.e0) hipEventDestroy(l.e0); if (l.e1) hipEventDestroy(l.e1); if (i > 0) { if (l.d_part) hipFree(l.d_part); if (l.d_scal) hipFree(l.d_scal); if (l.d_iscal) hipFree(l.d_iscal); if (l.stream) hipStreamDestroy(l.stream); } }
 	if (c->d_in) hipFree(c->d_in); if (c->d_wk) hipFree(c->d_wk); if (c->d_next) hipFree(c->d_next); if (c->d_part) hipFree(c->d_part); if (c->d_scal) hipFree(c->d_scal); if (c->d_iscal) hipFree(c->d_iscal);
 	for (int i = 0; i < srba_hip_ctx::kRing; i++) { if (c->ring0[i]) hipEventDestroy(c->ring0[i]); if (c->ring1[i]) hipEventDestroy(c->ring1[i]); }
 	if (c->ev_fork) hipEventDestroy(c->ev_fork);
@@ -818,6 +861,9 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	// ---- pass 1: descriptors and totals
 	long long t_edge = 0, t_unk = 0, t_ulm = 0, t_klm = 0, t_pair = 0, t_path = 0, t_obs = 0, t_valid = 0, t_bp = 0, t_bf = 0, t_hap = 0, t_hapt = 0, t_hf = 0, t_hft = 0, t_hapf = 0, t_hapft = 0, t_sch = 0, t_req = 0, t_scal = 0, t_yw = 0, t_dense = 0;
 	std::vector<int> cls(n, 0), big_lds(n, 0); int cls_nbmax[SRBA_NCLS] = {0}; std::vector<Symbolic> sym(n); long long t_spcol = 0, t_sprow = 0, t_spitem = 0, t_spfill = 0;
+	// capsules whose system cannot fit one wavefront's LDS even as bare numbers (more than 63 block rows) but is no deep-window system either: a handful go to the
+	// multi-workgroup path; when the batch holds many, they keep one wavefront each with the system in HBM (see below)
+	bool many_mid = false; { int cnt = 0; for (int p = 0; p < n; p++) { const int nsys = (schur_solver && caps[p].n_unk_lms > 0 && caps[p].n_unk_edges > 0) ? P * caps[p].n_unk_edges : P * caps[p].n_unk_edges + L * caps[p].n_unk_lms; if ((nsys + 2) / 3 > 63 && nsys <= c->big_min_sys) cnt++; } many_mid = cnt > 4 * kBigLanes; }
 	for (int p = 0; p < n; p++) {
 		const srba_problem_capsule &k = caps[p]; ProbDesc &d = c->desc[p];
 		if (const char *why = validate_capsule(k)) { c->fail(std::string("upload: malformed capsule (") + why + ")"); return -1; }
@@ -834,25 +880,38 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 		if (!surely_big) symbolic_factor(k, d, P, L, !schur_solver, sym[p]);
 		else { Symbolic &y = sym[p]; y.col_off.assign(d.nb + 1, 0); y.item_off.assign(d.nb + 1, 0); y.rptr.assign(d.nb + 1, 0); y.perm.resize(d.nb); for (int q = 0; q < d.nb; q++) y.perm[q] = q;
 			y.hap_dst.assign((size_t)k.n_hap * (P / 3) * (P / 3), 0); y.hapf_dst.assign((size_t)k.n_hapf * (P / 3), 0); y.hf_dst.assign(k.n_hf, 0); y.aligned = true; }
-		d.nnzoff = (int)sym[p].row.size(); d.n_items = (int)sym[p].tgt.size(); d.aligned = sym[p].aligned ? 1 : 0;
-		d.o_spcol = t_spcol; d.o_sprow = t_sprow; d.o_spitem = t_spitem; d.o_spperm = t_spcol - p;
-		t_spcol += d.nb + 1; t_sprow += d.nnzoff; t_spitem += (long long)sym[p].tgt.size();
-		d.n_fill = (int)sym[p].fill.size(); d.o_spfill = t_spfill; t_spfill += d.n_fill;
-		const size_t n_ints = 2 * ((size_t)d.nb + 1) + 2 * (size_t)d.nnzoff + (size_t)d.n_items + (size_t)d.nb;
-		const bool packable = d.nb + d.nnzoff < 16384 && d.nb < 16384 && sym[p].max_cn < 512; // item / row-entry words of the LDS copy
-		const size_t tri_n = 9 * (size_t)d.nb + 9 * (size_t)d.nnzoff + 3 * (size_t)d.nb + (n_ints + 1) / 2; // diag | off | rhs | symbolic ints
+		d.nnzoff = (int)sym[p].row.size(); d.n_items = (int)sym[p].tgt.size(); d.aligned = sym[p].aligned ? 1 : 0; d.dense_blocks = 0;
+		size_t n_ints = 2 * ((size_t)d.nb + 1) + 2 * (size_t)d.nnzoff + (size_t)d.n_items + (size_t)d.nb;
+		bool packable = d.nb + d.nnzoff < 16384 && d.nb < 16384 && sym[p].max_cn < 512; // item / row-entry words of the LDS copy
+		size_t tri_n = 9 * (size_t)d.nb + 9 * (size_t)d.nnzoff + 3 * (size_t)d.nb + (n_ints + 1) / 2; // diag | off | rhs | symbolic ints
+		if (!surely_big && c->dense_blocks_ok) { // nearly full factor: the dense block layout (numbers + the permutation only) is smaller than the sparse one with its item list
+			const size_t nnz_d = (size_t)d.nb * (d.nb - 1) / 2, tri_d = 9 * (size_t)d.nb + 9 * nnz_d + 3 * (size_t)d.nb + ((size_t)d.nb + 1) / 2;
+			if (tri_d < tri_n && tri_d * 8 <= 152 * 1024) { symbolic_dense(k, d, P, L, !schur_solver, sym[p]); d.dense_blocks = 1; d.nnzoff = (int)nnz_d; d.n_items = 0; d.aligned = sym[p].aligned ? 1 : 0; n_ints = d.nb; packable = true; tri_n = tri_d; }
+		}
 		// LDS footprint x residency time is what bounds the batch: capsules are grouped in fine size classes so that each launch
-		// reserves little more LDS per wavefront than its capsules need; systems above 152 KB are factored in an HBM workspace
-		const size_t bytes = tri_n * 8;
+		// reserves little more LDS per wavefront than its capsules need
+		size_t bytes = tri_n * 8;
 		static const int kClsKB[SRBA_NCLS - 1] = {6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64, 80, 96, 112, 128, 152};
 		cls[p] = SRBA_NCLS - 1; for (int q = 0; q < SRBA_NCLS - 1 && packable && !surely_big && kClsKB[q] <= c->max_lds_kb; q++) if (bytes <= (size_t)kClsKB[q] * 1024) { cls[p] = q; break; }
-		d.dense_in_lds = cls[p] < SRBA_NCLS - 1 ? 1 : 0; if (d.dense_in_lds) cls_nbmax[cls[p]] = std::max(cls_nbmax[cls[p]], (int)tri_n);
-		const long long big_ld = d.dense_in_lds ? 0 : ((d.n_sys + srbadev::CB - 1) / srbadev::CB) * srbadev::CB; // dense path: ld x ld matrix + ld x CB diagonal factors + rhs + y
+		long long wave_ws = 0; // doubles of HBM workspace of a capsule that keeps one wavefront but holds its (dense block) system in HBM
+		if (cls[p] == SRBA_NCLS - 1 && !surely_big && many_mid && c->dense_blocks_ok) {
+			// Does not fit any LDS class and the batch has many like it: the multi-workgroup path would run them a few at a time from the host. They stay on the
+			// one-wavefront kernel with the dense block system in an HBM workspace (slow per capsule, but thousands run side by side).
+			const size_t nnz_d = (size_t)d.nb * (d.nb - 1) / 2;
+			symbolic_dense(k, d, P, L, !schur_solver, sym[p]); d.dense_blocks = 2; d.nnzoff = (int)nnz_d; d.n_items = 0; d.aligned = sym[p].aligned ? 1 : 0;
+			tri_n = ((size_t)d.nb + 1) / 2 + 16; bytes = tri_n * 8; cls[p] = 0; wave_ws = 12 * (long long)d.nb + 9 * (long long)nnz_d;
+		}
+		const int n_row_store = (int)sym[p].row.size(); // entries of the row / row-view arrays in the input arena (none in the dense layout)
+		d.o_spcol = t_spcol; d.o_sprow = t_sprow; d.o_spitem = t_spitem; d.o_spperm = t_spcol - p;
+		t_spcol += d.nb + 1; t_sprow += n_row_store; t_spitem += (long long)sym[p].tgt.size();
+		d.n_fill = (int)sym[p].fill.size(); d.o_spfill = t_spfill; t_spfill += d.n_fill;
+		d.dense_in_lds = (cls[p] < SRBA_NCLS - 1 && d.dense_blocks != 2) ? 1 : 0; if (cls[p] < SRBA_NCLS - 1) cls_nbmax[cls[p]] = std::max(cls_nbmax[cls[p]], (int)tri_n);
+		const long long big_ld = cls[p] < SRBA_NCLS - 1 ? 0 : ((d.n_sys + srbadev::CB - 1) / srbadev::CB) * srbadev::CB; // dense path: ld x ld matrix + ld x CB diagonal factors + rhs + y
 		int nyw = 0; if (k.n_sch_terms > 0) for (int b = 0; b < k.n_hap; b++) if (k.hap_i[b] == k.hap_j[b]) nyw += k.sch_term_off[b + 1] - k.sch_term_off[b];
 		long long npath_needed = 0; for (int q = 0; q < k.n_pairs; q++) if (k.pair_needed[q]) { st.n_pairs_needed++; npath_needed += k.pair_path_off[q + 1] - k.pair_path_off[q]; }
 		st.n_path_needed += npath_needed;
 		t_edge += k.n_edges; t_unk += d.nK; t_ulm += d.nF; t_klm += d.n_klm; t_pair += k.n_pairs; t_path += k.n_path; t_obs += k.n_obs; t_valid += k.n_valid; t_bp += k.n_bp; t_bf += k.n_bf;
-		t_hap += k.n_hap; t_hapt += k.n_hap_terms; t_hf += k.n_hf; t_hft += k.n_hf_terms; t_hapf += k.n_hapf; t_hapft += k.n_hapf_terms; t_sch += k.n_sch_terms; t_req += nreq; t_scal += d.n_scal; t_yw += nyw; t_dense += big_ld * big_ld + big_ld * srbadev::CB + 2 * big_ld; big_lds[p] = (int)big_ld;
+		t_hap += k.n_hap; t_hapt += k.n_hap_terms; t_hf += k.n_hf; t_hft += k.n_hf_terms; t_hapf += k.n_hapf; t_hapft += k.n_hapf_terms; t_sch += k.n_sch_terms; t_req += nreq; t_scal += d.n_scal; t_yw += nyw; t_dense += big_ld * big_ld + big_ld * srbadev::CB + 2 * big_ld + wave_ws; big_lds[p] = (int)big_ld;
 	}
 	st.n_edges = t_edge; st.n_unk_edges = t_unk; st.n_unk_lms = t_ulm; st.n_pairs = t_pair; st.n_path = t_path; st.n_obs = t_obs; st.n_bp = t_bp; st.n_bf = t_bf; st.n_hap = t_hap; st.n_hap_terms = t_hapt;
 	st.n_hf_terms = t_hft; st.n_hapf_terms = t_hapft; st.n_sch_terms = t_sch; st.n_scalars = t_scal;
@@ -909,9 +968,9 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 		  c->desc[p].n_need = cnt; c->desc[p].need_flat = flat; }
 		{ int32_t *rq = (int32_t *)(h + o.req_idx) + d.o_req; int cnt = 0; for (int i = 0; i < 2 * k.n_pairs; i++) if (k.pose_required[i]) rq[cnt++] = i; }
 		CPY(o.pair_needed, d.o_pair, k.pair_needed, k.n_pairs, uint8_t); CPY(o.bp_normal, d.o_bp, k.bp_normal, k.n_bp, uint8_t);
-		CPY(o.sp_col_off, d.o_spcol, sym[p].col_off.data(), d.nb + 1, int32_t); CPY(o.sp_row, d.o_sprow, sym[p].row.data(), d.nnzoff, int32_t);
+		CPY(o.sp_col_off, d.o_spcol, sym[p].col_off.data(), d.nb + 1, int32_t); CPY(o.sp_row, d.o_sprow, sym[p].row.data(), sym[p].row.size(), int32_t);
 		CPY(o.sp_item_off, d.o_spcol, sym[p].item_off.data(), d.nb + 1, int32_t); CPY(o.sp_perm, d.o_spperm, sym[p].perm.data(), d.nb, int32_t); CPY(o.sp_tgt, d.o_spitem, sym[p].tgt.data(), sym[p].tgt.size(), int32_t); CPY(o.sp_ab, d.o_spitem, sym[p].ab.data(), sym[p].ab.size(), int32_t);
-		CPY(o.sp_rptr, d.o_spcol, sym[p].rptr.data(), d.nb + 1, int32_t); CPY(o.sp_rcol, d.o_sprow, sym[p].rcol.data(), d.nnzoff, int32_t); CPY(o.sp_rblk, d.o_sprow, sym[p].rblk.data(), d.nnzoff, int32_t); CPY(o.sp_fill, d.o_spfill, sym[p].fill.data(), d.n_fill, int32_t);
+		CPY(o.sp_rptr, d.o_spcol, sym[p].rptr.data(), d.nb + 1, int32_t); CPY(o.sp_rcol, d.o_sprow, sym[p].rcol.data(), sym[p].rcol.size(), int32_t); CPY(o.sp_rblk, d.o_sprow, sym[p].rblk.data(), sym[p].rblk.size(), int32_t); CPY(o.sp_fill, d.o_spfill, sym[p].fill.data(), d.n_fill, int32_t);
 		{ std::vector<int32_t> ho(k.n_hap); for (int b = 0; b < k.n_hap; b++) ho[b] = b;
 		  std::stable_sort(ho.begin(), ho.end(), [&](int x, int y) { return k.hap_term_off[x + 1] - k.hap_term_off[x] > k.hap_term_off[y + 1] - k.hap_term_off[y]; });
 		  int32_t *hr = (int32_t *)(h + o.hap_rec) + 3 * d.o_hap; for (int i = 0; i < k.n_hap; i++) { hr[3 * i] = ho[i]; hr[3 * i + 1] = k.hap_term_off[ho[i]]; hr[3 * i + 2] = k.hap_term_off[ho[i] + 1]; } }
@@ -928,7 +987,8 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 			c->cls_lds[k] = k < SRBA_NCLS - 1 ? (size_t)cls_nbmax[k] * 8 : 0;
 			// longest (most block updates per factorisation) first, dealt round-robin to the queue slices of lm_run_async
 			int32_t *b = ord + c->cls_first[k]; const int cnt = c->cls_count[k], nq = c->n_queues;
-			std::stable_sort(b, b + cnt, [&](int x, int y) { return c->desc[x].n_items > c->desc[y].n_items; });
+			auto work = [&](int x) -> long long { const ProbDesc &dx = c->desc[x]; return dx.dense_blocks ? (long long)dx.nb * dx.nb * dx.nb / 6 : dx.n_items; }; // block updates per factorisation
+			std::stable_sort(b, b + cnt, [&](int x, int y) { return work(x) > work(y); });
 			if (c->sched == 0 && cnt >= 16 * nq) { std::vector<int32_t> t(b, b + cnt); for (int q = 0; q < nq; q++) { int i = slice_begin(cnt, q, nq); for (int src = q; src < cnt; src += nq) b[i++] = t[src]; } }
 		}
 		plan_launches(c, ord);
@@ -1023,100 +1083,102 @@ __attribute__((constructor)) static void srba_hip_runtime_defaults() { setenv("G
 
 // =================================================================================================== the multi-workgroup path for large capsules (srba_big.hpp)
 static inline int big_grid(long long items, int block) { return (int)std::max<long long>(1, std::min<long long>((items + block - 1) / block, 4096)); }
-static srbadev::BigSys big_sys(srba_hip_ctx *c, int p) {
+// The LM loop of a large capsule is driven from the host (one stream synchronisation per trial). When a batch holds several of them, up to kBigLanes are in flight at
+// once, each on its own host thread + stream with its own scalar / partial-sum buffers: their short dependent launches interleave on the device.
+static srbadev::BigSys big_sys(srba_hip_ctx *c, BigLane *ln, int p) {
 	const ProbDesc &d = c->desc[p]; const int ld = c->big_ld[p]; srbadev::BigSys S;
-	double *base = c->B.dense + d.o_dense; S.A = base; S.Ldiag = base + (size_t)ld * ld; S.rhs = S.Ldiag + (size_t)ld * srbadev::CB; S.y = S.rhs + ld; S.flag = c->d_iscal + 1; S.n = d.n_sys; S.ld = ld; return S;
+	double *base = c->B.dense + d.o_dense; S.A = base; S.Ldiag = base + (size_t)ld * ld; S.rhs = S.Ldiag + (size_t)ld * srbadev::CB; S.y = S.rhs + ld; S.flag = ln->d_iscal + 1; S.n = d.n_sys; S.ld = ld; return S;
 }
-#define BIGKG(KERNEL, grid, block, ...) with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), dim3(std::max(1, (int)(grid))), dim3(block), 0, c->stream, c->B, c->dp, p, ##__VA_ARGS__); })
-#define BIGK(KERNEL, items, block, ...) with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), dim3(big_grid((items), (block))), dim3(block), 0, c->stream, c->B, c->dp, p, ##__VA_ARGS__); })
+#define BIGKG(KERNEL, grid, block, ...) with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), dim3(std::max(1, (int)(grid))), dim3(block), 0, ln->stream, c->B, c->dp, p, ##__VA_ARGS__); })
+#define BIGK(KERNEL, items, block, ...) with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), dim3(big_grid((items), (block))), dim3(block), 0, ln->stream, c->B, c->dp, p, ##__VA_ARGS__); })
 // deterministic reduction of per-workgroup partials into d_scal[slot]
-static void big_reduce(srba_hip_ctx *c, int which, int nblk, int slot, int is_max) { hipLaunchKernelGGL(srbadev::kb_reduce, dim3(1), dim3(256), 0, c->stream, c->d_part + (size_t)which * kBigPart, nblk, c->d_scal + slot, is_max); }
+static void big_reduce(srba_hip_ctx *c, BigLane *ln, int which, int nblk, int slot, int is_max) { hipLaunchKernelGGL(srbadev::kb_reduce, dim3(1), dim3(256), 0, ln->stream, ln->d_part + (size_t)which * kBigPart, nblk, ln->d_scal + slot, is_max); }
 // scalar slots of the big path on the device: d_scal = {chi2, max diag, rho denominator, |g|_inf, lambda}; d_iscal = {invalid Jacobians, not-positive-definite flag}
 enum { BS_CHI2 = 0, BS_MAXDIAG = 1, BS_DEN = 2, BS_NINF = 3, BS_LAMBDA = 4 };
 // A trial of the host-driven LM loop is ~80 short dependent launches; their sequence depends only on the capsule, so it is captured once per capsule into
 // HIP graphs (lambda travels through d_scal, a failed factorisation through the device flag that the later kernels test) and replayed.
-template <class F> static int big_replay(srba_hip_ctx *c, int p, int which, F &&enqueue) {
+template <class F> static int big_replay(srba_hip_ctx *c, BigLane *ln, int p, int which, F &&enqueue) {
 	if (!c->big_use_graphs) { enqueue(); return 0; }
-	hipGraphExec_t &slot = c->big_graphs[p].g[which];
+	hipGraphExec_t &slot = c->big_graphs[p * kBigLanes + ln->id].g[which]; // (only lane 0 runs when graphs are on)
 	if (!slot) {
 		hipGraph_t g = nullptr;
-		HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+		LNCHK(ln, hipStreamBeginCapture(ln->stream, hipStreamCaptureModeThreadLocal));
 		enqueue();
-		HIPCHK(c, hipStreamEndCapture(c->stream, &g));
-		HIPCHK(c, hipGraphInstantiate(&slot, g, nullptr, nullptr, 0));
-		HIPCHK(c, hipGraphDestroy(g));
+		LNCHK(ln, hipStreamEndCapture(ln->stream, &g));
+		LNCHK(ln, hipGraphInstantiate(&slot, g, nullptr, nullptr, 0));
+		LNCHK(ln, hipGraphDestroy(g));
 	}
-	HIPCHK(c, hipGraphLaunch(slot, c->stream));
+	LNCHK(ln, hipGraphLaunch(slot, ln->stream));
 	return 0;
 }
 static void big_drop_graphs(srba_hip_ctx *c) { for (auto &kv : c->big_graphs) for (hipGraphExec_t g : kv.second.g) if (g) hipGraphExecDestroy(g); c->big_graphs.clear(); }
 // solve(lambda) of lev-marq_solvers.h for one big capsule, lambda in d_scal[BS_LAMBDA]: (a) Schur reduction (if the solver has one) + dense assembly,
 // (b) blocked Cholesky, (c) back-substitution + landmark increments. The not-positive-definite verdict stays in the device flag.
-static void big_enqueue_assemble(srba_hip_ctx *c, int p) {
-	const ProbDesc &d = c->desc[p]; const srbadev::BigSys S = big_sys(c, p); const int P = c->dm.P; const double *lam = c->d_scal + BS_LAMBDA;
+static void big_enqueue_assemble(srba_hip_ctx *c, BigLane *ln, int p) {
+	const ProbDesc &d = c->desc[p]; const srbadev::BigSys S = big_sys(c, ln, p); const int P = c->dm.P; const double *lam = ln->d_scal + BS_LAMBDA;
 	const bool schur = c->params.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0;
 	if (schur) { BIGK(kb_schur_inv, std::max<long long>(d.nF, (long long)d.n_hap * P * P), 128, lam); BIGKG(kb_schur_reduce, d.n_hap, 256); BIGKG(kb_schur_grad, d.nK, 256); }
-	hipLaunchKernelGGL(srbadev::kb_dense_clear, dim3(big_grid((long long)S.ld * S.ld, 256)), dim3(256), 0, c->stream, S);
+	hipLaunchKernelGGL(srbadev::kb_dense_clear, dim3(big_grid((long long)S.ld * S.ld, 256)), dim3(256), 0, ln->stream, S);
 	BIGK(kb_dense_assemble, d.n_hap + d.n_hapf + d.n_hf, 128, S, lam, schur ? 0 : 1);
 }
-static void big_enqueue_cholesky(srba_hip_ctx *c, int p) {
-	const srbadev::BigSys S = big_sys(c, p);
+static void big_enqueue_cholesky(srba_hip_ctx *c, BigLane *ln, int p) {
+	const srbadev::BigSys S = big_sys(c, ln, p);
 	for (int k0 = 0; k0 < S.ld; k0 += srbadev::CB) {
 		const int below = S.ld - k0 - srbadev::CB;
-		hipLaunchKernelGGL(srbadev::k_chol_panel, dim3(1 + (below + 63) / 64), dim3(64), 0, c->stream, S, k0);
-		if (below > 0) { const int nt = (below + srbadev::CT - 1) / srbadev::CT; hipLaunchKernelGGL(srbadev::k_chol_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, S, k0, nt); }
+		hipLaunchKernelGGL(srbadev::k_chol_panel, dim3(1 + (below + 63) / 64), dim3(64), 0, ln->stream, S, k0);
+		if (below > 0) { const int nt = (below + srbadev::CT - 1) / srbadev::CT; hipLaunchKernelGGL(srbadev::k_chol_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, ln->stream, S, k0, nt); }
 	}
 }
-static void big_enqueue_backsub(srba_hip_ctx *c, int p) {
-	const ProbDesc &d = c->desc[p]; const srbadev::BigSys S = big_sys(c, p);
+static void big_enqueue_backsub(srba_hip_ctx *c, BigLane *ln, int p) {
+	const ProbDesc &d = c->desc[p]; const srbadev::BigSys S = big_sys(c, ln, p);
 	const bool schur = c->params.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0;
-	hipLaunchKernelGGL(srbadev::k_chol_bsub, dim3(1), dim3(256), 0, c->stream, S);
-	hipLaunchKernelGGL(srbadev::kb_take_delta, dim3(big_grid(d.n_scal, 256)), dim3(256), 0, c->stream, c->B, p, S);
+	hipLaunchKernelGGL(srbadev::k_chol_bsub, dim3(1), dim3(256), 0, ln->stream, S);
+	hipLaunchKernelGGL(srbadev::kb_take_delta, dim3(big_grid(d.n_scal, 256)), dim3(256), 0, ln->stream, c->B, p, S);
 	if (schur) BIGK(kb_schur_features, d.nF, 128, S.flag);
 }
-static int big_timed_cholesky(srba_hip_ctx *c, int p) {
-	if (!c->big_e0) { HIPCHK(c, hipEventCreate(&c->big_e0)); HIPCHK(c, hipEventCreate(&c->big_e1)); }
-	HIPCHK(c, hipEventRecord(c->big_e0, c->stream));
-	if (big_replay(c, p, 1, [&]() { big_enqueue_cholesky(c, p); }) != 0) return -1;
-	HIPCHK(c, hipEventRecord(c->big_e1, c->stream));
+static int big_timed_cholesky(srba_hip_ctx *c, BigLane *ln, int p) {
+	if (!ln->e0) { LNCHK(ln, hipEventCreate(&ln->e0)); LNCHK(ln, hipEventCreate(&ln->e1)); }
+	LNCHK(ln, hipEventRecord(ln->e0, ln->stream));
+	if (big_replay(c, ln, p, 1, [&]() { big_enqueue_cholesky(c, ln, p); }) != 0) return -1;
+	LNCHK(ln, hipEventRecord(ln->e1, ln->stream));
 	return 0;
 }
-static void big_account_cholesky(srba_hip_ctx *c, int p) { // after a stream synchronisation
+static void big_account_cholesky(srba_hip_ctx *c, BigLane *ln, int p) { // after a stream synchronisation
 	float ms = 0; const int ld = c->big_ld[p];
-	if (hipEventElapsedTime(&ms, c->big_e0, c->big_e1) == hipSuccess) { c->big_chol_ms += ms; c->big_chol_flops += (double)ld * ld * ld / 3.0; c->big_chol_count++; c->big_chol_nmax = std::max(c->big_chol_nmax, c->desc[p].n_sys); }
+	if (hipEventElapsedTime(&ms, ln->e0, ln->e1) == hipSuccess) { ln->chol_ms += ms; ln->chol_flops += (double)ld * ld * ld / 3.0; ln->chol_count++; ln->chol_nmax = std::max(ln->chol_nmax, c->desc[p].n_sys); }
 }
-static int big_solve(srba_hip_ctx *c, int p, double lambda, bool *pos_def) { // the stepwise entry point (srba_hip_solve)
-	hipLaunchKernelGGL(srbadev::kb_set_scalar, dim3(1), dim3(1), 0, c->stream, c->d_scal + BS_LAMBDA, lambda);
-	big_enqueue_assemble(c, p);
-	if (big_timed_cholesky(c, p) != 0) return -1;
-	big_enqueue_backsub(c, p);
-	int flag = 0; HIPCHK(c, hipMemcpyAsync(&flag, c->d_iscal + 1, 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
-	big_account_cholesky(c, p);
+static int big_solve(srba_hip_ctx *c, BigLane *ln, int p, double lambda, bool *pos_def) { // the stepwise entry point (srba_hip_solve)
+	hipLaunchKernelGGL(srbadev::kb_set_scalar, dim3(1), dim3(1), 0, ln->stream, ln->d_scal + BS_LAMBDA, lambda);
+	big_enqueue_assemble(c, ln, p);
+	if (big_timed_cholesky(c, ln, p) != 0) return -1;
+	big_enqueue_backsub(c, ln, p);
+	int flag = 0; LNCHK(ln, hipMemcpyAsync(&flag, ln->d_iscal + 1, 4, hipMemcpyDeviceToHost, ln->stream)); LNCHK(ln, hipStreamSynchronize(ln->stream));
+	big_account_cholesky(c, ln, p);
 	*pos_def = (flag == 0);
-	HIPCHK(c, hipGetLastError());
+	LNCHK(ln, hipGetLastError());
 	return 0;
 }
 // optimize_edges S5..S17 for one big capsule: the control flow of k_lm_run (optimize_edges.h:256-751) on the host, every phase a grid-wide launch
-static int big_lm_run(srba_hip_ctx *c, int p) {
+static int big_lm_run(srba_hip_ctx *c, BigLane *ln, int p) {
 	const ProbDesc &d = c->desc[p]; const int O = c->dm.O, L = c->dm.L; const srba_hip_params &prm = c->params;
 	const bool schur = prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0;
 	srba_lm_result out; std::memset(&out, 0, sizeof(out));
 	for (int k = 0; k < SRBA_TRACE_LEN; k++) { out.trace_chi2[k] = NAN; out.trace_lambda[k] = NAN; out.trace_rho[k] = NAN; }
-	double *resid = c->B.resid, *resid2 = c->B.resid2; const int *flag = c->d_iscal + 1; const double *lam = c->d_scal + BS_LAMBDA;
-	auto enqueue_residuals = [&](double *dst, const int *skip) { const int nb = big_grid(d.n_obs, 256); BIGK(kb_residuals, d.n_obs, 256, dst, c->d_part, skip); big_reduce(c, 0, nb, BS_CHI2, 0); };
-	auto enqueue_linearize = [&]() { BIGK(kb_jac_init, d.n_valid, 256); BIGK(kb_jac, d.n_bp + d.n_bf, 128); BIGK(kb_jac_post, d.n_bp + d.n_bf, 256); BIGK(kb_hessian, d.n_hap + d.n_hf + d.n_hapf, 128, c->d_iscal); BIGKG(kb_hessian_heavy, d.n_hap, 256, c->d_iscal); };
+	double *resid = c->B.resid, *resid2 = c->B.resid2; const int *flag = ln->d_iscal + 1; const double *lam = ln->d_scal + BS_LAMBDA;
+	auto enqueue_residuals = [&](double *dst, const int *skip) { const int nb = big_grid(d.n_obs, 256); BIGK(kb_residuals, d.n_obs, 256, dst, ln->d_part, skip); big_reduce(c, ln, 0, nb, BS_CHI2, 0); };
+	auto enqueue_linearize = [&]() { BIGK(kb_jac_init, d.n_valid, 256); BIGK(kb_jac, d.n_bp + d.n_bf, 128); BIGK(kb_jac_post, d.n_bp + d.n_bf, 256); BIGK(kb_hessian, d.n_hap + d.n_hf + d.n_hapf, 128, ln->d_iscal); BIGKG(kb_hessian_heavy, d.n_hap, 256, ln->d_iscal); };
 	auto enqueue_gradient = [&]() { BIGKG(kb_gradient, d.nK + (d.nF + 255) / 256, 256, resid); };
-	auto enqueue_dot = [&](int which, int slot, int is_max, const int *skip) { const int nb = big_grid(d.n_scal, 256); BIGK(kb_dot, d.n_scal, 256, lam, c->d_part + kBigPart, c->d_part + 2 * kBigPart, skip); big_reduce(c, which, nb, slot, is_max); };
+	auto enqueue_dot = [&](int which, int slot, int is_max, const int *skip) { const int nb = big_grid(d.n_scal, 256); BIGK(kb_dot, d.n_scal, 256, lam, ln->d_part + kBigPart, ln->d_part + 2 * kBigPart, skip); big_reduce(c, ln, which, nb, slot, is_max); };
 	double hs[4] = {0, 0, 0, 0}; int hflag = 0;
-	auto fetch = [&]() -> int { HIPCHK(c, hipMemcpyAsync(hs, c->d_scal, 32, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipMemcpyAsync(&hflag, flag, 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; };
-	HIPCHK(c, hipMemsetAsync(c->d_iscal, 0, 32, c->stream));
+	auto fetch = [&]() -> int { LNCHK(ln, hipMemcpyAsync(hs, ln->d_scal, 32, hipMemcpyDeviceToHost, ln->stream)); LNCHK(ln, hipMemcpyAsync(&hflag, flag, 4, hipMemcpyDeviceToHost, ln->stream)); LNCHK(ln, hipStreamSynchronize(ln->stream)); return 0; };
+	LNCHK(ln, hipMemsetAsync(ln->d_iscal, 0, 32, ln->stream));
 	BIGK(kb_spantree, d.n_pairs, 256, 0, (const int *)nullptr);   // S5
 	enqueue_linearize();                                          // S6, S7, S10
-	int ninv = 0; HIPCHK(c, hipMemcpyAsync(&ninv, c->d_iscal, 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+	int ninv = 0; LNCHK(ln, hipMemcpyAsync(&ninv, ln->d_iscal, 4, hipMemcpyDeviceToHost, ln->stream)); LNCHK(ln, hipStreamSynchronize(ln->stream));
 	out.num_invalid_jacobs = ninv; out.num_observations = d.n_obs; out.num_jacobians = d.n_bp + d.n_bf; out.num_span_tree_numeric_updates = d.n_pairs;
-	auto finish = [&]() -> int { HIPCHK(c, hipMemcpyAsync(c->B.results + p, &out, sizeof(out), hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; };
+	auto finish = [&]() -> int { LNCHK(ln, hipMemcpyAsync(c->B.results + p, &out, sizeof(out), hipMemcpyHostToDevice, ln->stream)); LNCHK(ln, hipStreamSynchronize(ln->stream)); return 0; };
 	if ((long long)O * d.n_obs < (long long)d.n_scal) { out.status = 1; return finish(); } // S11
-	{ const int nb = big_grid(d.nK + d.nF, 256); BIGK(kb_maxdiag, d.nK + d.nF, 256, c->d_part + kBigPart); big_reduce(c, 1, nb, BS_MAXDIAG, 1); } // S12
+	{ const int nb = big_grid(d.nK + d.nF, 256); BIGK(kb_maxdiag, d.nK + d.nF, 256, ln->d_part + kBigPart); big_reduce(c, ln, 1, nb, BS_MAXDIAG, 1); } // S12
 	enqueue_residuals(resid, nullptr);   // S13
 	enqueue_gradient();                  // S14
 	if (fetch() != 0) return -1;
@@ -1130,17 +1192,17 @@ static int big_lm_run(srba_hip_ctx *c, int p) {
 		while (rho <= 0 && !stop) {
 			const int tr = trials++; if (tr < SRBA_TRACE_LEN) out.trace_lambda[tr] = lambda;
 			// one trial = solve, apply, numeric spanning tree of the poses in use, residuals, rho denominator; kernels after the factorisation return at once if it failed
-			hipLaunchKernelGGL(srbadev::kb_set_scalar, dim3(1), dim3(1), 0, c->stream, c->d_scal + BS_LAMBDA, lambda);
-			if (big_replay(c, p, 0, [&]() { big_enqueue_assemble(c, p); }) != 0) return -1;
-			if (big_timed_cholesky(c, p) != 0) return -1;
-			if (big_replay(c, p, 2, [&]() {
-				big_enqueue_backsub(c, p);
+			hipLaunchKernelGGL(srbadev::kb_set_scalar, dim3(1), dim3(1), 0, ln->stream, ln->d_scal + BS_LAMBDA, lambda);
+			if (big_replay(c, ln, p, 0, [&]() { big_enqueue_assemble(c, ln, p); }) != 0) return -1;
+			if (big_timed_cholesky(c, ln, p) != 0) return -1;
+			if (big_replay(c, ln, p, 2, [&]() {
+				big_enqueue_backsub(c, ln, p);
 				BIGK(kb_apply, d.nK + (long long)d.nF * L + d.n_req, 128, flag);
 				BIGK(kb_spantree, d.n_need, 256, 1, flag);
 				enqueue_residuals(resid2, flag);
 				enqueue_dot(1, BS_DEN, 0, flag); }) != 0) return -1;
 			if (fetch() != 0) return -1;
-			big_account_cholesky(c, p);
+			big_account_cholesky(c, ln, p);
 			if (hflag) { n_notpd++; lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA; continue; }
 			const double new_err = hs[BS_CHI2], new_RMSE = std::sqrt(new_err / d.n_obs), err_red = total_err > 0 ? (total_err - new_err) / total_err : 0;
 			rho = (total_err - new_err) / hs[BS_DEN];
@@ -1150,8 +1212,8 @@ static int big_lm_run(srba_hip_ctx *c, int p) {
 				const bool relin = (err_red < 0 || err_red > prm.min_error_reduction_ratio_to_relinearize);
 				total_err = new_err; RMSE = new_RMSE;
 				if (relin) n_relin++;
-				if (big_replay(c, p, relin ? 3 : 4, [&]() {
-					hipMemcpyAsync(resid + (long long)d.o_obs * O, resid2 + (long long)d.o_obs * O, sizeof(double) * (size_t)d.n_obs * O, hipMemcpyDeviceToDevice, c->stream);
+				if (big_replay(c, ln, p, relin ? 3 : 4, [&]() {
+					hipMemcpyAsync(resid + (long long)d.o_obs * O, resid2 + (long long)d.o_obs * O, sizeof(double) * (size_t)d.n_obs * O, hipMemcpyDeviceToDevice, ln->stream);
 					if (relin) enqueue_linearize();
 					enqueue_gradient();
 					enqueue_dot(2, BS_NINF, 1, nullptr); }) != 0) return -1;
@@ -1170,8 +1232,44 @@ static int big_lm_run(srba_hip_ctx *c, int p) {
 	BIGK(kb_cov_recovery, std::max(d.nF, 1), 128, schur ? 1 : 0); // S17
 	out.num_iters = iter; out.num_trials = trials; out.num_not_pd = n_notpd; out.num_accepted = n_acc; out.num_relinearized = n_relin; out.stop_reason = stopmask;
 	out.total_sqr_error_final = total_err; out.obs_rmse = RMSE; out.lambda_final = lambda;
-	HIPCHK(c, hipGetLastError());
+	LNCHK(ln, hipGetLastError());
 	return finish();
+}
+// lanes [0, n): lane 0 is the context's own stream and buffers, the others get theirs on first use
+static int big_prepare_lanes(srba_hip_ctx *c, int n) {
+	n = std::max(1, std::min(n, kBigLanes));
+	BigLane &l0 = c->lanes[0]; l0.id = 0; l0.stream = c->stream; l0.d_part = c->d_part; l0.d_scal = c->d_scal; l0.d_iscal = c->d_iscal;
+	c->n_lanes_ready = std::max(c->n_lanes_ready, 1);
+	for (int i = c->n_lanes_ready; i < n; i++) {
+		BigLane &l = c->lanes[i]; l.id = i;
+		HIPCHK(c, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+		HIPCHK(c, hipMalloc((void **)&l.d_part, 8 * 3 * kBigPart)); HIPCHK(c, hipMalloc((void **)&l.d_scal, 8 * 16)); HIPCHK(c, hipMalloc((void **)&l.d_iscal, 4 * 8));
+		c->n_lanes_ready = i + 1;
+	}
+	return n;
+}
+static void big_collect_lane_stats(srba_hip_ctx *c) { for (int i = 0; i < c->n_lanes_ready; i++) { BigLane &l = c->lanes[i]; c->big_chol_ms += l.chol_ms; c->big_chol_flops += l.chol_flops; c->big_chol_count += l.chol_count; c->big_chol_nmax = std::max(c->big_chol_nmax, l.chol_nmax); l.chol_ms = l.chol_flops = 0; l.chol_count = 0; l.chol_nmax = 0; } }
+// all capsules of the big class: one after the other on lane 0, or dealt to several lanes (host threads) when there are several
+static int big_run_class(srba_hip_ctx *c, const int32_t *caps, int count) {
+	if (count <= 0) return 0;
+	const int n = big_prepare_lanes(c, (c->big_use_graphs || c->big_lanes_max <= 1) ? 1 : std::min(count, c->big_lanes_max)); if (n < 1) return -1;
+	int rc = 0;
+	if (n == 1) { for (int i = 0; i < count && rc == 0; i++) rc = big_lm_run(c, &c->lanes[0], caps[i]); }
+	else {
+		// the lanes start after everything already queued on the context stream (uploads, state resets)
+		hipEvent_t ready = nullptr; HIPCHK(c, hipEventCreateWithFlags(&ready, hipEventDisableTiming)); HIPCHK(c, hipEventRecord(ready, c->stream));
+		for (int i = 1; i < n; i++) HIPCHK(c, hipStreamWaitEvent(c->lanes[i].stream, ready, 0));
+		std::atomic<int> next(0); std::vector<int> rcs(n, 0); std::vector<std::thread> th;
+		auto work = [&](int li) { hipSetDevice(c->device); BigLane *ln = &c->lanes[li]; for (;;) { const int i = next.fetch_add(1); if (i >= count || rcs[li] != 0) break; rcs[li] = big_lm_run(c, ln, caps[i]); } hipStreamSynchronize(ln->stream); };
+		for (int i = 1; i < n; i++) th.emplace_back(work, i);
+		work(0);
+		for (auto &t : th) t.join();
+		hipEventDestroy(ready);
+		for (int i = 0; i < n; i++) if (rcs[i] != 0 && rc == 0) { rc = -1; c->fail(c->lanes[i].error.empty() ? std::string("large-capsule path failed") : c->lanes[i].error); }
+	}
+	if (rc != 0 && c->error.empty()) c->fail(c->lanes[0].error);
+	big_collect_lane_stats(c);
+	return rc;
 }
 #undef BIGK
 #undef BIGKG
@@ -1201,7 +1299,7 @@ int srba_hip_lm_run_async(srba_hip_ctx *c) {
 	// capsules too large for one wavefront's LDS: the multi-workgroup path, one capsule after the other on the context stream (host-driven LM loop: this part
 	// of the call synchronises with the device once per LM trial), overlapping with the persistent launches of the other classes on their own streams
 	{ const int32_t *ord = (const int32_t *)(c->h_in.data() + c->h_off_order);
-	  for (int i = 0; i < c->cls_count[SRBA_NCLS - 1]; i++) if (big_lm_run(c, ord[c->cls_first[SRBA_NCLS - 1] + i]) != 0) return -1; }
+	  if (big_run_class(c, ord + c->cls_first[SRBA_NCLS - 1], c->cls_count[SRBA_NCLS - 1]) != 0) return -1; }
 	for (int q = 1; q < nq; q++) { HIPCHK(c, hipEventRecord(c->cls_done[q], c->cls_stream[q])); HIPCHK(c, hipStreamWaitEvent(c->stream, c->cls_done[q], 0)); }
 	HIPCHK(c, hipEventRecord(c->ev1, c->stream));
 	return 0;
@@ -1295,7 +1393,7 @@ int srba_hip_solve(srba_hip_ctx *c, const double *lambda, int32_t *not_pd_out) {
 	for (int k = 0; k < SRBA_NCLS - 1; k++) if (c->cls_count[k]) { hipStream_t launch_stream = c->stream; SRBA_DISPATCH_LDS(c, k_solve, c->cls_count[k], c->cls_lds[k], c->cls_first[k]); HIPCHK(c, hipGetLastError()); }
 	{ const int32_t *ord = (const int32_t *)(c->h_in.data() + c->h_off_order); // dense multi-workgroup solver for the capsules of the big class
 	  for (int i = 0; i < c->cls_count[SRBA_NCLS - 1]; i++) { const int p = ord[c->cls_first[SRBA_NCLS - 1] + i]; double lam = 0; HIPCHK(c, hipMemcpyAsync(&lam, c->B.lambda_io + p, 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
-		bool pd = true; if (big_solve(c, p, lam, &pd) != 0) return -1; const int np = pd ? 0 : 1; HIPCHK(c, hipMemcpyAsync(c->B.notpd + p, &np, 4, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); } }
+		bool pd = true; if (big_prepare_lanes(c, 1) < 1) return -1; if (big_solve(c, &c->lanes[0], p, lam, &pd) != 0) { c->fail(c->lanes[0].error); return -1; } big_collect_lane_stats(c); const int np = pd ? 0 : 1; HIPCHK(c, hipMemcpyAsync(c->B.notpd + p, &np, 4, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); } }
 	if (not_pd_out) { HIPCHK(c, hipMemcpyAsync(not_pd_out, c->B.notpd, 4 * (size_t)c->n_prob, hipMemcpyDeviceToHost, c->stream)); }
 	HIPCHK(c, hipStreamSynchronize(c->stream)); return 0;
 }

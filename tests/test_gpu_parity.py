@@ -357,3 +357,32 @@ def test_deep_monocular_window_on_the_big_path_matches_oracle():
     for i in range(sub.n):
         g = work.array(i, "edge_pose", np.float64, sub[i].n_unk_edges * 12); c = ref["state"].array(i, "edge_pose", np.float64, sub[i].n_unk_edges * 12)
         assert np.allclose(g, c, rtol=1e-5, atol=1e-6), i
+
+
+@pytest.mark.gpu
+def test_many_mid_size_windows_keep_one_wavefront_each():
+    """A batch with MANY windows whose Schur-reduced system is too large for one wavefront's LDS (more than 63 block rows: > 31 SE3 edges) but far from a deep window:
+    they must not be serialised through the host-driven multi-workgroup path. Such capsules stay on the fused kernel with a dense block system in an HBM workspace;
+    smaller ones use the dense block layout in LDS. Every replica must reproduce the oracle's chi2 of its original."""
+    import ctypes as C
+    ds, _ = datasets.landmarks_dataset_se3("stereo", n_kf=60, n_lm=600, seed=5, noise=0.1)
+    eng = runner.landmark_engine("stereo", backend=_oracle.BACKEND); eng.run(ds); b = eng.harvest(); b.engine = eng
+    nk = np.array([b[i].n_unk_edges for i in range(b.n)])
+    big = np.flatnonzero(2 * nk > 63); small = np.flatnonzero((2 * nk <= 63) & (nk >= 20))[:6]
+    assert len(big) >= 5 and len(small) >= 3
+    pick = list(big[:5]) + list(small); copies = 8   # 40 replicas of the mid-size windows (> 4 x the lanes of the multi-workgroup path)
+    ref = _oracle.run_batch(b)
+    arr = (capi.Capsule * (len(pick) * copies))()
+    for r in range(copies):
+        for j, i in enumerate(pick): arr[r * len(pick) + j] = b.ptr[i]
+    class Rep: pass
+    fb = Rep(); fb.ptr = C.cast(arr, capi.PCAP); fb.n = len(pick) * copies; fb.params = b.params; fb.family = b.family
+    ctx = runner.HipContext(b.params); ctx.upload(fb); gpu = ctx.lm_run()
+    st = (C.c_double * 4)(); ctx.lib.srba_hip_big_path_stats(ctx.ctx, st); ctx.close()
+    assert st[2] == 0                                                        # nothing went through the dense Cholesky of the multi-workgroup path
+    for r in range(copies):
+        for j, i in enumerate(pick):
+            q = r * len(pick) + j
+            assert gpu["status"][q] == 0 and gpu["num_observations"][q] == ref["num_observations"][i]
+            assert abs(gpu["chi2_init"][q] - ref["chi2_init"][i]) <= 1e-9 * ref["chi2_init"][i]
+            assert abs(gpu["chi2_final"][q] - ref["chi2_final"][i]) <= 1e-6 * ref["chi2_final"][i] + 1e-20, (q, i)
