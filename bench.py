@@ -142,7 +142,7 @@ def bench_cfg4(args, dist, rank, world, local_rank, backend):
                            "parallelism": "replicas x%d" % world, "solver": "Schur complement (grid-wide), dense blocked LL^t across workgroups (32-column panels, v_mfma_f64_16x16x4_f64 trailing updates)"},
                 "roofline": {"bound": "mfma", "achieved": achieved, "peak": 78.6, "unit": "TFLOP/s", "frac": achieved / 78.6, "traffic": None,
                              "kernel": "k_chol_panel + k_chol_update (dense LL^t of the reduced system)", "factorisations": int(chol_n), "kernel_ms": chol_ms / max(chol_n, 1), "flops_per_factorisation": chol_flops / max(chol_n, 1),
-                             "lane_time_over_step_time": chol_ms / (1e3 * elapsed) if elapsed > 0 else None,
+                             "lane_time_over_step_time": chol_ms / (1e3 * elapsed) if elapsed > 0 else None, "aggregate_TFLOPs_over_timed_region": chol_flops / max(elapsed, 1e-9) / 1e12,
                              "note": "peak = AMD's published FP64 matrix figure for MI355X (the guide lists none); kernel_ms = event time of one factorisation on its stream (several windows are in flight at once on separate streams, so the sum over the lanes can exceed the step time: lane_time_over_step_time); the factorisation is bound by its ~60 dependent launches, DESIGN 4c"},
                 "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
