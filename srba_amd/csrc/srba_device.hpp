@@ -370,18 +370,30 @@ template <bool GLOBAL> __device__ __forceinline__ bool sp_factor_fsub_dense(cons
 			S.rhs[3 * k] = y0; S.rhs[3 * k + 1] = y1; S.rhs[3 * k + 2] = y2;
 		}
 		dense_sync<GLOBAL>();
-		if (worker) for (int t = grp; t < nitems; t += 21) { // trailing update, row `sub` of block (k+1+a, k+1+b) -= L_ak L_bk^t
-			int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f); a += ((a + 1) * (a + 2) / 2 <= t) ? 1 : 0; a -= (a * (a + 1) / 2 > t) ? 1 : 0; const int b = t - a * (a + 1) / 2;
-			const double *La = S.off + 9 * (cb + a) + 3 * sub, *Lb = S.off + 9 * (cb + b);
-			double *T = (a == b ? S.diag + 9 * (k + 1 + a) : S.off + 9 * (dense_col_start(nb, k + 1 + b) + (a - b - 1))) + 3 * sub;
-			const double la0 = La[0], la1 = La[1], la2 = La[2];
-			double lb[9];
+		// trailing update, row `sub` of block (k+1+a, k+1+b) -= L_ak L_bk^t. With the numbers in HBM two items are in flight per lane and pass (their loads are
+		// independent): the pass is a memory round trip, and a column of a 60..90-row system has thousands of items
+		constexpr int U = GLOBAL ? 2 : 1;
+		if (worker) for (int t0 = grp; t0 < nitems; t0 += 21 * U) {
+			double la[U][3], lb[U][9], tv[U][3]; double *T[U]; bool live[U];
 #pragma unroll
-			for (int q = 0; q < 9; q++) lb[q] = Lb[q];
-			const double t0 = T[0], t1 = T[1], t2 = T[2];
-			T[0] = t0 - (la0 * lb[0] + la1 * lb[1] + la2 * lb[2]);
-			T[1] = t1 - (la0 * lb[3] + la1 * lb[4] + la2 * lb[5]);
-			T[2] = t2 - (la0 * lb[6] + la1 * lb[7] + la2 * lb[8]);
+			for (int u = 0; u < U; u++) {
+				const int t = t0 + 21 * u; live[u] = t < nitems; const int tt = live[u] ? t : 0;
+				int a = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f); a += ((a + 1) * (a + 2) / 2 <= tt) ? 1 : 0; a -= (a * (a + 1) / 2 > tt) ? 1 : 0; const int b = tt - a * (a + 1) / 2;
+				const double *La = S.off + 9 * (cb + a) + 3 * sub, *Lb = S.off + 9 * (cb + b);
+				T[u] = (a == b ? S.diag + 9 * (k + 1 + a) : S.off + 9 * (dense_col_start(nb, k + 1 + b) + (a - b - 1))) + 3 * sub;
+				if (live[u]) {
+#pragma unroll
+					for (int q = 0; q < 3; q++) { la[u][q] = La[q]; tv[u][q] = T[u][q]; }
+#pragma unroll
+					for (int q = 0; q < 9; q++) lb[u][q] = Lb[q];
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < U; u++) if (live[u]) {
+				T[u][0] = tv[u][0] - (la[u][0] * lb[u][0] + la[u][1] * lb[u][1] + la[u][2] * lb[u][2]);
+				T[u][1] = tv[u][1] - (la[u][0] * lb[u][3] + la[u][1] * lb[u][4] + la[u][2] * lb[u][5]);
+				T[u][2] = tv[u][2] - (la[u][0] * lb[u][6] + la[u][1] * lb[u][7] + la[u][2] * lb[u][8]);
+			}
 		}
 		dense_sync<GLOBAL>();
 	}

@@ -193,9 +193,9 @@ struct Solver : public Worker<FAM> {
 		STIC(); assemble(S, lambda); STOC(10);
 		// (the dense block layouts are never chosen for the relative-pose families -- srba_hip_upload_problems -- whose kernels therefore carry the sparse solver only: the
 		//  headline kernel sits 22 VGPRs below the two-wavefronts-per-SIMD limit)
-		STIC(); bool ok; if constexpr (W::T::REL) ok = sp_factor_fsub_rows(S); else ok = d.dense_blocks == 2 ? sp_factor_fsub_dense<true>(S) : (S.dense ? sp_factor_fsub_dense<false>(S) : sp_factor_fsub_rows(S)); STOC(11);
+		STIC(); bool ok; if constexpr (W::T::REL || !W::T::SE3) ok = sp_factor_fsub_rows(S); else ok = d.dense_blocks == 2 ? sp_factor_fsub_dense<true>(S) : (S.dense ? sp_factor_fsub_dense<false>(S) : sp_factor_fsub_rows(S)); STOC(11);
 		if (!ok) return false;
-		STIC(); if constexpr (W::T::REL) sp_bsub_rows(S); else { if (d.dense_blocks == 2) sp_bsub_dense<true>(S); else if (S.dense) sp_bsub_dense<false>(S); else sp_bsub_rows(S); }
+		STIC(); if constexpr (W::T::REL || !W::T::SE3) sp_bsub_rows(S); else { if (d.dense_blocks == 2) sp_bsub_dense<true>(S); else if (S.dense) sp_bsub_dense<false>(S); else sp_bsub_rows(S); }
 		double *dl = B.delta + d.o_scal;
 		for (int k = tid; k < d.n_scal; k += SRBA_WG) dl[k] = (k < d.n_sys) ? S.rhs[3 * S.perm[k / 3] + k % 3] : 0.0;
 		__syncthreads(); STOC(12);
@@ -205,10 +205,10 @@ struct Solver : public Worker<FAM> {
 #undef STOC
 	}
 	__device__ __forceinline__ SparseSys make_sys(double *lds) const {
-		SparseSys S; S.nb = d.nb; S.nnzoff = d.nnzoff; S.dense = W::T::REL ? 0 : d.dense_blocks;
+		SparseSys S; S.nb = d.nb; S.nnzoff = d.nnzoff; S.dense = (W::T::REL || !W::T::SE3) ? 0 : d.dense_blocks;
 		S.col_off = B.sp_col_off + d.o_spcol; S.row = B.sp_row + d.o_sprow; S.item = B.sp_tgt + d.o_spitem; S.item_ab = B.sp_ab + d.o_spitem; S.perm = B.sp_perm + d.o_spperm;
 		S.rptr = B.sp_rptr + d.o_spcol; S.rent = B.sp_rcol + d.o_sprow; S.rent_blk = B.sp_rblk + d.o_sprow;
-		double *base = (!W::T::REL && d.dense_blocks == 2) ? B.dense + d.o_dense : lds; // 2: the numbers live in an HBM workspace, LDS holds the permutation only
+		double *base = (!W::T::REL && W::T::SE3 && d.dense_blocks == 2) ? B.dense + d.o_dense : lds; // 2: the numbers live in an HBM workspace, LDS holds the permutation only
 		S.diag = base; S.off = base + 9 * d.nb; S.rhs = S.off + 9 * d.nnzoff;
 		if (S.dense) { // numbers only: every index of the dense block layout is arithmetic; the block permutation is the one table kept
 			int *p0 = d.dense_blocks == 2 ? (int *)lds : (int *)(S.rhs + 3 * d.nb);
@@ -886,7 +886,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 		size_t n_ints = 2 * ((size_t)d.nb + 1) + 2 * (size_t)d.nnzoff + (size_t)d.n_items + (size_t)d.nb;
 		bool packable = d.nb + d.nnzoff < 16384 && d.nb < 16384 && sym[p].max_cn < 512; // item / row-entry words of the LDS copy
 		size_t tri_n = 9 * (size_t)d.nb + 9 * (size_t)d.nnzoff + 3 * (size_t)d.nb + (n_ints + 1) / 2; // diag | off | rhs | symbolic ints
-		const bool rel_family = c->params.family == SRBA_SE2_RELPOSE2D || c->params.family == SRBA_SE3_RELPOSE3D; // their kernels carry the sparse solver only
+		const bool rel_family = c->params.family == SRBA_SE2_RELPOSE2D || c->params.family == SRBA_SE3_RELPOSE3D || c->dm.P == 3; // relative-pose and SE2 families: their kernels carry the sparse solver only (one 3x3 block per edge: the sparse image fits)
 		if (!surely_big && c->dense_blocks_ok && !rel_family) { // nearly full factor: the dense block layout (numbers + the permutation only) is smaller than the sparse one with its item list
 			const size_t nnz_d = (size_t)d.nb * (d.nb - 1) / 2, tri_d = 9 * (size_t)d.nb + 9 * nnz_d + 3 * (size_t)d.nb + ((size_t)d.nb + 1) / 2;
 			if (tri_d < tri_n && tri_d * 8 <= 152 * 1024) { symbolic_dense(k, d, P, L, !schur_solver, sym[p]); d.dense_blocks = 1; d.nnzoff = (int)nnz_d; d.n_items = 0; d.aligned = sym[p].aligned ? 1 : 0; n_ints = d.nb; packable = true; tri_n = tri_d; }
