@@ -53,17 +53,41 @@ struct Solver : public Worker<FAM> {
 				double *H = B.HAp + (d.o_hap + b) * P * P;
 				const int tb = B.sch_term_off[d.o_hapoff + b], te = B.sch_term_off[d.o_hapoff + b + 1];
 				if (tb == te) continue;
-				double Hl[P * P]; for (int k = 0; k < P * P; k++) Hl[k] = H[k];
-				for (int t = tb; t < te; t++) {
-					const int l = B.sch_lm[d.o_sch + t]; if (!B.hf_ok[d.o_ulm + l]) continue;
-					const double *W1 = B.HApf + (d.o_hapf + B.sch_b1[d.o_sch + t]) * P * L, *W2 = B.HApf + (d.o_hapf + B.sch_b2[d.o_sch + t]) * P * L, *Hi = B.Hfinv + (d.o_ulm + l) * L * L;
-					double Y[P * L];
-					for (int i = 0; i < P; i++) for (int j = 0; j < L; j++) { double s = 0; for (int k = 0; k < L; k++) s += W1[i * L + k] * Hi[k * L + j]; Y[i * L + j] = s; }
-					for (int i = 0; i < P; i++) for (int j = 0; j < P; j++) { double s = 0; for (int k = 0; k < L; k++) s += Y[i * L + k] * W2[j * L + k]; Hl[i * P + j] -= s; }
-					const int yw = B.sch_yw[d.o_sch + t];
-					if (yw >= 0) for (int k = 0; k < P * L; k++) B.YW[(d.o_yw + yw) * P * L + k] = Y[k];
+				double Hl[P * P]; ldn<P * P>(Hl, H);
+				// two terms per pass: indices and records of both are requested before either is used (one wavefront per SIMD for these families: the registers are there,
+				// the latency is not hidden by anything else); same summation order as one term at a time
+				for (int t = tb; t < te; t += 2) {
+					const bool two = t + 1 < te; const int t1 = two ? t + 1 : t;
+					const int l0 = B.sch_lm[d.o_sch + t], l1 = B.sch_lm[d.o_sch + t1];
+					const int a0 = B.sch_b1[d.o_sch + t], c0 = B.sch_b2[d.o_sch + t], a1 = B.sch_b1[d.o_sch + t1], c1 = B.sch_b2[d.o_sch + t1];
+					const int yw0 = B.sch_yw[d.o_sch + t], yw1 = B.sch_yw[d.o_sch + t1];
+					const bool ok0 = B.hf_ok[d.o_ulm + l0] != 0, ok1 = two && B.hf_ok[d.o_ulm + l1] != 0;
+					double W1[2][P * L], W2[2][P * L], Hi[2][L * L];
+					ldn<P * L>(W1[0], B.HApf + (d.o_hapf + a0) * P * L); ldn<P * L>(W2[0], B.HApf + (d.o_hapf + c0) * P * L); ldn<L * L>(Hi[0], B.Hfinv + (d.o_ulm + l0) * L * L);
+					ldn<P * L>(W1[1], B.HApf + (d.o_hapf + a1) * P * L); ldn<P * L>(W2[1], B.HApf + (d.o_hapf + c1) * P * L); ldn<L * L>(Hi[1], B.Hfinv + (d.o_ulm + l1) * L * L);
+#pragma unroll
+					for (int u = 0; u < 2; u++) {
+						if (!(u ? ok1 : ok0)) continue;
+						double Y[P * L];
+#pragma unroll
+						for (int i = 0; i < P; i++)
+#pragma unroll
+							for (int j = 0; j < L; j++) { double sm = 0;
+#pragma unroll
+								for (int k = 0; k < L; k++) sm += W1[u][i * L + k] * Hi[u][k * L + j];
+								Y[i * L + j] = sm; }
+#pragma unroll
+						for (int i = 0; i < P; i++)
+#pragma unroll
+							for (int j = 0; j < P; j++) { double sm = 0;
+#pragma unroll
+								for (int k = 0; k < L; k++) sm += Y[i * L + k] * W2[u][j * L + k];
+								Hl[i * P + j] -= sm; }
+						const int yw = u ? yw1 : yw0;
+						if (yw >= 0) stn<P * L>(B.YW + (d.o_yw + yw) * P * L, Y);
+					}
 				}
-				for (int k = 0; k < P * P; k++) H[k] = Hl[k];
+				stn<P * P>(H, Hl);
 			}
 			__syncthreads();
 			double *g = B.grad + d.o_scal; const double *gf = g + d.nK * P;
@@ -72,8 +96,12 @@ struct Solver : public Worker<FAM> {
 				double acc[P]; for (int r = 0; r < P; r++) acc[r] = g[i * P + r];
 				for (int t = B.sch_term_off[d.o_hapoff + b]; t < B.sch_term_off[d.o_hapoff + b + 1]; t++) {
 					const int l = B.sch_lm[d.o_sch + t]; if (!B.hf_ok[d.o_ulm + l]) continue;
-					const double *Y = B.YW + (d.o_yw + B.sch_yw[d.o_sch + t]) * P * L;
-					for (int r = 0; r < P; r++) { double s = 0; for (int k = 0; k < L; k++) s += Y[r * L + k] * gf[l * L + k]; acc[r] -= s; }
+					double Y[P * L], gl[L]; ldn<P * L>(Y, B.YW + (d.o_yw + B.sch_yw[d.o_sch + t]) * P * L); ldn<L>(gl, gf + l * L);
+#pragma unroll
+					for (int r = 0; r < P; r++) { double s = 0;
+#pragma unroll
+						for (int k = 0; k < L; k++) s += Y[r * L + k] * gl[k];
+						acc[r] -= s; }
 				}
 				for (int r = 0; r < P; r++) g[i * P + r] = acc[r];
 			}
