@@ -828,7 +828,7 @@ struct Worker {
 		#ifdef SRBA_NOPAIR
 		constexpr bool PAIR = false;
 #else
-		constexpr bool PAIR = (O * (M1 + M2) <= 24);
+		constexpr bool PAIR = (O * (M1 + M2) <= 24) || (T::SE3 && O * (M1 + M2) <= 48); // (the SE3 kernels run one wavefront per SIMD anyway: registers buy memory-level parallelism)
 #endif // two terms in flight when their Jacobian blocks fit the register budget
 		int t = tb;
 		if constexpr (PAIR) {
