@@ -7,8 +7,8 @@ bench = last_json(os.path.join(src, "bench.json")); cfg4 = last_json(os.path.joi
 json.dump(bench, open(os.path.join(dst, tag + "bench.json"), "w"), indent=1)
 json.dump(cfg4, open(os.path.join(dst, tag + "bench_cfg4.json"), "w"), indent=1)
 json.dump(sq, open(os.path.join(dst, tag + "sq_summary.json"), "w"), indent=1, sort_keys=True)
-for a, b in (("prof/lm_kernel_stats.csv", "bench_kernel_stats.csv"), ("prof_cfg4/c4_kernel_stats.csv", "cfg4_kernel_stats.csv"), ("pytest_gpu.log", "pytest_gpu.log"), ("smoke.log", "smoke.log")):
-    shutil.copy(os.path.join(src, a), os.path.join(dst, tag + b))
+for a, b in (("prof/lm_kernel_stats.csv", "bench_kernel_stats.csv"), ("prof_cfg4/c4_kernel_stats.csv", "cfg4_kernel_stats.csv"), ("pytest_gpu.log", "pytest_gpu.log"), ("smoke.log", "smoke.log"), ("families.log", "families.log")):
+    if os.path.exists(os.path.join(src, a)): shutil.copy(os.path.join(src, a), os.path.join(dst, tag + b))
 lm = sq["k_lm_run"]; fetch_kb, write_kb = lm["FETCH_SIZE"], lm["WRITE_SIZE"]
 traffic = {"round": rnd, "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --steps 1 --warmup 0 --cpu-seconds 0 (tools/pmc_bench.sh)",
            "workload": {"n_kf": bench["config"]["keyframes_per_gpu"], "capsules": bench["config"]["capsules_per_gpu"]},

@@ -14,5 +14,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg4 -o c4 -- py
 cd $R
 bash tools/pmc_bench.sh > $O/pmc_bench.log 2>&1
 cp gpurun_out/sq_summary.json $O/sq_summary.json
+bash tools/fam_compare.sh > $O/families.log 2>&1   # fused-kernel throughput per landmark family
 find $O -name "*kernel_trace*" -delete
 tail -3 $O/pytest_gpu.log; cat $O/smoke.log | tail -2; cut -c1-600 $O/bench.json; cut -c1-400 $O/bench_cfg4.json
