@@ -97,6 +97,64 @@ def per_problem_counts(batch, family):
     return out
 
 
+def bench_cfg3(args, dist, rank, world, local_rank, backend):
+    """BASELINE configs[2]: SE3 + StereoCamera landmarks, Schur landmark reduction. SURVEY 8d cfg3-stereo: 200 key-frames on a forward spiral in a 20 m room, 2 000 landmarks, stereo
+    fx=200 fy=150 cx=512 cy=384 baseline 0.2 m, range 5 m, pixel noise 0.5, robust kernel on, sensor pose (0,0,0,-90,0,-90) deg, depth 3. The map is built key-frame by key-frame through the
+    engine with the GPU back-end (sequential_ms_per_kf); a step re-optimises every harvested local area, --cfg3-copies replicas of each (one map alone does not fill the chip)."""
+    import ctypes as Ct
+    import numpy as np
+    import torch
+    from srba_amd import capi, datasets, multi, runner
+    n_kf = args.cfg3_kf
+    ds, _ = datasets.landmarks_dataset_se3("stereo", n_kf=n_kf, n_lm=2000, seed=multi.replica_seed(rank), max_range=5.0, noise=0.5, room=10.0)
+    eng = runner.landmark_engine("stereo", backend="hip", depth=3, submap=15, sigma=0.5, robust=1, harvest=1, hip_device=local_rank, refresh_all_read_poses=2)
+    t0 = time.time(); eng.run(ds); t_map = time.time() - t0
+    b = eng.harvest(); b.engine = eng; n0 = b.n; copies = max(1, args.cfg3_copies)
+    arr = (capi.Capsule * (n0 * copies))()
+    for r in range(copies):
+        for i in range(n0):
+            arr[r * n0 + i] = b.ptr[i]
+    class Replicas: pass
+    fb = Replicas(); fb.ptr = Ct.cast(arr, capi.PCAP); fb.n = n0 * copies; fb.params = b.params; fb.family = b.family
+    ctx = runner.HipContext(b.params, device=local_rank); ctx.upload(fb); lib = ctx.lib
+    res = ctx.lm_run(); trials = int(res["num_trials"].sum()); obs_trials = int((res["num_trials"] * res["num_observations"]).sum())
+    for _ in range(args.warmup):
+        lib.srba_hip_reset_state(ctx.ctx); lib.srba_hip_lm_run_async(ctx.ctx)
+    def step():
+        lib.srba_hip_reset_state(ctx.ctx); lib.srba_hip_lm_run_async(ctx.ctx)
+    def device_sync():
+        lib.srba_hip_sync(ctx.ctx); torch.cuda.synchronize()
+    elapsed = multi.timed_region(dist, device_sync, step, args.steps)
+    hist = (C.c_double * 64)(); nh = lib.srba_hip_kernel_ms_history(ctx.ctx, hist, min(64, args.steps)); kernel_ms = float(np.mean([hist[i] for i in range(max(nh, 0))])) if nh > 0 else float("nan")
+    tot_trials, tot_obs, max_elapsed = multi.aggregate(dist, "cuda" if backend == "nccl" else "cpu", trials, obs_trials, elapsed)
+    if rank == 0:
+        nk = np.array([b[i].n_unk_edges for i in range(n0)]); nf = np.array([b[i].n_unk_lms for i in range(n0)]); no = np.array([b[i].n_obs for i in range(n0)])
+        cpu = None
+        if args.cpu_seconds > 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import _oracle  # the CPU checker: only this cpu_baseline leg uses it
+            cores = max(1, min(os.cpu_count() or 1, args.cpu_threads if args.cpu_threads > 0 else 64))
+            t1 = time.perf_counter(); r = _oracle.run_batch(b, threads=cores); dt = time.perf_counter() - t1
+            rel = np.abs(r["chi2_final"] - res["chi2_final"][:n0]) / np.maximum(r["chi2_final"], 1e-300)
+            sane = r["obs_rmse"] < 3.0   # windows the optimiser brings within 3 sigma per observation; a window of a map that is being lost is a chaotic problem (DESIGN 5) and is not compared
+            cpu = {"value": float(r["num_trials"].sum() / dt), "unit": "LM iterations/s", "cores": cores, "kind": "port",
+                   "sample": "oracle/srba_oracle.cpp (g++ -O2, %d threads pulling capsules from a shared queue) on the %d local areas of the map, %.1f s" % (cores, n0, dt),
+                   "max_chi2_final_rel_diff_vs_gpu_on_converged_windows": float(rel[sane].max()) if sane.any() else None, "converged_windows": int(sane.sum()), "windows": int(n0)}
+        line = {"metric": "LM iterations/sec (and obs/sec) on stereo SE3 local areas with Schur landmark reduction; chi2 match vs CPU", "value": tot_trials * args.steps / max_elapsed, "unit": "LM iterations/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * max_elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "cfg3-stereo: %d key-frames, 2000 landmarks, stereo fx=200 fy=150 cx=512 cy=384 baseline 0.2 m, range 5 m, px noise 0.5, robust kernel, depth 3: %d local areas x %d replicas re-optimised per step" % (n_kf, n0, copies),
+                           "local_areas": n0, "replicas": copies, "unknown_edges_mean_max": [float(nk.mean()), int(nk.max())], "unknown_landmarks_mean_max": [float(nf.mean()), int(nf.max())], "observations_mean_max": [float(no.mean()), int(no.max())],
+                           "lm_trials_per_step": trials, "obs_per_s": tot_obs * args.steps / max_elapsed, "map_build_s": round(t_map, 2), "sequential_ms_per_kf": round(1e3 * t_map / n_kf, 3),
+                           "parallelism": "replicas x%d" % world, "solver": "Schur complement + LL^t of the reduced system in LDS (dense block layout; windows beyond LDS: HBM-resident layout or the multi-workgroup path)"},
+                "roofline": {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None, "kernel": "k_lm_run<SE3_STEREO>", "kernel_ms": kernel_ms,
+                             "note": "no algorithmic-byte model is defined for the Schur families (SURVEY 8d prices configs[1]); per-phase times: tools/diag_family_phases.py"},
+                "cpu_baseline": cpu}
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
+
+
 def bench_cfg4(args, dist, rank, world, local_rank, backend):
     """BASELINE configs[3] family: monocular SE3, max_tree_depth = max_optimize_depth = 8, sub-maps of 20, Schur complement + dense Cholesky. The map is built key-frame by
     key-frame through the engine with the GPU back-end (every define_new_keyframe() is one big-path LM run); a step re-optimises the last --cfg4-windows local areas."""
@@ -159,7 +217,9 @@ def main():
     ap.add_argument("--n-kf", type=int, default=30000, help="keyframes of the synthetic SE2 graph-SLAM map (BASELINE: 30000)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = all host cores, at most 64)")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4"], help="cfg2 = BASELINE configs[1] (the headline metric); cfg4 = deep monocular window, Schur + dense Cholesky on the multi-workgroup path")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"], help="cfg2 = BASELINE configs[1] (the headline metric); cfg3 = stereo SE3 windows with Schur reduction (configs[2]); cfg4 = deep monocular window, Schur + dense Cholesky on the multi-workgroup path")
+    ap.add_argument("--cfg3-kf", type=int, default=80, help="cfg3: key-frames of the stereo map (BASELINE: ~200; beyond ~90 key-frames of this synthetic room the reference algorithm itself loses the map at loop closures -- with the oracle back-end as well, DESIGN 8 -- and the windows stop being meaningful problems)")
+    ap.add_argument("--cfg3-copies", type=int, default=32, help="cfg3: the harvested local areas are re-optimised in this many replicas per step (fills the chip)")
     ap.add_argument("--cfg4-kf", type=int, default=300, help="key-frames of the cfg4 map (BASELINE: 5000; the depth-8 window saturates at ~260 key-frames, see DESIGN)")
     ap.add_argument("--cfg4-windows", type=int, default=4, help="local areas (the last ones of the map) re-optimised per step")
     ap.add_argument("--cache-dir", default="/tmp/srba_bench_cache", help="keep the harvested capsules here so that a second invocation (e.g. under rocprofv3) skips the sequential SLAM run; '' disables")
@@ -187,6 +247,8 @@ def main():
     from srba_amd import capi, datasets, runner
     if args.workload == "cfg4":
         return bench_cfg4(args, dist, rank, world, local_rank, backend)
+    if args.workload == "cfg3":
+        return bench_cfg3(args, dist, rank, world, local_rank, backend)
 
     t0 = time.time()
     ds = datasets.graph_slam_se2(n_kf=args.n_kf, seed=multi.replica_seed(rank), path="tour")

@@ -8,6 +8,7 @@ python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --workload cfg4 > $O/bench_cfg4.json 2> $O/bench_cfg4.err
+python bench.py --workload cfg3 > $O/bench_cfg3.json 2> $O/bench_cfg3.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o lm -- python $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 > $O/bench_prof.json 2> $O/bench_prof.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg4 -o c4 -- python $R/bench.py --workload cfg4 --cfg4-kf 200 --steps 3 --warmup 1 --cpu-seconds 0 > $O/bench_cfg4_prof.json 2> $O/bench_cfg4_prof.err
