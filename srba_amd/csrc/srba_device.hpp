@@ -239,7 +239,6 @@ struct SparseSys { // per-capsule symbolic structure (LDS copy of the host's sym
 	const int *rent_blk;
 	const int *perm;           // perm[original 3-row block] = position in the fill-reducing elimination order
 	double *diag, *off, *rhs;
-	double *col_lds; // numbers in HBM (ProbDesc::dense_blocks == 2): 9 (nb-1) doubles of LDS for the factored blocks of the current column, else null
 };
 // Cross-lane hand-off inside the solver. LDS instructions of one wavefront execute in issue order, so a ds_write followed by a ds_read of
 // another lane's data needs no s_waitcnt -- only the compiler must keep the program order (wavefront-scope fence = no instructions).
@@ -350,9 +349,7 @@ __device__ __forceinline__ void sp_bsub_rows(const SparseSys &S) {
 __device__ __forceinline__ int dense_col_start(int nb, int c) { return c * (nb - 1) - c * (c - 1) / 2; }
 // GLOBAL: the numbers live in HBM (ProbDesc::dense_blocks == 2): the hand-off between the sub-steps waits for the memory operations instead of relying on LDS order
 template <bool GLOBAL> __device__ __forceinline__ void dense_sync() { if constexpr (GLOBAL) __syncthreads(); else solver_sync(); }
-// col_lds (GLOBAL only): 9 (nb - 1) doubles of LDS; the factored blocks of the current column are left there so that the update items read their two operands on chip
-// and only the target block travels to and from HBM (the factorisation of these systems is bandwidth-bound: hundreds of them stream 0.5 MB each at the same time)
-template <bool GLOBAL> __device__ __forceinline__ bool sp_factor_fsub_dense(const SparseSys &S, double *col_lds = nullptr) {
+template <bool GLOBAL> __device__ __forceinline__ bool sp_factor_fsub_dense(const SparseSys &S) {
 	const int lane = threadIdx.x, nb = S.nb;
 	const int grp = (lane * 171) >> 9, sub = lane - 3 * grp; const bool worker = lane < 63;
 	for (int k = 0; k < nb; k++) {
@@ -363,62 +360,39 @@ template <bool GLOBAL> __device__ __forceinline__ bool sp_factor_fsub_dense(cons
 		Chol3 c;
 		if (!chol3v(a00, a10, a11, a20, a21, a22, c)) return false;
 		const double y0 = b0 * c.r0, y1 = (b1 - c.l10 * y0) * c.r1, y2 = (b2 - c.l20 * y0 - c.l21 * y1) * c.r2;
-		if constexpr (GLOBAL) {
-			// Numbers in HBM: a pass is a memory round trip whatever the lanes do, so ONE lane takes a whole 3x3 block (64 blocks per pass instead of 21)
-			for (int p = lane; p < cn; p += SRBA_WG) { // panel block (k+1+p, k) and its share of the forward substitution
-				double *Ax = S.off + 9 * (cb + p); double *rx = S.rhs + 3 * (k + 1 + p);
-				double A[9], r[3]; ldn<9>(A, Ax); ldn<3>(r, rx);
-#pragma unroll
-				for (int q = 0; q < 3; q++) {
-					const double x0 = A[3 * q] * c.r0, x1 = (A[3 * q + 1] - x0 * c.l10) * c.r1, x2 = (A[3 * q + 2] - x0 * c.l20 - x1 * c.l21) * c.r2;
-					A[3 * q] = x0; A[3 * q + 1] = x1; A[3 * q + 2] = x2; r[q] -= x0 * y0 + x1 * y1 + x2 * y2;
-				}
-				stn<9>(Ax, A); stn<3>(rx, r);
-				if (col_lds) {
-#pragma unroll
-					for (int q = 0; q < 9; q++) col_lds[9 * p + q] = A[q]; }
-			}
-		} else {
-			if (worker) for (int p = grp; p < cn; p += 21) { // row `sub` of panel block (k+1+p, k) and its share of the forward substitution
-				double *Ax = S.off + 9 * (cb + p) + 3 * sub; double *rx = S.rhs + 3 * (k + 1 + p) + sub;
-				const double x0 = Ax[0] * c.r0, x1 = (Ax[1] - x0 * c.l10) * c.r1, x2 = (Ax[2] - x0 * c.l20 - x1 * c.l21) * c.r2;
-				Ax[0] = x0; Ax[1] = x1; Ax[2] = x2; *rx -= x0 * y0 + x1 * y1 + x2 * y2;
-			}
+		if (worker) for (int p = grp; p < cn; p += 21) { // row `sub` of panel block (k+1+p, k) and its share of the forward substitution
+			double *Ax = S.off + 9 * (cb + p) + 3 * sub; double *rx = S.rhs + 3 * (k + 1 + p) + sub;
+			const double x0 = Ax[0] * c.r0, x1 = (Ax[1] - x0 * c.l10) * c.r1, x2 = (Ax[2] - x0 * c.l20 - x1 * c.l21) * c.r2;
+			Ax[0] = x0; Ax[1] = x1; Ax[2] = x2; *rx -= x0 * y0 + x1 * y1 + x2 * y2;
 		}
 		if (lane == SRBA_WG - 1) { // L_kk, reciprocal diagonal in the unused upper part, y_k
 			D[0] = c.l00; D[3] = c.l10; D[4] = c.l11; D[6] = c.l20; D[7] = c.l21; D[8] = c.l22; D[1] = c.r0; D[2] = c.r1; D[5] = c.r2;
 			S.rhs[3 * k] = y0; S.rhs[3 * k + 1] = y1; S.rhs[3 * k + 2] = y2;
 		}
 		dense_sync<GLOBAL>();
-		// trailing update: block (k+1+a, k+1+b) -= L_ak L_bk^t
-		if constexpr (GLOBAL) {
-			for (int t = lane; t < nitems; t += SRBA_WG) { // one lane per item: its three records are requested together
-				int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f); a += ((a + 1) * (a + 2) / 2 <= t) ? 1 : 0; a -= (a * (a + 1) / 2 > t) ? 1 : 0; const int b = t - a * (a + 1) / 2;
-				double *T = (a == b ? S.diag + 9 * (k + 1 + a) : S.off + 9 * (dense_col_start(nb, k + 1 + b) + (a - b - 1)));
-				double la[9], lb[9], tv[9]; ldn<9>(tv, T);
-				if (col_lds) {
+		// trailing update, row `sub` of block (k+1+a, k+1+b) -= L_ak L_bk^t. With the numbers in HBM two items are in flight per lane and pass (their loads are
+		// independent): the pass is a memory round trip, and a column of a 60..90-row system has thousands of items
+		constexpr int U = GLOBAL ? 2 : 1;
+		if (worker) for (int t0 = grp; t0 < nitems; t0 += 21 * U) {
+			double la[U][3], lb[U][9], tv[U][3]; double *T[U]; bool live[U];
 #pragma unroll
-					for (int q = 0; q < 9; q++) { la[q] = col_lds[9 * a + q]; lb[q] = col_lds[9 * b + q]; }
-				} else { ldn<9>(la, S.off + 9 * (cb + a)); ldn<9>(lb, S.off + 9 * (cb + b)); }
-#pragma unroll
-				for (int i = 0; i < 3; i++)
-#pragma unroll
-					for (int j = 0; j < 3; j++) tv[3 * i + j] -= la[3 * i] * lb[3 * j] + la[3 * i + 1] * lb[3 * j + 1] + la[3 * i + 2] * lb[3 * j + 2];
-				stn<9>(T, tv);
-			}
-		} else {
-			if (worker) for (int t = grp; t < nitems; t += 21) { // row `sub` of the target, three lanes per item
-				int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f); a += ((a + 1) * (a + 2) / 2 <= t) ? 1 : 0; a -= (a * (a + 1) / 2 > t) ? 1 : 0; const int b = t - a * (a + 1) / 2;
+			for (int u = 0; u < U; u++) {
+				const int t = t0 + 21 * u; live[u] = t < nitems; const int tt = live[u] ? t : 0;
+				int a = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f); a += ((a + 1) * (a + 2) / 2 <= tt) ? 1 : 0; a -= (a * (a + 1) / 2 > tt) ? 1 : 0; const int b = tt - a * (a + 1) / 2;
 				const double *La = S.off + 9 * (cb + a) + 3 * sub, *Lb = S.off + 9 * (cb + b);
-				double *T = (a == b ? S.diag + 9 * (k + 1 + a) : S.off + 9 * (dense_col_start(nb, k + 1 + b) + (a - b - 1))) + 3 * sub;
-				const double la0 = La[0], la1 = La[1], la2 = La[2];
-				double lb[9];
+				T[u] = (a == b ? S.diag + 9 * (k + 1 + a) : S.off + 9 * (dense_col_start(nb, k + 1 + b) + (a - b - 1))) + 3 * sub;
+				if (live[u]) {
 #pragma unroll
-				for (int q = 0; q < 9; q++) lb[q] = Lb[q];
-				const double t0 = T[0], t1 = T[1], t2 = T[2];
-				T[0] = t0 - (la0 * lb[0] + la1 * lb[1] + la2 * lb[2]);
-				T[1] = t1 - (la0 * lb[3] + la1 * lb[4] + la2 * lb[5]);
-				T[2] = t2 - (la0 * lb[6] + la1 * lb[7] + la2 * lb[8]);
+					for (int q = 0; q < 3; q++) { la[u][q] = La[q]; tv[u][q] = T[u][q]; }
+#pragma unroll
+					for (int q = 0; q < 9; q++) lb[u][q] = Lb[q];
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < U; u++) if (live[u]) {
+				T[u][0] = tv[u][0] - (la[u][0] * lb[u][0] + la[u][1] * lb[u][1] + la[u][2] * lb[u][2]);
+				T[u][1] = tv[u][1] - (la[u][0] * lb[u][3] + la[u][1] * lb[u][4] + la[u][2] * lb[u][5]);
+				T[u][2] = tv[u][2] - (la[u][0] * lb[u][6] + la[u][1] * lb[u][7] + la[u][2] * lb[u][8]);
 			}
 		}
 		dense_sync<GLOBAL>();
@@ -432,18 +406,9 @@ template <bool GLOBAL> __device__ __forceinline__ void sp_bsub_dense(const Spars
 		const double *D = S.diag + 9 * a;
 		const double r0 = S.rhs[3 * a], r1 = S.rhs[3 * a + 1], r2 = S.rhs[3 * a + 2], d5 = D[5], d7 = D[7], d2 = D[2], d3 = D[3], d6 = D[6], d1 = D[1];
 		const double x2 = r2 * d5, x1 = (r1 - d7 * x2) * d2, x0 = (r0 - d3 * x1 - d6 * x2) * d1;
-		if constexpr (GLOBAL) {
-			for (int cidx = lane; cidx < a; cidx += SRBA_WG) { // y_c -= L_ac^t x_a for every column c < a, one lane per column
-				double Lx[9], yv[3]; ldn<9>(Lx, S.off + 9 * (dense_col_start(nb, cidx) + (a - cidx - 1))); double *yx = S.rhs + 3 * cidx; ldn<3>(yv, yx);
-#pragma unroll
-				for (int q = 0; q < 3; q++) yv[q] -= Lx[q] * x0 + Lx[3 + q] * x1 + Lx[6 + q] * x2;
-				stn<3>(yx, yv);
-			}
-		} else {
-			if (worker) for (int cidx = grp; cidx < a; cidx += 21) { // y_c[sub] -= (L_ac^t x_a)[sub] for every column c < a
-				const double *Lx = S.off + 9 * (dense_col_start(nb, cidx) + (a - cidx - 1)) + sub; double *yx = S.rhs + 3 * cidx + sub;
-				*yx -= Lx[0] * x0 + Lx[3] * x1 + Lx[6] * x2;
-			}
+		if (worker) for (int cidx = grp; cidx < a; cidx += 21) { // y_c[sub] -= (L_ac^t x_a)[sub] for every column c < a
+			const double *Lx = S.off + 9 * (dense_col_start(nb, cidx) + (a - cidx - 1)) + sub; double *yx = S.rhs + 3 * cidx + sub;
+			*yx -= Lx[0] * x0 + Lx[3] * x1 + Lx[6] * x2;
 		}
 		if (lane == SRBA_WG - 1) { S.rhs[3 * a] = x0; S.rhs[3 * a + 1] = x1; S.rhs[3 * a + 2] = x2; }
 		dense_sync<GLOBAL>();
