@@ -42,7 +42,7 @@ struct ProbDesc {
 };
 
 struct Batch {
-	int n_prob; int max_lds_doubles; int hess_terms; // hess_terms: the fused kernel accumulates U_Ap term-parallel in LDS
+	int n_prob; int max_lds_doubles; int hess_terms; int dense_left; // hess_terms: the fused kernel accumulates U_Ap term-parallel in LDS; dense_left: left-looking sweeps on the HBM-resident dense layout
 	const ProbDesc *desc; const int *order; // order: capsule indices grouped by LDS size class (one launch per class)
 	// inputs
 	const double *edge0, *ulm0, *klm, *obs_z;
@@ -239,6 +239,7 @@ struct SparseSys { // per-capsule symbolic structure (LDS copy of the host's sym
 	const int *rent_blk;
 	const int *perm;           // perm[original 3-row block] = position in the fill-reducing elimination order
 	double *diag, *off, *rhs;
+	double *row_lds;           // HBM-resident dense layout with left-looking sweeps: 12 nb doubles of LDS (row k of the factor | y), else null
 };
 // Cross-lane hand-off inside the solver. LDS instructions of one wavefront execute in issue order, so a ds_write followed by a ds_read of
 // another lane's data needs no s_waitcnt -- only the compiler must keep the program order (wavefront-scope fence = no instructions).
@@ -413,6 +414,103 @@ template <bool GLOBAL> __device__ __forceinline__ void sp_bsub_dense(const Spars
 		if (lane == SRBA_WG - 1) { S.rhs[3 * a] = x0; S.rhs[3 * a + 1] = x1; S.rhs[3 * a + 2] = x2; }
 		dense_sync<GLOBAL>();
 	}
+}
+// ---- HBM-resident dense layout (ProbDesc::dense_blocks == 2), LEFT-looking. The right-looking sweep above, run on numbers in HBM, is a read-modify-write of every
+// target block per column: ~nb^3/6 dependent round trips shared by 64 lanes, two barriers with a store drain per column. Here column k is finished in one go:
+//   row k of L (blocks (k,j), j<k, written by earlier columns) is staged in LDS (9 doubles per block);
+//   the lane that owns row `sub` of block (r,k), r = k..nb-1, keeps that row in registers and subtracts L_rj L_kj^t for j = 0..k-1 -- its own operand streams from HBM
+//   (loads only, eight columns requested before the first is used; the 21 blocks x 3 rows of a pass are one contiguous span of column j), the shared one comes from LDS;
+//   the three lanes of the diagonal block hand their rows to everybody (v_readlane), every lane factors it, the panel rows are scaled and stored once.
+// The right-hand side follows the same pattern (y_k = L_kk^-1 (b_k - sum_j L_kj y_j), y kept in LDS) and the backward sweep is the column-dot form
+// x_a = L_aa^-t (y_a - sum_{r>a} L_ra^t x_r) on the LDS copy: no read-modify-write of HBM anywhere, one barrier with a store drain per column of the factor, none in the
+// backward sweep. Same operations in the same order per scalar of the factor as the right-looking form (updates of a block arrive in increasing j in both).
+// rowk: 9 nb doubles of LDS, yl: 3 nb doubles of LDS. nb <= 168 (eight passes of 21 blocks).
+template <int LN> __device__ __forceinline__ double readlane_c(double v) {
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), LN), hi = __builtin_amdgcn_readlane(__double2hiint(v), LN);
+	return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ bool sp_factor_fsub_dense_left(const SparseSys &S, double *rowk, double *yl) {
+	const int lane = threadIdx.x, nb = S.nb;
+	const int grp = (lane * 171) >> 9, sub = lane - 3 * grp; const bool worker = lane < 63;
+	constexpr int U = 8;
+	for (int k = 0; k < nb; k++) {
+		const int cn = nb - 1 - k, cb = dense_col_start(nb, k);
+		const double bk = (lane < 3) ? S.rhs[3 * k + lane] : 0.0; // b_k (assembled long ago)
+		{ // (1) row k of L -> LDS
+			double st[8][3];
+#pragma unroll
+			for (int i = 0; i < 8; i++) { const int j = grp + 21 * i; if (worker && j < k) { const double *src = S.off + 9 * (dense_col_start(nb, j) + (k - j - 1)) + 3 * sub; st[i][0] = src[0]; st[i][1] = src[1]; st[i][2] = src[2]; } }
+#pragma unroll
+			for (int i = 0; i < 8; i++) { const int j = grp + 21 * i; if (worker && j < k) { double *dst = rowk + 9 * j + 3 * sub; dst[0] = st[i][0]; dst[1] = st[i][1]; dst[2] = st[i][2]; } }
+		}
+		solver_sync();
+		// (2) b_k - sum_j L_kj y_j, columns j spread over the lanes
+		double s0 = 0, s1 = 0, s2 = 0;
+		for (int j = lane; j < k; j += SRBA_WG) {
+			const double *Lr = rowk + 9 * j; const double q0 = yl[3 * j], q1 = yl[3 * j + 1], q2 = yl[3 * j + 2];
+			s0 += Lr[0] * q0 + Lr[1] * q1 + Lr[2] * q2; s1 += Lr[3] * q0 + Lr[4] * q1 + Lr[5] * q2; s2 += Lr[6] * q0 + Lr[7] * q1 + Lr[8] * q2;
+		}
+		s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+		const double b0 = readlane_c<0>(bk) - s0, b1 = readlane_c<1>(bk) - s1, b2 = readlane_c<2>(bk) - s2;
+		// (3) the blocks of column k, 21 per pass (pass 0 starts with the diagonal block)
+		Chol3 c; double y0 = 0, y1 = 0, y2 = 0;
+		for (int i = 0; 21 * i <= cn; i++) {
+			const int p = grp + 21 * i, r = k + p; const bool act = worker && p <= cn;
+			double *A = (p == 0 ? S.diag + 9 * k : S.off + 9 * (cb + p - 1)) + 3 * sub;
+			double a0 = 0, a1 = 0, a2 = 0;
+			if (act) {
+				a0 = A[0]; a1 = A[1]; a2 = A[2];
+				int j = 0;
+				for (; j + U <= k; j += U) {
+					double la[U][3];
+#pragma unroll
+					for (int u = 0; u < U; u++) { const double *src = S.off + 9 * (dense_col_start(nb, j + u) + (r - j - u - 1)) + 3 * sub; la[u][0] = src[0]; la[u][1] = src[1]; la[u][2] = src[2]; }
+#pragma unroll
+					for (int u = 0; u < U; u++) { const double *lb = rowk + 9 * (j + u);
+						a0 -= la[u][0] * lb[0] + la[u][1] * lb[1] + la[u][2] * lb[2]; a1 -= la[u][0] * lb[3] + la[u][1] * lb[4] + la[u][2] * lb[5]; a2 -= la[u][0] * lb[6] + la[u][1] * lb[7] + la[u][2] * lb[8]; }
+				}
+				{ double la[U][3]; // the last k % U columns
+#pragma unroll
+					for (int u = 0; u < U; u++) if (j + u < k) { const double *src = S.off + 9 * (dense_col_start(nb, j + u) + (r - j - u - 1)) + 3 * sub; la[u][0] = src[0]; la[u][1] = src[1]; la[u][2] = src[2]; }
+#pragma unroll
+					for (int u = 0; u < U; u++) if (j + u < k) { const double *lb = rowk + 9 * (j + u);
+						a0 -= la[u][0] * lb[0] + la[u][1] * lb[1] + la[u][2] * lb[2]; a1 -= la[u][0] * lb[3] + la[u][1] * lb[4] + la[u][2] * lb[5]; a2 -= la[u][0] * lb[6] + la[u][1] * lb[7] + la[u][2] * lb[8]; }
+				}
+			}
+			if (i == 0) { // rows 0,1,2 of the updated diagonal block sit in lanes 0,1,2
+				const double d00 = readlane_c<0>(a0), d10 = readlane_c<1>(a0), d11 = readlane_c<1>(a1), d20 = readlane_c<2>(a0), d21 = readlane_c<2>(a1), d22 = readlane_c<2>(a2);
+				if (!chol3v(d00, d10, d11, d20, d21, d22, c)) return false;
+				y0 = b0 * c.r0; y1 = (b1 - c.l10 * y0) * c.r1; y2 = (b2 - c.l20 * y0 - c.l21 * y1) * c.r2;
+			}
+			if (act && p > 0) { const double x0 = a0 * c.r0, x1 = (a1 - x0 * c.l10) * c.r1, x2 = (a2 - x0 * c.l20 - x1 * c.l21) * c.r2; A[0] = x0; A[1] = x1; A[2] = x2; }
+		}
+		if (lane == SRBA_WG - 1) { // L_kk, reciprocal diagonal in the unused upper part, y_k
+			double *D = S.diag + 9 * k;
+			D[0] = c.l00; D[3] = c.l10; D[4] = c.l11; D[6] = c.l20; D[7] = c.l21; D[8] = c.l22; D[1] = c.r0; D[2] = c.r1; D[5] = c.r2;
+			yl[3 * k] = y0; yl[3 * k + 1] = y1; yl[3 * k + 2] = y2;
+		}
+		__syncthreads(); // the panel stores of this column are read (row k+1) by the next one
+	}
+	return true;
+}
+// backward sweep on the LDS copy of y (in: y, out: x, also written to S.rhs)
+__device__ __forceinline__ void sp_bsub_dense_left(const SparseSys &S, double *yl) {
+	const int lane = threadIdx.x, nb = S.nb;
+	const int grp = (lane * 171) >> 9, sub = lane - 3 * grp; const bool worker = lane < 63;
+	for (int a = nb - 1; a >= 0; a--) {
+		const double *D = S.diag + 9 * a; const int cb = dense_col_start(nb, a), cn = nb - 1 - a;
+		const double d5 = D[5], d7 = D[7], d2 = D[2], d3 = D[3], d6 = D[6], d1 = D[1];
+		double s = 0; // component `sub` of sum_{r>a} L_ra^t x_r, rows r spread over the lane groups
+		if (worker) for (int p = grp; p < cn; p += 21) { const double *Lx = S.off + 9 * (cb + p) + sub; const double *x = yl + 3 * (a + 1 + p); s += Lx[0] * x[0] + Lx[3] * x[1] + Lx[6] * x[2]; }
+		const double t0 = wave_sum((worker && sub == 0) ? s : 0.0), t1 = wave_sum((worker && sub == 1) ? s : 0.0), t2 = wave_sum((worker && sub == 2) ? s : 0.0);
+		const double r0 = yl[3 * a] - t0, r1 = yl[3 * a + 1] - t1, r2 = yl[3 * a + 2] - t2;
+		const double x2 = r2 * d5, x1 = (r1 - d7 * x2) * d2, x0 = (r0 - d3 * x1 - d6 * x2) * d1;
+		solver_sync(); // every lane has read y_a
+		if (lane == SRBA_WG - 1) { yl[3 * a] = x0; yl[3 * a + 1] = x1; yl[3 * a + 2] = x2; }
+		solver_sync();
+	}
+	for (int k = lane; k < 3 * nb; k += SRBA_WG) S.rhs[k] = yl[k];
+	__syncthreads();
 }
 // location of scalar element (r,c), r>=c (block-permutation already applied); returns nullptr if the block is structurally absent
 __device__ __forceinline__ double *sp_elem(const SparseSys &S, int r, int c) {

@@ -221,9 +221,9 @@ struct Solver : public Worker<FAM> {
 		STIC(); assemble(S, lambda); STOC(10);
 		// (the dense block layouts are never chosen for the relative-pose families -- srba_hip_upload_problems -- whose kernels therefore carry the sparse solver only: the
 		//  headline kernel sits 22 VGPRs below the two-wavefronts-per-SIMD limit)
-		STIC(); bool ok; if constexpr (W::T::REL || !W::T::SE3) ok = sp_factor_fsub_rows(S); else ok = d.dense_blocks == 2 ? sp_factor_fsub_dense<true>(S) : (S.dense ? sp_factor_fsub_dense<false>(S) : sp_factor_fsub_rows(S)); STOC(11);
+		STIC(); bool ok; if constexpr (W::T::REL || !W::T::SE3) ok = sp_factor_fsub_rows(S); else ok = d.dense_blocks == 2 ? (S.row_lds ? sp_factor_fsub_dense_left(S, S.row_lds, S.row_lds + 9 * S.nb) : sp_factor_fsub_dense<true>(S)) : (S.dense ? sp_factor_fsub_dense<false>(S) : sp_factor_fsub_rows(S)); STOC(11);
 		if (!ok) return false;
-		STIC(); if constexpr (W::T::REL || !W::T::SE3) sp_bsub_rows(S); else { if (d.dense_blocks == 2) sp_bsub_dense<true>(S); else if (S.dense) sp_bsub_dense<false>(S); else sp_bsub_rows(S); }
+		STIC(); if constexpr (W::T::REL || !W::T::SE3) sp_bsub_rows(S); else { if (d.dense_blocks == 2) { if (S.row_lds) sp_bsub_dense_left(S, S.row_lds + 9 * S.nb); else sp_bsub_dense<true>(S); } else if (S.dense) sp_bsub_dense<false>(S); else sp_bsub_rows(S); }
 		double *dl = B.delta + d.o_scal;
 		for (int k = tid; k < d.n_scal; k += SRBA_WG) dl[k] = (k < d.n_sys) ? S.rhs[3 * S.perm[k / 3] + k % 3] : 0.0;
 		__syncthreads(); STOC(12);
@@ -234,6 +234,7 @@ struct Solver : public Worker<FAM> {
 	}
 	__device__ __forceinline__ SparseSys make_sys(double *lds) const {
 		SparseSys S; S.nb = d.nb; S.nnzoff = d.nnzoff; S.dense = (W::T::REL || !W::T::SE3) ? 0 : d.dense_blocks;
+		S.row_lds = (S.dense == 2 && B.dense_left && d.nb <= 168) ? lds + (d.nb + 1) / 2 + 16 : nullptr; // HBM-resident layout, left-looking sweeps: 12 nb doubles of LDS after the permutation
 		S.col_off = B.sp_col_off + d.o_spcol; S.row = B.sp_row + d.o_sprow; S.item = B.sp_tgt + d.o_spitem; S.item_ab = B.sp_ab + d.o_spitem; S.perm = B.sp_perm + d.o_spperm;
 		S.rptr = B.sp_rptr + d.o_spcol; S.rent = B.sp_rcol + d.o_sprow; S.rent_blk = B.sp_rblk + d.o_sprow;
 		double *base = (!W::T::REL && W::T::SE3 && d.dense_blocks == 2) ? B.dense + d.o_dense : lds; // 2: the numbers live in an HBM workspace, LDS holds the permutation only
@@ -704,7 +705,7 @@ struct srba_hip_ctx {
 	BigLane lanes[kBigLanes]; int n_lanes_ready = 0; // lane 0 = the context stream and buffers; the others are created on first use
 	struct BigGraphSet { hipGraphExec_t g[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; }; // assemble, Cholesky, back-substitution .. rho, accept + relinearise, accept
 	std::map<int, BigGraphSet> big_graphs; bool big_use_graphs = false; int big_lanes_max = kBigLanes; // captured launch sequences of the big path, per capsule; dropped at upload
-	bool dense_blocks_ok = true; // mid-size nearly-full systems use the dense block layout in LDS
+	bool dense_left = true; bool dense_blocks_ok = true; // mid-size nearly-full systems use the dense block layout in LDS
 	bool lin_terms = true, lm_terms = true; // term-parallel U_Ap accumulation in LDS: srba_hip_linearize / the fused LM kernel
 	srbadev::FlatMap flat; bool flat_ready = false, use_flat = true; // pair -> capsule map of the flat spanning-tree kernel (srba_flat.hpp), filled on first use after an upload
 	int big_min_sys = 480;   // systems with more scalar unknowns than this skip the block-sparse symbolic analysis and go dense (big path)
@@ -836,6 +837,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	if (!ok || hipMalloc((void **)&c->d_next, sizeof(int) * kMaxJobs) != hipSuccess || hipMalloc((void **)&c->d_part, 8 * 3 * kBigPart) != hipSuccess || hipMalloc((void **)&c->d_scal, 8 * 16) != hipSuccess || hipMalloc((void **)&c->d_iscal, 4 * 8) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	{ const char *e = getenv("SRBA_HIP_BIG_MIN_SYS"); if (e && atoi(e) >= 0) c->big_min_sys = atoi(e); } // tuning / test knob
 	{ const char *e = getenv("SRBA_HIP_DENSE_BLOCKS"); if (e) c->dense_blocks_ok = atoi(e) != 0; }
+	{ const char *e = getenv("SRBA_HIP_DENSE_LEFT"); if (e) c->dense_left = atoi(e) != 0; } // 0: right-looking sweeps on the HBM-resident dense layout (round-2 first version)
 	{ const char *e = getenv("SRBA_HIP_LIN_TERMS"); if (e) c->lin_terms = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_LM_TERMS"); if (e) c->lm_terms = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_FLAT"); if (e) c->use_flat = atoi(e) != 0; }                     // 0 = one wavefront per capsule for the stepwise spanning-tree launch
@@ -930,7 +932,9 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 			// one-wavefront kernel with the dense block system in an HBM workspace (slow per capsule, but thousands run side by side).
 			const size_t nnz_d = (size_t)d.nb * (d.nb - 1) / 2;
 			symbolic_dense(k, d, P, L, !schur_solver, sym[p]); d.dense_blocks = 2; d.nnzoff = (int)nnz_d; d.n_items = 0; d.aligned = sym[p].aligned ? 1 : 0;
-			tri_n = ((size_t)d.nb + 1) / 2 + 16; bytes = tri_n * 8; cls[p] = 0; wave_ws = 12 * (long long)d.nb + 9 * (long long)nnz_d;
+			tri_n = ((size_t)d.nb + 1) / 2 + 16 + (c->dense_left ? 12 * (size_t)d.nb : 0); bytes = tri_n * 8; /* LDS: the permutation (+ one row of the factor and the right-hand side: left-looking sweeps) */
+			cls[p] = 0; while (cls[p] < SRBA_NCLS - 2 && bytes > (size_t)kClsKB[cls[p]] * 1024) cls[p]++;
+			wave_ws = 12 * (long long)d.nb + 9 * (long long)nnz_d;
 		}
 		const int n_row_store = (int)sym[p].row.size(); // entries of the row / row-view arrays in the input arena (none in the dense layout)
 		d.o_spcol = t_spcol; d.o_sprow = t_sprow; d.o_spitem = t_spitem; d.o_spperm = t_spcol - p;
@@ -1038,7 +1042,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	HIPCHK(c, hipMemcpyAsync(c->d_in, h, in.size, hipMemcpyHostToDevice, c->stream));
 	HIPCHK(c, hipMemsetAsync(c->d_wk, 0, wk.size, c->stream));
 	// ---- batch struct
-	Batch &B = c->B; std::memset(&B, 0, sizeof(B)); B.n_prob = n; B.max_lds_doubles = 0; B.hess_terms = c->lm_terms ? 1 : 0;
+	Batch &B = c->B; std::memset(&B, 0, sizeof(B)); B.n_prob = n; B.max_lds_doubles = 0; B.hess_terms = c->lm_terms ? 1 : 0; B.dense_left = c->dense_left ? 1 : 0;
 	char *di = c->d_in, *dw = c->d_wk;
 #define DI(field, T) B.field = (const T *)(di + o.field)
 	B.desc = (const ProbDesc *)(di + o.desc); DI(order, int); DI(sp_col_off, int); DI(sp_row, int); DI(sp_item_off, int); DI(sp_tgt, int); DI(sp_ab, int); DI(sp_rptr, int); DI(sp_rcol, int); DI(sp_rblk, int); DI(sp_perm, int); DI(hap_rec, int); DI(sp_fill, int); DI(hap_dst, int); DI(hapf_dst, int); DI(hf_dst, int); DI(edge0, double); DI(ulm0, double); DI(klm, double); DI(obs_z, double);
