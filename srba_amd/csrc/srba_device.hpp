@@ -239,7 +239,7 @@ struct SparseSys { // per-capsule symbolic structure (LDS copy of the host's sym
 	const int *rent_blk;
 	const int *perm;           // perm[original 3-row block] = position in the fill-reducing elimination order
 	double *diag, *off, *rhs;
-	double *row_lds;           // HBM-resident dense layout with left-looking sweeps: 12 nb doubles of LDS (row k of the factor | y), else null
+	double *row_lds;           // HBM-resident dense layout with left-looking sweeps: 21 nb doubles of LDS (rows k, k+1 of the factor | y), else null
 };
 // Cross-lane hand-off inside the solver. LDS instructions of one wavefront execute in issue order, so a ds_write followed by a ds_read of
 // another lane's data needs no s_waitcnt -- only the compiler must keep the program order (wavefront-scope fence = no instructions).
@@ -424,72 +424,96 @@ template <bool GLOBAL> __device__ __forceinline__ void sp_bsub_dense(const Spars
 // The right-hand side follows the same pattern (y_k = L_kk^-1 (b_k - sum_j L_kj y_j), y kept in LDS) and the backward sweep is the column-dot form
 // x_a = L_aa^-t (y_a - sum_{r>a} L_ra^t x_r) on the LDS copy: no read-modify-write of HBM anywhere, one barrier with a store drain per column of the factor, none in the
 // backward sweep. Same operations in the same order per scalar of the factor as the right-looking form (updates of a block arrive in increasing j in both).
-// rowk: 9 nb doubles of LDS, yl: 3 nb doubles of LDS. nb <= 168 (eight passes of 21 blocks).
+// nb <= 168 (eight passes of 21 blocks).
 template <int LN> __device__ __forceinline__ double readlane_c(double v) {
 	const int lo = __builtin_amdgcn_readlane(__double2loint(v), LN), hi = __builtin_amdgcn_readlane(__double2hiint(v), LN);
 	return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double readlane_v(double v, int l) { // l uniform
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+	return __hiloint2double(hi, lo);
+}
+// Two columns (k, k+1) per step: every operand L_rj streamed from HBM serves both (the sweep is bound by that stream: hundreds of wavefronts each re-read their
+// 0.1 .. 0.8 MB factor nb/3 times), then column k is finished, applied to column k+1 inside the registers (L_{k+1,k} is handed over by the three lanes that hold it)
+// and column k+1 is finished. rowk: two rows of L (18 nb doubles of LDS), yl: 3 nb doubles.
 __device__ __forceinline__ bool sp_factor_fsub_dense_left(const SparseSys &S, double *rowk, double *yl) {
 	const int lane = threadIdx.x, nb = S.nb;
 	const int grp = (lane * 171) >> 9, sub = lane - 3 * grp; const bool worker = lane < 63;
 	constexpr int U = 8;
-	for (int k = 0; k < nb; k++) {
-		const int cn = nb - 1 - k, cb = dense_col_start(nb, k);
-		const double bk = (lane < 3) ? S.rhs[3 * k + lane] : 0.0; // b_k (assembled long ago)
-		{ // (1) row k of L -> LDS
-			double st[8][3];
+	double *row0 = rowk, *row1 = rowk + 9 * nb;
+	for (int k = 0; k < nb; k += 2) {
+		const bool two = k + 1 < nb;
+		const int cn = nb - 1 - k, cb = dense_col_start(nb, k), cb1 = dense_col_start(nb, k + 1);
+		const double bk = (lane < 3) ? S.rhs[3 * k + lane] : ((lane < 6 && two) ? S.rhs[3 * k + lane] : 0.0); // b_k, b_k+1 (assembled long ago)
+		for (int h = 0; 84 * h < k; h++) { // (1) rows k, k+1 of L (columns j < k) -> LDS, 84 columns per round trip
+			double st[4][6];
 #pragma unroll
-			for (int i = 0; i < 8; i++) { const int j = grp + 21 * i; if (worker && j < k) { const double *src = S.off + 9 * (dense_col_start(nb, j) + (k - j - 1)) + 3 * sub; st[i][0] = src[0]; st[i][1] = src[1]; st[i][2] = src[2]; } }
+			for (int i = 0; i < 4; i++) { const int j = grp + 21 * (4 * h + i); if (worker && j < k) { const double *src = S.off + 9 * (dense_col_start(nb, j) + (k - j - 1)) + 3 * sub;
+				st[i][0] = src[0]; st[i][1] = src[1]; st[i][2] = src[2]; if (two) { st[i][3] = src[9]; st[i][4] = src[10]; st[i][5] = src[11]; } } }
 #pragma unroll
-			for (int i = 0; i < 8; i++) { const int j = grp + 21 * i; if (worker && j < k) { double *dst = rowk + 9 * j + 3 * sub; dst[0] = st[i][0]; dst[1] = st[i][1]; dst[2] = st[i][2]; } }
+			for (int i = 0; i < 4; i++) { const int j = grp + 21 * (4 * h + i); if (worker && j < k) { double *d0 = row0 + 9 * j + 3 * sub, *d1 = row1 + 9 * j + 3 * sub;
+				d0[0] = st[i][0]; d0[1] = st[i][1]; d0[2] = st[i][2]; if (two) { d1[0] = st[i][3]; d1[1] = st[i][4]; d1[2] = st[i][5]; } } }
 		}
 		solver_sync();
-		// (2) b_k - sum_j L_kj y_j, columns j spread over the lanes
-		double s0 = 0, s1 = 0, s2 = 0;
+		// (2) b - sum_j L_kj y_j for both rows, columns j spread over the lanes
+		double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
 		for (int j = lane; j < k; j += SRBA_WG) {
-			const double *Lr = rowk + 9 * j; const double q0 = yl[3 * j], q1 = yl[3 * j + 1], q2 = yl[3 * j + 2];
-			s0 += Lr[0] * q0 + Lr[1] * q1 + Lr[2] * q2; s1 += Lr[3] * q0 + Lr[4] * q1 + Lr[5] * q2; s2 += Lr[6] * q0 + Lr[7] * q1 + Lr[8] * q2;
+			const double *L0 = row0 + 9 * j, *L1 = row1 + 9 * j; const double q0 = yl[3 * j], q1 = yl[3 * j + 1], q2 = yl[3 * j + 2];
+			s0 += L0[0] * q0 + L0[1] * q1 + L0[2] * q2; s1 += L0[3] * q0 + L0[4] * q1 + L0[5] * q2; s2 += L0[6] * q0 + L0[7] * q1 + L0[8] * q2;
+			if (two) { s3 += L1[0] * q0 + L1[1] * q1 + L1[2] * q2; s4 += L1[3] * q0 + L1[4] * q1 + L1[5] * q2; s5 += L1[6] * q0 + L1[7] * q1 + L1[8] * q2; }
 		}
 		s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
 		const double b0 = readlane_c<0>(bk) - s0, b1 = readlane_c<1>(bk) - s1, b2 = readlane_c<2>(bk) - s2;
-		// (3) the blocks of column k, 21 per pass (pass 0 starts with the diagonal block)
-		Chol3 c; double y0 = 0, y1 = 0, y2 = 0;
+		double e0 = 0, e1 = 0, e2 = 0; // b_k+1 - ...
+		if (two) { s3 = wave_sum(s3); s4 = wave_sum(s4); s5 = wave_sum(s5); e0 = readlane_c<3>(bk) - s3; e1 = readlane_c<4>(bk) - s4; e2 = readlane_c<5>(bk) - s5; }
+		// (3) the blocks of the two columns, 21 block rows per pass: item p is block row r = k + p; pass 0 holds the diagonal blocks (p = 0 of column k, p = 1 of column k+1)
+		Chol3 c, c1; double y0 = 0, y1 = 0, y2 = 0, z0 = 0, z1 = 0, z2 = 0, m[9];
 		for (int i = 0; 21 * i <= cn; i++) {
-			const int p = grp + 21 * i, r = k + p; const bool act = worker && p <= cn;
+			const int p = grp + 21 * i, r = k + p; const bool act = worker && p <= cn, act1 = act && two && p >= 1;
 			double *A = (p == 0 ? S.diag + 9 * k : S.off + 9 * (cb + p - 1)) + 3 * sub;
-			double a0 = 0, a1 = 0, a2 = 0;
+			double *E = (p == 1 ? S.diag + 9 * (k + 1) : S.off + 9 * (cb1 + p - 2)) + 3 * sub;
+			double a0 = 0, a1 = 0, a2 = 0, f0 = 0, f1 = 0, f2 = 0;
 			if (act) {
-				a0 = A[0]; a1 = A[1]; a2 = A[2];
-				int j = 0;
-				for (; j + U <= k; j += U) {
+				a0 = A[0]; a1 = A[1]; a2 = A[2]; if (act1) { f0 = E[0]; f1 = E[1]; f2 = E[2]; }
+				for (int j = 0; j < k; j += U) {
 					double la[U][3];
-#pragma unroll
-					for (int u = 0; u < U; u++) { const double *src = S.off + 9 * (dense_col_start(nb, j + u) + (r - j - u - 1)) + 3 * sub; la[u][0] = src[0]; la[u][1] = src[1]; la[u][2] = src[2]; }
-#pragma unroll
-					for (int u = 0; u < U; u++) { const double *lb = rowk + 9 * (j + u);
-						a0 -= la[u][0] * lb[0] + la[u][1] * lb[1] + la[u][2] * lb[2]; a1 -= la[u][0] * lb[3] + la[u][1] * lb[4] + la[u][2] * lb[5]; a2 -= la[u][0] * lb[6] + la[u][1] * lb[7] + la[u][2] * lb[8]; }
-				}
-				{ double la[U][3]; // the last k % U columns
 #pragma unroll
 					for (int u = 0; u < U; u++) if (j + u < k) { const double *src = S.off + 9 * (dense_col_start(nb, j + u) + (r - j - u - 1)) + 3 * sub; la[u][0] = src[0]; la[u][1] = src[1]; la[u][2] = src[2]; }
 #pragma unroll
-					for (int u = 0; u < U; u++) if (j + u < k) { const double *lb = rowk + 9 * (j + u);
-						a0 -= la[u][0] * lb[0] + la[u][1] * lb[1] + la[u][2] * lb[2]; a1 -= la[u][0] * lb[3] + la[u][1] * lb[4] + la[u][2] * lb[5]; a2 -= la[u][0] * lb[6] + la[u][1] * lb[7] + la[u][2] * lb[8]; }
+					for (int u = 0; u < U; u++) if (j + u < k) { const double *lb = row0 + 9 * (j + u), *lc = row1 + 9 * (j + u);
+						a0 -= la[u][0] * lb[0] + la[u][1] * lb[1] + la[u][2] * lb[2]; a1 -= la[u][0] * lb[3] + la[u][1] * lb[4] + la[u][2] * lb[5]; a2 -= la[u][0] * lb[6] + la[u][1] * lb[7] + la[u][2] * lb[8];
+						if (two) { f0 -= la[u][0] * lc[0] + la[u][1] * lc[1] + la[u][2] * lc[2]; f1 -= la[u][0] * lc[3] + la[u][1] * lc[4] + la[u][2] * lc[5]; f2 -= la[u][0] * lc[6] + la[u][1] * lc[7] + la[u][2] * lc[8]; } }
 				}
 			}
-			if (i == 0) { // rows 0,1,2 of the updated diagonal block sit in lanes 0,1,2
+			if (i == 0) { // rows 0,1,2 of the updated diagonal block of column k sit in lanes 0,1,2
 				const double d00 = readlane_c<0>(a0), d10 = readlane_c<1>(a0), d11 = readlane_c<1>(a1), d20 = readlane_c<2>(a0), d21 = readlane_c<2>(a1), d22 = readlane_c<2>(a2);
 				if (!chol3v(d00, d10, d11, d20, d21, d22, c)) return false;
 				y0 = b0 * c.r0; y1 = (b1 - c.l10 * y0) * c.r1; y2 = (b2 - c.l20 * y0 - c.l21 * y1) * c.r2;
 			}
-			if (act && p > 0) { const double x0 = a0 * c.r0, x1 = (a1 - x0 * c.l10) * c.r1, x2 = (a2 - x0 * c.l20 - x1 * c.l21) * c.r2; A[0] = x0; A[1] = x1; A[2] = x2; }
+			if (act && p > 0) { const double x0 = a0 * c.r0, x1 = (a1 - x0 * c.l10) * c.r1, x2 = (a2 - x0 * c.l20 - x1 * c.l21) * c.r2; A[0] = x0; A[1] = x1; A[2] = x2; a0 = x0; a1 = x1; a2 = x2; }
+			if (two) {
+				if (i == 0) { // L_{k+1,k}: rows in lanes 3,4,5
+					m[0] = readlane_c<3>(a0); m[1] = readlane_c<3>(a1); m[2] = readlane_c<3>(a2); m[3] = readlane_c<4>(a0); m[4] = readlane_c<4>(a1); m[5] = readlane_c<4>(a2);
+					m[6] = readlane_c<5>(a0); m[7] = readlane_c<5>(a1); m[8] = readlane_c<5>(a2);
+					e0 -= m[0] * y0 + m[1] * y1 + m[2] * y2; e1 -= m[3] * y0 + m[4] * y1 + m[5] * y2; e2 -= m[6] * y0 + m[7] * y1 + m[8] * y2;
+				}
+				f0 -= a0 * m[0] + a1 * m[1] + a2 * m[2]; f1 -= a0 * m[3] + a1 * m[4] + a2 * m[5]; f2 -= a0 * m[6] + a1 * m[7] + a2 * m[8];
+				if (i == 0) { // the updated diagonal block of column k+1: lanes 3,4,5
+					const double d00 = readlane_c<3>(f0), d10 = readlane_c<4>(f0), d11 = readlane_c<4>(f1), d20 = readlane_c<5>(f0), d21 = readlane_c<5>(f1), d22 = readlane_c<5>(f2);
+					if (!chol3v(d00, d10, d11, d20, d21, d22, c1)) return false;
+					z0 = e0 * c1.r0; z1 = (e1 - c1.l10 * z0) * c1.r1; z2 = (e2 - c1.l20 * z0 - c1.l21 * z1) * c1.r2;
+				}
+				if (act1 && p > 1) { const double x0 = f0 * c1.r0, x1 = (f1 - x0 * c1.l10) * c1.r1, x2 = (f2 - x0 * c1.l20 - x1 * c1.l21) * c1.r2; E[0] = x0; E[1] = x1; E[2] = x2; }
+			}
 		}
-		if (lane == SRBA_WG - 1) { // L_kk, reciprocal diagonal in the unused upper part, y_k
+		if (lane == SRBA_WG - 1) { // L_kk, reciprocal diagonal in the unused upper part, y_k (and the same for column k+1)
 			double *D = S.diag + 9 * k;
 			D[0] = c.l00; D[3] = c.l10; D[4] = c.l11; D[6] = c.l20; D[7] = c.l21; D[8] = c.l22; D[1] = c.r0; D[2] = c.r1; D[5] = c.r2;
 			yl[3 * k] = y0; yl[3 * k + 1] = y1; yl[3 * k + 2] = y2;
+			if (two) { D += 9; D[0] = c1.l00; D[3] = c1.l10; D[4] = c1.l11; D[6] = c1.l20; D[7] = c1.l21; D[8] = c1.l22; D[1] = c1.r0; D[2] = c1.r1; D[5] = c1.r2;
+				yl[3 * k + 3] = z0; yl[3 * k + 4] = z1; yl[3 * k + 5] = z2; }
 		}
-		__syncthreads(); // the panel stores of this column are read (row k+1) by the next one
+		__syncthreads(); // the panel stores of these columns are read (rows k+2, k+3) by the next step
 	}
 	return true;
 }

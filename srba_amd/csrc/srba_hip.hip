@@ -221,9 +221,9 @@ struct Solver : public Worker<FAM> {
 		STIC(); assemble(S, lambda); STOC(10);
 		// (the dense block layouts are never chosen for the relative-pose families -- srba_hip_upload_problems -- whose kernels therefore carry the sparse solver only: the
 		//  headline kernel sits 22 VGPRs below the two-wavefronts-per-SIMD limit)
-		STIC(); bool ok; if constexpr (W::T::REL || !W::T::SE3) ok = sp_factor_fsub_rows(S); else ok = d.dense_blocks == 2 ? (S.row_lds ? sp_factor_fsub_dense_left(S, S.row_lds, S.row_lds + 9 * S.nb) : sp_factor_fsub_dense<true>(S)) : (S.dense ? sp_factor_fsub_dense<false>(S) : sp_factor_fsub_rows(S)); STOC(11);
+		STIC(); bool ok; if constexpr (W::T::REL || !W::T::SE3) ok = sp_factor_fsub_rows(S); else ok = d.dense_blocks == 2 ? (S.row_lds ? sp_factor_fsub_dense_left(S, S.row_lds, S.row_lds + 18 * S.nb) : sp_factor_fsub_dense<true>(S)) : (S.dense ? sp_factor_fsub_dense<false>(S) : sp_factor_fsub_rows(S)); STOC(11);
 		if (!ok) return false;
-		STIC(); if constexpr (W::T::REL || !W::T::SE3) sp_bsub_rows(S); else { if (d.dense_blocks == 2) { if (S.row_lds) sp_bsub_dense_left(S, S.row_lds + 9 * S.nb); else sp_bsub_dense<true>(S); } else if (S.dense) sp_bsub_dense<false>(S); else sp_bsub_rows(S); }
+		STIC(); if constexpr (W::T::REL || !W::T::SE3) sp_bsub_rows(S); else { if (d.dense_blocks == 2) { if (S.row_lds) sp_bsub_dense_left(S, S.row_lds + 18 * S.nb); else sp_bsub_dense<true>(S); } else if (S.dense) sp_bsub_dense<false>(S); else sp_bsub_rows(S); }
 		double *dl = B.delta + d.o_scal;
 		for (int k = tid; k < d.n_scal; k += SRBA_WG) dl[k] = (k < d.n_sys) ? S.rhs[3 * S.perm[k / 3] + k % 3] : 0.0;
 		__syncthreads(); STOC(12);
@@ -234,7 +234,7 @@ struct Solver : public Worker<FAM> {
 	}
 	__device__ __forceinline__ SparseSys make_sys(double *lds) const {
 		SparseSys S; S.nb = d.nb; S.nnzoff = d.nnzoff; S.dense = (W::T::REL || !W::T::SE3) ? 0 : d.dense_blocks;
-		S.row_lds = (S.dense == 2 && B.dense_left && d.nb <= 168) ? lds + (d.nb + 1) / 2 + 16 : nullptr; // HBM-resident layout, left-looking sweeps: 12 nb doubles of LDS after the permutation
+		S.row_lds = (S.dense == 2 && B.dense_left && d.nb <= 168) ? lds + (d.nb + 1) / 2 + 16 : nullptr; // HBM-resident layout, left-looking sweeps: 21 nb doubles of LDS after the permutation (two rows of the factor | y)
 		S.col_off = B.sp_col_off + d.o_spcol; S.row = B.sp_row + d.o_sprow; S.item = B.sp_tgt + d.o_spitem; S.item_ab = B.sp_ab + d.o_spitem; S.perm = B.sp_perm + d.o_spperm;
 		S.rptr = B.sp_rptr + d.o_spcol; S.rent = B.sp_rcol + d.o_sprow; S.rent_blk = B.sp_rblk + d.o_sprow;
 		double *base = (!W::T::REL && W::T::SE3 && d.dense_blocks == 2) ? B.dense + d.o_dense : lds; // 2: the numbers live in an HBM workspace, LDS holds the permutation only
@@ -932,7 +932,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 			// one-wavefront kernel with the dense block system in an HBM workspace (slow per capsule, but thousands run side by side).
 			const size_t nnz_d = (size_t)d.nb * (d.nb - 1) / 2;
 			symbolic_dense(k, d, P, L, !schur_solver, sym[p]); d.dense_blocks = 2; d.nnzoff = (int)nnz_d; d.n_items = 0; d.aligned = sym[p].aligned ? 1 : 0;
-			tri_n = ((size_t)d.nb + 1) / 2 + 16 + (c->dense_left ? 12 * (size_t)d.nb : 0); bytes = tri_n * 8; /* LDS: the permutation (+ one row of the factor and the right-hand side: left-looking sweeps) */
+			tri_n = ((size_t)d.nb + 1) / 2 + 16 + (c->dense_left ? 21 * (size_t)d.nb : 0); bytes = tri_n * 8; /* LDS: the permutation (+ two rows of the factor and the right-hand side: left-looking sweeps) */
 			cls[p] = 0; while (cls[p] < SRBA_NCLS - 2 && bytes > (size_t)kClsKB[cls[p]] * 1024) cls[p]++;
 			wave_ws = 12 * (long long)d.nb + 9 * (long long)nnz_d;
 		}
