@@ -50,7 +50,7 @@ struct Batch {
 	const int *bp_col, *bp_res, *bp_A, *bp_D, *bp_lm, *colp_off, *bf_col, *bf_res, *bf_pose, *colf_off;
 	const int *hap_i, *hap_j, *hap_term_off, *hap_t1, *hap_t2, *hap_tblk /* block of every U_Ap term */, *hf_i, *hf_j, *hf_term_off, *hf_t1, *hf_t2;
 	const int *hapf_i, *hapf_j, *hapf_term_off, *hapf_t1, *hapf_t2, *hap_diag, *hf_diag;
-	const int *sch_term_off, *sch_b1, *sch_b2, *sch_lm, *sch_yw, *lm_hapf_off, *lm_hapf_idx, *req_idx, *need_idx, *need_rec; // need_rec: per needed pair {pair, 4 path entries (edge<<1|inv, -1 = none)}
+	const int *sch_term_off, *sch_b1, *sch_b2, *sch_lm, *sch_yw, *sch_tblk /* U_Ap block of every Schur term */, *lm_hapf_off, *lm_hapf_idx, *req_idx, *need_idx, *need_rec; // need_rec: per needed pair {pair, 4 path entries (edge<<1|inv, -1 = none)}
 	const unsigned char *pair_needed, *bp_normal;
 	const int *sp_fill; // unified block indices (diag k -> k, off-diagonal i -> nb+i)
 	const int *hap_rec; // per H block, sorted by decreasing term count (longest first: balances the lanes of K6): {block, first term, end term}

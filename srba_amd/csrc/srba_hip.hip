@@ -37,7 +37,7 @@ struct Solver : public Worker<FAM> {
 	__device__ __forceinline__ bool schur_active() const { return prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0; }
 
 	// K7 + K8 (schur.h:180-268). Mutates HAp and minus_grad in place like the reference.
-	__device__ __forceinline__ void schur_reduce(double lambda) { this->fresh();
+	__device__ __forceinline__ void schur_reduce(double lambda, long long *pc = nullptr) { this->fresh(); long long tq = pc ? wall_clock64() : 0;
 		if constexpr (!W::T::REL) {
 			for (int l = tid; l < d.nF; l += SRBA_WG) {
 				double M[L * L], Mi[L * L]; const double *src = B.Hf + (d.o_hf + B.hf_diag[d.o_ulm + l]) * L * L;
@@ -49,25 +49,41 @@ struct Solver : public Worker<FAM> {
 			}
 			for (int k = tid; k < d.n_hap * P * P; k += SRBA_WG) B.HAp[d.o_hap * P * P + k] = B.HAp0[d.o_hap * P * P + k];
 			__syncthreads();
-			for (int b = tid; b < d.n_hap; b += SRBA_WG) {
-				double *H = B.HAp + (d.o_hap + b) * P * P;
-				const int tb = B.sch_term_off[d.o_hapoff + b], te = B.sch_term_off[d.o_hapoff + b + 1];
-				if (tb == te) continue;
-				double Hl[P * P]; ldn<P * P>(Hl, H);
-				// two terms per pass: indices and records of both are requested before either is used (one wavefront per SIMD for these families: the registers are there,
-				// the latency is not hidden by anything else); same summation order as one term at a time
-				for (int t = tb; t < te; t += 2) {
+			if (pc) { if (tid == 0) pc[14] += wall_clock64() - tq; tq = wall_clock64(); }
+			// Balanced over the lanes: the flat term list of the capsule (sorted by U_Ap block) is cut into 64 equal runs, one per lane. A lane keeps the running block in
+			// registers and adds it to HBM when its run moves on to the next block (a block cut by a run boundary receives two or three such additions: atomics), so the
+			// pass is as long as 1/64 of the terms, not as the diagonal block with the longest list in every group of 64 blocks. The terms of the diagonal blocks also
+			// carry the gradient correction g_i -= Y_t g_l (K8), which used to be a third sweep over Y stored in HBM by this one.
+			double *g = B.grad + d.o_scal; const double *gf = g + d.nK * P;
+			{
+				const int T = B.sch_term_off[d.o_hapoff + d.n_hap], per = (T + SRBA_WG - 1) / SRBA_WG, tb = tid * per, te = min(T, tb + per);
+				const int *s_lm = B.sch_lm + d.o_sch, *s_b1 = B.sch_b1 + d.o_sch, *s_b2 = B.sch_b2 + d.o_sch, *s_yw = B.sch_yw + d.o_sch, *s_blk = B.sch_tblk + d.o_sch;
+				int cur = -1; bool curdiag = false; double Hl[P * P], ga[P];
+				auto flush = [&]() {
+					if (cur < 0) return;
+					double *H = B.HAp + (d.o_hap + cur) * P * P;
+#pragma unroll
+					for (int k = 0; k < P * P; k++) unsafeAtomicAdd(H + k, Hl[k]); // global_atomic_add_f64 (the workspace is ordinary device memory)
+					if (curdiag) { double *gi = g + B.hap_i[d.o_hap + cur] * P;
+#pragma unroll
+						for (int r = 0; r < P; r++) unsafeAtomicAdd(gi + r, ga[r]); }
+				};
+				for (int t = tb; t < te; t += 2) { // two terms per pass: indices and records of both are requested before either is used
 					const bool two = t + 1 < te; const int t1 = two ? t + 1 : t;
-					const int l0 = B.sch_lm[d.o_sch + t], l1 = B.sch_lm[d.o_sch + t1];
-					const int a0 = B.sch_b1[d.o_sch + t], c0 = B.sch_b2[d.o_sch + t], a1 = B.sch_b1[d.o_sch + t1], c1 = B.sch_b2[d.o_sch + t1];
-					const int yw0 = B.sch_yw[d.o_sch + t], yw1 = B.sch_yw[d.o_sch + t1];
+					const int l0 = s_lm[t], l1 = s_lm[t1], a0 = s_b1[t], c0 = s_b2[t], a1 = s_b1[t1], c1 = s_b2[t1], yw0 = s_yw[t], yw1 = s_yw[t1], k0 = s_blk[t], k1 = s_blk[t1];
 					const bool ok0 = B.hf_ok[d.o_ulm + l0] != 0, ok1 = two && B.hf_ok[d.o_ulm + l1] != 0;
-					double W1[2][P * L], W2[2][P * L], Hi[2][L * L];
-					ldn<P * L>(W1[0], B.HApf + (d.o_hapf + a0) * P * L); ldn<P * L>(W2[0], B.HApf + (d.o_hapf + c0) * P * L); ldn<L * L>(Hi[0], B.Hfinv + (d.o_ulm + l0) * L * L);
-					ldn<P * L>(W1[1], B.HApf + (d.o_hapf + a1) * P * L); ldn<P * L>(W2[1], B.HApf + (d.o_hapf + c1) * P * L); ldn<L * L>(Hi[1], B.Hfinv + (d.o_ulm + l1) * L * L);
+					double W1[2][P * L], W2[2][P * L], Hi[2][L * L], gl[2][L];
+					ldn<P * L>(W1[0], B.HApf + (d.o_hapf + a0) * P * L); ldn<P * L>(W2[0], B.HApf + (d.o_hapf + c0) * P * L); ldn<L * L>(Hi[0], B.Hfinv + (d.o_ulm + l0) * L * L); ldn<L>(gl[0], gf + l0 * L);
+					ldn<P * L>(W1[1], B.HApf + (d.o_hapf + a1) * P * L); ldn<P * L>(W2[1], B.HApf + (d.o_hapf + c1) * P * L); ldn<L * L>(Hi[1], B.Hfinv + (d.o_ulm + l1) * L * L); ldn<L>(gl[1], gf + l1 * L);
 #pragma unroll
 					for (int u = 0; u < 2; u++) {
 						if (!(u ? ok1 : ok0)) continue;
+						const int kb = u ? k1 : k0;
+						if (kb != cur) { flush(); cur = kb; curdiag = (u ? yw1 : yw0) >= 0;
+#pragma unroll
+							for (int k = 0; k < P * P; k++) Hl[k] = 0;
+#pragma unroll
+							for (int r = 0; r < P; r++) ga[r] = 0; }
 						double Y[P * L];
 #pragma unroll
 						for (int i = 0; i < P; i++)
@@ -83,29 +99,18 @@ struct Solver : public Worker<FAM> {
 #pragma unroll
 								for (int k = 0; k < L; k++) sm += Y[i * L + k] * W2[u][j * L + k];
 								Hl[i * P + j] -= sm; }
-						const int yw = u ? yw1 : yw0;
-						if (yw >= 0) stn<P * L>(B.YW + (d.o_yw + yw) * P * L, Y);
+						if (curdiag) {
+#pragma unroll
+							for (int r = 0; r < P; r++) { double sm = 0;
+#pragma unroll
+								for (int k = 0; k < L; k++) sm += Y[r * L + k] * gl[u][k];
+								ga[r] -= sm; } }
 					}
 				}
-				stn<P * P>(H, Hl);
+				flush();
 			}
 			__syncthreads();
-			double *g = B.grad + d.o_scal; const double *gf = g + d.nK * P;
-			for (int i = tid; i < d.nK; i += SRBA_WG) {
-				const int b = B.hap_diag[d.o_unk + i];
-				double acc[P]; for (int r = 0; r < P; r++) acc[r] = g[i * P + r];
-				for (int t = B.sch_term_off[d.o_hapoff + b]; t < B.sch_term_off[d.o_hapoff + b + 1]; t++) {
-					const int l = B.sch_lm[d.o_sch + t]; if (!B.hf_ok[d.o_ulm + l]) continue;
-					double Y[P * L], gl[L]; ldn<P * L>(Y, B.YW + (d.o_yw + B.sch_yw[d.o_sch + t]) * P * L); ldn<L>(gl, gf + l * L);
-#pragma unroll
-					for (int r = 0; r < P; r++) { double s = 0;
-#pragma unroll
-						for (int k = 0; k < L; k++) s += Y[r * L + k] * gl[k];
-						acc[r] -= s; }
-				}
-				for (int r = 0; r < P; r++) g[i * P + r] = acc[r];
-			}
-			__syncthreads();
+			if (pc) { if (tid == 0) pc[15] += wall_clock64() - tq; }
 		}
 	}
 	// K10 (schur.h:271-311)
@@ -217,7 +222,7 @@ struct Solver : public Worker<FAM> {
 		long long t0 = 0;
 #define STIC() do { if (pc) { __syncthreads(); t0 = wall_clock64(); } } while (0)
 #define STOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - t0; } } while (0)
-		STIC(); if (schur_active()) schur_reduce(lambda); STOC(9);
+		STIC(); if (schur_active()) schur_reduce(lambda, pc); STOC(9);
 		STIC(); assemble(S, lambda); STOC(10);
 		// (the dense block layouts are never chosen for the relative-pose families -- srba_hip_upload_problems -- whose kernels therefore carry the sparse solver only: the
 		//  headline kernel sits 22 VGPRs below the two-wavefronts-per-SIMD limit)
@@ -705,7 +710,7 @@ struct srba_hip_ctx {
 	BigLane lanes[kBigLanes]; int n_lanes_ready = 0; // lane 0 = the context stream and buffers; the others are created on first use
 	struct BigGraphSet { hipGraphExec_t g[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; }; // assemble, Cholesky, back-substitution .. rho, accept + relinearise, accept
 	std::map<int, BigGraphSet> big_graphs; bool big_use_graphs = false; int big_lanes_max = kBigLanes; // captured launch sequences of the big path, per capsule; dropped at upload
-	bool dense_left = true; bool dense_blocks_ok = true; // mid-size nearly-full systems use the dense block layout in LDS
+	bool dense_left = true; int hbm_from_kb = 48; bool dense_blocks_ok = true; // mid-size nearly-full systems use the dense block layout in LDS
 	bool lin_terms = true, lm_terms = true; // term-parallel U_Ap accumulation in LDS: srba_hip_linearize / the fused LM kernel
 	srbadev::FlatMap flat; bool flat_ready = false, use_flat = true; // pair -> capsule map of the flat spanning-tree kernel (srba_flat.hpp), filled on first use after an upload
 	int big_min_sys = 480;   // systems with more scalar unknowns than this skip the block-sparse symbolic analysis and go dense (big path)
@@ -837,6 +842,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	if (!ok || hipMalloc((void **)&c->d_next, sizeof(int) * kMaxJobs) != hipSuccess || hipMalloc((void **)&c->d_part, 8 * 3 * kBigPart) != hipSuccess || hipMalloc((void **)&c->d_scal, 8 * 16) != hipSuccess || hipMalloc((void **)&c->d_iscal, 4 * 8) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	{ const char *e = getenv("SRBA_HIP_BIG_MIN_SYS"); if (e && atoi(e) >= 0) c->big_min_sys = atoi(e); } // tuning / test knob
 	{ const char *e = getenv("SRBA_HIP_DENSE_BLOCKS"); if (e) c->dense_blocks_ok = atoi(e) != 0; }
+	{ const char *e = getenv("SRBA_HIP_HBM_FROM_KB"); if (e) c->hbm_from_kb = atoi(e); } // (default 48; 0 = off) in batches of 1024+ capsules, landmark windows whose LDS image needs this many KB or more keep their system in HBM instead: above 40 KB the LDS, not the registers, limits the wavefronts resident per CU
 	{ const char *e = getenv("SRBA_HIP_DENSE_LEFT"); if (e) c->dense_left = atoi(e) != 0; } // 0: right-looking sweeps on the HBM-resident dense layout (round-2 first version)
 	{ const char *e = getenv("SRBA_HIP_LIN_TERMS"); if (e) c->lin_terms = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_LM_TERMS"); if (e) c->lm_terms = atoi(e) != 0; }
@@ -927,7 +933,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 		static const int kClsKB[SRBA_NCLS - 1] = {6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64, 80, 96, 112, 128, 152};
 		cls[p] = SRBA_NCLS - 1; for (int q = 0; q < SRBA_NCLS - 1 && packable && !surely_big && kClsKB[q] <= c->max_lds_kb; q++) if (bytes <= (size_t)kClsKB[q] * 1024) { cls[p] = q; break; }
 		long long wave_ws = 0; // doubles of HBM workspace of a capsule that keeps one wavefront but holds its (dense block) system in HBM
-		if (cls[p] == SRBA_NCLS - 1 && !surely_big && many_mid && c->dense_blocks_ok && !rel_family) {
+		if ((cls[p] == SRBA_NCLS - 1 ? many_mid : (c->hbm_from_kb > 0 && n >= 1024 && kClsKB[cls[p]] >= c->hbm_from_kb && d.nb <= 168)) && !surely_big && c->dense_blocks_ok && !rel_family) {
 			// Does not fit any LDS class and the batch has many like it: the multi-workgroup path would run them a few at a time from the host. They stay on the
 			// one-wavefront kernel with the dense block system in an HBM workspace (slow per capsule, but thousands run side by side).
 			const size_t nnz_d = (size_t)d.nb * (d.nb - 1) / 2;
@@ -953,7 +959,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	c->tot_edge = t_edge; c->tot_ulm = t_ulm;
 	// ---- input arena layout
 	Arena in; struct { size_t desc, edge0, ulm0, klm, obs_z, pair_path_off, path_edge, obs_pose, obs_lm, obs_valid, bp_col, bp_res, bp_A, bp_D, bp_lm, colp_off, bf_col, bf_res, bf_pose, colf_off,
-		hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hap_tblk, hf_i, hf_j, hf_term_off, hf_t1, hf_t2, hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag, sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw,
+		hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hap_tblk, hf_i, hf_j, hf_term_off, hf_t1, hf_t2, hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag, sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw, sch_tblk,
 		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, pair_needed, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_ab, sp_rptr, sp_rcol, sp_rblk, sp_perm, sp_fill, hap_rec, hap_dst, hapf_dst, hf_dst; } o;
 	o.desc = in.add(sizeof(ProbDesc) * n);
 	o.edge0 = in.add(8 * t_edge * PDX); o.ulm0 = in.add(8 * t_ulm * L); o.klm = in.add(8 * t_klm * L); o.obs_z = in.add(8 * t_obs * O);
@@ -964,7 +970,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	o.hf_i = in.add(4 * t_hf); o.hf_j = in.add(4 * t_hf); o.hf_term_off = in.add(4 * (t_hf + n)); o.hf_t1 = in.add(4 * t_hft); o.hf_t2 = in.add(4 * t_hft);
 	o.hapf_i = in.add(4 * t_hapf); o.hapf_j = in.add(4 * t_hapf); o.hapf_term_off = in.add(4 * (t_hapf + n)); o.hapf_t1 = in.add(4 * t_hapft); o.hapf_t2 = in.add(4 * t_hapft);
 	o.hap_diag = in.add(4 * t_unk); o.hf_diag = in.add(4 * t_ulm);
-	o.sch_term_off = in.add(4 * (t_hap + n)); o.sch_b1 = in.add(4 * t_sch); o.sch_b2 = in.add(4 * t_sch); o.sch_lm = in.add(4 * t_sch); o.sch_yw = in.add(4 * t_sch);
+	o.sch_term_off = in.add(4 * (t_hap + n)); o.sch_b1 = in.add(4 * t_sch); o.sch_b2 = in.add(4 * t_sch); o.sch_lm = in.add(4 * t_sch); o.sch_yw = in.add(4 * t_sch); o.sch_tblk = in.add(4 * t_sch);
 	o.lm_hapf_off = in.add(4 * (t_ulm + n)); o.lm_hapf_idx = in.add(4 * t_hapf); o.req_idx = in.add(4 * t_req); o.need_idx = in.add(4 * t_pair); o.need_rec = in.add(4 * 5 * std::max<long long>(t_pair, 1)); o.pair_needed = in.add(t_pair); o.bp_normal = in.add(t_bp); o.order = in.add(4 * (size_t)n);
 	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_ab = in.add(4 * t_spitem); o.sp_rptr = in.add(4 * t_spcol); o.sp_rcol = in.add(4 * t_sprow); o.sp_rblk = in.add(4 * t_sprow); o.sp_perm = in.add(4 * t_spcol); o.hap_rec = in.add(4 * 3 * std::max<long long>(t_hap, 1)); o.sp_fill = in.add(4 * std::max<long long>(t_spfill, 1));
 	o.hap_dst = in.add(4 * t_hap * (P / 3) * (P / 3)); o.hapf_dst = in.add(4 * t_hapf * (P / 3)); o.hf_dst = in.add(4 * t_hf);
@@ -991,8 +997,8 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 		CPY(o.hap_diag, d.o_unk, k.hap_diag, d.nK, int32_t); CPY(o.hf_diag, d.o_ulm, k.hf_diag, d.nF, int32_t);
 		if (k.n_sch_terms > 0) {
 			CPY(o.sch_term_off, d.o_hapoff, k.sch_term_off, k.n_hap + 1, int32_t); CPY(o.sch_b1, d.o_sch, k.sch_b1, k.n_sch_terms, int32_t); CPY(o.sch_b2, d.o_sch, k.sch_b2, k.n_sch_terms, int32_t); CPY(o.sch_lm, d.o_sch, k.sch_lm, k.n_sch_terms, int32_t);
-			int32_t *yw = (int32_t *)(h + o.sch_yw) + d.o_sch; int cnt = 0;
-			for (int b = 0; b < k.n_hap; b++) for (int t = k.sch_term_off[b]; t < k.sch_term_off[b + 1]; t++) yw[t] = (k.hap_i[b] == k.hap_j[b]) ? cnt++ : -1;
+			int32_t *yw = (int32_t *)(h + o.sch_yw) + d.o_sch, *tbk = (int32_t *)(h + o.sch_tblk) + d.o_sch; int cnt = 0;
+			for (int b = 0; b < k.n_hap; b++) for (int t = k.sch_term_off[b]; t < k.sch_term_off[b + 1]; t++) { yw[t] = (k.hap_i[b] == k.hap_j[b]) ? cnt++ : -1; tbk[t] = b; }
 		} // else: zeros = empty term lists
 		if (k.lm_hapf_off) CPY(o.lm_hapf_off, d.o_lmoff, k.lm_hapf_off, d.nF + 1, int32_t); CPY(o.lm_hapf_idx, d.o_hapf, k.lm_hapf_idx, k.n_hapf, int32_t);
 		{ int32_t *nd = (int32_t *)(h + o.need_idx) + d.o_pair, *nr = (int32_t *)(h + o.need_rec) + 5 * d.o_pair; int cnt = 0, flat = 1;
@@ -1048,7 +1054,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	B.desc = (const ProbDesc *)(di + o.desc); DI(order, int); DI(sp_col_off, int); DI(sp_row, int); DI(sp_item_off, int); DI(sp_tgt, int); DI(sp_ab, int); DI(sp_rptr, int); DI(sp_rcol, int); DI(sp_rblk, int); DI(sp_perm, int); DI(hap_rec, int); DI(sp_fill, int); DI(hap_dst, int); DI(hapf_dst, int); DI(hf_dst, int); DI(edge0, double); DI(ulm0, double); DI(klm, double); DI(obs_z, double);
 	DI(pair_path_off, int); DI(path_edge, int); DI(obs_pose, int); DI(obs_lm, int); DI(obs_valid, int); DI(bp_col, int); DI(bp_res, int); DI(bp_A, int); DI(bp_D, int); DI(bp_lm, int); DI(colp_off, int);
 	DI(bf_col, int); DI(bf_res, int); DI(bf_pose, int); DI(colf_off, int); DI(hap_i, int); DI(hap_j, int); DI(hap_term_off, int); DI(hap_t1, int); DI(hap_t2, int); DI(hap_tblk, int); DI(hf_i, int); DI(hf_j, int); DI(hf_term_off, int); DI(hf_t1, int); DI(hf_t2, int);
-	DI(hapf_i, int); DI(hapf_j, int); DI(hapf_term_off, int); DI(hapf_t1, int); DI(hapf_t2, int); DI(hap_diag, int); DI(hf_diag, int); DI(sch_term_off, int); DI(sch_b1, int); DI(sch_b2, int); DI(sch_lm, int); DI(sch_yw, int);
+	DI(hapf_i, int); DI(hapf_j, int); DI(hapf_term_off, int); DI(hapf_t1, int); DI(hapf_t2, int); DI(hap_diag, int); DI(hf_diag, int); DI(sch_term_off, int); DI(sch_b1, int); DI(sch_b2, int); DI(sch_lm, int); DI(sch_yw, int); DI(sch_tblk, int);
 	DI(lm_hapf_off, int); DI(lm_hapf_idx, int); DI(req_idx, int); DI(need_idx, int); DI(need_rec, int); DI(pair_needed, unsigned char); DI(bp_normal, unsigned char);
 #undef DI
 #define DW(field, T) B.field = (T *)(dw + w.field)

@@ -16,10 +16,10 @@ fb = Fake(); fb.ptr = C.cast(arr, capi.PCAP); fb.n = n0 * copies; fb.params = b.
 ctx = runner.HipContext(b.params); ctx.upload(fb); ctx.lm_run(); r = ctx.lm_run(); kms = ctx.lib.srba_hip_last_kernel_ms(ctx.ctx)
 pc = ctx.debug(10).reshape(fb.n, 16); shp = ctx.debug(11).reshape(fb.n, 4)
 nk = np.array([b.ptr[i % n0].n_unk_edges for i in range(fb.n)]); tr = r["num_trials"]
-names = ["K1all", "jac", "hess", "resid", "grad", "solve", "apply", "K1need", "restore", "schur", "assemble", "factor", "bsub", "feat"]
+names = ["K1all", "jac", "hess", "resid", "grad", "solve", "apply", "K1need", "restore", "schur", "assemble", "factor", "bsub", "feat", "sch_inv", "sch_terms"]
 print("%s: kernel %.1f ms, %d capsules" % (kind, kms, fb.n))
 for lo, hi in ((0, 20), (20, 32), (32, 40), (40, 70)):
     m = (nk >= lo) & (nk < hi)
     if not m.any(): continue
     t = pc[m].sum(axis=0) * 1e-2 / max(tr[m].sum(), 1)   # us per trial
-    print("edges [%d,%d): %d caps, LDS %.0f KB, %.1f trials/cap, per trial us: total %.0f | " % (lo, hi, m.sum(), shp[m, 0].mean() / 1024, tr[m].mean(), t[:9].sum()) + " ".join("%s %.0f" % (names[k], t[k]) for k in (9, 10, 11, 12, 13, 7, 3, 2, 4, 6, 1, 0)) + " | per capsule ms %.1f" % (pc[m][:, :9].sum(axis=1).mean() * 1e-5))
+    print("edges [%d,%d): %d caps, LDS %.0f KB, %.1f trials/cap, per trial us: total %.0f | " % (lo, hi, m.sum(), shp[m, 0].mean() / 1024, tr[m].mean(), t[:9].sum()) + " ".join("%s %.0f" % (names[k], t[k]) for k in (9, 14, 15, 10, 11, 12, 13, 7, 3, 2, 4, 6, 1, 0)) + " | per capsule ms %.1f" % (pc[m][:, :9].sum(axis=1).mean() * 1e-5))
