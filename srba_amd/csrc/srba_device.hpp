@@ -436,11 +436,12 @@ __device__ __forceinline__ double readlane_v(double v, int l) { // l uniform
 // Two columns (k, k+1) per step: every operand L_rj streamed from HBM serves both (the sweep is bound by that stream: hundreds of wavefronts each re-read their
 // 0.1 .. 0.8 MB factor nb/3 times), then column k is finished, applied to column k+1 inside the registers (L_{k+1,k} is handed over by the three lanes that hold it)
 // and column k+1 is finished. rowk: two rows of L (18 nb doubles of LDS), yl: 3 nb doubles.
-__device__ __forceinline__ bool sp_factor_fsub_dense_left(const SparseSys &S, double *rowk, double *yl) {
+typedef __attribute__((address_space(3))) double lds_f64; // explicit LDS operands: ds_read / ds_write whatever the optimiser can or cannot infer
+__device__ __forceinline__ bool sp_factor_fsub_dense_left(const SparseSys &S, lds_f64 *rowk, lds_f64 *yl) {
 	const int lane = threadIdx.x, nb = S.nb;
 	const int grp = (lane * 171) >> 9, sub = lane - 3 * grp; const bool worker = lane < 63;
 	constexpr int U = 8;
-	double *row0 = rowk, *row1 = rowk + 9 * nb;
+	lds_f64 *row0 = rowk, *row1 = rowk + 9 * nb;
 	for (int k = 0; k < nb; k += 2) {
 		const bool two = k + 1 < nb;
 		const int cn = nb - 1 - k, cb = dense_col_start(nb, k), cb1 = dense_col_start(nb, k + 1);
@@ -451,14 +452,14 @@ __device__ __forceinline__ bool sp_factor_fsub_dense_left(const SparseSys &S, do
 			for (int i = 0; i < 4; i++) { const int j = grp + 21 * (4 * h + i); if (worker && j < k) { const double *src = S.off + 9 * (dense_col_start(nb, j) + (k - j - 1)) + 3 * sub;
 				st[i][0] = src[0]; st[i][1] = src[1]; st[i][2] = src[2]; if (two) { st[i][3] = src[9]; st[i][4] = src[10]; st[i][5] = src[11]; } } }
 #pragma unroll
-			for (int i = 0; i < 4; i++) { const int j = grp + 21 * (4 * h + i); if (worker && j < k) { double *d0 = row0 + 9 * j + 3 * sub, *d1 = row1 + 9 * j + 3 * sub;
+			for (int i = 0; i < 4; i++) { const int j = grp + 21 * (4 * h + i); if (worker && j < k) { lds_f64 *d0 = row0 + 9 * j + 3 * sub, *d1 = row1 + 9 * j + 3 * sub;
 				d0[0] = st[i][0]; d0[1] = st[i][1]; d0[2] = st[i][2]; if (two) { d1[0] = st[i][3]; d1[1] = st[i][4]; d1[2] = st[i][5]; } } }
 		}
 		solver_sync();
 		// (2) b - sum_j L_kj y_j for both rows, columns j spread over the lanes
 		double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
 		for (int j = lane; j < k; j += SRBA_WG) {
-			const double *L0 = row0 + 9 * j, *L1 = row1 + 9 * j; const double q0 = yl[3 * j], q1 = yl[3 * j + 1], q2 = yl[3 * j + 2];
+			const lds_f64 *L0 = row0 + 9 * j, *L1 = row1 + 9 * j; const double q0 = yl[3 * j], q1 = yl[3 * j + 1], q2 = yl[3 * j + 2];
 			s0 += L0[0] * q0 + L0[1] * q1 + L0[2] * q2; s1 += L0[3] * q0 + L0[4] * q1 + L0[5] * q2; s2 += L0[6] * q0 + L0[7] * q1 + L0[8] * q2;
 			if (two) { s3 += L1[0] * q0 + L1[1] * q1 + L1[2] * q2; s4 += L1[3] * q0 + L1[4] * q1 + L1[5] * q2; s5 += L1[6] * q0 + L1[7] * q1 + L1[8] * q2; }
 		}
@@ -480,7 +481,7 @@ __device__ __forceinline__ bool sp_factor_fsub_dense_left(const SparseSys &S, do
 #pragma unroll
 					for (int u = 0; u < U; u++) if (j + u < k) { const double *src = S.off + 9 * (dense_col_start(nb, j + u) + (r - j - u - 1)) + 3 * sub; la[u][0] = src[0]; la[u][1] = src[1]; la[u][2] = src[2]; }
 #pragma unroll
-					for (int u = 0; u < U; u++) if (j + u < k) { const double *lb = row0 + 9 * (j + u), *lc = row1 + 9 * (j + u);
+					for (int u = 0; u < U; u++) if (j + u < k) { const lds_f64 *lb = row0 + 9 * (j + u), *lc = row1 + 9 * (j + u);
 						a0 -= la[u][0] * lb[0] + la[u][1] * lb[1] + la[u][2] * lb[2]; a1 -= la[u][0] * lb[3] + la[u][1] * lb[4] + la[u][2] * lb[5]; a2 -= la[u][0] * lb[6] + la[u][1] * lb[7] + la[u][2] * lb[8];
 						if (two) { f0 -= la[u][0] * lc[0] + la[u][1] * lc[1] + la[u][2] * lc[2]; f1 -= la[u][0] * lc[3] + la[u][1] * lc[4] + la[u][2] * lc[5]; f2 -= la[u][0] * lc[6] + la[u][1] * lc[7] + la[u][2] * lc[8]; } }
 				}
@@ -518,14 +519,14 @@ __device__ __forceinline__ bool sp_factor_fsub_dense_left(const SparseSys &S, do
 	return true;
 }
 // backward sweep on the LDS copy of y (in: y, out: x, also written to S.rhs)
-__device__ __forceinline__ void sp_bsub_dense_left(const SparseSys &S, double *yl) {
+__device__ __forceinline__ void sp_bsub_dense_left(const SparseSys &S, lds_f64 *yl) {
 	const int lane = threadIdx.x, nb = S.nb;
 	const int grp = (lane * 171) >> 9, sub = lane - 3 * grp; const bool worker = lane < 63;
 	for (int a = nb - 1; a >= 0; a--) {
 		const double *D = S.diag + 9 * a; const int cb = dense_col_start(nb, a), cn = nb - 1 - a;
 		const double d5 = D[5], d7 = D[7], d2 = D[2], d3 = D[3], d6 = D[6], d1 = D[1];
 		double s = 0; // component `sub` of sum_{r>a} L_ra^t x_r, rows r spread over the lane groups
-		if (worker) for (int p = grp; p < cn; p += 21) { const double *Lx = S.off + 9 * (cb + p) + sub; const double *x = yl + 3 * (a + 1 + p); s += Lx[0] * x[0] + Lx[3] * x[1] + Lx[6] * x[2]; }
+		if (worker) for (int p = grp; p < cn; p += 21) { const double *Lx = S.off + 9 * (cb + p) + sub; const lds_f64 *x = yl + 3 * (a + 1 + p); s += Lx[0] * x[0] + Lx[3] * x[1] + Lx[6] * x[2]; }
 		const double t0 = wave_sum((worker && sub == 0) ? s : 0.0), t1 = wave_sum((worker && sub == 1) ? s : 0.0), t2 = wave_sum((worker && sub == 2) ? s : 0.0);
 		const double r0 = yl[3 * a] - t0, r1 = yl[3 * a + 1] - t1, r2 = yl[3 * a + 2] - t2;
 		const double x2 = r2 * d5, x1 = (r1 - d7 * x2) * d2, x0 = (r0 - d3 * x1 - d6 * x2) * d1;

@@ -29,6 +29,10 @@ using namespace srbadev;
 // =================================================================================================== device: phases that need the dense system
 namespace srbadev {
 
+extern __shared__ double srba_lds[]; // block-sparse system of the capsule (diag | off | rhs) when it fits
+// (LDS operands are addressed from this symbol where it matters: a pointer that went through SparseSys -- whose numbers may live in HBM -- is a generic pointer, and
+//  its loads become flat_load instead of ds_read)
+
 template <int FAM>
 struct Solver : public Worker<FAM> {
 	typedef Worker<FAM> W; using W::B; using W::d; using W::prm; using W::tid;
@@ -226,9 +230,9 @@ struct Solver : public Worker<FAM> {
 		STIC(); assemble(S, lambda); STOC(10);
 		// (the dense block layouts are never chosen for the relative-pose families -- srba_hip_upload_problems -- whose kernels therefore carry the sparse solver only: the
 		//  headline kernel sits 22 VGPRs below the two-wavefronts-per-SIMD limit)
-		STIC(); bool ok; if constexpr (W::T::REL || !W::T::SE3) ok = sp_factor_fsub_rows(S); else ok = d.dense_blocks == 2 ? (S.row_lds ? sp_factor_fsub_dense_left(S, S.row_lds, S.row_lds + 18 * S.nb) : sp_factor_fsub_dense<true>(S)) : (S.dense ? sp_factor_fsub_dense<false>(S) : sp_factor_fsub_rows(S)); STOC(11);
+		STIC(); bool ok; if constexpr (W::T::REL || !W::T::SE3) ok = sp_factor_fsub_rows(S); else ok = d.dense_blocks == 2 ? (S.row_lds ? sp_factor_fsub_dense_left(S, (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16), (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16 + 18 * S.nb)) : sp_factor_fsub_dense<true>(S)) : (S.dense ? sp_factor_fsub_dense<false>(S) : sp_factor_fsub_rows(S)); STOC(11);
 		if (!ok) return false;
-		STIC(); if constexpr (W::T::REL || !W::T::SE3) sp_bsub_rows(S); else { if (d.dense_blocks == 2) { if (S.row_lds) sp_bsub_dense_left(S, S.row_lds + 18 * S.nb); else sp_bsub_dense<true>(S); } else if (S.dense) sp_bsub_dense<false>(S); else sp_bsub_rows(S); }
+		STIC(); if constexpr (W::T::REL || !W::T::SE3) sp_bsub_rows(S); else { if (d.dense_blocks == 2) { if (S.row_lds) sp_bsub_dense_left(S, (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16 + 18 * S.nb)); else sp_bsub_dense<true>(S); } else if (S.dense) sp_bsub_dense<false>(S); else sp_bsub_rows(S); }
 		double *dl = B.delta + d.o_scal;
 		for (int k = tid; k < d.n_scal; k += SRBA_WG) dl[k] = (k < d.n_sys) ? S.rhs[3 * S.perm[k / 3] + k % 3] : 0.0;
 		__syncthreads(); STOC(12);
@@ -329,7 +333,6 @@ struct Solver : public Worker<FAM> {
 	}
 };
 
-extern __shared__ double srba_lds[]; // block-sparse system of the capsule (diag | off | rhs) when it fits
 
 #ifdef SRBA_WAVES_PER_EU
 #define SRBA_OCC __attribute__((amdgpu_waves_per_eu(SRBA_WAVES_PER_EU, SRBA_WAVES_PER_EU)))
@@ -355,7 +358,7 @@ __device__ __forceinline__ void lm_one(const Batch &B, const DevParams &prm, con
 	TIC(); S.phase_jacobians(); TOC(1); // S6,S7
 	// K6: the LDS image of the system is idle while the capsule is linearised (it is assembled per trial): the U_Ap accumulators of the term-parallel form live there
 	const bool hess_terms = B.hess_terms && d.dense_in_lds && d.n_hap * P * P <= 9 * (d.nb + d.nnzoff);
-	auto hessian = [&]() -> int { return hess_terms ? S.phase_hessian_terms(A.diag) + S.phase_hessian_landmark_blocks() : S.phase_hessian(); };
+	auto hessian = [&]() -> int { return hess_terms ? S.phase_hessian_terms(srba_lds) /* == A.diag: the LDS image, idle while the capsule is linearised */ + S.phase_hessian_landmark_blocks() : S.phase_hessian(); };
 	TIC(); const int ninv = (int)block_sum((double)hessian(), red); // S10
 	__syncthreads(); TOC(2);
 	if (tid == 0) {
