@@ -22,6 +22,7 @@
  * sincos instead of four; results agree with the reference formula to rounding.
  */
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include "../../include/srba_hip.h"
 
@@ -572,6 +573,8 @@ struct Worker {
 		constexpr int V = T::SE3 ? 1 : 2; // pairs per lane and pass (all their loads are issued before the first store)
 #endif
 		if (only_needed && d.need_flat) { // in-loop refresh: one flat record per pair -> two dependent memory levels (record, edges) instead of four
+			// (two copies of the loop, LDS source / HBM source: with the choice inside, the compiler merges the last load of both into a flat_load on a selected pointer)
+			auto refresh = [&](auto from_lds) { constexpr bool FROM_LDS = decltype(from_lds)::value;
 			for (int q0 = tid; q0 < d.n_need; q0 += V * SRBA_WG) {
 				int p[V], pe[V][4]; pose_t acc[V];
 #pragma unroll
@@ -590,7 +593,7 @@ struct Worker {
 					for (int v = 0; v < V; v++)
 #pragma unroll
 						for (int u = 0; u < U; u++) if (pe[v][u0 + u] >= 0) {
-							if (edge_lds) { double t[PD]; const double *src = edge_lds + (pe[v][u0 + u] >> 1) * PD;
+							if constexpr (FROM_LDS) { double t[PD]; const double *src = edge_lds + (pe[v][u0 + u] >> 1) * PD;
 #pragma unroll
 								for (int k = 0; k < PD; k++) t[k] = src[k];
 								ed[v][u] = PO::from(t); }
@@ -606,7 +609,8 @@ struct Worker {
 					PO::st(B.pose + (d.o_pair + p[v]) * 2 * PD, acc[v]);
 					PO::st(B.pose + ((d.o_pair + p[v]) * 2 + 1) * PD, inv(acc[v]));
 				}
-			}
+			} };
+			if (edge_lds) refresh(std::true_type()); else refresh(std::false_type());
 			return;
 		}
 		const int cnt = only_needed ? d.n_need : d.n_pairs;
