@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <memory>
 #include <string>
 #include <thread>
 #include <type_traits>
@@ -713,11 +714,11 @@ struct srba_hip_ctx {
 	BigLane lanes[kBigLanes]; int n_lanes_ready = 0; // lane 0 = the context stream and buffers; the others are created on first use
 	struct BigGraphSet { hipGraphExec_t g[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; }; // assemble, Cholesky, back-substitution .. rho, accept + relinearise, accept
 	std::map<int, BigGraphSet> big_graphs; bool big_use_graphs = false; int big_lanes_max = kBigLanes; // captured launch sequences of the big path, per capsule; dropped at upload
-	bool dense_left = true; int hbm_from_kb = 48; bool dense_blocks_ok = true; // mid-size nearly-full systems use the dense block layout in LDS
+	int upload_threads = 1; bool dense_left = true; int hbm_from_kb = 48; bool dense_blocks_ok = true; // mid-size nearly-full systems use the dense block layout in LDS
 	bool lin_terms = true, lm_terms = true; // term-parallel U_Ap accumulation in LDS: srba_hip_linearize / the fused LM kernel
 	srbadev::FlatMap flat; bool flat_ready = false, use_flat = true; // pair -> capsule map of the flat spanning-tree kernel (srba_flat.hpp), filled on first use after an upload
 	int big_min_sys = 480;   // systems with more scalar unknowns than this skip the block-sparse symbolic analysis and go dense (big path)
-	std::vector<char> h_in; size_t h_off_order = 0; // host staging of the input arena (kept: the launch order is read back from it)
+	std::unique_ptr<char[]> h_in; size_t h_in_cap = 0; size_t h_off_order = 0; // host staging of the input arena (kept: the launch order is read back from it)
 	int max_lds_kb = 1 << 20, min_chunk = 384, max_parts_per_queue = 2; int n_queues = 16, sched = 3, n_streams_used = 1, n_cu = 256, waves_per_cu = 8, lds_per_cu = 160 * 1024; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
 	// offsets needed for downloads (bytes inside the wk arena)
 	size_t off_edge = 0, off_ulm = 0, off_pose = 0, off_inf = 0, off_infv = 0, off_res = 0;
@@ -802,6 +803,15 @@ static int check_params(const srba_hip_params *p) {
 	return 0;
 }
 
+// Host side of an upload is per-capsule work on disjoint outputs (validation, symbolic factorisation, packing into the staging arena): spread over threads.
+template <class F> static void parallel_ranges(int n, int threads, F fn) { // fn(begin, end, thread)
+	if (threads <= 1 || n < 512) { fn(0, n, 0); return; }
+	std::atomic<int> next(0); const int chunk = std::max(16, n / (threads * 8));
+	auto work = [&](int t) { for (;;) { const int b = next.fetch_add(chunk); if (b >= n) break; fn(b, std::min(n, b + chunk), t); } };
+	std::vector<std::thread> th; for (int t = 1; t < threads; t++) th.emplace_back(work, t);
+	work(0); for (auto &x : th) x.join();
+}
+
 extern "C" {
 
 int srba_family_dims(int family, int *P, int *L, int *O, int *PD) {
@@ -845,6 +855,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	if (!ok || hipMalloc((void **)&c->d_next, sizeof(int) * kMaxJobs) != hipSuccess || hipMalloc((void **)&c->d_part, 8 * 3 * kBigPart) != hipSuccess || hipMalloc((void **)&c->d_scal, 8 * 16) != hipSuccess || hipMalloc((void **)&c->d_iscal, 4 * 8) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	{ const char *e = getenv("SRBA_HIP_BIG_MIN_SYS"); if (e && atoi(e) >= 0) c->big_min_sys = atoi(e); } // tuning / test knob
 	{ const char *e = getenv("SRBA_HIP_DENSE_BLOCKS"); if (e) c->dense_blocks_ok = atoi(e) != 0; }
+	{ const unsigned hc = std::thread::hardware_concurrency(); c->upload_threads = (int)std::min(32u, std::max(1u, hc)); const char *e = getenv("SRBA_HIP_UPLOAD_THREADS"); if (e) c->upload_threads = std::max(1, atoi(e)); } // host threads of srba_hip_upload_problems
 	{ const char *e = getenv("SRBA_HIP_HBM_FROM_KB"); if (e) c->hbm_from_kb = atoi(e); } // (default 48; 0 = off) in batches of 1024+ capsules, landmark windows whose LDS image needs this many KB or more keep their system in HBM instead: above 40 KB the LDS, not the registers, limits the wavefronts resident per CU
 	{ const char *e = getenv("SRBA_HIP_DENSE_LEFT"); if (e) c->dense_left = atoi(e) != 0; } // 0: right-looking sweeps on the HBM-resident dense layout (round-2 first version)
 	{ const char *e = getenv("SRBA_HIP_LIN_TERMS"); if (e) c->lin_terms = atoi(e) != 0; }
@@ -905,9 +916,19 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	// capsules whose system cannot fit one wavefront's LDS even as bare numbers (more than 63 block rows) but is no deep-window system either: a handful go to the
 	// multi-workgroup path; when the batch holds many, they keep one wavefront each with the system in HBM (see below)
 	bool many_mid = false; { int cnt = 0; for (int p = 0; p < n; p++) { const int nsys = (schur_solver && caps[p].n_unk_lms > 0 && caps[p].n_unk_edges > 0) ? P * caps[p].n_unk_edges : P * caps[p].n_unk_edges + L * caps[p].n_unk_lms; if ((nsys + 2) / 3 > 63 && nsys <= c->big_min_sys) cnt++; } many_mid = cnt > 4 * kBigLanes; }
+	std::vector<const char *> why(n, nullptr);
+	parallel_ranges(n, c->upload_threads, [&](int b, int e, int) { // validation and the block-sparse symbolic factorisation (the expensive part of this pass) of every capsule
+		for (int p = b; p < e; p++) {
+			const srba_problem_capsule &k = caps[p];
+			if ((why[p] = validate_capsule(k)) != nullptr) continue;
+			ProbDesc t; t.nK = k.n_unk_edges; t.nF = k.n_unk_lms; t.n_scal = P * t.nK + L * t.nF; t.n_sys = (schur_solver && t.nF > 0 && t.nK > 0) ? P * t.nK : t.n_scal; t.nb = (t.n_sys + 2) / 3;
+			if (schur_solver && t.nK == 0) continue;
+			if (t.n_sys <= c->big_min_sys) symbolic_factor(k, t, P, L, !schur_solver, sym[p]);
+		}
+	});
 	for (int p = 0; p < n; p++) {
 		const srba_problem_capsule &k = caps[p]; ProbDesc &d = c->desc[p];
-		if (const char *why = validate_capsule(k)) { c->fail(std::string("upload: malformed capsule (") + why + ")"); return -1; }
+		if (why[p]) { c->fail(std::string("upload: malformed capsule (") + why[p] + ")"); return -1; }
 		d.n_edges = k.n_edges; d.nK = k.n_unk_edges; d.nF = k.n_unk_lms; d.n_klm = k.n_known_lms; d.n_pairs = k.n_pairs; d.n_obs = k.n_obs; d.n_valid = k.n_valid; d.n_bp = k.n_bp; d.n_bf = k.n_bf;
 		d.n_hap = k.n_hap; d.n_hf = k.n_hf; d.n_hapf = k.n_hapf; d.n_sch = k.n_sch_terms;
 		d.n_scal = P * d.nK + L * d.nF; d.n_sys = (schur_solver && d.nF > 0 && d.nK > 0) ? P * d.nK : d.n_scal;
@@ -918,7 +939,7 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 		d.o_hapf = t_hapf; d.o_hapfoff = t_hapf + p; d.o_hapft = t_hapft; d.o_sch = t_sch; d.o_lmoff = t_ulm + p; d.o_req = t_req; d.o_scal = t_scal; d.o_yw = t_yw; d.o_dense = t_dense;
 		d.nb = (d.n_sys + 2) / 3;
 		const bool surely_big = d.n_sys > c->big_min_sys; // far beyond what one wavefront's LDS holds: dense system on the multi-workgroup path, no block-sparse symbolic analysis
-		if (!surely_big) symbolic_factor(k, d, P, L, !schur_solver, sym[p]);
+		if (!surely_big) { /* sym[p]: computed above */ }
 		else { Symbolic &y = sym[p]; y.col_off.assign(d.nb + 1, 0); y.item_off.assign(d.nb + 1, 0); y.rptr.assign(d.nb + 1, 0); y.perm.resize(d.nb); for (int q = 0; q < d.nb; q++) y.perm[q] = q;
 			y.hap_dst.assign((size_t)k.n_hap * (P / 3) * (P / 3), 0); y.hapf_dst.assign((size_t)k.n_hapf * (P / 3), 0); y.hf_dst.assign(k.n_hf, 0); y.aligned = true; }
 		d.nnzoff = (int)sym[p].row.size(); d.n_items = (int)sym[p].tgt.size(); d.aligned = sym[p].aligned ? 1 : 0; d.dense_blocks = 0;
@@ -978,11 +999,16 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_ab = in.add(4 * t_spitem); o.sp_rptr = in.add(4 * t_spcol); o.sp_rcol = in.add(4 * t_sprow); o.sp_rblk = in.add(4 * t_sprow); o.sp_perm = in.add(4 * t_spcol); o.hap_rec = in.add(4 * 3 * std::max<long long>(t_hap, 1)); o.sp_fill = in.add(4 * std::max<long long>(t_spfill, 1));
 	o.hap_dst = in.add(4 * t_hap * (P / 3) * (P / 3)); o.hapf_dst = in.add(4 * t_hapf * (P / 3)); o.hf_dst = in.add(4 * t_hf);
 	in.add(0);
-	c->h_in.assign(in.size + 256, 0); char *h = c->h_in.data();
+	if (c->h_in_cap < in.size + 256) { c->h_in.reset(); c->h_in.reset(new char[in.size + 256]); c->h_in_cap = in.size + 256; } // uninitialised: cleared below, in parallel
+	char *h = c->h_in.get();
+	{ const size_t tot = in.size + 256, slab = (size_t)4 << 20; const int nslab = (int)((tot + slab - 1) / slab);
+	  parallel_ranges(std::max(nslab, 512), nslab > 1 ? c->upload_threads : 1, [&](int b, int e, int) { for (int q = b; q < e && q < nslab; q++) std::memset(h + (size_t)q * slab, 0, std::min(slab, tot - (size_t)q * slab)); }); }
 	c->in_off_edge0 = o.edge0; c->in_off_ulm0 = o.ulm0; c->h_off_order = o.order;
 	// ---- pass 2: pack
 #define CPY(dstoff, elem_off, src, count, T) do { if ((count) > 0) std::memcpy(h + (dstoff) + sizeof(T) * (size_t)(elem_off), (src), sizeof(T) * (size_t)(count)); } while (0)
-	for (int p = 0; p < n; p++) {
+	std::vector<int64_t> acc_blocks(std::max(1, c->upload_threads), 0), acc_items(std::max(1, c->upload_threads), 0);
+	parallel_ranges(n, c->upload_threads, [&](int p_begin, int p_end, int thread) {
+	for (int p = p_begin; p < p_end; p++) {
 		const srba_problem_capsule &k = caps[p]; const ProbDesc &d = c->desc[p];
 		if (PDX == PD) { CPY(o.edge0, d.o_edge * PD, k.edge_pose, (size_t)k.n_edges * PD, double); }
 		else { double *e = (double *)(h + o.edge0) + d.o_edge * PDX; for (int q = 0; q < k.n_edges; q++) { const double *s3 = k.edge_pose + 3 * (size_t)q; e[5 * q] = s3[0]; e[5 * q + 1] = s3[1]; e[5 * q + 2] = s3[2]; e[5 * q + 3] = std::cos(s3[2]); e[5 * q + 4] = std::sin(s3[2]); } }
@@ -1019,8 +1045,10 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 		  std::stable_sort(ho.begin(), ho.end(), [&](int x, int y) { return k.hap_term_off[x + 1] - k.hap_term_off[x] > k.hap_term_off[y + 1] - k.hap_term_off[y]; });
 		  int32_t *hr = (int32_t *)(h + o.hap_rec) + 3 * d.o_hap; for (int i = 0; i < k.n_hap; i++) { hr[3 * i] = ho[i]; hr[3 * i + 1] = k.hap_term_off[ho[i]]; hr[3 * i + 2] = k.hap_term_off[ho[i] + 1]; } }
 		CPY(o.hap_dst, d.o_hap * (P / 3) * (P / 3), sym[p].hap_dst.data(), sym[p].hap_dst.size(), int32_t); CPY(o.hapf_dst, d.o_hapf * (P / 3), sym[p].hapf_dst.data(), sym[p].hapf_dst.size(), int32_t); CPY(o.hf_dst, d.o_hf, sym[p].hf_dst.data(), sym[p].hf_dst.size(), int32_t);
-		st.n_chol_blocks += d.nb + d.nnzoff; st.n_chol_items += (int64_t)sym[p].tgt.size();
+		acc_blocks[thread] += d.nb + d.nnzoff; acc_items[thread] += (int64_t)sym[p].tgt.size();
 	}
+	});
+	for (size_t t = 0; t < acc_blocks.size(); t++) { st.n_chol_blocks += acc_blocks[t]; st.n_chol_items += acc_items[t]; }
 #undef CPY
 	std::memcpy(h + o.desc, c->desc.data(), sizeof(ProbDesc) * n);
 	c->cls_of = cls; c->big_ld = big_lds;
@@ -1342,7 +1370,7 @@ int srba_hip_lm_run_async(srba_hip_ctx *c) {
 	}
 	// capsules too large for one wavefront's LDS: the multi-workgroup path, one capsule after the other on the context stream (host-driven LM loop: this part
 	// of the call synchronises with the device once per LM trial), overlapping with the persistent launches of the other classes on their own streams
-	{ const int32_t *ord = (const int32_t *)(c->h_in.data() + c->h_off_order);
+	{ const int32_t *ord = (const int32_t *)(c->h_in.get() + c->h_off_order);
 	  if (big_run_class(c, ord + c->cls_first[SRBA_NCLS - 1], c->cls_count[SRBA_NCLS - 1]) != 0) return -1; }
 	for (int q = 1; q < nq; q++) { HIPCHK(c, hipEventRecord(c->cls_done[q], c->cls_stream[q])); HIPCHK(c, hipStreamWaitEvent(c->stream, c->cls_done[q], 0)); }
 	HIPCHK(c, hipEventRecord(c->ev1, c->stream));
@@ -1435,7 +1463,7 @@ int srba_hip_solve(srba_hip_ctx *c, const double *lambda, int32_t *not_pd_out) {
 	if (lambda) HIPCHK(c, hipMemcpyAsync(c->B.lambda_io, lambda, 8 * (size_t)c->n_prob, hipMemcpyHostToDevice, c->stream)); // else: use the lambda guess left by srba_hip_linearize
 	if (prep_lds(c, false) != 0) return -1;
 	for (int k = 0; k < SRBA_NCLS - 1; k++) if (c->cls_count[k]) { hipStream_t launch_stream = c->stream; SRBA_DISPATCH_LDS(c, k_solve, c->cls_count[k], c->cls_lds[k], c->cls_first[k]); HIPCHK(c, hipGetLastError()); }
-	{ const int32_t *ord = (const int32_t *)(c->h_in.data() + c->h_off_order); // dense multi-workgroup solver for the capsules of the big class
+	{ const int32_t *ord = (const int32_t *)(c->h_in.get() + c->h_off_order); // dense multi-workgroup solver for the capsules of the big class
 	  for (int i = 0; i < c->cls_count[SRBA_NCLS - 1]; i++) { const int p = ord[c->cls_first[SRBA_NCLS - 1] + i]; double lam = 0; HIPCHK(c, hipMemcpyAsync(&lam, c->B.lambda_io + p, 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
 		bool pd = true; if (big_prepare_lanes(c, 1) < 1) return -1; if (big_solve(c, &c->lanes[0], p, lam, &pd) != 0) { c->fail(c->lanes[0].error); return -1; } big_collect_lane_stats(c); const int np = pd ? 0 : 1; HIPCHK(c, hipMemcpyAsync(c->B.notpd + p, &np, 4, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); } }
 	if (not_pd_out) { HIPCHK(c, hipMemcpyAsync(not_pd_out, c->B.notpd, 4 * (size_t)c->n_prob, hipMemcpyDeviceToHost, c->stream)); }
