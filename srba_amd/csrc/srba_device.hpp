@@ -185,36 +185,68 @@ __device__ __forceinline__ double block_sum(double v, double *) { return wave_su
 __device__ __forceinline__ double block_max(double v, double *) { return wave_max(v); }
 
 // ------------------------------------------------------------------------------------------------ full-pivot LU inverse (schur.h:200-206)
+// Every index below is a compile-time constant (the loops are fully unrolled and the pivot position acts through selects): the matrices stay in registers. With
+// run-time row / column indices the arrays lived in scratch memory (48..80 bytes per lane in every landmark-family kernel).
 template <int N> __device__ __forceinline__ bool fullpiv_inverse(const double *A, double *Ai) {
 	double lu[N * N]; int rp[N], cp[N]; double piv[N];
 #pragma unroll
 	for (int i = 0; i < N * N; i++) lu[i] = A[i];
 #pragma unroll
 	for (int i = 0; i < N; i++) { rp[i] = i; cp[i] = i; piv[i] = 0; }
-	double maxpiv = 0;
+	double maxpiv = 0; bool live = true; // live: no exactly-zero remainder met yet (the reference's loop ends there)
 #pragma unroll
 	for (int k = 0; k < N; k++) {
 		int br = k, bc = k; double best = -1;
-		for (int c = k; c < N; c++) for (int r = k; r < N; r++) { const double v = fabs(lu[r * N + c]); if (v > best) { best = v; br = r; bc = c; } }
-		if (best == 0.0) break;
-		if (best > maxpiv) maxpiv = best;
-		if (br != k) { for (int c = 0; c < N; c++) { const double t = lu[k * N + c]; lu[k * N + c] = lu[br * N + c]; lu[br * N + c] = t; } const int t = rp[k]; rp[k] = rp[br]; rp[br] = t; }
-		if (bc != k) { for (int r = 0; r < N; r++) { const double t = lu[r * N + k]; lu[r * N + k] = lu[r * N + bc]; lu[r * N + bc] = t; } const int t = cp[k]; cp[k] = cp[bc]; cp[bc] = t; }
-		piv[k] = lu[k * N + k];
-		for (int r = k + 1; r < N; r++) lu[r * N + k] /= lu[k * N + k];
-		for (int r = k + 1; r < N; r++) for (int c = k + 1; c < N; c++) lu[r * N + c] -= lu[r * N + k] * lu[k * N + c];
+#pragma unroll
+		for (int c = k; c < N; c++)
+#pragma unroll
+			for (int r = k; r < N; r++) { const double v = fabs(lu[r * N + c]); const bool up = v > best; best = up ? v : best; br = up ? r : br; bc = up ? c : bc; }
+		live = live && !(best == 0.0);
+		if (live) {
+			if (best > maxpiv) maxpiv = best;
+#pragma unroll
+			for (int r = k + 1; r < N; r++) { const bool sw = (br == r); // rows k <-> br
+#pragma unroll
+				for (int c = 0; c < N; c++) { const double a = lu[k * N + c], b = lu[r * N + c]; lu[k * N + c] = sw ? b : a; lu[r * N + c] = sw ? a : b; }
+				const int a = rp[k], b = rp[r]; rp[k] = sw ? b : a; rp[r] = sw ? a : b; }
+#pragma unroll
+			for (int c = k + 1; c < N; c++) { const bool sw = (bc == c); // columns k <-> bc
+#pragma unroll
+				for (int r = 0; r < N; r++) { const double a = lu[r * N + k], b = lu[r * N + c]; lu[r * N + k] = sw ? b : a; lu[r * N + c] = sw ? a : b; }
+				const int a = cp[k], b = cp[c]; cp[k] = sw ? b : a; cp[c] = sw ? a : b; }
+			piv[k] = lu[k * N + k];
+#pragma unroll
+			for (int r = k + 1; r < N; r++) lu[r * N + k] /= lu[k * N + k];
+#pragma unroll
+			for (int r = k + 1; r < N; r++)
+#pragma unroll
+				for (int c = k + 1; c < N; c++) lu[r * N + c] -= lu[r * N + k] * lu[k * N + c];
+		}
 	}
 	const double thr = 2.220446049250313e-16 * N * fabs(maxpiv);
 	int rank = 0;
 #pragma unroll
 	for (int k = 0; k < N; k++) if (fabs(piv[k]) > thr) rank++;
 	if (rank != N) return false;
+#pragma unroll
 	for (int col = 0; col < N; col++) {
 		double b[N];
+#pragma unroll
 		for (int r = 0; r < N; r++) b[r] = (rp[r] == col) ? 1.0 : 0.0;
-		for (int r = 0; r < N; r++) for (int c = 0; c < r; c++) b[r] -= lu[r * N + c] * b[c];
-		for (int r = N - 1; r >= 0; r--) { for (int c = r + 1; c < N; c++) b[r] -= lu[r * N + c] * b[c]; b[r] /= lu[r * N + r]; }
-		for (int r = 0; r < N; r++) Ai[cp[r] * N + col] = b[r];
+#pragma unroll
+		for (int r = 0; r < N; r++)
+#pragma unroll
+			for (int c = 0; c < r; c++) b[r] -= lu[r * N + c] * b[c];
+#pragma unroll
+		for (int r = N - 1; r >= 0; r--) {
+#pragma unroll
+			for (int c = r + 1; c < N; c++) b[r] -= lu[r * N + c] * b[c];
+			b[r] /= lu[r * N + r]; }
+#pragma unroll
+		for (int i = 0; i < N; i++) { double v = 0; // Ai[cp[r]][col] = b[r]
+#pragma unroll
+			for (int r = 0; r < N; r++) v = (cp[r] == i) ? b[r] : v;
+			Ai[i * N + col] = v; }
 	}
 	return true;
 }
