@@ -38,3 +38,7 @@ def test_headline_kernel_keeps_two_wavefronts_per_simd(tmp_path):
     assert vgpr <= 256 and scratch == 0, (vgpr, scratch)
     # no kernel may copy the Batch argument block into scratch (a phase left out of line does that: ~1.4 KB)
     assert all(s <= 256 for _, s in lm.values()), lm
+    # private arrays indexed at run time live in scratch (the full-pivot inverse of the landmark blocks did: 48..80 bytes per lane): only the two kernels that
+    # run out of their 512 registers (stereo, range-bearing 3D) may use any, for spills
+    fam = lambda i: res["_ZN7srbadev8k_lm_runILi%dEEEvNS_5BatchENS_9DevParamsEiiPi" % i]
+    assert all(fam(i)[1] == 0 for i in (0, 1, 2, 4, 5, 7, 8)), lm
