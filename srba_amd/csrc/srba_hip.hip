@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <exception>
 #include <memory>
 #include <string>
 #include <thread>
@@ -804,12 +805,17 @@ static int check_params(const srba_hip_params *p) {
 }
 
 // Host side of an upload is per-capsule work on disjoint outputs (validation, symbolic factorisation, packing into the staging arena): spread over threads.
-template <class F> static void parallel_ranges(int n, int threads, F fn) { // fn(begin, end, thread)
+template <class F> static void parallel_ranges(int n, int threads, F fn) { // fn(begin, end, thread); an exception of a worker (std::bad_alloc) is rethrown in the caller
 	if (threads <= 1 || n < 512) { fn(0, n, 0); return; }
-	std::atomic<int> next(0); const int chunk = std::max(16, n / (threads * 8));
-	auto work = [&](int t) { for (;;) { const int b = next.fetch_add(chunk); if (b >= n) break; fn(b, std::min(n, b + chunk), t); } };
-	std::vector<std::thread> th; for (int t = 1; t < threads; t++) th.emplace_back(work, t);
+	std::atomic<int> next(0); const int chunk = std::max(16, n / (threads * 8)); std::exception_ptr err; std::atomic<bool> failed(false);
+	auto work = [&](int t) {
+		try { for (;;) { const int b = next.fetch_add(chunk); if (b >= n || failed.load()) break; fn(b, std::min(n, b + chunk), t); } }
+		catch (...) { if (!failed.exchange(true)) err = std::current_exception(); }
+	};
+	std::vector<std::thread> th;
+	try { for (int t = 1; t < threads; t++) th.emplace_back(work, t); } catch (...) { /* fewer threads than asked for: the ones that started share the work */ }
 	work(0); for (auto &x : th) x.join();
+	if (failed.load() && err) std::rethrow_exception(err);
 }
 
 extern "C" {
@@ -902,7 +908,13 @@ int srba_hip_kernel_ms_history(srba_hip_ctx *c, double *out_ms, int n) {
 	return have;
 }
 
-int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, int n) {
+static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *caps, int n);
+int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, int n) { // no C++ exception crosses the C ABI
+	try { return upload_problems_impl(c, caps, n); }
+	catch (const std::exception &e) { if (c) { c->n_prob = 0; c->fail(std::string("upload: ") + e.what()); } return -1; }
+	catch (...) { if (c) { c->n_prob = 0; c->fail("upload: unknown exception"); } return -1; }
+}
+static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *caps, int n) {
 	if (!c || !caps || n <= 0) { if (c) c->fail("upload: bad arguments"); return -1; }
 	HIPCHK(c, hipSetDevice(c->device));
 	c->big_chol_ms = c->big_chol_flops = 0; c->big_chol_count = 0; c->big_chol_nmax = 0; big_drop_graphs(c);
