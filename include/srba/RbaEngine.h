@@ -335,9 +335,19 @@ public:
 		 *  the ones Jacobian blocks read (optimize_edges.h:664-670): the twin keeps the value of the rejected trial until some later optimisation refreshes it, and meanwhile
 		 *  determine_kf2kf_edges_to_create may seed the next edge from it. true: back up and restore both. */
 		bool restore_spanning_tree_twins;
+		/** (extension, default false = reference behaviour) the Schur solvers reduce minus_grad in place (impl/schur.h:248-265, :294) and nothing recomputes it after a rejected
+		 *  LM trial (impl/optimize_edges.h:658-690): every retry then solves for an already reduced gradient, and a rejection in mid-descent sends the window (and the map) to
+		 *  infinity. true: every solve starts from the gradient compute_minus_gradient produced (SRBA_EXT_SCHUR_KEEPS_GRADIENT of the numeric back-end). */
+		bool schur_keeps_gradient;
+		/** (extension, default false = reference behaviour) initial value of a loop-closure edge between two EXISTING area centres (impl/determine_kf2kf_edges_to_create.h:196-248):
+		 *  the reference stores pose_local_wrt_remote, i.e. the pose of `to` with respect to `from`, unless `to` is the key-frame being inserted -- the inverse of what inv_pose means
+		 *  everywhere else (:60-62, :204-206) -- and takes the observer's pose in its own area as the identity, because num[centre][new key-frame] does not exist before the first
+		 *  numeric update. The edge then starts metres away, is marked has_approx_init_val (so it is not initialised alone, define_new_keyframe.h:75-76) and the landmark families
+		 *  do not recover. true: inv_pose = pose of `from` w.r.t. `to`, and the observer's pose comes from the initial value just given to its own new edge. */
+		bool consistent_loop_closure_init;
 		TSRBAParameters() : max_tree_depth(4), max_optimize_depth(4), optimize_new_edges_alone(true), use_robust_kernel(false), use_robust_kernel_stage1(false), kernel_param(3.), max_iters(20),
 			max_error_per_obs_to_stop(1e-6), max_rho(10.0), max_lambda(1e20), min_error_reduction_ratio_to_relinearize(0.01), numeric_jacobians(false), feedback_user_iteration(NULL),
-			compute_condition_number(false), compute_sparsity_stats(false), max_rmse_show_red_warning(0.5), cov_recovery(crpLandmarksApprox), refresh_all_read_poses(false), restore_spanning_tree_twins(false) {}
+			compute_condition_number(false), compute_sparsity_stats(false), max_rmse_show_red_warning(0.5), cov_recovery(crpLandmarksApprox), refresh_all_read_poses(false), restore_spanning_tree_twins(false), schur_keeps_gradient(false), consistent_loop_closure_init(false) {}
 		/** keys of the reference's configuration files (impl/rba_problem_common.h:60-92); cov_recovery by enumerator name or number */
 		void loadFromConfigFile(const mrpt::utils::CConfigFileBase &source, const std::string &section) override {
 			max_tree_depth = (topo_dist_t)source.read<uint64_t>(section, "max_tree_depth", max_tree_depth); max_optimize_depth = (topo_dist_t)source.read<uint64_t>(section, "max_optimize_depth", max_optimize_depth);
@@ -673,6 +683,7 @@ public:
 		hp.max_iters = (int)parameters.srba.max_iters; hp.use_robust_kernel = parameters.srba.use_robust_kernel ? 1 : 0; hp.kernel_param = parameters.srba.kernel_param;
 		hp.max_error_per_obs_to_stop = parameters.srba.max_error_per_obs_to_stop; hp.max_rho = parameters.srba.max_rho; hp.max_lambda = parameters.srba.max_lambda;
 		hp.min_error_reduction_ratio_to_relinearize = parameters.srba.min_error_reduction_ratio_to_relinearize; hp.cov_recovery = (parameters.srba.cov_recovery == crpLandmarksApprox) ? 1 : 0;
+		hp.extensions = parameters.srba.schur_keeps_gradient ? SRBA_EXT_SCHUR_KEEPS_GRADIENT : 0;
 	}
 
 	/** One observation of key-frame observing_kf_id: stores it, creates the landmark on first sight (fixed position, caller's initial value, or the inverse
@@ -719,6 +730,7 @@ protected:
 			bool ok = touches_new_kf ? align_by_common_landmarks(obs, true, new_kf_id, points_to_new_kf ? ed.from : ed.to, align)
 			                         : align_by_common_landmarks(obs, false, ed.from, ed.to, align);
 			const bool have_lc_hint = info.loopclosure_observer_kf != SRBA_INVALID_KEYFRAMEID && info.loopclosure_base_kf != SRBA_INVALID_KEYFRAMEID;
+			const bool direct = ok; // the alignment relates the two ends of the edge themselves (the reference nevertheless sends it through the observer / base chain below when the edge does not touch the new key-frame)
 			if (!ok && have_lc_hint) ok = align_by_common_landmarks(obs, info.loopclosure_observer_kf == new_kf_id, info.loopclosure_observer_kf, info.loopclosure_base_kf, align);
 			if (!ok) { if (m_verbose_level >= 2) std::cout << "[determine_kf2kf_edges_to_create] Could not provide initial value to relative pose " << ed.from << "<=>" << ed.to << "\n"; continue; }
 			// the alignment relates SENSOR frames: move it to the robot frames
@@ -726,14 +738,23 @@ protected:
 			align = pose_t((S + mrpt::poses::CPose3D(align)) + (-S));
 			info.has_approx_init_val = true;
 			if (touches_new_kf) { ed.inv_pose = points_to_new_kf ? -align : align; continue; }
+			if (direct && parameters.srba.consistent_loop_closure_init) { ed.inv_pose = align; continue; } // (extension) align = pose of `from` w.r.t. `to` = inv_pose
 			// edge between two older key-frames: (base wrt remote end) (+) align (+) (-)(observer wrt local end), the "local" end being the one the observer is known from
 			const pose_t I; const TKeyFrameID ob = info.loopclosure_observer_kf, bs = info.loopclosure_base_kf;
 			const pose_t *ob_to = (ob == ed.to) ? &I : get_kf_relative_pose(ob, ed.to), *bs_to = (bs == ed.to) ? &I : get_kf_relative_pose(bs, ed.to);
 			const pose_t *ob_from = (ob == ed.from) ? &I : get_kf_relative_pose(ob, ed.from), *bs_from = (bs == ed.from) ? &I : get_kf_relative_pose(bs, ed.from);
 			const bool local_is_to = (ob_to || bs_from) || !(ob_from || bs_to);
 			const pose_t *ob_local = local_is_to ? ob_to : ob_from, *bs_remote = local_is_to ? bs_from : bs_to;
+			pose_t ob_guess; // (extension) the observer is the key-frame being inserted: its pose in its own area is the initial value just given to the edge that links it to the local end
+			if (!ob_local && parameters.srba.consistent_loop_closure_init && ob == new_kf_id) {
+				const TKeyFrameID local = local_is_to ? ed.to : ed.from;
+				for (size_t j = 0; j < created.size(); j++) { const k2k_edge_t &e2 = rba_state.k2k_edges[created[j].id]; if (!created[j].has_approx_init_val || j == i) continue;
+					if (e2.from == local && e2.to == ob) { ob_guess = -e2.inv_pose; ob_local = &ob_guess; break; }      // inv_pose = pose of `from` (local) w.r.t. `to` (observer)
+					if (e2.to == local && e2.from == ob) { ob_guess = e2.inv_pose; ob_local = &ob_guess; break; } }
+			}
 			const pose_t local_wrt_remote = ((bs_remote ? *bs_remote : I) + align) + (-(ob_local ? *ob_local : I));
-			ed.inv_pose = points_to_new_kf ? -local_wrt_remote : local_wrt_remote;
+			if (parameters.srba.consistent_loop_closure_init) ed.inv_pose = local_is_to ? -local_wrt_remote : local_wrt_remote; // pose of `from` w.r.t. `to`
+			else ed.inv_pose = points_to_new_kf ? -local_wrt_remote : local_wrt_remote;
 		}
 		T.last_touched_kfs.clear();
 		for (size_t i = 0; i < created.size(); i++) { T.last_touched_kfs.push_back((graph::id32)rba_state.k2k_edges[created[i].id].from); T.last_touched_kfs.push_back((graph::id32)rba_state.k2k_edges[created[i].id].to); }

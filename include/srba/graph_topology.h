@@ -136,6 +136,7 @@ public:
 	 *  names as "new" (impl/spantree_update_symbolic.h:19-211). */
 	void st_attach_edge(id32 n, id32 other, uint32_t max_depth) {
 		if (max_depth < 1) throw std::invalid_argument("srba: max_tree_depth must be >= 1");
+		if (max_depth > 65535) throw std::invalid_argument("srba: max_tree_depth must be <= 65535 (path lengths of the spanning-tree rows are 16-bit)");
 		st.ensure_rows(n_keyframes());
 		// the two node sets are fixed before anything is modified: `near` = nodes closer than max_depth to `other` (+ itself), `mine` = tree of n (+ itself)
 		m_near.clear(); m_mine.clear();

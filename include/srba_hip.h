@@ -92,8 +92,14 @@ typedef struct srba_hip_params {
 	double  max_lambda;                 /* default 1e20 */
 	double  min_error_reduction_ratio_to_relinearize; /* default 0.01 */
 	int32_t cov_recovery;               /* 0 crpNone, 1 crpLandmarksApprox (optimize_edges.h:728-750) */
-	int32_t reserved;
+	int32_t extensions;                 /* bit mask of SRBA_EXT_*; 0 = the reference's behaviour to the letter (default) */
 } srba_hip_params;
+
+/* Opt-in deviations from the reference (all default off). Each one repairs a behaviour of the reference that loses maps on landmark problems:
+ * SRBA_EXT_SCHUR_KEEPS_GRADIENT: the Schur solvers reduce minus_grad IN PLACE (impl/schur.h:248-265, :294) and the LM loop does not recompute it after a rejected
+ *   step (impl/optimize_edges.h:658-690), so every retry of a rejected trial starts from a gradient that has already been reduced once per earlier retry. With this
+ *   bit every solve starts from the gradient that compute_minus_gradient produced (the reduction works on it afresh). */
+enum srba_extensions { SRBA_EXT_SCHUR_KEEPS_GRADIENT = 1 };
 
 /* Fill with the reference's defaults for a family (rba_problem_common.h:35-56). */
 void srba_hip_params_default(srba_hip_params *p, int family);

@@ -704,9 +704,11 @@ struct Problem {
 			for (int k = 0; k < M; k++) g[i * M + k] = acc[k];
 		}
 	}
+	std::vector<double> grad_pristine; // SRBA_EXT_SCHUR_KEEPS_GRADIENT: what compute_minus_gradient produced (the Schur reduction mutates `grad`)
 	void compute_minus_gradient() {
 		grad_cols<P>(nK, c.colp_off, Jp.data(), c.bp_res, grad.data());
 		if (nF) grad_cols<L>(nF, c.colf_off, Jf.data(), c.bf_res, grad.data() + (size_t)P * nK);
+		if (prm.extensions & SRBA_EXT_SCHUR_KEEPS_GRADIENT) grad_pristine = grad;
 	}
 
 	// ---------------- Schur: schur.h ----------------
@@ -808,6 +810,7 @@ struct Problem {
 	}
 	std::vector<double> denseU;
 	bool solve(double lambda) {
+		if (schur_active() && (prm.extensions & SRBA_EXT_SCHUR_KEEPS_GRADIENT)) grad = grad_pristine; // (extension, default off: the reference keeps reducing the already reduced vector, App. B-3)
 		if (schur_active()) schur_build_reduced(lambda); // :286 / :481
 		if (use_schur && dense_chol) { // :489-551 (denseChol_is_uptodate is false at every call, see optimize_edges.h:656,689)
 			const int m = P * nK; denseU.assign((size_t)m * m, 0.0);

@@ -23,7 +23,7 @@ class HipParams(C.Structure):
                 ("cam_left", c_f64 * 4), ("cam_right", c_f64 * 4), ("right_cam_pose", c_f64 * 7),
                 ("max_iters", c_i32), ("use_robust_kernel", c_i32), ("kernel_param", c_f64),
                 ("max_error_per_obs_to_stop", c_f64), ("max_rho", c_f64), ("max_lambda", c_f64),
-                ("min_error_reduction_ratio_to_relinearize", c_f64), ("cov_recovery", c_i32), ("reserved", c_i32)]
+                ("min_error_reduction_ratio_to_relinearize", c_f64), ("cov_recovery", c_i32), ("extensions", c_i32)]
 
 
 class Capsule(C.Structure):

@@ -77,7 +77,7 @@ struct EngineImpl : public EngineBase {
 		s.max_tree_depth = c.max_tree_depth; s.max_optimize_depth = c.max_optimize_depth; s.optimize_new_edges_alone = c.optimize_new_edges_alone != 0;
 		s.use_robust_kernel = c.use_robust_kernel != 0; s.use_robust_kernel_stage1 = c.use_robust_kernel_stage1 != 0; s.kernel_param = c.kernel_param; s.max_iters = c.max_iters;
 		s.max_error_per_obs_to_stop = c.max_error_per_obs_to_stop; s.max_rho = c.max_rho; s.max_lambda = c.max_lambda; s.min_error_reduction_ratio_to_relinearize = c.min_error_reduction_ratio_to_relinearize;
-		s.cov_recovery = c.cov_recovery ? crpLandmarksApprox : crpNone; s.refresh_all_read_poses = (c.refresh_all_read_poses & 1) != 0; s.restore_spanning_tree_twins = (c.refresh_all_read_poses & 2) != 0; // bit 0 / bit 1 of the config field: the two extensions of SURVEY App. B-12
+		s.cov_recovery = c.cov_recovery ? crpLandmarksApprox : crpNone; s.refresh_all_read_poses = (c.refresh_all_read_poses & 1) != 0; s.restore_spanning_tree_twins = (c.refresh_all_read_poses & 2) != 0; s.schur_keeps_gradient = (c.refresh_all_read_poses & 4) != 0; s.consistent_loop_closure_init = (c.refresh_all_read_poses & 8) != 0; // bit 0 / bit 1 of the config field: the two extensions of SURVEY App. B-12
 		ecp_io<ECP>::set(rba.parameters.ecp, c);
 		noise_io<NOISE>::set(rba.parameters.obs_noise, c); spose_io<SPOSE>::set(rba.parameters.sensor_pose, c); sensor_io<OBS>::set(rba.parameters.sensor, c);
 		rba.set_hip_device(c.hip_device);
@@ -270,7 +270,10 @@ int srba_engine_get_rel_pose(void *h, uint64_t query, uint64_t reference, double
 uint64_t srba_engine_alloc_keyframe(void *h) { return static_cast<EngineBase *>(h)->alloc_keyframe(); }
 int64_t srba_engine_create_edge(void *h, uint64_t new_kf, uint64_t from, uint64_t to, const double *pose) { return static_cast<EngineBase *>(h)->create_edge(new_kf, from, to, pose); }
 int64_t srba_engine_export_graphslam(void *h, uint64_t root, uint64_t *node_id, double *node_pose, int64_t node_cap, uint64_t *edge_from_to, double *edge_pose, int64_t edge_cap) {
-	return static_cast<EngineBase *>(h)->export_graphslam(root, node_id, node_pose, node_cap, edge_from_to, edge_pose, edge_cap); }
+	EngineBase *e = static_cast<EngineBase *>(h); // no C++ exception crosses the C ABI (narrow() of an out-of-range id, allocation failures)
+	try { return e->export_graphslam(root, node_id, node_pose, node_cap, edge_from_to, edge_pose, edge_cap); }
+	catch (const std::exception &ex) { e->error = std::string("export_graphslam: ") + ex.what(); return -1; }
+	catch (...) { e->error = "export_graphslam: unknown exception"; return -1; } }
 double srba_engine_profiler_mean(void *h, const char *name) { return static_cast<EngineBase *>(h)->profiler_mean(name); }
 
 int64_t srba_engine_harvest_count(void *h) { return (int64_t)static_cast<EngineBase *>(h)->harvest.data.size(); }

@@ -58,7 +58,7 @@ struct Batch {
 	const int *sp_col_off, *sp_row, *sp_item_off, *sp_tgt, *sp_ab, *sp_rptr, *sp_rcol, *sp_rblk, *sp_perm; // symbolic factorisation of every capsule's system
 	const int *hap_dst, *hapf_dst, *hf_dst; // destination 3x3 block of every aligned sub-block of the Hessian blocks (see symbolic_factor)
 	// state + workspace
-	double *edge, *ulm, *pose, *Jp, *Jf, *resid, *resid2, *HAp, *HAp0, *Hf, *HApf, *grad, *delta, *Hfinv, *YW;
+	double *edge, *ulm, *pose, *Jp, *Jf, *resid, *resid2, *HAp, *HAp0, *Hf, *HApf, *grad, *grad0 /* SRBA_EXT_SCHUR_KEEPS_GRADIENT: the gradient as K5 produced it */, *delta, *Hfinv, *YW;
 	double *old_edge, *old_ulm, *old_pose, *dense, *ulm_inf;
 	int *valid, *first_fail, *hf_ok;
 	unsigned char *bp_ok, *bf_ok; // per Jacobian block: its observation row is valid (set by phase_jacobians, read by phase_hessian)
@@ -69,7 +69,7 @@ struct Batch {
 };
 
 struct DevParams {
-	int solver, noise, sensor_pose, max_iters, use_robust_kernel, cov_recovery;
+	int solver, noise, sensor_pose, max_iters, use_robust_kernel, cov_recovery, ext /* srba_hip_params::extensions */;
 	double inv_sigma, lambda[36], kernel_param, max_err, max_rho, max_lambda, min_relin;
 	double SPt[3], SPR[9];      // sensor pose on the robot
 	double camL[4], camR[4];    // fx fy cx cy

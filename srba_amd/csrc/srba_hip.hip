@@ -228,6 +228,8 @@ struct Solver : public Worker<FAM> {
 		long long t0 = 0;
 #define STIC() do { if (pc) { __syncthreads(); t0 = wall_clock64(); } } while (0)
 #define STOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - t0; } } while (0)
+		if (schur_active() && (prm.ext & SRBA_EXT_SCHUR_KEEPS_GRADIENT)) { // (extension, default off) every solve starts from the gradient K5 produced: same lane -> same elements as keep_gradient()
+			double *g = B.grad + d.o_scal; const double *g0 = B.grad0 + d.o_scal; for (int k = tid; k < d.n_scal; k += SRBA_WG) g[k] = g0[k]; __syncthreads(); }
 		STIC(); if (schur_active()) schur_reduce(lambda, pc); STOC(9);
 		STIC(); assemble(S, lambda); STOC(10);
 		// (the dense block layouts are never chosen for the relative-pose families -- srba_hip_upload_problems -- whose kernels therefore carry the sparse solver only: the
@@ -242,6 +244,9 @@ struct Solver : public Worker<FAM> {
 		return true;
 #undef STIC
 #undef STOC
+	}
+	__device__ __forceinline__ void keep_gradient() { // call after phase_gradient + barrier
+		if (schur_active() && (prm.ext & SRBA_EXT_SCHUR_KEEPS_GRADIENT)) { const double *g = B.grad + d.o_scal; double *g0 = B.grad0 + d.o_scal; for (int k = tid; k < d.n_scal; k += SRBA_WG) g0[k] = g[k]; }
 	}
 	__device__ __forceinline__ SparseSys make_sys(double *lds) const {
 		SparseSys S; S.nb = d.nb; S.nnzoff = d.nnzoff; S.dense = (W::T::REL || !W::T::SE3) ? 0 : d.dense_blocks;
@@ -375,7 +380,7 @@ __device__ __forceinline__ void lm_one(const Batch &B, const DevParams &prm, con
 	if (tid == 0) { out->lambda_init = lambda; out->total_sqr_error_init = total_err; }
 	__syncthreads();
 	TIC(); S.phase_gradient(resid); // S14
-	__syncthreads(); TOC(4);
+	__syncthreads(); S.keep_gradient(); TOC(4);
 	int iter = 0, trials = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0; bool stop = false;
 	for (iter = 0; iter < prm.max_iters && !stop; iter++) {
 		double rho = 0;
@@ -408,7 +413,7 @@ __device__ __forceinline__ void lm_one(const Batch &B, const DevParams &prm, con
 				__syncthreads();
 				if (relin) { n_relin++; TIC(); S.phase_jacobians(); TOC(1); TIC(); hessian(); __syncthreads(); TOC(2); }
 				TIC(); S.phase_gradient(resid);
-				__syncthreads(); TOC(4);
+				__syncthreads(); S.keep_gradient(); TOC(4);
 				double ninf = 0; { const double *g = B.grad + d.o_scal; for (int k = tid; k < n; k += SRBA_WG) ninf = fmax(ninf, fabs(g[k])); }
 				ninf = block_max(ninf, red);
 				if (ninf <= 1e-15) { stop = true; stopmask |= 1 << SRBA_STOP_GRADIENT; }
@@ -463,7 +468,7 @@ template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_linearize(const 
 	// U_Ap blocks term-parallel with LDS accumulators when they fit the launch's LDS (lds_doubles; the first 16 doubles are the reduction scratch), else one lane per block
 	int nv = (d.n_hap * P * P <= lds_doubles - 16) ? S.phase_hessian_terms(srba_lds + 16) + S.phase_hessian_landmark_blocks() : S.phase_hessian();
 	const int ninv = (int)block_sum((double)nv, srba_lds); __syncthreads();
-	S.phase_gradient(B.resid); __syncthreads();
+	S.phase_gradient(B.resid); __syncthreads(); S.keep_gradient();
 	const double l0 = S.lambda_guess(srba_lds);
 	if (threadIdx.x == 0) { B.lambda_io[blockIdx.x] = l0; B.results[blockIdx.x].num_invalid_jacobs = ninv; }
 }
@@ -659,11 +664,13 @@ static const char *validate_capsule(const srba_problem_capsule &k) {
 	if (k.n_unk_edges > k.n_edges || k.n_unk_edges + k.n_unk_lms == 0) return "no unknowns / more unknown edges than edges";
 	const int np2 = 2 * k.n_pairs;
 	auto lmref = [&](int v) { return v >= 0 ? v < k.n_unk_lms : (-1 - v) < k.n_known_lms; };
+	// every array is checked for presence before any loop below reads it (validation runs on upload worker threads: a crash here would take the process down off the calling thread)
+	if (!k.edge_pose || (k.n_unk_lms && !k.ulm_pos) || (k.n_known_lms && !k.klm_pos) || (k.n_obs && (!k.obs_pose || !k.obs_lm || !k.obs_valid || !k.obs_z)) || (k.n_path && !k.path_edge)) return "null data array";
+	if (k.n_path > 0 && k.n_pairs == 0) return "path entries without pairs";
 	if (k.n_pairs && (!k.pair_path_off || !k.pair_needed || !k.pose_required || k.pair_path_off[0] != 0 || k.pair_path_off[k.n_pairs] != k.n_path)) return "pair_path_off";
 	for (int i = 0; i < k.n_pairs; i++) if (k.pair_path_off[i + 1] < k.pair_path_off[i]) return "pair_path_off not monotone";
 	for (int i = 0; i < k.n_path; i++) if (k.path_edge[i] < 0 || (k.path_edge[i] >> 1) >= k.n_edges) return "path_edge";
 	for (int i = 0; i < k.n_obs; i++) if (!in(k.obs_pose[i], -1, np2) || !lmref(k.obs_lm[i]) || !in(k.obs_valid[i], 0, std::max(k.n_valid, 1))) return "observation table";
-	if (!k.edge_pose || (k.n_unk_lms && !k.ulm_pos) || (k.n_known_lms && !k.klm_pos) || (k.n_obs && (!k.obs_pose || !k.obs_lm || !k.obs_valid || !k.obs_z)) || (k.n_path && !k.path_edge)) return "null data array";
 	if (k.n_bp && (!k.bp_col || !k.bp_res || !k.bp_A || !k.bp_D || !k.bp_lm || !k.bp_normal)) return "null dh_dAp table";
 	if (k.n_bf && (!k.bf_col || !k.bf_res || !k.bf_pose)) return "null dh_df table";
 	if (k.n_unk_edges && (!k.colp_off || k.colp_off[0] != 0 || k.colp_off[k.n_unk_edges] != k.n_bp)) return "colp_off";
@@ -781,7 +788,7 @@ static void plan_launches(srba_hip_ctx *c, const int32_t *ord) {
 
 static void make_dev_params(const srba_hip_params &p, DevParams &dp, const FamDims &dm) {
 	std::memset(&dp, 0, sizeof(dp));
-	dp.solver = p.solver; dp.noise = p.noise; dp.sensor_pose = p.sensor_pose; dp.max_iters = p.max_iters; dp.use_robust_kernel = p.use_robust_kernel; dp.cov_recovery = p.cov_recovery;
+	dp.solver = p.solver; dp.noise = p.noise; dp.sensor_pose = p.sensor_pose; dp.max_iters = p.max_iters; dp.use_robust_kernel = p.use_robust_kernel; dp.cov_recovery = p.cov_recovery; dp.ext = p.extensions;
 	dp.inv_sigma = 1.0 / p.std_noise_observations;
 	for (int i = 0; i < dm.O * dm.O; i++) dp.lambda[i] = p.lambda[i];
 	dp.kernel_param = p.kernel_param; dp.max_err = p.max_error_per_obs_to_stop; dp.max_rho = p.max_rho; dp.max_lambda = p.max_lambda; dp.min_relin = p.min_error_reduction_ratio_to_relinearize;
@@ -876,7 +883,7 @@ int srba_hip_set_params(srba_hip_ctx *c, const srba_hip_params *params) {
 	if (!c) return -1;
 	if (check_params(params) != 0) { c->fail(g_last_error); return -1; }
 	if (params->family != c->params.family) { c->fail("srba_hip_set_params: the family of a context cannot change"); return -1; }
-	if (c->n_prob && (params->solver != c->params.solver || params->noise != c->params.noise)) c->n_prob = 0; // the uploaded batch was laid out for the old solver / noise policy: upload again
+	if (c->n_prob && (params->solver != c->params.solver || params->noise != c->params.noise || params->extensions != c->params.extensions)) c->n_prob = 0; // the uploaded batch was laid out for the old solver / noise policy: upload again
 	big_drop_graphs(c); // the captured launches carry the old parameters by value
 	c->params = *params; make_dev_params(*params, c->dp, c->dm); return 0;
 }
@@ -1078,13 +1085,14 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		plan_launches(c, ord);
 	}
 	// ---- work arena layout
-	Arena wk; struct { size_t edge, ulm, pose, Jp, Jf, resid, resid2, HAp, HAp0, Hf, HApf, grad, delta, Hfinv, YW, old_edge, old_ulm, old_pose, dense, ulm_inf, valid, first_fail, hf_ok, bp_ok, bf_ok, ulm_inf_valid, results, lambda_io, chi2, notpd, phase_cycles, m_pair; } w;
+	Arena wk; struct { size_t edge, ulm, pose, Jp, Jf, resid, resid2, HAp, HAp0, Hf, HApf, grad, delta, Hfinv, YW, old_edge, old_ulm, old_pose, dense, ulm_inf, valid, first_fail, hf_ok, bp_ok, bf_ok, ulm_inf_valid, results, lambda_io, chi2, notpd, phase_cycles, m_pair, grad0; } w;
 	w.edge = wk.add(8 * t_edge * PDX); w.ulm = wk.add(8 * t_ulm * L); w.pose = wk.add(8 * 2 * t_pair * PDX); w.Jp = wk.add(8 * t_bp * O * P); w.Jf = wk.add(8 * t_bf * O * L);
 	w.resid = wk.add(8 * t_obs * O); w.resid2 = wk.add(8 * t_obs * O); w.HAp = wk.add(8 * t_hap * P * P); w.HAp0 = wk.add(8 * t_hap * P * P); w.Hf = wk.add(8 * t_hf * L * L); w.HApf = wk.add(8 * t_hapf * P * L);
 	w.grad = wk.add(8 * t_scal); w.delta = wk.add(8 * t_scal); w.Hfinv = wk.add(8 * t_ulm * L * L); w.YW = wk.add(8 * t_yw * P * L); w.old_edge = wk.add(8 * t_unk * PDX); w.old_ulm = wk.add(8 * t_ulm * L); w.old_pose = wk.add(8 * t_req * PDX);
 	w.dense = wk.add(8 * t_dense); w.ulm_inf = wk.add(8 * t_ulm * L * L); w.valid = wk.add(4 * t_valid); w.first_fail = wk.add(4 * t_valid); w.hf_ok = wk.add(4 * t_ulm); w.bp_ok = wk.add(t_bp); w.bf_ok = wk.add(t_bf); w.ulm_inf_valid = wk.add(t_ulm);
 	w.results = wk.add(sizeof(srba_lm_result) * n); w.lambda_io = wk.add(8 * n); w.chi2 = wk.add(8 * n); w.notpd = wk.add(4 * n); w.phase_cycles = wk.add(8 * 16 * (size_t)n);
 	w.m_pair = wk.add(4 * t_pair);
+	w.grad0 = wk.add((c->params.extensions & SRBA_EXT_SCHUR_KEEPS_GRADIENT) ? 8 * t_scal : 0);
 	wk.add(0);
 	if (in.size + 256 > c->cap_in) { if (c->d_in) hipFree(c->d_in); c->d_in = nullptr; c->cap_in = 0; const size_t want = (in.size + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_in, want)); c->cap_in = want; }
 	if (wk.size + 256 > c->cap_wk) { if (c->d_wk) hipFree(c->d_wk); c->d_wk = nullptr; c->cap_wk = 0; const size_t want = (wk.size + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_wk, want)); c->cap_wk = want; }
@@ -1101,7 +1109,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	DI(lm_hapf_off, int); DI(lm_hapf_idx, int); DI(req_idx, int); DI(need_idx, int); DI(need_rec, int); DI(pair_needed, unsigned char); DI(bp_normal, unsigned char);
 #undef DI
 #define DW(field, T) B.field = (T *)(dw + w.field)
-	DW(edge, double); DW(ulm, double); DW(pose, double); DW(Jp, double); DW(Jf, double); DW(resid, double); DW(resid2, double); DW(HAp, double); DW(HAp0, double); DW(Hf, double); DW(HApf, double); DW(grad, double); DW(delta, double);
+	DW(edge, double); DW(ulm, double); DW(pose, double); DW(Jp, double); DW(Jf, double); DW(resid, double); DW(resid2, double); DW(HAp, double); DW(HAp0, double); DW(Hf, double); DW(HApf, double); DW(grad, double); DW(grad0, double); DW(delta, double);
 	DW(Hfinv, double); DW(YW, double); DW(old_edge, double); DW(old_ulm, double); DW(old_pose, double); DW(dense, double); DW(ulm_inf, double); DW(valid, int); DW(first_fail, int); DW(hf_ok, int); DW(bp_ok, unsigned char); DW(bf_ok, unsigned char); DW(ulm_inf_valid, unsigned char);
 	DW(results, srba_lm_result); DW(lambda_io, double); DW(chi2, double); DW(notpd, int);
 	c->flat.pair = (int *)(dw + w.m_pair); c->flat.n_pair = t_pair; c->flat_ready = false;
@@ -1233,6 +1241,8 @@ static void big_account_cholesky(srba_hip_ctx *c, BigLane *ln, int p) { // after
 }
 static int big_solve(srba_hip_ctx *c, BigLane *ln, int p, double lambda, bool *pos_def) { // the stepwise entry point (srba_hip_solve)
 	hipLaunchKernelGGL(srbadev::kb_set_scalar, dim3(1), dim3(1), 0, ln->stream, ln->d_scal + BS_LAMBDA, lambda);
+	{ const ProbDesc &d = c->desc[p]; // (extension) start from the gradient as srba_hip_linearize left it
+	  if ((c->params.extensions & SRBA_EXT_SCHUR_KEEPS_GRADIENT) && c->params.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0) LNCHK(ln, hipMemcpyAsync(c->B.grad + d.o_scal, c->B.grad0 + d.o_scal, sizeof(double) * (size_t)d.n_scal, hipMemcpyDeviceToDevice, ln->stream)); }
 	big_enqueue_assemble(c, ln, p);
 	if (big_timed_cholesky(c, ln, p) != 0) return -1;
 	big_enqueue_backsub(c, ln, p);
@@ -1251,7 +1261,8 @@ static int big_lm_run(srba_hip_ctx *c, BigLane *ln, int p) {
 	double *resid = c->B.resid, *resid2 = c->B.resid2; const int *flag = ln->d_iscal + 1; const double *lam = ln->d_scal + BS_LAMBDA;
 	auto enqueue_residuals = [&](double *dst, const int *skip) { const int nb = big_grid(d.n_obs, 256); BIGK(kb_residuals, d.n_obs, 256, dst, ln->d_part, skip); big_reduce(c, ln, 0, nb, BS_CHI2, 0); };
 	auto enqueue_linearize = [&]() { BIGK(kb_jac_init, d.n_valid, 256); BIGK(kb_jac, d.n_bp + d.n_bf, 128); BIGK(kb_jac_post, d.n_bp + d.n_bf, 256); BIGK(kb_hessian, d.n_hap + d.n_hf + d.n_hapf, 128, ln->d_iscal); BIGKG(kb_hessian_heavy, d.n_hap, 256, ln->d_iscal); };
-	auto enqueue_gradient = [&]() { BIGKG(kb_gradient, d.nK + (d.nF + 255) / 256, 256, resid); };
+	const bool keep_g = schur && (prm.extensions & SRBA_EXT_SCHUR_KEEPS_GRADIENT); // (extension) the Schur kernels reduce B.grad in place: keep what K5 produced and start every solve from it
+	auto enqueue_gradient = [&]() { BIGKG(kb_gradient, d.nK + (d.nF + 255) / 256, 256, resid); if (keep_g) hipMemcpyAsync(c->B.grad0 + d.o_scal, c->B.grad + d.o_scal, sizeof(double) * (size_t)d.n_scal, hipMemcpyDeviceToDevice, ln->stream); };
 	auto enqueue_dot = [&](int which, int slot, int is_max, const int *skip) { const int nb = big_grid(d.n_scal, 256); BIGK(kb_dot, d.n_scal, 256, lam, ln->d_part + kBigPart, ln->d_part + 2 * kBigPart, skip); big_reduce(c, ln, which, nb, slot, is_max); };
 	double hs[4] = {0, 0, 0, 0}; int hflag = 0;
 	auto fetch = [&]() -> int { LNCHK(ln, hipMemcpyAsync(hs, ln->d_scal, 32, hipMemcpyDeviceToHost, ln->stream)); LNCHK(ln, hipMemcpyAsync(&hflag, flag, 4, hipMemcpyDeviceToHost, ln->stream)); LNCHK(ln, hipStreamSynchronize(ln->stream)); return 0; };
@@ -1277,7 +1288,7 @@ static int big_lm_run(srba_hip_ctx *c, BigLane *ln, int p) {
 			const int tr = trials++; if (tr < SRBA_TRACE_LEN) out.trace_lambda[tr] = lambda;
 			// one trial = solve, apply, numeric spanning tree of the poses in use, residuals, rho denominator; kernels after the factorisation return at once if it failed
 			hipLaunchKernelGGL(srbadev::kb_set_scalar, dim3(1), dim3(1), 0, ln->stream, ln->d_scal + BS_LAMBDA, lambda);
-			if (big_replay(c, ln, p, 0, [&]() { big_enqueue_assemble(c, ln, p); }) != 0) return -1;
+			if (big_replay(c, ln, p, 0, [&]() { if (keep_g) hipMemcpyAsync(c->B.grad + d.o_scal, c->B.grad0 + d.o_scal, sizeof(double) * (size_t)d.n_scal, hipMemcpyDeviceToDevice, ln->stream); big_enqueue_assemble(c, ln, p); }) != 0) return -1;
 			if (big_timed_cholesky(c, ln, p) != 0) return -1;
 			if (big_replay(c, ln, p, 2, [&]() {
 				big_enqueue_backsub(c, ln, p);
@@ -1341,11 +1352,16 @@ static int big_run_class(srba_hip_ctx *c, const int32_t *caps, int count) {
 	if (n == 1) { for (int i = 0; i < count && rc == 0; i++) rc = big_lm_run(c, &c->lanes[0], caps[i]); }
 	else {
 		// the lanes start after everything already queued on the context stream (uploads, state resets)
-		hipEvent_t ready = nullptr; HIPCHK(c, hipEventCreateWithFlags(&ready, hipEventDisableTiming)); HIPCHK(c, hipEventRecord(ready, c->stream));
-		for (int i = 1; i < n; i++) HIPCHK(c, hipStreamWaitEvent(c->lanes[i].stream, ready, 0));
+		hipEvent_t ready = nullptr; HIPCHK(c, hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+		hipError_t e = hipEventRecord(ready, c->stream);
+		for (int i = 1; i < n && e == hipSuccess; i++) e = hipStreamWaitEvent(c->lanes[i].stream, ready, 0);
+		if (e != hipSuccess) { hipEventDestroy(ready); c->fail(std::string("large-capsule path: ") + hipGetErrorString(e)); return -1; }
 		std::atomic<int> next(0); std::vector<int> rcs(n, 0); std::vector<std::thread> th;
-		auto work = [&](int li) { hipSetDevice(c->device); BigLane *ln = &c->lanes[li]; for (;;) { const int i = next.fetch_add(1); if (i >= count || rcs[li] != 0) break; rcs[li] = big_lm_run(c, ln, caps[i]); } hipStreamSynchronize(ln->stream); };
-		for (int i = 1; i < n; i++) th.emplace_back(work, i);
+		auto work = [&](int li) { // no exception leaves a worker (std::terminate otherwise) nor this function (it is reached from an extern "C" entry)
+			try { hipSetDevice(c->device); BigLane *ln = &c->lanes[li]; for (;;) { const int i = next.fetch_add(1); if (i >= count || rcs[li] != 0) break; rcs[li] = big_lm_run(c, ln, caps[i]); } hipStreamSynchronize(ln->stream); }
+			catch (const std::exception &ex) { rcs[li] = -1; c->lanes[li].error = std::string("large-capsule path: ") + ex.what(); }
+			catch (...) { rcs[li] = -1; c->lanes[li].error = "large-capsule path: unknown exception"; } };
+		try { for (int i = 1; i < n; i++) th.emplace_back(work, i); } catch (...) { /* fewer threads than lanes: the ones that started (and this thread) share the capsules */ }
 		work(0);
 		for (auto &t : th) t.join();
 		hipEventDestroy(ready);
@@ -1362,7 +1378,13 @@ extern "C" {
 
 int srba_hip_sync(srba_hip_ctx *c) { if (!c) return -1; HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
 
-int srba_hip_lm_run_async(srba_hip_ctx *c) {
+static int lm_run_async_impl(srba_hip_ctx *c);
+int srba_hip_lm_run_async(srba_hip_ctx *c) { // no C++ exception crosses the C ABI
+	try { return lm_run_async_impl(c); }
+	catch (const std::exception &e) { if (c) c->fail(std::string("lm_run: ") + e.what()); return -1; }
+	catch (...) { if (c) c->fail("lm_run: unknown exception"); return -1; }
+}
+static int lm_run_async_impl(srba_hip_ctx *c) {
 	if (!c || !c->n_prob) { if (c) c->fail("lm_run: no batch uploaded"); return -1; }
 	HIPCHK(c, hipSetDevice(c->device));
 	if (prep_lds(c, true) != 0) return -1;
@@ -1383,9 +1405,11 @@ int srba_hip_lm_run_async(srba_hip_ctx *c) {
 	// capsules too large for one wavefront's LDS: the multi-workgroup path, one capsule after the other on the context stream (host-driven LM loop: this part
 	// of the call synchronises with the device once per LM trial), overlapping with the persistent launches of the other classes on their own streams
 	{ const int32_t *ord = (const int32_t *)(c->h_in.get() + c->h_off_order);
-	  if (big_run_class(c, ord + c->cls_first[SRBA_NCLS - 1], c->cls_count[SRBA_NCLS - 1]) != 0) return -1; }
-	for (int q = 1; q < nq; q++) { HIPCHK(c, hipEventRecord(c->cls_done[q], c->cls_stream[q])); HIPCHK(c, hipStreamWaitEvent(c->stream, c->cls_done[q], 0)); }
-	HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+	  const int big_rc = big_run_class(c, ord + c->cls_first[SRBA_NCLS - 1], c->cls_count[SRBA_NCLS - 1]);
+	  // join the class streams and close the timing pair whatever the large-capsule path returned: the launches above are in flight either way
+	  for (int q = 1; q < nq; q++) { HIPCHK(c, hipEventRecord(c->cls_done[q], c->cls_stream[q])); HIPCHK(c, hipStreamWaitEvent(c->stream, c->cls_done[q], 0)); }
+	  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+	  if (big_rc != 0) { hipStreamSynchronize(c->stream); return -1; } }
 	return 0;
 }
 
@@ -1485,7 +1509,9 @@ int srba_hip_hessian_from_jacobians(srba_hip_ctx *c) { if (!c || !c->n_prob) ret
 int srba_hip_debug_write(srba_hip_ctx *c, int what, const double *in, int64_t n_doubles) {
 	if (!c || !in || !(what == 1 || what == 2 || what == 6) || n_doubles != c->len_dbg[what]) { if (c) c->fail("debug_write: only the Jacobian blocks (1, 2) and the minus-gradient (6) can be written, with their exact sizes"); return -1; }
 	HIPCHK(c, hipSetDevice(c->device));
-	HIPCHK(c, hipMemcpyAsync(c->d_wk + c->off_dbg[what], in, 8 * (size_t)n_doubles, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0;
+	HIPCHK(c, hipMemcpyAsync(c->d_wk + c->off_dbg[what], in, 8 * (size_t)n_doubles, hipMemcpyHostToDevice, c->stream));
+	if (what == 6 && (c->params.extensions & SRBA_EXT_SCHUR_KEEPS_GRADIENT)) HIPCHK(c, hipMemcpyAsync(c->B.grad0, in, 8 * (size_t)n_doubles, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream)); return 0;
 }
 int srba_hip_apply_update(srba_hip_ctx *c) { if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device)); SRBA_DISPATCH(c, k_apply, 0); HIPCHK(c, hipGetLastError()); return 0; }
 int srba_hip_rollback(srba_hip_ctx *c) { if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device)); SRBA_DISPATCH(c, k_rollback, 0); HIPCHK(c, hipGetLastError()); return 0; }

@@ -388,33 +388,74 @@ def test_many_mid_size_windows_keep_one_wavefront_each():
             assert abs(gpu["chi2_final"][q] - ref["chi2_final"][i]) <= 1e-6 * ref["chi2_final"][i] + 1e-20, (q, i)
 
 
+def _mono_dataset(gauge_fixed):
+    """60-key-frame monocular map. gauge_fixed: the landmarks first seen from key-frame 0 are given with their known relative position (what the reference's monocular
+    tutorial does, tutorial-srba-monocular-se3.cpp) and new landmarks enter 5 cm from the truth -> every window converges to the pixel noise and the reference's two Schur
+    solvers agree to 1e-13. Without it (free global scale, 20 cm depth noise) the map is lost (RMSE ~ 100 px) and the windows are ill-conditioned: the oracle's Schur+dense
+    and Schur+sparse code paths -- the same algebra in two elimination orders -- end 1e-5 apart (tests/test_conditioning.py)."""
+    if gauge_fixed:
+        return datasets.landmarks_dataset_se3("mono", n_kf=60, n_lm=600, seed=5, noise=0.1, init_from_gt_noise=0.05, known_first=1000)[0]
+    return datasets.landmarks_dataset_se3("mono", n_kf=60, n_lm=600, seed=5, noise=0.1, init_from_gt_noise=0.2)[0]
+
+
+def _replicate(b, copies):
+    import ctypes as C
+    n0 = b.n; arr = (capi.Capsule * (n0 * copies))()
+    for r in range(copies):
+        for i in range(n0): arr[r * n0 + i] = b.ptr[i]
+    class Rep: pass
+    fb = Rep(); fb.ptr = C.cast(arr, capi.PCAP); fb.n = n0 * copies; fb.params = b.params; fb.family = b.family; fb._keep = (arr, b)
+    return fb
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["stereo", "mono"])
 def test_large_batch_moves_wide_lds_images_to_hbm(kind):
     """In batches of 1 024 capsules or more, landmark windows whose LDS image would need 48 KB or more keep one wavefront but hold their dense block system in HBM
-    (left-looking sweeps), so that LDS does not cap the wavefronts per CU. Every window of a 60-key-frame map x 18 replicas must reproduce the oracle's chi2 of its
-    original, whichever layout it got (sparse in LDS, dense in LDS, dense in HBM)."""
+    (left-looking sweeps), so that LDS does not cap the wavefronts per CU. EVERY window of a 60-key-frame map x 18 replicas must reproduce the oracle's chi2 of its
+    original at 1e-6, whichever layout it got (sparse in LDS, dense in LDS, dense in HBM)."""
     import ctypes as C
-    ds, _ = datasets.landmarks_dataset_se3(kind, n_kf=60, n_lm=600, seed=5, noise=0.1, init_from_gt_noise=(0.2 if kind == "mono" else None))
+    ds = _mono_dataset(True) if kind == "mono" else datasets.landmarks_dataset_se3(kind, n_kf=60, n_lm=600, seed=5, noise=0.1)[0]
     eng = runner.landmark_engine(kind, backend=_oracle.BACKEND); eng.run(ds); b = eng.harvest(); b.engine = eng
     ref = _oracle.run_batch(b); n0 = b.n; copies = 18
     assert n0 * copies >= 1024
-    arr = (capi.Capsule * (n0 * copies))()
-    for r in range(copies):
-        for i in range(n0): arr[r * n0 + i] = b.ptr[i]
-    class Rep: pass
-    fb = Rep(); fb.ptr = C.cast(arr, capi.PCAP); fb.n = n0 * copies; fb.params = b.params; fb.family = b.family
+    fb = _replicate(b, copies)
     ctx = runner.HipContext(b.params); ctx.upload(fb); gpu = ctx.lm_run()
     st = (C.c_double * 4)(); ctx.lib.srba_hip_big_path_stats(ctx.ctx, st); ctx.close()
     assert st[2] == 0                                                        # nothing went through the multi-workgroup path
-    conv = 0
     for q in range(fb.n):
         i = q % n0
         assert gpu["status"][q] == 0 and gpu["num_observations"][q] == ref["num_observations"][i]
-        # (monocular with noisy initial depths: chi2_init ~ 1e7 px^2 from points that start almost in the camera plane, whose pixel coordinates amplify the last bits of
-        #  the composed pose; 2.5e-8 observed. Stereo: 1e-9 like everywhere else)
-        assert abs(gpu["chi2_init"][q] - ref["chi2_init"][i]) <= (1e-9 if kind == "stereo" else 1e-6) * ref["chi2_init"][i]
-        if abs(gpu["chi2_final"][q] - ref["chi2_final"][i]) <= 1e-6 * ref["chi2_final"][i] + 1e-20: conv += 1
-    # stereo must agree everywhere; two of the 59 monocular windows (noisy initial depths) stop 2e-6 / 4e-4 away from the oracle under EVERY layout, the round-1 one
-    # included (tools/diag_layout_parity.py): the stop criterion fires one trial apart
-    assert (conv == fb.n) if kind == "stereo" else (conv >= 0.9 * fb.n), (conv, fb.n)
+        assert abs(gpu["chi2_init"][q] - ref["chi2_init"][i]) <= 1e-9 * ref["chi2_init"][i], (q, i)
+        assert abs(gpu["chi2_final"][q] - ref["chi2_final"][i]) <= 1e-6 * ref["chi2_final"][i] + 1e-20, (q, i, gpu["chi2_final"][q], ref["chi2_final"][i])
+
+
+@pytest.mark.gpu
+def test_ill_conditioned_mono_windows_match_wherever_the_reference_pins_them():
+    """The gauge-free monocular map (round 2's dataset of the test above): its windows are ill-conditioned enough that the reference's own Schur+dense and Schur+sparse
+    solvers part ways (tests/test_conditioning.py), so chi2_final is not a reference-defined number there. What IS defined is every trial up to the one where the two
+    reference code paths stop agreeing with each other: on that prefix the GPU must take the same accept / reject decisions as the oracle and reproduce every accepted
+    chi2 -- to 1e-6, or to 100x the reference's own solver-to-solver spread at that trial where that is larger (the spread grows geometrically along the trace)."""
+    ds = _mono_dataset(False)
+    eng = runner.landmark_engine("mono", backend=_oracle.BACKEND); eng.run(ds); b = eng.harvest(); b.engine = eng
+    r0 = _oracle.run_batch(b); b.params.solver = capi.SOLVER_SCHUR_SPARSE; r1 = _oracle.run_batch(b); b.params.solver = capi.SOLVER_SCHUR_DENSE
+    gpu = runner.run_batch_hip(b)
+    assert np.all(gpu["status"] == r0["status"]) and np.array_equal(gpu["num_observations"], r0["num_observations"])
+    # (chi2_init ~ 1e7 px^2 comes from points that start almost in the camera plane, whose pixel coordinates amplify the last bits of the composed pose)
+    assert _close(gpu["chi2_init"], r0["chi2_init"], rel=1e-6) and _close(gpu["lambda_init"], r0["lambda_init"], rel=1e-6)
+    pinned_trials = 0; full = 0
+    for i in range(b.n):
+        m = int(min(gpu["num_trials"][i], r0["num_trials"][i], r1["num_trials"][i], capi.TRACE_LEN))
+        c0, c1, g = r0["trace_chi2"][i][:m], r1["trace_chi2"][i][:m], gpu["trace_chi2"][i][:m]
+        spread = np.abs(c1 - c0) / np.maximum(np.abs(c0), 1e-300)
+        ref_agree = (np.sign(r0["trace_rho"][i][:m]) == np.sign(r1["trace_rho"][i][:m])) & (np.isnan(c0) == np.isnan(c1)) & ~(spread > 1e-7)
+        k = m if ref_agree.all() else int(np.argmin(ref_agree))              # trials [0, k) are pinned by the reference
+        assert k >= min(m, 2), (i, k, m)
+        assert np.array_equal(np.sign(gpu["trace_rho"][i][:k]), np.sign(r0["trace_rho"][i][:k])), (i, k)
+        assert np.array_equal(np.isnan(g[:k]), np.isnan(c0[:k])), i
+        acc = r0["trace_rho"][i][:k] > 0
+        tol = np.maximum(1e-6, 100.0 * spread[:k])
+        assert np.all(np.abs(g[:k][acc] - c0[:k][acc]) <= tol[acc] * np.abs(c0[:k][acc])), (i, k, g[:k][acc], c0[:k][acc])
+        assert _close(gpu["trace_lambda"][i][:k], r0["trace_lambda"][i][:k], rel=1e-9), i
+        pinned_trials += k; full += int(k == m)
+    assert pinned_trials >= 0.5 * min(r0["num_trials"].sum(), gpu["num_trials"].sum()) and full >= b.n // 2, (pinned_trials, full)
