@@ -60,6 +60,7 @@ struct Batch {
 	// state + workspace
 	double *edge, *ulm, *pose, *Jp, *Jf, *resid, *resid2, *HAp, *HAp0, *Hf, *HApf, *grad, *grad0 /* SRBA_EXT_SCHUR_KEEPS_GRADIENT: the gradient as K5 produced it */, *delta, *Hfinv, *YW;
 	double *old_edge, *old_ulm, *old_pose, *dense, *ulm_inf;
+	double *edge1, *ulm1, *pose1; const unsigned char *pose_req; // rounds path (srba_rounds.hpp): second copy of the unknowns and of the spanning-tree poses; per pose: a Jacobian block reads it (list_of_required_num_poses)
 	int *valid, *first_fail, *hf_ok;
 	unsigned char *bp_ok, *bf_ok; // per Jacobian block: its observation row is valid (set by phase_jacobians, read by phase_hessian)
 	unsigned char *ulm_inf_valid;

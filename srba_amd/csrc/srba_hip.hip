@@ -492,6 +492,7 @@ template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_rollback(const B
 } // namespace srbadev
 #include "srba_big.hpp"
 #include "srba_flat.hpp"
+#include "srba_rounds.hpp"
 namespace srbadev {
 // ---- whole-map squared error (eval_overall_error.h:15-137): a plain streaming pair of kernels over ONE problem (desc[0]), grid-stride
 // K1 over all (observer, base) pairs: compose the breadth-first path from the root of the pair (spantree_create_complete.h:96-124)
@@ -733,6 +734,10 @@ struct srba_hip_ctx {
 	size_t off_dbg[10] = {0}; int64_t len_dbg[10] = {0};
 	size_t in_off_edge0 = 0, in_off_ulm0 = 0; long long tot_edge = 0, tot_ulm = 0;
 	size_t off_phase = 0; bool phase_timing = false; long long n_pose_total = 0; std::vector<int> cls_of;
+	// rounds path (srba_rounds.hpp): groups of capsules (LDS size classes, the big ones split) that run their LM rounds on separate streams
+	struct RGroup { int cls, first, count; size_t lds; int rounds_needed /* most LM trials of any of its capsules, once a run's results have been downloaded; else 0 */, rounds_done; int grid[5]; };
+	int rounds_env = -1, rounds_split = 4, rounds_first = 64, rounds_min_batch = 1 << 30 /* (off by default until validated) */; bool rounds_on = false, rounds_pending = false; std::vector<RGroup> rgroups; srbadev::Rounds R; int *h_unfinished = nullptr;
+	static constexpr int kRStreams = 32; hipStream_t rstream[kRStreams] = {nullptr}; hipEvent_t rdone[kRStreams] = {nullptr};
 	void fail(const std::string &m) { error = m; g_last_error = m; }
 };
 static void big_drop_graphs(srba_hip_ctx *c);
@@ -873,6 +878,8 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_DENSE_LEFT"); if (e) c->dense_left = atoi(e) != 0; } // 0: right-looking sweeps on the HBM-resident dense layout (round-2 first version)
 	{ const char *e = getenv("SRBA_HIP_LIN_TERMS"); if (e) c->lin_terms = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_LM_TERMS"); if (e) c->lm_terms = atoi(e) != 0; }
+	{ const char *e = getenv("SRBA_HIP_ROUNDS"); if (e) c->rounds_env = atoi(e); e = getenv("SRBA_HIP_ROUNDS_SPLIT"); if (e && atoi(e) >= 1) c->rounds_split = std::min(atoi(e), 16); e = getenv("SRBA_HIP_ROUNDS_FIRST"); if (e && atoi(e) >= 1) c->rounds_first = atoi(e);
+	  e = getenv("SRBA_HIP_ROUNDS_MIN_BATCH"); if (e) c->rounds_min_batch = atoi(e); }
 	{ const char *e = getenv("SRBA_HIP_FLAT"); if (e) c->use_flat = atoi(e) != 0; }                     // 0 = one wavefront per capsule for the stepwise spanning-tree launch
 	{ const char *e = getenv("SRBA_HIP_BIG_LANES"); if (e && atoi(e) >= 1) c->big_lanes_max = std::min(atoi(e), kBigLanes); } // large capsules of one batch in flight at once
 	{ const char *e = getenv("SRBA_HIP_BIG_GRAPHS"); if (e) c->big_use_graphs = atoi(e) != 0; }         // 1 = replay the big path's launch sequences as HIP graphs (measured: no gain, the path is bound by its kernels)
@@ -1003,7 +1010,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	// ---- input arena layout
 	Arena in; struct { size_t desc, edge0, ulm0, klm, obs_z, pair_path_off, path_edge, obs_pose, obs_lm, obs_valid, bp_col, bp_res, bp_A, bp_D, bp_lm, colp_off, bf_col, bf_res, bf_pose, colf_off,
 		hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hap_tblk, hf_i, hf_j, hf_term_off, hf_t1, hf_t2, hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag, sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw, sch_tblk,
-		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, pair_needed, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_ab, sp_rptr, sp_rcol, sp_rblk, sp_perm, sp_fill, hap_rec, hap_dst, hapf_dst, hf_dst; } o;
+		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, pair_needed, pose_req, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_ab, sp_rptr, sp_rcol, sp_rblk, sp_perm, sp_fill, hap_rec, hap_dst, hapf_dst, hf_dst; } o;
 	o.desc = in.add(sizeof(ProbDesc) * n);
 	o.edge0 = in.add(8 * t_edge * PDX); o.ulm0 = in.add(8 * t_ulm * L); o.klm = in.add(8 * t_klm * L); o.obs_z = in.add(8 * t_obs * O);
 	o.pair_path_off = in.add(4 * (t_pair + n)); o.path_edge = in.add(4 * t_path); o.obs_pose = in.add(4 * t_obs); o.obs_lm = in.add(4 * t_obs); o.obs_valid = in.add(4 * t_obs);
@@ -1014,7 +1021,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	o.hapf_i = in.add(4 * t_hapf); o.hapf_j = in.add(4 * t_hapf); o.hapf_term_off = in.add(4 * (t_hapf + n)); o.hapf_t1 = in.add(4 * t_hapft); o.hapf_t2 = in.add(4 * t_hapft);
 	o.hap_diag = in.add(4 * t_unk); o.hf_diag = in.add(4 * t_ulm);
 	o.sch_term_off = in.add(4 * (t_hap + n)); o.sch_b1 = in.add(4 * t_sch); o.sch_b2 = in.add(4 * t_sch); o.sch_lm = in.add(4 * t_sch); o.sch_yw = in.add(4 * t_sch); o.sch_tblk = in.add(4 * t_sch);
-	o.lm_hapf_off = in.add(4 * (t_ulm + n)); o.lm_hapf_idx = in.add(4 * t_hapf); o.req_idx = in.add(4 * t_req); o.need_idx = in.add(4 * t_pair); o.need_rec = in.add(4 * 5 * std::max<long long>(t_pair, 1)); o.pair_needed = in.add(t_pair); o.bp_normal = in.add(t_bp); o.order = in.add(4 * (size_t)n);
+	o.lm_hapf_off = in.add(4 * (t_ulm + n)); o.lm_hapf_idx = in.add(4 * t_hapf); o.req_idx = in.add(4 * t_req); o.need_idx = in.add(4 * t_pair); o.need_rec = in.add(4 * 5 * std::max<long long>(t_pair, 1)); o.pair_needed = in.add(t_pair); o.pose_req = in.add(2 * t_pair); o.bp_normal = in.add(t_bp); o.order = in.add(4 * (size_t)n);
 	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_ab = in.add(4 * t_spitem); o.sp_rptr = in.add(4 * t_spcol); o.sp_rcol = in.add(4 * t_sprow); o.sp_rblk = in.add(4 * t_sprow); o.sp_perm = in.add(4 * t_spcol); o.hap_rec = in.add(4 * 3 * std::max<long long>(t_hap, 1)); o.sp_fill = in.add(4 * std::max<long long>(t_spfill, 1));
 	o.hap_dst = in.add(4 * t_hap * (P / 3) * (P / 3)); o.hapf_dst = in.add(4 * t_hapf * (P / 3)); o.hf_dst = in.add(4 * t_hf);
 	in.add(0);
@@ -1056,7 +1063,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 			nd[cnt++] = i; }
 		  c->desc[p].n_need = cnt; c->desc[p].need_flat = flat; }
 		{ int32_t *rq = (int32_t *)(h + o.req_idx) + d.o_req; int cnt = 0; for (int i = 0; i < 2 * k.n_pairs; i++) if (k.pose_required[i]) rq[cnt++] = i; }
-		CPY(o.pair_needed, d.o_pair, k.pair_needed, k.n_pairs, uint8_t); CPY(o.bp_normal, d.o_bp, k.bp_normal, k.n_bp, uint8_t);
+		CPY(o.pair_needed, d.o_pair, k.pair_needed, k.n_pairs, uint8_t); CPY(o.pose_req, 2 * d.o_pair, k.pose_required, 2 * (size_t)k.n_pairs, uint8_t); CPY(o.bp_normal, d.o_bp, k.bp_normal, k.n_bp, uint8_t);
 		CPY(o.sp_col_off, d.o_spcol, sym[p].col_off.data(), d.nb + 1, int32_t); CPY(o.sp_row, d.o_sprow, sym[p].row.data(), sym[p].row.size(), int32_t);
 		CPY(o.sp_item_off, d.o_spcol, sym[p].item_off.data(), d.nb + 1, int32_t); CPY(o.sp_perm, d.o_spperm, sym[p].perm.data(), d.nb, int32_t); CPY(o.sp_tgt, d.o_spitem, sym[p].tgt.data(), sym[p].tgt.size(), int32_t); CPY(o.sp_ab, d.o_spitem, sym[p].ab.data(), sym[p].ab.size(), int32_t);
 		CPY(o.sp_rptr, d.o_spcol, sym[p].rptr.data(), d.nb + 1, int32_t); CPY(o.sp_rcol, d.o_sprow, sym[p].rcol.data(), sym[p].rcol.size(), int32_t); CPY(o.sp_rblk, d.o_sprow, sym[p].rblk.data(), sym[p].rblk.size(), int32_t); CPY(o.sp_fill, d.o_spfill, sym[p].fill.data(), d.n_fill, int32_t);
@@ -1073,6 +1080,8 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	c->cls_of = cls; c->big_ld = big_lds;
 	{ // launch order: capsules grouped by LDS size class
 		int32_t *ord = (int32_t *)(h + o.order); int pos = 0;
+		// the LM loop as rounds over the batch (srba_rounds.hpp) instead of one fused kernel per capsule: SRBA_HIP_ROUNDS = 1 / 0, default: large batches of the relative-pose SE2 family
+		c->rgroups.clear(); c->rounds_on = c->rounds_env >= 0 ? (c->rounds_env != 0) : (c->params.family == SRBA_SE2_RELPOSE2D && n >= c->rounds_min_batch); c->rounds_pending = false;
 		for (int k = 0; k < SRBA_NCLS; k++) {
 			c->cls_first[k] = pos; for (int p = 0; p < n; p++) if (cls[p] == k) ord[pos++] = p; c->cls_count[k] = pos - c->cls_first[k];
 			c->cls_lds[k] = k < SRBA_NCLS - 1 ? (size_t)cls_nbmax[k] * 8 : 0;
@@ -1080,18 +1089,26 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 			int32_t *b = ord + c->cls_first[k]; const int cnt = c->cls_count[k], nq = c->n_queues;
 			auto work = [&](int x) -> long long { const ProbDesc &dx = c->desc[x]; return dx.dense_blocks ? (long long)dx.nb * dx.nb * dx.nb / 6 : dx.n_items; }; // block updates per factorisation
 			std::stable_sort(b, b + cnt, [&](int x, int y) { return work(x) > work(y); });
+			if (c->rounds_on && k < SRBA_NCLS - 1 && cnt > 0) { // rounds path: a big class is split into interleaved slices (each a group with its own stream: their round kernels overlap)
+				const int parts = cnt >= 2048 * c->rounds_split ? c->rounds_split : (cnt >= 4096 ? 2 : 1);
+				if (parts > 1) { std::vector<int32_t> t(b, b + cnt); for (int q = 0; q < parts; q++) { int i = slice_begin(cnt, q, parts); for (int src = q; src < cnt; src += parts) b[i++] = t[src]; } }
+				for (int q = 0; q < parts; q++) { const int a = slice_begin(cnt, q, parts), e = slice_begin(cnt, q + 1, parts); if (e > a) c->rgroups.push_back({k, c->cls_first[k] + a, e - a, c->cls_lds[k], 0, 0, {0, 0, 0, 0, 0}}); }
+			}
 			if (c->sched == 0 && cnt >= 16 * nq) { std::vector<int32_t> t(b, b + cnt); for (int q = 0; q < nq; q++) { int i = slice_begin(cnt, q, nq); for (int src = q; src < cnt; src += nq) b[i++] = t[src]; } }
 		}
 		plan_launches(c, ord);
 	}
 	// ---- work arena layout
-	Arena wk; struct { size_t edge, ulm, pose, Jp, Jf, resid, resid2, HAp, HAp0, Hf, HApf, grad, delta, Hfinv, YW, old_edge, old_ulm, old_pose, dense, ulm_inf, valid, first_fail, hf_ok, bp_ok, bf_ok, ulm_inf_valid, results, lambda_io, chi2, notpd, phase_cycles, m_pair, grad0; } w;
+	Arena wk; struct { size_t edge, ulm, pose, Jp, Jf, resid, resid2, HAp, HAp0, Hf, HApf, grad, delta, Hfinv, YW, old_edge, old_ulm, old_pose, dense, ulm_inf, valid, first_fail, hf_ok, bp_ok, bf_ok, ulm_inf_valid, results, lambda_io, chi2, notpd, phase_cycles, m_pair, grad0, edge1, ulm1, pose1, lmst, rlist, rcount, rctr, runf; } w;
 	w.edge = wk.add(8 * t_edge * PDX); w.ulm = wk.add(8 * t_ulm * L); w.pose = wk.add(8 * 2 * t_pair * PDX); w.Jp = wk.add(8 * t_bp * O * P); w.Jf = wk.add(8 * t_bf * O * L);
 	w.resid = wk.add(8 * t_obs * O); w.resid2 = wk.add(8 * t_obs * O); w.HAp = wk.add(8 * t_hap * P * P); w.HAp0 = wk.add(8 * t_hap * P * P); w.Hf = wk.add(8 * t_hf * L * L); w.HApf = wk.add(8 * t_hapf * P * L);
 	w.grad = wk.add(8 * t_scal); w.delta = wk.add(8 * t_scal); w.Hfinv = wk.add(8 * t_ulm * L * L); w.YW = wk.add(8 * t_yw * P * L); w.old_edge = wk.add(8 * t_unk * PDX); w.old_ulm = wk.add(8 * t_ulm * L); w.old_pose = wk.add(8 * t_req * PDX);
 	w.dense = wk.add(8 * t_dense); w.ulm_inf = wk.add(8 * t_ulm * L * L); w.valid = wk.add(4 * t_valid); w.first_fail = wk.add(4 * t_valid); w.hf_ok = wk.add(4 * t_ulm); w.bp_ok = wk.add(t_bp); w.bf_ok = wk.add(t_bf); w.ulm_inf_valid = wk.add(t_ulm);
 	w.results = wk.add(sizeof(srba_lm_result) * n); w.lambda_io = wk.add(8 * n); w.chi2 = wk.add(8 * n); w.notpd = wk.add(4 * n); w.phase_cycles = wk.add(8 * 16 * (size_t)n);
 	w.m_pair = wk.add(4 * t_pair);
+	{ const bool r = c->rounds_on; const size_t ng = c->rgroups.size() + 1;
+	  w.edge1 = wk.add(r ? 8 * t_edge * PDX : 0); w.ulm1 = wk.add(r ? 8 * t_ulm * L : 0); w.pose1 = wk.add(r ? 8 * 2 * t_pair * PDX : 0); w.lmst = wk.add(r ? sizeof(srbadev::LmState) * (size_t)n : 0);
+	  w.rlist = wk.add(r ? 4 * 3 * (size_t)n : 0); w.rcount = wk.add(r ? 4 * 3 * ng : 0); w.rctr = wk.add(r ? 4 * 5 * ng : 0); w.runf = wk.add(4); }
 	w.grad0 = wk.add((c->params.extensions & SRBA_EXT_SCHUR_KEEPS_GRADIENT) ? 8 * t_scal : 0);
 	wk.add(0);
 	if (in.size + 256 > c->cap_in) { if (c->d_in) hipFree(c->d_in); c->d_in = nullptr; c->cap_in = 0; const size_t want = (in.size + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_in, want)); c->cap_in = want; }
@@ -1106,10 +1123,11 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	DI(pair_path_off, int); DI(path_edge, int); DI(obs_pose, int); DI(obs_lm, int); DI(obs_valid, int); DI(bp_col, int); DI(bp_res, int); DI(bp_A, int); DI(bp_D, int); DI(bp_lm, int); DI(colp_off, int);
 	DI(bf_col, int); DI(bf_res, int); DI(bf_pose, int); DI(colf_off, int); DI(hap_i, int); DI(hap_j, int); DI(hap_term_off, int); DI(hap_t1, int); DI(hap_t2, int); DI(hap_tblk, int); DI(hf_i, int); DI(hf_j, int); DI(hf_term_off, int); DI(hf_t1, int); DI(hf_t2, int);
 	DI(hapf_i, int); DI(hapf_j, int); DI(hapf_term_off, int); DI(hapf_t1, int); DI(hapf_t2, int); DI(hap_diag, int); DI(hf_diag, int); DI(sch_term_off, int); DI(sch_b1, int); DI(sch_b2, int); DI(sch_lm, int); DI(sch_yw, int); DI(sch_tblk, int);
-	DI(lm_hapf_off, int); DI(lm_hapf_idx, int); DI(req_idx, int); DI(need_idx, int); DI(need_rec, int); DI(pair_needed, unsigned char); DI(bp_normal, unsigned char);
+	DI(lm_hapf_off, int); DI(lm_hapf_idx, int); DI(req_idx, int); DI(need_idx, int); DI(need_rec, int); DI(pair_needed, unsigned char); DI(pose_req, unsigned char); DI(bp_normal, unsigned char);
 #undef DI
 #define DW(field, T) B.field = (T *)(dw + w.field)
-	DW(edge, double); DW(ulm, double); DW(pose, double); DW(Jp, double); DW(Jf, double); DW(resid, double); DW(resid2, double); DW(HAp, double); DW(HAp0, double); DW(Hf, double); DW(HApf, double); DW(grad, double); DW(grad0, double); DW(delta, double);
+	DW(edge, double); DW(ulm, double); DW(pose, double); DW(Jp, double); DW(Jf, double); DW(resid, double); DW(resid2, double); DW(HAp, double); DW(HAp0, double); DW(Hf, double); DW(HApf, double); DW(grad, double); DW(grad0, double); DW(delta, double); DW(edge1, double); DW(ulm1, double); DW(pose1, double);
+	c->R.st = (srbadev::LmState *)(dw + w.lmst); c->R.list = (int *)(dw + w.rlist); c->R.count = (int *)(dw + w.rcount); c->R.ctr = (int *)(dw + w.rctr); c->R.unfinished = (int *)(dw + w.runf); c->R.n_prob = n;
 	DW(Hfinv, double); DW(YW, double); DW(old_edge, double); DW(old_ulm, double); DW(old_pose, double); DW(dense, double); DW(ulm_inf, double); DW(valid, int); DW(first_fail, int); DW(hf_ok, int); DW(bp_ok, unsigned char); DW(bf_ok, unsigned char); DW(ulm_inf_valid, unsigned char);
 	DW(results, srba_lm_result); DW(lambda_io, double); DW(chi2, double); DW(notpd, int);
 	c->flat.pair = (int *)(dw + w.m_pair); c->flat.n_pair = t_pair; c->flat_ready = false;
@@ -1374,9 +1392,84 @@ static int big_run_class(srba_hip_ctx *c, const int32_t *caps, int count) {
 #undef BIGK
 #undef BIGKG
 
+// =================================================================================================== the LM loop as rounds over the batch (srba_rounds.hpp)
+// grid of a persistent round kernel: what the chip holds of it for that much dynamic LDS, at most one wavefront per capsule
+template <class K> static int rounds_grid(srba_hip_ctx *c, K kernel, size_t lds, int count) {
+	int per_cu = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kernel, SRBA_WG, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+	return std::max(1, std::min(count, c->n_cu * per_cu));
+}
+// rounds [r0, r1) of every group (each on its own stream), interleaved round by round so that every stream has work from the start
+static int rounds_enqueue(srba_hip_ctx *c, bool with_init, const std::vector<int> &r0, const std::vector<int> &r1) {
+	const int ng = (int)c->rgroups.size(); int rc = 0;
+	with_family(c->params.family, [&](auto fam_) { constexpr int F = decltype(fam_)::value;
+		for (int g = 0; g < ng && rc == 0; g++) { srba_hip_ctx::RGroup &G = c->rgroups[g]; // grids once per upload; big LDS images need the attribute
+			if (G.grid[0]) continue;
+			if (allow_big_lds(c, srbadev::kr_init<F>, G.lds) != 0 || allow_big_lds(c, srbadev::kr_solve<F>, G.lds) != 0 || allow_big_lds(c, srbadev::kr_lin<F>, G.lds) != 0) { rc = -1; break; }
+			G.grid[0] = rounds_grid(c, srbadev::kr_init<F>, G.lds, G.count); G.grid[1] = rounds_grid(c, srbadev::kr_solve<F>, G.lds, G.count); G.grid[2] = rounds_grid(c, srbadev::kr_eval<F>, 0, G.count);
+			G.grid[3] = rounds_grid(c, srbadev::kr_lin<F>, G.lds, G.count); G.grid[4] = rounds_grid(c, srbadev::kr_finish<F>, 0, G.count);
+		}
+		if (rc != 0) return;
+		if (with_init) for (int g = 0; g < ng; g++) { const srba_hip_ctx::RGroup &G = c->rgroups[g];
+			hipLaunchKernelGGL((srbadev::kr_init<F>), dim3(G.grid[0]), dim3(SRBA_WG), G.lds, c->rstream[g % srba_hip_ctx::kRStreams], c->B, c->dp, c->R, g, G.first, G.count); }
+		int rmax = 0; for (int g = 0; g < ng; g++) rmax = std::max(rmax, r1[g]);
+		for (int r = 0; r < rmax; r++) for (int g = 0; g < ng; g++) { const srba_hip_ctx::RGroup &G = c->rgroups[g]; if (r < r0[g] || r >= r1[g]) continue; hipStream_t st = c->rstream[g % srba_hip_ctx::kRStreams];
+			hipLaunchKernelGGL((srbadev::kr_solve<F>), dim3(G.grid[1]), dim3(SRBA_WG), G.lds, st, c->B, c->dp, c->R, g, G.first, r);
+			hipLaunchKernelGGL((srbadev::kr_eval<F>), dim3(G.grid[2]), dim3(SRBA_WG), 0, st, c->B, c->dp, c->R, g, G.first, r);
+			hipLaunchKernelGGL((srbadev::kr_lin<F>), dim3(G.grid[3]), dim3(SRBA_WG), G.lds, st, c->B, c->dp, c->R, g, G.first, r); }
+		for (int g = 0; g < ng; g++) { const srba_hip_ctx::RGroup &G = c->rgroups[g];
+			hipLaunchKernelGGL((srbadev::kr_finish<F>), dim3(G.grid[4]), dim3(SRBA_WG), 0, c->rstream[g % srba_hip_ctx::kRStreams], c->B, c->dp, c->R, g, G.first, G.count); }
+	});
+	if (rc != 0) return -1;
+	HIPCHK(c, hipGetLastError());
+	for (int g = 0; g < ng; g++) c->rgroups[g].rounds_done = r1[g];
+	return 0;
+}
+static int rounds_fork(srba_hip_ctx *c) { // the group streams start after what is queued on the context stream
+	const int ns = std::min((int)c->rgroups.size(), (int)srba_hip_ctx::kRStreams);
+	for (int q = 0; q < ns; q++) if (!c->rstream[q]) { HIPCHK(c, hipStreamCreateWithFlags(&c->rstream[q], hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->rdone[q], hipEventDisableTiming)); }
+	HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+	for (int q = 0; q < ns; q++) HIPCHK(c, hipStreamWaitEvent(c->rstream[q], c->ev_fork, 0));
+	return 0;
+}
+static int rounds_join(srba_hip_ctx *c) {
+	const int ns = std::min((int)c->rgroups.size(), (int)srba_hip_ctx::kRStreams);
+	for (int q = 0; q < ns; q++) { HIPCHK(c, hipEventRecord(c->rdone[q], c->rstream[q])); HIPCHK(c, hipStreamWaitEvent(c->stream, c->rdone[q], 0)); }
+	return 0;
+}
+static int rounds_run_async(srba_hip_ctx *c) {
+	const int ng = (int)c->rgroups.size();
+	// counters of the round kernels, list lengths, the "still iterating" count: all zero at the start of a run
+	HIPCHK(c, hipMemsetAsync(c->R.count, 0, sizeof(int) * 3 * (size_t)(ng + 1), c->stream)); HIPCHK(c, hipMemsetAsync(c->R.ctr, 0, sizeof(int) * 5 * (size_t)(ng + 1), c->stream)); HIPCHK(c, hipMemsetAsync(c->R.unfinished, 0, sizeof(int), c->stream));
+	if (ng) { if (rounds_fork(c) != 0) return -1;
+		std::vector<int> r0(ng, 0), r1(ng); for (int g = 0; g < ng; g++) r1[g] = c->rgroups[g].rounds_needed > 0 ? c->rgroups[g].rounds_needed : c->rounds_first; // (a round = one LM trial of every capsule still iterating)
+		if (rounds_enqueue(c, true, r0, r1) != 0) return -1; }
+	int big_rc = 0; { const int32_t *ord = (const int32_t *)(c->h_in.get() + c->h_off_order); big_rc = big_run_class(c, ord + c->cls_first[SRBA_NCLS - 1], c->cls_count[SRBA_NCLS - 1]); }
+	if (ng && rounds_join(c) != 0) return -1;
+	HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+	c->rounds_pending = ng > 0;
+	if (big_rc != 0) { hipStreamSynchronize(c->stream); return -1; }
+	return 0;
+}
+// after the context stream has been synchronised: capsules that needed more rounds than were enqueued (first run of a batch: the number of rounds is a guess) get them now
+static int rounds_complete(srba_hip_ctx *c) {
+	if (!c->rounds_pending) return 0;
+	c->rounds_pending = false; const int ng = (int)c->rgroups.size();
+	for (int pass = 0; pass < 64; pass++) {
+		int unf = 0; HIPCHK(c, hipMemcpyAsync(&unf, c->R.unfinished, sizeof(int), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+		if (unf == 0) return 0;
+		HIPCHK(c, hipMemsetAsync(c->R.unfinished, 0, sizeof(int), c->stream));
+		for (int g = 0; g < ng; g++) { HIPCHK(c, hipMemsetAsync(c->R.ctr + 5 * g + 4, 0, sizeof(int), c->stream)); }
+		if (rounds_fork(c) != 0) return -1;
+		std::vector<int> r0(ng), r1(ng); for (int g = 0; g < ng; g++) { r0[g] = c->rgroups[g].rounds_done; r1[g] = r0[g] + 32; }
+		if (rounds_enqueue(c, false, r0, r1) != 0) return -1;
+		if (rounds_join(c) != 0) return -1;
+	}
+	c->fail("lm_run: capsules still iterating after the extra rounds"); return -1;
+}
+
 extern "C" {
 
-int srba_hip_sync(srba_hip_ctx *c) { if (!c) return -1; HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+int srba_hip_sync(srba_hip_ctx *c) { if (!c) return -1; HIPCHK(c, hipStreamSynchronize(c->stream)); return rounds_complete(c); }
 
 static int lm_run_async_impl(srba_hip_ctx *c);
 int srba_hip_lm_run_async(srba_hip_ctx *c) { // no C++ exception crosses the C ABI
@@ -1392,6 +1485,7 @@ static int lm_run_async_impl(srba_hip_ctx *c) {
 	  if (!c->ring0[slot]) { HIPCHK(c, hipEventCreate(&c->ring0[slot])); HIPCHK(c, hipEventCreate(&c->ring1[slot])); }
 	  c->ev0 = c->ring0[slot]; c->ev1 = c->ring1[slot]; c->n_launches++; }
 	HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+	if (c->rounds_on) return rounds_run_async(c);
 	HIPCHK(c, hipMemsetAsync(c->d_next, 0, sizeof(int) * kMaxJobs, c->stream)); // work counters of the persistent launches
 	// fork/join: the launch plan (made at upload) spreads the size classes over a few streams; see plan_launches()
 	const int nq = c->plan.size() <= 1 ? 1 : c->n_streams_used; // a single launch (the per-key-frame use) stays on the context stream: no fork / join
@@ -1458,12 +1552,18 @@ int srba_hip_eval_overall_sqr_error(srba_hip_ctx *c, const srba_overall_problem 
 }
 int srba_hip_download_results(srba_hip_ctx *c, srba_lm_result *results, int n) {
 	if (!c || !results || n > c->n_prob) return -1;
+	HIPCHK(c, hipStreamSynchronize(c->stream)); if (rounds_complete(c) != 0) return -1;
 	HIPCHK(c, hipMemcpyAsync(results, c->d_wk + c->off_res, sizeof(srba_lm_result) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(c, hipStreamSynchronize(c->stream)); return 0;
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	if (c->rounds_on && n == c->n_prob) { // the rounds a later run of this batch needs: one per LM trial of the slowest capsule of each group
+		const int32_t *ord = (const int32_t *)(c->h_in.get() + c->h_off_order);
+		for (auto &G : c->rgroups) { int mx = 0; for (int i = 0; i < G.count; i++) mx = std::max(mx, (int)results[ord[G.first + i]].num_trials); G.rounds_needed = mx + 1; } }
+	return 0;
 }
 int srba_hip_lm_run(srba_hip_ctx *c, srba_lm_result *results) {
 	if (srba_hip_lm_run_async(c) != 0) return -1;
 	HIPCHK(c, hipStreamSynchronize(c->stream));
+	if (rounds_complete(c) != 0) return -1;
 	float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_ms = ms;
 	if (results) return srba_hip_download_results(c, results, c->n_prob);
 	return 0;
