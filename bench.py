@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 
-def algorithmic_bytes(stats, res, P, L, O, PD, relpose):
+def algorithmic_bytes(stats, res, P, L, O, PD, relpose, schur=False):
     """Algorithmic HBM bytes of one fused launch (DESIGN.md "Roofline accounting"; per-unit figures from SURVEY.md 8d)."""
     import numpy as np
     pb = 8 * PD
@@ -43,7 +43,11 @@ def algorithmic_bytes(stats, res, P, L, O, PD, relpose):
     hwrite = per["n_hap"] * P * P * 8 + per["n_hf"] * L * L * 8 + per["n_hapf"] * P * L * 8
     k4 = per["n_obs"] * (pb + (0 if relpose else L * 8) + O * 8 + 12 + O * 8)
     k5 = per["n_scal"] * 8
-    k9 = (per["n_hap"] * P * P + per["n_hf"] * L * L + per["n_hapf"] * P * L) * 8.0  # block-sparse system read once per factorisation
+    if schur:   # K7 / K8 / K10 per landmark with d observing edges: read L*L*8 + d*P*L*8 + L*8, read-modify-write d(d+1)/2 reduced P x P blocks; K9: the dense reduced system, n^2 * 8
+        k78 = per["n_unk_lms"] * (L * L * 8 + L * 8) + per["sch_d"] * P * L * 8 + per["sch_dd"] * 2 * P * P * 8
+        k9 = (P * per["n_unk_edges"]) ** 2 * 8.0 + k78 + per["n_unk_lms"] * (L * 8 + L * L * 8) + per["sch_d"] * P * L * 8   # + K10: g_l, Hf^-1, the d blocks H_il again, delta_l out
+    else:
+        k9 = (per["n_hap"] * P * P + per["n_hf"] * L * L + per["n_hapf"] * P * L) * 8.0  # block-sparse system read once per factorisation
     k11 = per["n_unk_edges"] * 2 * pb + per["n_unk_lms"] * 2 * L * 8
     total = (k1_init + relin * (k2 + hwrite) + (1 + solves_ok) * k4 + grad_evals * k5 + res["num_trials"] * k9 + solves_ok * (k1_trial + k11))
     return float(total.sum())
@@ -81,7 +85,7 @@ def per_problem_counts(batch, family):
     from srba_amd import capi
     P, L, O, PD = capi.DIMS[family]
     n = batch.n
-    out = {k: np.zeros(n, np.int64) for k in ("n_path", "n_pairs", "n_path_needed", "n_pairs_needed", "n_bp", "n_bf", "n_hap", "n_hf", "n_hapf", "n_obs", "n_scal", "n_sys", "n_unk_edges", "n_unk_lms")}
+    out = {k: np.zeros(n, np.int64) for k in ("n_path", "n_pairs", "n_path_needed", "n_pairs_needed", "n_bp", "n_bf", "n_hap", "n_hf", "n_hapf", "n_obs", "n_scal", "n_sys", "n_unk_edges", "n_unk_lms", "sch_d", "sch_dd")}
     schur = batch.params.solver != capi.SOLVER_NO_SCHUR_SPARSE
     for i in range(n):
         c = batch.ptr[i]
@@ -90,6 +94,9 @@ def per_problem_counts(batch, family):
         out["n_unk_edges"][i] = c.n_unk_edges; out["n_unk_lms"][i] = c.n_unk_lms
         out["n_scal"][i] = P * c.n_unk_edges + L * c.n_unk_lms
         out["n_sys"][i] = P * c.n_unk_edges if (schur and c.n_unk_lms > 0) else out["n_scal"][i]
+        if schur and c.n_unk_lms and c.n_hapf:   # d = edges observing each unknown landmark (its U_Apf blocks)
+            dl = np.diff(np.ctypeslib.as_array(c.lm_hapf_off, shape=(c.n_unk_lms + 1,)).astype(np.int64))
+            out["sch_d"][i] = int(dl.sum()); out["sch_dd"][i] = int((dl * (dl + 1) // 2).sum())
         if c.n_pairs:
             need = np.ctypeslib.as_array(c.pair_needed, shape=(c.n_pairs,)).astype(bool)
             off = np.ctypeslib.as_array(c.pair_path_off, shape=(c.n_pairs + 1,))
@@ -97,7 +104,7 @@ def per_problem_counts(batch, family):
     return out
 
 
-def bench_cfg3(args, dist, rank, world, local_rank, backend):
+def bench_cfg3(args, dist, rank, world, local_rank, backend, emit=True):
     """BASELINE configs[2]: SE3 + StereoCamera landmarks, Schur landmark reduction. SURVEY 8d cfg3-stereo: 200 key-frames on a forward spiral in a 20 m room, 2 000 landmarks, stereo
     fx=200 fy=150 cx=512 cy=384 baseline 0.2 m, range 5 m, pixel noise 0.5, robust kernel on, sensor pose (0,0,0,-90,0,-90) deg, depth 3. The map is built key-frame by key-frame through the
     engine with the GPU back-end (sequential_ms_per_kf); a step re-optimises every harvested local area, --cfg3-copies replicas of each (one map alone does not fill the chip)."""
@@ -107,7 +114,9 @@ def bench_cfg3(args, dist, rank, world, local_rank, backend):
     from srba_amd import capi, datasets, multi, runner
     n_kf = args.cfg3_kf
     ds, _ = datasets.landmarks_dataset_se3("stereo", n_kf=n_kf, n_lm=2000, seed=multi.replica_seed(rank), max_range=5.0, noise=0.5, room=10.0)
-    eng = runner.landmark_engine("stereo", backend="hip", depth=3, submap=15, sigma=0.5, robust=1, harvest=1, hip_device=local_rank, refresh_all_read_poses=2)
+    # extensions 4 | 8: the two opt-in repairs of reference defects without which this map is lost at key-frame 68..77 (Schur gradient reduced again at every retry of a
+    # rejected trial) and at its first loop closure, key-frame 95 (inverted initial value of the edge between the two area centres): DESIGN.md section 8
+    eng = runner.landmark_engine("stereo", backend="hip", depth=3, submap=15, sigma=0.5, robust=1, harvest=1, hip_device=local_rank, refresh_all_read_poses=args.cfg3_ext)
     t0 = time.time(); eng.run(ds); t_map = time.time() - t0
     b = eng.harvest(); b.engine = eng; n0 = b.n; copies = max(1, args.cfg3_copies)
     arr = (capi.Capsule * (n0 * copies))()
@@ -140,22 +149,28 @@ def bench_cfg3(args, dist, rank, world, local_rank, backend):
             cpu = {"value": float(r["num_trials"].sum() / dt), "unit": "LM iterations/s", "cores": cores, "kind": "port",
                    "sample": "oracle/srba_oracle.cpp (g++ -O2, %d threads pulling capsules from a shared queue) on the %d local areas of the map, %.1f s" % (cores, n0, dt),
                    "max_chi2_final_rel_diff_vs_gpu_on_converged_windows": float(rel[sane].max()) if sane.any() else None, "converged_windows": int(sane.sum()), "windows": int(n0)}
+        P, L, O, PD = capi.DIMS[b.family]
+        stats = {"per_problem": {k: np.tile(v, copies) for k, v in per_problem_counts(b, b.family).items()}}
+        abytes = algorithmic_bytes(stats, res, P, L, O, PD, relpose=False, schur=True); achieved = abytes / (kernel_ms * 1e-3) / 1e9
         line = {"metric": "LM iterations/sec (and obs/sec) on stereo SE3 local areas with Schur landmark reduction; chi2 match vs CPU", "value": tot_trials * args.steps / max_elapsed, "unit": "LM iterations/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * max_elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                 "config": {"workload": "cfg3-stereo: %d key-frames, 2000 landmarks, stereo fx=200 fy=150 cx=512 cy=384 baseline 0.2 m, range 5 m, px noise 0.5, robust kernel, depth 3: %d local areas x %d replicas re-optimised per step" % (n_kf, n0, copies),
                            "local_areas": n0, "replicas": copies, "unknown_edges_mean_max": [float(nk.mean()), int(nk.max())], "unknown_landmarks_mean_max": [float(nf.mean()), int(nf.max())], "observations_mean_max": [float(no.mean()), int(no.max())],
                            "lm_trials_per_step": trials, "obs_per_s": tot_obs * args.steps / max_elapsed, "map_build_s": round(t_map, 2), "sequential_ms_per_kf": round(1e3 * t_map / n_kf, 3),
                            "parallelism": "replicas x%d" % world, "solver": "Schur complement + LL^t of the reduced system in LDS (dense block layout; windows beyond LDS: HBM-resident layout or the multi-workgroup path)"},
-                "roofline": {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None, "kernel": "k_lm_run<SE3_STEREO>", "kernel_ms": kernel_ms,
-                             "note": "no algorithmic-byte model is defined for the Schur families (SURVEY 8d prices configs[1]); per-phase times: tools/diag_family_phases.py"},
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None, "kernel": "k_lm_run<SE3_STEREO>", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
+                             "note": "algorithmic bytes per SURVEY 8d: K1, K2 + K3 per block, K4 per observation, K5, K6 block writes, per trial K7/K8/K10 per landmark with d observing edges (L*L*8 + d*P*L*8 + L*8 in, d(d+1)/2 P x P blocks read-modify-write) and the dense reduced system (n^2 * 8)"},
                 "cpu_baseline": cpu}
-        print(json.dumps(line), flush=True)
+        if emit:
+            print(json.dumps(line), flush=True)
     ctx.close()
+    if not emit:
+        return line if rank == 0 else None
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()
 
 
-def bench_cfg4(args, dist, rank, world, local_rank, backend):
+def bench_cfg4(args, dist, rank, world, local_rank, backend, emit=True):
     """BASELINE configs[3] family: monocular SE3, max_tree_depth = max_optimize_depth = 8, sub-maps of 20, Schur complement + dense Cholesky. The map is built key-frame by
     key-frame through the engine with the GPU back-end (every define_new_keyframe() is one big-path LM run); a step re-optimises the last --cfg4-windows local areas."""
     import numpy as np
@@ -193,7 +208,7 @@ def bench_cfg4(args, dist, rank, world, local_rank, backend):
         achieved = chol_flops / max(chol_ms, 1e-9) / 1e9   # flop / ms / 1e9 = TFLOP/s
         line = {"metric": "LM iterations/sec (and obs/sec) on a deep monocular SE3 window (Schur + dense Cholesky); chi2 match vs CPU", "value": tot_trials * args.steps / max_elapsed, "unit": "LM iterations/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * max_elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                "config": {"workload": "cfg4-mono-deep (reduced): %d key-frames x %d landmarks, monocular SE3 fx=fy=200 cx=400 cy=320, px noise 0.5, max_tree_depth = max_optimize_depth = 8, submap 20; the last %d local areas re-optimised per step" % (n_kf, n_lm, W),
+                "config": {"workload": "cfg4-mono-deep%s: %d key-frames x %d landmarks, monocular SE3 fx=fy=200 cx=400 cy=320, px noise 0.5, max_tree_depth = max_optimize_depth = 8, submap 20; the last %d local areas re-optimised per step" % ("" if n_kf >= 5000 else " (reduced)", n_kf, n_lm, W),
                            "keyframes": n_kf, "landmarks": n_lm, "unknown_edges": [int(c.n_unk_edges) for c in caps], "unknown_landmarks": [int(c.n_unk_lms) for c in caps], "observations": [int(c.n_obs) for c in caps],
                            "reduced_system": [6 * int(c.n_unk_edges) for c in caps], "lm_trials_per_step": trials, "obs_per_s": tot_obs * args.steps / max_elapsed,
                            "map_build_s": round(t_map, 2), "sequential_ms_per_kf": round(1e3 * t_map / n_kf, 3), "dataset_s": round(t_gen, 2),
@@ -203,8 +218,11 @@ def bench_cfg4(args, dist, rank, world, local_rank, backend):
                              "lane_time_over_step_time": chol_ms / (1e3 * elapsed) if elapsed > 0 else None, "aggregate_TFLOPs_over_timed_region": chol_flops / max(elapsed, 1e-9) / 1e12,
                              "note": "peak = AMD's published FP64 matrix figure for MI355X (the guide lists none); kernel_ms = event time of one factorisation on its stream (several windows are in flight at once on separate streams, so the sum over the lanes can exceed the step time: lane_time_over_step_time); the factorisation is bound by its ~60 dependent launches, DESIGN 4c"},
                 "cpu_baseline": cpu}
-        print(json.dumps(line), flush=True)
+        if emit:
+            print(json.dumps(line), flush=True)
     ctx.close()
+    if not emit:
+        return line if rank == 0 else None
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()
 
@@ -218,7 +236,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = all host cores, at most 64)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"], help="cfg2 = BASELINE configs[1] (the headline metric); cfg3 = stereo SE3 windows with Schur reduction (configs[2]); cfg4 = deep monocular window, Schur + dense Cholesky on the multi-workgroup path")
-    ap.add_argument("--cfg3-kf", type=int, default=80, help="cfg3: key-frames of the stereo map (BASELINE: ~200; beyond ~90 key-frames of this synthetic room the reference algorithm itself loses the map at loop closures -- with the oracle back-end as well, DESIGN 8 -- and the windows stop being meaningful problems)")
+    ap.add_argument("--cfg3-kf", type=int, default=119, help="cfg3: key-frames of the stereo map (BASELINE: ~200). The reference's algorithm as it is loses this map at key-frame 68..77 and, with that repaired, at its first loop closure (95); with the two opt-in repairs (--cfg3-ext) it holds until the loop closure of key-frame 120, where a noisy alignment plus the rho > max_rho stop end it (DESIGN 8). Windows of a lost map are chaotic problems and are neither timed nor compared")
+    ap.add_argument("--cfg3-ext", type=int, default=12, help="cfg3: extension bits of the engine (4 schur_keeps_gradient, 8 consistent_loop_closure_init, 2 restore_spanning_tree_twins; 0 = the reference to the letter, which keeps this map for 67 key-frames)")
+    ap.add_argument("--no-secondary", action="store_true", help="do not append the cfg3 / cfg4 measurements (secondary_workloads) to the cfg2 line")
     ap.add_argument("--cfg3-copies", type=int, default=32, help="cfg3: the harvested local areas are re-optimised in this many replicas per step (fills the chip)")
     ap.add_argument("--cfg4-kf", type=int, default=300, help="key-frames of the cfg4 map (BASELINE: 5000; the depth-8 window saturates at ~260 key-frames, see DESIGN)")
     ap.add_argument("--cfg4-windows", type=int, default=4, help="local areas (the last ones of the map) re-optimised per step")
@@ -237,6 +257,8 @@ def main():
     torch.cuda.set_device(local_rank)
     backend = os.environ.get("SRBA_BENCH_BACKEND", "nccl")
     dist = multi.init_process_group(backend)  # RCCL; used for the barrier and the sum/max of the result line only
+    if world > 1:   # N ranks share the host: each rank's upload (validation, symbolic factorisation, packing) takes its share of the cores instead of min(32, cores) each
+        os.environ.setdefault("SRBA_HIP_UPLOAD_THREADS", str(max(2, (os.cpu_count() or 8) // world)))
 
     import __graft_entry__ as ge
     # one builder per node: N ranks running hipcc / g++ into the same .so files would race (a rank could dlopen a half-written library)
@@ -276,9 +298,10 @@ def main():
     obs_trials_per_step = int((res["num_trials"] * res["num_observations"]).sum())
     for _ in range(args.warmup):
         lib.srba_hip_reset_state(ctx.ctx); lib.srba_hip_lm_run_async(ctx.ctx)
+    enq = [0.0]
     def step():
         lib.srba_hip_reset_state(ctx.ctx)
-        lib.srba_hip_lm_run_async(ctx.ctx)
+        t_e = time.perf_counter(); lib.srba_hip_lm_run_async(ctx.ctx); enq[0] += time.perf_counter() - t_e   # host time spent enqueueing the step (the launches themselves are asynchronous)
 
     def device_sync():
         lib.srba_hip_sync(ctx.ctx)   # the library launches on its own (non-blocking) stream ...
@@ -296,7 +319,7 @@ def main():
         abytes = algorithmic_bytes(stats, res, P, L, O, PD, relpose=True)
         achieved = abytes / (kernel_ms * 1e-3) / 1e9
         cpu = None
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:   # (the CPU leg is a rank-0, N = 1 measurement)
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import _oracle  # tests/_oracle.py: the CPU checker (test infrastructure) -- only this cpu_baseline leg uses it
             # the oracle batched over the host cores (dynamic queue of capsules), on a bounded sample of the same batch
@@ -352,12 +375,24 @@ def main():
                        "parallelism": "replicas x%d (independent maps, no collective)" % world, "solver": "no-Schur, block-sparse LL^t in LDS, symbolic factorisation on the host (reference: CSparse)",
                        "setup_s": {"dataset": round(t_gen, 2), "sequential_slam_harvest_gpu_backend": round(t_harvest, 2), "upload_batch_host_to_hbm": round(t_upload, 3)},
                        "sequential_ms_per_kf": (None if cached else round(1e3 * t_harvest / max(1, args.n_kf), 4)),
+                       "host_enqueue_ms_per_step": 1e3 * enq[0] / max(1, args.steps),
                        "pcie_inclusive_lm_iterations_per_s": trials_per_step / (t_upload + 1e-3 * kernel_ms)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_lm_run<SE2_RELPOSE2D> (one launch per LDS size class, concurrent; duration = fork..join)", "kernel_ms": kernel_ms, "kernel_ms_samples": len(kern_ms), "algorithmic_bytes_per_launch": abytes},
             "cpu_baseline": cpu,
             "streaming_kernels": stream,
         }
+        if world == 1 and not args.no_secondary:   # BASELINE configs[2] and [3] measured in the same (driver-witnessed) run, in short form
+            ctx.close(); sec = {}; import copy
+            for name, fn in (("cfg3", bench_cfg3), ("cfg4", bench_cfg4)):
+                try:
+                    a2 = copy.copy(args); a2.steps = min(args.steps, 5); a2.warmup = 1; a2.cpu_seconds = min(args.cpu_seconds, 5.0)
+                    l2 = fn(a2, None, 0, 1, local_rank, backend, emit=False)
+                    sec[name] = {"value": l2["value"], "unit": l2["unit"], "ms_per_step": l2["ms_per_step"], "steps": l2["steps"], "workload": l2["config"]["workload"], "roofline": l2["roofline"],
+                                 "cpu_baseline": l2["cpu_baseline"], "sequential_ms_per_kf": l2["config"].get("sequential_ms_per_kf")}
+                except Exception as e:  # noqa: BLE001  (a secondary measurement must not take the headline line down)
+                    sec[name] = {"error": repr(e)}
+            line["secondary_workloads"] = sec
         print(json.dumps(line), flush=True)
         if cpu is not None and not (cpu["max_chi2_final_rel_diff_vs_gpu"] <= 1e-6 and cpu["max_chi2_init_rel_diff_vs_gpu"] <= 1e-9):
             raise SystemExit("bench.py: chi2 mismatch GPU vs CPU on the sample (final %.3e, init %.3e): the timing above does not count" % (cpu["max_chi2_final_rel_diff_vs_gpu"], cpu["max_chi2_init_rel_diff_vs_gpu"]))

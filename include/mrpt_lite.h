@@ -10,7 +10,8 @@
  * impl/optimize_edges.h:517-521; impl/determine_kf2kf_edges_to_create.h:54-55,193-197,251;
  * models/observations_*.h (landmark_matcher<>::find_relative_pose).
  *
- * Define SRBA_HAVE_MRPT to use the real library instead (not available in this image).
+ * There is no switch to the real library: these headers always use the value types below (a build against an installed MRPT 1.x would have to convert at the
+ * boundary -- CPose3D::getHomogeneousMatrix <-> storeTo / loadFrom -- and is not provided).
  */
 #pragma once
 #include <algorithm>

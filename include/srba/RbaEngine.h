@@ -27,6 +27,25 @@
 namespace srba {
 
 // -------------------------------------------------------------------------------------------------
+namespace internal {
+/** sigma_max / sigma_min of a dense SYMMETRIC matrix (row-major n x n): its singular values are the moduli of its eigenvalues; cyclic Jacobi rotations.
+ *  Stands where Eigen::JacobiSVD stands in the reference (optimize_edges.h:761-762). */
+inline double symmetric_condition_number(std::vector<double> A, const size_t n) {
+	if (n == 0) return 0;
+	for (int sweep = 0; sweep < 60; sweep++) {
+		double off = 0, diag = 0; for (size_t i = 0; i < n; i++) { diag += A[i * n + i] * A[i * n + i]; for (size_t j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j]; }
+		if (off <= 1e-30 * diag || off == 0) break;
+		for (size_t p = 0; p + 1 < n; p++) for (size_t q = p + 1; q < n; q++) {
+			const double apq = A[p * n + q]; if (apq == 0) continue;
+			const double th = (A[q * n + q] - A[p * n + p]) / (2 * apq), t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1)), c = 1 / std::sqrt(t * t + 1), sn = t * c;
+			for (size_t k = 0; k < n; k++) { const double akp = A[k * n + p], akq = A[k * n + q]; A[k * n + p] = c * akp - sn * akq; A[k * n + q] = sn * akp + c * akq; }
+			for (size_t k = 0; k < n; k++) { const double apk = A[p * n + k], aqk = A[q * n + k]; A[p * n + k] = c * apk - sn * aqk; A[q * n + k] = sn * apk + c * aqk; }
+		}
+	}
+	double mx = 0, mn = std::numeric_limits<double>::infinity(); for (size_t i = 0; i < n; i++) { const double v = std::fabs(A[i * n + i]); mx = std::max(mx, v); mn = std::min(mn, v); }
+	return mx / mn;
+}
+} // namespace internal
 // Numeric back-end seam: replaces the reference's compile-time internal::solver_engine<> together with its CPU loops
 // -------------------------------------------------------------------------------------------------
 struct numeric_backend {
@@ -38,6 +57,9 @@ struct numeric_backend {
 	virtual void set_profiler(mrpt::utils::CTimeLogger *) {}
 	/** Whole-map squared error over prepared path lists (eval_overall_squared_error). */
 	virtual double eval_overall(const srba_hip_params &, const srba_overall_problem &) { throw std::runtime_error(std::string("numeric back-end '") + name() + "' does not implement eval_overall"); }
+	/** Optional: one block array of the capsule just optimised as the back-end left it (3 = HAp, after the last Schur reduction for the Schur solvers; 4 = Hf; 5 = HApf).
+	 *  Serves extra_results.hessian and HAp_condition_number; false if the back-end keeps nothing to read. */
+	virtual bool read_blocks(int /*what*/, std::vector<double> & /*out*/) { return false; }
 };
 /** Adapter over a plain C function (tests plug the CPU oracle in from outside the product this way). */
 struct function_backend : public numeric_backend {
@@ -345,9 +367,12 @@ public:
 		 *  numeric update. The edge then starts metres away, is marked has_approx_init_val (so it is not initialised alone, define_new_keyframe.h:75-76) and the landmark families
 		 *  do not recover. true: inv_pose = pose of `from` w.r.t. `to`, and the observer's pose comes from the initial value just given to its own new edge. */
 		bool consistent_loop_closure_init;
+		/** (extension, default false) fill TOptimizeExtraOutputInfo::extra_results.hessian (dense, row-major, both triangles) after every optimisation: the reference's solvers hand their
+		 *  last system matrix over for free (lev-marq_solvers.h:204-208, :586-590); here it has to be downloaded from the device, so it is done on request only. */
+		bool return_hessian;
 		TSRBAParameters() : max_tree_depth(4), max_optimize_depth(4), optimize_new_edges_alone(true), use_robust_kernel(false), use_robust_kernel_stage1(false), kernel_param(3.), max_iters(20),
 			max_error_per_obs_to_stop(1e-6), max_rho(10.0), max_lambda(1e20), min_error_reduction_ratio_to_relinearize(0.01), numeric_jacobians(false), feedback_user_iteration(NULL),
-			compute_condition_number(false), compute_sparsity_stats(false), max_rmse_show_red_warning(0.5), cov_recovery(crpLandmarksApprox), refresh_all_read_poses(false), restore_spanning_tree_twins(false), schur_keeps_gradient(false), consistent_loop_closure_init(false) {}
+			compute_condition_number(false), compute_sparsity_stats(false), max_rmse_show_red_warning(0.5), cov_recovery(crpLandmarksApprox), refresh_all_read_poses(false), restore_spanning_tree_twins(false), schur_keeps_gradient(false), consistent_loop_closure_init(false), return_hessian(false) {}
 		/** keys of the reference's configuration files (impl/rba_problem_common.h:60-92); cov_recovery by enumerator name or number */
 		void loadFromConfigFile(const mrpt::utils::CConfigFileBase &source, const std::string &section) override {
 			max_tree_depth = (topo_dist_t)source.read<uint64_t>(section, "max_tree_depth", max_tree_depth); max_optimize_depth = (topo_dist_t)source.read<uint64_t>(section, "max_optimize_depth", max_optimize_depth);
@@ -784,7 +809,6 @@ protected:
 		internal::profiler_scope ps(m_profiler, "opt");
 		const int stage = m_capsule_stage; m_capsule_stage = 0;
 		out_info.clear();
-		if (parameters.srba.compute_condition_number) throw std::runtime_error("RbaEngine: parameters.srba.compute_condition_number is not available with the GPU back-end (the Hessian never leaves the device)");
 		if (parameters.srba.numeric_jacobians) throw std::runtime_error("RbaEngine: parameters.srba.numeric_jacobians (debug path of the reference) is not available with the GPU back-end");
 		const int P = REL_POSE_DIMS, L = LM_DIMS, O = OBS_DIMS, PD = (int)pose_t::storage_doubles();
 		graph::topology &T = rba_state.topo;
@@ -824,6 +848,30 @@ protected:
 		out_info.num_total_scalar_optimized = P * nK + L * nF; out_info.num_span_tree_numeric_updates = res.num_span_tree_numeric_updates;
 		out_info.total_sqr_error_init = res.total_sqr_error_init; out_info.total_sqr_error_final = res.total_sqr_error_final; out_info.obs_rmse = res.obs_rmse; out_info.lm = res;
 		out_info.optimized_k2k_edge_indices.assign(ix.edge_ids.begin(), ix.edge_ids.begin() + nK); out_info.optimized_landmark_indices.assign(ix.unk_lms.begin(), ix.unk_lms.end());
+		// The Hessian never leaves the device unless it is asked for (one more download per call): extra_results.hessian as the reference's solvers return it
+		// (lev-marq_solvers.h:204-208, :586-590: the system matrix of the last solve, H + lambda I, reduced by the Schur complement for the Schur solvers) and
+		// HAp_condition_number (optimize_edges.h:753-766: ratio of the extreme singular values of the dense HAp, both triangles)
+		if (parameters.srba.compute_condition_number || parameters.srba.return_hessian) {
+			std::vector<double> hap, hf, hapf;
+			if (!m_backend->read_blocks(3, hap)) throw std::runtime_error(std::string("RbaEngine: numeric back-end '") + m_backend->name() + "' cannot return the Hessian (compute_condition_number / return_hessian)");
+			const size_t nA = (size_t)P * nK; std::vector<double> dA(nA * nA, 0.0);
+			for (size_t b = 0; b < cd.hap_i.size(); b++) { const size_t i = cd.hap_i[b], j = cd.hap_j[b]; // upper blocks (i <= j); diagonal blocks hold both triangles
+				for (int r = 0; r < P; r++) for (int q = 0; q < P; q++) { const double v = hap[b * P * P + r * P + q]; dA[(P * i + r) * nA + P * j + q] = v; if (i != j) dA[(P * j + q) * nA + P * i + r] = v; } }
+			if (parameters.srba.compute_condition_number) out_info.HAp_condition_number = internal::symmetric_condition_number(dA, nA);
+			if (parameters.srba.return_hessian && res.num_trials > 0 && res.num_trials <= SRBA_TRACE_LEN) {
+				const double lam = res.trace_lambda[res.num_trials - 1]; const bool full = !RBA_OPTIONS::solver_t::USE_SCHUR && nF > 0;
+				const size_t n = full ? nA + (size_t)L * nF : nA; std::vector<double> &H = out_info.extra_results.hessian; H.assign(n * n, 0.0);
+				for (size_t r = 0; r < nA; r++) for (size_t q = 0; q < nA; q++) H[r * n + q] = dA[r * nA + q];
+				if (full && m_backend->read_blocks(4, hf) && m_backend->read_blocks(5, hapf)) {
+					for (size_t b = 0; b < cd.hf_i.size(); b++) { const size_t i = cd.hf_i[b], j = cd.hf_j[b];
+						for (int r = 0; r < L; r++) for (int q = 0; q < L; q++) { const double v = hf[b * L * L + r * L + q]; H[(nA + L * i + r) * n + nA + L * j + q] = v; if (i != j) H[(nA + L * j + q) * n + nA + L * i + r] = v; } }
+					for (size_t b = 0; b < cd.hapf_i.size(); b++) { const size_t i = cd.hapf_i[b], j = cd.hapf_j[b];
+						for (int r = 0; r < P; r++) for (int q = 0; q < L; q++) { const double v = hapf[b * P * L + r * L + q]; H[(P * i + r) * n + nA + L * j + q] = v; H[(nA + L * j + q) * n + P * i + r] = v; } }
+				}
+				for (size_t k = 0; k < n; k++) H[k * n + k] += lam;
+				out_info.extra_results.hessian_valid = true;
+			}
+		}
 		if (parameters.srba.compute_sparsity_stats) { // occupancy of the block matrices: non-zero blocks / blocks of the bounding rectangle (reference optimize_edges.h:315-323 over [EXT] MatrixBlockSparseCols::getSparsityStats)
 			out_info.sparsity_dh_dAp_nnz = T.jp.size(); out_info.sparsity_dh_dAp_max_size = T.n_edges() * T.n_observations();
 			size_t ndf = 0, ncol = 0; for (size_t l = 0; l < T.lm_df_count.size(); l++) if (T.lm_base[l] != graph::NIL && !T.lm_known[l]) { ndf += T.lm_df_count[l]; ncol++; }

@@ -6,6 +6,11 @@
  */
 #pragma once
 #include "RbaEngine.h"
+#include <cstdlib>
+
+#ifndef SRBA_DETAILED_TIME_PROFILING
+#	define SRBA_DETAILED_TIME_PROFILING 0   // as in the reference (impl/optimize_edges.h:16-27): define it to 1 before including <srba.h> to get the per-stage "opt.*" sections
+#endif
 
 namespace srba {
 
@@ -16,6 +21,9 @@ public:
 	const char *name() const { return "hip-gfx950"; }
 	void ensure(const srba_hip_params &p) {
 		if (!m_ctx) {
+#if SRBA_DETAILED_TIME_PROFILING
+			setenv("SRBA_HIP_PHASE_TIMING", "1", 1); // the fused kernel keeps one cycle counter per stage and capsule (read below)
+#endif
 			m_ctx = srba_hip_create(m_device, &p);
 			if (!m_ctx) throw std::runtime_error(std::string("srba::hip_backend: cannot create the HIP context: ") + srba_hip_last_error(NULL));
 			m_params = p;
@@ -32,14 +40,34 @@ public:
 		if (m_prof) { m_prof->leave("opt.backend.lm_run"); m_prof->registerUserMeasure("opt.backend.lm_run.kernel", 1e-3 * srba_hip_last_kernel_ms(m_ctx)); m_prof->enter("opt.backend.download"); }
 		check(srba_hip_download_state(m_ctx, &c, 1), "srba_hip_download_state");
 		if (m_prof) m_prof->leave("opt.backend.download");
+#if SRBA_DETAILED_TIME_PROFILING
+		if (m_prof) report_stages(p);
+#endif
 	}
 	void set_profiler(mrpt::utils::CTimeLogger *p) { m_prof = p; }
 	double eval_overall(const srba_hip_params &p, const srba_overall_problem &q) {
 		ensure(p);
 		double v = 0; check(srba_hip_eval_overall_sqr_error(m_ctx, &q, &v), "srba_hip_eval_overall_sqr_error"); return v;
 	}
+	bool read_blocks(int what, std::vector<double> &out) { // the arrays of the capsule of the last run(), still on the device
+		if (!m_ctx || !(what == 3 || what == 4 || what == 5)) return false;
+		const int64_t n = srba_hip_debug_size(m_ctx, what); if (n < 0) return false;
+		out.assign((size_t)std::max<int64_t>(n, 1), 0.0); if (n > 0) check(srba_hip_debug_read(m_ctx, what, out.data(), n), "srba_hip_debug_read"); out.resize((size_t)n); return true;
+	}
 	srba_hip_ctx *context() { return m_ctx; }
 private:
+	/** The reference's detailed sections (impl/optimize_edges.h, impl/lev-marq_solvers.h: DETAILED_PROFILING_ENTER) fed from the stage counters of the fused kernel
+	 *  (100 MHz ticks per stage of the capsule just run). Stages the device fuses are reported under the name of the first one: the backups of optimize_edges.h:486-557 are
+	 *  part of "opt.add_se3_deltas_to_frames", the triplet compression of the sparse solvers does not exist (the symbolic factorisation is done at upload). INTEGRATION.md
+	 *  has the section -> kernel / device function table. */
+	void report_stages(const srba_hip_params &p) {
+		double t[16]; if (srba_hip_debug_size(m_ctx, 10) < 16 || srba_hip_debug_read(m_ctx, 10, t, 16) != 0) return;
+		const bool dense = p.solver == SRBA_SOLVER_SCHUR_DENSE_CHOL;
+		const struct { int slot; const char *name; } map[] = {{0, "opt.update_spanning_tree_num"}, {7, "opt.update_spanning_tree_num"}, {1, "opt.recompute_all_Jacobians"}, {2, "opt.sparse_hessian_update_numeric"},
+			{3, "opt.reprojection_residuals"}, {4, "opt.compute_minus_gradient"}, {6, "opt.add_se3_deltas_to_frames"}, {8, "opt.failedstep_restore_backup"}, {9, "opt.schur_build_reduced"},
+			{10, dense ? "opt.DenseFill" : "opt.SparseTripletFill"}, {11, dense ? "opt.DenseChol" : "opt.SparseChol"}, {12, "opt.backsub"}, {13, "opt.schur_features"}};
+		for (const auto &m : map) if (t[m.slot] > 0) m_prof->registerUserMeasure(m.name, 1e-8 * t[m.slot]);
+	}
 	void check(int rc, const char *what) { if (rc != 0) throw std::runtime_error(std::string("srba::hip_backend: ") + what + " failed: " + srba_hip_last_error(m_ctx)); }
 	srba_hip_ctx *m_ctx; int m_device; srba_hip_params m_params; mrpt::utils::CTimeLogger *m_prof;
 };

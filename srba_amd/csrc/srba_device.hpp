@@ -592,8 +592,14 @@ struct Worker {
 	__device__ __forceinline__ void fresh() { int t = threadIdx.x; asm volatile("" : "+v"(t)); tid = t; }
 	__device__ Worker(const Batch &B_, const ProbDesc &d_, const DevParams &p_) : B(B_), d(d_), prm(p_), tid(threadIdx.x) {}
 
-	__device__ __forceinline__ pose_t pose_at(int idx) const { return idx >= 0 ? PO::ld(B.pose + (d.o_pair * 2 + idx) * PD) : PO::ident(); }
-	__device__ __forceinline__ const double *lm_ptr(int ref) const { return ref >= 0 ? B.ulm + (d.o_ulm + ref) * L : B.klm + (d.o_klm + (-1 - ref)) * L; }
+	// A table index that widens to 64 bits for address arithmetic is made an opaque 64-bit value first. Why: clang 22 (ROCm 7.2) proves `idx >= 0` inside the guarded branch, drops the
+	// extension and, in the 400..512-VGPR landmark kernels, built the register pair v[N:N+1] of the widened index from the loaded dword and a register that had meanwhile been reused for
+	// the high half of a double -- a wild address, HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION (round 2's shelved fault; root cause with the debugger transcript: profiles/r03_fault_root_cause.md).
+	// The empty asm takes the sign-extended value as a 64-bit register operand, so both halves exist before the address is formed. (The relative-pose SE2 kernel, 22 VGPRs under its
+	// two-wavefront budget and never affected, is left as it is.)
+	static __device__ __forceinline__ long long wide(int i) { long long w = i; if constexpr (FAM != SRBA_SE2_RELPOSE2D) asm volatile("" : "+v"(w)); return w; }
+	__device__ __forceinline__ pose_t pose_at(int idx) const { return idx >= 0 ? PO::ld(B.pose + (d.o_pair * 2 + wide(idx)) * PD) : PO::ident(); }
+	__device__ __forceinline__ const double *lm_ptr(int ref) const { return ref >= 0 ? B.ulm + (d.o_ulm + wide(ref)) * L : B.klm + (d.o_klm + wide(-1 - ref)) * L; }
 
 	// ---- K1
 	// edge_lds: optional copy of ALL edge poses of the capsule in LDS (stride PD, local edge order) -- the in-loop refresh then composes from LDS instead of

@@ -736,7 +736,7 @@ struct srba_hip_ctx {
 	size_t off_phase = 0; bool phase_timing = false; long long n_pose_total = 0; std::vector<int> cls_of;
 	// rounds path (srba_rounds.hpp): groups of capsules (LDS size classes, the big ones split) that run their LM rounds on separate streams
 	struct RGroup { int cls, first, count; size_t lds; int rounds_needed /* most LM trials of any of its capsules, once a run's results have been downloaded; else 0 */, rounds_done; int grid[5]; };
-	int rounds_env = -1, rounds_split = 4, rounds_first = 64, rounds_min_batch = 1 << 30 /* (off by default until validated) */; bool rounds_on = false, rounds_pending = false; std::vector<RGroup> rgroups; srbadev::Rounds R; int *h_unfinished = nullptr;
+	int rounds_env = -1, rounds_split = 4, rounds_first = 64, rounds_min_batch = 1 << 30 /* (off by default until validated) */; bool rounds_on = false, rounds_pending = false; int rounds_debug = 0; std::vector<RGroup> rgroups; srbadev::Rounds R; int *h_unfinished = nullptr; std::vector<int> rhist; /* host copy of R.hist once a run's results have been downloaded */
 	static constexpr int kRStreams = 32; hipStream_t rstream[kRStreams] = {nullptr}; hipEvent_t rdone[kRStreams] = {nullptr};
 	void fail(const std::string &m) { error = m; g_last_error = m; }
 };
@@ -879,7 +879,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_LIN_TERMS"); if (e) c->lin_terms = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_LM_TERMS"); if (e) c->lm_terms = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_ROUNDS"); if (e) c->rounds_env = atoi(e); e = getenv("SRBA_HIP_ROUNDS_SPLIT"); if (e && atoi(e) >= 1) c->rounds_split = std::min(atoi(e), 16); e = getenv("SRBA_HIP_ROUNDS_FIRST"); if (e && atoi(e) >= 1) c->rounds_first = atoi(e);
-	  e = getenv("SRBA_HIP_ROUNDS_MIN_BATCH"); if (e) c->rounds_min_batch = atoi(e); }
+	  e = getenv("SRBA_HIP_ROUNDS_MIN_BATCH"); if (e) c->rounds_min_batch = atoi(e); e = getenv("SRBA_HIP_ROUNDS_DEBUG"); if (e) c->rounds_debug = atoi(e); }
 	{ const char *e = getenv("SRBA_HIP_FLAT"); if (e) c->use_flat = atoi(e) != 0; }                     // 0 = one wavefront per capsule for the stepwise spanning-tree launch
 	{ const char *e = getenv("SRBA_HIP_BIG_LANES"); if (e && atoi(e) >= 1) c->big_lanes_max = std::min(atoi(e), kBigLanes); } // large capsules of one batch in flight at once
 	{ const char *e = getenv("SRBA_HIP_BIG_GRAPHS"); if (e) c->big_use_graphs = atoi(e) != 0; }         // 1 = replay the big path's launch sequences as HIP graphs (measured: no gain, the path is bound by its kernels)
@@ -1099,7 +1099,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		plan_launches(c, ord);
 	}
 	// ---- work arena layout
-	Arena wk; struct { size_t edge, ulm, pose, Jp, Jf, resid, resid2, HAp, HAp0, Hf, HApf, grad, delta, Hfinv, YW, old_edge, old_ulm, old_pose, dense, ulm_inf, valid, first_fail, hf_ok, bp_ok, bf_ok, ulm_inf_valid, results, lambda_io, chi2, notpd, phase_cycles, m_pair, grad0, edge1, ulm1, pose1, lmst, rlist, rcount, rctr, runf; } w;
+	Arena wk; struct { size_t edge, ulm, pose, Jp, Jf, resid, resid2, HAp, HAp0, Hf, HApf, grad, delta, Hfinv, YW, old_edge, old_ulm, old_pose, dense, ulm_inf, valid, first_fail, hf_ok, bp_ok, bf_ok, ulm_inf_valid, results, lambda_io, chi2, notpd, phase_cycles, m_pair, grad0, edge1, ulm1, pose1, lmst, rlist, rcount, rctr, runf, rhist; } w;
 	w.edge = wk.add(8 * t_edge * PDX); w.ulm = wk.add(8 * t_ulm * L); w.pose = wk.add(8 * 2 * t_pair * PDX); w.Jp = wk.add(8 * t_bp * O * P); w.Jf = wk.add(8 * t_bf * O * L);
 	w.resid = wk.add(8 * t_obs * O); w.resid2 = wk.add(8 * t_obs * O); w.HAp = wk.add(8 * t_hap * P * P); w.HAp0 = wk.add(8 * t_hap * P * P); w.Hf = wk.add(8 * t_hf * L * L); w.HApf = wk.add(8 * t_hapf * P * L);
 	w.grad = wk.add(8 * t_scal); w.delta = wk.add(8 * t_scal); w.Hfinv = wk.add(8 * t_ulm * L * L); w.YW = wk.add(8 * t_yw * P * L); w.old_edge = wk.add(8 * t_unk * PDX); w.old_ulm = wk.add(8 * t_ulm * L); w.old_pose = wk.add(8 * t_req * PDX);
@@ -1108,7 +1108,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	w.m_pair = wk.add(4 * t_pair);
 	{ const bool r = c->rounds_on; const size_t ng = c->rgroups.size() + 1;
 	  w.edge1 = wk.add(r ? 8 * t_edge * PDX : 0); w.ulm1 = wk.add(r ? 8 * t_ulm * L : 0); w.pose1 = wk.add(r ? 8 * 2 * t_pair * PDX : 0); w.lmst = wk.add(r ? sizeof(srbadev::LmState) * (size_t)n : 0);
-	  w.rlist = wk.add(r ? 4 * 3 * (size_t)n : 0); w.rcount = wk.add(r ? 4 * 3 * ng : 0); w.rctr = wk.add(r ? 4 * 5 * ng : 0); w.runf = wk.add(4); }
+	  w.rlist = wk.add(r ? 4 * 3 * (size_t)n : 0); w.rcount = wk.add(r ? 4 * 3 * ng : 0); w.rctr = wk.add(r ? 4 * 5 * ng : 0); w.runf = wk.add(4); w.rhist = wk.add(r ? 4 * SRBA_ROUNDS_HIST * ng : 0); }
 	w.grad0 = wk.add((c->params.extensions & SRBA_EXT_SCHUR_KEEPS_GRADIENT) ? 8 * t_scal : 0);
 	wk.add(0);
 	if (in.size + 256 > c->cap_in) { if (c->d_in) hipFree(c->d_in); c->d_in = nullptr; c->cap_in = 0; const size_t want = (in.size + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_in, want)); c->cap_in = want; }
@@ -1127,7 +1127,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 #undef DI
 #define DW(field, T) B.field = (T *)(dw + w.field)
 	DW(edge, double); DW(ulm, double); DW(pose, double); DW(Jp, double); DW(Jf, double); DW(resid, double); DW(resid2, double); DW(HAp, double); DW(HAp0, double); DW(Hf, double); DW(HApf, double); DW(grad, double); DW(grad0, double); DW(delta, double); DW(edge1, double); DW(ulm1, double); DW(pose1, double);
-	c->R.st = (srbadev::LmState *)(dw + w.lmst); c->R.list = (int *)(dw + w.rlist); c->R.count = (int *)(dw + w.rcount); c->R.ctr = (int *)(dw + w.rctr); c->R.unfinished = (int *)(dw + w.runf); c->R.n_prob = n;
+	c->R.st = (srbadev::LmState *)(dw + w.lmst); c->R.list = (int *)(dw + w.rlist); c->R.count = (int *)(dw + w.rcount); c->R.ctr = (int *)(dw + w.rctr); c->R.unfinished = (int *)(dw + w.runf); c->R.hist = (int *)(dw + w.rhist); c->R.n_prob = n; c->rhist.clear();
 	DW(Hfinv, double); DW(YW, double); DW(old_edge, double); DW(old_ulm, double); DW(old_pose, double); DW(dense, double); DW(ulm_inf, double); DW(valid, int); DW(first_fail, int); DW(hf_ok, int); DW(bp_ok, unsigned char); DW(bf_ok, unsigned char); DW(ulm_inf_valid, unsigned char);
 	DW(results, srba_lm_result); DW(lambda_io, double); DW(chi2, double); DW(notpd, int);
 	c->flat.pair = (int *)(dw + w.m_pair); c->flat.n_pair = t_pair; c->flat_ready = false;
@@ -1393,6 +1393,7 @@ static int big_run_class(srba_hip_ctx *c, const int32_t *caps, int count) {
 #undef BIGKG
 
 // =================================================================================================== the LM loop as rounds over the batch (srba_rounds.hpp)
+#define RDBG(...) do { if (c->rounds_debug) { std::fprintf(stderr, "[rounds] " __VA_ARGS__); std::fprintf(stderr, "\n"); std::fflush(stderr); } } while (0)
 // grid of a persistent round kernel: what the chip holds of it for that much dynamic LDS, at most one wavefront per capsule
 template <class K> static int rounds_grid(srba_hip_ctx *c, K kernel, size_t lds, int count) {
 	int per_cu = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kernel, SRBA_WG, lds) != hipSuccess || per_cu < 1) per_cu = 1;
@@ -1406,16 +1407,21 @@ static int rounds_enqueue(srba_hip_ctx *c, bool with_init, const std::vector<int
 			if (G.grid[0]) continue;
 			if (allow_big_lds(c, srbadev::kr_init<F>, G.lds) != 0 || allow_big_lds(c, srbadev::kr_solve<F>, G.lds) != 0 || allow_big_lds(c, srbadev::kr_lin<F>, G.lds) != 0) { rc = -1; break; }
 			G.grid[0] = rounds_grid(c, srbadev::kr_init<F>, G.lds, G.count); G.grid[1] = rounds_grid(c, srbadev::kr_solve<F>, G.lds, G.count); G.grid[2] = rounds_grid(c, srbadev::kr_eval<F>, 0, G.count);
-			G.grid[3] = rounds_grid(c, srbadev::kr_lin<F>, G.lds, G.count); G.grid[4] = rounds_grid(c, srbadev::kr_finish<F>, 0, G.count);
+			G.grid[3] = rounds_grid(c, srbadev::kr_lin<F>, G.lds, G.count); G.grid[4] = G.count; // kr_finish: one workgroup per capsule
 		}
 		if (rc != 0) return;
 		if (with_init) for (int g = 0; g < ng; g++) { const srba_hip_ctx::RGroup &G = c->rgroups[g];
-			hipLaunchKernelGGL((srbadev::kr_init<F>), dim3(G.grid[0]), dim3(SRBA_WG), G.lds, c->rstream[g % srba_hip_ctx::kRStreams], c->B, c->dp, c->R, g, G.first, G.count); }
+			hipLaunchKernelGGL((srbadev::kr_init<F>), dim3(G.grid[0]), dim3(SRBA_WG), G.lds, c->rstream[g % srba_hip_ctx::kRStreams], c->B, c->dp, c->R, g, G.first, G.count);
+			if (c->rounds_debug >= 3) { hipError_t e = hipStreamSynchronize(c->rstream[g % srba_hip_ctx::kRStreams]); int cnt3[3] = {0, 0, 0}; hipMemcpy(cnt3, c->R.count + 3 * g, 12, hipMemcpyDeviceToHost); RDBG("init of group %d done: %s; active %d", g, hipGetErrorString(e), cnt3[0]); } }
 		int rmax = 0; for (int g = 0; g < ng; g++) rmax = std::max(rmax, r1[g]);
 		for (int r = 0; r < rmax; r++) for (int g = 0; g < ng; g++) { const srba_hip_ctx::RGroup &G = c->rgroups[g]; if (r < r0[g] || r >= r1[g]) continue; hipStream_t st = c->rstream[g % srba_hip_ctx::kRStreams];
-			hipLaunchKernelGGL((srbadev::kr_solve<F>), dim3(G.grid[1]), dim3(SRBA_WG), G.lds, st, c->B, c->dp, c->R, g, G.first, r);
-			hipLaunchKernelGGL((srbadev::kr_eval<F>), dim3(G.grid[2]), dim3(SRBA_WG), 0, st, c->B, c->dp, c->R, g, G.first, r);
-			hipLaunchKernelGGL((srbadev::kr_lin<F>), dim3(G.grid[3]), dim3(SRBA_WG), G.lds, st, c->B, c->dp, c->R, g, G.first, r); }
+			// a launch is as wide as the list of the round was in the previous run of this batch (any width is correct: a workgroup takes further capsules from a counter); a late
+			// round has a handful of capsules, and thousands of workgroups that start only to find the list empty cost more than the round's work
+			int cap = G.count; if (!c->rhist.empty() && r < SRBA_ROUNDS_HIST) cap = std::max(1, std::min(G.count, c->rhist[(size_t)g * SRBA_ROUNDS_HIST + r] + 8));
+			hipLaunchKernelGGL((srbadev::kr_solve<F>), dim3(std::min(G.grid[1], cap)), dim3(SRBA_WG), G.lds, st, c->B, c->dp, c->R, g, G.first, r);
+			hipLaunchKernelGGL((srbadev::kr_eval<F>), dim3(std::min(G.grid[2], cap)), dim3(SRBA_WG), 0, st, c->B, c->dp, c->R, g, G.first, r);
+			hipLaunchKernelGGL((srbadev::kr_lin<F>), dim3(std::min(G.grid[3], cap)), dim3(SRBA_WG), G.lds, st, c->B, c->dp, c->R, g, G.first, r);
+			if (c->rounds_debug >= 3) { hipError_t e = hipStreamSynchronize(st); int cnt3[3] = {0, 0, 0}; hipMemcpy(cnt3, c->R.count + 3 * g, 12, hipMemcpyDeviceToHost); RDBG("round %d of group %d done: %s; lists %d %d %d", r, g, hipGetErrorString(e), cnt3[0], cnt3[1], cnt3[2]); } }
 		for (int g = 0; g < ng; g++) { const srba_hip_ctx::RGroup &G = c->rgroups[g];
 			hipLaunchKernelGGL((srbadev::kr_finish<F>), dim3(G.grid[4]), dim3(SRBA_WG), 0, c->rstream[g % srba_hip_ctx::kRStreams], c->B, c->dp, c->R, g, G.first, G.count); }
 	});
@@ -1438,11 +1444,15 @@ static int rounds_join(srba_hip_ctx *c) {
 }
 static int rounds_run_async(srba_hip_ctx *c) {
 	const int ng = (int)c->rgroups.size();
+	RDBG("run: %d groups, %d capsules", ng, c->n_prob);
 	// counters of the round kernels, list lengths, the "still iterating" count: all zero at the start of a run
 	HIPCHK(c, hipMemsetAsync(c->R.count, 0, sizeof(int) * 3 * (size_t)(ng + 1), c->stream)); HIPCHK(c, hipMemsetAsync(c->R.ctr, 0, sizeof(int) * 5 * (size_t)(ng + 1), c->stream)); HIPCHK(c, hipMemsetAsync(c->R.unfinished, 0, sizeof(int), c->stream));
+	if (ng) HIPCHK(c, hipMemsetAsync(c->R.hist, 0, sizeof(int) * SRBA_ROUNDS_HIST * (size_t)ng, c->stream));
 	if (ng) { if (rounds_fork(c) != 0) return -1;
 		std::vector<int> r0(ng, 0), r1(ng); for (int g = 0; g < ng; g++) r1[g] = c->rgroups[g].rounds_needed > 0 ? c->rgroups[g].rounds_needed : c->rounds_first; // (a round = one LM trial of every capsule still iterating)
-		if (rounds_enqueue(c, true, r0, r1) != 0) return -1; }
+		if (rounds_enqueue(c, true, r0, r1) != 0) return -1;
+		RDBG("enqueued: rounds of group 0 = %d", r1[0]);
+		if (c->rounds_debug >= 2) { for (int g = 0; g < ng; g++) { hipError_t e = hipStreamSynchronize(c->rstream[g % srba_hip_ctx::kRStreams]); RDBG("group %d (class %d, first %d, count %d, lds %zu, grids %d %d %d %d %d) synchronised: %s", g, c->rgroups[g].cls, c->rgroups[g].first, c->rgroups[g].count, c->rgroups[g].lds, c->rgroups[g].grid[0], c->rgroups[g].grid[1], c->rgroups[g].grid[2], c->rgroups[g].grid[3], c->rgroups[g].grid[4], hipGetErrorString(e)); } } }
 	int big_rc = 0; { const int32_t *ord = (const int32_t *)(c->h_in.get() + c->h_off_order); big_rc = big_run_class(c, ord + c->cls_first[SRBA_NCLS - 1], c->cls_count[SRBA_NCLS - 1]); }
 	if (ng && rounds_join(c) != 0) return -1;
 	HIPCHK(c, hipEventRecord(c->ev1, c->stream));
@@ -1456,6 +1466,7 @@ static int rounds_complete(srba_hip_ctx *c) {
 	c->rounds_pending = false; const int ng = (int)c->rgroups.size();
 	for (int pass = 0; pass < 64; pass++) {
 		int unf = 0; HIPCHK(c, hipMemcpyAsync(&unf, c->R.unfinished, sizeof(int), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+		RDBG("complete: pass %d, %d capsules still iterating", pass, unf);
 		if (unf == 0) return 0;
 		HIPCHK(c, hipMemsetAsync(c->R.unfinished, 0, sizeof(int), c->stream));
 		for (int g = 0; g < ng; g++) { HIPCHK(c, hipMemsetAsync(c->R.ctr + 5 * g + 4, 0, sizeof(int), c->stream)); }
@@ -1557,7 +1568,9 @@ int srba_hip_download_results(srba_hip_ctx *c, srba_lm_result *results, int n) {
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	if (c->rounds_on && n == c->n_prob) { // the rounds a later run of this batch needs: one per LM trial of the slowest capsule of each group
 		const int32_t *ord = (const int32_t *)(c->h_in.get() + c->h_off_order);
-		for (auto &G : c->rgroups) { int mx = 0; for (int i = 0; i < G.count; i++) mx = std::max(mx, (int)results[ord[G.first + i]].num_trials); G.rounds_needed = mx + 1; } }
+		for (auto &G : c->rgroups) { int mx = 0; for (int i = 0; i < G.count; i++) mx = std::max(mx, (int)results[ord[G.first + i]].num_trials); G.rounds_needed = mx + 1; }
+		c->rhist.assign((size_t)SRBA_ROUNDS_HIST * c->rgroups.size(), 0);
+		if (!c->rhist.empty()) { HIPCHK(c, hipMemcpyAsync(c->rhist.data(), c->R.hist, sizeof(int) * c->rhist.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); } }
 	return 0;
 }
 int srba_hip_lm_run(srba_hip_ctx *c, srba_lm_result *results) {

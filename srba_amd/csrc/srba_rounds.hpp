@@ -20,6 +20,7 @@
 
 namespace srbadev {
 
+#define SRBA_ROUNDS_HIST 256
 struct LmState {        // per capsule; wave-uniform, read by every lane, written by lane 0
 	double lambda, nu, total_err, rmse, rho_last;
 	int iter, trials, n_notpd, n_acc, n_relin, stopmask, stop;
@@ -32,7 +33,7 @@ struct LmState {        // per capsule; wave-uniform, read by every lane, writte
 };
 struct Rounds {
 	LmState *st; int *list /* three rotating lists of n_prob entries (a group uses [first, first + count) of each) */; int *count /* [group][3] */;
-	int *ctr /* [group][5]: work counters of kr_solve / kr_eval / kr_lin, kr_init, kr_finish */; int *unfinished; int n_prob;
+	int *ctr /* [group][5]: work counters of kr_solve / kr_eval / kr_lin, kr_init, kr_finish */; int *unfinished; int *hist /* [group][SRBA_ROUNDS_HIST]: capsules still iterating at every round of the last run */; int n_prob;
 };
 
 // the state of a capsule is the same for all lanes: keep it in scalar registers
@@ -61,8 +62,7 @@ template <int FAM> __device__ __forceinline__ bool rounds_hess_terms(const Batch
 // ---- S5 .. S14 of optimize_edges() for every capsule of a group, then the head of the first LM pass
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) kr_init(const Batch B, const DevParams prm, const Rounds R, int g, int first, int count) {
 	typedef Solver<FAM> SV; constexpr int P = SV::P, L = SV::L, O = SV::O, PD = SV::PD;
-	for (;;) {
-		const int i = rounds_pull(R.ctr + 5 * g + 3); if (i >= count) break;
+	for (int i = blockIdx.x; i < count; i = gridDim.x + rounds_pull(R.ctr + 5 * g + 3)) { // first capsule: one per workgroup, no atomic; then the shared counter
 		const int pidx = B.order[first + i]; const ProbDesc &d = B.desc[pidx]; const int tid = threadIdx.x;
 		SV S(B, d, prm); srba_lm_result *out = B.results + pidx; double *red = nullptr;
 		S.phase_spantree(false); __syncthreads();
@@ -80,7 +80,8 @@ template <int FAM> __global__ void __launch_bounds__(SRBA_WG) kr_init(const Batc
 			for (int k = 0; k < SRBA_TRACE_LEN; k++) { out->trace_chi2[k] = NAN; out->trace_lambda[k] = NAN; out->trace_rho[k] = NAN; }
 		}
 		LmState s; s.lambda = 0; s.nu = 2.0; s.total_err = 0; s.rmse = 0; s.rho_last = 0; s.iter = s.trials = s.n_notpd = s.n_acc = s.n_relin = s.stopmask = s.stop = 0; s.phase = 1; s.cur = s.rcur = s.solved = s.need_lin = s.last_rejected = s.pad = 0;
-		if ((long long)O * d.n_obs < (long long)d.n_scal) { if (tid == 0) { out->status = 1; R.st[pidx] = s; } __syncthreads(); continue; } // S11
+		if ((long long)O * d.n_obs < (long long)d.n_scal) { if (tid == 0) { out->status = 1; R.st[pidx] = s; } } // S11
+		else {
 		s.lambda = S.lambda_guess(red);
 		s.total_err = S.phase_residuals(B.resid, red); s.rmse = sqrt(s.total_err / d.n_obs);
 		if (tid == 0) { out->lambda_init = s.lambda; out->total_sqr_error_init = s.total_err; }
@@ -89,6 +90,7 @@ template <int FAM> __global__ void __launch_bounds__(SRBA_WG) kr_init(const Batc
 		rounds_enter_iteration(s, prm);
 		if (tid == 0) R.st[pidx] = s;
 		if (s.phase == 0) rounds_append(R, g, 0, first, pidx);
+		}
 		__syncthreads(); // the LDS accumulators are reused by the next capsule
 	}
 }
@@ -97,10 +99,9 @@ template <int FAM> __global__ void __launch_bounds__(SRBA_WG) kr_init(const Batc
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) kr_solve(const Batch B, const DevParams prm, const Rounds R, int g, int first, int round) {
 	typedef Solver<FAM> SV; constexpr int P = SV::P, L = SV::L, PD = SV::PD; typedef typename SV::W::PO PO; typedef typename SV::W::pose_t pose_t;
 	const int rd = round % 3, wr = (round + 1) % 3, zr = (round + 2) % 3; int *cnt = R.count + 3 * g, *ctr = R.ctr + 5 * g;
-	if (blockIdx.x == 0 && threadIdx.x == 0) { ctr[1] = 0; cnt[zr] = 0; } // the counter of this round's kr_eval; the list the NEXT round will fill
 	const int n = cnt[rd]; const int *list = R.list + (size_t)rd * R.n_prob + first;
-	for (;;) {
-		const int i = rounds_pull(ctr + 0); if (i >= n) break;
+	if (blockIdx.x == 0 && threadIdx.x == 0) { ctr[1] = 0; cnt[zr] = 0; if (round < SRBA_ROUNDS_HIST) R.hist[g * SRBA_ROUNDS_HIST + round] = n; } // the counter of this round's kr_eval; the list the NEXT round will fill; how many capsules this round has (sizes the launches of the next run) const int *list = R.list + (size_t)rd * R.n_prob + first;
+	for (int i = blockIdx.x; i < n; i = gridDim.x + rounds_pull(ctr + 0)) { // (a workgroup beyond the list leaves without touching the counter: late rounds launch far more workgroups than capsules)
 		const int pidx = rounds_uni(list[i]); const ProbDesc &d = B.desc[pidx]; const int tid = threadIdx.x;
 		LmState s = rounds_state(R.st + pidx); srba_lm_result *out = B.results + pidx;
 		const Batch Ba = rounds_view(B, s.cur); SV S(Ba, d, prm);
@@ -134,9 +135,9 @@ template <int FAM> __global__ void __launch_bounds__(SRBA_WG) kr_eval(const Batc
 	const int rd = round % 3, wr = (round + 1) % 3; int *cnt = R.count + 3 * g, *ctr = R.ctr + 5 * g;
 	if (blockIdx.x == 0 && threadIdx.x == 0) ctr[2] = 0;
 	const int n = cnt[rd]; const int *list = R.list + (size_t)rd * R.n_prob + first;
-	for (;;) {
-		const int i = rounds_pull(ctr + 1); if (i >= n) break;
-		const int pidx = rounds_uni(list[i]); LmState s = rounds_state(R.st + pidx); if (!s.solved) continue;
+	for (int i = blockIdx.x; i < n; i = gridDim.x + rounds_pull(ctr + 1)) { // (a workgroup beyond the list leaves without touching the counter: late rounds launch far more workgroups than capsules)
+		const int pidx = rounds_uni(list[i]); LmState s = rounds_state(R.st + pidx);
+		if (s.solved) { // (no `continue` in these loops: one structured body per capsule)
 		const ProbDesc &d = B.desc[pidx]; const int tid = threadIdx.x; srba_lm_result *out = B.results + pidx; double *red = nullptr;
 		const Batch Bt = rounds_view(B, s.cur ^ 1); SV S(Bt, d, prm);
 		S.phase_spantree(true); __syncthreads();
@@ -157,6 +158,7 @@ template <int FAM> __global__ void __launch_bounds__(SRBA_WG) kr_eval(const Batc
 		}
 		if (tid == 0) R.st[pidx] = s;
 		if (s.phase == 0 && !s.need_lin) rounds_append(R, g, wr, first, pidx);
+		}
 	}
 }
 
@@ -166,9 +168,9 @@ template <int FAM> __global__ void __launch_bounds__(SRBA_WG) kr_lin(const Batch
 	const int rd = round % 3, wr = (round + 1) % 3; int *cnt = R.count + 3 * g, *ctr = R.ctr + 5 * g;
 	if (blockIdx.x == 0 && threadIdx.x == 0) ctr[0] = 0; // the counter of the next round's kr_solve
 	const int n = cnt[rd]; const int *list = R.list + (size_t)rd * R.n_prob + first;
-	for (;;) {
-		const int i = rounds_pull(ctr + 2); if (i >= n) break;
-		const int pidx = rounds_uni(list[i]); LmState s = rounds_state(R.st + pidx); if (!s.need_lin) continue;
+	for (int i = blockIdx.x; i < n; i = gridDim.x + rounds_pull(ctr + 2)) { // (a workgroup beyond the list leaves without touching the counter: late rounds launch far more workgroups than capsules)
+		const int pidx = rounds_uni(list[i]); LmState s = rounds_state(R.st + pidx);
+		if (s.need_lin) {
 		const ProbDesc &d = B.desc[pidx]; const int tid = threadIdx.x; double *red = nullptr;
 		const Batch Ba = rounds_view(B, s.cur); SV S(Ba, d, prm);
 		const double *resid = s.rcur ? B.resid2 : B.resid;
@@ -183,45 +185,44 @@ template <int FAM> __global__ void __launch_bounds__(SRBA_WG) kr_lin(const Batch
 		s.iter++; rounds_enter_iteration(s, prm); // the inner loop ended with rho > 0: the pass is over
 		if (tid == 0) R.st[pidx] = s;
 		if (s.phase == 0) rounds_append(R, g, wr, first, pidx);
+		}
 		__syncthreads(); // the LDS accumulators are reused by the next capsule
 	}
 }
 
-// ---- S17 + results; the accepted state goes back to the primary arrays (what srba_hip_download_state reads), with the reference's twin semantics
+// ---- S17 + results; the accepted state goes back to the primary arrays (what srba_hip_download_state reads), with the reference's twin semantics. One workgroup per capsule.
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) kr_finish(const Batch B, const DevParams prm, const Rounds R, int g, int first, int count) {
 	typedef Solver<FAM> SV; constexpr int L = SV::L, PD = SV::PD;
-	for (;;) {
-		const int i = rounds_pull(R.ctr + 5 * g + 4); if (i >= count) break;
-		const int pidx = B.order[first + i]; const ProbDesc &d = B.desc[pidx]; const int tid = threadIdx.x; srba_lm_result *out = B.results + pidx;
-		LmState s = rounds_state(R.st + pidx);
-		if (s.phase == 0) { if (tid == 0) atomicAdd(R.unfinished, 1); continue; } // still iterating: the host enqueues more rounds (rounds_complete)
-		if (s.phase == 2 || B.results[pidx].status != 0) continue;
-		if (!s.stop) s.stopmask |= 1 << SRBA_STOP_MAX_ITERS;
-		const Batch Ba = rounds_view(B, s.cur), Bt = rounds_view(B, s.cur ^ 1);
-		// a rejected trial refreshed BOTH poses of every pair in use, the reference then restored only the ones Jacobian blocks read (optimize_edges.h:664-670)
-		if (s.last_rejected) for (int q = tid; q < 2 * d.n_need; q += SRBA_WG) {
-			const long long ps = 2LL * B.need_idx[d.o_pair + (q >> 1)] + (q & 1);
-			if (!B.pose_req[d.o_pair * 2 + ps]) { double v[PD]; ldn<PD>(v, Bt.pose + (d.o_pair * 2 + ps) * PD); stn<PD>(Ba.pose + (d.o_pair * 2 + ps) * PD, v); }
+	if ((int)blockIdx.x >= count) return;
+	const int pidx = B.order[first + blockIdx.x]; const ProbDesc &d = B.desc[pidx]; const int tid = threadIdx.x; srba_lm_result *out = B.results + pidx;
+	LmState s = rounds_state(R.st + pidx);
+	if (s.phase == 0) { if (tid == 0) atomicAdd(R.unfinished, 1); return; } // still iterating: the host enqueues more rounds (rounds_complete)
+	if (s.phase == 2 || out->status != 0) return;                           // results already written by an earlier kr_finish / under-determined problem
+	if (!s.stop) s.stopmask |= 1 << SRBA_STOP_MAX_ITERS;
+	const Batch Ba = rounds_view(B, s.cur), Bt = rounds_view(B, s.cur ^ 1);
+	// a rejected trial refreshed BOTH poses of every pair in use, the reference then restored only the ones Jacobian blocks read (optimize_edges.h:664-670)
+	if (s.last_rejected) for (int q = tid; q < 2 * d.n_need; q += SRBA_WG) {
+		const long long ps = 2LL * B.need_idx[d.o_pair + (q >> 1)] + (q & 1);
+		if (!B.pose_req[d.o_pair * 2 + ps]) { double v[PD]; ldn<PD>(v, Bt.pose + (d.o_pair * 2 + ps) * PD); stn<PD>(Ba.pose + (d.o_pair * 2 + ps) * PD, v); }
+	}
+	__syncthreads();
+	if (s.cur) { // the accepted copy is the second one: bring what can differ (unknowns, refreshed pairs) back to the primary arrays
+		for (int k = tid; k < d.nK * PD; k += SRBA_WG) B.edge[d.o_edge * PD + k] = B.edge1[d.o_edge * PD + k];
+		for (int k = tid; k < d.nF * L; k += SRBA_WG) B.ulm[d.o_ulm * L + k] = B.ulm1[d.o_ulm * L + k];
+		for (int q = tid; q < 2 * d.n_need; q += SRBA_WG) { const long long ps = 2LL * B.need_idx[d.o_pair + (q >> 1)] + (q & 1); double v[PD]; ldn<PD>(v, B.pose1 + (d.o_pair * 2 + ps) * PD); stn<PD>(B.pose + (d.o_pair * 2 + ps) * PD, v); }
+	}
+	if constexpr (!SV::W::T::REL) { // S17: crpLandmarksApprox
+		SV S(Ba, d, prm);
+		for (int l = tid; l < d.nF; l += SRBA_WG) {
+			const bool ok = prm.cov_recovery == 1 && (S.schur_active() ? (B.hf_ok[d.o_ulm + l] != 0) : true);
+			B.ulm_inf_valid[d.o_ulm + l] = ok ? 1 : 0;
+			if (ok) for (int k = 0; k < L * L; k++) B.ulm_inf[(d.o_ulm + l) * L * L + k] = B.Hf[(d.o_hf + B.hf_diag[d.o_ulm + l]) * L * L + k];
 		}
-		__syncthreads();
-		if (s.cur) { // the accepted copy is the second one: bring what can differ (unknowns, refreshed pairs) back to the primary arrays
-			for (int k = tid; k < d.nK * PD; k += SRBA_WG) B.edge[d.o_edge * PD + k] = B.edge1[d.o_edge * PD + k];
-			for (int k = tid; k < d.nF * L; k += SRBA_WG) B.ulm[d.o_ulm * L + k] = B.ulm1[d.o_ulm * L + k];
-			for (int q = tid; q < 2 * d.n_need; q += SRBA_WG) { const long long ps = 2LL * B.need_idx[d.o_pair + (q >> 1)] + (q & 1); double v[PD]; ldn<PD>(v, B.pose1 + (d.o_pair * 2 + ps) * PD); stn<PD>(B.pose + (d.o_pair * 2 + ps) * PD, v); }
-		}
-		if constexpr (!SV::W::T::REL) { // S17: crpLandmarksApprox
-			SV S(Ba, d, prm);
-			for (int l = tid; l < d.nF; l += SRBA_WG) {
-				const bool ok = prm.cov_recovery == 1 && (S.schur_active() ? (B.hf_ok[d.o_ulm + l] != 0) : true);
-				B.ulm_inf_valid[d.o_ulm + l] = ok ? 1 : 0;
-				if (ok) for (int k = 0; k < L * L; k++) B.ulm_inf[(d.o_ulm + l) * L * L + k] = B.Hf[(d.o_hf + B.hf_diag[d.o_ulm + l]) * L * L + k];
-			}
-		}
-		if (tid == 0) {
-			out->num_iters = s.iter; out->num_trials = s.trials; out->num_not_pd = s.n_notpd; out->num_accepted = s.n_acc; out->num_relinearized = s.n_relin; out->stop_reason = s.stopmask;
-			out->total_sqr_error_final = s.total_err; out->obs_rmse = s.rmse; out->lambda_final = s.lambda;
-			s.phase = 2; R.st[pidx] = s; // results written: a later kr_finish (after extra rounds) leaves this capsule alone
-		}
+	}
+	if (tid == 0) {
+		out->num_iters = s.iter; out->num_trials = s.trials; out->num_not_pd = s.n_notpd; out->num_accepted = s.n_acc; out->num_relinearized = s.n_relin; out->stop_reason = s.stopmask;
+		out->total_sqr_error_final = s.total_err; out->obs_rmse = s.rmse; out->lambda_final = s.lambda;
+		s.phase = 2; R.st[pidx] = s;
 	}
 }
 

@@ -33,7 +33,17 @@ def save(name, eng, first, count):
     print("%-28s %d capsules, %d bytes" % (name, sub.n, os.path.getsize(path)))
 
 
+def new_families():
+    """the two families added in round 2 (fixtures added in round 3; the older fixtures are left as they are)"""
+    ds, _ = datasets.graph_slam_se3(n_kf=40, seed=6)
+    eng = runner.graph_slam_engine_se3(backend=_oracle.BACKEND); eng.run(ds); save("lm_relpose3d", eng, 30, 4)
+    ds, _ = datasets.landmarks_dataset_se2_stereo(n_kf=16, n_lm=90, seed=7, noise=0.1)
+    eng = runner.landmark_engine("stereo_se2", backend=_oracle.BACKEND); eng.run(ds); save("lm_stereo_se2", eng, 12, 3)
+
+
 def main():
+    if "--new-families" in sys.argv:
+        return new_families()
     # C-1: tests/submaps_edge_init_values.cpp (loop closure at KF 11)
     eng = runner.graph_slam_engine(backend=_oracle.BACKEND, submap=5, depth=3, sigma_xy=1e-3, sigma_yaw_deg=0.05, solver=capi.SOLVER_SCHUR_DENSE, max_error_per_obs_to_stop=1e-6)
     eng.run(datasets.graph_slam_from_entries(datasets.C1_SUBMAPS, 1e-3, np.radians(0.05), seed=1)); save("c1_submaps_se2", eng, 8, 6)
@@ -50,6 +60,7 @@ def main():
     for kind, noise in (("cart3d", 1e-3), ("rb3d", 1e-3), ("stereo", 0.1), ("mono", 0.1)):
         ds, _ = datasets.landmarks_dataset_se3(kind, n_kf=12, n_lm=300, seed=5, noise=noise, init_from_gt_noise=(0.2 if kind == "mono" else None))
         eng = runner.landmark_engine(kind, backend=_oracle.BACKEND, robust=(1 if kind == "stereo" else 0)); eng.run(ds); save("lm_" + kind, eng, 9, 3)
+    new_families()
 
 
 if __name__ == "__main__":

@@ -33,3 +33,25 @@ def test_bench_two_ranks_one_json_line(tmp_path):
     total_per_step = d["value"] * d["ms_per_step"] * 1e-3
     assert 1.6 * per_rank < total_per_step < 2.4 * per_rank      # two different maps of the same size
     assert d["roofline"]["frac"] > 0 and d["roofline"]["kernel_ms_samples"] == 3
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_line_comes_out(tmp_path):
+    """The driver's N = 8 launch line. With fewer than 8 devices the ranks share device 0 over gloo (a readiness check of the launch / harvest / aggregate logic, not a
+    scaling measurement): one JSON line, n_gpus = 8, whole-job value = the eight maps' trials over the slowest rank's time, inside a few minutes."""
+    import time
+    import torch
+    env = dict(os.environ)
+    if torch.cuda.device_count() < 8:
+        env.update(SRBA_BENCH_DEVICE="0", SRBA_BENCH_BACKEND="gloo")
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--n-kf", "500", "--cpu-seconds", "0", "--cache-dir", str(tmp_path)]
+    t0 = time.time(); p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT); dt = time.time() - t0
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and dt < 600
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and "replicas x8" in d["config"]["parallelism"] and d["cpu_baseline"] is None and "secondary_workloads" not in d
+    per_rank = d["config"]["lm_trials_per_step_per_gpu"]; total_per_step = d["value"] * d["ms_per_step"] * 1e-3
+    assert 6.4 * per_rank < total_per_step < 9.6 * per_rank

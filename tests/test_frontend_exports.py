@@ -37,3 +37,33 @@ def test_dot_scene_config_and_mrpt_stand_ins(tmp_path):
     assert v["cam_left"] == ["200", "150", "512", "384", "1024"] and v["cam_right"] == ["201", "151", "511", "383"] and v["cam_baseline"] == ["0.2"]
     assert float(v["pose_roundtrip"][0]) < 1e-12 and v["eigen_alias"] == ["4", "9"]
     assert abs(float(v["gauss_mean"][0]) - 2.0) < 0.02 and abs(float(v["gauss_std"][0]) - 0.5) < 0.02
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_hessian_condition_number_and_detailed_profiler_sections(tmp_path):
+    """What the reference hands back next to the unknowns, through the front-end with the GPU back-end (tests/cpp/extra_results_gpu.cpp): extra_results.hessian = the
+    system matrix of the last LM trial (symmetric, positive definite, 3 x unknown edges), HAp_condition_number, and the reference's per-stage opt.* profiler sections
+    (SRBA_DETAILED_TIME_PROFILING) fed from the stage counters of the fused kernel."""
+    import __graft_entry__ as ge
+    ge.build()
+    exe = str(tmp_path / "extra_results_gpu")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "include", "mrpt_shims"), os.path.join(ROOT, "tests", "cpp", "extra_results_gpu.cpp"), "-o", exe,
+                    "-L" + os.path.join(ROOT, "srba_amd", "lib"), "-lsrba_hip", "-Wl,-rpath," + os.path.join(ROOT, "srba_amd", "lib")], check=True, timeout=600)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    v = {}; sec = {}
+    for l in p.stdout.splitlines():
+        w = l.split()
+        if w and w[0] == "section": sec[w[1]] = float(w[2])
+        elif w: v[w[0]] = w[1]
+    n = 3 * int(v["edges"])
+    assert int(v["edges"]) == 2 and v["hessian_valid"] == "1" and int(v["hessian_size"]) == n * n
+    assert float(v["hessian_asym"]) == 0.0 and v["hessian_pd"] == "1" and float(v["hessian_min_diag"]) > 0
+    assert 1.0 <= float(v["condition_number"]) < 1e12 and float(v["rmse"]) < 1.0
+    for name in ("opt", "opt.update_spanning_tree_num", "opt.recompute_all_Jacobians", "opt.sparse_hessian_update_numeric", "opt.reprojection_residuals", "opt.compute_minus_gradient",
+                 "opt.schur_build_reduced", "opt.DenseFill", "opt.DenseChol", "opt.backsub", "opt.schur_features", "opt.add_se3_deltas_to_frames"):
+        assert sec[name] > 0, name
+    assert sec["opt"] > sec["opt.DenseChol"]

@@ -431,32 +431,36 @@ def test_large_batch_moves_wide_lds_images_to_hbm(kind):
 
 
 @pytest.mark.gpu
-def test_ill_conditioned_mono_windows_match_wherever_the_reference_pins_them():
-    """The gauge-free monocular map (round 2's dataset of the test above): its windows are ill-conditioned enough that the reference's own Schur+dense and Schur+sparse
-    solvers part ways (tests/test_conditioning.py), so chi2_final is not a reference-defined number there. What IS defined is every trial up to the one where the two
-    reference code paths stop agreeing with each other: on that prefix the GPU must take the same accept / reject decisions as the oracle and reproduce every accepted
-    chi2 -- to 1e-6, or to 100x the reference's own solver-to-solver spread at that trial where that is larger (the spread grows geometrically along the trace)."""
+def test_lost_monocular_map_agrees_up_to_a_rounding_floor_decision():
+    """The gauge-free monocular map (round 2's dataset of the test above) is LOST (RMSE ~ 100 px, chi2 ~ 1e7): its windows are not problems whose minimum the reference's arithmetic
+    defines to 1e-6 -- on some hosts the oracle's own Schur+dense and Schur+sparse code paths end 1e-5 apart on them. What two correct implementations must still share:
+    every trial up to the first accept / reject decision they take differently, that decision being a coin toss at the rounding floor (the trial moves chi2 by less than 1e-6 of its
+    value in BOTH runs), and on that common prefix every accepted chi2 at 1e-6 and the same lambda schedule. Where the runs never part (most windows) the final chi2 agrees at 1e-6;
+    where they do, the continuations are different but both legitimate (one run may stop on rho > max_rho or lambda > max_lambda a dozen trials before the other: round 2's
+    "4e-4 window")."""
     ds = _mono_dataset(False)
     eng = runner.landmark_engine("mono", backend=_oracle.BACKEND); eng.run(ds); b = eng.harvest(); b.engine = eng
-    r0 = _oracle.run_batch(b); b.params.solver = capi.SOLVER_SCHUR_SPARSE; r1 = _oracle.run_batch(b); b.params.solver = capi.SOLVER_SCHUR_DENSE
-    gpu = runner.run_batch_hip(b)
-    assert np.all(gpu["status"] == r0["status"]) and np.array_equal(gpu["num_observations"], r0["num_observations"])
+    cpu = _oracle.run_batch(b); gpu = runner.run_batch_hip(b)
+    assert np.all(gpu["status"] == cpu["status"]) and np.array_equal(gpu["num_observations"], cpu["num_observations"]) and np.array_equal(gpu["num_jacobians"], cpu["num_jacobians"])
     # (chi2_init ~ 1e7 px^2 comes from points that start almost in the camera plane: their pixel coordinates, and the 1/z^2 of their Jacobians that sets
     #  lambda_0 = 1e-3 max diag H, amplify the last bits of the composed pose)
-    assert _close(gpu["chi2_init"], r0["chi2_init"], rel=1e-6) and _close(gpu["lambda_init"], r0["lambda_init"], rel=1e-4)
-    pinned_trials = 0; full = 0
+    assert _close(gpu["chi2_init"], cpu["chi2_init"], rel=1e-6) and _close(gpu["lambda_init"], cpu["lambda_init"], rel=1e-4)
+    together = 0
     for i in range(b.n):
-        m = int(min(gpu["num_trials"][i], r0["num_trials"][i], r1["num_trials"][i], capi.TRACE_LEN))
-        c0, c1, g = r0["trace_chi2"][i][:m], r1["trace_chi2"][i][:m], gpu["trace_chi2"][i][:m]
-        spread = np.abs(c1 - c0) / np.maximum(np.abs(c0), 1e-300)
-        ref_agree = (np.sign(r0["trace_rho"][i][:m]) == np.sign(r1["trace_rho"][i][:m])) & (np.isnan(c0) == np.isnan(c1)) & ~(spread > 1e-7)
-        k = m if ref_agree.all() else int(np.argmin(ref_agree))              # trials [0, k) are pinned by the reference
+        m = int(min(gpu["num_trials"][i], cpu["num_trials"][i], capi.TRACE_LEN))
+        g, c = gpu["trace_chi2"][i][:m], cpu["trace_chi2"][i][:m]
+        same_dec = (np.sign(gpu["trace_rho"][i][:m]) == np.sign(cpu["trace_rho"][i][:m])) & (np.isnan(g) == np.isnan(c))
+        k = m if same_dec.all() else int(np.argmin(same_dec))
         assert k >= min(m, 2), (i, k, m)
-        assert np.array_equal(np.sign(gpu["trace_rho"][i][:k]), np.sign(r0["trace_rho"][i][:k])), (i, k)
-        assert np.array_equal(np.isnan(g[:k]), np.isnan(c0[:k])), i
-        acc = r0["trace_rho"][i][:k] > 0
-        tol = np.maximum(1e-6, 100.0 * spread[:k])
-        assert np.all(np.abs(g[:k][acc] - c0[:k][acc]) <= tol[acc] * np.abs(c0[:k][acc])), (i, k, g[:k][acc], c0[:k][acc])
-        assert _close(gpu["trace_lambda"][i][:k] / gpu["lambda_init"][i], r0["trace_lambda"][i][:k] / r0["lambda_init"][i], rel=1e-9), i   # the same lambda schedule
-        pinned_trials += k; full += int(k == m)
-    assert pinned_trials >= 0.5 * min(r0["num_trials"].sum(), gpu["num_trials"].sum()) and full >= b.n // 2, (pinned_trials, full)
+        acc = cpu["trace_rho"][i][:k] > 0
+        assert _close(g[:k][acc], c[:k][acc], rel=1e-6, abs_=1e-20), (i, k)
+        assert _close(gpu["trace_lambda"][i][:k] / gpu["lambda_init"][i], cpu["trace_lambda"][i][:k] / cpu["lambda_init"][i], rel=1e-9), i   # the same lambda schedule
+        if k < m:   # the runs part ways: only at the rounding floor
+            e_prev = c[np.flatnonzero(acc)[-1]] if acc.any() else cpu["chi2_init"][i]
+            for e_k in (g[k], c[k]):
+                assert np.isnan(e_k) or abs(e_k - e_prev) <= 1e-6 * e_prev, (i, k, e_prev, g[k], c[k])
+            assert gpu["chi2_final"][i] <= e_prev * (1 + 1e-9) and cpu["chi2_final"][i] <= e_prev * (1 + 1e-9), i   # both continuations only go down from the common point
+        elif gpu["num_trials"][i] == cpu["num_trials"][i]:
+            together += 1
+            assert abs(gpu["chi2_final"][i] - cpu["chi2_final"][i]) <= 1e-6 * cpu["chi2_final"][i], i
+    assert together >= b.n // 3, together
