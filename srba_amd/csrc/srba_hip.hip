@@ -346,26 +346,34 @@ struct Solver : public Worker<FAM> {
 #else
 #define SRBA_OCC
 #endif
-template <int FAM>
-__device__ __forceinline__ void lm_one(const Batch &B, const DevParams &prm, const int pidx) {
-	const ProbDesc &d = B.desc[pidx];
+// RESUME: the capsule comes from the rounds path (srba_rounds.hpp) with a trial pending: S5..S14 are done, the scalars of the loop are in *st0 and `B0` is the batch as the
+// kernel got it (the loop then works IN PLACE on the copy of the unknowns / poses that holds the accepted state, with the reference's backup / restore); the fused kernel
+// instantiates RESUME = false, which is the code it always was.
+template <int FAM, bool RESUME = false>
+__device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, const int pidx, LmState *st0 = nullptr) {
+	const ProbDesc &d = B0.desc[pidx];
+	LmState s0; if constexpr (RESUME) s0 = rounds_state(st0);
+	const Batch Bv = RESUME ? rounds_view(B0, s0.cur) : B0; const Batch &B = RESUME ? Bv : B0;
 	Solver<FAM> S(B, d, prm);
 	constexpr int P = Solver<FAM>::P, L = Solver<FAM>::L, O = Solver<FAM>::O;
 	double *red = nullptr;
 	const SparseSys A = S.make_sys(srba_lds);
 	const int tid = threadIdx.x; srba_lm_result *out = B.results + pidx;
 	const int nObs = d.n_obs, n = d.n_scal;
-	double *resid = B.resid, *resid2 = B.resid2;
+	double *resid = (RESUME && s0.rcur) ? B.resid2 : B.resid, *resid2 = (RESUME && s0.rcur) ? B.resid : B.resid2;
 
 	long long *pc = B.phase_cycles ? B.phase_cycles + (long long)pidx * 16 : nullptr; long long tc0 = 0;
 #define TIC() do { if (pc) { __syncthreads(); tc0 = wall_clock64(); } } while (0)
 #define TOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - tc0; } } while (0)
-	TIC(); S.phase_spantree(false); // S5
-	__syncthreads(); TOC(0);
-	TIC(); S.phase_jacobians(); TOC(1); // S6,S7
 	// K6: the LDS image of the system is idle while the capsule is linearised (it is assembled per trial): the U_Ap accumulators of the term-parallel form live there
 	const bool hess_terms = B.hess_terms && d.dense_in_lds && d.n_hap * P * P <= 9 * (d.nb + d.nnzoff);
 	auto hessian = [&]() -> int { return hess_terms ? S.phase_hessian_terms(srba_lds) /* == A.diag: the LDS image, idle while the capsule is linearised */ + S.phase_hessian_landmark_blocks() : S.phase_hessian(); };
+	double lambda, nu = 2.0, total_err, RMSE;
+	int iter = 0, trials = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0; bool stop = false;
+	if constexpr (!RESUME) {
+	TIC(); S.phase_spantree(false); // S5
+	__syncthreads(); TOC(0);
+	TIC(); S.phase_jacobians(); TOC(1); // S6,S7
 	TIC(); const int ninv = (int)block_sum((double)hessian(), red); // S10
 	__syncthreads(); TOC(2);
 	if (tid == 0) {
@@ -374,18 +382,30 @@ __device__ __forceinline__ void lm_one(const Batch &B, const DevParams &prm, con
 		for (int k = 0; k < SRBA_TRACE_LEN; k++) { out->trace_chi2[k] = NAN; out->trace_lambda[k] = NAN; out->trace_rho[k] = NAN; }
 	}
 	if ((long long)O * nObs < (long long)n) { if (tid == 0) out->status = 1; return; } // S11
-	double lambda = S.lambda_guess(red), nu = 2.0; // S12
-	TIC(); double total_err = S.phase_residuals(resid, red); TOC(3); // S13
-	double RMSE = sqrt(total_err / nObs);
+	lambda = S.lambda_guess(red); // S12
+	TIC(); total_err = S.phase_residuals(resid, red); TOC(3); // S13
+	RMSE = sqrt(total_err / nObs);
 	if (tid == 0) { out->lambda_init = lambda; out->total_sqr_error_init = total_err; }
 	__syncthreads();
 	TIC(); S.phase_gradient(resid); // S14
 	__syncthreads(); S.keep_gradient(); TOC(4);
-	int iter = 0, trials = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0; bool stop = false;
-	for (iter = 0; iter < prm.max_iters && !stop; iter++) {
+	} else { // the scalars of the loop as the rounds left them; the twins of the refreshed spanning-tree pairs as the reference would have them after a rejected trial
+		lambda = s0.lambda; nu = s0.nu; total_err = s0.total_err; RMSE = s0.rmse; iter = s0.iter; trials = s0.trials; n_notpd = s0.n_notpd; n_acc = s0.n_acc; n_relin = s0.n_relin; stopmask = s0.stopmask;
+		constexpr int PD = Solver<FAM>::PD; const Batch Bt = rounds_view(B0, s0.cur ^ 1);
+		if (s0.last_rejected) for (int q = tid; q < 2 * d.n_need; q += SRBA_WG) {
+			const long long ps = 2LL * B.need_idx[d.o_pair + (q >> 1)] + (q & 1);
+			if (!B.pose_req[d.o_pair * 2 + ps]) { double v[PD]; ldn<PD>(v, Bt.pose + (d.o_pair * 2 + ps) * PD); stn<PD>(B.pose + (d.o_pair * 2 + ps) * PD, v); }
+		}
+		__syncthreads();
+	}
+	bool resumed = RESUME; // (the tests at the head of the pass in progress were made by the rounds path)
+	for (; iter < prm.max_iters && !stop; iter++) {
 		double rho = 0;
+		if (!resumed) {
 		if (lambda >= prm.max_lambda) { stop = true; stopmask |= 1 << SRBA_STOP_LAMBDA; }
 		if (RMSE < prm.max_err) { stop = true; stopmask |= 1 << SRBA_STOP_RMSE; }
+		}
+		resumed = false;
 		while (rho <= 0 && !stop) {
 			const int tr = trials++;
 			if (tid == 0 && tr < SRBA_TRACE_LEN) out->trace_lambda[tr] = lambda;
@@ -438,6 +458,16 @@ __device__ __forceinline__ void lm_one(const Batch &B, const DevParams &prm, con
 	if (tid == 0) {
 		out->num_iters = iter; out->num_trials = trials; out->num_not_pd = n_notpd; out->num_accepted = n_acc; out->num_relinearized = n_relin; out->stop_reason = stopmask;
 		out->total_sqr_error_final = total_err; out->obs_rmse = RMSE; out->lambda_final = lambda;
+	}
+	if constexpr (RESUME) { // the accepted state goes back to the primary arrays (cf. kr_finish); the capsule is marked done
+		constexpr int PD = Solver<FAM>::PD;
+		__syncthreads();
+		if (s0.cur) {
+			for (int k = tid; k < d.nK * PD; k += SRBA_WG) B0.edge[d.o_edge * PD + k] = B0.edge1[d.o_edge * PD + k];
+			for (int k = tid; k < d.nF * L; k += SRBA_WG) B0.ulm[d.o_ulm * L + k] = B0.ulm1[d.o_ulm * L + k];
+			for (int q = tid; q < 2 * d.n_need; q += SRBA_WG) { const long long ps = 2LL * B0.need_idx[d.o_pair + (q >> 1)] + (q & 1); double v[PD]; ldn<PD>(v, B0.pose1 + (d.o_pair * 2 + ps) * PD); stn<PD>(B0.pose + (d.o_pair * 2 + ps) * PD, v); }
+		}
+		if (tid == 0) { st0->phase = 2; }
 	}
 	(void)P;
 }
@@ -735,8 +765,8 @@ struct srba_hip_ctx {
 	size_t in_off_edge0 = 0, in_off_ulm0 = 0; long long tot_edge = 0, tot_ulm = 0;
 	size_t off_phase = 0; bool phase_timing = false; long long n_pose_total = 0; std::vector<int> cls_of;
 	// rounds path (srba_rounds.hpp): groups of capsules (LDS size classes, the big ones split) that run their LM rounds on separate streams
-	struct RGroup { int cls, first, count; size_t lds; int rounds_needed /* most LM trials of any of its capsules, once a run's results have been downloaded; else 0 */, rounds_done; int grid[5]; };
-	int rounds_env = -1, rounds_split = 4, rounds_first = 64, rounds_min_batch = 1 << 30 /* (off by default until validated) */; bool rounds_on = false, rounds_pending = false; int rounds_debug = 0; std::vector<RGroup> rgroups; srbadev::Rounds R; int *h_unfinished = nullptr; std::vector<int> rhist; /* host copy of R.hist once a run's results have been downloaded */
+	struct RGroup { int cls, first, count; size_t lds; int rounds_needed /* most LM trials of any of its capsules, once a run's results have been downloaded; else 0 */, rounds_done; int grid[6]; };
+	int rounds_env = -1, rounds_split = 4, rounds_first = 64, rounds_min_batch = 1 << 30 /* (off by default until validated) */; bool rounds_on = false, rounds_pending = false; int rounds_debug = 0, rounds_threads = 1, rounds_last = 0; std::vector<RGroup> rgroups; srbadev::Rounds R; int *h_unfinished = nullptr; std::vector<int> rhist; int rhist_rounds = 0, rounds_switch = 20; /* host copy of R.hist once a run's results have been downloaded (valid for the rounds that run enqueued); round after which the fused loop takes over */
 	static constexpr int kRStreams = 32; hipStream_t rstream[kRStreams] = {nullptr}; hipEvent_t rdone[kRStreams] = {nullptr};
 	void fail(const std::string &m) { error = m; g_last_error = m; }
 };
@@ -879,7 +909,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_LIN_TERMS"); if (e) c->lin_terms = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_LM_TERMS"); if (e) c->lm_terms = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_ROUNDS"); if (e) c->rounds_env = atoi(e); e = getenv("SRBA_HIP_ROUNDS_SPLIT"); if (e && atoi(e) >= 1) c->rounds_split = std::min(atoi(e), 16); e = getenv("SRBA_HIP_ROUNDS_FIRST"); if (e && atoi(e) >= 1) c->rounds_first = atoi(e);
-	  e = getenv("SRBA_HIP_ROUNDS_MIN_BATCH"); if (e) c->rounds_min_batch = atoi(e); e = getenv("SRBA_HIP_ROUNDS_DEBUG"); if (e) c->rounds_debug = atoi(e); }
+	  e = getenv("SRBA_HIP_ROUNDS_MIN_BATCH"); if (e) c->rounds_min_batch = atoi(e); e = getenv("SRBA_HIP_ROUNDS_DEBUG"); if (e) c->rounds_debug = atoi(e); e = getenv("SRBA_HIP_ROUNDS_SWITCH"); if (e) c->rounds_switch = atoi(e); e = getenv("SRBA_HIP_ROUNDS_THREADS"); if (e && atoi(e) >= 1) c->rounds_threads = atoi(e); }
 	{ const char *e = getenv("SRBA_HIP_FLAT"); if (e) c->use_flat = atoi(e) != 0; }                     // 0 = one wavefront per capsule for the stepwise spanning-tree launch
 	{ const char *e = getenv("SRBA_HIP_BIG_LANES"); if (e && atoi(e) >= 1) c->big_lanes_max = std::min(atoi(e), kBigLanes); } // large capsules of one batch in flight at once
 	{ const char *e = getenv("SRBA_HIP_BIG_GRAPHS"); if (e) c->big_use_graphs = atoi(e) != 0; }         // 1 = replay the big path's launch sequences as HIP graphs (measured: no gain, the path is bound by its kernels)
@@ -1092,7 +1122,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 			if (c->rounds_on && k < SRBA_NCLS - 1 && cnt > 0) { // rounds path: a big class is split into interleaved slices (each a group with its own stream: their round kernels overlap)
 				const int parts = cnt >= 2048 * c->rounds_split ? c->rounds_split : (cnt >= 4096 ? 2 : 1);
 				if (parts > 1) { std::vector<int32_t> t(b, b + cnt); for (int q = 0; q < parts; q++) { int i = slice_begin(cnt, q, parts); for (int src = q; src < cnt; src += parts) b[i++] = t[src]; } }
-				for (int q = 0; q < parts; q++) { const int a = slice_begin(cnt, q, parts), e = slice_begin(cnt, q + 1, parts); if (e > a) c->rgroups.push_back({k, c->cls_first[k] + a, e - a, c->cls_lds[k], 0, 0, {0, 0, 0, 0, 0}}); }
+				for (int q = 0; q < parts; q++) { const int a = slice_begin(cnt, q, parts), e = slice_begin(cnt, q + 1, parts); if (e > a) c->rgroups.push_back({k, c->cls_first[k] + a, e - a, c->cls_lds[k], 0, 0, {0, 0, 0, 0, 0, 0}}); }
 			}
 			if (c->sched == 0 && cnt >= 16 * nq) { std::vector<int32_t> t(b, b + cnt); for (int q = 0; q < nq; q++) { int i = slice_begin(cnt, q, nq); for (int src = q; src < cnt; src += nq) b[i++] = t[src]; } }
 		}
@@ -1400,30 +1430,41 @@ template <class K> static int rounds_grid(srba_hip_ctx *c, K kernel, size_t lds,
 	return std::max(1, std::min(count, c->n_cu * per_cu));
 }
 // rounds [r0, r1) of every group (each on its own stream), interleaved round by round so that every stream has work from the start
-static int rounds_enqueue(srba_hip_ctx *c, bool with_init, const std::vector<int> &r0, const std::vector<int> &r1) {
+static int rounds_enqueue(srba_hip_ctx *c, bool with_init, const std::vector<int> &r0, const std::vector<int> &r1, bool tail) {
 	const int ng = (int)c->rgroups.size(); int rc = 0;
 	with_family(c->params.family, [&](auto fam_) { constexpr int F = decltype(fam_)::value;
 		for (int g = 0; g < ng && rc == 0; g++) { srba_hip_ctx::RGroup &G = c->rgroups[g]; // grids once per upload; big LDS images need the attribute
 			if (G.grid[0]) continue;
-			if (allow_big_lds(c, srbadev::kr_init<F>, G.lds) != 0 || allow_big_lds(c, srbadev::kr_solve<F>, G.lds) != 0 || allow_big_lds(c, srbadev::kr_lin<F>, G.lds) != 0) { rc = -1; break; }
+			if (allow_big_lds(c, srbadev::kr_init<F>, G.lds) != 0 || allow_big_lds(c, srbadev::kr_solve<F>, G.lds) != 0 || allow_big_lds(c, srbadev::kr_lin<F>, G.lds) != 0 || allow_big_lds(c, srbadev::kr_tail<F>, G.lds) != 0) { rc = -1; break; }
+			G.grid[5] = rounds_grid(c, srbadev::kr_tail<F>, G.lds, G.count);
 			G.grid[0] = rounds_grid(c, srbadev::kr_init<F>, G.lds, G.count); G.grid[1] = rounds_grid(c, srbadev::kr_solve<F>, G.lds, G.count); G.grid[2] = rounds_grid(c, srbadev::kr_eval<F>, 0, G.count);
 			G.grid[3] = rounds_grid(c, srbadev::kr_lin<F>, G.lds, G.count); G.grid[4] = G.count; // kr_finish: one workgroup per capsule
 		}
 		if (rc != 0) return;
-		if (with_init) for (int g = 0; g < ng; g++) { const srba_hip_ctx::RGroup &G = c->rgroups[g];
-			hipLaunchKernelGGL((srbadev::kr_init<F>), dim3(G.grid[0]), dim3(SRBA_WG), G.lds, c->rstream[g % srba_hip_ctx::kRStreams], c->B, c->dp, c->R, g, G.first, G.count);
-			if (c->rounds_debug >= 3) { hipError_t e = hipStreamSynchronize(c->rstream[g % srba_hip_ctx::kRStreams]); int cnt3[3] = {0, 0, 0}; hipMemcpy(cnt3, c->R.count + 3 * g, 12, hipMemcpyDeviceToHost); RDBG("init of group %d done: %s; active %d", g, hipGetErrorString(e), cnt3[0]); } }
-		int rmax = 0; for (int g = 0; g < ng; g++) rmax = std::max(rmax, r1[g]);
-		for (int r = 0; r < rmax; r++) for (int g = 0; g < ng; g++) { const srba_hip_ctx::RGroup &G = c->rgroups[g]; if (r < r0[g] || r >= r1[g]) continue; hipStream_t st = c->rstream[g % srba_hip_ctx::kRStreams];
-			// a launch is as wide as the list of the round was in the previous run of this batch (any width is correct: a workgroup takes further capsules from a counter); a late
-			// round has a handful of capsules, and thousands of workgroups that start only to find the list empty cost more than the round's work
-			int cap = G.count; if (!c->rhist.empty() && r < SRBA_ROUNDS_HIST) cap = std::max(1, std::min(G.count, c->rhist[(size_t)g * SRBA_ROUNDS_HIST + r] + 8));
-			hipLaunchKernelGGL((srbadev::kr_solve<F>), dim3(std::min(G.grid[1], cap)), dim3(SRBA_WG), G.lds, st, c->B, c->dp, c->R, g, G.first, r);
-			hipLaunchKernelGGL((srbadev::kr_eval<F>), dim3(std::min(G.grid[2], cap)), dim3(SRBA_WG), 0, st, c->B, c->dp, c->R, g, G.first, r);
-			hipLaunchKernelGGL((srbadev::kr_lin<F>), dim3(std::min(G.grid[3], cap)), dim3(SRBA_WG), G.lds, st, c->B, c->dp, c->R, g, G.first, r);
-			if (c->rounds_debug >= 3) { hipError_t e = hipStreamSynchronize(st); int cnt3[3] = {0, 0, 0}; hipMemcpy(cnt3, c->R.count + 3 * g, 12, hipMemcpyDeviceToHost); RDBG("round %d of group %d done: %s; lists %d %d %d", r, g, hipGetErrorString(e), cnt3[0], cnt3[1], cnt3[2]); } }
-		for (int g = 0; g < ng; g++) { const srba_hip_ctx::RGroup &G = c->rgroups[g];
-			hipLaunchKernelGGL((srbadev::kr_finish<F>), dim3(G.grid[4]), dim3(SRBA_WG), 0, c->rstream[g % srba_hip_ctx::kRStreams], c->B, c->dp, c->R, g, G.first, G.count); }
+		// One group = one stream = one chain of launches (init, its rounds, finish) that depends on nothing outside it: the chains are enqueued by several host threads.
+		// Why: a late round has a handful of capsules and lasts ~0.2 ms on the device while its 3 x 17 launches cost one host thread ~0.6 ms (measured: 36 ms of enqueue per
+		// step for 2 900 launches, the device waiting for the next round of every group).
+		auto chain = [&](int g) { const srba_hip_ctx::RGroup &G = c->rgroups[g]; hipStream_t st = c->rstream[g % srba_hip_ctx::kRStreams];
+			if (with_init) hipLaunchKernelGGL((srbadev::kr_init<F>), dim3(G.grid[0]), dim3(SRBA_WG), G.lds, st, c->B, c->dp, c->R, g, G.first, G.count);
+			for (int r = r0[g]; r < r1[g]; r++) {
+				// a launch is as wide as the list of the round was in the previous run of this batch (any width is correct: a workgroup takes further capsules from a counter); a late
+				// round has a handful of capsules, and thousands of workgroups that start only to find the list empty cost more than the round's work
+				int cap = G.count; if (!c->rhist.empty() && r < SRBA_ROUNDS_HIST && r < c->rhist_rounds) cap = std::max(1, std::min(G.count, c->rhist[(size_t)g * SRBA_ROUNDS_HIST + r] + 8));
+				hipLaunchKernelGGL((srbadev::kr_solve<F>), dim3(std::min(G.grid[1], cap)), dim3(SRBA_WG), G.lds, st, c->B, c->dp, c->R, g, G.first, r);
+				hipLaunchKernelGGL((srbadev::kr_eval<F>), dim3(std::min(G.grid[2], cap)), dim3(SRBA_WG), 0, st, c->B, c->dp, c->R, g, G.first, r);
+				hipLaunchKernelGGL((srbadev::kr_lin<F>), dim3(std::min(G.grid[3], cap)), dim3(SRBA_WG), G.lds, st, c->B, c->dp, c->R, g, G.first, r);
+				if (c->rounds_debug >= 3) { hipError_t e = hipStreamSynchronize(st); int cnt3[3] = {0, 0, 0}; hipMemcpy(cnt3, c->R.count + 3 * g, 12, hipMemcpyDeviceToHost); RDBG("round %d of group %d done: %s; lists %d %d %d", r, g, hipGetErrorString(e), cnt3[0], cnt3[1], cnt3[2]); }
+			}
+			if (tail) { // whoever still iterates after the last round enqueued finishes inside one launch of the fused loop
+				int cap = G.count; if (!c->rhist.empty() && r1[g] < SRBA_ROUNDS_HIST && r1[g] <= c->rhist_rounds) cap = std::max(1, std::min(G.count, c->rhist[(size_t)g * SRBA_ROUNDS_HIST + r1[g]] + 8));
+				hipLaunchKernelGGL((srbadev::kr_tail<F>), dim3(std::min(G.grid[5], cap)), dim3(SRBA_WG), G.lds, st, c->B, c->dp, c->R, g, G.first, r1[g]); }
+			hipLaunchKernelGGL((srbadev::kr_finish<F>), dim3(G.grid[4]), dim3(SRBA_WG), 0, st, c->B, c->dp, c->R, g, G.first, G.count); };
+		const int nt = c->rounds_debug >= 3 ? 1 : std::max(1, std::min(c->rounds_threads, ng));
+		std::atomic<int> next(0);
+		auto work = [&]() { hipSetDevice(c->device); for (;;) { const int g = next.fetch_add(1); if (g >= ng) break; chain(g); } };
+		std::vector<std::thread> th;
+		try { for (int t = 1; t < nt; t++) th.emplace_back(work); } catch (...) { /* fewer threads than asked for: the ones that started (and this one) share the groups */ }
+		work(); for (auto &x : th) x.join();
 	});
 	if (rc != 0) return -1;
 	HIPCHK(c, hipGetLastError());
@@ -1449,8 +1490,10 @@ static int rounds_run_async(srba_hip_ctx *c) {
 	HIPCHK(c, hipMemsetAsync(c->R.count, 0, sizeof(int) * 3 * (size_t)(ng + 1), c->stream)); HIPCHK(c, hipMemsetAsync(c->R.ctr, 0, sizeof(int) * 5 * (size_t)(ng + 1), c->stream)); HIPCHK(c, hipMemsetAsync(c->R.unfinished, 0, sizeof(int), c->stream));
 	if (ng) HIPCHK(c, hipMemsetAsync(c->R.hist, 0, sizeof(int) * SRBA_ROUNDS_HIST * (size_t)ng, c->stream));
 	if (ng) { if (rounds_fork(c) != 0) return -1;
-		std::vector<int> r0(ng, 0), r1(ng); for (int g = 0; g < ng; g++) r1[g] = c->rgroups[g].rounds_needed > 0 ? c->rgroups[g].rounds_needed : c->rounds_first; // (a round = one LM trial of every capsule still iterating)
-		if (rounds_enqueue(c, true, r0, r1) != 0) return -1;
+		const bool tail = c->rounds_switch > 0;
+		std::vector<int> r0(ng, 0), r1(ng); for (int g = 0; g < ng; g++) { r1[g] = c->rgroups[g].rounds_needed > 0 ? c->rgroups[g].rounds_needed : c->rounds_first; if (tail) r1[g] = std::min(r1[g], c->rounds_switch); } // (a round = one LM trial of every capsule still iterating)
+		if (rounds_enqueue(c, true, r0, r1, tail) != 0) return -1;
+		c->rounds_last = r1[0];
 		RDBG("enqueued: rounds of group 0 = %d", r1[0]);
 		if (c->rounds_debug >= 2) { for (int g = 0; g < ng; g++) { hipError_t e = hipStreamSynchronize(c->rstream[g % srba_hip_ctx::kRStreams]); RDBG("group %d (class %d, first %d, count %d, lds %zu, grids %d %d %d %d %d) synchronised: %s", g, c->rgroups[g].cls, c->rgroups[g].first, c->rgroups[g].count, c->rgroups[g].lds, c->rgroups[g].grid[0], c->rgroups[g].grid[1], c->rgroups[g].grid[2], c->rgroups[g].grid[3], c->rgroups[g].grid[4], hipGetErrorString(e)); } } }
 	int big_rc = 0; { const int32_t *ord = (const int32_t *)(c->h_in.get() + c->h_off_order); big_rc = big_run_class(c, ord + c->cls_first[SRBA_NCLS - 1], c->cls_count[SRBA_NCLS - 1]); }
@@ -1472,7 +1515,7 @@ static int rounds_complete(srba_hip_ctx *c) {
 		for (int g = 0; g < ng; g++) { HIPCHK(c, hipMemsetAsync(c->R.ctr + 5 * g + 4, 0, sizeof(int), c->stream)); }
 		if (rounds_fork(c) != 0) return -1;
 		std::vector<int> r0(ng), r1(ng); for (int g = 0; g < ng; g++) { r0[g] = c->rgroups[g].rounds_done; r1[g] = r0[g] + 32; }
-		if (rounds_enqueue(c, false, r0, r1) != 0) return -1;
+		if (rounds_enqueue(c, false, r0, r1, false) != 0) return -1;
 		if (rounds_join(c) != 0) return -1;
 	}
 	c->fail("lm_run: capsules still iterating after the extra rounds"); return -1;
@@ -1570,6 +1613,7 @@ int srba_hip_download_results(srba_hip_ctx *c, srba_lm_result *results, int n) {
 		const int32_t *ord = (const int32_t *)(c->h_in.get() + c->h_off_order);
 		for (auto &G : c->rgroups) { int mx = 0; for (int i = 0; i < G.count; i++) mx = std::max(mx, (int)results[ord[G.first + i]].num_trials); G.rounds_needed = mx + 1; }
 		c->rhist.assign((size_t)SRBA_ROUNDS_HIST * c->rgroups.size(), 0);
+		c->rhist_rounds = c->rounds_last;
 		if (!c->rhist.empty()) { HIPCHK(c, hipMemcpyAsync(c->rhist.data(), c->R.hist, sizeof(int) * c->rhist.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); } }
 	return 0;
 }
