@@ -604,7 +604,7 @@ struct Worker {
 	// ---- K1
 	// edge_lds: optional copy of ALL edge poses of the capsule in LDS (stride PD, local edge order) -- the in-loop refresh then composes from LDS instead of
 	// waiting for the global stores of the update it follows
-	__device__ __forceinline__ void phase_spantree(bool only_needed, const double *edge_lds = nullptr) { fresh();
+	__device__ __forceinline__ void phase_spantree(bool only_needed, const double *edge_lds = nullptr, double *pose2 = nullptr /* a second copy of every pose written (all-pairs pass of the double-buffered loop) */) { fresh();
 #ifdef SRBA_K1SMALL
 		constexpr int U = 2, V = 1;
 #else
@@ -680,8 +680,10 @@ struct Worker {
 			}
 #pragma unroll
 			for (int v = 0; v < V; v++) if (p[v] >= 0) {
+				const pose_t ia = inv(acc[v]);
 				PO::st(B.pose + (d.o_pair + p[v]) * 2 * PD, acc[v]);
-				PO::st(B.pose + ((d.o_pair + p[v]) * 2 + 1) * PD, inv(acc[v]));
+				PO::st(B.pose + ((d.o_pair + p[v]) * 2 + 1) * PD, ia);
+				if (pose2) { PO::st(pose2 + (d.o_pair + p[v]) * 2 * PD, acc[v]); PO::st(pose2 + ((d.o_pair + p[v]) * 2 + 1) * PD, ia); }
 			}
 		}
 	}

@@ -332,6 +332,30 @@ struct Solver : public Worker<FAM> {
 		if (stage) solver_sync(); else __syncthreads();
 		return stage ? el : nullptr;
 	}
+	// K11 for the double-buffered loop: the trial unknowns exp(delta) (+) edge, lm + delta go to the OTHER copy (Bt), nothing is backed up (a rejected trial simply leaves the
+	// accepted copy as it is); like apply_update_lds the increment comes from the solved right-hand side in LDS and all edge poses of the trial are staged in the idle part of the
+	// LDS image for the spanning-tree refresh that follows. Returns that copy or nullptr.
+	__device__ __forceinline__ const double *apply_trial(const SparseSys &S, const Batch &Bt) { this->fresh();
+		typedef typename W::PO PO; typedef typename W::pose_t pose_t;
+		const double *dl = B.delta + d.o_scal;
+		const bool stage = d.dense_in_lds && d.n_edges * PD <= 9 * S.nnzoff; double *el = S.off;
+		for (int i = tid; i < (stage ? d.n_edges : d.nK); i += SRBA_WG) {
+			pose_t cur = PO::ld(B.edge + (d.o_edge + i) * PD);
+			if (i < d.nK) {
+				double inc[P];
+#pragma unroll
+				for (int k = 0; k < P; k++) { const int q = i * P + k; inc[k] = S.rhs[3 * S.perm[q / 3] + q % 3]; }
+				cur = comp(PO::expm(inc), cur);
+				PO::st(Bt.edge + (d.o_edge + i) * PD, cur);
+			}
+			if (stage) { double t[PD]; PO::to(t, cur);
+#pragma unroll
+				for (int k = 0; k < PD; k++) el[i * PD + k] = t[k]; }
+		}
+		for (int k = tid; k < d.nF * L; k += SRBA_WG) Bt.ulm[d.o_ulm * L + k] = B.ulm[d.o_ulm * L + k] + dl[d.nK * P + k];
+		if (stage) solver_sync(); else __syncthreads();
+		return stage ? el : nullptr;
+	}
 	__device__ __forceinline__ void restore() { this->fresh(); // optimize_edges.h:664-680
 		for (int i = tid; i < d.nK * PD; i += SRBA_WG) B.edge[d.o_edge * PD + i] = B.old_edge[d.o_unk * PD + i];
 		for (int k = tid; k < d.nF * L; k += SRBA_WG) B.ulm[d.o_ulm * L + k] = B.old_ulm[d.o_ulm * L + k];
@@ -349,11 +373,15 @@ struct Solver : public Worker<FAM> {
 // RESUME: the capsule comes from the rounds path (srba_rounds.hpp) with a trial pending: S5..S14 are done, the scalars of the loop are in *st0 and `B0` is the batch as the
 // kernel got it (the loop then works IN PLACE on the copy of the unknowns / poses that holds the accepted state, with the reference's backup / restore); the fused kernel
 // instantiates RESUME = false, which is the code it always was.
-template <int FAM, bool RESUME = false>
+#ifndef SRBA_LM_DB
+#define SRBA_LM_DB 1   /* the fused loop keeps two copies of the unknowns and of the spanning-tree poses (trial -> the other copy, accept = flip) instead of backup / restore */
+#endif
+template <int FAM, bool RESUME = false, bool DB = (SRBA_LM_DB != 0)>
 __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, const int pidx, LmState *st0 = nullptr) {
 	const ProbDesc &d = B0.desc[pidx];
 	LmState s0; if constexpr (RESUME) s0 = rounds_state(st0);
-	const Batch Bv = RESUME ? rounds_view(B0, s0.cur) : B0; const Batch &B = RESUME ? Bv : B0;
+	const Batch Bv = (RESUME && !DB) ? rounds_view(B0, s0.cur) : B0; const Batch &B = (RESUME && !DB) ? Bv : B0; // (!DB: the loop works in place on the accepted copy)
+	int cur = (RESUME && DB) ? s0.cur : 0, last_rej = (RESUME && DB) ? s0.last_rejected : 0; // DB: which copy holds the accepted state; the last evaluated trial was rejected
 	Solver<FAM> S(B, d, prm);
 	constexpr int P = Solver<FAM>::P, L = Solver<FAM>::L, O = Solver<FAM>::O;
 	double *red = nullptr;
@@ -367,14 +395,17 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 #define TOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - tc0; } } while (0)
 	// K6: the LDS image of the system is idle while the capsule is linearised (it is assembled per trial): the U_Ap accumulators of the term-parallel form live there
 	const bool hess_terms = B.hess_terms && d.dense_in_lds && d.n_hap * P * P <= 9 * (d.nb + d.nnzoff);
-	auto hessian = [&]() -> int { return hess_terms ? S.phase_hessian_terms(srba_lds) /* == A.diag: the LDS image, idle while the capsule is linearised */ + S.phase_hessian_landmark_blocks() : S.phase_hessian(); };
+	auto hessian = [&](Solver<FAM> &X) -> int { return hess_terms ? X.phase_hessian_terms(srba_lds) /* == A.diag: the LDS image, idle while the capsule is linearised */ + X.phase_hessian_landmark_blocks() : X.phase_hessian(); };
 	double lambda, nu = 2.0, total_err, RMSE;
 	int iter = 0, trials = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0; bool stop = false;
 	if constexpr (!RESUME) {
-	TIC(); S.phase_spantree(false); // S5
+	TIC(); S.phase_spantree(false, nullptr, DB ? B0.pose1 : nullptr); // S5 (DB: both copies of the poses)
+	if constexpr (DB) { constexpr int PD = Solver<FAM>::PD; // the second copy of the unknowns (the fixed edges of the paths stay equal in both for good)
+		for (int k = tid; k < d.n_edges * PD; k += SRBA_WG) B0.edge1[d.o_edge * PD + k] = B0.edge[d.o_edge * PD + k];
+		for (int k = tid; k < d.nF * L; k += SRBA_WG) B0.ulm1[d.o_ulm * L + k] = B0.ulm[d.o_ulm * L + k]; }
 	__syncthreads(); TOC(0);
 	TIC(); S.phase_jacobians(); TOC(1); // S6,S7
-	TIC(); const int ninv = (int)block_sum((double)hessian(), red); // S10
+	TIC(); const int ninv = (int)block_sum((double)hessian(S), red); // S10
 	__syncthreads(); TOC(2);
 	if (tid == 0) {
 		out->status = 0; out->num_iters = 0; out->num_trials = 0; out->num_not_pd = 0; out->num_accepted = 0; out->num_relinearized = 0; out->stop_reason = 0;
@@ -392,7 +423,7 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 	} else { // the scalars of the loop as the rounds left them; the twins of the refreshed spanning-tree pairs as the reference would have them after a rejected trial
 		lambda = s0.lambda; nu = s0.nu; total_err = s0.total_err; RMSE = s0.rmse; iter = s0.iter; trials = s0.trials; n_notpd = s0.n_notpd; n_acc = s0.n_acc; n_relin = s0.n_relin; stopmask = s0.stopmask;
 		constexpr int PD = Solver<FAM>::PD; const Batch Bt = rounds_view(B0, s0.cur ^ 1);
-		if (s0.last_rejected) for (int q = tid; q < 2 * d.n_need; q += SRBA_WG) {
+		if (!DB && s0.last_rejected) for (int q = tid; q < 2 * d.n_need; q += SRBA_WG) {
 			const long long ps = 2LL * B.need_idx[d.o_pair + (q >> 1)] + (q & 1);
 			if (!B.pose_req[d.o_pair * 2 + ps]) { double v[PD]; ldn<PD>(v, Bt.pose + (d.o_pair * 2 + ps) * PD); stn<PD>(B.pose + (d.o_pair * 2 + ps) * PD, v); }
 		}
@@ -409,16 +440,17 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 		while (rho <= 0 && !stop) {
 			const int tr = trials++;
 			if (tid == 0 && tr < SRBA_TRACE_LEN) out->trace_lambda[tr] = lambda;
-			TIC(); const bool solved = S.solve(A, lambda, pc); TOC(5);
+			const Batch Ba = DB ? rounds_view(B0, cur) : B, Bt = DB ? rounds_view(B0, cur ^ 1) : B; Solver<FAM> Sa(Ba, d, prm), St(Bt, d, prm); // accepted / trial copy (the same one without DB)
+			TIC(); const bool solved = Sa.solve(A, lambda, pc); TOC(5);
 			if (!solved) {
 				n_notpd++; lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
 				__syncthreads();
 				continue;
 			}
-			TIC(); const double *edge_lds = S.apply_update_lds(A); TOC(6);
-			TIC(); S.phase_spantree(true, edge_lds);
+			TIC(); const double *edge_lds = DB ? Sa.apply_trial(A, Bt) : Sa.apply_update_lds(A); TOC(6);
+			TIC(); St.phase_spantree(true, edge_lds);
 			__syncthreads(); TOC(7);
-			TIC(); const double new_err = S.phase_residuals(resid2, red); TOC(3);
+			TIC(); const double new_err = St.phase_residuals(resid2, red); TOC(3);
 			const double new_RMSE = sqrt(new_err / nObs);
 			const double err_red = total_err > 0 ? (total_err - new_err) / total_err : 0;
 			double den = 0; { const double *dl = B.delta + d.o_scal, *g = B.grad + d.o_scal; for (int k = tid; k < n; k += SRBA_WG) den += dl[k] * (lambda * dl[k] + g[k]); }
@@ -430,10 +462,11 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 				const bool relin = (err_red < 0 || err_red > prm.min_relin);
 				{ double *t = resid; resid = resid2; resid2 = t; }
 				total_err = new_err; RMSE = new_RMSE;
+				if constexpr (DB) { cur ^= 1; last_rej = 0; } // the trial copy is the accepted one from here on
 				__syncthreads();
-				if (relin) { n_relin++; TIC(); S.phase_jacobians(); TOC(1); TIC(); hessian(); __syncthreads(); TOC(2); }
-				TIC(); S.phase_gradient(resid);
-				__syncthreads(); S.keep_gradient(); TOC(4);
+				if (relin) { n_relin++; TIC(); St.phase_jacobians(); TOC(1); TIC(); hessian(St); __syncthreads(); TOC(2); }
+				TIC(); St.phase_gradient(resid);
+				__syncthreads(); St.keep_gradient(); TOC(4);
 				double ninf = 0; { const double *g = B.grad + d.o_scal; for (int k = tid; k < n; k += SRBA_WG) ninf = fmax(ninf, fabs(g[k])); }
 				ninf = block_max(ninf, red);
 				if (ninf <= 1e-15) { stop = true; stopmask |= 1 << SRBA_STOP_GRADIENT; }
@@ -441,7 +474,7 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 				if (rho > prm.max_rho) { stop = true; stopmask |= 1 << SRBA_STOP_RHO; }
 				lambda *= 1.0 / 3.0; nu = 2.0;
 			} else {
-				TIC(); S.restore(); TOC(8);
+				if constexpr (DB) last_rej = 1; else { TIC(); Sa.restore(); TOC(8); }
 				lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
 			}
 		}
@@ -459,15 +492,23 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 		out->num_iters = iter; out->num_trials = trials; out->num_not_pd = n_notpd; out->num_accepted = n_acc; out->num_relinearized = n_relin; out->stop_reason = stopmask;
 		out->total_sqr_error_final = total_err; out->obs_rmse = RMSE; out->lambda_final = lambda;
 	}
-	if constexpr (RESUME) { // the accepted state goes back to the primary arrays (cf. kr_finish); the capsule is marked done
+	if constexpr (DB) { // the reference's partial restore, where it becomes visible: a rejected trial refreshed BOTH poses of every pair in use and only the ones Jacobian blocks read went back (optimize_edges.h:664-670)
+		constexpr int PD = Solver<FAM>::PD; const Batch Ba = rounds_view(B0, cur), Bt = rounds_view(B0, cur ^ 1);
+		__syncthreads();
+		if (last_rej) for (int q = tid; q < 2 * d.n_need; q += SRBA_WG) {
+			const long long ps = 2LL * B0.need_idx[d.o_pair + (q >> 1)] + (q & 1);
+			if (!B0.pose_req[d.o_pair * 2 + ps]) { double v[PD]; ldn<PD>(v, Bt.pose + (d.o_pair * 2 + ps) * PD); stn<PD>(Ba.pose + (d.o_pair * 2 + ps) * PD, v); }
+		}
+	}
+	if constexpr (RESUME || DB) { // the accepted state goes back to the primary arrays (cf. kr_finish)
 		constexpr int PD = Solver<FAM>::PD;
 		__syncthreads();
-		if (s0.cur) {
+		if (DB ? cur : s0.cur) {
 			for (int k = tid; k < d.nK * PD; k += SRBA_WG) B0.edge[d.o_edge * PD + k] = B0.edge1[d.o_edge * PD + k];
 			for (int k = tid; k < d.nF * L; k += SRBA_WG) B0.ulm[d.o_ulm * L + k] = B0.ulm1[d.o_ulm * L + k];
 			for (int q = tid; q < 2 * d.n_need; q += SRBA_WG) { const long long ps = 2LL * B0.need_idx[d.o_pair + (q >> 1)] + (q & 1); double v[PD]; ldn<PD>(v, B0.pose1 + (d.o_pair * 2 + ps) * PD); stn<PD>(B0.pose + (d.o_pair * 2 + ps) * PD, v); }
 		}
-		if (tid == 0) { st0->phase = 2; }
+		if constexpr (RESUME) { if (tid == 0) st0->phase = 2; } // the capsule is marked done
 	}
 	(void)P;
 }
@@ -1137,7 +1178,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	w.results = wk.add(sizeof(srba_lm_result) * n); w.lambda_io = wk.add(8 * n); w.chi2 = wk.add(8 * n); w.notpd = wk.add(4 * n); w.phase_cycles = wk.add(8 * 16 * (size_t)n);
 	w.m_pair = wk.add(4 * t_pair);
 	{ const bool r = c->rounds_on; const size_t ng = c->rgroups.size() + 1;
-	  w.edge1 = wk.add(r ? 8 * t_edge * PDX : 0); w.ulm1 = wk.add(r ? 8 * t_ulm * L : 0); w.pose1 = wk.add(r ? 8 * 2 * t_pair * PDX : 0); w.lmst = wk.add(r ? sizeof(srbadev::LmState) * (size_t)n : 0);
+	  w.edge1 = wk.add(8 * t_edge * PDX); w.ulm1 = wk.add(8 * t_ulm * L); w.pose1 = wk.add(8 * 2 * t_pair * PDX); /* second copy of the unknowns and of the spanning-tree poses: the fused loop and the rounds path are double-buffered */ w.lmst = wk.add(r ? sizeof(srbadev::LmState) * (size_t)n : 0);
 	  w.rlist = wk.add(r ? 4 * 3 * (size_t)n : 0); w.rcount = wk.add(r ? 4 * 3 * ng : 0); w.rctr = wk.add(r ? 4 * 5 * ng : 0); w.runf = wk.add(4); w.rhist = wk.add(r ? 4 * SRBA_ROUNDS_HIST * ng : 0); }
 	w.grad0 = wk.add((c->params.extensions & SRBA_EXT_SCHUR_KEEPS_GRADIENT) ? 8 * t_scal : 0);
 	wk.add(0);

@@ -459,7 +459,7 @@ def test_lost_monocular_map_agrees_up_to_a_rounding_floor_decision():
             e_prev = c[np.flatnonzero(acc)[-1]] if acc.any() else cpu["chi2_init"][i]
             for e_k in (g[k], c[k]):
                 assert np.isnan(e_k) or abs(e_k - e_prev) <= 1e-6 * e_prev, (i, k, e_prev, g[k], c[k])
-            assert gpu["chi2_final"][i] <= e_prev * (1 + 1e-9) and cpu["chi2_final"][i] <= e_prev * (1 + 1e-9), i   # both continuations only go down from the common point
+            assert gpu["chi2_final"][i] <= e_prev * (1 + 2e-6) and cpu["chi2_final"][i] <= e_prev * (1 + 2e-6), i   # both continuations only go down from the common point (known to 1e-6 in either run)
         elif gpu["num_trials"][i] == cpu["num_trials"][i]:
             together += 1
             assert abs(gpu["chi2_final"][i] - cpu["chi2_final"][i]) <= 1e-6 * cpu["chi2_final"][i], i
