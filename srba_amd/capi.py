@@ -10,6 +10,7 @@ SE2_RELPOSE2D, SE2_RB2D, SE2_CART2D, SE3_STEREO, SE3_MONO, SE3_CART3D, SE3_RB3D,
 SOLVER_SCHUR_DENSE, SOLVER_SCHUR_SPARSE, SOLVER_NO_SCHUR_SPARSE = range(3)
 NOISE_IDENTITY, NOISE_MATRIX = range(2)
 SENSOR_POSE_NONE, SENSOR_POSE_SE3 = range(2)
+EXT_SCHUR_KEEPS_GRADIENT = 1   # enum srba_extensions
 DIMS = {0: (3, 3, 3, 3), 1: (3, 2, 2, 3), 2: (3, 2, 2, 3), 3: (6, 3, 4, 12), 4: (6, 3, 2, 12), 5: (6, 3, 3, 12), 6: (6, 3, 3, 12), 7: (6, 6, 6, 12), 8: (3, 3, 4, 3)}  # P, L, O, PD
 TRACE_LEN = 48
 

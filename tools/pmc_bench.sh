@@ -3,10 +3,10 @@
 # Output: gpurun_out/sq_summary.json (per-launch sums over the k_lm_run dispatches) -> copy to profiles/rNN_sq_summary.json
 R=$PWD; mkdir -p gpurun_out/pmcb; rm -rf gpurun_out/pmcb/*
 export GPU_MAX_HW_QUEUES=16
-python bench.py --steps 2 --warmup 1 --cpu-seconds 0 > gpurun_out/pmcb_bench.json 2> gpurun_out/pmcb_bench.err   # fills the capsule cache
+python bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-secondary > gpurun_out/pmcb_bench.json 2> gpurun_out/pmcb_bench.err   # fills the capsule cache
 cd /tmp; export TMPDIR=/tmp
 N=1
-run() { timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmcb -o p$N -- python $R/bench.py --steps 1 --warmup 0 --cpu-seconds 0 > /dev/null 2> $R/gpurun_out/pmcb/p$N.err; N=$((N+1)); }
+run() { timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmcb -o p$N -- python $R/bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-secondary > /dev/null 2> $R/gpurun_out/pmcb/p$N.err; N=$((N+1)); }
 run SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU
 run SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA
 run SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_BRANCH
