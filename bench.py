@@ -362,9 +362,11 @@ def main():
         stream = []
         for name, fn, by in (("k_spantree (K1, all pairs)", lambda: lib.srba_hip_update_spantree(ctx.ctx, 0), stats["n_path"] * (pbytes + 4) + stats["n_pairs"] * 2 * pbytes),
                              ("k_residuals (K4)", lambda: lib.srba_hip_eval_residuals(ctx.ctx, None), stats["n_obs"] * (pbytes + O * 8 + 12 + O * 8)),
-                             ("k_linearize (K2+K6+K5: Jacobians, Hessian blocks, gradient)", lambda: lib.srba_hip_linearize(ctx.ctx),
-                              stats["n_bp"] * (3 * pbytes + 16 + O * P * 8) + stats["n_hap"] * P * P * 8 + stats["n_hap_terms"] * 2 * O * P * 8 + stats["n_unk_edges"] * P * 8)):
+                             ("srba_hip_linearize = k_assemble_se2rel (K2 + K5 + K6 fused: Jacobian blocks stay in LDS; bytes = SURVEY 8d fused price, 88 B per block in, Hessian blocks and gradient out)", lambda: lib.srba_hip_linearize(ctx.ctx),
+                              stats["n_bp"] * (3 * pbytes + 16) + stats["n_hap"] * P * P * 8 + stats["n_unk_edges"] * P * 8)):
             tt = _timed(fn); stream.append({"kernel": name, "ms": 1e3 * tt, "algorithmic_bytes": float(by), "GBps": by / tt / 1e9, "frac_of_hbm_peak": by / tt / 8e12})
+        # the same launch priced with the UNFUSED bytes of SURVEY 8d (160 B per block + 144 B per Hessian term: what rounds 1-2 printed for the kernel that wrote the blocks to HBM)
+        stream[-1]["unfused_algorithmic_bytes"] = float(stats["n_bp"] * (3 * pbytes + 16 + O * P * 8) + stats["n_hap"] * P * P * 8 + stats["n_hap_terms"] * 2 * O * P * 8 + stats["n_unk_edges"] * P * 8)
         traffic, traffic_src = measured_traffic(args.n_kf, batch.n)
         line = {
             "metric": "LM iterations/sec (and obs/sec) on 30k-KF graph-SLAM; chi2 match vs CPU", "value": tot_trials * args.steps / max_elapsed, "unit": "LM iterations/s",

@@ -32,7 +32,7 @@ namespace srbadev {
 
 // ------------------------------------------------------------------------------------------------ problem descriptor
 struct ProbDesc {
-	int n_edges, nK, nF, n_klm, n_pairs, n_obs, n_valid, n_bp, n_bf, n_hap, n_hf, n_hapf, n_sch, n_req, n_sys, n_scal, nb, nnzoff;
+	int n_edges, nK, nF, n_klm, n_pairs, n_obs, n_valid, n_bp, n_bf, n_hap, n_hf, n_hapf, n_sch, n_req, n_sys, n_scal, nb, nnzoff, n_hapt /* U_Ap terms */;
 	// element offsets into the batch-wide arrays
 	long long o_edge, o_unk, o_ulm, o_klm, o_pair, o_ppoff, o_path, o_obs, o_valid, o_bp, o_colp, o_bf, o_colf;
 	int n_fill; long long o_spfill; // blocks of the factor that no Hessian block maps onto (fill-in): the only ones the assembly has to zero

@@ -531,18 +531,21 @@ template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_spantree(const B
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_residuals(const Batch B, const DevParams prm) {
 	Solver<FAM> S(B, B.desc[blockIdx.x], prm); const double e = S.phase_residuals(B.resid, srba_lds); if (threadIdx.x == 0) B.chi2[blockIdx.x] = e;
 }
-template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_linearize(const Batch B, const DevParams prm, int lds_doubles) {
+template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_linearize(const Batch B, const DevParams prm, int lds_doubles, const int *list /* capsule of every workgroup, or NULL: the whole batch */) {
 	constexpr int P = Worker<FAM>::P;
-	Solver<FAM> S(B, B.desc[blockIdx.x], prm);
-	const ProbDesc &d = B.desc[blockIdx.x];
+	const int pidx = list ? list[blockIdx.x] : blockIdx.x;
+	Solver<FAM> S(B, B.desc[pidx], prm);
+	const ProbDesc &d = B.desc[pidx];
 	S.phase_jacobians();
 	// U_Ap blocks term-parallel with LDS accumulators when they fit the launch's LDS (lds_doubles; the first 16 doubles are the reduction scratch), else one lane per block
 	int nv = (d.n_hap * P * P <= lds_doubles - 16) ? S.phase_hessian_terms(srba_lds + 16) + S.phase_hessian_landmark_blocks() : S.phase_hessian();
 	const int ninv = (int)block_sum((double)nv, srba_lds); __syncthreads();
 	S.phase_gradient(B.resid); __syncthreads(); S.keep_gradient();
 	const double l0 = S.lambda_guess(srba_lds);
-	if (threadIdx.x == 0) { B.lambda_io[blockIdx.x] = l0; B.results[blockIdx.x].num_invalid_jacobs = ninv; }
+	if (threadIdx.x == 0) { B.lambda_io[pidx] = l0; B.results[pidx].num_invalid_jacobs = ninv; }
 }
+// K2 (+ K3) alone: the Jacobian blocks in HBM, for srba_hip_debug_read after a fused srba_hip_linearize
+template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_jacobians_only(const Batch B, const DevParams prm) { Solver<FAM> S(B, B.desc[blockIdx.x], prm); S.phase_jacobians(); }
 // K6 alone on whatever Jacobian blocks are in device memory (every row taken as valid): the algebra of the reference's SchurTests starts from given blocks
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_hessian_only(const Batch B, const DevParams prm) {
 	Solver<FAM> S(B, B.desc[blockIdx.x], prm); const ProbDesc &d = B.desc[blockIdx.x];
@@ -563,6 +566,7 @@ template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_rollback(const B
 } // namespace srbadev
 #include "srba_big.hpp"
 #include "srba_flat.hpp"
+#include "srba_assemble.hpp"
 #include "srba_rounds.hpp"
 namespace srbadev {
 // ---- whole-map squared error (eval_overall_error.h:15-137): a plain streaming pair of kernels over ONE problem (desc[0]), grid-stride
@@ -796,6 +800,9 @@ struct srba_hip_ctx {
 	std::map<int, BigGraphSet> big_graphs; bool big_use_graphs = false; int big_lanes_max = kBigLanes; // captured launch sequences of the big path, per capsule; dropped at upload
 	int upload_threads = 1; bool dense_left = true; int hbm_from_kb = 48; bool dense_blocks_ok = true; // mid-size nearly-full systems use the dense block layout in LDS
 	bool lin_terms = true, lm_terms = true; // term-parallel U_Ap accumulation in LDS: srba_hip_linearize / the fused LM kernel
+	// fused normal equations of the relative-pose SE2 family (srba_assemble.hpp): capsules packed into bins (workgroups) by the LDS image they need, one launch; the rest take k_linearize
+	bool asm_on = true, asm_ready = false, jp_stale = false; int asm_max_kb = srbadev::ASM_BIN_BYTES / 1024; srbadev::AsmTables asm_tab = {nullptr, nullptr, nullptr, nullptr}; const int *asm_list = nullptr;
+	int asm_bins = 0, asm_rest = 0; // bins of the fused launch; capsules left to the unfused kernel (asm_list holds their indices)
 	srbadev::FlatMap flat; bool flat_ready = false, use_flat = true; // pair -> capsule map of the flat spanning-tree kernel (srba_flat.hpp), filled on first use after an upload
 	int big_min_sys = 480;   // systems with more scalar unknowns than this skip the block-sparse symbolic analysis and go dense (big path)
 	std::unique_ptr<char[]> h_in; size_t h_in_cap = 0; size_t h_off_order = 0; // host staging of the input arena (kept: the launch order is read back from it)
@@ -951,6 +958,8 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_LM_TERMS"); if (e) c->lm_terms = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_ROUNDS"); if (e) c->rounds_env = atoi(e); e = getenv("SRBA_HIP_ROUNDS_SPLIT"); if (e && atoi(e) >= 1) c->rounds_split = std::min(atoi(e), 16); e = getenv("SRBA_HIP_ROUNDS_FIRST"); if (e && atoi(e) >= 1) c->rounds_first = atoi(e);
 	  e = getenv("SRBA_HIP_ROUNDS_MIN_BATCH"); if (e) c->rounds_min_batch = atoi(e); e = getenv("SRBA_HIP_ROUNDS_DEBUG"); if (e) c->rounds_debug = atoi(e); e = getenv("SRBA_HIP_ROUNDS_SWITCH"); if (e) c->rounds_switch = atoi(e); e = getenv("SRBA_HIP_ROUNDS_THREADS"); if (e && atoi(e) >= 1) c->rounds_threads = atoi(e); }
+	{ const char *e = getenv("SRBA_HIP_ASSEMBLE_MAX_KB"); if (e) c->asm_max_kb = atoi(e); }            // capsules whose LDS image exceeds this take the unfused kernel (tests)
+	{ const char *e = getenv("SRBA_HIP_ASSEMBLE"); if (e) c->asm_on = atoi(e) != 0; }                   // 0 = srba_hip_linearize always runs the unfused kernel (Jacobian blocks through HBM)
 	{ const char *e = getenv("SRBA_HIP_FLAT"); if (e) c->use_flat = atoi(e) != 0; }                     // 0 = one wavefront per capsule for the stepwise spanning-tree launch
 	{ const char *e = getenv("SRBA_HIP_BIG_LANES"); if (e && atoi(e) >= 1) c->big_lanes_max = std::min(atoi(e), kBigLanes); } // large capsules of one batch in flight at once
 	{ const char *e = getenv("SRBA_HIP_BIG_GRAPHS"); if (e) c->big_use_graphs = atoi(e) != 0; }         // 1 = replay the big path's launch sequences as HIP graphs (measured: no gain, the path is bound by its kernels)
@@ -1027,7 +1036,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		const srba_problem_capsule &k = caps[p]; ProbDesc &d = c->desc[p];
 		if (why[p]) { c->fail(std::string("upload: malformed capsule (") + why[p] + ")"); return -1; }
 		d.n_edges = k.n_edges; d.nK = k.n_unk_edges; d.nF = k.n_unk_lms; d.n_klm = k.n_known_lms; d.n_pairs = k.n_pairs; d.n_obs = k.n_obs; d.n_valid = k.n_valid; d.n_bp = k.n_bp; d.n_bf = k.n_bf;
-		d.n_hap = k.n_hap; d.n_hf = k.n_hf; d.n_hapf = k.n_hapf; d.n_sch = k.n_sch_terms;
+		d.n_hap = k.n_hap; d.n_hf = k.n_hf; d.n_hapf = k.n_hapf; d.n_sch = k.n_sch_terms; d.n_hapt = k.n_hap_terms;
 		d.n_scal = P * d.nK + L * d.nF; d.n_sys = (schur_solver && d.nF > 0 && d.nK > 0) ? P * d.nK : d.n_scal;
 		if (schur_solver && d.nK == 0) { c->fail("upload: Schur solvers need at least one unknown kf2kf edge (the reference has the same restriction, schur.h:34)"); return -1; }
 		int nreq = 0; for (int i = 0; i < 2 * k.n_pairs; i++) nreq += k.pose_required[i] ? 1 : 0; d.n_req = nreq;
@@ -1081,7 +1090,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	// ---- input arena layout
 	Arena in; struct { size_t desc, edge0, ulm0, klm, obs_z, pair_path_off, path_edge, obs_pose, obs_lm, obs_valid, bp_col, bp_res, bp_A, bp_D, bp_lm, colp_off, bf_col, bf_res, bf_pose, colf_off,
 		hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hap_tblk, hf_i, hf_j, hf_term_off, hf_t1, hf_t2, hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag, sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw, sch_tblk,
-		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, pair_needed, pose_req, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_ab, sp_rptr, sp_rcol, sp_rblk, sp_perm, sp_fill, hap_rec, hap_dst, hapf_dst, hf_dst; } o;
+		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, pair_needed, pose_req, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_ab, sp_rptr, sp_rcol, sp_rblk, sp_perm, sp_fill, hap_rec, hap_dst, hapf_dst, hf_dst, asm_term, asm_blk, asm_desc, asm_list, asm_slot; } o;
 	o.desc = in.add(sizeof(ProbDesc) * n);
 	o.edge0 = in.add(8 * t_edge * PDX); o.ulm0 = in.add(8 * t_ulm * L); o.klm = in.add(8 * t_klm * L); o.obs_z = in.add(8 * t_obs * O);
 	o.pair_path_off = in.add(4 * (t_pair + n)); o.path_edge = in.add(4 * t_path); o.obs_pose = in.add(4 * t_obs); o.obs_lm = in.add(4 * t_obs); o.obs_valid = in.add(4 * t_obs);
@@ -1095,6 +1104,10 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	o.lm_hapf_off = in.add(4 * (t_ulm + n)); o.lm_hapf_idx = in.add(4 * t_hapf); o.req_idx = in.add(4 * t_req); o.need_idx = in.add(4 * t_pair); o.need_rec = in.add(4 * 5 * std::max<long long>(t_pair, 1)); o.pair_needed = in.add(t_pair); o.pose_req = in.add(2 * t_pair); o.bp_normal = in.add(t_bp); o.order = in.add(4 * (size_t)n);
 	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_ab = in.add(4 * t_spitem); o.sp_rptr = in.add(4 * t_spcol); o.sp_rcol = in.add(4 * t_sprow); o.sp_rblk = in.add(4 * t_sprow); o.sp_perm = in.add(4 * t_spcol); o.hap_rec = in.add(4 * 3 * std::max<long long>(t_hap, 1)); o.sp_fill = in.add(4 * std::max<long long>(t_spfill, 1));
 	o.hap_dst = in.add(4 * t_hap * (P / 3) * (P / 3)); o.hapf_dst = in.add(4 * t_hapf * (P / 3)); o.hf_dst = in.add(4 * t_hf);
+	bool asm_fam = c->asm_on && c->params.family == SRBA_SE2_RELPOSE2D;
+	if (asm_fam && c->dp.noise == SRBA_NOISE_CONSTANT_MATRIX) for (int i = 0; i < 3; i++) for (int j = 0; j < i; j++) if (c->dp.lambda[3 * i + j] != c->dp.lambda[3 * j + i]) asm_fam = false; // the fused kernel sums the upper triangle of J^t Lambda J only
+	o.asm_term = in.add(asm_fam ? 8 * std::max<long long>(t_hapt, 1) : 0); o.asm_blk = in.add(asm_fam ? 8 * std::max<long long>(t_bp, 1) : 0); o.asm_desc = in.add(asm_fam ? sizeof(srbadev::AsmDesc) * (size_t)n : 0); o.asm_list = in.add(asm_fam ? 4 * (size_t)n : 0); o.asm_slot = in.add(asm_fam ? 8 * (size_t)srbadev::ASM_WAVES_PER_WG * (size_t)n : 0); // (at most one bin per capsule)
+	std::vector<unsigned char> asm_fit(asm_fam ? n : 0, 0); std::vector<int> asm_nt(asm_fam ? n : 0, 0); // per capsule: its indices fit the packed records; off-diagonal terms
 	in.add(0);
 	if (c->h_in_cap < in.size + 256) { c->h_in.reset(); c->h_in.reset(new char[in.size + 256]); c->h_in_cap = in.size + 256; } // uninitialised: cleared below, in parallel
 	char *h = c->h_in.get();
@@ -1141,6 +1154,19 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		{ std::vector<int32_t> ho(k.n_hap); for (int b = 0; b < k.n_hap; b++) ho[b] = b;
 		  std::stable_sort(ho.begin(), ho.end(), [&](int x, int y) { return k.hap_term_off[x + 1] - k.hap_term_off[x] > k.hap_term_off[y + 1] - k.hap_term_off[y]; });
 		  int32_t *hr = (int32_t *)(h + o.hap_rec) + 3 * d.o_hap; for (int i = 0; i < k.n_hap; i++) { hr[3 * i] = ho[i]; hr[3 * i + 1] = k.hap_term_off[ho[i]]; hr[3 * i + 2] = k.hap_term_off[ho[i] + 1]; } }
+		if (asm_fam && k.n_bp >= 1 && k.n_bp <= 65536 && 2 * k.n_pairs < 65535 && k.n_obs <= 65536 && d.nK <= 8191 && k.n_hap <= 65536) { // packed records of the fused normal-equations kernel (srba_assemble.hpp)
+			uint64_t *ab = (uint64_t *)(h + o.asm_blk) + d.o_bp, *at = (uint64_t *)(h + o.asm_term) + d.o_hapt; bool fit = true; const int cb = (k.n_bp + 63) / 64;
+			for (int i = 0; i < d.nK && fit; i++) { // the blocks of unknown i are colp_off[i] .. colp_off[i + 1] - 1, and its diagonal Hessian block sums exactly their J^t Lambda J
+				const int bb = k.colp_off[i], be = k.colp_off[i + 1], hd = k.hap_diag[i]; if (be <= bb || hd < 0 || k.hap_term_off[hd + 1] - k.hap_term_off[hd] != be - bb) { fit = false; break; }
+				for (int b = bb; b < be; b++) { const int t = k.hap_term_off[hd] + (b - bb); if (k.bp_col[b] != i || k.hap_t1[t] != b || k.hap_t2[t] != b || k.bp_D[b] < -1) fit = false;
+					ab[b] = (uint64_t)((uint32_t)(k.bp_D[b] + 1) | ((uint32_t)i << 16) | (k.bp_normal[b] ? 0u : 0x20000000u) | (b == bb ? 0x40000000u : 0u) | (b + 1 == be ? 0x80000000u : 0u)) | ((uint64_t)((uint32_t)k.bp_res[b] | ((uint32_t)hd << 16)) << 32); }
+			}
+			if (fit && k.colp_off[d.nK] != k.n_bp) fit = false;
+			int nt = 0; auto slot = [&](int b) { return (uint32_t)((b % cb) * 64 + b / cb); };
+			for (int b = 0; b < k.n_hap && fit; b++) if (k.hap_i[b] != k.hap_j[b]) { const int tb = k.hap_term_off[b], te = k.hap_term_off[b + 1]; if (te <= tb) { fit = false; break; }
+				for (int t = tb; t < te; t++) at[nt++] = (uint64_t)(slot(k.hap_t1[t]) | ((k.bp_normal[k.hap_t1[t]] != 0) != (k.bp_normal[k.hap_t2[t]] != 0) ? 0x8000u : 0u) | (slot(k.hap_t2[t]) << 16)) | ((uint64_t)((uint32_t)b | (t == tb ? 0x40000000u : 0u) | (t + 1 == te ? 0x80000000u : 0u)) << 32); }
+			if (fit) { asm_fit[p] = 1; asm_nt[p] = nt; }
+		}
 		CPY(o.hap_dst, d.o_hap * (P / 3) * (P / 3), sym[p].hap_dst.data(), sym[p].hap_dst.size(), int32_t); CPY(o.hapf_dst, d.o_hapf * (P / 3), sym[p].hapf_dst.data(), sym[p].hapf_dst.size(), int32_t); CPY(o.hf_dst, d.o_hf, sym[p].hf_dst.data(), sym[p].hf_dst.size(), int32_t);
 		acc_blocks[thread] += d.nb + d.nnzoff; acc_items[thread] += (int64_t)sym[p].tgt.size();
 	}
@@ -1169,6 +1195,26 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		}
 		plan_launches(c, ord);
 	}
+	c->asm_ready = false; c->jp_stale = false;
+	if (asm_fam) { // fused normal equations: the LDS image of a capsule = 32 B per block slot (64 * cb slots) + gradient + poses of the unknown edges, + 72 B per Hessian block when
+		// the blocks are staged (windows whose full image fits a bin; larger ones store their blocks directly). Capsules of similar size share a bin (one workgroup, ASM_BIN_BYTES of
+		// LDS, a wavefront each): neighbours in the order of their images, as long as they fit together.
+		constexpr int W = srbadev::ASM_WAVES_PER_WG; const size_t cap = std::min<size_t>(srbadev::ASM_BIN_BYTES, (size_t)c->asm_max_kb * 1024);
+		std::vector<size_t> need(n, 0); std::vector<int> fit; fit.reserve(n); int32_t *al = (int32_t *)(h + o.asm_list); c->asm_rest = 0;
+		srbadev::AsmDesc *ad = (srbadev::AsmDesc *)(h + o.asm_desc);
+		for (int p = 0; p < n; p++) { const ProbDesc &d = c->desc[p]; const int cb = (d.n_bp + 63) / 64; const size_t lean = (8 * (4 * 64 * (size_t)cb + 3 * (size_t)d.nK + PDX * (size_t)d.nK) + 255) & ~(size_t)255, full = lean + 72 * (size_t)d.n_hap + 256;
+			const int stage = full <= cap ? 1 : 0; need[p] = stage ? full : lean;
+			if (asm_fit[p] && need[p] <= cap && cb <= 511) fit.push_back(p); else al[c->asm_rest++] = p;
+			ad[p] = {p, d.n_bp, asm_nt[p], cb, (asm_nt[p] + 63) / 64, d.n_hap, d.nK, stage, d.o_bp, d.o_hapt, d.o_pair * 2 * PDX, d.o_edge * PDX, d.o_obs * O, d.o_hap, d.o_scal}; }
+		std::stable_sort(fit.begin(), fit.end(), [&](int x, int y) { return need[x] < need[y]; });
+		int32_t *sl = (int32_t *)(h + o.asm_slot); int nb = 0;
+		for (size_t i = 0; i < fit.size();) { int32_t *e = sl + 2 * W * (size_t)nb; size_t used = 0; int cnt = 0;
+			while (cnt < W && i < fit.size() && used + need[fit[i]] <= cap) { e[2 * cnt] = fit[i]; e[2 * cnt + 1] = (int32_t)used; used += need[fit[i]]; cnt++; i++; }
+			for (; cnt < W; cnt++) { e[2 * cnt] = -1; e[2 * cnt + 1] = 0; }
+			nb++; }
+		for (int a = 0, b = nb - 1; a < b; a++, b--) for (int q = 0; q < 2 * W; q++) std::swap(sl[2 * W * (size_t)a + q], sl[2 * W * (size_t)b + q]); // the longest-running bins are dispatched first
+		c->asm_bins = nb; c->asm_ready = true;
+	}
 	// ---- work arena layout
 	Arena wk; struct { size_t edge, ulm, pose, Jp, Jf, resid, resid2, HAp, HAp0, Hf, HApf, grad, delta, Hfinv, YW, old_edge, old_ulm, old_pose, dense, ulm_inf, valid, first_fail, hf_ok, bp_ok, bf_ok, ulm_inf_valid, results, lambda_io, chi2, notpd, phase_cycles, m_pair, grad0, edge1, ulm1, pose1, lmst, rlist, rcount, rctr, runf, rhist; } w;
 	w.edge = wk.add(8 * t_edge * PDX); w.ulm = wk.add(8 * t_ulm * L); w.pose = wk.add(8 * 2 * t_pair * PDX); w.Jp = wk.add(8 * t_bp * O * P); w.Jf = wk.add(8 * t_bf * O * L);
@@ -1195,6 +1241,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	DI(bf_col, int); DI(bf_res, int); DI(bf_pose, int); DI(colf_off, int); DI(hap_i, int); DI(hap_j, int); DI(hap_term_off, int); DI(hap_t1, int); DI(hap_t2, int); DI(hap_tblk, int); DI(hf_i, int); DI(hf_j, int); DI(hf_term_off, int); DI(hf_t1, int); DI(hf_t2, int);
 	DI(hapf_i, int); DI(hapf_j, int); DI(hapf_term_off, int); DI(hapf_t1, int); DI(hapf_t2, int); DI(hap_diag, int); DI(hf_diag, int); DI(sch_term_off, int); DI(sch_b1, int); DI(sch_b2, int); DI(sch_lm, int); DI(sch_yw, int); DI(sch_tblk, int);
 	DI(lm_hapf_off, int); DI(lm_hapf_idx, int); DI(req_idx, int); DI(need_idx, int); DI(need_rec, int); DI(pair_needed, unsigned char); DI(pose_req, unsigned char); DI(bp_normal, unsigned char);
+c->asm_tab.term = asm_fam ? (const unsigned long long *)(di + o.asm_term) : nullptr; c->asm_tab.blk = asm_fam ? (const unsigned long long *)(di + o.asm_blk) : nullptr; c->asm_tab.desc = asm_fam ? (const srbadev::AsmDesc *)(di + o.asm_desc) : nullptr; c->asm_tab.slot = asm_fam ? (const int2 *)(di + o.asm_slot) : nullptr; c->asm_list = asm_fam ? (const int *)(di + o.asm_list) : nullptr;
 #undef DI
 #define DW(field, T) B.field = (T *)(dw + w.field)
 	DW(edge, double); DW(ulm, double); DW(pose, double); DW(Jp, double); DW(Jf, double); DW(resid, double); DW(resid2, double); DW(HAp, double); DW(HAp0, double); DW(Hf, double); DW(HApf, double); DW(grad, double); DW(grad0, double); DW(delta, double); DW(edge1, double); DW(ulm1, double); DW(pose1, double);
@@ -1210,6 +1257,10 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	c->n_pose_total = 2 * t_pair;
 	for (int i = 0; i < 10; i++) { c->off_dbg[i] = dbg_off[i]; c->len_dbg[i] = dbg_len[i]; }
 	c->n_prob = n; st.device_bytes = (int64_t)(in.size + wk.size);
+	if (c->asm_ready) { // every observation row of this family is valid (its Jacobian blocks have no failure case): the flags the unfused kernel rewrites at every call are set once
+		if (t_valid) HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)(dw + w.valid), 1, (size_t)t_valid, c->stream));
+		if (t_bp) HIPCHK(c, hipMemsetD8Async((hipDeviceptr_t)(dw + w.bp_ok), 1, (size_t)t_bp, c->stream));
+	}
 	if (srba_hip_reset_state(c) != 0) return -1;
 	HIPCHK(c, hipStreamSynchronize(c->stream)); // the staging buffer is pageable and reused by the next upload
 	return 0;
@@ -1690,7 +1741,12 @@ int srba_hip_eval_residuals(srba_hip_ctx *c, double *chi2_out) {
 int srba_hip_linearize(srba_hip_ctx *c) {
 	if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device));
 	const int lds_doubles = c->lin_terms ? 16 + 1536 : 16; // 12 KB of Hessian accumulators per wavefront: U_Ap of up to 170 SE2 / 42 SE3 blocks (bigger capsules take the per-block path)
-	SRBA_DISPATCH(c, k_linearize, (size_t)lds_doubles * 8, lds_doubles); HIPCHK(c, hipGetLastError()); return 0;
+	if (c->asm_ready) { // relative-pose SE2: fused, Jacobian blocks never leave the chip (srba_assemble.hpp): one launch, a workgroup per bin of capsules; what does not fit a bin takes the unfused kernel
+		if (c->asm_bins > 0 && srbadev::asm_launch(c->dp.noise == SRBA_NOISE_CONSTANT_MATRIX, c->asm_bins, srbadev::ASM_BIN_BYTES, c->stream, c->B, c->dp, c->asm_tab) != 0) { c->fail("k_assemble_se2rel: launch failed"); return -1; }
+		if (c->asm_rest > 0) { with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::k_linearize<decltype(fam_)::value>), dim3(c->asm_rest), dim3(SRBA_WG), (size_t)lds_doubles * 8, c->stream, c->B, c->dp, lds_doubles, c->asm_list); }); HIPCHK(c, hipGetLastError()); }
+		c->jp_stale = c->asm_bins > 0; return 0;
+	}
+	SRBA_DISPATCH(c, k_linearize, (size_t)lds_doubles * 8, lds_doubles, (const int *)nullptr); HIPCHK(c, hipGetLastError()); c->jp_stale = false; return 0;
 }
 int srba_hip_solve(srba_hip_ctx *c, const double *lambda, int32_t *not_pd_out) {
 	if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device));
@@ -1749,6 +1805,7 @@ int srba_hip_debug_read(srba_hip_ctx *c, int what, double *out, int64_t n_double
 	}
 	if (!c || what < 0 || what >= 10 || n_doubles < c->len_dbg[what]) return -1;
 	HIPCHK(c, hipSetDevice(c->device));
+	if (what == 1 && c->jp_stale) { SRBA_DISPATCH(c, k_jacobians_only, 0); HIPCHK(c, hipGetLastError()); c->jp_stale = false; } // the fused linearisation keeps the Jacobian blocks on the chip: materialise them for the reader
 	if (what == 9 && c->dm.PDX() != c->dm.PD) { // ST poses: strip the cached cos/sin of the device layout
 		const int PD = c->dm.PD, PDX = c->dm.PDX(); std::vector<double> v((size_t)c->n_pose_total * PDX);
 		HIPCHK(c, hipMemcpyAsync(v.data(), c->d_wk + c->off_dbg[9], 8 * v.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
