@@ -349,6 +349,12 @@ def main():
                 cpu["value_O3"] = float(r3["num_trials"].sum() / dt3)
             except Exception as e:  # noqa: BLE001
                 cpu["value_O3"] = None; cpu["value_O3_error"] = str(e)
+            try:   # the sequential drop-in run (define_new_keyframe key-frame by key-frame) with the oracle as numeric back-end, beside config.sequential_ms_per_kf of the GPU back-end
+                n_seq = 2000; ds_seq = datasets.graph_slam_se2(n_kf=n_seq, seed=multi.replica_seed(rank), path="tour"); t1 = time.perf_counter()
+                eng_seq = runner.graph_slam_engine(backend=_oracle.BACKEND, submap=10, depth=3, sigma_xy=1e-3, sigma_yaw_deg=0.2, harvest=0); eng_seq.run(ds_seq); eng_seq.close(); cpu["sequential_ms_per_kf"] = 1e3 * (time.perf_counter() - t1) / n_seq
+                cpu["sequential_note"] = "the first %d key-frames of the same map built through the same front-end with the oracle (one host thread) as numeric back-end" % n_seq
+            except Exception as e:  # noqa: BLE001
+                cpu["sequential_ms_per_kf"] = None; cpu["sequential_note"] = str(e)
             if cores > 1:   # and the scalar figure (the reference is single-threaded), on a smaller sample
                 m1 = max(200, m // (2 * cores)); t1 = time.perf_counter(); r1 = _oracle.run_batch(batch.sub(0, m1), threads=1); dt1 = time.perf_counter() - t1
                 cpu["one_thread_value"] = float(r1["num_trials"].sum() / dt1)

@@ -156,6 +156,143 @@ __global__ void __launch_bounds__(256) k_chol_update(const BigSys S, int k0, int
 			}
 }
 
+// ---- the whole factorisation in ONE launch ("a device-resident factorisation does not exist"): the panel steps and trailing updates above as phases of a
+// persistent kernel, separated by grid-wide barriers (a counter in HBM: every workgroup adds one and waits for all `gridDim.x` of the phase; release / acquire fences at
+// agent scope carry the matrix across the eight L2s). The grid is sized so that every workgroup is resident (at most 120 workgroups of 256 threads and 34 KB of LDS per
+// factorisation, a few factorisations side by side on 256 CUs); a wait that lasts more than ~0.5 s gives up and raises flag 2 (reported as an error by the host) instead
+// of hanging the device. Same arithmetic in the same order as k_chol_panel / k_chol_update: bit-identical factors.
+__device__ __forceinline__ bool grid_barrier(unsigned *count, unsigned target, int *flag) {
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		__threadfence();
+		atomicAdd(count, 1u);
+		long long spins = 0;
+		while ((int)(__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+			__builtin_amdgcn_s_sleep(4);
+			if (++spins > (1ll << 23)) { atomicExch(flag, 2); break; }
+		}
+		__threadfence();
+	}
+	__syncthreads();
+	return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+}
+__global__ void __launch_bounds__(256) k_chol_persistent(const BigSys S, unsigned *bar) {
+	__shared__ double sh[2 * CT * (CB + 1)]; // trailing update: X_i | X_j ; panel step: L_kk with the right-hand side row (33 x 33) | reciprocal diagonal
+	const int G = gridDim.x, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ld = S.ld;
+	unsigned target = 0; bool ok = true;
+	for (int k0 = 0; k0 < ld && ok; k0 += CB) {
+		const int below = ld - k0 - CB, nchunk = 1 + (below + 63) / 64; // chunk 0 publishes L_kk and y_k, chunk c >= 1 solves rows k0 + CB + 64 (c - 1) .. + 63 of the panel
+		// ---- panel step (first wavefront of every workgroup: the diagonal block is factored redundantly, as in k_chol_panel, so that every workgroup sees a bad pivot itself)
+		if (w == 0) {
+			double *Ls = sh, *ri = sh + (CB + 1) * (CB + 1);
+			for (int c = b; c < nchunk || c == b; c += G) { // (every workgroup factors at least once per step)
+				const int row = k0 + CB + 64 * (c - 1) + lane; const bool has_row = c >= 1 && c < nchunk && row < ld;
+				double *Arow = (double *)__builtin_assume_aligned(S.A + (size_t)(has_row ? row : k0) * ld + k0, 16);
+				double x[CB];
+				if (has_row) {
+#pragma unroll
+					for (int q = 0; q < CB; q++) x[q] = Arow[q];
+				}
+				double a[CB], rinv[CB];
+				{ const double *src = (const double *)__builtin_assume_aligned(S.A + (size_t)(k0 + (lane & (CB - 1))) * ld + k0, 16);
+				  const double *rh = (const double *)__builtin_assume_aligned(S.rhs + k0, 16);
+#pragma unroll
+				  for (int q = 0; q < CB; q++) { const double v = src[q], bb = rh[q]; a[q] = lane < CB ? (q <= lane ? v : 0.0) : (lane == CB ? bb : 0.0); } }
+				if (!chol_block_regs(a, rinv, lane)) { if (b == 0 && lane == 0) atomicExch(S.flag, 1); ok = false; break; }
+				if (c == 0) {
+					if (lane < CB) {
+						double *dst = (double *)__builtin_assume_aligned(S.Ldiag + (size_t)(k0 + lane) * CB, 16);
+#pragma unroll
+						for (int q = 0; q < CB; q++) dst[q] = a[q];
+					} else if (lane == CB) {
+#pragma unroll
+						for (int q = 0; q < CB; q++) S.y[k0 + q] = a[q];
+					}
+				} else if (c < nchunk) {
+					if (lane <= CB) {
+#pragma unroll
+						for (int q = 0; q < CB; q++) Ls[lane * (CB + 1) + q] = a[q];
+					}
+					if (lane == 0) {
+#pragma unroll
+						for (int q = 0; q < CB; q++) ri[q] = rinv[q];
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+					if (has_row) {
+						double acc = 0;
+#pragma unroll
+						for (int j = 0; j < CB; j++) {
+							double sm = x[j];
+#pragma unroll
+							for (int m = 0; m < j; m++) sm -= x[m] * Ls[j * (CB + 1) + m];
+							x[j] = sm * ri[j];
+							acc += x[j] * Ls[CB * (CB + 1) + j];
+						}
+#pragma unroll
+						for (int q = 0; q < CB; q++) Arow[q] = x[q];
+						S.rhs[row] -= acc;
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				}
+				if (c >= nchunk) break;
+			}
+		}
+		// a bad pivot is seen by the first wavefront of EVERY workgroup (same data, same arithmetic): all of them leave the loop after this barrier
+		{ __shared__ int bad; if (tid == 0) bad = 0; __syncthreads(); if (w == 0 && lane == 0 && !ok) bad = 1; __syncthreads(); ok = bad == 0; }
+		target += G; if (!grid_barrier(bar, target, S.flag)) break;
+		if (!ok || below <= 0) break;
+		// ---- trailing update C -= X_i X_j^t, one 64 x 64 tile of the lower triangle per workgroup and pass
+		double *Xi = sh, *Xj = sh + CT * (CB + 1);
+		const int nt = (below + CT - 1) / CT, ntile = nt * (nt + 1) / 2, base = k0 + CB;
+		for (int t = b; t < ntile; t += G) {
+			int ti = 0; while ((ti + 1) * (ti + 2) / 2 <= t) ti++; const int tj = t - ti * (ti + 1) / 2;
+			const int i0 = base + CT * ti, j0 = base + CT * tj, wr = w >> 1, wc = w & 1;
+			const bool active = !(ti == tj && wc > wr);
+			f64x4 acc[2][2];
+#pragma unroll
+			for (int a2 = 0; a2 < 2; a2++)
+#pragma unroll
+				for (int b2 = 0; b2 < 2; b2++)
+#pragma unroll
+					for (int r = 0; r < 4; r++) {
+						const int gi = i0 + wr * 32 + a2 * 16 + (lane >> 4) + 4 * r, gj = j0 + wc * 32 + b2 * 16 + (lane & 15);
+						acc[a2][b2][r] = (active && gi < ld && gj < ld) ? S.A[(size_t)gi * ld + gj] : 0.0;
+					}
+			for (int e = tid; e < CT * CB; e += 256) {
+				const int r = e / CB, cc = e % CB;
+				Xi[r * (CB + 1) + cc] = (i0 + r < ld) ? -S.A[(size_t)(i0 + r) * ld + k0 + cc] : 0.0;
+				Xj[r * (CB + 1) + cc] = (j0 + r < ld) ? S.A[(size_t)(j0 + r) * ld + k0 + cc] : 0.0;
+			}
+			__syncthreads();
+			if (active) {
+#pragma unroll
+				for (int kk = 0; kk < CB / 4; kk++) {
+					double fa[2], fb[2];
+#pragma unroll
+					for (int a2 = 0; a2 < 2; a2++) fa[a2] = Xi[(wr * 32 + a2 * 16 + (lane & 15)) * (CB + 1) + 4 * kk + (lane >> 4)];
+#pragma unroll
+					for (int b2 = 0; b2 < 2; b2++) fb[b2] = Xj[(wc * 32 + b2 * 16 + (lane & 15)) * (CB + 1) + 4 * kk + (lane >> 4)];
+#pragma unroll
+					for (int a2 = 0; a2 < 2; a2++)
+#pragma unroll
+						for (int b2 = 0; b2 < 2; b2++) acc[a2][b2] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a2], fb[b2], acc[a2][b2], 0, 0, 0);
+				}
+#pragma unroll
+				for (int a2 = 0; a2 < 2; a2++)
+#pragma unroll
+					for (int b2 = 0; b2 < 2; b2++)
+#pragma unroll
+						for (int r = 0; r < 4; r++) {
+							const int gi = i0 + wr * 32 + a2 * 16 + (lane >> 4) + 4 * r, gj = j0 + wc * 32 + b2 * 16 + (lane & 15);
+							if (gi < ld && gj < ld) S.A[(size_t)gi * ld + gj] = acc[a2][b2][r];
+						}
+			}
+			__syncthreads(); // the operands in LDS are rewritten by the next tile
+		}
+		target += G; if (!grid_barrier(bar, target, S.flag)) break;
+	}
+}
+
 // L^t x = y in place in S.y (one workgroup): block rows from the last to the first. The CB x CB triangular solve runs in the first wavefront with column
 // `lane` of L_kk in registers (x_c travels by v_readlane); all four wavefronts then eliminate x_k from the rows above.
 __global__ void __launch_bounds__(256) k_chol_bsub(const BigSys S) {

@@ -797,7 +797,7 @@ struct srba_hip_ctx {
 	double big_chol_ms = 0, big_chol_flops = 0; long long big_chol_count = 0; int big_chol_nmax = 0; // Cholesky time / flops of the big path since the last upload (sum over the lanes)
 	BigLane lanes[kBigLanes]; int n_lanes_ready = 0; // lane 0 = the context stream and buffers; the others are created on first use
 	struct BigGraphSet { hipGraphExec_t g[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; }; // assemble, Cholesky, back-substitution .. rho, accept + relinearise, accept
-	std::map<int, BigGraphSet> big_graphs; bool big_use_graphs = false; int big_lanes_max = kBigLanes; // captured launch sequences of the big path, per capsule; dropped at upload
+	std::map<int, BigGraphSet> big_graphs; bool big_use_graphs = false, big_persistent = false; int big_lanes_max = kBigLanes; // captured launch sequences of the big path, per capsule; dropped at upload
 	int upload_threads = 1; bool dense_left = true; int hbm_from_kb = 48; bool dense_blocks_ok = true; // mid-size nearly-full systems use the dense block layout in LDS
 	bool lin_terms = true, lm_terms = true; // term-parallel U_Ap accumulation in LDS: srba_hip_linearize / the fused LM kernel
 	// fused normal equations of the relative-pose SE2 family (srba_assemble.hpp): capsules packed into bins (workgroups) by the LDS image they need, one launch; the rest take k_linearize
@@ -962,6 +962,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_ASSEMBLE"); if (e) c->asm_on = atoi(e) != 0; }                   // 0 = srba_hip_linearize always runs the unfused kernel (Jacobian blocks through HBM)
 	{ const char *e = getenv("SRBA_HIP_FLAT"); if (e) c->use_flat = atoi(e) != 0; }                     // 0 = one wavefront per capsule for the stepwise spanning-tree launch
 	{ const char *e = getenv("SRBA_HIP_BIG_LANES"); if (e && atoi(e) >= 1) c->big_lanes_max = std::min(atoi(e), kBigLanes); } // large capsules of one batch in flight at once
+	{ const char *e = getenv("SRBA_HIP_BIG_PERSISTENT"); if (e) c->big_persistent = atoi(e) != 0; }   // 1 = the blocked Cholesky of the big path as ONE persistent launch with grid barriers (k_chol_persistent) instead of one launch per panel step and per trailing update (~60 launches); measured slower, DESIGN 4c
 	{ const char *e = getenv("SRBA_HIP_BIG_GRAPHS"); if (e) c->big_use_graphs = atoi(e) != 0; }         // 1 = replay the big path's launch sequences as HIP graphs (measured: no gain, the path is bound by its kernels)
 	return c;
 }
@@ -1355,6 +1356,13 @@ static void big_enqueue_assemble(srba_hip_ctx *c, BigLane *ln, int p) {
 }
 static void big_enqueue_cholesky(srba_hip_ctx *c, BigLane *ln, int p) {
 	const srbadev::BigSys S = big_sys(c, ln, p);
+	if (c->big_persistent) { // the whole factorisation in one launch: panel steps and trailing updates separated by grid barriers (srba_big.hpp, k_chol_persistent)
+		const int below0 = S.ld - srbadev::CB, nt0 = below0 > 0 ? (below0 + srbadev::CT - 1) / srbadev::CT : 0, G = std::max(1, std::min(120, std::max(nt0 * (nt0 + 1) / 2, 1 + (below0 > 0 ? (below0 + 63) / 64 : 0))));
+		unsigned *bar = (unsigned *)(ln->d_iscal + 4);
+		(void)hipMemsetAsync(bar, 0, 4, ln->stream);
+		hipLaunchKernelGGL(srbadev::k_chol_persistent, dim3(G), dim3(256), 0, ln->stream, S, bar);
+		return;
+	}
 	for (int k0 = 0; k0 < S.ld; k0 += srbadev::CB) {
 		const int below = S.ld - k0 - srbadev::CB;
 		hipLaunchKernelGGL(srbadev::k_chol_panel, dim3(1 + (below + 63) / 64), dim3(64), 0, ln->stream, S, k0);
@@ -1388,6 +1396,7 @@ static int big_solve(srba_hip_ctx *c, BigLane *ln, int p, double lambda, bool *p
 	big_enqueue_backsub(c, ln, p);
 	int flag = 0; LNCHK(ln, hipMemcpyAsync(&flag, ln->d_iscal + 1, 4, hipMemcpyDeviceToHost, ln->stream)); LNCHK(ln, hipStreamSynchronize(ln->stream));
 	big_account_cholesky(c, ln, p);
+	if (flag == 2) { ln->error = "k_chol_persistent: a grid barrier timed out (the workgroups of the factorisation were not all resident)"; return -1; }
 	*pos_def = (flag == 0);
 	LNCHK(ln, hipGetLastError());
 	return 0;
@@ -1438,6 +1447,7 @@ static int big_lm_run(srba_hip_ctx *c, BigLane *ln, int p) {
 				enqueue_dot(1, BS_DEN, 0, flag); }) != 0) return -1;
 			if (fetch() != 0) return -1;
 			big_account_cholesky(c, ln, p);
+			if (hflag == 2) { ln->error = "k_chol_persistent: a grid barrier timed out (the workgroups of the factorisation were not all resident)"; return -1; }
 			if (hflag) { n_notpd++; lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA; continue; }
 			const double new_err = hs[BS_CHI2], new_RMSE = std::sqrt(new_err / d.n_obs), err_red = total_err > 0 ? (total_err - new_err) / total_err : 0;
 			rho = (total_err - new_err) / hs[BS_DEN];

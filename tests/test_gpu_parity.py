@@ -507,3 +507,40 @@ def test_schur_gradient_defect_is_reproduced_and_its_repair_matches_the_oracle(m
     gput = runner.run_batch_hip(tail)
     monkeypatch.delenv("SRBA_HIP_MAX_LDS_KB")
     assert _close(gput["chi2_final"], reft["chi2_final"], rel=1e-6) and gput["obs_rmse"].max() < 1.5
+
+
+@pytest.mark.gpu
+def test_deep_monocular_window_with_the_reference_defaults(monkeypatch):
+    """The deep window (max_tree_depth = max_optimize_depth = 8) with the reference's spanning-tree refresh to the letter (no extension bit): the map holds for 25 key-frames
+    (the stale twin of DESIGN section 8, item 2, ends it at the 26th); the last windows before that -- every key-frame of the map is in the window -- on the one-wavefront
+    path and on the multi-workgroup path against the oracle at 1e-6."""
+    ds, _ = datasets.mono_deep_window(n_kf=29, n_lm=600, seed=1)
+    eng = runner.landmark_engine("mono", backend=_oracle.BACKEND, depth=8, submap=20, sigma=0.5, robust=0, harvest=1, cam=(200., 200., 400., 320.), refresh_all_read_poses=0)
+    eng.run(ds); b = eng.harvest(); b.engine = eng
+    assert b.params.extensions == 0
+    sub = b.sub(20, 5); ref = _oracle.run_batch(sub)
+    assert ref["obs_rmse"].max() < 1.0 and sub[4].n_unk_edges == 25
+    gpu = runner.run_batch_hip(sub)
+    _compare_lm(sub, gpu, ref)
+    monkeypatch.setenv("SRBA_HIP_MAX_LDS_KB", "0")
+    big = runner.run_batch_hip(sub)
+    monkeypatch.delenv("SRBA_HIP_MAX_LDS_KB")
+    assert np.all(big["status"] == ref["status"]) and _close(big["chi2_init"], ref["chi2_init"], rel=1e-9) and _close(big["chi2_final"], ref["chi2_final"], rel=1e-6)
+    assert np.array_equal(big["num_observations"], ref["num_observations"]) and np.array_equal(big["num_jacobians"], ref["num_jacobians"])
+
+
+@pytest.mark.gpu
+def test_big_path_with_the_one_launch_factorisation(monkeypatch):
+    """SRBA_HIP_BIG_PERSISTENT=1: the blocked Cholesky of the multi-workgroup path as one persistent launch with grid barriers (srba_big.hpp, k_chol_persistent) instead of one
+    launch per panel step and trailing update. Same arithmetic in the same order: the results equal those of the default launches bit for bit, and the oracle's at 1e-6."""
+    from test_oracle_numeric import _harvest
+    b = _harvest("stereo", solver=capi.SOLVER_SCHUR_DENSE, n_kf=14)
+    sub = b.sub(max(0, b.n - 4), min(4, b.n)); ref = _oracle.run_batch(sub)
+    monkeypatch.setenv("SRBA_HIP_MAX_LDS_KB", "0")
+    base = runner.run_batch_hip(sub)
+    monkeypatch.setenv("SRBA_HIP_BIG_PERSISTENT", "1")
+    one = runner.run_batch_hip(sub)
+    monkeypatch.delenv("SRBA_HIP_BIG_PERSISTENT"); monkeypatch.delenv("SRBA_HIP_MAX_LDS_KB")
+    assert np.all(one["status"] == ref["status"]) and _close(one["chi2_final"], ref["chi2_final"], rel=1e-6, abs_=1e-18)
+    for k in ("chi2_final", "chi2_init", "num_trials", "trace_chi2", "trace_lambda"):
+        assert np.array_equal(np.nan_to_num(np.asarray(one[k], float), nan=-1.0), np.nan_to_num(np.asarray(base[k], float), nan=-1.0)), k
