@@ -1208,12 +1208,12 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 			if (asm_fit[p] && need[p] <= cap && cb <= 511) fit.push_back(p); else al[c->asm_rest++] = p;
 			ad[p] = {p, d.n_bp, asm_nt[p], cb, (asm_nt[p] + 63) / 64, d.n_hap, d.nK, stage, d.o_bp, d.o_hapt, d.o_pair * 2 * PDX, d.o_edge * PDX, d.o_obs * O, d.o_hap, d.o_scal}; }
 		std::stable_sort(fit.begin(), fit.end(), [&](int x, int y) { return need[x] < need[y]; });
-		int32_t *sl = (int32_t *)(h + o.asm_slot); int nb = 0;
-		for (size_t i = 0; i < fit.size();) { int32_t *e = sl + 2 * W * (size_t)nb; size_t used = 0; int cnt = 0;
-			while (cnt < W && i < fit.size() && used + need[fit[i]] <= cap) { e[2 * cnt] = fit[i]; e[2 * cnt + 1] = (int32_t)used; used += need[fit[i]]; cnt++; i++; }
-			for (; cnt < W; cnt++) { e[2 * cnt] = -1; e[2 * cnt + 1] = 0; }
+		// bins of two: the largest remaining image takes the smallest remaining one that fits beside it (a window too large for any partner stays alone); bins come out
+		// largest first, which is also the dispatch order (the longest-running workgroups start first)
+		int32_t *sl = (int32_t *)(h + o.asm_slot); int nb = 0; static_assert(W == 2, "the packing below makes pairs");
+		for (size_t lo = 0, hi = fit.size(); lo < hi;) { int32_t *e = sl + 2 * W * (size_t)nb; hi--; e[0] = fit[hi]; e[1] = 0;
+			if (lo < hi && need[fit[hi]] + need[fit[lo]] <= cap) { e[2] = fit[lo]; e[3] = (int32_t)need[fit[hi]]; lo++; } else { e[2] = -1; e[3] = 0; }
 			nb++; }
-		for (int a = 0, b = nb - 1; a < b; a++, b--) for (int q = 0; q < 2 * W; q++) std::swap(sl[2 * W * (size_t)a + q], sl[2 * W * (size_t)b + q]); // the longest-running bins are dispatched first
 		c->asm_bins = nb; c->asm_ready = true;
 	}
 	// ---- work arena layout
