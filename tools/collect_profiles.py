@@ -6,7 +6,7 @@ def last_json(path):
 bench = last_json(os.path.join(src, "bench.json")); cfg4 = bench["secondary_workloads"]["cfg4"]; sq = json.load(open(os.path.join(src, "sq_summary.json")))
 json.dump(bench, open(os.path.join(dst, tag + "bench.json"), "w"), indent=1)
 json.dump(sq, open(os.path.join(dst, tag + "sq_summary.json"), "w"), indent=1, sort_keys=True)
-for a, b in (("prof/lm_kernel_stats.csv", "bench_kernel_stats.csv"), ("prof_cfg4/c4_kernel_stats.csv", "cfg4_kernel_stats.csv"), ("prof/lm_domain_stats.csv", "bench_domain_stats.csv"), ("pytest_gpu.log", "pytest_gpu.log"), ("smoke.log", "smoke.log"), ("families.log", "families.log")):
+for a, b in (("prof/lm_kernel_stats.csv", "bench_kernel_stats.csv"), ("prof_cfg4/c4_kernel_stats.csv", "cfg4_kernel_stats.csv"), ("prof/lm_domain_stats.csv", "bench_domain_stats.csv"), ("pytest_gpu.log", "pytest_gpu.log"), ("smoke.log", "smoke.log"), ("families.log", "families.log"), ("soak.log", "soak_parity.log")):
     if os.path.exists(os.path.join(src, a)): shutil.copy(os.path.join(src, a), os.path.join(dst, tag + b))
 lm = sq["k_lm_run"]; fetch_kb, write_kb = lm["FETCH_SIZE"], lm["WRITE_SIZE"]
 traffic = {"round": rnd, "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --steps 1 --warmup 0 --cpu-seconds 0 (tools/pmc_bench.sh)",
