@@ -18,7 +18,7 @@ python - <<'PY'
 import csv, glob, collections, json
 d = json.loads([l for l in open('gpurun_out/pmcb_bench.json') if l.startswith('{')][-1])
 # per launch: the bench (--steps 1 --warmup 0) makes 2 fused launches (functional run + timed step) and 11 launches of each streaming kernel
-KERNELS = {'k_lm_run': 2, 'k_linearize': 11, 'kf_spantree': 11, 'k_residuals': 11}
+KERNELS = {'k_lm_run': 2, 'k_linearize': 11, 'k_assemble_se2rel': 11, 'kf_spantree': 11, 'k_residuals': 11}
 res = {}
 for kname, n_launch in KERNELS.items():
     out = {}
