@@ -28,8 +28,10 @@ template <int N> __device__ __forceinline__ void asm_scan_up(double (&O)[N], int
 
 // A block of this family is J = sg * K, K = [ c s k2 ; -s c k3 ; 0 0 1 ] with k2 = x s - y c, k3 = x c + y s: FOUR numbers {c, s, k2, k3} and a sign.
 // M = Lambda * K(b)   (identity Lambda: M = K)
-template <bool LAMBDA> __device__ __forceinline__ void asm_lambda_k(double (&M)[9], const double (&b)[4], const double *l) {
-	if constexpr (LAMBDA) {
+// LAMBDA: 0 = identity (scaled afterwards), 1 = diagonal matrix (the usual information matrix of a relative-pose observation: a third of the products), 2 = full matrix
+template <int LAMBDA> __device__ __forceinline__ void asm_lambda_k(double (&M)[9], const double (&b)[4], const double *l) {
+	if constexpr (LAMBDA == 1) { M[0] = l[0] * b[0]; M[1] = l[0] * b[1]; M[2] = l[0] * b[2]; M[3] = -(l[4] * b[1]); M[4] = l[4] * b[0]; M[5] = l[4] * b[3]; M[6] = 0; M[7] = 0; M[8] = l[8]; }
+	else if constexpr (LAMBDA == 2) {
 #pragma unroll
 		for (int k = 0; k < 3; k++) { M[3 * k] = l[3 * k] * b[0] - l[3 * k + 1] * b[1]; M[3 * k + 1] = l[3 * k] * b[1] + l[3 * k + 1] * b[0]; M[3 * k + 2] = l[3 * k] * b[2] + l[3 * k + 1] * b[3] + l[3 * k + 2]; }
 	} else { M[0] = b[0]; M[1] = b[1]; M[2] = b[2]; M[3] = -b[1]; M[4] = b[0]; M[5] = b[3]; M[6] = 0; M[7] = 0; M[8] = 1; }
@@ -50,16 +52,10 @@ template <int N> struct AsmRuns {
 		for (int k = 0; k < N; k++) { acc[k] = 0; lead[k] = 0; } }
 	// item `idx_in_lane` of this lane: value v, record words lo / hi (bit 30 of `flags`: first of its run, bit 31: last); emit(lo, hi, total) writes a finished run
 	template <class Emit> __device__ __forceinline__ void item(int idx_in_lane, const double (&v)[N], unsigned lo, unsigned hi, unsigned flags, Emit emit) {
-		if (flags & 0x40000000u) { started = true;
+		const bool first = (flags & 0x40000000u) != 0, fresh = first || idx_in_lane == 0; // (idx 0 without the flag: the run began in an earlier lane)
+		if (fresh) started = first;
 #pragma unroll
-			for (int k = 0; k < N; k++) acc[k] = v[k];
-		} else if (idx_in_lane == 0) { started = false; // the run began in an earlier lane
-#pragma unroll
-			for (int k = 0; k < N; k++) acc[k] = v[k];
-		} else {
-#pragma unroll
-			for (int k = 0; k < N; k++) acc[k] += v[k];
-		}
+		for (int k = 0; k < N; k++) acc[k] = fresh ? v[k] : acc[k] + v[k];
 		cur_lo = lo; cur_hi = hi;
 		if (flags & 0x80000000u) {
 			open = false;
@@ -99,7 +95,7 @@ template <int N> struct AsmRuns {
 #ifndef SRBA_ASM_U
 #define SRBA_ASM_U 4   /* blocks / terms in flight per lane */
 #endif
-template <bool LAMBDA>
+template <int LAMBDA>
 __global__ void __launch_bounds__(64 * ASM_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(SRBA_ASM_WAVES))) k_assemble_se2rel(const Batch B, const DevParams prm, const AsmTables T) {
 	constexpr int PD = 5, U = SRBA_ASM_U;
 	// a workgroup is a bin of up to four capsules whose LDS images share its allocation (packed at upload); its wavefronts work independently, one capsule each
@@ -111,7 +107,8 @@ __global__ void __launch_bounds__(64 * ASM_WAVES_PER_WG) __attribute__((amdgpu_w
 	const bool STAGE = d.stage != 0; // the Hessian blocks go through LDS and leave as one contiguous span; 0 (large windows): every block is stored by the lane that summed it, half the image
 	const int tid = threadIdx.x & 63, n_bp = d.n_bp, n_terms = d.n_terms, cb = d.cb, ct = d.ct, n_hap = d.n_hap, nK = d.nK;
 	// LDS image of the capsule: four numbers per block slot | the Hessian blocks | the gradient | the unknown edges' own poses
-	double *K4 = srba_lds + (slot.y >> 3), *Hb = K4 + 4 * 64 * cb, *gb = Hb + (STAGE ? 9 * n_hap : 0), *eb = gb + 3 * nK;
+	const int nslot = 64 * cb;
+	double *K4 = srba_lds + (slot.y >> 3), *Hb = K4 + 4 * nslot, *gb = Hb + (STAGE ? 9 * n_hap : 0), *eb = gb + 3 * nK;
 	double *Hglob = B.HAp + d.o_hap * 9;
 	const double *lam = prm.lambda; // wave-uniform: stays in scalar registers
 	const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0; const bool latch = prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL, keep = (prm.ext & SRBA_EXT_SCHUR_KEEPS_GRADIENT) != 0;
@@ -163,11 +160,12 @@ __global__ void __launch_bounds__(64 * ASM_WAVES_PER_WG) __attribute__((amdgpu_w
 					const double nx = px + x * pc - y * ps, ny = py + x * ps + y * pc, nc = pc * c - ps * s, ns = ps * c + pc * s; x = nx; y = ny; c = nc; s = ns;
 				}
 				const double kk[4] = {c, s, x * s - y * c, x * c + y * s};
-				double *dst = K4 + ((s0 + u) * 64 + tid) * 4;
+				double *dst = K4 + (s0 + u) * 64 + tid; // four planes of 64 cb slots: consecutive lanes write consecutive doubles (no bank conflict)
 #pragma unroll
-				for (int k = 0; k < 4; k++) dst[k] = kk[k];
+				for (int k = 0; k < 4; k++) dst[k * nslot] = kk[k];
 				double v[9], t[3], M[9], Hd[9];
-				if constexpr (LAMBDA) { for (int k = 0; k < 3; k++) t[k] = lam[k * 3] * r[u][0] + lam[k * 3 + 1] * r[u][1] + lam[k * 3 + 2] * r[u][2]; }
+				if constexpr (LAMBDA == 2) { for (int k = 0; k < 3; k++) t[k] = lam[k * 3] * r[u][0] + lam[k * 3 + 1] * r[u][1] + lam[k * 3 + 2] * r[u][2]; }
+				else if constexpr (LAMBDA == 1) { for (int k = 0; k < 3; k++) t[k] = lam[k * 4] * r[u][k]; }
 				else { for (int k = 0; k < 3; k++) t[k] = r[u][k]; }
 				const double sg = inverse ? -1.0 : 1.0;
 				v[0] = sg * (c * t[0] - s * t[1]); v[1] = sg * (s * t[0] + c * t[1]); v[2] = sg * (kk[2] * t[0] + kk[3] * t[1] + t[2]); // J^t Lambda r, J = sg K
@@ -204,9 +202,9 @@ __global__ void __launch_bounds__(64 * ASM_WAVES_PER_WG) __attribute__((amdgpu_w
 				if (tid * ct + s0 + u < n_terms) {
 					const unsigned lo = (unsigned)cur[u], hi = (unsigned)(cur[u] >> 32);
 					double A[4], Bm[4], M[9], v[9];
-					const double *pa = K4 + (lo & 0x7fff) * 4, *pb = K4 + (lo >> 16) * 4;
+					const double *pa = K4 + (lo & 0x7fff), *pb = K4 + (lo >> 16);
 #pragma unroll
-					for (int k = 0; k < 4; k++) { A[k] = pa[k]; Bm[k] = pb[k]; }
+					for (int k = 0; k < 4; k++) { A[k] = pa[k * nslot]; Bm[k] = pb[k * nslot]; }
 					asm_lambda_k<LAMBDA>(M, Bm, lam); asm_kt_m(v, A, M);
 					if (lo & 0x8000u) { // the two blocks have opposite directions: J1^t Lambda J2 = - K1^t Lambda K2
 #pragma unroll
@@ -233,13 +231,13 @@ __global__ void __launch_bounds__(64 * ASM_WAVES_PER_WG) __attribute__((amdgpu_w
 	if (tid == 0) { B.lambda_io[d.pidx] = l0; B.results[d.pidx].num_invalid_jacobs = 0; if (tick) tick[3] = wall_clock64(); }
 }
 
-int asm_launch(bool lambda_matrix, int n_bins, size_t lds_bytes, hipStream_t stream, const Batch &B, const DevParams &prm, const AsmTables &T) {
-	static bool attr_done[2] = {false, false}; // the bins are larger than the 64 KB a launch may ask for by default
+int asm_launch(int lambda_mode, int n_bins, size_t lds_bytes, hipStream_t stream, const Batch &B, const DevParams &prm, const AsmTables &T) {
+	static bool attr_done[3] = {false, false, false}; // the bins are larger than the 64 KB a launch may ask for by default
 	auto go = [&](auto kernel, int which) -> int {
-		if (!attr_done[which]) { hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_BIN_BYTES); if (e != hipSuccess) return (int)e; attr_done[which] = true; }
+		if (lds_bytes > 64 * 1024 && !attr_done[which]) { hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_BIN_BYTES); if (e != hipSuccess) return (int)e; attr_done[which] = true; }
 		hipLaunchKernelGGL(kernel, dim3(n_bins), dim3(64 * ASM_WAVES_PER_WG), lds_bytes, stream, B, prm, T);
 		return (int)hipGetLastError();
 	};
-	return lambda_matrix ? go(k_assemble_se2rel<true>, 0) : go(k_assemble_se2rel<false>, 1);
+	return lambda_mode == 2 ? go(k_assemble_se2rel<2>, 2) : lambda_mode == 1 ? go(k_assemble_se2rel<1>, 1) : go(k_assemble_se2rel<0>, 0);
 }
 } // namespace srbadev

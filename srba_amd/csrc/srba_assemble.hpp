@@ -40,6 +40,6 @@ struct AsmTables { const AsmDesc *desc; const unsigned long long *blk, *term; co
 constexpr int ASM_WAVES_PER_WG = 2, ASM_BIN_BYTES = 40 * 1024; // four bins per CU (160 KB of LDS), eight wavefronts
 
 // host entry of the translation unit that holds the kernels (srba_assemble.hip): ONE launch, a workgroup per bin
-int asm_launch(bool lambda_matrix, int n_bins, size_t lds_bytes, hipStream_t stream, const Batch &B, const DevParams &prm, const AsmTables &T);
+int asm_launch(int lambda_mode /* 0 identity, 1 diagonal, 2 full matrix */, int n_bins, size_t lds_bytes, hipStream_t stream, const Batch &B, const DevParams &prm, const AsmTables &T);
 
 } // namespace srbadev

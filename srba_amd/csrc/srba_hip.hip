@@ -1752,7 +1752,7 @@ int srba_hip_linearize(srba_hip_ctx *c) {
 	if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device));
 	const int lds_doubles = c->lin_terms ? 16 + 1536 : 16; // 12 KB of Hessian accumulators per wavefront: U_Ap of up to 170 SE2 / 42 SE3 blocks (bigger capsules take the per-block path)
 	if (c->asm_ready) { // relative-pose SE2: fused, Jacobian blocks never leave the chip (srba_assemble.hpp): one launch, a workgroup per bin of capsules; what does not fit a bin takes the unfused kernel
-		if (c->asm_bins > 0 && srbadev::asm_launch(c->dp.noise == SRBA_NOISE_CONSTANT_MATRIX, c->asm_bins, srbadev::ASM_BIN_BYTES, c->stream, c->B, c->dp, c->asm_tab) != 0) { c->fail("k_assemble_se2rel: launch failed"); return -1; }
+		if (c->asm_bins > 0 && srbadev::asm_launch(c->dp.noise != SRBA_NOISE_CONSTANT_MATRIX ? 0 : (c->dp.lambda[1] == 0 && c->dp.lambda[2] == 0 && c->dp.lambda[5] == 0 && c->dp.lambda[3] == 0 && c->dp.lambda[6] == 0 && c->dp.lambda[7] == 0) ? 1 : 2, c->asm_bins, srbadev::ASM_BIN_BYTES, c->stream, c->B, c->dp, c->asm_tab) != 0) { c->fail("k_assemble_se2rel: launch failed"); return -1; }
 		if (c->asm_rest > 0) { with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::k_linearize<decltype(fam_)::value>), dim3(c->asm_rest), dim3(SRBA_WG), (size_t)lds_doubles * 8, c->stream, c->B, c->dp, lds_doubles, c->asm_list); }); HIPCHK(c, hipGetLastError()); }
 		c->jp_stale = c->asm_bins > 0; return 0;
 	}
