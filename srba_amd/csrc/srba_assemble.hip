@@ -99,16 +99,15 @@ template <int LAMBDA>
 __global__ void __launch_bounds__(64 * ASM_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(SRBA_ASM_WAVES))) k_assemble_se2rel(const Batch B, const DevParams prm, const AsmTables T) {
 	constexpr int PD = 5, U = SRBA_ASM_U;
 	// a workgroup is a bin of up to four capsules whose LDS images share its allocation (packed at upload); its wavefronts work independently, one capsule each
-	const int2 slot = T.slot[blockIdx.x * ASM_WAVES_PER_WG + (threadIdx.x >> 6)];
-	if (slot.x < 0) return;
-	const AsmDesc &d = T.desc[slot.x];
+	const AsmDesc &d = T.desc[blockIdx.x * ASM_WAVES_PER_WG + (threadIdx.x >> 6)]; // descriptors in bin order: one dependent load less than bin -> capsule -> descriptor
+	if (d.pidx < 0) return;
 	long long *tick = B.phase_cycles ? B.phase_cycles + 16 * (long long)d.pidx : nullptr; // SRBA_HIP_PHASE_TIMING=1: slots 0..3 = start, end of A, end of B, end (100 MHz ticks)
 	if (tick && (threadIdx.x & 63) == 0) tick[0] = wall_clock64();
 	const bool STAGE = d.stage != 0; // the Hessian blocks go through LDS and leave as one contiguous span; 0 (large windows): every block is stored by the lane that summed it, half the image
 	const int tid = threadIdx.x & 63, n_bp = d.n_bp, n_terms = d.n_terms, cb = d.cb, ct = d.ct, n_hap = d.n_hap, nK = d.nK;
 	// LDS image of the capsule: four numbers per block slot | the Hessian blocks | the gradient | the unknown edges' own poses
 	const int nslot = 64 * cb;
-	double *K4 = srba_lds + (slot.y >> 3), *Hb = K4 + 4 * nslot, *gb = Hb + (STAGE ? 9 * n_hap : 0), *eb = gb + 3 * nK;
+	double *K4 = srba_lds + (d.lds_off >> 3), *Hb = K4 + 4 * nslot, *gb = Hb + (STAGE ? 9 * n_hap : 0), *eb = gb + 3 * nK;
 	double *Hglob = B.HAp + d.o_hap * 9;
 	const double *lam = prm.lambda; // wave-uniform: stays in scalar registers
 	const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0; const bool latch = prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL, keep = (prm.ext & SRBA_EXT_SCHUR_KEEPS_GRADIENT) != 0;
@@ -134,7 +133,13 @@ __global__ void __launch_bounds__(64 * ASM_WAVES_PER_WG) __attribute__((amdgpu_w
 		} else { stn<9>(Hglob + 9 * (long long)diag, H); if (latch) stn<9>(B.HAp0 + (d.o_hap + diag) * 9, H); }
 		dmax = fmax(dmax, fmax(H[0], fmax(H[4], H[8])));
 	};
+#ifdef SRBA_ASM_TICKS
+#define ASM_TICK(slot, cond) do { if (tick && (cond)) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (tid == 0) tick[slot] = wall_clock64(); } } while (0)
+#else
+#define ASM_TICK(slot, cond) do { } while (0)
+#endif
 	AsmRuns<9> RA; RA.init();
+	ASM_TICK(4, true);
 	for (int s0 = 0; s0 < cb; s0 += U) {
 		unsigned long long m[U];
 #pragma unroll
@@ -149,6 +154,7 @@ __global__ void __launch_bounds__(64 * ASM_WAVES_PER_WG) __attribute__((amdgpu_w
 			const double *pd = pose0 + (unsigned)max(iD, 0) * PD; if (!(SRBA_ASM_KO & 4)) { ldn<2>(D[u], pd); ldn<2>(D[u] + 2, pd + 3); } else { D[u][0] = (double)lo; D[u][1] = 1; D[u][2] = 0.6; D[u][3] = 0.8; }
 			if (!(SRBA_ASM_KO & 2)) ldn<3>(r[u], res0 + (hi & 0xffff) * 3); else { r[u][0] = (double)hi; r[u][1] = 1; r[u][2] = 2; }
 		}
+		ASM_TICK(5, s0 == 0);
 #pragma unroll
 		for (int u = 0; u < U; u++) if (s0 + u < cb) {
 			const unsigned lo = (unsigned)m[u], hi = (unsigned)(m[u] >> 32); const int iD = (int)(lo & 0xffff) - 1; const bool inverse = (lo & 0x20000000u) != 0;
@@ -174,7 +180,9 @@ __global__ void __launch_bounds__(64 * ASM_WAVES_PER_WG) __attribute__((amdgpu_w
 				RA.item(s0 + u, v, lo, hi, lo, emitA);
 			}
 		}
+		ASM_TICK(6, s0 == 0);
 	}
+	ASM_TICK(7, true);
 	RA.finish(tid, [](unsigned lo, unsigned) { return (int)((lo >> 16) & 0x1fff); }, emitA);
 	asm_sync();
 	if (tick && tid == 0) tick[1] = wall_clock64();

@@ -30,13 +30,13 @@
 
 namespace srbadev {
 
-// per capsule, in launch (size class) order. cb / ct: consecutive blocks / off-diagonal terms per lane (ceil(n / 64)); block b lives in LDS slot (b % cb) * 64 + b / cb
-struct AsmDesc { int pidx, n_bp, n_terms /* off-diagonal */, cb, ct, n_hap, nK, stage /* its Hessian blocks are staged in LDS */; long long o_bp, o_hapt, o_pose /* doubles */, o_edge /* doubles */, o_res /* doubles */, o_hap, o_scal; };
+// per wavefront of every bin (workgroup), in launch order. cb / ct: consecutive blocks / off-diagonal terms per lane (ceil(n / 64)); block b lives in LDS slot (b % cb) * 64 + b / cb
+struct AsmDesc { int pidx /* -1: this wavefront of the bin has no capsule */, n_bp, n_terms /* off-diagonal */, cb, ct, n_hap, nK, stage /* its Hessian blocks are staged in LDS */, lds_off /* bytes: its image inside the bin */, pad; long long o_bp, o_hapt, o_pose /* doubles */, o_edge /* doubles */, o_res /* doubles */, o_hap, o_scal; };
 // blk : per Jacobian block, sorted by unknown   lo = (D pose index + 1) | unknown slot << 16 | inverse << 29 | first block of its unknown << 30 | last << 31
 //                                               hi = residual row | index of the unknown's diagonal Hessian block << 16
 // term: per OFF-DIAGONAL U_Ap term, sorted by Hessian block   lo = LDS slot of block t1 | (the two blocks have opposite directions) << 15 | slot of t2 << 16 ;  hi = Hessian block | first term of its block << 30 | last << 31
 //       (the terms of a diagonal block pair every Jacobian block of the unknown with itself: they are formed with the blocks, in phase A)
-struct AsmTables { const AsmDesc *desc; const unsigned long long *blk, *term; const int2 *slot; /* per wavefront of every bin: {descriptor index or -1, byte offset of its image in the bin} */ };
+struct AsmTables { const AsmDesc *desc; const unsigned long long *blk, *term; };
 constexpr int ASM_WAVES_PER_WG = 2, ASM_BIN_BYTES = 40 * 1024; // four bins per CU (160 KB of LDS), eight wavefronts
 
 // host entry of the translation unit that holds the kernels (srba_assemble.hip): ONE launch, a workgroup per bin

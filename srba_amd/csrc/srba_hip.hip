@@ -801,7 +801,7 @@ struct srba_hip_ctx {
 	int upload_threads = 1; bool dense_left = true; int hbm_from_kb = 48; bool dense_blocks_ok = true; // mid-size nearly-full systems use the dense block layout in LDS
 	bool lin_terms = true, lm_terms = true; // term-parallel U_Ap accumulation in LDS: srba_hip_linearize / the fused LM kernel
 	// fused normal equations of the relative-pose SE2 family (srba_assemble.hpp): capsules packed into bins (workgroups) by the LDS image they need, one launch; the rest take k_linearize
-	bool asm_on = true, asm_ready = false, jp_stale = false; int asm_max_kb = srbadev::ASM_BIN_BYTES / 1024; srbadev::AsmTables asm_tab = {nullptr, nullptr, nullptr, nullptr}; const int *asm_list = nullptr;
+	bool asm_on = true, asm_ready = false, jp_stale = false; int asm_max_kb = srbadev::ASM_BIN_BYTES / 1024; srbadev::AsmTables asm_tab = {nullptr, nullptr, nullptr}; const int *asm_list = nullptr;
 	int asm_bins = 0, asm_rest = 0; // bins of the fused launch; capsules left to the unfused kernel (asm_list holds their indices)
 	srbadev::FlatMap flat; bool flat_ready = false, use_flat = true; // pair -> capsule map of the flat spanning-tree kernel (srba_flat.hpp), filled on first use after an upload
 	int big_min_sys = 480;   // systems with more scalar unknowns than this skip the block-sparse symbolic analysis and go dense (big path)
@@ -1107,7 +1107,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	o.hap_dst = in.add(4 * t_hap * (P / 3) * (P / 3)); o.hapf_dst = in.add(4 * t_hapf * (P / 3)); o.hf_dst = in.add(4 * t_hf);
 	bool asm_fam = c->asm_on && c->params.family == SRBA_SE2_RELPOSE2D;
 	if (asm_fam && c->dp.noise == SRBA_NOISE_CONSTANT_MATRIX) for (int i = 0; i < 3; i++) for (int j = 0; j < i; j++) if (c->dp.lambda[3 * i + j] != c->dp.lambda[3 * j + i]) asm_fam = false; // the fused kernel sums the upper triangle of J^t Lambda J only
-	o.asm_term = in.add(asm_fam ? 8 * std::max<long long>(t_hapt, 1) : 0); o.asm_blk = in.add(asm_fam ? 8 * std::max<long long>(t_bp, 1) : 0); o.asm_desc = in.add(asm_fam ? sizeof(srbadev::AsmDesc) * (size_t)n : 0); o.asm_list = in.add(asm_fam ? 4 * (size_t)n : 0); o.asm_slot = in.add(asm_fam ? 8 * (size_t)srbadev::ASM_WAVES_PER_WG * (size_t)n : 0); // (at most one bin per capsule)
+	o.asm_term = in.add(asm_fam ? 8 * std::max<long long>(t_hapt, 1) : 0); o.asm_blk = in.add(asm_fam ? 8 * std::max<long long>(t_bp, 1) : 0); o.asm_desc = in.add(asm_fam ? sizeof(srbadev::AsmDesc) * (size_t)srbadev::ASM_WAVES_PER_WG * (size_t)n : 0); /* (at most one bin per capsule) */ o.asm_list = in.add(asm_fam ? 4 * (size_t)n : 0); o.asm_slot = in.add(0);
 	std::vector<unsigned char> asm_fit(asm_fam ? n : 0, 0); std::vector<int> asm_nt(asm_fam ? n : 0, 0); // per capsule: its indices fit the packed records; off-diagonal terms
 	in.add(0);
 	if (c->h_in_cap < in.size + 256) { c->h_in.reset(); c->h_in.reset(new char[in.size + 256]); c->h_in_cap = in.size + 256; } // uninitialised: cleared below, in parallel
@@ -1202,17 +1202,17 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		// LDS, a wavefront each): neighbours in the order of their images, as long as they fit together.
 		constexpr int W = srbadev::ASM_WAVES_PER_WG; const size_t cap = std::min<size_t>(srbadev::ASM_BIN_BYTES, (size_t)c->asm_max_kb * 1024);
 		std::vector<size_t> need(n, 0); std::vector<int> fit; fit.reserve(n); int32_t *al = (int32_t *)(h + o.asm_list); c->asm_rest = 0;
-		srbadev::AsmDesc *ad = (srbadev::AsmDesc *)(h + o.asm_desc);
+		srbadev::AsmDesc *ad = (srbadev::AsmDesc *)(h + o.asm_desc); std::vector<srbadev::AsmDesc> dsc(n);
 		for (int p = 0; p < n; p++) { const ProbDesc &d = c->desc[p]; const int cb = (d.n_bp + 63) / 64; const size_t lean = (8 * (4 * 64 * (size_t)cb + 3 * (size_t)d.nK + PDX * (size_t)d.nK) + 255) & ~(size_t)255, full = lean + 72 * (size_t)d.n_hap + 256;
 			const int stage = full <= cap ? 1 : 0; need[p] = stage ? full : lean;
 			if (asm_fit[p] && need[p] <= cap && cb <= 511) fit.push_back(p); else al[c->asm_rest++] = p;
-			ad[p] = {p, d.n_bp, asm_nt[p], cb, (asm_nt[p] + 63) / 64, d.n_hap, d.nK, stage, d.o_bp, d.o_hapt, d.o_pair * 2 * PDX, d.o_edge * PDX, d.o_obs * O, d.o_hap, d.o_scal}; }
+			dsc[p] = {p, d.n_bp, asm_nt[p], cb, (asm_nt[p] + 63) / 64, d.n_hap, d.nK, stage, 0, 0, d.o_bp, d.o_hapt, d.o_pair * 2 * PDX, d.o_edge * PDX, d.o_obs * O, d.o_hap, d.o_scal}; }
 		std::stable_sort(fit.begin(), fit.end(), [&](int x, int y) { return need[x] < need[y]; });
 		// bins of two: the largest remaining image takes the smallest remaining one that fits beside it (a window too large for any partner stays alone); bins come out
-		// largest first, which is also the dispatch order (the longest-running workgroups start first)
-		int32_t *sl = (int32_t *)(h + o.asm_slot); int nb = 0; static_assert(W == 2, "the packing below makes pairs");
-		for (size_t lo = 0, hi = fit.size(); lo < hi;) { int32_t *e = sl + 2 * W * (size_t)nb; hi--; e[0] = fit[hi]; e[1] = 0;
-			if (lo < hi && need[fit[hi]] + need[fit[lo]] <= cap) { e[2] = fit[lo]; e[3] = (int32_t)need[fit[hi]]; lo++; } else { e[2] = -1; e[3] = 0; }
+		// largest first, which is also the dispatch order (the longest-running workgroups start first). The descriptors are stored in bin order, one per wavefront.
+		int nb = 0; static_assert(W == 2, "the packing below makes pairs"); srbadev::AsmDesc none; std::memset(&none, 0, sizeof(none)); none.pidx = -1;
+		for (size_t lo = 0, hi = fit.size(); lo < hi;) { srbadev::AsmDesc *e = ad + W * (size_t)nb; hi--; e[0] = dsc[fit[hi]]; e[0].lds_off = 0;
+			if (lo < hi && need[fit[hi]] + need[fit[lo]] <= cap) { e[1] = dsc[fit[lo]]; e[1].lds_off = (int)need[fit[hi]]; lo++; } else e[1] = none;
 			nb++; }
 		c->asm_bins = nb; c->asm_ready = true;
 	}
@@ -1242,7 +1242,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	DI(bf_col, int); DI(bf_res, int); DI(bf_pose, int); DI(colf_off, int); DI(hap_i, int); DI(hap_j, int); DI(hap_term_off, int); DI(hap_t1, int); DI(hap_t2, int); DI(hap_tblk, int); DI(hf_i, int); DI(hf_j, int); DI(hf_term_off, int); DI(hf_t1, int); DI(hf_t2, int);
 	DI(hapf_i, int); DI(hapf_j, int); DI(hapf_term_off, int); DI(hapf_t1, int); DI(hapf_t2, int); DI(hap_diag, int); DI(hf_diag, int); DI(sch_term_off, int); DI(sch_b1, int); DI(sch_b2, int); DI(sch_lm, int); DI(sch_yw, int); DI(sch_tblk, int);
 	DI(lm_hapf_off, int); DI(lm_hapf_idx, int); DI(req_idx, int); DI(need_idx, int); DI(need_rec, int); DI(pair_needed, unsigned char); DI(pose_req, unsigned char); DI(bp_normal, unsigned char);
-c->asm_tab.term = asm_fam ? (const unsigned long long *)(di + o.asm_term) : nullptr; c->asm_tab.blk = asm_fam ? (const unsigned long long *)(di + o.asm_blk) : nullptr; c->asm_tab.desc = asm_fam ? (const srbadev::AsmDesc *)(di + o.asm_desc) : nullptr; c->asm_tab.slot = asm_fam ? (const int2 *)(di + o.asm_slot) : nullptr; c->asm_list = asm_fam ? (const int *)(di + o.asm_list) : nullptr;
+c->asm_tab.term = asm_fam ? (const unsigned long long *)(di + o.asm_term) : nullptr; c->asm_tab.blk = asm_fam ? (const unsigned long long *)(di + o.asm_blk) : nullptr; c->asm_tab.desc = asm_fam ? (const srbadev::AsmDesc *)(di + o.asm_desc) : nullptr; c->asm_list = asm_fam ? (const int *)(di + o.asm_list) : nullptr;
 #undef DI
 #define DW(field, T) B.field = (T *)(dw + w.field)
 	DW(edge, double); DW(ulm, double); DW(pose, double); DW(Jp, double); DW(Jf, double); DW(resid, double); DW(resid2, double); DW(HAp, double); DW(HAp0, double); DW(Hf, double); DW(HApf, double); DW(grad, double); DW(grad0, double); DW(delta, double); DW(edge1, double); DW(ulm1, double); DW(pose1, double);

@@ -23,3 +23,7 @@ if os.environ.get("SRBA_HIP_PHASE_TIMING") == "1":   # per-capsule phase ticks o
     for lo, hi in ((0, 150), (150, 200), (200, 300), (300, 400), (400, 600), (600, 1000), (1000, 100000)):
         m = ok & (nbp >= lo) & (nbp < hi)
         if m.any(): print("  blocks %4d..%-6d %6d capsules: A %.1f  B %.1f  C %.1f us" % (lo, hi, m.sum(), a[m].mean(), bb[m].mean(), cc[m].mean()))
+    tk8 = ctx.debug(10).reshape(b.n, 16)[:, :8]
+    if (tk8[:, 7] > 0).any():   # library built with -DSRBA_ASM_TICKS: phase A in pieces
+        m = ok & (tk8[:, 7] > 0); d = lambda i, j: ((tk8[m, i] - tk8[m, j]) / 100.0).mean()
+        print("phase A in pieces (us): start -> records + edge poses in %.1f | -> first gathers in %.1f | -> first group computed %.1f | -> all groups %.1f | -> scan + emits %.1f" % (d(4, 0), d(5, 4), d(6, 5), d(7, 6), d(1, 7)))
