@@ -1,4 +1,4 @@
-"""Register / scratch budget of the headline kernel, read from the gfx950 code object inside the built libsrba_hip.so (no GPU needed).
+"""Register / scratch budget of the headline kernel, read from the gfx950 code objects of the translation units libsrba_hip.so is linked from (no GPU needed).
 
 k_lm_run<SE2_RELPOSE2D> runs two wavefronts per SIMD only while it needs at most 256 VGPRs and no scratch; one more live pose pushes it over and the 30 000-key-frame
 benchmark drops from 45 ms to 74 ms per step (measured twice in round 2). The numbers come from the AMDGPU metadata note of the code object."""
@@ -17,15 +17,17 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 def kernel_resources(tmp_path):
     import __graft_entry__ as ge
     ge.build()
-    so = os.path.join(ROOT, "srba_amd", "lib", "libsrba_hip.so"); fat = str(tmp_path / "fat.bin"); co = str(tmp_path / "co.o")
-    subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", so, fat], check=True)
-    subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True)
-    notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
+    # one code object per translation unit: read them from the objects the library is linked from (build() keeps them beside it)
     out = {}
-    for blk in notes.split("- .agpr_count:")[1:]:
-        name = re.search(r"\.name:\s+(\S+)", blk); v = re.search(r"\.vgpr_count:\s+(\d+)", blk); s = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
-        if name and v and s:
-            out[name.group(1)] = (int(v.group(1)), int(s.group(1)))
+    for unit in ("srba_hip", "srba_assemble"):
+        obj = os.path.join(ROOT, "srba_amd", "lib", unit + ".o"); fat = str(tmp_path / (unit + ".fat")); co = str(tmp_path / (unit + ".co"))
+        subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True)
+        subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True)
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
+        for blk in notes.split("- .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk); v = re.search(r"\.vgpr_count:\s+(\d+)", blk); sc = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
+            if name and v and sc:
+                out[name.group(1)] = (int(v.group(1)), int(sc.group(1)))
     return out
 
 
@@ -42,3 +44,12 @@ def test_headline_kernel_keeps_two_wavefronts_per_simd(tmp_path):
     # run out of their 512 registers (stereo, range-bearing 3D) may use any, for spills
     fam = lambda i: res["_ZN7srbadev8k_lm_runILi%dEEEvNS_5BatchENS_9DevParamsEiiPi" % i]
     assert all(fam(i)[1] == 0 for i in (0, 1, 2, 4, 5, 7, 8)), lm
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "clang-offload-bundler")), reason="ROCm LLVM tools not found")
+def test_fused_normal_equations_kernel_keeps_two_wavefronts_per_simd(tmp_path):
+    """k_assemble_se2rel (srba_assemble.hip): its bins are sized for eight wavefronts per CU, i.e. two per SIMD -- at most 256 VGPRs, no scratch, in its three Lambda instantiations."""
+    res = kernel_resources(tmp_path)
+    ks = {k: v for k, v in res.items() if "k_assemble_se2rel" in k}
+    assert len(ks) == 3, ks
+    assert all(v <= 256 and s == 0 for v, s in ks.values()), ks
