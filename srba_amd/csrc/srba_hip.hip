@@ -614,7 +614,7 @@ struct Arena { // layout builder: 256-byte aligned sub-allocations inside one bu
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->fail(std::string(#call) + ": " + hipGetErrorString(e_)); return -1; } } while (0)
 #define LNCHK(lane, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (lane)->error = std::string(#call) + ": " + hipGetErrorString(e_); return -1; } } while (0)
-static const int kBigLanes = 8;
+static const int kBigLanes = 16;
 struct BigLane { int id = 0; hipStream_t stream = nullptr; double *d_part = nullptr, *d_scal = nullptr; int *d_iscal = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; double chol_ms = 0, chol_flops = 0; long long chol_count = 0; int chol_nmax = 0; std::string error; };
 
 } // namespace
@@ -1022,7 +1022,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	std::vector<int> cls(n, 0), big_lds(n, 0); int cls_nbmax[SRBA_NCLS] = {0}; std::vector<Symbolic> sym(n); long long t_spcol = 0, t_sprow = 0, t_spitem = 0, t_spfill = 0;
 	// capsules whose system cannot fit one wavefront's LDS even as bare numbers (more than 63 block rows) but is no deep-window system either: a handful go to the
 	// multi-workgroup path; when the batch holds many, they keep one wavefront each with the system in HBM (see below)
-	bool many_mid = false; { int cnt = 0; for (int p = 0; p < n; p++) { const int nsys = (schur_solver && caps[p].n_unk_lms > 0 && caps[p].n_unk_edges > 0) ? P * caps[p].n_unk_edges : P * caps[p].n_unk_edges + L * caps[p].n_unk_lms; if ((nsys + 2) / 3 > 63 && nsys <= c->big_min_sys) cnt++; } many_mid = cnt > 4 * kBigLanes; }
+	bool many_mid = false; { int cnt = 0; for (int p = 0; p < n; p++) { const int nsys = (schur_solver && caps[p].n_unk_lms > 0 && caps[p].n_unk_edges > 0) ? P * caps[p].n_unk_edges : P * caps[p].n_unk_edges + L * caps[p].n_unk_lms; if ((nsys + 2) / 3 > 63 && nsys <= c->big_min_sys) cnt++; } many_mid = cnt > 32; }
 	std::vector<const char *> why(n, nullptr);
 	parallel_ranges(n, c->upload_threads, [&](int b, int e, int) { // validation and the block-sparse symbolic factorisation (the expensive part of this pass) of every capsule
 		for (int p = b; p < e; p++) {
