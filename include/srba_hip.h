@@ -235,7 +235,8 @@ int  srba_hip_update_spantree(srba_hip_ctx *ctx, int only_needed);          /* K
 int  srba_hip_eval_residuals(srba_hip_ctx *ctx, double *chi2_out /*[n] host, may be NULL*/); /* K4 reprojection_residuals.h:16-81 */
 int  srba_hip_linearize(srba_hip_ctx *ctx);  /* K2,K3 (jacobians.h:1083-1117) + K6 (sparse_hessian_update_numeric.h:22-60) + K5 (compute_minus_gradient.h:20-91).
                                                 For <SE2, RelativePoses2D> one fused launch that keeps the Jacobian blocks on the chip (srba_assemble.hpp): Hessian blocks, gradient and the
-                                                lambda guess come out as always, the dh_dAp blocks are written to device memory only when srba_hip_debug_read(ctx, 1, ...) asks for them */
+                                                lambda guess come out as always, the dh_dAp blocks are written to device memory only when srba_hip_debug_read(ctx, 1, ...) or
+                                                srba_hip_hessian_from_jacobians() asks for them (from the state of that moment: read them before the next srba_hip_apply_update / rollback) */
 int  srba_hip_solve(srba_hip_ctx *ctx, const double *lambda /*[n] host*/, int32_t *not_pd_out /*[n] host*/); /* K7-K10 lev-marq_solvers.h solve() */
 int  srba_hip_apply_update(srba_hip_ctx *ctx);   /* K11+K12 backup then x <- x (+) delta (optimize_edges.h:491-539) */
 int  srba_hip_rollback(srba_hip_ctx *ctx);       /* K12 restore (optimize_edges.h:664-680) */

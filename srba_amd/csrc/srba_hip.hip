@@ -1628,7 +1628,9 @@ extern "C" {
 int srba_hip_sync(srba_hip_ctx *c) { if (!c) return -1; HIPCHK(c, hipStreamSynchronize(c->stream)); return rounds_complete(c); }
 
 static int lm_run_async_impl(srba_hip_ctx *c);
-int srba_hip_lm_run_async(srba_hip_ctx *c) { // no C++ exception crosses the C ABI
+int srba_hip_lm_run_async(srba_hip_ctx *c) {
+	if (c) c->jp_stale = false; // the LM loop writes the Jacobian blocks of its own linearisation points
+ // no C++ exception crosses the C ABI
 	try { return lm_run_async_impl(c); }
 	catch (const std::exception &e) { if (c) c->fail(std::string("lm_run: ") + e.what()); return -1; }
 	catch (...) { if (c) c->fail("lm_run: unknown exception"); return -1; }
@@ -1769,11 +1771,14 @@ int srba_hip_solve(srba_hip_ctx *c, const double *lambda, int32_t *not_pd_out) {
 	if (not_pd_out) { HIPCHK(c, hipMemcpyAsync(not_pd_out, c->B.notpd, 4 * (size_t)c->n_prob, hipMemcpyDeviceToHost, c->stream)); }
 	HIPCHK(c, hipStreamSynchronize(c->stream)); return 0;
 }
-int srba_hip_hessian_from_jacobians(srba_hip_ctx *c) { if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device)); SRBA_DISPATCH(c, k_hessian_only, 0); HIPCHK(c, hipGetLastError()); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+int srba_hip_hessian_from_jacobians(srba_hip_ctx *c) { if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device));
+	if (c->jp_stale) { SRBA_DISPATCH(c, k_jacobians_only, 0); HIPCHK(c, hipGetLastError()); c->jp_stale = false; } // the blocks of a fused srba_hip_linearize were never written: do it now
+	SRBA_DISPATCH(c, k_hessian_only, 0); HIPCHK(c, hipGetLastError()); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
 int srba_hip_debug_write(srba_hip_ctx *c, int what, const double *in, int64_t n_doubles) {
 	if (!c || !in || !(what == 1 || what == 2 || what == 6) || n_doubles != c->len_dbg[what]) { if (c) c->fail("debug_write: only the Jacobian blocks (1, 2) and the minus-gradient (6) can be written, with their exact sizes"); return -1; }
 	HIPCHK(c, hipSetDevice(c->device));
 	HIPCHK(c, hipMemcpyAsync(c->d_wk + c->off_dbg[what], in, 8 * (size_t)n_doubles, hipMemcpyHostToDevice, c->stream));
+	if (what == 1) c->jp_stale = false; // the caller's blocks are the current ones
 	if (what == 6 && (c->params.extensions & SRBA_EXT_SCHUR_KEEPS_GRADIENT)) HIPCHK(c, hipMemcpyAsync(c->B.grad0, in, 8 * (size_t)n_doubles, hipMemcpyHostToDevice, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream)); return 0;
 }

@@ -544,3 +544,17 @@ def test_big_path_with_the_one_launch_factorisation(monkeypatch):
     assert np.all(one["status"] == ref["status"]) and _close(one["chi2_final"], ref["chi2_final"], rel=1e-6, abs_=1e-18)
     for k in ("chi2_final", "chi2_init", "num_trials", "trace_chi2", "trace_lambda"):
         assert np.array_equal(np.nan_to_num(np.asarray(one[k], float), nan=-1.0), np.nan_to_num(np.asarray(base[k], float), nan=-1.0)), k
+
+
+@pytest.mark.gpu
+def test_fused_linearisation_and_k6_on_materialised_blocks_agree(se2_batch):
+    """srba_hip_linearize for <SE2, RelativePoses2D> keeps the Jacobian blocks on the chip; srba_hip_hessian_from_jacobians (K6 alone) afterwards first has them written
+    by the unfused kernel and must reproduce the Hessian blocks of the fused launch (different summation trees: equal to rounding)."""
+    b = se2_batch
+    ctx = runner.HipContext(b.params); ctx.upload(b); lib = ctx.lib
+    assert lib.srba_hip_update_spantree(ctx.ctx, 0) == 0 and lib.srba_hip_eval_residuals(ctx.ctx, None) == 0 and lib.srba_hip_linearize(ctx.ctx) == 0
+    fused = ctx.debug(3).copy()
+    assert lib.srba_hip_hessian_from_jacobians(ctx.ctx) == 0
+    k6 = ctx.debug(3)
+    assert np.abs(fused).max() > 0 and np.allclose(k6, fused, rtol=1e-12, atol=1e-12 * np.abs(fused).max())
+    ctx.close()
