@@ -1,0 +1,18 @@
+"""Duration of the fused LM launch when launches follow one another without a pause, and after pauses: is the sustained rate a clock / power effect? usage: diag_sustained.py"""
+import glob, os, sys, time, ctypes as C
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+from srba_amd import capi, datasets, runner
+cache = sorted(glob.glob("/tmp/srba_bench_cache/caps_se2_tour_30000_seed*_*.bin"))
+b = runner.CapsuleBatch.load(cache[-1]) if cache else runner.harvest_graph_slam(datasets.graph_slam_se2(n_kf=30000, seed=1, path="tour"), backend="hip", submap=10, depth=3)
+ctx = runner.HipContext(b.params); ctx.upload(b); lib = ctx.lib; hist = (C.c_double * 4)()
+def one():
+    lib.srba_hip_reset_state(ctx.ctx); lib.srba_hip_lm_run_async(ctx.ctx); lib.srba_hip_sync(ctx.ctx); lib.srba_hip_kernel_ms_history(ctx.ctx, hist, 1); return hist[0]
+one()
+print("back to back :", " ".join("%.2f" % one() for _ in range(12)))
+for pause in (0.05, 0.2, 1.0):
+    v = []
+    for _ in range(6): time.sleep(pause); v.append(one())
+    print("pause %.2f s  :" % pause, " ".join("%.2f" % x for x in v))
+print("back to back :", " ".join("%.2f" % one() for _ in range(12)))
