@@ -806,7 +806,7 @@ struct srba_hip_ctx {
 	srbadev::FlatMap flat; bool flat_ready = false, use_flat = true; // pair -> capsule map of the flat spanning-tree kernel (srba_flat.hpp), filled on first use after an upload
 	int big_min_sys = 480;   // systems with more scalar unknowns than this skip the block-sparse symbolic analysis and go dense (big path)
 	std::unique_ptr<char[]> h_in; size_t h_in_cap = 0; size_t h_off_order = 0; // host staging of the input arena (kept: the launch order is read back from it)
-	int max_lds_kb = 1 << 20, min_chunk = 384, max_parts_per_queue = 2; int n_queues = 16, sched = 3, n_streams_used = 1, n_cu = 256, waves_per_cu = 8, lds_per_cu = 160 * 1024; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
+	int max_lds_kb = 1 << 20, min_chunk = 384, max_parts_per_queue = 2; int class_streams = 64 /* sched 3: the class launches are dealt round-robin to at most this many streams */, n_queues = 16, sched = 3, n_streams_used = 1, n_cu = 256, waves_per_cu = 8, lds_per_cu = 160 * 1024; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
 	// offsets needed for downloads (bytes inside the wk arena)
 	size_t off_edge = 0, off_ulm = 0, off_pose = 0, off_inf = 0, off_infv = 0, off_res = 0;
 	size_t off_dbg[10] = {0}; int64_t len_dbg[10] = {0};
@@ -832,17 +832,17 @@ static void plan_launches(srba_hip_ctx *c, const int32_t *ord) {
 		for (size_t j = 0; j < c->plan.size(); j++) { LaunchJob &J = c->plan[j]; J.grid = J.count;
 			if (c->sched == 3) { const size_t lds = c->cls_lds[J.cls] + c->lds_pad; const int fit = lds ? (int)std::max<size_t>(1, (size_t)c->lds_per_cu / lds) : c->waves_per_cu; J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(c->waves_per_cu, fit))); } } } } finish = {c};
 	if (c->sched == 3) { // one persistent launch per size class, every class on its own stream, biggest LDS footprint first (the HBM class is the biggest)
-		int q = 0;
-		for (int k = SRBA_NCLS - 2; k >= 0; k--) if (c->cls_count[k]) { c->plan.push_back({q, k, c->cls_first[k], c->cls_count[k], 0.0, 0}); q++; }
-		c->n_streams_used = std::max(q, 1); return;
+		int q = 0; const int qmax = std::max(1, c->class_streams);
+		for (int k = SRBA_NCLS - 2; k >= 0; k--) if (c->cls_count[k]) { c->plan.push_back({q % qmax, k, c->cls_first[k], c->cls_count[k], 0.0, 0}); q++; }
+		c->n_streams_used = std::max(std::min(q, qmax), 1); return;
 	}
 	// cost of a chunk ~ sum over its capsules of (system size) x (LDS footprint): a trial takes time ~ nb, and how many capsules run at once
 	// is set by the LDS they hold (measured on the benchmark: 43 us per loop-closure window vs 5.5 us per typical window, chip-wide)
 	auto cost_of = [&](int cls, int first, int count) { const double w = cls == SRBA_NCLS - 1 ? 24.0 : std::max(1.0, (double)c->cls_lds[cls] / 8192.0); double s = 0; for (int i = 0; i < count; i++) s += (c->desc[ord[first + i]].nb + 4) * w; return s; };
 	if (c->sched == 2) {
-		int q = 0;
-		for (int k = SRBA_NCLS - 2; k >= 0; k--) if (c->cls_count[k]) { c->plan.push_back({q, k, c->cls_first[k], c->cls_count[k], 0.0, 0}); q++; }
-		c->n_streams_used = std::max(q, 1); return;
+		int q = 0; const int qmax = std::max(1, c->class_streams);
+		for (int k = SRBA_NCLS - 2; k >= 0; k--) if (c->cls_count[k]) { c->plan.push_back({q % qmax, k, c->cls_first[k], c->cls_count[k], 0.0, 0}); q++; }
+		c->n_streams_used = std::max(std::min(q, qmax), 1); return;
 	}
 	c->n_streams_used = nq;
 	if (c->sched == 0) {
@@ -943,6 +943,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_CHUNK"); if (e && atoi(e) > 0) c->min_chunk = atoi(e); e = getenv("SRBA_HIP_PARTS"); if (e && atoi(e) > 0) c->max_parts_per_queue = atoi(e); } // tuning knobs of the launch plan
 	{ const char *e = getenv("SRBA_HIP_SCHED"); if (e) c->sched = atoi(e); } // tuning knob: launch plan (see plan_launches)
 	{ hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) c->n_cu = pr.multiProcessorCount; }
+	{ const char *e = getenv("SRBA_HIP_CLASS_STREAMS"); if (e && atoi(e) > 0) c->class_streams = atoi(e); }
 	{ const char *e = getenv("SRBA_HIP_WAVES_PER_CU"); if (e && atoi(e) > 0) c->waves_per_cu = atoi(e); e = getenv("SRBA_HIP_LDS_PER_CU_KB"); if (e && atoi(e) > 0) c->lds_per_cu = atoi(e) * 1024; } // tuning knobs: resident wavefronts / LDS per CU assumed by the persistent plan
 	{ const char *e = getenv("SRBA_HIP_QUEUES"); if (e && atoi(e) >= 1 && atoi(e) < SRBA_NCLS) c->n_queues = atoi(e); } // tuning knob: concurrent launch streams
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || false) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
