@@ -558,3 +558,32 @@ def test_fused_linearisation_and_k6_on_materialised_blocks_agree(se2_batch):
     k6 = ctx.debug(3)
     assert np.abs(fused).max() > 0 and np.allclose(k6, fused, rtol=1e-12, atol=1e-12 * np.abs(fused).max())
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["identity", "full"])
+def test_fused_linearisation_noise_instantiations(se2_batch, mode):
+    """k_assemble_se2rel has three instantiations: Lambda = identity (scaled by 1 / sigma afterwards), diagonal (the benchmark's, covered above) and full symmetric matrix.
+    The other two against the oracle: Hessian blocks and gradient of every capsule."""
+    b = se2_batch; P, L, O, PD = capi.DIMS[b.family]
+    saved = (b.params.noise, b.params.std_noise_observations, [b.params.lambda_[k] for k in range(36)])
+    try:
+        if mode == "identity":
+            b.params.noise = capi.NOISE_IDENTITY; b.params.std_noise_observations = 0.05
+        else:   # a symmetric positive definite information matrix with off-diagonal entries
+            A = np.array([[2.0e5, 3.0e4, -1.0e4], [3.0e4, 1.5e5, 2.0e4], [-1.0e4, 2.0e4, 8.0e4]])
+            for i in range(3):
+                for j in range(3): b.params.lambda_[3 * i + j] = A[i, j]
+        ctx = runner.HipContext(b.params); ctx.upload(b); lib = ctx.lib
+        assert lib.srba_hip_update_spantree(ctx.ctx, 0) == 0 and lib.srba_hip_eval_residuals(ctx.ctx, None) == 0 and lib.srba_hip_linearize(ctx.ctx) == 0
+        HAp, grad = ctx.debug(3), ctx.debug(6)
+        oh = og = 0
+        for i in range(b.n):
+            c = b[i]; ref = _oracle.stage(b, i, do_solve=False, lam=0.0); n = P * c.n_unk_edges
+            assert np.allclose(HAp[oh:oh + c.n_hap * P * P], ref["HAp"], rtol=1e-9, atol=1e-9 * np.abs(ref["HAp"]).max()), (mode, i)
+            assert ref["scalars"][0] < 1e-24 or np.allclose(grad[og:og + n], ref["grad"], rtol=1e-7, atol=1e-9 * np.abs(ref["grad"]).max()), (mode, i)
+            oh += c.n_hap * P * P; og += n
+        ctx.close()
+    finally:
+        b.params.noise, b.params.std_noise_observations = saved[0], saved[1]
+        for k in range(36): b.params.lambda_[k] = saved[2][k]
