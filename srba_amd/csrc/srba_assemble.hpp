@@ -6,25 +6,27 @@
  * (sparse_hessian_update_numeric.h:26-58), minus_grad_i = sum_k J_ki^t Lambda r_k (compute_minus_gradient.h:20-91) and the initial lambda
  * (optimize_edges.h:366-390: 1e-3 * the largest diagonal entry).
  *
- * How (one wavefront per capsule; two capsules of similar size share a workgroup = a bin of 40 KB of LDS packed at upload, ONE launch for the batch; per capsule the chip holds
+ * How (one wavefront per capsule; two capsules share a workgroup = a bin of 40 KB of LDS packed at upload -- the largest remaining image with the smallest that fits beside
+ * it --, ONE launch for the batch, largest bins first; per capsule the chip holds
  * 32 bytes per block, its Hessian blocks, its gradient and the poses of its unknown edges in LDS):
  *   A  every lane owns cb = ceil(n_bp / 64) CONSECUTIVE blocks (the capsule lists its blocks unknown by unknown), four in flight: it reads their packed records (8 bytes:
  *      D pose, unknown slot, residual row, direction, diagonal Hessian block), gathers the keyframe-relative pose D (and the edge's own pose for an inverse edge) and
  *      the residual row, and forms the block in registers. A block of this family is
- *          J = sg * [ c  s  x s - y c ;  -s  c  x c + y s ;  0 0 1 ]      (c, s, x, y of D' = D or p (+) D; the device keeps cos / sin next to every pose)
- *      i.e. FIVE numbers: they go to LDS. J^t Lambda r (gradient) and J^t Lambda J (the term this block adds to the diagonal Hessian block of its unknown) are summed
+ *          J = sg * K,  K = [ c  s  x s - y c ;  -s  c  x c + y s ;  0 0 1 ]      (c, s, x, y of D' = D or p (+) D; the device keeps cos / sin next to every pose)
+ *      i.e. FOUR numbers and a sign: the numbers go to LDS (four planes: no bank conflicts), the sign stays in the records. J^t Lambda r (gradient) and J^t Lambda J (the term this block adds to the diagonal Hessian block of its unknown) are summed
  *      over the run of blocks of the unknown: serially inside a lane, and -- for a run that crosses lanes -- through ONE prefix scan over the wavefront per capsule;
- *      the lane that holds the last block of the run stores the unknown's gradient and diagonal block.
+ *      the lane that holds the last block of the run puts the unknown's gradient and diagonal block into the LDS image.
  *   B  every lane owns ct consecutive OFF-DIAGONAL terms (the list is sorted by Hessian block; its first records were requested before phase A): J1^t Lambda J2 from
- *      the two five-number blocks in LDS, the same run sums, 72-byte block stores.
- *   C  lambda guess out.
- * The run sums replace the per-pass segmented reductions of the first version of this kernel (54 cross-lane double moves per 64 terms: the kernel was bound by VALU
- * and LDS-crossbar issue, 0.8 ms for the benchmark batch) and the one-lane-per-Hessian-block form before it (lanes idle behind the longest list, 0.6 ms).
+ *      the two blocks in LDS (times the product of their signs), the same run sums, blocks into the LDS image.
+ *   C  the Hessian blocks and the gradient leave the image as contiguous spans, 16 bytes per lane and request (windows whose image with the Hessian blocks does not fit a
+ *      bin store every block from the lane that summed it and keep half the image); lambda guess out.
+ * The run sums replace the per-pass segmented reductions of an earlier version of this kernel (54 cross-lane double moves per 64 terms: bound by VALU and
+ * LDS-crossbar issue, 0.8 ms for the benchmark batch) and the one-lane-per-Hessian-block form before it (lanes idle behind the longest list, 0.6 ms); DESIGN 4b has the history.
  * HBM sees: 8 B of record, one pose gather (40 B; 80 B for inverse edges) and one residual row (24 B) per block, 8 B per off-diagonal term, 72 B per Hessian block,
  * 24 B per unknown, 96 B of descriptor per capsule. The Jacobian array is not touched: srba_hip_debug_read(1) materialises it on demand with the unfused kernel.
  *
  * Sums are formed in a fixed tree order (not the reference's sequential order): results are reproducible run to run and agree with the oracle to rounding.
- * Capsules whose image exceeds the largest class, or whose indices do not fit the packed records, take k_linearize.
+ * Capsules whose image exceeds a bin even without its Hessian blocks, or whose indices do not fit the packed records, take k_linearize.
  */
 #pragma once
 
