@@ -604,7 +604,11 @@ namespace {
 struct FamDims { int P, L, O, PD; int PDX() const { return PD == 3 ? 5 : PD; } }; // PDX: device pose stride (SE2: [x y phi cos sin])
 const FamDims kDims[SRBA_NUM_FAMILIES] = {{3, 3, 3, 3}, {3, 2, 2, 3}, {3, 2, 2, 3}, {6, 3, 4, 12}, {6, 3, 2, 12}, {6, 3, 3, 12}, {6, 3, 3, 12}, {6, 6, 6, 12}, {3, 3, 4, 3}};
 // every model family the kernels are instantiated for
+#ifdef SRBA_ONLY_RELPOSE2D /* experiment builds (tools/quick_build.sh): only the headline family is instantiated, the unit compiles in a fraction of the time; other families are rejected at run time */
+#define SRBA_ALL_FAMILIES(X) X(SRBA_SE2_RELPOSE2D)
+#else
 #define SRBA_ALL_FAMILIES(X) X(SRBA_SE2_RELPOSE2D) X(SRBA_SE2_RB2D) X(SRBA_SE2_CART2D) X(SRBA_SE3_STEREO) X(SRBA_SE3_MONO) X(SRBA_SE3_CART3D) X(SRBA_SE3_RB3D) X(SRBA_SE3_RELPOSE3D) X(SRBA_SE2_STEREO)
+#endif
 thread_local std::string g_last_error;
 
 struct Arena { // layout builder: 256-byte aligned sub-allocations inside one buffer
