@@ -256,7 +256,7 @@ def main():
         local_rank = int(os.environ["SRBA_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     backend = os.environ.get("SRBA_BENCH_BACKEND", "nccl")
-    dist = multi.init_process_group(backend)  # RCCL; used for the barrier and the sum/max of the result line only
+    dist = multi.init_process_group(backend, force=os.environ.get("SRBA_BENCH_FORCE_DIST") == "1")  # RCCL; used for the barrier and the sum/max of the result line only
     if world > 1:   # N ranks share the host: each rank's upload (validation, symbolic factorisation, packing) takes its share of the cores instead of min(32, cores) each
         os.environ.setdefault("SRBA_HIP_UPLOAD_THREADS", str(max(2, (os.cpu_count() or 8) // world)))
 
@@ -380,7 +380,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "world-2d-30k relative graph-SLAM, SE2 graph-slam, submap=10 depth=3: %d keyframes per GPU -> %d optimize_local_area capsules per GPU, re-optimised per step" % (args.n_kf, batch.n),
                        "keyframes_per_gpu": args.n_kf, "capsules_per_gpu": batch.n, "lm_trials_per_step_per_gpu": trials_per_step, "obs_per_s": tot_obs * args.steps / max_elapsed,
-                       "parallelism": "replicas x%d (independent maps, no collective)" % world, "solver": "no-Schur, block-sparse LL^t in LDS, symbolic factorisation on the host (reference: CSparse)",
+                       "parallelism": "replicas x%d (independent maps, no collective)" % world, "process_group": (None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "aggregate_device": "cuda" if backend == "nccl" else "cpu"}),
+                       "solver": "no-Schur, block-sparse LL^t in LDS, symbolic factorisation on the host (reference: CSparse)",
                        "setup_s": {"dataset": round(t_gen, 2), "sequential_slam_harvest_gpu_backend": round(t_harvest, 2), "upload_batch_host_to_hbm": round(t_upload, 3)},
                        "sequential_ms_per_kf": (None if cached else round(1e3 * t_harvest / max(1, args.n_kf), 4)),
                        "host_enqueue_ms_per_step": 1e3 * enq[0] / max(1, args.steps),

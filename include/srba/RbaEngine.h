@@ -858,8 +858,8 @@ protected:
 			for (size_t b = 0; b < cd.hap_i.size(); b++) { const size_t i = cd.hap_i[b], j = cd.hap_j[b]; // upper blocks (i <= j); diagonal blocks hold both triangles
 				for (int r = 0; r < P; r++) for (int q = 0; q < P; q++) { const double v = hap[b * P * P + r * P + q]; dA[(P * i + r) * nA + P * j + q] = v; if (i != j) dA[(P * j + q) * nA + P * i + r] = v; } }
 			if (parameters.srba.compute_condition_number) out_info.HAp_condition_number = internal::symmetric_condition_number(dA, nA);
-			if (parameters.srba.return_hessian && res.num_trials > 0 && res.num_trials <= SRBA_TRACE_LEN) {
-				const double lam = res.trace_lambda[res.num_trials - 1]; const bool full = !RBA_OPTIONS::solver_t::USE_SCHUR && nF > 0;
+			if (parameters.srba.return_hessian && res.num_trials > 0) { // (no trial: no solve, the reference's solver object holds no system either; hessian_valid stays false)
+				const double lam = res.lambda_last_trial; const bool full = !RBA_OPTIONS::solver_t::USE_SCHUR && nF > 0;
 				const size_t n = full ? nA + (size_t)L * nF : nA; std::vector<double> &H = out_info.extra_results.hessian; H.assign(n * n, 0.0);
 				for (size_t r = 0; r < nA; r++) for (size_t q = 0; q < nA; q++) H[r * n + q] = dA[r * nA + q];
 				if (full && m_backend->read_blocks(4, hf) && m_backend->read_blocks(5, hapf)) {

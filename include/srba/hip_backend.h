@@ -21,11 +21,11 @@ public:
 	const char *name() const { return "hip-gfx950"; }
 	void ensure(const srba_hip_params &p) {
 		if (!m_ctx) {
-#if SRBA_DETAILED_TIME_PROFILING
-			setenv("SRBA_HIP_PHASE_TIMING", "1", 1); // the fused kernel keeps one cycle counter per stage and capsule (read below)
-#endif
 			m_ctx = srba_hip_create(m_device, &p);
 			if (!m_ctx) throw std::runtime_error(std::string("srba::hip_backend: cannot create the HIP context: ") + srba_hip_last_error(NULL));
+#if SRBA_DETAILED_TIME_PROFILING
+			srba_hip_set_phase_timing(m_ctx, 1); // the fused kernel keeps one cycle counter per stage and capsule of THIS context (read below); no process-wide setting
+#endif
 			m_params = p;
 		} else if (std::memcmp(&m_params, &p, sizeof(p)) != 0) {
 			check(srba_hip_set_params(m_ctx, &p), "srba_hip_set_params"); m_params = p;

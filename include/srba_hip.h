@@ -210,6 +210,7 @@ typedef struct srba_lm_result {
 	double  trace_chi2[SRBA_TRACE_LEN];
 	double  trace_lambda[SRBA_TRACE_LEN];
 	double  trace_rho[SRBA_TRACE_LEN];
+	double  lambda_last_trial; /* lambda of the last trial (the one the solver's extra_results refer to, lev-marq_solvers.h:204-208); NaN when no trial ran. Unlike the trace it is not limited to SRBA_TRACE_LEN trials */
 } srba_lm_result;
 
 typedef struct srba_hip_ctx srba_hip_ctx;
@@ -299,6 +300,9 @@ double srba_hip_last_kernel_ms(srba_hip_ctx *ctx);
 /* Durations (ms, most recent first) of the last `n` srba_hip_lm_run / srba_hip_lm_run_async launches: HIP events recorded on the context
  * stream around the launch (fork to join of the size-class kernels). Synchronises the stream; returns how many were written (<= 64). */
 int    srba_hip_kernel_ms_history(srba_hip_ctx *ctx, double *out_ms, int n);
+/* Per-stage cycle counters of the fused kernel (the reference's SRBA_DETAILED_TIME_PROFILING sections, impl/optimize_edges.h:16-27), read with srba_hip_debug_read(ctx, 10, ...): on != 0 switches
+ * them on for the batches uploaded to THIS context from now on (the environment variable SRBA_HIP_PHASE_TIMING=1 sets the default of new contexts). */
+int    srba_hip_set_phase_timing(srba_hip_ctx *ctx, int on);
 
 #ifdef __cplusplus
 }

@@ -830,9 +830,14 @@ struct Problem {
 	}
 
 	// ---------------- the driver: optimize_edges.h S5..S17 ----------------
-	void run(srba_lm_result &out) {
+	// Decision replay (test infrastructure of the test infrastructure: tests/test_gpu_parity.py, tools/soak_parity.py): instead of deciding not-PD / reject / accept itself the loop
+	// takes the sequence another run took (the GPU's, read from its trial trace) and reports, per trial, what it would have decided: its own rho, the chi2 of the trial point and the chi2
+	// it started from. Two runs that part at a rounding-floor decision can then be compared over their WHOLE length instead of over the common prefix (optimize_edges.h:579-656).
+	struct Replay { const int32_t *dec; int n; double *rho, *chi2, *E; int32_t *flags; int diverged_at; }; // dec: 0 not PD, 1 rejected, 2 accepted; flags: 1 own factorisation PD, 2 own rho sign differs from the decision, 4 forced not-PD although PD
+	void run(srba_lm_result &out, Replay *rp = nullptr) {
 		std::memset(&out, 0, sizeof(out));
 		for (int k = 0; k < SRBA_TRACE_LEN; k++) { out.trace_chi2[k] = out.trace_lambda[k] = out.trace_rho[k] = std::numeric_limits<double>::quiet_NaN(); }
+		out.lambda_last_trial = std::numeric_limits<double>::quiet_NaN();
 		const int nObs = c.n_obs;
 		out.num_observations = nObs;
 		out.num_span_tree_numeric_updates = update_spantree(false); // S5 :256
@@ -859,17 +864,20 @@ struct Problem {
 		std::vector<int> req; for (int i = 0; i < 2 * c.n_pairs; i++) if (c.pose_required[i] || g_refresh_all) req.push_back(i);
 		old_poses.resize(req.size());
 		int iter; bool stop = false; int trials = 0;
-		for (iter = 0; iter < prm.max_iters && !stop; iter++) { // :454
-			double rho = 0;
-			if (lambda >= MAX_LAMBDA) { stop = true; out.stop_reason |= 1 << SRBA_STOP_LAMBDA; } // :460-464
-			if (RMSE < prm.max_error_per_obs_to_stop) { stop = true; out.stop_reason |= 1 << SRBA_STOP_RMSE; } // :465-469
-			while (rho <= 0 && !stop) { // :471
+		double rho = 0;
+		// one pass of the inner while (optimize_edges.h:471-692); forced < 0: the loop's own decisions (the reference), else the replayed one. Returns false when a replay cannot be followed.
+		auto trial = [&](int forced) -> bool {
 				const int tr = trials++;
 				if (tr < SRBA_TRACE_LEN) out.trace_lambda[tr] = lambda;
-				if (!solve(lambda)) { // :476-485
+				out.lambda_last_trial = lambda;
+				const bool solved = solve(lambda);
+				if (rp) { rp->flags[tr] = solved ? 1 : 0; rp->rho[tr] = rp->chi2[tr] = std::numeric_limits<double>::quiet_NaN(); rp->E[tr] = total_err; }
+				if (forced > 0 && !solved) { rp->diverged_at = tr; trials--; return false; } // the other run solved a system this one calls not positive definite: nothing to follow
+				if (!solved || forced == 0) { // :476-485
+					if (solved) rp->flags[tr] |= 4;
 					out.num_not_pd++;
 					lambda *= nu; nu *= 2.; stop = (lambda > MAX_LAMBDA); if (stop) out.stop_reason |= 1 << SRBA_STOP_LAMBDA;
-					continue;
+					return true;
 				}
 				for (int i = 0; i < nK; i++) old_edges[i] = edge[i]; // :491-495
 				old_ulm = ulm; // :497-501
@@ -886,9 +894,12 @@ struct Problem {
 				double den = 0; for (int k = 0; k < n; k++) den += delta[k] * (lambda * delta[k] + grad[k]);
 				rho = (total_err - new_err) / den; // :585
 				if (tr < SRBA_TRACE_LEN) { out.trace_chi2[tr] = new_err; out.trace_rho[tr] = rho; }
-				if (rho > 0) { // :587
+				const bool own_accept = rho > 0, accept = forced < 0 ? own_accept : forced == 2;
+				if (rp) { rp->rho[tr] = rho; rp->chi2[tr] = new_err; if (own_accept != accept) rp->flags[tr] |= 2; }
+				if (accept) { // :587
 					out.num_accepted++;
-					const bool relin = (err_red < 0 || err_red > prm.min_error_reduction_ratio_to_relinearize); // :592
+					// (a replayed acceptance of a step this run would have rejected is a step that does not reduce the error here: the run that accepted it saw a reduction below its rounding, far below the relinearisation threshold)
+					const bool relin = (forced >= 0 && !own_accept) ? false : (err_red < 0 || err_red > prm.min_error_reduction_ratio_to_relinearize); // :592
 					resid.swap(new_resid); total_err = new_err; RMSE = new_RMSE; // :601-604
 					if (relin) { // :606-629
 						out.num_relinearized++;
@@ -909,7 +920,17 @@ struct Problem {
 					ulm = old_ulm; // :677-680
 					lambda *= nu; nu *= 2.0; stop = (lambda > MAX_LAMBDA); if (stop) out.stop_reason |= 1 << SRBA_STOP_LAMBDA; // :685-687
 				}
-			}
+				return true;
+		};
+		if (rp) { // the other run's trial sequence, whatever this run's stop tests say
+			rp->diverged_at = -1; iter = 0;
+			for (int t = 0; t < rp->n; t++) if (!trial(rp->dec[t])) break;
+		} else
+		for (iter = 0; iter < prm.max_iters && !stop; iter++) { // :454
+			rho = 0;
+			if (lambda >= MAX_LAMBDA) { stop = true; out.stop_reason |= 1 << SRBA_STOP_LAMBDA; } // :460-464
+			if (RMSE < prm.max_error_per_obs_to_stop) { stop = true; out.stop_reason |= 1 << SRBA_STOP_RMSE; } // :465-469
+			while (rho <= 0 && !stop) trial(-1); // :471
 		}
 		if (!stop) out.stop_reason |= 1 << SRBA_STOP_MAX_ITERS;
 		out.num_iters = iter; out.num_trials = trials;
@@ -928,11 +949,16 @@ struct Problem {
 	}
 };
 
-template <int FAM> void run_one(const srba_hip_params &p, srba_problem_capsule &c, srba_lm_result &r) { Problem<FAM> pr(p, c); pr.run(r); }
+struct ReplayIO { const int32_t *dec; int n; double *rho, *chi2, *E; int32_t *flags; int diverged_at; };
+template <int FAM> void run_one(const srba_hip_params &p, srba_problem_capsule &c, srba_lm_result &r, ReplayIO *io = nullptr) {
+	Problem<FAM> pr(p, c);
+	if (!io) { pr.run(r); return; }
+	typename Problem<FAM>::Replay rp = {io->dec, io->n, io->rho, io->chi2, io->E, io->flags, -1}; pr.run(r, &rp); io->diverged_at = rp.diverged_at;
+}
 
-void dispatch_run(const srba_hip_params &p, srba_problem_capsule &c, srba_lm_result &r) {
+void dispatch_run(const srba_hip_params &p, srba_problem_capsule &c, srba_lm_result &r, ReplayIO *io = nullptr) {
 	switch (p.family) {
-#define X(F) case F: run_one<F>(p, c, r); break;
+#define X(F) case F: run_one<F>(p, c, r, io); break;
 		ORACLE_ALL_FAMILIES(X)
 #undef X
 		default: std::memset(&r, 0, sizeof(r)); r.status = -1;
@@ -1010,6 +1036,21 @@ int srba_oracle_lm_run(const srba_hip_params *params, srba_problem_capsule *caps
 	std::atomic<int> next(0); const int chunk = 4;
 	std::vector<std::thread> th;
 	for (int t = 0; t < n_threads; t++) th.emplace_back([&, params, caps, results, n]() { for (;;) { const int b = next.fetch_add(chunk); if (b >= n) break; for (int i = b; i < std::min(n, b + chunk); i++) dispatch_run(*params, caps[i], results[i]); } });
+	for (auto &x : th) x.join();
+	return 0;
+}
+/* Decision replay (see Problem::run): capsule i runs the n_decisions[i] trials of decisions[i * stride ...] (0 not PD, 1 rejected, 2 accepted) and reports, per trial, its own rho, the chi2 of the
+ * trial point, the chi2 it started from and flags (1 own factorisation PD, 2 own rho sign differs from the decision, 4 not-PD forced on a PD system); diverged_at[i] = the trial at which the sequence
+ * could not be followed (the other run solved a system this one calls not PD), else -1. results[i] is the usual result of the replayed run (final chi2 = after the last replayed trial). */
+int srba_oracle_lm_run_replay(const srba_hip_params *params, srba_problem_capsule *caps, int n, const int32_t *decisions, const int32_t *n_decisions, int stride,
+                              double *own_rho, double *own_chi2, double *own_E, int32_t *flags, int32_t *diverged_at, srba_lm_result *results, int n_threads) {
+	if (!params || !caps || n < 0 || !decisions || !n_decisions || stride < 1 || !own_rho || !own_chi2 || !own_E || !flags || !diverged_at || !results) return -1;
+	std::atomic<int> next(0);
+	auto work = [&]() { for (;;) { const int i = next.fetch_add(1); if (i >= n) break;
+		ReplayIO io = {decisions + (size_t)i * stride, std::min(n_decisions[i], stride), own_rho + (size_t)i * stride, own_chi2 + (size_t)i * stride, own_E + (size_t)i * stride, flags + (size_t)i * stride, -1};
+		dispatch_run(*params, caps[i], results[i], &io); diverged_at[i] = io.diverged_at; } };
+	if (n_threads <= 1) { work(); return 0; }
+	std::vector<std::thread> th; for (int t = 0; t < n_threads; t++) th.emplace_back(work);
 	for (auto &x : th) x.join();
 	return 0;
 }

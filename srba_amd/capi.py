@@ -47,7 +47,7 @@ class LmResult(C.Structure):
     _fields_ = [(n, c_i32) for n in ("status", "num_iters", "num_trials", "num_not_pd", "num_accepted", "num_relinearized", "num_invalid_jacobs", "stop_reason",
                                      "num_observations", "num_jacobians", "num_span_tree_numeric_updates", "reserved")] + \
                [(n, c_f64) for n in ("total_sqr_error_init", "total_sqr_error_final", "obs_rmse", "lambda_init", "lambda_final")] + \
-               [("trace_chi2", c_f64 * TRACE_LEN), ("trace_lambda", c_f64 * TRACE_LEN), ("trace_rho", c_f64 * TRACE_LEN)]
+               [("trace_chi2", c_f64 * TRACE_LEN), ("trace_lambda", c_f64 * TRACE_LEN), ("trace_rho", c_f64 * TRACE_LEN), ("lambda_last_trial", c_f64)]
 
 
 class BatchStats(C.Structure):

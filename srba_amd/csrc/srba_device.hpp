@@ -60,7 +60,7 @@ struct Batch {
 	// state + workspace
 	double *edge, *ulm, *pose, *Jp, *Jf, *resid, *resid2, *HAp, *HAp0, *Hf, *HApf, *grad, *grad0 /* SRBA_EXT_SCHUR_KEEPS_GRADIENT: the gradient as K5 produced it */, *delta, *Hfinv, *YW;
 	double *old_edge, *old_ulm, *old_pose, *dense, *ulm_inf;
-	double *edge1, *ulm1, *pose1; const unsigned char *pose_req; // rounds path (srba_rounds.hpp): second copy of the unknowns and of the spanning-tree poses; per pose: a Jacobian block reads it (list_of_required_num_poses)
+	double *edge1, *ulm1, *pose1; const unsigned char *pose_req; // second copy of the unknowns and of the spanning-tree poses (double-buffered LM loop); per pose: a Jacobian block reads it (list_of_required_num_poses)
 	int *valid, *first_fail, *hf_ok;
 	unsigned char *bp_ok, *bf_ok; // per Jacobian block: its observation row is valid (set by phase_jacobians, read by phase_hessian)
 	unsigned char *ulm_inf_valid;
@@ -1149,33 +1149,7 @@ struct Worker {
 	}
 };
 
-// ------------------------------------------------------------------------------------------------ per-capsule LM state of the rounds path (srba_rounds.hpp; the fused loop can resume from it)
-#define SRBA_ROUNDS_HIST 256
-struct LmState {        // per capsule; wave-uniform, read by every lane, written by lane 0
-	double lambda, nu, total_err, rmse, rho_last;
-	int iter, trials, n_notpd, n_acc, n_relin, stopmask, stop;
-	int phase;          // 0: a trial is pending; 1: finished
-	int cur, rcur;      // which copy holds the accepted unknowns + spanning-tree poses (0: edge/ulm/pose, 1: edge1/ulm1/pose1) / the accepted residuals (0: resid, 1: resid2)
-	int solved;         // this round's solve succeeded: the trial point waits for its evaluation
-	int need_lin;       // this round's trial was accepted: 1 = gradient, 3 = Jacobians + Hessian blocks + gradient
-	int last_rejected;  // the last EVALUATED trial was rejected: the twins of the refreshed spanning-tree pairs keep its values (kr_finish)
-	int pad;
-};
-struct Rounds {
-	LmState *st; int *list /* three rotating lists of n_prob entries (a group uses [first, first + count) of each) */; int *count /* [group][3] */;
-	int *ctr /* [group][5]: work counters of kr_solve / kr_eval / kr_lin, kr_init, kr_finish */; int *unfinished; int *hist /* [group][SRBA_ROUNDS_HIST]: capsules still iterating at every round of the last run */; int n_prob;
-};
-
-// the state of a capsule is the same for all lanes: keep it in scalar registers
-__device__ __forceinline__ double rounds_uni(double v) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v))); }
-__device__ __forceinline__ int rounds_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ LmState rounds_state(const LmState *p) {
-	LmState s = *p;
-	s.lambda = rounds_uni(s.lambda); s.nu = rounds_uni(s.nu); s.total_err = rounds_uni(s.total_err); s.rmse = rounds_uni(s.rmse); s.rho_last = rounds_uni(s.rho_last);
-	s.iter = rounds_uni(s.iter); s.trials = rounds_uni(s.trials); s.n_notpd = rounds_uni(s.n_notpd); s.n_acc = rounds_uni(s.n_acc); s.n_relin = rounds_uni(s.n_relin); s.stopmask = rounds_uni(s.stopmask); s.stop = rounds_uni(s.stop);
-	s.phase = rounds_uni(s.phase); s.cur = rounds_uni(s.cur); s.rcur = rounds_uni(s.rcur); s.solved = rounds_uni(s.solved); s.need_lin = rounds_uni(s.need_lin); s.last_rejected = rounds_uni(s.last_rejected); s.pad = 0;
-	return s;
-}
-__device__ __forceinline__ Batch rounds_view(const Batch &B, int copy) { Batch V = B; if (copy) { V.edge = B.edge1; V.ulm = B.ulm1; V.pose = B.pose1; } return V; }
+// the batch with its second copy of the unknowns / spanning-tree poses in place of the first (double-buffered LM loop)
+__device__ __forceinline__ Batch copy_view(const Batch &B, int copy) { Batch V = B; if (copy) { V.edge = B.edge1; V.ulm = B.ulm1; V.pose = B.pose1; } return V; }
 
 } // namespace srbadev

@@ -370,25 +370,21 @@ struct Solver : public Worker<FAM> {
 #else
 #define SRBA_OCC
 #endif
-// RESUME: the capsule comes from the rounds path (srba_rounds.hpp) with a trial pending: S5..S14 are done, the scalars of the loop are in *st0 and `B0` is the batch as the
-// kernel got it (the loop then works IN PLACE on the copy of the unknowns / poses that holds the accepted state, with the reference's backup / restore); the fused kernel
-// instantiates RESUME = false, which is the code it always was.
 #ifndef SRBA_LM_DB
 #define SRBA_LM_DB 1   /* the fused loop keeps two copies of the unknowns and of the spanning-tree poses (trial -> the other copy, accept = flip) instead of backup / restore */
 #endif
-template <int FAM, bool RESUME = false, bool DB = (SRBA_LM_DB != 0)>
-__device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, const int pidx, LmState *st0 = nullptr) {
+template <int FAM, bool DB = (SRBA_LM_DB != 0)>
+__device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, const int pidx) {
 	const ProbDesc &d = B0.desc[pidx];
-	LmState s0; if constexpr (RESUME) s0 = rounds_state(st0);
-	const Batch Bv = (RESUME && !DB) ? rounds_view(B0, s0.cur) : B0; const Batch &B = (RESUME && !DB) ? Bv : B0; // (!DB: the loop works in place on the accepted copy)
-	int cur = (RESUME && DB) ? s0.cur : 0, last_rej = (RESUME && DB) ? s0.last_rejected : 0; // DB: which copy holds the accepted state; the last evaluated trial was rejected
+	const Batch &B = B0;
+	int cur = 0, last_rej = 0; // DB: which copy holds the accepted state; the last evaluated trial was rejected
 	Solver<FAM> S(B, d, prm);
 	constexpr int P = Solver<FAM>::P, L = Solver<FAM>::L, O = Solver<FAM>::O;
 	double *red = nullptr;
 	const SparseSys A = S.make_sys(srba_lds);
 	const int tid = threadIdx.x; srba_lm_result *out = B.results + pidx;
 	const int nObs = d.n_obs, n = d.n_scal;
-	double *resid = (RESUME && s0.rcur) ? B.resid2 : B.resid, *resid2 = (RESUME && s0.rcur) ? B.resid : B.resid2;
+	double *resid = B.resid, *resid2 = B.resid2;
 
 	long long *pc = B.phase_cycles ? B.phase_cycles + (long long)pidx * 16 : nullptr; long long tc0 = 0;
 #define TIC() do { if (pc) { __syncthreads(); tc0 = wall_clock64(); } } while (0)
@@ -398,7 +394,6 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 	auto hessian = [&](Solver<FAM> &X) -> int { return hess_terms ? X.phase_hessian_terms(srba_lds) /* == A.diag: the LDS image, idle while the capsule is linearised */ + X.phase_hessian_landmark_blocks() : X.phase_hessian(); };
 	double lambda, nu = 2.0, total_err, RMSE;
 	int iter = 0, trials = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0; bool stop = false;
-	if constexpr (!RESUME) {
 	TIC(); S.phase_spantree(false, nullptr, DB ? B0.pose1 : nullptr); // S5 (DB: both copies of the poses)
 	if constexpr (DB) { constexpr int PD = Solver<FAM>::PD; // the second copy of the unknowns (the fixed edges of the paths stay equal in both for good)
 		for (int k = tid; k < d.n_edges * PD; k += SRBA_WG) B0.edge1[d.o_edge * PD + k] = B0.edge[d.o_edge * PD + k];
@@ -411,6 +406,7 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 		out->status = 0; out->num_iters = 0; out->num_trials = 0; out->num_not_pd = 0; out->num_accepted = 0; out->num_relinearized = 0; out->stop_reason = 0;
 		out->num_invalid_jacobs = ninv; out->num_observations = nObs; out->num_jacobians = d.n_bp + d.n_bf; out->num_span_tree_numeric_updates = d.n_pairs;
 		for (int k = 0; k < SRBA_TRACE_LEN; k++) { out->trace_chi2[k] = NAN; out->trace_lambda[k] = NAN; out->trace_rho[k] = NAN; }
+		out->lambda_last_trial = NAN;
 	}
 	if ((long long)O * nObs < (long long)n) { if (tid == 0) out->status = 1; return; } // S11
 	lambda = S.lambda_guess(red); // S12
@@ -420,27 +416,14 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 	__syncthreads();
 	TIC(); S.phase_gradient(resid); // S14
 	__syncthreads(); S.keep_gradient(); TOC(4);
-	} else { // the scalars of the loop as the rounds left them; the twins of the refreshed spanning-tree pairs as the reference would have them after a rejected trial
-		lambda = s0.lambda; nu = s0.nu; total_err = s0.total_err; RMSE = s0.rmse; iter = s0.iter; trials = s0.trials; n_notpd = s0.n_notpd; n_acc = s0.n_acc; n_relin = s0.n_relin; stopmask = s0.stopmask;
-		constexpr int PD = Solver<FAM>::PD; const Batch Bt = rounds_view(B0, s0.cur ^ 1);
-		if (!DB && s0.last_rejected) for (int q = tid; q < 2 * d.n_need; q += SRBA_WG) {
-			const long long ps = 2LL * B.need_idx[d.o_pair + (q >> 1)] + (q & 1);
-			if (!B.pose_req[d.o_pair * 2 + ps]) { double v[PD]; ldn<PD>(v, Bt.pose + (d.o_pair * 2 + ps) * PD); stn<PD>(B.pose + (d.o_pair * 2 + ps) * PD, v); }
-		}
-		__syncthreads();
-	}
-	bool resumed = RESUME; // (the tests at the head of the pass in progress were made by the rounds path)
 	for (; iter < prm.max_iters && !stop; iter++) {
 		double rho = 0;
-		if (!resumed) {
 		if (lambda >= prm.max_lambda) { stop = true; stopmask |= 1 << SRBA_STOP_LAMBDA; }
 		if (RMSE < prm.max_err) { stop = true; stopmask |= 1 << SRBA_STOP_RMSE; }
-		}
-		resumed = false;
 		while (rho <= 0 && !stop) {
 			const int tr = trials++;
-			if (tid == 0 && tr < SRBA_TRACE_LEN) out->trace_lambda[tr] = lambda;
-			const Batch Ba = DB ? rounds_view(B0, cur) : B, Bt = DB ? rounds_view(B0, cur ^ 1) : B; Solver<FAM> Sa(Ba, d, prm), St(Bt, d, prm); // accepted / trial copy (the same one without DB)
+			if (tid == 0) { if (tr < SRBA_TRACE_LEN) out->trace_lambda[tr] = lambda; out->lambda_last_trial = lambda; }
+			const Batch Ba = DB ? copy_view(B0, cur) : B, Bt = DB ? copy_view(B0, cur ^ 1) : B; Solver<FAM> Sa(Ba, d, prm), St(Bt, d, prm); // accepted / trial copy (the same one without DB)
 			TIC(); const bool solved = Sa.solve(A, lambda, pc); TOC(5);
 			if (!solved) {
 				n_notpd++; lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
@@ -493,22 +476,21 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 		out->total_sqr_error_final = total_err; out->obs_rmse = RMSE; out->lambda_final = lambda;
 	}
 	if constexpr (DB) { // the reference's partial restore, where it becomes visible: a rejected trial refreshed BOTH poses of every pair in use and only the ones Jacobian blocks read went back (optimize_edges.h:664-670)
-		constexpr int PD = Solver<FAM>::PD; const Batch Ba = rounds_view(B0, cur), Bt = rounds_view(B0, cur ^ 1);
+		constexpr int PD = Solver<FAM>::PD; const Batch Ba = copy_view(B0, cur), Bt = copy_view(B0, cur ^ 1);
 		__syncthreads();
 		if (last_rej) for (int q = tid; q < 2 * d.n_need; q += SRBA_WG) {
 			const long long ps = 2LL * B0.need_idx[d.o_pair + (q >> 1)] + (q & 1);
 			if (!B0.pose_req[d.o_pair * 2 + ps]) { double v[PD]; ldn<PD>(v, Bt.pose + (d.o_pair * 2 + ps) * PD); stn<PD>(Ba.pose + (d.o_pair * 2 + ps) * PD, v); }
 		}
 	}
-	if constexpr (RESUME || DB) { // the accepted state goes back to the primary arrays (cf. kr_finish)
+	if constexpr (DB) { // the accepted state goes back to the primary arrays
 		constexpr int PD = Solver<FAM>::PD;
 		__syncthreads();
-		if (DB ? cur : s0.cur) {
+		if (cur) {
 			for (int k = tid; k < d.nK * PD; k += SRBA_WG) B0.edge[d.o_edge * PD + k] = B0.edge1[d.o_edge * PD + k];
 			for (int k = tid; k < d.nF * L; k += SRBA_WG) B0.ulm[d.o_ulm * L + k] = B0.ulm1[d.o_ulm * L + k];
 			for (int q = tid; q < 2 * d.n_need; q += SRBA_WG) { const long long ps = 2LL * B0.need_idx[d.o_pair + (q >> 1)] + (q & 1); double v[PD]; ldn<PD>(v, B0.pose1 + (d.o_pair * 2 + ps) * PD); stn<PD>(B0.pose + (d.o_pair * 2 + ps) * PD, v); }
 		}
-		if constexpr (RESUME) { if (tid == 0) st0->phase = 2; } // the capsule is marked done
 	}
 	(void)P;
 }
@@ -567,7 +549,6 @@ template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_rollback(const B
 #include "srba_big.hpp"
 #include "srba_flat.hpp"
 #include "srba_assemble.hpp"
-#include "srba_rounds.hpp"
 namespace srbadev {
 // ---- whole-map squared error (eval_overall_error.h:15-137): a plain streaming pair of kernels over ONE problem (desc[0]), grid-stride
 // K1 over all (observer, base) pairs: compose the breadth-first path from the root of the pair (spantree_create_complete.h:96-124)
@@ -816,10 +797,6 @@ struct srba_hip_ctx {
 	size_t off_dbg[10] = {0}; int64_t len_dbg[10] = {0};
 	size_t in_off_edge0 = 0, in_off_ulm0 = 0; long long tot_edge = 0, tot_ulm = 0;
 	size_t off_phase = 0; bool phase_timing = false; long long n_pose_total = 0; std::vector<int> cls_of;
-	// rounds path (srba_rounds.hpp): groups of capsules (LDS size classes, the big ones split) that run their LM rounds on separate streams
-	struct RGroup { int cls, first, count; size_t lds; int rounds_needed /* most LM trials of any of its capsules, once a run's results have been downloaded; else 0 */, rounds_done; int grid[6]; };
-	int rounds_env = -1, rounds_split = 4, rounds_first = 64, rounds_min_batch = 1 << 30 /* (off by default until validated) */; bool rounds_on = false, rounds_pending = false; int rounds_debug = 0, rounds_threads = 1, rounds_last = 0; std::vector<RGroup> rgroups; srbadev::Rounds R; int *h_unfinished = nullptr; std::vector<int> rhist; int rhist_rounds = 0, rounds_switch = 20; /* host copy of R.hist once a run's results have been downloaded (valid for the rounds that run enqueued); round after which the fused loop takes over */
-	static constexpr int kRStreams = 32; hipStream_t rstream[kRStreams] = {nullptr}; hipEvent_t rdone[kRStreams] = {nullptr};
 	void fail(const std::string &m) { error = m; g_last_error = m; }
 };
 static void big_drop_graphs(srba_hip_ctx *c);
@@ -961,8 +938,6 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_DENSE_LEFT"); if (e) c->dense_left = atoi(e) != 0; } // 0: right-looking sweeps on the HBM-resident dense layout (round-2 first version)
 	{ const char *e = getenv("SRBA_HIP_LIN_TERMS"); if (e) c->lin_terms = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_LM_TERMS"); if (e) c->lm_terms = atoi(e) != 0; }
-	{ const char *e = getenv("SRBA_HIP_ROUNDS"); if (e) c->rounds_env = atoi(e); e = getenv("SRBA_HIP_ROUNDS_SPLIT"); if (e && atoi(e) >= 1) c->rounds_split = std::min(atoi(e), 16); e = getenv("SRBA_HIP_ROUNDS_FIRST"); if (e && atoi(e) >= 1) c->rounds_first = atoi(e);
-	  e = getenv("SRBA_HIP_ROUNDS_MIN_BATCH"); if (e) c->rounds_min_batch = atoi(e); e = getenv("SRBA_HIP_ROUNDS_DEBUG"); if (e) c->rounds_debug = atoi(e); e = getenv("SRBA_HIP_ROUNDS_SWITCH"); if (e) c->rounds_switch = atoi(e); e = getenv("SRBA_HIP_ROUNDS_THREADS"); if (e && atoi(e) >= 1) c->rounds_threads = atoi(e); }
 	{ const char *e = getenv("SRBA_HIP_ASSEMBLE_MAX_KB"); if (e) c->asm_max_kb = atoi(e); }            // capsules whose LDS image exceeds this take the unfused kernel (tests)
 	{ const char *e = getenv("SRBA_HIP_ASSEMBLE"); if (e) c->asm_on = atoi(e) != 0; }                   // 0 = srba_hip_linearize always runs the unfused kernel (Jacobian blocks through HBM)
 	{ const char *e = getenv("SRBA_HIP_FLAT"); if (e) c->use_flat = atoi(e) != 0; }                     // 0 = one wavefront per capsule for the stepwise spanning-tree launch
@@ -1183,8 +1158,6 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	c->cls_of = cls; c->big_ld = big_lds;
 	{ // launch order: capsules grouped by LDS size class
 		int32_t *ord = (int32_t *)(h + o.order); int pos = 0;
-		// the LM loop as rounds over the batch (srba_rounds.hpp) instead of one fused kernel per capsule: SRBA_HIP_ROUNDS = 1 / 0, default: large batches of the relative-pose SE2 family
-		c->rgroups.clear(); c->rounds_on = c->rounds_env >= 0 ? (c->rounds_env != 0) : (c->params.family == SRBA_SE2_RELPOSE2D && n >= c->rounds_min_batch); c->rounds_pending = false;
 		for (int k = 0; k < SRBA_NCLS; k++) {
 			c->cls_first[k] = pos; for (int p = 0; p < n; p++) if (cls[p] == k) ord[pos++] = p; c->cls_count[k] = pos - c->cls_first[k];
 			c->cls_lds[k] = k < SRBA_NCLS - 1 ? (size_t)cls_nbmax[k] * 8 : 0;
@@ -1192,11 +1165,6 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 			int32_t *b = ord + c->cls_first[k]; const int cnt = c->cls_count[k], nq = c->n_queues;
 			auto work = [&](int x) -> long long { const ProbDesc &dx = c->desc[x]; return dx.dense_blocks ? (long long)dx.nb * dx.nb * dx.nb / 6 : dx.n_items; }; // block updates per factorisation
 			std::stable_sort(b, b + cnt, [&](int x, int y) { return work(x) > work(y); });
-			if (c->rounds_on && k < SRBA_NCLS - 1 && cnt > 0) { // rounds path: a big class is split into interleaved slices (each a group with its own stream: their round kernels overlap)
-				const int parts = cnt >= 2048 * c->rounds_split ? c->rounds_split : (cnt >= 4096 ? 2 : 1);
-				if (parts > 1) { std::vector<int32_t> t(b, b + cnt); for (int q = 0; q < parts; q++) { int i = slice_begin(cnt, q, parts); for (int src = q; src < cnt; src += parts) b[i++] = t[src]; } }
-				for (int q = 0; q < parts; q++) { const int a = slice_begin(cnt, q, parts), e = slice_begin(cnt, q + 1, parts); if (e > a) c->rgroups.push_back({k, c->cls_first[k] + a, e - a, c->cls_lds[k], 0, 0, {0, 0, 0, 0, 0, 0}}); }
-			}
 			if (c->sched == 0 && cnt >= 16 * nq) { std::vector<int32_t> t(b, b + cnt); for (int q = 0; q < nq; q++) { int i = slice_begin(cnt, q, nq); for (int src = q; src < cnt; src += nq) b[i++] = t[src]; } }
 		}
 		plan_launches(c, ord);
@@ -1222,16 +1190,14 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		c->asm_bins = nb; c->asm_ready = true;
 	}
 	// ---- work arena layout
-	Arena wk; struct { size_t edge, ulm, pose, Jp, Jf, resid, resid2, HAp, HAp0, Hf, HApf, grad, delta, Hfinv, YW, old_edge, old_ulm, old_pose, dense, ulm_inf, valid, first_fail, hf_ok, bp_ok, bf_ok, ulm_inf_valid, results, lambda_io, chi2, notpd, phase_cycles, m_pair, grad0, edge1, ulm1, pose1, lmst, rlist, rcount, rctr, runf, rhist; } w;
+	Arena wk; struct { size_t edge, ulm, pose, Jp, Jf, resid, resid2, HAp, HAp0, Hf, HApf, grad, delta, Hfinv, YW, old_edge, old_ulm, old_pose, dense, ulm_inf, valid, first_fail, hf_ok, bp_ok, bf_ok, ulm_inf_valid, results, lambda_io, chi2, notpd, phase_cycles, m_pair, grad0, edge1, ulm1, pose1; } w;
 	w.edge = wk.add(8 * t_edge * PDX); w.ulm = wk.add(8 * t_ulm * L); w.pose = wk.add(8 * 2 * t_pair * PDX); w.Jp = wk.add(8 * t_bp * O * P); w.Jf = wk.add(8 * t_bf * O * L);
 	w.resid = wk.add(8 * t_obs * O); w.resid2 = wk.add(8 * t_obs * O); w.HAp = wk.add(8 * t_hap * P * P); w.HAp0 = wk.add(8 * t_hap * P * P); w.Hf = wk.add(8 * t_hf * L * L); w.HApf = wk.add(8 * t_hapf * P * L);
 	w.grad = wk.add(8 * t_scal); w.delta = wk.add(8 * t_scal); w.Hfinv = wk.add(8 * t_ulm * L * L); w.YW = wk.add(8 * t_yw * P * L); w.old_edge = wk.add(8 * t_unk * PDX); w.old_ulm = wk.add(8 * t_ulm * L); w.old_pose = wk.add(8 * t_req * PDX);
 	w.dense = wk.add(8 * t_dense); w.ulm_inf = wk.add(8 * t_ulm * L * L); w.valid = wk.add(4 * t_valid); w.first_fail = wk.add(4 * t_valid); w.hf_ok = wk.add(4 * t_ulm); w.bp_ok = wk.add(t_bp); w.bf_ok = wk.add(t_bf); w.ulm_inf_valid = wk.add(t_ulm);
 	w.results = wk.add(sizeof(srba_lm_result) * n); w.lambda_io = wk.add(8 * n); w.chi2 = wk.add(8 * n); w.notpd = wk.add(4 * n); w.phase_cycles = wk.add(8 * 16 * (size_t)n);
 	w.m_pair = wk.add(4 * t_pair);
-	{ const bool r = c->rounds_on; const size_t ng = c->rgroups.size() + 1;
-	  w.edge1 = wk.add(8 * t_edge * PDX); w.ulm1 = wk.add(8 * t_ulm * L); w.pose1 = wk.add(8 * 2 * t_pair * PDX); /* second copy of the unknowns and of the spanning-tree poses: the fused loop and the rounds path are double-buffered */ w.lmst = wk.add(r ? sizeof(srbadev::LmState) * (size_t)n : 0);
-	  w.rlist = wk.add(r ? 4 * 3 * (size_t)n : 0); w.rcount = wk.add(r ? 4 * 3 * ng : 0); w.rctr = wk.add(r ? 4 * 5 * ng : 0); w.runf = wk.add(4); w.rhist = wk.add(r ? 4 * SRBA_ROUNDS_HIST * ng : 0); }
+	w.edge1 = wk.add(8 * t_edge * PDX); w.ulm1 = wk.add(8 * t_ulm * L); w.pose1 = wk.add(8 * 2 * t_pair * PDX); // second copy of the unknowns and of the spanning-tree poses: the fused loop is double-buffered
 	w.grad0 = wk.add((c->params.extensions & SRBA_EXT_SCHUR_KEEPS_GRADIENT) ? 8 * t_scal : 0);
 	wk.add(0);
 	if (in.size + 256 > c->cap_in) { if (c->d_in) hipFree(c->d_in); c->d_in = nullptr; c->cap_in = 0; const size_t want = (in.size + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_in, want)); c->cap_in = want; }
@@ -1251,7 +1217,6 @@ c->asm_tab.term = asm_fam ? (const unsigned long long *)(di + o.asm_term) : null
 #undef DI
 #define DW(field, T) B.field = (T *)(dw + w.field)
 	DW(edge, double); DW(ulm, double); DW(pose, double); DW(Jp, double); DW(Jf, double); DW(resid, double); DW(resid2, double); DW(HAp, double); DW(HAp0, double); DW(Hf, double); DW(HApf, double); DW(grad, double); DW(grad0, double); DW(delta, double); DW(edge1, double); DW(ulm1, double); DW(pose1, double);
-	c->R.st = (srbadev::LmState *)(dw + w.lmst); c->R.list = (int *)(dw + w.rlist); c->R.count = (int *)(dw + w.rcount); c->R.ctr = (int *)(dw + w.rctr); c->R.unfinished = (int *)(dw + w.runf); c->R.hist = (int *)(dw + w.rhist); c->R.n_prob = n; c->rhist.clear();
 	DW(Hfinv, double); DW(YW, double); DW(old_edge, double); DW(old_ulm, double); DW(old_pose, double); DW(dense, double); DW(ulm_inf, double); DW(valid, int); DW(first_fail, int); DW(hf_ok, int); DW(bp_ok, unsigned char); DW(bf_ok, unsigned char); DW(ulm_inf_valid, unsigned char);
 	DW(results, srba_lm_result); DW(lambda_io, double); DW(chi2, double); DW(notpd, int);
 	c->flat.pair = (int *)(dw + w.m_pair); c->flat.n_pair = t_pair; c->flat_ready = false;
@@ -1362,7 +1327,8 @@ static void big_enqueue_assemble(srba_hip_ctx *c, BigLane *ln, int p) {
 static void big_enqueue_cholesky(srba_hip_ctx *c, BigLane *ln, int p) {
 	const srbadev::BigSys S = big_sys(c, ln, p);
 	if (c->big_persistent) { // the whole factorisation in one launch: panel steps and trailing updates separated by grid barriers (srba_big.hpp, k_chol_persistent)
-		const int below0 = S.ld - srbadev::CB, nt0 = below0 > 0 ? (below0 + srbadev::CT - 1) / srbadev::CT : 0, G = std::max(1, std::min(120, std::max(nt0 * (nt0 + 1) / 2, 1 + (below0 > 0 ? (below0 + 63) / 64 : 0))));
+		const int below0 = S.ld - srbadev::CB, nt0 = below0 > 0 ? (below0 + srbadev::CT - 1) / srbadev::CT : 0, resident = 4 * c->n_cu / std::max(1, c->n_lanes_ready) /* the grid barriers need every workgroup of every window in flight resident: 4 workgroups per CU (34 KB of LDS, 256 threads each) shared by the lanes */,
+		          G = std::max(1, std::min(std::min(120, resident), std::max(nt0 * (nt0 + 1) / 2, 1 + (below0 > 0 ? (below0 + 63) / 64 : 0))));
 		unsigned *bar = (unsigned *)(ln->d_iscal + 4);
 		(void)hipMemsetAsync(bar, 0, 4, ln->stream);
 		hipLaunchKernelGGL(srbadev::k_chol_persistent, dim3(G), dim3(256), 0, ln->stream, S, bar);
@@ -1412,6 +1378,7 @@ static int big_lm_run(srba_hip_ctx *c, BigLane *ln, int p) {
 	const bool schur = prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0;
 	srba_lm_result out; std::memset(&out, 0, sizeof(out));
 	for (int k = 0; k < SRBA_TRACE_LEN; k++) { out.trace_chi2[k] = NAN; out.trace_lambda[k] = NAN; out.trace_rho[k] = NAN; }
+	out.lambda_last_trial = NAN;
 	double *resid = c->B.resid, *resid2 = c->B.resid2; const int *flag = ln->d_iscal + 1; const double *lam = ln->d_scal + BS_LAMBDA;
 	auto enqueue_residuals = [&](double *dst, const int *skip) { const int nb = big_grid(d.n_obs, 256); BIGK(kb_residuals, d.n_obs, 256, dst, ln->d_part, skip); big_reduce(c, ln, 0, nb, BS_CHI2, 0); };
 	auto enqueue_linearize = [&]() { BIGK(kb_jac_init, d.n_valid, 256); BIGK(kb_jac, d.n_bp + d.n_bf, 128); BIGK(kb_jac_post, d.n_bp + d.n_bf, 256); BIGK(kb_hessian, d.n_hap + d.n_hf + d.n_hapf, 128, ln->d_iscal); BIGKG(kb_hessian_heavy, d.n_hap, 256, ln->d_iscal); };
@@ -1439,7 +1406,7 @@ static int big_lm_run(srba_hip_ctx *c, BigLane *ln, int p) {
 		if (lambda >= prm.max_lambda) { stop = true; stopmask |= 1 << SRBA_STOP_LAMBDA; }
 		if (RMSE < prm.max_error_per_obs_to_stop) { stop = true; stopmask |= 1 << SRBA_STOP_RMSE; }
 		while (rho <= 0 && !stop) {
-			const int tr = trials++; if (tr < SRBA_TRACE_LEN) out.trace_lambda[tr] = lambda;
+			const int tr = trials++; if (tr < SRBA_TRACE_LEN) out.trace_lambda[tr] = lambda; out.lambda_last_trial = lambda;
 			// one trial = solve, apply, numeric spanning tree of the poses in use, residuals, rho denominator; kernels after the factorisation return at once if it failed
 			hipLaunchKernelGGL(srbadev::kb_set_scalar, dim3(1), dim3(1), 0, ln->stream, ln->d_scal + BS_LAMBDA, lambda);
 			if (big_replay(c, ln, p, 0, [&]() { if (keep_g) hipMemcpyAsync(c->B.grad + d.o_scal, c->B.grad0 + d.o_scal, sizeof(double) * (size_t)d.n_scal, hipMemcpyDeviceToDevice, ln->stream); big_enqueue_assemble(c, ln, p); }) != 0) return -1;
@@ -1529,108 +1496,9 @@ static int big_run_class(srba_hip_ctx *c, const int32_t *caps, int count) {
 #undef BIGK
 #undef BIGKG
 
-// =================================================================================================== the LM loop as rounds over the batch (srba_rounds.hpp)
-#define RDBG(...) do { if (c->rounds_debug) { std::fprintf(stderr, "[rounds] " __VA_ARGS__); std::fprintf(stderr, "\n"); std::fflush(stderr); } } while (0)
-// grid of a persistent round kernel: what the chip holds of it for that much dynamic LDS, at most one wavefront per capsule
-template <class K> static int rounds_grid(srba_hip_ctx *c, K kernel, size_t lds, int count) {
-	int per_cu = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kernel, SRBA_WG, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-	return std::max(1, std::min(count, c->n_cu * per_cu));
-}
-// rounds [r0, r1) of every group (each on its own stream), interleaved round by round so that every stream has work from the start
-static int rounds_enqueue(srba_hip_ctx *c, bool with_init, const std::vector<int> &r0, const std::vector<int> &r1, bool tail) {
-	const int ng = (int)c->rgroups.size(); int rc = 0;
-	with_family(c->params.family, [&](auto fam_) { constexpr int F = decltype(fam_)::value;
-		for (int g = 0; g < ng && rc == 0; g++) { srba_hip_ctx::RGroup &G = c->rgroups[g]; // grids once per upload; big LDS images need the attribute
-			if (G.grid[0]) continue;
-			if (allow_big_lds(c, srbadev::kr_init<F>, G.lds) != 0 || allow_big_lds(c, srbadev::kr_solve<F>, G.lds) != 0 || allow_big_lds(c, srbadev::kr_lin<F>, G.lds) != 0 || allow_big_lds(c, srbadev::kr_tail<F>, G.lds) != 0) { rc = -1; break; }
-			G.grid[5] = rounds_grid(c, srbadev::kr_tail<F>, G.lds, G.count);
-			G.grid[0] = rounds_grid(c, srbadev::kr_init<F>, G.lds, G.count); G.grid[1] = rounds_grid(c, srbadev::kr_solve<F>, G.lds, G.count); G.grid[2] = rounds_grid(c, srbadev::kr_eval<F>, 0, G.count);
-			G.grid[3] = rounds_grid(c, srbadev::kr_lin<F>, G.lds, G.count); G.grid[4] = G.count; // kr_finish: one workgroup per capsule
-		}
-		if (rc != 0) return;
-		// One group = one stream = one chain of launches (init, its rounds, finish) that depends on nothing outside it: the chains are enqueued by several host threads.
-		// Why: a late round has a handful of capsules and lasts ~0.2 ms on the device while its 3 x 17 launches cost one host thread ~0.6 ms (measured: 36 ms of enqueue per
-		// step for 2 900 launches, the device waiting for the next round of every group).
-		auto chain = [&](int g) { const srba_hip_ctx::RGroup &G = c->rgroups[g]; hipStream_t st = c->rstream[g % srba_hip_ctx::kRStreams];
-			if (with_init) hipLaunchKernelGGL((srbadev::kr_init<F>), dim3(G.grid[0]), dim3(SRBA_WG), G.lds, st, c->B, c->dp, c->R, g, G.first, G.count);
-			for (int r = r0[g]; r < r1[g]; r++) {
-				// a launch is as wide as the list of the round was in the previous run of this batch (any width is correct: a workgroup takes further capsules from a counter); a late
-				// round has a handful of capsules, and thousands of workgroups that start only to find the list empty cost more than the round's work
-				int cap = G.count; if (!c->rhist.empty() && r < SRBA_ROUNDS_HIST && r < c->rhist_rounds) cap = std::max(1, std::min(G.count, c->rhist[(size_t)g * SRBA_ROUNDS_HIST + r] + 8));
-				hipLaunchKernelGGL((srbadev::kr_solve<F>), dim3(std::min(G.grid[1], cap)), dim3(SRBA_WG), G.lds, st, c->B, c->dp, c->R, g, G.first, r);
-				hipLaunchKernelGGL((srbadev::kr_eval<F>), dim3(std::min(G.grid[2], cap)), dim3(SRBA_WG), 0, st, c->B, c->dp, c->R, g, G.first, r);
-				hipLaunchKernelGGL((srbadev::kr_lin<F>), dim3(std::min(G.grid[3], cap)), dim3(SRBA_WG), G.lds, st, c->B, c->dp, c->R, g, G.first, r);
-				if (c->rounds_debug >= 3) { hipError_t e = hipStreamSynchronize(st); int cnt3[3] = {0, 0, 0}; hipMemcpy(cnt3, c->R.count + 3 * g, 12, hipMemcpyDeviceToHost); RDBG("round %d of group %d done: %s; lists %d %d %d", r, g, hipGetErrorString(e), cnt3[0], cnt3[1], cnt3[2]); }
-			}
-			if (tail) { // whoever still iterates after the last round enqueued finishes inside one launch of the fused loop
-				int cap = G.count; if (!c->rhist.empty() && r1[g] < SRBA_ROUNDS_HIST && r1[g] <= c->rhist_rounds) cap = std::max(1, std::min(G.count, c->rhist[(size_t)g * SRBA_ROUNDS_HIST + r1[g]] + 8));
-				hipLaunchKernelGGL((srbadev::kr_tail<F>), dim3(std::min(G.grid[5], cap)), dim3(SRBA_WG), G.lds, st, c->B, c->dp, c->R, g, G.first, r1[g]); }
-			hipLaunchKernelGGL((srbadev::kr_finish<F>), dim3(G.grid[4]), dim3(SRBA_WG), 0, st, c->B, c->dp, c->R, g, G.first, G.count); };
-		const int nt = c->rounds_debug >= 3 ? 1 : std::max(1, std::min(c->rounds_threads, ng));
-		std::atomic<int> next(0);
-		auto work = [&]() { hipSetDevice(c->device); for (;;) { const int g = next.fetch_add(1); if (g >= ng) break; chain(g); } };
-		std::vector<std::thread> th;
-		try { for (int t = 1; t < nt; t++) th.emplace_back(work); } catch (...) { /* fewer threads than asked for: the ones that started (and this one) share the groups */ }
-		work(); for (auto &x : th) x.join();
-	});
-	if (rc != 0) return -1;
-	HIPCHK(c, hipGetLastError());
-	for (int g = 0; g < ng; g++) c->rgroups[g].rounds_done = r1[g];
-	return 0;
-}
-static int rounds_fork(srba_hip_ctx *c) { // the group streams start after what is queued on the context stream
-	const int ns = std::min((int)c->rgroups.size(), (int)srba_hip_ctx::kRStreams);
-	for (int q = 0; q < ns; q++) if (!c->rstream[q]) { HIPCHK(c, hipStreamCreateWithFlags(&c->rstream[q], hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->rdone[q], hipEventDisableTiming)); }
-	HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-	for (int q = 0; q < ns; q++) HIPCHK(c, hipStreamWaitEvent(c->rstream[q], c->ev_fork, 0));
-	return 0;
-}
-static int rounds_join(srba_hip_ctx *c) {
-	const int ns = std::min((int)c->rgroups.size(), (int)srba_hip_ctx::kRStreams);
-	for (int q = 0; q < ns; q++) { HIPCHK(c, hipEventRecord(c->rdone[q], c->rstream[q])); HIPCHK(c, hipStreamWaitEvent(c->stream, c->rdone[q], 0)); }
-	return 0;
-}
-static int rounds_run_async(srba_hip_ctx *c) {
-	const int ng = (int)c->rgroups.size();
-	RDBG("run: %d groups, %d capsules", ng, c->n_prob);
-	// counters of the round kernels, list lengths, the "still iterating" count: all zero at the start of a run
-	HIPCHK(c, hipMemsetAsync(c->R.count, 0, sizeof(int) * 3 * (size_t)(ng + 1), c->stream)); HIPCHK(c, hipMemsetAsync(c->R.ctr, 0, sizeof(int) * 5 * (size_t)(ng + 1), c->stream)); HIPCHK(c, hipMemsetAsync(c->R.unfinished, 0, sizeof(int), c->stream));
-	if (ng) HIPCHK(c, hipMemsetAsync(c->R.hist, 0, sizeof(int) * SRBA_ROUNDS_HIST * (size_t)ng, c->stream));
-	if (ng) { if (rounds_fork(c) != 0) return -1;
-		const bool tail = c->rounds_switch > 0;
-		std::vector<int> r0(ng, 0), r1(ng); for (int g = 0; g < ng; g++) { r1[g] = c->rgroups[g].rounds_needed > 0 ? c->rgroups[g].rounds_needed : c->rounds_first; if (tail) r1[g] = std::min(r1[g], c->rounds_switch); } // (a round = one LM trial of every capsule still iterating)
-		if (rounds_enqueue(c, true, r0, r1, tail) != 0) return -1;
-		c->rounds_last = r1[0];
-		RDBG("enqueued: rounds of group 0 = %d", r1[0]);
-		if (c->rounds_debug >= 2) { for (int g = 0; g < ng; g++) { hipError_t e = hipStreamSynchronize(c->rstream[g % srba_hip_ctx::kRStreams]); RDBG("group %d (class %d, first %d, count %d, lds %zu, grids %d %d %d %d %d) synchronised: %s", g, c->rgroups[g].cls, c->rgroups[g].first, c->rgroups[g].count, c->rgroups[g].lds, c->rgroups[g].grid[0], c->rgroups[g].grid[1], c->rgroups[g].grid[2], c->rgroups[g].grid[3], c->rgroups[g].grid[4], hipGetErrorString(e)); } } }
-	int big_rc = 0; { const int32_t *ord = (const int32_t *)(c->h_in.get() + c->h_off_order); big_rc = big_run_class(c, ord + c->cls_first[SRBA_NCLS - 1], c->cls_count[SRBA_NCLS - 1]); }
-	if (ng && rounds_join(c) != 0) return -1;
-	HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-	c->rounds_pending = ng > 0;
-	if (big_rc != 0) { hipStreamSynchronize(c->stream); return -1; }
-	return 0;
-}
-// after the context stream has been synchronised: capsules that needed more rounds than were enqueued (first run of a batch: the number of rounds is a guess) get them now
-static int rounds_complete(srba_hip_ctx *c) {
-	if (!c->rounds_pending) return 0;
-	c->rounds_pending = false; const int ng = (int)c->rgroups.size();
-	for (int pass = 0; pass < 64; pass++) {
-		int unf = 0; HIPCHK(c, hipMemcpyAsync(&unf, c->R.unfinished, sizeof(int), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
-		RDBG("complete: pass %d, %d capsules still iterating", pass, unf);
-		if (unf == 0) return 0;
-		HIPCHK(c, hipMemsetAsync(c->R.unfinished, 0, sizeof(int), c->stream));
-		for (int g = 0; g < ng; g++) { HIPCHK(c, hipMemsetAsync(c->R.ctr + 5 * g + 4, 0, sizeof(int), c->stream)); }
-		if (rounds_fork(c) != 0) return -1;
-		std::vector<int> r0(ng), r1(ng); for (int g = 0; g < ng; g++) { r0[g] = c->rgroups[g].rounds_done; r1[g] = r0[g] + 32; }
-		if (rounds_enqueue(c, false, r0, r1, false) != 0) return -1;
-		if (rounds_join(c) != 0) return -1;
-	}
-	c->fail("lm_run: capsules still iterating after the extra rounds"); return -1;
-}
-
 extern "C" {
 
-int srba_hip_sync(srba_hip_ctx *c) { if (!c) return -1; HIPCHK(c, hipStreamSynchronize(c->stream)); return rounds_complete(c); }
+int srba_hip_sync(srba_hip_ctx *c) { if (!c) return -1; HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
 
 static int lm_run_async_impl(srba_hip_ctx *c);
 int srba_hip_lm_run_async(srba_hip_ctx *c) {
@@ -1648,7 +1516,6 @@ static int lm_run_async_impl(srba_hip_ctx *c) {
 	  if (!c->ring0[slot]) { HIPCHK(c, hipEventCreate(&c->ring0[slot])); HIPCHK(c, hipEventCreate(&c->ring1[slot])); }
 	  c->ev0 = c->ring0[slot]; c->ev1 = c->ring1[slot]; c->n_launches++; }
 	HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-	if (c->rounds_on) return rounds_run_async(c);
 	HIPCHK(c, hipMemsetAsync(c->d_next, 0, sizeof(int) * kMaxJobs, c->stream)); // work counters of the persistent launches
 	// fork/join: the launch plan (made at upload) spreads the size classes over a few streams; see plan_launches()
 	const int nq = c->plan.size() <= 1 ? 1 : c->n_streams_used; // a single launch (the per-key-frame use) stays on the context stream: no fork / join
@@ -1715,21 +1582,14 @@ int srba_hip_eval_overall_sqr_error(srba_hip_ctx *c, const srba_overall_problem 
 }
 int srba_hip_download_results(srba_hip_ctx *c, srba_lm_result *results, int n) {
 	if (!c || !results || n > c->n_prob) return -1;
-	HIPCHK(c, hipStreamSynchronize(c->stream)); if (rounds_complete(c) != 0) return -1;
+	HIPCHK(c, hipStreamSynchronize(c->stream));
 	HIPCHK(c, hipMemcpyAsync(results, c->d_wk + c->off_res, sizeof(srba_lm_result) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
-	if (c->rounds_on && n == c->n_prob) { // the rounds a later run of this batch needs: one per LM trial of the slowest capsule of each group
-		const int32_t *ord = (const int32_t *)(c->h_in.get() + c->h_off_order);
-		for (auto &G : c->rgroups) { int mx = 0; for (int i = 0; i < G.count; i++) mx = std::max(mx, (int)results[ord[G.first + i]].num_trials); G.rounds_needed = mx + 1; }
-		c->rhist.assign((size_t)SRBA_ROUNDS_HIST * c->rgroups.size(), 0);
-		c->rhist_rounds = c->rounds_last;
-		if (!c->rhist.empty()) { HIPCHK(c, hipMemcpyAsync(c->rhist.data(), c->R.hist, sizeof(int) * c->rhist.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); } }
 	return 0;
 }
 int srba_hip_lm_run(srba_hip_ctx *c, srba_lm_result *results) {
 	if (srba_hip_lm_run_async(c) != 0) return -1;
 	HIPCHK(c, hipStreamSynchronize(c->stream));
-	if (rounds_complete(c) != 0) return -1;
 	float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_ms = ms;
 	if (results) return srba_hip_download_results(c, results, c->n_prob);
 	return 0;
@@ -1758,7 +1618,9 @@ int srba_hip_eval_residuals(srba_hip_ctx *c, double *chi2_out) {
 int srba_hip_linearize(srba_hip_ctx *c) {
 	if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device));
 	const int lds_doubles = c->lin_terms ? 16 + 1536 : 16; // 12 KB of Hessian accumulators per wavefront: U_Ap of up to 170 SE2 / 42 SE3 blocks (bigger capsules take the per-block path)
-	if (c->asm_ready) { // relative-pose SE2: fused, Jacobian blocks never leave the chip (srba_assemble.hpp): one launch, a workgroup per bin of capsules; what does not fit a bin takes the unfused kernel
+	bool lam_sym = true; // the fused kernel sums the upper triangle of J^t Lambda J only: an information matrix set after the upload (srba_hip_set_params) is checked again here
+	if (c->dp.noise == SRBA_NOISE_CONSTANT_MATRIX) for (int i = 0; i < 3; i++) for (int j = 0; j < i; j++) if (c->dp.lambda[3 * i + j] != c->dp.lambda[3 * j + i]) lam_sym = false;
+	if (c->asm_ready && lam_sym) { // relative-pose SE2: fused, Jacobian blocks never leave the chip (srba_assemble.hpp): one launch, a workgroup per bin of capsules; what does not fit a bin takes the unfused kernel
 		if (c->asm_bins > 0 && srbadev::asm_launch(c->dp.noise != SRBA_NOISE_CONSTANT_MATRIX ? 0 : (c->dp.lambda[1] == 0 && c->dp.lambda[2] == 0 && c->dp.lambda[5] == 0 && c->dp.lambda[3] == 0 && c->dp.lambda[6] == 0 && c->dp.lambda[7] == 0) ? 1 : 2, c->asm_bins, srbadev::ASM_BIN_BYTES, c->stream, c->B, c->dp, c->asm_tab) != 0) { c->fail("k_assemble_se2rel: launch failed"); return -1; }
 		if (c->asm_rest > 0) { with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::k_linearize<decltype(fam_)::value>), dim3(c->asm_rest), dim3(SRBA_WG), (size_t)lds_doubles * 8, c->stream, c->B, c->dp, lds_doubles, c->asm_list); }); HIPCHK(c, hipGetLastError()); }
 		c->jp_stale = c->asm_bins > 0; return 0;
@@ -1811,6 +1673,7 @@ int srba_hip_download_state(srba_hip_ctx *c, srba_problem_capsule *caps, int n) 
 	return 0;
 }
 
+int srba_hip_set_phase_timing(srba_hip_ctx *c, int on) { if (!c) return -1; c->phase_timing = on != 0; return 0; } // takes effect at the next upload (the counters are part of the work arena layout)
 int64_t srba_hip_debug_size(srba_hip_ctx *c, int what) { if (c && what == 10) return c->phase_timing ? 16 * (int64_t)c->n_prob : 0; if (c && what == 11) return 4 * (int64_t)c->n_prob; return (c && what >= 0 && what < 10) ? c->len_dbg[what] : -1; }
 int srba_hip_debug_read(srba_hip_ctx *c, int what, double *out, int64_t n_doubles) {
 	if (c && what == 11) { // per-capsule solver shape: [LDS bytes reserved by its launch, nb, off-diagonal blocks, block updates per factorisation]

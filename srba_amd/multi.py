@@ -9,10 +9,11 @@ def rank_info():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init_process_group(backend):
-    """one process per GPU; rendezvous on 127.0.0.1 unless the launcher says otherwise"""
+def init_process_group(backend, force=False):
+    """one process per GPU; rendezvous on 127.0.0.1 unless the launcher says otherwise. force: create the group for a single rank as well (tests/test_rccl_single_rank.py
+    runs the nccl = RCCL branch -- init, barrier, the two all-reduces of aggregate() on device tensors -- on the one GPU of the test box)"""
     rank, world, _ = rank_info()
-    if world <= 1:
+    if world <= 1 and not force:
         return None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")

@@ -44,6 +44,7 @@ def _proto(l):
     l.srba_oracle_lm_run.argtypes = [C.POINTER(capi.HipParams), capi.PCAP, capi.c_i32, C.POINTER(capi.LmResult), capi.c_i32]
     l.srba_oracle_run_one.argtypes = [C.POINTER(capi.HipParams), capi.PCAP, C.POINTER(capi.LmResult)]
     l.srba_oracle_take_symbolic_seconds.restype = capi.c_f64
+    l.srba_oracle_lm_run_replay.argtypes = [C.POINTER(capi.HipParams), capi.PCAP, capi.c_i32, capi.PI32, capi.PI32, capi.c_i32, capi.PF64, capi.PF64, capi.PF64, capi.PI32, capi.PI32, C.POINTER(capi.LmResult), capi.c_i32]
     l.srba_oracle_schur_from_jacobians.argtypes = [C.POINTER(capi.HipParams), capi.PCAP, capi.PF64, capi.PF64, capi.PF64, capi.c_f64] + [capi.PF64] * 4
     l.srba_oracle_stage.argtypes = [C.POINTER(capi.HipParams), capi.PCAP, capi.c_i32, capi.c_f64] + [capi.PF64] * 10
 
@@ -72,6 +73,60 @@ def run_batch(batch, threads=1, keep_state=False, opt="O2"):
     if keep_state:
         out["state"] = work
     return out
+
+
+def decisions_of(res):
+    """The trial sequence of a run, from its trace (first TRACE_LEN trials): 0 = solve failed (not positive definite), 1 = rejected, 2 = accepted; and how many of them there are."""
+    n = len(res["num_trials"]); k = np.minimum(res["num_trials"], capi.TRACE_LEN).astype(np.int32)
+    rho = res["trace_rho"]; dec = np.where(np.isnan(rho), 0, np.where(rho > 0, 2, 1)).astype(np.int32)
+    dec[np.arange(capi.TRACE_LEN)[None, :] >= k[:, None]] = -1
+    return np.ascontiguousarray(dec), k
+
+
+def run_batch_replay(batch, other, threads=1):
+    """The oracle's LM loop on a deep copy of the batch, taking the accept / reject / not-PD sequence of ANOTHER run (`other`: a results dict, normally the GPU's) instead of its own
+    decisions (oracle/srba_oracle.cpp, Problem::run). Returns the usual results dict of the replayed run plus, per trial: own_rho, own_chi2 (chi2 of the trial point), own_E (chi2 the
+    trial started from), flags (1 own factorisation PD, 2 own rho sign differs from the replayed decision, 4 not-PD forced on a PD system), and per capsule diverged_at, replayed (trials
+    replayed), complete (the other run's whole sequence fitted the trace and was followed to its end)."""
+    ora = lib(); work = batch.clone(); n = work.n; T = capi.TRACE_LEN
+    dec, k = decisions_of(other)
+    own_rho = np.full((n, T), np.nan); own_chi2 = np.full((n, T), np.nan); own_E = np.full((n, T), np.nan); flags = np.zeros((n, T), np.int32); div = np.full(n, -1, np.int32)
+    res = (capi.LmResult * n)()
+    rc = ora.srba_oracle_lm_run_replay(C.byref(batch.params), work.ptr, n, dec.ctypes.data_as(capi.PI32), k.ctypes.data_as(capi.PI32), T, own_rho.ctypes.data_as(capi.PF64), own_chi2.ctypes.data_as(capi.PF64),
+                                       own_E.ctypes.data_as(capi.PF64), flags.ctypes.data_as(capi.PI32), div.ctypes.data_as(capi.PI32), res, threads)
+    if rc != 0:
+        raise RuntimeError("oracle replay failed")
+    out = runner.results_to_dict(res, n)
+    out.update(own_rho=own_rho, own_chi2=own_chi2, own_E=own_E, flags=flags, diverged_at=div, decisions=dec, replayed=k, complete=(div < 0) & (other["num_trials"] <= T), state=work)
+    return out
+
+
+def replay_report(gpu, rep, tol_trace=1e-9, tol_floor=1e-9):
+    """What the replay of a GPU run by the oracle proves, window by window:
+      trace_ok  -- on every ACCEPTED trial the chi2 of the two runs agree to tol_trace (relative)
+      floor_ok  -- wherever the oracle's own rho sign disagrees with the GPU's decision, the step moves chi2 by less than tol_floor of its value in BOTH runs (a rounding-floor decision)
+      final_rel -- relative distance of the final chi2 (replayed oracle vs GPU); only meaningful where `complete`
+    Returns a dict of per-capsule arrays."""
+    T = capi.TRACE_LEN; n = len(gpu["num_trials"])
+    dec = rep["decisions"]; acc = dec == 2; ev = dec >= 1
+    g_chi2 = gpu["trace_chi2"]; o_chi2 = rep["own_chi2"]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        rel = np.abs(g_chi2 - o_chi2) / np.maximum(np.abs(o_chi2), 1e-300)
+        rel = np.where(np.abs(g_chi2 - o_chi2) < 1e-20, 0.0, rel)   # (absolute floor: noise-free windows end at chi2 ~ 1e-25)
+    trace_err = np.where(acc, rel, 0.0); trace_err[np.isnan(trace_err)] = np.inf
+    worst_trace = trace_err.max(axis=1)
+    # the chi2 the GPU trial started from = chi2 of its last accepted trial before (or the initial one)
+    g_E = np.empty((n, T)); cur = gpu["chi2_init"].astype(float).copy()
+    for t in range(T):
+        g_E[:, t] = cur; a = acc[:, t]; cur = np.where(a, g_chi2[:, t], cur)
+    dis = (rep["flags"] & 2) != 0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        move_o = np.abs(rep["own_E"] - o_chi2) / np.maximum(np.abs(rep["own_E"]), 1e-300); move_g = np.abs(g_E - g_chi2) / np.maximum(np.abs(g_E), 1e-300)
+    floor_move = np.where(dis, np.maximum(move_o, move_g), 0.0); floor_move[np.isnan(floor_move)] = np.inf
+    worst_floor = floor_move.max(axis=1)
+    fin = np.abs(rep["chi2_final"] - gpu["chi2_final"]); final_rel = np.where(fin < 1e-20, 0.0, fin / np.maximum(np.abs(rep["chi2_final"]), 1e-300))
+    return dict(worst_trace=worst_trace, worst_floor=worst_floor, final_rel=final_rel, complete=rep["complete"], diverged_at=rep["diverged_at"], n_disagree=dis.sum(axis=1), forced_notpd=((rep["flags"] & 4) != 0).sum(axis=1),
+                trace_ok=worst_trace <= tol_trace, floor_ok=worst_floor <= tol_floor)
 
 
 def stage(batch, i, do_solve=False, lam=0.0):
