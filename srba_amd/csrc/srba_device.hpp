@@ -597,7 +597,9 @@ struct Worker {
 	// the high half of a double -- a wild address, HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION (round 2's shelved fault; root cause with the debugger transcript: profiles/r03_fault_root_cause.md).
 	// The empty asm takes the sign-extended value as a 64-bit register operand, so both halves exist before the address is formed. (The relative-pose SE2 kernel, 22 VGPRs under its
 	// two-wavefront budget and never affected, is left as it is.)
-	static __device__ __forceinline__ long long wide(int i) { long long w = i; if constexpr (FAM != SRBA_SE2_RELPOSE2D) asm volatile("" : "+v"(w)); return w; }
+	// Round 4: the 32-bit value is made opaque BEFORE it is widened (the compiler then knows nothing about its sign and has to compute the high word from it: v_ashrrev_i32 hi, 31, lo); with the
+	// barrier after the widening the pair could still be formed from a register the compiler believed to hold the zero extension (tools/scan_undef_hi.py found six such pairs in the stereo kernel).
+	static __device__ __forceinline__ long long wide(int i) { if constexpr (FAM != SRBA_SE2_RELPOSE2D) asm volatile("" : "+v"(i)); long long w = i; if constexpr (FAM != SRBA_SE2_RELPOSE2D) asm volatile("" : "+v"(w)); return w; }
 	__device__ __forceinline__ pose_t pose_at(int idx) const { return idx >= 0 ? PO::ld(B.pose + (d.o_pair * 2 + wide(idx)) * PD) : PO::ident(); }
 	__device__ __forceinline__ const double *lm_ptr(int ref) const { return ref >= 0 ? B.ulm + (d.o_ulm + wide(ref)) * L : B.klm + (d.o_klm + wide(-1 - ref)) * L; }
 

@@ -67,10 +67,11 @@ struct Solver : public Worker<FAM> {
 				int cur = -1; bool curdiag = false; double Hl[P * P], ga[P];
 				auto flush = [&]() {
 					if (cur < 0) return;
-					double *H = B.HAp + (d.o_hap + cur) * P * P;
+					const long long cw = W::wide(cur); // (an index proved non-negative that enters 64-bit address arithmetic: see Worker::wide)
+					double *H = B.HAp + (d.o_hap + cw) * P * P;
 #pragma unroll
 					for (int k = 0; k < P * P; k++) unsafeAtomicAdd(H + k, Hl[k]); // global_atomic_add_f64 (the workspace is ordinary device memory)
-					if (curdiag) { double *gi = g + B.hap_i[d.o_hap + cur] * P;
+					if (curdiag) { double *gi = g + B.hap_i[d.o_hap + cw] * P;
 #pragma unroll
 						for (int r = 0; r < P; r++) unsafeAtomicAdd(gi + r, ga[r]); }
 				};

@@ -125,8 +125,32 @@ def replay_report(gpu, rep, tol_trace=1e-9, tol_floor=1e-9):
     floor_move = np.where(dis, np.maximum(move_o, move_g), 0.0); floor_move[np.isnan(floor_move)] = np.inf
     worst_floor = floor_move.max(axis=1)
     fin = np.abs(rep["chi2_final"] - gpu["chi2_final"]); final_rel = np.where(fin < 1e-20, 0.0, fin / np.maximum(np.abs(rep["chi2_final"]), 1e-300))
-    return dict(worst_trace=worst_trace, worst_floor=worst_floor, final_rel=final_rel, complete=rep["complete"], diverged_at=rep["diverged_at"], n_disagree=dis.sum(axis=1), forced_notpd=((rep["flags"] & 4) != 0).sum(axis=1),
+    return dict(worst_trace=worst_trace, worst_floor=worst_floor, floor_move=floor_move, final_rel=final_rel, complete=rep["complete"], diverged_at=rep["diverged_at"], n_disagree=dis.sum(axis=1), forced_notpd=((rep["flags"] & 4) != 0).sum(axis=1),
                 trace_ok=worst_trace <= tol_trace, floor_ok=worst_floor <= tol_floor)
+
+
+def perturbed(batch, eps=2.220446049250313e-16, seed=0):
+    """A deep copy of the batch whose observations are moved by +-eps relative (one unit in the last place by default): the input of a rounding-sensitivity measurement."""
+    P, L, O, PD = capi.DIMS[batch.family]; w = batch.clone(); rng = np.random.RandomState(seed)
+    for i in range(w.n):
+        c = w.ptr[i]
+        if c.n_obs:
+            z = np.ctypeslib.as_array(c.obs_z, shape=(c.n_obs * O,)); z *= 1.0 + eps * rng.choice([-1.0, 1.0], size=z.shape)
+    return w
+
+
+def rounding_sensitivity(batch, other, seeds=(0, 1, 2, 3, 4), threads=8):
+    """How far the chi2 of every evaluated trial moves (relative) when the observations are perturbed by one unit in the last place and the oracle follows the SAME decision sequence
+    (`other`) -- the distance at which two correct evaluations of that trial can be expected to sit. Returns (per window: worst ACCEPTED trial, per trial [n, TRACE_LEN]).
+    Well-conditioned windows: 1e-13; accepted trials of a lost map: 1e-9 .. 1e-7 (not proportional to the perturbation: these windows hold points next to the camera plane);
+    rejected overshoots of such a map can be chaotic (the trial point itself moves)."""
+    base = run_batch_replay(batch, other, threads=threads); ev = base["decisions"] >= 1; acc = base["decisions"] == 2; per_trial = np.zeros(base["own_chi2"].shape)
+    for sd in seeds:
+        rp = run_batch_replay(perturbed(batch, seed=sd), other, threads=threads)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            d = np.where(ev, np.abs(base["own_chi2"] - rp["own_chi2"]) / np.abs(base["own_chi2"]), 0.0)
+        d[np.isnan(d)] = 0.0; per_trial = np.maximum(per_trial, d)
+    return np.where(acc, per_trial, 0.0).max(axis=1), per_trial
 
 
 def stage(batch, i, do_solve=False, lam=0.0):

@@ -19,6 +19,22 @@ def _close(a, b, rel=REL, abs_=1e-15):
     return np.all(np.abs(a - b) <= rel * np.maximum(np.abs(a), np.abs(b)) + abs_)
 
 
+def _replay_exact(b, gpu, tol_trace=1e-9, tol_floor=1e-9, tol_final=1e-6, tol=None, tol_trial=None, threads=8):
+    """Exact form of "the two runs may part only at a rounding-floor decision" (round 4; oracle/srba_oracle.cpp Problem::run, Replay): the oracle re-runs every window taking the GPU's
+    own not-PD / reject / accept sequence and reports its own rho and chi2 per trial. For EVERY window: (i) the chi2 of every accepted trial of the whole run agrees to tol_trace,
+    (ii) every decision the oracle would have taken the other way is a step that moves chi2 by less than tol_floor of its value in BOTH runs, (iii) where the whole sequence fits
+    the trace, the final chi2 agrees to tol_final; the oracle can follow every sequence (it never calls a system the GPU solved not positive definite, nor the other way round).
+    tol / tol_trial: optional per-window / per-trial arrays that replace the scalars (windows whose rounding sensitivity is measured, see the lost monocular map)."""
+    rep = _oracle.run_batch_replay(b, gpu, threads=threads); R = _oracle.replay_report(gpu, rep)
+    tt = np.full(b.n, tol_trace) if tol is None else tol; te = np.full(b.n, tol_final) if tol is None else np.maximum(tol, tol_final)
+    tf = np.full(R["floor_move"].shape, tol_floor) if tol_trial is None else tol_trial
+    assert (R["diverged_at"] < 0).all() and R["forced_notpd"].sum() == 0, (np.flatnonzero(R["diverged_at"] >= 0), R["forced_notpd"].sum())
+    bad = np.flatnonzero(R["worst_trace"] > tt); assert len(bad) == 0, ("accepted-trial chi2", bad[:8], R["worst_trace"][bad[:8]])
+    bad = np.argwhere(R["floor_move"] > tf); assert len(bad) == 0, ("decision not at the rounding floor", bad[:8], R["floor_move"][R["floor_move"] > tf][:8])
+    bad = np.flatnonzero(R["complete"] & (R["final_rel"] > te)); assert len(bad) == 0, ("final chi2", bad[:8], R["final_rel"][bad[:8]])
+    return rep, R
+
+
 @pytest.fixture(scope="module")
 def se2_batch():
     # capsules harvested with the oracle as numeric back-end (tests may use the oracle); 240 keyframes with loop closures
@@ -53,6 +69,7 @@ def _compare_lm(b, gpu, cpu):
         assert _close(g[:k][ok], c[:k][ok], rel=1e-6, abs_=1e-20), i
         assert _close(gpu["trace_lambda"][i][:k], cpu["trace_lambda"][i][:k], rel=1e-9), i
         n_full += int(k == m and gpu["num_trials"][i] == cpu["num_trials"][i])
+    _replay_exact(b, gpu)   # ... and over the WHOLE run of every window, the oracle following the GPU's decisions: 1e-9 on accepted trials, 1e-9 at every disputed decision, 1e-6 at the end
     return n_full
 
 
@@ -450,31 +467,16 @@ def test_lost_monocular_map_agrees_up_to_a_rounding_floor_decision():
     # (chi2_init ~ 1e7 px^2 comes from points that start almost in the camera plane: their pixel coordinates, and the 1/z^2 of their Jacobians that sets
     #  lambda_0 = 1e-3 max diag H, amplify the last bits of the composed pose)
     assert _close(gpu["chi2_init"], cpu["chi2_init"], rel=1e-6) and _close(gpu["lambda_init"], cpu["lambda_init"], rel=1e-4)
-    together = tight = split = at_floor = 0
-    for i in range(b.n):
-        m = int(min(gpu["num_trials"][i], cpu["num_trials"][i], capi.TRACE_LEN))
-        g, c = gpu["trace_chi2"][i][:m], cpu["trace_chi2"][i][:m]
-        same_dec = (np.sign(gpu["trace_rho"][i][:m]) == np.sign(cpu["trace_rho"][i][:m])) & (np.isnan(g) == np.isnan(c))
-        k = m if same_dec.all() else int(np.argmin(same_dec))
-        assert k >= min(m, 2), (i, k, m)
-        acc = cpu["trace_rho"][i][:k] > 0
-        # (the deviation between any two runs grows geometrically along a chaotic trace -- 5e-11 at the first trial, 1e-6 some twenty trials later also between the reference's own two
-        #  Schur solvers, tests/test_conditioning.py: accepted chi2 values are compared on the first ten trials at 1e-6 and at 1e-4 after that, decisions on the whole common prefix)
-        k10 = min(k, 10)
-        assert _close(g[:k10][acc[:k10]], c[:k10][acc[:k10]], rel=1e-6, abs_=1e-20), (i, k)
-        assert _close(g[:k][acc], c[:k][acc], rel=1e-4, abs_=1e-20), (i, k)
-        assert _close(gpu["trace_lambda"][i][:k] / gpu["lambda_init"][i], cpu["trace_lambda"][i][:k] / cpu["lambda_init"][i], rel=1e-9), i   # the same lambda schedule
-        if k < m:   # the runs part ways: at the rounding floor (the trial they decide differently moves chi2 by less than 1e-6 of its value in both runs)
-            split += 1
-            e_prev = c[np.flatnonzero(acc)[-1]] if acc.any() else cpu["chi2_init"][i]
-            at_floor += int(all(np.isnan(e_k) or abs(e_k - e_prev) <= 1e-6 * e_prev for e_k in (g[k], c[k])))
-            assert gpu["chi2_final"][i] <= e_prev * (1 + 1e-4) and cpu["chi2_final"][i] <= e_prev * (1 + 1e-4), i   # both continuations only go down from the common point
-        elif gpu["num_trials"][i] == cpu["num_trials"][i]:
-            together += 1
-            assert abs(gpu["chi2_final"][i] - cpu["chi2_final"][i]) <= 1e-4 * cpu["chi2_final"][i], i
-            tight += int(abs(gpu["chi2_final"][i] - cpu["chi2_final"][i]) <= 1e-6 * cpu["chi2_final"][i])
-    # (counts, not per-window assertions: which windows of a chaotic map split, and where, changes with the host's libm; observed: 59 windows, 27 split, all at the floor; 30 together, all at 1e-6)
-    assert together >= b.n // 3 and tight >= 0.9 * together and at_floor >= 0.9 * split, (together, tight, split, at_floor)
+    # Exact, window by window (round 4): the oracle follows the GPU's own decision sequence (tests/_oracle.py run_batch_replay), so the two runs are compared over their WHOLE length
+    # instead of up to their first different decision. EVERY window of this lost map (RMSE 60 .. 140 px, chi2 ~ 1e7, points next to the camera plane), nothing counted:
+    # accepted trials and final chi2 within 1e-5, every disputed decision a step that moves chi2 by less than 1e-6 of its value in both runs (measured on the MI355X box: 2.4e-6 /
+    # 2.4e-6 / 2.5e-8; 23 of the 59 windows sit below 1e-9). The 1e-9 / 1e-9 / 1e-6 of the other tests is not attainable here by ANY two evaluations: the oracle following the same
+    # decisions on observations moved by one unit in the last place ends 1e-9 .. 1e-7 away from itself on the accepted trials (checked below; tools/diag_replay.py prints the
+    # GPU-vs-oracle distance and that sensitivity side by side, window by window: they go together).
+    rep, R = _replay_exact(b, gpu, tol_trace=1e-5, tol_floor=1e-6, tol_final=1e-5)
+    sens, _ = _oracle.rounding_sensitivity(b, gpu, seeds=(0, 1))
+    assert 1e-8 < sens.max() < 1e-5, sens.max()
+    assert R["complete"].sum() >= b.n - 2   # nearly every window's whole run fits the trial trace and is compared to its end
 
 
 @pytest.mark.gpu
@@ -600,7 +602,9 @@ def test_flat_valley_windows_part_at_a_rounding_floor_decision():
     eng = runner.landmark_engine("rb2d", backend=_oracle.BACKEND, solver=capi.SOLVER_SCHUR_DENSE, depth=2 + seed % 3); eng.run(ds); b = eng.harvest(); b.engine = eng
     sub = b.sub(max(0, b.n - 40), min(40, b.n)); ref = _oracle.run_batch(sub); gpu = runner.run_batch_hip(sub)
     rel = np.abs(gpu["chi2_final"] - ref["chi2_final"]) / ref["chi2_final"]
-    assert (rel > 1e-6).sum() <= 1 and rel.max() < 2e-5
+    assert rel.max() > 1e-6   # (the dataset still shows what it was chosen for: the two runs' OWN final chi2 differ by more than the parity tolerance in at least one window ...)
+    # ... and the oracle following the GPU's decisions lands on the GPU's chi2: every accepted trial of every window, every disputed decision and the end at 1e-9 (measured: 3e-13, 1e-13, 1e-13)
+    _replay_exact(sub, gpu, tol_trace=1e-9, tol_floor=1e-9, tol_final=1e-9)
     for i in range(sub.n):
         m = int(min(gpu["num_trials"][i], ref["num_trials"][i], capi.TRACE_LEN)); g, c = gpu["trace_chi2"][i][:m], ref["trace_chi2"][i][:m]
         same = (np.sign(gpu["trace_rho"][i][:m]) == np.sign(ref["trace_rho"][i][:m])) & (np.isnan(g) == np.isnan(c)); k = m if same.all() else int(np.argmin(same))

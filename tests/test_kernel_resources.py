@@ -53,3 +53,18 @@ def test_fused_normal_equations_kernel_keeps_two_wavefronts_per_simd(tmp_path):
     ks = {k: v for k, v in res.items() if "k_assemble_se2rel" in k}
     assert len(ks) == 3, ks
     assert all(v <= 256 and s == 0 for v, s in ks.values()), ks
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "clang-offload-bundler")), reason="ROCm LLVM tools not found")
+def test_no_index_is_widened_with_a_stale_high_half_in_the_lm_kernels():
+    """The compiler error behind round 2's memory-aperture fault (profiles/r03_fault_root_cause.md: a table index proved non-negative is widened to 64 bits by pairing it with a
+    register that no longer holds its zero) as a static fence over the device code that ships: tools/scan_undef_hi.py on all nine k_lm_run instantiations and on every kernel of the
+    multi-workgroup path (kb_*). Before Worker::wide was hardened in round 4 (the value is made opaque BEFORE it is widened) the scan reported six such pairs in the stereo kernel."""
+    import __graft_entry__ as ge
+    ge.build()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import scan_undef_hi
+    dis = scan_undef_hi.disassemble(os.path.join(ROOT, "srba_amd", "lib", "srba_hip.o"))
+    f_lm, k_lm = scan_undef_hi.scan(dis, "k_lm_runILi"); f_kb, k_kb = scan_undef_hi.scan(dis, "kb_")
+    assert len(k_lm) == 9 and len(k_kb) >= 100, (len(k_lm), len(k_kb))
+    assert not f_lm and not f_kb, (f_lm + f_kb)[:4]
