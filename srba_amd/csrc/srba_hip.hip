@@ -509,6 +509,8 @@ __global__ void __launch_bounds__(SRBA_WG) SRBA_OCC k_lm_run(const Batch B, cons
 	}
 }
 
+// holds a class stream back for a while before its persistent launch (staggered start of the class launches, plan_launches)
+__global__ void k_delay(int us) { const long long t0 = wall_clock64(); while (wall_clock64() - t0 < 100LL * us) __builtin_amdgcn_s_sleep(20); }
 // ---- stepwise kernels
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_spantree(const Batch B, const DevParams prm, int only_needed) { Solver<FAM> S(B, B.desc[blockIdx.x], prm); S.phase_spantree(only_needed != 0); }
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_residuals(const Batch B, const DevParams prm) {
@@ -715,7 +717,7 @@ static void symbolic_dense(const srba_problem_capsule &k, const ProbDesc &d, int
 	for (size_t u = 0; u < covered.size(); u++) if (!covered[u]) out.fill.push_back((int32_t)u);
 }
 
-struct LaunchJob { int queue, cls, first, count; double cost; int grid; };
+struct LaunchJob { int queue, cls, first, count; double cost; int grid; int delay_us = 0; };
 static const int kBigPart = 4096;
 static const int kMaxJobs = 1024;
 
@@ -792,6 +794,8 @@ struct srba_hip_ctx {
 	srbadev::FlatMap flat; bool flat_ready = false, use_flat = true; // pair -> capsule map of the flat spanning-tree kernel (srba_flat.hpp), filled on first use after an upload
 	int big_min_sys = 480;   // systems with more scalar unknowns than this skip the block-sparse symbolic analysis and go dense (big path)
 	std::unique_ptr<char[]> h_in; size_t h_in_cap = 0; size_t h_off_order = 0; // host staging of the input arena (kept: the launch order is read back from it)
+	std::vector<int> delay_us; int class_prio = 0; // experiment knobs: per plan job delay before its launch (overrides the staggered start); stream priorities by class size
+	int stagger_ns = 300, stagger_max_us = 5000; // staggered start of the class launches: see plan_launches
 	int max_lds_kb = 1 << 20, min_chunk = 384, max_parts_per_queue = 2; int class_streams = 64 /* sched 3: the class launches are dealt round-robin to at most this many streams */, n_queues = 16, sched = 3, n_streams_used = 1, n_cu = 256, waves_per_cu = 8, lds_per_cu = 160 * 1024; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
 	// offsets needed for downloads (bytes inside the wk arena)
 	size_t off_edge = 0, off_ulm = 0, off_pose = 0, off_inf = 0, off_infv = 0, off_res = 0;
@@ -812,7 +816,14 @@ static void plan_launches(srba_hip_ctx *c, const int32_t *ord) {
 	c->plan.clear(); const int nq = c->n_queues;
 	struct fin { srba_hip_ctx *c; ~fin() { // grid of every job: persistent launches hold as many wavefronts as the chip can keep resident for that LDS size, the rest one per capsule
 		for (size_t j = 0; j < c->plan.size(); j++) { LaunchJob &J = c->plan[j]; J.grid = J.count;
-			if (c->sched == 3) { const size_t lds = c->cls_lds[J.cls] + c->lds_pad; const int fit = lds ? (int)std::max<size_t>(1, (size_t)c->lds_per_cu / lds) : c->waves_per_cu; J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(c->waves_per_cu, fit))); } } } } finish = {c};
+			if (c->sched == 3) { const size_t lds = c->cls_lds[J.cls] + c->lds_pad; const int fit = lds ? (int)std::max<size_t>(1, (size_t)c->lds_per_cu / lds) : c->waves_per_cu; J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(c->waves_per_cu, fit))); }
+		}
+		// Staggered start (round 4): the persistent launches of all classes are enqueued at once on their own streams, and which workgroups the dispatcher places first was a race --
+		// when the small (wave-slot bound) classes won it they filled every wave slot, the big (LDS bound, longest running) capsules trickled in late and the launch ended in their tail:
+		// 42-43 ms instead of 38 ms on the benchmark batch, from one launch to the next (tools/diag_launch_order.py, profiles/r04_launch_order.txt). Largest-footprint-first is now enforced:
+		// the stream of job j is held back by a one-thread delay kernel for stagger_ns x (workgroups of all the jobs before it) -- the time the dispatcher needs to place those.
+		if (c->sched == 3 && c->plan.size() > 1) { long long ahead = 0; for (size_t j = 0; j < c->plan.size(); j++) { LaunchJob &J = c->plan[j]; J.delay_us = (int)std::min<long long>(c->stagger_max_us, ahead * c->stagger_ns / 1000); if (j < c->delay_us.size()) J.delay_us = c->delay_us[j]; ahead += J.grid; } }
+		if (getenv("SRBA_HIP_PLAN_DEBUG")) for (size_t j = 0; j < c->plan.size(); j++) { const LaunchJob &J = c->plan[j]; std::fprintf(stderr, "[plan] job %zu: stream %d class %d lds %zu B capsules %d grid %d delay %d us\n", j, J.queue, J.cls, c->cls_lds[J.cls], J.count, J.grid, J.delay_us); } } } finish = {c};
 	if (c->sched == 3) { // one persistent launch per size class, every class on its own stream, biggest LDS footprint first (the HBM class is the biggest)
 		int q = 0; const int qmax = std::max(1, c->class_streams);
 		for (int k = SRBA_NCLS - 2; k >= 0; k--) if (c->cls_count[k]) { c->plan.push_back({q % qmax, k, c->cls_first[k], c->cls_count[k], 0.0, 0}); q++; }
@@ -930,7 +941,11 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_QUEUES"); if (e && atoi(e) >= 1 && atoi(e) < SRBA_NCLS) c->n_queues = atoi(e); } // tuning knob: concurrent launch streams
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || false) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
-	for (int k = 1; k < SRBA_NCLS && ok; k++) ok = hipStreamCreateWithFlags(&c->cls_stream[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->cls_done[k], hipEventDisableTiming) == hipSuccess;
+	{ const char *e = getenv("SRBA_HIP_CLASS_PRIO"); if (e) c->class_prio = atoi(e); e = getenv("SRBA_HIP_STAGGER_NS"); if (e && atoi(e) >= 0) c->stagger_ns = atoi(e); e = getenv("SRBA_HIP_DELAY_US"); if (e) { std::string t(e); size_t p0 = 0; while (p0 <= t.size()) { size_t p1 = t.find(',', p0); if (p1 == std::string::npos) p1 = t.size(); c->delay_us.push_back(atoi(t.substr(p0, p1 - p0).c_str())); p0 = p1 + 1; } } }
+	int pr_least = 0, pr_greatest = 0; hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+	for (int k = 1; k < SRBA_NCLS && ok; k++) { // (class_prio 1: the streams of the biggest classes -- low stream index, see plan_launches -- get the highest priority, 2: the lowest)
+		const int split = 4, pri = c->class_prio == 0 ? 0 : ((c->class_prio == 1) == (k < split) ? pr_greatest : pr_least);
+		ok = (c->class_prio ? hipStreamCreateWithPriority(&c->cls_stream[k], hipStreamNonBlocking, pri) : hipStreamCreateWithFlags(&c->cls_stream[k], hipStreamNonBlocking)) == hipSuccess && hipEventCreateWithFlags(&c->cls_done[k], hipEventDisableTiming) == hipSuccess; }
 	if (!ok || hipMalloc((void **)&c->d_next, sizeof(int) * kMaxJobs) != hipSuccess || hipMalloc((void **)&c->d_part, 8 * 3 * kBigPart) != hipSuccess || hipMalloc((void **)&c->d_scal, 8 * 16) != hipSuccess || hipMalloc((void **)&c->d_iscal, 4 * 8) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	{ const char *e = getenv("SRBA_HIP_BIG_MIN_SYS"); if (e && atoi(e) >= 0) c->big_min_sys = atoi(e); } // tuning / test knob
 	{ const char *e = getenv("SRBA_HIP_DENSE_BLOCKS"); if (e) c->dense_blocks_ok = atoi(e) != 0; }
@@ -1525,6 +1540,7 @@ static int lm_run_async_impl(srba_hip_ctx *c) {
 	for (size_t j = 0; j < c->plan.size(); j++) {
 		const LaunchJob &J = c->plan[j]; const int k = J.cls;
 		hipStream_t launch_stream = (J.queue && nq > 1) ? c->cls_stream[J.queue] : c->stream;
+		if (J.delay_us > 0) hipLaunchKernelGGL(srbadev::k_delay, dim3(1), dim3(1), 0, launch_stream, J.delay_us);
 		SRBA_DISPATCH_LDS(c, k_lm_run, J.grid, c->cls_lds[k] + c->lds_pad, J.first, J.count, c->d_next + j); HIPCHK(c, hipGetLastError());
 	}
 	// capsules too large for one wavefront's LDS: the multi-workgroup path, one capsule after the other on the context stream (host-driven LM loop: this part

@@ -4,7 +4,7 @@ R=$PWD; mkdir -p gpurun_out/calib; rm -rf gpurun_out/calib/*
 hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/calib/counter_calib.hip -o gpurun_out/calib/counter_calib 2> gpurun_out/calib/build.err || { cat gpurun_out/calib/build.err; exit 1; }
 gpurun_out/calib/counter_calib > gpurun_out/calib/plain.txt
 cd /tmp; export TMPDIR=/tmp
-for c in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_EA0_RD_UNCACHED_32B_sum TCC_EA0_RDREQ_DRAM_sum" "TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WR_UNCACHED_32B_sum" "TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum"; do
+for c in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_EA0_RD_UNCACHED_32B_sum TCC_EA0_RDREQ_DRAM_sum" "TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WR_UNCACHED_32B_sum" "TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum"; do
   tag=$(echo $c | tr ' ' '+')
   timeout 180 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/calib -o $tag -- $R/gpurun_out/calib/counter_calib > $R/gpurun_out/calib/$tag.out 2> $R/gpurun_out/calib/$tag.err || echo "pass $tag failed (rc $?)" >> $R/gpurun_out/calib/failed.txt
 done

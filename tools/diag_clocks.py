@@ -6,7 +6,7 @@ usage (GPU box): python tools/diag_clocks.py [n_kf] > gpurun_out/clock_trace.txt
 import ctypes as C, glob, os, subprocess, sys, threading, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16"); os.environ.setdefault("SRBA_HIP_CLASS_STREAMS", "10")   # context stream + 10 class streams + the probe stream: every stream gets its own hardware queue (a probe that shares a queue with a class launch would hold that launch back until it ends)
 from srba_amd import capi, datasets, runner
 n_kf = int(sys.argv[1]) if len(sys.argv) > 1 else 30000
 so = "/tmp/libclock_probe.so"
@@ -39,7 +39,7 @@ def sampler():
         samples.append(row)
 th = threading.Thread(target=sampler, daemon=True); th.start()
 # ---- schedule: idle 0.3 s | 12 launches back to back | 5 launches with 0.3 s pauses | 6 back to back
-N = 120000; assert probe.probe_start(N, 40) == 0
+N = 120000; assert probe.probe_start(N, 6) == 0   # ~25 us per sample -> 3 s of trace
 marks = []; t0 = time.perf_counter()
 def mark(name, ms=None): marks.append((time.perf_counter() - t0, name, ms))
 time.sleep(0.3); mark("start back-to-back")
