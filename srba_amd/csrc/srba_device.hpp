@@ -184,27 +184,6 @@ __device__ __forceinline__ double wave_max(double v) { // operands are >= 0 here
 // One wavefront per capsule: "block" reductions are wave reductions; every lane gets the same result.
 __device__ __forceinline__ double block_sum(double v, double *) { return wave_sum(v); }
 __device__ __forceinline__ double block_max(double v, double *) { return wave_max(v); }
-// ---- capsule GROUPS (round 4): the lanes that work on one capsule. G = 64: a whole wavefront (the kernels of rounds 1-3); G = 32: two capsules per wavefront, one per half
-// (k_lm_pair: the small, wave-slot-bound size classes, whose phase of the launch is bound by vector-instruction issue -- every instruction of the solver serves two capsules).
-template <int G> __device__ __forceinline__ int grp_lane() { if constexpr (G == 64) return (int)threadIdx.x; else return (int)(threadIdx.x & (G - 1)); }
-// hand-off of global / LDS data between the lanes of a group. G = 64 (one wavefront = the workgroup): the barrier the kernels always had. G = 32: the halves of a wavefront may be in
-// different branches, so no s_barrier: a workgroup-scope fence pair (waits for the wavefront's outstanding memory operations) around a wave barrier
-template <int G> __device__ __forceinline__ void grp_sync() {
-	if constexpr (G == 64) __syncthreads();
-	else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
-}
-__device__ __forceinline__ double readlane_k(double v, int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l)); }
-template <int G> __device__ __forceinline__ double grp_sum(double v) {
-	if constexpr (G == 64) return wave_sum(v);
-	else { // rows of 16 lanes, then row 1 += row 0 and row 3 += row 2: the totals of the halves sit in lanes 31 and 63
-		v += dpp_shift0<0x111, 0xf>(v); v += dpp_shift0<0x112, 0xf>(v); v += dpp_shift0<0x114, 0xf>(v); v += dpp_shift0<0x118, 0xf>(v); v += dpp_shift0<0x142, 0xa>(v);
-		const double lo = readlane_k(v, 31), hi = readlane_k(v, 63); return (threadIdx.x & 32) ? hi : lo; }
-}
-template <int G> __device__ __forceinline__ double grp_max(double v) { // operands >= 0
-	if constexpr (G == 64) return wave_max(v);
-	else { v = fmax(v, dpp_shift0<0x111, 0xf>(v)); v = fmax(v, dpp_shift0<0x112, 0xf>(v)); v = fmax(v, dpp_shift0<0x114, 0xf>(v)); v = fmax(v, dpp_shift0<0x118, 0xf>(v)); { const double t = dpp_shift0<0x142, 0xa>(v); v = fmax(v, t); }
-		const double lo = readlane_k(v, 31), hi = readlane_k(v, 63); return (threadIdx.x & 32) ? hi : lo; }
-}
 
 // ------------------------------------------------------------------------------------------------ full-pivot LU inverse (schur.h:200-206)
 // Every index below is a compile-time constant (the loops are fully unrolled and the pivot position acts through selects): the matrices stay in registers. With
@@ -321,11 +300,10 @@ __device__ __forceinline__ bool chol3(const double *D, Chol3 &c) { return chol3v
 // so a column with 4 panel blocks and 10 update items occupies 12 / 30 lanes instead of 4 / 10 and the dependent chain per lane is a third as
 // long; the instruction count per column drops to about half. The diagonal 3x3 Cholesky stays redundant in every lane (no broadcast).
 // Same arithmetic per scalar as the lane-per-block form (same operation order inside every dot product): results are bit-identical.
-template <int G = 64> __device__ __forceinline__ bool sp_factor_fsub_rows(const SparseSys &S) {
-	constexpr int NG = G / 3; // groups of three lanes (one per block row): 21 in a wavefront, 10 in a half
-	const int lane = grp_lane<G>(), nb = S.nb;
+__device__ __forceinline__ bool sp_factor_fsub_rows(const SparseSys &S) {
+	const int lane = threadIdx.x, nb = S.nb;
 	const int grp = (lane * 171) >> 9, sub = lane - 3 * grp; // lane / 3, lane % 3 for lane < 64
-	const bool worker = lane < 3 * NG;
+	const bool worker = lane < 63;
 	int cb = S.col_off[0], ce = nb > 0 ? S.col_off[1] : cb, ib = 0;
 	int ra = (worker && cb + grp < ce) ? S.row[cb + grp] : 0; // block-row of this lane's panel block in the coming column
 	for (int k = 0; k < nb; k++) {
@@ -348,17 +326,17 @@ template <int G = 64> __device__ __forceinline__ bool sp_factor_fsub_rows(const 
 			Arow[0] = x0; Arow[1] = x1; Arow[2] = x2;
 			*rr = rv - (x0 * y0 + x1 * y1 + x2 * y2);
 		}
-		if (worker) for (int p = grp + NG; p < cn; p += NG) { // columns with more blocks than groups
+		if (worker) for (int p = grp + 21; p < cn; p += 21) { // columns with more than 21 blocks
 			double *Ax = S.off + 9 * (cb + p) + 3 * sub; double *rx = S.rhs + 3 * S.row[cb + p] + sub;
 			const double x0 = Ax[0] * c.r0, x1 = (Ax[1] - x0 * c.l10) * c.r1, x2 = (Ax[2] - x0 * c.l20 - x1 * c.l21) * c.r2;
 			Ax[0] = x0; Ax[1] = x1; Ax[2] = x2; *rx -= x0 * y0 + x1 * y1 + x2 * y2;
 		}
-		if (lane == G - 1) { // L_kk, reciprocal diagonal in the unused upper part, y_k
+		if (lane == SRBA_WG - 1) { // L_kk, reciprocal diagonal in the unused upper part, y_k
 			D[0] = c.l00; D[3] = c.l10; D[4] = c.l11; D[6] = c.l20; D[7] = c.l21; D[8] = c.l22; D[1] = c.r0; D[2] = c.r1; D[5] = c.r2;
 			S.rhs[3 * k] = y0; S.rhs[3 * k + 1] = y1; S.rhs[3 * k + 2] = y2;
 		}
 		solver_sync();
-		if (worker) for (int t = grp; t < nitems; t += NG) { // trailing update, row `sub` of target -= L_ak L_bk^t
+		if (worker) for (int t = grp; t < nitems; t += 21) { // trailing update, row `sub` of target -= L_ak L_bk^t
 			const unsigned w = (unsigned)S.item[ib + t];
 			const double *La = S.off + 9 * (cb + ((w >> 9) & 511)) + 3 * sub, *Lb = S.off + 9 * (cb + (w & 511)); double *T = S.diag + 9 * (w >> 18) + 3 * sub;
 			const double la0 = La[0], la1 = La[1], la2 = La[2];
@@ -375,11 +353,10 @@ template <int G = 64> __device__ __forceinline__ bool sp_factor_fsub_rows(const 
 	}
 	return true;
 }
-template <int G = 64> __device__ __forceinline__ void sp_bsub_rows(const SparseSys &S) {
-	constexpr int NG = G / 3;
-	const int lane = grp_lane<G>(), nb = S.nb;
+__device__ __forceinline__ void sp_bsub_rows(const SparseSys &S) {
+	const int lane = threadIdx.x, nb = S.nb;
 	if (nb <= 0) return;
-	const int grp = (lane * 171) >> 9, sub = lane - 3 * grp; const bool worker = lane < 3 * NG;
+	const int grp = (lane * 171) >> 9, sub = lane - 3 * grp; const bool worker = lane < 63;
 	int re = S.rptr[nb], rb = S.rptr[nb - 1], rb_n = nb >= 2 ? S.rptr[nb - 2] : 0;
 	unsigned w = (worker && rb + grp < re) ? (unsigned)S.rent[rb + grp] : 0u; // col << 14 | off-diagonal block
 	for (int a = nb - 1; a >= 0; a--) {
@@ -392,11 +369,11 @@ template <int G = 64> __device__ __forceinline__ void sp_bsub_rows(const SparseS
 		const int rb_nn = a >= 2 ? S.rptr[a - 2] : 0;
 		const double x2 = r2 * d5, x1 = (r1 - d7 * x2) * d2, x0 = (r0 - d3 * x1 - d6 * x2) * d1;
 		if (act) *y = yv - (l0 * x0 + l1 * x1 + l2 * x2);
-		if (worker) for (int j = rb + grp + NG; j < re; j += NG) { // rows with more blocks than groups
+		if (worker) for (int j = rb + grp + 21; j < re; j += 21) { // rows with more than 21 blocks
 			const unsigned wx = (unsigned)S.rent[j]; const double *Lx = S.off + 9 * (wx & 0x3fff) + sub; double *yx = S.rhs + 3 * (wx >> 14) + sub;
 			*yx -= Lx[0] * x0 + Lx[3] * x1 + Lx[6] * x2;
 		}
-		if (lane == G - 1) { S.rhs[3 * a] = x0; S.rhs[3 * a + 1] = x1; S.rhs[3 * a + 2] = x2; }
+		if (lane == SRBA_WG - 1) { S.rhs[3 * a] = x0; S.rhs[3 * a + 1] = x1; S.rhs[3 * a + 2] = x2; }
 		solver_sync();
 		re = rb; rb = rb_n; rb_n = rb_nn; w = w_n;
 	}
@@ -605,16 +582,15 @@ __device__ __forceinline__ double *sp_elem(const SparseSys &S, int r, int c) {
 }
 
 // ------------------------------------------------------------------------------------------------ the per-problem worker
-template <int FAM, int G = 64>
+template <int FAM>
 struct Worker {
-	static constexpr int GRP = G; // lanes per capsule
 	typedef Tr<FAM> T; typedef PoseOps<T::SE3> PO; typedef typename PO::T pose_t;
 	static constexpr int P = T::P, L = T::L, O = T::O, PD = T::PD;
 	const Batch &B; const ProbDesc &d; const DevParams &prm; int tid;
 	// Re-materialise the lane id at the head of every phase: it stops the compiler from hoisting the per-lane address arithmetic of ALL
 	// phases out of the LM loop (which costs >100 VGPRs of loop-invariant addresses and halves the occupancy).
-	__device__ __forceinline__ void fresh() { int t = grp_lane<G>(); asm volatile("" : "+v"(t)); tid = t; }
-	__device__ Worker(const Batch &B_, const ProbDesc &d_, const DevParams &p_) : B(B_), d(d_), prm(p_), tid(grp_lane<G>()) {}
+	__device__ __forceinline__ void fresh() { int t = threadIdx.x; asm volatile("" : "+v"(t)); tid = t; }
+	__device__ Worker(const Batch &B_, const ProbDesc &d_, const DevParams &p_) : B(B_), d(d_), prm(p_), tid(threadIdx.x) {}
 
 	// A table index that widens to 64 bits for address arithmetic is made an opaque 64-bit value first. Why: clang 22 (ROCm 7.2) proves `idx >= 0` inside the guarded branch, drops the
 	// extension and, in the 400..512-VGPR landmark kernels, built the register pair v[N:N+1] of the widened index from the loaded dword and a register that had meanwhile been reused for
@@ -640,11 +616,11 @@ struct Worker {
 		if (only_needed && d.need_flat) { // in-loop refresh: one flat record per pair -> two dependent memory levels (record, edges) instead of four
 			// (two copies of the loop, LDS source / HBM source: with the choice inside, the compiler merges the last load of both into a flat_load on a selected pointer)
 			auto refresh = [&](auto from_lds) { constexpr bool FROM_LDS = decltype(from_lds)::value;
-			for (int q0 = tid; q0 < d.n_need; q0 += V * G) {
+			for (int q0 = tid; q0 < d.n_need; q0 += V * SRBA_WG) {
 				int p[V], pe[V][4]; pose_t acc[V];
 #pragma unroll
 				for (int v = 0; v < V; v++) {
-					const int q = q0 + v * G; const int *rec = B.need_rec + (d.o_pair + (q < d.n_need ? q : 0)) * 5;
+					const int q = q0 + v * SRBA_WG; const int *rec = B.need_rec + (d.o_pair + (q < d.n_need ? q : 0)) * 5;
 					p[v] = q < d.n_need ? rec[0] : -1;
 #pragma unroll
 					for (int u = 0; u < 4; u++) pe[v][u] = q < d.n_need ? rec[1 + u] : -1;
@@ -679,10 +655,10 @@ struct Worker {
 			return;
 		}
 		const int cnt = only_needed ? d.n_need : d.n_pairs;
-		for (int q0 = tid; q0 < cnt; q0 += V * G) {
+		for (int q0 = tid; q0 < cnt; q0 += V * SRBA_WG) {
 			int p[V], pe[V][U], b[V], e[V]; pose_t ed[V][U], acc[V];
 #pragma unroll
-			for (int v = 0; v < V; v++) { const int q = q0 + v * G; p[v] = q < cnt ? (only_needed ? B.need_idx[d.o_pair + q] : q) : -1; }
+			for (int v = 0; v < V; v++) { const int q = q0 + v * SRBA_WG; p[v] = q < cnt ? (only_needed ? B.need_idx[d.o_pair + q] : q) : -1; }
 #pragma unroll
 			for (int v = 0; v < V; v++) { b[v] = e[v] = 0; if (p[v] >= 0) { b[v] = B.pair_path_off[d.o_ppoff + p[v]]; e[v] = B.pair_path_off[d.o_ppoff + p[v] + 1]; } }
 #pragma unroll
@@ -819,8 +795,8 @@ struct Worker {
 	}
 	__device__ __forceinline__ double phase_residuals(double *out, double *red) { fresh();
 		double acc = 0;
-		for (int i = tid; i < d.n_obs; i += 2 * G) { // two rows per lane and pass: both rows' loads are issued before either row's stores
-			double r0[O], r1[O]; const int j = i + G; const bool two = j < d.n_obs;
+		for (int i = tid; i < d.n_obs; i += 2 * SRBA_WG) { // two rows per lane and pass: both rows' loads are issued before either row's stores
+			double r0[O], r1[O]; const int j = i + SRBA_WG; const bool two = j < d.n_obs;
 			const double c0 = residual_row(i, r0); double c1 = 0; if (two) c1 = residual_row(j, r1);
 #pragma unroll
 			for (int k = 0; k < O; k++) out[(long long)(d.o_obs + i) * O + k] = r0[k];
@@ -830,7 +806,7 @@ struct Worker {
 			}
 			acc += c0; if (two) acc += c1;
 		}
-		return grp_sum<G>(acc);
+		return block_sum(acc, red);
 	}
 
 	// ---- K2
@@ -896,17 +872,17 @@ struct Worker {
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
 				const double v0 = i < 3 ? D.R[i] : D.t[0], v1 = i < 3 ? D.R[3 + i] : D.t[1], v2 = i < 3 ? D.R[6 + i] : D.t[2];
-				const double sk[9] = {0, -v2, v1, v2, 0, -v0, -v1, v0, 0}; double Gm[9];
+				const double sk[9] = {0, -v2, v1, v2, 0, -v0, -v1, v0, 0}; double G[9];
 #pragma unroll
 				for (int r = 0; r < 3; r++)
 #pragma unroll
-					for (int q = 0; q < 3; q++) Gm[3 * r + q] = -(RA[3 * r] * sk[q] + RA[3 * r + 1] * sk[3 + q] + RA[3 * r + 2] * sk[6 + q]);
+					for (int q = 0; q < 3; q++) G[3 * r + q] = -(RA[3 * r] * sk[q] + RA[3 * r + 1] * sk[3 + q] + RA[3 * r + 2] * sk[6 + q]);
 				if (i < 3) {
 #pragma unroll
 					for (int m = 0; m < 3; m++)
 #pragma unroll
-						for (int q = 0; q < 3; q++) Jr[3 * m + q] += M[9 * m + 3 * i] * Gm[q] + M[9 * m + 3 * i + 1] * Gm[3 + q] + M[9 * m + 3 * i + 2] * Gm[6 + q];
-				} else for (int k = 0; k < 9; k++) Gt[k] = Gm[k];
+						for (int q = 0; q < 3; q++) Jr[3 * m + q] += M[9 * m + 3 * i] * G[q] + M[9 * m + 3 * i + 1] * G[3 + q] + M[9 * m + 3 * i + 2] * G[6 + q];
+				} else for (int k = 0; k < 9; k++) Gt[k] = G[k];
 			}
 			const double sg = normal ? 1.0 : -1.0;
 #pragma unroll
@@ -982,22 +958,22 @@ struct Worker {
 	}
 	// Jacobians of all blocks + validity semantics of jacobians.h:215-216,321-327 (see DESIGN.md "invalid rows")
 	__device__ __forceinline__ void phase_jacobians() { fresh();
-		for (int i = tid; i < d.n_valid; i += G) { B.valid[d.o_valid + i] = 1; B.first_fail[d.o_valid + i] = 0x7fffffff; }
-		grp_sync<G>();
-		for (int b = tid; b < d.n_bp; b += G) jac_dh_dp(b);
-		for (int b = tid; b < d.n_bf; b += G) jac_dh_df(b);
-		grp_sync<G>();
-		for (int i = tid; i < d.n_valid; i += G) if (B.first_fail[d.o_valid + i] != 0x7fffffff) B.valid[d.o_valid + i] = 0;
+		for (int i = tid; i < d.n_valid; i += SRBA_WG) { B.valid[d.o_valid + i] = 1; B.first_fail[d.o_valid + i] = 0x7fffffff; }
+		__syncthreads();
+		for (int b = tid; b < d.n_bp; b += SRBA_WG) jac_dh_dp(b);
+		for (int b = tid; b < d.n_bf; b += SRBA_WG) jac_dh_df(b);
+		__syncthreads();
+		for (int i = tid; i < d.n_valid; i += SRBA_WG) if (B.first_fail[d.o_valid + i] != 0x7fffffff) B.valid[d.o_valid + i] = 0;
 		// the first failing block of a row (in sweep order) is zeroed; later ones keep stale values
-		for (int b = tid; b < d.n_bp; b += G) {
+		for (int b = tid; b < d.n_bp; b += SRBA_WG) {
 			const int ff = B.first_fail[d.o_valid + B.obs_valid[d.o_obs + B.bp_res[d.o_bp + b]]]; B.bp_ok[d.o_bp + b] = (ff == 0x7fffffff);
 			if (ff == b) { double *J = B.Jp + (long long)(d.o_bp + b) * O * P; for (int k = 0; k < O * P; k++) J[k] = 0; }
 		}
-		for (int b = tid; b < d.n_bf; b += G) {
+		for (int b = tid; b < d.n_bf; b += SRBA_WG) {
 			const int ff = B.first_fail[d.o_valid + B.obs_valid[d.o_obs + B.bf_res[d.o_bf + b]]]; B.bf_ok[d.o_bf + b] = (ff == 0x7fffffff);
 			if (ff == d.n_bp + b) { double *J = B.Jf + (long long)(d.o_bf + b) * O * L; for (int k = 0; k < O * L; k++) J[k] = 0; }
 		}
-		grp_sync<G>();
+		__syncthreads();
 	}
 
 	// ---- K6: H_ij = sum J1^t Lambda J2
@@ -1052,15 +1028,15 @@ struct Worker {
 		const double *Jp = B.Jp + d.o_bp * O * P, *Jf = B.Jf + d.o_bf * O * L;
 		const unsigned char *rp = B.bp_ok + d.o_bp, *rf = B.bf_ok + d.o_bf;
 		const bool latch = prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL;
-		for (int bi = tid; bi < d.n_hap; bi += G) {
+		for (int bi = tid; bi < d.n_hap; bi += SRBA_WG) {
 			const int *rec = B.hap_rec + (d.o_hap + bi) * 3; const int b = rec[0]; const long long g = d.o_hap + b; // {block, first term, end term}: longest lists first
 			// the Schur complement works on HAp in place and restores it from the latch for every lambda (schur.h:38,165-168,188)
 			ninv += hess_block<P, P>(B.HAp + g * P * P, latch ? B.HAp0 + g * P * P : nullptr, B.hap_t1 + d.o_hapt, B.hap_t2 + d.o_hapt, rec[1], rec[2], Jp, Jp, rp, rp);
 		}
 		if constexpr (!T::REL) {
-			for (int b = tid; b < d.n_hf; b += G)
+			for (int b = tid; b < d.n_hf; b += SRBA_WG)
 				ninv += hess_block<L, L>(B.Hf + (d.o_hf + b) * L * L, nullptr, B.hf_t1 + d.o_hft, B.hf_t2 + d.o_hft, B.hf_term_off[d.o_hfoff + b], B.hf_term_off[d.o_hfoff + b + 1], Jf, Jf, rf, rf);
-			for (int b = tid; b < d.n_hapf; b += G)
+			for (int b = tid; b < d.n_hapf; b += SRBA_WG)
 				ninv += hess_block<P, L>(B.HApf + (d.o_hapf + b) * P * L, nullptr, B.hapf_t1 + d.o_hapft, B.hapf_t2 + d.o_hapft, B.hapf_term_off[d.o_hapfoff + b], B.hapf_term_off[d.o_hapfoff + b + 1], Jp, Jf, rp, rf);
 		}
 		return ninv;
@@ -1073,11 +1049,11 @@ struct Worker {
 	// acc: n_hap * P * P doubles of LDS. Returns the per-lane count of skipped terms.
 	__device__ __forceinline__ int phase_hessian_terms(double *acc) { fresh();
 		const int n_acc = d.n_hap * P * P, n_terms = B.hap_term_off[d.o_hapoff + d.n_hap];
-		for (int k = tid; k < n_acc; k += G) acc[k] = 0;
+		for (int k = tid; k < n_acc; k += SRBA_WG) acc[k] = 0;
 		solver_sync();
 		const double *Jp = B.Jp + d.o_bp * O * P; const unsigned char *rp = B.bp_ok + d.o_bp; const int *t1 = B.hap_t1 + d.o_hapt, *t2 = B.hap_t2 + d.o_hapt, *tb = B.hap_tblk + d.o_hapt;
 		int ninv = 0;
-		for (int t = tid; t < n_terms; t += G) {
+		for (int t = tid; t < n_terms; t += SRBA_WG) {
 			const int b1 = t1[t], b2 = t2[t], blk = tb[t];
 			double A[O * P], Bm[O * P]; ldn<O * P>(A, Jp + (long long)b1 * O * P); ldn<O * P>(Bm, Jp + (long long)b2 * O * P);
 			if (rp[b1] && rp[b2]) {
@@ -1093,7 +1069,7 @@ struct Worker {
 		solver_sync();
 		const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0; const bool latch = prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL;
 		double *Hg = B.HAp + d.o_hap * P * P, *H0 = B.HAp0 + d.o_hap * P * P;
-		for (int k = 2 * tid; k < n_acc; k += 2 * G) { // n_acc is a multiple of 9 or 36; an odd tail is a single double
+		for (int k = 2 * tid; k < n_acc; k += 2 * SRBA_WG) { // n_acc is a multiple of 9 or 36; an odd tail is a single double
 			if (k + 1 < n_acc) { f64x2u v; v.x = acc[k] * sc; v.y = acc[k + 1] * sc; *(f64x2u *)(Hg + k) = v; if (latch) *(f64x2u *)(H0 + k) = v; }
 			else { const double v = acc[k] * sc; Hg[k] = v; if (latch) H0[k] = v; }
 		}
@@ -1104,9 +1080,9 @@ struct Worker {
 		int ninv = 0;
 		if constexpr (!T::REL) {
 			const double *Jp = B.Jp + d.o_bp * O * P, *Jf = B.Jf + d.o_bf * O * L; const unsigned char *rp = B.bp_ok + d.o_bp, *rf = B.bf_ok + d.o_bf;
-			for (int b = tid; b < d.n_hf; b += G)
+			for (int b = tid; b < d.n_hf; b += SRBA_WG)
 				ninv += hess_block<L, L>(B.Hf + (d.o_hf + b) * L * L, nullptr, B.hf_t1 + d.o_hft, B.hf_t2 + d.o_hft, B.hf_term_off[d.o_hfoff + b], B.hf_term_off[d.o_hfoff + b + 1], Jf, Jf, rf, rf);
-			for (int b = tid; b < d.n_hapf; b += G)
+			for (int b = tid; b < d.n_hapf; b += SRBA_WG)
 				ninv += hess_block<P, L>(B.HApf + (d.o_hapf + b) * P * L, nullptr, B.hapf_t1 + d.o_hapft, B.hapf_t2 + d.o_hapft, B.hapf_term_off[d.o_hapfoff + b], B.hapf_term_off[d.o_hapfoff + b + 1], Jp, Jf, rp, rf);
 		}
 		return ninv;
@@ -1118,8 +1094,8 @@ struct Worker {
 	__device__ __forceinline__ void grad_cols(double *g, int ncol, const double *J, const int *res, const int *col_off, const double *resid) {
 		// lanes per column: 8 while a single pass covers all columns, else 4 -- ceil(4*ncol/64) quarter-length passes beat ceil(ncol/64) full-length ones
 		// whenever ncol is not a multiple of 64 (67 columns: 1.25 instead of 2 column-times)
-		const int S = 8 * ncol <= G ? 8 : 4;
-		const int per = G / S, sub = tid % S;
+		const int S = 8 * ncol <= SRBA_WG ? 8 : 4;
+		const int per = SRBA_WG / S, sub = tid % S;
 		const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0;
 		for (int base = 0; base < ncol; base += per) {
 			const int i = base + tid / S; const bool live = i < ncol;
@@ -1169,9 +1145,9 @@ struct Worker {
 	}
 	__device__ __forceinline__ double lambda_guess(double *red) { fresh(); // optimize_edges.h:366-390
 		double mx = 0;
-		for (int i = tid; i < d.nK; i += G) { const double *H = B.HAp + (d.o_hap + B.hap_diag[d.o_unk + i]) * P * P; double m = H[0]; for (int k = 1; k < P; k++) m = fmax(m, H[k * P + k]); mx = fmax(mx, m); }
-		if constexpr (!T::REL) for (int i = tid; i < d.nF; i += G) { const double *H = B.Hf + (d.o_hf + B.hf_diag[d.o_ulm + i]) * L * L; double m = H[0]; for (int k = 1; k < L; k++) m = fmax(m, H[k * L + k]); mx = fmax(mx, m); }
-		return 1e-3 * grp_max<G>(mx);
+		for (int i = tid; i < d.nK; i += SRBA_WG) { const double *H = B.HAp + (d.o_hap + B.hap_diag[d.o_unk + i]) * P * P; double m = H[0]; for (int k = 1; k < P; k++) m = fmax(m, H[k * P + k]); mx = fmax(mx, m); }
+		if constexpr (!T::REL) for (int i = tid; i < d.nF; i += SRBA_WG) { const double *H = B.Hf + (d.o_hf + B.hf_diag[d.o_ulm + i]) * L * L; double m = H[0]; for (int k = 1; k < L; k++) m = fmax(m, H[k * L + k]); mx = fmax(mx, m); }
+		return 1e-3 * block_max(mx, red);
 	}
 };
 

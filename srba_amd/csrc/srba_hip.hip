@@ -35,9 +35,9 @@ extern __shared__ double srba_lds[]; // block-sparse system of the capsule (diag
 // (LDS operands are addressed from this symbol where it matters: a pointer that went through SparseSys -- whose numbers may live in HBM -- is a generic pointer, and
 //  its loads become flat_load instead of ds_read)
 
-template <int FAM, int G = 64>
-struct Solver : public Worker<FAM, G> {
-	typedef Worker<FAM, G> W; using W::B; using W::d; using W::prm; using W::tid;
+template <int FAM>
+struct Solver : public Worker<FAM> {
+	typedef Worker<FAM> W; using W::B; using W::d; using W::prm; using W::tid;
 	static constexpr int P = W::P, L = W::L, O = W::O, PD = W::PD;
 	__device__ Solver(const Batch &B_, const ProbDesc &d_, const DevParams &p_) : W(B_, d_, p_) {}
 	__device__ __forceinline__ bool schur_active() const { return prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0; }
@@ -45,7 +45,7 @@ struct Solver : public Worker<FAM, G> {
 	// K7 + K8 (schur.h:180-268). Mutates HAp and minus_grad in place like the reference.
 	__device__ __forceinline__ void schur_reduce(double lambda, long long *pc = nullptr) { this->fresh(); long long tq = pc ? wall_clock64() : 0;
 		if constexpr (!W::T::REL) {
-			for (int l = tid; l < d.nF; l += G) {
+			for (int l = tid; l < d.nF; l += SRBA_WG) {
 				double M[L * L], Mi[L * L]; const double *src = B.Hf + (d.o_hf + B.hf_diag[d.o_ulm + l]) * L * L;
 				for (int k = 0; k < L * L; k++) M[k] = src[k];
 				for (int k = 0; k < L; k++) M[k * L + k] += lambda;
@@ -53,8 +53,8 @@ struct Solver : public Worker<FAM, G> {
 				B.hf_ok[d.o_ulm + l] = ok ? 1 : 0;
 				if (ok) for (int k = 0; k < L * L; k++) B.Hfinv[(d.o_ulm + l) * L * L + k] = Mi[k];
 			}
-			for (int k = tid; k < d.n_hap * P * P; k += G) B.HAp[d.o_hap * P * P + k] = B.HAp0[d.o_hap * P * P + k];
-			grp_sync<G>();
+			for (int k = tid; k < d.n_hap * P * P; k += SRBA_WG) B.HAp[d.o_hap * P * P + k] = B.HAp0[d.o_hap * P * P + k];
+			__syncthreads();
 			if (pc) { if (tid == 0) pc[14] += wall_clock64() - tq; tq = wall_clock64(); }
 			// Balanced over the lanes: the flat term list of the capsule (sorted by U_Ap block) is cut into 64 equal runs, one per lane. A lane keeps the running block in
 			// registers and adds it to HBM when its run moves on to the next block (a block cut by a run boundary receives two or three such additions: atomics), so the
@@ -62,7 +62,7 @@ struct Solver : public Worker<FAM, G> {
 			// carry the gradient correction g_i -= Y_t g_l (K8), which used to be a third sweep over Y stored in HBM by this one.
 			double *g = B.grad + d.o_scal; const double *gf = g + d.nK * P;
 			{
-				const int T = B.sch_term_off[d.o_hapoff + d.n_hap], per = (T + G - 1) / G, tb = tid * per, te = min(T, tb + per);
+				const int T = B.sch_term_off[d.o_hapoff + d.n_hap], per = (T + SRBA_WG - 1) / SRBA_WG, tb = tid * per, te = min(T, tb + per);
 				const int *s_lm = B.sch_lm + d.o_sch, *s_b1 = B.sch_b1 + d.o_sch, *s_b2 = B.sch_b2 + d.o_sch, *s_yw = B.sch_yw + d.o_sch, *s_blk = B.sch_tblk + d.o_sch;
 				int cur = -1; bool curdiag = false; double Hl[P * P], ga[P];
 				auto flush = [&]() {
@@ -116,7 +116,7 @@ struct Solver : public Worker<FAM, G> {
 				}
 				flush();
 			}
-			grp_sync<G>();
+			__syncthreads();
 			if (pc) { if (tid == 0) pc[15] += wall_clock64() - tq; }
 		}
 	}
@@ -124,7 +124,7 @@ struct Solver : public Worker<FAM, G> {
 	__device__ __forceinline__ void schur_features() { this->fresh();
 		if constexpr (!W::T::REL) {
 			double *g = B.grad + d.o_scal, *dl = B.delta + d.o_scal;
-			for (int l = tid; l < d.nF; l += G) {
+			for (int l = tid; l < d.nF; l += SRBA_WG) {
 				if (!B.hf_ok[d.o_ulm + l]) continue;
 				double gl[L]; for (int k = 0; k < L; k++) gl[k] = g[d.nK * P + l * L + k];
 				for (int q = B.lm_hapf_off[d.o_lmoff + l]; q < B.lm_hapf_off[d.o_lmoff + l + 1]; q++) {
@@ -136,7 +136,7 @@ struct Solver : public Worker<FAM, G> {
 				for (int k = 0; k < L; k++) g[d.nK * P + l * L + k] = gl[k];
 				for (int r = 0; r < L; r++) { double s = 0; for (int k = 0; k < L; k++) s += Hi[r * L + k] * gl[k]; dl[d.nK * P + l * L + r] = s; }
 			}
-			grp_sync<G>();
+			__syncthreads();
 		}
 	}
 	// (H + lambda I) scattered into the block-sparse storage + right-hand side (lev-marq_solvers.h:88-150 / :303-325 / :492-519)
@@ -179,19 +179,19 @@ struct Solver : public Worker<FAM, G> {
 	__device__ __forceinline__ void assemble(const SparseSys &S, double lambda) { this->fresh();
 		const int n = d.n_sys, nb = d.nb;
 		if (d.aligned) { // every block is overwritten whole by put_block below, except the fill-in blocks (listed by the host): zero only those
-			for (int i = tid; i < d.n_fill; i += G) { double *o = S.diag + 9 * B.sp_fill[d.o_spfill + i];
+			for (int i = tid; i < d.n_fill; i += SRBA_WG) { double *o = S.diag + 9 * B.sp_fill[d.o_spfill + i];
 #pragma unroll
 				for (int q = 0; q < 9; q++) o[q] = 0; }
 		} else {
-			for (int k = tid; k < 9 * nb; k += G) S.diag[k] = 0;
-			for (int k = tid; k < 9 * S.nnzoff; k += G) S.off[k] = 0;
+			for (int k = tid; k < 9 * nb; k += SRBA_WG) S.diag[k] = 0;
+			for (int k = tid; k < 9 * S.nnzoff; k += SRBA_WG) S.off[k] = 0;
 		}
 		const double *g = B.grad + d.o_scal;
-		for (int k = tid; k < 3 * nb; k += G) S.rhs[3 * S.perm[k / 3] + k % 3] = (k < n) ? g[k] : 0.0;
-		grp_sync<G>();
+		for (int k = tid; k < 3 * nb; k += SRBA_WG) S.rhs[3 * S.perm[k / 3] + k % 3] = (k < n) ? g[k] : 0.0;
+		__syncthreads();
 		constexpr int PB = P / 3;
 		// one lane per aligned 3x3 sub-block: its 9 loads are in flight together (one memory round trip per pass instead of one per element)
-		for (int sb = tid; sb < d.n_hap * PB * PB; sb += G) {
+		for (int sb = tid; sb < d.n_hap * PB * PB; sb += SRBA_WG) {
 			const int dst = B.hap_dst[d.o_hap * PB * PB + sb]; if (dst == (int)0x80000000) continue;
 			const int b = sb / (PB * PB), si = (sb / PB) % PB, sj = sb % PB;
 			put_block<P>(S, dst, B.HAp + (d.o_hap + b) * P * P + si * 3 * P + sj * 3, lambda);
@@ -200,57 +200,56 @@ struct Solver : public Worker<FAM, G> {
 			const int base = P * d.nK;
 			if (d.aligned) {
 				if constexpr (L == 3) {
-					for (int sb = tid; sb < d.n_hapf * PB; sb += G) {
+					for (int sb = tid; sb < d.n_hapf * PB; sb += SRBA_WG) {
 						const int dst = B.hapf_dst[d.o_hapf * PB + sb]; if (dst == (int)0x80000000) continue;
 						put_block<L>(S, dst, B.HApf + (d.o_hapf + sb / PB) * P * L + (sb % PB) * 3 * L, 0.0);
 					}
-					for (int b = tid; b < d.n_hf; b += G) {
+					for (int b = tid; b < d.n_hf; b += SRBA_WG) {
 						const int dst = B.hf_dst[d.o_hf + b]; if (dst == (int)0x80000000) continue;
 						put_block<L>(S, dst, B.Hf + (d.o_hf + b) * L * L, lambda);
 					}
 				}
 			} else { // landmark blocks straddle 3x3 block boundaries (L == 2): generic per-element placement
-				for (int e = tid; e < d.n_hapf * P * L; e += G) {
+				for (int e = tid; e < d.n_hapf * P * L; e += SRBA_WG) {
 					const int b = e / (P * L), r = (e / L) % P, q = e % L;
 					put(S, P * B.hapf_i[d.o_hapf + b] + r, base + L * B.hapf_j[d.o_hapf + b] + q, B.HApf[(d.o_hapf + b) * P * L + r * L + q]);
 				}
-				for (int e = tid; e < d.n_hf * L * L; e += G) {
+				for (int e = tid; e < d.n_hf * L * L; e += SRBA_WG) {
 					const int b = e / (L * L), r = (e / L) % L, q = e % L; const int i = B.hf_i[d.o_hf + b], j = B.hf_j[d.o_hf + b];
 					if (i == j && r > q) continue;
 					put(S, base + L * i + r, base + L * j + q, B.Hf[(d.o_hf + b) * L * L + r * L + q] + ((i == j && r == q) ? lambda : 0.0));
 				}
 			}
 		}
-		for (int k = n + tid; k < 3 * nb; k += G) S.diag[9 * S.perm[k / 3] + 4 * (k % 3)] = 1.0; // identity padding
-		grp_sync<G>();
+		for (int k = n + tid; k < 3 * nb; k += SRBA_WG) S.diag[9 * S.perm[k / 3] + 4 * (k % 3)] = 1.0; // identity padding
+		__syncthreads();
 	}
 	// solve(lambda): returns false if not positive definite (uniform across the wavefront)
 	__device__ __forceinline__ bool solve(const SparseSys &S, double lambda, long long *pc = nullptr) {
 		long long t0 = 0;
-#define STIC() do { if (pc) { grp_sync<G>(); t0 = wall_clock64(); } } while (0)
-#define STOC(slot) do { if (pc) { grp_sync<G>(); if (tid == 0) pc[slot] += wall_clock64() - t0; } } while (0)
+#define STIC() do { if (pc) { __syncthreads(); t0 = wall_clock64(); } } while (0)
+#define STOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - t0; } } while (0)
 		if (schur_active() && (prm.ext & SRBA_EXT_SCHUR_KEEPS_GRADIENT)) { // (extension, default off) every solve starts from the gradient K5 produced: same lane -> same elements as keep_gradient()
-			double *g = B.grad + d.o_scal; const double *g0 = B.grad0 + d.o_scal; for (int k = tid; k < d.n_scal; k += G) g[k] = g0[k]; grp_sync<G>(); }
+			double *g = B.grad + d.o_scal; const double *g0 = B.grad0 + d.o_scal; for (int k = tid; k < d.n_scal; k += SRBA_WG) g[k] = g0[k]; __syncthreads(); }
 		STIC(); if (schur_active()) schur_reduce(lambda, pc); STOC(9);
 		STIC(); assemble(S, lambda); STOC(10);
 		// (the dense block layouts are never chosen for the relative-pose families -- srba_hip_upload_problems -- whose kernels therefore carry the sparse solver only: the
 		//  headline kernel sits 22 VGPRs below the two-wavefronts-per-SIMD limit)
-		STIC(); bool ok; if constexpr (W::T::REL || !W::T::SE3) ok = sp_factor_fsub_rows<G>(S); else ok = d.dense_blocks == 2 ? (S.row_lds ? sp_factor_fsub_dense_left(S, (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16), (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16 + 18 * S.nb)) : sp_factor_fsub_dense<true>(S)) : (S.dense ? sp_factor_fsub_dense<false>(S) : sp_factor_fsub_rows(S)); STOC(11);
+		STIC(); bool ok; if constexpr (W::T::REL || !W::T::SE3) ok = sp_factor_fsub_rows(S); else ok = d.dense_blocks == 2 ? (S.row_lds ? sp_factor_fsub_dense_left(S, (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16), (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16 + 18 * S.nb)) : sp_factor_fsub_dense<true>(S)) : (S.dense ? sp_factor_fsub_dense<false>(S) : sp_factor_fsub_rows(S)); STOC(11);
 		if (!ok) return false;
-		STIC(); if constexpr (W::T::REL || !W::T::SE3) sp_bsub_rows<G>(S); else { if (d.dense_blocks == 2) { if (S.row_lds) sp_bsub_dense_left(S, (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16 + 18 * S.nb)); else sp_bsub_dense<true>(S); } else if (S.dense) sp_bsub_dense<false>(S); else sp_bsub_rows(S); }
+		STIC(); if constexpr (W::T::REL || !W::T::SE3) sp_bsub_rows(S); else { if (d.dense_blocks == 2) { if (S.row_lds) sp_bsub_dense_left(S, (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16 + 18 * S.nb)); else sp_bsub_dense<true>(S); } else if (S.dense) sp_bsub_dense<false>(S); else sp_bsub_rows(S); }
 		double *dl = B.delta + d.o_scal;
-		for (int k = tid; k < d.n_scal; k += G) dl[k] = (k < d.n_sys) ? S.rhs[3 * S.perm[k / 3] + k % 3] : 0.0;
-		grp_sync<G>(); STOC(12);
+		for (int k = tid; k < d.n_scal; k += SRBA_WG) dl[k] = (k < d.n_sys) ? S.rhs[3 * S.perm[k / 3] + k % 3] : 0.0;
+		__syncthreads(); STOC(12);
 		STIC(); if (schur_active()) schur_features(); STOC(13);
 		return true;
 #undef STIC
 #undef STOC
 	}
 	__device__ __forceinline__ void keep_gradient() { // call after phase_gradient + barrier
-		if (schur_active() && (prm.ext & SRBA_EXT_SCHUR_KEEPS_GRADIENT)) { const double *g = B.grad + d.o_scal; double *g0 = B.grad0 + d.o_scal; for (int k = tid; k < d.n_scal; k += G) g0[k] = g[k]; }
+		if (schur_active() && (prm.ext & SRBA_EXT_SCHUR_KEEPS_GRADIENT)) { const double *g = B.grad + d.o_scal; double *g0 = B.grad0 + d.o_scal; for (int k = tid; k < d.n_scal; k += SRBA_WG) g0[k] = g[k]; }
 	}
-	// fill = false: only the pointers (the image and its symbolic copy are in place: k_lm_pair re-derives the view in every pass of its loop instead of keeping fourteen per-lane pointers alive)
-	__device__ __forceinline__ SparseSys make_sys(double *lds, bool fill = true) const {
+	__device__ __forceinline__ SparseSys make_sys(double *lds) const {
 		SparseSys S; S.nb = d.nb; S.nnzoff = d.nnzoff; S.dense = (W::T::REL || !W::T::SE3) ? 0 : d.dense_blocks;
 		S.row_lds = (S.dense == 2 && B.dense_left && d.nb <= 168) ? lds + (d.nb + 1) / 2 + 16 : nullptr; // HBM-resident layout, left-looking sweeps: 21 nb doubles of LDS after the permutation (two rows of the factor | y)
 		S.col_off = B.sp_col_off + d.o_spcol; S.row = B.sp_row + d.o_sprow; S.item = B.sp_tgt + d.o_spitem; S.item_ab = B.sp_ab + d.o_spitem; S.perm = B.sp_perm + d.o_spperm;
@@ -259,19 +258,17 @@ struct Solver : public Worker<FAM, G> {
 		S.diag = base; S.off = base + 9 * d.nb; S.rhs = S.off + 9 * d.nnzoff;
 		if (S.dense) { // numbers only: every index of the dense block layout is arithmetic; the block permutation is the one table kept
 			int *p0 = d.dense_blocks == 2 ? (int *)lds : (int *)(S.rhs + 3 * d.nb);
-			if (fill) for (int k = tid; k < d.nb; k += G) p0[k] = S.perm[k];
+			for (int k = tid; k < d.nb; k += SRBA_WG) p0[k] = S.perm[k];
 			S.perm = p0; S.col_off = S.row = S.item = S.rptr = S.rent = nullptr;
-			if (fill) grp_sync<G>();
+			__syncthreads();
 		} else { // symbolic structure next to the numbers (packed): the factorisation's dependent index loads hit LDS, not L2
 			int *ip = (int *)(S.rhs + 3 * d.nb); int *c0 = ip, *rp0 = c0 + d.nb + 1, *p0 = rp0 + d.nb + 1, *r0 = p0 + d.nb, *re0 = r0 + d.nnzoff, *t0 = re0 + d.nnzoff;
-			if (fill) {
-			for (int k = tid; k <= d.nb; k += G) { c0[k] = S.col_off[k]; rp0[k] = S.rptr[k]; }
-			for (int k = tid; k < d.nb; k += G) p0[k] = S.perm[k];
-			for (int k = tid; k < d.nnzoff; k += G) { r0[k] = S.row[k]; re0[k] = (S.rent[k] << 14) | S.rent_blk[k]; }
-			for (int k = tid; k < d.n_items; k += G) { const int tg = S.item[k], ab = S.item_ab[k]; t0[k] = ((tg >= 0 ? d.nb + tg : -1 - tg) << 18) | ((ab >> 16) << 9) | (ab & 0xffff); }
-			}
+			for (int k = tid; k <= d.nb; k += SRBA_WG) { c0[k] = S.col_off[k]; rp0[k] = S.rptr[k]; }
+			for (int k = tid; k < d.nb; k += SRBA_WG) p0[k] = S.perm[k];
+			for (int k = tid; k < d.nnzoff; k += SRBA_WG) { r0[k] = S.row[k]; re0[k] = (S.rent[k] << 14) | S.rent_blk[k]; }
+			for (int k = tid; k < d.n_items; k += SRBA_WG) { const int tg = S.item[k], ab = S.item_ab[k]; t0[k] = ((tg >= 0 ? d.nb + tg : -1 - tg) << 18) | ((ab >> 16) << 9) | (ab & 0xffff); }
 			S.col_off = c0; S.rptr = rp0; S.perm = p0; S.row = r0; S.rent = re0; S.item = t0;
-			if (fill) grp_sync<G>();
+			__syncthreads();
 		}
 		return S;
 	}
@@ -280,15 +277,15 @@ struct Solver : public Worker<FAM, G> {
 	__device__ __forceinline__ void apply_update() { this->fresh();
 		typedef typename W::PO PO;
 		const double *dl = B.delta + d.o_scal;
-		for (int i = tid; i < d.nK; i += G) {
+		for (int i = tid; i < d.nK; i += SRBA_WG) {
 			double *e = B.edge + (d.o_edge + i) * PD, *o = B.old_edge + (d.o_unk + i) * PD;
 			for (int k = 0; k < PD; k++) o[k] = e[k];
 			const typename W::pose_t np = comp(PO::expm(dl + i * P), PO::ld(e));
 			PO::st(e, np);
 		}
-		for (int k = tid; k < d.nF * L; k += G) { B.old_ulm[d.o_ulm * L + k] = B.ulm[d.o_ulm * L + k]; B.ulm[d.o_ulm * L + k] += dl[d.nK * P + k]; }
-		for (int r = tid; r < d.n_req; r += 2 * G) { // two poses per lane and pass: both loads before the stores
-			const int r2 = r + G; const bool two = r2 < d.n_req;
+		for (int k = tid; k < d.nF * L; k += SRBA_WG) { B.old_ulm[d.o_ulm * L + k] = B.ulm[d.o_ulm * L + k]; B.ulm[d.o_ulm * L + k] += dl[d.nK * P + k]; }
+		for (int r = tid; r < d.n_req; r += 2 * SRBA_WG) { // two poses per lane and pass: both loads before the stores
+			const int r2 = r + SRBA_WG; const bool two = r2 < d.n_req;
 			const double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD, *s2 = two ? B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r2]) * PD : s;
 			double v[PD], v2[PD];
 #pragma unroll
@@ -301,7 +298,7 @@ struct Solver : public Worker<FAM, G> {
 				for (int k = 0; k < PD; k++) o2[k] = v2[k];
 			}
 		}
-		grp_sync<G>();
+		__syncthreads();
 	}
 	// K12 + K11 with the increment of the edges taken straight from the solved right-hand side in LDS (no round trip through B.delta) and, when it fits, a copy of
 	// ALL edge poses of the capsule left in the (now idle) off-diagonal area of the LDS image for the spanning-tree refresh that follows. Returns that copy or nullptr.
@@ -309,7 +306,7 @@ struct Solver : public Worker<FAM, G> {
 		typedef typename W::PO PO; typedef typename W::pose_t pose_t;
 		const double *dl = B.delta + d.o_scal;
 		const bool stage = d.dense_in_lds && d.n_edges * PD <= 9 * S.nnzoff; double *el = S.off;
-		for (int i = tid; i < (stage ? d.n_edges : d.nK); i += G) {
+		for (int i = tid; i < (stage ? d.n_edges : d.nK); i += SRBA_WG) {
 			double *e = B.edge + (d.o_edge + i) * PD; pose_t cur = PO::ld(e);
 			if (i < d.nK) {
 				double inc[P];
@@ -323,9 +320,9 @@ struct Solver : public Worker<FAM, G> {
 #pragma unroll
 				for (int k = 0; k < PD; k++) el[i * PD + k] = t[k]; }
 		}
-		for (int k = tid; k < d.nF * L; k += G) { B.old_ulm[d.o_ulm * L + k] = B.ulm[d.o_ulm * L + k]; B.ulm[d.o_ulm * L + k] += dl[d.nK * P + k]; }
-		for (int r = tid; r < d.n_req; r += 2 * G) { // two poses per lane and pass: both loads before the stores
-			const int r2 = r + G; const bool two = r2 < d.n_req;
+		for (int k = tid; k < d.nF * L; k += SRBA_WG) { B.old_ulm[d.o_ulm * L + k] = B.ulm[d.o_ulm * L + k]; B.ulm[d.o_ulm * L + k] += dl[d.nK * P + k]; }
+		for (int r = tid; r < d.n_req; r += 2 * SRBA_WG) { // two poses per lane and pass: both loads before the stores
+			const int r2 = r + SRBA_WG; const bool two = r2 < d.n_req;
 			const double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD, *s2 = two ? B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r2]) * PD : s;
 			double v[PD], v2[PD]; ldn<PD>(v, s); ldn<PD>(v2, s2);
 			stn<PD>(B.old_pose + (d.o_req + r) * PD, v);
@@ -333,7 +330,7 @@ struct Solver : public Worker<FAM, G> {
 		}
 		// with the staged copy the refresh that follows reads LDS only, and nothing reads the arrays written here before the next full barrier (end of that refresh):
 		// the hand-off is an LDS one (no wait for the global stores to be acknowledged)
-		if (stage) solver_sync(); else grp_sync<G>();
+		if (stage) solver_sync(); else __syncthreads();
 		return stage ? el : nullptr;
 	}
 	// K11 for the double-buffered loop: the trial unknowns exp(delta) (+) edge, lm + delta go to the OTHER copy (Bt), nothing is backed up (a rejected trial simply leaves the
@@ -343,7 +340,7 @@ struct Solver : public Worker<FAM, G> {
 		typedef typename W::PO PO; typedef typename W::pose_t pose_t;
 		const double *dl = B.delta + d.o_scal;
 		const bool stage = d.dense_in_lds && d.n_edges * PD <= 9 * S.nnzoff; double *el = S.off;
-		for (int i = tid; i < (stage ? d.n_edges : d.nK); i += G) {
+		for (int i = tid; i < (stage ? d.n_edges : d.nK); i += SRBA_WG) {
 			pose_t cur = PO::ld(B.edge + (d.o_edge + i) * PD);
 			if (i < d.nK) {
 				double inc[P];
@@ -356,15 +353,15 @@ struct Solver : public Worker<FAM, G> {
 #pragma unroll
 				for (int k = 0; k < PD; k++) el[i * PD + k] = t[k]; }
 		}
-		for (int k = tid; k < d.nF * L; k += G) Bt.ulm[d.o_ulm * L + k] = B.ulm[d.o_ulm * L + k] + dl[d.nK * P + k];
-		if (stage) solver_sync(); else grp_sync<G>();
+		for (int k = tid; k < d.nF * L; k += SRBA_WG) Bt.ulm[d.o_ulm * L + k] = B.ulm[d.o_ulm * L + k] + dl[d.nK * P + k];
+		if (stage) solver_sync(); else __syncthreads();
 		return stage ? el : nullptr;
 	}
 	__device__ __forceinline__ void restore() { this->fresh(); // optimize_edges.h:664-680
-		for (int i = tid; i < d.nK * PD; i += G) B.edge[d.o_edge * PD + i] = B.old_edge[d.o_unk * PD + i];
-		for (int k = tid; k < d.nF * L; k += G) B.ulm[d.o_ulm * L + k] = B.old_ulm[d.o_ulm * L + k];
-		for (int r = tid; r < d.n_req; r += G) { double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD; const double *o = B.old_pose + (d.o_req + r) * PD; for (int k = 0; k < PD; k++) s[k] = o[k]; }
-		grp_sync<G>();
+		for (int i = tid; i < d.nK * PD; i += SRBA_WG) B.edge[d.o_edge * PD + i] = B.old_edge[d.o_unk * PD + i];
+		for (int k = tid; k < d.nF * L; k += SRBA_WG) B.ulm[d.o_ulm * L + k] = B.old_ulm[d.o_ulm * L + k];
+		for (int r = tid; r < d.n_req; r += SRBA_WG) { double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD; const double *o = B.old_pose + (d.o_req + r) * PD; for (int k = 0; k < PD; k++) s[k] = o[k]; }
+		__syncthreads();
 	}
 };
 
@@ -509,144 +506,6 @@ __global__ void __launch_bounds__(SRBA_WG) SRBA_OCC k_lm_run(const Batch B, cons
 		if (i >= count) break;
 		lm_one<FAM>(B, prm, B.order[first + i]);
 		__syncthreads(); // the LDS image and the symbolic copy are rebuilt by the next capsule
-	}
-}
-
-// ---- two capsules per wavefront (round 4). The small size classes are bound by wave slots (registers), and their share of the launch by vector-instruction issue: six resident wavefronts
-// per CU run as fast as eight (tools/r4_variants.sh), and in the block-sparse solver -- two thirds of a trial -- an instruction keeps 3..30 of 64 lanes busy. Here every half of a wavefront
-// (G = 32: ten groups of three lanes in the solver) owns a capsule with its own LDS image and its own LM state, and the loop below is ONE loop with one trial per pass: the nested
-// for / while of optimize_edges.h:454-692 flattened into a state (at the head of an iteration / inside its retry loop), so that the two halves re-converge at the top of every pass and
-// execute the trial -- assemble, factor, substitute, apply, refresh, residuals -- in the same instructions whatever their accept / reject history; only relinearisation, the initial
-// linearisation of a fresh capsule and the final copy-back run with one half masked. Each half pulls its next capsule from the class counter on its own. Same device functions as
-// k_lm_run (Solver<FAM, 32>): per scalar the same operations; sums over the lanes of a group are formed over 32 instead of 64 partial sums (results agree with k_lm_run to rounding).
-template <int FAM>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_lm_pair(const Batch B0, const DevParams prm, int first, int count, int *next, int lds_doubles /* LDS doubles per capsule */) {
-	constexpr int G = 32; typedef Solver<FAM, G> Sv; constexpr int P = Sv::P, L = Sv::L, O = Sv::O, PD = Sv::PD;
-	const int gl = grp_lane<G>(), half = (int)(threadIdx.x >> 5);
-	double *img = srba_lds + half * lds_doubles;
-	bool running = false, done = false, in_while = false, stop = false; int pidx = 0, cur = 0, last_rej = 0, iter = 0, trials = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0, rswap = 0;
-	double lambda = 0, nu = 2.0, total_err = 0, RMSE = 0, rho = 0;
-	while (!done) {
-		if (!running) { // the next capsule of the class for this half
-			int i = 0; if (gl == 0) i = atomicAdd(next, 1);
-			{ const int i0 = __builtin_amdgcn_readlane(i, 0), i1 = __builtin_amdgcn_readlane(i, 32); i = half ? i1 : i0; }
-			if (i >= count) done = true;
-			else {
-				pidx = B0.order[first + i]; const ProbDesc &d = B0.desc[pidx]; Sv S(B0, d, prm); srba_lm_result *out = B0.results + pidx;
-				(void)S.make_sys(img, true);
-				S.phase_spantree(false, nullptr, B0.pose1); // S5, both copies of the poses
-				for (int k = gl; k < d.n_edges * PD; k += G) B0.edge1[d.o_edge * PD + k] = B0.edge[d.o_edge * PD + k];
-				for (int k = gl; k < d.nF * L; k += G) B0.ulm1[d.o_ulm * L + k] = B0.ulm[d.o_ulm * L + k];
-				grp_sync<G>();
-				S.phase_jacobians(); // S6, S7
-				const bool hess_terms = B0.hess_terms && d.dense_in_lds && d.n_hap * P * P <= 9 * (d.nb + d.nnzoff);
-				const int ninv = (int)grp_sum<G>((double)(hess_terms ? S.phase_hessian_terms(img) + S.phase_hessian_landmark_blocks() : S.phase_hessian())); // S10
-				grp_sync<G>();
-				for (int k = gl; k < SRBA_TRACE_LEN; k += G) { out->trace_chi2[k] = NAN; out->trace_lambda[k] = NAN; out->trace_rho[k] = NAN; }
-				if (gl == 0) {
-					out->status = 0; out->num_iters = 0; out->num_trials = 0; out->num_not_pd = 0; out->num_accepted = 0; out->num_relinearized = 0; out->stop_reason = 0;
-					out->num_invalid_jacobs = ninv; out->num_observations = d.n_obs; out->num_jacobians = d.n_bp + d.n_bf; out->num_span_tree_numeric_updates = d.n_pairs; out->lambda_last_trial = NAN;
-				}
-				if ((long long)O * d.n_obs < (long long)d.n_scal) { if (gl == 0) out->status = 1; } // S11: the problem is left as it is
-				else {
-					lambda = S.lambda_guess(nullptr); // S12
-					total_err = S.phase_residuals(B0.resid, nullptr); RMSE = sqrt(total_err / d.n_obs); // S13
-					if (gl == 0) { out->lambda_init = lambda; out->total_sqr_error_init = total_err; }
-					grp_sync<G>();
-					S.phase_gradient(B0.resid); // S14
-					grp_sync<G>(); S.keep_gradient();
-					nu = 2.0; iter = 0; trials = 0; n_notpd = 0; n_acc = 0; n_relin = 0; stopmask = 0; stop = false; cur = 0; last_rej = 0; rswap = 0; rho = 0; in_while = false; running = true;
-				}
-			}
-		}
-		if (running) {
-			const ProbDesc &d = B0.desc[pidx]; srba_lm_result *out = B0.results + pidx; const int nObs = d.n_obs, n = d.n_scal;
-			double *resid = rswap ? B0.resid2 : B0.resid, *resid2 = rswap ? B0.resid : B0.resid2;
-			bool fin = false;
-			if (!in_while) { // head of an iteration (optimize_edges.h:454-469)
-				if (iter < prm.max_iters && !stop) {
-					rho = 0;
-					if (lambda >= prm.max_lambda) { stop = true; stopmask |= 1 << SRBA_STOP_LAMBDA; }
-					if (RMSE < prm.max_err) { stop = true; stopmask |= 1 << SRBA_STOP_RMSE; }
-					in_while = true;
-				} else fin = true;
-			}
-			if (in_while) {
-				if (rho <= 0 && !stop) { // one trial (optimize_edges.h:471-692)
-					const int tr = trials++;
-					if (gl == 0) { if (tr < SRBA_TRACE_LEN) out->trace_lambda[tr] = lambda; out->lambda_last_trial = lambda; }
-					const Batch Ba = copy_view(B0, cur), Bt = copy_view(B0, cur ^ 1); Sv Sa(Ba, d, prm), St(Bt, d, prm);
-					const SparseSys A = Sa.make_sys(img, false);
-					const bool solved = Sa.solve(A, lambda, nullptr);
-					if (!solved) {
-						n_notpd++; lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
-						grp_sync<G>();
-					} else {
-						const double *edge_lds = Sa.apply_trial(A, Bt);
-						St.phase_spantree(true, edge_lds);
-						grp_sync<G>();
-						const double new_err = St.phase_residuals(resid2, nullptr);
-						const double new_RMSE = sqrt(new_err / nObs);
-						const double err_red = total_err > 0 ? (total_err - new_err) / total_err : 0;
-						double den = 0; { const double *dl = B0.delta + d.o_scal, *g = B0.grad + d.o_scal; for (int k = gl; k < n; k += G) den += dl[k] * (lambda * dl[k] + g[k]); }
-						den = grp_sum<G>(den);
-						rho = (total_err - new_err) / den;
-						if (gl == 0 && tr < SRBA_TRACE_LEN) { out->trace_chi2[tr] = new_err; out->trace_rho[tr] = rho; }
-						if (rho > 0) {
-							n_acc++;
-							const bool relin = (err_red < 0 || err_red > prm.min_relin);
-							rswap ^= 1; total_err = new_err; RMSE = new_RMSE; cur ^= 1; last_rej = 0;
-							grp_sync<G>();
-							if (relin) { n_relin++; St.phase_jacobians();
-								const bool hess_terms = B0.hess_terms && d.dense_in_lds && d.n_hap * P * P <= 9 * (d.nb + d.nnzoff);
-								if (hess_terms) { St.phase_hessian_terms(img); St.phase_hessian_landmark_blocks(); } else St.phase_hessian();
-								grp_sync<G>(); }
-							St.phase_gradient(resid2 /* the accepted residuals (the roles were just swapped) */);
-							grp_sync<G>(); St.keep_gradient();
-							double ninf = 0; { const double *g = B0.grad + d.o_scal; for (int k = gl; k < n; k += G) ninf = fmax(ninf, fabs(g[k])); }
-							ninf = grp_max<G>(ninf);
-							if (ninf <= 1e-15) { stop = true; stopmask |= 1 << SRBA_STOP_GRADIENT; }
-							if (RMSE < prm.max_err) { stop = true; stopmask |= 1 << SRBA_STOP_RMSE; }
-							if (rho > prm.max_rho) { stop = true; stopmask |= 1 << SRBA_STOP_RHO; }
-							lambda *= 1.0 / 3.0; nu = 2.0;
-						} else {
-							last_rej = 1;
-							lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
-						}
-					}
-				}
-				if (!(rho <= 0 && !stop)) { iter++; in_while = false; }
-			}
-			if (fin) { // S17 + results + the accepted state back to the primary arrays (as lm_one)
-				Sv S(B0, d, prm);
-				if (!stop) stopmask |= 1 << SRBA_STOP_MAX_ITERS;
-				if constexpr (!Sv::W::T::REL) {
-					for (int l = gl; l < d.nF; l += G) {
-						const bool ok = prm.cov_recovery == 1 && (S.schur_active() ? (B0.hf_ok[d.o_ulm + l] != 0) : true);
-						B0.ulm_inf_valid[d.o_ulm + l] = ok ? 1 : 0;
-						if (ok) for (int k = 0; k < L * L; k++) B0.ulm_inf[(d.o_ulm + l) * L * L + k] = B0.Hf[(d.o_hf + B0.hf_diag[d.o_ulm + l]) * L * L + k];
-					}
-				}
-				if (gl == 0) {
-					out->num_iters = iter; out->num_trials = trials; out->num_not_pd = n_notpd; out->num_accepted = n_acc; out->num_relinearized = n_relin; out->stop_reason = stopmask;
-					out->total_sqr_error_final = total_err; out->obs_rmse = RMSE; out->lambda_final = lambda;
-				}
-				const Batch Ba = copy_view(B0, cur), Bt = copy_view(B0, cur ^ 1);
-				grp_sync<G>();
-				if (last_rej) for (int q = gl; q < 2 * d.n_need; q += G) { // the reference's partial restore (optimize_edges.h:664-670), where it becomes visible
-					const long long ps = 2LL * B0.need_idx[d.o_pair + (q >> 1)] + (q & 1);
-					if (!B0.pose_req[d.o_pair * 2 + ps]) { double v[PD]; ldn<PD>(v, Bt.pose + (d.o_pair * 2 + ps) * PD); stn<PD>(Ba.pose + (d.o_pair * 2 + ps) * PD, v); }
-				}
-				grp_sync<G>();
-				if (cur) {
-					for (int k = gl; k < d.nK * PD; k += G) B0.edge[d.o_edge * PD + k] = B0.edge1[d.o_edge * PD + k];
-					for (int k = gl; k < d.nF * L; k += G) B0.ulm[d.o_ulm * L + k] = B0.ulm1[d.o_ulm * L + k];
-					for (int q = gl; q < 2 * d.n_need; q += G) { const long long ps = 2LL * B0.need_idx[d.o_pair + (q >> 1)] + (q & 1); double v[PD]; ldn<PD>(v, B0.pose1 + (d.o_pair * 2 + ps) * PD); stn<PD>(B0.pose + (d.o_pair * 2 + ps) * PD, v); }
-				}
-				grp_sync<G>(); // the LDS image is rebuilt by the next capsule of this half
-				running = false;
-			}
-		}
 	}
 }
 
@@ -858,7 +717,7 @@ static void symbolic_dense(const srba_problem_capsule &k, const ProbDesc &d, int
 	for (size_t u = 0; u < covered.size(); u++) if (!covered[u]) out.fill.push_back((int32_t)u);
 }
 
-struct LaunchJob { int queue, cls, first, count; double cost; int grid; int delay_us = 0; int pair = 0 /* two capsules per wavefront (k_lm_pair) */; };
+struct LaunchJob { int queue, cls, first, count; double cost; int grid; int delay_us = 0; };
 static const int kBigPart = 4096;
 static const int kMaxJobs = 1024;
 
@@ -937,7 +796,6 @@ struct srba_hip_ctx {
 	std::unique_ptr<char[]> h_in; size_t h_in_cap = 0; size_t h_off_order = 0; // host staging of the input arena (kept: the launch order is read back from it)
 	std::vector<int> delay_us; int class_prio = 0; // experiment knobs: per plan job delay before its launch (overrides the staggered start); stream priorities by class size
 	int stagger_ns = 300, stagger_max_us = 5000; // staggered start of the class launches: see plan_launches
-	bool pair_on = true; int pair_max_kb = 16, pair_min_count = 256; // two capsules per wavefront for the small size classes of the relative-pose SE2 family (k_lm_pair): classes up to this LDS image, with at least this many capsules
 	int max_lds_kb = 1 << 20, min_chunk = 384, max_parts_per_queue = 2; int class_streams = 64 /* sched 3: the class launches are dealt round-robin to at most this many streams */, n_queues = 16, sched = 3, n_streams_used = 1, n_cu = 256, waves_per_cu = 8, lds_per_cu = 160 * 1024; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
 	// offsets needed for downloads (bytes inside the wk arena)
 	size_t off_edge = 0, off_ulm = 0, off_pose = 0, off_inf = 0, off_infv = 0, off_res = 0;
@@ -958,16 +816,14 @@ static void plan_launches(srba_hip_ctx *c, const int32_t *ord) {
 	c->plan.clear(); const int nq = c->n_queues;
 	struct fin { srba_hip_ctx *c; ~fin() { // grid of every job: persistent launches hold as many wavefronts as the chip can keep resident for that LDS size, the rest one per capsule
 		for (size_t j = 0; j < c->plan.size(); j++) { LaunchJob &J = c->plan[j]; J.grid = J.count;
-			if (c->sched == 3) { const size_t lds = c->cls_lds[J.cls] + c->lds_pad; const int fit = lds ? (int)std::max<size_t>(1, (size_t)c->lds_per_cu / lds) : c->waves_per_cu; J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(c->waves_per_cu, fit)));
-				J.pair = (c->pair_on && c->params.family == SRBA_SE2_RELPOSE2D && J.cls < SRBA_NCLS - 1 && lds > 0 && lds <= (size_t)c->pair_max_kb * 1024 && J.count >= c->pair_min_count) ? 1 : 0;
-				if (J.pair) { const int fit2 = (int)std::max<size_t>(1, (size_t)c->lds_per_cu / (2 * lds)); J.grid = std::max(1, std::min((J.count + 1) / 2, c->n_cu * std::min(c->waves_per_cu, fit2))); } }
+			if (c->sched == 3) { const size_t lds = c->cls_lds[J.cls] + c->lds_pad; const int fit = lds ? (int)std::max<size_t>(1, (size_t)c->lds_per_cu / lds) : c->waves_per_cu; J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(c->waves_per_cu, fit))); }
 		}
 		// Staggered start (round 4): the persistent launches of all classes are enqueued at once on their own streams, and which workgroups the dispatcher places first was a race --
 		// when the small (wave-slot bound) classes won it they filled every wave slot, the big (LDS bound, longest running) capsules trickled in late and the launch ended in their tail:
 		// 42-43 ms instead of 38 ms on the benchmark batch, from one launch to the next (tools/diag_launch_order.py, profiles/r04_launch_order.txt). Largest-footprint-first is now enforced:
 		// the stream of job j is held back by a one-thread delay kernel for stagger_ns x (workgroups of all the jobs before it) -- the time the dispatcher needs to place those.
 		if (c->sched == 3 && c->plan.size() > 1) { long long ahead = 0; for (size_t j = 0; j < c->plan.size(); j++) { LaunchJob &J = c->plan[j]; J.delay_us = (int)std::min<long long>(c->stagger_max_us, ahead * c->stagger_ns / 1000); if (j < c->delay_us.size()) J.delay_us = c->delay_us[j]; ahead += J.grid; } }
-		if (getenv("SRBA_HIP_PLAN_DEBUG")) for (size_t j = 0; j < c->plan.size(); j++) { const LaunchJob &J = c->plan[j]; std::fprintf(stderr, "[plan] job %zu: stream %d class %d lds %zu B capsules %d grid %d delay %d us%s\n", j, J.queue, J.cls, c->cls_lds[J.cls], J.count, J.grid, J.delay_us, J.pair ? " (two capsules per wavefront)" : ""); } } } finish = {c};
+		if (getenv("SRBA_HIP_PLAN_DEBUG")) for (size_t j = 0; j < c->plan.size(); j++) { const LaunchJob &J = c->plan[j]; std::fprintf(stderr, "[plan] job %zu: stream %d class %d lds %zu B capsules %d grid %d delay %d us\n", j, J.queue, J.cls, c->cls_lds[J.cls], J.count, J.grid, J.delay_us); } } } finish = {c};
 	if (c->sched == 3) { // one persistent launch per size class, every class on its own stream, biggest LDS footprint first (the HBM class is the biggest)
 		int q = 0; const int qmax = std::max(1, c->class_streams);
 		for (int k = SRBA_NCLS - 2; k >= 0; k--) if (c->cls_count[k]) { c->plan.push_back({q % qmax, k, c->cls_first[k], c->cls_count[k], 0.0, 0}); q++; }
@@ -1085,7 +941,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_QUEUES"); if (e && atoi(e) >= 1 && atoi(e) < SRBA_NCLS) c->n_queues = atoi(e); } // tuning knob: concurrent launch streams
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || false) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
-	{ const char *e = getenv("SRBA_HIP_CLASS_PRIO"); if (e) c->class_prio = atoi(e); e = getenv("SRBA_HIP_STAGGER_NS"); if (e && atoi(e) >= 0) c->stagger_ns = atoi(e); e = getenv("SRBA_HIP_PAIR"); if (e) c->pair_on = atoi(e) != 0; e = getenv("SRBA_HIP_PAIR_MAX_KB"); if (e && atoi(e) > 0) c->pair_max_kb = atoi(e); e = getenv("SRBA_HIP_DELAY_US"); if (e) { std::string t(e); size_t p0 = 0; while (p0 <= t.size()) { size_t p1 = t.find(',', p0); if (p1 == std::string::npos) p1 = t.size(); c->delay_us.push_back(atoi(t.substr(p0, p1 - p0).c_str())); p0 = p1 + 1; } } }
+	{ const char *e = getenv("SRBA_HIP_CLASS_PRIO"); if (e) c->class_prio = atoi(e); e = getenv("SRBA_HIP_STAGGER_NS"); if (e && atoi(e) >= 0) c->stagger_ns = atoi(e); e = getenv("SRBA_HIP_DELAY_US"); if (e) { std::string t(e); size_t p0 = 0; while (p0 <= t.size()) { size_t p1 = t.find(',', p0); if (p1 == std::string::npos) p1 = t.size(); c->delay_us.push_back(atoi(t.substr(p0, p1 - p0).c_str())); p0 = p1 + 1; } } }
 	int pr_least = 0, pr_greatest = 0; hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
 	for (int k = 1; k < SRBA_NCLS && ok; k++) { // (class_prio 1: the streams of the biggest classes -- low stream index, see plan_launches -- get the highest priority, 2: the lowest)
 		const int split = 4, pri = c->class_prio == 0 ? 0 : ((c->class_prio == 1) == (k < split) ? pr_greatest : pr_least);
@@ -1685,7 +1541,6 @@ static int lm_run_async_impl(srba_hip_ctx *c) {
 		const LaunchJob &J = c->plan[j]; const int k = J.cls;
 		hipStream_t launch_stream = (J.queue && nq > 1) ? c->cls_stream[J.queue] : c->stream;
 		if (J.delay_us > 0) hipLaunchKernelGGL(srbadev::k_delay, dim3(1), dim3(1), 0, launch_stream, J.delay_us);
-		if (J.pair) { const size_t lds1 = (c->cls_lds[k] + c->lds_pad + 7) & ~(size_t)7; hipLaunchKernelGGL((srbadev::k_lm_pair<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(SRBA_WG), 2 * lds1, launch_stream, c->B, c->dp, J.first, J.count, c->d_next + j, (int)(lds1 / 8)); HIPCHK(c, hipGetLastError()); continue; }
 		SRBA_DISPATCH_LDS(c, k_lm_run, J.grid, c->cls_lds[k] + c->lds_pad, J.first, J.count, c->d_next + j); HIPCHK(c, hipGetLastError());
 	}
 	// capsules too large for one wavefront's LDS: the multi-workgroup path, one capsule after the other on the context stream (host-driven LM loop: this part
