@@ -55,7 +55,7 @@ struct Batch {
 	const unsigned char *pair_needed, *bp_normal;
 	const int *sp_fill; // unified block indices (diag k -> k, off-diagonal i -> nb+i)
 	const int *hap_rec; // per H block, sorted by decreasing term count (longest first: balances the lanes of K6): {block, first term, end term}
-	const int *sp_col_off, *sp_row, *sp_item_off, *sp_tgt, *sp_ab, *sp_rptr, *sp_rcol, *sp_rblk, *sp_perm; // symbolic factorisation of every capsule's system
+	const int *sp_col_off, *sp_row, *sp_item_off, *sp_tgt /* packed update items: unified target block << 18 | a << 9 | b (packed at upload) */, *sp_rptr, *sp_rcol /* packed row-view entries: column << 14 | off-diagonal block */, *sp_perm; // symbolic factorisation of every capsule's system
 	const int *hap_dst, *hapf_dst, *hf_dst; // destination 3x3 block of every aligned sub-block of the Hessian blocks (see symbolic_factor)
 	// state + workspace
 	double *edge, *ulm, *pose, *Jp, *Jf, *resid, *resid2, *HAp, *HAp0, *Hf, *HApf, *grad, *grad0 /* SRBA_EXT_SCHUR_KEEPS_GRADIENT: the gradient as K5 produced it */, *delta, *Hfinv, *YW;
@@ -268,9 +268,7 @@ struct SparseSys { // per-capsule symbolic structure (LDS copy of the host's sym
 	const int *col_off, *row;  // col_off[nb+1], row[nnzoff] (rows ascending inside a column)
 	const int *item;           // update items of all columns, column after column (cn(cn+1)/2 each, a>=b row positions inside the column):
 	                           //   one packed word  u<<18 | a<<9 | b  (u = unified block index: diag k -> k, off-diag i -> nb+i)
-	const int *item_ab;        //   (global-memory source: target / a<<16|b pairs, packed into `item` when copied to LDS)
 	const int *rptr, *rent;    // row view for the backward substitution: entries of block-row a = rent[rptr[a]..rptr[a+1]) = col<<14 | off-diag index
-	const int *rent_blk;
 	const int *perm;           // perm[original 3-row block] = position in the fill-reducing elimination order
 	double *diag, *off, *rhs;
 	double *row_lds;           // HBM-resident dense layout with left-looking sweeps: 21 nb doubles of LDS (rows k, k+1 of the factor | y), else null
@@ -582,7 +580,9 @@ __device__ __forceinline__ double *sp_elem(const SparseSys &S, int r, int c) {
 }
 
 // ------------------------------------------------------------------------------------------------ the per-problem worker
-template <int FAM>
+// LEAN (round 4): the instantiation for the small, wave-slot-bound size classes of a big batch -- fewer loads in flight per lane (pairs, Jacobian blocks, Hessian terms) so that the kernel
+// fits 168 registers and three wavefronts share a SIMD (k_lm_run_lean): the memory-level parallelism that the per-lane prefetches buy is bought with wavefronts instead. Same arithmetic.
+template <int FAM, bool LEAN = false>
 struct Worker {
 	typedef Tr<FAM> T; typedef PoseOps<T::SE3> PO; typedef typename PO::T pose_t;
 	static constexpr int P = T::P, L = T::L, O = T::O, PD = T::PD;
@@ -610,8 +610,8 @@ struct Worker {
 #ifdef SRBA_K1SMALL
 		constexpr int U = 2, V = 1;
 #else
-		constexpr int U = T::SE3 ? 2 : 4; // path edges fetched together (their loads do not depend on the running composition)
-		constexpr int V = T::SE3 ? 1 : 2; // pairs per lane and pass (all their loads are issued before the first store)
+		constexpr int U = LEAN ? 2 : (T::SE3 ? 2 : 4); // path edges fetched together (their loads do not depend on the running composition)
+		constexpr int V = LEAN ? 1 : (T::SE3 ? 1 : 2); // pairs per lane and pass (all their loads are issued before the first store)
 #endif
 		if (only_needed && d.need_flat) { // in-loop refresh: one flat record per pair -> two dependent memory levels (record, edges) instead of four
 			// (two copies of the loop, LDS source / HBM source: with the choice inside, the compiler merges the last load of both into a flat_load on a selected pointer)
@@ -998,7 +998,7 @@ struct Worker {
 		#ifdef SRBA_NOPAIR
 		constexpr bool PAIR = false;
 #else
-		constexpr bool PAIR = (O * (M1 + M2) <= 24) || (T::SE3 && O * (M1 + M2) <= 48); // (the SE3 kernels run one wavefront per SIMD anyway: registers buy memory-level parallelism)
+		constexpr bool PAIR = !LEAN && ((O * (M1 + M2) <= 24) || (T::SE3 && O * (M1 + M2) <= 48)); // (the SE3 kernels run one wavefront per SIMD anyway: registers buy memory-level parallelism)
 #endif // two terms in flight when their Jacobian blocks fit the register budget
 		int t = tb;
 		if constexpr (PAIR) {
@@ -1107,7 +1107,7 @@ struct Worker {
 #ifdef SRBA_GRADU2
 				constexpr int U = 2;
 #else
-				constexpr int U = (O * M <= 9) ? 4 : (O * M <= 24 ? 2 : 1); // blocks in flight per lane (their loads do not depend on the running sum)
+				constexpr int U = LEAN ? 2 : ((O * M <= 9) ? 4 : (O * M <= 24 ? 2 : 1)); // blocks in flight per lane (their loads do not depend on the running sum)
 #endif
 				for (int b0 = bb + sub; b0 < be; b0 += U * S) {
 					double A[U][O * M], lr[U][O];

@@ -35,9 +35,9 @@ extern __shared__ double srba_lds[]; // block-sparse system of the capsule (diag
 // (LDS operands are addressed from this symbol where it matters: a pointer that went through SparseSys -- whose numbers may live in HBM -- is a generic pointer, and
 //  its loads become flat_load instead of ds_read)
 
-template <int FAM>
-struct Solver : public Worker<FAM> {
-	typedef Worker<FAM> W; using W::B; using W::d; using W::prm; using W::tid;
+template <int FAM, bool LEAN = false>
+struct Solver : public Worker<FAM, LEAN> {
+	typedef Worker<FAM, LEAN> W; using W::B; using W::d; using W::prm; using W::tid;
 	static constexpr int P = W::P, L = W::L, O = W::O, PD = W::PD;
 	__device__ Solver(const Batch &B_, const ProbDesc &d_, const DevParams &p_) : W(B_, d_, p_) {}
 	__device__ __forceinline__ bool schur_active() const { return prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0; }
@@ -252,8 +252,8 @@ struct Solver : public Worker<FAM> {
 	__device__ __forceinline__ SparseSys make_sys(double *lds) const {
 		SparseSys S; S.nb = d.nb; S.nnzoff = d.nnzoff; S.dense = (W::T::REL || !W::T::SE3) ? 0 : d.dense_blocks;
 		S.row_lds = (S.dense == 2 && B.dense_left && d.nb <= 168) ? lds + (d.nb + 1) / 2 + 16 : nullptr; // HBM-resident layout, left-looking sweeps: 21 nb doubles of LDS after the permutation (two rows of the factor | y)
-		S.col_off = B.sp_col_off + d.o_spcol; S.row = B.sp_row + d.o_sprow; S.item = B.sp_tgt + d.o_spitem; S.item_ab = B.sp_ab + d.o_spitem; S.perm = B.sp_perm + d.o_spperm;
-		S.rptr = B.sp_rptr + d.o_spcol; S.rent = B.sp_rcol + d.o_sprow; S.rent_blk = B.sp_rblk + d.o_sprow;
+		S.col_off = B.sp_col_off + d.o_spcol; S.row = B.sp_row + d.o_sprow; S.item = B.sp_tgt + d.o_spitem; S.perm = B.sp_perm + d.o_spperm;
+		S.rptr = B.sp_rptr + d.o_spcol; S.rent = B.sp_rcol + d.o_sprow;
 		double *base = (!W::T::REL && W::T::SE3 && d.dense_blocks == 2) ? B.dense + d.o_dense : lds; // 2: the numbers live in an HBM workspace, LDS holds the permutation only
 		S.diag = base; S.off = base + 9 * d.nb; S.rhs = S.off + 9 * d.nnzoff;
 		if (S.dense) { // numbers only: every index of the dense block layout is arithmetic; the block permutation is the one table kept
@@ -265,8 +265,8 @@ struct Solver : public Worker<FAM> {
 			int *ip = (int *)(S.rhs + 3 * d.nb); int *c0 = ip, *rp0 = c0 + d.nb + 1, *p0 = rp0 + d.nb + 1, *r0 = p0 + d.nb, *re0 = r0 + d.nnzoff, *t0 = re0 + d.nnzoff;
 			for (int k = tid; k <= d.nb; k += SRBA_WG) { c0[k] = S.col_off[k]; rp0[k] = S.rptr[k]; }
 			for (int k = tid; k < d.nb; k += SRBA_WG) p0[k] = S.perm[k];
-			for (int k = tid; k < d.nnzoff; k += SRBA_WG) { r0[k] = S.row[k]; re0[k] = (S.rent[k] << 14) | S.rent_blk[k]; }
-			for (int k = tid; k < d.n_items; k += SRBA_WG) { const int tg = S.item[k], ab = S.item_ab[k]; t0[k] = ((tg >= 0 ? d.nb + tg : -1 - tg) << 18) | ((ab >> 16) << 9) | (ab & 0xffff); }
+			for (int k = tid; k < d.nnzoff; k += SRBA_WG) { r0[k] = S.row[k]; re0[k] = S.rent[k]; } // (the item / row-view words were packed at upload)
+			for (int k = tid; k < d.n_items; k += SRBA_WG) t0[k] = S.item[k];
 			S.col_off = c0; S.rptr = rp0; S.perm = p0; S.row = r0; S.rent = re0; S.item = t0;
 			__syncthreads();
 		}
@@ -374,13 +374,13 @@ struct Solver : public Worker<FAM> {
 #ifndef SRBA_LM_DB
 #define SRBA_LM_DB 1   /* the fused loop keeps two copies of the unknowns and of the spanning-tree poses (trial -> the other copy, accept = flip) instead of backup / restore */
 #endif
-template <int FAM, bool DB = (SRBA_LM_DB != 0)>
+template <int FAM, bool DB = (SRBA_LM_DB != 0), bool LEAN = false>
 __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, const int pidx) {
 	const ProbDesc &d = B0.desc[pidx];
 	const Batch &B = B0;
 	int cur = 0, last_rej = 0; // DB: which copy holds the accepted state; the last evaluated trial was rejected
-	Solver<FAM> S(B, d, prm);
-	constexpr int P = Solver<FAM>::P, L = Solver<FAM>::L, O = Solver<FAM>::O;
+	Solver<FAM, LEAN> S(B, d, prm);
+	constexpr int P = Solver<FAM, LEAN>::P, L = Solver<FAM, LEAN>::L, O = Solver<FAM, LEAN>::O;
 	double *red = nullptr;
 	const SparseSys A = S.make_sys(srba_lds);
 	const int tid = threadIdx.x; srba_lm_result *out = B.results + pidx;
@@ -392,11 +392,11 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 #define TOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - tc0; } } while (0)
 	// K6: the LDS image of the system is idle while the capsule is linearised (it is assembled per trial): the U_Ap accumulators of the term-parallel form live there
 	const bool hess_terms = B.hess_terms && d.dense_in_lds && d.n_hap * P * P <= 9 * (d.nb + d.nnzoff);
-	auto hessian = [&](Solver<FAM> &X) -> int { return hess_terms ? X.phase_hessian_terms(srba_lds) /* == A.diag: the LDS image, idle while the capsule is linearised */ + X.phase_hessian_landmark_blocks() : X.phase_hessian(); };
+	auto hessian = [&](Solver<FAM, LEAN> &X) -> int { return hess_terms ? X.phase_hessian_terms(srba_lds) /* == A.diag: the LDS image, idle while the capsule is linearised */ + X.phase_hessian_landmark_blocks() : X.phase_hessian(); };
 	double lambda, nu = 2.0, total_err, RMSE;
 	int iter = 0, trials = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0; bool stop = false;
 	TIC(); S.phase_spantree(false, nullptr, DB ? B0.pose1 : nullptr); // S5 (DB: both copies of the poses)
-	if constexpr (DB) { constexpr int PD = Solver<FAM>::PD; // the second copy of the unknowns (the fixed edges of the paths stay equal in both for good)
+	if constexpr (DB) { constexpr int PD = Solver<FAM, LEAN>::PD; // the second copy of the unknowns (the fixed edges of the paths stay equal in both for good)
 		for (int k = tid; k < d.n_edges * PD; k += SRBA_WG) B0.edge1[d.o_edge * PD + k] = B0.edge[d.o_edge * PD + k];
 		for (int k = tid; k < d.nF * L; k += SRBA_WG) B0.ulm1[d.o_ulm * L + k] = B0.ulm[d.o_ulm * L + k]; }
 	__syncthreads(); TOC(0);
@@ -424,7 +424,7 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 		while (rho <= 0 && !stop) {
 			const int tr = trials++;
 			if (tid == 0) { if (tr < SRBA_TRACE_LEN) out->trace_lambda[tr] = lambda; out->lambda_last_trial = lambda; }
-			const Batch Ba = DB ? copy_view(B0, cur) : B, Bt = DB ? copy_view(B0, cur ^ 1) : B; Solver<FAM> Sa(Ba, d, prm), St(Bt, d, prm); // accepted / trial copy (the same one without DB)
+			const Batch Ba = DB ? copy_view(B0, cur) : B, Bt = DB ? copy_view(B0, cur ^ 1) : B; Solver<FAM, LEAN> Sa(Ba, d, prm), St(Bt, d, prm); // accepted / trial copy (the same one without DB)
 			TIC(); const bool solved = Sa.solve(A, lambda, pc); TOC(5);
 			if (!solved) {
 				n_notpd++; lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
@@ -465,7 +465,7 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 	}
 	if (!stop) stopmask |= 1 << SRBA_STOP_MAX_ITERS;
 	// S17: crpLandmarksApprox
-	if constexpr (!Solver<FAM>::W::T::REL) {
+	if constexpr (!Solver<FAM, LEAN>::W::T::REL) {
 		for (int l = tid; l < d.nF; l += SRBA_WG) {
 			const bool ok = prm.cov_recovery == 1 && (S.schur_active() ? (B.hf_ok[d.o_ulm + l] != 0) : true);
 			B.ulm_inf_valid[d.o_ulm + l] = ok ? 1 : 0;
@@ -477,7 +477,7 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 		out->total_sqr_error_final = total_err; out->obs_rmse = RMSE; out->lambda_final = lambda;
 	}
 	if constexpr (DB) { // the reference's partial restore, where it becomes visible: a rejected trial refreshed BOTH poses of every pair in use and only the ones Jacobian blocks read went back (optimize_edges.h:664-670)
-		constexpr int PD = Solver<FAM>::PD; const Batch Ba = copy_view(B0, cur), Bt = copy_view(B0, cur ^ 1);
+		constexpr int PD = Solver<FAM, LEAN>::PD; const Batch Ba = copy_view(B0, cur), Bt = copy_view(B0, cur ^ 1);
 		__syncthreads();
 		if (last_rej) for (int q = tid; q < 2 * d.n_need; q += SRBA_WG) {
 			const long long ps = 2LL * B0.need_idx[d.o_pair + (q >> 1)] + (q & 1);
@@ -485,7 +485,7 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 		}
 	}
 	if constexpr (DB) { // the accepted state goes back to the primary arrays
-		constexpr int PD = Solver<FAM>::PD;
+		constexpr int PD = Solver<FAM, LEAN>::PD;
 		__syncthreads();
 		if (cur) {
 			for (int k = tid; k < d.nK * PD; k += SRBA_WG) B0.edge[d.o_edge * PD + k] = B0.edge1[d.o_edge * PD + k];
@@ -511,6 +511,20 @@ __global__ void __launch_bounds__(SRBA_WG) SRBA_OCC k_lm_run(const Batch B, cons
 
 // holds a class stream back for a while before its persistent launch (staggered start of the class launches, plan_launches)
 __global__ void k_delay(int us) { const long long t0 = wall_clock64(); while (wall_clock64() - t0 < 100LL * us) __builtin_amdgcn_s_sleep(20); }
+// The same loop for the small size classes of a big batch: three wavefronts per SIMD (at most 168 registers; Worker<FAM, LEAN = true> keeps fewer loads in flight per lane). On the 23 460 windows
+// with at most 31 unknown edges of the benchmark batch: 16.6 ms against 19.0 ms for k_lm_run, whose two wavefronts per SIMD leave 40 % of the LDS of a CU unused while those classes run;
+// the big (LDS-bound) classes are 3 % slower with it and keep k_lm_run. Only instantiated where the plan uses it (relative-pose SE2: plan_launches).
+template <int FAM>
+__global__ void __launch_bounds__(SRBA_WG) __attribute__((amdgpu_waves_per_eu(3, 3))) k_lm_run_lean(const Batch B, const DevParams prm, int first, int count, int *next) {
+	for (;;) {
+		int i = 0; if (threadIdx.x == 0) i = atomicAdd(next, 1);
+		i = __builtin_amdgcn_readfirstlane(i);
+		if (i >= count) break;
+		lm_one<FAM, (SRBA_LM_DB != 0), true>(B, prm, B.order[first + i]);
+		__syncthreads();
+	}
+}
+
 // ---- stepwise kernels
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_spantree(const Batch B, const DevParams prm, int only_needed) { Solver<FAM> S(B, B.desc[blockIdx.x], prm); S.phase_spantree(only_needed != 0); }
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_residuals(const Batch B, const DevParams prm) {
@@ -717,7 +731,7 @@ static void symbolic_dense(const srba_problem_capsule &k, const ProbDesc &d, int
 	for (size_t u = 0; u < covered.size(); u++) if (!covered[u]) out.fill.push_back((int32_t)u);
 }
 
-struct LaunchJob { int queue, cls, first, count; double cost; int grid; int delay_us = 0; };
+struct LaunchJob { int queue, cls, first, count; double cost; int grid; int delay_us = 0; int lean = 0 /* k_lm_run_lean: three wavefronts per SIMD */; };
 static const int kBigPart = 4096;
 static const int kMaxJobs = 1024;
 
@@ -796,6 +810,7 @@ struct srba_hip_ctx {
 	std::unique_ptr<char[]> h_in; size_t h_in_cap = 0; size_t h_off_order = 0; // host staging of the input arena (kept: the launch order is read back from it)
 	std::vector<int> delay_us; int class_prio = 0; // experiment knobs: per plan job delay before its launch (overrides the staggered start); stream priorities by class size
 	int stagger_ns = 300, stagger_max_us = 5000; // staggered start of the class launches: see plan_launches
+	bool lean_on = true; int lean_min_count = 512; // k_lm_run_lean for the size classes of which at least nine wavefronts fit the LDS of a CU (relative-pose SE2, classes with at least this many capsules)
 	int max_lds_kb = 1 << 20, min_chunk = 384, max_parts_per_queue = 2; int class_streams = 64 /* sched 3: the class launches are dealt round-robin to at most this many streams */, n_queues = 16, sched = 3, n_streams_used = 1, n_cu = 256, waves_per_cu = 8, lds_per_cu = 160 * 1024; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
 	// offsets needed for downloads (bytes inside the wk arena)
 	size_t off_edge = 0, off_ulm = 0, off_pose = 0, off_inf = 0, off_infv = 0, off_res = 0;
@@ -816,14 +831,16 @@ static void plan_launches(srba_hip_ctx *c, const int32_t *ord) {
 	c->plan.clear(); const int nq = c->n_queues;
 	struct fin { srba_hip_ctx *c; ~fin() { // grid of every job: persistent launches hold as many wavefronts as the chip can keep resident for that LDS size, the rest one per capsule
 		for (size_t j = 0; j < c->plan.size(); j++) { LaunchJob &J = c->plan[j]; J.grid = J.count;
-			if (c->sched == 3) { const size_t lds = c->cls_lds[J.cls] + c->lds_pad; const int fit = lds ? (int)std::max<size_t>(1, (size_t)c->lds_per_cu / lds) : c->waves_per_cu; J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(c->waves_per_cu, fit))); }
+			if (c->sched == 3) { const size_t lds = c->cls_lds[J.cls] + c->lds_pad; const int fit = lds ? (int)std::max<size_t>(1, (size_t)c->lds_per_cu / lds) : c->waves_per_cu; J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(c->waves_per_cu, fit)));
+				J.lean = (c->lean_on && c->params.family == SRBA_SE2_RELPOSE2D && J.cls < SRBA_NCLS - 1 && fit >= 9 && J.count >= c->lean_min_count) ? 1 : 0;
+				if (J.lean) J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(12, fit))); }
 		}
 		// Staggered start (round 4): the persistent launches of all classes are enqueued at once on their own streams, and which workgroups the dispatcher places first was a race --
 		// when the small (wave-slot bound) classes won it they filled every wave slot, the big (LDS bound, longest running) capsules trickled in late and the launch ended in their tail:
 		// 42-43 ms instead of 38 ms on the benchmark batch, from one launch to the next (tools/diag_launch_order.py, profiles/r04_launch_order.txt). Largest-footprint-first is now enforced:
 		// the stream of job j is held back by a one-thread delay kernel for stagger_ns x (workgroups of all the jobs before it) -- the time the dispatcher needs to place those.
 		if (c->sched == 3 && c->plan.size() > 1) { long long ahead = 0; for (size_t j = 0; j < c->plan.size(); j++) { LaunchJob &J = c->plan[j]; J.delay_us = (int)std::min<long long>(c->stagger_max_us, ahead * c->stagger_ns / 1000); if (j < c->delay_us.size()) J.delay_us = c->delay_us[j]; ahead += J.grid; } }
-		if (getenv("SRBA_HIP_PLAN_DEBUG")) for (size_t j = 0; j < c->plan.size(); j++) { const LaunchJob &J = c->plan[j]; std::fprintf(stderr, "[plan] job %zu: stream %d class %d lds %zu B capsules %d grid %d delay %d us\n", j, J.queue, J.cls, c->cls_lds[J.cls], J.count, J.grid, J.delay_us); } } } finish = {c};
+		if (getenv("SRBA_HIP_PLAN_DEBUG")) for (size_t j = 0; j < c->plan.size(); j++) { const LaunchJob &J = c->plan[j]; std::fprintf(stderr, "[plan] job %zu: stream %d class %d lds %zu B capsules %d grid %d delay %d us%s\n", j, J.queue, J.cls, c->cls_lds[J.cls], J.count, J.grid, J.delay_us, J.lean ? " (lean: three wavefronts per SIMD)" : ""); } } } finish = {c};
 	if (c->sched == 3) { // one persistent launch per size class, every class on its own stream, biggest LDS footprint first (the HBM class is the biggest)
 		int q = 0; const int qmax = std::max(1, c->class_streams);
 		for (int k = SRBA_NCLS - 2; k >= 0; k--) if (c->cls_count[k]) { c->plan.push_back({q % qmax, k, c->cls_first[k], c->cls_count[k], 0.0, 0}); q++; }
@@ -941,7 +958,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_QUEUES"); if (e && atoi(e) >= 1 && atoi(e) < SRBA_NCLS) c->n_queues = atoi(e); } // tuning knob: concurrent launch streams
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || false) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
-	{ const char *e = getenv("SRBA_HIP_CLASS_PRIO"); if (e) c->class_prio = atoi(e); e = getenv("SRBA_HIP_STAGGER_NS"); if (e && atoi(e) >= 0) c->stagger_ns = atoi(e); e = getenv("SRBA_HIP_DELAY_US"); if (e) { std::string t(e); size_t p0 = 0; while (p0 <= t.size()) { size_t p1 = t.find(',', p0); if (p1 == std::string::npos) p1 = t.size(); c->delay_us.push_back(atoi(t.substr(p0, p1 - p0).c_str())); p0 = p1 + 1; } } }
+	{ const char *e = getenv("SRBA_HIP_CLASS_PRIO"); if (e) c->class_prio = atoi(e); e = getenv("SRBA_HIP_STAGGER_NS"); if (e && atoi(e) >= 0) c->stagger_ns = atoi(e); e = getenv("SRBA_HIP_LEAN"); if (e) c->lean_on = atoi(e) != 0; e = getenv("SRBA_HIP_LEAN_MIN_COUNT"); if (e && atoi(e) >= 1) c->lean_min_count = atoi(e); e = getenv("SRBA_HIP_DELAY_US"); if (e) { std::string t(e); size_t p0 = 0; while (p0 <= t.size()) { size_t p1 = t.find(',', p0); if (p1 == std::string::npos) p1 = t.size(); c->delay_us.push_back(atoi(t.substr(p0, p1 - p0).c_str())); p0 = p1 + 1; } } }
 	int pr_least = 0, pr_greatest = 0; hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
 	for (int k = 1; k < SRBA_NCLS && ok; k++) { // (class_prio 1: the streams of the biggest classes -- low stream index, see plan_launches -- get the highest priority, 2: the lowest)
 		const int split = 4, pri = c->class_prio == 0 ? 0 : ((c->class_prio == 1) == (k < split) ? pr_greatest : pr_least);
@@ -1087,7 +1104,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	// ---- input arena layout
 	Arena in; struct { size_t desc, edge0, ulm0, klm, obs_z, pair_path_off, path_edge, obs_pose, obs_lm, obs_valid, bp_col, bp_res, bp_A, bp_D, bp_lm, colp_off, bf_col, bf_res, bf_pose, colf_off,
 		hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hap_tblk, hf_i, hf_j, hf_term_off, hf_t1, hf_t2, hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag, sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw, sch_tblk,
-		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, pair_needed, pose_req, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_ab, sp_rptr, sp_rcol, sp_rblk, sp_perm, sp_fill, hap_rec, hap_dst, hapf_dst, hf_dst, asm_term, asm_blk, asm_desc, asm_list, asm_slot; } o;
+		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, pair_needed, pose_req, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_rptr, sp_rcol, sp_perm, sp_fill, hap_rec, hap_dst, hapf_dst, hf_dst, asm_term, asm_blk, asm_desc, asm_list, asm_slot; } o;
 	o.desc = in.add(sizeof(ProbDesc) * n);
 	o.edge0 = in.add(8 * t_edge * PDX); o.ulm0 = in.add(8 * t_ulm * L); o.klm = in.add(8 * t_klm * L); o.obs_z = in.add(8 * t_obs * O);
 	o.pair_path_off = in.add(4 * (t_pair + n)); o.path_edge = in.add(4 * t_path); o.obs_pose = in.add(4 * t_obs); o.obs_lm = in.add(4 * t_obs); o.obs_valid = in.add(4 * t_obs);
@@ -1099,7 +1116,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	o.hap_diag = in.add(4 * t_unk); o.hf_diag = in.add(4 * t_ulm);
 	o.sch_term_off = in.add(4 * (t_hap + n)); o.sch_b1 = in.add(4 * t_sch); o.sch_b2 = in.add(4 * t_sch); o.sch_lm = in.add(4 * t_sch); o.sch_yw = in.add(4 * t_sch); o.sch_tblk = in.add(4 * t_sch);
 	o.lm_hapf_off = in.add(4 * (t_ulm + n)); o.lm_hapf_idx = in.add(4 * t_hapf); o.req_idx = in.add(4 * t_req); o.need_idx = in.add(4 * t_pair); o.need_rec = in.add(4 * 5 * std::max<long long>(t_pair, 1)); o.pair_needed = in.add(t_pair); o.pose_req = in.add(2 * t_pair); o.bp_normal = in.add(t_bp); o.order = in.add(4 * (size_t)n);
-	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_ab = in.add(4 * t_spitem); o.sp_rptr = in.add(4 * t_spcol); o.sp_rcol = in.add(4 * t_sprow); o.sp_rblk = in.add(4 * t_sprow); o.sp_perm = in.add(4 * t_spcol); o.hap_rec = in.add(4 * 3 * std::max<long long>(t_hap, 1)); o.sp_fill = in.add(4 * std::max<long long>(t_spfill, 1));
+	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_rptr = in.add(4 * t_spcol); o.sp_rcol = in.add(4 * t_sprow); o.sp_perm = in.add(4 * t_spcol); o.hap_rec = in.add(4 * 3 * std::max<long long>(t_hap, 1)); o.sp_fill = in.add(4 * std::max<long long>(t_spfill, 1));
 	o.hap_dst = in.add(4 * t_hap * (P / 3) * (P / 3)); o.hapf_dst = in.add(4 * t_hapf * (P / 3)); o.hf_dst = in.add(4 * t_hf);
 	bool asm_fam = c->asm_on && c->params.family == SRBA_SE2_RELPOSE2D;
 	if (asm_fam && c->dp.noise == SRBA_NOISE_CONSTANT_MATRIX) for (int i = 0; i < 3; i++) for (int j = 0; j < i; j++) if (c->dp.lambda[3 * i + j] != c->dp.lambda[3 * j + i]) asm_fam = false; // the fused kernel sums the upper triangle of J^t Lambda J only
@@ -1146,8 +1163,8 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		{ int32_t *rq = (int32_t *)(h + o.req_idx) + d.o_req; int cnt = 0; for (int i = 0; i < 2 * k.n_pairs; i++) if (k.pose_required[i]) rq[cnt++] = i; }
 		CPY(o.pair_needed, d.o_pair, k.pair_needed, k.n_pairs, uint8_t); CPY(o.pose_req, 2 * d.o_pair, k.pose_required, 2 * (size_t)k.n_pairs, uint8_t); CPY(o.bp_normal, d.o_bp, k.bp_normal, k.n_bp, uint8_t);
 		CPY(o.sp_col_off, d.o_spcol, sym[p].col_off.data(), d.nb + 1, int32_t); CPY(o.sp_row, d.o_sprow, sym[p].row.data(), sym[p].row.size(), int32_t);
-		CPY(o.sp_item_off, d.o_spcol, sym[p].item_off.data(), d.nb + 1, int32_t); CPY(o.sp_perm, d.o_spperm, sym[p].perm.data(), d.nb, int32_t); CPY(o.sp_tgt, d.o_spitem, sym[p].tgt.data(), sym[p].tgt.size(), int32_t); CPY(o.sp_ab, d.o_spitem, sym[p].ab.data(), sym[p].ab.size(), int32_t);
-		CPY(o.sp_rptr, d.o_spcol, sym[p].rptr.data(), d.nb + 1, int32_t); CPY(o.sp_rcol, d.o_sprow, sym[p].rcol.data(), sym[p].rcol.size(), int32_t); CPY(o.sp_rblk, d.o_sprow, sym[p].rblk.data(), sym[p].rblk.size(), int32_t); CPY(o.sp_fill, d.o_spfill, sym[p].fill.data(), d.n_fill, int32_t);
+		CPY(o.sp_item_off, d.o_spcol, sym[p].item_off.data(), d.nb + 1, int32_t); CPY(o.sp_perm, d.o_spperm, sym[p].perm.data(), d.nb, int32_t); { std::vector<int32_t> &tg = sym[p].tgt; const std::vector<int32_t> &ab = sym[p].ab; for (size_t q = 0; q < tg.size(); q++) tg[q] = (int32_t)((((unsigned)(tg[q] >= 0 ? d.nb + tg[q] : -1 - tg[q])) << 18) | (((unsigned)ab[q] >> 16) << 9) | ((unsigned)ab[q] & 0xffffu)); } /* packed words (only capsules with packable indices reach the kernels that read them) */ CPY(o.sp_tgt, d.o_spitem, sym[p].tgt.data(), sym[p].tgt.size(), int32_t);
+		CPY(o.sp_rptr, d.o_spcol, sym[p].rptr.data(), d.nb + 1, int32_t); { std::vector<int32_t> &rc = sym[p].rcol; const std::vector<int32_t> &rbk = sym[p].rblk; for (size_t q = 0; q < rc.size(); q++) rc[q] = (int32_t)(((unsigned)rc[q] << 14) | (unsigned)rbk[q]); } CPY(o.sp_rcol, d.o_sprow, sym[p].rcol.data(), sym[p].rcol.size(), int32_t); CPY(o.sp_fill, d.o_spfill, sym[p].fill.data(), d.n_fill, int32_t);
 		{ std::vector<int32_t> ho(k.n_hap); for (int b = 0; b < k.n_hap; b++) ho[b] = b;
 		  std::stable_sort(ho.begin(), ho.end(), [&](int x, int y) { return k.hap_term_off[x + 1] - k.hap_term_off[x] > k.hap_term_off[y + 1] - k.hap_term_off[y]; });
 		  int32_t *hr = (int32_t *)(h + o.hap_rec) + 3 * d.o_hap; for (int i = 0; i < k.n_hap; i++) { hr[3 * i] = ho[i]; hr[3 * i + 1] = k.hap_term_off[ho[i]]; hr[3 * i + 2] = k.hap_term_off[ho[i] + 1]; } }
@@ -1224,7 +1241,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	Batch &B = c->B; std::memset(&B, 0, sizeof(B)); B.n_prob = n; B.max_lds_doubles = 0; B.hess_terms = c->lm_terms ? 1 : 0; B.dense_left = c->dense_left ? 1 : 0;
 	char *di = c->d_in, *dw = c->d_wk;
 #define DI(field, T) B.field = (const T *)(di + o.field)
-	B.desc = (const ProbDesc *)(di + o.desc); DI(order, int); DI(sp_col_off, int); DI(sp_row, int); DI(sp_item_off, int); DI(sp_tgt, int); DI(sp_ab, int); DI(sp_rptr, int); DI(sp_rcol, int); DI(sp_rblk, int); DI(sp_perm, int); DI(hap_rec, int); DI(sp_fill, int); DI(hap_dst, int); DI(hapf_dst, int); DI(hf_dst, int); DI(edge0, double); DI(ulm0, double); DI(klm, double); DI(obs_z, double);
+	B.desc = (const ProbDesc *)(di + o.desc); DI(order, int); DI(sp_col_off, int); DI(sp_row, int); DI(sp_item_off, int); DI(sp_tgt, int); DI(sp_rptr, int); DI(sp_rcol, int); DI(sp_perm, int); DI(hap_rec, int); DI(sp_fill, int); DI(hap_dst, int); DI(hapf_dst, int); DI(hf_dst, int); DI(edge0, double); DI(ulm0, double); DI(klm, double); DI(obs_z, double);
 	DI(pair_path_off, int); DI(path_edge, int); DI(obs_pose, int); DI(obs_lm, int); DI(obs_valid, int); DI(bp_col, int); DI(bp_res, int); DI(bp_A, int); DI(bp_D, int); DI(bp_lm, int); DI(colp_off, int);
 	DI(bf_col, int); DI(bf_res, int); DI(bf_pose, int); DI(colf_off, int); DI(hap_i, int); DI(hap_j, int); DI(hap_term_off, int); DI(hap_t1, int); DI(hap_t2, int); DI(hap_tblk, int); DI(hf_i, int); DI(hf_j, int); DI(hf_term_off, int); DI(hf_t1, int); DI(hf_t2, int);
 	DI(hapf_i, int); DI(hapf_j, int); DI(hapf_term_off, int); DI(hapf_t1, int); DI(hapf_t2, int); DI(hap_diag, int); DI(hf_diag, int); DI(sch_term_off, int); DI(sch_b1, int); DI(sch_b2, int); DI(sch_lm, int); DI(sch_yw, int); DI(sch_tblk, int);
@@ -1541,6 +1558,7 @@ static int lm_run_async_impl(srba_hip_ctx *c) {
 		const LaunchJob &J = c->plan[j]; const int k = J.cls;
 		hipStream_t launch_stream = (J.queue && nq > 1) ? c->cls_stream[J.queue] : c->stream;
 		if (J.delay_us > 0) hipLaunchKernelGGL(srbadev::k_delay, dim3(1), dim3(1), 0, launch_stream, J.delay_us);
+		if (J.lean) { hipLaunchKernelGGL((srbadev::k_lm_run_lean<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(SRBA_WG), c->cls_lds[k] + c->lds_pad, launch_stream, c->B, c->dp, J.first, J.count, c->d_next + j); HIPCHK(c, hipGetLastError()); continue; }
 		SRBA_DISPATCH_LDS(c, k_lm_run, J.grid, c->cls_lds[k] + c->lds_pad, J.first, J.count, c->d_next + j); HIPCHK(c, hipGetLastError());
 	}
 	// capsules too large for one wavefront's LDS: the multi-workgroup path, one capsule after the other on the context stream (host-driven LM loop: this part
