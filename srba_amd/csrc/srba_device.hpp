@@ -38,6 +38,7 @@ struct ProbDesc {
 	int n_fill; long long o_spfill; // blocks of the factor that no Hessian block maps onto (fill-in): the only ones the assembly has to zero
 	int n_need, need_flat; // pairs whose pose is re-evaluated inside the LM loop (pair_needed != 0); need_flat: all their paths have <= 4 edges (need_rec usable)
 	long long o_hap, o_hapoff, o_hapt, o_hf, o_hfoff, o_hft, o_hapf, o_hapfoff, o_hapft, o_sch, o_lmoff, o_req, o_scal, o_yw, o_dense, o_spcol, o_sprow, o_spitem, o_spperm;
+	int hapt_split; // two wavefronts per capsule: the second one takes the U_Ap terms from this index on (the first term of a Hessian block at or after the middle of the list: no block is summed by both)
 	int n_items, aligned; // block updates per factorisation; 1 if every Hessian block maps onto whole 3x3 blocks (always, except L==2 with the no-Schur solver)
 	int dense_in_lds, dense_blocks; // dense_blocks: the LDS image holds ALL blocks of the lower triangle (column-major), no symbolic structure (mid-size, nearly dense systems)
 };
@@ -184,6 +185,21 @@ __device__ __forceinline__ double wave_max(double v) { // operands are >= 0 here
 // One wavefront per capsule: "block" reductions are wave reductions; every lane gets the same result.
 __device__ __forceinline__ double block_sum(double v, double *) { return wave_sum(v); }
 __device__ __forceinline__ double block_max(double v, double *) { return wave_max(v); }
+// ---- capsule GROUPS (round 4): the lanes that work on one capsule. G = 64: one wavefront (every kernel of rounds 1-3). G = 128: TWO wavefronts per capsule (k_lm_run2: the big,
+// LDS-bound windows of a big batch -- their wavefronts sit alone on a SIMD and the launch waits for their latency: the lane-parallel phases go twice as wide, the block-sparse
+// solver stays on the first wavefront). Reductions over a group: per wavefront (DPP tree), then the two totals through two doubles of LDS (`red`) in a fixed order: deterministic.
+template <int G> __device__ __forceinline__ double grp_sum(double v, double *red) {
+	v = wave_sum(v);
+	if constexpr (G > 64) { if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v; __syncthreads(); v = red[0] + red[1]; __syncthreads(); }
+	return v;
+}
+template <int G> __device__ __forceinline__ double grp_max(double v, double *red) {
+	v = wave_max(v);
+	if constexpr (G > 64) { if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v; __syncthreads(); v = fmax(red[0], red[1]); __syncthreads(); }
+	return v;
+}
+// hand-off through LDS inside a phase: one wavefront needs no barrier (its LDS instructions execute in order), two do
+template <int G> __device__ __forceinline__ void grp_lds_sync() { if constexpr (G > 64) __syncthreads(); else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } }
 
 // ------------------------------------------------------------------------------------------------ full-pivot LU inverse (schur.h:200-206)
 // Every index below is a compile-time constant (the loops are fully unrolled and the pivot position acts through selects): the matrices stay in registers. With
@@ -582,8 +598,9 @@ __device__ __forceinline__ double *sp_elem(const SparseSys &S, int r, int c) {
 // ------------------------------------------------------------------------------------------------ the per-problem worker
 // LEAN (round 4): the instantiation for the small, wave-slot-bound size classes of a big batch -- fewer loads in flight per lane (pairs, Jacobian blocks, Hessian terms) so that the kernel
 // fits 168 registers and three wavefronts share a SIMD (k_lm_run_lean): the memory-level parallelism that the per-lane prefetches buy is bought with wavefronts instead. Same arithmetic.
-template <int FAM, bool LEAN = false>
+template <int FAM, bool LEAN = false, int G = 64>
 struct Worker {
+	static constexpr int GRP = G; // lanes per capsule (64, or 128 = two wavefronts)
 	typedef Tr<FAM> T; typedef PoseOps<T::SE3> PO; typedef typename PO::T pose_t;
 	static constexpr int P = T::P, L = T::L, O = T::O, PD = T::PD;
 	const Batch &B; const ProbDesc &d; const DevParams &prm; int tid;
@@ -616,11 +633,11 @@ struct Worker {
 		if (only_needed && d.need_flat) { // in-loop refresh: one flat record per pair -> two dependent memory levels (record, edges) instead of four
 			// (two copies of the loop, LDS source / HBM source: with the choice inside, the compiler merges the last load of both into a flat_load on a selected pointer)
 			auto refresh = [&](auto from_lds) { constexpr bool FROM_LDS = decltype(from_lds)::value;
-			for (int q0 = tid; q0 < d.n_need; q0 += V * SRBA_WG) {
+			for (int q0 = tid; q0 < d.n_need; q0 += V * G) {
 				int p[V], pe[V][4]; pose_t acc[V];
 #pragma unroll
 				for (int v = 0; v < V; v++) {
-					const int q = q0 + v * SRBA_WG; const int *rec = B.need_rec + (d.o_pair + (q < d.n_need ? q : 0)) * 5;
+					const int q = q0 + v * G; const int *rec = B.need_rec + (d.o_pair + (q < d.n_need ? q : 0)) * 5;
 					p[v] = q < d.n_need ? rec[0] : -1;
 #pragma unroll
 					for (int u = 0; u < 4; u++) pe[v][u] = q < d.n_need ? rec[1 + u] : -1;
@@ -655,10 +672,10 @@ struct Worker {
 			return;
 		}
 		const int cnt = only_needed ? d.n_need : d.n_pairs;
-		for (int q0 = tid; q0 < cnt; q0 += V * SRBA_WG) {
+		for (int q0 = tid; q0 < cnt; q0 += V * G) {
 			int p[V], pe[V][U], b[V], e[V]; pose_t ed[V][U], acc[V];
 #pragma unroll
-			for (int v = 0; v < V; v++) { const int q = q0 + v * SRBA_WG; p[v] = q < cnt ? (only_needed ? B.need_idx[d.o_pair + q] : q) : -1; }
+			for (int v = 0; v < V; v++) { const int q = q0 + v * G; p[v] = q < cnt ? (only_needed ? B.need_idx[d.o_pair + q] : q) : -1; }
 #pragma unroll
 			for (int v = 0; v < V; v++) { b[v] = e[v] = 0; if (p[v] >= 0) { b[v] = B.pair_path_off[d.o_ppoff + p[v]]; e[v] = B.pair_path_off[d.o_ppoff + p[v] + 1]; } }
 #pragma unroll
@@ -795,8 +812,8 @@ struct Worker {
 	}
 	__device__ __forceinline__ double phase_residuals(double *out, double *red) { fresh();
 		double acc = 0;
-		for (int i = tid; i < d.n_obs; i += 2 * SRBA_WG) { // two rows per lane and pass: both rows' loads are issued before either row's stores
-			double r0[O], r1[O]; const int j = i + SRBA_WG; const bool two = j < d.n_obs;
+		for (int i = tid; i < d.n_obs; i += 2 * G) { // two rows per lane and pass: both rows' loads are issued before either row's stores
+			double r0[O], r1[O]; const int j = i + G; const bool two = j < d.n_obs;
 			const double c0 = residual_row(i, r0); double c1 = 0; if (two) c1 = residual_row(j, r1);
 #pragma unroll
 			for (int k = 0; k < O; k++) out[(long long)(d.o_obs + i) * O + k] = r0[k];
@@ -806,7 +823,7 @@ struct Worker {
 			}
 			acc += c0; if (two) acc += c1;
 		}
-		return block_sum(acc, red);
+		return grp_sum<G>(acc, red);
 	}
 
 	// ---- K2
@@ -872,17 +889,17 @@ struct Worker {
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
 				const double v0 = i < 3 ? D.R[i] : D.t[0], v1 = i < 3 ? D.R[3 + i] : D.t[1], v2 = i < 3 ? D.R[6 + i] : D.t[2];
-				const double sk[9] = {0, -v2, v1, v2, 0, -v0, -v1, v0, 0}; double G[9];
+				const double sk[9] = {0, -v2, v1, v2, 0, -v0, -v1, v0, 0}; double Gm[9];
 #pragma unroll
 				for (int r = 0; r < 3; r++)
 #pragma unroll
-					for (int q = 0; q < 3; q++) G[3 * r + q] = -(RA[3 * r] * sk[q] + RA[3 * r + 1] * sk[3 + q] + RA[3 * r + 2] * sk[6 + q]);
+					for (int q = 0; q < 3; q++) Gm[3 * r + q] = -(RA[3 * r] * sk[q] + RA[3 * r + 1] * sk[3 + q] + RA[3 * r + 2] * sk[6 + q]);
 				if (i < 3) {
 #pragma unroll
 					for (int m = 0; m < 3; m++)
 #pragma unroll
-						for (int q = 0; q < 3; q++) Jr[3 * m + q] += M[9 * m + 3 * i] * G[q] + M[9 * m + 3 * i + 1] * G[3 + q] + M[9 * m + 3 * i + 2] * G[6 + q];
-				} else for (int k = 0; k < 9; k++) Gt[k] = G[k];
+						for (int q = 0; q < 3; q++) Jr[3 * m + q] += M[9 * m + 3 * i] * Gm[q] + M[9 * m + 3 * i + 1] * Gm[3 + q] + M[9 * m + 3 * i + 2] * Gm[6 + q];
+				} else for (int k = 0; k < 9; k++) Gt[k] = Gm[k];
 			}
 			const double sg = normal ? 1.0 : -1.0;
 #pragma unroll
@@ -958,18 +975,18 @@ struct Worker {
 	}
 	// Jacobians of all blocks + validity semantics of jacobians.h:215-216,321-327 (see DESIGN.md "invalid rows")
 	__device__ __forceinline__ void phase_jacobians() { fresh();
-		for (int i = tid; i < d.n_valid; i += SRBA_WG) { B.valid[d.o_valid + i] = 1; B.first_fail[d.o_valid + i] = 0x7fffffff; }
+		for (int i = tid; i < d.n_valid; i += G) { B.valid[d.o_valid + i] = 1; B.first_fail[d.o_valid + i] = 0x7fffffff; }
 		__syncthreads();
-		for (int b = tid; b < d.n_bp; b += SRBA_WG) jac_dh_dp(b);
-		for (int b = tid; b < d.n_bf; b += SRBA_WG) jac_dh_df(b);
+		for (int b = tid; b < d.n_bp; b += G) jac_dh_dp(b);
+		for (int b = tid; b < d.n_bf; b += G) jac_dh_df(b);
 		__syncthreads();
-		for (int i = tid; i < d.n_valid; i += SRBA_WG) if (B.first_fail[d.o_valid + i] != 0x7fffffff) B.valid[d.o_valid + i] = 0;
+		for (int i = tid; i < d.n_valid; i += G) if (B.first_fail[d.o_valid + i] != 0x7fffffff) B.valid[d.o_valid + i] = 0;
 		// the first failing block of a row (in sweep order) is zeroed; later ones keep stale values
-		for (int b = tid; b < d.n_bp; b += SRBA_WG) {
+		for (int b = tid; b < d.n_bp; b += G) {
 			const int ff = B.first_fail[d.o_valid + B.obs_valid[d.o_obs + B.bp_res[d.o_bp + b]]]; B.bp_ok[d.o_bp + b] = (ff == 0x7fffffff);
 			if (ff == b) { double *J = B.Jp + (long long)(d.o_bp + b) * O * P; for (int k = 0; k < O * P; k++) J[k] = 0; }
 		}
-		for (int b = tid; b < d.n_bf; b += SRBA_WG) {
+		for (int b = tid; b < d.n_bf; b += G) {
 			const int ff = B.first_fail[d.o_valid + B.obs_valid[d.o_obs + B.bf_res[d.o_bf + b]]]; B.bf_ok[d.o_bf + b] = (ff == 0x7fffffff);
 			if (ff == d.n_bp + b) { double *J = B.Jf + (long long)(d.o_bf + b) * O * L; for (int k = 0; k < O * L; k++) J[k] = 0; }
 		}
@@ -1028,15 +1045,15 @@ struct Worker {
 		const double *Jp = B.Jp + d.o_bp * O * P, *Jf = B.Jf + d.o_bf * O * L;
 		const unsigned char *rp = B.bp_ok + d.o_bp, *rf = B.bf_ok + d.o_bf;
 		const bool latch = prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL;
-		for (int bi = tid; bi < d.n_hap; bi += SRBA_WG) {
+		for (int bi = tid; bi < d.n_hap; bi += G) {
 			const int *rec = B.hap_rec + (d.o_hap + bi) * 3; const int b = rec[0]; const long long g = d.o_hap + b; // {block, first term, end term}: longest lists first
 			// the Schur complement works on HAp in place and restores it from the latch for every lambda (schur.h:38,165-168,188)
 			ninv += hess_block<P, P>(B.HAp + g * P * P, latch ? B.HAp0 + g * P * P : nullptr, B.hap_t1 + d.o_hapt, B.hap_t2 + d.o_hapt, rec[1], rec[2], Jp, Jp, rp, rp);
 		}
 		if constexpr (!T::REL) {
-			for (int b = tid; b < d.n_hf; b += SRBA_WG)
+			for (int b = tid; b < d.n_hf; b += G)
 				ninv += hess_block<L, L>(B.Hf + (d.o_hf + b) * L * L, nullptr, B.hf_t1 + d.o_hft, B.hf_t2 + d.o_hft, B.hf_term_off[d.o_hfoff + b], B.hf_term_off[d.o_hfoff + b + 1], Jf, Jf, rf, rf);
-			for (int b = tid; b < d.n_hapf; b += SRBA_WG)
+			for (int b = tid; b < d.n_hapf; b += G)
 				ninv += hess_block<P, L>(B.HApf + (d.o_hapf + b) * P * L, nullptr, B.hapf_t1 + d.o_hapft, B.hapf_t2 + d.o_hapft, B.hapf_term_off[d.o_hapfoff + b], B.hapf_term_off[d.o_hapfoff + b + 1], Jp, Jf, rp, rf);
 		}
 		return ninv;
@@ -1049,11 +1066,13 @@ struct Worker {
 	// acc: n_hap * P * P doubles of LDS. Returns the per-lane count of skipped terms.
 	__device__ __forceinline__ int phase_hessian_terms(double *acc) { fresh();
 		const int n_acc = d.n_hap * P * P, n_terms = B.hap_term_off[d.o_hapoff + d.n_hap];
-		for (int k = tid; k < n_acc; k += SRBA_WG) acc[k] = 0;
-		solver_sync();
+		for (int k = tid; k < n_acc; k += G) acc[k] = 0;
+		grp_lds_sync<G>();
 		const double *Jp = B.Jp + d.o_bp * O * P; const unsigned char *rp = B.bp_ok + d.o_bp; const int *t1 = B.hap_t1 + d.o_hapt, *t2 = B.hap_t2 + d.o_hapt, *tb = B.hap_tblk + d.o_hapt;
 		int ninv = 0;
-		for (int t = tid; t < n_terms; t += SRBA_WG) {
+		// (two wavefronts: each takes a contiguous part of the list, cut between two Hessian blocks -- the additions into one accumulator all come from one wavefront, in program order)
+		const int t_first = G > 64 ? ((threadIdx.x >> 6) ? d.hapt_split : 0) + (tid & 63) : tid, t_end = (G > 64 && !(threadIdx.x >> 6)) ? d.hapt_split : n_terms, t_step = G > 64 ? 64 : G;
+		for (int t = t_first; t < t_end; t += t_step) {
 			const int b1 = t1[t], b2 = t2[t], blk = tb[t];
 			double A[O * P], Bm[O * P]; ldn<O * P>(A, Jp + (long long)b1 * O * P); ldn<O * P>(Bm, Jp + (long long)b2 * O * P);
 			if (rp[b1] && rp[b2]) {
@@ -1066,10 +1085,10 @@ struct Worker {
 				for (int k = 0; k < P * P; k++) atomicAdd(dst + k, H[k]);
 			} else ninv++;
 		}
-		solver_sync();
+		grp_lds_sync<G>();
 		const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0; const bool latch = prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL;
 		double *Hg = B.HAp + d.o_hap * P * P, *H0 = B.HAp0 + d.o_hap * P * P;
-		for (int k = 2 * tid; k < n_acc; k += 2 * SRBA_WG) { // n_acc is a multiple of 9 or 36; an odd tail is a single double
+		for (int k = 2 * tid; k < n_acc; k += 2 * G) { // n_acc is a multiple of 9 or 36; an odd tail is a single double
 			if (k + 1 < n_acc) { f64x2u v; v.x = acc[k] * sc; v.y = acc[k + 1] * sc; *(f64x2u *)(Hg + k) = v; if (latch) *(f64x2u *)(H0 + k) = v; }
 			else { const double v = acc[k] * sc; Hg[k] = v; if (latch) H0[k] = v; }
 		}
@@ -1080,9 +1099,9 @@ struct Worker {
 		int ninv = 0;
 		if constexpr (!T::REL) {
 			const double *Jp = B.Jp + d.o_bp * O * P, *Jf = B.Jf + d.o_bf * O * L; const unsigned char *rp = B.bp_ok + d.o_bp, *rf = B.bf_ok + d.o_bf;
-			for (int b = tid; b < d.n_hf; b += SRBA_WG)
+			for (int b = tid; b < d.n_hf; b += G)
 				ninv += hess_block<L, L>(B.Hf + (d.o_hf + b) * L * L, nullptr, B.hf_t1 + d.o_hft, B.hf_t2 + d.o_hft, B.hf_term_off[d.o_hfoff + b], B.hf_term_off[d.o_hfoff + b + 1], Jf, Jf, rf, rf);
-			for (int b = tid; b < d.n_hapf; b += SRBA_WG)
+			for (int b = tid; b < d.n_hapf; b += G)
 				ninv += hess_block<P, L>(B.HApf + (d.o_hapf + b) * P * L, nullptr, B.hapf_t1 + d.o_hapft, B.hapf_t2 + d.o_hapft, B.hapf_term_off[d.o_hapfoff + b], B.hapf_term_off[d.o_hapfoff + b + 1], Jp, Jf, rp, rf);
 		}
 		return ninv;
@@ -1094,8 +1113,8 @@ struct Worker {
 	__device__ __forceinline__ void grad_cols(double *g, int ncol, const double *J, const int *res, const int *col_off, const double *resid) {
 		// lanes per column: 8 while a single pass covers all columns, else 4 -- ceil(4*ncol/64) quarter-length passes beat ceil(ncol/64) full-length ones
 		// whenever ncol is not a multiple of 64 (67 columns: 1.25 instead of 2 column-times)
-		const int S = 8 * ncol <= SRBA_WG ? 8 : 4;
-		const int per = SRBA_WG / S, sub = tid % S;
+		const int S = 8 * ncol <= G ? 8 : 4;
+		const int per = G / S, sub = tid % S;
 		const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0;
 		for (int base = 0; base < ncol; base += per) {
 			const int i = base + tid / S; const bool live = i < ncol;
@@ -1145,9 +1164,9 @@ struct Worker {
 	}
 	__device__ __forceinline__ double lambda_guess(double *red) { fresh(); // optimize_edges.h:366-390
 		double mx = 0;
-		for (int i = tid; i < d.nK; i += SRBA_WG) { const double *H = B.HAp + (d.o_hap + B.hap_diag[d.o_unk + i]) * P * P; double m = H[0]; for (int k = 1; k < P; k++) m = fmax(m, H[k * P + k]); mx = fmax(mx, m); }
-		if constexpr (!T::REL) for (int i = tid; i < d.nF; i += SRBA_WG) { const double *H = B.Hf + (d.o_hf + B.hf_diag[d.o_ulm + i]) * L * L; double m = H[0]; for (int k = 1; k < L; k++) m = fmax(m, H[k * L + k]); mx = fmax(mx, m); }
-		return 1e-3 * block_max(mx, red);
+		for (int i = tid; i < d.nK; i += G) { const double *H = B.HAp + (d.o_hap + B.hap_diag[d.o_unk + i]) * P * P; double m = H[0]; for (int k = 1; k < P; k++) m = fmax(m, H[k * P + k]); mx = fmax(mx, m); }
+		if constexpr (!T::REL) for (int i = tid; i < d.nF; i += G) { const double *H = B.Hf + (d.o_hf + B.hf_diag[d.o_ulm + i]) * L * L; double m = H[0]; for (int k = 1; k < L; k++) m = fmax(m, H[k * L + k]); mx = fmax(mx, m); }
+		return 1e-3 * grp_max<G>(mx, red);
 	}
 };
 

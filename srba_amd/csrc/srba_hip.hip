@@ -35,17 +35,18 @@ extern __shared__ double srba_lds[]; // block-sparse system of the capsule (diag
 // (LDS operands are addressed from this symbol where it matters: a pointer that went through SparseSys -- whose numbers may live in HBM -- is a generic pointer, and
 //  its loads become flat_load instead of ds_read)
 
-template <int FAM, bool LEAN = false>
-struct Solver : public Worker<FAM, LEAN> {
-	typedef Worker<FAM, LEAN> W; using W::B; using W::d; using W::prm; using W::tid;
+template <int FAM, bool LEAN = false, int G = 64>
+struct Solver : public Worker<FAM, LEAN, G> {
+	typedef Worker<FAM, LEAN, G> W; using W::B; using W::d; using W::prm; using W::tid;
 	static constexpr int P = W::P, L = W::L, O = W::O, PD = W::PD;
-	__device__ Solver(const Batch &B_, const ProbDesc &d_, const DevParams &p_) : W(B_, d_, p_) {}
+	double *red2w = nullptr; // G = 128: two doubles of LDS behind the image (group reductions, the solver's verdict)
+	__device__ Solver(const Batch &B_, const ProbDesc &d_, const DevParams &p_, double *red_ = nullptr) : W(B_, d_, p_), red2w(red_) {}
 	__device__ __forceinline__ bool schur_active() const { return prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0; }
 
 	// K7 + K8 (schur.h:180-268). Mutates HAp and minus_grad in place like the reference.
 	__device__ __forceinline__ void schur_reduce(double lambda, long long *pc = nullptr) { this->fresh(); long long tq = pc ? wall_clock64() : 0;
 		if constexpr (!W::T::REL) {
-			for (int l = tid; l < d.nF; l += SRBA_WG) {
+			for (int l = tid; l < d.nF; l += G) {
 				double M[L * L], Mi[L * L]; const double *src = B.Hf + (d.o_hf + B.hf_diag[d.o_ulm + l]) * L * L;
 				for (int k = 0; k < L * L; k++) M[k] = src[k];
 				for (int k = 0; k < L; k++) M[k * L + k] += lambda;
@@ -53,7 +54,7 @@ struct Solver : public Worker<FAM, LEAN> {
 				B.hf_ok[d.o_ulm + l] = ok ? 1 : 0;
 				if (ok) for (int k = 0; k < L * L; k++) B.Hfinv[(d.o_ulm + l) * L * L + k] = Mi[k];
 			}
-			for (int k = tid; k < d.n_hap * P * P; k += SRBA_WG) B.HAp[d.o_hap * P * P + k] = B.HAp0[d.o_hap * P * P + k];
+			for (int k = tid; k < d.n_hap * P * P; k += G) B.HAp[d.o_hap * P * P + k] = B.HAp0[d.o_hap * P * P + k];
 			__syncthreads();
 			if (pc) { if (tid == 0) pc[14] += wall_clock64() - tq; tq = wall_clock64(); }
 			// Balanced over the lanes: the flat term list of the capsule (sorted by U_Ap block) is cut into 64 equal runs, one per lane. A lane keeps the running block in
@@ -62,7 +63,7 @@ struct Solver : public Worker<FAM, LEAN> {
 			// carry the gradient correction g_i -= Y_t g_l (K8), which used to be a third sweep over Y stored in HBM by this one.
 			double *g = B.grad + d.o_scal; const double *gf = g + d.nK * P;
 			{
-				const int T = B.sch_term_off[d.o_hapoff + d.n_hap], per = (T + SRBA_WG - 1) / SRBA_WG, tb = tid * per, te = min(T, tb + per);
+				const int T = B.sch_term_off[d.o_hapoff + d.n_hap], per = (T + G - 1) / G, tb = tid * per, te = min(T, tb + per);
 				const int *s_lm = B.sch_lm + d.o_sch, *s_b1 = B.sch_b1 + d.o_sch, *s_b2 = B.sch_b2 + d.o_sch, *s_yw = B.sch_yw + d.o_sch, *s_blk = B.sch_tblk + d.o_sch;
 				int cur = -1; bool curdiag = false; double Hl[P * P], ga[P];
 				auto flush = [&]() {
@@ -124,7 +125,7 @@ struct Solver : public Worker<FAM, LEAN> {
 	__device__ __forceinline__ void schur_features() { this->fresh();
 		if constexpr (!W::T::REL) {
 			double *g = B.grad + d.o_scal, *dl = B.delta + d.o_scal;
-			for (int l = tid; l < d.nF; l += SRBA_WG) {
+			for (int l = tid; l < d.nF; l += G) {
 				if (!B.hf_ok[d.o_ulm + l]) continue;
 				double gl[L]; for (int k = 0; k < L; k++) gl[k] = g[d.nK * P + l * L + k];
 				for (int q = B.lm_hapf_off[d.o_lmoff + l]; q < B.lm_hapf_off[d.o_lmoff + l + 1]; q++) {
@@ -179,19 +180,19 @@ struct Solver : public Worker<FAM, LEAN> {
 	__device__ __forceinline__ void assemble(const SparseSys &S, double lambda) { this->fresh();
 		const int n = d.n_sys, nb = d.nb;
 		if (d.aligned) { // every block is overwritten whole by put_block below, except the fill-in blocks (listed by the host): zero only those
-			for (int i = tid; i < d.n_fill; i += SRBA_WG) { double *o = S.diag + 9 * B.sp_fill[d.o_spfill + i];
+			for (int i = tid; i < d.n_fill; i += G) { double *o = S.diag + 9 * B.sp_fill[d.o_spfill + i];
 #pragma unroll
 				for (int q = 0; q < 9; q++) o[q] = 0; }
 		} else {
-			for (int k = tid; k < 9 * nb; k += SRBA_WG) S.diag[k] = 0;
-			for (int k = tid; k < 9 * S.nnzoff; k += SRBA_WG) S.off[k] = 0;
+			for (int k = tid; k < 9 * nb; k += G) S.diag[k] = 0;
+			for (int k = tid; k < 9 * S.nnzoff; k += G) S.off[k] = 0;
 		}
 		const double *g = B.grad + d.o_scal;
-		for (int k = tid; k < 3 * nb; k += SRBA_WG) S.rhs[3 * S.perm[k / 3] + k % 3] = (k < n) ? g[k] : 0.0;
+		for (int k = tid; k < 3 * nb; k += G) S.rhs[3 * S.perm[k / 3] + k % 3] = (k < n) ? g[k] : 0.0;
 		__syncthreads();
 		constexpr int PB = P / 3;
 		// one lane per aligned 3x3 sub-block: its 9 loads are in flight together (one memory round trip per pass instead of one per element)
-		for (int sb = tid; sb < d.n_hap * PB * PB; sb += SRBA_WG) {
+		for (int sb = tid; sb < d.n_hap * PB * PB; sb += G) {
 			const int dst = B.hap_dst[d.o_hap * PB * PB + sb]; if (dst == (int)0x80000000) continue;
 			const int b = sb / (PB * PB), si = (sb / PB) % PB, sj = sb % PB;
 			put_block<P>(S, dst, B.HAp + (d.o_hap + b) * P * P + si * 3 * P + sj * 3, lambda);
@@ -200,28 +201,28 @@ struct Solver : public Worker<FAM, LEAN> {
 			const int base = P * d.nK;
 			if (d.aligned) {
 				if constexpr (L == 3) {
-					for (int sb = tid; sb < d.n_hapf * PB; sb += SRBA_WG) {
+					for (int sb = tid; sb < d.n_hapf * PB; sb += G) {
 						const int dst = B.hapf_dst[d.o_hapf * PB + sb]; if (dst == (int)0x80000000) continue;
 						put_block<L>(S, dst, B.HApf + (d.o_hapf + sb / PB) * P * L + (sb % PB) * 3 * L, 0.0);
 					}
-					for (int b = tid; b < d.n_hf; b += SRBA_WG) {
+					for (int b = tid; b < d.n_hf; b += G) {
 						const int dst = B.hf_dst[d.o_hf + b]; if (dst == (int)0x80000000) continue;
 						put_block<L>(S, dst, B.Hf + (d.o_hf + b) * L * L, lambda);
 					}
 				}
 			} else { // landmark blocks straddle 3x3 block boundaries (L == 2): generic per-element placement
-				for (int e = tid; e < d.n_hapf * P * L; e += SRBA_WG) {
+				for (int e = tid; e < d.n_hapf * P * L; e += G) {
 					const int b = e / (P * L), r = (e / L) % P, q = e % L;
 					put(S, P * B.hapf_i[d.o_hapf + b] + r, base + L * B.hapf_j[d.o_hapf + b] + q, B.HApf[(d.o_hapf + b) * P * L + r * L + q]);
 				}
-				for (int e = tid; e < d.n_hf * L * L; e += SRBA_WG) {
+				for (int e = tid; e < d.n_hf * L * L; e += G) {
 					const int b = e / (L * L), r = (e / L) % L, q = e % L; const int i = B.hf_i[d.o_hf + b], j = B.hf_j[d.o_hf + b];
 					if (i == j && r > q) continue;
 					put(S, base + L * i + r, base + L * j + q, B.Hf[(d.o_hf + b) * L * L + r * L + q] + ((i == j && r == q) ? lambda : 0.0));
 				}
 			}
 		}
-		for (int k = n + tid; k < 3 * nb; k += SRBA_WG) S.diag[9 * S.perm[k / 3] + 4 * (k % 3)] = 1.0; // identity padding
+		for (int k = n + tid; k < 3 * nb; k += G) S.diag[9 * S.perm[k / 3] + 4 * (k % 3)] = 1.0; // identity padding
 		__syncthreads();
 	}
 	// solve(lambda): returns false if not positive definite (uniform across the wavefront)
@@ -230,16 +231,20 @@ struct Solver : public Worker<FAM, LEAN> {
 #define STIC() do { if (pc) { __syncthreads(); t0 = wall_clock64(); } } while (0)
 #define STOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - t0; } } while (0)
 		if (schur_active() && (prm.ext & SRBA_EXT_SCHUR_KEEPS_GRADIENT)) { // (extension, default off) every solve starts from the gradient K5 produced: same lane -> same elements as keep_gradient()
-			double *g = B.grad + d.o_scal; const double *g0 = B.grad0 + d.o_scal; for (int k = tid; k < d.n_scal; k += SRBA_WG) g[k] = g0[k]; __syncthreads(); }
+			double *g = B.grad + d.o_scal; const double *g0 = B.grad0 + d.o_scal; for (int k = tid; k < d.n_scal; k += G) g[k] = g0[k]; __syncthreads(); }
 		STIC(); if (schur_active()) schur_reduce(lambda, pc); STOC(9);
 		STIC(); assemble(S, lambda); STOC(10);
 		// (the dense block layouts are never chosen for the relative-pose families -- srba_hip_upload_problems -- whose kernels therefore carry the sparse solver only: the
 		//  headline kernel sits 22 VGPRs below the two-wavefronts-per-SIMD limit)
-		STIC(); bool ok; if constexpr (W::T::REL || !W::T::SE3) ok = sp_factor_fsub_rows(S); else ok = d.dense_blocks == 2 ? (S.row_lds ? sp_factor_fsub_dense_left(S, (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16), (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16 + 18 * S.nb)) : sp_factor_fsub_dense<true>(S)) : (S.dense ? sp_factor_fsub_dense<false>(S) : sp_factor_fsub_rows(S)); STOC(11);
+		STIC(); bool ok;
+		if constexpr (G > 64) { // two wavefronts per capsule (sparse layout only): the first one factors and substitutes, the verdict travels through the reduction scratch behind the image
+			int *flag = (int *)red2w; if (threadIdx.x < 64) { const bool k1 = sp_factor_fsub_rows(S); if (k1) sp_bsub_rows(S); if (threadIdx.x == 0) *flag = k1 ? 1 : 0; }
+			__syncthreads(); ok = *flag != 0; __syncthreads();
+		} else if constexpr (W::T::REL || !W::T::SE3) ok = sp_factor_fsub_rows(S); else ok = d.dense_blocks == 2 ? (S.row_lds ? sp_factor_fsub_dense_left(S, (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16), (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16 + 18 * S.nb)) : sp_factor_fsub_dense<true>(S)) : (S.dense ? sp_factor_fsub_dense<false>(S) : sp_factor_fsub_rows(S)); STOC(11);
 		if (!ok) return false;
-		STIC(); if constexpr (W::T::REL || !W::T::SE3) sp_bsub_rows(S); else { if (d.dense_blocks == 2) { if (S.row_lds) sp_bsub_dense_left(S, (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16 + 18 * S.nb)); else sp_bsub_dense<true>(S); } else if (S.dense) sp_bsub_dense<false>(S); else sp_bsub_rows(S); }
+		STIC(); if constexpr (G > 64) { /* done above */ } else if constexpr (W::T::REL || !W::T::SE3) sp_bsub_rows(S); else { if (d.dense_blocks == 2) { if (S.row_lds) sp_bsub_dense_left(S, (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16 + 18 * S.nb)); else sp_bsub_dense<true>(S); } else if (S.dense) sp_bsub_dense<false>(S); else sp_bsub_rows(S); }
 		double *dl = B.delta + d.o_scal;
-		for (int k = tid; k < d.n_scal; k += SRBA_WG) dl[k] = (k < d.n_sys) ? S.rhs[3 * S.perm[k / 3] + k % 3] : 0.0;
+		for (int k = tid; k < d.n_scal; k += G) dl[k] = (k < d.n_sys) ? S.rhs[3 * S.perm[k / 3] + k % 3] : 0.0;
 		__syncthreads(); STOC(12);
 		STIC(); if (schur_active()) schur_features(); STOC(13);
 		return true;
@@ -247,7 +252,7 @@ struct Solver : public Worker<FAM, LEAN> {
 #undef STOC
 	}
 	__device__ __forceinline__ void keep_gradient() { // call after phase_gradient + barrier
-		if (schur_active() && (prm.ext & SRBA_EXT_SCHUR_KEEPS_GRADIENT)) { const double *g = B.grad + d.o_scal; double *g0 = B.grad0 + d.o_scal; for (int k = tid; k < d.n_scal; k += SRBA_WG) g0[k] = g[k]; }
+		if (schur_active() && (prm.ext & SRBA_EXT_SCHUR_KEEPS_GRADIENT)) { const double *g = B.grad + d.o_scal; double *g0 = B.grad0 + d.o_scal; for (int k = tid; k < d.n_scal; k += G) g0[k] = g[k]; }
 	}
 	__device__ __forceinline__ SparseSys make_sys(double *lds) const {
 		SparseSys S; S.nb = d.nb; S.nnzoff = d.nnzoff; S.dense = (W::T::REL || !W::T::SE3) ? 0 : d.dense_blocks;
@@ -258,15 +263,15 @@ struct Solver : public Worker<FAM, LEAN> {
 		S.diag = base; S.off = base + 9 * d.nb; S.rhs = S.off + 9 * d.nnzoff;
 		if (S.dense) { // numbers only: every index of the dense block layout is arithmetic; the block permutation is the one table kept
 			int *p0 = d.dense_blocks == 2 ? (int *)lds : (int *)(S.rhs + 3 * d.nb);
-			for (int k = tid; k < d.nb; k += SRBA_WG) p0[k] = S.perm[k];
+			for (int k = tid; k < d.nb; k += G) p0[k] = S.perm[k];
 			S.perm = p0; S.col_off = S.row = S.item = S.rptr = S.rent = nullptr;
 			__syncthreads();
 		} else { // symbolic structure next to the numbers (packed): the factorisation's dependent index loads hit LDS, not L2
 			int *ip = (int *)(S.rhs + 3 * d.nb); int *c0 = ip, *rp0 = c0 + d.nb + 1, *p0 = rp0 + d.nb + 1, *r0 = p0 + d.nb, *re0 = r0 + d.nnzoff, *t0 = re0 + d.nnzoff;
-			for (int k = tid; k <= d.nb; k += SRBA_WG) { c0[k] = S.col_off[k]; rp0[k] = S.rptr[k]; }
-			for (int k = tid; k < d.nb; k += SRBA_WG) p0[k] = S.perm[k];
-			for (int k = tid; k < d.nnzoff; k += SRBA_WG) { r0[k] = S.row[k]; re0[k] = S.rent[k]; } // (the item / row-view words were packed at upload)
-			for (int k = tid; k < d.n_items; k += SRBA_WG) t0[k] = S.item[k];
+			for (int k = tid; k <= d.nb; k += G) { c0[k] = S.col_off[k]; rp0[k] = S.rptr[k]; }
+			for (int k = tid; k < d.nb; k += G) p0[k] = S.perm[k];
+			for (int k = tid; k < d.nnzoff; k += G) { r0[k] = S.row[k]; re0[k] = S.rent[k]; } // (the item / row-view words were packed at upload)
+			for (int k = tid; k < d.n_items; k += G) t0[k] = S.item[k];
 			S.col_off = c0; S.rptr = rp0; S.perm = p0; S.row = r0; S.rent = re0; S.item = t0;
 			__syncthreads();
 		}
@@ -277,15 +282,15 @@ struct Solver : public Worker<FAM, LEAN> {
 	__device__ __forceinline__ void apply_update() { this->fresh();
 		typedef typename W::PO PO;
 		const double *dl = B.delta + d.o_scal;
-		for (int i = tid; i < d.nK; i += SRBA_WG) {
+		for (int i = tid; i < d.nK; i += G) {
 			double *e = B.edge + (d.o_edge + i) * PD, *o = B.old_edge + (d.o_unk + i) * PD;
 			for (int k = 0; k < PD; k++) o[k] = e[k];
 			const typename W::pose_t np = comp(PO::expm(dl + i * P), PO::ld(e));
 			PO::st(e, np);
 		}
-		for (int k = tid; k < d.nF * L; k += SRBA_WG) { B.old_ulm[d.o_ulm * L + k] = B.ulm[d.o_ulm * L + k]; B.ulm[d.o_ulm * L + k] += dl[d.nK * P + k]; }
-		for (int r = tid; r < d.n_req; r += 2 * SRBA_WG) { // two poses per lane and pass: both loads before the stores
-			const int r2 = r + SRBA_WG; const bool two = r2 < d.n_req;
+		for (int k = tid; k < d.nF * L; k += G) { B.old_ulm[d.o_ulm * L + k] = B.ulm[d.o_ulm * L + k]; B.ulm[d.o_ulm * L + k] += dl[d.nK * P + k]; }
+		for (int r = tid; r < d.n_req; r += 2 * G) { // two poses per lane and pass: both loads before the stores
+			const int r2 = r + G; const bool two = r2 < d.n_req;
 			const double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD, *s2 = two ? B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r2]) * PD : s;
 			double v[PD], v2[PD];
 #pragma unroll
@@ -306,7 +311,7 @@ struct Solver : public Worker<FAM, LEAN> {
 		typedef typename W::PO PO; typedef typename W::pose_t pose_t;
 		const double *dl = B.delta + d.o_scal;
 		const bool stage = d.dense_in_lds && d.n_edges * PD <= 9 * S.nnzoff; double *el = S.off;
-		for (int i = tid; i < (stage ? d.n_edges : d.nK); i += SRBA_WG) {
+		for (int i = tid; i < (stage ? d.n_edges : d.nK); i += G) {
 			double *e = B.edge + (d.o_edge + i) * PD; pose_t cur = PO::ld(e);
 			if (i < d.nK) {
 				double inc[P];
@@ -320,9 +325,9 @@ struct Solver : public Worker<FAM, LEAN> {
 #pragma unroll
 				for (int k = 0; k < PD; k++) el[i * PD + k] = t[k]; }
 		}
-		for (int k = tid; k < d.nF * L; k += SRBA_WG) { B.old_ulm[d.o_ulm * L + k] = B.ulm[d.o_ulm * L + k]; B.ulm[d.o_ulm * L + k] += dl[d.nK * P + k]; }
-		for (int r = tid; r < d.n_req; r += 2 * SRBA_WG) { // two poses per lane and pass: both loads before the stores
-			const int r2 = r + SRBA_WG; const bool two = r2 < d.n_req;
+		for (int k = tid; k < d.nF * L; k += G) { B.old_ulm[d.o_ulm * L + k] = B.ulm[d.o_ulm * L + k]; B.ulm[d.o_ulm * L + k] += dl[d.nK * P + k]; }
+		for (int r = tid; r < d.n_req; r += 2 * G) { // two poses per lane and pass: both loads before the stores
+			const int r2 = r + G; const bool two = r2 < d.n_req;
 			const double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD, *s2 = two ? B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r2]) * PD : s;
 			double v[PD], v2[PD]; ldn<PD>(v, s); ldn<PD>(v2, s2);
 			stn<PD>(B.old_pose + (d.o_req + r) * PD, v);
@@ -330,7 +335,7 @@ struct Solver : public Worker<FAM, LEAN> {
 		}
 		// with the staged copy the refresh that follows reads LDS only, and nothing reads the arrays written here before the next full barrier (end of that refresh):
 		// the hand-off is an LDS one (no wait for the global stores to be acknowledged)
-		if (stage) solver_sync(); else __syncthreads();
+		if (stage) grp_lds_sync<G>(); else __syncthreads();
 		return stage ? el : nullptr;
 	}
 	// K11 for the double-buffered loop: the trial unknowns exp(delta) (+) edge, lm + delta go to the OTHER copy (Bt), nothing is backed up (a rejected trial simply leaves the
@@ -340,7 +345,7 @@ struct Solver : public Worker<FAM, LEAN> {
 		typedef typename W::PO PO; typedef typename W::pose_t pose_t;
 		const double *dl = B.delta + d.o_scal;
 		const bool stage = d.dense_in_lds && d.n_edges * PD <= 9 * S.nnzoff; double *el = S.off;
-		for (int i = tid; i < (stage ? d.n_edges : d.nK); i += SRBA_WG) {
+		for (int i = tid; i < (stage ? d.n_edges : d.nK); i += G) {
 			pose_t cur = PO::ld(B.edge + (d.o_edge + i) * PD);
 			if (i < d.nK) {
 				double inc[P];
@@ -353,14 +358,14 @@ struct Solver : public Worker<FAM, LEAN> {
 #pragma unroll
 				for (int k = 0; k < PD; k++) el[i * PD + k] = t[k]; }
 		}
-		for (int k = tid; k < d.nF * L; k += SRBA_WG) Bt.ulm[d.o_ulm * L + k] = B.ulm[d.o_ulm * L + k] + dl[d.nK * P + k];
-		if (stage) solver_sync(); else __syncthreads();
+		for (int k = tid; k < d.nF * L; k += G) Bt.ulm[d.o_ulm * L + k] = B.ulm[d.o_ulm * L + k] + dl[d.nK * P + k];
+		if (stage) grp_lds_sync<G>(); else __syncthreads();
 		return stage ? el : nullptr;
 	}
 	__device__ __forceinline__ void restore() { this->fresh(); // optimize_edges.h:664-680
-		for (int i = tid; i < d.nK * PD; i += SRBA_WG) B.edge[d.o_edge * PD + i] = B.old_edge[d.o_unk * PD + i];
-		for (int k = tid; k < d.nF * L; k += SRBA_WG) B.ulm[d.o_ulm * L + k] = B.old_ulm[d.o_ulm * L + k];
-		for (int r = tid; r < d.n_req; r += SRBA_WG) { double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD; const double *o = B.old_pose + (d.o_req + r) * PD; for (int k = 0; k < PD; k++) s[k] = o[k]; }
+		for (int i = tid; i < d.nK * PD; i += G) B.edge[d.o_edge * PD + i] = B.old_edge[d.o_unk * PD + i];
+		for (int k = tid; k < d.nF * L; k += G) B.ulm[d.o_ulm * L + k] = B.old_ulm[d.o_ulm * L + k];
+		for (int r = tid; r < d.n_req; r += G) { double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD; const double *o = B.old_pose + (d.o_req + r) * PD; for (int k = 0; k < PD; k++) s[k] = o[k]; }
 		__syncthreads();
 	}
 };
@@ -374,14 +379,13 @@ struct Solver : public Worker<FAM, LEAN> {
 #ifndef SRBA_LM_DB
 #define SRBA_LM_DB 1   /* the fused loop keeps two copies of the unknowns and of the spanning-tree poses (trial -> the other copy, accept = flip) instead of backup / restore */
 #endif
-template <int FAM, bool DB = (SRBA_LM_DB != 0), bool LEAN = false>
-__device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, const int pidx) {
+template <int FAM, bool DB = (SRBA_LM_DB != 0), bool LEAN = false, int G = 64>
+__device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, const int pidx, double *red = nullptr /* G = 128: LDS scratch of the group reductions */) {
 	const ProbDesc &d = B0.desc[pidx];
 	const Batch &B = B0;
 	int cur = 0, last_rej = 0; // DB: which copy holds the accepted state; the last evaluated trial was rejected
-	Solver<FAM, LEAN> S(B, d, prm);
-	constexpr int P = Solver<FAM, LEAN>::P, L = Solver<FAM, LEAN>::L, O = Solver<FAM, LEAN>::O;
-	double *red = nullptr;
+	Solver<FAM, LEAN, G> S(B, d, prm, red);
+	constexpr int P = Solver<FAM, LEAN, G>::P, L = Solver<FAM, LEAN, G>::L, O = Solver<FAM, LEAN, G>::O;
 	const SparseSys A = S.make_sys(srba_lds);
 	const int tid = threadIdx.x; srba_lm_result *out = B.results + pidx;
 	const int nObs = d.n_obs, n = d.n_scal;
@@ -392,16 +396,16 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 #define TOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - tc0; } } while (0)
 	// K6: the LDS image of the system is idle while the capsule is linearised (it is assembled per trial): the U_Ap accumulators of the term-parallel form live there
 	const bool hess_terms = B.hess_terms && d.dense_in_lds && d.n_hap * P * P <= 9 * (d.nb + d.nnzoff);
-	auto hessian = [&](Solver<FAM, LEAN> &X) -> int { return hess_terms ? X.phase_hessian_terms(srba_lds) /* == A.diag: the LDS image, idle while the capsule is linearised */ + X.phase_hessian_landmark_blocks() : X.phase_hessian(); };
+	auto hessian = [&](Solver<FAM, LEAN, G> &X) -> int { return hess_terms ? X.phase_hessian_terms(srba_lds) /* == A.diag: the LDS image, idle while the capsule is linearised */ + X.phase_hessian_landmark_blocks() : X.phase_hessian(); };
 	double lambda, nu = 2.0, total_err, RMSE;
 	int iter = 0, trials = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0; bool stop = false;
 	TIC(); S.phase_spantree(false, nullptr, DB ? B0.pose1 : nullptr); // S5 (DB: both copies of the poses)
-	if constexpr (DB) { constexpr int PD = Solver<FAM, LEAN>::PD; // the second copy of the unknowns (the fixed edges of the paths stay equal in both for good)
-		for (int k = tid; k < d.n_edges * PD; k += SRBA_WG) B0.edge1[d.o_edge * PD + k] = B0.edge[d.o_edge * PD + k];
-		for (int k = tid; k < d.nF * L; k += SRBA_WG) B0.ulm1[d.o_ulm * L + k] = B0.ulm[d.o_ulm * L + k]; }
+	if constexpr (DB) { constexpr int PD = Solver<FAM, LEAN, G>::PD; // the second copy of the unknowns (the fixed edges of the paths stay equal in both for good)
+		for (int k = tid; k < d.n_edges * PD; k += G) B0.edge1[d.o_edge * PD + k] = B0.edge[d.o_edge * PD + k];
+		for (int k = tid; k < d.nF * L; k += G) B0.ulm1[d.o_ulm * L + k] = B0.ulm[d.o_ulm * L + k]; }
 	__syncthreads(); TOC(0);
 	TIC(); S.phase_jacobians(); TOC(1); // S6,S7
-	TIC(); const int ninv = (int)block_sum((double)hessian(S), red); // S10
+	TIC(); const int ninv = (int)grp_sum<G>((double)hessian(S), red); // S10
 	__syncthreads(); TOC(2);
 	if (tid == 0) {
 		out->status = 0; out->num_iters = 0; out->num_trials = 0; out->num_not_pd = 0; out->num_accepted = 0; out->num_relinearized = 0; out->stop_reason = 0;
@@ -424,7 +428,7 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 		while (rho <= 0 && !stop) {
 			const int tr = trials++;
 			if (tid == 0) { if (tr < SRBA_TRACE_LEN) out->trace_lambda[tr] = lambda; out->lambda_last_trial = lambda; }
-			const Batch Ba = DB ? copy_view(B0, cur) : B, Bt = DB ? copy_view(B0, cur ^ 1) : B; Solver<FAM, LEAN> Sa(Ba, d, prm), St(Bt, d, prm); // accepted / trial copy (the same one without DB)
+			const Batch Ba = DB ? copy_view(B0, cur) : B, Bt = DB ? copy_view(B0, cur ^ 1) : B; Solver<FAM, LEAN, G> Sa(Ba, d, prm, red), St(Bt, d, prm, red); // accepted / trial copy (the same one without DB)
 			TIC(); const bool solved = Sa.solve(A, lambda, pc); TOC(5);
 			if (!solved) {
 				n_notpd++; lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
@@ -437,8 +441,8 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 			TIC(); const double new_err = St.phase_residuals(resid2, red); TOC(3);
 			const double new_RMSE = sqrt(new_err / nObs);
 			const double err_red = total_err > 0 ? (total_err - new_err) / total_err : 0;
-			double den = 0; { const double *dl = B.delta + d.o_scal, *g = B.grad + d.o_scal; for (int k = tid; k < n; k += SRBA_WG) den += dl[k] * (lambda * dl[k] + g[k]); }
-			den = block_sum(den, red);
+			double den = 0; { const double *dl = B.delta + d.o_scal, *g = B.grad + d.o_scal; for (int k = tid; k < n; k += G) den += dl[k] * (lambda * dl[k] + g[k]); }
+			den = grp_sum<G>(den, red);
 			rho = (total_err - new_err) / den;
 			if (tid == 0 && tr < SRBA_TRACE_LEN) { out->trace_chi2[tr] = new_err; out->trace_rho[tr] = rho; }
 			if (rho > 0) {
@@ -451,8 +455,8 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 				if (relin) { n_relin++; TIC(); St.phase_jacobians(); TOC(1); TIC(); hessian(St); __syncthreads(); TOC(2); }
 				TIC(); St.phase_gradient(resid);
 				__syncthreads(); St.keep_gradient(); TOC(4);
-				double ninf = 0; { const double *g = B.grad + d.o_scal; for (int k = tid; k < n; k += SRBA_WG) ninf = fmax(ninf, fabs(g[k])); }
-				ninf = block_max(ninf, red);
+				double ninf = 0; { const double *g = B.grad + d.o_scal; for (int k = tid; k < n; k += G) ninf = fmax(ninf, fabs(g[k])); }
+				ninf = grp_max<G>(ninf, red);
 				if (ninf <= 1e-15) { stop = true; stopmask |= 1 << SRBA_STOP_GRADIENT; }
 				if (RMSE < prm.max_err) { stop = true; stopmask |= 1 << SRBA_STOP_RMSE; }
 				if (rho > prm.max_rho) { stop = true; stopmask |= 1 << SRBA_STOP_RHO; }
@@ -465,8 +469,8 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 	}
 	if (!stop) stopmask |= 1 << SRBA_STOP_MAX_ITERS;
 	// S17: crpLandmarksApprox
-	if constexpr (!Solver<FAM, LEAN>::W::T::REL) {
-		for (int l = tid; l < d.nF; l += SRBA_WG) {
+	if constexpr (!Solver<FAM, LEAN, G>::W::T::REL) {
+		for (int l = tid; l < d.nF; l += G) {
 			const bool ok = prm.cov_recovery == 1 && (S.schur_active() ? (B.hf_ok[d.o_ulm + l] != 0) : true);
 			B.ulm_inf_valid[d.o_ulm + l] = ok ? 1 : 0;
 			if (ok) for (int k = 0; k < L * L; k++) B.ulm_inf[(d.o_ulm + l) * L * L + k] = B.Hf[(d.o_hf + B.hf_diag[d.o_ulm + l]) * L * L + k];
@@ -477,20 +481,20 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 		out->total_sqr_error_final = total_err; out->obs_rmse = RMSE; out->lambda_final = lambda;
 	}
 	if constexpr (DB) { // the reference's partial restore, where it becomes visible: a rejected trial refreshed BOTH poses of every pair in use and only the ones Jacobian blocks read went back (optimize_edges.h:664-670)
-		constexpr int PD = Solver<FAM, LEAN>::PD; const Batch Ba = copy_view(B0, cur), Bt = copy_view(B0, cur ^ 1);
+		constexpr int PD = Solver<FAM, LEAN, G>::PD; const Batch Ba = copy_view(B0, cur), Bt = copy_view(B0, cur ^ 1);
 		__syncthreads();
-		if (last_rej) for (int q = tid; q < 2 * d.n_need; q += SRBA_WG) {
+		if (last_rej) for (int q = tid; q < 2 * d.n_need; q += G) {
 			const long long ps = 2LL * B0.need_idx[d.o_pair + (q >> 1)] + (q & 1);
 			if (!B0.pose_req[d.o_pair * 2 + ps]) { double v[PD]; ldn<PD>(v, Bt.pose + (d.o_pair * 2 + ps) * PD); stn<PD>(Ba.pose + (d.o_pair * 2 + ps) * PD, v); }
 		}
 	}
 	if constexpr (DB) { // the accepted state goes back to the primary arrays
-		constexpr int PD = Solver<FAM, LEAN>::PD;
+		constexpr int PD = Solver<FAM, LEAN, G>::PD;
 		__syncthreads();
 		if (cur) {
-			for (int k = tid; k < d.nK * PD; k += SRBA_WG) B0.edge[d.o_edge * PD + k] = B0.edge1[d.o_edge * PD + k];
-			for (int k = tid; k < d.nF * L; k += SRBA_WG) B0.ulm[d.o_ulm * L + k] = B0.ulm1[d.o_ulm * L + k];
-			for (int q = tid; q < 2 * d.n_need; q += SRBA_WG) { const long long ps = 2LL * B0.need_idx[d.o_pair + (q >> 1)] + (q & 1); double v[PD]; ldn<PD>(v, B0.pose1 + (d.o_pair * 2 + ps) * PD); stn<PD>(B0.pose + (d.o_pair * 2 + ps) * PD, v); }
+			for (int k = tid; k < d.nK * PD; k += G) B0.edge[d.o_edge * PD + k] = B0.edge1[d.o_edge * PD + k];
+			for (int k = tid; k < d.nF * L; k += G) B0.ulm[d.o_ulm * L + k] = B0.ulm1[d.o_ulm * L + k];
+			for (int q = tid; q < 2 * d.n_need; q += G) { const long long ps = 2LL * B0.need_idx[d.o_pair + (q >> 1)] + (q & 1); double v[PD]; ldn<PD>(v, B0.pose1 + (d.o_pair * 2 + ps) * PD); stn<PD>(B0.pose + (d.o_pair * 2 + ps) * PD, v); }
 		}
 	}
 	(void)P;
@@ -521,6 +525,24 @@ __global__ void __launch_bounds__(SRBA_WG) __attribute__((amdgpu_waves_per_eu(3,
 		i = __builtin_amdgcn_readfirstlane(i);
 		if (i >= count) break;
 		lm_one<FAM, (SRBA_LM_DB != 0), true>(B, prm, B.order[first + i]);
+		__syncthreads();
+	}
+}
+
+// Two wavefronts per capsule for the big, LDS-bound windows of a big batch (round 4). Those windows hold 20 .. 43 KB of LDS each, so 4 .. 7 of them fill a CU and their wavefronts sit (nearly) alone
+// on a SIMD; the launch then waits for the latency of their trials (tools/diag_residency.py: dead LDS that removes a resident window costs its share of the throughput), nearly half of which
+// is spent in the lane-parallel phases (spanning-tree refresh, residuals, Jacobians, Hessian terms, gradient, assembly of the LDS image: 71 of 154 us per trial for the 67-edge windows) at one
+// record gather per lane and pass. With a second wavefront on the same LDS image those phases run twice as wide; the block-sparse factorisation and substitution stay on the first wavefront.
+// Worker / Solver<FAM, LEAN, 128>: strides of 128, workgroup barriers, group reductions through two doubles of LDS behind the image (fixed order: deterministic), the U_Ap terms cut between two
+// Hessian blocks. Three wavefronts per SIMD (the LEAN register diet): six such workgroups per CU.
+template <int FAM>
+__global__ void __launch_bounds__(2 * SRBA_WG) __attribute__((amdgpu_waves_per_eu(3, 3))) k_lm_run2(const Batch B, const DevParams prm, int first, int count, int *next, int lds_doubles) {
+	double *red = srba_lds + lds_doubles; int *slot = (int *)(red + 2);
+	for (;;) {
+		if (threadIdx.x == 0) *slot = atomicAdd(next, 1);
+		__syncthreads(); const int i = *slot; __syncthreads();
+		if (i >= count) break;
+		lm_one<FAM, (SRBA_LM_DB != 0), true, 2 * SRBA_WG>(B, prm, B.order[first + i], red);
 		__syncthreads();
 	}
 }
@@ -731,7 +753,7 @@ static void symbolic_dense(const srba_problem_capsule &k, const ProbDesc &d, int
 	for (size_t u = 0; u < covered.size(); u++) if (!covered[u]) out.fill.push_back((int32_t)u);
 }
 
-struct LaunchJob { int queue, cls, first, count; double cost; int grid; int delay_us = 0; int lean = 0 /* k_lm_run_lean: three wavefronts per SIMD */; };
+struct LaunchJob { int queue, cls, first, count; double cost; int grid; int delay_us = 0; int lean = 0 /* k_lm_run_lean: three wavefronts per SIMD */, two = 0 /* k_lm_run2: two wavefronts per capsule */; };
 static const int kBigPart = 4096;
 static const int kMaxJobs = 1024;
 
@@ -810,6 +832,7 @@ struct srba_hip_ctx {
 	std::unique_ptr<char[]> h_in; size_t h_in_cap = 0; size_t h_off_order = 0; // host staging of the input arena (kept: the launch order is read back from it)
 	std::vector<int> delay_us; int class_prio = 0; // experiment knobs: per plan job delay before its launch (overrides the staggered start); stream priorities by class size
 	int stagger_ns = 300, stagger_max_us = 5000; // staggered start of the class launches: see plan_launches
+	bool two_on = true; int two_from_kb = 20, two_min_count = 128; // k_lm_run2 (two wavefronts per capsule) for the relative-pose SE2 classes whose LDS image is at least this big
 	bool lean_on = true; int lean_min_count = 512; // k_lm_run_lean for the size classes of which at least nine wavefronts fit the LDS of a CU (relative-pose SE2, classes with at least this many capsules)
 	int max_lds_kb = 1 << 20, min_chunk = 384, max_parts_per_queue = 2; int class_streams = 64 /* sched 3: the class launches are dealt round-robin to at most this many streams */, n_queues = 16, sched = 3, n_streams_used = 1, n_cu = 256, waves_per_cu = 8, lds_per_cu = 160 * 1024; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
 	// offsets needed for downloads (bytes inside the wk arena)
@@ -833,14 +856,16 @@ static void plan_launches(srba_hip_ctx *c, const int32_t *ord) {
 		for (size_t j = 0; j < c->plan.size(); j++) { LaunchJob &J = c->plan[j]; J.grid = J.count;
 			if (c->sched == 3) { const size_t lds = c->cls_lds[J.cls] + c->lds_pad; const int fit = lds ? (int)std::max<size_t>(1, (size_t)c->lds_per_cu / lds) : c->waves_per_cu; J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(c->waves_per_cu, fit)));
 				J.lean = (c->lean_on && c->params.family == SRBA_SE2_RELPOSE2D && J.cls < SRBA_NCLS - 1 && fit >= 9 && J.count >= c->lean_min_count) ? 1 : 0;
-				if (J.lean) J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(12, fit))); }
+				if (J.lean) J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(12, fit)));
+				J.two = (c->two_on && c->params.family == SRBA_SE2_RELPOSE2D && J.cls < SRBA_NCLS - 1 && lds >= (size_t)c->two_from_kb * 1024 && J.count >= c->two_min_count) ? 1 : 0;
+				if (J.two) J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(6, fit))); }
 		}
 		// Staggered start (round 4): the persistent launches of all classes are enqueued at once on their own streams, and which workgroups the dispatcher places first was a race --
 		// when the small (wave-slot bound) classes won it they filled every wave slot, the big (LDS bound, longest running) capsules trickled in late and the launch ended in their tail:
 		// 42-43 ms instead of 38 ms on the benchmark batch, from one launch to the next (tools/diag_launch_order.py, profiles/r04_launch_order.txt). Largest-footprint-first is now enforced:
 		// the stream of job j is held back by a one-thread delay kernel for stagger_ns x (workgroups of all the jobs before it) -- the time the dispatcher needs to place those.
 		if (c->sched == 3 && c->plan.size() > 1) { long long ahead = 0; for (size_t j = 0; j < c->plan.size(); j++) { LaunchJob &J = c->plan[j]; J.delay_us = (int)std::min<long long>(c->stagger_max_us, ahead * c->stagger_ns / 1000); if (j < c->delay_us.size()) J.delay_us = c->delay_us[j]; ahead += J.grid; } }
-		if (getenv("SRBA_HIP_PLAN_DEBUG")) for (size_t j = 0; j < c->plan.size(); j++) { const LaunchJob &J = c->plan[j]; std::fprintf(stderr, "[plan] job %zu: stream %d class %d lds %zu B capsules %d grid %d delay %d us%s\n", j, J.queue, J.cls, c->cls_lds[J.cls], J.count, J.grid, J.delay_us, J.lean ? " (lean: three wavefronts per SIMD)" : ""); } } } finish = {c};
+		if (getenv("SRBA_HIP_PLAN_DEBUG")) for (size_t j = 0; j < c->plan.size(); j++) { const LaunchJob &J = c->plan[j]; std::fprintf(stderr, "[plan] job %zu: stream %d class %d lds %zu B capsules %d grid %d delay %d us%s\n", j, J.queue, J.cls, c->cls_lds[J.cls], J.count, J.grid, J.delay_us, J.lean ? " (lean: three wavefronts per SIMD)" : (J.two ? " (two wavefronts per capsule)" : "")); } } } finish = {c};
 	if (c->sched == 3) { // one persistent launch per size class, every class on its own stream, biggest LDS footprint first (the HBM class is the biggest)
 		int q = 0; const int qmax = std::max(1, c->class_streams);
 		for (int k = SRBA_NCLS - 2; k >= 0; k--) if (c->cls_count[k]) { c->plan.push_back({q % qmax, k, c->cls_first[k], c->cls_count[k], 0.0, 0}); q++; }
@@ -958,7 +983,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_QUEUES"); if (e && atoi(e) >= 1 && atoi(e) < SRBA_NCLS) c->n_queues = atoi(e); } // tuning knob: concurrent launch streams
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || false) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
-	{ const char *e = getenv("SRBA_HIP_CLASS_PRIO"); if (e) c->class_prio = atoi(e); e = getenv("SRBA_HIP_STAGGER_NS"); if (e && atoi(e) >= 0) c->stagger_ns = atoi(e); e = getenv("SRBA_HIP_LEAN"); if (e) c->lean_on = atoi(e) != 0; e = getenv("SRBA_HIP_LEAN_MIN_COUNT"); if (e && atoi(e) >= 1) c->lean_min_count = atoi(e); e = getenv("SRBA_HIP_DELAY_US"); if (e) { std::string t(e); size_t p0 = 0; while (p0 <= t.size()) { size_t p1 = t.find(',', p0); if (p1 == std::string::npos) p1 = t.size(); c->delay_us.push_back(atoi(t.substr(p0, p1 - p0).c_str())); p0 = p1 + 1; } } }
+	{ const char *e = getenv("SRBA_HIP_CLASS_PRIO"); if (e) c->class_prio = atoi(e); e = getenv("SRBA_HIP_STAGGER_NS"); if (e && atoi(e) >= 0) c->stagger_ns = atoi(e); e = getenv("SRBA_HIP_TWO"); if (e) c->two_on = atoi(e) != 0; e = getenv("SRBA_HIP_TWO_FROM_KB"); if (e && atoi(e) > 0) c->two_from_kb = atoi(e); e = getenv("SRBA_HIP_TWO_MIN_COUNT"); if (e && atoi(e) >= 1) c->two_min_count = atoi(e); e = getenv("SRBA_HIP_LEAN"); if (e) c->lean_on = atoi(e) != 0; e = getenv("SRBA_HIP_LEAN_MIN_COUNT"); if (e && atoi(e) >= 1) c->lean_min_count = atoi(e); e = getenv("SRBA_HIP_DELAY_US"); if (e) { std::string t(e); size_t p0 = 0; while (p0 <= t.size()) { size_t p1 = t.find(',', p0); if (p1 == std::string::npos) p1 = t.size(); c->delay_us.push_back(atoi(t.substr(p0, p1 - p0).c_str())); p0 = p1 + 1; } } }
 	int pr_least = 0, pr_greatest = 0; hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
 	for (int k = 1; k < SRBA_NCLS && ok; k++) { // (class_prio 1: the streams of the biggest classes -- low stream index, see plan_launches -- get the highest priority, 2: the lowest)
 		const int split = 4, pri = c->class_prio == 0 ? 0 : ((c->class_prio == 1) == (k < split) ? pr_greatest : pr_least);
@@ -1051,6 +1076,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		if (why[p]) { c->fail(std::string("upload: malformed capsule (") + why[p] + ")"); return -1; }
 		d.n_edges = k.n_edges; d.nK = k.n_unk_edges; d.nF = k.n_unk_lms; d.n_klm = k.n_known_lms; d.n_pairs = k.n_pairs; d.n_obs = k.n_obs; d.n_valid = k.n_valid; d.n_bp = k.n_bp; d.n_bf = k.n_bf;
 		d.n_hap = k.n_hap; d.n_hf = k.n_hf; d.n_hapf = k.n_hapf; d.n_sch = k.n_sch_terms; d.n_hapt = k.n_hap_terms;
+		{ int sp = k.n_hap_terms; for (int b = 0; b <= k.n_hap; b++) if (2 * (long long)k.hap_term_off[b] >= k.n_hap_terms) { sp = k.hap_term_off[b]; break; } d.hapt_split = sp; } // k_lm_run2: where the second wavefront's share of the U_Ap terms begins (a block boundary)
 		d.n_scal = P * d.nK + L * d.nF; d.n_sys = (schur_solver && d.nF > 0 && d.nK > 0) ? P * d.nK : d.n_scal;
 		if (schur_solver && d.nK == 0) { c->fail("upload: Schur solvers need at least one unknown kf2kf edge (the reference has the same restriction, schur.h:34)"); return -1; }
 		int nreq = 0; for (int i = 0; i < 2 * k.n_pairs; i++) nreq += k.pose_required[i] ? 1 : 0; d.n_req = nreq;
@@ -1309,6 +1335,7 @@ static int prep_lds(srba_hip_ctx *c, bool for_lm) {
 	if (b <= 64 * 1024) return 0;
 	int rc = -1;
 	with_family(c->params.family, [&](auto fam_) { constexpr int F = decltype(fam_)::value; rc = for_lm ? allow_big_lds(c, srbadev::k_lm_run<F>, b) : allow_big_lds(c, srbadev::k_solve<F>, b); });
+	if (rc == 0 && for_lm && c->params.family == SRBA_SE2_RELPOSE2D) rc = allow_big_lds(c, srbadev::k_lm_run2<SRBA_SE2_RELPOSE2D>, b + 64);
 	return rc;
 }
 
@@ -1558,6 +1585,7 @@ static int lm_run_async_impl(srba_hip_ctx *c) {
 		const LaunchJob &J = c->plan[j]; const int k = J.cls;
 		hipStream_t launch_stream = (J.queue && nq > 1) ? c->cls_stream[J.queue] : c->stream;
 		if (J.delay_us > 0) hipLaunchKernelGGL(srbadev::k_delay, dim3(1), dim3(1), 0, launch_stream, J.delay_us);
+		if (J.two) { const size_t lds1 = (c->cls_lds[k] + c->lds_pad + 7) & ~(size_t)7; hipLaunchKernelGGL((srbadev::k_lm_run2<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(2 * SRBA_WG), lds1 + 32, launch_stream, c->B, c->dp, J.first, J.count, c->d_next + j, (int)(lds1 / 8)); HIPCHK(c, hipGetLastError()); continue; }
 		if (J.lean) { hipLaunchKernelGGL((srbadev::k_lm_run_lean<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(SRBA_WG), c->cls_lds[k] + c->lds_pad, launch_stream, c->B, c->dp, J.first, J.count, c->d_next + j); HIPCHK(c, hipGetLastError()); continue; }
 		SRBA_DISPATCH_LDS(c, k_lm_run, J.grid, c->cls_lds[k] + c->lds_pad, J.first, J.count, c->d_next + j); HIPCHK(c, hipGetLastError());
 	}

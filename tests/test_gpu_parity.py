@@ -86,6 +86,28 @@ def test_lean_instantiation_of_the_small_classes_matches_oracle(se2_batch, monke
     assert (lean["num_trials"] == plain["num_trials"]).mean() > 0.7
 
 
+@pytest.mark.gpu
+def test_two_wavefronts_per_capsule_match_oracle(se2_batch, monkeypatch):
+    """k_lm_run2 (round 4: two wavefronts on one capsule -- what a big relative-pose batch runs its big, LDS-bound windows on) forced onto every class of this batch, loop-closure
+    windows included: the same parity statements as k_lm_run (decision replay over the whole run of every window), reproducible run to run (its group reductions and the
+    split of the Hessian terms between the wavefronts have a fixed order), and within rounding of the one-wavefront kernel."""
+    b = se2_batch
+    monkeypatch.setenv("SRBA_HIP_TWO_FROM_KB", "1"); monkeypatch.setenv("SRBA_HIP_TWO_MIN_COUNT", "1"); monkeypatch.setenv("SRBA_HIP_LEAN", "0")
+    two = runner.run_batch_hip(b, download=True); again = runner.run_batch_hip(b)
+    monkeypatch.setenv("SRBA_HIP_TWO", "0"); plain = runner.run_batch_hip(b, download=True)
+    cpu = _oracle.run_batch(b)
+    _compare_lm(b, two, cpu)
+    for k in ("num_trials", "chi2_final", "trace_chi2", "trace_rho"):
+        assert np.array_equal(two[k], again[k], equal_nan=True), k
+    assert _close(two["chi2_final"], plain["chi2_final"], rel=1e-9, abs_=1e-20) and _close(two["chi2_init"], plain["chi2_init"], rel=1e-12)
+    P, L, O, PD = capi.DIMS[b.family]
+    for i in range(b.n):
+        g = two["state"].array(i, "edge_pose", np.float64, b[i].n_unk_edges * PD); c = plain["state"].array(i, "edge_pose", np.float64, b[i].n_unk_edges * PD)
+        assert np.allclose(g, c, rtol=1e-7, atol=1e-8), i
+        g = two["state"].array(i, "pose", np.float64, 2 * b[i].n_pairs * PD); c = plain["state"].array(i, "pose", np.float64, 2 * b[i].n_pairs * PD)
+        assert np.allclose(g, c, rtol=1e-7, atol=1e-7), i
+
+
 def test_lm_run_matches_oracle_se2(se2_batch):
     b = se2_batch
     assert b.n > 200
