@@ -853,11 +853,13 @@ static void big_drop_graphs(srba_hip_ctx *c);
 static void plan_launches(srba_hip_ctx *c, const int32_t *ord) {
 	c->plan.clear(); const int nq = c->n_queues;
 	struct fin { srba_hip_ctx *c; ~fin() { // grid of every job: persistent launches hold as many wavefronts as the chip can keep resident for that LDS size, the rest one per capsule
+		int batch_total = 0; for (int k = 0; k < SRBA_NCLS; k++) batch_total += c->cls_count[k];
 		for (size_t j = 0; j < c->plan.size(); j++) { LaunchJob &J = c->plan[j]; J.grid = J.count;
 			if (c->sched == 3) { const size_t lds = c->cls_lds[J.cls] + c->lds_pad; const int fit = lds ? (int)std::max<size_t>(1, (size_t)c->lds_per_cu / lds) : c->waves_per_cu; J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(c->waves_per_cu, fit)));
 				J.lean = (c->lean_on && c->params.family == SRBA_SE2_RELPOSE2D && J.cls < SRBA_NCLS - 1 && fit >= 9 && J.count >= c->lean_min_count) ? 1 : 0;
 				if (J.lean) J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(12, fit)));
-				J.two = (c->two_on && c->params.family == SRBA_SE2_RELPOSE2D && J.cls < SRBA_NCLS - 1 && lds >= (size_t)c->two_from_kb * 1024 && J.count >= c->two_min_count) ? 1 : 0;
+				// (also for a batch of a few capsules -- the per-key-frame use of the engine is a batch of ONE: its latency is the whole cost, 1.55 -> 1.41 ms per key-frame of the sequential run)
+				J.two = (c->two_on && c->params.family == SRBA_SE2_RELPOSE2D && J.cls < SRBA_NCLS - 1 && lds > 0 && ((lds >= (size_t)c->two_from_kb * 1024 && J.count >= c->two_min_count) || batch_total <= 4)) ? 1 : 0; if (J.two) J.lean = 0;
 				if (J.two) J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(6, fit))); }
 		}
 		// Staggered start (round 4): the persistent launches of all classes are enqueued at once on their own streams, and which workgroups the dispatcher places first was a race --
