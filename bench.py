@@ -399,7 +399,7 @@ def main():
                        "host_enqueue_ms_per_step": 1e3 * enq[0] / max(1, args.steps),
                        "pcie_inclusive_lm_iterations_per_s": trials_per_step / (t_upload + 1e-3 * kernel_ms)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_lm_run<SE2_RELPOSE2D> (one launch per LDS size class, concurrent; duration = fork..join)", "kernel_ms": kernel_ms, "kernel_ms_samples": len(kern_ms), "algorithmic_bytes_per_launch": abytes},
+                         "kernel": "the fused LM launch of <SE2, RelativePoses2D>: one persistent launch per LDS size class on its own stream, largest footprint first (k_lm_run2 = two wavefronts per capsule for the windows of 20 KB and more, k_lm_run_lean = three wavefronts per SIMD for the classes of which nine or more fit a CU, k_lm_run for the rest); duration = fork..join", "kernel_ms": kernel_ms, "kernel_ms_samples": len(kern_ms), "algorithmic_bytes_per_launch": abytes},
             "cpu_baseline": cpu,
             "streaming_kernels": stream,
         }

@@ -130,12 +130,14 @@ def replay_report(gpu, rep, tol_trace=1e-9, tol_floor=1e-9):
 
 
 def perturbed(batch, eps=2.220446049250313e-16, seed=0):
-    """A deep copy of the batch whose observations are moved by +-eps relative (one unit in the last place by default): the input of a rounding-sensitivity measurement."""
+    """A deep copy of the batch whose observations, initial unknowns and known landmarks are moved by +-eps relative (one unit in the last place by default): the input of a
+    rounding-sensitivity measurement."""
     P, L, O, PD = capi.DIMS[batch.family]; w = batch.clone(); rng = np.random.RandomState(seed)
     for i in range(w.n):
         c = w.ptr[i]
-        if c.n_obs:
-            z = np.ctypeslib.as_array(c.obs_z, shape=(c.n_obs * O,)); z *= 1.0 + eps * rng.choice([-1.0, 1.0], size=z.shape)
+        for ptr, cnt in ((c.obs_z, c.n_obs * O), (c.edge_pose, c.n_edges * PD), (c.ulm_pos, c.n_unk_lms * L), (c.klm_pos, c.n_known_lms * L)):   # observations, initial unknowns, known landmarks
+            if cnt:
+                z = np.ctypeslib.as_array(ptr, shape=(cnt,)); z *= 1.0 + eps * rng.choice([-1.0, 1.0], size=z.shape)
     return w
 
 

@@ -506,11 +506,11 @@ def test_lost_monocular_map_agrees_up_to_a_rounding_floor_decision():
     # instead of up to their first different decision. EVERY window of this lost map (RMSE 60 .. 140 px, chi2 ~ 1e7, points next to the camera plane), nothing counted:
     # accepted trials and final chi2 within 1e-5, every disputed decision a step that moves chi2 by less than 1e-6 of its value in both runs (measured on the MI355X box: 2.4e-6 /
     # 2.4e-6 / 2.5e-8; 23 of the 59 windows sit below 1e-9). The 1e-9 / 1e-9 / 1e-6 of the other tests is not attainable here by ANY two evaluations: the oracle following the same
-    # decisions on observations moved by one unit in the last place ends 1e-9 .. 1e-7 away from itself on the accepted trials (checked below; tools/diag_replay.py prints the
+    # decisions on inputs (observations, initial unknowns) moved by one unit in the last place ends 1e-9 .. 1e-6 away from itself on the accepted trials (checked below; tools/diag_replay.py prints the
     # GPU-vs-oracle distance and that sensitivity side by side, window by window: they go together).
     rep, R = _replay_exact(b, gpu, tol_trace=1e-5, tol_floor=1e-6, tol_final=1e-5)
     sens, _ = _oracle.rounding_sensitivity(b, gpu, seeds=(0, 1))
-    assert 1e-8 < sens.max() < 1e-5, sens.max()
+    assert sens.max() > 1e-8, sens.max()   # (the oracle against itself, same decisions, inputs moved by one ulp: this map amplifies rounding by seven orders of magnitude or more)
     assert R["complete"].sum() >= b.n - 2   # nearly every window's whole run fits the trial trace and is compared to its end
 
 

@@ -47,6 +47,17 @@ def test_headline_kernel_keeps_two_wavefronts_per_simd(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "clang-offload-bundler")), reason="ROCm LLVM tools not found")
+def test_round4_instantiations_keep_three_wavefronts_per_simd(tmp_path):
+    """k_lm_run_lean (the small size classes of a big relative-pose batch: twelve wavefronts per CU) and k_lm_run2 (two wavefronts per capsule: six workgroups per CU) are sized for three
+    wavefronts per SIMD: at most 168 VGPRs, and what they spill stays small (measured: 24 and 31 dwords; a kernel that starts spilling its hot loops shows hundreds)."""
+    res = kernel_resources(tmp_path)
+    lean = [v for k, v in res.items() if "k_lm_run_leanILi0" in k]; two = [v for k, v in res.items() if "k_lm_run2ILi0" in k]
+    assert len(lean) == 1 and len(two) == 1, (lean, two)
+    for vgpr, scratch in lean + two:
+        assert vgpr <= 168 and scratch <= 256, (vgpr, scratch)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "clang-offload-bundler")), reason="ROCm LLVM tools not found")
 def test_fused_normal_equations_kernel_keeps_two_wavefronts_per_simd(tmp_path):
     """k_assemble_se2rel (srba_assemble.hip): its bins are sized for eight wavefronts per CU, i.e. two per SIMD -- at most 256 VGPRs, no scratch, in its three Lambda instantiations."""
     res = kernel_resources(tmp_path)
