@@ -26,8 +26,9 @@ res = {}
 for kname, n_launch in KERNELS.items():
     out = {}
     for f in sorted(glob.glob('gpurun_out/pmcb/*counter_collection.csv')):
-        rows = [r for r in csv.DictReader(open(f)) if kname + '<' in r['Kernel_Name'] or kname + 'ILi' in r['Kernel_Name']]
-        rows = [r for r in rows if int(r.get('Grid_Size', 1 << 20)) > 4096]   # not the single-capsule launches of the sequential harvest (when the cache is cold)
+        # (k_lm_run = the FUSED LAUNCH: since round 4 its size classes run on three instantiations of the same loop -- k_lm_run, k_lm_run_lean, k_lm_run2 -- summed here)
+        rows = [r for r in csv.DictReader(open(f)) if any((kn + '<' in r['Kernel_Name'] or kn + 'ILi' in r['Kernel_Name']) for kn in (('k_lm_run', 'k_lm_run_lean', 'k_lm_run2') if kname == 'k_lm_run' else (kname,)))]
+        rows = [r for r in rows if kname == 'k_lm_run' and int(r.get('Grid_Size', 0)) >= 192 or int(r.get('Grid_Size', 1 << 20)) > 4096]   # not the single-capsule launches of the sequential harvest (when the cache is cold)
         if not rows: continue
         disp = sorted(set(int(r['Dispatch_Id']) for r in rows))
         acc = collections.defaultdict(float)
