@@ -152,13 +152,21 @@ def bench_cfg3(args, dist, rank, world, local_rank, backend, emit=True):
         P, L, O, PD = capi.DIMS[b.family]
         stats = {"per_problem": {k: np.tile(v, copies) for k, v in per_problem_counts(b, b.family).items()}}
         abytes = algorithmic_bytes(stats, res, P, L, O, PD, relpose=False, schur=True); achieved = abytes / (kernel_ms * 1e-3) / 1e9
+        cfg3_traffic = (None, None)   # L2-miss bytes per launch from the committed PMC passes of THIS workload (tools/pmc_cfg3.sh), else None
+        try:
+            import glob
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_cfg3.json"))):
+                t = json.load(open(f)); w = t["workload"]
+                if int(w["local_areas"]) == n0 and int(w["replicas"]) == copies and int(w["extensions"]) == int(args.cfg3_ext): cfg3_traffic = (float(t["traffic_bytes_per_launch"]), os.path.relpath(f, ROOT) + " (rocprofv3 --pmc passes of this command, committed; not measured in this run)")
+        except Exception:  # noqa: BLE001
+            pass
         line = {"metric": "LM iterations/sec (and obs/sec) on stereo SE3 local areas with Schur landmark reduction; chi2 match vs CPU", "value": tot_trials * args.steps / max_elapsed, "unit": "LM iterations/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * max_elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                 "config": {"workload": "cfg3-stereo: %d key-frames, 2000 landmarks, stereo fx=200 fy=150 cx=512 cy=384 baseline 0.2 m, range 5 m, px noise 0.5, robust kernel, depth 3: %d local areas x %d replicas re-optimised per step" % (n_kf, n0, copies),
                            "extensions": int(args.cfg3_ext), "local_areas": n0, "replicas": copies, "unknown_edges_mean_max": [float(nk.mean()), int(nk.max())], "unknown_landmarks_mean_max": [float(nf.mean()), int(nf.max())], "observations_mean_max": [float(no.mean()), int(no.max())],
                            "lm_trials_per_step": trials, "obs_per_s": tot_obs * args.steps / max_elapsed, "map_build_s": round(t_map, 2), "sequential_ms_per_kf": round(1e3 * t_map / n_kf, 3),
                            "parallelism": "replicas x%d" % world, "solver": "Schur complement + LL^t of the reduced system in LDS (dense block layout; windows beyond LDS: HBM-resident layout or the multi-workgroup path)"},
-                "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None, "kernel": "k_lm_run<SE3_STEREO>", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": cfg3_traffic[0], "traffic_source": cfg3_traffic[1], "kernel": "k_lm_run<SE3_STEREO>", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
                              "note": "algorithmic bytes per SURVEY 8d: K1, K2 + K3 per block, K4 per observation, K5, K6 block writes, per trial K7/K8/K10 per landmark with d observing edges (L*L*8 + d*P*L*8 + L*8 in, d(d+1)/2 P x P blocks read-modify-write) and the dense reduced system (n^2 * 8)"},
                 "cpu_baseline": cpu}
         if emit:

@@ -49,6 +49,7 @@ struct Batch {
 	// inputs
 	const double *edge0, *ulm0, *klm, *obs_z;
 	const int *pair_path_off, *path_edge, *obs_pose, *obs_lm, *obs_valid;
+	const int *obs_rec; // per observation {-2: identity | -1, pose index: a pose of the table no trial changes | 0 / 1 = which pose of its pair, four path entries (edge << 1 | inverse, -1 = none)}: phase_residuals_fused
 	const int *bp_col, *bp_res, *bp_A, *bp_D, *bp_lm, *colp_off, *bf_col, *bf_res, *bf_pose, *colf_off;
 	const int *hap_i, *hap_j, *hap_term_off, *hap_t1, *hap_t2, *hap_tblk /* block of every U_Ap term */, *hf_i, *hf_j, *hf_term_off, *hf_t1, *hf_t2;
 	const int *hapf_i, *hapf_j, *hapf_term_off, *hapf_t1, *hapf_t2, *hap_diag, *hf_diag;
@@ -753,9 +754,9 @@ struct Worker {
 		r[2] = z[2] - (prm.camR[2] + prm.camR[0] * rr[0] / rr[2]); r[3] = z[3] - (prm.camR[3] + prm.camR[1] * rr[1] / rr[2]);
 	}
 	// ---- K4 : one residual row
-	__device__ __forceinline__ double residual_row(int i, double *r) const { // r[O] <- (robustified) residual of row i ; returns its chi2 term
+	__device__ __forceinline__ double residual_row(int i, double *r) const { return residual_row_at(i, r, pose_at(B.obs_pose[d.o_obs + i])); }
+	__device__ __forceinline__ double residual_row_at(int i, double *r, const pose_t &bp) const { // r[O] <- (robustified) residual of row i whose base-from-observer pose is bp ; returns its chi2 term
 		const int gi = d.o_obs + i;
-		const pose_t bp = pose_at(B.obs_pose[gi]);
 		const double *z = B.obs_z + (long long)gi * O; const double *lm = lm_ptr(B.obs_lm[gi]);
 		if constexpr (FAM == SRBA_SE2_RELPOSE2D) { // r = P(z) (-) pose (sensors.h:780-784)
 			const double s = bp.s, c = bp.c, dx = z[0] - bp.x, dy = z[1] - bp.y;
@@ -822,6 +823,34 @@ struct Worker {
 				for (int k = 0; k < O; k++) out[(long long)(d.o_obs + j) * O + k] = r1[k];
 			}
 			acc += c0; if (two) acc += c1;
+		}
+		return grp_sum<G>(acc, red);
+	}
+
+	// K4 of a trial WITHOUT the spanning-tree refresh before it (round 4): the pose of a refreshed pair is composed on the spot from the edge poses of the trial staged in LDS
+	// (obs_rec: per observation either its pose index in the table -- a pose no trial changes -- or the path of its pair, at most four edges, and which of the pair's two poses it reads),
+	// in the order phase_spantree composes it: the same bits. A trial's evaluation then has no global store -> barrier -> gather between the update and the residuals, and a REJECTED
+	// trial (60 % of them) never writes the pose table; an accepted one runs the refresh afterwards (lm_one). One row per lane and pass, the next row's record requested ahead.
+	__device__ __forceinline__ double phase_residuals_fused(double *out, double *red, const double *edge_lds) { fresh();
+		double acc = 0;
+		const int *rec0 = B.obs_rec + (d.o_obs + (tid < d.n_obs ? tid : 0)) * 5; int m = rec0[0], e0 = rec0[1], e1 = rec0[2], e2 = rec0[3], e3 = rec0[4];
+		for (int i = tid; i < d.n_obs; i += G) {
+			const int j = i + G; const int *recn = B.obs_rec + (d.o_obs + (j < d.n_obs ? j : i)) * 5; const int mn = recn[0], n0 = recn[1], n1 = recn[2], n2 = recn[3], n3 = recn[4];
+			pose_t bp;
+			if (m >= 0) {
+				pose_t a = PO::ident(); const int pe[4] = {e0, e1, e2, e3};
+#pragma unroll
+				for (int u = 0; u < 4; u++) if (pe[u] >= 0) { double t[PD]; const double *src = edge_lds + (pe[u] >> 1) * PD;
+#pragma unroll
+					for (int k = 0; k < PD; k++) t[k] = src[k];
+					const pose_t ed = PO::from(t); a = (pe[u] & 1) ? comp(a, inv(ed)) : comp(a, ed); }
+				bp = m ? inv(a) : a;
+			} else bp = pose_at(m == -1 ? e0 : -1);
+			double r[O]; const double c = residual_row_at(i, r, bp);
+#pragma unroll
+			for (int k = 0; k < O; k++) out[(long long)(d.o_obs + i) * O + k] = r[k];
+			acc += c;
+			m = mn; e0 = n0; e1 = n1; e2 = n2; e3 = n3;
 		}
 		return grp_sum<G>(acc, red);
 	}

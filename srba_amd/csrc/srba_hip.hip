@@ -379,11 +379,14 @@ struct Solver : public Worker<FAM, LEAN, G> {
 #ifndef SRBA_LM_DB
 #define SRBA_LM_DB 1   /* the fused loop keeps two copies of the unknowns and of the spanning-tree poses (trial -> the other copy, accept = flip) instead of backup / restore */
 #endif
-template <int FAM, bool DB = (SRBA_LM_DB != 0), bool LEAN = false, int G = 64>
+#ifndef SRBA_FUSE_K4
+#define SRBA_FUSE_K4 1 /* a trial's residuals compose the poses of the refreshed pairs themselves (Worker::phase_residuals_fused); 0: refresh the pose table, then gather from it (rounds 1-3) */
+#endif
+template <int FAM, bool DB = (SRBA_LM_DB != 0), bool LEAN = false, int G = 64, bool FUSE_K4 = (SRBA_FUSE_K4 != 0) && (LEAN || G > 64) /* k_lm_run itself (every family, 253 registers for the headline one) keeps the table path: the fused form costs it 13 registers and with them its second wavefront per SIMD */>
 __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, const int pidx, double *red = nullptr /* G = 128: LDS scratch of the group reductions */) {
 	const ProbDesc &d = B0.desc[pidx];
 	const Batch &B = B0;
-	int cur = 0, last_rej = 0; // DB: which copy holds the accepted state; the last evaluated trial was rejected
+	int cur = 0, last_rej = 0; bool lazy_rej = false; // DB: which copy holds the accepted state; the last evaluated trial was rejected (lazy_rej: ... and the pose table of the trial copy was not refreshed for it)
 	Solver<FAM, LEAN, G> S(B, d, prm, red);
 	constexpr int P = Solver<FAM, LEAN, G>::P, L = Solver<FAM, LEAN, G>::L, O = Solver<FAM, LEAN, G>::O;
 	const SparseSys A = S.make_sys(srba_lds);
@@ -436,9 +439,13 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 				continue;
 			}
 			TIC(); const double *edge_lds = DB ? Sa.apply_trial(A, Bt) : Sa.apply_update_lds(A); TOC(6);
-			TIC(); St.phase_spantree(true, edge_lds);
-			__syncthreads(); TOC(7);
-			TIC(); const double new_err = St.phase_residuals(resid2, red); TOC(3);
+			// (DB, edges staged, every refreshed path of four edges or fewer: the residuals compose their poses themselves and the refresh of the pose table waits for an accepted trial)
+			const bool lazy = DB && FUSE_K4 && edge_lds != nullptr && d.need_flat != 0;
+			double new_err;
+			if (lazy) { TIC(); new_err = St.phase_residuals_fused(resid2, red, edge_lds); TOC(3); }
+			else { TIC(); St.phase_spantree(true, edge_lds);
+				__syncthreads(); TOC(7);
+				TIC(); new_err = St.phase_residuals(resid2, red); TOC(3); }
 			const double new_RMSE = sqrt(new_err / nObs);
 			const double err_red = total_err > 0 ? (total_err - new_err) / total_err : 0;
 			double den = 0; { const double *dl = B.delta + d.o_scal, *g = B.grad + d.o_scal; for (int k = tid; k < n; k += G) den += dl[k] * (lambda * dl[k] + g[k]); }
@@ -452,6 +459,7 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 				total_err = new_err; RMSE = new_RMSE;
 				if constexpr (DB) { cur ^= 1; last_rej = 0; } // the trial copy is the accepted one from here on
 				__syncthreads();
+				if (lazy) { TIC(); St.phase_spantree(true, edge_lds); __syncthreads(); TOC(7); } // the poses of the accepted trial, for the Jacobians and for the output
 				if (relin) { n_relin++; TIC(); St.phase_jacobians(); TOC(1); TIC(); hessian(St); __syncthreads(); TOC(2); }
 				TIC(); St.phase_gradient(resid);
 				__syncthreads(); St.keep_gradient(); TOC(4);
@@ -462,7 +470,7 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 				if (rho > prm.max_rho) { stop = true; stopmask |= 1 << SRBA_STOP_RHO; }
 				lambda *= 1.0 / 3.0; nu = 2.0;
 			} else {
-				if constexpr (DB) last_rej = 1; else { TIC(); Sa.restore(); TOC(8); }
+				if constexpr (DB) { last_rej = 1; lazy_rej = lazy; } else { TIC(); Sa.restore(); TOC(8); }
 				lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
 			}
 		}
@@ -483,6 +491,7 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 	if constexpr (DB) { // the reference's partial restore, where it becomes visible: a rejected trial refreshed BOTH poses of every pair in use and only the ones Jacobian blocks read went back (optimize_edges.h:664-670)
 		constexpr int PD = Solver<FAM, LEAN, G>::PD; const Batch Ba = copy_view(B0, cur), Bt = copy_view(B0, cur ^ 1);
 		__syncthreads();
+		if (last_rej && lazy_rej) { Solver<FAM, LEAN, G> Sl(Bt, d, prm, red); Sl.phase_spantree(true, nullptr); __syncthreads(); } // (the last rejected trial's poses, from its edges in the trial copy)
 		if (last_rej) for (int q = tid; q < 2 * d.n_need; q += G) {
 			const long long ps = 2LL * B0.need_idx[d.o_pair + (q >> 1)] + (q & 1);
 			if (!B0.pose_req[d.o_pair * 2 + ps]) { double v[PD]; ldn<PD>(v, Bt.pose + (d.o_pair * 2 + ps) * PD); stn<PD>(Ba.pose + (d.o_pair * 2 + ps) * PD, v); }
@@ -1132,7 +1141,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	// ---- input arena layout
 	Arena in; struct { size_t desc, edge0, ulm0, klm, obs_z, pair_path_off, path_edge, obs_pose, obs_lm, obs_valid, bp_col, bp_res, bp_A, bp_D, bp_lm, colp_off, bf_col, bf_res, bf_pose, colf_off,
 		hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hap_tblk, hf_i, hf_j, hf_term_off, hf_t1, hf_t2, hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag, sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw, sch_tblk,
-		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, pair_needed, pose_req, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_rptr, sp_rcol, sp_perm, sp_fill, hap_rec, hap_dst, hapf_dst, hf_dst, asm_term, asm_blk, asm_desc, asm_list, asm_slot; } o;
+		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, obs_rec, pair_needed, pose_req, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_rptr, sp_rcol, sp_perm, sp_fill, hap_rec, hap_dst, hapf_dst, hf_dst, asm_term, asm_blk, asm_desc, asm_list, asm_slot; } o;
 	o.desc = in.add(sizeof(ProbDesc) * n);
 	o.edge0 = in.add(8 * t_edge * PDX); o.ulm0 = in.add(8 * t_ulm * L); o.klm = in.add(8 * t_klm * L); o.obs_z = in.add(8 * t_obs * O);
 	o.pair_path_off = in.add(4 * (t_pair + n)); o.path_edge = in.add(4 * t_path); o.obs_pose = in.add(4 * t_obs); o.obs_lm = in.add(4 * t_obs); o.obs_valid = in.add(4 * t_obs);
@@ -1143,7 +1152,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	o.hapf_i = in.add(4 * t_hapf); o.hapf_j = in.add(4 * t_hapf); o.hapf_term_off = in.add(4 * (t_hapf + n)); o.hapf_t1 = in.add(4 * t_hapft); o.hapf_t2 = in.add(4 * t_hapft);
 	o.hap_diag = in.add(4 * t_unk); o.hf_diag = in.add(4 * t_ulm);
 	o.sch_term_off = in.add(4 * (t_hap + n)); o.sch_b1 = in.add(4 * t_sch); o.sch_b2 = in.add(4 * t_sch); o.sch_lm = in.add(4 * t_sch); o.sch_yw = in.add(4 * t_sch); o.sch_tblk = in.add(4 * t_sch);
-	o.lm_hapf_off = in.add(4 * (t_ulm + n)); o.lm_hapf_idx = in.add(4 * t_hapf); o.req_idx = in.add(4 * t_req); o.need_idx = in.add(4 * t_pair); o.need_rec = in.add(4 * 5 * std::max<long long>(t_pair, 1)); o.pair_needed = in.add(t_pair); o.pose_req = in.add(2 * t_pair); o.bp_normal = in.add(t_bp); o.order = in.add(4 * (size_t)n);
+	o.lm_hapf_off = in.add(4 * (t_ulm + n)); o.lm_hapf_idx = in.add(4 * t_hapf); o.req_idx = in.add(4 * t_req); o.need_idx = in.add(4 * t_pair); o.need_rec = in.add(4 * 5 * std::max<long long>(t_pair, 1)); o.obs_rec = in.add(4 * 5 * std::max<long long>(t_obs, 1)); o.pair_needed = in.add(t_pair); o.pose_req = in.add(2 * t_pair); o.bp_normal = in.add(t_bp); o.order = in.add(4 * (size_t)n);
 	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_rptr = in.add(4 * t_spcol); o.sp_rcol = in.add(4 * t_sprow); o.sp_perm = in.add(4 * t_spcol); o.hap_rec = in.add(4 * 3 * std::max<long long>(t_hap, 1)); o.sp_fill = in.add(4 * std::max<long long>(t_spfill, 1));
 	o.hap_dst = in.add(4 * t_hap * (P / 3) * (P / 3)); o.hapf_dst = in.add(4 * t_hapf * (P / 3)); o.hf_dst = in.add(4 * t_hf);
 	bool asm_fam = c->asm_on && c->params.family == SRBA_SE2_RELPOSE2D;
@@ -1188,6 +1197,11 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 			nr[5 * cnt] = i; for (int u = 0; u < 4; u++) nr[5 * cnt + 1 + u] = u < pl ? k.path_edge[pb + u] : -1;
 			nd[cnt++] = i; }
 		  c->desc[p].n_need = cnt; c->desc[p].need_flat = flat; }
+		{ int32_t *orc = (int32_t *)(h + o.obs_rec) + 5 * d.o_obs; // per observation: how its pose is obtained inside a trial (Worker::phase_residuals_fused)
+		  for (int i = 0; i < k.n_obs; i++) { const int ip = k.obs_pose[i]; int32_t *r = orc + 5 * i; r[1] = r[2] = r[3] = r[4] = -1;
+			if (ip < 0) { r[0] = -2; continue; }
+			const int pr = ip >> 1, pb = k.pair_path_off[pr], pl = k.pair_path_off[pr + 1] - pb;
+			if (k.pair_needed[pr] && pl <= 4) { r[0] = ip & 1; for (int u = 0; u < pl; u++) r[1 + u] = k.path_edge[pb + u]; } else { r[0] = -1; r[1] = ip; } } }
 		{ int32_t *rq = (int32_t *)(h + o.req_idx) + d.o_req; int cnt = 0; for (int i = 0; i < 2 * k.n_pairs; i++) if (k.pose_required[i]) rq[cnt++] = i; }
 		CPY(o.pair_needed, d.o_pair, k.pair_needed, k.n_pairs, uint8_t); CPY(o.pose_req, 2 * d.o_pair, k.pose_required, 2 * (size_t)k.n_pairs, uint8_t); CPY(o.bp_normal, d.o_bp, k.bp_normal, k.n_bp, uint8_t);
 		CPY(o.sp_col_off, d.o_spcol, sym[p].col_off.data(), d.nb + 1, int32_t); CPY(o.sp_row, d.o_sprow, sym[p].row.data(), sym[p].row.size(), int32_t);
@@ -1273,7 +1287,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	DI(pair_path_off, int); DI(path_edge, int); DI(obs_pose, int); DI(obs_lm, int); DI(obs_valid, int); DI(bp_col, int); DI(bp_res, int); DI(bp_A, int); DI(bp_D, int); DI(bp_lm, int); DI(colp_off, int);
 	DI(bf_col, int); DI(bf_res, int); DI(bf_pose, int); DI(colf_off, int); DI(hap_i, int); DI(hap_j, int); DI(hap_term_off, int); DI(hap_t1, int); DI(hap_t2, int); DI(hap_tblk, int); DI(hf_i, int); DI(hf_j, int); DI(hf_term_off, int); DI(hf_t1, int); DI(hf_t2, int);
 	DI(hapf_i, int); DI(hapf_j, int); DI(hapf_term_off, int); DI(hapf_t1, int); DI(hapf_t2, int); DI(hap_diag, int); DI(hf_diag, int); DI(sch_term_off, int); DI(sch_b1, int); DI(sch_b2, int); DI(sch_lm, int); DI(sch_yw, int); DI(sch_tblk, int);
-	DI(lm_hapf_off, int); DI(lm_hapf_idx, int); DI(req_idx, int); DI(need_idx, int); DI(need_rec, int); DI(pair_needed, unsigned char); DI(pose_req, unsigned char); DI(bp_normal, unsigned char);
+	DI(lm_hapf_off, int); DI(lm_hapf_idx, int); DI(req_idx, int); DI(need_idx, int); DI(need_rec, int); DI(obs_rec, int); DI(pair_needed, unsigned char); DI(pose_req, unsigned char); DI(bp_normal, unsigned char);
 c->asm_tab.term = asm_fam ? (const unsigned long long *)(di + o.asm_term) : nullptr; c->asm_tab.blk = asm_fam ? (const unsigned long long *)(di + o.asm_blk) : nullptr; c->asm_tab.desc = asm_fam ? (const srbadev::AsmDesc *)(di + o.asm_desc) : nullptr; c->asm_list = asm_fam ? (const int *)(di + o.asm_list) : nullptr;
 #undef DI
 #define DW(field, T) B.field = (T *)(dw + w.field)
