@@ -189,7 +189,7 @@ struct Solver : public Worker<FAM, LEAN, G> {
 		}
 		const double *g = B.grad + d.o_scal;
 		for (int k = tid; k < 3 * nb; k += G) S.rhs[3 * S.perm[k / 3] + k % 3] = (k < n) ? g[k] : 0.0;
-		__syncthreads();
+		if (!d.aligned) __syncthreads(); // (aligned: the fill-in blocks zeroed above, the right-hand side and the blocks written below are disjoint pieces of the image -- no order between them, and the loads of the gradient and of the Hessian blocks are in flight together)
 		constexpr int PB = P / 3;
 		// one lane per aligned 3x3 sub-block: its 9 loads are in flight together (one memory round trip per pass instead of one per element)
 		for (int sb = tid; sb < d.n_hap * PB * PB; sb += G) {
@@ -245,7 +245,7 @@ struct Solver : public Worker<FAM, LEAN, G> {
 		STIC(); if constexpr (G > 64) { /* done above */ } else if constexpr (W::T::REL || !W::T::SE3) sp_bsub_rows(S); else { if (d.dense_blocks == 2) { if (S.row_lds) sp_bsub_dense_left(S, (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16 + 18 * S.nb)); else sp_bsub_dense<true>(S); } else if (S.dense) sp_bsub_dense<false>(S); else sp_bsub_rows(S); }
 		double *dl = B.delta + d.o_scal;
 		for (int k = tid; k < d.n_scal; k += G) dl[k] = (k < d.n_sys) ? S.rhs[3 * S.perm[k / 3] + k % 3] : 0.0;
-		__syncthreads(); STOC(12);
+		if (schur_active()) __syncthreads(); /* (K10 reads the increments of the edges back from memory; without landmarks to solve for, the loop takes them from the LDS image: no reader waits for these stores) */ STOC(12);
 		STIC(); if (schur_active()) schur_features(); STOC(13);
 		return true;
 #undef STIC
@@ -448,7 +448,9 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 				TIC(); new_err = St.phase_residuals(resid2, red); TOC(3); }
 			const double new_RMSE = sqrt(new_err / nObs);
 			const double err_red = total_err > 0 ? (total_err - new_err) / total_err : 0;
-			double den = 0; { const double *dl = B.delta + d.o_scal, *g = B.grad + d.o_scal; for (int k = tid; k < n; k += G) den += dl[k] * (lambda * dl[k] + g[k]); }
+			double den = 0; { const double *dl = B.delta + d.o_scal, *g = B.grad + d.o_scal;
+				if (S.schur_active() || !d.dense_in_lds) { for (int k = tid; k < n; k += G) den += dl[k] * (lambda * dl[k] + g[k]); }
+				else for (int k = tid; k < n; k += G) { const double dk = A.rhs[3 * A.perm[k / 3] + k % 3]; den += dk * (lambda * dk + g[k]); } } // (the solved right-hand side is still in the LDS image: the same numbers, no round trip through memory)
 			den = grp_sum<G>(den, red);
 			rho = (total_err - new_err) / den;
 			if (tid == 0 && tr < SRBA_TRACE_LEN) { out->trace_chi2[tr] = new_err; out->trace_rho[tr] = rho; }
