@@ -1200,6 +1200,38 @@ struct Worker {
 };
 
 // the batch with its second copy of the unknowns / spanning-tree poses in place of the first (double-buffered LM loop)
+// ---- lambda-ladder speculation for a batch of ONE capsule (the per-key-frame use of the engine: define_new_keyframe -> optimize_local_area -> one optimize_edges call).
+// A rejected trial leaves the state as it was and only moves lambda (lambda *= nu, nu *= 2: optimize_edges.h:685-687), so the trials of a run of rejections all start from the
+// same accepted state with a lambda known in advance: W workgroups ("replicas", each with its own copy of the work arena: shift_work) evaluate the W next steps of the ladder at
+// once, exchange {solved, rho, chi2} through memory, and every replica then walks the SAME control flow as the sequential loop, taking the outcome of trial j from replica j
+// instead of computing it. On the first accepted step the other replicas adopt the winner's increment (re-applied to their copy of the accepted state: the same arithmetic on
+// the same numbers, bit-identical) and all of them relinearise redundantly. Results are those of the sequential loop bit for bit; the chain of ~26 dependent trials of a
+// key-frame becomes ~12 rounds (the floor tail of a run, up to lambda > max_lambda, is one or two rounds).
+struct SpecCtl {
+	int w, W;          // this replica, replicas
+	int *flag;         // [W]: the last round replica j has published
+	double *box;       // [2][W][4]: per round parity and replica {code (1 = not positive definite, 2 = evaluated), rho, chi2 of the trial point, lambda}
+	double *xdelta;    // [2][W][xstride]: the increment replica j solved for in that round
+	int xstride;
+};
+// the work arena of a replica: every state / workspace pointer of the batch moved by `bytes` (the arenas of the replicas lie one after the other: srba_hip_upload_problems)
+__device__ __forceinline__ Batch shift_work(Batch B, long long bytes) {
+#define SRBA_SH(f) B.f = (decltype(B.f))((char *)B.f + bytes)
+	SRBA_SH(edge); SRBA_SH(ulm); SRBA_SH(pose); SRBA_SH(Jp); SRBA_SH(Jf); SRBA_SH(resid); SRBA_SH(resid2); SRBA_SH(HAp); SRBA_SH(HAp0); SRBA_SH(Hf); SRBA_SH(HApf); SRBA_SH(grad); SRBA_SH(grad0); SRBA_SH(delta); SRBA_SH(Hfinv); SRBA_SH(YW);
+	SRBA_SH(old_edge); SRBA_SH(old_ulm); SRBA_SH(old_pose); SRBA_SH(dense); SRBA_SH(ulm_inf); SRBA_SH(edge1); SRBA_SH(ulm1); SRBA_SH(pose1); SRBA_SH(valid); SRBA_SH(first_fail); SRBA_SH(hf_ok); SRBA_SH(bp_ok); SRBA_SH(bf_ok); SRBA_SH(ulm_inf_valid);
+	SRBA_SH(results); SRBA_SH(lambda_io); SRBA_SH(chi2); SRBA_SH(notpd); if (B.phase_cycles) SRBA_SH(phase_cycles);
+#undef SRBA_SH
+	return B;
+}
+// publish this replica's outcome of the round and wait for all the others (every replica is resident: W workgroups on 256 CUs). Release / acquire at agent scope carry the
+// outcome and the increment across the L2s of the XCDs.
+__device__ __forceinline__ void spec_exchange(const SpecCtl &sc, int round, int code, double rho, double chi2, double lam) {
+	__threadfence(); __syncthreads();
+	if (threadIdx.x == 0) { double *b = sc.box + ((round & 1) * sc.W + sc.w) * 4; b[0] = (double)code; b[1] = rho; b[2] = chi2; b[3] = lam; __hip_atomic_store(sc.flag + sc.w, round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+	if ((int)threadIdx.x < sc.W) { long long spins = 0; while (__hip_atomic_load(sc.flag + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < round) { __builtin_amdgcn_s_sleep(1); if (++spins > (1ll << 26)) break; /* (a replica that never comes: give up instead of hanging the device; the lambda check of the caller reports it) */ } }
+	__syncthreads(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__device__ __forceinline__ double spec_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ Batch copy_view(const Batch &B, int copy) { Batch V = B; if (copy) { V.edge = B.edge1; V.ulm = B.ulm1; V.pose = B.pose1; } return V; }
 
 } // namespace srbadev

@@ -510,6 +510,161 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 	}
 	(void)P;
 }
+// The LM loop of ONE capsule as one of sc->W replicas that speculate on the lambda ladder (SpecCtl, srba_device.hpp; k_lm_spec below): lm_one<FAM, true, true, 128> with the trial
+// evaluation replaced by "take the outcome of step sp_j of the current round". The control flow (stop rules, counters, traces, the partial-restore quirk) is lm_one's, statement by
+// statement; kept as a separate function so that the register allocation of the batch kernels does not depend on it. Relative-pose families (no landmark unknowns, no Schur complement).
+template <int FAM>
+__device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, const int pidx, double *red, const SpecCtl *sc) {
+	constexpr bool LEAN = true, FUSE_K4 = (SRBA_FUSE_K4 != 0); constexpr int G = 2 * SRBA_WG;
+	static_assert(Tr<FAM>::REL, "speculation: no landmark unknowns");
+	const ProbDesc &d = B0.desc[pidx];
+	const Batch &B = B0;
+	int sp_j = sc->W, sp_round = 0, rej_owner = 0, rej_round = 0; const double *own_el = nullptr; // SPEC: next outcome of the round to take (W: none left), rounds so far, who evaluated the last rejected trial and in which round, this replica's staged trial edges
+	int cur = 0, last_rej = 0; bool lazy_rej = false; // DB: which copy holds the accepted state; the last evaluated trial was rejected (lazy_rej: ... and the pose table of the trial copy was not refreshed for it)
+	Solver<FAM, LEAN, G> S(B, d, prm, red);
+	constexpr int P = Solver<FAM, LEAN, G>::P, L = Solver<FAM, LEAN, G>::L, O = Solver<FAM, LEAN, G>::O;
+	const SparseSys A = S.make_sys(srba_lds);
+	const int tid = threadIdx.x; srba_lm_result *out = B.results + pidx;
+	const int nObs = d.n_obs, n = d.n_scal;
+	double *resid = B.resid, *resid2 = B.resid2;
+
+	long long *pc = B.phase_cycles ? B.phase_cycles + (long long)pidx * 16 : nullptr; long long tc0 = 0;
+#define TIC() do { if (pc) { __syncthreads(); tc0 = wall_clock64(); } } while (0)
+#define TOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - tc0; } } while (0)
+	// K6: the LDS image of the system is idle while the capsule is linearised (it is assembled per trial): the U_Ap accumulators of the term-parallel form live there
+	const bool hess_terms = B.hess_terms && d.dense_in_lds && d.n_hap * P * P <= 9 * (d.nb + d.nnzoff);
+	auto hessian = [&](Solver<FAM, LEAN, G> &X) -> int { return hess_terms ? X.phase_hessian_terms(srba_lds) /* == A.diag: the LDS image, idle while the capsule is linearised */ + X.phase_hessian_landmark_blocks() : X.phase_hessian(); };
+	double lambda, nu = 2.0, total_err, RMSE;
+	int iter = 0, trials = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0; bool stop = false;
+	TIC(); S.phase_spantree(false, nullptr, B0.pose1); // S5 (both copies of the poses)
+	{ constexpr int PD = Solver<FAM, LEAN, G>::PD; // the second copy of the unknowns (the fixed edges of the paths stay equal in both for good)
+		for (int k = tid; k < d.n_edges * PD; k += G) B0.edge1[d.o_edge * PD + k] = B0.edge[d.o_edge * PD + k]; }
+	__syncthreads(); TOC(0);
+	TIC(); S.phase_jacobians(); TOC(1); // S6,S7
+	TIC(); const int ninv = (int)grp_sum<G>((double)hessian(S), red); // S10
+	__syncthreads(); TOC(2);
+	if (tid == 0) {
+		out->status = 0; out->num_iters = 0; out->num_trials = 0; out->num_not_pd = 0; out->num_accepted = 0; out->num_relinearized = 0; out->stop_reason = 0;
+		out->num_invalid_jacobs = ninv; out->num_observations = nObs; out->num_jacobians = d.n_bp + d.n_bf; out->num_span_tree_numeric_updates = d.n_pairs;
+		for (int k = 0; k < SRBA_TRACE_LEN; k++) { out->trace_chi2[k] = NAN; out->trace_lambda[k] = NAN; out->trace_rho[k] = NAN; }
+		out->lambda_last_trial = NAN;
+	}
+	if ((long long)O * nObs < (long long)n) { if (tid == 0) out->status = 1; return; } // S11
+	lambda = S.lambda_guess(red); // S12
+	TIC(); total_err = S.phase_residuals(resid, red); TOC(3); // S13
+	RMSE = sqrt(total_err / nObs);
+	if (tid == 0) { out->lambda_init = lambda; out->total_sqr_error_init = total_err; }
+	__syncthreads();
+	TIC(); S.phase_gradient(resid); // S14
+	__syncthreads(); S.keep_gradient(); TOC(4);
+	for (; iter < prm.max_iters && !stop; iter++) {
+		double rho = 0;
+		if (lambda >= prm.max_lambda) { stop = true; stopmask |= 1 << SRBA_STOP_LAMBDA; }
+		if (RMSE < prm.max_err) { stop = true; stopmask |= 1 << SRBA_STOP_RMSE; }
+		while (rho <= 0 && !stop) {
+			const int tr = trials++;
+			if (tid == 0) { if (tr < SRBA_TRACE_LEN) out->trace_lambda[tr] = lambda; out->lambda_last_trial = lambda; }
+			const Batch Ba = copy_view(B0, cur), Bt = copy_view(B0, cur ^ 1); Solver<FAM, LEAN, G> Sa(Ba, d, prm, red), St(Bt, d, prm, red); // accepted / trial copy (the same one without DB)
+			bool lazy; const double *edge_lds = nullptr; double new_err, new_RMSE, err_red;
+			{
+				lazy = FUSE_K4 && d.need_flat != 0 && d.n_edges * Solver<FAM, LEAN, G>::PD <= 9 * d.nnzoff; // (dense_in_lds is a condition of the launch)
+				if (sp_j == sc->W) { // no outcome left of the last round (or the state has changed since): all replicas evaluate their step of the ladder that starts at (lambda, nu)
+					if (last_rej && rej_round == sp_round) { const double *src = sc->xdelta + ((rej_round & 1) * sc->W + rej_owner) * sc->xstride; double *keep = B.old_edge + d.o_unk * Solver<FAM, LEAN, G>::PD; // (that round's increments are overwritten two rounds from now: keep the last rejected one; old_edge is idle in the double-buffered loop)
+						for (int k = tid; k < n; k += G) keep[k] = spec_ld(src + k); }
+					sp_round++;
+					double lam_w = lambda, nu_w = nu; for (int q = 0; q < sc->w; q++) { lam_w *= nu_w; nu_w *= 2.0; }
+					TIC(); const bool ok_w = Sa.solve(A, lam_w, pc); TOC(5);
+					double rho_w = NAN, err_w = NAN;
+					if (ok_w) {
+						double *xd = sc->xdelta + ((sp_round & 1) * sc->W + sc->w) * sc->xstride;
+						for (int k = tid; k < n; k += G) xd[k] = A.rhs[3 * A.perm[k / 3] + k % 3];
+						TIC(); own_el = Sa.apply_trial(A, Bt); TOC(6);
+						TIC(); if (lazy) err_w = St.phase_residuals_fused(resid2, red, own_el); else { St.phase_spantree(true, own_el); __syncthreads(); err_w = St.phase_residuals(resid2, red); } TOC(3);
+						double den = 0; { const double *g = B.grad + d.o_scal; for (int k = tid; k < n; k += G) { const double dk = A.rhs[3 * A.perm[k / 3] + k % 3]; den += dk * (lam_w * dk + g[k]); } }
+						den = grp_sum<G>(den, red);
+						rho_w = (total_err - err_w) / den;
+					}
+					TIC(); spec_exchange(*sc, sp_round, ok_w ? 2 : 1, rho_w, err_w, lam_w); TOC(14);
+					sp_j = 0;
+				}
+				const double *b = sc->box + ((sp_round & 1) * sc->W + sp_j) * 4; const int code = (int)spec_ld(b);
+				if ((code != 1 && code != 2) || spec_ld(b + 3) != lambda) { if (tid == 0) out->status = 2; stop = true; break; } // a replica that did not answer, or one that is not where this one is: reported by the host as an error
+				if (code != 2) { // that step of the ladder was not positive definite
+					n_notpd++; lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
+					sp_j++;
+					__syncthreads();
+					continue;
+				}
+				rho = spec_ld(b + 1); new_err = spec_ld(b + 2);
+				new_RMSE = sqrt(new_err / nObs);
+				err_red = total_err > 0 ? (total_err - new_err) / total_err : 0;
+			}
+			if (tid == 0 && tr < SRBA_TRACE_LEN) { out->trace_chi2[tr] = new_err; out->trace_rho[tr] = rho; }
+			if (rho > 0) {
+				n_acc++;
+				{ // the accepted trial is replica sp_j's: the others re-apply its increment to their copy of the accepted state (same numbers, same arithmetic)
+					if (sp_j != sc->w) { const double *src = sc->xdelta + ((sp_round & 1) * sc->W + sp_j) * sc->xstride; double *dl = B.delta + d.o_scal;
+						__syncthreads();
+						for (int k = tid; k < n; k += G) { const double v = spec_ld(src + k); A.rhs[3 * A.perm[k / 3] + k % 3] = v; dl[k] = v; }
+						__syncthreads();
+						TIC(); edge_lds = Sa.apply_trial(A, Bt); TOC(6);
+						TIC(); if (lazy) (void)St.phase_residuals_fused(resid2, red, edge_lds); else { St.phase_spantree(true, edge_lds); __syncthreads(); (void)St.phase_residuals(resid2, red); } TOC(3);
+					} else edge_lds = own_el;
+					sp_j = sc->W; // the state changes: the other outcomes of the round are void
+				}
+				const bool relin = (err_red < 0 || err_red > prm.min_relin);
+				{ double *t = resid; resid = resid2; resid2 = t; }
+				total_err = new_err; RMSE = new_RMSE;
+				cur ^= 1; last_rej = 0; // the trial copy is the accepted one from here on
+				__syncthreads();
+				if (lazy) { TIC(); St.phase_spantree(true, edge_lds); __syncthreads(); TOC(7); } // the poses of the accepted trial, for the Jacobians and for the output
+				if (relin) { n_relin++; TIC(); St.phase_jacobians(); TOC(1); TIC(); hessian(St); __syncthreads(); TOC(2); }
+				TIC(); St.phase_gradient(resid);
+				__syncthreads(); St.keep_gradient(); TOC(4);
+				double ninf = 0; { const double *g = B.grad + d.o_scal; for (int k = tid; k < n; k += G) ninf = fmax(ninf, fabs(g[k])); }
+				ninf = grp_max<G>(ninf, red);
+				if (ninf <= 1e-15) { stop = true; stopmask |= 1 << SRBA_STOP_GRADIENT; }
+				if (RMSE < prm.max_err) { stop = true; stopmask |= 1 << SRBA_STOP_RMSE; }
+				if (rho > prm.max_rho) { stop = true; stopmask |= 1 << SRBA_STOP_RHO; }
+				lambda *= 1.0 / 3.0; nu = 2.0;
+			} else {
+				last_rej = 1; lazy_rej = lazy; rej_owner = sp_j; rej_round = sp_round; sp_j++;
+				lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
+			}
+		}
+	}
+	if (!stop) stopmask |= 1 << SRBA_STOP_MAX_ITERS;
+	if (tid == 0) {
+		out->num_iters = iter; out->num_trials = trials; out->num_not_pd = n_notpd; out->num_accepted = n_acc; out->num_relinearized = n_relin; out->stop_reason = stopmask;
+		out->total_sqr_error_final = total_err; out->obs_rmse = RMSE; out->lambda_final = lambda;
+	}
+	{ // the reference's partial restore, where it becomes visible: a rejected trial refreshed BOTH poses of every pair in use and only the ones Jacobian blocks read went back (optimize_edges.h:664-670)
+		constexpr int PD = Solver<FAM, LEAN, G>::PD; const Batch Ba = copy_view(B0, cur), Bt = copy_view(B0, cur ^ 1);
+		__syncthreads();
+		if (last_rej && !(rej_round == sp_round && rej_owner == sc->w)) { // the trial copy of this replica holds ITS last trial: make it the sequentially last evaluated one (the quirk below shows it)
+			const double *src = rej_round == sp_round ? sc->xdelta + ((rej_round & 1) * sc->W + rej_owner) * sc->xstride : B.old_edge + d.o_unk * PD;
+			for (int k = tid; k < n; k += G) A.rhs[3 * A.perm[k / 3] + k % 3] = rej_round == sp_round ? spec_ld(src + k) : src[k];
+			__syncthreads();
+			Solver<FAM, LEAN, G> Sa(Ba, d, prm, red), Sl(Bt, d, prm, red); const double *el = Sa.apply_trial(A, Bt);
+			if (!lazy_rej) Sl.phase_spantree(true, el);
+			__syncthreads();
+		}
+		if (last_rej && lazy_rej) { Solver<FAM, LEAN, G> Sl(Bt, d, prm, red); Sl.phase_spantree(true, nullptr); __syncthreads(); } // (the last rejected trial's poses, from its edges in the trial copy)
+		if (last_rej) for (int q = tid; q < 2 * d.n_need; q += G) {
+			const long long ps = 2LL * B0.need_idx[d.o_pair + (q >> 1)] + (q & 1);
+			if (!B0.pose_req[d.o_pair * 2 + ps]) { double v[PD]; ldn<PD>(v, Bt.pose + (d.o_pair * 2 + ps) * PD); stn<PD>(Ba.pose + (d.o_pair * 2 + ps) * PD, v); }
+		}
+	}
+	{ // the accepted state goes back to the primary arrays
+		constexpr int PD = Solver<FAM, LEAN, G>::PD;
+		__syncthreads();
+		if (cur) {
+			for (int k = tid; k < d.nK * PD; k += G) B0.edge[d.o_edge * PD + k] = B0.edge1[d.o_edge * PD + k];
+			for (int q = tid; q < 2 * d.n_need; q += G) { const long long ps = 2LL * B0.need_idx[d.o_pair + (q >> 1)] + (q & 1); double v[PD]; ldn<PD>(v, B0.pose1 + (d.o_pair * 2 + ps) * PD); stn<PD>(B0.pose + (d.o_pair * 2 + ps) * PD, v); }
+		}
+	}
+	(void)P; (void)L;
+}
 // Persistent workgroups: a launch covers one LDS size class with a grid of at most the number of wavefronts the chip can hold for that class; every
 // wavefront pulls capsules (sorted longest-first inside the class) from a shared counter until the class is exhausted. A launch therefore has ONE
 // tail (its last capsules) instead of one per chunk, and the chip stays full while big (LDS-bound) and small (wave-slot-bound) classes drain side by side.
@@ -556,6 +711,18 @@ __global__ void __launch_bounds__(2 * SRBA_WG) __attribute__((amdgpu_waves_per_e
 		lm_one<FAM, (SRBA_LM_DB != 0), true, 2 * SRBA_WG>(B, prm, B.order[first + i], red);
 		__syncthreads();
 	}
+}
+
+// A batch of ONE capsule (the per-key-frame use of the engine): W replicas of it, one workgroup of two wavefronts each, speculate on the lambda ladder (SpecCtl, srba_device.hpp).
+// Replica w works in its own copy of the work arena (`stride` bytes apart, zeroed at upload); replica 0's is the one the host reads back.
+template <int FAM>
+__global__ void __launch_bounds__(2 * SRBA_WG) __attribute__((amdgpu_waves_per_eu(3, 3))) k_lm_spec(const Batch B, const DevParams prm, int lds_doubles, long long stride, SpecCtl sc) {
+	double *red = srba_lds + lds_doubles; sc.w = blockIdx.x;
+	const Batch Bw = shift_work(B, stride * sc.w); const ProbDesc &d = B.desc[0];
+	if (sc.w) { constexpr int PD = Tr<FAM>::PD; // the accepted state the run starts from (replica 0's: srba_hip_reset_state, or what an earlier run left); replica 0 writes there after the first exchange only
+		for (int k = threadIdx.x; k < d.n_edges * PD; k += 2 * SRBA_WG) Bw.edge[d.o_edge * PD + k] = B.edge[d.o_edge * PD + k];
+		__syncthreads(); }
+	lm_spec<FAM>(Bw, prm, 0, red, &sc);
 }
 
 // ---- stepwise kernels
@@ -843,6 +1010,8 @@ struct srba_hip_ctx {
 	std::unique_ptr<char[]> h_in; size_t h_in_cap = 0; size_t h_off_order = 0; // host staging of the input arena (kept: the launch order is read back from it)
 	std::vector<int> delay_us; int class_prio = 0; // experiment knobs: per plan job delay before its launch (overrides the staggered start); stream priorities by class size
 	int stagger_ns = 300, stagger_max_us = 5000; // staggered start of the class launches: see plan_launches
+	// lambda-ladder speculation for a batch of ONE capsule (k_lm_spec): spec_w replicas of the work arena, spec_stride bytes apart; d_spec = flags | outcomes | increments (SpecCtl)
+	bool spec_on = true, spec_ready = false; int spec_w = 8; size_t spec_stride = 0; char *d_spec = nullptr; static constexpr int kSpecMaxW = 32, kSpecMaxN = 192; static constexpr size_t kSpecBytes = 256 + 8 * (2 * kSpecMaxW * 4) + 8 * (2 * (size_t)kSpecMaxW * kSpecMaxN);
 	bool two_on = true; int two_from_kb = 20, two_min_count = 128; // k_lm_run2 (two wavefronts per capsule) for the relative-pose SE2 classes whose LDS image is at least this big
 	bool lean_on = true; int lean_min_count = 512; // k_lm_run_lean for the size classes of which at least nine wavefronts fit the LDS of a CU (relative-pose SE2, classes with at least this many capsules)
 	int max_lds_kb = 1 << 20, min_chunk = 384, max_parts_per_queue = 2; int class_streams = 64 /* sched 3: the class launches are dealt round-robin to at most this many streams */, n_queues = 16, sched = 3, n_streams_used = 1, n_cu = 256, waves_per_cu = 8, lds_per_cu = 160 * 1024; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
@@ -996,7 +1165,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_QUEUES"); if (e && atoi(e) >= 1 && atoi(e) < SRBA_NCLS) c->n_queues = atoi(e); } // tuning knob: concurrent launch streams
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || false) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
-	{ const char *e = getenv("SRBA_HIP_CLASS_PRIO"); if (e) c->class_prio = atoi(e); e = getenv("SRBA_HIP_STAGGER_NS"); if (e && atoi(e) >= 0) c->stagger_ns = atoi(e); e = getenv("SRBA_HIP_TWO"); if (e) c->two_on = atoi(e) != 0; e = getenv("SRBA_HIP_TWO_FROM_KB"); if (e && atoi(e) > 0) c->two_from_kb = atoi(e); e = getenv("SRBA_HIP_TWO_MIN_COUNT"); if (e && atoi(e) >= 1) c->two_min_count = atoi(e); e = getenv("SRBA_HIP_LEAN"); if (e) c->lean_on = atoi(e) != 0; e = getenv("SRBA_HIP_LEAN_MIN_COUNT"); if (e && atoi(e) >= 1) c->lean_min_count = atoi(e); e = getenv("SRBA_HIP_DELAY_US"); if (e) { std::string t(e); size_t p0 = 0; while (p0 <= t.size()) { size_t p1 = t.find(',', p0); if (p1 == std::string::npos) p1 = t.size(); c->delay_us.push_back(atoi(t.substr(p0, p1 - p0).c_str())); p0 = p1 + 1; } } }
+	{ const char *e = getenv("SRBA_HIP_CLASS_PRIO"); if (e) c->class_prio = atoi(e); e = getenv("SRBA_HIP_STAGGER_NS"); if (e && atoi(e) >= 0) c->stagger_ns = atoi(e); e = getenv("SRBA_HIP_TWO"); if (e) c->two_on = atoi(e) != 0; e = getenv("SRBA_HIP_SPEC"); if (e) { c->spec_on = atoi(e) != 0; if (atoi(e) >= 2) c->spec_w = std::min((int)srba_hip_ctx::kSpecMaxW, atoi(e)); } e = getenv("SRBA_HIP_TWO_FROM_KB"); if (e && atoi(e) > 0) c->two_from_kb = atoi(e); e = getenv("SRBA_HIP_TWO_MIN_COUNT"); if (e && atoi(e) >= 1) c->two_min_count = atoi(e); e = getenv("SRBA_HIP_LEAN"); if (e) c->lean_on = atoi(e) != 0; e = getenv("SRBA_HIP_LEAN_MIN_COUNT"); if (e && atoi(e) >= 1) c->lean_min_count = atoi(e); e = getenv("SRBA_HIP_DELAY_US"); if (e) { std::string t(e); size_t p0 = 0; while (p0 <= t.size()) { size_t p1 = t.find(',', p0); if (p1 == std::string::npos) p1 = t.size(); c->delay_us.push_back(atoi(t.substr(p0, p1 - p0).c_str())); p0 = p1 + 1; } } }
 	int pr_least = 0, pr_greatest = 0; hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
 	for (int k = 1; k < SRBA_NCLS && ok; k++) { // (class_prio 1: the streams of the biggest classes -- low stream index, see plan_launches -- get the highest priority, 2: the lowest)
 		const int split = 4, pri = c->class_prio == 0 ? 0 : ((c->class_prio == 1) == (k < split) ? pr_greatest : pr_least);
@@ -1032,7 +1201,7 @@ int srba_hip_destroy(srba_hip_ctx *c) {
 	hipSetDevice(c->device);
 	big_drop_graphs(c);
 	for (int i = 0; i < kBigLanes; i++) { BigLane &l = c->lanes[i]; if (l.e0) hipEventDestroy(l.e0); if (l.e1) hipEventDestroy(l.e1); if (i > 0) { if (l.d_part) hipFree(l.d_part); if (l.d_scal) hipFree(l.d_scal); if (l.d_iscal) hipFree(l.d_iscal); if (l.stream) hipStreamDestroy(l.stream); } }
-	if (c->d_in) hipFree(c->d_in); if (c->d_wk) hipFree(c->d_wk); if (c->d_next) hipFree(c->d_next); if (c->d_part) hipFree(c->d_part); if (c->d_scal) hipFree(c->d_scal); if (c->d_iscal) hipFree(c->d_iscal);
+	if (c->d_in) hipFree(c->d_in); if (c->d_wk) hipFree(c->d_wk); if (c->d_next) hipFree(c->d_next); if (c->d_spec) hipFree(c->d_spec); if (c->d_part) hipFree(c->d_part); if (c->d_scal) hipFree(c->d_scal); if (c->d_iscal) hipFree(c->d_iscal);
 	for (int i = 0; i < srba_hip_ctx::kRing; i++) { if (c->ring0[i]) hipEventDestroy(c->ring0[i]); if (c->ring1[i]) hipEventDestroy(c->ring1[i]); }
 	if (c->ev_fork) hipEventDestroy(c->ev_fork);
 	for (int k = 1; k < SRBA_NCLS; k++) { if (c->cls_done[k]) hipEventDestroy(c->cls_done[k]); if (c->cls_stream[k]) hipStreamDestroy(c->cls_stream[k]); }
@@ -1278,9 +1447,13 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	w.grad0 = wk.add((c->params.extensions & SRBA_EXT_SCHUR_KEEPS_GRADIENT) ? 8 * t_scal : 0);
 	wk.add(0);
 	if (in.size + 256 > c->cap_in) { if (c->d_in) hipFree(c->d_in); c->d_in = nullptr; c->cap_in = 0; const size_t want = (in.size + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_in, want)); c->cap_in = want; }
-	if (wk.size + 256 > c->cap_wk) { if (c->d_wk) hipFree(c->d_wk); c->d_wk = nullptr; c->cap_wk = 0; const size_t want = (wk.size + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_wk, want)); c->cap_wk = want; }
+	// a batch of one relative-pose SE2 capsule whose system lives in LDS: spec_w replicas of the work arena for the lambda-ladder speculation (k_lm_spec)
+	c->spec_ready = c->spec_on && n == 1 && c->params.family == SRBA_SE2_RELPOSE2D && c->two_on && c->sched == 3 && cls[0] < SRBA_NCLS - 1 && c->desc[0].dense_in_lds && c->desc[0].n_scal <= srba_hip_ctx::kSpecMaxN && c->desc[0].n_scal == c->desc[0].n_sys;
+	c->spec_stride = (wk.size + 255) & ~(size_t)255; const size_t wk_need = c->spec_ready ? c->spec_stride * (size_t)c->spec_w : wk.size;
+	if (c->spec_ready && !c->d_spec) HIPCHK(c, hipMalloc((void **)&c->d_spec, srba_hip_ctx::kSpecBytes));
+	if (wk_need + 256 > c->cap_wk) { if (c->d_wk) hipFree(c->d_wk); c->d_wk = nullptr; c->cap_wk = 0; const size_t want = (wk_need + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_wk, want)); c->cap_wk = want; }
 	HIPCHK(c, hipMemcpyAsync(c->d_in, h, in.size, hipMemcpyHostToDevice, c->stream));
-	HIPCHK(c, hipMemsetAsync(c->d_wk, 0, wk.size, c->stream));
+	HIPCHK(c, hipMemsetAsync(c->d_wk, 0, wk_need, c->stream));
 	// ---- batch struct
 	Batch &B = c->B; std::memset(&B, 0, sizeof(B)); B.n_prob = n; B.max_lds_doubles = 0; B.hess_terms = c->lm_terms ? 1 : 0; B.dense_left = c->dense_left ? 1 : 0;
 	char *di = c->d_in, *dw = c->d_wk;
@@ -1354,6 +1527,7 @@ static int prep_lds(srba_hip_ctx *c, bool for_lm) {
 	int rc = -1;
 	with_family(c->params.family, [&](auto fam_) { constexpr int F = decltype(fam_)::value; rc = for_lm ? allow_big_lds(c, srbadev::k_lm_run<F>, b) : allow_big_lds(c, srbadev::k_solve<F>, b); });
 	if (rc == 0 && for_lm && c->params.family == SRBA_SE2_RELPOSE2D) rc = allow_big_lds(c, srbadev::k_lm_run2<SRBA_SE2_RELPOSE2D>, b + 64);
+	if (rc == 0 && for_lm && c->params.family == SRBA_SE2_RELPOSE2D) rc = allow_big_lds(c, srbadev::k_lm_spec<SRBA_SE2_RELPOSE2D>, b + 64);
 	return rc;
 }
 
@@ -1594,6 +1768,14 @@ static int lm_run_async_impl(srba_hip_ctx *c) {
 	  if (!c->ring0[slot]) { HIPCHK(c, hipEventCreate(&c->ring0[slot])); HIPCHK(c, hipEventCreate(&c->ring1[slot])); }
 	  c->ev0 = c->ring0[slot]; c->ev1 = c->ring1[slot]; c->n_launches++; }
 	HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+	if (c->spec_ready && c->plan.size() == 1 && c->cls_count[SRBA_NCLS - 1] == 0) { // a batch of one capsule: its lambda ladder on spec_w workgroups
+		const int k = c->plan[0].cls; const size_t lds1 = (c->cls_lds[k] + c->lds_pad + 7) & ~(size_t)7; const int W = c->spec_w;
+		HIPCHK(c, hipMemsetAsync(c->d_spec, 0, 256, c->stream));
+		srbadev::SpecCtl sc; sc.w = 0; sc.W = W; sc.flag = (int *)c->d_spec; sc.box = (double *)(c->d_spec + 256); sc.xdelta = sc.box + 2 * srba_hip_ctx::kSpecMaxW * 4; sc.xstride = srba_hip_ctx::kSpecMaxN;
+		hipLaunchKernelGGL((srbadev::k_lm_spec<SRBA_SE2_RELPOSE2D>), dim3(W), dim3(2 * SRBA_WG), lds1 + 32, c->stream, c->B, c->dp, (int)(lds1 / 8), (long long)c->spec_stride, sc); HIPCHK(c, hipGetLastError());
+		HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+		return 0;
+	}
 	HIPCHK(c, hipMemsetAsync(c->d_next, 0, sizeof(int) * kMaxJobs, c->stream)); // work counters of the persistent launches
 	// fork/join: the launch plan (made at upload) spreads the size classes over a few streams; see plan_launches()
 	const int nq = c->plan.size() <= 1 ? 1 : c->n_streams_used; // a single launch (the per-key-frame use) stays on the context stream: no fork / join
@@ -1666,6 +1848,7 @@ int srba_hip_download_results(srba_hip_ctx *c, srba_lm_result *results, int n) {
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	HIPCHK(c, hipMemcpyAsync(results, c->d_wk + c->off_res, sizeof(srba_lm_result) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
+	if (c->spec_ready && n >= 1 && results[0].status == 2) { c->fail("lm_run: the replicas of the speculative run lost step with each other (k_lm_spec)"); return -1; }
 	return 0;
 }
 int srba_hip_lm_run(srba_hip_ctx *c, srba_lm_result *results) {

@@ -87,6 +87,32 @@ def test_lean_instantiation_of_the_small_classes_matches_oracle(se2_batch, monke
 
 
 @pytest.mark.gpu
+def test_speculative_single_capsule_run_is_the_sequential_loop_bit_for_bit(se2_batch, monkeypatch):
+    """A batch of ONE capsule (what define_new_keyframe -> optimize_edges hands over) runs as spec_w replicas that evaluate the next steps of the lambda ladder at once (k_lm_spec,
+    optimize_edges.h:685-687: a rejected trial only moves lambda). Every result field, trace entry, unknown edge and spanning-tree pose must be bit-identical to the plain
+    two-wavefront run of the same capsule (SRBA_HIP_SPEC=0), for 4, 8 and 16 replicas; and that run agrees with the oracle (decision replay)."""
+    b = se2_batch; P, L, O, PD = capi.DIMS[b.family]
+    idx = list(range(0, b.n, 3))
+    def run(spec):
+        monkeypatch.setenv("SRBA_HIP_SPEC", str(spec)); out = []
+        ctx = runner.HipContext(b.params)
+        for i in idx:
+            s = b.sub(i, 1); ctx.upload(s); r = ctx.lm_run(); w = s.clone(); ctx._chk(ctx.lib.srba_hip_download_state(ctx.ctx, w.ptr, 1), "download_state")
+            r["edge"] = w.array(0, "edge_pose", np.float64, s[0].n_unk_edges * PD); r["pose"] = w.array(0, "pose", np.float64, 2 * s[0].n_pairs * PD); out.append(r)
+        ctx.close(); return out
+    plain = run(0)
+    assert np.mean([r["num_trials"][0] for r in plain]) > 10
+    for W in (8, 4, 16):
+        got = run(W)
+        for i, (p, g) in enumerate(zip(plain, got)):
+            for k in p:
+                assert np.array_equal(np.asarray(p[k]), np.asarray(g[k]), equal_nan=True), (W, idx[i], k)
+    monkeypatch.setenv("SRBA_HIP_SPEC", "8")
+    for i in idx[:40]:
+        s = b.sub(i, 1); _replay_exact(s, runner.run_batch_hip(s))
+
+
+@pytest.mark.gpu
 def test_two_wavefronts_per_capsule_match_oracle(se2_batch, monkeypatch):
     """k_lm_run2 (round 4: two wavefronts on one capsule -- what a big relative-pose batch runs its big, LDS-bound windows on) forced onto every class of this batch, loop-closure
     windows included: the same parity statements as k_lm_run (decision replay over the whole run of every window), reproducible run to run (its group reductions and the

@@ -51,9 +51,9 @@ def test_round4_instantiations_keep_three_wavefronts_per_simd(tmp_path):
     """k_lm_run_lean (the small size classes of a big relative-pose batch: twelve wavefronts per CU) and k_lm_run2 (two wavefronts per capsule: six workgroups per CU) are sized for three
     wavefronts per SIMD: at most 168 VGPRs, and what they spill stays small (measured: 24 and 31 dwords; a kernel that starts spilling its hot loops shows hundreds)."""
     res = kernel_resources(tmp_path)
-    lean = [v for k, v in res.items() if "k_lm_run_leanILi0" in k]; two = [v for k, v in res.items() if "k_lm_run2ILi0" in k]
-    assert len(lean) == 1 and len(two) == 1, (lean, two)
-    for vgpr, scratch in lean + two:
+    lean = [v for k, v in res.items() if "k_lm_run_leanILi0" in k]; two = [v for k, v in res.items() if "k_lm_run2ILi0" in k]; spec = [v for k, v in res.items() if "k_lm_specILi0" in k]
+    assert len(lean) == 1 and len(two) == 1 and len(spec) == 1, (lean, two, spec)
+    for vgpr, scratch in lean + two + spec:  # (k_lm_spec: the replicas of a batch of one capsule, same workgroup shape as k_lm_run2)
         assert vgpr <= 168 and scratch <= 256, (vgpr, scratch)
 
 
@@ -76,6 +76,6 @@ def test_no_index_is_widened_with_a_stale_high_half_in_the_lm_kernels():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import scan_undef_hi
     dis = scan_undef_hi.disassemble(os.path.join(ROOT, "srba_amd", "lib", "srba_hip.o"))
-    f_lm, k_lm = scan_undef_hi.scan(dis, "k_lm_runILi"); f_kb, k_kb = scan_undef_hi.scan(dis, "kb_")
-    assert len(k_lm) == 9 and len(k_kb) >= 100, (len(k_lm), len(k_kb))
-    assert not f_lm and not f_kb, (f_lm + f_kb)[:4]
+    f_lm, k_lm = scan_undef_hi.scan(dis, "k_lm_runILi"); f_kb, k_kb = scan_undef_hi.scan(dis, "kb_"); f_r4, k_r4 = scan_undef_hi.scan(dis, "k_lm_run_lean"); f_2, k_2 = scan_undef_hi.scan(dis, "k_lm_run2"); f_sp, k_sp = scan_undef_hi.scan(dis, "k_lm_spec")
+    assert len(k_lm) == 9 and len(k_kb) >= 100 and len(k_r4) == 1 and len(k_2) == 1 and len(k_sp) == 1, (len(k_lm), len(k_kb), len(k_r4), len(k_2), len(k_sp))
+    assert not f_lm and not f_kb and not f_r4 and not f_2 and not f_sp, (f_lm + f_kb + f_r4 + f_2 + f_sp)[:4]
