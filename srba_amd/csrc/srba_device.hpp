@@ -1213,6 +1213,7 @@ struct SpecCtl {
 	double *box;       // [2][W][4]: per round parity and replica {code (1 = not positive definite, 2 = evaluated), rho, chi2 of the trial point, lambda}
 	double *xdelta;    // [2][W][xstride]: the increment replica j solved for in that round
 	int xstride;
+	long long stride;  // bytes between the work arenas of two consecutive replicas
 };
 // the work arena of a replica: every state / workspace pointer of the batch moved by `bytes` (the arenas of the replicas lie one after the other: srba_hip_upload_problems)
 __device__ __forceinline__ Batch shift_work(Batch B, long long bytes) {

@@ -603,12 +603,21 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 			if (rho > 0) {
 				n_acc++;
 				{ // the accepted trial is replica sp_j's: the others re-apply its increment to their copy of the accepted state (same numbers, same arithmetic)
-					if (sp_j != sc->w) { const double *src = sc->xdelta + ((sp_round & 1) * sc->W + sp_j) * sc->xstride; double *dl = B.delta + d.o_scal;
+					if (sp_j != sc->w && lazy) { // ... or, where a trial leaves nothing but its edges and its residuals (lazy), copy those from the winner's arena (written before its exchange, untouched until two accepted trials from now)
+						constexpr int PD = Solver<FAM, LEAN, G>::PD; typedef typename Solver<FAM, LEAN, G>::PO PO; const long long off = sc->stride * (sp_j - sc->w);
+						const double *we = (const double *)((const char *)Bt.edge + off) + d.o_edge * PD, *wr = (const double *)((const char *)resid2 + off) + (long long)d.o_obs * O; double *el = A.off;
+						TIC(); __syncthreads();
+						for (int i = tid; i < d.n_edges; i += G) { const typename Solver<FAM, LEAN, G>::pose_t e = PO::ld(we + i * PD); if (i < d.nK) PO::st(Bt.edge + (d.o_edge + i) * PD, e); double t[PD]; PO::to(t, e);
+#pragma unroll
+							for (int k = 0; k < PD; k++) el[i * PD + k] = t[k]; }
+						{ double *mr = resid2 + (long long)d.o_obs * O; for (int k = tid; k < nObs * O; k += G) mr[k] = wr[k]; }
+						__syncthreads(); edge_lds = el; TOC(6);
+					} else if (sp_j != sc->w) { const double *src = sc->xdelta + ((sp_round & 1) * sc->W + sp_j) * sc->xstride; double *dl = B.delta + d.o_scal;
 						__syncthreads();
 						for (int k = tid; k < n; k += G) { const double v = spec_ld(src + k); A.rhs[3 * A.perm[k / 3] + k % 3] = v; dl[k] = v; }
 						__syncthreads();
 						TIC(); edge_lds = Sa.apply_trial(A, Bt); TOC(6);
-						TIC(); if (lazy) (void)St.phase_residuals_fused(resid2, red, edge_lds); else { St.phase_spantree(true, edge_lds); __syncthreads(); (void)St.phase_residuals(resid2, red); } TOC(3);
+						TIC(); St.phase_spantree(true, edge_lds); __syncthreads(); (void)St.phase_residuals(resid2, red); TOC(3);
 					} else edge_lds = own_el;
 					sp_j = sc->W; // the state changes: the other outcomes of the round are void
 				}
@@ -717,7 +726,7 @@ __global__ void __launch_bounds__(2 * SRBA_WG) __attribute__((amdgpu_waves_per_e
 // Replica w works in its own copy of the work arena (`stride` bytes apart, zeroed at upload); replica 0's is the one the host reads back.
 template <int FAM>
 __global__ void __launch_bounds__(2 * SRBA_WG) __attribute__((amdgpu_waves_per_eu(3, 3))) k_lm_spec(const Batch B, const DevParams prm, int lds_doubles, long long stride, SpecCtl sc) {
-	double *red = srba_lds + lds_doubles; sc.w = blockIdx.x;
+	double *red = srba_lds + lds_doubles; sc.w = blockIdx.x; sc.stride = stride;
 	const Batch Bw = shift_work(B, stride * sc.w); const ProbDesc &d = B.desc[0];
 	if (sc.w) { constexpr int PD = Tr<FAM>::PD; // the accepted state the run starts from (replica 0's: srba_hip_reset_state, or what an earlier run left); replica 0 writes there after the first exchange only
 		for (int k = threadIdx.x; k < d.n_edges * PD; k += 2 * SRBA_WG) Bw.edge[d.o_edge * PD + k] = B.edge[d.o_edge * PD + k];

@@ -8,17 +8,22 @@ import _oracle
 
 def run_all(b, spec):
     os.environ["SRBA_HIP_SPEC"] = str(spec)
-    ctx = runner.HipContext(b.params); P, L, O, PD = capi.DIMS[b.family]; out = []; t_run = 0.0; ms = 0.0
+    ctx = runner.HipContext(b.params); P, L, O, PD = capi.DIMS[b.family]; out = []; t_run = 0.0; ms = 0.0; ph = np.zeros(16)
     for rep in range(2):  # second pass timed (first pass sizes the arenas)
-        out = []; t_run = 0.0; ms = 0.0
+        out = []; t_run = 0.0; ms = 0.0; ph[:] = 0
         for i in range(b.n):
             s = b.sub(i, 1); ctx.upload(s)
             t0 = time.perf_counter(); r = ctx.lm_run(); t_run += time.perf_counter() - t0; ms += ctx.lib.srba_hip_last_kernel_ms(ctx.ctx)
+            if PHASES: ph += ctx.debug(10)[:16]
             w = s.clone(); ctx._chk(ctx.lib.srba_hip_download_state(ctx.ctx, w.ptr, 1), "download_state")
             r["edge"] = w.array(0, "edge_pose", np.float64, s[0].n_unk_edges * PD); r["pose"] = w.array(0, "pose", np.float64, 2 * s[0].n_pairs * PD); out.append(r)
     ctx.close()
+    if PHASES:  # 100 MHz ticks per stage of replica 0 (SRBA_HIP_PHASE_TIMING=1: barriers around every stage, the totals are longer than the untimed run)
+        names = {0: "spantree(all)", 1: "jacobians", 2: "hessian", 3: "residuals", 4: "gradient", 5: "solve", 6: "apply/adopt", 7: "spantree(trial)", 10: "  assemble", 11: "  factor+bsub", 14: "exchange"}
+        print("   us per capsule: " + "  ".join("%s %.1f" % (names[k], ph[k] / b.n / 100.0) for k in sorted(names) if ph[k] > 0))
     return out, 1e3 * t_run / b.n, ms / b.n
 
+PHASES = os.environ.get("SRBA_HIP_PHASE_TIMING") == "1"
 n_kf = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 Ws = [int(x) for x in sys.argv[2:]] or [8]
 b = runner.harvest_graph_slam(datasets.graph_slam_se2(n_kf=n_kf, seed=1, path="tour"), backend=_oracle.BACKEND, submap=10, depth=3)
