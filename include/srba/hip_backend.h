@@ -33,13 +33,9 @@ public:
 	}
 	void run(const srba_hip_params &p, srba_problem_capsule &c, srba_lm_result &r) {
 		ensure(p);
-		if (m_prof) m_prof->enter("opt.backend.upload");
-		check(srba_hip_upload_problems(m_ctx, &c, 1), "srba_hip_upload_problems");
-		if (m_prof) { m_prof->leave("opt.backend.upload"); m_prof->enter("opt.backend.lm_run"); }
-		check(srba_hip_lm_run(m_ctx, &r), "srba_hip_lm_run");
-		if (m_prof) { m_prof->leave("opt.backend.lm_run"); m_prof->registerUserMeasure("opt.backend.lm_run.kernel", 1e-3 * srba_hip_last_kernel_ms(m_ctx)); m_prof->enter("opt.backend.download"); }
-		check(srba_hip_download_state(m_ctx, &c, 1), "srba_hip_download_state");
-		if (m_prof) m_prof->leave("opt.backend.download");
+		if (m_prof) m_prof->enter("opt.backend.optimize_capsule"); // upload + LM loop + write-back, one wait for the device (srba_hip_optimize_capsule)
+		check(srba_hip_optimize_capsule(m_ctx, &c, &r), "srba_hip_optimize_capsule");
+		if (m_prof) { m_prof->leave("opt.backend.optimize_capsule"); m_prof->registerUserMeasure("opt.backend.lm_run.kernel", 1e-3 * srba_hip_last_kernel_ms(m_ctx)); }
 #if SRBA_DETAILED_TIME_PROFILING
 		if (m_prof) report_stages(p);
 #endif

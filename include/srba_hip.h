@@ -244,6 +244,9 @@ int  srba_hip_rollback(srba_hip_ctx *ctx);       /* K12 restore (optimize_edges.
 
 /* ---- fused API: the whole of optimize_edges S5..S17 on the device, one workgroup per capsule ---- */
 int  srba_hip_lm_run(srba_hip_ctx *ctx, srba_lm_result *results /*[n] host, may be NULL*/);
+/* One optimize_edges() call of the reference (impl/optimize_edges.h:256-751, write-back in place: 526, 538) in one call: srba_hip_upload_problems(ctx, capsule, 1) +
+ * srba_hip_lm_run(ctx, result) + srba_hip_download_state(ctx, capsule, 1) with a single wait for the device. What RbaEngine<>::optimize_edges() binds per key-frame. */
+int  srba_hip_optimize_capsule(srba_hip_ctx *ctx, srba_problem_capsule *capsule, srba_lm_result *result);
 /* Same, asynchronous on the context's stream, no host copies: for timing loops. */
 int  srba_hip_lm_run_async(srba_hip_ctx *ctx);
 int  srba_hip_sync(srba_hip_ctx *ctx);

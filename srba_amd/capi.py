@@ -104,6 +104,7 @@ def hip_lib():
         lib.srba_hip_eval_residuals.argtypes = [C.c_void_p, PF64]
         lib.srba_hip_solve.argtypes = [C.c_void_p, PF64, PI32]
         lib.srba_hip_lm_run.argtypes = [C.c_void_p, C.POINTER(LmResult)]
+        lib.srba_hip_optimize_capsule.argtypes = [C.c_void_p, PCAP, C.POINTER(LmResult)]
         lib.srba_hip_stream.argtypes = [C.c_void_p]; lib.srba_hip_stream.restype = C.c_void_p
         lib.srba_hip_download_state.argtypes = [C.c_void_p, PCAP, c_i32]
         lib.srba_hip_download_results.argtypes = [C.c_void_p, C.POINTER(LmResult), c_i32]

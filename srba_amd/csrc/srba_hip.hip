@@ -1016,7 +1016,9 @@ struct srba_hip_ctx {
 	int asm_bins = 0, asm_rest = 0; // bins of the fused launch; capsules left to the unfused kernel (asm_list holds their indices)
 	srbadev::FlatMap flat; bool flat_ready = false, use_flat = true; // pair -> capsule map of the flat spanning-tree kernel (srba_flat.hpp), filled on first use after an upload
 	int big_min_sys = 480;   // systems with more scalar unknowns than this skip the block-sparse symbolic analysis and go dense (big path)
-	std::unique_ptr<char[]> h_in; size_t h_in_cap = 0; size_t h_off_order = 0; // host staging of the input arena (kept: the launch order is read back from it)
+	struct Staging { char *p = nullptr; bool pinned = false; char *get() const { return p; } void release() { if (p) { if (pinned) hipHostFree(p); else delete[] p; } p = nullptr; } } h_in; size_t h_in_cap = 0; size_t h_off_order = 0; // host staging of the input arena (kept: the launch order is read back from it); page-locked while it is small (the per-key-frame use: the copy to the device then needs no wait)
+	static constexpr size_t kPinnedMax = (size_t)8 << 20; hipEvent_t ev_h2d = nullptr; bool h2d_pending = false, defer_upload_sync = false; // optimize_capsule: the upload is not waited for; the next writer of the staging buffer waits for this event
+	char *h_out = nullptr; size_t h_out_cap = 0; // page-locked landing area of srba_hip_optimize_capsule (result record | unknowns .. spanning-tree poses)
 	std::vector<int> delay_us; int class_prio = 0; // experiment knobs: per plan job delay before its launch (overrides the staggered start); stream priorities by class size
 	int stagger_ns = 300, stagger_max_us = 5000; // staggered start of the class launches: see plan_launches
 	// lambda-ladder speculation for a batch of ONE capsule (k_lm_spec): spec_w replicas of the work arena, spec_stride bytes apart; d_spec = flags | outcomes | increments (SpecCtl)
@@ -1210,7 +1212,7 @@ int srba_hip_destroy(srba_hip_ctx *c) {
 	hipSetDevice(c->device);
 	big_drop_graphs(c);
 	for (int i = 0; i < kBigLanes; i++) { BigLane &l = c->lanes[i]; if (l.e0) hipEventDestroy(l.e0); if (l.e1) hipEventDestroy(l.e1); if (i > 0) { if (l.d_part) hipFree(l.d_part); if (l.d_scal) hipFree(l.d_scal); if (l.d_iscal) hipFree(l.d_iscal); if (l.stream) hipStreamDestroy(l.stream); } }
-	if (c->d_in) hipFree(c->d_in); if (c->d_wk) hipFree(c->d_wk); if (c->d_next) hipFree(c->d_next); if (c->d_spec) hipFree(c->d_spec); if (c->d_part) hipFree(c->d_part); if (c->d_scal) hipFree(c->d_scal); if (c->d_iscal) hipFree(c->d_iscal);
+	if (c->d_in) hipFree(c->d_in); if (c->d_wk) hipFree(c->d_wk); if (c->d_next) hipFree(c->d_next); if (c->d_spec) hipFree(c->d_spec); c->h_in.release(); if (c->h_out) hipHostFree(c->h_out); if (c->ev_h2d) hipEventDestroy(c->ev_h2d); if (c->d_part) hipFree(c->d_part); if (c->d_scal) hipFree(c->d_scal); if (c->d_iscal) hipFree(c->d_iscal);
 	for (int i = 0; i < srba_hip_ctx::kRing; i++) { if (c->ring0[i]) hipEventDestroy(c->ring0[i]); if (c->ring1[i]) hipEventDestroy(c->ring1[i]); }
 	if (c->ev_fork) hipEventDestroy(c->ev_fork);
 	for (int k = 1; k < SRBA_NCLS; k++) { if (c->cls_done[k]) hipEventDestroy(c->cls_done[k]); if (c->cls_stream[k]) hipStreamDestroy(c->cls_stream[k]); }
@@ -1340,7 +1342,10 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	o.asm_term = in.add(asm_fam ? 8 * std::max<long long>(t_hapt, 1) : 0); o.asm_blk = in.add(asm_fam ? 8 * std::max<long long>(t_bp, 1) : 0); o.asm_desc = in.add(asm_fam ? sizeof(srbadev::AsmDesc) * (size_t)srbadev::ASM_WAVES_PER_WG * (size_t)n : 0); /* (at most one bin per capsule) */ o.asm_list = in.add(asm_fam ? 4 * (size_t)n : 0); o.asm_slot = in.add(0);
 	std::vector<unsigned char> asm_fit(asm_fam ? n : 0, 0); std::vector<int> asm_nt(asm_fam ? n : 0, 0); // per capsule: its indices fit the packed records; off-diagonal terms
 	in.add(0);
-	if (c->h_in_cap < in.size + 256) { c->h_in.reset(); c->h_in.reset(new char[in.size + 256]); c->h_in_cap = in.size + 256; } // uninitialised: cleared below, in parallel
+	if (c->h2d_pending) { HIPCHK(c, hipEventSynchronize(c->ev_h2d)); c->h2d_pending = false; } // (an upload nobody waited for may still be reading the staging buffer)
+	if (c->h_in_cap < in.size + 256) { c->h_in.release(); c->h_in_cap = 0; const size_t want = in.size + 256 <= srba_hip_ctx::kPinnedMax / 2 ? 2 * (in.size + 256) : in.size + 256; // uninitialised: cleared below, in parallel
+		if (want <= srba_hip_ctx::kPinnedMax && hipHostMalloc((void **)&c->h_in.p, want, hipHostMallocDefault) == hipSuccess) c->h_in.pinned = true; else { (void)hipGetLastError(); c->h_in.p = new char[want]; c->h_in.pinned = false; }
+		c->h_in_cap = want; }
 	char *h = c->h_in.get();
 	{ const size_t tot = in.size + 256, slab = (size_t)4 << 20; const int nslab = (int)((tot + slab - 1) / slab);
 	  parallel_ranges(std::max(nslab, 512), nslab > 1 ? c->upload_threads : 1, [&](int b, int e, int) { for (int q = b; q < e && q < nslab; q++) std::memset(h + (size_t)q * slab, 0, std::min(slab, tot - (size_t)q * slab)); }); }
@@ -1492,7 +1497,8 @@ c->asm_tab.term = asm_fam ? (const unsigned long long *)(di + o.asm_term) : null
 		if (t_bp) HIPCHK(c, hipMemsetD8Async((hipDeviceptr_t)(dw + w.bp_ok), 1, (size_t)t_bp, c->stream));
 	}
 	if (srba_hip_reset_state(c) != 0) return -1;
-	HIPCHK(c, hipStreamSynchronize(c->stream)); // the staging buffer is pageable and reused by the next upload
+	if (c->defer_upload_sync && c->h_in.pinned) { if (!c->ev_h2d) HIPCHK(c, hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming)); HIPCHK(c, hipEventRecord(c->ev_h2d, c->stream)); c->h2d_pending = true; } // (srba_hip_optimize_capsule waits once, at its end)
+	else HIPCHK(c, hipStreamSynchronize(c->stream)); // the staging buffer is reused by the next upload
 	return 0;
 }
 
@@ -1943,6 +1949,32 @@ int srba_hip_download_state(srba_hip_ctx *c, srba_problem_capsule *caps, int n) 
 		if (k.ulm_inf && d.nF) std::memcpy(k.ulm_inf, &inf[(size_t)d.o_ulm * L * L], 8 * (size_t)d.nF * L * L);
 		if (k.ulm_inf_valid && d.nF) std::memcpy(k.ulm_inf_valid, &infv[(size_t)d.o_ulm], (size_t)d.nF);
 	}
+	return 0;
+}
+
+// The per-key-frame use of the engine in one call: srba_hip_upload_problems(ctx, capsule, 1) + srba_hip_lm_run(ctx, result) + srba_hip_download_state(ctx, capsule, 1), i.e. one
+// optimize_edges() call of the reference (optimize_edges.h:256-751) with its in-place write-back (526, 538), with ONE wait for the device instead of four: the input arena leaves from
+// page-locked memory without a wait, the result record and the contiguous [unknowns .. spanning-tree poses] span of the work arena come back in two copies queued behind the kernel.
+int srba_hip_optimize_capsule(srba_hip_ctx *c, srba_problem_capsule *cap, srba_lm_result *res) {
+	if (!c || !cap || !res) { if (c) c->fail("optimize_capsule: bad arguments"); return -1; }
+	c->defer_upload_sync = true; const int rc_up = srba_hip_upload_problems(c, cap, 1); c->defer_upload_sync = false;
+	if (rc_up != 0) return rc_up;
+	const bool one_wait = c->h2d_pending && c->tot_ulm == 0 && c->cls_count[SRBA_NCLS - 1] == 0; // relative-pose families, system in LDS; everything else takes the three calls
+	if (!one_wait) { if (srba_hip_lm_run(c, res) != 0) return -1; return srba_hip_download_state(c, cap, 1); }
+	if (srba_hip_lm_run_async(c) != 0) return -1;
+	const int PD = c->dm.PD, PDX = c->dm.PDX(); const ProbDesc &d = c->desc[0];
+	const size_t st_bytes = c->off_pose + 8 * (size_t)2 * d.n_pairs * PDX - c->off_edge, r_bytes = (sizeof(srba_lm_result) + 255) & ~(size_t)255;
+	if (c->h_out_cap < r_bytes + st_bytes) { if (c->h_out) hipHostFree(c->h_out); c->h_out = nullptr; c->h_out_cap = 0; HIPCHK(c, hipHostMalloc((void **)&c->h_out, 2 * (r_bytes + st_bytes), hipHostMallocDefault)); c->h_out_cap = 2 * (r_bytes + st_bytes); }
+	HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_wk + c->off_res, sizeof(srba_lm_result), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipMemcpyAsync(c->h_out + r_bytes, c->d_wk + c->off_edge, st_bytes, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream)); c->h2d_pending = false;
+	float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_ms = ms;
+	std::memcpy(res, c->h_out, sizeof(srba_lm_result));
+	if (c->spec_ready && res->status == 2) { c->fail("lm_run: the replicas of the speculative run lost step with each other (k_lm_spec)"); return -1; }
+	if (cap->n_unk_edges != d.nK || cap->n_pairs != d.n_pairs) { c->fail("optimize_capsule: capsule layout differs from the uploaded one"); return -1; }
+	const double *edge = (const double *)(c->h_out + r_bytes), *pose = (const double *)(c->h_out + r_bytes + (c->off_pose - c->off_edge));
+	for (int q = 0; q < d.nK; q++) std::memcpy(cap->edge_pose + (size_t)q * PD, edge + ((size_t)d.o_edge + q) * PDX, 8 * (size_t)PD); // SE2: drop the cached cos/sin
+	if (cap->pose) for (long long q = 0; q < 2LL * d.n_pairs; q++) std::memcpy(cap->pose + (size_t)q * PD, pose + ((size_t)d.o_pair * 2 + q) * PDX, 8 * (size_t)PD);
 	return 0;
 }
 

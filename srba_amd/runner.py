@@ -204,6 +204,12 @@ class HipContext(object):
         self._chk(self.lib.srba_hip_lm_run(self.ctx, res), "lm_run")
         return results_to_dict(res, self.n)
 
+    def optimize_capsule(self, batch):
+        """srba_hip_optimize_capsule: upload + LM loop + write-back of ONE capsule (written into the capsule's own arrays), one wait for the device"""
+        res = (capi.LmResult * 1)()
+        self._chk(self.lib.srba_hip_optimize_capsule(self.ctx, batch.ptr, res), "optimize_capsule"); self.n = 1; self.batch = batch
+        return results_to_dict(res, 1)
+
     def stats(self):
         s = capi.BatchStats(); self.lib.srba_hip_batch_stats(self.ctx, C.byref(s))
         return {f[0]: getattr(s, f[0]) for f in capi.BatchStats._fields_}

@@ -113,6 +113,37 @@ def test_speculative_single_capsule_run_is_the_sequential_loop_bit_for_bit(se2_b
 
 
 @pytest.mark.gpu
+def test_optimize_capsule_is_upload_run_download_in_one_call(se2_batch):
+    """srba_hip_optimize_capsule (what RbaEngine<>::optimize_edges binds per key-frame: one wait for the device) against the three calls it stands for, on the same context, capsule
+    after capsule (the staging buffers are reused from one call to the next): result records and written-back unknowns / spanning-tree poses bit-identical; and a landmark family,
+    which takes the three calls inside."""
+    b = se2_batch; P, L, O, PD = capi.DIMS[b.family]
+    ctx = runner.HipContext(b.params)
+    for i in range(0, b.n, 5):
+        one = b.clone(i, 1); three = b.clone(i, 1)
+        ctx.upload(three); r3 = ctx.lm_run(); ctx._chk(ctx.lib.srba_hip_download_state(ctx.ctx, three.ptr, 1), "download_state")
+        r1 = ctx.optimize_capsule(one)
+        for k in r3:
+            assert np.array_equal(np.asarray(r3[k]), np.asarray(r1[k]), equal_nan=True), (i, k)
+        for field, cnt in (("edge_pose", one[0].n_unk_edges * PD), ("pose", 2 * one[0].n_pairs * PD)):
+            assert np.array_equal(one.array(0, field, np.float64, cnt), three.array(0, field, np.float64, cnt)), (i, field)
+        assert not np.array_equal(one.array(0, "edge_pose", np.float64, one[0].n_unk_edges * PD), b.array(i, "edge_pose", np.float64, one[0].n_unk_edges * PD)) or r1["num_accepted"][0] == 0
+    ctx.close()
+    ds, _ = datasets.landmarks_dataset_se2("rb2d", n_kf=12, n_lm=200, seed=3, noise=1e-3)
+    eng = runner.landmark_engine("rb2d", backend=_oracle.BACKEND, solver=capi.SOLVER_SCHUR_DENSE, depth=2); eng.run(ds); lb = eng.harvest(); lb.engine = eng
+    P, L, O, PD = capi.DIMS[lb.family]; ctx = runner.HipContext(lb.params)
+    for i in range(max(0, lb.n - 4), lb.n):
+        one = lb.clone(i, 1); three = lb.clone(i, 1)
+        ctx.upload(three); r3 = ctx.lm_run(); ctx._chk(ctx.lib.srba_hip_download_state(ctx.ctx, three.ptr, 1), "download_state")
+        r1 = ctx.optimize_capsule(one)
+        for k in ("num_trials", "chi2_final", "trace_chi2"):
+            assert np.array_equal(np.asarray(r3[k]), np.asarray(r1[k]), equal_nan=True), (i, k)
+        for field, cnt in (("edge_pose", one[0].n_unk_edges * PD), ("ulm_pos", one[0].n_unk_lms * L), ("pose", 2 * one[0].n_pairs * PD)):
+            assert np.array_equal(one.array(0, field, np.float64, cnt), three.array(0, field, np.float64, cnt)), (i, field)
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_two_wavefronts_per_capsule_match_oracle(se2_batch, monkeypatch):
     """k_lm_run2 (round 4: two wavefronts on one capsule -- what a big relative-pose batch runs its big, LDS-bound windows on) forced onto every class of this batch, loop-closure
     windows included: the same parity statements as k_lm_run (decision replay over the whole run of every window), reproducible run to run (its group reductions and the

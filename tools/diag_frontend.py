@@ -8,5 +8,5 @@ eng = runner.graph_slam_engine(backend="hip", submap=10, depth=3, harvest=0, ena
 t = time.time(); eng.run(ds); dt = time.time() - t
 print("n=%d sequential run with the GPU back-end: %.2f s = %.3f ms/KF" % (n, dt, 1e3 * dt / n))
 for name in ("define_new_keyframe", "define_new_keyframe.determine_edges", "define_new_keyframe.st.update_symbolic", "define_new_keyframe.optimize", "opt", "opt.sparse_hessian_build_symbolic",
-             "opt.backend", "opt.backend.upload", "opt.backend.lm_run", "opt.backend.lm_run.kernel", "opt.backend.download"):
+             "opt.backend", "opt.backend.optimize_capsule", "opt.backend.lm_run.kernel"):
     print("   %-45s mean %.4f ms" % (name, 1e3 * eng.lib.srba_engine_profiler_mean(eng.h, name.encode())))
