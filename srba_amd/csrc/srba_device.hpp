@@ -1214,6 +1214,7 @@ struct SpecCtl {
 	double *xdelta;    // [2][W][xstride]: the increment replica j solved for in that round
 	int xstride;
 	long long stride;  // bytes between the work arenas of two consecutive replicas
+	int round0;        // the rounds of this launch are numbered round0 + 1 ...: above every round of the launches before it (at most 8192 rounds per launch: one per trial), so `flag` needs no clearing
 };
 // the work arena of a replica: every state / workspace pointer of the batch moved by `bytes` (the arenas of the replicas lie one after the other: srba_hip_upload_problems)
 __device__ __forceinline__ Batch shift_work(Batch B, long long bytes) {

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <atomic>
 #include <exception>
 #include <memory>
@@ -519,7 +520,7 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 	static_assert(Tr<FAM>::REL, "speculation: no landmark unknowns");
 	const ProbDesc &d = B0.desc[pidx];
 	const Batch &B = B0;
-	int sp_j = sc->W, sp_round = 0, rej_owner = 0, rej_round = 0; const double *own_el = nullptr; // SPEC: next outcome of the round to take (W: none left), rounds so far, who evaluated the last rejected trial and in which round, this replica's staged trial edges
+	int sp_j = sc->W, sp_round = sc->round0, rej_owner = 0, rej_round = 0; const double *own_el = nullptr; // SPEC: next outcome of the round to take (W: none left), rounds so far, who evaluated the last rejected trial and in which round, this replica's staged trial edges
 	int cur = 0, last_rej = 0; bool lazy_rej = false; // DB: which copy holds the accepted state; the last evaluated trial was rejected (lazy_rej: ... and the pose table of the trial copy was not refreshed for it)
 	Solver<FAM, LEAN, G> S(B, d, prm, red);
 	constexpr int P = Solver<FAM, LEAN, G>::P, L = Solver<FAM, LEAN, G>::L, O = Solver<FAM, LEAN, G>::O;
@@ -1012,7 +1013,7 @@ struct srba_hip_ctx {
 	int upload_threads = 1; bool dense_left = true; int hbm_from_kb = 48; bool dense_blocks_ok = true; // mid-size nearly-full systems use the dense block layout in LDS
 	bool lin_terms = true, lm_terms = true; // term-parallel U_Ap accumulation in LDS: srba_hip_linearize / the fused LM kernel
 	// fused normal equations of the relative-pose SE2 family (srba_assemble.hpp): capsules packed into bins (workgroups) by the LDS image they need, one launch; the rest take k_linearize
-	bool asm_on = true, asm_ready = false, jp_stale = false; int asm_max_kb = srbadev::ASM_BIN_BYTES / 1024; srbadev::AsmTables asm_tab = {nullptr, nullptr, nullptr}; const int *asm_list = nullptr;
+	bool asm_on = true, asm_ready = false, asm_flags_set = false, jp_stale = false; size_t off_valid = 0, off_bp_ok = 0; long long n_valid_total = 0, n_bp_total = 0; int asm_max_kb = srbadev::ASM_BIN_BYTES / 1024; srbadev::AsmTables asm_tab = {nullptr, nullptr, nullptr}; const int *asm_list = nullptr;
 	int asm_bins = 0, asm_rest = 0; // bins of the fused launch; capsules left to the unfused kernel (asm_list holds their indices)
 	srbadev::FlatMap flat; bool flat_ready = false, use_flat = true; // pair -> capsule map of the flat spanning-tree kernel (srba_flat.hpp), filled on first use after an upload
 	int big_min_sys = 480;   // systems with more scalar unknowns than this skip the block-sparse symbolic analysis and go dense (big path)
@@ -1022,7 +1023,7 @@ struct srba_hip_ctx {
 	std::vector<int> delay_us; int class_prio = 0; // experiment knobs: per plan job delay before its launch (overrides the staggered start); stream priorities by class size
 	int stagger_ns = 300, stagger_max_us = 5000; // staggered start of the class launches: see plan_launches
 	// lambda-ladder speculation for a batch of ONE capsule (k_lm_spec): spec_w replicas of the work arena, spec_stride bytes apart; d_spec = flags | outcomes | increments (SpecCtl)
-	bool spec_on = true, spec_ready = false; int spec_w = 8; size_t spec_stride = 0; char *d_spec = nullptr; static constexpr int kSpecMaxW = 32, kSpecMaxN = 192; static constexpr size_t kSpecBytes = 256 + 8 * (2 * kSpecMaxW * 4) + 8 * (2 * (size_t)kSpecMaxW * kSpecMaxN);
+	long long spec_launches = 0; bool spec_on = true, spec_ready = false; int spec_w = 8; size_t spec_stride = 0; char *d_spec = nullptr; static constexpr int kSpecMaxW = 32, kSpecMaxN = 192; static constexpr size_t kSpecBytes = 256 + 8 * (2 * kSpecMaxW * 4) + 8 * (2 * (size_t)kSpecMaxW * kSpecMaxN);
 	bool two_on = true; int two_from_kb = 20, two_min_count = 128; // k_lm_run2 (two wavefronts per capsule) for the relative-pose SE2 classes whose LDS image is at least this big
 	bool lean_on = true; int lean_min_count = 512; // k_lm_run_lean for the size classes of which at least nine wavefronts fit the LDS of a CU (relative-pose SE2, classes with at least this many capsules)
 	int max_lds_kb = 1 << 20, min_chunk = 384, max_parts_per_queue = 2; int class_streams = 64 /* sched 3: the class launches are dealt round-robin to at most this many streams */, n_queues = 16, sched = 3, n_streams_used = 1, n_cu = 256, waves_per_cu = 8, lds_per_cu = 160 * 1024; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
@@ -1240,11 +1241,19 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	catch (const std::exception &e) { if (c) { c->n_prob = 0; c->fail(std::string("upload: ") + e.what()); } return -1; }
 	catch (...) { if (c) { c->n_prob = 0; c->fail("upload: unknown exception"); } return -1; }
 }
+// every observation row of the relative-pose SE2 family is valid (its Jacobian blocks have no failure case): the flags the unfused kernel rewrites at every call are set once per upload for the fused one
+static int set_asm_flags(srba_hip_ctx *c) {
+	if (c->asm_flags_set) return 0;
+	if (c->n_valid_total) HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)(c->d_wk + c->off_valid), 1, (size_t)c->n_valid_total, c->stream));
+	if (c->n_bp_total) HIPCHK(c, hipMemsetD8Async((hipDeviceptr_t)(c->d_wk + c->off_bp_ok), 1, (size_t)c->n_bp_total, c->stream));
+	c->asm_flags_set = true; return 0;
+}
 static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *caps, int n) {
 	if (!c || !caps || n <= 0) { if (c) c->fail("upload: bad arguments"); return -1; }
 	HIPCHK(c, hipSetDevice(c->device));
 	c->big_chol_ms = c->big_chol_flops = 0; c->big_chol_count = 0; c->big_chol_nmax = 0; big_drop_graphs(c);
 	c->n_prob = 0; // whatever was uploaded before stops being launchable / readable now: a failed upload leaves the context empty, not half-updated
+	static const bool host_timing = getenv("SRBA_HIP_HOST_TIMING") != nullptr; static double acc[4] = {0, 0, 0, 0}; static long long calls = 0; auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }; const double ht0 = host_timing ? now() : 0; double ht1 = 0, ht2 = 0;
 	const int P = c->dm.P, L = c->dm.L, O = c->dm.O, PD = c->dm.PD, PDX = c->dm.PDX();
 	const bool schur_solver = c->params.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL;
 	c->desc.assign(n, ProbDesc()); srba_batch_stats &st = c->stats; std::memset(&st, 0, sizeof(st)); st.n_problems = n;
@@ -1350,6 +1359,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	{ const size_t tot = in.size + 256, slab = (size_t)4 << 20; const int nslab = (int)((tot + slab - 1) / slab);
 	  parallel_ranges(std::max(nslab, 512), nslab > 1 ? c->upload_threads : 1, [&](int b, int e, int) { for (int q = b; q < e && q < nslab; q++) std::memset(h + (size_t)q * slab, 0, std::min(slab, tot - (size_t)q * slab)); }); }
 	c->in_off_edge0 = o.edge0; c->in_off_ulm0 = o.ulm0; c->h_off_order = o.order;
+	if (host_timing) ht1 = now();
 	// ---- pass 2: pack
 #define CPY(dstoff, elem_off, src, count, T) do { if ((count) > 0) std::memcpy(h + (dstoff) + sizeof(T) * (size_t)(elem_off), (src), sizeof(T) * (size_t)(count)); } while (0)
 	std::vector<int64_t> acc_blocks(std::max(1, c->upload_threads), 0), acc_items(std::max(1, c->upload_threads), 0);
@@ -1449,13 +1459,15 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 			nb++; }
 		c->asm_bins = nb; c->asm_ready = true;
 	}
+	if (host_timing) ht2 = now();
 	// ---- work arena layout
 	Arena wk; struct { size_t edge, ulm, pose, Jp, Jf, resid, resid2, HAp, HAp0, Hf, HApf, grad, delta, Hfinv, YW, old_edge, old_ulm, old_pose, dense, ulm_inf, valid, first_fail, hf_ok, bp_ok, bf_ok, ulm_inf_valid, results, lambda_io, chi2, notpd, phase_cycles, m_pair, grad0, edge1, ulm1, pose1; } w;
+	w.results = wk.add(sizeof(srba_lm_result) * n); // (first: [result records | unknowns | spanning-tree poses] is one span -- srba_hip_optimize_capsule reads it back in one copy)
 	w.edge = wk.add(8 * t_edge * PDX); w.ulm = wk.add(8 * t_ulm * L); w.pose = wk.add(8 * 2 * t_pair * PDX); w.Jp = wk.add(8 * t_bp * O * P); w.Jf = wk.add(8 * t_bf * O * L);
 	w.resid = wk.add(8 * t_obs * O); w.resid2 = wk.add(8 * t_obs * O); w.HAp = wk.add(8 * t_hap * P * P); w.HAp0 = wk.add(8 * t_hap * P * P); w.Hf = wk.add(8 * t_hf * L * L); w.HApf = wk.add(8 * t_hapf * P * L);
 	w.grad = wk.add(8 * t_scal); w.delta = wk.add(8 * t_scal); w.Hfinv = wk.add(8 * t_ulm * L * L); w.YW = wk.add(8 * t_yw * P * L); w.old_edge = wk.add(8 * t_unk * PDX); w.old_ulm = wk.add(8 * t_ulm * L); w.old_pose = wk.add(8 * t_req * PDX);
 	w.dense = wk.add(8 * t_dense); w.ulm_inf = wk.add(8 * t_ulm * L * L); w.valid = wk.add(4 * t_valid); w.first_fail = wk.add(4 * t_valid); w.hf_ok = wk.add(4 * t_ulm); w.bp_ok = wk.add(t_bp); w.bf_ok = wk.add(t_bf); w.ulm_inf_valid = wk.add(t_ulm);
-	w.results = wk.add(sizeof(srba_lm_result) * n); w.lambda_io = wk.add(8 * n); w.chi2 = wk.add(8 * n); w.notpd = wk.add(4 * n); w.phase_cycles = wk.add(8 * 16 * (size_t)n);
+	w.lambda_io = wk.add(8 * n); w.chi2 = wk.add(8 * n); w.notpd = wk.add(4 * n); w.phase_cycles = wk.add(8 * 16 * (size_t)n);
 	w.m_pair = wk.add(4 * t_pair);
 	w.edge1 = wk.add(8 * t_edge * PDX); w.ulm1 = wk.add(8 * t_ulm * L); w.pose1 = wk.add(8 * 2 * t_pair * PDX); // second copy of the unknowns and of the spanning-tree poses: the fused loop is double-buffered
 	w.grad0 = wk.add((c->params.extensions & SRBA_EXT_SCHUR_KEEPS_GRADIENT) ? 8 * t_scal : 0);
@@ -1492,13 +1504,12 @@ c->asm_tab.term = asm_fam ? (const unsigned long long *)(di + o.asm_term) : null
 	c->n_pose_total = 2 * t_pair;
 	for (int i = 0; i < 10; i++) { c->off_dbg[i] = dbg_off[i]; c->len_dbg[i] = dbg_len[i]; }
 	c->n_prob = n; st.device_bytes = (int64_t)(in.size + wk.size);
-	if (c->asm_ready) { // every observation row of this family is valid (its Jacobian blocks have no failure case): the flags the unfused kernel rewrites at every call are set once
-		if (t_valid) HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)(dw + w.valid), 1, (size_t)t_valid, c->stream));
-		if (t_bp) HIPCHK(c, hipMemsetD8Async((hipDeviceptr_t)(dw + w.bp_ok), 1, (size_t)t_bp, c->stream));
-	}
+	c->off_valid = w.valid; c->off_bp_ok = w.bp_ok; c->n_valid_total = t_valid; c->n_bp_total = t_bp; c->asm_flags_set = false;
+	if (c->asm_ready && !c->defer_upload_sync && set_asm_flags(c) != 0) return -1; // (srba_hip_optimize_capsule runs the LM loop only, whose Jacobian phase writes the flags itself: srba_hip_linearize sets them on demand)
 	if (srba_hip_reset_state(c) != 0) return -1;
 	if (c->defer_upload_sync && c->h_in.pinned) { if (!c->ev_h2d) HIPCHK(c, hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming)); HIPCHK(c, hipEventRecord(c->ev_h2d, c->stream)); c->h2d_pending = true; } // (srba_hip_optimize_capsule waits once, at its end)
 	else HIPCHK(c, hipStreamSynchronize(c->stream)); // the staging buffer is reused by the next upload
+	if (host_timing) { const double ht3 = now(); acc[0] += ht1 - ht0; acc[1] += ht2 - ht1; acc[2] += ht3 - ht2; if (++calls % 1000 == 0) { std::fprintf(stderr, "[upload] per call: descriptors + symbolic factorisation %.1f us, packing %.1f us, arena + copies queued %.1f us\n", acc[0] / 1000, acc[1] / 1000, acc[2] / 1000); acc[0] = acc[1] = acc[2] = 0; } }
 	return 0;
 }
 
@@ -1785,8 +1796,7 @@ static int lm_run_async_impl(srba_hip_ctx *c) {
 	HIPCHK(c, hipEventRecord(c->ev0, c->stream));
 	if (c->spec_ready && c->plan.size() == 1 && c->cls_count[SRBA_NCLS - 1] == 0) { // a batch of one capsule: its lambda ladder on spec_w workgroups
 		const int k = c->plan[0].cls; const size_t lds1 = (c->cls_lds[k] + c->lds_pad + 7) & ~(size_t)7; const int W = c->spec_w;
-		HIPCHK(c, hipMemsetAsync(c->d_spec, 0, 256, c->stream));
-		srbadev::SpecCtl sc; sc.w = 0; sc.W = W; sc.flag = (int *)c->d_spec; sc.box = (double *)(c->d_spec + 256); sc.xdelta = sc.box + 2 * srba_hip_ctx::kSpecMaxW * 4; sc.xstride = srba_hip_ctx::kSpecMaxN;
+		srbadev::SpecCtl sc; sc.w = 0; sc.W = W; sc.round0 = (int)((c->spec_launches++ % 200000) * 8192); if (sc.round0 == 0) HIPCHK(c, hipMemsetAsync(c->d_spec, 0, 256, c->stream)); sc.flag = (int *)c->d_spec; sc.box = (double *)(c->d_spec + 256); sc.xdelta = sc.box + 2 * srba_hip_ctx::kSpecMaxW * 4; sc.xstride = srba_hip_ctx::kSpecMaxN; // (the round numbers of a launch continue where no earlier launch has been: the flags are cleared once per 200 000 launches, not per launch)
 		hipLaunchKernelGGL((srbadev::k_lm_spec<SRBA_SE2_RELPOSE2D>), dim3(W), dim3(2 * SRBA_WG), lds1 + 32, c->stream, c->B, c->dp, (int)(lds1 / 8), (long long)c->spec_stride, sc); HIPCHK(c, hipGetLastError());
 		HIPCHK(c, hipEventRecord(c->ev1, c->stream));
 		return 0;
@@ -1899,6 +1909,7 @@ int srba_hip_linearize(srba_hip_ctx *c) {
 	const int lds_doubles = c->lin_terms ? 16 + 1536 : 16; // 12 KB of Hessian accumulators per wavefront: U_Ap of up to 170 SE2 / 42 SE3 blocks (bigger capsules take the per-block path)
 	bool lam_sym = true; // the fused kernel sums the upper triangle of J^t Lambda J only: an information matrix set after the upload (srba_hip_set_params) is checked again here
 	if (c->dp.noise == SRBA_NOISE_CONSTANT_MATRIX) for (int i = 0; i < 3; i++) for (int j = 0; j < i; j++) if (c->dp.lambda[3 * i + j] != c->dp.lambda[3 * j + i]) lam_sym = false;
+	if (c->asm_ready && lam_sym && set_asm_flags(c) != 0) return -1;
 	if (c->asm_ready && lam_sym) { // relative-pose SE2: fused, Jacobian blocks never leave the chip (srba_assemble.hpp): one launch, a workgroup per bin of capsules; what does not fit a bin takes the unfused kernel
 		if (c->asm_bins > 0 && srbadev::asm_launch(c->dp.noise != SRBA_NOISE_CONSTANT_MATRIX ? 0 : (c->dp.lambda[1] == 0 && c->dp.lambda[2] == 0 && c->dp.lambda[5] == 0 && c->dp.lambda[3] == 0 && c->dp.lambda[6] == 0 && c->dp.lambda[7] == 0) ? 1 : 2, c->asm_bins, srbadev::ASM_BIN_BYTES, c->stream, c->B, c->dp, c->asm_tab) != 0) { c->fail("k_assemble_se2rel: launch failed"); return -1; }
 		if (c->asm_rest > 0) { with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::k_linearize<decltype(fam_)::value>), dim3(c->asm_rest), dim3(SRBA_WG), (size_t)lds_doubles * 8, c->stream, c->B, c->dp, lds_doubles, c->asm_list); }); HIPCHK(c, hipGetLastError()); }
@@ -1954,25 +1965,29 @@ int srba_hip_download_state(srba_hip_ctx *c, srba_problem_capsule *caps, int n) 
 
 // The per-key-frame use of the engine in one call: srba_hip_upload_problems(ctx, capsule, 1) + srba_hip_lm_run(ctx, result) + srba_hip_download_state(ctx, capsule, 1), i.e. one
 // optimize_edges() call of the reference (optimize_edges.h:256-751) with its in-place write-back (526, 538), with ONE wait for the device instead of four: the input arena leaves from
-// page-locked memory without a wait, the result record and the contiguous [unknowns .. spanning-tree poses] span of the work arena come back in two copies queued behind the kernel.
+// page-locked memory without a wait, the [result record | unknowns | spanning-tree poses] head of the work arena comes back in one copy queued behind the kernel.
 int srba_hip_optimize_capsule(srba_hip_ctx *c, srba_problem_capsule *cap, srba_lm_result *res) {
 	if (!c || !cap || !res) { if (c) c->fail("optimize_capsule: bad arguments"); return -1; }
-	c->defer_upload_sync = true; const int rc_up = srba_hip_upload_problems(c, cap, 1); c->defer_upload_sync = false;
+	static const bool host_timing = getenv("SRBA_HIP_HOST_TIMING") != nullptr; static double acc[5] = {0, 0, 0, 0, 0}; static long long calls = 0; // (diagnostic: where the host side of a call goes; printed every 1000 calls)
+	auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }; const double t0 = host_timing ? now() : 0;
+	c->defer_upload_sync = true; const int rc_up = srba_hip_upload_problems(c, cap, 1); c->defer_upload_sync = false; const double t1 = host_timing ? now() : 0;
 	if (rc_up != 0) return rc_up;
 	const bool one_wait = c->h2d_pending && c->tot_ulm == 0 && c->cls_count[SRBA_NCLS - 1] == 0; // relative-pose families, system in LDS; everything else takes the three calls
 	if (!one_wait) { if (srba_hip_lm_run(c, res) != 0) return -1; return srba_hip_download_state(c, cap, 1); }
 	if (srba_hip_lm_run_async(c) != 0) return -1;
 	const int PD = c->dm.PD, PDX = c->dm.PDX(); const ProbDesc &d = c->desc[0];
-	const size_t st_bytes = c->off_pose + 8 * (size_t)2 * d.n_pairs * PDX - c->off_edge, r_bytes = (sizeof(srba_lm_result) + 255) & ~(size_t)255;
-	if (c->h_out_cap < r_bytes + st_bytes) { if (c->h_out) hipHostFree(c->h_out); c->h_out = nullptr; c->h_out_cap = 0; HIPCHK(c, hipHostMalloc((void **)&c->h_out, 2 * (r_bytes + st_bytes), hipHostMallocDefault)); c->h_out_cap = 2 * (r_bytes + st_bytes); }
-	HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_wk + c->off_res, sizeof(srba_lm_result), hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(c, hipMemcpyAsync(c->h_out + r_bytes, c->d_wk + c->off_edge, st_bytes, hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(c, hipStreamSynchronize(c->stream)); c->h2d_pending = false;
+	const size_t span = c->off_pose + 8 * (size_t)2 * d.n_pairs * PDX - c->off_res; // [result record | unknowns | spanning-tree poses]: the head of the work arena
+	if (c->off_res > c->off_edge || c->off_edge > c->off_pose) { c->fail("optimize_capsule: unexpected work arena layout"); return -1; }
+	if (c->h_out_cap < span) { if (c->h_out) hipHostFree(c->h_out); c->h_out = nullptr; c->h_out_cap = 0; HIPCHK(c, hipHostMalloc((void **)&c->h_out, 2 * span, hipHostMallocDefault)); c->h_out_cap = 2 * span; }
+	HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_wk + c->off_res, span, hipMemcpyDeviceToHost, c->stream));
+	const double t2 = host_timing ? now() : 0;
+	HIPCHK(c, hipStreamSynchronize(c->stream)); c->h2d_pending = false; const double t3 = host_timing ? now() : 0;
 	float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_ms = ms;
+	if (host_timing) { acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; acc[3] += 1e3 * ms; if (++calls % 1000 == 0) { std::fprintf(stderr, "[optimize_capsule] per call: upload (host) %.1f us, launch + copies queued %.1f us, wait %.1f us (kernel %.1f us)\n", acc[0] / 1000, acc[1] / 1000, acc[2] / 1000, acc[3] / 1000); acc[0] = acc[1] = acc[2] = acc[3] = 0; } }
 	std::memcpy(res, c->h_out, sizeof(srba_lm_result));
 	if (c->spec_ready && res->status == 2) { c->fail("lm_run: the replicas of the speculative run lost step with each other (k_lm_spec)"); return -1; }
 	if (cap->n_unk_edges != d.nK || cap->n_pairs != d.n_pairs) { c->fail("optimize_capsule: capsule layout differs from the uploaded one"); return -1; }
-	const double *edge = (const double *)(c->h_out + r_bytes), *pose = (const double *)(c->h_out + r_bytes + (c->off_pose - c->off_edge));
+	const double *edge = (const double *)(c->h_out + (c->off_edge - c->off_res)), *pose = (const double *)(c->h_out + (c->off_pose - c->off_res));
 	for (int q = 0; q < d.nK; q++) std::memcpy(cap->edge_pose + (size_t)q * PD, edge + ((size_t)d.o_edge + q) * PDX, 8 * (size_t)PD); // SE2: drop the cached cos/sin
 	if (cap->pose) for (long long q = 0; q < 2LL * d.n_pairs; q++) std::memcpy(cap->pose + (size_t)q * PD, pose + ((size_t)d.o_pair * 2 + q) * PDX, 8 * (size_t)PD);
 	return 0;
