@@ -373,6 +373,8 @@ def main():
                 n_seq = 2000; ds_seq = datasets.graph_slam_se2(n_kf=n_seq, seed=multi.replica_seed(rank), path="tour"); t1 = time.perf_counter()
                 eng_seq = runner.graph_slam_engine(backend=_oracle.BACKEND, submap=10, depth=3, sigma_xy=1e-3, sigma_yaw_deg=0.2, harvest=0); eng_seq.run(ds_seq); eng_seq.close(); cpu["sequential_ms_per_kf"] = 1e3 * (time.perf_counter() - t1) / n_seq
                 cpu["sequential_note"] = "the first %d key-frames of the same map built through the same front-end with the oracle (one host thread) as numeric back-end" % n_seq
+                t1 = time.perf_counter(); eng_g = runner.graph_slam_engine(backend="hip", submap=10, depth=3, sigma_xy=1e-3, sigma_yaw_deg=0.2, harvest=0, hip_device=local_rank); eng_g.run(ds_seq); eng_g.close()
+                cpu["sequential_ms_per_kf_gpu_same_prefix"] = 1e3 * (time.perf_counter() - t1) / n_seq   # like for like: the same 2 000 key-frames, no harvesting, GPU back-end (config.sequential_ms_per_kf is the whole 30 000-key-frame run with harvesting)
             except Exception as e:  # noqa: BLE001
                 cpu["sequential_ms_per_kf"] = None; cpu["sequential_note"] = str(e)
             if cores > 1:   # and the scalar figure (the reference is single-threaded), on a smaller sample

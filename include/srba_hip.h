@@ -192,7 +192,7 @@ enum srba_stop_reason {
 };
 #define SRBA_TRACE_LEN 48
 typedef struct srba_lm_result {
-	int32_t status;           /* 0 ok; 1 rank assert failed (optimize_edges.h:355): problem left untouched */
+	int32_t status;           /* 0 ok; 1 rank assert failed (optimize_edges.h:355): problem left untouched; 2 internal: the replicas of a speculative single-capsule run lost step (the call fails) */
 	int32_t num_iters;        /* value of "iter" at loop exit (optimize_edges.h:452-454) */
 	int32_t num_trials;       /* passes of the inner while (optimize_edges.h:471-692) = "LM trials" */
 	int32_t num_not_pd;       /* solve() returned false (:476-485) */
