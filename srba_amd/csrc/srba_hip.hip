@@ -1023,7 +1023,7 @@ struct srba_hip_ctx {
 	std::vector<int> delay_us; int class_prio = 0; // experiment knobs: per plan job delay before its launch (overrides the staggered start); stream priorities by class size
 	int stagger_ns = 300, stagger_max_us = 5000; // staggered start of the class launches: see plan_launches
 	// lambda-ladder speculation for a batch of ONE capsule (k_lm_spec): spec_w replicas of the work arena, spec_stride bytes apart; d_spec = flags | outcomes | increments (SpecCtl)
-	long long spec_launches = 0; bool spec_on = true, spec_ready = false; int spec_w = 8; size_t spec_stride = 0; char *d_spec = nullptr; static constexpr int kSpecMaxW = 32, kSpecMaxN = 192; static constexpr size_t kSpecBytes = 256 + 8 * (2 * kSpecMaxW * 4) + 8 * (2 * (size_t)kSpecMaxW * kSpecMaxN);
+	long long spec_launches = 0; bool spec_on = true, spec_ready = false; int spec_w = 12; size_t spec_stride = 0; char *d_spec = nullptr; static constexpr int kSpecMaxW = 32, kSpecMaxN = 768; static constexpr size_t kSpecBytes = 256 + 8 * (2 * kSpecMaxW * 4) + 8 * (2 * (size_t)kSpecMaxW * kSpecMaxN);
 	bool two_on = true; int two_from_kb = 20, two_min_count = 128; // k_lm_run2 (two wavefronts per capsule) for the relative-pose SE2 classes whose LDS image is at least this big
 	bool lean_on = true; int lean_min_count = 512; // k_lm_run_lean for the size classes of which at least nine wavefronts fit the LDS of a CU (relative-pose SE2, classes with at least this many capsules)
 	int max_lds_kb = 1 << 20, min_chunk = 384, max_parts_per_queue = 2; int class_streams = 64 /* sched 3: the class launches are dealt round-robin to at most this many streams */, n_queues = 16, sched = 3, n_streams_used = 1, n_cu = 256, waves_per_cu = 8, lds_per_cu = 160 * 1024; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
