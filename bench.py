@@ -194,14 +194,14 @@ def bench_cfg4(args, dist, rank, world, local_rank, backend, emit=True):
     res = ctx.lm_run(); trials = int(res["num_trials"].sum()); obs_trials = int((res["num_trials"] * res["num_observations"]).sum())
     for _ in range(args.warmup):
         lib.srba_hip_reset_state(ctx.ctx); lib.srba_hip_lm_run_async(ctx.ctx)
-    st0 = (C.c_double * 4)(); lib.srba_hip_sync(ctx.ctx); lib.srba_hip_big_path_stats(ctx.ctx, st0)
+    st0 = (C.c_double * 8)(); lib.srba_hip_sync(ctx.ctx); lib.srba_hip_big_path_stats2(ctx.ctx, st0)
     def step():
         lib.srba_hip_reset_state(ctx.ctx); lib.srba_hip_lm_run_async(ctx.ctx)
     def device_sync():
         lib.srba_hip_sync(ctx.ctx); torch.cuda.synchronize()
     elapsed = multi.timed_region(dist, device_sync, step, args.steps)
-    st1 = (C.c_double * 4)(); lib.srba_hip_big_path_stats(ctx.ctx, st1)
-    chol_ms, chol_flops, chol_n = st1[0] - st0[0], st1[1] - st0[1], st1[2] - st0[2]
+    st1 = (C.c_double * 8)(); lib.srba_hip_big_path_stats2(ctx.ctx, st1)
+    chol_ms, chol_flops, chol_n, chol_seqs, gang = st1[0] - st0[0], st1[1] - st0[1], st1[2] - st0[2], st1[4] - st0[4], bool(st1[5])
     tot_trials, tot_obs, max_elapsed = multi.aggregate(dist, "cuda" if backend == "nccl" else "cpu", trials, obs_trials, elapsed)
     if rank == 0:
         caps = [batch[i] for i in range(W)]
@@ -222,9 +222,9 @@ def bench_cfg4(args, dist, rank, world, local_rank, backend, emit=True):
                            "map_build_s": round(t_map, 2), "sequential_ms_per_kf": round(1e3 * t_map / n_kf, 3), "dataset_s": round(t_gen, 2),
                            "parallelism": "replicas x%d" % world, "solver": "Schur complement (grid-wide), dense blocked LL^t across workgroups (32-column panels, v_mfma_f64_16x16x4_f64 trailing updates)"},
                 "roofline": {"bound": "mfma", "achieved": achieved, "peak": 78.6, "unit": "TFLOP/s", "frac": achieved / 78.6, "traffic": None,
-                             "kernel": "k_chol_panel + k_chol_update (dense LL^t of the reduced system)", "factorisations": int(chol_n), "kernel_ms": chol_ms / max(chol_n, 1), "flops_per_factorisation": chol_flops / max(chol_n, 1),
+                             "kernel": "k_chol_panel + k_chol_update (dense LL^t of the reduced system)", "factorisations": int(chol_n), "launch_sequences": int(chol_seqs), "windows_per_sequence": chol_n / max(chol_seqs, 1), "kernel_ms": chol_ms / max(chol_seqs, 1), "ms_per_factorisation": chol_ms / max(chol_n, 1), "flops_per_factorisation": chol_flops / max(chol_n, 1), "lock_step_gang": gang,
                              "lane_time_over_step_time": chol_ms / (1e3 * elapsed) if elapsed > 0 else None, "aggregate_TFLOPs_over_timed_region": chol_flops / max(elapsed, 1e-9) / 1e12,
-                             "note": "peak = AMD's published FP64 matrix figure for MI355X (the guide lists none); kernel_ms = event time of one factorisation on its stream (several windows are in flight at once on separate streams, so the sum over the lanes can exceed the step time: lane_time_over_step_time); the factorisation is bound by its ~60 dependent launches, DESIGN 4c"},
+                             "note": "peak = AMD's published FP64 matrix figure for MI355X (the guide lists none); the large windows of a step run in lock-step (DESIGN 4c, Gang): ONE sequence of panel / update launches factors the reduced systems of all windows that are in a trial, kernel_ms = HIP-event time of one such sequence on the context stream (the sequences do not overlap: lane_time_over_step_time is the share of the step inside them), achieved = flops of all its windows / that time; with SRBA_HIP_BIG_GANG=0 every window has its own stream and sequence and the times overlap"},
                 "cpu_baseline": cpu}
         if emit:
             print(json.dumps(line), flush=True)

@@ -298,6 +298,9 @@ int  srba_hip_batch_stats(srba_hip_ctx *ctx, srba_batch_stats *out);
 /* Large-window path (capsules whose system does not fit one wavefront's LDS; srba_amd/csrc/srba_big.hpp): dense Cholesky factorisations since the last upload.
  * out = { total milliseconds inside the blocked factorisation (HIP events on the context stream), total flops ld^3/3, number of factorisations, largest system }. */
 int    srba_hip_big_path_stats(srba_hip_ctx *ctx, double out[4]);
+/* The same with the launch sequences counted: since round 4 the large windows of a batch run in lock-step and ONE sequence of panel / update launches factors the systems of all
+ * windows that are in a trial (srba_big.hpp, Gang). out = { ms, flops, factorisations, largest system, launch sequences, 1 if the lock-step gang is on, 0, 0 }. */
+int    srba_hip_big_path_stats2(srba_hip_ctx *ctx, double out[8]);
 /* Time (ms) spent inside the last srba_hip_lm_run* kernel launch, measured with HIP events on the context stream. */
 double srba_hip_last_kernel_ms(srba_hip_ctx *ctx);
 /* Durations (ms, most recent first) of the last `n` srba_hip_lm_run / srba_hip_lm_run_async launches: HIP events recorded on the context

@@ -23,6 +23,20 @@ constexpr int CT = 64;   // trailing-update tile
 
 struct BigSys { double *A; double *Ldiag; double *rhs; double *y; int *flag; int n, ld; }; // A: ld x ld row-major (lower triangle used), Ldiag: [ld][CB] factored diagonal blocks
 
+// A GANG of large capsules in lock-step (round 4): every grid-wide phase below is launched ONCE for up to kGang capsules, blockIdx.y = slot of the gang; `mask` says which
+// slots take part in this launch (the host knows which windows need a trial, which an accepted step's relinearisation, which a restore). A slot owns a region of the
+// partial-sum / scalar / flag buffers (slot w: part + w * 3 * kBigPart, scal + w * 16, iscal + w * 8) and its dense system lies where its capsule's does (A[w]).
+// Every slot uses the grid it would have alone for the phases that reduce over workgroups (fixed partition of the sums): a window's numbers do not depend on its gang.
+constexpr int kGang = 16, kBigPart = 4096;
+struct Gang { int p[kGang]; int ld[kGang]; int nsys[kGang]; double *A[kGang]; unsigned mask; int n; double *part; double *scal; int *iscal; };
+enum { BS_CHI2 = 0, BS_MAXDIAG = 1, BS_DEN = 2, BS_NINF = 3, BS_LAMBDA = 4 }; // scal[w * 16 + .]; iscal[w * 8 + .] = {invalid Jacobians, not-positive-definite flag}
+__device__ __forceinline__ BigSys gang_sys(const Gang &G, int w) {
+	BigSys S; const int ld = G.ld[w]; S.A = G.A[w]; S.Ldiag = S.A + (size_t)ld * ld; S.rhs = S.Ldiag + (size_t)ld * CB; S.y = S.rhs + ld; S.flag = G.iscal + w * 8 + 1; S.n = G.nsys[w]; S.ld = ld; return S;
+}
+__device__ __forceinline__ int big_grid_dev(long long items, int block) { const long long g = (items + block - 1) / block; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+#define BIG_ENTER() const int gw = blockIdx.y; if (!((G.mask >> gw) & 1u)) return; const int p = G.p[gw]
+#define BIG_FLAG() (G.iscal[gw * 8 + 1])
+
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double lane_bcast(double v, int l) { // l is wave-uniform
@@ -54,9 +68,11 @@ __device__ __forceinline__ bool chol_block_regs(double (&a)[CB], double (&rinv)[
 
 // Panel step k0: every workgroup factors the diagonal block itself (registers, lane CB carries the right-hand side); workgroup 0 publishes L_kk (Ldiag) and
 // y_k, workgroup b >= 1 solves rows k0+CB+64(b-1) .. +63 of the panel against it and eliminates them from the right-hand side.
-__global__ void __launch_bounds__(64) k_chol_panel(const BigSys S, int k0) {
+__global__ void __launch_bounds__(64) k_chol_panel(const Gang G, int k0) {
 	__shared__ double Ls[(CB + 1) * (CB + 1)]; __shared__ double ri[CB];
+	BIG_ENTER(); (void)p; const BigSys S = gang_sys(G, gw);
 	const int lane = threadIdx.x, ld = S.ld;
+	if (k0 >= ld || (int)blockIdx.x > (ld - k0 - CB + 63) / 64) return; // this window is smaller than the largest of the gang
 	if (*S.flag) return; // an earlier panel met a non-positive pivot
 	const int row = k0 + CB + 64 * ((int)blockIdx.x - 1) + lane; const bool has_row = blockIdx.x > 0 && row < ld;
 	double *Arow = (double *)__builtin_assume_aligned(S.A + (size_t)(has_row ? row : k0) * ld + k0, 16);
@@ -108,11 +124,12 @@ __global__ void __launch_bounds__(64) k_chol_panel(const BigSys S, int k0) {
 
 // Trailing update after panel k0: tile (ti, tj), tj <= ti, of the matrix below/right of the panel: C -= X_i X_j^t, X = A[:, k0 .. k0+CB). C is loaded straight
 // into the MFMA accumulators (D = (-X_i) X_j^t + C) while the operands travel through LDS: two dependent memory phases instead of three.
-__global__ void __launch_bounds__(256) k_chol_update(const BigSys S, int k0, int ntile) {
+__global__ void __launch_bounds__(256) k_chol_update(const Gang G, int k0) {
 	__shared__ double Xi[CT * (CB + 1)], Xj[CT * (CB + 1)];
+	BIG_ENTER(); (void)p; const BigSys S = gang_sys(G, gw);
+	{ const int below = S.ld - k0 - CB, nt = below > 0 ? (below + CT - 1) / CT : 0; if ((int)blockIdx.x >= nt * (nt + 1) / 2) return; }
 	if (*S.flag) return;
 	int t = blockIdx.x, ti = 0; while ((ti + 1) * (ti + 2) / 2 <= t) ti++; const int tj = t - ti * (ti + 1) / 2; // linear tile index -> (ti, tj) of the lower triangle
-	(void)ntile;
 	const int base = k0 + CB, i0 = base + CT * ti, j0 = base + CT * tj, ld = S.ld, tid = threadIdx.x;
 	const int w = tid >> 6, lane = tid & 63, wr = w >> 1, wc = w & 1;
 	const bool active = !(ti == tj && wc > wr); // the strictly upper quarter of a diagonal tile is never read
@@ -295,8 +312,9 @@ __global__ void __launch_bounds__(256) k_chol_persistent(const BigSys S, unsigne
 
 // L^t x = y in place in S.y (one workgroup): block rows from the last to the first. The CB x CB triangular solve runs in the first wavefront with column
 // `lane` of L_kk in registers (x_c travels by v_readlane); all four wavefronts then eliminate x_k from the rows above.
-__global__ void __launch_bounds__(256) k_chol_bsub(const BigSys S) {
+__global__ void __launch_bounds__(256) k_chol_bsub(const Gang G) {
 	__shared__ double xs[CB];
+	BIG_ENTER(); (void)p; const BigSys S = gang_sys(G, gw);
 	const int tid = threadIdx.x, lane = tid & 63, ld = S.ld, nblk = ld / CB;
 	if (*S.flag) return;
 	for (int kb = nblk - 1; kb >= 0; kb--) {
@@ -330,9 +348,10 @@ __global__ void __launch_bounds__(256) k_chol_bsub(const BigSys S) {
 #define BIG_GID() (blockIdx.x * blockDim.x + threadIdx.x)
 #define BIG_STRIDE() (gridDim.x * blockDim.x)
 
-template <int FAM> __global__ void __launch_bounds__(256) kb_spantree(const Batch B, const DevParams prm, int p, int only_needed, const int *skip) {
+template <int FAM> __global__ void __launch_bounds__(256) kb_spantree(const Batch B, const DevParams prm, const Gang G, int only_needed, int use_skip) {
+	BIG_ENTER();
 	typedef Worker<FAM> W; typedef typename W::PO PO; typedef typename W::pose_t pose_t; constexpr int PD = W::PD;
-	if (skip && *skip) return;
+	if (use_skip && BIG_FLAG()) return;
 	const ProbDesc &d = B.desc[p]; const int cnt = only_needed ? d.n_need : d.n_pairs;
 	for (int q = BIG_GID(); q < cnt; q += BIG_STRIDE()) {
 		const int pr = only_needed ? B.need_idx[d.o_pair + q] : q;
@@ -344,15 +363,18 @@ template <int FAM> __global__ void __launch_bounds__(256) kb_spantree(const Batc
 		PO::st(B.pose + (d.o_pair + pr) * 2 * PD, acc); PO::st(B.pose + ((d.o_pair + pr) * 2 + 1) * PD, inv(acc));
 	}
 }
-template <int FAM> __global__ void __launch_bounds__(256) kb_jac_init(const Batch B, const DevParams prm, int p) {
+template <int FAM> __global__ void __launch_bounds__(256) kb_jac_init(const Batch B, const DevParams prm, const Gang G) {
+	BIG_ENTER();
 	const ProbDesc &d = B.desc[p];
 	for (int i = BIG_GID(); i < d.n_valid; i += BIG_STRIDE()) { B.valid[d.o_valid + i] = 1; B.first_fail[d.o_valid + i] = 0x7fffffff; }
 }
-template <int FAM> __global__ void __launch_bounds__(128) kb_jac(const Batch B, const DevParams prm, int p) {
+template <int FAM> __global__ void __launch_bounds__(128) kb_jac(const Batch B, const DevParams prm, const Gang G) {
+	BIG_ENTER();
 	Worker<FAM> Wk(B, B.desc[p], prm); const ProbDesc &d = B.desc[p];
 	for (int b = BIG_GID(); b < d.n_bp + d.n_bf; b += BIG_STRIDE()) { if (b < d.n_bp) Wk.jac_dh_dp(b); else Wk.jac_dh_df(b - d.n_bp); }
 }
-template <int FAM> __global__ void __launch_bounds__(256) kb_jac_post(const Batch B, const DevParams prm, int p) { // invalid-row semantics of Worker::phase_jacobians
+template <int FAM> __global__ void __launch_bounds__(256) kb_jac_post(const Batch B, const DevParams prm, const Gang G) {
+	BIG_ENTER(); // invalid-row semantics of Worker::phase_jacobians
 	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L, O = W::O; const ProbDesc &d = B.desc[p];
 	for (int b = BIG_GID(); b < d.n_bp + d.n_bf; b += BIG_STRIDE()) {
 		if (b < d.n_bp) {
@@ -379,7 +401,8 @@ constexpr int BIG_HEAVY = 48;   // Hessian / Schur blocks with more terms than t
 
 // Hessian blocks (K6): one thread per block; the U_Ap blocks with many terms (an edge near the root of a deep window collects thousands of observations) are left
 // to kb_hessian_heavy.
-template <int FAM> __global__ void __launch_bounds__(128) kb_hessian(const Batch B, const DevParams prm, int p, int *ninv_out) {
+template <int FAM> __global__ void __launch_bounds__(128) kb_hessian(const Batch B, const DevParams prm, const Gang G) {
+	BIG_ENTER(); int *ninv_out = G.iscal + gw * 8;
 	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L, O = W::O; Worker<FAM> Wk(B, B.desc[p], prm); const ProbDesc &d = B.desc[p];
 	const double *Jp = B.Jp + d.o_bp * O * P, *Jf = B.Jf + d.o_bf * O * L; const unsigned char *rp = B.bp_ok + d.o_bp, *rf = B.bf_ok + d.o_bf;
 	const bool latch = prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL; int ninv = 0;
@@ -396,9 +419,11 @@ template <int FAM> __global__ void __launch_bounds__(128) kb_hessian(const Batch
 	if (ninv) atomicAdd(ninv_out, ninv);
 }
 // one workgroup per U_Ap block (grid = n_hap; the light ones return at once): terms strided over the threads, fixed-order reduction
-template <int FAM> __global__ void __launch_bounds__(256) kb_hessian_heavy(const Batch B, const DevParams prm, int p, int *ninv_out) {
+template <int FAM> __global__ void __launch_bounds__(256) kb_hessian_heavy(const Batch B, const DevParams prm, const Gang G) {
+	BIG_ENTER(); int *ninv_out = G.iscal + gw * 8;
 	typedef Worker<FAM> W; constexpr int P = W::P, O = W::O; Worker<FAM> Wk(B, B.desc[p], prm); const ProbDesc &d = B.desc[p];
 	__shared__ double sh[4 * P * P];
+	if ((int)blockIdx.x >= d.n_hap) return;
 	const int b = blockIdx.x, tb = B.hap_term_off[d.o_hapoff + b], te = B.hap_term_off[d.o_hapoff + b + 1];
 	if (te - tb <= BIG_HEAVY) return;
 	const double *Jp = B.Jp + d.o_bp * O * P; const unsigned char *rp = B.bp_ok + d.o_bp; const int *t1 = B.hap_t1 + d.o_hapt, *t2 = B.hap_t2 + d.o_hapt;
@@ -414,25 +439,39 @@ template <int FAM> __global__ void __launch_bounds__(256) kb_hessian_heavy(const
 	if (ninv) atomicAdd(ninv_out, ninv);
 }
 // per-workgroup partial sums in a fixed order; kb_reduce adds them sequentially (deterministic)
-template <int FAM> __global__ void __launch_bounds__(256) kb_residuals(const Batch B, const DevParams prm, int p, double *out, double *partial, const int *skip) {
-	if (skip && *skip) return;
+template <int FAM> __global__ void __launch_bounds__(256) kb_residuals(const Batch B, const DevParams prm, const Gang G, int to_trial_copy, int use_skip) {
+	BIG_ENTER();
+	if (use_skip && BIG_FLAG()) return;
 	Worker<FAM> Wk(B, B.desc[p], prm); constexpr int O = Worker<FAM>::O; const ProbDesc &d = B.desc[p];
+	const int ngx = big_grid_dev(d.n_obs, 256); if ((int)blockIdx.x >= ngx) return; // the partition of the sum is the window's own
+	double *out = to_trial_copy ? B.resid2 : B.resid, *partial = G.part + (size_t)gw * 3 * kBigPart;
 	double acc = 0;
-	for (int i = BIG_GID(); i < d.n_obs; i += BIG_STRIDE()) { double r[O]; acc += Wk.residual_row(i, r); for (int k = 0; k < O; k++) out[(long long)(d.o_obs + i) * O + k] = r[k]; }
+	for (int i = BIG_GID(); i < d.n_obs; i += ngx * 256) { double r[O]; acc += Wk.residual_row(i, r); for (int k = 0; k < O; k++) out[(long long)(d.o_obs + i) * O + k] = r[k]; }
 	__shared__ double sh[4]; const double v = wave_sum(acc);
 	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
 	__syncthreads();
 	if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
-__global__ void __launch_bounds__(256) kb_reduce(const double *partial, int n, double *out, int is_max) { // one workgroup, fixed order (n <= 4096)
+// kind: 0 = one partial per workgroup of kb_residuals (n_obs items), 1 = kb_maxdiag (nK + nF), 2 = kb_dot (n_scal)
+__global__ void __launch_bounds__(256) kb_reduce(const Batch B, const Gang G, int which, int kind, int slot, int is_max) { // one workgroup per window, fixed order (n <= 4096)
 	__shared__ double sh[4];
+	BIG_ENTER(); const ProbDesc &d = B.desc[p];
+	const int n = big_grid_dev(kind == 0 ? d.n_obs : (kind == 1 ? d.nK + d.nF : d.n_scal), 256);
+	const double *partial = G.part + ((size_t)gw * 3 + which) * kBigPart; double *out = G.scal + gw * 16 + slot;
 	double v = 0; for (int i = threadIdx.x; i < n; i += 256) v = is_max ? fmax(v, partial[i]) : v + partial[i];
 	v = is_max ? wave_max(v) : wave_sum(v);
 	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
 	__syncthreads();
 	if (threadIdx.x == 0) *out = is_max ? fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3])) : (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
-__global__ void kb_set_scalar(double *dst, double v) { *dst = v; }
+struct GangLambda { double v[kGang]; };
+__global__ void kb_set_lambda(const Gang G, const GangLambda lam) { const int w = threadIdx.x; if (w < kGang && ((G.mask >> w) & 1u)) G.scal[w * 16 + BS_LAMBDA] = lam.v[w]; }
+// what the host path did with device-to-device copies, for all windows of a gang at once: 0 = grad0 -> grad, 1 = grad -> grad0 (extension: the Schur kernels reduce grad in place), 2 = residuals of the accepted trial -> current
+__global__ void __launch_bounds__(256) kb_copy_vec(const Batch B, const Gang G, int kind, int O) {
+	BIG_ENTER(); const ProbDesc &d = B.desc[p];
+	if (kind == 2) { const double *s = B.resid2 + (long long)d.o_obs * O; double *t = B.resid + (long long)d.o_obs * O; for (long long k = BIG_GID(); k < (long long)d.n_obs * O; k += BIG_STRIDE()) t[k] = s[k]; }
+	else { const double *s = (kind == 0 ? B.grad0 : B.grad) + d.o_scal; double *t = (kind == 0 ? B.grad : B.grad0) + d.o_scal; for (int k = BIG_GID(); k < d.n_scal; k += BIG_STRIDE()) t[k] = s[k]; }
+}
 template <int O, int M> __device__ __forceinline__ void grad_term(double (&acc)[M], const double *A, const double *r, const DevParams &prm) {
 	double lr[O], a[O * M]; ldn<O>(lr, r); ldn<O * M>(a, A);
 	if (prm.noise == SRBA_NOISE_CONSTANT_MATRIX) { double t[O]; for (int k = 0; k < O; k++) { double q = 0; for (int j = 0; j < O; j++) q += prm.lambda[k * O + j] * lr[j]; t[k] = q; } for (int k = 0; k < O; k++) lr[k] = t[k]; }
@@ -444,10 +483,12 @@ template <int O, int M> __device__ __forceinline__ void grad_term(double (&acc)[
 }
 // Gradient (K5). Workgroups 0 .. nK-1: one per unknown edge, its dh_dAp blocks strided over the 256 threads (an edge of a deep window has 10^3..10^4 of them),
 // fixed-order reduction; the following workgroups: one thread per unknown landmark (tens of dh_df blocks each).
-template <int FAM> __global__ void __launch_bounds__(256) kb_gradient(const Batch B, const DevParams prm, int p, const double *resid) {
+template <int FAM> __global__ void __launch_bounds__(256) kb_gradient(const Batch B, const DevParams prm, const Gang G) {
+	BIG_ENTER(); const double *resid = B.resid;
 	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L, O = W::O; const ProbDesc &d = B.desc[p];
 	const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0; double *g = B.grad + d.o_scal;
 	__shared__ double sh[4 * P];
+	if ((int)blockIdx.x >= d.nK + (d.nF + 255) / 256) return;
 	if ((int)blockIdx.x < d.nK) {
 		const int ci = blockIdx.x, bb = B.colp_off[d.o_colp + ci], be = B.colp_off[d.o_colp + ci + 1];
 		double acc[P];
@@ -467,9 +508,12 @@ template <int FAM> __global__ void __launch_bounds__(256) kb_gradient(const Batc
 		for (int q = 0; q < L; q++) g[d.nK * P + ci * L + q] = acc[q] * sc;
 	}
 }
-template <int FAM> __global__ void __launch_bounds__(256) kb_maxdiag(const Batch B, const DevParams prm, int p, double *partial) {
+template <int FAM> __global__ void __launch_bounds__(256) kb_maxdiag(const Batch B, const DevParams prm, const Gang G) {
+	BIG_ENTER();
 	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L; const ProbDesc &d = B.desc[p]; double mx = 0;
-	for (int i = BIG_GID(); i < d.nK + d.nF; i += BIG_STRIDE()) {
+	const int ngx = big_grid_dev(d.nK + d.nF, 256); if ((int)blockIdx.x >= ngx) return;
+	double *partial = G.part + ((size_t)gw * 3 + 1) * kBigPart;
+	for (int i = BIG_GID(); i < d.nK + d.nF; i += ngx * 256) {
 		if (i < d.nK) { const double *H = B.HAp + (d.o_hap + B.hap_diag[d.o_unk + i]) * P * P; for (int k = 0; k < P; k++) mx = fmax(mx, H[k * P + k]); }
 		else { const int l = i - d.nK; const double *H = B.Hf + (d.o_hf + B.hf_diag[d.o_ulm + l]) * L * L; for (int k = 0; k < L; k++) mx = fmax(mx, H[k * L + k]); }
 	}
@@ -479,18 +523,22 @@ template <int FAM> __global__ void __launch_bounds__(256) kb_maxdiag(const Batch
 	if (threadIdx.x == 0) partial[blockIdx.x] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
 }
 // rho denominator sum dl (lambda dl + g) and |g|_inf
-template <int FAM> __global__ void __launch_bounds__(256) kb_dot(const Batch B, const DevParams prm, int p, const double *lam, double *partial_den, double *partial_ninf, const int *skip) {
-	if (skip && *skip) return;
-	const double lambda = *lam; const ProbDesc &d = B.desc[p]; const double *dl = B.delta + d.o_scal, *g = B.grad + d.o_scal; double den = 0, ninf = 0;
-	for (int k = BIG_GID(); k < d.n_scal; k += BIG_STRIDE()) { den += dl[k] * (lambda * dl[k] + g[k]); ninf = fmax(ninf, fabs(g[k])); }
+template <int FAM> __global__ void __launch_bounds__(256) kb_dot(const Batch B, const DevParams prm, const Gang G, int use_skip) {
+	BIG_ENTER();
+	if (use_skip && BIG_FLAG()) return;
+	const double lambda = G.scal[gw * 16 + BS_LAMBDA]; const ProbDesc &d = B.desc[p]; const double *dl = B.delta + d.o_scal, *g = B.grad + d.o_scal; double den = 0, ninf = 0;
+	const int ngx = big_grid_dev(d.n_scal, 256); if ((int)blockIdx.x >= ngx) return;
+	double *partial_den = G.part + ((size_t)gw * 3 + 1) * kBigPart, *partial_ninf = G.part + ((size_t)gw * 3 + 2) * kBigPart;
+	for (int k = BIG_GID(); k < d.n_scal; k += ngx * 256) { den += dl[k] * (lambda * dl[k] + g[k]); ninf = fmax(ninf, fabs(g[k])); }
 	__shared__ double sh[8]; const double v = wave_sum(den), m = wave_max(ninf);
 	if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = v; sh[4 + (threadIdx.x >> 6)] = m; }
 	__syncthreads();
 	if (threadIdx.x == 0) { partial_den[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]); partial_ninf[blockIdx.x] = fmax(fmax(sh[4], sh[5]), fmax(sh[6], sh[7])); }
 }
 // ---- Schur complement (schur.h:180-311), grid-wide
-template <int FAM> __global__ void __launch_bounds__(128) kb_schur_inv(const Batch B, const DevParams prm, int p, const double *lam) {
-	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L; const ProbDesc &d = B.desc[p]; const double lambda = *lam;
+template <int FAM> __global__ void __launch_bounds__(128) kb_schur_inv(const Batch B, const DevParams prm, const Gang G) {
+	BIG_ENTER();
+	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L; const ProbDesc &d = B.desc[p]; const double lambda = G.scal[gw * 16 + BS_LAMBDA];
 	if constexpr (!W::T::REL) {
 		for (int l = BIG_GID(); l < d.nF; l += BIG_STRIDE()) {
 			double M[L * L], Mi[L * L]; const double *src = B.Hf + (d.o_hf + B.hf_diag[d.o_ulm + l]) * L * L;
@@ -504,10 +552,12 @@ template <int FAM> __global__ void __launch_bounds__(128) kb_schur_inv(const Bat
 }
 // H_Ap(i,j) -= sum_l W_il Hf_l^-1 W_jl^t (schur.h:213-260). One workgroup per U_Ap block: the terms (landmarks seen through both edges, up to
 // all of them for a diagonal block) are strided over the 256 threads, each term writes its own Y = W Hf^-1 where the gradient / back-substitution need it.
-template <int FAM> __global__ void __launch_bounds__(256) kb_schur_reduce(const Batch B, const DevParams prm, int p) {
+template <int FAM> __global__ void __launch_bounds__(256) kb_schur_reduce(const Batch B, const DevParams prm, const Gang G) {
+	BIG_ENTER();
 	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L; const ProbDesc &d = B.desc[p];
 	if constexpr (!W::T::REL) {
 		__shared__ double sh[4 * P * P];
+		if ((int)blockIdx.x >= d.n_hap) return;
 		const int b = blockIdx.x, tb = B.sch_term_off[d.o_hapoff + b], te = B.sch_term_off[d.o_hapoff + b + 1];
 		if (tb == te) return;
 		double Hl[P * P];
@@ -546,11 +596,13 @@ template <int FAM> __global__ void __launch_bounds__(256) kb_schur_reduce(const 
 	}
 }
 // g_Ap(i) -= sum_l Y_il g_f(l) (schur.h:262-283): one workgroup per unknown edge
-template <int FAM> __global__ void __launch_bounds__(256) kb_schur_grad(const Batch B, const DevParams prm, int p) {
+template <int FAM> __global__ void __launch_bounds__(256) kb_schur_grad(const Batch B, const DevParams prm, const Gang G) {
+	BIG_ENTER();
 	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L; const ProbDesc &d = B.desc[p];
 	if constexpr (!W::T::REL) {
 		__shared__ double sh[4 * P];
 		double *g = B.grad + d.o_scal; const double *gf = g + d.nK * P;
+		if ((int)blockIdx.x >= d.nK) return;
 		const int i = blockIdx.x, b = B.hap_diag[d.o_unk + i];
 		double acc[P];
 #pragma unroll
@@ -568,9 +620,10 @@ template <int FAM> __global__ void __launch_bounds__(256) kb_schur_grad(const Ba
 		if (threadIdx.x < P) g[i * P + threadIdx.x] -= v;
 	}
 }
-template <int FAM> __global__ void __launch_bounds__(128) kb_schur_features(const Batch B, const DevParams prm, int p, const int *skip) {
+template <int FAM> __global__ void __launch_bounds__(128) kb_schur_features(const Batch B, const DevParams prm, const Gang G, int use_skip) {
+	BIG_ENTER();
 	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L; const ProbDesc &d = B.desc[p];
-	if (skip && *skip) return;
+	if (use_skip && BIG_FLAG()) return;
 	if constexpr (!W::T::REL) {
 		double *g = B.grad + d.o_scal, *dl = B.delta + d.o_scal;
 		for (int l = BIG_GID(); l < d.nF; l += BIG_STRIDE()) {
@@ -587,9 +640,10 @@ template <int FAM> __global__ void __launch_bounds__(128) kb_schur_features(cons
 	}
 }
 // (H + lambda I) into the dense lower triangle + right-hand side; identity padding up to ld
-__global__ void kb_dense_clear(const BigSys S) { for (size_t k = BIG_GID(); k < (size_t)S.ld * S.ld; k += BIG_STRIDE()) { const int r = (int)(k / S.ld), c = (int)(k % S.ld); S.A[k] = (r == c && r >= S.n) ? 1.0 : 0.0; } if (BIG_GID() == 0) *S.flag = 0; }
-template <int FAM> __global__ void __launch_bounds__(128) kb_dense_assemble(const Batch B, const DevParams prm, int p, const BigSys S, const double *lam, int full_system) {
-	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L; const ProbDesc &d = B.desc[p]; const double lambda = *lam;
+__global__ void kb_dense_clear(const Gang G) { BIG_ENTER(); (void)p; const BigSys S = gang_sys(G, gw); for (size_t k = BIG_GID(); k < (size_t)S.ld * S.ld; k += BIG_STRIDE()) { const int r = (int)(k / S.ld), c = (int)(k % S.ld); S.A[k] = (r == c && r >= S.n) ? 1.0 : 0.0; } if (BIG_GID() == 0) *S.flag = 0; }
+template <int FAM> __global__ void __launch_bounds__(128) kb_dense_assemble(const Batch B, const DevParams prm, const Gang G, int full_system) {
+	BIG_ENTER(); const BigSys S = gang_sys(G, gw);
+	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L; const ProbDesc &d = B.desc[p]; const double lambda = G.scal[gw * 16 + BS_LAMBDA];
 	const int total = d.n_hap + (full_system ? d.n_hapf + d.n_hf : 0);
 	for (int b = BIG_GID(); b < total; b += BIG_STRIDE()) {
 		if (b < d.n_hap) { // upper block (i <= j) -> lower triangle: A[Pj+q][Pi+r] = H[r][q]
@@ -606,18 +660,20 @@ template <int FAM> __global__ void __launch_bounds__(128) kb_dense_assemble(cons
 	const double *g = B.grad + d.o_scal;
 	for (int k = BIG_GID(); k < S.ld; k += BIG_STRIDE()) S.rhs[k] = k < S.n ? g[k] : 0.0;
 }
-__global__ void kb_take_delta(const Batch B, int p, const BigSys S) { if (*S.flag) return; const ProbDesc &d = B.desc[p]; double *dl = B.delta + d.o_scal; for (int k = BIG_GID(); k < d.n_scal; k += BIG_STRIDE()) if (k < S.n) dl[k] = S.y[k]; else if (S.n == d.n_scal) dl[k] = 0; }
+__global__ void kb_take_delta(const Batch B, const Gang G) { BIG_ENTER(); const BigSys S = gang_sys(G, gw); if (*S.flag) return; const ProbDesc &d = B.desc[p]; double *dl = B.delta + d.o_scal; for (int k = BIG_GID(); k < d.n_scal; k += BIG_STRIDE()) if (k < S.n) dl[k] = S.y[k]; else if (S.n == d.n_scal) dl[k] = 0; }
 // K12 backup + K11 apply / restore
-template <int FAM> __global__ void __launch_bounds__(128) kb_apply(const Batch B, const DevParams prm, int p, const int *skip) {
+template <int FAM> __global__ void __launch_bounds__(128) kb_apply(const Batch B, const DevParams prm, const Gang G, int use_skip) {
+	BIG_ENTER();
 	typedef Worker<FAM> W; typedef typename W::PO PO; constexpr int P = W::P, L = W::L, PD = W::PD; const ProbDesc &d = B.desc[p]; const double *dl = B.delta + d.o_scal;
-	if (skip && *skip) return;
+	if (use_skip && BIG_FLAG()) return;
 	for (int i = BIG_GID(); i < d.nK + d.nF * L + d.n_req; i += BIG_STRIDE()) {
 		if (i < d.nK) { double *e = B.edge + (d.o_edge + i) * PD, *o = B.old_edge + (d.o_unk + i) * PD; for (int k = 0; k < PD; k++) o[k] = e[k]; PO::st(e, comp(PO::expm(dl + i * P), PO::ld(e))); }
 		else if (i < d.nK + d.nF * L) { const int k = i - d.nK; B.old_ulm[d.o_ulm * L + k] = B.ulm[d.o_ulm * L + k]; B.ulm[d.o_ulm * L + k] += dl[d.nK * P + k]; }
 		else { const int r = i - d.nK - d.nF * L; const double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD; double *o = B.old_pose + (d.o_req + r) * PD; for (int k = 0; k < PD; k++) o[k] = s[k]; }
 	}
 }
-template <int FAM> __global__ void __launch_bounds__(128) kb_restore(const Batch B, const DevParams prm, int p) {
+template <int FAM> __global__ void __launch_bounds__(128) kb_restore(const Batch B, const DevParams prm, const Gang G) {
+	BIG_ENTER();
 	typedef Worker<FAM> W; constexpr int L = W::L, PD = W::PD; const ProbDesc &d = B.desc[p];
 	for (int i = BIG_GID(); i < d.nK + d.nF * L + d.n_req; i += BIG_STRIDE()) {
 		if (i < d.nK) { for (int k = 0; k < PD; k++) B.edge[(d.o_edge + i) * PD + k] = B.old_edge[(d.o_unk + i) * PD + k]; }
@@ -625,7 +681,8 @@ template <int FAM> __global__ void __launch_bounds__(128) kb_restore(const Batch
 		else { const int r = i - d.nK - d.nF * L; double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD; const double *o = B.old_pose + (d.o_req + r) * PD; for (int k = 0; k < PD; k++) s[k] = o[k]; }
 	}
 }
-template <int FAM> __global__ void __launch_bounds__(128) kb_cov_recovery(const Batch B, const DevParams prm, int p, int schur_active) {
+template <int FAM> __global__ void __launch_bounds__(128) kb_cov_recovery(const Batch B, const DevParams prm, const Gang G, int schur_active) {
+	BIG_ENTER();
 	typedef Worker<FAM> W; constexpr int L = W::L; const ProbDesc &d = B.desc[p];
 	if constexpr (!W::T::REL) for (int l = BIG_GID(); l < d.nF; l += BIG_STRIDE()) {
 		const bool ok = prm.cov_recovery == 1 && (schur_active ? (B.hf_ok[d.o_ulm + l] != 0) : true); B.ulm_inf_valid[d.o_ulm + l] = ok ? 1 : 0;

@@ -827,7 +827,7 @@ struct Arena { // layout builder: 256-byte aligned sub-allocations inside one bu
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->fail(std::string(#call) + ": " + hipGetErrorString(e_)); return -1; } } while (0)
 #define LNCHK(lane, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (lane)->error = std::string(#call) + ": " + hipGetErrorString(e_); return -1; } } while (0)
 static const int kBigLanes = 16;
-struct BigLane { int id = 0; hipStream_t stream = nullptr; double *d_part = nullptr, *d_scal = nullptr; int *d_iscal = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; double chol_ms = 0, chol_flops = 0; long long chol_count = 0; int chol_nmax = 0; std::string error; };
+struct BigLane { int id = 0, slots = 1 /* windows its buffers have room for (srbadev::Gang) */; hipStream_t stream = nullptr; double *d_part = nullptr, *d_scal = nullptr; int *d_iscal = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; double chol_ms = 0, chol_flops = 0; long long chol_count = 0, chol_seqs = 0; int chol_nmax = 0; std::string error; };
 
 } // namespace
 
@@ -942,7 +942,7 @@ static void symbolic_dense(const srba_problem_capsule &k, const ProbDesc &d, int
 }
 
 struct LaunchJob { int queue, cls, first, count; double cost; int grid; int delay_us = 0; int lean = 0 /* k_lm_run_lean: three wavefronts per SIMD */, two = 0 /* k_lm_run2: two wavefronts per capsule */; };
-static const int kBigPart = 4096;
+using srbadev::kBigPart;
 static const int kMaxJobs = 1024;
 
 // Index-range check of one capsule (every index the kernels dereference): a wrong capsule is reported at upload instead of reading out of bounds on the device
@@ -1006,10 +1006,9 @@ struct srba_hip_ctx {
 	char *d_in = nullptr; size_t cap_in = 0; char *d_wk = nullptr; size_t cap_wk = 0; int *d_next = nullptr;
 	double *d_part = nullptr; double *d_scal = nullptr; int *d_iscal = nullptr; // big path: partial sums [3][kBigPart], scalars, int flags (ninv, not-pd)
 	std::vector<int> big_ld; // per capsule: leading dimension of its dense system when it runs on the big path, else 0
-	double big_chol_ms = 0, big_chol_flops = 0; long long big_chol_count = 0; int big_chol_nmax = 0; // Cholesky time / flops of the big path since the last upload (sum over the lanes)
+	double big_chol_ms = 0, big_chol_flops = 0; long long big_chol_count = 0, big_chol_seqs = 0 /* launch sequences: one factors all windows of a gang */; int big_chol_nmax = 0; // Cholesky time / flops of the big path since the last upload (sum over the lanes)
 	BigLane lanes[kBigLanes]; int n_lanes_ready = 0; // lane 0 = the context stream and buffers; the others are created on first use
-	struct BigGraphSet { hipGraphExec_t g[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; }; // assemble, Cholesky, back-substitution .. rho, accept + relinearise, accept
-	std::map<int, BigGraphSet> big_graphs; bool big_use_graphs = false, big_persistent = false; int big_lanes_max = kBigLanes; // captured launch sequences of the big path, per capsule; dropped at upload
+	bool big_gang = true, big_persistent = false; int big_lanes_max = kBigLanes; // big path: windows of a batch in lock-step on one stream (gang) or one host thread + stream per window
 	int upload_threads = 1; bool dense_left = true; int hbm_from_kb = 48; bool dense_blocks_ok = true; // mid-size nearly-full systems use the dense block layout in LDS
 	bool lin_terms = true, lm_terms = true; // term-parallel U_Ap accumulation in LDS: srba_hip_linearize / the fused LM kernel
 	// fused normal equations of the relative-pose SE2 family (srba_assemble.hpp): capsules packed into bins (workgroups) by the LDS image they need, one launch; the rest take k_linearize
@@ -1034,7 +1033,6 @@ struct srba_hip_ctx {
 	size_t off_phase = 0; bool phase_timing = false; long long n_pose_total = 0; std::vector<int> cls_of;
 	void fail(const std::string &m) { error = m; g_last_error = m; }
 };
-static void big_drop_graphs(srba_hip_ctx *c);
 // Launch plan of the fused LM kernel. Every size class is one or more launches (a launch has ONE dynamic-LDS size); the HIP runtime
 // multiplexes streams onto 4 hardware queues and kernels of one queue run in order, so the plan uses n_queues streams and decides what
 // shares the chip at any time. Small capsules are wave-slot bound (VGPRs), big ones LDS bound: running them side by side fills both.
@@ -1182,7 +1180,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	for (int k = 1; k < SRBA_NCLS && ok; k++) { // (class_prio 1: the streams of the biggest classes -- low stream index, see plan_launches -- get the highest priority, 2: the lowest)
 		const int split = 4, pri = c->class_prio == 0 ? 0 : ((c->class_prio == 1) == (k < split) ? pr_greatest : pr_least);
 		ok = (c->class_prio ? hipStreamCreateWithPriority(&c->cls_stream[k], hipStreamNonBlocking, pri) : hipStreamCreateWithFlags(&c->cls_stream[k], hipStreamNonBlocking)) == hipSuccess && hipEventCreateWithFlags(&c->cls_done[k], hipEventDisableTiming) == hipSuccess; }
-	if (!ok || hipMalloc((void **)&c->d_next, sizeof(int) * kMaxJobs) != hipSuccess || hipMalloc((void **)&c->d_part, 8 * 3 * kBigPart) != hipSuccess || hipMalloc((void **)&c->d_scal, 8 * 16) != hipSuccess || hipMalloc((void **)&c->d_iscal, 4 * 8) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
+	if (!ok || hipMalloc((void **)&c->d_next, sizeof(int) * kMaxJobs) != hipSuccess || hipMalloc((void **)&c->d_part, 8 * 3 * kBigPart * srbadev::kGang) != hipSuccess || hipMalloc((void **)&c->d_scal, 8 * 16 * srbadev::kGang) != hipSuccess || hipMalloc((void **)&c->d_iscal, 4 * 8 * srbadev::kGang) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	{ const char *e = getenv("SRBA_HIP_BIG_MIN_SYS"); if (e && atoi(e) >= 0) c->big_min_sys = atoi(e); } // tuning / test knob
 	{ const char *e = getenv("SRBA_HIP_DENSE_BLOCKS"); if (e) c->dense_blocks_ok = atoi(e) != 0; }
 	{ const unsigned hc = std::thread::hardware_concurrency(); c->upload_threads = (int)std::min(32u, std::max(1u, hc)); const char *e = getenv("SRBA_HIP_UPLOAD_THREADS"); if (e) c->upload_threads = std::max(1, atoi(e)); } // host threads of srba_hip_upload_problems
@@ -1195,7 +1193,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_FLAT"); if (e) c->use_flat = atoi(e) != 0; }                     // 0 = one wavefront per capsule for the stepwise spanning-tree launch
 	{ const char *e = getenv("SRBA_HIP_BIG_LANES"); if (e && atoi(e) >= 1) c->big_lanes_max = std::min(atoi(e), kBigLanes); } // large capsules of one batch in flight at once
 	{ const char *e = getenv("SRBA_HIP_BIG_PERSISTENT"); if (e) c->big_persistent = atoi(e) != 0; }   // 1 = the blocked Cholesky of the big path as ONE persistent launch with grid barriers (k_chol_persistent) instead of one launch per panel step and per trailing update (~60 launches); measured slower, DESIGN 4c
-	{ const char *e = getenv("SRBA_HIP_BIG_GRAPHS"); if (e) c->big_use_graphs = atoi(e) != 0; }         // 1 = replay the big path's launch sequences as HIP graphs (measured: no gain, the path is bound by its kernels)
+	{ const char *e = getenv("SRBA_HIP_BIG_GANG"); if (e) c->big_gang = atoi(e) != 0; }                // 0 = one host thread + stream per large window instead of the lock-step gang on one stream
 	return c;
 }
 
@@ -1204,14 +1202,12 @@ int srba_hip_set_params(srba_hip_ctx *c, const srba_hip_params *params) {
 	if (check_params(params) != 0) { c->fail(g_last_error); return -1; }
 	if (params->family != c->params.family) { c->fail("srba_hip_set_params: the family of a context cannot change"); return -1; }
 	if (c->n_prob && (params->solver != c->params.solver || params->noise != c->params.noise || params->extensions != c->params.extensions)) c->n_prob = 0; // the uploaded batch was laid out for the old solver / noise policy: upload again
-	big_drop_graphs(c); // the captured launches carry the old parameters by value
 	c->params = *params; make_dev_params(*params, c->dp, c->dm); return 0;
 }
 
 int srba_hip_destroy(srba_hip_ctx *c) {
 	if (!c) return 0;
 	hipSetDevice(c->device);
-	big_drop_graphs(c);
 	for (int i = 0; i < kBigLanes; i++) { BigLane &l = c->lanes[i]; if (l.e0) hipEventDestroy(l.e0); if (l.e1) hipEventDestroy(l.e1); if (i > 0) { if (l.d_part) hipFree(l.d_part); if (l.d_scal) hipFree(l.d_scal); if (l.d_iscal) hipFree(l.d_iscal); if (l.stream) hipStreamDestroy(l.stream); } }
 	if (c->d_in) hipFree(c->d_in); if (c->d_wk) hipFree(c->d_wk); if (c->d_next) hipFree(c->d_next); if (c->d_spec) hipFree(c->d_spec); c->h_in.release(); if (c->h_out) hipHostFree(c->h_out); if (c->ev_h2d) hipEventDestroy(c->ev_h2d); if (c->d_part) hipFree(c->d_part); if (c->d_scal) hipFree(c->d_scal); if (c->d_iscal) hipFree(c->d_iscal);
 	for (int i = 0; i < srba_hip_ctx::kRing; i++) { if (c->ring0[i]) hipEventDestroy(c->ring0[i]); if (c->ring1[i]) hipEventDestroy(c->ring1[i]); }
@@ -1251,7 +1247,7 @@ static int set_asm_flags(srba_hip_ctx *c) {
 static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *caps, int n) {
 	if (!c || !caps || n <= 0) { if (c) c->fail("upload: bad arguments"); return -1; }
 	HIPCHK(c, hipSetDevice(c->device));
-	c->big_chol_ms = c->big_chol_flops = 0; c->big_chol_count = 0; c->big_chol_nmax = 0; big_drop_graphs(c);
+	c->big_chol_ms = c->big_chol_flops = 0; c->big_chol_count = c->big_chol_seqs = 0; c->big_chol_nmax = 0;
 	c->n_prob = 0; // whatever was uploaded before stops being launchable / readable now: a failed upload leaves the context empty, not half-updated
 	static const bool host_timing = getenv("SRBA_HIP_HOST_TIMING") != nullptr; static double acc[4] = {0, 0, 0, 0}; static long long calls = 0; auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }; const double ht0 = host_timing ? now() : 0; double ht1 = 0, ht2 = 0;
 	const int P = c->dm.P, L = c->dm.L, O = c->dm.O, PD = c->dm.PD, PDX = c->dm.PDX();
@@ -1522,6 +1518,7 @@ int srba_hip_reset_state(srba_hip_ctx *c) {
 }
 
 int srba_hip_big_path_stats(srba_hip_ctx *c, double out[4]) { if (!c || !out) return -1; out[0] = c->big_chol_ms; out[1] = c->big_chol_flops; out[2] = (double)c->big_chol_count; out[3] = c->big_chol_nmax; return 0; }
+int srba_hip_big_path_stats2(srba_hip_ctx *c, double out[8]) { if (!c || !out) return -1; out[0] = c->big_chol_ms; out[1] = c->big_chol_flops; out[2] = (double)c->big_chol_count; out[3] = c->big_chol_nmax; out[4] = (double)c->big_chol_seqs; out[5] = c->big_gang && !c->big_persistent ? 1 : 0; out[6] = out[7] = 0; return 0; }
 int srba_hip_batch_stats(srba_hip_ctx *c, srba_batch_stats *out) { if (!c || !out) return -1; *out = c->stats; return 0; }
 
 } // extern "C"
@@ -1564,201 +1561,238 @@ __attribute__((constructor)) static void srba_hip_runtime_defaults() { setenv("G
 
 // =================================================================================================== the multi-workgroup path for large capsules (srba_big.hpp)
 static inline int big_grid(long long items, int block) { return (int)std::max<long long>(1, std::min<long long>((items + block - 1) / block, 4096)); }
-// The LM loop of a large capsule is driven from the host (one stream synchronisation per trial). When a batch holds several of them, up to kBigLanes are in flight at
-// once, each on its own host thread + stream with its own scalar / partial-sum buffers: their short dependent launches interleave on the device.
-static srbadev::BigSys big_sys(srba_hip_ctx *c, BigLane *ln, int p) {
-	const ProbDesc &d = c->desc[p]; const int ld = c->big_ld[p]; srbadev::BigSys S;
-	double *base = c->B.dense + d.o_dense; S.A = base; S.Ldiag = base + (size_t)ld * ld; S.rhs = S.Ldiag + (size_t)ld * srbadev::CB; S.y = S.rhs + ld; S.flag = ln->d_iscal + 1; S.n = d.n_sys; S.ld = ld; return S;
+// The LM loop of a large capsule is driven from the host. Since round 4 a batch that holds several such capsules runs them as a GANG in lock-step (big_gang_run): every
+// grid-wide phase is ONE launch for all windows that need it (blockIdx.y = slot of the gang, srbadev::Gang::mask = who takes part), the host reads the scalars of all
+// windows back with one stream synchronisation per phase group and walks the control flow of optimize_edges.h:454-696 for each window on its own; a window that finishes
+// hands its slot to the next capsule of the class. The ~60 short dependent launches of a factorisation are shared by up to 16 windows instead of being queued 16 times.
+// SRBA_HIP_BIG_GANG=0 selects the earlier scheme: up to kBigLanes host threads, each driving a gang of one on its own stream with its own scalar / partial-sum buffers.
+using srbadev::BS_CHI2; using srbadev::BS_MAXDIAG; using srbadev::BS_DEN; using srbadev::BS_NINF; using srbadev::BS_LAMBDA;
+static void gang_set(srba_hip_ctx *c, srbadev::Gang &G, int w, int p) {
+	const ProbDesc &d = c->desc[p]; G.p[w] = p; G.ld[w] = c->big_ld[p]; G.nsys[w] = d.n_sys; G.A[w] = c->B.dense + d.o_dense; G.n = std::max(G.n, w + 1);
 }
-#define BIGKG(KERNEL, grid, block, ...) with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), dim3(std::max(1, (int)(grid))), dim3(block), 0, ln->stream, c->B, c->dp, p, ##__VA_ARGS__); })
-#define BIGK(KERNEL, items, block, ...) with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), dim3(big_grid((items), (block))), dim3(block), 0, ln->stream, c->B, c->dp, p, ##__VA_ARGS__); })
-// deterministic reduction of per-workgroup partials into d_scal[slot]
-static void big_reduce(srba_hip_ctx *c, BigLane *ln, int which, int nblk, int slot, int is_max) { hipLaunchKernelGGL(srbadev::kb_reduce, dim3(1), dim3(256), 0, ln->stream, ln->d_part + (size_t)which * kBigPart, nblk, ln->d_scal + slot, is_max); }
-// scalar slots of the big path on the device: d_scal = {chi2, max diag, rho denominator, |g|_inf, lambda}; d_iscal = {invalid Jacobians, not-positive-definite flag}
-enum { BS_CHI2 = 0, BS_MAXDIAG = 1, BS_DEN = 2, BS_NINF = 3, BS_LAMBDA = 4 };
-// A trial of the host-driven LM loop is ~80 short dependent launches; their sequence depends only on the capsule, so it is captured once per capsule into
-// HIP graphs (lambda travels through d_scal, a failed factorisation through the device flag that the later kernels test) and replayed.
-template <class F> static int big_replay(srba_hip_ctx *c, BigLane *ln, int p, int which, F &&enqueue) {
-	if (!c->big_use_graphs) { enqueue(); return 0; }
-	hipGraphExec_t &slot = c->big_graphs[p * kBigLanes + ln->id].g[which]; // (only lane 0 runs when graphs are on)
-	if (!slot) {
-		hipGraph_t g = nullptr;
-		LNCHK(ln, hipStreamBeginCapture(ln->stream, hipStreamCaptureModeThreadLocal));
-		enqueue();
-		LNCHK(ln, hipStreamEndCapture(ln->stream, &g));
-		LNCHK(ln, hipGraphInstantiate(&slot, g, nullptr, nullptr, 0));
-		LNCHK(ln, hipGraphDestroy(g));
-	}
-	LNCHK(ln, hipGraphLaunch(slot, ln->stream));
-	return 0;
+static srbadev::Gang gang_of(const BigLane *ln) { srbadev::Gang G; std::memset(&G, 0, sizeof(G)); G.part = ln->d_part; G.scal = ln->d_scal; G.iscal = ln->d_iscal; return G; }
+static srbadev::Gang gang_masked(const srbadev::Gang &G, unsigned mask) { srbadev::Gang H = G; H.mask = mask; return H; }
+// grid of a gang launch: x = the largest grid any participating window would have alone, y = slots
+template <class ItemsF> static dim3 gang_grid(srba_hip_ctx *c, const srbadev::Gang &G, int block, bool one_workgroup_per_item, ItemsF &&items) {
+	long long gx = 1; int gy = 1;
+	for (int w = 0; w < G.n; w++) if ((G.mask >> w) & 1u) { const long long it = items(c->desc[G.p[w]], w); gx = std::max<long long>(gx, one_workgroup_per_item ? std::max<long long>(1, it) : big_grid(it, block)); gy = w + 1; }
+	return dim3((unsigned)gx, (unsigned)gy);
 }
-static void big_drop_graphs(srba_hip_ctx *c) { for (auto &kv : c->big_graphs) for (hipGraphExec_t g : kv.second.g) if (g) hipGraphExecDestroy(g); c->big_graphs.clear(); }
-// solve(lambda) of lev-marq_solvers.h for one big capsule, lambda in d_scal[BS_LAMBDA]: (a) Schur reduction (if the solver has one) + dense assembly,
-// (b) blocked Cholesky, (c) back-substitution + landmark increments. The not-positive-definite verdict stays in the device flag.
-static void big_enqueue_assemble(srba_hip_ctx *c, BigLane *ln, int p) {
-	const ProbDesc &d = c->desc[p]; const srbadev::BigSys S = big_sys(c, ln, p); const int P = c->dm.P; const double *lam = ln->d_scal + BS_LAMBDA;
-	const bool schur = c->params.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0;
-	if (schur) { BIGK(kb_schur_inv, std::max<long long>(d.nF, (long long)d.n_hap * P * P), 128, lam); BIGKG(kb_schur_reduce, d.n_hap, 256); BIGKG(kb_schur_grad, d.nK, 256); }
-	hipLaunchKernelGGL(srbadev::kb_dense_clear, dim3(big_grid((long long)S.ld * S.ld, 256)), dim3(256), 0, ln->stream, S);
-	BIGK(kb_dense_assemble, d.n_hap + d.n_hapf + d.n_hf, 128, S, lam, schur ? 0 : 1);
+#define BIGKG(KERNEL, ITEMS, block, ...) do { if (G.mask) with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), gang_grid(c, G, (block), true, [&](const ProbDesc &d, int) -> long long { return (ITEMS); }), dim3(block), 0, st, c->B, c->dp, G, ##__VA_ARGS__); }); } while (0)
+#define BIGK(KERNEL, ITEMS, block, ...) do { if (G.mask) with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), gang_grid(c, G, (block), false, [&](const ProbDesc &d, int) -> long long { return (ITEMS); }), dim3(block), 0, st, c->B, c->dp, G, ##__VA_ARGS__); }); } while (0)
+// deterministic reduction of per-workgroup partials into scal[slot] of every participating window
+static void big_reduce(srba_hip_ctx *c, hipStream_t st, const srbadev::Gang &G, int which, int kind, int slot, int is_max) { if (G.mask) hipLaunchKernelGGL(srbadev::kb_reduce, dim3(1, G.n), dim3(256), 0, st, c->B, G, which, kind, slot, is_max); }
+static bool big_schur(const srba_hip_ctx *c, const ProbDesc &d) { return c->params.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0; }
+static unsigned gang_schur_mask(srba_hip_ctx *c, const srbadev::Gang &G) { unsigned m = 0; for (int w = 0; w < G.n; w++) if (((G.mask >> w) & 1u) && big_schur(c, c->desc[G.p[w]])) m |= 1u << w; return m; }
+static void big_copy_vec(srba_hip_ctx *c, hipStream_t st, const srbadev::Gang &G, int kind) {
+	if (!G.mask) return;
+	hipLaunchKernelGGL(srbadev::kb_copy_vec, gang_grid(c, G, 256, false, [&](const ProbDesc &d, int) -> long long { return kind == 2 ? (long long)d.n_obs * c->dm.O : d.n_scal; }), dim3(256), 0, st, c->B, G, kind, c->dm.O);
 }
-static void big_enqueue_cholesky(srba_hip_ctx *c, BigLane *ln, int p) {
-	const srbadev::BigSys S = big_sys(c, ln, p);
-	if (c->big_persistent) { // the whole factorisation in one launch: panel steps and trailing updates separated by grid barriers (srba_big.hpp, k_chol_persistent)
+static void big_set_lambda(hipStream_t st, const srbadev::Gang &G, const srbadev::GangLambda &lam) { if (G.mask) hipLaunchKernelGGL(srbadev::kb_set_lambda, dim3(1), dim3(64), 0, st, G, lam); }
+// solve(lambda) of lev-marq_solvers.h for the windows of G.mask, lambda in scal[BS_LAMBDA] of each: (a) Schur reduction (if the solver has one) + dense assembly,
+// (b) blocked Cholesky, (c) back-substitution + landmark increments. The not-positive-definite verdict of a window stays in its device flag.
+static void big_enqueue_assemble(srba_hip_ctx *c, hipStream_t st, const srbadev::Gang &Gall) {
+	const int P = c->dm.P;
+	{ const srbadev::Gang G = gang_masked(Gall, gang_schur_mask(c, Gall));
+	  BIGK(kb_schur_inv, std::max<long long>(d.nF, (long long)d.n_hap * P * P), 128); BIGKG(kb_schur_reduce, d.n_hap, 256); BIGKG(kb_schur_grad, d.nK, 256); }
+	if (!Gall.mask) return;
+	hipLaunchKernelGGL(srbadev::kb_dense_clear, gang_grid(c, Gall, 256, false, [&](const ProbDesc &, int w) -> long long { return (long long)Gall.ld[w] * Gall.ld[w]; }), dim3(256), 0, st, Gall);
+	const unsigned ms = gang_schur_mask(c, Gall);
+	{ const srbadev::Gang G = gang_masked(Gall, ms); BIGK(kb_dense_assemble, d.n_hap + d.n_hapf + d.n_hf, 128, 0); }
+	{ const srbadev::Gang G = gang_masked(Gall, Gall.mask & ~ms); BIGK(kb_dense_assemble, d.n_hap + d.n_hapf + d.n_hf, 128, 1); }
+}
+static srbadev::BigSys big_sys(const srbadev::Gang &G, int w) { srbadev::BigSys S; const int ld = G.ld[w]; S.A = G.A[w]; S.Ldiag = S.A + (size_t)ld * ld; S.rhs = S.Ldiag + (size_t)ld * srbadev::CB; S.y = S.rhs + ld; S.flag = G.iscal + w * 8 + 1; S.n = G.nsys[w]; S.ld = ld; return S; }
+static void big_enqueue_cholesky(srba_hip_ctx *c, hipStream_t st, const srbadev::Gang &G) {
+	if (!G.mask) return;
+	int ldmax = 0, nw = 0, w1 = 0; for (int w = 0; w < G.n; w++) if ((G.mask >> w) & 1u) { ldmax = std::max(ldmax, G.ld[w]); nw++; w1 = w; }
+	if (c->big_persistent && nw == 1) { // the whole factorisation in one launch: panel steps and trailing updates separated by grid barriers (srba_big.hpp, k_chol_persistent); one window per launch
+		const srbadev::BigSys S = big_sys(G, w1);
 		const int below0 = S.ld - srbadev::CB, nt0 = below0 > 0 ? (below0 + srbadev::CT - 1) / srbadev::CT : 0, resident = 4 * c->n_cu / std::max(1, c->n_lanes_ready) /* the grid barriers need every workgroup of every window in flight resident: 4 workgroups per CU (34 KB of LDS, 256 threads each) shared by the lanes */,
-		          G = std::max(1, std::min(std::min(120, resident), std::max(nt0 * (nt0 + 1) / 2, 1 + (below0 > 0 ? (below0 + 63) / 64 : 0))));
-		unsigned *bar = (unsigned *)(ln->d_iscal + 4);
-		(void)hipMemsetAsync(bar, 0, 4, ln->stream);
-		hipLaunchKernelGGL(srbadev::k_chol_persistent, dim3(G), dim3(256), 0, ln->stream, S, bar);
+		          Gn = std::max(1, std::min(std::min(120, resident), std::max(nt0 * (nt0 + 1) / 2, 1 + (below0 > 0 ? (below0 + 63) / 64 : 0))));
+		unsigned *bar = (unsigned *)(G.iscal + w1 * 8 + 4);
+		(void)hipMemsetAsync(bar, 0, 4, st);
+		hipLaunchKernelGGL(srbadev::k_chol_persistent, dim3(Gn), dim3(256), 0, st, S, bar);
 		return;
 	}
-	for (int k0 = 0; k0 < S.ld; k0 += srbadev::CB) {
-		const int below = S.ld - k0 - srbadev::CB;
-		hipLaunchKernelGGL(srbadev::k_chol_panel, dim3(1 + (below + 63) / 64), dim3(64), 0, ln->stream, S, k0);
-		if (below > 0) { const int nt = (below + srbadev::CT - 1) / srbadev::CT; hipLaunchKernelGGL(srbadev::k_chol_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, ln->stream, S, k0, nt); }
+	for (int k0 = 0; k0 < ldmax; k0 += srbadev::CB) { // windows smaller than the largest of the gang drop out of the later steps inside the kernels
+		const int below = ldmax - k0 - srbadev::CB;
+		hipLaunchKernelGGL(srbadev::k_chol_panel, dim3(1 + (below + 63) / 64, G.n), dim3(64), 0, st, G, k0);
+		if (below > 0) { const int nt = (below + srbadev::CT - 1) / srbadev::CT; hipLaunchKernelGGL(srbadev::k_chol_update, dim3(nt * (nt + 1) / 2, G.n), dim3(256), 0, st, G, k0); }
 	}
 }
-static void big_enqueue_backsub(srba_hip_ctx *c, BigLane *ln, int p) {
-	const ProbDesc &d = c->desc[p]; const srbadev::BigSys S = big_sys(c, ln, p);
-	const bool schur = c->params.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0;
-	hipLaunchKernelGGL(srbadev::k_chol_bsub, dim3(1), dim3(256), 0, ln->stream, S);
-	hipLaunchKernelGGL(srbadev::kb_take_delta, dim3(big_grid(d.n_scal, 256)), dim3(256), 0, ln->stream, c->B, p, S);
-	if (schur) BIGK(kb_schur_features, d.nF, 128, S.flag);
+static void big_enqueue_backsub(srba_hip_ctx *c, hipStream_t st, const srbadev::Gang &Gall) {
+	if (!Gall.mask) return;
+	hipLaunchKernelGGL(srbadev::k_chol_bsub, dim3(1, Gall.n), dim3(256), 0, st, Gall);
+	hipLaunchKernelGGL(srbadev::kb_take_delta, gang_grid(c, Gall, 256, false, [&](const ProbDesc &d, int) -> long long { return d.n_scal; }), dim3(256), 0, st, c->B, Gall);
+	{ const srbadev::Gang G = gang_masked(Gall, gang_schur_mask(c, Gall)); BIGK(kb_schur_features, d.nF, 128, 1); }
 }
-static int big_timed_cholesky(srba_hip_ctx *c, BigLane *ln, int p) {
+static int big_timed_cholesky(srba_hip_ctx *c, BigLane *ln, const srbadev::Gang &G) {
 	if (!ln->e0) { LNCHK(ln, hipEventCreate(&ln->e0)); LNCHK(ln, hipEventCreate(&ln->e1)); }
 	LNCHK(ln, hipEventRecord(ln->e0, ln->stream));
-	if (big_replay(c, ln, p, 1, [&]() { big_enqueue_cholesky(c, ln, p); }) != 0) return -1;
+	big_enqueue_cholesky(c, ln->stream, G);
 	LNCHK(ln, hipEventRecord(ln->e1, ln->stream));
 	return 0;
 }
-static void big_account_cholesky(srba_hip_ctx *c, BigLane *ln, int p) { // after a stream synchronisation
-	float ms = 0; const int ld = c->big_ld[p];
-	if (hipEventElapsedTime(&ms, ln->e0, ln->e1) == hipSuccess) { ln->chol_ms += ms; ln->chol_flops += (double)ld * ld * ld / 3.0; ln->chol_count++; ln->chol_nmax = std::max(ln->chol_nmax, c->desc[p].n_sys); }
+static void big_account_cholesky(srba_hip_ctx *c, BigLane *ln, const srbadev::Gang &G) { // after a stream synchronisation; chol_ms is the time of the launch sequence, shared by the windows of the gang
+	float ms = 0;
+	if (hipEventElapsedTime(&ms, ln->e0, ln->e1) == hipSuccess) { ln->chol_ms += ms; ln->chol_seqs++; for (int w = 0; w < G.n; w++) if ((G.mask >> w) & 1u) { const double ld = G.ld[w]; ln->chol_flops += ld * ld * ld / 3.0; ln->chol_count++; ln->chol_nmax = std::max(ln->chol_nmax, G.nsys[w]); } }
 }
 static int big_solve(srba_hip_ctx *c, BigLane *ln, int p, double lambda, bool *pos_def) { // the stepwise entry point (srba_hip_solve)
-	hipLaunchKernelGGL(srbadev::kb_set_scalar, dim3(1), dim3(1), 0, ln->stream, ln->d_scal + BS_LAMBDA, lambda);
+	hipStream_t st = ln->stream; srbadev::Gang G = gang_of(ln); gang_set(c, G, 0, p); G.mask = 1u;
+	{ srbadev::GangLambda lam; std::memset(&lam, 0, sizeof(lam)); lam.v[0] = lambda; big_set_lambda(st, G, lam); }
 	{ const ProbDesc &d = c->desc[p]; // (extension) start from the gradient as srba_hip_linearize left it
-	  if ((c->params.extensions & SRBA_EXT_SCHUR_KEEPS_GRADIENT) && c->params.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0) LNCHK(ln, hipMemcpyAsync(c->B.grad + d.o_scal, c->B.grad0 + d.o_scal, sizeof(double) * (size_t)d.n_scal, hipMemcpyDeviceToDevice, ln->stream)); }
-	big_enqueue_assemble(c, ln, p);
-	if (big_timed_cholesky(c, ln, p) != 0) return -1;
-	big_enqueue_backsub(c, ln, p);
+	  if ((c->params.extensions & SRBA_EXT_SCHUR_KEEPS_GRADIENT) && big_schur(c, d)) big_copy_vec(c, st, G, 0); }
+	big_enqueue_assemble(c, st, G);
+	if (big_timed_cholesky(c, ln, G) != 0) return -1;
+	big_enqueue_backsub(c, st, G);
 	int flag = 0; LNCHK(ln, hipMemcpyAsync(&flag, ln->d_iscal + 1, 4, hipMemcpyDeviceToHost, ln->stream)); LNCHK(ln, hipStreamSynchronize(ln->stream));
-	big_account_cholesky(c, ln, p);
+	big_account_cholesky(c, ln, G);
 	if (flag == 2) { ln->error = "k_chol_persistent: a grid barrier timed out (the workgroups of the factorisation were not all resident)"; return -1; }
 	*pos_def = (flag == 0);
 	LNCHK(ln, hipGetLastError());
 	return 0;
 }
-// optimize_edges S5..S17 for one big capsule: the control flow of k_lm_run (optimize_edges.h:256-751) on the host, every phase a grid-wide launch
-static int big_lm_run(srba_hip_ctx *c, BigLane *ln, int p) {
-	const ProbDesc &d = c->desc[p]; const int O = c->dm.O, L = c->dm.L; const srba_hip_params &prm = c->params;
-	const bool schur = prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0;
-	srba_lm_result out; std::memset(&out, 0, sizeof(out));
-	for (int k = 0; k < SRBA_TRACE_LEN; k++) { out.trace_chi2[k] = NAN; out.trace_lambda[k] = NAN; out.trace_rho[k] = NAN; }
-	out.lambda_last_trial = NAN;
-	double *resid = c->B.resid, *resid2 = c->B.resid2; const int *flag = ln->d_iscal + 1; const double *lam = ln->d_scal + BS_LAMBDA;
-	auto enqueue_residuals = [&](double *dst, const int *skip) { const int nb = big_grid(d.n_obs, 256); BIGK(kb_residuals, d.n_obs, 256, dst, ln->d_part, skip); big_reduce(c, ln, 0, nb, BS_CHI2, 0); };
-	auto enqueue_linearize = [&]() { BIGK(kb_jac_init, d.n_valid, 256); BIGK(kb_jac, d.n_bp + d.n_bf, 128); BIGK(kb_jac_post, d.n_bp + d.n_bf, 256); BIGK(kb_hessian, d.n_hap + d.n_hf + d.n_hapf, 128, ln->d_iscal); BIGKG(kb_hessian_heavy, d.n_hap, 256, ln->d_iscal); };
-	const bool keep_g = schur && (prm.extensions & SRBA_EXT_SCHUR_KEEPS_GRADIENT); // (extension) the Schur kernels reduce B.grad in place: keep what K5 produced and start every solve from it
-	auto enqueue_gradient = [&]() { BIGKG(kb_gradient, d.nK + (d.nF + 255) / 256, 256, resid); if (keep_g) hipMemcpyAsync(c->B.grad0 + d.o_scal, c->B.grad + d.o_scal, sizeof(double) * (size_t)d.n_scal, hipMemcpyDeviceToDevice, ln->stream); };
-	auto enqueue_dot = [&](int which, int slot, int is_max, const int *skip) { const int nb = big_grid(d.n_scal, 256); BIGK(kb_dot, d.n_scal, 256, lam, ln->d_part + kBigPart, ln->d_part + 2 * kBigPart, skip); big_reduce(c, ln, which, nb, slot, is_max); };
-	double hs[4] = {0, 0, 0, 0}; int hflag = 0;
-	auto fetch = [&]() -> int { LNCHK(ln, hipMemcpyAsync(hs, ln->d_scal, 32, hipMemcpyDeviceToHost, ln->stream)); LNCHK(ln, hipMemcpyAsync(&hflag, flag, 4, hipMemcpyDeviceToHost, ln->stream)); LNCHK(ln, hipStreamSynchronize(ln->stream)); return 0; };
-	LNCHK(ln, hipMemsetAsync(ln->d_iscal, 0, 32, ln->stream));
-	BIGK(kb_spantree, d.n_pairs, 256, 0, (const int *)nullptr);   // S5
-	enqueue_linearize();                                          // S6, S7, S10
-	int ninv = 0; LNCHK(ln, hipMemcpyAsync(&ninv, ln->d_iscal, 4, hipMemcpyDeviceToHost, ln->stream)); LNCHK(ln, hipStreamSynchronize(ln->stream));
-	out.num_invalid_jacobs = ninv; out.num_observations = d.n_obs; out.num_jacobians = d.n_bp + d.n_bf; out.num_span_tree_numeric_updates = d.n_pairs;
-	auto finish = [&]() -> int { LNCHK(ln, hipMemcpyAsync(c->B.results + p, &out, sizeof(out), hipMemcpyHostToDevice, ln->stream)); LNCHK(ln, hipStreamSynchronize(ln->stream)); return 0; };
-	if ((long long)O * d.n_obs < (long long)d.n_scal) { out.status = 1; return finish(); } // S11
-	{ const int nb = big_grid(d.nK + d.nF, 256); BIGK(kb_maxdiag, d.nK + d.nF, 256, ln->d_part + kBigPart); big_reduce(c, ln, 1, nb, BS_MAXDIAG, 1); } // S12
-	enqueue_residuals(resid, nullptr);   // S13
-	enqueue_gradient();                  // S14
-	if (fetch() != 0) return -1;
-	double lambda = hs[BS_MAXDIAG] * 1e-3, nu = 2.0, total_err = hs[BS_CHI2], RMSE = std::sqrt(total_err / d.n_obs);
-	out.lambda_init = lambda; out.total_sqr_error_init = total_err;
-	int iter = 0, trials = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0; bool stop = false;
-	for (iter = 0; iter < prm.max_iters && !stop; iter++) {
-		double rho = 0;
-		if (lambda >= prm.max_lambda) { stop = true; stopmask |= 1 << SRBA_STOP_LAMBDA; }
-		if (RMSE < prm.max_error_per_obs_to_stop) { stop = true; stopmask |= 1 << SRBA_STOP_RMSE; }
-		while (rho <= 0 && !stop) {
-			const int tr = trials++; if (tr < SRBA_TRACE_LEN) out.trace_lambda[tr] = lambda; out.lambda_last_trial = lambda;
-			// one trial = solve, apply, numeric spanning tree of the poses in use, residuals, rho denominator; kernels after the factorisation return at once if it failed
-			hipLaunchKernelGGL(srbadev::kb_set_scalar, dim3(1), dim3(1), 0, ln->stream, ln->d_scal + BS_LAMBDA, lambda);
-			if (big_replay(c, ln, p, 0, [&]() { if (keep_g) hipMemcpyAsync(c->B.grad + d.o_scal, c->B.grad0 + d.o_scal, sizeof(double) * (size_t)d.n_scal, hipMemcpyDeviceToDevice, ln->stream); big_enqueue_assemble(c, ln, p); }) != 0) return -1;
-			if (big_timed_cholesky(c, ln, p) != 0) return -1;
-			if (big_replay(c, ln, p, 2, [&]() {
-				big_enqueue_backsub(c, ln, p);
-				BIGK(kb_apply, d.nK + (long long)d.nF * L + d.n_req, 128, flag);
-				BIGK(kb_spantree, d.n_need, 256, 1, flag);
-				enqueue_residuals(resid2, flag);
-				enqueue_dot(1, BS_DEN, 0, flag); }) != 0) return -1;
+// optimize_edges S5..S17 for the large capsules caps[next++ ...]: the control flow of k_lm_run (optimize_edges.h:256-751) on the host for up to `nslots` windows at once,
+// every phase a grid-wide launch over the windows that are at that point of their loop. `ln` supplies the stream and buffers with room for nslots slots.
+namespace {
+enum { GS_IDLE = 0, GS_NEW, GS_TRIAL, GS_ACCEPT, GS_FINAL };
+struct GangSlot {
+	int p = -1, st = GS_IDLE; bool schur = false, keep_g = false, s11 = false, relin = false, restore = false, stop = false;
+	srba_lm_result out; double lambda = 0, nu = 2, total_err = 0, RMSE = 0, rho = 0, new_err = 0, new_RMSE = 0; int iter = 0, trials = 0, tr = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0;
+};
+}
+// host control flow of one window from the head of the inner loop (`while (rho <= 0 && !stop)`) to its next trial or to the end of the run
+static void gang_advance(const srba_hip_params &prm, GangSlot &s, bool from_iter_head) {
+	for (;;) {
+		if (!from_iter_head) {
+			if (s.rho <= 0 && !s.stop) { s.tr = s.trials++; if (s.tr < SRBA_TRACE_LEN) s.out.trace_lambda[s.tr] = s.lambda; s.out.lambda_last_trial = s.lambda; s.st = GS_TRIAL; return; }
+			s.iter++;
+		}
+		from_iter_head = false;
+		if (!(s.iter < prm.max_iters && !s.stop)) { if (!s.stop) s.stopmask |= 1 << SRBA_STOP_MAX_ITERS; s.st = GS_FINAL; return; }
+		s.rho = 0;
+		if (s.lambda >= prm.max_lambda) { s.stop = true; s.stopmask |= 1 << SRBA_STOP_LAMBDA; }
+		if (s.RMSE < prm.max_error_per_obs_to_stop) { s.stop = true; s.stopmask |= 1 << SRBA_STOP_RMSE; }
+	}
+}
+static int big_gang_run(srba_hip_ctx *c, BigLane *ln, const int32_t *caps, int count, std::atomic<int> &next, int nslots) {
+	const int O = c->dm.O, L = c->dm.L; const srba_hip_params &prm = c->params; hipStream_t st = ln->stream;
+	nslots = std::max(1, std::min(nslots, ln->slots));
+	std::vector<GangSlot> S(nslots); std::vector<std::unique_ptr<srba_lm_result>> results; // result records stay alive until the last copy has been waited for
+	srbadev::Gang G0 = gang_of(ln);
+	std::vector<double> hs((size_t)nslots * 16); std::vector<int> hi((size_t)nslots * 8);
+	auto fetch = [&]() -> int { LNCHK(ln, hipMemcpyAsync(hs.data(), ln->d_scal, 8 * 16 * (size_t)nslots, hipMemcpyDeviceToHost, st)); LNCHK(ln, hipMemcpyAsync(hi.data(), ln->d_iscal, 4 * 8 * (size_t)nslots, hipMemcpyDeviceToHost, st)); LNCHK(ln, hipStreamSynchronize(st)); return 0; };
+	auto mask_of = [&](auto pred) { unsigned m = 0; for (int w = 0; w < nslots; w++) if (S[w].p >= 0 && pred(S[w])) m |= 1u << w; return m; };
+	auto enqueue_residuals = [&](const srbadev::Gang &G, int to_trial_copy, int use_skip) { BIGK(kb_residuals, d.n_obs, 256, to_trial_copy, use_skip); big_reduce(c, st, G, 0, 0, BS_CHI2, 0); };
+	auto enqueue_linearize = [&](const srbadev::Gang &G) { BIGK(kb_jac_init, d.n_valid, 256); BIGK(kb_jac, d.n_bp + d.n_bf, 128); BIGK(kb_jac_post, d.n_bp + d.n_bf, 256); BIGK(kb_hessian, d.n_hap + d.n_hf + d.n_hapf, 128); BIGKG(kb_hessian_heavy, d.n_hap, 256); };
+	// (extension) the Schur kernels reduce B.grad in place: keep what K5 produced and start every solve from it
+	auto enqueue_gradient = [&](const srbadev::Gang &G) { BIGKG(kb_gradient, d.nK + (d.nF + 255) / 256, 256); big_copy_vec(c, st, gang_masked(G, G.mask & mask_of([](const GangSlot &s) { return s.keep_g; })), 1); };
+	auto enqueue_dot = [&](const srbadev::Gang &G, int which, int slot, int is_max, int use_skip) { BIGK(kb_dot, d.n_scal, 256, use_skip); big_reduce(c, st, G, which, 2, slot, is_max); };
+	for (;;) {
+		// ---- windows that ended: covariance recovery (S17) and the result record; their slots take the next capsules of the class
+		{ srbadev::Gang G = G0; for (int w = 0; w < nslots; w++) if (S[w].st == GS_FINAL) { gang_set(c, G, w, S[w].p); G.mask |= 1u << w; }
+		  // a rejected last trial is undone first
+		  { const srbadev::Gang Gr = gang_masked(G, G.mask & mask_of([](const GangSlot &s) { return s.restore; })); const srbadev::Gang &G = Gr; BIGK(kb_restore, d.nK + (long long)d.nF * L + d.n_req, 128); }
+		  if (G.mask) { const srbadev::Gang Gs = gang_masked(G, gang_schur_mask(c, G)), Gn = gang_masked(G, G.mask & ~Gs.mask);
+		    { const srbadev::Gang &G = Gs; BIGK(kb_cov_recovery, std::max(d.nF, 1), 128, 1); } { const srbadev::Gang &G = Gn; BIGK(kb_cov_recovery, std::max(d.nF, 1), 128, 0); } }
+		  for (int w = 0; w < nslots; w++) if (S[w].st == GS_FINAL) { GangSlot &s = S[w];
+		    s.out.num_iters = s.iter; s.out.num_trials = s.trials; s.out.num_not_pd = s.n_notpd; s.out.num_accepted = s.n_acc; s.out.num_relinearized = s.n_relin; s.out.stop_reason = s.stopmask;
+		    s.out.total_sqr_error_final = s.total_err; s.out.obs_rmse = s.RMSE; s.out.lambda_final = s.lambda;
+		    results.emplace_back(new srba_lm_result(s.out)); LNCHK(ln, hipMemcpyAsync(c->B.results + s.p, results.back().get(), sizeof(srba_lm_result), hipMemcpyHostToDevice, st));
+		    s = GangSlot(); } }
+		for (int w = 0; w < nslots; w++) if (S[w].st == GS_IDLE) { const int i = next.fetch_add(1); if (i >= count) break; GangSlot &s = S[w]; s = GangSlot(); s.p = caps[i]; s.st = GS_NEW;
+			const ProbDesc &d = c->desc[s.p]; s.schur = big_schur(c, d); s.keep_g = s.schur && (prm.extensions & SRBA_EXT_SCHUR_KEEPS_GRADIENT); s.s11 = (long long)O * d.n_obs < (long long)d.n_scal;
+			std::memset(&s.out, 0, sizeof(s.out)); for (int k = 0; k < SRBA_TRACE_LEN; k++) { s.out.trace_chi2[k] = NAN; s.out.trace_lambda[k] = NAN; s.out.trace_rho[k] = NAN; } s.out.lambda_last_trial = NAN; }
+		srbadev::Gang Gall = G0; bool any = false; for (int w = 0; w < nslots; w++) if (S[w].p >= 0) { gang_set(c, Gall, w, S[w].p); any = true; }
+		if (!any) break;
+		// ---- rejected trials: restore (K12); accepted trials: residuals of the trial become current, relinearise where the error moved enough, gradient, |g|_inf;
+		//      new windows: S5 numeric spanning tree, S6/S7/S10 linearisation, S12 lambda_0, S13 residuals, S14 gradient
+		const unsigned m_restore = mask_of([](const GangSlot &s) { return s.restore && s.st != GS_FINAL; }), m_accept = mask_of([](const GangSlot &s) { return s.st == GS_ACCEPT; }), m_relin = mask_of([](const GangSlot &s) { return s.st == GS_ACCEPT && s.relin; }),
+		               m_new = mask_of([](const GangSlot &s) { return s.st == GS_NEW; }), m_new_full = mask_of([](const GangSlot &s) { return s.st == GS_NEW && !s.s11; });
+		{ const srbadev::Gang G = gang_masked(Gall, m_restore); BIGK(kb_restore, d.nK + (long long)d.nF * L + d.n_req, 128); for (int w = 0; w < nslots; w++) S[w].restore = false; }
+		for (int w = 0; w < nslots; w++) if ((m_new >> w) & 1u) LNCHK(ln, hipMemsetAsync(ln->d_iscal + w * 8, 0, 32, st));
+		big_copy_vec(c, st, gang_masked(Gall, m_accept), 2);
+		{ const srbadev::Gang G = gang_masked(Gall, m_new); BIGK(kb_spantree, d.n_pairs, 256, 0, 0); }
+		enqueue_linearize(gang_masked(Gall, m_relin | m_new));
+		{ const srbadev::Gang G = gang_masked(Gall, m_new_full); BIGK(kb_maxdiag, d.nK + d.nF, 256); big_reduce(c, st, G, 1, 1, BS_MAXDIAG, 1); enqueue_residuals(G, 0, 0); }
+		enqueue_gradient(gang_masked(Gall, m_accept | m_new_full));
+		enqueue_dot(gang_masked(Gall, m_accept), 2, BS_NINF, 1, 0);
+		if (m_accept | m_new) {
 			if (fetch() != 0) return -1;
-			big_account_cholesky(c, ln, p);
-			if (hflag == 2) { ln->error = "k_chol_persistent: a grid barrier timed out (the workgroups of the factorisation were not all resident)"; return -1; }
-			if (hflag) { n_notpd++; lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA; continue; }
-			const double new_err = hs[BS_CHI2], new_RMSE = std::sqrt(new_err / d.n_obs), err_red = total_err > 0 ? (total_err - new_err) / total_err : 0;
-			rho = (total_err - new_err) / hs[BS_DEN];
-			if (tr < SRBA_TRACE_LEN) { out.trace_chi2[tr] = new_err; out.trace_rho[tr] = rho; }
-			if (rho > 0) {
-				n_acc++;
-				const bool relin = (err_red < 0 || err_red > prm.min_error_reduction_ratio_to_relinearize);
-				total_err = new_err; RMSE = new_RMSE;
-				if (relin) n_relin++;
-				if (big_replay(c, ln, p, relin ? 3 : 4, [&]() {
-					hipMemcpyAsync(resid + (long long)d.o_obs * O, resid2 + (long long)d.o_obs * O, sizeof(double) * (size_t)d.n_obs * O, hipMemcpyDeviceToDevice, ln->stream);
-					if (relin) enqueue_linearize();
-					enqueue_gradient();
-					enqueue_dot(2, BS_NINF, 1, nullptr); }) != 0) return -1;
-				if (fetch() != 0) return -1;
-				if (hs[BS_NINF] <= 1e-15) { stop = true; stopmask |= 1 << SRBA_STOP_GRADIENT; }
-				if (RMSE < prm.max_error_per_obs_to_stop) { stop = true; stopmask |= 1 << SRBA_STOP_RMSE; }
-				if (rho > prm.max_rho) { stop = true; stopmask |= 1 << SRBA_STOP_RHO; }
-				lambda *= 1.0 / 3.0; nu = 2.0;
-			} else {
-				BIGK(kb_restore, d.nK + (long long)d.nF * L + d.n_req, 128);
-				lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
+			for (int w = 0; w < nslots; w++) { GangSlot &s = S[w]; const double *h = hs.data() + (size_t)w * 16;
+				if ((m_new >> w) & 1u) { const ProbDesc &d = c->desc[s.p];
+					s.out.num_invalid_jacobs = hi[(size_t)w * 8]; s.out.num_observations = d.n_obs; s.out.num_jacobians = d.n_bp + d.n_bf; s.out.num_span_tree_numeric_updates = d.n_pairs;
+					if (s.s11) { s.out.status = 1; results.emplace_back(new srba_lm_result(s.out)); LNCHK(ln, hipMemcpyAsync(c->B.results + s.p, results.back().get(), sizeof(srba_lm_result), hipMemcpyHostToDevice, st)); s = GangSlot(); continue; } // S11
+					s.lambda = h[BS_MAXDIAG] * 1e-3; s.nu = 2.0; s.total_err = h[BS_CHI2]; s.RMSE = std::sqrt(s.total_err / d.n_obs); s.out.lambda_init = s.lambda; s.out.total_sqr_error_init = s.total_err;
+					s.iter = 0; gang_advance(prm, s, true);
+				} else if ((m_accept >> w) & 1u) {
+					if (h[BS_NINF] <= 1e-15) { s.stop = true; s.stopmask |= 1 << SRBA_STOP_GRADIENT; }
+					if (s.RMSE < prm.max_error_per_obs_to_stop) { s.stop = true; s.stopmask |= 1 << SRBA_STOP_RMSE; }
+					if (s.rho > prm.max_rho) { s.stop = true; s.stopmask |= 1 << SRBA_STOP_RHO; }
+					s.lambda *= 1.0 / 3.0; s.nu = 2.0; gang_advance(prm, s, false);
+				} }
+		}
+		// ---- one trial of every window that is in its inner loop: solve, apply, numeric spanning tree of the poses in use, residuals, rho denominator; the kernels after
+		//      the factorisation return at once for a window whose factorisation failed
+		const unsigned m_trial = mask_of([](const GangSlot &s) { return s.st == GS_TRIAL; });
+		if (m_trial) {
+			const srbadev::Gang G = gang_masked(Gall, m_trial);
+			{ srbadev::GangLambda lam; std::memset(&lam, 0, sizeof(lam)); for (int w = 0; w < nslots; w++) lam.v[w] = S[w].lambda; big_set_lambda(st, G, lam); }
+			big_copy_vec(c, st, gang_masked(G, m_trial & mask_of([](const GangSlot &s) { return s.keep_g; })), 0);
+			big_enqueue_assemble(c, st, G);
+			if (big_timed_cholesky(c, ln, G) != 0) return -1;
+			big_enqueue_backsub(c, st, G);
+			BIGK(kb_apply, d.nK + (long long)d.nF * L + d.n_req, 128, 1);
+			BIGK(kb_spantree, d.n_need, 256, 1, 1);
+			enqueue_residuals(G, 1, 1);
+			enqueue_dot(G, 1, BS_DEN, 0, 1);
+			if (fetch() != 0) return -1;
+			big_account_cholesky(c, ln, G);
+			for (int w = 0; w < nslots; w++) if ((m_trial >> w) & 1u) { GangSlot &s = S[w]; const double *h = hs.data() + (size_t)w * 16; const int hflag = hi[(size_t)w * 8 + 1]; const ProbDesc &d = c->desc[s.p];
+				if (hflag == 2) { ln->error = "k_chol_persistent: a grid barrier timed out (the workgroups of the factorisation were not all resident)"; return -1; }
+				if (hflag) { s.n_notpd++; s.lambda *= s.nu; s.nu *= 2.0; s.stop = (s.lambda > prm.max_lambda); if (s.stop) s.stopmask |= 1 << SRBA_STOP_LAMBDA; gang_advance(prm, s, false); continue; }
+				const double new_err = h[BS_CHI2], new_RMSE = std::sqrt(new_err / d.n_obs), err_red = s.total_err > 0 ? (s.total_err - new_err) / s.total_err : 0;
+				s.rho = (s.total_err - new_err) / h[BS_DEN];
+				if (s.tr < SRBA_TRACE_LEN) { s.out.trace_chi2[s.tr] = new_err; s.out.trace_rho[s.tr] = s.rho; }
+				if (s.rho > 0) { s.n_acc++; s.relin = (err_red < 0 || err_red > prm.min_error_reduction_ratio_to_relinearize); s.total_err = new_err; s.RMSE = new_RMSE; if (s.relin) s.n_relin++; s.st = GS_ACCEPT; }
+				else { s.restore = true; s.lambda *= s.nu; s.nu *= 2.0; s.stop = (s.lambda > prm.max_lambda); if (s.stop) s.stopmask |= 1 << SRBA_STOP_LAMBDA; gang_advance(prm, s, false); }
 			}
 		}
 	}
-	if (!stop) stopmask |= 1 << SRBA_STOP_MAX_ITERS;
-	BIGK(kb_cov_recovery, std::max(d.nF, 1), 128, schur ? 1 : 0); // S17
-	out.num_iters = iter; out.num_trials = trials; out.num_not_pd = n_notpd; out.num_accepted = n_acc; out.num_relinearized = n_relin; out.stop_reason = stopmask;
-	out.total_sqr_error_final = total_err; out.obs_rmse = RMSE; out.lambda_final = lambda;
+	LNCHK(ln, hipStreamSynchronize(st));
 	LNCHK(ln, hipGetLastError());
-	return finish();
+	return 0;
 }
-// lanes [0, n): lane 0 is the context's own stream and buffers, the others get theirs on first use
+// lanes [0, n): lane 0 is the context's own stream with buffers for a whole gang, the others (one window each, SRBA_HIP_BIG_GANG=0) get theirs on first use
 static int big_prepare_lanes(srba_hip_ctx *c, int n) {
 	n = std::max(1, std::min(n, kBigLanes));
-	BigLane &l0 = c->lanes[0]; l0.id = 0; l0.stream = c->stream; l0.d_part = c->d_part; l0.d_scal = c->d_scal; l0.d_iscal = c->d_iscal;
+	BigLane &l0 = c->lanes[0]; l0.id = 0; l0.stream = c->stream; l0.d_part = c->d_part; l0.d_scal = c->d_scal; l0.d_iscal = c->d_iscal; l0.slots = srbadev::kGang;
 	c->n_lanes_ready = std::max(c->n_lanes_ready, 1);
 	for (int i = c->n_lanes_ready; i < n; i++) {
-		BigLane &l = c->lanes[i]; l.id = i;
+		BigLane &l = c->lanes[i]; l.id = i; l.slots = 1;
 		HIPCHK(c, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
 		HIPCHK(c, hipMalloc((void **)&l.d_part, 8 * 3 * kBigPart)); HIPCHK(c, hipMalloc((void **)&l.d_scal, 8 * 16)); HIPCHK(c, hipMalloc((void **)&l.d_iscal, 4 * 8));
 		c->n_lanes_ready = i + 1;
 	}
 	return n;
 }
-static void big_collect_lane_stats(srba_hip_ctx *c) { for (int i = 0; i < c->n_lanes_ready; i++) { BigLane &l = c->lanes[i]; c->big_chol_ms += l.chol_ms; c->big_chol_flops += l.chol_flops; c->big_chol_count += l.chol_count; c->big_chol_nmax = std::max(c->big_chol_nmax, l.chol_nmax); l.chol_ms = l.chol_flops = 0; l.chol_count = 0; l.chol_nmax = 0; } }
-// all capsules of the big class: one after the other on lane 0, or dealt to several lanes (host threads) when there are several
+static void big_collect_lane_stats(srba_hip_ctx *c) { for (int i = 0; i < c->n_lanes_ready; i++) { BigLane &l = c->lanes[i]; c->big_chol_ms += l.chol_ms; c->big_chol_flops += l.chol_flops; c->big_chol_count += l.chol_count; c->big_chol_seqs += l.chol_seqs; c->big_chol_nmax = std::max(c->big_chol_nmax, l.chol_nmax); l.chol_ms = l.chol_flops = 0; l.chol_count = l.chol_seqs = 0; l.chol_nmax = 0; } }
+// all capsules of the big class: a gang on lane 0 (default), or dealt to several lanes (host threads) with one window each
 static int big_run_class(srba_hip_ctx *c, const int32_t *caps, int count) {
 	if (count <= 0) return 0;
-	const int n = big_prepare_lanes(c, (c->big_use_graphs || c->big_lanes_max <= 1) ? 1 : std::min(count, c->big_lanes_max)); if (n < 1) return -1;
-	int rc = 0;
-	if (n == 1) { for (int i = 0; i < count && rc == 0; i++) rc = big_lm_run(c, &c->lanes[0], caps[i]); }
+	const bool gang = c->big_gang && !c->big_persistent;
+	const int n = big_prepare_lanes(c, (gang || c->big_lanes_max <= 1) ? 1 : std::min(count, c->big_lanes_max)); if (n < 1) return -1;
+	int rc = 0; std::atomic<int> next(0);
+	if (n == 1) { rc = big_gang_run(c, &c->lanes[0], caps, count, next, gang ? std::min(c->big_lanes_max, srbadev::kGang) : 1); }
 	else {
 		// the lanes start after everything already queued on the context stream (uploads, state resets)
 		hipEvent_t ready = nullptr; HIPCHK(c, hipEventCreateWithFlags(&ready, hipEventDisableTiming));
 		hipError_t e = hipEventRecord(ready, c->stream);
 		for (int i = 1; i < n && e == hipSuccess; i++) e = hipStreamWaitEvent(c->lanes[i].stream, ready, 0);
 		if (e != hipSuccess) { hipEventDestroy(ready); c->fail(std::string("large-capsule path: ") + hipGetErrorString(e)); return -1; }
-		std::atomic<int> next(0); std::vector<int> rcs(n, 0); std::vector<std::thread> th;
+		std::vector<int> rcs(n, 0); std::vector<std::thread> th;
 		auto work = [&](int li) { // no exception leaves a worker (std::terminate otherwise) nor this function (it is reached from an extern "C" entry)
-			try { hipSetDevice(c->device); BigLane *ln = &c->lanes[li]; for (;;) { const int i = next.fetch_add(1); if (i >= count || rcs[li] != 0) break; rcs[li] = big_lm_run(c, ln, caps[i]); } hipStreamSynchronize(ln->stream); }
+			try { hipSetDevice(c->device); BigLane *ln = &c->lanes[li]; rcs[li] = big_gang_run(c, ln, caps, count, next, 1); hipStreamSynchronize(ln->stream); }
 			catch (const std::exception &ex) { rcs[li] = -1; c->lanes[li].error = std::string("large-capsule path: ") + ex.what(); }
 			catch (...) { rcs[li] = -1; c->lanes[li].error = "large-capsule path: unknown exception"; } };
 		try { for (int i = 1; i < n; i++) th.emplace_back(work, i); } catch (...) { /* fewer threads than lanes: the ones that started (and this thread) share the capsules */ }

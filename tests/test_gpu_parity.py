@@ -641,6 +641,38 @@ def test_big_path_with_the_one_launch_factorisation(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,solver", [("stereo", "dense"), ("mono", "dense"), ("stereo", "sparse")])
+def test_big_path_gang_equals_one_window_per_stream(monkeypatch, kind, solver):
+    """The large windows of a batch run as a GANG in lock-step (srba_big.hpp `Gang`, srba_hip.hip `big_gang_run`): one launch per phase for every window that is at that
+    point of its LM loop, slots refilled as windows end. A window's numbers must not depend on its gang: every result field, every trace entry and the written-back state equal,
+    bit for bit, those of the earlier scheme (SRBA_HIP_BIG_GANG=0: one host thread + stream per window), with more windows than slots (refills) and with a single slot;
+    and the oracle's at 1e-6. Windows of different sizes (the map grows), two Schur solvers."""
+    from test_oracle_numeric import _harvest
+    b = _harvest(kind, solver=capi.SOLVER_SCHUR_DENSE if solver == "dense" else capi.SOLVER_SCHUR_SPARSE, n_kf=14)
+    sub = b.sub(max(0, b.n - 9), min(9, b.n)); ref = _oracle.run_batch(sub)
+    monkeypatch.setenv("SRBA_HIP_MAX_LDS_KB", "0")   # every window on the multi-workgroup path
+    import ctypes as C
+    def run(gang, lanes):
+        monkeypatch.setenv("SRBA_HIP_BIG_GANG", gang); monkeypatch.setenv("SRBA_HIP_BIG_LANES", lanes)
+        ctx = runner.HipContext(sub.params); ctx.upload(sub); out = ctx.lm_run()
+        st = (C.c_double * 8)(); ctx.lib.srba_hip_big_path_stats2(ctx.ctx, st)
+        work = sub.clone(); ctx._chk(ctx.lib.srba_hip_download_state(ctx.ctx, work.ptr, work.n), "download"); ctx.close()
+        state = [work.array(i, "edge_pose", np.float64, sub[i].n_unk_edges * capi.DIMS[sub.family][3]).copy() for i in range(sub.n)]
+        return out, state, list(st)
+    base, base_state, st0 = run("0", "4")
+    assert st0[5] == 0 and st0[4] == st0[2] and st0[2] > 0        # one launch sequence per factorisation
+    for lanes in ("16", "4", "1"):
+        g, g_state, st = run("1", lanes)
+        assert st[5] == 1 and st[2] == st0[2]                      # the same factorisations ...
+        if lanes != "1": assert st[4] < 0.5 * st[2]                # ... in far fewer launch sequences
+        for k in base:
+            assert np.array_equal(np.nan_to_num(np.asarray(g[k], float), nan=-1.0), np.nan_to_num(np.asarray(base[k], float), nan=-1.0)), (lanes, k)
+        for i in range(sub.n): assert np.array_equal(g_state[i], base_state[i]), (lanes, i)
+    monkeypatch.delenv("SRBA_HIP_BIG_GANG"); monkeypatch.delenv("SRBA_HIP_BIG_LANES"); monkeypatch.delenv("SRBA_HIP_MAX_LDS_KB")
+    assert np.all(base["status"] == ref["status"]) and _close(base["chi2_final"], ref["chi2_final"], rel=1e-6, abs_=1e-18)
+
+
+@pytest.mark.gpu
 def test_fused_linearisation_and_k6_on_materialised_blocks_agree(se2_batch):
     """srba_hip_linearize for <SE2, RelativePoses2D> keeps the Jacobian blocks on the chip; srba_hip_hessian_from_jacobians (K6 alone) afterwards first has them written
     by the unfused kernel and must reproduce the Hessian blocks of the fused launch (different summation trees: equal to rounding)."""
