@@ -53,17 +53,19 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 // the critical path. Lanes >= CB may carry extra rows b^t of an augmented matrix [A b; b^t .]: they come out as (L^-1 b)^t, i.e. the forward substitution of a
 // right-hand side rides along for free. rinv[j] = 1 / L_jj (every lane). Uniform result.
 __device__ __forceinline__ bool chol_block_regs(double (&a)[CB], double (&rinv)[CB], int lane) {
+	bool ok = true; // no branch inside the chain: with one per pivot the compiler sinks the updates of later columns past it to their uses and keeps every broadcast L_kj alive (SGPRs spilled to VGPR lanes); a bad pivot turns the rest into NaNs, which nobody reads
 #pragma unroll
 	for (int j = 0; j < CB; j++) {
 		const double d = lane_bcast(a[j], j);
-		if (!(d > 0.0)) return false;
+		ok &= (d > 0.0);
 		const double r = rsqrt_nr(d); rinv[j] = r;
 		const double l = (lane == j) ? d * r : ((lane > j) ? a[j] * r : 0.0);
 		a[j] = l;
 #pragma unroll
-		for (int k = j + 1; k < CB; k++) a[k] -= l * lane_bcast(l, k); // only the lower part (lane >= k) is ever read back
+		for (int k = j + 1; k < CB; k++) { a[k] -= l * lane_bcast(l, k); /* only the lower part (lane >= k) is ever read back */ if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
+		__builtin_amdgcn_sched_barrier(0); // (and every four columns above) the scheduler otherwise issues all v_readlane of a pivot step first: 62 SGPRs live, spilled to VGPR lanes and read back -- three instructions per value instead of one
 	}
-	return true;
+	return ok;
 }
 
 // Panel step k0: every workgroup factors the diagonal block itself (registers, lane CB carries the right-hand side); workgroup 0 publishes L_kk (Ldiag) and
@@ -171,6 +173,156 @@ __global__ void __launch_bounds__(256) k_chol_update(const Gang G, int k0) {
 				const int gi = i0 + wr * 32 + a * 16 + (lane >> 4) + 4 * r, gj = j0 + wc * 32 + b * 16 + (lane & 15);
 				if (gi < ld && gj < ld) S.A[(size_t)gi * ld + gj] = acc[a][b][r];
 			}
+}
+
+// ---- panel step k AND the trailing update of step k-1 in ONE launch (round 4): launch k0 holds
+//   * the panel workgroups of step k0 (256 threads): they first apply the update of step k0-CB to what they are about to read -- their 64 rows of the panel columns and the
+//     32 x 32 diagonal block, C -= X_prev X_prev^t with the same MFMA sequence as k_chol_update (bit-identical numbers), four wavefronts, results handed over in LDS --
+//     then the first wavefront factors the diagonal block and solves the rows in ONE loop (chol_block_solve_regs: the row solve x_k -= x_j L_kj shares the v_readlane of
+//     L_kj with the factorisation's own update; same operations in the same order as k_chol_panel's separate substitution, no LDS copy of L, no barrier);
+//   * the tile workgroups of step k0-CB's update for the columns right of the panel (region [k0+CB, ld)^2): they only read X_prev, so they run beside the panel chain.
+// One launch per 32 columns instead of two, and the update's time disappears behind the panel's dependent chain.
+__device__ __forceinline__ bool chol_block_solve_regs(double (&a)[CB], double (&x)[CB], double &acc, int lane) {
+	bool ok = true; // (branch-free, as in chol_block_regs)
+#pragma unroll
+	for (int j = 0; j < CB; j++) {
+		const double d = lane_bcast(a[j], j);
+		ok &= (d > 0.0);
+		const double r = rsqrt_nr(d);
+		const double l = (lane == j) ? d * r : ((lane > j) ? a[j] * r : 0.0);
+		a[j] = l;
+		const double xj = x[j] * r; x[j] = xj;
+#pragma unroll
+		for (int k = j + 1; k < CB; k++) { const double lk = lane_bcast(l, k); a[k] -= l * lk; x[k] -= xj * lk; asm volatile("" : "+v"(a[k]), "+v"(x[k])); /* pins the pair where the broadcast is: instruction selection otherwise emits the whole factorisation first and the substitution after it, every L_kj kept (spilled) for the second pass */ }
+		__builtin_amdgcn_sched_barrier(0); // (as in chol_block_regs: no SGPR spills)
+	}
+#pragma unroll
+	for (int j = 0; j < CB; j++) acc += x[j] * lane_bcast(a[j], CB); // lane CB carried the right-hand side: its row is y_k now
+	return ok;
+}
+__global__ void __launch_bounds__(256) k_chol_step(const Gang G, int k0) {
+	__shared__ double sh[2 * CT * (CB + 1)];
+	BIG_ENTER(); (void)p; const BigSys S = gang_sys(G, gw);
+	const int ld = S.ld, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+	if (k0 >= ld) return; // this window is smaller than the largest of the gang
+	const int below = ld - k0 - CB, npan = 1 + (below + 63) / 64, kp = k0 - CB;
+	if (*S.flag) return; // an earlier panel met a non-positive pivot
+	if ((int)blockIdx.x >= npan) { // ---- trailing update of step kp, columns right of this panel (k_chol_update's tile body with X = A[:, kp .. kp+CB))
+		if (k0 == 0) return;
+		const int nt = below > 0 ? (below + CT - 1) / CT : 0; int t = (int)blockIdx.x - npan; if (t >= nt * (nt + 1) / 2) return;
+		double *Xi = sh, *Xj = sh + CT * (CB + 1);
+		int ti = 0; while ((ti + 1) * (ti + 2) / 2 <= t) ti++; const int tj = t - ti * (ti + 1) / 2;
+		const int base = k0 + CB, i0 = base + CT * ti, j0 = base + CT * tj, wr = w >> 1, wc = w & 1;
+		const bool active = !(ti == tj && wc > wr);
+		f64x4 acc[2][2];
+#pragma unroll
+		for (int a = 0; a < 2; a++)
+#pragma unroll
+			for (int b = 0; b < 2; b++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					const int gi = i0 + wr * 32 + a * 16 + (lane >> 4) + 4 * r, gj = j0 + wc * 32 + b * 16 + (lane & 15);
+					acc[a][b][r] = (active && gi < ld && gj < ld) ? S.A[(size_t)gi * ld + gj] : 0.0;
+				}
+		for (int e = tid; e < CT * CB; e += 256) {
+			const int r = e / CB, c = e % CB;
+			Xi[r * (CB + 1) + c] = (i0 + r < ld) ? -S.A[(size_t)(i0 + r) * ld + kp + c] : 0.0;
+			Xj[r * (CB + 1) + c] = (j0 + r < ld) ? S.A[(size_t)(j0 + r) * ld + kp + c] : 0.0;
+		}
+		__syncthreads();
+		if (!active) return;
+#pragma unroll
+		for (int kk = 0; kk < CB / 4; kk++) {
+			double fa[2], fb[2];
+#pragma unroll
+			for (int a = 0; a < 2; a++) fa[a] = Xi[(wr * 32 + a * 16 + (lane & 15)) * (CB + 1) + 4 * kk + (lane >> 4)];
+#pragma unroll
+			for (int b = 0; b < 2; b++) fb[b] = Xj[(wc * 32 + b * 16 + (lane & 15)) * (CB + 1) + 4 * kk + (lane >> 4)];
+#pragma unroll
+			for (int a = 0; a < 2; a++)
+#pragma unroll
+				for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+		}
+#pragma unroll
+		for (int a = 0; a < 2; a++)
+#pragma unroll
+			for (int b = 0; b < 2; b++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					const int gi = i0 + wr * 32 + a * 16 + (lane >> 4) + 4 * r, gj = j0 + wc * 32 + b * 16 + (lane & 15);
+					if (gi < ld && gj < ld) S.A[(size_t)gi * ld + gj] = acc[a][b][r];
+				}
+		return;
+	}
+	// ---- panel workgroup b: rows k0+CB+64(b-1) .. +63 (b >= 1); b = 0 publishes L_kk and y_k
+	const int b = blockIdx.x, row0 = k0 + CB + 64 * (b - 1);
+	const int row = row0 + lane; const bool has_row = b > 0 && row < ld;
+	double a[CB], x[CB];
+	if (k0 == 0) {
+		if (w != 0) return;
+		const double *Arow = (const double *)__builtin_assume_aligned(S.A + (size_t)(has_row ? row : k0) * ld + k0, 16);
+#pragma unroll
+		for (int c = 0; c < CB; c++) x[c] = has_row ? Arow[c] : 0.0;
+		const double *src = (const double *)__builtin_assume_aligned(S.A + (size_t)(k0 + (lane & (CB - 1))) * ld + k0, 16), *rh = (const double *)__builtin_assume_aligned(S.rhs + k0, 16);
+#pragma unroll
+		for (int c = 0; c < CB; c++) { const double v = src[c], bb = rh[c]; a[c] = lane < CB ? (c <= lane ? v : 0.0) : (lane == CB ? bb : 0.0); }
+	} else {
+		double *Xo = sh, *Xk = sh + CT * (CB + 1); // -X_prev of the own rows | X_prev of rows k0 .. k0+CB-1
+		// C of this wavefront's tiles straight into the accumulators: own rows 16 w .. 16 w + 15, both column halves; wavefronts 0..2 also take the tiles (0,0) (1,0) (1,1) of the diagonal block
+		f64x4 co[2], cd; const int dr = (w == 0) ? 0 : 16, dc = (w == 2) ? 16 : 0;
+#pragma unroll
+		for (int h = 0; h < 2; h++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) { const int gi = row0 + 16 * w + (lane >> 4) + 4 * r, gj = k0 + 16 * h + (lane & 15); co[h][r] = (b > 0 && gi < ld) ? S.A[(size_t)gi * ld + gj] : 0.0; }
+#pragma unroll
+		for (int r = 0; r < 4; r++) { const int gi = k0 + dr + (lane >> 4) + 4 * r, gj = k0 + dc + (lane & 15); cd[r] = (w < 3) ? S.A[(size_t)gi * ld + gj] : 0.0; }
+		for (int e = tid; e < CT * CB; e += 256) { const int r = e / CB, c = e % CB; Xo[r * (CB + 1) + c] = (b > 0 && row0 + r < ld) ? -S.A[(size_t)(row0 + r) * ld + kp + c] : 0.0; }
+		for (int e = tid; e < CB * CB; e += 256) { const int r = e / CB, c = e % CB; Xk[r * (CB + 1) + c] = S.A[(size_t)(k0 + r) * ld + kp + c]; }
+		__syncthreads();
+#pragma unroll
+		for (int kk = 0; kk < CB / 4; kk++) {
+			const double fa = Xo[(16 * w + (lane & 15)) * (CB + 1) + 4 * kk + (lane >> 4)];
+			const double fd = -Xk[(dr + (lane & 15)) * (CB + 1) + 4 * kk + (lane >> 4)];
+			double fb[2];
+#pragma unroll
+			for (int h = 0; h < 2; h++) fb[h] = Xk[(16 * h + (lane & 15)) * (CB + 1) + 4 * kk + (lane >> 4)];
+#pragma unroll
+			for (int h = 0; h < 2; h++) co[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb[h], co[h], 0, 0, 0);
+			if (w < 3) cd = __builtin_amdgcn_mfma_f64_16x16x4f64(fd, fb[dc >> 4], cd, 0, 0, 0);
+		}
+		__syncthreads(); // every wavefront has read its operands: the updated blocks take their place (own rows | diagonal block)
+#pragma unroll
+		for (int h = 0; h < 2; h++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) Xo[(16 * w + (lane >> 4) + 4 * r) * (CB + 1) + 16 * h + (lane & 15)] = co[h][r];
+		if (w < 3) {
+#pragma unroll
+			for (int r = 0; r < 4; r++) Xk[(dr + (lane >> 4) + 4 * r) * (CB + 1) + dc + (lane & 15)] = cd[r];
+		}
+		__syncthreads();
+		if (w != 0) return;
+		const double *rh = (const double *)__builtin_assume_aligned(S.rhs + k0, 16);
+#pragma unroll
+		for (int c = 0; c < CB; c++) { x[c] = has_row ? Xo[lane * (CB + 1) + c] : 0.0; const double v = Xk[(lane & (CB - 1)) * (CB + 1) + c], bb = rh[c]; a[c] = lane < CB ? (c <= lane ? v : 0.0) : (lane == CB ? bb : 0.0); }
+	}
+	double acc = 0;
+	if (!chol_block_solve_regs(a, x, acc, lane)) { if (b == 0 && lane == 0) *S.flag = 1; return; }
+	if (b == 0) {
+		if (lane < CB) {
+			double *dst = (double *)__builtin_assume_aligned(S.Ldiag + (size_t)(k0 + lane) * CB, 16);
+#pragma unroll
+			for (int c = 0; c < CB; c++) dst[c] = a[c];
+		} else if (lane == CB) {
+#pragma unroll
+			for (int c = 0; c < CB; c++) S.y[k0 + c] = a[c];
+		}
+		return;
+	}
+	if (!has_row) return;
+	double *Arow = (double *)__builtin_assume_aligned(S.A + (size_t)row * ld + k0, 16);
+#pragma unroll
+	for (int c = 0; c < CB; c++) Arow[c] = x[c];
+	S.rhs[row] -= acc;
 }
 
 // ---- the whole factorisation in ONE launch ("a device-resident factorisation does not exist"): the panel steps and trailing updates above as phases of a

@@ -1008,7 +1008,7 @@ struct srba_hip_ctx {
 	std::vector<int> big_ld; // per capsule: leading dimension of its dense system when it runs on the big path, else 0
 	double big_chol_ms = 0, big_chol_flops = 0; long long big_chol_count = 0, big_chol_seqs = 0 /* launch sequences: one factors all windows of a gang */; int big_chol_nmax = 0; // Cholesky time / flops of the big path since the last upload (sum over the lanes)
 	BigLane lanes[kBigLanes]; int n_lanes_ready = 0; // lane 0 = the context stream and buffers; the others are created on first use
-	bool big_gang = true, big_persistent = false; int big_lanes_max = kBigLanes; // big path: windows of a batch in lock-step on one stream (gang) or one host thread + stream per window
+	bool big_gang = true, big_persistent = false, big_fused_step = true; int big_lanes_max = kBigLanes; // big path: windows of a batch in lock-step on one stream (gang) or one host thread + stream per window
 	int upload_threads = 1; bool dense_left = true; int hbm_from_kb = 48; bool dense_blocks_ok = true; // mid-size nearly-full systems use the dense block layout in LDS
 	bool lin_terms = true, lm_terms = true; // term-parallel U_Ap accumulation in LDS: srba_hip_linearize / the fused LM kernel
 	// fused normal equations of the relative-pose SE2 family (srba_assemble.hpp): capsules packed into bins (workgroups) by the LDS image they need, one launch; the rest take k_linearize
@@ -1193,6 +1193,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_FLAT"); if (e) c->use_flat = atoi(e) != 0; }                     // 0 = one wavefront per capsule for the stepwise spanning-tree launch
 	{ const char *e = getenv("SRBA_HIP_BIG_LANES"); if (e && atoi(e) >= 1) c->big_lanes_max = std::min(atoi(e), kBigLanes); } // large capsules of one batch in flight at once
 	{ const char *e = getenv("SRBA_HIP_BIG_PERSISTENT"); if (e) c->big_persistent = atoi(e) != 0; }   // 1 = the blocked Cholesky of the big path as ONE persistent launch with grid barriers (k_chol_persistent) instead of one launch per panel step and per trailing update (~60 launches); measured slower, DESIGN 4c
+	{ const char *e = getenv("SRBA_HIP_BIG_FUSED_STEP"); if (e) c->big_fused_step = atoi(e) != 0; }    // 0 = panel step and trailing update as two launches per 32 columns (k_chol_panel, k_chol_update)
 	{ const char *e = getenv("SRBA_HIP_BIG_GANG"); if (e) c->big_gang = atoi(e) != 0; }                // 0 = one host thread + stream per large window instead of the lock-step gang on one stream
 	return c;
 }
@@ -1612,6 +1613,11 @@ static void big_enqueue_cholesky(srba_hip_ctx *c, hipStream_t st, const srbadev:
 		unsigned *bar = (unsigned *)(G.iscal + w1 * 8 + 4);
 		(void)hipMemsetAsync(bar, 0, 4, st);
 		hipLaunchKernelGGL(srbadev::k_chol_persistent, dim3(Gn), dim3(256), 0, st, S, bar);
+		return;
+	}
+	if (c->big_fused_step) { // one launch per 32 columns: the panel step and, beside it, the trailing update of the step before (srba_big.hpp, k_chol_step)
+		for (int k0 = 0; k0 < ldmax; k0 += srbadev::CB) { const int below = ldmax - k0 - srbadev::CB, nt = below > 0 ? (below + srbadev::CT - 1) / srbadev::CT : 0;
+			hipLaunchKernelGGL(srbadev::k_chol_step, dim3(1 + (below + 63) / 64 + (k0 > 0 ? nt * (nt + 1) / 2 : 0), G.n), dim3(256), 0, st, G, k0); }
 		return;
 	}
 	for (int k0 = 0; k0 < ldmax; k0 += srbadev::CB) { // windows smaller than the largest of the gang drop out of the later steps inside the kernels
