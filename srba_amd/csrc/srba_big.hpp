@@ -27,7 +27,7 @@ struct BigSys { double *A; double *Ldiag; double *rhs; double *y; int *flag; int
 // slots take part in this launch (the host knows which windows need a trial, which an accepted step's relinearisation, which a restore). A slot owns a region of the
 // partial-sum / scalar / flag buffers (slot w: part + w * 3 * kBigPart, scal + w * 16, iscal + w * 8) and its dense system lies where its capsule's does (A[w]).
 // Every slot uses the grid it would have alone for the phases that reduce over workgroups (fixed partition of the sums): a window's numbers do not depend on its gang.
-constexpr int kGang = 16, kBigPart = 4096;
+constexpr int kGang = 32, kBigPart = 4096;
 struct Gang { int p[kGang]; int ld[kGang]; int nsys[kGang]; double *A[kGang]; unsigned mask; int n; double *part; double *scal; int *iscal; };
 enum { BS_CHI2 = 0, BS_MAXDIAG = 1, BS_DEN = 2, BS_NINF = 3, BS_LAMBDA = 4 }; // scal[w * 16 + .]; iscal[w * 8 + .] = {invalid Jacobians, not-positive-definite flag}
 __device__ __forceinline__ BigSys gang_sys(const Gang &G, int w) {

@@ -827,7 +827,7 @@ struct Arena { // layout builder: 256-byte aligned sub-allocations inside one bu
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->fail(std::string(#call) + ": " + hipGetErrorString(e_)); return -1; } } while (0)
 #define LNCHK(lane, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (lane)->error = std::string(#call) + ": " + hipGetErrorString(e_); return -1; } } while (0)
 static const int kBigLanes = 16;
-struct BigLane { int id = 0, slots = 1 /* windows its buffers have room for (srbadev::Gang) */; hipStream_t stream = nullptr; double *d_part = nullptr, *d_scal = nullptr; int *d_iscal = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; double chol_ms = 0, chol_flops = 0; long long chol_count = 0, chol_seqs = 0; int chol_nmax = 0; std::string error; };
+struct BigLane { int id = 0, slots = 1 /* windows its buffers have room for (srbadev::Gang) */; hipStream_t stream = nullptr; double *d_part = nullptr, *d_scal = nullptr; int *d_iscal = nullptr /* behind the scalars in the same allocation: one copy reads both back */; void *h_fetch = nullptr /* page-locked landing buffer of that copy */; hipEvent_t e0 = nullptr, e1 = nullptr; double chol_ms = 0, chol_flops = 0; long long chol_count = 0, chol_seqs = 0; int chol_nmax = 0; std::string error; };
 
 } // namespace
 
@@ -1008,7 +1008,7 @@ struct srba_hip_ctx {
 	std::vector<int> big_ld; // per capsule: leading dimension of its dense system when it runs on the big path, else 0
 	double big_chol_ms = 0, big_chol_flops = 0; long long big_chol_count = 0, big_chol_seqs = 0 /* launch sequences: one factors all windows of a gang */; int big_chol_nmax = 0; // Cholesky time / flops of the big path since the last upload (sum over the lanes)
 	BigLane lanes[kBigLanes]; int n_lanes_ready = 0; // lane 0 = the context stream and buffers; the others are created on first use
-	bool big_gang = true, big_persistent = false, big_fused_step = true; int big_lanes_max = kBigLanes; // big path: windows of a batch in lock-step on one stream (gang) or one host thread + stream per window
+	bool big_gang = true, big_persistent = false, big_fused_step = true; int big_lanes_max = kBigLanes, big_gang_slots = srbadev::kGang, gang_from_nb = 0 /* landmark windows with this many block rows or more take the gang instead of one wavefront (0: off) */; // big path: windows of a batch in lock-step on one stream (gang) or one host thread + stream per window
 	int upload_threads = 1; bool dense_left = true; int hbm_from_kb = 48; bool dense_blocks_ok = true; // mid-size nearly-full systems use the dense block layout in LDS
 	bool lin_terms = true, lm_terms = true; // term-parallel U_Ap accumulation in LDS: srba_hip_linearize / the fused LM kernel
 	// fused normal equations of the relative-pose SE2 family (srba_assemble.hpp): capsules packed into bins (workgroups) by the LDS image they need, one launch; the rest take k_linearize
@@ -1180,7 +1180,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	for (int k = 1; k < SRBA_NCLS && ok; k++) { // (class_prio 1: the streams of the biggest classes -- low stream index, see plan_launches -- get the highest priority, 2: the lowest)
 		const int split = 4, pri = c->class_prio == 0 ? 0 : ((c->class_prio == 1) == (k < split) ? pr_greatest : pr_least);
 		ok = (c->class_prio ? hipStreamCreateWithPriority(&c->cls_stream[k], hipStreamNonBlocking, pri) : hipStreamCreateWithFlags(&c->cls_stream[k], hipStreamNonBlocking)) == hipSuccess && hipEventCreateWithFlags(&c->cls_done[k], hipEventDisableTiming) == hipSuccess; }
-	if (!ok || hipMalloc((void **)&c->d_next, sizeof(int) * kMaxJobs) != hipSuccess || hipMalloc((void **)&c->d_part, 8 * 3 * kBigPart * srbadev::kGang) != hipSuccess || hipMalloc((void **)&c->d_scal, 8 * 16 * srbadev::kGang) != hipSuccess || hipMalloc((void **)&c->d_iscal, 4 * 8 * srbadev::kGang) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
+	if (!ok || hipMalloc((void **)&c->d_next, sizeof(int) * kMaxJobs) != hipSuccess || hipMalloc((void **)&c->d_part, 8 * 3 * kBigPart * srbadev::kGang) != hipSuccess || hipMalloc((void **)&c->d_scal, (8 * 16 + 4 * 8) * srbadev::kGang) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	{ const char *e = getenv("SRBA_HIP_BIG_MIN_SYS"); if (e && atoi(e) >= 0) c->big_min_sys = atoi(e); } // tuning / test knob
 	{ const char *e = getenv("SRBA_HIP_DENSE_BLOCKS"); if (e) c->dense_blocks_ok = atoi(e) != 0; }
 	{ const unsigned hc = std::thread::hardware_concurrency(); c->upload_threads = (int)std::min(32u, std::max(1u, hc)); const char *e = getenv("SRBA_HIP_UPLOAD_THREADS"); if (e) c->upload_threads = std::max(1, atoi(e)); } // host threads of srba_hip_upload_problems
@@ -1191,7 +1191,8 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_ASSEMBLE_MAX_KB"); if (e) c->asm_max_kb = atoi(e); }            // capsules whose LDS image exceeds this take the unfused kernel (tests)
 	{ const char *e = getenv("SRBA_HIP_ASSEMBLE"); if (e) c->asm_on = atoi(e) != 0; }                   // 0 = srba_hip_linearize always runs the unfused kernel (Jacobian blocks through HBM)
 	{ const char *e = getenv("SRBA_HIP_FLAT"); if (e) c->use_flat = atoi(e) != 0; }                     // 0 = one wavefront per capsule for the stepwise spanning-tree launch
-	{ const char *e = getenv("SRBA_HIP_BIG_LANES"); if (e && atoi(e) >= 1) c->big_lanes_max = std::min(atoi(e), kBigLanes); } // large capsules of one batch in flight at once
+	{ const char *e = getenv("SRBA_HIP_BIG_LANES"); if (e && atoi(e) >= 1) { c->big_lanes_max = std::min(atoi(e), kBigLanes); c->big_gang_slots = std::min(atoi(e), srbadev::kGang); } }
+	{ const char *e = getenv("SRBA_HIP_GANG_FROM_NB"); if (e) c->gang_from_nb = atoi(e); } // large capsules of one batch in flight at once
 	{ const char *e = getenv("SRBA_HIP_BIG_PERSISTENT"); if (e) c->big_persistent = atoi(e) != 0; }   // 1 = the blocked Cholesky of the big path as ONE persistent launch with grid barriers (k_chol_persistent) instead of one launch per panel step and per trailing update (~60 launches); measured slower, DESIGN 4c
 	{ const char *e = getenv("SRBA_HIP_BIG_FUSED_STEP"); if (e) c->big_fused_step = atoi(e) != 0; }    // 0 = panel step and trailing update as two launches per 32 columns (k_chol_panel, k_chol_update)
 	{ const char *e = getenv("SRBA_HIP_BIG_GANG"); if (e) c->big_gang = atoi(e) != 0; }                // 0 = one host thread + stream per large window instead of the lock-step gang on one stream
@@ -1209,8 +1210,8 @@ int srba_hip_set_params(srba_hip_ctx *c, const srba_hip_params *params) {
 int srba_hip_destroy(srba_hip_ctx *c) {
 	if (!c) return 0;
 	hipSetDevice(c->device);
-	for (int i = 0; i < kBigLanes; i++) { BigLane &l = c->lanes[i]; if (l.e0) hipEventDestroy(l.e0); if (l.e1) hipEventDestroy(l.e1); if (i > 0) { if (l.d_part) hipFree(l.d_part); if (l.d_scal) hipFree(l.d_scal); if (l.d_iscal) hipFree(l.d_iscal); if (l.stream) hipStreamDestroy(l.stream); } }
-	if (c->d_in) hipFree(c->d_in); if (c->d_wk) hipFree(c->d_wk); if (c->d_next) hipFree(c->d_next); if (c->d_spec) hipFree(c->d_spec); c->h_in.release(); if (c->h_out) hipHostFree(c->h_out); if (c->ev_h2d) hipEventDestroy(c->ev_h2d); if (c->d_part) hipFree(c->d_part); if (c->d_scal) hipFree(c->d_scal); if (c->d_iscal) hipFree(c->d_iscal);
+	for (int i = 0; i < kBigLanes; i++) { BigLane &l = c->lanes[i]; if (l.h_fetch) hipHostFree(l.h_fetch); if (l.e0) hipEventDestroy(l.e0); if (l.e1) hipEventDestroy(l.e1); if (i > 0) { if (l.d_part) hipFree(l.d_part); if (l.d_scal) hipFree(l.d_scal); if (l.stream) hipStreamDestroy(l.stream); } }
+	if (c->d_in) hipFree(c->d_in); if (c->d_wk) hipFree(c->d_wk); if (c->d_next) hipFree(c->d_next); if (c->d_spec) hipFree(c->d_spec); c->h_in.release(); if (c->h_out) hipHostFree(c->h_out); if (c->ev_h2d) hipEventDestroy(c->ev_h2d); if (c->d_part) hipFree(c->d_part); if (c->d_scal) hipFree(c->d_scal);
 	for (int i = 0; i < srba_hip_ctx::kRing; i++) { if (c->ring0[i]) hipEventDestroy(c->ring0[i]); if (c->ring1[i]) hipEventDestroy(c->ring1[i]); }
 	if (c->ev_fork) hipEventDestroy(c->ev_fork);
 	for (int k = 1; k < SRBA_NCLS; k++) { if (c->cls_done[k]) hipEventDestroy(c->cls_done[k]); if (c->cls_stream[k]) hipStreamDestroy(c->cls_stream[k]); }
@@ -1291,7 +1292,8 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		size_t n_ints = 2 * ((size_t)d.nb + 1) + 2 * (size_t)d.nnzoff + (size_t)d.n_items + (size_t)d.nb;
 		bool packable = d.nb + d.nnzoff < 16384 && d.nb < 16384 && sym[p].max_cn < 512; // item / row-entry words of the LDS copy
 		size_t tri_n = 9 * (size_t)d.nb + 9 * (size_t)d.nnzoff + 3 * (size_t)d.nb + (n_ints + 1) / 2; // diag | off | rhs | symbolic ints
-		const bool rel_family = c->params.family == SRBA_SE2_RELPOSE2D || c->params.family == SRBA_SE3_RELPOSE3D || c->dm.P == 3; // relative-pose and SE2 families: their kernels carry the sparse solver only (one 3x3 block per edge: the sparse image fits)
+		const bool rel_family = c->params.family == SRBA_SE2_RELPOSE2D || c->params.family == SRBA_SE3_RELPOSE3D || c->dm.P == 3;
+		const bool to_gang = c->gang_from_nb > 0 && !rel_family && schur_solver && caps[p].n_unk_lms > 0 && caps[p].n_unk_edges > 0 && d.nb >= c->gang_from_nb; // big enough for the lock-step multi-workgroup path to beat one wavefront // relative-pose and SE2 families: their kernels carry the sparse solver only (one 3x3 block per edge: the sparse image fits)
 		if (!surely_big && c->dense_blocks_ok && !rel_family) { // nearly full factor: the dense block layout (numbers + the permutation only) is smaller than the sparse one with its item list
 			const size_t nnz_d = (size_t)d.nb * (d.nb - 1) / 2, tri_d = 9 * (size_t)d.nb + 9 * nnz_d + 3 * (size_t)d.nb + ((size_t)d.nb + 1) / 2;
 			if (tri_d < tri_n && tri_d * 8 <= 152 * 1024) { symbolic_dense(k, d, P, L, !schur_solver, sym[p]); d.dense_blocks = 1; d.nnzoff = (int)nnz_d; d.n_items = 0; d.aligned = sym[p].aligned ? 1 : 0; n_ints = d.nb; packable = true; tri_n = tri_d; }
@@ -1300,9 +1302,9 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		// reserves little more LDS per wavefront than its capsules need
 		size_t bytes = tri_n * 8;
 		static const int kClsKB[SRBA_NCLS - 1] = {6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64, 80, 96, 112, 128, 152};
-		cls[p] = SRBA_NCLS - 1; for (int q = 0; q < SRBA_NCLS - 1 && packable && !surely_big && kClsKB[q] <= c->max_lds_kb; q++) if (bytes <= (size_t)kClsKB[q] * 1024) { cls[p] = q; break; }
+		cls[p] = SRBA_NCLS - 1; for (int q = 0; q < SRBA_NCLS - 1 && packable && !surely_big && !to_gang && kClsKB[q] <= c->max_lds_kb; q++) if (bytes <= (size_t)kClsKB[q] * 1024) { cls[p] = q; break; }
 		long long wave_ws = 0; // doubles of HBM workspace of a capsule that keeps one wavefront but holds its (dense block) system in HBM
-		if ((cls[p] == SRBA_NCLS - 1 ? many_mid : (c->hbm_from_kb > 0 && n >= 1024 && kClsKB[cls[p]] >= c->hbm_from_kb && d.nb <= 168)) && !surely_big && c->dense_blocks_ok && !rel_family) {
+		if ((cls[p] == SRBA_NCLS - 1 ? many_mid : (c->hbm_from_kb > 0 && n >= 1024 && kClsKB[cls[p]] >= c->hbm_from_kb && d.nb <= 168)) && !surely_big && !to_gang && c->dense_blocks_ok && !rel_family) {
 			// Does not fit any LDS class and the batch has many like it: the multi-workgroup path would run them a few at a time from the host. They stay on the
 			// one-wavefront kernel with the dense block system in an HBM workspace (slow per capsule, but thousands run side by side).
 			const size_t nnz_d = (size_t)d.nb * (d.nb - 1) / 2;
@@ -1686,8 +1688,10 @@ static int big_gang_run(srba_hip_ctx *c, BigLane *ln, const int32_t *caps, int c
 	nslots = std::max(1, std::min(nslots, ln->slots));
 	std::vector<GangSlot> S(nslots); std::vector<std::unique_ptr<srba_lm_result>> results; // result records stay alive until the last copy has been waited for
 	srbadev::Gang G0 = gang_of(ln);
-	std::vector<double> hs((size_t)nslots * 16); std::vector<int> hi((size_t)nslots * 8);
-	auto fetch = [&]() -> int { LNCHK(ln, hipMemcpyAsync(hs.data(), ln->d_scal, 8 * 16 * (size_t)nslots, hipMemcpyDeviceToHost, st)); LNCHK(ln, hipMemcpyAsync(hi.data(), ln->d_iscal, 4 * 8 * (size_t)nslots, hipMemcpyDeviceToHost, st)); LNCHK(ln, hipStreamSynchronize(st)); return 0; };
+	const size_t fetch_bytes = (8 * 16 + 4 * 8) * (size_t)ln->slots; // scalars of all slots, then their flags: one allocation, one copy into page-locked memory
+	if (!ln->h_fetch) LNCHK(ln, hipHostMalloc(&ln->h_fetch, fetch_bytes, hipHostMallocDefault));
+	const double *hs = (const double *)ln->h_fetch; const int *hi = (const int *)(hs + 16 * (size_t)ln->slots);
+	auto fetch = [&]() -> int { LNCHK(ln, hipMemcpyAsync(ln->h_fetch, ln->d_scal, fetch_bytes, hipMemcpyDeviceToHost, st)); LNCHK(ln, hipStreamSynchronize(st)); return 0; };
 	auto mask_of = [&](auto pred) { unsigned m = 0; for (int w = 0; w < nslots; w++) if (S[w].p >= 0 && pred(S[w])) m |= 1u << w; return m; };
 	auto enqueue_residuals = [&](const srbadev::Gang &G, int to_trial_copy, int use_skip) { BIGK(kb_residuals, d.n_obs, 256, to_trial_copy, use_skip); big_reduce(c, st, G, 0, 0, BS_CHI2, 0); };
 	auto enqueue_linearize = [&](const srbadev::Gang &G) { BIGK(kb_jac_init, d.n_valid, 256); BIGK(kb_jac, d.n_bp + d.n_bf, 128); BIGK(kb_jac_post, d.n_bp + d.n_bf, 256); BIGK(kb_hessian, d.n_hap + d.n_hf + d.n_hapf, 128); BIGKG(kb_hessian_heavy, d.n_hap, 256); };
@@ -1725,7 +1729,7 @@ static int big_gang_run(srba_hip_ctx *c, BigLane *ln, const int32_t *caps, int c
 		enqueue_dot(gang_masked(Gall, m_accept), 2, BS_NINF, 1, 0);
 		if (m_accept | m_new) {
 			if (fetch() != 0) return -1;
-			for (int w = 0; w < nslots; w++) { GangSlot &s = S[w]; const double *h = hs.data() + (size_t)w * 16;
+			for (int w = 0; w < nslots; w++) { GangSlot &s = S[w]; const double *h = hs + (size_t)w * 16;
 				if ((m_new >> w) & 1u) { const ProbDesc &d = c->desc[s.p];
 					s.out.num_invalid_jacobs = hi[(size_t)w * 8]; s.out.num_observations = d.n_obs; s.out.num_jacobians = d.n_bp + d.n_bf; s.out.num_span_tree_numeric_updates = d.n_pairs;
 					if (s.s11) { s.out.status = 1; results.emplace_back(new srba_lm_result(s.out)); LNCHK(ln, hipMemcpyAsync(c->B.results + s.p, results.back().get(), sizeof(srba_lm_result), hipMemcpyHostToDevice, st)); s = GangSlot(); continue; } // S11
@@ -1754,7 +1758,7 @@ static int big_gang_run(srba_hip_ctx *c, BigLane *ln, const int32_t *caps, int c
 			enqueue_dot(G, 1, BS_DEN, 0, 1);
 			if (fetch() != 0) return -1;
 			big_account_cholesky(c, ln, G);
-			for (int w = 0; w < nslots; w++) if ((m_trial >> w) & 1u) { GangSlot &s = S[w]; const double *h = hs.data() + (size_t)w * 16; const int hflag = hi[(size_t)w * 8 + 1]; const ProbDesc &d = c->desc[s.p];
+			for (int w = 0; w < nslots; w++) if ((m_trial >> w) & 1u) { GangSlot &s = S[w]; const double *h = hs + (size_t)w * 16; const int hflag = hi[(size_t)w * 8 + 1]; const ProbDesc &d = c->desc[s.p];
 				if (hflag == 2) { ln->error = "k_chol_persistent: a grid barrier timed out (the workgroups of the factorisation were not all resident)"; return -1; }
 				if (hflag) { s.n_notpd++; s.lambda *= s.nu; s.nu *= 2.0; s.stop = (s.lambda > prm.max_lambda); if (s.stop) s.stopmask |= 1 << SRBA_STOP_LAMBDA; gang_advance(prm, s, false); continue; }
 				const double new_err = h[BS_CHI2], new_RMSE = std::sqrt(new_err / d.n_obs), err_red = s.total_err > 0 ? (s.total_err - new_err) / s.total_err : 0;
@@ -1772,12 +1776,12 @@ static int big_gang_run(srba_hip_ctx *c, BigLane *ln, const int32_t *caps, int c
 // lanes [0, n): lane 0 is the context's own stream with buffers for a whole gang, the others (one window each, SRBA_HIP_BIG_GANG=0) get theirs on first use
 static int big_prepare_lanes(srba_hip_ctx *c, int n) {
 	n = std::max(1, std::min(n, kBigLanes));
-	BigLane &l0 = c->lanes[0]; l0.id = 0; l0.stream = c->stream; l0.d_part = c->d_part; l0.d_scal = c->d_scal; l0.d_iscal = c->d_iscal; l0.slots = srbadev::kGang;
+	BigLane &l0 = c->lanes[0]; l0.id = 0; l0.stream = c->stream; l0.d_part = c->d_part; l0.d_scal = c->d_scal; l0.d_iscal = (int *)(c->d_scal + 16 * srbadev::kGang); l0.slots = srbadev::kGang;
 	c->n_lanes_ready = std::max(c->n_lanes_ready, 1);
 	for (int i = c->n_lanes_ready; i < n; i++) {
 		BigLane &l = c->lanes[i]; l.id = i; l.slots = 1;
 		HIPCHK(c, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
-		HIPCHK(c, hipMalloc((void **)&l.d_part, 8 * 3 * kBigPart)); HIPCHK(c, hipMalloc((void **)&l.d_scal, 8 * 16)); HIPCHK(c, hipMalloc((void **)&l.d_iscal, 4 * 8));
+		HIPCHK(c, hipMalloc((void **)&l.d_part, 8 * 3 * kBigPart)); HIPCHK(c, hipMalloc((void **)&l.d_scal, 8 * 16 + 4 * 8)); l.d_iscal = (int *)(l.d_scal + 16);
 		c->n_lanes_ready = i + 1;
 	}
 	return n;
@@ -1789,7 +1793,7 @@ static int big_run_class(srba_hip_ctx *c, const int32_t *caps, int count) {
 	const bool gang = c->big_gang && !c->big_persistent;
 	const int n = big_prepare_lanes(c, (gang || c->big_lanes_max <= 1) ? 1 : std::min(count, c->big_lanes_max)); if (n < 1) return -1;
 	int rc = 0; std::atomic<int> next(0);
-	if (n == 1) { rc = big_gang_run(c, &c->lanes[0], caps, count, next, gang ? std::min(c->big_lanes_max, srbadev::kGang) : 1); }
+	if (n == 1) { rc = big_gang_run(c, &c->lanes[0], caps, count, next, gang ? c->big_gang_slots : 1); }
 	else {
 		// the lanes start after everything already queued on the context stream (uploads, state resets)
 		hipEvent_t ready = nullptr; HIPCHK(c, hipEventCreateWithFlags(&ready, hipEventDisableTiming));

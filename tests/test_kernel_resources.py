@@ -58,6 +58,23 @@ def test_round4_instantiations_keep_three_wavefronts_per_simd(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "clang-offload-bundler")), reason="ROCm LLVM tools not found")
+def test_dense_factorisation_kernels_do_not_spill_their_broadcasts(tmp_path):
+    """k_chol_step / k_chol_panel (srba_big.hpp) hand the pivot column round by v_readlane: 31 SGPR pairs per pivot step. Left to itself the compiler issued them all first and spilled
+    them to VGPR lanes (538 SGPR spills in k_chol_panel, 984 in k_chol_step: three instructions per broadcast instead of one, 20 % of the factorisation's time); the loops are written
+    so that it cannot (branch-free pivots, update pairs pinned to their broadcast). Keep it so: no SGPR or VGPR spill, no scratch."""
+    obj = os.path.join(ROOT, "srba_amd", "lib", "srba_hip.o"); fat = str(tmp_path / "u.fat"); co = str(tmp_path / "u.co")
+    subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True)
+    subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True)
+    notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
+    seen = {}
+    for blk in notes.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        if "k_chol_step" in name or "k_chol_panel" in name:
+            seen[name] = tuple(int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1)) for k in ("sgpr_spill_count", "vgpr_spill_count", "private_segment_fixed_size"))
+    assert len(seen) == 2 and all(v == (0, 0, 0) for v in seen.values()), seen
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "clang-offload-bundler")), reason="ROCm LLVM tools not found")
 def test_fused_normal_equations_kernel_keeps_two_wavefronts_per_simd(tmp_path):
     """k_assemble_se2rel (srba_assemble.hip): its bins are sized for eight wavefronts per CU, i.e. two per SIMD -- at most 256 VGPRs, no scratch, in its three Lambda instantiations."""
     res = kernel_resources(tmp_path)
