@@ -17,4 +17,4 @@ cp gpurun_out/sq_summary.json $O/sq_summary.json
 timeout 600 bash tools/fam_compare.sh > $O/families.log 2>&1   # fused-kernel throughput per landmark family
 find $O -name "*kernel_trace*" -delete
 tail -3 $O/pytest_gpu.log; cat $O/smoke.log | tail -2; cut -c1-600 $O/bench.json
-timeout 1200 python tools/soak_parity.py 10 2>&1 | grep -v "^\[build" | tail -5 > $O/soak.log; tail -2 $O/soak.log
+if [ "${SOAK:-1}" != "0" ]; then timeout 1200 python tools/soak_parity.py 10 2>&1 | grep -v "^\[build" | tail -5 > $O/soak.log; tail -2 $O/soak.log; fi
