@@ -704,13 +704,16 @@ template <int FAM> __global__ void __launch_bounds__(128) kb_schur_inv(const Bat
 }
 // H_Ap(i,j) -= sum_l W_il Hf_l^-1 W_jl^t (schur.h:213-260). One workgroup per U_Ap block: the terms (landmarks seen through both edges, up to
 // all of them for a diagonal block) are strided over the 256 threads, each term writes its own Y = W Hf^-1 where the gradient / back-substitution need it.
-template <int FAM> __global__ void __launch_bounds__(256) kb_schur_reduce(const Batch B, const DevParams prm, const Gang G) {
+template <int FAM> __global__ void __launch_bounds__(256) kb_schur_reduce(const Batch B, const DevParams prm, const Gang G, int xcd_ranges) {
 	BIG_ENTER();
 	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L; const ProbDesc &d = B.desc[p];
 	if constexpr (!W::T::REL) {
 		__shared__ double sh[4 * P * P];
-		if ((int)blockIdx.x >= d.n_hap) return;
-		const int b = blockIdx.x, tb = B.sch_term_off[d.o_hapoff + b], te = B.sch_term_off[d.o_hapoff + b + 1];
+		// Workgroups are dealt to the eight XCDs round-robin (the grid's x extent is a multiple of 8): with xcd_ranges every XCD works through ONE contiguous eighth of the block list
+		// (blocks sorted by edge pair), so the W blocks of its edges stay in its own L2 instead of all eight L2s streaming the whole of W. Which workgroup sums a block does not change the sum.
+		int b = blockIdx.x; if (xcd_ranges) { const int per = (d.n_hap + 7) >> 3; b = (b & 7) * per + (b >> 3); if ((int)(blockIdx.x >> 3) >= per) return; }
+		if (b >= d.n_hap) return;
+		const int tb = B.sch_term_off[d.o_hapoff + b], te = B.sch_term_off[d.o_hapoff + b + 1];
 		if (tb == te) return;
 		double Hl[P * P];
 #pragma unroll
