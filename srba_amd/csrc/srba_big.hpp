@@ -462,34 +462,46 @@ __global__ void __launch_bounds__(256) k_chol_persistent(const BigSys S, unsigne
 	}
 }
 
-// L^t x = y in place in S.y (one workgroup): block rows from the last to the first. The CB x CB triangular solve runs in the first wavefront with column
-// `lane` of L_kk in registers (x_c travels by v_readlane); all four wavefronts then eliminate x_k from the rows above.
+// L^t x = y in place in S.y (one workgroup per window): block rows from the last to the first. The CB x CB triangular solve runs in the first wavefront with column
+// `lane` of L_kk in registers (lane c forms x_c, one v_readlane broadcast per step); all four wavefronts then eliminate x_k from the rows above, all CB loads of a row in
+// flight. The registers of the NEXT diagonal block are requested right after the solve (its own are dead then), so that load rides under the elimination.
+// (A pipelined form -- y in LDS, the first wavefront alone on the chain with the coupling block in registers, the other three eliminating one step behind -- was built and is
+// slower, 628 against 221 us per launch: a step then lasts as long as the elimination by 192 threads, which is what bounds the step here too; profiles/r04_cfg4_timeline.txt.)
 __global__ void __launch_bounds__(256) k_chol_bsub(const Gang G) {
 	__shared__ double xs[CB];
 	BIG_ENTER(); (void)p; const BigSys S = gang_sys(G, gw);
 	const int tid = threadIdx.x, lane = tid & 63, ld = S.ld, nblk = ld / CB;
 	if (*S.flag) return;
+	double a[CB]; // a[m] = L[m][lane] of the current diagonal block (first wavefront)
+	if (tid < 64) {
+#pragma unroll
+		for (int m = 0; m < CB; m++) a[m] = (lane < CB) ? S.Ldiag[(size_t)((nblk - 1) * CB + m) * CB + lane] : 0.0;
+	}
 	for (int kb = nblk - 1; kb >= 0; kb--) {
 		const int k0 = kb * CB;
 		if (tid < 64) {
-			double a[CB];
-#pragma unroll
-			for (int m = 0; m < CB; m++) a[m] = (lane < CB) ? S.Ldiag[(size_t)(k0 + m) * CB + lane] : 0.0; // a[m] = L[m][lane]
 			double acc = lane < CB ? S.y[k0 + lane] : 0.0, dinv = 1.0;
 #pragma unroll
 			for (int c = 0; c < CB; c++) if (lane == c) dinv = 1.0 / a[c]; // all the reciprocals of the diagonal at once
 #pragma unroll
 			for (int c = CB - 1; c >= 0; c--) { // x_c = (y_c - sum_{m>c} L[m][c] x_m) / L[c][c]
-				const double xc = lane_bcast(acc, c) * lane_bcast(dinv, c);
+				const double xc = lane_bcast(acc * dinv, c);
 				if (lane == c) acc = xc; else if (lane < c) acc -= a[c] * xc;
 			}
 			if (lane < CB) { xs[lane] = acc; S.y[k0 + lane] = acc; }
+			if (kb > 0) {
+#pragma unroll
+				for (int m = 0; m < CB; m++) a[m] = (lane < CB) ? S.Ldiag[(size_t)(k0 - CB + m) * CB + lane] : 0.0;
+			}
 		}
 		__syncthreads();
 		for (int i = tid; i < k0; i += 256) { // y_i -= sum_c L[k0+c][i] x_c
+			double v[CB];
+#pragma unroll
+			for (int c = 0; c < CB; c++) v[c] = S.A[(size_t)(k0 + c) * ld + i];
 			double s = 0;
-#pragma unroll 8
-			for (int c = 0; c < CB; c++) s += S.A[(size_t)(k0 + c) * ld + i] * xs[c];
+#pragma unroll
+			for (int c = 0; c < CB; c++) s += v[c] * xs[c];
 			S.y[i] -= s;
 		}
 		__syncthreads();
@@ -704,16 +716,13 @@ template <int FAM> __global__ void __launch_bounds__(128) kb_schur_inv(const Bat
 }
 // H_Ap(i,j) -= sum_l W_il Hf_l^-1 W_jl^t (schur.h:213-260). One workgroup per U_Ap block: the terms (landmarks seen through both edges, up to
 // all of them for a diagonal block) are strided over the 256 threads, each term writes its own Y = W Hf^-1 where the gradient / back-substitution need it.
-template <int FAM> __global__ void __launch_bounds__(256) kb_schur_reduce(const Batch B, const DevParams prm, const Gang G, int xcd_ranges) {
+template <int FAM> __global__ void __launch_bounds__(256) kb_schur_reduce(const Batch B, const DevParams prm, const Gang G) {
 	BIG_ENTER();
 	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L; const ProbDesc &d = B.desc[p];
 	if constexpr (!W::T::REL) {
 		__shared__ double sh[4 * P * P];
-		// Workgroups are dealt to the eight XCDs round-robin (the grid's x extent is a multiple of 8): with xcd_ranges every XCD works through ONE contiguous eighth of the block list
-		// (blocks sorted by edge pair), so the W blocks of its edges stay in its own L2 instead of all eight L2s streaming the whole of W. Which workgroup sums a block does not change the sum.
-		int b = blockIdx.x; if (xcd_ranges) { const int per = (d.n_hap + 7) >> 3; b = (b & 7) * per + (b >> 3); if ((int)(blockIdx.x >> 3) >= per) return; }
-		if (b >= d.n_hap) return;
-		const int tb = B.sch_term_off[d.o_hapoff + b], te = B.sch_term_off[d.o_hapoff + b + 1];
+		if ((int)blockIdx.x >= d.n_hap) return;
+		const int b = blockIdx.x, tb = B.sch_term_off[d.o_hapoff + b], te = B.sch_term_off[d.o_hapoff + b + 1];
 		if (tb == te) return;
 		double Hl[P * P];
 #pragma unroll
@@ -722,10 +731,7 @@ template <int FAM> __global__ void __launch_bounds__(256) kb_schur_reduce(const 
 			const int l = B.sch_lm[d.o_sch + t]; if (!B.hf_ok[d.o_ulm + l]) continue;
 			const double *W1 = B.HApf + (d.o_hapf + B.sch_b1[d.o_sch + t]) * P * L, *W2 = B.HApf + (d.o_hapf + B.sch_b2[d.o_sch + t]) * P * L, *Hi = B.Hfinv + (d.o_ulm + l) * L * L;
 			double Y[P * L], w1[P * L], w2[P * L], hi[L * L];
-#pragma unroll
-			for (int k = 0; k < P * L; k++) { w1[k] = W1[k]; w2[k] = W2[k]; }
-#pragma unroll
-			for (int k = 0; k < L * L; k++) hi[k] = Hi[k];
+			ldn<P * L>(w1, W1); ldn<P * L>(w2, W2); ldn<L * L>(hi, Hi); // 16-byte requests at 8-byte alignment: the launch is bound by the gathers' address traffic (every lane its own blocks), not by flops, L2 locality or the reductions (profiles/r04_cfg4_schur_reduce_variants.txt)
 #pragma unroll
 			for (int i = 0; i < P; i++)
 #pragma unroll
@@ -741,10 +747,7 @@ template <int FAM> __global__ void __launch_bounds__(256) kb_schur_reduce(const 
 					for (int k = 0; k < L; k++) s += Y[i * L + k] * w2[j * L + k];
 					Hl[i * P + j] += s; }
 			const int yw = B.sch_yw[d.o_sch + t];
-			if (yw >= 0) {
-#pragma unroll
-				for (int k = 0; k < P * L; k++) B.YW[(d.o_yw + yw) * P * L + k] = Y[k];
-			}
+			if (yw >= 0) stn<P * L>(B.YW + (d.o_yw + yw) * P * L, Y);
 		}
 		const double v = wg_sum<P * P>(Hl, sh);
 		if (threadIdx.x < P * P) B.HAp[(d.o_hap + b) * P * P + threadIdx.x] -= v;
@@ -764,11 +767,11 @@ template <int FAM> __global__ void __launch_bounds__(256) kb_schur_grad(const Ba
 		for (int r = 0; r < P; r++) acc[r] = 0;
 		for (int t = B.sch_term_off[d.o_hapoff + b] + threadIdx.x; t < B.sch_term_off[d.o_hapoff + b + 1]; t += 256) {
 			const int l = B.sch_lm[d.o_sch + t]; if (!B.hf_ok[d.o_ulm + l]) continue;
-			const double *Y = B.YW + (d.o_yw + B.sch_yw[d.o_sch + t]) * P * L;
+			double Y[P * L], gl[L]; ldn<P * L>(Y, B.YW + (d.o_yw + B.sch_yw[d.o_sch + t]) * P * L); ldn<L>(gl, gf + l * L);
 #pragma unroll
 			for (int r = 0; r < P; r++) { double s = 0;
 #pragma unroll
-				for (int k = 0; k < L; k++) s += Y[r * L + k] * gf[l * L + k];
+				for (int k = 0; k < L; k++) s += Y[r * L + k] * gl[k];
 				acc[r] += s; }
 		}
 		const double v = wg_sum<P>(acc, sh);
@@ -785,8 +788,8 @@ template <int FAM> __global__ void __launch_bounds__(128) kb_schur_features(cons
 			if (!B.hf_ok[d.o_ulm + l]) continue;
 			double gl[L]; for (int k = 0; k < L; k++) gl[k] = g[d.nK * P + l * L + k];
 			for (int q = B.lm_hapf_off[d.o_lmoff + l]; q < B.lm_hapf_off[d.o_lmoff + l + 1]; q++) {
-				const int hb = B.lm_hapf_idx[d.o_hapf + q], i = B.hapf_i[d.o_hapf + hb]; const double *Wm = B.HApf + (d.o_hapf + hb) * P * L;
-				for (int k = 0; k < L; k++) { double s = 0; for (int r = 0; r < P; r++) s += Wm[r * L + k] * dl[i * P + r]; gl[k] -= s; }
+				const int hb = B.lm_hapf_idx[d.o_hapf + q], i = B.hapf_i[d.o_hapf + hb]; double Wm[P * L], di[P]; ldn<P * L>(Wm, B.HApf + (d.o_hapf + hb) * P * L); ldn<P>(di, dl + i * P);
+				for (int k = 0; k < L; k++) { double s = 0; for (int r = 0; r < P; r++) s += Wm[r * L + k] * di[r]; gl[k] -= s; }
 			}
 			const double *Hi = B.Hfinv + (d.o_ulm + l) * L * L;
 			for (int k = 0; k < L; k++) g[d.nK * P + l * L + k] = gl[k];

@@ -1008,7 +1008,7 @@ struct srba_hip_ctx {
 	std::vector<int> big_ld; // per capsule: leading dimension of its dense system when it runs on the big path, else 0
 	double big_chol_ms = 0, big_chol_flops = 0; long long big_chol_count = 0, big_chol_seqs = 0 /* launch sequences: one factors all windows of a gang */; int big_chol_nmax = 0; // Cholesky time / flops of the big path since the last upload (sum over the lanes)
 	BigLane lanes[kBigLanes]; int n_lanes_ready = 0; // lane 0 = the context stream and buffers; the others are created on first use
-	bool big_gang = true, big_persistent = false, big_fused_step = true, big_xcd = true; int big_lanes_max = kBigLanes, big_gang_slots = srbadev::kGang, gang_from_nb = 0 /* landmark windows with this many block rows or more take the gang instead of one wavefront (0: off) */; // big path: windows of a batch in lock-step on one stream (gang) or one host thread + stream per window
+	bool big_gang = true, big_persistent = false, big_fused_step = true; int big_lanes_max = kBigLanes, big_gang_slots = srbadev::kGang, gang_from_nb = 0 /* landmark windows with this many block rows or more take the gang instead of one wavefront (0: off) */; // big path: windows of a batch in lock-step on one stream (gang) or one host thread + stream per window
 	int upload_threads = 1; bool dense_left = true; int hbm_from_kb = 48; bool dense_blocks_ok = true; // mid-size nearly-full systems use the dense block layout in LDS
 	bool lin_terms = true, lm_terms = true; // term-parallel U_Ap accumulation in LDS: srba_hip_linearize / the fused LM kernel
 	// fused normal equations of the relative-pose SE2 family (srba_assemble.hpp): capsules packed into bins (workgroups) by the LDS image they need, one launch; the rest take k_linearize
@@ -1195,7 +1195,6 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_GANG_FROM_NB"); if (e) c->gang_from_nb = atoi(e); } // large capsules of one batch in flight at once
 	{ const char *e = getenv("SRBA_HIP_BIG_PERSISTENT"); if (e) c->big_persistent = atoi(e) != 0; }   // 1 = the blocked Cholesky of the big path as ONE persistent launch with grid barriers (k_chol_persistent) instead of one launch per panel step and per trailing update (~60 launches); measured slower, DESIGN 4c
 	{ const char *e = getenv("SRBA_HIP_BIG_FUSED_STEP"); if (e) c->big_fused_step = atoi(e) != 0; }    // 0 = panel step and trailing update as two launches per 32 columns (k_chol_panel, k_chol_update)
-	{ const char *e = getenv("SRBA_HIP_BIG_XCD"); if (e) c->big_xcd = atoi(e) != 0; }                  // 0 = U_Ap blocks of the Schur reduction dealt to the XCDs round-robin instead of one contiguous range per XCD
 	{ const char *e = getenv("SRBA_HIP_BIG_GANG"); if (e) c->big_gang = atoi(e) != 0; }                // 0 = one host thread + stream per large window instead of the lock-step gang on one stream
 	return c;
 }
@@ -1598,7 +1597,7 @@ static void big_set_lambda(hipStream_t st, const srbadev::Gang &G, const srbadev
 static void big_enqueue_assemble(srba_hip_ctx *c, hipStream_t st, const srbadev::Gang &Gall) {
 	const int P = c->dm.P;
 	{ const srbadev::Gang G = gang_masked(Gall, gang_schur_mask(c, Gall));
-	  BIGK(kb_schur_inv, std::max<long long>(d.nF, (long long)d.n_hap * P * P), 128); BIGKG(kb_schur_reduce, 8 * ((d.n_hap + 7) / 8), 256, c->big_xcd ? 1 : 0); BIGKG(kb_schur_grad, d.nK, 256); }
+	  BIGK(kb_schur_inv, std::max<long long>(d.nF, (long long)d.n_hap * P * P), 128); BIGKG(kb_schur_reduce, d.n_hap, 256); BIGKG(kb_schur_grad, d.nK, 256); }
 	if (!Gall.mask) return;
 	hipLaunchKernelGGL(srbadev::kb_dense_clear, gang_grid(c, Gall, 256, false, [&](const ProbDesc &, int w) -> long long { return (long long)Gall.ld[w] * Gall.ld[w]; }), dim3(256), 0, st, Gall);
 	const unsigned ms = gang_schur_mask(c, Gall);
