@@ -716,7 +716,7 @@ template <int FAM> __global__ void __launch_bounds__(128) kb_schur_inv(const Bat
 }
 // H_Ap(i,j) -= sum_l W_il Hf_l^-1 W_jl^t (schur.h:213-260). One workgroup per U_Ap block: the terms (landmarks seen through both edges, up to
 // all of them for a diagonal block) are strided over the 256 threads, each term writes its own Y = W Hf^-1 where the gradient / back-substitution need it.
-template <int FAM> __global__ void __launch_bounds__(256) kb_schur_reduce(const Batch B, const DevParams prm, const Gang G) {
+template <int FAM> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) kb_schur_reduce(const Batch B, const DevParams prm, const Gang G) { // (172 registers left to itself: two wavefronts per SIMD; the launch waits for its gathers)
 	BIG_ENTER();
 	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L; const ProbDesc &d = B.desc[p];
 	if constexpr (!W::T::REL) {
