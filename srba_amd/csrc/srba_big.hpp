@@ -200,7 +200,7 @@ __device__ __forceinline__ bool chol_block_solve_regs(double (&a)[CB], double (&
 	for (int j = 0; j < CB; j++) acc += x[j] * lane_bcast(a[j], CB); // lane CB carried the right-hand side: its row is y_k now
 	return ok;
 }
-__global__ void __launch_bounds__(256) k_chol_step(const Gang G, int k0) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_chol_step(const Gang G, int k0) { // two workgroups per CU: left alone the kernel takes 232 + 32 registers -- eight over the budget that lets a second workgroup in -- and the many tile workgroups of the early steps queue behind one another
 	__shared__ double sh[2 * CT * (CB + 1)];
 	BIG_ENTER(); (void)p; const BigSys S = gang_sys(G, gw);
 	const int ld = S.ld, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
