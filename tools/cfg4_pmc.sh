@@ -26,3 +26,4 @@ for k in tot:
     if n('SQ_WAVE_CYCLES'): print('   -> waiting %.0f %% of the wave cycles, VALU issuing %.0f %%; lanes live per VALU instruction %.1f' % (100 * n('SQ_WAIT_ANY') / n('SQ_WAVE_CYCLES'), 100 * n('SQ_ACTIVE_INST_VALU') / n('SQ_WAVE_CYCLES') if n('SQ_ACTIVE_INST_VALU') else -1, n('SQ_THREAD_CYCLES_VALU') / max(1.0, n('SQ_ACTIVE_INST_VALU')) if n('SQ_THREAD_CYCLES_VALU') else -1))
 PY
 cat gpurun_out/cfg4_pmc.txt
+rm -rf $O   # the raw counter files exceed what gpurun copies back
