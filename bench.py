@@ -250,7 +250,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="do not append the cfg3 / cfg4 measurements (secondary_workloads) to the cfg2 line")
     ap.add_argument("--cfg3-copies", type=int, default=32, help="cfg3: the harvested local areas are re-optimised in this many replicas per step (fills the chip)")
     ap.add_argument("--cfg4-kf", type=int, default=300, help="key-frames of the cfg4 map (BASELINE: 5000; the depth-8 window saturates at ~260 key-frames, see DESIGN)")
-    ap.add_argument("--cfg4-windows", type=int, default=16, help="local areas (the last ones of the map) re-optimised per step; they run side by side on the lanes of the multi-workgroup path (up to 16): 4 windows 1.30 k, 8 windows 1.67 k, 16 windows 2.1-2.2 k, 32 windows 2.26 k LM iterations/s (rounds 1-2 measured 4)")
+    ap.add_argument("--cfg4-windows", type=int, default=16, help="local areas (the last ones of the map) re-optimised per step; since round 4 they run as a lock-step gang on the multi-workgroup path (up to 32 slots; more windows refill them): 16 windows 6.7-6.9 k, 32 windows 8.3 k, 64 windows 8.2 k LM iterations/s (round 3, one stream per window: 16 windows 2.1-2.2 k; rounds 1-2 measured 4)")
     ap.add_argument("--cache-dir", default="/tmp/srba_bench_cache", help="keep the harvested capsules here so that a second invocation (e.g. under rocprofv3) skips the sequential SLAM run; '' disables")
     args = ap.parse_args()
 
