@@ -1687,6 +1687,7 @@ static int big_gang_run(srba_hip_ctx *c, BigLane *ln, const int32_t *caps, int c
 	const int O = c->dm.O, L = c->dm.L; const srba_hip_params &prm = c->params; hipStream_t st = ln->stream;
 	nslots = std::max(1, std::min(nslots, ln->slots));
 	std::vector<GangSlot> S(nslots); std::vector<std::unique_ptr<srba_lm_result>> results; // result records stay alive until the last copy has been waited for
+	struct WaitOnExit { hipStream_t s; ~WaitOnExit() { (void)hipStreamSynchronize(s); } } wait_on_exit{st}; // (declared after `results`: destroyed before it, also on the error returns)
 	srbadev::Gang G0 = gang_of(ln);
 	const size_t fetch_bytes = (8 * 16 + 4 * 8) * (size_t)ln->slots; // scalars of all slots, then their flags: one allocation, one copy into page-locked memory
 	if (!ln->h_fetch) LNCHK(ln, hipHostMalloc(&ln->h_fetch, fetch_bytes, hipHostMallocDefault));
