@@ -166,7 +166,7 @@ def bench_cfg3(args, dist, rank, world, local_rank, backend, emit=True):
                            "extensions": int(args.cfg3_ext), "local_areas": n0, "replicas": copies, "unknown_edges_mean_max": [float(nk.mean()), int(nk.max())], "unknown_landmarks_mean_max": [float(nf.mean()), int(nf.max())], "observations_mean_max": [float(no.mean()), int(no.max())],
                            "lm_trials_per_step": trials, "obs_per_s": tot_obs * args.steps / max_elapsed, "map_build_s": round(t_map, 2), "sequential_ms_per_kf": round(1e3 * t_map / n_kf, 3),
                            "parallelism": "replicas x%d" % world, "solver": "Schur complement + LL^t of the reduced system in LDS (dense block layout; windows beyond LDS: HBM-resident layout or the multi-workgroup path)"},
-                "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": cfg3_traffic[0], "traffic_source": cfg3_traffic[1], "kernel": "k_lm_run<SE3_STEREO>", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None, "traffic_committed_profile": {"bytes_per_launch": cfg3_traffic[0], "source": cfg3_traffic[1], "note": "PMC passes are separate rocprofv3 runs (tools/pmc_cfg3.sh): a number of the committed profile, possibly of an older kernel build -- never mixed into this run's kernel_ms"}, "kernel": "k_lm_run<SE3_STEREO>", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
                              "note": "algorithmic bytes per SURVEY 8d: K1, K2 + K3 per block, K4 per observation, K5, K6 block writes, per trial K7/K8/K10 per landmark with d observing edges (L*L*8 + d*P*L*8 + L*8 in, d(d+1)/2 P x P blocks read-modify-write) and the dense reduced system (n^2 * 8)"},
                 "cpu_baseline": cpu}
         if emit:

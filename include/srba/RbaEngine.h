@@ -826,7 +826,7 @@ protected:
 		srba_hip_params hp; fill_hip_params(hp);
 		if (on_capsule) on_capsule(hp, cd, stage);
 		srba_problem_capsule cap = cd.view();
-		srba_lm_result res; std::memset(&res, 0, sizeof(res));
+		srba_lm_result res; std::memset(&res, 0, sizeof(res)); res.lambda_last_trial = std::numeric_limits<double>::quiet_NaN(); // (a back-end that does not know the field leaves the NaN: see return_hessian below)
 		if (!m_backend) m_backend = make_hip_backend(m_hip_device);
 		m_backend->set_profiler(&m_profiler);
 		{ internal::profiler_scope p2(m_profiler, "opt.backend"); m_backend->run(hp, cap, res); }
@@ -858,8 +858,12 @@ protected:
 			for (size_t b = 0; b < cd.hap_i.size(); b++) { const size_t i = cd.hap_i[b], j = cd.hap_j[b]; // upper blocks (i <= j); diagonal blocks hold both triangles
 				for (int r = 0; r < P; r++) for (int q = 0; q < P; q++) { const double v = hap[b * P * P + r * P + q]; dA[(P * i + r) * nA + P * j + q] = v; if (i != j) dA[(P * j + q) * nA + P * i + r] = v; } }
 			if (parameters.srba.compute_condition_number) out_info.HAp_condition_number = internal::symmetric_condition_number(dA, nA);
-			if (parameters.srba.return_hessian && res.num_trials > 0) { // (no trial: no solve, the reference's solver object holds no system either; hessian_valid stays false)
-				const double lam = res.lambda_last_trial; const bool full = !RBA_OPTIONS::solver_t::USE_SCHUR && nF > 0;
+			// lambda of the last trial: the trailing field srba_lm_result::lambda_last_trial (ABI: added in round 4 -- sizeof(srba_lm_result) grew by 8 bytes). A numeric back-end built
+			// against the older record leaves it as initialised before the run (NaN): fall back on the trace while it covers the run, else no Hessian rather than one with a wrong lambda
+			double lam_last = res.lambda_last_trial;
+			if (!(lam_last > 0.0) && res.num_trials > 0 && res.num_trials <= SRBA_TRACE_LEN) lam_last = res.trace_lambda[res.num_trials - 1];
+			if (parameters.srba.return_hessian && res.num_trials > 0 && lam_last > 0.0) { // (no trial: no solve, the reference's solver object holds no system either; hessian_valid stays false)
+				const double lam = lam_last; const bool full = !RBA_OPTIONS::solver_t::USE_SCHUR && nF > 0;
 				const size_t n = full ? nA + (size_t)L * nF : nA; std::vector<double> &H = out_info.extra_results.hessian; H.assign(n * n, 0.0);
 				for (size_t r = 0; r < nA; r++) for (size_t q = 0; q < nA; q++) H[r * n + q] = dA[r * nA + q];
 				if (full && m_backend->read_blocks(4, hf) && m_backend->read_blocks(5, hapf)) {

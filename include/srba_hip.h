@@ -192,7 +192,7 @@ enum srba_stop_reason {
 };
 #define SRBA_TRACE_LEN 48
 typedef struct srba_lm_result {
-	int32_t status;           /* 0 ok; 1 rank assert failed (optimize_edges.h:355): problem left untouched; 2 internal: the replicas of a speculative single-capsule run lost step (the call fails) */
+	int32_t status;           /* 0 ok; 1 rank assert failed (optimize_edges.h:355): problem left untouched; 2 internal, never returned: the replicas of a speculative single-capsule run lost step -- the library re-runs the capsule on the sequential path before it hands the record out */
 	int32_t num_iters;        /* value of "iter" at loop exit (optimize_edges.h:452-454) */
 	int32_t num_trials;       /* passes of the inner while (optimize_edges.h:471-692) = "LM trials" */
 	int32_t num_not_pd;       /* solve() returned false (:476-485) */
@@ -301,6 +301,10 @@ int    srba_hip_big_path_stats(srba_hip_ctx *ctx, double out[4]);
 /* The same with the launch sequences counted: since round 4 the large windows of a batch run in lock-step and ONE sequence of panel / update launches factors the systems of all
  * windows that are in a trial (srba_big.hpp, Gang). out = { ms, flops, factorisations, largest system, launch sequences, 1 if the lock-step gang is on, 0, 0 }. */
 int    srba_hip_big_path_stats2(srba_hip_ctx *ctx, double out[8]);
+/* Single-capsule batches of the relative-pose SE2 family (the per-key-frame use: RbaEngine<>::optimize_edges, impl/optimize_edges.h:471-692) speculate on the lambda ladder with several
+ * workgroups. out = { speculative launches since the context was created, launches whose replicas lost step (one of them not resident within the spin bound: another context holding
+ * the CUs) and that were therefore run again on the sequential path }. */
+int    srba_hip_spec_stats(srba_hip_ctx *ctx, int64_t out[2]);
 /* Time (ms) spent inside the last srba_hip_lm_run* kernel launch, measured with HIP events on the context stream. */
 double srba_hip_last_kernel_ms(srba_hip_ctx *ctx);
 /* Durations (ms, most recent first) of the last `n` srba_hip_lm_run / srba_hip_lm_run_async launches: HIP events recorded on the context

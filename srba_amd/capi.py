@@ -114,6 +114,7 @@ def hip_lib():
         lib.srba_hip_hessian_from_jacobians.argtypes = [C.c_void_p]
         lib.srba_hip_big_path_stats.argtypes = [C.c_void_p, PF64]
         lib.srba_hip_big_path_stats2.argtypes = [C.c_void_p, PF64]
+        lib.srba_hip_spec_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         lib.srba_hip_batch_stats.argtypes = [C.c_void_p, C.POINTER(BatchStats)]
         lib.srba_hip_last_kernel_ms.argtypes = [C.c_void_p]; lib.srba_hip_last_kernel_ms.restype = c_f64
         lib.srba_hip_kernel_ms_history.argtypes = [C.c_void_p, PF64, c_i32]

@@ -315,6 +315,10 @@ __device__ __forceinline__ bool chol3(const double *D, Chol3 &c) { return chol3v
 // so a column with 4 panel blocks and 10 update items occupies 12 / 30 lanes instead of 4 / 10 and the dependent chain per lane is a third as
 // long; the instruction count per column drops to about half. The diagonal 3x3 Cholesky stays redundant in every lane (no broadcast).
 // Same arithmetic per scalar as the lane-per-block form (same operation order inside every dot product): results are bit-identical.
+#ifndef SRBA_SOLVER_LDL
+#define SRBA_SOLVER_LDL 1 /* 1: square-root-free block LDL^t sweeps (round 5), 0: the block LL^t sweeps of rounds 2-4 */
+#endif
+#if !SRBA_SOLVER_LDL
 __device__ __forceinline__ bool sp_factor_fsub_rows(const SparseSys &S) {
 	const int lane = threadIdx.x, nb = S.nb;
 	const int grp = (lane * 171) >> 9, sub = lane - 3 * grp; // lane / 3, lane % 3 for lane < 64
@@ -393,6 +397,116 @@ __device__ __forceinline__ void sp_bsub_rows(const SparseSys &S) {
 		re = rb; rb = rb_n; rb_n = rb_nn; w = w_n;
 	}
 }
+#else
+// ---- Round 5: the same two sweeps as a square-root-free BLOCK LDL^t (H + lambda I = L D L^t, D = 3x3 diagonal blocks, L unit block-lower-triangular).
+// Why: a column of the LL^t form is a dependent chain of ~70 FP64 instructions (14-16 cycles each for a lone wavefront), 45 of them the redundant 3x3 Cholesky with three
+// refined rsqrt (71 cycles each), then the panel solve, an LDS hand-off, the update. Here the pivot block is INVERTED by cofactors (two products deep, then det: three, one
+// refined v_rcp_f64: five) and the panel is never written back: with W_ak = the (updated) block (a,k) as it stands when column k is reached,
+//     L_ak = W_ak D_k^-1,   target(a,b) -= L_ak W_bk^t = (W_ak D_k^-1) W_bk^t,   z_a -= W_ak (D_k^-1 z_k),   x_k = D_k^-1 (z_k - sum_a W_ak^t x_a)
+// so the update reads the blocks of column k as the previous columns left them -- no panel store, and ONE LDS hand-off per column instead of two. The factor kept in the
+// image is {D_k^-1 (lower triangle, in the diagonal block's place), W_ak (in place)}; the right-hand side keeps z_k (not D_k^-1 z_k) until the backward sweep.
+// "Not positive definite" == a leading minor of a pivot block <= 0 (a00, a00 a11 - a10^2, det): in exact arithmetic the same verdict as a Cholesky pivot <= 0
+// (Sylvester), decided identically by all lanes. Rounding differs from the LL^t sweeps (and from the oracle's) -- parity is the decision-replay check, not bit identity.
+struct Inv3 { double i00, i10, i11, i20, i21, i22; };
+__device__ __forceinline__ double rcp_refined(double d) { // 1/d: v_rcp_f64 + two Newton steps (the reciprocal of the division expansion without its numerator steps)
+	double x = __builtin_amdgcn_rcp(d); double e = fma(-d, x, 1.0); x = fma(x, e, x); e = fma(-d, x, 1.0); return fma(x, e, x);
+}
+__device__ __forceinline__ bool inv3v(double a00, double a10, double a11, double a20, double a21, double a22, Inv3 &v) {
+	const double c00 = fma(a11, a22, -(a21 * a21)), c10 = fma(a20, a21, -(a10 * a22)), c20 = fma(a10, a21, -(a20 * a11));
+	const double c11 = fma(a00, a22, -(a20 * a20)), c21 = fma(a10, a20, -(a00 * a21)), c22 = fma(a00, a11, -(a10 * a10));
+	const double det = fma(a20, c20, fma(a10, c10, a00 * c00));
+	const double r = rcp_refined(det);
+	v.i00 = c00 * r; v.i10 = c10 * r; v.i11 = c11 * r; v.i20 = c20 * r; v.i21 = c21 * r; v.i22 = c22 * r;
+	return (a00 > 0.0) & (c22 > 0.0) & (det > 0.0); // NaN-safe: any non-positive or NaN minor fails
+}
+__device__ __forceinline__ bool sp_factor_fsub_rows(const SparseSys &S) {
+	const int lane = threadIdx.x, nb = S.nb;
+	const int grp = (lane * 171) >> 9, sub = lane - 3 * grp; // lane / 3, lane % 3 for lane < 64
+	const bool worker = lane < 63;
+	int cb = S.col_off[0], ce = nb > 0 ? S.col_off[1] : cb, ib = 0;
+	int ra = (worker && cb + grp < ce) ? S.row[cb + grp] : 0; // block-row of this lane's panel block in the coming column
+	unsigned w0 = (worker && nb > 0 && grp < (ce - cb) * (ce - cb + 1) / 2) ? (unsigned)S.item[grp] : 0u; // this lane's first update item of the coming column
+	for (int k = 0; k < nb; k++) {
+		const int cn = ce - cb, nitems = cn * (cn + 1) / 2;
+		double *D = S.diag + 9 * k;
+		const double a00 = D[0], a10 = D[3], a11 = D[4], a20 = D[6], a21 = D[7], a22 = D[8];
+		const double z0 = S.rhs[3 * k], z1 = S.rhs[3 * k + 1], z2 = S.rhs[3 * k + 2];
+		const bool pl = worker && grp < cn, up = worker && grp < nitems;
+		const double *Arow = S.off + 9 * (cb + grp) + 3 * sub; double *rr = S.rhs + 3 * ra + sub;
+		double A0 = 0, A1 = 0, A2 = 0, rv = 0;
+		if (pl) { A0 = Arow[0]; A1 = Arow[1]; A2 = Arow[2]; rv = *rr; }
+		// operands of this lane's first update item: none of them depends on the inverse, their loads travel with the pivot block's
+		const double *La = S.off + 9 * (cb + ((w0 >> 9) & 511)) + 3 * sub, *Lb = S.off + 9 * (cb + (w0 & 511)); double *T = S.diag + 9 * (w0 >> 18) + 3 * sub;
+		double la0 = 0, la1 = 0, la2 = 0, lb[9], t0 = 0, t1 = 0, t2 = 0;
+#pragma unroll
+		for (int q = 0; q < 9; q++) lb[q] = 0;
+		if (up) { la0 = La[0]; la1 = La[1]; la2 = La[2];
+#pragma unroll
+			for (int q = 0; q < 9; q++) lb[q] = Lb[q];
+			t0 = T[0]; t1 = T[1]; t2 = T[2]; }
+		// index loads for the next column
+		const int ce_n = (k + 2 <= nb) ? S.col_off[k + 2] : ce;
+		const int ra_n = (worker && ce + grp < ce_n) ? S.row[ce + grp] : 0;
+		const int cn_n = ce_n - ce; const unsigned w0_n = (worker && k + 1 < nb && grp < cn_n * (cn_n + 1) / 2) ? (unsigned)S.item[ib + nitems + grp] : 0u;
+		Inv3 v;
+		if (!inv3v(a00, a10, a11, a20, a21, a22, v)) return false;
+		const double u0 = fma(v.i20, z2, fma(v.i10, z1, v.i00 * z0)), u1 = fma(v.i21, z2, fma(v.i11, z1, v.i10 * z0)), u2 = fma(v.i22, z2, fma(v.i21, z1, v.i20 * z0)); // D_k^-1 z_k
+		if (pl) *rr = rv - fma(A2, u2, fma(A1, u1, A0 * u0));
+		if (worker) for (int p = grp + 21; p < cn; p += 21) { // columns with more than 21 blocks
+			const double *Ax = S.off + 9 * (cb + p) + 3 * sub; double *rx = S.rhs + 3 * S.row[cb + p] + sub;
+			*rx -= fma(Ax[2], u2, fma(Ax[1], u1, Ax[0] * u0));
+		}
+		if (up) { // row `sub` of target -= (W_ak D_k^-1) W_bk^t
+			const double l0 = fma(la2, v.i20, fma(la1, v.i10, la0 * v.i00)), l1 = fma(la2, v.i21, fma(la1, v.i11, la0 * v.i10)), l2 = fma(la2, v.i22, fma(la1, v.i21, la0 * v.i20));
+			T[0] = t0 - fma(l2, lb[2], fma(l1, lb[1], l0 * lb[0]));
+			T[1] = t1 - fma(l2, lb[5], fma(l1, lb[4], l0 * lb[3]));
+			T[2] = t2 - fma(l2, lb[8], fma(l1, lb[7], l0 * lb[6]));
+		}
+		if (worker) for (int t = grp + 21; t < nitems; t += 21) { // the other update items of a column with more than 21
+			const unsigned w = (unsigned)S.item[ib + t];
+			const double *Lx = S.off + 9 * (cb + ((w >> 9) & 511)) + 3 * sub, *Ly = S.off + 9 * (cb + (w & 511)); double *Tx = S.diag + 9 * (w >> 18) + 3 * sub;
+			const double x0 = Lx[0], x1 = Lx[1], x2 = Lx[2];
+			double ly[9];
+#pragma unroll
+			for (int q = 0; q < 9; q++) ly[q] = Ly[q];
+			const double s0 = Tx[0], s1 = Tx[1], s2 = Tx[2];
+			const double l0 = fma(x2, v.i20, fma(x1, v.i10, x0 * v.i00)), l1 = fma(x2, v.i21, fma(x1, v.i11, x0 * v.i10)), l2 = fma(x2, v.i22, fma(x1, v.i21, x0 * v.i20));
+			Tx[0] = s0 - fma(l2, ly[2], fma(l1, ly[1], l0 * ly[0]));
+			Tx[1] = s1 - fma(l2, ly[5], fma(l1, ly[4], l0 * ly[3]));
+			Tx[2] = s2 - fma(l2, ly[8], fma(l1, ly[7], l0 * ly[6]));
+		}
+		if (lane == SRBA_WG - 1) { D[0] = v.i00; D[3] = v.i10; D[4] = v.i11; D[6] = v.i20; D[7] = v.i21; D[8] = v.i22; } // D_k^-1 in the pivot block's place (z_k stays in the right-hand side)
+		solver_sync();
+		cb = ce; ce = ce_n; ib += nitems; ra = ra_n; w0 = w0_n;
+	}
+	return true;
+}
+__device__ __forceinline__ void sp_bsub_rows(const SparseSys &S) {
+	const int lane = threadIdx.x, nb = S.nb;
+	if (nb <= 0) return;
+	const int grp = (lane * 171) >> 9, sub = lane - 3 * grp; const bool worker = lane < 63;
+	int re = S.rptr[nb], rb = S.rptr[nb - 1], rb_n = nb >= 2 ? S.rptr[nb - 2] : 0;
+	unsigned w = (worker && rb + grp < re) ? (unsigned)S.rent[rb + grp] : 0u; // col << 14 | off-diagonal block
+	for (int a = nb - 1; a >= 0; a--) {
+		const bool act = worker && rb + grp < re;
+		const double *D = S.diag + 9 * a; const double *Lb = S.off + 9 * (w & 0x3fff) + sub; double *y = S.rhs + 3 * (w >> 14) + sub;
+		const double r0 = S.rhs[3 * a], r1 = S.rhs[3 * a + 1], r2 = S.rhs[3 * a + 2], i00 = D[0], i10 = D[3], i11 = D[4], i20 = D[6], i21 = D[7], i22 = D[8];
+		double l0 = 0, l1 = 0, l2 = 0, yv = 0;
+		if (act) { l0 = Lb[0]; l1 = Lb[3]; l2 = Lb[6]; yv = *y; }
+		const unsigned w_n = (worker && a > 0 && rb_n + grp < rb) ? (unsigned)S.rent[rb_n + grp] : 0u;
+		const int rb_nn = a >= 2 ? S.rptr[a - 2] : 0;
+		const double x0 = fma(i20, r2, fma(i10, r1, i00 * r0)), x1 = fma(i21, r2, fma(i11, r1, i10 * r0)), x2 = fma(i22, r2, fma(i21, r1, i20 * r0)); // x_a = D_a^-1 (z_a - sum_{r > a} W_ra^t x_r)
+		if (act) *y = yv - fma(l2, x2, fma(l1, x1, l0 * x0));
+		if (worker) for (int j = rb + grp + 21; j < re; j += 21) { // rows with more than 21 blocks
+			const unsigned wx = (unsigned)S.rent[j]; const double *Lx = S.off + 9 * (wx & 0x3fff) + sub; double *yx = S.rhs + 3 * (wx >> 14) + sub;
+			*yx -= fma(Lx[6], x2, fma(Lx[3], x1, Lx[0] * x0));
+		}
+		if (lane == SRBA_WG - 1) { S.rhs[3 * a] = x0; S.rhs[3 * a + 1] = x1; S.rhs[3 * a + 2] = x2; }
+		solver_sync();
+		re = rb; rb = rb_n; rb_n = rb_nn; w = w_n;
+	}
+}
+#endif
 // ---- the same two sweeps for the DENSE block layout (SparseSys::dense): column k holds the blocks of rows k+1 .. nb-1, update item t = a(a+1)/2 + b of column k
 // targets block (k+1+a, k+1+b); every index is arithmetic, the LDS image carries numbers only. Used for mid-size systems whose factor is (nearly) full -- the
 // Schur-reduced systems of landmark windows -- where the item list of the sparse form (~nb^3/6 words) would not fit next to the numbers.
@@ -1214,7 +1328,8 @@ struct SpecCtl {
 	double *xdelta;    // [2][W][xstride]: the increment replica j solved for in that round
 	int xstride;
 	long long stride;  // bytes between the work arenas of two consecutive replicas
-	int round0;        // the rounds of this launch are numbered round0 + 1 ...: above every round of the launches before it (at most 8192 rounds per launch: one per trial), so `flag` needs no clearing
+	int round0;        // the rounds of this launch are numbered round0 + 1 ...: above every round of the launches before it (at most 8192 rounds per launch: one per trial -- the host only speculates when max_iters keeps a run below that), so `flag` needs no clearing
+	double *edge_backup; // [nK * PD]: the unknown edges as the launch found them (written by replica 0 before anything else): what the host restores before it re-runs a capsule whose replicas lost step (status 2) on the plain path
 };
 // the work arena of a replica: every state / workspace pointer of the batch moved by `bytes` (the arenas of the replicas lie one after the other: srba_hip_upload_problems)
 __device__ __forceinline__ Batch shift_work(Batch B, long long bytes) {
@@ -1227,11 +1342,13 @@ __device__ __forceinline__ Batch shift_work(Batch B, long long bytes) {
 }
 // publish this replica's outcome of the round and wait for all the others (every replica is resident: W workgroups on 256 CUs). Release / acquire at agent scope carry the
 // outcome and the increment across the L2s of the XCDs.
-__device__ __forceinline__ void spec_exchange(const SpecCtl &sc, int round, int code, double rho, double chi2, double lam) {
+__device__ __forceinline__ bool spec_exchange(const SpecCtl &sc, int round, int code, double rho, double chi2, double lam) { // false: a replica did not answer within the spin bound
 	__threadfence(); __syncthreads();
 	if (threadIdx.x == 0) { double *b = sc.box + ((round & 1) * sc.W + sc.w) * 4; b[0] = (double)code; b[1] = rho; b[2] = chi2; b[3] = lam; __hip_atomic_store(sc.flag + sc.w, round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
-	if ((int)threadIdx.x < sc.W) { long long spins = 0; while (__hip_atomic_load(sc.flag + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < round) { __builtin_amdgcn_s_sleep(1); if (++spins > (1ll << 26)) break; /* (a replica that never comes: give up instead of hanging the device; the lambda check of the caller reports it) */ } }
-	__syncthreads(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	int late = 0;
+	if ((int)threadIdx.x < sc.W) { long long spins = 0; while (__hip_atomic_load(sc.flag + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < round) { __builtin_amdgcn_s_sleep(1); if (++spins > (1ll << 19)) { late = 1; break; } /* (a replica that never comes -- not resident because something else holds the CUs: give up after about a second instead of hanging the device; the caller sets status 2 and the host re-runs the capsule on the sequential path) */ } }
+	const int any_late = __syncthreads_or(late); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	return any_late == 0;
 }
 __device__ __forceinline__ double spec_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ Batch copy_view(const Batch &B, int copy) { Batch V = B; if (copy) { V.edge = B.edge1; V.ulm = B.ulm1; V.pose = B.pose1; } return V; }

@@ -585,7 +585,8 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 						den = grp_sum<G>(den, red);
 						rho_w = (total_err - err_w) / den;
 					}
-					TIC(); spec_exchange(*sc, sp_round, ok_w ? 2 : 1, rho_w, err_w, lam_w); TOC(14);
+					TIC(); const bool all_there = spec_exchange(*sc, sp_round, ok_w ? 2 : 1, rho_w, err_w, lam_w); TOC(14);
+					if (!all_there) { if (tid == 0) out->status = 2; stop = true; break; } // a replica is not resident: the host re-runs the capsule on the sequential path (spec_fallback)
 					sp_j = 0;
 				}
 				const double *b = sc->box + ((sp_round & 1) * sc->W + sp_j) * 4; const int code = (int)spec_ld(b);
@@ -729,6 +730,7 @@ template <int FAM>
 __global__ void __launch_bounds__(2 * SRBA_WG) __attribute__((amdgpu_waves_per_eu(3, 3))) k_lm_spec(const Batch B, const DevParams prm, int lds_doubles, long long stride, SpecCtl sc) {
 	double *red = srba_lds + lds_doubles; sc.w = blockIdx.x; sc.stride = stride;
 	const Batch Bw = shift_work(B, stride * sc.w); const ProbDesc &d = B.desc[0];
+	if (!sc.w) { constexpr int PD = Tr<FAM>::PD; for (int k = threadIdx.x; k < d.nK * PD; k += 2 * SRBA_WG) sc.edge_backup[k] = B.edge[d.o_edge * PD + k]; } // (the host's way back if the replicas lose step: SpecCtl::edge_backup)
 	if (sc.w) { constexpr int PD = Tr<FAM>::PD; // the accepted state the run starts from (replica 0's: srba_hip_reset_state, or what an earlier run left); replica 0 writes there after the first exchange only
 		for (int k = threadIdx.x; k < d.n_edges * PD; k += 2 * SRBA_WG) Bw.edge[d.o_edge * PD + k] = B.edge[d.o_edge * PD + k];
 		__syncthreads(); }
@@ -1022,7 +1024,7 @@ struct srba_hip_ctx {
 	std::vector<int> delay_us; int class_prio = 0; // experiment knobs: per plan job delay before its launch (overrides the staggered start); stream priorities by class size
 	int stagger_ns = 300, stagger_max_us = 5000; // staggered start of the class launches: see plan_launches
 	// lambda-ladder speculation for a batch of ONE capsule (k_lm_spec): spec_w replicas of the work arena, spec_stride bytes apart; d_spec = flags | outcomes | increments (SpecCtl)
-	long long spec_launches = 0; bool spec_on = true, spec_ready = false; int spec_w = 12; size_t spec_stride = 0; char *d_spec = nullptr; static constexpr int kSpecMaxW = 32, kSpecMaxN = 768; static constexpr size_t kSpecBytes = 256 + 8 * (2 * kSpecMaxW * 4) + 8 * (2 * (size_t)kSpecMaxW * kSpecMaxN);
+	long long spec_launches = 0; bool spec_on = true, spec_ready = false; int spec_w = 12; size_t spec_stride = 0; char *d_spec = nullptr; static constexpr int kSpecMaxW = 32, kSpecMaxN = 768; static constexpr size_t kSpecBackupOff = 256 + 8 * (2 * kSpecMaxW * 4) + 8 * (2 * (size_t)kSpecMaxW * kSpecMaxN), kSpecBytes = kSpecBackupOff + 8 * 5 * (size_t)kSpecMaxN; bool spec_suppress = false, spec_test_drop = false; long long spec_fallbacks = 0;
 	bool two_on = true; int two_from_kb = 20, two_min_count = 128; // k_lm_run2 (two wavefronts per capsule) for the relative-pose SE2 classes whose LDS image is at least this big
 	bool lean_on = true; int lean_min_count = 512; // k_lm_run_lean for the size classes of which at least nine wavefronts fit the LDS of a CU (relative-pose SE2, classes with at least this many capsules)
 	int max_lds_kb = 1 << 20, min_chunk = 384, max_parts_per_queue = 2; int class_streams = 64 /* sched 3: the class launches are dealt round-robin to at most this many streams */, n_queues = 16, sched = 3, n_streams_used = 1, n_cu = 256, waves_per_cu = 8, lds_per_cu = 160 * 1024; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
@@ -1181,6 +1183,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 		const int split = 4, pri = c->class_prio == 0 ? 0 : ((c->class_prio == 1) == (k < split) ? pr_greatest : pr_least);
 		ok = (c->class_prio ? hipStreamCreateWithPriority(&c->cls_stream[k], hipStreamNonBlocking, pri) : hipStreamCreateWithFlags(&c->cls_stream[k], hipStreamNonBlocking)) == hipSuccess && hipEventCreateWithFlags(&c->cls_done[k], hipEventDisableTiming) == hipSuccess; }
 	if (!ok || hipMalloc((void **)&c->d_next, sizeof(int) * kMaxJobs) != hipSuccess || hipMalloc((void **)&c->d_part, 8 * 3 * kBigPart * srbadev::kGang) != hipSuccess || hipMalloc((void **)&c->d_scal, (8 * 16 + 4 * 8) * srbadev::kGang) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
+	c->spec_test_drop = getenv("SRBA_HIP_SPEC_TEST_DROP") != nullptr;
 	{ const char *e = getenv("SRBA_HIP_BIG_MIN_SYS"); if (e && atoi(e) >= 0) c->big_min_sys = atoi(e); } // tuning / test knob
 	{ const char *e = getenv("SRBA_HIP_DENSE_BLOCKS"); if (e) c->dense_blocks_ok = atoi(e) != 0; }
 	{ const unsigned hc = std::thread::hardware_concurrency(); c->upload_threads = (int)std::min(32u, std::max(1u, hc)); const char *e = getenv("SRBA_HIP_UPLOAD_THREADS"); if (e) c->upload_threads = std::max(1, atoi(e)); } // host threads of srba_hip_upload_problems
@@ -1473,7 +1476,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	wk.add(0);
 	if (in.size + 256 > c->cap_in) { if (c->d_in) hipFree(c->d_in); c->d_in = nullptr; c->cap_in = 0; const size_t want = (in.size + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_in, want)); c->cap_in = want; }
 	// a batch of one relative-pose SE2 capsule whose system lives in LDS: spec_w replicas of the work arena for the lambda-ladder speculation (k_lm_spec)
-	c->spec_ready = c->spec_on && n == 1 && c->params.family == SRBA_SE2_RELPOSE2D && c->two_on && c->sched == 3 && cls[0] < SRBA_NCLS - 1 && c->desc[0].dense_in_lds && c->desc[0].n_scal <= srba_hip_ctx::kSpecMaxN && c->desc[0].n_scal == c->desc[0].n_sys;
+	c->spec_ready = c->spec_on && n == 1 && c->params.family == SRBA_SE2_RELPOSE2D && c->two_on && c->sched == 3 && cls[0] < SRBA_NCLS - 1 && c->desc[0].dense_in_lds && c->desc[0].n_scal <= srba_hip_ctx::kSpecMaxN && c->desc[0].n_scal == c->desc[0].n_sys && c->params.max_iters <= 100 /* rounds <= trials <= ~ 70 per iteration (lambda *= nu, nu *= 2 reaches max_lambda within that): below the 8192 round numbers a launch owns (SpecCtl::round0) */;
 	c->spec_stride = (wk.size + 255) & ~(size_t)255; const size_t wk_need = c->spec_ready ? c->spec_stride * (size_t)c->spec_w : wk.size;
 	if (c->spec_ready && !c->d_spec) HIPCHK(c, hipMalloc((void **)&c->d_spec, srba_hip_ctx::kSpecBytes));
 	if (wk_need + 256 > c->cap_wk) { if (c->d_wk) hipFree(c->d_wk); c->d_wk = nullptr; c->cap_wk = 0; const size_t want = (wk_need + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_wk, want)); c->cap_wk = want; }
@@ -1522,6 +1525,7 @@ int srba_hip_reset_state(srba_hip_ctx *c) {
 
 int srba_hip_big_path_stats(srba_hip_ctx *c, double out[4]) { if (!c || !out) return -1; out[0] = c->big_chol_ms; out[1] = c->big_chol_flops; out[2] = (double)c->big_chol_count; out[3] = c->big_chol_nmax; return 0; }
 int srba_hip_big_path_stats2(srba_hip_ctx *c, double out[8]) { if (!c || !out) return -1; out[0] = c->big_chol_ms; out[1] = c->big_chol_flops; out[2] = (double)c->big_chol_count; out[3] = c->big_chol_nmax; out[4] = (double)c->big_chol_seqs; out[5] = c->big_gang && !c->big_persistent ? 1 : 0; out[6] = out[7] = 0; return 0; }
+int srba_hip_spec_stats(srba_hip_ctx *c, int64_t out[2]) { if (!c || !out) return -1; out[0] = c->spec_launches; out[1] = c->spec_fallbacks; return 0; }
 int srba_hip_batch_stats(srba_hip_ctx *c, srba_batch_stats *out) { if (!c || !out) return -1; *out = c->stats; return 0; }
 
 } // extern "C"
@@ -1839,10 +1843,11 @@ static int lm_run_async_impl(srba_hip_ctx *c) {
 	  if (!c->ring0[slot]) { HIPCHK(c, hipEventCreate(&c->ring0[slot])); HIPCHK(c, hipEventCreate(&c->ring1[slot])); }
 	  c->ev0 = c->ring0[slot]; c->ev1 = c->ring1[slot]; c->n_launches++; }
 	HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-	if (c->spec_ready && c->plan.size() == 1 && c->cls_count[SRBA_NCLS - 1] == 0) { // a batch of one capsule: its lambda ladder on spec_w workgroups
+	if (c->spec_ready && !c->spec_suppress && c->plan.size() == 1 && c->cls_count[SRBA_NCLS - 1] == 0) { // a batch of one capsule: its lambda ladder on spec_w workgroups
 		const int k = c->plan[0].cls; const size_t lds1 = (c->cls_lds[k] + c->lds_pad + 7) & ~(size_t)7; const int W = c->spec_w;
-		srbadev::SpecCtl sc; sc.w = 0; sc.W = W; sc.round0 = (int)((c->spec_launches++ % 200000) * 8192); if (sc.round0 == 0) HIPCHK(c, hipMemsetAsync(c->d_spec, 0, 256, c->stream)); sc.flag = (int *)c->d_spec; sc.box = (double *)(c->d_spec + 256); sc.xdelta = sc.box + 2 * srba_hip_ctx::kSpecMaxW * 4; sc.xstride = srba_hip_ctx::kSpecMaxN; // (the round numbers of a launch continue where no earlier launch has been: the flags are cleared once per 200 000 launches, not per launch)
-		hipLaunchKernelGGL((srbadev::k_lm_spec<SRBA_SE2_RELPOSE2D>), dim3(W), dim3(2 * SRBA_WG), lds1 + 32, c->stream, c->B, c->dp, (int)(lds1 / 8), (long long)c->spec_stride, sc); HIPCHK(c, hipGetLastError());
+		srbadev::SpecCtl sc; sc.w = 0; sc.W = W; sc.round0 = (int)((c->spec_launches++ % 200000) * 8192); if (sc.round0 == 0) HIPCHK(c, hipMemsetAsync(c->d_spec, 0, 256, c->stream)); sc.flag = (int *)c->d_spec; sc.box = (double *)(c->d_spec + 256); sc.xdelta = sc.box + 2 * srba_hip_ctx::kSpecMaxW * 4; sc.xstride = srba_hip_ctx::kSpecMaxN; sc.edge_backup = (double *)(c->d_spec + srba_hip_ctx::kSpecBackupOff); // (the round numbers of a launch continue where no earlier launch has been: the flags are cleared once per 200 000 launches, not per launch)
+		const bool test_drop = c->spec_test_drop; /* test knob (SRBA_HIP_SPEC_TEST_DROP, read when the context is created): the last replica is never launched -- the others give up after the spin bound, status 2, and the host falls back (tests/test_gpu_parity.py) */
+		hipLaunchKernelGGL((srbadev::k_lm_spec<SRBA_SE2_RELPOSE2D>), dim3(test_drop ? W - 1 : W), dim3(2 * SRBA_WG), lds1 + 32, c->stream, c->B, c->dp, (int)(lds1 / 8), (long long)c->spec_stride, sc); HIPCHK(c, hipGetLastError());
 		HIPCHK(c, hipEventRecord(c->ev1, c->stream));
 		return 0;
 	}
@@ -1913,12 +1918,28 @@ int srba_hip_eval_overall_sqr_error(srba_hip_ctx *c, const srba_overall_problem 
 	double s = 0; for (int b = 0; b < nblk; b++) s += part[b];
 	*out = s; return 0;
 }
+// The replicas of a speculative single-capsule run lost step with each other (status 2: one of them was not resident within the spin bound of spec_exchange -- a shared
+// GPU, another context filling the CUs): put the unknown edges back as the launch found them (SpecCtl::edge_backup, written by replica 0 before anything else) and run
+// the capsule once on the sequential path (k_lm_run2: recomputes every pose, Jacobian and result field from the edges). The stream is idle on entry and on return.
+static int spec_fallback(srba_hip_ctx *c) {
+	const ProbDesc &d = c->desc[0];
+	HIPCHK(c, hipMemcpyAsync(c->d_wk + c->off_edge + 8 * (size_t)d.o_edge * c->dm.PDX(), c->d_spec + srba_hip_ctx::kSpecBackupOff, 8 * (size_t)d.nK * c->dm.PDX(), hipMemcpyDeviceToDevice, c->stream));
+	c->spec_suppress = true; const int rc = lm_run_async_impl(c); c->spec_suppress = false; c->spec_fallbacks++;
+	if (rc != 0) return -1;
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_ms = ms;
+	return 0;
+}
 int srba_hip_download_results(srba_hip_ctx *c, srba_lm_result *results, int n) {
 	if (!c || !results || n > c->n_prob) return -1;
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	HIPCHK(c, hipMemcpyAsync(results, c->d_wk + c->off_res, sizeof(srba_lm_result) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
-	if (c->spec_ready && n >= 1 && results[0].status == 2) { c->fail("lm_run: the replicas of the speculative run lost step with each other (k_lm_spec)"); return -1; }
+	if (c->spec_ready && n >= 1 && results[0].status == 2) { // the speculative run gave up: once more on the sequential path
+		if (spec_fallback(c) != 0) return -1;
+		HIPCHK(c, hipMemcpyAsync(results, c->d_wk + c->off_res, sizeof(srba_lm_result) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+	}
 	return 0;
 }
 int srba_hip_lm_run(srba_hip_ctx *c, srba_lm_result *results) {
@@ -2030,7 +2051,11 @@ int srba_hip_optimize_capsule(srba_hip_ctx *c, srba_problem_capsule *cap, srba_l
 	float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_ms = ms;
 	if (host_timing) { acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; acc[3] += 1e3 * ms; if (++calls % 1000 == 0) { std::fprintf(stderr, "[optimize_capsule] per call: upload (host) %.1f us, launch + copies queued %.1f us, wait %.1f us (kernel %.1f us)\n", acc[0] / 1000, acc[1] / 1000, acc[2] / 1000, acc[3] / 1000); acc[0] = acc[1] = acc[2] = acc[3] = 0; } }
 	std::memcpy(res, c->h_out, sizeof(srba_lm_result));
-	if (c->spec_ready && res->status == 2) { c->fail("lm_run: the replicas of the speculative run lost step with each other (k_lm_spec)"); return -1; }
+	if (c->spec_ready && res->status == 2) { // the speculative run gave up: once more on the sequential path, read back the same span
+		if (spec_fallback(c) != 0) return -1;
+		HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_wk + c->off_res, span, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+		std::memcpy(res, c->h_out, sizeof(srba_lm_result));
+	}
 	if (cap->n_unk_edges != d.nK || cap->n_pairs != d.n_pairs) { c->fail("optimize_capsule: capsule layout differs from the uploaded one"); return -1; }
 	const double *edge = (const double *)(c->h_out + (c->off_edge - c->off_res)), *pose = (const double *)(c->h_out + (c->off_pose - c->off_res));
 	for (int q = 0; q < d.nK; q++) std::memcpy(cap->edge_pose + (size_t)q * PD, edge + ((size_t)d.o_edge + q) * PDX, 8 * (size_t)PD); // SE2: drop the cached cos/sin

@@ -113,6 +113,35 @@ def test_speculative_single_capsule_run_is_the_sequential_loop_bit_for_bit(se2_b
 
 
 @pytest.mark.gpu
+def test_speculative_run_whose_replicas_lose_step_falls_back_to_the_sequential_loop(se2_batch, monkeypatch):
+    """k_lm_spec needs all its replicas resident; when one does not come (a shared GPU, another context on the CUs) the waiters give up after the spin bound
+    and the capsule used to FAIL (status 2, RbaEngine throws). Now the library restores the unknown edges the launch started from and runs the capsule once on the sequential
+    path: same record, same written-back state as a plain run, bit for bit. The test knob SRBA_HIP_SPEC_TEST_DROP never launches the last replica."""
+    import ctypes as C
+    b = se2_batch; P, L, O, PD = capi.DIMS[b.family]
+    idx = [i for i in range(b.n) if b[i].n_unk_edges >= 3][:3]
+    def run(drop, one_call):
+        monkeypatch.setenv("SRBA_HIP_SPEC", "0" if drop is None else "8")
+        if drop: monkeypatch.setenv("SRBA_HIP_SPEC_TEST_DROP", "1")
+        else: monkeypatch.delenv("SRBA_HIP_SPEC_TEST_DROP", raising=False)
+        out = []; ctx = runner.HipContext(b.params)
+        for i in idx:
+            w = b.clone(i, 1)
+            if one_call: r = ctx.optimize_capsule(w)
+            else: ctx.upload(w); r = ctx.lm_run(); ctx._chk(ctx.lib.srba_hip_download_state(ctx.ctx, w.ptr, 1), "download_state")
+            r["edge"] = w.array(0, "edge_pose", np.float64, w[0].n_unk_edges * PD).copy(); r["pose"] = w.array(0, "pose", np.float64, 2 * w[0].n_pairs * PD).copy(); out.append(r)
+        st = (C.c_int64 * 2)(); ctx.lib.srba_hip_spec_stats(ctx.ctx, st); ctx.close(); return out, (int(st[0]), int(st[1]))
+    plain, st0 = run(None, False); assert st0 == (0, 0)
+    for one_call in (False, True):
+        got, st = run(True, one_call)
+        assert st[0] == len(idx) and st[1] >= 1, st          # every capsule was tried speculatively; at least one run consulted the missing replica and fell back
+        for i, (p_, g) in enumerate(zip(plain, got)):
+            assert g["status"][0] == 0
+            for k in p_:
+                assert np.array_equal(np.asarray(p_[k]), np.asarray(g[k]), equal_nan=True), (one_call, idx[i], k)
+
+
+@pytest.mark.gpu
 def test_optimize_capsule_is_upload_run_download_in_one_call(se2_batch):
     """srba_hip_optimize_capsule (what RbaEngine<>::optimize_edges binds per key-frame: one wait for the device) against the three calls it stands for, on the same context, capsule
     after capsule (the staging buffers are reused from one call to the next): result records and written-back unknowns / spanning-tree poses bit-identical; and a landmark family,
