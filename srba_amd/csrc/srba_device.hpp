@@ -189,14 +189,18 @@ __device__ __forceinline__ double block_max(double v, double *) { return wave_ma
 // ---- capsule GROUPS (round 4): the lanes that work on one capsule. G = 64: one wavefront (every kernel of rounds 1-3). G = 128: TWO wavefronts per capsule (k_lm_run2: the big,
 // LDS-bound windows of a big batch -- their wavefronts sit alone on a SIMD and the launch waits for their latency: the lane-parallel phases go twice as wide, the block-sparse
 // solver stays on the first wavefront). Reductions over a group: per wavefront (DPP tree), then the two totals through two doubles of LDS (`red`) in a fixed order: deterministic.
-template <int G> __device__ __forceinline__ double grp_sum(double v, double *red) {
+template <int G> __device__ __forceinline__ double grp_sum(double v, double *red) { // red: G / 64 doubles of LDS
 	v = wave_sum(v);
-	if constexpr (G > 64) { if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v; __syncthreads(); v = red[0] + red[1]; __syncthreads(); }
+	if constexpr (G > 64) { if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v; __syncthreads(); v = red[0] + red[1];
+		if constexpr (G > 128) { static_assert(G == 256, "groups of one, two or four wavefronts"); v = v + (red[2] + red[3]); }
+		__syncthreads(); }
 	return v;
 }
 template <int G> __device__ __forceinline__ double grp_max(double v, double *red) {
 	v = wave_max(v);
-	if constexpr (G > 64) { if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v; __syncthreads(); v = fmax(red[0], red[1]); __syncthreads(); }
+	if constexpr (G > 64) { if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v; __syncthreads(); v = fmax(red[0], red[1]);
+		if constexpr (G > 128) v = fmax(v, fmax(red[2], red[3]));
+		__syncthreads(); }
 	return v;
 }
 // hand-off through LDS inside a phase: one wavefront needs no barrier (its LDS instructions execute in order), two do
@@ -289,6 +293,8 @@ struct SparseSys { // per-capsule symbolic structure (LDS copy of the host's sym
 	const int *perm;           // perm[original 3-row block] = position in the fill-reducing elimination order
 	double *diag, *off, *rhs;
 	double *row_lds;           // HBM-resident dense layout with left-looking sweeps: 21 nb doubles of LDS (rows k, k+1 of the factor | y), else null
+	double *tiles, *linv; int nt; // workgroup path (srba_wg.hpp, ProbDesc::dense_blocks == 3): lower triangle of 16 x 16 frag tiles + the right-hand-side tile row | inverse diagonal factors; rhs then points at x in LDS, natural order (no permutation)
+	__device__ __forceinline__ double sol(int q) const { return tiles ? rhs[q] : rhs[3 * perm[q / 3] + q % 3]; } // component q (original numbering) of the solved right-hand side
 };
 // Cross-lane hand-off inside the solver. LDS instructions of one wavefront execute in issue order, so a ds_write followed by a ds_read of
 // another lane's data needs no s_waitcnt -- only the compiler must keep the program order (wavefront-scope fence = no instructions).
@@ -432,18 +438,14 @@ __device__ __forceinline__ bool sp_factor_fsub_rows(const SparseSys &S) {
 		const double a00 = D[0], a10 = D[3], a11 = D[4], a20 = D[6], a21 = D[7], a22 = D[8];
 		const double z0 = S.rhs[3 * k], z1 = S.rhs[3 * k + 1], z2 = S.rhs[3 * k + 2];
 		const bool pl = worker && grp < cn, up = worker && grp < nitems;
-		const double *Arow = S.off + 9 * (cb + grp) + 3 * sub; double *rr = S.rhs + 3 * ra + sub;
-		double A0 = 0, A1 = 0, A2 = 0, rv = 0;
-		if (pl) { A0 = Arow[0]; A1 = Arow[1]; A2 = Arow[2]; rv = *rr; }
-		// operands of this lane's first update item: none of them depends on the inverse, their loads travel with the pivot block's
+		// (loads are unconditional -- an idle lane reads block 0 of the column / of the image, inside the LDS image -- only the stores are guarded: no zero-fill, no exec juggling around them)
+		const double *Arow = S.off + 9 * (cb + (pl ? grp : 0)) + 3 * sub; double *rr = S.rhs + 3 * ra + sub;
+		const double A0 = Arow[0], A1 = Arow[1], A2 = Arow[2], rv = *rr;
+		// operands of this lane's first update item (w0 = 0 for an idle lane): none of them depends on the inverse, their loads travel with the pivot block's
 		const double *La = S.off + 9 * (cb + ((w0 >> 9) & 511)) + 3 * sub, *Lb = S.off + 9 * (cb + (w0 & 511)); double *T = S.diag + 9 * (w0 >> 18) + 3 * sub;
-		double la0 = 0, la1 = 0, la2 = 0, lb[9], t0 = 0, t1 = 0, t2 = 0;
+		const double la0 = La[0], la1 = La[1], la2 = La[2], t0 = T[0], t1 = T[1], t2 = T[2]; double lb[9];
 #pragma unroll
-		for (int q = 0; q < 9; q++) lb[q] = 0;
-		if (up) { la0 = La[0]; la1 = La[1]; la2 = La[2];
-#pragma unroll
-			for (int q = 0; q < 9; q++) lb[q] = Lb[q];
-			t0 = T[0]; t1 = T[1]; t2 = T[2]; }
+		for (int q = 0; q < 9; q++) lb[q] = Lb[q];
 		// index loads for the next column
 		const int ce_n = (k + 2 <= nb) ? S.col_off[k + 2] : ce;
 		const int ra_n = (worker && ce + grp < ce_n) ? S.row[ce + grp] : 0;

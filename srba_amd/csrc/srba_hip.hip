@@ -11,6 +11,7 @@
  * holds state + workspaces.  A per-capsule descriptor (ProbDesc) carries sizes and element offsets.
  */
 #include "srba_device.hpp"
+#include "srba_wg.hpp"
 #include <algorithm>
 #include <iterator>
 #include <map>
@@ -77,18 +78,21 @@ struct Solver : public Worker<FAM, LEAN, G> {
 #pragma unroll
 						for (int r = 0; r < P; r++) unsafeAtomicAdd(gi + r, ga[r]); }
 				};
-				for (int t = tb; t < te; t += 2) { // two terms per pass: indices and records of both are requested before either is used
-					const bool two = t + 1 < te; const int t1 = two ? t + 1 : t;
-					const int l0 = s_lm[t], l1 = s_lm[t1], a0 = s_b1[t], c0 = s_b2[t], a1 = s_b1[t1], c1 = s_b2[t1], yw0 = s_yw[t], yw1 = s_yw[t1], k0 = s_blk[t], k1 = s_blk[t1];
-					const bool ok0 = B.hf_ok[d.o_ulm + l0] != 0, ok1 = two && B.hf_ok[d.o_ulm + l1] != 0;
-					double W1[2][P * L], W2[2][P * L], Hi[2][L * L], gl[2][L];
-					ldn<P * L>(W1[0], B.HApf + (d.o_hapf + a0) * P * L); ldn<P * L>(W2[0], B.HApf + (d.o_hapf + c0) * P * L); ldn<L * L>(Hi[0], B.Hfinv + (d.o_ulm + l0) * L * L); ldn<L>(gl[0], gf + l0 * L);
-					ldn<P * L>(W1[1], B.HApf + (d.o_hapf + a1) * P * L); ldn<P * L>(W2[1], B.HApf + (d.o_hapf + c1) * P * L); ldn<L * L>(Hi[1], B.Hfinv + (d.o_ulm + l1) * L * L); ldn<L>(gl[1], gf + l1 * L);
+				constexpr int NT = LEAN ? 1 : 2; // terms per pass: indices and records of all of them are requested before any is used (LEAN: one -- the register diet of the workgroup kernels)
+				for (int t = tb; t < te; t += NT) {
+					int lq[NT], aq[NT], cq[NT], ywq[NT], kq[NT]; bool okq[NT];
 #pragma unroll
-					for (int u = 0; u < 2; u++) {
-						if (!(u ? ok1 : ok0)) continue;
-						const int kb = u ? k1 : k0;
-						if (kb != cur) { flush(); cur = kb; curdiag = (u ? yw1 : yw0) >= 0;
+					for (int u = 0; u < NT; u++) { const bool live = t + u < te; const int tu = live ? t + u : t; lq[u] = s_lm[tu]; aq[u] = s_b1[tu]; cq[u] = s_b2[tu]; ywq[u] = s_yw[tu]; kq[u] = s_blk[tu]; okq[u] = live; }
+#pragma unroll
+					for (int u = 0; u < NT; u++) okq[u] = okq[u] && B.hf_ok[d.o_ulm + lq[u]] != 0;
+					double W1[NT][P * L], W2[NT][P * L], Hi[NT][L * L], gl[NT][L];
+#pragma unroll
+					for (int u = 0; u < NT; u++) { ldn<P * L>(W1[u], B.HApf + (d.o_hapf + aq[u]) * P * L); ldn<P * L>(W2[u], B.HApf + (d.o_hapf + cq[u]) * P * L); ldn<L * L>(Hi[u], B.Hfinv + (d.o_ulm + lq[u]) * L * L); ldn<L>(gl[u], gf + lq[u] * L); }
+#pragma unroll
+					for (int u = 0; u < NT; u++) {
+						if (!okq[u]) continue;
+						const int kb = kq[u];
+						if (kb != cur) { flush(); cur = kb; curdiag = ywq[u] >= 0;
 #pragma unroll
 							for (int k = 0; k < P * P; k++) Hl[k] = 0;
 #pragma unroll
@@ -226,6 +230,23 @@ struct Solver : public Worker<FAM, LEAN, G> {
 		for (int k = n + tid; k < 3 * nb; k += G) S.diag[9 * S.perm[k / 3] + 4 * (k % 3)] = 1.0; // identity padding
 		__syncthreads();
 	}
+	// The Schur-reduced system H_Ap' + lambda I and its right-hand side as 16 x 16 frag tiles (srba_wg.hpp; lev-marq_solvers.h:492-519 builds the same dense matrix for Eigen::LLT):
+	// the area is cleared, then every upper-triangle U_Ap block (i <= j) lands transposed in the lower triangle; rows beyond n_sys get an identity diagonal; the gradient is tile row nt.
+	__device__ __forceinline__ void assemble_tiles(const SparseSys &S, double lambda) { this->fresh();
+		const int n = d.n_sys, nt = S.nt; double *T = S.tiles;
+		{ const long long n2 = 128LL * (nt + 1) * (nt + 2) / 2; f64x2u z; z.x = 0; z.y = 0; for (long long k = tid; k < n2; k += G) *(f64x2u *)(T + 2 * k) = z; }
+		__syncthreads();
+		auto at = [&](int r, int c) -> double * { return T + 256 * (long long)wg_tile(r >> 4, c >> 4) + wg_frag_off(r & 15, c & 15); }; // element (r, c), r >= c
+		for (int e = tid; e < d.n_hap * P * P; e += G) {
+			const int b = e / (P * P), r = (e / P) % P, q = e % P; const int i = B.hap_i[d.o_hap + b], j = B.hap_j[d.o_hap + b];
+			const double v = B.HAp[(d.o_hap + b) * P * P + r * P + q]; // element (P i + r, P j + q) of the upper triangle (i <= j)
+			if (i != j) *at(P * j + q, P * i + r) = v;
+			else if (r >= q) *at(P * i + r, P * i + q) = v + (r == q ? lambda : 0.0); // (a diagonal block holds both triangles)
+		}
+		const double *g = B.grad + d.o_scal;
+		for (int k = tid; k < 16 * nt; k += G) { T[256 * (long long)wg_tile(nt, k >> 4) + wg_frag_off(0, k & 15)] = (k < n) ? g[k] : 0.0; if (k >= n) *at(k, k) = 1.0; }
+		__syncthreads();
+	}
 	// solve(lambda): returns false if not positive definite (uniform across the wavefront)
 	__device__ __forceinline__ bool solve(const SparseSys &S, double lambda, long long *pc = nullptr) {
 		long long t0 = 0;
@@ -234,18 +255,28 @@ struct Solver : public Worker<FAM, LEAN, G> {
 		if (schur_active() && (prm.ext & SRBA_EXT_SCHUR_KEEPS_GRADIENT)) { // (extension, default off) every solve starts from the gradient K5 produced: same lane -> same elements as keep_gradient()
 			double *g = B.grad + d.o_scal; const double *g0 = B.grad0 + d.o_scal; for (int k = tid; k < d.n_scal; k += G) g[k] = g0[k]; __syncthreads(); }
 		STIC(); if (schur_active()) schur_reduce(lambda, pc); STOC(9);
+		if constexpr (G > 64 && !W::T::REL) { // landmark window on a workgroup: dense LL^t on the matrix cores (srba_wg.hpp)
+			STIC(); assemble_tiles(S, lambda); STOC(10);
+			STIC(); const bool okw = wg_chol_solve<G / 64>(S.tiles, S.linv, S.nt, (lds_f64 *)srba_lds); STOC(11);
+			if (!okw) return false;
+			double *dlw = B.delta + d.o_scal;
+			for (int k = tid; k < d.n_scal; k += G) dlw[k] = (k < d.n_sys) ? S.rhs[k] : 0.0;
+			__syncthreads();
+			STIC(); if (schur_active()) schur_features(); STOC(13);
+			return true;
+		}
 		STIC(); assemble(S, lambda); STOC(10);
 		// (the dense block layouts are never chosen for the relative-pose families -- srba_hip_upload_problems -- whose kernels therefore carry the sparse solver only: the
 		//  headline kernel sits 22 VGPRs below the two-wavefronts-per-SIMD limit)
 		STIC(); bool ok;
-		if constexpr (G > 64) { // two wavefronts per capsule (sparse layout only): the first one factors and substitutes, the verdict travels through the reduction scratch behind the image
+		if constexpr (G > 64 && !W::T::REL) { ok = false; /* (unreachable: the workgroup branch above returned) */ } else if constexpr (G > 64) { // two wavefronts per capsule (sparse layout only): the first one factors and substitutes, the verdict travels through the reduction scratch behind the image
 			int *flag = (int *)red2w; if (threadIdx.x < 64) { const bool k1 = sp_factor_fsub_rows(S); if (k1) sp_bsub_rows(S); if (threadIdx.x == 0) *flag = k1 ? 1 : 0; }
 			__syncthreads(); ok = *flag != 0; __syncthreads();
 		} else if constexpr (W::T::REL || !W::T::SE3) ok = sp_factor_fsub_rows(S); else ok = d.dense_blocks == 2 ? (S.row_lds ? sp_factor_fsub_dense_left(S, (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16), (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16 + 18 * S.nb)) : sp_factor_fsub_dense<true>(S)) : (S.dense ? sp_factor_fsub_dense<false>(S) : sp_factor_fsub_rows(S)); STOC(11);
 		if (!ok) return false;
 		STIC(); if constexpr (G > 64) { /* done above */ } else if constexpr (W::T::REL || !W::T::SE3) sp_bsub_rows(S); else { if (d.dense_blocks == 2) { if (S.row_lds) sp_bsub_dense_left(S, (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16 + 18 * S.nb)); else sp_bsub_dense<true>(S); } else if (S.dense) sp_bsub_dense<false>(S); else sp_bsub_rows(S); }
 		double *dl = B.delta + d.o_scal;
-		for (int k = tid; k < d.n_scal; k += G) dl[k] = (k < d.n_sys) ? S.rhs[3 * S.perm[k / 3] + k % 3] : 0.0;
+		for (int k = tid; k < d.n_scal; k += G) dl[k] = (k < d.n_sys) ? S.sol(k) : 0.0;
 		if (schur_active()) __syncthreads(); /* (K10 reads the increments of the edges back from memory; without landmarks to solve for, the loop takes them from the LDS image: no reader waits for these stores) */ STOC(12);
 		STIC(); if (schur_active()) schur_features(); STOC(13);
 		return true;
@@ -256,7 +287,13 @@ struct Solver : public Worker<FAM, LEAN, G> {
 		if (schur_active() && (prm.ext & SRBA_EXT_SCHUR_KEEPS_GRADIENT)) { const double *g = B.grad + d.o_scal; double *g0 = B.grad0 + d.o_scal; for (int k = tid; k < d.n_scal; k += G) g0[k] = g[k]; }
 	}
 	__device__ __forceinline__ SparseSys make_sys(double *lds) const {
-		SparseSys S; S.nb = d.nb; S.nnzoff = d.nnzoff; S.dense = (W::T::REL || !W::T::SE3) ? 0 : d.dense_blocks;
+		SparseSys S; S.tiles = S.linv = nullptr; S.nt = 0;
+		if constexpr (G > 64 && !W::T::REL) { // a landmark window on a workgroup (srba_wg.hpp): tile system in the capsule's HBM workspace, x in LDS; no symbolic structure, no permutation
+			S.nb = d.nb; S.nnzoff = 0; S.dense = 3; S.row_lds = nullptr; S.col_off = S.row = S.item = S.rptr = S.rent = S.perm = nullptr; S.diag = S.off = nullptr;
+			S.nt = (d.n_sys + WT - 1) / WT; S.tiles = B.dense + d.o_dense; S.linv = S.tiles + 256 * (long long)((S.nt + 1) * (S.nt + 2) / 2); S.rhs = lds + 768;
+			return S;
+		}
+		S.nb = d.nb; S.nnzoff = d.nnzoff; S.dense = (W::T::REL || !W::T::SE3) ? 0 : d.dense_blocks;
 		S.row_lds = (S.dense == 2 && B.dense_left && d.nb <= 168) ? lds + (d.nb + 1) / 2 + 16 : nullptr; // HBM-resident layout, left-looking sweeps: 21 nb doubles of LDS after the permutation (two rows of the factor | y)
 		S.col_off = B.sp_col_off + d.o_spcol; S.row = B.sp_row + d.o_sprow; S.item = B.sp_tgt + d.o_spitem; S.perm = B.sp_perm + d.o_spperm;
 		S.rptr = B.sp_rptr + d.o_spcol; S.rent = B.sp_rcol + d.o_sprow;
@@ -317,7 +354,7 @@ struct Solver : public Worker<FAM, LEAN, G> {
 			if (i < d.nK) {
 				double inc[P];
 #pragma unroll
-				for (int k = 0; k < P; k++) { const int q = i * P + k; inc[k] = S.rhs[3 * S.perm[q / 3] + q % 3]; }
+				for (int k = 0; k < P; k++) { const int q = i * P + k; inc[k] = S.sol(q); }
 				PO::st(B.old_edge + (d.o_unk + i) * PD, cur);
 				cur = comp(PO::expm(inc), cur);
 				PO::st(e, cur);
@@ -351,7 +388,7 @@ struct Solver : public Worker<FAM, LEAN, G> {
 			if (i < d.nK) {
 				double inc[P];
 #pragma unroll
-				for (int k = 0; k < P; k++) { const int q = i * P + k; inc[k] = S.rhs[3 * S.perm[q / 3] + q % 3]; }
+				for (int k = 0; k < P; k++) { const int q = i * P + k; inc[k] = S.sol(q); }
 				cur = comp(PO::expm(inc), cur);
 				PO::st(Bt.edge + (d.o_edge + i) * PD, cur);
 			}
@@ -399,7 +436,7 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 #define TIC() do { if (pc) { __syncthreads(); tc0 = wall_clock64(); } } while (0)
 #define TOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - tc0; } } while (0)
 	// K6: the LDS image of the system is idle while the capsule is linearised (it is assembled per trial): the U_Ap accumulators of the term-parallel form live there
-	const bool hess_terms = B.hess_terms && d.dense_in_lds && d.n_hap * P * P <= 9 * (d.nb + d.nnzoff);
+	const bool hess_terms = G <= 128 && B.hess_terms && d.dense_in_lds && d.n_hap * P * P <= 9 * (d.nb + d.nnzoff); // (the term-parallel form cuts the list between TWO wavefronts; workgroup windows keep no system in LDS anyway)
 	auto hessian = [&](Solver<FAM, LEAN, G> &X) -> int { return hess_terms ? X.phase_hessian_terms(srba_lds) /* == A.diag: the LDS image, idle while the capsule is linearised */ + X.phase_hessian_landmark_blocks() : X.phase_hessian(); };
 	double lambda, nu = 2.0, total_err, RMSE;
 	int iter = 0, trials = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0; bool stop = false;
@@ -451,7 +488,7 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 			const double err_red = total_err > 0 ? (total_err - new_err) / total_err : 0;
 			double den = 0; { const double *dl = B.delta + d.o_scal, *g = B.grad + d.o_scal;
 				if (S.schur_active() || !d.dense_in_lds) { for (int k = tid; k < n; k += G) den += dl[k] * (lambda * dl[k] + g[k]); }
-				else for (int k = tid; k < n; k += G) { const double dk = A.rhs[3 * A.perm[k / 3] + k % 3]; den += dk * (lambda * dk + g[k]); } } // (the solved right-hand side is still in the LDS image: the same numbers, no round trip through memory)
+				else for (int k = tid; k < n; k += G) { const double dk = A.sol(k); den += dk * (lambda * dk + g[k]); } } // (the solved right-hand side is still in the LDS image: the same numbers, no round trip through memory)
 			den = grp_sum<G>(den, red);
 			rho = (total_err - new_err) / den;
 			if (tid == 0 && tr < SRBA_TRACE_LEN) { out->trace_chi2[tr] = new_err; out->trace_rho[tr] = rho; }
@@ -578,10 +615,10 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 					double rho_w = NAN, err_w = NAN;
 					if (ok_w) {
 						double *xd = sc->xdelta + ((sp_round & 1) * sc->W + sc->w) * sc->xstride;
-						for (int k = tid; k < n; k += G) xd[k] = A.rhs[3 * A.perm[k / 3] + k % 3];
+						for (int k = tid; k < n; k += G) xd[k] = A.sol(k);
 						TIC(); own_el = Sa.apply_trial(A, Bt); TOC(6);
 						TIC(); if (lazy) err_w = St.phase_residuals_fused(resid2, red, own_el); else { St.phase_spantree(true, own_el); __syncthreads(); err_w = St.phase_residuals(resid2, red); } TOC(3);
-						double den = 0; { const double *g = B.grad + d.o_scal; for (int k = tid; k < n; k += G) { const double dk = A.rhs[3 * A.perm[k / 3] + k % 3]; den += dk * (lam_w * dk + g[k]); } }
+						double den = 0; { const double *g = B.grad + d.o_scal; for (int k = tid; k < n; k += G) { const double dk = A.sol(k); den += dk * (lam_w * dk + g[k]); } }
 						den = grp_sum<G>(den, red);
 						rho_w = (total_err - err_w) / den;
 					}
@@ -724,6 +761,29 @@ __global__ void __launch_bounds__(2 * SRBA_WG) __attribute__((amdgpu_waves_per_e
 	}
 }
 
+// One WORKGROUP of G = 128 or 256 threads per capsule for the SE3 landmark families (round 5; srba_wg.hpp): every lane-parallel phase runs G wide, the Schur-reduced system is a
+// lower triangle of 16 x 16 tiles in the capsule's HBM workspace and is factored on the matrix cores by the G / 64 wavefronts. Replaces, for the windows the plan sends here, the
+// one-wavefront k_lm_run<3..6> (504 - 512 registers, one wavefront per SIMD, the 3x3-block sweeps of a 40 - 59-edge stereo window 6.5 of the 15.5 ms of a trial). Registers: the
+// LEAN diet (one Schur term, one Hessian term, one spanning-tree pair in flight) under a cap of 256 -- two wavefronts per SIMD, i.e. two 256-thread workgroups per CU.
+// LDS: WG_LDS_DOUBLES (the solver's staging, x, reduction scratch, flags, the work counter's slot).
+template <int FAM, int G>
+__global__ void __launch_bounds__(G) __attribute__((amdgpu_waves_per_eu(2, 2))) k_lm_wg(const Batch B, const DevParams prm, int first, int count, int *next) {
+	double *red = srba_lds + 768 + 16 * WG_NT_MAX; int *slot = (int *)(red + 5); // (red[0 .. 3]: group reductions, red + 4: the solver's flag)
+	for (;;) {
+		if (threadIdx.x == 0) *slot = atomicAdd(next, 1);
+		__syncthreads(); const int i = *slot; __syncthreads();
+		if (i >= count) break;
+		lm_one<FAM, (SRBA_LM_DB != 0), true, G, false>(B, prm, B.order[first + i], red);
+		__syncthreads();
+	}
+}
+template <int FAM, int G> __global__ void __launch_bounds__(G) __attribute__((amdgpu_waves_per_eu(2, 2))) k_solve_wg(const Batch B, const DevParams prm, int first) {
+	const int pidx = B.order[first + blockIdx.x]; const ProbDesc &d = B.desc[pidx]; Solver<FAM, true, G> S(B, d, prm, srba_lds + 768 + 16 * WG_NT_MAX);
+	const SparseSys A = S.make_sys(srba_lds);
+	const bool ok = S.solve(A, B.lambda_io[pidx]);
+	if (threadIdx.x == 0) B.notpd[pidx] = ok ? 0 : 1;
+}
+
 // A batch of ONE capsule (the per-key-frame use of the engine): W replicas of it, one workgroup of two wavefronts each, speculate on the lambda ladder (SpecCtl, srba_device.hpp).
 // Replica w works in its own copy of the work arena (`stride` bytes apart, zeroed at upload); replica 0's is the one the host reads back.
 template <int FAM>
@@ -816,6 +876,8 @@ const FamDims kDims[SRBA_NUM_FAMILIES] = {{3, 3, 3, 3}, {3, 2, 2, 3}, {3, 2, 2, 
 // every model family the kernels are instantiated for
 #ifdef SRBA_ONLY_RELPOSE2D /* experiment builds (tools/quick_build.sh): only the headline family is instantiated, the unit compiles in a fraction of the time; other families are rejected at run time */
 #define SRBA_ALL_FAMILIES(X) X(SRBA_SE2_RELPOSE2D)
+#elif defined(SRBA_ONLY_FAMILY) /* ... or any one family: -DSRBA_ONLY_FAMILY=SRBA_SE3_STEREO */
+#define SRBA_ALL_FAMILIES(X) X(SRBA_ONLY_FAMILY)
 #else
 #define SRBA_ALL_FAMILIES(X) X(SRBA_SE2_RELPOSE2D) X(SRBA_SE2_RB2D) X(SRBA_SE2_CART2D) X(SRBA_SE3_STEREO) X(SRBA_SE3_MONO) X(SRBA_SE3_CART3D) X(SRBA_SE3_RB3D) X(SRBA_SE3_RELPOSE3D) X(SRBA_SE2_STEREO)
 #endif
@@ -833,7 +895,10 @@ struct BigLane { int id = 0, slots = 1 /* windows its buffers have room for (srb
 
 } // namespace
 
-#define SRBA_NCLS 20  /* 19 LDS size classes (6 KB ... 152 KB per wavefront) + one class for systems factored in HBM */
+#define SRBA_NLDS 19        /* LDS size classes (6 KB ... 152 KB per wavefront) of the one-wavefront kernels */
+#define SRBA_CLS_WG128 19   /* landmark windows on a workgroup of two wavefronts (k_lm_wg<FAM, 128>) */
+#define SRBA_CLS_WG256 20   /* ... of four wavefronts */
+#define SRBA_NCLS 22        /* + the last class: systems factored by the multi-workgroup path (srba_big.hpp) */
 // Symbolic block factorisation of one capsule's system (natural block order): the numeric kernel never discovers structure.
 struct Symbolic { std::vector<int32_t> fill; std::vector<int32_t> col_off, row, item_off, tgt, ab, rptr, rcol, rblk, perm, hap_dst, hapf_dst, hf_dst; int max_cn = 0; bool aligned = true; };
 static void symbolic_factor(const srba_problem_capsule &k, const ProbDesc &d, int P, int L, bool full_system, Symbolic &out) {
@@ -1025,6 +1090,7 @@ struct srba_hip_ctx {
 	int stagger_ns = 300, stagger_max_us = 5000; // staggered start of the class launches: see plan_launches
 	// lambda-ladder speculation for a batch of ONE capsule (k_lm_spec): spec_w replicas of the work arena, spec_stride bytes apart; d_spec = flags | outcomes | increments (SpecCtl)
 	long long spec_launches = 0; bool spec_on = true, spec_ready = false; int spec_w = 12; size_t spec_stride = 0; char *d_spec = nullptr; static constexpr int kSpecMaxW = 32, kSpecMaxN = 768; static constexpr size_t kSpecBackupOff = 256 + 8 * (2 * kSpecMaxW * 4) + 8 * (2 * (size_t)kSpecMaxW * kSpecMaxN), kSpecBytes = kSpecBackupOff + 8 * 5 * (size_t)kSpecMaxN; bool spec_suppress = false, spec_test_drop = false; long long spec_fallbacks = 0;
+	bool wg_on = true; int wg_from_sys = 24, wg256_from_sys = 96; // SE3 landmark windows with a Schur-reduced system of at least wg_from_sys scalars run on a workgroup (k_lm_wg: 128 threads, 256 from wg256_from_sys); SRBA_HIP_WG=0 / SRBA_HIP_WG_FROM / SRBA_HIP_WG256_FROM
 	bool two_on = true; int two_from_kb = 20, two_min_count = 128; // k_lm_run2 (two wavefronts per capsule) for the relative-pose SE2 classes whose LDS image is at least this big
 	bool lean_on = true; int lean_min_count = 512; // k_lm_run_lean for the size classes of which at least nine wavefronts fit the LDS of a CU (relative-pose SE2, classes with at least this many capsules)
 	int max_lds_kb = 1 << 20, min_chunk = 384, max_parts_per_queue = 2; int class_streams = 64 /* sched 3: the class launches are dealt round-robin to at most this many streams */, n_queues = 16, sched = 3, n_streams_used = 1, n_cu = 256, waves_per_cu = 8, lds_per_cu = 160 * 1024; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
@@ -1048,6 +1114,7 @@ static void plan_launches(srba_hip_ctx *c, const int32_t *ord) {
 		int batch_total = 0; for (int k = 0; k < SRBA_NCLS; k++) batch_total += c->cls_count[k];
 		for (size_t j = 0; j < c->plan.size(); j++) { LaunchJob &J = c->plan[j]; J.grid = J.count;
 			if (c->sched == 3) { const size_t lds = c->cls_lds[J.cls] + c->lds_pad; const int fit = lds ? (int)std::max<size_t>(1, (size_t)c->lds_per_cu / lds) : c->waves_per_cu; J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(c->waves_per_cu, fit)));
+				if (J.cls >= SRBA_NLDS) J.grid = std::max(1, std::min(J.count, c->n_cu * (J.cls == SRBA_CLS_WG256 ? 2 : 4))); // workgroup classes: 256 registers -> two wavefronts per SIMD = two 256-thread / four 128-thread workgroups per CU
 				J.lean = (c->lean_on && c->params.family == SRBA_SE2_RELPOSE2D && J.cls < SRBA_NCLS - 1 && fit >= 9 && J.count >= c->lean_min_count) ? 1 : 0;
 				if (J.lean) J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(12, fit)));
 				// (also for a batch of a few capsules -- the per-key-frame use of the engine is a batch of ONE: its latency is the whole cost, 1.55 -> 1.41 ms per key-frame of the sequential run)
@@ -1184,6 +1251,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 		ok = (c->class_prio ? hipStreamCreateWithPriority(&c->cls_stream[k], hipStreamNonBlocking, pri) : hipStreamCreateWithFlags(&c->cls_stream[k], hipStreamNonBlocking)) == hipSuccess && hipEventCreateWithFlags(&c->cls_done[k], hipEventDisableTiming) == hipSuccess; }
 	if (!ok || hipMalloc((void **)&c->d_next, sizeof(int) * kMaxJobs) != hipSuccess || hipMalloc((void **)&c->d_part, 8 * 3 * kBigPart * srbadev::kGang) != hipSuccess || hipMalloc((void **)&c->d_scal, (8 * 16 + 4 * 8) * srbadev::kGang) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	c->spec_test_drop = getenv("SRBA_HIP_SPEC_TEST_DROP") != nullptr;
+	{ const char *e = getenv("SRBA_HIP_WG"); if (e) c->wg_on = atoi(e) != 0; e = getenv("SRBA_HIP_WG_FROM"); if (e && atoi(e) >= 1) c->wg_from_sys = atoi(e); e = getenv("SRBA_HIP_WG256_FROM"); if (e && atoi(e) >= 1) c->wg256_from_sys = atoi(e); }
 	{ const char *e = getenv("SRBA_HIP_BIG_MIN_SYS"); if (e && atoi(e) >= 0) c->big_min_sys = atoi(e); } // tuning / test knob
 	{ const char *e = getenv("SRBA_HIP_DENSE_BLOCKS"); if (e) c->dense_blocks_ok = atoi(e) != 0; }
 	{ const unsigned hc = std::thread::hardware_concurrency(); c->upload_threads = (int)std::min(32u, std::max(1u, hc)); const char *e = getenv("SRBA_HIP_UPLOAD_THREADS"); if (e) c->upload_threads = std::max(1, atoi(e)); } // host threads of srba_hip_upload_problems
@@ -1271,7 +1339,8 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 			if ((why[p] = validate_capsule(k)) != nullptr) continue;
 			ProbDesc t; t.nK = k.n_unk_edges; t.nF = k.n_unk_lms; t.n_scal = P * t.nK + L * t.nF; t.n_sys = (schur_solver && t.nF > 0 && t.nK > 0) ? P * t.nK : t.n_scal; t.nb = (t.n_sys + 2) / 3;
 			if (schur_solver && t.nK == 0) continue;
-			if (t.n_sys <= c->big_min_sys) symbolic_factor(k, t, P, L, !schur_solver, sym[p]);
+			const bool wg = c->wg_on && c->dm.PD == 12 && c->dm.L == 3 && schur_solver && t.nF > 0 && t.nK > 0 && t.n_sys >= c->wg_from_sys && t.n_sys <= 16 * srbadev::WG_NT_MAX && c->gang_from_nb <= 0; // (SE3 point-landmark families, Schur solvers: the workgroup path needs no symbolic analysis)
+			if (t.n_sys <= c->big_min_sys && !wg) symbolic_factor(k, t, P, L, !schur_solver, sym[p]);
 		}
 	});
 	for (int p = 0; p < n; p++) {
@@ -1287,7 +1356,8 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		d.o_bp = t_bp; d.o_colp = t_unk + p; d.o_bf = t_bf; d.o_colf = t_ulm + p; d.o_hap = t_hap; d.o_hapoff = t_hap + p; d.o_hapt = t_hapt; d.o_hf = t_hf; d.o_hfoff = t_hf + p; d.o_hft = t_hft;
 		d.o_hapf = t_hapf; d.o_hapfoff = t_hapf + p; d.o_hapft = t_hapft; d.o_sch = t_sch; d.o_lmoff = t_ulm + p; d.o_req = t_req; d.o_scal = t_scal; d.o_yw = t_yw; d.o_dense = t_dense;
 		d.nb = (d.n_sys + 2) / 3;
-		const bool surely_big = d.n_sys > c->big_min_sys; // far beyond what one wavefront's LDS holds: dense system on the multi-workgroup path, no block-sparse symbolic analysis
+		const bool to_wg = c->wg_on && c->dm.PD == 12 && c->dm.L == 3 && schur_solver && d.nF > 0 && d.nK > 0 && d.n_sys >= c->wg_from_sys && d.n_sys <= 16 * srbadev::WG_NT_MAX && c->gang_from_nb <= 0; // one workgroup, tile system in HBM, matrix cores (srba_wg.hpp)
+		const bool surely_big = d.n_sys > c->big_min_sys || to_wg; // far beyond what one wavefront's LDS holds (or a workgroup window): dense system on the multi-workgroup path, no block-sparse symbolic analysis
 		if (!surely_big) { /* sym[p]: computed above */ }
 		else { Symbolic &y = sym[p]; y.col_off.assign(d.nb + 1, 0); y.item_off.assign(d.nb + 1, 0); y.rptr.assign(d.nb + 1, 0); y.perm.resize(d.nb); for (int q = 0; q < d.nb; q++) y.perm[q] = q;
 			y.hap_dst.assign((size_t)k.n_hap * (P / 3) * (P / 3), 0); y.hapf_dst.assign((size_t)k.n_hapf * (P / 3), 0); y.hf_dst.assign(k.n_hf, 0); y.aligned = true; }
@@ -1304,29 +1374,30 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		// LDS footprint x residency time is what bounds the batch: capsules are grouped in fine size classes so that each launch
 		// reserves little more LDS per wavefront than its capsules need
 		size_t bytes = tri_n * 8;
-		static const int kClsKB[SRBA_NCLS - 1] = {6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64, 80, 96, 112, 128, 152};
-		cls[p] = SRBA_NCLS - 1; for (int q = 0; q < SRBA_NCLS - 1 && packable && !surely_big && !to_gang && kClsKB[q] <= c->max_lds_kb; q++) if (bytes <= (size_t)kClsKB[q] * 1024) { cls[p] = q; break; }
+		static const int kClsKB[SRBA_NLDS] = {6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64, 80, 96, 112, 128, 152};
+		cls[p] = SRBA_NCLS - 1; for (int q = 0; q < SRBA_NLDS && packable && !surely_big && !to_gang && kClsKB[q] <= c->max_lds_kb; q++) if (bytes <= (size_t)kClsKB[q] * 1024) { cls[p] = q; break; }
 		long long wave_ws = 0; // doubles of HBM workspace of a capsule that keeps one wavefront but holds its (dense block) system in HBM
-		if ((cls[p] == SRBA_NCLS - 1 ? many_mid : (c->hbm_from_kb > 0 && n >= 1024 && kClsKB[cls[p]] >= c->hbm_from_kb && d.nb <= 168)) && !surely_big && !to_gang && c->dense_blocks_ok && !rel_family) {
+		if (to_wg) { const int nt = (d.n_sys + srbadev::WT - 1) / srbadev::WT; d.dense_blocks = 3; d.nnzoff = 0; d.n_items = 0; cls[p] = d.n_sys >= c->wg256_from_sys ? SRBA_CLS_WG256 : SRBA_CLS_WG128; wave_ws = srbadev::wg_ws_doubles(nt); }
+		if ((cls[p] == SRBA_NCLS - 1 ? many_mid : (c->hbm_from_kb > 0 && n >= 1024 && kClsKB[cls[p]] >= c->hbm_from_kb && d.nb <= 168)) && !surely_big && !to_gang && !to_wg && c->dense_blocks_ok && !rel_family) {
 			// Does not fit any LDS class and the batch has many like it: the multi-workgroup path would run them a few at a time from the host. They stay on the
 			// one-wavefront kernel with the dense block system in an HBM workspace (slow per capsule, but thousands run side by side).
 			const size_t nnz_d = (size_t)d.nb * (d.nb - 1) / 2;
 			symbolic_dense(k, d, P, L, !schur_solver, sym[p]); d.dense_blocks = 2; d.nnzoff = (int)nnz_d; d.n_items = 0; d.aligned = sym[p].aligned ? 1 : 0;
 			tri_n = ((size_t)d.nb + 1) / 2 + 16 + (c->dense_left ? 21 * (size_t)d.nb : 0); bytes = tri_n * 8; /* LDS: the permutation (+ two rows of the factor and the right-hand side: left-looking sweeps) */
-			cls[p] = 0; while (cls[p] < SRBA_NCLS - 2 && bytes > (size_t)kClsKB[cls[p]] * 1024) cls[p]++;
+			cls[p] = 0; while (cls[p] < SRBA_NLDS - 1 && bytes > (size_t)kClsKB[cls[p]] * 1024) cls[p]++;
 			wave_ws = 12 * (long long)d.nb + 9 * (long long)nnz_d;
 		}
 		const int n_row_store = (int)sym[p].row.size(); // entries of the row / row-view arrays in the input arena (none in the dense layout)
 		d.o_spcol = t_spcol; d.o_sprow = t_sprow; d.o_spitem = t_spitem; d.o_spperm = t_spcol - p;
 		t_spcol += d.nb + 1; t_sprow += n_row_store; t_spitem += (long long)sym[p].tgt.size();
 		d.n_fill = (int)sym[p].fill.size(); d.o_spfill = t_spfill; t_spfill += d.n_fill;
-		d.dense_in_lds = (cls[p] < SRBA_NCLS - 1 && d.dense_blocks != 2) ? 1 : 0; if (cls[p] < SRBA_NCLS - 1) cls_nbmax[cls[p]] = std::max(cls_nbmax[cls[p]], (int)tri_n);
+		d.dense_in_lds = (cls[p] < SRBA_NLDS && d.dense_blocks < 2) ? 1 : 0; if (cls[p] < SRBA_NLDS) cls_nbmax[cls[p]] = std::max(cls_nbmax[cls[p]], (int)tri_n);
 		const long long big_ld = cls[p] < SRBA_NCLS - 1 ? 0 : ((d.n_sys + srbadev::CB - 1) / srbadev::CB) * srbadev::CB; // dense path: ld x ld matrix + ld x CB diagonal factors + rhs + y
 		int nyw = 0; if (k.n_sch_terms > 0) for (int b = 0; b < k.n_hap; b++) if (k.hap_i[b] == k.hap_j[b]) nyw += k.sch_term_off[b + 1] - k.sch_term_off[b];
 		long long npath_needed = 0; for (int q = 0; q < k.n_pairs; q++) if (k.pair_needed[q]) { st.n_pairs_needed++; npath_needed += k.pair_path_off[q + 1] - k.pair_path_off[q]; }
 		st.n_path_needed += npath_needed;
 		t_edge += k.n_edges; t_unk += d.nK; t_ulm += d.nF; t_klm += d.n_klm; t_pair += k.n_pairs; t_path += k.n_path; t_obs += k.n_obs; t_valid += k.n_valid; t_bp += k.n_bp; t_bf += k.n_bf;
-		t_hap += k.n_hap; t_hapt += k.n_hap_terms; t_hf += k.n_hf; t_hft += k.n_hf_terms; t_hapf += k.n_hapf; t_hapft += k.n_hapf_terms; t_sch += k.n_sch_terms; t_req += nreq; t_scal += d.n_scal; t_yw += nyw; t_dense += big_ld * big_ld + big_ld * srbadev::CB + 2 * big_ld + wave_ws; big_lds[p] = (int)big_ld;
+		t_hap += k.n_hap; t_hapt += k.n_hap_terms; t_hf += k.n_hf; t_hft += k.n_hf_terms; t_hapf += k.n_hapf; t_hapft += k.n_hapf_terms; t_sch += k.n_sch_terms; t_req += nreq; t_scal += d.n_scal; t_yw += nyw; t_dense += (big_ld * big_ld + big_ld * srbadev::CB + 2 * big_ld + wave_ws + 1) & ~1LL; /* (even: the tile systems of the workgroup path move 16 bytes at a time) */ big_lds[p] = (int)big_ld;
 	}
 	st.n_edges = t_edge; st.n_unk_edges = t_unk; st.n_unk_lms = t_ulm; st.n_pairs = t_pair; st.n_path = t_path; st.n_obs = t_obs; st.n_bp = t_bp; st.n_bf = t_bf; st.n_hap = t_hap; st.n_hap_terms = t_hapt;
 	st.n_hf_terms = t_hft; st.n_hapf_terms = t_hapft; st.n_sch_terms = t_sch; st.n_scalars = t_scal;
@@ -1432,7 +1503,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		int32_t *ord = (int32_t *)(h + o.order); int pos = 0;
 		for (int k = 0; k < SRBA_NCLS; k++) {
 			c->cls_first[k] = pos; for (int p = 0; p < n; p++) if (cls[p] == k) ord[pos++] = p; c->cls_count[k] = pos - c->cls_first[k];
-			c->cls_lds[k] = k < SRBA_NCLS - 1 ? (size_t)cls_nbmax[k] * 8 : 0;
+			c->cls_lds[k] = k < SRBA_NLDS ? (size_t)cls_nbmax[k] * 8 : (k < SRBA_NCLS - 1 ? (size_t)srbadev::WG_LDS_DOUBLES * 8 : 0);
 			// longest (most block updates per factorisation) first, dealt round-robin to the queue slices of lm_run_async
 			int32_t *b = ord + c->cls_first[k]; const int cnt = c->cls_count[k], nq = c->n_queues;
 			auto work = [&](int x) -> long long { const ProbDesc &dx = c->desc[x]; return dx.dense_blocks ? (long long)dx.nb * dx.nb * dx.nb / 6 : dx.n_items; }; // block updates per factorisation
@@ -1860,6 +1931,11 @@ static int lm_run_async_impl(srba_hip_ctx *c) {
 		const LaunchJob &J = c->plan[j]; const int k = J.cls;
 		hipStream_t launch_stream = (J.queue && nq > 1) ? c->cls_stream[J.queue] : c->stream;
 		if (J.delay_us > 0) hipLaunchKernelGGL(srbadev::k_delay, dim3(1), dim3(1), 0, launch_stream, J.delay_us);
+		if (k >= SRBA_NLDS) { // landmark windows on a workgroup (k_lm_wg)
+			with_family(c->params.family, [&](auto fam_) { constexpr int F = decltype(fam_)::value; if constexpr (srbadev::Tr<F>::SE3 && !srbadev::Tr<F>::REL) {
+				if (k == SRBA_CLS_WG256) hipLaunchKernelGGL((srbadev::k_lm_wg<F, 256>), dim3(J.grid), dim3(256), c->cls_lds[k], launch_stream, c->B, c->dp, J.first, J.count, c->d_next + j);
+				else hipLaunchKernelGGL((srbadev::k_lm_wg<F, 128>), dim3(J.grid), dim3(128), c->cls_lds[k], launch_stream, c->B, c->dp, J.first, J.count, c->d_next + j); } });
+			HIPCHK(c, hipGetLastError()); continue; }
 		if (J.two) { const size_t lds1 = (c->cls_lds[k] + c->lds_pad + 7) & ~(size_t)7; hipLaunchKernelGGL((srbadev::k_lm_run2<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(2 * SRBA_WG), lds1 + 32, launch_stream, c->B, c->dp, J.first, J.count, c->d_next + j, (int)(lds1 / 8)); HIPCHK(c, hipGetLastError()); continue; }
 		if (J.lean) { hipLaunchKernelGGL((srbadev::k_lm_run_lean<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(SRBA_WG), c->cls_lds[k] + c->lds_pad, launch_stream, c->B, c->dp, J.first, J.count, c->d_next + j); HIPCHK(c, hipGetLastError()); continue; }
 		SRBA_DISPATCH_LDS(c, k_lm_run, J.grid, c->cls_lds[k] + c->lds_pad, J.first, J.count, c->d_next + j); HIPCHK(c, hipGetLastError());
@@ -1987,7 +2063,12 @@ int srba_hip_solve(srba_hip_ctx *c, const double *lambda, int32_t *not_pd_out) {
 	if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device));
 	if (lambda) HIPCHK(c, hipMemcpyAsync(c->B.lambda_io, lambda, 8 * (size_t)c->n_prob, hipMemcpyHostToDevice, c->stream)); // else: use the lambda guess left by srba_hip_linearize
 	if (prep_lds(c, false) != 0) return -1;
-	for (int k = 0; k < SRBA_NCLS - 1; k++) if (c->cls_count[k]) { hipStream_t launch_stream = c->stream; SRBA_DISPATCH_LDS(c, k_solve, c->cls_count[k], c->cls_lds[k], c->cls_first[k]); HIPCHK(c, hipGetLastError()); }
+	for (int k = 0; k < SRBA_NLDS; k++) if (c->cls_count[k]) { hipStream_t launch_stream = c->stream; SRBA_DISPATCH_LDS(c, k_solve, c->cls_count[k], c->cls_lds[k], c->cls_first[k]); HIPCHK(c, hipGetLastError()); }
+	for (int k = SRBA_NLDS; k < SRBA_NCLS - 1; k++) if (c->cls_count[k]) { // landmark windows on a workgroup
+		with_family(c->params.family, [&](auto fam_) { constexpr int F = decltype(fam_)::value; if constexpr (srbadev::Tr<F>::SE3 && !srbadev::Tr<F>::REL) {
+			if (k == SRBA_CLS_WG256) hipLaunchKernelGGL((srbadev::k_solve_wg<F, 256>), dim3(c->cls_count[k]), dim3(256), c->cls_lds[k], c->stream, c->B, c->dp, c->cls_first[k]);
+			else hipLaunchKernelGGL((srbadev::k_solve_wg<F, 128>), dim3(c->cls_count[k]), dim3(128), c->cls_lds[k], c->stream, c->B, c->dp, c->cls_first[k]); } });
+		HIPCHK(c, hipGetLastError()); }
 	{ const int32_t *ord = (const int32_t *)(c->h_in.get() + c->h_off_order); // dense multi-workgroup solver for the capsules of the big class
 	  for (int i = 0; i < c->cls_count[SRBA_NCLS - 1]; i++) { const int p = ord[c->cls_first[SRBA_NCLS - 1] + i]; double lam = 0; HIPCHK(c, hipMemcpyAsync(&lam, c->B.lambda_io + p, 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
 		bool pd = true; if (big_prepare_lanes(c, 1) < 1) return -1; if (big_solve(c, &c->lanes[0], p, lam, &pd) != 0) { c->fail(c->lanes[0].error); return -1; } big_collect_lane_stats(c); const int np = pd ? 0 : 1; HIPCHK(c, hipMemcpyAsync(c->B.notpd + p, &np, 4, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); } }

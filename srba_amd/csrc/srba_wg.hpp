@@ -1,0 +1,167 @@
+/*
+ * srba_wg.hpp -- one WORKGROUP per capsule for the landmark families (round 5): the dense Cholesky of the Schur-reduced system on the matrix cores.
+ *
+ * Rounds 2-4 ran a landmark window on ONE wavefront (k_lm_run<3..6>: 504-512 registers, one wavefront per SIMD). The Schur-reduced system of such a window is (nearly)
+ * full, n = 6 x unknown edges = 60 .. 360 scalars, and its factorisation was a 3x3-block sweep on the vector ALU with the numbers in HBM: 5.5 of the 15.5 ms of a trial of
+ * the 40-59-edge stereo windows, at ~11 live lanes. That contraction is what `north_star` calls MFMA-worthy: here the system is a lower triangle of 16 x 16 TILES and one
+ * workgroup of NW = 2 or 4 wavefronts factors it left-looking with v_mfma_f64_16x16x4_f64 (reference: the dense LL^t of lev-marq_solvers.h:474-568, Eigen::LLT).
+ *
+ * Tile storage = the MFMA fragment itself ("frag"): tile[4 l + r] = M[l & 15][(l >> 4) + 4 r], lane l = 0 .. 63, r = 0 .. 3. Why it is the right layout:
+ *   - a lane's four doubles are contiguous: a tile moves as two 16-byte requests per lane, the wavefront covers the 2 KB tile as one contiguous span;
+ *   - as the A operand of step kk of D = A B (A[i][k]: i = l & 15, k = (l >> 4) + 4 kk) the lane feeds tile[4 l + kk]: the tile is M;
+ *     as the B operand (B[k][j]: k = (l >> 4) + 4 kk, j = l & 15) the same double reads as M^t: frag(M1) x frag(M2) computes M1 M2^t without a transpose anywhere;
+ *   - the accumulator D[(l >> 4) + 4 r][l & 15] of lane l, read as a frag, is D^t -- so the sweep keeps TRANSPOSED accumulators: C_ik^t = A_ik^t - sum_j L_kj L_ij^t starts
+ *     from frag(A_ik) as loaded, the accumulators ARE the B operand of the triangular solve L_ik^t = L_kk^-1 C_ik^t (A operand: frag(L_kk^-1) from LDS), and the result,
+ *     dumped as it lies in the registers, is frag(L_ik): nothing is ever re-laid-out, every global access is a full-line span.
+ * Step k of the sweep (one workgroup barrier per step): wavefront 0 takes tile row k + 1 -- finishes L_{k+1,k}, then the diagonal tile of step k + 1, its Cholesky and the
+ * inverse of its factor (one lane per row, columns handed round by v_readlane; the only serial part, ~5 us) -- WHILE the other wavefronts finish the rows below. The
+ * right-hand side rides along as tile row nt (forward substitution for free); the backward substitution runs on the LDS copy of y with DPP row sums.
+ * "Not positive definite" == a non-positive pivot of a diagonal tile's Cholesky (Eigen::LLT's criterion), seen by all wavefronts through an LDS flag.
+ */
+#pragma once
+#include "srba_device.hpp"
+
+namespace srbadev {
+
+typedef double f64x4w __attribute__((ext_vector_type(4)));
+typedef double f64x2w __attribute__((ext_vector_type(2), aligned(16)));
+constexpr int WT = 16;                             // tile edge = the shape of v_mfma_f64_16x16x4_f64
+constexpr int WG_NT_MAX = 32;                      // tile rows of the largest system this path takes: n <= 512 scalars
+constexpr int WG_LDS_DOUBLES = 256 + 512 + 16 * WG_NT_MAX + 8; // diagonal tile staging | two inverse factors (double-buffered) | y / x | group-reduction scratch (4) + flags
+__host__ __device__ inline int wg_tile(int i, int j) { return i * (i + 1) / 2 + j; } // tile (i, j), j <= i; tile row nt = the right-hand side
+__host__ __device__ inline long long wg_ws_doubles(int nt) { return 256LL * ((long long)(nt + 1) * (nt + 2) / 2 + nt); } // tiles of rows 0 .. nt | nt inverse diagonal factors
+// offset of element (r, c) inside a frag tile
+__host__ __device__ inline int wg_frag_off(int r, int c) { return ((r + 16 * (c & 3)) << 2) + (c >> 2); }
+
+__device__ __forceinline__ f64x4w wg_ld(const double *tile, int l) { const f64x2w a = *(const f64x2w *)(tile + 4 * l), b = *(const f64x2w *)(tile + 4 * l + 2); f64x4w v; v.x = a.x; v.y = a.y; v.z = b.x; v.w = b.y; return v; }
+__device__ __forceinline__ void wg_st(double *tile, int l, const f64x4w &v) { f64x2w a, b; a.x = v.x; a.y = v.y; b.x = v.z; b.y = v.w; *(f64x2w *)(tile + 4 * l) = a; *(f64x2w *)(tile + 4 * l + 2) = b; }
+// acc += M1 M2^t for two frag tiles (four matrix instructions, K = 16)
+__device__ __forceinline__ f64x4w wg_mma(const f64x4w &m1, const f64x4w &m2, f64x4w acc) {
+	acc = __builtin_amdgcn_mfma_f64_16x16x4f64(m1.x, m2.x, acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f64_16x16x4f64(m1.y, m2.y, acc, 0, 0, 0);
+	acc = __builtin_amdgcn_mfma_f64_16x16x4f64(m1.z, m2.z, acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f64_16x16x4f64(m1.w, m2.w, acc, 0, 0, 0); return acc;
+}
+__device__ __forceinline__ double wg_bcast(double v, int lane /* uniform */) { return readlane_v(v, lane); }
+__device__ __forceinline__ double wg_rsqrt(double d) { // 1 / sqrt(d): v_rsq_f64 + two Newton steps
+	double y = __builtin_amdgcn_rsq(d); double h = 0.5 * d * y, e = fma(-h, y, 0.5); y = fma(y, e, y); h = 0.5 * d * y; e = fma(-h, y, 0.5); return fma(y, e, y);
+}
+// sum over the 16 lanes of a row (DPP row_shr 1, 2, 4, 8: the total lands in the last lane of the row)
+__device__ __forceinline__ double wg_rowsum16(double v) { v += dpp_shift0<0x111, 0xf>(v); v += dpp_shift0<0x112, 0xf>(v); v += dpp_shift0<0x114, 0xf>(v); v += dpp_shift0<0x118, 0xf>(v); return v; }
+
+// Wavefront 0: Cholesky of a diagonal tile given as accumulators (frag of the symmetric C_kk) and the inverse of its factor, one lane per row. The inverse goes to LDS
+// (frag order: the A operand of this step's triangular solves) and to `LIk` in memory (the backward substitution reads it). Returns false on a non-positive pivot.
+__device__ __forceinline__ bool wg_diag(const f64x4w &c, lds_f64 *smC, lds_f64 *smL, double *LIk, int l) {
+	smC[4 * l] = c.x; smC[4 * l + 1] = c.y; smC[4 * l + 2] = c.z; smC[4 * l + 3] = c.w;
+	solver_sync();
+	const int row = l & 15; // lanes 16 .. 63 mirror lanes 0 .. 15 (their copies are never read)
+	double a[16], x[16];
+#pragma unroll
+	for (int q = 0; q < 16; q++) a[q] = smC[wg_frag_off(row, q)];
+	bool ok = true; double rinv = 0;
+#pragma unroll
+	for (int j = 0; j < 16; j++) { // column j of L: lane i >= j ends with a[j] = L[i][j]; lanes i < j with 0
+		const double dj = wg_bcast(a[j], j);
+		ok &= (dj > 0.0);
+		const double r = wg_rsqrt(dj);
+		const double lj = (row == j) ? dj * r : ((row > j) ? a[j] * r : 0.0);
+		a[j] = lj; rinv = (row == j) ? r : rinv;
+#pragma unroll
+		for (int q = j + 1; q < 16; q++) { const double lq = wg_bcast(lj, q); a[q] = fma(-lj, lq, a[q]); asm volatile("" : "+v"(a[q])); /* (pinned where its broadcast is: no pile of spilled v_readlane pairs, cf. chol_block_regs) */ }
+		__builtin_amdgcn_sched_barrier(0);
+	}
+	// X = L^-1, row by row: row m is final once rows 0 .. m-1 have been pushed into it; lane m then hands it round
+#pragma unroll
+	for (int q = 0; q < 16; q++) x[q] = 0;
+#pragma unroll
+	for (int m = 0; m < 16; m++) {
+#pragma unroll
+		for (int q = 0; q <= m; q++) {
+			const double t = ((q == m ? 1.0 : 0.0) - x[q]) * rinv;  // lane m: X[m][q]
+			const double xb = wg_bcast(t, m);
+			x[q] = (row == m) ? t : fma(a[m], xb, x[q]);            // lanes i > m gather L[i][m] X[m][q]; lanes i < m hold a[m] = 0
+			asm volatile("" : "+v"(x[q]));
+		}
+		__builtin_amdgcn_sched_barrier(0);
+	}
+	if (l < 16) {
+#pragma unroll
+		for (int q = 0; q < 16; q++) smL[wg_frag_off(row, q)] = (q <= row) ? x[q] : 0.0;
+	}
+	solver_sync();
+	f64x4w v; v.x = smL[4 * l]; v.y = smL[4 * l + 1]; v.z = smL[4 * l + 2]; v.w = smL[4 * l + 3];
+	wg_st(LIk, l, v);
+	return ok;
+}
+
+// Factorisation + both substitutions of the tile system T (nt tile rows + the right-hand-side row) by the NW wavefronts of the workgroup. On return x (16 nt doubles) is in
+// sm + 768; false: not positive definite (uniform over the workgroup). All threads of the workgroup call it.
+template <int NW>
+__device__ __forceinline__ bool wg_chol_solve(double *T, double *LI, const int nt, lds_f64 *sm) {
+	static_assert(NW >= 2, "wavefront 0 runs the diagonal chain beside the panel wavefronts");
+	const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+	lds_f64 *smC = sm, *smL = sm + 256, *yb = sm + 768; int __attribute__((address_space(3))) *flag = (int __attribute__((address_space(3))) *)(sm + 768 + 16 * WG_NT_MAX + 4);
+	if (threadIdx.x == 0) *flag = 0;
+	__syncthreads();
+	if (w == 0) { const f64x4w c = wg_ld(T + 256 * (size_t)wg_tile(0, 0), l); if (!wg_diag(c, smC, smL, LI, l) && l == 0) *flag = 1; }
+	__syncthreads();
+	for (int k = 0; k < nt; k++) {
+		if (*flag) return false;
+		const lds_f64 *Lk = smL + 256 * (k & 1);
+		f64x4w li; li.x = Lk[4 * l]; li.y = Lk[4 * l + 1]; li.z = Lk[4 * l + 2]; li.w = Lk[4 * l + 3]; // frag(L_kk^-1): A operand of the triangular solves
+		const double *rowk = T + 256 * (size_t)wg_tile(k, 0);
+		auto finish_row = [&](int i, f64x4w *diag_sum) -> f64x4w { // L_ik (frag) = (A_ik - sum_{j<k} L_ij L_kj^t) L_kk^-t ; diag_sum (row k+1 only): += sum_{j<k} L_ij L_ij^t
+			const double *rowi = T + 256 * (size_t)wg_tile(i, 0);
+			f64x4w s = {0, 0, 0, 0};
+			const f64x4w a0 = wg_ld(rowi + 256 * (size_t)k, l);
+			// two columns j per pass, the tiles of the next pass requested before this pass's matrix instructions (the tiles come from L2 / the Infinity Cache: hundreds of cycles)
+			f64x4w A0 = {0, 0, 0, 0}, B0 = A0, A1 = A0, B1 = A0, nA0 = A0, nB0 = A0, nA1 = A0, nB1 = A0;
+			if (k > 0) { A0 = wg_ld(rowk, l); B0 = wg_ld(rowi, l); } if (k > 1) { A1 = wg_ld(rowk + 256, l); B1 = wg_ld(rowi + 256, l); }
+			for (int j = 0; j < k; j += 2) {
+				if (j + 2 < k) { nA0 = wg_ld(rowk + 256 * (size_t)(j + 2), l); nB0 = wg_ld(rowi + 256 * (size_t)(j + 2), l); }
+				if (j + 3 < k) { nA1 = wg_ld(rowk + 256 * (size_t)(j + 3), l); nB1 = wg_ld(rowi + 256 * (size_t)(j + 3), l); }
+				s = wg_mma(A0, B0, s); if (diag_sum) *diag_sum = wg_mma(B0, B0, *diag_sum);
+				if (j + 1 < k) { s = wg_mma(A1, B1, s); if (diag_sum) *diag_sum = wg_mma(B1, B1, *diag_sum); }
+				A0 = nA0; B0 = nB0; A1 = nA1; B1 = nB1;
+			}
+			const f64x4w ct = a0 - s; // C_ik^t as accumulators == the B operand of the solve
+			f64x4w dd = {0, 0, 0, 0};
+			dd = __builtin_amdgcn_mfma_f64_16x16x4f64(li.x, ct.x, dd, 0, 0, 0); dd = __builtin_amdgcn_mfma_f64_16x16x4f64(li.y, ct.y, dd, 0, 0, 0);
+			dd = __builtin_amdgcn_mfma_f64_16x16x4f64(li.z, ct.z, dd, 0, 0, 0); dd = __builtin_amdgcn_mfma_f64_16x16x4f64(li.w, ct.w, dd, 0, 0, 0);
+			wg_st(T + 256 * (size_t)wg_tile(i, k), l, dd);
+			if (i == nt && (l & 15) == 0) { const int c0 = 16 * k + (l >> 4); yb[c0] = dd.x; yb[c0 + 4] = dd.y; yb[c0 + 8] = dd.z; yb[c0 + 12] = dd.w; } // row 0 of the right-hand-side tile: y_k
+			return dd;
+		};
+		if (w == 0) {
+			if (k + 1 < nt) {
+				f64x4w ds = {0, 0, 0, 0};
+				const f64x4w d1 = finish_row(k + 1, &ds);
+				ds = wg_mma(d1, d1, ds);
+				const f64x4w c = wg_ld(T + 256 * (size_t)wg_tile(k + 1, k + 1), l) - ds;
+				if (!wg_diag(c, smC, smL + 256 * ((k + 1) & 1), LI + 256 * (size_t)(k + 1), l) && l == 0) *flag = 1;
+			} else finish_row(nt, nullptr);
+		} else {
+			for (int i = k + 1 + w; i <= nt; i += NW - 1) finish_row(i, nullptr);
+		}
+		__syncthreads();
+	}
+	if (*flag) return false;
+	// backward substitution x = L^-t y on the LDS copy: x_k = L_kk^-t y_k (wavefront 0), then y_j -= L_kj^t x_k for the tiles of row k (all wavefronts)
+	for (int k = nt - 1; k >= 0; k--) {
+		if (w == 0) {
+			const f64x4w v = wg_ld(LI + 256 * (size_t)k, l); const double yk = yb[16 * k + (l & 15)];
+			const double p0 = wg_rowsum16(v.x * yk), p1 = wg_rowsum16(v.y * yk), p2 = wg_rowsum16(v.z * yk), p3 = wg_rowsum16(v.w * yk); // sum_r Linv[r][c] y[r], c = (l >> 4) + 4 q
+			solver_sync(); // every lane has read y_k
+			if ((l & 15) == 15) { const int c0 = 16 * k + (l >> 4); yb[c0] = p0; yb[c0 + 4] = p1; yb[c0 + 8] = p2; yb[c0 + 12] = p3; }
+		}
+		__syncthreads();
+		const double xk = yb[16 * k + (l & 15)];
+		for (int j = w; j < k; j += NW) {
+			const f64x4w v = wg_ld(T + 256 * (size_t)wg_tile(k, j), l);
+			const double p0 = wg_rowsum16(v.x * xk), p1 = wg_rowsum16(v.y * xk), p2 = wg_rowsum16(v.z * xk), p3 = wg_rowsum16(v.w * xk);
+			if ((l & 15) == 15) { const int c0 = 16 * j + (l >> 4); yb[c0] -= p0; yb[c0 + 4] -= p1; yb[c0 + 8] -= p2; yb[c0 + 12] -= p3; }
+		}
+		__syncthreads();
+	}
+	return true;
+}
+
+} // namespace srbadev
