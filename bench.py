@@ -331,6 +331,11 @@ def main():
     hist = (C.c_double * 64)(); nh = lib.srba_hip_kernel_ms_history(ctx.ctx, hist, min(64, args.steps))
     kern_ms = [hist[i] for i in range(max(nh, 0))]
     kernel_ms = float(np.mean(kern_ms)) if kern_ms else float("nan")
+    # did the class launches of the last timed launch start largest-footprint-first (device time stamps of their first capsules, srba_hip_launch_order), and what the delay kernels cost
+    lo_stamp = (C.c_int64 * 64)(); lo_wg = (C.c_int32 * 64)(); lo_dly = (C.c_int32 * 64)(); lo_n = lib.srba_hip_launch_order(ctx.ctx, lo_stamp, lo_wg, lo_dly, 64)
+    lo_t = [int(lo_stamp[j]) for j in range(max(lo_n, 0))]
+    launch_order = {"class_launches": int(lo_n), "launch_order_held": bool(lo_n > 0 and all(t > 0 for t in lo_t) and all(b >= a for a, b in zip(lo_t, lo_t[1:]))),
+                    "first_to_last_start_us": (max(lo_t) - min(lo_t)) / 100.0 if lo_t else None, "k_delay_device_us_per_launch": int(sum(lo_dly[j] for j in range(max(lo_n, 0))))}
 
     tot_trials, tot_obs, max_elapsed = multi.aggregate(dist, "cuda" if backend == "nccl" else "cpu", trials_per_step, obs_trials_per_step, elapsed)
 
@@ -401,7 +406,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * max_elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "world-2d-30k relative graph-SLAM, SE2 graph-slam, submap=10 depth=3: %d keyframes per GPU -> %d optimize_local_area capsules per GPU, re-optimised per step" % (args.n_kf, batch.n),
-                       "keyframes_per_gpu": args.n_kf, "capsules_per_gpu": batch.n, "lm_trials_per_step_per_gpu": trials_per_step, "floor_trial_share": floor_trial_share, "obs_per_s": tot_obs * args.steps / max_elapsed,
+                       "keyframes_per_gpu": args.n_kf, "capsules_per_gpu": batch.n, "lm_trials_per_step_per_gpu": trials_per_step, "floor_trial_share": floor_trial_share, "launch_order": launch_order, "obs_per_s": tot_obs * args.steps / max_elapsed,
                        "parallelism": "replicas x%d (independent maps, no collective)" % world, "process_group": (None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "aggregate_device": "cuda" if backend == "nccl" else "cpu"}),
                        "solver": "no-Schur, block-sparse LL^t in LDS, symbolic factorisation on the host (reference: CSparse)",
                        "setup_s": {"dataset": round(t_gen, 2), "sequential_slam_harvest_gpu_backend": round(t_harvest, 2), "upload_batch_host_to_hbm": round(t_upload, 3)},

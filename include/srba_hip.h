@@ -301,6 +301,11 @@ int    srba_hip_big_path_stats(srba_hip_ctx *ctx, double out[4]);
 /* The same with the launch sequences counted: since round 4 the large windows of a batch run in lock-step and ONE sequence of panel / update launches factors the systems of all
  * windows that are in a trial (srba_big.hpp, Gang). out = { ms, flops, factorisations, largest system, launch sequences, 1 if the lock-step gang is on, 0, 0 }. */
 int    srba_hip_big_path_stats2(srba_hip_ctx *ctx, double out[8]);
+/* Order in which the class launches of the last srba_hip_lm_run* started on the device. The fused LM kernel is one persistent launch per size class, all enqueued at once on their own
+ * streams; the plan holds each stream back so that the launches start largest-footprint-first (DESIGN 4a "staggered start"). For plan job j (in plan order = the intended order):
+ * stamp[j] = device time (ticks of the constant 100 MHz counter) at which its first capsule was taken, 0 if it never started; workgroups[j], delay_us[j] (either may be NULL) = its grid and
+ * the delay its stream was held back by. Returns the number of jobs written (<= n). The order held iff the non-zero stamps are non-decreasing. Synchronises the stream. */
+int    srba_hip_launch_order(srba_hip_ctx *ctx, int64_t *stamp, int32_t *workgroups, int32_t *delay_us, int n);
 /* Single-capsule batches of the relative-pose SE2 family (the per-key-frame use: RbaEngine<>::optimize_edges, impl/optimize_edges.h:471-692) speculate on the lambda ladder with several
  * workgroups. out = { speculative launches since the context was created, launches whose replicas lost step (one of them not resident within the spin bound: another context holding
  * the CUs) and that were therefore run again on the sequential path }. */

@@ -40,6 +40,7 @@ struct ProbDesc {
 	long long o_hap, o_hapoff, o_hapt, o_hf, o_hfoff, o_hft, o_hapf, o_hapfoff, o_hapft, o_sch, o_lmoff, o_req, o_scal, o_yw, o_dense, o_spcol, o_sprow, o_spitem, o_spperm;
 	int hapt_split; // two wavefronts per capsule: the second one takes the U_Ap terms from this index on (the first term of a Hessian block at or after the middle of the list: no block is summed by both)
 	int n_items, aligned; // block updates per factorisation; 1 if every Hessian block maps onto whole 3x3 blocks (always, except L==2 with the no-Schur solver)
+	int n_hrec, hap_chunked; long long o_hrec; // K6 work records {U_Ap block, first term, end term} (Batch::hap_rec): one per block, or (hap_chunked, the workgroup path) several of at most 8 terms each whose partial blocks are ADDED into a cleared U_Ap
 	int dense_in_lds, dense_blocks; // dense_blocks: the LDS image holds ALL blocks of the lower triangle (column-major), no symbolic structure (mid-size, nearly dense systems)
 };
 
@@ -56,11 +57,11 @@ struct Batch {
 	const int *sch_term_off, *sch_b1, *sch_b2, *sch_lm, *sch_yw, *sch_tblk /* U_Ap block of every Schur term */, *lm_hapf_off, *lm_hapf_idx, *req_idx, *need_idx, *need_rec; // need_rec: per needed pair {pair, 4 path entries (edge<<1|inv, -1 = none)}
 	const unsigned char *pair_needed, *bp_normal;
 	const int *sp_fill; // unified block indices (diag k -> k, off-diagonal i -> nb+i)
-	const int *hap_rec; // per H block, sorted by decreasing term count (longest first: balances the lanes of K6): {block, first term, end term}
+	const int *hap_rec; // K6 work records, sorted by decreasing term count (longest first: balances the lanes of K6): {block, first term, end term}; ProbDesc::n_hrec of them from o_hrec
 	const int *sp_col_off, *sp_row, *sp_item_off, *sp_tgt /* packed update items: unified target block << 18 | a << 9 | b (packed at upload) */, *sp_rptr, *sp_rcol /* packed row-view entries: column << 14 | off-diagonal block */, *sp_perm; // symbolic factorisation of every capsule's system
 	const int *hap_dst, *hapf_dst, *hf_dst; // destination 3x3 block of every aligned sub-block of the Hessian blocks (see symbolic_factor)
 	// state + workspace
-	double *edge, *ulm, *pose, *Jp, *Jf, *resid, *resid2, *HAp, *HAp0, *Hf, *HApf, *grad, *grad0 /* SRBA_EXT_SCHUR_KEEPS_GRADIENT: the gradient as K5 produced it */, *delta, *Hfinv, *YW;
+	double *edge, *ulm, *pose, *Jp, *Jf, *resid, *resid2, *HAp, *HAp0, *Hf, *HApf, *grad, *grad0 /* SRBA_EXT_SCHUR_KEEPS_GRADIENT: the gradient as K5 produced it */, *delta, *Hfinv, *YW, *Yh /* workgroup path: Y = W Hf^-1 of every U_Apf block, written once per solve (schur_reduce) */;
 	double *old_edge, *old_ulm, *old_pose, *dense, *ulm_inf;
 	double *edge1, *ulm1, *pose1; const unsigned char *pose_req; // second copy of the unknowns and of the spanning-tree poses (double-buffered LM loop); per pose: a Jacobian block reads it (list_of_required_num_poses)
 	int *valid, *first_fail, *hf_ok;
@@ -1151,7 +1152,7 @@ struct Worker {
 			for (int i = 0; i < M1; i++) for (int j = 0; j < M2; j++) { double s = 0; for (int k = 0; k < O; k++) s += A[k * M1 + i] * Bm[k * M2 + j]; H[i * M2 + j] += s; }
 		}
 	}
-	template <int M1, int M2>
+	template <int M1, int M2, bool ATOMIC = false>
 	__device__ __forceinline__ int hess_block(double *Hout, double *Hlatch, const int *t1, const int *t2, int tb, int te, const double *J1, const double *J2, const unsigned char *ok1, const unsigned char *ok2) {
 		double H[M1 * M2];
 #pragma unroll
@@ -1182,7 +1183,10 @@ struct Worker {
 		const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0;
 #pragma unroll
 		for (int k = 0; k < M1 * M2; k++) H[k] *= sc;
-		stn<M1 * M2>(Hout, H); if (Hlatch) stn<M1 * M2>(Hlatch, H);
+		if constexpr (ATOMIC) { // a partial sum of the block (its term list is cut into records of a few terms: ProbDesc::hap_chunked): added into the cleared block
+#pragma unroll
+			for (int k = 0; k < M1 * M2; k++) unsafeAtomicAdd(Hout + k, H[k]);
+		} else { stn<M1 * M2>(Hout, H); if (Hlatch) stn<M1 * M2>(Hlatch, H); }
 		return ninv;
 	}
 	__device__ __forceinline__ int phase_hessian() { fresh(); // returns the per-thread invalid count (to be reduced by the caller if wanted)
@@ -1190,8 +1194,18 @@ struct Worker {
 		const double *Jp = B.Jp + d.o_bp * O * P, *Jf = B.Jf + d.o_bf * O * L;
 		const unsigned char *rp = B.bp_ok + d.o_bp, *rf = B.bf_ok + d.o_bf;
 		const bool latch = prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL;
-		for (int bi = tid; bi < d.n_hap; bi += G) {
-			const int *rec = B.hap_rec + (d.o_hap + bi) * 3; const int b = rec[0]; const long long g = d.o_hap + b; // {block, first term, end term}: longest lists first
+		bool chunked = false; if constexpr (T::SE3 && !T::REL) chunked = d.hap_chunked != 0;
+		if (chunked) { // the workgroup path: an edge near the root of a landmark window collects thousands of observations -- its diagonal block's term list would keep ONE lane busy for
+			// the whole phase. The lists are cut into records of at most 8 terms (host, at upload), a lane per record, partial blocks added into the cleared block.
+			{ f64x2u z; z.x = 0; z.y = 0; double *H0 = B.HAp + d.o_hap * P * P; for (int k = tid; k < d.n_hap * P * P / 2; k += G) *(f64x2u *)(H0 + 2 * k) = z; }
+			__syncthreads();
+			for (int bi = tid; bi < d.n_hrec; bi += G) {
+				const int *rec = B.hap_rec + (d.o_hrec + bi) * 3; const long long g = d.o_hap + rec[0];
+				ninv += hess_block<P, P, true>(B.HAp + g * P * P, nullptr, B.hap_t1 + d.o_hapt, B.hap_t2 + d.o_hapt, rec[1], rec[2], Jp, Jp, rp, rp);
+			}
+		} else
+		for (int bi = tid; bi < d.n_hrec; bi += G) {
+			const int *rec = B.hap_rec + (d.o_hrec + bi) * 3; const int b = rec[0]; const long long g = d.o_hap + b; // {block, first term, end term}: longest lists first
 			// the Schur complement works on HAp in place and restores it from the latch for every lambda (schur.h:38,165-168,188)
 			ninv += hess_block<P, P>(B.HAp + g * P * P, latch ? B.HAp0 + g * P * P : nullptr, B.hap_t1 + d.o_hapt, B.hap_t2 + d.o_hapt, rec[1], rec[2], Jp, Jp, rp, rp);
 		}
@@ -1200,6 +1214,10 @@ struct Worker {
 				ninv += hess_block<L, L>(B.Hf + (d.o_hf + b) * L * L, nullptr, B.hf_t1 + d.o_hft, B.hf_t2 + d.o_hft, B.hf_term_off[d.o_hfoff + b], B.hf_term_off[d.o_hfoff + b + 1], Jf, Jf, rf, rf);
 			for (int b = tid; b < d.n_hapf; b += G)
 				ninv += hess_block<P, L>(B.HApf + (d.o_hapf + b) * P * L, nullptr, B.hapf_t1 + d.o_hapft, B.hapf_t2 + d.o_hapft, B.hapf_term_off[d.o_hapfoff + b], B.hapf_term_off[d.o_hapfoff + b + 1], Jp, Jf, rp, rf);
+		}
+		if (chunked && latch) { // the latch of the summed blocks (schur.h:188 restores U_Ap from it for every lambda)
+			__syncthreads();
+			const double *H0 = B.HAp + d.o_hap * P * P; double *H1 = B.HAp0 + d.o_hap * P * P; for (int k = tid; k < d.n_hap * P * P / 2; k += G) *(f64x2u *)(H1 + 2 * k) = *(const f64x2u *)(H0 + 2 * k);
 		}
 		return ninv;
 	}
@@ -1336,7 +1354,7 @@ struct SpecCtl {
 // the work arena of a replica: every state / workspace pointer of the batch moved by `bytes` (the arenas of the replicas lie one after the other: srba_hip_upload_problems)
 __device__ __forceinline__ Batch shift_work(Batch B, long long bytes) {
 #define SRBA_SH(f) B.f = (decltype(B.f))((char *)B.f + bytes)
-	SRBA_SH(edge); SRBA_SH(ulm); SRBA_SH(pose); SRBA_SH(Jp); SRBA_SH(Jf); SRBA_SH(resid); SRBA_SH(resid2); SRBA_SH(HAp); SRBA_SH(HAp0); SRBA_SH(Hf); SRBA_SH(HApf); SRBA_SH(grad); SRBA_SH(grad0); SRBA_SH(delta); SRBA_SH(Hfinv); SRBA_SH(YW);
+	SRBA_SH(edge); SRBA_SH(ulm); SRBA_SH(pose); SRBA_SH(Jp); SRBA_SH(Jf); SRBA_SH(resid); SRBA_SH(resid2); SRBA_SH(HAp); SRBA_SH(HAp0); SRBA_SH(Hf); SRBA_SH(HApf); SRBA_SH(grad); SRBA_SH(grad0); SRBA_SH(delta); SRBA_SH(Hfinv); SRBA_SH(YW); SRBA_SH(Yh);
 	SRBA_SH(old_edge); SRBA_SH(old_ulm); SRBA_SH(old_pose); SRBA_SH(dense); SRBA_SH(ulm_inf); SRBA_SH(edge1); SRBA_SH(ulm1); SRBA_SH(pose1); SRBA_SH(valid); SRBA_SH(first_fail); SRBA_SH(hf_ok); SRBA_SH(bp_ok); SRBA_SH(bf_ok); SRBA_SH(ulm_inf_valid);
 	SRBA_SH(results); SRBA_SH(lambda_io); SRBA_SH(chi2); SRBA_SH(notpd); if (B.phase_cycles) SRBA_SH(phase_cycles);
 #undef SRBA_SH

@@ -59,6 +59,21 @@ struct Solver : public Worker<FAM, LEAN, G> {
 			for (int k = tid; k < d.n_hap * P * P; k += G) B.HAp[d.o_hap * P * P + k] = B.HAp0[d.o_hap * P * P + k];
 			__syncthreads();
 			if (pc) { if (tid == 0) pc[14] += wall_clock64() - tq; tq = wall_clock64(); }
+			if constexpr (LEAN) { // the workgroup kernels: Y = W Hf^-1 once per U_Apf block (a lane per block) instead of once per term -- a third of a term's multiplications and its Hf^-1 load
+				for (int hb = tid; hb < d.n_hapf; hb += G) {
+					const int l = B.hapf_j[d.o_hapf + hb]; if (!B.hf_ok[d.o_ulm + l]) continue;
+					double Wm[P * L], Hi[L * L], Y[P * L]; ldn<P * L>(Wm, B.HApf + (d.o_hapf + hb) * P * L); ldn<L * L>(Hi, B.Hfinv + (d.o_ulm + l) * L * L);
+#pragma unroll
+					for (int i = 0; i < P; i++)
+#pragma unroll
+						for (int j = 0; j < L; j++) { double sm = 0;
+#pragma unroll
+							for (int k = 0; k < L; k++) sm += Wm[i * L + k] * Hi[k * L + j];
+							Y[i * L + j] = sm; }
+					stn<P * L>(B.Yh + (d.o_hapf + hb) * P * L, Y);
+				}
+				__syncthreads();
+			}
 			// Balanced over the lanes: the flat term list of the capsule (sorted by U_Ap block) is cut into 64 equal runs, one per lane. A lane keeps the running block in
 			// registers and adds it to HBM when its run moves on to the next block (a block cut by a run boundary receives two or three such additions: atomics), so the
 			// pass is as long as 1/64 of the terms, not as the diagonal block with the longest list in every group of 64 blocks. The terms of the diagonal blocks also
@@ -85,9 +100,9 @@ struct Solver : public Worker<FAM, LEAN, G> {
 					for (int u = 0; u < NT; u++) { const bool live = t + u < te; const int tu = live ? t + u : t; lq[u] = s_lm[tu]; aq[u] = s_b1[tu]; cq[u] = s_b2[tu]; ywq[u] = s_yw[tu]; kq[u] = s_blk[tu]; okq[u] = live; }
 #pragma unroll
 					for (int u = 0; u < NT; u++) okq[u] = okq[u] && B.hf_ok[d.o_ulm + lq[u]] != 0;
-					double W1[NT][P * L], W2[NT][P * L], Hi[NT][L * L], gl[NT][L];
+					double W1[NT][P * L], W2[NT][P * L], Hi[NT][LEAN ? 1 : L * L], gl[NT][L]; // (LEAN: W1 holds Y = W1 Hf^-1 itself)
 #pragma unroll
-					for (int u = 0; u < NT; u++) { ldn<P * L>(W1[u], B.HApf + (d.o_hapf + aq[u]) * P * L); ldn<P * L>(W2[u], B.HApf + (d.o_hapf + cq[u]) * P * L); ldn<L * L>(Hi[u], B.Hfinv + (d.o_ulm + lq[u]) * L * L); ldn<L>(gl[u], gf + lq[u] * L); }
+					for (int u = 0; u < NT; u++) { ldn<P * L>(W1[u], (LEAN ? B.Yh : B.HApf) + (d.o_hapf + aq[u]) * P * L); ldn<P * L>(W2[u], B.HApf + (d.o_hapf + cq[u]) * P * L); if constexpr (!LEAN) ldn<L * L>(Hi[u], B.Hfinv + (d.o_ulm + lq[u]) * L * L); ldn<L>(gl[u], gf + lq[u] * L); }
 #pragma unroll
 					for (int u = 0; u < NT; u++) {
 						if (!okq[u]) continue;
@@ -102,8 +117,10 @@ struct Solver : public Worker<FAM, LEAN, G> {
 						for (int i = 0; i < P; i++)
 #pragma unroll
 							for (int j = 0; j < L; j++) { double sm = 0;
+								if constexpr (LEAN) sm = W1[u][i * L + j];
+								else {
 #pragma unroll
-								for (int k = 0; k < L; k++) sm += W1[u][i * L + k] * Hi[u][k * L + j];
+									for (int k = 0; k < L; k++) sm += W1[u][i * L + k] * Hi[u][k * L + j]; }
 								Y[i * L + j] = sm; }
 #pragma unroll
 						for (int i = 0; i < P; i++)
@@ -237,11 +254,17 @@ struct Solver : public Worker<FAM, LEAN, G> {
 		{ const long long n2 = 128LL * (nt + 1) * (nt + 2) / 2; f64x2u z; z.x = 0; z.y = 0; for (long long k = tid; k < n2; k += G) *(f64x2u *)(T + 2 * k) = z; }
 		__syncthreads();
 		auto at = [&](int r, int c) -> double * { return T + 256 * (long long)wg_tile(r >> 4, c >> 4) + wg_frag_off(r & 15, c & 15); }; // element (r, c), r >= c
-		for (int e = tid; e < d.n_hap * P * P; e += G) {
-			const int b = e / (P * P), r = (e / P) % P, q = e % P; const int i = B.hap_i[d.o_hap + b], j = B.hap_j[d.o_hap + b];
-			const double v = B.HAp[(d.o_hap + b) * P * P + r * P + q]; // element (P i + r, P j + q) of the upper triangle (i <= j)
-			if (i != j) *at(P * j + q, P * i + r) = v;
-			else if (r >= q) *at(P * i + r, P * i + q) = v + (r == q ? lambda : 0.0); // (a diagonal block holds both triangles)
+		for (int e0 = tid; e0 < d.n_hap * P; e0 += 2 * G) { // a lane per block ROW, two in flight: the block's position and its six numbers are requested together (the loop waits for memory, not for arithmetic)
+			int bi[2], bj[2], rr[2]; bool live[2]; double v[2][P];
+#pragma unroll
+			for (int u = 0; u < 2; u++) { const int e = e0 + u * G; live[u] = e < d.n_hap * P; const int b = live[u] ? e / P : 0; rr[u] = e % P; bi[u] = B.hap_i[d.o_hap + b]; bj[u] = B.hap_j[d.o_hap + b]; ldn<P>(v[u], B.HAp + (d.o_hap + b) * P * P + rr[u] * P); }
+#pragma unroll
+			for (int u = 0; u < 2; u++) if (live[u]) { const int i = bi[u], j = bj[u], r = rr[u]; // row r of the upper-triangle block (i <= j): elements (P i + r, P j + q)
+#pragma unroll
+				for (int q = 0; q < P; q++) {
+					if (i != j) *at(P * j + q, P * i + r) = v[u][q];
+					else if (r >= q) *at(P * i + r, P * i + q) = v[u][q] + (r == q ? lambda : 0.0); // (a diagonal block holds both triangles)
+				} }
 		}
 		const double *g = B.grad + d.o_scal;
 		for (int k = tid; k < 16 * nt; k += G) { T[256 * (long long)wg_tile(nt, k >> 4) + wg_frag_off(0, k & 15)] = (k < n) ? g[k] : 0.0; if (k >= n) *at(k, k) = 1.0; }
@@ -719,7 +742,7 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 template <int FAM>
 __global__ void __launch_bounds__(SRBA_WG) SRBA_OCC k_lm_run(const Batch B, const DevParams prm, int first, int count, int *next) {
 	for (;;) {
-		int i = 0; if (threadIdx.x == 0) i = atomicAdd(next, 1);
+		int i = 0; if (threadIdx.x == 0) { i = atomicAdd(next, 1); if (i == 0) *(long long *)(next + 2) = wall_clock64(); /* when the class started (srba_hip_launch_order): record = {counter, pad, stamp} */ }
 		i = __builtin_amdgcn_readfirstlane(i);
 		if (i >= count) break;
 		lm_one<FAM>(B, prm, B.order[first + i]);
@@ -735,7 +758,7 @@ __global__ void k_delay(int us) { const long long t0 = wall_clock64(); while (wa
 template <int FAM>
 __global__ void __launch_bounds__(SRBA_WG) __attribute__((amdgpu_waves_per_eu(3, 3))) k_lm_run_lean(const Batch B, const DevParams prm, int first, int count, int *next) {
 	for (;;) {
-		int i = 0; if (threadIdx.x == 0) i = atomicAdd(next, 1);
+		int i = 0; if (threadIdx.x == 0) { i = atomicAdd(next, 1); if (i == 0) *(long long *)(next + 2) = wall_clock64(); }
 		i = __builtin_amdgcn_readfirstlane(i);
 		if (i >= count) break;
 		lm_one<FAM, (SRBA_LM_DB != 0), true>(B, prm, B.order[first + i]);
@@ -753,7 +776,7 @@ template <int FAM>
 __global__ void __launch_bounds__(2 * SRBA_WG) __attribute__((amdgpu_waves_per_eu(3, 3))) k_lm_run2(const Batch B, const DevParams prm, int first, int count, int *next, int lds_doubles) {
 	double *red = srba_lds + lds_doubles; int *slot = (int *)(red + 2);
 	for (;;) {
-		if (threadIdx.x == 0) *slot = atomicAdd(next, 1);
+		if (threadIdx.x == 0) { const int i0 = atomicAdd(next, 1); *slot = i0; if (i0 == 0) *(long long *)(next + 2) = wall_clock64(); }
 		__syncthreads(); const int i = *slot; __syncthreads();
 		if (i >= count) break;
 		lm_one<FAM, (SRBA_LM_DB != 0), true, 2 * SRBA_WG>(B, prm, B.order[first + i], red);
@@ -770,7 +793,7 @@ template <int FAM, int G>
 __global__ void __launch_bounds__(G) __attribute__((amdgpu_waves_per_eu(2, 2))) k_lm_wg(const Batch B, const DevParams prm, int first, int count, int *next) {
 	double *red = srba_lds + 768 + 16 * WG_NT_MAX; int *slot = (int *)(red + 5); // (red[0 .. 3]: group reductions, red + 4: the solver's flag)
 	for (;;) {
-		if (threadIdx.x == 0) *slot = atomicAdd(next, 1);
+		if (threadIdx.x == 0) { const int i0 = atomicAdd(next, 1); *slot = i0; if (i0 == 0) *(long long *)(next + 2) = wall_clock64(); }
 		__syncthreads(); const int i = *slot; __syncthreads();
 		if (i >= count) break;
 		lm_one<FAM, (SRBA_LM_DB != 0), true, G, false>(B, prm, B.order[first + i], red);
@@ -1249,7 +1272,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	for (int k = 1; k < SRBA_NCLS && ok; k++) { // (class_prio 1: the streams of the biggest classes -- low stream index, see plan_launches -- get the highest priority, 2: the lowest)
 		const int split = 4, pri = c->class_prio == 0 ? 0 : ((c->class_prio == 1) == (k < split) ? pr_greatest : pr_least);
 		ok = (c->class_prio ? hipStreamCreateWithPriority(&c->cls_stream[k], hipStreamNonBlocking, pri) : hipStreamCreateWithFlags(&c->cls_stream[k], hipStreamNonBlocking)) == hipSuccess && hipEventCreateWithFlags(&c->cls_done[k], hipEventDisableTiming) == hipSuccess; }
-	if (!ok || hipMalloc((void **)&c->d_next, sizeof(int) * kMaxJobs) != hipSuccess || hipMalloc((void **)&c->d_part, 8 * 3 * kBigPart * srbadev::kGang) != hipSuccess || hipMalloc((void **)&c->d_scal, (8 * 16 + 4 * 8) * srbadev::kGang) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
+	if (!ok || hipMalloc((void **)&c->d_next, sizeof(int) * 4 * kMaxJobs) != hipSuccess || hipMalloc((void **)&c->d_part, 8 * 3 * kBigPart * srbadev::kGang) != hipSuccess || hipMalloc((void **)&c->d_scal, (8 * 16 + 4 * 8) * srbadev::kGang) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	c->spec_test_drop = getenv("SRBA_HIP_SPEC_TEST_DROP") != nullptr;
 	{ const char *e = getenv("SRBA_HIP_WG"); if (e) c->wg_on = atoi(e) != 0; e = getenv("SRBA_HIP_WG_FROM"); if (e && atoi(e) >= 1) c->wg_from_sys = atoi(e); e = getenv("SRBA_HIP_WG256_FROM"); if (e && atoi(e) >= 1) c->wg256_from_sys = atoi(e); }
 	{ const char *e = getenv("SRBA_HIP_BIG_MIN_SYS"); if (e && atoi(e) >= 0) c->big_min_sys = atoi(e); } // tuning / test knob
@@ -1327,7 +1350,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	const bool schur_solver = c->params.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL;
 	c->desc.assign(n, ProbDesc()); srba_batch_stats &st = c->stats; std::memset(&st, 0, sizeof(st)); st.n_problems = n;
 	// ---- pass 1: descriptors and totals
-	long long t_edge = 0, t_unk = 0, t_ulm = 0, t_klm = 0, t_pair = 0, t_path = 0, t_obs = 0, t_valid = 0, t_bp = 0, t_bf = 0, t_hap = 0, t_hapt = 0, t_hf = 0, t_hft = 0, t_hapf = 0, t_hapft = 0, t_sch = 0, t_req = 0, t_scal = 0, t_yw = 0, t_dense = 0;
+	long long t_hrec = 0, t_edge = 0, t_unk = 0, t_ulm = 0, t_klm = 0, t_pair = 0, t_path = 0, t_obs = 0, t_valid = 0, t_bp = 0, t_bf = 0, t_hap = 0, t_hapt = 0, t_hf = 0, t_hft = 0, t_hapf = 0, t_hapft = 0, t_sch = 0, t_req = 0, t_scal = 0, t_yw = 0, t_dense = 0;
 	std::vector<int> cls(n, 0), big_lds(n, 0); int cls_nbmax[SRBA_NCLS] = {0}; std::vector<Symbolic> sym(n); long long t_spcol = 0, t_sprow = 0, t_spitem = 0, t_spfill = 0;
 	// capsules whose system cannot fit one wavefront's LDS even as bare numbers (more than 63 block rows) but is no deep-window system either: a handful go to the
 	// multi-workgroup path; when the batch holds many, they keep one wavefront each with the system in HBM (see below)
@@ -1339,7 +1362,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 			if ((why[p] = validate_capsule(k)) != nullptr) continue;
 			ProbDesc t; t.nK = k.n_unk_edges; t.nF = k.n_unk_lms; t.n_scal = P * t.nK + L * t.nF; t.n_sys = (schur_solver && t.nF > 0 && t.nK > 0) ? P * t.nK : t.n_scal; t.nb = (t.n_sys + 2) / 3;
 			if (schur_solver && t.nK == 0) continue;
-			const bool wg = c->wg_on && c->dm.PD == 12 && c->dm.L == 3 && schur_solver && t.nF > 0 && t.nK > 0 && t.n_sys >= c->wg_from_sys && t.n_sys <= 16 * srbadev::WG_NT_MAX && c->gang_from_nb <= 0; // (SE3 point-landmark families, Schur solvers: the workgroup path needs no symbolic analysis)
+			const bool wg = c->wg_on && c->max_lds_kb > 0 /* (0: the test knob that sends every window to the multi-workgroup path) */ && c->dm.PD == 12 && c->dm.L == 3 && schur_solver && t.nF > 0 && t.nK > 0 && t.n_sys >= c->wg_from_sys && t.n_sys <= 16 * srbadev::WG_NT_MAX && c->gang_from_nb <= 0; // (SE3 point-landmark families, Schur solvers: the workgroup path needs no symbolic analysis)
 			if (t.n_sys <= c->big_min_sys && !wg) symbolic_factor(k, t, P, L, !schur_solver, sym[p]);
 		}
 	});
@@ -1356,7 +1379,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		d.o_bp = t_bp; d.o_colp = t_unk + p; d.o_bf = t_bf; d.o_colf = t_ulm + p; d.o_hap = t_hap; d.o_hapoff = t_hap + p; d.o_hapt = t_hapt; d.o_hf = t_hf; d.o_hfoff = t_hf + p; d.o_hft = t_hft;
 		d.o_hapf = t_hapf; d.o_hapfoff = t_hapf + p; d.o_hapft = t_hapft; d.o_sch = t_sch; d.o_lmoff = t_ulm + p; d.o_req = t_req; d.o_scal = t_scal; d.o_yw = t_yw; d.o_dense = t_dense;
 		d.nb = (d.n_sys + 2) / 3;
-		const bool to_wg = c->wg_on && c->dm.PD == 12 && c->dm.L == 3 && schur_solver && d.nF > 0 && d.nK > 0 && d.n_sys >= c->wg_from_sys && d.n_sys <= 16 * srbadev::WG_NT_MAX && c->gang_from_nb <= 0; // one workgroup, tile system in HBM, matrix cores (srba_wg.hpp)
+		const bool to_wg = c->wg_on && c->max_lds_kb > 0 && c->dm.PD == 12 && c->dm.L == 3 && schur_solver && d.nF > 0 && d.nK > 0 && d.n_sys >= c->wg_from_sys && d.n_sys <= 16 * srbadev::WG_NT_MAX && c->gang_from_nb <= 0; // one workgroup, tile system in HBM, matrix cores (srba_wg.hpp)
 		const bool surely_big = d.n_sys > c->big_min_sys || to_wg; // far beyond what one wavefront's LDS holds (or a workgroup window): dense system on the multi-workgroup path, no block-sparse symbolic analysis
 		if (!surely_big) { /* sym[p]: computed above */ }
 		else { Symbolic &y = sym[p]; y.col_off.assign(d.nb + 1, 0); y.item_off.assign(d.nb + 1, 0); y.rptr.assign(d.nb + 1, 0); y.perm.resize(d.nb); for (int q = 0; q < d.nb; q++) y.perm[q] = q;
@@ -1377,6 +1400,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		static const int kClsKB[SRBA_NLDS] = {6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64, 80, 96, 112, 128, 152};
 		cls[p] = SRBA_NCLS - 1; for (int q = 0; q < SRBA_NLDS && packable && !surely_big && !to_gang && kClsKB[q] <= c->max_lds_kb; q++) if (bytes <= (size_t)kClsKB[q] * 1024) { cls[p] = q; break; }
 		long long wave_ws = 0; // doubles of HBM workspace of a capsule that keeps one wavefront but holds its (dense block) system in HBM
+		{ d.hap_chunked = to_wg ? 1 : 0; int nr = k.n_hap; if (to_wg) { nr = 0; for (int b = 0; b < k.n_hap; b++) nr += std::max(1, (k.hap_term_off[b + 1] - k.hap_term_off[b] + 7) / 8); } d.n_hrec = nr; d.o_hrec = t_hrec; t_hrec += nr; } // K6 work records (ProbDesc::hap_chunked)
 		if (to_wg) { const int nt = (d.n_sys + srbadev::WT - 1) / srbadev::WT; d.dense_blocks = 3; d.nnzoff = 0; d.n_items = 0; cls[p] = d.n_sys >= c->wg256_from_sys ? SRBA_CLS_WG256 : SRBA_CLS_WG128; wave_ws = srbadev::wg_ws_doubles(nt); }
 		if ((cls[p] == SRBA_NCLS - 1 ? many_mid : (c->hbm_from_kb > 0 && n >= 1024 && kClsKB[cls[p]] >= c->hbm_from_kb && d.nb <= 168)) && !surely_big && !to_gang && !to_wg && c->dense_blocks_ok && !rel_family) {
 			// Does not fit any LDS class and the batch has many like it: the multi-workgroup path would run them a few at a time from the host. They stay on the
@@ -1417,7 +1441,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	o.hap_diag = in.add(4 * t_unk); o.hf_diag = in.add(4 * t_ulm);
 	o.sch_term_off = in.add(4 * (t_hap + n)); o.sch_b1 = in.add(4 * t_sch); o.sch_b2 = in.add(4 * t_sch); o.sch_lm = in.add(4 * t_sch); o.sch_yw = in.add(4 * t_sch); o.sch_tblk = in.add(4 * t_sch);
 	o.lm_hapf_off = in.add(4 * (t_ulm + n)); o.lm_hapf_idx = in.add(4 * t_hapf); o.req_idx = in.add(4 * t_req); o.need_idx = in.add(4 * t_pair); o.need_rec = in.add(4 * 5 * std::max<long long>(t_pair, 1)); o.obs_rec = in.add(4 * 5 * std::max<long long>(t_obs, 1)); o.pair_needed = in.add(t_pair); o.pose_req = in.add(2 * t_pair); o.bp_normal = in.add(t_bp); o.order = in.add(4 * (size_t)n);
-	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_rptr = in.add(4 * t_spcol); o.sp_rcol = in.add(4 * t_sprow); o.sp_perm = in.add(4 * t_spcol); o.hap_rec = in.add(4 * 3 * std::max<long long>(t_hap, 1)); o.sp_fill = in.add(4 * std::max<long long>(t_spfill, 1));
+	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_rptr = in.add(4 * t_spcol); o.sp_rcol = in.add(4 * t_sprow); o.sp_perm = in.add(4 * t_spcol); o.hap_rec = in.add(4 * 3 * std::max<long long>(t_hrec, 1)); o.sp_fill = in.add(4 * std::max<long long>(t_spfill, 1));
 	o.hap_dst = in.add(4 * t_hap * (P / 3) * (P / 3)); o.hapf_dst = in.add(4 * t_hapf * (P / 3)); o.hf_dst = in.add(4 * t_hf);
 	bool asm_fam = c->asm_on && c->params.family == SRBA_SE2_RELPOSE2D;
 	if (asm_fam && c->dp.noise == SRBA_NOISE_CONSTANT_MATRIX) for (int i = 0; i < 3; i++) for (int j = 0; j < i; j++) if (c->dp.lambda[3 * i + j] != c->dp.lambda[3 * j + i]) asm_fam = false; // the fused kernel sums the upper triangle of J^t Lambda J only
@@ -1477,7 +1501,10 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		CPY(o.sp_rptr, d.o_spcol, sym[p].rptr.data(), d.nb + 1, int32_t); { std::vector<int32_t> &rc = sym[p].rcol; const std::vector<int32_t> &rbk = sym[p].rblk; for (size_t q = 0; q < rc.size(); q++) rc[q] = (int32_t)(((unsigned)rc[q] << 14) | (unsigned)rbk[q]); } CPY(o.sp_rcol, d.o_sprow, sym[p].rcol.data(), sym[p].rcol.size(), int32_t); CPY(o.sp_fill, d.o_spfill, sym[p].fill.data(), d.n_fill, int32_t);
 		{ std::vector<int32_t> ho(k.n_hap); for (int b = 0; b < k.n_hap; b++) ho[b] = b;
 		  std::stable_sort(ho.begin(), ho.end(), [&](int x, int y) { return k.hap_term_off[x + 1] - k.hap_term_off[x] > k.hap_term_off[y + 1] - k.hap_term_off[y]; });
-		  int32_t *hr = (int32_t *)(h + o.hap_rec) + 3 * d.o_hap; for (int i = 0; i < k.n_hap; i++) { hr[3 * i] = ho[i]; hr[3 * i + 1] = k.hap_term_off[ho[i]]; hr[3 * i + 2] = k.hap_term_off[ho[i] + 1]; } }
+		  int32_t *hr = (int32_t *)(h + o.hap_rec) + 3 * d.o_hrec; int nr = 0;
+		  for (int i = 0; i < k.n_hap; i++) { const int b = ho[i], tb = k.hap_term_off[b], te = k.hap_term_off[b + 1];
+			if (!d.hap_chunked) { hr[3 * nr] = b; hr[3 * nr + 1] = tb; hr[3 * nr + 2] = te; nr++; }
+			else { int t0 = tb; do { const int t1 = std::min(te, t0 + 8); hr[3 * nr] = b; hr[3 * nr + 1] = t0; hr[3 * nr + 2] = t1; nr++; t0 = t1; } while (t0 < te); } } /* (records of at most 8 terms, full ones first) */ }
 		if (asm_fam && k.n_bp >= 1 && k.n_bp <= 65536 && 2 * k.n_pairs < 65535 && k.n_obs <= 65536 && d.nK <= 8191 && k.n_hap <= 65536) { // packed records of the fused normal-equations kernel (srba_assemble.hpp)
 			uint64_t *ab = (uint64_t *)(h + o.asm_blk) + d.o_bp, *at = (uint64_t *)(h + o.asm_term) + d.o_hapt; bool fit = true; const int cb = (k.n_bp + 63) / 64;
 			for (int i = 0; i < d.nK && fit; i++) { // the blocks of unknown i are colp_off[i] .. colp_off[i + 1] - 1, and its diagonal Hessian block sums exactly their J^t Lambda J
@@ -1534,11 +1561,11 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	}
 	if (host_timing) ht2 = now();
 	// ---- work arena layout
-	Arena wk; struct { size_t edge, ulm, pose, Jp, Jf, resid, resid2, HAp, HAp0, Hf, HApf, grad, delta, Hfinv, YW, old_edge, old_ulm, old_pose, dense, ulm_inf, valid, first_fail, hf_ok, bp_ok, bf_ok, ulm_inf_valid, results, lambda_io, chi2, notpd, phase_cycles, m_pair, grad0, edge1, ulm1, pose1; } w;
+	Arena wk; struct { size_t edge, ulm, pose, Jp, Jf, resid, resid2, HAp, HAp0, Hf, HApf, grad, delta, Hfinv, YW, Yh, old_edge, old_ulm, old_pose, dense, ulm_inf, valid, first_fail, hf_ok, bp_ok, bf_ok, ulm_inf_valid, results, lambda_io, chi2, notpd, phase_cycles, m_pair, grad0, edge1, ulm1, pose1; } w;
 	w.results = wk.add(sizeof(srba_lm_result) * n); // (first: [result records | unknowns | spanning-tree poses] is one span -- srba_hip_optimize_capsule reads it back in one copy)
 	w.edge = wk.add(8 * t_edge * PDX); w.ulm = wk.add(8 * t_ulm * L); w.pose = wk.add(8 * 2 * t_pair * PDX); w.Jp = wk.add(8 * t_bp * O * P); w.Jf = wk.add(8 * t_bf * O * L);
 	w.resid = wk.add(8 * t_obs * O); w.resid2 = wk.add(8 * t_obs * O); w.HAp = wk.add(8 * t_hap * P * P); w.HAp0 = wk.add(8 * t_hap * P * P); w.Hf = wk.add(8 * t_hf * L * L); w.HApf = wk.add(8 * t_hapf * P * L);
-	w.grad = wk.add(8 * t_scal); w.delta = wk.add(8 * t_scal); w.Hfinv = wk.add(8 * t_ulm * L * L); w.YW = wk.add(8 * t_yw * P * L); w.old_edge = wk.add(8 * t_unk * PDX); w.old_ulm = wk.add(8 * t_ulm * L); w.old_pose = wk.add(8 * t_req * PDX);
+	w.grad = wk.add(8 * t_scal); w.delta = wk.add(8 * t_scal); w.Hfinv = wk.add(8 * t_ulm * L * L); w.YW = wk.add(8 * t_yw * P * L); w.Yh = wk.add(c->wg_on ? 8 * t_hapf * P * L : 0); w.old_edge = wk.add(8 * t_unk * PDX); w.old_ulm = wk.add(8 * t_ulm * L); w.old_pose = wk.add(8 * t_req * PDX);
 	w.dense = wk.add(8 * t_dense); w.ulm_inf = wk.add(8 * t_ulm * L * L); w.valid = wk.add(4 * t_valid); w.first_fail = wk.add(4 * t_valid); w.hf_ok = wk.add(4 * t_ulm); w.bp_ok = wk.add(t_bp); w.bf_ok = wk.add(t_bf); w.ulm_inf_valid = wk.add(t_ulm);
 	w.lambda_io = wk.add(8 * n); w.chi2 = wk.add(8 * n); w.notpd = wk.add(4 * n); w.phase_cycles = wk.add(8 * 16 * (size_t)n);
 	w.m_pair = wk.add(4 * t_pair);
@@ -1566,7 +1593,7 @@ c->asm_tab.term = asm_fam ? (const unsigned long long *)(di + o.asm_term) : null
 #undef DI
 #define DW(field, T) B.field = (T *)(dw + w.field)
 	DW(edge, double); DW(ulm, double); DW(pose, double); DW(Jp, double); DW(Jf, double); DW(resid, double); DW(resid2, double); DW(HAp, double); DW(HAp0, double); DW(Hf, double); DW(HApf, double); DW(grad, double); DW(grad0, double); DW(delta, double); DW(edge1, double); DW(ulm1, double); DW(pose1, double);
-	DW(Hfinv, double); DW(YW, double); DW(old_edge, double); DW(old_ulm, double); DW(old_pose, double); DW(dense, double); DW(ulm_inf, double); DW(valid, int); DW(first_fail, int); DW(hf_ok, int); DW(bp_ok, unsigned char); DW(bf_ok, unsigned char); DW(ulm_inf_valid, unsigned char);
+	DW(Hfinv, double); DW(YW, double); DW(Yh, double); DW(old_edge, double); DW(old_ulm, double); DW(old_pose, double); DW(dense, double); DW(ulm_inf, double); DW(valid, int); DW(first_fail, int); DW(hf_ok, int); DW(bp_ok, unsigned char); DW(bf_ok, unsigned char); DW(ulm_inf_valid, unsigned char);
 	DW(results, srba_lm_result); DW(lambda_io, double); DW(chi2, double); DW(notpd, int);
 	c->flat.pair = (int *)(dw + w.m_pair); c->flat.n_pair = t_pair; c->flat_ready = false;
 	c->off_phase = w.phase_cycles; B.phase_cycles = c->phase_timing ? (long long *)(dw + w.phase_cycles) : nullptr;
@@ -1596,6 +1623,14 @@ int srba_hip_reset_state(srba_hip_ctx *c) {
 
 int srba_hip_big_path_stats(srba_hip_ctx *c, double out[4]) { if (!c || !out) return -1; out[0] = c->big_chol_ms; out[1] = c->big_chol_flops; out[2] = (double)c->big_chol_count; out[3] = c->big_chol_nmax; return 0; }
 int srba_hip_big_path_stats2(srba_hip_ctx *c, double out[8]) { if (!c || !out) return -1; out[0] = c->big_chol_ms; out[1] = c->big_chol_flops; out[2] = (double)c->big_chol_count; out[3] = c->big_chol_nmax; out[4] = (double)c->big_chol_seqs; out[5] = c->big_gang && !c->big_persistent ? 1 : 0; out[6] = out[7] = 0; return 0; }
+int srba_hip_launch_order(srba_hip_ctx *c, int64_t *stamp, int32_t *workgroups, int32_t *delay_us, int n) { // see srba_hip.h
+	if (!c || !stamp || n < 0) return -1;
+	HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream));
+	const int m = (int)std::min<size_t>(std::min<size_t>((size_t)n, c->plan.size()), kMaxJobs); std::vector<int32_t> rec(4 * (size_t)std::max(m, 1));
+	if (m > 0) HIPCHK(c, hipMemcpy(rec.data(), c->d_next, sizeof(int32_t) * 4 * (size_t)m, hipMemcpyDeviceToHost));
+	for (int j = 0; j < m; j++) { int64_t t; std::memcpy(&t, &rec[4 * j + 2], 8); stamp[j] = t; if (workgroups) workgroups[j] = c->plan[j].grid; if (delay_us) delay_us[j] = c->plan[j].delay_us; }
+	return m;
+}
 int srba_hip_spec_stats(srba_hip_ctx *c, int64_t out[2]) { if (!c || !out) return -1; out[0] = c->spec_launches; out[1] = c->spec_fallbacks; return 0; }
 int srba_hip_batch_stats(srba_hip_ctx *c, srba_batch_stats *out) { if (!c || !out) return -1; *out = c->stats; return 0; }
 
@@ -1922,7 +1957,7 @@ static int lm_run_async_impl(srba_hip_ctx *c) {
 		HIPCHK(c, hipEventRecord(c->ev1, c->stream));
 		return 0;
 	}
-	HIPCHK(c, hipMemsetAsync(c->d_next, 0, sizeof(int) * kMaxJobs, c->stream)); // work counters of the persistent launches
+	HIPCHK(c, hipMemsetAsync(c->d_next, 0, sizeof(int) * 4 * std::max<size_t>(1, std::min<size_t>(kMaxJobs, c->plan.size())), c->stream)); // per launch {work counter, pad, device time stamp of its first capsule}
 	// fork/join: the launch plan (made at upload) spreads the size classes over a few streams; see plan_launches()
 	const int nq = c->plan.size() <= 1 ? 1 : c->n_streams_used; // a single launch (the per-key-frame use) stays on the context stream: no fork / join
 	if (nq > 1) HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
@@ -1933,12 +1968,12 @@ static int lm_run_async_impl(srba_hip_ctx *c) {
 		if (J.delay_us > 0) hipLaunchKernelGGL(srbadev::k_delay, dim3(1), dim3(1), 0, launch_stream, J.delay_us);
 		if (k >= SRBA_NLDS) { // landmark windows on a workgroup (k_lm_wg)
 			with_family(c->params.family, [&](auto fam_) { constexpr int F = decltype(fam_)::value; if constexpr (srbadev::Tr<F>::SE3 && !srbadev::Tr<F>::REL) {
-				if (k == SRBA_CLS_WG256) hipLaunchKernelGGL((srbadev::k_lm_wg<F, 256>), dim3(J.grid), dim3(256), c->cls_lds[k], launch_stream, c->B, c->dp, J.first, J.count, c->d_next + j);
-				else hipLaunchKernelGGL((srbadev::k_lm_wg<F, 128>), dim3(J.grid), dim3(128), c->cls_lds[k], launch_stream, c->B, c->dp, J.first, J.count, c->d_next + j); } });
+				if (k == SRBA_CLS_WG256) hipLaunchKernelGGL((srbadev::k_lm_wg<F, 256>), dim3(J.grid), dim3(256), c->cls_lds[k], launch_stream, c->B, c->dp, J.first, J.count, c->d_next + 4 * j);
+				else hipLaunchKernelGGL((srbadev::k_lm_wg<F, 128>), dim3(J.grid), dim3(128), c->cls_lds[k], launch_stream, c->B, c->dp, J.first, J.count, c->d_next + 4 * j); } });
 			HIPCHK(c, hipGetLastError()); continue; }
 		if (J.two) { const size_t lds1 = (c->cls_lds[k] + c->lds_pad + 7) & ~(size_t)7; hipLaunchKernelGGL((srbadev::k_lm_run2<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(2 * SRBA_WG), lds1 + 32, launch_stream, c->B, c->dp, J.first, J.count, c->d_next + j, (int)(lds1 / 8)); HIPCHK(c, hipGetLastError()); continue; }
-		if (J.lean) { hipLaunchKernelGGL((srbadev::k_lm_run_lean<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(SRBA_WG), c->cls_lds[k] + c->lds_pad, launch_stream, c->B, c->dp, J.first, J.count, c->d_next + j); HIPCHK(c, hipGetLastError()); continue; }
-		SRBA_DISPATCH_LDS(c, k_lm_run, J.grid, c->cls_lds[k] + c->lds_pad, J.first, J.count, c->d_next + j); HIPCHK(c, hipGetLastError());
+		if (J.lean) { hipLaunchKernelGGL((srbadev::k_lm_run_lean<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(SRBA_WG), c->cls_lds[k] + c->lds_pad, launch_stream, c->B, c->dp, J.first, J.count, c->d_next + 4 * j); HIPCHK(c, hipGetLastError()); continue; }
+		SRBA_DISPATCH_LDS(c, k_lm_run, J.grid, c->cls_lds[k] + c->lds_pad, J.first, J.count, c->d_next + 4 * j); HIPCHK(c, hipGetLastError());
 	}
 	// capsules too large for one wavefront's LDS: the multi-workgroup path, one capsule after the other on the context stream (host-driven LM loop: this part
 	// of the call synchronises with the device once per LM trial), overlapping with the persistent launches of the other classes on their own streams

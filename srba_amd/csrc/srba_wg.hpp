@@ -108,12 +108,23 @@ __device__ __forceinline__ bool wg_chol_solve(double *T, double *LI, const int n
 		const lds_f64 *Lk = smL + 256 * (k & 1);
 		f64x4w li; li.x = Lk[4 * l]; li.y = Lk[4 * l + 1]; li.z = Lk[4 * l + 2]; li.w = Lk[4 * l + 3]; // frag(L_kk^-1): A operand of the triangular solves
 		const double *rowk = T + 256 * (size_t)wg_tile(k, 0);
-		auto finish_row = [&](int i, f64x4w *diag_sum) -> f64x4w { // L_ik (frag) = (A_ik - sum_{j<k} L_ij L_kj^t) L_kk^-t ; diag_sum (row k+1 only): += sum_{j<k} L_ij L_ij^t
+		const f64x4w zero4 = {0, 0, 0, 0};
+		auto solve_store = [&](int i, const f64x4w &a0, const f64x4w &s) -> f64x4w { // L_ik = (A_ik - s) L_kk^-t, stored as it lies in the accumulators
+			const f64x4w ct = a0 - s; // C_ik^t as accumulators == the B operand of the solve
+			f64x4w dd = zero4;
+			dd = __builtin_amdgcn_mfma_f64_16x16x4f64(li.x, ct.x, dd, 0, 0, 0); dd = __builtin_amdgcn_mfma_f64_16x16x4f64(li.y, ct.y, dd, 0, 0, 0);
+			dd = __builtin_amdgcn_mfma_f64_16x16x4f64(li.z, ct.z, dd, 0, 0, 0); dd = __builtin_amdgcn_mfma_f64_16x16x4f64(li.w, ct.w, dd, 0, 0, 0);
+			wg_st(T + 256 * (size_t)wg_tile(i, k), l, dd);
+			if (i == nt && (l & 15) == 0) { const int c0 = 16 * k + (l >> 4); yb[c0] = dd.x; yb[c0 + 4] = dd.y; yb[c0 + 8] = dd.z; yb[c0 + 12] = dd.w; } // row 0 of the right-hand-side tile: y_k
+			return dd;
+		};
+		// L_ik = (A_ik - sum_{j<k} L_ij L_kj^t) L_kk^-t for one tile row; diag_sum (row k + 1 only): += sum_{j<k} L_ij L_ij^t. Two columns j per pass, the tiles of the next pass
+		// requested before this pass's matrix instructions (the tiles come from L2 / the Infinity Cache: hundreds of cycles)
+		auto finish_row = [&](int i, f64x4w *diag_sum) -> f64x4w {
 			const double *rowi = T + 256 * (size_t)wg_tile(i, 0);
-			f64x4w s = {0, 0, 0, 0};
+			f64x4w s = zero4;
 			const f64x4w a0 = wg_ld(rowi + 256 * (size_t)k, l);
-			// two columns j per pass, the tiles of the next pass requested before this pass's matrix instructions (the tiles come from L2 / the Infinity Cache: hundreds of cycles)
-			f64x4w A0 = {0, 0, 0, 0}, B0 = A0, A1 = A0, B1 = A0, nA0 = A0, nB0 = A0, nA1 = A0, nB1 = A0;
+			f64x4w A0 = zero4, B0 = zero4, A1 = zero4, B1 = zero4, nA0 = zero4, nB0 = zero4, nA1 = zero4, nB1 = zero4;
 			if (k > 0) { A0 = wg_ld(rowk, l); B0 = wg_ld(rowi, l); } if (k > 1) { A1 = wg_ld(rowk + 256, l); B1 = wg_ld(rowi + 256, l); }
 			for (int j = 0; j < k; j += 2) {
 				if (j + 2 < k) { nA0 = wg_ld(rowk + 256 * (size_t)(j + 2), l); nB0 = wg_ld(rowi + 256 * (size_t)(j + 2), l); }
@@ -122,24 +133,36 @@ __device__ __forceinline__ bool wg_chol_solve(double *T, double *LI, const int n
 				if (j + 1 < k) { s = wg_mma(A1, B1, s); if (diag_sum) *diag_sum = wg_mma(B1, B1, *diag_sum); }
 				A0 = nA0; B0 = nB0; A1 = nA1; B1 = nB1;
 			}
-			const f64x4w ct = a0 - s; // C_ik^t as accumulators == the B operand of the solve
-			f64x4w dd = {0, 0, 0, 0};
-			dd = __builtin_amdgcn_mfma_f64_16x16x4f64(li.x, ct.x, dd, 0, 0, 0); dd = __builtin_amdgcn_mfma_f64_16x16x4f64(li.y, ct.y, dd, 0, 0, 0);
-			dd = __builtin_amdgcn_mfma_f64_16x16x4f64(li.z, ct.z, dd, 0, 0, 0); dd = __builtin_amdgcn_mfma_f64_16x16x4f64(li.w, ct.w, dd, 0, 0, 0);
-			wg_st(T + 256 * (size_t)wg_tile(i, k), l, dd);
-			if (i == nt && (l & 15) == 0) { const int c0 = 16 * k + (l >> 4); yb[c0] = dd.x; yb[c0 + 4] = dd.y; yb[c0 + 8] = dd.z; yb[c0 + 12] = dd.w; } // row 0 of the right-hand-side tile: y_k
-			return dd;
+			return solve_store(i, a0, s);
+		};
+		// the same for TWO tile rows at once: the tiles of row k serve both, five tiles per pass in flight instead of four for twice the work (the sweep waits for its tiles)
+		auto finish_rows2 = [&](int i0, int i1) {
+			const double *r0 = T + 256 * (size_t)wg_tile(i0, 0), *r1 = T + 256 * (size_t)wg_tile(i1, 0);
+			f64x4w s0 = zero4, s1 = zero4;
+			const f64x4w a00 = wg_ld(r0 + 256 * (size_t)k, l), a01 = wg_ld(r1 + 256 * (size_t)k, l);
+			f64x4w A0 = zero4, P0 = zero4, Q0 = zero4, A1 = zero4, P1 = zero4, Q1 = zero4, nA0 = zero4, nP0 = zero4, nQ0 = zero4, nA1 = zero4, nP1 = zero4, nQ1 = zero4;
+			if (k > 0) { A0 = wg_ld(rowk, l); P0 = wg_ld(r0, l); Q0 = wg_ld(r1, l); } if (k > 1) { A1 = wg_ld(rowk + 256, l); P1 = wg_ld(r0 + 256, l); Q1 = wg_ld(r1 + 256, l); }
+			for (int j = 0; j < k; j += 2) {
+				if (j + 2 < k) { const size_t o = 256 * (size_t)(j + 2); nA0 = wg_ld(rowk + o, l); nP0 = wg_ld(r0 + o, l); nQ0 = wg_ld(r1 + o, l); }
+				if (j + 3 < k) { const size_t o = 256 * (size_t)(j + 3); nA1 = wg_ld(rowk + o, l); nP1 = wg_ld(r0 + o, l); nQ1 = wg_ld(r1 + o, l); }
+				s0 = wg_mma(A0, P0, s0); s1 = wg_mma(A0, Q0, s1);
+				if (j + 1 < k) { s0 = wg_mma(A1, P1, s0); s1 = wg_mma(A1, Q1, s1); }
+				A0 = nA0; P0 = nP0; Q0 = nQ0; A1 = nA1; P1 = nP1; Q1 = nQ1;
+			}
+			solve_store(i0, a00, s0); solve_store(i1, a01, s1);
 		};
 		if (w == 0) {
 			if (k + 1 < nt) {
-				f64x4w ds = {0, 0, 0, 0};
+				f64x4w ds = zero4;
 				const f64x4w d1 = finish_row(k + 1, &ds);
 				ds = wg_mma(d1, d1, ds);
 				const f64x4w c = wg_ld(T + 256 * (size_t)wg_tile(k + 1, k + 1), l) - ds;
 				if (!wg_diag(c, smC, smL + 256 * ((k + 1) & 1), LI + 256 * (size_t)(k + 1), l) && l == 0) *flag = 1;
 			} else finish_row(nt, nullptr);
 		} else {
-			for (int i = k + 1 + w; i <= nt; i += NW - 1) finish_row(i, nullptr);
+			int i = k + 1 + w;
+			for (; i + (NW - 1) <= nt; i += 2 * (NW - 1)) finish_rows2(i, i + (NW - 1));
+			if (i <= nt) finish_row(i, nullptr);
 		}
 		__syncthreads();
 	}
