@@ -40,6 +40,7 @@ struct ProbDesc {
 	long long o_hap, o_hapoff, o_hapt, o_hf, o_hfoff, o_hft, o_hapf, o_hapfoff, o_hapft, o_sch, o_lmoff, o_req, o_scal, o_yw, o_dense, o_spcol, o_sprow, o_spitem, o_spperm;
 	int hapt_split; // two wavefronts per capsule: the second one takes the U_Ap terms from this index on (the first term of a Hessian block at or after the middle of the list: no block is summed by both)
 	int n_items, aligned; // block updates per factorisation; 1 if every Hessian block maps onto whole 3x3 blocks (always, except L==2 with the no-Schur solver)
+	int hs_lds; long long o_hapo, o_schl; // workgroup path, U_Ap accumulators in LDS (Solver::phase_hessian_lds / schur_reduce_lds): the U_Ap terms sorted by observation {t1, t2, block} from o_hapo (x3), the Schur terms sorted by landmark {lm, b1, b2, block | edge << 16 | diagonal << 31} from o_schl (x4)
 	int n_hrec, hap_chunked; long long o_hrec; // K6 work records {U_Ap block, first term, end term} (Batch::hap_rec): one per block, or (hap_chunked, the workgroup path) several of at most 8 terms each whose partial blocks are ADDED into a cleared U_Ap
 	int dense_in_lds, dense_blocks; // dense_blocks: the LDS image holds ALL blocks of the lower triangle (column-major), no symbolic structure (mid-size, nearly dense systems)
 };
@@ -57,6 +58,7 @@ struct Batch {
 	const int *sch_term_off, *sch_b1, *sch_b2, *sch_lm, *sch_yw, *sch_tblk /* U_Ap block of every Schur term */, *lm_hapf_off, *lm_hapf_idx, *req_idx, *need_idx, *need_rec; // need_rec: per needed pair {pair, 4 path entries (edge<<1|inv, -1 = none)}
 	const unsigned char *pair_needed, *bp_normal;
 	const int *sp_fill; // unified block indices (diag k -> k, off-diagonal i -> nb+i)
+	const int *hapo, *schl; // see ProbDesc::hs_lds
 	const int *hap_rec; // K6 work records, sorted by decreasing term count (longest first: balances the lanes of K6): {block, first term, end term}; ProbDesc::n_hrec of them from o_hrec
 	const int *sp_col_off, *sp_row, *sp_item_off, *sp_tgt /* packed update items: unified target block << 18 | a << 9 | b (packed at upload) */, *sp_rptr, *sp_rcol /* packed row-view entries: column << 14 | off-diagonal block */, *sp_perm; // symbolic factorisation of every capsule's system
 	const int *hap_dst, *hapf_dst, *hf_dst; // destination 3x3 block of every aligned sub-block of the Hessian blocks (see symbolic_factor)
@@ -192,8 +194,10 @@ __device__ __forceinline__ double block_max(double v, double *) { return wave_ma
 // solver stays on the first wavefront). Reductions over a group: per wavefront (DPP tree), then the two totals through two doubles of LDS (`red`) in a fixed order: deterministic.
 template <int G> __device__ __forceinline__ double grp_sum(double v, double *red) { // red: G / 64 doubles of LDS
 	v = wave_sum(v);
-	if constexpr (G > 64) { if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v; __syncthreads(); v = red[0] + red[1];
-		if constexpr (G > 128) { static_assert(G == 256, "groups of one, two or four wavefronts"); v = v + (red[2] + red[3]); }
+	if constexpr (G > 64) { static_assert(G == 128 || G == 256 || G == 512, "groups of one, two, four or eight wavefronts");
+		if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v; __syncthreads(); v = red[0] + red[1];
+		if constexpr (G > 128) v = v + (red[2] + red[3]);
+		if constexpr (G > 256) v = v + ((red[4] + red[5]) + (red[6] + red[7]));
 		__syncthreads(); }
 	return v;
 }
@@ -201,6 +205,7 @@ template <int G> __device__ __forceinline__ double grp_max(double v, double *red
 	v = wave_max(v);
 	if constexpr (G > 64) { if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v; __syncthreads(); v = fmax(red[0], red[1]);
 		if constexpr (G > 128) v = fmax(v, fmax(red[2], red[3]));
+		if constexpr (G > 256) v = fmax(v, fmax(fmax(red[4], red[5]), fmax(red[6], red[7])));
 		__syncthreads(); }
 	return v;
 }
@@ -1150,6 +1155,29 @@ struct Worker {
 			}
 		} else {
 			for (int i = 0; i < M1; i++) for (int j = 0; j < M2; j++) { double s = 0; for (int k = 0; k < O; k++) s += A[k * M1 + i] * Bm[k * M2 + j]; H[i * M2 + j] += s; }
+		}
+	}
+	// one ROW i of J1^t Lambda J2 (the term above, row by row: the caller adds each row to its accumulator as soon as it is formed -- six live sums instead of thirty-six)
+	template <int M1, int M2>
+	__device__ __forceinline__ void hess_row(double *row, const double *A, const double *Bm, int i) const {
+		if (prm.noise == SRBA_NOISE_CONSTANT_MATRIX) {
+			double jl[O];
+#pragma unroll
+			for (int j = 0; j < O; j++) { double s = 0;
+#pragma unroll
+				for (int k = 0; k < O; k++) s += A[k * M1 + i] * prm.lambda[k * O + j];
+				jl[j] = s; }
+#pragma unroll
+			for (int j = 0; j < M2; j++) { double s = 0;
+#pragma unroll
+				for (int k = 0; k < O; k++) s += jl[k] * Bm[k * M2 + j];
+				row[j] = s; }
+		} else {
+#pragma unroll
+			for (int j = 0; j < M2; j++) { double s = 0;
+#pragma unroll
+				for (int k = 0; k < O; k++) s += A[k * M1 + i] * Bm[k * M2 + j];
+				row[j] = s; }
 		}
 	}
 	template <int M1, int M2, bool ATOMIC = false>

@@ -143,6 +143,97 @@ struct Solver : public Worker<FAM, LEAN, G> {
 			if (pc) { if (tid == 0) pc[15] += wall_clock64() - tq; }
 		}
 	}
+	// ---- Workgroup path with the U_Ap blocks in LDS (ProbDesc::hs_lds; round 5). The landmark kernels run at 2 - 3 TB/s of HBM traffic: the one-wavefront forms above read both Jacobian
+	// blocks of every K6 term and both U_Apf blocks of every Schur term from memory (terms sorted by OUTPUT block, the sum kept in registers), i.e. every input block 3 .. 9 times per pass.
+	// Here the OUTPUT lives on chip -- n_hap x P x P doubles of LDS, summed with ds_add_f64 -- and the terms are sorted by INPUT (K6: by observation, K7/K8: by landmark), a lane per
+	// term: the lanes of a wavefront touch the same few input blocks at the same time, which then come from the vector L1; HBM sees every input block about once.
+	__device__ __forceinline__ double *hs() const { return srba_lds + WG_HS; }
+	__device__ __forceinline__ void store_hs(bool latch_too) { this->fresh(); // the LDS blocks -> U_Ap (and its latch, schur.h:38) in memory, 16 bytes per lane and request
+		const double *H = hs(); double *Hg = B.HAp + d.o_hap * P * P, *H0 = B.HAp0 + d.o_hap * P * P; const int n_acc = d.n_hap * P * P;
+		for (int k = 2 * tid; k + 1 < n_acc; k += 2 * G) { f64x2u v; v.x = H[k]; v.y = H[k + 1]; *(f64x2u *)(Hg + k) = v; if (latch_too) *(f64x2u *)(H0 + k) = v; }
+		if ((n_acc & 1) && tid == 0) { Hg[n_acc - 1] = H[n_acc - 1]; if (latch_too) H0[n_acc - 1] = H[n_acc - 1]; }
+	}
+	// K6 (sparse_hessian_update_numeric.h:22-60): U_Ap summed in LDS from the term list sorted by observation; U_f and U_Apf as before (their lists are a landmark's observations: short)
+	__device__ __forceinline__ int phase_hessian_lds() { this->fresh();
+		double *H = hs(); const int n_acc = d.n_hap * P * P, nt = d.n_hapt;
+		for (int k = tid; k < n_acc; k += G) H[k] = 0;
+		__syncthreads();
+		const double *Jp = B.Jp + d.o_bp * O * P; const unsigned char *rp = B.bp_ok + d.o_bp; const int *rec = B.hapo + d.o_hapo * 3;
+		const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0;
+		int ninv = 0, b1 = 0, b2 = 0, blk = 0;
+		if (tid < nt) { b1 = rec[3 * tid]; b2 = rec[3 * tid + 1]; blk = rec[3 * tid + 2]; }
+		for (int t = tid; t < nt; t += G) {
+			const int tn = t + G; int n1 = 0, n2 = 0, nb = 0; if (tn < nt) { n1 = rec[3 * tn]; n2 = rec[3 * tn + 1]; nb = rec[3 * tn + 2]; } // (the next record is requested before this term's blocks are waited for)
+			double A[O * P], Bm[O * P]; ldn<O * P>(A, Jp + (long long)b1 * O * P); ldn<O * P>(Bm, Jp + (long long)b2 * O * P);
+			if (rp[b1] && rp[b2]) {
+				double *dst = H + blk * P * P;
+#pragma unroll
+				for (int i = 0; i < P; i++) { double row[P]; W::template hess_row<P, P>(row, A, Bm, i);
+#pragma unroll
+					for (int j = 0; j < P; j++) atomicAdd(dst + i * P + j, row[j] * sc); }
+			} else ninv++;
+			b1 = n1; b2 = n2; blk = nb;
+		}
+		ninv += this->phase_hessian_landmark_blocks();
+		__syncthreads();
+		store_hs(prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL);
+		return ninv;
+	}
+	// K7 + K8 (schur.h:180-268) with the reduced U_Ap in LDS: starts from the latch, a lane per Schur term (sorted by landmark), Y = W Hf^-1 formed per term from cached inputs
+	__device__ __forceinline__ void schur_reduce_lds(double lambda, long long *pc = nullptr) { this->fresh(); long long tq = pc ? wall_clock64() : 0;
+		if constexpr (!W::T::REL) {
+			double *H = hs(), *gacc = srba_lds + WG_GACC; const int n_acc = d.n_hap * P * P;
+			for (int l = tid; l < d.nF; l += G) {
+				double M[L * L], Mi[L * L]; const double *src = B.Hf + (d.o_hf + B.hf_diag[d.o_ulm + l]) * L * L;
+				for (int k = 0; k < L * L; k++) M[k] = src[k];
+				for (int k = 0; k < L; k++) M[k * L + k] += lambda;
+				const bool ok = fullpiv_inverse<L>(M, Mi);
+				B.hf_ok[d.o_ulm + l] = ok ? 1 : 0;
+				if (ok) for (int k = 0; k < L * L; k++) B.Hfinv[(d.o_ulm + l) * L * L + k] = Mi[k];
+			}
+			{ const double *H0 = B.HAp0 + d.o_hap * P * P;
+			  for (int k = 2 * tid; k + 1 < n_acc; k += 2 * G) { const f64x2u v = *(const f64x2u *)(H0 + k); H[k] = v.x; H[k + 1] = v.y; }
+			  if ((n_acc & 1) && tid == 0) H[n_acc - 1] = H0[n_acc - 1];
+			  for (int k = tid; k < d.nK * P; k += G) gacc[k] = 0; }
+			__syncthreads();
+			if (pc) { if (tid == 0) pc[14] += wall_clock64() - tq; tq = wall_clock64(); }
+			const int *rec = B.schl + d.o_schl * 4; const double *gf = B.grad + d.o_scal + d.nK * P; const int nt = d.n_sch;
+			int l = 0, b1 = 0, b2 = 0, w = 0;
+			if (tid < nt) { l = rec[4 * tid]; b1 = rec[4 * tid + 1]; b2 = rec[4 * tid + 2]; w = rec[4 * tid + 3]; }
+			for (int t = tid; t < nt; t += G) {
+				const int tn = t + G; int nl = 0, n1 = 0, n2 = 0, nw = 0; if (tn < nt) { nl = rec[4 * tn]; n1 = rec[4 * tn + 1]; n2 = rec[4 * tn + 2]; nw = rec[4 * tn + 3]; }
+				double W1[P * L], W2[P * L], Hi[L * L], gl[L];
+				ldn<P * L>(W1, B.HApf + (d.o_hapf + b1) * P * L); ldn<P * L>(W2, B.HApf + (d.o_hapf + b2) * P * L); ldn<L * L>(Hi, B.Hfinv + (d.o_ulm + l) * L * L); ldn<L>(gl, gf + l * L);
+				if (B.hf_ok[d.o_ulm + l] != 0) {
+					const int blk = w & 0xffff, e = (w >> 16) & 0x7fff; const bool diag = w < 0;
+					double *dst = H + blk * P * P;
+#pragma unroll
+					for (int i = 0; i < P; i++) {
+						double y[L];
+#pragma unroll
+						for (int j = 0; j < L; j++) { double sm = 0;
+#pragma unroll
+							for (int k = 0; k < L; k++) sm += W1[i * L + k] * Hi[k * L + j];
+							y[j] = sm; }
+#pragma unroll
+						for (int j = 0; j < P; j++) { double sm = 0;
+#pragma unroll
+							for (int k = 0; k < L; k++) sm += y[k] * W2[j * L + k];
+							atomicAdd(dst + i * P + j, -sm); }
+						if (diag) { double sm = 0;
+#pragma unroll
+							for (int k = 0; k < L; k++) sm += y[k] * gl[k];
+							atomicAdd(gacc + e * P + i, -sm); }
+					}
+				}
+				l = nl; b1 = n1; b2 = n2; w = nw;
+			}
+			__syncthreads();
+			{ double *g = B.grad + d.o_scal; for (int k = tid; k < d.nK * P; k += G) g[k] += gacc[k]; }
+			__syncthreads();
+			if (pc) { if (tid == 0) pc[15] += wall_clock64() - tq; }
+		}
+	}
 	// K10 (schur.h:271-311)
 	__device__ __forceinline__ void schur_features() { this->fresh();
 		if constexpr (!W::T::REL) {
@@ -250,14 +341,16 @@ struct Solver : public Worker<FAM, LEAN, G> {
 	// The Schur-reduced system H_Ap' + lambda I and its right-hand side as 16 x 16 frag tiles (srba_wg.hpp; lev-marq_solvers.h:492-519 builds the same dense matrix for Eigen::LLT):
 	// the area is cleared, then every upper-triangle U_Ap block (i <= j) lands transposed in the lower triangle; rows beyond n_sys get an identity diagonal; the gradient is tile row nt.
 	__device__ __forceinline__ void assemble_tiles(const SparseSys &S, double lambda) { this->fresh();
-		const int n = d.n_sys, nt = S.nt; double *T = S.tiles;
+		const int n = d.n_sys, nt = S.nt; double *T = S.tiles; const double *Hsrc = d.hs_lds ? hs() : B.HAp + d.o_hap * P * P; // the reduced U_Ap blocks: in LDS or in memory
 		{ const long long n2 = 128LL * (nt + 1) * (nt + 2) / 2; f64x2u z; z.x = 0; z.y = 0; for (long long k = tid; k < n2; k += G) *(f64x2u *)(T + 2 * k) = z; }
 		__syncthreads();
 		auto at = [&](int r, int c) -> double * { return T + 256 * (long long)wg_tile(r >> 4, c >> 4) + wg_frag_off(r & 15, c & 15); }; // element (r, c), r >= c
 		for (int e0 = tid; e0 < d.n_hap * P; e0 += 2 * G) { // a lane per block ROW, two in flight: the block's position and its six numbers are requested together (the loop waits for memory, not for arithmetic)
 			int bi[2], bj[2], rr[2]; bool live[2]; double v[2][P];
 #pragma unroll
-			for (int u = 0; u < 2; u++) { const int e = e0 + u * G; live[u] = e < d.n_hap * P; const int b = live[u] ? e / P : 0; rr[u] = e % P; bi[u] = B.hap_i[d.o_hap + b]; bj[u] = B.hap_j[d.o_hap + b]; ldn<P>(v[u], B.HAp + (d.o_hap + b) * P * P + rr[u] * P); }
+			for (int u = 0; u < 2; u++) { const int e = e0 + u * G; live[u] = e < d.n_hap * P; const int b = live[u] ? e / P : 0; rr[u] = e % P; bi[u] = B.hap_i[d.o_hap + b]; bj[u] = B.hap_j[d.o_hap + b]; const double *src = Hsrc + b * P * P + rr[u] * P;
+#pragma unroll
+				for (int q = 0; q < P; q++) v[u][q] = src[q]; }
 #pragma unroll
 			for (int u = 0; u < 2; u++) if (live[u]) { const int i = bi[u], j = bj[u], r = rr[u]; // row r of the upper-triangle block (i <= j): elements (P i + r, P j + q)
 #pragma unroll
@@ -277,7 +370,7 @@ struct Solver : public Worker<FAM, LEAN, G> {
 #define STOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - t0; } } while (0)
 		if (schur_active() && (prm.ext & SRBA_EXT_SCHUR_KEEPS_GRADIENT)) { // (extension, default off) every solve starts from the gradient K5 produced: same lane -> same elements as keep_gradient()
 			double *g = B.grad + d.o_scal; const double *g0 = B.grad0 + d.o_scal; for (int k = tid; k < d.n_scal; k += G) g[k] = g0[k]; __syncthreads(); }
-		STIC(); if (schur_active()) schur_reduce(lambda, pc); STOC(9);
+		STIC(); if (schur_active()) { bool in_lds = false; if constexpr (G > 64 && !W::T::REL) in_lds = d.hs_lds != 0; if (in_lds) schur_reduce_lds(lambda, pc); else schur_reduce(lambda, pc); } STOC(9);
 		if constexpr (G > 64 && !W::T::REL) { // landmark window on a workgroup: dense LL^t on the matrix cores (srba_wg.hpp)
 			STIC(); assemble_tiles(S, lambda); STOC(10);
 			STIC(); const bool okw = wg_chol_solve<G / 64>(S.tiles, S.linv, S.nt, (lds_f64 *)srba_lds); STOC(11);
@@ -460,7 +553,8 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 #define TOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - tc0; } } while (0)
 	// K6: the LDS image of the system is idle while the capsule is linearised (it is assembled per trial): the U_Ap accumulators of the term-parallel form live there
 	const bool hess_terms = G <= 128 && B.hess_terms && d.dense_in_lds && d.n_hap * P * P <= 9 * (d.nb + d.nnzoff); // (the term-parallel form cuts the list between TWO wavefronts; workgroup windows keep no system in LDS anyway)
-	auto hessian = [&](Solver<FAM, LEAN, G> &X) -> int { return hess_terms ? X.phase_hessian_terms(srba_lds) /* == A.diag: the LDS image, idle while the capsule is linearised */ + X.phase_hessian_landmark_blocks() : X.phase_hessian(); };
+	bool hs_reduced = false; // workgroup path, U_Ap in LDS: the LDS blocks hold the Schur-reduced system of the last solve (what the reference leaves in HAp), not yet written back
+	auto hessian = [&](Solver<FAM, LEAN, G> &X) -> int { if constexpr (G > 64 && !Tr<FAM>::REL) { if (d.hs_lds) { hs_reduced = false; return X.phase_hessian_lds(); } } return hess_terms ? X.phase_hessian_terms(srba_lds) /* == A.diag: the LDS image, idle while the capsule is linearised */ + X.phase_hessian_landmark_blocks() : X.phase_hessian(); };
 	double lambda, nu = 2.0, total_err, RMSE;
 	int iter = 0, trials = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0; bool stop = false;
 	TIC(); S.phase_spantree(false, nullptr, DB ? B0.pose1 : nullptr); // S5 (DB: both copies of the poses)
@@ -493,7 +587,7 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 			const int tr = trials++;
 			if (tid == 0) { if (tr < SRBA_TRACE_LEN) out->trace_lambda[tr] = lambda; out->lambda_last_trial = lambda; }
 			const Batch Ba = DB ? copy_view(B0, cur) : B, Bt = DB ? copy_view(B0, cur ^ 1) : B; Solver<FAM, LEAN, G> Sa(Ba, d, prm, red), St(Bt, d, prm, red); // accepted / trial copy (the same one without DB)
-			TIC(); const bool solved = Sa.solve(A, lambda, pc); TOC(5);
+			TIC(); const bool solved = Sa.solve(A, lambda, pc); TOC(5); hs_reduced = true;
 			if (!solved) {
 				n_notpd++; lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
 				__syncthreads();
@@ -539,6 +633,7 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 		}
 	}
 	if (!stop) stopmask |= 1 << SRBA_STOP_MAX_ITERS;
+	if constexpr (G > 64 && !Tr<FAM>::REL) { if (d.hs_lds && hs_reduced && S.schur_active()) { __syncthreads(); S.store_hs(false); } } // (the reference's Schur complement works on HAp in place: its reduced blocks are what a caller reads after the run)
 	// S17: crpLandmarksApprox
 	if constexpr (!Solver<FAM, LEAN, G>::W::T::REL) {
 		for (int l = tid; l < d.nF; l += G) {
@@ -784,14 +879,27 @@ __global__ void __launch_bounds__(2 * SRBA_WG) __attribute__((amdgpu_waves_per_e
 	}
 }
 
+#ifndef SRBA_WG_BY_POINTER
+#define SRBA_WG_BY_POINTER 1 /* the workgroup kernels read the ~100 array pointers of the batch from a device copy of `Batch` (scalar loads where a pointer is used) instead of keeping them all in scalar registers from the kernel arguments: their phases last tens of microseconds, a scalar load is nothing there, and 450 - 530 spilled scalars (v_readlane restores: a quarter of the instructions of the Hessian and Schur loops) are */
+#endif
+#if SRBA_WG_BY_POINTER
+#define SRBA_WG_BATCH_ARG const Batch *__restrict__ Bptr
+#define SRBA_WG_BATCH_REF const Batch &B = *Bptr
+#define SRBA_WG_BATCH_VAL(c) (const srbadev::Batch *)(c)->d_batch
+#else
+#define SRBA_WG_BATCH_ARG const Batch B
+#define SRBA_WG_BATCH_REF
+#define SRBA_WG_BATCH_VAL(c) (c)->B
+#endif
 // One WORKGROUP of G = 128 or 256 threads per capsule for the SE3 landmark families (round 5; srba_wg.hpp): every lane-parallel phase runs G wide, the Schur-reduced system is a
 // lower triangle of 16 x 16 tiles in the capsule's HBM workspace and is factored on the matrix cores by the G / 64 wavefronts. Replaces, for the windows the plan sends here, the
 // one-wavefront k_lm_run<3..6> (504 - 512 registers, one wavefront per SIMD, the 3x3-block sweeps of a 40 - 59-edge stereo window 6.5 of the 15.5 ms of a trial). Registers: the
 // LEAN diet (one Schur term, one Hessian term, one spanning-tree pair in flight) under a cap of 256 -- two wavefronts per SIMD, i.e. two 256-thread workgroups per CU.
 // LDS: WG_LDS_DOUBLES (the solver's staging, x, reduction scratch, flags, the work counter's slot).
 template <int FAM, int G>
-__global__ void __launch_bounds__(G) __attribute__((amdgpu_waves_per_eu(2, 2))) k_lm_wg(const Batch B, const DevParams prm, int first, int count, int *next) {
-	double *red = srba_lds + 768 + 16 * WG_NT_MAX; int *slot = (int *)(red + 5); // (red[0 .. 3]: group reductions, red + 4: the solver's flag)
+__global__ void __launch_bounds__(G) __attribute__((amdgpu_waves_per_eu(2, 2))) k_lm_wg(SRBA_WG_BATCH_ARG, const DevParams prm, int first, int count, int *next) {
+	SRBA_WG_BATCH_REF;
+	double *red = srba_lds + WG_RED; int *slot = (int *)(red + 9); // (red[0 .. 7]: group reductions, red + 8: the solver's flag)
 	for (;;) {
 		if (threadIdx.x == 0) { const int i0 = atomicAdd(next, 1); *slot = i0; if (i0 == 0) *(long long *)(next + 2) = wall_clock64(); }
 		__syncthreads(); const int i = *slot; __syncthreads();
@@ -801,9 +909,10 @@ __global__ void __launch_bounds__(G) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 	}
 }
 template <int FAM, int G> __global__ void __launch_bounds__(G) __attribute__((amdgpu_waves_per_eu(2, 2))) k_solve_wg(const Batch B, const DevParams prm, int first) {
-	const int pidx = B.order[first + blockIdx.x]; const ProbDesc &d = B.desc[pidx]; Solver<FAM, true, G> S(B, d, prm, srba_lds + 768 + 16 * WG_NT_MAX);
+	const int pidx = B.order[first + blockIdx.x]; const ProbDesc &d = B.desc[pidx]; Solver<FAM, true, G> S(B, d, prm, srba_lds + WG_RED);
 	const SparseSys A = S.make_sys(srba_lds);
 	const bool ok = S.solve(A, B.lambda_io[pidx]);
+	if (d.hs_lds && S.schur_active()) { __syncthreads(); S.store_hs(false); }
 	if (threadIdx.x == 0) B.notpd[pidx] = ok ? 0 : 1;
 }
 
@@ -856,6 +965,25 @@ template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_solve(const Batc
 }
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_apply(const Batch B, const DevParams prm) { Solver<FAM> S(B, B.desc[blockIdx.x], prm); S.apply_update(); }
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_rollback(const Batch B, const DevParams prm) { Solver<FAM> S(B, B.desc[blockIdx.x], prm); S.restore(); }
+
+#ifdef SRBA_PROBE_KERNELS /* diagnostic build only (tools/probe_phases.sh): every phase of the workgroup kernel as a kernel of its own, to read its register need from the code object */
+#define SRBA_PROBE(NAME, BODY) template <int FAM> __global__ void __launch_bounds__(256) NAME(const Batch B, const DevParams prm) { Solver<FAM, true, 256> S(B, B.desc[blockIdx.x], prm, srba_lds + WG_RED); const SparseSys A = S.make_sys(srba_lds); (void)A; BODY; }
+SRBA_PROBE(kp_spantree, S.phase_spantree(false, nullptr, B.pose1))
+SRBA_PROBE(kp_spantree_need, S.phase_spantree(true, nullptr))
+SRBA_PROBE(kp_jacobians, S.phase_jacobians())
+SRBA_PROBE(kp_hessian, B.notpd[blockIdx.x] = S.phase_hessian())
+SRBA_PROBE(kp_gradient, S.phase_gradient(B.resid))
+SRBA_PROBE(kp_residuals, B.chi2[blockIdx.x] = S.phase_residuals(B.resid, srba_lds + WG_RED))
+SRBA_PROBE(kp_schur, S.schur_reduce(B.lambda_io[blockIdx.x]))
+SRBA_PROBE(kp_assemble, S.assemble_tiles(A, B.lambda_io[blockIdx.x]))
+SRBA_PROBE(kp_chol, B.notpd[blockIdx.x] = wg_chol_solve<4>(A.tiles, A.linv, A.nt, (lds_f64 *)srba_lds))
+SRBA_PROBE(kp_features, S.schur_features())
+SRBA_PROBE(kp_apply, S.apply_trial(A, B))
+template <int FAM> void probe_instantiate() { Batch B; DevParams p; hipLaunchKernelGGL(kp_spantree<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_spantree_need<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_jacobians<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_hessian<FAM>, 1, 256, 0, 0, B, p);
+	hipLaunchKernelGGL(kp_gradient<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_residuals<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_schur<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_assemble<FAM>, 1, 256, 0, 0, B, p);
+	hipLaunchKernelGGL(kp_chol<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_features<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_apply<FAM>, 1, 256, 0, 0, B, p); }
+template void probe_instantiate<SRBA_PROBE_KERNELS>();
+#endif
 
 } // namespace srbadev
 #include "srba_big.hpp"
@@ -919,9 +1047,10 @@ struct BigLane { int id = 0, slots = 1 /* windows its buffers have room for (srb
 } // namespace
 
 #define SRBA_NLDS 19        /* LDS size classes (6 KB ... 152 KB per wavefront) of the one-wavefront kernels */
-#define SRBA_CLS_WG128 19   /* landmark windows on a workgroup of two wavefronts (k_lm_wg<FAM, 128>) */
-#define SRBA_CLS_WG256 20   /* ... of four wavefronts */
-#define SRBA_NCLS 22        /* + the last class: systems factored by the multi-workgroup path (srba_big.hpp) */
+#define SRBA_CLS_WG128 19   /* landmark windows on a workgroup of two wavefronts (k_lm_wg<FAM, 128>), four workgroups per CU: at most 40 KB of LDS each */
+#define SRBA_CLS_WG256 20   /* ... of four wavefronts, two per CU: at most 80 KB */
+#define SRBA_CLS_WG512 21   /* ... of eight wavefronts, one per CU: the windows whose U_Ap blocks need up to 158 KB of LDS */
+#define SRBA_NCLS 23        /* + the last class: systems factored by the multi-workgroup path (srba_big.hpp) */
 // Symbolic block factorisation of one capsule's system (natural block order): the numeric kernel never discovers structure.
 struct Symbolic { std::vector<int32_t> fill; std::vector<int32_t> col_off, row, item_off, tgt, ab, rptr, rcol, rblk, perm, hap_dst, hapf_dst, hf_dst; int max_cn = 0; bool aligned = true; };
 static void symbolic_factor(const srba_problem_capsule &k, const ProbDesc &d, int P, int L, bool full_system, Symbolic &out) {
@@ -1093,7 +1222,7 @@ struct srba_hip_ctx {
 	std::string error;
 	// batch
 	int n_prob = 0; std::vector<ProbDesc> desc; Batch B; srba_batch_stats stats;
-	char *d_in = nullptr; size_t cap_in = 0; char *d_wk = nullptr; size_t cap_wk = 0; int *d_next = nullptr;
+	char *d_in = nullptr; size_t cap_in = 0; char *d_wk = nullptr; size_t cap_wk = 0; int *d_next = nullptr; Batch *d_batch = nullptr; // d_batch: device copy of B (the workgroup kernels read the batch's pointers from it)
 	double *d_part = nullptr; double *d_scal = nullptr; int *d_iscal = nullptr; // big path: partial sums [3][kBigPart], scalars, int flags (ninv, not-pd)
 	std::vector<int> big_ld; // per capsule: leading dimension of its dense system when it runs on the big path, else 0
 	double big_chol_ms = 0, big_chol_flops = 0; long long big_chol_count = 0, big_chol_seqs = 0 /* launch sequences: one factors all windows of a gang */; int big_chol_nmax = 0; // Cholesky time / flops of the big path since the last upload (sum over the lanes)
@@ -1113,6 +1242,7 @@ struct srba_hip_ctx {
 	int stagger_ns = 300, stagger_max_us = 5000; // staggered start of the class launches: see plan_launches
 	// lambda-ladder speculation for a batch of ONE capsule (k_lm_spec): spec_w replicas of the work arena, spec_stride bytes apart; d_spec = flags | outcomes | increments (SpecCtl)
 	long long spec_launches = 0; bool spec_on = true, spec_ready = false; int spec_w = 12; size_t spec_stride = 0; char *d_spec = nullptr; static constexpr int kSpecMaxW = 32, kSpecMaxN = 768; static constexpr size_t kSpecBackupOff = 256 + 8 * (2 * kSpecMaxW * 4) + 8 * (2 * (size_t)kSpecMaxW * kSpecMaxN), kSpecBytes = kSpecBackupOff + 8 * 5 * (size_t)kSpecMaxN; bool spec_suppress = false, spec_test_drop = false; long long spec_fallbacks = 0;
+	bool wg_hs = true; /* SRBA_HIP_WG_HS=0: U_Ap blocks of the workgroup windows in memory (the first version of the path) instead of in LDS */
 	bool wg_on = true; int wg_from_sys = 24, wg256_from_sys = 96; // SE3 landmark windows with a Schur-reduced system of at least wg_from_sys scalars run on a workgroup (k_lm_wg: 128 threads, 256 from wg256_from_sys); SRBA_HIP_WG=0 / SRBA_HIP_WG_FROM / SRBA_HIP_WG256_FROM
 	bool two_on = true; int two_from_kb = 20, two_min_count = 128; // k_lm_run2 (two wavefronts per capsule) for the relative-pose SE2 classes whose LDS image is at least this big
 	bool lean_on = true; int lean_min_count = 512; // k_lm_run_lean for the size classes of which at least nine wavefronts fit the LDS of a CU (relative-pose SE2, classes with at least this many capsules)
@@ -1137,7 +1267,7 @@ static void plan_launches(srba_hip_ctx *c, const int32_t *ord) {
 		int batch_total = 0; for (int k = 0; k < SRBA_NCLS; k++) batch_total += c->cls_count[k];
 		for (size_t j = 0; j < c->plan.size(); j++) { LaunchJob &J = c->plan[j]; J.grid = J.count;
 			if (c->sched == 3) { const size_t lds = c->cls_lds[J.cls] + c->lds_pad; const int fit = lds ? (int)std::max<size_t>(1, (size_t)c->lds_per_cu / lds) : c->waves_per_cu; J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(c->waves_per_cu, fit)));
-				if (J.cls >= SRBA_NLDS) J.grid = std::max(1, std::min(J.count, c->n_cu * (J.cls == SRBA_CLS_WG256 ? 2 : 4))); // workgroup classes: 256 registers -> two wavefronts per SIMD = two 256-thread / four 128-thread workgroups per CU
+				if (J.cls >= SRBA_NLDS) J.grid = std::max(1, std::min(J.count, c->n_cu * (J.cls == SRBA_CLS_WG512 ? 1 : (J.cls == SRBA_CLS_WG256 ? 2 : 4)))); // workgroup classes: 256 registers -> two wavefronts per SIMD = two 256-thread / four 128-thread workgroups per CU
 				J.lean = (c->lean_on && c->params.family == SRBA_SE2_RELPOSE2D && J.cls < SRBA_NCLS - 1 && fit >= 9 && J.count >= c->lean_min_count) ? 1 : 0;
 				if (J.lean) J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(12, fit)));
 				// (also for a batch of a few capsules -- the per-key-frame use of the engine is a batch of ONE: its latency is the whole cost, 1.55 -> 1.41 ms per key-frame of the sequential run)
@@ -1274,7 +1404,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 		ok = (c->class_prio ? hipStreamCreateWithPriority(&c->cls_stream[k], hipStreamNonBlocking, pri) : hipStreamCreateWithFlags(&c->cls_stream[k], hipStreamNonBlocking)) == hipSuccess && hipEventCreateWithFlags(&c->cls_done[k], hipEventDisableTiming) == hipSuccess; }
 	if (!ok || hipMalloc((void **)&c->d_next, sizeof(int) * 4 * kMaxJobs) != hipSuccess || hipMalloc((void **)&c->d_part, 8 * 3 * kBigPart * srbadev::kGang) != hipSuccess || hipMalloc((void **)&c->d_scal, (8 * 16 + 4 * 8) * srbadev::kGang) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	c->spec_test_drop = getenv("SRBA_HIP_SPEC_TEST_DROP") != nullptr;
-	{ const char *e = getenv("SRBA_HIP_WG"); if (e) c->wg_on = atoi(e) != 0; e = getenv("SRBA_HIP_WG_FROM"); if (e && atoi(e) >= 1) c->wg_from_sys = atoi(e); e = getenv("SRBA_HIP_WG256_FROM"); if (e && atoi(e) >= 1) c->wg256_from_sys = atoi(e); }
+	{ const char *e = getenv("SRBA_HIP_WG"); if (e) c->wg_on = atoi(e) != 0; e = getenv("SRBA_HIP_WG_FROM"); if (e && atoi(e) >= 1) c->wg_from_sys = atoi(e); e = getenv("SRBA_HIP_WG256_FROM"); if (e && atoi(e) >= 1) c->wg256_from_sys = atoi(e); e = getenv("SRBA_HIP_WG_HS"); if (e) c->wg_hs = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_BIG_MIN_SYS"); if (e && atoi(e) >= 0) c->big_min_sys = atoi(e); } // tuning / test knob
 	{ const char *e = getenv("SRBA_HIP_DENSE_BLOCKS"); if (e) c->dense_blocks_ok = atoi(e) != 0; }
 	{ const unsigned hc = std::thread::hardware_concurrency(); c->upload_threads = (int)std::min(32u, std::max(1u, hc)); const char *e = getenv("SRBA_HIP_UPLOAD_THREADS"); if (e) c->upload_threads = std::max(1, atoi(e)); } // host threads of srba_hip_upload_problems
@@ -1305,7 +1435,7 @@ int srba_hip_destroy(srba_hip_ctx *c) {
 	if (!c) return 0;
 	hipSetDevice(c->device);
 	for (int i = 0; i < kBigLanes; i++) { BigLane &l = c->lanes[i]; if (l.h_fetch) hipHostFree(l.h_fetch); if (l.e0) hipEventDestroy(l.e0); if (l.e1) hipEventDestroy(l.e1); if (i > 0) { if (l.d_part) hipFree(l.d_part); if (l.d_scal) hipFree(l.d_scal); if (l.stream) hipStreamDestroy(l.stream); } }
-	if (c->d_in) hipFree(c->d_in); if (c->d_wk) hipFree(c->d_wk); if (c->d_next) hipFree(c->d_next); if (c->d_spec) hipFree(c->d_spec); c->h_in.release(); if (c->h_out) hipHostFree(c->h_out); if (c->ev_h2d) hipEventDestroy(c->ev_h2d); if (c->d_part) hipFree(c->d_part); if (c->d_scal) hipFree(c->d_scal);
+	if (c->d_in) hipFree(c->d_in); if (c->d_wk) hipFree(c->d_wk); if (c->d_next) hipFree(c->d_next); if (c->d_batch) hipFree(c->d_batch); if (c->d_spec) hipFree(c->d_spec); c->h_in.release(); if (c->h_out) hipHostFree(c->h_out); if (c->ev_h2d) hipEventDestroy(c->ev_h2d); if (c->d_part) hipFree(c->d_part); if (c->d_scal) hipFree(c->d_scal);
 	for (int i = 0; i < srba_hip_ctx::kRing; i++) { if (c->ring0[i]) hipEventDestroy(c->ring0[i]); if (c->ring1[i]) hipEventDestroy(c->ring1[i]); }
 	if (c->ev_fork) hipEventDestroy(c->ev_fork);
 	for (int k = 1; k < SRBA_NCLS; k++) { if (c->cls_done[k]) hipEventDestroy(c->cls_done[k]); if (c->cls_stream[k]) hipStreamDestroy(c->cls_stream[k]); }
@@ -1350,8 +1480,8 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	const bool schur_solver = c->params.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL;
 	c->desc.assign(n, ProbDesc()); srba_batch_stats &st = c->stats; std::memset(&st, 0, sizeof(st)); st.n_problems = n;
 	// ---- pass 1: descriptors and totals
-	long long t_hrec = 0, t_edge = 0, t_unk = 0, t_ulm = 0, t_klm = 0, t_pair = 0, t_path = 0, t_obs = 0, t_valid = 0, t_bp = 0, t_bf = 0, t_hap = 0, t_hapt = 0, t_hf = 0, t_hft = 0, t_hapf = 0, t_hapft = 0, t_sch = 0, t_req = 0, t_scal = 0, t_yw = 0, t_dense = 0;
-	std::vector<int> cls(n, 0), big_lds(n, 0); int cls_nbmax[SRBA_NCLS] = {0}; std::vector<Symbolic> sym(n); long long t_spcol = 0, t_sprow = 0, t_spitem = 0, t_spfill = 0;
+	long long t_hapo = 0, t_schl = 0, t_hrec = 0, t_edge = 0, t_unk = 0, t_ulm = 0, t_klm = 0, t_pair = 0, t_path = 0, t_obs = 0, t_valid = 0, t_bp = 0, t_bf = 0, t_hap = 0, t_hapt = 0, t_hf = 0, t_hft = 0, t_hapf = 0, t_hapft = 0, t_sch = 0, t_req = 0, t_scal = 0, t_yw = 0, t_dense = 0;
+	std::vector<int> cls(n, 0), big_lds(n, 0); int cls_nbmax[SRBA_NCLS] = {0}; size_t wg_lds[3] = {0, 0, 0}; std::vector<Symbolic> sym(n); long long t_spcol = 0, t_sprow = 0, t_spitem = 0, t_spfill = 0;
 	// capsules whose system cannot fit one wavefront's LDS even as bare numbers (more than 63 block rows) but is no deep-window system either: a handful go to the
 	// multi-workgroup path; when the batch holds many, they keep one wavefront each with the system in HBM (see below)
 	bool many_mid = false; { int cnt = 0; for (int p = 0; p < n; p++) { const int nsys = (schur_solver && caps[p].n_unk_lms > 0 && caps[p].n_unk_edges > 0) ? P * caps[p].n_unk_edges : P * caps[p].n_unk_edges + L * caps[p].n_unk_lms; if ((nsys + 2) / 3 > 63 && nsys <= c->big_min_sys) cnt++; } many_mid = cnt > 32; }
@@ -1401,7 +1531,17 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		cls[p] = SRBA_NCLS - 1; for (int q = 0; q < SRBA_NLDS && packable && !surely_big && !to_gang && kClsKB[q] <= c->max_lds_kb; q++) if (bytes <= (size_t)kClsKB[q] * 1024) { cls[p] = q; break; }
 		long long wave_ws = 0; // doubles of HBM workspace of a capsule that keeps one wavefront but holds its (dense block) system in HBM
 		{ d.hap_chunked = to_wg ? 1 : 0; int nr = k.n_hap; if (to_wg) { nr = 0; for (int b = 0; b < k.n_hap; b++) nr += std::max(1, (k.hap_term_off[b + 1] - k.hap_term_off[b] + 7) / 8); } d.n_hrec = nr; d.o_hrec = t_hrec; t_hrec += nr; } // K6 work records (ProbDesc::hap_chunked)
-		if (to_wg) { const int nt = (d.n_sys + srbadev::WT - 1) / srbadev::WT; d.dense_blocks = 3; d.nnzoff = 0; d.n_items = 0; cls[p] = d.n_sys >= c->wg256_from_sys ? SRBA_CLS_WG256 : SRBA_CLS_WG128; wave_ws = srbadev::wg_ws_doubles(nt); }
+		d.hs_lds = 0; d.o_hapo = t_hapo; d.o_schl = t_schl;
+		if (to_wg) { const int nt = (d.n_sys + srbadev::WT - 1) / srbadev::WT; d.dense_blocks = 3; d.nnzoff = 0; d.n_items = 0; wave_ws = srbadev::wg_ws_doubles(nt);
+			// LDS of the workgroup: the solver's scratch + (when they fit its class) the U_Ap blocks of the window, summed on chip (Solver::phase_hessian_lds / schur_reduce_lds)
+			const size_t base = 8 * (size_t)srbadev::WG_LDS_DOUBLES, with_hs = 8 * ((size_t)srbadev::WG_HS + (size_t)k.n_hap * P * P); const bool idx_ok = k.n_hap < 65536 && d.nK < 32768;
+			size_t need = base;
+			if (c->wg_hs && idx_ok && with_hs <= (size_t)40 * 1024 && d.n_sys < c->wg256_from_sys) { cls[p] = SRBA_CLS_WG128; d.hs_lds = 1; need = with_hs; }
+			else if (c->wg_hs && idx_ok && with_hs <= (size_t)80 * 1024) { cls[p] = SRBA_CLS_WG256; d.hs_lds = 1; need = with_hs; }
+			else if (c->wg_hs && idx_ok && with_hs <= (size_t)158 * 1024) { cls[p] = SRBA_CLS_WG512; d.hs_lds = 1; need = with_hs; }
+			else cls[p] = d.n_sys >= c->wg256_from_sys ? SRBA_CLS_WG256 : SRBA_CLS_WG128; // U_Ap in memory (round-5 first version): more blocks than a CU's LDS holds
+			wg_lds[cls[p] - SRBA_NLDS] = std::max(wg_lds[cls[p] - SRBA_NLDS], need);
+			if (d.hs_lds) { d.hap_chunked = 0; t_hrec -= d.n_hrec - k.n_hap; d.n_hrec = k.n_hap; /* (the K6 records are not used on this path: one per block) */ t_hapo += k.n_hap_terms; t_schl += k.n_sch_terms; } }
 		if ((cls[p] == SRBA_NCLS - 1 ? many_mid : (c->hbm_from_kb > 0 && n >= 1024 && kClsKB[cls[p]] >= c->hbm_from_kb && d.nb <= 168)) && !surely_big && !to_gang && !to_wg && c->dense_blocks_ok && !rel_family) {
 			// Does not fit any LDS class and the batch has many like it: the multi-workgroup path would run them a few at a time from the host. They stay on the
 			// one-wavefront kernel with the dense block system in an HBM workspace (slow per capsule, but thousands run side by side).
@@ -1429,7 +1569,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	// ---- input arena layout
 	Arena in; struct { size_t desc, edge0, ulm0, klm, obs_z, pair_path_off, path_edge, obs_pose, obs_lm, obs_valid, bp_col, bp_res, bp_A, bp_D, bp_lm, colp_off, bf_col, bf_res, bf_pose, colf_off,
 		hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hap_tblk, hf_i, hf_j, hf_term_off, hf_t1, hf_t2, hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag, sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw, sch_tblk,
-		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, obs_rec, pair_needed, pose_req, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_rptr, sp_rcol, sp_perm, sp_fill, hap_rec, hap_dst, hapf_dst, hf_dst, asm_term, asm_blk, asm_desc, asm_list, asm_slot; } o;
+		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, obs_rec, pair_needed, pose_req, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_rptr, sp_rcol, sp_perm, sp_fill, hap_rec, hapo, schl, hap_dst, hapf_dst, hf_dst, asm_term, asm_blk, asm_desc, asm_list, asm_slot; } o;
 	o.desc = in.add(sizeof(ProbDesc) * n);
 	o.edge0 = in.add(8 * t_edge * PDX); o.ulm0 = in.add(8 * t_ulm * L); o.klm = in.add(8 * t_klm * L); o.obs_z = in.add(8 * t_obs * O);
 	o.pair_path_off = in.add(4 * (t_pair + n)); o.path_edge = in.add(4 * t_path); o.obs_pose = in.add(4 * t_obs); o.obs_lm = in.add(4 * t_obs); o.obs_valid = in.add(4 * t_obs);
@@ -1441,7 +1581,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	o.hap_diag = in.add(4 * t_unk); o.hf_diag = in.add(4 * t_ulm);
 	o.sch_term_off = in.add(4 * (t_hap + n)); o.sch_b1 = in.add(4 * t_sch); o.sch_b2 = in.add(4 * t_sch); o.sch_lm = in.add(4 * t_sch); o.sch_yw = in.add(4 * t_sch); o.sch_tblk = in.add(4 * t_sch);
 	o.lm_hapf_off = in.add(4 * (t_ulm + n)); o.lm_hapf_idx = in.add(4 * t_hapf); o.req_idx = in.add(4 * t_req); o.need_idx = in.add(4 * t_pair); o.need_rec = in.add(4 * 5 * std::max<long long>(t_pair, 1)); o.obs_rec = in.add(4 * 5 * std::max<long long>(t_obs, 1)); o.pair_needed = in.add(t_pair); o.pose_req = in.add(2 * t_pair); o.bp_normal = in.add(t_bp); o.order = in.add(4 * (size_t)n);
-	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_rptr = in.add(4 * t_spcol); o.sp_rcol = in.add(4 * t_sprow); o.sp_perm = in.add(4 * t_spcol); o.hap_rec = in.add(4 * 3 * std::max<long long>(t_hrec, 1)); o.sp_fill = in.add(4 * std::max<long long>(t_spfill, 1));
+	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_rptr = in.add(4 * t_spcol); o.sp_rcol = in.add(4 * t_sprow); o.sp_perm = in.add(4 * t_spcol); o.hap_rec = in.add(4 * 3 * std::max<long long>(t_hrec, 1)); o.hapo = in.add(4 * 3 * t_hapo); o.schl = in.add(4 * 4 * t_schl); o.sp_fill = in.add(4 * std::max<long long>(t_spfill, 1));
 	o.hap_dst = in.add(4 * t_hap * (P / 3) * (P / 3)); o.hapf_dst = in.add(4 * t_hapf * (P / 3)); o.hf_dst = in.add(4 * t_hf);
 	bool asm_fam = c->asm_on && c->params.family == SRBA_SE2_RELPOSE2D;
 	if (asm_fam && c->dp.noise == SRBA_NOISE_CONSTANT_MATRIX) for (int i = 0; i < 3; i++) for (int j = 0; j < i; j++) if (c->dp.lambda[3 * i + j] != c->dp.lambda[3 * j + i]) asm_fam = false; // the fused kernel sums the upper triangle of J^t Lambda J only
@@ -1505,6 +1645,18 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		  for (int i = 0; i < k.n_hap; i++) { const int b = ho[i], tb = k.hap_term_off[b], te = k.hap_term_off[b + 1];
 			if (!d.hap_chunked) { hr[3 * nr] = b; hr[3 * nr + 1] = tb; hr[3 * nr + 2] = te; nr++; }
 			else { int t0 = tb; do { const int t1 = std::min(te, t0 + 8); hr[3 * nr] = b; hr[3 * nr + 1] = t0; hr[3 * nr + 2] = t1; nr++; t0 = t1; } while (t0 < te); } } /* (records of at most 8 terms, full ones first) */ }
+		if (d.hs_lds) { // the term lists of the LDS path: K6 terms by observation, Schur terms by landmark (stable: a block's terms keep their order inside an observation / a landmark)
+			std::vector<int32_t> ix(k.n_hap_terms), tb(k.n_hap_terms); for (int b = 0; b < k.n_hap; b++) for (int t = k.hap_term_off[b]; t < k.hap_term_off[b + 1]; t++) tb[t] = b;
+			for (int t = 0; t < k.n_hap_terms; t++) ix[t] = t;
+			std::stable_sort(ix.begin(), ix.end(), [&](int x, int y) { return k.bp_res[k.hap_t1[x]] < k.bp_res[k.hap_t1[y]]; });
+			int32_t *ho = (int32_t *)(h + o.hapo) + 3 * d.o_hapo; for (int q = 0; q < k.n_hap_terms; q++) { const int t = ix[q]; ho[3 * q] = k.hap_t1[t]; ho[3 * q + 1] = k.hap_t2[t]; ho[3 * q + 2] = tb[t]; }
+			std::vector<int32_t> sx(k.n_sch_terms), sb(k.n_sch_terms); for (int b = 0; b < k.n_hap; b++) for (int t = k.sch_term_off[b]; t < k.sch_term_off[b + 1]; t++) sb[t] = b;
+			for (int t = 0; t < k.n_sch_terms; t++) sx[t] = t;
+			std::stable_sort(sx.begin(), sx.end(), [&](int x, int y) { return k.sch_lm[x] < k.sch_lm[y]; });
+			int32_t *so = (int32_t *)(h + o.schl) + 4 * d.o_schl;
+			for (int q = 0; q < k.n_sch_terms; q++) { const int t = sx[q], b = sb[t]; const bool dg = k.hap_i[b] == k.hap_j[b];
+				so[4 * q] = k.sch_lm[t]; so[4 * q + 1] = k.sch_b1[t]; so[4 * q + 2] = k.sch_b2[t]; so[4 * q + 3] = (int32_t)((uint32_t)b | ((uint32_t)k.hap_i[b] << 16) | (dg ? 0x80000000u : 0u)); }
+		}
 		if (asm_fam && k.n_bp >= 1 && k.n_bp <= 65536 && 2 * k.n_pairs < 65535 && k.n_obs <= 65536 && d.nK <= 8191 && k.n_hap <= 65536) { // packed records of the fused normal-equations kernel (srba_assemble.hpp)
 			uint64_t *ab = (uint64_t *)(h + o.asm_blk) + d.o_bp, *at = (uint64_t *)(h + o.asm_term) + d.o_hapt; bool fit = true; const int cb = (k.n_bp + 63) / 64;
 			for (int i = 0; i < d.nK && fit; i++) { // the blocks of unknown i are colp_off[i] .. colp_off[i + 1] - 1, and its diagonal Hessian block sums exactly their J^t Lambda J
@@ -1530,7 +1682,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		int32_t *ord = (int32_t *)(h + o.order); int pos = 0;
 		for (int k = 0; k < SRBA_NCLS; k++) {
 			c->cls_first[k] = pos; for (int p = 0; p < n; p++) if (cls[p] == k) ord[pos++] = p; c->cls_count[k] = pos - c->cls_first[k];
-			c->cls_lds[k] = k < SRBA_NLDS ? (size_t)cls_nbmax[k] * 8 : (k < SRBA_NCLS - 1 ? (size_t)srbadev::WG_LDS_DOUBLES * 8 : 0);
+			c->cls_lds[k] = k < SRBA_NLDS ? (size_t)cls_nbmax[k] * 8 : (k < SRBA_NCLS - 1 ? std::max(wg_lds[k - SRBA_NLDS], (size_t)srbadev::WG_LDS_DOUBLES * 8) : 0);
 			// longest (most block updates per factorisation) first, dealt round-robin to the queue slices of lm_run_async
 			int32_t *b = ord + c->cls_first[k]; const int cnt = c->cls_count[k], nq = c->n_queues;
 			auto work = [&](int x) -> long long { const ProbDesc &dx = c->desc[x]; return dx.dense_blocks ? (long long)dx.nb * dx.nb * dx.nb / 6 : dx.n_items; }; // block updates per factorisation
@@ -1584,7 +1736,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	Batch &B = c->B; std::memset(&B, 0, sizeof(B)); B.n_prob = n; B.max_lds_doubles = 0; B.hess_terms = c->lm_terms ? 1 : 0; B.dense_left = c->dense_left ? 1 : 0;
 	char *di = c->d_in, *dw = c->d_wk;
 #define DI(field, T) B.field = (const T *)(di + o.field)
-	B.desc = (const ProbDesc *)(di + o.desc); DI(order, int); DI(sp_col_off, int); DI(sp_row, int); DI(sp_item_off, int); DI(sp_tgt, int); DI(sp_rptr, int); DI(sp_rcol, int); DI(sp_perm, int); DI(hap_rec, int); DI(sp_fill, int); DI(hap_dst, int); DI(hapf_dst, int); DI(hf_dst, int); DI(edge0, double); DI(ulm0, double); DI(klm, double); DI(obs_z, double);
+	B.desc = (const ProbDesc *)(di + o.desc); DI(order, int); DI(sp_col_off, int); DI(sp_row, int); DI(sp_item_off, int); DI(sp_tgt, int); DI(sp_rptr, int); DI(sp_rcol, int); DI(sp_perm, int); DI(hap_rec, int); DI(hapo, int); DI(schl, int); DI(sp_fill, int); DI(hap_dst, int); DI(hapf_dst, int); DI(hf_dst, int); DI(edge0, double); DI(ulm0, double); DI(klm, double); DI(obs_z, double);
 	DI(pair_path_off, int); DI(path_edge, int); DI(obs_pose, int); DI(obs_lm, int); DI(obs_valid, int); DI(bp_col, int); DI(bp_res, int); DI(bp_A, int); DI(bp_D, int); DI(bp_lm, int); DI(colp_off, int);
 	DI(bf_col, int); DI(bf_res, int); DI(bf_pose, int); DI(colf_off, int); DI(hap_i, int); DI(hap_j, int); DI(hap_term_off, int); DI(hap_t1, int); DI(hap_t2, int); DI(hap_tblk, int); DI(hf_i, int); DI(hf_j, int); DI(hf_term_off, int); DI(hf_t1, int); DI(hf_t2, int);
 	DI(hapf_i, int); DI(hapf_j, int); DI(hapf_term_off, int); DI(hapf_t1, int); DI(hapf_t2, int); DI(hap_diag, int); DI(hf_diag, int); DI(sch_term_off, int); DI(sch_b1, int); DI(sch_b2, int); DI(sch_lm, int); DI(sch_yw, int); DI(sch_tblk, int);
@@ -1603,6 +1755,7 @@ c->asm_tab.term = asm_fam ? (const unsigned long long *)(di + o.asm_term) : null
 	const int64_t dbg_len[10] = {t_obs * O, t_bp * O * P, t_bf * O * L, t_hap * P * P, t_hf * L * L, t_hapf * P * L, t_scal, t_scal, t_valid, 2 * t_pair * PD};
 	c->n_pose_total = 2 * t_pair;
 	for (int i = 0; i < 10; i++) { c->off_dbg[i] = dbg_off[i]; c->len_dbg[i] = dbg_len[i]; }
+	if (c->cls_count[SRBA_CLS_WG128] + c->cls_count[SRBA_CLS_WG256] + c->cls_count[SRBA_CLS_WG512] > 0) { if (!c->d_batch) HIPCHK(c, hipMalloc((void **)&c->d_batch, sizeof(Batch))); HIPCHK(c, hipMemcpyAsync(c->d_batch, &c->B, sizeof(Batch), hipMemcpyHostToDevice, c->stream)); /* (c->B lives as long as the context; the stream is waited for before this function returns) */ }
 	c->n_prob = n; st.device_bytes = (int64_t)(in.size + wk.size);
 	c->off_valid = w.valid; c->off_bp_ok = w.bp_ok; c->n_valid_total = t_valid; c->n_bp_total = t_bp; c->asm_flags_set = false;
 	if (c->asm_ready && !c->defer_upload_sync && set_asm_flags(c) != 0) return -1; // (srba_hip_optimize_capsule runs the LM loop only, whose Jacobian phase writes the flags itself: srba_hip_linearize sets them on demand)
@@ -1967,11 +2120,14 @@ static int lm_run_async_impl(srba_hip_ctx *c) {
 		hipStream_t launch_stream = (J.queue && nq > 1) ? c->cls_stream[J.queue] : c->stream;
 		if (J.delay_us > 0) hipLaunchKernelGGL(srbadev::k_delay, dim3(1), dim3(1), 0, launch_stream, J.delay_us);
 		if (k >= SRBA_NLDS) { // landmark windows on a workgroup (k_lm_wg)
+			int rc_attr = 0;
 			with_family(c->params.family, [&](auto fam_) { constexpr int F = decltype(fam_)::value; if constexpr (srbadev::Tr<F>::SE3 && !srbadev::Tr<F>::REL) {
-				if (k == SRBA_CLS_WG256) hipLaunchKernelGGL((srbadev::k_lm_wg<F, 256>), dim3(J.grid), dim3(256), c->cls_lds[k], launch_stream, c->B, c->dp, J.first, J.count, c->d_next + 4 * j);
-				else hipLaunchKernelGGL((srbadev::k_lm_wg<F, 128>), dim3(J.grid), dim3(128), c->cls_lds[k], launch_stream, c->B, c->dp, J.first, J.count, c->d_next + 4 * j); } });
+				if (k == SRBA_CLS_WG512) { if ((rc_attr = allow_big_lds(c, srbadev::k_lm_wg<F, 512>, c->cls_lds[k])) == 0) hipLaunchKernelGGL((srbadev::k_lm_wg<F, 512>), dim3(J.grid), dim3(512), c->cls_lds[k], launch_stream, SRBA_WG_BATCH_VAL(c), c->dp, J.first, J.count, c->d_next + 4 * j); }
+				else if (k == SRBA_CLS_WG256) { if ((rc_attr = allow_big_lds(c, srbadev::k_lm_wg<F, 256>, c->cls_lds[k])) == 0) hipLaunchKernelGGL((srbadev::k_lm_wg<F, 256>), dim3(J.grid), dim3(256), c->cls_lds[k], launch_stream, SRBA_WG_BATCH_VAL(c), c->dp, J.first, J.count, c->d_next + 4 * j); }
+				else hipLaunchKernelGGL((srbadev::k_lm_wg<F, 128>), dim3(J.grid), dim3(128), c->cls_lds[k], launch_stream, SRBA_WG_BATCH_VAL(c), c->dp, J.first, J.count, c->d_next + 4 * j); } });
+			if (rc_attr != 0) return -1;
 			HIPCHK(c, hipGetLastError()); continue; }
-		if (J.two) { const size_t lds1 = (c->cls_lds[k] + c->lds_pad + 7) & ~(size_t)7; hipLaunchKernelGGL((srbadev::k_lm_run2<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(2 * SRBA_WG), lds1 + 32, launch_stream, c->B, c->dp, J.first, J.count, c->d_next + j, (int)(lds1 / 8)); HIPCHK(c, hipGetLastError()); continue; }
+		if (J.two) { const size_t lds1 = (c->cls_lds[k] + c->lds_pad + 7) & ~(size_t)7; hipLaunchKernelGGL((srbadev::k_lm_run2<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(2 * SRBA_WG), lds1 + 32, launch_stream, c->B, c->dp, J.first, J.count, c->d_next + 4 * j, (int)(lds1 / 8)); HIPCHK(c, hipGetLastError()); continue; }
 		if (J.lean) { hipLaunchKernelGGL((srbadev::k_lm_run_lean<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(SRBA_WG), c->cls_lds[k] + c->lds_pad, launch_stream, c->B, c->dp, J.first, J.count, c->d_next + 4 * j); HIPCHK(c, hipGetLastError()); continue; }
 		SRBA_DISPATCH_LDS(c, k_lm_run, J.grid, c->cls_lds[k] + c->lds_pad, J.first, J.count, c->d_next + 4 * j); HIPCHK(c, hipGetLastError());
 	}
@@ -2101,7 +2257,8 @@ int srba_hip_solve(srba_hip_ctx *c, const double *lambda, int32_t *not_pd_out) {
 	for (int k = 0; k < SRBA_NLDS; k++) if (c->cls_count[k]) { hipStream_t launch_stream = c->stream; SRBA_DISPATCH_LDS(c, k_solve, c->cls_count[k], c->cls_lds[k], c->cls_first[k]); HIPCHK(c, hipGetLastError()); }
 	for (int k = SRBA_NLDS; k < SRBA_NCLS - 1; k++) if (c->cls_count[k]) { // landmark windows on a workgroup
 		with_family(c->params.family, [&](auto fam_) { constexpr int F = decltype(fam_)::value; if constexpr (srbadev::Tr<F>::SE3 && !srbadev::Tr<F>::REL) {
-			if (k == SRBA_CLS_WG256) hipLaunchKernelGGL((srbadev::k_solve_wg<F, 256>), dim3(c->cls_count[k]), dim3(256), c->cls_lds[k], c->stream, c->B, c->dp, c->cls_first[k]);
+			if (k == SRBA_CLS_WG512) { if (allow_big_lds(c, srbadev::k_solve_wg<F, 512>, c->cls_lds[k]) == 0) hipLaunchKernelGGL((srbadev::k_solve_wg<F, 512>), dim3(c->cls_count[k]), dim3(512), c->cls_lds[k], c->stream, c->B, c->dp, c->cls_first[k]); }
+			else if (k == SRBA_CLS_WG256) { if (allow_big_lds(c, srbadev::k_solve_wg<F, 256>, c->cls_lds[k]) == 0) hipLaunchKernelGGL((srbadev::k_solve_wg<F, 256>), dim3(c->cls_count[k]), dim3(256), c->cls_lds[k], c->stream, c->B, c->dp, c->cls_first[k]); }
 			else hipLaunchKernelGGL((srbadev::k_solve_wg<F, 128>), dim3(c->cls_count[k]), dim3(128), c->cls_lds[k], c->stream, c->B, c->dp, c->cls_first[k]); } });
 		HIPCHK(c, hipGetLastError()); }
 	{ const int32_t *ord = (const int32_t *)(c->h_in.get() + c->h_off_order); // dense multi-workgroup solver for the capsules of the big class

@@ -27,7 +27,10 @@ typedef double f64x4w __attribute__((ext_vector_type(4)));
 typedef double f64x2w __attribute__((ext_vector_type(2), aligned(16)));
 constexpr int WT = 16;                             // tile edge = the shape of v_mfma_f64_16x16x4_f64
 constexpr int WG_NT_MAX = 32;                      // tile rows of the largest system this path takes: n <= 512 scalars
-constexpr int WG_LDS_DOUBLES = 256 + 512 + 16 * WG_NT_MAX + 8; // diagonal tile staging | two inverse factors (double-buffered) | y / x | group-reduction scratch (4) + flags
+constexpr int WG_LDS_DOUBLES = 256 + 512 + 16 * WG_NT_MAX + 12; // diagonal tile staging | two inverse factors (double-buffered) | y / x | group-reduction scratch (8) | flag, work-counter slot
+constexpr int WG_RED = 768 + 16 * WG_NT_MAX;        // offset of the reduction scratch; the solver's flag is the int at double WG_RED + 8, the kernels' work-counter slot at WG_RED + 9
+constexpr int WG_GACC = WG_LDS_DOUBLES;             // U_Ap-in-LDS path: accumulators of the Schur gradient correction (one per scalar of the reduced system, <= 16 WG_NT_MAX) ...
+constexpr int WG_HS = WG_LDS_DOUBLES + 16 * WG_NT_MAX; // ... and the U_Ap blocks themselves, n_hap x P x P doubles from here
 __host__ __device__ inline int wg_tile(int i, int j) { return i * (i + 1) / 2 + j; } // tile (i, j), j <= i; tile row nt = the right-hand side
 __host__ __device__ inline long long wg_ws_doubles(int nt) { return 256LL * ((long long)(nt + 1) * (nt + 2) / 2 + nt); } // tiles of rows 0 .. nt | nt inverse diagonal factors
 // offset of element (r, c) inside a frag tile
@@ -98,7 +101,7 @@ template <int NW>
 __device__ __forceinline__ bool wg_chol_solve(double *T, double *LI, const int nt, lds_f64 *sm) {
 	static_assert(NW >= 2, "wavefront 0 runs the diagonal chain beside the panel wavefronts");
 	const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-	lds_f64 *smC = sm, *smL = sm + 256, *yb = sm + 768; int __attribute__((address_space(3))) *flag = (int __attribute__((address_space(3))) *)(sm + 768 + 16 * WG_NT_MAX + 4);
+	lds_f64 *smC = sm, *smL = sm + 256, *yb = sm + 768; int __attribute__((address_space(3))) *flag = (int __attribute__((address_space(3))) *)(sm + WG_RED + 8);
 	if (threadIdx.x == 0) *flag = 0;
 	__syncthreads();
 	if (w == 0) { const f64x4w c = wg_ld(T + 256 * (size_t)wg_tile(0, 0), l); if (!wg_diag(c, smC, smL, LI, l) && l == 0) *flag = 1; }
