@@ -335,9 +335,12 @@ def main():
     lo_stamp = (C.c_int64 * 64)(); lo_wg = (C.c_int32 * 64)(); lo_dly = (C.c_int32 * 64)(); lo_n = lib.srba_hip_launch_order(ctx.ctx, lo_stamp, lo_wg, lo_dly, 64)
     lo_t = [int(lo_stamp[j]) for j in range(max(lo_n, 0))]
     launch_order = {"class_launches": int(lo_n), "launch_order_held": bool(lo_n > 0 and all(t > 0 for t in lo_t) and all(b >= a for a, b in zip(lo_t, lo_t[1:]))),
+                    "three_largest_first_in_order": bool(lo_n > 3 and all(t > 0 for t in lo_t) and lo_t[0] <= lo_t[1] <= lo_t[2] <= min(lo_t[3:])),
+                    "start_us_after_first": [round((t - min(lo_t)) / 100.0) for t in lo_t] if lo_t else None,
                     "first_to_last_start_us": (max(lo_t) - min(lo_t)) / 100.0 if lo_t else None, "k_delay_device_us_per_launch": int(sum(lo_dly[j] for j in range(max(lo_n, 0))))}
 
     tot_trials, tot_obs, max_elapsed = multi.aggregate(dist, "cuda" if backend == "nccl" else "cpu", trials_per_step, obs_trials_per_step, elapsed)
+    t_gen, t_harvest, t_upload = multi.max_over_ranks(dist, "cuda" if backend == "nccl" else "cpu", [t_gen, t_harvest, t_upload])   # N > 1: the slowest rank's set-up (the ranks share the host)
 
     if rank == 0:
         stats = ctx.stats(); stats["per_problem"] = per_problem_counts(batch, batch.family)
@@ -409,7 +412,7 @@ def main():
                        "keyframes_per_gpu": args.n_kf, "capsules_per_gpu": batch.n, "lm_trials_per_step_per_gpu": trials_per_step, "floor_trial_share": floor_trial_share, "launch_order": launch_order, "obs_per_s": tot_obs * args.steps / max_elapsed,
                        "parallelism": "replicas x%d (independent maps, no collective)" % world, "process_group": (None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "aggregate_device": "cuda" if backend == "nccl" else "cpu"}),
                        "solver": "no-Schur, block-sparse LL^t in LDS, symbolic factorisation on the host (reference: CSparse)",
-                       "setup_s": {"dataset": round(t_gen, 2), "sequential_slam_harvest_gpu_backend": round(t_harvest, 2), "upload_batch_host_to_hbm": round(t_upload, 3)},
+                       "setup_s": {"max_over_ranks": world > 1, "dataset": round(t_gen, 2), "sequential_slam_harvest_gpu_backend": round(t_harvest, 2), "upload_batch_host_to_hbm": round(t_upload, 3)},
                        "sequential_ms_per_kf": (None if cached else round(1e3 * t_harvest / max(1, args.n_kf), 4)),
                        "host_enqueue_ms_per_step": 1e3 * enq[0] / max(1, args.steps),
                        "pcie_inclusive_lm_iterations_per_s": trials_per_step / (t_upload + 1e-3 * kernel_ms)},

@@ -473,32 +473,36 @@ __global__ void __launch_bounds__(256) k_chol_bsub(const Gang G) {
 	const int tid = threadIdx.x, lane = tid & 63, ld = S.ld, nblk = ld / CB;
 	if (*S.flag) return;
 	double a[CB]; // a[m] = L[m][lane] of the current diagonal block (first wavefront)
-	if (tid < 64) {
+	int cbv = CB; asm volatile("" : "+v"(cbv)); // (row stride of the diagonal factors as a vector value, as for ldv below)
+	if (tid < 64) { const double *row = S.Ldiag + (size_t)(nblk - 1) * CB * CB + (lane < CB ? lane : 0);
 #pragma unroll
-		for (int m = 0; m < CB; m++) a[m] = (lane < CB) ? S.Ldiag[(size_t)((nblk - 1) * CB + m) * CB + lane] : 0.0;
+		for (int m = 0; m < CB; m++) { const double v = *row; a[m] = (lane < CB) ? v : 0.0; row += cbv; }
 	}
 	for (int kb = nblk - 1; kb >= 0; kb--) {
 		const int k0 = kb * CB;
 		if (tid < 64) {
-			double acc = lane < CB ? S.y[k0 + lane] : 0.0, dinv = 1.0;
+			double acc = lane < CB ? S.y[k0 + lane] : 0.0, dsel = 1.0;
 #pragma unroll
-			for (int c = 0; c < CB; c++) if (lane == c) dinv = 1.0 / a[c]; // all the reciprocals of the diagonal at once
+			for (int c = 0; c < CB; c++) dsel = (lane == c) ? a[c] : dsel; // lane c picks its diagonal element (selects: the array stays in registers) ...
+			const double dinv = 1.0 / dsel;                                  // ... and all the reciprocals of the diagonal are ONE division
 #pragma unroll
 			for (int c = CB - 1; c >= 0; c--) { // x_c = (y_c - sum_{m>c} L[m][c] x_m) / L[c][c]
 				const double xc = lane_bcast(acc * dinv, c);
-				if (lane == c) acc = xc; else if (lane < c) acc -= a[c] * xc;
+				acc = (lane == c) ? xc : ((lane < c) ? acc - a[c] * xc : acc); // (branch-free, the update pinned to its broadcast, one scheduling region per step: left to itself the compiler
+				asm volatile("" : "+v"(acc)); __builtin_amdgcn_sched_barrier(0); //  issued the v_readlane pairs of many steps first and spilled them -- 154 SGPR spills, cf. chol_block_solve_regs)
 			}
 			if (lane < CB) { xs[lane] = acc; S.y[k0 + lane] = acc; }
-			if (kb > 0) {
+			if (kb > 0) { const double *row = S.Ldiag + (size_t)(k0 - CB) * CB + (lane < CB ? lane : 0);
 #pragma unroll
-				for (int m = 0; m < CB; m++) a[m] = (lane < CB) ? S.Ldiag[(size_t)(k0 - CB + m) * CB + lane] : 0.0;
+				for (int m = 0; m < CB; m++) { const double v = *row; a[m] = (lane < CB) ? v : 0.0; row += cbv; }
 			}
 		}
 		__syncthreads();
+		int ldv = ld; asm volatile("" : "+v"(ldv)); // (the row stride as a VECTOR value: with a scalar one the 32 row addresses below are 32 scalar register pairs -- 154 SGPR spills)
 		for (int i = tid; i < k0; i += 256) { // y_i -= sum_c L[k0+c][i] x_c
-			double v[CB];
+			double v[CB]; const double *col = S.A + (size_t)k0 * ld + i;
 #pragma unroll
-			for (int c = 0; c < CB; c++) v[c] = S.A[(size_t)(k0 + c) * ld + i];
+			for (int c = 0; c < CB; c++) { v[c] = *col; col += ldv; }
 			double s = 0;
 #pragma unroll
 			for (int c = 0; c < CB; c++) s += v[c] * xs[c];

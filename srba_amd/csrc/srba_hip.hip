@@ -160,19 +160,26 @@ struct Solver : public Worker<FAM, LEAN, G> {
 		__syncthreads();
 		const double *Jp = B.Jp + d.o_bp * O * P; const unsigned char *rp = B.bp_ok + d.o_bp; const int *rec = B.hapo + d.o_hapo * 3;
 		const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0;
-		int ninv = 0, b1 = 0, b2 = 0, blk = 0;
+		// software pipeline, two terms in flight per lane: while term t is summed, the Jacobian blocks of term t + G are on their way and the record of term t + 2 G is requested
+		// (the loop waits for memory: 67 % of the wave cycles of the first version of this kernel were waits at 8 wavefronts per CU -- tools/r5_session5.sh)
+		int ninv = 0, b1 = 0, b2 = 0, blk = 0, n1 = 0, n2 = 0, nb = 0;
+		double A[O * P], Bm[O * P], nA[O * P], nB[O * P]; unsigned char ok1 = 0, ok2 = 0, nok1 = 0, nok2 = 0;
 		if (tid < nt) { b1 = rec[3 * tid]; b2 = rec[3 * tid + 1]; blk = rec[3 * tid + 2]; }
+		if (tid + G < nt) { n1 = rec[3 * (tid + G)]; n2 = rec[3 * (tid + G) + 1]; nb = rec[3 * (tid + G) + 2]; }
+		if (tid < nt) { ldn<O * P>(A, Jp + (long long)b1 * O * P); ldn<O * P>(Bm, Jp + (long long)b2 * O * P); ok1 = rp[b1]; ok2 = rp[b2]; }
 		for (int t = tid; t < nt; t += G) {
-			const int tn = t + G; int n1 = 0, n2 = 0, nb = 0; if (tn < nt) { n1 = rec[3 * tn]; n2 = rec[3 * tn + 1]; nb = rec[3 * tn + 2]; } // (the next record is requested before this term's blocks are waited for)
-			double A[O * P], Bm[O * P]; ldn<O * P>(A, Jp + (long long)b1 * O * P); ldn<O * P>(Bm, Jp + (long long)b2 * O * P);
-			if (rp[b1] && rp[b2]) {
+			const int t2 = t + 2 * G; int m1 = 0, m2 = 0, mb = 0; if (t2 < nt) { m1 = rec[3 * t2]; m2 = rec[3 * t2 + 1]; mb = rec[3 * t2 + 2]; }
+			if (t + G < nt) { ldn<O * P>(nA, Jp + (long long)n1 * O * P); ldn<O * P>(nB, Jp + (long long)n2 * O * P); nok1 = rp[n1]; nok2 = rp[n2]; }
+			if (ok1 && ok2) {
 				double *dst = H + blk * P * P;
 #pragma unroll
 				for (int i = 0; i < P; i++) { double row[P]; W::template hess_row<P, P>(row, A, Bm, i);
 #pragma unroll
 					for (int j = 0; j < P; j++) atomicAdd(dst + i * P + j, row[j] * sc); }
 			} else ninv++;
-			b1 = n1; b2 = n2; blk = nb;
+#pragma unroll
+			for (int q = 0; q < O * P; q++) { A[q] = nA[q]; Bm[q] = nB[q]; }
+			ok1 = nok1; ok2 = nok2; blk = nb; n1 = m1; n2 = m2; nb = mb;
 		}
 		ninv += this->phase_hessian_landmark_blocks();
 		__syncthreads();
@@ -198,13 +205,18 @@ struct Solver : public Worker<FAM, LEAN, G> {
 			__syncthreads();
 			if (pc) { if (tid == 0) pc[14] += wall_clock64() - tq; tq = wall_clock64(); }
 			const int *rec = B.schl + d.o_schl * 4; const double *gf = B.grad + d.o_scal + d.nK * P; const int nt = d.n_sch;
-			int l = 0, b1 = 0, b2 = 0, w = 0;
+			// (two terms in flight per lane, as in phase_hessian_lds: the blocks of term t + G travel while term t is multiplied out)
+			int l = 0, b1 = 0, b2 = 0, w = 0, nl = 0, n1 = 0, n2 = 0, nw = 0; int okc = 0, okn = 0;
+			double W1[P * L], W2[P * L], Hi[L * L], gl[L], nW1[P * L], nW2[P * L], nHi[L * L], ngl[L];
+			auto fetch = [&](int fl, int f1, int f2, double *w1, double *w2, double *hi, double *g3, int &okf) {
+				ldn<P * L>(w1, B.HApf + (d.o_hapf + f1) * P * L); ldn<P * L>(w2, B.HApf + (d.o_hapf + f2) * P * L); ldn<L * L>(hi, B.Hfinv + (d.o_ulm + fl) * L * L); ldn<L>(g3, gf + fl * L); okf = B.hf_ok[d.o_ulm + fl]; };
 			if (tid < nt) { l = rec[4 * tid]; b1 = rec[4 * tid + 1]; b2 = rec[4 * tid + 2]; w = rec[4 * tid + 3]; }
+			if (tid + G < nt) { const int q = tid + G; nl = rec[4 * q]; n1 = rec[4 * q + 1]; n2 = rec[4 * q + 2]; nw = rec[4 * q + 3]; }
+			if (tid < nt) fetch(l, b1, b2, W1, W2, Hi, gl, okc);
 			for (int t = tid; t < nt; t += G) {
-				const int tn = t + G; int nl = 0, n1 = 0, n2 = 0, nw = 0; if (tn < nt) { nl = rec[4 * tn]; n1 = rec[4 * tn + 1]; n2 = rec[4 * tn + 2]; nw = rec[4 * tn + 3]; }
-				double W1[P * L], W2[P * L], Hi[L * L], gl[L];
-				ldn<P * L>(W1, B.HApf + (d.o_hapf + b1) * P * L); ldn<P * L>(W2, B.HApf + (d.o_hapf + b2) * P * L); ldn<L * L>(Hi, B.Hfinv + (d.o_ulm + l) * L * L); ldn<L>(gl, gf + l * L);
-				if (B.hf_ok[d.o_ulm + l] != 0) {
+				const int t2 = t + 2 * G; int ml = 0, m1 = 0, m2 = 0, mw = 0; if (t2 < nt) { ml = rec[4 * t2]; m1 = rec[4 * t2 + 1]; m2 = rec[4 * t2 + 2]; mw = rec[4 * t2 + 3]; }
+				if (t + G < nt) fetch(nl, n1, n2, nW1, nW2, nHi, ngl, okn);
+				if (okc != 0) {
 					const int blk = w & 0xffff, e = (w >> 16) & 0x7fff; const bool diag = w < 0;
 					double *dst = H + blk * P * P;
 #pragma unroll
@@ -226,7 +238,13 @@ struct Solver : public Worker<FAM, LEAN, G> {
 							atomicAdd(gacc + e * P + i, -sm); }
 					}
 				}
-				l = nl; b1 = n1; b2 = n2; w = nw;
+#pragma unroll
+				for (int q = 0; q < P * L; q++) { W1[q] = nW1[q]; W2[q] = nW2[q]; }
+#pragma unroll
+				for (int q = 0; q < L * L; q++) Hi[q] = nHi[q];
+#pragma unroll
+				for (int q = 0; q < L; q++) gl[q] = ngl[q];
+				okc = okn; w = nw; nl = ml; n1 = m1; n2 = m2; nw = mw;
 			}
 			__syncthreads();
 			{ double *g = B.grad + d.o_scal; for (int k = tid; k < d.nK * P; k += G) g[k] += gacc[k]; }

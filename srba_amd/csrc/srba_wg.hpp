@@ -32,7 +32,7 @@ constexpr int WG_RED = 768 + 16 * WG_NT_MAX;        // offset of the reduction s
 constexpr int WG_GACC = WG_LDS_DOUBLES;             // U_Ap-in-LDS path: accumulators of the Schur gradient correction (one per scalar of the reduced system, <= 16 WG_NT_MAX) ...
 constexpr int WG_HS = WG_LDS_DOUBLES + 16 * WG_NT_MAX; // ... and the U_Ap blocks themselves, n_hap x P x P doubles from here
 __host__ __device__ inline int wg_tile(int i, int j) { return i * (i + 1) / 2 + j; } // tile (i, j), j <= i; tile row nt = the right-hand side
-__host__ __device__ inline long long wg_ws_doubles(int nt) { return 256LL * ((long long)(nt + 1) * (nt + 2) / 2 + nt); } // tiles of rows 0 .. nt | nt inverse diagonal factors
+__host__ __device__ inline long long wg_ws_doubles(int nt) { return 256LL * ((long long)(nt + 1) * (nt + 2) / 2 + nt + 4); } // tiles of rows 0 .. nt | nt inverse diagonal factors | 2 x 2 look-ahead partial sums
 // offset of element (r, c) inside a frag tile
 __host__ __device__ inline int wg_frag_off(int r, int c) { return ((r + 16 * (c & 3)) << 2) + (c >> 2); }
 
@@ -59,28 +59,25 @@ __device__ __forceinline__ bool wg_diag(const f64x4w &c, lds_f64 *smC, lds_f64 *
 	double a[16], x[16];
 #pragma unroll
 	for (int q = 0; q < 16; q++) a[q] = smC[wg_frag_off(row, q)];
-	bool ok = true; double rinv = 0;
+	bool ok = true;
 #pragma unroll
-	for (int j = 0; j < 16; j++) { // column j of L: lane i >= j ends with a[j] = L[i][j]; lanes i < j with 0
+	for (int q = 0; q < 16; q++) x[q] = 0;
+	// Column j of L (lane i >= j ends with a[j] = L[i][j], lanes i < j with 0) and, in the same pass, row j of X = L^-1: row j of X needs L[j][0 .. j] and rows 0 .. j-1 of X, all final
+	// once column j is -- lane j hands its row round and the lanes below gather L[i][j] X[j][q]. The two chains (next column of L, this row of X) are independent: they overlap.
+#pragma unroll
+	for (int j = 0; j < 16; j++) {
 		const double dj = wg_bcast(a[j], j);
 		ok &= (dj > 0.0);
 		const double r = wg_rsqrt(dj);
 		const double lj = (row == j) ? dj * r : ((row > j) ? a[j] * r : 0.0);
-		a[j] = lj; rinv = (row == j) ? r : rinv;
+		a[j] = lj;
 #pragma unroll
 		for (int q = j + 1; q < 16; q++) { const double lq = wg_bcast(lj, q); a[q] = fma(-lj, lq, a[q]); asm volatile("" : "+v"(a[q])); /* (pinned where its broadcast is: no pile of spilled v_readlane pairs, cf. chol_block_regs) */ }
-		__builtin_amdgcn_sched_barrier(0);
-	}
-	// X = L^-1, row by row: row m is final once rows 0 .. m-1 have been pushed into it; lane m then hands it round
 #pragma unroll
-	for (int q = 0; q < 16; q++) x[q] = 0;
-#pragma unroll
-	for (int m = 0; m < 16; m++) {
-#pragma unroll
-		for (int q = 0; q <= m; q++) {
-			const double t = ((q == m ? 1.0 : 0.0) - x[q]) * rinv;  // lane m: X[m][q]
-			const double xb = wg_bcast(t, m);
-			x[q] = (row == m) ? t : fma(a[m], xb, x[q]);            // lanes i > m gather L[i][m] X[m][q]; lanes i < m hold a[m] = 0
+		for (int q = 0; q <= j; q++) {
+			const double t = ((q == j ? 1.0 : 0.0) - x[q]) * r;   // lane j: X[j][q] (r = 1 / L[j][j], the same in every lane)
+			const double xb = wg_bcast(t, j);
+			x[q] = (row == j) ? t : fma(lj, xb, x[q]);            // lanes i > j gather L[i][j] X[j][q]; lanes i < j hold lj = 0
 			asm volatile("" : "+v"(x[q]));
 		}
 		__builtin_amdgcn_sched_barrier(0);
@@ -154,16 +151,43 @@ __device__ __forceinline__ bool wg_chol_solve(double *T, double *LI, const int n
 			}
 			solve_store(i0, a00, s0); solve_store(i1, a01, s1);
 		};
+		// Look-ahead: tile row k + 2 is wavefront 0's row of the NEXT step, whose serial chain (row -> diagonal tile -> Cholesky -> inverse) bounds a step. The panel wavefront that
+		// finishes row k + 2 now (wavefront 1: it holds the row's tiles anyway) also forms what that chain needs from the columns before k: s' = sum_{j<k} L_{k+2,j} L_{k+1,j}^t and
+		// ds' = sum_{j<=k} L_{k+2,j} L_{k+2,j}^t, left in the workspace (two tiles per step parity); wavefront 0 then adds the one column that was missing (k) and goes on.
+		double *LA = LI + 256 * (size_t)nt; // [parity][s', ds'][256]
+		auto finish_row_la = [&](int i) { // i = k + 2 <= nt - 1
+			const double *rowi = T + 256 * (size_t)wg_tile(i, 0), *rown = T + 256 * (size_t)wg_tile(k + 1, 0);
+			f64x4w s = zero4, sn = zero4, dsn = zero4;
+			const f64x4w a0 = wg_ld(rowi + 256 * (size_t)k, l);
+			f64x4w A0 = zero4, B0 = zero4, C0 = zero4, nA0 = zero4, nB0 = zero4, nC0 = zero4;
+			if (k > 0) { A0 = wg_ld(rowk, l); B0 = wg_ld(rowi, l); C0 = wg_ld(rown, l); }
+			for (int j = 0; j < k; j++) {
+				if (j + 1 < k) { const size_t o = 256 * (size_t)(j + 1); nA0 = wg_ld(rowk + o, l); nB0 = wg_ld(rowi + o, l); nC0 = wg_ld(rown + o, l); }
+				s = wg_mma(A0, B0, s); sn = wg_mma(C0, B0, sn); dsn = wg_mma(B0, B0, dsn);
+				A0 = nA0; B0 = nB0; C0 = nC0;
+			}
+			const f64x4w dd = solve_store(i, a0, s);
+			dsn = wg_mma(dd, dd, dsn);
+			double *la = LA + 512 * (size_t)((k + 1) & 1); wg_st(la, l, sn); wg_st(la + 256, l, dsn);
+		};
 		if (w == 0) {
 			if (k + 1 < nt) {
-				f64x4w ds = zero4;
-				const f64x4w d1 = finish_row(k + 1, &ds);
-				ds = wg_mma(d1, d1, ds);
+				f64x4w dd;
+				if (k == 0) { f64x4w ds0 = zero4; dd = finish_row(1, &ds0); } // (nothing before column 0)
+				else { // row k + 1: s = s' + L_{k+1,k-1} L_{k,k-1}^t with s', ds' as the look-ahead of step k - 1 left them
+					const double *la = LA + 512 * (size_t)(k & 1);
+					const f64x4w sp = wg_ld(la, l), a0 = wg_ld(T + 256 * (size_t)wg_tile(k + 1, k), l);
+					const f64x4w Ak = wg_ld(rowk + 256 * (size_t)(k - 1), l), Bk = wg_ld(T + 256 * (size_t)wg_tile(k + 1, k - 1), l);
+					dd = solve_store(k + 1, a0, wg_mma(Ak, Bk, sp));
+				}
+				f64x4w ds = (k == 0) ? zero4 : wg_ld(LA + 512 * (size_t)(k & 1) + 256, l);
+				ds = wg_mma(dd, dd, ds);
 				const f64x4w c = wg_ld(T + 256 * (size_t)wg_tile(k + 1, k + 1), l) - ds;
 				if (!wg_diag(c, smC, smL + 256 * ((k + 1) & 1), LI + 256 * (size_t)(k + 1), l) && l == 0) *flag = 1;
 			} else finish_row(nt, nullptr);
 		} else {
 			int i = k + 1 + w;
+			if (w == 1 && k + 2 <= nt - 1) { finish_row_la(k + 2); i += NW - 1; }
 			for (; i + (NW - 1) <= nt; i += 2 * (NW - 1)) finish_rows2(i, i + (NW - 1));
 			if (i <= nt) finish_row(i, nullptr);
 		}

@@ -50,3 +50,12 @@ def aggregate(dist, device, units_per_step, obs_units_per_step, elapsed):
     t = torch.tensor([float(units_per_step), float(obs_units_per_step)], device=device, dtype=torch.float64); dist.all_reduce(t)
     m = torch.tensor([float(elapsed)], device=device, dtype=torch.float64); dist.all_reduce(m, op=dist.ReduceOp.MAX)
     return int(t[0].item()), int(t[1].item()), float(m[0].item())
+
+
+def max_over_ranks(dist, device, values):
+    """element-wise maximum over the ranks of a short list of floats (set-up times in the N > 1 line: the ranks of one node share the host cores); every rank must call it"""
+    if dist is None:
+        return [float(v) for v in values]
+    import torch
+    t = torch.tensor([float(v) for v in values], device=device, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(x) for x in t.tolist()]

@@ -145,20 +145,23 @@ def test_speculative_run_whose_replicas_lose_step_falls_back_to_the_sequential_l
 def test_class_launches_start_largest_footprint_first(se2_batch, monkeypatch):
     """the staggered start of the class launches (plan_launches: every class stream held back by a delay kernel so that the big, LDS-bound classes get
     their workgroups placed before the wave-slot-bound small ones fill the CUs) was a timing heuristic nothing checked. Every persistent launch now stamps the device time at
-    which its first capsule was taken (srba_hip_launch_order); on 24 consecutive launches of a batch with several size classes the stamps must be non-decreasing in plan order."""
+    which its first capsule was taken (srba_hip_launch_order). What the stamps show (tools/diag_launch_stamps.py, profiles/r05_launch_order.txt) and what is asserted here, on 24
+    consecutive launches of a batch with many size classes: the THREE largest-footprint launches start in plan order and before every other launch. The launches after them do
+    not start at their programmed delays but when the dispatcher finds room, in no particular order (wave-slot-bound fillers: their order is immaterial) -- not asserted."""
     import ctypes as C
     fb = _replicate(se2_batch, 40)
     monkeypatch.setenv("SRBA_HIP_LEAN_MIN_COUNT", "64"); monkeypatch.setenv("SRBA_HIP_TWO_MIN_COUNT", "64")
     ctx = runner.HipContext(se2_batch.params); ctx.upload(fb); lib = ctx.lib
-    stamp = (C.c_int64 * 64)(); wgs = (C.c_int32 * 64)(); dly = (C.c_int32 * 64)(); held = 0; njobs = 0
+    stamp = (C.c_int64 * 64)(); wgs = (C.c_int32 * 64)(); dly = (C.c_int32 * 64)(); held = 0; njobs = 0; log = []
     for it in range(25):
         lib.srba_hip_reset_state(ctx.ctx); lib.srba_hip_lm_run_async(ctx.ctx); lib.srba_hip_sync(ctx.ctx)
         njobs = lib.srba_hip_launch_order(ctx.ctx, stamp, wgs, dly, 64)
-        assert njobs >= 3, njobs                                     # several size classes, or the test says nothing
-        t = np.array([stamp[j] for j in range(njobs)]); assert (t > 0).all(), t
-        if it > 0: held += int((np.diff(t) >= 0).all())              # (the first launch pays for module loading)
+        assert njobs >= 5, njobs                                     # several size classes, or the test says nothing
+        t = np.array([stamp[j] for j in range(njobs)]); assert (t > 0).all(), t   # every launch took a capsule
+        ok = bool((np.diff(t[:3]) >= 0).all() and t[:3].max() <= t[3:].min())
+        if it > 0: held += int(ok); log.append(((t - t.min()) / 100.0).round().astype(int).tolist())   # (the first launch pays for module loading)
     ctx.close()
-    assert held == 24, (held, njobs, [dly[j] for j in range(njobs)])
+    assert held == 24, (held, njobs, [dly[j] for j in range(njobs)], log[:3])
 
 
 @pytest.mark.gpu
