@@ -147,16 +147,17 @@ struct Solver : public Worker<FAM, LEAN, G> {
 	// blocks of every K6 term and both U_Apf blocks of every Schur term from memory (terms sorted by OUTPUT block, the sum kept in registers), i.e. every input block 3 .. 9 times per pass.
 	// Here the OUTPUT lives on chip -- n_hap x P x P doubles of LDS, summed with ds_add_f64 -- and the terms are sorted by INPUT (K6: by observation, K7/K8: by landmark), a lane per
 	// term: the lanes of a wavefront touch the same few input blocks at the same time, which then come from the vector L1; HBM sees every input block about once.
+	// (block stride P P + 1 doubles: with 36 the same element of 64 different blocks falls on 8 of the 32 bank pairs of the LDS -- an 8-way conflict on every ds_add_f64 of the term loops)
+	static constexpr int HS = P * P + 1;
 	__device__ __forceinline__ double *hs() const { return srba_lds + WG_HS; }
 	__device__ __forceinline__ void store_hs(bool latch_too) { this->fresh(); // the LDS blocks -> U_Ap (and its latch, schur.h:38) in memory, 16 bytes per lane and request
-		const double *H = hs(); double *Hg = B.HAp + d.o_hap * P * P, *H0 = B.HAp0 + d.o_hap * P * P; const int n_acc = d.n_hap * P * P;
-		for (int k = 2 * tid; k + 1 < n_acc; k += 2 * G) { f64x2u v; v.x = H[k]; v.y = H[k + 1]; *(f64x2u *)(Hg + k) = v; if (latch_too) *(f64x2u *)(H0 + k) = v; }
-		if ((n_acc & 1) && tid == 0) { Hg[n_acc - 1] = H[n_acc - 1]; if (latch_too) H0[n_acc - 1] = H[n_acc - 1]; }
+		const double *H = hs(); double *Hg = B.HAp + d.o_hap * P * P, *H0 = B.HAp0 + d.o_hap * P * P; const int n_acc = d.n_hap * P * P; static_assert((P * P) % 2 == 0, "pairs of doubles inside a block");
+		for (int k = 2 * tid; k < n_acc; k += 2 * G) { const int b = k / (P * P), e = k - b * (P * P); f64x2u v; v.x = H[b * HS + e]; v.y = H[b * HS + e + 1]; *(f64x2u *)(Hg + k) = v; if (latch_too) *(f64x2u *)(H0 + k) = v; }
 	}
 	// K6 (sparse_hessian_update_numeric.h:22-60): U_Ap summed in LDS from the term list sorted by observation; U_f and U_Apf as before (their lists are a landmark's observations: short)
 	__device__ __forceinline__ int phase_hessian_lds() { this->fresh();
-		double *H = hs(); const int n_acc = d.n_hap * P * P, nt = d.n_hapt;
-		for (int k = tid; k < n_acc; k += G) H[k] = 0;
+		double *H = hs(); const int nt = d.n_hapt;
+		for (int k = tid; k < d.n_hap * HS; k += G) H[k] = 0;
 		__syncthreads();
 		const double *Jp = B.Jp + d.o_bp * O * P; const unsigned char *rp = B.bp_ok + d.o_bp; const int *rec = B.hapo + d.o_hapo * 3;
 		const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0;
@@ -171,7 +172,7 @@ struct Solver : public Worker<FAM, LEAN, G> {
 			const int t2 = t + 2 * G; int m1 = 0, m2 = 0, mb = 0; if (t2 < nt) { m1 = rec[3 * t2]; m2 = rec[3 * t2 + 1]; mb = rec[3 * t2 + 2]; }
 			if (t + G < nt) { ldn<O * P>(nA, Jp + (long long)n1 * O * P); ldn<O * P>(nB, Jp + (long long)n2 * O * P); nok1 = rp[n1]; nok2 = rp[n2]; }
 			if (ok1 && ok2) {
-				double *dst = H + blk * P * P;
+				double *dst = H + blk * HS;
 #pragma unroll
 				for (int i = 0; i < P; i++) { double row[P]; W::template hess_row<P, P>(row, A, Bm, i);
 #pragma unroll
@@ -199,8 +200,7 @@ struct Solver : public Worker<FAM, LEAN, G> {
 				if (ok) for (int k = 0; k < L * L; k++) B.Hfinv[(d.o_ulm + l) * L * L + k] = Mi[k];
 			}
 			{ const double *H0 = B.HAp0 + d.o_hap * P * P;
-			  for (int k = 2 * tid; k + 1 < n_acc; k += 2 * G) { const f64x2u v = *(const f64x2u *)(H0 + k); H[k] = v.x; H[k + 1] = v.y; }
-			  if ((n_acc & 1) && tid == 0) H[n_acc - 1] = H0[n_acc - 1];
+			  for (int k = 2 * tid; k < n_acc; k += 2 * G) { const int b = k / (P * P), e = k - b * (P * P); const f64x2u v = *(const f64x2u *)(H0 + k); H[b * HS + e] = v.x; H[b * HS + e + 1] = v.y; }
 			  for (int k = tid; k < d.nK * P; k += G) gacc[k] = 0; }
 			__syncthreads();
 			if (pc) { if (tid == 0) pc[14] += wall_clock64() - tq; tq = wall_clock64(); }
@@ -218,7 +218,7 @@ struct Solver : public Worker<FAM, LEAN, G> {
 				if (t + G < nt) fetch(nl, n1, n2, nW1, nW2, nHi, ngl, okn);
 				if (okc != 0) {
 					const int blk = w & 0xffff, e = (w >> 16) & 0x7fff; const bool diag = w < 0;
-					double *dst = H + blk * P * P;
+					double *dst = H + blk * HS;
 #pragma unroll
 					for (int i = 0; i < P; i++) {
 						double y[L];
@@ -254,6 +254,49 @@ struct Solver : public Worker<FAM, LEAN, G> {
 	}
 	// K10 (schur.h:271-311)
 	__device__ __forceinline__ void schur_features() { this->fresh();
+		if constexpr (!W::T::REL && LEAN) { // workgroup kernels: a landmark's U_Apf blocks were a serial chain of (index, block, increment) loads per lane, with as many lanes busy as the window has
+			// landmarks. Two passes instead: a lane per U_Apf block forms W^t delta_i (three numbers, parked in the block's slot of Yh), then a lane per landmark sums its blocks' three
+			// numbers (independent loads), finishes g_l and multiplies by Hf^-1. Same sums in the same order per landmark.
+			double *g = B.grad + d.o_scal, *dl = B.delta + d.o_scal;
+			for (int hb = tid; hb < d.n_hapf; hb += G) {
+				const int i = B.hapf_i[d.o_hapf + hb]; double Wm[P * L], di[P]; ldn<P * L>(Wm, B.HApf + (d.o_hapf + hb) * P * L); ldn<P>(di, dl + i * P);
+				double pk[L];
+#pragma unroll
+				for (int k = 0; k < L; k++) { double sm = 0;
+#pragma unroll
+					for (int r = 0; r < P; r++) sm += Wm[r * L + k] * di[r];
+					pk[k] = sm; }
+				double *o = B.Yh + (d.o_hapf + hb) * P * L;
+#pragma unroll
+				for (int k = 0; k < L; k++) o[k] = pk[k];
+			}
+			__syncthreads();
+			for (int l = tid; l < d.nF; l += G) {
+				if (!B.hf_ok[d.o_ulm + l]) continue;
+				double gl[L]; ldn<L>(gl, g + d.nK * P + l * L);
+				const int qb = B.lm_hapf_off[d.o_lmoff + l], qe = B.lm_hapf_off[d.o_lmoff + l + 1];
+				for (int q = qb; q < qe; q += 4) { // four blocks' numbers in flight
+					double pk[4][L];
+#pragma unroll
+					for (int u = 0; u < 4; u++) if (q + u < qe) { const int hb = B.lm_hapf_idx[d.o_hapf + q + u]; const double *o = B.Yh + (d.o_hapf + hb) * P * L;
+#pragma unroll
+						for (int k = 0; k < L; k++) pk[u][k] = o[k]; }
+#pragma unroll
+					for (int u = 0; u < 4; u++) if (q + u < qe) {
+#pragma unroll
+						for (int k = 0; k < L; k++) gl[k] -= pk[u][k]; }
+				}
+				double Hi[L * L]; ldn<L * L>(Hi, B.Hfinv + (d.o_ulm + l) * L * L);
+#pragma unroll
+				for (int k = 0; k < L; k++) g[d.nK * P + l * L + k] = gl[k];
+#pragma unroll
+				for (int r = 0; r < L; r++) { double sm = 0;
+#pragma unroll
+					for (int k = 0; k < L; k++) sm += Hi[r * L + k] * gl[k];
+					dl[d.nK * P + l * L + r] = sm; }
+			}
+			__syncthreads();
+		} else
 		if constexpr (!W::T::REL) {
 			double *g = B.grad + d.o_scal, *dl = B.delta + d.o_scal;
 			for (int l = tid; l < d.nF; l += G) {
@@ -359,14 +402,14 @@ struct Solver : public Worker<FAM, LEAN, G> {
 	// The Schur-reduced system H_Ap' + lambda I and its right-hand side as 16 x 16 frag tiles (srba_wg.hpp; lev-marq_solvers.h:492-519 builds the same dense matrix for Eigen::LLT):
 	// the area is cleared, then every upper-triangle U_Ap block (i <= j) lands transposed in the lower triangle; rows beyond n_sys get an identity diagonal; the gradient is tile row nt.
 	__device__ __forceinline__ void assemble_tiles(const SparseSys &S, double lambda) { this->fresh();
-		const int n = d.n_sys, nt = S.nt; double *T = S.tiles; const double *Hsrc = d.hs_lds ? hs() : B.HAp + d.o_hap * P * P; // the reduced U_Ap blocks: in LDS or in memory
+		const int n = d.n_sys, nt = S.nt; double *T = S.tiles; const double *Hsrc = d.hs_lds ? hs() : B.HAp + d.o_hap * P * P; const int hstride = d.hs_lds ? HS : P * P; // the reduced U_Ap blocks: in LDS or in memory
 		{ const long long n2 = 128LL * (nt + 1) * (nt + 2) / 2; f64x2u z; z.x = 0; z.y = 0; for (long long k = tid; k < n2; k += G) *(f64x2u *)(T + 2 * k) = z; }
 		__syncthreads();
 		auto at = [&](int r, int c) -> double * { return T + 256 * (long long)wg_tile(r >> 4, c >> 4) + wg_frag_off(r & 15, c & 15); }; // element (r, c), r >= c
 		for (int e0 = tid; e0 < d.n_hap * P; e0 += 2 * G) { // a lane per block ROW, two in flight: the block's position and its six numbers are requested together (the loop waits for memory, not for arithmetic)
 			int bi[2], bj[2], rr[2]; bool live[2]; double v[2][P];
 #pragma unroll
-			for (int u = 0; u < 2; u++) { const int e = e0 + u * G; live[u] = e < d.n_hap * P; const int b = live[u] ? e / P : 0; rr[u] = e % P; bi[u] = B.hap_i[d.o_hap + b]; bj[u] = B.hap_j[d.o_hap + b]; const double *src = Hsrc + b * P * P + rr[u] * P;
+			for (int u = 0; u < 2; u++) { const int e = e0 + u * G; live[u] = e < d.n_hap * P; const int b = live[u] ? e / P : 0; rr[u] = e % P; bi[u] = B.hap_i[d.o_hap + b]; bj[u] = B.hap_j[d.o_hap + b]; const double *src = Hsrc + b * hstride + rr[u] * P;
 #pragma unroll
 				for (int q = 0; q < P; q++) v[u][q] = src[q]; }
 #pragma unroll
@@ -1552,7 +1595,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		d.hs_lds = 0; d.o_hapo = t_hapo; d.o_schl = t_schl;
 		if (to_wg) { const int nt = (d.n_sys + srbadev::WT - 1) / srbadev::WT; d.dense_blocks = 3; d.nnzoff = 0; d.n_items = 0; wave_ws = srbadev::wg_ws_doubles(nt);
 			// LDS of the workgroup: the solver's scratch + (when they fit its class) the U_Ap blocks of the window, summed on chip (Solver::phase_hessian_lds / schur_reduce_lds)
-			const size_t base = 8 * (size_t)srbadev::WG_LDS_DOUBLES, with_hs = 8 * ((size_t)srbadev::WG_HS + (size_t)k.n_hap * P * P); const bool idx_ok = k.n_hap < 65536 && d.nK < 32768;
+			const size_t base = 8 * (size_t)srbadev::WG_LDS_DOUBLES, with_hs = 8 * ((size_t)srbadev::WG_HS + (size_t)k.n_hap * (P * P + 1)); const bool idx_ok = k.n_hap < 65536 && d.nK < 32768;
 			size_t need = base;
 			if (c->wg_hs && idx_ok && with_hs <= (size_t)40 * 1024 && d.n_sys < c->wg256_from_sys) { cls[p] = SRBA_CLS_WG128; d.hs_lds = 1; need = with_hs; }
 			else if (c->wg_hs && idx_ok && with_hs <= (size_t)80 * 1024) { cls[p] = SRBA_CLS_WG256; d.hs_lds = 1; need = with_hs; }
