@@ -727,10 +727,16 @@ struct Worker {
 	typedef Tr<FAM> T; typedef PoseOps<T::SE3> PO; typedef typename PO::T pose_t;
 	static constexpr int P = T::P, L = T::L, O = T::O, PD = T::PD;
 	const Batch &B; const ProbDesc &d; const DevParams &prm; int tid;
+	const int cp; // which copy of the unknowns / spanning-tree poses this worker reads and writes as "the state" (double-buffered LM loop: 0 = edge / ulm / pose, 1 = edge1 / ulm1 / pose1)
+	__device__ __forceinline__ double *E() const { return cp ? B.edge1 : B.edge; }    // the state ...
+	__device__ __forceinline__ double *U() const { return cp ? B.ulm1 : B.ulm; }
+	__device__ __forceinline__ double *Pz() const { return cp ? B.pose1 : B.pose; }
+	__device__ __forceinline__ double *Eo() const { return cp ? B.edge : B.edge1; }   // ... and the other copy (where a trial goes)
+	__device__ __forceinline__ double *Uo() const { return cp ? B.ulm : B.ulm1; }
 	// Re-materialise the lane id at the head of every phase: it stops the compiler from hoisting the per-lane address arithmetic of ALL
 	// phases out of the LM loop (which costs >100 VGPRs of loop-invariant addresses and halves the occupancy).
 	__device__ __forceinline__ void fresh() { int t = threadIdx.x; asm volatile("" : "+v"(t)); tid = t; }
-	__device__ Worker(const Batch &B_, const ProbDesc &d_, const DevParams &p_) : B(B_), d(d_), prm(p_), tid(threadIdx.x) {}
+	__device__ Worker(const Batch &B_, const ProbDesc &d_, const DevParams &p_, int cp_ = 0) : B(B_), d(d_), prm(p_), tid(threadIdx.x), cp(cp_) {}
 
 	// A table index that widens to 64 bits for address arithmetic is made an opaque 64-bit value first. Why: clang 22 (ROCm 7.2) proves `idx >= 0` inside the guarded branch, drops the
 	// extension and, in the 400..512-VGPR landmark kernels, built the register pair v[N:N+1] of the widened index from the loaded dword and a register that had meanwhile been reused for
@@ -740,8 +746,8 @@ struct Worker {
 	// Round 4: the 32-bit value is made opaque BEFORE it is widened (the compiler then knows nothing about its sign and has to compute the high word from it: v_ashrrev_i32 hi, 31, lo); with the
 	// barrier after the widening the pair could still be formed from a register the compiler believed to hold the zero extension (tools/scan_undef_hi.py found six such pairs in the stereo kernel).
 	static __device__ __forceinline__ long long wide(int i) { if constexpr (FAM != SRBA_SE2_RELPOSE2D) asm volatile("" : "+v"(i)); long long w = i; if constexpr (FAM != SRBA_SE2_RELPOSE2D) asm volatile("" : "+v"(w)); return w; }
-	__device__ __forceinline__ pose_t pose_at(int idx) const { return idx >= 0 ? PO::ld(B.pose + (d.o_pair * 2 + wide(idx)) * PD) : PO::ident(); }
-	__device__ __forceinline__ const double *lm_ptr(int ref) const { return ref >= 0 ? B.ulm + (d.o_ulm + wide(ref)) * L : B.klm + (d.o_klm + wide(-1 - ref)) * L; }
+	__device__ __forceinline__ pose_t pose_at(int idx) const { return idx >= 0 ? PO::ld(Pz() + (d.o_pair * 2 + wide(idx)) * PD) : PO::ident(); }
+	__device__ __forceinline__ const double *lm_ptr(int ref) const { return ref >= 0 ? U() + (d.o_ulm + wide(ref)) * L : B.klm + (d.o_klm + wide(-1 - ref)) * L; }
 
 	// ---- K1
 	// edge_lds: optional copy of ALL edge poses of the capsule in LDS (stride PD, local edge order) -- the in-loop refresh then composes from LDS instead of
@@ -778,7 +784,7 @@ struct Worker {
 #pragma unroll
 								for (int k = 0; k < PD; k++) t[k] = src[k];
 								ed[v][u] = PO::from(t); }
-							else ed[v][u] = PO::ld(B.edge + (d.o_edge + (pe[v][u0 + u] >> 1)) * PD);
+							else ed[v][u] = PO::ld(E() + (d.o_edge + (pe[v][u0 + u] >> 1)) * PD);
 						}
 #pragma unroll
 					for (int v = 0; v < V; v++)
@@ -787,8 +793,8 @@ struct Worker {
 				}
 #pragma unroll
 				for (int v = 0; v < V; v++) if (p[v] >= 0) {
-					PO::st(B.pose + (d.o_pair + p[v]) * 2 * PD, acc[v]);
-					PO::st(B.pose + ((d.o_pair + p[v]) * 2 + 1) * PD, inv(acc[v]));
+					PO::st(Pz() + (d.o_pair + p[v]) * 2 * PD, acc[v]);
+					PO::st(Pz() + ((d.o_pair + p[v]) * 2 + 1) * PD, inv(acc[v]));
 				}
 			} };
 			if (edge_lds) refresh(std::true_type()); else refresh(std::false_type());
@@ -808,7 +814,7 @@ struct Worker {
 #pragma unroll
 			for (int v = 0; v < V; v++)
 #pragma unroll
-				for (int u = 0; u < U; u++) if (pe[v][u] >= 0) ed[v][u] = PO::ld(B.edge + (d.o_edge + (pe[v][u] >> 1)) * PD);
+				for (int u = 0; u < U; u++) if (pe[v][u] >= 0) ed[v][u] = PO::ld(E() + (d.o_edge + (pe[v][u] >> 1)) * PD);
 #pragma unroll
 			for (int v = 0; v < V; v++) {
 				acc[v] = PO::ident();
@@ -816,15 +822,15 @@ struct Worker {
 				for (int u = 0; u < U; u++) if (pe[v][u] >= 0) acc[v] = (pe[v][u] & 1) ? comp(acc[v], inv(ed[v][u])) : comp(acc[v], ed[v][u]);
 				for (int k = b[v] + U; k < e[v]; k++) {
 					const int pk = B.path_edge[d.o_path + k];
-					const pose_t ek = PO::ld(B.edge + (d.o_edge + (pk >> 1)) * PD);
+					const pose_t ek = PO::ld(E() + (d.o_edge + (pk >> 1)) * PD);
 					acc[v] = (pk & 1) ? comp(acc[v], inv(ek)) : comp(acc[v], ek);
 				}
 			}
 #pragma unroll
 			for (int v = 0; v < V; v++) if (p[v] >= 0) {
 				const pose_t ia = inv(acc[v]);
-				PO::st(B.pose + (d.o_pair + p[v]) * 2 * PD, acc[v]);
-				PO::st(B.pose + ((d.o_pair + p[v]) * 2 + 1) * PD, ia);
+				PO::st(Pz() + (d.o_pair + p[v]) * 2 * PD, acc[v]);
+				PO::st(Pz() + ((d.o_pair + p[v]) * 2 + 1) * PD, ia);
 				if (pose2) { PO::st(pose2 + (d.o_pair + p[v]) * 2 * PD, acc[v]); PO::st(pose2 + ((d.o_pair + p[v]) * 2 + 1) * PD, ia); }
 			}
 		}
@@ -988,7 +994,7 @@ struct Worker {
 		double Jl[O * P]; bool ok = true;
 		if constexpr (!T::SE3) {
 			if (!normal) { // D' = p (+) D ; A' = A (+) (-)p (jacobians.h:565-587,684-711)
-				const P2 p = ld2(B.edge + (d.o_edge + B.bp_col[gb]) * PD);
+				const P2 p = ld2(E() + (d.o_edge + B.bp_col[gb]) * PD);
 				D = comp(p, D);
 				if constexpr (!T::REL) { A = hasA ? comp(A, inv(p)) : inv(p); hasA = true; } // the relative-pose block depends on D' only
 			}
@@ -1025,7 +1031,7 @@ struct Worker {
 		} else if constexpr (FAM == SRBA_SE3_RELPOSE3D) { // jacobians.h:748-873: J = [d pseudo_ln / d (R,t)] (6x12) * [d (A e^eps D) / d eps] (12x6)
 			double RA[9];
 			if (!normal) { // D' = p (+) D ; A' = A (+) (-)p
-				const P3 p = ld3(B.edge + (d.o_edge + B.bp_col[gb]) * PD); const P3 pin = inv(p);
+				const P3 p = ld3(E() + (d.o_edge + B.bp_col[gb]) * PD); const P3 pin = inv(p);
 				D = comp(p, D); const P3 Ap = hasA ? comp(A, pin) : pin;
 				for (int k = 0; k < 9; k++) RA[k] = Ap.R[k]; A = Ap; hasA = true;
 			} else if (hasA) { for (int k = 0; k < 9; k++) RA[k] = A.R[k]; }
@@ -1071,7 +1077,7 @@ struct Worker {
 			double H[O * 3]; ok = dh_dx(H, xl);
 			if (ok) {
 				if (!normal) { // D' = p (+) D ; R(A') = R(A) R(p)^t (jacobians.h:436-461)
-					const P3 p = ld3(B.edge + (d.o_edge + B.bp_col[gb]) * PD);
+					const P3 p = ld3(E() + (d.o_edge + B.bp_col[gb]) * PD);
 					D = comp(p, D);
 					double T2[9];
 					if (hasA) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) T2[3 * i + j] = A.R[3 * i] * p.R[3 * j] + A.R[3 * i + 1] * p.R[3 * j + 1] + A.R[3 * i + 2] * p.R[3 * j + 2]; }
@@ -1101,7 +1107,7 @@ struct Worker {
 			double *J = B.Jf + (long long)gb * O * L;
 			const int ip = B.bf_pose[gb];
 			const pose_t bp = pose_at(ip);
-			const double *xi = B.ulm + (d.o_ulm + B.bf_col[gb]) * L;
+			const double *xi = U() + (d.o_ulm + B.bf_col[gb]) * L;
 			double Jl[O * L]; bool ok;
 			if constexpr (FAM == SRBA_SE2_STEREO) { // dh_dx * R(base <- obs), R = the 3x3 rotation about z of the 2D pose (jacobians.h:984-989)
 				const double s = bp.s, c = bp.c;
@@ -1399,6 +1405,17 @@ __device__ __forceinline__ bool spec_exchange(const SpecCtl &sc, int round, int 
 	return any_late == 0;
 }
 __device__ __forceinline__ double spec_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// A reference to an object in (read-only) global memory through a pointer the optimiser knows nothing about. Why: the ~100 array pointers of `Batch` and the ~50 sizes / offsets of a
+// `ProbDesc` are uniform, loop-invariant loads; the compiler hoists every one of them to the top of the LM loop and keeps them live across it -- far more than the 102 scalar registers hold,
+// so they live in VGPR lanes (220 - 530 spilled scalars per kernel) and every use inside a hot loop is a v_readlane first. Each PHASE of the loop is handed its own laundered reference
+// (lm_one: a fresh Solver per phase call): its loads cannot be merged with another phase's, so a pointer is live for one phase -- a scalar load when the phase starts instead of a
+// register for the whole run. The memory is read-only for the duration of the kernel: constant address space, scalar loads.
+template <class T> __device__ __forceinline__ const T &lnd(const T &r) {
+	unsigned long long a = (unsigned long long)&r; // (uniform in fact -- the capsule index comes from a work counter -- but not always to the divergence analysis: v_readfirstlane makes it a scalar either way)
+	const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+	a = ((unsigned long long)hi << 32) | lo; asm volatile("" : "+s"(a));
+	return *(const T *)(const __attribute__((address_space(4))) T *)a;
+}
 __device__ __forceinline__ Batch copy_view(const Batch &B, int copy) { Batch V = B; if (copy) { V.edge = B.edge1; V.ulm = B.ulm1; V.pose = B.pose1; } return V; }
 
 } // namespace srbadev

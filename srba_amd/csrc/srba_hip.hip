@@ -39,10 +39,10 @@ extern __shared__ double srba_lds[]; // block-sparse system of the capsule (diag
 
 template <int FAM, bool LEAN = false, int G = 64>
 struct Solver : public Worker<FAM, LEAN, G> {
-	typedef Worker<FAM, LEAN, G> W; using W::B; using W::d; using W::prm; using W::tid;
+	typedef Worker<FAM, LEAN, G> W; using W::B; using W::d; using W::prm; using W::tid; using W::E; using W::U; using W::Pz; using W::Eo; using W::Uo;
 	static constexpr int P = W::P, L = W::L, O = W::O, PD = W::PD;
 	double *red2w = nullptr; // G = 128: two doubles of LDS behind the image (group reductions, the solver's verdict)
-	__device__ Solver(const Batch &B_, const ProbDesc &d_, const DevParams &p_, double *red_ = nullptr) : W(B_, d_, p_), red2w(red_) {}
+	__device__ Solver(const Batch &B_, const ProbDesc &d_, const DevParams &p_, double *red_ = nullptr, int cp_ = 0) : W(B_, d_, p_, cp_), red2w(red_) {}
 	__device__ __forceinline__ bool schur_active() const { return prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0; }
 
 	// K7 + K8 (schur.h:180-268). Mutates HAp and minus_grad in place like the reference.
@@ -83,7 +83,7 @@ struct Solver : public Worker<FAM, LEAN, G> {
 				const int T = B.sch_term_off[d.o_hapoff + d.n_hap], per = (T + G - 1) / G, tb = tid * per, te = min(T, tb + per);
 				const int *s_lm = B.sch_lm + d.o_sch, *s_b1 = B.sch_b1 + d.o_sch, *s_b2 = B.sch_b2 + d.o_sch, *s_yw = B.sch_yw + d.o_sch, *s_blk = B.sch_tblk + d.o_sch;
 				int cur = -1; bool curdiag = false; double Hl[P * P], ga[P];
-				auto flush = [&]() {
+				auto flush = [&]() __attribute__((always_inline)) {
 					if (cur < 0) return;
 					const long long cw = W::wide(cur); // (an index proved non-negative that enters 64-bit address arithmetic: see Worker::wide)
 					double *H = B.HAp + (d.o_hap + cw) * P * P;
@@ -208,7 +208,7 @@ struct Solver : public Worker<FAM, LEAN, G> {
 			// (two terms in flight per lane, as in phase_hessian_lds: the blocks of term t + G travel while term t is multiplied out)
 			int l = 0, b1 = 0, b2 = 0, w = 0, nl = 0, n1 = 0, n2 = 0, nw = 0; int okc = 0, okn = 0;
 			double W1[P * L], W2[P * L], Hi[L * L], gl[L], nW1[P * L], nW2[P * L], nHi[L * L], ngl[L];
-			auto fetch = [&](int fl, int f1, int f2, double *w1, double *w2, double *hi, double *g3, int &okf) {
+			auto fetch = [&](int fl, int f1, int f2, double *w1, double *w2, double *hi, double *g3, int &okf) __attribute__((always_inline)) {
 				ldn<P * L>(w1, B.HApf + (d.o_hapf + f1) * P * L); ldn<P * L>(w2, B.HApf + (d.o_hapf + f2) * P * L); ldn<L * L>(hi, B.Hfinv + (d.o_ulm + fl) * L * L); ldn<L>(g3, gf + fl * L); okf = B.hf_ok[d.o_ulm + fl]; };
 			if (tid < nt) { l = rec[4 * tid]; b1 = rec[4 * tid + 1]; b2 = rec[4 * tid + 2]; w = rec[4 * tid + 3]; }
 			if (tid + G < nt) { const int q = tid + G; nl = rec[4 * q]; n1 = rec[4 * q + 1]; n2 = rec[4 * q + 2]; nw = rec[4 * q + 3]; }
@@ -405,7 +405,7 @@ struct Solver : public Worker<FAM, LEAN, G> {
 		const int n = d.n_sys, nt = S.nt; double *T = S.tiles; const double *Hsrc = d.hs_lds ? hs() : B.HAp + d.o_hap * P * P; const int hstride = d.hs_lds ? HS : P * P; // the reduced U_Ap blocks: in LDS or in memory
 		{ const long long n2 = 128LL * (nt + 1) * (nt + 2) / 2; f64x2u z; z.x = 0; z.y = 0; for (long long k = tid; k < n2; k += G) *(f64x2u *)(T + 2 * k) = z; }
 		__syncthreads();
-		auto at = [&](int r, int c) -> double * { return T + 256 * (long long)wg_tile(r >> 4, c >> 4) + wg_frag_off(r & 15, c & 15); }; // element (r, c), r >= c
+		auto at = [&](int r, int c) __attribute__((always_inline)) -> double * { return T + 256 * (long long)wg_tile(r >> 4, c >> 4) + wg_frag_off(r & 15, c & 15); }; // element (r, c), r >= c
 		for (int e0 = tid; e0 < d.n_hap * P; e0 += 2 * G) { // a lane per block ROW, two in flight: the block's position and its six numbers are requested together (the loop waits for memory, not for arithmetic)
 			int bi[2], bj[2], rr[2]; bool live[2]; double v[2][P];
 #pragma unroll
@@ -498,15 +498,15 @@ struct Solver : public Worker<FAM, LEAN, G> {
 		typedef typename W::PO PO;
 		const double *dl = B.delta + d.o_scal;
 		for (int i = tid; i < d.nK; i += G) {
-			double *e = B.edge + (d.o_edge + i) * PD, *o = B.old_edge + (d.o_unk + i) * PD;
+			double *e = E() + (d.o_edge + i) * PD, *o = B.old_edge + (d.o_unk + i) * PD;
 			for (int k = 0; k < PD; k++) o[k] = e[k];
 			const typename W::pose_t np = comp(PO::expm(dl + i * P), PO::ld(e));
 			PO::st(e, np);
 		}
-		for (int k = tid; k < d.nF * L; k += G) { B.old_ulm[d.o_ulm * L + k] = B.ulm[d.o_ulm * L + k]; B.ulm[d.o_ulm * L + k] += dl[d.nK * P + k]; }
+		for (int k = tid; k < d.nF * L; k += G) { B.old_ulm[d.o_ulm * L + k] = U()[d.o_ulm * L + k]; U()[d.o_ulm * L + k] += dl[d.nK * P + k]; }
 		for (int r = tid; r < d.n_req; r += 2 * G) { // two poses per lane and pass: both loads before the stores
 			const int r2 = r + G; const bool two = r2 < d.n_req;
-			const double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD, *s2 = two ? B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r2]) * PD : s;
+			const double *s = Pz() + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD, *s2 = two ? Pz() + (d.o_pair * 2 + B.req_idx[d.o_req + r2]) * PD : s;
 			double v[PD], v2[PD];
 #pragma unroll
 			for (int k = 0; k < PD; k++) { v[k] = s[k]; v2[k] = s2[k]; }
@@ -527,7 +527,7 @@ struct Solver : public Worker<FAM, LEAN, G> {
 		const double *dl = B.delta + d.o_scal;
 		const bool stage = d.dense_in_lds && d.n_edges * PD <= 9 * S.nnzoff; double *el = S.off;
 		for (int i = tid; i < (stage ? d.n_edges : d.nK); i += G) {
-			double *e = B.edge + (d.o_edge + i) * PD; pose_t cur = PO::ld(e);
+			double *e = E() + (d.o_edge + i) * PD; pose_t cur = PO::ld(e);
 			if (i < d.nK) {
 				double inc[P];
 #pragma unroll
@@ -540,10 +540,10 @@ struct Solver : public Worker<FAM, LEAN, G> {
 #pragma unroll
 				for (int k = 0; k < PD; k++) el[i * PD + k] = t[k]; }
 		}
-		for (int k = tid; k < d.nF * L; k += G) { B.old_ulm[d.o_ulm * L + k] = B.ulm[d.o_ulm * L + k]; B.ulm[d.o_ulm * L + k] += dl[d.nK * P + k]; }
+		for (int k = tid; k < d.nF * L; k += G) { B.old_ulm[d.o_ulm * L + k] = U()[d.o_ulm * L + k]; U()[d.o_ulm * L + k] += dl[d.nK * P + k]; }
 		for (int r = tid; r < d.n_req; r += 2 * G) { // two poses per lane and pass: both loads before the stores
 			const int r2 = r + G; const bool two = r2 < d.n_req;
-			const double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD, *s2 = two ? B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r2]) * PD : s;
+			const double *s = Pz() + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD, *s2 = two ? Pz() + (d.o_pair * 2 + B.req_idx[d.o_req + r2]) * PD : s;
 			double v[PD], v2[PD]; ldn<PD>(v, s); ldn<PD>(v2, s2);
 			stn<PD>(B.old_pose + (d.o_req + r) * PD, v);
 			if (two) stn<PD>(B.old_pose + (d.o_req + r2) * PD, v2);
@@ -556,31 +556,31 @@ struct Solver : public Worker<FAM, LEAN, G> {
 	// K11 for the double-buffered loop: the trial unknowns exp(delta) (+) edge, lm + delta go to the OTHER copy (Bt), nothing is backed up (a rejected trial simply leaves the
 	// accepted copy as it is); like apply_update_lds the increment comes from the solved right-hand side in LDS and all edge poses of the trial are staged in the idle part of the
 	// LDS image for the spanning-tree refresh that follows. Returns that copy or nullptr.
-	__device__ __forceinline__ const double *apply_trial(const SparseSys &S, const Batch &Bt) { this->fresh();
+	__device__ __forceinline__ const double *apply_trial(const SparseSys &S) { this->fresh();
 		typedef typename W::PO PO; typedef typename W::pose_t pose_t;
 		const double *dl = B.delta + d.o_scal;
 		const bool stage = d.dense_in_lds && d.n_edges * PD <= 9 * S.nnzoff; double *el = S.off;
 		for (int i = tid; i < (stage ? d.n_edges : d.nK); i += G) {
-			pose_t cur = PO::ld(B.edge + (d.o_edge + i) * PD);
+			pose_t cur = PO::ld(E() + (d.o_edge + i) * PD);
 			if (i < d.nK) {
 				double inc[P];
 #pragma unroll
 				for (int k = 0; k < P; k++) { const int q = i * P + k; inc[k] = S.sol(q); }
 				cur = comp(PO::expm(inc), cur);
-				PO::st(Bt.edge + (d.o_edge + i) * PD, cur);
+				PO::st(Eo() + (d.o_edge + i) * PD, cur);
 			}
 			if (stage) { double t[PD]; PO::to(t, cur);
 #pragma unroll
 				for (int k = 0; k < PD; k++) el[i * PD + k] = t[k]; }
 		}
-		for (int k = tid; k < d.nF * L; k += G) Bt.ulm[d.o_ulm * L + k] = B.ulm[d.o_ulm * L + k] + dl[d.nK * P + k];
+		{ double *uo = Uo(); const double *ua = U(); for (int k = tid; k < d.nF * L; k += G) uo[d.o_ulm * L + k] = ua[d.o_ulm * L + k] + dl[d.nK * P + k]; }
 		if (stage) grp_lds_sync<G>(); else __syncthreads();
 		return stage ? el : nullptr;
 	}
 	__device__ __forceinline__ void restore() { this->fresh(); // optimize_edges.h:664-680
-		for (int i = tid; i < d.nK * PD; i += G) B.edge[d.o_edge * PD + i] = B.old_edge[d.o_unk * PD + i];
-		for (int k = tid; k < d.nF * L; k += G) B.ulm[d.o_ulm * L + k] = B.old_ulm[d.o_ulm * L + k];
-		for (int r = tid; r < d.n_req; r += G) { double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD; const double *o = B.old_pose + (d.o_req + r) * PD; for (int k = 0; k < PD; k++) s[k] = o[k]; }
+		for (int i = tid; i < d.nK * PD; i += G) E()[d.o_edge * PD + i] = B.old_edge[d.o_unk * PD + i];
+		for (int k = tid; k < d.nF * L; k += G) U()[d.o_ulm * L + k] = B.old_ulm[d.o_ulm * L + k];
+		for (int r = tid; r < d.n_req; r += G) { double *s = Pz() + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD; const double *o = B.old_pose + (d.o_req + r) * PD; for (int k = 0; k < PD; k++) s[k] = o[k]; }
 		__syncthreads();
 	}
 };
@@ -597,11 +597,15 @@ struct Solver : public Worker<FAM, LEAN, G> {
 #ifndef SRBA_FUSE_K4
 #define SRBA_FUSE_K4 1 /* a trial's residuals compose the poses of the refreshed pairs themselves (Worker::phase_residuals_fused); 0: refresh the pose table, then gather from it (rounds 1-3) */
 #endif
-template <int FAM, bool DB = (SRBA_LM_DB != 0), bool LEAN = false, int G = 64, bool FUSE_K4 = (SRBA_FUSE_K4 != 0) && (LEAN || G > 64) /* k_lm_run itself (every family, 253 registers for the headline one) keeps the table path: the fused form costs it 13 registers and with them its second wavefront per SIMD */>
+template <int FAM, bool DB = (SRBA_LM_DB != 0), bool LEAN = false, int G = 64, bool FUSE_K4 = (SRBA_FUSE_K4 != 0) && (LEAN || G > 64) /* k_lm_run itself (every family, 253 registers for the headline one) keeps the table path: the fused form costs it 13 registers and with them its second wavefront per SIMD */,
+          bool LND = false /* B0 lies in global memory (a kernel that takes `const Batch *`): every phase works through its own laundered reference to it and to the descriptor (srba_device.hpp lnd) */>
 __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, const int pidx, double *red = nullptr /* G = 128: LDS scratch of the group reductions */) {
 	const ProbDesc &d = B0.desc[pidx];
 	const Batch &B = B0;
 	int cur = 0, last_rej = 0; bool lazy_rej = false; // DB: which copy holds the accepted state; the last evaluated trial was rejected (lazy_rej: ... and the pose table of the trial copy was not refreshed for it)
+	typedef Solver<FAM, LEAN, G> Sv;
+	// a worker on copy `cp` of the state for ONE phase call (LND: through references nothing else shares -- the pointers a phase uses are loaded when it starts and die when it ends)
+	auto Wk = [&](int cp) __attribute__((always_inline)) -> Sv { if constexpr (LND) return Sv(lnd(B0), lnd(d), prm, red, cp); else return Sv(B0, d, prm, red, cp); };
 	Solver<FAM, LEAN, G> S(B, d, prm, red);
 	constexpr int P = Solver<FAM, LEAN, G>::P, L = Solver<FAM, LEAN, G>::L, O = Solver<FAM, LEAN, G>::O;
 	const SparseSys A = S.make_sys(srba_lds);
@@ -615,16 +619,16 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 	// K6: the LDS image of the system is idle while the capsule is linearised (it is assembled per trial): the U_Ap accumulators of the term-parallel form live there
 	const bool hess_terms = G <= 128 && B.hess_terms && d.dense_in_lds && d.n_hap * P * P <= 9 * (d.nb + d.nnzoff); // (the term-parallel form cuts the list between TWO wavefronts; workgroup windows keep no system in LDS anyway)
 	bool hs_reduced = false; // workgroup path, U_Ap in LDS: the LDS blocks hold the Schur-reduced system of the last solve (what the reference leaves in HAp), not yet written back
-	auto hessian = [&](Solver<FAM, LEAN, G> &X) -> int { if constexpr (G > 64 && !Tr<FAM>::REL) { if (d.hs_lds) { hs_reduced = false; return X.phase_hessian_lds(); } } return hess_terms ? X.phase_hessian_terms(srba_lds) /* == A.diag: the LDS image, idle while the capsule is linearised */ + X.phase_hessian_landmark_blocks() : X.phase_hessian(); };
+	auto hessian = [&](int cp) __attribute__((always_inline)) -> int { Sv X = Wk(cp); if constexpr (G > 64 && !Tr<FAM>::REL) { if (d.hs_lds) { hs_reduced = false; return X.phase_hessian_lds(); } } return hess_terms ? X.phase_hessian_terms(srba_lds) /* == A.diag: the LDS image, idle while the capsule is linearised */ + X.phase_hessian_landmark_blocks() : X.phase_hessian(); };
 	double lambda, nu = 2.0, total_err, RMSE;
 	int iter = 0, trials = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0; bool stop = false;
-	TIC(); S.phase_spantree(false, nullptr, DB ? B0.pose1 : nullptr); // S5 (DB: both copies of the poses)
+	TIC(); Wk(0).phase_spantree(false, nullptr, DB ? B0.pose1 : nullptr); // S5 (DB: both copies of the poses)
 	if constexpr (DB) { constexpr int PD = Solver<FAM, LEAN, G>::PD; // the second copy of the unknowns (the fixed edges of the paths stay equal in both for good)
 		for (int k = tid; k < d.n_edges * PD; k += G) B0.edge1[d.o_edge * PD + k] = B0.edge[d.o_edge * PD + k];
 		for (int k = tid; k < d.nF * L; k += G) B0.ulm1[d.o_ulm * L + k] = B0.ulm[d.o_ulm * L + k]; }
 	__syncthreads(); TOC(0);
-	TIC(); S.phase_jacobians(); TOC(1); // S6,S7
-	TIC(); const int ninv = (int)grp_sum<G>((double)hessian(S), red); // S10
+	TIC(); Wk(0).phase_jacobians(); TOC(1); // S6,S7
+	TIC(); const int ninv = (int)grp_sum<G>((double)hessian(0), red); // S10
 	__syncthreads(); TOC(2);
 	if (tid == 0) {
 		out->status = 0; out->num_iters = 0; out->num_trials = 0; out->num_not_pd = 0; out->num_accepted = 0; out->num_relinearized = 0; out->stop_reason = 0;
@@ -633,13 +637,13 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 		out->lambda_last_trial = NAN;
 	}
 	if ((long long)O * nObs < (long long)n) { if (tid == 0) out->status = 1; return; } // S11
-	lambda = S.lambda_guess(red); // S12
-	TIC(); total_err = S.phase_residuals(resid, red); TOC(3); // S13
+	lambda = Wk(0).lambda_guess(red); // S12
+	TIC(); total_err = Wk(0).phase_residuals(resid, red); TOC(3); // S13
 	RMSE = sqrt(total_err / nObs);
 	if (tid == 0) { out->lambda_init = lambda; out->total_sqr_error_init = total_err; }
 	__syncthreads();
-	TIC(); S.phase_gradient(resid); // S14
-	__syncthreads(); S.keep_gradient(); TOC(4);
+	TIC(); Wk(0).phase_gradient(resid); // S14
+	__syncthreads(); Wk(0).keep_gradient(); TOC(4);
 	for (; iter < prm.max_iters && !stop; iter++) {
 		double rho = 0;
 		if (lambda >= prm.max_lambda) { stop = true; stopmask |= 1 << SRBA_STOP_LAMBDA; }
@@ -647,21 +651,21 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 		while (rho <= 0 && !stop) {
 			const int tr = trials++;
 			if (tid == 0) { if (tr < SRBA_TRACE_LEN) out->trace_lambda[tr] = lambda; out->lambda_last_trial = lambda; }
-			const Batch Ba = DB ? copy_view(B0, cur) : B, Bt = DB ? copy_view(B0, cur ^ 1) : B; Solver<FAM, LEAN, G> Sa(Ba, d, prm, red), St(Bt, d, prm, red); // accepted / trial copy (the same one without DB)
-			TIC(); const bool solved = Sa.solve(A, lambda, pc); TOC(5); hs_reduced = true;
+			const int ca = DB ? cur : 0, ct = DB ? (cur ^ 1) : 0; // accepted / trial copy of the state (the same one without DB)
+			TIC(); const bool solved = Wk(ca).solve(A, lambda, pc); TOC(5); hs_reduced = true;
 			if (!solved) {
 				n_notpd++; lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
 				__syncthreads();
 				continue;
 			}
-			TIC(); const double *edge_lds = DB ? Sa.apply_trial(A, Bt) : Sa.apply_update_lds(A); TOC(6);
+			TIC(); const double *edge_lds = DB ? Wk(ca).apply_trial(A) : Wk(ca).apply_update_lds(A); TOC(6);
 			// (DB, edges staged, every refreshed path of four edges or fewer: the residuals compose their poses themselves and the refresh of the pose table waits for an accepted trial)
 			const bool lazy = DB && FUSE_K4 && edge_lds != nullptr && d.need_flat != 0;
 			double new_err;
-			if (lazy) { TIC(); new_err = St.phase_residuals_fused(resid2, red, edge_lds); TOC(3); }
-			else { TIC(); St.phase_spantree(true, edge_lds);
+			if (lazy) { TIC(); new_err = Wk(ct).phase_residuals_fused(resid2, red, edge_lds); TOC(3); }
+			else { TIC(); Wk(ct).phase_spantree(true, edge_lds);
 				__syncthreads(); TOC(7);
-				TIC(); new_err = St.phase_residuals(resid2, red); TOC(3); }
+				TIC(); new_err = Wk(ct).phase_residuals(resid2, red); TOC(3); }
 			const double new_RMSE = sqrt(new_err / nObs);
 			const double err_red = total_err > 0 ? (total_err - new_err) / total_err : 0;
 			double den = 0; { const double *dl = B.delta + d.o_scal, *g = B.grad + d.o_scal;
@@ -677,10 +681,10 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 				total_err = new_err; RMSE = new_RMSE;
 				if constexpr (DB) { cur ^= 1; last_rej = 0; } // the trial copy is the accepted one from here on
 				__syncthreads();
-				if (lazy) { TIC(); St.phase_spantree(true, edge_lds); __syncthreads(); TOC(7); } // the poses of the accepted trial, for the Jacobians and for the output
-				if (relin) { n_relin++; TIC(); St.phase_jacobians(); TOC(1); TIC(); hessian(St); __syncthreads(); TOC(2); }
-				TIC(); St.phase_gradient(resid);
-				__syncthreads(); St.keep_gradient(); TOC(4);
+				if (lazy) { TIC(); Wk(ct).phase_spantree(true, edge_lds); __syncthreads(); TOC(7); } // the poses of the accepted trial, for the Jacobians and for the output
+				if (relin) { n_relin++; TIC(); Wk(ct).phase_jacobians(); TOC(1); TIC(); hessian(ct); __syncthreads(); TOC(2); }
+				TIC(); Wk(ct).phase_gradient(resid);
+				__syncthreads(); Wk(ct).keep_gradient(); TOC(4);
 				double ninf = 0; { const double *g = B.grad + d.o_scal; for (int k = tid; k < n; k += G) ninf = fmax(ninf, fabs(g[k])); }
 				ninf = grp_max<G>(ninf, red);
 				if (ninf <= 1e-15) { stop = true; stopmask |= 1 << SRBA_STOP_GRADIENT; }
@@ -688,13 +692,13 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 				if (rho > prm.max_rho) { stop = true; stopmask |= 1 << SRBA_STOP_RHO; }
 				lambda *= 1.0 / 3.0; nu = 2.0;
 			} else {
-				if constexpr (DB) { last_rej = 1; lazy_rej = lazy; } else { TIC(); Sa.restore(); TOC(8); }
+				if constexpr (DB) { last_rej = 1; lazy_rej = lazy; } else { TIC(); Wk(ca).restore(); TOC(8); }
 				lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
 			}
 		}
 	}
 	if (!stop) stopmask |= 1 << SRBA_STOP_MAX_ITERS;
-	if constexpr (G > 64 && !Tr<FAM>::REL) { if (d.hs_lds && hs_reduced && S.schur_active()) { __syncthreads(); S.store_hs(false); } } // (the reference's Schur complement works on HAp in place: its reduced blocks are what a caller reads after the run)
+	if constexpr (G > 64 && !Tr<FAM>::REL) { if (d.hs_lds && hs_reduced && S.schur_active()) { __syncthreads(); Wk(0).store_hs(false); } } // (the reference's Schur complement works on HAp in place: its reduced blocks are what a caller reads after the run)
 	// S17: crpLandmarksApprox
 	if constexpr (!Solver<FAM, LEAN, G>::W::T::REL) {
 		for (int l = tid; l < d.nF; l += G) {
@@ -708,12 +712,12 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 		out->total_sqr_error_final = total_err; out->obs_rmse = RMSE; out->lambda_final = lambda;
 	}
 	if constexpr (DB) { // the reference's partial restore, where it becomes visible: a rejected trial refreshed BOTH poses of every pair in use and only the ones Jacobian blocks read went back (optimize_edges.h:664-670)
-		constexpr int PD = Solver<FAM, LEAN, G>::PD; const Batch Ba = copy_view(B0, cur), Bt = copy_view(B0, cur ^ 1);
+		constexpr int PD = Solver<FAM, LEAN, G>::PD; double *pose_a = cur ? B0.pose1 : B0.pose, *pose_t = cur ? B0.pose : B0.pose1; // accepted / trial copy of the pose table
 		__syncthreads();
-		if (last_rej && lazy_rej) { Solver<FAM, LEAN, G> Sl(Bt, d, prm, red); Sl.phase_spantree(true, nullptr); __syncthreads(); } // (the last rejected trial's poses, from its edges in the trial copy)
+		if (last_rej && lazy_rej) { Wk(cur ^ 1).phase_spantree(true, nullptr); __syncthreads(); } // (the last rejected trial's poses, from its edges in the trial copy)
 		if (last_rej) for (int q = tid; q < 2 * d.n_need; q += G) {
 			const long long ps = 2LL * B0.need_idx[d.o_pair + (q >> 1)] + (q & 1);
-			if (!B0.pose_req[d.o_pair * 2 + ps]) { double v[PD]; ldn<PD>(v, Bt.pose + (d.o_pair * 2 + ps) * PD); stn<PD>(Ba.pose + (d.o_pair * 2 + ps) * PD, v); }
+			if (!B0.pose_req[d.o_pair * 2 + ps]) { double v[PD]; ldn<PD>(v, pose_t + (d.o_pair * 2 + ps) * PD); stn<PD>(pose_a + (d.o_pair * 2 + ps) * PD, v); }
 		}
 	}
 	if constexpr (DB) { // the accepted state goes back to the primary arrays
@@ -781,7 +785,7 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 		while (rho <= 0 && !stop) {
 			const int tr = trials++;
 			if (tid == 0) { if (tr < SRBA_TRACE_LEN) out->trace_lambda[tr] = lambda; out->lambda_last_trial = lambda; }
-			const Batch Ba = copy_view(B0, cur), Bt = copy_view(B0, cur ^ 1); Solver<FAM, LEAN, G> Sa(Ba, d, prm, red), St(Bt, d, prm, red); // accepted / trial copy (the same one without DB)
+			const Batch Bt = copy_view(B0, cur ^ 1); Solver<FAM, LEAN, G> Sa(B0, d, prm, red, cur), St(B0, d, prm, red, cur ^ 1); // accepted / trial copy of the state
 			bool lazy; const double *edge_lds = nullptr; double new_err, new_RMSE, err_red;
 			{
 				lazy = FUSE_K4 && d.need_flat != 0 && d.n_edges * Solver<FAM, LEAN, G>::PD <= 9 * d.nnzoff; // (dense_in_lds is a condition of the launch)
@@ -795,7 +799,7 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 					if (ok_w) {
 						double *xd = sc->xdelta + ((sp_round & 1) * sc->W + sc->w) * sc->xstride;
 						for (int k = tid; k < n; k += G) xd[k] = A.sol(k);
-						TIC(); own_el = Sa.apply_trial(A, Bt); TOC(6);
+						TIC(); own_el = Sa.apply_trial(A); TOC(6);
 						TIC(); if (lazy) err_w = St.phase_residuals_fused(resid2, red, own_el); else { St.phase_spantree(true, own_el); __syncthreads(); err_w = St.phase_residuals(resid2, red); } TOC(3);
 						double den = 0; { const double *g = B.grad + d.o_scal; for (int k = tid; k < n; k += G) { const double dk = A.sol(k); den += dk * (lam_w * dk + g[k]); } }
 						den = grp_sum<G>(den, red);
@@ -834,7 +838,7 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 						__syncthreads();
 						for (int k = tid; k < n; k += G) { const double v = spec_ld(src + k); A.rhs[3 * A.perm[k / 3] + k % 3] = v; dl[k] = v; }
 						__syncthreads();
-						TIC(); edge_lds = Sa.apply_trial(A, Bt); TOC(6);
+						TIC(); edge_lds = Sa.apply_trial(A); TOC(6);
 						TIC(); St.phase_spantree(true, edge_lds); __syncthreads(); (void)St.phase_residuals(resid2, red); TOC(3);
 					} else edge_lds = own_el;
 					sp_j = sc->W; // the state changes: the other outcomes of the round are void
@@ -872,11 +876,11 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 			const double *src = rej_round == sp_round ? sc->xdelta + ((rej_round & 1) * sc->W + rej_owner) * sc->xstride : B.old_edge + d.o_unk * PD;
 			for (int k = tid; k < n; k += G) A.rhs[3 * A.perm[k / 3] + k % 3] = rej_round == sp_round ? spec_ld(src + k) : src[k];
 			__syncthreads();
-			Solver<FAM, LEAN, G> Sa(Ba, d, prm, red), Sl(Bt, d, prm, red); const double *el = Sa.apply_trial(A, Bt);
+			Solver<FAM, LEAN, G> Sa(B0, d, prm, red, cur), Sl(B0, d, prm, red, cur ^ 1); const double *el = Sa.apply_trial(A);
 			if (!lazy_rej) Sl.phase_spantree(true, el);
 			__syncthreads();
 		}
-		if (last_rej && lazy_rej) { Solver<FAM, LEAN, G> Sl(Bt, d, prm, red); Sl.phase_spantree(true, nullptr); __syncthreads(); } // (the last rejected trial's poses, from its edges in the trial copy)
+		if (last_rej && lazy_rej) { Solver<FAM, LEAN, G> Sl(B0, d, prm, red, cur ^ 1); Sl.phase_spantree(true, nullptr); __syncthreads(); } // (the last rejected trial's poses, from its edges in the trial copy)
 		if (last_rej) for (int q = tid; q < 2 * d.n_need; q += G) {
 			const long long ps = 2LL * B0.need_idx[d.o_pair + (q >> 1)] + (q & 1);
 			if (!B0.pose_req[d.o_pair * 2 + ps]) { double v[PD]; ldn<PD>(v, Bt.pose + (d.o_pair * 2 + ps) * PD); stn<PD>(Ba.pose + (d.o_pair * 2 + ps) * PD, v); }
@@ -895,13 +899,27 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 // Persistent workgroups: a launch covers one LDS size class with a grid of at most the number of wavefronts the chip can hold for that class; every
 // wavefront pulls capsules (sorted longest-first inside the class) from a shared counter until the class is exhausted. A launch therefore has ONE
 // tail (its last capsules) instead of one per chunk, and the chip stays full while big (LDS-bound) and small (wave-slot-bound) classes drain side by side.
+#ifndef SRBA_LM_BY_POINTER
+#define SRBA_LM_BY_POINTER 1 /* the fused LM kernels take `const Batch *` (a device copy of the batch record, uploaded with the input arena) and every phase of lm_one works through its own laundered reference (srba_device.hpp lnd): the batch's ~100 array pointers are scalar loads at the start of the phase that uses them instead of 220 - 530 spilled scalar registers. 0: the record as a kernel argument (rounds 1 - 4) */
+#endif
+#if SRBA_LM_BY_POINTER
+#define SRBA_LM_BATCH_ARG const Batch *__restrict__ Bptr
+#define SRBA_LM_BATCH_REF const Batch &B = *Bptr
+#define SRBA_LM_BATCH_VAL(c) (const srbadev::Batch *)(c)->d_batch
+#define SRBA_LM_LND true
+#else
+#define SRBA_LM_BATCH_ARG const Batch B
+#define SRBA_LM_BATCH_REF
+#define SRBA_LM_BATCH_VAL(c) (c)->B
+#define SRBA_LM_LND false
+#endif
 template <int FAM>
-__global__ void __launch_bounds__(SRBA_WG) SRBA_OCC k_lm_run(const Batch B, const DevParams prm, int first, int count, int *next) {
+__global__ void __launch_bounds__(SRBA_WG) SRBA_OCC k_lm_run(SRBA_LM_BATCH_ARG, const DevParams prm, int first, int count, int *next) { SRBA_LM_BATCH_REF;
 	for (;;) {
 		int i = 0; if (threadIdx.x == 0) { i = atomicAdd(next, 1); if (i == 0) *(long long *)(next + 2) = wall_clock64(); /* when the class started (srba_hip_launch_order): record = {counter, pad, stamp} */ }
 		i = __builtin_amdgcn_readfirstlane(i);
 		if (i >= count) break;
-		lm_one<FAM>(B, prm, B.order[first + i]);
+		lm_one<FAM, (SRBA_LM_DB != 0), false, 64, false, SRBA_LM_LND>(B, prm, B.order[first + i]);
 		__syncthreads(); // the LDS image and the symbolic copy are rebuilt by the next capsule
 	}
 }
@@ -912,12 +930,12 @@ __global__ void k_delay(int us) { const long long t0 = wall_clock64(); while (wa
 // with at most 31 unknown edges of the benchmark batch: 16.6 ms against 19.0 ms for k_lm_run, whose two wavefronts per SIMD leave 40 % of the LDS of a CU unused while those classes run;
 // the big (LDS-bound) classes are 3 % slower with it and keep k_lm_run. Only instantiated where the plan uses it (relative-pose SE2: plan_launches).
 template <int FAM>
-__global__ void __launch_bounds__(SRBA_WG) __attribute__((amdgpu_waves_per_eu(3, 3))) k_lm_run_lean(const Batch B, const DevParams prm, int first, int count, int *next) {
+__global__ void __launch_bounds__(SRBA_WG) __attribute__((amdgpu_waves_per_eu(3, 3))) k_lm_run_lean(SRBA_LM_BATCH_ARG, const DevParams prm, int first, int count, int *next) { SRBA_LM_BATCH_REF;
 	for (;;) {
 		int i = 0; if (threadIdx.x == 0) { i = atomicAdd(next, 1); if (i == 0) *(long long *)(next + 2) = wall_clock64(); }
 		i = __builtin_amdgcn_readfirstlane(i);
 		if (i >= count) break;
-		lm_one<FAM, (SRBA_LM_DB != 0), true>(B, prm, B.order[first + i]);
+		lm_one<FAM, (SRBA_LM_DB != 0), true, 64, (SRBA_FUSE_K4 != 0), SRBA_LM_LND>(B, prm, B.order[first + i]);
 		__syncthreads();
 	}
 }
@@ -929,13 +947,13 @@ __global__ void __launch_bounds__(SRBA_WG) __attribute__((amdgpu_waves_per_eu(3,
 // Worker / Solver<FAM, LEAN, 128>: strides of 128, workgroup barriers, group reductions through two doubles of LDS behind the image (fixed order: deterministic), the U_Ap terms cut between two
 // Hessian blocks. Three wavefronts per SIMD (the LEAN register diet): six such workgroups per CU.
 template <int FAM>
-__global__ void __launch_bounds__(2 * SRBA_WG) __attribute__((amdgpu_waves_per_eu(3, 3))) k_lm_run2(const Batch B, const DevParams prm, int first, int count, int *next, int lds_doubles) {
+__global__ void __launch_bounds__(2 * SRBA_WG) __attribute__((amdgpu_waves_per_eu(3, 3))) k_lm_run2(SRBA_LM_BATCH_ARG, const DevParams prm, int first, int count, int *next, int lds_doubles) { SRBA_LM_BATCH_REF;
 	double *red = srba_lds + lds_doubles; int *slot = (int *)(red + 2);
 	for (;;) {
 		if (threadIdx.x == 0) { const int i0 = atomicAdd(next, 1); *slot = i0; if (i0 == 0) *(long long *)(next + 2) = wall_clock64(); }
 		__syncthreads(); const int i = *slot; __syncthreads();
 		if (i >= count) break;
-		lm_one<FAM, (SRBA_LM_DB != 0), true, 2 * SRBA_WG>(B, prm, B.order[first + i], red);
+		lm_one<FAM, (SRBA_LM_DB != 0), true, 2 * SRBA_WG, (SRBA_FUSE_K4 != 0), SRBA_LM_LND>(B, prm, B.order[first + i], red);
 		__syncthreads();
 	}
 }
@@ -965,7 +983,7 @@ __global__ void __launch_bounds__(G) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 		if (threadIdx.x == 0) { const int i0 = atomicAdd(next, 1); *slot = i0; if (i0 == 0) *(long long *)(next + 2) = wall_clock64(); }
 		__syncthreads(); const int i = *slot; __syncthreads();
 		if (i >= count) break;
-		lm_one<FAM, (SRBA_LM_DB != 0), true, G, false>(B, prm, B.order[first + i], red);
+		lm_one<FAM, (SRBA_LM_DB != 0), true, G, false, (SRBA_WG_BY_POINTER != 0)>(B, prm, B.order[first + i], red);
 		__syncthreads();
 	}
 }
@@ -1033,15 +1051,17 @@ SRBA_PROBE(kp_spantree, S.phase_spantree(false, nullptr, B.pose1))
 SRBA_PROBE(kp_spantree_need, S.phase_spantree(true, nullptr))
 SRBA_PROBE(kp_jacobians, S.phase_jacobians())
 SRBA_PROBE(kp_hessian, B.notpd[blockIdx.x] = S.phase_hessian())
+SRBA_PROBE(kp_hessian_lds, B.notpd[blockIdx.x] = S.phase_hessian_lds())
+SRBA_PROBE(kp_schur_lds, S.schur_reduce_lds(B.lambda_io[blockIdx.x]))
 SRBA_PROBE(kp_gradient, S.phase_gradient(B.resid))
 SRBA_PROBE(kp_residuals, B.chi2[blockIdx.x] = S.phase_residuals(B.resid, srba_lds + WG_RED))
 SRBA_PROBE(kp_schur, S.schur_reduce(B.lambda_io[blockIdx.x]))
 SRBA_PROBE(kp_assemble, S.assemble_tiles(A, B.lambda_io[blockIdx.x]))
 SRBA_PROBE(kp_chol, B.notpd[blockIdx.x] = wg_chol_solve<4>(A.tiles, A.linv, A.nt, (lds_f64 *)srba_lds))
 SRBA_PROBE(kp_features, S.schur_features())
-SRBA_PROBE(kp_apply, S.apply_trial(A, B))
+SRBA_PROBE(kp_apply, S.apply_trial(A))
 template <int FAM> void probe_instantiate() { Batch B; DevParams p; hipLaunchKernelGGL(kp_spantree<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_spantree_need<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_jacobians<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_hessian<FAM>, 1, 256, 0, 0, B, p);
-	hipLaunchKernelGGL(kp_gradient<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_residuals<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_schur<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_assemble<FAM>, 1, 256, 0, 0, B, p);
+	hipLaunchKernelGGL(kp_gradient<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_hessian_lds<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_schur_lds<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_residuals<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_schur<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_assemble<FAM>, 1, 256, 0, 0, B, p);
 	hipLaunchKernelGGL(kp_chol<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_features<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_apply<FAM>, 1, 256, 0, 0, B, p); }
 template void probe_instantiate<SRBA_PROBE_KERNELS>();
 #endif
@@ -1110,7 +1130,7 @@ struct BigLane { int id = 0, slots = 1 /* windows its buffers have room for (srb
 #define SRBA_NLDS 19        /* LDS size classes (6 KB ... 152 KB per wavefront) of the one-wavefront kernels */
 #define SRBA_CLS_WG128 19   /* landmark windows on a workgroup of two wavefronts (k_lm_wg<FAM, 128>), four workgroups per CU: at most 40 KB of LDS each */
 #define SRBA_CLS_WG256 20   /* ... of four wavefronts, two per CU: at most 80 KB */
-#define SRBA_CLS_WG512 21   /* ... of eight wavefronts, one per CU: the windows whose U_Ap blocks need up to 158 KB of LDS */
+#define SRBA_CLS_WG512 21   /* ... of eight wavefronts, one per CU: the windows whose U_Ap blocks need up to 159 KB of LDS */
 #define SRBA_NCLS 23        /* + the last class: systems factored by the multi-workgroup path (srba_big.hpp) */
 // Symbolic block factorisation of one capsule's system (natural block order): the numeric kernel never discovers structure.
 struct Symbolic { std::vector<int32_t> fill; std::vector<int32_t> col_off, row, item_off, tgt, ab, rptr, rcol, rblk, perm, hap_dst, hapf_dst, hf_dst; int max_cn = 0; bool aligned = true; };
@@ -1283,7 +1303,7 @@ struct srba_hip_ctx {
 	std::string error;
 	// batch
 	int n_prob = 0; std::vector<ProbDesc> desc; Batch B; srba_batch_stats stats;
-	char *d_in = nullptr; size_t cap_in = 0; char *d_wk = nullptr; size_t cap_wk = 0; int *d_next = nullptr; Batch *d_batch = nullptr; // d_batch: device copy of B (the workgroup kernels read the batch's pointers from it)
+	char *d_in = nullptr; size_t cap_in = 0; char *d_wk = nullptr; size_t cap_wk = 0; int *d_next = nullptr; Batch *d_batch = nullptr; bool batch_copied = false; // d_batch: device copy of B (the workgroup kernels read the batch's pointers from it)
 	double *d_part = nullptr; double *d_scal = nullptr; int *d_iscal = nullptr; // big path: partial sums [3][kBigPart], scalars, int flags (ninv, not-pd)
 	std::vector<int> big_ld; // per capsule: leading dimension of its dense system when it runs on the big path, else 0
 	double big_chol_ms = 0, big_chol_flops = 0; long long big_chol_count = 0, big_chol_seqs = 0 /* launch sequences: one factors all windows of a gang */; int big_chol_nmax = 0; // Cholesky time / flops of the big path since the last upload (sum over the lanes)
@@ -1599,7 +1619,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 			size_t need = base;
 			if (c->wg_hs && idx_ok && with_hs <= (size_t)40 * 1024 && d.n_sys < c->wg256_from_sys) { cls[p] = SRBA_CLS_WG128; d.hs_lds = 1; need = with_hs; }
 			else if (c->wg_hs && idx_ok && with_hs <= (size_t)80 * 1024) { cls[p] = SRBA_CLS_WG256; d.hs_lds = 1; need = with_hs; }
-			else if (c->wg_hs && idx_ok && with_hs <= (size_t)158 * 1024) { cls[p] = SRBA_CLS_WG512; d.hs_lds = 1; need = with_hs; }
+			else if (c->wg_hs && idx_ok && with_hs <= (size_t)159 * 1024) { cls[p] = SRBA_CLS_WG512; d.hs_lds = 1; need = with_hs; } // (nearly the whole LDS of a CU: 515 blocks)
 			else cls[p] = d.n_sys >= c->wg256_from_sys ? SRBA_CLS_WG256 : SRBA_CLS_WG128; // U_Ap in memory (round-5 first version): more blocks than a CU's LDS holds
 			wg_lds[cls[p] - SRBA_NLDS] = std::max(wg_lds[cls[p] - SRBA_NLDS], need);
 			if (d.hs_lds) { d.hap_chunked = 0; t_hrec -= d.n_hrec - k.n_hap; d.n_hrec = k.n_hap; /* (the K6 records are not used on this path: one per block) */ t_hapo += k.n_hap_terms; t_schl += k.n_sch_terms; } }
@@ -1816,7 +1836,7 @@ c->asm_tab.term = asm_fam ? (const unsigned long long *)(di + o.asm_term) : null
 	const int64_t dbg_len[10] = {t_obs * O, t_bp * O * P, t_bf * O * L, t_hap * P * P, t_hf * L * L, t_hapf * P * L, t_scal, t_scal, t_valid, 2 * t_pair * PD};
 	c->n_pose_total = 2 * t_pair;
 	for (int i = 0; i < 10; i++) { c->off_dbg[i] = dbg_off[i]; c->len_dbg[i] = dbg_len[i]; }
-	if (c->cls_count[SRBA_CLS_WG128] + c->cls_count[SRBA_CLS_WG256] + c->cls_count[SRBA_CLS_WG512] > 0) { if (!c->d_batch) HIPCHK(c, hipMalloc((void **)&c->d_batch, sizeof(Batch))); HIPCHK(c, hipMemcpyAsync(c->d_batch, &c->B, sizeof(Batch), hipMemcpyHostToDevice, c->stream)); /* (c->B lives as long as the context; the stream is waited for before this function returns) */ }
+	c->batch_copied = false; // (the device copy of the batch record is made by the first launch that needs it: the speculative single-capsule kernel takes the record by value)
 	c->n_prob = n; st.device_bytes = (int64_t)(in.size + wk.size);
 	c->off_valid = w.valid; c->off_bp_ok = w.bp_ok; c->n_valid_total = t_valid; c->n_bp_total = t_bp; c->asm_flags_set = false;
 	if (c->asm_ready && !c->defer_upload_sync && set_asm_flags(c) != 0) return -1; // (srba_hip_optimize_capsule runs the LM loop only, whose Jacobian phase writes the flags itself: srba_hip_linearize sets them on demand)
@@ -2171,6 +2191,7 @@ static int lm_run_async_impl(srba_hip_ctx *c) {
 		HIPCHK(c, hipEventRecord(c->ev1, c->stream));
 		return 0;
 	}
+	if (!c->batch_copied) { if (!c->d_batch) HIPCHK(c, hipMalloc((void **)&c->d_batch, sizeof(Batch))); HIPCHK(c, hipMemcpyAsync(c->d_batch, &c->B, sizeof(Batch), hipMemcpyHostToDevice, c->stream)); c->batch_copied = true; } // the kernels read the batch record from device memory (c->B lives as long as the context and only changes at an upload)
 	HIPCHK(c, hipMemsetAsync(c->d_next, 0, sizeof(int) * 4 * std::max<size_t>(1, std::min<size_t>(kMaxJobs, c->plan.size())), c->stream)); // per launch {work counter, pad, device time stamp of its first capsule}
 	// fork/join: the launch plan (made at upload) spreads the size classes over a few streams; see plan_launches()
 	const int nq = c->plan.size() <= 1 ? 1 : c->n_streams_used; // a single launch (the per-key-frame use) stays on the context stream: no fork / join
@@ -2188,9 +2209,9 @@ static int lm_run_async_impl(srba_hip_ctx *c) {
 				else hipLaunchKernelGGL((srbadev::k_lm_wg<F, 128>), dim3(J.grid), dim3(128), c->cls_lds[k], launch_stream, SRBA_WG_BATCH_VAL(c), c->dp, J.first, J.count, c->d_next + 4 * j); } });
 			if (rc_attr != 0) return -1;
 			HIPCHK(c, hipGetLastError()); continue; }
-		if (J.two) { const size_t lds1 = (c->cls_lds[k] + c->lds_pad + 7) & ~(size_t)7; hipLaunchKernelGGL((srbadev::k_lm_run2<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(2 * SRBA_WG), lds1 + 32, launch_stream, c->B, c->dp, J.first, J.count, c->d_next + 4 * j, (int)(lds1 / 8)); HIPCHK(c, hipGetLastError()); continue; }
-		if (J.lean) { hipLaunchKernelGGL((srbadev::k_lm_run_lean<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(SRBA_WG), c->cls_lds[k] + c->lds_pad, launch_stream, c->B, c->dp, J.first, J.count, c->d_next + 4 * j); HIPCHK(c, hipGetLastError()); continue; }
-		SRBA_DISPATCH_LDS(c, k_lm_run, J.grid, c->cls_lds[k] + c->lds_pad, J.first, J.count, c->d_next + 4 * j); HIPCHK(c, hipGetLastError());
+		if (J.two) { const size_t lds1 = (c->cls_lds[k] + c->lds_pad + 7) & ~(size_t)7; hipLaunchKernelGGL((srbadev::k_lm_run2<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(2 * SRBA_WG), lds1 + 32, launch_stream, SRBA_LM_BATCH_VAL(c), c->dp, J.first, J.count, c->d_next + 4 * j, (int)(lds1 / 8)); HIPCHK(c, hipGetLastError()); continue; }
+		if (J.lean) { hipLaunchKernelGGL((srbadev::k_lm_run_lean<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(SRBA_WG), c->cls_lds[k] + c->lds_pad, launch_stream, SRBA_LM_BATCH_VAL(c), c->dp, J.first, J.count, c->d_next + 4 * j); HIPCHK(c, hipGetLastError()); continue; }
+		with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::k_lm_run<decltype(fam_)::value>), dim3(J.grid), dim3(SRBA_WG), c->cls_lds[k] + c->lds_pad, launch_stream, SRBA_LM_BATCH_VAL(c), c->dp, J.first, J.count, c->d_next + 4 * j); }); HIPCHK(c, hipGetLastError());
 	}
 	// capsules too large for one wavefront's LDS: the multi-workgroup path, one capsule after the other on the context stream (host-driven LM loop: this part
 	// of the call synchronises with the device once per LM trial), overlapping with the persistent launches of the other classes on their own streams

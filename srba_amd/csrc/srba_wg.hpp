@@ -29,8 +29,9 @@ constexpr int WT = 16;                             // tile edge = the shape of v
 constexpr int WG_NT_MAX = 32;                      // tile rows of the largest system this path takes: n <= 512 scalars
 constexpr int WG_LDS_DOUBLES = 256 + 512 + 16 * WG_NT_MAX + 12; // diagonal tile staging | two inverse factors (double-buffered) | y / x | group-reduction scratch (8) | flag, work-counter slot
 constexpr int WG_RED = 768 + 16 * WG_NT_MAX;        // offset of the reduction scratch; the solver's flag is the int at double WG_RED + 8, the kernels' work-counter slot at WG_RED + 9
-constexpr int WG_GACC = WG_LDS_DOUBLES;             // U_Ap-in-LDS path: accumulators of the Schur gradient correction (one per scalar of the reduced system, <= 16 WG_NT_MAX) ...
-constexpr int WG_HS = WG_LDS_DOUBLES + 16 * WG_NT_MAX; // ... and the U_Ap blocks themselves, n_hap x P x P doubles from here
+constexpr int WG_GACC = 0;                          // U_Ap-in-LDS path: accumulators of the Schur gradient correction (one per scalar of the reduced system, <= 16 WG_NT_MAX = 512): they share the
+                                                    // staging area of the factorisation (768 doubles; the correction is added to the gradient before the system is assembled) ...
+constexpr int WG_HS = WG_LDS_DOUBLES;               // ... and the U_Ap blocks themselves, n_hap x (P x P + 1) doubles from here
 __host__ __device__ inline int wg_tile(int i, int j) { return i * (i + 1) / 2 + j; } // tile (i, j), j <= i; tile row nt = the right-hand side
 __host__ __device__ inline long long wg_ws_doubles(int nt) { return 256LL * ((long long)(nt + 1) * (nt + 2) / 2 + nt + 4); } // tiles of rows 0 .. nt | nt inverse diagonal factors | 2 x 2 look-ahead partial sums
 // offset of element (r, c) inside a frag tile
@@ -59,29 +60,30 @@ __device__ __forceinline__ bool wg_diag(const f64x4w &c, lds_f64 *smC, lds_f64 *
 	double a[16], x[16];
 #pragma unroll
 	for (int q = 0; q < 16; q++) a[q] = smC[wg_frag_off(row, q)];
-	bool ok = true;
+	bool ok = true; double rrow = 0;
 #pragma unroll
-	for (int q = 0; q < 16; q++) x[q] = 0;
-	// Column j of L (lane i >= j ends with a[j] = L[i][j], lanes i < j with 0) and, in the same pass, row j of X = L^-1: row j of X needs L[j][0 .. j] and rows 0 .. j-1 of X, all final
-	// once column j is -- lane j hands its row round and the lanes below gather L[i][j] X[j][q]. The two chains (next column of L, this row of X) are independent: they overlap.
+	for (int q = 0; q < 16; q++) x[q] = (row == q) ? 1.0 : 0.0; // x[q] = delta_{row,q} - sum_{m < j} L[row][m] X[m][q]: row `row` of X = L^-1 is x[.] / L[row][row] once its turn has come
+	// Column j of L (lane i >= j ends with a[j] = L[i][j], lanes i < j with 0) and, in the same pass, row j of X: it needs L[j][0 .. j] and rows 0 .. j-1 of X, all final once
+	// column j is -- lane j hands its row round and the lanes below subtract L[i][j] X[j][q]. The two chains (next column of L, this row of X) are independent: they overlap.
 #pragma unroll
 	for (int j = 0; j < 16; j++) {
 		const double dj = wg_bcast(a[j], j);
 		ok &= (dj > 0.0);
 		const double r = wg_rsqrt(dj);
-		const double lj = (row == j) ? dj * r : ((row > j) ? a[j] * r : 0.0);
-		a[j] = lj;
+		const double lj = (row == j) ? dj * r : ((row > j) ? a[j] * r : 0.0), lbelow = (row > j) ? lj : 0.0;
+		a[j] = lj; rrow = (row == j) ? r : rrow;
 #pragma unroll
 		for (int q = j + 1; q < 16; q++) { const double lq = wg_bcast(lj, q); a[q] = fma(-lj, lq, a[q]); asm volatile("" : "+v"(a[q])); /* (pinned where its broadcast is: no pile of spilled v_readlane pairs, cf. chol_block_regs) */ }
 #pragma unroll
 		for (int q = 0; q <= j; q++) {
-			const double t = ((q == j ? 1.0 : 0.0) - x[q]) * r;   // lane j: X[j][q] (r = 1 / L[j][j], the same in every lane)
-			const double xb = wg_bcast(t, j);
-			x[q] = (row == j) ? t : fma(lj, xb, x[q]);            // lanes i > j gather L[i][j] X[j][q]; lanes i < j hold lj = 0
+			const double xb = wg_bcast(x[q] * r, j);   // X[j][q] (r = 1 / L[j][j], the same in every lane)
+			x[q] = fma(-lbelow, xb, x[q]);             // lanes i > j subtract L[i][j] X[j][q]; lane j and the lanes above keep theirs
 			asm volatile("" : "+v"(x[q]));
 		}
 		__builtin_amdgcn_sched_barrier(0);
 	}
+#pragma unroll
+	for (int q = 0; q < 16; q++) x[q] *= rrow;
 	if (l < 16) {
 #pragma unroll
 		for (int q = 0; q < 16; q++) smL[wg_frag_off(row, q)] = (q <= row) ? x[q] : 0.0;
@@ -109,7 +111,7 @@ __device__ __forceinline__ bool wg_chol_solve(double *T, double *LI, const int n
 		f64x4w li; li.x = Lk[4 * l]; li.y = Lk[4 * l + 1]; li.z = Lk[4 * l + 2]; li.w = Lk[4 * l + 3]; // frag(L_kk^-1): A operand of the triangular solves
 		const double *rowk = T + 256 * (size_t)wg_tile(k, 0);
 		const f64x4w zero4 = {0, 0, 0, 0};
-		auto solve_store = [&](int i, const f64x4w &a0, const f64x4w &s) -> f64x4w { // L_ik = (A_ik - s) L_kk^-t, stored as it lies in the accumulators
+		auto solve_store = [&](int i, const f64x4w &a0, const f64x4w &s) __attribute__((always_inline)) -> f64x4w { // L_ik = (A_ik - s) L_kk^-t, stored as it lies in the accumulators
 			const f64x4w ct = a0 - s; // C_ik^t as accumulators == the B operand of the solve
 			f64x4w dd = zero4;
 			dd = __builtin_amdgcn_mfma_f64_16x16x4f64(li.x, ct.x, dd, 0, 0, 0); dd = __builtin_amdgcn_mfma_f64_16x16x4f64(li.y, ct.y, dd, 0, 0, 0);
@@ -120,7 +122,7 @@ __device__ __forceinline__ bool wg_chol_solve(double *T, double *LI, const int n
 		};
 		// L_ik = (A_ik - sum_{j<k} L_ij L_kj^t) L_kk^-t for one tile row; diag_sum (row k + 1 only): += sum_{j<k} L_ij L_ij^t. Two columns j per pass, the tiles of the next pass
 		// requested before this pass's matrix instructions (the tiles come from L2 / the Infinity Cache: hundreds of cycles)
-		auto finish_row = [&](int i, f64x4w *diag_sum) -> f64x4w {
+		auto finish_row = [&](int i, f64x4w *diag_sum) __attribute__((always_inline)) -> f64x4w {
 			const double *rowi = T + 256 * (size_t)wg_tile(i, 0);
 			f64x4w s = zero4;
 			const f64x4w a0 = wg_ld(rowi + 256 * (size_t)k, l);
@@ -136,7 +138,7 @@ __device__ __forceinline__ bool wg_chol_solve(double *T, double *LI, const int n
 			return solve_store(i, a0, s);
 		};
 		// the same for TWO tile rows at once: the tiles of row k serve both, five tiles per pass in flight instead of four for twice the work (the sweep waits for its tiles)
-		auto finish_rows2 = [&](int i0, int i1) {
+		auto finish_rows2 = [&](int i0, int i1) __attribute__((always_inline)) {
 			const double *r0 = T + 256 * (size_t)wg_tile(i0, 0), *r1 = T + 256 * (size_t)wg_tile(i1, 0);
 			f64x4w s0 = zero4, s1 = zero4;
 			const f64x4w a00 = wg_ld(r0 + 256 * (size_t)k, l), a01 = wg_ld(r1 + 256 * (size_t)k, l);
@@ -155,7 +157,7 @@ __device__ __forceinline__ bool wg_chol_solve(double *T, double *LI, const int n
 		// finishes row k + 2 now (wavefront 1: it holds the row's tiles anyway) also forms what that chain needs from the columns before k: s' = sum_{j<k} L_{k+2,j} L_{k+1,j}^t and
 		// ds' = sum_{j<=k} L_{k+2,j} L_{k+2,j}^t, left in the workspace (two tiles per step parity); wavefront 0 then adds the one column that was missing (k) and goes on.
 		double *LA = LI + 256 * (size_t)nt; // [parity][s', ds'][256]
-		auto finish_row_la = [&](int i) { // i = k + 2 <= nt - 1
+		auto finish_row_la = [&](int i) __attribute__((always_inline)) { // i = k + 2 <= nt - 1
 			const double *rowi = T + 256 * (size_t)wg_tile(i, 0), *rown = T + 256 * (size_t)wg_tile(k + 1, 0);
 			f64x4w s = zero4, sn = zero4, dsn = zero4;
 			const f64x4w a0 = wg_ld(rowi + 256 * (size_t)k, l);
@@ -172,17 +174,17 @@ __device__ __forceinline__ bool wg_chol_solve(double *T, double *LI, const int n
 		};
 		if (w == 0) {
 			if (k + 1 < nt) {
-				f64x4w dd;
+				f64x4w dd, ds = zero4; const f64x4w ckk = wg_ld(T + 256 * (size_t)wg_tile(k + 1, k + 1), l); // (everything this chain reads is requested up front: one round trip)
 				if (k == 0) { f64x4w ds0 = zero4; dd = finish_row(1, &ds0); } // (nothing before column 0)
 				else { // row k + 1: s = s' + L_{k+1,k-1} L_{k,k-1}^t with s', ds' as the look-ahead of step k - 1 left them
 					const double *la = LA + 512 * (size_t)(k & 1);
 					const f64x4w sp = wg_ld(la, l), a0 = wg_ld(T + 256 * (size_t)wg_tile(k + 1, k), l);
 					const f64x4w Ak = wg_ld(rowk + 256 * (size_t)(k - 1), l), Bk = wg_ld(T + 256 * (size_t)wg_tile(k + 1, k - 1), l);
+					ds = wg_ld(la + 256, l);
 					dd = solve_store(k + 1, a0, wg_mma(Ak, Bk, sp));
 				}
-				f64x4w ds = (k == 0) ? zero4 : wg_ld(LA + 512 * (size_t)(k & 1) + 256, l);
 				ds = wg_mma(dd, dd, ds);
-				const f64x4w c = wg_ld(T + 256 * (size_t)wg_tile(k + 1, k + 1), l) - ds;
+				const f64x4w c = ckk - ds;
 				if (!wg_diag(c, smC, smL + 256 * ((k + 1) & 1), LI + 256 * (size_t)(k + 1), l) && l == 0) *flag = 1;
 			} else finish_row(nt, nullptr);
 		} else {
