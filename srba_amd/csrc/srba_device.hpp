@@ -41,7 +41,7 @@ struct ProbDesc {
 	int hapt_split; // two wavefronts per capsule: the second one takes the U_Ap terms from this index on (the first term of a Hessian block at or after the middle of the list: no block is summed by both)
 	int n_items, aligned; // block updates per factorisation; 1 if every Hessian block maps onto whole 3x3 blocks (always, except L==2 with the no-Schur solver)
 	int hs_lds; long long o_hapo, o_schl; // workgroup path, U_Ap accumulators in LDS (Solver::phase_hessian_lds / schur_reduce_lds): the U_Ap terms sorted by observation {t1, t2, block} from o_hapo (x3), the Schur terms sorted by landmark {lm, b1, b2, block | edge << 16 | diagonal << 31} from o_schl (x4)
-	int n_hrec, hap_chunked; long long o_hrec; // K6 work records {U_Ap block, first term, end term} (Batch::hap_rec): one per block, or (hap_chunked, the workgroup path) several of at most 8 terms each whose partial blocks are ADDED into a cleared U_Ap
+	int n_hrec, hap_chunked /* unused since the workgroup path sums U_Ap in LDS */; long long o_hrec; // K6 work records {U_Ap block, first term, end term} (Batch::hap_rec), one per block
 	int dense_in_lds, dense_blocks; // dense_blocks: the LDS image holds ALL blocks of the lower triangle (column-major), no symbolic structure (mid-size, nearly dense systems)
 };
 
@@ -1228,16 +1228,6 @@ struct Worker {
 		const double *Jp = B.Jp + d.o_bp * O * P, *Jf = B.Jf + d.o_bf * O * L;
 		const unsigned char *rp = B.bp_ok + d.o_bp, *rf = B.bf_ok + d.o_bf;
 		const bool latch = prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL;
-		bool chunked = false; if constexpr (T::SE3 && !T::REL) chunked = d.hap_chunked != 0;
-		if (chunked) { // the workgroup path: an edge near the root of a landmark window collects thousands of observations -- its diagonal block's term list would keep ONE lane busy for
-			// the whole phase. The lists are cut into records of at most 8 terms (host, at upload), a lane per record, partial blocks added into the cleared block.
-			{ f64x2u z; z.x = 0; z.y = 0; double *H0 = B.HAp + d.o_hap * P * P; for (int k = tid; k < d.n_hap * P * P / 2; k += G) *(f64x2u *)(H0 + 2 * k) = z; }
-			__syncthreads();
-			for (int bi = tid; bi < d.n_hrec; bi += G) {
-				const int *rec = B.hap_rec + (d.o_hrec + bi) * 3; const long long g = d.o_hap + rec[0];
-				ninv += hess_block<P, P, true>(B.HAp + g * P * P, nullptr, B.hap_t1 + d.o_hapt, B.hap_t2 + d.o_hapt, rec[1], rec[2], Jp, Jp, rp, rp);
-			}
-		} else
 		for (int bi = tid; bi < d.n_hrec; bi += G) {
 			const int *rec = B.hap_rec + (d.o_hrec + bi) * 3; const int b = rec[0]; const long long g = d.o_hap + b; // {block, first term, end term}: longest lists first
 			// the Schur complement works on HAp in place and restores it from the latch for every lambda (schur.h:38,165-168,188)
@@ -1248,10 +1238,6 @@ struct Worker {
 				ninv += hess_block<L, L>(B.Hf + (d.o_hf + b) * L * L, nullptr, B.hf_t1 + d.o_hft, B.hf_t2 + d.o_hft, B.hf_term_off[d.o_hfoff + b], B.hf_term_off[d.o_hfoff + b + 1], Jf, Jf, rf, rf);
 			for (int b = tid; b < d.n_hapf; b += G)
 				ninv += hess_block<P, L>(B.HApf + (d.o_hapf + b) * P * L, nullptr, B.hapf_t1 + d.o_hapft, B.hapf_t2 + d.o_hapft, B.hapf_term_off[d.o_hapfoff + b], B.hapf_term_off[d.o_hapfoff + b + 1], Jp, Jf, rp, rf);
-		}
-		if (chunked && latch) { // the latch of the summed blocks (schur.h:188 restores U_Ap from it for every lambda)
-			__syncthreads();
-			const double *H0 = B.HAp + d.o_hap * P * P; double *H1 = B.HAp0 + d.o_hap * P * P; for (int k = tid; k < d.n_hap * P * P / 2; k += G) *(f64x2u *)(H1 + 2 * k) = *(const f64x2u *)(H0 + 2 * k);
 		}
 		return ninv;
 	}

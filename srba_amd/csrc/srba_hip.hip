@@ -59,21 +59,6 @@ struct Solver : public Worker<FAM, LEAN, G> {
 			for (int k = tid; k < d.n_hap * P * P; k += G) B.HAp[d.o_hap * P * P + k] = B.HAp0[d.o_hap * P * P + k];
 			__syncthreads();
 			if (pc) { if (tid == 0) pc[14] += wall_clock64() - tq; tq = wall_clock64(); }
-			if constexpr (LEAN) { // the workgroup kernels: Y = W Hf^-1 once per U_Apf block (a lane per block) instead of once per term -- a third of a term's multiplications and its Hf^-1 load
-				for (int hb = tid; hb < d.n_hapf; hb += G) {
-					const int l = B.hapf_j[d.o_hapf + hb]; if (!B.hf_ok[d.o_ulm + l]) continue;
-					double Wm[P * L], Hi[L * L], Y[P * L]; ldn<P * L>(Wm, B.HApf + (d.o_hapf + hb) * P * L); ldn<L * L>(Hi, B.Hfinv + (d.o_ulm + l) * L * L);
-#pragma unroll
-					for (int i = 0; i < P; i++)
-#pragma unroll
-						for (int j = 0; j < L; j++) { double sm = 0;
-#pragma unroll
-							for (int k = 0; k < L; k++) sm += Wm[i * L + k] * Hi[k * L + j];
-							Y[i * L + j] = sm; }
-					stn<P * L>(B.Yh + (d.o_hapf + hb) * P * L, Y);
-				}
-				__syncthreads();
-			}
 			// Balanced over the lanes: the flat term list of the capsule (sorted by U_Ap block) is cut into 64 equal runs, one per lane. A lane keeps the running block in
 			// registers and adds it to HBM when its run moves on to the next block (a block cut by a run boundary receives two or three such additions: atomics), so the
 			// pass is as long as 1/64 of the terms, not as the diagonal block with the longest list in every group of 64 blocks. The terms of the diagonal blocks also
@@ -93,16 +78,16 @@ struct Solver : public Worker<FAM, LEAN, G> {
 #pragma unroll
 						for (int r = 0; r < P; r++) unsafeAtomicAdd(gi + r, ga[r]); }
 				};
-				constexpr int NT = LEAN ? 1 : 2; // terms per pass: indices and records of all of them are requested before any is used (LEAN: one -- the register diet of the workgroup kernels)
+				constexpr int NT = 2; // terms per pass: indices and records of both are requested before either is used
 				for (int t = tb; t < te; t += NT) {
 					int lq[NT], aq[NT], cq[NT], ywq[NT], kq[NT]; bool okq[NT];
 #pragma unroll
 					for (int u = 0; u < NT; u++) { const bool live = t + u < te; const int tu = live ? t + u : t; lq[u] = s_lm[tu]; aq[u] = s_b1[tu]; cq[u] = s_b2[tu]; ywq[u] = s_yw[tu]; kq[u] = s_blk[tu]; okq[u] = live; }
 #pragma unroll
 					for (int u = 0; u < NT; u++) okq[u] = okq[u] && B.hf_ok[d.o_ulm + lq[u]] != 0;
-					double W1[NT][P * L], W2[NT][P * L], Hi[NT][LEAN ? 1 : L * L], gl[NT][L]; // (LEAN: W1 holds Y = W1 Hf^-1 itself)
+					double W1[NT][P * L], W2[NT][P * L], Hi[NT][L * L], gl[NT][L];
 #pragma unroll
-					for (int u = 0; u < NT; u++) { ldn<P * L>(W1[u], (LEAN ? B.Yh : B.HApf) + (d.o_hapf + aq[u]) * P * L); ldn<P * L>(W2[u], B.HApf + (d.o_hapf + cq[u]) * P * L); if constexpr (!LEAN) ldn<L * L>(Hi[u], B.Hfinv + (d.o_ulm + lq[u]) * L * L); ldn<L>(gl[u], gf + lq[u] * L); }
+					for (int u = 0; u < NT; u++) { ldn<P * L>(W1[u], B.HApf + (d.o_hapf + aq[u]) * P * L); ldn<P * L>(W2[u], B.HApf + (d.o_hapf + cq[u]) * P * L); ldn<L * L>(Hi[u], B.Hfinv + (d.o_ulm + lq[u]) * L * L); ldn<L>(gl[u], gf + lq[u] * L); }
 #pragma unroll
 					for (int u = 0; u < NT; u++) {
 						if (!okq[u]) continue;
@@ -117,10 +102,8 @@ struct Solver : public Worker<FAM, LEAN, G> {
 						for (int i = 0; i < P; i++)
 #pragma unroll
 							for (int j = 0; j < L; j++) { double sm = 0;
-								if constexpr (LEAN) sm = W1[u][i * L + j];
-								else {
 #pragma unroll
-									for (int k = 0; k < L; k++) sm += W1[u][i * L + k] * Hi[u][k * L + j]; }
+								for (int k = 0; k < L; k++) sm += W1[u][i * L + k] * Hi[u][k * L + j];
 								Y[i * L + j] = sm; }
 #pragma unroll
 						for (int i = 0; i < P; i++)
@@ -161,26 +144,21 @@ struct Solver : public Worker<FAM, LEAN, G> {
 		__syncthreads();
 		const double *Jp = B.Jp + d.o_bp * O * P; const unsigned char *rp = B.bp_ok + d.o_bp; const int *rec = B.hapo + d.o_hapo * 3;
 		const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0;
-		// software pipeline, two terms in flight per lane: while term t is summed, the Jacobian blocks of term t + G are on their way and the record of term t + 2 G is requested
-		// (the loop waits for memory: 67 % of the wave cycles of the first version of this kernel were waits at 8 wavefronts per CU -- tools/r5_session5.sh)
-		int ninv = 0, b1 = 0, b2 = 0, blk = 0, n1 = 0, n2 = 0, nb = 0;
-		double A[O * P], Bm[O * P], nA[O * P], nB[O * P]; unsigned char ok1 = 0, ok2 = 0, nok1 = 0, nok2 = 0;
+		// (one term in flight per lane, the next record requested ahead. Two terms in flight -- 96 more registers -- were measured and changed nothing, tools/r5_session6.sh:
+		//  with the blocks of a wavefront's terms shared through the vector L1 the loop is bound by its 36 ds_add_f64 per term, not by the loads)
+		int ninv = 0, b1 = 0, b2 = 0, blk = 0;
 		if (tid < nt) { b1 = rec[3 * tid]; b2 = rec[3 * tid + 1]; blk = rec[3 * tid + 2]; }
-		if (tid + G < nt) { n1 = rec[3 * (tid + G)]; n2 = rec[3 * (tid + G) + 1]; nb = rec[3 * (tid + G) + 2]; }
-		if (tid < nt) { ldn<O * P>(A, Jp + (long long)b1 * O * P); ldn<O * P>(Bm, Jp + (long long)b2 * O * P); ok1 = rp[b1]; ok2 = rp[b2]; }
 		for (int t = tid; t < nt; t += G) {
-			const int t2 = t + 2 * G; int m1 = 0, m2 = 0, mb = 0; if (t2 < nt) { m1 = rec[3 * t2]; m2 = rec[3 * t2 + 1]; mb = rec[3 * t2 + 2]; }
-			if (t + G < nt) { ldn<O * P>(nA, Jp + (long long)n1 * O * P); ldn<O * P>(nB, Jp + (long long)n2 * O * P); nok1 = rp[n1]; nok2 = rp[n2]; }
-			if (ok1 && ok2) {
+			const int tn = t + G; int n1 = 0, n2 = 0, nb = 0; if (tn < nt) { n1 = rec[3 * tn]; n2 = rec[3 * tn + 1]; nb = rec[3 * tn + 2]; }
+			double A[O * P], Bm[O * P]; ldn<O * P>(A, Jp + (long long)b1 * O * P); ldn<O * P>(Bm, Jp + (long long)b2 * O * P);
+			if (rp[b1] && rp[b2]) {
 				double *dst = H + blk * HS;
 #pragma unroll
 				for (int i = 0; i < P; i++) { double row[P]; W::template hess_row<P, P>(row, A, Bm, i);
 #pragma unroll
 					for (int j = 0; j < P; j++) atomicAdd(dst + i * P + j, row[j] * sc); }
 			} else ninv++;
-#pragma unroll
-			for (int q = 0; q < O * P; q++) { A[q] = nA[q]; Bm[q] = nB[q]; }
-			ok1 = nok1; ok2 = nok2; blk = nb; n1 = m1; n2 = m2; nb = mb;
+			b1 = n1; b2 = n2; blk = nb;
 		}
 		ninv += this->phase_hessian_landmark_blocks();
 		__syncthreads();
@@ -205,18 +183,13 @@ struct Solver : public Worker<FAM, LEAN, G> {
 			__syncthreads();
 			if (pc) { if (tid == 0) pc[14] += wall_clock64() - tq; tq = wall_clock64(); }
 			const int *rec = B.schl + d.o_schl * 4; const double *gf = B.grad + d.o_scal + d.nK * P; const int nt = d.n_sch;
-			// (two terms in flight per lane, as in phase_hessian_lds: the blocks of term t + G travel while term t is multiplied out)
-			int l = 0, b1 = 0, b2 = 0, w = 0, nl = 0, n1 = 0, n2 = 0, nw = 0; int okc = 0, okn = 0;
-			double W1[P * L], W2[P * L], Hi[L * L], gl[L], nW1[P * L], nW2[P * L], nHi[L * L], ngl[L];
-			auto fetch = [&](int fl, int f1, int f2, double *w1, double *w2, double *hi, double *g3, int &okf) __attribute__((always_inline)) {
-				ldn<P * L>(w1, B.HApf + (d.o_hapf + f1) * P * L); ldn<P * L>(w2, B.HApf + (d.o_hapf + f2) * P * L); ldn<L * L>(hi, B.Hfinv + (d.o_ulm + fl) * L * L); ldn<L>(g3, gf + fl * L); okf = B.hf_ok[d.o_ulm + fl]; };
+			int l = 0, b1 = 0, b2 = 0, w = 0;
 			if (tid < nt) { l = rec[4 * tid]; b1 = rec[4 * tid + 1]; b2 = rec[4 * tid + 2]; w = rec[4 * tid + 3]; }
-			if (tid + G < nt) { const int q = tid + G; nl = rec[4 * q]; n1 = rec[4 * q + 1]; n2 = rec[4 * q + 2]; nw = rec[4 * q + 3]; }
-			if (tid < nt) fetch(l, b1, b2, W1, W2, Hi, gl, okc);
 			for (int t = tid; t < nt; t += G) {
-				const int t2 = t + 2 * G; int ml = 0, m1 = 0, m2 = 0, mw = 0; if (t2 < nt) { ml = rec[4 * t2]; m1 = rec[4 * t2 + 1]; m2 = rec[4 * t2 + 2]; mw = rec[4 * t2 + 3]; }
-				if (t + G < nt) fetch(nl, n1, n2, nW1, nW2, nHi, ngl, okn);
-				if (okc != 0) {
+				const int tn = t + G; int nl = 0, n1 = 0, n2 = 0, nw = 0; if (tn < nt) { nl = rec[4 * tn]; n1 = rec[4 * tn + 1]; n2 = rec[4 * tn + 2]; nw = rec[4 * tn + 3]; }
+				double W1[P * L], W2[P * L], Hi[L * L], gl[L];
+				ldn<P * L>(W1, B.HApf + (d.o_hapf + b1) * P * L); ldn<P * L>(W2, B.HApf + (d.o_hapf + b2) * P * L); ldn<L * L>(Hi, B.Hfinv + (d.o_ulm + l) * L * L); ldn<L>(gl, gf + l * L);
+				if (B.hf_ok[d.o_ulm + l] != 0) {
 					const int blk = w & 0xffff, e = (w >> 16) & 0x7fff; const bool diag = w < 0;
 					double *dst = H + blk * HS;
 #pragma unroll
@@ -238,13 +211,7 @@ struct Solver : public Worker<FAM, LEAN, G> {
 							atomicAdd(gacc + e * P + i, -sm); }
 					}
 				}
-#pragma unroll
-				for (int q = 0; q < P * L; q++) { W1[q] = nW1[q]; W2[q] = nW2[q]; }
-#pragma unroll
-				for (int q = 0; q < L * L; q++) Hi[q] = nHi[q];
-#pragma unroll
-				for (int q = 0; q < L; q++) gl[q] = ngl[q];
-				okc = okn; w = nw; nl = ml; n1 = m1; n2 = m2; nw = mw;
+				l = nl; b1 = n1; b2 = n2; w = nw;
 			}
 			__syncthreads();
 			{ double *g = B.grad + d.o_scal; for (int k = tid; k < d.nK * P; k += G) g[k] += gacc[k]; }
@@ -402,7 +369,7 @@ struct Solver : public Worker<FAM, LEAN, G> {
 	// The Schur-reduced system H_Ap' + lambda I and its right-hand side as 16 x 16 frag tiles (srba_wg.hpp; lev-marq_solvers.h:492-519 builds the same dense matrix for Eigen::LLT):
 	// the area is cleared, then every upper-triangle U_Ap block (i <= j) lands transposed in the lower triangle; rows beyond n_sys get an identity diagonal; the gradient is tile row nt.
 	__device__ __forceinline__ void assemble_tiles(const SparseSys &S, double lambda) { this->fresh();
-		const int n = d.n_sys, nt = S.nt; double *T = S.tiles; const double *Hsrc = d.hs_lds ? hs() : B.HAp + d.o_hap * P * P; const int hstride = d.hs_lds ? HS : P * P; // the reduced U_Ap blocks: in LDS or in memory
+		const int n = d.n_sys, nt = S.nt; double *T = S.tiles; const double *Hsrc = hs(); constexpr int hstride = HS; // the reduced U_Ap blocks, in LDS
 		{ const long long n2 = 128LL * (nt + 1) * (nt + 2) / 2; f64x2u z; z.x = 0; z.y = 0; for (long long k = tid; k < n2; k += G) *(f64x2u *)(T + 2 * k) = z; }
 		__syncthreads();
 		auto at = [&](int r, int c) __attribute__((always_inline)) -> double * { return T + 256 * (long long)wg_tile(r >> 4, c >> 4) + wg_frag_off(r & 15, c & 15); }; // element (r, c), r >= c
@@ -431,7 +398,7 @@ struct Solver : public Worker<FAM, LEAN, G> {
 #define STOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - t0; } } while (0)
 		if (schur_active() && (prm.ext & SRBA_EXT_SCHUR_KEEPS_GRADIENT)) { // (extension, default off) every solve starts from the gradient K5 produced: same lane -> same elements as keep_gradient()
 			double *g = B.grad + d.o_scal; const double *g0 = B.grad0 + d.o_scal; for (int k = tid; k < d.n_scal; k += G) g[k] = g0[k]; __syncthreads(); }
-		STIC(); if (schur_active()) { bool in_lds = false; if constexpr (G > 64 && !W::T::REL) in_lds = d.hs_lds != 0; if (in_lds) schur_reduce_lds(lambda, pc); else schur_reduce(lambda, pc); } STOC(9);
+		STIC(); if (schur_active()) { if constexpr (G > 64 && !W::T::REL) schur_reduce_lds(lambda, pc); /* (a workgroup window keeps its U_Ap blocks in LDS: the host sends no other here) */ else schur_reduce(lambda, pc); } STOC(9);
 		if constexpr (G > 64 && !W::T::REL) { // landmark window on a workgroup: dense LL^t on the matrix cores (srba_wg.hpp)
 			STIC(); assemble_tiles(S, lambda); STOC(10);
 			STIC(); const bool okw = wg_chol_solve<G / 64>(S.tiles, S.linv, S.nt, (lds_f64 *)srba_lds); STOC(11);
@@ -605,7 +572,7 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 	int cur = 0, last_rej = 0; bool lazy_rej = false; // DB: which copy holds the accepted state; the last evaluated trial was rejected (lazy_rej: ... and the pose table of the trial copy was not refreshed for it)
 	typedef Solver<FAM, LEAN, G> Sv;
 	// a worker on copy `cp` of the state for ONE phase call (LND: through references nothing else shares -- the pointers a phase uses are loaded when it starts and die when it ends)
-	auto Wk = [&](int cp) __attribute__((always_inline)) -> Sv { if constexpr (LND) return Sv(lnd(B0), lnd(d), prm, red, cp); else return Sv(B0, d, prm, red, cp); };
+	auto Wk = [&](int cp) __attribute__((always_inline)) -> Sv { if constexpr (LND) return Sv(lnd(B0), lnd(d), lnd(prm), red, cp); else return Sv(B0, d, prm, red, cp); };
 	Solver<FAM, LEAN, G> S(B, d, prm, red);
 	constexpr int P = Solver<FAM, LEAN, G>::P, L = Solver<FAM, LEAN, G>::L, O = Solver<FAM, LEAN, G>::O;
 	const SparseSys A = S.make_sys(srba_lds);
@@ -619,7 +586,7 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 	// K6: the LDS image of the system is idle while the capsule is linearised (it is assembled per trial): the U_Ap accumulators of the term-parallel form live there
 	const bool hess_terms = G <= 128 && B.hess_terms && d.dense_in_lds && d.n_hap * P * P <= 9 * (d.nb + d.nnzoff); // (the term-parallel form cuts the list between TWO wavefronts; workgroup windows keep no system in LDS anyway)
 	bool hs_reduced = false; // workgroup path, U_Ap in LDS: the LDS blocks hold the Schur-reduced system of the last solve (what the reference leaves in HAp), not yet written back
-	auto hessian = [&](int cp) __attribute__((always_inline)) -> int { Sv X = Wk(cp); if constexpr (G > 64 && !Tr<FAM>::REL) { if (d.hs_lds) { hs_reduced = false; return X.phase_hessian_lds(); } } return hess_terms ? X.phase_hessian_terms(srba_lds) /* == A.diag: the LDS image, idle while the capsule is linearised */ + X.phase_hessian_landmark_blocks() : X.phase_hessian(); };
+	auto hessian = [&](int cp) __attribute__((always_inline)) -> int { Sv X = Wk(cp); if constexpr (G > 64 && !Tr<FAM>::REL) { hs_reduced = false; return X.phase_hessian_lds(); } else return hess_terms ? X.phase_hessian_terms(srba_lds) /* == A.diag: the LDS image, idle while the capsule is linearised */ + X.phase_hessian_landmark_blocks() : X.phase_hessian(); };
 	double lambda, nu = 2.0, total_err, RMSE;
 	int iter = 0, trials = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0; bool stop = false;
 	TIC(); Wk(0).phase_spantree(false, nullptr, DB ? B0.pose1 : nullptr); // S5 (DB: both copies of the poses)
@@ -698,7 +665,7 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 		}
 	}
 	if (!stop) stopmask |= 1 << SRBA_STOP_MAX_ITERS;
-	if constexpr (G > 64 && !Tr<FAM>::REL) { if (d.hs_lds && hs_reduced && S.schur_active()) { __syncthreads(); Wk(0).store_hs(false); } } // (the reference's Schur complement works on HAp in place: its reduced blocks are what a caller reads after the run)
+	if constexpr (G > 64 && !Tr<FAM>::REL) { if (hs_reduced && S.schur_active()) { __syncthreads(); Wk(0).store_hs(false); } } // (the reference's Schur complement works on HAp in place: its reduced blocks are what a caller reads after the run)
 	// S17: crpLandmarksApprox
 	if constexpr (!Solver<FAM, LEAN, G>::W::T::REL) {
 		for (int l = tid; l < d.nF; l += G) {
@@ -903,18 +870,18 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 #define SRBA_LM_BY_POINTER 1 /* the fused LM kernels take `const Batch *` (a device copy of the batch record, uploaded with the input arena) and every phase of lm_one works through its own laundered reference (srba_device.hpp lnd): the batch's ~100 array pointers are scalar loads at the start of the phase that uses them instead of 220 - 530 spilled scalar registers. 0: the record as a kernel argument (rounds 1 - 4) */
 #endif
 #if SRBA_LM_BY_POINTER
-#define SRBA_LM_BATCH_ARG const Batch *__restrict__ Bptr
-#define SRBA_LM_BATCH_REF const Batch &B = *Bptr
-#define SRBA_LM_BATCH_VAL(c) (const srbadev::Batch *)(c)->d_batch
+#define SRBA_LM_BATCH_ARG const Batch *__restrict__ Bptr, const DevParams *__restrict__ Pptr
+#define SRBA_LM_BATCH_REF const Batch &B = *Bptr; const DevParams &prm = *Pptr
+#define SRBA_LM_BATCH_VAL(c) (const srbadev::Batch *)(c)->d_batch, (const srbadev::DevParams *)((c)->d_batch + 1)
 #define SRBA_LM_LND true
 #else
-#define SRBA_LM_BATCH_ARG const Batch B
+#define SRBA_LM_BATCH_ARG const Batch B, const DevParams prm
 #define SRBA_LM_BATCH_REF
-#define SRBA_LM_BATCH_VAL(c) (c)->B
+#define SRBA_LM_BATCH_VAL(c) (c)->B, (c)->dp
 #define SRBA_LM_LND false
 #endif
 template <int FAM>
-__global__ void __launch_bounds__(SRBA_WG) SRBA_OCC k_lm_run(SRBA_LM_BATCH_ARG, const DevParams prm, int first, int count, int *next) { SRBA_LM_BATCH_REF;
+__global__ void __launch_bounds__(SRBA_WG) SRBA_OCC k_lm_run(SRBA_LM_BATCH_ARG, int first, int count, int *next) { SRBA_LM_BATCH_REF;
 	for (;;) {
 		int i = 0; if (threadIdx.x == 0) { i = atomicAdd(next, 1); if (i == 0) *(long long *)(next + 2) = wall_clock64(); /* when the class started (srba_hip_launch_order): record = {counter, pad, stamp} */ }
 		i = __builtin_amdgcn_readfirstlane(i);
@@ -930,7 +897,7 @@ __global__ void k_delay(int us) { const long long t0 = wall_clock64(); while (wa
 // with at most 31 unknown edges of the benchmark batch: 16.6 ms against 19.0 ms for k_lm_run, whose two wavefronts per SIMD leave 40 % of the LDS of a CU unused while those classes run;
 // the big (LDS-bound) classes are 3 % slower with it and keep k_lm_run. Only instantiated where the plan uses it (relative-pose SE2: plan_launches).
 template <int FAM>
-__global__ void __launch_bounds__(SRBA_WG) __attribute__((amdgpu_waves_per_eu(3, 3))) k_lm_run_lean(SRBA_LM_BATCH_ARG, const DevParams prm, int first, int count, int *next) { SRBA_LM_BATCH_REF;
+__global__ void __launch_bounds__(SRBA_WG) __attribute__((amdgpu_waves_per_eu(3, 3))) k_lm_run_lean(SRBA_LM_BATCH_ARG, int first, int count, int *next) { SRBA_LM_BATCH_REF;
 	for (;;) {
 		int i = 0; if (threadIdx.x == 0) { i = atomicAdd(next, 1); if (i == 0) *(long long *)(next + 2) = wall_clock64(); }
 		i = __builtin_amdgcn_readfirstlane(i);
@@ -947,7 +914,7 @@ __global__ void __launch_bounds__(SRBA_WG) __attribute__((amdgpu_waves_per_eu(3,
 // Worker / Solver<FAM, LEAN, 128>: strides of 128, workgroup barriers, group reductions through two doubles of LDS behind the image (fixed order: deterministic), the U_Ap terms cut between two
 // Hessian blocks. Three wavefronts per SIMD (the LEAN register diet): six such workgroups per CU.
 template <int FAM>
-__global__ void __launch_bounds__(2 * SRBA_WG) __attribute__((amdgpu_waves_per_eu(3, 3))) k_lm_run2(SRBA_LM_BATCH_ARG, const DevParams prm, int first, int count, int *next, int lds_doubles) { SRBA_LM_BATCH_REF;
+__global__ void __launch_bounds__(2 * SRBA_WG) __attribute__((amdgpu_waves_per_eu(3, 3))) k_lm_run2(SRBA_LM_BATCH_ARG, int first, int count, int *next, int lds_doubles) { SRBA_LM_BATCH_REF;
 	double *red = srba_lds + lds_doubles; int *slot = (int *)(red + 2);
 	for (;;) {
 		if (threadIdx.x == 0) { const int i0 = atomicAdd(next, 1); *slot = i0; if (i0 == 0) *(long long *)(next + 2) = wall_clock64(); }
@@ -962,13 +929,13 @@ __global__ void __launch_bounds__(2 * SRBA_WG) __attribute__((amdgpu_waves_per_e
 #define SRBA_WG_BY_POINTER 1 /* the workgroup kernels read the ~100 array pointers of the batch from a device copy of `Batch` (scalar loads where a pointer is used) instead of keeping them all in scalar registers from the kernel arguments: their phases last tens of microseconds, a scalar load is nothing there, and 450 - 530 spilled scalars (v_readlane restores: a quarter of the instructions of the Hessian and Schur loops) are */
 #endif
 #if SRBA_WG_BY_POINTER
-#define SRBA_WG_BATCH_ARG const Batch *__restrict__ Bptr
-#define SRBA_WG_BATCH_REF const Batch &B = *Bptr
-#define SRBA_WG_BATCH_VAL(c) (const srbadev::Batch *)(c)->d_batch
+#define SRBA_WG_BATCH_ARG const Batch *__restrict__ Bptr, const DevParams *__restrict__ Pptr
+#define SRBA_WG_BATCH_REF const Batch &B = *Bptr; const DevParams &prm = *Pptr
+#define SRBA_WG_BATCH_VAL(c) (const srbadev::Batch *)(c)->d_batch, (const srbadev::DevParams *)((c)->d_batch + 1)
 #else
-#define SRBA_WG_BATCH_ARG const Batch B
+#define SRBA_WG_BATCH_ARG const Batch B, const DevParams prm
 #define SRBA_WG_BATCH_REF
-#define SRBA_WG_BATCH_VAL(c) (c)->B
+#define SRBA_WG_BATCH_VAL(c) (c)->B, (c)->dp
 #endif
 // One WORKGROUP of G = 128 or 256 threads per capsule for the SE3 landmark families (round 5; srba_wg.hpp): every lane-parallel phase runs G wide, the Schur-reduced system is a
 // lower triangle of 16 x 16 tiles in the capsule's HBM workspace and is factored on the matrix cores by the G / 64 wavefronts. Replaces, for the windows the plan sends here, the
@@ -976,7 +943,7 @@ __global__ void __launch_bounds__(2 * SRBA_WG) __attribute__((amdgpu_waves_per_e
 // LEAN diet (one Schur term, one Hessian term, one spanning-tree pair in flight) under a cap of 256 -- two wavefronts per SIMD, i.e. two 256-thread workgroups per CU.
 // LDS: WG_LDS_DOUBLES (the solver's staging, x, reduction scratch, flags, the work counter's slot).
 template <int FAM, int G>
-__global__ void __launch_bounds__(G) __attribute__((amdgpu_waves_per_eu(2, 2))) k_lm_wg(SRBA_WG_BATCH_ARG, const DevParams prm, int first, int count, int *next) {
+__global__ void __launch_bounds__(G) __attribute__((amdgpu_waves_per_eu(2, 2))) k_lm_wg(SRBA_WG_BATCH_ARG, int first, int count, int *next) {
 	SRBA_WG_BATCH_REF;
 	double *red = srba_lds + WG_RED; int *slot = (int *)(red + 9); // (red[0 .. 7]: group reductions, red + 8: the solver's flag)
 	for (;;) {
@@ -991,7 +958,7 @@ template <int FAM, int G> __global__ void __launch_bounds__(G) __attribute__((am
 	const int pidx = B.order[first + blockIdx.x]; const ProbDesc &d = B.desc[pidx]; Solver<FAM, true, G> S(B, d, prm, srba_lds + WG_RED);
 	const SparseSys A = S.make_sys(srba_lds);
 	const bool ok = S.solve(A, B.lambda_io[pidx]);
-	if (d.hs_lds && S.schur_active()) { __syncthreads(); S.store_hs(false); }
+	if (S.schur_active()) { __syncthreads(); S.store_hs(false); }
 	if (threadIdx.x == 0) B.notpd[pidx] = ok ? 0 : 1;
 }
 
@@ -1509,7 +1476,7 @@ int srba_hip_set_params(srba_hip_ctx *c, const srba_hip_params *params) {
 	if (check_params(params) != 0) { c->fail(g_last_error); return -1; }
 	if (params->family != c->params.family) { c->fail("srba_hip_set_params: the family of a context cannot change"); return -1; }
 	if (c->n_prob && (params->solver != c->params.solver || params->noise != c->params.noise || params->extensions != c->params.extensions)) c->n_prob = 0; // the uploaded batch was laid out for the old solver / noise policy: upload again
-	c->params = *params; make_dev_params(*params, c->dp, c->dm); return 0;
+	c->params = *params; make_dev_params(*params, c->dp, c->dm); c->batch_copied = false; /* (the kernels read the parameters from the device copy) */ return 0;
 }
 
 int srba_hip_destroy(srba_hip_ctx *c) {
@@ -1538,6 +1505,19 @@ int srba_hip_kernel_ms_history(srba_hip_ctx *c, double *out_ms, int n) {
 	return have;
 }
 
+// Class of a capsule on the workgroup path of the SE3 landmark families (k_lm_wg, srba_wg.hpp), or -1: Schur solvers, a reduced system of wg_from_sys .. 16 WG_NT_MAX scalars, and U_Ap blocks
+// that fit the LDS of the workgroup shape (128 threads: four per CU, 40 KB; 256: two, 80 KB; 512: one, 159 KB). *lds_bytes: what the window needs. Windows with more blocks than a CU's
+// LDS holds keep the one-wavefront kernel (or the multi-workgroup path).
+static int wg_class_of(const srba_hip_ctx *c, const srba_problem_capsule &k, bool schur_solver, size_t *lds_bytes) {
+	const int P = c->dm.P, L = c->dm.L; const int n_sys = P * k.n_unk_edges;
+	if (!(c->wg_on && c->wg_hs && c->max_lds_kb > 0 /* (0: the test knob that sends every window to the multi-workgroup path) */ && c->dm.PD == 12 && L == 3 && schur_solver && k.n_unk_lms > 0 && k.n_unk_edges > 0 && c->gang_from_nb <= 0)) return -1;
+	if (n_sys < c->wg_from_sys || n_sys > 16 * srbadev::WG_NT_MAX || k.n_hap >= 65536 || k.n_unk_edges >= 32768) return -1;
+	const size_t need = 8 * ((size_t)srbadev::WG_HS + (size_t)k.n_hap * (P * P + 1)); if (lds_bytes) *lds_bytes = need;
+	if (need <= (size_t)40 * 1024 && n_sys < c->wg256_from_sys) return SRBA_CLS_WG128;
+	if (need <= (size_t)80 * 1024) return SRBA_CLS_WG256;
+	if (need <= (size_t)159 * 1024) return SRBA_CLS_WG512; // (nearly the whole LDS of a CU: 515 blocks)
+	return -1;
+}
 static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *caps, int n);
 int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, int n) { // no C++ exception crosses the C ABI
 	try { return upload_problems_impl(c, caps, n); }
@@ -1573,7 +1553,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 			if ((why[p] = validate_capsule(k)) != nullptr) continue;
 			ProbDesc t; t.nK = k.n_unk_edges; t.nF = k.n_unk_lms; t.n_scal = P * t.nK + L * t.nF; t.n_sys = (schur_solver && t.nF > 0 && t.nK > 0) ? P * t.nK : t.n_scal; t.nb = (t.n_sys + 2) / 3;
 			if (schur_solver && t.nK == 0) continue;
-			const bool wg = c->wg_on && c->max_lds_kb > 0 /* (0: the test knob that sends every window to the multi-workgroup path) */ && c->dm.PD == 12 && c->dm.L == 3 && schur_solver && t.nF > 0 && t.nK > 0 && t.n_sys >= c->wg_from_sys && t.n_sys <= 16 * srbadev::WG_NT_MAX && c->gang_from_nb <= 0; // (SE3 point-landmark families, Schur solvers: the workgroup path needs no symbolic analysis)
+			const bool wg = wg_class_of(c, k, schur_solver, nullptr) >= 0; // (the workgroup path needs no symbolic analysis)
 			if (t.n_sys <= c->big_min_sys && !wg) symbolic_factor(k, t, P, L, !schur_solver, sym[p]);
 		}
 	});
@@ -1590,7 +1570,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		d.o_bp = t_bp; d.o_colp = t_unk + p; d.o_bf = t_bf; d.o_colf = t_ulm + p; d.o_hap = t_hap; d.o_hapoff = t_hap + p; d.o_hapt = t_hapt; d.o_hf = t_hf; d.o_hfoff = t_hf + p; d.o_hft = t_hft;
 		d.o_hapf = t_hapf; d.o_hapfoff = t_hapf + p; d.o_hapft = t_hapft; d.o_sch = t_sch; d.o_lmoff = t_ulm + p; d.o_req = t_req; d.o_scal = t_scal; d.o_yw = t_yw; d.o_dense = t_dense;
 		d.nb = (d.n_sys + 2) / 3;
-		const bool to_wg = c->wg_on && c->max_lds_kb > 0 && c->dm.PD == 12 && c->dm.L == 3 && schur_solver && d.nF > 0 && d.nK > 0 && d.n_sys >= c->wg_from_sys && d.n_sys <= 16 * srbadev::WG_NT_MAX && c->gang_from_nb <= 0; // one workgroup, tile system in HBM, matrix cores (srba_wg.hpp)
+		size_t wg_need = 0; const int wg_cls = wg_class_of(c, k, schur_solver, &wg_need); const bool to_wg = wg_cls >= 0; // one workgroup, tile system in HBM, U_Ap blocks in LDS, matrix cores (srba_wg.hpp)
 		const bool surely_big = d.n_sys > c->big_min_sys || to_wg; // far beyond what one wavefront's LDS holds (or a workgroup window): dense system on the multi-workgroup path, no block-sparse symbolic analysis
 		if (!surely_big) { /* sym[p]: computed above */ }
 		else { Symbolic &y = sym[p]; y.col_off.assign(d.nb + 1, 0); y.item_off.assign(d.nb + 1, 0); y.rptr.assign(d.nb + 1, 0); y.perm.resize(d.nb); for (int q = 0; q < d.nb; q++) y.perm[q] = q;
@@ -1611,18 +1591,10 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		static const int kClsKB[SRBA_NLDS] = {6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64, 80, 96, 112, 128, 152};
 		cls[p] = SRBA_NCLS - 1; for (int q = 0; q < SRBA_NLDS && packable && !surely_big && !to_gang && kClsKB[q] <= c->max_lds_kb; q++) if (bytes <= (size_t)kClsKB[q] * 1024) { cls[p] = q; break; }
 		long long wave_ws = 0; // doubles of HBM workspace of a capsule that keeps one wavefront but holds its (dense block) system in HBM
-		{ d.hap_chunked = to_wg ? 1 : 0; int nr = k.n_hap; if (to_wg) { nr = 0; for (int b = 0; b < k.n_hap; b++) nr += std::max(1, (k.hap_term_off[b + 1] - k.hap_term_off[b] + 7) / 8); } d.n_hrec = nr; d.o_hrec = t_hrec; t_hrec += nr; } // K6 work records (ProbDesc::hap_chunked)
+		d.hap_chunked = 0; d.n_hrec = k.n_hap; d.o_hrec = t_hrec; t_hrec += k.n_hap; // K6 work records: one per block
 		d.hs_lds = 0; d.o_hapo = t_hapo; d.o_schl = t_schl;
 		if (to_wg) { const int nt = (d.n_sys + srbadev::WT - 1) / srbadev::WT; d.dense_blocks = 3; d.nnzoff = 0; d.n_items = 0; wave_ws = srbadev::wg_ws_doubles(nt);
-			// LDS of the workgroup: the solver's scratch + (when they fit its class) the U_Ap blocks of the window, summed on chip (Solver::phase_hessian_lds / schur_reduce_lds)
-			const size_t base = 8 * (size_t)srbadev::WG_LDS_DOUBLES, with_hs = 8 * ((size_t)srbadev::WG_HS + (size_t)k.n_hap * (P * P + 1)); const bool idx_ok = k.n_hap < 65536 && d.nK < 32768;
-			size_t need = base;
-			if (c->wg_hs && idx_ok && with_hs <= (size_t)40 * 1024 && d.n_sys < c->wg256_from_sys) { cls[p] = SRBA_CLS_WG128; d.hs_lds = 1; need = with_hs; }
-			else if (c->wg_hs && idx_ok && with_hs <= (size_t)80 * 1024) { cls[p] = SRBA_CLS_WG256; d.hs_lds = 1; need = with_hs; }
-			else if (c->wg_hs && idx_ok && with_hs <= (size_t)159 * 1024) { cls[p] = SRBA_CLS_WG512; d.hs_lds = 1; need = with_hs; } // (nearly the whole LDS of a CU: 515 blocks)
-			else cls[p] = d.n_sys >= c->wg256_from_sys ? SRBA_CLS_WG256 : SRBA_CLS_WG128; // U_Ap in memory (round-5 first version): more blocks than a CU's LDS holds
-			wg_lds[cls[p] - SRBA_NLDS] = std::max(wg_lds[cls[p] - SRBA_NLDS], need);
-			if (d.hs_lds) { d.hap_chunked = 0; t_hrec -= d.n_hrec - k.n_hap; d.n_hrec = k.n_hap; /* (the K6 records are not used on this path: one per block) */ t_hapo += k.n_hap_terms; t_schl += k.n_sch_terms; } }
+			cls[p] = wg_cls; d.hs_lds = 1; wg_lds[wg_cls - SRBA_NLDS] = std::max(wg_lds[wg_cls - SRBA_NLDS], wg_need); t_hapo += k.n_hap_terms; t_schl += k.n_sch_terms; }
 		if ((cls[p] == SRBA_NCLS - 1 ? many_mid : (c->hbm_from_kb > 0 && n >= 1024 && kClsKB[cls[p]] >= c->hbm_from_kb && d.nb <= 168)) && !surely_big && !to_gang && !to_wg && c->dense_blocks_ok && !rel_family) {
 			// Does not fit any LDS class and the batch has many like it: the multi-workgroup path would run them a few at a time from the host. They stay on the
 			// one-wavefront kernel with the dense block system in an HBM workspace (slow per capsule, but thousands run side by side).
@@ -1724,8 +1696,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		  std::stable_sort(ho.begin(), ho.end(), [&](int x, int y) { return k.hap_term_off[x + 1] - k.hap_term_off[x] > k.hap_term_off[y + 1] - k.hap_term_off[y]; });
 		  int32_t *hr = (int32_t *)(h + o.hap_rec) + 3 * d.o_hrec; int nr = 0;
 		  for (int i = 0; i < k.n_hap; i++) { const int b = ho[i], tb = k.hap_term_off[b], te = k.hap_term_off[b + 1];
-			if (!d.hap_chunked) { hr[3 * nr] = b; hr[3 * nr + 1] = tb; hr[3 * nr + 2] = te; nr++; }
-			else { int t0 = tb; do { const int t1 = std::min(te, t0 + 8); hr[3 * nr] = b; hr[3 * nr + 1] = t0; hr[3 * nr + 2] = t1; nr++; t0 = t1; } while (t0 < te); } } /* (records of at most 8 terms, full ones first) */ }
+			hr[3 * nr] = b; hr[3 * nr + 1] = tb; hr[3 * nr + 2] = te; nr++; } }
 		if (d.hs_lds) { // the term lists of the LDS path: K6 terms by observation, Schur terms by landmark (stable: a block's terms keep their order inside an observation / a landmark)
 			std::vector<int32_t> ix(k.n_hap_terms), tb(k.n_hap_terms); for (int b = 0; b < k.n_hap; b++) for (int t = k.hap_term_off[b]; t < k.hap_term_off[b + 1]; t++) tb[t] = b;
 			for (int t = 0; t < k.n_hap_terms; t++) ix[t] = t;
@@ -2191,7 +2162,7 @@ static int lm_run_async_impl(srba_hip_ctx *c) {
 		HIPCHK(c, hipEventRecord(c->ev1, c->stream));
 		return 0;
 	}
-	if (!c->batch_copied) { if (!c->d_batch) HIPCHK(c, hipMalloc((void **)&c->d_batch, sizeof(Batch))); HIPCHK(c, hipMemcpyAsync(c->d_batch, &c->B, sizeof(Batch), hipMemcpyHostToDevice, c->stream)); c->batch_copied = true; } // the kernels read the batch record from device memory (c->B lives as long as the context and only changes at an upload)
+	if (!c->batch_copied) { if (!c->d_batch) HIPCHK(c, hipMalloc((void **)&c->d_batch, sizeof(Batch) + sizeof(DevParams))); HIPCHK(c, hipMemcpyAsync(c->d_batch, &c->B, sizeof(Batch), hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipMemcpyAsync(c->d_batch + 1, &c->dp, sizeof(DevParams), hipMemcpyHostToDevice, c->stream)); c->batch_copied = true; } // the kernels read the batch record from device memory (c->B lives as long as the context and only changes at an upload)
 	HIPCHK(c, hipMemsetAsync(c->d_next, 0, sizeof(int) * 4 * std::max<size_t>(1, std::min<size_t>(kMaxJobs, c->plan.size())), c->stream)); // per launch {work counter, pad, device time stamp of its first capsule}
 	// fork/join: the launch plan (made at upload) spreads the size classes over a few streams; see plan_launches()
 	const int nq = c->plan.size() <= 1 ? 1 : c->n_streams_used; // a single launch (the per-key-frame use) stays on the context stream: no fork / join
@@ -2204,14 +2175,14 @@ static int lm_run_async_impl(srba_hip_ctx *c) {
 		if (k >= SRBA_NLDS) { // landmark windows on a workgroup (k_lm_wg)
 			int rc_attr = 0;
 			with_family(c->params.family, [&](auto fam_) { constexpr int F = decltype(fam_)::value; if constexpr (srbadev::Tr<F>::SE3 && !srbadev::Tr<F>::REL) {
-				if (k == SRBA_CLS_WG512) { if ((rc_attr = allow_big_lds(c, srbadev::k_lm_wg<F, 512>, c->cls_lds[k])) == 0) hipLaunchKernelGGL((srbadev::k_lm_wg<F, 512>), dim3(J.grid), dim3(512), c->cls_lds[k], launch_stream, SRBA_WG_BATCH_VAL(c), c->dp, J.first, J.count, c->d_next + 4 * j); }
-				else if (k == SRBA_CLS_WG256) { if ((rc_attr = allow_big_lds(c, srbadev::k_lm_wg<F, 256>, c->cls_lds[k])) == 0) hipLaunchKernelGGL((srbadev::k_lm_wg<F, 256>), dim3(J.grid), dim3(256), c->cls_lds[k], launch_stream, SRBA_WG_BATCH_VAL(c), c->dp, J.first, J.count, c->d_next + 4 * j); }
-				else hipLaunchKernelGGL((srbadev::k_lm_wg<F, 128>), dim3(J.grid), dim3(128), c->cls_lds[k], launch_stream, SRBA_WG_BATCH_VAL(c), c->dp, J.first, J.count, c->d_next + 4 * j); } });
+				if (k == SRBA_CLS_WG512) { if ((rc_attr = allow_big_lds(c, srbadev::k_lm_wg<F, 512>, c->cls_lds[k])) == 0) hipLaunchKernelGGL((srbadev::k_lm_wg<F, 512>), dim3(J.grid), dim3(512), c->cls_lds[k], launch_stream, SRBA_WG_BATCH_VAL(c), J.first, J.count, c->d_next + 4 * j); }
+				else if (k == SRBA_CLS_WG256) { if ((rc_attr = allow_big_lds(c, srbadev::k_lm_wg<F, 256>, c->cls_lds[k])) == 0) hipLaunchKernelGGL((srbadev::k_lm_wg<F, 256>), dim3(J.grid), dim3(256), c->cls_lds[k], launch_stream, SRBA_WG_BATCH_VAL(c), J.first, J.count, c->d_next + 4 * j); }
+				else hipLaunchKernelGGL((srbadev::k_lm_wg<F, 128>), dim3(J.grid), dim3(128), c->cls_lds[k], launch_stream, SRBA_WG_BATCH_VAL(c), J.first, J.count, c->d_next + 4 * j); } });
 			if (rc_attr != 0) return -1;
 			HIPCHK(c, hipGetLastError()); continue; }
-		if (J.two) { const size_t lds1 = (c->cls_lds[k] + c->lds_pad + 7) & ~(size_t)7; hipLaunchKernelGGL((srbadev::k_lm_run2<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(2 * SRBA_WG), lds1 + 32, launch_stream, SRBA_LM_BATCH_VAL(c), c->dp, J.first, J.count, c->d_next + 4 * j, (int)(lds1 / 8)); HIPCHK(c, hipGetLastError()); continue; }
-		if (J.lean) { hipLaunchKernelGGL((srbadev::k_lm_run_lean<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(SRBA_WG), c->cls_lds[k] + c->lds_pad, launch_stream, SRBA_LM_BATCH_VAL(c), c->dp, J.first, J.count, c->d_next + 4 * j); HIPCHK(c, hipGetLastError()); continue; }
-		with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::k_lm_run<decltype(fam_)::value>), dim3(J.grid), dim3(SRBA_WG), c->cls_lds[k] + c->lds_pad, launch_stream, SRBA_LM_BATCH_VAL(c), c->dp, J.first, J.count, c->d_next + 4 * j); }); HIPCHK(c, hipGetLastError());
+		if (J.two) { const size_t lds1 = (c->cls_lds[k] + c->lds_pad + 7) & ~(size_t)7; hipLaunchKernelGGL((srbadev::k_lm_run2<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(2 * SRBA_WG), lds1 + 32, launch_stream, SRBA_LM_BATCH_VAL(c), J.first, J.count, c->d_next + 4 * j, (int)(lds1 / 8)); HIPCHK(c, hipGetLastError()); continue; }
+		if (J.lean) { hipLaunchKernelGGL((srbadev::k_lm_run_lean<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(SRBA_WG), c->cls_lds[k] + c->lds_pad, launch_stream, SRBA_LM_BATCH_VAL(c), J.first, J.count, c->d_next + 4 * j); HIPCHK(c, hipGetLastError()); continue; }
+		with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::k_lm_run<decltype(fam_)::value>), dim3(J.grid), dim3(SRBA_WG), c->cls_lds[k] + c->lds_pad, launch_stream, SRBA_LM_BATCH_VAL(c), J.first, J.count, c->d_next + 4 * j); }); HIPCHK(c, hipGetLastError());
 	}
 	// capsules too large for one wavefront's LDS: the multi-workgroup path, one capsule after the other on the context stream (host-driven LM loop: this part
 	// of the call synchronises with the device once per LM trial), overlapping with the persistent launches of the other classes on their own streams

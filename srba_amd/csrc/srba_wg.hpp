@@ -120,20 +120,18 @@ __device__ __forceinline__ bool wg_chol_solve(double *T, double *LI, const int n
 			if (i == nt && (l & 15) == 0) { const int c0 = 16 * k + (l >> 4); yb[c0] = dd.x; yb[c0 + 4] = dd.y; yb[c0 + 8] = dd.z; yb[c0 + 12] = dd.w; } // row 0 of the right-hand-side tile: y_k
 			return dd;
 		};
-		// L_ik = (A_ik - sum_{j<k} L_ij L_kj^t) L_kk^-t for one tile row; diag_sum (row k + 1 only): += sum_{j<k} L_ij L_ij^t. Two columns j per pass, the tiles of the next pass
+		// L_ik = (A_ik - sum_{j<k} L_ij L_kj^t) L_kk^-t for one tile row; diag_sum (row k + 1 only): += sum_{j<k} L_ij L_ij^t. One column j per pass, the tiles of the next pass
 		// requested before this pass's matrix instructions (the tiles come from L2 / the Infinity Cache: hundreds of cycles)
 		auto finish_row = [&](int i, f64x4w *diag_sum) __attribute__((always_inline)) -> f64x4w {
 			const double *rowi = T + 256 * (size_t)wg_tile(i, 0);
 			f64x4w s = zero4;
 			const f64x4w a0 = wg_ld(rowi + 256 * (size_t)k, l);
-			f64x4w A0 = zero4, B0 = zero4, A1 = zero4, B1 = zero4, nA0 = zero4, nB0 = zero4, nA1 = zero4, nB1 = zero4;
-			if (k > 0) { A0 = wg_ld(rowk, l); B0 = wg_ld(rowi, l); } if (k > 1) { A1 = wg_ld(rowk + 256, l); B1 = wg_ld(rowi + 256, l); }
-			for (int j = 0; j < k; j += 2) {
-				if (j + 2 < k) { nA0 = wg_ld(rowk + 256 * (size_t)(j + 2), l); nB0 = wg_ld(rowi + 256 * (size_t)(j + 2), l); }
-				if (j + 3 < k) { nA1 = wg_ld(rowk + 256 * (size_t)(j + 3), l); nB1 = wg_ld(rowi + 256 * (size_t)(j + 3), l); }
+			f64x4w A0 = zero4, B0 = zero4, nA0 = zero4, nB0 = zero4;
+			if (k > 0) { A0 = wg_ld(rowk, l); B0 = wg_ld(rowi, l); }
+			for (int j = 0; j < k; j++) {
+				if (j + 1 < k) { const size_t o = 256 * (size_t)(j + 1); nA0 = wg_ld(rowk + o, l); nB0 = wg_ld(rowi + o, l); }
 				s = wg_mma(A0, B0, s); if (diag_sum) *diag_sum = wg_mma(B0, B0, *diag_sum);
-				if (j + 1 < k) { s = wg_mma(A1, B1, s); if (diag_sum) *diag_sum = wg_mma(B1, B1, *diag_sum); }
-				A0 = nA0; B0 = nB0; A1 = nA1; B1 = nB1;
+				A0 = nA0; B0 = nB0;
 			}
 			return solve_store(i, a0, s);
 		};
@@ -142,14 +140,12 @@ __device__ __forceinline__ bool wg_chol_solve(double *T, double *LI, const int n
 			const double *r0 = T + 256 * (size_t)wg_tile(i0, 0), *r1 = T + 256 * (size_t)wg_tile(i1, 0);
 			f64x4w s0 = zero4, s1 = zero4;
 			const f64x4w a00 = wg_ld(r0 + 256 * (size_t)k, l), a01 = wg_ld(r1 + 256 * (size_t)k, l);
-			f64x4w A0 = zero4, P0 = zero4, Q0 = zero4, A1 = zero4, P1 = zero4, Q1 = zero4, nA0 = zero4, nP0 = zero4, nQ0 = zero4, nA1 = zero4, nP1 = zero4, nQ1 = zero4;
-			if (k > 0) { A0 = wg_ld(rowk, l); P0 = wg_ld(r0, l); Q0 = wg_ld(r1, l); } if (k > 1) { A1 = wg_ld(rowk + 256, l); P1 = wg_ld(r0 + 256, l); Q1 = wg_ld(r1 + 256, l); }
-			for (int j = 0; j < k; j += 2) {
-				if (j + 2 < k) { const size_t o = 256 * (size_t)(j + 2); nA0 = wg_ld(rowk + o, l); nP0 = wg_ld(r0 + o, l); nQ0 = wg_ld(r1 + o, l); }
-				if (j + 3 < k) { const size_t o = 256 * (size_t)(j + 3); nA1 = wg_ld(rowk + o, l); nP1 = wg_ld(r0 + o, l); nQ1 = wg_ld(r1 + o, l); }
+			f64x4w A0 = zero4, P0 = zero4, Q0 = zero4, nA0 = zero4, nP0 = zero4, nQ0 = zero4; // (one column per pass, the next one's three tiles on their way: six tiles of registers)
+			if (k > 0) { A0 = wg_ld(rowk, l); P0 = wg_ld(r0, l); Q0 = wg_ld(r1, l); }
+			for (int j = 0; j < k; j++) {
+				if (j + 1 < k) { const size_t o = 256 * (size_t)(j + 1); nA0 = wg_ld(rowk + o, l); nP0 = wg_ld(r0 + o, l); nQ0 = wg_ld(r1 + o, l); }
 				s0 = wg_mma(A0, P0, s0); s1 = wg_mma(A0, Q0, s1);
-				if (j + 1 < k) { s0 = wg_mma(A1, P1, s0); s1 = wg_mma(A1, Q1, s1); }
-				A0 = nA0; P0 = nP0; Q0 = nQ0; A1 = nA1; P1 = nP1; Q1 = nQ1;
+				A0 = nA0; P0 = nP0; Q0 = nQ0;
 			}
 			solve_store(i0, a00, s0); solve_store(i1, a01, s1);
 		};
