@@ -31,6 +31,18 @@
 namespace srbadev {
 
 // ------------------------------------------------------------------------------------------------ problem descriptor
+// A pointer into device (global) memory that says so in its type. The array pointers of `Batch` are read from a copy of the record in device memory (round 5: lnd below); a plain `double *`
+// loaded from memory is a GENERIC pointer to the compiler -- flat_load / flat_store instead of global_load / global_store, and every flat operation also counts as an LDS operation for
+// s_waitcnt. The wrapper holds an address_space(1) pointer and converts to the plain pointer on use: the conversion is an address-space cast the optimiser traces back, so the accesses are
+// global again. Same size and layout as a pointer, trivially copyable (the host fills the record with memset / assignments and copies it as bytes).
+template <class T> struct gptr {
+	typedef __attribute__((address_space(1))) T *gp_t;
+	gp_t p;
+	__host__ __device__ __forceinline__ operator T *() const { return (T *)p; }
+	__host__ __device__ __forceinline__ gptr &operator=(T *q) { p = (gp_t)q; return *this; }
+	__host__ __device__ __forceinline__ T *operator+(long long i) const { return (T *)p + i; }
+	__host__ __device__ __forceinline__ T &operator[](long long i) const { return ((T *)p)[i]; }
+};
 struct ProbDesc {
 	int n_edges, nK, nF, n_klm, n_pairs, n_obs, n_valid, n_bp, n_bf, n_hap, n_hf, n_hapf, n_sch, n_req, n_sys, n_scal, nb, nnzoff, n_hapt /* U_Ap terms */;
 	// element offsets into the batch-wide arrays
@@ -47,19 +59,19 @@ struct ProbDesc {
 
 struct Batch {
 	int n_prob; int max_lds_doubles; int hess_terms; int dense_left; // hess_terms: the fused kernel accumulates U_Ap term-parallel in LDS; dense_left: left-looking sweeps on the HBM-resident dense layout
-	const ProbDesc *desc; const int *order; // order: capsule indices grouped by LDS size class (one launch per class)
+	gptr<const ProbDesc> desc; gptr<const int> order; // order: capsule indices grouped by LDS size class (one launch per class)
 	// inputs
-	const double *edge0, *ulm0, *klm, *obs_z;
-	const int *pair_path_off, *path_edge, *obs_pose, *obs_lm, *obs_valid;
-	const int *obs_rec; // per observation {-2: identity | -1, pose index: a pose of the table no trial changes | 0 / 1 = which pose of its pair, four path entries (edge << 1 | inverse, -1 = none)}: phase_residuals_fused
-	const int *bp_col, *bp_res, *bp_A, *bp_D, *bp_lm, *colp_off, *bf_col, *bf_res, *bf_pose, *colf_off;
-	const int *hap_i, *hap_j, *hap_term_off, *hap_t1, *hap_t2, *hap_tblk /* block of every U_Ap term */, *hf_i, *hf_j, *hf_term_off, *hf_t1, *hf_t2;
-	const int *hapf_i, *hapf_j, *hapf_term_off, *hapf_t1, *hapf_t2, *hap_diag, *hf_diag;
-	const int *sch_term_off, *sch_b1, *sch_b2, *sch_lm, *sch_yw, *sch_tblk /* U_Ap block of every Schur term */, *lm_hapf_off, *lm_hapf_idx, *req_idx, *need_idx, *need_rec; // need_rec: per needed pair {pair, 4 path entries (edge<<1|inv, -1 = none)}
-	const unsigned char *pair_needed, *bp_normal;
-	const int *sp_fill; // unified block indices (diag k -> k, off-diagonal i -> nb+i)
-	const int *hapo, *schl; // see ProbDesc::hs_lds
-	const int *hap_rec; // K6 work records, sorted by decreasing term count (longest first: balances the lanes of K6): {block, first term, end term}; ProbDesc::n_hrec of them from o_hrec
+	gptr<const double> edge0, ulm0, klm, obs_z;
+	gptr<const int> pair_path_off, path_edge, obs_pose, obs_lm, obs_valid;
+	gptr<const int> obs_rec; // per observation {-2: identity | -1, pose index: a pose of the table no trial changes | 0 / 1 = which pose of its pair, four path entries (edge << 1 | inverse, -1 = none)}: phase_residuals_fused
+	gptr<const int> bp_col, bp_res, bp_A, bp_D, bp_lm, colp_off, bf_col, bf_res, bf_pose, colf_off;
+	gptr<const int> hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hap_tblk /* block of every U_Ap term */, hf_i, hf_j, hf_term_off, hf_t1, hf_t2;
+	gptr<const int> hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag;
+	gptr<const int> sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw, sch_tblk /* U_Ap block of every Schur term */, lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec; // need_rec: per needed pair {pair, 4 path entries (edge<<1|inv, -1 = none)}
+	gptr<const unsigned char> pair_needed, bp_normal;
+	gptr<const int> sp_fill; // unified block indices (diag k -> k, off-diagonal i -> nb+i)
+	gptr<const int> hapo, schl; // see ProbDesc::hs_lds
+	gptr<const int> hap_rec; // K6 work records, sorted by decreasing term count (longest first: balances the lanes of K6): {block, first term, end term}; ProbDesc::n_hrec of them from o_hrec
 	const int *sp_col_off, *sp_row, *sp_item_off, *sp_tgt /* packed update items: unified target block << 18 | a << 9 | b (packed at upload) */, *sp_rptr, *sp_rcol /* packed row-view entries: column << 14 | off-diagonal block */, *sp_perm; // symbolic factorisation of every capsule's system
 	const int *hap_dst, *hapf_dst, *hf_dst; // destination 3x3 block of every aligned sub-block of the Hessian blocks (see symbolic_factor)
 	// state + workspace

@@ -568,31 +568,32 @@ template <int FAM, bool DB = (SRBA_LM_DB != 0), bool LEAN = false, int G = 64, b
           bool LND = false /* B0 lies in global memory (a kernel that takes `const Batch *`): every phase works through its own laundered reference to it and to the descriptor (srba_device.hpp lnd) */>
 __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, const int pidx, double *red = nullptr /* G = 128: LDS scratch of the group reductions */) {
 	const ProbDesc &d = B0.desc[pidx];
-	const Batch &B = B0;
+	// the batch record for this function's own few accesses: a reference of its own at every use (LND), like the phases (srba_device.hpp lnd)
+	auto LB = [&]() __attribute__((always_inline)) -> const Batch & { if constexpr (LND) return lnd(B0); else return B0; };
 	int cur = 0, last_rej = 0; bool lazy_rej = false; // DB: which copy holds the accepted state; the last evaluated trial was rejected (lazy_rej: ... and the pose table of the trial copy was not refreshed for it)
 	typedef Solver<FAM, LEAN, G> Sv;
 	// a worker on copy `cp` of the state for ONE phase call (LND: through references nothing else shares -- the pointers a phase uses are loaded when it starts and die when it ends)
 	auto Wk = [&](int cp) __attribute__((always_inline)) -> Sv { if constexpr (LND) return Sv(lnd(B0), lnd(d), lnd(prm), red, cp); else return Sv(B0, d, prm, red, cp); };
-	Solver<FAM, LEAN, G> S(B, d, prm, red);
+	Solver<FAM, LEAN, G> S(B0, d, prm, red); // (for the questions that touch no array: schur_active)
 	constexpr int P = Solver<FAM, LEAN, G>::P, L = Solver<FAM, LEAN, G>::L, O = Solver<FAM, LEAN, G>::O;
-	const SparseSys A = S.make_sys(srba_lds);
-	const int tid = threadIdx.x; srba_lm_result *out = B.results + pidx;
+	const SparseSys A = Wk(0).make_sys(srba_lds);
+	const int tid = threadIdx.x; srba_lm_result *out = LB().results + pidx;
 	const int nObs = d.n_obs, n = d.n_scal;
-	double *resid = B.resid, *resid2 = B.resid2;
+	double *resid, *resid2; { const Batch &Bl = LB(); resid = Bl.resid; resid2 = Bl.resid2; }
 
-	long long *pc = B.phase_cycles ? B.phase_cycles + (long long)pidx * 16 : nullptr; long long tc0 = 0;
+	long long *pc; { const Batch &Bl = LB(); pc = Bl.phase_cycles ? Bl.phase_cycles + (long long)pidx * 16 : nullptr; } long long tc0 = 0;
 #define TIC() do { if (pc) { __syncthreads(); tc0 = wall_clock64(); } } while (0)
 #define TOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - tc0; } } while (0)
 	// K6: the LDS image of the system is idle while the capsule is linearised (it is assembled per trial): the U_Ap accumulators of the term-parallel form live there
-	const bool hess_terms = G <= 128 && B.hess_terms && d.dense_in_lds && d.n_hap * P * P <= 9 * (d.nb + d.nnzoff); // (the term-parallel form cuts the list between TWO wavefronts; workgroup windows keep no system in LDS anyway)
+	const bool hess_terms = G <= 128 && LB().hess_terms && d.dense_in_lds && d.n_hap * P * P <= 9 * (d.nb + d.nnzoff); // (the term-parallel form cuts the list between TWO wavefronts; workgroup windows keep no system in LDS anyway)
 	bool hs_reduced = false; // workgroup path, U_Ap in LDS: the LDS blocks hold the Schur-reduced system of the last solve (what the reference leaves in HAp), not yet written back
 	auto hessian = [&](int cp) __attribute__((always_inline)) -> int { Sv X = Wk(cp); if constexpr (G > 64 && !Tr<FAM>::REL) { hs_reduced = false; return X.phase_hessian_lds(); } else return hess_terms ? X.phase_hessian_terms(srba_lds) /* == A.diag: the LDS image, idle while the capsule is linearised */ + X.phase_hessian_landmark_blocks() : X.phase_hessian(); };
 	double lambda, nu = 2.0, total_err, RMSE;
 	int iter = 0, trials = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0; bool stop = false;
-	TIC(); Wk(0).phase_spantree(false, nullptr, DB ? B0.pose1 : nullptr); // S5 (DB: both copies of the poses)
-	if constexpr (DB) { constexpr int PD = Solver<FAM, LEAN, G>::PD; // the second copy of the unknowns (the fixed edges of the paths stay equal in both for good)
-		for (int k = tid; k < d.n_edges * PD; k += G) B0.edge1[d.o_edge * PD + k] = B0.edge[d.o_edge * PD + k];
-		for (int k = tid; k < d.nF * L; k += G) B0.ulm1[d.o_ulm * L + k] = B0.ulm[d.o_ulm * L + k]; }
+	TIC(); Wk(0).phase_spantree(false, nullptr, DB ? (double *)LB().pose1 : nullptr); // S5 (DB: both copies of the poses)
+	if constexpr (DB) { constexpr int PD = Solver<FAM, LEAN, G>::PD; const Batch &Bl = LB(); // the second copy of the unknowns (the fixed edges of the paths stay equal in both for good)
+		for (int k = tid; k < d.n_edges * PD; k += G) Bl.edge1[d.o_edge * PD + k] = Bl.edge[d.o_edge * PD + k];
+		for (int k = tid; k < d.nF * L; k += G) Bl.ulm1[d.o_ulm * L + k] = Bl.ulm[d.o_ulm * L + k]; }
 	__syncthreads(); TOC(0);
 	TIC(); Wk(0).phase_jacobians(); TOC(1); // S6,S7
 	TIC(); const int ninv = (int)grp_sum<G>((double)hessian(0), red); // S10
@@ -635,7 +636,7 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 				TIC(); new_err = Wk(ct).phase_residuals(resid2, red); TOC(3); }
 			const double new_RMSE = sqrt(new_err / nObs);
 			const double err_red = total_err > 0 ? (total_err - new_err) / total_err : 0;
-			double den = 0; { const double *dl = B.delta + d.o_scal, *g = B.grad + d.o_scal;
+			double den = 0; { const Batch &Bl = LB(); const double *dl = Bl.delta + d.o_scal, *g = Bl.grad + d.o_scal;
 				if (S.schur_active() || !d.dense_in_lds) { for (int k = tid; k < n; k += G) den += dl[k] * (lambda * dl[k] + g[k]); }
 				else for (int k = tid; k < n; k += G) { const double dk = A.sol(k); den += dk * (lambda * dk + g[k]); } } // (the solved right-hand side is still in the LDS image: the same numbers, no round trip through memory)
 			den = grp_sum<G>(den, red);
@@ -652,7 +653,7 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 				if (relin) { n_relin++; TIC(); Wk(ct).phase_jacobians(); TOC(1); TIC(); hessian(ct); __syncthreads(); TOC(2); }
 				TIC(); Wk(ct).phase_gradient(resid);
 				__syncthreads(); Wk(ct).keep_gradient(); TOC(4);
-				double ninf = 0; { const double *g = B.grad + d.o_scal; for (int k = tid; k < n; k += G) ninf = fmax(ninf, fabs(g[k])); }
+				double ninf = 0; { const double *g = LB().grad + d.o_scal; for (int k = tid; k < n; k += G) ninf = fmax(ninf, fabs(g[k])); }
 				ninf = grp_max<G>(ninf, red);
 				if (ninf <= 1e-15) { stop = true; stopmask |= 1 << SRBA_STOP_GRADIENT; }
 				if (RMSE < prm.max_err) { stop = true; stopmask |= 1 << SRBA_STOP_RMSE; }
@@ -668,10 +669,11 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 	if constexpr (G > 64 && !Tr<FAM>::REL) { if (hs_reduced && S.schur_active()) { __syncthreads(); Wk(0).store_hs(false); } } // (the reference's Schur complement works on HAp in place: its reduced blocks are what a caller reads after the run)
 	// S17: crpLandmarksApprox
 	if constexpr (!Solver<FAM, LEAN, G>::W::T::REL) {
+		const Batch &Bl = LB();
 		for (int l = tid; l < d.nF; l += G) {
-			const bool ok = prm.cov_recovery == 1 && (S.schur_active() ? (B.hf_ok[d.o_ulm + l] != 0) : true);
-			B.ulm_inf_valid[d.o_ulm + l] = ok ? 1 : 0;
-			if (ok) for (int k = 0; k < L * L; k++) B.ulm_inf[(d.o_ulm + l) * L * L + k] = B.Hf[(d.o_hf + B.hf_diag[d.o_ulm + l]) * L * L + k];
+			const bool ok = prm.cov_recovery == 1 && (S.schur_active() ? (Bl.hf_ok[d.o_ulm + l] != 0) : true);
+			Bl.ulm_inf_valid[d.o_ulm + l] = ok ? 1 : 0;
+			if (ok) for (int k = 0; k < L * L; k++) Bl.ulm_inf[(d.o_ulm + l) * L * L + k] = Bl.Hf[(d.o_hf + Bl.hf_diag[d.o_ulm + l]) * L * L + k];
 		}
 	}
 	if (tid == 0) {
@@ -679,21 +681,21 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 		out->total_sqr_error_final = total_err; out->obs_rmse = RMSE; out->lambda_final = lambda;
 	}
 	if constexpr (DB) { // the reference's partial restore, where it becomes visible: a rejected trial refreshed BOTH poses of every pair in use and only the ones Jacobian blocks read went back (optimize_edges.h:664-670)
-		constexpr int PD = Solver<FAM, LEAN, G>::PD; double *pose_a = cur ? B0.pose1 : B0.pose, *pose_t = cur ? B0.pose : B0.pose1; // accepted / trial copy of the pose table
+		constexpr int PD = Solver<FAM, LEAN, G>::PD; const Batch &Bl = LB(); double *pose_a = cur ? Bl.pose1 : Bl.pose, *pose_t = cur ? Bl.pose : Bl.pose1; // accepted / trial copy of the pose table
 		__syncthreads();
 		if (last_rej && lazy_rej) { Wk(cur ^ 1).phase_spantree(true, nullptr); __syncthreads(); } // (the last rejected trial's poses, from its edges in the trial copy)
 		if (last_rej) for (int q = tid; q < 2 * d.n_need; q += G) {
-			const long long ps = 2LL * B0.need_idx[d.o_pair + (q >> 1)] + (q & 1);
-			if (!B0.pose_req[d.o_pair * 2 + ps]) { double v[PD]; ldn<PD>(v, pose_t + (d.o_pair * 2 + ps) * PD); stn<PD>(pose_a + (d.o_pair * 2 + ps) * PD, v); }
+			const long long ps = 2LL * Bl.need_idx[d.o_pair + (q >> 1)] + (q & 1);
+			if (!Bl.pose_req[d.o_pair * 2 + ps]) { double v[PD]; ldn<PD>(v, pose_t + (d.o_pair * 2 + ps) * PD); stn<PD>(pose_a + (d.o_pair * 2 + ps) * PD, v); }
 		}
 	}
 	if constexpr (DB) { // the accepted state goes back to the primary arrays
-		constexpr int PD = Solver<FAM, LEAN, G>::PD;
+		constexpr int PD = Solver<FAM, LEAN, G>::PD; const Batch &Bl = LB();
 		__syncthreads();
 		if (cur) {
-			for (int k = tid; k < d.nK * PD; k += G) B0.edge[d.o_edge * PD + k] = B0.edge1[d.o_edge * PD + k];
-			for (int k = tid; k < d.nF * L; k += G) B0.ulm[d.o_ulm * L + k] = B0.ulm1[d.o_ulm * L + k];
-			for (int q = tid; q < 2 * d.n_need; q += G) { const long long ps = 2LL * B0.need_idx[d.o_pair + (q >> 1)] + (q & 1); double v[PD]; ldn<PD>(v, B0.pose1 + (d.o_pair * 2 + ps) * PD); stn<PD>(B0.pose + (d.o_pair * 2 + ps) * PD, v); }
+			for (int k = tid; k < d.nK * PD; k += G) Bl.edge[d.o_edge * PD + k] = Bl.edge1[d.o_edge * PD + k];
+			for (int k = tid; k < d.nF * L; k += G) Bl.ulm[d.o_ulm * L + k] = Bl.ulm1[d.o_ulm * L + k];
+			for (int q = tid; q < 2 * d.n_need; q += G) { const long long ps = 2LL * Bl.need_idx[d.o_pair + (q >> 1)] + (q & 1); double v[PD]; ldn<PD>(v, Bl.pose1 + (d.o_pair * 2 + ps) * PD); stn<PD>(Bl.pose + (d.o_pair * 2 + ps) * PD, v); }
 		}
 	}
 	(void)P;
