@@ -52,6 +52,7 @@ struct ProbDesc {
 	long long o_hap, o_hapoff, o_hapt, o_hf, o_hfoff, o_hft, o_hapf, o_hapfoff, o_hapft, o_sch, o_lmoff, o_req, o_scal, o_yw, o_spcol, o_sprow, o_spitem, o_spperm, o_dense;
 	int hapt_split; // two wavefronts per capsule: the second one takes the U_Ap terms from this index on (the first term of a Hessian block at or after the middle of the list: no block is summed by both)
 	int n_items, aligned; // block updates per factorisation; 1 if every Hessian block maps onto whole 3x3 blocks (always, except L==2 with the no-Schur solver)
+	int n_panel; long long o_ptab; // ... in n_panel passes over block ranges that fit the LDS of the workgroup (one for most windows): Batch::ptab holds, from o_ptab, the n_panel + 1 block bounds, then the bounds of the panels' K6 terms, then those of their Schur terms (both lists sorted by panel first)
 	int hs_lds; long long o_hapo, o_schl; // workgroup path, U_Ap accumulators in LDS (Solver::phase_hessian_lds / schur_reduce_lds): the U_Ap terms sorted by observation {t1, t2, block} from o_hapo (x3), the Schur terms sorted by landmark {lm, b1, b2, block | edge << 16 | diagonal << 31} from o_schl (x4)
 	int n_hrec, hap_chunked /* unused since the workgroup path sums U_Ap in LDS */; long long o_hrec; // K6 work records {U_Ap block, first term, end term} (Batch::hap_rec), one per block
 	int dense_in_lds, dense_blocks; // dense_blocks: the LDS image holds ALL blocks of the lower triangle (column-major), no symbolic structure (mid-size, nearly dense systems)
@@ -70,7 +71,7 @@ struct Batch {
 	gptr<const int> sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw, sch_tblk /* U_Ap block of every Schur term */, lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec; // need_rec: per needed pair {pair, 4 path entries (edge<<1|inv, -1 = none)}
 	gptr<const unsigned char> pair_needed, bp_normal;
 	gptr<const int> sp_fill; // unified block indices (diag k -> k, off-diagonal i -> nb+i)
-	gptr<const int> hapo, schl; // see ProbDesc::hs_lds
+	gptr<const int> hapo, schl, ptab; // see ProbDesc::hs_lds, n_panel
 	gptr<const int> hap_rec; // K6 work records, sorted by decreasing term count (longest first: balances the lanes of K6): {block, first term, end term}; ProbDesc::n_hrec of them from o_hrec
 	const int *sp_col_off, *sp_row, *sp_item_off, *sp_tgt /* packed update items: unified target block << 18 | a << 9 | b (packed at upload) */, *sp_rptr, *sp_rcol /* packed row-view entries: column << 14 | off-diagonal block */, *sp_perm; // symbolic factorisation of every capsule's system
 	const int *hap_dst, *hapf_dst, *hf_dst; // destination 3x3 block of every aligned sub-block of the Hessian blocks (see symbolic_factor)

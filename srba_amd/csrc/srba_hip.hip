@@ -133,42 +133,54 @@ struct Solver : public Worker<FAM, LEAN, G> {
 	// (block stride P P + 1 doubles: with 36 the same element of 64 different blocks falls on 8 of the 32 bank pairs of the LDS -- an 8-way conflict on every ds_add_f64 of the term loops)
 	static constexpr int HS = P * P + 1;
 	__device__ __forceinline__ double *hs() const { return srba_lds + WG_HS; }
-	__device__ __forceinline__ void store_hs(bool latch_too) { this->fresh(); // the LDS blocks -> U_Ap (and its latch, schur.h:38) in memory, 16 bytes per lane and request
-		const double *H = hs(); double *Hg = B.HAp + d.o_hap * P * P, *H0 = B.HAp0 + d.o_hap * P * P; const int n_acc = d.n_hap * P * P; static_assert((P * P) % 2 == 0, "pairs of doubles inside a block");
+	// A window whose U_Ap blocks do not all fit the LDS of a CU (more than 515: a third of the windows of the cfg3 room, half of its work) is swept in PANELS: block ranges that do fit, each
+	// with its own share of the two term lists (the host sorts the lists by panel first: every term still runs once). ProbDesc::n_panel, Batch::ptab.
+	__device__ __forceinline__ const int *ptab() const { return B.ptab + d.o_ptab; }
+	// the LDS blocks [b0, b1) -> U_Ap (and its latch, schur.h:38) in memory, 16 bytes per lane and request
+	__device__ __forceinline__ void store_hs(bool latch_too, int b0, int b1) { this->fresh();
+		const double *H = hs(); double *Hg = B.HAp + (d.o_hap + b0) * P * P, *H0 = B.HAp0 + (d.o_hap + b0) * P * P; const int n_acc = (b1 - b0) * P * P; static_assert((P * P) % 2 == 0, "pairs of doubles inside a block");
 		for (int k = 2 * tid; k < n_acc; k += 2 * G) { const int b = k / (P * P), e = k - b * (P * P); f64x2u v; v.x = H[b * HS + e]; v.y = H[b * HS + e + 1]; *(f64x2u *)(Hg + k) = v; if (latch_too) *(f64x2u *)(H0 + k) = v; }
 	}
+	__device__ __forceinline__ void store_hs(bool latch_too) { store_hs(latch_too, 0, d.n_hap); } // (single-panel windows: the reduced blocks go to memory once, when the run ends)
 	// K6 (sparse_hessian_update_numeric.h:22-60): U_Ap summed in LDS from the term list sorted by observation; U_f and U_Apf as before (their lists are a landmark's observations: short)
 	__device__ __forceinline__ int phase_hessian_lds() { this->fresh();
-		double *H = hs(); const int nt = d.n_hapt;
-		for (int k = tid; k < d.n_hap * HS; k += G) H[k] = 0;
-		__syncthreads();
+		double *H = hs(); const int *pt = ptab(); const int np = d.n_panel;
 		const double *Jp = B.Jp + d.o_bp * O * P; const unsigned char *rp = B.bp_ok + d.o_bp; const int *rec = B.hapo + d.o_hapo * 3;
 		const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0;
-		// (one term in flight per lane, the next record requested ahead. Two terms in flight -- 96 more registers -- were measured and changed nothing, tools/r5_session6.sh:
-		//  with the blocks of a wavefront's terms shared through the vector L1 the loop is bound by its 36 ds_add_f64 per term, not by the loads)
-		int ninv = 0, b1 = 0, b2 = 0, blk = 0;
-		if (tid < nt) { b1 = rec[3 * tid]; b2 = rec[3 * tid + 1]; blk = rec[3 * tid + 2]; }
-		for (int t = tid; t < nt; t += G) {
-			const int tn = t + G; int n1 = 0, n2 = 0, nb = 0; if (tn < nt) { n1 = rec[3 * tn]; n2 = rec[3 * tn + 1]; nb = rec[3 * tn + 2]; }
-			double A[O * P], Bm[O * P]; ldn<O * P>(A, Jp + (long long)b1 * O * P); ldn<O * P>(Bm, Jp + (long long)b2 * O * P);
-			if (rp[b1] && rp[b2]) {
-				double *dst = H + blk * HS;
+		int ninv = 0;
+		for (int q = 0; q < np; q++) {
+			const int pb0 = pt[q], pb1 = pt[q + 1], t0 = pt[np + 1 + q], t1 = pt[np + 2 + q];
+			for (int k = tid; k < (pb1 - pb0) * HS; k += G) H[k] = 0;
+			__syncthreads();
+			// (one term in flight per lane, the next record requested ahead. Two terms in flight -- 96 more registers -- were measured and changed nothing, tools/r5_session6.sh:
+			//  with the blocks of a wavefront's terms shared through the vector L1 the loop is bound by its 36 ds_add_f64 per term, not by the loads)
+			int b1 = 0, b2 = 0, blk = 0;
+			if (t0 + tid < t1) { b1 = rec[3 * (t0 + tid)]; b2 = rec[3 * (t0 + tid) + 1]; blk = rec[3 * (t0 + tid) + 2]; }
+			for (int t = t0 + tid; t < t1; t += G) {
+				const int tn = t + G; int n1 = 0, n2 = 0, nb = 0; if (tn < t1) { n1 = rec[3 * tn]; n2 = rec[3 * tn + 1]; nb = rec[3 * tn + 2]; }
+				double A[O * P], Bm[O * P]; ldn<O * P>(A, Jp + (long long)b1 * O * P); ldn<O * P>(Bm, Jp + (long long)b2 * O * P);
+				if (rp[b1] && rp[b2]) {
+					double *dst = H + (blk - pb0) * HS;
 #pragma unroll
-				for (int i = 0; i < P; i++) { double row[P]; W::template hess_row<P, P>(row, A, Bm, i);
+					for (int i = 0; i < P; i++) { double row[P]; W::template hess_row<P, P>(row, A, Bm, i);
 #pragma unroll
-					for (int j = 0; j < P; j++) atomicAdd(dst + i * P + j, row[j] * sc); }
-			} else ninv++;
-			b1 = n1; b2 = n2; blk = nb;
+						for (int j = 0; j < P; j++) atomicAdd(dst + i * P + j, row[j] * sc); }
+				} else ninv++;
+				b1 = n1; b2 = n2; blk = nb;
+			}
+			if (q == 0) ninv += this->phase_hessian_landmark_blocks();
+			__syncthreads();
+			store_hs(prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL, pb0, pb1);
+			if (q + 1 < np) __syncthreads();
 		}
-		ninv += this->phase_hessian_landmark_blocks();
-		__syncthreads();
-		store_hs(prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL);
 		return ninv;
 	}
-	// K7 + K8 (schur.h:180-268) with the reduced U_Ap in LDS: starts from the latch, a lane per Schur term (sorted by landmark), Y = W Hf^-1 formed per term from cached inputs
-	__device__ __forceinline__ void schur_reduce_lds(double lambda, long long *pc = nullptr) { this->fresh(); long long tq = pc ? wall_clock64() : 0;
+	// K7 + K8 (schur.h:180-268) AND the assembly of the reduced system into the tile layout (assemble_tiles): the reduced U_Ap blocks start from the latch in LDS, a lane per Schur term (sorted
+	// by landmark) adds -Y W^t with Y = W Hf^-1 formed per term from cached inputs, and the finished blocks go from LDS straight into the lower triangle of 16 x 16 tiles -- panel by panel.
+	__device__ __forceinline__ void schur_assemble_lds(const SparseSys &S, double lambda, long long *pc = nullptr) { this->fresh(); long long tq = pc ? wall_clock64() : 0;
 		if constexpr (!W::T::REL) {
-			double *H = hs(), *gacc = srba_lds + WG_GACC; const int n_acc = d.n_hap * P * P;
+			double *H = hs(), *gacc = srba_lds + WG_GACC; const int *pt = ptab(); const int np = d.n_panel;
+			const int n = d.n_sys, ntl = S.nt; double *T = S.tiles;
 			for (int l = tid; l < d.nF; l += G) {
 				double M[L * L], Mi[L * L]; const double *src = B.Hf + (d.o_hf + B.hf_diag[d.o_ulm + l]) * L * L;
 				for (int k = 0; k < L * L; k++) M[k] = src[k];
@@ -177,46 +189,66 @@ struct Solver : public Worker<FAM, LEAN, G> {
 				B.hf_ok[d.o_ulm + l] = ok ? 1 : 0;
 				if (ok) for (int k = 0; k < L * L; k++) B.Hfinv[(d.o_ulm + l) * L * L + k] = Mi[k];
 			}
-			{ const double *H0 = B.HAp0 + d.o_hap * P * P;
-			  for (int k = 2 * tid; k < n_acc; k += 2 * G) { const int b = k / (P * P), e = k - b * (P * P); const f64x2u v = *(const f64x2u *)(H0 + k); H[b * HS + e] = v.x; H[b * HS + e + 1] = v.y; }
-			  for (int k = tid; k < d.nK * P; k += G) gacc[k] = 0; }
-			__syncthreads();
-			if (pc) { if (tid == 0) pc[14] += wall_clock64() - tq; tq = wall_clock64(); }
-			const int *rec = B.schl + d.o_schl * 4; const double *gf = B.grad + d.o_scal + d.nK * P; const int nt = d.n_sch;
-			int l = 0, b1 = 0, b2 = 0, w = 0;
-			if (tid < nt) { l = rec[4 * tid]; b1 = rec[4 * tid + 1]; b2 = rec[4 * tid + 2]; w = rec[4 * tid + 3]; }
-			for (int t = tid; t < nt; t += G) {
-				const int tn = t + G; int nl = 0, n1 = 0, n2 = 0, nw = 0; if (tn < nt) { nl = rec[4 * tn]; n1 = rec[4 * tn + 1]; n2 = rec[4 * tn + 2]; nw = rec[4 * tn + 3]; }
-				double W1[P * L], W2[P * L], Hi[L * L], gl[L];
-				ldn<P * L>(W1, B.HApf + (d.o_hapf + b1) * P * L); ldn<P * L>(W2, B.HApf + (d.o_hapf + b2) * P * L); ldn<L * L>(Hi, B.Hfinv + (d.o_ulm + l) * L * L); ldn<L>(gl, gf + l * L);
-				if (B.hf_ok[d.o_ulm + l] != 0) {
-					const int blk = w & 0xffff, e = (w >> 16) & 0x7fff; const bool diag = w < 0;
-					double *dst = H + blk * HS;
+			{ const long long n2 = 128LL * (ntl + 1) * (ntl + 2) / 2; f64x2u z; z.x = 0; z.y = 0; for (long long k = tid; k < n2; k += G) *(f64x2u *)(T + 2 * k) = z; } // the tile area is cleared ...
+			for (int k = tid; k < d.nK * P; k += G) gacc[k] = 0;
+			auto at = [&](int r, int c) __attribute__((always_inline)) -> double * { return T + 256 * (long long)wg_tile(r >> 4, c >> 4) + wg_frag_off(r & 15, c & 15); }; // element (r, c), r >= c
+			const int *rec = B.schl + d.o_schl * 4; const double *gf = B.grad + d.o_scal + d.nK * P;
+			for (int q = 0; q < np; q++) {
+				const int pb0 = pt[q], pb1 = pt[q + 1], t0 = pt[2 * np + 2 + q], t1 = pt[2 * np + 3 + q], n_acc = (pb1 - pb0) * P * P;
+				{ const double *H0 = B.HAp0 + (d.o_hap + pb0) * P * P;
+				  for (int k = 2 * tid; k < n_acc; k += 2 * G) { const int b = k / (P * P), e = k - b * (P * P); const f64x2u v = *(const f64x2u *)(H0 + k); H[b * HS + e] = v.x; H[b * HS + e + 1] = v.y; } }
+				__syncthreads();
+				if (pc && q == 0) { if (tid == 0) pc[14] += wall_clock64() - tq; tq = wall_clock64(); }
+				int l = 0, b1 = 0, b2 = 0, w = 0;
+				if (t0 + tid < t1) { const int t = t0 + tid; l = rec[4 * t]; b1 = rec[4 * t + 1]; b2 = rec[4 * t + 2]; w = rec[4 * t + 3]; }
+				for (int t = t0 + tid; t < t1; t += G) {
+					const int tn = t + G; int nl = 0, n1 = 0, n2 = 0, nw = 0; if (tn < t1) { nl = rec[4 * tn]; n1 = rec[4 * tn + 1]; n2 = rec[4 * tn + 2]; nw = rec[4 * tn + 3]; }
+					double W1[P * L], W2[P * L], Hi[L * L], gl[L];
+					ldn<P * L>(W1, B.HApf + (d.o_hapf + b1) * P * L); ldn<P * L>(W2, B.HApf + (d.o_hapf + b2) * P * L); ldn<L * L>(Hi, B.Hfinv + (d.o_ulm + l) * L * L); ldn<L>(gl, gf + l * L);
+					if (B.hf_ok[d.o_ulm + l] != 0) {
+						const int blk = w & 0xffff, e = (w >> 16) & 0x7fff; const bool diag = w < 0;
+						double *dst = H + (blk - pb0) * HS;
 #pragma unroll
-					for (int i = 0; i < P; i++) {
-						double y[L];
+						for (int i = 0; i < P; i++) {
+							double y[L];
 #pragma unroll
-						for (int j = 0; j < L; j++) { double sm = 0;
+							for (int j = 0; j < L; j++) { double sm = 0;
 #pragma unroll
-							for (int k = 0; k < L; k++) sm += W1[i * L + k] * Hi[k * L + j];
-							y[j] = sm; }
+								for (int k = 0; k < L; k++) sm += W1[i * L + k] * Hi[k * L + j];
+								y[j] = sm; }
 #pragma unroll
-						for (int j = 0; j < P; j++) { double sm = 0;
+							for (int j = 0; j < P; j++) { double sm = 0;
 #pragma unroll
-							for (int k = 0; k < L; k++) sm += y[k] * W2[j * L + k];
-							atomicAdd(dst + i * P + j, -sm); }
-						if (diag) { double sm = 0;
+								for (int k = 0; k < L; k++) sm += y[k] * W2[j * L + k];
+								atomicAdd(dst + i * P + j, -sm); }
+							if (diag) { double sm = 0;
 #pragma unroll
-							for (int k = 0; k < L; k++) sm += y[k] * gl[k];
-							atomicAdd(gacc + e * P + i, -sm); }
+								for (int k = 0; k < L; k++) sm += y[k] * gl[k];
+								atomicAdd(gacc + e * P + i, -sm); }
+						}
+					}
+					l = nl; b1 = n1; b2 = n2; w = nw;
+				}
+				__syncthreads();
+				if (pc && q + 1 == np) { if (tid == 0) pc[15] += wall_clock64() - tq; tq = wall_clock64(); }
+				// ... and the panel's reduced blocks leave LDS for the tiles: a lane per block ROW, every upper-triangle block (i <= j) transposed into the lower triangle
+				for (int e0 = tid; e0 < (pb1 - pb0) * P; e0 += G) {
+					const int b = e0 / P, r = e0 - b * P; const int i = B.hap_i[d.o_hap + pb0 + b], j = B.hap_j[d.o_hap + pb0 + b]; const double *src = H + b * HS + r * P;
+#pragma unroll
+					for (int c = 0; c < P; c++) {
+						if (i != j) *at(P * j + c, P * i + r) = src[c];
+						else if (r >= c) *at(P * i + r, P * i + c) = src[c] + (r == c ? lambda : 0.0); // (a diagonal block holds both triangles)
 					}
 				}
-				l = nl; b1 = n1; b2 = n2; w = nw;
+				if (np > 1) store_hs(false, pb0, pb1); // (what the reference's in-place Schur complement leaves in HAp; a single panel is written once, when the run ends)
+				if (q + 1 < np) __syncthreads();
 			}
-			__syncthreads();
 			{ double *g = B.grad + d.o_scal; for (int k = tid; k < d.nK * P; k += G) g[k] += gacc[k]; }
 			__syncthreads();
-			if (pc) { if (tid == 0) pc[15] += wall_clock64() - tq; }
+			const double *g = B.grad + d.o_scal; // the (corrected) gradient is tile row nt; rows beyond n_sys get an identity diagonal
+			for (int k = tid; k < 16 * ntl; k += G) { T[256 * (long long)wg_tile(ntl, k >> 4) + wg_frag_off(0, k & 15)] = (k < n) ? g[k] : 0.0; if (k >= n) *at(k, k) = 1.0; }
+			__syncthreads();
+			if (pc) { if (tid == 0) pc[10] += wall_clock64() - tq; }
 		}
 	}
 	// K10 (schur.h:271-311)
@@ -366,31 +398,6 @@ struct Solver : public Worker<FAM, LEAN, G> {
 		for (int k = n + tid; k < 3 * nb; k += G) S.diag[9 * S.perm[k / 3] + 4 * (k % 3)] = 1.0; // identity padding
 		__syncthreads();
 	}
-	// The Schur-reduced system H_Ap' + lambda I and its right-hand side as 16 x 16 frag tiles (srba_wg.hpp; lev-marq_solvers.h:492-519 builds the same dense matrix for Eigen::LLT):
-	// the area is cleared, then every upper-triangle U_Ap block (i <= j) lands transposed in the lower triangle; rows beyond n_sys get an identity diagonal; the gradient is tile row nt.
-	__device__ __forceinline__ void assemble_tiles(const SparseSys &S, double lambda) { this->fresh();
-		const int n = d.n_sys, nt = S.nt; double *T = S.tiles; const double *Hsrc = hs(); constexpr int hstride = HS; // the reduced U_Ap blocks, in LDS
-		{ const long long n2 = 128LL * (nt + 1) * (nt + 2) / 2; f64x2u z; z.x = 0; z.y = 0; for (long long k = tid; k < n2; k += G) *(f64x2u *)(T + 2 * k) = z; }
-		__syncthreads();
-		auto at = [&](int r, int c) __attribute__((always_inline)) -> double * { return T + 256 * (long long)wg_tile(r >> 4, c >> 4) + wg_frag_off(r & 15, c & 15); }; // element (r, c), r >= c
-		for (int e0 = tid; e0 < d.n_hap * P; e0 += 2 * G) { // a lane per block ROW, two in flight: the block's position and its six numbers are requested together (the loop waits for memory, not for arithmetic)
-			int bi[2], bj[2], rr[2]; bool live[2]; double v[2][P];
-#pragma unroll
-			for (int u = 0; u < 2; u++) { const int e = e0 + u * G; live[u] = e < d.n_hap * P; const int b = live[u] ? e / P : 0; rr[u] = e % P; bi[u] = B.hap_i[d.o_hap + b]; bj[u] = B.hap_j[d.o_hap + b]; const double *src = Hsrc + b * hstride + rr[u] * P;
-#pragma unroll
-				for (int q = 0; q < P; q++) v[u][q] = src[q]; }
-#pragma unroll
-			for (int u = 0; u < 2; u++) if (live[u]) { const int i = bi[u], j = bj[u], r = rr[u]; // row r of the upper-triangle block (i <= j): elements (P i + r, P j + q)
-#pragma unroll
-				for (int q = 0; q < P; q++) {
-					if (i != j) *at(P * j + q, P * i + r) = v[u][q];
-					else if (r >= q) *at(P * i + r, P * i + q) = v[u][q] + (r == q ? lambda : 0.0); // (a diagonal block holds both triangles)
-				} }
-		}
-		const double *g = B.grad + d.o_scal;
-		for (int k = tid; k < 16 * nt; k += G) { T[256 * (long long)wg_tile(nt, k >> 4) + wg_frag_off(0, k & 15)] = (k < n) ? g[k] : 0.0; if (k >= n) *at(k, k) = 1.0; }
-		__syncthreads();
-	}
 	// solve(lambda): returns false if not positive definite (uniform across the wavefront)
 	__device__ __forceinline__ bool solve(const SparseSys &S, double lambda, long long *pc = nullptr) {
 		long long t0 = 0;
@@ -398,9 +405,8 @@ struct Solver : public Worker<FAM, LEAN, G> {
 #define STOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - t0; } } while (0)
 		if (schur_active() && (prm.ext & SRBA_EXT_SCHUR_KEEPS_GRADIENT)) { // (extension, default off) every solve starts from the gradient K5 produced: same lane -> same elements as keep_gradient()
 			double *g = B.grad + d.o_scal; const double *g0 = B.grad0 + d.o_scal; for (int k = tid; k < d.n_scal; k += G) g[k] = g0[k]; __syncthreads(); }
-		STIC(); if (schur_active()) { if constexpr (G > 64 && !W::T::REL) schur_reduce_lds(lambda, pc); /* (a workgroup window keeps its U_Ap blocks in LDS: the host sends no other here) */ else schur_reduce(lambda, pc); } STOC(9);
-		if constexpr (G > 64 && !W::T::REL) { // landmark window on a workgroup: dense LL^t on the matrix cores (srba_wg.hpp)
-			STIC(); assemble_tiles(S, lambda); STOC(10);
+		if constexpr (G > 64 && !W::T::REL) { // landmark window on a workgroup (the host sends Schur windows only): U_Ap in LDS, dense LL^t on the matrix cores (srba_wg.hpp)
+			STIC(); schur_assemble_lds(S, lambda, pc); STOC(9);
 			STIC(); const bool okw = wg_chol_solve<G / 64>(S.tiles, S.linv, S.nt, (lds_f64 *)srba_lds); STOC(11);
 			if (!okw) return false;
 			double *dlw = B.delta + d.o_scal;
@@ -409,6 +415,7 @@ struct Solver : public Worker<FAM, LEAN, G> {
 			STIC(); if (schur_active()) schur_features(); STOC(13);
 			return true;
 		}
+		STIC(); if (schur_active()) schur_reduce(lambda, pc); STOC(9);
 		STIC(); assemble(S, lambda); STOC(10);
 		// (the dense block layouts are never chosen for the relative-pose families -- srba_hip_upload_problems -- whose kernels therefore carry the sparse solver only: the
 		//  headline kernel sits 22 VGPRs below the two-wavefronts-per-SIMD limit)
@@ -666,7 +673,7 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 		}
 	}
 	if (!stop) stopmask |= 1 << SRBA_STOP_MAX_ITERS;
-	if constexpr (G > 64 && !Tr<FAM>::REL) { if (hs_reduced && S.schur_active()) { __syncthreads(); Wk(0).store_hs(false); } } // (the reference's Schur complement works on HAp in place: its reduced blocks are what a caller reads after the run)
+	if constexpr (G > 64 && !Tr<FAM>::REL) { if (hs_reduced && d.n_panel == 1 && S.schur_active()) { __syncthreads(); Wk(0).store_hs(false); } } // (the reference's Schur complement works on HAp in place: its reduced blocks are what a caller reads after the run)
 	// S17: crpLandmarksApprox
 	if constexpr (!Solver<FAM, LEAN, G>::W::T::REL) {
 		const Batch &Bl = LB();
@@ -960,7 +967,7 @@ template <int FAM, int G> __global__ void __launch_bounds__(G) __attribute__((am
 	const int pidx = B.order[first + blockIdx.x]; const ProbDesc &d = B.desc[pidx]; Solver<FAM, true, G> S(B, d, prm, srba_lds + WG_RED);
 	const SparseSys A = S.make_sys(srba_lds);
 	const bool ok = S.solve(A, B.lambda_io[pidx]);
-	if (S.schur_active()) { __syncthreads(); S.store_hs(false); }
+	if (d.n_panel == 1 && S.schur_active()) { __syncthreads(); S.store_hs(false); }
 	if (threadIdx.x == 0) B.notpd[pidx] = ok ? 0 : 1;
 }
 
@@ -1021,16 +1028,15 @@ SRBA_PROBE(kp_spantree_need, S.phase_spantree(true, nullptr))
 SRBA_PROBE(kp_jacobians, S.phase_jacobians())
 SRBA_PROBE(kp_hessian, B.notpd[blockIdx.x] = S.phase_hessian())
 SRBA_PROBE(kp_hessian_lds, B.notpd[blockIdx.x] = S.phase_hessian_lds())
-SRBA_PROBE(kp_schur_lds, S.schur_reduce_lds(B.lambda_io[blockIdx.x]))
+SRBA_PROBE(kp_schur_lds, S.schur_assemble_lds(A, B.lambda_io[blockIdx.x]))
 SRBA_PROBE(kp_gradient, S.phase_gradient(B.resid))
 SRBA_PROBE(kp_residuals, B.chi2[blockIdx.x] = S.phase_residuals(B.resid, srba_lds + WG_RED))
 SRBA_PROBE(kp_schur, S.schur_reduce(B.lambda_io[blockIdx.x]))
-SRBA_PROBE(kp_assemble, S.assemble_tiles(A, B.lambda_io[blockIdx.x]))
 SRBA_PROBE(kp_chol, B.notpd[blockIdx.x] = wg_chol_solve<4>(A.tiles, A.linv, A.nt, (lds_f64 *)srba_lds))
 SRBA_PROBE(kp_features, S.schur_features())
 SRBA_PROBE(kp_apply, S.apply_trial(A))
 template <int FAM> void probe_instantiate() { Batch B; DevParams p; hipLaunchKernelGGL(kp_spantree<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_spantree_need<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_jacobians<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_hessian<FAM>, 1, 256, 0, 0, B, p);
-	hipLaunchKernelGGL(kp_gradient<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_hessian_lds<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_schur_lds<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_residuals<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_schur<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_assemble<FAM>, 1, 256, 0, 0, B, p);
+	hipLaunchKernelGGL(kp_gradient<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_hessian_lds<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_schur_lds<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_residuals<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_schur<FAM>, 1, 256, 0, 0, B, p);
 	hipLaunchKernelGGL(kp_chol<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_features<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_apply<FAM>, 1, 256, 0, 0, B, p); }
 template void probe_instantiate<SRBA_PROBE_KERNELS>();
 #endif
@@ -1510,7 +1516,8 @@ int srba_hip_kernel_ms_history(srba_hip_ctx *c, double *out_ms, int n) {
 // Class of a capsule on the workgroup path of the SE3 landmark families (k_lm_wg, srba_wg.hpp), or -1: Schur solvers, a reduced system of wg_from_sys .. 16 WG_NT_MAX scalars, and U_Ap blocks
 // that fit the LDS of the workgroup shape (128 threads: four per CU, 40 KB; 256: two, 80 KB; 512: one, 159 KB). *lds_bytes: what the window needs. Windows with more blocks than a CU's
 // LDS holds keep the one-wavefront kernel (or the multi-workgroup path).
-static int wg_class_of(const srba_hip_ctx *c, const srba_problem_capsule &k, bool schur_solver, size_t *lds_bytes) {
+static int wg_class_of(const srba_hip_ctx *c, const srba_problem_capsule &k, bool schur_solver, size_t *lds_bytes, int *panels = nullptr) {
+	if (panels) *panels = 1;
 	const int P = c->dm.P, L = c->dm.L; const int n_sys = P * k.n_unk_edges;
 	if (!(c->wg_on && c->wg_hs && c->max_lds_kb > 0 /* (0: the test knob that sends every window to the multi-workgroup path) */ && c->dm.PD == 12 && L == 3 && schur_solver && k.n_unk_lms > 0 && k.n_unk_edges > 0 && c->gang_from_nb <= 0)) return -1;
 	if (n_sys < c->wg_from_sys || n_sys > 16 * srbadev::WG_NT_MAX || k.n_hap >= 65536 || k.n_unk_edges >= 32768) return -1;
@@ -1518,7 +1525,11 @@ static int wg_class_of(const srba_hip_ctx *c, const srba_problem_capsule &k, boo
 	if (need <= (size_t)40 * 1024 && n_sys < c->wg256_from_sys) return SRBA_CLS_WG128;
 	if (need <= (size_t)80 * 1024) return SRBA_CLS_WG256;
 	if (need <= (size_t)159 * 1024) return SRBA_CLS_WG512; // (nearly the whole LDS of a CU: 515 blocks)
-	return -1;
+	// more blocks than a CU's LDS holds: the window is swept in panels of equal size (ProbDesc::n_panel)
+	const int cap = (int)(((size_t)159 * 1024 / 8 - (size_t)srbadev::WG_HS) / (size_t)(P * P + 1)), np = (k.n_hap + cap - 1) / cap, psize = (k.n_hap + np - 1) / np;
+	if (np > 16) return -1;
+	if (panels) *panels = np; if (lds_bytes) *lds_bytes = 8 * ((size_t)srbadev::WG_HS + (size_t)psize * (P * P + 1));
+	return SRBA_CLS_WG512;
 }
 static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *caps, int n);
 int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, int n) { // no C++ exception crosses the C ABI
@@ -1543,7 +1554,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	const bool schur_solver = c->params.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL;
 	c->desc.assign(n, ProbDesc()); srba_batch_stats &st = c->stats; std::memset(&st, 0, sizeof(st)); st.n_problems = n;
 	// ---- pass 1: descriptors and totals
-	long long t_hapo = 0, t_schl = 0, t_hrec = 0, t_edge = 0, t_unk = 0, t_ulm = 0, t_klm = 0, t_pair = 0, t_path = 0, t_obs = 0, t_valid = 0, t_bp = 0, t_bf = 0, t_hap = 0, t_hapt = 0, t_hf = 0, t_hft = 0, t_hapf = 0, t_hapft = 0, t_sch = 0, t_req = 0, t_scal = 0, t_yw = 0, t_dense = 0;
+	long long t_ptab = 0, t_hapo = 0, t_schl = 0, t_hrec = 0, t_edge = 0, t_unk = 0, t_ulm = 0, t_klm = 0, t_pair = 0, t_path = 0, t_obs = 0, t_valid = 0, t_bp = 0, t_bf = 0, t_hap = 0, t_hapt = 0, t_hf = 0, t_hft = 0, t_hapf = 0, t_hapft = 0, t_sch = 0, t_req = 0, t_scal = 0, t_yw = 0, t_dense = 0;
 	std::vector<int> cls(n, 0), big_lds(n, 0); int cls_nbmax[SRBA_NCLS] = {0}; size_t wg_lds[3] = {0, 0, 0}; std::vector<Symbolic> sym(n); long long t_spcol = 0, t_sprow = 0, t_spitem = 0, t_spfill = 0;
 	// capsules whose system cannot fit one wavefront's LDS even as bare numbers (more than 63 block rows) but is no deep-window system either: a handful go to the
 	// multi-workgroup path; when the batch holds many, they keep one wavefront each with the system in HBM (see below)
@@ -1572,7 +1583,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		d.o_bp = t_bp; d.o_colp = t_unk + p; d.o_bf = t_bf; d.o_colf = t_ulm + p; d.o_hap = t_hap; d.o_hapoff = t_hap + p; d.o_hapt = t_hapt; d.o_hf = t_hf; d.o_hfoff = t_hf + p; d.o_hft = t_hft;
 		d.o_hapf = t_hapf; d.o_hapfoff = t_hapf + p; d.o_hapft = t_hapft; d.o_sch = t_sch; d.o_lmoff = t_ulm + p; d.o_req = t_req; d.o_scal = t_scal; d.o_yw = t_yw; d.o_dense = t_dense;
 		d.nb = (d.n_sys + 2) / 3;
-		size_t wg_need = 0; const int wg_cls = wg_class_of(c, k, schur_solver, &wg_need); const bool to_wg = wg_cls >= 0; // one workgroup, tile system in HBM, U_Ap blocks in LDS, matrix cores (srba_wg.hpp)
+		size_t wg_need = 0; int wg_panels = 1; const int wg_cls = wg_class_of(c, k, schur_solver, &wg_need, &wg_panels); const bool to_wg = wg_cls >= 0; // one workgroup, tile system in HBM, U_Ap blocks in LDS, matrix cores (srba_wg.hpp)
 		const bool surely_big = d.n_sys > c->big_min_sys || to_wg; // far beyond what one wavefront's LDS holds (or a workgroup window): dense system on the multi-workgroup path, no block-sparse symbolic analysis
 		if (!surely_big) { /* sym[p]: computed above */ }
 		else { Symbolic &y = sym[p]; y.col_off.assign(d.nb + 1, 0); y.item_off.assign(d.nb + 1, 0); y.rptr.assign(d.nb + 1, 0); y.perm.resize(d.nb); for (int q = 0; q < d.nb; q++) y.perm[q] = q;
@@ -1594,8 +1605,8 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		cls[p] = SRBA_NCLS - 1; for (int q = 0; q < SRBA_NLDS && packable && !surely_big && !to_gang && kClsKB[q] <= c->max_lds_kb; q++) if (bytes <= (size_t)kClsKB[q] * 1024) { cls[p] = q; break; }
 		long long wave_ws = 0; // doubles of HBM workspace of a capsule that keeps one wavefront but holds its (dense block) system in HBM
 		d.hap_chunked = 0; d.n_hrec = k.n_hap; d.o_hrec = t_hrec; t_hrec += k.n_hap; // K6 work records: one per block
-		d.hs_lds = 0; d.o_hapo = t_hapo; d.o_schl = t_schl;
-		if (to_wg) { const int nt = (d.n_sys + srbadev::WT - 1) / srbadev::WT; d.dense_blocks = 3; d.nnzoff = 0; d.n_items = 0; wave_ws = srbadev::wg_ws_doubles(nt);
+		d.hs_lds = 0; d.o_hapo = t_hapo; d.o_schl = t_schl; d.n_panel = 1; d.o_ptab = t_ptab;
+		if (to_wg) { d.n_panel = wg_panels; t_ptab += 3 * (wg_panels + 1); const int nt = (d.n_sys + srbadev::WT - 1) / srbadev::WT; d.dense_blocks = 3; d.nnzoff = 0; d.n_items = 0; wave_ws = srbadev::wg_ws_doubles(nt);
 			cls[p] = wg_cls; d.hs_lds = 1; wg_lds[wg_cls - SRBA_NLDS] = std::max(wg_lds[wg_cls - SRBA_NLDS], wg_need); t_hapo += k.n_hap_terms; t_schl += k.n_sch_terms; }
 		if ((cls[p] == SRBA_NCLS - 1 ? many_mid : (c->hbm_from_kb > 0 && n >= 1024 && kClsKB[cls[p]] >= c->hbm_from_kb && d.nb <= 168)) && !surely_big && !to_gang && !to_wg && c->dense_blocks_ok && !rel_family) {
 			// Does not fit any LDS class and the batch has many like it: the multi-workgroup path would run them a few at a time from the host. They stay on the
@@ -1624,7 +1635,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	// ---- input arena layout
 	Arena in; struct { size_t desc, edge0, ulm0, klm, obs_z, pair_path_off, path_edge, obs_pose, obs_lm, obs_valid, bp_col, bp_res, bp_A, bp_D, bp_lm, colp_off, bf_col, bf_res, bf_pose, colf_off,
 		hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hap_tblk, hf_i, hf_j, hf_term_off, hf_t1, hf_t2, hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag, sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw, sch_tblk,
-		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, obs_rec, pair_needed, pose_req, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_rptr, sp_rcol, sp_perm, sp_fill, hap_rec, hapo, schl, hap_dst, hapf_dst, hf_dst, asm_term, asm_blk, asm_desc, asm_list, asm_slot; } o;
+		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, obs_rec, pair_needed, pose_req, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_rptr, sp_rcol, sp_perm, sp_fill, hap_rec, hapo, schl, ptab, hap_dst, hapf_dst, hf_dst, asm_term, asm_blk, asm_desc, asm_list, asm_slot; } o;
 	o.desc = in.add(sizeof(ProbDesc) * n);
 	o.edge0 = in.add(8 * t_edge * PDX); o.ulm0 = in.add(8 * t_ulm * L); o.klm = in.add(8 * t_klm * L); o.obs_z = in.add(8 * t_obs * O);
 	o.pair_path_off = in.add(4 * (t_pair + n)); o.path_edge = in.add(4 * t_path); o.obs_pose = in.add(4 * t_obs); o.obs_lm = in.add(4 * t_obs); o.obs_valid = in.add(4 * t_obs);
@@ -1636,7 +1647,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	o.hap_diag = in.add(4 * t_unk); o.hf_diag = in.add(4 * t_ulm);
 	o.sch_term_off = in.add(4 * (t_hap + n)); o.sch_b1 = in.add(4 * t_sch); o.sch_b2 = in.add(4 * t_sch); o.sch_lm = in.add(4 * t_sch); o.sch_yw = in.add(4 * t_sch); o.sch_tblk = in.add(4 * t_sch);
 	o.lm_hapf_off = in.add(4 * (t_ulm + n)); o.lm_hapf_idx = in.add(4 * t_hapf); o.req_idx = in.add(4 * t_req); o.need_idx = in.add(4 * t_pair); o.need_rec = in.add(4 * 5 * std::max<long long>(t_pair, 1)); o.obs_rec = in.add(4 * 5 * std::max<long long>(t_obs, 1)); o.pair_needed = in.add(t_pair); o.pose_req = in.add(2 * t_pair); o.bp_normal = in.add(t_bp); o.order = in.add(4 * (size_t)n);
-	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_rptr = in.add(4 * t_spcol); o.sp_rcol = in.add(4 * t_sprow); o.sp_perm = in.add(4 * t_spcol); o.hap_rec = in.add(4 * 3 * std::max<long long>(t_hrec, 1)); o.hapo = in.add(4 * 3 * t_hapo); o.schl = in.add(4 * 4 * t_schl); o.sp_fill = in.add(4 * std::max<long long>(t_spfill, 1));
+	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_rptr = in.add(4 * t_spcol); o.sp_rcol = in.add(4 * t_sprow); o.sp_perm = in.add(4 * t_spcol); o.hap_rec = in.add(4 * 3 * std::max<long long>(t_hrec, 1)); o.hapo = in.add(4 * 3 * t_hapo); o.schl = in.add(4 * 4 * t_schl); o.ptab = in.add(4 * std::max<long long>(t_ptab, 1)); o.sp_fill = in.add(4 * std::max<long long>(t_spfill, 1));
 	o.hap_dst = in.add(4 * t_hap * (P / 3) * (P / 3)); o.hapf_dst = in.add(4 * t_hapf * (P / 3)); o.hf_dst = in.add(4 * t_hf);
 	bool asm_fam = c->asm_on && c->params.family == SRBA_SE2_RELPOSE2D;
 	if (asm_fam && c->dp.noise == SRBA_NOISE_CONSTANT_MATRIX) for (int i = 0; i < 3; i++) for (int j = 0; j < i; j++) if (c->dp.lambda[3 * i + j] != c->dp.lambda[3 * j + i]) asm_fam = false; // the fused kernel sums the upper triangle of J^t Lambda J only
@@ -1699,17 +1710,23 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		  int32_t *hr = (int32_t *)(h + o.hap_rec) + 3 * d.o_hrec; int nr = 0;
 		  for (int i = 0; i < k.n_hap; i++) { const int b = ho[i], tb = k.hap_term_off[b], te = k.hap_term_off[b + 1];
 			hr[3 * nr] = b; hr[3 * nr + 1] = tb; hr[3 * nr + 2] = te; nr++; } }
-		if (d.hs_lds) { // the term lists of the LDS path: K6 terms by observation, Schur terms by landmark (stable: a block's terms keep their order inside an observation / a landmark)
+		if (d.hs_lds) { // the term lists of the LDS path, panel by panel (block ranges that fit the LDS: one for most windows): K6 terms by observation, Schur terms by landmark
+			// (stable: a block's terms keep their order inside an observation / a landmark), and the table of the panels' bounds
+			const int np = d.n_panel, psize = (k.n_hap + np - 1) / np; auto panel_of = [&](int b) { return b / psize; };
+			int32_t *pt = (int32_t *)(h + o.ptab) + d.o_ptab; for (int q = 0; q <= np; q++) pt[q] = std::min(k.n_hap, q * psize);
 			std::vector<int32_t> ix(k.n_hap_terms), tb(k.n_hap_terms); for (int b = 0; b < k.n_hap; b++) for (int t = k.hap_term_off[b]; t < k.hap_term_off[b + 1]; t++) tb[t] = b;
 			for (int t = 0; t < k.n_hap_terms; t++) ix[t] = t;
-			std::stable_sort(ix.begin(), ix.end(), [&](int x, int y) { return k.bp_res[k.hap_t1[x]] < k.bp_res[k.hap_t1[y]]; });
-			int32_t *ho = (int32_t *)(h + o.hapo) + 3 * d.o_hapo; for (int q = 0; q < k.n_hap_terms; q++) { const int t = ix[q]; ho[3 * q] = k.hap_t1[t]; ho[3 * q + 1] = k.hap_t2[t]; ho[3 * q + 2] = tb[t]; }
+			std::stable_sort(ix.begin(), ix.end(), [&](int x, int y) { const int px = panel_of(tb[x]), py = panel_of(tb[y]); return px != py ? px < py : k.bp_res[k.hap_t1[x]] < k.bp_res[k.hap_t1[y]]; });
+			int32_t *ho = (int32_t *)(h + o.hapo) + 3 * d.o_hapo; for (int q = 0; q <= np; q++) pt[np + 1 + q] = 0;
+			for (int q = 0; q < k.n_hap_terms; q++) { const int t = ix[q]; ho[3 * q] = k.hap_t1[t]; ho[3 * q + 1] = k.hap_t2[t]; ho[3 * q + 2] = tb[t]; pt[np + 2 + panel_of(tb[t])] = q + 1; }
+			for (int q = 1; q <= np; q++) pt[np + 1 + q] = std::max(pt[np + 1 + q], pt[np + q]); // (a panel without terms: empty range)
 			std::vector<int32_t> sx(k.n_sch_terms), sb(k.n_sch_terms); for (int b = 0; b < k.n_hap; b++) for (int t = k.sch_term_off[b]; t < k.sch_term_off[b + 1]; t++) sb[t] = b;
 			for (int t = 0; t < k.n_sch_terms; t++) sx[t] = t;
-			std::stable_sort(sx.begin(), sx.end(), [&](int x, int y) { return k.sch_lm[x] < k.sch_lm[y]; });
-			int32_t *so = (int32_t *)(h + o.schl) + 4 * d.o_schl;
+			std::stable_sort(sx.begin(), sx.end(), [&](int x, int y) { const int px = panel_of(sb[x]), py = panel_of(sb[y]); return px != py ? px < py : k.sch_lm[x] < k.sch_lm[y]; });
+			int32_t *so = (int32_t *)(h + o.schl) + 4 * d.o_schl; for (int q = 0; q <= np; q++) pt[2 * np + 2 + q] = 0;
 			for (int q = 0; q < k.n_sch_terms; q++) { const int t = sx[q], b = sb[t]; const bool dg = k.hap_i[b] == k.hap_j[b];
-				so[4 * q] = k.sch_lm[t]; so[4 * q + 1] = k.sch_b1[t]; so[4 * q + 2] = k.sch_b2[t]; so[4 * q + 3] = (int32_t)((uint32_t)b | ((uint32_t)k.hap_i[b] << 16) | (dg ? 0x80000000u : 0u)); }
+				so[4 * q] = k.sch_lm[t]; so[4 * q + 1] = k.sch_b1[t]; so[4 * q + 2] = k.sch_b2[t]; so[4 * q + 3] = (int32_t)((uint32_t)b | ((uint32_t)k.hap_i[b] << 16) | (dg ? 0x80000000u : 0u)); pt[2 * np + 3 + panel_of(b)] = q + 1; }
+			for (int q = 1; q <= np; q++) pt[2 * np + 2 + q] = std::max(pt[2 * np + 2 + q], pt[2 * np + 1 + q]);
 		}
 		if (asm_fam && k.n_bp >= 1 && k.n_bp <= 65536 && 2 * k.n_pairs < 65535 && k.n_obs <= 65536 && d.nK <= 8191 && k.n_hap <= 65536) { // packed records of the fused normal-equations kernel (srba_assemble.hpp)
 			uint64_t *ab = (uint64_t *)(h + o.asm_blk) + d.o_bp, *at = (uint64_t *)(h + o.asm_term) + d.o_hapt; bool fit = true; const int cb = (k.n_bp + 63) / 64;
@@ -1790,7 +1807,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	Batch &B = c->B; std::memset(&B, 0, sizeof(B)); B.n_prob = n; B.max_lds_doubles = 0; B.hess_terms = c->lm_terms ? 1 : 0; B.dense_left = c->dense_left ? 1 : 0;
 	char *di = c->d_in, *dw = c->d_wk;
 #define DI(field, T) B.field = (const T *)(di + o.field)
-	B.desc = (const ProbDesc *)(di + o.desc); DI(order, int); DI(sp_col_off, int); DI(sp_row, int); DI(sp_item_off, int); DI(sp_tgt, int); DI(sp_rptr, int); DI(sp_rcol, int); DI(sp_perm, int); DI(hap_rec, int); DI(hapo, int); DI(schl, int); DI(sp_fill, int); DI(hap_dst, int); DI(hapf_dst, int); DI(hf_dst, int); DI(edge0, double); DI(ulm0, double); DI(klm, double); DI(obs_z, double);
+	B.desc = (const ProbDesc *)(di + o.desc); DI(order, int); DI(sp_col_off, int); DI(sp_row, int); DI(sp_item_off, int); DI(sp_tgt, int); DI(sp_rptr, int); DI(sp_rcol, int); DI(sp_perm, int); DI(hap_rec, int); DI(hapo, int); DI(schl, int); DI(ptab, int); DI(sp_fill, int); DI(hap_dst, int); DI(hapf_dst, int); DI(hf_dst, int); DI(edge0, double); DI(ulm0, double); DI(klm, double); DI(obs_z, double);
 	DI(pair_path_off, int); DI(path_edge, int); DI(obs_pose, int); DI(obs_lm, int); DI(obs_valid, int); DI(bp_col, int); DI(bp_res, int); DI(bp_A, int); DI(bp_D, int); DI(bp_lm, int); DI(colp_off, int);
 	DI(bf_col, int); DI(bf_res, int); DI(bf_pose, int); DI(colf_off, int); DI(hap_i, int); DI(hap_j, int); DI(hap_term_off, int); DI(hap_t1, int); DI(hap_t2, int); DI(hap_tblk, int); DI(hf_i, int); DI(hf_j, int); DI(hf_term_off, int); DI(hf_t1, int); DI(hf_t2, int);
 	DI(hapf_i, int); DI(hapf_j, int); DI(hapf_term_off, int); DI(hapf_t1, int); DI(hapf_t2, int); DI(hap_diag, int); DI(hf_diag, int); DI(sch_term_off, int); DI(sch_b1, int); DI(sch_b2, int); DI(sch_lm, int); DI(sch_yw, int); DI(sch_tblk, int);
