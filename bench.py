@@ -85,7 +85,8 @@ def per_problem_counts(batch, family):
     from srba_amd import capi
     P, L, O, PD = capi.DIMS[family]
     n = batch.n
-    out = {k: np.zeros(n, np.int64) for k in ("n_path", "n_pairs", "n_path_needed", "n_pairs_needed", "n_bp", "n_bf", "n_hap", "n_hf", "n_hapf", "n_obs", "n_scal", "n_sys", "n_unk_edges", "n_unk_lms", "sch_d", "sch_dd")}
+    out = {k: np.zeros(n, np.int64) for k in ("n_path", "n_pairs", "n_path_needed", "n_pairs_needed", "n_bp", "n_bf", "n_hap", "n_hf", "n_hapf", "n_obs", "n_scal", "n_sys", "n_unk_edges", "n_unk_lms",
+            "sch_d", "sch_dd")}
     schur = batch.params.solver != capi.SOLVER_NO_SCHUR_SPARSE
     for i in range(n):
         c = batch.ptr[i]
@@ -157,17 +158,27 @@ def bench_cfg3(args, dist, rank, world, local_rank, backend, emit=True):
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_cfg3.json"))):
                 t = json.load(open(f)); w = t["workload"]
-                if int(w["local_areas"]) == n0 and int(w["replicas"]) == copies and int(w["extensions"]) == int(args.cfg3_ext): cfg3_traffic = (float(t["traffic_bytes_per_launch"]), os.path.relpath(f, ROOT) + " (rocprofv3 --pmc passes of this command, committed; not measured in this run)")
+                if int(w["local_areas"]) == n0 and int(w["replicas"]) == copies and int(w["extensions"]) == int(args.cfg3_ext): cfg3_traffic = (float(t["traffic_bytes_per_launch"]), os.path.relpath(f,
+                        ROOT) + " (rocprofv3 --pmc passes of this command, committed; not measured in this run)")
         except Exception:  # noqa: BLE001
             pass
-        line = {"metric": "LM iterations/sec (and obs/sec) on stereo SE3 local areas with Schur landmark reduction; chi2 match vs CPU", "value": tot_trials * args.steps / max_elapsed, "unit": "LM iterations/s",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * max_elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                "config": {"workload": "cfg3-stereo: %d key-frames, 2000 landmarks, stereo fx=200 fy=150 cx=512 cy=384 baseline 0.2 m, range 5 m, px noise 0.5, robust kernel, depth 3: %d local areas x %d replicas re-optimised per step" % (n_kf, n0, copies),
-                           "extensions": int(args.cfg3_ext), "local_areas": n0, "replicas": copies, "unknown_edges_mean_max": [float(nk.mean()), int(nk.max())], "unknown_landmarks_mean_max": [float(nf.mean()), int(nf.max())], "observations_mean_max": [float(no.mean()), int(no.max())],
+        line = {"metric": "LM iterations/sec (and obs/sec) on stereo SE3 local areas with Schur landmark reduction; chi2 match vs CPU", "value": tot_trials * args.steps / max_elapsed,
+                "unit": "LM iterations/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * max_elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                        "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "cfg3-stereo: %d key-frames, 2000 landmarks, stereo fx=200 fy=150 cx=512 cy=384 baseline 0.2 m, range 5 m, px noise 0.5, robust kernel, depth 3: %d local "
+                        "areas x %d replicas re-optimised per step" % (n_kf, n0, copies),
+                           "extensions": int(args.cfg3_ext), "local_areas": n0, "replicas": copies, "unknown_edges_mean_max": [float(nk.mean()),
+                                   int(nk.max())], "unknown_landmarks_mean_max": [float(nf.mean()), int(nf.max())], "observations_mean_max": [float(no.mean()), int(no.max())],
                            "lm_trials_per_step": trials, "obs_per_s": tot_obs * args.steps / max_elapsed, "map_build_s": round(t_map, 2), "sequential_ms_per_kf": round(1e3 * t_map / n_kf, 3),
-                           "parallelism": "replicas x%d" % world, "solver": "Schur complement + LL^t of the reduced system in LDS (dense block layout; windows beyond LDS: HBM-resident layout or the multi-workgroup path)"},
-                "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None, "traffic_committed_profile": {"bytes_per_launch": cfg3_traffic[0], "source": cfg3_traffic[1], "note": "PMC passes are separate rocprofv3 runs (tools/pmc_cfg3.sh): a number of the committed profile, possibly of an older kernel build -- never mixed into this run's kernel_ms"}, "kernel": "k_lm_run<SE3_STEREO>", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
-                             "note": "algorithmic bytes per SURVEY 8d: K1, K2 + K3 per block, K4 per observation, K5, K6 block writes, per trial K7/K8/K10 per landmark with d observing edges (L*L*8 + d*P*L*8 + L*8 in, d(d+1)/2 P x P blocks read-modify-write) and the dense reduced system (n^2 * 8)"},
+                           "parallelism": "replicas x%d" % world,
+                                   "solver": "Schur complement + LL^t of the reduced system in LDS (dense block layout; windows beyond LDS: HBM-resident layout or the multi-workgroup path)"},
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                        "traffic_committed_profile": {"bytes_per_launch": cfg3_traffic[0], "source": cfg3_traffic[1],
+                        "note": "PMC passes are separate rocprofv3 runs (tools/pmc_cfg3.sh): a number of the committed profile, possibly of an older kernel build -- never mixed into this "
+                                "run's kernel_ms"}, "kernel": "k_lm_run<SE3_STEREO>", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
+                             "note": "algorithmic bytes per SURVEY 8d: K1, K2 + K3 per block, K4 per observation, K5, K6 block writes, per trial K7/K8/K10 per landmark with d observing edges "
+                                     "(L*L*8 + d*P*L*8 + L*8 in, d(d+1)/2 P x P blocks read-modify-write) and the dense reduced system (n^2 * 8)"},
                 "cpu_baseline": cpu}
         if emit:
             print(json.dumps(line), flush=True)
@@ -214,17 +225,27 @@ def bench_cfg4(args, dist, rank, world, local_rank, backend, emit=True):
                    "sample": "oracle/srba_oracle.cpp (g++ -O2, one thread: a single capsule has no capsule-level parallelism) on the last local area of the same map, %.1f s" % dt,
                    "chi2_final_rel_diff_vs_gpu": float(abs(r["chi2_final"][0] - res["chi2_final"][W - 1]) / max(r["chi2_final"][0], 1e-300))}
         achieved = chol_flops / max(chol_ms, 1e-9) / 1e9   # flop / ms / 1e9 = TFLOP/s
-        line = {"metric": "LM iterations/sec (and obs/sec) on a deep monocular SE3 window (Schur + dense Cholesky); chi2 match vs CPU", "value": tot_trials * args.steps / max_elapsed, "unit": "LM iterations/s",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * max_elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                "config": {"workload": "cfg4-mono-deep%s: %d key-frames x %d landmarks, monocular SE3 fx=fy=200 cx=400 cy=320, px noise 0.5, max_tree_depth = max_optimize_depth = 8, submap 20; the last %d local areas re-optimised per step" % ("" if n_kf >= 5000 else " (reduced)", n_kf, n_lm, W),
-                           "extensions": int(args.cfg4_ext), "keyframes": n_kf, "landmarks": n_lm, "unknown_edges": [int(c.n_unk_edges) for c in caps], "unknown_landmarks": [int(c.n_unk_lms) for c in caps], "observations": [int(c.n_obs) for c in caps],
+        line = {"metric": "LM iterations/sec (and obs/sec) on a deep monocular SE3 window (Schur + dense Cholesky); chi2 match vs CPU", "value": tot_trials * args.steps / max_elapsed,
+                "unit": "LM iterations/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * max_elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                        "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "cfg4-mono-deep%s: %d key-frames x %d landmarks, monocular SE3 fx=fy=200 cx=400 cy=320, px noise 0.5, max_tree_depth = max_optimize_depth = 8, submap 20; "
+                        "the last %d local areas re-optimised per step" % ("" if n_kf >= 5000 else " (reduced)", n_kf, n_lm, W),
+                           "extensions": int(args.cfg4_ext), "keyframes": n_kf, "landmarks": n_lm, "unknown_edges": [int(c.n_unk_edges) for c in caps],
+                                   "unknown_landmarks": [int(c.n_unk_lms) for c in caps], "observations": [int(c.n_obs) for c in caps],
                            "reduced_system": [6 * int(c.n_unk_edges) for c in caps], "lm_trials_per_step": trials, "obs_per_s": tot_obs * args.steps / max_elapsed,
                            "map_build_s": round(t_map, 2), "sequential_ms_per_kf": round(1e3 * t_map / n_kf, 3), "dataset_s": round(t_gen, 2),
-                           "parallelism": "replicas x%d" % world, "solver": "Schur complement (grid-wide), dense blocked LL^t across workgroups (32-column panels, v_mfma_f64_16x16x4_f64 trailing updates)"},
+                           "parallelism": "replicas x%d" % world,
+                                   "solver": "Schur complement (grid-wide), dense blocked LL^t across workgroups (32-column panels, v_mfma_f64_16x16x4_f64 trailing updates)"},
                 "roofline": {"bound": "mfma", "achieved": achieved, "peak": 78.6, "unit": "TFLOP/s", "frac": achieved / 78.6, "traffic": None,
-                             "kernel": "k_chol_panel + k_chol_update (dense LL^t of the reduced system)", "factorisations": int(chol_n), "launch_sequences": int(chol_seqs), "windows_per_sequence": chol_n / max(chol_seqs, 1), "kernel_ms": chol_ms / max(chol_seqs, 1), "ms_per_factorisation": chol_ms / max(chol_n, 1), "flops_per_factorisation": chol_flops / max(chol_n, 1), "lock_step_gang": gang,
+                             "kernel": "k_chol_panel + k_chol_update (dense LL^t of the reduced system)", "factorisations": int(chol_n), "launch_sequences": int(chol_seqs),
+                                     "windows_per_sequence": chol_n / max(chol_seqs, 1), "kernel_ms": chol_ms / max(chol_seqs, 1), "ms_per_factorisation": chol_ms / max(chol_n, 1),
+                                     "flops_per_factorisation": chol_flops / max(chol_n, 1), "lock_step_gang": gang,
                              "lane_time_over_step_time": chol_ms / (1e3 * elapsed) if elapsed > 0 else None, "aggregate_TFLOPs_over_timed_region": chol_flops / max(elapsed, 1e-9) / 1e12,
-                             "note": "peak = AMD's published FP64 matrix figure for MI355X (the guide lists none); the large windows of a step run in lock-step (DESIGN 4c, Gang): ONE sequence of panel / update launches factors the reduced systems of all windows that are in a trial, kernel_ms = HIP-event time of one such sequence on the context stream (the sequences do not overlap: lane_time_over_step_time is the share of the step inside them), achieved = flops of all its windows / that time; with SRBA_HIP_BIG_GANG=0 every window has its own stream and sequence and the times overlap"},
+                             "note": "peak = AMD's published FP64 matrix figure for MI355X (the guide lists none); the large windows of a step run in lock-step (DESIGN 4c, Gang): ONE sequence "
+                                     "of panel / update launches factors the reduced systems of all windows that are in a trial, kernel_ms = HIP-event time of one such sequence on the context "
+                                     "stream (the sequences do not overlap: lane_time_over_step_time is the share of the step inside them), achieved = flops of all its windows / that time; "
+                                     "with SRBA_HIP_BIG_GANG=0 every window has its own stream and sequence and the times overlap"},
                 "cpu_baseline": cpu}
         if emit:
             print(json.dumps(line), flush=True)
@@ -243,15 +264,28 @@ def main():
     ap.add_argument("--n-kf", type=int, default=30000, help="keyframes of the synthetic SE2 graph-SLAM map (BASELINE: 30000)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = all host cores, at most 64)")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"], help="cfg2 = BASELINE configs[1] (the headline metric); cfg3 = stereo SE3 windows with Schur reduction (configs[2]); cfg4 = deep monocular window, Schur + dense Cholesky on the multi-workgroup path")
-    ap.add_argument("--cfg3-kf", type=int, default=119, help="cfg3: key-frames of the stereo map (BASELINE: ~200). The reference's algorithm as it is loses this map at key-frame 68..77 and, with that repaired, at its first loop closure (95); with the two opt-in repairs (--cfg3-ext) it holds until the loop closure of key-frame 120, where a noisy alignment plus the rho > max_rho stop end it (DESIGN 8). Windows of a lost map are chaotic problems and are neither timed nor compared")
-    ap.add_argument("--cfg3-ext", type=int, default=12, help="cfg3: extension bits of the engine (4 schur_keeps_gradient, 8 consistent_loop_closure_init, 2 restore_spanning_tree_twins; 0 = the reference to the letter, which keeps this map for 67 key-frames)")
-    ap.add_argument("--cfg4-ext", type=int, default=2, help="cfg4: extension bits of the engine (2 restore_spanning_tree_twins: without it the reference's algorithm loses this map at key-frame ~30, DESIGN 8 item 2; 0 = the reference to the letter)")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"],
+            help="cfg2 = BASELINE configs[1] (the headline metric); cfg3 = stereo SE3 windows with Schur reduction (configs[2]); cfg4 = deep monocular window, Schur + dense Cholesky on the multi-workgroup path")
+    ap.add_argument("--cfg3-kf", type=int, default=119,
+            help="cfg3: key-frames of the stereo map (BASELINE: ~200). The reference's algorithm as it is loses this map at key-frame 68..77 and, with that repaired, at "
+                    "its first loop closure (95); with the two opt-in repairs (--cfg3-ext) it holds until the loop closure of key-frame 120, where a noisy alignment plus the "
+                    "rho > max_rho stop end it (DESIGN 8). Windows of a lost map are chaotic problems and are neither timed nor compared")
+    ap.add_argument("--cfg3-ext", type=int, default=12,
+            help="cfg3: extension bits of the engine (4 schur_keeps_gradient, 8 consistent_loop_closure_init, 2 restore_spanning_tree_twins; 0 = the reference to the letter, which keeps this map for 67 key-frames)")
+    ap.add_argument("--cfg4-ext", type=int, default=2,
+            help="cfg4: extension bits of the engine (2 restore_spanning_tree_twins: without it the reference's algorithm loses this map at key-frame ~30, DESIGN 8 item 2; 0 = the reference to the letter)")
+    ap.add_argument("--cfg4-full-budget-s", type=float, default=480.0,
+            help="wall budget of the BASELINE-size cfg4 leg of the secondary workloads (5 000 key-frames x 200 000 landmarks: the map is built key-frame by key-frame, about "
+                    "five minutes); 0 = skip it; a leg that exceeds the budget is reported as skipped with the reason")
     ap.add_argument("--no-secondary", action="store_true", help="do not append the cfg3 / cfg4 measurements (secondary_workloads) to the cfg2 line")
     ap.add_argument("--cfg3-copies", type=int, default=32, help="cfg3: the harvested local areas are re-optimised in this many replicas per step (fills the chip)")
     ap.add_argument("--cfg4-kf", type=int, default=300, help="key-frames of the cfg4 map (BASELINE: 5000; the depth-8 window saturates at ~260 key-frames, see DESIGN)")
-    ap.add_argument("--cfg4-windows", type=int, default=16, help="local areas (the last ones of the map) re-optimised per step; since round 4 they run as a lock-step gang on the multi-workgroup path (up to 32 slots; more windows refill them): 16 windows 6.7-6.9 k, 32 windows 8.3 k, 64 windows 8.2 k LM iterations/s (round 3, one stream per window: 16 windows 2.1-2.2 k; rounds 1-2 measured 4)")
-    ap.add_argument("--cache-dir", default="/tmp/srba_bench_cache", help="keep the harvested capsules here so that a second invocation (e.g. under rocprofv3) skips the sequential SLAM run; '' disables")
+    ap.add_argument("--cfg4-windows", type=int, default=16,
+            help="local areas (the last ones of the map) re-optimised per step; since round 4 they run as a lock-step gang on the multi-workgroup path (up to 32 slots; more "
+                    "windows refill them): 16 windows 6.7-6.9 k, 32 windows 8.3 k, 64 windows 8.2 k LM iterations/s (round 3, one stream per window: 16 windows 2.1-2.2 k; rounds "
+                    "1-2 measured 4)")
+    ap.add_argument("--cache-dir", default="/tmp/srba_bench_cache",
+            help="keep the harvested capsules here so that a second invocation (e.g. under rocprofv3) skips the sequential SLAM run; '' disables")
     args = ap.parse_args()
 
     import numpy as np
@@ -369,9 +403,11 @@ def main():
                    "obs_per_s": float((r["num_trials"] * r["num_observations"]).sum() / dt),
                    "lm_trials_cpu_on_sample": cpu_trials, "lm_trials_gpu_on_sample": gpu_trials_same,
                    "max_chi2_final_rel_diff_vs_gpu": chi2_rel, "max_chi2_init_rel_diff_vs_gpu": chi2_init_rel, "capsules_with_identical_trial_sequence": same_seq, "capsules_compared": m,
-                   "note": "chi2 of every capsule of the sample compared with the GPU run of the same capsule (computed here, not asserted elsewhere: the run fails above 1e-6); trial counts differ because both runs keep iterating at the rounding floor until lambda > max_lambda (DESIGN 5)",
+                   "note": "chi2 of every capsule of the sample compared with the GPU run of the same capsule (computed here, not asserted elsewhere: the run fails above 1e-6); trial "
+                           "counts differ because both runs keep iterating at the rounding floor until lambda > max_lambda (DESIGN 5)",
                    "symbolic_setup_share": sym_s / dt, "value_excluding_symbolic_setup": float(cpu_trials / max(dt - sym_s, 1e-9)),
-                   "symbolic_note": "the CPU figure includes the per-call symbolic Cholesky analysis like the reference (lev-marq_solvers.h:164-166); the GPU value excludes its host-side equivalent, which runs once at upload (config.setup_s.upload_batch_host_to_hbm)"}
+                   "symbolic_note": "the CPU figure includes the per-call symbolic Cholesky analysis like the reference (lev-marq_solvers.h:164-166); the GPU value excludes its host-side equivalent, "
+                           "which runs once at upload (config.setup_s.upload_batch_host_to_hbm)"}
             try:   # -O3 as the reference's apps / examples are built
                 t1 = time.perf_counter(); r3 = _oracle.run_batch(batch.sub(0, m), threads=cores, opt="O3"); dt3 = time.perf_counter() - t1
                 cpu["value_O3"] = float(r3["num_trials"].sum() / dt3)
@@ -379,10 +415,13 @@ def main():
                 cpu["value_O3"] = None; cpu["value_O3_error"] = str(e)
             try:   # the sequential drop-in run (define_new_keyframe key-frame by key-frame) with the oracle as numeric back-end, beside config.sequential_ms_per_kf of the GPU back-end
                 n_seq = 2000; ds_seq = datasets.graph_slam_se2(n_kf=n_seq, seed=multi.replica_seed(rank), path="tour"); t1 = time.perf_counter()
-                eng_seq = runner.graph_slam_engine(backend=_oracle.BACKEND, submap=10, depth=3, sigma_xy=1e-3, sigma_yaw_deg=0.2, harvest=0); eng_seq.run(ds_seq); eng_seq.close(); cpu["sequential_ms_per_kf"] = 1e3 * (time.perf_counter() - t1) / n_seq
+                eng_seq = runner.graph_slam_engine(backend=_oracle.BACKEND, submap=10, depth=3, sigma_xy=1e-3, sigma_yaw_deg=0.2,
+                        harvest=0); eng_seq.run(ds_seq); eng_seq.close(); cpu["sequential_ms_per_kf"] = 1e3 * (time.perf_counter() - t1) / n_seq
                 cpu["sequential_note"] = "the first %d key-frames of the same map built through the same front-end with the oracle (one host thread) as numeric back-end" % n_seq
-                t1 = time.perf_counter(); eng_g = runner.graph_slam_engine(backend="hip", submap=10, depth=3, sigma_xy=1e-3, sigma_yaw_deg=0.2, harvest=0, hip_device=local_rank); eng_g.run(ds_seq); eng_g.close()
-                cpu["sequential_ms_per_kf_gpu_same_prefix"] = 1e3 * (time.perf_counter() - t1) / n_seq   # like for like: the same 2 000 key-frames, no harvesting, GPU back-end (config.sequential_ms_per_kf is the whole 30 000-key-frame run with harvesting)
+                t1 = time.perf_counter(); eng_g = runner.graph_slam_engine(backend="hip", submap=10, depth=3, sigma_xy=1e-3, sigma_yaw_deg=0.2, harvest=0,
+                        hip_device=local_rank); eng_g.run(ds_seq); eng_g.close()
+                # like for like: the same 2 000 key-frames, no harvesting, GPU back-end (config.sequential_ms_per_kf is the whole 30 000-key-frame run with harvesting)
+                cpu["sequential_ms_per_kf_gpu_same_prefix"] = 1e3 * (time.perf_counter() - t1) / n_seq
             except Exception as e:  # noqa: BLE001
                 cpu["sequential_ms_per_kf"] = None; cpu["sequential_note"] = str(e)
             if cores > 1:   # and the scalar figure (the reference is single-threaded), on a smaller sample
@@ -398,7 +437,8 @@ def main():
         stream = []
         for name, fn, by in (("k_spantree (K1, all pairs)", lambda: lib.srba_hip_update_spantree(ctx.ctx, 0), stats["n_path"] * (pbytes + 4) + stats["n_pairs"] * 2 * pbytes),
                              ("k_residuals (K4)", lambda: lib.srba_hip_eval_residuals(ctx.ctx, None), stats["n_obs"] * (pbytes + O * 8 + 12 + O * 8)),
-                             ("srba_hip_linearize = k_assemble_se2rel (K2 + K5 + K6 fused: Jacobian blocks stay in LDS; bytes = SURVEY 8d fused price, 88 B per block in, Hessian blocks and gradient out)", lambda: lib.srba_hip_linearize(ctx.ctx),
+                             ("srba_hip_linearize = k_assemble_se2rel (K2 + K5 + K6 fused: Jacobian blocks stay in LDS; bytes = SURVEY 8d fused price, 88 B per block in, Hessian blocks "
+                                     "and gradient out)", lambda: lib.srba_hip_linearize(ctx.ctx),
                               stats["n_bp"] * (3 * pbytes + 16) + stats["n_hap"] * P * P * 8 + stats["n_unk_edges"] * P * 8)):
             tt = _timed(fn); stream.append({"kernel": name, "ms": 1e3 * tt, "algorithmic_bytes": float(by), "GBps": by / tt / 1e9, "frac_of_hbm_peak": by / tt / 8e12})
         # the same launch priced with the UNFUSED bytes of SURVEY 8d (160 B per block + 144 B per Hessian term: what rounds 1-2 printed for the kernel that wrote the blocks to HBM)
@@ -409,15 +449,19 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * max_elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "world-2d-30k relative graph-SLAM, SE2 graph-slam, submap=10 depth=3: %d keyframes per GPU -> %d optimize_local_area capsules per GPU, re-optimised per step" % (args.n_kf, batch.n),
-                       "keyframes_per_gpu": args.n_kf, "capsules_per_gpu": batch.n, "lm_trials_per_step_per_gpu": trials_per_step, "floor_trial_share": floor_trial_share, "launch_order": launch_order, "obs_per_s": tot_obs * args.steps / max_elapsed,
-                       "parallelism": "replicas x%d (independent maps, no collective)" % world, "process_group": (None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "aggregate_device": "cuda" if backend == "nccl" else "cpu"}),
+                       "keyframes_per_gpu": args.n_kf, "capsules_per_gpu": batch.n, "lm_trials_per_step_per_gpu": trials_per_step, "floor_trial_share": floor_trial_share, "launch_order": launch_order,
+                               "obs_per_s": tot_obs * args.steps / max_elapsed,
+                       "parallelism": "replicas x%d (independent maps, no collective)" % world, "process_group": (None if dist is None else {"backend": dist.get_backend(),
+                               "world_size": dist.get_world_size(), "aggregate_device": "cuda" if backend == "nccl" else "cpu"}),
                        "solver": "no-Schur, block-sparse LL^t in LDS, symbolic factorisation on the host (reference: CSparse)",
                        "setup_s": {"max_over_ranks": world > 1, "dataset": round(t_gen, 2), "sequential_slam_harvest_gpu_backend": round(t_harvest, 2), "upload_batch_host_to_hbm": round(t_upload, 3)},
                        "sequential_ms_per_kf": (None if cached else round(1e3 * t_harvest / max(1, args.n_kf), 4)),
                        "host_enqueue_ms_per_step": 1e3 * enq[0] / max(1, args.steps),
                        "pcie_inclusive_lm_iterations_per_s": trials_per_step / (t_upload + 1e-3 * kernel_ms)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "the fused LM launch of <SE2, RelativePoses2D>: one persistent launch per LDS size class on its own stream, largest footprint first (k_lm_run2 = two wavefronts per capsule for the windows of 20 KB and more, k_lm_run_lean = three wavefronts per SIMD for the classes of which nine or more fit a CU, k_lm_run for the rest); duration = fork..join", "kernel_ms": kernel_ms, "kernel_ms_samples": len(kern_ms), "algorithmic_bytes_per_launch": abytes},
+                         "kernel": "the fused LM launch of <SE2, RelativePoses2D>: one persistent launch per LDS size class on its own stream, largest footprint first (k_lm_run2 = two wavefronts "
+                                 "per capsule for the windows of 20 KB and more, k_lm_run_lean = three wavefronts per SIMD for the classes of which nine or more fit a CU, k_lm_run for the "
+                                 "rest); duration = fork..join", "kernel_ms": kernel_ms, "kernel_ms_samples": len(kern_ms), "algorithmic_bytes_per_launch": abytes},
             "cpu_baseline": cpu,
             "streaming_kernels": stream,
         }
@@ -427,27 +471,37 @@ def main():
             # the reference's algorithm keeps, cfg4 on the same deep windows of the map it has lost by then (chaotic problems: throughput is comparable, chi2 parity is what the replay tests state).
             ctx.close(); sec = {}; import subprocess
             legs = (("cfg3", ["--workload", "cfg3"]), ("cfg3_reference_defaults", ["--workload", "cfg3", "--cfg3-ext", "0", "--cfg3-kf", "67"]),
-                    ("cfg4", ["--workload", "cfg4"]), ("cfg4_reference_defaults", ["--workload", "cfg4", "--cfg4-ext", "0"]))
+                    ("cfg4", ["--workload", "cfg4"]), ("cfg4_reference_defaults", ["--workload", "cfg4", "--cfg4-ext", "0"]),
+                    ("cfg4_full", ["--workload", "cfg4", "--cfg4-kf", "5000"]))   # BASELINE configs[3] at its stated size: 5 000 key-frames x 200 000 landmarks, behind a wall budget
             for name, extra in legs:
+                if name == "cfg4_full" and args.cfg4_full_budget_s <= 0:
+                    sec[name] = {"skipped": "--cfg4-full-budget-s 0: the 5 000-key-frame x 200 000-landmark map is built key-frame by key-frame through the engine (about five minutes)"}; continue
                 cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(min(args.steps, 5)), "--warmup", "1", "--cpu-seconds", str(min(args.cpu_seconds, 5.0)),
-                       "--cfg3-copies", str(args.cfg3_copies), "--cfg4-kf", str(args.cfg4_kf), "--cfg4-windows", str(args.cfg4_windows)] + extra
+                       "--cfg3-copies", str(args.cfg3_copies), "--cfg4-windows", str(args.cfg4_windows)] + ([] if "--cfg4-kf" in extra else ["--cfg4-kf", str(args.cfg4_kf)]) + extra
                 if "--cfg3-ext" not in extra: cmd += ["--cfg3-ext", str(args.cfg3_ext), "--cfg3-kf", str(args.cfg3_kf)]
                 if "--cfg4-ext" not in extra: cmd += ["--cfg4-ext", str(args.cfg4_ext)]
                 try:
                     env = dict(os.environ); env.pop("SRBA_BENCH_FORCE_DIST", None); env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local_rank))
-                    pr = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+                    t_leg = time.time()
+                    try:
+                        pr = subprocess.run(cmd, capture_output=True, text=True, timeout=(args.cfg4_full_budget_s if name == "cfg4_full" else 1500), env=env, cwd=ROOT)
+                    except subprocess.TimeoutExpired:
+                        sec[name] = {"skipped": "exceeded its wall budget of %.0f s (--cfg4-full-budget-s): the map is built key-frame by key-frame, every define_new_keyframe() a depth-8 LM run" % args.cfg4_full_budget_s}; continue
                     ls = [l for l in pr.stdout.splitlines() if l.startswith("{")]
                     if pr.returncode != 0 or not ls:
                         sec[name] = {"error": "exit %d: %s" % (pr.returncode, pr.stderr.strip()[-300:])}; continue
                     l2 = json.loads(ls[-1])
-                    sec[name] = {"value": l2["value"], "unit": l2["unit"], "ms_per_step": l2["ms_per_step"], "steps": l2["steps"], "workload": l2["config"]["workload"], "extensions": l2["config"].get("extensions"),
-                                 "roofline": l2["roofline"], "cpu_baseline": l2["cpu_baseline"], "sequential_ms_per_kf": l2["config"].get("sequential_ms_per_kf")}
+                    sec[name] = {"value": l2["value"], "unit": l2["unit"], "ms_per_step": l2["ms_per_step"], "steps": l2["steps"], "workload": l2["config"]["workload"],
+                            "extensions": l2["config"].get("extensions"),
+                                 "roofline": l2["roofline"], "cpu_baseline": l2["cpu_baseline"], "sequential_ms_per_kf": l2["config"].get("sequential_ms_per_kf"),
+                                         "leg_wall_s": round(time.time() - t_leg, 1)}
                 except Exception as e:  # noqa: BLE001  (a secondary measurement must not take the headline line down)
                     sec[name] = {"error": repr(e)}
             line["secondary_workloads"] = sec
         print(json.dumps(line), flush=True)
         if cpu is not None and not (cpu["max_chi2_final_rel_diff_vs_gpu"] <= 1e-6 and cpu["max_chi2_init_rel_diff_vs_gpu"] <= 1e-9):
-            raise SystemExit("bench.py: chi2 mismatch GPU vs CPU on the sample (final %.3e, init %.3e): the timing above does not count" % (cpu["max_chi2_final_rel_diff_vs_gpu"], cpu["max_chi2_init_rel_diff_vs_gpu"]))
+            raise SystemExit("bench.py: chi2 mismatch GPU vs CPU on the sample (final %.3e, init %.3e): the timing above does not count" % (cpu["max_chi2_final_rel_diff_vs_gpu"],
+                    cpu["max_chi2_init_rel_diff_vs_gpu"]))
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()
 

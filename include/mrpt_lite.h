@@ -71,7 +71,8 @@ struct TPixelCoordf { float x, y; TPixelCoordf() : x(0), y(0) {} TPixelCoordf(fl
 /** Pinhole intrinsics, the subset SRBA reads (models/sensors.h:59-60,98-99). */
 struct TCamera {
 	double m_fx, m_fy, m_cx, m_cy; unsigned ncols, nrows;
-	struct dist_t { double v[5]; dist_t() { setZero(); } void setZero() { for (int i = 0; i < 5; i++) v[i] = 0; } double &operator[](int i) { return v[i]; } const double &operator[](int i) const { return v[i]; } } dist; // [k1 k2 t1 t2 k3]; SRBA's sensor models ignore distortion
+	struct dist_t { double v[5]; dist_t() { setZero(); } void setZero() { for (int i = 0; i < 5; i++) v[i] = 0; } double &operator[](int i) { return v[i]; } const double &operator[](int i) const {
+		return v[i]; } } dist; // [k1 k2 t1 t2 k3]; SRBA's sensor models ignore distortion
 	TCamera() : m_fx(1), m_fy(1), m_cx(0), m_cy(0), ncols(640), nrows(480) {}
 	double fx() const { return m_fx; } double fy() const { return m_fy; } double cx() const { return m_cx; } double cy() const { return m_cy; }
 	void fx(double v) { m_fx = v; } void fy(double v) { m_fy = v; } void cx(double v) { m_cx = v; } void cy(double v) { m_cy = v; }
@@ -121,7 +122,8 @@ struct CMatrixDouble {
 	void setSize(std::size_t r, std::size_t c) { nr = r; nc = c; m.assign(r * c, 0.0); }
 	double &operator()(std::size_t r, std::size_t c) { return m[r * nc + c]; } const double &operator()(std::size_t r, std::size_t c) const { return m[r * nc + c]; }
 	double &coeffRef(std::size_t r, std::size_t c) { return m[r * nc + c]; } double coeff(std::size_t r, std::size_t c) const { return m[r * nc + c]; }
-	std::size_t size() const { return nr * nc; } std::size_t rows() const { return nr; } std::size_t cols() const { return nc; } std::size_t getRowCount() const { return nr; } std::size_t getColCount() const { return nc; }
+	std::size_t size() const { return nr * nc; } std::size_t rows() const { return nr; } std::size_t cols() const { return nc; } std::size_t getRowCount() const { return nr; }
+		std::size_t getColCount() const { return nc; }
 	void loadFromTextFile(const std::string &file); void saveToTextFile(const std::string &file) const;
 };
 typedef CMatrixDouble CMatrixD;
@@ -171,7 +173,8 @@ public:
 	void inverse() { const double c = std::cos(m_phi), s = std::sin(m_phi); const double nx = -m_x * c - m_y * s, ny = m_x * s - m_y * c; m_x = nx; m_y = ny; m_phi = -m_phi; }
 	void composePoint(double lx, double ly, double &gx, double &gy) const { const double c = std::cos(m_phi), s = std::sin(m_phi); gx = m_x + lx * c - ly * s; gy = m_y + lx * s + ly * c; }
 	void composePoint(double lx, double ly, double lz, double &gx, double &gy, double &gz) const { composePoint(lx, ly, gx, gy); gz = lz; }
-	void inverseComposePoint(double gx, double gy, double &lx, double &ly) const { const double c = std::cos(m_phi), s = std::sin(m_phi); lx = (gx - m_x) * c + (gy - m_y) * s; ly = -(gx - m_x) * s + (gy - m_y) * c; }
+	void inverseComposePoint(double gx, double gy, double &lx, double &ly) const { const double c = std::cos(m_phi), s = std::sin(m_phi); lx = (gx - m_x) * c + (gy - m_y) * s;
+		ly = -(gx - m_x) * s + (gy - m_y) * c; }
 	CPose2D operator+(const CPose2D &b) const { CPose2D r; r.composeFrom(*this, b); return r; }
 	CPose2D operator-(const CPose2D &b) const { CPose2D r; r.inverseComposeFrom(*this, b); return r; }
 	void getAsVector(double v[3]) const { v[0] = m_x; v[1] = m_y; v[2] = m_phi; }
@@ -249,7 +252,8 @@ public:
 		double a, b; if (th < 1e-8) { a = 1 - th2 / 6; b = 0.5 - th2 / 24; } else { a = std::sin(th) / th; b = (1 - std::cos(th)) / th2; }
 		const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
 		math::CMatrixDouble33 R;
-		for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { const double w2 = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j]; R(i, j) = (i == j ? 1.0 : 0.0) + a * W[3 * i + j] + b * w2; }
+		for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { const double w2 = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j]; R(i,
+			j) = (i == j ? 1.0 : 0.0) + a * W[3 * i + j] + b * w2; }
 		return R;
 	}
 	/** log map of SO(3) */
@@ -261,7 +265,8 @@ public:
 	}
 };
 inline CPose3D operator-(const CPose3D &p) { CPose3D r(p); r.inverse(); return r; }
-inline std::ostream &operator<<(std::ostream &o, const CPose3D &p) { double y, pi, r; p.getYawPitchRoll(y, pi, r); return o << "(" << p.x() << "," << p.y() << "," << p.z() << "," << utils::RAD2DEG(y) << "deg," << utils::RAD2DEG(pi) << "deg," << utils::RAD2DEG(r) << "deg)"; }
+inline std::ostream &operator<<(std::ostream &o, const CPose3D &p) { double y, pi, r; p.getYawPitchRoll(y, pi, r); return o << "(" << p.x() << "," << p.y() << "," << p.z() << "," << utils::RAD2DEG(y)
+	<< "deg," << utils::RAD2DEG(pi) << "deg," << utils::RAD2DEG(r) << "deg)"; }
 inline CPose2D::CPose2D(const CPose3D &p) : m_x(p.x()), m_y(p.y()), m_phi(p.yaw()) {}
 
 /** 3D pose with quaternion (x y z qr qx qy qz). */
@@ -274,8 +279,10 @@ public:
 	const math::CQuaternionDouble &quat() const { return m_q; }
 	explicit CPose3DQuat(const CPose3D &p);
 	/** "[x y z qr qx qy qz]" */
-	void fromString(const std::string &s) { std::string t(s); for (char &ch : t) if (ch == '[' || ch == ']' || ch == ',') ch = ' '; std::istringstream is(t); double v[7] = {0, 0, 0, 1, 0, 0, 0}; for (int i = 0; i < 7 && (is >> v[i]); i++) {} *this = CPose3DQuat(v[0], v[1], v[2], math::CQuaternionDouble(v[3], v[4], v[5], v[6])); }
-	std::string asString() const { std::ostringstream o; o << "[" << m_t[0] << " " << m_t[1] << " " << m_t[2] << " " << m_q.r() << " " << m_q.x() << " " << m_q.y() << " " << m_q.z() << "]"; return o.str(); }
+	void fromString(const std::string &s) { std::string t(s); for (char &ch : t) if (ch == '[' || ch == ']' || ch == ',') ch = ' '; std::istringstream is(t); double v[7] = {0, 0, 0, 1, 0, 0, 0};
+		for (int i = 0; i < 7 && (is >> v[i]); i++) {} *this = CPose3DQuat(v[0], v[1], v[2], math::CQuaternionDouble(v[3], v[4], v[5], v[6])); }
+	std::string asString() const { std::ostringstream o; o << "[" << m_t[0] << " " << m_t[1] << " " << m_t[2] << " " << m_q.r() << " " << m_q.x() << " " << m_q.y() << " " << m_q.z() << "]";
+		return o.str(); }
 };
 inline CPose3D::CPose3D(const CPose3DQuat &q) { m_t[0] = q.m_t[0]; m_t[1] = q.m_t[1]; m_t[2] = q.m_t[2]; q.m_q.rotationMatrix(m_R); }
 
@@ -315,7 +322,8 @@ struct TStereoCamera {
 };
 struct TMatchingPair {
 	unsigned this_idx, other_idx; double this_x, this_y, this_z, other_x, other_y, other_z;
-	TMatchingPair(unsigned ti, unsigned oi, double tx, double ty, double tz, double ox, double oy, double oz) : this_idx(ti), other_idx(oi), this_x(tx), this_y(ty), this_z(tz), other_x(ox), other_y(oy), other_z(oz) {}
+	TMatchingPair(unsigned ti, unsigned oi, double tx, double ty, double tz, double ox, double oy, double oz) : this_idx(ti), other_idx(oi), this_x(tx), this_y(ty), this_z(tz), other_x(ox),
+		other_y(oy), other_z(oz) {}
 };
 typedef std::vector<TMatchingPair> TMatchingPairList;
 } // namespace utils
@@ -397,9 +405,11 @@ public:
 	const std::map<std::string, TCallData> &getStats() const { return m_data; }
 	struct TCallStats { double min_t, max_t, mean_t, total_t; std::size_t n_calls; TCallStats() : min_t(0), max_t(0), mean_t(0), total_t(0), n_calls(0) {} };
 	/** per-section summary with the reference's field names (min / max are not tracked here: both report the mean) */
-	void getStats(std::map<std::string, TCallStats> &out) const { out.clear(); for (std::map<std::string, TCallData>::const_iterator it = m_data.begin(); it != m_data.end(); ++it) { TCallStats &s = out[it->first]; s.n_calls = it->second.n; s.total_t = it->second.total; s.mean_t = it->second.n ? it->second.total / it->second.n : 0; s.min_t = s.max_t = s.mean_t; } }
+	void getStats(std::map<std::string, TCallStats> &out) const { out.clear(); for (std::map<std::string, TCallData>::const_iterator it = m_data.begin(); it != m_data.end(); ++it) {
+		TCallStats &s = out[it->first]; s.n_calls = it->second.n; s.total_t = it->second.total; s.mean_t = it->second.n ? it->second.total / it->second.n : 0; s.min_t = s.max_t = s.mean_t; } }
 	void clear(bool = false) { m_data.clear(); }
-	void dumpAllStats(std::size_t = 0) const { for (std::map<std::string, TCallData>::const_iterator it = m_data.begin(); it != m_data.end(); ++it) std::cout << it->first << ": calls " << it->second.n << " total " << it->second.total << " s\n"; }
+	void dumpAllStats(std::size_t = 0) const { for (std::map<std::string, TCallData>::const_iterator it = m_data.begin(); it != m_data.end();
+		++it) std::cout << it->first << ": calls " << it->second.n << " total " << it->second.total << " s\n"; }
 	double getMeanTime(const std::string &name) const { auto it = m_data.find(name); return (it == m_data.end() || !it->second.n) ? 0 : it->second.total / it->second.n; }
 private:
 	bool m_enabled; std::map<std::string, TCallData> m_data;
@@ -422,7 +432,8 @@ inline double mrpt::utils::CTimeLogger::leave(const char *name) {
 inline void mrpt::math::CMatrixDouble::loadFromTextFile(const std::string &file) {
 	std::ifstream f(file.c_str()); if (!f) throw std::runtime_error("CMatrixDouble::loadFromTextFile: cannot open " + file);
 	std::vector<std::vector<double> > rowsv; std::string line;
-	while (std::getline(f, line)) { if (line.empty() || line[0] == '%' || line[0] == '#') continue; std::istringstream is(line); std::vector<double> r; double v; while (is >> v) r.push_back(v); if (!r.empty()) rowsv.push_back(r); }
+	while (std::getline(f, line)) { if (line.empty() || line[0] == '%' || line[0] == '#') continue; std::istringstream is(line); std::vector<double> r; double v; while (is >> v) r.push_back(v);
+		if (!r.empty()) rowsv.push_back(r); }
 	setSize(rowsv.size(), rowsv.empty() ? 0 : rowsv[0].size());
 	for (std::size_t r = 0; r < nr; r++) for (std::size_t c = 0; c < nc && c < rowsv[r].size(); c++) m[r * nc + c] = rowsv[r][c];
 }
@@ -450,7 +461,8 @@ public:
 	template <class T> void write(const std::string &section, const std::string &name, const T &value, int = -1, int = -1, const std::string &comment = std::string()) {
 		std::ostringstream o; o.precision(17); o << value; m_data[section][name] = o.str(); if (!comment.empty()) m_comments[section + "\n" + name] = comment; m_dirty = true;
 	}
-	void write(const std::string &section, const std::string &name, const bool &value, int = -1, int = -1, const std::string &comment = std::string()) { write<std::string>(section, name, value ? "true" : "false", -1, -1, comment); }
+	void write(const std::string &section, const std::string &name, const bool &value, int = -1, int = -1, const std::string &comment = std::string()) { write<std::string>(section, name,
+		value ? "true" : "false", -1, -1, comment); }
 protected:
 	const std::string *find(const std::string &section, const std::string &name) const {
 		const std::map<std::string, std::map<std::string, std::string> >::const_iterator s = m_data.find(section); if (s == m_data.end()) return NULL;
@@ -482,7 +494,8 @@ public:
 		for (std::map<std::string, std::map<std::string, std::string> >::const_iterator s = m_data.begin(); s != m_data.end(); ++s) {
 			f << "[" << s->first << "]\n";
 			for (std::map<std::string, std::string>::const_iterator v = s->second.begin(); v != s->second.end(); ++v) {
-				f << v->first << " = " << v->second; const std::map<std::string, std::string>::const_iterator c = m_comments.find(s->first + "\n" + v->first); if (c != m_comments.end()) f << "   // " << c->second; f << "\n";
+				f << v->first << " = " << v->second; const std::map<std::string, std::string>::const_iterator c = m_comments.find(s->first + "\n" + v->first);
+					if (c != m_comments.end()) f << "   // " << c->second; f << "\n";
 			}
 			f << "\n";
 		}
@@ -494,7 +507,9 @@ private:
 /** in-memory variant */
 class CConfigFileMemory : public CConfigFileBase {
 public:
-	std::string getContent() const { std::ostringstream o; for (std::map<std::string, std::map<std::string, std::string> >::const_iterator s = m_data.begin(); s != m_data.end(); ++s) { o << "[" << s->first << "]\n"; for (std::map<std::string, std::string>::const_iterator v = s->second.begin(); v != s->second.end(); ++v) o << v->first << " = " << v->second << "\n"; } return o.str(); }
+	std::string getContent() const { std::ostringstream o; for (std::map<std::string, std::map<std::string, std::string> >::const_iterator s = m_data.begin(); s != m_data.end(); ++s) {
+		o << "[" << s->first << "]\n"; for (std::map<std::string, std::string>::const_iterator v = s->second.begin(); v != s->second.end(); ++v) o << v->first << " = " << v->second << "\n"; }
+		return o.str(); }
 };
 /** parameter blocks that read / write themselves from a configuration section (mrpt::utils::CLoadableOptions) */
 class CLoadableOptions {
@@ -508,7 +523,8 @@ public:
 };
 } // namespace utils
 namespace utils {
-namespace detail { inline std::vector<double> numbers_of(const std::string &s) { std::string t(s); for (char &ch : t) if (ch == '[' || ch == ']' || ch == ',' || ch == ';') ch = ' '; std::istringstream is(t); std::vector<double> v; double x; while (is >> x) v.push_back(x); return v; } }
+namespace detail { inline std::vector<double> numbers_of(const std::string &s) { std::string t(s); for (char &ch : t) if (ch == '[' || ch == ']' || ch == ',' || ch == ';') ch = ' ';
+	std::istringstream is(t); std::vector<double> v; double x; while (is >> x) v.push_back(x); return v; } }
 inline void TCamera::loadFromConfigFile(const std::string &section, const CConfigFileBase &cfg) {
 	const std::vector<double> res = detail::numbers_of(cfg.read<std::string>(section, "resolution", "", true));
 	if (res.size() != 2) throw std::runtime_error("[" + section + "] resolution: expected [W H]");

@@ -69,7 +69,8 @@ struct function_backend : public numeric_backend {
 	function_backend(fn_t f, const std::string &n) : fn(f), overall_fn(NULL), nm(n) {}
 	void run(const srba_hip_params &p, srba_problem_capsule &c, srba_lm_result &r) { if (fn(&p, &c, &r) != 0) throw std::runtime_error("numeric back-end '" + nm + "' failed"); }
 	const char *name() const { return nm.c_str(); }
-	double eval_overall(const srba_hip_params &p, const srba_overall_problem &q) { double v = 0; if (!overall_fn || overall_fn(&p, &q, &v) != 0) throw std::runtime_error("numeric back-end '" + nm + "': eval_overall failed or not provided"); return v; }
+	double eval_overall(const srba_hip_params &p, const srba_overall_problem &q) { double v = 0; if (!overall_fn || overall_fn(&p, &q, &v) != 0) throw std::runtime_error("numeric back-end '" + nm +
+		"': eval_overall failed or not provided"); return v; }
 };
 std::shared_ptr<numeric_backend> make_hip_backend(int device); // srba/hip_backend.h
 
@@ -126,7 +127,8 @@ struct TRBA_Problem_state {
 		bool empty() const { return m_ids.empty(); }
 		const_iterator begin() const { return const_iterator(this, 0); }
 		const_iterator end() const { return const_iterator(this, m_ids.size()); }
-		const_iterator find(TLandmarkID id) const { const std::vector<TLandmarkID>::const_iterator p = std::lower_bound(m_ids.begin(), m_ids.end(), id); return (p != m_ids.end() && *p == id) ? const_iterator(this, (size_t)(p - m_ids.begin())) : end(); }
+		const_iterator find(TLandmarkID id) const { const std::vector<TLandmarkID>::const_iterator p = std::lower_bound(m_ids.begin(), m_ids.end(), id);
+			return (p != m_ids.end() && *p == id) ? const_iterator(this, (size_t)(p - m_ids.begin())) : end(); }
 		// engine side
 		void bind(const std::vector<TRelativeLandmarkPos> *t) { m_table = t; }
 		void add(TLandmarkID id) { if (m_ids.empty() || m_ids.back() < id) m_ids.push_back(id); else m_ids.insert(std::lower_bound(m_ids.begin(), m_ids.end(), id), id); }
@@ -143,14 +145,16 @@ struct TRBA_Problem_state {
 		const TRBA_Problem_state *s;
 		size_t size() const { return s->obs_table.size(); }
 		bool empty() const { return s->obs_table.empty(); }
-		k2f_edge_t operator[](size_t i) const { k2f_edge_t e; e.obs = s->obs_table[i]; e.feat_has_known_rel_pos = s->topo.obs_known[i] != 0; e.is_first_obs_of_unknown = s->topo.obs_first_of_unknown[i] != 0; e.feat_rel_pos = &s->lm_table[e.obs.obs.feat_id]; return e; }
+		k2f_edge_t operator[](size_t i) const { k2f_edge_t e; e.obs = s->obs_table[i]; e.feat_has_known_rel_pos = s->topo.obs_known[i] != 0;
+			e.is_first_obs_of_unknown = s->topo.obs_first_of_unknown[i] != 0; e.feat_rel_pos = &s->lm_table[e.obs.obs.feat_id]; return e; }
 	} all_observations;
 
 	/** read access to the spanning trees in the reference's terms */
 	struct TSpanningTree {
 		const TRBA_Problem_state *s;
 		/** next_edge[src][trg] (false if trg is not within max_tree_depth of src) */
-		bool get_next_edge(TKeyFrameID src, TKeyFrameID trg, TSpanTreeEntry &out) const { const graph::st_entry *e = s->topo.st.find((graph::id32)src, (graph::id32)trg); if (!e) return false; out.next = e->next; out.distance = e->dist; return true; }
+		bool get_next_edge(TKeyFrameID src, TKeyFrameID trg, TSpanTreeEntry &out) const { const graph::st_entry *e = s->topo.st.find((graph::id32)src, (graph::id32)trg); if (!e) return false;
+			out.next = e->next; out.distance = e->dist; return true; }
 		/** all_edges[max(a,b)][min(a,b)]: edge ids of the stored shortest path, walking from the larger id */
 		bool get_path(TKeyFrameID a, TKeyFrameID b, std::vector<size_t> &edge_ids) const {
 			edge_ids.clear(); const graph::id32 hi = (graph::id32)std::max(a, b), lo = (graph::id32)std::min(a, b);
@@ -159,18 +163,21 @@ struct TRBA_Problem_state {
 			return true;
 		}
 		/** num[src][trg]: pose of trg as seen from src, NULL if never requested */
-		const pose_flag_t *get_num(TKeyFrameID src, TKeyFrameID trg) const { const int32_t slot = s->topo.find_num((graph::id32)src, (graph::id32)trg); return (slot >= 0 && (size_t)slot < s->num_pool.size()) ? &s->num_pool[slot] : (const pose_flag_t *)0; }
+		const pose_flag_t *get_num(TKeyFrameID src, TKeyFrameID trg) const { const int32_t slot = s->topo.find_num((graph::id32)src, (graph::id32)trg);
+			return (slot >= 0 && (size_t)slot < s->num_pool.size()) ? &s->num_pool[slot] : (const pose_flag_t *)0; }
 		/** number of key-frames in each symbolic tree: min / max / mean / standard deviation (reference impl/spantree_misc.h) */
 		void get_stats(size_t &num_nodes_min, size_t &num_nodes_max, double &num_nodes_mean, double &num_nodes_std) const {
 			num_nodes_min = num_nodes_max = 0; num_nodes_mean = num_nodes_std = 0; const size_t n = s->topo.st.rows(); if (!n) return;
 			num_nodes_min = std::numeric_limits<size_t>::max(); double sum = 0, sum2 = 0;
-			for (size_t k = 0; k < n; k++) { const size_t c = s->topo.st.len((graph::id32)k); num_nodes_min = std::min(num_nodes_min, c); num_nodes_max = std::max(num_nodes_max, c); sum += c; sum2 += (double)c * c; }
+			for (size_t k = 0; k < n; k++) { const size_t c = s->topo.st.len((graph::id32)k); num_nodes_min = std::min(num_nodes_min, c); num_nodes_max = std::max(num_nodes_max, c); sum += c;
+				sum2 += (double)c * c; }
 			num_nodes_mean = sum / n; num_nodes_std = std::sqrt(std::max(0.0, sum2 / n - num_nodes_mean * num_nodes_mean));
 		}
 		/** plain-text listing of every tree: "src: trg(next,dist) ..." */
 		bool dump_as_text_to_file(const std::string &file) const {
 			FILE *f = std::fopen(file.c_str(), "wt"); if (!f) return false;
-			for (size_t k = 0; k < s->topo.st.rows(); k++) { std::fprintf(f, "%zu:", k); const graph::st_entry *r = s->topo.st.row((graph::id32)k); for (size_t i = 0; i < s->topo.st.len((graph::id32)k); i++) std::fprintf(f, " %u(%u,%u)", r[i].trg, r[i].next, r[i].dist); std::fprintf(f, "\n"); }
+			for (size_t k = 0; k < s->topo.st.rows(); k++) { std::fprintf(f, "%zu:", k); const graph::st_entry *r = s->topo.st.row((graph::id32)k); for (size_t i = 0;
+				i < s->topo.st.len((graph::id32)k); i++) std::fprintf(f, " %u(%u,%u)", r[i].trg, r[i].next, r[i].dist); std::fprintf(f, "\n"); }
 			std::fclose(f); return true;
 		}
 		/** Graphviz file with one cluster per requested root (all roots if the list is empty) */
@@ -181,7 +188,8 @@ struct TRBA_Problem_state {
 			for (size_t q = 0; q < rs.size(); q++) {
 				const graph::id32 root = (graph::id32)rs[q]; std::fprintf(f, " subgraph cluster_%u { label=\"root %u\";\n", root, root);
 				const graph::st_entry *r = s->topo.st.row(root);
-				for (size_t i = 0; i < s->topo.st.len(root); i++) { TSpanTreeEntry back; if (get_next_edge(r[i].trg, root, back)) std::fprintf(f, "  n%u_%u -> n%u_%llu;\n", root, r[i].trg, root, (unsigned long long)back.next); }
+				for (size_t i = 0; i < s->topo.st.len(root); i++) { TSpanTreeEntry back; if (get_next_edge(r[i].trg, root, back)) std::fprintf(f, "  n%u_%u -> n%u_%llu;\n", root, r[i].trg, root,
+					(unsigned long long)back.next); }
 				std::fprintf(f, " }\n");
 			}
 			std::fprintf(f, "}\n"); std::fclose(f); return true;
@@ -197,7 +205,8 @@ struct TRBA_Problem_state {
 		double sum = 0, sum2 = 0; for (size_t k = 0; k < n; k++) { const double d = topo.kf_degree[k]; sum += d; sum2 += d * d; out_max_degree = std::max(out_max_degree, d); }
 		out_mean_degree = sum / n; out_std_degree = std::sqrt(std::max(0.0, sum2 / n - out_mean_degree * out_mean_degree));
 	}
-	const lm_inf_matrix_t *find_inf_matrix(TLandmarkID id) const { for (size_t i = 0; i < unknown_lms_inf_matrices.size(); i++) if (unknown_lms_inf_matrices[i].first == id) return &unknown_lms_inf_matrices[i].second; return NULL; }
+	const lm_inf_matrix_t *find_inf_matrix(TLandmarkID id) const { for (size_t i = 0; i < unknown_lms_inf_matrices.size();
+		i++) if (unknown_lms_inf_matrices[i].first == id) return &unknown_lms_inf_matrices[i].second; return NULL; }
 	pose_flag_t &num_at(int32_t slot) { if ((size_t)slot >= num_pool.size()) num_pool.resize((size_t)topo.num_slots); return num_pool[slot]; }
 private:
 	void wire() { known_lms.bind(&lm_table); unknown_lms.bind(&lm_table); keyframes.t = &topo; all_observations.s = this; spanning_tree.s = this; }
@@ -213,8 +222,11 @@ namespace ecps {
 struct local_areas_fixed_size {
 	struct parameters_t : public mrpt::utils::CLoadableOptions {
 		size_t submap_size, min_obs_to_loop_closure; parameters_t() : submap_size(15), min_obs_to_loop_closure(4) {}
-		void loadFromConfigFile(const mrpt::utils::CConfigFileBase &source, const std::string &section) override { submap_size = (size_t)source.read<uint64_t>(section, "submap_size", submap_size); min_obs_to_loop_closure = (size_t)source.read<uint64_t>(section, "min_obs_to_loop_closure", min_obs_to_loop_closure); }
-		void saveToConfigFile(mrpt::utils::CConfigFileBase &out, const std::string &section) const override { out.write(section, "submap_size", (uint64_t)submap_size, 30, 30, "Key-frames per sub-map"); out.write(section, "min_obs_to_loop_closure", (uint64_t)min_obs_to_loop_closure, 30, 30, "shared landmark observations needed before a loop-closure edge is created"); }
+		void loadFromConfigFile(const mrpt::utils::CConfigFileBase &source, const std::string &section) override { submap_size = (size_t)source.read<uint64_t>(section, "submap_size", submap_size);
+			min_obs_to_loop_closure = (size_t)source.read<uint64_t>(section, "min_obs_to_loop_closure", min_obs_to_loop_closure); }
+		void saveToConfigFile(mrpt::utils::CConfigFileBase &out, const std::string &section) const override { out.write(section, "submap_size", (uint64_t)submap_size, 30, 30,
+			"Key-frames per sub-map"); out.write(section, "min_obs_to_loop_closure", (uint64_t)min_obs_to_loop_closure, 30, 30,
+			"shared landmark observations needed before a loop-closure edge is created"); }
 	};
 	TKeyFrameID get_center_kf_for_kf(const TKeyFrameID kf_id, const parameters_t &params) const { return params.submap_size * (kf_id / params.submap_size); }
 
@@ -262,8 +274,10 @@ struct local_areas_fixed_size {
 struct classic_linear_rba {
 	struct parameters_t : public mrpt::utils::CLoadableOptions {
 		size_t min_obs_to_loop_closure; parameters_t() : min_obs_to_loop_closure(4) {}
-		void loadFromConfigFile(const mrpt::utils::CConfigFileBase &source, const std::string &section) override { min_obs_to_loop_closure = (size_t)source.read<uint64_t>(section, "min_obs_to_loop_closure", min_obs_to_loop_closure); }
-		void saveToConfigFile(mrpt::utils::CConfigFileBase &out, const std::string &section) const override { out.write(section, "min_obs_to_loop_closure", (uint64_t)min_obs_to_loop_closure, 30, 30, "shared landmark observations needed before a loop-closure edge is created"); }
+		void loadFromConfigFile(const mrpt::utils::CConfigFileBase &source, const std::string &section) override { min_obs_to_loop_closure = (size_t)source.read<uint64_t>(section,
+			"min_obs_to_loop_closure", min_obs_to_loop_closure); }
+		void saveToConfigFile(mrpt::utils::CConfigFileBase &out, const std::string &section) const override { out.write(section, "min_obs_to_loop_closure", (uint64_t)min_obs_to_loop_closure, 30, 30,
+			"shared landmark observations needed before a loop-closure edge is created"); }
 	};
 
 	template <class traits_t, class rba_engine_t>
@@ -312,7 +326,8 @@ public:
 	typedef typename kf2kf_pose_traits_t::pose_flag_t pose_flag_t; typedef typename kf2kf_pose_traits_t::frameid2pose_map_t frameid2pose_map_t;
 	typedef typename rba_problem_state_t::TRelativeLandmarkPosMap TRelativeLandmarkPosMap; typedef typename landmark_traits_t::TRelativeLandmarkPos TRelativeLandmarkPos;
 	typedef typename traits_t::new_kf_observation_t new_kf_observation_t; typedef typename traits_t::new_kf_observations_t new_kf_observations_t;
-	typedef typename kf2kf_pose_traits_t::array_pose_t array_pose_t; typedef typename landmark_traits_t::array_landmark_t array_landmark_t; typedef typename observation_traits_t::array_obs_t array_obs_t;
+	typedef typename kf2kf_pose_traits_t::array_pose_t array_pose_t; typedef typename landmark_traits_t::array_landmark_t array_landmark_t;
+		typedef typename observation_traits_t::array_obs_t array_obs_t;
 	typedef typename observation_traits_t::residual_t residual_t; typedef typename observation_traits_t::vector_residuals_t vector_residuals_t;
 
 	RbaEngine() : m_verbose_level(1), m_profiler(true), m_hip_device(-1) {}
@@ -322,14 +337,17 @@ public:
 		TOptimizeExtraOutputInfo() { clear(); }
 		size_t num_observations, num_jacobians, num_kf2kf_edges_optimized, num_kf2lm_edges_optimized, num_total_scalar_optimized, num_kf_optimized, num_lm_optimized, num_span_tree_numeric_updates;
 		double obs_rmse, total_sqr_error_init, total_sqr_error_final, HAp_condition_number;
-		size_t sparsity_dh_dAp_nnz, sparsity_dh_dAp_max_size, sparsity_dh_df_nnz, sparsity_dh_df_max_size, sparsity_HAp_nnz, sparsity_HAp_max_size, sparsity_Hf_nnz, sparsity_Hf_max_size, sparsity_HApf_nnz, sparsity_HApf_max_size;
+		size_t sparsity_dh_dAp_nnz, sparsity_dh_dAp_max_size, sparsity_dh_df_nnz, sparsity_dh_df_max_size, sparsity_HAp_nnz, sparsity_HAp_max_size, sparsity_Hf_nnz, sparsity_Hf_max_size,
+			sparsity_HApf_nnz, sparsity_HApf_max_size;
 		std::vector<size_t> optimized_k2k_edge_indices, optimized_landmark_indices;
 		typename RBA_OPTIONS::solver_t::extra_results_t extra_results;
 		srba_lm_result lm; //!< (extension) raw record of the numeric back-end: LM trials, lambda, per-trial chi2 / rho trace
 		void clear() {
-			num_observations = num_jacobians = num_kf2kf_edges_optimized = num_kf2lm_edges_optimized = num_total_scalar_optimized = num_kf_optimized = num_lm_optimized = num_span_tree_numeric_updates = 0;
+			num_observations = num_jacobians = num_kf2kf_edges_optimized = num_kf2lm_edges_optimized = num_total_scalar_optimized = num_kf_optimized = num_lm_optimized = num_span_tree_numeric_updates
+				= 0;
 			obs_rmse = 0; total_sqr_error_init = total_sqr_error_final = HAp_condition_number = 0;
-			sparsity_dh_dAp_nnz = sparsity_dh_dAp_max_size = sparsity_dh_df_nnz = sparsity_dh_df_max_size = sparsity_HAp_nnz = sparsity_HAp_max_size = sparsity_Hf_nnz = sparsity_Hf_max_size = sparsity_HApf_nnz = sparsity_HApf_max_size = 0;
+			sparsity_dh_dAp_nnz = sparsity_dh_dAp_max_size = sparsity_dh_df_nnz = sparsity_dh_df_max_size = sparsity_HAp_nnz = sparsity_HAp_max_size = sparsity_Hf_nnz = sparsity_Hf_max_size =
+				sparsity_HApf_nnz = sparsity_HApf_max_size = 0;
 			optimized_k2k_edge_indices.clear(); optimized_landmark_indices.clear(); extra_results.clear(); std::memset(&lm, 0, sizeof(lm));
 		}
 	};
@@ -372,23 +390,32 @@ public:
 		bool return_hessian;
 		TSRBAParameters() : max_tree_depth(4), max_optimize_depth(4), optimize_new_edges_alone(true), use_robust_kernel(false), use_robust_kernel_stage1(false), kernel_param(3.), max_iters(20),
 			max_error_per_obs_to_stop(1e-6), max_rho(10.0), max_lambda(1e20), min_error_reduction_ratio_to_relinearize(0.01), numeric_jacobians(false), feedback_user_iteration(NULL),
-			compute_condition_number(false), compute_sparsity_stats(false), max_rmse_show_red_warning(0.5), cov_recovery(crpLandmarksApprox), refresh_all_read_poses(false), restore_spanning_tree_twins(false), schur_keeps_gradient(false), consistent_loop_closure_init(false), return_hessian(false) {}
+			compute_condition_number(false), compute_sparsity_stats(false), max_rmse_show_red_warning(0.5), cov_recovery(crpLandmarksApprox), refresh_all_read_poses(false),
+				restore_spanning_tree_twins(false), schur_keeps_gradient(false), consistent_loop_closure_init(false), return_hessian(false) {}
 		/** keys of the reference's configuration files (impl/rba_problem_common.h:60-92); cov_recovery by enumerator name or number */
 		void loadFromConfigFile(const mrpt::utils::CConfigFileBase &source, const std::string &section) override {
-			max_tree_depth = (topo_dist_t)source.read<uint64_t>(section, "max_tree_depth", max_tree_depth); max_optimize_depth = (topo_dist_t)source.read<uint64_t>(section, "max_optimize_depth", max_optimize_depth);
+			max_tree_depth = (topo_dist_t)source.read<uint64_t>(section, "max_tree_depth", max_tree_depth); max_optimize_depth = (topo_dist_t)source.read<uint64_t>(section, "max_optimize_depth",
+				max_optimize_depth);
 			optimize_new_edges_alone = source.read<bool>(section, "optimize_new_edges_alone", optimize_new_edges_alone);
-			use_robust_kernel = source.read<bool>(section, "use_robust_kernel", use_robust_kernel); use_robust_kernel_stage1 = source.read<bool>(section, "use_robust_kernel_stage1", use_robust_kernel_stage1);
-			max_rho = source.read<double>(section, "max_rho", max_rho); max_lambda = source.read<double>(section, "max_lambda", max_lambda); kernel_param = source.read<double>(section, "kernel_param", kernel_param);
-			max_iters = (size_t)source.read<uint64_t>(section, "max_iters", max_iters); max_error_per_obs_to_stop = source.read<double>(section, "max_error_per_obs_to_stop", max_error_per_obs_to_stop);
+			use_robust_kernel = source.read<bool>(section, "use_robust_kernel", use_robust_kernel); use_robust_kernel_stage1 = source.read<bool>(section, "use_robust_kernel_stage1",
+				use_robust_kernel_stage1);
+			max_rho = source.read<double>(section, "max_rho", max_rho); max_lambda = source.read<double>(section, "max_lambda", max_lambda); kernel_param = source.read<double>(section,
+				"kernel_param", kernel_param);
+			max_iters = (size_t)source.read<uint64_t>(section, "max_iters", max_iters); max_error_per_obs_to_stop = source.read<double>(section, "max_error_per_obs_to_stop",
+				max_error_per_obs_to_stop);
 			const std::string cr = source.read<std::string>(section, "cov_recovery", cov_recovery == crpNone ? "crpNone" : "crpLandmarksApprox");
 			cov_recovery = (cr == "crpNone" || cr == "0") ? crpNone : crpLandmarksApprox;
 		}
 		void saveToConfigFile(mrpt::utils::CConfigFileBase &out, const std::string &section) const override {
-			out.write(section, "max_tree_depth", (uint64_t)max_tree_depth, 30, 30, "depth limit of the spanning trees kept per key-frame"); out.write(section, "max_optimize_depth", (uint64_t)max_optimize_depth, 30, 30, "radius (in kf2kf edges) of the local area that is optimised");
+			out.write(section, "max_tree_depth", (uint64_t)max_tree_depth, 30, 30, "depth limit of the spanning trees kept per key-frame"); out.write(section, "max_optimize_depth",
+				(uint64_t)max_optimize_depth, 30, 30, "radius (in kf2kf edges) of the local area that is optimised");
 			out.write(section, "optimize_new_edges_alone", optimize_new_edges_alone, 30, 30, "first optimise each new kf2kf edge on its own");
-			out.write(section, "use_robust_kernel", use_robust_kernel, 30, 30, "pseudo-Huber robust cost in the local-area optimisation"); out.write(section, "use_robust_kernel_stage1", use_robust_kernel_stage1, 30, 30, "pseudo-Huber robust cost while new edges are optimised alone");
-			out.write(section, "kernel_param", kernel_param, 30, 30, "threshold of the pseudo-Huber cost"); out.write(section, "max_rho", max_rho, 30, 30, "LM stops once the gain ratio rho exceeds this");
-			out.write(section, "max_lambda", max_lambda, 30, 30, "LM stops once the damping lambda exceeds this"); out.write(section, "max_iters", (uint64_t)max_iters, 30, 30, "upper bound on LM iterations");
+			out.write(section, "use_robust_kernel", use_robust_kernel, 30, 30, "pseudo-Huber robust cost in the local-area optimisation"); out.write(section, "use_robust_kernel_stage1",
+				use_robust_kernel_stage1, 30, 30, "pseudo-Huber robust cost while new edges are optimised alone");
+			out.write(section, "kernel_param", kernel_param, 30, 30, "threshold of the pseudo-Huber cost"); out.write(section, "max_rho", max_rho, 30, 30,
+				"LM stops once the gain ratio rho exceeds this");
+			out.write(section, "max_lambda", max_lambda, 30, 30, "LM stops once the damping lambda exceeds this"); out.write(section, "max_iters", (uint64_t)max_iters, 30, 30,
+				"upper bound on LM iterations");
 			out.write(section, "max_error_per_obs_to_stop", max_error_per_obs_to_stop, 30, 30, "LM stops below this RMSE per observation");
 			out.write(section, "cov_recovery", std::string(cov_recovery == crpNone ? "crpNone" : "crpLandmarksApprox"), 30, 30, "crpNone | crpLandmarksApprox");
 		}
@@ -417,9 +444,11 @@ public:
 		if (run_local_optimization) {
 			if (parameters.srba.optimize_new_edges_alone) { // stage 1: every new edge that got no initial value is optimised alone, with the stage-1 kernel switch
 				internal::profiler_scope p2(m_profiler, "define_new_keyframe.opt_new_edges");
-				struct kernel_swap { bool &flag; const bool saved; kernel_swap(bool &f, bool v) : flag(f), saved(f) { flag = v; } ~kernel_swap() { flag = saved; } } swap(parameters.srba.use_robust_kernel, parameters.srba.use_robust_kernel_stage1);
+				struct kernel_swap { bool &flag; const bool saved; kernel_swap(bool &f, bool v) : flag(f), saved(f) { flag = v; } ~kernel_swap() { flag = saved; } }
+					swap(parameters.srba.use_robust_kernel, parameters.srba.use_robust_kernel_stage1);
 				std::vector<size_t> one_edge(1), no_landmarks;
-				for (size_t i = 0; i < created.size(); i++) if (!created[i].has_approx_init_val) { one_edge[0] = created[i].id; m_capsule_stage = 1; optimize_edges(one_edge, no_landmarks, out_new_kf_info.optimize_results_stg1); }
+				for (size_t i = 0; i < created.size(); i++) if (!created[i].has_approx_init_val) { one_edge[0] = created[i].id; m_capsule_stage = 1; optimize_edges(one_edge, no_landmarks,
+					out_new_kf_info.optimize_results_stg1); }
 			}
 			internal::profiler_scope p2(m_profiler, "define_new_keyframe.optimize");
 			optimize_local_area(new_kf_id, (unsigned int)parameters.srba.max_optimize_depth, out_new_kf_info.optimize_results, TOptimizeLocalAreaParams());
@@ -429,7 +458,8 @@ public:
 	}
 
 	/** Optimise every kf2kf edge touching, and every landmark seen often enough from, the key-frames within win_size of root_id. */
-	void optimize_local_area(const TKeyFrameID root_id, const unsigned int win_size, TOptimizeExtraOutputInfo &out_info, const TOptimizeLocalAreaParams &params = TOptimizeLocalAreaParams(), const std::vector<size_t> &observation_indices_to_optimize = std::vector<size_t>()) {
+	void optimize_local_area(const TKeyFrameID root_id, const unsigned int win_size, TOptimizeExtraOutputInfo &out_info, const TOptimizeLocalAreaParams &params = TOptimizeLocalAreaParams(),
+		const std::vector<size_t> &observation_indices_to_optimize = std::vector<size_t>()) {
 		internal::profiler_scope ps(m_profiler, "optimize_local_area");
 		const bool use_prebuilt_st = (win_size <= parameters.srba.max_tree_depth);
 		if (!use_prebuilt_st && m_verbose_level >= 1) std::cout << "[optimize_local_area] *WARNING* Optimize win_size > max_tree_depth of prebuilt spanning trees. This is not efficient!\n";
@@ -469,7 +499,8 @@ public:
 	/** (base key-frame, number of observations) over the observations of already-known landmarks, most observed first, ties by ascending id (impl/make_ordered_list_base_kfs.h) */
 	void count_observations_per_base_kf(const new_kf_observations_t &obs, std::vector<std::pair<TKeyFrameID, size_t> > &out) const {
 		out.clear(); std::vector<TKeyFrameID> bases;
-		for (typename new_kf_observations_t::const_iterator o = obs.begin(); o != obs.end(); ++o) { const TLandmarkID id = o->obs.feat_id; if (id < rba_state.topo.lm_base.size() && rba_state.topo.lm_base[id] != graph::NIL) bases.push_back(rba_state.topo.lm_base[id]); }
+		for (typename new_kf_observations_t::const_iterator o = obs.begin(); o != obs.end(); ++o) { const TLandmarkID id = o->obs.feat_id;
+			if (id < rba_state.topo.lm_base.size() && rba_state.topo.lm_base[id] != graph::NIL) bases.push_back(rba_state.topo.lm_base[id]); }
 		std::sort(bases.begin(), bases.end());
 		for (size_t i = 0; i < bases.size();) { size_t j = i; while (j < bases.size() && bases[j] == bases[i]) j++; out.push_back(std::make_pair(bases[i], j - i)); i = j; }
 		struct more_votes { bool operator()(const std::pair<TKeyFrameID, size_t> &a, const std::pair<TKeyFrameID, size_t> &b) const { return a.second > b.second; } };
@@ -479,7 +510,8 @@ public:
 	/** Generic breadth-first visit of the neighbourhood of root_id up to max_distance (reference impl/bfs_visitor.h:21-177): key-frames in BFS order -- or, with
 	 *  rely_on_prebuilt_spanning_trees, the root and then its spanning tree by ascending id -- each followed by its key-frame->feature edges and its kf2kf edges. */
 	template <class KF_VISITOR, class FEAT_VISITOR, class K2K_EDGE_VISITOR, class K2F_EDGE_VISITOR>
-	void bfs_visitor(const TKeyFrameID root_id, const topo_dist_t max_distance, const bool rely_on_prebuilt_spanning_trees, KF_VISITOR &kf_visitor, FEAT_VISITOR &feat_visitor, K2K_EDGE_VISITOR &k2k_edge_visitor, K2F_EDGE_VISITOR &k2f_edge_visitor) const {
+	void bfs_visitor(const TKeyFrameID root_id, const topo_dist_t max_distance, const bool rely_on_prebuilt_spanning_trees, KF_VISITOR &kf_visitor, FEAT_VISITOR &feat_visitor,
+		K2K_EDGE_VISITOR &k2k_edge_visitor, K2F_EDGE_VISITOR &k2f_edge_visitor) const {
 		const graph::topology &T = rba_state.topo; const graph::id32 root = graph::topology::narrow(root_id); if (root >= T.n_keyframes()) return;
 		std::vector<char> lm_done(T.lm_base.size(), 0), edge_done(T.n_edges(), 0), kf_done(T.n_keyframes(), 0);
 		std::vector<std::pair<graph::id32, topo_dist_t> > order;
@@ -501,7 +533,8 @@ public:
 				const graph::id32 kf = order[i].first; const topo_dist_t d = order[i].second; if (d > max_distance) continue;
 				if (kf_visitor.visit_filter_kf(kf, d)) kf_visitor.visit_kf(kf, d);
 				visit::features(*this, kf, d, lm_done, feat_visitor, k2f_edge_visitor);
-				for (graph::id32 e = T.kf_adj_head[kf]; e != graph::NIL; e = T.next_adjacent(e, kf)) if (!edge_done[e]) { edge_done[e] = 1; const graph::id32 nk = T.other_end(e, kf); const k2k_edge_t *ed = &rba_state.k2k_edges[e]; if (k2k_edge_visitor.visit_filter_k2k(kf, nk, ed, d)) k2k_edge_visitor.visit_k2k(kf, nk, ed, d); }
+				for (graph::id32 e = T.kf_adj_head[kf]; e != graph::NIL; e = T.next_adjacent(e, kf)) if (!edge_done[e]) { edge_done[e] = 1; const graph::id32 nk = T.other_end(e, kf);
+					const k2k_edge_t *ed = &rba_state.k2k_edges[e]; if (k2k_edge_visitor.visit_filter_k2k(kf, nk, ed, d)) k2k_edge_visitor.visit_k2k(kf, nk, ed, d); }
 			}
 			return;
 		}
@@ -514,7 +547,8 @@ public:
 			for (graph::id32 e = T.kf_adj_head[kf]; e != graph::NIL; e = T.next_adjacent(e, kf)) {
 				const graph::id32 nk = T.other_end(e, kf);
 				if (!kf_done[nk]) { kf_done[nk] = 1; if (kf_visitor.visit_filter_kf(nk, d)) order.push_back(std::make_pair(nk, d + 1)); }
-				if (!edge_done[e]) { edge_done[e] = 1; const k2k_edge_t *ed = &rba_state.k2k_edges[e]; if (k2k_edge_visitor.visit_filter_k2k(kf, nk, ed, d)) k2k_edge_visitor.visit_k2k(kf, nk, ed, d); }
+				if (!edge_done[e]) { edge_done[e] = 1; const k2k_edge_t *ed = &rba_state.k2k_edges[e]; if (k2k_edge_visitor.visit_filter_k2k(kf, nk, ed, d)) k2k_edge_visitor.visit_k2k(kf, nk, ed, d);
+					}
 			}
 		}
 	}
@@ -554,7 +588,8 @@ public:
 			for (size_t e = 0; e < rba_state.k2k_edges.size(); e++) f << rba_state.k2k_edges[e].from << "->" << rba_state.k2k_edges[e].to << ";\n";
 			if (all_landmarks) {
 				const struct { const TRelativeLandmarkPosMap *lms; const char *header; } groups[2] = {
-					{&rba_state.known_lms, "/* LANDMARKS with known relative position, and its base keyframe */\nnode [shape=triangle,style=filled,fillcolor=gray80];\nedge [style=bold,color=black];\n"},
+					{&rba_state.known_lms,
+						"/* LANDMARKS with known relative position, and its base keyframe */\nnode [shape=triangle,style=filled,fillcolor=gray80];\nedge [style=bold,color=black];\n"},
 					{&rba_state.unknown_lms, "/* LANDMARKS with unknown relative position */\nnode [shape=triangle,style=filled,fillcolor=white];\nedge [style=solid,color=gray20];\n"}};
 				for (int g = 0; g < 2; g++) {
 					f << groups[g].header;
@@ -582,11 +617,13 @@ public:
 			f << "/* KEYFRAMES */\nnode [shape=box,style=filled];\n";
 			for (size_t id = 0; id < nKF; id++) if (degree[id] >= 2) {
 				f << id;
-				if (set_node_coordinates) { const typename frameid2pose_map_t::const_iterator it = tree.find((TKeyFrameID)id); if (it != tree.end()) f << " [pos=\"" << it->second.pose.x() << "," << it->second.pose.y() << "!\"]"; }
+				if (set_node_coordinates) { const typename frameid2pose_map_t::const_iterator it = tree.find((TKeyFrameID)id); if (it != tree.end()) f << " [pos=\"" << it->second.pose.x() << "," <<
+					it->second.pose.y() << "!\"]"; }
 				f << "; ";
 			}
 			f << "\n/* KEYFRAME->KEYFRAME edges */\nedge [style=bold];\n";
-			for (size_t e = 0; e < rba_state.k2k_edges.size(); e++) if (degree[rba_state.k2k_edges[e].from] >= 2 && degree[rba_state.k2k_edges[e].to] >= 2) f << rba_state.k2k_edges[e].from << "--" << rba_state.k2k_edges[e].to << ";\n";
+			for (size_t e = 0; e < rba_state.k2k_edges.size(); e++) if (degree[rba_state.k2k_edges[e].from] >= 2 && degree[rba_state.k2k_edges[e].to] >= 2) f << rba_state.k2k_edges[e].from << "--" <<
+				rba_state.k2k_edges[e].to << ";\n";
 		}
 		f << "\n}\n";
 		return f.good();
@@ -594,22 +631,27 @@ public:
 
 	/** Rendering options of build_opengl_representation() (RbaEngine.h:244-264 of the reference). */
 	struct TOpenGLRepresentationOptions {
-		size_t span_tree_max_depth; bool draw_unknown_feats, draw_unknown_feats_ellipses; double draw_unknown_feats_ellipses_quantiles; bool show_unknown_feats_ids, draw_kf_hierarchical; double draw_kf_hierarchical_height;
-		TOpenGLRepresentationOptions() : span_tree_max_depth(std::numeric_limits<size_t>::max()), draw_unknown_feats(true), draw_unknown_feats_ellipses(true), draw_unknown_feats_ellipses_quantiles(1), show_unknown_feats_ids(true), draw_kf_hierarchical(false), draw_kf_hierarchical_height(10.0) {}
+		size_t span_tree_max_depth; bool draw_unknown_feats, draw_unknown_feats_ellipses; double draw_unknown_feats_ellipses_quantiles; bool show_unknown_feats_ids, draw_kf_hierarchical;
+			double draw_kf_hierarchical_height;
+		TOpenGLRepresentationOptions() : span_tree_max_depth(std::numeric_limits<size_t>::max()), draw_unknown_feats(true), draw_unknown_feats_ellipses(true),
+			draw_unknown_feats_ellipses_quantiles(1), show_unknown_feats_ids(true), draw_kf_hierarchical(false), draw_kf_hierarchical_height(10.0) {}
 	};
 	/** The geometry of the 3D view of the reference (impl/export_opengl.h:24-224): every key-frame within span_tree_max_depth of root_keyframe as a corner at its
 	 *  pose in the root's frame, a line per kf2kf edge between drawn key-frames, and the landmarks as points (relative position composed with their base key-frame).
 	 *  SCENE_PTR is mrpt::opengl::CSetOfObjectsPtr; this layer only emits primitives through insert_corner / insert_line / insert_point / insert_text (the
 	 *  mrpt_lite stand-in records them, a build against the real MRPT maps them onto stock_objects::CornerXYZSimple, CSetOfLines and CPointCloud). */
-	template <class SCENE_PTR> void build_opengl_representation(const TKeyFrameID root_keyframe, const TOpenGLRepresentationOptions &options, SCENE_PTR out_scene, SCENE_PTR out_root_tree = SCENE_PTR()) const {
+	template <class SCENE_PTR> void build_opengl_representation(const TKeyFrameID root_keyframe, const TOpenGLRepresentationOptions &options, SCENE_PTR out_scene,
+		SCENE_PTR out_root_tree = SCENE_PTR()) const {
 		if (out_scene) {
 			out_scene->clear();
 			if (rba_state.keyframes.empty()) return;
 			frameid2pose_map_t tree; create_complete_spanning_tree(root_keyframe, tree, options.span_tree_max_depth);
 			std::vector<size_t> degree(rba_state.keyframes.size(), 0);
 			for (size_t e = 0; e < rba_state.k2k_edges.size(); e++) { degree[rba_state.k2k_edges[e].from]++; degree[rba_state.k2k_edges[e].to]++; }
-			auto lifted = [&](TKeyFrameID id, const pose_t &p) { mrpt::poses::CPose3D q(p); if (options.draw_kf_hierarchical && degree[id] >= 2) q.m_t[2] += options.draw_kf_hierarchical_height; return q; };
-			for (typename frameid2pose_map_t::const_iterator it = tree.begin(); it != tree.end(); ++it) { out_scene->insert_corner(lifted(it->first, it->second.pose), it->first == root_keyframe ? 1.0 : 0.25); out_scene->insert_text(lifted(it->first, it->second.pose), mrpt::format("%u", (unsigned)it->first)); }
+			auto lifted = [&](TKeyFrameID id, const pose_t &p) { mrpt::poses::CPose3D q(p); if (options.draw_kf_hierarchical && degree[id] >= 2) q.m_t[2] += options.draw_kf_hierarchical_height;
+				return q; };
+			for (typename frameid2pose_map_t::const_iterator it = tree.begin(); it != tree.end(); ++it) { out_scene->insert_corner(lifted(it->first, it->second.pose),
+				it->first == root_keyframe ? 1.0 : 0.25); out_scene->insert_text(lifted(it->first, it->second.pose), mrpt::format("%u", (unsigned)it->first)); }
 			for (size_t e = 0; e < rba_state.k2k_edges.size(); e++) {
 				const typename frameid2pose_map_t::const_iterator a = tree.find(rba_state.k2k_edges[e].from), b = tree.find(rba_state.k2k_edges[e].to);
 				if (a != tree.end() && b != tree.end()) out_scene->insert_line(lifted(a->first, a->second.pose), lifted(b->first, b->second.pose));
@@ -671,7 +713,8 @@ public:
 			for (size_t k = g; k < h; k++) {
 				if (!T.shortest_path(want[k].first, want[k].second, &edges, NULL)) throw std::runtime_error("eval_overall_squared_error: an observation relates two key-frames that are not connected");
 				graph::id32 cur = want[k].first;
-				for (size_t q = 0; q < edges.size(); q++) { const graph::id32 nxt = T.other_end(edges[q], cur); path_edge.push_back((int32_t)((edges[q] << 1) | (T.edge_to[edges[q]] == nxt ? 1 : 0))); cur = nxt; } // stepping parent->child along the edge direction composes the inverse of inv_pose
+				for (size_t q = 0; q < edges.size(); q++) { const graph::id32 nxt = T.other_end(edges[q], cur); path_edge.push_back((int32_t)((edges[q] << 1) | (T.edge_to[edges[q]] == nxt ? 1 : 0)));
+					cur = nxt; } // stepping parent->child along the edge direction composes the inverse of inv_pose
 				pair_path_off.push_back((int32_t)path_edge.size());
 			}
 			g = h;
@@ -681,7 +724,8 @@ public:
 		for (size_t i = 0; i < nObs; i++) {
 			const graph::id32 a = T.obs_kf[i], lm = T.obs_lm[i], b = T.lm_base[lm];
 			if (a == b) obs_pose[i] = -1;
-			else { const size_t p = (size_t)(std::lower_bound(want.begin(), want.end(), std::make_pair(std::min(a, b), std::max(a, b))) - want.begin()); obs_pose[i] = (int32_t)(a < b ? 2 * p : 2 * p + 1); } // observer is the root: pose of the target; else its inverse
+			else { const size_t p = (size_t)(std::lower_bound(want.begin(), want.end(), std::make_pair(std::min(a, b), std::max(a, b))) - want.begin());
+				obs_pose[i] = (int32_t)(a < b ? 2 * p : 2 * p + 1); } // observer is the root: pose of the target; else its inverse
 			if (lm_slot[lm] < 0) { lm_slot[lm] = (int32_t)(lm_pos.size() / L); for (size_t k = 0; k < L; k++) lm_pos.push_back(rba_state.lm_table[lm].pos[k]); }
 			obs_lm[i] = lm_slot[lm];
 			for (size_t k = 0; k < O; k++) obs_z[i * O + k] = rba_state.obs_table[i].obs_arr[k];
@@ -689,8 +733,10 @@ public:
 		std::vector<double> edge_pose(rba_state.k2k_edges.size() * PD);
 		for (size_t e = 0; e < rba_state.k2k_edges.size(); e++) rba_state.k2k_edges[e].inv_pose.storeTo(&edge_pose[e * PD]);
 		srba_overall_problem q; std::memset(&q, 0, sizeof(q));
-		q.n_edges = (int32_t)rba_state.k2k_edges.size(); q.n_pairs = (int32_t)pair_path_off.size() - 1; q.n_path = (int32_t)path_edge.size(); q.n_obs = (int32_t)nObs; q.n_lms = (int32_t)(lm_pos.size() / L);
-		q.edge_pose = edge_pose.data(); q.pair_path_off = pair_path_off.data(); q.path_edge = path_edge.data(); q.obs_pose = obs_pose.data(); q.obs_lm = obs_lm.data(); q.obs_z = obs_z.data(); q.lm_pos = lm_pos.data();
+		q.n_edges = (int32_t)rba_state.k2k_edges.size(); q.n_pairs = (int32_t)pair_path_off.size() - 1; q.n_path = (int32_t)path_edge.size(); q.n_obs = (int32_t)nObs;
+			q.n_lms = (int32_t)(lm_pos.size() / L);
+		q.edge_pose = edge_pose.data(); q.pair_path_off = pair_path_off.data(); q.path_edge = path_edge.data(); q.obs_pose = obs_pose.data(); q.obs_lm = obs_lm.data(); q.obs_z = obs_z.data();
+			q.lm_pos = lm_pos.data();
 		srba_hip_params hp; fill_hip_params(hp);
 		if (!m_backend) m_backend = make_hip_backend(m_hip_device);
 		return m_backend->eval_overall(hp, q);
@@ -713,7 +759,8 @@ public:
 
 	/** One observation of key-frame observing_kf_id: stores it, creates the landmark on first sight (fixed position, caller's initial value, or the inverse
 	 *  sensor model moved to the robot frame) and extends the symbolic Jacobians. Returns the observation index. */
-	size_t add_observation(const TKeyFrameID observing_kf_id, const typename observation_traits_t::observation_t &new_obs, const array_landmark_t *fixed_relative_position = NULL, const array_landmark_t *unknown_relative_position_init_val = NULL) {
+	size_t add_observation(const TKeyFrameID observing_kf_id, const typename observation_traits_t::observation_t &new_obs, const array_landmark_t *fixed_relative_position = NULL,
+		const array_landmark_t *unknown_relative_position_init_val = NULL) {
 		ASSERT_(!(fixed_relative_position != NULL && unknown_relative_position_init_val != NULL));
 		const graph::id32 kf = graph::topology::narrow(observing_kf_id), lm = graph::topology::narrow(new_obs.feat_id);
 		const graph::topology::obs_result r = rba_state.topo.add_observation(kf, lm, fixed_relative_position != NULL);
@@ -725,7 +772,8 @@ public:
 			if (r.fixed) { p.pos = *fixed_relative_position; rba_state.known_lms.add(new_obs.feat_id); }
 			else {
 				if (unknown_relative_position_init_val) p.pos = *unknown_relative_position_init_val;
-				else { sensor_model_t::inverse_sensor_model(p.pos, new_obs.obs_data, parameters.sensor); RBA_OPTIONS::sensor_pose_on_robot_t::template sensor2robot_point<landmark_t>(p.pos, parameters.sensor_pose); }
+				else { sensor_model_t::inverse_sensor_model(p.pos, new_obs.obs_data, parameters.sensor); RBA_OPTIONS::sensor_pose_on_robot_t::template sensor2robot_point<landmark_t>(p.pos,
+					parameters.sensor_pose); }
 				rba_state.unknown_lms.add(new_obs.feat_id);
 			}
 		}
@@ -755,7 +803,8 @@ protected:
 			bool ok = touches_new_kf ? align_by_common_landmarks(obs, true, new_kf_id, points_to_new_kf ? ed.from : ed.to, align)
 			                         : align_by_common_landmarks(obs, false, ed.from, ed.to, align);
 			const bool have_lc_hint = info.loopclosure_observer_kf != SRBA_INVALID_KEYFRAMEID && info.loopclosure_base_kf != SRBA_INVALID_KEYFRAMEID;
-			const bool direct = ok; // the alignment relates the two ends of the edge themselves (the reference nevertheless sends it through the observer / base chain below when the edge does not touch the new key-frame)
+			const bool direct = ok; // the alignment relates the two ends of the edge themselves (the reference nevertheless sends it through the observer / base chain below when the edge does not
+				// touch the new key-frame)
 			if (!ok && have_lc_hint) ok = align_by_common_landmarks(obs, info.loopclosure_observer_kf == new_kf_id, info.loopclosure_observer_kf, info.loopclosure_base_kf, align);
 			if (!ok) { if (m_verbose_level >= 2) std::cout << "[determine_kf2kf_edges_to_create] Could not provide initial value to relative pose " << ed.from << "<=>" << ed.to << "\n"; continue; }
 			// the alignment relates SENSOR frames: move it to the robot frames
@@ -782,7 +831,8 @@ protected:
 			else ed.inv_pose = points_to_new_kf ? -local_wrt_remote : local_wrt_remote;
 		}
 		T.last_touched_kfs.clear();
-		for (size_t i = 0; i < created.size(); i++) { T.last_touched_kfs.push_back((graph::id32)rba_state.k2k_edges[created[i].id].from); T.last_touched_kfs.push_back((graph::id32)rba_state.k2k_edges[created[i].id].to); }
+		for (size_t i = 0; i < created.size(); i++) { T.last_touched_kfs.push_back((graph::id32)rba_state.k2k_edges[created[i].id].from);
+			T.last_touched_kfs.push_back((graph::id32)rba_state.k2k_edges[created[i].id].to); }
 		std::sort(T.last_touched_kfs.begin(), T.last_touched_kfs.end()); T.last_touched_kfs.erase(std::unique(T.last_touched_kfs.begin(), T.last_touched_kfs.end()), T.last_touched_kfs.end());
 	}
 	/** Relative pose of key-frame `later` with respect to `earlier` from the landmarks both observe (landmark_matcher<OBS>). `later` is either the key-frame being
@@ -805,7 +855,8 @@ protected:
 	}
 
 	/** The optimiser entry (reference impl/optimize_edges.h:44-793): flatten the call into a capsule, hand it to the numeric back-end, write the results back. */
-	void optimize_edges(const std::vector<size_t> &run_k2k_edges_in, const std::vector<size_t> &run_feat_ids_in, TOptimizeExtraOutputInfo &out_info, const std::vector<size_t> &in_observation_indices_to_optimize = std::vector<size_t>()) {
+	void optimize_edges(const std::vector<size_t> &run_k2k_edges_in, const std::vector<size_t> &run_feat_ids_in, TOptimizeExtraOutputInfo &out_info,
+		const std::vector<size_t> &in_observation_indices_to_optimize = std::vector<size_t>()) {
 		internal::profiler_scope ps(m_profiler, "opt");
 		const int stage = m_capsule_stage; m_capsule_stage = 0;
 		out_info.clear();
@@ -814,7 +865,8 @@ protected:
 		graph::topology &T = rba_state.topo;
 		CapsuleData &cd = m_cd; graph::capsule_index &ix = m_ix;
 		{ internal::profiler_scope p2(m_profiler, "opt.capsule");
-		  if (!m_builder.build(T, run_k2k_edges_in, run_feat_ids_in, in_observation_indices_to_optimize, parameters.srba.refresh_all_read_poses, RBA_OPTIONS::solver_t::USE_SCHUR, P, L, O, PD, cd, ix, parameters.srba.restore_spanning_tree_twins)) return;
+		  if (!m_builder.build(T, run_k2k_edges_in, run_feat_ids_in, in_observation_indices_to_optimize, parameters.srba.refresh_all_read_poses, RBA_OPTIONS::solver_t::USE_SCHUR, P, L, O, PD, cd, ix,
+		  	parameters.srba.restore_spanning_tree_twins)) return;
 		  // typed payload
 		  cd.edge_pose.resize(ix.edge_ids.size() * PD); for (size_t i = 0; i < ix.edge_ids.size(); i++) rba_state.k2k_edges[ix.edge_ids[i]].inv_pose.storeTo(&cd.edge_pose[i * PD]);
 		  cd.ulm_pos.resize(ix.unk_lms.size() * L); for (size_t i = 0; i < ix.unk_lms.size(); i++) for (int k = 0; k < L; k++) cd.ulm_pos[i * L + k] = rba_state.lm_table[ix.unk_lms[i]].pos[k];
@@ -826,7 +878,8 @@ protected:
 		srba_hip_params hp; fill_hip_params(hp);
 		if (on_capsule) on_capsule(hp, cd, stage);
 		srba_problem_capsule cap = cd.view();
-		srba_lm_result res; std::memset(&res, 0, sizeof(res)); res.lambda_last_trial = std::numeric_limits<double>::quiet_NaN(); // (a back-end that does not know the field leaves the NaN: see return_hessian below)
+		srba_lm_result res; std::memset(&res, 0, sizeof(res)); res.lambda_last_trial = std::numeric_limits<double>::quiet_NaN(); // (a back-end that does not know the field leaves the NaN: see
+			// return_hessian below)
 		if (!m_backend) m_backend = make_hip_backend(m_hip_device);
 		m_backend->set_profiler(&m_profiler);
 		{ internal::profiler_scope p2(m_profiler, "opt.backend"); m_backend->run(hp, cap, res); }
@@ -842,7 +895,8 @@ protected:
 		}
 		rba_state.unknown_lms_inf_matrices.clear();
 		if (parameters.srba.cov_recovery == crpLandmarksApprox)
-			for (size_t i = 0; i < nF; i++) if (cd.ulm_inf_valid[i]) { rba_state.unknown_lms_inf_matrices.push_back(std::make_pair((TLandmarkID)ix.unk_lms[i], typename rba_problem_state_t::lm_inf_matrix_t())); for (int k = 0; k < L * L; k++) rba_state.unknown_lms_inf_matrices.back().second.m[k] = cd.ulm_inf[i * L * L + k]; }
+			for (size_t i = 0; i < nF; i++) if (cd.ulm_inf_valid[i]) { rba_state.unknown_lms_inf_matrices.push_back(std::make_pair((TLandmarkID)ix.unk_lms[i],
+				typename rba_problem_state_t::lm_inf_matrix_t())); for (int k = 0; k < L * L; k++) rba_state.unknown_lms_inf_matrices.back().second.m[k] = cd.ulm_inf[i * L * L + k]; }
 
 		out_info.num_observations = nObs; out_info.num_jacobians = res.num_jacobians; out_info.num_kf2kf_edges_optimized = nK; out_info.num_kf2lm_edges_optimized = nF;
 		out_info.num_total_scalar_optimized = P * nK + L * nF; out_info.num_span_tree_numeric_updates = res.num_span_tree_numeric_updates;
@@ -853,10 +907,12 @@ protected:
 		// HAp_condition_number (optimize_edges.h:753-766: ratio of the extreme singular values of the dense HAp, both triangles)
 		if (parameters.srba.compute_condition_number || parameters.srba.return_hessian) {
 			std::vector<double> hap, hf, hapf;
-			if (!m_backend->read_blocks(3, hap)) throw std::runtime_error(std::string("RbaEngine: numeric back-end '") + m_backend->name() + "' cannot return the Hessian (compute_condition_number / return_hessian)");
+			if (!m_backend->read_blocks(3, hap)) throw std::runtime_error(std::string("RbaEngine: numeric back-end '") + m_backend->name() +
+				"' cannot return the Hessian (compute_condition_number / return_hessian)");
 			const size_t nA = (size_t)P * nK; std::vector<double> dA(nA * nA, 0.0);
 			for (size_t b = 0; b < cd.hap_i.size(); b++) { const size_t i = cd.hap_i[b], j = cd.hap_j[b]; // upper blocks (i <= j); diagonal blocks hold both triangles
-				for (int r = 0; r < P; r++) for (int q = 0; q < P; q++) { const double v = hap[b * P * P + r * P + q]; dA[(P * i + r) * nA + P * j + q] = v; if (i != j) dA[(P * j + q) * nA + P * i + r] = v; } }
+				for (int r = 0; r < P; r++) for (int q = 0; q < P; q++) { const double v = hap[b * P * P + r * P + q]; dA[(P * i + r) * nA + P * j + q] = v;
+					if (i != j) dA[(P * j + q) * nA + P * i + r] = v; } }
 			if (parameters.srba.compute_condition_number) out_info.HAp_condition_number = internal::symmetric_condition_number(dA, nA);
 			// lambda of the last trial: the trailing field srba_lm_result::lambda_last_trial (ABI: added in round 4 -- sizeof(srba_lm_result) grew by 8 bytes). A numeric back-end built
 			// against the older record leaves it as initialised before the run (NaN): fall back on the trace while it covers the run, else no Hessian rather than one with a wrong lambda
@@ -868,15 +924,18 @@ protected:
 				for (size_t r = 0; r < nA; r++) for (size_t q = 0; q < nA; q++) H[r * n + q] = dA[r * nA + q];
 				if (full && m_backend->read_blocks(4, hf) && m_backend->read_blocks(5, hapf)) {
 					for (size_t b = 0; b < cd.hf_i.size(); b++) { const size_t i = cd.hf_i[b], j = cd.hf_j[b];
-						for (int r = 0; r < L; r++) for (int q = 0; q < L; q++) { const double v = hf[b * L * L + r * L + q]; H[(nA + L * i + r) * n + nA + L * j + q] = v; if (i != j) H[(nA + L * j + q) * n + nA + L * i + r] = v; } }
+						for (int r = 0; r < L; r++) for (int q = 0; q < L; q++) { const double v = hf[b * L * L + r * L + q]; H[(nA + L * i + r) * n + nA + L * j + q] = v;
+							if (i != j) H[(nA + L * j + q) * n + nA + L * i + r] = v; } }
 					for (size_t b = 0; b < cd.hapf_i.size(); b++) { const size_t i = cd.hapf_i[b], j = cd.hapf_j[b];
-						for (int r = 0; r < P; r++) for (int q = 0; q < L; q++) { const double v = hapf[b * P * L + r * L + q]; H[(P * i + r) * n + nA + L * j + q] = v; H[(nA + L * j + q) * n + P * i + r] = v; } }
+						for (int r = 0; r < P; r++) for (int q = 0; q < L; q++) { const double v = hapf[b * P * L + r * L + q]; H[(P * i + r) * n + nA + L * j + q] = v;
+							H[(nA + L * j + q) * n + P * i + r] = v; } }
 				}
 				for (size_t k = 0; k < n; k++) H[k * n + k] += lam;
 				out_info.extra_results.hessian_valid = true;
 			}
 		}
-		if (parameters.srba.compute_sparsity_stats) { // occupancy of the block matrices: non-zero blocks / blocks of the bounding rectangle (reference optimize_edges.h:315-323 over [EXT] MatrixBlockSparseCols::getSparsityStats)
+		if (parameters.srba.compute_sparsity_stats) { // occupancy of the block matrices: non-zero blocks / blocks of the bounding rectangle (reference optimize_edges.h:315-323 over [EXT]
+			// MatrixBlockSparseCols::getSparsityStats)
 			out_info.sparsity_dh_dAp_nnz = T.jp.size(); out_info.sparsity_dh_dAp_max_size = T.n_edges() * T.n_observations();
 			size_t ndf = 0, ncol = 0; for (size_t l = 0; l < T.lm_df_count.size(); l++) if (T.lm_base[l] != graph::NIL && !T.lm_known[l]) { ndf += T.lm_df_count[l]; ncol++; }
 			out_info.sparsity_dh_df_nnz = ndf; out_info.sparsity_dh_df_max_size = ncol * T.n_observations();
@@ -886,7 +945,8 @@ protected:
 		if (parameters.srba.feedback_user_iteration) { // served after the fact from the back-end's trial trace: the initial point, then every accepted step (optimize_edges.h:417-418,:595-596)
 			(*parameters.srba.feedback_user_iteration)(0, res.total_sqr_error_init, std::sqrt(res.total_sqr_error_init / std::max<size_t>(1, nObs)));
 			unsigned int it = 0;
-			for (int t = 0; t < res.num_trials && t < SRBA_TRACE_LEN; t++) if (res.trace_rho[t] > 0) (*parameters.srba.feedback_user_iteration)(it++, res.trace_chi2[t], std::sqrt(res.trace_chi2[t] / std::max<size_t>(1, nObs)));
+			for (int t = 0; t < res.num_trials && t < SRBA_TRACE_LEN; t++) if (res.trace_rho[t] > 0) (*parameters.srba.feedback_user_iteration)(it++, res.trace_chi2[t],
+				std::sqrt(res.trace_chi2[t] / std::max<size_t>(1, nObs)));
 		}
 		if (m_verbose_level >= 1) std::cout << "[OPT] Final RMSE=" << res.obs_rmse << " #iters=" << res.num_iters << "\n";
 	}

@@ -64,7 +64,8 @@ struct CapsuleData {
 		// ---- HApf: blocks in (edge, landmark) order
 		hapf_i.clear(); hapf_j.clear(); hapf_term_off.assign(1, 0); hapf_t1.clear(); hapf_t2.clear();
 		for (size_t t = 0; t < tpf.size(); t++) {
-			if (t == 0 || tpf[t].key != tpf[t - 1].key) { if (t) hapf_term_off.push_back((int32_t)hapf_t1.size()); hapf_i.push_back((int32_t)(tpf[t].key / (uint64_t)nF)); hapf_j.push_back((int32_t)(tpf[t].key % (uint64_t)nF)); }
+			if (t == 0 || tpf[t].key != tpf[t - 1].key) { if (t) hapf_term_off.push_back((int32_t)hapf_t1.size()); hapf_i.push_back((int32_t)(tpf[t].key / (uint64_t)nF));
+				hapf_j.push_back((int32_t)(tpf[t].key % (uint64_t)nF)); }
 			hapf_t1.push_back(tpf[t].a); hapf_t2.push_back(tpf[t].b);
 		}
 		if (!tpf.empty()) hapf_term_off.push_back((int32_t)hapf_t1.size());
@@ -104,7 +105,8 @@ struct CapsuleData {
 			hap_j.push_back(j); hap_i.push_back(i);
 			for (; it < tp.size() && tp[it].key == keys[k]; it++) { hap_t1.push_back(tp[it].a); hap_t2.push_back(tp[it].b); }
 			hap_term_off.push_back((int32_t)hap_t1.size());
-			if (schur) { for (; is < ts.size() && ts[is].key == keys[k]; is++) { sch_b1.push_back(ts[is].a); sch_b2.push_back(ts[is].b); sch_lm.push_back(ts_lm[is]); } sch_term_off.push_back((int32_t)sch_b1.size()); }
+			if (schur) { for (; is < ts.size() && ts[is].key == keys[k]; is++) { sch_b1.push_back(ts[is].a); sch_b2.push_back(ts[is].b); sch_lm.push_back(ts_lm[is]); }
+				sch_term_off.push_back((int32_t)sch_b1.size()); }
 		}
 		// ---- Hf: block-diagonal (one landmark per observation); the terms of landmark l are its own dh_df blocks in column order
 		hf_i.clear(); hf_j.clear(); hf_term_off.assign(1, 0); hf_t1.clear(); hf_t2.clear(); hf_diag.assign(nF, -1);
@@ -142,7 +144,8 @@ struct CapsuleData {
 
 	// ------------------------------------------------------------------ binary (de)serialisation: golden fixtures
 	template <class T> static void wv(FILE *f, const std::vector<T> &v) { const uint64_t n = v.size(); fwrite(&n, 8, 1, f); if (n) fwrite(&v[0], sizeof(T), n, f); }
-	template <class T> static void rv(FILE *f, std::vector<T> &v) { uint64_t n = 0; if (fread(&n, 8, 1, f) != 1) throw std::runtime_error("capsule: short read"); v.resize(n); if (n && fread(&v[0], sizeof(T), n, f) != n) throw std::runtime_error("capsule: short read"); }
+	template <class T> static void rv(FILE *f, std::vector<T> &v) { uint64_t n = 0; if (fread(&n, 8, 1, f) != 1) throw std::runtime_error("capsule: short read"); v.resize(n); if (n && fread(&v[0],
+		sizeof(T), n, f) != n) throw std::runtime_error("capsule: short read"); }
 	template <class FN> void for_all_vectors(FN &fn) {
 		fn(edge_pose); fn(ulm_pos); fn(klm_pos); fn(obs_z);
 		fn(pair_path_off); fn(path_edge); fn(obs_pose); fn(obs_lm); fn(obs_valid); fn(pair_needed); fn(pose_required); fn(bp_normal);
@@ -154,7 +157,8 @@ struct CapsuleData {
 	struct Writer { FILE *f; template <class T> void operator()(std::vector<T> &v) { wv(f, v); } };
 	struct Reader { FILE *f; template <class T> void operator()(std::vector<T> &v) { rv(f, v); } };
 	void write(FILE *f) { int32_t h[7] = {n_unk_edges, n_unk_lms, n_valid, PD, L, O, P}; fwrite(h, 4, 7, f); Writer w = {f}; for_all_vectors(w); }
-	void read(FILE *f) { int32_t h[7]; if (fread(h, 4, 7, f) != 7) throw std::runtime_error("capsule: short read"); n_unk_edges = h[0]; n_unk_lms = h[1]; n_valid = h[2]; PD = h[3]; L = h[4]; O = h[5]; P = h[6]; Reader r = {f}; for_all_vectors(r); }
+	void read(FILE *f) { int32_t h[7]; if (fread(h, 4, 7, f) != 7) throw std::runtime_error("capsule: short read"); n_unk_edges = h[0]; n_unk_lms = h[1]; n_valid = h[2]; PD = h[3]; L = h[4];
+		O = h[5]; P = h[6]; Reader r = {f}; for_all_vectors(r); }
 };
 
 } // namespace srba

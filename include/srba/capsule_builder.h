@@ -44,7 +44,8 @@ public:
 			const id32 e = topology::narrow(edges_in[i]);
 			if (e >= T.n_edges()) throw std::out_of_range("optimize_edges: unknown kf2kf edge id");
 			if (T.edge_jp_count[e]) { m_edge_slot[e] = (int32_t)ix.edge_ids.size(); m_edge_tag[e] = m_tag; ix.edge_ids.push_back(e); m_kfs.push_back(T.edge_from[e]); m_kfs.push_back(T.edge_to[e]); }
-			else std::cerr << "[RbaEngine::optimize_edges] *Warning*: Skipping optimization of k2k edge #" << e << " (" << T.edge_from[e] << "->" << T.edge_to[e] << ") since no observation depends on it.\n";
+			else std::cerr << "[RbaEngine::optimize_edges] *Warning*: Skipping optimization of k2k edge #" << e << " (" << T.edge_from[e] << "->" << T.edge_to[e] <<
+				") since no observation depends on it.\n";
 		}
 		std::sort(m_kfs.begin(), m_kfs.end()); ix.n_kfs_touched = (size_t)(std::unique(m_kfs.begin(), m_kfs.end()) - m_kfs.begin());
 		for (size_t i = 0; i < lms_in.size(); i++) {
@@ -63,14 +64,19 @@ public:
 
 		// ---- S3: residual rows
 		if (obs_subset.empty()) {
-			for (int i = 0; i < nK; i++) for (id32 b = T.edge_jp_head[ix.edge_ids[i]]; b != NIL; b = T.jp[b].next) { const id32 o = T.jp[b].obs; m_obs_row[o] = (int32_t)ix.obs_rows.size(); m_obs_tag[o] = m_tag; ix.obs_rows.push_back(o); }
-			for (int i = 0; i < nF; i++) for (id32 o = T.lm_df_head[ix.unk_lms[i]]; o != NIL; o = T.obs_next_in_lm[o]) if (m_obs_tag[o] != m_tag) { m_obs_row[o] = (int32_t)ix.obs_rows.size(); m_obs_tag[o] = m_tag; ix.obs_rows.push_back(o); }
-		} else for (size_t i = 0; i < obs_subset.size(); i++) { const id32 o = topology::narrow(obs_subset[i]); if (o >= T.n_observations()) throw std::out_of_range("optimize_edges: unknown observation index"); m_obs_row[o] = (int32_t)ix.obs_rows.size(); m_obs_tag[o] = m_tag; ix.obs_rows.push_back(o); }
+			for (int i = 0; i < nK; i++) for (id32 b = T.edge_jp_head[ix.edge_ids[i]]; b != NIL; b = T.jp[b].next) { const id32 o = T.jp[b].obs; m_obs_row[o] = (int32_t)ix.obs_rows.size();
+				m_obs_tag[o] = m_tag; ix.obs_rows.push_back(o); }
+			for (int i = 0; i < nF; i++) for (id32 o = T.lm_df_head[ix.unk_lms[i]]; o != NIL; o = T.obs_next_in_lm[o]) if (m_obs_tag[o] != m_tag) { m_obs_row[o] = (int32_t)ix.obs_rows.size();
+				m_obs_tag[o] = m_tag; ix.obs_rows.push_back(o); }
+		} else for (size_t i = 0; i < obs_subset.size(); i++) { const id32 o = topology::narrow(obs_subset[i]);
+			if (o >= T.n_observations()) throw std::out_of_range("optimize_edges: unknown observation index"); m_obs_row[o] = (int32_t)ix.obs_rows.size(); m_obs_tag[o] = m_tag;
+			ix.obs_rows.push_back(o); }
 		const size_t nObs = ix.obs_rows.size();
 
 		// ---- S4: roots of the numeric spanning trees to refresh, ascending
 		m_roots.clear();
-		for (int i = 0; i < nK; i++) for (id32 b = T.edge_jp_head[ix.edge_ids[i]]; b != NIL; b = T.jp[b].next) { const id32 o = T.jp[b].obs; m_roots.push_back(T.jp[b].kf_d); m_roots.push_back(T.obs_kf[o]); m_roots.push_back(T.lm_base[T.obs_lm[o]]); }
+		for (int i = 0; i < nK; i++) for (id32 b = T.edge_jp_head[ix.edge_ids[i]]; b != NIL; b = T.jp[b].next) { const id32 o = T.jp[b].obs; m_roots.push_back(T.jp[b].kf_d);
+			m_roots.push_back(T.obs_kf[o]); m_roots.push_back(T.lm_base[T.obs_lm[o]]); }
 		for (int i = 0; i < nF; i++) for (id32 o = T.lm_df_head[ix.unk_lms[i]]; o != NIL; o = T.obs_next_in_lm[o]) { m_roots.push_back(T.lm_base[T.obs_lm[o]]); m_roots.push_back(T.obs_kf[o]); }
 		std::sort(m_roots.begin(), m_roots.end()); m_roots.erase(std::unique(m_roots.begin(), m_roots.end()), m_roots.end());
 
@@ -134,7 +140,8 @@ public:
 			cd.colf_off.push_back((int32_t)cd.bf_col.size());
 		}
 		for (size_t p = 0; p < nPairs; p++) cd.pair_needed[p] = (cd.pose_required[2 * p] || cd.pose_required[2 * p + 1]) ? 1 : 0;
-		if (restore_twins) for (size_t p = 0; p < nPairs; p++) if (cd.pair_needed[p]) cd.pose_required[2 * p] = cd.pose_required[2 * p + 1] = 1; // (extension) back up / restore both poses of every refreshed pair
+		if (restore_twins) for (size_t p = 0; p < nPairs; p++) if (cd.pair_needed[p]) cd.pose_required[2 * p] = cd.pose_required[2 * p + 1] = 1;
+			// (extension) back up / restore both poses of every refreshed pair
 		cd.pair_kfs.resize(nPairs); for (size_t p = 0; p < nPairs; p++) cd.pair_kfs[p] = std::make_pair((uint64_t)ix.pairs[p].first, (uint64_t)ix.pairs[p].second);
 		cd.build_plan(m_bp_row, m_bf_row, with_schur);
 		return true;
@@ -142,7 +149,8 @@ public:
 
 private:
 	void next_tag(const topology &T) {
-		if (++m_tag == 0) { std::fill(m_edge_tag.begin(), m_edge_tag.end(), 0u); std::fill(m_lm_tag.begin(), m_lm_tag.end(), 0u); std::fill(m_obs_tag.begin(), m_obs_tag.end(), 0u); std::fill(m_valid_tag.begin(), m_valid_tag.end(), 0u); std::fill(m_root_tag.begin(), m_root_tag.end(), 0u); m_tag = 1; }
+		if (++m_tag == 0) { std::fill(m_edge_tag.begin(), m_edge_tag.end(), 0u); std::fill(m_lm_tag.begin(), m_lm_tag.end(), 0u); std::fill(m_obs_tag.begin(), m_obs_tag.end(), 0u);
+			std::fill(m_valid_tag.begin(), m_valid_tag.end(), 0u); std::fill(m_root_tag.begin(), m_root_tag.end(), 0u); m_tag = 1; }
 		grow(m_edge_tag, T.n_edges()); grow(m_edge_slot, T.n_edges()); grow(m_lm_tag, T.lm_base.size()); grow(m_lm_ref, T.lm_base.size());
 		grow(m_obs_tag, T.n_observations()); grow(m_obs_row, T.n_observations()); grow(m_valid_tag, T.n_observations()); grow(m_valid_slot, T.n_observations());
 		grow(m_root_tag, T.n_keyframes()); grow(m_root_base, T.n_keyframes());

@@ -212,7 +212,8 @@ public:
 	/** Registers one observation of landmark lm from key-frame kf and appends its symbolic Jacobian blocks: one dh_dAp block per edge of the
 	 *  stored path observer -> base, walked from the observer (impl/add-observations.h:139-215), and the dh_df block of an unknown landmark (:220-257). */
 	obs_result add_observation(id32 kf, id32 lm, bool fixed_position_given) {
-		if (lm >= lm_base.size()) { lm_base.resize((size_t)lm + 1, NIL); lm_df_head.resize((size_t)lm + 1, NIL); lm_df_tail.resize((size_t)lm + 1, NIL); lm_known.resize((size_t)lm + 1, 1); lm_df_count.resize((size_t)lm + 1, 0); }
+		if (lm >= lm_base.size()) { lm_base.resize((size_t)lm + 1, NIL); lm_df_head.resize((size_t)lm + 1, NIL); lm_df_tail.resize((size_t)lm + 1, NIL); lm_known.resize((size_t)lm + 1, 1);
+			lm_df_count.resize((size_t)lm + 1, 0); }
 		obs_result R; R.first_seen = (lm_base[lm] == NIL); R.fixed = fixed_position_given || (!R.first_seen && lm_known[lm]); R.ignored_by_graph = false;
 		if (R.first_seen) { lm_base[lm] = kf; lm_known[lm] = R.fixed ? 1 : 0; }
 		const id32 o = R.obs = (id32)obs_kf.size(), base = lm_base[lm];

@@ -59,7 +59,8 @@ private:
 	void report_stages(const srba_hip_params &p) {
 		double t[16]; if (srba_hip_debug_size(m_ctx, 10) < 16 || srba_hip_debug_read(m_ctx, 10, t, 16) != 0) return;
 		const bool dense = p.solver == SRBA_SOLVER_SCHUR_DENSE_CHOL;
-		const struct { int slot; const char *name; } map[] = {{0, "opt.update_spanning_tree_num"}, {7, "opt.update_spanning_tree_num"}, {1, "opt.recompute_all_Jacobians"}, {2, "opt.sparse_hessian_update_numeric"},
+		const struct { int slot; const char *name; } map[] = {{0, "opt.update_spanning_tree_num"}, {7, "opt.update_spanning_tree_num"}, {1, "opt.recompute_all_Jacobians"}, {2,
+			"opt.sparse_hessian_update_numeric"},
 			{3, "opt.reprojection_residuals"}, {4, "opt.compute_minus_gradient"}, {6, "opt.add_se3_deltas_to_frames"}, {8, "opt.failedstep_restore_backup"}, {9, "opt.schur_build_reduced"},
 			{10, dense ? "opt.DenseFill" : "opt.SparseTripletFill"}, {11, dense ? "opt.DenseChol" : "opt.SparseChol"}, {12, "opt.backsub"}, {13, "opt.schur_features"}};
 		for (const auto &m : map) if (t[m.slot] > 0) m_prof->registerUserMeasure(m.name, 1e-8 * t[m.slot]);

@@ -80,7 +80,8 @@ struct RelativePoses_2D {
 
 struct RelativePoses_3D {
 	static const size_t OBS_DIMS = 6;
-	struct obs_data_t { double x, y, z, yaw, pitch, roll; obs_data_t() : x(0), y(0), z(0), yaw(0), pitch(0), roll(0) {} template <class A> void getAsArray(A &o) const { o[0] = x; o[1] = y; o[2] = z; o[3] = yaw; o[4] = pitch; o[5] = roll; } };
+	struct obs_data_t { double x, y, z, yaw, pitch, roll; obs_data_t() : x(0), y(0), z(0), yaw(0), pitch(0), roll(0) {} template <class A> void getAsArray(A &o) const { o[0] = x; o[1] = y; o[2] = z;
+		o[3] = yaw; o[4] = pitch; o[5] = roll; } };
 	struct TObservationParams {};
 };
 
@@ -94,7 +95,8 @@ template <class POSE> bool pose_from_matches(const mrpt::utils::TMatchingPairLis
 
 /** observations_RelativePoses_2D.h:46-71: use the observation of one KF made from the other (its own is exactly 0) */
 template <> struct landmark_matcher<RelativePoses_2D> {
-	template <class POSE> static bool find_relative_pose(const std::vector<RelativePoses_2D::obs_data_t> &new_kf_obs, const std::vector<RelativePoses_2D::obs_data_t> &old_kf_obs, const RelativePoses_2D::TObservationParams &, POSE &pose_new_kf_wrt_old_kf) {
+	template <class POSE> static bool find_relative_pose(const std::vector<RelativePoses_2D::obs_data_t> &new_kf_obs, const std::vector<RelativePoses_2D::obs_data_t> &old_kf_obs,
+		const RelativePoses_2D::TObservationParams &, POSE &pose_new_kf_wrt_old_kf) {
 		for (size_t i = 0; i < new_kf_obs.size(); i++) {
 			const RelativePoses_2D::obs_data_t &kf0 = new_kf_obs[i], &kf1 = old_kf_obs[i];
 			if ((kf0.x != 0 || kf0.y != 0 || kf0.yaw != 0) && (kf1.x != 0 || kf1.y != 0 || kf1.yaw != 0)) continue;
@@ -107,7 +109,8 @@ template <> struct landmark_matcher<RelativePoses_2D> {
 };
 /** observations_RelativePoses_3D.h:47-72: as in 2D, one of the two key-frames observes itself at exactly the null pose */
 template <> struct landmark_matcher<RelativePoses_3D> {
-	template <class POSE> static bool find_relative_pose(const std::vector<RelativePoses_3D::obs_data_t> &new_kf_obs, const std::vector<RelativePoses_3D::obs_data_t> &old_kf_obs, const RelativePoses_3D::TObservationParams &, POSE &pose_new_kf_wrt_old_kf) {
+	template <class POSE> static bool find_relative_pose(const std::vector<RelativePoses_3D::obs_data_t> &new_kf_obs, const std::vector<RelativePoses_3D::obs_data_t> &old_kf_obs,
+		const RelativePoses_3D::TObservationParams &, POSE &pose_new_kf_wrt_old_kf) {
 		struct is_null { static bool of(const RelativePoses_3D::obs_data_t &o) { return o.x == 0 && o.y == 0 && o.z == 0 && o.yaw == 0 && o.pitch == 0 && o.roll == 0; } };
 		for (size_t i = 0; i < new_kf_obs.size(); i++) {
 			const RelativePoses_3D::obs_data_t &n = new_kf_obs[i], &o = old_kf_obs[i];
@@ -120,14 +123,17 @@ template <> struct landmark_matcher<RelativePoses_3D> {
 };
 /** observations_RangeBearing_2D.h:46-82 */
 template <> struct landmark_matcher<RangeBearing_2D> {
-	template <class POSE> static bool find_relative_pose(const std::vector<RangeBearing_2D::obs_data_t> &n, const std::vector<RangeBearing_2D::obs_data_t> &o, const RangeBearing_2D::TObservationParams &, POSE &out) {
+	template <class POSE> static bool find_relative_pose(const std::vector<RangeBearing_2D::obs_data_t> &n, const std::vector<RangeBearing_2D::obs_data_t> &o,
+		const RangeBearing_2D::TObservationParams &, POSE &out) {
 		mrpt::utils::TMatchingPairList m;
-		for (size_t i = 0; i < n.size(); i++) m.push_back(mrpt::utils::TMatchingPair(i, i, o[i].range * std::cos(o[i].yaw), o[i].range * std::sin(o[i].yaw), 0, n[i].range * std::cos(n[i].yaw), n[i].range * std::sin(n[i].yaw), 0));
+		for (size_t i = 0; i < n.size(); i++) m.push_back(mrpt::utils::TMatchingPair(i, i, o[i].range * std::cos(o[i].yaw), o[i].range * std::sin(o[i].yaw), 0, n[i].range * std::cos(n[i].yaw),
+			n[i].range * std::sin(n[i].yaw), 0));
 		return detail::pose_from_matches(m, out);
 	}
 };
 template <> struct landmark_matcher<Cartesian_2D> {
-	template <class POSE> static bool find_relative_pose(const std::vector<Cartesian_2D::obs_data_t> &n, const std::vector<Cartesian_2D::obs_data_t> &o, const Cartesian_2D::TObservationParams &, POSE &out) {
+	template <class POSE> static bool find_relative_pose(const std::vector<Cartesian_2D::obs_data_t> &n, const std::vector<Cartesian_2D::obs_data_t> &o, const Cartesian_2D::TObservationParams &,
+		POSE &out) {
 		mrpt::utils::TMatchingPairList m;
 		for (size_t i = 0; i < n.size(); i++) m.push_back(mrpt::utils::TMatchingPair(i, i, o[i].pt.x, o[i].pt.y, 0, n[i].pt.x, n[i].pt.y, 0));
 		return detail::pose_from_matches(m, out);
@@ -135,16 +141,19 @@ template <> struct landmark_matcher<Cartesian_2D> {
 };
 /** observations_RangeBearing_3D.h:47-86 */
 template <> struct landmark_matcher<RangeBearing_3D> {
-	template <class POSE> static bool find_relative_pose(const std::vector<RangeBearing_3D::obs_data_t> &n, const std::vector<RangeBearing_3D::obs_data_t> &o, const RangeBearing_3D::TObservationParams &, POSE &out) {
+	template <class POSE> static bool find_relative_pose(const std::vector<RangeBearing_3D::obs_data_t> &n, const std::vector<RangeBearing_3D::obs_data_t> &o,
+		const RangeBearing_3D::TObservationParams &, POSE &out) {
 		mrpt::utils::TMatchingPairList m;
-		for (size_t i = 0; i < n.size(); i++) m.push_back(mrpt::utils::TMatchingPair(i, i, o[i].range * std::cos(o[i].yaw) * std::cos(o[i].pitch), o[i].range * std::sin(o[i].yaw) * std::cos(o[i].pitch), -o[i].range * std::sin(o[i].pitch),
+		for (size_t i = 0; i < n.size(); i++) m.push_back(mrpt::utils::TMatchingPair(i, i, o[i].range * std::cos(o[i].yaw) * std::cos(o[i].pitch),
+			o[i].range * std::sin(o[i].yaw) * std::cos(o[i].pitch), -o[i].range * std::sin(o[i].pitch),
 			n[i].range * std::cos(n[i].yaw) * std::cos(n[i].pitch), n[i].range * std::sin(n[i].yaw) * std::cos(n[i].pitch), -n[i].range * std::sin(n[i].pitch)));
 		return detail::pose_from_matches(m, out);
 	}
 };
 /** observations_Cartesian_3D.h:45-79 */
 template <> struct landmark_matcher<Cartesian_3D> {
-	template <class POSE> static bool find_relative_pose(const std::vector<Cartesian_3D::obs_data_t> &n, const std::vector<Cartesian_3D::obs_data_t> &o, const Cartesian_3D::TObservationParams &, POSE &out) {
+	template <class POSE> static bool find_relative_pose(const std::vector<Cartesian_3D::obs_data_t> &n, const std::vector<Cartesian_3D::obs_data_t> &o, const Cartesian_3D::TObservationParams &,
+		POSE &out) {
 		mrpt::utils::TMatchingPairList m;
 		for (size_t i = 0; i < n.size(); i++) m.push_back(mrpt::utils::TMatchingPair(i, i, o[i].pt.x, o[i].pt.y, o[i].pt.z, n[i].pt.x, n[i].pt.y, n[i].pt.z));
 		return detail::pose_from_matches(m, out);
@@ -152,7 +161,8 @@ template <> struct landmark_matcher<Cartesian_3D> {
 };
 /** observations_StereoCamera.h:52-110: triangulate both sets, then least-squares alignment */
 template <> struct landmark_matcher<StereoCamera> {
-	template <class POSE> static bool find_relative_pose(const std::vector<StereoCamera::obs_data_t> &n, const std::vector<StereoCamera::obs_data_t> &o, const StereoCamera::TObservationParams &p, POSE &out) {
+	template <class POSE> static bool find_relative_pose(const std::vector<StereoCamera::obs_data_t> &n, const std::vector<StereoCamera::obs_data_t> &o, const StereoCamera::TObservationParams &p,
+		POSE &out) {
 		const double cx = p.camera_calib.leftCamera.cx(), cy = p.camera_calib.leftCamera.cy(), b = p.camera_calib.rightCameraPose.x(), f = p.camera_calib.leftCamera.fx();
 		mrpt::utils::TMatchingPairList m;
 		for (size_t i = 0; i < n.size(); i++) {
@@ -167,7 +177,8 @@ template <> struct landmark_matcher<StereoCamera> {
 };
 /** observations_MonocularCamera.h:45-58: no metric relative pose from two monocular views */
 template <> struct landmark_matcher<MonocularCamera> {
-	template <class POSE> static bool find_relative_pose(const std::vector<MonocularCamera::obs_data_t> &, const std::vector<MonocularCamera::obs_data_t> &, const MonocularCamera::TObservationParams &, POSE &) { return false; }
+	template <class POSE> static bool find_relative_pose(const std::vector<MonocularCamera::obs_data_t> &, const std::vector<MonocularCamera::obs_data_t> &,
+		const MonocularCamera::TObservationParams &, POSE &) { return false; }
 };
 } // namespace observations
 
@@ -179,7 +190,8 @@ template <> struct sensor_model<landmarks::Euclidean3D, observations::MonocularC
 	template <class LM, class OBSD, class PRM> static void inverse_sensor_model(LM &out, const OBSD &obs, const PRM &p) { // sensors.h:121-141
 		out[0] = (obs.px.x - p.camera_calib.cx()) / p.camera_calib.fx(); out[1] = (obs.px.y - p.camera_calib.cy()) / p.camera_calib.fy(); out[2] = 1;
 	}
-	template <class PRM> static void fill_params(srba_hip_params &hp, const PRM &p) { hp.cam_left[0] = p.camera_calib.fx(); hp.cam_left[1] = p.camera_calib.fy(); hp.cam_left[2] = p.camera_calib.cx(); hp.cam_left[3] = p.camera_calib.cy(); }
+	template <class PRM> static void fill_params(srba_hip_params &hp, const PRM &p) { hp.cam_left[0] = p.camera_calib.fx(); hp.cam_left[1] = p.camera_calib.fy(); hp.cam_left[2] = p.camera_calib.cx();
+		hp.cam_left[3] = p.camera_calib.cy(); }
 };
 template <> struct sensor_model<landmarks::Euclidean3D, observations::StereoCamera> {
 	static const int family = SRBA_SE3_STEREO;
@@ -219,12 +231,14 @@ template <> struct sensor_model<landmarks::Euclidean2D, observations::Cartesian_
 };
 template <> struct sensor_model<landmarks::Euclidean2D, observations::RangeBearing_2D> {
 	static const int family = SRBA_SE2_RB2D;
-	template <class LM, class OBSD, class PRM> static void inverse_sensor_model(LM &out, const OBSD &obs, const PRM &) { out[0] = obs.range * std::cos(obs.yaw); out[1] = obs.range * std::sin(obs.yaw); } // sensors.h:726-736
+	template <class LM, class OBSD, class PRM> static void inverse_sensor_model(LM &out, const OBSD &obs, const PRM &) { out[0] = obs.range * std::cos(obs.yaw);
+		out[1] = obs.range * std::sin(obs.yaw); } // sensors.h:726-736
 	template <class PRM> static void fill_params(srba_hip_params &, const PRM &) {}
 };
 template <> struct sensor_model<landmarks::RelativePoses3D, observations::RelativePoses_3D> {
 	static const int family = SRBA_SE3_RELPOSE3D;
-	template <class LM, class OBSD, class PRM> static void inverse_sensor_model(LM &out, const OBSD &obs, const PRM &) { out[0] = obs.x; out[1] = obs.y; out[2] = obs.z; out[3] = obs.yaw; out[4] = obs.pitch; out[5] = obs.roll; } // sensors.h:915-927
+	template <class LM, class OBSD, class PRM> static void inverse_sensor_model(LM &out, const OBSD &obs, const PRM &) { out[0] = obs.x; out[1] = obs.y; out[2] = obs.z; out[3] = obs.yaw;
+		out[4] = obs.pitch; out[5] = obs.roll; } // sensors.h:915-927
 	template <class PRM> static void fill_params(srba_hip_params &, const PRM &) {}
 };
 template <> struct sensor_model<landmarks::RelativePoses2D, observations::RelativePoses_2D> {
@@ -235,7 +249,8 @@ template <> struct sensor_model<landmarks::RelativePoses2D, observations::Relati
 
 /** Device family of a <key-frame pose, landmark, observation> triple: the sensor model's family, except where the pose parameterisation changes the kernels */
 template <class KF, class LM, class OBS> struct device_family { static const int value = sensor_model<LM, OBS>::family; };
-template <> struct device_family<kf2kf_poses::SE2, landmarks::Euclidean3D, observations::StereoCamera> { static const int value = SRBA_SE2_STEREO; }; // SE(2) key-frames, 3D points (tutorial-srba-stereo-se2.cpp)
+template <> struct device_family<kf2kf_poses::SE2, landmarks::Euclidean3D, observations::StereoCamera> { static const int value = SRBA_SE2_STEREO; }; // SE(2) key-frames,
+	// 3D points (tutorial-srba-stereo-se2.cpp)
 /** REL_POSE_DIMS the kernels of a family are written for (checked against KF::REL_POSE_DIMS at compile time in RbaEngine) */
 constexpr int family_pose_dims(int family) { return (family == SRBA_SE2_RELPOSE2D || family == SRBA_SE2_RB2D || family == SRBA_SE2_CART2D || family == SRBA_SE2_STEREO) ? 3 : 6; }
 

@@ -40,9 +40,12 @@ struct sensor_pose_on_robot_se3 {
  * The device keeps it in HBM; it is not downloaded unless asked for, so hessian_valid stays false by default. */
 struct hessian_result_t { bool hessian_valid; std::vector<double> hessian; hessian_result_t() { clear(); } void clear() { hessian_valid = false; } };
 
-struct solver_LM_schur_dense_cholesky { static const bool USE_SCHUR = true; static const bool DENSE_CHOLESKY = true; static const int solver_id = SRBA_SOLVER_SCHUR_DENSE_CHOL; typedef hessian_result_t extra_results_t; };
-struct solver_LM_schur_sparse_cholesky { static const bool USE_SCHUR = true; static const bool DENSE_CHOLESKY = false; static const int solver_id = SRBA_SOLVER_SCHUR_SPARSE_CHOL; typedef hessian_result_t extra_results_t; };
-struct solver_LM_no_schur_sparse_cholesky { static const bool USE_SCHUR = false; static const bool DENSE_CHOLESKY = false; static const int solver_id = SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL; typedef hessian_result_t extra_results_t; };
+struct solver_LM_schur_dense_cholesky { static const bool USE_SCHUR = true; static const bool DENSE_CHOLESKY = true; static const int solver_id = SRBA_SOLVER_SCHUR_DENSE_CHOL;
+	typedef hessian_result_t extra_results_t; };
+struct solver_LM_schur_sparse_cholesky { static const bool USE_SCHUR = true; static const bool DENSE_CHOLESKY = false; static const int solver_id = SRBA_SOLVER_SCHUR_SPARSE_CHOL;
+	typedef hessian_result_t extra_results_t; };
+struct solver_LM_no_schur_sparse_cholesky { static const bool USE_SCHUR = false; static const bool DENSE_CHOLESKY = false; static const int solver_id = SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL;
+	typedef hessian_result_t extra_results_t; };
 
 } // namespace options
 } // namespace srba

@@ -192,7 +192,8 @@ enum srba_stop_reason {
 };
 #define SRBA_TRACE_LEN 48
 typedef struct srba_lm_result {
-	int32_t status;           /* 0 ok; 1 rank assert failed (optimize_edges.h:355): problem left untouched; 2 internal, never returned: the replicas of a speculative single-capsule run lost step -- the library re-runs the capsule on the sequential path before it hands the record out */
+	int32_t status;           /* 0 ok; 1 rank assert failed (optimize_edges.h:355): problem left untouched; 2 internal, never returned: the replicas of a speculative single-capsule run lost step --
+		the library re-runs the capsule on the sequential path before it hands the record out */
 	int32_t num_iters;        /* value of "iter" at loop exit (optimize_edges.h:452-454) */
 	int32_t num_trials;       /* passes of the inner while (optimize_edges.h:471-692) = "LM trials" */
 	int32_t num_not_pd;       /* solve() returned false (:476-485) */
@@ -210,7 +211,8 @@ typedef struct srba_lm_result {
 	double  trace_chi2[SRBA_TRACE_LEN];
 	double  trace_lambda[SRBA_TRACE_LEN];
 	double  trace_rho[SRBA_TRACE_LEN];
-	double  lambda_last_trial; /* lambda of the last trial (the one the solver's extra_results refer to, lev-marq_solvers.h:204-208); NaN when no trial ran. Unlike the trace it is not limited to SRBA_TRACE_LEN trials */
+	double  lambda_last_trial; /* lambda of the last trial (the one the solver's extra_results refer to, lev-marq_solvers.h:204-208); NaN when no trial ran. Unlike the trace it is not limited to
+		SRBA_TRACE_LEN trials */
 } srba_lm_result;
 
 typedef struct srba_hip_ctx srba_hip_ctx;

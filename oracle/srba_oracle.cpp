@@ -563,7 +563,8 @@ struct Problem {
 			}
 		} else if constexpr (FAM == SRBA_SE3_RELPOSE3D) { // jacobians.h:748-873, verbatim: jacob = dLnRelPose_deps (6x12) * dAeD_de (12x6)
 			Pose3 Dd, ad; double ROTA[9];
-			if (!inverse_edge) { Dd = D; if (hasA) { ad = compose(A, Dd); for (int k = 0; k < 9; k++) ROTA[k] = A.R[k]; } else { ad = Dd; for (int k = 0; k < 9; k++) ROTA[k] = (k % 4 == 0) ? 1.0 : 0.0; } }
+			if (!inverse_edge) { Dd = D; if (hasA) { ad = compose(A, Dd); for (int k = 0; k < 9; k++) ROTA[k] = A.R[k]; } else { ad = Dd; for (int k = 0; k < 9;
+				k++) ROTA[k] = (k % 4 == 0) ? 1.0 : 0.0; } }
 			else {
 				const Pose3 Dp = compose(pe, D), pinv = inverse(pe); const Pose3 Ap = hasA ? compose(A, pinv) : pinv;
 				for (int k = 0; k < 9; k++) ROTA[k] = Ap.R[k]; Dd = Dp; ad = compose(Ap, Dp);
@@ -649,7 +650,8 @@ struct Problem {
 			dh_dx_rotate(dh_dx); // :980
 			if (hasP) { // J = dh_dx * R(base<-obs) (:984-989)
 				if constexpr (SE3) mm<O, 3, 3>(dh_dx, bp.R, J);
-				else if constexpr (SE2_3D) { const double cc = std::cos(bp.phi), ss = std::sin(bp.phi); const double R[9] = {cc, -ss, 0, ss, cc, 0, 0, 0, 1}; mm<O, 3, 3>(dh_dx, R, J); } // [EXT] CPose2D::getRotationMatrix into a 3x3
+				else if constexpr (SE2_3D) { const double cc = std::cos(bp.phi), ss = std::sin(bp.phi); const double R[9] = {cc, -ss, 0, ss, cc, 0, 0, 0, 1}; mm<O, 3, 3>(dh_dx, R, J); }
+					// [EXT] CPose2D::getRotationMatrix into a 3x3
 				else { const double cc = std::cos(bp.phi), ss = std::sin(bp.phi); const double R[4] = {cc, -ss, ss, cc}; mm<O, 2, 2>(dh_dx, R, J); }
 			} else for (int k = 0; k < O * L; k++) J[k] = dh_dx[k];
 		}
@@ -697,7 +699,8 @@ struct Problem {
 			for (int b = coff[i]; b < coff[i + 1]; b++) {
 				const double *A = J + (size_t)b * O * M, *r = &resid[(size_t)res[b] * O];
 				if (prm.noise == SRBA_NOISE_CONSTANT_MATRIX) { // g += (J^t Lambda) r (:117-123)
-					for (int ii = 0; ii < M; ii++) { double s = 0; for (int j = 0; j < O; j++) { double jl = 0; for (int k = 0; k < O; k++) jl += A[k * M + ii] * prm.lambda[k * O + j]; s += jl * r[j]; } acc[ii] += s; }
+					for (int ii = 0; ii < M; ii++) { double s = 0; for (int j = 0; j < O; j++) { double jl = 0; for (int k = 0; k < O; k++) jl += A[k * M + ii] * prm.lambda[k * O + j];
+						s += jl * r[j]; } acc[ii] += s; }
 				} else for (int ii = 0; ii < M; ii++) { double s = 0; for (int k = 0; k < O; k++) s += A[k * M + ii] * r[k]; acc[ii] += s; }
 			}
 			if (prm.noise == SRBA_NOISE_IDENTITY) { const double s = 1.0 / prm.std_noise_observations; for (int k = 0; k < M; k++) acc[k] *= s; } // scale_Jtr :67-71
@@ -763,7 +766,8 @@ struct Problem {
 
 	// ---------------- K9: lev-marq_solvers.h ----------------
 	void sparse_setup() { // symbolic part of CholeskyDecomp ctor (cs_schol), once per optimize_edges call (:164-166)
-		struct stopwatch { std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); ~stopwatch() { g_symbolic_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); } } sw; // bench.py reports the CPU rate with and without this setup
+		struct stopwatch { std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); ~stopwatch() {
+			g_symbolic_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); } } sw; // bench.py reports the CPU rate with and without this setup
 		const bool full = !use_schur; // full system vs HAp only
 		n_sys = full ? n : P * nK;
 		const int nb = full ? nK + nF : nK;
@@ -790,7 +794,8 @@ struct Problem {
 			for (int b = 0; b < c.n_hf; b++) add_block(P * nK + L * c.hf_i[b], P * nK + L * c.hf_j[b], L, L, c.hf_i[b] == c.hf_j[b]);
 		}
 		Cp.assign(n_sys + 1, 0); Ci.clear();
-		for (int j = 0; j < n_sys; j++) { std::sort(cols[j].begin(), cols[j].end()); cols[j].erase(std::unique(cols[j].begin(), cols[j].end()), cols[j].end()); Cp[j + 1] = Cp[j] + (int)cols[j].size(); Ci.insert(Ci.end(), cols[j].begin(), cols[j].end()); }
+		for (int j = 0; j < n_sys; j++) { std::sort(cols[j].begin(), cols[j].end()); cols[j].erase(std::unique(cols[j].begin(), cols[j].end()), cols[j].end());
+			Cp[j + 1] = Cp[j] + (int)cols[j].size(); Ci.insert(Ci.end(), cols[j].begin(), cols[j].end()); }
 		Cx.assign(Ci.size(), 0.0);
 	}
 	void sparse_fill(double lambda) { // SparseTripletFill + compressFromTriplet (:88-156 / :303-332)
@@ -833,7 +838,8 @@ struct Problem {
 	// Decision replay (test infrastructure of the test infrastructure: tests/test_gpu_parity.py, tools/soak_parity.py): instead of deciding not-PD / reject / accept itself the loop
 	// takes the sequence another run took (the GPU's, read from its trial trace) and reports, per trial, what it would have decided: its own rho, the chi2 of the trial point and the chi2
 	// it started from. Two runs that part at a rounding-floor decision can then be compared over their WHOLE length instead of over the common prefix (optimize_edges.h:579-656).
-	struct Replay { const int32_t *dec; int n; double *rho, *chi2, *E; int32_t *flags; int diverged_at; }; // dec: 0 not PD, 1 rejected, 2 accepted; flags: 1 own factorisation PD, 2 own rho sign differs from the decision, 4 forced not-PD although PD
+	struct Replay { const int32_t *dec; int n; double *rho, *chi2, *E; int32_t *flags; int diverged_at; }; // dec: 0 not PD, 1 rejected, 2 accepted; flags: 1 own factorisation PD,
+		// 2 own rho sign differs from the decision, 4 forced not-PD although PD
 	void run(srba_lm_result &out, Replay *rp = nullptr) {
 		std::memset(&out, 0, sizeof(out));
 		for (int k = 0; k < SRBA_TRACE_LEN; k++) { out.trace_chi2[k] = out.trace_lambda[k] = out.trace_rho[k] = std::numeric_limits<double>::quiet_NaN(); }
@@ -898,7 +904,8 @@ struct Problem {
 				if (rp) { rp->rho[tr] = rho; rp->chi2[tr] = new_err; if (own_accept != accept) rp->flags[tr] |= 2; }
 				if (accept) { // :587
 					out.num_accepted++;
-					// (a replayed acceptance of a step this run would have rejected is a step that does not reduce the error here: the run that accepted it saw a reduction below its rounding, far below the relinearisation threshold)
+					// (a replayed acceptance of a step this run would have rejected is a step that does not reduce the error here: the run that accepted it saw a reduction below its rounding,
+						// far below the relinearisation threshold)
 					const bool relin = (forced >= 0 && !own_accept) ? false : (err_red < 0 || err_red > prm.min_error_reduction_ratio_to_relinearize); // :592
 					resid.swap(new_resid); total_err = new_err; RMSE = new_RMSE; // :601-604
 					if (relin) { // :606-629
@@ -998,7 +1005,8 @@ void stage_one(const srba_hip_params &p, srba_problem_capsule &c, int do_solve, 
 // The reference's SchurTests body (tests/schur_unittest.cpp:71-279) on GIVEN Jacobian blocks: numeric Hessians over the capsule's symbolic plan
 // (sparse_hessian_update_numeric), then SchurComplement::numeric_build_reduced_system(lambda) with the given minus-gradient.
 template <int FAM>
-void schur_from_jacobians(const srba_hip_params &p, srba_problem_capsule &c, const double *Jp, const double *Jf, const double *grad_in, double lambda, double *HAp_out, double *Hf_out, double *HApf_out, double *grad_out) {
+void schur_from_jacobians(const srba_hip_params &p, srba_problem_capsule &c, const double *Jp, const double *Jf, const double *grad_in, double lambda, double *HAp_out, double *Hf_out,
+	double *HApf_out, double *grad_out) {
 	Problem<FAM> pr(p, c);
 	std::fill(pr.valid.begin(), pr.valid.end(), 1);
 	std::copy(Jp, Jp + pr.Jp.size(), pr.Jp.begin()); std::copy(Jf, Jf + pr.Jf.size(), pr.Jf.begin());
@@ -1035,7 +1043,8 @@ int srba_oracle_lm_run(const srba_hip_params *params, srba_problem_capsule *caps
 	// dynamic work queue: capsules differ 10x in cost (loop-closure windows), static interleaving leaves threads idle at the end
 	std::atomic<int> next(0); const int chunk = 4;
 	std::vector<std::thread> th;
-	for (int t = 0; t < n_threads; t++) th.emplace_back([&, params, caps, results, n]() { for (;;) { const int b = next.fetch_add(chunk); if (b >= n) break; for (int i = b; i < std::min(n, b + chunk); i++) dispatch_run(*params, caps[i], results[i]); } });
+	for (int t = 0; t < n_threads; t++) th.emplace_back([&, params, caps, results, n]() { for (;;) { const int b = next.fetch_add(chunk); if (b >= n) break; for (int i = b; i < std::min(n,
+		b + chunk); i++) dispatch_run(*params, caps[i], results[i]); } });
 	for (auto &x : th) x.join();
 	return 0;
 }
@@ -1047,7 +1056,8 @@ int srba_oracle_lm_run_replay(const srba_hip_params *params, srba_problem_capsul
 	if (!params || !caps || n < 0 || !decisions || !n_decisions || stride < 1 || !own_rho || !own_chi2 || !own_E || !flags || !diverged_at || !results) return -1;
 	std::atomic<int> next(0);
 	auto work = [&]() { for (;;) { const int i = next.fetch_add(1); if (i >= n) break;
-		ReplayIO io = {decisions + (size_t)i * stride, std::min(n_decisions[i], stride), own_rho + (size_t)i * stride, own_chi2 + (size_t)i * stride, own_E + (size_t)i * stride, flags + (size_t)i * stride, -1};
+		ReplayIO io = {decisions + (size_t)i * stride, std::min(n_decisions[i], stride), own_rho + (size_t)i * stride, own_chi2 + (size_t)i * stride, own_E + (size_t)i * stride,
+			flags + (size_t)i * stride, -1};
 		dispatch_run(*params, caps[i], results[i], &io); diverged_at[i] = io.diverged_at; } };
 	if (n_threads <= 1) { work(); return 0; }
 	std::vector<std::thread> th; for (int t = 0; t < n_threads; t++) th.emplace_back(work);

@@ -62,7 +62,8 @@ class EngineConfig(C.Structure):
                 ("max_tree_depth", C.c_uint64), ("max_optimize_depth", C.c_uint64), ("submap_size", C.c_uint64), ("min_obs_to_loop_closure", C.c_uint64),
                 ("optimize_new_edges_alone", c_i32), ("use_robust_kernel", c_i32), ("use_robust_kernel_stage1", c_i32), ("max_iters", c_i32),
                 ("kernel_param", c_f64), ("max_error_per_obs_to_stop", c_f64), ("max_rho", c_f64), ("max_lambda", c_f64), ("min_error_reduction_ratio_to_relinearize", c_f64),
-                ("cov_recovery", c_i32), ("run_local_optimization", c_i32), ("harvest", c_i32), ("verbose", c_i32), ("enable_profiler", c_i32), ("hip_device", c_i32), ("refresh_all_read_poses", c_i32), ("ecp", c_i32)]
+                ("cov_recovery", c_i32), ("run_local_optimization", c_i32), ("harvest", c_i32), ("verbose", c_i32), ("enable_profiler", c_i32), ("hip_device", c_i32), ("refresh_all_read_poses",
+                        c_i32), ("ecp", c_i32)]
 
 
 class KfInfo(C.Structure):
@@ -148,7 +149,8 @@ def engine_lib():
         lib.srba_engine_eval_overall_sqr_error.argtypes = [C.c_void_p, C.POINTER(c_f64)]
         lib.srba_engine_alloc_keyframe.argtypes = [C.c_void_p]; lib.srba_engine_alloc_keyframe.restype = C.c_uint64
         lib.srba_engine_create_edge.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, PF64]; lib.srba_engine_create_edge.restype = C.c_int64
-        lib.srba_engine_export_graphslam.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), PF64, C.c_int64, C.POINTER(C.c_uint64), PF64, C.c_int64]; lib.srba_engine_export_graphslam.restype = C.c_int64
+        lib.srba_engine_export_graphslam.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), PF64, C.c_int64, C.POINTER(C.c_uint64), PF64,
+                C.c_int64]; lib.srba_engine_export_graphslam.restype = C.c_int64
         lib.srba_engine_harvest_count.argtypes = [C.c_void_p]; lib.srba_engine_harvest_count.restype = C.c_int64
         lib.srba_engine_harvest_capsules.argtypes = [C.c_void_p]; lib.srba_engine_harvest_capsules.restype = PCAP
         lib.srba_engine_harvest_kf.argtypes = [C.c_void_p, C.c_int64]; lib.srba_engine_harvest_kf.restype = C.c_uint64

@@ -21,22 +21,28 @@ template <> struct obs_io<observations::RangeBearing_2D> { static void set(obser
 template <> struct obs_io<observations::Cartesian_2D> { static void set(observations::Cartesian_2D::obs_data_t &o, const double *z) { o.pt.x = z[0]; o.pt.y = z[1]; } };
 template <> struct obs_io<observations::Cartesian_3D> { static void set(observations::Cartesian_3D::obs_data_t &o, const double *z) { o.pt.x = z[0]; o.pt.y = z[1]; o.pt.z = z[2]; } };
 template <> struct obs_io<observations::RangeBearing_3D> { static void set(observations::RangeBearing_3D::obs_data_t &o, const double *z) { o.range = z[0]; o.yaw = z[1]; o.pitch = z[2]; } };
-template <> struct obs_io<observations::RelativePoses_3D> { static void set(observations::RelativePoses_3D::obs_data_t &o, const double *z) { o.x = z[0]; o.y = z[1]; o.z = z[2]; o.yaw = z[3]; o.pitch = z[4]; o.roll = z[5]; } };
+template <> struct obs_io<observations::RelativePoses_3D> { static void set(observations::RelativePoses_3D::obs_data_t &o, const double *z) { o.x = z[0]; o.y = z[1]; o.z = z[2]; o.yaw = z[3];
+	o.pitch = z[4]; o.roll = z[5]; } };
 template <> struct obs_io<observations::MonocularCamera> { static void set(observations::MonocularCamera::obs_data_t &o, const double *z) { o.px.x = (float)z[0]; o.px.y = (float)z[1]; } };
-template <> struct obs_io<observations::StereoCamera> { static void set(observations::StereoCamera::obs_data_t &o, const double *z) { o.left_px.x = (float)z[0]; o.left_px.y = (float)z[1]; o.right_px.x = (float)z[2]; o.right_px.y = (float)z[3]; } };
+template <> struct obs_io<observations::StereoCamera> { static void set(observations::StereoCamera::obs_data_t &o, const double *z) { o.left_px.x = (float)z[0]; o.left_px.y = (float)z[1];
+	o.right_px.x = (float)z[2]; o.right_px.y = (float)z[3]; } };
 
 template <class NOISE> struct noise_io;
 template <> struct noise_io<options::observation_noise_identity> { template <class P> static void set(P &p, const srba_engine_config &c) { p.std_noise_observations = c.std_noise_observations; } };
-template <class OBS> struct noise_io<options::observation_noise_constant_matrix<OBS> > { template <class P> static void set(P &p, const srba_engine_config &c) { for (size_t i = 0; i < OBS::OBS_DIMS * OBS::OBS_DIMS; i++) p.lambda.m[i] = c.lambda[i]; } };
+template <class OBS> struct noise_io<options::observation_noise_constant_matrix<OBS> > { template <class P> static void set(P &p, const srba_engine_config &c) { for (size_t i = 0;
+	i < OBS::OBS_DIMS * OBS::OBS_DIMS; i++) p.lambda.m[i] = c.lambda[i]; } };
 template <class SP> struct spose_io;
 template <> struct spose_io<options::sensor_pose_on_robot_none> { template <class P> static void set(P &, const srba_engine_config &) {} };
-template <> struct spose_io<options::sensor_pose_on_robot_se3> { template <class P> static void set(P &p, const srba_engine_config &c) { p.relative_pose = mrpt::poses::CPose3D(c.sensor_pose_xyzypr[0], c.sensor_pose_xyzypr[1], c.sensor_pose_xyzypr[2], c.sensor_pose_xyzypr[3], c.sensor_pose_xyzypr[4], c.sensor_pose_xyzypr[5]); } };
+template <> struct spose_io<options::sensor_pose_on_robot_se3> { template <class P> static void set(P &p, const srba_engine_config &c) {
+	p.relative_pose = mrpt::poses::CPose3D(c.sensor_pose_xyzypr[0], c.sensor_pose_xyzypr[1], c.sensor_pose_xyzypr[2], c.sensor_pose_xyzypr[3], c.sensor_pose_xyzypr[4], c.sensor_pose_xyzypr[5]); } };
 template <class OBS> struct sensor_io { template <class P> static void set(P &, const srba_engine_config &) {} };
-template <> struct sensor_io<observations::MonocularCamera> { template <class P> static void set(P &p, const srba_engine_config &c) { p.camera_calib.setIntrinsicParamsFromValues(c.cam_left[0], c.cam_left[1], c.cam_left[2], c.cam_left[3]); } };
+template <> struct sensor_io<observations::MonocularCamera> { template <class P> static void set(P &p, const srba_engine_config &c) { p.camera_calib.setIntrinsicParamsFromValues(c.cam_left[0],
+	c.cam_left[1], c.cam_left[2], c.cam_left[3]); } };
 template <> struct sensor_io<observations::StereoCamera> { template <class P> static void set(P &p, const srba_engine_config &c) {
 	p.camera_calib.leftCamera.setIntrinsicParamsFromValues(c.cam_left[0], c.cam_left[1], c.cam_left[2], c.cam_left[3]);
 	p.camera_calib.rightCamera.setIntrinsicParamsFromValues(c.cam_right[0], c.cam_right[1], c.cam_right[2], c.cam_right[3]);
-	p.camera_calib.rightCameraPose = mrpt::poses::CPose3DQuat(c.right_cam_pose[0], c.right_cam_pose[1], c.right_cam_pose[2], mrpt::math::CQuaternionDouble(c.right_cam_pose[3], c.right_cam_pose[4], c.right_cam_pose[5], c.right_cam_pose[6])); } };
+	p.camera_calib.rightCameraPose = mrpt::poses::CPose3DQuat(c.right_cam_pose[0], c.right_cam_pose[1], c.right_cam_pose[2], mrpt::math::CQuaternionDouble(c.right_cam_pose[3], c.right_cam_pose[4],
+		c.right_cam_pose[5], c.right_cam_pose[6])); } };
 
 struct Harvest {
 	std::deque<CapsuleData> data; std::vector<srba_problem_capsule> views; std::vector<uint64_t> kf_of; bool dirty = true;
@@ -61,7 +67,8 @@ struct EngineBase {
 };
 
 template <class ECP> struct ecp_io;
-template <> struct ecp_io<ecps::local_areas_fixed_size> { template <class P> static void set(P &p, const srba_engine_config &c) { p.submap_size = c.submap_size; p.min_obs_to_loop_closure = c.min_obs_to_loop_closure; } };
+template <> struct ecp_io<ecps::local_areas_fixed_size> { template <class P> static void set(P &p, const srba_engine_config &c) { p.submap_size = c.submap_size;
+	p.min_obs_to_loop_closure = c.min_obs_to_loop_closure; } };
 template <> struct ecp_io<ecps::classic_linear_rba> { template <class P> static void set(P &p, const srba_engine_config &c) { p.min_obs_to_loop_closure = c.min_obs_to_loop_closure; } };
 
 template <class KF, class LM, class OBS, class NOISE, class SPOSE, class SOLVER, class ECP = ecps::local_areas_fixed_size>
@@ -76,8 +83,11 @@ struct EngineImpl : public EngineBase {
 		typename rba_t::TSRBAParameters &s = rba.parameters.srba;
 		s.max_tree_depth = c.max_tree_depth; s.max_optimize_depth = c.max_optimize_depth; s.optimize_new_edges_alone = c.optimize_new_edges_alone != 0;
 		s.use_robust_kernel = c.use_robust_kernel != 0; s.use_robust_kernel_stage1 = c.use_robust_kernel_stage1 != 0; s.kernel_param = c.kernel_param; s.max_iters = c.max_iters;
-		s.max_error_per_obs_to_stop = c.max_error_per_obs_to_stop; s.max_rho = c.max_rho; s.max_lambda = c.max_lambda; s.min_error_reduction_ratio_to_relinearize = c.min_error_reduction_ratio_to_relinearize;
-		s.cov_recovery = c.cov_recovery ? crpLandmarksApprox : crpNone; s.refresh_all_read_poses = (c.refresh_all_read_poses & 1) != 0; s.restore_spanning_tree_twins = (c.refresh_all_read_poses & 2) != 0; s.schur_keeps_gradient = (c.refresh_all_read_poses & 4) != 0; s.consistent_loop_closure_init = (c.refresh_all_read_poses & 8) != 0; // bit 0 / bit 1 of the config field: the two extensions of SURVEY App. B-12
+		s.max_error_per_obs_to_stop = c.max_error_per_obs_to_stop; s.max_rho = c.max_rho; s.max_lambda = c.max_lambda;
+			s.min_error_reduction_ratio_to_relinearize = c.min_error_reduction_ratio_to_relinearize;
+		s.cov_recovery = c.cov_recovery ? crpLandmarksApprox : crpNone; s.refresh_all_read_poses = (c.refresh_all_read_poses & 1) != 0; s.restore_spanning_tree_twins = (c.refresh_all_read_poses & 2)
+			!= 0; s.schur_keeps_gradient = (c.refresh_all_read_poses & 4) != 0; s.consistent_loop_closure_init = (c.refresh_all_read_poses & 8) != 0;
+			// bit 0 / bit 1 of the config field: the two extensions of SURVEY App. B-12
 		ecp_io<ECP>::set(rba.parameters.ecp, c);
 		noise_io<NOISE>::set(rba.parameters.obs_noise, c); spose_io<SPOSE>::set(rba.parameters.sensor_pose, c); sensor_io<OBS>::set(rba.parameters.sensor, c);
 		rba.set_hip_device(c.hip_device);
@@ -110,7 +120,8 @@ struct EngineImpl : public EngineBase {
 			if (out) {
 				std::memset(out, 0, sizeof(*out));
 				out->kf_id = info.kf_id; out->n_new_edges = (int)std::min<size_t>(info.created_edge_ids.size(), 4);
-				for (int i = 0; i < out->n_new_edges; i++) { const TNewEdgeInfo &e = info.created_edge_ids[i]; out->edge_id[i] = e.id; out->edge_has_init[i] = e.has_approx_init_val; out->lc_observer[i] = e.loopclosure_observer_kf; out->lc_base[i] = e.loopclosure_base_kf; }
+				for (int i = 0; i < out->n_new_edges; i++) { const TNewEdgeInfo &e = info.created_edge_ids[i]; out->edge_id[i] = e.id; out->edge_has_init[i] = e.has_approx_init_val;
+					out->lc_observer[i] = e.loopclosure_observer_kf; out->lc_base[i] = e.loopclosure_base_kf; }
 				fill_info(out, info.optimize_results, &info.optimize_results_stg1);
 			}
 			return 0;
@@ -128,7 +139,8 @@ struct EngineImpl : public EngineBase {
 	int64_t num_unknown_lms() const { return (int64_t)rba.get_unknown_feats().size(); }
 	int get_unknown_lms(uint64_t *ids, uint64_t *base, double *pos) const {
 		size_t i = 0;
-		for (typename rba_t::TRelativeLandmarkPosMap::const_iterator it = rba.get_unknown_feats().begin(); it != rba.get_unknown_feats().end(); ++it, ++i) { ids[i] = it->first; base[i] = it->second.id_frame_base; for (size_t k = 0; k < LM::LM_DIMS; k++) pos[i * LM::LM_DIMS + k] = it->second.pos[k]; }
+		for (typename rba_t::TRelativeLandmarkPosMap::const_iterator it = rba.get_unknown_feats().begin(); it != rba.get_unknown_feats().end(); ++it, ++i) { ids[i] = it->first;
+			base[i] = it->second.id_frame_base; for (size_t k = 0; k < LM::LM_DIMS; k++) pos[i * LM::LM_DIMS + k] = it->second.pos[k]; }
 		return 0;
 	}
 	/** what=0: next_edge rows [src trg next dist]; what=1: all_edges rows [from to len e0 e1 ...] ; returns the number of int64 needed */
@@ -144,7 +156,8 @@ struct EngineImpl : public EngineBase {
 		}
 		return n;
 	}
-	int get_rel_pose(uint64_t query, uint64_t reference, double *pose) const { const typename rba_t::pose_t *p = rba.get_kf_relative_pose(query, reference); if (!p) return -1; p->storeTo(pose); return 0; }
+	int get_rel_pose(uint64_t query, uint64_t reference, double *pose) const { const typename rba_t::pose_t *p = rba.get_kf_relative_pose(query, reference); if (!p) return -1; p->storeTo(pose);
+		return 0; }
 	double profiler_mean(const char *name) const { return const_cast<rba_t &>(rba).get_time_profiler().getMeanTime(name); }
 	int eval_overall(double *out) { try { *out = rba.eval_overall_squared_error(); return 0; } catch (std::exception &e) { error = e.what(); return -1; } }
 	uint64_t alloc_keyframe() { return rba.alloc_keyframe(); }
@@ -158,8 +171,10 @@ struct EngineImpl : public EngineBase {
 		pose_graph_t g; typename rba_t::ExportGraphSLAM_Params prm; prm.root_kf_id = root;
 		rba.get_global_graphslam_problem(g, prm);
 		const size_t PD = rba_t::pose_t::storage_doubles(); int64_t i = 0;
-		for (typename std::map<uint64_t, typename rba_t::pose_t>::const_iterator it = g.nodes.begin(); it != g.nodes.end() && i < node_cap; ++it, ++i) { node_id[i] = it->first; it->second.storeTo(node_pose + (size_t)i * PD); }
-		for (size_t e = 0; e < g.edges.size() && (int64_t)e < edge_cap; e++) { edge_from_to[2 * e] = g.edges[e].first.first; edge_from_to[2 * e + 1] = g.edges[e].first.second; g.edges[e].second.storeTo(edge_pose + e * PD); }
+		for (typename std::map<uint64_t, typename rba_t::pose_t>::const_iterator it = g.nodes.begin(); it != g.nodes.end() && i < node_cap; ++it, ++i) { node_id[i] = it->first;
+			it->second.storeTo(node_pose + (size_t)i * PD); }
+		for (size_t e = 0; e < g.edges.size() && (int64_t)e < edge_cap; e++) { edge_from_to[2 * e] = g.edges[e].first.first; edge_from_to[2 * e + 1] = g.edges[e].first.second;
+			g.edges[e].second.storeTo(edge_pose + e * PD); }
 		return (int64_t)g.nodes.size();
 	}
 	int64_t create_edge(uint64_t new_kf, uint64_t from, uint64_t to, const double *pose) {
@@ -217,14 +232,16 @@ void *srba_engine_create(const srba_engine_config *c) {
 	try {
 		if (c->ecp == 1) { // classic linear RBA: the two problem types the reference tutorials use it with
 			if (c->family == SRBA_SE2_RELPOSE2D && c->noise == SRBA_NOISE_CONSTANT_MATRIX && c->sensor_pose == SRBA_SENSOR_POSE_NONE && c->solver == SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL)
-				e = new EngineImpl<kf2kf_poses::SE2, landmarks::RelativePoses2D, observations::RelativePoses_2D, options::observation_noise_constant_matrix<observations::RelativePoses_2D>, SP_NONE, S_NS, ecps::classic_linear_rba>(*c);
+				e = new EngineImpl<kf2kf_poses::SE2, landmarks::RelativePoses2D, observations::RelativePoses_2D, options::observation_noise_constant_matrix<observations::RelativePoses_2D>, SP_NONE,
+					S_NS, ecps::classic_linear_rba>(*c);
 			else if (c->family == SRBA_SE3_CART3D && c->noise == SRBA_NOISE_IDENTITY && c->sensor_pose == SRBA_SENSOR_POSE_NONE && c->solver == SRBA_SOLVER_SCHUR_DENSE_CHOL)
 				e = new EngineImpl<kf2kf_poses::SE3, landmarks::Euclidean3D, observations::Cartesian_3D, N_ID, SP_NONE, S_SD, ecps::classic_linear_rba>(*c);
 		} else
 		switch (c->family) {
 			case SRBA_SE2_RELPOSE2D:
 				if (c->noise == SRBA_NOISE_CONSTANT_MATRIX && c->sensor_pose == SRBA_SENSOR_POSE_NONE)
-					e = make_solver<kf2kf_poses::SE2, landmarks::RelativePoses2D, observations::RelativePoses_2D, options::observation_noise_constant_matrix<observations::RelativePoses_2D>, SP_NONE>(*c);
+					e = make_solver<kf2kf_poses::SE2, landmarks::RelativePoses2D, observations::RelativePoses_2D, options::observation_noise_constant_matrix<observations::RelativePoses_2D>,
+						SP_NONE>(*c);
 				else if (c->noise == SRBA_NOISE_IDENTITY && c->sensor_pose == SRBA_SENSOR_POSE_NONE)
 					e = make_solver<kf2kf_poses::SE2, landmarks::RelativePoses2D, observations::RelativePoses_2D, N_ID, SP_NONE>(*c);
 				break;
@@ -236,13 +253,15 @@ void *srba_engine_create(const srba_engine_config *c) {
 			case SRBA_SE3_RB3D: e = make_point_engine<kf2kf_poses::SE3, landmarks::Euclidean3D, observations::RangeBearing_3D>(*c); break;
 			case SRBA_SE3_RELPOSE3D: // SE(3) relative graph-SLAM (tutorial-srba-relative-graph-slam-se3.cpp): constant 6x6 information matrix, or identity noise
 				if (c->noise == SRBA_NOISE_CONSTANT_MATRIX && c->sensor_pose == SRBA_SENSOR_POSE_NONE)
-					e = make_solver<kf2kf_poses::SE3, landmarks::RelativePoses3D, observations::RelativePoses_3D, options::observation_noise_constant_matrix<observations::RelativePoses_3D>, SP_NONE>(*c);
+					e = make_solver<kf2kf_poses::SE3, landmarks::RelativePoses3D, observations::RelativePoses_3D, options::observation_noise_constant_matrix<observations::RelativePoses_3D>,
+						SP_NONE>(*c);
 				else if (c->noise == SRBA_NOISE_IDENTITY && c->sensor_pose == SRBA_SENSOR_POSE_NONE)
 					e = make_solver<kf2kf_poses::SE3, landmarks::RelativePoses3D, observations::RelativePoses_3D, N_ID, SP_NONE>(*c);
 				break;
 			case SRBA_SE2_STEREO: // SE(2) key-frames + 3D landmarks + stereo camera (tutorial-srba-stereo-se2.cpp)
 				if (c->noise == SRBA_NOISE_IDENTITY) e = (c->sensor_pose == SRBA_SENSOR_POSE_SE3) ? make_solver<kf2kf_poses::SE2, landmarks::Euclidean3D, observations::StereoCamera, N_ID, SP_SE3>(*c)
-				                                                                                     : make_solver<kf2kf_poses::SE2, landmarks::Euclidean3D, observations::StereoCamera, N_ID, SP_NONE>(*c);
+				                                                                                     : make_solver<kf2kf_poses::SE2, landmarks::Euclidean3D, observations::StereoCamera, N_ID,
+				                                                                                     	SP_NONE>(*c);
 				break;
 		}
 	} catch (std::exception &ex) { g_error = ex.what(); return NULL; }
@@ -255,7 +274,8 @@ int srba_engine_set_backend_fn(void *h, srba_backend_fn fn, const char *name) {
 	EngineBase *e = static_cast<EngineBase *>(h);
 	e->fn_backend.reset(new function_backend(fn, name ? name : "external")); e->set_backend(e->fn_backend); return 0;
 }
-int srba_engine_set_overall_fn(void *h, srba_overall_fn fn) { EngineBase *e = static_cast<EngineBase *>(h); if (!e->fn_backend) { e->error = "set_overall_fn: plug a back-end function first"; return -1; } e->fn_backend->overall_fn = fn; return 0; }
+int srba_engine_set_overall_fn(void *h, srba_overall_fn fn) { EngineBase *e = static_cast<EngineBase *>(h); if (!e->fn_backend) { e->error = "set_overall_fn: plug a back-end function first";
+	return -1; } e->fn_backend->overall_fn = fn; return 0; }
 int srba_engine_eval_overall_sqr_error(void *h, double *out) { return static_cast<EngineBase *>(h)->eval_overall(out); }
 int srba_engine_add_keyframe(void *h, int n_obs, const uint64_t *feat_id, const double *z, const uint8_t *flags, const double *relpos, srba_kf_info *out) {
 	return static_cast<EngineBase *>(h)->add_keyframe(n_obs, feat_id, z, flags, relpos, out);
@@ -302,7 +322,8 @@ void *srba_capsule_file_load(const char *path) {
 	CapsuleFile *cf = new CapsuleFile();
 	try {
 		uint64_t magic = 0; int64_t n = 0;
-		if (fread(&magic, 8, 1, f) != 1 || magic != 0x53524241434150ULL || fread(&n, 8, 1, f) != 1 || fread(&cf->params, sizeof(srba_hip_params), 1, f) != 1) throw std::runtime_error("bad capsule file header");
+		if (fread(&magic, 8, 1, f) != 1 || magic != 0x53524241434150ULL || fread(&n, 8, 1, f) != 1 || fread(&cf->params, sizeof(srba_hip_params), 1,
+			f) != 1) throw std::runtime_error("bad capsule file header");
 		for (int64_t i = 0; i < n; i++) { cf->data.push_back(CapsuleData()); cf->data.back().read(f); }
 		for (size_t i = 0; i < cf->data.size(); i++) cf->views.push_back(cf->data[i].view());
 	} catch (std::exception &e) { g_error = e.what(); delete cf; fclose(f); return NULL; }
@@ -325,9 +346,11 @@ void *srba_capsule_from_blocks(int family, int nK, int nF, int n_obs, const int3
 	std::vector<uint64_t> bp_row, bf_row;
 	for (int r = 0; r < n_obs; r++) { d.obs_pose.push_back(-1); d.obs_lm.push_back(row_bf_col[r] >= 0 ? row_bf_col[r] : 0); d.obs_valid.push_back(r); }
 	d.colp_off.assign(1, 0);
-	for (int c = 0; c < nK; c++) { for (int r = 0; r < n_obs; r++) if (row_bp_col[r] == c) { d.bp_col.push_back(c); d.bp_res.push_back(r); d.bp_A.push_back(-1); d.bp_D.push_back(-1); d.bp_lm.push_back(d.obs_lm[r]); d.bp_normal.push_back(1); bp_row.push_back(r); } d.colp_off.push_back((int32_t)d.bp_col.size()); }
+	for (int c = 0; c < nK; c++) { for (int r = 0; r < n_obs; r++) if (row_bp_col[r] == c) { d.bp_col.push_back(c); d.bp_res.push_back(r); d.bp_A.push_back(-1); d.bp_D.push_back(-1);
+		d.bp_lm.push_back(d.obs_lm[r]); d.bp_normal.push_back(1); bp_row.push_back(r); } d.colp_off.push_back((int32_t)d.bp_col.size()); }
 	d.colf_off.assign(1, 0);
-	for (int c = 0; c < nF; c++) { for (int r = 0; r < n_obs; r++) if (row_bf_col[r] == c) { d.bf_col.push_back(c); d.bf_res.push_back(r); d.bf_pose.push_back(-1); bf_row.push_back(r); } d.colf_off.push_back((int32_t)d.bf_col.size()); }
+	for (int c = 0; c < nF; c++) { for (int r = 0; r < n_obs; r++) if (row_bf_col[r] == c) { d.bf_col.push_back(c); d.bf_res.push_back(r); d.bf_pose.push_back(-1); bf_row.push_back(r); }
+		d.colf_off.push_back((int32_t)d.bf_col.size()); }
 	d.build_plan(bp_row, bf_row, with_schur != 0);
 	cf->views.push_back(d.view());
 	return cf;
@@ -344,11 +367,13 @@ void *srba_capsule_clone(const srba_problem_capsule *caps, int64_t n, int family
 		CP(edge_pose, c.edge_pose, (size_t)c.n_edges * PD); CP(ulm_pos, c.ulm_pos, (size_t)c.n_unk_lms * L); CP(klm_pos, c.klm_pos, (size_t)c.n_known_lms * L); CP(obs_z, c.obs_z, (size_t)c.n_obs * O);
 		CP(pair_path_off, c.pair_path_off, c.n_pairs + 1); CP(path_edge, c.path_edge, c.n_path); CP(pair_needed, c.pair_needed, c.n_pairs); CP(pose_required, c.pose_required, 2 * c.n_pairs);
 		CP(obs_pose, c.obs_pose, c.n_obs); CP(obs_lm, c.obs_lm, c.n_obs); CP(obs_valid, c.obs_valid, c.n_obs);
-		CP(bp_col, c.bp_col, c.n_bp); CP(bp_res, c.bp_res, c.n_bp); CP(bp_A, c.bp_A, c.n_bp); CP(bp_D, c.bp_D, c.n_bp); CP(bp_lm, c.bp_lm, c.n_bp); CP(bp_normal, c.bp_normal, c.n_bp); CP(colp_off, c.colp_off, c.n_unk_edges + 1);
+		CP(bp_col, c.bp_col, c.n_bp); CP(bp_res, c.bp_res, c.n_bp); CP(bp_A, c.bp_A, c.n_bp); CP(bp_D, c.bp_D, c.n_bp); CP(bp_lm, c.bp_lm, c.n_bp); CP(bp_normal, c.bp_normal, c.n_bp); CP(colp_off,
+			c.colp_off, c.n_unk_edges + 1);
 		CP(bf_col, c.bf_col, c.n_bf); CP(bf_res, c.bf_res, c.n_bf); CP(bf_pose, c.bf_pose, c.n_bf); CP(colf_off, c.colf_off, c.n_unk_lms + 1);
 		CP(hap_i, c.hap_i, c.n_hap); CP(hap_j, c.hap_j, c.n_hap); CP(hap_term_off, c.hap_term_off, c.n_hap + 1); CP(hap_t1, c.hap_t1, c.n_hap_terms); CP(hap_t2, c.hap_t2, c.n_hap_terms);
 		CP(hf_i, c.hf_i, c.n_hf); CP(hf_j, c.hf_j, c.n_hf); CP(hf_term_off, c.hf_term_off, c.n_hf + 1); CP(hf_t1, c.hf_t1, c.n_hf_terms); CP(hf_t2, c.hf_t2, c.n_hf_terms);
-		CP(hapf_i, c.hapf_i, c.n_hapf); CP(hapf_j, c.hapf_j, c.n_hapf); CP(hapf_term_off, c.hapf_term_off, c.n_hapf + 1); CP(hapf_t1, c.hapf_t1, c.n_hapf_terms); CP(hapf_t2, c.hapf_t2, c.n_hapf_terms);
+		CP(hapf_i, c.hapf_i, c.n_hapf); CP(hapf_j, c.hapf_j, c.n_hapf); CP(hapf_term_off, c.hapf_term_off, c.n_hapf + 1); CP(hapf_t1, c.hapf_t1, c.n_hapf_terms); CP(hapf_t2, c.hapf_t2,
+			c.n_hapf_terms);
 		CP(hap_diag, c.hap_diag, c.n_unk_edges); CP(hf_diag, c.hf_diag, c.n_unk_lms);
 		if (c.sch_term_off) { CP(sch_term_off, c.sch_term_off, c.n_hap + 1); CP(sch_b1, c.sch_b1, c.n_sch_terms); CP(sch_b2, c.sch_b2, c.n_sch_terms); CP(sch_lm, c.sch_lm, c.n_sch_terms); }
 		CP(lm_hapf_off, c.lm_hapf_off, c.n_unk_lms + 1); CP(lm_hapf_idx, c.lm_hapf_idx, c.n_hapf);

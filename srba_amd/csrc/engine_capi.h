@@ -23,7 +23,8 @@ typedef struct srba_engine_config {
 	int32_t run_local_optimization;                      /* 3rd argument of define_new_keyframe */
 	int32_t harvest;                                     /* bit0: keep a copy of every optimize_local_area capsule; bit1: of stage-1 capsules */
 	int32_t verbose, enable_profiler, hip_device;
-	int32_t refresh_all_read_poses;                      /* extensions (default 0 = reference behaviour), see RbaEngine.h TSRBAParameters: bit 0 refresh_all_read_poses, bit 1 restore_spanning_tree_twins, bit 2 schur_keeps_gradient, bit 3 consistent_loop_closure_init */
+	int32_t refresh_all_read_poses;                      /* extensions (default 0 = reference behaviour), see RbaEngine.h TSRBAParameters: bit 0 refresh_all_read_poses,
+		bit 1 restore_spanning_tree_twins, bit 2 schur_keeps_gradient, bit 3 consistent_loop_closure_init */
 	int32_t ecp;                                         /* RBA_OPTIONS::edge_creation_policy_t: 0 ecps::local_areas_fixed_size (default), 1 ecps::classic_linear_rba */
 } srba_engine_config;
 

@@ -33,7 +33,8 @@ template <int LAMBDA> __device__ __forceinline__ void asm_lambda_k(double (&M)[9
 	if constexpr (LAMBDA == 1) { M[0] = l[0] * b[0]; M[1] = l[0] * b[1]; M[2] = l[0] * b[2]; M[3] = -(l[4] * b[1]); M[4] = l[4] * b[0]; M[5] = l[4] * b[3]; M[6] = 0; M[7] = 0; M[8] = l[8]; }
 	else if constexpr (LAMBDA == 2) {
 #pragma unroll
-		for (int k = 0; k < 3; k++) { M[3 * k] = l[3 * k] * b[0] - l[3 * k + 1] * b[1]; M[3 * k + 1] = l[3 * k] * b[1] + l[3 * k + 1] * b[0]; M[3 * k + 2] = l[3 * k] * b[2] + l[3 * k + 1] * b[3] + l[3 * k + 2]; }
+		for (int k = 0; k < 3; k++) { M[3 * k] = l[3 * k] * b[0] - l[3 * k + 1] * b[1]; M[3 * k + 1] = l[3 * k] * b[1] + l[3 * k + 1] * b[0];
+			M[3 * k + 2] = l[3 * k] * b[2] + l[3 * k + 1] * b[3] + l[3 * k + 2]; }
 	} else { M[0] = b[0]; M[1] = b[1]; M[2] = b[2]; M[3] = -b[1]; M[4] = b[0]; M[5] = b[3]; M[6] = 0; M[7] = 0; M[8] = 1; }
 }
 // H = K(a)^t * M (row-major 3 x 3)
@@ -110,7 +111,8 @@ __global__ void __launch_bounds__(64 * ASM_WAVES_PER_WG) __attribute__((amdgpu_w
 	double *K4 = srba_lds + (d.lds_off >> 3), *Hb = K4 + 4 * nslot, *gb = Hb + (STAGE ? 9 * n_hap : 0), *eb = gb + 3 * nK;
 	double *Hglob = B.HAp + d.o_hap * 9;
 	const double *lam = prm.lambda; // wave-uniform: stays in scalar registers
-	const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0; const bool latch = prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL, keep = (prm.ext & SRBA_EXT_SCHUR_KEEPS_GRADIENT) != 0;
+	const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0; const bool latch = prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL,
+		keep = (prm.ext & SRBA_EXT_SCHUR_KEEPS_GRADIENT) != 0;
 	double dmax = 0;
 	const double *pose0 = B.pose + d.o_pose, *edge0 = B.edge + d.o_edge, *res0 = B.resid + d.o_res;
 	const unsigned long long *br = T.blk + d.o_bp, *tr = T.term + d.o_hapt;
@@ -151,7 +153,8 @@ __global__ void __launch_bounds__(64 * ASM_WAVES_PER_WG) __attribute__((amdgpu_w
 #pragma unroll
 		for (int u = 0; u < U; u++) if (s0 + u < cb) {
 			const unsigned lo = (unsigned)m[u], hi = (unsigned)(m[u] >> 32); const int iD = (int)(lo & 0xffff) - 1;
-			const double *pd = pose0 + (unsigned)max(iD, 0) * PD; if (!(SRBA_ASM_KO & 4)) { ldn<2>(D[u], pd); ldn<2>(D[u] + 2, pd + 3); } else { D[u][0] = (double)lo; D[u][1] = 1; D[u][2] = 0.6; D[u][3] = 0.8; }
+			const double *pd = pose0 + (unsigned)max(iD, 0) * PD; if (!(SRBA_ASM_KO & 4)) { ldn<2>(D[u], pd); ldn<2>(D[u] + 2, pd + 3); } else { D[u][0] = (double)lo; D[u][1] = 1; D[u][2] = 0.6;
+				D[u][3] = 0.8; }
 			if (!(SRBA_ASM_KO & 2)) ldn<3>(r[u], res0 + (hi & 0xffff) * 3); else { r[u][0] = (double)hi; r[u][1] = 1; r[u][2] = 2; }
 		}
 		ASM_TICK(5, s0 == 0);
@@ -242,7 +245,8 @@ __global__ void __launch_bounds__(64 * ASM_WAVES_PER_WG) __attribute__((amdgpu_w
 int asm_launch(int lambda_mode, int n_bins, size_t lds_bytes, hipStream_t stream, const Batch &B, const DevParams &prm, const AsmTables &T) {
 	static bool attr_done[3] = {false, false, false}; // the bins are larger than the 64 KB a launch may ask for by default
 	auto go = [&](auto kernel, int which) -> int {
-		if (lds_bytes > 64 * 1024 && !attr_done[which]) { hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_BIN_BYTES); if (e != hipSuccess) return (int)e; attr_done[which] = true; }
+		if (lds_bytes > 64 * 1024 && !attr_done[which]) { hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_BIN_BYTES);
+			if (e != hipSuccess) return (int)e; attr_done[which] = true; }
 		hipLaunchKernelGGL(kernel, dim3(n_bins), dim3(64 * ASM_WAVES_PER_WG), lds_bytes, stream, B, prm, T);
 		return (int)hipGetLastError();
 	};

@@ -13,7 +13,8 @@
  *      D pose, unknown slot, residual row, direction, diagonal Hessian block), gathers the keyframe-relative pose D (and the edge's own pose for an inverse edge) and
  *      the residual row, and forms the block in registers. A block of this family is
  *          J = sg * K,  K = [ c  s  x s - y c ;  -s  c  x c + y s ;  0 0 1 ]      (c, s, x, y of D' = D or p (+) D; the device keeps cos / sin next to every pose)
- *      i.e. FOUR numbers and a sign: the numbers go to LDS (four planes: no bank conflicts), the sign stays in the records. J^t Lambda r (gradient) and J^t Lambda J (the term this block adds to the diagonal Hessian block of its unknown) are summed
+ *      i.e. FOUR numbers and a sign: the numbers go to LDS (four planes: no bank conflicts), the sign stays in the records. J^t Lambda r (gradient) and J^t Lambda J (the term this block adds to the
+ 	diagonal Hessian block of its unknown) are summed
  *      over the run of blocks of the unknown: serially inside a lane, and -- for a run that crosses lanes -- through ONE prefix scan over the wavefront per capsule;
  *      the lane that holds the last block of the run puts the unknown's gradient and diagonal block into the LDS image.
  *   B  every lane owns ct consecutive OFF-DIAGONAL terms (the list is sorted by Hessian block; its first records were requested before phase A): J1^t Lambda J2 from
@@ -33,10 +34,12 @@
 namespace srbadev {
 
 // per wavefront of every bin (workgroup), in launch order. cb / ct: consecutive blocks / off-diagonal terms per lane (ceil(n / 64)); block b lives in LDS slot (b % cb) * 64 + b / cb
-struct AsmDesc { int pidx /* -1: this wavefront of the bin has no capsule */, n_bp, n_terms /* off-diagonal */, cb, ct, n_hap, nK, stage /* its Hessian blocks are staged in LDS */, lds_off /* bytes: its image inside the bin */, pad; long long o_bp, o_hapt, o_pose /* doubles */, o_edge /* doubles */, o_res /* doubles */, o_hap, o_scal; };
+struct AsmDesc { int pidx /* -1: this wavefront of the bin has no capsule */, n_bp, n_terms /* off-diagonal */, cb, ct, n_hap, nK, stage /* its Hessian blocks are staged in LDS */,
+	lds_off /* bytes: its image inside the bin */, pad; long long o_bp, o_hapt, o_pose /* doubles */, o_edge /* doubles */, o_res /* doubles */, o_hap, o_scal; };
 // blk : per Jacobian block, sorted by unknown   lo = (D pose index + 1) | unknown slot << 16 | inverse << 29 | first block of its unknown << 30 | last << 31
 //                                               hi = residual row | index of the unknown's diagonal Hessian block << 16
-// term: per OFF-DIAGONAL U_Ap term, sorted by Hessian block   lo = LDS slot of block t1 | (the two blocks have opposite directions) << 15 | slot of t2 << 16 ;  hi = Hessian block | first term of its block << 30 | last << 31
+// term: per OFF-DIAGONAL U_Ap term, sorted by Hessian block   lo = LDS slot of block t1 | (the two blocks have opposite directions) << 15 | slot of t2 << 16 ;
+	// hi = Hessian block | first term of its block << 30 | last << 31
 //       (the terms of a diagonal block pair every Jacobian block of the unknown with itself: they are formed with the blocks, in phase A)
 struct AsmTables { const AsmDesc *desc; const unsigned long long *blk, *term; };
 constexpr int ASM_WAVES_PER_WG = 2, ASM_BIN_BYTES = 40 * 1024; // four bins per CU (160 KB of LDS), eight wavefronts

@@ -31,7 +31,8 @@ constexpr int kGang = 32, kBigPart = 4096;
 struct Gang { int p[kGang]; int ld[kGang]; int nsys[kGang]; double *A[kGang]; unsigned mask; int n; double *part; double *scal; int *iscal; };
 enum { BS_CHI2 = 0, BS_MAXDIAG = 1, BS_DEN = 2, BS_NINF = 3, BS_LAMBDA = 4 }; // scal[w * 16 + .]; iscal[w * 8 + .] = {invalid Jacobians, not-positive-definite flag}
 __device__ __forceinline__ BigSys gang_sys(const Gang &G, int w) {
-	BigSys S; const int ld = G.ld[w]; S.A = G.A[w]; S.Ldiag = S.A + (size_t)ld * ld; S.rhs = S.Ldiag + (size_t)ld * CB; S.y = S.rhs + ld; S.flag = G.iscal + w * 8 + 1; S.n = G.nsys[w]; S.ld = ld; return S;
+	BigSys S; const int ld = G.ld[w]; S.A = G.A[w]; S.Ldiag = S.A + (size_t)ld * ld; S.rhs = S.Ldiag + (size_t)ld * CB; S.y = S.rhs + ld; S.flag = G.iscal + w * 8 + 1; S.n = G.nsys[w]; S.ld = ld;
+		return S;
 }
 __device__ __forceinline__ int big_grid_dev(long long items, int block) { const long long g = (items + block - 1) / block; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 #define BIG_ENTER() const int gw = blockIdx.y; if (!((G.mask >> gw) & 1u)) return; const int p = G.p[gw]
@@ -53,7 +54,8 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 // the critical path. Lanes >= CB may carry extra rows b^t of an augmented matrix [A b; b^t .]: they come out as (L^-1 b)^t, i.e. the forward substitution of a
 // right-hand side rides along for free. rinv[j] = 1 / L_jj (every lane). Uniform result.
 __device__ __forceinline__ bool chol_block_regs(double (&a)[CB], double (&rinv)[CB], int lane) {
-	bool ok = true; // no branch inside the chain: with one per pivot the compiler sinks the updates of later columns past it to their uses and keeps every broadcast L_kj alive (SGPRs spilled to VGPR lanes); a bad pivot turns the rest into NaNs, which nobody reads
+	bool ok = true; // no branch inside the chain: with one per pivot the compiler sinks the updates of later columns past it to their uses and keeps every broadcast L_kj alive (SGPRs spilled to VGPR
+		// lanes); a bad pivot turns the rest into NaNs, which nobody reads
 #pragma unroll
 	for (int j = 0; j < CB; j++) {
 		const double d = lane_bcast(a[j], j);
@@ -63,7 +65,8 @@ __device__ __forceinline__ bool chol_block_regs(double (&a)[CB], double (&rinv)[
 		a[j] = l;
 #pragma unroll
 		for (int k = j + 1; k < CB; k++) { a[k] -= l * lane_bcast(l, k); /* only the lower part (lane >= k) is ever read back */ if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
-		__builtin_amdgcn_sched_barrier(0); // (and every four columns above) the scheduler otherwise issues all v_readlane of a pivot step first: 62 SGPRs live, spilled to VGPR lanes and read back -- three instructions per value instead of one
+		__builtin_amdgcn_sched_barrier(0); // (and every four columns above) the scheduler otherwise issues all v_readlane of a pivot step first: 62 SGPRs live,
+			// spilled to VGPR lanes and read back -- three instructions per value instead of one
 	}
 	return ok;
 }
@@ -193,14 +196,17 @@ __device__ __forceinline__ bool chol_block_solve_regs(double (&a)[CB], double (&
 		a[j] = l;
 		const double xj = x[j] * r; x[j] = xj;
 #pragma unroll
-		for (int k = j + 1; k < CB; k++) { const double lk = lane_bcast(l, k); a[k] -= l * lk; x[k] -= xj * lk; asm volatile("" : "+v"(a[k]), "+v"(x[k])); /* pins the pair where the broadcast is: instruction selection otherwise emits the whole factorisation first and the substitution after it, every L_kj kept (spilled) for the second pass */ }
+		for (int k = j + 1; k < CB; k++) { const double lk = lane_bcast(l, k); a[k] -= l * lk; x[k] -= xj * lk; asm volatile("" : "+v"(a[k]), "+v"(x[k]));
+			/* pins the pair where the broadcast is: instruction selection otherwise emits the whole factorisation first and the substitution after it,
+			every L_kj kept (spilled) for the second pass */ }
 		__builtin_amdgcn_sched_barrier(0); // (as in chol_block_regs: no SGPR spills)
 	}
 #pragma unroll
 	for (int j = 0; j < CB; j++) acc += x[j] * lane_bcast(a[j], CB); // lane CB carried the right-hand side: its row is y_k now
 	return ok;
 }
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_chol_step(const Gang G, int k0) { // two workgroups per CU: left alone the kernel takes 232 + 32 registers -- eight over the budget that lets a second workgroup in -- and the many tile workgroups of the early steps queue behind one another
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_chol_step(const Gang G, int k0) { // two workgroups per CU: left alone the kernel takes 232 + 32 registers -- eight
+	// over the budget that lets a second workgroup in -- and the many tile workgroups of the early steps queue behind one another
 	__shared__ double sh[2 * CT * (CB + 1)];
 	BIG_ENTER(); (void)p; const BigSys S = gang_sys(G, gw);
 	const int ld = S.ld, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
@@ -303,7 +309,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 		if (w != 0) return;
 		const double *rh = (const double *)__builtin_assume_aligned(S.rhs + k0, 16);
 #pragma unroll
-		for (int c = 0; c < CB; c++) { x[c] = has_row ? Xo[lane * (CB + 1) + c] : 0.0; const double v = Xk[(lane & (CB - 1)) * (CB + 1) + c], bb = rh[c]; a[c] = lane < CB ? (c <= lane ? v : 0.0) : (lane == CB ? bb : 0.0); }
+		for (int c = 0; c < CB; c++) { x[c] = has_row ? Xo[lane * (CB + 1) + c] : 0.0; const double v = Xk[(lane & (CB - 1)) * (CB + 1) + c], bb = rh[c];
+			a[c] = lane < CB ? (c <= lane ? v : 0.0) : (lane == CB ? bb : 0.0); }
 	}
 	double acc = 0;
 	if (!chol_block_solve_regs(a, x, acc, lane)) { if (b == 0 && lane == 0) *S.flag = 1; return; }
@@ -578,10 +585,13 @@ template <int FAM> __global__ void __launch_bounds__(128) kb_hessian(const Batch
 	for (int b = BIG_GID(); b < total; b += BIG_STRIDE()) {
 		if (b < d.n_hap) {
 			const int tb = B.hap_term_off[d.o_hapoff + b], te = B.hap_term_off[d.o_hapoff + b + 1]; if (te - tb > BIG_HEAVY) continue;
-			const long long g = d.o_hap + b; ninv += Wk.template hess_block<P, P>(B.HAp + g * P * P, latch ? B.HAp0 + g * P * P : nullptr, B.hap_t1 + d.o_hapt, B.hap_t2 + d.o_hapt, tb, te, Jp, Jp, rp, rp); }
+			const long long g = d.o_hap + b; ninv += Wk.template hess_block<P, P>(B.HAp + g * P * P, latch ? B.HAp0 + g * P * P : nullptr, B.hap_t1 + d.o_hapt, B.hap_t2 + d.o_hapt, tb, te, Jp, Jp,
+				rp, rp); }
 		else if constexpr (!W::T::REL) {
-			if (b < d.n_hap + d.n_hf) { const int q = b - d.n_hap; ninv += Wk.template hess_block<L, L>(B.Hf + (d.o_hf + q) * L * L, nullptr, B.hf_t1 + d.o_hft, B.hf_t2 + d.o_hft, B.hf_term_off[d.o_hfoff + q], B.hf_term_off[d.o_hfoff + q + 1], Jf, Jf, rf, rf); }
-			else { const int q = b - d.n_hap - d.n_hf; ninv += Wk.template hess_block<P, L>(B.HApf + (d.o_hapf + q) * P * L, nullptr, B.hapf_t1 + d.o_hapft, B.hapf_t2 + d.o_hapft, B.hapf_term_off[d.o_hapfoff + q], B.hapf_term_off[d.o_hapfoff + q + 1], Jp, Jf, rp, rf); }
+			if (b < d.n_hap + d.n_hf) { const int q = b - d.n_hap; ninv += Wk.template hess_block<L, L>(B.Hf + (d.o_hf + q) * L * L, nullptr, B.hf_t1 + d.o_hft, B.hf_t2 + d.o_hft,
+				B.hf_term_off[d.o_hfoff + q], B.hf_term_off[d.o_hfoff + q + 1], Jf, Jf, rf, rf); }
+			else { const int q = b - d.n_hap - d.n_hf; ninv += Wk.template hess_block<P, L>(B.HApf + (d.o_hapf + q) * P * L, nullptr, B.hapf_t1 + d.o_hapft, B.hapf_t2 + d.o_hapft,
+				B.hapf_term_off[d.o_hapfoff + q], B.hapf_term_off[d.o_hapfoff + q + 1], Jp, Jf, rp, rf); }
 		}
 	}
 	if (ninv) atomicAdd(ninv_out, ninv);
@@ -634,15 +644,18 @@ __global__ void __launch_bounds__(256) kb_reduce(const Batch B, const Gang G, in
 }
 struct GangLambda { double v[kGang]; };
 __global__ void kb_set_lambda(const Gang G, const GangLambda lam) { const int w = threadIdx.x; if (w < kGang && ((G.mask >> w) & 1u)) G.scal[w * 16 + BS_LAMBDA] = lam.v[w]; }
-// what the host path did with device-to-device copies, for all windows of a gang at once: 0 = grad0 -> grad, 1 = grad -> grad0 (extension: the Schur kernels reduce grad in place), 2 = residuals of the accepted trial -> current
+// what the host path did with device-to-device copies, for all windows of a gang at once: 0 = grad0 -> grad, 1 = grad -> grad0 (extension: the Schur kernels reduce grad in place),
+	// 2 = residuals of the accepted trial -> current
 __global__ void __launch_bounds__(256) kb_copy_vec(const Batch B, const Gang G, int kind, int O) {
 	BIG_ENTER(); const ProbDesc &d = B.desc[p];
-	if (kind == 2) { const double *s = B.resid2 + (long long)d.o_obs * O; double *t = B.resid + (long long)d.o_obs * O; for (long long k = BIG_GID(); k < (long long)d.n_obs * O; k += BIG_STRIDE()) t[k] = s[k]; }
+	if (kind == 2) { const double *s = B.resid2 + (long long)d.o_obs * O; double *t = B.resid + (long long)d.o_obs * O; for (long long k = BIG_GID(); k < (long long)d.n_obs * O;
+		k += BIG_STRIDE()) t[k] = s[k]; }
 	else { const double *s = (kind == 0 ? B.grad0 : B.grad) + d.o_scal; double *t = (kind == 0 ? B.grad : B.grad0) + d.o_scal; for (int k = BIG_GID(); k < d.n_scal; k += BIG_STRIDE()) t[k] = s[k]; }
 }
 template <int O, int M> __device__ __forceinline__ void grad_term(double (&acc)[M], const double *A, const double *r, const DevParams &prm) {
 	double lr[O], a[O * M]; ldn<O>(lr, r); ldn<O * M>(a, A);
-	if (prm.noise == SRBA_NOISE_CONSTANT_MATRIX) { double t[O]; for (int k = 0; k < O; k++) { double q = 0; for (int j = 0; j < O; j++) q += prm.lambda[k * O + j] * lr[j]; t[k] = q; } for (int k = 0; k < O; k++) lr[k] = t[k]; }
+	if (prm.noise == SRBA_NOISE_CONSTANT_MATRIX) { double t[O]; for (int k = 0; k < O; k++) { double q = 0; for (int j = 0; j < O; j++) q += prm.lambda[k * O + j] * lr[j]; t[k] = q; } for (int k = 0;
+		k < O; k++) lr[k] = t[k]; }
 #pragma unroll
 	for (int q = 0; q < M; q++) { double sm = 0;
 #pragma unroll
@@ -672,7 +685,8 @@ template <int FAM> __global__ void __launch_bounds__(256) kb_gradient(const Batc
 		double acc[L];
 #pragma unroll
 		for (int q = 0; q < L; q++) acc[q] = 0;
-		for (int b = B.colf_off[d.o_colf + ci]; b < B.colf_off[d.o_colf + ci + 1]; b++) grad_term<O, L>(acc, B.Jf + (long long)(d.o_bf + b) * O * L, resid + (long long)(d.o_obs + B.bf_res[d.o_bf + b]) * O, prm);
+		for (int b = B.colf_off[d.o_colf + ci]; b < B.colf_off[d.o_colf + ci + 1]; b++) grad_term<O, L>(acc, B.Jf + (long long)(d.o_bf + b) * O * L,
+			resid + (long long)(d.o_obs + B.bf_res[d.o_bf + b]) * O, prm);
 		for (int q = 0; q < L; q++) g[d.nK * P + ci * L + q] = acc[q] * sc;
 	}
 }
@@ -720,7 +734,8 @@ template <int FAM> __global__ void __launch_bounds__(128) kb_schur_inv(const Bat
 }
 // H_Ap(i,j) -= sum_l W_il Hf_l^-1 W_jl^t (schur.h:213-260). One workgroup per U_Ap block: the terms (landmarks seen through both edges, up to
 // all of them for a diagonal block) are strided over the 256 threads, each term writes its own Y = W Hf^-1 where the gradient / back-substitution need it.
-template <int FAM> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) kb_schur_reduce(const Batch B, const DevParams prm, const Gang G) { // (172 registers left to itself: two wavefronts per SIMD; the launch waits for its gathers)
+template <int FAM> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) kb_schur_reduce(const Batch B, const DevParams prm, const Gang G) {
+	// (172 registers left to itself: two wavefronts per SIMD; the launch waits for its gathers)
 	BIG_ENTER();
 	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L; const ProbDesc &d = B.desc[p];
 	if constexpr (!W::T::REL) {
@@ -735,7 +750,8 @@ template <int FAM> __global__ void __launch_bounds__(256) __attribute__((amdgpu_
 			const int l = B.sch_lm[d.o_sch + t]; if (!B.hf_ok[d.o_ulm + l]) continue;
 			const double *W1 = B.HApf + (d.o_hapf + B.sch_b1[d.o_sch + t]) * P * L, *W2 = B.HApf + (d.o_hapf + B.sch_b2[d.o_sch + t]) * P * L, *Hi = B.Hfinv + (d.o_ulm + l) * L * L;
 			double Y[P * L], w1[P * L], w2[P * L], hi[L * L];
-			ldn<P * L>(w1, W1); ldn<P * L>(w2, W2); ldn<L * L>(hi, Hi); // 16-byte requests at 8-byte alignment: the launch is bound by the gathers' address traffic (every lane its own blocks), not by flops, L2 locality or the reductions (profiles/r04_cfg4_schur_reduce_variants.txt)
+			ldn<P * L>(w1, W1); ldn<P * L>(w2, W2); ldn<L * L>(hi, Hi); // 16-byte requests at 8-byte alignment: the launch is bound by the gathers' address traffic (every lane its own blocks),
+				// not by flops, L2 locality or the reductions (profiles/r04_cfg4_schur_reduce_variants.txt)
 #pragma unroll
 			for (int i = 0; i < P; i++)
 #pragma unroll
@@ -802,7 +818,8 @@ template <int FAM> __global__ void __launch_bounds__(128) kb_schur_features(cons
 	}
 }
 // (H + lambda I) into the dense lower triangle + right-hand side; identity padding up to ld
-__global__ void kb_dense_clear(const Gang G) { BIG_ENTER(); (void)p; const BigSys S = gang_sys(G, gw); for (size_t k = BIG_GID(); k < (size_t)S.ld * S.ld; k += BIG_STRIDE()) { const int r = (int)(k / S.ld), c = (int)(k % S.ld); S.A[k] = (r == c && r >= S.n) ? 1.0 : 0.0; } if (BIG_GID() == 0) *S.flag = 0; }
+__global__ void kb_dense_clear(const Gang G) { BIG_ENTER(); (void)p; const BigSys S = gang_sys(G, gw); for (size_t k = BIG_GID(); k < (size_t)S.ld * S.ld; k += BIG_STRIDE()) {
+	const int r = (int)(k / S.ld), c = (int)(k % S.ld); S.A[k] = (r == c && r >= S.n) ? 1.0 : 0.0; } if (BIG_GID() == 0) *S.flag = 0; }
 template <int FAM> __global__ void __launch_bounds__(128) kb_dense_assemble(const Batch B, const DevParams prm, const Gang G, int full_system) {
 	BIG_ENTER(); const BigSys S = gang_sys(G, gw);
 	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L; const ProbDesc &d = B.desc[p]; const double lambda = G.scal[gw * 16 + BS_LAMBDA];
@@ -816,13 +833,15 @@ template <int FAM> __global__ void __launch_bounds__(128) kb_dense_assemble(cons
 			for (int r = 0; r < P; r++) for (int q = 0; q < L; q++) S.A[(size_t)(P * d.nK + L * j + q) * S.ld + P * i + r] = H[r * L + q];
 		} else {
 			const int q0 = b - d.n_hap - d.n_hapf, i = B.hf_i[d.o_hf + q0], j = B.hf_j[d.o_hf + q0]; const double *H = B.Hf + (d.o_hf + q0) * L * L;
-			for (int r = 0; r < L; r++) for (int q = 0; q < L; q++) { if (i == j && q < r) continue; S.A[(size_t)(P * d.nK + L * j + q) * S.ld + P * d.nK + L * i + r] = H[r * L + q] + ((i == j && r == q) ? lambda : 0.0); }
+			for (int r = 0; r < L; r++) for (int q = 0; q < L; q++) { if (i == j && q < r) continue; S.A[(size_t)(P * d.nK + L * j + q) * S.ld + P * d.nK + L * i + r] = H[r * L + q] + ((i == j && r
+				== q) ? lambda : 0.0); }
 		}
 	}
 	const double *g = B.grad + d.o_scal;
 	for (int k = BIG_GID(); k < S.ld; k += BIG_STRIDE()) S.rhs[k] = k < S.n ? g[k] : 0.0;
 }
-__global__ void kb_take_delta(const Batch B, const Gang G) { BIG_ENTER(); const BigSys S = gang_sys(G, gw); if (*S.flag) return; const ProbDesc &d = B.desc[p]; double *dl = B.delta + d.o_scal; for (int k = BIG_GID(); k < d.n_scal; k += BIG_STRIDE()) if (k < S.n) dl[k] = S.y[k]; else if (S.n == d.n_scal) dl[k] = 0; }
+__global__ void kb_take_delta(const Batch B, const Gang G) { BIG_ENTER(); const BigSys S = gang_sys(G, gw); if (*S.flag) return; const ProbDesc &d = B.desc[p]; double *dl = B.delta + d.o_scal;
+	for (int k = BIG_GID(); k < d.n_scal; k += BIG_STRIDE()) if (k < S.n) dl[k] = S.y[k]; else if (S.n == d.n_scal) dl[k] = 0; }
 // K12 backup + K11 apply / restore
 template <int FAM> __global__ void __launch_bounds__(128) kb_apply(const Batch B, const DevParams prm, const Gang G, int use_skip) {
 	BIG_ENTER();
@@ -831,7 +850,8 @@ template <int FAM> __global__ void __launch_bounds__(128) kb_apply(const Batch B
 	for (int i = BIG_GID(); i < d.nK + d.nF * L + d.n_req; i += BIG_STRIDE()) {
 		if (i < d.nK) { double *e = B.edge + (d.o_edge + i) * PD, *o = B.old_edge + (d.o_unk + i) * PD; for (int k = 0; k < PD; k++) o[k] = e[k]; PO::st(e, comp(PO::expm(dl + i * P), PO::ld(e))); }
 		else if (i < d.nK + d.nF * L) { const int k = i - d.nK; B.old_ulm[d.o_ulm * L + k] = B.ulm[d.o_ulm * L + k]; B.ulm[d.o_ulm * L + k] += dl[d.nK * P + k]; }
-		else { const int r = i - d.nK - d.nF * L; const double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD; double *o = B.old_pose + (d.o_req + r) * PD; for (int k = 0; k < PD; k++) o[k] = s[k]; }
+		else { const int r = i - d.nK - d.nF * L; const double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD; double *o = B.old_pose + (d.o_req + r) * PD; for (int k = 0; k < PD;
+			k++) o[k] = s[k]; }
 	}
 }
 template <int FAM> __global__ void __launch_bounds__(128) kb_restore(const Batch B, const DevParams prm, const Gang G) {
@@ -840,7 +860,8 @@ template <int FAM> __global__ void __launch_bounds__(128) kb_restore(const Batch
 	for (int i = BIG_GID(); i < d.nK + d.nF * L + d.n_req; i += BIG_STRIDE()) {
 		if (i < d.nK) { for (int k = 0; k < PD; k++) B.edge[(d.o_edge + i) * PD + k] = B.old_edge[(d.o_unk + i) * PD + k]; }
 		else if (i < d.nK + d.nF * L) { const int k = i - d.nK; B.ulm[d.o_ulm * L + k] = B.old_ulm[d.o_ulm * L + k]; }
-		else { const int r = i - d.nK - d.nF * L; double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD; const double *o = B.old_pose + (d.o_req + r) * PD; for (int k = 0; k < PD; k++) s[k] = o[k]; }
+		else { const int r = i - d.nK - d.nF * L; double *s = B.pose + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD; const double *o = B.old_pose + (d.o_req + r) * PD; for (int k = 0; k < PD;
+			k++) s[k] = o[k]; }
 	}
 }
 template <int FAM> __global__ void __launch_bounds__(128) kb_cov_recovery(const Batch B, const DevParams prm, const Gang G, int schur_active) {

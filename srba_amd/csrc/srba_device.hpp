@@ -50,35 +50,44 @@ struct ProbDesc {
 	int n_fill; long long o_spfill; // blocks of the factor that no Hessian block maps onto (fill-in): the only ones the assembly has to zero
 	int n_need, need_flat; // pairs whose pose is re-evaluated inside the LM loop (pair_needed != 0); need_flat: all their paths have <= 4 edges (need_rec usable)
 	long long o_hap, o_hapoff, o_hapt, o_hf, o_hfoff, o_hft, o_hapf, o_hapfoff, o_hapft, o_sch, o_lmoff, o_req, o_scal, o_yw, o_spcol, o_sprow, o_spitem, o_spperm, o_dense;
-	int hapt_split; // two wavefronts per capsule: the second one takes the U_Ap terms from this index on (the first term of a Hessian block at or after the middle of the list: no block is summed by both)
+	int hapt_split; // two wavefronts per capsule: the second one takes the U_Ap terms from this index on (the first term of a Hessian block at or after the middle of the list: no block is summed by
+		// both)
 	int n_items, aligned; // block updates per factorisation; 1 if every Hessian block maps onto whole 3x3 blocks (always, except L==2 with the no-Schur solver)
-	int n_panel; long long o_ptab; // ... in n_panel passes over block ranges that fit the LDS of the workgroup (one for most windows): Batch::ptab holds, from o_ptab, the n_panel + 1 block bounds, then the bounds of the panels' K6 terms, then those of their Schur terms (both lists sorted by panel first)
-	int hs_lds; long long o_hapo, o_schl; // workgroup path, U_Ap accumulators in LDS (Solver::phase_hessian_lds / schur_reduce_lds): the U_Ap terms sorted by observation {t1, t2, block} from o_hapo (x3), the Schur terms sorted by landmark {lm, b1, b2, block | edge << 16 | diagonal << 31} from o_schl (x4)
+	int n_panel; long long o_ptab; // ... in n_panel passes over block ranges that fit the LDS of the workgroup (one for most windows): Batch::ptab holds, from o_ptab, the n_panel + 1 block bounds,
+		// then the bounds of the panels' K6 terms, then those of their Schur terms (both lists sorted by panel first)
+	int hs_lds; long long o_hapo, o_schl; // workgroup path, U_Ap accumulators in LDS (Solver::phase_hessian_lds / schur_reduce_lds): the U_Ap terms sorted by observation {t1, t2, block}
+		// from o_hapo (x3), the Schur terms sorted by landmark {lm, b1, b2, block | edge << 16 | diagonal << 31} from o_schl (x4)
 	int n_hrec, hap_chunked /* unused since the workgroup path sums U_Ap in LDS */; long long o_hrec; // K6 work records {U_Ap block, first term, end term} (Batch::hap_rec), one per block
 	int dense_in_lds, dense_blocks; // dense_blocks: the LDS image holds ALL blocks of the lower triangle (column-major), no symbolic structure (mid-size, nearly dense systems)
 };
 
 struct Batch {
-	int n_prob; int max_lds_doubles; int hess_terms; int dense_left; // hess_terms: the fused kernel accumulates U_Ap term-parallel in LDS; dense_left: left-looking sweeps on the HBM-resident dense layout
+	int n_prob; int max_lds_doubles; int hess_terms; int dense_left; // hess_terms: the fused kernel accumulates U_Ap term-parallel in LDS;
+		// dense_left: left-looking sweeps on the HBM-resident dense layout
 	gptr<const ProbDesc> desc; gptr<const int> order; // order: capsule indices grouped by LDS size class (one launch per class)
 	// inputs
 	gptr<const double> edge0, ulm0, klm, obs_z;
 	gptr<const int> pair_path_off, path_edge, obs_pose, obs_lm, obs_valid;
-	gptr<const int> obs_rec; // per observation {-2: identity | -1, pose index: a pose of the table no trial changes | 0 / 1 = which pose of its pair, four path entries (edge << 1 | inverse, -1 = none)}: phase_residuals_fused
+	gptr<const int> obs_rec; // per observation {-2: identity | -1, pose index: a pose of the table no trial changes | 0 / 1 = which pose of its pair, four path entries (edge << 1 | inverse,
+		// -1 = none)}: phase_residuals_fused
 	gptr<const int> bp_col, bp_res, bp_A, bp_D, bp_lm, colp_off, bf_col, bf_res, bf_pose, colf_off;
 	gptr<const int> hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hap_tblk /* block of every U_Ap term */, hf_i, hf_j, hf_term_off, hf_t1, hf_t2;
 	gptr<const int> hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag;
-	gptr<const int> sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw, sch_tblk /* U_Ap block of every Schur term */, lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec; // need_rec: per needed pair {pair, 4 path entries (edge<<1|inv, -1 = none)}
+	gptr<const int> sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw, sch_tblk /* U_Ap block of every Schur term */, lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec;
+		// need_rec: per needed pair {pair, 4 path entries (edge<<1|inv, -1 = none)}
 	gptr<const unsigned char> pair_needed, bp_normal;
 	gptr<const int> sp_fill; // unified block indices (diag k -> k, off-diagonal i -> nb+i)
 	gptr<const int> hapo, schl, ptab; // see ProbDesc::hs_lds, n_panel
 	gptr<const int> hap_rec; // K6 work records, sorted by decreasing term count (longest first: balances the lanes of K6): {block, first term, end term}; ProbDesc::n_hrec of them from o_hrec
-	const int *sp_col_off, *sp_row, *sp_item_off, *sp_tgt /* packed update items: unified target block << 18 | a << 9 | b (packed at upload) */, *sp_rptr, *sp_rcol /* packed row-view entries: column << 14 | off-diagonal block */, *sp_perm; // symbolic factorisation of every capsule's system
+	const int *sp_col_off, *sp_row, *sp_item_off, *sp_tgt /* packed update items: unified target block << 18 | a << 9 | b (packed at upload) */, *sp_rptr,
+		*sp_rcol /* packed row-view entries: column << 14 | off-diagonal block */, *sp_perm; // symbolic factorisation of every capsule's system
 	const int *hap_dst, *hapf_dst, *hf_dst; // destination 3x3 block of every aligned sub-block of the Hessian blocks (see symbolic_factor)
 	// state + workspace
-	double *edge, *ulm, *pose, *Jp, *Jf, *resid, *resid2, *HAp, *HAp0, *Hf, *HApf, *grad, *grad0 /* SRBA_EXT_SCHUR_KEEPS_GRADIENT: the gradient as K5 produced it */, *delta, *Hfinv, *YW, *Yh /* workgroup path: Y = W Hf^-1 of every U_Apf block, written once per solve (schur_reduce) */;
+	double *edge, *ulm, *pose, *Jp, *Jf, *resid, *resid2, *HAp, *HAp0, *Hf, *HApf, *grad, *grad0 /* SRBA_EXT_SCHUR_KEEPS_GRADIENT: the gradient as K5 produced it */, *delta, *Hfinv, *YW,
+		*Yh /* workgroup path: Y = W Hf^-1 of every U_Apf block, written once per solve (schur_reduce) */;
 	double *old_edge, *old_ulm, *old_pose, *dense, *ulm_inf;
-	double *edge1, *ulm1, *pose1; const unsigned char *pose_req; // second copy of the unknowns and of the spanning-tree poses (double-buffered LM loop); per pose: a Jacobian block reads it (list_of_required_num_poses)
+	double *edge1, *ulm1, *pose1; const unsigned char *pose_req; // second copy of the unknowns and of the spanning-tree poses (double-buffered LM loop);
+		// per pose: a Jacobian block reads it (list_of_required_num_poses)
 	int *valid, *first_fail, *hf_ok;
 	unsigned char *bp_ok, *bf_ok; // per Jacobian block: its observation row is valid (set by phase_jacobians, read by phase_hessian)
 	unsigned char *ulm_inf_valid;
@@ -137,7 +146,8 @@ __device__ __forceinline__ P2 ld2(const double *p) { double v[5]; ldn<5>(v, p); 
 __device__ __forceinline__ void st2(double *p, const P2 &a) { const double v[5] = {a.x, a.y, a.phi, a.c, a.s}; stn<5>(p, v); }
 __device__ __forceinline__ P3 ld3(const double *p) { double v[12]; ldn<12>(v, p); P3 r; for (int i = 0; i < 3; i++) r.t[i] = v[i]; for (int i = 0; i < 9; i++) r.R[i] = v[3 + i]; return r; }
 __device__ __forceinline__ void st3(double *p, const P3 &a) { double v[12]; for (int i = 0; i < 3; i++) v[i] = a.t[i]; for (int i = 0; i < 9; i++) v[3 + i] = a.R[i]; stn<12>(p, v); }
-__device__ __forceinline__ P2 comp(const P2 &A, const P2 &B) { P2 r; r.x = A.x + B.x * A.c - B.y * A.s; r.y = A.y + B.x * A.s + B.y * A.c; r.phi = wrap_pi(A.phi + B.phi); r.c = A.c * B.c - A.s * B.s; r.s = A.s * B.c + A.c * B.s; return r; }
+__device__ __forceinline__ P2 comp(const P2 &A, const P2 &B) { P2 r; r.x = A.x + B.x * A.c - B.y * A.s; r.y = A.y + B.x * A.s + B.y * A.c; r.phi = wrap_pi(A.phi + B.phi); r.c = A.c * B.c - A.s * B.s;
+	r.s = A.s * B.c + A.c * B.s; return r; }
 __device__ __forceinline__ P2 inv(const P2 &A) { P2 r; r.x = -A.x * A.c - A.y * A.s; r.y = A.x * A.s - A.y * A.c; r.phi = -A.phi; r.c = A.c; r.s = -A.s; return r; }
 __device__ __forceinline__ P3 comp(const P3 &A, const P3 &B) {
 	P3 r;
@@ -170,11 +180,15 @@ __device__ __forceinline__ P3 exp_se3(const double *v) { // SE_traits<3>::pseudo
 	return r;
 }
 template <bool SE3> struct PoseOps;
-template <> struct PoseOps<false> { typedef P2 T; static __device__ __forceinline__ T ident() { return ident2(); } static __device__ __forceinline__ T ld(const double *p) { return ld2(p); } static __device__ __forceinline__ void st(double *p, const T &a) { st2(p, a); }
-	static __device__ __forceinline__ T from(const double *v) { P2 r; r.x = v[0]; r.y = v[1]; r.phi = v[2]; r.c = v[3]; r.s = v[4]; return r; } static __device__ __forceinline__ void to(double *v, const T &a) { v[0] = a.x; v[1] = a.y; v[2] = a.phi; v[3] = a.c; v[4] = a.s; }
+template <> struct PoseOps<false> { typedef P2 T; static __device__ __forceinline__ T ident() { return ident2(); } static __device__ __forceinline__ T ld(const double *p) { return ld2(p); }
+	static __device__ __forceinline__ void st(double *p, const T &a) { st2(p, a); }
+	static __device__ __forceinline__ T from(const double *v) { P2 r; r.x = v[0]; r.y = v[1]; r.phi = v[2]; r.c = v[3]; r.s = v[4]; return r; } static __device__ __forceinline__ void to(double *v,
+		const T &a) { v[0] = a.x; v[1] = a.y; v[2] = a.phi; v[3] = a.c; v[4] = a.s; }
 	static __device__ __forceinline__ T expm(const double *v) { T r; r.x = v[0]; r.y = v[1]; r.phi = v[2]; sincos(v[2], &r.s, &r.c); return r; } };
-template <> struct PoseOps<true> { typedef P3 T; static __device__ __forceinline__ T ident() { return ident3(); } static __device__ __forceinline__ T ld(const double *p) { return ld3(p); } static __device__ __forceinline__ void st(double *p, const T &a) { st3(p, a); }
-	static __device__ __forceinline__ T from(const double *v) { P3 r; for (int i = 0; i < 3; i++) r.t[i] = v[i]; for (int i = 0; i < 9; i++) r.R[i] = v[3 + i]; return r; } static __device__ __forceinline__ void to(double *v, const T &a) { for (int i = 0; i < 3; i++) v[i] = a.t[i]; for (int i = 0; i < 9; i++) v[3 + i] = a.R[i]; }
+template <> struct PoseOps<true> { typedef P3 T; static __device__ __forceinline__ T ident() { return ident3(); } static __device__ __forceinline__ T ld(const double *p) { return ld3(p); }
+	static __device__ __forceinline__ void st(double *p, const T &a) { st3(p, a); }
+	static __device__ __forceinline__ T from(const double *v) { P3 r; for (int i = 0; i < 3; i++) r.t[i] = v[i]; for (int i = 0; i < 9; i++) r.R[i] = v[3 + i]; return r; }
+		static __device__ __forceinline__ void to(double *v, const T &a) { for (int i = 0; i < 3; i++) v[i] = a.t[i]; for (int i = 0; i < 9; i++) v[3 + i] = a.R[i]; }
 	static __device__ __forceinline__ T expm(const double *v) { return exp_se3(v); } };
 
 // ------------------------------------------------------------------------------------------------ block reductions (deterministic)
@@ -205,12 +219,13 @@ __device__ __forceinline__ double block_max(double v, double *) { return wave_ma
 // ---- capsule GROUPS (round 4): the lanes that work on one capsule. G = 64: one wavefront (every kernel of rounds 1-3). G = 128: TWO wavefronts per capsule (k_lm_run2: the big,
 // LDS-bound windows of a big batch -- their wavefronts sit alone on a SIMD and the launch waits for their latency: the lane-parallel phases go twice as wide, the block-sparse
 // solver stays on the first wavefront). Reductions over a group: per wavefront (DPP tree), then the two totals through two doubles of LDS (`red`) in a fixed order: deterministic.
-template <int G> __device__ __forceinline__ double grp_sum(double v, double *red) { // red: G / 64 doubles of LDS
+template <int G> __device__ __forceinline__ double grp_sum(double v, double *red) { // red: G / 64 doubles of LDS (at most 12)
 	v = wave_sum(v);
-	if constexpr (G > 64) { static_assert(G == 128 || G == 256 || G == 512, "groups of one, two, four or eight wavefronts");
+	if constexpr (G > 64) { static_assert(G % 64 == 0 && G <= 768, "groups of up to twelve wavefronts");
 		if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v; __syncthreads(); v = red[0] + red[1];
 		if constexpr (G > 128) v = v + (red[2] + red[3]);
 		if constexpr (G > 256) v = v + ((red[4] + red[5]) + (red[6] + red[7]));
+		if constexpr (G > 512) v = v + ((red[8] + red[9]) + (red[10] + red[11]));
 		__syncthreads(); }
 	return v;
 }
@@ -219,11 +234,13 @@ template <int G> __device__ __forceinline__ double grp_max(double v, double *red
 	if constexpr (G > 64) { if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v; __syncthreads(); v = fmax(red[0], red[1]);
 		if constexpr (G > 128) v = fmax(v, fmax(red[2], red[3]));
 		if constexpr (G > 256) v = fmax(v, fmax(fmax(red[4], red[5]), fmax(red[6], red[7])));
+		if constexpr (G > 512) v = fmax(v, fmax(fmax(red[8], red[9]), fmax(red[10], red[11])));
 		__syncthreads(); }
 	return v;
 }
 // hand-off through LDS inside a phase: one wavefront needs no barrier (its LDS instructions execute in order), two do
-template <int G> __device__ __forceinline__ void grp_lds_sync() { if constexpr (G > 64) __syncthreads(); else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } }
+template <int G> __device__ __forceinline__ void grp_lds_sync() { if constexpr (G > 64) __syncthreads(); else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } }
 
 // ------------------------------------------------------------------------------------------------ full-pivot LU inverse (schur.h:200-206)
 // Every index below is a compile-time constant (the loops are fully unrolled and the pivot position acts through selects): the matrices stay in registers. With
@@ -312,7 +329,8 @@ struct SparseSys { // per-capsule symbolic structure (LDS copy of the host's sym
 	const int *perm;           // perm[original 3-row block] = position in the fill-reducing elimination order
 	double *diag, *off, *rhs;
 	double *row_lds;           // HBM-resident dense layout with left-looking sweeps: 21 nb doubles of LDS (rows k, k+1 of the factor | y), else null
-	double *tiles, *linv; int nt; // workgroup path (srba_wg.hpp, ProbDesc::dense_blocks == 3): lower triangle of 16 x 16 frag tiles + the right-hand-side tile row | inverse diagonal factors; rhs then points at x in LDS, natural order (no permutation)
+	double *tiles, *linv; int nt; // workgroup path (srba_wg.hpp, ProbDesc::dense_blocks == 3): lower triangle of 16 x 16 frag tiles + the right-hand-side tile row | inverse diagonal factors;
+		// rhs then points at x in LDS, natural order (no permutation)
 	__device__ __forceinline__ double sol(int q) const { return tiles ? rhs[q] : rhs[3 * perm[q / 3] + q % 3]; } // component q (original numbering) of the solved right-hand side
 };
 // Cross-lane hand-off inside the solver. LDS instructions of one wavefront execute in issue order, so a ds_write followed by a ds_read of
@@ -663,11 +681,14 @@ __device__ __forceinline__ bool sp_factor_fsub_dense_left(const SparseSys &S, ld
 				for (int j = 0; j < k; j += U) {
 					double la[U][3];
 #pragma unroll
-					for (int u = 0; u < U; u++) if (j + u < k) { const double *src = S.off + 9 * (dense_col_start(nb, j + u) + (r - j - u - 1)) + 3 * sub; la[u][0] = src[0]; la[u][1] = src[1]; la[u][2] = src[2]; }
+					for (int u = 0; u < U; u++) if (j + u < k) { const double *src = S.off + 9 * (dense_col_start(nb, j + u) + (r - j - u - 1)) + 3 * sub; la[u][0] = src[0]; la[u][1] = src[1];
+						la[u][2] = src[2]; }
 #pragma unroll
 					for (int u = 0; u < U; u++) if (j + u < k) { const lds_f64 *lb = row0 + 9 * (j + u), *lc = row1 + 9 * (j + u);
-						a0 -= la[u][0] * lb[0] + la[u][1] * lb[1] + la[u][2] * lb[2]; a1 -= la[u][0] * lb[3] + la[u][1] * lb[4] + la[u][2] * lb[5]; a2 -= la[u][0] * lb[6] + la[u][1] * lb[7] + la[u][2] * lb[8];
-						if (two) { f0 -= la[u][0] * lc[0] + la[u][1] * lc[1] + la[u][2] * lc[2]; f1 -= la[u][0] * lc[3] + la[u][1] * lc[4] + la[u][2] * lc[5]; f2 -= la[u][0] * lc[6] + la[u][1] * lc[7] + la[u][2] * lc[8]; } }
+						a0 -= la[u][0] * lb[0] + la[u][1] * lb[1] + la[u][2] * lb[2]; a1 -= la[u][0] * lb[3] + la[u][1] * lb[4] + la[u][2] * lb[5];
+							a2 -= la[u][0] * lb[6] + la[u][1] * lb[7] + la[u][2] * lb[8];
+						if (two) { f0 -= la[u][0] * lc[0] + la[u][1] * lc[1] + la[u][2] * lc[2]; f1 -= la[u][0] * lc[3] + la[u][1] * lc[4] + la[u][2] * lc[5];
+							f2 -= la[u][0] * lc[6] + la[u][1] * lc[7] + la[u][2] * lc[8]; } }
 				}
 			}
 			if (i == 0) { // rows 0,1,2 of the updated diagonal block of column k sit in lanes 0,1,2
@@ -758,14 +779,16 @@ struct Worker {
 	// two-wavefront budget and never affected, is left as it is.)
 	// Round 4: the 32-bit value is made opaque BEFORE it is widened (the compiler then knows nothing about its sign and has to compute the high word from it: v_ashrrev_i32 hi, 31, lo); with the
 	// barrier after the widening the pair could still be formed from a register the compiler believed to hold the zero extension (tools/scan_undef_hi.py found six such pairs in the stereo kernel).
-	static __device__ __forceinline__ long long wide(int i) { if constexpr (FAM != SRBA_SE2_RELPOSE2D) asm volatile("" : "+v"(i)); long long w = i; if constexpr (FAM != SRBA_SE2_RELPOSE2D) asm volatile("" : "+v"(w)); return w; }
+	static __device__ __forceinline__ long long wide(int i) { if constexpr (FAM != SRBA_SE2_RELPOSE2D) asm volatile("" : "+v"(i)); long long w = i;
+		if constexpr (FAM != SRBA_SE2_RELPOSE2D) asm volatile("" : "+v"(w)); return w; }
 	__device__ __forceinline__ pose_t pose_at(int idx) const { return idx >= 0 ? PO::ld(Pz() + (d.o_pair * 2 + wide(idx)) * PD) : PO::ident(); }
 	__device__ __forceinline__ const double *lm_ptr(int ref) const { return ref >= 0 ? U() + (d.o_ulm + wide(ref)) * L : B.klm + (d.o_klm + wide(-1 - ref)) * L; }
 
 	// ---- K1
 	// edge_lds: optional copy of ALL edge poses of the capsule in LDS (stride PD, local edge order) -- the in-loop refresh then composes from LDS instead of
 	// waiting for the global stores of the update it follows
-	__device__ __forceinline__ void phase_spantree(bool only_needed, const double *edge_lds = nullptr, double *pose2 = nullptr /* a second copy of every pose written (all-pairs pass of the double-buffered loop) */) { fresh();
+	__device__ __forceinline__ void phase_spantree(bool only_needed, const double *edge_lds = nullptr, double *pose2 = nullptr /* a second copy of every pose written (all-pairs pass of the
+		double-buffered loop) */) { fresh();
 #ifdef SRBA_K1SMALL
 		constexpr int U = 2, V = 1;
 #else
@@ -874,11 +897,13 @@ struct Worker {
 			}
 			else {
 				if (x[2] <= 0) return false;
-				{ const double zi = 1.0 / x[2], zi2 = zi * zi; Hs[0] = prm.camL[0] * zi; Hs[1] = 0; Hs[2] = -prm.camL[0] * x[0] * zi2; Hs[3] = 0; Hs[4] = prm.camL[1] * zi; Hs[5] = -prm.camL[1] * x[1] * zi2; }
+				{ const double zi = 1.0 / x[2], zi2 = zi * zi; Hs[0] = prm.camL[0] * zi; Hs[1] = 0; Hs[2] = -prm.camL[0] * x[0] * zi2; Hs[3] = 0; Hs[4] = prm.camL[1] * zi;
+					Hs[5] = -prm.camL[1] * x[1] * zi2; }
 				if constexpr (FAM == SRBA_SE3_STEREO || FAM == SRBA_SE2_STEREO) {
 					double xr[3];
 					for (int i = 0; i < 3; i++) xr[i] = prm.R2Lt[i] + prm.R2LR[3 * i] * x[0] + prm.R2LR[3 * i + 1] * x[1] + prm.R2LR[3 * i + 2] * x[2];
-					const double zi = 1.0 / xr[2], zi2 = zi * zi; Hs[6] = prm.camR[0] * zi; Hs[7] = 0; Hs[8] = -prm.camR[0] * xr[0] * zi2; Hs[9] = 0; Hs[10] = prm.camR[1] * zi; Hs[11] = -prm.camR[1] * xr[1] * zi2;
+					const double zi = 1.0 / xr[2], zi2 = zi * zi; Hs[6] = prm.camR[0] * zi; Hs[7] = 0; Hs[8] = -prm.camR[0] * xr[0] * zi2; Hs[9] = 0; Hs[10] = prm.camR[1] * zi;
+						Hs[11] = -prm.camR[1] * xr[1] * zi2;
 				}
 			}
 			if (prm.sensor_pose == SRBA_SENSOR_POSE_SE3) {
@@ -916,7 +941,8 @@ struct Worker {
 #pragma unroll
 				for (int j = 0; j < 3; j++) Rh[3 * i + j] = bp.R[i] * Rz[j] + bp.R[3 + i] * Rz[3 + j] + bp.R[6 + i] * Rz[6 + j];
 			}
-			const double ct = fmin(1.0, fmax(-1.0, 0.5 * (Rh[0] + Rh[4] + Rh[8] - 1.0))), th = acos(ct), f = th < 1e-8 ? 0.5 : th / (2.0 * sin(th)); // [EXT] CPose3D::ln_rotation as restated in include/mrpt_lite.h
+			const double ct = fmin(1.0, fmax(-1.0, 0.5 * (Rh[0] + Rh[4] + Rh[8] - 1.0))), th = acos(ct), f = th < 1e-8 ? 0.5 : th / (2.0 * sin(th));
+				// [EXT] CPose3D::ln_rotation as restated in include/mrpt_lite.h
 			r[3] = f * (Rh[7] - Rh[5]); r[4] = f * (Rh[2] - Rh[6]); r[5] = f * (Rh[3] - Rh[1]);
 		} else if constexpr (!T::SE3) {
 			const double s = bp.s, c = bp.c, lx = bp.x + lm[0] * c - lm[1] * s, ly = bp.y + lm[0] * s + lm[1] * c;
@@ -1038,7 +1064,8 @@ struct Worker {
 				double H[O * L]; ok = dh_dx(H, xl);
 				if (ok) {
 					const double m02 = (-sa * D.x - ca * D.y) + (-xi[0] * sad - xi[1] * cad), m12 = (ca * D.x - sa * D.y) + (xi[0] * cad - xi[1] * sad);
-					for (int i = 0; i < O; i++) { Jl[i * 3] = sg * (H[i * 2] * ca + H[i * 2 + 1] * sa); Jl[i * 3 + 1] = sg * (-H[i * 2] * sa + H[i * 2 + 1] * ca); Jl[i * 3 + 2] = sg * (H[i * 2] * m02 + H[i * 2 + 1] * m12); }
+					for (int i = 0; i < O; i++) { Jl[i * 3] = sg * (H[i * 2] * ca + H[i * 2 + 1] * sa); Jl[i * 3 + 1] = sg * (-H[i * 2] * sa + H[i * 2 + 1] * ca);
+						Jl[i * 3 + 2] = sg * (H[i * 2] * m02 + H[i * 2 + 1] * m12); }
 				}
 			}
 		} else if constexpr (FAM == SRBA_SE3_RELPOSE3D) { // jacobians.h:748-873: J = [d pseudo_ln / d (R,t)] (6x12) * [d (A e^eps D) / d eps] (12x6)
@@ -1052,7 +1079,8 @@ struct Worker {
 			const P3 AD = hasA ? comp(A, D) : D;
 			// d ln(R) / d vec(R), vec = stacked columns ([EXT] CPose3D::ln_rot_jacob: omega = theta / (2 sin theta) * vee(R - R^t), theta = acos((tr R - 1) / 2))
 			const double dd = 0.5 * (AD.R[0] + AD.R[4] + AD.R[8] - 1.0); double a0 = 0, a1 = 0, a2 = 0, bb = 0.5;
-			if (!(dd > 0.99999)) { const double th = acos(dd), sq = sqrt(1.0 - dd * dd), kk = (dd * th - sq) / (4.0 * sq * sq * sq); bb = th / (2.0 * sq); a0 = kk * (AD.R[7] - AD.R[5]); a1 = kk * (AD.R[2] - AD.R[6]); a2 = kk * (AD.R[3] - AD.R[1]); }
+			if (!(dd > 0.99999)) { const double th = acos(dd), sq = sqrt(1.0 - dd * dd), kk = (dd * th - sq) / (4.0 * sq * sq * sq); bb = th / (2.0 * sq); a0 = kk * (AD.R[7] - AD.R[5]);
+				a1 = kk * (AD.R[2] - AD.R[6]); a2 = kk * (AD.R[3] - AD.R[1]); }
 			const double M[27] = {a0, 0, 0, 0, a0, bb, 0, -bb, a0,   a1, 0, -bb, 0, a1, 0, bb, 0, a1,   a2, bb, 0, -bb, a2, 0, 0, 0, a2};
 			// G_i = -R(A) [c_i]_x for the three columns c_i of R(D) and for t(D): rows 3i..3i+2 of the right half of d(A e^eps D)/d eps
 			double Jr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Gt[9];
@@ -1200,7 +1228,8 @@ struct Worker {
 		}
 	}
 	template <int M1, int M2, bool ATOMIC = false>
-	__device__ __forceinline__ int hess_block(double *Hout, double *Hlatch, const int *t1, const int *t2, int tb, int te, const double *J1, const double *J2, const unsigned char *ok1, const unsigned char *ok2) {
+	__device__ __forceinline__ int hess_block(double *Hout, double *Hlatch, const int *t1, const int *t2, int tb, int te, const double *J1, const double *J2, const unsigned char *ok1,
+		const unsigned char *ok2) {
 		double H[M1 * M2];
 #pragma unroll
 		for (int k = 0; k < M1 * M2; k++) H[k] = 0;
@@ -1250,7 +1279,8 @@ struct Worker {
 			for (int b = tid; b < d.n_hf; b += G)
 				ninv += hess_block<L, L>(B.Hf + (d.o_hf + b) * L * L, nullptr, B.hf_t1 + d.o_hft, B.hf_t2 + d.o_hft, B.hf_term_off[d.o_hfoff + b], B.hf_term_off[d.o_hfoff + b + 1], Jf, Jf, rf, rf);
 			for (int b = tid; b < d.n_hapf; b += G)
-				ninv += hess_block<P, L>(B.HApf + (d.o_hapf + b) * P * L, nullptr, B.hapf_t1 + d.o_hapft, B.hapf_t2 + d.o_hapft, B.hapf_term_off[d.o_hapfoff + b], B.hapf_term_off[d.o_hapfoff + b + 1], Jp, Jf, rp, rf);
+				ninv += hess_block<P, L>(B.HApf + (d.o_hapf + b) * P * L, nullptr, B.hapf_t1 + d.o_hapft, B.hapf_t2 + d.o_hapft, B.hapf_term_off[d.o_hapfoff + b],
+					B.hapf_term_off[d.o_hapfoff + b + 1], Jp, Jf, rp, rf);
 		}
 		return ninv;
 	}
@@ -1298,7 +1328,8 @@ struct Worker {
 			for (int b = tid; b < d.n_hf; b += G)
 				ninv += hess_block<L, L>(B.Hf + (d.o_hf + b) * L * L, nullptr, B.hf_t1 + d.o_hft, B.hf_t2 + d.o_hft, B.hf_term_off[d.o_hfoff + b], B.hf_term_off[d.o_hfoff + b + 1], Jf, Jf, rf, rf);
 			for (int b = tid; b < d.n_hapf; b += G)
-				ninv += hess_block<P, L>(B.HApf + (d.o_hapf + b) * P * L, nullptr, B.hapf_t1 + d.o_hapft, B.hapf_t2 + d.o_hapft, B.hapf_term_off[d.o_hapfoff + b], B.hapf_term_off[d.o_hapfoff + b + 1], Jp, Jf, rp, rf);
+				ninv += hess_block<P, L>(B.HApf + (d.o_hapf + b) * P * L, nullptr, B.hapf_t1 + d.o_hapft, B.hapf_t2 + d.o_hapft, B.hapf_term_off[d.o_hapfoff + b],
+					B.hapf_term_off[d.o_hapfoff + b + 1], Jp, Jf, rp, rf);
 		}
 		return ninv;
 	}
@@ -1337,7 +1368,8 @@ struct Worker {
 #pragma unroll
 					for (int u = 0; u < U; u++) {
 						if (b0 + u * S < be) {
-							if (prm.noise == SRBA_NOISE_CONSTANT_MATRIX) { double t[O]; for (int k = 0; k < O; k++) { double q = 0; for (int j = 0; j < O; j++) q += prm.lambda[k * O + j] * lr[u][j]; t[k] = q; } for (int k = 0; k < O; k++) lr[u][k] = t[k]; }
+							if (prm.noise == SRBA_NOISE_CONSTANT_MATRIX) { double t[O]; for (int k = 0; k < O; k++) { double q = 0; for (int j = 0; j < O; j++) q += prm.lambda[k * O + j] * lr[u][j];
+								t[k] = q; } for (int k = 0; k < O; k++) lr[u][k] = t[k]; }
 							for (int q = 0; q < M; q++) { double sm = 0; for (int k = 0; k < O; k++) sm += A[u][k * M + q] * lr[u][k]; acc[q] += sm; }
 						}
 					}
@@ -1360,8 +1392,10 @@ struct Worker {
 	}
 	__device__ __forceinline__ double lambda_guess(double *red) { fresh(); // optimize_edges.h:366-390
 		double mx = 0;
-		for (int i = tid; i < d.nK; i += G) { const double *H = B.HAp + (d.o_hap + B.hap_diag[d.o_unk + i]) * P * P; double m = H[0]; for (int k = 1; k < P; k++) m = fmax(m, H[k * P + k]); mx = fmax(mx, m); }
-		if constexpr (!T::REL) for (int i = tid; i < d.nF; i += G) { const double *H = B.Hf + (d.o_hf + B.hf_diag[d.o_ulm + i]) * L * L; double m = H[0]; for (int k = 1; k < L; k++) m = fmax(m, H[k * L + k]); mx = fmax(mx, m); }
+		for (int i = tid; i < d.nK; i += G) { const double *H = B.HAp + (d.o_hap + B.hap_diag[d.o_unk + i]) * P * P; double m = H[0]; for (int k = 1; k < P; k++) m = fmax(m, H[k * P + k]);
+			mx = fmax(mx, m); }
+		if constexpr (!T::REL) for (int i = tid; i < d.nF; i += G) { const double *H = B.Hf + (d.o_hf + B.hf_diag[d.o_ulm + i]) * L * L; double m = H[0]; for (int k = 1; k < L; k++) m = fmax(m,
+			H[k * L + k]); mx = fmax(mx, m); }
 		return 1e-3 * grp_max<G>(mx, red);
 	}
 };
@@ -1381,14 +1415,18 @@ struct SpecCtl {
 	double *xdelta;    // [2][W][xstride]: the increment replica j solved for in that round
 	int xstride;
 	long long stride;  // bytes between the work arenas of two consecutive replicas
-	int round0;        // the rounds of this launch are numbered round0 + 1 ...: above every round of the launches before it (at most 8192 rounds per launch: one per trial -- the host only speculates when max_iters keeps a run below that), so `flag` needs no clearing
-	double *edge_backup; // [nK * PD]: the unknown edges as the launch found them (written by replica 0 before anything else): what the host restores before it re-runs a capsule whose replicas lost step (status 2) on the plain path
+	int round0;        // the rounds of this launch are numbered round0 + 1 ...: above every round of the launches before it (at most 8192 rounds per launch: one per trial -- the host only speculates
+		// when max_iters keeps a run below that), so `flag` needs no clearing
+	double *edge_backup; // [nK * PD]: the unknown edges as the launch found them (written by replica 0 before anything else): what the host restores before it re-runs a capsule whose replicas lost
+		// step (status 2) on the plain path
 };
 // the work arena of a replica: every state / workspace pointer of the batch moved by `bytes` (the arenas of the replicas lie one after the other: srba_hip_upload_problems)
 __device__ __forceinline__ Batch shift_work(Batch B, long long bytes) {
 #define SRBA_SH(f) B.f = (decltype(B.f))((char *)B.f + bytes)
-	SRBA_SH(edge); SRBA_SH(ulm); SRBA_SH(pose); SRBA_SH(Jp); SRBA_SH(Jf); SRBA_SH(resid); SRBA_SH(resid2); SRBA_SH(HAp); SRBA_SH(HAp0); SRBA_SH(Hf); SRBA_SH(HApf); SRBA_SH(grad); SRBA_SH(grad0); SRBA_SH(delta); SRBA_SH(Hfinv); SRBA_SH(YW); SRBA_SH(Yh);
-	SRBA_SH(old_edge); SRBA_SH(old_ulm); SRBA_SH(old_pose); SRBA_SH(dense); SRBA_SH(ulm_inf); SRBA_SH(edge1); SRBA_SH(ulm1); SRBA_SH(pose1); SRBA_SH(valid); SRBA_SH(first_fail); SRBA_SH(hf_ok); SRBA_SH(bp_ok); SRBA_SH(bf_ok); SRBA_SH(ulm_inf_valid);
+	SRBA_SH(edge); SRBA_SH(ulm); SRBA_SH(pose); SRBA_SH(Jp); SRBA_SH(Jf); SRBA_SH(resid); SRBA_SH(resid2); SRBA_SH(HAp); SRBA_SH(HAp0); SRBA_SH(Hf); SRBA_SH(HApf); SRBA_SH(grad); SRBA_SH(grad0);
+		SRBA_SH(delta); SRBA_SH(Hfinv); SRBA_SH(YW); SRBA_SH(Yh);
+	SRBA_SH(old_edge); SRBA_SH(old_ulm); SRBA_SH(old_pose); SRBA_SH(dense); SRBA_SH(ulm_inf); SRBA_SH(edge1); SRBA_SH(ulm1); SRBA_SH(pose1); SRBA_SH(valid); SRBA_SH(first_fail); SRBA_SH(hf_ok);
+		SRBA_SH(bp_ok); SRBA_SH(bf_ok); SRBA_SH(ulm_inf_valid);
 	SRBA_SH(results); SRBA_SH(lambda_io); SRBA_SH(chi2); SRBA_SH(notpd); if (B.phase_cycles) SRBA_SH(phase_cycles);
 #undef SRBA_SH
 	return B;
@@ -1397,9 +1435,12 @@ __device__ __forceinline__ Batch shift_work(Batch B, long long bytes) {
 // outcome and the increment across the L2s of the XCDs.
 __device__ __forceinline__ bool spec_exchange(const SpecCtl &sc, int round, int code, double rho, double chi2, double lam) { // false: a replica did not answer within the spin bound
 	__threadfence(); __syncthreads();
-	if (threadIdx.x == 0) { double *b = sc.box + ((round & 1) * sc.W + sc.w) * 4; b[0] = (double)code; b[1] = rho; b[2] = chi2; b[3] = lam; __hip_atomic_store(sc.flag + sc.w, round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+	if (threadIdx.x == 0) { double *b = sc.box + ((round & 1) * sc.W + sc.w) * 4; b[0] = (double)code; b[1] = rho; b[2] = chi2; b[3] = lam; __hip_atomic_store(sc.flag + sc.w, round, __ATOMIC_RELEASE,
+		__HIP_MEMORY_SCOPE_AGENT); }
 	int late = 0;
-	if ((int)threadIdx.x < sc.W) { long long spins = 0; while (__hip_atomic_load(sc.flag + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < round) { __builtin_amdgcn_s_sleep(1); if (++spins > (1ll << 19)) { late = 1; break; } /* (a replica that never comes -- not resident because something else holds the CUs: give up after about a second instead of hanging the device; the caller sets status 2 and the host re-runs the capsule on the sequential path) */ } }
+	if ((int)threadIdx.x < sc.W) { long long spins = 0; while (__hip_atomic_load(sc.flag + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < round) { __builtin_amdgcn_s_sleep(1);
+		if (++spins > (1ll << 19)) { late = 1; break; } /* (a replica that never comes -- not resident because something else holds the CUs: give up after about a second instead of hanging the
+		device; the caller sets status 2 and the host re-runs the capsule on the sequential path) */ } }
 	const int any_late = __syncthreads_or(late); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 	return any_late == 0;
 }
@@ -1410,7 +1451,8 @@ __device__ __forceinline__ double spec_ld(const double *p) { return __hip_atomic
 // (lm_one: a fresh Solver per phase call): its loads cannot be merged with another phase's, so a pointer is live for one phase -- a scalar load when the phase starts instead of a
 // register for the whole run. The memory is read-only for the duration of the kernel: constant address space, scalar loads.
 template <class T> __device__ __forceinline__ const T &lnd(const T &r) {
-	unsigned long long a = (unsigned long long)&r; // (uniform in fact -- the capsule index comes from a work counter -- but not always to the divergence analysis: v_readfirstlane makes it a scalar either way)
+	unsigned long long a = (unsigned long long)&r; // (uniform in fact -- the capsule index comes from a work counter -- but not always to the divergence analysis: v_readfirstlane makes it a scalar
+		// either way)
 	const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
 	a = ((unsigned long long)hi << 32) | lo; asm volatile("" : "+s"(a));
 	return *(const T *)(const __attribute__((address_space(4))) T *)a;

@@ -26,7 +26,8 @@ __device__ __forceinline__ long long flat_block() {
 #define FLAT_STRIDE() ((long long)gridDim.x * blockDim.x)
 // A wavefront that produced one fixed-size record per lane for 64 CONSECUTIVE items writes them through LDS: the records of consecutive items are contiguous in
 // memory, so the wavefront stores the whole span 16 bytes per lane and instruction (full 64-byte lines) instead of one partial line per lane and instruction.
-template <int N> __device__ __forceinline__ void wave_store_records(double *lds /* 64 * N doubles of this wavefront */, double *dst_first /* record of lane 0 */, const double (&rec)[N], bool live, int n_live) {
+template <int N> __device__ __forceinline__ void wave_store_records(double *lds /* 64 * N doubles of this wavefront */, double *dst_first /* record of lane 0 */, const double (&rec)[N], bool live,
+	int n_live) {
 	const int lane = threadIdx.x & 63;
 	if (live) {
 #pragma unroll

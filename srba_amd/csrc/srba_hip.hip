@@ -82,12 +82,14 @@ struct Solver : public Worker<FAM, LEAN, G> {
 				for (int t = tb; t < te; t += NT) {
 					int lq[NT], aq[NT], cq[NT], ywq[NT], kq[NT]; bool okq[NT];
 #pragma unroll
-					for (int u = 0; u < NT; u++) { const bool live = t + u < te; const int tu = live ? t + u : t; lq[u] = s_lm[tu]; aq[u] = s_b1[tu]; cq[u] = s_b2[tu]; ywq[u] = s_yw[tu]; kq[u] = s_blk[tu]; okq[u] = live; }
+					for (int u = 0; u < NT; u++) { const bool live = t + u < te; const int tu = live ? t + u : t; lq[u] = s_lm[tu]; aq[u] = s_b1[tu]; cq[u] = s_b2[tu]; ywq[u] = s_yw[tu];
+						kq[u] = s_blk[tu]; okq[u] = live; }
 #pragma unroll
 					for (int u = 0; u < NT; u++) okq[u] = okq[u] && B.hf_ok[d.o_ulm + lq[u]] != 0;
 					double W1[NT][P * L], W2[NT][P * L], Hi[NT][L * L], gl[NT][L];
 #pragma unroll
-					for (int u = 0; u < NT; u++) { ldn<P * L>(W1[u], B.HApf + (d.o_hapf + aq[u]) * P * L); ldn<P * L>(W2[u], B.HApf + (d.o_hapf + cq[u]) * P * L); ldn<L * L>(Hi[u], B.Hfinv + (d.o_ulm + lq[u]) * L * L); ldn<L>(gl[u], gf + lq[u] * L); }
+					for (int u = 0; u < NT; u++) { ldn<P * L>(W1[u], B.HApf + (d.o_hapf + aq[u]) * P * L); ldn<P * L>(W2[u], B.HApf + (d.o_hapf + cq[u]) * P * L); ldn<L * L>(Hi[u],
+						B.Hfinv + (d.o_ulm + lq[u]) * L * L); ldn<L>(gl[u], gf + lq[u] * L); }
 #pragma unroll
 					for (int u = 0; u < NT; u++) {
 						if (!okq[u]) continue;
@@ -138,8 +140,10 @@ struct Solver : public Worker<FAM, LEAN, G> {
 	__device__ __forceinline__ const int *ptab() const { return B.ptab + d.o_ptab; }
 	// the LDS blocks [b0, b1) -> U_Ap (and its latch, schur.h:38) in memory, 16 bytes per lane and request
 	__device__ __forceinline__ void store_hs(bool latch_too, int b0, int b1) { this->fresh();
-		const double *H = hs(); double *Hg = B.HAp + (d.o_hap + b0) * P * P, *H0 = B.HAp0 + (d.o_hap + b0) * P * P; const int n_acc = (b1 - b0) * P * P; static_assert((P * P) % 2 == 0, "pairs of doubles inside a block");
-		for (int k = 2 * tid; k < n_acc; k += 2 * G) { const int b = k / (P * P), e = k - b * (P * P); f64x2u v; v.x = H[b * HS + e]; v.y = H[b * HS + e + 1]; *(f64x2u *)(Hg + k) = v; if (latch_too) *(f64x2u *)(H0 + k) = v; }
+		const double *H = hs(); double *Hg = B.HAp + (d.o_hap + b0) * P * P, *H0 = B.HAp0 + (d.o_hap + b0) * P * P; const int n_acc = (b1 - b0) * P * P; static_assert((P * P) % 2 == 0,
+			"pairs of doubles inside a block");
+		for (int k = 2 * tid; k < n_acc; k += 2 * G) { const int b = k / (P * P), e = k - b * (P * P); f64x2u v; v.x = H[b * HS + e]; v.y = H[b * HS + e + 1]; *(f64x2u *)(Hg + k) = v;
+			if (latch_too) *(f64x2u *)(H0 + k) = v; }
 	}
 	__device__ __forceinline__ void store_hs(bool latch_too) { store_hs(latch_too, 0, d.n_hap); } // (single-panel windows: the reduced blocks go to memory once, when the run ends)
 	// K6 (sparse_hessian_update_numeric.h:22-60): U_Ap summed in LDS from the term list sorted by observation; U_f and U_Apf as before (their lists are a landmark's observations: short)
@@ -196,7 +200,8 @@ struct Solver : public Worker<FAM, LEAN, G> {
 			for (int q = 0; q < np; q++) {
 				const int pb0 = pt[q], pb1 = pt[q + 1], t0 = pt[2 * np + 2 + q], t1 = pt[2 * np + 3 + q], n_acc = (pb1 - pb0) * P * P;
 				{ const double *H0 = B.HAp0 + (d.o_hap + pb0) * P * P;
-				  for (int k = 2 * tid; k < n_acc; k += 2 * G) { const int b = k / (P * P), e = k - b * (P * P); const f64x2u v = *(const f64x2u *)(H0 + k); H[b * HS + e] = v.x; H[b * HS + e + 1] = v.y; } }
+				  for (int k = 2 * tid; k < n_acc; k += 2 * G) { const int b = k / (P * P), e = k - b * (P * P); const f64x2u v = *(const f64x2u *)(H0 + k); H[b * HS + e] = v.x;
+				  	H[b * HS + e + 1] = v.y; } }
 				__syncthreads();
 				if (pc && q == 0) { if (tid == 0) pc[14] += wall_clock64() - tq; tq = wall_clock64(); }
 				int l = 0, b1 = 0, b2 = 0, w = 0;
@@ -362,7 +367,8 @@ struct Solver : public Worker<FAM, LEAN, G> {
 		}
 		const double *g = B.grad + d.o_scal;
 		for (int k = tid; k < 3 * nb; k += G) S.rhs[3 * S.perm[k / 3] + k % 3] = (k < n) ? g[k] : 0.0;
-		if (!d.aligned) __syncthreads(); // (aligned: the fill-in blocks zeroed above, the right-hand side and the blocks written below are disjoint pieces of the image -- no order between them, and the loads of the gradient and of the Hessian blocks are in flight together)
+		if (!d.aligned) __syncthreads(); // (aligned: the fill-in blocks zeroed above, the right-hand side and the blocks written below are disjoint pieces of the image -- no order between them,
+			// and the loads of the gradient and of the Hessian blocks are in flight together)
 		constexpr int PB = P / 3;
 		// one lane per aligned 3x3 sub-block: its 9 loads are in flight together (one memory round trip per pass instead of one per element)
 		for (int sb = tid; sb < d.n_hap * PB * PB; sb += G) {
@@ -420,15 +426,20 @@ struct Solver : public Worker<FAM, LEAN, G> {
 		// (the dense block layouts are never chosen for the relative-pose families -- srba_hip_upload_problems -- whose kernels therefore carry the sparse solver only: the
 		//  headline kernel sits 22 VGPRs below the two-wavefronts-per-SIMD limit)
 		STIC(); bool ok;
-		if constexpr (G > 64 && !W::T::REL) { ok = false; /* (unreachable: the workgroup branch above returned) */ } else if constexpr (G > 64) { // two wavefronts per capsule (sparse layout only): the first one factors and substitutes, the verdict travels through the reduction scratch behind the image
+		if constexpr (G > 64 && !W::T::REL) { ok = false; /* (unreachable: the workgroup branch above returned) */ } else if constexpr (G > 64) {
+			// two wavefronts per capsule (sparse layout only): the first one factors and substitutes, the verdict travels through the reduction scratch behind the image
 			int *flag = (int *)red2w; if (threadIdx.x < 64) { const bool k1 = sp_factor_fsub_rows(S); if (k1) sp_bsub_rows(S); if (threadIdx.x == 0) *flag = k1 ? 1 : 0; }
 			__syncthreads(); ok = *flag != 0; __syncthreads();
-		} else if constexpr (W::T::REL || !W::T::SE3) ok = sp_factor_fsub_rows(S); else ok = d.dense_blocks == 2 ? (S.row_lds ? sp_factor_fsub_dense_left(S, (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16), (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16 + 18 * S.nb)) : sp_factor_fsub_dense<true>(S)) : (S.dense ? sp_factor_fsub_dense<false>(S) : sp_factor_fsub_rows(S)); STOC(11);
+		} else if constexpr (W::T::REL || !W::T::SE3) ok = sp_factor_fsub_rows(S); else ok = d.dense_blocks == 2 ? (S.row_lds ? sp_factor_fsub_dense_left(S,
+			(lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16), (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16 + 18 * S.nb)) : sp_factor_fsub_dense<true>(S)) : (S.dense ? sp_factor_fsub_dense<false>(S) :
+			sp_factor_fsub_rows(S)); STOC(11);
 		if (!ok) return false;
-		STIC(); if constexpr (G > 64) { /* done above */ } else if constexpr (W::T::REL || !W::T::SE3) sp_bsub_rows(S); else { if (d.dense_blocks == 2) { if (S.row_lds) sp_bsub_dense_left(S, (lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16 + 18 * S.nb)); else sp_bsub_dense<true>(S); } else if (S.dense) sp_bsub_dense<false>(S); else sp_bsub_rows(S); }
+		STIC(); if constexpr (G > 64) { /* done above */ } else if constexpr (W::T::REL || !W::T::SE3) sp_bsub_rows(S); else { if (d.dense_blocks == 2) { if (S.row_lds) sp_bsub_dense_left(S,
+			(lds_f64 *)srba_lds + ((S.nb + 1) / 2 + 16 + 18 * S.nb)); else sp_bsub_dense<true>(S); } else if (S.dense) sp_bsub_dense<false>(S); else sp_bsub_rows(S); }
 		double *dl = B.delta + d.o_scal;
 		for (int k = tid; k < d.n_scal; k += G) dl[k] = (k < d.n_sys) ? S.sol(k) : 0.0;
-		if (schur_active()) __syncthreads(); /* (K10 reads the increments of the edges back from memory; without landmarks to solve for, the loop takes them from the LDS image: no reader waits for these stores) */ STOC(12);
+		if (schur_active()) __syncthreads(); /* (K10 reads the increments of the edges back from memory; without landmarks to solve for,
+			the loop takes them from the LDS image: no reader waits for these stores) */ STOC(12);
 		STIC(); if (schur_active()) schur_features(); STOC(13);
 		return true;
 #undef STIC
@@ -445,7 +456,8 @@ struct Solver : public Worker<FAM, LEAN, G> {
 			return S;
 		}
 		S.nb = d.nb; S.nnzoff = d.nnzoff; S.dense = (W::T::REL || !W::T::SE3) ? 0 : d.dense_blocks;
-		S.row_lds = (S.dense == 2 && B.dense_left && d.nb <= 168) ? lds + (d.nb + 1) / 2 + 16 : nullptr; // HBM-resident layout, left-looking sweeps: 21 nb doubles of LDS after the permutation (two rows of the factor | y)
+		S.row_lds = (S.dense == 2 && B.dense_left && d.nb <= 168) ? lds + (d.nb + 1) / 2 + 16 : nullptr; // HBM-resident layout, left-looking sweeps: 21 nb doubles of LDS after the permutation (two
+			// rows of the factor | y)
 		S.col_off = B.sp_col_off + d.o_spcol; S.row = B.sp_row + d.o_sprow; S.item = B.sp_tgt + d.o_spitem; S.perm = B.sp_perm + d.o_spperm;
 		S.rptr = B.sp_rptr + d.o_spcol; S.rent = B.sp_rcol + d.o_sprow;
 		double *base = (!W::T::REL && W::T::SE3 && d.dense_blocks == 2) ? B.dense + d.o_dense : lds; // 2: the numbers live in an HBM workspace, LDS holds the permutation only
@@ -554,7 +566,8 @@ struct Solver : public Worker<FAM, LEAN, G> {
 	__device__ __forceinline__ void restore() { this->fresh(); // optimize_edges.h:664-680
 		for (int i = tid; i < d.nK * PD; i += G) E()[d.o_edge * PD + i] = B.old_edge[d.o_unk * PD + i];
 		for (int k = tid; k < d.nF * L; k += G) U()[d.o_ulm * L + k] = B.old_ulm[d.o_ulm * L + k];
-		for (int r = tid; r < d.n_req; r += G) { double *s = Pz() + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD; const double *o = B.old_pose + (d.o_req + r) * PD; for (int k = 0; k < PD; k++) s[k] = o[k]; }
+		for (int r = tid; r < d.n_req; r += G) { double *s = Pz() + (d.o_pair * 2 + B.req_idx[d.o_req + r]) * PD; const double *o = B.old_pose + (d.o_req + r) * PD; for (int k = 0; k < PD;
+			k++) s[k] = o[k]; }
 		__syncthreads();
 	}
 };
@@ -571,13 +584,16 @@ struct Solver : public Worker<FAM, LEAN, G> {
 #ifndef SRBA_FUSE_K4
 #define SRBA_FUSE_K4 1 /* a trial's residuals compose the poses of the refreshed pairs themselves (Worker::phase_residuals_fused); 0: refresh the pose table, then gather from it (rounds 1-3) */
 #endif
-template <int FAM, bool DB = (SRBA_LM_DB != 0), bool LEAN = false, int G = 64, bool FUSE_K4 = (SRBA_FUSE_K4 != 0) && (LEAN || G > 64) /* k_lm_run itself (every family, 253 registers for the headline one) keeps the table path: the fused form costs it 13 registers and with them its second wavefront per SIMD */,
-          bool LND = false /* B0 lies in global memory (a kernel that takes `const Batch *`): every phase works through its own laundered reference to it and to the descriptor (srba_device.hpp lnd) */>
+template <int FAM, bool DB = (SRBA_LM_DB != 0), bool LEAN = false, int G = 64, bool FUSE_K4 = (SRBA_FUSE_K4 != 0) && (LEAN || G > 64) /* k_lm_run itself (every family,
+	253 registers for the headline one) keeps the table path: the fused form costs it 13 registers and with them its second wavefront per SIMD */,
+          bool LND = false /* B0 lies in global memory (a kernel that takes `const Batch *`): every phase works through its own laundered reference to it and to the descriptor (srba_device.hpp lnd)
+          	*/>
 __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, const int pidx, double *red = nullptr /* G = 128: LDS scratch of the group reductions */) {
 	const ProbDesc &d = B0.desc[pidx];
 	// the batch record for this function's own few accesses: a reference of its own at every use (LND), like the phases (srba_device.hpp lnd)
 	auto LB = [&]() __attribute__((always_inline)) -> const Batch & { if constexpr (LND) return lnd(B0); else return B0; };
-	int cur = 0, last_rej = 0; bool lazy_rej = false; // DB: which copy holds the accepted state; the last evaluated trial was rejected (lazy_rej: ... and the pose table of the trial copy was not refreshed for it)
+	int cur = 0, last_rej = 0; bool lazy_rej = false; // DB: which copy holds the accepted state; the last evaluated trial was rejected (lazy_rej: ... and the pose table of the trial copy was not
+		// refreshed for it)
 	typedef Solver<FAM, LEAN, G> Sv;
 	// a worker on copy `cp` of the state for ONE phase call (LND: through references nothing else shares -- the pointers a phase uses are loaded when it starts and die when it ends)
 	auto Wk = [&](int cp) __attribute__((always_inline)) -> Sv { if constexpr (LND) return Sv(lnd(B0), lnd(d), lnd(prm), red, cp); else return Sv(B0, d, prm, red, cp); };
@@ -592,9 +608,11 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 #define TIC() do { if (pc) { __syncthreads(); tc0 = wall_clock64(); } } while (0)
 #define TOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - tc0; } } while (0)
 	// K6: the LDS image of the system is idle while the capsule is linearised (it is assembled per trial): the U_Ap accumulators of the term-parallel form live there
-	const bool hess_terms = G <= 128 && LB().hess_terms && d.dense_in_lds && d.n_hap * P * P <= 9 * (d.nb + d.nnzoff); // (the term-parallel form cuts the list between TWO wavefronts; workgroup windows keep no system in LDS anyway)
+	const bool hess_terms = G <= 128 && LB().hess_terms && d.dense_in_lds && d.n_hap * P * P <= 9 * (d.nb + d.nnzoff); // (the term-parallel form cuts the list between TWO wavefronts;
+		// workgroup windows keep no system in LDS anyway)
 	bool hs_reduced = false; // workgroup path, U_Ap in LDS: the LDS blocks hold the Schur-reduced system of the last solve (what the reference leaves in HAp), not yet written back
-	auto hessian = [&](int cp) __attribute__((always_inline)) -> int { Sv X = Wk(cp); if constexpr (G > 64 && !Tr<FAM>::REL) { hs_reduced = false; return X.phase_hessian_lds(); } else return hess_terms ? X.phase_hessian_terms(srba_lds) /* == A.diag: the LDS image, idle while the capsule is linearised */ + X.phase_hessian_landmark_blocks() : X.phase_hessian(); };
+	auto hessian = [&](int cp) __attribute__((always_inline)) -> int { Sv X = Wk(cp); if constexpr (G > 64 && !Tr<FAM>::REL) { hs_reduced = false; return X.phase_hessian_lds(); }
+		else return hess_terms ? X.phase_hessian_terms(srba_lds) /* == A.diag: the LDS image, idle while the capsule is linearised */ + X.phase_hessian_landmark_blocks() : X.phase_hessian(); };
 	double lambda, nu = 2.0, total_err, RMSE;
 	int iter = 0, trials = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0; bool stop = false;
 	TIC(); Wk(0).phase_spantree(false, nullptr, DB ? (double *)LB().pose1 : nullptr); // S5 (DB: both copies of the poses)
@@ -645,7 +663,8 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 			const double err_red = total_err > 0 ? (total_err - new_err) / total_err : 0;
 			double den = 0; { const Batch &Bl = LB(); const double *dl = Bl.delta + d.o_scal, *g = Bl.grad + d.o_scal;
 				if (S.schur_active() || !d.dense_in_lds) { for (int k = tid; k < n; k += G) den += dl[k] * (lambda * dl[k] + g[k]); }
-				else for (int k = tid; k < n; k += G) { const double dk = A.sol(k); den += dk * (lambda * dk + g[k]); } } // (the solved right-hand side is still in the LDS image: the same numbers, no round trip through memory)
+				else for (int k = tid; k < n; k += G) { const double dk = A.sol(k); den += dk * (lambda * dk + g[k]); } } // (the solved right-hand side is still in the LDS image: the same numbers,
+					// no round trip through memory)
 			den = grp_sum<G>(den, red);
 			rho = (total_err - new_err) / den;
 			if (tid == 0 && tr < SRBA_TRACE_LEN) { out->trace_chi2[tr] = new_err; out->trace_rho[tr] = rho; }
@@ -673,7 +692,8 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 		}
 	}
 	if (!stop) stopmask |= 1 << SRBA_STOP_MAX_ITERS;
-	if constexpr (G > 64 && !Tr<FAM>::REL) { if (hs_reduced && d.n_panel == 1 && S.schur_active()) { __syncthreads(); Wk(0).store_hs(false); } } // (the reference's Schur complement works on HAp in place: its reduced blocks are what a caller reads after the run)
+	if constexpr (G > 64 && !Tr<FAM>::REL) { if (hs_reduced && d.n_panel == 1 && S.schur_active()) { __syncthreads(); Wk(0).store_hs(false); } }
+		// (the reference's Schur complement works on HAp in place: its reduced blocks are what a caller reads after the run)
 	// S17: crpLandmarksApprox
 	if constexpr (!Solver<FAM, LEAN, G>::W::T::REL) {
 		const Batch &Bl = LB();
@@ -687,7 +707,8 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 		out->num_iters = iter; out->num_trials = trials; out->num_not_pd = n_notpd; out->num_accepted = n_acc; out->num_relinearized = n_relin; out->stop_reason = stopmask;
 		out->total_sqr_error_final = total_err; out->obs_rmse = RMSE; out->lambda_final = lambda;
 	}
-	if constexpr (DB) { // the reference's partial restore, where it becomes visible: a rejected trial refreshed BOTH poses of every pair in use and only the ones Jacobian blocks read went back (optimize_edges.h:664-670)
+	if constexpr (DB) { // the reference's partial restore, where it becomes visible: a rejected trial refreshed BOTH poses of every pair in use and only the ones Jacobian blocks read went back
+		// (optimize_edges.h:664-670)
 		constexpr int PD = Solver<FAM, LEAN, G>::PD; const Batch &Bl = LB(); double *pose_a = cur ? Bl.pose1 : Bl.pose, *pose_t = cur ? Bl.pose : Bl.pose1; // accepted / trial copy of the pose table
 		__syncthreads();
 		if (last_rej && lazy_rej) { Wk(cur ^ 1).phase_spantree(true, nullptr); __syncthreads(); } // (the last rejected trial's poses, from its edges in the trial copy)
@@ -702,7 +723,8 @@ __device__ __forceinline__ void lm_one(const Batch &B0, const DevParams &prm, co
 		if (cur) {
 			for (int k = tid; k < d.nK * PD; k += G) Bl.edge[d.o_edge * PD + k] = Bl.edge1[d.o_edge * PD + k];
 			for (int k = tid; k < d.nF * L; k += G) Bl.ulm[d.o_ulm * L + k] = Bl.ulm1[d.o_ulm * L + k];
-			for (int q = tid; q < 2 * d.n_need; q += G) { const long long ps = 2LL * Bl.need_idx[d.o_pair + (q >> 1)] + (q & 1); double v[PD]; ldn<PD>(v, Bl.pose1 + (d.o_pair * 2 + ps) * PD); stn<PD>(Bl.pose + (d.o_pair * 2 + ps) * PD, v); }
+			for (int q = tid; q < 2 * d.n_need; q += G) { const long long ps = 2LL * Bl.need_idx[d.o_pair + (q >> 1)] + (q & 1); double v[PD]; ldn<PD>(v, Bl.pose1 + (d.o_pair * 2 + ps) * PD);
+				stn<PD>(Bl.pose + (d.o_pair * 2 + ps) * PD, v); }
 		}
 	}
 	(void)P;
@@ -716,8 +738,10 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 	static_assert(Tr<FAM>::REL, "speculation: no landmark unknowns");
 	const ProbDesc &d = B0.desc[pidx];
 	const Batch &B = B0;
-	int sp_j = sc->W, sp_round = sc->round0, rej_owner = 0, rej_round = 0; const double *own_el = nullptr; // SPEC: next outcome of the round to take (W: none left), rounds so far, who evaluated the last rejected trial and in which round, this replica's staged trial edges
-	int cur = 0, last_rej = 0; bool lazy_rej = false; // DB: which copy holds the accepted state; the last evaluated trial was rejected (lazy_rej: ... and the pose table of the trial copy was not refreshed for it)
+	int sp_j = sc->W, sp_round = sc->round0, rej_owner = 0, rej_round = 0; const double *own_el = nullptr; // SPEC: next outcome of the round to take (W: none left), rounds so far,
+		// who evaluated the last rejected trial and in which round, this replica's staged trial edges
+	int cur = 0, last_rej = 0; bool lazy_rej = false; // DB: which copy holds the accepted state; the last evaluated trial was rejected (lazy_rej: ... and the pose table of the trial copy was not
+		// refreshed for it)
 	Solver<FAM, LEAN, G> S(B, d, prm, red);
 	constexpr int P = Solver<FAM, LEAN, G>::P, L = Solver<FAM, LEAN, G>::L, O = Solver<FAM, LEAN, G>::O;
 	const SparseSys A = S.make_sys(srba_lds);
@@ -730,7 +754,8 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 #define TOC(slot) do { if (pc) { __syncthreads(); if (tid == 0) pc[slot] += wall_clock64() - tc0; } } while (0)
 	// K6: the LDS image of the system is idle while the capsule is linearised (it is assembled per trial): the U_Ap accumulators of the term-parallel form live there
 	const bool hess_terms = B.hess_terms && d.dense_in_lds && d.n_hap * P * P <= 9 * (d.nb + d.nnzoff);
-	auto hessian = [&](Solver<FAM, LEAN, G> &X) -> int { return hess_terms ? X.phase_hessian_terms(srba_lds) /* == A.diag: the LDS image, idle while the capsule is linearised */ + X.phase_hessian_landmark_blocks() : X.phase_hessian(); };
+	auto hessian = [&](Solver<FAM, LEAN, G> &X) -> int { return hess_terms ? X.phase_hessian_terms(srba_lds) /* == A.diag: the LDS image,
+		idle while the capsule is linearised */ + X.phase_hessian_landmark_blocks() : X.phase_hessian(); };
 	double lambda, nu = 2.0, total_err, RMSE;
 	int iter = 0, trials = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0; bool stop = false;
 	TIC(); S.phase_spantree(false, nullptr, B0.pose1); // S5 (both copies of the poses)
@@ -766,7 +791,8 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 			{
 				lazy = FUSE_K4 && d.need_flat != 0 && d.n_edges * Solver<FAM, LEAN, G>::PD <= 9 * d.nnzoff; // (dense_in_lds is a condition of the launch)
 				if (sp_j == sc->W) { // no outcome left of the last round (or the state has changed since): all replicas evaluate their step of the ladder that starts at (lambda, nu)
-					if (last_rej && rej_round == sp_round) { const double *src = sc->xdelta + ((rej_round & 1) * sc->W + rej_owner) * sc->xstride; double *keep = B.old_edge + d.o_unk * Solver<FAM, LEAN, G>::PD; // (that round's increments are overwritten two rounds from now: keep the last rejected one; old_edge is idle in the double-buffered loop)
+					if (last_rej && rej_round == sp_round) { const double *src = sc->xdelta + ((rej_round & 1) * sc->W + rej_owner) * sc->xstride; double *keep = B.old_edge + d.o_unk * Solver<FAM,
+						LEAN, G>::PD; // (that round's increments are overwritten two rounds from now: keep the last rejected one; old_edge is idle in the double-buffered loop)
 						for (int k = tid; k < n; k += G) keep[k] = spec_ld(src + k); }
 					sp_round++;
 					double lam_w = lambda, nu_w = nu; for (int q = 0; q < sc->w; q++) { lam_w *= nu_w; nu_w *= 2.0; }
@@ -776,7 +802,8 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 						double *xd = sc->xdelta + ((sp_round & 1) * sc->W + sc->w) * sc->xstride;
 						for (int k = tid; k < n; k += G) xd[k] = A.sol(k);
 						TIC(); own_el = Sa.apply_trial(A); TOC(6);
-						TIC(); if (lazy) err_w = St.phase_residuals_fused(resid2, red, own_el); else { St.phase_spantree(true, own_el); __syncthreads(); err_w = St.phase_residuals(resid2, red); } TOC(3);
+						TIC(); if (lazy) err_w = St.phase_residuals_fused(resid2, red, own_el); else { St.phase_spantree(true, own_el); __syncthreads(); err_w = St.phase_residuals(resid2, red); }
+							TOC(3);
 						double den = 0; { const double *g = B.grad + d.o_scal; for (int k = tid; k < n; k += G) { const double dk = A.sol(k); den += dk * (lam_w * dk + g[k]); } }
 						den = grp_sum<G>(den, red);
 						rho_w = (total_err - err_w) / den;
@@ -786,7 +813,8 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 					sp_j = 0;
 				}
 				const double *b = sc->box + ((sp_round & 1) * sc->W + sp_j) * 4; const int code = (int)spec_ld(b);
-				if ((code != 1 && code != 2) || spec_ld(b + 3) != lambda) { if (tid == 0) out->status = 2; stop = true; break; } // a replica that did not answer, or one that is not where this one is: reported by the host as an error
+				if ((code != 1 && code != 2) || spec_ld(b + 3) != lambda) { if (tid == 0) out->status = 2; stop = true; break; } // a replica that did not answer,
+					// or one that is not where this one is: reported by the host as an error
 				if (code != 2) { // that step of the ladder was not positive definite
 					n_notpd++; lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
 					sp_j++;
@@ -801,11 +829,14 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 			if (rho > 0) {
 				n_acc++;
 				{ // the accepted trial is replica sp_j's: the others re-apply its increment to their copy of the accepted state (same numbers, same arithmetic)
-					if (sp_j != sc->w && lazy) { // ... or, where a trial leaves nothing but its edges and its residuals (lazy), copy those from the winner's arena (written before its exchange, untouched until two accepted trials from now)
+					if (sp_j != sc->w && lazy) { // ... or, where a trial leaves nothing but its edges and its residuals (lazy), copy those from the winner's arena (written before its exchange,
+						// untouched until two accepted trials from now)
 						constexpr int PD = Solver<FAM, LEAN, G>::PD; typedef typename Solver<FAM, LEAN, G>::PO PO; const long long off = sc->stride * (sp_j - sc->w);
-						const double *we = (const double *)((const char *)Bt.edge + off) + d.o_edge * PD, *wr = (const double *)((const char *)resid2 + off) + (long long)d.o_obs * O; double *el = A.off;
+						const double *we = (const double *)((const char *)Bt.edge + off) + d.o_edge * PD, *wr = (const double *)((const char *)resid2 + off) + (long long)d.o_obs * O;
+							double *el = A.off;
 						TIC(); __syncthreads();
-						for (int i = tid; i < d.n_edges; i += G) { const typename Solver<FAM, LEAN, G>::pose_t e = PO::ld(we + i * PD); if (i < d.nK) PO::st(Bt.edge + (d.o_edge + i) * PD, e); double t[PD]; PO::to(t, e);
+						for (int i = tid; i < d.n_edges; i += G) { const typename Solver<FAM, LEAN, G>::pose_t e = PO::ld(we + i * PD); if (i < d.nK) PO::st(Bt.edge + (d.o_edge + i) * PD, e);
+							double t[PD]; PO::to(t, e);
 #pragma unroll
 							for (int k = 0; k < PD; k++) el[i * PD + k] = t[k]; }
 						{ double *mr = resid2 + (long long)d.o_obs * O; for (int k = tid; k < nObs * O; k += G) mr[k] = wr[k]; }
@@ -845,7 +876,8 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 		out->num_iters = iter; out->num_trials = trials; out->num_not_pd = n_notpd; out->num_accepted = n_acc; out->num_relinearized = n_relin; out->stop_reason = stopmask;
 		out->total_sqr_error_final = total_err; out->obs_rmse = RMSE; out->lambda_final = lambda;
 	}
-	{ // the reference's partial restore, where it becomes visible: a rejected trial refreshed BOTH poses of every pair in use and only the ones Jacobian blocks read went back (optimize_edges.h:664-670)
+	{ // the reference's partial restore, where it becomes visible: a rejected trial refreshed BOTH poses of every pair in use and only the ones Jacobian blocks read went back
+		// (optimize_edges.h:664-670)
 		constexpr int PD = Solver<FAM, LEAN, G>::PD; const Batch Ba = copy_view(B0, cur), Bt = copy_view(B0, cur ^ 1);
 		__syncthreads();
 		if (last_rej && !(rej_round == sp_round && rej_owner == sc->w)) { // the trial copy of this replica holds ITS last trial: make it the sequentially last evaluated one (the quirk below shows it)
@@ -856,7 +888,8 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 			if (!lazy_rej) Sl.phase_spantree(true, el);
 			__syncthreads();
 		}
-		if (last_rej && lazy_rej) { Solver<FAM, LEAN, G> Sl(B0, d, prm, red, cur ^ 1); Sl.phase_spantree(true, nullptr); __syncthreads(); } // (the last rejected trial's poses, from its edges in the trial copy)
+		if (last_rej && lazy_rej) { Solver<FAM, LEAN, G> Sl(B0, d, prm, red, cur ^ 1); Sl.phase_spantree(true, nullptr); __syncthreads(); } // (the last rejected trial's poses,
+			// from its edges in the trial copy)
 		if (last_rej) for (int q = tid; q < 2 * d.n_need; q += G) {
 			const long long ps = 2LL * B0.need_idx[d.o_pair + (q >> 1)] + (q & 1);
 			if (!B0.pose_req[d.o_pair * 2 + ps]) { double v[PD]; ldn<PD>(v, Bt.pose + (d.o_pair * 2 + ps) * PD); stn<PD>(Ba.pose + (d.o_pair * 2 + ps) * PD, v); }
@@ -867,7 +900,8 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 		__syncthreads();
 		if (cur) {
 			for (int k = tid; k < d.nK * PD; k += G) B0.edge[d.o_edge * PD + k] = B0.edge1[d.o_edge * PD + k];
-			for (int q = tid; q < 2 * d.n_need; q += G) { const long long ps = 2LL * B0.need_idx[d.o_pair + (q >> 1)] + (q & 1); double v[PD]; ldn<PD>(v, B0.pose1 + (d.o_pair * 2 + ps) * PD); stn<PD>(B0.pose + (d.o_pair * 2 + ps) * PD, v); }
+			for (int q = tid; q < 2 * d.n_need; q += G) { const long long ps = 2LL * B0.need_idx[d.o_pair + (q >> 1)] + (q & 1); double v[PD]; ldn<PD>(v, B0.pose1 + (d.o_pair * 2 + ps) * PD);
+				stn<PD>(B0.pose + (d.o_pair * 2 + ps) * PD, v); }
 		}
 	}
 	(void)P; (void)L;
@@ -876,7 +910,10 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 // wavefront pulls capsules (sorted longest-first inside the class) from a shared counter until the class is exhausted. A launch therefore has ONE
 // tail (its last capsules) instead of one per chunk, and the chip stays full while big (LDS-bound) and small (wave-slot-bound) classes drain side by side.
 #ifndef SRBA_LM_BY_POINTER
-#define SRBA_LM_BY_POINTER 1 /* the fused LM kernels take `const Batch *` (a device copy of the batch record, uploaded with the input arena) and every phase of lm_one works through its own laundered reference (srba_device.hpp lnd): the batch's ~100 array pointers are scalar loads at the start of the phase that uses them instead of 220 - 530 spilled scalar registers. 0: the record as a kernel argument (rounds 1 - 4) */
+// the fused LM kernels take `const Batch *` (a device copy of the batch record, uploaded with the input arena) and every phase of lm_one works through its own laundered reference
+// (srba_device.hpp lnd): the batch's ~100 array pointers are scalar loads at the start of the phase that uses them instead of 220 - 530 spilled scalar registers. 0: the record as a kernel
+// argument (rounds 1 - 4)
+#define SRBA_LM_BY_POINTER 1
 #endif
 #if SRBA_LM_BY_POINTER
 #define SRBA_LM_BATCH_ARG const Batch *__restrict__ Bptr, const DevParams *__restrict__ Pptr
@@ -892,7 +929,8 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 template <int FAM>
 __global__ void __launch_bounds__(SRBA_WG) SRBA_OCC k_lm_run(SRBA_LM_BATCH_ARG, int first, int count, int *next) { SRBA_LM_BATCH_REF;
 	for (;;) {
-		int i = 0; if (threadIdx.x == 0) { i = atomicAdd(next, 1); if (i == 0) *(long long *)(next + 2) = wall_clock64(); /* when the class started (srba_hip_launch_order): record = {counter, pad, stamp} */ }
+		int i = 0; if (threadIdx.x == 0) { i = atomicAdd(next, 1); if (i == 0) *(long long *)(next + 2) = wall_clock64(); /* when the class started (srba_hip_launch_order): record = {counter, pad,
+			stamp} */ }
 		i = __builtin_amdgcn_readfirstlane(i);
 		if (i >= count) break;
 		lm_one<FAM, (SRBA_LM_DB != 0), false, 64, false, SRBA_LM_LND>(B, prm, B.order[first + i]);
@@ -934,8 +972,15 @@ __global__ void __launch_bounds__(2 * SRBA_WG) __attribute__((amdgpu_waves_per_e
 	}
 }
 
+#ifndef SRBA_WG_WAVES
+#define SRBA_WG_WAVES 2 /* wavefronts per SIMD the workgroup kernels are compiled for (256 registers) */
+#endif
+#define SRBA_WG_TOP (SRBA_WG_WAVES >= 3 ? 768 : 512) /* threads of the one-per-CU workgroup class: every wave slot of the CU */
 #ifndef SRBA_WG_BY_POINTER
-#define SRBA_WG_BY_POINTER 1 /* the workgroup kernels read the ~100 array pointers of the batch from a device copy of `Batch` (scalar loads where a pointer is used) instead of keeping them all in scalar registers from the kernel arguments: their phases last tens of microseconds, a scalar load is nothing there, and 450 - 530 spilled scalars (v_readlane restores: a quarter of the instructions of the Hessian and Schur loops) are */
+// the workgroup kernels read the ~100 array pointers of the batch from a device copy of `Batch` (scalar loads where a pointer is used) instead of keeping them all in scalar registers from
+// the kernel arguments: their phases last tens of microseconds, a scalar load is nothing there, and 450 - 530 spilled scalars (v_readlane restores: a quarter of the instructions of the
+// Hessian and Schur loops) are
+#define SRBA_WG_BY_POINTER 1
 #endif
 #if SRBA_WG_BY_POINTER
 #define SRBA_WG_BATCH_ARG const Batch *__restrict__ Bptr, const DevParams *__restrict__ Pptr
@@ -952,9 +997,9 @@ __global__ void __launch_bounds__(2 * SRBA_WG) __attribute__((amdgpu_waves_per_e
 // LEAN diet (one Schur term, one Hessian term, one spanning-tree pair in flight) under a cap of 256 -- two wavefronts per SIMD, i.e. two 256-thread workgroups per CU.
 // LDS: WG_LDS_DOUBLES (the solver's staging, x, reduction scratch, flags, the work counter's slot).
 template <int FAM, int G>
-__global__ void __launch_bounds__(G) __attribute__((amdgpu_waves_per_eu(2, 2))) k_lm_wg(SRBA_WG_BATCH_ARG, int first, int count, int *next) {
+__global__ void __launch_bounds__(G) __attribute__((amdgpu_waves_per_eu(SRBA_WG_WAVES, SRBA_WG_WAVES))) k_lm_wg(SRBA_WG_BATCH_ARG, int first, int count, int *next) {
 	SRBA_WG_BATCH_REF;
-	double *red = srba_lds + WG_RED; int *slot = (int *)(red + 9); // (red[0 .. 7]: group reductions, red + 8: the solver's flag)
+	double *red = srba_lds + WG_RED; int *slot = (int *)(red + 13); // (red[0 .. 11]: group reductions, red + 12: the solver's flag)
 	for (;;) {
 		if (threadIdx.x == 0) { const int i0 = atomicAdd(next, 1); *slot = i0; if (i0 == 0) *(long long *)(next + 2) = wall_clock64(); }
 		__syncthreads(); const int i = *slot; __syncthreads();
@@ -963,7 +1008,8 @@ __global__ void __launch_bounds__(G) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 		__syncthreads();
 	}
 }
-template <int FAM, int G> __global__ void __launch_bounds__(G) __attribute__((amdgpu_waves_per_eu(2, 2))) k_solve_wg(const Batch B, const DevParams prm, int first) {
+template <int FAM, int G> __global__ void __launch_bounds__(G) __attribute__((amdgpu_waves_per_eu(SRBA_WG_WAVES, SRBA_WG_WAVES))) k_solve_wg(const Batch B, const DevParams prm, int first) {
+	// (G = 768 only with SRBA_WG_WAVES = 3)
 	const int pidx = B.order[first + blockIdx.x]; const ProbDesc &d = B.desc[pidx]; Solver<FAM, true, G> S(B, d, prm, srba_lds + WG_RED);
 	const SparseSys A = S.make_sys(srba_lds);
 	const bool ok = S.solve(A, B.lambda_io[pidx]);
@@ -977,19 +1023,23 @@ template <int FAM>
 __global__ void __launch_bounds__(2 * SRBA_WG) __attribute__((amdgpu_waves_per_eu(3, 3))) k_lm_spec(const Batch B, const DevParams prm, int lds_doubles, long long stride, SpecCtl sc) {
 	double *red = srba_lds + lds_doubles; sc.w = blockIdx.x; sc.stride = stride;
 	const Batch Bw = shift_work(B, stride * sc.w); const ProbDesc &d = B.desc[0];
-	if (!sc.w) { constexpr int PD = Tr<FAM>::PD; for (int k = threadIdx.x; k < d.nK * PD; k += 2 * SRBA_WG) sc.edge_backup[k] = B.edge[d.o_edge * PD + k]; } // (the host's way back if the replicas lose step: SpecCtl::edge_backup)
-	if (sc.w) { constexpr int PD = Tr<FAM>::PD; // the accepted state the run starts from (replica 0's: srba_hip_reset_state, or what an earlier run left); replica 0 writes there after the first exchange only
+	if (!sc.w) { constexpr int PD = Tr<FAM>::PD; for (int k = threadIdx.x; k < d.nK * PD; k += 2 * SRBA_WG) sc.edge_backup[k] = B.edge[d.o_edge * PD + k]; }
+		// (the host's way back if the replicas lose step: SpecCtl::edge_backup)
+	if (sc.w) { constexpr int PD = Tr<FAM>::PD; // the accepted state the run starts from (replica 0's: srba_hip_reset_state, or what an earlier run left);
+		// replica 0 writes there after the first exchange only
 		for (int k = threadIdx.x; k < d.n_edges * PD; k += 2 * SRBA_WG) Bw.edge[d.o_edge * PD + k] = B.edge[d.o_edge * PD + k];
 		__syncthreads(); }
 	lm_spec<FAM>(Bw, prm, 0, red, &sc);
 }
 
 // ---- stepwise kernels
-template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_spantree(const Batch B, const DevParams prm, int only_needed) { Solver<FAM> S(B, B.desc[blockIdx.x], prm); S.phase_spantree(only_needed != 0); }
+template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_spantree(const Batch B, const DevParams prm, int only_needed) { Solver<FAM> S(B, B.desc[blockIdx.x], prm);
+	S.phase_spantree(only_needed != 0); }
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_residuals(const Batch B, const DevParams prm) {
 	Solver<FAM> S(B, B.desc[blockIdx.x], prm); const double e = S.phase_residuals(B.resid, srba_lds); if (threadIdx.x == 0) B.chi2[blockIdx.x] = e;
 }
-template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_linearize(const Batch B, const DevParams prm, int lds_doubles, const int *list /* capsule of every workgroup, or NULL: the whole batch */) {
+template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_linearize(const Batch B, const DevParams prm, int lds_doubles, const int *list /* capsule of every workgroup,
+	or NULL: the whole batch */) {
 	constexpr int P = Worker<FAM>::P;
 	const int pidx = list ? list[blockIdx.x] : blockIdx.x;
 	Solver<FAM> S(B, B.desc[pidx], prm);
@@ -1022,7 +1072,8 @@ template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_apply(const Batc
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_rollback(const Batch B, const DevParams prm) { Solver<FAM> S(B, B.desc[blockIdx.x], prm); S.restore(); }
 
 #ifdef SRBA_PROBE_KERNELS /* diagnostic build only (tools/probe_phases.sh): every phase of the workgroup kernel as a kernel of its own, to read its register need from the code object */
-#define SRBA_PROBE(NAME, BODY) template <int FAM> __global__ void __launch_bounds__(256) NAME(const Batch B, const DevParams prm) { Solver<FAM, true, 256> S(B, B.desc[blockIdx.x], prm, srba_lds + WG_RED); const SparseSys A = S.make_sys(srba_lds); (void)A; BODY; }
+#define SRBA_PROBE(NAME, BODY) template <int FAM> __global__ void __launch_bounds__(256) NAME(const Batch B, const DevParams prm) { Solver<FAM, true, 256> S(B, B.desc[blockIdx.x], prm, \
+	srba_lds + WG_RED); const SparseSys A = S.make_sys(srba_lds); (void)A; BODY; }
 SRBA_PROBE(kp_spantree, S.phase_spantree(false, nullptr, B.pose1))
 SRBA_PROBE(kp_spantree_need, S.phase_spantree(true, nullptr))
 SRBA_PROBE(kp_jacobians, S.phase_jacobians())
@@ -1035,8 +1086,10 @@ SRBA_PROBE(kp_schur, S.schur_reduce(B.lambda_io[blockIdx.x]))
 SRBA_PROBE(kp_chol, B.notpd[blockIdx.x] = wg_chol_solve<4>(A.tiles, A.linv, A.nt, (lds_f64 *)srba_lds))
 SRBA_PROBE(kp_features, S.schur_features())
 SRBA_PROBE(kp_apply, S.apply_trial(A))
-template <int FAM> void probe_instantiate() { Batch B; DevParams p; hipLaunchKernelGGL(kp_spantree<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_spantree_need<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_jacobians<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_hessian<FAM>, 1, 256, 0, 0, B, p);
-	hipLaunchKernelGGL(kp_gradient<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_hessian_lds<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_schur_lds<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_residuals<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_schur<FAM>, 1, 256, 0, 0, B, p);
+template <int FAM> void probe_instantiate() { Batch B; DevParams p; hipLaunchKernelGGL(kp_spantree<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_spantree_need<FAM>, 1, 256, 0, 0, B, p);
+	hipLaunchKernelGGL(kp_jacobians<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_hessian<FAM>, 1, 256, 0, 0, B, p);
+	hipLaunchKernelGGL(kp_gradient<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_hessian_lds<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_schur_lds<FAM>, 1, 256, 0, 0, B, p);
+		hipLaunchKernelGGL(kp_residuals<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_schur<FAM>, 1, 256, 0, 0, B, p);
 	hipLaunchKernelGGL(kp_chol<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_features<FAM>, 1, 256, 0, 0, B, p); hipLaunchKernelGGL(kp_apply<FAM>, 1, 256, 0, 0, B, p); }
 template void probe_instantiate<SRBA_PROBE_KERNELS>();
 #endif
@@ -1098,7 +1151,9 @@ struct Arena { // layout builder: 256-byte aligned sub-allocations inside one bu
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->fail(std::string(#call) + ": " + hipGetErrorString(e_)); return -1; } } while (0)
 #define LNCHK(lane, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (lane)->error = std::string(#call) + ": " + hipGetErrorString(e_); return -1; } } while (0)
 static const int kBigLanes = 16;
-struct BigLane { int id = 0, slots = 1 /* windows its buffers have room for (srbadev::Gang) */; hipStream_t stream = nullptr; double *d_part = nullptr, *d_scal = nullptr; int *d_iscal = nullptr /* behind the scalars in the same allocation: one copy reads both back */; void *h_fetch = nullptr /* page-locked landing buffer of that copy */; hipEvent_t e0 = nullptr, e1 = nullptr; double chol_ms = 0, chol_flops = 0; long long chol_count = 0, chol_seqs = 0; int chol_nmax = 0; std::string error; };
+struct BigLane { int id = 0, slots = 1 /* windows its buffers have room for (srbadev::Gang) */; hipStream_t stream = nullptr; double *d_part = nullptr, *d_scal = nullptr;
+	int *d_iscal = nullptr /* behind the scalars in the same allocation: one copy reads both back */; void *h_fetch = nullptr /* page-locked landing buffer of that copy */; hipEvent_t e0 = nullptr,
+	e1 = nullptr; double chol_ms = 0, chol_flops = 0; long long chol_count = 0, chol_seqs = 0; int chol_nmax = 0; std::string error; };
 
 } // namespace
 
@@ -1184,7 +1239,8 @@ static void symbolic_factor(const srba_problem_capsule &k, const ProbDesc &d, in
 	} else { out.hapf_dst.assign((size_t)k.n_hapf * PB, 0); out.hf_dst.assign(k.n_hf, 0); }
 	// 5) blocks without a source (fill-in; unified index: diag k -> k, off-diagonal i -> nb+i)
 	{ std::vector<char> covered(nb + out.row.size(), 0);
-	  auto mark = [&](const std::vector<int32_t> &v) { for (size_t i = 0; i < v.size(); i++) { const int32_t dsti = v[i]; if (dsti == (int32_t)0x80000000) continue; covered[dsti >= 0 ? nb + (dsti >> 1) : -1 - dsti] = 1; } };
+	  auto mark = [&](const std::vector<int32_t> &v) { for (size_t i = 0; i < v.size(); i++) { const int32_t dsti = v[i]; if (dsti == (int32_t)0x80000000) continue;
+	  	covered[dsti >= 0 ? nb + (dsti >> 1) : -1 - dsti] = 1; } };
 	  mark(out.hap_dst); if (full_system && L == 3) { mark(out.hapf_dst); mark(out.hf_dst); }
 	  out.fill.clear(); for (size_t u = 0; u < covered.size(); u++) if (!covered[u]) out.fill.push_back((int32_t)u); }
 }
@@ -1211,24 +1267,28 @@ static void symbolic_dense(const srba_problem_capsule &k, const ProbDesc &d, int
 		for (int b = 0; b < k.n_hf; b++) out.hf_dst.push_back(dst_of(lb + k.hf_i[b], lb + k.hf_j[b]));
 	} else { out.hapf_dst.assign((size_t)k.n_hapf * PB, 0); out.hf_dst.assign(k.n_hf, 0); }
 	const int nnz = nb * (nb - 1) / 2; std::vector<char> covered(nb + nnz, 0);
-	auto mark = [&](const std::vector<int32_t> &v) { for (size_t i = 0; i < v.size(); i++) { const int32_t dsti = v[i]; if (dsti == (int32_t)0x80000000) continue; covered[dsti >= 0 ? nb + (dsti >> 1) : -1 - dsti] = 1; } };
+	auto mark = [&](const std::vector<int32_t> &v) { for (size_t i = 0; i < v.size(); i++) { const int32_t dsti = v[i]; if (dsti == (int32_t)0x80000000) continue;
+		covered[dsti >= 0 ? nb + (dsti >> 1) : -1 - dsti] = 1; } };
 	mark(out.hap_dst); if (full_system && L == 3) { mark(out.hapf_dst); mark(out.hf_dst); }
 	for (size_t u = 0; u < covered.size(); u++) if (!covered[u]) out.fill.push_back((int32_t)u);
 }
 
-struct LaunchJob { int queue, cls, first, count; double cost; int grid; int delay_us = 0; int lean = 0 /* k_lm_run_lean: three wavefronts per SIMD */, two = 0 /* k_lm_run2: two wavefronts per capsule */; };
+struct LaunchJob { int queue, cls, first, count; double cost; int grid; int delay_us = 0; int lean = 0 /* k_lm_run_lean: three wavefronts per SIMD */,
+	two = 0 /* k_lm_run2: two wavefronts per capsule */; };
 using srbadev::kBigPart;
 static const int kMaxJobs = 1024;
 
 // Index-range check of one capsule (every index the kernels dereference): a wrong capsule is reported at upload instead of reading out of bounds on the device
 static const char *validate_capsule(const srba_problem_capsule &k) {
 	auto in = [](int v, int lo, int hi) { return v >= lo && v < hi; };
-	if (k.n_edges < 0 || k.n_unk_edges < 0 || k.n_unk_lms < 0 || k.n_known_lms < 0 || k.n_pairs < 0 || k.n_path < 0 || k.n_obs < 0 || k.n_valid < 0 || k.n_bp < 0 || k.n_bf < 0 || k.n_hap < 0 || k.n_hf < 0 || k.n_hapf < 0 || k.n_sch_terms < 0) return "negative size";
+	if (k.n_edges < 0 || k.n_unk_edges < 0 || k.n_unk_lms < 0 || k.n_known_lms < 0 || k.n_pairs < 0 || k.n_path < 0 || k.n_obs < 0 || k.n_valid < 0 || k.n_bp < 0 || k.n_bf < 0 || k.n_hap < 0 ||
+		k.n_hf < 0 || k.n_hapf < 0 || k.n_sch_terms < 0) return "negative size";
 	if (k.n_unk_edges > k.n_edges || k.n_unk_edges + k.n_unk_lms == 0) return "no unknowns / more unknown edges than edges";
 	const int np2 = 2 * k.n_pairs;
 	auto lmref = [&](int v) { return v >= 0 ? v < k.n_unk_lms : (-1 - v) < k.n_known_lms; };
 	// every array is checked for presence before any loop below reads it (validation runs on upload worker threads: a crash here would take the process down off the calling thread)
-	if (!k.edge_pose || (k.n_unk_lms && !k.ulm_pos) || (k.n_known_lms && !k.klm_pos) || (k.n_obs && (!k.obs_pose || !k.obs_lm || !k.obs_valid || !k.obs_z)) || (k.n_path && !k.path_edge)) return "null data array";
+	if (!k.edge_pose || (k.n_unk_lms && !k.ulm_pos) || (k.n_known_lms && !k.klm_pos) || (k.n_obs && (!k.obs_pose || !k.obs_lm || !k.obs_valid || !k.obs_z)) || (k.n_path && !k.path_edge)) return
+		"null data array";
 	if (k.n_path > 0 && k.n_pairs == 0) return "path entries without pairs";
 	if (k.n_pairs && (!k.pair_path_off || !k.pair_needed || !k.pose_required || k.pair_path_off[0] != 0 || k.pair_path_off[k.n_pairs] != k.n_path)) return "pair_path_off";
 	for (int i = 0; i < k.n_pairs; i++) if (k.pair_path_off[i + 1] < k.pair_path_off[i]) return "pair_path_off not monotone";
@@ -1238,7 +1298,8 @@ static const char *validate_capsule(const srba_problem_capsule &k) {
 	if (k.n_bf && (!k.bf_col || !k.bf_res || !k.bf_pose)) return "null dh_df table";
 	if (k.n_unk_edges && (!k.colp_off || k.colp_off[0] != 0 || k.colp_off[k.n_unk_edges] != k.n_bp)) return "colp_off";
 	for (int i = 0; i < k.n_unk_edges; i++) if (k.colp_off[i + 1] < k.colp_off[i]) return "colp_off not monotone";
-	for (int i = 0; i < k.n_bp; i++) if (!in(k.bp_col[i], 0, k.n_unk_edges) || !in(k.bp_res[i], 0, k.n_obs) || !in(k.bp_A[i], -1, np2) || !in(k.bp_D[i], -1, np2) || !lmref(k.bp_lm[i])) return "dh_dAp block table";
+	for (int i = 0; i < k.n_bp; i++) if (!in(k.bp_col[i], 0, k.n_unk_edges) || !in(k.bp_res[i], 0, k.n_obs) || !in(k.bp_A[i], -1, np2) || !in(k.bp_D[i], -1,
+		np2) || !lmref(k.bp_lm[i])) return "dh_dAp block table";
 	if (k.n_unk_lms && (!k.colf_off || k.colf_off[0] != 0 || k.colf_off[k.n_unk_lms] != k.n_bf)) return "colf_off";
 	for (int i = 0; i < k.n_unk_lms; i++) if (k.colf_off[i + 1] < k.colf_off[i]) return "colf_off not monotone";
 	for (int i = 0; i < k.n_bf; i++) if (!in(k.bf_col[i], 0, k.n_unk_lms) || !in(k.bf_res[i], 0, k.n_obs) || !in(k.bf_pose[i], -1, np2)) return "dh_df block table";
@@ -1257,7 +1318,8 @@ static const char *validate_capsule(const srba_problem_capsule &k) {
 	if (k.n_hapf && (!k.hapf_i || !k.hapf_j || !k.hapf_term_off || !k.hapf_t1 || !k.hapf_t2 || !k.lm_hapf_off || !k.lm_hapf_idx)) return "null HApf table";
 	if (k.n_hapf && (k.hapf_term_off[0] != 0 || k.hapf_term_off[k.n_hapf] != k.n_hapf_terms)) return "hapf_term_off";
 	for (int i = 0; i < k.n_hapf; i++) if (k.hapf_term_off[i + 1] < k.hapf_term_off[i]) return "hapf_term_off not monotone";
-	if (k.n_hapf) { if (k.lm_hapf_off[0] != 0 || k.lm_hapf_off[k.n_unk_lms] != k.n_hapf) return "lm_hapf_off"; for (int i = 0; i < k.n_unk_lms; i++) if (k.lm_hapf_off[i + 1] < k.lm_hapf_off[i]) return "lm_hapf_off not monotone";
+	if (k.n_hapf) { if (k.lm_hapf_off[0] != 0 || k.lm_hapf_off[k.n_unk_lms] != k.n_hapf) return "lm_hapf_off"; for (int i = 0; i < k.n_unk_lms;
+		i++) if (k.lm_hapf_off[i + 1] < k.lm_hapf_off[i]) return "lm_hapf_off not monotone";
 		for (int i = 0; i < k.n_hapf; i++) if (!in(k.lm_hapf_idx[i], 0, k.n_hapf)) return "lm_hapf_idx"; }
 	for (int i = 0; i < k.n_hapf; i++) if (!in(k.hapf_i[i], 0, k.n_unk_edges) || !in(k.hapf_j[i], 0, k.n_unk_lms)) return "HApf block table";
 	for (int i = 0; i < k.n_hapf_terms; i++) if (!in(k.hapf_t1[i], 0, k.n_bp) || !in(k.hapf_t2[i], 0, k.n_bf)) return "HApf terms";
@@ -1278,31 +1340,44 @@ struct srba_hip_ctx {
 	std::string error;
 	// batch
 	int n_prob = 0; std::vector<ProbDesc> desc; Batch B; srba_batch_stats stats;
-	char *d_in = nullptr; size_t cap_in = 0; char *d_wk = nullptr; size_t cap_wk = 0; int *d_next = nullptr; Batch *d_batch = nullptr; bool batch_copied = false; // d_batch: device copy of B (the workgroup kernels read the batch's pointers from it)
+	char *d_in = nullptr; size_t cap_in = 0; char *d_wk = nullptr; size_t cap_wk = 0; int *d_next = nullptr; Batch *d_batch = nullptr; bool batch_copied = false;
+		// d_batch: device copy of B (the workgroup kernels read the batch's pointers from it)
 	double *d_part = nullptr; double *d_scal = nullptr; int *d_iscal = nullptr; // big path: partial sums [3][kBigPart], scalars, int flags (ninv, not-pd)
 	std::vector<int> big_ld; // per capsule: leading dimension of its dense system when it runs on the big path, else 0
-	double big_chol_ms = 0, big_chol_flops = 0; long long big_chol_count = 0, big_chol_seqs = 0 /* launch sequences: one factors all windows of a gang */; int big_chol_nmax = 0; // Cholesky time / flops of the big path since the last upload (sum over the lanes)
+	double big_chol_ms = 0, big_chol_flops = 0; long long big_chol_count = 0, big_chol_seqs = 0 /* launch sequences: one factors all windows of a gang */; int big_chol_nmax = 0;
+		// Cholesky time / flops of the big path since the last upload (sum over the lanes)
 	BigLane lanes[kBigLanes]; int n_lanes_ready = 0; // lane 0 = the context stream and buffers; the others are created on first use
-	bool big_gang = true, big_persistent = false, big_fused_step = true; int big_lanes_max = kBigLanes, big_gang_slots = srbadev::kGang, gang_from_nb = 0 /* landmark windows with this many block rows or more take the gang instead of one wavefront (0: off) */; // big path: windows of a batch in lock-step on one stream (gang) or one host thread + stream per window
+	bool big_gang = true, big_persistent = false, big_fused_step = true; int big_lanes_max = kBigLanes, big_gang_slots = srbadev::kGang, gang_from_nb = 0 /* landmark windows with this many block rows
+		or more take the gang instead of one wavefront (0: off) */; // big path: windows of a batch in lock-step on one stream (gang) or one host thread + stream per window
 	int upload_threads = 1; bool dense_left = true; int hbm_from_kb = 48; bool dense_blocks_ok = true; // mid-size nearly-full systems use the dense block layout in LDS
 	bool lin_terms = true, lm_terms = true; // term-parallel U_Ap accumulation in LDS: srba_hip_linearize / the fused LM kernel
 	// fused normal equations of the relative-pose SE2 family (srba_assemble.hpp): capsules packed into bins (workgroups) by the LDS image they need, one launch; the rest take k_linearize
-	bool asm_on = true, asm_ready = false, asm_flags_set = false, jp_stale = false; size_t off_valid = 0, off_bp_ok = 0; long long n_valid_total = 0, n_bp_total = 0; int asm_max_kb = srbadev::ASM_BIN_BYTES / 1024; srbadev::AsmTables asm_tab = {nullptr, nullptr, nullptr}; const int *asm_list = nullptr;
+	bool asm_on = true, asm_ready = false, asm_flags_set = false, jp_stale = false; size_t off_valid = 0, off_bp_ok = 0; long long n_valid_total = 0, n_bp_total = 0;
+		int asm_max_kb = srbadev::ASM_BIN_BYTES / 1024; srbadev::AsmTables asm_tab = {nullptr, nullptr, nullptr}; const int *asm_list = nullptr;
 	int asm_bins = 0, asm_rest = 0; // bins of the fused launch; capsules left to the unfused kernel (asm_list holds their indices)
 	srbadev::FlatMap flat; bool flat_ready = false, use_flat = true; // pair -> capsule map of the flat spanning-tree kernel (srba_flat.hpp), filled on first use after an upload
 	int big_min_sys = 480;   // systems with more scalar unknowns than this skip the block-sparse symbolic analysis and go dense (big path)
-	struct Staging { char *p = nullptr; bool pinned = false; char *get() const { return p; } void release() { if (p) { if (pinned) hipHostFree(p); else delete[] p; } p = nullptr; } } h_in; size_t h_in_cap = 0; size_t h_off_order = 0; // host staging of the input arena (kept: the launch order is read back from it); page-locked while it is small (the per-key-frame use: the copy to the device then needs no wait)
-	static constexpr size_t kPinnedMax = (size_t)8 << 20; hipEvent_t ev_h2d = nullptr; bool h2d_pending = false, defer_upload_sync = false; // optimize_capsule: the upload is not waited for; the next writer of the staging buffer waits for this event
+	struct Staging { char *p = nullptr; bool pinned = false; char *get() const { return p; } void release() { if (p) { if (pinned) hipHostFree(p); else delete[] p; } p = nullptr; } } h_in;
+		size_t h_in_cap = 0; size_t h_off_order = 0; // host staging of the input arena (kept: the launch order is read back from it); page-locked while it is small (the per-key-frame use: the copy
+		// to the device then needs no wait)
+	static constexpr size_t kPinnedMax = (size_t)8 << 20; hipEvent_t ev_h2d = nullptr; bool h2d_pending = false, defer_upload_sync = false; // optimize_capsule: the upload is not waited for;
+		// the next writer of the staging buffer waits for this event
 	char *h_out = nullptr; size_t h_out_cap = 0; // page-locked landing area of srba_hip_optimize_capsule (result record | unknowns .. spanning-tree poses)
 	std::vector<int> delay_us; int class_prio = 0; // experiment knobs: per plan job delay before its launch (overrides the staggered start); stream priorities by class size
 	int stagger_ns = 300, stagger_max_us = 5000; // staggered start of the class launches: see plan_launches
 	// lambda-ladder speculation for a batch of ONE capsule (k_lm_spec): spec_w replicas of the work arena, spec_stride bytes apart; d_spec = flags | outcomes | increments (SpecCtl)
-	long long spec_launches = 0; bool spec_on = true, spec_ready = false; int spec_w = 12; size_t spec_stride = 0; char *d_spec = nullptr; static constexpr int kSpecMaxW = 32, kSpecMaxN = 768; static constexpr size_t kSpecBackupOff = 256 + 8 * (2 * kSpecMaxW * 4) + 8 * (2 * (size_t)kSpecMaxW * kSpecMaxN), kSpecBytes = kSpecBackupOff + 8 * 5 * (size_t)kSpecMaxN; bool spec_suppress = false, spec_test_drop = false; long long spec_fallbacks = 0;
+	long long spec_launches = 0; bool spec_on = true, spec_ready = false; int spec_w = 12; size_t spec_stride = 0; char *d_spec = nullptr; static constexpr int kSpecMaxW = 32, kSpecMaxN = 768;
+		static constexpr size_t kSpecBackupOff = 256 + 8 * (2 * kSpecMaxW * 4) + 8 * (2 * (size_t)kSpecMaxW * kSpecMaxN), kSpecBytes = kSpecBackupOff + 8 * 5 * (size_t)kSpecMaxN;
+		bool spec_suppress = false, spec_test_drop = false; long long spec_fallbacks = 0;
 	bool wg_hs = true; /* SRBA_HIP_WG_HS=0: U_Ap blocks of the workgroup windows in memory (the first version of the path) instead of in LDS */
-	bool wg_on = true; int wg_from_sys = 24, wg256_from_sys = 96; // SE3 landmark windows with a Schur-reduced system of at least wg_from_sys scalars run on a workgroup (k_lm_wg: 128 threads, 256 from wg256_from_sys); SRBA_HIP_WG=0 / SRBA_HIP_WG_FROM / SRBA_HIP_WG256_FROM
+	bool wg_on = true; int wg_from_sys = 24, wg256_from_sys = 96; // SE3 landmark windows with a Schur-reduced system of at least wg_from_sys scalars run on a workgroup (k_lm_wg: 128 threads,
+		// 256 from wg256_from_sys); SRBA_HIP_WG=0 / SRBA_HIP_WG_FROM / SRBA_HIP_WG256_FROM
 	bool two_on = true; int two_from_kb = 20, two_min_count = 128; // k_lm_run2 (two wavefronts per capsule) for the relative-pose SE2 classes whose LDS image is at least this big
-	bool lean_on = true; int lean_min_count = 512; // k_lm_run_lean for the size classes of which at least nine wavefronts fit the LDS of a CU (relative-pose SE2, classes with at least this many capsules)
-	int max_lds_kb = 1 << 20, min_chunk = 384, max_parts_per_queue = 2; int class_streams = 64 /* sched 3: the class launches are dealt round-robin to at most this many streams */, n_queues = 16, sched = 3, n_streams_used = 1, n_cu = 256, waves_per_cu = 8, lds_per_cu = 160 * 1024; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0}, cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
+	bool lean_on = true; int lean_min_count = 512; // k_lm_run_lean for the size classes of which at least nine wavefronts fit the LDS of a CU (relative-pose SE2,
+		// classes with at least this many capsules)
+	int max_lds_kb = 1 << 20, min_chunk = 384, max_parts_per_queue = 2; int class_streams = 64 /* sched 3: the class launches are dealt round-robin to at most this many streams */, n_queues = 16,
+		sched = 3, n_streams_used = 1, n_cu = 256, waves_per_cu = 8, lds_per_cu = 160 * 1024; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0},
+		cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
 	// offsets needed for downloads (bytes inside the wk arena)
 	size_t off_edge = 0, off_ulm = 0, off_pose = 0, off_inf = 0, off_infv = 0, off_res = 0;
 	size_t off_dbg[10] = {0}; int64_t len_dbg[10] = {0};
@@ -1322,20 +1397,26 @@ static void plan_launches(srba_hip_ctx *c, const int32_t *ord) {
 	struct fin { srba_hip_ctx *c; ~fin() { // grid of every job: persistent launches hold as many wavefronts as the chip can keep resident for that LDS size, the rest one per capsule
 		int batch_total = 0; for (int k = 0; k < SRBA_NCLS; k++) batch_total += c->cls_count[k];
 		for (size_t j = 0; j < c->plan.size(); j++) { LaunchJob &J = c->plan[j]; J.grid = J.count;
-			if (c->sched == 3) { const size_t lds = c->cls_lds[J.cls] + c->lds_pad; const int fit = lds ? (int)std::max<size_t>(1, (size_t)c->lds_per_cu / lds) : c->waves_per_cu; J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(c->waves_per_cu, fit)));
-				if (J.cls >= SRBA_NLDS) J.grid = std::max(1, std::min(J.count, c->n_cu * (J.cls == SRBA_CLS_WG512 ? 1 : (J.cls == SRBA_CLS_WG256 ? 2 : 4)))); // workgroup classes: 256 registers -> two wavefronts per SIMD = two 256-thread / four 128-thread workgroups per CU
+			if (c->sched == 3) { const size_t lds = c->cls_lds[J.cls] + c->lds_pad; const int fit = lds ? (int)std::max<size_t>(1, (size_t)c->lds_per_cu / lds) : c->waves_per_cu; J.grid = std::max(1,
+				std::min(J.count, c->n_cu * std::min(c->waves_per_cu, fit)));
+				if (J.cls >= SRBA_NLDS) J.grid = std::max(1, std::min(J.count, c->n_cu * (J.cls == SRBA_CLS_WG512 ? 1 : (J.cls == SRBA_CLS_WG256 ? SRBA_WG_WAVES : 2 * SRBA_WG_WAVES))));
+					// workgroup classes: 256 registers -> two wavefronts per SIMD = two 256-thread / four 128-thread workgroups per CU
 				J.lean = (c->lean_on && c->params.family == SRBA_SE2_RELPOSE2D && J.cls < SRBA_NCLS - 1 && fit >= 9 && J.count >= c->lean_min_count) ? 1 : 0;
 				if (J.lean) J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(12, fit)));
 				// (also for a batch of a few capsules -- the per-key-frame use of the engine is a batch of ONE: its latency is the whole cost, 1.55 -> 1.41 ms per key-frame of the sequential run)
-				J.two = (c->two_on && c->params.family == SRBA_SE2_RELPOSE2D && J.cls < SRBA_NCLS - 1 && lds > 0 && ((lds >= (size_t)c->two_from_kb * 1024 && J.count >= c->two_min_count) || batch_total <= 4)) ? 1 : 0; if (J.two) J.lean = 0;
+				J.two = (c->two_on && c->params.family == SRBA_SE2_RELPOSE2D && J.cls < SRBA_NCLS - 1 && lds > 0 && ((lds >= (size_t)c->two_from_kb * 1024 && J.count >= c->two_min_count) ||
+					batch_total <= 4)) ? 1 : 0; if (J.two) J.lean = 0;
 				if (J.two) J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(6, fit))); }
 		}
 		// Staggered start (round 4): the persistent launches of all classes are enqueued at once on their own streams, and which workgroups the dispatcher places first was a race --
 		// when the small (wave-slot bound) classes won it they filled every wave slot, the big (LDS bound, longest running) capsules trickled in late and the launch ended in their tail:
 		// 42-43 ms instead of 38 ms on the benchmark batch, from one launch to the next (tools/diag_launch_order.py, profiles/r04_launch_order.txt). Largest-footprint-first is now enforced:
 		// the stream of job j is held back by a one-thread delay kernel for stagger_ns x (workgroups of all the jobs before it) -- the time the dispatcher needs to place those.
-		if (c->sched == 3 && c->plan.size() > 1) { long long ahead = 0; for (size_t j = 0; j < c->plan.size(); j++) { LaunchJob &J = c->plan[j]; J.delay_us = (int)std::min<long long>(c->stagger_max_us, ahead * c->stagger_ns / 1000); if (j < c->delay_us.size()) J.delay_us = c->delay_us[j]; ahead += J.grid; } }
-		if (getenv("SRBA_HIP_PLAN_DEBUG")) for (size_t j = 0; j < c->plan.size(); j++) { const LaunchJob &J = c->plan[j]; std::fprintf(stderr, "[plan] job %zu: stream %d class %d lds %zu B capsules %d grid %d delay %d us%s\n", j, J.queue, J.cls, c->cls_lds[J.cls], J.count, J.grid, J.delay_us, J.lean ? " (lean: three wavefronts per SIMD)" : (J.two ? " (two wavefronts per capsule)" : "")); } } } finish = {c};
+		if (c->sched == 3 && c->plan.size() > 1) { long long ahead = 0; for (size_t j = 0; j < c->plan.size(); j++) { LaunchJob &J = c->plan[j];
+			J.delay_us = (int)std::min<long long>(c->stagger_max_us, ahead * c->stagger_ns / 1000); if (j < c->delay_us.size()) J.delay_us = c->delay_us[j]; ahead += J.grid; } }
+		if (getenv("SRBA_HIP_PLAN_DEBUG")) for (size_t j = 0; j < c->plan.size(); j++) { const LaunchJob &J = c->plan[j]; std::fprintf(stderr,
+			"[plan] job %zu: stream %d class %d lds %zu B capsules %d grid %d delay %d us%s\n", j, J.queue, J.cls, c->cls_lds[J.cls], J.count, J.grid, J.delay_us,
+			J.lean ? " (lean: three wavefronts per SIMD)" : (J.two ? " (two wavefronts per capsule)" : "")); } } } finish = {c};
 	if (c->sched == 3) { // one persistent launch per size class, every class on its own stream, biggest LDS footprint first (the HBM class is the biggest)
 		int q = 0; const int qmax = std::max(1, c->class_streams);
 		for (int k = SRBA_NCLS - 2; k >= 0; k--) if (c->cls_count[k]) { c->plan.push_back({q % qmax, k, c->cls_first[k], c->cls_count[k], 0.0, 0}); q++; }
@@ -1343,7 +1424,8 @@ static void plan_launches(srba_hip_ctx *c, const int32_t *ord) {
 	}
 	// cost of a chunk ~ sum over its capsules of (system size) x (LDS footprint): a trial takes time ~ nb, and how many capsules run at once
 	// is set by the LDS they hold (measured on the benchmark: 43 us per loop-closure window vs 5.5 us per typical window, chip-wide)
-	auto cost_of = [&](int cls, int first, int count) { const double w = cls == SRBA_NCLS - 1 ? 24.0 : std::max(1.0, (double)c->cls_lds[cls] / 8192.0); double s = 0; for (int i = 0; i < count; i++) s += (c->desc[ord[first + i]].nb + 4) * w; return s; };
+	auto cost_of = [&](int cls, int first, int count) { const double w = cls == SRBA_NCLS - 1 ? 24.0 : std::max(1.0, (double)c->cls_lds[cls] / 8192.0); double s = 0; for (int i = 0; i < count;
+		i++) s += (c->desc[ord[first + i]].nb + 4) * w; return s; };
 	if (c->sched == 2) {
 		int q = 0; const int qmax = std::max(1, c->class_streams);
 		for (int k = SRBA_NCLS - 2; k >= 0; k--) if (c->cls_count[k]) { c->plan.push_back({q % qmax, k, c->cls_first[k], c->cls_count[k], 0.0, 0}); q++; }
@@ -1354,19 +1436,22 @@ static void plan_launches(srba_hip_ctx *c, const int32_t *ord) {
 		int rr = 0;
 		for (int k = SRBA_NCLS - 2; k >= 0; k--) if (c->cls_count[k]) {
 			const int cnt = c->cls_count[k], parts = cnt >= 16 * nq ? nq : 1;
-			for (int q = 0; q < parts; q++) { const int a = slice_begin(cnt, q, parts), b = slice_begin(cnt, q + 1, parts); if (b > a) c->plan.push_back({parts == 1 ? (rr++ % nq) : q, k, c->cls_first[k] + a, b - a, 0.0, 0}); }
+			for (int q = 0; q < parts; q++) { const int a = slice_begin(cnt, q, parts), b = slice_begin(cnt, q + 1, parts); if (b > a) c->plan.push_back({parts == 1 ? (rr++ % nq) : q, k,
+				c->cls_first[k] + a, b - a, 0.0, 0}); }
 		}
 		return;
 	}
 	std::vector<LaunchJob> jobs;
 	for (int k = SRBA_NCLS - 2; k >= 0; k--) if (c->cls_count[k]) {
 		const int cnt = c->cls_count[k], parts = std::max(1, std::min(c->max_parts_per_queue * nq, cnt / c->min_chunk));
-		for (int q = 0; q < parts; q++) { const int a = slice_begin(cnt, q, parts), b = slice_begin(cnt, q + 1, parts); if (b > a) jobs.push_back({0, k, c->cls_first[k] + a, b - a, cost_of(k, c->cls_first[k] + a, b - a), 0}); }
+		for (int q = 0; q < parts; q++) { const int a = slice_begin(cnt, q, parts), b = slice_begin(cnt, q + 1, parts); if (b > a) jobs.push_back({0, k, c->cls_first[k] + a, b - a, cost_of(k,
+			c->cls_first[k] + a, b - a), 0}); }
 	}
 	std::vector<size_t> by_cost(jobs.size()); for (size_t i = 0; i < jobs.size(); i++) by_cost[i] = i;
 	std::stable_sort(by_cost.begin(), by_cost.end(), [&](size_t a, size_t b) { return jobs[a].cost > jobs[b].cost; });
 	std::vector<double> load(nq, 0.0); std::vector<std::vector<LaunchJob> > perq(nq);
-	for (size_t i = 0; i < by_cost.size(); i++) { int q = 0; for (int x = 1; x < nq; x++) if (load[x] < load[q]) q = x; LaunchJob J = jobs[by_cost[i]]; J.queue = q; load[q] += J.cost; perq[q].push_back(J); }
+	for (size_t i = 0; i < by_cost.size(); i++) { int q = 0; for (int x = 1; x < nq; x++) if (load[x] < load[q]) q = x; LaunchJob J = jobs[by_cost[i]]; J.queue = q; load[q] += J.cost;
+		perq[q].push_back(J); }
 	for (int q = 0; q < nq; q++) { // class index grows with the LDS footprint (the HBM class last = biggest)
 		std::stable_sort(perq[q].begin(), perq[q].end(), [&](const LaunchJob &a, const LaunchJob &b) { return (q & 1) ? a.cls < b.cls : a.cls > b.cls; });
 	}
@@ -1376,7 +1461,8 @@ static void plan_launches(srba_hip_ctx *c, const int32_t *ord) {
 
 static void make_dev_params(const srba_hip_params &p, DevParams &dp, const FamDims &dm) {
 	std::memset(&dp, 0, sizeof(dp));
-	dp.solver = p.solver; dp.noise = p.noise; dp.sensor_pose = p.sensor_pose; dp.max_iters = p.max_iters; dp.use_robust_kernel = p.use_robust_kernel; dp.cov_recovery = p.cov_recovery; dp.ext = p.extensions;
+	dp.solver = p.solver; dp.noise = p.noise; dp.sensor_pose = p.sensor_pose; dp.max_iters = p.max_iters; dp.use_robust_kernel = p.use_robust_kernel; dp.cov_recovery = p.cov_recovery;
+		dp.ext = p.extensions;
 	dp.inv_sigma = 1.0 / p.std_noise_observations;
 	for (int i = 0; i < dm.O * dm.O; i++) dp.lambda[i] = p.lambda[i];
 	dp.kernel_param = p.kernel_param; dp.max_err = p.max_error_per_obs_to_stop; dp.max_rho = p.max_rho; dp.max_lambda = p.max_lambda; dp.min_relin = p.min_error_reduction_ratio_to_relinearize;
@@ -1385,7 +1471,8 @@ static void make_dev_params(const srba_hip_params &p, DevParams &dp, const FamDi
 	for (int i = 0; i < 4; i++) { dp.camL[i] = p.cam_left[i]; dp.camR[i] = p.cam_right[i]; }
 	// R2L = (-)rightCameraPose (models/sensors.h:193): quaternion -> R, then invert
 	const double r = p.right_cam_pose[3], x = p.right_cam_pose[4], y = p.right_cam_pose[5], z = p.right_cam_pose[6];
-	const double R[9] = {r * r + x * x - y * y - z * z, 2 * (x * y - r * z), 2 * (z * x + r * y), 2 * (x * y + r * z), r * r - x * x + y * y - z * z, 2 * (y * z - r * x), 2 * (z * x - r * y), 2 * (y * z + r * x), r * r - x * x - y * y + z * z};
+	const double R[9] = {r * r + x * x - y * y - z * z, 2 * (x * y - r * z), 2 * (z * x + r * y), 2 * (x * y + r * z), r * r - x * x + y * y - z * z, 2 * (y * z - r * x), 2 * (z * x - r * y),
+		2 * (y * z + r * x), r * r - x * x - y * y + z * z};
 	for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) dp.R2LR[3 * i + j] = R[3 * j + i];
 	for (int i = 0; i < 3; i++) dp.R2Lt[i] = -(R[i] * p.right_cam_pose[0] + R[3 + i] * p.right_cam_pose[1] + R[6 + i] * p.right_cam_pose[2]);
 }
@@ -1394,7 +1481,8 @@ static int check_params(const srba_hip_params *p) {
 	if (!p || p->family < 0 || p->family >= SRBA_NUM_FAMILIES) { g_last_error = "bad family"; return -1; }
 	if (p->solver < 0 || p->solver > 2) { g_last_error = "bad solver"; return -1; }
 	if (p->noise == SRBA_NOISE_IDENTITY && !(p->std_noise_observations > 0)) { g_last_error = "std_noise_observations must be > 0"; return -1; }
-	if (p->sensor_pose == SRBA_SENSOR_POSE_SE3 && kDims[p->family].PD != 12 && p->family != SRBA_SE2_STEREO) { g_last_error = "sensor_pose_on_robot_se3 is supported with SE3 keyframe poses and with <SE2, Euclidean3D, StereoCamera>"; return -1; }
+	if (p->sensor_pose == SRBA_SENSOR_POSE_SE3 && kDims[p->family].PD != 12 && p->family != SRBA_SE2_STEREO) {
+		g_last_error = "sensor_pose_on_robot_se3 is supported with SE3 keyframe poses and with <SE2, Euclidean3D, StereoCamera>"; return -1; }
 	if (p->family == SRBA_SE3_RELPOSE3D && p->sensor_pose != SRBA_SENSOR_POSE_NONE) { g_last_error = "relative-pose observations take no sensor pose"; return -1; }
 	return 0;
 }
@@ -1445,26 +1533,38 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_PHASE_TIMING"); c->phase_timing = (e && e[0] == '1'); }
 	{ const char *e = getenv("SRBA_HIP_MAX_LDS_KB"); c->max_lds_kb = e ? atoi(e) : 1 << 20; } // test knob: systems above this many KB are factored in the HBM workspace (0 = all of them)
 	{ const char *e = getenv("SRBA_HIP_LDS_PAD"); c->lds_pad = e ? (size_t)atol(e) : 0; } // diagnostics: extra LDS bytes per workgroup (lowers residency)
-	{ const char *e = getenv("SRBA_HIP_CHUNK"); if (e && atoi(e) > 0) c->min_chunk = atoi(e); e = getenv("SRBA_HIP_PARTS"); if (e && atoi(e) > 0) c->max_parts_per_queue = atoi(e); } // tuning knobs of the launch plan
+	{ const char *e = getenv("SRBA_HIP_CHUNK"); if (e && atoi(e) > 0) c->min_chunk = atoi(e); e = getenv("SRBA_HIP_PARTS"); if (e && atoi(e) > 0) c->max_parts_per_queue = atoi(e); }
+		// tuning knobs of the launch plan
 	{ const char *e = getenv("SRBA_HIP_SCHED"); if (e) c->sched = atoi(e); } // tuning knob: launch plan (see plan_launches)
 	{ hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) c->n_cu = pr.multiProcessorCount; }
 	{ const char *e = getenv("SRBA_HIP_CLASS_STREAMS"); if (e && atoi(e) > 0) c->class_streams = atoi(e); }
-	{ const char *e = getenv("SRBA_HIP_WAVES_PER_CU"); if (e && atoi(e) > 0) c->waves_per_cu = atoi(e); e = getenv("SRBA_HIP_LDS_PER_CU_KB"); if (e && atoi(e) > 0) c->lds_per_cu = atoi(e) * 1024; } // tuning knobs: resident wavefronts / LDS per CU assumed by the persistent plan
+	{ const char *e = getenv("SRBA_HIP_WAVES_PER_CU"); if (e && atoi(e) > 0) c->waves_per_cu = atoi(e); e = getenv("SRBA_HIP_LDS_PER_CU_KB"); if (e && atoi(e) > 0) c->lds_per_cu = atoi(e) * 1024; }
+		// tuning knobs: resident wavefronts / LDS per CU assumed by the persistent plan
 	{ const char *e = getenv("SRBA_HIP_QUEUES"); if (e && atoi(e) >= 1 && atoi(e) < SRBA_NCLS) c->n_queues = atoi(e); } // tuning knob: concurrent launch streams
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || false) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
-	{ const char *e = getenv("SRBA_HIP_CLASS_PRIO"); if (e) c->class_prio = atoi(e); e = getenv("SRBA_HIP_STAGGER_NS"); if (e && atoi(e) >= 0) c->stagger_ns = atoi(e); e = getenv("SRBA_HIP_TWO"); if (e) c->two_on = atoi(e) != 0; e = getenv("SRBA_HIP_SPEC"); if (e) { c->spec_on = atoi(e) != 0; if (atoi(e) >= 2) c->spec_w = std::min((int)srba_hip_ctx::kSpecMaxW, atoi(e)); } e = getenv("SRBA_HIP_TWO_FROM_KB"); if (e && atoi(e) > 0) c->two_from_kb = atoi(e); e = getenv("SRBA_HIP_TWO_MIN_COUNT"); if (e && atoi(e) >= 1) c->two_min_count = atoi(e); e = getenv("SRBA_HIP_LEAN"); if (e) c->lean_on = atoi(e) != 0; e = getenv("SRBA_HIP_LEAN_MIN_COUNT"); if (e && atoi(e) >= 1) c->lean_min_count = atoi(e); e = getenv("SRBA_HIP_DELAY_US"); if (e) { std::string t(e); size_t p0 = 0; while (p0 <= t.size()) { size_t p1 = t.find(',', p0); if (p1 == std::string::npos) p1 = t.size(); c->delay_us.push_back(atoi(t.substr(p0, p1 - p0).c_str())); p0 = p1 + 1; } } }
+	{ const char *e = getenv("SRBA_HIP_CLASS_PRIO"); if (e) c->class_prio = atoi(e); e = getenv("SRBA_HIP_STAGGER_NS"); if (e && atoi(e) >= 0) c->stagger_ns = atoi(e); e = getenv("SRBA_HIP_TWO");
+		if (e) c->two_on = atoi(e) != 0; e = getenv("SRBA_HIP_SPEC"); if (e) { c->spec_on = atoi(e) != 0; if (atoi(e) >= 2) c->spec_w = std::min((int)srba_hip_ctx::kSpecMaxW, atoi(e)); }
+		e = getenv("SRBA_HIP_TWO_FROM_KB"); if (e && atoi(e) > 0) c->two_from_kb = atoi(e); e = getenv("SRBA_HIP_TWO_MIN_COUNT"); if (e && atoi(e) >= 1) c->two_min_count = atoi(e);
+		e = getenv("SRBA_HIP_LEAN"); if (e) c->lean_on = atoi(e) != 0; e = getenv("SRBA_HIP_LEAN_MIN_COUNT"); if (e && atoi(e) >= 1) c->lean_min_count = atoi(e); e = getenv("SRBA_HIP_DELAY_US");
+		if (e) { std::string t(e); size_t p0 = 0; while (p0 <= t.size()) { size_t p1 = t.find(',', p0); if (p1 == std::string::npos) p1 = t.size(); c->delay_us.push_back(atoi(t.substr(p0,
+		p1 - p0).c_str())); p0 = p1 + 1; } } }
 	int pr_least = 0, pr_greatest = 0; hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
 	for (int k = 1; k < SRBA_NCLS && ok; k++) { // (class_prio 1: the streams of the biggest classes -- low stream index, see plan_launches -- get the highest priority, 2: the lowest)
 		const int split = 4, pri = c->class_prio == 0 ? 0 : ((c->class_prio == 1) == (k < split) ? pr_greatest : pr_least);
-		ok = (c->class_prio ? hipStreamCreateWithPriority(&c->cls_stream[k], hipStreamNonBlocking, pri) : hipStreamCreateWithFlags(&c->cls_stream[k], hipStreamNonBlocking)) == hipSuccess && hipEventCreateWithFlags(&c->cls_done[k], hipEventDisableTiming) == hipSuccess; }
-	if (!ok || hipMalloc((void **)&c->d_next, sizeof(int) * 4 * kMaxJobs) != hipSuccess || hipMalloc((void **)&c->d_part, 8 * 3 * kBigPart * srbadev::kGang) != hipSuccess || hipMalloc((void **)&c->d_scal, (8 * 16 + 4 * 8) * srbadev::kGang) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
+		ok = (c->class_prio ? hipStreamCreateWithPriority(&c->cls_stream[k], hipStreamNonBlocking, pri) : hipStreamCreateWithFlags(&c->cls_stream[k],
+			hipStreamNonBlocking)) == hipSuccess && hipEventCreateWithFlags(&c->cls_done[k], hipEventDisableTiming) == hipSuccess; }
+	if (!ok || hipMalloc((void **)&c->d_next, sizeof(int) * 4 * kMaxJobs) != hipSuccess || hipMalloc((void **)&c->d_part, 8 * 3 * kBigPart * srbadev::kGang) != hipSuccess || hipMalloc((void
+		**)&c->d_scal, (8 * 16 + 4 * 8) * srbadev::kGang) != hipSuccess) { g_last_error = "cannot create HIP stream/events"; delete c; return nullptr; }
 	c->spec_test_drop = getenv("SRBA_HIP_SPEC_TEST_DROP") != nullptr;
-	{ const char *e = getenv("SRBA_HIP_WG"); if (e) c->wg_on = atoi(e) != 0; e = getenv("SRBA_HIP_WG_FROM"); if (e && atoi(e) >= 1) c->wg_from_sys = atoi(e); e = getenv("SRBA_HIP_WG256_FROM"); if (e && atoi(e) >= 1) c->wg256_from_sys = atoi(e); e = getenv("SRBA_HIP_WG_HS"); if (e) c->wg_hs = atoi(e) != 0; }
+	{ const char *e = getenv("SRBA_HIP_WG"); if (e) c->wg_on = atoi(e) != 0; e = getenv("SRBA_HIP_WG_FROM"); if (e && atoi(e) >= 1) c->wg_from_sys = atoi(e); e = getenv("SRBA_HIP_WG256_FROM");
+		if (e && atoi(e) >= 1) c->wg256_from_sys = atoi(e); e = getenv("SRBA_HIP_WG_HS"); if (e) c->wg_hs = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_BIG_MIN_SYS"); if (e && atoi(e) >= 0) c->big_min_sys = atoi(e); } // tuning / test knob
 	{ const char *e = getenv("SRBA_HIP_DENSE_BLOCKS"); if (e) c->dense_blocks_ok = atoi(e) != 0; }
-	{ const unsigned hc = std::thread::hardware_concurrency(); c->upload_threads = (int)std::min(32u, std::max(1u, hc)); const char *e = getenv("SRBA_HIP_UPLOAD_THREADS"); if (e) c->upload_threads = std::max(1, atoi(e)); } // host threads of srba_hip_upload_problems
-	{ const char *e = getenv("SRBA_HIP_HBM_FROM_KB"); if (e) c->hbm_from_kb = atoi(e); } // (default 48; 0 = off) in batches of 1024+ capsules, landmark windows whose LDS image needs this many KB or more keep their system in HBM instead: above 40 KB the LDS, not the registers, limits the wavefronts resident per CU
+	{ const unsigned hc = std::thread::hardware_concurrency(); c->upload_threads = (int)std::min(32u, std::max(1u, hc)); const char *e = getenv("SRBA_HIP_UPLOAD_THREADS");
+		if (e) c->upload_threads = std::max(1, atoi(e)); } // host threads of srba_hip_upload_problems
+	{ const char *e = getenv("SRBA_HIP_HBM_FROM_KB"); if (e) c->hbm_from_kb = atoi(e); } // (default 48; 0 = off) in batches of 1024+ capsules,
+		// landmark windows whose LDS image needs this many KB or more keep their system in HBM instead: above 40 KB the LDS, not the registers, limits the wavefronts resident per CU
 	{ const char *e = getenv("SRBA_HIP_DENSE_LEFT"); if (e) c->dense_left = atoi(e) != 0; } // 0: right-looking sweeps on the HBM-resident dense layout (round-2 first version)
 	{ const char *e = getenv("SRBA_HIP_LIN_TERMS"); if (e) c->lin_terms = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_LM_TERMS"); if (e) c->lm_terms = atoi(e) != 0; }
@@ -1473,9 +1573,12 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_FLAT"); if (e) c->use_flat = atoi(e) != 0; }                     // 0 = one wavefront per capsule for the stepwise spanning-tree launch
 	{ const char *e = getenv("SRBA_HIP_BIG_LANES"); if (e && atoi(e) >= 1) { c->big_lanes_max = std::min(atoi(e), kBigLanes); c->big_gang_slots = std::min(atoi(e), srbadev::kGang); } }
 	{ const char *e = getenv("SRBA_HIP_GANG_FROM_NB"); if (e) c->gang_from_nb = atoi(e); } // large capsules of one batch in flight at once
-	{ const char *e = getenv("SRBA_HIP_BIG_PERSISTENT"); if (e) c->big_persistent = atoi(e) != 0; }   // 1 = the blocked Cholesky of the big path as ONE persistent launch with grid barriers (k_chol_persistent) instead of one launch per panel step and per trailing update (~60 launches); measured slower, DESIGN 4c
-	{ const char *e = getenv("SRBA_HIP_BIG_FUSED_STEP"); if (e) c->big_fused_step = atoi(e) != 0; }    // 0 = panel step and trailing update as two launches per 32 columns (k_chol_panel, k_chol_update)
-	{ const char *e = getenv("SRBA_HIP_BIG_GANG"); if (e) c->big_gang = atoi(e) != 0; }                // 0 = one host thread + stream per large window instead of the lock-step gang on one stream (DESIGN 4c)
+	{ const char *e = getenv("SRBA_HIP_BIG_PERSISTENT"); if (e) c->big_persistent = atoi(e) != 0; }   // 1 = the blocked Cholesky of the big path as ONE persistent launch with grid barriers
+		// (k_chol_persistent) instead of one launch per panel step and per trailing update (~60 launches); measured slower, DESIGN 4c
+	{ const char *e = getenv("SRBA_HIP_BIG_FUSED_STEP"); if (e) c->big_fused_step = atoi(e) != 0; }    // 0 = panel step and trailing update as two launches per 32 columns (k_chol_panel,
+		// k_chol_update)
+	{ const char *e = getenv("SRBA_HIP_BIG_GANG"); if (e) c->big_gang = atoi(e) != 0; }                // 0 = one host thread + stream per large window instead of the lock-step gang on one stream
+		// 
 	return c;
 }
 
@@ -1483,15 +1586,18 @@ int srba_hip_set_params(srba_hip_ctx *c, const srba_hip_params *params) {
 	if (!c) return -1;
 	if (check_params(params) != 0) { c->fail(g_last_error); return -1; }
 	if (params->family != c->params.family) { c->fail("srba_hip_set_params: the family of a context cannot change"); return -1; }
-	if (c->n_prob && (params->solver != c->params.solver || params->noise != c->params.noise || params->extensions != c->params.extensions)) c->n_prob = 0; // the uploaded batch was laid out for the old solver / noise policy: upload again
+	if (c->n_prob && (params->solver != c->params.solver || params->noise != c->params.noise || params->extensions != c->params.extensions)) c->n_prob = 0;
+		// the uploaded batch was laid out for the old solver / noise policy: upload again
 	c->params = *params; make_dev_params(*params, c->dp, c->dm); c->batch_copied = false; /* (the kernels read the parameters from the device copy) */ return 0;
 }
 
 int srba_hip_destroy(srba_hip_ctx *c) {
 	if (!c) return 0;
 	hipSetDevice(c->device);
-	for (int i = 0; i < kBigLanes; i++) { BigLane &l = c->lanes[i]; if (l.h_fetch) hipHostFree(l.h_fetch); if (l.e0) hipEventDestroy(l.e0); if (l.e1) hipEventDestroy(l.e1); if (i > 0) { if (l.d_part) hipFree(l.d_part); if (l.d_scal) hipFree(l.d_scal); if (l.stream) hipStreamDestroy(l.stream); } }
-	if (c->d_in) hipFree(c->d_in); if (c->d_wk) hipFree(c->d_wk); if (c->d_next) hipFree(c->d_next); if (c->d_batch) hipFree(c->d_batch); if (c->d_spec) hipFree(c->d_spec); c->h_in.release(); if (c->h_out) hipHostFree(c->h_out); if (c->ev_h2d) hipEventDestroy(c->ev_h2d); if (c->d_part) hipFree(c->d_part); if (c->d_scal) hipFree(c->d_scal);
+	for (int i = 0; i < kBigLanes; i++) { BigLane &l = c->lanes[i]; if (l.h_fetch) hipHostFree(l.h_fetch); if (l.e0) hipEventDestroy(l.e0); if (l.e1) hipEventDestroy(l.e1); if (i > 0) {
+		if (l.d_part) hipFree(l.d_part); if (l.d_scal) hipFree(l.d_scal); if (l.stream) hipStreamDestroy(l.stream); } }
+	if (c->d_in) hipFree(c->d_in); if (c->d_wk) hipFree(c->d_wk); if (c->d_next) hipFree(c->d_next); if (c->d_batch) hipFree(c->d_batch); if (c->d_spec) hipFree(c->d_spec); c->h_in.release();
+		if (c->h_out) hipHostFree(c->h_out); if (c->ev_h2d) hipEventDestroy(c->ev_h2d); if (c->d_part) hipFree(c->d_part); if (c->d_scal) hipFree(c->d_scal);
 	for (int i = 0; i < srba_hip_ctx::kRing; i++) { if (c->ring0[i]) hipEventDestroy(c->ring0[i]); if (c->ring1[i]) hipEventDestroy(c->ring1[i]); }
 	if (c->ev_fork) hipEventDestroy(c->ev_fork);
 	for (int k = 1; k < SRBA_NCLS; k++) { if (c->cls_done[k]) hipEventDestroy(c->cls_done[k]); if (c->cls_stream[k]) hipStreamDestroy(c->cls_stream[k]); }
@@ -1519,11 +1625,12 @@ int srba_hip_kernel_ms_history(srba_hip_ctx *c, double *out_ms, int n) {
 static int wg_class_of(const srba_hip_ctx *c, const srba_problem_capsule &k, bool schur_solver, size_t *lds_bytes, int *panels = nullptr) {
 	if (panels) *panels = 1;
 	const int P = c->dm.P, L = c->dm.L; const int n_sys = P * k.n_unk_edges;
-	if (!(c->wg_on && c->wg_hs && c->max_lds_kb > 0 /* (0: the test knob that sends every window to the multi-workgroup path) */ && c->dm.PD == 12 && L == 3 && schur_solver && k.n_unk_lms > 0 && k.n_unk_edges > 0 && c->gang_from_nb <= 0)) return -1;
+	if (!(c->wg_on && c->wg_hs && c->max_lds_kb > 0 /* (0: the test knob that sends every window to the multi-workgroup path) */ && c->dm.PD == 12 && L == 3 && schur_solver && k.n_unk_lms > 0 &&
+		k.n_unk_edges > 0 && c->gang_from_nb <= 0)) return -1;
 	if (n_sys < c->wg_from_sys || n_sys > 16 * srbadev::WG_NT_MAX || k.n_hap >= 65536 || k.n_unk_edges >= 32768) return -1;
 	const size_t need = 8 * ((size_t)srbadev::WG_HS + (size_t)k.n_hap * (P * P + 1)); if (lds_bytes) *lds_bytes = need;
-	if (need <= (size_t)40 * 1024 && n_sys < c->wg256_from_sys) return SRBA_CLS_WG128;
-	if (need <= (size_t)80 * 1024) return SRBA_CLS_WG256;
+	if (need <= (size_t)160 * 1024 / (2 * SRBA_WG_WAVES) && n_sys < c->wg256_from_sys) return SRBA_CLS_WG128; // (two wavefronts: 2 x SRBA_WG_WAVES workgroups share the CU's LDS)
+	if (need <= (size_t)160 * 1024 / SRBA_WG_WAVES) return SRBA_CLS_WG256;
 	if (need <= (size_t)159 * 1024) return SRBA_CLS_WG512; // (nearly the whole LDS of a CU: 515 blocks)
 	// more blocks than a CU's LDS holds: the window is swept in panels of equal size (ProbDesc::n_panel)
 	const int cap = (int)(((size_t)159 * 1024 / 8 - (size_t)srbadev::WG_HS) / (size_t)(P * P + 1)), np = (k.n_hap + cap - 1) / cap, psize = (k.n_hap + np - 1) / np;
@@ -1537,7 +1644,8 @@ int srba_hip_upload_problems(srba_hip_ctx *c, const srba_problem_capsule *caps, 
 	catch (const std::exception &e) { if (c) { c->n_prob = 0; c->fail(std::string("upload: ") + e.what()); } return -1; }
 	catch (...) { if (c) { c->n_prob = 0; c->fail("upload: unknown exception"); } return -1; }
 }
-// every observation row of the relative-pose SE2 family is valid (its Jacobian blocks have no failure case): the flags the unfused kernel rewrites at every call are set once per upload for the fused one
+// every observation row of the relative-pose SE2 family is valid (its Jacobian blocks have no failure case): the flags the unfused kernel rewrites at every call are set once per upload for the fused
+	// one
 static int set_asm_flags(srba_hip_ctx *c) {
 	if (c->asm_flags_set) return 0;
 	if (c->n_valid_total) HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)(c->d_wk + c->off_valid), 1, (size_t)c->n_valid_total, c->stream));
@@ -1549,16 +1657,20 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	HIPCHK(c, hipSetDevice(c->device));
 	c->big_chol_ms = c->big_chol_flops = 0; c->big_chol_count = c->big_chol_seqs = 0; c->big_chol_nmax = 0;
 	c->n_prob = 0; // whatever was uploaded before stops being launchable / readable now: a failed upload leaves the context empty, not half-updated
-	static const bool host_timing = getenv("SRBA_HIP_HOST_TIMING") != nullptr; static double acc[4] = {0, 0, 0, 0}; static long long calls = 0; auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }; const double ht0 = host_timing ? now() : 0; double ht1 = 0, ht2 = 0;
+	static const bool host_timing = getenv("SRBA_HIP_HOST_TIMING") != nullptr; static double acc[4] = {0, 0, 0, 0}; static long long calls = 0; auto now = []() { return std::chrono::duration<double,
+		std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }; const double ht0 = host_timing ? now() : 0; double ht1 = 0, ht2 = 0;
 	const int P = c->dm.P, L = c->dm.L, O = c->dm.O, PD = c->dm.PD, PDX = c->dm.PDX();
 	const bool schur_solver = c->params.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL;
 	c->desc.assign(n, ProbDesc()); srba_batch_stats &st = c->stats; std::memset(&st, 0, sizeof(st)); st.n_problems = n;
 	// ---- pass 1: descriptors and totals
-	long long t_ptab = 0, t_hapo = 0, t_schl = 0, t_hrec = 0, t_edge = 0, t_unk = 0, t_ulm = 0, t_klm = 0, t_pair = 0, t_path = 0, t_obs = 0, t_valid = 0, t_bp = 0, t_bf = 0, t_hap = 0, t_hapt = 0, t_hf = 0, t_hft = 0, t_hapf = 0, t_hapft = 0, t_sch = 0, t_req = 0, t_scal = 0, t_yw = 0, t_dense = 0;
-	std::vector<int> cls(n, 0), big_lds(n, 0); int cls_nbmax[SRBA_NCLS] = {0}; size_t wg_lds[3] = {0, 0, 0}; std::vector<Symbolic> sym(n); long long t_spcol = 0, t_sprow = 0, t_spitem = 0, t_spfill = 0;
+	long long t_ptab = 0, t_hapo = 0, t_schl = 0, t_hrec = 0, t_edge = 0, t_unk = 0, t_ulm = 0, t_klm = 0, t_pair = 0, t_path = 0, t_obs = 0, t_valid = 0, t_bp = 0, t_bf = 0, t_hap = 0, t_hapt = 0,
+		t_hf = 0, t_hft = 0, t_hapf = 0, t_hapft = 0, t_sch = 0, t_req = 0, t_scal = 0, t_yw = 0, t_dense = 0;
+	std::vector<int> cls(n, 0), big_lds(n, 0); int cls_nbmax[SRBA_NCLS] = {0}; size_t wg_lds[3] = {0, 0, 0}; std::vector<Symbolic> sym(n); long long t_spcol = 0, t_sprow = 0, t_spitem = 0,
+		t_spfill = 0;
 	// capsules whose system cannot fit one wavefront's LDS even as bare numbers (more than 63 block rows) but is no deep-window system either: a handful go to the
 	// multi-workgroup path; when the batch holds many, they keep one wavefront each with the system in HBM (see below)
-	bool many_mid = false; { int cnt = 0; for (int p = 0; p < n; p++) { const int nsys = (schur_solver && caps[p].n_unk_lms > 0 && caps[p].n_unk_edges > 0) ? P * caps[p].n_unk_edges : P * caps[p].n_unk_edges + L * caps[p].n_unk_lms; if ((nsys + 2) / 3 > 63 && nsys <= c->big_min_sys) cnt++; } many_mid = cnt > 32; }
+	bool many_mid = false; { int cnt = 0; for (int p = 0; p < n; p++) { const int nsys = (schur_solver && caps[p].n_unk_lms > 0 && caps[p].n_unk_edges > 0) ? P * caps[p].n_unk_edges : P *
+		caps[p].n_unk_edges + L * caps[p].n_unk_lms; if ((nsys + 2) / 3 > 63 && nsys <= c->big_min_sys) cnt++; } many_mid = cnt > 32; }
 	std::vector<const char *> why(n, nullptr);
 	parallel_ranges(n, c->upload_threads, [&](int b, int e, int) { // validation and the block-sparse symbolic factorisation (the expensive part of this pass) of every capsule
 		for (int p = b; p < e; p++) {
@@ -1575,7 +1687,8 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		if (why[p]) { c->fail(std::string("upload: malformed capsule (") + why[p] + ")"); return -1; }
 		d.n_edges = k.n_edges; d.nK = k.n_unk_edges; d.nF = k.n_unk_lms; d.n_klm = k.n_known_lms; d.n_pairs = k.n_pairs; d.n_obs = k.n_obs; d.n_valid = k.n_valid; d.n_bp = k.n_bp; d.n_bf = k.n_bf;
 		d.n_hap = k.n_hap; d.n_hf = k.n_hf; d.n_hapf = k.n_hapf; d.n_sch = k.n_sch_terms; d.n_hapt = k.n_hap_terms;
-		{ int sp = k.n_hap_terms; for (int b = 0; b <= k.n_hap; b++) if (2 * (long long)k.hap_term_off[b] >= k.n_hap_terms) { sp = k.hap_term_off[b]; break; } d.hapt_split = sp; } // k_lm_run2: where the second wavefront's share of the U_Ap terms begins (a block boundary)
+		{ int sp = k.n_hap_terms; for (int b = 0; b <= k.n_hap; b++) if (2 * (long long)k.hap_term_off[b] >= k.n_hap_terms) { sp = k.hap_term_off[b]; break; } d.hapt_split = sp; }
+			// k_lm_run2: where the second wavefront's share of the U_Ap terms begins (a block boundary)
 		d.n_scal = P * d.nK + L * d.nF; d.n_sys = (schur_solver && d.nF > 0 && d.nK > 0) ? P * d.nK : d.n_scal;
 		if (schur_solver && d.nK == 0) { c->fail("upload: Schur solvers need at least one unknown kf2kf edge (the reference has the same restriction, schur.h:34)"); return -1; }
 		int nreq = 0; for (int i = 0; i < 2 * k.n_pairs; i++) nreq += k.pose_required[i] ? 1 : 0; d.n_req = nreq;
@@ -1583,8 +1696,10 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		d.o_bp = t_bp; d.o_colp = t_unk + p; d.o_bf = t_bf; d.o_colf = t_ulm + p; d.o_hap = t_hap; d.o_hapoff = t_hap + p; d.o_hapt = t_hapt; d.o_hf = t_hf; d.o_hfoff = t_hf + p; d.o_hft = t_hft;
 		d.o_hapf = t_hapf; d.o_hapfoff = t_hapf + p; d.o_hapft = t_hapft; d.o_sch = t_sch; d.o_lmoff = t_ulm + p; d.o_req = t_req; d.o_scal = t_scal; d.o_yw = t_yw; d.o_dense = t_dense;
 		d.nb = (d.n_sys + 2) / 3;
-		size_t wg_need = 0; int wg_panels = 1; const int wg_cls = wg_class_of(c, k, schur_solver, &wg_need, &wg_panels); const bool to_wg = wg_cls >= 0; // one workgroup, tile system in HBM, U_Ap blocks in LDS, matrix cores (srba_wg.hpp)
-		const bool surely_big = d.n_sys > c->big_min_sys || to_wg; // far beyond what one wavefront's LDS holds (or a workgroup window): dense system on the multi-workgroup path, no block-sparse symbolic analysis
+		size_t wg_need = 0; int wg_panels = 1; const int wg_cls = wg_class_of(c, k, schur_solver, &wg_need, &wg_panels); const bool to_wg = wg_cls >= 0; // one workgroup, tile system in HBM,
+			// U_Ap blocks in LDS, matrix cores (srba_wg.hpp)
+		const bool surely_big = d.n_sys > c->big_min_sys || to_wg; // far beyond what one wavefront's LDS holds (or a workgroup window): dense system on the multi-workgroup path,
+			// no block-sparse symbolic analysis
 		if (!surely_big) { /* sym[p]: computed above */ }
 		else { Symbolic &y = sym[p]; y.col_off.assign(d.nb + 1, 0); y.item_off.assign(d.nb + 1, 0); y.rptr.assign(d.nb + 1, 0); y.perm.resize(d.nb); for (int q = 0; q < d.nb; q++) y.perm[q] = q;
 			y.hap_dst.assign((size_t)k.n_hap * (P / 3) * (P / 3), 0); y.hapf_dst.assign((size_t)k.n_hapf * (P / 3), 0); y.hf_dst.assign(k.n_hf, 0); y.aligned = true; }
@@ -1593,10 +1708,13 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		bool packable = d.nb + d.nnzoff < 16384 && d.nb < 16384 && sym[p].max_cn < 512; // item / row-entry words of the LDS copy
 		size_t tri_n = 9 * (size_t)d.nb + 9 * (size_t)d.nnzoff + 3 * (size_t)d.nb + (n_ints + 1) / 2; // diag | off | rhs | symbolic ints
 		const bool rel_family = c->params.family == SRBA_SE2_RELPOSE2D || c->params.family == SRBA_SE3_RELPOSE3D || c->dm.P == 3;
-		const bool to_gang = c->gang_from_nb > 0 && !rel_family && schur_solver && caps[p].n_unk_lms > 0 && caps[p].n_unk_edges > 0 && d.nb >= c->gang_from_nb; // big enough for the lock-step multi-workgroup path to beat one wavefront // relative-pose and SE2 families: their kernels carry the sparse solver only (one 3x3 block per edge: the sparse image fits)
+		const bool to_gang = c->gang_from_nb > 0 && !rel_family && schur_solver && caps[p].n_unk_lms > 0 && caps[p].n_unk_edges > 0 && d.nb >= c->gang_from_nb;
+			// big enough for the lock-step multi-workgroup path to beat one wavefront // relative-pose and SE2 families: their kernels carry the sparse solver only (one 3x3 block per edge: the
+			// sparse image fits)
 		if (!surely_big && c->dense_blocks_ok && !rel_family) { // nearly full factor: the dense block layout (numbers + the permutation only) is smaller than the sparse one with its item list
 			const size_t nnz_d = (size_t)d.nb * (d.nb - 1) / 2, tri_d = 9 * (size_t)d.nb + 9 * nnz_d + 3 * (size_t)d.nb + ((size_t)d.nb + 1) / 2;
-			if (tri_d < tri_n && tri_d * 8 <= 152 * 1024) { symbolic_dense(k, d, P, L, !schur_solver, sym[p]); d.dense_blocks = 1; d.nnzoff = (int)nnz_d; d.n_items = 0; d.aligned = sym[p].aligned ? 1 : 0; n_ints = d.nb; packable = true; tri_n = tri_d; }
+			if (tri_d < tri_n && tri_d * 8 <= 152 * 1024) { symbolic_dense(k, d, P, L, !schur_solver, sym[p]); d.dense_blocks = 1; d.nnzoff = (int)nnz_d; d.n_items = 0;
+				d.aligned = sym[p].aligned ? 1 : 0; n_ints = d.nb; packable = true; tri_n = tri_d; }
 		}
 		// LDS footprint x residency time is what bounds the batch: capsules are grouped in fine size classes so that each launch
 		// reserves little more LDS per wavefront than its capsules need
@@ -1606,14 +1724,17 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		long long wave_ws = 0; // doubles of HBM workspace of a capsule that keeps one wavefront but holds its (dense block) system in HBM
 		d.hap_chunked = 0; d.n_hrec = k.n_hap; d.o_hrec = t_hrec; t_hrec += k.n_hap; // K6 work records: one per block
 		d.hs_lds = 0; d.o_hapo = t_hapo; d.o_schl = t_schl; d.n_panel = 1; d.o_ptab = t_ptab;
-		if (to_wg) { d.n_panel = wg_panels; t_ptab += 3 * (wg_panels + 1); const int nt = (d.n_sys + srbadev::WT - 1) / srbadev::WT; d.dense_blocks = 3; d.nnzoff = 0; d.n_items = 0; wave_ws = srbadev::wg_ws_doubles(nt);
+		if (to_wg) { d.n_panel = wg_panels; t_ptab += 3 * (wg_panels + 1); const int nt = (d.n_sys + srbadev::WT - 1) / srbadev::WT; d.dense_blocks = 3; d.nnzoff = 0; d.n_items = 0;
+			wave_ws = srbadev::wg_ws_doubles(nt);
 			cls[p] = wg_cls; d.hs_lds = 1; wg_lds[wg_cls - SRBA_NLDS] = std::max(wg_lds[wg_cls - SRBA_NLDS], wg_need); t_hapo += k.n_hap_terms; t_schl += k.n_sch_terms; }
-		if ((cls[p] == SRBA_NCLS - 1 ? many_mid : (c->hbm_from_kb > 0 && n >= 1024 && kClsKB[cls[p]] >= c->hbm_from_kb && d.nb <= 168)) && !surely_big && !to_gang && !to_wg && c->dense_blocks_ok && !rel_family) {
+		if ((cls[p] == SRBA_NCLS - 1 ? many_mid : (c->hbm_from_kb > 0 && n >= 1024 && kClsKB[cls[p]] >= c->hbm_from_kb && d.nb <= 168)) && !surely_big && !to_gang && !to_wg && c->dense_blocks_ok &&
+			!rel_family) {
 			// Does not fit any LDS class and the batch has many like it: the multi-workgroup path would run them a few at a time from the host. They stay on the
 			// one-wavefront kernel with the dense block system in an HBM workspace (slow per capsule, but thousands run side by side).
 			const size_t nnz_d = (size_t)d.nb * (d.nb - 1) / 2;
 			symbolic_dense(k, d, P, L, !schur_solver, sym[p]); d.dense_blocks = 2; d.nnzoff = (int)nnz_d; d.n_items = 0; d.aligned = sym[p].aligned ? 1 : 0;
-			tri_n = ((size_t)d.nb + 1) / 2 + 16 + (c->dense_left ? 21 * (size_t)d.nb : 0); bytes = tri_n * 8; /* LDS: the permutation (+ two rows of the factor and the right-hand side: left-looking sweeps) */
+			tri_n = ((size_t)d.nb + 1) / 2 + 16 + (c->dense_left ? 21 * (size_t)d.nb : 0); bytes = tri_n * 8; /* LDS: the permutation (+ two rows of the factor and the right-hand side: left-looking
+				sweeps) */
 			cls[p] = 0; while (cls[p] < SRBA_NLDS - 1 && bytes > (size_t)kClsKB[cls[p]] * 1024) cls[p]++;
 			wave_ws = 12 * (long long)d.nb + 9 * (long long)nnz_d;
 		}
@@ -1627,15 +1748,20 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		long long npath_needed = 0; for (int q = 0; q < k.n_pairs; q++) if (k.pair_needed[q]) { st.n_pairs_needed++; npath_needed += k.pair_path_off[q + 1] - k.pair_path_off[q]; }
 		st.n_path_needed += npath_needed;
 		t_edge += k.n_edges; t_unk += d.nK; t_ulm += d.nF; t_klm += d.n_klm; t_pair += k.n_pairs; t_path += k.n_path; t_obs += k.n_obs; t_valid += k.n_valid; t_bp += k.n_bp; t_bf += k.n_bf;
-		t_hap += k.n_hap; t_hapt += k.n_hap_terms; t_hf += k.n_hf; t_hft += k.n_hf_terms; t_hapf += k.n_hapf; t_hapft += k.n_hapf_terms; t_sch += k.n_sch_terms; t_req += nreq; t_scal += d.n_scal; t_yw += nyw; t_dense += (big_ld * big_ld + big_ld * srbadev::CB + 2 * big_ld + wave_ws + 1) & ~1LL; /* (even: the tile systems of the workgroup path move 16 bytes at a time) */ big_lds[p] = (int)big_ld;
+		t_hap += k.n_hap; t_hapt += k.n_hap_terms; t_hf += k.n_hf; t_hft += k.n_hf_terms; t_hapf += k.n_hapf; t_hapft += k.n_hapf_terms; t_sch += k.n_sch_terms; t_req += nreq; t_scal += d.n_scal;
+			t_yw += nyw; t_dense += (big_ld * big_ld + big_ld * srbadev::CB + 2 * big_ld + wave_ws + 1) & ~1LL; /* (even: the tile systems of the workgroup path move 16 bytes at a time) */ big_lds[p]
+			= (int)big_ld;
 	}
-	st.n_edges = t_edge; st.n_unk_edges = t_unk; st.n_unk_lms = t_ulm; st.n_pairs = t_pair; st.n_path = t_path; st.n_obs = t_obs; st.n_bp = t_bp; st.n_bf = t_bf; st.n_hap = t_hap; st.n_hap_terms = t_hapt;
+	st.n_edges = t_edge; st.n_unk_edges = t_unk; st.n_unk_lms = t_ulm; st.n_pairs = t_pair; st.n_path = t_path; st.n_obs = t_obs; st.n_bp = t_bp; st.n_bf = t_bf; st.n_hap = t_hap;
+		st.n_hap_terms = t_hapt;
 	st.n_hf_terms = t_hft; st.n_hapf_terms = t_hapft; st.n_sch_terms = t_sch; st.n_scalars = t_scal;
 	c->tot_edge = t_edge; c->tot_ulm = t_ulm;
 	// ---- input arena layout
 	Arena in; struct { size_t desc, edge0, ulm0, klm, obs_z, pair_path_off, path_edge, obs_pose, obs_lm, obs_valid, bp_col, bp_res, bp_A, bp_D, bp_lm, colp_off, bf_col, bf_res, bf_pose, colf_off,
-		hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hap_tblk, hf_i, hf_j, hf_term_off, hf_t1, hf_t2, hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag, sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw, sch_tblk,
-		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, obs_rec, pair_needed, pose_req, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_rptr, sp_rcol, sp_perm, sp_fill, hap_rec, hapo, schl, ptab, hap_dst, hapf_dst, hf_dst, asm_term, asm_blk, asm_desc, asm_list, asm_slot; } o;
+		hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hap_tblk, hf_i, hf_j, hf_term_off, hf_t1, hf_t2, hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag, sch_term_off, sch_b1, sch_b2,
+			sch_lm, sch_yw, sch_tblk,
+		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, obs_rec, pair_needed, pose_req, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_rptr, sp_rcol, sp_perm, sp_fill, hap_rec,
+			hapo, schl, ptab, hap_dst, hapf_dst, hf_dst, asm_term, asm_blk, asm_desc, asm_list, asm_slot; } o;
 	o.desc = in.add(sizeof(ProbDesc) * n);
 	o.edge0 = in.add(8 * t_edge * PDX); o.ulm0 = in.add(8 * t_ulm * L); o.klm = in.add(8 * t_klm * L); o.obs_z = in.add(8 * t_obs * O);
 	o.pair_path_off = in.add(4 * (t_pair + n)); o.path_edge = in.add(4 * t_path); o.obs_pose = in.add(4 * t_obs); o.obs_lm = in.add(4 * t_obs); o.obs_valid = in.add(4 * t_obs);
@@ -1646,21 +1772,31 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	o.hapf_i = in.add(4 * t_hapf); o.hapf_j = in.add(4 * t_hapf); o.hapf_term_off = in.add(4 * (t_hapf + n)); o.hapf_t1 = in.add(4 * t_hapft); o.hapf_t2 = in.add(4 * t_hapft);
 	o.hap_diag = in.add(4 * t_unk); o.hf_diag = in.add(4 * t_ulm);
 	o.sch_term_off = in.add(4 * (t_hap + n)); o.sch_b1 = in.add(4 * t_sch); o.sch_b2 = in.add(4 * t_sch); o.sch_lm = in.add(4 * t_sch); o.sch_yw = in.add(4 * t_sch); o.sch_tblk = in.add(4 * t_sch);
-	o.lm_hapf_off = in.add(4 * (t_ulm + n)); o.lm_hapf_idx = in.add(4 * t_hapf); o.req_idx = in.add(4 * t_req); o.need_idx = in.add(4 * t_pair); o.need_rec = in.add(4 * 5 * std::max<long long>(t_pair, 1)); o.obs_rec = in.add(4 * 5 * std::max<long long>(t_obs, 1)); o.pair_needed = in.add(t_pair); o.pose_req = in.add(2 * t_pair); o.bp_normal = in.add(t_bp); o.order = in.add(4 * (size_t)n);
-	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_rptr = in.add(4 * t_spcol); o.sp_rcol = in.add(4 * t_sprow); o.sp_perm = in.add(4 * t_spcol); o.hap_rec = in.add(4 * 3 * std::max<long long>(t_hrec, 1)); o.hapo = in.add(4 * 3 * t_hapo); o.schl = in.add(4 * 4 * t_schl); o.ptab = in.add(4 * std::max<long long>(t_ptab, 1)); o.sp_fill = in.add(4 * std::max<long long>(t_spfill, 1));
+	o.lm_hapf_off = in.add(4 * (t_ulm + n)); o.lm_hapf_idx = in.add(4 * t_hapf); o.req_idx = in.add(4 * t_req); o.need_idx = in.add(4 * t_pair);
+		o.need_rec = in.add(4 * 5 * std::max<long long>(t_pair, 1)); o.obs_rec = in.add(4 * 5 * std::max<long long>(t_obs, 1)); o.pair_needed = in.add(t_pair); o.pose_req = in.add(2 * t_pair);
+		o.bp_normal = in.add(t_bp); o.order = in.add(4 * (size_t)n);
+	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_rptr = in.add(4 * t_spcol);
+		o.sp_rcol = in.add(4 * t_sprow); o.sp_perm = in.add(4 * t_spcol); o.hap_rec = in.add(4 * 3 * std::max<long long>(t_hrec, 1)); o.hapo = in.add(4 * 3 * t_hapo); o.schl = in.add(4 * 4 * t_schl);
+		o.ptab = in.add(4 * std::max<long long>(t_ptab, 1)); o.sp_fill = in.add(4 * std::max<long long>(t_spfill, 1));
 	o.hap_dst = in.add(4 * t_hap * (P / 3) * (P / 3)); o.hapf_dst = in.add(4 * t_hapf * (P / 3)); o.hf_dst = in.add(4 * t_hf);
 	bool asm_fam = c->asm_on && c->params.family == SRBA_SE2_RELPOSE2D;
-	if (asm_fam && c->dp.noise == SRBA_NOISE_CONSTANT_MATRIX) for (int i = 0; i < 3; i++) for (int j = 0; j < i; j++) if (c->dp.lambda[3 * i + j] != c->dp.lambda[3 * j + i]) asm_fam = false; // the fused kernel sums the upper triangle of J^t Lambda J only
-	o.asm_term = in.add(asm_fam ? 8 * std::max<long long>(t_hapt, 1) : 0); o.asm_blk = in.add(asm_fam ? 8 * std::max<long long>(t_bp, 1) : 0); o.asm_desc = in.add(asm_fam ? sizeof(srbadev::AsmDesc) * (size_t)srbadev::ASM_WAVES_PER_WG * (size_t)n : 0); /* (at most one bin per capsule) */ o.asm_list = in.add(asm_fam ? 4 * (size_t)n : 0); o.asm_slot = in.add(0);
+	if (asm_fam && c->dp.noise == SRBA_NOISE_CONSTANT_MATRIX) for (int i = 0; i < 3; i++) for (int j = 0; j < i; j++) if (c->dp.lambda[3 * i + j] != c->dp.lambda[3 * j + i]) asm_fam = false;
+		// the fused kernel sums the upper triangle of J^t Lambda J only
+	o.asm_term = in.add(asm_fam ? 8 * std::max<long long>(t_hapt, 1) : 0); o.asm_blk = in.add(asm_fam ? 8 * std::max<long long>(t_bp, 1) : 0);
+		o.asm_desc = in.add(asm_fam ? sizeof(srbadev::AsmDesc) * (size_t)srbadev::ASM_WAVES_PER_WG * (size_t)n : 0); /* (at most one bin per capsule) */ o.asm_list = in.add(asm_fam ? 4 * (size_t)n :
+		0); o.asm_slot = in.add(0);
 	std::vector<unsigned char> asm_fit(asm_fam ? n : 0, 0); std::vector<int> asm_nt(asm_fam ? n : 0, 0); // per capsule: its indices fit the packed records; off-diagonal terms
 	in.add(0);
 	if (c->h2d_pending) { HIPCHK(c, hipEventSynchronize(c->ev_h2d)); c->h2d_pending = false; } // (an upload nobody waited for may still be reading the staging buffer)
-	if (c->h_in_cap < in.size + 256) { c->h_in.release(); c->h_in_cap = 0; const size_t want = in.size + 256 <= srba_hip_ctx::kPinnedMax / 2 ? 2 * (in.size + 256) : in.size + 256; // uninitialised: cleared below, in parallel
-		if (want <= srba_hip_ctx::kPinnedMax && hipHostMalloc((void **)&c->h_in.p, want, hipHostMallocDefault) == hipSuccess) c->h_in.pinned = true; else { (void)hipGetLastError(); c->h_in.p = new char[want]; c->h_in.pinned = false; }
+	if (c->h_in_cap < in.size + 256) { c->h_in.release(); c->h_in_cap = 0; const size_t want = in.size + 256 <= srba_hip_ctx::kPinnedMax / 2 ? 2 * (in.size + 256) : in.size + 256;
+		// uninitialised: cleared below, in parallel
+		if (want <= srba_hip_ctx::kPinnedMax && hipHostMalloc((void **)&c->h_in.p, want, hipHostMallocDefault) == hipSuccess) c->h_in.pinned = true; else { (void)hipGetLastError();
+			c->h_in.p = new char[want]; c->h_in.pinned = false; }
 		c->h_in_cap = want; }
 	char *h = c->h_in.get();
 	{ const size_t tot = in.size + 256, slab = (size_t)4 << 20; const int nslab = (int)((tot + slab - 1) / slab);
-	  parallel_ranges(std::max(nslab, 512), nslab > 1 ? c->upload_threads : 1, [&](int b, int e, int) { for (int q = b; q < e && q < nslab; q++) std::memset(h + (size_t)q * slab, 0, std::min(slab, tot - (size_t)q * slab)); }); }
+	  parallel_ranges(std::max(nslab, 512), nslab > 1 ? c->upload_threads : 1, [&](int b, int e, int) { for (int q = b; q < e && q < nslab; q++) std::memset(h + (size_t)q * slab, 0, std::min(slab,
+	  	tot - (size_t)q * slab)); }); }
 	c->in_off_edge0 = o.edge0; c->in_off_ulm0 = o.ulm0; c->h_off_order = o.order;
 	if (host_timing) ht1 = now();
 	// ---- pass 2: pack
@@ -1670,21 +1806,27 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	for (int p = p_begin; p < p_end; p++) {
 		const srba_problem_capsule &k = caps[p]; const ProbDesc &d = c->desc[p];
 		if (PDX == PD) { CPY(o.edge0, d.o_edge * PD, k.edge_pose, (size_t)k.n_edges * PD, double); }
-		else { double *e = (double *)(h + o.edge0) + d.o_edge * PDX; for (int q = 0; q < k.n_edges; q++) { const double *s3 = k.edge_pose + 3 * (size_t)q; e[5 * q] = s3[0]; e[5 * q + 1] = s3[1]; e[5 * q + 2] = s3[2]; e[5 * q + 3] = std::cos(s3[2]); e[5 * q + 4] = std::sin(s3[2]); } }
+		else { double *e = (double *)(h + o.edge0) + d.o_edge * PDX; for (int q = 0; q < k.n_edges; q++) { const double *s3 = k.edge_pose + 3 * (size_t)q; e[5 * q] = s3[0]; e[5 * q + 1] = s3[1];
+			e[5 * q + 2] = s3[2]; e[5 * q + 3] = std::cos(s3[2]); e[5 * q + 4] = std::sin(s3[2]); } }
 		CPY(o.ulm0, d.o_ulm * L, k.ulm_pos, (size_t)d.nF * L, double); CPY(o.klm, d.o_klm * L, k.klm_pos, (size_t)d.n_klm * L, double); CPY(o.obs_z, d.o_obs * O, k.obs_z, (size_t)k.n_obs * O, double);
 		CPY(o.pair_path_off, d.o_ppoff, k.pair_path_off, k.n_pairs + 1, int32_t); CPY(o.path_edge, d.o_path, k.path_edge, k.n_path, int32_t);
 		CPY(o.obs_pose, d.o_obs, k.obs_pose, k.n_obs, int32_t); CPY(o.obs_lm, d.o_obs, k.obs_lm, k.n_obs, int32_t); CPY(o.obs_valid, d.o_obs, k.obs_valid, k.n_obs, int32_t);
-		CPY(o.bp_col, d.o_bp, k.bp_col, k.n_bp, int32_t); CPY(o.bp_res, d.o_bp, k.bp_res, k.n_bp, int32_t); CPY(o.bp_A, d.o_bp, k.bp_A, k.n_bp, int32_t); CPY(o.bp_D, d.o_bp, k.bp_D, k.n_bp, int32_t); CPY(o.bp_lm, d.o_bp, k.bp_lm, k.n_bp, int32_t);
+		CPY(o.bp_col, d.o_bp, k.bp_col, k.n_bp, int32_t); CPY(o.bp_res, d.o_bp, k.bp_res, k.n_bp, int32_t); CPY(o.bp_A, d.o_bp, k.bp_A, k.n_bp, int32_t); CPY(o.bp_D, d.o_bp, k.bp_D, k.n_bp, int32_t);
+			CPY(o.bp_lm, d.o_bp, k.bp_lm, k.n_bp, int32_t);
 		CPY(o.colp_off, d.o_colp, k.colp_off, d.nK + 1, int32_t);
 		CPY(o.bf_col, d.o_bf, k.bf_col, k.n_bf, int32_t); CPY(o.bf_res, d.o_bf, k.bf_res, k.n_bf, int32_t); CPY(o.bf_pose, d.o_bf, k.bf_pose, k.n_bf, int32_t);
 		if (k.colf_off) CPY(o.colf_off, d.o_colf, k.colf_off, d.nF + 1, int32_t);
-		CPY(o.hap_i, d.o_hap, k.hap_i, k.n_hap, int32_t); CPY(o.hap_j, d.o_hap, k.hap_j, k.n_hap, int32_t); CPY(o.hap_term_off, d.o_hapoff, k.hap_term_off, k.n_hap + 1, int32_t); CPY(o.hap_t1, d.o_hapt, k.hap_t1, k.n_hap_terms, int32_t); CPY(o.hap_t2, d.o_hapt, k.hap_t2, k.n_hap_terms, int32_t);
+		CPY(o.hap_i, d.o_hap, k.hap_i, k.n_hap, int32_t); CPY(o.hap_j, d.o_hap, k.hap_j, k.n_hap, int32_t); CPY(o.hap_term_off, d.o_hapoff, k.hap_term_off, k.n_hap + 1, int32_t); CPY(o.hap_t1,
+			d.o_hapt, k.hap_t1, k.n_hap_terms, int32_t); CPY(o.hap_t2, d.o_hapt, k.hap_t2, k.n_hap_terms, int32_t);
 		{ int32_t *tb = (int32_t *)(h + o.hap_tblk) + d.o_hapt; for (int b = 0; b < k.n_hap; b++) for (int t = k.hap_term_off[b]; t < k.hap_term_off[b + 1]; t++) tb[t] = b; }
-		CPY(o.hf_i, d.o_hf, k.hf_i, k.n_hf, int32_t); CPY(o.hf_j, d.o_hf, k.hf_j, k.n_hf, int32_t); if (k.hf_term_off) CPY(o.hf_term_off, d.o_hfoff, k.hf_term_off, k.n_hf + 1, int32_t); CPY(o.hf_t1, d.o_hft, k.hf_t1, k.n_hf_terms, int32_t); CPY(o.hf_t2, d.o_hft, k.hf_t2, k.n_hf_terms, int32_t);
-		CPY(o.hapf_i, d.o_hapf, k.hapf_i, k.n_hapf, int32_t); CPY(o.hapf_j, d.o_hapf, k.hapf_j, k.n_hapf, int32_t); if (k.hapf_term_off) CPY(o.hapf_term_off, d.o_hapfoff, k.hapf_term_off, k.n_hapf + 1, int32_t); CPY(o.hapf_t1, d.o_hapft, k.hapf_t1, k.n_hapf_terms, int32_t); CPY(o.hapf_t2, d.o_hapft, k.hapf_t2, k.n_hapf_terms, int32_t);
+		CPY(o.hf_i, d.o_hf, k.hf_i, k.n_hf, int32_t); CPY(o.hf_j, d.o_hf, k.hf_j, k.n_hf, int32_t); if (k.hf_term_off) CPY(o.hf_term_off, d.o_hfoff, k.hf_term_off, k.n_hf + 1, int32_t); CPY(o.hf_t1,
+			d.o_hft, k.hf_t1, k.n_hf_terms, int32_t); CPY(o.hf_t2, d.o_hft, k.hf_t2, k.n_hf_terms, int32_t);
+		CPY(o.hapf_i, d.o_hapf, k.hapf_i, k.n_hapf, int32_t); CPY(o.hapf_j, d.o_hapf, k.hapf_j, k.n_hapf, int32_t); if (k.hapf_term_off) CPY(o.hapf_term_off, d.o_hapfoff, k.hapf_term_off,
+			k.n_hapf + 1, int32_t); CPY(o.hapf_t1, d.o_hapft, k.hapf_t1, k.n_hapf_terms, int32_t); CPY(o.hapf_t2, d.o_hapft, k.hapf_t2, k.n_hapf_terms, int32_t);
 		CPY(o.hap_diag, d.o_unk, k.hap_diag, d.nK, int32_t); CPY(o.hf_diag, d.o_ulm, k.hf_diag, d.nF, int32_t);
 		if (k.n_sch_terms > 0) {
-			CPY(o.sch_term_off, d.o_hapoff, k.sch_term_off, k.n_hap + 1, int32_t); CPY(o.sch_b1, d.o_sch, k.sch_b1, k.n_sch_terms, int32_t); CPY(o.sch_b2, d.o_sch, k.sch_b2, k.n_sch_terms, int32_t); CPY(o.sch_lm, d.o_sch, k.sch_lm, k.n_sch_terms, int32_t);
+			CPY(o.sch_term_off, d.o_hapoff, k.sch_term_off, k.n_hap + 1, int32_t); CPY(o.sch_b1, d.o_sch, k.sch_b1, k.n_sch_terms, int32_t); CPY(o.sch_b2, d.o_sch, k.sch_b2, k.n_sch_terms, int32_t);
+				CPY(o.sch_lm, d.o_sch, k.sch_lm, k.n_sch_terms, int32_t);
 			int32_t *yw = (int32_t *)(h + o.sch_yw) + d.o_sch, *tbk = (int32_t *)(h + o.sch_tblk) + d.o_sch; int cnt = 0;
 			for (int b = 0; b < k.n_hap; b++) for (int t = k.sch_term_off[b]; t < k.sch_term_off[b + 1]; t++) { yw[t] = (k.hap_i[b] == k.hap_j[b]) ? cnt++ : -1; tbk[t] = b; }
 		} // else: zeros = empty term lists
@@ -1701,10 +1843,16 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 			const int pr = ip >> 1, pb = k.pair_path_off[pr], pl = k.pair_path_off[pr + 1] - pb;
 			if (k.pair_needed[pr] && pl <= 4) { r[0] = ip & 1; for (int u = 0; u < pl; u++) r[1 + u] = k.path_edge[pb + u]; } else { r[0] = -1; r[1] = ip; } } }
 		{ int32_t *rq = (int32_t *)(h + o.req_idx) + d.o_req; int cnt = 0; for (int i = 0; i < 2 * k.n_pairs; i++) if (k.pose_required[i]) rq[cnt++] = i; }
-		CPY(o.pair_needed, d.o_pair, k.pair_needed, k.n_pairs, uint8_t); CPY(o.pose_req, 2 * d.o_pair, k.pose_required, 2 * (size_t)k.n_pairs, uint8_t); CPY(o.bp_normal, d.o_bp, k.bp_normal, k.n_bp, uint8_t);
+		CPY(o.pair_needed, d.o_pair, k.pair_needed, k.n_pairs, uint8_t); CPY(o.pose_req, 2 * d.o_pair, k.pose_required, 2 * (size_t)k.n_pairs, uint8_t); CPY(o.bp_normal, d.o_bp, k.bp_normal, k.n_bp,
+			uint8_t);
 		CPY(o.sp_col_off, d.o_spcol, sym[p].col_off.data(), d.nb + 1, int32_t); CPY(o.sp_row, d.o_sprow, sym[p].row.data(), sym[p].row.size(), int32_t);
-		CPY(o.sp_item_off, d.o_spcol, sym[p].item_off.data(), d.nb + 1, int32_t); CPY(o.sp_perm, d.o_spperm, sym[p].perm.data(), d.nb, int32_t); { std::vector<int32_t> &tg = sym[p].tgt; const std::vector<int32_t> &ab = sym[p].ab; for (size_t q = 0; q < tg.size(); q++) tg[q] = (int32_t)((((unsigned)(tg[q] >= 0 ? d.nb + tg[q] : -1 - tg[q])) << 18) | (((unsigned)ab[q] >> 16) << 9) | ((unsigned)ab[q] & 0xffffu)); } /* packed words (only capsules with packable indices reach the kernels that read them) */ CPY(o.sp_tgt, d.o_spitem, sym[p].tgt.data(), sym[p].tgt.size(), int32_t);
-		CPY(o.sp_rptr, d.o_spcol, sym[p].rptr.data(), d.nb + 1, int32_t); { std::vector<int32_t> &rc = sym[p].rcol; const std::vector<int32_t> &rbk = sym[p].rblk; for (size_t q = 0; q < rc.size(); q++) rc[q] = (int32_t)(((unsigned)rc[q] << 14) | (unsigned)rbk[q]); } CPY(o.sp_rcol, d.o_sprow, sym[p].rcol.data(), sym[p].rcol.size(), int32_t); CPY(o.sp_fill, d.o_spfill, sym[p].fill.data(), d.n_fill, int32_t);
+		CPY(o.sp_item_off, d.o_spcol, sym[p].item_off.data(), d.nb + 1, int32_t); CPY(o.sp_perm, d.o_spperm, sym[p].perm.data(), d.nb, int32_t); { std::vector<int32_t> &tg = sym[p].tgt;
+			const std::vector<int32_t> &ab = sym[p].ab; for (size_t q = 0; q < tg.size(); q++) tg[q] = (int32_t)((((unsigned)(tg[q] >= 0 ? d.nb + tg[q] : -1 - tg[q])) << 18) | (((unsigned)ab[q] >>
+			16) << 9) | ((unsigned)ab[q] & 0xffffu)); } /* packed words (only capsules with packable indices reach the kernels that read them) */ CPY(o.sp_tgt, d.o_spitem, sym[p].tgt.data(),
+			sym[p].tgt.size(), int32_t);
+		CPY(o.sp_rptr, d.o_spcol, sym[p].rptr.data(), d.nb + 1, int32_t); { std::vector<int32_t> &rc = sym[p].rcol; const std::vector<int32_t> &rbk = sym[p].rblk; for (size_t q = 0; q < rc.size();
+			q++) rc[q] = (int32_t)(((unsigned)rc[q] << 14) | (unsigned)rbk[q]); } CPY(o.sp_rcol, d.o_sprow, sym[p].rcol.data(), sym[p].rcol.size(), int32_t); CPY(o.sp_fill, d.o_spfill,
+			sym[p].fill.data(), d.n_fill, int32_t);
 		{ std::vector<int32_t> ho(k.n_hap); for (int b = 0; b < k.n_hap; b++) ho[b] = b;
 		  std::stable_sort(ho.begin(), ho.end(), [&](int x, int y) { return k.hap_term_off[x + 1] - k.hap_term_off[x] > k.hap_term_off[y + 1] - k.hap_term_off[y]; });
 		  int32_t *hr = (int32_t *)(h + o.hap_rec) + 3 * d.o_hrec; int nr = 0;
@@ -1716,7 +1864,8 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 			int32_t *pt = (int32_t *)(h + o.ptab) + d.o_ptab; for (int q = 0; q <= np; q++) pt[q] = std::min(k.n_hap, q * psize);
 			std::vector<int32_t> ix(k.n_hap_terms), tb(k.n_hap_terms); for (int b = 0; b < k.n_hap; b++) for (int t = k.hap_term_off[b]; t < k.hap_term_off[b + 1]; t++) tb[t] = b;
 			for (int t = 0; t < k.n_hap_terms; t++) ix[t] = t;
-			std::stable_sort(ix.begin(), ix.end(), [&](int x, int y) { const int px = panel_of(tb[x]), py = panel_of(tb[y]); return px != py ? px < py : k.bp_res[k.hap_t1[x]] < k.bp_res[k.hap_t1[y]]; });
+			std::stable_sort(ix.begin(), ix.end(), [&](int x, int y) { const int px = panel_of(tb[x]), py = panel_of(tb[y]); return px != py ? px < py : k.bp_res[k.hap_t1[x]] < k.bp_res[k.hap_t1[y]];
+				});
 			int32_t *ho = (int32_t *)(h + o.hapo) + 3 * d.o_hapo; for (int q = 0; q <= np; q++) pt[np + 1 + q] = 0;
 			for (int q = 0; q < k.n_hap_terms; q++) { const int t = ix[q]; ho[3 * q] = k.hap_t1[t]; ho[3 * q + 1] = k.hap_t2[t]; ho[3 * q + 2] = tb[t]; pt[np + 2 + panel_of(tb[t])] = q + 1; }
 			for (int q = 1; q <= np; q++) pt[np + 1 + q] = std::max(pt[np + 1 + q], pt[np + q]); // (a panel without terms: empty range)
@@ -1725,23 +1874,28 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 			std::stable_sort(sx.begin(), sx.end(), [&](int x, int y) { const int px = panel_of(sb[x]), py = panel_of(sb[y]); return px != py ? px < py : k.sch_lm[x] < k.sch_lm[y]; });
 			int32_t *so = (int32_t *)(h + o.schl) + 4 * d.o_schl; for (int q = 0; q <= np; q++) pt[2 * np + 2 + q] = 0;
 			for (int q = 0; q < k.n_sch_terms; q++) { const int t = sx[q], b = sb[t]; const bool dg = k.hap_i[b] == k.hap_j[b];
-				so[4 * q] = k.sch_lm[t]; so[4 * q + 1] = k.sch_b1[t]; so[4 * q + 2] = k.sch_b2[t]; so[4 * q + 3] = (int32_t)((uint32_t)b | ((uint32_t)k.hap_i[b] << 16) | (dg ? 0x80000000u : 0u)); pt[2 * np + 3 + panel_of(b)] = q + 1; }
+				so[4 * q] = k.sch_lm[t]; so[4 * q + 1] = k.sch_b1[t]; so[4 * q + 2] = k.sch_b2[t]; so[4 * q + 3] = (int32_t)((uint32_t)b | ((uint32_t)k.hap_i[b] << 16) | (dg ? 0x80000000u : 0u));
+					pt[2 * np + 3 + panel_of(b)] = q + 1; }
 			for (int q = 1; q <= np; q++) pt[2 * np + 2 + q] = std::max(pt[2 * np + 2 + q], pt[2 * np + 1 + q]);
 		}
-		if (asm_fam && k.n_bp >= 1 && k.n_bp <= 65536 && 2 * k.n_pairs < 65535 && k.n_obs <= 65536 && d.nK <= 8191 && k.n_hap <= 65536) { // packed records of the fused normal-equations kernel (srba_assemble.hpp)
+		if (asm_fam && k.n_bp >= 1 && k.n_bp <= 65536 && 2 * k.n_pairs < 65535 && k.n_obs <= 65536 && d.nK <= 8191 && k.n_hap <= 65536) {
+			// packed records of the fused normal-equations kernel (srba_assemble.hpp)
 			uint64_t *ab = (uint64_t *)(h + o.asm_blk) + d.o_bp, *at = (uint64_t *)(h + o.asm_term) + d.o_hapt; bool fit = true; const int cb = (k.n_bp + 63) / 64;
 			for (int i = 0; i < d.nK && fit; i++) { // the blocks of unknown i are colp_off[i] .. colp_off[i + 1] - 1, and its diagonal Hessian block sums exactly their J^t Lambda J
 				const int bb = k.colp_off[i], be = k.colp_off[i + 1], hd = k.hap_diag[i]; if (be <= bb || hd < 0 || k.hap_term_off[hd + 1] - k.hap_term_off[hd] != be - bb) { fit = false; break; }
 				for (int b = bb; b < be; b++) { const int t = k.hap_term_off[hd] + (b - bb); if (k.bp_col[b] != i || k.hap_t1[t] != b || k.hap_t2[t] != b || k.bp_D[b] < -1) fit = false;
-					ab[b] = (uint64_t)((uint32_t)(k.bp_D[b] + 1) | ((uint32_t)i << 16) | (k.bp_normal[b] ? 0u : 0x20000000u) | (b == bb ? 0x40000000u : 0u) | (b + 1 == be ? 0x80000000u : 0u)) | ((uint64_t)((uint32_t)k.bp_res[b] | ((uint32_t)hd << 16)) << 32); }
+					ab[b] = (uint64_t)((uint32_t)(k.bp_D[b] + 1) | ((uint32_t)i << 16) | (k.bp_normal[b] ? 0u : 0x20000000u) | (b == bb ? 0x40000000u : 0u) | (b + 1 == be ? 0x80000000u : 0u)) |
+						((uint64_t)((uint32_t)k.bp_res[b] | ((uint32_t)hd << 16)) << 32); }
 			}
 			if (fit && k.colp_off[d.nK] != k.n_bp) fit = false;
 			int nt = 0; auto slot = [&](int b) { return (uint32_t)((b % cb) * 64 + b / cb); };
 			for (int b = 0; b < k.n_hap && fit; b++) if (k.hap_i[b] != k.hap_j[b]) { const int tb = k.hap_term_off[b], te = k.hap_term_off[b + 1]; if (te <= tb) { fit = false; break; }
-				for (int t = tb; t < te; t++) at[nt++] = (uint64_t)(slot(k.hap_t1[t]) | ((k.bp_normal[k.hap_t1[t]] != 0) != (k.bp_normal[k.hap_t2[t]] != 0) ? 0x8000u : 0u) | (slot(k.hap_t2[t]) << 16)) | ((uint64_t)((uint32_t)b | (t == tb ? 0x40000000u : 0u) | (t + 1 == te ? 0x80000000u : 0u)) << 32); }
+				for (int t = tb; t < te; t++) at[nt++] = (uint64_t)(slot(k.hap_t1[t]) | ((k.bp_normal[k.hap_t1[t]] != 0) != (k.bp_normal[k.hap_t2[t]] != 0) ? 0x8000u : 0u) | (slot(k.hap_t2[t]) <<
+					16)) | ((uint64_t)((uint32_t)b | (t == tb ? 0x40000000u : 0u) | (t + 1 == te ? 0x80000000u : 0u)) << 32); }
 			if (fit) { asm_fit[p] = 1; asm_nt[p] = nt; }
 		}
-		CPY(o.hap_dst, d.o_hap * (P / 3) * (P / 3), sym[p].hap_dst.data(), sym[p].hap_dst.size(), int32_t); CPY(o.hapf_dst, d.o_hapf * (P / 3), sym[p].hapf_dst.data(), sym[p].hapf_dst.size(), int32_t); CPY(o.hf_dst, d.o_hf, sym[p].hf_dst.data(), sym[p].hf_dst.size(), int32_t);
+		CPY(o.hap_dst, d.o_hap * (P / 3) * (P / 3), sym[p].hap_dst.data(), sym[p].hap_dst.size(), int32_t); CPY(o.hapf_dst, d.o_hapf * (P / 3), sym[p].hapf_dst.data(), sym[p].hapf_dst.size(),
+			int32_t); CPY(o.hf_dst, d.o_hf, sym[p].hf_dst.data(), sym[p].hf_dst.size(), int32_t);
 		acc_blocks[thread] += d.nb + d.nnzoff; acc_items[thread] += (int64_t)sym[p].tgt.size();
 	}
 	});
@@ -1758,7 +1912,8 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 			int32_t *b = ord + c->cls_first[k]; const int cnt = c->cls_count[k], nq = c->n_queues;
 			auto work = [&](int x) -> long long { const ProbDesc &dx = c->desc[x]; return dx.dense_blocks ? (long long)dx.nb * dx.nb * dx.nb / 6 : dx.n_items; }; // block updates per factorisation
 			std::stable_sort(b, b + cnt, [&](int x, int y) { return work(x) > work(y); });
-			if (c->sched == 0 && cnt >= 16 * nq) { std::vector<int32_t> t(b, b + cnt); for (int q = 0; q < nq; q++) { int i = slice_begin(cnt, q, nq); for (int src = q; src < cnt; src += nq) b[i++] = t[src]; } }
+			if (c->sched == 0 && cnt >= 16 * nq) { std::vector<int32_t> t(b, b + cnt); for (int q = 0; q < nq; q++) { int i = slice_begin(cnt, q, nq); for (int src = q; src < cnt;
+				src += nq) b[i++] = t[src]; } }
 		}
 		plan_launches(c, ord);
 	}
@@ -1769,7 +1924,8 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		constexpr int W = srbadev::ASM_WAVES_PER_WG; const size_t cap = std::min<size_t>(srbadev::ASM_BIN_BYTES, (size_t)c->asm_max_kb * 1024);
 		std::vector<size_t> need(n, 0); std::vector<int> fit; fit.reserve(n); int32_t *al = (int32_t *)(h + o.asm_list); c->asm_rest = 0;
 		srbadev::AsmDesc *ad = (srbadev::AsmDesc *)(h + o.asm_desc); std::vector<srbadev::AsmDesc> dsc(n);
-		for (int p = 0; p < n; p++) { const ProbDesc &d = c->desc[p]; const int cb = (d.n_bp + 63) / 64; const size_t lean = (8 * (4 * 64 * (size_t)cb + 3 * (size_t)d.nK + PDX * (size_t)d.nK) + 255) & ~(size_t)255, full = lean + 72 * (size_t)d.n_hap + 256;
+		for (int p = 0; p < n; p++) { const ProbDesc &d = c->desc[p]; const int cb = (d.n_bp + 63) / 64; const size_t lean = (8 * (4 * 64 * (size_t)cb + 3 * (size_t)d.nK + PDX * (size_t)d.nK) + 255)
+			& ~(size_t)255, full = lean + 72 * (size_t)d.n_hap + 256;
 			const int stage = full <= cap ? 1 : 0; need[p] = stage ? full : lean;
 			if (asm_fit[p] && need[p] <= cap && cb <= 511) fit.push_back(p); else al[c->asm_rest++] = p;
 			dsc[p] = {p, d.n_bp, asm_nt[p], cb, (asm_nt[p] + 63) / 64, d.n_hap, d.nK, stage, 0, 0, d.o_bp, d.o_hapt, d.o_pair * 2 * PDX, d.o_edge * PDX, d.o_obs * O, d.o_hap, d.o_scal}; }
@@ -1784,39 +1940,57 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	}
 	if (host_timing) ht2 = now();
 	// ---- work arena layout
-	Arena wk; struct { size_t edge, ulm, pose, Jp, Jf, resid, resid2, HAp, HAp0, Hf, HApf, grad, delta, Hfinv, YW, Yh, old_edge, old_ulm, old_pose, dense, ulm_inf, valid, first_fail, hf_ok, bp_ok, bf_ok, ulm_inf_valid, results, lambda_io, chi2, notpd, phase_cycles, m_pair, grad0, edge1, ulm1, pose1; } w;
+	Arena wk; struct { size_t edge, ulm, pose, Jp, Jf, resid, resid2, HAp, HAp0, Hf, HApf, grad, delta, Hfinv, YW, Yh, old_edge, old_ulm, old_pose, dense, ulm_inf, valid, first_fail, hf_ok, bp_ok,
+		bf_ok, ulm_inf_valid, results, lambda_io, chi2, notpd, phase_cycles, m_pair, grad0, edge1, ulm1, pose1; } w;
 	w.results = wk.add(sizeof(srba_lm_result) * n); // (first: [result records | unknowns | spanning-tree poses] is one span -- srba_hip_optimize_capsule reads it back in one copy)
 	w.edge = wk.add(8 * t_edge * PDX); w.ulm = wk.add(8 * t_ulm * L); w.pose = wk.add(8 * 2 * t_pair * PDX); w.Jp = wk.add(8 * t_bp * O * P); w.Jf = wk.add(8 * t_bf * O * L);
-	w.resid = wk.add(8 * t_obs * O); w.resid2 = wk.add(8 * t_obs * O); w.HAp = wk.add(8 * t_hap * P * P); w.HAp0 = wk.add(8 * t_hap * P * P); w.Hf = wk.add(8 * t_hf * L * L); w.HApf = wk.add(8 * t_hapf * P * L);
-	w.grad = wk.add(8 * t_scal); w.delta = wk.add(8 * t_scal); w.Hfinv = wk.add(8 * t_ulm * L * L); w.YW = wk.add(8 * t_yw * P * L); w.Yh = wk.add(c->wg_on ? 8 * t_hapf * P * L : 0); w.old_edge = wk.add(8 * t_unk * PDX); w.old_ulm = wk.add(8 * t_ulm * L); w.old_pose = wk.add(8 * t_req * PDX);
-	w.dense = wk.add(8 * t_dense); w.ulm_inf = wk.add(8 * t_ulm * L * L); w.valid = wk.add(4 * t_valid); w.first_fail = wk.add(4 * t_valid); w.hf_ok = wk.add(4 * t_ulm); w.bp_ok = wk.add(t_bp); w.bf_ok = wk.add(t_bf); w.ulm_inf_valid = wk.add(t_ulm);
+	w.resid = wk.add(8 * t_obs * O); w.resid2 = wk.add(8 * t_obs * O); w.HAp = wk.add(8 * t_hap * P * P); w.HAp0 = wk.add(8 * t_hap * P * P); w.Hf = wk.add(8 * t_hf * L * L);
+		w.HApf = wk.add(8 * t_hapf * P * L);
+	w.grad = wk.add(8 * t_scal); w.delta = wk.add(8 * t_scal); w.Hfinv = wk.add(8 * t_ulm * L * L); w.YW = wk.add(8 * t_yw * P * L); w.Yh = wk.add(c->wg_on ? 8 * t_hapf * P * L : 0);
+		w.old_edge = wk.add(8 * t_unk * PDX); w.old_ulm = wk.add(8 * t_ulm * L); w.old_pose = wk.add(8 * t_req * PDX);
+	w.dense = wk.add(8 * t_dense); w.ulm_inf = wk.add(8 * t_ulm * L * L); w.valid = wk.add(4 * t_valid); w.first_fail = wk.add(4 * t_valid); w.hf_ok = wk.add(4 * t_ulm); w.bp_ok = wk.add(t_bp);
+		w.bf_ok = wk.add(t_bf); w.ulm_inf_valid = wk.add(t_ulm);
 	w.lambda_io = wk.add(8 * n); w.chi2 = wk.add(8 * n); w.notpd = wk.add(4 * n); w.phase_cycles = wk.add(8 * 16 * (size_t)n);
 	w.m_pair = wk.add(4 * t_pair);
-	w.edge1 = wk.add(8 * t_edge * PDX); w.ulm1 = wk.add(8 * t_ulm * L); w.pose1 = wk.add(8 * 2 * t_pair * PDX); // second copy of the unknowns and of the spanning-tree poses: the fused loop is double-buffered
+	w.edge1 = wk.add(8 * t_edge * PDX); w.ulm1 = wk.add(8 * t_ulm * L); w.pose1 = wk.add(8 * 2 * t_pair * PDX); // second copy of the unknowns and of the spanning-tree poses: the fused loop is
+		// double-buffered
 	w.grad0 = wk.add((c->params.extensions & SRBA_EXT_SCHUR_KEEPS_GRADIENT) ? 8 * t_scal : 0);
 	wk.add(0);
-	if (in.size + 256 > c->cap_in) { if (c->d_in) hipFree(c->d_in); c->d_in = nullptr; c->cap_in = 0; const size_t want = (in.size + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_in, want)); c->cap_in = want; }
+	if (in.size + 256 > c->cap_in) { if (c->d_in) hipFree(c->d_in); c->d_in = nullptr; c->cap_in = 0; const size_t want = (in.size + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_in,
+		want)); c->cap_in = want; }
 	// a batch of one relative-pose SE2 capsule whose system lives in LDS: spec_w replicas of the work arena for the lambda-ladder speculation (k_lm_spec)
-	c->spec_ready = c->spec_on && n == 1 && c->params.family == SRBA_SE2_RELPOSE2D && c->two_on && c->sched == 3 && cls[0] < SRBA_NCLS - 1 && c->desc[0].dense_in_lds && c->desc[0].n_scal <= srba_hip_ctx::kSpecMaxN && c->desc[0].n_scal == c->desc[0].n_sys && c->params.max_iters <= 100 /* rounds <= trials <= ~ 70 per iteration (lambda *= nu, nu *= 2 reaches max_lambda within that): below the 8192 round numbers a launch owns (SpecCtl::round0) */;
+	c->spec_ready = c->spec_on && n == 1 && c->params.family == SRBA_SE2_RELPOSE2D && c->two_on && c->sched == 3 && cls[0] < SRBA_NCLS - 1 && c->desc[0].dense_in_lds && c->desc[0].n_scal <=
+		srba_hip_ctx::kSpecMaxN && c->desc[0].n_scal == c->desc[0].n_sys && c->params.max_iters <= 100 /* rounds <= trials <= ~ 70 per iteration (lambda *= nu,
+		nu *= 2 reaches max_lambda within that): below the 8192 round numbers a launch owns (SpecCtl::round0) */;
 	c->spec_stride = (wk.size + 255) & ~(size_t)255; const size_t wk_need = c->spec_ready ? c->spec_stride * (size_t)c->spec_w : wk.size;
 	if (c->spec_ready && !c->d_spec) HIPCHK(c, hipMalloc((void **)&c->d_spec, srba_hip_ctx::kSpecBytes));
-	if (wk_need + 256 > c->cap_wk) { if (c->d_wk) hipFree(c->d_wk); c->d_wk = nullptr; c->cap_wk = 0; const size_t want = (wk_need + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_wk, want)); c->cap_wk = want; }
+	if (wk_need + 256 > c->cap_wk) { if (c->d_wk) hipFree(c->d_wk); c->d_wk = nullptr; c->cap_wk = 0; const size_t want = (wk_need + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_wk,
+		want)); c->cap_wk = want; }
 	HIPCHK(c, hipMemcpyAsync(c->d_in, h, in.size, hipMemcpyHostToDevice, c->stream));
 	HIPCHK(c, hipMemsetAsync(c->d_wk, 0, wk_need, c->stream));
 	// ---- batch struct
 	Batch &B = c->B; std::memset(&B, 0, sizeof(B)); B.n_prob = n; B.max_lds_doubles = 0; B.hess_terms = c->lm_terms ? 1 : 0; B.dense_left = c->dense_left ? 1 : 0;
 	char *di = c->d_in, *dw = c->d_wk;
 #define DI(field, T) B.field = (const T *)(di + o.field)
-	B.desc = (const ProbDesc *)(di + o.desc); DI(order, int); DI(sp_col_off, int); DI(sp_row, int); DI(sp_item_off, int); DI(sp_tgt, int); DI(sp_rptr, int); DI(sp_rcol, int); DI(sp_perm, int); DI(hap_rec, int); DI(hapo, int); DI(schl, int); DI(ptab, int); DI(sp_fill, int); DI(hap_dst, int); DI(hapf_dst, int); DI(hf_dst, int); DI(edge0, double); DI(ulm0, double); DI(klm, double); DI(obs_z, double);
-	DI(pair_path_off, int); DI(path_edge, int); DI(obs_pose, int); DI(obs_lm, int); DI(obs_valid, int); DI(bp_col, int); DI(bp_res, int); DI(bp_A, int); DI(bp_D, int); DI(bp_lm, int); DI(colp_off, int);
-	DI(bf_col, int); DI(bf_res, int); DI(bf_pose, int); DI(colf_off, int); DI(hap_i, int); DI(hap_j, int); DI(hap_term_off, int); DI(hap_t1, int); DI(hap_t2, int); DI(hap_tblk, int); DI(hf_i, int); DI(hf_j, int); DI(hf_term_off, int); DI(hf_t1, int); DI(hf_t2, int);
-	DI(hapf_i, int); DI(hapf_j, int); DI(hapf_term_off, int); DI(hapf_t1, int); DI(hapf_t2, int); DI(hap_diag, int); DI(hf_diag, int); DI(sch_term_off, int); DI(sch_b1, int); DI(sch_b2, int); DI(sch_lm, int); DI(sch_yw, int); DI(sch_tblk, int);
-	DI(lm_hapf_off, int); DI(lm_hapf_idx, int); DI(req_idx, int); DI(need_idx, int); DI(need_rec, int); DI(obs_rec, int); DI(pair_needed, unsigned char); DI(pose_req, unsigned char); DI(bp_normal, unsigned char);
-c->asm_tab.term = asm_fam ? (const unsigned long long *)(di + o.asm_term) : nullptr; c->asm_tab.blk = asm_fam ? (const unsigned long long *)(di + o.asm_blk) : nullptr; c->asm_tab.desc = asm_fam ? (const srbadev::AsmDesc *)(di + o.asm_desc) : nullptr; c->asm_list = asm_fam ? (const int *)(di + o.asm_list) : nullptr;
+	B.desc = (const ProbDesc *)(di + o.desc); DI(order, int); DI(sp_col_off, int); DI(sp_row, int); DI(sp_item_off, int); DI(sp_tgt, int); DI(sp_rptr, int); DI(sp_rcol, int); DI(sp_perm, int);
+		DI(hap_rec, int); DI(hapo, int); DI(schl, int); DI(ptab, int); DI(sp_fill, int); DI(hap_dst, int); DI(hapf_dst, int); DI(hf_dst, int); DI(edge0, double); DI(ulm0, double); DI(klm, double);
+		DI(obs_z, double);
+	DI(pair_path_off, int); DI(path_edge, int); DI(obs_pose, int); DI(obs_lm, int); DI(obs_valid, int); DI(bp_col, int); DI(bp_res, int); DI(bp_A, int); DI(bp_D, int); DI(bp_lm, int); DI(colp_off,
+		int);
+	DI(bf_col, int); DI(bf_res, int); DI(bf_pose, int); DI(colf_off, int); DI(hap_i, int); DI(hap_j, int); DI(hap_term_off, int); DI(hap_t1, int); DI(hap_t2, int); DI(hap_tblk, int); DI(hf_i, int);
+		DI(hf_j, int); DI(hf_term_off, int); DI(hf_t1, int); DI(hf_t2, int);
+	DI(hapf_i, int); DI(hapf_j, int); DI(hapf_term_off, int); DI(hapf_t1, int); DI(hapf_t2, int); DI(hap_diag, int); DI(hf_diag, int); DI(sch_term_off, int); DI(sch_b1, int); DI(sch_b2, int);
+		DI(sch_lm, int); DI(sch_yw, int); DI(sch_tblk, int);
+	DI(lm_hapf_off, int); DI(lm_hapf_idx, int); DI(req_idx, int); DI(need_idx, int); DI(need_rec, int); DI(obs_rec, int); DI(pair_needed, unsigned char); DI(pose_req, unsigned char); DI(bp_normal,
+		unsigned char);
+c->asm_tab.term = asm_fam ? (const unsigned long long *)(di + o.asm_term) : nullptr; c->asm_tab.blk = asm_fam ? (const unsigned long long *)(di + o.asm_blk) : nullptr;
+	c->asm_tab.desc = asm_fam ? (const srbadev::AsmDesc *)(di + o.asm_desc) : nullptr; c->asm_list = asm_fam ? (const int *)(di + o.asm_list) : nullptr;
 #undef DI
 #define DW(field, T) B.field = (T *)(dw + w.field)
-	DW(edge, double); DW(ulm, double); DW(pose, double); DW(Jp, double); DW(Jf, double); DW(resid, double); DW(resid2, double); DW(HAp, double); DW(HAp0, double); DW(Hf, double); DW(HApf, double); DW(grad, double); DW(grad0, double); DW(delta, double); DW(edge1, double); DW(ulm1, double); DW(pose1, double);
-	DW(Hfinv, double); DW(YW, double); DW(Yh, double); DW(old_edge, double); DW(old_ulm, double); DW(old_pose, double); DW(dense, double); DW(ulm_inf, double); DW(valid, int); DW(first_fail, int); DW(hf_ok, int); DW(bp_ok, unsigned char); DW(bf_ok, unsigned char); DW(ulm_inf_valid, unsigned char);
+	DW(edge, double); DW(ulm, double); DW(pose, double); DW(Jp, double); DW(Jf, double); DW(resid, double); DW(resid2, double); DW(HAp, double); DW(HAp0, double); DW(Hf, double); DW(HApf, double);
+		DW(grad, double); DW(grad0, double); DW(delta, double); DW(edge1, double); DW(ulm1, double); DW(pose1, double);
+	DW(Hfinv, double); DW(YW, double); DW(Yh, double); DW(old_edge, double); DW(old_ulm, double); DW(old_pose, double); DW(dense, double); DW(ulm_inf, double); DW(valid, int); DW(first_fail, int);
+		DW(hf_ok, int); DW(bp_ok, unsigned char); DW(bf_ok, unsigned char); DW(ulm_inf_valid, unsigned char);
 	DW(results, srba_lm_result); DW(lambda_io, double); DW(chi2, double); DW(notpd, int);
 	c->flat.pair = (int *)(dw + w.m_pair); c->flat.n_pair = t_pair; c->flat_ready = false;
 	c->off_phase = w.phase_cycles; B.phase_cycles = c->phase_timing ? (long long *)(dw + w.phase_cycles) : nullptr;
@@ -1829,11 +2003,15 @@ c->asm_tab.term = asm_fam ? (const unsigned long long *)(di + o.asm_term) : null
 	c->batch_copied = false; // (the device copy of the batch record is made by the first launch that needs it: the speculative single-capsule kernel takes the record by value)
 	c->n_prob = n; st.device_bytes = (int64_t)(in.size + wk.size);
 	c->off_valid = w.valid; c->off_bp_ok = w.bp_ok; c->n_valid_total = t_valid; c->n_bp_total = t_bp; c->asm_flags_set = false;
-	if (c->asm_ready && !c->defer_upload_sync && set_asm_flags(c) != 0) return -1; // (srba_hip_optimize_capsule runs the LM loop only, whose Jacobian phase writes the flags itself: srba_hip_linearize sets them on demand)
+	if (c->asm_ready && !c->defer_upload_sync && set_asm_flags(c) != 0) return -1; // (srba_hip_optimize_capsule runs the LM loop only,
+		// whose Jacobian phase writes the flags itself: srba_hip_linearize sets them on demand)
 	if (srba_hip_reset_state(c) != 0) return -1;
-	if (c->defer_upload_sync && c->h_in.pinned) { if (!c->ev_h2d) HIPCHK(c, hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming)); HIPCHK(c, hipEventRecord(c->ev_h2d, c->stream)); c->h2d_pending = true; } // (srba_hip_optimize_capsule waits once, at its end)
+	if (c->defer_upload_sync && c->h_in.pinned) { if (!c->ev_h2d) HIPCHK(c, hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming)); HIPCHK(c, hipEventRecord(c->ev_h2d, c->stream));
+		c->h2d_pending = true; } // (srba_hip_optimize_capsule waits once, at its end)
 	else HIPCHK(c, hipStreamSynchronize(c->stream)); // the staging buffer is reused by the next upload
-	if (host_timing) { const double ht3 = now(); acc[0] += ht1 - ht0; acc[1] += ht2 - ht1; acc[2] += ht3 - ht2; if (++calls % 1000 == 0) { std::fprintf(stderr, "[upload] per call: descriptors + symbolic factorisation %.1f us, packing %.1f us, arena + copies queued %.1f us\n", acc[0] / 1000, acc[1] / 1000, acc[2] / 1000); acc[0] = acc[1] = acc[2] = 0; } }
+	if (host_timing) { const double ht3 = now(); acc[0] += ht1 - ht0; acc[1] += ht2 - ht1; acc[2] += ht3 - ht2; if (++calls % 1000 == 0) { std::fprintf(stderr,
+		"[upload] per call: descriptors + symbolic factorisation %.1f us, packing %.1f us, arena + copies queued %.1f us\n", acc[0] / 1000, acc[1] / 1000, acc[2] / 1000);
+		acc[0] = acc[1] = acc[2] = 0; } }
 	return 0;
 }
 
@@ -1845,8 +2023,10 @@ int srba_hip_reset_state(srba_hip_ctx *c) {
 	return 0;
 }
 
-int srba_hip_big_path_stats(srba_hip_ctx *c, double out[4]) { if (!c || !out) return -1; out[0] = c->big_chol_ms; out[1] = c->big_chol_flops; out[2] = (double)c->big_chol_count; out[3] = c->big_chol_nmax; return 0; }
-int srba_hip_big_path_stats2(srba_hip_ctx *c, double out[8]) { if (!c || !out) return -1; out[0] = c->big_chol_ms; out[1] = c->big_chol_flops; out[2] = (double)c->big_chol_count; out[3] = c->big_chol_nmax; out[4] = (double)c->big_chol_seqs; out[5] = c->big_gang && !c->big_persistent ? 1 : 0; out[6] = out[7] = 0; return 0; }
+int srba_hip_big_path_stats(srba_hip_ctx *c, double out[4]) { if (!c || !out) return -1; out[0] = c->big_chol_ms; out[1] = c->big_chol_flops; out[2] = (double)c->big_chol_count;
+	out[3] = c->big_chol_nmax; return 0; }
+int srba_hip_big_path_stats2(srba_hip_ctx *c, double out[8]) { if (!c || !out) return -1; out[0] = c->big_chol_ms; out[1] = c->big_chol_flops; out[2] = (double)c->big_chol_count;
+	out[3] = c->big_chol_nmax; out[4] = (double)c->big_chol_seqs; out[5] = c->big_gang && !c->big_persistent ? 1 : 0; out[6] = out[7] = 0; return 0; }
 int srba_hip_launch_order(srba_hip_ctx *c, int64_t *stamp, int32_t *workgroups, int32_t *delay_us, int n) { // see srba_hip.h
 	if (!c || !stamp || n < 0) return -1;
 	HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1877,7 +2057,8 @@ template <class F> static bool with_family(int family, F &&f) {
 	hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), dim3(nblocks), dim3(SRBA_WG), (lds), launch_stream, (c)->B, (c)->dp, ##__VA_ARGS__); })
 
 template <class K> static int allow_big_lds(srba_hip_ctx *c, K kernel, size_t bytes) {
-	if (bytes > 64 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess) { c->fail(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e)); return -1; } }
+	if (bytes > 64 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); if (e != hipSuccess) {
+		c->fail(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e)); return -1; } }
 	return 0;
 }
 static int prep_lds(srba_hip_ctx *c, bool for_lm) {
@@ -1912,18 +2093,24 @@ static srbadev::Gang gang_masked(const srbadev::Gang &G, unsigned mask) { srbade
 // grid of a gang launch: x = the largest grid any participating window would have alone, y = slots
 template <class ItemsF> static dim3 gang_grid(srba_hip_ctx *c, const srbadev::Gang &G, int block, bool one_workgroup_per_item, ItemsF &&items) {
 	long long gx = 1; int gy = 1;
-	for (int w = 0; w < G.n; w++) if ((G.mask >> w) & 1u) { const long long it = items(c->desc[G.p[w]], w); gx = std::max<long long>(gx, one_workgroup_per_item ? std::max<long long>(1, it) : big_grid(it, block)); gy = w + 1; }
+	for (int w = 0; w < G.n; w++) if ((G.mask >> w) & 1u) { const long long it = items(c->desc[G.p[w]], w); gx = std::max<long long>(gx, one_workgroup_per_item ? std::max<long long>(1,
+		it) : big_grid(it, block)); gy = w + 1; }
 	return dim3((unsigned)gx, (unsigned)gy);
 }
-#define BIGKG(KERNEL, ITEMS, block, ...) do { if (G.mask) with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), gang_grid(c, G, (block), true, [&](const ProbDesc &d, int) -> long long { return (ITEMS); }), dim3(block), 0, st, c->B, c->dp, G, ##__VA_ARGS__); }); } while (0)
-#define BIGK(KERNEL, ITEMS, block, ...) do { if (G.mask) with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), gang_grid(c, G, (block), false, [&](const ProbDesc &d, int) -> long long { return (ITEMS); }), dim3(block), 0, st, c->B, c->dp, G, ##__VA_ARGS__); }); } while (0)
+#define BIGKG(KERNEL, ITEMS, block, ...) do { if (G.mask) with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), gang_grid(c, G, \
+	(block), true, [&](const ProbDesc &d, int) -> long long { return (ITEMS); }), dim3(block), 0, st, c->B, c->dp, G, ##__VA_ARGS__); }); } while (0)
+#define BIGK(KERNEL, ITEMS, block, ...) do { if (G.mask) with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), gang_grid(c, G, \
+	(block), false, [&](const ProbDesc &d, int) -> long long { return (ITEMS); }), dim3(block), 0, st, c->B, c->dp, G, ##__VA_ARGS__); }); } while (0)
 // deterministic reduction of per-workgroup partials into scal[slot] of every participating window
-static void big_reduce(srba_hip_ctx *c, hipStream_t st, const srbadev::Gang &G, int which, int kind, int slot, int is_max) { if (G.mask) hipLaunchKernelGGL(srbadev::kb_reduce, dim3(1, G.n), dim3(256), 0, st, c->B, G, which, kind, slot, is_max); }
+static void big_reduce(srba_hip_ctx *c, hipStream_t st, const srbadev::Gang &G, int which, int kind, int slot, int is_max) { if (G.mask) hipLaunchKernelGGL(srbadev::kb_reduce, dim3(1, G.n),
+	dim3(256), 0, st, c->B, G, which, kind, slot, is_max); }
 static bool big_schur(const srba_hip_ctx *c, const ProbDesc &d) { return c->params.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0; }
-static unsigned gang_schur_mask(srba_hip_ctx *c, const srbadev::Gang &G) { unsigned m = 0; for (int w = 0; w < G.n; w++) if (((G.mask >> w) & 1u) && big_schur(c, c->desc[G.p[w]])) m |= 1u << w; return m; }
+static unsigned gang_schur_mask(srba_hip_ctx *c, const srbadev::Gang &G) { unsigned m = 0; for (int w = 0; w < G.n; w++) if (((G.mask >> w) & 1u) && big_schur(c, c->desc[G.p[w]])) m |= 1u << w;
+	return m; }
 static void big_copy_vec(srba_hip_ctx *c, hipStream_t st, const srbadev::Gang &G, int kind) {
 	if (!G.mask) return;
-	hipLaunchKernelGGL(srbadev::kb_copy_vec, gang_grid(c, G, 256, false, [&](const ProbDesc &d, int) -> long long { return kind == 2 ? (long long)d.n_obs * c->dm.O : d.n_scal; }), dim3(256), 0, st, c->B, G, kind, c->dm.O);
+	hipLaunchKernelGGL(srbadev::kb_copy_vec, gang_grid(c, G, 256, false, [&](const ProbDesc &d, int) -> long long { return kind == 2 ? (long long)d.n_obs * c->dm.O : d.n_scal; }), dim3(256), 0, st,
+		c->B, G, kind, c->dm.O);
 }
 static void big_set_lambda(hipStream_t st, const srbadev::Gang &G, const srbadev::GangLambda &lam) { if (G.mask) hipLaunchKernelGGL(srbadev::kb_set_lambda, dim3(1), dim3(64), 0, st, G, lam); }
 // solve(lambda) of lev-marq_solvers.h for the windows of G.mask, lambda in scal[BS_LAMBDA] of each: (a) Schur reduction (if the solver has one) + dense assembly,
@@ -1938,13 +2125,15 @@ static void big_enqueue_assemble(srba_hip_ctx *c, hipStream_t st, const srbadev:
 	{ const srbadev::Gang G = gang_masked(Gall, ms); BIGK(kb_dense_assemble, d.n_hap + d.n_hapf + d.n_hf, 128, 0); }
 	{ const srbadev::Gang G = gang_masked(Gall, Gall.mask & ~ms); BIGK(kb_dense_assemble, d.n_hap + d.n_hapf + d.n_hf, 128, 1); }
 }
-static srbadev::BigSys big_sys(const srbadev::Gang &G, int w) { srbadev::BigSys S; const int ld = G.ld[w]; S.A = G.A[w]; S.Ldiag = S.A + (size_t)ld * ld; S.rhs = S.Ldiag + (size_t)ld * srbadev::CB; S.y = S.rhs + ld; S.flag = G.iscal + w * 8 + 1; S.n = G.nsys[w]; S.ld = ld; return S; }
+static srbadev::BigSys big_sys(const srbadev::Gang &G, int w) { srbadev::BigSys S; const int ld = G.ld[w]; S.A = G.A[w]; S.Ldiag = S.A + (size_t)ld * ld; S.rhs = S.Ldiag + (size_t)ld * srbadev::CB;
+	S.y = S.rhs + ld; S.flag = G.iscal + w * 8 + 1; S.n = G.nsys[w]; S.ld = ld; return S; }
 static void big_enqueue_cholesky(srba_hip_ctx *c, hipStream_t st, const srbadev::Gang &G) {
 	if (!G.mask) return;
 	int ldmax = 0, nw = 0, w1 = 0; for (int w = 0; w < G.n; w++) if ((G.mask >> w) & 1u) { ldmax = std::max(ldmax, G.ld[w]); nw++; w1 = w; }
 	if (c->big_persistent && nw == 1) { // the whole factorisation in one launch: panel steps and trailing updates separated by grid barriers (srba_big.hpp, k_chol_persistent); one window per launch
 		const srbadev::BigSys S = big_sys(G, w1);
-		const int below0 = S.ld - srbadev::CB, nt0 = below0 > 0 ? (below0 + srbadev::CT - 1) / srbadev::CT : 0, resident = 4 * c->n_cu / std::max(1, c->n_lanes_ready) /* the grid barriers need every workgroup of every window in flight resident: 4 workgroups per CU (34 KB of LDS, 256 threads each) shared by the lanes */,
+		const int below0 = S.ld - srbadev::CB, nt0 = below0 > 0 ? (below0 + srbadev::CT - 1) / srbadev::CT : 0, resident = 4 * c->n_cu / std::max(1,
+			c->n_lanes_ready) /* the grid barriers need every workgroup of every window in flight resident: 4 workgroups per CU (34 KB of LDS, 256 threads each) shared by the lanes */,
 		          Gn = std::max(1, std::min(std::min(120, resident), std::max(nt0 * (nt0 + 1) / 2, 1 + (below0 > 0 ? (below0 + 63) / 64 : 0))));
 		unsigned *bar = (unsigned *)(G.iscal + w1 * 8 + 4);
 		(void)hipMemsetAsync(bar, 0, 4, st);
@@ -1975,9 +2164,11 @@ static int big_timed_cholesky(srba_hip_ctx *c, BigLane *ln, const srbadev::Gang 
 	LNCHK(ln, hipEventRecord(ln->e1, ln->stream));
 	return 0;
 }
-static void big_account_cholesky(srba_hip_ctx *c, BigLane *ln, const srbadev::Gang &G) { // after a stream synchronisation; chol_ms is the time of the launch sequence, shared by the windows of the gang
+static void big_account_cholesky(srba_hip_ctx *c, BigLane *ln, const srbadev::Gang &G) { // after a stream synchronisation; chol_ms is the time of the launch sequence,
+	// shared by the windows of the gang
 	float ms = 0;
-	if (hipEventElapsedTime(&ms, ln->e0, ln->e1) == hipSuccess) { ln->chol_ms += ms; ln->chol_seqs++; for (int w = 0; w < G.n; w++) if ((G.mask >> w) & 1u) { const double ld = G.ld[w]; ln->chol_flops += ld * ld * ld / 3.0; ln->chol_count++; ln->chol_nmax = std::max(ln->chol_nmax, G.nsys[w]); } }
+	if (hipEventElapsedTime(&ms, ln->e0, ln->e1) == hipSuccess) { ln->chol_ms += ms; ln->chol_seqs++; for (int w = 0; w < G.n; w++) if ((G.mask >> w) & 1u) { const double ld = G.ld[w];
+		ln->chol_flops += ld * ld * ld / 3.0; ln->chol_count++; ln->chol_nmax = std::max(ln->chol_nmax, G.nsys[w]); } }
 }
 static int big_solve(srba_hip_ctx *c, BigLane *ln, int p, double lambda, bool *pos_def) { // the stepwise entry point (srba_hip_solve)
 	hipStream_t st = ln->stream; srbadev::Gang G = gang_of(ln); gang_set(c, G, 0, p); G.mask = 1u;
@@ -2029,15 +2220,18 @@ static int big_gang_run(srba_hip_ctx *c, BigLane *ln, const int32_t *caps, int c
 	auto fetch = [&]() -> int { LNCHK(ln, hipMemcpyAsync(ln->h_fetch, ln->d_scal, fetch_bytes, hipMemcpyDeviceToHost, st)); LNCHK(ln, hipStreamSynchronize(st)); return 0; };
 	auto mask_of = [&](auto pred) { unsigned m = 0; for (int w = 0; w < nslots; w++) if (S[w].p >= 0 && pred(S[w])) m |= 1u << w; return m; };
 	auto enqueue_residuals = [&](const srbadev::Gang &G, int to_trial_copy, int use_skip) { BIGK(kb_residuals, d.n_obs, 256, to_trial_copy, use_skip); big_reduce(c, st, G, 0, 0, BS_CHI2, 0); };
-	auto enqueue_linearize = [&](const srbadev::Gang &G) { BIGK(kb_jac_init, d.n_valid, 256); BIGK(kb_jac, d.n_bp + d.n_bf, 128); BIGK(kb_jac_post, d.n_bp + d.n_bf, 256); BIGK(kb_hessian, d.n_hap + d.n_hf + d.n_hapf, 128); BIGKG(kb_hessian_heavy, d.n_hap, 256); };
+	auto enqueue_linearize = [&](const srbadev::Gang &G) { BIGK(kb_jac_init, d.n_valid, 256); BIGK(kb_jac, d.n_bp + d.n_bf, 128); BIGK(kb_jac_post, d.n_bp + d.n_bf, 256); BIGK(kb_hessian,
+		d.n_hap + d.n_hf + d.n_hapf, 128); BIGKG(kb_hessian_heavy, d.n_hap, 256); };
 	// (extension) the Schur kernels reduce B.grad in place: keep what K5 produced and start every solve from it
-	auto enqueue_gradient = [&](const srbadev::Gang &G) { BIGKG(kb_gradient, d.nK + (d.nF + 255) / 256, 256); big_copy_vec(c, st, gang_masked(G, G.mask & mask_of([](const GangSlot &s) { return s.keep_g; })), 1); };
+	auto enqueue_gradient = [&](const srbadev::Gang &G) { BIGKG(kb_gradient, d.nK + (d.nF + 255) / 256, 256); big_copy_vec(c, st, gang_masked(G, G.mask & mask_of([](const GangSlot &s) {
+		return s.keep_g; })), 1); };
 	auto enqueue_dot = [&](const srbadev::Gang &G, int which, int slot, int is_max, int use_skip) { BIGK(kb_dot, d.n_scal, 256, use_skip); big_reduce(c, st, G, which, 2, slot, is_max); };
 	for (;;) {
 		// ---- windows that ended: covariance recovery (S17) and the result record; their slots take the next capsules of the class
 		{ srbadev::Gang G = G0; for (int w = 0; w < nslots; w++) if (S[w].st == GS_FINAL) { gang_set(c, G, w, S[w].p); G.mask |= 1u << w; }
 		  // a rejected last trial is undone first
-		  { const srbadev::Gang Gr = gang_masked(G, G.mask & mask_of([](const GangSlot &s) { return s.restore; })); const srbadev::Gang &G = Gr; BIGK(kb_restore, d.nK + (long long)d.nF * L + d.n_req, 128); }
+		  { const srbadev::Gang Gr = gang_masked(G, G.mask & mask_of([](const GangSlot &s) { return s.restore; })); const srbadev::Gang &G = Gr; BIGK(kb_restore, d.nK + (long long)d.nF * L + d.n_req,
+		  	128); }
 		  if (G.mask) { const srbadev::Gang Gs = gang_masked(G, gang_schur_mask(c, G)), Gn = gang_masked(G, G.mask & ~Gs.mask);
 		    { const srbadev::Gang &G = Gs; BIGK(kb_cov_recovery, std::max(d.nF, 1), 128, 1); } { const srbadev::Gang &G = Gn; BIGK(kb_cov_recovery, std::max(d.nF, 1), 128, 0); } }
 		  for (int w = 0; w < nslots; w++) if (S[w].st == GS_FINAL) { GangSlot &s = S[w];
@@ -2047,12 +2241,14 @@ static int big_gang_run(srba_hip_ctx *c, BigLane *ln, const int32_t *caps, int c
 		    s = GangSlot(); } }
 		for (int w = 0; w < nslots; w++) if (S[w].st == GS_IDLE) { const int i = next.fetch_add(1); if (i >= count) break; GangSlot &s = S[w]; s = GangSlot(); s.p = caps[i]; s.st = GS_NEW;
 			const ProbDesc &d = c->desc[s.p]; s.schur = big_schur(c, d); s.keep_g = s.schur && (prm.extensions & SRBA_EXT_SCHUR_KEEPS_GRADIENT); s.s11 = (long long)O * d.n_obs < (long long)d.n_scal;
-			std::memset(&s.out, 0, sizeof(s.out)); for (int k = 0; k < SRBA_TRACE_LEN; k++) { s.out.trace_chi2[k] = NAN; s.out.trace_lambda[k] = NAN; s.out.trace_rho[k] = NAN; } s.out.lambda_last_trial = NAN; }
+			std::memset(&s.out, 0, sizeof(s.out)); for (int k = 0; k < SRBA_TRACE_LEN; k++) { s.out.trace_chi2[k] = NAN; s.out.trace_lambda[k] = NAN; s.out.trace_rho[k] = NAN; }
+				s.out.lambda_last_trial = NAN; }
 		srbadev::Gang Gall = G0; bool any = false; for (int w = 0; w < nslots; w++) if (S[w].p >= 0) { gang_set(c, Gall, w, S[w].p); any = true; }
 		if (!any) break;
 		// ---- rejected trials: restore (K12); accepted trials: residuals of the trial become current, relinearise where the error moved enough, gradient, |g|_inf;
 		//      new windows: S5 numeric spanning tree, S6/S7/S10 linearisation, S12 lambda_0, S13 residuals, S14 gradient
-		const unsigned m_restore = mask_of([](const GangSlot &s) { return s.restore && s.st != GS_FINAL; }), m_accept = mask_of([](const GangSlot &s) { return s.st == GS_ACCEPT; }), m_relin = mask_of([](const GangSlot &s) { return s.st == GS_ACCEPT && s.relin; }),
+		const unsigned m_restore = mask_of([](const GangSlot &s) { return s.restore && s.st != GS_FINAL; }), m_accept = mask_of([](const GangSlot &s) { return s.st == GS_ACCEPT; }),
+			m_relin = mask_of([](const GangSlot &s) { return s.st == GS_ACCEPT && s.relin; }),
 		               m_new = mask_of([](const GangSlot &s) { return s.st == GS_NEW; }), m_new_full = mask_of([](const GangSlot &s) { return s.st == GS_NEW && !s.s11; });
 		{ const srbadev::Gang G = gang_masked(Gall, m_restore); BIGK(kb_restore, d.nK + (long long)d.nF * L + d.n_req, 128); for (int w = 0; w < nslots; w++) S[w].restore = false; }
 		for (int w = 0; w < nslots; w++) if ((m_new >> w) & 1u) LNCHK(ln, hipMemsetAsync(ln->d_iscal + w * 8, 0, 32, st));
@@ -2067,8 +2263,10 @@ static int big_gang_run(srba_hip_ctx *c, BigLane *ln, const int32_t *caps, int c
 			for (int w = 0; w < nslots; w++) { GangSlot &s = S[w]; const double *h = hs + (size_t)w * 16;
 				if ((m_new >> w) & 1u) { const ProbDesc &d = c->desc[s.p];
 					s.out.num_invalid_jacobs = hi[(size_t)w * 8]; s.out.num_observations = d.n_obs; s.out.num_jacobians = d.n_bp + d.n_bf; s.out.num_span_tree_numeric_updates = d.n_pairs;
-					if (s.s11) { s.out.status = 1; results.emplace_back(new srba_lm_result(s.out)); LNCHK(ln, hipMemcpyAsync(c->B.results + s.p, results.back().get(), sizeof(srba_lm_result), hipMemcpyHostToDevice, st)); s = GangSlot(); continue; } // S11
-					s.lambda = h[BS_MAXDIAG] * 1e-3; s.nu = 2.0; s.total_err = h[BS_CHI2]; s.RMSE = std::sqrt(s.total_err / d.n_obs); s.out.lambda_init = s.lambda; s.out.total_sqr_error_init = s.total_err;
+					if (s.s11) { s.out.status = 1; results.emplace_back(new srba_lm_result(s.out)); LNCHK(ln, hipMemcpyAsync(c->B.results + s.p, results.back().get(), sizeof(srba_lm_result),
+						hipMemcpyHostToDevice, st)); s = GangSlot(); continue; } // S11
+					s.lambda = h[BS_MAXDIAG] * 1e-3; s.nu = 2.0; s.total_err = h[BS_CHI2]; s.RMSE = std::sqrt(s.total_err / d.n_obs); s.out.lambda_init = s.lambda;
+						s.out.total_sqr_error_init = s.total_err;
 					s.iter = 0; gang_advance(prm, s, true);
 				} else if ((m_accept >> w) & 1u) {
 					if (h[BS_NINF] <= 1e-15) { s.stop = true; s.stopmask |= 1 << SRBA_STOP_GRADIENT; }
@@ -2093,13 +2291,15 @@ static int big_gang_run(srba_hip_ctx *c, BigLane *ln, const int32_t *caps, int c
 			enqueue_dot(G, 1, BS_DEN, 0, 1);
 			if (fetch() != 0) return -1;
 			big_account_cholesky(c, ln, G);
-			for (int w = 0; w < nslots; w++) if ((m_trial >> w) & 1u) { GangSlot &s = S[w]; const double *h = hs + (size_t)w * 16; const int hflag = hi[(size_t)w * 8 + 1]; const ProbDesc &d = c->desc[s.p];
+			for (int w = 0; w < nslots; w++) if ((m_trial >> w) & 1u) { GangSlot &s = S[w]; const double *h = hs + (size_t)w * 16; const int hflag = hi[(size_t)w * 8 + 1];
+				const ProbDesc &d = c->desc[s.p];
 				if (hflag == 2) { ln->error = "k_chol_persistent: a grid barrier timed out (the workgroups of the factorisation were not all resident)"; return -1; }
 				if (hflag) { s.n_notpd++; s.lambda *= s.nu; s.nu *= 2.0; s.stop = (s.lambda > prm.max_lambda); if (s.stop) s.stopmask |= 1 << SRBA_STOP_LAMBDA; gang_advance(prm, s, false); continue; }
 				const double new_err = h[BS_CHI2], new_RMSE = std::sqrt(new_err / d.n_obs), err_red = s.total_err > 0 ? (s.total_err - new_err) / s.total_err : 0;
 				s.rho = (s.total_err - new_err) / h[BS_DEN];
 				if (s.tr < SRBA_TRACE_LEN) { s.out.trace_chi2[s.tr] = new_err; s.out.trace_rho[s.tr] = s.rho; }
-				if (s.rho > 0) { s.n_acc++; s.relin = (err_red < 0 || err_red > prm.min_error_reduction_ratio_to_relinearize); s.total_err = new_err; s.RMSE = new_RMSE; if (s.relin) s.n_relin++; s.st = GS_ACCEPT; }
+				if (s.rho > 0) { s.n_acc++; s.relin = (err_red < 0 || err_red > prm.min_error_reduction_ratio_to_relinearize); s.total_err = new_err; s.RMSE = new_RMSE; if (s.relin) s.n_relin++;
+					s.st = GS_ACCEPT; }
 				else { s.restore = true; s.lambda *= s.nu; s.nu *= 2.0; s.stop = (s.lambda > prm.max_lambda); if (s.stop) s.stopmask |= 1 << SRBA_STOP_LAMBDA; gang_advance(prm, s, false); }
 			}
 		}
@@ -2121,7 +2321,9 @@ static int big_prepare_lanes(srba_hip_ctx *c, int n) {
 	}
 	return n;
 }
-static void big_collect_lane_stats(srba_hip_ctx *c) { for (int i = 0; i < c->n_lanes_ready; i++) { BigLane &l = c->lanes[i]; c->big_chol_ms += l.chol_ms; c->big_chol_flops += l.chol_flops; c->big_chol_count += l.chol_count; c->big_chol_seqs += l.chol_seqs; c->big_chol_nmax = std::max(c->big_chol_nmax, l.chol_nmax); l.chol_ms = l.chol_flops = 0; l.chol_count = l.chol_seqs = 0; l.chol_nmax = 0; } }
+static void big_collect_lane_stats(srba_hip_ctx *c) { for (int i = 0; i < c->n_lanes_ready; i++) { BigLane &l = c->lanes[i]; c->big_chol_ms += l.chol_ms; c->big_chol_flops += l.chol_flops;
+	c->big_chol_count += l.chol_count; c->big_chol_seqs += l.chol_seqs; c->big_chol_nmax = std::max(c->big_chol_nmax, l.chol_nmax); l.chol_ms = l.chol_flops = 0; l.chol_count = l.chol_seqs = 0;
+	l.chol_nmax = 0; } }
 // all capsules of the big class: a gang on lane 0 (default), or dealt to several lanes (host threads) with one window each
 static int big_run_class(srba_hip_ctx *c, const int32_t *caps, int count) {
 	if (count <= 0) return 0;
@@ -2175,14 +2377,22 @@ static int lm_run_async_impl(srba_hip_ctx *c) {
 	HIPCHK(c, hipEventRecord(c->ev0, c->stream));
 	if (c->spec_ready && !c->spec_suppress && c->plan.size() == 1 && c->cls_count[SRBA_NCLS - 1] == 0) { // a batch of one capsule: its lambda ladder on spec_w workgroups
 		const int k = c->plan[0].cls; const size_t lds1 = (c->cls_lds[k] + c->lds_pad + 7) & ~(size_t)7; const int W = c->spec_w;
-		srbadev::SpecCtl sc; sc.w = 0; sc.W = W; sc.round0 = (int)((c->spec_launches++ % 200000) * 8192); if (sc.round0 == 0) HIPCHK(c, hipMemsetAsync(c->d_spec, 0, 256, c->stream)); sc.flag = (int *)c->d_spec; sc.box = (double *)(c->d_spec + 256); sc.xdelta = sc.box + 2 * srba_hip_ctx::kSpecMaxW * 4; sc.xstride = srba_hip_ctx::kSpecMaxN; sc.edge_backup = (double *)(c->d_spec + srba_hip_ctx::kSpecBackupOff); // (the round numbers of a launch continue where no earlier launch has been: the flags are cleared once per 200 000 launches, not per launch)
-		const bool test_drop = c->spec_test_drop; /* test knob (SRBA_HIP_SPEC_TEST_DROP, read when the context is created): the last replica is never launched -- the others give up after the spin bound, status 2, and the host falls back (tests/test_gpu_parity.py) */
-		hipLaunchKernelGGL((srbadev::k_lm_spec<SRBA_SE2_RELPOSE2D>), dim3(test_drop ? W - 1 : W), dim3(2 * SRBA_WG), lds1 + 32, c->stream, c->B, c->dp, (int)(lds1 / 8), (long long)c->spec_stride, sc); HIPCHK(c, hipGetLastError());
+		srbadev::SpecCtl sc; sc.w = 0; sc.W = W; sc.round0 = (int)((c->spec_launches++ % 200000) * 8192); if (sc.round0 == 0) HIPCHK(c, hipMemsetAsync(c->d_spec, 0, 256, c->stream));
+			sc.flag = (int *)c->d_spec; sc.box = (double *)(c->d_spec + 256); sc.xdelta = sc.box + 2 * srba_hip_ctx::kSpecMaxW * 4; sc.xstride = srba_hip_ctx::kSpecMaxN;
+			sc.edge_backup = (double *)(c->d_spec + srba_hip_ctx::kSpecBackupOff); // (the round numbers of a launch continue where no earlier launch has been: the flags are cleared once per 200 000
+			// launches, not per launch)
+		const bool test_drop = c->spec_test_drop; /* test knob (SRBA_HIP_SPEC_TEST_DROP, read when the context is created): the last replica is never launched -- the others give up after the spin
+			bound, status 2, and the host falls back (tests/test_gpu_parity.py) */
+		hipLaunchKernelGGL((srbadev::k_lm_spec<SRBA_SE2_RELPOSE2D>), dim3(test_drop ? W - 1 : W), dim3(2 * SRBA_WG), lds1 + 32, c->stream, c->B, c->dp, (int)(lds1 / 8), (long long)c->spec_stride,
+			sc); HIPCHK(c, hipGetLastError());
 		HIPCHK(c, hipEventRecord(c->ev1, c->stream));
 		return 0;
 	}
-	if (!c->batch_copied) { if (!c->d_batch) HIPCHK(c, hipMalloc((void **)&c->d_batch, sizeof(Batch) + sizeof(DevParams))); HIPCHK(c, hipMemcpyAsync(c->d_batch, &c->B, sizeof(Batch), hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipMemcpyAsync(c->d_batch + 1, &c->dp, sizeof(DevParams), hipMemcpyHostToDevice, c->stream)); c->batch_copied = true; } // the kernels read the batch record from device memory (c->B lives as long as the context and only changes at an upload)
-	HIPCHK(c, hipMemsetAsync(c->d_next, 0, sizeof(int) * 4 * std::max<size_t>(1, std::min<size_t>(kMaxJobs, c->plan.size())), c->stream)); // per launch {work counter, pad, device time stamp of its first capsule}
+	if (!c->batch_copied) { if (!c->d_batch) HIPCHK(c, hipMalloc((void **)&c->d_batch, sizeof(Batch) + sizeof(DevParams))); HIPCHK(c, hipMemcpyAsync(c->d_batch, &c->B, sizeof(Batch),
+		hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipMemcpyAsync(c->d_batch + 1, &c->dp, sizeof(DevParams), hipMemcpyHostToDevice, c->stream)); c->batch_copied = true; }
+		// the kernels read the batch record from device memory (c->B lives as long as the context and only changes at an upload)
+	HIPCHK(c, hipMemsetAsync(c->d_next, 0, sizeof(int) * 4 * std::max<size_t>(1, std::min<size_t>(kMaxJobs, c->plan.size())), c->stream)); // per launch {work counter, pad,
+		// device time stamp of its first capsule}
 	// fork/join: the launch plan (made at upload) spreads the size classes over a few streams; see plan_launches()
 	const int nq = c->plan.size() <= 1 ? 1 : c->n_streams_used; // a single launch (the per-key-frame use) stays on the context stream: no fork / join
 	if (nq > 1) HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
@@ -2194,14 +2404,19 @@ static int lm_run_async_impl(srba_hip_ctx *c) {
 		if (k >= SRBA_NLDS) { // landmark windows on a workgroup (k_lm_wg)
 			int rc_attr = 0;
 			with_family(c->params.family, [&](auto fam_) { constexpr int F = decltype(fam_)::value; if constexpr (srbadev::Tr<F>::SE3 && !srbadev::Tr<F>::REL) {
-				if (k == SRBA_CLS_WG512) { if ((rc_attr = allow_big_lds(c, srbadev::k_lm_wg<F, 512>, c->cls_lds[k])) == 0) hipLaunchKernelGGL((srbadev::k_lm_wg<F, 512>), dim3(J.grid), dim3(512), c->cls_lds[k], launch_stream, SRBA_WG_BATCH_VAL(c), J.first, J.count, c->d_next + 4 * j); }
-				else if (k == SRBA_CLS_WG256) { if ((rc_attr = allow_big_lds(c, srbadev::k_lm_wg<F, 256>, c->cls_lds[k])) == 0) hipLaunchKernelGGL((srbadev::k_lm_wg<F, 256>), dim3(J.grid), dim3(256), c->cls_lds[k], launch_stream, SRBA_WG_BATCH_VAL(c), J.first, J.count, c->d_next + 4 * j); }
+				if (k == SRBA_CLS_WG512) { if ((rc_attr = allow_big_lds(c, srbadev::k_lm_wg<F, SRBA_WG_TOP>, c->cls_lds[k])) == 0) hipLaunchKernelGGL((srbadev::k_lm_wg<F, SRBA_WG_TOP>), dim3(J.grid),
+					dim3(SRBA_WG_TOP), c->cls_lds[k], launch_stream, SRBA_WG_BATCH_VAL(c), J.first, J.count, c->d_next + 4 * j); }
+				else if (k == SRBA_CLS_WG256) { if ((rc_attr = allow_big_lds(c, srbadev::k_lm_wg<F, 256>, c->cls_lds[k])) == 0) hipLaunchKernelGGL((srbadev::k_lm_wg<F, 256>), dim3(J.grid), dim3(256),
+					c->cls_lds[k], launch_stream, SRBA_WG_BATCH_VAL(c), J.first, J.count, c->d_next + 4 * j); }
 				else hipLaunchKernelGGL((srbadev::k_lm_wg<F, 128>), dim3(J.grid), dim3(128), c->cls_lds[k], launch_stream, SRBA_WG_BATCH_VAL(c), J.first, J.count, c->d_next + 4 * j); } });
 			if (rc_attr != 0) return -1;
 			HIPCHK(c, hipGetLastError()); continue; }
-		if (J.two) { const size_t lds1 = (c->cls_lds[k] + c->lds_pad + 7) & ~(size_t)7; hipLaunchKernelGGL((srbadev::k_lm_run2<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(2 * SRBA_WG), lds1 + 32, launch_stream, SRBA_LM_BATCH_VAL(c), J.first, J.count, c->d_next + 4 * j, (int)(lds1 / 8)); HIPCHK(c, hipGetLastError()); continue; }
-		if (J.lean) { hipLaunchKernelGGL((srbadev::k_lm_run_lean<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(SRBA_WG), c->cls_lds[k] + c->lds_pad, launch_stream, SRBA_LM_BATCH_VAL(c), J.first, J.count, c->d_next + 4 * j); HIPCHK(c, hipGetLastError()); continue; }
-		with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::k_lm_run<decltype(fam_)::value>), dim3(J.grid), dim3(SRBA_WG), c->cls_lds[k] + c->lds_pad, launch_stream, SRBA_LM_BATCH_VAL(c), J.first, J.count, c->d_next + 4 * j); }); HIPCHK(c, hipGetLastError());
+		if (J.two) { const size_t lds1 = (c->cls_lds[k] + c->lds_pad + 7) & ~(size_t)7; hipLaunchKernelGGL((srbadev::k_lm_run2<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(2 * SRBA_WG), lds1 + 32,
+			launch_stream, SRBA_LM_BATCH_VAL(c), J.first, J.count, c->d_next + 4 * j, (int)(lds1 / 8)); HIPCHK(c, hipGetLastError()); continue; }
+		if (J.lean) { hipLaunchKernelGGL((srbadev::k_lm_run_lean<SRBA_SE2_RELPOSE2D>), dim3(J.grid), dim3(SRBA_WG), c->cls_lds[k] + c->lds_pad, launch_stream, SRBA_LM_BATCH_VAL(c), J.first, J.count,
+			c->d_next + 4 * j); HIPCHK(c, hipGetLastError()); continue; }
+		with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::k_lm_run<decltype(fam_)::value>), dim3(J.grid), dim3(SRBA_WG), c->cls_lds[k] + c->lds_pad, launch_stream,
+			SRBA_LM_BATCH_VAL(c), J.first, J.count, c->d_next + 4 * j); }); HIPCHK(c, hipGetLastError());
 	}
 	// capsules too large for one wavefront's LDS: the multi-workgroup path, one capsule after the other on the context stream (host-driven LM loop: this part
 	// of the call synchronises with the device once per LM trial), overlapping with the persistent launches of the other classes on their own streams
@@ -2216,14 +2431,17 @@ static int lm_run_async_impl(srba_hip_ctx *c) {
 
 int srba_hip_eval_overall_sqr_error(srba_hip_ctx *c, const srba_overall_problem *q, double *out) {
 	if (!c || !q || !out) return -1;
-	if (q->n_edges < 0 || q->n_pairs < 0 || q->n_obs < 0 || q->n_lms < 0 || (q->n_obs > 0 && (!q->obs_pose || !q->obs_lm || !q->obs_z)) || (q->n_pairs > 0 && (!q->pair_path_off || (q->n_path > 0 && !q->path_edge)))) { c->fail("eval_overall_sqr_error: malformed problem"); return -1; }
+	if (q->n_edges < 0 || q->n_pairs < 0 || q->n_obs < 0 || q->n_lms < 0 || (q->n_obs > 0 && (!q->obs_pose || !q->obs_lm || !q->obs_z)) || (q->n_pairs > 0 && (!q->pair_path_off || (q->n_path > 0 &&
+		!q->path_edge)))) { c->fail("eval_overall_sqr_error: malformed problem"); return -1; }
 	*out = 0; if (q->n_obs == 0) return 0;
 	HIPCHK(c, hipSetDevice(c->device));
 	const int L = c->dm.L, O = c->dm.O, PD = c->dm.PD, PDX = c->dm.PDX();
-	for (int i = 0; i < q->n_obs; i++) if (q->obs_pose[i] >= 2 * q->n_pairs || q->obs_lm[i] < 0 || q->obs_lm[i] >= q->n_lms) { c->fail("eval_overall_sqr_error: observation index out of range"); return -1; }
+	for (int i = 0; i < q->n_obs; i++) if (q->obs_pose[i] >= 2 * q->n_pairs || q->obs_lm[i] < 0 || q->obs_lm[i] >= q->n_lms) { c->fail("eval_overall_sqr_error: observation index out of range");
+		return -1; }
 	for (int k = 0; k < q->n_path; k++) if ((q->path_edge[k] >> 1) >= q->n_edges || q->path_edge[k] < 0) { c->fail("eval_overall_sqr_error: path edge out of range"); return -1; }
 	// one host arena -> one H2D copy
-	Arena in; const size_t o_desc = in.add(sizeof(ProbDesc)), o_edge = in.add(8 * (size_t)q->n_edges * PDX), o_ppo = in.add(4 * ((size_t)q->n_pairs + 1)), o_path = in.add(4 * (size_t)std::max(q->n_path, 1)),
+	Arena in; const size_t o_desc = in.add(sizeof(ProbDesc)), o_edge = in.add(8 * (size_t)q->n_edges * PDX), o_ppo = in.add(4 * ((size_t)q->n_pairs + 1)),
+		o_path = in.add(4 * (size_t)std::max(q->n_path, 1)),
 		o_op = in.add(4 * (size_t)q->n_obs), o_ol = in.add(4 * (size_t)q->n_obs), o_z = in.add(8 * (size_t)q->n_obs * O), o_lm = in.add(8 * (size_t)std::max(q->n_lms, 1) * L);
 	const int nblk = std::min(1024, (q->n_obs + 255) / 256);
 	Arena wk; const size_t o_pose = wk.add(8 * 2 * (size_t)std::max(q->n_pairs, 1) * PDX), o_part = wk.add(8 * (size_t)nblk);
@@ -2231,7 +2449,8 @@ int srba_hip_eval_overall_sqr_error(srba_hip_ctx *c, const srba_overall_problem 
 	ProbDesc d; std::memset(&d, 0, sizeof(d)); d.n_edges = q->n_edges; d.n_pairs = q->n_pairs; d.n_obs = q->n_obs; d.nF = q->n_lms;
 	std::memcpy(h.data() + o_desc, &d, sizeof(d));
 	{ double *e = (double *)(h.data() + o_edge);
-	  for (int i = 0; i < q->n_edges; i++) { const double *s = q->edge_pose + (size_t)i * PD; double *t = e + (size_t)i * PDX; for (int k = 0; k < PD; k++) t[k] = s[k]; if (PDX == 5) { t[3] = std::cos(s[2]); t[4] = std::sin(s[2]); } } }
+	  for (int i = 0; i < q->n_edges; i++) { const double *s = q->edge_pose + (size_t)i * PD; double *t = e + (size_t)i * PDX; for (int k = 0; k < PD; k++) t[k] = s[k]; if (PDX == 5) {
+	  	t[3] = std::cos(s[2]); t[4] = std::sin(s[2]); } } }
 	if (q->n_pairs) std::memcpy(h.data() + o_ppo, q->pair_path_off, 4 * ((size_t)q->n_pairs + 1));
 	if (q->n_path) std::memcpy(h.data() + o_path, q->path_edge, 4 * (size_t)q->n_path);
 	std::memcpy(h.data() + o_op, q->obs_pose, 4 * (size_t)q->n_obs); std::memcpy(h.data() + o_ol, q->obs_lm, 4 * (size_t)q->n_obs);
@@ -2291,7 +2510,8 @@ int srba_hip_lm_run(srba_hip_ctx *c, srba_lm_result *results) {
 
 // the flat (one thread per item of the batch) launches of srba_flat.hpp
 static inline int flat_grid(long long items, int block) { return (int)std::max<long long>(1, std::min<long long>((items + block - 1) / block, 1 << 20)); }
-#define FLATK(KERNEL, items, block, ...) with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), dim3(flat_grid((items), (block))), dim3(block), 0, c->stream, c->B, c->dp, ##__VA_ARGS__); })
+#define FLATK(KERNEL, items, block, ...) with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), dim3(flat_grid((items), (block))), \
+	dim3(block), 0, c->stream, c->B, c->dp, ##__VA_ARGS__); })
 static int flat_prepare(srba_hip_ctx *c) {
 	if (c->flat_ready) return 0;
 	hipLaunchKernelGGL(srbadev::kf_fill_maps, dim3(c->n_prob), dim3(256), 0, c->stream, c->B, c->flat); HIPCHK(c, hipGetLastError());
@@ -2315,9 +2535,13 @@ int srba_hip_linearize(srba_hip_ctx *c) {
 	bool lam_sym = true; // the fused kernel sums the upper triangle of J^t Lambda J only: an information matrix set after the upload (srba_hip_set_params) is checked again here
 	if (c->dp.noise == SRBA_NOISE_CONSTANT_MATRIX) for (int i = 0; i < 3; i++) for (int j = 0; j < i; j++) if (c->dp.lambda[3 * i + j] != c->dp.lambda[3 * j + i]) lam_sym = false;
 	if (c->asm_ready && lam_sym && set_asm_flags(c) != 0) return -1;
-	if (c->asm_ready && lam_sym) { // relative-pose SE2: fused, Jacobian blocks never leave the chip (srba_assemble.hpp): one launch, a workgroup per bin of capsules; what does not fit a bin takes the unfused kernel
-		if (c->asm_bins > 0 && srbadev::asm_launch(c->dp.noise != SRBA_NOISE_CONSTANT_MATRIX ? 0 : (c->dp.lambda[1] == 0 && c->dp.lambda[2] == 0 && c->dp.lambda[5] == 0 && c->dp.lambda[3] == 0 && c->dp.lambda[6] == 0 && c->dp.lambda[7] == 0) ? 1 : 2, c->asm_bins, srbadev::ASM_BIN_BYTES, c->stream, c->B, c->dp, c->asm_tab) != 0) { c->fail("k_assemble_se2rel: launch failed"); return -1; }
-		if (c->asm_rest > 0) { with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::k_linearize<decltype(fam_)::value>), dim3(c->asm_rest), dim3(SRBA_WG), (size_t)lds_doubles * 8, c->stream, c->B, c->dp, lds_doubles, c->asm_list); }); HIPCHK(c, hipGetLastError()); }
+	if (c->asm_ready && lam_sym) { // relative-pose SE2: fused, Jacobian blocks never leave the chip (srba_assemble.hpp): one launch, a workgroup per bin of capsules;
+		// what does not fit a bin takes the unfused kernel
+		if (c->asm_bins > 0 && srbadev::asm_launch(c->dp.noise != SRBA_NOISE_CONSTANT_MATRIX ? 0 : (c->dp.lambda[1] == 0 && c->dp.lambda[2] == 0 && c->dp.lambda[5] == 0 && c->dp.lambda[3] == 0 &&
+			c->dp.lambda[6] == 0 && c->dp.lambda[7] == 0) ? 1 : 2, c->asm_bins, srbadev::ASM_BIN_BYTES, c->stream, c->B, c->dp, c->asm_tab) != 0) { c->fail("k_assemble_se2rel: launch failed");
+			return -1; }
+		if (c->asm_rest > 0) { with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::k_linearize<decltype(fam_)::value>), dim3(c->asm_rest), dim3(SRBA_WG),
+			(size_t)lds_doubles * 8, c->stream, c->B, c->dp, lds_doubles, c->asm_list); }); HIPCHK(c, hipGetLastError()); }
 		c->jp_stale = c->asm_bins > 0; return 0;
 	}
 	SRBA_DISPATCH(c, k_linearize, (size_t)lds_doubles * 8, lds_doubles, (const int *)nullptr); HIPCHK(c, hipGetLastError()); c->jp_stale = false; return 0;
@@ -2326,16 +2550,21 @@ int srba_hip_solve(srba_hip_ctx *c, const double *lambda, int32_t *not_pd_out) {
 	if (!c || !c->n_prob) return -1; HIPCHK(c, hipSetDevice(c->device));
 	if (lambda) HIPCHK(c, hipMemcpyAsync(c->B.lambda_io, lambda, 8 * (size_t)c->n_prob, hipMemcpyHostToDevice, c->stream)); // else: use the lambda guess left by srba_hip_linearize
 	if (prep_lds(c, false) != 0) return -1;
-	for (int k = 0; k < SRBA_NLDS; k++) if (c->cls_count[k]) { hipStream_t launch_stream = c->stream; SRBA_DISPATCH_LDS(c, k_solve, c->cls_count[k], c->cls_lds[k], c->cls_first[k]); HIPCHK(c, hipGetLastError()); }
+	for (int k = 0; k < SRBA_NLDS; k++) if (c->cls_count[k]) { hipStream_t launch_stream = c->stream; SRBA_DISPATCH_LDS(c, k_solve, c->cls_count[k], c->cls_lds[k], c->cls_first[k]); HIPCHK(c,
+		hipGetLastError()); }
 	for (int k = SRBA_NLDS; k < SRBA_NCLS - 1; k++) if (c->cls_count[k]) { // landmark windows on a workgroup
 		with_family(c->params.family, [&](auto fam_) { constexpr int F = decltype(fam_)::value; if constexpr (srbadev::Tr<F>::SE3 && !srbadev::Tr<F>::REL) {
-			if (k == SRBA_CLS_WG512) { if (allow_big_lds(c, srbadev::k_solve_wg<F, 512>, c->cls_lds[k]) == 0) hipLaunchKernelGGL((srbadev::k_solve_wg<F, 512>), dim3(c->cls_count[k]), dim3(512), c->cls_lds[k], c->stream, c->B, c->dp, c->cls_first[k]); }
-			else if (k == SRBA_CLS_WG256) { if (allow_big_lds(c, srbadev::k_solve_wg<F, 256>, c->cls_lds[k]) == 0) hipLaunchKernelGGL((srbadev::k_solve_wg<F, 256>), dim3(c->cls_count[k]), dim3(256), c->cls_lds[k], c->stream, c->B, c->dp, c->cls_first[k]); }
+			if (k == SRBA_CLS_WG512) { if (allow_big_lds(c, srbadev::k_solve_wg<F, SRBA_WG_TOP>, c->cls_lds[k]) == 0) hipLaunchKernelGGL((srbadev::k_solve_wg<F, SRBA_WG_TOP>), dim3(c->cls_count[k]),
+				dim3(SRBA_WG_TOP), c->cls_lds[k], c->stream, c->B, c->dp, c->cls_first[k]); }
+			else if (k == SRBA_CLS_WG256) { if (allow_big_lds(c, srbadev::k_solve_wg<F, 256>, c->cls_lds[k]) == 0) hipLaunchKernelGGL((srbadev::k_solve_wg<F, 256>), dim3(c->cls_count[k]), dim3(256),
+				c->cls_lds[k], c->stream, c->B, c->dp, c->cls_first[k]); }
 			else hipLaunchKernelGGL((srbadev::k_solve_wg<F, 128>), dim3(c->cls_count[k]), dim3(128), c->cls_lds[k], c->stream, c->B, c->dp, c->cls_first[k]); } });
 		HIPCHK(c, hipGetLastError()); }
 	{ const int32_t *ord = (const int32_t *)(c->h_in.get() + c->h_off_order); // dense multi-workgroup solver for the capsules of the big class
-	  for (int i = 0; i < c->cls_count[SRBA_NCLS - 1]; i++) { const int p = ord[c->cls_first[SRBA_NCLS - 1] + i]; double lam = 0; HIPCHK(c, hipMemcpyAsync(&lam, c->B.lambda_io + p, 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
-		bool pd = true; if (big_prepare_lanes(c, 1) < 1) return -1; if (big_solve(c, &c->lanes[0], p, lam, &pd) != 0) { c->fail(c->lanes[0].error); return -1; } big_collect_lane_stats(c); const int np = pd ? 0 : 1; HIPCHK(c, hipMemcpyAsync(c->B.notpd + p, &np, 4, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); } }
+	  for (int i = 0; i < c->cls_count[SRBA_NCLS - 1]; i++) { const int p = ord[c->cls_first[SRBA_NCLS - 1] + i]; double lam = 0; HIPCHK(c, hipMemcpyAsync(&lam, c->B.lambda_io + p, 8,
+	  	hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+		bool pd = true; if (big_prepare_lanes(c, 1) < 1) return -1; if (big_solve(c, &c->lanes[0], p, lam, &pd) != 0) { c->fail(c->lanes[0].error); return -1; } big_collect_lane_stats(c);
+			const int np = pd ? 0 : 1; HIPCHK(c, hipMemcpyAsync(c->B.notpd + p, &np, 4, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); } }
 	if (not_pd_out) { HIPCHK(c, hipMemcpyAsync(not_pd_out, c->B.notpd, 4 * (size_t)c->n_prob, hipMemcpyDeviceToHost, c->stream)); }
 	HIPCHK(c, hipStreamSynchronize(c->stream)); return 0;
 }
@@ -2343,7 +2572,8 @@ int srba_hip_hessian_from_jacobians(srba_hip_ctx *c) { if (!c || !c->n_prob) ret
 	if (c->jp_stale) { SRBA_DISPATCH(c, k_jacobians_only, 0); HIPCHK(c, hipGetLastError()); c->jp_stale = false; } // the blocks of a fused srba_hip_linearize were never written: do it now
 	SRBA_DISPATCH(c, k_hessian_only, 0); HIPCHK(c, hipGetLastError()); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
 int srba_hip_debug_write(srba_hip_ctx *c, int what, const double *in, int64_t n_doubles) {
-	if (!c || !in || !(what == 1 || what == 2 || what == 6) || n_doubles != c->len_dbg[what]) { if (c) c->fail("debug_write: only the Jacobian blocks (1, 2) and the minus-gradient (6) can be written, with their exact sizes"); return -1; }
+	if (!c || !in || !(what == 1 || what == 2 || what == 6) || n_doubles != c->len_dbg[what]) {
+		if (c) c->fail("debug_write: only the Jacobian blocks (1, 2) and the minus-gradient (6) can be written, with their exact sizes"); return -1; }
 	HIPCHK(c, hipSetDevice(c->device));
 	HIPCHK(c, hipMemcpyAsync(c->d_wk + c->off_dbg[what], in, 8 * (size_t)n_doubles, hipMemcpyHostToDevice, c->stream));
 	if (what == 1) c->jp_stale = false; // the caller's blocks are the current ones
@@ -2357,9 +2587,11 @@ int srba_hip_download_state(srba_hip_ctx *c, srba_problem_capsule *caps, int n) 
 	if (!c || !caps || n != c->n_prob) { if (c) c->fail("download_state: capsule count differs from the uploaded batch"); return -1; }
 	HIPCHK(c, hipSetDevice(c->device));
 	const int L = c->dm.L, PD = c->dm.PD, PDX = c->dm.PDX();
-	std::vector<double> edge((size_t)c->tot_edge * PDX), ulm((size_t)c->tot_ulm * L), inf((size_t)c->tot_ulm * L * L), pose((size_t)2 * c->stats.n_pairs * PDX); std::vector<uint8_t> infv((size_t)c->tot_ulm);
+	std::vector<double> edge((size_t)c->tot_edge * PDX), ulm((size_t)c->tot_ulm * L), inf((size_t)c->tot_ulm * L * L), pose((size_t)2 * c->stats.n_pairs * PDX);
+		std::vector<uint8_t> infv((size_t)c->tot_ulm);
 	HIPCHK(c, hipMemcpyAsync(edge.data(), c->d_wk + c->off_edge, 8 * edge.size(), hipMemcpyDeviceToHost, c->stream));
-	if (!ulm.empty()) { HIPCHK(c, hipMemcpyAsync(ulm.data(), c->d_wk + c->off_ulm, 8 * ulm.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipMemcpyAsync(inf.data(), c->d_wk + c->off_inf, 8 * inf.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipMemcpyAsync(infv.data(), c->d_wk + c->off_infv, infv.size(), hipMemcpyDeviceToHost, c->stream)); }
+	if (!ulm.empty()) { HIPCHK(c, hipMemcpyAsync(ulm.data(), c->d_wk + c->off_ulm, 8 * ulm.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipMemcpyAsync(inf.data(), c->d_wk + c->off_inf,
+		8 * inf.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipMemcpyAsync(infv.data(), c->d_wk + c->off_infv, infv.size(), hipMemcpyDeviceToHost, c->stream)); }
 	if (!pose.empty()) HIPCHK(c, hipMemcpyAsync(pose.data(), c->d_wk + c->off_pose, 8 * pose.size(), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	for (int p = 0; p < n; p++) {
@@ -2379,7 +2611,8 @@ int srba_hip_download_state(srba_hip_ctx *c, srba_problem_capsule *caps, int n) 
 // page-locked memory without a wait, the [result record | unknowns | spanning-tree poses] head of the work arena comes back in one copy queued behind the kernel.
 int srba_hip_optimize_capsule(srba_hip_ctx *c, srba_problem_capsule *cap, srba_lm_result *res) {
 	if (!c || !cap || !res) { if (c) c->fail("optimize_capsule: bad arguments"); return -1; }
-	static const bool host_timing = getenv("SRBA_HIP_HOST_TIMING") != nullptr; static double acc[5] = {0, 0, 0, 0, 0}; static long long calls = 0; // (diagnostic: where the host side of a call goes; printed every 1000 calls)
+	static const bool host_timing = getenv("SRBA_HIP_HOST_TIMING") != nullptr; static double acc[5] = {0, 0, 0, 0, 0}; static long long calls = 0; // (diagnostic: where the host side of a call goes;
+		// printed every 1000 calls)
 	auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }; const double t0 = host_timing ? now() : 0;
 	c->defer_upload_sync = true; const int rc_up = srba_hip_upload_problems(c, cap, 1); c->defer_upload_sync = false; const double t1 = host_timing ? now() : 0;
 	if (rc_up != 0) return rc_up;
@@ -2389,12 +2622,15 @@ int srba_hip_optimize_capsule(srba_hip_ctx *c, srba_problem_capsule *cap, srba_l
 	const int PD = c->dm.PD, PDX = c->dm.PDX(); const ProbDesc &d = c->desc[0];
 	const size_t span = c->off_pose + 8 * (size_t)2 * d.n_pairs * PDX - c->off_res; // [result record | unknowns | spanning-tree poses]: the head of the work arena
 	if (c->off_res > c->off_edge || c->off_edge > c->off_pose) { c->fail("optimize_capsule: unexpected work arena layout"); return -1; }
-	if (c->h_out_cap < span) { if (c->h_out) hipHostFree(c->h_out); c->h_out = nullptr; c->h_out_cap = 0; HIPCHK(c, hipHostMalloc((void **)&c->h_out, 2 * span, hipHostMallocDefault)); c->h_out_cap = 2 * span; }
+	if (c->h_out_cap < span) { if (c->h_out) hipHostFree(c->h_out); c->h_out = nullptr; c->h_out_cap = 0; HIPCHK(c, hipHostMalloc((void **)&c->h_out, 2 * span, hipHostMallocDefault));
+		c->h_out_cap = 2 * span; }
 	HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_wk + c->off_res, span, hipMemcpyDeviceToHost, c->stream));
 	const double t2 = host_timing ? now() : 0;
 	HIPCHK(c, hipStreamSynchronize(c->stream)); c->h2d_pending = false; const double t3 = host_timing ? now() : 0;
 	float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_ms = ms;
-	if (host_timing) { acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; acc[3] += 1e3 * ms; if (++calls % 1000 == 0) { std::fprintf(stderr, "[optimize_capsule] per call: upload (host) %.1f us, launch + copies queued %.1f us, wait %.1f us (kernel %.1f us)\n", acc[0] / 1000, acc[1] / 1000, acc[2] / 1000, acc[3] / 1000); acc[0] = acc[1] = acc[2] = acc[3] = 0; } }
+	if (host_timing) { acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; acc[3] += 1e3 * ms; if (++calls % 1000 == 0) { std::fprintf(stderr,
+		"[optimize_capsule] per call: upload (host) %.1f us, launch + copies queued %.1f us, wait %.1f us (kernel %.1f us)\n", acc[0] / 1000, acc[1] / 1000, acc[2] / 1000, acc[3] / 1000);
+		acc[0] = acc[1] = acc[2] = acc[3] = 0; } }
 	std::memcpy(res, c->h_out, sizeof(srba_lm_result));
 	if (c->spec_ready && res->status == 2) { // the speculative run gave up: once more on the sequential path, read back the same span
 		if (spec_fallback(c) != 0) return -1;
@@ -2409,28 +2645,33 @@ int srba_hip_optimize_capsule(srba_hip_ctx *c, srba_problem_capsule *cap, srba_l
 }
 
 int srba_hip_set_phase_timing(srba_hip_ctx *c, int on) { if (!c) return -1; c->phase_timing = on != 0; return 0; } // takes effect at the next upload (the counters are part of the work arena layout)
-int64_t srba_hip_debug_size(srba_hip_ctx *c, int what) { if (c && what == 10) return c->phase_timing ? 16 * (int64_t)c->n_prob : 0; if (c && what == 11) return 4 * (int64_t)c->n_prob; return (c && what >= 0 && what < 10) ? c->len_dbg[what] : -1; }
+int64_t srba_hip_debug_size(srba_hip_ctx *c, int what) { if (c && what == 10) return c->phase_timing ? 16 * (int64_t)c->n_prob : 0; if (c && what == 11) return 4 * (int64_t)c->n_prob;
+	return (c && what >= 0 && what < 10) ? c->len_dbg[what] : -1; }
 int srba_hip_debug_read(srba_hip_ctx *c, int what, double *out, int64_t n_doubles) {
 	if (c && what == 11) { // per-capsule solver shape: [LDS bytes reserved by its launch, nb, off-diagonal blocks, block updates per factorisation]
 		if (n_doubles < 4 * (int64_t)c->n_prob) return -1;
-		for (int p = 0; p < c->n_prob; p++) { const ProbDesc &d = c->desc[p]; out[4 * p] = (double)c->cls_lds[c->cls_of[p]]; out[4 * p + 1] = d.nb; out[4 * p + 2] = d.nnzoff; out[4 * p + 3] = d.n_items; }
+		for (int p = 0; p < c->n_prob; p++) { const ProbDesc &d = c->desc[p]; out[4 * p] = (double)c->cls_lds[c->cls_of[p]]; out[4 * p + 1] = d.nb; out[4 * p + 2] = d.nnzoff;
+			out[4 * p + 3] = d.n_items; }
 		return 0;
 	}
 	if (c && what == 10) { // per-capsule phase cycle counters (100 MHz wall clock ticks), as doubles
 		if (!c->phase_timing) return -1;
-		std::vector<long long> v(16 * (size_t)c->n_prob); HIPCHK(c, hipMemcpyAsync(v.data(), c->d_wk + c->off_phase, 8 * v.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+		std::vector<long long> v(16 * (size_t)c->n_prob); HIPCHK(c, hipMemcpyAsync(v.data(), c->d_wk + c->off_phase, 8 * v.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c,
+			hipStreamSynchronize(c->stream));
 		for (size_t i = 0; i < v.size() && (int64_t)i < n_doubles; i++) out[i] = (double)v[i]; return 0;
 	}
 	if (!c || what < 0 || what >= 10 || n_doubles < c->len_dbg[what]) return -1;
 	HIPCHK(c, hipSetDevice(c->device));
-	if (what == 1 && c->jp_stale) { SRBA_DISPATCH(c, k_jacobians_only, 0); HIPCHK(c, hipGetLastError()); c->jp_stale = false; } // the fused linearisation keeps the Jacobian blocks on the chip: materialise them for the reader
+	if (what == 1 && c->jp_stale) { SRBA_DISPATCH(c, k_jacobians_only, 0); HIPCHK(c, hipGetLastError()); c->jp_stale = false; } // the fused linearisation keeps the Jacobian blocks on the chip:
+		// materialise them for the reader
 	if (what == 9 && c->dm.PDX() != c->dm.PD) { // ST poses: strip the cached cos/sin of the device layout
 		const int PD = c->dm.PD, PDX = c->dm.PDX(); std::vector<double> v((size_t)c->n_pose_total * PDX);
 		HIPCHK(c, hipMemcpyAsync(v.data(), c->d_wk + c->off_dbg[9], 8 * v.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
 		for (long long q = 0; q < c->n_pose_total; q++) for (int k = 0; k < PD; k++) out[q * PD + k] = v[(size_t)q * PDX + k];
 		return 0;
 	}
-	if (what == 8) { std::vector<int> v((size_t)c->len_dbg[8]); HIPCHK(c, hipMemcpyAsync(v.data(), c->d_wk + c->off_dbg[8], 4 * v.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); for (size_t i = 0; i < v.size(); i++) out[i] = v[i]; return 0; }
+	if (what == 8) { std::vector<int> v((size_t)c->len_dbg[8]); HIPCHK(c, hipMemcpyAsync(v.data(), c->d_wk + c->off_dbg[8], 4 * v.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c,
+		hipStreamSynchronize(c->stream)); for (size_t i = 0; i < v.size(); i++) out[i] = v[i]; return 0; }
 	HIPCHK(c, hipMemcpyAsync(out, c->d_wk + c->off_dbg[what], 8 * (size_t)c->len_dbg[what], hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream)); return 0;
 }

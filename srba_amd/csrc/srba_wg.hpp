@@ -27,18 +27,21 @@ typedef double f64x4w __attribute__((ext_vector_type(4)));
 typedef double f64x2w __attribute__((ext_vector_type(2), aligned(16)));
 constexpr int WT = 16;                             // tile edge = the shape of v_mfma_f64_16x16x4_f64
 constexpr int WG_NT_MAX = 32;                      // tile rows of the largest system this path takes: n <= 512 scalars
-constexpr int WG_LDS_DOUBLES = 256 + 512 + 16 * WG_NT_MAX + 12; // diagonal tile staging | two inverse factors (double-buffered) | y / x | group-reduction scratch (8) | flag, work-counter slot
-constexpr int WG_RED = 768 + 16 * WG_NT_MAX;        // offset of the reduction scratch; the solver's flag is the int at double WG_RED + 8, the kernels' work-counter slot at WG_RED + 9
+constexpr int WG_LDS_DOUBLES = 256 + 512 + 16 * WG_NT_MAX + 16; // diagonal tile staging | two inverse factors (double-buffered) | y / x | group-reduction scratch (12) | flag, work-counter slot
+constexpr int WG_RED = 768 + 16 * WG_NT_MAX;        // offset of the reduction scratch; the solver's flag is the int at double WG_RED + 12, the kernels' work-counter slot at WG_RED + 13
 constexpr int WG_GACC = 0;                          // U_Ap-in-LDS path: accumulators of the Schur gradient correction (one per scalar of the reduced system, <= 16 WG_NT_MAX = 512): they share the
                                                     // staging area of the factorisation (768 doubles; the correction is added to the gradient before the system is assembled) ...
 constexpr int WG_HS = WG_LDS_DOUBLES;               // ... and the U_Ap blocks themselves, n_hap x (P x P + 1) doubles from here
 __host__ __device__ inline int wg_tile(int i, int j) { return i * (i + 1) / 2 + j; } // tile (i, j), j <= i; tile row nt = the right-hand side
-__host__ __device__ inline long long wg_ws_doubles(int nt) { return 256LL * ((long long)(nt + 1) * (nt + 2) / 2 + nt + 4); } // tiles of rows 0 .. nt | nt inverse diagonal factors | 2 x 2 look-ahead partial sums
+__host__ __device__ inline long long wg_ws_doubles(int nt) { return 256LL * ((long long)(nt + 1) * (nt + 2) / 2 + nt + 4); } // tiles of rows 0 .. nt | nt inverse diagonal factors | 2 x 2 look-ahead
+	// partial sums
 // offset of element (r, c) inside a frag tile
 __host__ __device__ inline int wg_frag_off(int r, int c) { return ((r + 16 * (c & 3)) << 2) + (c >> 2); }
 
-__device__ __forceinline__ f64x4w wg_ld(const double *tile, int l) { const f64x2w a = *(const f64x2w *)(tile + 4 * l), b = *(const f64x2w *)(tile + 4 * l + 2); f64x4w v; v.x = a.x; v.y = a.y; v.z = b.x; v.w = b.y; return v; }
-__device__ __forceinline__ void wg_st(double *tile, int l, const f64x4w &v) { f64x2w a, b; a.x = v.x; a.y = v.y; b.x = v.z; b.y = v.w; *(f64x2w *)(tile + 4 * l) = a; *(f64x2w *)(tile + 4 * l + 2) = b; }
+__device__ __forceinline__ f64x4w wg_ld(const double *tile, int l) { const f64x2w a = *(const f64x2w *)(tile + 4 * l), b = *(const f64x2w *)(tile + 4 * l + 2); f64x4w v; v.x = a.x; v.y = a.y;
+	v.z = b.x; v.w = b.y; return v; }
+__device__ __forceinline__ void wg_st(double *tile, int l, const f64x4w &v) { f64x2w a, b; a.x = v.x; a.y = v.y; b.x = v.z; b.y = v.w; *(f64x2w *)(tile + 4 * l) = a;
+	*(f64x2w *)(tile + 4 * l + 2) = b; }
 // acc += M1 M2^t for two frag tiles (four matrix instructions, K = 16)
 __device__ __forceinline__ f64x4w wg_mma(const f64x4w &m1, const f64x4w &m2, f64x4w acc) {
 	acc = __builtin_amdgcn_mfma_f64_16x16x4f64(m1.x, m2.x, acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f64_16x16x4f64(m1.y, m2.y, acc, 0, 0, 0);
@@ -73,7 +76,8 @@ __device__ __forceinline__ bool wg_diag(const f64x4w &c, lds_f64 *smC, lds_f64 *
 		const double lj = (row == j) ? dj * r : ((row > j) ? a[j] * r : 0.0), lbelow = (row > j) ? lj : 0.0;
 		a[j] = lj; rrow = (row == j) ? r : rrow;
 #pragma unroll
-		for (int q = j + 1; q < 16; q++) { const double lq = wg_bcast(lj, q); a[q] = fma(-lj, lq, a[q]); asm volatile("" : "+v"(a[q])); /* (pinned where its broadcast is: no pile of spilled v_readlane pairs, cf. chol_block_regs) */ }
+		for (int q = j + 1; q < 16; q++) { const double lq = wg_bcast(lj, q); a[q] = fma(-lj, lq, a[q]); asm volatile("" : "+v"(a[q]));
+			/* (pinned where its broadcast is: no pile of spilled v_readlane pairs, cf. chol_block_regs) */ }
 #pragma unroll
 		for (int q = 0; q <= j; q++) {
 			const double xb = wg_bcast(x[q] * r, j);   // X[j][q] (r = 1 / L[j][j], the same in every lane)
@@ -100,7 +104,7 @@ template <int NW>
 __device__ __forceinline__ bool wg_chol_solve(double *T, double *LI, const int nt, lds_f64 *sm) {
 	static_assert(NW >= 2, "wavefront 0 runs the diagonal chain beside the panel wavefronts");
 	const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-	lds_f64 *smC = sm, *smL = sm + 256, *yb = sm + 768; int __attribute__((address_space(3))) *flag = (int __attribute__((address_space(3))) *)(sm + WG_RED + 8);
+	lds_f64 *smC = sm, *smL = sm + 256, *yb = sm + 768; int __attribute__((address_space(3))) *flag = (int __attribute__((address_space(3))) *)(sm + WG_RED + 12);
 	if (threadIdx.x == 0) *flag = 0;
 	__syncthreads();
 	if (w == 0) { const f64x4w c = wg_ld(T + 256 * (size_t)wg_tile(0, 0), l); if (!wg_diag(c, smC, smL, LI, l) && l == 0) *flag = 1; }

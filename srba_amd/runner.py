@@ -113,7 +113,8 @@ class Engine(object):
         """RbaEngine<>::get_global_graphslam_problem(): (node ids, node poses [n, PD], edge (from, to) [m, 2], edge poses [m, PD])"""
         n_kf = int(max(self.edges()[0].max(), self.edges()[1].max())) + 1 if self.lib.srba_engine_num_edges(self.h) else 1; m = self.lib.srba_engine_num_edges(self.h)
         ids = np.zeros(n_kf, np.uint64); poses = np.zeros((n_kf, self.PD)); ft = np.zeros((max(m, 1), 2), np.uint64); ep = np.zeros((max(m, 1), self.PD))
-        n = self.lib.srba_engine_export_graphslam(self.h, root, ids.ctypes.data_as(C.POINTER(C.c_uint64)), poses.ctypes.data_as(capi.PF64), n_kf, ft.ctypes.data_as(C.POINTER(C.c_uint64)), ep.ctypes.data_as(capi.PF64), m)
+        n = self.lib.srba_engine_export_graphslam(self.h, root, ids.ctypes.data_as(C.POINTER(C.c_uint64)), poses.ctypes.data_as(capi.PF64), n_kf, ft.ctypes.data_as(C.POINTER(C.c_uint64)),
+                ep.ctypes.data_as(capi.PF64), m)
         return ids[:n], poses[:n], ft[:m], ep[:m]
 
     def eval_overall_squared_error(self):

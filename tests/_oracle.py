@@ -44,7 +44,8 @@ def _proto(l):
     l.srba_oracle_lm_run.argtypes = [C.POINTER(capi.HipParams), capi.PCAP, capi.c_i32, C.POINTER(capi.LmResult), capi.c_i32]
     l.srba_oracle_run_one.argtypes = [C.POINTER(capi.HipParams), capi.PCAP, C.POINTER(capi.LmResult)]
     l.srba_oracle_take_symbolic_seconds.restype = capi.c_f64
-    l.srba_oracle_lm_run_replay.argtypes = [C.POINTER(capi.HipParams), capi.PCAP, capi.c_i32, capi.PI32, capi.PI32, capi.c_i32, capi.PF64, capi.PF64, capi.PF64, capi.PI32, capi.PI32, C.POINTER(capi.LmResult), capi.c_i32]
+    l.srba_oracle_lm_run_replay.argtypes = [C.POINTER(capi.HipParams), capi.PCAP, capi.c_i32, capi.PI32, capi.PI32, capi.c_i32, capi.PF64, capi.PF64, capi.PF64, capi.PI32, capi.PI32,
+            C.POINTER(capi.LmResult), capi.c_i32]
     l.srba_oracle_schur_from_jacobians.argtypes = [C.POINTER(capi.HipParams), capi.PCAP, capi.PF64, capi.PF64, capi.PF64, capi.c_f64] + [capi.PF64] * 4
     l.srba_oracle_stage.argtypes = [C.POINTER(capi.HipParams), capi.PCAP, capi.c_i32, capi.c_f64] + [capi.PF64] * 10
 
@@ -92,7 +93,8 @@ def run_batch_replay(batch, other, threads=1):
     dec, k = decisions_of(other)
     own_rho = np.full((n, T), np.nan); own_chi2 = np.full((n, T), np.nan); own_E = np.full((n, T), np.nan); flags = np.zeros((n, T), np.int32); div = np.full(n, -1, np.int32)
     res = (capi.LmResult * n)()
-    rc = ora.srba_oracle_lm_run_replay(C.byref(batch.params), work.ptr, n, dec.ctypes.data_as(capi.PI32), k.ctypes.data_as(capi.PI32), T, own_rho.ctypes.data_as(capi.PF64), own_chi2.ctypes.data_as(capi.PF64),
+    rc = ora.srba_oracle_lm_run_replay(C.byref(batch.params), work.ptr, n, dec.ctypes.data_as(capi.PI32), k.ctypes.data_as(capi.PI32), T, own_rho.ctypes.data_as(capi.PF64),
+            own_chi2.ctypes.data_as(capi.PF64),
                                        own_E.ctypes.data_as(capi.PF64), flags.ctypes.data_as(capi.PI32), div.ctypes.data_as(capi.PI32), res, threads)
     if rc != 0:
         raise RuntimeError("oracle replay failed")
@@ -125,7 +127,8 @@ def replay_report(gpu, rep, tol_trace=1e-9, tol_floor=1e-9):
     floor_move = np.where(dis, np.maximum(move_o, move_g), 0.0); floor_move[np.isnan(floor_move)] = np.inf
     worst_floor = floor_move.max(axis=1)
     fin = np.abs(rep["chi2_final"] - gpu["chi2_final"]); final_rel = np.where(fin < 1e-20, 0.0, fin / np.maximum(np.abs(rep["chi2_final"]), 1e-300))
-    return dict(worst_trace=worst_trace, worst_floor=worst_floor, floor_move=floor_move, final_rel=final_rel, complete=rep["complete"], diverged_at=rep["diverged_at"], n_disagree=dis.sum(axis=1), forced_notpd=((rep["flags"] & 4) != 0).sum(axis=1),
+    return dict(worst_trace=worst_trace, worst_floor=worst_floor, floor_move=floor_move, final_rel=final_rel, complete=rep["complete"], diverged_at=rep["diverged_at"], n_disagree=dis.sum(axis=1),
+            forced_notpd=((rep["flags"] & 4) != 0).sum(axis=1),
                 trace_ok=worst_trace <= tol_trace, floor_ok=worst_floor <= tol_floor)
 
 

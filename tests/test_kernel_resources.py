@@ -26,7 +26,8 @@ def kernel_resources(tmp_path):
         subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True)
         notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
         for blk in notes.split("- .agpr_count:")[1:]:
-            name = re.search(r"\.name:\s+(\S+)", blk); v = re.search(r"\.vgpr_count:\s+(\d+)", blk); sc = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk); ss = re.search(r"\.sgpr_spill_count:\s+(\d+)", blk)
+            name = re.search(r"\.name:\s+(\S+)", blk); v = re.search(r"\.vgpr_count:\s+(\d+)", blk); sc = re.search(r"\.private_segment_fixed_size:\s+(\d+)",
+                    blk); ss = re.search(r"\.sgpr_spill_count:\s+(\d+)", blk)
             if name and v and sc:
                 out[name.group(1)] = (int(v.group(1)), int(sc.group(1))); SGPR_SPILLS[name.group(1)] = int(ss.group(1)) if ss else 0
     return out
@@ -116,6 +117,7 @@ def test_no_index_is_widened_with_a_stale_high_half_in_the_lm_kernels():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import scan_undef_hi
     dis = scan_undef_hi.disassemble(os.path.join(ROOT, "srba_amd", "lib", "srba_hip.o"))
-    f_lm, k_lm = scan_undef_hi.scan(dis, "k_lm_runILi"); f_kb, k_kb = scan_undef_hi.scan(dis, "kb_"); f_r4, k_r4 = scan_undef_hi.scan(dis, "k_lm_run_lean"); f_2, k_2 = scan_undef_hi.scan(dis, "k_lm_run2"); f_sp, k_sp = scan_undef_hi.scan(dis, "k_lm_spec")
+    f_lm, k_lm = scan_undef_hi.scan(dis, "k_lm_runILi"); f_kb, k_kb = scan_undef_hi.scan(dis, "kb_"); f_r4, k_r4 = scan_undef_hi.scan(dis, "k_lm_run_lean"); f_2, k_2 = scan_undef_hi.scan(dis,
+            "k_lm_run2"); f_sp, k_sp = scan_undef_hi.scan(dis, "k_lm_spec")
     assert len(k_lm) == 9 and len(k_kb) >= 100 and len(k_r4) == 1 and len(k_2) == 1 and len(k_sp) == 1, (len(k_lm), len(k_kb), len(k_r4), len(k_2), len(k_sp))
     assert not f_lm and not f_kb and not f_r4 and not f_2 and not f_sp, (f_lm + f_kb + f_r4 + f_2 + f_sp)[:4]

@@ -22,7 +22,8 @@ needs_reference = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "exampl
 
 
 def syntax_check(src):
-    p = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-w", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "include", "mrpt_shims"), src], capture_output=True, text=True, timeout=600)
+    p = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-w", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "include", "mrpt_shims"), src], capture_output=True, text=True,
+            timeout=600)
     return src, p.returncode, "\n".join(l for l in p.stderr.splitlines() if "error" in l)[:2000]
 
 

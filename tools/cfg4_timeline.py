@@ -22,7 +22,8 @@ for i, (s, e, n) in enumerate(rows):
 span = rows[-1][1] - rows[0][0]
 print("window %.1f ms: %d kernels, device busy %.1f ms (%.0f %%), idle between kernels %.1f ms" % (span / 1e6, len(rows), busy / 1e6, 100.0 * busy / span, idle / 1e6))
 gaps.sort()
-if gaps: print("gaps: median %.1f us, p90 %.1f us, max %.1f us, over 20 us: %d (%.1f ms)" % (gaps[len(gaps) // 2] / 1e3, gaps[int(0.9 * len(gaps))] / 1e3, gaps[-1] / 1e3, sum(g > 20000 for g in gaps), sum(g for g in gaps if g > 20000) / 1e6))
+if gaps: print("gaps: median %.1f us, p90 %.1f us, max %.1f us, over 20 us: %d (%.1f ms)" % (gaps[len(gaps) // 2] / 1e3, gaps[int(0.9 * len(gaps))] / 1e3, gaps[-1] / 1e3, sum(g > 20000 for g in gaps),
+        sum(g for g in gaps if g > 20000) / 1e6))
 print("%-28s %8s %10s %9s %12s" % ("kernel", "calls", "total ms", "avg us", "idle after ms"))
 for n, (c, d, g) in sorted(per.items(), key=lambda kv: -kv[1][1] - kv[1][2]):
     print("%-28s %8d %10.2f %9.1f %12.2f" % (n[:28], c, d / 1e6, d / 1e3 / c, g / 1e6))

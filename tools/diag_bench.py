@@ -20,5 +20,7 @@ for lo, hi in ((0, 16), (16, 24), (24, 32), (32, 48), (48, 64), (64, 96), (96, 1
     if hi > 1e6: m = lds == 0
     if not m.any(): continue
     tr = gpu["num_trials"][m].sum(); tt = pc[m].sum(axis=0)
-    print("LDS (%3d,%3d] KB: %5d caps, nb %.0f nnzoff %.0f items %.0f, %6d trials (%.1f/cap); us/trial: total %.0f |" % (lo, min(hi, 999), m.sum(), shp[m, 1].mean(), shp[m, 2].mean(), shp[m, 3].mean(), tr, tr / m.sum(), tt[:9].sum() * 1e-2 / tr),
-          " ".join("%s %.1f" % (names[k], tt[k] * 1e-2 / tr) for k in (11, 12, 10, 7, 3, 2, 4, 6, 1, 0)), "| share of LDS*time %.0f%%" % (100 * (lds[m] * t_ms[m]).sum() / (lds * t_ms).sum()), "share of wave time %.0f%%" % (100 * t_ms[m].sum() / t_ms.sum()))
+    print("LDS (%3d,%3d] KB: %5d caps, nb %.0f nnzoff %.0f items %.0f, %6d trials (%.1f/cap); us/trial: total %.0f |" % (lo, min(hi, 999), m.sum(), shp[m, 1].mean(), shp[m, 2].mean(), shp[m,
+            3].mean(), tr, tr / m.sum(), tt[:9].sum() * 1e-2 / tr),
+          " ".join("%s %.1f" % (names[k], tt[k] * 1e-2 / tr) for k in (11, 12, 10, 7, 3, 2, 4, 6, 1,
+                  0)), "| share of LDS*time %.0f%%" % (100 * (lds[m] * t_ms[m]).sum() / (lds * t_ms).sum()), "share of wave time %.0f%%" % (100 * t_ms[m].sum() / t_ms.sum()))

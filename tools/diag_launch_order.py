@@ -14,5 +14,7 @@ def one():
 one(); one()
 import hashlib; lib.srba_hip_reset_state(ctx.ctx); r = ctx.lm_run(); sig = hashlib.sha1(r["chi2_final"].tobytes() + r["num_trials"].tobytes() + r["trace_chi2"].tobytes()).hexdigest()[:12]
 v = np.array([one() for _ in range(24)])
-print("%-60s mean %.2f  median %.2f  min %.2f  max %.2f | fast (<40 ms): %d of %d | %s" % (" ".join("%s=%s" % (k, os.environ[k]) for k in ("SRBA_HIP_STAGGER_NS", "SRBA_HIP_DELAY_US", "SRBA_HIP_CLASS_PRIO", "SRBA_HIP_CLASS_STREAMS", "SRBA_HIP_SCHED", "SRBA_HIP_WAVES_PER_CU", "SRBA_HIP_LDS_PER_CU_KB", "SRBA_HIP_LEAN", "SRBA_HIP_TWO", "SRBA_HIP_TWO_FROM_KB") if k in os.environ) or "(defaults)",
+print("%-60s mean %.2f  median %.2f  min %.2f  max %.2f | fast (<40 ms): %d of %d | %s" % (" ".join("%s=%s" % (k, os.environ[k]) for k in ("SRBA_HIP_STAGGER_NS", "SRBA_HIP_DELAY_US",
+        "SRBA_HIP_CLASS_PRIO", "SRBA_HIP_CLASS_STREAMS", "SRBA_HIP_SCHED", "SRBA_HIP_WAVES_PER_CU", "SRBA_HIP_LDS_PER_CU_KB", "SRBA_HIP_LEAN", "SRBA_HIP_TWO",
+        "SRBA_HIP_TWO_FROM_KB") if k in os.environ) or "(defaults)",
       v.mean(), np.median(v), v.min(), v.max(), (v < 40).sum(), len(v), " ".join("%.1f" % x for x in v[:6]) + " | results " + sig + " trials %d" % r["num_trials"].sum()))

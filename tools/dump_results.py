@@ -21,7 +21,8 @@ else:
     eng = runner.landmark_engine(fam, backend=_oracle.BACKEND); eng.run(ds); b = eng.harvest(); b.engine = eng
 r = runner.run_batch_hip(b, download=True)
 P, L, O, PD = capi.DIMS[b.family]
-out = {k: r[k] for k in ("status", "num_iters", "num_trials", "num_not_pd", "num_accepted", "num_relinearized", "stop_reason", "chi2_init", "chi2_final", "obs_rmse", "lambda_final", "trace_chi2", "trace_lambda", "trace_rho")}
+out = {k: r[k] for k in ("status", "num_iters", "num_trials", "num_not_pd", "num_accepted", "num_relinearized", "stop_reason", "chi2_init", "chi2_final", "obs_rmse", "lambda_final", "trace_chi2",
+        "trace_lambda", "trace_rho")}
 out["edges"] = np.concatenate([r["state"].array(i, "edge_pose", np.float64, b[i].n_unk_edges * PD) for i in range(b.n)])
 out["poses"] = np.concatenate([r["state"].array(i, "pose", np.float64, 2 * b[i].n_pairs * PD) for i in range(b.n)])
 out["lms"] = np.concatenate([r["state"].array(i, "ulm_pos", np.float64, b[i].n_unk_lms * L) for i in range(b.n)] + [np.zeros(0)])

@@ -31,13 +31,15 @@ for st in settings:
     rel = np.abs(g - ro["chi2_final"]) / np.maximum(ro["chi2_final"], 1e-300)
     same = all(np.array_equal(r["chi2_final"][q * n0:(q + 1) * n0], g, equal_nan=True) for q in range(copies))
     print("[%s %s] kernel %.2f ms (%s) -> %.3f M LM it/s ; trials %d (oracle %d x %d) ; max rel chi2 diff vs oracle %.2e on %d converged windows (all %d: %.2e) ; status!=0: %d ; copies identical: %s" % (
-        kind, st, min(ms), " ".join("%.1f" % x for x in ms), r["num_trials"].sum() / min(ms) / 1e3, r["num_trials"].sum(), ro["num_trials"].sum(), copies, rel[sane].max() if sane.any() else float("nan"), sane.sum(), n0, rel.max(), int((r["status"] != 0).sum()), same), flush=True)
+        kind, st, min(ms), " ".join("%.1f" % x for x in ms), r["num_trials"].sum() / min(ms) / 1e3, r["num_trials"].sum(), ro["num_trials"].sum(), copies,
+                rel[sane].max() if sane.any() else float("nan"), sane.sum(), n0, rel.max(), int((r["status"] != 0).sum()), same), flush=True)
     if os.environ.get("SRBA_HIP_PHASE_TIMING") == "1":
         pc = ctx.debug(10).reshape(fb.n, 16); tr = r["num_trials"]
         for lo, hi in ((0, 20), (20, 32), (32, 40), (40, 70)):
             m = (nk >= lo) & (nk < hi)
             if not m.any(): continue
             t = pc[m].sum(axis=0) * 1e-2 / max(tr[m].sum(), 1)
-            print("   edges [%d,%d): %d caps, %.1f trials/cap, per trial us: total %.0f | " % (lo, hi, m.sum(), tr[m].mean(), t[:9].sum()) + " ".join("%s %.0f" % (names[k], t[k]) for k in (9, 14, 15, 10, 11, 12, 13, 7, 3, 2, 4, 6, 1, 0)), flush=True)
+            print("   edges [%d,%d): %d caps, %.1f trials/cap, per trial us: total %.0f | " % (lo, hi, m.sum(), tr[m].mean(), t[:9].sum()) + " ".join("%s %.0f" % (names[k], t[k]) for k in (9, 14, 15,
+                    10, 11, 12, 13, 7, 3, 2, 4, 6, 1, 0)), flush=True)
     ctx.close()
     for k in keys: os.environ.pop(k, None)

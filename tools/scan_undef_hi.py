@@ -4,14 +4,16 @@ holds whatever an earlier, unrelated instruction left there (clang 22 / ROCm 7.2
 that stood for its zero in kernels with AGPR spill traffic).
 
 Heuristic, linear in program order (branches ignored). A pair v[N:N+1] is STALE when vN was last written by a 32-bit load and v(N+1) was last written BEFORE that load by an
-instruction that is not a move of 0 (directly, through another register or through an accumulation register the zero was parked in) / the arithmetic shift that produces a sign word; staleness travels through v_mov_b64 (the compiler shuffles such pairs around, which by
+instruction that is not a move of 0 (directly,
+        through another register or through an accumulation register the zero was parked in) / the arithmetic shift that produces a sign word; staleness travels through v_mov_b64 (the compiler shuffles such pairs around, which by
 itself is harmless: it later writes the high half). A FINDING is a stale pair consumed as a 64-bit integer: the address operand of a global / flat memory instruction or an operand
 of v_lshl_add_u64 / v_lshlrev_b64 / v_mad_u64_u32 / v_mad_i64_i32. tests/test_kernel_resources.py runs it over every k_lm_run and kb_ kernel (round 4).
 usage: scan_undef_hi.py <libsrba_hip.so | object file> [kernel-name-substring]"""
 import os, re, subprocess, sys, tempfile
 LLVM = "/opt/rocm/lib/llvm/bin"
 _pair = re.compile(r"\bv\[(\d+):(\d+)\]")
-LOAD32 = ("global_load_dword ", "global_load_ubyte ", "global_load_sbyte ", "global_load_ushort ", "global_load_sshort ", "ds_read_b32 ", "ds_read_u8 ", "ds_read_u16 ", "flat_load_dword ", "scratch_load_dword ", "buffer_load_dword ")
+LOAD32 = ("global_load_dword ", "global_load_ubyte ", "global_load_sbyte ", "global_load_ushort ", "global_load_sshort ", "ds_read_b32 ", "ds_read_u8 ", "ds_read_u16 ", "flat_load_dword ",
+        "scratch_load_dword ", "buffer_load_dword ")
 CONSUME = ("v_lshl_add_u64", "v_lshlrev_b64", "v_mad_u64_u32", "v_mad_i64_i32")
 MEM = ("global_load", "global_store", "global_atomic", "flat_load", "flat_store", "flat_atomic")
 

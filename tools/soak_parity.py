@@ -41,13 +41,16 @@ for seed in range(first, first + n_seeds):
         worst["final"] = max(worst["final"], float(np.where(cm, R["final_rel"], 0).max())); worst["own_final"] = max(worst["own_final"], float(own_rel.max()))
         bad = sane & (~R["trace_ok"] | ~R["floor_ok"] | (R["complete"] & (R["final_rel"] > 1e-6)))
         if bad.any():   # beyond 1e-9: is it the window's own rounding amplification (observations moved by one ulp, same decisions)?
-            sens, _st = _oracle.rounding_sensitivity(sub, gpu); tolw = np.minimum(1e-4, np.maximum(1e-9, 50.0 * sens))   # capped: a window whose own arithmetic moves by more than 2e-6 per ulp is "not comparable", never a pass
+            sens, _st = _oracle.rounding_sensitivity(sub, gpu); tolw = np.minimum(1e-4, np.maximum(1e-9,
+                    50.0 * sens))   # capped: a window whose own arithmetic moves by more than 2e-6 per ulp is "not comparable", never a pass
             chaotic = bad & (sens > 2e-6); tot["not_comparable"] = tot.get("not_comparable", 0) + int(chaotic.sum())
-            for i in np.flatnonzero(bad): print("   %s solver %d seed %d window %d: trace %.2e floor %.2e final %.2e ; rounding sensitivity %.2e -> %s" % (kind, solver, seed, i, R["worst_trace"][i], R["worst_floor"][i], R["final_rel"][i], sens[i], "within 50x" if max(R["worst_trace"][i], R["worst_floor"][i]) <= tolw[i] else "BEYOND"))
+            for i in np.flatnonzero(bad): print("   %s solver %d seed %d window %d: trace %.2e floor %.2e final %.2e ; rounding sensitivity %.2e -> %s" % (kind, solver, seed, i, R["worst_trace"][i],
+                    R["worst_floor"][i], R["final_rel"][i], sens[i], "within 50x" if max(R["worst_trace"][i], R["worst_floor"][i]) <= tolw[i] else "BEYOND"))
             bad = bad & ((R["worst_trace"] > tolw) | (R["worst_floor"] > tolw) | (R["complete"] & (R["final_rel"] > np.maximum(tolw, 1e-6))))
         if not ok: fails.append((kind, solver, seed, -1, "status / finite mismatch between the GPU and the oracle"))
         if bad.any():
-            for i in np.flatnonzero(bad): fails.append((kind, solver, seed, int(i), "trace %.2e floor %.2e final %.2e complete %d trials %d cond-proxy rmse %.3g" % (R["worst_trace"][i], R["worst_floor"][i], R["final_rel"][i], R["complete"][i], gpu["num_trials"][i], gpu["obs_rmse"][i])))
+            for i in np.flatnonzero(bad): fails.append((kind, solver, seed, int(i), "trace %.2e floor %.2e final %.2e complete %d trials %d cond-proxy rmse %.3g" % (R["worst_trace"][i],
+                    R["worst_floor"][i], R["final_rel"][i], R["complete"][i], gpu["num_trials"][i], gpu["obs_rmse"][i])))
 print("totals", tot); print("worst", worst)
 print("failures (%d):" % len(fails))
 for f in fails: print("  ", f)

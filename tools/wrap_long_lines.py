@@ -63,12 +63,12 @@ def wrap_cpp_line(line, width, in_block):
     return out, out_block, False
 
 
-def wrap_py_line(line, width):
+def wrap_py_line(line, width, depth0=0):
     body = line.rstrip("\n")
     if len(body) <= width: return [line], False
     indent = body[: len(body) - len(body.lstrip())]; cont = indent + " " * 8
     # bracket depth and string state per character
-    depth = 0; quote = ""; cand = []; i = 0; n = len(body)
+    depth = depth0; quote = ""; cand = []; i = 0; n = len(body)   # depth0: bracket depth at the start of the line (a continuation line of a bracketed expression)
     while i < n:
         ch = body[i]
         if quote:
@@ -107,9 +107,18 @@ def main():
             for i, l in enumerate(lines):
                 if len(l.rstrip("\n")) > 240: print("%s:%d: %d characters" % (f, i + 1, len(l.rstrip("\n")))); bad += 1
             continue
-        out = []; in_block = False; py = f.endswith(".py")
+        out = []; in_block = False; py = f.endswith(".py"); depth_at = {}
+        if py:   # bracket depth at the start of every physical line
+            import io, tokenize
+            d = 0
+            try:
+                for t in tokenize.generate_tokens(io.StringIO("".join(lines)).readline):
+                    if t.type == tokenize.OP and t.string in "([{": d += 1
+                    elif t.type == tokenize.OP and t.string in ")]}": d -= 1
+                    elif t.type in (tokenize.NL, tokenize.NEWLINE): depth_at[t.end[0]] = d   # depth when line t.end[0] + 1 starts (0-based index t.end[0])
+            except tokenize.TokenError: pass
         for i, l in enumerate(lines):
-            if py: pieces, gave_up = wrap_py_line(l, width)
+            if py: pieces, gave_up = wrap_py_line(l, width, depth_at.get(i, 0))
             else: pieces, in_block, gave_up = wrap_cpp_line(l, width, in_block)
             if gave_up and len(l.rstrip("\n")) > 240: print("%s:%d: left as it is (%d characters)" % (f, i + 1, len(l.rstrip("\n"))))
             out.extend(pieces)
