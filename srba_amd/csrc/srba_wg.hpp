@@ -59,7 +59,8 @@ __device__ __forceinline__ double wg_rowsum16(double v) { v += dpp_shift0<0x111,
 __device__ __forceinline__ bool wg_diag(const f64x4w &c, lds_f64 *smC, lds_f64 *smL, double *LIk, int l) {
 	smC[4 * l] = c.x; smC[4 * l + 1] = c.y; smC[4 * l + 2] = c.z; smC[4 * l + 3] = c.w;
 	solver_sync();
-	const int row = l & 15; // lanes 16 .. 63 mirror lanes 0 .. 15 (their copies are never read)
+	int row = l & 15; // lanes 16 .. 63 mirror lanes 0 .. 15 (their copies are never read)
+	asm volatile("" : "+v"(row)); // opaque: the ~50 lane predicates below (row == j, row > j) were otherwise formed once at kernel entry and kept, spilled, across every phase (100 scalars)
 	double a[16], x[16];
 #pragma unroll
 	for (int q = 0; q < 16; q++) a[q] = smC[wg_frag_off(row, q)];
