@@ -773,6 +773,60 @@ template <int FAM> __global__ void __launch_bounds__(256) __attribute__((amdgpu_
 		if (threadIdx.x < P * P) B.HAp[(d.o_hap + b) * P * P + threadIdx.x] -= v;
 	}
 }
+// The same reduction with ONE WAVEFRONT per U_Ap block (round 5). A deep window of cfg4 has ~2 300 U_Ap blocks with 16 ... 440 terms (mean 156: tools/diag_cfg4_schur_hist.py). The
+// workgroup-per-block form above spends a block's life waiting: four dependent round trips (term range -> indices -> hf_ok -> operands), a 36-value reduction through LDS with two
+// barriers, three workgroups per CU in flight -- 6 % of the FP64 rate, 530 us per launch for sixteen windows. Here a wavefront walks its block 64 terms at a time (packed 16-byte
+// term records, the next pass's records requested with this pass's operands, hf_ok read beside them), keeps the 36 sums in registers across passes and reduces them once with DPP;
+// no LDS, no barrier, four independent blocks per workgroup = twelve blocks per CU in flight, the longest blocks first (records sorted at upload: ProbDesc::n_vb). One wavefront
+// sums a block in a fixed order: reproducible run to run. (Measured and dropped on the way: a LANE per light block, <= 64 terms -- 125 us for 5 % of the terms.)
+template <int FAM> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) kb_schur_reduce_wave(const Batch B, const DevParams prm, const Gang G, int xcd_rows) {
+	// xcd_rows (gridDim.y a multiple of 8): the workgroups of window w all run on XCD w % 8 -- workgroups go to the XCDs round-robin in dispatch order (x fastest), so the linear
+	// id is re-read as (XCD, position on that XCD) and the position as (window, workgroup of the window). A window's W blocks (8 MB, each read ~ 13 times) then stay in ONE L2
+	// instead of passing through all eight.
+	int gw = blockIdx.y, bx = blockIdx.x;
+	if (xcd_rows) { const unsigned id = blockIdx.x + blockIdx.y * gridDim.x, xcd = id & 7u, j = id >> 3; gw = (int)(xcd + 8u * (j / gridDim.x)); bx = (int)(j % gridDim.x); }
+	if (!((G.mask >> gw) & 1u)) return; const int p = G.p[gw];
+	typedef Worker<FAM> W; constexpr int P = W::P, L = W::L; const ProbDesc &d = B.desc[p];
+	if constexpr (!W::T::REL) {
+		const int v = bx * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63; if (v >= d.n_vb) return;
+		const int *vr = B.sch_vb + 4 * (d.o_vb + v);
+		const int t0 = __builtin_amdgcn_readfirstlane(vr[0]), t1 = __builtin_amdgcn_readfirstlane(vr[1]), b = __builtin_amdgcn_readfirstlane(vr[2]);
+		const int4 *tr = (const int4 *)(B.sch_rec + 4 * d.o_sch); const double *HApf = B.HApf + d.o_hapf * P * L, *Hfinv = B.Hfinv + d.o_ulm * L * L; const int *ok = B.hf_ok + d.o_ulm;
+		double Hl[P * P];
+#pragma unroll
+		for (int k = 0; k < P * P; k++) Hl[k] = 0;
+		int4 nx = tr[min(t0 + lane, t1 - 1)];
+		for (int t = t0; t < t1; t += 64) {
+			const int4 cur = nx; const bool act = t + lane < t1;
+			if (t + 64 < t1) nx = tr[min(t + 64 + lane, t1 - 1)]; // (clamped, unconditional: the records of the next pass travel with the operands of this one)
+			double w1[P * L], w2[P * L], hi[L * L];
+			ldn<P * L>(w1, HApf + (long long)cur.y * P * L); ldn<P * L>(w2, HApf + (long long)cur.z * P * L); ldn<L * L>(hi, Hfinv + (long long)cur.x * L * L);
+			const bool use = act && ok[cur.x] != 0;
+			double *Yout = (use && cur.w >= 0) ? B.YW + (d.o_yw + cur.w) * P * L : nullptr;
+#pragma unroll
+			for (int i = 0; i < P; i++) { double y[L];
+#pragma unroll
+				for (int j = 0; j < L; j++) { double s = 0;
+#pragma unroll
+					for (int k = 0; k < L; k++) s += w1[i * L + k] * hi[k * L + j];
+					y[j] = s; }
+#pragma unroll
+				for (int j = 0; j < P; j++) { double s = 0;
+#pragma unroll
+					for (int k = 0; k < L; k++) s += y[k] * w2[j * L + k];
+					Hl[i * P + j] += use ? s : 0.0; }
+				if (Yout) {
+#pragma unroll
+					for (int j = 0; j < L; j++) Yout[i * L + j] = y[j];
+				}
+			}
+		}
+		double mine = 0;
+#pragma unroll
+		for (int k = 0; k < P * P; k++) { const double tot = wave_sum(Hl[k]); mine = (lane == k) ? tot : mine; }
+		if (lane < P * P) B.HAp[(d.o_hap + b) * P * P + lane] -= mine;
+	}
+}
 // g_Ap(i) -= sum_l Y_il g_f(l) (schur.h:262-283): one workgroup per unknown edge
 template <int FAM> __global__ void __launch_bounds__(256) kb_schur_grad(const Batch B, const DevParams prm, const Gang G) {
 	BIG_ENTER();

@@ -58,6 +58,8 @@ struct ProbDesc {
 	int hs_lds; long long o_hapo, o_schl; // workgroup path, U_Ap accumulators in LDS (Solver::phase_hessian_lds / schur_reduce_lds): the U_Ap terms sorted by observation {t1, t2, block}
 		// from o_hapo (x3), the Schur terms sorted by landmark {lm, b1, b2, block | edge << 16 | diagonal << 31} from o_schl (x4)
 	int n_hrec, hap_chunked /* unused since the workgroup path sums U_Ap in LDS */; long long o_hrec; // K6 work records {U_Ap block, first term, end term} (Batch::hap_rec), one per block
+	int n_vb; long long o_vb; // multi-workgroup path, Schur reduction with a wavefront per U_Ap block (kb_schur_reduce_wave): n_vb work records {first term, end term, block, 0} from o_vb (x4) in
+		// Batch::sch_vb, longest list first; the terms themselves as packed records {landmark, W block 1, W block 2, Y slot} from o_sch (x4) in Batch::sch_rec
 	int dense_in_lds, dense_blocks; // dense_blocks: the LDS image holds ALL blocks of the lower triangle (column-major), no symbolic structure (mid-size, nearly dense systems)
 };
 
@@ -73,7 +75,7 @@ struct Batch {
 	gptr<const int> bp_col, bp_res, bp_A, bp_D, bp_lm, colp_off, bf_col, bf_res, bf_pose, colf_off;
 	gptr<const int> hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hap_tblk /* block of every U_Ap term */, hf_i, hf_j, hf_term_off, hf_t1, hf_t2;
 	gptr<const int> hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag;
-	gptr<const int> sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw, sch_tblk /* U_Ap block of every Schur term */, lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec;
+	gptr<const int> sch_term_off, sch_b1, sch_b2, sch_lm, sch_yw, sch_tblk /* U_Ap block of every Schur term */, sch_vb, sch_rec /* ProbDesc::n_vb */, lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec;
 		// need_rec: per needed pair {pair, 4 path entries (edge<<1|inv, -1 = none)}
 	gptr<const unsigned char> pair_needed, bp_normal;
 	gptr<const int> sp_fill; // unified block indices (diag k -> k, off-diagonal i -> nb+i)

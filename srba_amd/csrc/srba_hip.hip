@@ -1347,7 +1347,7 @@ struct srba_hip_ctx {
 	double big_chol_ms = 0, big_chol_flops = 0; long long big_chol_count = 0, big_chol_seqs = 0 /* launch sequences: one factors all windows of a gang */; int big_chol_nmax = 0;
 		// Cholesky time / flops of the big path since the last upload (sum over the lanes)
 	BigLane lanes[kBigLanes]; int n_lanes_ready = 0; // lane 0 = the context stream and buffers; the others are created on first use
-	bool big_gang = true, big_persistent = false, big_fused_step = true; int big_lanes_max = kBigLanes, big_gang_slots = srbadev::kGang, gang_from_nb = 0 /* landmark windows with this many block rows
+	bool big_gang = true, big_persistent = false, big_fused_step = true; int big_lanes_max = kBigLanes, big_gang_slots = srbadev::kGang, big_gangs = 2 /* SRBA_HIP_BIG_GANGS: gangs side by side (big_run_class); measured 1: 7 100, 2: 7 900, 3: 4 800, 4: 4 700 - 5 800 LM iterations/s on cfg4 */, sch_xcd = 1 /* SRBA_HIP_SCHUR_XCD: a window's workgroups of that kernel on one XCD */, sch_sort = 1 /* SRBA_HIP_SCHUR_SORT: its blocks longest first (0: block order) */, sch_wave = 1 /* SRBA_HIP_SCHUR_WAVE: kb_schur_reduce_wave (a wavefront per U_Ap block) on the multi-workgroup class; 0: a workgroup per block */, gang_from_nb = 0 /* landmark windows with this many block rows
 		or more take the gang instead of one wavefront (0: off) */; // big path: windows of a batch in lock-step on one stream (gang) or one host thread + stream per window
 	int upload_threads = 1; bool dense_left = true; int hbm_from_kb = 48; bool dense_blocks_ok = true; // mid-size nearly-full systems use the dense block layout in LDS
 	bool lin_terms = true, lm_terms = true; // term-parallel U_Ap accumulation in LDS: srba_hip_linearize / the fused LM kernel
@@ -1571,6 +1571,9 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_ASSEMBLE_MAX_KB"); if (e) c->asm_max_kb = atoi(e); }            // capsules whose LDS image exceeds this take the unfused kernel (tests)
 	{ const char *e = getenv("SRBA_HIP_ASSEMBLE"); if (e) c->asm_on = atoi(e) != 0; }                   // 0 = srba_hip_linearize always runs the unfused kernel (Jacobian blocks through HBM)
 	{ const char *e = getenv("SRBA_HIP_FLAT"); if (e) c->use_flat = atoi(e) != 0; }                     // 0 = one wavefront per capsule for the stepwise spanning-tree launch
+	{ const char *e = getenv("SRBA_HIP_SCHUR_XCD"); if (e) c->sch_xcd = atoi(e) != 0; } { const char *e = getenv("SRBA_HIP_SCHUR_SORT"); if (e) c->sch_sort = atoi(e) != 0; }
+	{ const char *e = getenv("SRBA_HIP_SCHUR_WAVE"); if (e) c->sch_wave = atoi(e) != 0; }
+	{ const char *e = getenv("SRBA_HIP_BIG_GANGS"); if (e && atoi(e) >= 1) c->big_gangs = std::min(atoi(e), kBigLanes); }
 	{ const char *e = getenv("SRBA_HIP_BIG_LANES"); if (e && atoi(e) >= 1) { c->big_lanes_max = std::min(atoi(e), kBigLanes); c->big_gang_slots = std::min(atoi(e), srbadev::kGang); } }
 	{ const char *e = getenv("SRBA_HIP_GANG_FROM_NB"); if (e) c->gang_from_nb = atoi(e); } // large capsules of one batch in flight at once
 	{ const char *e = getenv("SRBA_HIP_BIG_PERSISTENT"); if (e) c->big_persistent = atoi(e) != 0; }   // 1 = the blocked Cholesky of the big path as ONE persistent launch with grid barriers
@@ -1664,7 +1667,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	c->desc.assign(n, ProbDesc()); srba_batch_stats &st = c->stats; std::memset(&st, 0, sizeof(st)); st.n_problems = n;
 	// ---- pass 1: descriptors and totals
 	long long t_ptab = 0, t_hapo = 0, t_schl = 0, t_hrec = 0, t_edge = 0, t_unk = 0, t_ulm = 0, t_klm = 0, t_pair = 0, t_path = 0, t_obs = 0, t_valid = 0, t_bp = 0, t_bf = 0, t_hap = 0, t_hapt = 0,
-		t_hf = 0, t_hft = 0, t_hapf = 0, t_hapft = 0, t_sch = 0, t_req = 0, t_scal = 0, t_yw = 0, t_dense = 0;
+		t_hf = 0, t_hft = 0, t_hapf = 0, t_hapft = 0, t_sch = 0, t_req = 0, t_scal = 0, t_yw = 0, t_dense = 0, t_vb = 0; bool any_vb = false;
 	std::vector<int> cls(n, 0), big_lds(n, 0); int cls_nbmax[SRBA_NCLS] = {0}; size_t wg_lds[3] = {0, 0, 0}; std::vector<Symbolic> sym(n); long long t_spcol = 0, t_sprow = 0, t_spitem = 0,
 		t_spfill = 0;
 	// capsules whose system cannot fit one wavefront's LDS even as bare numbers (more than 63 block rows) but is no deep-window system either: a handful go to the
@@ -1745,6 +1748,9 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		d.dense_in_lds = (cls[p] < SRBA_NLDS && d.dense_blocks < 2) ? 1 : 0; if (cls[p] < SRBA_NLDS) cls_nbmax[cls[p]] = std::max(cls_nbmax[cls[p]], (int)tri_n);
 		const long long big_ld = cls[p] < SRBA_NCLS - 1 ? 0 : ((d.n_sys + srbadev::CB - 1) / srbadev::CB) * srbadev::CB; // dense path: ld x ld matrix + ld x CB diagonal factors + rhs + y
 		int nyw = 0; if (k.n_sch_terms > 0) for (int b = 0; b < k.n_hap; b++) if (k.hap_i[b] == k.hap_j[b]) nyw += k.sch_term_off[b + 1] - k.sch_term_off[b];
+		d.n_vb = 0; d.o_vb = t_vb; // Schur reduction, a wavefront per U_Ap block (multi-workgroup class): one work record per block that has terms
+		if (c->sch_wave && cls[p] == SRBA_NCLS - 1 && k.n_sch_terms > 0) { any_vb = true; for (int b = 0; b < k.n_hap; b++) if (k.sch_term_off[b + 1] > k.sch_term_off[b]) d.n_vb++;
+			t_vb += d.n_vb; }
 		long long npath_needed = 0; for (int q = 0; q < k.n_pairs; q++) if (k.pair_needed[q]) { st.n_pairs_needed++; npath_needed += k.pair_path_off[q + 1] - k.pair_path_off[q]; }
 		st.n_path_needed += npath_needed;
 		t_edge += k.n_edges; t_unk += d.nK; t_ulm += d.nF; t_klm += d.n_klm; t_pair += k.n_pairs; t_path += k.n_path; t_obs += k.n_obs; t_valid += k.n_valid; t_bp += k.n_bp; t_bf += k.n_bf;
@@ -1759,7 +1765,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	// ---- input arena layout
 	Arena in; struct { size_t desc, edge0, ulm0, klm, obs_z, pair_path_off, path_edge, obs_pose, obs_lm, obs_valid, bp_col, bp_res, bp_A, bp_D, bp_lm, colp_off, bf_col, bf_res, bf_pose, colf_off,
 		hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hap_tblk, hf_i, hf_j, hf_term_off, hf_t1, hf_t2, hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag, sch_term_off, sch_b1, sch_b2,
-			sch_lm, sch_yw, sch_tblk,
+			sch_lm, sch_yw, sch_tblk, sch_vb, sch_rec,
 		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, obs_rec, pair_needed, pose_req, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_rptr, sp_rcol, sp_perm, sp_fill, hap_rec,
 			hapo, schl, ptab, hap_dst, hapf_dst, hf_dst, asm_term, asm_blk, asm_desc, asm_list, asm_slot; } o;
 	o.desc = in.add(sizeof(ProbDesc) * n);
@@ -1772,6 +1778,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	o.hapf_i = in.add(4 * t_hapf); o.hapf_j = in.add(4 * t_hapf); o.hapf_term_off = in.add(4 * (t_hapf + n)); o.hapf_t1 = in.add(4 * t_hapft); o.hapf_t2 = in.add(4 * t_hapft);
 	o.hap_diag = in.add(4 * t_unk); o.hf_diag = in.add(4 * t_ulm);
 	o.sch_term_off = in.add(4 * (t_hap + n)); o.sch_b1 = in.add(4 * t_sch); o.sch_b2 = in.add(4 * t_sch); o.sch_lm = in.add(4 * t_sch); o.sch_yw = in.add(4 * t_sch); o.sch_tblk = in.add(4 * t_sch);
+	o.sch_vb = in.add(16 * (size_t)t_vb); o.sch_rec = in.add(any_vb ? 16 * (size_t)t_sch : 0);
 	o.lm_hapf_off = in.add(4 * (t_ulm + n)); o.lm_hapf_idx = in.add(4 * t_hapf); o.req_idx = in.add(4 * t_req); o.need_idx = in.add(4 * t_pair);
 		o.need_rec = in.add(4 * 5 * std::max<long long>(t_pair, 1)); o.obs_rec = in.add(4 * 5 * std::max<long long>(t_obs, 1)); o.pair_needed = in.add(t_pair); o.pose_req = in.add(2 * t_pair);
 		o.bp_normal = in.add(t_bp); o.order = in.add(4 * (size_t)n);
@@ -1829,6 +1836,13 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 				CPY(o.sch_lm, d.o_sch, k.sch_lm, k.n_sch_terms, int32_t);
 			int32_t *yw = (int32_t *)(h + o.sch_yw) + d.o_sch, *tbk = (int32_t *)(h + o.sch_tblk) + d.o_sch; int cnt = 0;
 			for (int b = 0; b < k.n_hap; b++) for (int t = k.sch_term_off[b]; t < k.sch_term_off[b + 1]; t++) { yw[t] = (k.hap_i[b] == k.hap_j[b]) ? cnt++ : -1; tbk[t] = b; }
+			if (d.n_vb > 0) { // work records of kb_schur_reduce_wave {first term, end term, block, 0}, longest list first (stable: equal lengths keep the block order); packed term records
+				int32_t *vb = (int32_t *)(h + o.sch_vb) + 4 * d.o_vb, *rec = (int32_t *)(h + o.sch_rec) + 4 * d.o_sch;
+				std::vector<int32_t> ord; ord.reserve(d.n_vb); for (int b = 0; b < k.n_hap; b++) if (k.sch_term_off[b + 1] > k.sch_term_off[b]) ord.push_back(b);
+				if (c->sch_sort) std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return k.sch_term_off[x + 1] - k.sch_term_off[x] > k.sch_term_off[y + 1] - k.sch_term_off[y]; });
+				for (int q = 0; q < d.n_vb; q++) { const int b = ord[q]; vb[4 * q] = k.sch_term_off[b]; vb[4 * q + 1] = k.sch_term_off[b + 1]; vb[4 * q + 2] = b; vb[4 * q + 3] = 0; }
+				for (int t = 0; t < k.n_sch_terms; t++) { rec[4 * t] = k.sch_lm[t]; rec[4 * t + 1] = k.sch_b1[t]; rec[4 * t + 2] = k.sch_b2[t]; rec[4 * t + 3] = yw[t]; }
+			}
 		} // else: zeros = empty term lists
 		if (k.lm_hapf_off) CPY(o.lm_hapf_off, d.o_lmoff, k.lm_hapf_off, d.nF + 1, int32_t); CPY(o.lm_hapf_idx, d.o_hapf, k.lm_hapf_idx, k.n_hapf, int32_t);
 		{ int32_t *nd = (int32_t *)(h + o.need_idx) + d.o_pair, *nr = (int32_t *)(h + o.need_rec) + 5 * d.o_pair; int cnt = 0, flat = 1;
@@ -1980,7 +1994,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	DI(bf_col, int); DI(bf_res, int); DI(bf_pose, int); DI(colf_off, int); DI(hap_i, int); DI(hap_j, int); DI(hap_term_off, int); DI(hap_t1, int); DI(hap_t2, int); DI(hap_tblk, int); DI(hf_i, int);
 		DI(hf_j, int); DI(hf_term_off, int); DI(hf_t1, int); DI(hf_t2, int);
 	DI(hapf_i, int); DI(hapf_j, int); DI(hapf_term_off, int); DI(hapf_t1, int); DI(hapf_t2, int); DI(hap_diag, int); DI(hf_diag, int); DI(sch_term_off, int); DI(sch_b1, int); DI(sch_b2, int);
-		DI(sch_lm, int); DI(sch_yw, int); DI(sch_tblk, int);
+		DI(sch_lm, int); DI(sch_yw, int); DI(sch_tblk, int); DI(sch_vb, int); DI(sch_rec, int);
 	DI(lm_hapf_off, int); DI(lm_hapf_idx, int); DI(req_idx, int); DI(need_idx, int); DI(need_rec, int); DI(obs_rec, int); DI(pair_needed, unsigned char); DI(pose_req, unsigned char); DI(bp_normal,
 		unsigned char);
 c->asm_tab.term = asm_fam ? (const unsigned long long *)(di + o.asm_term) : nullptr; c->asm_tab.blk = asm_fam ? (const unsigned long long *)(di + o.asm_blk) : nullptr;
@@ -2118,7 +2132,9 @@ static void big_set_lambda(hipStream_t st, const srbadev::Gang &G, const srbadev
 static void big_enqueue_assemble(srba_hip_ctx *c, hipStream_t st, const srbadev::Gang &Gall) {
 	const int P = c->dm.P;
 	{ const srbadev::Gang G = gang_masked(Gall, gang_schur_mask(c, Gall));
-	  BIGK(kb_schur_inv, std::max<long long>(d.nF, (long long)d.n_hap * P * P), 128); BIGKG(kb_schur_reduce, d.n_hap, 256); BIGKG(kb_schur_grad, d.nK, 256); }
+	  BIGK(kb_schur_inv, std::max<long long>(d.nF, (long long)d.n_hap * P * P), 128); if (c->sch_wave) { int gy = 0; for (int w = 0; w < G.n; w++) if ((G.mask >> w) & 1u) gy = w + 1; /* = the grid's y (gang_grid) */
+	    BIGKG(kb_schur_reduce_wave, (d.n_vb + 3) / 4, 256, (c->sch_xcd && gy % 8 == 0) ? 1 : 0); } else BIGKG(kb_schur_reduce, d.n_hap, 256);
+	  BIGKG(kb_schur_grad, d.nK, 256); }
 	if (!Gall.mask) return;
 	hipLaunchKernelGGL(srbadev::kb_dense_clear, gang_grid(c, Gall, 256, false, [&](const ProbDesc &, int w) -> long long { return (long long)Gall.ld[w] * Gall.ld[w]; }), dim3(256), 0, st, Gall);
 	const unsigned ms = gang_schur_mask(c, Gall);
@@ -2314,9 +2330,10 @@ static int big_prepare_lanes(srba_hip_ctx *c, int n) {
 	BigLane &l0 = c->lanes[0]; l0.id = 0; l0.stream = c->stream; l0.d_part = c->d_part; l0.d_scal = c->d_scal; l0.d_iscal = (int *)(c->d_scal + 16 * srbadev::kGang); l0.slots = srbadev::kGang;
 	c->n_lanes_ready = std::max(c->n_lanes_ready, 1);
 	for (int i = c->n_lanes_ready; i < n; i++) {
-		BigLane &l = c->lanes[i]; l.id = i; l.slots = 1;
+		BigLane &l = c->lanes[i]; l.id = i; l.slots = srbadev::kGang; // (every lane can hold a gang: SRBA_HIP_BIG_GANGS > 1 runs several gangs side by side)
 		HIPCHK(c, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
-		HIPCHK(c, hipMalloc((void **)&l.d_part, 8 * 3 * kBigPart)); HIPCHK(c, hipMalloc((void **)&l.d_scal, 8 * 16 + 4 * 8)); l.d_iscal = (int *)(l.d_scal + 16);
+		HIPCHK(c, hipMalloc((void **)&l.d_part, 8 * 3 * kBigPart * srbadev::kGang)); HIPCHK(c, hipMalloc((void **)&l.d_scal, (8 * 16 + 4 * 8) * srbadev::kGang));
+			l.d_iscal = (int *)(l.d_scal + 16 * srbadev::kGang);
 		c->n_lanes_ready = i + 1;
 	}
 	return n;
@@ -2328,7 +2345,11 @@ static void big_collect_lane_stats(srba_hip_ctx *c) { for (int i = 0; i < c->n_l
 static int big_run_class(srba_hip_ctx *c, const int32_t *caps, int count) {
 	if (count <= 0) return 0;
 	const bool gang = c->big_gang && !c->big_persistent;
-	const int n = big_prepare_lanes(c, (gang || c->big_lanes_max <= 1) ? 1 : std::min(count, c->big_lanes_max)); if (n < 1) return -1;
+	// several gangs side by side (big_gangs > 1): the windows of the class are dealt to that many lanes, each a lock-step gang on its own stream and host thread -- the latency-bound
+	// phases of one gang (the panel chains of the factorisation use a few CUs) run under the throughput-bound ones of the others (Schur reduction, Hessian)
+	const int ngang = gang ? std::max(1, std::min(std::min(c->big_gangs, kBigLanes), count)) : 1;
+	const int per_gang = gang ? std::max(1, std::min(c->big_gang_slots, (count + ngang - 1) / ngang)) : 1;
+	const int n = big_prepare_lanes(c, gang ? ngang : (c->big_lanes_max <= 1 ? 1 : std::min(count, c->big_lanes_max))); if (n < 1) return -1;
 	int rc = 0; std::atomic<int> next(0);
 	if (n == 1) { rc = big_gang_run(c, &c->lanes[0], caps, count, next, gang ? c->big_gang_slots : 1); }
 	else {
@@ -2339,7 +2360,7 @@ static int big_run_class(srba_hip_ctx *c, const int32_t *caps, int count) {
 		if (e != hipSuccess) { hipEventDestroy(ready); c->fail(std::string("large-capsule path: ") + hipGetErrorString(e)); return -1; }
 		std::vector<int> rcs(n, 0); std::vector<std::thread> th;
 		auto work = [&](int li) { // no exception leaves a worker (std::terminate otherwise) nor this function (it is reached from an extern "C" entry)
-			try { hipSetDevice(c->device); BigLane *ln = &c->lanes[li]; rcs[li] = big_gang_run(c, ln, caps, count, next, 1); hipStreamSynchronize(ln->stream); }
+			try { hipSetDevice(c->device); BigLane *ln = &c->lanes[li]; rcs[li] = big_gang_run(c, ln, caps, count, next, per_gang); hipStreamSynchronize(ln->stream); }
 			catch (const std::exception &ex) { rcs[li] = -1; c->lanes[li].error = std::string("large-capsule path: ") + ex.what(); }
 			catch (...) { rcs[li] = -1; c->lanes[li].error = "large-capsule path: unknown exception"; } };
 		try { for (int i = 1; i < n; i++) th.emplace_back(work, i); } catch (...) { /* fewer threads than lanes: the ones that started (and this thread) share the capsules */ }
