@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 5, session 2: first run of the workgroup kernel of the landmark families
-export GPU_MAX_HW_QUEUES=16
-O=gpurun_out/s2; mkdir -p $O
-timeout 600 python tools/r5_wg_check.py stereo 8 "WG=0" "WG=1" "WG=1,WG256_FROM=1000" "WG=1,WG256_FROM=24" > $O/wg_stereo_small.txt 2>&1; tail -8 $O/wg_stereo_small.txt
-timeout 900 python tools/r5_wg_check.py stereo 64 "WG=0" "WG=1" "WG=1,PHASES=1" "WG=1,WG256_FROM=48" "WG=1,WG_FROM=60" > $O/wg_stereo.txt 2>&1; tail -14 $O/wg_stereo.txt
-timeout 900 python tools/r5_wg_check.py mono 64 "WG=0" "WG=1" > $O/wg_mono.txt 2>&1; tail -4 $O/wg_mono.txt
-timeout 900 python -m pytest tests -m gpu -x -q -k "landmark or stereo or mono or schur or families or cfg3 or room" 2>&1 | tail -15 > $O/pytest_lm.log; tail -6 $O/pytest_lm.log
+# (GPU box) second measurement session of round 5: product = -disable-machine-licm -sink-insts-to-avoid-spills + opaque lane row in wg_diag
+out=gpurun_out/s2; mkdir -p $out
+timeout 900 python -m pytest tests -x -q -m gpu > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log
+bash tools/r4_variants.sh "" "lib=nl" "" "lib=nl" > $out/headline.txt 2>&1
+for k in stereo mono cart3d rb3d; do timeout 300 python tools/r5_wg_check.py $k 64 WG=1 2>&1 | tail -1 >> $out/families.txt; done
+bash tools/diag_cfg4_timeline.sh
+timeout 900 python bench.py --cfg4-full-budget-s 0 > $out/bench.json 2> $out/bench.err
