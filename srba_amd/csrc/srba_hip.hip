@@ -943,8 +943,11 @@ __global__ void k_delay(int us) { const long long t0 = wall_clock64(); while (wa
 // The same loop for the small size classes of a big batch: three wavefronts per SIMD (at most 168 registers; Worker<FAM, LEAN = true> keeps fewer loads in flight per lane). On the 23 460 windows
 // with at most 31 unknown edges of the benchmark batch: 16.6 ms against 19.0 ms for k_lm_run, whose two wavefronts per SIMD leave 40 % of the LDS of a CU unused while those classes run;
 // the big (LDS-bound) classes are 3 % slower with it and keep k_lm_run. Only instantiated where the plan uses it (relative-pose SE2: plan_launches).
+#ifndef SRBA_LEAN_WAVES
+#define SRBA_LEAN_WAVES 3 /* wavefronts per SIMD k_lm_run_lean is compiled for (4: 128 registers) */
+#endif
 template <int FAM>
-__global__ void __launch_bounds__(SRBA_WG) __attribute__((amdgpu_waves_per_eu(3, 3))) k_lm_run_lean(SRBA_LM_BATCH_ARG, int first, int count, int *next) { SRBA_LM_BATCH_REF;
+__global__ void __launch_bounds__(SRBA_WG) __attribute__((amdgpu_waves_per_eu(SRBA_LEAN_WAVES, SRBA_LEAN_WAVES))) k_lm_run_lean(SRBA_LM_BATCH_ARG, int first, int count, int *next) { SRBA_LM_BATCH_REF;
 	for (;;) {
 		int i = 0; if (threadIdx.x == 0) { i = atomicAdd(next, 1); if (i == 0) *(long long *)(next + 2) = wall_clock64(); }
 		i = __builtin_amdgcn_readfirstlane(i);
@@ -1402,7 +1405,7 @@ static void plan_launches(srba_hip_ctx *c, const int32_t *ord) {
 				if (J.cls >= SRBA_NLDS) J.grid = std::max(1, std::min(J.count, c->n_cu * (J.cls == SRBA_CLS_WG512 ? 1 : (J.cls == SRBA_CLS_WG256 ? SRBA_WG_WAVES : 2 * SRBA_WG_WAVES))));
 					// workgroup classes: 256 registers -> two wavefronts per SIMD = two 256-thread / four 128-thread workgroups per CU
 				J.lean = (c->lean_on && c->params.family == SRBA_SE2_RELPOSE2D && J.cls < SRBA_NCLS - 1 && fit >= 9 && J.count >= c->lean_min_count) ? 1 : 0;
-				if (J.lean) J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(12, fit)));
+				if (J.lean) J.grid = std::max(1, std::min(J.count, c->n_cu * std::min(4 * SRBA_LEAN_WAVES, fit)));
 				// (also for a batch of a few capsules -- the per-key-frame use of the engine is a batch of ONE: its latency is the whole cost, 1.55 -> 1.41 ms per key-frame of the sequential run)
 				J.two = (c->two_on && c->params.family == SRBA_SE2_RELPOSE2D && J.cls < SRBA_NCLS - 1 && lds > 0 && ((lds >= (size_t)c->two_from_kb * 1024 && J.count >= c->two_min_count) ||
 					batch_total <= 4)) ? 1 : 0; if (J.two) J.lean = 0;
