@@ -1350,7 +1350,11 @@ struct srba_hip_ctx {
 	double big_chol_ms = 0, big_chol_flops = 0; long long big_chol_count = 0, big_chol_seqs = 0 /* launch sequences: one factors all windows of a gang */; int big_chol_nmax = 0;
 		// Cholesky time / flops of the big path since the last upload (sum over the lanes)
 	BigLane lanes[kBigLanes]; int n_lanes_ready = 0; // lane 0 = the context stream and buffers; the others are created on first use
-	bool big_gang = true, big_persistent = false, big_fused_step = true; int big_lanes_max = kBigLanes, big_gang_slots = srbadev::kGang, big_gangs = 2 /* SRBA_HIP_BIG_GANGS: gangs side by side (big_run_class); measured 1: 7 100, 2: 7 900, 3: 4 800, 4: 4 700 - 5 800 LM iterations/s on cfg4 */, sch_xcd = 1 /* SRBA_HIP_SCHUR_XCD: a window's workgroups of that kernel on one XCD */, sch_sort = 1 /* SRBA_HIP_SCHUR_SORT: its blocks longest first (0: block order) */, sch_wave = 1 /* SRBA_HIP_SCHUR_WAVE: kb_schur_reduce_wave (a wavefront per U_Ap block) on the multi-workgroup class; 0: a workgroup per block */, gang_from_nb = 0 /* landmark windows with this many block rows
+	bool big_gang = true, big_persistent = false, big_fused_step = true; int big_lanes_max = kBigLanes, big_gang_slots = srbadev::kGang,
+		big_gangs = 2 /* SRBA_HIP_BIG_GANGS: gangs side by side (big_run_class); measured 1: 8 100, 2: 9 000, 3: 5 100, 4: 5 100 LM iterations/s on cfg4 */,
+		sch_xcd = 1 /* SRBA_HIP_SCHUR_XCD: a window's workgroups of kb_schur_reduce_wave on one XCD */, sch_sort = 1 /* SRBA_HIP_SCHUR_SORT: its blocks longest first (0: block order) */,
+		sch_wave = 1 /* SRBA_HIP_SCHUR_WAVE: kb_schur_reduce_wave (a wavefront per U_Ap block) on the multi-workgroup class; 0: a workgroup per block */,
+		gang_from_nb = 0 /* landmark windows with this many block rows
 		or more take the gang instead of one wavefront (0: off) */; // big path: windows of a batch in lock-step on one stream (gang) or one host thread + stream per window
 	int upload_threads = 1; bool dense_left = true; int hbm_from_kb = 48; bool dense_blocks_ok = true; // mid-size nearly-full systems use the dense block layout in LDS
 	bool lin_terms = true, lm_terms = true; // term-parallel U_Ap accumulation in LDS: srba_hip_linearize / the fused LM kernel

@@ -16,7 +16,8 @@ static const Obs kf2[] = {{2, 1.93, 0.91}, {3, 1.41, -0.66}, {5, 2.12, 1.47}, {6
 
 template <size_t N> static void add_kf(rba_t &rba, const Obs (&o)[N], rba_t::TNewKeyFrameInfo &info) {
 	rba_t::new_kf_observations_t obs;
-	for (size_t i = 0; i < N; i++) { rba_t::new_kf_observation_t k; k.is_fixed = false; k.is_unknown_with_init_val = false; k.obs.feat_id = o[i].lm; k.obs.obs_data.range = o[i].range; k.obs.obs_data.yaw = o[i].yaw; obs.push_back(k); }
+	for (size_t i = 0; i < N; i++) { rba_t::new_kf_observation_t k; k.is_fixed = false; k.is_unknown_with_init_val = false; k.obs.feat_id = o[i].lm; k.obs.obs_data.range = o[i].range;
+		k.obs.obs_data.yaw = o[i].yaw; obs.push_back(k); }
 	rba.define_new_keyframe(obs, info, true);
 }
 int main() {
@@ -33,7 +34,8 @@ int main() {
 		for (size_t k = 0; k < n && pd; k++) { if (!(Lc[k * n + k] > 0)) { pd = false; break; } const double d = std::sqrt(Lc[k * n + k]); for (size_t i = k; i < n; i++) Lc[i * n + k] /= d;
 			for (size_t j = k + 1; j < n; j++) for (size_t i = j; i < n; i++) Lc[i * n + j] -= Lc[i * n + k] * Lc[j * n + k]; } }
 	std::printf("hessian_asym %.3e\nhessian_pd %d\nhessian_min_diag %.6g\ncondition_number %.6g\nrmse %.6g\n", asym, (int)pd, mind, r.HAp_condition_number, r.obs_rmse);
-	const char *secs[] = {"opt", "opt.update_spanning_tree_num", "opt.recompute_all_Jacobians", "opt.sparse_hessian_update_numeric", "opt.reprojection_residuals", "opt.compute_minus_gradient", "opt.schur_build_reduced", "opt.DenseFill", "opt.DenseChol", "opt.backsub", "opt.schur_features", "opt.add_se3_deltas_to_frames"};
+	const char *secs[] = {"opt", "opt.update_spanning_tree_num", "opt.recompute_all_Jacobians", "opt.sparse_hessian_update_numeric", "opt.reprojection_residuals", "opt.compute_minus_gradient",
+		"opt.schur_build_reduced", "opt.DenseFill", "opt.DenseChol", "opt.backsub", "opt.schur_features", "opt.add_se3_deltas_to_frames"};
 	for (const char *s : secs) std::printf("section %s %.3e\n", s, rba.get_time_profiler().getMeanTime(s));
 	return 0;
 }

@@ -16,7 +16,8 @@ timeout 1500 bash tools/pmc_bench.sh > $O/pmc_bench.log 2>&1
 cp gpurun_out/sq_summary.json $O/sq_summary.json
 timeout 900 bash tools/pmc_cfg3.sh > $O/pmc_cfg3.log 2>&1; cp gpurun_out/pmc_traffic_cfg3.json gpurun_out/sq_summary_cfg3.json $O/ 2>/dev/null   # the workgroup landmark kernels on the cfg3 workload
 # the driver's N = 8 line with the FULL 30 000-key-frame map per rank, eight ranks on this one GPU over gloo: do the eight harvests serialise on the shared host?
-( time env SRBA_BENCH_DEVICE=0 SRBA_BENCH_BACKEND=gloo timeout 1200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 8 --steps 3 --warmup 1 --cpu-seconds 0 --cache-dir "" ) > $O/eight_ranks_full_map.log 2>&1
+( time env SRBA_BENCH_DEVICE=0 SRBA_BENCH_BACKEND=gloo timeout 1200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
+	--master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 8 --steps 3 --warmup 1 --cpu-seconds 0 --cache-dir "" ) > $O/eight_ranks_full_map.log 2>&1
 timeout 300 python tools/diag_launch_stamps.py > $O/launch_order.txt 2>&1
 timeout 400 bash tools/diag_cfg4_timeline.sh > /dev/null 2>&1; cp gpurun_out/cfg4_timeline.txt $O/cfg4_timeline.txt   # where a cfg4 step goes, kernel by kernel
 timeout 600 bash tools/fam_compare.sh > $O/families.log 2>&1   # fused-kernel throughput per landmark family

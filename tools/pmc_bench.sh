@@ -42,9 +42,14 @@ for kname, n_launch in KERNELS.items():
                        'active_inst_any_over_wave_cycles': out.get('SQ_ACTIVE_INST_ANY', 0) / max(1, out.get('SQ_WAVE_CYCLES', 1)),
                        'mean_active_lanes_per_valu_inst': out.get('SQ_THREAD_CYCLES_VALU', 0) / max(1, 4 * out.get('SQ_ACTIVE_INST_VALU', 1)) if out.get('SQ_THREAD_CYCLES_VALU') else None,
                        'hbm_bytes_per_launch': {'FETCH_SIZE_KB_raw': out.get('FETCH_SIZE'), 'WRITE_SIZE_KB_raw': out.get('WRITE_SIZE'),
-                                                'read_bytes_by_request_size': (128 * out.get('TCC_EA0_RDREQ_128B_sum', 0) + 64 * out.get('TCC_EA0_RDREQ_64B_sum', 0) + 32 * out.get('TCC_EA0_RDREQ_32B_sum', 0)) if 'TCC_EA0_RDREQ_128B_sum' in out else None,
-                                                'write_bytes_by_request_size': (64 * out.get('TCC_EA0_WRREQ_64B_sum', 0) + 32 * (out.get('TCC_EA0_WRREQ_sum', 0) - out.get('TCC_EA0_WRREQ_64B_sum', 0))) if 'TCC_EA0_WRREQ_sum' in out else None,
-                                                'note': 'FETCH_SIZE / WRITE_SIZE: rocprofv3 derived counters in KB, as reported. Calibrated in round 4 (profiles/r04_counter_calibration.md): FETCH_SIZE = TCC_EA0_RDREQ x 64 B whatever the request size, so it halves 128-B requests (coalesced streaming reads) and is exact for the 64-B requests of scattered record gathers; WRITE_SIZE is exact. read_bytes_by_request_size = 128 x RDREQ_128B + 64 x RDREQ_64B + 32 x RDREQ_32B needs no factor'}}
+                                                'read_bytes_by_request_size': (128 * out.get('TCC_EA0_RDREQ_128B_sum', 0) + 64 * out.get('TCC_EA0_RDREQ_64B_sum', 0)
+                                                        + 32 * out.get('TCC_EA0_RDREQ_32B_sum', 0)) if 'TCC_EA0_RDREQ_128B_sum' in out else None,
+                                                'write_bytes_by_request_size': (64 * out.get('TCC_EA0_WRREQ_64B_sum', 0)
+                                                        + 32 * (out.get('TCC_EA0_WRREQ_sum', 0) - out.get('TCC_EA0_WRREQ_64B_sum', 0))) if 'TCC_EA0_WRREQ_sum' in out else None,
+                                                'note': 'FETCH_SIZE / WRITE_SIZE: rocprofv3 derived counters in KB, as reported. Calibrated in round 4 (profiles/r04_counter_calibration.md): '
+                                                        'FETCH_SIZE = TCC_EA0_RDREQ x 64 B whatever the request size, so it halves 128-B requests (coalesced streaming reads) and is exact for the 64-B '
+                                                        'requests of scattered record gathers; WRITE_SIZE is exact. read_bytes_by_request_size = 128 x RDREQ_128B + 64 x RDREQ_64B + 32 x RDREQ_32B '
+                                                        'needs no factor'}}
     res[kname] = out
 res['k_lm_run']['_lm_trials_per_launch'] = d['config']['lm_trials_per_step_per_gpu']; res['k_lm_run']['_kernel_ms'] = d['roofline']['kernel_ms']
 res['k_lm_run']['_derived']['wave_instructions_per_trial'] = res['k_lm_run']['_derived']['wave_instructions_per_launch'] / max(1, d['config']['lm_trials_per_step_per_gpu'])

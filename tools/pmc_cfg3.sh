@@ -6,7 +6,10 @@ R=$PWD; O=$R/gpurun_out/pmc3; mkdir -p $O; rm -rf $O/*
 python bench.py --workload cfg3 --steps 1 --warmup 0 --cpu-seconds 0 > $O/plain.json 2> $O/plain.err
 cd /tmp; export TMPDIR=/tmp
 n=0
-for c in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU" "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_LDS" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do n=$((n+1)); timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O -o p$n -- python $R/bench.py --workload cfg3 --steps 1 --warmup 0 --cpu-seconds 0 > $O/p$n.log 2> $O/p$n.err; done
+for c in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU" \
+	"SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_LDS" \
+	"TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
+	n=$((n+1)); timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O -o p$n -- python $R/bench.py --workload cfg3 --steps 1 --warmup 0 --cpu-seconds 0 > $O/p$n.log 2> $O/p$n.err; done
 cd $R
 python - <<'PY'
 import csv, glob, collections, json

@@ -8,6 +8,8 @@ t=$(mktemp -d); objcopy -O binary --only-section=.hip_fatbin /tmp/qb/probe.o $t/
 import sys, re
 for blk in sys.stdin.read().split("- .agpr_count:")[1:]:
     g = lambda k: (re.search(r"\.%s:\s+(\S+)" % k, blk) or [None, "?"])[1]
-    if "kp_" in g("name") or "k_lm_wg" in g("name") or "k_solve_wg" in g("name"): print("%-60s vgpr %3s sgpr-spill %4s vgpr-spill %4s scratch %5s" % (g("name")[:60], g("vgpr_count"), g("sgpr_spill_count"), g("vgpr_spill_count"), g("private_segment_fixed_size")))
+    if "kp_" in g("name") or "k_lm_wg" in g("name") or "k_solve_wg" in g("name"):
+        print("%-60s vgpr %3s sgpr-spill %4s vgpr-spill %4s scratch %5s" % (g("name")[:60], g("vgpr_count"), g("sgpr_spill_count"), g("vgpr_spill_count"),
+                g("private_segment_fixed_size")))
 ' | c++filt
 rm -rf $t
