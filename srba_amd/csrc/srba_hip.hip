@@ -1351,7 +1351,8 @@ struct srba_hip_ctx {
 		// Cholesky time / flops of the big path since the last upload (sum over the lanes)
 	BigLane lanes[kBigLanes]; int n_lanes_ready = 0; // lane 0 = the context stream and buffers; the others are created on first use
 	bool big_gang = true, big_persistent = false, big_fused_step = true; int big_lanes_max = kBigLanes, big_gang_slots = srbadev::kGang,
-		big_gangs = 2 /* SRBA_HIP_BIG_GANGS: gangs side by side (big_run_class); measured 1: 8 100, 2: 9 000, 3: 5 100, 4: 5 100 LM iterations/s on cfg4 */,
+		big_fresh = 1 /* SRBA_HIP_BIG_FRESH: see big_run_class */,
+		big_gangs = 4 /* SRBA_HIP_BIG_GANGS: gangs side by side (big_run_class); measured 1: 8 100, 2: 9 000, 3: 9 100, 4: 9 350, 5: 9 340, 6: 5 200 LM iterations/s on cfg4 */,
 		sch_xcd = 1 /* SRBA_HIP_SCHUR_XCD: a window's workgroups of kb_schur_reduce_wave on one XCD */, sch_sort = 1 /* SRBA_HIP_SCHUR_SORT: its blocks longest first (0: block order) */,
 		sch_wave = 1 /* SRBA_HIP_SCHUR_WAVE: kb_schur_reduce_wave (a wavefront per U_Ap block) on the multi-workgroup class; 0: a workgroup per block */,
 		gang_from_nb = 0 /* landmark windows with this many block rows
@@ -1578,6 +1579,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_ASSEMBLE_MAX_KB"); if (e) c->asm_max_kb = atoi(e); }            // capsules whose LDS image exceeds this take the unfused kernel (tests)
 	{ const char *e = getenv("SRBA_HIP_ASSEMBLE"); if (e) c->asm_on = atoi(e) != 0; }                   // 0 = srba_hip_linearize always runs the unfused kernel (Jacobian blocks through HBM)
 	{ const char *e = getenv("SRBA_HIP_FLAT"); if (e) c->use_flat = atoi(e) != 0; }                     // 0 = one wavefront per capsule for the stepwise spanning-tree launch
+	{ const char *e = getenv("SRBA_HIP_BIG_FRESH"); if (e) c->big_fresh = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_SCHUR_XCD"); if (e) c->sch_xcd = atoi(e) != 0; } { const char *e = getenv("SRBA_HIP_SCHUR_SORT"); if (e) c->sch_sort = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_SCHUR_WAVE"); if (e) c->sch_wave = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_BIG_GANGS"); if (e && atoi(e) >= 1) c->big_gangs = std::min(atoi(e), kBigLanes); }
@@ -2356,7 +2358,10 @@ static int big_run_class(srba_hip_ctx *c, const int32_t *caps, int count) {
 	// phases of one gang (the panel chains of the factorisation use a few CUs) run under the throughput-bound ones of the others (Schur reduction, Hessian)
 	const int ngang = gang ? std::max(1, std::min(std::min(c->big_gangs, kBigLanes), count)) : 1;
 	const int per_gang = gang ? std::max(1, std::min(c->big_gang_slots, (count + ngang - 1) / ngang)) : 1;
-	const int n = big_prepare_lanes(c, gang ? ngang : (c->big_lanes_max <= 1 ? 1 : std::min(count, c->big_lanes_max))); if (n < 1) return -1;
+	// lane 0 is the context stream; SRBA_HIP_BIG_FRESH=1 keeps the gangs off it: their streams are then created one after the other, and the runtime deals streams to its hardware
+	// queues round-robin -- consecutive streams never share a queue, while the context stream (created long before, dozens of streams ago) may share one with a lane
+	const int l0 = (gang && ngang > 1 && c->big_fresh) ? 1 : 0;
+	const int n = big_prepare_lanes(c, l0 + (gang ? ngang : (c->big_lanes_max <= 1 ? 1 : std::min(count, c->big_lanes_max)))); if (n < 1) return -1;
 	int rc = 0; std::atomic<int> next(0);
 	if (n == 1) { rc = big_gang_run(c, &c->lanes[0], caps, count, next, gang ? c->big_gang_slots : 1); }
 	else {
@@ -2370,8 +2375,8 @@ static int big_run_class(srba_hip_ctx *c, const int32_t *caps, int count) {
 			try { hipSetDevice(c->device); BigLane *ln = &c->lanes[li]; rcs[li] = big_gang_run(c, ln, caps, count, next, per_gang); hipStreamSynchronize(ln->stream); }
 			catch (const std::exception &ex) { rcs[li] = -1; c->lanes[li].error = std::string("large-capsule path: ") + ex.what(); }
 			catch (...) { rcs[li] = -1; c->lanes[li].error = "large-capsule path: unknown exception"; } };
-		try { for (int i = 1; i < n; i++) th.emplace_back(work, i); } catch (...) { /* fewer threads than lanes: the ones that started (and this thread) share the capsules */ }
-		work(0);
+		try { for (int i = l0 + 1; i < n; i++) th.emplace_back(work, i); } catch (...) { /* fewer threads than lanes: the ones that started (and this thread) share the capsules */ }
+		work(l0);
 		for (auto &t : th) t.join();
 		hipEventDestroy(ready);
 		for (int i = 0; i < n; i++) if (rcs[i] != 0 && rc == 0) { rc = -1; c->fail(c->lanes[i].error.empty() ? std::string("large-capsule path failed") : c->lanes[i].error); }

@@ -529,7 +529,7 @@ def test_deep_monocular_window_on_the_big_path_matches_oracle():
 @pytest.mark.gpu
 def test_deep_windows_schur_reduction_forms_and_gang_count_agree(monkeypatch):
     """Round 5, multi-workgroup path: the Schur reduction with a wavefront per U_Ap block (kb_schur_reduce_wave, default) against the workgroup-per-block kernel of rounds 3-4
-    (SRBA_HIP_SCHUR_WAVE=0) -- different summation trees: chi2 to 1e-9 of each other, both within 1e-6 of the oracle -- and one gang against two gangs side by side
+    (SRBA_HIP_SCHUR_WAVE=0) -- different summation trees: chi2 to 1e-9 of each other, both within 1e-6 of the oracle -- and one gang against two and four gangs side by side
     (SRBA_HIP_BIG_GANGS): a window's numbers do not depend on which gang it ran in, bit for bit. Four deep monocular windows of different sizes."""
     ds, _ = datasets.mono_deep_window(n_kf=100, n_lm=2000, seed=1)
     eng = runner.landmark_engine("mono", backend=_oracle.BACKEND, depth=8, submap=20, sigma=0.5, robust=0, harvest=1, cam=(200., 200., 400., 320.), refresh_all_read_poses=2)
@@ -538,10 +538,11 @@ def test_deep_windows_schur_reduction_forms_and_gang_count_agree(monkeypatch):
     def run(wave, gangs):
         monkeypatch.setenv("SRBA_HIP_SCHUR_WAVE", wave); monkeypatch.setenv("SRBA_HIP_BIG_GANGS", gangs)
         ctx = runner.HipContext(sub.params); ctx.upload(sub); out = ctx.lm_run(); ctx.close(); return out
-    w1g1, w1g2, w0g1 = run("1", "1"), run("1", "2"), run("0", "1")
+    w1g1, w1g2, w1g4, w0g1 = run("1", "1"), run("1", "2"), run("1", "4"), run("0", "1")
     monkeypatch.delenv("SRBA_HIP_SCHUR_WAVE"); monkeypatch.delenv("SRBA_HIP_BIG_GANGS")
-    for k in w1g1:
-        assert np.array_equal(np.nan_to_num(np.asarray(w1g1[k], float), nan=-1.0), np.nan_to_num(np.asarray(w1g2[k], float), nan=-1.0)), k
+    for other in (w1g2, w1g4):
+        for k in w1g1:
+            assert np.array_equal(np.nan_to_num(np.asarray(w1g1[k], float), nan=-1.0), np.nan_to_num(np.asarray(other[k], float), nan=-1.0)), k
     for out in (w1g1, w0g1):
         assert np.all(out["status"] == 0) and _close(out["chi2_init"], ref["chi2_init"], rel=1e-9) and _close(out["chi2_final"], ref["chi2_final"], rel=1e-6)
     assert _close(w1g1["chi2_final"], w0g1["chi2_final"], rel=1e-9)
