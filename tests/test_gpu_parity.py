@@ -76,14 +76,14 @@ def _compare_lm(b, gpu, cpu):
 @pytest.mark.gpu
 def test_lean_instantiation_of_the_small_classes_matches_oracle(se2_batch, monkeypatch):
     """k_lm_run_lean (round 4: three wavefronts per SIMD, fewer loads in flight per lane; what a big batch runs its small size classes on) forced onto every class it can take of this batch:
-    the same parity statements as k_lm_run, and the two kernels within rounding of each other."""
+    the same parity statements (decision replay against the oracle) for it and for k_lm_run on the same batch, and the two kernels within rounding of each other."""
     b = se2_batch
     monkeypatch.setenv("SRBA_HIP_LEAN_MIN_COUNT", "1"); lean = runner.run_batch_hip(b)
     monkeypatch.setenv("SRBA_HIP_LEAN", "0"); plain = runner.run_batch_hip(b)
     cpu = _oracle.run_batch(b)
     _compare_lm(b, lean, cpu)
     assert _close(lean["chi2_final"], plain["chi2_final"], rel=1e-9, abs_=1e-20) and _close(lean["chi2_init"], plain["chi2_init"], rel=1e-12)
-    assert (lean["num_trials"] == plain["num_trials"]).mean() > 0.7
+    _compare_lm(b, plain, cpu)   # (both kernels carry the exact statement -- decision replay -- on their own; how often their trial counts coincide is not asserted)
 
 
 @pytest.mark.gpu
