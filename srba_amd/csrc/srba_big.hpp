@@ -30,6 +30,8 @@ struct BigSys { double *A; double *Ldiag; double *rhs; double *y; int *flag; int
 constexpr int kGang = 32, kBigPart = 4096;
 struct Gang { int p[kGang]; int ld[kGang]; int nsys[kGang]; double *A[kGang]; unsigned mask; int n; double *part; double *scal; int *iscal; };
 enum { BS_CHI2 = 0, BS_MAXDIAG = 1, BS_DEN = 2, BS_NINF = 3, BS_LAMBDA = 4 }; // scal[w * 16 + .]; iscal[w * 8 + .] = {invalid Jacobians, not-positive-definite flag}
+struct GangLambda { double v[kGang]; };
+#ifndef SRBA_BIG_DECLS_ONLY /* (srba_hip.hip sizes buffers with the constants above; the device code below belongs to srba_big.hip) */
 __device__ __forceinline__ BigSys gang_sys(const Gang &G, int w) {
 	BigSys S; const int ld = G.ld[w]; S.A = G.A[w]; S.Ldiag = S.A + (size_t)ld * ld; S.rhs = S.Ldiag + (size_t)ld * CB; S.y = S.rhs + ld; S.flag = G.iscal + w * 8 + 1; S.n = G.nsys[w]; S.ld = ld;
 		return S;
@@ -642,7 +644,6 @@ __global__ void __launch_bounds__(256) kb_reduce(const Batch B, const Gang G, in
 	__syncthreads();
 	if (threadIdx.x == 0) *out = is_max ? fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3])) : (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
-struct GangLambda { double v[kGang]; };
 __global__ void kb_set_lambda(const Gang G, const GangLambda lam) { const int w = threadIdx.x; if (w < kGang && ((G.mask >> w) & 1u)) G.scal[w * 16 + BS_LAMBDA] = lam.v[w]; }
 // what the host path did with device-to-device copies, for all windows of a gang at once: 0 = grad0 -> grad, 1 = grad -> grad0 (extension: the Schur kernels reduce grad in place),
 	// 2 = residuals of the accepted trial -> current
@@ -927,4 +928,5 @@ template <int FAM> __global__ void __launch_bounds__(128) kb_cov_recovery(const 
 	}
 }
 
+#endif // SRBA_BIG_DECLS_ONLY
 } // namespace srbadev

@@ -14,6 +14,7 @@
 namespace srbadev {
 
 struct FlatMap { int *pair; long long n_pair; };
+#ifndef SRBA_FLAT_DECLS_ONLY /* (srba_big.hip needs the record only: it is a member of the context) */
 
 // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): consecutive LOGICAL workgroups -- which share a capsule's poses, Jacobians and term lists --
 // are mapped onto workgroup ids of the same XCD, so that a capsule's data is fetched into one L2 instead of up to eight.
@@ -71,4 +72,5 @@ template <int FAM> __global__ void __launch_bounds__(256) kf_spantree(const Batc
 		}
 	}
 }
+#endif // SRBA_FLAT_DECLS_ONLY
 } // namespace srbadev

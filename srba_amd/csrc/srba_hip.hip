@@ -1098,6 +1098,7 @@ template void probe_instantiate<SRBA_PROBE_KERNELS>();
 #endif
 
 } // namespace srbadev
+#define SRBA_BIG_DECLS_ONLY /* the kernels of srba_big.hpp are compiled in srba_big.hip: here only its constants and records */
 #include "srba_big.hpp"
 #include "srba_flat.hpp"
 #include "srba_assemble.hpp"
@@ -1132,39 +1133,9 @@ template <int FAM> __global__ void __launch_bounds__(256) k_overall_residuals(co
 } // namespace srbadev
 
 // =================================================================================================== host side
-namespace {
-
-struct FamDims { int P, L, O, PD; int PDX() const { return PD == 3 ? 5 : PD; } }; // PDX: device pose stride (SE2: [x y phi cos sin])
-const FamDims kDims[SRBA_NUM_FAMILIES] = {{3, 3, 3, 3}, {3, 2, 2, 3}, {3, 2, 2, 3}, {6, 3, 4, 12}, {6, 3, 2, 12}, {6, 3, 3, 12}, {6, 3, 3, 12}, {6, 6, 6, 12}, {3, 3, 4, 3}};
-// every model family the kernels are instantiated for
-#ifdef SRBA_ONLY_RELPOSE2D /* experiment builds (tools/quick_build.sh): only the headline family is instantiated, the unit compiles in a fraction of the time; other families are rejected at run time */
-#define SRBA_ALL_FAMILIES(X) X(SRBA_SE2_RELPOSE2D)
-#elif defined(SRBA_ONLY_FAMILY) /* ... or any one family: -DSRBA_ONLY_FAMILY=SRBA_SE3_STEREO */
-#define SRBA_ALL_FAMILIES(X) X(SRBA_ONLY_FAMILY)
-#else
-#define SRBA_ALL_FAMILIES(X) X(SRBA_SE2_RELPOSE2D) X(SRBA_SE2_RB2D) X(SRBA_SE2_CART2D) X(SRBA_SE3_STEREO) X(SRBA_SE3_MONO) X(SRBA_SE3_CART3D) X(SRBA_SE3_RB3D) X(SRBA_SE3_RELPOSE3D) X(SRBA_SE2_STEREO)
-#endif
+#include "srba_ctx.hpp"
 thread_local std::string g_last_error;
 
-struct Arena { // layout builder: 256-byte aligned sub-allocations inside one buffer
-	size_t size = 0;
-	size_t add(size_t bytes) { const size_t off = (size + 255) & ~size_t(255); size = off + bytes; return off; }
-};
-
-#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->fail(std::string(#call) + ": " + hipGetErrorString(e_)); return -1; } } while (0)
-#define LNCHK(lane, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (lane)->error = std::string(#call) + ": " + hipGetErrorString(e_); return -1; } } while (0)
-static const int kBigLanes = 16;
-struct BigLane { int id = 0, slots = 1 /* windows its buffers have room for (srbadev::Gang) */; hipStream_t stream = nullptr; double *d_part = nullptr, *d_scal = nullptr;
-	int *d_iscal = nullptr /* behind the scalars in the same allocation: one copy reads both back */; void *h_fetch = nullptr /* page-locked landing buffer of that copy */; hipEvent_t e0 = nullptr,
-	e1 = nullptr; double chol_ms = 0, chol_flops = 0; long long chol_count = 0, chol_seqs = 0; int chol_nmax = 0; std::string error; };
-
-} // namespace
-
-#define SRBA_NLDS 19        /* LDS size classes (6 KB ... 152 KB per wavefront) of the one-wavefront kernels */
-#define SRBA_CLS_WG128 19   /* landmark windows on a workgroup of two wavefronts (k_lm_wg<FAM, 128>), four workgroups per CU: at most 40 KB of LDS each */
-#define SRBA_CLS_WG256 20   /* ... of four wavefronts, two per CU: at most 80 KB */
-#define SRBA_CLS_WG512 21   /* ... of eight wavefronts, one per CU: the windows whose U_Ap blocks need up to 159 KB of LDS */
-#define SRBA_NCLS 23        /* + the last class: systems factored by the multi-workgroup path (srba_big.hpp) */
 // Symbolic block factorisation of one capsule's system (natural block order): the numeric kernel never discovers structure.
 struct Symbolic { std::vector<int32_t> fill; std::vector<int32_t> col_off, row, item_off, tgt, ab, rptr, rcol, rblk, perm, hap_dst, hapf_dst, hf_dst; int max_cn = 0; bool aligned = true; };
 static void symbolic_factor(const srba_problem_capsule &k, const ProbDesc &d, int P, int L, bool full_system, Symbolic &out) {
@@ -1276,10 +1247,6 @@ static void symbolic_dense(const srba_problem_capsule &k, const ProbDesc &d, int
 	for (size_t u = 0; u < covered.size(); u++) if (!covered[u]) out.fill.push_back((int32_t)u);
 }
 
-struct LaunchJob { int queue, cls, first, count; double cost; int grid; int delay_us = 0; int lean = 0 /* k_lm_run_lean: three wavefronts per SIMD */,
-	two = 0 /* k_lm_run2: two wavefronts per capsule */; };
-using srbadev::kBigPart;
-static const int kMaxJobs = 1024;
 
 // Index-range check of one capsule (every index the kernels dereference): a wrong capsule is reported at upload instead of reading out of bounds on the device
 static const char *validate_capsule(const srba_problem_capsule &k) {
@@ -1335,64 +1302,6 @@ static const char *validate_capsule(const srba_problem_capsule &k) {
 // first element of slice q when cnt items are dealt round-robin to nq slices
 static inline int slice_begin(int cnt, int q, int nq) { return q * (cnt / nq) + std::min(q, cnt % nq); }
 
-struct srba_hip_ctx {
-	int device = 0; srba_hip_params params; DevParams dp; FamDims dm;
-	hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
-	static constexpr int kRing = 64; hipEvent_t ring0[kRing] = {nullptr}, ring1[kRing] = {nullptr}; long long n_launches = 0; // event pairs of the last launches (srba_hip_kernel_ms_history)
-	hipStream_t cls_stream[SRBA_NCLS] = {nullptr}; hipEvent_t ev_fork = nullptr, cls_done[SRBA_NCLS] = {nullptr}; // size classes run concurrently
-	std::string error;
-	// batch
-	int n_prob = 0; std::vector<ProbDesc> desc; Batch B; srba_batch_stats stats;
-	char *d_in = nullptr; size_t cap_in = 0; char *d_wk = nullptr; size_t cap_wk = 0; int *d_next = nullptr; Batch *d_batch = nullptr; bool batch_copied = false;
-		// d_batch: device copy of B (the workgroup kernels read the batch's pointers from it)
-	double *d_part = nullptr; double *d_scal = nullptr; int *d_iscal = nullptr; // big path: partial sums [3][kBigPart], scalars, int flags (ninv, not-pd)
-	std::vector<int> big_ld; // per capsule: leading dimension of its dense system when it runs on the big path, else 0
-	double big_chol_ms = 0, big_chol_flops = 0; long long big_chol_count = 0, big_chol_seqs = 0 /* launch sequences: one factors all windows of a gang */; int big_chol_nmax = 0;
-		// Cholesky time / flops of the big path since the last upload (sum over the lanes)
-	BigLane lanes[kBigLanes]; int n_lanes_ready = 0; // lane 0 = the context stream and buffers; the others are created on first use
-	bool big_gang = true, big_persistent = false, big_fused_step = true; int big_lanes_max = kBigLanes, big_gang_slots = srbadev::kGang,
-		big_fresh = 1 /* SRBA_HIP_BIG_FRESH: see big_run_class */,
-		big_gangs = 4 /* SRBA_HIP_BIG_GANGS: gangs side by side (big_run_class); measured 1: 8 100, 2: 9 000, 3: 9 100, 4: 9 350, 5: 9 340, 6: 5 200 LM iterations/s on cfg4 */,
-		sch_xcd = 1 /* SRBA_HIP_SCHUR_XCD: a window's workgroups of kb_schur_reduce_wave on one XCD */, sch_sort = 1 /* SRBA_HIP_SCHUR_SORT: its blocks longest first (0: block order) */,
-		sch_wave = 1 /* SRBA_HIP_SCHUR_WAVE: kb_schur_reduce_wave (a wavefront per U_Ap block) on the multi-workgroup class; 0: a workgroup per block */,
-		gang_from_nb = 0 /* landmark windows with this many block rows
-		or more take the gang instead of one wavefront (0: off) */; // big path: windows of a batch in lock-step on one stream (gang) or one host thread + stream per window
-	int upload_threads = 1; bool dense_left = true; int hbm_from_kb = 48; bool dense_blocks_ok = true; // mid-size nearly-full systems use the dense block layout in LDS
-	bool lin_terms = true, lm_terms = true; // term-parallel U_Ap accumulation in LDS: srba_hip_linearize / the fused LM kernel
-	// fused normal equations of the relative-pose SE2 family (srba_assemble.hpp): capsules packed into bins (workgroups) by the LDS image they need, one launch; the rest take k_linearize
-	bool asm_on = true, asm_ready = false, asm_flags_set = false, jp_stale = false; size_t off_valid = 0, off_bp_ok = 0; long long n_valid_total = 0, n_bp_total = 0;
-		int asm_max_kb = srbadev::ASM_BIN_BYTES / 1024; srbadev::AsmTables asm_tab = {nullptr, nullptr, nullptr}; const int *asm_list = nullptr;
-	int asm_bins = 0, asm_rest = 0; // bins of the fused launch; capsules left to the unfused kernel (asm_list holds their indices)
-	srbadev::FlatMap flat; bool flat_ready = false, use_flat = true; // pair -> capsule map of the flat spanning-tree kernel (srba_flat.hpp), filled on first use after an upload
-	int big_min_sys = 480;   // systems with more scalar unknowns than this skip the block-sparse symbolic analysis and go dense (big path)
-	struct Staging { char *p = nullptr; bool pinned = false; char *get() const { return p; } void release() { if (p) { if (pinned) hipHostFree(p); else delete[] p; } p = nullptr; } } h_in;
-		size_t h_in_cap = 0; size_t h_off_order = 0; // host staging of the input arena (kept: the launch order is read back from it); page-locked while it is small (the per-key-frame use: the copy
-		// to the device then needs no wait)
-	static constexpr size_t kPinnedMax = (size_t)8 << 20; hipEvent_t ev_h2d = nullptr; bool h2d_pending = false, defer_upload_sync = false; // optimize_capsule: the upload is not waited for;
-		// the next writer of the staging buffer waits for this event
-	char *h_out = nullptr; size_t h_out_cap = 0; // page-locked landing area of srba_hip_optimize_capsule (result record | unknowns .. spanning-tree poses)
-	std::vector<int> delay_us; int class_prio = 0; // experiment knobs: per plan job delay before its launch (overrides the staggered start); stream priorities by class size
-	int stagger_ns = 300, stagger_max_us = 5000; // staggered start of the class launches: see plan_launches
-	// lambda-ladder speculation for a batch of ONE capsule (k_lm_spec): spec_w replicas of the work arena, spec_stride bytes apart; d_spec = flags | outcomes | increments (SpecCtl)
-	long long spec_launches = 0; bool spec_on = true, spec_ready = false; int spec_w = 12; size_t spec_stride = 0; char *d_spec = nullptr; static constexpr int kSpecMaxW = 32, kSpecMaxN = 768;
-		static constexpr size_t kSpecBackupOff = 256 + 8 * (2 * kSpecMaxW * 4) + 8 * (2 * (size_t)kSpecMaxW * kSpecMaxN), kSpecBytes = kSpecBackupOff + 8 * 5 * (size_t)kSpecMaxN;
-		bool spec_suppress = false, spec_test_drop = false; long long spec_fallbacks = 0;
-	bool wg_hs = true; /* SRBA_HIP_WG_HS=0: U_Ap blocks of the workgroup windows in memory (the first version of the path) instead of in LDS */
-	bool wg_on = true; int wg_from_sys = 24, wg256_from_sys = 96; // SE3 landmark windows with a Schur-reduced system of at least wg_from_sys scalars run on a workgroup (k_lm_wg: 128 threads,
-		// 256 from wg256_from_sys); SRBA_HIP_WG=0 / SRBA_HIP_WG_FROM / SRBA_HIP_WG256_FROM
-	bool two_on = true; int two_from_kb = 20, two_min_count = 128; // k_lm_run2 (two wavefronts per capsule) for the relative-pose SE2 classes whose LDS image is at least this big
-	bool lean_on = true; int lean_min_count = 512; // k_lm_run_lean for the size classes of which at least nine wavefronts fit the LDS of a CU (relative-pose SE2,
-		// classes with at least this many capsules)
-	int max_lds_kb = 1 << 20, min_chunk = 384, max_parts_per_queue = 2; int class_streams = 64 /* sched 3: the class launches are dealt round-robin to at most this many streams */, n_queues = 16,
-		sched = 3, n_streams_used = 1, n_cu = 256, waves_per_cu = 8, lds_per_cu = 160 * 1024; std::vector<LaunchJob> plan; size_t lds_pad = 0; double last_ms = 0; int cls_first[SRBA_NCLS] = {0},
-		cls_count[SRBA_NCLS] = {0}; size_t cls_lds[SRBA_NCLS] = {0};
-	// offsets needed for downloads (bytes inside the wk arena)
-	size_t off_edge = 0, off_ulm = 0, off_pose = 0, off_inf = 0, off_infv = 0, off_res = 0;
-	size_t off_dbg[10] = {0}; int64_t len_dbg[10] = {0};
-	size_t in_off_edge0 = 0, in_off_ulm0 = 0; long long tot_edge = 0, tot_ulm = 0;
-	size_t off_phase = 0; bool phase_timing = false; long long n_pose_total = 0; std::vector<int> cls_of;
-	void fail(const std::string &m) { error = m; g_last_error = m; }
-};
 // Launch plan of the fused LM kernel. Every size class is one or more launches (a launch has ONE dynamic-LDS size); the HIP runtime
 // multiplexes streams onto 4 hardware queues and kernels of one queue run in order, so the plan uses n_queues streams and decides what
 // shares the chip at any time. Small capsules are wave-slot bound (VGPRs), big ones LDS bound: running them side by side fills both.
@@ -2063,16 +1972,6 @@ int srba_hip_batch_stats(srba_hip_ctx *c, srba_batch_stats *out) { if (!c || !ou
 
 } // extern "C"
 
-// ---- launch helpers
-// family id -> template argument: f(std::integral_constant<int, FAM>()) for the family of the context
-template <class F> static bool with_family(int family, F &&f) {
-	switch (family) {
-#define X(FAM) case FAM: f(std::integral_constant<int, FAM>()); return true;
-		SRBA_ALL_FAMILIES(X)
-#undef X
-	}
-	return false;
-}
 #define SRBA_DISPATCH_N(c, KERNEL, nblocks, lds, ...) with_family((c)->params.family, [&](auto fam_) { \
 	hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), dim3(nblocks), dim3(SRBA_WG), (lds), (c)->stream, (c)->B, (c)->dp, ##__VA_ARGS__); })
 #define SRBA_DISPATCH(c, KERNEL, lds, ...) SRBA_DISPATCH_N(c, KERNEL, (c)->n_prob, lds, ##__VA_ARGS__)
@@ -2100,293 +1999,6 @@ static int prep_lds(srba_hip_ctx *c, bool for_lm) {
 __attribute__((constructor)) static void srba_hip_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 
-// =================================================================================================== the multi-workgroup path for large capsules (srba_big.hpp)
-static inline int big_grid(long long items, int block) { return (int)std::max<long long>(1, std::min<long long>((items + block - 1) / block, 4096)); }
-// The LM loop of a large capsule is driven from the host. Since round 4 a batch that holds several such capsules runs them as a GANG in lock-step (big_gang_run): every
-// grid-wide phase is ONE launch for all windows that need it (blockIdx.y = slot of the gang, srbadev::Gang::mask = who takes part), the host reads the scalars of all
-// windows back with one stream synchronisation per phase group and walks the control flow of optimize_edges.h:454-696 for each window on its own; a window that finishes
-// hands its slot to the next capsule of the class. The ~60 short dependent launches of a factorisation are shared by up to 16 windows instead of being queued 16 times.
-// SRBA_HIP_BIG_GANG=0 selects the earlier scheme: up to kBigLanes host threads, each driving a gang of one on its own stream with its own scalar / partial-sum buffers.
-using srbadev::BS_CHI2; using srbadev::BS_MAXDIAG; using srbadev::BS_DEN; using srbadev::BS_NINF; using srbadev::BS_LAMBDA;
-static void gang_set(srba_hip_ctx *c, srbadev::Gang &G, int w, int p) {
-	const ProbDesc &d = c->desc[p]; G.p[w] = p; G.ld[w] = c->big_ld[p]; G.nsys[w] = d.n_sys; G.A[w] = c->B.dense + d.o_dense; G.n = std::max(G.n, w + 1);
-}
-static srbadev::Gang gang_of(const BigLane *ln) { srbadev::Gang G; std::memset(&G, 0, sizeof(G)); G.part = ln->d_part; G.scal = ln->d_scal; G.iscal = ln->d_iscal; return G; }
-static srbadev::Gang gang_masked(const srbadev::Gang &G, unsigned mask) { srbadev::Gang H = G; H.mask = mask; return H; }
-// grid of a gang launch: x = the largest grid any participating window would have alone, y = slots
-template <class ItemsF> static dim3 gang_grid(srba_hip_ctx *c, const srbadev::Gang &G, int block, bool one_workgroup_per_item, ItemsF &&items) {
-	long long gx = 1; int gy = 1;
-	for (int w = 0; w < G.n; w++) if ((G.mask >> w) & 1u) { const long long it = items(c->desc[G.p[w]], w); gx = std::max<long long>(gx, one_workgroup_per_item ? std::max<long long>(1,
-		it) : big_grid(it, block)); gy = w + 1; }
-	return dim3((unsigned)gx, (unsigned)gy);
-}
-#define BIGKG(KERNEL, ITEMS, block, ...) do { if (G.mask) with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), gang_grid(c, G, \
-	(block), true, [&](const ProbDesc &d, int) -> long long { return (ITEMS); }), dim3(block), 0, st, c->B, c->dp, G, ##__VA_ARGS__); }); } while (0)
-#define BIGK(KERNEL, ITEMS, block, ...) do { if (G.mask) with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::KERNEL<decltype(fam_)::value>), gang_grid(c, G, \
-	(block), false, [&](const ProbDesc &d, int) -> long long { return (ITEMS); }), dim3(block), 0, st, c->B, c->dp, G, ##__VA_ARGS__); }); } while (0)
-// deterministic reduction of per-workgroup partials into scal[slot] of every participating window
-static void big_reduce(srba_hip_ctx *c, hipStream_t st, const srbadev::Gang &G, int which, int kind, int slot, int is_max) { if (G.mask) hipLaunchKernelGGL(srbadev::kb_reduce, dim3(1, G.n),
-	dim3(256), 0, st, c->B, G, which, kind, slot, is_max); }
-static bool big_schur(const srba_hip_ctx *c, const ProbDesc &d) { return c->params.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL && d.nF > 0 && d.nK > 0; }
-static unsigned gang_schur_mask(srba_hip_ctx *c, const srbadev::Gang &G) { unsigned m = 0; for (int w = 0; w < G.n; w++) if (((G.mask >> w) & 1u) && big_schur(c, c->desc[G.p[w]])) m |= 1u << w;
-	return m; }
-static void big_copy_vec(srba_hip_ctx *c, hipStream_t st, const srbadev::Gang &G, int kind) {
-	if (!G.mask) return;
-	hipLaunchKernelGGL(srbadev::kb_copy_vec, gang_grid(c, G, 256, false, [&](const ProbDesc &d, int) -> long long { return kind == 2 ? (long long)d.n_obs * c->dm.O : d.n_scal; }), dim3(256), 0, st,
-		c->B, G, kind, c->dm.O);
-}
-static void big_set_lambda(hipStream_t st, const srbadev::Gang &G, const srbadev::GangLambda &lam) { if (G.mask) hipLaunchKernelGGL(srbadev::kb_set_lambda, dim3(1), dim3(64), 0, st, G, lam); }
-// solve(lambda) of lev-marq_solvers.h for the windows of G.mask, lambda in scal[BS_LAMBDA] of each: (a) Schur reduction (if the solver has one) + dense assembly,
-// (b) blocked Cholesky, (c) back-substitution + landmark increments. The not-positive-definite verdict of a window stays in its device flag.
-static void big_enqueue_assemble(srba_hip_ctx *c, hipStream_t st, const srbadev::Gang &Gall) {
-	const int P = c->dm.P;
-	{ const srbadev::Gang G = gang_masked(Gall, gang_schur_mask(c, Gall));
-	  BIGK(kb_schur_inv, std::max<long long>(d.nF, (long long)d.n_hap * P * P), 128); if (c->sch_wave) { int gy = 0; for (int w = 0; w < G.n; w++) if ((G.mask >> w) & 1u) gy = w + 1; /* = the grid's y (gang_grid) */
-	    BIGKG(kb_schur_reduce_wave, (d.n_vb + 3) / 4, 256, (c->sch_xcd && gy % 8 == 0) ? 1 : 0); } else BIGKG(kb_schur_reduce, d.n_hap, 256);
-	  BIGKG(kb_schur_grad, d.nK, 256); }
-	if (!Gall.mask) return;
-	hipLaunchKernelGGL(srbadev::kb_dense_clear, gang_grid(c, Gall, 256, false, [&](const ProbDesc &, int w) -> long long { return (long long)Gall.ld[w] * Gall.ld[w]; }), dim3(256), 0, st, Gall);
-	const unsigned ms = gang_schur_mask(c, Gall);
-	{ const srbadev::Gang G = gang_masked(Gall, ms); BIGK(kb_dense_assemble, d.n_hap + d.n_hapf + d.n_hf, 128, 0); }
-	{ const srbadev::Gang G = gang_masked(Gall, Gall.mask & ~ms); BIGK(kb_dense_assemble, d.n_hap + d.n_hapf + d.n_hf, 128, 1); }
-}
-static srbadev::BigSys big_sys(const srbadev::Gang &G, int w) { srbadev::BigSys S; const int ld = G.ld[w]; S.A = G.A[w]; S.Ldiag = S.A + (size_t)ld * ld; S.rhs = S.Ldiag + (size_t)ld * srbadev::CB;
-	S.y = S.rhs + ld; S.flag = G.iscal + w * 8 + 1; S.n = G.nsys[w]; S.ld = ld; return S; }
-static void big_enqueue_cholesky(srba_hip_ctx *c, hipStream_t st, const srbadev::Gang &G) {
-	if (!G.mask) return;
-	int ldmax = 0, nw = 0, w1 = 0; for (int w = 0; w < G.n; w++) if ((G.mask >> w) & 1u) { ldmax = std::max(ldmax, G.ld[w]); nw++; w1 = w; }
-	if (c->big_persistent && nw == 1) { // the whole factorisation in one launch: panel steps and trailing updates separated by grid barriers (srba_big.hpp, k_chol_persistent); one window per launch
-		const srbadev::BigSys S = big_sys(G, w1);
-		const int below0 = S.ld - srbadev::CB, nt0 = below0 > 0 ? (below0 + srbadev::CT - 1) / srbadev::CT : 0, resident = 4 * c->n_cu / std::max(1,
-			c->n_lanes_ready) /* the grid barriers need every workgroup of every window in flight resident: 4 workgroups per CU (34 KB of LDS, 256 threads each) shared by the lanes */,
-		          Gn = std::max(1, std::min(std::min(120, resident), std::max(nt0 * (nt0 + 1) / 2, 1 + (below0 > 0 ? (below0 + 63) / 64 : 0))));
-		unsigned *bar = (unsigned *)(G.iscal + w1 * 8 + 4);
-		(void)hipMemsetAsync(bar, 0, 4, st);
-		hipLaunchKernelGGL(srbadev::k_chol_persistent, dim3(Gn), dim3(256), 0, st, S, bar);
-		return;
-	}
-	if (c->big_fused_step) { // one launch per 32 columns: the panel step and, beside it, the trailing update of the step before (srba_big.hpp, k_chol_step)
-		for (int k0 = 0; k0 < ldmax; k0 += srbadev::CB) { const int below = ldmax - k0 - srbadev::CB, nt = below > 0 ? (below + srbadev::CT - 1) / srbadev::CT : 0;
-			hipLaunchKernelGGL(srbadev::k_chol_step, dim3(1 + (below + 63) / 64 + (k0 > 0 ? nt * (nt + 1) / 2 : 0), G.n), dim3(256), 0, st, G, k0); }
-		return;
-	}
-	for (int k0 = 0; k0 < ldmax; k0 += srbadev::CB) { // windows smaller than the largest of the gang drop out of the later steps inside the kernels
-		const int below = ldmax - k0 - srbadev::CB;
-		hipLaunchKernelGGL(srbadev::k_chol_panel, dim3(1 + (below + 63) / 64, G.n), dim3(64), 0, st, G, k0);
-		if (below > 0) { const int nt = (below + srbadev::CT - 1) / srbadev::CT; hipLaunchKernelGGL(srbadev::k_chol_update, dim3(nt * (nt + 1) / 2, G.n), dim3(256), 0, st, G, k0); }
-	}
-}
-static void big_enqueue_backsub(srba_hip_ctx *c, hipStream_t st, const srbadev::Gang &Gall) {
-	if (!Gall.mask) return;
-	hipLaunchKernelGGL(srbadev::k_chol_bsub, dim3(1, Gall.n), dim3(256), 0, st, Gall);
-	hipLaunchKernelGGL(srbadev::kb_take_delta, gang_grid(c, Gall, 256, false, [&](const ProbDesc &d, int) -> long long { return d.n_scal; }), dim3(256), 0, st, c->B, Gall);
-	{ const srbadev::Gang G = gang_masked(Gall, gang_schur_mask(c, Gall)); BIGK(kb_schur_features, d.nF, 128, 1); }
-}
-static int big_timed_cholesky(srba_hip_ctx *c, BigLane *ln, const srbadev::Gang &G) {
-	if (!ln->e0) { LNCHK(ln, hipEventCreate(&ln->e0)); LNCHK(ln, hipEventCreate(&ln->e1)); }
-	LNCHK(ln, hipEventRecord(ln->e0, ln->stream));
-	big_enqueue_cholesky(c, ln->stream, G);
-	LNCHK(ln, hipEventRecord(ln->e1, ln->stream));
-	return 0;
-}
-static void big_account_cholesky(srba_hip_ctx *c, BigLane *ln, const srbadev::Gang &G) { // after a stream synchronisation; chol_ms is the time of the launch sequence,
-	// shared by the windows of the gang
-	float ms = 0;
-	if (hipEventElapsedTime(&ms, ln->e0, ln->e1) == hipSuccess) { ln->chol_ms += ms; ln->chol_seqs++; for (int w = 0; w < G.n; w++) if ((G.mask >> w) & 1u) { const double ld = G.ld[w];
-		ln->chol_flops += ld * ld * ld / 3.0; ln->chol_count++; ln->chol_nmax = std::max(ln->chol_nmax, G.nsys[w]); } }
-}
-static int big_solve(srba_hip_ctx *c, BigLane *ln, int p, double lambda, bool *pos_def) { // the stepwise entry point (srba_hip_solve)
-	hipStream_t st = ln->stream; srbadev::Gang G = gang_of(ln); gang_set(c, G, 0, p); G.mask = 1u;
-	{ srbadev::GangLambda lam; std::memset(&lam, 0, sizeof(lam)); lam.v[0] = lambda; big_set_lambda(st, G, lam); }
-	{ const ProbDesc &d = c->desc[p]; // (extension) start from the gradient as srba_hip_linearize left it
-	  if ((c->params.extensions & SRBA_EXT_SCHUR_KEEPS_GRADIENT) && big_schur(c, d)) big_copy_vec(c, st, G, 0); }
-	big_enqueue_assemble(c, st, G);
-	if (big_timed_cholesky(c, ln, G) != 0) return -1;
-	big_enqueue_backsub(c, st, G);
-	int flag = 0; LNCHK(ln, hipMemcpyAsync(&flag, ln->d_iscal + 1, 4, hipMemcpyDeviceToHost, ln->stream)); LNCHK(ln, hipStreamSynchronize(ln->stream));
-	big_account_cholesky(c, ln, G);
-	if (flag == 2) { ln->error = "k_chol_persistent: a grid barrier timed out (the workgroups of the factorisation were not all resident)"; return -1; }
-	*pos_def = (flag == 0);
-	LNCHK(ln, hipGetLastError());
-	return 0;
-}
-// optimize_edges S5..S17 for the large capsules caps[next++ ...]: the control flow of k_lm_run (optimize_edges.h:256-751) on the host for up to `nslots` windows at once,
-// every phase a grid-wide launch over the windows that are at that point of their loop. `ln` supplies the stream and buffers with room for nslots slots.
-namespace {
-enum { GS_IDLE = 0, GS_NEW, GS_TRIAL, GS_ACCEPT, GS_FINAL };
-struct GangSlot {
-	int p = -1, st = GS_IDLE; bool schur = false, keep_g = false, s11 = false, relin = false, restore = false, stop = false;
-	srba_lm_result out; double lambda = 0, nu = 2, total_err = 0, RMSE = 0, rho = 0, new_err = 0, new_RMSE = 0; int iter = 0, trials = 0, tr = 0, n_notpd = 0, n_acc = 0, n_relin = 0, stopmask = 0;
-};
-}
-// host control flow of one window from the head of the inner loop (`while (rho <= 0 && !stop)`) to its next trial or to the end of the run
-static void gang_advance(const srba_hip_params &prm, GangSlot &s, bool from_iter_head) {
-	for (;;) {
-		if (!from_iter_head) {
-			if (s.rho <= 0 && !s.stop) { s.tr = s.trials++; if (s.tr < SRBA_TRACE_LEN) s.out.trace_lambda[s.tr] = s.lambda; s.out.lambda_last_trial = s.lambda; s.st = GS_TRIAL; return; }
-			s.iter++;
-		}
-		from_iter_head = false;
-		if (!(s.iter < prm.max_iters && !s.stop)) { if (!s.stop) s.stopmask |= 1 << SRBA_STOP_MAX_ITERS; s.st = GS_FINAL; return; }
-		s.rho = 0;
-		if (s.lambda >= prm.max_lambda) { s.stop = true; s.stopmask |= 1 << SRBA_STOP_LAMBDA; }
-		if (s.RMSE < prm.max_error_per_obs_to_stop) { s.stop = true; s.stopmask |= 1 << SRBA_STOP_RMSE; }
-	}
-}
-static int big_gang_run(srba_hip_ctx *c, BigLane *ln, const int32_t *caps, int count, std::atomic<int> &next, int nslots) {
-	const int O = c->dm.O, L = c->dm.L; const srba_hip_params &prm = c->params; hipStream_t st = ln->stream;
-	nslots = std::max(1, std::min(nslots, ln->slots));
-	std::vector<GangSlot> S(nslots); std::vector<std::unique_ptr<srba_lm_result>> results; // result records stay alive until the last copy has been waited for
-	struct WaitOnExit { hipStream_t s; ~WaitOnExit() { (void)hipStreamSynchronize(s); } } wait_on_exit{st}; // (declared after `results`: destroyed before it, also on the error returns)
-	srbadev::Gang G0 = gang_of(ln);
-	const size_t fetch_bytes = (8 * 16 + 4 * 8) * (size_t)ln->slots; // scalars of all slots, then their flags: one allocation, one copy into page-locked memory
-	if (!ln->h_fetch) LNCHK(ln, hipHostMalloc(&ln->h_fetch, fetch_bytes, hipHostMallocDefault));
-	const double *hs = (const double *)ln->h_fetch; const int *hi = (const int *)(hs + 16 * (size_t)ln->slots);
-	auto fetch = [&]() -> int { LNCHK(ln, hipMemcpyAsync(ln->h_fetch, ln->d_scal, fetch_bytes, hipMemcpyDeviceToHost, st)); LNCHK(ln, hipStreamSynchronize(st)); return 0; };
-	auto mask_of = [&](auto pred) { unsigned m = 0; for (int w = 0; w < nslots; w++) if (S[w].p >= 0 && pred(S[w])) m |= 1u << w; return m; };
-	auto enqueue_residuals = [&](const srbadev::Gang &G, int to_trial_copy, int use_skip) { BIGK(kb_residuals, d.n_obs, 256, to_trial_copy, use_skip); big_reduce(c, st, G, 0, 0, BS_CHI2, 0); };
-	auto enqueue_linearize = [&](const srbadev::Gang &G) { BIGK(kb_jac_init, d.n_valid, 256); BIGK(kb_jac, d.n_bp + d.n_bf, 128); BIGK(kb_jac_post, d.n_bp + d.n_bf, 256); BIGK(kb_hessian,
-		d.n_hap + d.n_hf + d.n_hapf, 128); BIGKG(kb_hessian_heavy, d.n_hap, 256); };
-	// (extension) the Schur kernels reduce B.grad in place: keep what K5 produced and start every solve from it
-	auto enqueue_gradient = [&](const srbadev::Gang &G) { BIGKG(kb_gradient, d.nK + (d.nF + 255) / 256, 256); big_copy_vec(c, st, gang_masked(G, G.mask & mask_of([](const GangSlot &s) {
-		return s.keep_g; })), 1); };
-	auto enqueue_dot = [&](const srbadev::Gang &G, int which, int slot, int is_max, int use_skip) { BIGK(kb_dot, d.n_scal, 256, use_skip); big_reduce(c, st, G, which, 2, slot, is_max); };
-	for (;;) {
-		// ---- windows that ended: covariance recovery (S17) and the result record; their slots take the next capsules of the class
-		{ srbadev::Gang G = G0; for (int w = 0; w < nslots; w++) if (S[w].st == GS_FINAL) { gang_set(c, G, w, S[w].p); G.mask |= 1u << w; }
-		  // a rejected last trial is undone first
-		  { const srbadev::Gang Gr = gang_masked(G, G.mask & mask_of([](const GangSlot &s) { return s.restore; })); const srbadev::Gang &G = Gr; BIGK(kb_restore, d.nK + (long long)d.nF * L + d.n_req,
-		  	128); }
-		  if (G.mask) { const srbadev::Gang Gs = gang_masked(G, gang_schur_mask(c, G)), Gn = gang_masked(G, G.mask & ~Gs.mask);
-		    { const srbadev::Gang &G = Gs; BIGK(kb_cov_recovery, std::max(d.nF, 1), 128, 1); } { const srbadev::Gang &G = Gn; BIGK(kb_cov_recovery, std::max(d.nF, 1), 128, 0); } }
-		  for (int w = 0; w < nslots; w++) if (S[w].st == GS_FINAL) { GangSlot &s = S[w];
-		    s.out.num_iters = s.iter; s.out.num_trials = s.trials; s.out.num_not_pd = s.n_notpd; s.out.num_accepted = s.n_acc; s.out.num_relinearized = s.n_relin; s.out.stop_reason = s.stopmask;
-		    s.out.total_sqr_error_final = s.total_err; s.out.obs_rmse = s.RMSE; s.out.lambda_final = s.lambda;
-		    results.emplace_back(new srba_lm_result(s.out)); LNCHK(ln, hipMemcpyAsync(c->B.results + s.p, results.back().get(), sizeof(srba_lm_result), hipMemcpyHostToDevice, st));
-		    s = GangSlot(); } }
-		for (int w = 0; w < nslots; w++) if (S[w].st == GS_IDLE) { const int i = next.fetch_add(1); if (i >= count) break; GangSlot &s = S[w]; s = GangSlot(); s.p = caps[i]; s.st = GS_NEW;
-			const ProbDesc &d = c->desc[s.p]; s.schur = big_schur(c, d); s.keep_g = s.schur && (prm.extensions & SRBA_EXT_SCHUR_KEEPS_GRADIENT); s.s11 = (long long)O * d.n_obs < (long long)d.n_scal;
-			std::memset(&s.out, 0, sizeof(s.out)); for (int k = 0; k < SRBA_TRACE_LEN; k++) { s.out.trace_chi2[k] = NAN; s.out.trace_lambda[k] = NAN; s.out.trace_rho[k] = NAN; }
-				s.out.lambda_last_trial = NAN; }
-		srbadev::Gang Gall = G0; bool any = false; for (int w = 0; w < nslots; w++) if (S[w].p >= 0) { gang_set(c, Gall, w, S[w].p); any = true; }
-		if (!any) break;
-		// ---- rejected trials: restore (K12); accepted trials: residuals of the trial become current, relinearise where the error moved enough, gradient, |g|_inf;
-		//      new windows: S5 numeric spanning tree, S6/S7/S10 linearisation, S12 lambda_0, S13 residuals, S14 gradient
-		const unsigned m_restore = mask_of([](const GangSlot &s) { return s.restore && s.st != GS_FINAL; }), m_accept = mask_of([](const GangSlot &s) { return s.st == GS_ACCEPT; }),
-			m_relin = mask_of([](const GangSlot &s) { return s.st == GS_ACCEPT && s.relin; }),
-		               m_new = mask_of([](const GangSlot &s) { return s.st == GS_NEW; }), m_new_full = mask_of([](const GangSlot &s) { return s.st == GS_NEW && !s.s11; });
-		{ const srbadev::Gang G = gang_masked(Gall, m_restore); BIGK(kb_restore, d.nK + (long long)d.nF * L + d.n_req, 128); for (int w = 0; w < nslots; w++) S[w].restore = false; }
-		for (int w = 0; w < nslots; w++) if ((m_new >> w) & 1u) LNCHK(ln, hipMemsetAsync(ln->d_iscal + w * 8, 0, 32, st));
-		big_copy_vec(c, st, gang_masked(Gall, m_accept), 2);
-		{ const srbadev::Gang G = gang_masked(Gall, m_new); BIGK(kb_spantree, d.n_pairs, 256, 0, 0); }
-		enqueue_linearize(gang_masked(Gall, m_relin | m_new));
-		{ const srbadev::Gang G = gang_masked(Gall, m_new_full); BIGK(kb_maxdiag, d.nK + d.nF, 256); big_reduce(c, st, G, 1, 1, BS_MAXDIAG, 1); enqueue_residuals(G, 0, 0); }
-		enqueue_gradient(gang_masked(Gall, m_accept | m_new_full));
-		enqueue_dot(gang_masked(Gall, m_accept), 2, BS_NINF, 1, 0);
-		if (m_accept | m_new) {
-			if (fetch() != 0) return -1;
-			for (int w = 0; w < nslots; w++) { GangSlot &s = S[w]; const double *h = hs + (size_t)w * 16;
-				if ((m_new >> w) & 1u) { const ProbDesc &d = c->desc[s.p];
-					s.out.num_invalid_jacobs = hi[(size_t)w * 8]; s.out.num_observations = d.n_obs; s.out.num_jacobians = d.n_bp + d.n_bf; s.out.num_span_tree_numeric_updates = d.n_pairs;
-					if (s.s11) { s.out.status = 1; results.emplace_back(new srba_lm_result(s.out)); LNCHK(ln, hipMemcpyAsync(c->B.results + s.p, results.back().get(), sizeof(srba_lm_result),
-						hipMemcpyHostToDevice, st)); s = GangSlot(); continue; } // S11
-					s.lambda = h[BS_MAXDIAG] * 1e-3; s.nu = 2.0; s.total_err = h[BS_CHI2]; s.RMSE = std::sqrt(s.total_err / d.n_obs); s.out.lambda_init = s.lambda;
-						s.out.total_sqr_error_init = s.total_err;
-					s.iter = 0; gang_advance(prm, s, true);
-				} else if ((m_accept >> w) & 1u) {
-					if (h[BS_NINF] <= 1e-15) { s.stop = true; s.stopmask |= 1 << SRBA_STOP_GRADIENT; }
-					if (s.RMSE < prm.max_error_per_obs_to_stop) { s.stop = true; s.stopmask |= 1 << SRBA_STOP_RMSE; }
-					if (s.rho > prm.max_rho) { s.stop = true; s.stopmask |= 1 << SRBA_STOP_RHO; }
-					s.lambda *= 1.0 / 3.0; s.nu = 2.0; gang_advance(prm, s, false);
-				} }
-		}
-		// ---- one trial of every window that is in its inner loop: solve, apply, numeric spanning tree of the poses in use, residuals, rho denominator; the kernels after
-		//      the factorisation return at once for a window whose factorisation failed
-		const unsigned m_trial = mask_of([](const GangSlot &s) { return s.st == GS_TRIAL; });
-		if (m_trial) {
-			const srbadev::Gang G = gang_masked(Gall, m_trial);
-			{ srbadev::GangLambda lam; std::memset(&lam, 0, sizeof(lam)); for (int w = 0; w < nslots; w++) lam.v[w] = S[w].lambda; big_set_lambda(st, G, lam); }
-			big_copy_vec(c, st, gang_masked(G, m_trial & mask_of([](const GangSlot &s) { return s.keep_g; })), 0);
-			big_enqueue_assemble(c, st, G);
-			if (big_timed_cholesky(c, ln, G) != 0) return -1;
-			big_enqueue_backsub(c, st, G);
-			BIGK(kb_apply, d.nK + (long long)d.nF * L + d.n_req, 128, 1);
-			BIGK(kb_spantree, d.n_need, 256, 1, 1);
-			enqueue_residuals(G, 1, 1);
-			enqueue_dot(G, 1, BS_DEN, 0, 1);
-			if (fetch() != 0) return -1;
-			big_account_cholesky(c, ln, G);
-			for (int w = 0; w < nslots; w++) if ((m_trial >> w) & 1u) { GangSlot &s = S[w]; const double *h = hs + (size_t)w * 16; const int hflag = hi[(size_t)w * 8 + 1];
-				const ProbDesc &d = c->desc[s.p];
-				if (hflag == 2) { ln->error = "k_chol_persistent: a grid barrier timed out (the workgroups of the factorisation were not all resident)"; return -1; }
-				if (hflag) { s.n_notpd++; s.lambda *= s.nu; s.nu *= 2.0; s.stop = (s.lambda > prm.max_lambda); if (s.stop) s.stopmask |= 1 << SRBA_STOP_LAMBDA; gang_advance(prm, s, false); continue; }
-				const double new_err = h[BS_CHI2], new_RMSE = std::sqrt(new_err / d.n_obs), err_red = s.total_err > 0 ? (s.total_err - new_err) / s.total_err : 0;
-				s.rho = (s.total_err - new_err) / h[BS_DEN];
-				if (s.tr < SRBA_TRACE_LEN) { s.out.trace_chi2[s.tr] = new_err; s.out.trace_rho[s.tr] = s.rho; }
-				if (s.rho > 0) { s.n_acc++; s.relin = (err_red < 0 || err_red > prm.min_error_reduction_ratio_to_relinearize); s.total_err = new_err; s.RMSE = new_RMSE; if (s.relin) s.n_relin++;
-					s.st = GS_ACCEPT; }
-				else { s.restore = true; s.lambda *= s.nu; s.nu *= 2.0; s.stop = (s.lambda > prm.max_lambda); if (s.stop) s.stopmask |= 1 << SRBA_STOP_LAMBDA; gang_advance(prm, s, false); }
-			}
-		}
-	}
-	LNCHK(ln, hipStreamSynchronize(st));
-	LNCHK(ln, hipGetLastError());
-	return 0;
-}
-// lanes [0, n): lane 0 is the context's own stream with buffers for a whole gang, the others (one window each, SRBA_HIP_BIG_GANG=0) get theirs on first use
-static int big_prepare_lanes(srba_hip_ctx *c, int n) {
-	n = std::max(1, std::min(n, kBigLanes));
-	BigLane &l0 = c->lanes[0]; l0.id = 0; l0.stream = c->stream; l0.d_part = c->d_part; l0.d_scal = c->d_scal; l0.d_iscal = (int *)(c->d_scal + 16 * srbadev::kGang); l0.slots = srbadev::kGang;
-	c->n_lanes_ready = std::max(c->n_lanes_ready, 1);
-	for (int i = c->n_lanes_ready; i < n; i++) {
-		BigLane &l = c->lanes[i]; l.id = i; l.slots = srbadev::kGang; // (every lane can hold a gang: SRBA_HIP_BIG_GANGS > 1 runs several gangs side by side)
-		HIPCHK(c, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
-		HIPCHK(c, hipMalloc((void **)&l.d_part, 8 * 3 * kBigPart * srbadev::kGang)); HIPCHK(c, hipMalloc((void **)&l.d_scal, (8 * 16 + 4 * 8) * srbadev::kGang));
-			l.d_iscal = (int *)(l.d_scal + 16 * srbadev::kGang);
-		c->n_lanes_ready = i + 1;
-	}
-	return n;
-}
-static void big_collect_lane_stats(srba_hip_ctx *c) { for (int i = 0; i < c->n_lanes_ready; i++) { BigLane &l = c->lanes[i]; c->big_chol_ms += l.chol_ms; c->big_chol_flops += l.chol_flops;
-	c->big_chol_count += l.chol_count; c->big_chol_seqs += l.chol_seqs; c->big_chol_nmax = std::max(c->big_chol_nmax, l.chol_nmax); l.chol_ms = l.chol_flops = 0; l.chol_count = l.chol_seqs = 0;
-	l.chol_nmax = 0; } }
-// all capsules of the big class: a gang on lane 0 (default), or dealt to several lanes (host threads) with one window each
-static int big_run_class(srba_hip_ctx *c, const int32_t *caps, int count) {
-	if (count <= 0) return 0;
-	const bool gang = c->big_gang && !c->big_persistent;
-	// several gangs side by side (big_gangs > 1): the windows of the class are dealt to that many lanes, each a lock-step gang on its own stream and host thread -- the latency-bound
-	// phases of one gang (the panel chains of the factorisation use a few CUs) run under the throughput-bound ones of the others (Schur reduction, Hessian)
-	const int ngang = gang ? std::max(1, std::min(std::min(c->big_gangs, kBigLanes), count)) : 1;
-	const int per_gang = gang ? std::max(1, std::min(c->big_gang_slots, (count + ngang - 1) / ngang)) : 1;
-	// lane 0 is the context stream; SRBA_HIP_BIG_FRESH=1 keeps the gangs off it: their streams are then created one after the other, and the runtime deals streams to its hardware
-	// queues round-robin -- consecutive streams never share a queue, while the context stream (created long before, dozens of streams ago) may share one with a lane
-	const int l0 = (gang && ngang > 1 && c->big_fresh) ? 1 : 0;
-	const int n = big_prepare_lanes(c, l0 + (gang ? ngang : (c->big_lanes_max <= 1 ? 1 : std::min(count, c->big_lanes_max)))); if (n < 1) return -1;
-	int rc = 0; std::atomic<int> next(0);
-	if (n == 1) { rc = big_gang_run(c, &c->lanes[0], caps, count, next, gang ? c->big_gang_slots : 1); }
-	else {
-		// the lanes start after everything already queued on the context stream (uploads, state resets)
-		hipEvent_t ready = nullptr; HIPCHK(c, hipEventCreateWithFlags(&ready, hipEventDisableTiming));
-		hipError_t e = hipEventRecord(ready, c->stream);
-		for (int i = 1; i < n && e == hipSuccess; i++) e = hipStreamWaitEvent(c->lanes[i].stream, ready, 0);
-		if (e != hipSuccess) { hipEventDestroy(ready); c->fail(std::string("large-capsule path: ") + hipGetErrorString(e)); return -1; }
-		std::vector<int> rcs(n, 0); std::vector<std::thread> th;
-		auto work = [&](int li) { // no exception leaves a worker (std::terminate otherwise) nor this function (it is reached from an extern "C" entry)
-			try { hipSetDevice(c->device); BigLane *ln = &c->lanes[li]; rcs[li] = big_gang_run(c, ln, caps, count, next, per_gang); hipStreamSynchronize(ln->stream); }
-			catch (const std::exception &ex) { rcs[li] = -1; c->lanes[li].error = std::string("large-capsule path: ") + ex.what(); }
-			catch (...) { rcs[li] = -1; c->lanes[li].error = "large-capsule path: unknown exception"; } };
-		try { for (int i = l0 + 1; i < n; i++) th.emplace_back(work, i); } catch (...) { /* fewer threads than lanes: the ones that started (and this thread) share the capsules */ }
-		work(l0);
-		for (auto &t : th) t.join();
-		hipEventDestroy(ready);
-		for (int i = 0; i < n; i++) if (rcs[i] != 0 && rc == 0) { rc = -1; c->fail(c->lanes[i].error.empty() ? std::string("large-capsule path failed") : c->lanes[i].error); }
-	}
-	if (rc != 0 && c->error.empty()) c->fail(c->lanes[0].error);
-	big_collect_lane_stats(c);
-	return rc;
-}
-#undef BIGK
-#undef BIGKG
 
 extern "C" {
 

@@ -20,7 +20,7 @@ def kernel_resources(tmp_path):
     ge.build()
     # one code object per translation unit: read them from the objects the library is linked from (build() keeps them beside it)
     out = {}
-    for unit in ("srba_hip", "srba_assemble"):
+    for unit in ("srba_hip", "srba_big", "srba_assemble"):
         obj = os.path.join(ROOT, "srba_amd", "lib", unit + ".o"); fat = str(tmp_path / (unit + ".fat")); co = str(tmp_path / (unit + ".co"))
         subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True)
         subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True)
@@ -88,7 +88,7 @@ def test_dense_factorisation_kernels_do_not_spill_their_broadcasts(tmp_path):
     """k_chol_step / k_chol_panel (srba_big.hpp) hand the pivot column round by v_readlane: 31 SGPR pairs per pivot step. Left to itself the compiler issued them all first and spilled
     them to VGPR lanes (538 SGPR spills in k_chol_panel, 984 in k_chol_step: three instructions per broadcast instead of one, 20 % of the factorisation's time); the loops are written
     so that it cannot (branch-free pivots, update pairs pinned to their broadcast). Keep it so: no SGPR or VGPR spill, no scratch."""
-    obj = os.path.join(ROOT, "srba_amd", "lib", "srba_hip.o"); fat = str(tmp_path / "u.fat"); co = str(tmp_path / "u.co")
+    obj = os.path.join(ROOT, "srba_amd", "lib", "srba_big.o"); fat = str(tmp_path / "u.fat"); co = str(tmp_path / "u.co")
     subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True)
     subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True)
     notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
@@ -118,8 +118,8 @@ def test_no_index_is_widened_with_a_stale_high_half_in_the_lm_kernels():
     ge.build()
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import scan_undef_hi
-    dis = scan_undef_hi.disassemble(os.path.join(ROOT, "srba_amd", "lib", "srba_hip.o"))
-    f_lm, k_lm = scan_undef_hi.scan(dis, "k_lm_runILi"); f_kb, k_kb = scan_undef_hi.scan(dis, "kb_"); f_r4, k_r4 = scan_undef_hi.scan(dis, "k_lm_run_lean"); f_2, k_2 = scan_undef_hi.scan(dis,
+    dis = scan_undef_hi.disassemble(os.path.join(ROOT, "srba_amd", "lib", "srba_hip.o")); dis_big = scan_undef_hi.disassemble(os.path.join(ROOT, "srba_amd", "lib", "srba_big.o"))
+    f_lm, k_lm = scan_undef_hi.scan(dis, "k_lm_runILi"); f_kb, k_kb = scan_undef_hi.scan(dis_big, "kb_"); f_r4, k_r4 = scan_undef_hi.scan(dis, "k_lm_run_lean"); f_2, k_2 = scan_undef_hi.scan(dis,
             "k_lm_run2"); f_sp, k_sp = scan_undef_hi.scan(dis, "k_lm_spec")
     assert len(k_lm) == 9 and len(k_kb) >= 100 and len(k_r4) == 1 and len(k_2) == 1 and len(k_sp) == 1, (len(k_lm), len(k_kb), len(k_r4), len(k_2), len(k_sp))
     assert not f_lm and not f_kb and not f_r4 and not f_2 and not f_sp, (f_lm + f_kb + f_r4 + f_2 + f_sp)[:4]
