@@ -207,6 +207,27 @@ __device__ __forceinline__ bool chol_block_solve_regs(double (&a)[CB], double (&
 	for (int j = 0; j < CB; j++) acc += x[j] * lane_bcast(a[j], CB); // lane CB carried the right-hand side: its row is y_k now
 	return ok;
 }
+// The same chain with ONE array (round 5, late): the rows a panel wavefront solves are augmented rows of the block exactly like the right-hand side -- lane >= CB carries a row
+// r^t and comes out as (L^-1 r)^t --, so the solve needs no second array: lanes 0 .. CB-1 the diagonal block, lane CB the right-hand side, lanes CB+1 .. 63 THIRTY-ONE panel
+// rows, one multiply-add per remaining column instead of two. The 64 rows of a panel workgroup go to three wavefronts (31 + 31 + 2) that run the chain side by side, each with
+// its own copy of the diagonal block. Same operations on the same numbers as chol_block_solve_regs: bit-identical factors. acc (lanes > CB): the row's share of y.
+__device__ __forceinline__ bool chol_block_rows_regs(double (&v)[CB], double &acc, int lane) {
+	bool ok = true;
+#pragma unroll
+	for (int j = 0; j < CB; j++) {
+		const double d = lane_bcast(v[j], j);
+		ok &= (d > 0.0);
+		const double r = rsqrt_nr(d);
+		const double l = (lane == j) ? d * r : ((lane > j) ? v[j] * r : 0.0);
+		v[j] = l;
+#pragma unroll
+		for (int k = j + 1; k < CB; k++) { const double lk = lane_bcast(l, k); v[k] -= l * lk; asm volatile("" : "+v"(v[k])); }
+		__builtin_amdgcn_sched_barrier(0);
+	}
+#pragma unroll
+	for (int j = 0; j < CB; j++) acc += v[j] * lane_bcast(v[j], CB);
+	return ok;
+}
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_chol_step(const Gang G, int k0) { // two workgroups per CU: left alone the kernel takes 232 + 32 registers -- eight
 	// over the budget that lets a second workgroup in -- and the many tile workgroups of the early steps queue behind one another
 	__shared__ double sh[2 * CT * (CB + 1)];
@@ -264,16 +285,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 	}
 	// ---- panel workgroup b: rows k0+CB+64(b-1) .. +63 (b >= 1); b = 0 publishes L_kk and y_k
 	const int b = blockIdx.x, row0 = k0 + CB + 64 * (b - 1);
-	const int row = row0 + lane; const bool has_row = b > 0 && row < ld;
-	double a[CB], x[CB];
+	// the chain runs on wavefronts 0 .. 2 (workgroup 0: wavefront 0 alone): lanes 0 .. CB-1 the diagonal block, lane CB the right-hand side, lane CB+1+i row 31 w + i of the 64
+	const int xr = 31 * w + lane - (CB + 1), row = row0 + xr; const bool has_row = b > 0 && w < 3 && lane > CB && xr < 64 && row < ld;
+	double a[CB];
 	if (k0 == 0) {
-		if (w != 0) return;
+		if (w > 2 || (b == 0 && w != 0)) return;
 		const double *Arow = (const double *)__builtin_assume_aligned(S.A + (size_t)(has_row ? row : k0) * ld + k0, 16);
-#pragma unroll
-		for (int c = 0; c < CB; c++) x[c] = has_row ? Arow[c] : 0.0;
 		const double *src = (const double *)__builtin_assume_aligned(S.A + (size_t)(k0 + (lane & (CB - 1))) * ld + k0, 16), *rh = (const double *)__builtin_assume_aligned(S.rhs + k0, 16);
 #pragma unroll
-		for (int c = 0; c < CB; c++) { const double v = src[c], bb = rh[c]; a[c] = lane < CB ? (c <= lane ? v : 0.0) : (lane == CB ? bb : 0.0); }
+		for (int c = 0; c < CB; c++) { const double v = src[c], bb = rh[c], xv = Arow[c]; a[c] = lane < CB ? (c <= lane ? v : 0.0) : (lane == CB ? bb : (has_row ? xv : 0.0)); }
 	} else {
 		double *Xo = sh, *Xk = sh + CT * (CB + 1); // -X_prev of the own rows | X_prev of rows k0 .. k0+CB-1
 		// C of this wavefront's tiles straight into the accumulators: own rows 16 w .. 16 w + 15, both column halves; wavefronts 0..2 also take the tiles (0,0) (1,0) (1,1) of the diagonal block
@@ -308,14 +328,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 			for (int r = 0; r < 4; r++) Xk[(dr + (lane >> 4) + 4 * r) * (CB + 1) + dc + (lane & 15)] = cd[r];
 		}
 		__syncthreads();
-		if (w != 0) return;
-		const double *rh = (const double *)__builtin_assume_aligned(S.rhs + k0, 16);
+		if (w > 2 || (b == 0 && w != 0)) return;
+		const double *rh = (const double *)__builtin_assume_aligned(S.rhs + k0, 16); const int xo = has_row ? xr : 0;
 #pragma unroll
-		for (int c = 0; c < CB; c++) { x[c] = has_row ? Xo[lane * (CB + 1) + c] : 0.0; const double v = Xk[(lane & (CB - 1)) * (CB + 1) + c], bb = rh[c];
-			a[c] = lane < CB ? (c <= lane ? v : 0.0) : (lane == CB ? bb : 0.0); }
+		for (int c = 0; c < CB; c++) { const double xv = Xo[xo * (CB + 1) + c], v = Xk[(lane & (CB - 1)) * (CB + 1) + c], bb = rh[c];
+			a[c] = lane < CB ? (c <= lane ? v : 0.0) : (lane == CB ? bb : (has_row ? xv : 0.0)); }
 	}
 	double acc = 0;
-	if (!chol_block_solve_regs(a, x, acc, lane)) { if (b == 0 && lane == 0) *S.flag = 1; return; }
+	if (!chol_block_rows_regs(a, acc, lane)) { if (b == 0 && lane == 0) *S.flag = 1; return; }
 	if (b == 0) {
 		if (lane < CB) {
 			double *dst = (double *)__builtin_assume_aligned(S.Ldiag + (size_t)(k0 + lane) * CB, 16);
@@ -330,7 +350,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 	if (!has_row) return;
 	double *Arow = (double *)__builtin_assume_aligned(S.A + (size_t)row * ld + k0, 16);
 #pragma unroll
-	for (int c = 0; c < CB; c++) Arow[c] = x[c];
+	for (int c = 0; c < CB; c++) Arow[c] = a[c];
 	S.rhs[row] -= acc;
 }
 
