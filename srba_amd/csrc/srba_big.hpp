@@ -800,7 +800,10 @@ template <int FAM> __global__ void __launch_bounds__(256) __attribute__((amdgpu_
 // term records, the next pass's records requested with this pass's operands, hf_ok read beside them), keeps the 36 sums in registers across passes and reduces them once with DPP;
 // no LDS, no barrier, four independent blocks per workgroup = twelve blocks per CU in flight, the longest blocks first (records sorted at upload: ProbDesc::n_vb). One wavefront
 // sums a block in a fixed order: reproducible run to run. (Measured and dropped on the way: a LANE per light block, <= 64 terms -- 125 us for 5 % of the terms.)
-template <int FAM> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) kb_schur_reduce_wave(const Batch B, const DevParams prm, const Gang G, int xcd_rows) {
+#ifndef SRBA_SCHUR_WAVES
+#define SRBA_SCHUR_WAVES 2 /* wavefronts per SIMD: 175 registers, nothing spilled; at three (168, 16 spilled in the term loop) the launch is 4 % of a cfg4 step slower, at four 17 % */
+#endif
+template <int FAM> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SRBA_SCHUR_WAVES, SRBA_SCHUR_WAVES))) kb_schur_reduce_wave(const Batch B, const DevParams prm, const Gang G, int xcd_rows) {
 	// xcd_rows (gridDim.y a multiple of 8): the workgroups of window w all run on XCD w % 8 -- workgroups go to the XCDs round-robin in dispatch order (x fastest), so the linear
 	// id is re-read as (XCD, position on that XCD) and the position as (window, workgroup of the window). A window's W blocks (8 MB, each read ~ 13 times) then stay in ONE L2
 	// instead of passing through all eight.
