@@ -298,10 +298,12 @@ typedef struct srba_batch_stats {
 int  srba_hip_batch_stats(srba_hip_ctx *ctx, srba_batch_stats *out);
 
 /* Large-window path (capsules whose system does not fit one wavefront's LDS; srba_amd/csrc/srba_big.hpp): dense Cholesky factorisations since the last upload.
- * out = { total milliseconds inside the blocked factorisation (HIP events on the context stream), total flops ld^3/3, number of factorisations, largest system }. */
+ * out = { milliseconds inside the TIMED factorisation sequences (HIP events on the lane's stream; since round 5 every 8th sequence of a lane is timed, SRBA_HIP_BIG_TIME_EVERY:
+ * a time-stamp event drains the queue around it), total flops ld^3/3 of ALL factorisations, number of factorisations, largest system }. */
 int    srba_hip_big_path_stats(srba_hip_ctx *ctx, double out[4]);
 /* The same with the launch sequences counted: since round 4 the large windows of a batch run in lock-step and ONE sequence of panel / update launches factors the systems of all
- * windows that are in a trial (srba_big.hpp, Gang). out = { ms, flops, factorisations, largest system, launch sequences, 1 if the lock-step gang is on, 0, 0 }. */
+ * windows that are in a trial (srba_big.hpp, Gang). out = { ms of the timed sequences, flops, factorisations, largest system, launch sequences, 1 if the lock-step gang is on,
+ * timed launch sequences, flops of the timed sequences }: achieved rate = out[7] / out[0], time of a sequence = out[0] / out[6]. */
 int    srba_hip_big_path_stats2(srba_hip_ctx *ctx, double out[8]);
 /* Order in which the class launches of the last srba_hip_lm_run* started on the device. The fused LM kernel is one persistent launch per size class, all enqueued at once on their own
  * streams; the plan holds each stream back so that the launches start largest-footprint-first (DESIGN 4a "staggered start"). For plan job j (in plan order = the intended order):

@@ -102,18 +102,23 @@ static void big_enqueue_backsub(srba_hip_ctx *c, hipStream_t st, const srbadev::
 	hipLaunchKernelGGL(srbadev::kb_take_delta, gang_grid(c, Gall, 256, false, [&](const ProbDesc &d, int) -> long long { return d.n_scal; }), dim3(256), 0, st, c->B, Gall);
 	{ const srbadev::Gang G = gang_masked(Gall, gang_schur_mask(c, Gall)); BIGK(kb_schur_features, d.nF, 128, 1); }
 }
+// The factorisation sequence between two timing events -- on every big_time_every-th sequence of a lane only (SRBA_HIP_BIG_TIME_EVERY, default 8): an event with a time stamp
+// drains the queue before and after it, 30 - 40 us per sequence in the kernel trace (4 - 5 % of a gang's time when every sequence was timed). The counts stay complete.
 static int big_timed_cholesky(srba_hip_ctx *c, BigLane *ln, const srbadev::Gang &G) {
+	ln->timed = (ln->seq_no++ % std::max(1, c->big_time_every)) == 0;
+	if (!ln->timed) { big_enqueue_cholesky(c, ln->stream, G); return 0; }
 	if (!ln->e0) { LNCHK(ln, hipEventCreate(&ln->e0)); LNCHK(ln, hipEventCreate(&ln->e1)); }
 	LNCHK(ln, hipEventRecord(ln->e0, ln->stream));
 	big_enqueue_cholesky(c, ln->stream, G);
 	LNCHK(ln, hipEventRecord(ln->e1, ln->stream));
 	return 0;
 }
-static void big_account_cholesky(srba_hip_ctx *c, BigLane *ln, const srbadev::Gang &G) { // after a stream synchronisation; chol_ms is the time of the launch sequence,
-	// shared by the windows of the gang
-	float ms = 0;
-	if (hipEventElapsedTime(&ms, ln->e0, ln->e1) == hipSuccess) { ln->chol_ms += ms; ln->chol_seqs++; for (int w = 0; w < G.n; w++) if ((G.mask >> w) & 1u) { const double ld = G.ld[w];
-		ln->chol_flops += ld * ld * ld / 3.0; ln->chol_count++; ln->chol_nmax = std::max(ln->chol_nmax, G.nsys[w]); } }
+static void big_account_cholesky(srba_hip_ctx *c, BigLane *ln, const srbadev::Gang &G) { // after a stream synchronisation; chol_ms is the time of the TIMED launch sequences
+	// (each shared by the windows of its gang), t_seqs / t_flops what they factored; chol_seqs / chol_count / chol_flops count every sequence
+	float ms = 0; const bool timed = ln->timed && hipEventElapsedTime(&ms, ln->e0, ln->e1) == hipSuccess; double fl = 0;
+	for (int w = 0; w < G.n; w++) if ((G.mask >> w) & 1u) { const double ld = G.ld[w]; fl += ld * ld * ld / 3.0; ln->chol_count++; ln->chol_nmax = std::max(ln->chol_nmax, G.nsys[w]); }
+	ln->chol_flops += fl; ln->chol_seqs++;
+	if (timed) { ln->chol_ms += ms; ln->t_seqs++; ln->t_flops += fl; }
 }
 int big_solve(srba_hip_ctx *c, BigLane *ln, int p, double lambda, bool *pos_def) { // the stepwise entry point (srba_hip_solve)
 	hipStream_t st = ln->stream; srbadev::Gang G = gang_of(ln); gang_set(c, G, 0, p); G.mask = 1u;
@@ -268,7 +273,8 @@ int big_prepare_lanes(srba_hip_ctx *c, int n) {
 	return n;
 }
 void big_collect_lane_stats(srba_hip_ctx *c) { for (int i = 0; i < c->n_lanes_ready; i++) { BigLane &l = c->lanes[i]; c->big_chol_ms += l.chol_ms; c->big_chol_flops += l.chol_flops;
-	c->big_chol_count += l.chol_count; c->big_chol_seqs += l.chol_seqs; c->big_chol_nmax = std::max(c->big_chol_nmax, l.chol_nmax); l.chol_ms = l.chol_flops = 0; l.chol_count = l.chol_seqs = 0;
+	c->big_chol_count += l.chol_count; c->big_chol_seqs += l.chol_seqs; c->big_chol_nmax = std::max(c->big_chol_nmax, l.chol_nmax); c->big_t_seqs += l.t_seqs; c->big_t_flops += l.t_flops;
+	l.chol_ms = l.chol_flops = l.t_flops = 0; l.chol_count = l.chol_seqs = l.t_seqs = 0;
 	l.chol_nmax = 0; } }
 // all capsules of the big class: a gang on lane 0 (default), or dealt to several lanes (host threads) with one window each
 int big_run_class(srba_hip_ctx *c, const int32_t *caps, int count) {

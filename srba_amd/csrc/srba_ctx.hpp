@@ -36,7 +36,8 @@ struct Arena { // layout builder: 256-byte aligned sub-allocations inside one bu
 static const int kBigLanes = 16;
 struct BigLane { int id = 0, slots = 1 /* windows its buffers have room for (srbadev::Gang) */; hipStream_t stream = nullptr; double *d_part = nullptr, *d_scal = nullptr;
 	int *d_iscal = nullptr /* behind the scalars in the same allocation: one copy reads both back */; void *h_fetch = nullptr /* page-locked landing buffer of that copy */; hipEvent_t e0 = nullptr,
-	e1 = nullptr; double chol_ms = 0, chol_flops = 0; long long chol_count = 0, chol_seqs = 0; int chol_nmax = 0; std::string error; };
+	e1 = nullptr; double chol_ms = 0, chol_flops = 0, t_flops = 0; long long chol_count = 0, chol_seqs = 0, t_seqs = 0 /* t_*: the sequences that were timed */, seq_no = 0; bool timed = false;
+	int chol_nmax = 0; std::string error; };
 
 } // namespace srbahost
 using namespace srbahost;
@@ -64,6 +65,7 @@ struct srba_hip_ctx {
 		// d_batch: device copy of B (the workgroup kernels read the batch's pointers from it)
 	double *d_part = nullptr; double *d_scal = nullptr; int *d_iscal = nullptr; // big path: partial sums [3][kBigPart], scalars, int flags (ninv, not-pd)
 	std::vector<int> big_ld; // per capsule: leading dimension of its dense system when it runs on the big path, else 0
+	double big_t_flops = 0; long long big_t_seqs = 0; int big_time_every = 8; // timing events around every n-th factorisation sequence of a lane (big_timed_cholesky)
 	double big_chol_ms = 0, big_chol_flops = 0; long long big_chol_count = 0, big_chol_seqs = 0 /* launch sequences: one factors all windows of a gang */; int big_chol_nmax = 0;
 		// Cholesky time / flops of the big path since the last upload (sum over the lanes)
 	BigLane lanes[kBigLanes]; int n_lanes_ready = 0; // lane 0 = the context stream and buffers; the others are created on first use

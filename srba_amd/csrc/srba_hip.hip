@@ -1488,6 +1488,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_ASSEMBLE_MAX_KB"); if (e) c->asm_max_kb = atoi(e); }            // capsules whose LDS image exceeds this take the unfused kernel (tests)
 	{ const char *e = getenv("SRBA_HIP_ASSEMBLE"); if (e) c->asm_on = atoi(e) != 0; }                   // 0 = srba_hip_linearize always runs the unfused kernel (Jacobian blocks through HBM)
 	{ const char *e = getenv("SRBA_HIP_FLAT"); if (e) c->use_flat = atoi(e) != 0; }                     // 0 = one wavefront per capsule for the stepwise spanning-tree launch
+	{ const char *e = getenv("SRBA_HIP_BIG_TIME_EVERY"); if (e && atoi(e) >= 1) c->big_time_every = atoi(e); }
 	{ const char *e = getenv("SRBA_HIP_BIG_FRESH"); if (e) c->big_fresh = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_SCHUR_XCD"); if (e) c->sch_xcd = atoi(e) != 0; } { const char *e = getenv("SRBA_HIP_SCHUR_SORT"); if (e) c->sch_sort = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_SCHUR_WAVE"); if (e) c->sch_wave = atoi(e) != 0; }
@@ -1576,7 +1577,7 @@ static int set_asm_flags(srba_hip_ctx *c) {
 static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *caps, int n) {
 	if (!c || !caps || n <= 0) { if (c) c->fail("upload: bad arguments"); return -1; }
 	HIPCHK(c, hipSetDevice(c->device));
-	c->big_chol_ms = c->big_chol_flops = 0; c->big_chol_count = c->big_chol_seqs = 0; c->big_chol_nmax = 0;
+	c->big_chol_ms = c->big_chol_flops = 0; c->big_chol_count = c->big_chol_seqs = 0; c->big_chol_nmax = 0; c->big_t_flops = 0; c->big_t_seqs = 0;
 	c->n_prob = 0; // whatever was uploaded before stops being launchable / readable now: a failed upload leaves the context empty, not half-updated
 	static const bool host_timing = getenv("SRBA_HIP_HOST_TIMING") != nullptr; static double acc[4] = {0, 0, 0, 0}; static long long calls = 0; auto now = []() { return std::chrono::duration<double,
 		std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }; const double ht0 = host_timing ? now() : 0; double ht1 = 0, ht2 = 0;
@@ -1958,7 +1959,7 @@ int srba_hip_reset_state(srba_hip_ctx *c) {
 int srba_hip_big_path_stats(srba_hip_ctx *c, double out[4]) { if (!c || !out) return -1; out[0] = c->big_chol_ms; out[1] = c->big_chol_flops; out[2] = (double)c->big_chol_count;
 	out[3] = c->big_chol_nmax; return 0; }
 int srba_hip_big_path_stats2(srba_hip_ctx *c, double out[8]) { if (!c || !out) return -1; out[0] = c->big_chol_ms; out[1] = c->big_chol_flops; out[2] = (double)c->big_chol_count;
-	out[3] = c->big_chol_nmax; out[4] = (double)c->big_chol_seqs; out[5] = c->big_gang && !c->big_persistent ? 1 : 0; out[6] = out[7] = 0; return 0; }
+	out[3] = c->big_chol_nmax; out[4] = (double)c->big_chol_seqs; out[5] = c->big_gang && !c->big_persistent ? 1 : 0; out[6] = (double)c->big_t_seqs; out[7] = c->big_t_flops; return 0; }
 int srba_hip_launch_order(srba_hip_ctx *c, int64_t *stamp, int32_t *workgroups, int32_t *delay_us, int n) { // see srba_hip.h
 	if (!c || !stamp || n < 0) return -1;
 	HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream));
