@@ -276,7 +276,7 @@ def main():
             help="cfg3: extension bits of the engine (4 schur_keeps_gradient, 8 consistent_loop_closure_init, 2 restore_spanning_tree_twins; 0 = the reference to the letter, which keeps this map for 67 key-frames)")
     ap.add_argument("--cfg4-ext", type=int, default=2,
             help="cfg4: extension bits of the engine (2 restore_spanning_tree_twins: without it the reference's algorithm loses this map at key-frame ~30, DESIGN 8 item 2; 0 = the reference to the letter)")
-    ap.add_argument("--cfg4-full-budget-s", type=float, default=480.0,
+    ap.add_argument("--cfg4-full-budget-s", type=float, default=540.0,
             help="wall budget of the BASELINE-size cfg4 leg of the secondary workloads (5 000 key-frames x 200 000 landmarks: the map is built key-frame by key-frame, about "
                     "five minutes); 0 = skip it; a leg that exceeds the budget is reported as skipped with the reason")
     ap.add_argument("--no-secondary", action="store_true", help="do not append the cfg3 / cfg4 measurements (secondary_workloads) to the cfg2 line")
