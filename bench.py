@@ -472,6 +472,10 @@ def main():
             # landmark kernels cannot take the headline line down (advisor r03). Beside each repaired workload, the reference to the letter (extensions = 0): cfg3 on the 67 key-frames
             # the reference's algorithm keeps, cfg4 on the same deep windows of the map it has lost by then (chaotic problems: throughput is comparable, chi2 parity is what the replay tests state).
             ctx.close(); sec = {}; import subprocess
+            # ... and nothing of this process stays on the device while they run: the engine that harvested the batch holds a context with its own streams (hardware queues are
+            # shared between processes; the deep-window leg runs four gangs on four of them). `batch` is not used past this point.
+            for holder in (getattr(batch, "engine", None), getattr(batch, "owner", None)):
+                if holder is not None: holder.close()
             legs = (("cfg3", ["--workload", "cfg3"]), ("cfg3_reference_defaults", ["--workload", "cfg3", "--cfg3-ext", "0", "--cfg3-kf", "67"]),
                     ("cfg4", ["--workload", "cfg4"]), ("cfg4_reference_defaults", ["--workload", "cfg4", "--cfg4-ext", "0"]),
                     ("cfg4_full", ["--workload", "cfg4", "--cfg4-kf", "5000"]))   # BASELINE configs[3] at its stated size: 5 000 key-frames x 200 000 landmarks, behind a wall budget
