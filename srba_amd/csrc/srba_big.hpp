@@ -211,6 +211,9 @@ __device__ __forceinline__ bool chol_block_solve_regs(double (&a)[CB], double (&
 // r^t and comes out as (L^-1 r)^t --, so the solve needs no second array: lanes 0 .. CB-1 the diagonal block, lane CB the right-hand side, lanes CB+1 .. 63 THIRTY-ONE panel
 // rows, one multiply-add per remaining column instead of two. The 64 rows of a panel workgroup go to three wavefronts (31 + 31 + 2) that run the chain side by side, each with
 // its own copy of the diagonal block. Same operations on the same numbers as chol_block_solve_regs: bit-identical factors. acc (lanes > CB): the row's share of y.
+#ifndef SRBA_CHAIN_U
+#define SRBA_CHAIN_U 2
+#endif
 __device__ __forceinline__ bool chol_block_rows_regs(double (&v)[CB], double &acc, int lane) {
 	bool ok = true;
 #pragma unroll
@@ -221,7 +224,14 @@ __device__ __forceinline__ bool chol_block_rows_regs(double (&v)[CB], double &ac
 		const double l = (lane == j) ? d * r : ((lane > j) ? v[j] * r : 0.0);
 		v[j] = l;
 #pragma unroll
-		for (int k = j + 1; k < CB; k++) { const double lk = lane_bcast(l, k); v[k] -= l * lk; asm volatile("" : "+v"(v[k])); }
+		for (int k = j + 1; k < CB; k += SRBA_CHAIN_U) { // SRBA_CHAIN_U columns per pin: the later v_readlane pairs fill the wait states the first multiply-add would spend in an s_nop
+			double lk[SRBA_CHAIN_U];
+#pragma unroll
+			for (int u = 0; u < SRBA_CHAIN_U; u++) lk[u] = (k + u < CB) ? lane_bcast(l, k + u) : 0.0;
+#pragma unroll
+			for (int u = 0; u < SRBA_CHAIN_U; u++) if (k + u < CB) v[k + u] -= l * lk[u];
+#pragma unroll
+			for (int u = 0; u < SRBA_CHAIN_U; u++) if (k + u < CB) asm volatile("" : "+v"(v[k + u])); }
 		__builtin_amdgcn_sched_barrier(0);
 	}
 #pragma unroll
