@@ -2,29 +2,19 @@
  * srba_assemble.hip -- the fused normal-equations kernel (description and tables: srba_assemble.hpp); its own translation unit, so that it builds in seconds.
  */
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
 #include "../../include/srba_hip.h"
 #include "srba_device.hpp"
-extern __shared__ double srba_lds[]; // five numbers per Jacobian block, then the gradient of the capsule
+extern __shared__ double srba_lds[]; // per capsule of the bin: Hessian blocks | gradient | poses of the unknown edges
 #include "srba_assemble.hpp"
 
 namespace srbadev {
 
 __device__ __forceinline__ void asm_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
-
-// O[lane] <- sum of O over the lanes (start of the run of equal keys that `lane` belongs to) .. lane; runs are contiguous. The shuffles of a step are all issued
-// before the (exec-masked) additions.
-template <int N> __device__ __forceinline__ void asm_scan_up(double (&O)[N], int key, int lane) {
-#pragma unroll
-	for (int off = 1; off < 64; off <<= 1) {
-		const int ko = __shfl_up(key, off); double o[N];
-#pragma unroll
-		for (int k = 0; k < N; k++) o[k] = __shfl_up(O[k], off);
-		if (lane >= off && ko == key) {
-#pragma unroll
-			for (int k = 0; k < N; k++) O[k] += o[k];
-		}
-	}
-}
+__device__ __forceinline__ void lds_add(double *p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } // ds_add_f64, nothing returned
 
 // A block of this family is J = sg * K, K = [ c s k2 ; -s c k3 ; 0 0 1 ] with k2 = x s - y c, k3 = x c + y s: FOUR numbers {c, s, k2, k3} and a sign.
 // M = Lambda * K(b)   (identity Lambda: M = K)
@@ -43,213 +33,196 @@ __device__ __forceinline__ void asm_kt_m(double *H, const double (&a)[4], const 
 	for (int j = 0; j < 3; j++) { H[j] = a[0] * M[j] - a[1] * M[3 + j]; H[3 + j] = a[1] * M[j] + a[0] * M[3 + j]; H[6 + j] = a[2] * M[j] + a[3] * M[3 + j] + M[6 + j]; }
 }
 
-// Sums over runs of consecutive items when every lane owns C consecutive items: a run inside one lane is summed serially and emitted on the spot; the piece of a run
-// that a lane leaves open to its right goes through ONE prefix scan over the lanes, and the lane that holds the last item of such a run adds what its left neighbours
-// summed. N values per item.
-template <int N> struct AsmRuns {
-	double acc[N], lead[N]; unsigned lead_lo, lead_hi, cur_lo, cur_hi; bool open, started, have_lead;
-	__device__ __forceinline__ void init() { open = false; started = false; have_lead = false; lead_lo = lead_hi = cur_lo = cur_hi = 0;
-#pragma unroll
-		for (int k = 0; k < N; k++) { acc[k] = 0; lead[k] = 0; } }
-	// item `idx_in_lane` of this lane: value v, record words lo / hi (bit 30 of `flags`: first of its run, bit 31: last); emit(lo, hi, total) writes a finished run
-	template <class Emit> __device__ __forceinline__ void item(int idx_in_lane, const double (&v)[N], unsigned lo, unsigned hi, unsigned flags, Emit emit) {
-		const bool first = (flags & 0x40000000u) != 0, fresh = first || idx_in_lane == 0; // (idx 0 without the flag: the run began in an earlier lane)
-		if (fresh) started = first;
-#pragma unroll
-		for (int k = 0; k < N; k++) acc[k] = fresh ? v[k] : acc[k] + v[k];
-		cur_lo = lo; cur_hi = hi;
-		if (flags & 0x80000000u) {
-			open = false;
-			if (started) emit(lo, hi, acc);
-			else { have_lead = true; lead_lo = lo; lead_hi = hi;
-#pragma unroll
-				for (int k = 0; k < N; k++) lead[k] = acc[k];
-			}
-		} else open = true;
-	}
-	// after the last item: key(lo, hi) identifies the run
-	template <class Key, class Emit> __device__ __forceinline__ void finish(int lane, Key key, Emit emit) {
-		double O[N];
-#pragma unroll
-		for (int k = 0; k < N; k++) O[k] = open ? acc[k] : 0.0;
-		const int okey = open ? key(cur_lo, cur_hi) : -1 - lane;
-		asm_scan_up<N>(O, okey, lane);
-		const int kprev = __shfl_up(okey, 1); double P[N];
-#pragma unroll
-		for (int k = 0; k < N; k++) P[k] = __shfl_up(O[k], 1);
-		if (have_lead) {
-			if (lane > 0 && kprev == key(lead_lo, lead_hi)) {
-#pragma unroll
-				for (int k = 0; k < N; k++) lead[k] += P[k];
-			}
-			emit(lead_lo, lead_hi, lead);
-		}
-	}
-};
-
 #ifndef SRBA_ASM_WAVES
-#define SRBA_ASM_WAVES 2 /* wavefronts per SIMD the register budget is cut for */
+#define SRBA_ASM_WAVES 3 /* wavefronts per SIMD the register budget is cut for */
 #endif
 #ifndef SRBA_ASM_KO
-#define SRBA_ASM_KO 0 /* knock-out experiments (wrong results): 1 no Hessian stores, 2 no residual gather, 4 no pose gather, 16 no gradient stores */
+#define SRBA_ASM_KO 0 /* knock-out experiments (wrong results): 1 no Hessian stores, 2 no residual gather, 4 no pose gather, 8 no LDS adds, 16 no gradient stores */
 #endif
-#ifndef SRBA_ASM_U
-#define SRBA_ASM_U 4   /* blocks / terms in flight per lane */
-#endif
-template <int LAMBDA>
-__global__ void __launch_bounds__(64 * ASM_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(SRBA_ASM_WAVES))) k_assemble_se2rel(const Batch B, const DevParams prm, const AsmTables T) {
-	constexpr int PD = 5, U = SRBA_ASM_U;
-	// a workgroup is a bin of up to four capsules whose LDS images share its allocation (packed at upload); its wavefronts work independently, one capsule each
-	const AsmDesc &d = T.desc[blockIdx.x * ASM_WAVES_PER_WG + (threadIdx.x >> 6)]; // descriptors in bin order: one dependent load less than bin -> capsule -> descriptor
+
+struct AsmRow { uint4 a, b; };                       // the 32-byte record of a row
+struct AsmGather { double D[3][4]; double r[3]; };   // what a row gathers: {x, y, cos, sin} of the pose D of each block, its residual
+
+__device__ __forceinline__ AsmRow asm_row(const AsmRec *rp, int idx) { const uint4 *q = (const uint4 *)(rp + idx); AsmRow R; R.a = q[0]; R.b = q[1]; return R; }
+__device__ __forceinline__ void asm_gather(AsmGather &G, const AsmRow &R, const double *pose0, const double *res0) {
+	const int m = (int)(R.a.z >> 30); const unsigned iD[3] = {R.a.x & 0xffffu, R.a.x >> 16, R.a.y & 0xffffu};
+	// a pose is [x y phi cos sin]: the blocks need x, y, cos, sin -- two 16-byte requests per lane instead of three
+#pragma unroll
+	for (int a = 0; a < 3; a++) if (a < m) {
+		const double *pd = pose0 + (iD[a] ? iD[a] - 1 : 0u) * 5u;
+		if (!(SRBA_ASM_KO & 4)) { ldn<2>(G.D[a], pd); ldn<2>(G.D[a] + 2, pd + 3); } else { G.D[a][0] = (double)iD[a]; G.D[a][1] = 1; G.D[a][2] = 0.6; G.D[a][3] = 0.8; }
+	}
+	if (m > 0) { if (!(SRBA_ASM_KO & 2)) ldn<3>(G.r, res0 + (R.a.y >> 16) * 3u); else { G.r[0] = (double)R.a.y; G.r[1] = 1; G.r[2] = 2; } }
+}
+
+template <int LAMBDA, int WPW>
+__global__ void __launch_bounds__(64 * WPW) __attribute__((amdgpu_waves_per_eu(SRBA_ASM_WAVES))) k_assemble_se2rel(const Batch B, const DevParams prm, const AsmTables T) {
+	// a workgroup is a bin of capsules whose LDS images share its allocation (packed at upload); its wavefronts work independently, one capsule each
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const AsmDesc &d = T.desc[blockIdx.x * WPW + wave]; // descriptors in bin order; wave-uniform: scalar loads
 	if (d.pidx < 0) return;
-	long long *tick = B.phase_cycles ? B.phase_cycles + 16 * (long long)d.pidx : nullptr; // SRBA_HIP_PHASE_TIMING=1: slots 0..3 = start, end of A, end of B, end (100 MHz ticks)
-	if (tick && (threadIdx.x & 63) == 0) tick[0] = wall_clock64();
-	const bool STAGE = d.stage != 0; // the Hessian blocks go through LDS and leave as one contiguous span; 0 (large windows): every block is stored by the lane that summed it, half the image
-	const int tid = threadIdx.x & 63, n_bp = d.n_bp, n_terms = d.n_terms, cb = d.cb, ct = d.ct, n_hap = d.n_hap, nK = d.nK;
-	// LDS image of the capsule: four numbers per block slot | the Hessian blocks | the gradient | the unknown edges' own poses
-	const int nslot = 64 * cb;
-	double *K4 = srba_lds + (d.lds_off >> 3), *Hb = K4 + 4 * nslot, *gb = Hb + (STAGE ? 9 * n_hap : 0), *eb = gb + 3 * nK;
-	double *Hglob = B.HAp + d.o_hap * 9;
+	long long *tick = B.phase_cycles ? B.phase_cycles + 16 * (long long)d.pidx : nullptr; // SRBA_HIP_PHASE_TIMING=1: slots 0..3 = start, image ready, sums done, end (100 MHz ticks)
+	const int tid = threadIdx.x & 63, rounds = d.rounds, n_hap = d.n_hap, nK = d.nK;
+	if (tick && tid == 0) { tick[0] = wall_clock64(); // slot 4: where it ran (HW_ID: wave [3:0] SIMD [5:4] CU [11:8] SH [12] SE [15:13]; XCC_ID) -- tools/diag_assemble.py builds the per-CU timeline from it
+		tick[4] = (long long)(unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | (long long)(__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0xf) << 32; }
+	double *Hb = srba_lds + (d.lds_off >> 3), *gb = Hb + 9 * n_hap, *eb = gb + 3 * nK + ((n_hap + nK) & 1); // (eb on 16 bytes)
 	const double *lam = prm.lambda; // wave-uniform: stays in scalar registers
 	const double sc = (prm.noise == SRBA_NOISE_IDENTITY) ? prm.inv_sigma : 1.0; const bool latch = prm.solver != SRBA_SOLVER_NO_SCHUR_SPARSE_CHOL,
 		keep = (prm.ext & SRBA_EXT_SCHUR_KEEPS_GRADIENT) != 0;
-	double dmax = 0;
 	const double *pose0 = B.pose + d.o_pose, *edge0 = B.edge + d.o_edge, *res0 = B.resid + d.o_res;
-	const unsigned long long *br = T.blk + d.o_bp, *tr = T.term + d.o_hapt;
-	// requests that do not depend on one another leave together: the first block records, the first term records, the poses of the unknown edges (one contiguous span)
-	unsigned long long mn[U], rec[U];
+	const AsmRec *rp = T.rec + d.o_rec + tid;
+	// requests that depend on the descriptor only leave together: the records of the first two passes, the poses of the unknown edges, the diagonal block of every unknown
+	AsmRow R0 = asm_row(rp, 0), R1 = R0; if (rounds > 1) R1 = asm_row(rp, 64);
+	const int hd0 = tid < nK ? B.hap_diag[d.o_unk + tid] : 0;
+	for (int k0 = 0; k0 < 5 * nK; k0 += 256) { double v[4]; // (four requests in flight: a loop of load -> store waits a round trip per 64 doubles)
 #pragma unroll
-	for (int u = 0; u < U; u++) if (u < cb) mn[u] = br[min(tid * cb + u, n_bp - 1)]; // (wave-uniform conditions) clamped, unconditional loads
+		for (int u = 0; u < 4; u++) { const int k = k0 + 64 * u + tid; v[u] = edge0[min(k, 5 * nK - 1)]; }
 #pragma unroll
-	for (int u = 0; u < U; u++) rec[u] = (n_terms > 0 && u < ct) ? tr[min(tid * ct + u, n_terms - 1)] : 0ull;
-	for (int k = tid; k < PD * nK; k += 64) eb[k] = edge0[k];
-	asm_sync();
-	// ---- A: blocks (cb consecutive blocks per lane; the blocks are sorted by unknown): four numbers per block to LDS, gradient and diagonal Hessian block per unknown
-	auto emitA = [&](unsigned lo, unsigned hi, const double (&tot)[9]) { // tot: gradient (3), upper triangle of the diagonal block (00 01 02 11 12 22; Lambda is symmetric)
-		const int col = (lo >> 16) & 0x1fff, diag = hi >> 16;
-		double *go = gb + 3 * col; go[0] = tot[0] * sc; go[1] = tot[1] * sc; go[2] = tot[2] * sc;
-		const double H[9] = {tot[3] * sc, tot[4] * sc, tot[5] * sc, tot[4] * sc, tot[6] * sc, tot[7] * sc, tot[5] * sc, tot[7] * sc, tot[8] * sc};
-		if (STAGE) { double *ho = Hb + 9 * diag;
-#pragma unroll
-			for (int k = 0; k < 9; k++) ho[k] = H[k];
-		} else { stn<9>(Hglob + 9 * (long long)diag, H); if (latch) stn<9>(B.HAp0 + (d.o_hap + diag) * 9, H); }
-		dmax = fmax(dmax, fmax(H[0], fmax(H[4], H[8])));
-	};
-#ifdef SRBA_ASM_TICKS
-#define ASM_TICK(slot, cond) do { if (tick && (cond)) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (tid == 0) tick[slot] = wall_clock64(); } } while (0)
-#else
-#define ASM_TICK(slot, cond) do { } while (0)
-#endif
-	AsmRuns<9> RA; RA.init();
-	ASM_TICK(4, true);
-	for (int s0 = 0; s0 < cb; s0 += U) {
-		unsigned long long m[U];
-#pragma unroll
-		for (int u = 0; u < U; u++) m[u] = mn[u];
-#pragma unroll
-		for (int u = 0; u < U; u++) if (s0 + U + u < cb) mn[u] = br[min(tid * cb + s0 + U + u, n_bp - 1)]; // the records of the next four blocks travel with this group's gathers
-		// a pose is [x y phi cos sin]: the blocks need x, y, cos, sin -- two 16-byte requests per lane instead of three
-		double D[U][4], r[U][3];
-#pragma unroll
-		for (int u = 0; u < U; u++) if (s0 + u < cb) {
-			const unsigned lo = (unsigned)m[u], hi = (unsigned)(m[u] >> 32); const int iD = (int)(lo & 0xffff) - 1;
-			const double *pd = pose0 + (unsigned)max(iD, 0) * PD; if (!(SRBA_ASM_KO & 4)) { ldn<2>(D[u], pd); ldn<2>(D[u] + 2, pd + 3); } else { D[u][0] = (double)lo; D[u][1] = 1; D[u][2] = 0.6;
-				D[u][3] = 0.8; }
-			if (!(SRBA_ASM_KO & 2)) ldn<3>(r[u], res0 + (hi & 0xffff) * 3); else { r[u][0] = (double)hi; r[u][1] = 1; r[u][2] = 2; }
-		}
-		ASM_TICK(5, s0 == 0);
-#pragma unroll
-		for (int u = 0; u < U; u++) if (s0 + u < cb) {
-			const unsigned lo = (unsigned)m[u], hi = (unsigned)(m[u] >> 32); const int iD = (int)(lo & 0xffff) - 1; const bool inverse = (lo & 0x20000000u) != 0;
-			if (tid * cb + s0 + u < n_bp) {
-				double x = D[u][0], y = D[u][1], c = D[u][2], s = D[u][3];
-				if (iD < 0) { x = 0; y = 0; c = 1; s = 0; }
-				if (inverse) { // D' = p (+) D (jacobians.h:684-711), p = the edge's own pose (staged in LDS)
-					const double *pp = eb + ((lo >> 16) & 0x1fff) * PD; const double px = pp[0], py = pp[1], pc = pp[3], ps = pp[4];
-					const double nx = px + x * pc - y * ps, ny = py + x * ps + y * pc, nc = pc * c - ps * s, ns = ps * c + pc * s; x = nx; y = ny; c = nc; s = ns;
-				}
-				const double kk[4] = {c, s, x * s - y * c, x * c + y * s};
-				double *dst = K4 + (s0 + u) * 64 + tid; // four planes of 64 cb slots: consecutive lanes write consecutive doubles (no bank conflict)
-#pragma unroll
-				for (int k = 0; k < 4; k++) dst[k * nslot] = kk[k];
-				double v[9], t[3], M[9], Hd[9];
-				if constexpr (LAMBDA == 2) { for (int k = 0; k < 3; k++) t[k] = lam[k * 3] * r[u][0] + lam[k * 3 + 1] * r[u][1] + lam[k * 3 + 2] * r[u][2]; }
-				else if constexpr (LAMBDA == 1) { for (int k = 0; k < 3; k++) t[k] = lam[k * 4] * r[u][k]; }
-				else { for (int k = 0; k < 3; k++) t[k] = r[u][k]; }
-				const double sg = inverse ? -1.0 : 1.0;
-				v[0] = sg * (c * t[0] - s * t[1]); v[1] = sg * (s * t[0] + c * t[1]); v[2] = sg * (kk[2] * t[0] + kk[3] * t[1] + t[2]); // J^t Lambda r, J = sg K
-				asm_lambda_k<LAMBDA>(M, kk, lam); asm_kt_m(Hd, kk, M);                                                               // J^t Lambda J = K^t Lambda K (symmetric)
-				v[3] = Hd[0]; v[4] = Hd[1]; v[5] = Hd[2]; v[6] = Hd[4]; v[7] = Hd[5]; v[8] = Hd[8];
-				RA.item(s0 + u, v, lo, hi, lo, emitA);
-			}
-		}
-		ASM_TICK(6, s0 == 0);
-	}
-	ASM_TICK(7, true);
-	RA.finish(tid, [](unsigned lo, unsigned) { return (int)((lo >> 16) & 0x1fff); }, emitA);
+		for (int u = 0; u < 4; u++) { const int k = k0 + 64 * u + tid; if (k < 5 * nK) eb[k] = v[u]; } }
+	{ const int nz = 9 * n_hap + 3 * nK; f64x2u z; z.x = 0; z.y = 0; for (int k = 2 * tid; k < nz; k += 128) *(f64x2u *)(Hb + k) = z; } // (the image has room for an odd tail)
+	AsmGather G0, G1; asm_gather(G0, R0, pose0, res0);
 	asm_sync();
 	if (tick && tid == 0) tick[1] = wall_clock64();
-	// ---- B: off-diagonal Hessian blocks: ct consecutive terms per lane (the term list is sorted by Hessian block)
-	if (n_terms > 0) {
-		auto emitB = [&](unsigned, unsigned hi, const double (&tot)[9]) {
-			const long long blk = hi & 0x3fffffff;
-			if (STAGE) { double *ho = Hb + 9 * blk;
+	for (int r = 0; r < rounds; r++) {
+		AsmRow R2 = R1; if (r + 2 < rounds) R2 = asm_row(rp, 64 * (r + 2));
+		if (r + 1 < rounds) asm_gather(G1, R1, pose0, res0);
+		{ // the sums of the rows of this pass
+			const uint4 qa = R0.a, qb = R0.b; const int m = (int)(qa.z >> 30);
+			if (m > 0) {
+				const unsigned col[3] = {qa.z & 0x3ffu, (qa.z >> 10) & 0x3ffu, (qa.z >> 20) & 0x3ffu}, dg[3] = {qb.x & 0xffffu, qb.x >> 16, qb.y & 0xffffu},
+					xb[3] = {qb.y >> 16, qb.z & 0xffffu, qb.z >> 16}, iD[3] = {qa.x & 0xffffu, qa.x >> 16, qa.y & 0xffffu};
+				double t[3];
+				if constexpr (LAMBDA == 2) { for (int k = 0; k < 3; k++) t[k] = lam[k * 3] * G0.r[0] + lam[k * 3 + 1] * G0.r[1] + lam[k * 3 + 2] * G0.r[2]; }
+				else if constexpr (LAMBDA == 1) { for (int k = 0; k < 3; k++) t[k] = lam[k * 4] * G0.r[k]; }
+				else { for (int k = 0; k < 3; k++) t[k] = G0.r[k]; }
+				double K[3][4], M[3][9];
 #pragma unroll
-				for (int k = 0; k < 9; k++) ho[k] = tot[k] * sc;
-			} else { double H[9];
-#pragma unroll
-				for (int k = 0; k < 9; k++) H[k] = tot[k] * sc;
-				stn<9>(Hglob + 9 * blk, H); if (latch) stn<9>(B.HAp0 + (d.o_hap + blk) * 9, H); }
-		};
-		AsmRuns<9> RB; RB.init();
-		for (int s0 = 0; s0 < ct; s0 += U) {
-			unsigned long long cur[U];
-#pragma unroll
-			for (int u = 0; u < U; u++) cur[u] = rec[u];
-#pragma unroll
-			for (int u = 0; u < U; u++) if (s0 + U + u < ct) rec[u] = tr[min(tid * ct + s0 + U + u, n_terms - 1)]; // the next group
-#pragma unroll
-			for (int u = 0; u < U; u++) if (s0 + u < ct) {
-				if (tid * ct + s0 + u < n_terms) {
-					const unsigned lo = (unsigned)cur[u], hi = (unsigned)(cur[u] >> 32);
-					double A[4], Bm[4], M[9], v[9];
-					const double *pa = K4 + (lo & 0x7fff), *pb = K4 + (lo >> 16);
-#pragma unroll
-					for (int k = 0; k < 4; k++) { A[k] = pa[k * nslot]; Bm[k] = pb[k * nslot]; }
-					asm_lambda_k<LAMBDA>(M, Bm, lam); asm_kt_m(v, A, M);
-					if (lo & 0x8000u) { // the two blocks have opposite directions: J1^t Lambda J2 = - K1^t Lambda K2
-#pragma unroll
-						for (int k = 0; k < 9; k++) v[k] = -v[k];
+				for (int a = 0; a < 3; a++) if (a < m) {
+					double x = G0.D[a][0], y = G0.D[a][1], c = G0.D[a][2], s = G0.D[a][3];
+					if (iD[a] == 0) { x = 0; y = 0; c = 1; s = 0; }
+					const bool inverse = ((qa.w >> a) & 1u) != 0;
+					if (inverse) { // D' = p (+) D (jacobians.h:684-711), p = the edge's own pose (staged in LDS)
+						const double *pp = eb + col[a] * 5u; const double px = pp[0], py = pp[1], pc = pp[3], ps = pp[4];
+						const double nx = px + x * pc - y * ps, ny = py + x * ps + y * pc, nc = pc * c - ps * s, ns = ps * c + pc * s; x = nx; y = ny; c = nc; s = ns;
 					}
-					RB.item(s0 + u, v, lo, hi, hi, emitB);
+					K[a][0] = c; K[a][1] = s; K[a][2] = x * s - y * c; K[a][3] = x * c + y * s;
+					const double sg = inverse ? -1.0 : 1.0;
+					asm_lambda_k<LAMBDA>(M[a], K[a], lam);
+					if (!(SRBA_ASM_KO & 8)) {
+						double *go = gb + 3 * col[a]; // J^t Lambda r, J = sg K
+						lds_add(go, sg * (c * t[0] - s * t[1])); lds_add(go + 1, sg * (s * t[0] + c * t[1])); lds_add(go + 2, sg * (K[a][2] * t[0] + K[a][3] * t[1] + t[2]));
+						double Hd[9]; asm_kt_m(Hd, K[a], M[a]); // J^t Lambda J = K^t Lambda K: symmetric, the upper triangle is summed (mirrored below)
+						double *ho = Hb + 9 * dg[a]; lds_add(ho, Hd[0]); lds_add(ho + 1, Hd[1]); lds_add(ho + 2, Hd[2]); lds_add(ho + 4, Hd[4]); lds_add(ho + 5, Hd[5]); lds_add(ho + 8, Hd[8]);
+					}
+				}
+				// cross terms (a, b), a < b: J_a^t Lambda J_b = sg_a sg_b K_a^t Lambda K_b into the block (unknown of a, unknown of b)
+#pragma unroll
+				for (int sidx = 0; sidx < 3; sidx++) { const int a = sidx == 2 ? 1 : 0, b = sidx == 0 ? 1 : 2;
+					if (b < m && xb[sidx] != 0xffffu && !(SRBA_ASM_KO & 8)) {
+						double v[9]; asm_kt_m(v, K[a], M[b]); const double sg = ((qa.w >> (4 + sidx)) & 1u) ? -1.0 : 1.0; double *ho = Hb + 9 * xb[sidx];
+#pragma unroll
+						for (int k = 0; k < 9; k++) lds_add(ho + k, sg * v[k]);
+					}
 				}
 			}
 		}
-		RB.finish(tid, [](unsigned, unsigned hi) { return (int)(hi & 0x3fffffff); }, emitB);
+		R0 = R1; R1 = R2; G0 = G1;
 	}
 	asm_sync();
 	if (tick && tid == 0) tick[2] = wall_clock64();
-	// ---- C: the Hessian blocks and the gradient leave as contiguous spans (16 bytes per lane and request), lambda guess
-	if (STAGE && !(SRBA_ASM_KO & 1)) {
-		double *Hg = B.HAp + d.o_hap * 9, *H0 = B.HAp0 + d.o_hap * 9; const int nh = 9 * n_hap;
-		for (int k = 2 * tid; k < nh; k += 128) {
-			if (k + 1 < nh) { f64x2u v; v.x = Hb[k]; v.y = Hb[k + 1]; *(f64x2u *)(Hg + k) = v; if (latch) *(f64x2u *)(H0 + k) = v; }
-			else { Hg[k] = Hb[k]; if (latch) H0[k] = Hb[k]; }
+	// the lower triangle of the diagonal blocks, lambda guess
+	double dmax = 0;
+	for (int k = tid; k < nK; k += 64) { const int hd = k < 64 ? hd0 : B.hap_diag[d.o_unk + k]; double *h = Hb + 9 * hd; const double h1 = h[1], h2 = h[2], h5 = h[5]; h[3] = h1; h[6] = h2; h[7] = h5;
+		dmax = fmax(dmax, fmax(h[0], fmax(h[4], h[8]))); }
+	asm_sync();
+	// the Hessian blocks and the gradient leave as contiguous spans (16 bytes per lane and request)
+	if (!(SRBA_ASM_KO & 1)) {
+		double *Hg = B.HAp + d.o_hap * 9, *H0 = B.HAp0 + d.o_hap * 9; const int nh = 9 * n_hap; typedef double f64x2a __attribute__((ext_vector_type(2), aligned(16)));
+		for (int k0 = 0; k0 < nh; k0 += 512) { f64x2a v[4]; // four 16-byte reads of the image in flight, then the stores
+#pragma unroll
+			for (int u = 0; u < 4; u++) { const int k = k0 + 128 * u + 2 * tid; if (k < nh) v[u] = *(const f64x2a *)(Hb + k); } // (an odd tail reads the pad / first gradient entry)
+#pragma unroll
+			for (int u = 0; u < 4; u++) { const int k = k0 + 128 * u + 2 * tid;
+				if (k + 1 < nh) { f64x2u w; w.x = v[u].x * sc; w.y = v[u].y * sc; *(f64x2u *)(Hg + k) = w; if (latch) *(f64x2u *)(H0 + k) = w; }
+				else if (k < nh) { const double w = v[u].x * sc; Hg[k] = w; if (latch) H0[k] = w; } }
 		}
 	}
-	if (!(SRBA_ASM_KO & 16)) { double *go = B.grad + d.o_scal; for (int k = tid; k < 3 * nK; k += 64) { const double v = gb[k]; go[k] = v; if (keep) B.grad0[d.o_scal + k] = v; } }
-	const double l0 = 1e-3 * wave_max(dmax);
+	if (!(SRBA_ASM_KO & 16)) { double *go = B.grad + d.o_scal; for (int k = tid; k < 3 * nK; k += 64) { const double v = gb[k] * sc; go[k] = v; if (keep) B.grad0[d.o_scal + k] = v; } }
+	const double l0 = 1e-3 * (wave_max(dmax) * sc);
 	if (tid == 0) { B.lambda_io[d.pidx] = l0; B.results[d.pidx].num_invalid_jacobs = 0; if (tick) tick[3] = wall_clock64(); }
 }
 
-int asm_launch(int lambda_mode, int n_bins, size_t lds_bytes, hipStream_t stream, const Batch &B, const DevParams &prm, const AsmTables &T) {
-	static bool attr_done[3] = {false, false, false}; // the bins are larger than the 64 KB a launch may ask for by default
-	auto go = [&](auto kernel, int which) -> int {
-		if (lds_bytes > 64 * 1024 && !attr_done[which]) { hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_BIN_BYTES);
-			if (e != hipSuccess) return (int)e; attr_done[which] = true; }
-		hipLaunchKernelGGL(kernel, dim3(n_bins), dim3(64 * ASM_WAVES_PER_WG), lds_bytes, stream, B, prm, T);
+int asm_launch(int lambda_mode, int wpw, int n_bins, size_t lds_bytes, hipStream_t stream, const Batch &B, const DevParams &prm, const AsmTables &T) {
+	static bool attr_done[3][3] = {}; // the bins may be larger than the 64 KB a launch may ask for by default
+	auto go = [&](auto kernel, int which, int threads) -> int { const int wi = wpw == 4 ? 2 : wpw == 2 ? 1 : 0;
+		if (lds_bytes > 64 * 1024 && !attr_done[which][wi]) { hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+			if (e != hipSuccess) return (int)e; attr_done[which][wi] = true; }
+		hipLaunchKernelGGL(kernel, dim3(n_bins), dim3(threads), lds_bytes, stream, B, prm, T);
 		return (int)hipGetLastError();
 	};
-	return lambda_mode == 2 ? go(k_assemble_se2rel<2>, 2) : lambda_mode == 1 ? go(k_assemble_se2rel<1>, 1) : go(k_assemble_se2rel<0>, 0);
+#define SRBA_ASM_GO(L) (wpw == 4 ? go(k_assemble_se2rel<L, 4>, L, 256) : wpw == 2 ? go(k_assemble_se2rel<L, 2>, L, 128) : go(k_assemble_se2rel<L, 1>, L, 64))
+	return lambda_mode == 2 ? SRBA_ASM_GO(2) : lambda_mode == 1 ? SRBA_ASM_GO(1) : SRBA_ASM_GO(0);
+#undef SRBA_ASM_GO
+}
+
+void asm_config(int &wpw, int &bin_bytes) {
+	wpw = ASM_MAX_WPW; int kb = ASM_DEFAULT_BIN_KB;
+	if (const char *e = getenv("SRBA_HIP_ASM_WPW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) wpw = v; }
+	if (const char *e = getenv("SRBA_HIP_ASM_BIN_KB")) { const int v = atoi(e); if (v >= 4 && v <= 160) kb = v; }
+	bin_bytes = kb * 1024;
+}
+
+// Bins: the largest remaining image opens a bin, takes the next largest ones that fit beside it (similar windows end at similar times) and then the smallest ones that fill what is
+// left. Bins come out largest first = dispatch order.
+int asm_plan(int n, const AsmDesc *dsc, const int *rounds, size_t cap, int wpw, int bin_bytes, AsmDesc *out, int32_t *rest, int &n_rest) {
+	std::vector<size_t> need(n); std::vector<int> fit; fit.reserve(n); n_rest = 0; cap = std::min(cap, (size_t)bin_bytes);
+	for (int p = 0; p < n; p++) { need[p] = asm_image_bytes(dsc[p].n_hap, dsc[p].nK); if (rounds[p] > 0 && need[p] <= cap) fit.push_back(p); else rest[n_rest++] = p; }
+	std::stable_sort(fit.begin(), fit.end(), [&](int x, int y) { return need[x] != need[y] ? need[x] < need[y] : rounds[x] < rounds[y]; });
+	int nb = 0; AsmDesc none; std::memset(&none, 0, sizeof(none)); none.pidx = -1;
+	for (size_t lo = 0, hi = fit.size(); lo < hi;) { AsmDesc *e = out + (size_t)wpw * nb; size_t used = 0; int w = 0;
+		while (w < wpw && lo < hi && used + need[fit[hi - 1]] <= (size_t)bin_bytes) { hi--; e[w] = dsc[fit[hi]]; e[w].lds_off = (int)used; used += need[fit[hi]]; w++; }
+		while (w < wpw && lo < hi && used + need[fit[lo]] <= (size_t)bin_bytes) { e[w] = dsc[fit[lo]]; e[w].lds_off = (int)used; used += need[fit[lo]]; w++; lo++; }
+		for (; w < wpw; w++) e[w] = none;
+		nb++; }
+	static const int mix = getenv("SRBA_HIP_ASM_MIX") ? atoi(getenv("SRBA_HIP_ASM_MIX")) : 0; // experiment: bins of big and small windows alternate in the dispatch order
+	if (mix > 0 && nb > 2) { std::vector<AsmDesc> t(out, out + (size_t)wpw * nb); int lo = 0, hi = nb - 1;
+		for (int q = 0; q < nb; q++) { const int src = (q % (mix + 1)) == 0 ? lo++ : hi--; std::memcpy(out + (size_t)wpw * q, t.data() + (size_t)wpw * src, sizeof(AsmDesc) * wpw); } }
+	return nb;
+}
+
+// ---- host: the records of one capsule (srba_assemble.hpp)
+int asm_pack(const srba_problem_capsule &k, AsmRec *dst) {
+	const int nK = k.n_unk_edges, n_obs = k.n_obs, n_bp = k.n_bp;
+	if (n_bp < 1 || 2 * (long long)k.n_pairs > ASM_MAX_IDX || n_obs > ASM_MAX_IDX || nK > ASM_MAX_NK || nK < 1 || k.n_hap > ASM_MAX_IDX) return 0;
+	// the blocks of every row, in block order (= ascending unknown: the blocks are listed unknown by unknown)
+	std::vector<unsigned char> cnt(n_obs, 0); std::vector<int> blk(3 * (size_t)n_obs, -1), loc(n_bp, 0);
+	for (int b = 0; b < n_bp; b++) { const int r = k.bp_res[b]; if (r < 0 || r >= n_obs || cnt[r] == 3 || k.bp_D[b] < -1 || k.bp_col[b] < 0 || k.bp_col[b] >= nK) return 0;
+		if (cnt[r] > 0 && k.bp_col[blk[3 * (size_t)r + cnt[r] - 1]] >= k.bp_col[b]) return 0; loc[b] = cnt[r]; blk[3 * (size_t)r + cnt[r]++] = b; }
+	// the diagonal Hessian block of unknown i sums exactly the self products of the blocks of its column
+	for (int i = 0; i < nK; i++) { const int bb = k.colp_off[i], be = k.colp_off[i + 1], hd = k.hap_diag[i]; if (be < bb || hd < 0 || hd >= k.n_hap || k.hap_term_off[hd + 1] - k.hap_term_off[hd] != be - bb) return 0;
+		for (int b = bb; b < be; b++) { const int t = k.hap_term_off[hd] + (b - bb); if (k.bp_col[b] != i || k.hap_t1[t] != b || k.hap_t2[t] != b) return 0; } }
+	if (k.colp_off[nK] != n_bp) return 0;
+	// every off-diagonal term pairs two blocks of one row, the lower block first
+	std::vector<uint16_t> xb(3 * (size_t)n_obs, 0xffff); long long n_off = 0;
+	for (int h = 0; h < k.n_hap; h++) if (k.hap_i[h] != k.hap_j[h]) for (int t = k.hap_term_off[h]; t < k.hap_term_off[h + 1]; t++) {
+		const int t1 = k.hap_t1[t], t2 = k.hap_t2[t]; if (t1 < 0 || t2 < 0 || t1 >= n_bp || t2 >= n_bp) return 0;
+		const int r = k.bp_res[t1], a = loc[t1], b = loc[t2]; if (k.bp_res[t2] != r || a >= b || k.bp_col[t1] != k.hap_i[h] || k.bp_col[t2] != k.hap_j[h]) return 0;
+		uint16_t &s = xb[3 * (size_t)r + (a + b - 1)]; if (s != 0xffff) return 0; s = (uint16_t)h; n_off++; }
+	if (n_off + n_bp != k.n_hap_terms) return 0;
+	// rows with blocks, sorted by their unknowns and dealt to the 16-lane groups of the passes round-robin: rows that add to the same gradient entries and Hessian blocks are
+	// neighbours in the sorted list and land in different groups (the LDS serialises lanes of one group that hit one address)
+	std::vector<int> act; act.reserve(n_obs); for (int r = 0; r < n_obs; r++) if (cnt[r]) act.push_back(r);
+	auto key = [&](int r) { unsigned long long v = 0; for (int a = 0; a < 3; a++) v = v << 16 | (unsigned long long)(a < cnt[r] ? k.bp_col[blk[3 * (size_t)r + a]] + 1 : 0); return v; };
+	static const int deal = getenv("SRBA_HIP_ASM_DEAL") ? atoi(getenv("SRBA_HIP_ASM_DEAL")) : 0; // experiments: 1 = rows in ascending order, lane after lane; 2 = by the pose of their first block
+	if (deal == 0) std::stable_sort(act.begin(), act.end(), [&](int x, int y) { return key(x) < key(y); });
+	if (deal == 2) std::stable_sort(act.begin(), act.end(), [&](int x, int y) { return k.bp_D[blk[3 * (size_t)x]] < k.bp_D[blk[3 * (size_t)y]]; });
+	const int n_act = (int)act.size(), rounds = (n_act + 63) / 64, ng = deal == 0 ? 4 * rounds : 1;
+	for (int i = 0; i < n_act; i++) { const int r = act[i], m = cnt[r]; AsmRec &R = dst[deal == 0 ? (size_t)(i % ng) * 16 + i / ng : (size_t)i]; uint32_t D[3] = {0, 0, 0}, col[3] = {0, 0, 0}, dg[3] = {0, 0, 0}, fl = 0;
+		for (int a = 0; a < m; a++) { const int b = blk[3 * (size_t)r + a]; D[a] = (uint32_t)(k.bp_D[b] + 1); col[a] = (uint32_t)k.bp_col[b]; dg[a] = (uint32_t)k.hap_diag[k.bp_col[b]]; if (!k.bp_normal[b]) fl |= 1u << a; }
+		for (int s = 0; s < 3; s++) { const int a = s == 2 ? 1 : 0, b = s == 0 ? 1 : 2; if (b < m && (((fl >> a) ^ (fl >> b)) & 1u)) fl |= 1u << (4 + s); }
+		const uint16_t *x = &xb[3 * (size_t)r];
+		R.w[0] = D[0] | D[1] << 16; R.w[1] = D[2] | (uint32_t)r << 16; R.w[2] = col[0] | col[1] << 10 | col[2] << 20 | (uint32_t)m << 30; R.w[3] = fl;
+		R.w[4] = dg[0] | dg[1] << 16; R.w[5] = dg[2] | (uint32_t)x[0] << 16; R.w[6] = (uint32_t)x[1] | (uint32_t)x[2] << 16; R.w[7] = 0; }
+	return rounds;
 }
 } // namespace srbadev

@@ -6,45 +6,63 @@
  * (sparse_hessian_update_numeric.h:26-58), minus_grad_i = sum_k J_ki^t Lambda r_k (compute_minus_gradient.h:20-91) and the initial lambda
  * (optimize_edges.h:366-390: 1e-3 * the largest diagonal entry).
  *
- * How (one wavefront per capsule; two capsules share a workgroup = a bin of 40 KB of LDS packed at upload -- the largest remaining image with the smallest that fits beside
- * it --, ONE launch for the batch, largest bins first; per capsule the chip holds
- * 32 bytes per block, its Hessian blocks, its gradient and the poses of its unknown edges in LDS):
- *   A  every lane owns cb = ceil(n_bp / 64) CONSECUTIVE blocks (the capsule lists its blocks unknown by unknown), four in flight: it reads their packed records (8 bytes:
- *      D pose, unknown slot, residual row, direction, diagonal Hessian block), gathers the keyframe-relative pose D (and the edge's own pose for an inverse edge) and
- *      the residual row, and forms the block in registers. A block of this family is
+ * How (round 6: OBSERVATION-major). Every Hessian term pairs two Jacobian blocks of ONE observation row, and a row of this family has at most three blocks (the unknown
+ * edges on the spanning-tree path between its two key-frames, tree depth 3: 49 % of the rows of the benchmark batch have none, 6 % one, 33 % two, 8 % three). So a LANE
+ * owns an observation row: it gathers the row's residual and the key-frame-relative pose D of each of its blocks, forms the blocks in registers -- a block of this family is
  *          J = sg * K,  K = [ c  s  x s - y c ;  -s  c  x c + y s ;  0 0 1 ]      (c, s, x, y of D' = D or p (+) D; the device keeps cos / sin next to every pose)
- *      i.e. FOUR numbers and a sign: the numbers go to LDS (four planes: no bank conflicts), the sign stays in the records. J^t Lambda r (gradient) and J^t Lambda J (the term this block adds to the
- 	diagonal Hessian block of its unknown) are summed
- *      over the run of blocks of the unknown: serially inside a lane, and -- for a run that crosses lanes -- through ONE prefix scan over the wavefront per capsule;
- *      the lane that holds the last block of the run puts the unknown's gradient and diagonal block into the LDS image.
- *   B  every lane owns ct consecutive OFF-DIAGONAL terms (the list is sorted by Hessian block; its first records were requested before phase A): J1^t Lambda J2 from
- *      the two blocks in LDS (times the product of their signs), the same run sums, blocks into the LDS image.
- *   C  the Hessian blocks and the gradient leave the image as contiguous spans, 16 bytes per lane and request (windows whose image with the Hessian blocks does not fit a
- *      bin store every block from the lane that summed it and keep half the image); lambda guess out.
- * The run sums replace the per-pass segmented reductions of an earlier version of this kernel (54 cross-lane double moves per 64 terms: bound by VALU and
- * LDS-crossbar issue, 0.8 ms for the benchmark batch) and the one-lane-per-Hessian-block form before it (lanes idle behind the longest list, 0.6 ms); DESIGN 4b has the history.
- * HBM sees: 8 B of record, one pose gather (40 B; 80 B for inverse edges) and one residual row (24 B) per block, 8 B per off-diagonal term, 72 B per Hessian block,
- * 24 B per unknown, 96 B of descriptor per capsule. The Jacobian array is not touched: srba_hip_debug_read(1) materialises it on demand with the unfused kernel.
- *
- * Sums are formed in a fixed tree order (not the reference's sequential order): results are reproducible run to run and agree with the oracle to rounding.
- * Capsules whose image exceeds a bin even without its Hessian blocks, or whose indices do not fit the packed records, take k_linearize.
+ * i.e. FOUR numbers and a sign -- and adds J^t Lambda r, the three self products J_a^t Lambda J_a and the up to three cross products J_a^t Lambda J_b into the image of
+ * its capsule in LDS with ds_add_f64. A wavefront per capsule, `rounds` = ceil(rows with blocks / 64) passes; the records of the next pass and the gathers of the one after
+ * travel under the arithmetic of the current one. The image is the OUTPUT only (72 B per Hessian block + gradient + the poses of the unknown edges: 11 KB for the median
+ * window), not the Jacobian blocks: twelve capsules fit a CU instead of eight, and nothing is handed from one lane to another (the block-major kernel of rounds 3-5 kept 32 B per
+ * block in LDS for a second phase that paired blocks across lanes, ran two prefix scans per capsule and was bound by capsules-resident x latency: 0.37 ms, HISTORY 4b).
+ * One wavefront alone adds to an image and the LDS serves the lanes of an instruction in a fixed order: sums are reproducible run to run (tools/probes/lds_atomic_rate.hip
+ * measures both: 2.7 ns per conflict-free wavefront instruction at eight wavefronts per CU, x (lanes on one address) within a group of 16 lanes). The host deals the rows of a
+ * capsule to the lanes so that rows on the same unknowns land in different 16-lane groups.
+ * ONE launch: capsules are packed into bins (workgroups of four wavefronts sharing 52 KB of LDS), largest images first.
+ * HBM sees: 32 B of record per row with blocks, its residual row (24 B), one pose gather (32 of 40 B) per block, 72 B per Hessian block, 24 B per unknown out.
+ * The Jacobian array is not touched: srba_hip_debug_read(1) materialises it on demand with the unfused kernel.
+ * Capsules whose image exceeds a bin, with a row of more than three blocks or whose indices do not fit the packed records take k_linearize.
  */
 #pragma once
+#include <cstdint>
 
 namespace srbadev {
 
-// per wavefront of every bin (workgroup), in launch order. cb / ct: consecutive blocks / off-diagonal terms per lane (ceil(n / 64)); block b lives in LDS slot (b % cb) * 64 + b / cb
-struct AsmDesc { int pidx /* -1: this wavefront of the bin has no capsule */, n_bp, n_terms /* off-diagonal */, cb, ct, n_hap, nK, stage /* its Hessian blocks are staged in LDS */,
-	lds_off /* bytes: its image inside the bin */, pad; long long o_bp, o_hapt, o_pose /* doubles */, o_edge /* doubles */, o_res /* doubles */, o_hap, o_scal; };
-// blk : per Jacobian block, sorted by unknown   lo = (D pose index + 1) | unknown slot << 16 | inverse << 29 | first block of its unknown << 30 | last << 31
-//                                               hi = residual row | index of the unknown's diagonal Hessian block << 16
-// term: per OFF-DIAGONAL U_Ap term, sorted by Hessian block   lo = LDS slot of block t1 | (the two blocks have opposite directions) << 15 | slot of t2 << 16 ;
-	// hi = Hessian block | first term of its block << 30 | last << 31
-//       (the terms of a diagonal block pair every Jacobian block of the unknown with itself: they are formed with the blocks, in phase A)
-struct AsmTables { const AsmDesc *desc; const unsigned long long *blk, *term; };
-constexpr int ASM_WAVES_PER_WG = 2, ASM_BIN_BYTES = 40 * 1024; // four bins per CU (160 KB of LDS), eight wavefronts
+// per wavefront of every bin (workgroup), in launch order
+struct AsmDesc { int pidx /* -1: this wavefront of the bin has no capsule */, rounds /* passes of 64 rows */, n_hap, nK, lds_off /* bytes: its image inside the bin */, pad;
+	long long o_rec /* 32-byte records */, o_pose /* doubles */, o_edge /* doubles */, o_res /* doubles */, o_hap /* blocks */, o_scal /* doubles */, o_unk /* unknowns: hap_diag */; };
+// one observation row with m <= 3 blocks (a = 0..2 in block order = ascending unknown), 32 bytes:
+//   w0 = (D pose index of block 0) + 1 | (block 1) << 16        (0: D = identity)
+//   w1 = (block 2) + 1 | residual row << 16
+//   w2 = unknown slot of block 0 | block 1 << 10 | block 2 << 20 | m << 30
+//   w3 = bit a: block a belongs to an edge taken in its inverse direction ; bit 4 + s: the two blocks of cross term s have opposite directions
+//   w4 = diagonal Hessian block of unknown 0 | of unknown 1 << 16
+//   w5 = of unknown 2 | Hessian block of cross term (0,1) << 16      (0xffff: the plan has no such term)
+//   w6 = of cross term (0,2) | of cross term (1,2) << 16
+struct AsmRec { uint32_t w[8]; };
+struct AsmTables { const AsmDesc *desc; const AsmRec *rec; };
+constexpr int ASM_MAX_WPW = 4;          // wavefronts (capsules) per bin: 1, 2 or 4 (SRBA_HIP_ASM_WPW, default 4)
+constexpr int ASM_DEFAULT_BIN_KB = 52;  // three bins per CU: the LDS is handed out in granules, 3 x 53 KB does not fit the 160 KB of a CU (SRBA_HIP_ASM_BIN_KB)
+constexpr int ASM_MAX_NK = 1023, ASM_MAX_IDX = 65534;
 
+// LDS image of a capsule: Hessian blocks | gradient | poses of the unknown edges (5 doubles each), rounded to 64 bytes
+inline size_t asm_image_bytes(int n_hap, int nK) { return ((size_t)8 * (9 * (size_t)n_hap + 8 * (size_t)nK + 2) + 63) & ~(size_t)63; }
+// room for the records of a capsule (an upper bound known before they are built)
+inline long long asm_rec_room(int n_obs, int n_bp) { const int a = n_obs < n_bp ? n_obs : n_bp; return 64LL * ((a + 63) / 64); }
+
+} // namespace srbadev
+struct srba_problem_capsule;
+namespace srbadev {
+struct Batch; struct DevParams;
+// host: the packed records of one capsule into dst (asm_rec_room of them, cleared by the caller); returns the number of passes, 0 if the capsule does not fit the kernel
+int asm_pack(const srba_problem_capsule &k, AsmRec *dst);
+// host: launch geometry (environment or defaults)
+void asm_config(int &waves_per_bin, int &bin_bytes);
+// host: packs the capsules into bins. dsc[p]: descriptor of capsule p (lds_off unset), rounds[p] == 0: does not fit the kernel; cap: largest image taken. Writes waves_per_bin descriptors
+// per bin into out (room: ASM_MAX_WPW * n), the capsules left over into rest[0 .. n_rest); returns the number of bins
+int asm_plan(int n, const AsmDesc *dsc, const int *rounds, size_t cap, int waves_per_bin, int bin_bytes, AsmDesc *out, int32_t *rest, int &n_rest);
 // host entry of the translation unit that holds the kernels (srba_assemble.hip): ONE launch, a workgroup per bin
-int asm_launch(int lambda_mode /* 0 identity, 1 diagonal, 2 full matrix */, int n_bins, size_t lds_bytes, hipStream_t stream, const Batch &B, const DevParams &prm, const AsmTables &T);
+int asm_launch(int lambda_mode /* 0 identity, 1 diagonal, 2 full matrix */, int waves_per_bin, int n_bins, size_t lds_bytes, hipStream_t stream, const Batch &B, const DevParams &prm,
+	const AsmTables &T);
 
 } // namespace srbadev

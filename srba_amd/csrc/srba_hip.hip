@@ -1686,7 +1686,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hap_tblk, hf_i, hf_j, hf_term_off, hf_t1, hf_t2, hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag, sch_term_off, sch_b1, sch_b2,
 			sch_lm, sch_yw, sch_tblk, sch_vb, sch_rec,
 		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, obs_rec, pair_needed, pose_req, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_rptr, sp_rcol, sp_perm, sp_fill, hap_rec,
-			hapo, schl, ptab, hap_dst, hapf_dst, hf_dst, asm_term, asm_blk, asm_desc, asm_list, asm_slot; } o;
+			hapo, schl, ptab, hap_dst, hapf_dst, hf_dst, asm_rec, asm_desc, asm_list; } o;
 	o.desc = in.add(sizeof(ProbDesc) * n);
 	o.edge0 = in.add(8 * t_edge * PDX); o.ulm0 = in.add(8 * t_ulm * L); o.klm = in.add(8 * t_klm * L); o.obs_z = in.add(8 * t_obs * O);
 	o.pair_path_off = in.add(4 * (t_pair + n)); o.path_edge = in.add(4 * t_path); o.obs_pose = in.add(4 * t_obs); o.obs_lm = in.add(4 * t_obs); o.obs_valid = in.add(4 * t_obs);
@@ -1708,10 +1708,12 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	bool asm_fam = c->asm_on && c->params.family == SRBA_SE2_RELPOSE2D;
 	if (asm_fam && c->dp.noise == SRBA_NOISE_CONSTANT_MATRIX) for (int i = 0; i < 3; i++) for (int j = 0; j < i; j++) if (c->dp.lambda[3 * i + j] != c->dp.lambda[3 * j + i]) asm_fam = false;
 		// the fused kernel sums the upper triangle of J^t Lambda J only
-	o.asm_term = in.add(asm_fam ? 8 * std::max<long long>(t_hapt, 1) : 0); o.asm_blk = in.add(asm_fam ? 8 * std::max<long long>(t_bp, 1) : 0);
-		o.asm_desc = in.add(asm_fam ? sizeof(srbadev::AsmDesc) * (size_t)srbadev::ASM_WAVES_PER_WG * (size_t)n : 0); /* (at most one bin per capsule) */ o.asm_list = in.add(asm_fam ? 4 * (size_t)n :
-		0); o.asm_slot = in.add(0);
-	std::vector<unsigned char> asm_fit(asm_fam ? n : 0, 0); std::vector<int> asm_nt(asm_fam ? n : 0, 0); // per capsule: its indices fit the packed records; off-diagonal terms
+	// fused normal-equations kernel (srba_assemble.hpp): 32-byte row records, room per capsule known from its sizes
+	std::vector<long long> asm_ro(asm_fam ? n + 1 : 1, 0); if (asm_fam) for (int p = 0; p < n; p++) asm_ro[p + 1] = asm_ro[p] + srbadev::asm_rec_room(caps[p].n_obs, caps[p].n_bp);
+	o.asm_rec = in.add(asm_fam ? sizeof(srbadev::AsmRec) * (size_t)std::max<long long>(asm_ro[n], 1) : 0);
+		o.asm_desc = in.add(asm_fam ? sizeof(srbadev::AsmDesc) * (size_t)srbadev::ASM_MAX_WPW * (size_t)n : 0); /* (at most one bin per capsule) */ o.asm_list = in.add(asm_fam ? 4 * (size_t)n :
+		0);
+	std::vector<int> asm_rounds(asm_fam ? n : 0, 0); // per capsule: passes of the fused kernel (0: it does not fit its packed records)
 	in.add(0);
 	if (c->h2d_pending) { HIPCHK(c, hipEventSynchronize(c->ev_h2d)); c->h2d_pending = false; } // (an upload nobody waited for may still be reading the staging buffer)
 	if (c->h_in_cap < in.size + 256) { c->h_in.release(); c->h_in_cap = 0; const size_t want = in.size + 256 <= srba_hip_ctx::kPinnedMax / 2 ? 2 * (in.size + 256) : in.size + 256;
@@ -1811,22 +1813,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 					pt[2 * np + 3 + panel_of(b)] = q + 1; }
 			for (int q = 1; q <= np; q++) pt[2 * np + 2 + q] = std::max(pt[2 * np + 2 + q], pt[2 * np + 1 + q]);
 		}
-		if (asm_fam && k.n_bp >= 1 && k.n_bp <= 65536 && 2 * k.n_pairs < 65535 && k.n_obs <= 65536 && d.nK <= 8191 && k.n_hap <= 65536) {
-			// packed records of the fused normal-equations kernel (srba_assemble.hpp)
-			uint64_t *ab = (uint64_t *)(h + o.asm_blk) + d.o_bp, *at = (uint64_t *)(h + o.asm_term) + d.o_hapt; bool fit = true; const int cb = (k.n_bp + 63) / 64;
-			for (int i = 0; i < d.nK && fit; i++) { // the blocks of unknown i are colp_off[i] .. colp_off[i + 1] - 1, and its diagonal Hessian block sums exactly their J^t Lambda J
-				const int bb = k.colp_off[i], be = k.colp_off[i + 1], hd = k.hap_diag[i]; if (be <= bb || hd < 0 || k.hap_term_off[hd + 1] - k.hap_term_off[hd] != be - bb) { fit = false; break; }
-				for (int b = bb; b < be; b++) { const int t = k.hap_term_off[hd] + (b - bb); if (k.bp_col[b] != i || k.hap_t1[t] != b || k.hap_t2[t] != b || k.bp_D[b] < -1) fit = false;
-					ab[b] = (uint64_t)((uint32_t)(k.bp_D[b] + 1) | ((uint32_t)i << 16) | (k.bp_normal[b] ? 0u : 0x20000000u) | (b == bb ? 0x40000000u : 0u) | (b + 1 == be ? 0x80000000u : 0u)) |
-						((uint64_t)((uint32_t)k.bp_res[b] | ((uint32_t)hd << 16)) << 32); }
-			}
-			if (fit && k.colp_off[d.nK] != k.n_bp) fit = false;
-			int nt = 0; auto slot = [&](int b) { return (uint32_t)((b % cb) * 64 + b / cb); };
-			for (int b = 0; b < k.n_hap && fit; b++) if (k.hap_i[b] != k.hap_j[b]) { const int tb = k.hap_term_off[b], te = k.hap_term_off[b + 1]; if (te <= tb) { fit = false; break; }
-				for (int t = tb; t < te; t++) at[nt++] = (uint64_t)(slot(k.hap_t1[t]) | ((k.bp_normal[k.hap_t1[t]] != 0) != (k.bp_normal[k.hap_t2[t]] != 0) ? 0x8000u : 0u) | (slot(k.hap_t2[t]) <<
-					16)) | ((uint64_t)((uint32_t)b | (t == tb ? 0x40000000u : 0u) | (t + 1 == te ? 0x80000000u : 0u)) << 32); }
-			if (fit) { asm_fit[p] = 1; asm_nt[p] = nt; }
-		}
+		if (asm_fam) asm_rounds[p] = srbadev::asm_pack(k, (srbadev::AsmRec *)(h + o.asm_rec) + asm_ro[p]); // packed row records of the fused normal-equations kernel
 		CPY(o.hap_dst, d.o_hap * (P / 3) * (P / 3), sym[p].hap_dst.data(), sym[p].hap_dst.size(), int32_t); CPY(o.hapf_dst, d.o_hapf * (P / 3), sym[p].hapf_dst.data(), sym[p].hapf_dst.size(),
 			int32_t); CPY(o.hf_dst, d.o_hf, sym[p].hf_dst.data(), sym[p].hf_dst.size(), int32_t);
 		acc_blocks[thread] += d.nb + d.nnzoff; acc_items[thread] += (int64_t)sym[p].tgt.size();
@@ -1851,25 +1838,13 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		plan_launches(c, ord);
 	}
 	c->asm_ready = false; c->jp_stale = false;
-	if (asm_fam) { // fused normal equations: the LDS image of a capsule = 32 B per block slot (64 * cb slots) + gradient + poses of the unknown edges, + 72 B per Hessian block when
-		// the blocks are staged (windows whose full image fits a bin; larger ones store their blocks directly). Capsules of similar size share a bin (one workgroup, ASM_BIN_BYTES of
-		// LDS, a wavefront each): neighbours in the order of their images, as long as they fit together.
-		constexpr int W = srbadev::ASM_WAVES_PER_WG; const size_t cap = std::min<size_t>(srbadev::ASM_BIN_BYTES, (size_t)c->asm_max_kb * 1024);
-		std::vector<size_t> need(n, 0); std::vector<int> fit; fit.reserve(n); int32_t *al = (int32_t *)(h + o.asm_list); c->asm_rest = 0;
-		srbadev::AsmDesc *ad = (srbadev::AsmDesc *)(h + o.asm_desc); std::vector<srbadev::AsmDesc> dsc(n);
-		for (int p = 0; p < n; p++) { const ProbDesc &d = c->desc[p]; const int cb = (d.n_bp + 63) / 64; const size_t lean = (8 * (4 * 64 * (size_t)cb + 3 * (size_t)d.nK + PDX * (size_t)d.nK) + 255)
-			& ~(size_t)255, full = lean + 72 * (size_t)d.n_hap + 256;
-			const int stage = full <= cap ? 1 : 0; need[p] = stage ? full : lean;
-			if (asm_fit[p] && need[p] <= cap && cb <= 511) fit.push_back(p); else al[c->asm_rest++] = p;
-			dsc[p] = {p, d.n_bp, asm_nt[p], cb, (asm_nt[p] + 63) / 64, d.n_hap, d.nK, stage, 0, 0, d.o_bp, d.o_hapt, d.o_pair * 2 * PDX, d.o_edge * PDX, d.o_obs * O, d.o_hap, d.o_scal}; }
-		std::stable_sort(fit.begin(), fit.end(), [&](int x, int y) { return need[x] < need[y]; });
-		// bins of two: the largest remaining image takes the smallest remaining one that fits beside it (a window too large for any partner stays alone); bins come out
-		// largest first, which is also the dispatch order (the longest-running workgroups start first). The descriptors are stored in bin order, one per wavefront.
-		int nb = 0; static_assert(W == 2, "the packing below makes pairs"); srbadev::AsmDesc none; std::memset(&none, 0, sizeof(none)); none.pidx = -1;
-		for (size_t lo = 0, hi = fit.size(); lo < hi;) { srbadev::AsmDesc *e = ad + W * (size_t)nb; hi--; e[0] = dsc[fit[hi]]; e[0].lds_off = 0;
-			if (lo < hi && need[fit[hi]] + need[fit[lo]] <= cap) { e[1] = dsc[fit[lo]]; e[1].lds_off = (int)need[fit[hi]]; lo++; } else e[1] = none;
-			nb++; }
-		c->asm_bins = nb; c->asm_ready = true;
+	if (asm_fam) { // fused normal equations (srba_assemble.hpp): capsules packed into bins (one workgroup, a wavefront per capsule), descriptors in bin order
+		std::vector<srbadev::AsmDesc> dsc(n);
+		for (int p = 0; p < n; p++) { const ProbDesc &d = c->desc[p]; dsc[p] = {p, asm_rounds[p], d.n_hap, d.nK, 0, 0, asm_ro[p], d.o_pair * 2 * PDX, d.o_edge * PDX, d.o_obs * O, d.o_hap, d.o_scal, d.o_unk}; }
+		srbadev::asm_config(c->asm_wpw, c->asm_bin_bytes);
+		c->asm_bins = srbadev::asm_plan(n, dsc.data(), asm_rounds.data(), (size_t)c->asm_max_kb * 1024, c->asm_wpw, c->asm_bin_bytes, (srbadev::AsmDesc *)(h + o.asm_desc), (int32_t *)(h + o.asm_list),
+			c->asm_rest);
+		c->asm_ready = true;
 	}
 	if (host_timing) ht2 = now();
 	// ---- work arena layout
@@ -1916,7 +1891,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		DI(sch_lm, int); DI(sch_yw, int); DI(sch_tblk, int); DI(sch_vb, int); DI(sch_rec, int);
 	DI(lm_hapf_off, int); DI(lm_hapf_idx, int); DI(req_idx, int); DI(need_idx, int); DI(need_rec, int); DI(obs_rec, int); DI(pair_needed, unsigned char); DI(pose_req, unsigned char); DI(bp_normal,
 		unsigned char);
-c->asm_tab.term = asm_fam ? (const unsigned long long *)(di + o.asm_term) : nullptr; c->asm_tab.blk = asm_fam ? (const unsigned long long *)(di + o.asm_blk) : nullptr;
+	c->asm_tab.rec = asm_fam ? (const srbadev::AsmRec *)(di + o.asm_rec) : nullptr;
 	c->asm_tab.desc = asm_fam ? (const srbadev::AsmDesc *)(di + o.asm_desc) : nullptr; c->asm_list = asm_fam ? (const int *)(di + o.asm_list) : nullptr;
 #undef DI
 #define DW(field, T) B.field = (T *)(dw + w.field)
@@ -2184,7 +2159,7 @@ int srba_hip_linearize(srba_hip_ctx *c) {
 	if (c->asm_ready && lam_sym) { // relative-pose SE2: fused, Jacobian blocks never leave the chip (srba_assemble.hpp): one launch, a workgroup per bin of capsules;
 		// what does not fit a bin takes the unfused kernel
 		if (c->asm_bins > 0 && srbadev::asm_launch(c->dp.noise != SRBA_NOISE_CONSTANT_MATRIX ? 0 : (c->dp.lambda[1] == 0 && c->dp.lambda[2] == 0 && c->dp.lambda[5] == 0 && c->dp.lambda[3] == 0 &&
-			c->dp.lambda[6] == 0 && c->dp.lambda[7] == 0) ? 1 : 2, c->asm_bins, srbadev::ASM_BIN_BYTES, c->stream, c->B, c->dp, c->asm_tab) != 0) { c->fail("k_assemble_se2rel: launch failed");
+			c->dp.lambda[6] == 0 && c->dp.lambda[7] == 0) ? 1 : 2, c->asm_wpw, c->asm_bins, (size_t)c->asm_bin_bytes, c->stream, c->B, c->dp, c->asm_tab) != 0) { c->fail("k_assemble_se2rel: launch failed");
 			return -1; }
 		if (c->asm_rest > 0) { with_family(c->params.family, [&](auto fam_) { hipLaunchKernelGGL((srbadev::k_linearize<decltype(fam_)::value>), dim3(c->asm_rest), dim3(SRBA_WG),
 			(size_t)lds_doubles * 8, c->stream, c->B, c->dp, lds_doubles, c->asm_list); }); HIPCHK(c, hipGetLastError()); }

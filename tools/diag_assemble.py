@@ -2,7 +2,7 @@
 rocprofv3 --kernel-trace to see the launches of the LDS size classes one by one (tools/assemble_trace.py prints them). usage: diag_assemble.py [n_kf] [reps]"""
 import glob, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # the repo root
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 from srba_amd import capi, datasets, runner
 n_kf = int(sys.argv[1]) if len(sys.argv) > 1 else 30000; reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
@@ -27,3 +27,11 @@ if os.environ.get("SRBA_HIP_PHASE_TIMING") == "1":   # per-capsule phase ticks o
     if (tk8[:, 7] > 0).any():   # library built with -DSRBA_ASM_TICKS: phase A in pieces
         m = ok & (tk8[:, 7] > 0); d = lambda i, j: ((tk8[m, i] - tk8[m, j]) / 100.0).mean()
         print("phase A in pieces (us): start -> records + edge poses in %.1f | -> first gathers in %.1f | -> first group computed %.1f | -> all groups %.1f | -> scan + emits %.1f" % (d(4, 0), d(5, 4), d(6, 5), d(7, 6), d(1, 7)))
+    hw = tk8[:, 4].astype(np.int64)
+    if (hw != 0).any():   # where every capsule ran: per-CU residency over the call
+        cu = ((hw >> 32) & 0xf) * 4096 + ((hw >> 8) & 0xff); t0, t1 = tk[:, 0].astype(np.int64), tk[:, 3].astype(np.int64); T0, T1 = t0[ok].min(), t1[ok].max()
+        print("CUs seen: %d ; waves seen per SIMD slot ids: %s" % (len(np.unique(cu[ok])), np.unique(hw[ok] & 0xf)))
+        ev = np.concatenate([np.stack([t0[ok], np.ones(ok.sum(), np.int64)], 1), np.stack([t1[ok], -np.ones(ok.sum(), np.int64)], 1)]); ev = ev[np.argsort(ev[:, 0], kind="stable")]
+        infl = np.cumsum(ev[:, 1]); dt = np.diff(ev[:, 0]); avg = (infl[:-1] * dt).sum() / max(1, (T1 - T0))
+        print("capsules in flight: time-average %.0f (%.2f per CU), peak %d ; by tenth of the call: %s" % (avg, avg / 256, infl.max(), " ".join("%.0f" % ((infl[:-1] * dt)[(ev[:-1, 0] >= T0 + (T1 - T0) * q / 10) & (ev[:-1, 0] < T0 + (T1 - T0) * (q + 1) / 10)].sum() / ((T1 - T0) / 10.0)) for q in range(10))))
+        starts = np.sort(t0[ok] - T0) / 100.0; print("capsule starts (us after the first): 10%% %.0f  50%% %.0f  90%% %.0f  last %.0f ; ends: last %.0f" % (starts[len(starts) // 10], starts[len(starts) // 2], starts[9 * len(starts) // 10], starts[-1], (T1 - T0) / 100.0))
