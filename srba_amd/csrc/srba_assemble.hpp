@@ -19,7 +19,7 @@
  * measures both: 2.7 ns per conflict-free wavefront instruction at eight wavefronts per CU, x (lanes on one address) within a group of 16 lanes). The host deals the rows of a
  * capsule to the lanes so that rows on the same unknowns land in different 16-lane groups.
  * ONE launch: capsules are packed into bins (workgroups of four wavefronts sharing 52 KB of LDS), largest images first.
- * HBM sees: 32 B of record per row with blocks, its residual row (24 B), one pose gather (32 of 40 B) per block, 72 B per Hessian block, 24 B per unknown out.
+ * HBM sees: 16 B of record per row with blocks, its residual row (24 B), one pose gather (32 of 40 B) per block, 72 B per Hessian block, 24 B per unknown out.
  * The Jacobian array is not touched: srba_hip_debug_read(1) materialises it on demand with the unfused kernel.
  * Capsules whose image exceeds a bin, with a row of more than three blocks or whose indices do not fit the packed records take k_linearize.
  */
@@ -29,32 +29,32 @@
 namespace srbadev {
 
 // per wavefront of every bin (workgroup), in launch order
-struct AsmDesc { int pidx /* -1: this wavefront of the bin has no capsule */, rounds /* passes of 64 rows */, n_hap, nK, lds_off /* bytes: its image inside the bin */, pad;
-	long long o_rec /* 32-byte records */, o_pose /* doubles */, o_edge /* doubles */, o_res /* doubles */, o_hap /* blocks */, o_scal /* doubles */, o_unk /* unknowns: hap_diag */; };
-// one observation row with m <= 3 blocks (a = 0..2 in block order = ascending unknown), 32 bytes:
-//   w0 = (D pose index of block 0) + 1 | (block 1) << 16        (0: D = identity)
-//   w1 = (block 2) + 1 | residual row << 16
-//   w2 = unknown slot of block 0 | block 1 << 10 | block 2 << 20 | m << 30
-//   w3 = bit a: block a belongs to an edge taken in its inverse direction ; bit 4 + s: the two blocks of cross term s have opposite directions
-//   w4 = diagonal Hessian block of unknown 0 | of unknown 1 << 16
-//   w5 = of unknown 2 | Hessian block of cross term (0,1) << 16      (0xffff: the plan has no such term)
-//   w6 = of cross term (0,2) | of cross term (1,2) << 16
-struct AsmRec { uint32_t w[8]; };
+struct AsmDesc { int pidx /* -1: this wavefront of the bin has no capsule */, n_rec /* row records (a multiple of 16) */, n_hap, nK, lds_off /* bytes: its image inside the bin */, pad;
+	long long o_rec /* records */, o_pose /* doubles */, o_edge /* doubles */, o_res /* doubles */, o_hap /* blocks */, o_scal /* doubles */, o_unk /* unknowns: hap_diag */; };
+// one observation row with m <= 3 blocks (a = 0..2 in block order = ascending unknown), 16 bytes:
+//   w0 = (D pose index of block 0) + 1 | (block 1) << 14 | m << 28                           (14 bits each; 0: D = identity)
+//   w1 = (block 2) + 1 | residual row << 14 (11 bits) | unknown slot of block 0 << 25 (7 bits)
+//   w2 = unknown of block 1 | of block 2 << 7 | Hessian block of cross term (0,1) << 14 (11 bits; 0x7ff: the plan has no such term) | flags << 25
+//        flags: bit a = block a belongs to an edge taken in its inverse direction ; bit 3 + s = the two blocks of cross term s have opposite directions
+//   w3 = Hessian block of cross term (0,2) | of cross term (1,2) << 11
+// (the diagonal Hessian block of an unknown comes from a table in LDS). An all-zero record (m = 0) is a lane without a row.
+struct AsmRec { uint32_t w[4]; };
 struct AsmTables { const AsmDesc *desc; const AsmRec *rec; };
 constexpr int ASM_MAX_WPW = 4;          // wavefronts (capsules) per bin: 1, 2 or 4 (SRBA_HIP_ASM_WPW, default 4)
 constexpr int ASM_DEFAULT_BIN_KB = 52;  // three bins per CU: the LDS is handed out in granules, 3 x 53 KB does not fit the 160 KB of a CU (SRBA_HIP_ASM_BIN_KB)
-constexpr int ASM_MAX_NK = 1023, ASM_MAX_IDX = 65534;
+constexpr int ASM_MIX_F = 0, ASM_MIX_S = 0; // dispatch order (asm_plan): the F % largest bins spread over the first S % of the launch (SRBA_HIP_ASM_MIX)
+constexpr int ASM_MAX_NK = 127, ASM_MAX_POSE = 16382, ASM_MAX_ROW = 2047, ASM_MAX_HAP = 2046; // what the record fields hold
 
-// LDS image of a capsule: Hessian blocks | gradient | poses of the unknown edges (5 doubles each), rounded to 64 bytes
-inline size_t asm_image_bytes(int n_hap, int nK) { return ((size_t)8 * (9 * (size_t)n_hap + 8 * (size_t)nK + 2) + 63) & ~(size_t)63; }
+// LDS image of a capsule: Hessian blocks | gradient | poses of the unknown edges (5 doubles each) | diagonal block of every unknown (int), rounded to 64 bytes
+inline size_t asm_image_bytes(int n_hap, int nK) { return ((size_t)8 * (9 * (size_t)n_hap + 8 * (size_t)nK + 2) + 4 * (size_t)nK + 63) & ~(size_t)63; }
 // room for the records of a capsule (an upper bound known before they are built)
-inline long long asm_rec_room(int n_obs, int n_bp) { const int a = n_obs < n_bp ? n_obs : n_bp; return 64LL * ((a + 63) / 64); }
+inline long long asm_rec_room(int n_obs, int n_bp) { const int a = n_obs < n_bp ? n_obs : n_bp; return 16LL * ((a + 15) / 16); }
 
 } // namespace srbadev
 struct srba_problem_capsule;
 namespace srbadev {
 struct Batch; struct DevParams;
-// host: the packed records of one capsule into dst (asm_rec_room of them, cleared by the caller); returns the number of passes, 0 if the capsule does not fit the kernel
+// host: the packed records of one capsule into dst (asm_rec_room of them, cleared by the caller); returns the number of records used (a multiple of 16), 0 if the capsule does not fit the kernel
 int asm_pack(const srba_problem_capsule &k, AsmRec *dst);
 // host: launch geometry (environment or defaults)
 void asm_config(int &waves_per_bin, int &bin_bytes);
