@@ -240,17 +240,22 @@ int asm_pack(const srba_problem_capsule &k, AsmRec *dst) {
 		const int r = k.bp_res[t1], a = loc[t1], b = loc[t2]; if (k.bp_res[t2] != r || a >= b || k.bp_col[t1] != k.hap_i[h] || k.bp_col[t2] != k.hap_j[h]) return 0;
 		uint16_t &s = xb[3 * (size_t)r + (a + b - 1)]; if (s != 0x7ff) return 0; s = (uint16_t)h; n_off++; }
 	if (n_off + n_bp != k.n_hap_terms) return 0;
-	// rows with blocks, sorted by their unknowns and dealt to the 16-lane groups round-robin: rows that add to the same gradient entries and Hessian blocks are neighbours in the
-	// sorted list and land in different groups (the LDS serialises lanes of one group that hit one address)
-	std::vector<int> act; act.reserve(n_obs); for (int r = 0; r < n_obs; r++) if (cnt[r]) act.push_back(r);
+	// Rows with blocks, by number of blocks (three, two, one), each class sorted by its unknowns and dealt round-robin to 16-lane groups of its own: an LDS instruction costs per group of 16
+	// lanes that has a lane in it, times the lanes of the group that hit one address (tools/probes/lds_atomic_rate.hip). Rows that add to the same gradient entries and Hessian blocks are
+	// neighbours in the sorted list and land in different groups; the 27 instructions of a third block find their rows (8 % of all) in two groups instead of one or two lanes of every group.
 	auto key = [&](int r) { unsigned long long v = 0; for (int a = 0; a < 3; a++) v = v << 16 | (unsigned long long)(a < cnt[r] ? k.bp_col[blk[3 * (size_t)r + a]] + 1 : 0); return v; };
-	std::stable_sort(act.begin(), act.end(), [&](int x, int y) { return key(x) < key(y); });
-	const int n_act = (int)act.size(), ng = (n_act + 15) / 16;
-	for (int i = 0; i < n_act; i++) { const int r = act[i], m = cnt[r]; AsmRec &R = dst[(size_t)(i % ng) * 16 + i / ng]; uint32_t D[3] = {0, 0, 0}, col[3] = {0, 0, 0}, fl = 0;
-		for (int a = 0; a < m; a++) { const int b = blk[3 * (size_t)r + a]; D[a] = (uint32_t)(k.bp_D[b] + 1); col[a] = (uint32_t)k.bp_col[b]; if (!k.bp_normal[b]) fl |= 1u << a; }
-		for (int s = 0; s < 3; s++) { const int a = s == 2 ? 1 : 0, b = s == 0 ? 1 : 2; if (b < m && (((fl >> a) ^ (fl >> b)) & 1u)) fl |= 1u << (3 + s); }
-		const uint16_t *x = &xb[3 * (size_t)r];
-		R.w[0] = D[0] | D[1] << 14 | (uint32_t)m << 28; R.w[1] = D[2] | (uint32_t)r << 14 | col[0] << 25; R.w[2] = col[1] | col[2] << 7 | (uint32_t)x[0] << 14 | fl << 25; R.w[3] = (uint32_t)x[1] | (uint32_t)x[2] << 11; }
-	return 16 * ng;
+	static const int by_m = getenv("SRBA_HIP_ASM_BY_M") ? atoi(getenv("SRBA_HIP_ASM_BY_M")) : 1; // 0: one class (the deal of the first version of this kernel)
+	int g0 = 0;
+	for (int mc = 3; mc >= 1; mc--) { std::vector<int> act; for (int r = 0; r < n_obs; r++) if (by_m ? cnt[r] == mc : (mc == 3 && cnt[r] > 0)) act.push_back(r);
+		if (act.empty()) continue;
+		std::stable_sort(act.begin(), act.end(), [&](int x, int y) { return key(x) < key(y); });
+		const int n_act = (int)act.size(), ng = (n_act + 15) / 16;
+		for (int i = 0; i < n_act; i++) { const int r = act[i], m = cnt[r]; AsmRec &R = dst[(size_t)(g0 + i % ng) * 16 + i / ng]; uint32_t D[3] = {0, 0, 0}, col[3] = {0, 0, 0}, fl = 0;
+			for (int a = 0; a < m; a++) { const int b = blk[3 * (size_t)r + a]; D[a] = (uint32_t)(k.bp_D[b] + 1); col[a] = (uint32_t)k.bp_col[b]; if (!k.bp_normal[b]) fl |= 1u << a; }
+			for (int s = 0; s < 3; s++) { const int a = s == 2 ? 1 : 0, b = s == 0 ? 1 : 2; if (b < m && (((fl >> a) ^ (fl >> b)) & 1u)) fl |= 1u << (3 + s); }
+			const uint16_t *x = &xb[3 * (size_t)r];
+			R.w[0] = D[0] | D[1] << 14 | (uint32_t)m << 28; R.w[1] = D[2] | (uint32_t)r << 14 | col[0] << 25; R.w[2] = col[1] | col[2] << 7 | (uint32_t)x[0] << 14 | fl << 25; R.w[3] = (uint32_t)x[1] | (uint32_t)x[2] << 11; }
+		g0 += ng; }
+	return 16 * g0;
 }
 } // namespace srbadev

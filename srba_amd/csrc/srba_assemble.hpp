@@ -48,7 +48,7 @@ constexpr int ASM_MAX_NK = 127, ASM_MAX_POSE = 16382, ASM_MAX_ROW = 2047, ASM_MA
 // LDS image of a capsule: Hessian blocks | gradient | poses of the unknown edges (5 doubles each) | diagonal block of every unknown (int), rounded to 64 bytes
 inline size_t asm_image_bytes(int n_hap, int nK) { return ((size_t)8 * (9 * (size_t)n_hap + 8 * (size_t)nK + 2) + 4 * (size_t)nK + 63) & ~(size_t)63; }
 // room for the records of a capsule (an upper bound known before they are built)
-inline long long asm_rec_room(int n_obs, int n_bp) { const int a = n_obs < n_bp ? n_obs : n_bp; return 16LL * ((a + 15) / 16); }
+inline long long asm_rec_room(int n_obs, int n_bp) { const int a = n_obs < n_bp ? n_obs : n_bp; return 16LL * ((a + 15) / 16) + 32; } // (rows of three, two, one blocks are padded to 16 each)
 
 } // namespace srbadev
 struct srba_problem_capsule;
