@@ -192,6 +192,8 @@ int asm_launch(int lambda_mode, int wpw, int n_bins, size_t lds_bytes, hipStream
 #undef SRBA_ASM_GO
 }
 
+unsigned long long asm_layout_signature() { return sizeof(Batch) * 10007ull + sizeof(DevParams); }
+
 void asm_config(int &wpw, int &bin_bytes) {
 	wpw = ASM_MAX_WPW; int kb = ASM_DEFAULT_BIN_KB;
 	if (const char *e = getenv("SRBA_HIP_ASM_WPW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) wpw = v; }

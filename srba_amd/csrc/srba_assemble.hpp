@@ -61,6 +61,8 @@ void asm_config(int &waves_per_bin, int &bin_bytes);
 // host: packs the capsules into bins. dsc[p]: descriptor of capsule p (lds_off unset), rounds[p] == 0: does not fit the kernel; cap: largest image taken. Writes waves_per_bin descriptors
 // per bin into out (room: ASM_MAX_WPW * n), the capsules left over into rest[0 .. n_rest); returns the number of bins
 int asm_plan(int n, const AsmDesc *dsc, const int *rounds, size_t cap, int waves_per_bin, int bin_bytes, AsmDesc *out, int32_t *rest, int &n_rest);
+// host: sizeof(Batch) * 10007 + sizeof(DevParams) as this translation unit sees them (srba_hip_create compares: srba_ctx.hpp)
+unsigned long long asm_layout_signature();
 // host entry of the translation unit that holds the kernels (srba_assemble.hip): ONE launch, a workgroup per bin
 int asm_launch(int lambda_mode /* 0 identity, 1 diagonal, 2 full matrix */, int waves_per_bin, int n_bins, size_t lds_bytes, hipStream_t stream, const Batch &B, const DevParams &prm,
 	const AsmTables &T);

@@ -313,3 +313,4 @@ int big_run_class(srba_hip_ctx *c, const int32_t *caps, int count) {
 }
 #undef BIGK
 #undef BIGKG
+unsigned long long big_layout_signature() { return layout_signature(); }

@@ -123,6 +123,13 @@ template <class F> static bool with_family(int family, F &&f) {
 	}
 	return false;
 }
+// ---- what the translation units of the library must agree on: the records they share by header only (srba_hip_ctx, Batch, ProbDesc, DevParams) and the families they instantiate.
+// Every unit defines its own signature from what IT sees; srba_hip_create compares them (a unit compiled with other SRBA_* macros would read the records at wrong offsets or find
+// no kernel for a family, silently).
+#define SRBA_FAM_BIT(FAM) | (1ull << (FAM))
+static inline unsigned long long layout_signature() { return ((unsigned long long)sizeof(srba_hip_ctx) * 1000003ull + sizeof(srbadev::Batch) * 10007ull + sizeof(srbadev::ProbDesc) * 101ull + sizeof(
+	srbadev::DevParams)) ^ ((0ull SRBA_ALL_FAMILIES(SRBA_FAM_BIT)) << 40); }
+unsigned long long big_layout_signature(); // srba_big.hip
 // ---- the multi-workgroup path for large capsules (srba_big.hip)
 int big_prepare_lanes(srba_hip_ctx *c, int n);
 void big_collect_lane_stats(srba_hip_ctx *c);

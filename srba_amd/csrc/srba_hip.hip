@@ -813,8 +813,9 @@ __device__ __forceinline__ void lm_spec(const Batch &B0, const DevParams &prm, c
 					sp_j = 0;
 				}
 				const double *b = sc->box + ((sp_round & 1) * sc->W + sp_j) * 4; const int code = (int)spec_ld(b);
-				if ((code != 1 && code != 2) || spec_ld(b + 3) != lambda) { if (tid == 0) out->status = 2; stop = true; break; } // a replica that did not answer,
-					// or one that is not where this one is: reported by the host as an error
+				if ((code != 1 && code != 2) || spec_ld(b + 3) != lambda) { if (tid == 0) out->status = 3; stop = true; break; } // every replica answered (spec_exchange said so) and yet the
+					// box holds no outcome, or one for another lambda: the protocol itself lost step -- status 3, which the host reports as an error (status 2, a replica that was not
+					// resident in time, is the only case it repairs by re-running the capsule on the sequential path)
 				if (code != 2) { // that step of the ladder was not positive definite
 					n_notpd++; lambda *= nu; nu *= 2.0; stop = (lambda > prm.max_lambda); if (stop) stopmask |= 1 << SRBA_STOP_LAMBDA;
 					sp_j++;
@@ -1444,6 +1445,9 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
 	if (device >= ndev) { g_last_error = "HIP device index out of range"; return nullptr; }
 	if ((e = hipSetDevice(device)) != hipSuccess) { g_last_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return nullptr; }
+	if (!with_family(params->family, [](auto) {})) { g_last_error = "srba_hip_create: this build of the library holds no kernels for the requested family (SRBA_ONLY_FAMILY build)"; return nullptr; }
+	if (big_layout_signature() != layout_signature() || srbadev::asm_layout_signature() != sizeof(srbadev::Batch) * 10007ull + sizeof(srbadev::DevParams)) { g_last_error =
+		"srba_hip_create: the translation units of libsrba_hip.so were compiled with different SRBA_* settings (their shared records differ)"; return nullptr; }
 	srba_hip_ctx *c = new srba_hip_ctx();
 	c->device = device; c->params = *params; c->dm = kDims[params->family]; make_dev_params(*params, c->dp, c->dm);
 	std::memset(&c->B, 0, sizeof(c->B)); std::memset(&c->stats, 0, sizeof(c->stats));
@@ -2114,6 +2118,7 @@ int srba_hip_download_results(srba_hip_ctx *c, srba_lm_result *results, int n) {
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	HIPCHK(c, hipMemcpyAsync(results, c->d_wk + c->off_res, sizeof(srba_lm_result) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
+	if (c->spec_ready && n >= 1 && results[0].status == 3) { c->fail("lm_run: the replicas of the speculative single-capsule run disagree (protocol error, not a time-out)"); return -1; }
 	if (c->spec_ready && n >= 1 && results[0].status == 2) { // the speculative run gave up: once more on the sequential path
 		if (spec_fallback(c) != 0) return -1;
 		HIPCHK(c, hipMemcpyAsync(results, c->d_wk + c->off_res, sizeof(srba_lm_result) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
@@ -2253,6 +2258,7 @@ int srba_hip_optimize_capsule(srba_hip_ctx *c, srba_problem_capsule *cap, srba_l
 		"[optimize_capsule] per call: upload (host) %.1f us, launch + copies queued %.1f us, wait %.1f us (kernel %.1f us)\n", acc[0] / 1000, acc[1] / 1000, acc[2] / 1000, acc[3] / 1000);
 		acc[0] = acc[1] = acc[2] = acc[3] = 0; } }
 	std::memcpy(res, c->h_out, sizeof(srba_lm_result));
+	if (c->spec_ready && res->status == 3) { c->fail("optimize_capsule: the replicas of the speculative single-capsule run disagree (protocol error, not a time-out)"); return -1; }
 	if (c->spec_ready && res->status == 2) { // the speculative run gave up: once more on the sequential path, read back the same span
 		if (spec_fallback(c) != 0) return -1;
 		HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_wk + c->off_res, span, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));

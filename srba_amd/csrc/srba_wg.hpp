@@ -111,7 +111,8 @@ __device__ __forceinline__ bool wg_chol_solve(double *T, double *LI, const int n
 	if (w == 0) { const f64x4w c = wg_ld(T + 256 * (size_t)wg_tile(0, 0), l); if (!wg_diag(c, smC, smL, LI, l) && l == 0) *flag = 1; }
 	__syncthreads();
 	for (int k = 0; k < nt; k++) {
-		if (*flag) return false;
+		{ const int f = *flag; if (f != 0 && f <= k + 1) return false; } // the verdict is stamped with the step from which it counts: wavefront 0 may write the one of tile k + 1 (= k + 2)
+			// while a late wavefront still reads here, in step k -- that one must go on like the others did, or the barrier counts part
 		const lds_f64 *Lk = smL + 256 * (k & 1);
 		f64x4w li; li.x = Lk[4 * l]; li.y = Lk[4 * l + 1]; li.z = Lk[4 * l + 2]; li.w = Lk[4 * l + 3]; // frag(L_kk^-1): A operand of the triangular solves
 		const double *rowk = T + 256 * (size_t)wg_tile(k, 0);
@@ -186,7 +187,7 @@ __device__ __forceinline__ bool wg_chol_solve(double *T, double *LI, const int n
 				}
 				ds = wg_mma(dd, dd, ds);
 				const f64x4w c = ckk - ds;
-				if (!wg_diag(c, smC, smL + 256 * ((k + 1) & 1), LI + 256 * (size_t)(k + 1), l) && l == 0) *flag = 1;
+				if (!wg_diag(c, smC, smL + 256 * ((k + 1) & 1), LI + 256 * (size_t)(k + 1), l) && l == 0) *flag = k + 2;
 			} else finish_row(nt, nullptr);
 		} else {
 			int i = k + 1 + w;
