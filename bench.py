@@ -258,6 +258,42 @@ def bench_cfg4(args, dist, rank, world, local_rank, backend, emit=True):
         dist.barrier(); dist.destroy_process_group()
 
 
+def bench_sweep(args, dist, rank, world, local_rank, backend):
+    """ONE map sharded over the ranks (north_star: "sub-maps shard across the GPUs of one node with RCCL only for shared-edge reduction"; SURVEY 8e "new mode", no counterpart in the
+    reference): every rank builds the same map key-frame by key-frame through the engine, then a step = one sweep that re-optimises the local area of every key-frame, the windows
+    dealt to rounds of independent windows (RbaEngine<>::plan_local_area_sweep), a round = one batch per rank on its GPU + one all-reduce of the shared edges the round wrote
+    (srba_amd.multi.sweep_map). value = LM trials of all ranks / wall time (strong scaling: the map is fixed). Host-bound: the capsule of every window is built by one host thread."""
+    import numpy as np
+    import torch
+    from srba_amd import datasets, multi, runner
+    n_kf = min(args.n_kf, args.sweep_kf); dev = "cuda" if backend == "nccl" else "cpu"
+    eng = runner.graph_slam_engine(backend="hip", submap=10, depth=3, sigma_xy=1e-3, sigma_yaw_deg=0.2, harvest=0, hip_device=local_rank)
+    t0 = time.time(); eng.run(datasets.graph_slam_se2(n_kf=n_kf, seed=1, path="tour")); t_build = time.time() - t0     # the SAME map on every rank (seed 1)
+    roots = np.arange(1, n_kf, dtype=np.uint64); chi0 = eng.eval_overall_squared_error()
+    trials = []; stats = None
+    def step():
+        nonlocal stats
+        stats = multi.sweep_map(eng, roots, 3, dist=dist, device=dev); trials.append(sum(int(i.lm.num_trials) for i in stats["info"].values()))
+    for _ in range(args.warmup): step()
+    trials.clear()
+    steps = max(1, min(args.steps, 3))
+    elapsed = multi.timed_region(dist, torch.cuda.synchronize, step, steps)
+    tot, _, mx = multi.aggregate(dist, dev, sum(trials), 0, elapsed)
+    chi1 = eng.eval_overall_squared_error()
+    if rank == 0:
+        print(json.dumps({"metric": "LM iterations/sec of a map sweep (one map sharded over the ranks, shared-edge exchange per round)", "value": tot / mx, "unit": "LM iterations/s", "n_gpus": world,
+            "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * mx / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "sweep: ONE %d-key-frame SE2 graph-SLAM map (submap 10, depth 3), the local area of every key-frame re-optimised per step in %d rounds of independent windows; "
+                       "%d rank(s), windows dealt by contiguous key-frame ranges" % (n_kf, stats["rounds"], world), "windows_per_step": int(len(roots)), "rounds": stats["rounds"],
+                       "windows_this_rank": stats["windows"], "shared_edges": stats["shared_edges"], "exchange_bytes_per_step": int(sum(stats["exchange_bytes_per_round"])),
+                       "exchange": (None if dist is None else "%s all-reduce, one per round with shared edges written + one final" % dist.get_backend()),
+                       "map_build_s": round(t_build, 2), "overall_sqr_error_before": chi0, "overall_sqr_error_after_%d_sweeps" % (args.warmup + steps): chi1,
+                       "ms_per_window": 1e3 * mx / steps / len(roots)},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,7 +302,7 @@ def main():
     ap.add_argument("--n-kf", type=int, default=30000, help="keyframes of the synthetic SE2 graph-SLAM map (BASELINE: 30000)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = all host cores, at most 64)")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"],
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "sweep"],
             help="cfg2 = BASELINE configs[1] (the headline metric); cfg3 = stereo SE3 windows with Schur reduction (configs[2]); cfg4 = deep monocular window, Schur + dense Cholesky on the multi-workgroup path")
     ap.add_argument("--cfg3-kf", type=int, default=119,
             help="cfg3: key-frames of the stereo map (BASELINE: ~200). The reference's algorithm as it is loses this map at key-frame 68..77 and, with that repaired, at "
@@ -286,6 +322,7 @@ def main():
             help="local areas (the last ones of the map) re-optimised per step; since round 4 they run as a lock-step gang on the multi-workgroup path (up to 32 slots; more "
                     "windows refill them): 16 windows 6.7-6.9 k, 32 windows 8.3 k, 64 windows 8.2 k LM iterations/s (round 3, one stream per window: 16 windows 2.1-2.2 k; rounds "
                     "1-2 measured 4)")
+    ap.add_argument("--sweep-kf", type=int, default=6000, help="--workload sweep: key-frames of the one map that is sharded over the ranks")
     ap.add_argument("--cache-dir", default="/tmp/srba_bench_cache",
             help="keep the harvested capsules here so that a second invocation (e.g. under rocprofv3) skips the sequential SLAM run; '' disables")
     args = ap.parse_args()
@@ -312,6 +349,8 @@ def main():
     if dist is not None:
         dist.barrier()
     from srba_amd import capi, datasets, runner
+    if args.workload == "sweep":
+        return bench_sweep(args, dist, rank, world, local_rank, backend)
     if args.workload == "cfg4":
         return bench_cfg4(args, dist, rank, world, local_rank, backend)
     if args.workload == "cfg3":
@@ -478,6 +517,7 @@ def main():
                 if holder is not None: holder.close()
             legs = (("cfg3", ["--workload", "cfg3"]), ("cfg3_reference_defaults", ["--workload", "cfg3", "--cfg3-ext", "0", "--cfg3-kf", "67"]),
                     ("cfg4", ["--workload", "cfg4"]), ("cfg4_reference_defaults", ["--workload", "cfg4", "--cfg4-ext", "0"]),
+                    ("map_sweep", ["--workload", "sweep", "--sweep-kf", "3000"]),   # one map, batched rounds of independent local areas (the mode that shards over GPUs: N > 1 with --workload sweep)
                     ("cfg4_full", ["--workload", "cfg4", "--cfg4-kf", "5000"]))   # BASELINE configs[3] at its stated size: 5 000 key-frames x 200 000 landmarks, behind a wall budget
             for name, extra in legs:
                 if name == "cfg4_full" and args.cfg4_full_budget_s <= 0:
@@ -497,6 +537,8 @@ def main():
                     if pr.returncode != 0 or not ls:
                         sec[name] = {"error": "exit %d: %s" % (pr.returncode, pr.stderr.strip()[-300:])}; continue
                     l2 = json.loads(ls[-1])
+                    if name == "map_sweep":
+                        sec[name] = {"value": l2["value"], "unit": l2["unit"], "ms_per_step": l2["ms_per_step"], "steps": l2["steps"], "config": l2["config"], "leg_wall_s": round(time.time() - t_leg, 1)}; continue
                     sec[name] = {"value": l2["value"], "unit": l2["unit"], "ms_per_step": l2["ms_per_step"], "steps": l2["steps"], "workload": l2["config"]["workload"],
                             "extensions": l2["config"].get("extensions"),
                                  "roofline": l2["roofline"], "cpu_baseline": l2["cpu_baseline"], "sequential_ms_per_kf": l2["config"].get("sequential_ms_per_kf"),

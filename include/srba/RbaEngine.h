@@ -52,6 +52,8 @@ struct numeric_backend {
 	virtual ~numeric_backend() {}
 	/** Optimise the capsule in place (unknowns, spanning-tree poses, landmark information matrices) and fill the result. Throws on failure. */
 	virtual void run(const srba_hip_params &params, srba_problem_capsule &capsule, srba_lm_result &result) = 0;
+	/** Optimise n mutually independent capsules (RbaEngine<>::optimize_local_areas_batch). Default: one after the other; the GPU back-end uploads them as ONE batch. */
+	virtual void run_batch(const srba_hip_params &params, srba_problem_capsule *capsules, int n, srba_lm_result *results) { for (int i = 0; i < n; i++) run(params, capsules[i], results[i]); }
 	virtual const char *name() const = 0;
 	/** Optional: where to record the back-end's own stage timings ("opt.backend.*"). */
 	virtual void set_profiler(mrpt::utils::CTimeLogger *) {}
@@ -861,17 +863,10 @@ protected:
 		const int stage = m_capsule_stage; m_capsule_stage = 0;
 		out_info.clear();
 		if (parameters.srba.numeric_jacobians) throw std::runtime_error("RbaEngine: parameters.srba.numeric_jacobians (debug path of the reference) is not available with the GPU back-end");
-		const int P = REL_POSE_DIMS, L = LM_DIMS, O = OBS_DIMS, PD = (int)pose_t::storage_doubles();
+		const int P = REL_POSE_DIMS, L = LM_DIMS;
 		graph::topology &T = rba_state.topo;
 		CapsuleData &cd = m_cd; graph::capsule_index &ix = m_ix;
-		{ internal::profiler_scope p2(m_profiler, "opt.capsule");
-		  if (!m_builder.build(T, run_k2k_edges_in, run_feat_ids_in, in_observation_indices_to_optimize, parameters.srba.refresh_all_read_poses, RBA_OPTIONS::solver_t::USE_SCHUR, P, L, O, PD, cd, ix,
-		  	parameters.srba.restore_spanning_tree_twins)) return;
-		  // typed payload
-		  cd.edge_pose.resize(ix.edge_ids.size() * PD); for (size_t i = 0; i < ix.edge_ids.size(); i++) rba_state.k2k_edges[ix.edge_ids[i]].inv_pose.storeTo(&cd.edge_pose[i * PD]);
-		  cd.ulm_pos.resize(ix.unk_lms.size() * L); for (size_t i = 0; i < ix.unk_lms.size(); i++) for (int k = 0; k < L; k++) cd.ulm_pos[i * L + k] = rba_state.lm_table[ix.unk_lms[i]].pos[k];
-		  cd.klm_pos.resize(ix.const_lms.size() * L); for (size_t i = 0; i < ix.const_lms.size(); i++) for (int k = 0; k < L; k++) cd.klm_pos[i * L + k] = rba_state.lm_table[ix.const_lms[i]].pos[k];
-		  cd.obs_z.resize(ix.obs_rows.size() * O); for (size_t i = 0; i < ix.obs_rows.size(); i++) for (int k = 0; k < O; k++) cd.obs_z[i * O + k] = rba_state.obs_table[ix.obs_rows[i]].obs_arr[k]; }
+		if (!build_capsule(run_k2k_edges_in, run_feat_ids_in, in_observation_indices_to_optimize, cd, ix)) return;
 		const size_t nK = cd.n_unk_edges, nF = cd.n_unk_lms, nObs = ix.obs_rows.size();
 		out_info.num_kf_optimized = ix.n_kfs_touched; out_info.num_lm_optimized = ix.n_lms_touched;
 
@@ -885,23 +880,7 @@ protected:
 		{ internal::profiler_scope p2(m_profiler, "opt.backend"); m_backend->run(hp, cap, res); }
 		if (res.status == 1) throw std::logic_error("optimize_edges: OBS_DIMS*nObs < number of unknown scalars (reference ASSERT_ABOVEEQ_, optimize_edges.h:355)");
 
-		// the reference optimises in place: copy the unknowns, every refreshed spanning-tree pose and the landmark information matrices back
-		for (size_t i = 0; i < nK; i++) rba_state.k2k_edges[ix.edge_ids[i]].inv_pose.loadFrom(&cd.edge_pose[i * PD]);
-		for (size_t i = 0; i < nF; i++) for (int k = 0; k < L; k++) rba_state.lm_table[ix.unk_lms[i]].pos[k] = cd.ulm_pos[i * L + k];
-		for (size_t p = 0; p < ix.pairs.size(); p++) {
-			const int32_t s0 = T.ensure_num(ix.pairs[p].first, ix.pairs[p].second), s1 = T.ensure_num(ix.pairs[p].second, ix.pairs[p].first);
-			pose_flag_t &a = rba_state.num_at(s0); a.pose.loadFrom(&cd.pose[(2 * p) * PD]); a.updated = true;
-			pose_flag_t &b = rba_state.num_at(s1); b.pose.loadFrom(&cd.pose[(2 * p + 1) * PD]); b.updated = true;
-		}
-		rba_state.unknown_lms_inf_matrices.clear();
-		if (parameters.srba.cov_recovery == crpLandmarksApprox)
-			for (size_t i = 0; i < nF; i++) if (cd.ulm_inf_valid[i]) { rba_state.unknown_lms_inf_matrices.push_back(std::make_pair((TLandmarkID)ix.unk_lms[i],
-				typename rba_problem_state_t::lm_inf_matrix_t())); for (int k = 0; k < L * L; k++) rba_state.unknown_lms_inf_matrices.back().second.m[k] = cd.ulm_inf[i * L * L + k]; }
-
-		out_info.num_observations = nObs; out_info.num_jacobians = res.num_jacobians; out_info.num_kf2kf_edges_optimized = nK; out_info.num_kf2lm_edges_optimized = nF;
-		out_info.num_total_scalar_optimized = P * nK + L * nF; out_info.num_span_tree_numeric_updates = res.num_span_tree_numeric_updates;
-		out_info.total_sqr_error_init = res.total_sqr_error_init; out_info.total_sqr_error_final = res.total_sqr_error_final; out_info.obs_rmse = res.obs_rmse; out_info.lm = res;
-		out_info.optimized_k2k_edge_indices.assign(ix.edge_ids.begin(), ix.edge_ids.begin() + nK); out_info.optimized_landmark_indices.assign(ix.unk_lms.begin(), ix.unk_lms.end());
+		write_back(cd, ix, res, out_info, true);
 		// The Hessian never leaves the device unless it is asked for (one more download per call): extra_results.hessian as the reference's solvers return it
 		// (lev-marq_solvers.h:204-208, :586-590: the system matrix of the last solve, H + lambda I, reduced by the Schur complement for the Schur solvers) and
 		// HAp_condition_number (optimize_edges.h:753-766: ratio of the extreme singular values of the dense HAp, both triangles)
@@ -950,6 +929,135 @@ protected:
 		}
 		if (m_verbose_level >= 1) std::cout << "[OPT] Final RMSE=" << res.obs_rmse << " #iters=" << res.num_iters << "\n";
 	}
+
+	/** The integer tables and the typed payload of one optimize_edges() call from the map as it stands (no arithmetic); false: nothing to optimise */
+	bool build_capsule(const std::vector<size_t> &run_k2k_edges_in, const std::vector<size_t> &run_feat_ids_in, const std::vector<size_t> &obs_subset, CapsuleData &cd, graph::capsule_index &ix) {
+		const int P = REL_POSE_DIMS, L = LM_DIMS, O = OBS_DIMS, PD = (int)pose_t::storage_doubles();
+		internal::profiler_scope p2(m_profiler, "opt.capsule");
+		if (!m_builder.build(rba_state.topo, run_k2k_edges_in, run_feat_ids_in, obs_subset, parameters.srba.refresh_all_read_poses, RBA_OPTIONS::solver_t::USE_SCHUR, P, L, O, PD, cd, ix,
+			parameters.srba.restore_spanning_tree_twins)) return false;
+		// typed payload
+		cd.edge_pose.resize(ix.edge_ids.size() * PD); for (size_t i = 0; i < ix.edge_ids.size(); i++) rba_state.k2k_edges[ix.edge_ids[i]].inv_pose.storeTo(&cd.edge_pose[i * PD]);
+		cd.ulm_pos.resize(ix.unk_lms.size() * L); for (size_t i = 0; i < ix.unk_lms.size(); i++) for (int k = 0; k < L; k++) cd.ulm_pos[i * L + k] = rba_state.lm_table[ix.unk_lms[i]].pos[k];
+		cd.klm_pos.resize(ix.const_lms.size() * L); for (size_t i = 0; i < ix.const_lms.size(); i++) for (int k = 0; k < L; k++) cd.klm_pos[i * L + k] = rba_state.lm_table[ix.const_lms[i]].pos[k];
+		cd.obs_z.resize(ix.obs_rows.size() * O); for (size_t i = 0; i < ix.obs_rows.size(); i++) for (int k = 0; k < O; k++) cd.obs_z[i * O + k] = rba_state.obs_table[ix.obs_rows[i]].obs_arr[k];
+		return true;
+	}
+	/** The reference optimises in place (optimize_edges.h:526,538,727-751): the unknowns, every refreshed spanning-tree pose and the landmark information matrices go back into the map */
+	void write_back(const CapsuleData &cd, const graph::capsule_index &ix, const srba_lm_result &res, TOptimizeExtraOutputInfo &out_info, bool replace_inf_matrices) {
+		const int P = REL_POSE_DIMS, L = LM_DIMS, PD = (int)pose_t::storage_doubles(); graph::topology &T = rba_state.topo;
+		const size_t nK = cd.n_unk_edges, nF = cd.n_unk_lms, nObs = ix.obs_rows.size();
+		for (size_t i = 0; i < nK; i++) rba_state.k2k_edges[ix.edge_ids[i]].inv_pose.loadFrom(&cd.edge_pose[i * PD]);
+		for (size_t i = 0; i < nF; i++) for (int k = 0; k < L; k++) rba_state.lm_table[ix.unk_lms[i]].pos[k] = cd.ulm_pos[i * L + k];
+		for (size_t p = 0; p < ix.pairs.size(); p++) {
+			const int32_t s0 = T.ensure_num(ix.pairs[p].first, ix.pairs[p].second), s1 = T.ensure_num(ix.pairs[p].second, ix.pairs[p].first);
+			pose_flag_t &a = rba_state.num_at(s0); a.pose.loadFrom(&cd.pose[(2 * p) * PD]); a.updated = true;
+			pose_flag_t &b = rba_state.num_at(s1); b.pose.loadFrom(&cd.pose[(2 * p + 1) * PD]); b.updated = true;
+		}
+		if (replace_inf_matrices) rba_state.unknown_lms_inf_matrices.clear();
+		if (parameters.srba.cov_recovery == crpLandmarksApprox)
+			for (size_t i = 0; i < nF; i++) if (cd.ulm_inf_valid[i]) { rba_state.unknown_lms_inf_matrices.push_back(std::make_pair((TLandmarkID)ix.unk_lms[i],
+				typename rba_problem_state_t::lm_inf_matrix_t())); for (int k = 0; k < L * L; k++) rba_state.unknown_lms_inf_matrices.back().second.m[k] = cd.ulm_inf[i * L * L + k]; }
+		out_info.num_kf_optimized = ix.n_kfs_touched; out_info.num_lm_optimized = ix.n_lms_touched;
+		out_info.num_observations = nObs; out_info.num_jacobians = res.num_jacobians; out_info.num_kf2kf_edges_optimized = nK; out_info.num_kf2lm_edges_optimized = nF;
+		out_info.num_total_scalar_optimized = P * nK + L * nF; out_info.num_span_tree_numeric_updates = res.num_span_tree_numeric_updates;
+		out_info.total_sqr_error_init = res.total_sqr_error_init; out_info.total_sqr_error_final = res.total_sqr_error_final; out_info.obs_rmse = res.obs_rmse; out_info.lm = res;
+		out_info.optimized_k2k_edge_indices.assign(ix.edge_ids.begin(), ix.edge_ids.begin() + nK); out_info.optimized_landmark_indices.assign(ix.unk_lms.begin(), ix.unk_lms.end());
+	}
+
+public:
+	// ---------------------------------------------------------------------------------------------------------------------------------------------------------------
+	// Map sweeps (NO counterpart in the reference, which optimises one local area per call: SURVEY 8e "new mode", north_star "sub-maps shard across the GPUs ... RCCL only for
+	// shared-edge reduction"). Re-optimising the local areas of MANY roots of one map is a sequence of optimize_local_area() calls; two of them commute when neither writes what
+	// the other touches: a window WRITES its unknown kf2kf edges and landmarks and READS every edge on the spanning-tree paths of its observations and every landmark it observes
+	// (window disjointness follows from impl/bfs_visitor.h:105-176 and ecps/local_areas_fixed_size.h:51-55: roots four sub-maps apart share nothing). plan_local_area_sweep()
+	// deals the roots to ROUNDS of mutually independent windows (first round that fits, roots in the given order); a round is ONE batch for the numeric back-end
+	// (optimize_local_areas_batch: one upload, one fused launch per size class) and -- with the roots of a round dealt to several processes, one GPU each -- one exchange of the
+	// edges written in it (srba_amd/multi.py: an all-reduce over RCCL). Running the rounds in order, the windows of a round in any order, IS a sequential schedule of
+	// optimize_local_area() calls: that schedule on the CPU engine is what parity is defined against (tests/test_sweep.py).
+	struct TSweepPlan {
+		std::vector<int32_t> round_of;      //!< per root: its round, -1 = nothing to optimise there
+		std::vector<int64_t> touch_off;     //!< per root: [touch_off[i], touch_off[i + 1]) of `touch`
+		std::vector<uint32_t> touch;        //!< kf2kf edge id | 0x80000000 if the window writes it (unknown), else it only reads it
+		int32_t n_rounds; bool has_unknown_landmarks; //!< (a window with unknown landmarks: the exchange of srba_amd/multi.py covers kf2kf edges only)
+	};
+	void plan_local_area_sweep(const std::vector<TKeyFrameID> &roots, const unsigned int win_size, TSweepPlan &plan, const TOptimizeLocalAreaParams &params = TOptimizeLocalAreaParams()) {
+		const size_t n = roots.size(), nE = rba_state.k2k_edges.size(), nL = rba_state.lm_table.size();
+		plan.round_of.assign(n, -1); plan.touch_off.assign(n + 1, 0); plan.touch.clear(); plan.n_rounds = 0; plan.has_unknown_landmarks = false;
+		std::vector<std::vector<uint8_t> > mark; // per round, per edge then per landmark: 1 read, 2 written
+		CapsuleData cd; graph::capsule_index ix; const std::vector<size_t> no_subset;
+		const bool use_prebuilt_st = (win_size <= parameters.srba.max_tree_depth);
+		const graph::window_params wp = {params.optimize_k2k_edges, params.optimize_landmarks, params.dont_optimize_landmarks_seen_less_than_n_times, params.max_visitable_kf_id};
+		for (size_t i = 0; i < n; i++) {
+			rba_state.topo.select_local_area(graph::topology::narrow(roots[i]), win_size, use_prebuilt_st, wp, m_sel_edges, m_sel_lms);
+			plan.touch_off[i + 1] = plan.touch_off[i];
+			if (m_sel_edges.empty() && m_sel_lms.empty()) continue;
+			if (!m_builder.build(rba_state.topo, m_sel_edges, m_sel_lms, no_subset, parameters.srba.refresh_all_read_poses, RBA_OPTIONS::solver_t::USE_SCHUR, REL_POSE_DIMS, LM_DIMS, OBS_DIMS,
+				(int)pose_t::storage_doubles(), cd, ix, parameters.srba.restore_spanning_tree_twins)) continue;
+			const size_t nK = cd.n_unk_edges, nF = cd.n_unk_lms; if (nF) plan.has_unknown_landmarks = true;
+			for (size_t k = 0; k < ix.edge_ids.size(); k++) plan.touch.push_back((uint32_t)ix.edge_ids[k] | (k < nK ? 0x80000000u : 0u));
+			plan.touch_off[i + 1] = (int64_t)plan.touch.size();
+			int r = 0;
+			for (;; r++) { // first round in which this window neither writes what a member touches nor touches what a member writes
+				if (r == (int)mark.size()) { mark.push_back(std::vector<uint8_t>(nE + nL, 0)); break; }
+				const std::vector<uint8_t> &m = mark[r]; bool clash = false;
+				for (size_t k = 0; k < ix.edge_ids.size() && !clash; k++) clash = k < nK ? m[ix.edge_ids[k]] != 0 : m[ix.edge_ids[k]] == 2;
+				for (size_t k = 0; k < nF && !clash; k++) clash = m[nE + ix.unk_lms[k]] != 0;
+				for (size_t k = 0; k < ix.const_lms.size() && !clash; k++) clash = m[nE + ix.const_lms[k]] == 2;
+				if (!clash) break;
+			}
+			std::vector<uint8_t> &m = mark[r];
+			for (size_t k = 0; k < ix.edge_ids.size(); k++) m[ix.edge_ids[k]] = std::max<uint8_t>(m[ix.edge_ids[k]], k < nK ? 2 : 1);
+			for (size_t k = 0; k < nF; k++) m[nE + ix.unk_lms[k]] = 2;
+			for (size_t k = 0; k < ix.const_lms.size(); k++) m[nE + ix.const_lms[k]] = std::max<uint8_t>(m[nE + ix.const_lms[k]], 1);
+			plan.round_of[i] = r;
+		}
+		plan.n_rounds = (int32_t)mark.size();
+	}
+	/** optimize_local_area() of every root as ONE batch of the numeric back-end. The windows must be mutually independent (one round of plan_local_area_sweep): checked, std::logic_error
+	 *  otherwise. out[i] as optimize_local_area() would fill it (roots with nothing to optimise: cleared). */
+	void optimize_local_areas_batch(const std::vector<TKeyFrameID> &roots, const unsigned int win_size, std::vector<TOptimizeExtraOutputInfo> &out,
+		const TOptimizeLocalAreaParams &params = TOptimizeLocalAreaParams()) {
+		internal::profiler_scope ps(m_profiler, "optimize_local_areas_batch");
+		if (parameters.srba.numeric_jacobians) throw std::runtime_error("RbaEngine: parameters.srba.numeric_jacobians (debug path of the reference) is not available with the GPU back-end");
+		const size_t n = roots.size(), nE = rba_state.k2k_edges.size(), nL = rba_state.lm_table.size(); out.resize(n); for (size_t i = 0; i < n; i++) out[i].clear();
+		const bool use_prebuilt_st = (win_size <= parameters.srba.max_tree_depth);
+		const graph::window_params wp = {params.optimize_k2k_edges, params.optimize_landmarks, params.dont_optimize_landmarks_seen_less_than_n_times, params.max_visitable_kf_id};
+		std::deque<CapsuleData> cds; std::deque<graph::capsule_index> ixs; std::vector<size_t> who; const std::vector<size_t> no_subset; std::vector<uint8_t> m(nE + nL, 0);
+		for (size_t i = 0; i < n; i++) {
+			rba_state.topo.select_local_area(graph::topology::narrow(roots[i]), win_size, use_prebuilt_st, wp, m_sel_edges, m_sel_lms);
+			if (m_sel_edges.empty() && m_sel_lms.empty()) continue;
+			cds.push_back(CapsuleData()); ixs.push_back(graph::capsule_index());
+			if (!build_capsule(m_sel_edges, m_sel_lms, no_subset, cds.back(), ixs.back())) { cds.pop_back(); ixs.pop_back(); continue; }
+			const CapsuleData &cd = cds.back(); const graph::capsule_index &ix = ixs.back(); const size_t nK = cd.n_unk_edges, nF = cd.n_unk_lms; bool clash = false;
+			for (size_t k = 0; k < ix.edge_ids.size() && !clash; k++) clash = k < nK ? m[ix.edge_ids[k]] != 0 : m[ix.edge_ids[k]] == 2;
+			for (size_t k = 0; k < nF && !clash; k++) clash = m[nE + ix.unk_lms[k]] != 0;
+			for (size_t k = 0; k < ix.const_lms.size() && !clash; k++) clash = m[nE + ix.const_lms[k]] == 2;
+			if (clash) throw std::logic_error("optimize_local_areas_batch: the local areas of the batch are not independent (use the rounds of plan_local_area_sweep)");
+			for (size_t k = 0; k < ix.edge_ids.size(); k++) m[ix.edge_ids[k]] = std::max<uint8_t>(m[ix.edge_ids[k]], k < nK ? 2 : 1);
+			for (size_t k = 0; k < nF; k++) m[nE + ix.unk_lms[k]] = 2;
+			for (size_t k = 0; k < ix.const_lms.size(); k++) m[nE + ix.const_lms[k]] = std::max<uint8_t>(m[nE + ix.const_lms[k]], 1);
+			who.push_back(i);
+		}
+		if (who.empty()) return;
+		srba_hip_params hp; fill_hip_params(hp);
+		std::vector<srba_problem_capsule> caps(who.size()); std::vector<srba_lm_result> res(who.size());
+		for (size_t q = 0; q < who.size(); q++) { if (on_capsule) on_capsule(hp, cds[q], 0); caps[q] = cds[q].view(); std::memset(&res[q], 0, sizeof(res[q]));
+			res[q].lambda_last_trial = std::numeric_limits<double>::quiet_NaN(); }
+		if (!m_backend) m_backend = make_hip_backend(m_hip_device);
+		m_backend->set_profiler(&m_profiler);
+		{ internal::profiler_scope p2(m_profiler, "opt.backend"); m_backend->run_batch(hp, caps.data(), (int)caps.size(), res.data()); }
+		rba_state.unknown_lms_inf_matrices.clear();
+		for (size_t q = 0; q < who.size(); q++) {
+			if (res[q].status == 1) throw std::logic_error("optimize_edges: OBS_DIMS*nObs < number of unknown scalars (reference ASSERT_ABOVEEQ_, optimize_edges.h:355)");
+			write_back(cds[q], ixs[q], res[q], out[who[q]], false);
+		}
+	}
+	/** kf2kf edge values by id (the exchange step of a sharded sweep reads and sets them in bulk) */
+	void get_k2k_edge_poses(const size_t *ids, size_t n, double *out /* n x storage_doubles */) const { const size_t PD = pose_t::storage_doubles(); for (size_t i = 0; i < n; i++)
+		rba_state.k2k_edges[ids[i]].inv_pose.storeTo(out + i * PD); }
+	void set_k2k_edge_poses(const size_t *ids, size_t n, const double *in) { const size_t PD = pose_t::storage_doubles(); for (size_t i = 0; i < n; i++) rba_state.k2k_edges[ids[i]].inv_pose.loadFrom(
+		in + i * PD); }
 
 private:
 	rba_problem_state_t rba_state;

@@ -40,6 +40,14 @@ public:
 		if (m_prof) report_stages(p);
 #endif
 	}
+	/** n independent capsules as ONE batch: one upload, one fused launch per size class, one read-back (RbaEngine<>::optimize_local_areas_batch) */
+	void run_batch(const srba_hip_params &p, srba_problem_capsule *caps, int n, srba_lm_result *res) {
+		if (n <= 0) return; ensure(p);
+		if (m_prof) m_prof->enter("opt.backend.optimize_batch");
+		check(srba_hip_upload_problems(m_ctx, caps, n), "srba_hip_upload_problems"); check(srba_hip_lm_run(m_ctx, res), "srba_hip_lm_run"); check(srba_hip_download_state(m_ctx, caps, n),
+			"srba_hip_download_state");
+		if (m_prof) { m_prof->leave("opt.backend.optimize_batch"); m_prof->registerUserMeasure("opt.backend.lm_run.kernel", 1e-3 * srba_hip_last_kernel_ms(m_ctx)); }
+	}
 	void set_profiler(mrpt::utils::CTimeLogger *p) { m_prof = p; }
 	double eval_overall(const srba_hip_params &p, const srba_overall_problem &q) {
 		ensure(p);

@@ -63,6 +63,9 @@ struct EngineBase {
 	std::shared_ptr<function_backend> fn_backend; // set when a C function was plugged in
 	virtual uint64_t alloc_keyframe() = 0;
 	virtual int64_t export_graphslam(uint64_t root, uint64_t *node_id, double *node_pose, int64_t node_cap, uint64_t *edge_from_to, double *edge_pose, int64_t edge_cap) const = 0;
+	virtual int64_t plan_sweep(const uint64_t *roots, int64_t n, unsigned win, int32_t *round_of, int64_t *touch_off, uint32_t *touch, int64_t cap) = 0;
+	virtual int optimize_batch(const uint64_t *roots, int64_t n, unsigned win, srba_kf_info *out) = 0;
+	virtual int edge_poses(const uint64_t *ids, int64_t n, double *out, const double *in) = 0;
 	virtual int64_t create_edge(uint64_t new_kf, uint64_t from, uint64_t to, const double *pose) = 0;
 };
 
@@ -167,6 +170,25 @@ struct EngineImpl : public EngineBase {
 		void clear() { nodes.clear(); edges.clear(); }
 		void insertEdgeAtEnd(uint64_t from, uint64_t to, const typename rba_t::pose_t &p) { edges.push_back(std::make_pair(std::make_pair(from, to), p)); }
 	};
+	int64_t plan_sweep(const uint64_t *roots, int64_t n, unsigned win, int32_t *round_of, int64_t *touch_off, uint32_t *touch, int64_t cap) {
+		std::vector<TKeyFrameID> r(roots, roots + n); typename rba_t::TSweepPlan plan; rba.plan_local_area_sweep(r, win, plan);
+		if ((int64_t)plan.touch.size() > cap) return -2 - (int64_t)plan.touch.size();
+		for (int64_t i = 0; i < n; i++) round_of[i] = plan.round_of[i];
+		for (int64_t i = 0; i <= n; i++) touch_off[i] = plan.touch_off[i];
+		std::copy(plan.touch.begin(), plan.touch.end(), touch);
+		return plan.n_rounds;
+	}
+	int optimize_batch(const uint64_t *roots, int64_t n, unsigned win, srba_kf_info *out) {
+		std::vector<TKeyFrameID> r(roots, roots + n); std::vector<typename rba_t::TOptimizeExtraOutputInfo> res; cur_kf = n > 0 ? roots[0] : 0;
+		rba.optimize_local_areas_batch(r, win, res);
+		if (out) for (int64_t i = 0; i < n; i++) { std::memset(&out[i], 0, sizeof(out[i])); out[i].kf_id = roots[i]; fill_info(&out[i], res[i], NULL); }
+		return 0;
+	}
+	int edge_poses(const uint64_t *ids, int64_t n, double *out, const double *in) {
+		const size_t nE = rba.get_k2k_edges().size(); std::vector<size_t> id(n); for (int64_t i = 0; i < n; i++) { if (ids[i] >= nE) throw std::out_of_range("kf2kf edge id out of range"); id[i] = (size_t)ids[i]; }
+		if (out) rba.get_k2k_edge_poses(id.data(), (size_t)n, out); if (in) rba.set_k2k_edge_poses(id.data(), (size_t)n, in);
+		return 0;
+	}
 	int64_t export_graphslam(uint64_t root, uint64_t *node_id, double *node_pose, int64_t node_cap, uint64_t *edge_from_to, double *edge_pose, int64_t edge_cap) const {
 		pose_graph_t g; typename rba_t::ExportGraphSLAM_Params prm; prm.root_kf_id = root;
 		rba.get_global_graphslam_problem(g, prm);
@@ -289,6 +311,14 @@ int64_t srba_engine_st_dump(void *h, int what, int64_t *out, int64_t cap) { retu
 int srba_engine_get_rel_pose(void *h, uint64_t query, uint64_t reference, double *pose) { return static_cast<EngineBase *>(h)->get_rel_pose(query, reference, pose); }
 uint64_t srba_engine_alloc_keyframe(void *h) { return static_cast<EngineBase *>(h)->alloc_keyframe(); }
 int64_t srba_engine_create_edge(void *h, uint64_t new_kf, uint64_t from, uint64_t to, const double *pose) { return static_cast<EngineBase *>(h)->create_edge(new_kf, from, to, pose); }
+#define SRBA_ENGINE_GUARD(label, expr, fail) EngineBase *e = static_cast<EngineBase *>(h); try { return (expr); } catch (const std::exception &ex) { e->error = std::string(label ": ") + ex.what(); return (fail); } \
+	catch (...) { e->error = label ": unknown exception"; return (fail); }
+int64_t srba_engine_plan_sweep(void *h, const uint64_t *roots, int64_t n, unsigned win, int32_t *round_of, int64_t *touch_off, uint32_t *touch, int64_t cap) {
+	SRBA_ENGINE_GUARD("plan_sweep", e->plan_sweep(roots, n, win, round_of, touch_off, touch, cap), -1) }
+int srba_engine_optimize_batch(void *h, const uint64_t *roots, int64_t n, unsigned win, srba_kf_info *out) { SRBA_ENGINE_GUARD("optimize_batch", e->optimize_batch(roots, n, win, out), -1) }
+int srba_engine_get_edge_poses(void *h, const uint64_t *ids, int64_t n, double *out) { SRBA_ENGINE_GUARD("get_edge_poses", e->edge_poses(ids, n, out, NULL), -1) }
+int srba_engine_set_edge_poses(void *h, const uint64_t *ids, int64_t n, const double *in) { SRBA_ENGINE_GUARD("set_edge_poses", e->edge_poses(ids, n, NULL, in), -1) }
+#undef SRBA_ENGINE_GUARD
 int64_t srba_engine_export_graphslam(void *h, uint64_t root, uint64_t *node_id, double *node_pose, int64_t node_cap, uint64_t *edge_from_to, double *edge_pose, int64_t edge_cap) {
 	EngineBase *e = static_cast<EngineBase *>(h); // no C++ exception crosses the C ABI (narrow() of an out-of-range id, allocation failures)
 	try { return e->export_graphslam(root, node_id, node_pose, node_cap, edge_from_to, edge_pose, edge_cap); }

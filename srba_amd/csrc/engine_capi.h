@@ -74,6 +74,13 @@ int64_t srba_capsule_file_count(void *h);
 srba_problem_capsule *srba_capsule_file_capsules(void *h);
 int   srba_capsule_file_params(void *h, srba_hip_params *out);
 void  srba_capsule_file_free(void *h);
+/* Map sweeps (RbaEngine<>::plan_local_area_sweep / optimize_local_areas_batch; no counterpart in the reference: SURVEY 8e "new mode"). plan: round_of[n] (-1: nothing to optimise at that root);
+ * touch_off[n + 1] / touch[cap]: per root the kf2kf edges its window touches, id | 0x80000000 when it writes them; returns the number of rounds, < 0 on error (touch too small: -2 - needed). */
+int64_t srba_engine_plan_sweep(void *h, const uint64_t *roots, int64_t n, unsigned win, int32_t *round_of, int64_t *touch_off, uint32_t *touch, int64_t cap);
+/* optimize_local_area() of n mutually independent roots as one batch of the numeric back-end; out: n records (may be NULL) */
+int   srba_engine_optimize_batch(void *h, const uint64_t *roots, int64_t n, unsigned win, srba_kf_info *out);
+int   srba_engine_get_edge_poses(void *h, const uint64_t *ids, int64_t n, double *out /* n x PD */);
+int   srba_engine_set_edge_poses(void *h, const uint64_t *ids, int64_t n, const double *in);
 /* RbaEngine<>::get_global_graphslam_problem(): global node poses (complete breadth-first spanning tree from `root`) + one constraint per kf2kf edge as (to, from, inv_pose). Returns the node count. */
 int64_t srba_engine_export_graphslam(void *h, uint64_t root, uint64_t *node_id, double *node_pose, int64_t node_cap, uint64_t *edge_from_to, double *edge_pose, int64_t edge_cap);
 void *srba_capsule_clone(const srba_problem_capsule *caps, int64_t n, int family);

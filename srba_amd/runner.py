@@ -124,6 +124,46 @@ class Engine(object):
             raise RuntimeError(self.lib.srba_engine_last_error(self.h).decode())
         return v.value
 
+    # ---- map sweeps (RbaEngine<>::plan_local_area_sweep / optimize_local_areas_batch; srba_amd/multi.py shards them over GPUs)
+    def _chk(self, rc):
+        if rc < 0:
+            raise RuntimeError(self.lib.srba_engine_last_error(self.h).decode())
+        return rc
+
+    def plan_sweep(self, roots, win):
+        """rounds of mutually independent local areas: (round_of [n], touch_off [n + 1], touch [edge id | 0x80000000 if written], n_rounds)"""
+        roots = np.ascontiguousarray(roots, np.uint64); n = len(roots); PU64 = C.POINTER(C.c_uint64)
+        round_of = np.zeros(n, np.int32); off = np.zeros(n + 1, np.int64); cap = max(1024, 64 * n)
+        while True:
+            touch = np.zeros(cap, np.uint32)
+            rc = self.lib.srba_engine_plan_sweep(self.h, roots.ctypes.data_as(PU64), n, win, round_of.ctypes.data_as(capi.PI32), off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                  touch.ctypes.data_as(C.POINTER(C.c_uint32)), cap)
+            if rc <= -2:
+                cap = -2 - rc; continue
+            self._chk(rc)
+            return round_of, off, touch[:off[n]], int(rc)
+
+    def optimize_batch(self, roots, win):
+        """optimize_local_area() of mutually independent roots as ONE batch of the numeric back-end; returns the KfInfo records"""
+        roots = np.ascontiguousarray(roots, np.uint64); n = len(roots); out = (capi.KfInfo * max(n, 1))()
+        if n:
+            self._chk(self.lib.srba_engine_optimize_batch(self.h, roots.ctypes.data_as(C.POINTER(C.c_uint64)), n, win, out))
+        return out
+
+    def optimize_local_area(self, root, win):
+        info = capi.KfInfo(); self._chk(self.lib.srba_engine_optimize_local_area(self.h, int(root), win, C.byref(info))); return info
+
+    def get_edge_poses(self, ids):
+        ids = np.ascontiguousarray(ids, np.uint64); out = np.zeros((len(ids), self.PD))
+        if len(ids):
+            self._chk(self.lib.srba_engine_get_edge_poses(self.h, ids.ctypes.data_as(C.POINTER(C.c_uint64)), len(ids), out.ctypes.data_as(capi.PF64)))
+        return out
+
+    def set_edge_poses(self, ids, poses):
+        ids = np.ascontiguousarray(ids, np.uint64); poses = np.ascontiguousarray(poses, np.float64).reshape(len(ids), self.PD)
+        if len(ids):
+            self._chk(self.lib.srba_engine_set_edge_poses(self.h, ids.ctypes.data_as(C.POINTER(C.c_uint64)), len(ids), poses.ctypes.data_as(capi.PF64)))
+
     def harvest(self):
         return CapsuleBatch(self)
 
