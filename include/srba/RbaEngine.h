@@ -23,6 +23,7 @@
 #include <functional>
 #include <limits>
 #include <memory>
+#include <thread>
 
 namespace srba {
 
@@ -975,6 +976,39 @@ public:
 	// (optimize_local_areas_batch: one upload, one fused launch per size class) and -- with the roots of a round dealt to several processes, one GPU each -- one exchange of the
 	// edges written in it (srba_amd/multi.py: an all-reduce over RCCL). Running the rounds in order, the windows of a round in any order, IS a sequential schedule of
 	// optimize_local_area() calls: that schedule on the CPU engine is what parity is defined against (tests/test_sweep.py).
+	/** The capsules of many local areas at once: the windows are selected one after the other (the selection stamps scratch of the topology), their tables are built side by side -- the
+	 *  builder only READS the topology and the map, one builder per thread (SRBA_ENGINE_THREADS, default min(16, cores)). ok[i] = 0: nothing to optimise at roots[i]. */
+	void build_capsules_parallel(const std::vector<TKeyFrameID> &roots, const unsigned int win_size, const TOptimizeLocalAreaParams &params, std::vector<CapsuleData> &cds,
+		std::vector<graph::capsule_index> &ixs, std::vector<uint8_t> &ok, bool payload) {
+		const size_t n = roots.size(); cds.assign(n, CapsuleData()); ixs.assign(n, graph::capsule_index()); ok.assign(n, 0);
+		const bool use_prebuilt_st = (win_size <= parameters.srba.max_tree_depth);
+		const graph::window_params wp = {params.optimize_k2k_edges, params.optimize_landmarks, params.dont_optimize_landmarks_seen_less_than_n_times, params.max_visitable_kf_id};
+		std::vector<std::vector<size_t> > se(n), sl(n);
+		for (size_t i = 0; i < n; i++) rba_state.topo.select_local_area(graph::topology::narrow(roots[i]), win_size, use_prebuilt_st, wp, se[i], sl[i]);
+		int nt = (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())); if (const char *e = std::getenv("SRBA_ENGINE_THREADS")) nt = std::max(1, std::atoi(e));
+		nt = (int)std::min<size_t>((size_t)nt, std::max<size_t>(1, n / 4));
+		const int P = REL_POSE_DIMS, L = LM_DIMS, O = OBS_DIMS, PD = (int)pose_t::storage_doubles(); const std::vector<size_t> no_subset;
+		std::vector<std::string> err(nt);
+		auto work = [&](int t) {
+			graph::capsule_builder builder;
+			try { for (size_t i = (size_t)t; i < n; i += (size_t)nt) {
+				if (se[i].empty() && sl[i].empty()) continue;
+				CapsuleData &cd = cds[i]; graph::capsule_index &ix = ixs[i];
+				if (!builder.build(rba_state.topo, se[i], sl[i], no_subset, parameters.srba.refresh_all_read_poses, RBA_OPTIONS::solver_t::USE_SCHUR, P, L, O, PD, cd, ix,
+					parameters.srba.restore_spanning_tree_twins)) continue;
+				if (payload) {
+					cd.edge_pose.resize(ix.edge_ids.size() * PD); for (size_t k = 0; k < ix.edge_ids.size(); k++) rba_state.k2k_edges[ix.edge_ids[k]].inv_pose.storeTo(&cd.edge_pose[k * PD]);
+					cd.ulm_pos.resize(ix.unk_lms.size() * L); for (size_t k = 0; k < ix.unk_lms.size(); k++) for (int q = 0; q < L; q++) cd.ulm_pos[k * L + q] = rba_state.lm_table[ix.unk_lms[k]].pos[q];
+					cd.klm_pos.resize(ix.const_lms.size() * L); for (size_t k = 0; k < ix.const_lms.size(); k++) for (int q = 0; q < L; q++) cd.klm_pos[k * L + q] = rba_state.lm_table[ix.const_lms[k]].pos[q];
+					cd.obs_z.resize(ix.obs_rows.size() * O); for (size_t k = 0; k < ix.obs_rows.size(); k++) for (int q = 0; q < O; q++) cd.obs_z[k * O + q] = rba_state.obs_table[ix.obs_rows[k]].obs_arr[q];
+				}
+				ok[i] = 1; } }
+			catch (const std::exception &e) { err[t] = e.what(); }
+		};
+		if (nt <= 1) work(0);
+		else { std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(work, t); for (auto &x : th) x.join(); }
+		for (int t = 0; t < nt; t++) if (!err[t].empty()) throw std::runtime_error(err[t]);
+	}
 	struct TSweepPlan {
 		std::vector<int32_t> round_of;      //!< per root: its round, -1 = nothing to optimise there
 		std::vector<int64_t> touch_off;     //!< per root: [touch_off[i], touch_off[i + 1]) of `touch`
@@ -985,32 +1019,32 @@ public:
 		const size_t n = roots.size(), nE = rba_state.k2k_edges.size(), nL = rba_state.lm_table.size();
 		plan.round_of.assign(n, -1); plan.touch_off.assign(n + 1, 0); plan.touch.clear(); plan.n_rounds = 0; plan.has_unknown_landmarks = false;
 		std::vector<std::vector<uint8_t> > mark; // per round, per edge then per landmark: 1 read, 2 written
-		CapsuleData cd; graph::capsule_index ix; const std::vector<size_t> no_subset;
-		const bool use_prebuilt_st = (win_size <= parameters.srba.max_tree_depth);
-		const graph::window_params wp = {params.optimize_k2k_edges, params.optimize_landmarks, params.dont_optimize_landmarks_seen_less_than_n_times, params.max_visitable_kf_id};
-		for (size_t i = 0; i < n; i++) {
-			rba_state.topo.select_local_area(graph::topology::narrow(roots[i]), win_size, use_prebuilt_st, wp, m_sel_edges, m_sel_lms);
-			plan.touch_off[i + 1] = plan.touch_off[i];
-			if (m_sel_edges.empty() && m_sel_lms.empty()) continue;
-			if (!m_builder.build(rba_state.topo, m_sel_edges, m_sel_lms, no_subset, parameters.srba.refresh_all_read_poses, RBA_OPTIONS::solver_t::USE_SCHUR, REL_POSE_DIMS, LM_DIMS, OBS_DIMS,
-				(int)pose_t::storage_doubles(), cd, ix, parameters.srba.restore_spanning_tree_twins)) continue;
-			const size_t nK = cd.n_unk_edges, nF = cd.n_unk_lms; if (nF) plan.has_unknown_landmarks = true;
-			for (size_t k = 0; k < ix.edge_ids.size(); k++) plan.touch.push_back((uint32_t)ix.edge_ids[k] | (k < nK ? 0x80000000u : 0u));
-			plan.touch_off[i + 1] = (int64_t)plan.touch.size();
-			int r = 0;
-			for (;; r++) { // first round in which this window neither writes what a member touches nor touches what a member writes
-				if (r == (int)mark.size()) { mark.push_back(std::vector<uint8_t>(nE + nL, 0)); break; }
-				const std::vector<uint8_t> &m = mark[r]; bool clash = false;
-				for (size_t k = 0; k < ix.edge_ids.size() && !clash; k++) clash = k < nK ? m[ix.edge_ids[k]] != 0 : m[ix.edge_ids[k]] == 2;
-				for (size_t k = 0; k < nF && !clash; k++) clash = m[nE + ix.unk_lms[k]] != 0;
-				for (size_t k = 0; k < ix.const_lms.size() && !clash; k++) clash = m[nE + ix.const_lms[k]] == 2;
-				if (!clash) break;
+		const size_t CH = 2048; std::vector<CapsuleData> cds; std::vector<graph::capsule_index> ixs; std::vector<uint8_t> ok; // (the tables of a chunk of roots at a time: a capsule is ~100 KB)
+		for (size_t c0 = 0; c0 < n; c0 += CH) {
+			const std::vector<TKeyFrameID> part(roots.begin() + c0, roots.begin() + std::min(n, c0 + CH));
+			build_capsules_parallel(part, win_size, params, cds, ixs, ok, false);
+			for (size_t j = 0; j < part.size(); j++) { const size_t i = c0 + j;
+				plan.touch_off[i + 1] = plan.touch_off[i];
+				if (!ok[j]) continue;
+				const CapsuleData &cd = cds[j]; const graph::capsule_index &ix = ixs[j];
+				const size_t nK = cd.n_unk_edges, nF = cd.n_unk_lms; if (nF) plan.has_unknown_landmarks = true;
+				for (size_t k = 0; k < ix.edge_ids.size(); k++) plan.touch.push_back((uint32_t)ix.edge_ids[k] | (k < nK ? 0x80000000u : 0u));
+				plan.touch_off[i + 1] = (int64_t)plan.touch.size();
+				int r = 0;
+				for (;; r++) { // first round in which this window neither writes what a member touches nor touches what a member writes
+					if (r == (int)mark.size()) { mark.push_back(std::vector<uint8_t>(nE + nL, 0)); break; }
+					const std::vector<uint8_t> &m = mark[r]; bool clash = false;
+					for (size_t k = 0; k < ix.edge_ids.size() && !clash; k++) clash = k < nK ? m[ix.edge_ids[k]] != 0 : m[ix.edge_ids[k]] == 2;
+					for (size_t k = 0; k < nF && !clash; k++) clash = m[nE + ix.unk_lms[k]] != 0;
+					for (size_t k = 0; k < ix.const_lms.size() && !clash; k++) clash = m[nE + ix.const_lms[k]] == 2;
+					if (!clash) break;
+				}
+				std::vector<uint8_t> &m = mark[r];
+				for (size_t k = 0; k < ix.edge_ids.size(); k++) m[ix.edge_ids[k]] = std::max<uint8_t>(m[ix.edge_ids[k]], k < nK ? 2 : 1);
+				for (size_t k = 0; k < nF; k++) m[nE + ix.unk_lms[k]] = 2;
+				for (size_t k = 0; k < ix.const_lms.size(); k++) m[nE + ix.const_lms[k]] = std::max<uint8_t>(m[nE + ix.const_lms[k]], 1);
+				plan.round_of[i] = r;
 			}
-			std::vector<uint8_t> &m = mark[r];
-			for (size_t k = 0; k < ix.edge_ids.size(); k++) m[ix.edge_ids[k]] = std::max<uint8_t>(m[ix.edge_ids[k]], k < nK ? 2 : 1);
-			for (size_t k = 0; k < nF; k++) m[nE + ix.unk_lms[k]] = 2;
-			for (size_t k = 0; k < ix.const_lms.size(); k++) m[nE + ix.const_lms[k]] = std::max<uint8_t>(m[nE + ix.const_lms[k]], 1);
-			plan.round_of[i] = r;
 		}
 		plan.n_rounds = (int32_t)mark.size();
 	}
@@ -1021,15 +1055,10 @@ public:
 		internal::profiler_scope ps(m_profiler, "optimize_local_areas_batch");
 		if (parameters.srba.numeric_jacobians) throw std::runtime_error("RbaEngine: parameters.srba.numeric_jacobians (debug path of the reference) is not available with the GPU back-end");
 		const size_t n = roots.size(), nE = rba_state.k2k_edges.size(), nL = rba_state.lm_table.size(); out.resize(n); for (size_t i = 0; i < n; i++) out[i].clear();
-		const bool use_prebuilt_st = (win_size <= parameters.srba.max_tree_depth);
-		const graph::window_params wp = {params.optimize_k2k_edges, params.optimize_landmarks, params.dont_optimize_landmarks_seen_less_than_n_times, params.max_visitable_kf_id};
-		std::deque<CapsuleData> cds; std::deque<graph::capsule_index> ixs; std::vector<size_t> who; const std::vector<size_t> no_subset; std::vector<uint8_t> m(nE + nL, 0);
-		for (size_t i = 0; i < n; i++) {
-			rba_state.topo.select_local_area(graph::topology::narrow(roots[i]), win_size, use_prebuilt_st, wp, m_sel_edges, m_sel_lms);
-			if (m_sel_edges.empty() && m_sel_lms.empty()) continue;
-			cds.push_back(CapsuleData()); ixs.push_back(graph::capsule_index());
-			if (!build_capsule(m_sel_edges, m_sel_lms, no_subset, cds.back(), ixs.back())) { cds.pop_back(); ixs.pop_back(); continue; }
-			const CapsuleData &cd = cds.back(); const graph::capsule_index &ix = ixs.back(); const size_t nK = cd.n_unk_edges, nF = cd.n_unk_lms; bool clash = false;
+		std::vector<CapsuleData> cds; std::vector<graph::capsule_index> ixs; std::vector<uint8_t> ok; std::vector<size_t> who; std::vector<uint8_t> m(nE + nL, 0);
+		{ internal::profiler_scope p2(m_profiler, "opt.capsule"); build_capsules_parallel(roots, win_size, params, cds, ixs, ok, true); }
+		for (size_t i = 0; i < n; i++) { if (!ok[i]) continue;
+			const CapsuleData &cd = cds[i]; const graph::capsule_index &ix = ixs[i]; const size_t nK = cd.n_unk_edges, nF = cd.n_unk_lms; bool clash = false;
 			for (size_t k = 0; k < ix.edge_ids.size() && !clash; k++) clash = k < nK ? m[ix.edge_ids[k]] != 0 : m[ix.edge_ids[k]] == 2;
 			for (size_t k = 0; k < nF && !clash; k++) clash = m[nE + ix.unk_lms[k]] != 0;
 			for (size_t k = 0; k < ix.const_lms.size() && !clash; k++) clash = m[nE + ix.const_lms[k]] == 2;
@@ -1042,7 +1071,7 @@ public:
 		if (who.empty()) return;
 		srba_hip_params hp; fill_hip_params(hp);
 		std::vector<srba_problem_capsule> caps(who.size()); std::vector<srba_lm_result> res(who.size());
-		for (size_t q = 0; q < who.size(); q++) { if (on_capsule) on_capsule(hp, cds[q], 0); caps[q] = cds[q].view(); std::memset(&res[q], 0, sizeof(res[q]));
+		for (size_t q = 0; q < who.size(); q++) { if (on_capsule) on_capsule(hp, cds[who[q]], 0); caps[q] = cds[who[q]].view(); std::memset(&res[q], 0, sizeof(res[q]));
 			res[q].lambda_last_trial = std::numeric_limits<double>::quiet_NaN(); }
 		if (!m_backend) m_backend = make_hip_backend(m_hip_device);
 		m_backend->set_profiler(&m_profiler);
@@ -1050,7 +1079,7 @@ public:
 		rba_state.unknown_lms_inf_matrices.clear();
 		for (size_t q = 0; q < who.size(); q++) {
 			if (res[q].status == 1) throw std::logic_error("optimize_edges: OBS_DIMS*nObs < number of unknown scalars (reference ASSERT_ABOVEEQ_, optimize_edges.h:355)");
-			write_back(cds[q], ixs[q], res[q], out[who[q]], false);
+			write_back(cds[who[q]], ixs[who[q]], res[q], out[who[q]], false);
 		}
 	}
 	/** kf2kf edge values by id (the exchange step of a sharded sweep reads and sets them in bulk) */

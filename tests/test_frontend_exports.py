@@ -14,7 +14,7 @@ def test_dot_scene_config_and_mrpt_stand_ins(tmp_path):
     import __graft_entry__ as ge
     ge.build()
     exe = str(tmp_path / "frontend_exports")
-    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "include", "mrpt_shims"), os.path.join(ROOT, "tests", "cpp", "frontend_exports.cpp"),
+    subprocess.run(["g++", "-std=c++17", "-O1", "-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "include", "mrpt_shims"), os.path.join(ROOT, "tests", "cpp", "frontend_exports.cpp"),
             "-o", exe,
                     "-L" + os.path.join(ROOT, "srba_amd", "lib"), "-lsrba_hip", "-Wl,-rpath," + os.path.join(ROOT, "srba_amd", "lib")], check=True, timeout=600)
     p = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=120)
@@ -51,7 +51,7 @@ def test_hessian_condition_number_and_detailed_profiler_sections(tmp_path):
     import __graft_entry__ as ge
     ge.build()
     exe = str(tmp_path / "extra_results_gpu")
-    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "include", "mrpt_shims"), os.path.join(ROOT, "tests", "cpp", "extra_results_gpu.cpp"),
+    subprocess.run(["g++", "-std=c++17", "-O1", "-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "include", "mrpt_shims"), os.path.join(ROOT, "tests", "cpp", "extra_results_gpu.cpp"),
             "-o", exe,
                     "-L" + os.path.join(ROOT, "srba_amd", "lib"), "-lsrba_hip", "-Wl,-rpath," + os.path.join(ROOT, "srba_amd", "lib")], check=True, timeout=600)
     p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
