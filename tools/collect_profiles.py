@@ -9,7 +9,7 @@ json.dump(sq, open(os.path.join(dst, tag + "sq_summary.json"), "w"), indent=1, s
 for a, b in (("prof/lm_kernel_stats.csv", "bench_kernel_stats.csv"), ("prof_cfg4/c4_kernel_stats.csv", "cfg4_kernel_stats.csv"), ("prof/lm_domain_stats.csv", "bench_domain_stats.csv"),
         ("pytest_gpu.log", "pytest_gpu.log"), ("smoke.log", "smoke.log"), ("families.log", "families.log"), ("soak.log", "soak_parity.log"),
         ("pmc_traffic_cfg3.json", "pmc_traffic_cfg3.json"), ("sq_summary_cfg3.json", "sq_summary_cfg3.json"), ("eight_ranks_full_map.log", "eight_ranks_full_map.log"), ("launch_order.txt",
-                "launch_order.txt"), ("cfg4_timeline.txt", "cfg4_timeline.txt")):
+                "launch_order.txt"), ("cfg4_timeline.txt", "cfg4_timeline.txt"), ("assemble_timeline.txt", "assemble_timeline.txt"), ("assemble_pmc.txt", "assemble_pmc.txt"), ("sweep.txt", "sweep.txt")):
     if os.path.exists(os.path.join(src, a)): shutil.copy(os.path.join(src, a), os.path.join(dst, tag + b))
 lm = sq["k_lm_run"]; fetch_kb, write_kb = lm["FETCH_SIZE"], lm["WRITE_SIZE"]
 traffic = {"round": rnd, "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --steps 1 --warmup 0 --cpu-seconds 0 (tools/pmc_bench.sh)",

@@ -19,6 +19,10 @@ timeout 900 bash tools/pmc_cfg3.sh > $O/pmc_cfg3.log 2>&1; cp gpurun_out/pmc_tra
 ( time env SRBA_BENCH_DEVICE=0 SRBA_BENCH_BACKEND=gloo timeout 1200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
 	--master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 8 --steps 3 --warmup 1 --cpu-seconds 0 --cache-dir "" ) > $O/eight_ranks_full_map.log 2>&1
 timeout 300 python tools/diag_launch_stamps.py > $O/launch_order.txt 2>&1
+# round 6: the fused normal equations (per-CU timeline of the launch, counters) and the one-map sweep
+SRBA_HIP_PHASE_TIMING=1 timeout 300 python tools/diag_assemble.py 30000 20 > $O/assemble_timeline.txt 2>&1; timeout 300 python tools/diag_assemble.py 30000 20 2>&1 | tail -1 >> $O/assemble_timeline.txt
+timeout 900 bash tools/asm_pmc.sh > $O/assemble_pmc.log 2>&1; cp gpurun_out/asm_pmc/summary.txt $O/assemble_pmc.txt
+timeout 400 python tools/diag_sweep.py 6000 1 > $O/sweep.txt 2>&1
 timeout 400 bash tools/diag_cfg4_timeline.sh > /dev/null 2>&1; cp gpurun_out/cfg4_timeline.txt $O/cfg4_timeline.txt   # where a cfg4 step goes, kernel by kernel
 timeout 600 bash tools/fam_compare.sh > $O/families.log 2>&1   # fused-kernel throughput per landmark family
 find $O -name "*kernel_trace*" -delete
