@@ -1013,23 +1013,28 @@ public:
 		std::vector<int32_t> round_of;      //!< per root: its round, -1 = nothing to optimise there
 		std::vector<int64_t> touch_off;     //!< per root: [touch_off[i], touch_off[i + 1]) of `touch`
 		std::vector<uint32_t> touch;        //!< kf2kf edge id | 0x80000000 if the window writes it (unknown), else it only reads it
-		int32_t n_rounds; bool has_unknown_landmarks; //!< (a window with unknown landmarks: the exchange of srba_amd/multi.py covers kf2kf edges only)
+		std::vector<int64_t> touch_lm_off;  //!< per root: [touch_lm_off[i], touch_lm_off[i + 1]) of `touch_lm`
+		std::vector<uint32_t> touch_lm;     //!< landmark id | 0x80000000 if the window writes its position (unknown landmark of the window), else it only reads it
+		int32_t n_rounds; bool has_unknown_landmarks; //!< (some window optimises landmarks: the exchange of a sharded sweep then carries landmark positions too)
 	};
 	void plan_local_area_sweep(const std::vector<TKeyFrameID> &roots, const unsigned int win_size, TSweepPlan &plan, const TOptimizeLocalAreaParams &params = TOptimizeLocalAreaParams()) {
 		const size_t n = roots.size(), nE = rba_state.k2k_edges.size(), nL = rba_state.lm_table.size();
-		plan.round_of.assign(n, -1); plan.touch_off.assign(n + 1, 0); plan.touch.clear(); plan.n_rounds = 0; plan.has_unknown_landmarks = false;
+		plan.round_of.assign(n, -1); plan.touch_off.assign(n + 1, 0); plan.touch.clear(); plan.touch_lm_off.assign(n + 1, 0); plan.touch_lm.clear(); plan.n_rounds = 0; plan.has_unknown_landmarks = false;
 		std::vector<std::vector<uint8_t> > mark; // per round, per edge then per landmark: 1 read, 2 written
 		const size_t CH = 2048; std::vector<CapsuleData> cds; std::vector<graph::capsule_index> ixs; std::vector<uint8_t> ok; // (the tables of a chunk of roots at a time: a capsule is ~100 KB)
 		for (size_t c0 = 0; c0 < n; c0 += CH) {
 			const std::vector<TKeyFrameID> part(roots.begin() + c0, roots.begin() + std::min(n, c0 + CH));
 			build_capsules_parallel(part, win_size, params, cds, ixs, ok, false);
 			for (size_t j = 0; j < part.size(); j++) { const size_t i = c0 + j;
-				plan.touch_off[i + 1] = plan.touch_off[i];
+				plan.touch_off[i + 1] = plan.touch_off[i]; plan.touch_lm_off[i + 1] = plan.touch_lm_off[i];
 				if (!ok[j]) continue;
 				const CapsuleData &cd = cds[j]; const graph::capsule_index &ix = ixs[j];
 				const size_t nK = cd.n_unk_edges, nF = cd.n_unk_lms; if (nF) plan.has_unknown_landmarks = true;
 				for (size_t k = 0; k < ix.edge_ids.size(); k++) plan.touch.push_back((uint32_t)ix.edge_ids[k] | (k < nK ? 0x80000000u : 0u));
 				plan.touch_off[i + 1] = (int64_t)plan.touch.size();
+				for (size_t k = 0; k < nF; k++) plan.touch_lm.push_back((uint32_t)ix.unk_lms[k] | 0x80000000u);
+				for (size_t k = 0; k < ix.const_lms.size(); k++) plan.touch_lm.push_back((uint32_t)ix.const_lms[k]);
+				plan.touch_lm_off[i + 1] = (int64_t)plan.touch_lm.size();
 				int r = 0;
 				for (;; r++) { // first round in which this window neither writes what a member touches nor touches what a member writes
 					if (r == (int)mark.size()) { mark.push_back(std::vector<uint8_t>(nE + nL, 0)); break; }
@@ -1085,6 +1090,10 @@ public:
 	/** kf2kf edge values by id (the exchange step of a sharded sweep reads and sets them in bulk) */
 	void get_k2k_edge_poses(const size_t *ids, size_t n, double *out /* n x storage_doubles */) const { const size_t PD = pose_t::storage_doubles(); for (size_t i = 0; i < n; i++)
 		rba_state.k2k_edges[ids[i]].inv_pose.storeTo(out + i * PD); }
+	void get_lm_positions(const size_t *ids, size_t n, double *out /* n x LM_DIMS */) const { for (size_t i = 0; i < n; i++) for (size_t k = 0; k < LM_DIMS; k++) out[i * LM_DIMS + k] =
+		rba_state.lm_table[ids[i]].pos[k]; }
+	void set_lm_positions(const size_t *ids, size_t n, const double *in) { for (size_t i = 0; i < n; i++) for (size_t k = 0; k < LM_DIMS; k++) rba_state.lm_table[ids[i]].pos[k] = in[i * LM_DIMS + k]; }
+	size_t lm_table_size() const { return rba_state.lm_table.size(); }
 	void set_k2k_edge_poses(const size_t *ids, size_t n, const double *in) { const size_t PD = pose_t::storage_doubles(); for (size_t i = 0; i < n; i++) rba_state.k2k_edges[ids[i]].inv_pose.loadFrom(
 		in + i * PD); }
 

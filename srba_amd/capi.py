@@ -143,6 +143,8 @@ def engine_lib():
         lib.srba_engine_plan_sweep.argtypes = [C.c_void_p, PU64, C.c_int64, C.c_uint, PI32, C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.c_int64]; lib.srba_engine_plan_sweep.restype = C.c_int64
         lib.srba_engine_optimize_batch.argtypes = [C.c_void_p, PU64, C.c_int64, C.c_uint, C.POINTER(KfInfo)]
         lib.srba_engine_get_edge_poses.argtypes = [C.c_void_p, PU64, C.c_int64, PF64]; lib.srba_engine_set_edge_poses.argtypes = [C.c_void_p, PU64, C.c_int64, PF64]
+        lib.srba_engine_plan_sweep_lms.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.c_int64]; lib.srba_engine_plan_sweep_lms.restype = C.c_int64
+        lib.srba_engine_get_lm_positions.argtypes = [C.c_void_p, PU64, C.c_int64, PF64]; lib.srba_engine_set_lm_positions.argtypes = [C.c_void_p, PU64, C.c_int64, PF64]
         lib.srba_engine_get_edge.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), PF64]
         lib.srba_engine_num_unknown_lms.argtypes = [C.c_void_p]; lib.srba_engine_num_unknown_lms.restype = C.c_int64
         lib.srba_engine_get_unknown_lms.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), PF64]

@@ -66,6 +66,8 @@ struct EngineBase {
 	virtual int64_t plan_sweep(const uint64_t *roots, int64_t n, unsigned win, int32_t *round_of, int64_t *touch_off, uint32_t *touch, int64_t cap) = 0;
 	virtual int optimize_batch(const uint64_t *roots, int64_t n, unsigned win, srba_kf_info *out) = 0;
 	virtual int edge_poses(const uint64_t *ids, int64_t n, double *out, const double *in) = 0;
+	virtual int64_t plan_sweep_lms(int64_t *off, uint32_t *touch, int64_t cap) = 0;
+	virtual int lm_positions(const uint64_t *ids, int64_t n, double *out, const double *in) = 0;
 	virtual int64_t create_edge(uint64_t new_kf, uint64_t from, uint64_t to, const double *pose) = 0;
 };
 
@@ -171,7 +173,7 @@ struct EngineImpl : public EngineBase {
 		void insertEdgeAtEnd(uint64_t from, uint64_t to, const typename rba_t::pose_t &p) { edges.push_back(std::make_pair(std::make_pair(from, to), p)); }
 	};
 	int64_t plan_sweep(const uint64_t *roots, int64_t n, unsigned win, int32_t *round_of, int64_t *touch_off, uint32_t *touch, int64_t cap) {
-		std::vector<TKeyFrameID> r(roots, roots + n); typename rba_t::TSweepPlan plan; rba.plan_local_area_sweep(r, win, plan);
+		std::vector<TKeyFrameID> r(roots, roots + n); typename rba_t::TSweepPlan &plan = last_plan; rba.plan_local_area_sweep(r, win, plan);
 		if ((int64_t)plan.touch.size() > cap) return -2 - (int64_t)plan.touch.size();
 		for (int64_t i = 0; i < n; i++) round_of[i] = plan.round_of[i];
 		for (int64_t i = 0; i <= n; i++) touch_off[i] = plan.touch_off[i];
@@ -182,6 +184,16 @@ struct EngineImpl : public EngineBase {
 		std::vector<TKeyFrameID> r(roots, roots + n); std::vector<typename rba_t::TOptimizeExtraOutputInfo> res; cur_kf = n > 0 ? roots[0] : 0;
 		rba.optimize_local_areas_batch(r, win, res);
 		if (out) for (int64_t i = 0; i < n; i++) { std::memset(&out[i], 0, sizeof(out[i])); out[i].kf_id = roots[i]; fill_info(&out[i], res[i], NULL); }
+		return 0;
+	}
+	typename rba_t::TSweepPlan last_plan;
+	int64_t plan_sweep_lms(int64_t *off, uint32_t *touch, int64_t cap) { // the landmarks the windows of the LAST plan_sweep touch (id | 0x80000000: written)
+		const typename rba_t::TSweepPlan &plan = last_plan; if ((int64_t)plan.touch_lm.size() > cap) return -2 - (int64_t)plan.touch_lm.size();
+		std::copy(plan.touch_lm_off.begin(), plan.touch_lm_off.end(), off); std::copy(plan.touch_lm.begin(), plan.touch_lm.end(), touch); return (int64_t)plan.touch_lm.size();
+	}
+	int lm_positions(const uint64_t *ids, int64_t n, double *out, const double *in) {
+		const size_t nL = rba.lm_table_size(); std::vector<size_t> id(n); for (int64_t i = 0; i < n; i++) { if (ids[i] >= nL) throw std::out_of_range("landmark id out of range"); id[i] = (size_t)ids[i]; }
+		if (out) rba.get_lm_positions(id.data(), (size_t)n, out); if (in) rba.set_lm_positions(id.data(), (size_t)n, in);
 		return 0;
 	}
 	int edge_poses(const uint64_t *ids, int64_t n, double *out, const double *in) {
@@ -318,6 +330,9 @@ int64_t srba_engine_plan_sweep(void *h, const uint64_t *roots, int64_t n, unsign
 int srba_engine_optimize_batch(void *h, const uint64_t *roots, int64_t n, unsigned win, srba_kf_info *out) { SRBA_ENGINE_GUARD("optimize_batch", e->optimize_batch(roots, n, win, out), -1) }
 int srba_engine_get_edge_poses(void *h, const uint64_t *ids, int64_t n, double *out) { SRBA_ENGINE_GUARD("get_edge_poses", e->edge_poses(ids, n, out, NULL), -1) }
 int srba_engine_set_edge_poses(void *h, const uint64_t *ids, int64_t n, const double *in) { SRBA_ENGINE_GUARD("set_edge_poses", e->edge_poses(ids, n, NULL, in), -1) }
+int64_t srba_engine_plan_sweep_lms(void *h, int64_t *off, uint32_t *touch, int64_t cap) { SRBA_ENGINE_GUARD("plan_sweep_lms", e->plan_sweep_lms(off, touch, cap), -1) }
+int srba_engine_get_lm_positions(void *h, const uint64_t *ids, int64_t n, double *out) { SRBA_ENGINE_GUARD("get_lm_positions", e->lm_positions(ids, n, out, NULL), -1) }
+int srba_engine_set_lm_positions(void *h, const uint64_t *ids, int64_t n, const double *in) { SRBA_ENGINE_GUARD("set_lm_positions", e->lm_positions(ids, n, NULL, in), -1) }
 #undef SRBA_ENGINE_GUARD
 int64_t srba_engine_export_graphslam(void *h, uint64_t root, uint64_t *node_id, double *node_pose, int64_t node_cap, uint64_t *edge_from_to, double *edge_pose, int64_t edge_cap) {
 	EngineBase *e = static_cast<EngineBase *>(h); // no C++ exception crosses the C ABI (narrow() of an out-of-range id, allocation failures)

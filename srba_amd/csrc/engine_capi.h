@@ -79,6 +79,10 @@ void  srba_capsule_file_free(void *h);
 int64_t srba_engine_plan_sweep(void *h, const uint64_t *roots, int64_t n, unsigned win, int32_t *round_of, int64_t *touch_off, uint32_t *touch, int64_t cap);
 /* optimize_local_area() of n mutually independent roots as one batch of the numeric back-end; out: n records (may be NULL) */
 int   srba_engine_optimize_batch(void *h, const uint64_t *roots, int64_t n, unsigned win, srba_kf_info *out);
+/* the landmarks the windows of the LAST srba_engine_plan_sweep touch: off[n + 1], touch[cap] = landmark id | 0x80000000 when the window optimises it; returns the entry count (-2 - needed: touch too small) */
+int64_t srba_engine_plan_sweep_lms(void *h, int64_t *off, uint32_t *touch, int64_t cap);
+int   srba_engine_get_lm_positions(void *h, const uint64_t *ids, int64_t n, double *out /* n x L */);
+int   srba_engine_set_lm_positions(void *h, const uint64_t *ids, int64_t n, const double *in);
 int   srba_engine_get_edge_poses(void *h, const uint64_t *ids, int64_t n, double *out /* n x PD */);
 int   srba_engine_set_edge_poses(void *h, const uint64_t *ids, int64_t n, const double *in);
 /* RbaEngine<>::get_global_graphslam_problem(): global node poses (complete breadth-first spanning tree from `root`) + one constraint per kf2kf edge as (to, from, inv_pose). Returns the node count. */

@@ -66,55 +66,81 @@ def max_over_ranks(dist, device, values):
     return [float(x) for x in t.tolist()]
 
 
+class _Shared(object):
+    """One kind of unknown of a sweep (kf2kf edge poses, landmark positions): who touches / writes what in which round, what is shared between ranks"""
+    def __init__(self, off, touch, round_of, owner, world, n_rounds, width, get, put):
+        import numpy as np
+        self.width, self.get, self.put = width, get, put
+        n = len(round_of); self.ids = (touch & 0x7fffffff).astype(np.int64); self.written = (touch >> 31).astype(bool); self.win_of = np.repeat(np.arange(n), np.diff(off))
+        self.n_ids = int(self.ids.max()) + 1 if len(self.ids) else 0; self.owner = owner
+        first = np.full(self.n_ids, -1, np.int64); self.shared = np.zeros(self.n_ids, bool)   # shared: touched by windows of more than one rank
+        for r in range(world):
+            e = np.unique(self.ids[owner[self.win_of] == r]); self.shared[e[first[e] >= 0]] = True; first[e[first[e] < 0]] = r
+        t_round = round_of[self.win_of]; self.by_round = np.argsort(t_round, kind="stable")   # the touch entries of every round, grouped once
+        self.lo = np.searchsorted(t_round[self.by_round], np.arange(n_rounds)); self.hi = np.searchsorted(t_round[self.by_round], np.arange(n_rounds), side="right")
+        self.last_writer = np.full(self.n_ids, -1, np.int64)
+
+    def written_in(self, c):
+        """(ids written in round c, their writer's rank) -- one writer per id and round: the windows of a round are independent"""
+        import numpy as np
+        sel = self.by_round[self.lo[c]:self.hi[c]]; sel = sel[self.written[sel]]; w = np.unique(self.ids[sel]); who = np.zeros(self.n_ids, np.int64); who[self.ids[sel]] = self.owner[self.win_of[sel]]
+        self.last_writer[w] = who[w]
+        return w, who[w]
+
+
 def sweep_map(eng, roots, win, dist=None, device="cpu", final_sync=True):
     """Re-optimise the local areas of `roots` (key-frame ids, any order) of ONE map, sharded over the ranks of `dist` (None: a single process).
 
     The schedule -- rounds in order, the windows of a round in any order -- is a sequential schedule of optimize_local_area() calls: windows of a round commute (none writes what
     another touches), so every rank's map after the sweep equals, bit for bit, the map of ONE process running the same rounds (and, to the 1e-6 of the back-ends, the CPU engine's).
-    Exchange: an edge is SHARED when windows of more than one rank touch it. After round c every rank contributes the values of the shared edges ITS windows wrote in c (zeros
-    elsewhere) to one all-reduce(sum): x + 0 + ... + 0 = x exactly -- no rank adds to another's entry, so this is a gather, not an arithmetic reduction, and it moves
-    n_shared_written(c) x P doubles (KB-scale). Edges no other rank touches stay local until the final all-reduce (final_sync) that leaves the whole map on every rank.
-    Returns a dict: rounds, windows run by this rank, shared edges, bytes exchanged per round, the KfInfo records of this rank's windows {root: info}."""
+    Exchange: an unknown (kf2kf edge pose, landmark position) is SHARED when windows of more than one rank touch it. After round c every rank contributes the values of the shared
+    unknowns ITS windows wrote in c (zeros elsewhere) to one all-reduce(sum): x + 0 + ... + 0 = x exactly -- no rank adds to another's entry, so this is a gather, not an arithmetic
+    reduction, and it moves n_shared_written(c) x (3 .. 12) doubles (KB-scale). Unknowns no other rank touches stay local until the final all-reduce (final_sync) that leaves the
+    whole map on every rank.
+    Returns a dict: rounds, windows run by this rank, shared edges / landmarks, bytes exchanged per round, the KfInfo records of this rank's windows {root: info}."""
     import numpy as np
     rank, world = (0, 1) if dist is None else (dist.get_rank(), dist.get_world_size())
     roots = np.asarray(roots, np.uint64); n = len(roots)
     round_of, off, touch, n_rounds = eng.plan_sweep(roots, win)             # identical on every rank: integer work on identical maps
+    lm_off, lm_touch = eng.plan_sweep_lms(n)
     order = np.argsort(roots, kind="stable"); owner = np.zeros(n, np.int64); owner[order] = (np.arange(n) * world) // max(n, 1)   # contiguous ranges of key-frames per rank
-    edge = (touch & 0x7fffffff).astype(np.int64); written = (touch >> 31).astype(bool); win_of = np.repeat(np.arange(n), np.diff(off))
-    n_edges = int(edge.max()) + 1 if len(edge) else 0
-    # shared edges: touched by windows of more than one rank
-    first = np.full(n_edges, -1, np.int64); shared = np.zeros(n_edges, bool)
-    for r in range(world):
-        e = np.unique(edge[owner[win_of] == r]); shared[e[first[e] >= 0]] = True; first[e[first[e] < 0]] = r
-    # per round: the shared edges written in it (by whom: known to everybody) ; last writer of every written edge (final sync)
-    stats = {"rounds": n_rounds, "windows": 0, "shared_edges": int(shared.sum()), "exchange_bytes_per_round": [], "info": {}}
-    last_writer = np.full(n_edges, -1, np.int64)
-    t_round = round_of[win_of]; by_round = np.argsort(t_round, kind="stable"); r_lo = np.searchsorted(t_round[by_round], np.arange(n_rounds)); r_hi = np.searchsorted(t_round[by_round],
-            np.arange(n_rounds), side="right")                                       # the touch entries of every round, grouped once
+    kinds = [_Shared(off, touch, round_of, owner, world, n_rounds, eng.PD, eng.get_edge_poses, eng.set_edge_poses)]
+    if len(lm_touch):
+        kinds.append(_Shared(lm_off, lm_touch, round_of, owner, world, n_rounds, eng.L, eng.get_lm_positions, eng.set_lm_positions))
+    stats = {"rounds": n_rounds, "windows": 0, "shared_edges": int(kinds[0].shared.sum()), "shared_landmarks": int(kinds[1].shared.sum()) if len(kinds) > 1 else 0,
+             "exchange_bytes_per_round": [], "info": {}}
     for c in range(n_rounds):
         mine = np.nonzero((round_of == c) & (owner == rank))[0]
         infos = eng.optimize_batch(roots[mine], win)
         for k, i in enumerate(mine):
             stats["info"][int(roots[i])] = infos[k]
         stats["windows"] += len(mine)
-        sel = by_round[r_lo[c]:r_hi[c]]; sel = sel[written[sel]]; w_edges = np.unique(edge[sel]); w_owner = np.zeros(n_edges, np.int64)
-        w_owner[edge[sel]] = owner[win_of[sel]]                                         # (one writer per edge and round: the windows of a round are independent)
-        last_writer[w_edges] = w_owner[w_edges]
-        ex = w_edges[shared[w_edges]]                                                     # exchanged now; the same list on every rank
-        stats["exchange_bytes_per_round"].append(int(len(ex) * eng.PD * 8))
-        if dist is not None and len(ex):
-            _exchange(eng, dist, device, ex, w_owner[ex] == rank)
+        parts = []
+        for K in kinds:
+            w, who = K.written_in(c); ex = K.shared[w]; parts.append((K, w[ex], who[ex] == rank))      # exchanged now; the same lists on every rank
+        stats["exchange_bytes_per_round"].append(int(sum(len(w) * K.width * 8 for K, w, _ in parts)))
+        if dist is not None and stats["exchange_bytes_per_round"][-1]:
+            _exchange(dist, device, parts)
     if dist is not None and final_sync:
-        w = np.nonzero(last_writer >= 0)[0]; w = w[~shared[w]]                           # shared edges are current everywhere already
-        if len(w):
-            _exchange(eng, dist, device, w, last_writer[w] == rank)
+        parts = []
+        for K in kinds:
+            w = np.nonzero(K.last_writer >= 0)[0]; w = w[~K.shared[w]]; parts.append((K, w, K.last_writer[w] == rank))     # shared unknowns are current everywhere already
+        if sum(len(w) for _, w, _ in parts):
+            _exchange(dist, device, parts)
     return stats
 
 
-def _exchange(eng, dist, device, ids, mine):
-    """all-reduce(sum) of the values of the edges `ids`, each contributed by exactly one rank (mine: this rank's), zeros by the others; the result is set on every rank"""
+def _exchange(dist, device, parts):
+    """ONE all-reduce(sum) of the values of the unknowns of `parts` [(kind, ids, mine)], each value contributed by exactly one rank (mine: this rank's), zeros by the others; the
+    result is set on every rank"""
     import numpy as np
     import torch
-    buf = np.zeros((len(ids), eng.PD)); buf[mine] = eng.get_edge_poses(ids[mine])
-    t = torch.from_numpy(buf).to(device); dist.all_reduce(t); out = t.cpu().numpy()
-    eng.set_edge_poses(ids[~mine], out[~mine])
+    bufs = []
+    for K, ids, mine in parts:
+        b = np.zeros((len(ids), K.width))
+        if mine.any(): b[mine] = K.get(ids[mine])
+        bufs.append(b.reshape(-1))
+    t = torch.from_numpy(np.concatenate(bufs)).to(device); dist.all_reduce(t); out = t.cpu().numpy(); pos = 0
+    for K, ids, mine in parts:
+        v = out[pos:pos + len(ids) * K.width].reshape(len(ids), K.width); pos += len(ids) * K.width
+        if (~mine).any(): K.put(ids[~mine], v[~mine])

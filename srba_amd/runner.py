@@ -143,6 +143,28 @@ class Engine(object):
             self._chk(rc)
             return round_of, off, touch[:off[n]], int(rc)
 
+    def plan_sweep_lms(self, n):
+        """landmarks the windows of the LAST plan_sweep (n roots) touch: (off [n + 1], touch [landmark id | 0x80000000 if the window optimises it])"""
+        off = np.zeros(n + 1, np.int64); cap = 1024
+        while True:
+            touch = np.zeros(cap, np.uint32)
+            rc = self.lib.srba_engine_plan_sweep_lms(self.h, off.ctypes.data_as(C.POINTER(C.c_int64)), touch.ctypes.data_as(C.POINTER(C.c_uint32)), cap)
+            if rc <= -2:
+                cap = -2 - rc; continue
+            self._chk(rc)
+            return off, touch[:rc]
+
+    def get_lm_positions(self, ids):
+        ids = np.ascontiguousarray(ids, np.uint64); out = np.zeros((len(ids), self.L))
+        if len(ids):
+            self._chk(self.lib.srba_engine_get_lm_positions(self.h, ids.ctypes.data_as(C.POINTER(C.c_uint64)), len(ids), out.ctypes.data_as(capi.PF64)))
+        return out
+
+    def set_lm_positions(self, ids, pos):
+        ids = np.ascontiguousarray(ids, np.uint64); pos = np.ascontiguousarray(pos, np.float64).reshape(len(ids), self.L)
+        if len(ids):
+            self._chk(self.lib.srba_engine_set_lm_positions(self.h, ids.ctypes.data_as(C.POINTER(C.c_uint64)), len(ids), pos.ctypes.data_as(capi.PF64)))
+
     def optimize_batch(self, roots, win):
         """optimize_local_area() of mutually independent roots as ONE batch of the numeric back-end; returns the KfInfo records"""
         roots = np.ascontiguousarray(roots, np.uint64); n = len(roots); out = (capi.KfInfo * max(n, 1))()

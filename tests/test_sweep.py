@@ -115,6 +115,42 @@ def test_two_ranks_over_gloo_end_with_the_map_of_one_process(tmp_path):
     ref.close()
 
 
+def _lm_map():
+    from srba_amd import capi
+    ds, _ = datasets.landmarks_dataset_se2("rb2d", n_kf=36, n_lm=1080, seed=7, noise=1e-3)
+    eng = runner.landmark_engine("rb2d", backend=_oracle.BACKEND, solver=capi.SOLVER_SCHUR_DENSE, harvest=0); eng.run(ds); return eng
+
+
+def _lm_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch  # noqa: F401
+    dist = multi.init_process_group("gloo")
+    eng = _lm_map(); st = multi.sweep_map(eng, np.arange(2, 36, dtype=np.uint64), WIN, dist=dist, device="cpu")
+    np.savez(os.path.join(out_dir, "lm_rank%d.npz" % rank), poses=eng.edges()[2], lms=eng.unknown_lms()[2], shared=st["shared_landmarks"], nbytes=np.array(st["exchange_bytes_per_round"]))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_landmark_map_over_two_ranks(tmp_path):
+    """windows with unknown landmarks: the exchange carries landmark positions beside the edge poses (range-bearing 2D, Schur solver); both ranks end with the one-process map"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn"); port = _free_port()
+    ps = [ctx.Process(target=_lm_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in ps: p.start()
+    for p in ps:
+        p.join(timeout=900); assert p.exitcode == 0
+    ref = _lm_map(); roots = np.arange(2, 36, dtype=np.uint64)
+    round_of, _, _, n_rounds = ref.plan_sweep(roots, WIN); seq = _lm_map(); _sequential(seq, roots, round_of, n_rounds)
+    st = multi.sweep_map(ref, roots, WIN)
+    assert np.array_equal(ref.edges()[2], seq.edges()[2]) and np.array_equal(ref.unknown_lms()[2], seq.unknown_lms()[2])
+    assert sum(int(i.lm.num_trials) for i in st["info"].values()) > 0 and max(int(i.num_k2f) for i in st["info"].values()) > 0     # windows with unknown landmarks did run
+    for r in range(2):
+        d = np.load(os.path.join(str(tmp_path), "lm_rank%d.npz" % r))
+        assert np.array_equal(d["poses"], ref.edges()[2]) and np.array_equal(d["lms"], ref.unknown_lms()[2]), r
+        assert int(d["shared"]) > 0 and d["nbytes"].sum() > 0
+    assert st["shared_landmarks"] == 0
+    ref.close(); seq.close()
+
+
 @pytest.mark.gpu
 def test_gpu_sweep_matches_the_oracle_schedule():
     """the HIP back-end runs every round as ONE batch (upload, fused launch per size class, read-back); the oracle runs the same rounds window by window"""
@@ -146,7 +182,9 @@ def build():
 a, b = build(), build(); roots = np.arange(3, 200, 2, dtype=np.uint64)
 multi.sweep_map(a, roots, 3, dist=dist, device="cuda"); multi.sweep_map(b, roots, 3)
 assert np.array_equal(a.edges()[2], b.edges()[2])
-ids = np.arange(10, dtype=np.uint64); before = a.get_edge_poses(ids).copy(); multi._exchange(a, dist, "cuda", ids, np.ones(10, bool)); assert np.array_equal(a.get_edge_poses(ids), before)
+ids = np.arange(10, dtype=np.int64); before = a.get_edge_poses(ids).copy()
+class K: width = a.PD; get = staticmethod(a.get_edge_poses); put = staticmethod(a.set_edge_poses)
+multi._exchange(dist, "cuda", [(K, ids, np.ones(10, bool))]); assert np.array_equal(a.get_edge_poses(ids), before)
 dist.barrier(); dist.destroy_process_group(); print("sweep-rccl-ok")
 ''' % (ROOT, ROOT)
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
