@@ -22,20 +22,19 @@ __device__ __forceinline__ void lds_add(double *p, double v) { // ds_add_f64, no
 	if (SRBA_ASM_KO & 32) *(volatile double *)p = v; else __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // A block of this family is J = sg * K, K = [ c s k2 ; -s c k3 ; 0 0 1 ] with k2 = x s - y c, k3 = x c + y s: FOUR numbers {c, s, k2, k3} and a sign.
-// M = Lambda * K(b)   (identity Lambda: M = K)
 // LAMBDA: 0 = identity (scaled afterwards), 1 = diagonal matrix (the usual information matrix of a relative-pose observation: a third of the products), 2 = full matrix
-template <int LAMBDA> __device__ __forceinline__ void asm_lambda_k(double (&M)[9], const double (&b)[4], const double *l) {
-	if constexpr (LAMBDA == 1) { M[0] = l[0] * b[0]; M[1] = l[0] * b[1]; M[2] = l[0] * b[2]; M[3] = -(l[4] * b[1]); M[4] = l[4] * b[0]; M[5] = l[4] * b[3]; M[6] = 0; M[7] = 0; M[8] = l[8]; }
+// With the sign inside: b = sg * {c, s, k2, k3}, J = [ b0 b1 b2 ; -b1 b0 b3 ; 0 0 sg ].  M = Lambda * J(b);  H = J(a)^t * M
+template <int LAMBDA> __device__ __forceinline__ void asm_lambda_sk(double (&M)[9], const double (&b)[4], const double sg, const double *l) {
+	if constexpr (LAMBDA == 1) { M[0] = l[0] * b[0]; M[1] = l[0] * b[1]; M[2] = l[0] * b[2]; M[3] = -(l[4] * b[1]); M[4] = l[4] * b[0]; M[5] = l[4] * b[3]; M[6] = 0; M[7] = 0; M[8] = l[8] * sg; }
 	else if constexpr (LAMBDA == 2) {
 #pragma unroll
 		for (int k = 0; k < 3; k++) { M[3 * k] = l[3 * k] * b[0] - l[3 * k + 1] * b[1]; M[3 * k + 1] = l[3 * k] * b[1] + l[3 * k + 1] * b[0];
-			M[3 * k + 2] = l[3 * k] * b[2] + l[3 * k + 1] * b[3] + l[3 * k + 2]; }
-	} else { M[0] = b[0]; M[1] = b[1]; M[2] = b[2]; M[3] = -b[1]; M[4] = b[0]; M[5] = b[3]; M[6] = 0; M[7] = 0; M[8] = 1; }
+			M[3 * k + 2] = l[3 * k] * b[2] + l[3 * k + 1] * b[3] + l[3 * k + 2] * sg; }
+	} else { M[0] = b[0]; M[1] = b[1]; M[2] = b[2]; M[3] = -b[1]; M[4] = b[0]; M[5] = b[3]; M[6] = 0; M[7] = 0; M[8] = sg; }
 }
-// H = K(a)^t * M (row-major 3 x 3)
-__device__ __forceinline__ void asm_kt_m(double *H, const double (&a)[4], const double (&M)[9]) {
+__device__ __forceinline__ void asm_skt_m(double *H, const double (&a)[4], const double sg, const double (&M)[9]) {
 #pragma unroll
-	for (int j = 0; j < 3; j++) { H[j] = a[0] * M[j] - a[1] * M[3 + j]; H[3 + j] = a[1] * M[j] + a[0] * M[3 + j]; H[6 + j] = a[2] * M[j] + a[3] * M[3 + j] + M[6 + j]; }
+	for (int j = 0; j < 3; j++) { H[j] = a[0] * M[j] - a[1] * M[3 + j]; H[3 + j] = a[1] * M[j] + a[0] * M[3 + j]; H[6 + j] = a[2] * M[j] + a[3] * M[3 + j] + sg * M[6 + j]; }
 }
 
 #ifndef SRBA_ASM_WAVES
@@ -82,13 +81,14 @@ template <int LAMBDA> __device__ __forceinline__ void asm_row_sums(const uint4 &
 			const double *pp = eb + col * 5u; const double px = pp[0], py = pp[1], pc = pp[3], ps = pp[4];
 			const double nx = px + x * pc - y * ps, ny = py + x * ps + y * pc, nc = pc * c - ps * s, ns = ps * c + pc * s; x = nx; y = ny; c = nc; s = ns;
 		}
-		K[a][0] = c; K[a][1] = s; K[a][2] = x * s - y * c; K[a][3] = x * c + y * s;
-		const double sg = inverse ? -1.0 : 1.0;
-		asm_lambda_k<LAMBDA>(M[a], K[a], lam);
+		// J = sg K: the sign goes into the four numbers (an exact operation), J^t Lambda r and every product of two blocks then carry theirs by themselves
+		const double sg = inverse ? -1.0 : 1.0, k2 = x * s - y * c, k3 = x * c + y * s;
+		K[a][0] = sg * c; K[a][1] = sg * s; K[a][2] = sg * k2; K[a][3] = sg * k3;
+		asm_lambda_sk<LAMBDA>(M[a], K[a], sg, lam);
 		if (!(SRBA_ASM_KO & 8)) {
-			double *go = gb + 3 * col; // J^t Lambda r, J = sg K
-			lds_add(go, sg * (c * t[0] - s * t[1])); lds_add(go + 1, sg * (s * t[0] + c * t[1])); lds_add(go + 2, sg * (K[a][2] * t[0] + K[a][3] * t[1] + t[2]));
-			double Hd[9]; asm_kt_m(Hd, K[a], M[a]); // J^t Lambda J = K^t Lambda K: symmetric, the upper triangle is summed (mirrored afterwards)
+			double *go = gb + 3 * col; // J^t Lambda r
+			lds_add(go, K[a][0] * t[0] - K[a][1] * t[1]); lds_add(go + 1, K[a][1] * t[0] + K[a][0] * t[1]); lds_add(go + 2, K[a][2] * t[0] + K[a][3] * t[1] + sg * t[2]);
+			double Hd[9]; asm_skt_m(Hd, K[a], sg, M[a]); // J^t Lambda J: symmetric, the upper triangle is summed (mirrored afterwards)
 			double *ho = Hb + 9 * dgt[col]; lds_add(ho, Hd[0]); lds_add(ho + 1, Hd[1]); lds_add(ho + 2, Hd[2]); lds_add(ho + 4, Hd[4]); lds_add(ho + 5, Hd[5]); lds_add(ho + 8, Hd[8]);
 		}
 	}
@@ -96,9 +96,9 @@ template <int LAMBDA> __device__ __forceinline__ void asm_row_sums(const uint4 &
 #pragma unroll
 	for (int sidx = 0; sidx < 3; sidx++) { const int a = sidx == 2 ? 1 : 0, b = sidx == 0 ? 1 : 2; const unsigned xb = asm_xb(q, sidx);
 		if (b < m && xb != 0x7ffu && !(SRBA_ASM_KO & 8)) {
-			double v[9]; asm_kt_m(v, K[a], M[b]); const double sg = ((fl >> (3 + sidx)) & 1u) ? -1.0 : 1.0; double *ho = Hb + 9 * xb;
+			double v[9]; asm_skt_m(v, K[a], ((fl >> a) & 1u) ? -1.0 : 1.0, M[b]); double *ho = Hb + 9 * xb;
 #pragma unroll
-			for (int k = 0; k < 9; k++) lds_add(ho + k, sg * v[k]);
+			for (int k = 0; k < 9; k++) lds_add(ho + k, v[k]);
 		}
 	}
 }

@@ -35,7 +35,7 @@ struct AsmDesc { int pidx /* -1: this wavefront of the bin has no capsule */, n_
 //   w0 = (D pose index of block 0) + 1 | (block 1) << 14 | m << 28                           (14 bits each; 0: D = identity)
 //   w1 = (block 2) + 1 | residual row << 14 (11 bits) | unknown slot of block 0 << 25 (7 bits)
 //   w2 = unknown of block 1 | of block 2 << 7 | Hessian block of cross term (0,1) << 14 (11 bits; 0x7ff: the plan has no such term) | flags << 25
-//        flags: bit a = block a belongs to an edge taken in its inverse direction ; bit 3 + s = the two blocks of cross term s have opposite directions
+//        flags: bit a = block a belongs to an edge taken in its inverse direction (its sign; a cross term carries the product of the two)
 //   w3 = Hessian block of cross term (0,2) | of cross term (1,2) << 11
 // (the diagonal Hessian block of an unknown comes from a table in LDS). An all-zero record (m = 0) is a lane without a row.
 struct AsmRec { uint32_t w[4]; };
