@@ -18,7 +18,8 @@
  * One wavefront alone adds to an image and the LDS serves the lanes of an instruction in a fixed order: sums are reproducible run to run (tools/probes/lds_atomic_rate.hip
  * measures both: 2.7 ns per conflict-free wavefront instruction at eight wavefronts per CU, x (lanes on one address) within a group of 16 lanes). The host deals the rows of a
  * capsule to the lanes so that rows on the same unknowns land in different 16-lane groups.
- * ONE launch: capsules are packed into bins (workgroups of four wavefronts sharing 52 KB of LDS), largest images first.
+ * ONE launch: capsules are packed into bins (workgroups of four wavefronts sharing 52 KB of LDS); the bins of the largest windows -- few capsules for their LDS -- are spread over
+ * the first 70 % of the launch with bins of small windows between them (asm_plan).
  * HBM sees: 16 B of record per row with blocks, its residual row (24 B), one pose gather (32 of 40 B) per block, 72 B per Hessian block, 24 B per unknown out.
  * The Jacobian array is not touched: srba_hip_debug_read(1) materialises it on demand with the unfused kernel.
  * Capsules whose image exceeds a bin, with a row of more than three blocks or whose indices do not fit the packed records take k_linearize.
@@ -42,7 +43,7 @@ struct AsmRec { uint32_t w[4]; };
 struct AsmTables { const AsmDesc *desc; const AsmRec *rec; };
 constexpr int ASM_MAX_WPW = 4;          // wavefronts (capsules) per bin: 1, 2 or 4 (SRBA_HIP_ASM_WPW, default 4)
 constexpr int ASM_DEFAULT_BIN_KB = 52;  // three bins per CU: the LDS is handed out in granules, 3 x 53 KB does not fit the 160 KB of a CU (SRBA_HIP_ASM_BIN_KB)
-constexpr int ASM_MIX_F = 0, ASM_MIX_S = 0; // dispatch order (asm_plan): the F % largest bins spread over the first S % of the launch (SRBA_HIP_ASM_MIX)
+constexpr int ASM_MIX_F = 50, ASM_MIX_S = 70; // dispatch order (asm_plan): the F % largest bins spread over the first S % of the launch (SRBA_HIP_ASM_MIX="F,S"; "0,0": largest first)
 constexpr int ASM_MAX_NK = 127, ASM_MAX_POSE = 16382, ASM_MAX_ROW = 2047, ASM_MAX_HAP = 2046; // what the record fields hold
 
 // LDS image of a capsule: Hessian blocks | gradient | poses of the unknown edges (5 doubles each) | diagonal block of every unknown (int), rounded to 64 bytes
