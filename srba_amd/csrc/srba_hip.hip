@@ -1869,15 +1869,15 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		// double-buffered
 	w.grad0 = wk.add((c->params.extensions & SRBA_EXT_SCHUR_KEEPS_GRADIENT) ? 8 * t_scal : 0);
 	wk.add(0);
-	if (in.size + 256 > c->cap_in) { if (c->d_in) hipFree(c->d_in); c->d_in = nullptr; c->cap_in = 0; const size_t want = (in.size + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_in,
-		want)); c->cap_in = want; }
+	if (in.size + 256 > c->cap_in) { const size_t old_cap = c->cap_in; if (c->d_in) hipFree(c->d_in); c->d_in = nullptr; c->cap_in = 0; const size_t want = n > 1 ? std::max(in.size + 256, old_cap + old_cap / 2) : (in.size + 256) * 4; /* (batches of a map sweep grow and shrink from round to round: no
+		reallocation per round; the first batch of a context gets what it asks for) */ HIPCHK(c, hipMalloc((void **)&c->d_in, want)); c->cap_in = want; }
 	// a batch of one relative-pose SE2 capsule whose system lives in LDS: spec_w replicas of the work arena for the lambda-ladder speculation (k_lm_spec)
 	c->spec_ready = c->spec_on && n == 1 && c->params.family == SRBA_SE2_RELPOSE2D && c->two_on && c->sched == 3 && cls[0] < SRBA_NCLS - 1 && c->desc[0].dense_in_lds && c->desc[0].n_scal <=
 		srba_hip_ctx::kSpecMaxN && c->desc[0].n_scal == c->desc[0].n_sys && c->params.max_iters <= 100 /* rounds <= trials <= ~ 70 per iteration (lambda *= nu,
 		nu *= 2 reaches max_lambda within that): below the 8192 round numbers a launch owns (SpecCtl::round0) */;
 	c->spec_stride = (wk.size + 255) & ~(size_t)255; const size_t wk_need = c->spec_ready ? c->spec_stride * (size_t)c->spec_w : wk.size;
 	if (c->spec_ready && !c->d_spec) HIPCHK(c, hipMalloc((void **)&c->d_spec, srba_hip_ctx::kSpecBytes));
-	if (wk_need + 256 > c->cap_wk) { if (c->d_wk) hipFree(c->d_wk); c->d_wk = nullptr; c->cap_wk = 0; const size_t want = (wk_need + 256) * (n > 1 ? 1 : 4); HIPCHK(c, hipMalloc((void **)&c->d_wk,
+	if (wk_need + 256 > c->cap_wk) { const size_t old_cap = c->cap_wk; if (c->d_wk) hipFree(c->d_wk); c->d_wk = nullptr; c->cap_wk = 0; const size_t want = n > 1 ? std::max(wk_need + 256, old_cap + old_cap / 2) : (wk_need + 256) * 4; HIPCHK(c, hipMalloc((void **)&c->d_wk,
 		want)); c->cap_wk = want; }
 	HIPCHK(c, hipMemcpyAsync(c->d_in, h, in.size, hipMemcpyHostToDevice, c->stream));
 	HIPCHK(c, hipMemsetAsync(c->d_wk, 0, wk_need, c->stream));
