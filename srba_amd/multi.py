@@ -97,6 +97,10 @@ def sweep_map(eng, roots, win, dist=None, device="cpu", final_sync=True):
     unknowns ITS windows wrote in c (zeros elsewhere) to one all-reduce(sum): x + 0 + ... + 0 = x exactly -- no rank adds to another's entry, so this is a gather, not an arithmetic
     reduction, and it moves n_shared_written(c) x (3 .. 12) doubles (KB-scale). Unknowns no other rank touches stay local until the final all-reduce (final_sync) that leaves the
     whole map on every rank.
+    What is NOT exchanged: the numeric spanning-tree table (TSpanningTree::num). Every optimisation recomputes the poses it reads from the edges (K1) and writes them back; after a
+    sharded sweep a rank's table holds the poses ITS windows refreshed and older values elsewhere -- as the reference's own table does for pairs no recent optimisation touched
+    (SURVEY App. B-11/12). define_new_keyframe() reads the table only for the INITIAL value of a new edge (RbaEngine.h: determine_kf2kf_edges_to_create), so a map can be continued on
+    any rank; the continuations of two ranks agree to the optimiser's tolerance, not bit for bit.
     Returns a dict: rounds, windows run by this rank, shared edges / landmarks, bytes exchanged per round, the KfInfo records of this rank's windows {root: info}."""
     import numpy as np
     rank, world = (0, 1) if dist is None else (dist.get_rank(), dist.get_world_size())
