@@ -1408,8 +1408,8 @@ static int check_params(const srba_hip_params *p) {
 // Host side of an upload is per-capsule work on disjoint outputs (validation, symbolic factorisation, packing into the staging arena): spread over threads.
 template <class F> static void parallel_ranges(int n, int threads, F fn) { // fn(begin, end, thread); an exception of a worker (std::bad_alloc) is rethrown in the caller
 	if (threads <= 1 || n < 24) { fn(0, n, 0); return; }
-	if (n < 512) threads = std::min(threads, std::max(2, n / 8)); // a round of a map sweep is a batch of tens to hundreds of capsules (~30 us of host work each): a few threads pay, thirty-two do not
-	std::atomic<int> next(0); const int chunk = n < 512 ? std::max(2, n / (threads * 3)) : std::max(16, n / (threads * 8)); std::exception_ptr err; std::atomic<bool> failed(false);
+	if (n < 512) threads = std::min(threads, std::max(2, n / 3)); // a round of a map sweep is a batch of tens to hundreds of capsules (~30 us of host work each): a few threads pay, thirty-two do not
+	std::atomic<int> next(0); const int chunk = n < 512 ? std::max(1, n / (threads * 2)) : std::max(16, n / (threads * 8)); std::exception_ptr err; std::atomic<bool> failed(false);
 	auto work = [&](int t) {
 		try { for (;;) { const int b = next.fetch_add(chunk); if (b >= n || failed.load()) break; fn(b, std::min(n, b + chunk), t); } }
 		catch (...) { if (!failed.exchange(true)) err = std::current_exception(); }
