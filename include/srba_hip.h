@@ -314,6 +314,11 @@ int    srba_hip_launch_order(srba_hip_ctx *ctx, int64_t *stamp, int32_t *workgro
  * workgroups. out = { speculative launches since the context was created, launches whose replicas lost step (one of them not resident within the spin bound: another context holding
  * the CUs) and that were therefore run again on the sequential path }. */
 int    srba_hip_spec_stats(srba_hip_ctx *ctx, int64_t out[2]);
+/* Host only (no device, no context): the packed row records of the fused normal-equations kernel of <SE2, RelativePoses2D> for ONE capsule (srba_amd/csrc/srba_assemble.hpp: 16 bytes =
+ * four words per observation row that has Jacobian blocks, rows dealt to the lanes the kernel will run them on) -- what srba_hip_upload_problems builds for srba_hip_linearize, exposed
+ * so that the packing can be checked against the capsule's own Hessian plan without a GPU (tests/test_assemble_records.py). words: room for 4 * cap_records; returns the number of
+ * records (a multiple of 16), 0 if the capsule does not fit the kernel (it then takes the unfused one), -1 - needed if cap_records is too small. */
+int64_t srba_hip_debug_assemble_records(const srba_problem_capsule *capsule, uint32_t *words, int64_t cap_records);
 /* Time (ms) spent inside the last srba_hip_lm_run* kernel launch, measured with HIP events on the context stream. */
 double srba_hip_last_kernel_ms(srba_hip_ctx *ctx);
 /* Durations (ms, most recent first) of the last `n` srba_hip_lm_run / srba_hip_lm_run_async launches: HIP events recorded on the context

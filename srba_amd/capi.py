@@ -116,6 +116,7 @@ def hip_lib():
         lib.srba_hip_big_path_stats.argtypes = [C.c_void_p, PF64]
         lib.srba_hip_big_path_stats2.argtypes = [C.c_void_p, PF64]
         lib.srba_hip_spec_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        lib.srba_hip_debug_assemble_records.argtypes = [PCAP, C.POINTER(C.c_uint32), C.c_int64]; lib.srba_hip_debug_assemble_records.restype = C.c_int64
         lib.srba_hip_launch_order.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]
         lib.srba_hip_batch_stats.argtypes = [C.c_void_p, C.POINTER(BatchStats)]
         lib.srba_hip_last_kernel_ms.argtypes = [C.c_void_p]; lib.srba_hip_last_kernel_ms.restype = c_f64

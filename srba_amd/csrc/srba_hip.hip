@@ -1948,6 +1948,12 @@ int srba_hip_launch_order(srba_hip_ctx *c, int64_t *stamp, int32_t *workgroups, 
 	for (int j = 0; j < m; j++) { int64_t t; std::memcpy(&t, &rec[4 * j + 2], 8); stamp[j] = t; if (workgroups) workgroups[j] = c->plan[j].grid; if (delay_us) delay_us[j] = c->plan[j].delay_us; }
 	return m;
 }
+int64_t srba_hip_debug_assemble_records(const srba_problem_capsule *cap, uint32_t *words, int64_t cap_records) {
+	if (!cap || !words) return 0;
+	try { const int64_t room = srbadev::asm_rec_room(cap->n_obs, cap->n_bp); if (room > cap_records) return -1 - room;
+		std::memset(words, 0, sizeof(srbadev::AsmRec) * (size_t)room); return srbadev::asm_pack(*cap, (srbadev::AsmRec *)words); }
+	catch (...) { return 0; }
+}
 int srba_hip_spec_stats(srba_hip_ctx *c, int64_t out[2]) { if (!c || !out) return -1; out[0] = c->spec_launches; out[1] = c->spec_fallbacks; return 0; }
 int srba_hip_batch_stats(srba_hip_ctx *c, srba_batch_stats *out) { if (!c || !out) return -1; *out = c->stats; return 0; }
 
