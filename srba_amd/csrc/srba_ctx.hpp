@@ -79,6 +79,7 @@ struct srba_hip_ctx {
 	int upload_threads = 1; bool dense_left = true; int hbm_from_kb = 48; bool dense_blocks_ok = true; // mid-size nearly-full systems use the dense block layout in LDS
 	bool lin_terms = true, lm_terms = true; // term-parallel U_Ap accumulation in LDS: srba_hip_linearize / the fused LM kernel
 	// fused normal equations of the relative-pose SE2 family (srba_assemble.hpp): capsules packed into bins (workgroups) by the LDS image they need, one launch; the rest take k_linearize
+	bool od_on = true; // K4 over distinct observations (Worker::residuals_distinct)
 	bool asm_on = true, asm_ready = false, asm_flags_set = false, jp_stale = false; size_t off_valid = 0, off_bp_ok = 0; long long n_valid_total = 0, n_bp_total = 0;
 		int asm_max_kb = 160, asm_wpw = srbadev::ASM_MAX_WPW, asm_bin_bytes = srbadev::ASM_DEFAULT_BIN_KB * 1024; srbadev::AsmTables asm_tab = {nullptr, nullptr}; const int *asm_list = nullptr;
 	int asm_bins = 0, asm_rest = 0; // bins of the fused launch; capsules left to the unfused kernel (asm_list holds their indices)

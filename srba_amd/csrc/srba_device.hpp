@@ -60,6 +60,7 @@ struct ProbDesc {
 	int n_hrec, hap_chunked /* unused since the workgroup path sums U_Ap in LDS */; long long o_hrec; // K6 work records {U_Ap block, first term, end term} (Batch::hap_rec), one per block
 	int n_vb; long long o_vb; // multi-workgroup path, Schur reduction with a wavefront per U_Ap block (kb_schur_reduce_wave): n_vb work records {first term, end term, block, 0} from o_vb (x4) in
 		// Batch::sch_vb, longest list first; the terms themselves as packed records {landmark, W block 1, W block 2, Y slot} from o_sch (x4) in Batch::sch_rec
+	int od_ok; // every observation of the capsule appears in at most three residual rows: Batch::od_tab holds one record per DISTINCT observation (Worker::residuals_distinct)
 	int dense_in_lds, dense_blocks; // dense_blocks: the LDS image holds ALL blocks of the lower triangle (column-major), no symbolic structure (mid-size, nearly dense systems)
 };
 
@@ -80,6 +81,9 @@ struct Batch {
 	gptr<const unsigned char> pair_needed, bp_normal;
 	gptr<const int> sp_fill; // unified block indices (diag k -> k, off-diagonal i -> nb+i)
 	gptr<const int> hapo, schl, ptab; // see ProbDesc::hs_lds, n_panel
+	gptr<const int> od_tab; // per DISTINCT observation (validity slot; ProbDesc::o_valid, x12): {representative row, second row | -1, third row | -1, pose index | -1, the five words of obs_rec of the
+		// representative row, 0, 0, 0}. The reference lists an observation once per Jacobian block that refers to it (optimize_edges.h:177-193: involved_obs with duplicates): the rows
+		// of one observation are copies, their residual is evaluated once and stored to each of them
 	gptr<const int> hap_rec; // K6 work records, sorted by decreasing term count (longest first: balances the lanes of K6): {block, first term, end term}; ProbDesc::n_hrec of them from o_hrec
 	const int *sp_col_off, *sp_row, *sp_item_off, *sp_tgt /* packed update items: unified target block << 18 | a << 9 | b (packed at upload) */, *sp_rptr,
 		*sp_rcol /* packed row-view entries: column << 14 | off-diagonal block */, *sp_perm; // symbolic factorisation of every capsule's system
@@ -980,7 +984,49 @@ struct Worker {
 		}
 		return contrib;
 	}
-	__device__ __forceinline__ double phase_residuals(double *out, double *red) { fresh();
+	// K4 over the DISTINCT observations of the capsule (round 6): an observation with m Jacobian blocks owns m identical residual rows -- 293 rows for 144 observations in the benchmark
+	// windows. One evaluation per observation, its (robustified) residual stored to every row of it, its chi2 term added once per row (the reference sums the duplicates too:
+	// reprojection_residuals.h:26-78 over involved_obs). FUSED: the pose is composed from the trial's edges in LDS (phase_residuals_fused), else read from the pose table.
+	template <bool FUSED> __device__ __forceinline__ double residuals_distinct(double *out, double *red, const double *edge_lds) {
+		double acc = 0; const int nv = d.n_valid; typedef int i32x4 __attribute__((ext_vector_type(4)));
+		const i32x4 *tab = (const i32x4 *)(B.od_tab + d.o_valid * 12);
+		auto store_rows = [&](const i32x4 &a, const double (&r)[O], double ch) __attribute__((always_inline)) { const int rows[3] = {a.x, a.y, a.z};
+#pragma unroll
+			for (int q = 0; q < 3; q++) if (rows[q] >= 0) {
+#pragma unroll
+				for (int k = 0; k < O; k++) out[(long long)(d.o_obs + rows[q]) * O + k] = r[k];
+				acc += ch; } };
+		if constexpr (!FUSED) { // two observations per lane and pass: the loads of both are issued before either's stores (the first 16 bytes of a record are all this form needs)
+			for (int v = tid; v < nv; v += 2 * G) {
+				const int w = v + G; const bool two = w < nv; const i32x4 a0 = tab[3 * v], a1 = tab[3 * (two ? w : v)];
+				double r0[O], r1[O]; const double c0 = residual_row_at(a0.x, r0, pose_at(a0.w)); double c1 = 0; if (two) c1 = residual_row_at(a1.x, r1, pose_at(a1.w));
+				store_rows(a0, r0, c0); if (two) store_rows(a1, r1, c1);
+			}
+		} else {
+			const int v0 = tid < nv ? tid : 0; i32x4 a = tab[3 * v0], b = tab[3 * v0 + 1], c = tab[3 * v0 + 2];
+			for (int v = tid; v < nv; v += G) {
+				const int w = v + G < nv ? v + G : v; const i32x4 an = tab[3 * w], bn = tab[3 * w + 1], cn = tab[3 * w + 2]; // the next record travels under this observation's work
+				const int m = b.x; pose_t bp;
+				if (m >= 0) {
+					pose_t acc_p = PO::ident(); const int pe[4] = {b.y, b.z, b.w, c.x};
+#pragma unroll
+					for (int u = 0; u < 4; u++) if (pe[u] >= 0) { double t[PD]; const double *src = edge_lds + (pe[u] >> 1) * PD;
+#pragma unroll
+						for (int k = 0; k < PD; k++) t[k] = src[k];
+						const pose_t ed = PO::from(t); acc_p = (pe[u] & 1) ? comp(acc_p, inv(ed)) : comp(acc_p, ed); }
+					bp = m ? inv(acc_p) : acc_p;
+				} else bp = pose_at(a.w);
+				double r[O]; const double ch = residual_row_at(a.x, r, bp);
+				store_rows(a, r, ch);
+				a = an; b = bn; c = cn;
+			}
+		}
+		return grp_sum<G>(acc, red);
+	}
+	// by_rows: every row evaluated, copies included -- the batch-wide launch of the stepwise API streams the residual array (consecutive lanes write consecutive rows: full lines) and is
+	// bound by that traffic, not by the evaluations: over distinct observations it measured 0.232 ms against 0.201
+	__device__ __forceinline__ double phase_residuals(double *out, double *red, bool by_rows = false) { fresh();
+		if (d.od_ok && !by_rows) return residuals_distinct<false>(out, red, nullptr);
 		double acc = 0;
 		for (int i = tid; i < d.n_obs; i += 2 * G) { // two rows per lane and pass: both rows' loads are issued before either row's stores
 			double r0[O], r1[O]; const int j = i + G; const bool two = j < d.n_obs;
@@ -1001,6 +1047,7 @@ struct Worker {
 	// in the order phase_spantree composes it: the same bits. A trial's evaluation then has no global store -> barrier -> gather between the update and the residuals, and a REJECTED
 	// trial (60 % of them) never writes the pose table; an accepted one runs the refresh afterwards (lm_one). One row per lane and pass, the next row's record requested ahead.
 	__device__ __forceinline__ double phase_residuals_fused(double *out, double *red, const double *edge_lds) { fresh();
+		if (d.od_ok) return residuals_distinct<true>(out, red, edge_lds);
 		double acc = 0;
 		const int *rec0 = B.obs_rec + (d.o_obs + (tid < d.n_obs ? tid : 0)) * 5; int m = rec0[0], e0 = rec0[1], e1 = rec0[2], e2 = rec0[3], e3 = rec0[4];
 		for (int i = tid; i < d.n_obs; i += G) {

@@ -1040,7 +1040,7 @@ __global__ void __launch_bounds__(2 * SRBA_WG) __attribute__((amdgpu_waves_per_e
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_spantree(const Batch B, const DevParams prm, int only_needed) { Solver<FAM> S(B, B.desc[blockIdx.x], prm);
 	S.phase_spantree(only_needed != 0); }
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_residuals(const Batch B, const DevParams prm) {
-	Solver<FAM> S(B, B.desc[blockIdx.x], prm); const double e = S.phase_residuals(B.resid, srba_lds); if (threadIdx.x == 0) B.chi2[blockIdx.x] = e;
+	Solver<FAM> S(B, B.desc[blockIdx.x], prm); const double e = S.phase_residuals(B.resid, srba_lds, true); if (threadIdx.x == 0) B.chi2[blockIdx.x] = e;
 }
 template <int FAM> __global__ void __launch_bounds__(SRBA_WG) k_linearize(const Batch B, const DevParams prm, int lds_doubles, const int *list /* capsule of every workgroup,
 	or NULL: the whole batch */) {
@@ -1491,6 +1491,7 @@ srba_hip_ctx *srba_hip_create(int device, const srba_hip_params *params) {
 	{ const char *e = getenv("SRBA_HIP_LIN_TERMS"); if (e) c->lin_terms = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_LM_TERMS"); if (e) c->lm_terms = atoi(e) != 0; }
 	{ const char *e = getenv("SRBA_HIP_ASSEMBLE_MAX_KB"); if (e) c->asm_max_kb = atoi(e); }            // capsules whose LDS image exceeds this take the unfused kernel (tests)
+	{ const char *e = getenv("SRBA_HIP_DISTINCT_OBS"); if (e) c->od_on = atoi(e) != 0; }               // 0 = K4 evaluates every residual row, copies included (rounds 1-5)
 	{ const char *e = getenv("SRBA_HIP_ASSEMBLE"); if (e) c->asm_on = atoi(e) != 0; }                   // 0 = srba_hip_linearize always runs the unfused kernel (Jacobian blocks through HBM)
 	{ const char *e = getenv("SRBA_HIP_FLAT"); if (e) c->use_flat = atoi(e) != 0; }                     // 0 = one wavefront per capsule for the stepwise spanning-tree launch
 	{ const char *e = getenv("SRBA_HIP_BIG_TIME_EVERY"); if (e && atoi(e) >= 1) c->big_time_every = atoi(e); }
@@ -1690,7 +1691,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	Arena in; struct { size_t desc, edge0, ulm0, klm, obs_z, pair_path_off, path_edge, obs_pose, obs_lm, obs_valid, bp_col, bp_res, bp_A, bp_D, bp_lm, colp_off, bf_col, bf_res, bf_pose, colf_off,
 		hap_i, hap_j, hap_term_off, hap_t1, hap_t2, hap_tblk, hf_i, hf_j, hf_term_off, hf_t1, hf_t2, hapf_i, hapf_j, hapf_term_off, hapf_t1, hapf_t2, hap_diag, hf_diag, sch_term_off, sch_b1, sch_b2,
 			sch_lm, sch_yw, sch_tblk, sch_vb, sch_rec,
-		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, obs_rec, pair_needed, pose_req, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_rptr, sp_rcol, sp_perm, sp_fill, hap_rec,
+		lm_hapf_off, lm_hapf_idx, req_idx, need_idx, need_rec, obs_rec, od_tab, pair_needed, pose_req, bp_normal, order, sp_col_off, sp_row, sp_item_off, sp_tgt, sp_rptr, sp_rcol, sp_perm, sp_fill, hap_rec,
 			hapo, schl, ptab, hap_dst, hapf_dst, hf_dst, asm_rec, asm_desc, asm_list; } o;
 	o.desc = in.add(sizeof(ProbDesc) * n);
 	o.edge0 = in.add(8 * t_edge * PDX); o.ulm0 = in.add(8 * t_ulm * L); o.klm = in.add(8 * t_klm * L); o.obs_z = in.add(8 * t_obs * O);
@@ -1704,7 +1705,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 	o.sch_term_off = in.add(4 * (t_hap + n)); o.sch_b1 = in.add(4 * t_sch); o.sch_b2 = in.add(4 * t_sch); o.sch_lm = in.add(4 * t_sch); o.sch_yw = in.add(4 * t_sch); o.sch_tblk = in.add(4 * t_sch);
 	o.sch_vb = in.add(16 * (size_t)t_vb); o.sch_rec = in.add(any_vb ? 16 * (size_t)t_sch : 0);
 	o.lm_hapf_off = in.add(4 * (t_ulm + n)); o.lm_hapf_idx = in.add(4 * t_hapf); o.req_idx = in.add(4 * t_req); o.need_idx = in.add(4 * t_pair);
-		o.need_rec = in.add(4 * 5 * std::max<long long>(t_pair, 1)); o.obs_rec = in.add(4 * 5 * std::max<long long>(t_obs, 1)); o.pair_needed = in.add(t_pair); o.pose_req = in.add(2 * t_pair);
+		o.need_rec = in.add(4 * 5 * std::max<long long>(t_pair, 1)); o.obs_rec = in.add(4 * 5 * std::max<long long>(t_obs, 1)); o.od_tab = in.add(4 * 12 * std::max<long long>(t_valid, 1)); o.pair_needed = in.add(t_pair); o.pose_req = in.add(2 * t_pair);
 		o.bp_normal = in.add(t_bp); o.order = in.add(4 * (size_t)n);
 	o.sp_col_off = in.add(4 * t_spcol); o.sp_row = in.add(4 * t_sprow); o.sp_item_off = in.add(4 * t_spcol); o.sp_tgt = in.add(4 * t_spitem); o.sp_rptr = in.add(4 * t_spcol);
 		o.sp_rcol = in.add(4 * t_sprow); o.sp_perm = in.add(4 * t_spcol); o.hap_rec = in.add(4 * 3 * std::max<long long>(t_hrec, 1)); o.hapo = in.add(4 * 3 * t_hapo); o.schl = in.add(4 * 4 * t_schl);
@@ -1782,6 +1783,17 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 			if (ip < 0) { r[0] = -2; continue; }
 			const int pr = ip >> 1, pb = k.pair_path_off[pr], pl = k.pair_path_off[pr + 1] - pb;
 			if (k.pair_needed[pr] && pl <= 4) { r[0] = ip & 1; for (int u = 0; u < pl; u++) r[1 + u] = k.path_edge[pb + u]; } else { r[0] = -1; r[1] = ip; } } }
+		{ // one record per DISTINCT observation (validity slot): its rows (at most three, else the capsule keeps the row-by-row residual phase), its pose, the obs_rec of the first row
+		  int32_t *od = (int32_t *)(h + o.od_tab) + 12 * d.o_valid; const int32_t *orc = (const int32_t *)(h + o.obs_rec) + 5 * d.o_obs; bool ok = k.n_valid > 0;
+		  for (int v = 0; v < k.n_valid; v++) { int32_t *r = od + 12 * v; r[0] = r[1] = r[2] = -1; for (int q = 3; q < 12; q++) r[q] = 0; }
+		  for (int i = 0; i < k.n_obs && ok; i++) { const int v = k.obs_valid[i]; if (v < 0 || v >= k.n_valid) { ok = false; break; } int32_t *r = od + 12 * v;
+			const int q = r[0] < 0 ? 0 : r[1] < 0 ? 1 : r[2] < 0 ? 2 : 3; if (q == 3) { ok = false; break; }
+			if (q == 0) { r[3] = k.obs_pose[i]; for (int u = 0; u < 5; u++) r[4 + u] = orc[5 * i + u]; }
+			else { const int f = r[0]; if (k.obs_pose[i] != k.obs_pose[f] || k.obs_lm[i] != k.obs_lm[f] || std::memcmp(k.obs_z + (size_t)i * O, k.obs_z + (size_t)f * O, sizeof(double) * O) != 0) { ok = false;
+				break; } } // (rows of one observation are copies of one another: anything else keeps the row-by-row phase)
+			r[q] = i; }
+		  for (int v = 0; v < k.n_valid && ok; v++) if (od[12 * v] < 0) ok = false; // a slot without a row
+		  c->desc[p].od_ok = (ok && c->od_on) ? 1 : 0; }
 		{ int32_t *rq = (int32_t *)(h + o.req_idx) + d.o_req; int cnt = 0; for (int i = 0; i < 2 * k.n_pairs; i++) if (k.pose_required[i]) rq[cnt++] = i; }
 		CPY(o.pair_needed, d.o_pair, k.pair_needed, k.n_pairs, uint8_t); CPY(o.pose_req, 2 * d.o_pair, k.pose_required, 2 * (size_t)k.n_pairs, uint8_t); CPY(o.bp_normal, d.o_bp, k.bp_normal, k.n_bp,
 			uint8_t);
@@ -1894,7 +1906,7 @@ static int upload_problems_impl(srba_hip_ctx *c, const srba_problem_capsule *cap
 		DI(hf_j, int); DI(hf_term_off, int); DI(hf_t1, int); DI(hf_t2, int);
 	DI(hapf_i, int); DI(hapf_j, int); DI(hapf_term_off, int); DI(hapf_t1, int); DI(hapf_t2, int); DI(hap_diag, int); DI(hf_diag, int); DI(sch_term_off, int); DI(sch_b1, int); DI(sch_b2, int);
 		DI(sch_lm, int); DI(sch_yw, int); DI(sch_tblk, int); DI(sch_vb, int); DI(sch_rec, int);
-	DI(lm_hapf_off, int); DI(lm_hapf_idx, int); DI(req_idx, int); DI(need_idx, int); DI(need_rec, int); DI(obs_rec, int); DI(pair_needed, unsigned char); DI(pose_req, unsigned char); DI(bp_normal,
+	DI(lm_hapf_off, int); DI(lm_hapf_idx, int); DI(req_idx, int); DI(need_idx, int); DI(need_rec, int); DI(obs_rec, int); DI(od_tab, int); DI(pair_needed, unsigned char); DI(pose_req, unsigned char); DI(bp_normal,
 		unsigned char);
 	c->asm_tab.rec = asm_fam ? (const srbadev::AsmRec *)(di + o.asm_rec) : nullptr;
 	c->asm_tab.desc = asm_fam ? (const srbadev::AsmDesc *)(di + o.asm_desc) : nullptr; c->asm_list = asm_fam ? (const int *)(di + o.asm_list) : nullptr;
