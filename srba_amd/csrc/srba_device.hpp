@@ -456,6 +456,18 @@ __device__ __forceinline__ void sp_bsub_rows(const SparseSys &S) {
 // image is {D_k^-1 (lower triangle, in the diagonal block's place), W_ak (in place)}; the right-hand side keeps z_k (not D_k^-1 z_k) until the backward sweep.
 // "Not positive definite" == a leading minor of a pivot block <= 0 (a00, a00 a11 - a10^2, det): in exact arithmetic the same verdict as a Cholesky pivot <= 0
 // (Sylvester), decided identically by all lanes. Rounding differs from the LL^t sweeps (and from the oracle's) -- parity is the decision-replay check, not bit identity.
+// A floating-point VALU instruction with eight or fewer live lanes costs three times one with nine or more (tools/probes/valu_mask_rate.hip: v_fma_f64 21 against 7 shader cycles per
+// wavefront, two wavefronts per SIMD; the same for FP32; integer 1.25 x). The panel / update / substitution arithmetic of a column with one or two off-diagonal blocks has 3 .. 6 live
+// lanes when it sits under its store's condition: it is formed by every lane instead (idle lanes work on block 0 of the image, their loads are unconditional anyway) and only the store
+// is conditional. The empty asm pins the value where all lanes are live, so that the compiler cannot sink the arithmetic back under the condition. Same numbers, bit for bit.
+#ifndef SRBA_SOLVER_ALL_LANES
+#define SRBA_SOLVER_ALL_LANES 1
+#endif
+#if SRBA_SOLVER_ALL_LANES
+#define SRBA_ALL_LANES(x) asm volatile("" : "+v"(x))
+#else
+#define SRBA_ALL_LANES(x) do { } while (0)
+#endif
 struct Inv3 { double i00, i10, i11, i20, i21, i22; };
 __device__ __forceinline__ double rcp_refined(double d) { // 1/d: v_rcp_f64 + two Newton steps (the reciprocal of the division expansion without its numerator steps)
 	double x = __builtin_amdgcn_rcp(d); double e = fma(-d, x, 1.0); x = fma(x, e, x); e = fma(-d, x, 1.0); return fma(x, e, x);
@@ -496,16 +508,16 @@ __device__ __forceinline__ bool sp_factor_fsub_rows(const SparseSys &S) {
 		Inv3 v;
 		if (!inv3v(a00, a10, a11, a20, a21, a22, v)) return false;
 		const double u0 = fma(v.i20, z2, fma(v.i10, z1, v.i00 * z0)), u1 = fma(v.i21, z2, fma(v.i11, z1, v.i10 * z0)), u2 = fma(v.i22, z2, fma(v.i21, z1, v.i20 * z0)); // D_k^-1 z_k
-		if (pl) *rr = rv - fma(A2, u2, fma(A1, u1, A0 * u0));
+		{ double nr = rv - fma(A2, u2, fma(A1, u1, A0 * u0)); SRBA_ALL_LANES(nr); if (pl) *rr = nr; }
 		if (worker) for (int p = grp + 21; p < cn; p += 21) { // columns with more than 21 blocks
 			const double *Ax = S.off + 9 * (cb + p) + 3 * sub; double *rx = S.rhs + 3 * S.row[cb + p] + sub;
 			*rx -= fma(Ax[2], u2, fma(Ax[1], u1, Ax[0] * u0));
 		}
-		if (up) { // row `sub` of target -= (W_ak D_k^-1) W_bk^t
+		{ // row `sub` of target -= (W_ak D_k^-1) W_bk^t: formed by EVERY lane (an idle lane works on block 0 of the image), stored by the lanes that own an item -- see SRBA_ALL_LANES
 			const double l0 = fma(la2, v.i20, fma(la1, v.i10, la0 * v.i00)), l1 = fma(la2, v.i21, fma(la1, v.i11, la0 * v.i10)), l2 = fma(la2, v.i22, fma(la1, v.i21, la0 * v.i20));
-			T[0] = t0 - fma(l2, lb[2], fma(l1, lb[1], l0 * lb[0]));
-			T[1] = t1 - fma(l2, lb[5], fma(l1, lb[4], l0 * lb[3]));
-			T[2] = t2 - fma(l2, lb[8], fma(l1, lb[7], l0 * lb[6]));
+			double n0 = t0 - fma(l2, lb[2], fma(l1, lb[1], l0 * lb[0])), n1 = t1 - fma(l2, lb[5], fma(l1, lb[4], l0 * lb[3])), n2 = t2 - fma(l2, lb[8], fma(l1, lb[7], l0 * lb[6]));
+			SRBA_ALL_LANES(n0); SRBA_ALL_LANES(n1); SRBA_ALL_LANES(n2);
+			if (up) { T[0] = n0; T[1] = n1; T[2] = n2; }
 		}
 		if (worker) for (int t = grp + 21; t < nitems; t += 21) { // the other update items of a column with more than 21
 			const unsigned w = (unsigned)S.item[ib + t];
@@ -541,7 +553,7 @@ __device__ __forceinline__ void sp_bsub_rows(const SparseSys &S) {
 		const unsigned w_n = (worker && a > 0 && rb_n + grp < rb) ? (unsigned)S.rent[rb_n + grp] : 0u;
 		const int rb_nn = a >= 2 ? S.rptr[a - 2] : 0;
 		const double x0 = fma(i20, r2, fma(i10, r1, i00 * r0)), x1 = fma(i21, r2, fma(i11, r1, i10 * r0)), x2 = fma(i22, r2, fma(i21, r1, i20 * r0)); // x_a = D_a^-1 (z_a - sum_{r > a} W_ra^t x_r)
-		if (act) *y = yv - fma(l2, x2, fma(l1, x1, l0 * x0));
+		{ double ny = yv - fma(l2, x2, fma(l1, x1, l0 * x0)); SRBA_ALL_LANES(ny); if (act) *y = ny; }
 		if (worker) for (int j = rb + grp + 21; j < re; j += 21) { // rows with more than 21 blocks
 			const unsigned wx = (unsigned)S.rent[j]; const double *Lx = S.off + 9 * (wx & 0x3fff) + sub; double *yx = S.rhs + 3 * (wx >> 14) + sub;
 			*yx -= fma(Lx[6], x2, fma(Lx[3], x1, Lx[0] * x0));
