@@ -94,7 +94,7 @@ def sweep_map(eng, roots, win, dist=None, device="cpu", final_sync=True):
     The schedule -- rounds in order, the windows of a round in any order -- is a sequential schedule of optimize_local_area() calls: windows of a round commute (none writes what
     another touches), so every rank's map after the sweep equals, bit for bit, the map of ONE process running the same rounds (and, to the 1e-6 of the back-ends, the CPU engine's).
     Exchange: an unknown (kf2kf edge pose, landmark position) is SHARED when windows of more than one rank touch it. After round c every rank contributes the values of the shared
-    unknowns ITS windows wrote in c (zeros elsewhere) to one all-reduce(sum): x + 0 + ... + 0 = x exactly -- no rank adds to another's entry, so this is a gather, not an arithmetic
+    unknowns ITS windows wrote in c (zeros elsewhere) to one all-reduce(sum) of 64-bit patterns: x + 0 + ... + 0 = x exactly -- no rank adds to another's entry, so this is a gather, not an arithmetic
     reduction, and it moves n_shared_written(c) x (3 .. 12) doubles (KB-scale). Unknowns no other rank touches stay local until the final all-reduce (final_sync) that leaves the
     whole map on every rank.
     What is NOT exchanged: the numeric spanning-tree table (TSpanningTree::num). Every optimisation recomputes the poses it reads from the edges (K1) and writes them back; after a
@@ -144,7 +144,8 @@ def _exchange(dist, device, parts):
         b = np.zeros((len(ids), K.width))
         if mine.any(): b[mine] = K.get(ids[mine])
         bufs.append(b.reshape(-1))
-    t = torch.from_numpy(np.concatenate(bufs)).to(device); dist.all_reduce(t); out = t.cpu().numpy(); pos = 0
+    # the doubles travel as their 64-bit patterns: an integer sum with zeros returns every pattern untouched (a floating-point sum would turn -0.0 into +0.0)
+    t = torch.from_numpy(np.concatenate(bufs).view(np.int64)).to(device); dist.all_reduce(t); out = t.cpu().numpy().view(np.float64); pos = 0
     for K, ids, mine in parts:
         v = out[pos:pos + len(ids) * K.width].reshape(len(ids), K.width); pos += len(ids) * K.width
         if (~mine).any(): K.put(ids[~mine], v[~mine])
